@@ -1,0 +1,27 @@
+# Builds libqdrant_amd.so (HIP, gfx950 only) and the CPU oracle (test infrastructure).
+HIPCC    ?= /opt/rocm/bin/hipcc
+ARCH     ?= gfx950
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden \
+            -Wall -Wno-unused-function -Iinclude
+CSRC     := qdrant_amd/csrc
+SRCS     := $(wildcard $(CSRC)/*.hip)
+OBJS     := $(patsubst $(CSRC)/%.hip,build/%.o,$(SRCS))
+HDRS     := $(wildcard $(CSRC)/*.hpp) include/qdrant_amd.h
+LIB      := qdrant_amd/libqdrant_amd.so
+
+all: $(LIB) oracle
+
+build/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf build $(LIB)
+	$(MAKE) -C oracle clean
+.PHONY: all oracle clean

@@ -1,0 +1,302 @@
+/*
+ * qdrant_amd.h — C-ABI of the MI355X-native vector-scoring library (libqdrant_amd.so).
+ *
+ * This is the drop-in boundary for ONE hot path of qdrant/qdrant v1.19.0: the batched
+ * vector-scoring path behind the `Metric` / `QueryScorer` / `RawScorer` traits of lib/segment
+ * and the `EncodedVectors` trait of lib/quantization.  Every entry point below names the
+ * reference interface (file:line under the qdrant tree) it replaces.  A Rust maintainer binds
+ * these with a plain `unsafe extern "C"` block, exactly like the reference
+ * already binds its own C SIMD leaves (lib/quantization/src/encoded_vectors_u8.rs:833-846).
+ *
+ * Conventions
+ *  - plain pointers + sizes; no C++/torch types; all functions return `int32_t` status
+ *    (`QMX_OK` == 0).  Nothing throws or aborts across the ABI.  `qmx_last_error` returns a
+ *    thread-local message for the last failing call on this thread.
+ *  - data pointers (`vectors`, `queries`, `ids`, `out`, ...) may point to HOST memory or to
+ *    DEVICE (HBM) memory of the segment's GPU; the library inspects the pointer.  Control
+ *    structs (descriptors, params, counters) are always host memory.
+ *  - a `qmx_segment` is immutable after creation and safe for concurrent use from any number
+ *    of host threads (reference: storages are shared `&` across search threads,
+ *    lib/segment/src/index/plain_vector_index/mod.rs:48-52).  A `qmx_query` (one batch of
+ *    queries = a batch of `RawScorer`s) belongs to one thread at a time, like
+ *    `Box<dyn RawScorer>` (lib/segment/src/vector_storage/raw_scorer.rs:60-64).
+ *  - there is NO CPU fallback inside the library: without a usable gfx950 device every call
+ *    returns QMX_ERR_NO_DEVICE and the caller keeps its CPU scorer, mirroring the reference's
+ *    "GPU error => fall back to CPU" contract (lib/segment/src/index/hnsw_index/hnsw/gpu_build.rs:134-139).
+ */
+#ifndef QDRANT_AMD_H
+#define QDRANT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QMX_API __attribute__((visibility("default")))
+
+/* Status codes.  1..6 mirror `gpu::GpuError` (lib/gpu/src/lib.rs:50-72); CANCELLED mirrors
+ * `OperationError::Cancelled` raised by `check_process_stopped`
+ * (lib/segment/src/common/operation_error.rs:399-411). */
+typedef enum qmx_status {
+    QMX_OK = 0,
+    QMX_ERR_OUT_OF_MEMORY = 1,
+    QMX_ERR_OUT_OF_BOUNDS = 2,
+    QMX_ERR_NOT_SUPPORTED = 3,
+    QMX_ERR_NOT_READY = 4,
+    QMX_ERR_TIMEOUT = 5,
+    QMX_ERR_OTHER = 6,
+    QMX_ERR_CANCELLED = 7,
+    QMX_ERR_BAD_ARG = 8,
+    QMX_ERR_NO_DEVICE = 9
+} qmx_status;
+
+/* Element type of the stored block.  F32/F16/U8 = `VectorStorageDatatype`
+ * (lib/segment/src/types.rs, Float32/Float16/Uint8); SQ_U8 = `EncodedVectorsU8`
+ * (lib/quantization/src/encoded_vectors_u8.rs:33-37); PQ = `EncodedVectorsPQ`
+ * (lib/quantization/src/encoded_vectors_pq.rs:33-37). */
+typedef enum qmx_dtype {
+    QMX_DTYPE_F32 = 0,
+    QMX_DTYPE_F16 = 1,
+    QMX_DTYPE_U8 = 2,
+    QMX_DTYPE_SQ_U8 = 3,
+    QMX_DTYPE_PQ = 4
+} qmx_dtype;
+
+/* Same order as `enum Distance` (lib/segment/src/types.rs:313-322). */
+typedef enum qmx_distance {
+    QMX_DISTANCE_COSINE = 0,
+    QMX_DISTANCE_EUCLID = 1,
+    QMX_DISTANCE_DOT = 2,
+    QMX_DISTANCE_MANHATTAN = 3
+} qmx_distance;
+
+/* `ScoredPointOffset` — #[repr(C)] {idx: u32, score: f32}, 8 bytes
+ * (lib/common/common/src/types.rs:12-17).  Usable verbatim across the FFI. */
+typedef struct qmx_scored_point {
+    uint32_t idx;
+    float score;
+} qmx_scored_point;
+
+/* What the Rust shim feeds into `HardwareCounterCell`
+ * (lib/segment/src/vector_storage/query_scorer/metric_query_scorer.rs:75-76,84-85). */
+typedef struct qmx_counters {
+    uint64_t vectors_scored; /* (row, query) pairs scored                                  */
+    uint64_t bytes_read;     /* algorithmic bytes of stored rows streamed / gathered       */
+    uint64_t kernel_launches;
+    float kernel_ms;         /* HIP-event time of the scoring kernels of the call (0 if not timed) */
+    float reserved;
+} qmx_counters;
+
+/* Flags for qmx_segment_desc.flags */
+#define QMX_SEG_DATA_ON_DEVICE 0x1u /* `data` is device memory; adopt it without copying (caller keeps it alive) */
+/* u8 metrics: how the exact i32 lane sums become f32.  0 (default) = AVX2 order of the live
+ * x86 reference path (8 i32 lanes -> cvtepi32_ps -> f32 hsum, spaces/metric_uint/avx2/dot.rs:51-52);
+ * 1 = scalar order (one i32 total cast once, spaces/metric_uint/simple_dot.rs:58-69).  The two
+ * differ only when a partial sum exceeds 2^24. */
+#define QMX_SEG_U8_SCALAR_ORDER 0x2u
+/* time every scoring kernel with HIP events on its stream and report it in qmx_counters.kernel_ms */
+#define QMX_SEG_TIME_KERNELS 0x4u
+
+/* SQ-int8 parameters = `MetadataInt8` (lib/quantization/src/encoded_vectors_u8.rs:84-91).
+ * Parity is defined on GIVEN (alpha, offset): the reference's quantile estimate samples
+ * randomly (lib/quantization/src/quantile.rs:35-82). */
+typedef struct qmx_sq_params {
+    uint32_t actual_dim; /* dim rounded up to 16 (encoded_vectors_u8.rs:622-624) */
+    float alpha;
+    float offset;
+    float multiplier;
+    uint8_t invert;      /* VectorParameters.invert: true for Euclid / Manhattan
+                            (lib/segment/src/vector_storage/quantized/quantized_vectors.rs:232) */
+    uint8_t pad_[3];
+} qmx_sq_params;
+
+/* PQ codebook = `Metadata{centroids, vector_division}` (encoded_vectors_pq.rs:46-51):
+ * 256 centroids, each a full `dim`-long f32 vector "flattened by chunks". */
+typedef struct qmx_pq_params {
+    uint32_t chunk_size;     /* f32 elements per chunk; m = ceil(dim / chunk_size) (get_vector_division :164-169) */
+    uint32_t n_centroids;    /* CENTROIDS_COUNT = 256 (or fewer when count <= 256, :354-362) */
+    const float *centroids;  /* [n_centroids][dim], host or device */
+    uint8_t invert;
+    uint8_t lut_mfma;        /* 1: build the query LUT with f32 MFMA (fma chain, <=1e-5 rel vs reference);
+                                0: exact reference order (mul then add, sequential)  */
+    uint8_t pad_[2];
+} qmx_pq_params;
+
+/* One stored vector block = what `DenseVectorStorageRead` exposes
+ * (lib/segment/src/vector_storage/vector_storage_base.rs:265-316): N rows of `dim` elements,
+ * row-major, fixed stride (immutable file layout: dense/immutable_dense_vectors.rs:100-115 —
+ * pass `file_base + 4` to skip the "data" header).  For SQ_U8 rows are the reference layout
+ * `[f32 vector_offset][u8 code x actual_dim]` (encoded_vectors_u8.rs:22-24,626-629), for PQ
+ * `m` code bytes (encoded_vectors_pq.rs:617-619). */
+typedef struct qmx_segment_desc {
+    uint32_t dtype;            /* qmx_dtype */
+    uint32_t distance;         /* qmx_distance */
+    uint32_t dim;              /* ORIGINAL vector dimension */
+    uint32_t flags;            /* QMX_SEG_* */
+    uint64_t n;                /* rows */
+    uint64_t row_stride_bytes; /* 0 = tightly packed */
+    const void *data;          /* host or device rows */
+    int32_t device_id;         /* HIP device ordinal */
+    int32_t reserved;
+    const qmx_sq_params *sq;   /* required for QMX_DTYPE_SQ_U8 */
+    const qmx_pq_params *pq;   /* required for QMX_DTYPE_PQ */
+} qmx_segment_desc;
+
+typedef struct qmx_segment qmx_segment;
+typedef struct qmx_query qmx_query;
+
+/* ---- library / device ------------------------------------------------------------------ */
+
+/* Number of usable gfx950 devices (replaces `GpuDevicesMaganer` enumeration,
+ * lib/segment/src/index/hnsw_index/gpu/gpu_devices_manager.rs:11-15). */
+QMX_API int32_t qmx_device_count(int32_t *out_count);
+/* Copies the calling thread's last error message (NUL-terminated) into buf. */
+QMX_API int32_t qmx_last_error(char *buf, size_t buf_len);
+/* ABI version; bumped on any signature change. */
+QMX_API uint32_t qmx_abi_version(void);
+
+/* ---- segment (device-resident copy of one vector storage) --------------------------------- */
+
+/* Uploads (or adopts) the block.  Replaces opening a `VectorStorageEnum` for scoring
+ * (raw_scorer.rs:60-114 matches on it) / `GpuVectorStorage::new`
+ * (hnsw_index/gpu/gpu_vector_storage/mod.rs).  OOM => QMX_ERR_OUT_OF_MEMORY, caller keeps CPU. */
+QMX_API int32_t qmx_segment_create(const qmx_segment_desc *desc, qmx_segment **out);
+QMX_API int32_t qmx_segment_destroy(qmx_segment *seg);
+/* Deleted flags = the two `BitSlice<u64, Lsb0>` of `NotDeletedChecker`
+ * (raw_scorer.rs:580-603; layout lib/common/common/src/bitvec.rs:6-7).  A point past
+ * `n_point_bits` counts as deleted, a vector past `n_vec_bits` as not deleted (:596-603).
+ * NULL/0 for both = nothing deleted, every row < n live.  Not thread-safe against running
+ * searches on the same segment (the reference takes these by shared borrow per search). */
+QMX_API int32_t qmx_segment_set_deleted(qmx_segment *seg, const uint64_t *point_deleted,
+                                        uint64_t n_point_bits, const uint64_t *vec_deleted,
+                                        uint64_t n_vec_bits);
+/* Reads rows back (device -> host), for tests: `get_dense` / `get_quantized_vector`. */
+QMX_API int32_t qmx_segment_read_rows(const qmx_segment *seg, const uint32_t *ids, uint32_t n,
+                                      void *out_rows /* [n][row_bytes] reference layout */);
+QMX_API int32_t qmx_segment_row_bytes(const qmx_segment *seg, uint64_t *out);
+
+/* ---- Metric::preprocess ---------------------------------------------------------------- */
+
+/* `Metric<T>::preprocess` on a batch (lib/segment/src/spaces/metric.rs:15-16): cosine
+ * normalisation with the reference's skip rule (spaces/tools.rs:14-16) and AVX accumulation
+ * order (spaces/simple_avx.rs:127-165); identity for the other distances.  `out` may alias `in`. */
+QMX_API int32_t qmx_preprocess_f32(int32_t device_id, uint32_t distance, const float *in,
+                                   uint64_t n, uint32_t dim, float *out);
+/* Element casts of `PrimitiveVectorElement::slice_from_float_cow`
+ * (lib/segment/src/data_types/primitive.rs:76-79 f16 RNE; :127-129 u8 saturating truncation). */
+QMX_API int32_t qmx_cast_f32(int32_t device_id, uint32_t dst_dtype, const float *in, uint64_t count,
+                             void *out);
+
+/* ---- query batch = batch of RawScorers ---------------------------------------------------- */
+
+/* `new_raw_scorer(QueryVector::Nearest(q), storage)` for each of `nq` queries
+ * (raw_scorer.rs:60-114 -> MetricQueryScorer::new, metric_query_scorer.rs:35-58): preprocess
+ * once, cast to the element type; for SQ/PQ segments `EncodedVectors::encode_query`
+ * (encoded_vectors_u8.rs:583-619; encoded_vectors_pq.rs:519-541 — the LUT), all on device.
+ * `queries`: [nq][dim] f32 ORIGINAL (un-preprocessed) vectors. */
+QMX_API int32_t qmx_query_create(const qmx_segment *seg, const float *queries, uint32_t nq,
+                                 qmx_query **out);
+/* `FilteredScorer::new_internal` (hnsw_index/point_scorer.rs:183-218): the stored vector
+ * `point_ids[i]` becomes query i (SQ: `encode_internal_vector`, encoded_vectors_u8.rs:715-728;
+ * PQ returns None there, so the caller passes the original vector to qmx_query_create). */
+QMX_API int32_t qmx_query_create_internal(const qmx_segment *seg, const uint32_t *point_ids,
+                                          uint32_t nq, qmx_query **out);
+QMX_API int32_t qmx_query_destroy(qmx_query *q);
+/* Run this query batch's kernels on a caller-owned hipStream_t (NULL = the query's own stream). */
+QMX_API int32_t qmx_query_set_stream(qmx_query *q, void *hip_stream);
+QMX_API int32_t qmx_query_synchronize(qmx_query *q);
+/* enabled != 0: bracket every scoring kernel of this query batch with HIP events on its stream and
+ * report the sum in qmx_counters.kernel_ms (forces a stream sync per launch: measurement only). */
+QMX_API int32_t qmx_query_set_timing(qmx_query *q, int32_t enabled);
+/* Encoded form read-back for tests: f32/f16/u8 preprocessed+cast query; SQ: [f32 offset][codes];
+ * PQ: the LUT [m][n_centroids] f32. */
+QMX_API int32_t qmx_query_read_encoded(const qmx_query *q, uint32_t query_index, void *out,
+                                       uint64_t out_bytes, uint64_t *written);
+
+/* ---- RawScorer surface (gather scoring) ---------------------------------------------------- */
+
+/* `RawScorer::score_points(points, scores)` (raw_scorer.rs:40, 561-564) for every query of the
+ * batch against the SAME id list: scores[qi * n + i] = similarity(query qi, row ids[i]).
+ * ids must be < n rows (QMX_ERR_OUT_OF_BOUNDS otherwise; the reference panics). */
+QMX_API int32_t qmx_score_points(qmx_query *q, const uint32_t *ids, uint32_t n, float *scores,
+                                 qmx_counters *counters);
+/* Ragged form for HNSW hops batched across concurrent searches: query qi scores
+ * ids[offsets[qi] .. offsets[qi+1]) into scores at the same positions
+ * (graph_layers.rs:305-313,125-139 produce <= m0 ids per hop per query). */
+QMX_API int32_t qmx_score_points_ragged(qmx_query *q, const uint32_t *ids, const uint32_t *offsets,
+                                        float *scores, qmx_counters *counters);
+/* `RawScorer::score_point` (raw_scorer.rs:43). */
+QMX_API int32_t qmx_score_point(qmx_query *q, uint32_t query_index, uint32_t id, float *out);
+/* `RawScorer::score_internal(a, b)` stored<->stored (raw_scorer.rs:50;
+ * metric_query_scorer.rs:94-99; SQ encoded_vectors_u8.rs:675-705; PQ encoded_vectors_pq.rs:574-618),
+ * batched: out[i] = score(a[i], b[i]). */
+QMX_API int32_t qmx_score_internal(const qmx_segment *seg, const uint32_t *a, const uint32_t *b,
+                                   uint32_t n, float *out);
+/* `QueryScorerBytes::score_bytes` (query_scorer/mod.rs:48-68): rows given as raw bytes in the
+ * segment's reference row layout (inline link vectors, graph_layers.rs:336-389). */
+QMX_API int32_t qmx_score_bytes(qmx_query *q, const void *rows, uint32_t n, uint64_t stride_bytes,
+                                float *scores /* [nq][n] */);
+
+/* ---- brute-force search ---------------------------------------------------------------------- */
+
+/* `BatchFilteredSearcher::peek_top_iter` (hnsw_index/point_scorer.rs:423-472) as driven by
+ * `PlainVectorIndexReadView::search` (plain_vector_index/read_view/search.rs:54-135):
+ *   ids == NULL : candidate stream = every row whose point-deleted bit is zero
+ *                 (`iter_not_deleted`, :400-406), vector-deleted rows skipped (`check_vector`);
+ *   ids != NULL : candidate stream = that list (payload-filtered ids, search.rs:104-108),
+ *                 still subject to the deleted flags.
+ * For each query keeps the `top` best by score (`FixedLengthPriorityQueue`,
+ * lib/common/common/src/fixed_length_priority_queue.rs:47-59) and returns them sorted by
+ * descending score (`into_sorted_vec`, :63-65); among equal scores the lower id comes first
+ * (the reference's order among equals is heap-dependent).
+ *   out        : [nq][top] ScoredPointOffset;  out_counts : [nq] number of valid entries.
+ *   is_stopped : polled between kernel launches; non-zero => QMX_ERR_CANCELLED
+ *                (`check_process_stopped`, point_scorer.rs:433,437).  May be NULL. */
+QMX_API int32_t qmx_search_topk(qmx_query *q, uint32_t top, const uint32_t *ids, uint64_t n_ids,
+                                qmx_scored_point *out, uint32_t *out_counts,
+                                const volatile uint8_t *is_stopped, qmx_counters *counters);
+/* Same, but only enqueues on the query's stream; `out`/`out_counts` must be device memory.
+ * Complete with qmx_query_synchronize. */
+QMX_API int32_t qmx_search_topk_async(qmx_query *q, uint32_t top, const uint32_t *ids,
+                                      uint64_t n_ids, qmx_scored_point *out_dev,
+                                      uint32_t *out_counts_dev);
+
+/* `postprocess_search_result` rescoring (lib/segment/src/index/vector_index_search_common.rs:73-90):
+ * query qi re-scores ids[qi * n_per_query .. +counts[qi]) with the ORIGINAL-vector scorer `q`,
+ * sorts descending, truncates to `top`. */
+QMX_API int32_t qmx_rescore(qmx_query *q, const uint32_t *ids, const uint32_t *counts,
+                            uint32_t n_per_query, uint32_t top, qmx_scored_point *out,
+                            uint32_t *out_counts);
+
+/* k-way merge of per-segment / per-GPU result lists = `BatchResultAggregator`
+ * (lib/shard/src/search_result_aggregator.rs:50-121) restricted to disjoint id spaces:
+ * lists[(l * nq + qi) * k ..], idx already globalised by the caller.  Runs on `device_id`. */
+QMX_API int32_t qmx_merge_topk(int32_t device_id, const qmx_scored_point *lists,
+                               const uint32_t *list_counts, uint32_t n_lists, uint32_t nq,
+                               uint32_t k, qmx_scored_point *out, uint32_t *out_counts);
+
+/* ---- quantizers -------------------------------------------------------------------------------- */
+
+/* `EncodedVectorsU8::encode` row loop (encoded_vectors_u8.rs:236-296) for given params:
+ * in [n][dim] f32 -> out [n][4 + actual_dim] reference rows. */
+QMX_API int32_t qmx_sq_encode(int32_t device_id, uint32_t distance, const qmx_sq_params *params,
+                              const float *in, uint64_t n, uint32_t dim, void *out_rows);
+/* `EncodedVectorsPQ::encode_vector` (encoded_vectors_pq.rs:301-329): L2 argmin per chunk,
+ * first minimum wins.  in [n][dim] f32 -> out [n][m] u8. */
+QMX_API int32_t qmx_pq_encode(int32_t device_id, const qmx_pq_params *params, const float *in,
+                              uint64_t n, uint32_t dim, uint8_t *out_codes);
+
+/* ---- synthetic data (bench / tests) -------------------------------------------------------------- */
+
+/* Counter-based generator (integer Irwin-Hall of four 16-bit uniforms, no libm), reproducible on any host:
+ * element (row, col) depends only on (seed, row, col).  Fills device or host-visible memory
+ * [n][dim] f32 starting at row `row0`. */
+QMX_API int32_t qmx_synth_fill_f32(int32_t device_id, uint64_t seed, uint64_t row0, uint64_t n,
+                                   uint32_t dim, float *out_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QDRANT_AMD_H */

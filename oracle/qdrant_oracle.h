@@ -1,0 +1,141 @@
+/*
+ * qdrant_oracle.h — CPU restatement of qdrant v1.19.0's vector-scoring hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may link or call this.  The product library (libqdrant_amd.so) never does.
+ *
+ * Every function cites the reference file:line (paths relative to the qdrant tree) it follows.
+ * x86 intrinsics are identical in C and Rust (`std::arch::x86_64` == <immintrin.h>), so the
+ * AVX / SSE paths are restated instruction-for-instruction: same accumulators, same horizontal
+ * sum order.  Built with -ffp-contract=off so that scalar `a*b + c` stays un-fused like rustc.
+ *
+ * Pinning: checked in tests/test_oracle_golden.py against every known-answer vector the
+ * reference's own unit tests hold for this path and, for the SQ integer
+ * leaves, against the reference's own C kernels compiled into oracle/_ref/.
+ * Unpinned by the reference (stated): order among EQUAL scores in the bounded
+ * heap (Rust std BinaryHeap, restated here from its published algorithm).
+ */
+#ifndef QDRANT_ORACLE_H
+#define QDRANT_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { QO_COSINE = 0, QO_EUCLID = 1, QO_DOT = 2, QO_MANHATTAN = 3 }; /* types.rs:313-322 */
+enum { QO_F32 = 0, QO_F16 = 1, QO_U8 = 2 };
+enum { QO_ISA_AUTO = 0, QO_ISA_AVX = 1, QO_ISA_SSE = 2, QO_ISA_SCALAR = 3 };
+
+typedef struct { uint32_t idx; float score; } qo_scored_point; /* common/src/types.rs:12-17 */
+
+/* ---- f32 metrics: spaces/simple.rs, simple_avx.rs, simple_sse.rs ---- */
+float qo_dot_f32(const float *a, const float *b, size_t n, int isa);
+float qo_euclid_f32(const float *a, const float *b, size_t n, int isa);
+float qo_manhattan_f32(const float *a, const float *b, size_t n, int isa);
+/* Metric::similarity with the reference's dispatch thresholds (simple.rs:15,22,129-155) */
+float qo_similarity_f32(int distance, const float *q, const float *v, size_t n);
+/* cosine_preprocess(_avx/_sse) ; out may alias in.  isa as above. */
+void qo_cosine_preprocess_f32(const float *in, float *out, size_t n, int isa);
+/* Metric::preprocess for `distance` (identity unless cosine) with reference dispatch */
+void qo_preprocess_f32(int distance, const float *in, float *out, size_t n);
+/* MetricPostProcessing::postprocess (simple.rs:74-78,118-122,162-166,208-212) */
+float qo_postprocess(int distance, float score);
+
+/* ---- f16: spaces/metric_f16 ---- */
+float qo_dot_f16(const uint16_t *a, const uint16_t *b, size_t n, int isa);
+float qo_euclid_f16(const uint16_t *a, const uint16_t *b, size_t n, int isa);
+float qo_manhattan_f16(const uint16_t *a, const uint16_t *b, size_t n, int isa);
+float qo_similarity_f16(int distance, const uint16_t *q, const uint16_t *v, size_t n);
+void qo_f32_to_f16(const float *in, uint16_t *out, size_t n); /* f16::from_f32, RNE (primitive.rs:77-79) */
+void qo_f16_to_f32(const uint16_t *in, float *out, size_t n);
+
+/* ---- u8: spaces/metric_uint ---- */
+float qo_dot_u8(const uint8_t *a, const uint8_t *b, size_t n, int isa);
+float qo_cosine_u8(const uint8_t *a, const uint8_t *b, size_t n, int isa);
+float qo_euclid_u8(const uint8_t *a, const uint8_t *b, size_t n, int isa);
+float qo_manhattan_u8(const uint8_t *a, const uint8_t *b, size_t n, int isa);
+float qo_similarity_u8(int distance, const uint8_t *q, const uint8_t *v, size_t n, int isa);
+void qo_f32_to_u8(const float *in, uint8_t *out, size_t n); /* `x as u8` (primitive.rs:127-129) */
+
+/* ---- bounded top-k: FixedLengthPriorityQueue over Rust BinaryHeap<Reverse<T>> ---- */
+typedef struct qo_topk qo_topk;
+qo_topk *qo_topk_new(size_t length);
+void qo_topk_free(qo_topk *);
+void qo_topk_push(qo_topk *, uint32_t idx, float score);            /* fixed_length_priority_queue.rs:47-59 */
+size_t qo_topk_into_sorted(qo_topk *, qo_scored_point *out);        /* :63-65 ; consumes content */
+
+/* ---- brute force: BatchFilteredSearcher::peek_top_iter (point_scorer.rs:423-472) ---- */
+typedef struct {
+    int dtype;            /* QO_F32 / QO_F16 / QO_U8 */
+    int distance;
+    int u8_isa;           /* isa used for u8 similarity (QO_ISA_AUTO = AVX2 as on this host) */
+    const void *rows;     /* [n][dim] elements */
+    size_t n, dim;
+    const uint64_t *point_deleted; size_t n_point_bits; /* NULL => all rows live */
+    const uint64_t *vec_deleted;   size_t n_vec_bits;
+} qo_storage;
+/* queries: already preprocessed + cast to the element type, [nq][dim] elements.
+ * ids == NULL: stream = iter_zeros(point_deleted); else that list.  out [nq][top]; counts [nq].
+ * Returns 0, or 7 if *is_stopped became non-zero. */
+int qo_peek_top_iter(const qo_storage *st, const void *queries, size_t nq, size_t top,
+                     const uint32_t *ids, size_t n_ids, qo_scored_point *out, uint32_t *counts,
+                     const volatile uint8_t *is_stopped);
+/* same scan with `threads` pthreads over disjoint row ranges and a final merge (the reference's
+ * segment-parallel model, segments_searcher.rs:250-285); for the CPU baseline only */
+int qo_peek_top_parallel(const qo_storage *st, const void *queries, size_t nq, size_t top,
+                         qo_scored_point *out, uint32_t *counts, int threads);
+/* RawScorer::score_points for one query */
+void qo_score_points(const qo_storage *st, const void *query, const uint32_t *ids, size_t n, float *out);
+
+/* ---- SQ int8: lib/quantization/src/encoded_vectors_u8.rs ---- */
+typedef struct {
+    uint32_t dim, actual_dim;
+    int distance;         /* QO_* ; Cosine is treated like Dot */
+    int invert;
+    float alpha, offset, multiplier;
+} qo_sq;
+/* alpha/offset from global min/max (find_alpha_offset_size_dim, :523-533) + multiplier (:205-221) */
+void qo_sq_init(qo_sq *sq, int distance, int invert, uint32_t dim, const float *data, size_t n);
+void qo_sq_init_params(qo_sq *sq, int distance, int invert, uint32_t dim, float alpha, float offset);
+uint8_t qo_sq_encode_value(const qo_sq *sq, float v);                       /* :94-98 */
+float qo_sq_get_shift(const qo_sq *sq);                                     /* :116-134 */
+void qo_sq_encode_row(const qo_sq *sq, const float *v, uint8_t *out_row);   /* :236-296 ; row = 4 + actual_dim */
+void qo_sq_encode_query(const qo_sq *sq, const float *q, uint8_t *codes, float *q_offset); /* :583-619 */
+/* score_bytes (:777-810) -> score_point_avx/sse/simple ; isa selects the integer leaf.
+ * use_ref != 0 calls the reference's own C kernels through fn pointers set by qo_sq_set_ref_kernels */
+float qo_sq_score(const qo_sq *sq, const uint8_t *q_codes, float q_offset, const uint8_t *row, int isa);
+float qo_sq_score_internal(const qo_sq *sq, const uint8_t *row_i, const uint8_t *row_j, int isa); /* :675-705 */
+float qo_sq_dot_avx(const uint8_t *q, const uint8_t *v, uint32_t dim);      /* cpp/avx2.c:25-63 restated */
+float qo_sq_l1_avx(const uint8_t *q, const uint8_t *v, uint32_t dim);       /* cpp/avx2.c:65-122 */
+float qo_sq_dot_sse(const uint8_t *q, const uint8_t *v, uint32_t dim);      /* cpp/sse.c:28-52 */
+float qo_sq_l1_sse(const uint8_t *q, const uint8_t *v, uint32_t dim);       /* cpp/sse.c:472-513 */
+typedef float (*qo_sq_leaf_fn)(const uint8_t *, const uint8_t *, uint32_t);
+void qo_sq_set_ref_kernels(qo_sq_leaf_fn dot_avx, qo_sq_leaf_fn l1_avx); /* from oracle/_ref */
+
+/* ---- PQ: lib/quantization/src/encoded_vectors_pq.rs ---- */
+typedef struct {
+    uint32_t dim, chunk_size, m, n_centroids;
+    int distance, invert;
+    const float *centroids; /* [n_centroids][dim] */
+} qo_pq;
+void qo_pq_init(qo_pq *pq, int distance, int invert, uint32_t dim, uint32_t chunk_size,
+                uint32_t n_centroids, const float *centroids);
+void qo_pq_encode_vector(const qo_pq *pq, const float *v, uint8_t *codes);      /* :301-329 */
+void qo_pq_encode_query(const qo_pq *pq, const float *q, float *lut);           /* :519-541 ; lut [m][n_centroids] */
+float qo_pq_score(const qo_pq *pq, const float *lut, const uint8_t *codes, int isa); /* :409-443 sse, :478-493 simple */
+float qo_pq_score_internal(const qo_pq *pq, const uint8_t *ci, const uint8_t *cj);   /* :574-618 */
+/* deterministic Lloyd k-means for tests (kmeans.rs:9-169 shape; the reference re-seeds empty
+ * clusters randomly, so centroids are an INPUT to parity, never compared) */
+void qo_pq_train(uint32_t dim, uint32_t chunk_size, uint32_t n_centroids, const float *data,
+                 size_t n, int iters, float *centroids_out);
+
+/* ---- synthetic data shared bit-for-bit with the device generator ---- */
+float qo_synth_value(uint64_t seed, uint64_t row, uint32_t col, uint32_t dim);
+void qo_synth_fill_f32(uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

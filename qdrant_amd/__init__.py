@@ -1,0 +1,9 @@
+"""qdrant_amd — MI355X-native (gfx950, HIP) implementation of Qdrant's batched vector-scoring path.
+
+Layout: `csrc/` (HIP kernels + the C-ABI of include/qdrant_amd.h), `_ffi.py` (ctypes binding),
+`scorer.py` (host-side mirror of the reference's RawScorer / BatchFilteredSearcher interface).
+"""
+from ._ffi import (COSINE, DOT, DTYPE_F16, DTYPE_F32, DTYPE_PQ, DTYPE_SQ_U8, DTYPE_U8, EUCLID, MANHATTAN,  # noqa: F401
+                   QmxError, lib)
+from .scorer import (BatchFilteredSearcher, Distance, RawScorer, ScoredPointOffset, VectorStorage,  # noqa: F401
+                     VectorStorageDatatype, device_count, new_raw_scorer)

@@ -1,0 +1,136 @@
+"""ctypes binding of include/qdrant_amd.h (libqdrant_amd.so, built in-tree by `make`).
+
+The product path has no fallback: if the HIP library is missing this module raises, and every
+call that cannot reach a gfx950 device raises `QmxError` with the library's status code.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqdrant_amd.so")
+
+# status codes (qmx_status)
+OK, ERR_OUT_OF_MEMORY, ERR_OUT_OF_BOUNDS, ERR_NOT_SUPPORTED, ERR_NOT_READY, ERR_TIMEOUT, ERR_OTHER, \
+    ERR_CANCELLED, ERR_BAD_ARG, ERR_NO_DEVICE = range(10)
+STATUS_NAMES = ["OK", "OUT_OF_MEMORY", "OUT_OF_BOUNDS", "NOT_SUPPORTED", "NOT_READY", "TIMEOUT", "OTHER",
+                "CANCELLED", "BAD_ARG", "NO_DEVICE"]
+
+DTYPE_F32, DTYPE_F16, DTYPE_U8, DTYPE_SQ_U8, DTYPE_PQ = range(5)
+COSINE, EUCLID, DOT, MANHATTAN = range(4)
+
+SEG_DATA_ON_DEVICE = 0x1
+SEG_U8_SCALAR_ORDER = 0x2
+SEG_TIME_KERNELS = 0x4
+
+
+class ScoredPoint(C.Structure):
+    _fields_ = [("idx", C.c_uint32), ("score", C.c_float)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("vectors_scored", C.c_uint64), ("bytes_read", C.c_uint64), ("kernel_launches", C.c_uint64),
+                ("kernel_ms", C.c_float), ("reserved", C.c_float)]
+
+
+class SqParams(C.Structure):
+    _fields_ = [("actual_dim", C.c_uint32), ("alpha", C.c_float), ("offset", C.c_float), ("multiplier", C.c_float),
+                ("invert", C.c_uint8), ("pad_", C.c_uint8 * 3)]
+
+
+class PqParams(C.Structure):
+    _fields_ = [("chunk_size", C.c_uint32), ("n_centroids", C.c_uint32), ("centroids", C.c_void_p),
+                ("invert", C.c_uint8), ("lut_mfma", C.c_uint8), ("pad_", C.c_uint8 * 2)]
+
+
+class SegmentDesc(C.Structure):
+    _fields_ = [("dtype", C.c_uint32), ("distance", C.c_uint32), ("dim", C.c_uint32), ("flags", C.c_uint32),
+                ("n", C.c_uint64), ("row_stride_bytes", C.c_uint64), ("data", C.c_void_p),
+                ("device_id", C.c_int32), ("reserved", C.c_int32), ("sq", C.POINTER(SqParams)),
+                ("pq", C.POINTER(PqParams))]
+
+
+class QmxError(RuntimeError):
+    def __init__(self, status, message):
+        self.status = status
+        name = STATUS_NAMES[status] if 0 <= status < len(STATUS_NAMES) else str(status)
+        super().__init__(f"qmx status {status} ({name}): {message}")
+
+
+# every exported symbol of include/qdrant_amd.h with its signature (checked by tests/test_abi.py)
+_P = C.c_void_p
+SIGNATURES = {
+    "qmx_abi_version": (C.c_uint32, []),
+    "qmx_device_count": (C.c_int32, [C.POINTER(C.c_int32)]),
+    "qmx_last_error": (C.c_int32, [C.c_char_p, C.c_size_t]),
+    "qmx_segment_create": (C.c_int32, [C.POINTER(SegmentDesc), C.POINTER(_P)]),
+    "qmx_segment_destroy": (C.c_int32, [_P]),
+    "qmx_segment_set_deleted": (C.c_int32, [_P, _P, C.c_uint64, _P, C.c_uint64]),
+    "qmx_segment_read_rows": (C.c_int32, [_P, _P, C.c_uint32, _P]),
+    "qmx_segment_row_bytes": (C.c_int32, [_P, C.POINTER(C.c_uint64)]),
+    "qmx_preprocess_f32": (C.c_int32, [C.c_int32, C.c_uint32, _P, C.c_uint64, C.c_uint32, _P]),
+    "qmx_cast_f32": (C.c_int32, [C.c_int32, C.c_uint32, _P, C.c_uint64, _P]),
+    "qmx_query_create": (C.c_int32, [_P, _P, C.c_uint32, C.POINTER(_P)]),
+    "qmx_query_create_internal": (C.c_int32, [_P, _P, C.c_uint32, C.POINTER(_P)]),
+    "qmx_query_destroy": (C.c_int32, [_P]),
+    "qmx_query_set_stream": (C.c_int32, [_P, _P]),
+    "qmx_query_synchronize": (C.c_int32, [_P]),
+    "qmx_query_set_timing": (C.c_int32, [_P, C.c_int32]),
+    "qmx_query_read_encoded": (C.c_int32, [_P, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "qmx_score_points": (C.c_int32, [_P, _P, C.c_uint32, _P, C.POINTER(Counters)]),
+    "qmx_score_points_ragged": (C.c_int32, [_P, _P, _P, _P, C.POINTER(Counters)]),
+    "qmx_score_point": (C.c_int32, [_P, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]),
+    "qmx_score_internal": (C.c_int32, [_P, _P, _P, C.c_uint32, _P]),
+    "qmx_score_bytes": (C.c_int32, [_P, _P, C.c_uint32, C.c_uint64, _P]),
+    "qmx_search_topk": (C.c_int32, [_P, C.c_uint32, _P, C.c_uint64, _P, _P, _P, C.POINTER(Counters)]),
+    "qmx_search_topk_async": (C.c_int32, [_P, C.c_uint32, _P, C.c_uint64, _P, _P]),
+    "qmx_rescore": (C.c_int32, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, _P]),
+    "qmx_merge_topk": (C.c_int32, [C.c_int32, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P]),
+    "qmx_sq_encode": (C.c_int32, [C.c_int32, C.c_uint32, C.POINTER(SqParams), _P, C.c_uint64, C.c_uint32, _P]),
+    "qmx_pq_encode": (C.c_int32, [C.c_int32, C.POINTER(PqParams), _P, C.c_uint64, C.c_uint32, _P]),
+    "qmx_synth_fill_f32": (C.c_int32, [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Loads libqdrant_amd.so; fails loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `make` (hipcc --offload-arch=gfx950). "
+                "qdrant_amd has no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def last_error():
+    buf = C.create_string_buffer(1024)
+    lib().qmx_last_error(buf, len(buf))
+    return buf.value.decode(errors="replace")
+
+
+def check(status):
+    if status != OK:
+        raise QmxError(status, last_error())
+
+
+def ptr(x):
+    """Raw pointer of a numpy array (host), a torch tensor (host or device), an int, or None."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    if hasattr(x, "data_ptr"):  # torch.Tensor
+        return C.c_void_p(x.data_ptr())
+    if hasattr(x, "ctypes"):  # numpy.ndarray
+        return C.c_void_p(x.ctypes.data)
+    if isinstance(x, C.Array) or hasattr(x, "_b_base_"):
+        return C.cast(x, C.c_void_p)
+    raise TypeError(f"cannot take a pointer of {type(x)}")

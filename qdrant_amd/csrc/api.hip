@@ -1,0 +1,818 @@
+// api.hip — the C-ABI of include/qdrant_amd.h on top of the HIP kernels.
+// Host-side logic only: handle lifetime, argument checks, staging of host buffers, stream order.
+// No CPU scoring path exists here: every score is produced by a gfx950 kernel or the call fails.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace qmx {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+int32_t hip_status(hipError_t e, const char *what, const char *file, int line) {
+    set_error("HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+    (void)hipGetLastError();
+    switch (e) {
+        case hipErrorOutOfMemory: return QMX_ERR_OUT_OF_MEMORY;
+        case hipErrorNoDevice:
+        case hipErrorInvalidDevice:
+        case hipErrorNoBinaryForGpu:
+        case hipErrorInsufficientDriver: return QMX_ERR_NO_DEVICE;
+        case hipErrorNotReady: return QMX_ERR_NOT_READY;
+        case hipErrorInvalidValue: return QMX_ERR_BAD_ARG;
+        default: return QMX_ERR_OTHER;
+    }
+}
+
+static bool is_device_ptr(const void *p) {
+    if (!p) return false;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+static uint32_t elem_bytes(uint32_t dtype) {
+    switch (dtype) {
+        case QMX_DTYPE_F32: return 4;
+        case QMX_DTYPE_F16: return 2;
+        default: return 1;
+    }
+}
+
+// growable device scratch
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int32_t reserve(size_t bytes) {
+        if (bytes <= cap) return QMX_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = std::max<size_t>(bytes, 4096);
+        QMX_HIP(hipMalloc(&p, want));
+        cap = want;
+        return QMX_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+static int32_t check_device(int32_t device_id, hipDeviceProp_t *prop_out) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) {
+        (void)hipGetLastError();
+        set_error("no HIP device visible (%s); libqdrant_amd has no CPU fallback", e == hipSuccess ? "count=0" : hipGetErrorString(e));
+        return QMX_ERR_NO_DEVICE;
+    }
+    QMX_REQUIRE(device_id >= 0 && device_id < count, QMX_ERR_NO_DEVICE, "device %d out of range (have %d)", device_id, count);
+    hipDeviceProp_t prop;
+    QMX_HIP(hipGetDeviceProperties(&prop, device_id));
+    QMX_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, QMX_ERR_NO_DEVICE,
+                "device %d is %s; this library ships gfx950 (MI355X) code objects only", device_id, prop.gcnArchName);
+    QMX_HIP(hipSetDevice(device_id));
+    if (prop_out) *prop_out = prop;
+    return QMX_OK;
+}
+
+}  // namespace qmx
+
+using namespace qmx;
+
+// ---------------------------------------------------------------------------------------------
+// handles
+// ---------------------------------------------------------------------------------------------
+struct qmx_segment {
+    int device = 0;
+    int num_cus = 256;
+    uint32_t dtype = 0, distance = 0, dim = 0, flags = 0;
+    uint64_t n = 0;
+    uint64_t row_bytes = 0;    // reference row layout
+    uint64_t row_stride = 0;   // bytes between rows in d_rows
+    uint32_t scan_dim = 0;     // elements the metric consumes per row
+    void *d_rows = nullptr;
+    bool owns_rows = false;
+    uint64_t *d_point_deleted = nullptr;
+    uint64_t n_point_bits = 0;
+    uint64_t *d_vec_deleted = nullptr;
+    uint64_t n_vec_bits = 0;
+    qmx_sq_params sq{};
+    qmx_pq_params pq{};
+    float *d_centroids = nullptr;
+    uint32_t pq_m = 0;
+
+    bool fast_layout() const {
+        if (dtype == QMX_DTYPE_F32)
+            return dim >= 32 && dim % 4 == 0 && row_stride % 16 == 0 && ((uintptr_t)d_rows % 16) == 0;
+        return false;
+    }
+    DeletedView deleted_view() const {
+        DeletedView v;
+        v.point_deleted = d_point_deleted;
+        v.n_point_bits = n_point_bits;
+        v.vec_deleted = d_vec_deleted;
+        v.n_vec_bits = n_vec_bits;
+        v.n_rows = n;
+        return v;
+    }
+    // rows the brute-force stream visits: iter_zeros(point_deleted) ends at the bitslice length
+    uint64_t scan_rows() const { return d_point_deleted ? std::min<uint64_t>(n, n_point_bits) : n; }
+};
+
+struct qmx_query {
+    const qmx_segment *seg = nullptr;
+    uint32_t nq = 0;
+    uint32_t nq_padded = 0;
+    uint32_t q_stride = 0;     // bytes
+    void *d_queries = nullptr; // [nq_padded][q_stride]
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    DevBuf partial, out, counts, ids, scores, misc;
+    int *d_err = nullptr;
+    uint32_t partial_grid_cap = 0;
+    bool timing = false;
+};
+
+// stage a possibly-host buffer on the query's stream; returns a device pointer
+static int32_t stage_in(qmx_query *q, DevBuf &buf, const void *src, size_t bytes, const void **dev_out) {
+    if (bytes == 0 || !src) {
+        *dev_out = nullptr;
+        return QMX_OK;
+    }
+    if (is_device_ptr(src)) {
+        *dev_out = src;
+        return QMX_OK;
+    }
+    QMX_TRY(buf.reserve(bytes));
+    QMX_HIP(hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, q->stream));
+    *dev_out = buf.p;
+    return QMX_OK;
+}
+
+static int32_t copy_out(hipStream_t st, void *dst, const void *src_dev, size_t bytes) {
+    if (bytes == 0) return QMX_OK;
+    QMX_HIP(hipMemcpyAsync(dst, src_dev, bytes, is_device_ptr(dst) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+    return QMX_OK;
+}
+
+static int32_t check_err_flag(qmx_query *q) {
+    int flag = 0;
+    QMX_HIP(hipMemcpyAsync(&flag, q->d_err, sizeof(int), hipMemcpyDeviceToHost, q->stream));
+    QMX_HIP(hipStreamSynchronize(q->stream));
+    if (flag) {
+        QMX_HIP(hipMemsetAsync(q->d_err, 0, sizeof(int), q->stream));
+        set_error("point offset out of range for this segment (the reference panics here)");
+        return QMX_ERR_OUT_OF_BOUNDS;
+    }
+    return QMX_OK;
+}
+
+static uint32_t pow2_ceil(uint32_t x) {
+    uint32_t p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// library / device
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+uint32_t qmx_abi_version(void) { return 1; }
+
+int32_t qmx_last_error(char *buf, size_t buf_len) {
+    if (!buf || buf_len == 0) return QMX_ERR_BAD_ARG;
+    snprintf(buf, buf_len, "%s", g_last_error.c_str());
+    return QMX_OK;
+}
+
+int32_t qmx_device_count(int32_t *out_count) {
+    QMX_REQUIRE(out_count, QMX_ERR_BAD_ARG, "out_count is NULL");
+    *out_count = 0;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+        return QMX_ERR_NO_DEVICE;
+    }
+    int ok = 0;
+    for (int i = 0; i < count; ++i) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, i) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) ok++;
+    }
+    *out_count = ok;
+    return QMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// segment
+// ---------------------------------------------------------------------------------------------
+int32_t qmx_segment_create(const qmx_segment_desc *desc, qmx_segment **out) {
+    QMX_REQUIRE(desc && out, QMX_ERR_BAD_ARG, "NULL argument");
+    *out = nullptr;
+    QMX_REQUIRE(desc->dtype <= QMX_DTYPE_PQ, QMX_ERR_BAD_ARG, "bad dtype %u", desc->dtype);
+    QMX_REQUIRE(desc->distance <= QMX_DISTANCE_MANHATTAN, QMX_ERR_BAD_ARG, "bad distance %u", desc->distance);
+    QMX_REQUIRE(desc->dim > 0, QMX_ERR_BAD_ARG, "dim must be > 0");
+    QMX_REQUIRE(desc->n <= 0xFFFFFFFFull, QMX_ERR_BAD_ARG, "PointOffsetType is u32: n=%llu too large", (unsigned long long)desc->n);
+    QMX_REQUIRE(desc->n == 0 || desc->data, QMX_ERR_BAD_ARG, "data is NULL");
+    hipDeviceProp_t prop;
+    QMX_TRY(check_device(desc->device_id, &prop));
+
+    qmx_segment *s = new (std::nothrow) qmx_segment();
+    QMX_REQUIRE(s, QMX_ERR_OUT_OF_MEMORY, "host allocation failed");
+    s->device = desc->device_id;
+    s->num_cus = prop.multiProcessorCount;
+    s->dtype = desc->dtype;
+    s->distance = desc->distance;
+    s->dim = desc->dim;
+    s->flags = desc->flags;
+    s->n = desc->n;
+    s->scan_dim = desc->dim;
+    switch (desc->dtype) {
+        case QMX_DTYPE_F32:
+        case QMX_DTYPE_F16:
+        case QMX_DTYPE_U8: s->row_bytes = (uint64_t)desc->dim * elem_bytes(desc->dtype); break;
+        default:
+            delete s;
+            set_error("dtype %u not built yet", desc->dtype);
+            return QMX_ERR_NOT_SUPPORTED;
+    }
+    const uint64_t src_stride = desc->row_stride_bytes ? desc->row_stride_bytes : s->row_bytes;
+    if (src_stride < s->row_bytes) {
+        delete s;
+        set_error("row_stride_bytes %llu < row size %llu", (unsigned long long)src_stride, (unsigned long long)s->row_bytes);
+        return QMX_ERR_BAD_ARG;
+    }
+    const bool on_device = (desc->flags & QMX_SEG_DATA_ON_DEVICE) != 0;
+    if (on_device) {
+        s->d_rows = const_cast<void *>(desc->data);
+        s->row_stride = src_stride;
+        s->owns_rows = false;
+    } else {
+        // rows are re-packed at a 16-byte multiple so the 16-B lane loads stay aligned
+        s->row_stride = (s->row_bytes + 15) & ~15ull;
+        const size_t bytes = (size_t)std::max<uint64_t>(1, s->n) * s->row_stride;
+        hipError_t e = hipMalloc(&s->d_rows, bytes);
+        if (e != hipSuccess) {
+            delete s;
+            return hip_status(e, "hipMalloc(segment rows)", __FILE__, __LINE__);
+        }
+        s->owns_rows = true;
+        if (s->n) {
+            if (s->row_stride != s->row_bytes) (void)hipMemset(s->d_rows, 0, bytes);
+            e = hipMemcpy2D(s->d_rows, s->row_stride, desc->data, src_stride, s->row_bytes, s->n, hipMemcpyDefault);
+            if (e != hipSuccess) {
+                (void)hipFree(s->d_rows);
+                delete s;
+                return hip_status(e, "hipMemcpy2D(segment rows)", __FILE__, __LINE__);
+            }
+        }
+    }
+    *out = s;
+    return QMX_OK;
+}
+
+int32_t qmx_segment_destroy(qmx_segment *seg) {
+    if (!seg) return QMX_OK;
+    (void)hipSetDevice(seg->device);
+    if (seg->owns_rows && seg->d_rows) (void)hipFree(seg->d_rows);
+    if (seg->d_point_deleted) (void)hipFree(seg->d_point_deleted);
+    if (seg->d_vec_deleted) (void)hipFree(seg->d_vec_deleted);
+    if (seg->d_centroids) (void)hipFree(seg->d_centroids);
+    delete seg;
+    return QMX_OK;
+}
+
+int32_t qmx_segment_set_deleted(qmx_segment *seg, const uint64_t *point_deleted, uint64_t n_point_bits,
+                                const uint64_t *vec_deleted, uint64_t n_vec_bits) {
+    QMX_REQUIRE(seg, QMX_ERR_BAD_ARG, "NULL segment");
+    QMX_HIP(hipSetDevice(seg->device));
+    auto upload = [&](const uint64_t *src, uint64_t nbits, uint64_t **dst, uint64_t *dst_bits) -> int32_t {
+        if (*dst) (void)hipFree(*dst);
+        *dst = nullptr;
+        *dst_bits = 0;
+        if (!src) return QMX_OK;
+        const size_t words = (size_t)((nbits + 63) / 64);
+        QMX_HIP(hipMalloc((void **)dst, std::max<size_t>(words, 1) * 8));
+        if (words) QMX_HIP(hipMemcpy(*dst, src, words * 8, hipMemcpyDefault));
+        *dst_bits = nbits;
+        return QMX_OK;
+    };
+    QMX_TRY(upload(point_deleted, n_point_bits, &seg->d_point_deleted, &seg->n_point_bits));
+    QMX_TRY(upload(vec_deleted, n_vec_bits, &seg->d_vec_deleted, &seg->n_vec_bits));
+    return QMX_OK;
+}
+
+int32_t qmx_segment_row_bytes(const qmx_segment *seg, uint64_t *out) {
+    QMX_REQUIRE(seg && out, QMX_ERR_BAD_ARG, "NULL argument");
+    *out = seg->row_bytes;
+    return QMX_OK;
+}
+
+int32_t qmx_segment_read_rows(const qmx_segment *seg, const uint32_t *ids, uint32_t n, void *out_rows) {
+    QMX_REQUIRE(seg && (n == 0 || (ids && out_rows)), QMX_ERR_BAD_ARG, "NULL argument");
+    QMX_HIP(hipSetDevice(seg->device));
+    for (uint32_t i = 0; i < n; ++i) {
+        QMX_REQUIRE(ids[i] < seg->n, QMX_ERR_OUT_OF_BOUNDS, "row %u out of range", ids[i]);
+        QMX_HIP(hipMemcpy((char *)out_rows + (size_t)i * seg->row_bytes,
+                          (const char *)seg->d_rows + (size_t)ids[i] * seg->row_stride, seg->row_bytes, hipMemcpyDefault));
+    }
+    return QMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// preprocess / casts / synth
+// ---------------------------------------------------------------------------------------------
+int32_t qmx_preprocess_f32(int32_t device_id, uint32_t distance, const float *in, uint64_t n, uint32_t dim, float *out) {
+    QMX_REQUIRE(in && out && dim > 0, QMX_ERR_BAD_ARG, "bad argument");
+    QMX_TRY(check_device(device_id, nullptr));
+    const size_t bytes = (size_t)n * dim * sizeof(float);
+    if (bytes == 0) return QMX_OK;
+    const bool in_dev = is_device_ptr(in), out_dev = is_device_ptr(out);
+    float *d_in = const_cast<float *>(in), *d_out = out;
+    DevBuf bin, bout;
+    if (!in_dev) {
+        QMX_TRY(bin.reserve(bytes));
+        QMX_HIP(hipMemcpy(bin.p, in, bytes, hipMemcpyHostToDevice));
+        d_in = (float *)bin.p;
+    }
+    if (!out_dev) {
+        QMX_TRY(bout.reserve(bytes));
+        d_out = (float *)bout.p;
+    }
+    int32_t rc = QMX_OK;
+    if (distance == QMX_DISTANCE_COSINE) rc = launch_cosine_preprocess_f32(nullptr, d_in, d_out, n, dim);
+    else if (d_out != d_in) rc = hipMemcpy(d_out, d_in, bytes, hipMemcpyDeviceToDevice) == hipSuccess ? QMX_OK : QMX_ERR_OTHER;
+    if (rc == QMX_OK && !out_dev) rc = hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost) == hipSuccess ? QMX_OK : QMX_ERR_OTHER;
+    if (rc == QMX_OK && hipDeviceSynchronize() != hipSuccess) rc = QMX_ERR_OTHER;
+    bin.release();
+    bout.release();
+    return rc;
+}
+
+int32_t qmx_cast_f32(int32_t device_id, uint32_t dst_dtype, const float *in, uint64_t count, void *out) {
+    QMX_REQUIRE(in && out, QMX_ERR_BAD_ARG, "NULL argument");
+    QMX_REQUIRE(dst_dtype <= QMX_DTYPE_U8, QMX_ERR_BAD_ARG, "bad dtype");
+    QMX_TRY(check_device(device_id, nullptr));
+    if (count == 0) return QMX_OK;
+    const size_t in_bytes = (size_t)count * 4, out_bytes = (size_t)count * elem_bytes(dst_dtype);
+    const bool in_dev = is_device_ptr(in), out_dev = is_device_ptr(out);
+    DevBuf bin, bout;
+    const float *d_in = in;
+    void *d_out = out;
+    if (!in_dev) {
+        QMX_TRY(bin.reserve(in_bytes));
+        QMX_HIP(hipMemcpy(bin.p, in, in_bytes, hipMemcpyHostToDevice));
+        d_in = (const float *)bin.p;
+    }
+    if (!out_dev) {
+        QMX_TRY(bout.reserve(out_bytes));
+        d_out = bout.p;
+    }
+    int32_t rc = launch_cast_f32(nullptr, (int)dst_dtype, d_in, d_out, count);
+    if (rc == QMX_OK && !out_dev) rc = hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost) == hipSuccess ? QMX_OK : QMX_ERR_OTHER;
+    if (rc == QMX_OK && hipDeviceSynchronize() != hipSuccess) rc = QMX_ERR_OTHER;
+    bin.release();
+    bout.release();
+    return rc;
+}
+
+int32_t qmx_synth_fill_f32(int32_t device_id, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, float *out_dev) {
+    QMX_REQUIRE(out_dev && dim > 0, QMX_ERR_BAD_ARG, "bad argument");
+    QMX_TRY(check_device(device_id, nullptr));
+    QMX_REQUIRE(is_device_ptr(out_dev), QMX_ERR_BAD_ARG, "out_dev must be device memory");
+    QMX_TRY(launch_synth_fill(nullptr, seed, row0, n, dim, out_dev));
+    QMX_HIP(hipDeviceSynchronize());
+    return QMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// query batch
+// ---------------------------------------------------------------------------------------------
+static int32_t query_alloc(const qmx_segment *seg, uint32_t nq, qmx_query **out) {
+    qmx_query *q = new (std::nothrow) qmx_query();
+    QMX_REQUIRE(q, QMX_ERR_OUT_OF_MEMORY, "host allocation failed");
+    q->seg = seg;
+    q->nq = nq;
+    q->nq_padded = ((nq + MAX_QT - 1) / MAX_QT) * MAX_QT;
+    if (q->nq_padded == 0) q->nq_padded = MAX_QT;
+    q->q_stride = (uint32_t)((seg->scan_dim * elem_bytes(seg->dtype) + 15) & ~15u);
+    auto fail = [&](hipError_t e, const char *what) {
+        int32_t rc = hip_status(e, what, __FILE__, __LINE__);
+        qmx_query_destroy(q);
+        return rc;
+    };
+    hipError_t e = hipStreamCreateWithFlags(&q->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) return fail(e, "hipStreamCreate");
+    q->stream = q->own_stream;
+    e = hipEventCreate(&q->ev0);
+    if (e != hipSuccess) return fail(e, "hipEventCreate");
+    e = hipEventCreate(&q->ev1);
+    if (e != hipSuccess) return fail(e, "hipEventCreate");
+    const size_t qbytes = (size_t)q->nq_padded * q->q_stride;
+    e = hipMalloc(&q->d_queries, qbytes);
+    if (e != hipSuccess) return fail(e, "hipMalloc(queries)");
+    e = hipMemsetAsync(q->d_queries, 0, qbytes, q->stream);
+    if (e != hipSuccess) return fail(e, "hipMemset(queries)");
+    e = hipMalloc((void **)&q->d_err, sizeof(int));
+    if (e != hipSuccess) return fail(e, "hipMalloc(err)");
+    e = hipMemsetAsync(q->d_err, 0, sizeof(int), q->stream);
+    if (e != hipSuccess) return fail(e, "hipMemset(err)");
+    *out = q;
+    return QMX_OK;
+}
+
+int32_t qmx_query_create(const qmx_segment *seg, const float *queries, uint32_t nq, qmx_query **out) {
+    QMX_REQUIRE(seg && out && (nq == 0 || queries), QMX_ERR_BAD_ARG, "NULL argument");
+    *out = nullptr;
+    QMX_HIP(hipSetDevice(seg->device));
+    qmx_query *q = nullptr;
+    QMX_TRY(query_alloc(seg, nq, &q));
+    int32_t rc = QMX_OK;
+    do {
+        if (nq == 0) break;
+        // MetricQueryScorer::new (metric_query_scorer.rs:35-58): preprocess once, then cast
+        const size_t fbytes = (size_t)nq * seg->dim * sizeof(float);
+        const void *d_src = nullptr;
+        if ((rc = stage_in(q, q->misc, queries, fbytes, &d_src)) != QMX_OK) break;
+        float *d_f32 = nullptr;
+        if ((rc = q->scores.reserve(fbytes)) != QMX_OK) break;
+        d_f32 = (float *)q->scores.p;
+        // u8 storages never normalise (metric_uint/simple_cosine.rs:53-55)
+        const bool normalise = seg->distance == QMX_DISTANCE_COSINE && seg->dtype != QMX_DTYPE_U8;
+        if (normalise) {
+            if ((rc = launch_cosine_preprocess_f32(q->stream, (const float *)d_src, d_f32, nq, seg->dim)) != QMX_OK) break;
+        } else {
+            hipError_t e = hipMemcpyAsync(d_f32, d_src, fbytes, hipMemcpyDeviceToDevice, q->stream);
+            if (e != hipSuccess) { rc = hip_status(e, "copy queries", __FILE__, __LINE__); break; }
+        }
+        if (seg->dtype == QMX_DTYPE_F32) {
+            hipError_t e = hipMemcpy2DAsync(q->d_queries, q->q_stride, d_f32, (size_t)seg->dim * 4, (size_t)seg->dim * 4, nq,
+                                            hipMemcpyDeviceToDevice, q->stream);
+            if (e != hipSuccess) { rc = hip_status(e, "pack queries", __FILE__, __LINE__); break; }
+        } else {
+            set_error("query encode for dtype %u not built yet", seg->dtype);
+            rc = QMX_ERR_NOT_SUPPORTED;
+            break;
+        }
+        hipError_t e = hipStreamSynchronize(q->stream);
+        if (e != hipSuccess) { rc = hip_status(e, "sync", __FILE__, __LINE__); break; }
+    } while (0);
+    if (rc != QMX_OK) {
+        qmx_query_destroy(q);
+        return rc;
+    }
+    *out = q;
+    return QMX_OK;
+}
+
+int32_t qmx_query_create_internal(const qmx_segment *seg, const uint32_t *point_ids, uint32_t nq, qmx_query **out) {
+    QMX_REQUIRE(seg && out && (nq == 0 || point_ids), QMX_ERR_BAD_ARG, "NULL argument");
+    *out = nullptr;
+    QMX_HIP(hipSetDevice(seg->device));
+    QMX_REQUIRE(seg->dtype <= QMX_DTYPE_U8, QMX_ERR_NOT_SUPPORTED, "internal queries for dtype %u not built yet", seg->dtype);
+    qmx_query *q = nullptr;
+    QMX_TRY(query_alloc(seg, nq, &q));
+    int32_t rc = QMX_OK;
+    do {
+        if (nq == 0) break;
+        const void *d_ids = nullptr;
+        if ((rc = stage_in(q, q->ids, point_ids, (size_t)nq * 4, &d_ids)) != QMX_OK) break;
+        // the stored row IS the query (already preprocessed at insert): FilteredScorer::new_internal
+        if ((rc = q->misc.reserve((size_t)nq * seg->row_bytes)) != QMX_OK) break;
+        if ((rc = launch_gather_rows(q->stream, seg->d_rows, seg->row_stride, seg->row_bytes, (const uint32_t *)d_ids, nq,
+                                     seg->n, q->misc.p, q->d_err)) != QMX_OK) break;
+        hipError_t e = hipMemcpy2DAsync(q->d_queries, q->q_stride, q->misc.p, seg->row_bytes, seg->row_bytes, nq,
+                                        hipMemcpyDeviceToDevice, q->stream);
+        if (e != hipSuccess) { rc = hip_status(e, "pack queries", __FILE__, __LINE__); break; }
+        if ((rc = check_err_flag(q)) != QMX_OK) break;
+    } while (0);
+    if (rc != QMX_OK) {
+        qmx_query_destroy(q);
+        return rc;
+    }
+    *out = q;
+    return QMX_OK;
+}
+
+int32_t qmx_query_destroy(qmx_query *q) {
+    if (!q) return QMX_OK;
+    if (q->seg) (void)hipSetDevice(q->seg->device);
+    if (q->stream) (void)hipStreamSynchronize(q->stream);
+    if (q->d_queries) (void)hipFree(q->d_queries);
+    if (q->d_err) (void)hipFree(q->d_err);
+    q->partial.release();
+    q->out.release();
+    q->counts.release();
+    q->ids.release();
+    q->scores.release();
+    q->misc.release();
+    if (q->ev0) (void)hipEventDestroy(q->ev0);
+    if (q->ev1) (void)hipEventDestroy(q->ev1);
+    if (q->own_stream) (void)hipStreamDestroy(q->own_stream);
+    delete q;
+    return QMX_OK;
+}
+
+int32_t qmx_query_set_stream(qmx_query *q, void *hip_stream) {
+    QMX_REQUIRE(q, QMX_ERR_BAD_ARG, "NULL query");
+    QMX_HIP(hipStreamSynchronize(q->stream));
+    q->stream = hip_stream ? (hipStream_t)hip_stream : q->own_stream;
+    return QMX_OK;
+}
+
+int32_t qmx_query_set_timing(qmx_query *q, int32_t enabled) {
+    QMX_REQUIRE(q, QMX_ERR_BAD_ARG, "NULL query");
+    q->timing = enabled != 0;
+    return QMX_OK;
+}
+
+int32_t qmx_query_synchronize(qmx_query *q) {
+    QMX_REQUIRE(q, QMX_ERR_BAD_ARG, "NULL query");
+    QMX_HIP(hipSetDevice(q->seg->device));
+    QMX_HIP(hipStreamSynchronize(q->stream));
+    return QMX_OK;
+}
+
+int32_t qmx_query_read_encoded(const qmx_query *q, uint32_t query_index, void *out, uint64_t out_bytes, uint64_t *written) {
+    QMX_REQUIRE(q && out, QMX_ERR_BAD_ARG, "NULL argument");
+    QMX_REQUIRE(query_index < q->nq, QMX_ERR_OUT_OF_BOUNDS, "query index %u >= %u", query_index, q->nq);
+    QMX_HIP(hipSetDevice(q->seg->device));
+    const uint64_t bytes = (uint64_t)q->seg->scan_dim * elem_bytes(q->seg->dtype);
+    QMX_REQUIRE(out_bytes >= bytes, QMX_ERR_BAD_ARG, "buffer too small: need %llu", (unsigned long long)bytes);
+    QMX_HIP(hipStreamSynchronize(q->stream));
+    QMX_HIP(hipMemcpy(out, (const char *)q->d_queries + (size_t)query_index * q->q_stride, bytes, hipMemcpyDefault));
+    if (written) *written = bytes;
+    return QMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// scoring
+// ---------------------------------------------------------------------------------------------
+static void fill_args(const qmx_query *q, uint32_t tile0, uint32_t nq_tile, ScanArgs &a) {
+    const qmx_segment *s = q->seg;
+    memset(&a, 0, sizeof(a));
+    a.rows = s->d_rows;
+    a.n_rows = s->n;
+    a.row_stride = s->row_stride;
+    a.dim = s->scan_dim;
+    a.nq = nq_tile;
+    a.queries = (const char *)q->d_queries + (size_t)tile0 * q->q_stride;
+    a.q_stride = q->q_stride;
+    a.del = s->deleted_view();
+    a.err_flag = q->d_err;
+    a.flags = s->flags;
+    a.sq_multiplier = s->sq.multiplier;
+    a.pq_m = s->pq_m;
+    a.pq_ncent = s->pq.n_centroids;
+}
+
+static int32_t launch_scan(const qmx_query *q, int qt, ScanMode mode, const ScanArgs &a, uint32_t *grid) {
+    const qmx_segment *s = q->seg;
+    if (s->dtype <= QMX_DTYPE_U8) {
+        QMX_REQUIRE(s->fast_layout(), QMX_ERR_NOT_SUPPORTED,
+                    "dtype %u dim %u stride %llu: generic-layout kernel not built yet", s->dtype, s->dim,
+                    (unsigned long long)s->row_stride);
+        return launch_scan_dense(q->stream, (int)s->dtype, (int)s->distance, qt, mode, a, s->num_cus, grid);
+    }
+    set_error("dtype %u not built yet", s->dtype);
+    return QMX_ERR_NOT_SUPPORTED;
+}
+
+// scores[qi * n + i] for every query of the batch
+static int32_t score_ids_device(qmx_query *q, const uint32_t *d_ids, uint64_t n, float *d_scores, qmx_counters *counters) {
+    const qmx_segment *s = q->seg;
+    for (uint32_t tile0 = 0; tile0 < q->nq; tile0 += MAX_QT) {
+        const uint32_t nq_tile = std::min<uint32_t>(MAX_QT, q->nq - tile0);
+        ScanArgs a;
+        fill_args(q, tile0, nq_tile, a);
+        a.ids = d_ids;
+        a.n_cand = n;
+        a.top = 1;
+        a.scores = d_scores + (size_t)tile0 * n;
+        a.scores_stride = n;
+        uint32_t grid = 0;
+        QMX_TRY(launch_scan(q, (int)pow2_ceil(nq_tile), SCAN_SCORES, a, &grid));
+        if (counters) counters->kernel_launches++;
+    }
+    if (counters) {
+        counters->vectors_scored += (uint64_t)q->nq * n;
+        counters->bytes_read += (uint64_t)((q->nq + MAX_QT - 1) / MAX_QT) * n * s->row_bytes;
+    }
+    return QMX_OK;
+}
+
+int32_t qmx_score_points(qmx_query *q, const uint32_t *ids, uint32_t n, float *scores, qmx_counters *counters) {
+    QMX_REQUIRE(q && (n == 0 || (ids && scores)), QMX_ERR_BAD_ARG, "NULL argument");
+    QMX_HIP(hipSetDevice(q->seg->device));
+    if (counters) memset(counters, 0, sizeof(*counters));
+    if (n == 0 || q->nq == 0) return QMX_OK;
+    const void *d_ids = nullptr;
+    QMX_TRY(stage_in(q, q->ids, ids, (size_t)n * 4, &d_ids));
+    const size_t sbytes = (size_t)q->nq * n * sizeof(float);
+    float *d_scores = scores;
+    const bool out_dev = is_device_ptr(scores);
+    if (!out_dev) {
+        QMX_TRY(q->scores.reserve(sbytes));
+        d_scores = (float *)q->scores.p;
+    }
+    QMX_TRY(score_ids_device(q, (const uint32_t *)d_ids, n, d_scores, counters));
+    if (!out_dev) QMX_HIP(hipMemcpyAsync(scores, d_scores, sbytes, hipMemcpyDeviceToHost, q->stream));
+    return check_err_flag(q);
+}
+
+int32_t qmx_score_point(qmx_query *q, uint32_t query_index, uint32_t id, float *out) {
+    QMX_REQUIRE(q && out, QMX_ERR_BAD_ARG, "NULL argument");
+    QMX_REQUIRE(query_index < q->nq, QMX_ERR_OUT_OF_BOUNDS, "query index out of range");
+    std::vector<float> tmp(q->nq);
+    QMX_TRY(qmx_score_points(q, &id, 1, tmp.data(), nullptr));
+    *out = tmp[query_index];
+    return QMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// brute-force top-k
+// ---------------------------------------------------------------------------------------------
+static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids, uint64_t n_ids,
+                              qmx_scored_point *d_out, uint32_t *d_counts, const volatile uint8_t *is_stopped,
+                              qmx_counters *counters, bool timed) {
+    const qmx_segment *s = q->seg;
+    const uint64_t n_cand = d_ids ? n_ids : s->scan_rows();
+    // partial lists: one per block; bound the grid by what the buffer holds
+    const uint32_t grid_cap = (uint32_t)s->num_cus * 8;
+    QMX_TRY(q->partial.reserve((size_t)grid_cap * MAX_QT * top * sizeof(uint64_t)));
+    float total_ms = 0.f;
+    for (uint32_t tile0 = 0; tile0 < q->nq; tile0 += MAX_QT) {
+        if (is_stopped && *is_stopped) {
+            set_error("search cancelled");
+            return QMX_ERR_CANCELLED;
+        }
+        const uint32_t nq_tile = std::min<uint32_t>(MAX_QT, q->nq - tile0);
+        const int qt = (int)pow2_ceil(nq_tile);
+        ScanArgs a;
+        fill_args(q, tile0, nq_tile, a);
+        a.ids = d_ids;
+        a.n_cand = n_cand;
+        a.top = top;
+        a.partial = (uint64_t *)q->partial.p;
+        uint32_t grid = grid_cap;
+        if (timed) QMX_HIP(hipEventRecord(q->ev0, q->stream));
+        QMX_TRY(launch_scan(q, qt, SCAN_TOPK, a, &grid));
+        if (timed) QMX_HIP(hipEventRecord(q->ev1, q->stream));
+        QMX_TRY(launch_merge_keys(q->stream, (const uint64_t *)q->partial.p, grid, (uint32_t)qt, nq_tile, top,
+                                  d_out + (size_t)tile0 * top, d_counts + tile0));
+        if (timed) {
+            QMX_HIP(hipEventSynchronize(q->ev1));
+            float ms = 0.f;
+            QMX_HIP(hipEventElapsedTime(&ms, q->ev0, q->ev1));
+            total_ms += ms;
+        }
+        if (counters) counters->kernel_launches += 2;
+    }
+    if (counters) {
+        counters->vectors_scored += (uint64_t)q->nq * n_cand;
+        counters->bytes_read += (uint64_t)((q->nq + MAX_QT - 1) / MAX_QT) * n_cand * s->row_bytes;
+        counters->kernel_ms += total_ms;
+    }
+    return QMX_OK;
+}
+
+int32_t qmx_search_topk(qmx_query *q, uint32_t top, const uint32_t *ids, uint64_t n_ids, qmx_scored_point *out,
+                        uint32_t *out_counts, const volatile uint8_t *is_stopped, qmx_counters *counters) {
+    QMX_REQUIRE(q && out && out_counts, QMX_ERR_BAD_ARG, "NULL argument");
+    QMX_REQUIRE(top >= 1, QMX_ERR_BAD_ARG, "top must be > 0 (FixedLengthPriorityQueue::new panics on 0)");
+    QMX_REQUIRE(top <= MAX_TOP_FAST, QMX_ERR_NOT_SUPPORTED, "top %u > %d not supported yet", top, MAX_TOP_FAST);
+    QMX_HIP(hipSetDevice(q->seg->device));
+    if (counters) memset(counters, 0, sizeof(*counters));
+    if (q->nq == 0) return QMX_OK;
+    const void *d_ids = nullptr;
+    if (ids) {
+        if (n_ids == 0) {  // empty candidate list: every queue stays empty
+            for (uint32_t i = 0; i < q->nq; ++i) out_counts[i] = 0;
+            return QMX_OK;
+        }
+        QMX_TRY(stage_in(q, q->ids, ids, (size_t)n_ids * 4, &d_ids));
+    }
+    const bool out_dev = is_device_ptr(out);
+    const bool cnt_dev = is_device_ptr(out_counts);
+    qmx_scored_point *d_out = out;
+    uint32_t *d_counts = out_counts;
+    if (!out_dev) {
+        QMX_TRY(q->out.reserve((size_t)q->nq * top * sizeof(qmx_scored_point)));
+        d_out = (qmx_scored_point *)q->out.p;
+    }
+    if (!cnt_dev) {
+        QMX_TRY(q->counts.reserve((size_t)q->nq * sizeof(uint32_t)));
+        d_counts = (uint32_t *)q->counts.p;
+    }
+    const bool timed = q->timing || (q->seg->flags & QMX_SEG_TIME_KERNELS) != 0;
+    QMX_TRY(search_enqueue(q, top, (const uint32_t *)d_ids, n_ids, d_out, d_counts, is_stopped, counters, timed));
+    if (!out_dev) QMX_TRY(copy_out(q->stream, out, d_out, (size_t)q->nq * top * sizeof(qmx_scored_point)));
+    if (!cnt_dev) QMX_TRY(copy_out(q->stream, out_counts, d_counts, (size_t)q->nq * sizeof(uint32_t)));
+    return check_err_flag(q);
+}
+
+int32_t qmx_search_topk_async(qmx_query *q, uint32_t top, const uint32_t *ids, uint64_t n_ids,
+                              qmx_scored_point *out_dev, uint32_t *out_counts_dev) {
+    QMX_REQUIRE(q && out_dev && out_counts_dev, QMX_ERR_BAD_ARG, "NULL argument");
+    QMX_REQUIRE(top >= 1 && top <= MAX_TOP_FAST, QMX_ERR_NOT_SUPPORTED, "top %u not in 1..%d", top, MAX_TOP_FAST);
+    QMX_REQUIRE(!ids || is_device_ptr(ids), QMX_ERR_BAD_ARG, "async search needs device ids");
+    QMX_HIP(hipSetDevice(q->seg->device));
+    if (q->nq == 0) return QMX_OK;
+    return search_enqueue(q, top, ids, n_ids, out_dev, out_counts_dev, nullptr, nullptr, false);
+}
+
+int32_t qmx_rescore(qmx_query *q, const uint32_t *ids, const uint32_t *counts, uint32_t n_per_query, uint32_t top,
+                    qmx_scored_point *out, uint32_t *out_counts) {
+    QMX_REQUIRE(q && ids && out && out_counts, QMX_ERR_BAD_ARG, "NULL argument");
+    QMX_REQUIRE(top >= 1 && top <= MAX_TOP_FAST, QMX_ERR_NOT_SUPPORTED, "top %u not in 1..%d", top, MAX_TOP_FAST);
+    set_error("qmx_rescore not built yet");
+    return QMX_ERR_NOT_SUPPORTED;
+}
+
+int32_t qmx_merge_topk(int32_t device_id, const qmx_scored_point *lists, const uint32_t *list_counts, uint32_t n_lists,
+                       uint32_t nq, uint32_t k, qmx_scored_point *out, uint32_t *out_counts) {
+    QMX_REQUIRE(lists && out && out_counts, QMX_ERR_BAD_ARG, "NULL argument");
+    QMX_REQUIRE(k >= 1 && k <= MAX_TOP_FAST, QMX_ERR_NOT_SUPPORTED, "k %u not in 1..%d", k, MAX_TOP_FAST);
+    QMX_TRY(check_device(device_id, nullptr));
+    if (nq == 0) return QMX_OK;
+    const size_t lbytes = (size_t)n_lists * nq * k * sizeof(qmx_scored_point);
+    const size_t cbytes = (size_t)n_lists * nq * sizeof(uint32_t);
+    const size_t obytes = (size_t)nq * k * sizeof(qmx_scored_point);
+    DevBuf bl, bc, bo, boc;
+    const qmx_scored_point *d_lists = lists;
+    const uint32_t *d_lc = list_counts;
+    qmx_scored_point *d_out = out;
+    uint32_t *d_oc = out_counts;
+    int32_t rc = QMX_OK;
+    do {
+        if (!is_device_ptr(lists)) {
+            if ((rc = bl.reserve(lbytes)) != QMX_OK) break;
+            if (hipMemcpy(bl.p, lists, lbytes, hipMemcpyHostToDevice) != hipSuccess) { rc = QMX_ERR_OTHER; break; }
+            d_lists = (const qmx_scored_point *)bl.p;
+        }
+        if (list_counts && !is_device_ptr(list_counts)) {
+            if ((rc = bc.reserve(cbytes)) != QMX_OK) break;
+            if (hipMemcpy(bc.p, list_counts, cbytes, hipMemcpyHostToDevice) != hipSuccess) { rc = QMX_ERR_OTHER; break; }
+            d_lc = (const uint32_t *)bc.p;
+        }
+        const bool od = is_device_ptr(out), ocd = is_device_ptr(out_counts);
+        if (!od) { if ((rc = bo.reserve(obytes)) != QMX_OK) break; d_out = (qmx_scored_point *)bo.p; }
+        if (!ocd) { if ((rc = boc.reserve((size_t)nq * 4)) != QMX_OK) break; d_oc = (uint32_t *)boc.p; }
+        if ((rc = launch_merge_points(nullptr, d_lists, d_lc, n_lists, nq, k, d_out, d_oc)) != QMX_OK) break;
+        if (!od && hipMemcpy(out, d_out, obytes, hipMemcpyDeviceToHost) != hipSuccess) { rc = QMX_ERR_OTHER; break; }
+        if (!ocd && hipMemcpy(out_counts, d_oc, (size_t)nq * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = QMX_ERR_OTHER; break; }
+        if (hipDeviceSynchronize() != hipSuccess) rc = QMX_ERR_OTHER;
+    } while (0);
+    bl.release(); bc.release(); bo.release(); boc.release();
+    return rc;
+}
+
+// ---- not built yet -----------------------------------------------------------------------------
+int32_t qmx_score_points_ragged(qmx_query *, const uint32_t *, const uint32_t *, float *, qmx_counters *) {
+    set_error("qmx_score_points_ragged not built yet");
+    return QMX_ERR_NOT_SUPPORTED;
+}
+int32_t qmx_score_internal(const qmx_segment *, const uint32_t *, const uint32_t *, uint32_t, float *) {
+    set_error("qmx_score_internal not built yet");
+    return QMX_ERR_NOT_SUPPORTED;
+}
+int32_t qmx_score_bytes(qmx_query *, const void *, uint32_t, uint64_t, float *) {
+    set_error("qmx_score_bytes not built yet");
+    return QMX_ERR_NOT_SUPPORTED;
+}
+int32_t qmx_sq_encode(int32_t, uint32_t, const qmx_sq_params *, const float *, uint64_t, uint32_t, void *) {
+    set_error("qmx_sq_encode not built yet");
+    return QMX_ERR_NOT_SUPPORTED;
+}
+int32_t qmx_pq_encode(int32_t, const qmx_pq_params *, const float *, uint64_t, uint32_t, uint8_t *) {
+    set_error("qmx_pq_encode not built yet");
+    return QMX_ERR_NOT_SUPPORTED;
+}
+
+}  // extern "C"

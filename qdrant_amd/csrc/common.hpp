@@ -1,0 +1,121 @@
+// common.hpp — shared host/device helpers for libqdrant_amd.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/qdrant_amd.h"
+
+namespace qmx {
+
+// ---- error plumbing ------------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+int32_t hip_status(hipError_t e, const char *what, const char *file, int line);
+
+#define QMX_HIP(expr)                                                        \
+    do {                                                                     \
+        hipError_t e__ = (expr);                                             \
+        if (e__ != hipSuccess) return ::qmx::hip_status(e__, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+#define QMX_TRY(expr)                           \
+    do {                                        \
+        int32_t s__ = (expr);                   \
+        if (s__ != QMX_OK) return s__;          \
+    } while (0)
+
+#define QMX_REQUIRE(cond, code, ...)            \
+    do {                                        \
+        if (!(cond)) {                          \
+            ::qmx::set_error(__VA_ARGS__);      \
+            return (code);                      \
+        }                                       \
+    } while (0)
+
+// ---- device helpers --------------------------------------------------------------------------
+#if defined(__HIPCC__)
+
+constexpr int WAVE = 64;
+
+// DPP controls (cdna4 ISA: quad_perm 0x00-0xFF, row_half_mirror 0x141, row_mirror 0x140)
+constexpr int DPP_QUAD_XOR1 = 0xB1;         // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;         // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;  // lane i <-> 7-i inside each group of 8
+constexpr int DPP_QUAD_BCAST0 = 0x00;       // quad_perm:[0,0,0,0]
+constexpr int DPP_QUAD_BCAST1 = 0x55;
+constexpr int DPP_QUAD_BCAST2 = 0xAA;
+constexpr int DPP_QUAD_BCAST3 = 0xFF;
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane_uniform) {
+    uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, lane_uniform);
+    uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane_uniform);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl_up1_u64(uint64_t v) {
+    uint32_t lo = __shfl_up((int)(uint32_t)v, 1, 64);
+    uint32_t hi = __shfl_up((int)(uint32_t)(v >> 32), 1, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Total order of ScoredPointOffset for the bounded queue, as one u64 (bigger key = better):
+//   high 32 bits: f32 score mapped monotonically to u32, NaN greatest (OrderedFloat,
+//                 lib/common/common/src/types.rs:21-25);
+//   low 32 bits : ~idx, so that among equal scores the LOWER offset wins — the element a linear
+//                 scan pushes first survives in FixedLengthPriorityQueue::push (strict `<`,
+//                 fixed_length_priority_queue.rs:53-57).
+// key 0 is never produced by a real point (idx 0xFFFFFFFF is not a valid offset): "empty slot".
+__device__ __forceinline__ uint32_t score_to_ord(float s) {
+    uint32_t b = __float_as_uint(s);
+    if (s != s) return 0xFFFFFFFFu;
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ord_to_score(uint32_t o) {
+    uint32_t b = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+    return __uint_as_float(b);
+}
+__device__ __forceinline__ uint64_t make_key(float s, uint32_t idx) {
+    return ((uint64_t)score_to_ord(s) << 32) | (uint32_t)(~idx);
+}
+__device__ __forceinline__ uint32_t key_idx(uint64_t k) { return ~(uint32_t)k; }
+__device__ __forceinline__ float key_score(uint64_t k) { return ord_to_score((uint32_t)(k >> 32)); }
+
+// BitSlice<u64, Lsb0> (lib/common/common/src/bitvec.rs:6-7)
+__device__ __forceinline__ bool bit_get(const uint64_t *bits, uint64_t i) {
+    return (bits[i >> 6] >> (i & 63)) & 1ull;
+}
+// NotDeletedChecker::check (lib/segment/src/vector_storage/raw_scorer.rs:596-603)
+struct DeletedView {
+    const uint64_t *point_deleted;
+    uint64_t n_point_bits;
+    const uint64_t *vec_deleted;
+    uint64_t n_vec_bits;
+    uint64_t n_rows;
+    __device__ __forceinline__ bool live(uint32_t id) const {
+        bool vdel = (vec_deleted && id < n_vec_bits) ? bit_get(vec_deleted, id) : false;
+        bool pdel = point_deleted ? (id < n_point_bits ? bit_get(point_deleted, id) : true)
+                                  : !(id < n_rows);
+        return !vdel && !pdel;
+    }
+};
+
+// One register-resident bounded list per wave: lane i holds the i-th best key (descending).
+// insert() is wave-uniform; returns nothing, the k-th best is readlane(list, top-1).
+__device__ __forceinline__ void wave_list_insert(uint64_t &list, uint64_t nk, int lane) {
+    uint64_t gt = __ballot(list > nk);
+    int p = __popcll(gt);
+    uint64_t up = shfl_up1_u64(list);
+    list = lane < p ? list : (lane == p ? nk : up);
+}
+
+#endif  // __HIPCC__
+}  // namespace qmx

@@ -1,0 +1,59 @@
+// kernels.hpp — host-callable launchers of the HIP kernels (internal to libqdrant_amd.so).
+#pragma once
+#include "common.hpp"
+
+namespace qmx {
+
+constexpr int MAX_QT = 16;         // queries scored per pass of the stored block
+constexpr int SCAN_BLOCK = 512;    // 8 wavefronts share one LDS copy of the query tile
+constexpr int MAX_TOP_FAST = 64;   // register-resident per-wave list: one entry per lane
+
+// What a scan / gather launch needs.  Plain data, passed by value to the kernels.
+struct ScanArgs {
+    const void *rows;          // stored block (reference row layout for the dtype)
+    uint64_t n_rows;
+    uint64_t row_stride;       // bytes
+    uint32_t dim;              // elements per row consumed by the metric (actual_dim for SQ)
+    uint32_t nq;               // live queries in this tile (<= QT)
+    const void *queries;       // device, [QT][q_stride] bytes, preprocessed + cast (+ aux)
+    uint32_t q_stride;         // bytes between queries
+    uint32_t top;
+    const uint32_t *ids;       // candidate list or nullptr (= rows 0..n_cand)
+    uint64_t n_cand;           // candidates to visit
+    DeletedView del;
+    uint64_t *partial;         // [grid][QT][top] keys (top-k mode)
+    float *scores;             // [nq][n_cand] (score mode)
+    uint64_t scores_stride;    // elements between queries in `scores`
+    int *err_flag;             // set to 1 on an out-of-range id
+    // SQ
+    float sq_multiplier;
+    const float *row_offsets;  // SQ: per-row f32 offset (SoA copy) or nullptr when inline in rows
+    uint32_t flags;            // QMX_SEG_U8_SCALAR_ORDER ...
+    // PQ
+    uint32_t pq_m, pq_ncent;
+};
+
+enum ScanMode { SCAN_TOPK = 0, SCAN_SCORES = 1 };
+
+// dense f32 / f16 / u8 (scan_dense.hip)
+int32_t launch_scan_dense(hipStream_t st, int dtype, int distance, int qt, ScanMode mode,
+                          const ScanArgs &a, int num_cus, uint32_t *grid_out);
+// top-k merge of `n_lists` key lists per query into ScoredPointOffset rows (topk_merge.hip)
+int32_t launch_merge_keys(hipStream_t st, const uint64_t *partial, uint32_t n_lists,
+                          uint32_t qt_stride, uint32_t nq, uint32_t top, qmx_scored_point *out,
+                          uint32_t *out_counts);
+int32_t launch_merge_points(hipStream_t st, const qmx_scored_point *lists, const uint32_t *list_counts,
+                            uint32_t n_lists, uint32_t nq, uint32_t k, qmx_scored_point *out,
+                            uint32_t *out_counts);
+int32_t launch_sort_scored(hipStream_t st, const float *scores, const uint32_t *ids,
+                           const uint32_t *counts, uint32_t n_per_query, uint32_t nq, uint32_t top,
+                           qmx_scored_point *out, uint32_t *out_counts);
+
+// Metric::preprocess + element casts (preprocess.hip)
+int32_t launch_cosine_preprocess_f32(hipStream_t st, const float *in, float *out, uint64_t n, uint32_t dim);
+int32_t launch_cast_f32(hipStream_t st, int dst_dtype, const float *in, void *out, uint64_t count);
+int32_t launch_synth_fill(hipStream_t st, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, float *out);
+int32_t launch_gather_rows(hipStream_t st, const void *rows, uint64_t row_stride, uint64_t row_bytes,
+                           const uint32_t *ids, uint32_t n, uint64_t n_rows, void *out, int *err_flag);
+
+}  // namespace qmx

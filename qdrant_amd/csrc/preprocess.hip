@@ -1,0 +1,152 @@
+// preprocess.hip — Metric::preprocess, element casts, row gather, synthetic data.
+#include "kernels.hpp"
+
+namespace qmx {
+
+// ------------------------------------------------------------------------------------------
+// CosineMetric::preprocess (lib/segment/src/spaces/simple.rs:178-204) with the reference's ISA
+// dispatch (simple.rs:15,22): dim >= 32 -> cosine_preprocess_avx (simple_avx.rs:127-165, FMA,
+// 4 x 8 accumulators, four_way_hsum), dim >= 16 -> cosine_preprocess_sse (simple_sse.rs:107-150,
+// mul+add, 4 x 4 accumulators, hsum128 each then scalar adds), else scalar (simple.rs:228-235).
+// One wavefront per vector; lane c owns SIMD accumulator class c and walks i = c, c+C, ... in
+// order, so the sum of squares is bit-identical to the x86 reference.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool is_length_zero_or_normalized(float length) {   // spaces/tools.rs:14-16
+    return length < 1.1920929e-7f || __builtin_fabsf(length - 1.0f) <= 1.0e-6f;
+}
+
+__global__ __launch_bounds__(256) void cosine_preprocess_kernel(const float *in, float *out, uint64_t n, uint32_t dim) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t vec = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (vec >= n) return;
+    const float *v = in + vec * dim;
+    float *o = out + vec * dim;
+    float length;
+    if (dim >= 32) {
+        const uint32_t m = dim - dim % 32;
+        float acc = 0.0f;
+        if (lane < 32)
+            for (uint32_t i = lane; i < m; i += 32) acc = __builtin_fmaf(v[i], v[i], acc);
+        const float s12 = acc + __shfl_xor(acc, 8, 64);    // sum1 = r0 + r1 | sum2 = r2 + r3
+        const float tot = s12 + __shfl_xor(s12, 16, 64);   // total
+        const float lr = tot + __shfl_xor(tot, 4, 64);     // hi128 + lo128
+        const float pr = lr + __shfl_xor(lr, 1, 64);       // hadd
+        length = pr + __shfl_xor(pr, 2, 64);               // p1 + p2
+        length = __shfl(length, 0, 64);
+        for (uint32_t i = m; i < dim; ++i) length += v[i] * v[i];
+    } else if (dim >= 16) {
+        const uint32_t m = dim - dim % 16;
+        float acc = 0.0f;
+        if (lane < 16)
+            for (uint32_t i = lane; i < m; i += 16) acc = v[i] * v[i] + acc;
+        const float x64 = acc + __shfl_xor(acc, 2, 64);    // x + movehl(x)
+        const float h = x64 + __shfl_xor(x64, 1, 64);      // add_ss(x64, shuffle 0x55)
+        const float h0 = __shfl(h, 0, 64), h1 = __shfl(h, 4, 64), h2 = __shfl(h, 8, 64), h3 = __shfl(h, 12, 64);
+        length = ((h0 + h1) + h2) + h3;
+        for (uint32_t i = m; i < dim; ++i) length += v[i] * v[i];
+    } else {
+        length = -0.0f;  // Rust f32 iter::Sum starts from -0.0
+        for (uint32_t i = 0; i < dim; ++i) length += v[i] * v[i];
+    }
+    if (is_length_zero_or_normalized(length)) {
+        if (o != v)
+            for (uint32_t i = lane; i < dim; i += 64) o[i] = v[i];
+        return;
+    }
+    length = __fsqrt_rn(length);
+    for (uint32_t i = lane; i < dim; i += 64) o[i] = __fdiv_rn(v[i], length);   // x / length, not x * (1/length)
+}
+
+int32_t launch_cosine_preprocess_f32(hipStream_t st, const float *in, float *out, uint64_t n, uint32_t dim) {
+    if (n == 0) return QMX_OK;
+    const uint32_t blocks = (uint32_t)((n + 3) / 4);
+    hipLaunchKernelGGL(cosine_preprocess_kernel, dim3(blocks), dim3(256), 0, st, in, out, n, dim);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// PrimitiveVectorElement::slice_from_float_cow (lib/segment/src/data_types/primitive.rs):
+//   f16: half::f16::from_f32, IEEE RNE (:77-79)      u8: `x as u8` saturating truncation, NaN -> 0 (:127-129)
+// ------------------------------------------------------------------------------------------
+__global__ void cast_f32_kernel(int dst_dtype, const float *in, void *out, uint64_t count) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const float x = in[i];
+        if (dst_dtype == QMX_DTYPE_F16) {
+            reinterpret_cast<__half *>(out)[i] = __float2half_rn(x);
+        } else if (dst_dtype == QMX_DTYPE_U8) {
+            uint8_t b = (x != x) ? 0 : (x <= 0.0f ? 0 : (x >= 255.0f ? 255 : (uint8_t)x));
+            reinterpret_cast<uint8_t *>(out)[i] = b;
+        } else {
+            reinterpret_cast<float *>(out)[i] = x;
+        }
+    }
+}
+int32_t launch_cast_f32(hipStream_t st, int dst_dtype, const float *in, void *out, uint64_t count) {
+    if (count == 0) return QMX_OK;
+    uint64_t blocks = (count + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(cast_f32_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, dst_dtype, in, out, count);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// counter-based synthetic rows (integer Irwin-Hall, no libm): the tests re-derive any element on the CPU
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__global__ void synth_fill_kernel(uint64_t seed_mixed, uint64_t row0, uint64_t n, uint32_t dim, float *out) {
+    const uint64_t total = n * dim;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const uint64_t h = splitmix64(seed_mixed ^ (row0 * dim + i));
+        const int s = (int)(h & 0xFFFF) + (int)((h >> 16) & 0xFFFF) + (int)((h >> 32) & 0xFFFF) + (int)(h >> 48);
+        out[i] = (float)(s - 131070) * (1.0f / 37837.0f);
+    }
+}
+static uint64_t host_splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+int32_t launch_synth_fill(hipStream_t st, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, float *out) {
+    if (n == 0) return QMX_OK;
+    hipLaunchKernelGGL(synth_fill_kernel, dim3(4096), dim3(256), 0, st, host_splitmix64(seed), row0, n, dim, out);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// row gather: get_dense / get_quantized_vector for a list of ids (one wavefront per row)
+// ------------------------------------------------------------------------------------------
+__global__ void gather_rows_kernel(const unsigned char *rows, uint64_t row_stride, uint64_t row_bytes,
+                                   const uint32_t *ids, uint32_t n, uint64_t n_rows, unsigned char *out, int *err_flag) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (w >= n) return;
+    const uint32_t id = ids[w];
+    if (id >= n_rows) {
+        if (lane == 0) *err_flag = 1;
+        return;
+    }
+    const unsigned char *src = rows + (uint64_t)id * row_stride;
+    unsigned char *dst = out + (uint64_t)w * row_bytes;
+    for (uint64_t i = lane; i < row_bytes; i += 64) dst[i] = src[i];
+}
+int32_t launch_gather_rows(hipStream_t st, const void *rows, uint64_t row_stride, uint64_t row_bytes,
+                           const uint32_t *ids, uint32_t n, uint64_t n_rows, void *out, int *err_flag) {
+    if (n == 0) return QMX_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, st, (const unsigned char *)rows,
+                       row_stride, row_bytes, ids, n, n_rows, (unsigned char *)out, err_flag);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
+}  // namespace qmx

@@ -1,0 +1,199 @@
+// scan_common.hpp — the wave64 row-streaming kernel shared by every stored element type.
+//
+// Replaces the reference's innermost loops
+//   BatchFilteredSearcher::peek_top_iter   lib/segment/src/index/hnsw_index/point_scorer.rs:423-472
+//   RawScorerImpl::score_points            lib/segment/src/vector_storage/raw_scorer.rs:561-564
+//   MetricQueryScorer::score_stored_batch  lib/segment/src/vector_storage/query_scorer/metric_query_scorer.rs:81-92
+// for a device-resident copy of the stored block.
+//
+// Mapping (HBM-bound, VALU only — no MFMA: intensity is 0.5*Q flop/B):
+//   * 8 lanes own one row per step: each lane loads one 16-byte piece of a 128-byte row segment,
+//     so one wave-level `global_load_dwordx4` touches 8 rows x one full 128-B cache line each
+//     (8 lines per instruction, exactly like a contiguous 1-KiB access) and every fetched byte
+//     is used once.  R row-groups per lane keep R x UNROLL loads in flight per wave.
+//   * the query tile (QT preprocessed queries) sits in LDS; the 8 row-groups of a wave read the
+//     same 128 bytes (LDS broadcast), one ds_read_b128 per query per segment, reused for R rows.
+//   * the lane->piece map is chosen so that a lane's NACC accumulators are exactly the SIMD lanes
+//     of the reference's AVX registers; the cross-lane sum is three DPP steps in the reference's
+//     own hsum order  =>  scores are bit-identical to the x86 reference, not just within 1e-5.
+//   * per-wave top-k lives in registers (lane i = i-th best, u64 keys); a row only reaches the
+//     insert path when it beats the wave's current k-th best (one v_cmp + ballot per row group).
+#pragma once
+#include "kernels.hpp"
+
+namespace qmx {
+
+// lane position inside its group of 8 -> which 16-byte piece of the 128-byte segment it loads.
+// t = 4*h + r  ->  piece = 2*r + h : a quad (4 consecutive lanes) holds one half (h) of every AVX
+// register r = 0..3, so "register a+b, c+d, (a+b)+(c+d)" are quad_perm DPPs and "high half + low
+// half" is row_half_mirror.
+__device__ __forceinline__ int lane_piece(int t) { return 2 * (t & 3) + (t >> 2); }
+
+template <class P, int QT, int R, int UNROLL, bool HAS_IDS, int MODE>
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_kernel(const ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NW = SCAN_BLOCK / WAVE;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- stage the query tile in LDS (once per block) ----
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.queries);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        const uint32_t n16 = (uint32_t)QT * a.q_stride / 16;
+        for (uint32_t i = tid; i < n16; i += SCAN_BLOCK) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const int t = lane & 7;
+    const int g = lane >> 3;
+    const int piece_off = lane_piece(t) * 16;
+    const unsigned char *rows = reinterpret_cast<const unsigned char *>(a.rows);
+
+    uint64_t list[QT];
+#pragma unroll
+    for (int q = 0; q < QT; ++q) list[q] = 0;
+
+    const uint32_t gw = blockIdx.x * NW + wave;
+    const uint32_t tw = gridDim.x * NW;
+    constexpr uint32_t TILE = 8 * R;
+    const uint64_t n_tiles = (a.n_cand + TILE - 1) / TILE;
+    const uint32_t nseg = (a.dim * P::ELEM) / P::SEG;
+
+    for (uint64_t tile = gw; tile < n_tiles; tile += tw) {
+        uint32_t rid[R];
+        bool valid[R];
+        uint64_t cand[R];
+        const unsigned char *rp[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            uint64_t c = tile * TILE + (uint32_t)(r * 8 + g);
+            valid[r] = c < a.n_cand;
+            cand[r] = c;
+            uint64_t cc = valid[r] ? c : 0;
+            uint32_t id = HAS_IDS ? a.ids[cc] : (uint32_t)cc;
+            if (HAS_IDS && id >= a.n_rows) {
+                if (valid[r]) *a.err_flag = 1;
+                id = 0;
+                valid[r] = false;
+            }
+            rid[r] = id;
+            rp[r] = rows + (uint64_t)id * a.row_stride + piece_off;
+        }
+
+        typename P::acc_t acc[QT][R][P::NACC];
+#pragma unroll
+        for (int q = 0; q < QT; ++q)
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int k = 0; k < P::NACC; ++k) acc[q][r][k] = 0;
+
+#pragma unroll UNROLL
+        for (uint32_t s = 0; s < nseg; ++s) {
+            typename P::vec_t v[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                v[r] = *reinterpret_cast<const typename P::vec_t *>(rp[r] + (uint64_t)s * P::SEG);
+#pragma unroll
+            for (int q = 0; q < QT; ++q) {
+                const typename P::vec_t qv = *reinterpret_cast<const typename P::vec_t *>(
+                    smem + (uint32_t)q * a.q_stride + s * P::SEG + piece_off);
+#pragma unroll
+                for (int r = 0; r < R; ++r) P::mac(acc[q][r], qv, v[r]);
+            }
+        }
+
+#pragma unroll
+        for (int q = 0; q < QT; ++q) {
+            if (q < (int)a.nq) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float score = P::finish(acc[q][r], smem + (uint32_t)q * a.q_stride,
+                                                  rows + (uint64_t)rid[r] * a.row_stride, rid[r], nseg, a);
+                    if (MODE == SCAN_SCORES) {
+                        if (valid[r] && t == 0) a.scores[(uint64_t)q * a.scores_stride + cand[r]] = score;
+                    } else {
+                        const uint64_t key = make_key(score, rid[r]);
+                        const uint64_t thr = readlane_u64(list[q], (int)a.top - 1);
+                        bool c = valid[r] && (t == 0) && (key > thr);
+                        if (__ballot(c)) {
+                            c = c && a.del.live(rid[r]);
+                            uint64_t m = __ballot(c);
+                            while (m) {
+                                const int src = __builtin_ctzll(m);
+                                m &= m - 1;
+                                const uint64_t nk = readlane_u64(key, src);
+                                if (nk > readlane_u64(list[q], (int)a.top - 1))
+                                    wave_list_insert(list[q], nk, lane);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    if (MODE == SCAN_SCORES) return;
+
+    // ---- block merge: 8 wave lists -> 1 list per query, then one global write per block ----
+    __syncthreads();  // everyone is done reading the query tile
+    uint64_t *lds_keys = reinterpret_cast<uint64_t *>(smem);
+    const uint32_t top = a.top;
+#pragma unroll
+    for (int q = 0; q < QT; ++q)
+        if (lane < (int)top) lds_keys[((uint32_t)wave * QT + q) * top + lane] = list[q];
+    __syncthreads();
+    for (uint32_t q = wave; q < a.nq; q += NW) {
+        uint64_t merged = 0;
+        for (int sw = 0; sw < NW; ++sw) {
+            const uint64_t key = lane < (int)top ? lds_keys[((uint32_t)sw * QT + q) * top + lane] : 0;
+            uint64_t m = __ballot(key > readlane_u64(merged, (int)top - 1));
+            while (m) {
+                const int src = __builtin_ctzll(m);
+                m &= m - 1;
+                const uint64_t nk = readlane_u64(key, src);
+                if (nk > readlane_u64(merged, (int)top - 1)) wave_list_insert(merged, nk, lane);
+            }
+        }
+        if (lane < (int)top) a.partial[((uint64_t)blockIdx.x * QT + q) * top + lane] = merged;
+    }
+}
+
+// Launch helper: picks the grid from the occupancy of this instantiation.
+template <class P, int QT, int R, int UNROLL, bool HAS_IDS, int MODE>
+int32_t launch_scan_inst(hipStream_t st, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
+    constexpr int NW = SCAN_BLOCK / WAVE;
+    size_t lds = (size_t)QT * a.q_stride;
+    if (MODE == SCAN_TOPK) {
+        size_t lk = (size_t)NW * QT * a.top * sizeof(uint64_t);
+        if (lk > lds) lds = lk;
+    }
+    lds = (lds + 15) & ~(size_t)15;
+    QMX_REQUIRE(lds <= 160 * 1024, QMX_ERR_NOT_SUPPORTED, "query tile needs %zu B of LDS (> 160 KiB)", lds);
+    auto kfn = scan_kernel<P, QT, R, UNROLL, HAS_IDS, MODE>;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    int per_cu = 0;
+    QMX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, SCAN_BLOCK, lds));
+    if (per_cu < 1) per_cu = 1;
+    const uint64_t n_tiles = (a.n_cand + 8 * R - 1) / (8 * R);
+    uint64_t want = (n_tiles + NW - 1) / NW;
+    uint64_t cap = (uint64_t)num_cus * per_cu;
+    uint32_t grid = (uint32_t)(want < cap ? want : cap);
+    if (grid < 1) grid = 1;
+    if (grid_out) {
+        if (*grid_out && MODE == SCAN_TOPK && grid > *grid_out) grid = *grid_out;  // caller's partial buffer bound
+        *grid_out = grid;
+    }
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(SCAN_BLOCK), lds, st, a);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
+}  // namespace qmx

@@ -1,0 +1,119 @@
+// topk_merge.hip — bounded-queue merges on device.
+//
+//  merge_keys   : per-block key lists of one scan  -> final `top` per query, sorted descending
+//                 (`into_sorted_vec`, lib/common/common/src/fixed_length_priority_queue.rs:63-65)
+//  merge_points : per-segment / per-GPU ScoredPointOffset lists -> one list per query
+//                 (`BatchResultAggregator`, lib/shard/src/search_result_aggregator.rs:50-121, for
+//                 disjoint id spaces)
+//  sort_scored  : rescoring tail of `postprocess_search_result`
+//                 (lib/segment/src/index/vector_index_search_common.rs:73-90): sort desc, truncate
+#include "kernels.hpp"
+
+namespace qmx {
+
+constexpr int MERGE_BLOCK = 256;
+constexpr int MERGE_NW = MERGE_BLOCK / WAVE;
+
+__device__ __forceinline__ void wave_offer(uint64_t &list, uint64_t key, int top, int lane) {
+    uint64_t m = __ballot(key > readlane_u64(list, top - 1));
+    while (m) {
+        const int src = __builtin_ctzll(m);
+        m &= m - 1;
+        const uint64_t nk = readlane_u64(key, src);
+        if (nk > readlane_u64(list, top - 1)) wave_list_insert(list, nk, lane);
+    }
+}
+
+// block-level finish: merge the MERGE_NW wave lists, write ScoredPointOffset rows
+__device__ __forceinline__ void block_finish(uint64_t list, int top, uint32_t q, qmx_scored_point *out,
+                                             uint32_t *out_counts) {
+    __shared__ uint64_t sh[MERGE_NW][WAVE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    sh[wave][lane] = list;
+    __syncthreads();
+    if (wave == 0) {
+        uint64_t merged = sh[0][lane];
+        for (int w = 1; w < MERGE_NW; ++w) wave_offer(merged, sh[w][lane], top, lane);
+        const bool ok = lane < top && merged != 0;
+        if (lane < top) {
+            qmx_scored_point p;
+            p.idx = ok ? key_idx(merged) : 0u;
+            p.score = ok ? key_score(merged) : 0.0f;
+            out[(uint64_t)q * top + lane] = p;
+        }
+        const uint64_t m = __ballot(ok);
+        if (lane == 0) out_counts[q] = (uint32_t)__popcll(m);
+    }
+}
+
+__global__ __launch_bounds__(MERGE_BLOCK) void merge_keys_kernel(const uint64_t *partial, uint32_t n_lists,
+                                                                 uint32_t qt_stride, uint32_t top,
+                                                                 qmx_scored_point *out, uint32_t *out_counts) {
+    const uint32_t q = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t list = 0;
+    for (uint32_t l = wave; l < n_lists; l += MERGE_NW) {
+        const uint64_t key = lane < (int)top ? partial[((uint64_t)l * qt_stride + q) * top + lane] : 0;
+        wave_offer(list, key, (int)top, lane);
+    }
+    block_finish(list, (int)top, q, out, out_counts);
+}
+
+__global__ __launch_bounds__(MERGE_BLOCK) void merge_points_kernel(const qmx_scored_point *lists,
+                                                                   const uint32_t *list_counts, uint32_t n_lists,
+                                                                   uint32_t nq, uint32_t k, qmx_scored_point *out,
+                                                                   uint32_t *out_counts) {
+    const uint32_t q = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t list = 0;
+    for (uint32_t l = wave; l < n_lists; l += MERGE_NW) {
+        const uint32_t cnt = list_counts ? list_counts[(uint64_t)l * nq + q] : k;
+        uint64_t key = 0;
+        if (lane < (int)k && lane < (int)cnt) {
+            const qmx_scored_point p = lists[((uint64_t)l * nq + q) * k + lane];
+            key = make_key(p.score, p.idx);
+        }
+        wave_offer(list, key, (int)k, lane);
+    }
+    block_finish(list, (int)k, q, out, out_counts);
+}
+
+__global__ __launch_bounds__(MERGE_BLOCK) void sort_scored_kernel(const float *scores, const uint32_t *ids,
+                                                                  const uint32_t *counts, uint32_t n_per_query,
+                                                                  uint32_t top, qmx_scored_point *out,
+                                                                  uint32_t *out_counts) {
+    const uint32_t q = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t cnt = counts ? (counts[q] < n_per_query ? counts[q] : n_per_query) : n_per_query;
+    uint64_t list = 0;
+    for (uint32_t base = wave * WAVE; base < cnt; base += MERGE_BLOCK) {
+        const uint32_t i = base + lane;
+        const uint64_t key = i < cnt ? make_key(scores[(uint64_t)q * n_per_query + i], ids[(uint64_t)q * n_per_query + i]) : 0;
+        wave_offer(list, key, (int)top, lane);
+    }
+    block_finish(list, (int)top, q, out, out_counts);
+}
+
+int32_t launch_merge_keys(hipStream_t st, const uint64_t *partial, uint32_t n_lists, uint32_t qt_stride,
+                          uint32_t nq, uint32_t top, qmx_scored_point *out, uint32_t *out_counts) {
+    if (nq == 0) return QMX_OK;
+    hipLaunchKernelGGL(merge_keys_kernel, dim3(nq), dim3(MERGE_BLOCK), 0, st, partial, n_lists, qt_stride, top, out, out_counts);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+int32_t launch_merge_points(hipStream_t st, const qmx_scored_point *lists, const uint32_t *list_counts,
+                            uint32_t n_lists, uint32_t nq, uint32_t k, qmx_scored_point *out, uint32_t *out_counts) {
+    if (nq == 0) return QMX_OK;
+    hipLaunchKernelGGL(merge_points_kernel, dim3(nq), dim3(MERGE_BLOCK), 0, st, lists, list_counts, n_lists, nq, k, out, out_counts);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+int32_t launch_sort_scored(hipStream_t st, const float *scores, const uint32_t *ids, const uint32_t *counts,
+                           uint32_t n_per_query, uint32_t nq, uint32_t top, qmx_scored_point *out, uint32_t *out_counts) {
+    if (nq == 0) return QMX_OK;
+    hipLaunchKernelGGL(sort_scored_kernel, dim3(nq), dim3(MERGE_BLOCK), 0, st, scores, ids, counts, n_per_query, top, out, out_counts);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
+}  // namespace qmx

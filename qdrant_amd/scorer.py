@@ -1,0 +1,215 @@
+"""Host-side mirror of the reference's scorer interface on top of the C-ABI.
+
+Same names, argument meaning and error behaviour as
+  lib/segment/src/vector_storage/raw_scorer.rs:39-58      (trait RawScorer, new_raw_scorer)
+  lib/segment/src/index/hnsw_index/point_scorer.rs:307-472 (BatchFilteredSearcher)
+  lib/common/common/src/types.rs:12-31                     (ScoredPointOffset)
+so that tests/ reads like the reference's own tests.  Everything here is plumbing: all scoring
+happens in libqdrant_amd.so on the GPU; there is no CPU path.
+"""
+import ctypes as C
+import enum
+from typing import Iterable, List, Optional, Sequence
+
+import numpy as np
+
+from . import _ffi as F
+
+
+class Distance(enum.IntEnum):  # lib/segment/src/types.rs:313-322
+    Cosine = F.COSINE
+    Euclid = F.EUCLID
+    Dot = F.DOT
+    Manhattan = F.MANHATTAN
+
+
+class VectorStorageDatatype(enum.IntEnum):
+    Float32 = F.DTYPE_F32
+    Float16 = F.DTYPE_F16
+    Uint8 = F.DTYPE_U8
+
+
+ScoredPointOffset = np.dtype([("idx", np.uint32), ("score", np.float32)])  # types.rs:12-17, 8 bytes
+
+_NP_ELEM = {F.DTYPE_F32: np.float32, F.DTYPE_F16: np.float16, F.DTYPE_U8: np.uint8}
+
+
+def device_count() -> int:
+    n = C.c_int32(0)
+    F.check(F.lib().qmx_device_count(C.byref(n)))
+    return n.value
+
+
+def _bits_to_words(bits) -> Optional[np.ndarray]:
+    """bool array -> BitSlice<u64, Lsb0> words (lib/common/common/src/bitvec.rs:6-7)."""
+    if bits is None:
+        return None
+    bits = np.asarray(bits, dtype=bool)
+    pad = (-len(bits)) % 64
+    b = np.concatenate([bits, np.zeros(pad, dtype=bool)]) if pad else bits
+    return np.packbits(b.reshape(-1, 8), axis=1, bitorder="little").reshape(-1).view(np.uint64).copy()
+
+
+class VectorStorage:
+    """Device-resident dense vector storage (the read side of `DenseVectorStorageRead`,
+    lib/segment/src/vector_storage/vector_storage_base.rs:265-316).
+
+    `vectors` are the STORED rows, i.e. already passed through `Distance::preprocess_vector`
+    at insert time (lib/segment/src/data_types/named_vectors.rs:350-368) and cast to `datatype`.
+    A numpy array is uploaded; a torch CUDA tensor is adopted in place.
+    """
+
+    def __init__(self, vectors, distance: Distance, datatype: VectorStorageDatatype = VectorStorageDatatype.Float32,
+                 device_id: int = 0, flags: int = 0, dim: Optional[int] = None):
+        self._h = C.c_void_p()
+        self.distance = Distance(distance)
+        self.datatype = VectorStorageDatatype(datatype)
+        on_device = hasattr(vectors, "data_ptr") and getattr(vectors, "is_cuda", False)
+        if not on_device:
+            vectors = np.ascontiguousarray(vectors, dtype=_NP_ELEM[int(datatype)])
+        self._keep = vectors
+        n = int(vectors.shape[0])
+        self.dim = int(dim if dim is not None else vectors.shape[1])
+        self.count = n
+        desc = F.SegmentDesc()
+        desc.dtype = int(datatype)
+        desc.distance = int(distance)
+        desc.dim = self.dim
+        desc.flags = flags | (F.SEG_DATA_ON_DEVICE if on_device else 0)
+        desc.n = n
+        desc.row_stride_bytes = 0
+        desc.data = F.ptr(vectors)
+        desc.device_id = device_id
+        F.check(F.lib().qmx_segment_create(C.byref(desc), C.byref(self._h)))
+        if on_device is False:
+            self._keep = None  # uploaded: the host copy may go away (ownership)
+
+    def total_vector_count(self) -> int:
+        return self.count
+
+    def set_deleted(self, point_deleted=None, vec_deleted=None):
+        """`NotDeletedChecker{point_deleted, vec_deleted}` (raw_scorer.rs:580-603); bool arrays."""
+        pw, vw = _bits_to_words(point_deleted), _bits_to_words(vec_deleted)
+        F.check(F.lib().qmx_segment_set_deleted(
+            self._h, F.ptr(pw), 0 if point_deleted is None else len(point_deleted),
+            F.ptr(vw), 0 if vec_deleted is None else len(vec_deleted)))
+
+    def get_dense(self, ids: Sequence[int]) -> np.ndarray:
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        out = np.empty((len(ids), self.dim), dtype=_NP_ELEM[int(self.datatype)])
+        F.check(F.lib().qmx_segment_read_rows(self._h, F.ptr(ids), len(ids), F.ptr(out)))
+        return out
+
+    def close(self):
+        if self._h:
+            F.lib().qmx_segment_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class RawScorer:
+    """`Box<dyn RawScorer>` for a batch of `QueryVector::Nearest` queries (raw_scorer.rs:39-58).
+    One instance holds `nq` scorers; single-query use is nq == 1."""
+
+    def __init__(self, handle, storage: VectorStorage, nq: int):
+        self._h = handle
+        self.storage = storage
+        self.nq = nq
+
+    def score_points(self, points: Sequence[int]) -> np.ndarray:
+        """scores[qi, i] = similarity(query qi, stored point points[i])  (raw_scorer.rs:40)."""
+        ids = np.ascontiguousarray(points, dtype=np.uint32)
+        scores = np.empty((self.nq, len(ids)), dtype=np.float32)
+        F.check(F.lib().qmx_score_points(self._h, F.ptr(ids), len(ids), F.ptr(scores), None))
+        return scores
+
+    def score_point(self, point: int, query_index: int = 0) -> float:
+        out = C.c_float()
+        F.check(F.lib().qmx_score_point(self._h, query_index, int(point), C.byref(out)))
+        return out.value
+
+    def score_internal(self, point_a, point_b) -> np.ndarray:
+        a = np.ascontiguousarray(np.atleast_1d(point_a), dtype=np.uint32)
+        b = np.ascontiguousarray(np.atleast_1d(point_b), dtype=np.uint32)
+        out = np.empty(len(a), dtype=np.float32)
+        F.check(F.lib().qmx_score_internal(self.storage._h, F.ptr(a), F.ptr(b), len(a), F.ptr(out)))
+        return out
+
+    def encoded_query(self, query_index: int = 0) -> np.ndarray:
+        nbytes = self.storage.dim * np.dtype(_NP_ELEM[int(self.storage.datatype)]).itemsize
+        out = np.empty(nbytes, dtype=np.uint8)
+        written = C.c_uint64()
+        F.check(F.lib().qmx_query_read_encoded(self._h, query_index, F.ptr(out), nbytes, C.byref(written)))
+        return out[:written.value].view(_NP_ELEM[int(self.storage.datatype)])
+
+    def close(self):
+        if self._h:
+            F.lib().qmx_query_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def new_raw_scorer(query, storage: VectorStorage) -> RawScorer:
+    """`new_raw_scorer(QueryVector::Nearest(query), storage, hc)` (raw_scorer.rs:60-114).
+    `query`: [dim] or [nq, dim] f32 ORIGINAL vectors; preprocessing + cast happen on device."""
+    q = np.ascontiguousarray(np.atleast_2d(query), dtype=np.float32)
+    if q.shape[1] != storage.dim:
+        raise ValueError(f"query dim {q.shape[1]} != storage dim {storage.dim}")
+    h = C.c_void_p()
+    F.check(F.lib().qmx_query_create(storage._h, F.ptr(q), q.shape[0], C.byref(h)))
+    return RawScorer(h, storage, q.shape[0])
+
+
+def new_raw_scorer_internal(point_ids, storage: VectorStorage) -> RawScorer:
+    """`FilteredScorer::new_internal` (point_scorer.rs:183-218): stored points as queries."""
+    ids = np.ascontiguousarray(np.atleast_1d(point_ids), dtype=np.uint32)
+    h = C.c_void_p()
+    F.check(F.lib().qmx_query_create_internal(storage._h, F.ptr(ids), len(ids), C.byref(h)))
+    return RawScorer(h, storage, len(ids))
+
+
+class BatchFilteredSearcher:
+    """`BatchFilteredSearcher` (point_scorer.rs:307-472): one scorer + one bounded queue per query."""
+
+    def __init__(self, queries, vectors: VectorStorage, top: int, quantized_vectors=None):
+        if top == 0:
+            raise ValueError("length must be greater than zero")  # FixedLengthPriorityQueue::new panics
+        self.top = int(top)
+        self.storage = quantized_vectors if quantized_vectors is not None else vectors
+        self.scorer = new_raw_scorer(queries, self.storage)
+        self.counters = F.Counters()
+
+    @classmethod
+    def new_for_test(cls, vectors: Sequence, vector_storage: VectorStorage, top: int):
+        return cls(vectors, vector_storage, top)
+
+    def _run(self, ids, is_stopped) -> List[np.ndarray]:
+        nq = self.scorer.nq
+        out = np.zeros((nq, self.top), dtype=ScoredPointOffset)
+        counts = np.zeros(nq, dtype=np.uint32)
+        stop = None
+        if is_stopped is not None:
+            stop = is_stopped if isinstance(is_stopped, np.ndarray) else np.array([1 if is_stopped else 0], dtype=np.uint8)
+        if ids is not None:
+            ids = np.ascontiguousarray(list(ids) if not isinstance(ids, np.ndarray) else ids, dtype=np.uint32)
+        F.check(F.lib().qmx_search_topk(self.scorer._h, self.top, F.ptr(ids), 0 if ids is None else len(ids),
+                                        F.ptr(out), F.ptr(counts), F.ptr(stop), C.byref(self.counters)))
+        return [out[i, :counts[i]].copy() for i in range(nq)]
+
+    def peek_top_all(self, is_stopped=None) -> List[np.ndarray]:
+        """Score every non-deleted point (point_scorer.rs:408-421)."""
+        return self._run(None, is_stopped)
+
+    def peek_top_iter(self, points: Iterable[int], is_stopped=None) -> List[np.ndarray]:
+        """Candidate stream given explicitly (point_scorer.rs:423-472)."""
+        return self._run(points, is_stopped)

@@ -1,0 +1,233 @@
+"""ctypes wrapper of oracle/libqdrant_oracle.so — TEST INFRASTRUCTURE ONLY (checker, never product)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_lib = C.CDLL(os.path.join(ROOT, "oracle", "libqdrant_oracle.so"))
+REF_QUANT_PATH = os.path.join(ROOT, "oracle", "_ref", "libqdrant_ref_quant.so")
+
+COSINE, EUCLID, DOT, MANHATTAN = range(4)
+F32, F16, U8 = range(3)
+ISA_AUTO, ISA_AVX, ISA_SSE, ISA_SCALAR = range(4)
+ISA_REF = 100  # SQ leaves from the reference's own C kernels (oracle/_ref)
+
+ScoredPointOffset = np.dtype([("idx", np.uint32), ("score", np.float32)])
+_P = C.c_void_p
+_f = C.c_float
+
+
+def _p(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def _sig(name, res, args):
+    fn = getattr(_lib, name)
+    fn.restype = res
+    fn.argtypes = args
+    return fn
+
+
+for _n in ("dot", "euclid", "manhattan"):
+    _sig(f"qo_{_n}_f32", _f, [_P, _P, C.c_size_t, C.c_int])
+    _sig(f"qo_{_n}_f16", _f, [_P, _P, C.c_size_t, C.c_int])
+_sig("qo_similarity_f32", _f, [C.c_int, _P, _P, C.c_size_t])
+_sig("qo_similarity_f16", _f, [C.c_int, _P, _P, C.c_size_t])
+_sig("qo_similarity_u8", _f, [C.c_int, _P, _P, C.c_size_t, C.c_int])
+_sig("qo_cosine_preprocess_f32", None, [_P, _P, C.c_size_t, C.c_int])
+_sig("qo_preprocess_f32", None, [C.c_int, _P, _P, C.c_size_t])
+_sig("qo_postprocess", _f, [C.c_int, _f])
+_sig("qo_f32_to_f16", None, [_P, _P, C.c_size_t])
+_sig("qo_f16_to_f32", None, [_P, _P, C.c_size_t])
+_sig("qo_f32_to_u8", None, [_P, _P, C.c_size_t])
+_sig("qo_topk_new", _P, [C.c_size_t])
+_sig("qo_topk_free", None, [_P])
+_sig("qo_topk_push", None, [_P, C.c_uint32, _f])
+_sig("qo_topk_into_sorted", C.c_size_t, [_P, _P])
+_sig("qo_synth_value", _f, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32])
+_sig("qo_synth_fill_f32", None, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, _P])
+
+
+class Storage(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("distance", C.c_int), ("u8_isa", C.c_int), ("rows", _P),
+                ("n", C.c_size_t), ("dim", C.c_size_t),
+                ("point_deleted", _P), ("n_point_bits", C.c_size_t),
+                ("vec_deleted", _P), ("n_vec_bits", C.c_size_t)]
+
+
+_sig("qo_peek_top_iter", C.c_int, [C.POINTER(Storage), _P, C.c_size_t, C.c_size_t, _P, C.c_size_t, _P, _P, _P])
+_sig("qo_peek_top_parallel", C.c_int, [C.POINTER(Storage), _P, C.c_size_t, C.c_size_t, _P, _P, C.c_int])
+_sig("qo_score_points", None, [C.POINTER(Storage), _P, _P, C.c_size_t, _P])
+
+
+class Sq(C.Structure):
+    _fields_ = [("dim", C.c_uint32), ("actual_dim", C.c_uint32), ("distance", C.c_int), ("invert", C.c_int),
+                ("alpha", _f), ("offset", _f), ("multiplier", _f)]
+
+
+_sig("qo_sq_init", None, [C.POINTER(Sq), C.c_int, C.c_int, C.c_uint32, _P, C.c_size_t])
+_sig("qo_sq_init_params", None, [C.POINTER(Sq), C.c_int, C.c_int, C.c_uint32, _f, _f])
+_sig("qo_sq_encode_value", C.c_uint8, [C.POINTER(Sq), _f])
+_sig("qo_sq_get_shift", _f, [C.POINTER(Sq)])
+_sig("qo_sq_encode_row", None, [C.POINTER(Sq), _P, _P])
+_sig("qo_sq_encode_query", None, [C.POINTER(Sq), _P, _P, C.POINTER(_f)])
+_sig("qo_sq_score", _f, [C.POINTER(Sq), _P, _f, _P, C.c_int])
+_sig("qo_sq_score_internal", _f, [C.POINTER(Sq), _P, _P, C.c_int])
+for _n in ("qo_sq_dot_avx", "qo_sq_l1_avx", "qo_sq_dot_sse", "qo_sq_l1_sse"):
+    _sig(_n, _f, [_P, _P, C.c_uint32])
+_sig("qo_sq_set_ref_kernels", None, [_P, _P])
+
+
+class Pq(C.Structure):
+    _fields_ = [("dim", C.c_uint32), ("chunk_size", C.c_uint32), ("m", C.c_uint32), ("n_centroids", C.c_uint32),
+                ("distance", C.c_int), ("invert", C.c_int), ("centroids", _P)]
+
+
+_sig("qo_pq_init", None, [C.POINTER(Pq), C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, _P])
+_sig("qo_pq_encode_vector", None, [C.POINTER(Pq), _P, _P])
+_sig("qo_pq_encode_query", None, [C.POINTER(Pq), _P, _P])
+_sig("qo_pq_score", _f, [C.POINTER(Pq), _P, _P, C.c_int])
+_sig("qo_pq_score_internal", _f, [C.POINTER(Pq), _P, _P])
+_sig("qo_pq_train", None, [C.c_uint32, C.c_uint32, C.c_uint32, _P, C.c_size_t, C.c_int, _P])
+
+lib = _lib
+_NP = {F32: np.float32, F16: np.uint16, U8: np.uint8}
+
+
+def f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def similarity(dtype, distance, q, v, isa=ISA_AUTO):
+    q = np.ascontiguousarray(q, dtype=_NP[dtype])
+    v = np.ascontiguousarray(v, dtype=_NP[dtype])
+    if dtype == F32:
+        if isa == ISA_AUTO:
+            return _lib.qo_similarity_f32(distance, _p(q), _p(v), len(q))
+        fn = {DOT: _lib.qo_dot_f32, COSINE: _lib.qo_dot_f32, EUCLID: _lib.qo_euclid_f32, MANHATTAN: _lib.qo_manhattan_f32}[distance]
+        return fn(_p(q), _p(v), len(q), isa)
+    if dtype == F16:
+        if isa == ISA_AUTO:
+            return _lib.qo_similarity_f16(distance, _p(q), _p(v), len(q))
+        fn = {DOT: _lib.qo_dot_f16, COSINE: _lib.qo_dot_f16, EUCLID: _lib.qo_euclid_f16, MANHATTAN: _lib.qo_manhattan_f16}[distance]
+        return fn(_p(q), _p(v), len(q), isa)
+    return _lib.qo_similarity_u8(distance, _p(q), _p(v), len(q), isa)
+
+
+def preprocess(distance, v, isa=ISA_AUTO):
+    """Metric::preprocess for f32 / f16 storages (u8 never normalises)."""
+    v = f32(v)
+    out = np.empty_like(v)
+    flat_in, flat_out = v.reshape(-1, v.shape[-1]), out.reshape(-1, v.shape[-1])
+    for i in range(flat_in.shape[0]):
+        if distance == COSINE:
+            _lib.qo_cosine_preprocess_f32(_p(flat_in[i]), _p(flat_out[i]), v.shape[-1], isa)
+        else:
+            flat_out[i] = flat_in[i]
+    return out
+
+
+def to_f16(v):
+    v = f32(v)
+    out = np.empty(v.shape, dtype=np.uint16)
+    _lib.qo_f32_to_f16(_p(v), _p(out), v.size)
+    return out
+
+
+def f16_to_f32(h):
+    h = np.ascontiguousarray(h, dtype=np.uint16)
+    out = np.empty(h.shape, dtype=np.float32)
+    _lib.qo_f16_to_f32(_p(h), _p(out), h.size)
+    return out
+
+
+def to_u8(v):
+    v = f32(v)
+    out = np.empty(v.shape, dtype=np.uint8)
+    _lib.qo_f32_to_u8(_p(v), _p(out), v.size)
+    return out
+
+
+def cast(dtype, v):
+    return f32(v) if dtype == F32 else to_f16(v) if dtype == F16 else to_u8(v)
+
+
+def bits_to_words(bits):
+    if bits is None:
+        return None
+    bits = np.asarray(bits, dtype=bool)
+    pad = (-len(bits)) % 64
+    b = np.concatenate([bits, np.zeros(pad, dtype=bool)]) if pad else bits
+    return np.packbits(b.reshape(-1, 8), axis=1, bitorder="little").reshape(-1).view(np.uint64).copy()
+
+
+class DenseStorage:
+    """rows already preprocessed + cast (what the reference keeps in its VectorStorage)."""
+
+    def __init__(self, dtype, distance, rows, point_deleted=None, vec_deleted=None, u8_isa=ISA_AUTO):
+        self.dtype, self.distance = dtype, distance
+        self.rows = np.ascontiguousarray(rows, dtype=_NP[dtype])
+        self.pw, self.vw = bits_to_words(point_deleted), bits_to_words(vec_deleted)
+        self.st = Storage(dtype, distance, u8_isa, _p(self.rows), self.rows.shape[0], self.rows.shape[1],
+                          _p(self.pw), 0 if point_deleted is None else len(point_deleted),
+                          _p(self.vw), 0 if vec_deleted is None else len(vec_deleted))
+
+    def encode_queries(self, queries):
+        """MetricQueryScorer::new: preprocess then cast (metric_query_scorer.rs:35-58)."""
+        q = f32(np.atleast_2d(queries))
+        if self.dtype != U8:
+            q = preprocess(self.distance, q)
+        return np.ascontiguousarray(cast(self.dtype, q))
+
+    def peek_top(self, queries, top, ids=None, encoded=False, threads=0):
+        q = np.ascontiguousarray(queries, dtype=_NP[self.dtype]) if encoded else self.encode_queries(queries)
+        nq = q.shape[0]
+        out = np.zeros((nq, top), dtype=ScoredPointOffset)
+        counts = np.zeros(nq, dtype=np.uint32)
+        if threads:
+            rc = _lib.qo_peek_top_parallel(C.byref(self.st), _p(q), nq, top, _p(out), _p(counts), threads)
+        else:
+            ids_a = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint32)
+            rc = _lib.qo_peek_top_iter(C.byref(self.st), _p(q), nq, top, _p(ids_a), 0 if ids_a is None else len(ids_a),
+                                       _p(out), _p(counts), None)
+        assert rc == 0
+        return [out[i, :counts[i]].copy() for i in range(nq)]
+
+    def score_points(self, queries, ids, encoded=False):
+        q = np.ascontiguousarray(queries, dtype=_NP[self.dtype]) if encoded else self.encode_queries(queries)
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        out = np.empty((q.shape[0], len(ids)), dtype=np.float32)
+        for i in range(q.shape[0]):
+            _lib.qo_score_points(C.byref(self.st), _p(q[i]), _p(ids), len(ids), _p(out[i]))
+        return out
+
+
+def topk_push_all(pairs, length):
+    """FixedLengthPriorityQueue: push (idx, score) pairs, return into_sorted_vec()."""
+    t = _lib.qo_topk_new(length)
+    for idx, score in pairs:
+        _lib.qo_topk_push(t, int(idx), float(score))
+    out = np.zeros(length, dtype=ScoredPointOffset)
+    n = _lib.qo_topk_into_sorted(t, _p(out))
+    _lib.qo_topk_free(t)
+    return out[:n]
+
+
+def synth(seed, row0, n, dim):
+    out = np.empty((n, dim), dtype=np.float32)
+    _lib.qo_synth_fill_f32(seed, row0, n, dim, _p(out))
+    return out
+
+
+def load_ref_quant():
+    """The reference's own C SQ kernels (oracle/_ref, built from /root/reference by oracle/Makefile)."""
+    if not os.path.exists(REF_QUANT_PATH):
+        return None
+    ref = C.CDLL(REF_QUANT_PATH)
+    for n in ("impl_score_dot_avx", "impl_score_l1_avx", "impl_score_dot_sse", "impl_score_l1_sse"):
+        fn = getattr(ref, n)
+        fn.restype = _f
+        fn.argtypes = [_P, _P, C.c_uint32]
+    _lib.qo_sq_set_ref_kernels(C.cast(ref.impl_score_dot_avx, _P), C.cast(ref.impl_score_l1_avx, _P))
+    return ref
