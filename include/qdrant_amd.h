@@ -203,13 +203,20 @@ QMX_API int32_t qmx_query_create(const qmx_segment *seg, const float *queries, u
  * PQ returns None there, so the caller passes the original vector to qmx_query_create). */
 QMX_API int32_t qmx_query_create_internal(const qmx_segment *seg, const uint32_t *point_ids,
                                           uint32_t nq, qmx_query **out);
+/* Re-encodes a NEW batch of the same size into an existing handle (the next request reusing the
+ * scorer slot): only enqueues the preprocess / cast kernels on the query's stream, no allocation.
+ * `queries` host or device. */
+QMX_API int32_t qmx_query_update(qmx_query *q, const float *queries);
 QMX_API int32_t qmx_query_destroy(qmx_query *q);
 /* Run this query batch's kernels on a caller-owned hipStream_t (NULL = the query's own stream). */
 QMX_API int32_t qmx_query_set_stream(qmx_query *q, void *hip_stream);
 QMX_API int32_t qmx_query_synchronize(qmx_query *q);
-/* enabled != 0: bracket every scoring kernel of this query batch with HIP events on its stream and
- * report the sum in qmx_counters.kernel_ms (forces a stream sync per launch: measurement only). */
+/* enabled != 0: bracket every scoring (scan / gather) kernel of this query batch with a HIP event
+ * pair on its stream.  Recording never synchronises; the synchronous entry points report the sum
+ * in qmx_counters.kernel_ms, and qmx_query_timing synchronises the stream, returns the total and
+ * launch count since the previous call and resets them (how bench.py derives roofline.achieved). */
 QMX_API int32_t qmx_query_set_timing(qmx_query *q, int32_t enabled);
+QMX_API int32_t qmx_query_timing(qmx_query *q, float *total_ms, uint32_t *n_launches);
 /* Encoded form read-back for tests: f32/f16/u8 preprocessed+cast query; SQ: [f32 offset][codes];
  * PQ: the LUT [m][n_centroids] f32. */
 QMX_API int32_t qmx_query_read_encoded(const qmx_query *q, uint32_t query_index, void *out,
@@ -276,6 +283,14 @@ QMX_API int32_t qmx_rescore(qmx_query *q, const uint32_t *ids, const uint32_t *c
 QMX_API int32_t qmx_merge_topk(int32_t device_id, const qmx_scored_point *lists,
                                const uint32_t *list_counts, uint32_t n_lists, uint32_t nq,
                                uint32_t k, qmx_scored_point *out, uint32_t *out_counts);
+
+/* Same merge, enqueued on `hip_stream` with every buffer in device memory (the multi-GPU path:
+ * lists = the RCCL all-gather of per-GPU top-k).  `list_idx_base_dev[l]` (optional) is added to
+ * every idx of list l: segment-local offsets -> (segment, offset) globalised ids. */
+QMX_API int32_t qmx_merge_topk_async(int32_t device_id, void *hip_stream, const qmx_scored_point *lists_dev,
+                                     const uint32_t *list_counts_dev, const uint32_t *list_idx_base_dev,
+                                     uint32_t n_lists, uint32_t nq, uint32_t k, qmx_scored_point *out_dev,
+                                     uint32_t *out_counts_dev);
 
 /* ---- quantizers -------------------------------------------------------------------------------- */
 

@@ -71,10 +71,12 @@ SIGNATURES = {
     "qmx_cast_f32": (C.c_int32, [C.c_int32, C.c_uint32, _P, C.c_uint64, _P]),
     "qmx_query_create": (C.c_int32, [_P, _P, C.c_uint32, C.POINTER(_P)]),
     "qmx_query_create_internal": (C.c_int32, [_P, _P, C.c_uint32, C.POINTER(_P)]),
+    "qmx_query_update": (C.c_int32, [_P, _P]),
     "qmx_query_destroy": (C.c_int32, [_P]),
     "qmx_query_set_stream": (C.c_int32, [_P, _P]),
     "qmx_query_synchronize": (C.c_int32, [_P]),
     "qmx_query_set_timing": (C.c_int32, [_P, C.c_int32]),
+    "qmx_query_timing": (C.c_int32, [_P, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     "qmx_query_read_encoded": (C.c_int32, [_P, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "qmx_score_points": (C.c_int32, [_P, _P, C.c_uint32, _P, C.POINTER(Counters)]),
     "qmx_score_points_ragged": (C.c_int32, [_P, _P, _P, _P, C.POINTER(Counters)]),
@@ -85,6 +87,7 @@ SIGNATURES = {
     "qmx_search_topk_async": (C.c_int32, [_P, C.c_uint32, _P, C.c_uint64, _P, _P]),
     "qmx_rescore": (C.c_int32, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, _P]),
     "qmx_merge_topk": (C.c_int32, [C.c_int32, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P]),
+    "qmx_merge_topk_async": (C.c_int32, [C.c_int32, _P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P]),
     "qmx_sq_encode": (C.c_int32, [C.c_int32, C.c_uint32, C.POINTER(SqParams), _P, C.c_uint64, C.c_uint32, _P]),
     "qmx_pq_encode": (C.c_int32, [C.c_int32, C.POINTER(PqParams), _P, C.c_uint64, C.c_uint32, _P]),
     "qmx_synth_fill_f32": (C.c_int32, [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, _P]),

@@ -126,7 +126,8 @@ struct qmx_segment {
 
     bool fast_layout() const {
         if (dtype == QMX_DTYPE_F32)
-            return dim >= 32 && dim % 4 == 0 && row_stride % 16 == 0 && ((uintptr_t)d_rows % 16) == 0;
+            return dim < 32 ? (row_stride % 4 == 0 && ((uintptr_t)d_rows % 4) == 0)
+                            : (row_stride % 16 == 0 && ((uintptr_t)d_rows % 16) == 0);
         return false;
     }
     DeletedView deleted_view() const {
@@ -150,8 +151,14 @@ struct qmx_query {
     void *d_queries = nullptr; // [nq_padded][q_stride]
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    DevBuf partial, out, counts, ids, scores, misc;
+    // HIP-event pairs around the scoring kernels (timing mode): recorded without synchronising,
+    // summed by timing_collect()
+    struct EvPair { hipEvent_t a = nullptr, b = nullptr; };
+    std::vector<EvPair> evs;
+    size_t ev_used = 0;
+    float timing_ms = 0.f;
+    uint32_t timing_launches = 0;
+    DevBuf partial, out, counts, ids, scores, misc, enc;
     int *d_err = nullptr;
     uint32_t partial_grid_cap = 0;
     bool timing = false;
@@ -188,6 +195,34 @@ static int32_t check_err_flag(qmx_query *q) {
         set_error("point offset out of range for this segment (the reference panics here)");
         return QMX_ERR_OUT_OF_BOUNDS;
     }
+    return QMX_OK;
+}
+
+// ---- kernel timing: event pairs on the query's stream, no host synchronisation while recording ----
+static int32_t timing_begin(qmx_query *q, size_t *slot) {
+    if (q->ev_used == q->evs.size()) {
+        qmx_query::EvPair p;
+        QMX_HIP(hipEventCreate(&p.a));
+        QMX_HIP(hipEventCreate(&p.b));
+        q->evs.push_back(p);
+    }
+    *slot = q->ev_used++;
+    QMX_HIP(hipEventRecord(q->evs[*slot].a, q->stream));
+    return QMX_OK;
+}
+static int32_t timing_end(qmx_query *q, size_t slot) {
+    QMX_HIP(hipEventRecord(q->evs[slot].b, q->stream));
+    return QMX_OK;
+}
+// stream must be idle (caller synchronised): folds the recorded pairs into timing_ms
+static int32_t timing_fold(qmx_query *q) {
+    for (size_t i = 0; i < q->ev_used; ++i) {
+        float ms = 0.f;
+        QMX_HIP(hipEventElapsedTime(&ms, q->evs[i].a, q->evs[i].b));
+        q->timing_ms += ms;
+        q->timing_launches++;
+    }
+    q->ev_used = 0;
     return QMX_OK;
 }
 
@@ -430,10 +465,6 @@ static int32_t query_alloc(const qmx_segment *seg, uint32_t nq, qmx_query **out)
     hipError_t e = hipStreamCreateWithFlags(&q->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) return fail(e, "hipStreamCreate");
     q->stream = q->own_stream;
-    e = hipEventCreate(&q->ev0);
-    if (e != hipSuccess) return fail(e, "hipEventCreate");
-    e = hipEventCreate(&q->ev1);
-    if (e != hipSuccess) return fail(e, "hipEventCreate");
     const size_t qbytes = (size_t)q->nq_padded * q->q_stride;
     e = hipMalloc(&q->d_queries, qbytes);
     if (e != hipSuccess) return fail(e, "hipMalloc(queries)");
@@ -447,48 +478,56 @@ static int32_t query_alloc(const qmx_segment *seg, uint32_t nq, qmx_query **out)
     return QMX_OK;
 }
 
+// MetricQueryScorer::new (metric_query_scorer.rs:35-58) for every query of the batch: preprocess
+// once, cast to the element type, pack into the LDS-tile layout.  Enqueued on the query's stream.
+static int32_t query_encode(qmx_query *q, const float *queries) {
+    const qmx_segment *seg = q->seg;
+    const uint32_t nq = q->nq;
+    if (nq == 0) return QMX_OK;
+    const size_t fbytes = (size_t)nq * seg->dim * sizeof(float);
+    const void *d_src = nullptr;
+    QMX_TRY(stage_in(q, q->misc, queries, fbytes, &d_src));
+    QMX_TRY(q->enc.reserve(fbytes));
+    float *d_f32 = (float *)q->enc.p;
+    // u8 storages never normalise (metric_uint/simple_cosine.rs:53-55)
+    const bool normalise = seg->distance == QMX_DISTANCE_COSINE && seg->dtype != QMX_DTYPE_U8;
+    if (normalise) {
+        QMX_TRY(launch_cosine_preprocess_f32(q->stream, (const float *)d_src, d_f32, nq, seg->dim));
+    } else {
+        QMX_HIP(hipMemcpyAsync(d_f32, d_src, fbytes, hipMemcpyDeviceToDevice, q->stream));
+    }
+    if (seg->dtype == QMX_DTYPE_F32) {
+        QMX_HIP(hipMemcpy2DAsync(q->d_queries, q->q_stride, d_f32, (size_t)seg->dim * 4, (size_t)seg->dim * 4, nq,
+                                 hipMemcpyDeviceToDevice, q->stream));
+        return QMX_OK;
+    }
+    set_error("query encode for dtype %u not built yet", seg->dtype);
+    return QMX_ERR_NOT_SUPPORTED;
+}
+
 int32_t qmx_query_create(const qmx_segment *seg, const float *queries, uint32_t nq, qmx_query **out) {
     QMX_REQUIRE(seg && out && (nq == 0 || queries), QMX_ERR_BAD_ARG, "NULL argument");
     *out = nullptr;
     QMX_HIP(hipSetDevice(seg->device));
     qmx_query *q = nullptr;
     QMX_TRY(query_alloc(seg, nq, &q));
-    int32_t rc = QMX_OK;
-    do {
-        if (nq == 0) break;
-        // MetricQueryScorer::new (metric_query_scorer.rs:35-58): preprocess once, then cast
-        const size_t fbytes = (size_t)nq * seg->dim * sizeof(float);
-        const void *d_src = nullptr;
-        if ((rc = stage_in(q, q->misc, queries, fbytes, &d_src)) != QMX_OK) break;
-        float *d_f32 = nullptr;
-        if ((rc = q->scores.reserve(fbytes)) != QMX_OK) break;
-        d_f32 = (float *)q->scores.p;
-        // u8 storages never normalise (metric_uint/simple_cosine.rs:53-55)
-        const bool normalise = seg->distance == QMX_DISTANCE_COSINE && seg->dtype != QMX_DTYPE_U8;
-        if (normalise) {
-            if ((rc = launch_cosine_preprocess_f32(q->stream, (const float *)d_src, d_f32, nq, seg->dim)) != QMX_OK) break;
-        } else {
-            hipError_t e = hipMemcpyAsync(d_f32, d_src, fbytes, hipMemcpyDeviceToDevice, q->stream);
-            if (e != hipSuccess) { rc = hip_status(e, "copy queries", __FILE__, __LINE__); break; }
-        }
-        if (seg->dtype == QMX_DTYPE_F32) {
-            hipError_t e = hipMemcpy2DAsync(q->d_queries, q->q_stride, d_f32, (size_t)seg->dim * 4, (size_t)seg->dim * 4, nq,
-                                            hipMemcpyDeviceToDevice, q->stream);
-            if (e != hipSuccess) { rc = hip_status(e, "pack queries", __FILE__, __LINE__); break; }
-        } else {
-            set_error("query encode for dtype %u not built yet", seg->dtype);
-            rc = QMX_ERR_NOT_SUPPORTED;
-            break;
-        }
+    int32_t rc = query_encode(q, queries);
+    if (rc == QMX_OK) {
         hipError_t e = hipStreamSynchronize(q->stream);
-        if (e != hipSuccess) { rc = hip_status(e, "sync", __FILE__, __LINE__); break; }
-    } while (0);
+        if (e != hipSuccess) rc = hip_status(e, "sync", __FILE__, __LINE__);
+    }
     if (rc != QMX_OK) {
         qmx_query_destroy(q);
         return rc;
     }
     *out = q;
     return QMX_OK;
+}
+
+int32_t qmx_query_update(qmx_query *q, const float *queries) {
+    QMX_REQUIRE(q && (q->nq == 0 || queries), QMX_ERR_BAD_ARG, "NULL argument");
+    QMX_HIP(hipSetDevice(q->seg->device));
+    return query_encode(q, queries);
 }
 
 int32_t qmx_query_create_internal(const qmx_segment *seg, const uint32_t *point_ids, uint32_t nq, qmx_query **out) {
@@ -532,8 +571,11 @@ int32_t qmx_query_destroy(qmx_query *q) {
     q->ids.release();
     q->scores.release();
     q->misc.release();
-    if (q->ev0) (void)hipEventDestroy(q->ev0);
-    if (q->ev1) (void)hipEventDestroy(q->ev1);
+    q->enc.release();
+    for (auto &p : q->evs) {
+        if (p.a) (void)hipEventDestroy(p.a);
+        if (p.b) (void)hipEventDestroy(p.b);
+    }
     if (q->own_stream) (void)hipStreamDestroy(q->own_stream);
     delete q;
     return QMX_OK;
@@ -549,6 +591,18 @@ int32_t qmx_query_set_stream(qmx_query *q, void *hip_stream) {
 int32_t qmx_query_set_timing(qmx_query *q, int32_t enabled) {
     QMX_REQUIRE(q, QMX_ERR_BAD_ARG, "NULL query");
     q->timing = enabled != 0;
+    return QMX_OK;
+}
+
+int32_t qmx_query_timing(qmx_query *q, float *total_ms, uint32_t *n_launches) {
+    QMX_REQUIRE(q, QMX_ERR_BAD_ARG, "NULL query");
+    QMX_HIP(hipSetDevice(q->seg->device));
+    QMX_HIP(hipStreamSynchronize(q->stream));
+    QMX_TRY(timing_fold(q));
+    if (total_ms) *total_ms = q->timing_ms;
+    if (n_launches) *n_launches = q->timing_launches;
+    q->timing_ms = 0.f;
+    q->timing_launches = 0;
     return QMX_OK;
 }
 
@@ -596,8 +650,8 @@ static int32_t launch_scan(const qmx_query *q, int qt, ScanMode mode, const Scan
     const qmx_segment *s = q->seg;
     if (s->dtype <= QMX_DTYPE_U8) {
         QMX_REQUIRE(s->fast_layout(), QMX_ERR_NOT_SUPPORTED,
-                    "dtype %u dim %u stride %llu: generic-layout kernel not built yet", s->dtype, s->dim,
-                    (unsigned long long)s->row_stride);
+                    "dtype %u dim %u: an adopted device block needs a 16-byte aligned base and row stride (got stride %llu); "
+                    "let qmx_segment_create upload it instead", s->dtype, s->dim, (unsigned long long)s->row_stride);
         return launch_scan_dense(q->stream, (int)s->dtype, (int)s->distance, qt, mode, a, s->num_cus, grid);
     }
     set_error("dtype %u not built yet", s->dtype);
@@ -666,7 +720,6 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
     // partial lists: one per block; bound the grid by what the buffer holds
     const uint32_t grid_cap = (uint32_t)s->num_cus * 8;
     QMX_TRY(q->partial.reserve((size_t)grid_cap * MAX_QT * top * sizeof(uint64_t)));
-    float total_ms = 0.f;
     for (uint32_t tile0 = 0; tile0 < q->nq; tile0 += MAX_QT) {
         if (is_stopped && *is_stopped) {
             set_error("search cancelled");
@@ -680,24 +733,19 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
         a.n_cand = n_cand;
         a.top = top;
         a.partial = (uint64_t *)q->partial.p;
+        a.partial_qt = (uint32_t)qt;
         uint32_t grid = grid_cap;
-        if (timed) QMX_HIP(hipEventRecord(q->ev0, q->stream));
+        size_t slot = 0;
+        if (timed) QMX_TRY(timing_begin(q, &slot));
         QMX_TRY(launch_scan(q, qt, SCAN_TOPK, a, &grid));
-        if (timed) QMX_HIP(hipEventRecord(q->ev1, q->stream));
+        if (timed) QMX_TRY(timing_end(q, slot));
         QMX_TRY(launch_merge_keys(q->stream, (const uint64_t *)q->partial.p, grid, (uint32_t)qt, nq_tile, top,
                                   d_out + (size_t)tile0 * top, d_counts + tile0));
-        if (timed) {
-            QMX_HIP(hipEventSynchronize(q->ev1));
-            float ms = 0.f;
-            QMX_HIP(hipEventElapsedTime(&ms, q->ev0, q->ev1));
-            total_ms += ms;
-        }
         if (counters) counters->kernel_launches += 2;
     }
     if (counters) {
         counters->vectors_scored += (uint64_t)q->nq * n_cand;
         counters->bytes_read += (uint64_t)((q->nq + MAX_QT - 1) / MAX_QT) * n_cand * s->row_bytes;
-        counters->kernel_ms += total_ms;
     }
     return QMX_OK;
 }
@@ -734,7 +782,13 @@ int32_t qmx_search_topk(qmx_query *q, uint32_t top, const uint32_t *ids, uint64_
     QMX_TRY(search_enqueue(q, top, (const uint32_t *)d_ids, n_ids, d_out, d_counts, is_stopped, counters, timed));
     if (!out_dev) QMX_TRY(copy_out(q->stream, out, d_out, (size_t)q->nq * top * sizeof(qmx_scored_point)));
     if (!cnt_dev) QMX_TRY(copy_out(q->stream, out_counts, d_counts, (size_t)q->nq * sizeof(uint32_t)));
-    return check_err_flag(q);
+    QMX_TRY(check_err_flag(q));  // synchronises the stream
+    if (timed) {
+        const float before = q->timing_ms;
+        QMX_TRY(timing_fold(q));
+        if (counters) counters->kernel_ms = q->timing_ms - before;
+    }
+    return QMX_OK;
 }
 
 int32_t qmx_search_topk_async(qmx_query *q, uint32_t top, const uint32_t *ids, uint64_t n_ids,
@@ -744,7 +798,8 @@ int32_t qmx_search_topk_async(qmx_query *q, uint32_t top, const uint32_t *ids, u
     QMX_REQUIRE(!ids || is_device_ptr(ids), QMX_ERR_BAD_ARG, "async search needs device ids");
     QMX_HIP(hipSetDevice(q->seg->device));
     if (q->nq == 0) return QMX_OK;
-    return search_enqueue(q, top, ids, n_ids, out_dev, out_counts_dev, nullptr, nullptr, false);
+    const bool timed = q->timing || (q->seg->flags & QMX_SEG_TIME_KERNELS) != 0;
+    return search_enqueue(q, top, ids, n_ids, out_dev, out_counts_dev, nullptr, nullptr, timed);
 }
 
 int32_t qmx_rescore(qmx_query *q, const uint32_t *ids, const uint32_t *counts, uint32_t n_per_query, uint32_t top,
@@ -784,13 +839,24 @@ int32_t qmx_merge_topk(int32_t device_id, const qmx_scored_point *lists, const u
         const bool od = is_device_ptr(out), ocd = is_device_ptr(out_counts);
         if (!od) { if ((rc = bo.reserve(obytes)) != QMX_OK) break; d_out = (qmx_scored_point *)bo.p; }
         if (!ocd) { if ((rc = boc.reserve((size_t)nq * 4)) != QMX_OK) break; d_oc = (uint32_t *)boc.p; }
-        if ((rc = launch_merge_points(nullptr, d_lists, d_lc, n_lists, nq, k, d_out, d_oc)) != QMX_OK) break;
+        if ((rc = launch_merge_points(nullptr, d_lists, d_lc, nullptr, n_lists, nq, k, d_out, d_oc)) != QMX_OK) break;
         if (!od && hipMemcpy(out, d_out, obytes, hipMemcpyDeviceToHost) != hipSuccess) { rc = QMX_ERR_OTHER; break; }
         if (!ocd && hipMemcpy(out_counts, d_oc, (size_t)nq * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = QMX_ERR_OTHER; break; }
         if (hipDeviceSynchronize() != hipSuccess) rc = QMX_ERR_OTHER;
     } while (0);
     bl.release(); bc.release(); bo.release(); boc.release();
     return rc;
+}
+
+int32_t qmx_merge_topk_async(int32_t device_id, void *hip_stream, const qmx_scored_point *lists_dev,
+                             const uint32_t *list_counts_dev, const uint32_t *list_idx_base_dev, uint32_t n_lists,
+                             uint32_t nq, uint32_t k, qmx_scored_point *out_dev, uint32_t *out_counts_dev) {
+    QMX_REQUIRE(lists_dev && out_dev && out_counts_dev, QMX_ERR_BAD_ARG, "NULL argument");
+    QMX_REQUIRE(k >= 1 && k <= MAX_TOP_FAST, QMX_ERR_NOT_SUPPORTED, "k %u not in 1..%d", k, MAX_TOP_FAST);
+    QMX_HIP(hipSetDevice(device_id));
+    if (nq == 0) return QMX_OK;
+    return launch_merge_points((hipStream_t)hip_stream, lists_dev, list_counts_dev, list_idx_base_dev, n_lists, nq, k,
+                               out_dev, out_counts_dev);
 }
 
 // ---- not built yet -----------------------------------------------------------------------------

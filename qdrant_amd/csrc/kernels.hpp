@@ -21,7 +21,8 @@ struct ScanArgs {
     const uint32_t *ids;       // candidate list or nullptr (= rows 0..n_cand)
     uint64_t n_cand;           // candidates to visit
     DeletedView del;
-    uint64_t *partial;         // [grid][QT][top] keys (top-k mode)
+    uint64_t *partial;         // [grid][partial_qt][top] keys (top-k mode)
+    uint32_t partial_qt;       // query stride of `partial` (the small-row kernel; the tiled one uses its QT)
     float *scores;             // [nq][n_cand] (score mode)
     uint64_t scores_stride;    // elements between queries in `scores`
     int *err_flag;             // set to 1 on an out-of-range id
@@ -43,7 +44,7 @@ int32_t launch_merge_keys(hipStream_t st, const uint64_t *partial, uint32_t n_li
                           uint32_t qt_stride, uint32_t nq, uint32_t top, qmx_scored_point *out,
                           uint32_t *out_counts);
 int32_t launch_merge_points(hipStream_t st, const qmx_scored_point *lists, const uint32_t *list_counts,
-                            uint32_t n_lists, uint32_t nq, uint32_t k, qmx_scored_point *out,
+                            const uint32_t *list_idx_base, uint32_t n_lists, uint32_t nq, uint32_t k, qmx_scored_point *out,
                             uint32_t *out_counts);
 int32_t launch_sort_scored(hipStream_t st, const float *scores, const uint32_t *ids,
                            const uint32_t *counts, uint32_t n_per_query, uint32_t nq, uint32_t top,

@@ -53,8 +53,10 @@ __global__ __launch_bounds__(256) void cosine_preprocess_kernel(const float *in,
             for (uint32_t i = lane; i < dim; i += 64) o[i] = v[i];
         return;
     }
-    length = __fsqrt_rn(length);
-    for (uint32_t i = lane; i < dim; i += 64) o[i] = __fdiv_rn(v[i], length);   // x / length, not x * (1/length)
+    // IEEE-correct sqrt and divide (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt); NOT
+    // __fsqrt_rn / __fdiv_rn: without OCML_BASIC_ROUNDED_OPERATIONS those lower to the 1-ulp native ops
+    length = __builtin_sqrtf(length);
+    for (uint32_t i = lane; i < dim; i += 64) o[i] = v[i] / length;   // x / length, not x * (1/length)
 }
 
 int32_t launch_cosine_preprocess_f32(hipStream_t st, const float *in, float *out, uint64_t n, uint32_t dim) {

@@ -196,4 +196,94 @@ int32_t launch_scan_inst(hipStream_t st, const ScanArgs &a, int num_cus, uint32_
     return QMX_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Small rows (below the reference's AVX threshold, spaces/simple.rs:15): one lane per candidate,
+// the policy S restates the reference's SSE / scalar leaf in a single thread, so scores stay
+// bit-identical.  blockIdx.y = query; rows this short are a few cache lines, re-reading them per
+// query costs nothing that matters.
+// ------------------------------------------------------------------------------------------
+constexpr int SMALL_BLOCK = 256;
+
+template <class S, bool HAS_IDS, int MODE>
+__global__ __launch_bounds__(SMALL_BLOCK) void scan_small_kernel(const ScanArgs a) {
+    constexpr int NW = SMALL_BLOCK / WAVE;
+    __shared__ uint64_t sh[NW][WAVE];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t q = blockIdx.y;
+    const unsigned char *qp = reinterpret_cast<const unsigned char *>(a.queries) + (uint64_t)q * a.q_stride;
+    const unsigned char *rows = reinterpret_cast<const unsigned char *>(a.rows);
+    const int top = (int)a.top;
+    uint64_t list = 0;
+    for (uint64_t base = ((uint64_t)blockIdx.x * NW + wave) * WAVE; base < a.n_cand;
+         base += (uint64_t)gridDim.x * NW * WAVE) {
+        const uint64_t c = base + lane;
+        bool valid = c < a.n_cand;
+        uint32_t id = HAS_IDS ? a.ids[valid ? c : 0] : (uint32_t)c;
+        if (HAS_IDS && valid && id >= a.n_rows) {
+            *a.err_flag = 1;
+            valid = false;
+        }
+        if (!valid) id = 0;
+        const float score = a.n_rows ? S::score(qp, rows + (uint64_t)id * a.row_stride, id, a) : 0.0f;
+        if (MODE == SCAN_SCORES) {
+            if (valid) a.scores[(uint64_t)q * a.scores_stride + c] = score;
+        } else {
+            const uint64_t key = make_key(score, id);
+            bool cnd = valid && key > readlane_u64(list, top - 1);
+            if (__ballot(cnd)) {
+                cnd = cnd && a.del.live(id);
+                uint64_t m = __ballot(cnd);
+                while (m) {
+                    const int src = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const uint64_t nk = readlane_u64(key, src);
+                    if (nk > readlane_u64(list, top - 1)) wave_list_insert(list, nk, lane);
+                }
+            }
+        }
+    }
+    if (MODE == SCAN_SCORES) return;
+    sh[wave][lane] = list;
+    __syncthreads();
+    if (wave == 0) {
+        uint64_t merged = sh[0][lane];
+        for (int w = 1; w < NW; ++w) {
+            const uint64_t key = sh[w][lane];
+            uint64_t m = __ballot(key > readlane_u64(merged, top - 1));
+            while (m) {
+                const int src = __builtin_ctzll(m);
+                m &= m - 1;
+                const uint64_t nk = readlane_u64(key, src);
+                if (nk > readlane_u64(merged, top - 1)) wave_list_insert(merged, nk, lane);
+            }
+        }
+        if (lane < top) a.partial[((uint64_t)blockIdx.x * a.partial_qt + q) * top + lane] = merged;
+    }
+}
+
+template <class S, bool HAS_IDS, int MODE>
+int32_t launch_small_inst(hipStream_t st, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
+    uint64_t want = (a.n_cand + SMALL_BLOCK - 1) / SMALL_BLOCK;
+    uint64_t cap = (uint64_t)num_cus * 8;
+    uint32_t grid = (uint32_t)(want < cap ? want : cap);
+    if (grid < 1) grid = 1;
+    if (grid_out) {
+        if (*grid_out && MODE == SCAN_TOPK && grid > *grid_out) grid = *grid_out;
+        *grid_out = grid;
+    }
+    hipLaunchKernelGGL((scan_small_kernel<S, HAS_IDS, MODE>), dim3(grid, a.nq), dim3(SMALL_BLOCK), 0, st, a);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+template <class S>
+int32_t launch_small(hipStream_t st, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid) {
+    const bool ids = a.ids != nullptr;
+    if (mode == SCAN_TOPK)
+        return ids ? launch_small_inst<S, true, SCAN_TOPK>(st, a, num_cus, grid)
+                   : launch_small_inst<S, false, SCAN_TOPK>(st, a, num_cus, grid);
+    return ids ? launch_small_inst<S, true, SCAN_SCORES>(st, a, num_cus, grid)
+               : launch_small_inst<S, false, SCAN_SCORES>(st, a, num_cus, grid);
+}
+
 }  // namespace qmx

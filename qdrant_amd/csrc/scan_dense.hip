@@ -68,6 +68,44 @@ struct RowF32 {
     }
 };
 
+
+// ------------------------------------------------------------------------------------------
+// f32 below the AVX threshold: SSE leaf for 16 <= dim < 32 (spaces/simple_sse.rs:19-243: 4 x __m128,
+// mul THEN add, hsum128 of each register, scalar adds, scalar tail), scalar leaf below 16
+// (spaces/simple.rs:214-239: sequential sum from -0.0).
+// ------------------------------------------------------------------------------------------
+template <int METRIC>
+struct SmallF32 {
+    static __device__ __forceinline__ float term(float q, float v) {
+        if (METRIC == M_DOT) return q * v;
+        const float d = q - v;
+        return METRIC == M_EUCLID ? d * d : __builtin_fabsf(d);
+    }
+    static __device__ float score(const unsigned char *qb, const unsigned char *rb, uint32_t, const ScanArgs &a) {
+        const float *q = reinterpret_cast<const float *>(qb);
+        const float *v = reinterpret_cast<const float *>(rb);
+        const uint32_t dim = a.dim;
+        float result;
+        uint32_t i0 = 0;
+        if (dim >= 16) {
+            float h[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[k] = term(q[4 * r + k], v[4 * r + k]) + 0.0f;  // _mm_add_ps(term, zero)
+                h[r] = (x[0] + x[2]) + (x[1] + x[3]);                                        // hsum128_ps_sse
+            }
+            result = ((h[0] + h[1]) + h[2]) + h[3];
+            i0 = 16;
+        } else {
+            result = -0.0f;
+        }
+        for (uint32_t i = i0; i < dim; ++i) result += term(q[i], v[i]);
+        return METRIC == M_DOT ? result : -result;
+    }
+};
+
 // ------------------------------------------------------------------------------------------
 // dispatch
 // ------------------------------------------------------------------------------------------
@@ -96,6 +134,14 @@ static int32_t launch_policy(hipStream_t st, int qt, ScanMode mode, const ScanAr
 
 int32_t launch_scan_dense(hipStream_t st, int dtype, int distance, int qt, ScanMode mode,
                           const ScanArgs &a, int num_cus, uint32_t *grid_out) {
+    if (dtype == QMX_DTYPE_F32 && a.dim < 32) {
+        switch (distance) {
+            case QMX_DISTANCE_COSINE:
+            case QMX_DISTANCE_DOT: return launch_small<SmallF32<M_DOT>>(st, mode, a, num_cus, grid_out);
+            case QMX_DISTANCE_EUCLID: return launch_small<SmallF32<M_EUCLID>>(st, mode, a, num_cus, grid_out);
+            case QMX_DISTANCE_MANHATTAN: return launch_small<SmallF32<M_MANHATTAN>>(st, mode, a, num_cus, grid_out);
+        }
+    }
     if (dtype == QMX_DTYPE_F32) {
         switch (distance) {
             case QMX_DISTANCE_COSINE:  // CosineMetric::similarity == DotProductMetric::similarity (simple.rs:174-176)

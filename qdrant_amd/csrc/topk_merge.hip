@@ -60,7 +60,8 @@ __global__ __launch_bounds__(MERGE_BLOCK) void merge_keys_kernel(const uint64_t 
 }
 
 __global__ __launch_bounds__(MERGE_BLOCK) void merge_points_kernel(const qmx_scored_point *lists,
-                                                                   const uint32_t *list_counts, uint32_t n_lists,
+                                                                   const uint32_t *list_counts,
+                                                                   const uint32_t *list_idx_base, uint32_t n_lists,
                                                                    uint32_t nq, uint32_t k, qmx_scored_point *out,
                                                                    uint32_t *out_counts) {
     const uint32_t q = blockIdx.x;
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(MERGE_BLOCK) void merge_points_kernel(const qmx_sco
         uint64_t key = 0;
         if (lane < (int)k && lane < (int)cnt) {
             const qmx_scored_point p = lists[((uint64_t)l * nq + q) * k + lane];
-            key = make_key(p.score, p.idx);
+            key = make_key(p.score, p.idx + (list_idx_base ? list_idx_base[l] : 0u));
         }
         wave_offer(list, key, (int)k, lane);
     }
@@ -102,9 +103,10 @@ int32_t launch_merge_keys(hipStream_t st, const uint64_t *partial, uint32_t n_li
     return QMX_OK;
 }
 int32_t launch_merge_points(hipStream_t st, const qmx_scored_point *lists, const uint32_t *list_counts,
-                            uint32_t n_lists, uint32_t nq, uint32_t k, qmx_scored_point *out, uint32_t *out_counts) {
+                            const uint32_t *list_idx_base, uint32_t n_lists, uint32_t nq, uint32_t k,
+                            qmx_scored_point *out, uint32_t *out_counts) {
     if (nq == 0) return QMX_OK;
-    hipLaunchKernelGGL(merge_points_kernel, dim3(nq), dim3(MERGE_BLOCK), 0, st, lists, list_counts, n_lists, nq, k, out, out_counts);
+    hipLaunchKernelGGL(merge_points_kernel, dim3(nq), dim3(MERGE_BLOCK), 0, st, lists, list_counts, list_idx_base, n_lists, nq, k, out, out_counts);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }

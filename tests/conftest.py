@@ -4,6 +4,14 @@ import sys
 
 import pytest
 
+# Load order with PyTorch: torch wheels bundle their own libamdhip64; whichever HIP runtime is mapped
+# first serves the whole process.  Import torch before libqdrant_amd.so so that both share torch's
+# runtime (the other order leaves torch without devices).  See INTEGRATION.md.
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
