@@ -3,6 +3,7 @@
 // No CPU scoring path exists here: every score is produced by a gfx950 kernel or the call fails.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -37,6 +38,14 @@ int32_t hip_status(hipError_t e, const char *what, const char *file, int line) {
         case hipErrorNotReady: return QMX_ERR_NOT_READY;
         case hipErrorInvalidValue: return QMX_ERR_BAD_ARG;
         default: return QMX_ERR_OTHER;
+    }
+}
+
+void clear_stale_error() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        static const bool debug = getenv("QMX_DEBUG") != nullptr;
+        if (debug) fprintf(stderr, "[qmx] dropped stale HIP error %d (%s) before a kernel launch\n", (int)e, hipGetErrorString(e));
     }
 }
 
@@ -125,10 +134,12 @@ struct qmx_segment {
     uint32_t pq_m = 0;
 
     bool fast_layout() const {
-        if (dtype == QMX_DTYPE_F32)
-            return dim < 32 ? (row_stride % 4 == 0 && ((uintptr_t)d_rows % 4) == 0)
+        if (dtype <= QMX_DTYPE_U8) {
+            const uint64_t eb = dtype == QMX_DTYPE_F32 ? 4 : dtype == QMX_DTYPE_F16 ? 2 : 1;
+            return dim < 32 ? (row_stride % eb == 0 && ((uintptr_t)d_rows % eb) == 0)
                             : (row_stride % 16 == 0 && ((uintptr_t)d_rows % 16) == 0);
-        return false;
+        }
+        return true;
     }
     DeletedView deleted_view() const {
         DeletedView v;
@@ -145,9 +156,11 @@ struct qmx_segment {
 
 struct qmx_query {
     const qmx_segment *seg = nullptr;
+    int device = 0;            // copy of seg->device: destroy must not touch a segment that died first
     uint32_t nq = 0;
     uint32_t nq_padded = 0;
     uint32_t q_stride = 0;     // bytes
+    uint32_t aux_off = 0;      // bytes
     void *d_queries = nullptr; // [nq_padded][q_stride]
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
@@ -453,10 +466,13 @@ static int32_t query_alloc(const qmx_segment *seg, uint32_t nq, qmx_query **out)
     qmx_query *q = new (std::nothrow) qmx_query();
     QMX_REQUIRE(q, QMX_ERR_OUT_OF_MEMORY, "host allocation failed");
     q->seg = seg;
+    q->device = seg->device;
     q->nq = nq;
     q->nq_padded = ((nq + MAX_QT - 1) / MAX_QT) * MAX_QT;
     if (q->nq_padded == 0) q->nq_padded = MAX_QT;
-    q->q_stride = (uint32_t)((seg->scan_dim * elem_bytes(seg->dtype) + 15) & ~15u);
+    // tile entry = elements zero-padded to whole 128-byte segments + the aux block
+    q->aux_off = (uint32_t)((seg->scan_dim * elem_bytes(seg->dtype) + 127) & ~127u);
+    q->q_stride = q->aux_off + QUERY_AUX_BYTES;
     auto fail = [&](hipError_t e, const char *what) {
         int32_t rc = hip_status(e, what, __FILE__, __LINE__);
         qmx_query_destroy(q);
@@ -496,11 +512,9 @@ static int32_t query_encode(qmx_query *q, const float *queries) {
     } else {
         QMX_HIP(hipMemcpyAsync(d_f32, d_src, fbytes, hipMemcpyDeviceToDevice, q->stream));
     }
-    if (seg->dtype == QMX_DTYPE_F32) {
-        QMX_HIP(hipMemcpy2DAsync(q->d_queries, q->q_stride, d_f32, (size_t)seg->dim * 4, (size_t)seg->dim * 4, nq,
-                                 hipMemcpyDeviceToDevice, q->stream));
-        return QMX_OK;
-    }
+    if (seg->dtype <= QMX_DTYPE_U8)
+        return launch_pack_queries(q->stream, (int)seg->dtype, (int)seg->distance, d_f32, 0, seg->dim * 4, nq, seg->dim,
+                                   q->d_queries, q->q_stride, q->aux_off);
     set_error("query encode for dtype %u not built yet", seg->dtype);
     return QMX_ERR_NOT_SUPPORTED;
 }
@@ -546,9 +560,8 @@ int32_t qmx_query_create_internal(const qmx_segment *seg, const uint32_t *point_
         if ((rc = q->misc.reserve((size_t)nq * seg->row_bytes)) != QMX_OK) break;
         if ((rc = launch_gather_rows(q->stream, seg->d_rows, seg->row_stride, seg->row_bytes, (const uint32_t *)d_ids, nq,
                                      seg->n, q->misc.p, q->d_err)) != QMX_OK) break;
-        hipError_t e = hipMemcpy2DAsync(q->d_queries, q->q_stride, q->misc.p, seg->row_bytes, seg->row_bytes, nq,
-                                        hipMemcpyDeviceToDevice, q->stream);
-        if (e != hipSuccess) { rc = hip_status(e, "pack queries", __FILE__, __LINE__); break; }
+        if ((rc = launch_pack_queries(q->stream, (int)seg->dtype, (int)seg->distance, q->misc.p, 1, (uint32_t)seg->row_bytes,
+                                      nq, seg->dim, q->d_queries, q->q_stride, q->aux_off)) != QMX_OK) break;
         if ((rc = check_err_flag(q)) != QMX_OK) break;
     } while (0);
     if (rc != QMX_OK) {
@@ -561,7 +574,7 @@ int32_t qmx_query_create_internal(const qmx_segment *seg, const uint32_t *point_
 
 int32_t qmx_query_destroy(qmx_query *q) {
     if (!q) return QMX_OK;
-    if (q->seg) (void)hipSetDevice(q->seg->device);
+    (void)hipSetDevice(q->device);
     if (q->stream) (void)hipStreamSynchronize(q->stream);
     if (q->d_queries) (void)hipFree(q->d_queries);
     if (q->d_err) (void)hipFree(q->d_err);
@@ -638,6 +651,15 @@ static void fill_args(const qmx_query *q, uint32_t tile0, uint32_t nq_tile, Scan
     a.nq = nq_tile;
     a.queries = (const char *)q->d_queries + (size_t)tile0 * q->q_stride;
     a.q_stride = q->q_stride;
+    a.aux_off = q->aux_off;
+    {   // SIMD body / scalar tail split of the reference leaf (AVX loops step 32 elements)
+        const uint32_t eb = elem_bytes(s->dtype);
+        const uint32_t full = s->dtype <= QMX_DTYPE_U8 ? s->scan_dim - s->scan_dim % 32 : s->scan_dim;
+        const uint32_t body_bytes = full * eb;
+        a.nseg = body_bytes / 128;
+        a.rem_pieces = (body_bytes % 128) / 16;
+        a.tail_start = full;
+    }
     a.del = s->deleted_view();
     a.err_flag = q->d_err;
     a.flags = s->flags;

@@ -12,6 +12,10 @@ namespace qmx {
 // ---- error plumbing ------------------------------------------------------------------------
 void set_error(const char *fmt, ...);
 int32_t hip_status(hipError_t e, const char *what, const char *file, int line);
+// hipGetLastError() reports the last error of ANY earlier runtime call of this thread (also one made
+// by another library sharing the runtime); drop such a stale error before a launch so that the
+// check after the launch speaks about this launch only.  QMX_DEBUG=1 prints what was dropped.
+void clear_stale_error();
 
 #define QMX_HIP(expr)                                                        \
     do {                                                                     \

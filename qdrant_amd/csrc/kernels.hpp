@@ -14,6 +14,10 @@ struct ScanArgs {
     uint64_t n_rows;
     uint64_t row_stride;       // bytes
     uint32_t dim;              // elements per row consumed by the metric (actual_dim for SQ)
+    uint32_t nseg;             // full 128-byte segments of the SIMD body
+    uint32_t rem_pieces;       // 16-byte pieces of the SIMD body in the last, partial segment (0 = none)
+    uint32_t tail_start;       // first element of the reference's scalar tail (== dim when none)
+    uint32_t aux_off;          // byte offset of the per-query aux block inside a query tile entry
     uint32_t nq;               // live queries in this tile (<= QT)
     const void *queries;       // device, [QT][q_stride] bytes, preprocessed + cast (+ aux)
     uint32_t q_stride;         // bytes between queries
@@ -36,9 +40,23 @@ struct ScanArgs {
 
 enum ScanMode { SCAN_TOPK = 0, SCAN_SCORES = 1 };
 
+// per-query aux block (64 bytes after the padded elements of each query in the tile)
+struct QueryAux {
+    float f0;           // u8 cosine: norm1 (reference order) ; SQ: query offset
+    int32_t i0;         // u8 cosine scalar order: norm1 as i32
+    uint32_t pad[14];
+};
+constexpr uint32_t QUERY_AUX_BYTES = 64;
+
 // dense f32 / f16 / u8 (scan_dense.hip)
 int32_t launch_scan_dense(hipStream_t st, int dtype, int distance, int qt, ScanMode mode,
                           const ScanArgs &a, int num_cus, uint32_t *grid_out);
+// SQ int8 rows: codes SoA + offsets (scan_quant.hip)
+int32_t launch_scan_sq(hipStream_t st, int distance, int qt, ScanMode mode, const ScanArgs &a, int num_cus,
+                       uint32_t *grid_out);
+// query tile packing: preprocessed f32 queries -> element type, padded, + aux (preprocess.hip)
+int32_t launch_pack_queries(hipStream_t st, int dtype, int distance, const void *src, int src_is_encoded,
+                            uint32_t src_stride, uint32_t nq, uint32_t dim, void *tile, uint32_t q_stride, uint32_t aux_off);
 // top-k merge of `n_lists` key lists per query into ScoredPointOffset rows (topk_merge.hip)
 int32_t launch_merge_keys(hipStream_t st, const uint64_t *partial, uint32_t n_lists,
                           uint32_t qt_stride, uint32_t nq, uint32_t top, qmx_scored_point *out,

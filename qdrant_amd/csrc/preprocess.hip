@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) void cosine_preprocess_kernel(const float *in,
 int32_t launch_cosine_preprocess_f32(hipStream_t st, const float *in, float *out, uint64_t n, uint32_t dim) {
     if (n == 0) return QMX_OK;
     const uint32_t blocks = (uint32_t)((n + 3) / 4);
+    ::qmx::clear_stale_error();
     hipLaunchKernelGGL(cosine_preprocess_kernel, dim3(blocks), dim3(256), 0, st, in, out, n, dim);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
@@ -71,6 +72,7 @@ int32_t launch_cosine_preprocess_f32(hipStream_t st, const float *in, float *out
 // PrimitiveVectorElement::slice_from_float_cow (lib/segment/src/data_types/primitive.rs):
 //   f16: half::f16::from_f32, IEEE RNE (:77-79)      u8: `x as u8` saturating truncation, NaN -> 0 (:127-129)
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint8_t f32_to_u8_sat(float x);
 __global__ void cast_f32_kernel(int dst_dtype, const float *in, void *out, uint64_t count) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
@@ -78,8 +80,7 @@ __global__ void cast_f32_kernel(int dst_dtype, const float *in, void *out, uint6
         if (dst_dtype == QMX_DTYPE_F16) {
             reinterpret_cast<__half *>(out)[i] = __float2half_rn(x);
         } else if (dst_dtype == QMX_DTYPE_U8) {
-            uint8_t b = (x != x) ? 0 : (x <= 0.0f ? 0 : (x >= 255.0f ? 255 : (uint8_t)x));
-            reinterpret_cast<uint8_t *>(out)[i] = b;
+            reinterpret_cast<uint8_t *>(out)[i] = f32_to_u8_sat(x);
         } else {
             reinterpret_cast<float *>(out)[i] = x;
         }
@@ -89,7 +90,72 @@ int32_t launch_cast_f32(hipStream_t st, int dst_dtype, const float *in, void *ou
     if (count == 0) return QMX_OK;
     uint64_t blocks = (count + 255) / 256;
     if (blocks > 8192) blocks = 8192;
+    ::qmx::clear_stale_error();
     hipLaunchKernelGGL(cast_f32_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, dst_dtype, in, out, count);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Query tile packing = the tail of MetricQueryScorer::new (metric_query_scorer.rs:51-53): cast the
+// preprocessed f32 query to the element type (or copy an already-encoded stored row for
+// FilteredScorer::new_internal), zero-pad the entry to whole 128-byte segments, fill the aux block.
+// One wavefront per query.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint8_t f32_to_u8_sat(float x) {   // `x as u8`: truncating, saturating, NaN -> 0
+    return (x != x) ? 0 : (x <= 0.0f ? 0 : (x >= 255.0f ? 255 : (uint8_t)x));
+}
+
+__global__ __launch_bounds__(64) void pack_queries_kernel(int dtype, int distance, const void *src, int src_is_encoded,
+                                                          uint32_t src_stride, uint32_t dim, unsigned char *tile,
+                                                          uint32_t q_stride, uint32_t aux_off) {
+    const uint32_t q = blockIdx.x;
+    const int lane = threadIdx.x;
+    unsigned char *dst = tile + (uint64_t)q * q_stride;
+    const unsigned char *sp = reinterpret_cast<const unsigned char *>(src) + (uint64_t)q * src_stride;
+    const uint32_t elem = dtype == QMX_DTYPE_F32 ? 4 : dtype == QMX_DTYPE_F16 ? 2 : 1;
+    const uint32_t nbytes = dim * elem;
+    for (uint32_t i = nbytes + lane; i < q_stride; i += 64) dst[i] = 0;
+    if (src_is_encoded) {
+        for (uint32_t i = lane; i < nbytes; i += 64) dst[i] = sp[i];
+    } else {
+        const float *f = reinterpret_cast<const float *>(sp);
+        for (uint32_t i = lane; i < dim; i += 64) {
+            const float x = f[i];
+            if (dtype == QMX_DTYPE_F32) reinterpret_cast<float *>(dst)[i] = x;
+            else if (dtype == QMX_DTYPE_F16) reinterpret_cast<__half *>(dst)[i] = __float2half_rn(x);
+            else dst[i] = f32_to_u8_sat(x);
+        }
+    }
+    if (dtype == QMX_DTYPE_U8 && distance == QMX_DISTANCE_COSINE && dim >= 32) {
+        __syncthreads();
+        if (lane == 0) {
+            // norm1 of avx_cosine_similarity_bytes (metric_uint/avx2/cosine.rs:47-50,80-99): 8 exact i32
+            // lanes (bytes 4j..4j+3 of every 32-byte block), cvtepi32_ps, hsum256, + remainder as f32
+            int32_t l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const uint32_t full = dim - dim % 32;
+            for (uint32_t i = 0; i < full; ++i) { const int32_t x = dst[i]; l[(i & 31) >> 2] += x * x; }
+            int32_t rem = 0;
+            for (uint32_t i = full; i < dim; ++i) { const int32_t x = dst[i]; rem += x * x; }
+            float lr[4];
+            for (int k = 0; k < 4; ++k) lr[k] = (float)l[k + 4] + (float)l[k];
+            float n1 = (lr[0] + lr[1]) + (lr[2] + lr[3]);
+            if (full < dim) n1 += (float)rem;
+            QueryAux *aux = reinterpret_cast<QueryAux *>(dst + aux_off);
+            aux->f0 = n1;
+            int32_t tot = rem;
+            for (int k = 0; k < 8; ++k) tot += l[k];
+            aux->i0 = tot;
+        }
+    }
+}
+
+int32_t launch_pack_queries(hipStream_t st, int dtype, int distance, const void *src, int src_is_encoded,
+                            uint32_t src_stride, uint32_t nq, uint32_t dim, void *tile, uint32_t q_stride, uint32_t aux_off) {
+    if (nq == 0) return QMX_OK;
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(pack_queries_kernel, dim3(nq), dim3(64), 0, st, dtype, distance, src, src_is_encoded, src_stride, dim,
+                       (unsigned char *)tile, q_stride, aux_off);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }
@@ -120,6 +186,7 @@ static uint64_t host_splitmix64(uint64_t x) {
 }
 int32_t launch_synth_fill(hipStream_t st, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, float *out) {
     if (n == 0) return QMX_OK;
+    ::qmx::clear_stale_error();
     hipLaunchKernelGGL(synth_fill_kernel, dim3(4096), dim3(256), 0, st, host_splitmix64(seed), row0, n, dim, out);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
@@ -145,6 +212,7 @@ __global__ void gather_rows_kernel(const unsigned char *rows, uint64_t row_strid
 int32_t launch_gather_rows(hipStream_t st, const void *rows, uint64_t row_stride, uint64_t row_bytes,
                            const uint32_t *ids, uint32_t n, uint64_t n_rows, void *out, int *err_flag) {
     if (n == 0) return QMX_OK;
+    ::qmx::clear_stale_error();
     hipLaunchKernelGGL(gather_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, st, (const unsigned char *)rows,
                        row_stride, row_bytes, ids, n, n_rows, (unsigned char *)out, err_flag);
     QMX_HIP(hipGetLastError());

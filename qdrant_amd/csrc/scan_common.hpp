@@ -29,10 +29,30 @@ namespace qmx {
 // half" is row_half_mirror.
 __device__ __forceinline__ int lane_piece(int t) { return 2 * (t & 3) + (t >> 2); }
 
+// one 128-byte segment step: the lane's 16-byte row pieces (R rows) against every query of the tile
+template <class P, int QT, int R>
+__device__ __forceinline__ void scan_step(typename P::acc_t (&acc)[QT][R][P::NACC],
+                                          typename P::acc_t (&raux)[R][P::NRAUX > 0 ? P::NRAUX : 1],
+                                          const uint4 (&v)[R], const unsigned char *q_lds, uint32_t q_stride,
+                                          bool lane_on) {
+    if (P::NRAUX > 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) P::row_aux(raux[r], v[r]);
+    }
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {
+        uint4 qv = *reinterpret_cast<const uint4 *>(q_lds + (uint32_t)q * q_stride);
+        if (!lane_on) qv = make_uint4(0, 0, 0, 0);   // partial segment: the scalar-tail elements sit right behind the body
+#pragma unroll
+        for (int r = 0; r < R; ++r) P::mac(acc[q][r], qv, v[r]);
+    }
+}
+
 template <class P, int QT, int R, int UNROLL, bool HAS_IDS, int MODE>
 __global__ __launch_bounds__(SCAN_BLOCK) void scan_kernel(const ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NW = SCAN_BLOCK / WAVE;
+    constexpr int NRA = P::NRAUX > 0 ? P::NRAUX : 1;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -48,7 +68,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_kernel(const ScanArgs a) {
 
     const int t = lane & 7;
     const int g = lane >> 3;
-    const int piece_off = lane_piece(t) * 16;
+    const int piece = lane_piece(t);
+    const int piece_off = piece * 16;
     const unsigned char *rows = reinterpret_cast<const unsigned char *>(a.rows);
 
     uint64_t list[QT];
@@ -59,7 +80,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_kernel(const ScanArgs a) {
     const uint32_t tw = gridDim.x * NW;
     constexpr uint32_t TILE = 8 * R;
     const uint64_t n_tiles = (a.n_cand + TILE - 1) / TILE;
-    const uint32_t nseg = (a.dim * P::ELEM) / P::SEG;
+    const uint32_t nseg = a.nseg;
+    const bool piece_in_rem = piece < (int)a.rem_pieces;
 
     for (uint64_t tile = gw; tile < n_tiles; tile += tw) {
         uint32_t rid[R];
@@ -83,26 +105,35 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_kernel(const ScanArgs a) {
         }
 
         typename P::acc_t acc[QT][R][P::NACC];
+        typename P::acc_t raux[R][NRA];
 #pragma unroll
         for (int q = 0; q < QT; ++q)
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
                 for (int k = 0; k < P::NACC; ++k) acc[q][r][k] = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int k = 0; k < NRA; ++k) raux[r][k] = 0;
 
 #pragma unroll UNROLL
         for (uint32_t s = 0; s < nseg; ++s) {
-            typename P::vec_t v[R];
+            uint4 v[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-                v[r] = *reinterpret_cast<const typename P::vec_t *>(rp[r] + (uint64_t)s * P::SEG);
+            for (int r = 0; r < R; ++r) v[r] = *reinterpret_cast<const uint4 *>(rp[r] + (uint64_t)s * 128);
+            scan_step<P, QT, R>(acc, raux, v, smem + s * 128 + piece_off, a.q_stride, true);
+        }
+        if (a.rem_pieces) {
+            // last, partial segment of the SIMD body (element types narrower than f32): pieces past
+            // it are zero on both sides (the query tile is zero-padded), rows are never read past
+            uint4 v[R];
 #pragma unroll
-            for (int q = 0; q < QT; ++q) {
-                const typename P::vec_t qv = *reinterpret_cast<const typename P::vec_t *>(
-                    smem + (uint32_t)q * a.q_stride + s * P::SEG + piece_off);
-#pragma unroll
-                for (int r = 0; r < R; ++r) P::mac(acc[q][r], qv, v[r]);
+            for (int r = 0; r < R; ++r) {
+                v[r] = make_uint4(0, 0, 0, 0);
+                if (piece_in_rem) v[r] = *reinterpret_cast<const uint4 *>(rp[r] + (uint64_t)nseg * 128);
             }
+            scan_step<P, QT, R>(acc, raux, v, smem + nseg * 128 + piece_off, a.q_stride, piece_in_rem);
         }
 
 #pragma unroll
@@ -110,8 +141,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_kernel(const ScanArgs a) {
             if (q < (int)a.nq) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const float score = P::finish(acc[q][r], smem + (uint32_t)q * a.q_stride,
-                                                  rows + (uint64_t)rid[r] * a.row_stride, rid[r], nseg, a);
+                    const float score = P::finish(acc[q][r], raux[r], smem + (uint32_t)q * a.q_stride,
+                                                  rows + (uint64_t)rid[r] * a.row_stride, rid[r], a);
                     if (MODE == SCAN_SCORES) {
                         if (valid[r] && t == 0) a.scores[(uint64_t)q * a.scores_stride + cand[r]] = score;
                     } else {
@@ -191,9 +222,48 @@ int32_t launch_scan_inst(hipStream_t st, const ScanArgs &a, int num_cus, uint32_
         if (*grid_out && MODE == SCAN_TOPK && grid > *grid_out) grid = *grid_out;  // caller's partial buffer bound
         *grid_out = grid;
     }
+    ::qmx::clear_stale_error();
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(SCAN_BLOCK), lds, st, a);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
+}
+
+template <class P, int QT, int R, int U>
+int32_t launch_qt(hipStream_t st, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid) {
+    const bool ids = a.ids != nullptr;
+    if (mode == SCAN_TOPK) {
+        return ids ? launch_scan_inst<P, QT, R, U, true, SCAN_TOPK>(st, a, num_cus, grid)
+                   : launch_scan_inst<P, QT, R, U, false, SCAN_TOPK>(st, a, num_cus, grid);
+    }
+    return ids ? launch_scan_inst<P, QT, R, U, true, SCAN_SCORES>(st, a, num_cus, grid)
+               : launch_scan_inst<P, QT, R, U, false, SCAN_SCORES>(st, a, num_cus, grid);
+}
+
+template <class P>
+int32_t launch_policy(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid) {
+    switch (qt) {
+        case 1: return launch_qt<P, 1, 4, 4>(st, mode, a, num_cus, grid);
+        case 2: return launch_qt<P, 2, 4, 2>(st, mode, a, num_cus, grid);
+        case 4: return launch_qt<P, 4, 2, 4>(st, mode, a, num_cus, grid);
+        case 8: return launch_qt<P, 8, 2, 2>(st, mode, a, num_cus, grid);
+        case 16: return launch_qt<P, 16, P::R16, 2>(st, mode, a, num_cus, grid);
+        default: set_error("unsupported query tile %d", qt); return QMX_ERR_BAD_ARG;
+    }
+}
+
+// 8-lane reductions of the per-lane partials of one row (DPP only, no LDS)
+__device__ __forceinline__ float reduce8_f32(float x) {
+    x += dpp_f32<DPP_QUAD_XOR1>(x);
+    x += dpp_f32<DPP_QUAD_XOR2>(x);
+    return x + dpp_f32<DPP_ROW_HALF_MIRROR>(x);
+}
+__device__ __forceinline__ uint32_t reduce4_u32(uint32_t x) {   // the 4 lanes of a quad
+    x += (uint32_t)dpp_i32<DPP_QUAD_XOR1>((int)x);
+    return x + (uint32_t)dpp_i32<DPP_QUAD_XOR2>((int)x);
+}
+__device__ __forceinline__ uint32_t reduce8_u32(uint32_t x) {
+    x = reduce4_u32(x);
+    return x + (uint32_t)dpp_i32<DPP_ROW_HALF_MIRROR>((int)x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -272,6 +342,7 @@ int32_t launch_small_inst(hipStream_t st, const ScanArgs &a, int num_cus, uint32
         if (*grid_out && MODE == SCAN_TOPK && grid > *grid_out) grid = *grid_out;
         *grid_out = grid;
     }
+    ::qmx::clear_stale_error();
     hipLaunchKernelGGL((scan_small_kernel<S, HAS_IDS, MODE>), dim3(grid, a.nq), dim3(SMALL_BLOCK), 0, st, a);
     QMX_HIP(hipGetLastError());
     return QMX_OK;

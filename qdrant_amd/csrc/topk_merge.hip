@@ -98,6 +98,7 @@ __global__ __launch_bounds__(MERGE_BLOCK) void sort_scored_kernel(const float *s
 int32_t launch_merge_keys(hipStream_t st, const uint64_t *partial, uint32_t n_lists, uint32_t qt_stride,
                           uint32_t nq, uint32_t top, qmx_scored_point *out, uint32_t *out_counts) {
     if (nq == 0) return QMX_OK;
+    ::qmx::clear_stale_error();
     hipLaunchKernelGGL(merge_keys_kernel, dim3(nq), dim3(MERGE_BLOCK), 0, st, partial, n_lists, qt_stride, top, out, out_counts);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
@@ -106,6 +107,7 @@ int32_t launch_merge_points(hipStream_t st, const qmx_scored_point *lists, const
                             const uint32_t *list_idx_base, uint32_t n_lists, uint32_t nq, uint32_t k,
                             qmx_scored_point *out, uint32_t *out_counts) {
     if (nq == 0) return QMX_OK;
+    ::qmx::clear_stale_error();
     hipLaunchKernelGGL(merge_points_kernel, dim3(nq), dim3(MERGE_BLOCK), 0, st, lists, list_counts, list_idx_base, n_lists, nq, k, out, out_counts);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
@@ -113,6 +115,7 @@ int32_t launch_merge_points(hipStream_t st, const qmx_scored_point *lists, const
 int32_t launch_sort_scored(hipStream_t st, const float *scores, const uint32_t *ids, const uint32_t *counts,
                            uint32_t n_per_query, uint32_t nq, uint32_t top, qmx_scored_point *out, uint32_t *out_counts) {
     if (nq == 0) return QMX_OK;
+    ::qmx::clear_stale_error();
     hipLaunchKernelGGL(sort_scored_kernel, dim3(nq), dim3(MERGE_BLOCK), 0, st, scores, ids, counts, n_per_query, top, out, out_counts);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
