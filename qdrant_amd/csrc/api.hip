@@ -132,6 +132,7 @@ struct qmx_segment {
     qmx_pq_params pq{};
     float *d_centroids = nullptr;
     uint32_t pq_m = 0;
+    float *d_row_offsets = nullptr;   // SQ: vector_offset column (rows hold the 16-byte aligned code block)
 
     bool fast_layout() const {
         if (dtype <= QMX_DTYPE_U8) {
@@ -280,6 +281,59 @@ int32_t qmx_device_count(int32_t *out_count) {
 // ---------------------------------------------------------------------------------------------
 // segment
 // ---------------------------------------------------------------------------------------------
+static void segment_free(qmx_segment *seg) {
+    if (seg->owns_rows && seg->d_rows) (void)hipFree(seg->d_rows);
+    if (seg->d_point_deleted) (void)hipFree(seg->d_point_deleted);
+    if (seg->d_vec_deleted) (void)hipFree(seg->d_vec_deleted);
+    if (seg->d_centroids) (void)hipFree(seg->d_centroids);
+    if (seg->d_row_offsets) (void)hipFree(seg->d_row_offsets);
+    delete seg;
+}
+
+static int32_t segment_upload(qmx_segment *s, const qmx_segment_desc *desc) {
+    const uint64_t src_stride = desc->row_stride_bytes ? desc->row_stride_bytes : s->row_bytes;
+    QMX_REQUIRE(src_stride >= s->row_bytes, QMX_ERR_BAD_ARG, "row_stride_bytes %llu < row size %llu",
+                (unsigned long long)src_stride, (unsigned long long)s->row_bytes);
+    const bool on_device = (desc->flags & QMX_SEG_DATA_ON_DEVICE) != 0;
+    if (s->dtype == QMX_DTYPE_SQ_U8) {
+        // split [f32 offset][codes] rows into a 16-byte aligned code block + an offset column
+        const uint32_t ad = s->sq.actual_dim;
+        s->row_stride = ad;
+        QMX_HIP(hipMalloc(&s->d_rows, (size_t)std::max<uint64_t>(1, s->n) * ad));
+        s->owns_rows = true;
+        QMX_HIP(hipMalloc((void **)&s->d_row_offsets, (size_t)std::max<uint64_t>(1, s->n) * sizeof(float)));
+        if (s->n == 0) return QMX_OK;
+        const void *d_src = desc->data;
+        DevBuf tmp;
+        if (!on_device && !is_device_ptr(desc->data)) {
+            QMX_TRY(tmp.reserve((size_t)s->n * src_stride));
+            hipError_t e = hipMemcpy(tmp.p, desc->data, (size_t)(s->n - 1) * src_stride + s->row_bytes, hipMemcpyHostToDevice);
+            if (e != hipSuccess) { tmp.release(); return hip_status(e, "hipMemcpy(SQ rows)", __FILE__, __LINE__); }
+            d_src = tmp.p;
+        }
+        int32_t rc = launch_sq_split(nullptr, d_src, src_stride, s->n, ad, s->d_rows, s->d_row_offsets);
+        if (rc == QMX_OK && hipDeviceSynchronize() != hipSuccess) rc = QMX_ERR_OTHER;
+        tmp.release();
+        return rc;
+    }
+    if (on_device) {
+        s->d_rows = const_cast<void *>(desc->data);
+        s->row_stride = src_stride;
+        s->owns_rows = false;
+        return QMX_OK;
+    }
+    // rows are re-packed at a 16-byte multiple so the 16-B lane loads stay aligned
+    s->row_stride = (s->row_bytes + 15) & ~15ull;
+    const size_t bytes = (size_t)std::max<uint64_t>(1, s->n) * s->row_stride;
+    QMX_HIP(hipMalloc(&s->d_rows, bytes));
+    s->owns_rows = true;
+    if (s->n) {
+        if (s->row_stride != s->row_bytes) QMX_HIP(hipMemset(s->d_rows, 0, bytes));
+        QMX_HIP(hipMemcpy2D(s->d_rows, s->row_stride, desc->data, src_stride, s->row_bytes, s->n, hipMemcpyDefault));
+    }
+    return QMX_OK;
+}
+
 int32_t qmx_segment_create(const qmx_segment_desc *desc, qmx_segment **out) {
     QMX_REQUIRE(desc && out, QMX_ERR_BAD_ARG, "NULL argument");
     *out = nullptr;
@@ -301,45 +355,30 @@ int32_t qmx_segment_create(const qmx_segment_desc *desc, qmx_segment **out) {
     s->flags = desc->flags;
     s->n = desc->n;
     s->scan_dim = desc->dim;
+    int32_t rc = QMX_OK;
     switch (desc->dtype) {
         case QMX_DTYPE_F32:
         case QMX_DTYPE_F16:
         case QMX_DTYPE_U8: s->row_bytes = (uint64_t)desc->dim * elem_bytes(desc->dtype); break;
-        default:
-            delete s;
-            set_error("dtype %u not built yet", desc->dtype);
-            return QMX_ERR_NOT_SUPPORTED;
-    }
-    const uint64_t src_stride = desc->row_stride_bytes ? desc->row_stride_bytes : s->row_bytes;
-    if (src_stride < s->row_bytes) {
-        delete s;
-        set_error("row_stride_bytes %llu < row size %llu", (unsigned long long)src_stride, (unsigned long long)s->row_bytes);
-        return QMX_ERR_BAD_ARG;
-    }
-    const bool on_device = (desc->flags & QMX_SEG_DATA_ON_DEVICE) != 0;
-    if (on_device) {
-        s->d_rows = const_cast<void *>(desc->data);
-        s->row_stride = src_stride;
-        s->owns_rows = false;
-    } else {
-        // rows are re-packed at a 16-byte multiple so the 16-B lane loads stay aligned
-        s->row_stride = (s->row_bytes + 15) & ~15ull;
-        const size_t bytes = (size_t)std::max<uint64_t>(1, s->n) * s->row_stride;
-        hipError_t e = hipMalloc(&s->d_rows, bytes);
-        if (e != hipSuccess) {
-            delete s;
-            return hip_status(e, "hipMalloc(segment rows)", __FILE__, __LINE__);
-        }
-        s->owns_rows = true;
-        if (s->n) {
-            if (s->row_stride != s->row_bytes) (void)hipMemset(s->d_rows, 0, bytes);
-            e = hipMemcpy2D(s->d_rows, s->row_stride, desc->data, src_stride, s->row_bytes, s->n, hipMemcpyDefault);
-            if (e != hipSuccess) {
-                (void)hipFree(s->d_rows);
-                delete s;
-                return hip_status(e, "hipMemcpy2D(segment rows)", __FILE__, __LINE__);
+        case QMX_DTYPE_SQ_U8:
+            if (!desc->sq) { set_error("SQ segment needs qmx_sq_params"); rc = QMX_ERR_BAD_ARG; break; }
+            s->sq = *desc->sq;
+            if (s->sq.actual_dim != ((desc->dim + 15) / 16) * 16) {   // get_actual_dim, encoded_vectors_u8.rs:622-624
+                set_error("actual_dim %u is not dim %u rounded up to 16", s->sq.actual_dim, desc->dim);
+                rc = QMX_ERR_BAD_ARG;
+                break;
             }
-        }
+            s->scan_dim = s->sq.actual_dim;
+            s->row_bytes = 4 + (uint64_t)s->sq.actual_dim;
+            break;
+        default:
+            set_error("dtype %u not built yet", desc->dtype);
+            rc = QMX_ERR_NOT_SUPPORTED;
+    }
+    if (rc == QMX_OK) rc = segment_upload(s, desc);
+    if (rc != QMX_OK) {
+        segment_free(s);
+        return rc;
     }
     *out = s;
     return QMX_OK;
@@ -348,11 +387,7 @@ int32_t qmx_segment_create(const qmx_segment_desc *desc, qmx_segment **out) {
 int32_t qmx_segment_destroy(qmx_segment *seg) {
     if (!seg) return QMX_OK;
     (void)hipSetDevice(seg->device);
-    if (seg->owns_rows && seg->d_rows) (void)hipFree(seg->d_rows);
-    if (seg->d_point_deleted) (void)hipFree(seg->d_point_deleted);
-    if (seg->d_vec_deleted) (void)hipFree(seg->d_vec_deleted);
-    if (seg->d_centroids) (void)hipFree(seg->d_centroids);
-    delete seg;
+    segment_free(seg);
     return QMX_OK;
 }
 
@@ -385,6 +420,15 @@ int32_t qmx_segment_row_bytes(const qmx_segment *seg, uint64_t *out) {
 int32_t qmx_segment_read_rows(const qmx_segment *seg, const uint32_t *ids, uint32_t n, void *out_rows) {
     QMX_REQUIRE(seg && (n == 0 || (ids && out_rows)), QMX_ERR_BAD_ARG, "NULL argument");
     QMX_HIP(hipSetDevice(seg->device));
+    if (seg->dtype == QMX_DTYPE_SQ_U8) {
+        for (uint32_t i = 0; i < n; ++i) {
+            QMX_REQUIRE(ids[i] < seg->n, QMX_ERR_OUT_OF_BOUNDS, "row %u out of range", ids[i]);
+            char *dst = (char *)out_rows + (size_t)i * seg->row_bytes;
+            QMX_HIP(hipMemcpy(dst, seg->d_row_offsets + ids[i], 4, hipMemcpyDefault));
+            QMX_HIP(hipMemcpy(dst + 4, (const char *)seg->d_rows + (size_t)ids[i] * seg->row_stride, seg->sq.actual_dim, hipMemcpyDefault));
+        }
+        return QMX_OK;
+    }
     for (uint32_t i = 0; i < n; ++i) {
         QMX_REQUIRE(ids[i] < seg->n, QMX_ERR_OUT_OF_BOUNDS, "row %u out of range", ids[i]);
         QMX_HIP(hipMemcpy((char *)out_rows + (size_t)i * seg->row_bytes,
@@ -515,6 +559,9 @@ static int32_t query_encode(qmx_query *q, const float *queries) {
     if (seg->dtype <= QMX_DTYPE_U8)
         return launch_pack_queries(q->stream, (int)seg->dtype, (int)seg->distance, d_f32, 0, seg->dim * 4, nq, seg->dim,
                                    q->d_queries, q->q_stride, q->aux_off);
+    if (seg->dtype == QMX_DTYPE_SQ_U8)   // EncodedVectorsU8::encode_query (encoded_vectors_u8.rs:583-619)
+        return launch_sq_encode(q->stream, (int)seg->distance, seg->sq, seg->dim, d_f32, nq, (uint8_t *)q->d_queries, q->q_stride,
+                                nullptr, nullptr, 1, q->aux_off);
     set_error("query encode for dtype %u not built yet", seg->dtype);
     return QMX_ERR_NOT_SUPPORTED;
 }
@@ -548,7 +595,9 @@ int32_t qmx_query_create_internal(const qmx_segment *seg, const uint32_t *point_
     QMX_REQUIRE(seg && out && (nq == 0 || point_ids), QMX_ERR_BAD_ARG, "NULL argument");
     *out = nullptr;
     QMX_HIP(hipSetDevice(seg->device));
-    QMX_REQUIRE(seg->dtype <= QMX_DTYPE_U8, QMX_ERR_NOT_SUPPORTED, "internal queries for dtype %u not built yet", seg->dtype);
+    QMX_REQUIRE(seg->dtype <= QMX_DTYPE_SQ_U8, QMX_ERR_NOT_SUPPORTED,
+                "dtype %u has no internal encoding (EncodedVectorsPQ::encode_internal_vector returns None): pass the original vector to qmx_query_create",
+                seg->dtype);
     qmx_query *q = nullptr;
     QMX_TRY(query_alloc(seg, nq, &q));
     int32_t rc = QMX_OK;
@@ -556,6 +605,15 @@ int32_t qmx_query_create_internal(const qmx_segment *seg, const uint32_t *point_
         if (nq == 0) break;
         const void *d_ids = nullptr;
         if ((rc = stage_in(q, q->ids, point_ids, (size_t)nq * 4, &d_ids)) != QMX_OK) break;
+        if (seg->dtype == QMX_DTYPE_SQ_U8) {   // encode_internal_vector (encoded_vectors_u8.rs:715-728)
+            float shift = (seg->distance == QMX_DISTANCE_DOT || seg->distance == QMX_DISTANCE_COSINE)
+                              ? (float)seg->sq.actual_dim * seg->sq.offset * seg->sq.offset : 0.0f;
+            if (seg->sq.invert) shift = -shift;
+            if ((rc = launch_sq_internal_query(q->stream, seg->d_rows, seg->d_row_offsets, seg->sq.actual_dim, (const uint32_t *)d_ids,
+                                               nq, seg->n, shift, q->d_queries, q->q_stride, q->aux_off, q->d_err)) != QMX_OK) break;
+            if ((rc = check_err_flag(q)) != QMX_OK) break;
+            break;
+        }
         // the stored row IS the query (already preprocessed at insert): FilteredScorer::new_internal
         if ((rc = q->misc.reserve((size_t)nq * seg->row_bytes)) != QMX_OK) break;
         if ((rc = launch_gather_rows(q->stream, seg->d_rows, seg->row_stride, seg->row_bytes, (const uint32_t *)d_ids, nq,
@@ -630,10 +688,14 @@ int32_t qmx_query_read_encoded(const qmx_query *q, uint32_t query_index, void *o
     QMX_REQUIRE(q && out, QMX_ERR_BAD_ARG, "NULL argument");
     QMX_REQUIRE(query_index < q->nq, QMX_ERR_OUT_OF_BOUNDS, "query index %u >= %u", query_index, q->nq);
     QMX_HIP(hipSetDevice(q->seg->device));
-    const uint64_t bytes = (uint64_t)q->seg->scan_dim * elem_bytes(q->seg->dtype);
+    const bool sq = q->seg->dtype == QMX_DTYPE_SQ_U8;
+    const uint64_t ebytes = (uint64_t)q->seg->scan_dim * elem_bytes(q->seg->dtype);
+    const uint64_t bytes = ebytes + (sq ? 4 : 0);
     QMX_REQUIRE(out_bytes >= bytes, QMX_ERR_BAD_ARG, "buffer too small: need %llu", (unsigned long long)bytes);
     QMX_HIP(hipStreamSynchronize(q->stream));
-    QMX_HIP(hipMemcpy(out, (const char *)q->d_queries + (size_t)query_index * q->q_stride, bytes, hipMemcpyDefault));
+    const char *entry = (const char *)q->d_queries + (size_t)query_index * q->q_stride;
+    if (sq) QMX_HIP(hipMemcpy(out, entry + q->aux_off, 4, hipMemcpyDefault));   // EncodedQueryU8{offset, encoded_query}
+    QMX_HIP(hipMemcpy((char *)out + (sq ? 4 : 0), entry, ebytes, hipMemcpyDefault));
     if (written) *written = bytes;
     return QMX_OK;
 }
@@ -664,6 +726,7 @@ static void fill_args(const qmx_query *q, uint32_t tile0, uint32_t nq_tile, Scan
     a.err_flag = q->d_err;
     a.flags = s->flags;
     a.sq_multiplier = s->sq.multiplier;
+    a.row_offsets = s->d_row_offsets;
     a.pq_m = s->pq_m;
     a.pq_ncent = s->pq.n_centroids;
 }
@@ -676,6 +739,7 @@ static int32_t launch_scan(const qmx_query *q, int qt, ScanMode mode, const Scan
                     "let qmx_segment_create upload it instead", s->dtype, s->dim, (unsigned long long)s->row_stride);
         return launch_scan_dense(q->stream, (int)s->dtype, (int)s->distance, qt, mode, a, s->num_cus, grid);
     }
+    if (s->dtype == QMX_DTYPE_SQ_U8) return launch_scan_sq(q->stream, (int)s->distance, qt, mode, a, s->num_cus, grid);
     set_error("dtype %u not built yet", s->dtype);
     return QMX_ERR_NOT_SUPPORTED;
 }
@@ -824,14 +888,6 @@ int32_t qmx_search_topk_async(qmx_query *q, uint32_t top, const uint32_t *ids, u
     return search_enqueue(q, top, ids, n_ids, out_dev, out_counts_dev, nullptr, nullptr, timed);
 }
 
-int32_t qmx_rescore(qmx_query *q, const uint32_t *ids, const uint32_t *counts, uint32_t n_per_query, uint32_t top,
-                    qmx_scored_point *out, uint32_t *out_counts) {
-    QMX_REQUIRE(q && ids && out && out_counts, QMX_ERR_BAD_ARG, "NULL argument");
-    QMX_REQUIRE(top >= 1 && top <= MAX_TOP_FAST, QMX_ERR_NOT_SUPPORTED, "top %u not in 1..%d", top, MAX_TOP_FAST);
-    set_error("qmx_rescore not built yet");
-    return QMX_ERR_NOT_SUPPORTED;
-}
-
 int32_t qmx_merge_topk(int32_t device_id, const qmx_scored_point *lists, const uint32_t *list_counts, uint32_t n_lists,
                        uint32_t nq, uint32_t k, qmx_scored_point *out, uint32_t *out_counts) {
     QMX_REQUIRE(lists && out && out_counts, QMX_ERR_BAD_ARG, "NULL argument");
@@ -881,23 +937,224 @@ int32_t qmx_merge_topk_async(int32_t device_id, void *hip_stream, const qmx_scor
                                out_dev, out_counts_dev);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// pair scoring (ragged score_points, rescoring, score_internal)
+// ---------------------------------------------------------------------------------------------
+static int32_t score_pairs_device(qmx_query *q, const PairSel &sel, const uint32_t *d_ids, uint64_t n_items, float *d_scores,
+                                  bool timed) {
+    const qmx_segment *s = q->seg;
+    ScanArgs a;
+    fill_args(q, 0, q->nq, a);
+    a.ids = d_ids;
+    a.n_cand = n_items;
+    a.scores = d_scores;
+    size_t slot = 0;
+    if (timed) QMX_TRY(timing_begin(q, &slot));
+    int32_t rc;
+    if (s->dtype <= QMX_DTYPE_U8) {
+        QMX_REQUIRE(s->fast_layout(), QMX_ERR_NOT_SUPPORTED, "adopted device block is not 16-byte aligned");
+        rc = launch_pairs_dense(q->stream, (int)s->dtype, (int)s->distance, a, sel, n_items, s->num_cus);
+    } else if (s->dtype == QMX_DTYPE_SQ_U8) {
+        rc = launch_pairs_sq(q->stream, (int)s->distance, a, sel, n_items, s->num_cus);
+    } else {
+        set_error("dtype %u not built yet", s->dtype);
+        rc = QMX_ERR_NOT_SUPPORTED;
+    }
+    if (timed && rc == QMX_OK) QMX_TRY(timing_end(q, slot));
+    return rc;
+}
+
+int32_t qmx_score_points_ragged(qmx_query *q, const uint32_t *ids, const uint32_t *offsets, float *scores, qmx_counters *counters) {
+    QMX_REQUIRE(q && offsets, QMX_ERR_BAD_ARG, "NULL argument");
+    QMX_HIP(hipSetDevice(q->device));
+    if (counters) memset(counters, 0, sizeof(*counters));
+    if (q->nq == 0) return QMX_OK;
+    std::vector<uint32_t> off(q->nq + 1);
+    QMX_HIP(hipMemcpy(off.data(), offsets, off.size() * 4, hipMemcpyDefault));
+    const uint64_t total = off[q->nq];
+    if (total == 0) return QMX_OK;
+    QMX_REQUIRE(ids && scores, QMX_ERR_BAD_ARG, "NULL argument");
+    std::vector<uint32_t> qsel(total);
+    for (uint32_t qi = 0; qi < q->nq; ++qi) {
+        QMX_REQUIRE(off[qi] <= off[qi + 1] && off[qi + 1] <= total, QMX_ERR_BAD_ARG, "offsets must be non-decreasing");
+        for (uint32_t j = off[qi]; j < off[qi + 1]; ++j) qsel[j] = qi;
+    }
+    const void *d_ids = nullptr;
+    QMX_TRY(stage_in(q, q->ids, ids, (size_t)total * 4, &d_ids));
+    QMX_TRY(q->misc.reserve((size_t)total * 4));
+    QMX_HIP(hipMemcpyAsync(q->misc.p, qsel.data(), (size_t)total * 4, hipMemcpyHostToDevice, q->stream));
+    const bool out_dev = is_device_ptr(scores);
+    float *d_scores = scores;
+    if (!out_dev) {
+        QMX_TRY(q->scores.reserve((size_t)total * 4));
+        d_scores = (float *)q->scores.p;
+    }
+    PairSel sel{(const uint32_t *)q->misc.p, 0, nullptr};
+    const bool timed = q->timing;
+    QMX_TRY(score_pairs_device(q, sel, (const uint32_t *)d_ids, total, d_scores, timed));
+    if (!out_dev) QMX_HIP(hipMemcpyAsync(scores, d_scores, (size_t)total * 4, hipMemcpyDeviceToHost, q->stream));
+    QMX_TRY(check_err_flag(q));   // synchronises: qsel / staged ids may go away
+    if (counters) {
+        counters->vectors_scored = total;
+        counters->bytes_read = total * q->seg->row_bytes;
+        counters->kernel_launches = 1;
+        if (timed) { const float before = q->timing_ms; QMX_TRY(timing_fold(q)); counters->kernel_ms = q->timing_ms - before; }
+    }
+    return QMX_OK;
+}
+
+int32_t qmx_rescore(qmx_query *q, const uint32_t *ids, const uint32_t *counts, uint32_t n_per_query, uint32_t top,
+                    qmx_scored_point *out, uint32_t *out_counts) {
+    QMX_REQUIRE(q && ids && out && out_counts, QMX_ERR_BAD_ARG, "NULL argument");
+    QMX_REQUIRE(top >= 1 && top <= MAX_TOP_FAST, QMX_ERR_NOT_SUPPORTED, "top %u not in 1..%d", top, MAX_TOP_FAST);
+    QMX_HIP(hipSetDevice(q->device));
+    if (q->nq == 0) return QMX_OK;
+    if (n_per_query == 0) {
+        for (uint32_t i = 0; i < q->nq; ++i) out_counts[i] = 0;
+        return QMX_OK;
+    }
+    const uint64_t total = (uint64_t)q->nq * n_per_query;
+    const void *d_ids = nullptr, *d_counts = nullptr;
+    QMX_TRY(stage_in(q, q->ids, ids, (size_t)total * 4, &d_ids));
+    QMX_TRY(stage_in(q, q->misc, counts, counts ? (size_t)q->nq * 4 : 0, &d_counts));
+    QMX_TRY(q->scores.reserve((size_t)total * 4));
+    PairSel sel{nullptr, n_per_query, (const uint32_t *)d_counts};
+    QMX_TRY(score_pairs_device(q, sel, (const uint32_t *)d_ids, total, (float *)q->scores.p, false));
+    const bool out_dev = is_device_ptr(out), cnt_dev = is_device_ptr(out_counts);
+    qmx_scored_point *d_out = out;
+    uint32_t *d_oc = out_counts;
+    if (!out_dev) { QMX_TRY(q->out.reserve((size_t)q->nq * top * sizeof(qmx_scored_point))); d_out = (qmx_scored_point *)q->out.p; }
+    if (!cnt_dev) { QMX_TRY(q->counts.reserve((size_t)q->nq * 4)); d_oc = (uint32_t *)q->counts.p; }
+    // sort descending, truncate to top (vector_index_search_common.rs:85-88)
+    QMX_TRY(launch_sort_scored(q->stream, (const float *)q->scores.p, (const uint32_t *)d_ids, (const uint32_t *)d_counts, n_per_query,
+                               q->nq, top, d_out, d_oc));
+    if (!out_dev) QMX_TRY(copy_out(q->stream, out, d_out, (size_t)q->nq * top * sizeof(qmx_scored_point)));
+    if (!cnt_dev) QMX_TRY(copy_out(q->stream, out_counts, d_oc, (size_t)q->nq * 4));
+    return check_err_flag(q);
+}
+
+int32_t qmx_score_internal(const qmx_segment *seg, const uint32_t *a_ids, const uint32_t *b_ids, uint32_t n, float *out) {
+    QMX_REQUIRE(seg && (n == 0 || (a_ids && b_ids && out)), QMX_ERR_BAD_ARG, "NULL argument");
+    if (n == 0) return QMX_OK;
+    // query i = stored point a[i] (FilteredScorer::new_internal), then the diagonal pairs (i, b[i])
+    qmx_query *q = nullptr;
+    QMX_TRY(qmx_query_create_internal(seg, a_ids, n, &q));
+    int32_t rc = QMX_OK;
+    do {
+        const void *d_ids = nullptr;
+        if ((rc = stage_in(q, q->ids, b_ids, (size_t)n * 4, &d_ids)) != QMX_OK) break;
+        const bool out_dev = is_device_ptr(out);
+        float *d_scores = out;
+        if (!out_dev) {
+            if ((rc = q->scores.reserve((size_t)n * 4)) != QMX_OK) break;
+            d_scores = (float *)q->scores.p;
+        }
+        PairSel sel{nullptr, 0, nullptr};
+        if ((rc = score_pairs_device(q, sel, (const uint32_t *)d_ids, n, d_scores, false)) != QMX_OK) break;
+        if (!out_dev) {
+            hipError_t e = hipMemcpyAsync(out, d_scores, (size_t)n * 4, hipMemcpyDeviceToHost, q->stream);
+            if (e != hipSuccess) { rc = hip_status(e, "copy scores", __FILE__, __LINE__); break; }
+        }
+        rc = check_err_flag(q);
+    } while (0);
+    qmx_query_destroy(q);
+    return rc;
+}
+
+int32_t qmx_score_bytes(qmx_query *q, const void *rows, uint32_t n, uint64_t stride_bytes, float *scores) {
+    QMX_REQUIRE(q && (n == 0 || (rows && scores)), QMX_ERR_BAD_ARG, "NULL argument");
+    QMX_HIP(hipSetDevice(q->device));
+    if (n == 0 || q->nq == 0) return QMX_OK;
+    const qmx_segment *s = q->seg;
+    // a transient block in the segment's own device layout (aligned rows / SQ split), scored by the scan kernel
+    qmx_segment_desc d;
+    memset(&d, 0, sizeof(d));
+    d.dtype = s->dtype;
+    d.distance = s->distance;
+    d.dim = s->dim;
+    d.flags = s->flags & ~QMX_SEG_DATA_ON_DEVICE;
+    d.n = n;
+    d.row_stride_bytes = stride_bytes;
+    d.data = rows;
+    d.device_id = s->device;
+    d.sq = &s->sq;
+    qmx_pq_params pq = s->pq;
+    pq.centroids = s->d_centroids;
+    d.pq = &pq;
+    qmx_segment *tmp = nullptr;
+    QMX_TRY(qmx_segment_create(&d, &tmp));
+    int32_t rc = QMX_OK;
+    do {
+        const size_t sbytes = (size_t)q->nq * n * sizeof(float);
+        const bool out_dev = is_device_ptr(scores);
+        float *d_scores = scores;
+        if (!out_dev) {
+            if ((rc = q->scores.reserve(sbytes)) != QMX_OK) break;
+            d_scores = (float *)q->scores.p;
+        }
+        for (uint32_t tile0 = 0; tile0 < q->nq && rc == QMX_OK; tile0 += MAX_QT) {
+            const uint32_t nq_tile = std::min<uint32_t>(MAX_QT, q->nq - tile0);
+            ScanArgs a;
+            fill_args(q, tile0, nq_tile, a);
+            a.rows = tmp->d_rows;
+            a.n_rows = n;
+            a.row_stride = tmp->row_stride;
+            a.row_offsets = tmp->d_row_offsets;
+            a.del = tmp->deleted_view();
+            a.n_cand = n;
+            a.top = 1;
+            a.scores = d_scores + (size_t)tile0 * n;
+            a.scores_stride = n;
+            uint32_t grid = 0;
+            rc = launch_scan(q, (int)pow2_ceil(nq_tile), SCAN_SCORES, a, &grid);
+        }
+        if (rc != QMX_OK) break;
+        if (!out_dev) {
+            hipError_t e = hipMemcpyAsync(scores, d_scores, sbytes, hipMemcpyDeviceToHost, q->stream);
+            if (e != hipSuccess) { rc = hip_status(e, "copy scores", __FILE__, __LINE__); break; }
+        }
+        rc = check_err_flag(q);
+    } while (0);
+    (void)hipStreamSynchronize(q->stream);
+    qmx_segment_destroy(tmp);
+    return rc;
+}
+
+int32_t qmx_sq_encode(int32_t device_id, uint32_t distance, const qmx_sq_params *params, const float *in, uint64_t n,
+                      uint32_t dim, void *out_rows) {
+    QMX_REQUIRE(params && (n == 0 || (in && out_rows)) && dim > 0, QMX_ERR_BAD_ARG, "bad argument");
+    QMX_REQUIRE(distance <= QMX_DISTANCE_MANHATTAN, QMX_ERR_BAD_ARG, "bad distance");
+    QMX_REQUIRE(params->actual_dim == ((dim + 15) / 16) * 16, QMX_ERR_BAD_ARG, "actual_dim must be dim rounded up to 16");
+    QMX_REQUIRE(params->alpha != 0.0f, QMX_ERR_BAD_ARG, "alpha must be non-zero");
+    QMX_TRY(check_device(device_id, nullptr));
+    if (n == 0) return QMX_OK;
+    const size_t in_bytes = (size_t)n * dim * 4, out_bytes = (size_t)n * (4 + (size_t)params->actual_dim);
+    DevBuf bin, bout;
+    const float *d_in = in;
+    void *d_out = out_rows;
+    int32_t rc = QMX_OK;
+    do {
+        if (!is_device_ptr(in)) {
+            if ((rc = bin.reserve(in_bytes)) != QMX_OK) break;
+            if (hipMemcpy(bin.p, in, in_bytes, hipMemcpyHostToDevice) != hipSuccess) { rc = QMX_ERR_OTHER; break; }
+            d_in = (const float *)bin.p;
+        }
+        const bool out_dev = is_device_ptr(out_rows);
+        if (!out_dev) {
+            if ((rc = bout.reserve(out_bytes)) != QMX_OK) break;
+            d_out = bout.p;
+        }
+        if ((rc = launch_sq_encode(nullptr, (int)distance, *params, dim, d_in, n, nullptr, 0, nullptr, (uint8_t *)d_out, 0, 0)) != QMX_OK) break;
+        if (!out_dev && hipMemcpy(out_rows, d_out, out_bytes, hipMemcpyDeviceToHost) != hipSuccess) { rc = QMX_ERR_OTHER; break; }
+        if (hipDeviceSynchronize() != hipSuccess) rc = QMX_ERR_OTHER;
+    } while (0);
+    bin.release();
+    bout.release();
+    return rc;
+}
+
 // ---- not built yet -----------------------------------------------------------------------------
-int32_t qmx_score_points_ragged(qmx_query *, const uint32_t *, const uint32_t *, float *, qmx_counters *) {
-    set_error("qmx_score_points_ragged not built yet");
-    return QMX_ERR_NOT_SUPPORTED;
-}
-int32_t qmx_score_internal(const qmx_segment *, const uint32_t *, const uint32_t *, uint32_t, float *) {
-    set_error("qmx_score_internal not built yet");
-    return QMX_ERR_NOT_SUPPORTED;
-}
-int32_t qmx_score_bytes(qmx_query *, const void *, uint32_t, uint64_t, float *) {
-    set_error("qmx_score_bytes not built yet");
-    return QMX_ERR_NOT_SUPPORTED;
-}
-int32_t qmx_sq_encode(int32_t, uint32_t, const qmx_sq_params *, const float *, uint64_t, uint32_t, void *) {
-    set_error("qmx_sq_encode not built yet");
-    return QMX_ERR_NOT_SUPPORTED;
-}
 int32_t qmx_pq_encode(int32_t, const qmx_pq_params *, const float *, uint64_t, uint32_t, uint8_t *) {
     set_error("qmx_pq_encode not built yet");
     return QMX_ERR_NOT_SUPPORTED;

@@ -51,9 +51,39 @@ constexpr uint32_t QUERY_AUX_BYTES = 64;
 // dense f32 / f16 / u8 (scan_dense.hip)
 int32_t launch_scan_dense(hipStream_t st, int dtype, int distance, int qt, ScanMode mode,
                           const ScanArgs &a, int num_cus, uint32_t *grid_out);
+// which query an item belongs to: explicit list, or fixed-size slots (item / per_query, with the
+// live prefix of each slot given by counts), or item == query (score_internal)
+struct PairSel {
+    const uint32_t *qsel;      // explicit query index per item, or nullptr
+    uint32_t per_query;        // > 0: query = item / per_query
+    const uint32_t *counts;    // with per_query: only the first counts[query] items of a slot are live
+    __device__ __forceinline__ uint32_t query_of(uint64_t item) const {
+        if (qsel) return qsel[item];
+        if (per_query) return (uint32_t)(item / per_query);
+        return (uint32_t)item;
+    }
+    __device__ __forceinline__ bool live(uint64_t item, uint32_t qi) const {
+        if (per_query && counts) return (uint32_t)(item % per_query) < counts[qi];
+        return true;
+    }
+};
+
+int32_t launch_pairs_dense(hipStream_t st, int dtype, int distance, const ScanArgs &a, const PairSel &sel,
+                           uint64_t n_items, int num_cus);
+int32_t launch_pairs_sq(hipStream_t st, int distance, const ScanArgs &a, const PairSel &sel, uint64_t n_items, int num_cus);
 // SQ int8 rows: codes SoA + offsets (scan_quant.hip)
 int32_t launch_scan_sq(hipStream_t st, int distance, int qt, ScanMode mode, const ScanArgs &a, int num_cus,
                        uint32_t *grid_out);
+int32_t launch_sq_encode(hipStream_t st, int distance, const qmx_sq_params &sp, uint32_t dim, const float *in, uint64_t n,
+                         uint8_t *codes_out, uint64_t codes_stride, float *offsets_out, uint8_t *rows_out, int is_query,
+                         uint32_t aux_off);
+int32_t launch_sq_split(hipStream_t st, const void *rows, uint64_t row_stride, uint64_t n, uint32_t actual_dim, void *codes,
+                        float *offsets);
+int32_t launch_sq_gather_rows(hipStream_t st, const void *codes, const float *offsets, uint32_t actual_dim, const uint32_t *ids,
+                              uint32_t n, uint64_t n_rows, void *rows_out, int *err_flag);
+int32_t launch_sq_internal_query(hipStream_t st, const void *codes, const float *offsets, uint32_t actual_dim, const uint32_t *ids,
+                                 uint32_t nq, uint64_t n_rows, float shift, void *tile, uint32_t q_stride, uint32_t aux_off,
+                                 int *err_flag);
 // query tile packing: preprocessed f32 queries -> element type, padded, + aux (preprocess.hip)
 int32_t launch_pack_queries(hipStream_t st, int dtype, int distance, const void *src, int src_is_encoded,
                             uint32_t src_stride, uint32_t nq, uint32_t dim, void *tile, uint32_t q_stride, uint32_t aux_off);

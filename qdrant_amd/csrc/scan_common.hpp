@@ -357,4 +357,114 @@ int32_t launch_small(hipStream_t st, ScanMode mode, const ScanArgs &a, int num_c
                : launch_small_inst<S, false, SCAN_SCORES>(st, a, num_cus, grid);
 }
 
+// ------------------------------------------------------------------------------------------
+// Pair scoring: item j = (query qsel[j], stored row ids[j]) -> scores[j].  Serves the ragged
+// RawScorer::score_points of HNSW hops batched across searches (graph_layers.rs:125-139,305-313),
+// the rescoring pass (vector_index_search_common.rs:73-90) and score_internal.  One 8-lane group
+// per item with the same lane policies as the scan (so the same bits); the query piece comes
+// from the query tile in HBM/L2 instead of LDS.
+// ------------------------------------------------------------------------------------------
+constexpr int PAIR_BLOCK = 256;
+
+template <class P>
+__global__ __launch_bounds__(PAIR_BLOCK) void pair_kernel(const ScanArgs a, const PairSel sel, uint64_t n_items) {
+    constexpr int NW = PAIR_BLOCK / WAVE;
+    constexpr int NRA = P::NRAUX > 0 ? P::NRAUX : 1;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int t = lane & 7, g = lane >> 3;
+    const int piece = lane_piece(t);
+    const int piece_off = piece * 16;
+    const bool piece_in_rem = piece < (int)a.rem_pieces;
+    const unsigned char *rows = reinterpret_cast<const unsigned char *>(a.rows);
+    const unsigned char *queries = reinterpret_cast<const unsigned char *>(a.queries);
+    for (uint64_t base = ((uint64_t)blockIdx.x * NW + wave) * 8; base < n_items; base += (uint64_t)gridDim.x * NW * 8) {
+        const uint64_t item = base + g;
+        bool valid = item < n_items;
+        uint32_t qi = valid ? sel.query_of(item) : 0;
+        valid = valid && sel.live(item, qi);
+        uint32_t id = valid ? a.ids[item] : 0;
+        if (valid && (id >= a.n_rows || qi >= a.nq)) {
+            *a.err_flag = 1;
+            valid = false;
+            id = 0;
+            qi = 0;
+        }
+        const unsigned char *qp = queries + (uint64_t)qi * a.q_stride;
+        const unsigned char *rp = rows + (uint64_t)id * a.row_stride + piece_off;
+        typename P::acc_t acc[1][1][P::NACC];
+        typename P::acc_t raux[1][NRA];
+#pragma unroll
+        for (int k = 0; k < P::NACC; ++k) acc[0][0][k] = 0;
+#pragma unroll
+        for (int k = 0; k < NRA; ++k) raux[0][k] = 0;
+#pragma unroll 4
+        for (uint32_t s = 0; s < a.nseg; ++s) {
+            uint4 v[1];
+            v[0] = *reinterpret_cast<const uint4 *>(rp + (uint64_t)s * 128);
+            scan_step<P, 1, 1>(acc, raux, v, qp + s * 128 + piece_off, 0, true);
+        }
+        if (a.rem_pieces) {
+            uint4 v[1];
+            v[0] = make_uint4(0, 0, 0, 0);
+            if (piece_in_rem) v[0] = *reinterpret_cast<const uint4 *>(rp + (uint64_t)a.nseg * 128);
+            scan_step<P, 1, 1>(acc, raux, v, qp + a.nseg * 128 + piece_off, 0, piece_in_rem);
+        }
+        const float score = P::finish(acc[0][0], raux[0], qp, rows + (uint64_t)id * a.row_stride, id, a);
+        if (valid && t == 0) a.scores[item] = score;
+    }
+}
+
+template <class S>
+__global__ __launch_bounds__(PAIR_BLOCK) void pair_small_kernel(const ScanArgs a, const PairSel sel, uint64_t n_items) {
+    const unsigned char *rows = reinterpret_cast<const unsigned char *>(a.rows);
+    const unsigned char *queries = reinterpret_cast<const unsigned char *>(a.queries);
+    for (uint64_t item = (uint64_t)blockIdx.x * PAIR_BLOCK + threadIdx.x; item < n_items; item += (uint64_t)gridDim.x * PAIR_BLOCK) {
+        const uint32_t qi = sel.query_of(item);
+        if (!sel.live(item, qi)) continue;
+        const uint32_t id = a.ids[item];
+        if (id >= a.n_rows || qi >= a.nq) {
+            *a.err_flag = 1;
+            continue;
+        }
+        a.scores[item] = S::score(queries + (uint64_t)qi * a.q_stride, rows + (uint64_t)id * a.row_stride, id, a);
+    }
+}
+
+// Launch functors handed to the per-dtype dispatchers: one switch over (dtype, distance) serves the
+// tiled scan and the pair kernel.
+struct ScanLauncher {
+    hipStream_t st;
+    int qt;
+    ScanMode mode;
+    int num_cus;
+    uint32_t *grid;
+    template <class P> int32_t row(const ScanArgs &a) const { return launch_policy<P>(st, qt, mode, a, num_cus, grid); }
+    template <class S> int32_t small(const ScanArgs &a) const { return launch_small<S>(st, mode, a, num_cus, grid); }
+};
+struct PairLauncher {
+    hipStream_t st;
+    PairSel sel;
+    uint64_t n_items;
+    int num_cus;
+    template <class P> int32_t row(const ScanArgs &a) const {
+        if (n_items == 0) return QMX_OK;
+        uint64_t want = (n_items + 31) / 32;
+        uint32_t grid = (uint32_t)(want < (uint64_t)num_cus * 8 ? want : (uint64_t)num_cus * 8);
+        ::qmx::clear_stale_error();
+        hipLaunchKernelGGL((pair_kernel<P>), dim3(grid), dim3(PAIR_BLOCK), 0, st, a, sel, n_items);
+        QMX_HIP(hipGetLastError());
+        return QMX_OK;
+    }
+    template <class S> int32_t small(const ScanArgs &a) const {
+        if (n_items == 0) return QMX_OK;
+        uint64_t want = (n_items + PAIR_BLOCK - 1) / PAIR_BLOCK;
+        uint32_t grid = (uint32_t)(want < (uint64_t)num_cus * 8 ? want : (uint64_t)num_cus * 8);
+        ::qmx::clear_stale_error();
+        hipLaunchKernelGGL((pair_small_kernel<S>), dim3(grid), dim3(PAIR_BLOCK), 0, st, a, sel, n_items);
+        QMX_HIP(hipGetLastError());
+        return QMX_OK;
+    }
+};
+
 }  // namespace qmx

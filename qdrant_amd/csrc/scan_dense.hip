@@ -318,39 +318,40 @@ struct SmallU8 {
 // ------------------------------------------------------------------------------------------
 // dispatch
 // ------------------------------------------------------------------------------------------
-template <template <int> class Row, template <int> class Small, bool COSINE_IS_DOT>
-static int32_t dispatch_metric(hipStream_t st, int distance, int qt, ScanMode mode, const ScanArgs &a, int num_cus,
-                               uint32_t *grid) {
+template <template <int> class Row, template <int> class Small, bool COSINE_IS_DOT, class L>
+static int32_t dispatch_metric(const L &l, int distance, const ScanArgs &a) {
     const bool small = a.dim < 32;
     switch (distance) {
         case QMX_DISTANCE_COSINE:
             if constexpr (!COSINE_IS_DOT)
-                return small ? launch_small<Small<M_COSINE>>(st, mode, a, num_cus, grid)
-                             : launch_policy<Row<M_COSINE>>(st, qt, mode, a, num_cus, grid);
+                return small ? l.template small<Small<M_COSINE>>(a) : l.template row<Row<M_COSINE>>(a);
             // CosineMetric::similarity == DotProductMetric::similarity on normalised vectors (simple.rs:174-176)
-        case QMX_DISTANCE_DOT:
-            return small ? launch_small<Small<M_DOT>>(st, mode, a, num_cus, grid)
-                         : launch_policy<Row<M_DOT>>(st, qt, mode, a, num_cus, grid);
-        case QMX_DISTANCE_EUCLID:
-            return small ? launch_small<Small<M_EUCLID>>(st, mode, a, num_cus, grid)
-                         : launch_policy<Row<M_EUCLID>>(st, qt, mode, a, num_cus, grid);
-        case QMX_DISTANCE_MANHATTAN:
-            return small ? launch_small<Small<M_MANHATTAN>>(st, mode, a, num_cus, grid)
-                         : launch_policy<Row<M_MANHATTAN>>(st, qt, mode, a, num_cus, grid);
+        case QMX_DISTANCE_DOT: return small ? l.template small<Small<M_DOT>>(a) : l.template row<Row<M_DOT>>(a);
+        case QMX_DISTANCE_EUCLID: return small ? l.template small<Small<M_EUCLID>>(a) : l.template row<Row<M_EUCLID>>(a);
+        case QMX_DISTANCE_MANHATTAN: return small ? l.template small<Small<M_MANHATTAN>>(a) : l.template row<Row<M_MANHATTAN>>(a);
     }
     set_error("bad distance %d", distance);
     return QMX_ERR_BAD_ARG;
 }
 
-int32_t launch_scan_dense(hipStream_t st, int dtype, int distance, int qt, ScanMode mode,
-                          const ScanArgs &a, int num_cus, uint32_t *grid_out) {
+template <class L>
+static int32_t dispatch_dense(const L &l, int dtype, int distance, const ScanArgs &a) {
     switch (dtype) {
-        case QMX_DTYPE_F32: return dispatch_metric<RowF32, SmallF32, true>(st, distance, qt, mode, a, num_cus, grid_out);
-        case QMX_DTYPE_F16: return dispatch_metric<RowF16, SmallF16, true>(st, distance, qt, mode, a, num_cus, grid_out);
-        case QMX_DTYPE_U8: return dispatch_metric<RowU8, SmallU8, false>(st, distance, qt, mode, a, num_cus, grid_out);
+        case QMX_DTYPE_F32: return dispatch_metric<RowF32, SmallF32, true>(l, distance, a);
+        case QMX_DTYPE_F16: return dispatch_metric<RowF16, SmallF16, true>(l, distance, a);
+        case QMX_DTYPE_U8: return dispatch_metric<RowU8, SmallU8, false>(l, distance, a);
     }
     set_error("scan: dtype %d / distance %d not supported", dtype, distance);
     return QMX_ERR_NOT_SUPPORTED;
+}
+
+int32_t launch_scan_dense(hipStream_t st, int dtype, int distance, int qt, ScanMode mode,
+                          const ScanArgs &a, int num_cus, uint32_t *grid_out) {
+    return dispatch_dense(ScanLauncher{st, qt, mode, num_cus, grid_out}, dtype, distance, a);
+}
+int32_t launch_pairs_dense(hipStream_t st, int dtype, int distance, const ScanArgs &a, const PairSel &sel,
+                           uint64_t n_items, int num_cus) {
+    return dispatch_dense(PairLauncher{st, sel, n_items, num_cus}, dtype, distance, a);
 }
 
 }  // namespace qmx

@@ -112,6 +112,91 @@ class VectorStorage:
             pass
 
 
+class ScalarQuantizer:
+    """`MetadataInt8` + `VectorParameters` of `EncodedVectorsU8` (lib/quantization/src/encoded_vectors_u8.rs:84-91):
+    the GIVEN (alpha, offset) — parity is defined on given parameters because the reference's quantile
+    estimate samples randomly (quantile.rs:35-82)."""
+
+    def __init__(self, dim: int, distance: Distance, alpha: float, offset: float):
+        self.dim = int(dim)
+        self.distance = Distance(distance)
+        self.alpha = np.float32(alpha)
+        self.offset = np.float32(offset)
+        self.actual_dim = (self.dim + 15) // 16 * 16                       # get_actual_dim :622-624
+        # invert: Euclid / Manhattan (vector_storage/quantized/quantized_vectors.rs:232)
+        self.invert = self.distance in (Distance.Euclid, Distance.Manhattan)
+        a = self.alpha
+        if self.distance in (Distance.Dot, Distance.Cosine):
+            m = a * a                                                      # :205-221
+        elif self.distance == Distance.Manhattan:
+            m = a
+        else:
+            m = np.float32(-2.0) * a * a
+        self.multiplier = np.float32(-m if self.invert else m)
+
+    @classmethod
+    def from_min_max(cls, data, dim: int, distance: Distance):
+        """quantile = None: alpha_offset_from_min_max over the whole data (:523-533), deterministic."""
+        d = np.asarray(data, dtype=np.float32)
+        mn, mx = np.float32(d.min()), np.float32(d.max())
+        return cls(dim, distance, (mx - mn) / np.float32(127.0), mn)
+
+    def params(self) -> "F.SqParams":
+        p = F.SqParams()
+        p.actual_dim = self.actual_dim
+        p.alpha = float(self.alpha)
+        p.offset = float(self.offset)
+        p.multiplier = float(self.multiplier)
+        p.invert = 1 if self.invert else 0
+        return p
+
+    def quantized_vector_size(self) -> int:
+        return self.actual_dim + 4
+
+    def encode(self, vectors, device_id: int = 0) -> np.ndarray:
+        """`EncodedVectorsU8::encode` row loop (:236-296) on device: [n, dim] f32 -> [n, 4 + actual_dim] u8 rows."""
+        v = np.ascontiguousarray(vectors, dtype=np.float32)
+        out = np.empty((v.shape[0], self.quantized_vector_size()), dtype=np.uint8)
+        p = self.params()
+        F.check(F.lib().qmx_sq_encode(device_id, int(self.distance), C.byref(p), F.ptr(v), v.shape[0], self.dim, F.ptr(out)))
+        return out
+
+
+class EncodedVectorsU8(VectorStorage):
+    """Device-resident `EncodedVectorsU8` storage = what `QuantizedVectors::raw_scorer` scores against
+    (vector_storage/quantized/quantized_vectors.rs:65-81).  `rows`: [n, 4 + actual_dim] u8 in the reference
+    layout `[f32 vector_offset][codes]`."""
+
+    def __init__(self, rows, quantizer: ScalarQuantizer, device_id: int = 0):
+        self._h = C.c_void_p()
+        self.quantizer = quantizer
+        self.distance = quantizer.distance
+        self.datatype = None
+        rows = np.ascontiguousarray(rows, dtype=np.uint8)
+        assert rows.shape[1] == quantizer.quantized_vector_size()
+        self.dim = quantizer.dim
+        self.count = int(rows.shape[0])
+        self._keep = None
+        self._sq = quantizer.params()
+        desc = F.SegmentDesc()
+        desc.dtype = F.DTYPE_SQ_U8
+        desc.distance = int(quantizer.distance)
+        desc.dim = quantizer.dim
+        desc.flags = 0
+        desc.n = self.count
+        desc.row_stride_bytes = 0
+        desc.data = F.ptr(rows)
+        desc.device_id = device_id
+        desc.sq = C.pointer(self._sq)
+        F.check(F.lib().qmx_segment_create(C.byref(desc), C.byref(self._h)))
+
+    def get_quantized_vector(self, ids: Sequence[int]) -> np.ndarray:
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        out = np.empty((len(ids), self.quantizer.quantized_vector_size()), dtype=np.uint8)
+        F.check(F.lib().qmx_segment_read_rows(self._h, F.ptr(ids), len(ids), F.ptr(out)))
+        return out
+
+
 class RawScorer:
     """`Box<dyn RawScorer>` for a batch of `QueryVector::Nearest` queries (raw_scorer.rs:39-58).
     One instance holds `nq` scorers; single-query use is nq == 1."""
@@ -140,7 +225,46 @@ class RawScorer:
         F.check(F.lib().qmx_score_internal(self.storage._h, F.ptr(a), F.ptr(b), len(a), F.ptr(out)))
         return out
 
+    def score_points_ragged(self, ids_per_query: Sequence[Sequence[int]]) -> List[np.ndarray]:
+        """Query qi scores its own id list: the HNSW hop of many concurrent searches in one launch
+        (graph_layers.rs:125-139 produce <= m0 ids per hop per search)."""
+        assert len(ids_per_query) == self.nq
+        lens = [len(x) for x in ids_per_query]
+        offsets = np.zeros(self.nq + 1, dtype=np.uint32)
+        offsets[1:] = np.cumsum(lens)
+        ids = (np.concatenate([np.asarray(x, dtype=np.uint32) for x in ids_per_query])
+               if offsets[-1] else np.zeros(0, dtype=np.uint32))
+        scores = np.empty(int(offsets[-1]), dtype=np.float32)
+        F.check(F.lib().qmx_score_points_ragged(self._h, F.ptr(ids), F.ptr(offsets), F.ptr(scores), None))
+        return [scores[offsets[i]:offsets[i + 1]] for i in range(self.nq)]
+
+    def score_bytes(self, rows) -> np.ndarray:
+        """`QueryScorerBytes::score_bytes` (query_scorer/mod.rs:48-68): rows given as raw bytes in the
+        storage's reference row layout."""
+        rows = np.ascontiguousarray(rows)
+        n = rows.shape[0]
+        stride = rows.strides[0]
+        scores = np.empty((self.nq, n), dtype=np.float32)
+        F.check(F.lib().qmx_score_bytes(self._h, F.ptr(rows), n, stride, F.ptr(scores)))
+        return scores
+
+    def rescore(self, ids, top: int, counts=None) -> List[np.ndarray]:
+        """The rescoring tail of `postprocess_search_result` (vector_index_search_common.rs:73-90):
+        query qi re-scores ids[qi] with THIS (original-vector) scorer, sorted descending, truncated to top."""
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        assert ids.ndim == 2 and ids.shape[0] == self.nq
+        cnt = None if counts is None else np.ascontiguousarray(counts, dtype=np.uint32)
+        out = np.zeros((self.nq, top), dtype=ScoredPointOffset)
+        oc = np.zeros(self.nq, dtype=np.uint32)
+        F.check(F.lib().qmx_rescore(self._h, F.ptr(ids), F.ptr(cnt), ids.shape[1], top, F.ptr(out), F.ptr(oc)))
+        return [out[i, :oc[i]].copy() for i in range(self.nq)]
+
     def encoded_query(self, query_index: int = 0) -> np.ndarray:
+        if isinstance(self.storage, EncodedVectorsU8):   # EncodedQueryU8 {offset: f32, encoded_query: Vec<u8>}
+            nbytes = 4 + self.storage.quantizer.actual_dim
+            out = np.empty(nbytes, dtype=np.uint8)
+            F.check(F.lib().qmx_query_read_encoded(self._h, query_index, F.ptr(out), nbytes, None))
+            return out
         nbytes = self.storage.dim * np.dtype(_NP_ELEM[int(self.storage.datatype)]).itemsize
         out = np.empty(nbytes, dtype=np.uint8)
         written = C.c_uint64()

@@ -231,3 +231,43 @@ def load_ref_quant():
         fn.argtypes = [_P, _P, C.c_uint32]
     _lib.qo_sq_set_ref_kernels(C.cast(ref.impl_score_dot_avx, _P), C.cast(ref.impl_score_l1_avx, _P))
     return ref
+
+
+class SqOracle:
+    """EncodedVectorsU8 on the CPU (oracle): given (alpha, offset)."""
+
+    def __init__(self, distance, dim, alpha, offset, isa=ISA_AUTO):
+        self.sq = Sq()
+        invert = 1 if distance in (EUCLID, MANHATTAN) else 0
+        _lib.qo_sq_init_params(C.byref(self.sq), distance, invert, dim, float(alpha), float(offset))
+        self.dim, self.ad, self.isa = dim, self.sq.actual_dim, isa
+        self.rows = None
+
+    def encode_rows(self, vectors):
+        v = f32(vectors)
+        out = np.zeros((v.shape[0], 4 + self.ad), dtype=np.uint8)
+        for i in range(v.shape[0]):
+            _lib.qo_sq_encode_row(C.byref(self.sq), _p(v[i]), _p(out[i]))
+        self.rows = out
+        return out
+
+    def encode_query(self, q):
+        q = f32(q)
+        codes = np.zeros(self.ad, dtype=np.uint8)
+        off = _f()
+        _lib.qo_sq_encode_query(C.byref(self.sq), _p(q), _p(codes), C.byref(off))
+        return codes, off.value
+
+    def score_points(self, queries, ids):
+        """queries: already metric-preprocessed f32 [nq, dim]"""
+        queries = f32(np.atleast_2d(queries))
+        out = np.empty((queries.shape[0], len(ids)), dtype=np.float32)
+        for qi in range(queries.shape[0]):
+            codes, off = self.encode_query(queries[qi])
+            for j, i in enumerate(ids):
+                out[qi, j] = _lib.qo_sq_score(C.byref(self.sq), _p(codes), off, _p(self.rows[i]), self.isa)
+        return out
+
+    def score_internal(self, a, b):
+        return np.array([_lib.qo_sq_score_internal(C.byref(self.sq), _p(self.rows[i]), _p(self.rows[j]), self.isa)
+                         for i, j in zip(a, b)], dtype=np.float32)
