@@ -371,6 +371,24 @@ int32_t qmx_segment_create(const qmx_segment_desc *desc, qmx_segment **out) {
             s->scan_dim = s->sq.actual_dim;
             s->row_bytes = 4 + (uint64_t)s->sq.actual_dim;
             break;
+        case QMX_DTYPE_PQ: {
+            if (!desc->pq || !desc->pq->centroids) { set_error("PQ segment needs qmx_pq_params with centroids"); rc = QMX_ERR_BAD_ARG; break; }
+            s->pq = *desc->pq;
+            if (s->pq.chunk_size == 0 || s->pq.chunk_size > 256 || s->pq.n_centroids == 0 || s->pq.n_centroids > 256) {
+                set_error("PQ: chunk_size %u must be 1..256 and n_centroids %u must be 1..256 (codes are u8)", s->pq.chunk_size, s->pq.n_centroids);
+                rc = QMX_ERR_BAD_ARG;
+                break;
+            }
+            s->pq_m = (desc->dim + s->pq.chunk_size - 1) / s->pq.chunk_size;   // get_vector_division, encoded_vectors_pq.rs:164-169
+            s->scan_dim = s->pq_m;
+            s->row_bytes = s->pq_m;
+            const size_t cbytes = (size_t)s->pq.n_centroids * desc->dim * sizeof(float);
+            hipError_t e = hipMalloc((void **)&s->d_centroids, cbytes);
+            if (e == hipSuccess) e = hipMemcpy(s->d_centroids, desc->pq->centroids, cbytes, hipMemcpyDefault);
+            if (e != hipSuccess) rc = hip_status(e, "PQ centroids upload", __FILE__, __LINE__);
+            s->pq.centroids = nullptr;   // the caller's table is not referenced after create
+            break;
+        }
         default:
             set_error("dtype %u not built yet", desc->dtype);
             rc = QMX_ERR_NOT_SUPPORTED;
@@ -514,9 +532,14 @@ static int32_t query_alloc(const qmx_segment *seg, uint32_t nq, qmx_query **out)
     q->nq = nq;
     q->nq_padded = ((nq + MAX_QT - 1) / MAX_QT) * MAX_QT;
     if (q->nq_padded == 0) q->nq_padded = MAX_QT;
+    if (seg->dtype == QMX_DTYPE_PQ) q->nq_padded = std::max<uint32_t>(nq, 1);   // LUTs are never read past nq
     // tile entry = elements zero-padded to whole 128-byte segments + the aux block
     q->aux_off = (uint32_t)((seg->scan_dim * elem_bytes(seg->dtype) + 127) & ~127u);
     q->q_stride = q->aux_off + QUERY_AUX_BYTES;
+    if (seg->dtype == QMX_DTYPE_PQ) {   // the encoded query is the LUT [m][n_centroids] f32 (EncodedQueryPQ)
+        q->q_stride = (uint32_t)(((size_t)seg->pq_m * seg->pq.n_centroids * sizeof(float) + 15) & ~(size_t)15);
+        q->aux_off = 0;
+    }
     auto fail = [&](hipError_t e, const char *what) {
         int32_t rc = hip_status(e, what, __FILE__, __LINE__);
         qmx_query_destroy(q);
@@ -562,6 +585,8 @@ static int32_t query_encode(qmx_query *q, const float *queries) {
     if (seg->dtype == QMX_DTYPE_SQ_U8)   // EncodedVectorsU8::encode_query (encoded_vectors_u8.rs:583-619)
         return launch_sq_encode(q->stream, (int)seg->distance, seg->sq, seg->dim, d_f32, nq, (uint8_t *)q->d_queries, q->q_stride,
                                 nullptr, nullptr, 1, q->aux_off);
+    if (seg->dtype == QMX_DTYPE_PQ)      // EncodedVectorsPQ::encode_query (encoded_vectors_pq.rs:519-541)
+        return launch_pq_lut(q->stream, seg->distance, seg->dim, seg->pq, seg->d_centroids, d_f32, nq, (float *)q->d_queries);
     set_error("query encode for dtype %u not built yet", seg->dtype);
     return QMX_ERR_NOT_SUPPORTED;
 }
@@ -689,7 +714,8 @@ int32_t qmx_query_read_encoded(const qmx_query *q, uint32_t query_index, void *o
     QMX_REQUIRE(query_index < q->nq, QMX_ERR_OUT_OF_BOUNDS, "query index %u >= %u", query_index, q->nq);
     QMX_HIP(hipSetDevice(q->seg->device));
     const bool sq = q->seg->dtype == QMX_DTYPE_SQ_U8;
-    const uint64_t ebytes = (uint64_t)q->seg->scan_dim * elem_bytes(q->seg->dtype);
+    const uint64_t ebytes = q->seg->dtype == QMX_DTYPE_PQ ? (uint64_t)q->seg->pq_m * q->seg->pq.n_centroids * sizeof(float)
+                                                          : (uint64_t)q->seg->scan_dim * elem_bytes(q->seg->dtype);
     const uint64_t bytes = ebytes + (sq ? 4 : 0);
     QMX_REQUIRE(out_bytes >= bytes, QMX_ERR_BAD_ARG, "buffer too small: need %llu", (unsigned long long)bytes);
     QMX_HIP(hipStreamSynchronize(q->stream));
@@ -740,6 +766,7 @@ static int32_t launch_scan(const qmx_query *q, int qt, ScanMode mode, const Scan
         return launch_scan_dense(q->stream, (int)s->dtype, (int)s->distance, qt, mode, a, s->num_cus, grid);
     }
     if (s->dtype == QMX_DTYPE_SQ_U8) return launch_scan_sq(q->stream, (int)s->distance, qt, mode, a, s->num_cus, grid);
+    if (s->dtype == QMX_DTYPE_PQ) return launch_scan_pq(q->stream, mode, a, s->num_cus, grid);
     set_error("dtype %u not built yet", s->dtype);
     return QMX_ERR_NOT_SUPPORTED;
 }
@@ -957,6 +984,8 @@ static int32_t score_pairs_device(qmx_query *q, const PairSel &sel, const uint32
         rc = launch_pairs_dense(q->stream, (int)s->dtype, (int)s->distance, a, sel, n_items, s->num_cus);
     } else if (s->dtype == QMX_DTYPE_SQ_U8) {
         rc = launch_pairs_sq(q->stream, (int)s->distance, a, sel, n_items, s->num_cus);
+    } else if (s->dtype == QMX_DTYPE_PQ) {
+        rc = launch_pairs_pq(q->stream, a, sel, n_items, s->num_cus);
     } else {
         set_error("dtype %u not built yet", s->dtype);
         rc = QMX_ERR_NOT_SUPPORTED;
@@ -1037,6 +1066,28 @@ int32_t qmx_rescore(qmx_query *q, const uint32_t *ids, const uint32_t *counts, u
 int32_t qmx_score_internal(const qmx_segment *seg, const uint32_t *a_ids, const uint32_t *b_ids, uint32_t n, float *out) {
     QMX_REQUIRE(seg && (n == 0 || (a_ids && b_ids && out)), QMX_ERR_BAD_ARG, "NULL argument");
     if (n == 0) return QMX_OK;
+    if (seg->dtype == QMX_DTYPE_PQ) {   // centroid <-> centroid (encoded_vectors_pq.rs:574-618); no query involved
+        QMX_HIP(hipSetDevice(seg->device));
+        DevBuf ba, bb, bo, be;
+        int32_t rc = QMX_OK;
+        do {
+            if ((rc = ba.reserve((size_t)n * 4)) != QMX_OK || (rc = bb.reserve((size_t)n * 4)) != QMX_OK ||
+                (rc = bo.reserve((size_t)n * 4)) != QMX_OK || (rc = be.reserve(4)) != QMX_OK) break;
+            hipError_t e = hipMemcpy(ba.p, a_ids, (size_t)n * 4, hipMemcpyDefault);
+            if (e == hipSuccess) e = hipMemcpy(bb.p, b_ids, (size_t)n * 4, hipMemcpyDefault);
+            if (e == hipSuccess) e = hipMemset(be.p, 0, 4);
+            if (e != hipSuccess) { rc = hip_status(e, "stage ids", __FILE__, __LINE__); break; }
+            if ((rc = launch_pq_internal(nullptr, seg->distance, seg->dim, seg->pq, seg->d_centroids, seg->d_rows, seg->row_stride, seg->n,
+                                         (const uint32_t *)ba.p, (const uint32_t *)bb.p, n, (float *)bo.p, (int *)be.p)) != QMX_OK) break;
+            int flag = 0;
+            e = hipMemcpy(&flag, be.p, 4, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(out, bo.p, (size_t)n * 4, hipMemcpyDefault);
+            if (e != hipSuccess) { rc = hip_status(e, "copy scores", __FILE__, __LINE__); break; }
+            if (flag) { set_error("point offset out of range for this segment"); rc = QMX_ERR_OUT_OF_BOUNDS; }
+        } while (0);
+        ba.release(); bb.release(); bo.release(); be.release();
+        return rc;
+    }
     // query i = stored point a[i] (FilteredScorer::new_internal), then the diagonal pairs (i, b[i])
     qmx_query *q = nullptr;
     QMX_TRY(qmx_query_create_internal(seg, a_ids, n, &q));
@@ -1154,10 +1205,40 @@ int32_t qmx_sq_encode(int32_t device_id, uint32_t distance, const qmx_sq_params 
     return rc;
 }
 
-// ---- not built yet -----------------------------------------------------------------------------
-int32_t qmx_pq_encode(int32_t, const qmx_pq_params *, const float *, uint64_t, uint32_t, uint8_t *) {
-    set_error("qmx_pq_encode not built yet");
-    return QMX_ERR_NOT_SUPPORTED;
+int32_t qmx_pq_encode(int32_t device_id, const qmx_pq_params *params, const float *in, uint64_t n, uint32_t dim, uint8_t *out_codes) {
+    QMX_REQUIRE(params && params->centroids && (n == 0 || (in && out_codes)) && dim > 0, QMX_ERR_BAD_ARG, "bad argument");
+    QMX_REQUIRE(params->chunk_size >= 1 && params->chunk_size <= 256 && params->n_centroids >= 1 && params->n_centroids <= 256,
+                QMX_ERR_BAD_ARG, "chunk_size / n_centroids out of range");
+    QMX_TRY(check_device(device_id, nullptr));
+    if (n == 0) return QMX_OK;
+    const uint32_t m = (dim + params->chunk_size - 1) / params->chunk_size;
+    const size_t in_bytes = (size_t)n * dim * 4, out_bytes = (size_t)n * m, cbytes = (size_t)params->n_centroids * dim * 4;
+    DevBuf bin, bout, bc;
+    const float *d_in = in, *d_c = params->centroids;
+    uint8_t *d_out = out_codes;
+    int32_t rc = QMX_OK;
+    do {
+        if (!is_device_ptr(in)) {
+            if ((rc = bin.reserve(in_bytes)) != QMX_OK) break;
+            if (hipMemcpy(bin.p, in, in_bytes, hipMemcpyHostToDevice) != hipSuccess) { rc = QMX_ERR_OTHER; break; }
+            d_in = (const float *)bin.p;
+        }
+        if (!is_device_ptr(params->centroids)) {
+            if ((rc = bc.reserve(cbytes)) != QMX_OK) break;
+            if (hipMemcpy(bc.p, params->centroids, cbytes, hipMemcpyHostToDevice) != hipSuccess) { rc = QMX_ERR_OTHER; break; }
+            d_c = (const float *)bc.p;
+        }
+        const bool out_dev = is_device_ptr(out_codes);
+        if (!out_dev) {
+            if ((rc = bout.reserve(out_bytes)) != QMX_OK) break;
+            d_out = (uint8_t *)bout.p;
+        }
+        if ((rc = launch_pq_encode(nullptr, dim, *params, d_c, d_in, n, d_out)) != QMX_OK) break;
+        if (!out_dev && hipMemcpy(out_codes, d_out, out_bytes, hipMemcpyDeviceToHost) != hipSuccess) { rc = QMX_ERR_OTHER; break; }
+        if (hipDeviceSynchronize() != hipSuccess) rc = QMX_ERR_OTHER;
+    } while (0);
+    bin.release(); bout.release(); bc.release();
+    return rc;
 }
 
 }  // extern "C"

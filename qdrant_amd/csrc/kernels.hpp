@@ -84,6 +84,16 @@ int32_t launch_sq_gather_rows(hipStream_t st, const void *codes, const float *of
 int32_t launch_sq_internal_query(hipStream_t st, const void *codes, const float *offsets, uint32_t actual_dim, const uint32_t *ids,
                                  uint32_t nq, uint64_t n_rows, float shift, void *tile, uint32_t q_stride, uint32_t aux_off,
                                  int *err_flag);
+// PQ (pq.hip)
+int32_t launch_scan_pq(hipStream_t st, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out);
+int32_t launch_pairs_pq(hipStream_t st, const ScanArgs &a, const PairSel &sel, uint64_t n_items, int num_cus);
+int32_t launch_pq_lut(hipStream_t st, uint32_t distance, uint32_t dim, const qmx_pq_params &pq, const float *d_centroids,
+                      const float *d_queries, uint32_t nq, float *d_lut);
+int32_t launch_pq_internal(hipStream_t st, uint32_t distance, uint32_t dim, const qmx_pq_params &pq, const float *d_centroids,
+                           const void *rows, uint64_t row_stride, uint64_t n_rows, const uint32_t *a_ids, const uint32_t *b_ids,
+                           uint32_t n, float *out, int *err_flag);
+int32_t launch_pq_encode(hipStream_t st, uint32_t dim, const qmx_pq_params &pq, const float *d_centroids, const float *d_in,
+                         uint64_t n, uint8_t *d_codes);
 // query tile packing: preprocessed f32 queries -> element type, padded, + aux (preprocess.hip)
 int32_t launch_pack_queries(hipStream_t st, int dtype, int distance, const void *src, int src_is_encoded,
                             uint32_t src_stride, uint32_t nq, uint32_t dim, void *tile, uint32_t q_stride, uint32_t aux_off);

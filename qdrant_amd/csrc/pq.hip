@@ -1,0 +1,383 @@
+// pq.hip — EncodedVectorsPQ (product quantization) on device.
+//
+// Reference (lib/quantization/src/encoded_vectors_pq.rs):
+//   encode_query (LUT)   :519-541   LUT[c][j] = DistanceType::distance(query chunk c, centroid j chunk c), negated if invert
+//                                    (DistanceType::distance: encoded_vectors.rs:119-127, sequential f32 sum, mul/add un-fused)
+//   score_point_sse      :409-443   4 f32 lane accumulators (lane j takes chunks j, j+4, ...), (l0+l2)+(l1+l3), sequential tail
+//   score_internal       :574-618   centroid <-> centroid distances summed over chunks
+//   encode_vector        :301-329   per chunk L2 argmin over the centroids, first minimum wins
+// Rows are `m` code bytes (one centroid index per chunk); the LUT of one query is m x n_centroids f32
+// (96 KiB at m = 96) and lives in LDS for the scan.
+//
+// MFMA is used in exactly one place: the LUT build for Dot/Cosine (`lut_mfma`), a genuine dense
+// contraction [nq x chunk] . [chunk x 256] per chunk with f32 inputs (v_mfma_f32_32x32x2_f32: an fmaf
+// chain, so <= 1e-5 relative to the reference's mul+add chain; the exact-order VALU kernel is the
+// bit-parity variant).
+#include "scan_common.hpp"
+
+namespace qmx {
+
+struct PqGeom {
+    uint32_t dim, chunk, m, ncent;
+    int kind;     // 0 dot/cosine, 1 L1, 2 L2
+    int invert;
+};
+
+__device__ __forceinline__ float pq_term(int kind, float a, float b) {
+    if (kind == 0) return a * b;
+    const float d = a - b;
+    return kind == 1 ? __builtin_fabsf(d) : d * d;
+}
+
+// ------------------------------------------------------------------------------------------
+// LUT build, reference order.  grid (m, nq), one thread per centroid.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pq_lut_kernel(PqGeom g, const float *queries /*[nq][dim] preprocessed*/,
+                                                     const float *centroids /*[ncent][dim]*/, float *lut /*[nq][m][ncent]*/) {
+    __shared__ float sub[256];
+    const uint32_t c = blockIdx.x, q = blockIdx.y;
+    const uint32_t lo = c * g.chunk, hi = min(lo + g.chunk, g.dim);
+    if (threadIdx.x < hi - lo) sub[threadIdx.x] = queries[(uint64_t)q * g.dim + lo + threadIdx.x];   // chunk <= 256 (host-checked)
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < g.ncent; j += 256) {
+        const float *cen = centroids + (uint64_t)j * g.dim + lo;
+        float s = -0.0f;
+        for (uint32_t i = 0; i < hi - lo; ++i) s += pq_term(g.kind, sub[i], cen[i]);
+        lut[((uint64_t)q * g.m + c) * g.ncent + j] = g.invert ? -s : s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// LUT build on the matrix cores (Dot / Cosine only): per chunk c, C[q][j] = sum_i Q[q][lo+i] * Cen[j][lo+i].
+// One wavefront computes a 32 (queries) x 32 (centroids) tile with v_mfma_f32_32x32x2_f32:
+//   A (32 x 2): lane l supplies Q[q0 + l%32][lo + k0 + l/32]
+//   B (2 x 32): lane l supplies Cen[j0 + l%32][lo + k0 + l/32]
+//   C (32 x 32): lane l, register v holds row 8*(v/4) + 4*(l/32) + v%4, column l%32
+// grid (m, ceil(nq/32)), block = 4 waves, wave w covers centroid tiles w, w+4, ...
+// ------------------------------------------------------------------------------------------
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void pq_lut_mfma_kernel(PqGeom g, uint32_t nq, const float *queries, const float *centroids,
+                                                          float *lut) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t c = blockIdx.x;
+    const uint32_t q0 = blockIdx.y * 32;
+    const uint32_t lo = c * g.chunk, hi = min(lo + g.chunk, g.dim);
+    const uint32_t len = hi - lo;
+    const uint32_t qrow = q0 + (lane & 31);
+    const uint32_t khalf = lane >> 5;
+    for (uint32_t j0 = wave * 32; j0 < g.ncent; j0 += 128) {
+        const uint32_t jcol = j0 + (lane & 31);
+        floatx16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+        for (uint32_t k0 = 0; k0 < len; k0 += 2) {
+            const uint32_t k = k0 + khalf;
+            const float a = (qrow < nq && k < len) ? queries[(uint64_t)qrow * g.dim + lo + k] : 0.0f;
+            const float b = (jcol < g.ncent && k < len) ? centroids[(uint64_t)jcol * g.dim + lo + k] : 0.0f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        if (jcol < g.ncent) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const uint32_t q = q0 + 8 * (v / 4) + 4 * khalf + (v % 4);
+                if (q < nq) {
+                    const float s = acc[v];
+                    lut[((uint64_t)q * g.m + c) * g.ncent + jcol] = g.invert ? -s : s;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// score of one code row against one LUT, in score_point_sse order
+// ------------------------------------------------------------------------------------------
+template <class LutPtr>
+__device__ __forceinline__ float pq_score_row(const LutPtr lut, const uint8_t *codes, uint32_t m, uint32_t ncent) {
+    float l0 = 0.0f, l1 = 0.0f, l2 = 0.0f, l3 = 0.0f;
+    const uint32_t m4 = m & ~3u;
+    uint32_t c = 0;
+    if ((reinterpret_cast<uintptr_t>(codes) & 3) == 0) {
+        for (; c < m4; c += 4) {
+            const uint32_t w = *reinterpret_cast<const uint32_t *>(codes + c);
+            l0 += lut[(c + 0) * ncent + (w & 0xFF)];
+            l1 += lut[(c + 1) * ncent + ((w >> 8) & 0xFF)];
+            l2 += lut[(c + 2) * ncent + ((w >> 16) & 0xFF)];
+            l3 += lut[(c + 3) * ncent + (w >> 24)];
+        }
+    } else {
+        for (; c < m4; c += 4) {
+            l0 += lut[(c + 0) * ncent + codes[c]];
+            l1 += lut[(c + 1) * ncent + codes[c + 1]];
+            l2 += lut[(c + 2) * ncent + codes[c + 2]];
+            l3 += lut[(c + 3) * ncent + codes[c + 3]];
+        }
+    }
+    float sum = (l0 + l2) + (l1 + l3);        // sum64 = sum128 + movehl; sum32 = sum64[0] + sum64[1]
+    for (; c < m; ++c) sum += lut[c * ncent + codes[c]];
+    return sum;
+}
+
+// ------------------------------------------------------------------------------------------
+// Brute-force scan over PQ codes.  blockIdx.y = query (its LUT staged in LDS when it fits),
+// blockIdx.x = row slab; one lane per row.  Consecutive blocks differ in the query first, so the
+// blocks resident at any moment share row slabs through L2 / Infinity Cache.
+// ------------------------------------------------------------------------------------------
+constexpr int PQ_BLOCK = 1024;
+
+template <bool LDS_LUT, bool HAS_IDS, int MODE>
+__global__ __launch_bounds__(PQ_BLOCK) void pq_scan_kernel(const ScanArgs a, uint32_t n_slabs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint64_t sh_keys[PQ_BLOCK / WAVE][WAVE];
+    constexpr int NW = PQ_BLOCK / WAVE;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // block -> (slab, query): query varies fastest
+    const uint32_t q = blockIdx.x % a.nq;
+    const uint32_t slab = blockIdx.x / a.nq;
+    const uint32_t m = a.pq_m, ncent = a.pq_ncent;
+    const float *glut = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(a.queries) + (uint64_t)q * a.q_stride);
+    if (LDS_LUT) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(glut);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        const uint32_t n16 = m * ncent / 4;
+        for (uint32_t i = threadIdx.x; i < n16; i += PQ_BLOCK) dst[i] = src[i];
+        for (uint32_t i = n16 * 4 + threadIdx.x; i < m * ncent; i += PQ_BLOCK) reinterpret_cast<float *>(smem)[i] = glut[i];
+        __syncthreads();
+    }
+    const float *slut = reinterpret_cast<const float *>(smem);
+    const uint8_t *rows = reinterpret_cast<const uint8_t *>(a.rows);
+    const int top = (int)a.top;
+    uint64_t list = 0;
+    for (uint64_t base = ((uint64_t)slab * NW + wave) * WAVE; base < a.n_cand; base += (uint64_t)n_slabs * NW * WAVE) {
+        const uint64_t cnd = base + lane;
+        bool valid = cnd < a.n_cand;
+        uint32_t id = HAS_IDS ? a.ids[valid ? cnd : 0] : (uint32_t)cnd;
+        if (HAS_IDS && valid && id >= a.n_rows) {
+            *a.err_flag = 1;
+            valid = false;
+        }
+        if (!valid) id = 0;
+        float score = 0.0f;
+        if (a.n_rows) {
+            const uint8_t *codes = rows + (uint64_t)id * a.row_stride;
+            score = LDS_LUT ? pq_score_row(slut, codes, m, ncent) : pq_score_row(glut, codes, m, ncent);
+        }
+        if (MODE == SCAN_SCORES) {
+            if (valid) a.scores[(uint64_t)q * a.scores_stride + cnd] = score;
+        } else {
+            const uint64_t key = make_key(score, id);
+            bool c = valid && key > readlane_u64(list, top - 1);
+            if (__ballot(c)) {
+                c = c && a.del.live(id);
+                uint64_t mask = __ballot(c);
+                while (mask) {
+                    const int src = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    const uint64_t nk = readlane_u64(key, src);
+                    if (nk > readlane_u64(list, top - 1)) wave_list_insert(list, nk, lane);
+                }
+            }
+        }
+    }
+    if (MODE == SCAN_SCORES) return;
+    sh_keys[wave][lane] = list;
+    __syncthreads();
+    if (wave == 0) {
+        uint64_t merged = sh_keys[0][lane];
+        for (int w = 1; w < NW; ++w) {
+            const uint64_t key = sh_keys[w][lane];
+            uint64_t mask = __ballot(key > readlane_u64(merged, top - 1));
+            while (mask) {
+                const int src = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const uint64_t nk = readlane_u64(key, src);
+                if (nk > readlane_u64(merged, top - 1)) wave_list_insert(merged, nk, lane);
+            }
+        }
+        if (lane < top) a.partial[((uint64_t)slab * a.partial_qt + q) * top + lane] = merged;
+    }
+}
+
+template <bool LDS_LUT, bool HAS_IDS, int MODE>
+static int32_t launch_pq_scan_inst(hipStream_t st, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
+    const size_t lds = LDS_LUT ? (((size_t)a.pq_m * a.pq_ncent * 4 + 15) & ~(size_t)15) : 0;
+    auto kfn = pq_scan_kernel<LDS_LUT, HAS_IDS, MODE>;
+    static thread_local bool attr_set = false;
+    if (!attr_set && LDS_LUT) {
+        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));   // + 8 KiB static
+        attr_set = true;
+    }
+    // slabs: enough blocks to fill the chip with nq queries each, bounded by the work
+    uint64_t want = (a.n_cand + PQ_BLOCK - 1) / PQ_BLOCK;
+    uint64_t cap = std::max<uint64_t>(1, ((uint64_t)num_cus * 2 + a.nq - 1) / a.nq);
+    uint32_t slabs = (uint32_t)std::max<uint64_t>(1, std::min(want, cap));
+    if (grid_out) {
+        if (*grid_out && MODE == SCAN_TOPK && slabs > *grid_out) slabs = *grid_out;
+        *grid_out = slabs;
+    }
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(kfn, dim3(slabs * a.nq), dim3(PQ_BLOCK), lds, st, a, slabs);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
+int32_t launch_scan_pq(hipStream_t st, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
+    const bool lds = (size_t)a.pq_m * a.pq_ncent * 4 <= 150 * 1024;
+    const bool ids = a.ids != nullptr;
+#define QMX_PQ_CASE(L, I, M) \
+    if (lds == L && ids == I && mode == M) return launch_pq_scan_inst<L, I, M>(st, a, num_cus, grid_out);
+    QMX_PQ_CASE(true, false, SCAN_TOPK)
+    QMX_PQ_CASE(true, true, SCAN_TOPK)
+    QMX_PQ_CASE(true, false, SCAN_SCORES)
+    QMX_PQ_CASE(true, true, SCAN_SCORES)
+    QMX_PQ_CASE(false, false, SCAN_TOPK)
+    QMX_PQ_CASE(false, true, SCAN_TOPK)
+    QMX_PQ_CASE(false, false, SCAN_SCORES)
+    QMX_PQ_CASE(false, true, SCAN_SCORES)
+#undef QMX_PQ_CASE
+    return QMX_ERR_OTHER;
+}
+
+// pair scoring (HNSW hops / ragged lists): one lane per item, LUT read through L2
+__global__ __launch_bounds__(256) void pq_pair_kernel(const ScanArgs a, const PairSel sel, uint64_t n_items) {
+    const uint8_t *rows = reinterpret_cast<const uint8_t *>(a.rows);
+    for (uint64_t item = (uint64_t)blockIdx.x * 256 + threadIdx.x; item < n_items; item += (uint64_t)gridDim.x * 256) {
+        const uint32_t qi = sel.query_of(item);
+        if (!sel.live(item, qi)) continue;
+        const uint32_t id = a.ids[item];
+        if (id >= a.n_rows || qi >= a.nq) {
+            *a.err_flag = 1;
+            continue;
+        }
+        const float *lut = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(a.queries) + (uint64_t)qi * a.q_stride);
+        a.scores[item] = pq_score_row(lut, rows + (uint64_t)id * a.row_stride, a.pq_m, a.pq_ncent);
+    }
+}
+int32_t launch_pairs_pq(hipStream_t st, const ScanArgs &a, const PairSel &sel, uint64_t n_items, int num_cus) {
+    if (n_items == 0) return QMX_OK;
+    uint64_t want = (n_items + 255) / 256;
+    uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)num_cus * 8);
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(pq_pair_kernel, dim3(grid), dim3(256), 0, st, a, sel, n_items);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// score_internal (:574-618): out[i] = (+/-) sum_c distance(centroid[a_code[c]] chunk c, centroid[b_code[c]] chunk c)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pq_internal_kernel(PqGeom g, const uint8_t *rows, uint64_t row_stride, uint64_t n_rows,
+                                                          const float *centroids, const uint32_t *a_ids, const uint32_t *b_ids,
+                                                          uint32_t n, float *out, int *err_flag) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t ia = a_ids[i], ib = b_ids[i];
+    if (ia >= n_rows || ib >= n_rows) {
+        *err_flag = 1;
+        return;
+    }
+    const uint8_t *ca = rows + (uint64_t)ia * row_stride, *cb = rows + (uint64_t)ib * row_stride;
+    float s = -0.0f;
+    for (uint32_t c = 0; c < g.m; ++c) {
+        const uint32_t lo = c * g.chunk, hi = min(lo + g.chunk, g.dim);
+        const float *da = centroids + (uint64_t)ca[c] * g.dim, *db = centroids + (uint64_t)cb[c] * g.dim;
+        float d = -0.0f;
+        for (uint32_t k = lo; k < hi; ++k) d += pq_term(g.kind, da[k], db[k]);
+        s += d;
+    }
+    out[i] = g.invert ? -s : s;
+}
+
+// ------------------------------------------------------------------------------------------
+// encode_vector (:301-329).  grid (ceil(n/256), m): block = 256 vectors x one chunk; the chunk of every
+// centroid sits in LDS (broadcast reads), each thread keeps its sub-vector in LDS column `tid`.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pq_encode_kernel(PqGeom g, const float *in, uint64_t n, const float *centroids,
+                                                        uint8_t *codes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t c = blockIdx.y;
+    const uint32_t lo = c * g.chunk, hi = min(lo + g.chunk, g.dim);
+    const uint32_t len = hi - lo;
+    float *cen = reinterpret_cast<float *>(smem);                 // [ncent][len]
+    float *sub = cen + (size_t)g.ncent * len;                     // [len][256]
+    const uint32_t tid = threadIdx.x;
+    const uint64_t vec = (uint64_t)blockIdx.x * 256 + tid;
+    for (uint32_t i = tid; i < g.ncent * len; i += 256) cen[i] = centroids[(uint64_t)(i / len) * g.dim + lo + i % len];
+    if (vec < n)
+        for (uint32_t k = 0; k < len; ++k) sub[k * 256 + tid] = in[vec * g.dim + lo + k];
+    __syncthreads();
+    if (vec >= n) return;
+    float min_distance = 3.40282347e+38f;   // f32::MAX
+    uint32_t min_index = 0;
+    for (uint32_t j = 0; j < g.ncent; ++j) {
+        float s = -0.0f;
+        for (uint32_t k = 0; k < len; ++k) {
+            const float d = sub[k * 256 + tid] - cen[j * len + k];
+            s += d * d;                                            // (a - b).powi(2), sequential sum
+        }
+        if (s < min_distance) {                                    // first minimum wins (:321)
+            min_distance = s;
+            min_index = j;
+        }
+    }
+    codes[vec * g.m + c] = (uint8_t)min_index;
+}
+
+static PqGeom make_geom(uint32_t distance, uint32_t dim, const qmx_pq_params &pq) {
+    PqGeom g;
+    g.dim = dim;
+    g.chunk = pq.chunk_size;
+    g.m = (dim + pq.chunk_size - 1) / pq.chunk_size;              // get_vector_division :164-169
+    g.ncent = pq.n_centroids;
+    g.kind = (distance == QMX_DISTANCE_DOT || distance == QMX_DISTANCE_COSINE) ? 0 : distance == QMX_DISTANCE_MANHATTAN ? 1 : 2;
+    g.invert = pq.invert;
+    return g;
+}
+
+int32_t launch_pq_lut(hipStream_t st, uint32_t distance, uint32_t dim, const qmx_pq_params &pq, const float *d_centroids,
+                      const float *d_queries, uint32_t nq, float *d_lut) {
+    if (nq == 0) return QMX_OK;
+    const PqGeom g = make_geom(distance, dim, pq);
+    ::qmx::clear_stale_error();
+    if (pq.lut_mfma && g.kind == 0) {
+        hipLaunchKernelGGL(pq_lut_mfma_kernel, dim3(g.m, (nq + 31) / 32), dim3(256), 0, st, g, nq, d_queries, d_centroids, d_lut);
+    } else {
+        hipLaunchKernelGGL(pq_lut_kernel, dim3(g.m, nq), dim3(256), 0, st, g, d_queries, d_centroids, d_lut);
+    }
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
+int32_t launch_pq_internal(hipStream_t st, uint32_t distance, uint32_t dim, const qmx_pq_params &pq, const float *d_centroids,
+                           const void *rows, uint64_t row_stride, uint64_t n_rows, const uint32_t *a_ids, const uint32_t *b_ids,
+                           uint32_t n, float *out, int *err_flag) {
+    if (n == 0) return QMX_OK;
+    const PqGeom g = make_geom(distance, dim, pq);
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(pq_internal_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g, (const uint8_t *)rows, row_stride, n_rows,
+                       d_centroids, a_ids, b_ids, n, out, err_flag);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
+int32_t launch_pq_encode(hipStream_t st, uint32_t dim, const qmx_pq_params &pq, const float *d_centroids, const float *d_in,
+                         uint64_t n, uint8_t *d_codes) {
+    if (n == 0) return QMX_OK;
+    const PqGeom g = make_geom(QMX_DISTANCE_EUCLID, dim, pq);
+    const size_t lds = ((size_t)g.ncent * g.chunk + (size_t)g.chunk * 256) * sizeof(float);
+    QMX_REQUIRE(lds <= 150 * 1024, QMX_ERR_NOT_SUPPORTED, "PQ encode: chunk %u x %u centroids needs %zu B of LDS", g.chunk, g.ncent, lds);
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pq_encode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+    }
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(pq_encode_kernel, dim3((uint32_t)((n + 255) / 256), g.m), dim3(256), lds, st, g, d_in, n, d_centroids, d_codes);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
+}  // namespace qmx

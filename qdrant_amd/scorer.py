@@ -197,6 +197,76 @@ class EncodedVectorsU8(VectorStorage):
         return out
 
 
+class ProductQuantizer:
+    """`Metadata{centroids, vector_division, vector_parameters}` of `EncodedVectorsPQ`
+    (lib/quantization/src/encoded_vectors_pq.rs:46-51).  Centroids are an INPUT: the reference's k-means
+    re-seeds empty clusters randomly (kmeans.rs:113-120), so parity is defined on given centroids."""
+
+    def __init__(self, dim: int, distance: Distance, chunk_size: int, centroids, lut_mfma: bool = False):
+        self.dim = int(dim)
+        self.distance = Distance(distance)
+        self.chunk_size = int(chunk_size)
+        self.centroids = np.ascontiguousarray(centroids, dtype=np.float32)   # [n_centroids, dim], flattened by chunks
+        assert self.centroids.ndim == 2 and self.centroids.shape[1] == self.dim
+        self.n_centroids = int(self.centroids.shape[0])
+        self.m = (self.dim + self.chunk_size - 1) // self.chunk_size          # get_vector_division :164-169
+        self.invert = self.distance in (Distance.Euclid, Distance.Manhattan)
+        self.lut_mfma = bool(lut_mfma)
+
+    def params(self) -> "F.PqParams":
+        p = F.PqParams()
+        p.chunk_size = self.chunk_size
+        p.n_centroids = self.n_centroids
+        p.centroids = self.centroids.ctypes.data
+        p.invert = 1 if self.invert else 0
+        p.lut_mfma = 1 if self.lut_mfma else 0
+        return p
+
+    def quantized_vector_size(self) -> int:
+        return self.m
+
+    def encode(self, vectors, device_id: int = 0) -> np.ndarray:
+        """`EncodedVectorsPQ::encode_vector` (:301-329) on device: [n, dim] f32 -> [n, m] u8 codes."""
+        v = np.ascontiguousarray(vectors, dtype=np.float32)
+        out = np.empty((v.shape[0], self.m), dtype=np.uint8)
+        p = self.params()
+        F.check(F.lib().qmx_pq_encode(device_id, C.byref(p), F.ptr(v), v.shape[0], self.dim, F.ptr(out)))
+        return out
+
+
+class EncodedVectorsPQ(VectorStorage):
+    """Device-resident `EncodedVectorsPQ` storage: rows = [n, m] u8 centroid indices."""
+
+    def __init__(self, codes, quantizer: ProductQuantizer, device_id: int = 0):
+        self._h = C.c_void_p()
+        self.quantizer = quantizer
+        self.distance = quantizer.distance
+        self.datatype = None
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        assert codes.shape[1] == quantizer.m
+        self.dim = quantizer.dim
+        self.count = int(codes.shape[0])
+        self._keep = None
+        self._pq = quantizer.params()
+        desc = F.SegmentDesc()
+        desc.dtype = F.DTYPE_PQ
+        desc.distance = int(quantizer.distance)
+        desc.dim = quantizer.dim
+        desc.flags = 0
+        desc.n = self.count
+        desc.row_stride_bytes = 0
+        desc.data = F.ptr(codes)
+        desc.device_id = device_id
+        desc.pq = C.pointer(self._pq)
+        F.check(F.lib().qmx_segment_create(C.byref(desc), C.byref(self._h)))
+
+    def get_quantized_vector(self, ids: Sequence[int]) -> np.ndarray:
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        out = np.empty((len(ids), self.quantizer.m), dtype=np.uint8)
+        F.check(F.lib().qmx_segment_read_rows(self._h, F.ptr(ids), len(ids), F.ptr(out)))
+        return out
+
+
 class RawScorer:
     """`Box<dyn RawScorer>` for a batch of `QueryVector::Nearest` queries (raw_scorer.rs:39-58).
     One instance holds `nq` scorers; single-query use is nq == 1."""
@@ -260,6 +330,11 @@ class RawScorer:
         return [out[i, :oc[i]].copy() for i in range(self.nq)]
 
     def encoded_query(self, query_index: int = 0) -> np.ndarray:
+        if isinstance(self.storage, EncodedVectorsPQ):   # EncodedQueryPQ {lut: Vec<f32>} = [m][n_centroids]
+            qz = self.storage.quantizer
+            out = np.empty((qz.m, qz.n_centroids), dtype=np.float32)
+            F.check(F.lib().qmx_query_read_encoded(self._h, query_index, F.ptr(out), out.nbytes, None))
+            return out
         if isinstance(self.storage, EncodedVectorsU8):   # EncodedQueryU8 {offset: f32, encoded_query: Vec<u8>}
             nbytes = 4 + self.storage.quantizer.actual_dim
             out = np.empty(nbytes, dtype=np.uint8)

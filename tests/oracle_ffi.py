@@ -271,3 +271,49 @@ class SqOracle:
     def score_internal(self, a, b):
         return np.array([_lib.qo_sq_score_internal(C.byref(self.sq), _p(self.rows[i]), _p(self.rows[j]), self.isa)
                          for i, j in zip(a, b)], dtype=np.float32)
+
+
+class PqOracle:
+    """EncodedVectorsPQ on the CPU (oracle): given centroids [n_centroids, dim]."""
+
+    def __init__(self, distance, dim, chunk_size, centroids, isa=ISA_AUTO):
+        self.centroids = f32(centroids)
+        self.pq = Pq()
+        invert = 1 if distance in (EUCLID, MANHATTAN) else 0
+        _lib.qo_pq_init(C.byref(self.pq), distance, invert, dim, chunk_size, self.centroids.shape[0], _p(self.centroids))
+        self.m, self.nc, self.isa, self.dim = self.pq.m, self.centroids.shape[0], isa, dim
+        self.codes = None
+
+    @staticmethod
+    def train(data, dim, chunk_size, n_centroids, iters=5):
+        data = f32(data)
+        cen = np.zeros((n_centroids, dim), dtype=np.float32)
+        _lib.qo_pq_train(dim, chunk_size, n_centroids, _p(data), data.shape[0], iters, _p(cen))
+        return cen
+
+    def encode(self, vectors):
+        v = f32(vectors)
+        out = np.zeros((v.shape[0], self.m), dtype=np.uint8)
+        for i in range(v.shape[0]):
+            _lib.qo_pq_encode_vector(C.byref(self.pq), _p(v[i]), _p(out[i]))
+        self.codes = out
+        return out
+
+    def lut(self, q):
+        q = f32(q)
+        lut = np.zeros((self.m, self.nc), dtype=np.float32)
+        _lib.qo_pq_encode_query(C.byref(self.pq), _p(q), _p(lut))
+        return lut
+
+    def score_points(self, queries, ids):
+        queries = f32(np.atleast_2d(queries))
+        out = np.empty((queries.shape[0], len(ids)), dtype=np.float32)
+        for qi in range(queries.shape[0]):
+            lut = self.lut(queries[qi])
+            for j, i in enumerate(ids):
+                out[qi, j] = _lib.qo_pq_score(C.byref(self.pq), _p(lut), _p(self.codes[i]), self.isa)
+        return out
+
+    def score_internal(self, a, b):
+        return np.array([_lib.qo_pq_score_internal(C.byref(self.pq), _p(self.codes[i]), _p(self.codes[j])) for i, j in zip(a, b)],
+                        dtype=np.float32)
