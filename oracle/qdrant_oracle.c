@@ -619,6 +619,37 @@ void qo_topk_push(qo_topk *t, uint32_t idx, float score) {
         sift_down_range(t->data, 0, t->len);
     }
 }
+/* push with the Option<T> result of FixedLengthPriorityQueue::push (:47-59):
+ * 0 = None (queue was not full), 1 = Some(old root) written to *removed (value entered),
+ * 2 = Some(value) (value rejected; *removed = value). */
+int qo_topk_push_ex(qo_topk *t, uint32_t idx, float score, qo_scored_point *removed) {
+    qo_scored_point v = {idx, score};
+    if (t->len < t->length) {
+        t->data[t->len] = v;
+        sift_up(t->data, 0, t->len);
+        t->len++;
+        return 0;
+    }
+    if (of_cmp(t->data[0].score, v.score) < 0) {
+        if (removed) *removed = t->data[0];
+        t->data[0] = v;
+        sift_down_range(t->data, 0, t->len);
+        return 1;
+    }
+    if (removed) *removed = v;
+    return 2;
+}
+/* top(): the smallest element kept (heap.peek()), :80-82 */
+int qo_topk_top(const qo_topk *t, qo_scored_point *out) {
+    if (t->len == 0) return 0;
+    *out = t->data[0];
+    return 1;
+}
+size_t qo_topk_len(const qo_topk *t) { return t->len; }
+/* iter_unsorted(): heap storage order (:68-70) */
+const qo_scored_point *qo_topk_data(const qo_topk *t) { return t->data; }
+int qo_ordered_float_cmp(float a, float b) { return of_cmp(a, b); }
+
 size_t qo_topk_into_sorted(qo_topk *t, qo_scored_point *out) {
     size_t end = t->len;
     while (end > 1) {

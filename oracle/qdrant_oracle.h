@@ -65,6 +65,11 @@ qo_topk *qo_topk_new(size_t length);
 void qo_topk_free(qo_topk *);
 void qo_topk_push(qo_topk *, uint32_t idx, float score);            /* fixed_length_priority_queue.rs:47-59 */
 size_t qo_topk_into_sorted(qo_topk *, qo_scored_point *out);        /* :63-65 ; consumes content */
+int qo_topk_push_ex(qo_topk *, uint32_t idx, float score, qo_scored_point *removed); /* push's Option<T>: 0 None, 1 Some(evicted), 2 Some(value) */
+int qo_topk_top(const qo_topk *, qo_scored_point *out);              /* top() :80-82, 0 if empty */
+size_t qo_topk_len(const qo_topk *);
+const qo_scored_point *qo_topk_data(const qo_topk *);                /* iter_unsorted() order */
+int qo_ordered_float_cmp(float a, float b);                          /* OrderedFloat::cmp */
 
 /* ---- brute force: BatchFilteredSearcher::peek_top_iter (point_scorer.rs:423-472) ---- */
 typedef struct {
@@ -130,6 +135,65 @@ float qo_pq_score_internal(const qo_pq *pq, const uint8_t *ci, const uint8_t *cj
  * clusters randomly, so centroids are an INPUT to parity, never compared) */
 void qo_pq_train(uint32_t dim, uint32_t chunk_size, uint32_t n_centroids, const float *data,
                  size_t n, int iters, float *centroids_out);
+
+/* ---- cross-segment merge: BatchResultAggregator (lib/shard/src/search_result_aggregator.rs:50-121) ----
+ * lists[(l * nq + qi) * k ..] with counts[l * nq + qi] valid entries; idx_base[l] (optional) is added to
+ * every idx of list l (segment-local offset -> global id).  Points are pushed list by list, each list in
+ * its own (descending) order; an id already seen for that query is skipped (:33-36).  All versions equal. */
+void qo_merge_topk(const qo_scored_point *lists, const uint32_t *counts, const uint32_t *idx_base,
+                   uint32_t n_lists, uint32_t nq, uint32_t k, qo_scored_point *out, uint32_t *out_counts);
+
+/* ---- scorer = FilteredScorer{RawScorer, NotDeletedChecker} (hnsw_index/point_scorer.rs:53-63) ---- */
+typedef struct {
+    int kind;                 /* 0 dense (Metric over st->rows), 1 SQ (EncodedVectorsU8), 2 PQ (EncodedVectorsPQ) */
+    const qo_storage *st;     /* dense rows for kind 0; the deleted flags and n for every kind */
+    const void *query;        /* kind 0: preprocessed + cast query, [dim] elements */
+    const qo_sq *sq; const uint8_t *sq_rows; const uint8_t *sq_query; float sq_query_offset;
+    const qo_pq *pq; const uint8_t *pq_codes; const float *pq_lut;
+    int isa;                  /* leaf used for SQ / PQ scoring */
+} qo_scorer;
+float qo_scorer_score_point(const qo_scorer *s, uint32_t id);              /* RawScorer::score_point */
+float qo_scorer_score_internal(const qo_scorer *s, uint32_t a, uint32_t b); /* RawScorer::score_internal */
+int qo_scorer_check_vector(const qo_scorer *s, uint32_t id);               /* raw_scorer.rs:596-603 */
+
+/* ---- HNSW: hnsw_index/{graph_layers.rs, graph_layers_builder.rs, links_container.rs, entry_points.rs} ---- */
+typedef struct qo_hnsw qo_hnsw;
+/* GraphLayersBuilder::new + set_levels for every point (level = round(-ln(U) / ln(max(m,2))),
+ * graph_layers_builder.rs:320,388-396, U from our own splitmix64 stream: the reference draws from
+ * rand's thread rng) + link_new_point(0..n) single-threaded with the internal scorer of each point
+ * (FilteredScorer::new_internal: query = stored row, dense storages only). */
+qo_hnsw *qo_hnsw_build(const qo_storage *st, uint32_t m, uint32_t m0, uint32_t ef_construct,
+                       uint32_t entry_points_num, int use_heuristic, uint64_t seed);
+/* same algorithm, `threads` workers inserting concurrently after the first 256 points
+ * (hnsw/build.rs:285-356): like the reference's rayon build the result depends on thread timing. */
+qo_hnsw *qo_hnsw_build_parallel(const qo_storage *st, uint32_t m, uint32_t m0, uint32_t ef_construct,
+                                uint32_t entry_points_num, int use_heuristic, uint64_t seed, int threads);
+void qo_hnsw_free(qo_hnsw *g);
+uint32_t qo_hnsw_point_level(const qo_hnsw *g, uint32_t id);
+uint32_t qo_hnsw_max_level(const qo_hnsw *g);
+/* links of (point, level) into out (capacity m0); returns the count */
+uint32_t qo_hnsw_links(const qo_hnsw *g, uint32_t id, uint32_t level, uint32_t *out);
+/* primary entry points (EntryPoints.entry_points): ids / levels, returns count (call with NULLs to size) */
+uint32_t qo_hnsw_entry_points(const qo_hnsw *g, uint32_t *ids, uint32_t *levels, uint32_t cap);
+/* the plain GraphLinks view (graph_links/view.rs:42-60,211-218 ; serializer.rs:52-87):
+ *   reindex[n]            point -> rank in descending-level order
+ *   level_offsets[L + 1]  index into `offsets` where each level starts (level 0 at 0, n entries), last = total
+ *   offsets[total + 1]    start of each (level, slot) neighbour run in `neighbors`
+ *   neighbors[]           u32 ids
+ * Call once with NULL arrays to get sizes. */
+void qo_hnsw_export_plain(const qo_hnsw *g, uint32_t *n_levels, uint64_t *n_offsets, uint64_t *n_neighbors,
+                          uint32_t *reindex, uint64_t *level_offsets, uint64_t *offsets, uint32_t *neighbors);
+/* GraphLayers::search (graph_layers.rs:530-562) with SearchAlgorithm::Hnsw: entry point, greedy
+ * search_entry down to level 0, search_on_level(ef = max(ef, top)), sorted take(top).
+ * Returns the number of results; *n_scored (optional) counts score_point evaluations. */
+uint32_t qo_hnsw_search(const qo_hnsw *g, const qo_scorer *scorer, uint32_t top, uint32_t ef,
+                        qo_scored_point *out, uint64_t *n_scored);
+/* LinksContainer::fill_from_sorted_with_heuristic (links_container.rs:47-71) and ::connect (:74-103) on
+ * an explicit pairwise score table score[a * n + b]; for the reference's literal test (:312-391). */
+uint32_t qo_links_heuristic(const qo_scored_point *sorted_candidates, uint32_t n_cand, uint32_t level_m,
+                            const float *score_table, uint32_t n, uint32_t *out_links);
+uint32_t qo_links_connect(uint32_t *links, uint32_t len, uint32_t new_point, uint32_t target, uint32_t level_m,
+                          const float *score_table, uint32_t n);
 
 /* ---- synthetic data shared bit-for-bit with the device generator ---- */
 float qo_synth_value(uint64_t seed, uint64_t row, uint32_t col, uint32_t dim);

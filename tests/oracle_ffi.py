@@ -317,3 +317,153 @@ class PqOracle:
     def score_internal(self, a, b):
         return np.array([_lib.qo_pq_score_internal(C.byref(self.pq), _p(self.codes[i]), _p(self.codes[j])) for i, j in zip(a, b)],
                         dtype=np.float32)
+
+
+# ---- cross-segment merge, scorer façade, HNSW (oracle/qdrant_oracle_hnsw.c) --------------------------
+class Scorer(C.Structure):
+    _fields_ = [("kind", C.c_int), ("st", C.POINTER(Storage)), ("query", _P),
+                ("sq", C.POINTER(Sq)), ("sq_rows", _P), ("sq_query", _P), ("sq_query_offset", _f),
+                ("pq", C.POINTER(Pq)), ("pq_codes", _P), ("pq_lut", _P), ("isa", C.c_int)]
+
+
+_sig("qo_merge_topk", None, [_P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P])
+_sig("qo_scorer_score_point", _f, [C.POINTER(Scorer), C.c_uint32])
+_sig("qo_scorer_score_internal", _f, [C.POINTER(Scorer), C.c_uint32, C.c_uint32])
+_sig("qo_hnsw_build", _P, [C.POINTER(Storage), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint64])
+_sig("qo_hnsw_build_parallel", _P, [C.POINTER(Storage), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint64, C.c_int])
+_sig("qo_hnsw_free", None, [_P])
+_sig("qo_hnsw_point_level", C.c_uint32, [_P, C.c_uint32])
+_sig("qo_hnsw_max_level", C.c_uint32, [_P])
+_sig("qo_hnsw_links", C.c_uint32, [_P, C.c_uint32, C.c_uint32, _P])
+_sig("qo_hnsw_entry_points", C.c_uint32, [_P, _P, _P, C.c_uint32])
+_sig("qo_hnsw_export_plain", None, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _P, _P, _P, _P])
+_sig("qo_hnsw_search", C.c_uint32, [_P, C.POINTER(Scorer), C.c_uint32, C.c_uint32, _P, C.POINTER(C.c_uint64)])
+_sig("qo_links_heuristic", C.c_uint32, [_P, C.c_uint32, C.c_uint32, _P, C.c_uint32, _P])
+_sig("qo_links_connect", C.c_uint32, [_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P, C.c_uint32])
+
+
+def merge_topk(lists, counts, k, idx_base=None):
+    """BatchResultAggregator: lists [n_lists, nq, k] ScoredPointOffset, counts [n_lists, nq]."""
+    lists = np.ascontiguousarray(lists, dtype=ScoredPointOffset)
+    n_lists, nq = lists.shape[0], lists.shape[1]
+    counts = None if counts is None else np.ascontiguousarray(counts, dtype=np.uint32)
+    base = None if idx_base is None else np.ascontiguousarray(idx_base, dtype=np.uint32)
+    out = np.zeros((nq, k), dtype=ScoredPointOffset)
+    oc = np.zeros(nq, dtype=np.uint32)
+    _lib.qo_merge_topk(_p(lists), _p(counts), _p(base), n_lists, nq, k, _p(out), _p(oc))
+    return [out[i, :oc[i]].copy() for i in range(nq)]
+
+
+class PlainLinks:
+    """The plain GraphLinks arrays (graph_links/view.rs) + entry points: what qmx_hnsw_create ingests."""
+
+    def __init__(self, m, m0, reindex, level_offsets, offsets, neighbors, ep_ids, ep_levels):
+        self.m, self.m0 = m, m0
+        self.reindex, self.level_offsets, self.offsets, self.neighbors = reindex, level_offsets, offsets, neighbors
+        self.ep_ids, self.ep_levels = ep_ids, ep_levels
+
+    def links(self, point, level):
+        idx = point if level == 0 else int(self.level_offsets[level]) + int(self.reindex[point])
+        return self.neighbors[int(self.offsets[idx]):int(self.offsets[idx + 1])]
+
+
+class Hnsw:
+    """GraphLayersBuilder -> GraphLayers on the CPU oracle, built over a DenseStorage."""
+
+    def __init__(self, storage: DenseStorage, m=16, m0=None, ef_construct=100, entry_points_num=10, use_heuristic=True,
+                 seed=42, threads=0):
+        self.storage = storage
+        self.m, self.m0 = m, (2 * m if m0 is None else m0)
+        if threads and threads > 1:
+            self.h = _lib.qo_hnsw_build_parallel(C.byref(storage.st), self.m, self.m0, ef_construct, entry_points_num,
+                                                 1 if use_heuristic else 0, seed, threads)
+        else:
+            self.h = _lib.qo_hnsw_build(C.byref(storage.st), self.m, self.m0, ef_construct, entry_points_num,
+                                        1 if use_heuristic else 0, seed)
+        self.n = storage.rows.shape[0]
+
+    def __del__(self):
+        try:
+            _lib.qo_hnsw_free(self.h)
+        except Exception:
+            pass
+
+    def point_level(self, i):
+        return _lib.qo_hnsw_point_level(self.h, i)
+
+    def links(self, i, level):
+        buf = np.zeros(self.m0 + self.m, dtype=np.uint32)
+        n = _lib.qo_hnsw_links(self.h, i, level, _p(buf))
+        return buf[:n].copy()
+
+    def entry_points(self):
+        n = _lib.qo_hnsw_entry_points(self.h, None, None, 0)
+        ids, lv = np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.uint32)
+        _lib.qo_hnsw_entry_points(self.h, _p(ids), _p(lv), n)
+        return ids, lv
+
+    def export_plain(self) -> PlainLinks:
+        nl, no, nn = C.c_uint32(), C.c_uint64(), C.c_uint64()
+        _lib.qo_hnsw_export_plain(self.h, C.byref(nl), C.byref(no), C.byref(nn), None, None, None, None)
+        reindex = np.zeros(self.n, dtype=np.uint32)
+        level_offsets = np.zeros(nl.value + 1, dtype=np.uint64)
+        offsets = np.zeros(no.value, dtype=np.uint64)
+        neighbors = np.zeros(max(1, nn.value), dtype=np.uint32)
+        _lib.qo_hnsw_export_plain(self.h, C.byref(nl), C.byref(no), C.byref(nn), _p(reindex), _p(level_offsets), _p(offsets),
+                                  _p(neighbors))
+        ids, lv = self.entry_points()
+        return PlainLinks(self.m, self.m0, reindex, level_offsets, offsets, neighbors[:nn.value], ids, lv)
+
+    # -- searches: one qo_scorer per query ------------------------------------------------------------
+    def _run(self, scorer, top, ef):
+        out = np.zeros(max(top, 1), dtype=ScoredPointOffset)
+        ns = C.c_uint64()
+        n = _lib.qo_hnsw_search(self.h, C.byref(scorer), top, ef, _p(out), C.byref(ns))
+        return out[:n].copy(), ns.value
+
+    def search_dense(self, storage: DenseStorage, queries, top, ef, encoded=False, with_stats=False):
+        q = np.ascontiguousarray(queries, dtype=_NP[storage.dtype]) if encoded else storage.encode_queries(queries)
+        res, stats = [], []
+        for i in range(q.shape[0]):
+            s = Scorer()
+            s.kind, s.st, s.query = 0, C.pointer(storage.st), q[i].ctypes.data
+            r, ns = self._run(s, top, ef)
+            res.append(r)
+            stats.append(ns)
+        return (res, stats) if with_stats else res
+
+    def search_sq(self, flags_storage: DenseStorage, sq: "SqOracle", queries_preprocessed, top, ef):
+        res = []
+        for qv in f32(np.atleast_2d(queries_preprocessed)):
+            codes, off = sq.encode_query(qv)
+            s = Scorer()
+            s.kind, s.st, s.sq, s.sq_rows = 1, C.pointer(flags_storage.st), C.pointer(sq.sq), sq.rows.ctypes.data
+            s.sq_query, s.sq_query_offset, s.isa = codes.ctypes.data, off, sq.isa
+            res.append(self._run(s, top, ef)[0])
+        return res
+
+    def search_pq(self, flags_storage: DenseStorage, pq: "PqOracle", queries_preprocessed, top, ef):
+        res = []
+        for qv in f32(np.atleast_2d(queries_preprocessed)):
+            lut = pq.lut(qv)
+            s = Scorer()
+            s.kind, s.st, s.pq, s.pq_codes = 2, C.pointer(flags_storage.st), C.pointer(pq.pq), pq.codes.ctypes.data
+            s.pq_lut, s.isa = lut.ctypes.data, pq.isa
+            res.append(self._run(s, top, ef)[0])
+        return res
+
+
+def links_heuristic(sorted_candidates, level_m, score_table):
+    c = np.ascontiguousarray(sorted_candidates, dtype=ScoredPointOffset)
+    t = f32(score_table)
+    out = np.zeros(max(level_m, 1), dtype=np.uint32)
+    n = _lib.qo_links_heuristic(_p(c), len(c), level_m, _p(t), t.shape[0], _p(out))
+    return out[:n].tolist()
+
+
+def links_connect(links, new_point, target, level_m, score_table):
+    t = f32(score_table)
+    buf = np.zeros(level_m + 1, dtype=np.uint32)
+    buf[:len(links)] = links
+    n = _lib.qo_links_connect(_p(buf), len(links), new_point, target, level_m, _p(t), t.shape[0])
+    return buf[:n].tolist()

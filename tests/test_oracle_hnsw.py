@@ -1,0 +1,175 @@
+"""CPU tests of the HNSW / merge part of the oracle (oracle/qdrant_oracle_hnsw.c).
+
+Pins the restatement against the reference's literal known-answer test
+lib/segment/src/index/hnsw_index/links_container.rs:312-391 (`test_connect_new_point`) and checks
+the structural invariants the reference's own tests check (graph_layers_builder.rs tests: link
+counts <= level_m, search recall against exact search)."""
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+
+# links_container.rs:349-361: target + 10 points; + = selected by the heuristic
+POINTS = np.array([
+    [21.79, 7.18],   # target
+    [20.58, 5.46],   # + 1 B
+    [21.19, 4.51],   #   2 C
+    [24.73, 8.24],   # + 3 D
+    [24.55, 9.98],   #   4 E
+    [26.11, 6.85],   #   5 F
+    [17.64, 11.14],  # + 6 G
+    [14.97, 11.52],  #   7 I
+    [14.97, 9.60],   #   8 J
+    [16.23, 14.32],  #   9 H
+    [12.69, 19.13],  #  10 K
+], dtype=np.float32)
+
+
+def _score_table():
+    # scorer(a, b) = -sqrt((ax-bx)^2 + (ay-by)^2) in f32 (links_container.rs:363-367)
+    d = POINTS[:, None, :] - POINTS[None, :, :]
+    return (-np.sqrt((d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]).astype(np.float32))).astype(np.float32)
+
+
+def test_reference_heuristic_known_answer():
+    t = _score_table()
+    m = 6
+    ids = list(range(1, len(POINTS)))
+    cand = O.topk_push_all([(i, t[0, i]) for i in ids], len(ids))          # FixedLengthPriorityQueue -> into_iter_sorted
+    assert O.links_heuristic(cand, m, t) == [1, 3, 6]                       # links_container.rs:381
+
+
+@pytest.mark.parametrize("seed", [0, 1, 42, 7])
+def test_reference_connect_known_answer(seed):
+    t = _score_table()
+    m = 6
+    ids = list(range(1, len(POINTS)))
+    np.random.default_rng(seed).shuffle(ids)
+    links = []
+    for i in ids:
+        links = O.links_connect(links, i, 0, m, t)
+    assert links == [1, 2, 3, 4, 5, 6]                                      # links_container.rs:390
+
+
+def _data(n, dim, seed, distance=O.COSINE):
+    raw = O.synth(seed, 0, n, dim)
+    return O.preprocess(distance, raw)
+
+
+def _recall(got, want):
+    hit = sum(len(set(g["idx"].tolist()) & set(w["idx"].tolist())) for g, w in zip(got, want))
+    return hit / sum(len(w) for w in want)
+
+
+@pytest.mark.parametrize("distance", [O.COSINE, O.EUCLID, O.DOT])
+@pytest.mark.parametrize("heuristic", [True, False])
+def test_build_invariants_and_recall(distance, heuristic):
+    n, dim, m = 1500, 24, 8
+    rows = _data(n, dim, 0x5EED0101, distance)
+    st = O.DenseStorage(O.F32, distance, rows)
+    g = O.Hnsw(st, m=m, ef_construct=64, use_heuristic=heuristic, seed=7)
+    levels = np.array([g.point_level(i) for i in range(n)])
+    assert levels.max() >= 1 and 0.55 < (levels == 0).mean() < 0.75      # P(round(-ln U / ln m) = 0) = 1 - m^-0.5 = 0.65 at m = 8
+    for i in range(0, n, 13):
+        for lv in range(levels[i] + 1):
+            ln = g.links(i, lv)
+            assert len(ln) <= (2 * m if lv == 0 else m)
+            assert len(set(ln.tolist())) == len(ln) and i not in ln
+            assert all(levels[j] >= lv for j in ln)
+    ep_ids, ep_levels = g.entry_points()
+    assert len(ep_ids) >= 1 and ep_levels[0] == levels.max()
+    queries = O.synth(0x5EED0102, 0, 20, dim)
+    exact = st.peek_top(queries, 10)
+    got = g.search_dense(st, queries, 10, 64)
+    for r in got:
+        assert len(r) == 10 and np.all(np.diff(r["score"]) <= 0)
+    assert _recall(got, exact) > (0.9 if heuristic else 0.8)
+
+
+def test_build_is_deterministic_and_export_matches():
+    n, dim = 800, 16
+    st = O.DenseStorage(O.F32, O.EUCLID, _data(n, dim, 3, O.EUCLID))
+    g1 = O.Hnsw(st, m=8, ef_construct=32, seed=5)
+    g2 = O.Hnsw(st, m=8, ef_construct=32, seed=5)
+    p1, p2 = g1.export_plain(), g2.export_plain()
+    assert np.array_equal(p1.neighbors, p2.neighbors) and np.array_equal(p1.offsets, p2.offsets)
+    assert np.array_equal(p1.reindex, p2.reindex) and np.array_equal(p1.level_offsets, p2.level_offsets)
+    # plain view == builder links (graph_links/view.rs:211-218 offset_idx)
+    assert int(p1.level_offsets[1]) == n
+    for i in range(n):
+        for lv in range(g1.point_level(i) + 1):
+            assert p1.links(i, lv).tolist() == g1.links(i, lv).tolist()
+    # reindex is a permutation ordered by descending level
+    assert sorted(p1.reindex.tolist()) == list(range(n))
+    lv = np.array([g1.point_level(i) for i in range(n)])
+    order = np.argsort(p1.reindex)
+    assert np.all(np.diff(lv[order]) <= 0)
+
+
+def test_parallel_build_gives_a_searchable_graph():
+    n, dim = 3000, 16
+    st = O.DenseStorage(O.F32, O.COSINE, _data(n, dim, 11))
+    g = O.Hnsw(st, m=8, ef_construct=64, seed=1, threads=4)
+    queries = O.synth(12, 0, 16, dim)
+    assert _recall(g.search_dense(st, queries, 10, 64), st.peek_top(queries, 10)) > 0.9
+
+
+def test_search_respects_deleted_flags_and_ef_semantics():
+    n, dim = 1200, 16
+    rows = _data(n, dim, 21)
+    deleted = np.zeros(n, dtype=bool)
+    deleted[::3] = True
+    st_all = O.DenseStorage(O.F32, O.COSINE, rows)
+    g = O.Hnsw(st_all, m=8, ef_construct=64, seed=2)
+    st_del = O.DenseStorage(O.F32, O.COSINE, rows, point_deleted=deleted)
+    queries = O.synth(22, 0, 10, dim)
+    got = g.search_dense(st_del, queries, 10, 128)
+    for r in got:
+        assert not deleted[r["idx"]].any()
+    assert _recall(got, st_del.peek_top(queries, 10)) > 0.85
+    # ef = max(ef, top) (graph_layers.rs:551): ef=1, top=10 still returns 10
+    assert all(len(r) == 10 for r in g.search_dense(st_all, queries, 10, 1))
+
+
+def test_sq_and_pq_scorers_drive_the_same_graph():
+    n, dim = 1000, 32
+    rows = _data(n, dim, 31, O.DOT)
+    st = O.DenseStorage(O.F32, O.DOT, rows)
+    g = O.Hnsw(st, m=8, ef_construct=64, seed=3)
+    queries = O.synth(32, 0, 8, dim)
+    exact = st.peek_top(queries, 10)
+    sq = O.SqOracle(O.DOT, dim, (rows.max() - rows.min()) / 127.0, rows.min())
+    sq.encode_rows(rows)
+    r_sq = g.search_sq(st, sq, queries, 10, 64)
+    assert _recall(r_sq, exact) > 0.4            # hnsw_quantized_search_test.rs:248-330 asks for > 40 %
+    cen = O.PqOracle.train(rows, dim, 4, 256, iters=3)
+    pq = O.PqOracle(O.DOT, dim, 4, cen)
+    pq.encode(rows)
+    r_pq = g.search_pq(st, pq, queries, 10, 64)
+    assert _recall(r_pq, exact) > 0.4
+
+
+def test_merge_matches_a_single_queue():
+    rng = np.random.default_rng(5)
+    n_lists, nq, k = 5, 7, 10
+    lists = np.zeros((n_lists, nq, k), dtype=O.ScoredPointOffset)
+    counts = rng.integers(0, k + 1, size=(n_lists, nq)).astype(np.uint32)
+    base = (np.arange(n_lists) * 1000).astype(np.uint32)
+    for l in range(n_lists):
+        for q in range(nq):
+            s = np.sort(rng.standard_normal(k).astype(np.float32))[::-1]
+            lists[l, q]["score"] = s
+            lists[l, q]["idx"] = rng.permutation(1000)[:k]
+    got = O.merge_topk(lists, counts, k, base)
+    for q in range(nq):
+        allp = [(int(lists[l, q, i]["idx"]) + int(base[l]), float(lists[l, q, i]["score"]))
+                for l in range(n_lists) for i in range(counts[l, q])]
+        want = O.topk_push_all(allp, k)
+        assert got[q]["idx"].tolist() == want["idx"].tolist()
+        assert got[q]["score"].tolist() == want["score"].tolist()
+    # duplicates of an id are dropped after the first occurrence (search_result_aggregator.rs:33-36)
+    dup = np.zeros((2, 1, 3), dtype=O.ScoredPointOffset)
+    dup[0, 0] = [(5, 3.0), (6, 2.0), (7, 1.0)]
+    dup[1, 0] = [(5, 9.0), (8, 2.5), (9, 0.5)]
+    r = O.merge_topk(dup, None, 3)[0]
+    assert r["idx"].tolist() == [5, 8, 6] and r["score"].tolist() == [3.0, 2.5, 2.0]
