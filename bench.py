@@ -85,31 +85,22 @@ def main():
     F.check(lib.qmx_synth_fill_f32(local_rank, seed + 1, 0, nbatches * Q, dim, F.ptr(queries)))
     qbytes = Q * dim * 4
 
-    qh = C.c_void_p()
-    F.check(lib.qmx_query_create(storage._h, F.ptr(queries), Q, C.byref(qh)))
     stream = torch.cuda.Stream(dev)  # every kernel, the RCCL gather and the merge are ordered on this stream
     torch.cuda.set_stream(stream)
-    F.check(lib.qmx_query_set_stream(qh, C.c_void_p(stream.cuda_stream)))
+    from qdrant_amd import sharded
+    backend = sharded.HipBackend(storage, Q, local_rank, stream)      # owns the qmx_query of this rank
+    qh = backend.qh
     F.check(lib.qmx_query_set_timing(qh, 1))
-
-    out = torch.zeros((Q, top, 2), dtype=torch.int32, device=dev)       # ScoredPointOffset rows
-    counts = torch.zeros((Q,), dtype=torch.int32, device=dev)
-    if world > 1:
-        gathered = torch.zeros((world, Q, top, 2), dtype=torch.int32, device=dev)
-        gcounts = torch.zeros((world, Q), dtype=torch.int32, device=dev)
-        idx_base = (torch.arange(world, dtype=torch.int64, device=dev) * n).to(torch.int32)
-        merged = torch.zeros((Q, top, 2), dtype=torch.int32, device=dev)
-        mcounts = torch.zeros((Q,), dtype=torch.int32, device=dev)
+    searcher = sharded.ShardedSearcher(backend, n, Q, top, device=dev)  # scan -> all-gather -> merge (world > 1)
+    out, counts = searcher.out, searcher.counts
 
     def step(i):
         b = i % nbatches
-        F.check(lib.qmx_query_update(qh, C.c_void_p(queries.data_ptr() + b * qbytes)))
-        F.check(lib.qmx_search_topk_async(qh, top, None, 0, F.ptr(out), F.ptr(counts)))
+        qb = queries[b * Q:(b + 1) * Q]
         if world > 1:
-            dist.all_gather_into_tensor(gathered, out)
-            dist.all_gather_into_tensor(gcounts, counts)
-            F.check(lib.qmx_merge_topk_async(local_rank, C.c_void_p(stream.cuda_stream), F.ptr(gathered), F.ptr(gcounts),
-                                             F.ptr(idx_base), world, Q, top, F.ptr(merged), F.ptr(mcounts)))
+            searcher.search(qb)
+        else:
+            backend.local_topk(qb, top, out, counts)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -171,7 +162,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline(args, rows, queries, out, counts, n, dim, Q, top, lib, qh, F, qa, np, torch)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    lib.qmx_query_destroy(qh)
+    backend.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -1,0 +1,133 @@
+"""Segment-sharded search: one process per GPU, one (or more) segments per process.
+
+The reference searches every segment of a shard independently and merges the per-segment top-k lists
+(`SegmentsSearcher::search`, lib/collection/src/collection_manager/segments_searcher.rs:212-285 ->
+`BatchResultAggregator`, lib/shard/src/search_result_aggregator.rs:50-121).  Here a segment lives on one
+GPU, every rank scores the same query batch against its own segment and the only exchange step is an
+all-gather of `Q x top x 8` bytes per rank (RCCL over xGMI under `torch.distributed`, backend "nccl"),
+followed by the k-way merge with segment-local offsets globalised by a per-segment id base.
+
+Host logic only.  The two compute steps are delegated to a backend object:
+  * `HipBackend`   — the product: qmx_search_topk_async + qmx_merge_topk_async of libqdrant_amd.so
+                     (fails loudly without a gfx950 device; there is no CPU fallback here);
+  * tests inject an oracle-based backend to exercise the collective / id-globalisation logic on CPU
+    with the gloo backend (tests/test_sharded_gloo.py).
+"""
+import ctypes as C
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from . import _ffi as F
+
+
+def _world(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def segment_id_bases(n_local: int, group=None, device=None) -> torch.Tensor:
+    """Exclusive prefix sum of the segment sizes over ranks: segment-local offset + base[rank] is the
+    collection-wide id (the reference maps (segment, offset) to an external point id through the
+    id tracker, lib/segment/src/id_tracker; disjoint ranges are the synthetic stand-in for it)."""
+    rank, world = _world(group)
+    sizes = torch.zeros(world, dtype=torch.int64, device=device)
+    if world > 1:
+        mine = torch.tensor([n_local], dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(sizes, mine, group=group)
+    else:
+        sizes[0] = n_local
+    base = torch.cumsum(sizes, 0) - sizes
+    if int(base[-1] + sizes[-1]) > 0xFFFFFFFF:
+        raise ValueError("globalised ids exceed PointOffsetType (u32)")
+    return base.to(torch.int32)  # bit pattern of u32
+
+
+def gather_topk(local_out: torch.Tensor, local_counts: torch.Tensor, gathered: Optional[torch.Tensor] = None,
+                gcounts: Optional[torch.Tensor] = None, group=None):
+    """All-gather of the per-rank result lists.
+    local_out [Q, top, 2] int32 (ScoredPointOffset rows: idx bits, f32 score bits), local_counts [Q] int32
+    -> gathered [world, Q, top, 2], gcounts [world, Q]  (list l = rank l's segment)."""
+    rank, world = _world(group)
+    if gathered is None:
+        gathered = torch.empty((world,) + tuple(local_out.shape), dtype=local_out.dtype, device=local_out.device)
+    if gcounts is None:
+        gcounts = torch.empty((world,) + tuple(local_counts.shape), dtype=local_counts.dtype, device=local_counts.device)
+    if world == 1:
+        gathered[0].copy_(local_out)
+        gcounts[0].copy_(local_counts)
+    else:
+        # output viewed as the concatenation along dim 0 (the layout both RCCL and gloo accept)
+        dist.all_gather_into_tensor(gathered.view((-1,) + tuple(local_out.shape[1:])), local_out.contiguous(), group=group)
+        dist.all_gather_into_tensor(gcounts.view(-1), local_counts.contiguous(), group=group)
+    return gathered, gcounts
+
+
+class HipBackend:
+    """Local brute-force top-k and the merge, both on this rank's GPU through the C-ABI."""
+
+    def __init__(self, storage, nq: int, device_id: int, stream: Optional[torch.cuda.Stream] = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipBackend needs a gfx950 device; qdrant_amd has no CPU fallback")
+        self.lib = F.lib()
+        self.storage = storage
+        self.nq = nq
+        self.device_id = device_id
+        self.device = torch.device("cuda", device_id)
+        self.stream = stream or torch.cuda.current_stream(self.device)
+        self.qh = C.c_void_p()
+        zeros = torch.zeros((nq, storage.dim), dtype=torch.float32, device=self.device)
+        F.check(self.lib.qmx_query_create(storage._h, F.ptr(zeros), nq, C.byref(self.qh)))
+        F.check(self.lib.qmx_query_set_stream(self.qh, C.c_void_p(self.stream.cuda_stream)))
+
+    def local_topk(self, queries: torch.Tensor, top: int, out: torch.Tensor, counts: torch.Tensor):
+        """queries [nq, dim] f32 on this device (original, un-preprocessed); enqueues only."""
+        assert queries.is_cuda and queries.shape[0] == self.nq
+        F.check(self.lib.qmx_query_update(self.qh, F.ptr(queries)))
+        F.check(self.lib.qmx_search_topk_async(self.qh, top, None, 0, F.ptr(out), F.ptr(counts)))
+
+    def merge(self, gathered, gcounts, idx_base, top: int, merged, mcounts):
+        n_lists, nq = gathered.shape[0], gathered.shape[1]
+        F.check(self.lib.qmx_merge_topk_async(self.device_id, C.c_void_p(self.stream.cuda_stream), F.ptr(gathered),
+                                              F.ptr(gcounts), F.ptr(idx_base), n_lists, nq, top, F.ptr(merged),
+                                              F.ptr(mcounts)))
+
+    def close(self):
+        if self.qh:
+            self.lib.qmx_query_destroy(self.qh)
+            self.qh = C.c_void_p()
+
+
+class ShardedSearcher:
+    """search(queries) on every rank returns the merged top-k over all ranks' segments.
+
+    All buffers are allocated once; `search` only enqueues work on the backend's stream
+    (scan -> all-gather -> merge are ordered on that stream), so consecutive batches pipeline."""
+
+    def __init__(self, backend, n_local: int, nq: int, top: int, device=None, group=None):
+        self.backend, self.nq, self.top, self.group = backend, nq, top, group
+        self.rank, self.world = _world(group)
+        self.device = device if device is not None else getattr(backend, "device", torch.device("cpu"))
+        dev = self.device
+        self.idx_base = segment_id_bases(n_local, group, dev)
+        self.out = torch.zeros((nq, top, 2), dtype=torch.int32, device=dev)
+        self.counts = torch.zeros((nq,), dtype=torch.int32, device=dev)
+        self.gathered = torch.zeros((self.world, nq, top, 2), dtype=torch.int32, device=dev)
+        self.gcounts = torch.zeros((self.world, nq), dtype=torch.int32, device=dev)
+        self.merged = torch.zeros((nq, top, 2), dtype=torch.int32, device=dev)
+        self.mcounts = torch.zeros((nq,), dtype=torch.int32, device=dev)
+
+    def search(self, queries):
+        self.backend.local_topk(queries, self.top, self.out, self.counts)
+        gather_topk(self.out, self.counts, self.gathered, self.gcounts, self.group)
+        self.backend.merge(self.gathered, self.gcounts, self.idx_base, self.top, self.merged, self.mcounts)
+        return self.merged, self.mcounts
+
+    def results(self):
+        """Host copy of the last search: list of (idx u32 [c], score f32 [c]) per query (synchronises)."""
+        m = self.merged.cpu().numpy()
+        c = self.mcounts.cpu().numpy()
+        import numpy as np
+        return [(m[i, :c[i], 0].view(np.uint32).copy(), m[i, :c[i], 1].copy().view(np.float32)) for i in range(self.nq)]

@@ -1,0 +1,108 @@
+"""N>1 path on CPU: world_size-2 (and 3) gloo process groups drive qdrant_amd.sharded with the oracle
+injected as the compute backend (the checker stands in for the two HIP calls; everything else — id
+bases, the all-gather layout, buffer reuse across batches, the merge contract — is the product code).
+The merged result must equal the oracle's exact search over the concatenation of all segments."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class OracleBackend:
+    """local_topk / merge with the CPU oracle (test only)."""
+
+    def __init__(self, O, rows, distance):
+        self.O = O
+        self.st = O.DenseStorage(O.F32, distance, rows)
+        self.device = torch.device("cpu")
+
+    def local_topk(self, queries, top, out, counts):
+        res = self.st.peek_top(queries.numpy(), top)
+        o = out.numpy()
+        o[:] = 0
+        for i, r in enumerate(res):
+            o[i, :len(r), 0] = r["idx"].view(np.int32)
+            o[i, :len(r), 1] = r["score"].view(np.int32)
+            counts[i] = len(r)
+
+    def merge(self, gathered, gcounts, idx_base, top, merged, mcounts):
+        O = self.O
+        g = gathered.numpy()
+        lists = np.zeros(g.shape[:3], dtype=O.ScoredPointOffset)
+        lists["idx"] = g[..., 0].view(np.uint32)
+        lists["score"] = g[..., 1].copy().view(np.float32)
+        res = O.merge_topk(lists, gcounts.numpy().astype(np.uint32), top, idx_base.numpy().view(np.uint32))
+        m = merged.numpy()
+        m[:] = 0
+        for i, r in enumerate(res):
+            m[i, :len(r), 0] = r["idx"].view(np.int32)
+            m[i, :len(r), 1] = r["score"].view(np.int32)
+            mcounts[i] = len(r)
+
+
+def _worker(rank, world, port, sizes, dim, nq, top, distance):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle_ffi as O
+        from qdrant_amd import sharded
+        seed = 0x5EED0005
+        rows = O.preprocess(distance, O.synth(seed + 16 * rank, 0, sizes[rank], dim))
+        backend = OracleBackend(O, rows, distance)
+        s = sharded.ShardedSearcher(backend, sizes[rank], nq, top)
+        base = s.idx_base.numpy().view(np.uint32)
+        assert base.tolist() == np.concatenate([[0], np.cumsum(sizes)[:-1]]).tolist()
+        # single-process truth over the union of all segments
+        all_rows = np.concatenate([O.preprocess(distance, O.synth(seed + 16 * r, 0, sizes[r], dim)) for r in range(world)])
+        truth = O.DenseStorage(O.F32, distance, all_rows)
+        for batch in range(3):     # buffers are reused across batches
+            queries = O.synth(seed + 1, batch * nq, nq, dim)
+            s.search(torch.from_numpy(queries))
+            got = s.results()
+            want = truth.peek_top(queries, top)
+            for (gi, gs), w in zip(got, want):
+                assert gi.tolist() == w["idx"].tolist(), (rank, batch)
+                assert gs.tolist() == w["score"].tolist()
+        # every rank holds the same merged lists
+        mine = s.merged.clone()
+        allm = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allm, mine)
+        for m in allm:
+            assert torch.equal(m, mine)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,sizes", [(2, [700, 500]), (3, [300, 5, 450])])
+def test_sharded_search_matches_single_process(world, sizes):
+    import oracle_ffi  # noqa: F401  (builds the oracle before the workers start)
+    mp.spawn(_worker, args=(world, _free_port(), sizes, 48, 5, 10, 0), nprocs=world, join=True)
+
+
+def test_gather_topk_single_process_is_a_copy():
+    sys.path.insert(0, ROOT)
+    from qdrant_amd import sharded
+    out = torch.arange(2 * 3 * 2, dtype=torch.int32).reshape(2, 3, 2)
+    cnt = torch.tensor([3, 1], dtype=torch.int32)
+    g, gc = sharded.gather_topk(out, cnt)
+    assert g.shape == (1, 2, 3, 2) and torch.equal(g[0], out) and torch.equal(gc[0], cnt)
+    assert sharded.segment_id_bases(123).tolist() == [0]
