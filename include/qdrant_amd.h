@@ -278,8 +278,10 @@ QMX_API int32_t qmx_rescore(qmx_query *q, const uint32_t *ids, const uint32_t *c
                             uint32_t *out_counts);
 
 /* k-way merge of per-segment / per-GPU result lists = `BatchResultAggregator`
- * (lib/shard/src/search_result_aggregator.rs:50-121) restricted to disjoint id spaces:
- * lists[(l * nq + qi) * k ..], idx already globalised by the caller.  Runs on `device_id`. */
+ * (lib/shard/src/search_result_aggregator.rs:50-121) with all point versions equal:
+ * lists[(l * nq + qi) * k ..], idx already globalised by the caller.  Items are pushed in list
+ * order; an id already seen in an earlier item is dropped whatever its score (`seen.insert`,
+ * :28-37).  n_lists * k <= 16384.  Runs on `device_id`. */
 QMX_API int32_t qmx_merge_topk(int32_t device_id, const qmx_scored_point *lists,
                                const uint32_t *list_counts, uint32_t n_lists, uint32_t nq,
                                uint32_t k, qmx_scored_point *out, uint32_t *out_counts);
@@ -291,6 +293,61 @@ QMX_API int32_t qmx_merge_topk_async(int32_t device_id, void *hip_stream, const 
                                      const uint32_t *list_counts_dev, const uint32_t *list_idx_base_dev,
                                      uint32_t n_lists, uint32_t nq, uint32_t k, qmx_scored_point *out_dev,
                                      uint32_t *out_counts_dev);
+
+/* ---- HNSW search on device -------------------------------------------------------------------- */
+
+/* One built graph = `GraphLayers` (lib/segment/src/index/hnsw_index/graph_layers.rs:58-72): the
+ * plain `GraphLinks` arrays exactly as `GraphLinksSerializer` lays them out
+ * (graph_links/serializer.rs:52-176, read by graph_links/view.rs) plus `EntryPoints`
+ * (entry_points.rs:10-16).  Links of point p on level 0 are
+ * neighbors[offsets[p] .. offsets[p + 1]); on level l > 0 the slot is
+ * level_offsets[l] + reindex[p].  All arrays host or device; they are copied to HBM. */
+typedef struct qmx_hnsw_desc {
+    uint32_t m;                       /* HnswM.m  (links per point on levels > 0)  */
+    uint32_t m0;                      /* HnswM.m0 (links per point on level 0)     */
+    uint32_t n_points;                /* == rows of the segment searched            */
+    uint32_t n_levels;                /* levels_count = max level + 1               */
+    const uint32_t *reindex;          /* [n_points]                                 */
+    const uint64_t *level_offsets;    /* [n_levels + 1]; last = n_offsets - 1       */
+    const uint64_t *offsets;          /* [n_offsets]                                */
+    uint64_t n_offsets;
+    const uint32_t *neighbors;        /* [n_neighbors]                              */
+    uint64_t n_neighbors;
+    const uint32_t *entry_point_ids;  /* EntryPoints::entry_points, in order        */
+    const uint32_t *entry_point_levels;
+    uint32_t n_entry_points;
+    uint32_t n_extra_entry_points;    /* EntryPoints::extra_entry_points (iter_unsorted order), may be 0 */
+    const uint32_t *extra_entry_point_ids;
+    const uint32_t *extra_entry_point_levels;
+    int32_t device_id;
+    int32_t reserved;
+} qmx_hnsw_desc;
+
+typedef struct qmx_hnsw qmx_hnsw;
+
+/* Uploads the graph (replaces `GraphLayers::load` for the search side).  Immutable afterwards and
+ * safe for concurrent searches from any number of threads (each with its own qmx_query). */
+QMX_API int32_t qmx_hnsw_create(const qmx_hnsw_desc *desc, qmx_hnsw **out);
+QMX_API int32_t qmx_hnsw_destroy(qmx_hnsw *g);
+
+/* `GraphLayers::search(top, ef, SearchAlgorithm::Hnsw, FilteredScorer, None, is_stopped)`
+ * (graph_layers.rs:530-562) for every query of the batch `q`, entirely on device: entry point
+ * selection under the segment's deleted flags, greedy descent through the upper levels
+ * (`search_entry`, :247-317), the ef-bounded beam on level 0 (`search_on_level`, :108-149) and
+ * `into_iter_sorted().take(top)`.  `q` may belong to a dense, SQ or PQ segment (the quantized
+ * scorer of `is_quantized_search`); rescoring with the original vectors is a separate
+ * qmx_rescore call, as in hnsw/read_view/search.rs.  ef is raised to `top` (:549); ef <= 512.
+ *   out : [nq][top], out_counts : [nq].  Results equal the reference's whenever the scores met
+ *   on the walk are distinct (ties are BinaryHeap-order dependent in the reference).
+ *   counters->vectors_scored = points scored over all searches (HardwareCounter cpu). */
+QMX_API int32_t qmx_hnsw_search(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
+                                qmx_scored_point *out, uint32_t *out_counts,
+                                const volatile uint8_t *is_stopped, qmx_counters *counters);
+/* Same, only enqueued on the query's stream; outputs in device memory.
+ * `out_scored_dev` ([nq] points scored per search) may be NULL. */
+QMX_API int32_t qmx_hnsw_search_async(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
+                                      qmx_scored_point *out_dev, uint32_t *out_counts_dev,
+                                      uint32_t *out_scored_dev);
 
 /* ---- quantizers -------------------------------------------------------------------------------- */
 

@@ -175,6 +175,7 @@ uint32_t qo_hnsw_max_level(const qo_hnsw *g);
 uint32_t qo_hnsw_links(const qo_hnsw *g, uint32_t id, uint32_t level, uint32_t *out);
 /* primary entry points (EntryPoints.entry_points): ids / levels, returns count (call with NULLs to size) */
 uint32_t qo_hnsw_entry_points(const qo_hnsw *g, uint32_t *ids, uint32_t *levels, uint32_t cap);
+uint32_t qo_hnsw_extra_entry_points(const qo_hnsw *g, uint32_t *ids, uint32_t *levels, uint32_t cap);
 /* the plain GraphLinks view (graph_links/view.rs:42-60,211-218 ; serializer.rs:52-87):
  *   reindex[n]            point -> rank in descending-level order
  *   level_offsets[L + 1]  index into `offsets` where each level starts (level 0 at 0, n entries), last = total

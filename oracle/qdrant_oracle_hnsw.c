@@ -185,6 +185,15 @@ uint32_t qo_hnsw_entry_points(const qo_hnsw *g, uint32_t *ids, uint32_t *levels,
     return g->ep_len;
 }
 
+/* EntryPoints::extra_entry_points in iter_unsorted order (entry_points.rs:13-15) */
+uint32_t qo_hnsw_extra_entry_points(const qo_hnsw *g, uint32_t *ids, uint32_t *levels, uint32_t cap) {
+    for (uint32_t i = 0; i < g->xp_len && i < cap; i++) {
+        if (ids) ids[i] = g->xp_ids[i];
+        if (levels) levels[i] = g->xp_levels[i];
+    }
+    return g->xp_len;
+}
+
 void qo_hnsw_free(qo_hnsw *g) {
     if (!g) return;
     for (uint32_t i = 0; i < g->n; i++) { free(g->links[i]); free(g->lens[i]); }

@@ -49,6 +49,15 @@ class SegmentDesc(C.Structure):
                 ("pq", C.POINTER(PqParams))]
 
 
+class HnswDesc(C.Structure):
+    _fields_ = [("m", C.c_uint32), ("m0", C.c_uint32), ("n_points", C.c_uint32), ("n_levels", C.c_uint32),
+                ("reindex", C.c_void_p), ("level_offsets", C.c_void_p), ("offsets", C.c_void_p), ("n_offsets", C.c_uint64),
+                ("neighbors", C.c_void_p), ("n_neighbors", C.c_uint64),
+                ("entry_point_ids", C.c_void_p), ("entry_point_levels", C.c_void_p), ("n_entry_points", C.c_uint32),
+                ("n_extra_entry_points", C.c_uint32), ("extra_entry_point_ids", C.c_void_p),
+                ("extra_entry_point_levels", C.c_void_p), ("device_id", C.c_int32), ("reserved", C.c_int32)]
+
+
 class QmxError(RuntimeError):
     def __init__(self, status, message):
         self.status = status
@@ -88,6 +97,10 @@ SIGNATURES = {
     "qmx_rescore": (C.c_int32, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, _P]),
     "qmx_merge_topk": (C.c_int32, [C.c_int32, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P]),
     "qmx_merge_topk_async": (C.c_int32, [C.c_int32, _P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P]),
+    "qmx_hnsw_create": (C.c_int32, [C.POINTER(HnswDesc), C.POINTER(_P)]),
+    "qmx_hnsw_destroy": (C.c_int32, [_P]),
+    "qmx_hnsw_search": (C.c_int32, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, _P, C.POINTER(Counters)]),
+    "qmx_hnsw_search_async": (C.c_int32, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, _P]),
     "qmx_sq_encode": (C.c_int32, [C.c_int32, C.c_uint32, C.POINTER(SqParams), _P, C.c_uint64, C.c_uint32, _P]),
     "qmx_pq_encode": (C.c_int32, [C.c_int32, C.POINTER(PqParams), _P, C.c_uint64, C.c_uint32, _P]),
     "qmx_synth_fill_f32": (C.c_int32, [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, _P]),

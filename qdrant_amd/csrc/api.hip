@@ -173,6 +173,9 @@ struct qmx_query {
     float timing_ms = 0.f;
     uint32_t timing_launches = 0;
     DevBuf partial, out, counts, ids, scores, misc, enc;
+    DevBuf hnsw_vis, hnsw_log, hnsw_scored;   // HNSW scratch: per-slot visited bitmaps (kept all-zero between launches) + logs
+    uint32_t hnsw_slots = 0;
+    uint64_t hnsw_vis_words = 0;
     int *d_err = nullptr;
     uint32_t partial_grid_cap = 0;
     bool timing = false;
@@ -668,6 +671,9 @@ int32_t qmx_query_destroy(qmx_query *q) {
     q->scores.release();
     q->misc.release();
     q->enc.release();
+    q->hnsw_vis.release();
+    q->hnsw_log.release();
+    q->hnsw_scored.release();
     for (auto &p : q->evs) {
         if (p.a) (void)hipEventDestroy(p.a);
         if (p.b) (void)hipEventDestroy(p.b);
@@ -964,6 +970,225 @@ int32_t qmx_merge_topk_async(int32_t device_id, void *hip_stream, const qmx_scor
                                out_dev, out_counts_dev);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// HNSW search on device
+// ---------------------------------------------------------------------------------------------
+struct qmx_hnsw {
+    int device = 0;
+    uint32_t m = 0, m0 = 0, n_points = 0, n_levels = 0, n_ep = 0, n_xp = 0;
+    uint64_t n_offsets = 0, n_neighbors = 0;
+    uint32_t *d_reindex = nullptr, *d_neighbors = nullptr, *d_ep_ids = nullptr, *d_ep_levels = nullptr, *d_xp_ids = nullptr,
+             *d_xp_levels = nullptr;
+    uint64_t *d_level_offsets = nullptr, *d_offsets = nullptr;
+};
+
+int32_t qmx_hnsw_destroy(qmx_hnsw *g) {
+    if (!g) return QMX_OK;
+    (void)hipSetDevice(g->device);
+    void *ptrs[] = {g->d_reindex, g->d_neighbors, g->d_ep_ids, g->d_ep_levels, g->d_xp_ids, g->d_xp_levels, g->d_level_offsets, g->d_offsets};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete g;
+    return QMX_OK;
+}
+
+static int32_t upload_bytes(void **dst, const void *src, uint64_t count, size_t elem) {
+    *dst = nullptr;
+    const size_t bytes = std::max<size_t>((size_t)count * elem, elem);
+    QMX_HIP(hipMalloc(dst, bytes));
+    if (count) QMX_HIP(hipMemcpy(*dst, src, (size_t)count * elem, hipMemcpyDefault));
+    return QMX_OK;
+}
+static int32_t upload_array(uint32_t **dst, const uint32_t *src, uint64_t count) { return upload_bytes((void **)dst, src, count, 4); }
+static int32_t upload_array(uint64_t **dst, const uint64_t *src, uint64_t count) { return upload_bytes((void **)dst, src, count, 8); }
+
+int32_t qmx_hnsw_create(const qmx_hnsw_desc *d, qmx_hnsw **out) {
+    QMX_REQUIRE(d && out, QMX_ERR_BAD_ARG, "NULL argument");
+    *out = nullptr;
+    QMX_REQUIRE(d->m >= 1 && d->m0 >= 1, QMX_ERR_BAD_ARG, "m / m0 must be > 0");
+    QMX_REQUIRE(d->n_points == 0 || (d->n_levels >= 1 && d->reindex && d->level_offsets && d->offsets), QMX_ERR_BAD_ARG,
+                "graph arrays missing");
+    QMX_REQUIRE(d->n_neighbors == 0 || d->neighbors, QMX_ERR_BAD_ARG, "neighbors missing");
+    QMX_REQUIRE(d->n_entry_points == 0 || (d->entry_point_ids && d->entry_point_levels), QMX_ERR_BAD_ARG, "entry points missing");
+    QMX_REQUIRE(d->n_extra_entry_points == 0 || (d->extra_entry_point_ids && d->extra_entry_point_levels), QMX_ERR_BAD_ARG,
+                "extra entry points missing");
+    QMX_REQUIRE(d->n_points == 0 || d->n_offsets >= (uint64_t)d->n_points + 1, QMX_ERR_BAD_ARG,
+                "offsets must hold n_points + 1 entries at least (level 0 has a slot per point)");
+    QMX_TRY(check_device(d->device_id, nullptr));
+    // structural checks on host-visible arrays (a corrupt links file must not crash the GPU)
+    if (d->n_points && !is_device_ptr(d->level_offsets)) {
+        QMX_REQUIRE(d->level_offsets[0] == 0 && d->level_offsets[d->n_levels] + 1 == d->n_offsets, QMX_ERR_BAD_ARG,
+                    "level_offsets do not span the offsets array");
+        for (uint32_t l = 0; l < d->n_levels; ++l)
+            QMX_REQUIRE(d->level_offsets[l] <= d->level_offsets[l + 1], QMX_ERR_BAD_ARG, "level_offsets must be non-decreasing");
+        QMX_REQUIRE(d->level_offsets[d->n_levels > 1 ? 1 : d->n_levels] == d->n_points, QMX_ERR_BAD_ARG,
+                    "level 0 must have one slot per point");
+    }
+    if (d->n_points && !is_device_ptr(d->offsets)) {
+        for (uint64_t i = 0; i + 1 < d->n_offsets; ++i)
+            QMX_REQUIRE(d->offsets[i] <= d->offsets[i + 1], QMX_ERR_BAD_ARG, "offsets must be non-decreasing");
+        QMX_REQUIRE(d->offsets[d->n_offsets - 1] <= d->n_neighbors, QMX_ERR_BAD_ARG, "offsets run past the neighbors array");
+    }
+    for (uint32_t i = 0; i < d->n_entry_points && !is_device_ptr(d->entry_point_ids); ++i)
+        QMX_REQUIRE(d->entry_point_ids[i] < d->n_points, QMX_ERR_OUT_OF_BOUNDS, "entry point %u out of range", d->entry_point_ids[i]);
+    for (uint32_t i = 0; i < d->n_extra_entry_points && !is_device_ptr(d->extra_entry_point_ids); ++i)
+        QMX_REQUIRE(d->extra_entry_point_ids[i] < d->n_points, QMX_ERR_OUT_OF_BOUNDS, "extra entry point out of range");
+    qmx_hnsw *g = new (std::nothrow) qmx_hnsw();
+    QMX_REQUIRE(g, QMX_ERR_OUT_OF_MEMORY, "host allocation failed");
+    g->device = d->device_id;
+    g->m = d->m; g->m0 = d->m0; g->n_points = d->n_points; g->n_levels = d->n_levels;
+    g->n_ep = d->n_entry_points; g->n_xp = d->n_extra_entry_points;
+    g->n_offsets = d->n_offsets; g->n_neighbors = d->n_neighbors;
+    int32_t rc = QMX_OK;
+    do {
+        if ((rc = upload_array(&g->d_reindex, d->reindex, d->n_points)) != QMX_OK) break;
+        if ((rc = upload_array(&g->d_level_offsets, d->level_offsets, d->n_points ? (uint64_t)d->n_levels + 1 : 0)) != QMX_OK) break;
+        if ((rc = upload_array(&g->d_offsets, d->offsets, d->n_points ? d->n_offsets : 0)) != QMX_OK) break;
+        if ((rc = upload_array(&g->d_neighbors, d->neighbors, d->n_neighbors)) != QMX_OK) break;
+        if ((rc = upload_array(&g->d_ep_ids, d->entry_point_ids, d->n_entry_points)) != QMX_OK) break;
+        if ((rc = upload_array(&g->d_ep_levels, d->entry_point_levels, d->n_entry_points)) != QMX_OK) break;
+        if ((rc = upload_array(&g->d_xp_ids, d->extra_entry_point_ids, d->n_extra_entry_points)) != QMX_OK) break;
+        if ((rc = upload_array(&g->d_xp_levels, d->extra_entry_point_levels, d->n_extra_entry_points)) != QMX_OK) break;
+    } while (0);
+    if (rc != QMX_OK) {
+        qmx_hnsw_destroy(g);
+        return rc;
+    }
+    *out = g;
+    return QMX_OK;
+}
+
+static int32_t launch_hnsw(const qmx_query *q, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
+    const qmx_segment *s = q->seg;
+    if (s->dtype <= QMX_DTYPE_U8) {
+        QMX_REQUIRE(s->fast_layout(), QMX_ERR_NOT_SUPPORTED, "adopted device block is not 16-byte aligned");
+        return launch_hnsw_dense(q->stream, (int)s->dtype, (int)s->distance, a, h, grid, per_cu);
+    }
+    if (s->dtype == QMX_DTYPE_SQ_U8) return launch_hnsw_sq(q->stream, (int)s->distance, a, h, grid, per_cu);
+    if (s->dtype == QMX_DTYPE_PQ) return launch_hnsw_pq(q->stream, a, h, grid, per_cu);
+    set_error("dtype %u not built yet", s->dtype);
+    return QMX_ERR_NOT_SUPPORTED;
+}
+
+constexpr uint32_t HNSW_SLOT_CAP = 4096;
+constexpr uint32_t HNSW_LOG_CAP = 16384;                    // words logged per search before falling back to a full clear
+constexpr uint64_t HNSW_VIS_BUDGET = 8ull << 30;            // bytes of visited bitmaps per query handle
+
+static int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef, qmx_scored_point *d_out,
+                            uint32_t *d_counts, uint32_t *d_scored, bool timed) {
+    const qmx_segment *s = q->seg;
+    ScanArgs a;
+    fill_args(q, 0, q->nq, a);
+    HnswArgs h;
+    memset(&h, 0, sizeof(h));
+    h.reindex = g->d_reindex; h.level_offsets = g->d_level_offsets; h.offsets = g->d_offsets; h.neighbors = g->d_neighbors;
+    h.n_points = g->n_points; h.n_levels = g->n_levels; h.m = g->m; h.m0 = g->m0;
+    h.ep_ids = g->d_ep_ids; h.ep_levels = g->d_ep_levels; h.n_ep = g->n_ep;
+    h.xp_ids = g->d_xp_ids; h.xp_levels = g->d_xp_levels; h.n_xp = g->n_xp;
+    h.ef = ef; h.top = top; h.nq = q->nq;
+    h.out = d_out; h.out_counts = d_counts; h.out_scored = d_scored;
+    h.lds_query_bytes = q->q_stride <= HNSW_LDS_QUERY_MAX ? q->q_stride : 0;
+    h.log_cap = HNSW_LOG_CAP;
+    if (const char *e = getenv("QMX_HNSW_LOG_CAP")) {   // tests: force the whole-bitmap clear path
+        const long v = atol(e);
+        if (v >= 1 && v <= (long)HNSW_LOG_CAP) h.log_cap = (uint32_t)v;
+    }
+    h.vis_words = ((uint64_t)g->n_points + 31) / 32;
+    if (h.vis_words == 0) h.vis_words = 1;
+    int per_cu = 1;
+    QMX_TRY(launch_hnsw(q, a, h, 0, &per_cu));
+    uint64_t slots = std::min<uint64_t>({(uint64_t)q->nq, (uint64_t)s->num_cus * per_cu, (uint64_t)HNSW_SLOT_CAP});
+    const uint64_t by_budget = std::max<uint64_t>(1, HNSW_VIS_BUDGET / (h.vis_words * 4));
+    slots = std::max<uint64_t>(1, std::min(slots, by_budget));
+    if (q->hnsw_slots < slots || q->hnsw_vis_words != h.vis_words) {
+        // (re)allocate for the largest slot count this handle can use, zero once: the kernel returns the bitmaps all-zero
+        const uint64_t want = std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)std::max<uint32_t>(q->nq, 1), (uint64_t)s->num_cus * per_cu,
+                                                                       (uint64_t)HNSW_SLOT_CAP, by_budget}));
+        QMX_HIP(hipStreamSynchronize(q->stream));
+        q->hnsw_slots = 0;
+        QMX_TRY(q->hnsw_vis.reserve((size_t)want * h.vis_words * 4));
+        QMX_TRY(q->hnsw_log.reserve((size_t)want * HNSW_LOG_CAP * 4));
+        QMX_HIP(hipMemsetAsync(q->hnsw_vis.p, 0, (size_t)want * h.vis_words * 4, q->stream));
+        q->hnsw_slots = (uint32_t)want;
+        q->hnsw_vis_words = h.vis_words;
+    }
+    h.visited = (uint32_t *)q->hnsw_vis.p;
+    h.vis_log = (uint32_t *)q->hnsw_log.p;
+    size_t slot = 0;
+    if (timed) QMX_TRY(timing_begin(q, &slot));
+    QMX_TRY(launch_hnsw(q, a, h, (uint32_t)slots, &per_cu));
+    if (timed) QMX_TRY(timing_end(q, slot));
+    return QMX_OK;
+}
+
+static int32_t hnsw_check(const qmx_hnsw *g, const qmx_query *q, uint32_t top, uint32_t ef) {
+    QMX_REQUIRE(g->device == q->seg->device, QMX_ERR_BAD_ARG, "graph lives on device %d, the segment on %d", g->device, q->seg->device);
+    QMX_REQUIRE((uint64_t)g->n_points <= q->seg->n, QMX_ERR_OUT_OF_BOUNDS, "graph has %u points, the segment %llu rows", g->n_points,
+                (unsigned long long)q->seg->n);
+    QMX_REQUIRE(top >= 1, QMX_ERR_BAD_ARG, "top must be > 0");
+    QMX_REQUIRE(std::max(top, ef) <= HNSW_MAX_EF, QMX_ERR_NOT_SUPPORTED, "max(top, ef) = %u > %u not supported yet", std::max(top, ef),
+                HNSW_MAX_EF);
+    return QMX_OK;
+}
+
+int32_t qmx_hnsw_search(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef, qmx_scored_point *out, uint32_t *out_counts,
+                        const volatile uint8_t *is_stopped, qmx_counters *counters) {
+    QMX_REQUIRE(g && q && out && out_counts, QMX_ERR_BAD_ARG, "NULL argument");
+    QMX_TRY(hnsw_check(g, q, top, ef));
+    QMX_HIP(hipSetDevice(q->device));
+    if (counters) memset(counters, 0, sizeof(*counters));
+    if (q->nq == 0) return QMX_OK;
+    if (is_stopped && *is_stopped) {
+        set_error("search cancelled");
+        return QMX_ERR_CANCELLED;
+    }
+    if (g->n_points == 0) {   // get_entry_point() -> None -> empty result (graph_layers.rs:539-542)
+        if (is_device_ptr(out_counts)) QMX_HIP(hipMemset(out_counts, 0, (size_t)q->nq * 4));
+        else memset(out_counts, 0, (size_t)q->nq * 4);
+        return QMX_OK;
+    }
+    const bool out_dev = is_device_ptr(out), cnt_dev = is_device_ptr(out_counts);
+    qmx_scored_point *d_out = out;
+    uint32_t *d_counts = out_counts;
+    if (!out_dev) { QMX_TRY(q->out.reserve((size_t)q->nq * top * sizeof(qmx_scored_point))); d_out = (qmx_scored_point *)q->out.p; }
+    if (!cnt_dev) { QMX_TRY(q->counts.reserve((size_t)q->nq * 4)); d_counts = (uint32_t *)q->counts.p; }
+    QMX_TRY(q->hnsw_scored.reserve((size_t)q->nq * 4));
+    const bool timed = q->timing || (q->seg->flags & QMX_SEG_TIME_KERNELS) != 0;
+    QMX_TRY(hnsw_enqueue(g, q, top, ef, d_out, d_counts, (uint32_t *)q->hnsw_scored.p, timed));
+    if (!out_dev) QMX_TRY(copy_out(q->stream, out, d_out, (size_t)q->nq * top * sizeof(qmx_scored_point)));
+    if (!cnt_dev) QMX_TRY(copy_out(q->stream, out_counts, d_counts, (size_t)q->nq * 4));
+    std::vector<uint32_t> scored(counters ? q->nq : 0);
+    if (counters) QMX_HIP(hipMemcpyAsync(scored.data(), q->hnsw_scored.p, (size_t)q->nq * 4, hipMemcpyDeviceToHost, q->stream));
+    QMX_TRY(check_err_flag(q));   // synchronises the stream
+    if (counters) {
+        uint64_t total = 0;
+        for (uint32_t v : scored) total += v;
+        counters->vectors_scored = total;
+        counters->bytes_read = total * q->seg->row_bytes;
+        counters->kernel_launches = 1;
+    }
+    if (timed) {
+        const float before = q->timing_ms;
+        QMX_TRY(timing_fold(q));
+        if (counters) counters->kernel_ms = q->timing_ms - before;
+    }
+    return QMX_OK;
+}
+
+int32_t qmx_hnsw_search_async(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef, qmx_scored_point *out_dev,
+                              uint32_t *out_counts_dev, uint32_t *out_scored_dev) {
+    QMX_REQUIRE(g && q && out_dev && out_counts_dev, QMX_ERR_BAD_ARG, "NULL argument");
+    QMX_TRY(hnsw_check(g, q, top, ef));
+    QMX_HIP(hipSetDevice(q->device));
+    if (q->nq == 0) return QMX_OK;
+    if (g->n_points == 0) {
+        QMX_HIP(hipMemsetAsync(out_counts_dev, 0, (size_t)q->nq * 4, q->stream));
+        return QMX_OK;
+    }
+    const bool timed = q->timing || (q->seg->flags & QMX_SEG_TIME_KERNELS) != 0;
+    return hnsw_enqueue(g, q, top, ef, out_dev, out_counts_dev, out_scored_dev, timed);
+}
 
 // ---------------------------------------------------------------------------------------------
 // pair scoring (ragged score_points, rescoring, score_internal)

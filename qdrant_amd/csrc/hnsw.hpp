@@ -1,0 +1,379 @@
+// hnsw.hpp — device-resident HNSW search: one wavefront walks the graph for one query.
+//
+// Replaces, for a graph whose links sit in HBM next to the stored block,
+//   GraphLayers::search                    lib/segment/src/index/hnsw_index/graph_layers.rs:530-562
+//   GraphLayersBase::search_on_level       graph_layers.rs:108-149   (ef-bounded beam, level 0)
+//   GraphLayersBase::search_entry_on_level graph_layers.rs:279-317   (greedy descent, levels > 0)
+//   GraphLayersBase::search_entry          graph_layers.rs:247-277
+//   GraphLayers::get_entry_point           graph_layers.rs:505-528 + entry_points.rs:96-112
+//   SearchContext::process_candidate       search_context.rs:32-40
+//   FilteredScorer::score_points           point_scorer.rs:265-304   (deleted filter + limit, then score)
+//   VisitedListHandle                      index/visited_pool.rs:18-80
+// The per-hop `RawScorer::score_points` call of the reference (<= m0 ids per hop) becomes an
+// in-kernel gather with the lane policies of the brute-force scan, so a hop never leaves the GPU
+// and every score carries the same bits as the scan / the x86 reference.
+//
+// Mapping
+//   * block = 1 wavefront = 1 search at a time; grid = "slots" (CUs x occupancy), each slot loops
+//     over queries slot, slot + grid, ...  Many independent searches per CU hide the latency of the
+//     dependent loads of a hop (offsets -> links -> visited word -> rows).
+//   * the query (tile entry / SQ codes / PQ LUT) is staged in LDS once per search.
+//   * `nearest` and `candidates` of SearchContext are ONE sorted register list of 64*E keys
+//     (entry e*64+lane) with an "expanded" flag per entry: every candidate the reference can still
+//     pop with score >= lower_bound is an element of `nearest` (an evicted candidate is below the
+//     bound and ends the loop), so "pop the best candidate" = "best unexpanded entry" and the loop
+//     ends when the first ef entries are all expanded.  Identical results whenever scores are
+//     distinct; among equal scores the reference's order is BinaryHeap-dependent (unpinned).
+//   * visited set = one bit per point in a per-slot HBM bitmap, test-and-set with an L2 atomic;
+//     the words a search touched are logged and cleared afterwards (whole-bitmap clear if the
+//     log overflows).
+//   * links = the plain GraphLinks arrays (graph_links/view.rs: reindex, level_offsets, offsets,
+//     neighbors) as serialised by graph_links/serializer.rs:52-176.
+#pragma once
+#include "scan_common.hpp"
+
+namespace qmx {
+
+// ---- hop scorers: LPI lanes score one stored row; the score is valid in the lane with sub == 0 ----
+template <class P>
+struct HopRow {
+    static constexpr int LPI = 8;
+    static __device__ __forceinline__ float score(const ScanArgs &a, const unsigned char *qp, uint32_t id, int sub) {
+        return group_score<P>(a, qp, id, sub);
+    }
+};
+template <class S>
+struct HopSmall {
+    static constexpr int LPI = 1;
+    static __device__ __forceinline__ float score(const ScanArgs &a, const unsigned char *qp, uint32_t id, int) {
+        return S::score(qp, reinterpret_cast<const unsigned char *>(a.rows) + (uint64_t)id * a.row_stride, id, a);
+    }
+};
+
+// ---- the beam: sorted descending, entry index = e * 64 + lane ------------------------------------
+template <int E>
+struct Beam {
+    uint64_t key[E];
+    uint32_t done[E];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int e = 0; e < E; ++e) { key[e] = 0; done[e] = 0; }
+    }
+    __device__ __forceinline__ uint64_t at(uint32_t idx) const {   // idx uniform
+        uint64_t r = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if ((idx >> 6) == (uint32_t)e) r = readlane_u64(key[e], (int)(idx & 63));
+        return r;
+    }
+    // insert nk (uniform, non-zero), keep the first `cap` entries
+    __device__ __forceinline__ void insert(uint64_t nk, uint32_t cap, int lane) {
+        uint32_t p = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) p += (uint32_t)__popcll(__ballot(key[e] > nk));
+        uint64_t carry_k = 0;
+        uint32_t carry_d = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            uint64_t up = shfl_up1_u64(key[e]);
+            uint32_t upd = (uint32_t)__shfl_up((int)done[e], 1, 64);
+            const uint64_t last_k = readlane_u64(key[e], 63);
+            const uint32_t last_d = (uint32_t)__builtin_amdgcn_readlane((int)done[e], 63);
+            if (lane == 0) { up = carry_k; upd = carry_d; }
+            const uint32_t idx = (uint32_t)e * 64 + (uint32_t)lane;
+            if (idx == p) { key[e] = nk; done[e] = 0; }
+            else if (idx > p) { key[e] = up; done[e] = upd; }
+            if (idx >= cap) { key[e] = 0; done[e] = 0; }
+            carry_k = last_k;
+            carry_d = last_d;
+        }
+    }
+    // best unexpanded entry -> its key (0 if none); marks it expanded
+    __device__ __forceinline__ uint64_t pop_best(int lane) {
+        uint64_t ck = 0;
+        bool found = false;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const uint64_t m = __ballot(key[e] != 0 && done[e] == 0);
+            if (!found && m) {
+                const int l = __builtin_ctzll(m);
+                ck = readlane_u64(key[e], l);
+                if (lane == l) done[e] = 1;
+                found = true;
+            }
+        }
+        return ck;
+    }
+};
+
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, off, 64);
+        const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), off, 64);
+        const uint64_t o = ((uint64_t)hi << 32) | lo;
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// scores hop_ids[0..k) into hop_scores[0..k); uniform control flow, k <= 64
+template <class H>
+__device__ __forceinline__ void hop_score(const ScanArgs &a, const unsigned char *qp, const uint32_t *hop_ids,
+                                          float *hop_scores, uint32_t k, int lane) {
+    constexpr int IPP = 64 / H::LPI;
+    const int sub = lane % H::LPI, g = lane / H::LPI;
+    __syncthreads();   // hop_ids written by other lanes
+    for (uint32_t base = 0; base < k; base += IPP) {
+        const uint32_t j = base + (uint32_t)g;
+        const bool on = j < k;
+        const uint32_t id = hop_ids[on ? j : 0];
+        const float s = H::score(a, qp, id, sub);
+        if (on && sub == 0) hop_scores[j] = s;
+    }
+    __syncthreads();
+}
+
+// One search.  `qp` = the query entry (LDS or global).
+template <class H, int E>
+__device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArgs &h, const unsigned char *qp,
+                                                uint32_t *hop_ids, float *hop_scores, uint32_t *vis, uint32_t *vlog,
+                                                uint32_t qi, int lane) {
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    uint32_t n_scored = 0;
+
+    // ---- get_entry_point: first live entry point, else the live extra point of the highest level ----
+    bool have_ep = false;
+    uint32_t ep_id = 0, ep_level = 0;
+    for (uint32_t base = 0; base < h.n_ep && !have_ep; base += 64) {
+        const uint32_t i = base + (uint32_t)lane;
+        const bool ok = i < h.n_ep && a.del.live(h.ep_ids[i < h.n_ep ? i : 0]);
+        const uint64_t m = __ballot(ok);
+        if (m) {
+            const uint32_t first = base + (uint32_t)__builtin_ctzll(m);
+            ep_id = h.ep_ids[first];
+            ep_level = h.ep_levels[first];
+            have_ep = true;
+        }
+    }
+    if (!have_ep) {
+        for (uint32_t i = 0; i < h.n_xp; ++i) {   // max_by_key(level): the last maximal element wins
+            const uint32_t id = h.xp_ids[i], lv = h.xp_levels[i];
+            if (a.del.live(id) && (!have_ep || lv >= ep_level)) { ep_id = id; ep_level = lv; have_ep = true; }
+        }
+    }
+    if (!have_ep) {
+        if (lane == 0) {
+            h.out_counts[qi] = 0;
+            if (h.out_scored) h.out_scored[qi] = 0;
+        }
+        return;
+    }
+    if (ep_level >= h.n_levels) ep_level = h.n_levels - 1;
+
+    // ---- search_entry: greedy descent over levels ep_level .. 1 ----
+    uint32_t cur_id = ep_id;
+    float cur_score;
+    {
+        if (lane == 0) hop_ids[0] = cur_id;
+        hop_score<H>(a, qp, hop_ids, hop_scores, 1, lane);
+        cur_score = hop_scores[0];
+        n_scored += 1;
+    }
+    for (uint32_t level = ep_level; level > 0; --level) {
+        if (level != ep_level) n_scored += 1;   // search_entry_on_level re-scores its entry (same value)
+        bool changed = true;
+        while (changed) {
+            changed = false;
+            const uint64_t slot = h.level_offsets[level] + h.reindex[cur_id];
+            const uint64_t o0 = h.offsets[slot], o1 = h.offsets[slot + 1];
+            uint32_t remaining = h.m;   // filter_truncate limit = level_m
+            for (uint64_t base = o0; base < o1 && remaining > 0; base += 64) {
+                const uint64_t i = base + (uint64_t)lane;
+                const bool on = i < o1;
+                const uint32_t id = on ? h.neighbors[i] : 0;
+                bool keep = on && id < h.n_points && a.del.live(id);
+                const uint64_t mask = __ballot(keep);
+                const uint32_t rank = (uint32_t)__popcll(mask & lt_mask);
+                keep = keep && rank < remaining;
+                uint32_t k = (uint32_t)__popcll(mask);
+                if (k > remaining) k = remaining;
+                remaining -= k;
+                __syncthreads();
+                if (keep) hop_ids[rank] = id;
+                hop_score<H>(a, qp, hop_ids, hop_scores, k, lane);
+                // sequential `if score > current.score` over the batch == first maximum above current
+                uint64_t mk = 0;
+                if ((uint32_t)lane < k && hop_scores[lane] > cur_score)
+                    mk = ((uint64_t)score_to_ord(hop_scores[lane]) << 32) | (uint32_t)(~(uint32_t)lane);
+                const uint64_t best = wave_max_u64(mk);
+                if (best) {
+                    const uint32_t bl = ~(uint32_t)best;
+                    cur_id = hop_ids[bl];
+                    cur_score = hop_scores[bl];
+                    changed = true;
+                }
+                n_scored += k;
+            }
+        }
+    }
+
+    // ---- search_on_level(level 0, ef) ----
+    const uint32_t ef = h.ef > h.top ? h.ef : h.top;
+    Beam<E> beam;
+    beam.clear();
+    uint32_t log_cnt = 0;
+    {
+        if (lane == 0) {
+            atomicOr(&vis[cur_id >> 5], 1u << (cur_id & 31));
+            vlog[0] = cur_id >> 5;
+        }
+        log_cnt = 1;
+        beam.insert(make_key(cur_score, cur_id), ef, lane);
+    }
+    while (true) {
+        const uint64_t ck = beam.pop_best(lane);
+        if (ck == 0) break;
+        const uint32_t cand = key_idx(ck);
+        const uint64_t o0 = h.offsets[cand], o1 = h.offsets[(uint64_t)cand + 1];
+        uint32_t remaining = h.m0;
+        for (uint64_t base = o0; base < o1 && remaining > 0; base += 64) {
+            const uint64_t i = base + (uint64_t)lane;
+            const bool on = i < o1;
+            const uint32_t id = on ? h.neighbors[i] : 0;
+            const bool live = on && id < h.n_points && a.del.live(id);
+            const uint32_t bit = 1u << (id & 31);
+            const uint32_t old = live ? atomicOr(&vis[id >> 5], bit) : bit;
+            bool keep = live && !(old & bit);
+            const uint64_t mask = __ballot(keep);
+            const uint32_t rank = (uint32_t)__popcll(mask & lt_mask);
+            uint32_t k = (uint32_t)__popcll(mask);
+            if (k > remaining) {   // more links than level_m: the reference scores only the first `limit`
+                if (keep && rank >= remaining) { atomicAnd(&vis[id >> 5], ~bit); keep = false; }
+                k = remaining;
+            }
+            remaining -= k;
+            __syncthreads();
+            if (keep) {
+                hop_ids[rank] = id;
+                if (log_cnt + rank < h.log_cap) vlog[log_cnt + rank] = id >> 5;
+            }
+            log_cnt += k;
+            hop_score<H>(a, qp, hop_ids, hop_scores, k, lane);
+            const uint64_t mykey = (uint32_t)lane < k ? make_key(hop_scores[lane], hop_ids[lane]) : 0;
+            uint64_t mm = __ballot(mykey > beam.at(ef - 1));
+            while (mm) {
+                const int src = __builtin_ctzll(mm);
+                mm &= mm - 1;
+                const uint64_t nk = readlane_u64(mykey, src);
+                if (nk > beam.at(ef - 1)) beam.insert(nk, ef, lane);
+            }
+            n_scored += k;
+        }
+    }
+
+    // ---- nearest.into_iter_sorted().take(top) ----
+    {
+        uint32_t count = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const uint32_t idx = (uint32_t)e * 64 + (uint32_t)lane;
+            const bool ok = beam.key[e] != 0 && idx < h.top;
+            if (ok) {
+                qmx_scored_point p;
+                p.idx = key_idx(beam.key[e]);
+                p.score = key_score(beam.key[e]);
+                h.out[(uint64_t)qi * h.top + idx] = p;
+            }
+            count += (uint32_t)__popcll(__ballot(ok));
+        }
+        if (lane == 0) {
+            h.out_counts[qi] = count;
+            if (h.out_scored) h.out_scored[qi] = n_scored;
+        }
+    }
+
+    // ---- give the visited bitmap back all-zero ----
+    __syncthreads();
+    if (log_cnt <= h.log_cap) {
+        for (uint32_t i = (uint32_t)lane; i < log_cnt; i += 64) vis[vlog[i]] = 0;
+    } else {
+        for (uint64_t w = (uint64_t)lane; w < h.vis_words; w += 64) vis[w] = 0;
+    }
+    __threadfence();
+}
+
+template <class H, int E, bool QLDS>
+__global__ __launch_bounds__(64) void hnsw_search_kernel(const ScanArgs a, const HnswArgs h) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    uint32_t *hop_ids = reinterpret_cast<uint32_t *>(smem);
+    float *hop_scores = reinterpret_cast<float *>(smem + 256);
+    unsigned char *q_lds = smem + 512;
+    uint32_t *vis = h.visited + (uint64_t)blockIdx.x * h.vis_words;
+    uint32_t *vlog = h.vis_log + (uint64_t)blockIdx.x * h.log_cap;
+    for (uint32_t qi = blockIdx.x; qi < h.nq; qi += gridDim.x) {
+        const unsigned char *qg = reinterpret_cast<const unsigned char *>(a.queries) + (uint64_t)qi * a.q_stride;
+        if constexpr (QLDS) {
+            __syncthreads();
+            const uint4 *src = reinterpret_cast<const uint4 *>(qg);
+            uint4 *dst = reinterpret_cast<uint4 *>(q_lds);
+            for (uint32_t i = (uint32_t)lane; i < h.lds_query_bytes / 16; i += 64) dst[i] = src[i];
+            __syncthreads();
+            hnsw_search_one<H, E>(a, h, q_lds, hop_ids, hop_scores, vis, vlog, qi, lane);
+        } else {
+            hnsw_search_one<H, E>(a, h, qg, hop_ids, hop_scores, vis, vlog, qi, lane);
+        }
+    }
+}
+
+// occupancy of an instantiation (blocks of one wave per CU) — used by the API to size the scratch
+template <class H, int E, bool QLDS>
+int32_t hnsw_occupancy_inst(uint32_t lds_query_bytes, int *per_cu) {
+    auto kfn = hnsw_search_kernel<H, E, QLDS>;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const size_t lds = 512 + (QLDS ? lds_query_bytes : 0);
+    int n = 0;
+    QMX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kfn, 64, lds));
+    *per_cu = n < 1 ? 1 : n;
+    return QMX_OK;
+}
+
+template <class H, int E, bool QLDS>
+int32_t launch_hnsw_inst(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid) {
+    const size_t lds = 512 + (QLDS ? h.lds_query_bytes : 0);
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL((hnsw_search_kernel<H, E, QLDS>), dim3(grid), dim3(64), lds, st, a, h);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
+// grid == 0: only report the occupancy in *per_cu (no launch)
+template <class H>
+int32_t launch_hnsw_hop(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
+    const uint32_t ef = h.ef > h.top ? h.ef : h.top;
+    QMX_REQUIRE(ef >= 1 && ef <= HNSW_MAX_EF, QMX_ERR_NOT_SUPPORTED, "hnsw ef %u not in 1..%u", ef, HNSW_MAX_EF);
+    const bool qlds = h.lds_query_bytes > 0;
+    if (grid == 0) {
+        if (ef <= 128) return qlds ? hnsw_occupancy_inst<H, 2, true>(h.lds_query_bytes, per_cu) : hnsw_occupancy_inst<H, 2, false>(0, per_cu);
+        return qlds ? hnsw_occupancy_inst<H, 8, true>(h.lds_query_bytes, per_cu) : hnsw_occupancy_inst<H, 8, false>(0, per_cu);
+    }
+    if (ef <= 128) return qlds ? launch_hnsw_inst<H, 2, true>(st, a, h, grid) : launch_hnsw_inst<H, 2, false>(st, a, h, grid);
+    return qlds ? launch_hnsw_inst<H, 8, true>(st, a, h, grid) : launch_hnsw_inst<H, 8, false>(st, a, h, grid);
+}
+
+// launch functor for the per-dtype dispatchers (dispatch_dense / dispatch_sq)
+struct HnswLauncher {
+    hipStream_t st;
+    const HnswArgs *h;
+    uint32_t grid;
+    int *per_cu;
+    template <class P> int32_t row(const ScanArgs &a) const { return launch_hnsw_hop<HopRow<P>>(st, a, *h, grid, per_cu); }
+    template <class S> int32_t small(const ScanArgs &a) const { return launch_hnsw_hop<HopSmall<S>>(st, a, *h, grid, per_cu); }
+};
+
+}  // namespace qmx

@@ -48,6 +48,35 @@ struct QueryAux {
 };
 constexpr uint32_t QUERY_AUX_BYTES = 64;
 
+// Device-resident HNSW search (hnsw.hpp): the graph + per-launch parameters.
+struct HnswArgs {
+    const uint32_t *reindex;        // [n_points]   point -> slot inside levels > 0
+    const uint64_t *level_offsets;  // [n_levels + 1] first offsets-slot of each level
+    const uint64_t *offsets;        // [n_slots + 1]  start of each links list inside `neighbors`
+    const uint32_t *neighbors;
+    uint32_t n_points, n_levels, m, m0;
+    const uint32_t *ep_ids, *ep_levels;   // EntryPoints::entry_points
+    uint32_t n_ep;
+    const uint32_t *xp_ids, *xp_levels;   // EntryPoints::extra_entry_points (iter_unsorted order)
+    uint32_t n_xp;
+    uint32_t ef, top, nq;
+    uint32_t *visited;              // [slots][vis_words], all zero between searches
+    uint64_t vis_words;
+    uint32_t *vis_log;              // [slots][log_cap] word indices touched by the running search
+    uint32_t log_cap;
+    qmx_scored_point *out;          // [nq][top]
+    uint32_t *out_counts;           // [nq]
+    uint32_t *out_scored;           // [nq] points scored by each search (HardwareCounter cpu_io), may be null
+    uint32_t lds_query_bytes;       // bytes of the query entry staged in LDS (16-byte multiple)
+};
+
+// grid == 0: only report the occupancy (blocks of one wave per CU) of the instantiation in *per_cu
+int32_t launch_hnsw_dense(hipStream_t st, int dtype, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
+int32_t launch_hnsw_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
+int32_t launch_hnsw_pq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
+constexpr uint32_t HNSW_MAX_EF = 512;
+constexpr uint32_t HNSW_LDS_QUERY_MAX = 150 * 1024;
+
 // dense f32 / f16 / u8 (scan_dense.hip)
 int32_t launch_scan_dense(hipStream_t st, int dtype, int distance, int qt, ScanMode mode,
                           const ScanArgs &a, int num_cus, uint32_t *grid_out);

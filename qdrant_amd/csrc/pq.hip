@@ -13,7 +13,7 @@
 // contraction [nq x chunk] . [chunk x 256] per chunk with f32 inputs (v_mfma_f32_32x32x2_f32: an fmaf
 // chain, so <= 1e-5 relative to the reference's mul+add chain; the exact-order VALU kernel is the
 // bit-parity variant).
-#include "scan_common.hpp"
+#include "hnsw.hpp"
 
 namespace qmx {
 
@@ -264,6 +264,33 @@ int32_t launch_pairs_pq(hipStream_t st, const ScanArgs &a, const PairSel &sel, u
     hipLaunchKernelGGL(pq_pair_kernel, dim3(grid), dim3(256), 0, st, a, sel, n_items);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
+}
+
+// HNSW hop scorer: 4 lanes per code row, lane `sub` owns SSE lane `sub` of score_point_sse (chunks
+// sub, sub+4, ... added in order), the quad is folded as (l0 + l2) + (l1 + l3) like pq_score_row.
+struct HopPQ {
+    static constexpr int LPI = 4;
+    static __device__ __forceinline__ float score(const ScanArgs &a, const unsigned char *qp, uint32_t id, int sub) {
+        const float *lut = reinterpret_cast<const float *>(qp);
+        const uint8_t *codes = reinterpret_cast<const uint8_t *>(a.rows) + (uint64_t)id * a.row_stride;
+        const uint32_t m = a.pq_m, ncent = a.pq_ncent, m4 = m & ~3u;
+        float l = 0.0f;
+        if ((reinterpret_cast<uintptr_t>(codes) & 3) == 0) {
+            for (uint32_t c = 0; c < m4; c += 4) {
+                const uint32_t w = *reinterpret_cast<const uint32_t *>(codes + c);
+                l += lut[(c + (uint32_t)sub) * ncent + ((w >> (8 * sub)) & 0xFF)];
+            }
+        } else {
+            for (uint32_t c = 0; c < m4; c += 4) l += lut[(c + (uint32_t)sub) * ncent + codes[c + (uint32_t)sub]];
+        }
+        const float x = l + dpp_f32<DPP_QUAD_XOR2>(l);          // lane 0: l0 + l2, lane 1: l1 + l3
+        float sum = x + dpp_f32<DPP_QUAD_XOR1>(x);              // lane 0: (l0 + l2) + (l1 + l3)
+        for (uint32_t c = m4; c < m; ++c) sum += lut[c * ncent + codes[c]];
+        return sum;
+    }
+};
+int32_t launch_hnsw_pq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
+    return launch_hnsw_hop<HopPQ>(st, a, h, grid, per_cu);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -366,17 +366,45 @@ int32_t launch_small(hipStream_t st, ScanMode mode, const ScanArgs &a, int num_c
 // ------------------------------------------------------------------------------------------
 constexpr int PAIR_BLOCK = 256;
 
+// score of one stored row against one query by the 8 lanes of a group (t = lane & 7); the result is
+// valid in every lane of the group.  `qp` = the query's tile entry (elements, zero padding, aux) in
+// LDS or in global memory.  Shared by pair_kernel and the HNSW hop scorer, so both produce the
+// bits of the scan.
 template <class P>
-__global__ __launch_bounds__(PAIR_BLOCK) void pair_kernel(const ScanArgs a, const PairSel sel, uint64_t n_items) {
-    constexpr int NW = PAIR_BLOCK / WAVE;
+__device__ __forceinline__ float group_score(const ScanArgs &a, const unsigned char *qp, uint32_t id, int t) {
     constexpr int NRA = P::NRAUX > 0 ? P::NRAUX : 1;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int t = lane & 7, g = lane >> 3;
     const int piece = lane_piece(t);
     const int piece_off = piece * 16;
     const bool piece_in_rem = piece < (int)a.rem_pieces;
-    const unsigned char *rows = reinterpret_cast<const unsigned char *>(a.rows);
+    const unsigned char *row = reinterpret_cast<const unsigned char *>(a.rows) + (uint64_t)id * a.row_stride;
+    const unsigned char *rp = row + piece_off;
+    typename P::acc_t acc[1][1][P::NACC];
+    typename P::acc_t raux[1][NRA];
+#pragma unroll
+    for (int k = 0; k < P::NACC; ++k) acc[0][0][k] = 0;
+#pragma unroll
+    for (int k = 0; k < NRA; ++k) raux[0][k] = 0;
+#pragma unroll 4
+    for (uint32_t s = 0; s < a.nseg; ++s) {
+        uint4 v[1];
+        v[0] = *reinterpret_cast<const uint4 *>(rp + (uint64_t)s * 128);
+        scan_step<P, 1, 1>(acc, raux, v, qp + s * 128 + piece_off, 0, true);
+    }
+    if (a.rem_pieces) {
+        uint4 v[1];
+        v[0] = make_uint4(0, 0, 0, 0);
+        if (piece_in_rem) v[0] = *reinterpret_cast<const uint4 *>(rp + (uint64_t)a.nseg * 128);
+        scan_step<P, 1, 1>(acc, raux, v, qp + a.nseg * 128 + piece_off, 0, piece_in_rem);
+    }
+    return P::finish(acc[0][0], raux[0], qp, row, id, a);
+}
+
+template <class P>
+__global__ __launch_bounds__(PAIR_BLOCK) void pair_kernel(const ScanArgs a, const PairSel sel, uint64_t n_items) {
+    constexpr int NW = PAIR_BLOCK / WAVE;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int t = lane & 7, g = lane >> 3;
     const unsigned char *queries = reinterpret_cast<const unsigned char *>(a.queries);
     for (uint64_t base = ((uint64_t)blockIdx.x * NW + wave) * 8; base < n_items; base += (uint64_t)gridDim.x * NW * 8) {
         const uint64_t item = base + g;
@@ -390,27 +418,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void pair_kernel(const ScanArgs a, cons
             id = 0;
             qi = 0;
         }
-        const unsigned char *qp = queries + (uint64_t)qi * a.q_stride;
-        const unsigned char *rp = rows + (uint64_t)id * a.row_stride + piece_off;
-        typename P::acc_t acc[1][1][P::NACC];
-        typename P::acc_t raux[1][NRA];
-#pragma unroll
-        for (int k = 0; k < P::NACC; ++k) acc[0][0][k] = 0;
-#pragma unroll
-        for (int k = 0; k < NRA; ++k) raux[0][k] = 0;
-#pragma unroll 4
-        for (uint32_t s = 0; s < a.nseg; ++s) {
-            uint4 v[1];
-            v[0] = *reinterpret_cast<const uint4 *>(rp + (uint64_t)s * 128);
-            scan_step<P, 1, 1>(acc, raux, v, qp + s * 128 + piece_off, 0, true);
-        }
-        if (a.rem_pieces) {
-            uint4 v[1];
-            v[0] = make_uint4(0, 0, 0, 0);
-            if (piece_in_rem) v[0] = *reinterpret_cast<const uint4 *>(rp + (uint64_t)a.nseg * 128);
-            scan_step<P, 1, 1>(acc, raux, v, qp + a.nseg * 128 + piece_off, 0, piece_in_rem);
-        }
-        const float score = P::finish(acc[0][0], raux[0], qp, rows + (uint64_t)id * a.row_stride, id, a);
+        const float score = group_score<P>(a, queries + (uint64_t)qi * a.q_stride, id, t);
         if (valid && t == 0) a.scores[item] = score;
     }
 }

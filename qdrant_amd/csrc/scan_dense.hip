@@ -7,7 +7,7 @@
 //        lib/segment/src/spaces/metric_uint/simple_*.rs      (scalar order, QMX_SEG_U8_SCALAR_ORDER)   bit-exact
 // Compiled with -ffp-contract=off: every fused multiply-add below is an explicit fmaf, every
 // separate mul/add stays separate, as in the Rust/C reference.
-#include "scan_common.hpp"
+#include "hnsw.hpp"
 
 namespace qmx {
 
@@ -352,6 +352,9 @@ int32_t launch_scan_dense(hipStream_t st, int dtype, int distance, int qt, ScanM
 int32_t launch_pairs_dense(hipStream_t st, int dtype, int distance, const ScanArgs &a, const PairSel &sel,
                            uint64_t n_items, int num_cus) {
     return dispatch_dense(PairLauncher{st, sel, n_items, num_cus}, dtype, distance, a);
+}
+int32_t launch_hnsw_dense(hipStream_t st, int dtype, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
+    return dispatch_dense(HnswLauncher{st, &h, grid, per_cu}, dtype, distance, a);
 }
 
 }  // namespace qmx

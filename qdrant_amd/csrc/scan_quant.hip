@@ -11,7 +11,7 @@
 // HBM layout: the reference row `[f32 vector_offset][u8 code x actual_dim]` (772 B at d=768, only
 // 4-byte aligned) is split at upload into a 16-byte aligned code block [n][actual_dim] and an
 // offset column [n] f32; algorithmic bytes per scored row stay 4 + actual_dim.
-#include "scan_common.hpp"
+#include "hnsw.hpp"
 
 namespace qmx {
 
@@ -83,6 +83,9 @@ int32_t launch_scan_sq(hipStream_t st, int distance, int qt, ScanMode mode, cons
 }
 int32_t launch_pairs_sq(hipStream_t st, int distance, const ScanArgs &a, const PairSel &sel, uint64_t n_items, int num_cus) {
     return dispatch_sq(PairLauncher{st, sel, n_items, num_cus}, distance, a);
+}
+int32_t launch_hnsw_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
+    return dispatch_sq(HnswLauncher{st, &h, grid, per_cu}, distance, a);
 }
 
 // ------------------------------------------------------------------------------------------

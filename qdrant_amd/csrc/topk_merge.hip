@@ -59,22 +59,41 @@ __global__ __launch_bounds__(MERGE_BLOCK) void merge_keys_kernel(const uint64_t 
     block_finish(list, (int)top, q, out, out_counts);
 }
 
+// Items are visited in the aggregator's order (list-major, then position); an id that was already
+// pushed by an earlier item is dropped whatever its score (`if self.seen.insert(point.id)`,
+// search_result_aggregator.rs:28-37).  The id of every item is staged in LDS and each item looks
+// for an earlier twin: O(T^2 / 256) compares per thread, T = n_lists * k is a few hundred at most.
 __global__ __launch_bounds__(MERGE_BLOCK) void merge_points_kernel(const qmx_scored_point *lists,
                                                                    const uint32_t *list_counts,
                                                                    const uint32_t *list_idx_base, uint32_t n_lists,
                                                                    uint32_t nq, uint32_t k, qmx_scored_point *out,
                                                                    uint32_t *out_counts) {
+    extern __shared__ uint32_t seen_ids[];   // [n_lists * k]; 0xFFFFFFFF = no item
     const uint32_t q = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t total = n_lists * k;
+    for (uint32_t j = threadIdx.x; j < total; j += MERGE_BLOCK) {
+        const uint32_t l = j / k, i = j - l * k;
+        const uint32_t cnt = list_counts ? list_counts[(uint64_t)l * nq + q] : k;
+        seen_ids[j] = i < cnt ? lists[((uint64_t)l * nq + q) * k + i].idx + (list_idx_base ? list_idx_base[l] : 0u)
+                              : 0xFFFFFFFFu;
+    }
+    __syncthreads();
     uint64_t list = 0;
     for (uint32_t l = wave; l < n_lists; l += MERGE_NW) {
         const uint32_t cnt = list_counts ? list_counts[(uint64_t)l * nq + q] : k;
-        uint64_t key = 0;
-        if (lane < (int)k && lane < (int)cnt) {
-            const qmx_scored_point p = lists[((uint64_t)l * nq + q) * k + lane];
-            key = make_key(p.score, p.idx + (list_idx_base ? list_idx_base[l] : 0u));
+        for (uint32_t base = 0; base < k; base += WAVE) {
+            const uint32_t i = base + lane;
+            uint64_t key = 0;
+            if (i < k && i < cnt) {
+                const uint32_t j = l * k + i;
+                const uint32_t id = seen_ids[j];
+                bool dup = false;
+                for (uint32_t e = 0; e < j; ++e) dup = dup || (seen_ids[e] == id);
+                if (!dup) key = make_key(lists[((uint64_t)l * nq + q) * k + i].score, id);
+            }
+            wave_offer(list, key, (int)k, lane);
         }
-        wave_offer(list, key, (int)k, lane);
     }
     block_finish(list, (int)k, q, out, out_counts);
 }
@@ -107,8 +126,10 @@ int32_t launch_merge_points(hipStream_t st, const qmx_scored_point *lists, const
                             const uint32_t *list_idx_base, uint32_t n_lists, uint32_t nq, uint32_t k,
                             qmx_scored_point *out, uint32_t *out_counts) {
     if (nq == 0) return QMX_OK;
+    QMX_REQUIRE((uint64_t)n_lists * k * sizeof(uint32_t) <= 64 * 1024, QMX_ERR_NOT_SUPPORTED,
+                "merge of %u lists x %u entries exceeds the 64 KiB seen-id table", n_lists, k);
     ::qmx::clear_stale_error();
-    hipLaunchKernelGGL(merge_points_kernel, dim3(nq), dim3(MERGE_BLOCK), 0, st, lists, list_counts, list_idx_base, n_lists, nq, k, out, out_counts);
+    hipLaunchKernelGGL(merge_points_kernel, dim3(nq), dim3(MERGE_BLOCK), (size_t)n_lists * k * sizeof(uint32_t), st, lists, list_counts, list_idx_base, n_lists, nq, k, out, out_counts);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }

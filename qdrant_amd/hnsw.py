@@ -1,0 +1,77 @@
+"""Host-side mirror of `GraphLayers` (lib/segment/src/index/hnsw_index/graph_layers.rs:58-72) for
+the device-resident search: the graph is given as the plain `GraphLinks` arrays
+(graph_links/serializer.rs:52-176) + `EntryPoints`, uploaded once, and `search` runs
+`GraphLayers::search` (:530-562) for a whole batch of queries in one kernel launch
+(`qmx_hnsw_search`).  No CPU fallback: without the HIP library / a gfx950 device this raises."""
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _ffi as F
+from .scorer import RawScorer, ScoredPointOffset
+
+
+def _u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+class GraphLayers:
+    """`GraphLayers {hnsw_m, links, entry_points}` on one GPU."""
+
+    def __init__(self, m: int, m0: int, reindex, level_offsets, offsets, neighbors, entry_point_ids, entry_point_levels,
+                 extra_entry_point_ids=(), extra_entry_point_levels=(), device_id: int = 0):
+        self.m, self.m0 = int(m), int(m0)
+        self._keep = [_u32(reindex), _u64(level_offsets), _u64(offsets), _u32(neighbors), _u32(entry_point_ids),
+                      _u32(entry_point_levels), _u32(extra_entry_point_ids), _u32(extra_entry_point_levels)]
+        re, lo, off, nb, ep, epl, xp, xpl = self._keep
+        d = F.HnswDesc()
+        d.m, d.m0 = self.m, self.m0
+        d.n_points = len(re)
+        d.n_levels = max(len(lo) - 1, 0)
+        d.reindex, d.level_offsets, d.offsets, d.neighbors = (F.ptr(re).value, F.ptr(lo).value, F.ptr(off).value,
+                                                              F.ptr(nb).value if len(nb) else None)
+        d.n_offsets, d.n_neighbors = len(off), len(nb)
+        d.entry_point_ids, d.entry_point_levels, d.n_entry_points = F.ptr(ep).value, F.ptr(epl).value, len(ep)
+        d.extra_entry_point_ids, d.extra_entry_point_levels, d.n_extra_entry_points = (F.ptr(xp).value, F.ptr(xpl).value,
+                                                                                        len(xp))
+        d.device_id = device_id
+        self.n_points = d.n_points
+        self._h = C.c_void_p()
+        F.check(F.lib().qmx_hnsw_create(C.byref(d), C.byref(self._h)))
+        self.counters = F.Counters()
+
+    @classmethod
+    def from_plain(cls, links, device_id: int = 0):
+        """`links`: any object with m, m0, reindex, level_offsets, offsets, neighbors, ep_ids, ep_levels."""
+        return cls(links.m, links.m0, links.reindex, links.level_offsets, links.offsets, links.neighbors, links.ep_ids,
+                   links.ep_levels, getattr(links, "xp_ids", ()), getattr(links, "xp_levels", ()), device_id)
+
+    def search(self, top: int, ef: int, points_scorer: RawScorer, is_stopped=None, with_scored: bool = False):
+        """`GraphLayers::search(top, ef, Hnsw, points_scorer, None, is_stopped)` for every query of the
+        scorer batch -> list of ScoredPointOffset arrays (descending score, at most `top`)."""
+        nq = points_scorer.nq
+        out = np.zeros((nq, max(top, 1)), dtype=ScoredPointOffset)
+        counts = np.zeros(nq, dtype=np.uint32)
+        stop = None
+        if is_stopped is not None:
+            stop = is_stopped if isinstance(is_stopped, np.ndarray) else np.array([1 if is_stopped else 0], dtype=np.uint8)
+        F.check(F.lib().qmx_hnsw_search(self._h, points_scorer._h, top, ef, F.ptr(out), F.ptr(counts), F.ptr(stop),
+                                        C.byref(self.counters)))
+        res = [out[i, :counts[i]].copy() for i in range(nq)]
+        return (res, int(self.counters.vectors_scored)) if with_scored else res
+
+    def close(self):
+        if self._h:
+            F.lib().qmx_hnsw_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -76,7 +76,12 @@ class HipBackend:
         self.nq = nq
         self.device_id = device_id
         self.device = torch.device("cuda", device_id)
+        # A NULL hipStream_t means "the query's own stream" in the C-ABI, so torch's legacy default stream
+        # (handle 0) cannot be handed over: use a dedicated stream then and order it against the caller's
+        # current stream around every call (_enter / _leave).
         self.stream = stream or torch.cuda.current_stream(self.device)
+        if self.stream.cuda_stream == 0:
+            self.stream = torch.cuda.Stream(self.device)
         self.qh = C.c_void_p()
         zeros = torch.zeros((nq, storage.dim), dtype=torch.float32, device=self.device)
         F.check(self.lib.qmx_query_create(storage._h, F.ptr(zeros), nq, C.byref(self.qh)))
@@ -85,14 +90,31 @@ class HipBackend:
     def local_topk(self, queries: torch.Tensor, top: int, out: torch.Tensor, counts: torch.Tensor):
         """queries [nq, dim] f32 on this device (original, un-preprocessed); enqueues only."""
         assert queries.is_cuda and queries.shape[0] == self.nq
+        cur = self._enter(queries, out, counts)
         F.check(self.lib.qmx_query_update(self.qh, F.ptr(queries)))
         F.check(self.lib.qmx_search_topk_async(self.qh, top, None, 0, F.ptr(out), F.ptr(counts)))
+        self._leave(cur)
 
     def merge(self, gathered, gcounts, idx_base, top: int, merged, mcounts):
         n_lists, nq = gathered.shape[0], gathered.shape[1]
+        cur = self._enter(gathered, gcounts, idx_base, merged, mcounts)
         F.check(self.lib.qmx_merge_topk_async(self.device_id, C.c_void_p(self.stream.cuda_stream), F.ptr(gathered),
                                               F.ptr(gcounts), F.ptr(idx_base), n_lists, nq, top, F.ptr(merged),
                                               F.ptr(mcounts)))
+        self._leave(cur)
+
+    def _enter(self, *tensors):
+        """Work enqueued on self.stream must see what the caller's current stream produced."""
+        cur = torch.cuda.current_stream(self.device)
+        if cur.cuda_stream != self.stream.cuda_stream:
+            self.stream.wait_stream(cur)
+            for t in tensors:
+                t.record_stream(self.stream)   # the caching allocator must not recycle them under our kernels
+        return cur
+
+    def _leave(self, cur):
+        if cur.cuda_stream != self.stream.cuda_stream:
+            cur.wait_stream(self.stream)
 
     def close(self):
         if self.qh:

@@ -336,6 +336,7 @@ _sig("qo_hnsw_point_level", C.c_uint32, [_P, C.c_uint32])
 _sig("qo_hnsw_max_level", C.c_uint32, [_P])
 _sig("qo_hnsw_links", C.c_uint32, [_P, C.c_uint32, C.c_uint32, _P])
 _sig("qo_hnsw_entry_points", C.c_uint32, [_P, _P, _P, C.c_uint32])
+_sig("qo_hnsw_extra_entry_points", C.c_uint32, [_P, _P, _P, C.c_uint32])
 _sig("qo_hnsw_export_plain", None, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _P, _P, _P, _P])
 _sig("qo_hnsw_search", C.c_uint32, [_P, C.POINTER(Scorer), C.c_uint32, C.c_uint32, _P, C.POINTER(C.c_uint64)])
 _sig("qo_links_heuristic", C.c_uint32, [_P, C.c_uint32, C.c_uint32, _P, C.c_uint32, _P])
@@ -357,10 +358,11 @@ def merge_topk(lists, counts, k, idx_base=None):
 class PlainLinks:
     """The plain GraphLinks arrays (graph_links/view.rs) + entry points: what qmx_hnsw_create ingests."""
 
-    def __init__(self, m, m0, reindex, level_offsets, offsets, neighbors, ep_ids, ep_levels):
+    def __init__(self, m, m0, reindex, level_offsets, offsets, neighbors, ep_ids, ep_levels, xp_ids=(), xp_levels=()):
         self.m, self.m0 = m, m0
         self.reindex, self.level_offsets, self.offsets, self.neighbors = reindex, level_offsets, offsets, neighbors
         self.ep_ids, self.ep_levels = ep_ids, ep_levels
+        self.xp_ids, self.xp_levels = xp_ids, xp_levels          # EntryPoints::extra_entry_points (iter_unsorted order)
 
     def links(self, point, level):
         idx = point if level == 0 else int(self.level_offsets[level]) + int(self.reindex[point])
@@ -402,6 +404,12 @@ class Hnsw:
         _lib.qo_hnsw_entry_points(self.h, _p(ids), _p(lv), n)
         return ids, lv
 
+    def extra_entry_points(self):
+        n = _lib.qo_hnsw_extra_entry_points(self.h, None, None, 0)
+        ids, lv = np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.uint32)
+        _lib.qo_hnsw_extra_entry_points(self.h, _p(ids), _p(lv), n)
+        return ids, lv
+
     def export_plain(self) -> PlainLinks:
         nl, no, nn = C.c_uint32(), C.c_uint64(), C.c_uint64()
         _lib.qo_hnsw_export_plain(self.h, C.byref(nl), C.byref(no), C.byref(nn), None, None, None, None)
@@ -412,7 +420,8 @@ class Hnsw:
         _lib.qo_hnsw_export_plain(self.h, C.byref(nl), C.byref(no), C.byref(nn), _p(reindex), _p(level_offsets), _p(offsets),
                                   _p(neighbors))
         ids, lv = self.entry_points()
-        return PlainLinks(self.m, self.m0, reindex, level_offsets, offsets, neighbors[:nn.value], ids, lv)
+        xids, xlv = self.extra_entry_points()
+        return PlainLinks(self.m, self.m0, reindex, level_offsets, offsets, neighbors[:nn.value], ids, lv, xids, xlv)
 
     # -- searches: one qo_scorer per query ------------------------------------------------------------
     def _run(self, scorer, top, ef):

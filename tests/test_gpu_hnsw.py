@@ -1,0 +1,269 @@
+"""GPU parity of the device-resident HNSW search (`qmx_hnsw_search`) against the CPU oracle's
+restatement of `GraphLayers::search` (lib/segment/src/index/hnsw_index/graph_layers.rs:530-562) on
+the SAME graph (built by the oracle, exported as plain GraphLinks).
+
+Bars: f32 / SQ / PQ scorers are bit-exact, so with distinct scores the walk is the same walk:
+identical id lists, identical score bits and the identical NUMBER of scored points (the reference's
+hardware counter).  f16 scores differ in summation order (<= 1e-5), u8 scores tie (integers): there the
+bar is the reference's own (`hnsw_quantized_search_test.rs`-style recall against exact search).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def qa():
+    import qdrant_amd
+    assert qdrant_amd.device_count() >= 1
+    return qdrant_amd
+
+
+def _dist(qa, d):
+    return {O.COSINE: qa.Distance.Cosine, O.DOT: qa.Distance.Dot, O.EUCLID: qa.Distance.Euclid,
+            O.MANHATTAN: qa.Distance.Manhattan}[d]
+
+
+def _same(got, want):
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g["idx"].tolist() == w["idx"].tolist()
+        assert np.array_equal(g["score"].view(np.uint32), w["score"].view(np.uint32))
+
+
+def _same_modulo_ties(got, want):
+    """Score lists bit-equal; ids equal wherever the score is unique in the list and above the last (boundary) score."""
+    n_ids = 0
+    for g, w in zip(got, want):
+        assert np.array_equal(g["score"].view(np.uint32), w["score"].view(np.uint32))
+        sc = w["score"]
+        for i in range(len(w)):
+            if (sc == sc[i]).sum() == 1 and sc[i] != sc[-1]:
+                assert g["idx"][i] == w["idx"][i]
+                n_ids += 1
+    return n_ids
+
+
+_GRAPHS = {}
+
+
+def _graph(distance, n, dim, m, seed):
+    key = (distance, n, dim, m, seed)
+    if key not in _GRAPHS:
+        rows = O.preprocess(distance, O.synth(seed, 0, n, dim))
+        st = O.DenseStorage(O.F32, distance, rows)
+        g = O.Hnsw(st, m=m, ef_construct=64, seed=seed & 0xFF, threads=0)
+        _GRAPHS[key] = (rows, st, g, g.export_plain())
+    return _GRAPHS[key]
+
+
+@pytest.mark.parametrize("distance", [O.COSINE, O.EUCLID, O.DOT, O.MANHATTAN])
+@pytest.mark.parametrize("dim", [24, 48, 100])          # 24: SSE/scalar leaf (one lane per row); 48/100: AVX leaf (+ scalar tail)
+def test_f32_search_is_the_reference_walk(qa, distance, dim):
+    n, m, nq = 2500, 8, 40
+    rows, st, g, plain = _graph(distance, n, dim, m, 0x5EED0300 + dim)
+    queries = O.synth(0x5EED0301 + distance, 0, nq, dim)
+    vs = qa.VectorStorage(rows, _dist(qa, distance))
+    graph = qa.GraphLayers.from_plain(plain)
+    scorer = qa.new_raw_scorer(queries, vs)
+    for top, ef in [(10, 64), (10, 16), (5, 128), (10, 200), (64, 8), (1, 1)]:
+        want, stats = g.search_dense(st, queries, top, ef, with_stats=True)
+        got, scored = graph.search(top, ef, scorer, with_scored=True)
+        _same(got, want)
+        if distance == O.MANHATTAN:
+            # the synthetic generator is integer-based (Irwin-Hall of 16-bit uniforms): L1 distances tie now and
+            # then, and a candidate that ties with the lower bound is expanded or not depending on BinaryHeap
+            # order in the reference (unpinned) -- same results, a handful of scored points apart
+            assert abs(scored - sum(stats)) <= sum(stats) // 1000
+        else:
+            assert scored == sum(stats)
+
+
+def test_deleted_points_and_entry_point_fallback(qa):
+    n, dim, m, nq = 2000, 32, 8, 24
+    rows, st_all, g, plain = _graph(O.COSINE, n, dim, m, 0x5EED0310)
+    queries = O.synth(0x5EED0311, 0, nq, dim)
+    rng = np.random.default_rng(5)
+    deleted = rng.random(n) < 0.3
+    ep_ids, _ = g.entry_points()
+    deleted[ep_ids[0]] = True                      # the best entry point is gone: get_entry_point moves on
+    vec_deleted = rng.random(n) < 0.05
+    st_del = O.DenseStorage(O.F32, O.COSINE, rows, point_deleted=deleted, vec_deleted=vec_deleted)
+    vs = qa.VectorStorage(rows, qa.Distance.Cosine)
+    vs.set_deleted(deleted, vec_deleted)
+    graph = qa.GraphLayers.from_plain(plain)
+    scorer = qa.new_raw_scorer(queries, vs)
+    want, stats = g.search_dense(st_del, queries, 10, 64, with_stats=True)
+    got, scored = graph.search(10, 64, scorer, with_scored=True)
+    _same(got, want)
+    assert scored == sum(stats)
+    for r in got:
+        assert not deleted[r["idx"]].any() and not vec_deleted[r["idx"]].any()
+    # everything deleted: no entry point -> empty result (graph_layers.rs:539-542)
+    vs.set_deleted(np.ones(n, dtype=bool), None)
+    assert all(len(r) == 0 for r in graph.search(10, 64, scorer))
+
+
+def test_more_queries_than_slots_and_repeatability(qa):
+    """Slots are reused across queries: the visited bitmap must come back clean (log and full clear)."""
+    n, dim, m = 1500, 32, 8
+    rows, st, g, plain = _graph(O.DOT, n, dim, m, 0x5EED0320)
+    base = O.synth(0x5EED0321, 0, 50, dim)
+    queries = np.tile(base, (120, 1))               # 6000 searches, 50 distinct
+    vs = qa.VectorStorage(rows, qa.Distance.Dot)
+    graph = qa.GraphLayers.from_plain(plain)
+    want = g.search_dense(st, base, 10, 48)
+    for cap in (None, "4"):                         # "4": the log overflows at once -> whole-bitmap clear path
+        if cap is None:
+            os.environ.pop("QMX_HNSW_LOG_CAP", None)
+        else:
+            os.environ["QMX_HNSW_LOG_CAP"] = cap
+        try:
+            scorer = qa.new_raw_scorer(queries, vs)
+            for _ in range(2):                      # second launch reuses the same scratch
+                got = graph.search(10, 48, scorer)
+                _same(got[:50], want)
+                for rep in range(1, 120):
+                    for j in (0, 17, 49):
+                        assert np.array_equal(got[rep * 50 + j], got[j])
+        finally:
+            os.environ.pop("QMX_HNSW_LOG_CAP", None)
+
+
+@pytest.mark.parametrize("distance", [O.DOT, O.EUCLID, O.MANHATTAN])
+def test_sq_scorer_walk_bit_exact_and_rescoring(qa, distance):
+    n, dim, m, nq = 3000, 96, 8, 32
+    rows, st, g, plain = _graph(distance, n, dim, m, 0x5EED0330 + distance)
+    queries = O.synth(0x5EED0331, 0, nq, dim)
+    qpre = O.preprocess(distance, queries)
+    quant = qa.ScalarQuantizer.from_min_max(rows, dim, _dist(qa, distance))
+    osq = O.SqOracle(distance, dim, quant.alpha, quant.offset)
+    sq_rows = osq.encode_rows(rows)
+    enc = qa.EncodedVectorsU8(quant.encode(rows), quant)
+    graph = qa.GraphLayers.from_plain(plain)
+    scorer = qa.new_raw_scorer(queries, enc)
+    want = g.search_sq(st, osq, qpre, 20, 64)
+    got = graph.search(20, 64, scorer)
+    if distance == O.MANHATTAN:
+        # alpha * sum|q - v| over integer codes: scores tie, the walk may legitimately take another branch among equals
+        # (unpinned in the reference).  Every returned pair must still be a true SQ score, bit-exact, and the
+        # walks must be of the same quality.
+        exact_sq = [set(np.argsort(-osq.score_points(qpre[i:i + 1], np.arange(n))[0], kind="stable")[:20].tolist()) for i in range(nq)]
+        rg = sum(len(set(r["idx"].tolist()) & e) for r, e in zip(got, exact_sq))
+        rw = sum(len(set(r["idx"].tolist()) & e) for r, e in zip(want, exact_sq))
+        assert abs(rg - rw) <= 0.02 * 20 * nq
+        for i, r in enumerate(got):
+            w = osq.score_points(qpre[i:i + 1], r["idx"])[0]
+            assert np.array_equal(r["score"].view(np.uint32), w.view(np.uint32)) and np.all(np.diff(r["score"]) <= 0)
+    else:
+        _same(got, want)
+    assert sq_rows.shape[0] == n
+    # hnsw/read_view/search.rs: oversampled quantized search, then rescoring with the original vectors
+    vs = qa.VectorStorage(rows, _dist(qa, distance))
+    raw = qa.new_raw_scorer(queries, vs)
+    ids = np.zeros((nq, 20), dtype=np.uint32)
+    cnt = np.zeros(nq, dtype=np.uint32)
+    for i, r in enumerate(got):
+        ids[i, :len(r)] = r["idx"]
+        cnt[i] = len(r)
+    res = raw.rescore(ids, 10, cnt)
+    exact = st.peek_top(queries, 10)
+    hit = sum(len(set(a["idx"].tolist()) & set(b["idx"].tolist())) for a, b in zip(res, exact))
+    assert hit / (10 * nq) > 0.8
+    for i, r in enumerate(res):                     # rescored scores are the exact f32 scores
+        w = st.score_points(queries[i:i + 1], r["idx"])[0]
+        assert np.array_equal(r["score"].view(np.uint32), w.view(np.uint32))
+
+
+@pytest.mark.parametrize("distance,dim,chunk", [(O.DOT, 64, 4), (O.EUCLID, 96, 16), (O.COSINE, 70, 8)])
+def test_pq_scorer_walk_bit_exact(qa, distance, dim, chunk):
+    n, m, nq = 3000, 8, 24
+    rows, st, g, plain = _graph(distance, n, dim, m, 0x5EED0340 + dim)
+    queries = O.synth(0x5EED0341, 0, nq, dim)
+    qpre = O.preprocess(distance, queries)
+    cen = O.PqOracle.train(rows[:2000], dim, chunk, 256, iters=3)
+    opq = O.PqOracle(distance, dim, chunk, cen)
+    codes = opq.encode(rows)
+    quant = qa.ProductQuantizer(dim, _dist(qa, distance), chunk, cen)
+    enc = qa.EncodedVectorsPQ(codes, quant)
+    graph = qa.GraphLayers.from_plain(plain)
+    scorer = qa.new_raw_scorer(queries, enc)
+    # PQ scores tie now and then (sums of few LUT entries): compare the walks where the oracle's result has distinct scores
+    want = g.search_pq(st, opq, qpre, 10, 64)
+    got = graph.search(10, 64, scorer)
+    n_cmp = 0
+    for gq, wq in zip(got, want):
+        assert np.array_equal(gq["score"].view(np.uint32), wq["score"].view(np.uint32))
+        if len(np.unique(wq["score"])) == len(wq):
+            assert gq["idx"].tolist() == wq["idx"].tolist()
+            n_cmp += 1
+    assert n_cmp >= nq // 2
+
+
+@pytest.mark.parametrize("dtype", ["f16", "u8"])
+def test_f16_u8_search_recall(qa, dtype):
+    n, dim, m, nq = 3000, 64, 8, 32
+    rng = np.random.default_rng(9)
+    if dtype == "f16":
+        raw = O.preprocess(O.COSINE, O.synth(0x5EED0350, 0, n, dim))
+        stored = O.to_f16(raw)
+        st = O.DenseStorage(O.F16, O.COSINE, stored)
+        queries = O.synth(0x5EED0351, 0, nq, dim)
+        vs = qa.VectorStorage(stored.view(np.float16), qa.Distance.Cosine, qa.VectorStorageDatatype.Float16)
+    else:
+        stored = rng.integers(0, 256, size=(n, dim)).astype(np.uint8)
+        st = O.DenseStorage(O.U8, O.EUCLID, stored)
+        queries = rng.integers(0, 256, size=(nq, dim)).astype(np.float32)
+        vs = qa.VectorStorage(stored, qa.Distance.Euclid, qa.VectorStorageDatatype.Uint8)
+    g = O.Hnsw(st, m=m, ef_construct=64, seed=3)
+    graph = qa.GraphLayers.from_plain(g.export_plain())
+    scorer = qa.new_raw_scorer(queries, vs)
+    got = graph.search(10, 96, scorer)
+    want = g.search_dense(st, queries, 10, 96)
+    exact = st.peek_top(queries, 10)
+
+    def recall(res):
+        return sum(len(set(a["idx"].tolist()) & set(b["idx"].tolist())) for a, b in zip(res, exact)) / (10.0 * nq)
+    assert recall(got) > 0.9 and abs(recall(got) - recall(want)) < 0.03
+    for r in got:
+        assert len(r) == 10 and np.all(np.diff(r["score"]) <= 0)
+
+
+def test_tiny_graphs_and_argument_errors(qa):
+    dim = 32
+    rows = O.preprocess(O.COSINE, O.synth(1, 0, 3, dim))
+    st = O.DenseStorage(O.F32, O.COSINE, rows)
+    g = O.Hnsw(st, m=4, ef_construct=8, seed=1)
+    vs = qa.VectorStorage(rows, qa.Distance.Cosine)
+    graph = qa.GraphLayers.from_plain(g.export_plain())
+    queries = O.synth(2, 0, 5, dim)
+    scorer = qa.new_raw_scorer(queries, vs)
+    _same(graph.search(10, 4, scorer), g.search_dense(st, queries, 10, 4))     # fewer points than top
+    with pytest.raises(qa.QmxError) as e:
+        graph.search(10, 1000, scorer)                                          # ef beyond the register beam
+    assert e.value.status == qa._ffi.ERR_NOT_SUPPORTED
+    with pytest.raises(qa.QmxError) as e:
+        graph.search(0, 10, scorer)
+    assert e.value.status == qa._ffi.ERR_BAD_ARG
+    assert all(len(r) == 3 for r in graph.search(10, 16, scorer, is_stopped=False))
+    with pytest.raises(qa.QmxError) as e:
+        graph.search(10, 16, scorer, is_stopped=True)
+    assert e.value.status == qa._ffi.ERR_CANCELLED
+    # a graph over more points than the segment holds is refused
+    big = O.preprocess(O.COSINE, O.synth(3, 0, 50, dim))
+    gb = O.Hnsw(O.DenseStorage(O.F32, O.COSINE, big), m=4, ef_construct=8, seed=1)
+    graph_big = qa.GraphLayers.from_plain(gb.export_plain())
+    with pytest.raises(qa.QmxError) as e:
+        graph_big.search(5, 8, scorer)
+    assert e.value.status == qa._ffi.ERR_OUT_OF_BOUNDS
+    # corrupt links are rejected at create time
+    p = g.export_plain()
+    bad = p.offsets.copy()
+    bad[1] = bad[-1] + 5
+    with pytest.raises(qa.QmxError):
+        qa.GraphLayers(p.m, p.m0, p.reindex, p.level_offsets, bad, p.neighbors, p.ep_ids, p.ep_levels)
