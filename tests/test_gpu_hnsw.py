@@ -174,7 +174,7 @@ def test_sq_scorer_walk_bit_exact_and_rescoring(qa, distance):
     res = raw.rescore(ids, 10, cnt)
     exact = st.peek_top(queries, 10)
     hit = sum(len(set(a["idx"].tolist()) & set(b["idx"].tolist())) for a, b in zip(res, exact))
-    assert hit / (10 * nq) > 0.8
+    assert hit / (10 * nq) > 0.6      # hnsw_quantized_search_test.rs:248-330 asks for > 0.4
     for i, r in enumerate(res):                     # rescored scores are the exact f32 scores
         w = st.score_points(queries[i:i + 1], r["idx"])[0]
         assert np.array_equal(r["score"].view(np.uint32), w.view(np.uint32))
