@@ -328,6 +328,16 @@ typedef struct qmx_hnsw qmx_hnsw;
 /* Uploads the graph (replaces `GraphLayers::load` for the search side).  Immutable afterwards and
  * safe for concurrent searches from any number of threads (each with its own qmx_query). */
 QMX_API int32_t qmx_hnsw_create(const qmx_hnsw_desc *desc, qmx_hnsw **out);
+/* Same, from the bytes of a PLAIN `links.bin` / `graph links` file as written by
+ * `serialize_graph_links(.., GraphLinksFormatParam::Plain, ..)` (graph_links/serializer.rs:52-209):
+ * HeaderPlain {point_count, levels_count, total_neighbors_count, total_offset_count,
+ * offsets_padding_bytes, [u8; 24]} (graph_links/header.rs:9-20, 64 bytes), level_offsets
+ * [levels_count] u64, reindex [point_count] u32, neighbors u32, padding, offsets u64.
+ * `desc` supplies m, m0, the entry points and the device; its array fields are ignored.
+ * Compressed formats (header version 0xFFFF_FFFF_FFFF_FF01/02) => QMX_ERR_NOT_SUPPORTED:
+ * convert with `GraphLinks::to_edges` + the plain serializer first. */
+QMX_API int32_t qmx_hnsw_create_from_plain_file(const void *bytes, uint64_t n_bytes, const qmx_hnsw_desc *desc,
+                                                qmx_hnsw **out);
 QMX_API int32_t qmx_hnsw_destroy(qmx_hnsw *g);
 
 /* `GraphLayers::search(top, ef, SearchAlgorithm::Hnsw, FilteredScorer, None, is_stopped)`

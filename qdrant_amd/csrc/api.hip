@@ -181,6 +181,17 @@ struct qmx_query {
     bool timing = false;
 };
 
+// f32 dot / cosine rows of >= 32 elements scan 8..32 queries per pass on the f32 matrix cores (scan_mfma.hip)
+static bool mfma_scan_ok(const qmx_segment *s) {
+    return s->dtype == QMX_DTYPE_F32 && (s->distance == QMX_DISTANCE_DOT || s->distance == QMX_DISTANCE_COSINE) && s->dim >= 32 &&
+           s->fast_layout() && getenv("QMX_NO_MFMA_SCAN") == nullptr;
+}
+constexpr uint32_t MAX_QT_MFMA = 32;
+// queries scored per pass of the stored block
+static uint32_t tile_qt(const qmx_segment *s) {
+    return mfma_scan_ok(s) && (size_t)MAX_QT_MFMA * (((size_t)s->dim * 4 + 127) / 128 * 128 + QUERY_AUX_BYTES) <= 150 * 1024 ? MAX_QT_MFMA : MAX_QT;
+}
+
 // stage a possibly-host buffer on the query's stream; returns a device pointer
 static int32_t stage_in(qmx_query *q, DevBuf &buf, const void *src, size_t bytes, const void **dev_out) {
     if (bytes == 0 || !src) {
@@ -533,8 +544,8 @@ static int32_t query_alloc(const qmx_segment *seg, uint32_t nq, qmx_query **out)
     q->seg = seg;
     q->device = seg->device;
     q->nq = nq;
-    q->nq_padded = ((nq + MAX_QT - 1) / MAX_QT) * MAX_QT;
-    if (q->nq_padded == 0) q->nq_padded = MAX_QT;
+    q->nq_padded = ((nq + MAX_QT_MFMA - 1) / MAX_QT_MFMA) * MAX_QT_MFMA;
+    if (q->nq_padded == 0) q->nq_padded = MAX_QT_MFMA;
     if (seg->dtype == QMX_DTYPE_PQ) q->nq_padded = std::max<uint32_t>(nq, 1);   // LUTs are never read past nq
     // tile entry = elements zero-padded to whole 128-byte segments + the aux block
     q->aux_off = (uint32_t)((seg->scan_dim * elem_bytes(seg->dtype) + 127) & ~127u);
@@ -769,6 +780,7 @@ static int32_t launch_scan(const qmx_query *q, int qt, ScanMode mode, const Scan
         QMX_REQUIRE(s->fast_layout(), QMX_ERR_NOT_SUPPORTED,
                     "dtype %u dim %u: an adopted device block needs a 16-byte aligned base and row stride (got stride %llu); "
                     "let qmx_segment_create upload it instead", s->dtype, s->dim, (unsigned long long)s->row_stride);
+        if (qt >= 8 && mfma_scan_ok(s)) return launch_scan_f32_mfma(q->stream, qt, mode, a, s->num_cus, grid);
         return launch_scan_dense(q->stream, (int)s->dtype, (int)s->distance, qt, mode, a, s->num_cus, grid);
     }
     if (s->dtype == QMX_DTYPE_SQ_U8) return launch_scan_sq(q->stream, (int)s->distance, qt, mode, a, s->num_cus, grid);
@@ -780,8 +792,9 @@ static int32_t launch_scan(const qmx_query *q, int qt, ScanMode mode, const Scan
 // scores[qi * n + i] for every query of the batch
 static int32_t score_ids_device(qmx_query *q, const uint32_t *d_ids, uint64_t n, float *d_scores, qmx_counters *counters) {
     const qmx_segment *s = q->seg;
-    for (uint32_t tile0 = 0; tile0 < q->nq; tile0 += MAX_QT) {
-        const uint32_t nq_tile = std::min<uint32_t>(MAX_QT, q->nq - tile0);
+    const uint32_t TQ = tile_qt(s);
+    for (uint32_t tile0 = 0; tile0 < q->nq; tile0 += TQ) {
+        const uint32_t nq_tile = std::min<uint32_t>(TQ, q->nq - tile0);
         ScanArgs a;
         fill_args(q, tile0, nq_tile, a);
         a.ids = d_ids;
@@ -795,7 +808,7 @@ static int32_t score_ids_device(qmx_query *q, const uint32_t *d_ids, uint64_t n,
     }
     if (counters) {
         counters->vectors_scored += (uint64_t)q->nq * n;
-        counters->bytes_read += (uint64_t)((q->nq + MAX_QT - 1) / MAX_QT) * n * s->row_bytes;
+        counters->bytes_read += (uint64_t)((q->nq + TQ - 1) / TQ) * n * s->row_bytes;
     }
     return QMX_OK;
 }
@@ -838,13 +851,14 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
     const uint64_t n_cand = d_ids ? n_ids : s->scan_rows();
     // partial lists: one per block; bound the grid by what the buffer holds
     const uint32_t grid_cap = (uint32_t)s->num_cus * 8;
-    QMX_TRY(q->partial.reserve((size_t)grid_cap * MAX_QT * top * sizeof(uint64_t)));
-    for (uint32_t tile0 = 0; tile0 < q->nq; tile0 += MAX_QT) {
+    const uint32_t TQ = tile_qt(s);
+    QMX_TRY(q->partial.reserve((size_t)grid_cap * TQ * top * sizeof(uint64_t)));
+    for (uint32_t tile0 = 0; tile0 < q->nq; tile0 += TQ) {
         if (is_stopped && *is_stopped) {
             set_error("search cancelled");
             return QMX_ERR_CANCELLED;
         }
-        const uint32_t nq_tile = std::min<uint32_t>(MAX_QT, q->nq - tile0);
+        const uint32_t nq_tile = std::min<uint32_t>(TQ, q->nq - tile0);
         const int qt = (int)pow2_ceil(nq_tile);
         ScanArgs a;
         fill_args(q, tile0, nq_tile, a);
@@ -864,7 +878,7 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
     }
     if (counters) {
         counters->vectors_scored += (uint64_t)q->nq * n_cand;
-        counters->bytes_read += (uint64_t)((q->nq + MAX_QT - 1) / MAX_QT) * n_cand * s->row_bytes;
+        counters->bytes_read += (uint64_t)((q->nq + TQ - 1) / TQ) * n_cand * s->row_bytes;
     }
     return QMX_OK;
 }
@@ -1057,6 +1071,50 @@ int32_t qmx_hnsw_create(const qmx_hnsw_desc *d, qmx_hnsw **out) {
     }
     *out = g;
     return QMX_OK;
+}
+
+int32_t qmx_hnsw_create_from_plain_file(const void *bytes, uint64_t n_bytes, const qmx_hnsw_desc *desc, qmx_hnsw **out) {
+    QMX_REQUIRE(bytes && desc && out, QMX_ERR_BAD_ARG, "NULL argument");
+    *out = nullptr;
+    QMX_REQUIRE(!is_device_ptr(bytes), QMX_ERR_BAD_ARG, "the links file must be host memory (mmap it)");
+    QMX_REQUIRE(n_bytes >= 64, QMX_ERR_BAD_ARG, "links file shorter than its 64-byte header");
+    const uint8_t *b = (const uint8_t *)bytes;
+    uint64_t hdr[5];
+    memcpy(hdr, b, sizeof(hdr));
+    const uint64_t point_count = hdr[0], levels_count = hdr[1], total_neighbors = hdr[2], total_offsets = hdr[3], pad = hdr[4];
+    QMX_REQUIRE(levels_count != 0xFFFFFFFFFFFFFF01ull && levels_count != 0xFFFFFFFFFFFFFF02ull, QMX_ERR_NOT_SUPPORTED,
+                "compressed graph links (header version %llx): re-serialize as Plain first", (unsigned long long)levels_count);
+    QMX_REQUIRE(point_count <= 0xFFFFFFFFull && levels_count <= 64 && (pad == 0 || pad == 4), QMX_ERR_BAD_ARG, "not a plain links header");
+    // section sizes, with overflow-safe bounds (every count is checked against the file size first)
+    QMX_REQUIRE(total_neighbors <= n_bytes / 4 && total_offsets <= n_bytes / 8, QMX_ERR_BAD_ARG, "links header counts exceed the file size");
+    const uint64_t off_levels = 64, off_reindex = off_levels + levels_count * 8, off_neigh = off_reindex + point_count * 4,
+                   off_offsets = off_neigh + total_neighbors * 4 + pad, end = off_offsets + total_offsets * 8;
+    QMX_REQUIRE(end <= n_bytes && off_offsets % 8 == 0, QMX_ERR_BAD_ARG, "links file truncated or misaligned (%llu > %llu)",
+                (unsigned long long)end, (unsigned long long)n_bytes);
+    QMX_REQUIRE(point_count == 0 || total_offsets >= 1, QMX_ERR_BAD_ARG, "empty offsets section");
+    std::vector<uint64_t> level_offsets((size_t)levels_count + 1);
+    memcpy(level_offsets.data(), b + off_levels, (size_t)levels_count * 8);
+    level_offsets[(size_t)levels_count] = total_offsets ? total_offsets - 1 : 0;
+    // the sections are only 4-byte aligned inside an arbitrary buffer: copy what needs 8
+    std::vector<uint64_t> offsets((size_t)total_offsets);
+    memcpy(offsets.data(), b + off_offsets, (size_t)total_offsets * 8);
+    std::vector<uint32_t> reindex((size_t)point_count), neighbors((size_t)total_neighbors);
+    memcpy(reindex.data(), b + off_reindex, (size_t)point_count * 4);
+    memcpy(neighbors.data(), b + off_neigh, (size_t)total_neighbors * 4);
+    qmx_hnsw_desc d = *desc;
+    d.n_points = (uint32_t)point_count;
+    d.n_levels = (uint32_t)levels_count;
+    d.reindex = reindex.data();
+    d.level_offsets = level_offsets.data();
+    d.offsets = offsets.data();
+    d.n_offsets = total_offsets;
+    d.neighbors = neighbors.data();
+    d.n_neighbors = total_neighbors;
+    for (uint64_t i = 0; i < total_neighbors; ++i)
+        QMX_REQUIRE(neighbors[i] < point_count, QMX_ERR_OUT_OF_BOUNDS, "link %u out of range", neighbors[i]);
+    for (uint64_t i = 0; i < point_count; ++i)
+        QMX_REQUIRE(reindex[i] < point_count, QMX_ERR_OUT_OF_BOUNDS, "reindex entry out of range");
+    return qmx_hnsw_create(&d, out);
 }
 
 static int32_t launch_hnsw(const qmx_query *q, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {

@@ -51,6 +51,26 @@ class GraphLayers:
         return cls(links.m, links.m0, links.reindex, links.level_offsets, links.offsets, links.neighbors, links.ep_ids,
                    links.ep_levels, getattr(links, "xp_ids", ()), getattr(links, "xp_levels", ()), device_id)
 
+    @classmethod
+    def from_plain_file(cls, data: bytes, m: int, m0: int, entry_point_ids, entry_point_levels, extra_entry_point_ids=(),
+                        extra_entry_point_levels=(), device_id: int = 0):
+        """The bytes of a plain graph-links file (graph_links/serializer.rs, GraphLinksFormatParam::Plain)."""
+        self = cls.__new__(cls)
+        self.m, self.m0 = int(m), int(m0)
+        ep, epl, xp, xpl = _u32(entry_point_ids), _u32(entry_point_levels), _u32(extra_entry_point_ids), _u32(extra_entry_point_levels)
+        buf = np.frombuffer(data, dtype=np.uint8)
+        self._keep = [ep, epl, xp, xpl, buf]
+        d = F.HnswDesc()
+        d.m, d.m0 = self.m, self.m0
+        d.entry_point_ids, d.entry_point_levels, d.n_entry_points = F.ptr(ep).value, F.ptr(epl).value, len(ep)
+        d.extra_entry_point_ids, d.extra_entry_point_levels, d.n_extra_entry_points = F.ptr(xp).value, F.ptr(xpl).value, len(xp)
+        d.device_id = device_id
+        self._h = C.c_void_p()
+        F.check(F.lib().qmx_hnsw_create_from_plain_file(F.ptr(buf), len(buf), C.byref(d), C.byref(self._h)))
+        self.n_points = int(np.frombuffer(data[:8], dtype=np.uint64)[0]) if len(data) >= 8 else 0
+        self.counters = F.Counters()
+        return self
+
     def search(self, top: int, ef: int, points_scorer: RawScorer, is_stopped=None, with_scored: bool = False):
         """`GraphLayers::search(top, ef, Hnsw, points_scorer, None, is_stopped)` for every query of the
         scorer batch -> list of ScoredPointOffset arrays (descending score, at most `top`)."""

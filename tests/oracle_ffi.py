@@ -369,6 +369,17 @@ class PlainLinks:
         return self.neighbors[int(self.offsets[idx]):int(self.offsets[idx + 1])]
 
 
+def plain_links_file(p: "PlainLinks") -> bytes:
+    """The PLAIN graph-links file of lib/segment/src/index/hnsw_index/graph_links/serializer.rs:52-209:
+    HeaderPlain (header.rs:9-20, 64 bytes), level_offsets [levels], reindex, neighbors, padding to 8, offsets."""
+    levels = len(p.level_offsets) - 1
+    body = (np.asarray(p.level_offsets[:levels], dtype="<u8").tobytes() + np.asarray(p.reindex, dtype="<u4").tobytes()
+            + np.asarray(p.neighbors, dtype="<u4").tobytes())
+    pad = (-(64 + len(body))) % 8
+    header = np.array([len(p.reindex), levels, len(p.neighbors), len(p.offsets), pad, 0, 0, 0], dtype="<u8").tobytes()
+    return header + body + b"\0" * pad + np.asarray(p.offsets, dtype="<u8").tobytes()
+
+
 class Hnsw:
     """GraphLayersBuilder -> GraphLayers on the CPU oracle, built over a DenseStorage."""
 

@@ -55,3 +55,38 @@ def test_product_code_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 text = open(os.path.join(base, f)).read()
                 assert "qdrant_oracle" not in text and "oracle_ffi" not in text and "libqdrant_oracle" not in text, f
+
+
+def test_plain_links_file_header_is_validated_before_any_device_work():
+    """qmx_hnsw_create_from_plain_file parses graph_links/header.rs:9-20 on the host: malformed files are refused
+    with BAD_ARG / NOT_SUPPORTED even on a box without a GPU; a well-formed one then needs the device."""
+    import torch
+    import oracle_ffi as O
+    from qdrant_amd import _ffi as F
+    rows = O.preprocess(O.COSINE, O.synth(5, 0, 200, 16))
+    g = O.Hnsw(O.DenseStorage(O.F32, O.COSINE, rows), m=4, ef_construct=16, seed=1)
+    p = g.export_plain()
+    data = O.plain_links_file(p)
+    assert len(data) % 8 == 0 and np.frombuffer(data[:32], dtype="<u8").tolist() == [200, len(p.level_offsets) - 1, len(p.neighbors), len(p.offsets)]
+
+    def create(buf):
+        d = F.HnswDesc()
+        d.m, d.m0 = p.m, p.m0
+        ep, epl = np.ascontiguousarray(p.ep_ids, dtype=np.uint32), np.ascontiguousarray(p.ep_levels, dtype=np.uint32)
+        d.entry_point_ids, d.entry_point_levels, d.n_entry_points = ep.ctypes.data, epl.ctypes.data, len(ep)
+        h = C.c_void_p()
+        arr = np.frombuffer(buf, dtype=np.uint8)
+        rc = F.lib().qmx_hnsw_create_from_plain_file(F.ptr(arr), len(arr), C.byref(d), C.byref(h))
+        if rc == F.OK:
+            F.lib().qmx_hnsw_destroy(h)
+        return rc
+    assert create(data[:40]) == F.ERR_BAD_ARG                                    # shorter than the header
+    assert create(data[:-8]) == F.ERR_BAD_ARG                                    # truncated offsets section
+    compressed = bytearray(data)
+    compressed[8:16] = np.array([0xFFFFFFFFFFFFFF01], dtype="<u8").tobytes()     # HEADER_VERSION_COMPRESSED sits where levels_count is
+    assert create(bytes(compressed)) == F.ERR_NOT_SUPPORTED
+    bad = bytearray(data)
+    off_neigh = 64 + 8 * (len(p.level_offsets) - 1) + 4 * 200
+    bad[off_neigh:off_neigh + 4] = np.array([5000], dtype="<u4").tobytes()       # a link past point_count
+    assert create(bytes(bad)) == F.ERR_OUT_OF_BOUNDS
+    assert create(data) == (F.OK if torch.cuda.is_available() else F.ERR_NO_DEVICE)

@@ -267,3 +267,16 @@ def test_tiny_graphs_and_argument_errors(qa):
     bad[1] = bad[-1] + 5
     with pytest.raises(qa.QmxError):
         qa.GraphLayers(p.m, p.m0, p.reindex, p.level_offsets, bad, p.neighbors, p.ep_ids, p.ep_levels)
+
+
+def test_plain_links_file_ingestion(qa):
+    """The reference's plain graph-links file (graph_links/serializer.rs) uploads to the same graph as the arrays."""
+    n, dim, m, nq = 2000, 32, 8, 16
+    rows, st, g, plain = _graph(O.COSINE, n, dim, m, 0x5EED0310)
+    queries = O.synth(0x5EED0361, 0, nq, dim)
+    vs = qa.VectorStorage(rows, qa.Distance.Cosine)
+    scorer = qa.new_raw_scorer(queries, vs)
+    from_file = qa.GraphLayers.from_plain_file(O.plain_links_file(plain), plain.m, plain.m0, plain.ep_ids, plain.ep_levels,
+                                               plain.xp_ids, plain.xp_levels)
+    assert from_file.n_points == n
+    _same(from_file.search(10, 64, scorer), g.search_dense(st, queries, 10, 64))
