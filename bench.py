@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=768)
-    ap.add_argument("--batch", type=int, default=4, help="queries per scan (Q)")
+    ap.add_argument("--batch", type=int, default=16, help="queries per scan (Q)")
     ap.add_argument("--top", type=int, default=10)
     ap.add_argument("--nqueries", type=int, default=1024)
     ap.add_argument("--cpu-rows", type=int, default=1_000_000, help="rows of the CPU-baseline sample")
@@ -154,7 +154,7 @@ def main():
                    "collection_qps": round(Q * args.steps / elapsed, 2)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": _pmc_traffic(n, dim, Q),
-                     "kernel": "scan_kernel<RowF32<DOT>,QT=%d>" % _pow2(min(Q, 16)), "kernel_ms": round(kernel_ms, 4),
+                     "kernel": _kernel_name(Q), "kernel_ms": round(kernel_ms, 4),
                      "launches_timed": int(kl.value), "algorithmic_bytes_per_launch": alg_bytes},
     }
 
@@ -216,6 +216,15 @@ def _pmc_traffic(n, dim, Q):
         return d.get("%dx%d_q%d" % (n, dim, Q))
     except Exception:
         return None
+
+
+def _kernel_name(Q):
+    """The scan kernel a batch of Q queries runs (api.hip launch_scan): <= 4 queries per pass stream through the VALU
+    kernel, 8..32 through the f32 matrix-core kernel (scan_mfma.hip); larger batches are cut into 32-query passes."""
+    qt = _pow2(min(Q, 32))
+    if qt >= 8:
+        return "scan_f32_mfma_kernel<QW=%d,QSPLIT=%d> (v_mfma_f32_4x4x1, %d queries per pass)" % (min(qt, 16), max(1, qt // 16), qt)
+    return "scan_kernel<RowF32<DOT>,QT=%d>" % qt
 
 
 def _human(n):

@@ -15,16 +15,21 @@
 // Mapping block -> chain, m -> stored row, n -> query, and issuing the instruction once per 32-float step
 // makes every accumulator element exactly one AVX chain.  The fold is done with the reference's tree.
 //
-// Lane roles (lane = 4 * blk + x,  blk = u + 8 * rh):
-//   u  = 0..7  which 16-byte piece of the 128-byte step the lane loads (columns 4u .. 4u+3)
-//   rh = 0..1  which half of the 8-row tile (rows 4 rh + x)
+// Lane roles.  lane = x + 4 u0 + 8 u2 + 16 u1 + 32 rh  (MFMA block = lane >> 2):
+//   u  = u0 + 2 u1 + 4 u2 = 0..7  which 16-byte piece of the 128-byte step the lane loads (columns 4u .. 4u+3)
+//   rh = 0..1  which half of the 8-row tile (rows 4 rh .. 4 rh + 3)
 //   x  = 0..3  A operand: stored row 4 rh + x;   B operand: query 4 g + x  (g = query group)
 // One global_load_dwordx4 per lane per step feeds 4 MFMAs (t = 0..3: column 4u + t) per query group;
 // the 8 lanes of a row read one full 128-byte line, every fetched byte is used once, as in the VALU scan.
-// The query piece comes from the LDS tile with one ds_read_b128 per query group per step.
-// acc[g][t] (float4 = rows 4rh .. 4rh+3) of lane (u, rh, x) is chain c = 4u + t of query 4g + x, so
-//   r = u >> 1, j = 4 (u & 1) + t  ->  a+b / c+d: lanes u ^ 2 (xor 8), (a+b)+(c+d): u ^ 4 (xor 16),
-//   hi128 + lo128: u ^ 1 (xor 4), then (lr0 + lr1) + (lr2 + lr3) over t in-lane.
+// The query piece comes from the LDS tile with one conflict-free ds_read_b128 per query group per step.
+// acc[g][t] (float4 = rows 4rh .. 4rh+3) of lane (u, rh, x) is chain c = 4u + t of query 4g + x, AVX register
+// r = c >> 3 = u1 + 2 u2, SIMD lane j = c & 7 = 4 u0 + t.  The reference's tree, with every exchange step also
+// halving the set of (row, query) results a lane is responsible for:
+//   a + b, c + d        partner u1 ^ 1 = lane ^ 16   v_permlane16_swap   keeps rows {0,1} / {2,3}
+//   (a+b) + (c+d)       partner u2 ^ 1 = lane ^ 8    DPP row_ror:8       keeps row 2 u1 + u2
+//   hi128 + lo128       partner u0 ^ 1 = lane ^ 4    ds_swizzle          keeps query groups [0,NG/2) / [NG/2,NG)
+//   (lr0+lr1)+(lr2+lr3) over t, in-lane
+// so each lane ends with NG/2 finished scores (row 4rh + 2u1 + u2, queries 4 (gp + u0 NG/2) + x).
 #include "scan_common.hpp"
 
 namespace qmx {
@@ -41,14 +46,25 @@ __device__ __forceinline__ float swz_xor(float v) {
 __device__ __forceinline__ float ror8(float v) {   // lane l <-> l ^ 8 inside each row of 16 lanes
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128 /* row_ror:8 */, 0xF, 0xF, true));
 }
+// lanes of even 16-lane rows get a_mine + a_partner, lanes of odd rows b_mine + b_partner (partner = lane ^ 16)
+__device__ __forceinline__ float swap16_add(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
-template <int QT, int UNROLL, bool HAS_IDS, int MODE>
+// QW queries per wave, QSPLIT waves share one row stream (each scores its own QW queries of the
+// QW * QSPLIT-query tile; the second read of a row line hits L1 / L2), D row loads in flight per lane.
+template <int QW, int QSPLIT, int D, bool NT, bool HAS_IDS, int MODE>
 __global__ __launch_bounds__(MF_BLOCK) void scan_f32_mfma_kernel(const ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NG = QT / 4;
+    constexpr int NG = QW / 4;
+    constexpr int QT = QW * QSPLIT;
+    constexpr int NSTREAM = MF_NW / QSPLIT;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qs = wave % QSPLIT;          // which QW-query slice of the tile this wave scores
+    const int stream = wave / QSPLIT;      // which row stream of the block
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.queries);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
@@ -58,27 +74,64 @@ __global__ __launch_bounds__(MF_BLOCK) void scan_f32_mfma_kernel(const ScanArgs 
     __syncthreads();
 
     const int x = lane & 3;
-    const int u = (lane >> 2) & 7;
+    const int u0 = (lane >> 2) & 1, u2 = (lane >> 3) & 1, u1 = (lane >> 4) & 1;
+    const int u = u0 + 2 * u1 + 4 * u2;
     const int rh = lane >> 5;
+    constexpr int NGH = NG / 2;                 // finished (row, query) results per lane and tile
+    const int my_m = 2 * u1 + u2;               // ... for row 4 rh + my_m
     const unsigned char *rows = reinterpret_cast<const unsigned char *>(a.rows);
-    const unsigned char *qbase = smem + (uint32_t)x * a.q_stride + (uint32_t)u * 16;   // + g * 4 * q_stride + i * 128
+    const uint32_t q0 = (uint32_t)qs * QW;                       // first query of this wave
+    const unsigned char *qbase = smem + (q0 + (uint32_t)x) * a.q_stride + (uint32_t)u * 16;   // + g * 4 * q_stride + s * 128
     const uint32_t gstride = 4u * a.q_stride;
     const int top = (int)a.top;
 
-    uint64_t list[QT];
-    uint64_t thr[NG];     // this lane's view: k-th best key of query 4g + x
+    uint64_t list[QW];
+    uint64_t thr[NGH];    // k-th best key of the lane's own queries
+    int my_q[NGH];        // ... which are (wave-local index) 4 (gp + u0 NGH) + x
 #pragma unroll
-    for (int q = 0; q < QT; ++q) list[q] = 0;
+    for (int q = 0; q < QW; ++q) list[q] = 0;
 #pragma unroll
-    for (int g = 0; g < NG; ++g) thr[g] = 0;
+    for (int gp = 0; gp < NGH; ++gp) {
+        thr[gp] = 0;
+        my_q[gp] = 4 * (gp + u0 * NGH) + x;
+    }
 
-    const uint32_t gw = blockIdx.x * MF_NW + wave;
-    const uint32_t tw = gridDim.x * MF_NW;
+    const uint32_t gw = blockIdx.x * NSTREAM + stream;
+    const uint32_t tw = gridDim.x * NSTREAM;
     const uint64_t n_tiles = (a.n_cand + 7) / 8;
     const uint32_t nseg = a.nseg;
 
-    for (uint64_t tile = gw; tile < n_tiles; tile += tw) {
-        // the 4 rows of this lane's half tile (rows 4rh + m); the lane itself streams row 4rh + x
+    // row pointer of this lane for a tile (the lane streams row 4rh + x of it); out-of-range tiles alias tile 0
+    auto lane_row_ptr = [&](uint64_t tile) -> const unsigned char * {
+        uint64_t c = tile * 8 + (uint32_t)(4 * rh + x);
+        if (c >= a.n_cand) c = 0;
+        uint32_t id = HAS_IDS ? a.ids[c] : (uint32_t)c;
+        if (HAS_IDS && id >= a.n_rows) id = 0;
+        return rows + (uint64_t)id * a.row_stride + (uint32_t)u * 16;
+    };
+    // D row pieces in flight per lane at all times: while chunk k is consumed, chunk k+1 (or the first chunk of
+    // the NEXT tile) is already on its way.
+    auto load_piece = [](const unsigned char *p) -> uint4 {
+        if (NT) {   // streamed once: keep the lines out of the way of the query tile / partial lists in L2
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+            return make_uint4(v[0], v[1], v[2], v[3]);
+        }
+        return *reinterpret_cast<const uint4 *>(p);
+    };
+    uint4 cur[D], nxt[D];
+    const unsigned char *rp = lane_row_ptr(gw < n_tiles ? gw : 0);
+#pragma unroll
+    for (int d = 0; d < D; ++d) cur[d] = load_piece(rp + (uint64_t)((uint32_t)d < nseg ? d : 0) * 128);
+
+    // every wave of the block runs the same number of iterations (QSPLIT > 1 synchronises per tile so that the
+    // waves sharing a row stream ask for the same lines at the same time: the second request hits L1 / L2)
+    const uint64_t n_iters = (n_tiles + tw - 1) / tw;
+    for (uint64_t it = 0; it < n_iters; ++it) {
+        const uint64_t tile = gw + it * tw;
+        if (QSPLIT > 1) __syncthreads();
+        if (tile >= n_tiles) continue;
+        // the 4 rows of this lane's half tile (rows 4rh + m)
         uint32_t rid[4];
         bool valid[4];
 #pragma unroll
@@ -94,8 +147,7 @@ __global__ __launch_bounds__(MF_BLOCK) void scan_f32_mfma_kernel(const ScanArgs 
             }
             rid[m] = id;
         }
-        const uint32_t my_row = x == 0 ? rid[0] : x == 1 ? rid[1] : x == 2 ? rid[2] : rid[3];
-        const unsigned char *rp = rows + (uint64_t)my_row * a.row_stride + (uint32_t)u * 16;
+        const unsigned char *rp_next = lane_row_ptr(tile + tw < n_tiles ? tile + tw : 0);
 
         f32x4 acc[NG][4];
 #pragma unroll
@@ -103,63 +155,95 @@ __global__ __launch_bounds__(MF_BLOCK) void scan_f32_mfma_kernel(const ScanArgs 
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[g][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll UNROLL
-        for (uint32_t s = 0; s < nseg; ++s) {
-            const uint4 vv = *reinterpret_cast<const uint4 *>(rp + (uint64_t)s * 128);
-            const float v0 = __uint_as_float(vv.x), v1 = __uint_as_float(vv.y), v2 = __uint_as_float(vv.z), v3 = __uint_as_float(vv.w);
+        uint4 qq[2][NG];     // query pieces of step s (qq[s & 1]) and s + 1, read one step ahead
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const uint4 qq = *reinterpret_cast<const uint4 *>(qbase + (uint32_t)g * gstride + s * 128);
-                // _mm256_fmadd_ps(v1, v2, sum) of chain 4u + t for rows 4rh..4rh+3 x queries 4g..4g+3
-                acc[g][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(v0, __uint_as_float(qq.x), acc[g][0], 0, 0, 0);
-                acc[g][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(v1, __uint_as_float(qq.y), acc[g][1], 0, 0, 0);
-                acc[g][2] = __builtin_amdgcn_mfma_f32_4x4x1f32(v2, __uint_as_float(qq.z), acc[g][2], 0, 0, 0);
-                acc[g][3] = __builtin_amdgcn_mfma_f32_4x4x1f32(v3, __uint_as_float(qq.w), acc[g][3], 0, 0, 0);
-            }
-        }
+        for (int g = 0; g < NG; ++g) qq[0][g] = *reinterpret_cast<const uint4 *>(qbase + (uint32_t)g * gstride);
 
-        // ---- fold the 32 chains (four_way_hsum, hsum256_ps_avx), scalar tail, top-k ----
+        for (uint32_t s0 = 0; s0 < nseg; s0 += D) {
+            const bool last_chunk = s0 + D >= nseg;
+            const unsigned char *np = last_chunk ? rp_next : rp;
+            const uint32_t ns0 = last_chunk ? 0 : s0 + D;
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const uint32_t q = (uint32_t)(4 * g + x);
-            const float *qf = reinterpret_cast<const float *>(smem + q * a.q_stride);
+            for (int d = 0; d < D; ++d) {
+                const uint32_t sn = ns0 + d < nseg ? ns0 + d : nseg - 1;
+                nxt[d] = load_piece(np + (uint64_t)sn * 128);
+            }
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                float lr[4];
+            for (int d = 0; d < D; ++d) {
+                const uint32_t sq = s0 + d + 1 < nseg ? s0 + d + 1 : 0;     // query pieces of the next step
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float c0 = acc[g][t][m];
-                    const float s12 = c0 + ror8(c0);                 // sum1 = a + b | sum2 = c + d
-                    const float tot = s12 + swz_xor<16>(s12);        // total = sum1 + sum2
-                    lr[t] = tot + swz_xor<4>(tot);                   // hi128 + lo128
+                for (int g = 0; g < NG; ++g)
+                    qq[(d + 1) & 1][g] = *reinterpret_cast<const uint4 *>(qbase + (uint32_t)g * gstride + sq * 128);
+                if (s0 + d < nseg) {
+                    const float v0 = __uint_as_float(cur[d].x), v1 = __uint_as_float(cur[d].y), v2 = __uint_as_float(cur[d].z),
+                                v3 = __uint_as_float(cur[d].w);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        const uint4 q4 = qq[d & 1][g];
+                        // _mm256_fmadd_ps(v1, v2, sum) of chain 4u + t for rows 4rh..4rh+3 x queries q0+4g..q0+4g+3
+                        acc[g][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(v0, __uint_as_float(q4.x), acc[g][0], 0, 0, 0);
+                        acc[g][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(v1, __uint_as_float(q4.y), acc[g][1], 0, 0, 0);
+                        acc[g][2] = __builtin_amdgcn_mfma_f32_4x4x1f32(v2, __uint_as_float(q4.z), acc[g][2], 0, 0, 0);
+                        acc[g][3] = __builtin_amdgcn_mfma_f32_4x4x1f32(v3, __uint_as_float(q4.w), acc[g][3], 0, 0, 0);
+                    }
                 }
-                float score = (lr[0] + lr[1]) + (lr[2] + lr[3]);
-                if (a.tail_start < a.dim) {                          // scalar tail: mul then add (simple_avx.rs:208-211)
-                    const float *vf = reinterpret_cast<const float *>(rows + (uint64_t)rid[m] * a.row_stride);
-                    for (uint32_t i = a.tail_start; i < a.dim; ++i) score += qf[i] * vf[i];
-                }
-                const bool mine = u == 0 && valid[m] && q < a.nq;
-                if (MODE == SCAN_SCORES) {
-                    if (mine) a.scores[(uint64_t)q * a.scores_stride + (tile * 8 + (uint32_t)(4 * rh + m))] = score;
-                } else {
-                    const uint64_t key = make_key(score, rid[m]);
-                    bool c = mine && key > thr[g];
-                    if (__ballot(c)) {
-                        c = c && a.del.live(rid[m]);
-                        uint64_t mask = __ballot(c);
-                        while (mask) {
-                            const int src = __builtin_ctzll(mask);
-                            mask &= mask - 1;
-                            const uint64_t nk = readlane_u64(key, src);
-                            const int n = src & 3;
+            }
 #pragma unroll
-                            for (int nn = 0; nn < 4; ++nn) {
-                                if (n == nn) {
-                                    if (nk > readlane_u64(list[4 * g + nn], top - 1)) {
-                                        wave_list_insert(list[4 * g + nn], nk, lane);
-                                        const uint64_t nt = readlane_u64(list[4 * g + nn], top - 1);
-                                        if (x == nn) thr[g] = nt;
-                                    }
+            for (int d = 0; d < D; ++d) cur[d] = nxt[d];
+        }
+        rp = rp_next;
+
+        // ---- fold the 32 chains in the reference's order (four_way_hsum, hsum256_ps_avx) ----
+        float s2[NG][4];
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float r01 = swap16_add(acc[g][t][0], acc[g][t][2]);      // u1 = 0: row 0, u1 = 1: row 2   (a + b | c + d)
+                const float r23 = swap16_add(acc[g][t][1], acc[g][t][3]);      // u1 = 0: row 1, u1 = 1: row 3
+                const float keep = u2 ? r23 : r01, send = u2 ? r01 : r23;
+                s2[g][t] = keep + ror8(send);                                  // (a + b) + (c + d), row 2 u1 + u2
+            }
+        const uint32_t res_row = my_m == 0 ? rid[0] : my_m == 1 ? rid[1] : my_m == 2 ? rid[2] : rid[3];
+        const bool res_valid = my_m == 0 ? valid[0] : my_m == 1 ? valid[1] : my_m == 2 ? valid[2] : valid[3];
+#pragma unroll
+        for (int gp = 0; gp < NGH; ++gp) {
+            float lr[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float keep = u0 ? s2[gp + NGH][t] : s2[gp][t], send = u0 ? s2[gp][t] : s2[gp + NGH][t];
+                lr[t] = keep + swz_xor<4>(send);                               // hi128 + lo128
+            }
+            float score = (lr[0] + lr[1]) + (lr[2] + lr[3]);
+            const uint32_t q = q0 + (uint32_t)my_q[gp];
+            if (a.tail_start < a.dim) {                                        // scalar tail: mul then add (simple_avx.rs:208-211)
+                const float *qf = reinterpret_cast<const float *>(smem + q * a.q_stride);
+                const float *vf = reinterpret_cast<const float *>(rows + (uint64_t)res_row * a.row_stride);
+                for (uint32_t i = a.tail_start; i < a.dim; ++i) score += qf[i] * vf[i];
+            }
+            const bool mine = res_valid && q < a.nq;
+            if (MODE == SCAN_SCORES) {
+                if (mine) a.scores[(uint64_t)q * a.scores_stride + (tile * 8 + (uint32_t)(4 * rh + my_m))] = score;
+            } else {
+                const uint64_t key = make_key(score, res_row);
+                bool c = mine && key > thr[gp];
+                if (__ballot(c)) {
+                    c = c && a.del.live(res_row);
+                    uint64_t mask = __ballot(c);
+                    while (mask) {
+                        const int src = __builtin_ctzll(mask);
+                        mask &= mask - 1;
+                        const uint64_t nk = readlane_u64(key, src);
+                        const int ql = __builtin_amdgcn_readlane(my_q[gp], src);
+#pragma unroll
+                        for (int qq = 0; qq < QW; ++qq) {
+                            if (ql == qq) {
+                                if (nk > readlane_u64(list[qq], top - 1)) {
+                                    wave_list_insert(list[qq], nk, lane);
+                                    const uint64_t nt = readlane_u64(list[qq], top - 1);
+#pragma unroll
+                                    for (int gg = 0; gg < NGH; ++gg)
+                                        if (my_q[gg] == qq) thr[gg] = nt;
                                 }
                             }
                         }
@@ -171,17 +255,17 @@ __global__ __launch_bounds__(MF_BLOCK) void scan_f32_mfma_kernel(const ScanArgs 
 
     if (MODE == SCAN_SCORES) return;
 
-    // ---- block merge: 8 wave lists -> 1 list per query, one global write per block (as scan_kernel) ----
+    // ---- block merge: the NSTREAM wave lists of each query -> 1 list, one global write per block ----
     __syncthreads();
     uint64_t *lds_keys = reinterpret_cast<uint64_t *>(smem);
     const uint32_t utop = a.top;
 #pragma unroll
-    for (int q = 0; q < QT; ++q)
-        if (lane < top) lds_keys[((uint32_t)wave * QT + q) * utop + lane] = list[q];
+    for (int q = 0; q < QW; ++q)
+        if (lane < top) lds_keys[((uint32_t)stream * QT + q0 + q) * utop + lane] = list[q];
     __syncthreads();
     for (uint32_t q = wave; q < a.nq; q += MF_NW) {
         uint64_t merged = 0;
-        for (int sw = 0; sw < MF_NW; ++sw) {
+        for (int sw = 0; sw < NSTREAM; ++sw) {
             const uint64_t key = lane < top ? lds_keys[((uint32_t)sw * QT + q) * utop + lane] : 0;
             uint64_t mk = __ballot(key > readlane_u64(merged, top - 1));
             while (mk) {
@@ -195,16 +279,18 @@ __global__ __launch_bounds__(MF_BLOCK) void scan_f32_mfma_kernel(const ScanArgs 
     }
 }
 
-template <int QT, int UNROLL, bool HAS_IDS, int MODE>
+template <int QW, int QSPLIT, int D, bool NT, bool HAS_IDS, int MODE>
 static int32_t launch_mfma_inst(hipStream_t st, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
+    constexpr int QT = QW * QSPLIT;
+    constexpr int NSTREAM = MF_NW / QSPLIT;
     size_t lds = (size_t)QT * a.q_stride;
     if (MODE == SCAN_TOPK) {
-        const size_t lk = (size_t)MF_NW * QT * a.top * sizeof(uint64_t);
+        const size_t lk = (size_t)NSTREAM * QT * a.top * sizeof(uint64_t);
         if (lk > lds) lds = lk;
     }
     lds = (lds + 15) & ~(size_t)15;
     QMX_REQUIRE(lds <= 160 * 1024, QMX_ERR_NOT_SUPPORTED, "query tile needs %zu B of LDS (> 160 KiB)", lds);
-    auto kfn = scan_f32_mfma_kernel<QT, UNROLL, HAS_IDS, MODE>;
+    auto kfn = scan_f32_mfma_kernel<QW, QSPLIT, D, NT, HAS_IDS, MODE>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -214,7 +300,7 @@ static int32_t launch_mfma_inst(hipStream_t st, const ScanArgs &a, int num_cus, 
     QMX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, MF_BLOCK, lds));
     if (per_cu < 1) per_cu = 1;
     const uint64_t n_tiles = (a.n_cand + 7) / 8;
-    const uint64_t want = (n_tiles + MF_NW - 1) / MF_NW;
+    const uint64_t want = (n_tiles + NSTREAM - 1) / NSTREAM;
     const uint64_t cap = (uint64_t)num_cus * per_cu;
     uint32_t grid = (uint32_t)(want < cap ? want : cap);
     if (grid < 1) grid = 1;
@@ -228,22 +314,26 @@ static int32_t launch_mfma_inst(hipStream_t st, const ScanArgs &a, int num_cus, 
     return QMX_OK;
 }
 
-template <int QT, int UNROLL>
+template <int QW, int QSPLIT, int D, bool NT>
 static int32_t launch_mfma_qt(hipStream_t st, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid) {
     const bool ids = a.ids != nullptr;
     if (mode == SCAN_TOPK)
-        return ids ? launch_mfma_inst<QT, UNROLL, true, SCAN_TOPK>(st, a, num_cus, grid)
-                   : launch_mfma_inst<QT, UNROLL, false, SCAN_TOPK>(st, a, num_cus, grid);
-    return ids ? launch_mfma_inst<QT, UNROLL, true, SCAN_SCORES>(st, a, num_cus, grid)
-               : launch_mfma_inst<QT, UNROLL, false, SCAN_SCORES>(st, a, num_cus, grid);
+        return ids ? launch_mfma_inst<QW, QSPLIT, D, NT, true, SCAN_TOPK>(st, a, num_cus, grid)
+                   : launch_mfma_inst<QW, QSPLIT, D, NT, false, SCAN_TOPK>(st, a, num_cus, grid);
+    return ids ? launch_mfma_inst<QW, QSPLIT, D, NT, true, SCAN_SCORES>(st, a, num_cus, grid)
+               : launch_mfma_inst<QW, QSPLIT, D, NT, false, SCAN_SCORES>(st, a, num_cus, grid);
 }
 
 // qt in {8, 16, 32}; f32 rows, dot (or cosine on normalised rows), dim >= 32
 int32_t launch_scan_f32_mfma(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
     switch (qt) {
-        case 8: return launch_mfma_qt<8, 4>(st, mode, a, num_cus, grid_out);
-        case 16: return launch_mfma_qt<16, 4>(st, mode, a, num_cus, grid_out);
-        case 32: return launch_mfma_qt<32, 2>(st, mode, a, num_cus, grid_out);
+        // measured on MI355X, C2 (10 M x 768): nontemporal row loads and 12 steps in flight per lane are worth ~3 %
+        case 8: {
+            static const bool nt = getenv("QMX_MFMA_NO_NT") == nullptr;
+            return nt ? launch_mfma_qt<8, 1, 4, true>(st, mode, a, num_cus, grid_out) : launch_mfma_qt<8, 1, 4, false>(st, mode, a, num_cus, grid_out);
+        }
+        case 16: return launch_mfma_qt<16, 1, 12, true>(st, mode, a, num_cus, grid_out);
+        case 32: return launch_mfma_qt<16, 2, 12, true>(st, mode, a, num_cus, grid_out);
     }
     set_error("unsupported MFMA query tile %d", qt);
     return QMX_ERR_BAD_ARG;
