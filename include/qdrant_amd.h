@@ -258,6 +258,9 @@ QMX_API int32_t qmx_score_bytes(qmx_query *q, const void *rows, uint32_t n, uint
  * lib/common/common/src/fixed_length_priority_queue.rs:47-59) and returns them sorted by
  * descending score (`into_sorted_vec`, :63-65); among equal scores the lower id comes first
  * (the reference's order among equals is heap-dependent).
+ *   top        : 1..1024.  Up to 64 entries live in one register list per wavefront; a larger `top` runs
+ *                ceil(top / 64) passes over the candidates, pass p keeping the best 64 keys strictly below the
+ *                last key of pass p - 1 (keys are unique: score, then offset), so the result is the same list.
  *   out        : [nq][top] ScoredPointOffset;  out_counts : [nq] number of valid entries.
  *   is_stopped : polled between kernel launches; non-zero => QMX_ERR_CANCELLED
  *                (`check_process_stopped`, point_scorer.rs:433,437).  May be NULL. */

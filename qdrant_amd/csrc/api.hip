@@ -172,7 +172,7 @@ struct qmx_query {
     size_t ev_used = 0;
     float timing_ms = 0.f;
     uint32_t timing_launches = 0;
-    DevBuf partial, out, counts, ids, scores, misc, enc;
+    DevBuf partial, out, counts, ids, scores, misc, enc, bounds;
     DevBuf hnsw_vis, hnsw_log, hnsw_scored;   // HNSW scratch: per-slot visited bitmaps (kept all-zero between launches) + logs
     uint32_t hnsw_slots = 0;
     uint64_t hnsw_vis_words = 0;
@@ -682,6 +682,7 @@ int32_t qmx_query_destroy(qmx_query *q) {
     q->scores.release();
     q->misc.release();
     q->enc.release();
+    q->bounds.release();
     q->hnsw_vis.release();
     q->hnsw_log.release();
     q->hnsw_scored.release();
@@ -844,6 +845,8 @@ int32_t qmx_score_point(qmx_query *q, uint32_t query_index, uint32_t id, float *
 // ---------------------------------------------------------------------------------------------
 // brute-force top-k
 // ---------------------------------------------------------------------------------------------
+constexpr uint32_t MAX_TOP = 1024;   // top > MAX_TOP_FAST runs in passes of MAX_TOP_FAST, each bounded by the last key of the one before
+
 static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids, uint64_t n_ids,
                               qmx_scored_point *d_out, uint32_t *d_counts, const volatile uint8_t *is_stopped,
                               qmx_counters *counters, bool timed) {
@@ -852,33 +855,42 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
     // partial lists: one per block; bound the grid by what the buffer holds
     const uint32_t grid_cap = (uint32_t)s->num_cus * 8;
     const uint32_t TQ = tile_qt(s);
-    QMX_TRY(q->partial.reserve((size_t)grid_cap * TQ * top * sizeof(uint64_t)));
+    const uint32_t ptop_max = std::min<uint32_t>(top, MAX_TOP_FAST);
+    const uint32_t n_pass = (top + MAX_TOP_FAST - 1) / MAX_TOP_FAST;
+    QMX_TRY(q->partial.reserve((size_t)grid_cap * TQ * ptop_max * sizeof(uint64_t)));
+    if (n_pass > 1) QMX_TRY(q->bounds.reserve((size_t)TQ * sizeof(uint64_t)));
     for (uint32_t tile0 = 0; tile0 < q->nq; tile0 += TQ) {
-        if (is_stopped && *is_stopped) {
-            set_error("search cancelled");
-            return QMX_ERR_CANCELLED;
-        }
         const uint32_t nq_tile = std::min<uint32_t>(TQ, q->nq - tile0);
         const int qt = (int)pow2_ceil(nq_tile);
-        ScanArgs a;
-        fill_args(q, tile0, nq_tile, a);
-        a.ids = d_ids;
-        a.n_cand = n_cand;
-        a.top = top;
-        a.partial = (uint64_t *)q->partial.p;
-        a.partial_qt = (uint32_t)qt;
-        uint32_t grid = grid_cap;
-        size_t slot = 0;
-        if (timed) QMX_TRY(timing_begin(q, &slot));
-        QMX_TRY(launch_scan(q, qt, SCAN_TOPK, a, &grid));
-        if (timed) QMX_TRY(timing_end(q, slot));
-        QMX_TRY(launch_merge_keys(q->stream, (const uint64_t *)q->partial.p, grid, (uint32_t)qt, nq_tile, top,
-                                  d_out + (size_t)tile0 * top, d_counts + tile0));
-        if (counters) counters->kernel_launches += 2;
+        for (uint32_t pass = 0; pass < n_pass; ++pass) {
+            if (is_stopped && *is_stopped) {
+                set_error("search cancelled");
+                return QMX_ERR_CANCELLED;
+            }
+            const uint32_t off = pass * MAX_TOP_FAST;
+            const uint32_t ptop = std::min<uint32_t>(MAX_TOP_FAST, top - off);
+            ScanArgs a;
+            fill_args(q, tile0, nq_tile, a);
+            a.ids = d_ids;
+            a.n_cand = n_cand;
+            a.top = ptop;
+            a.partial = (uint64_t *)q->partial.p;
+            a.partial_qt = (uint32_t)qt;
+            a.key_bound = pass ? (const uint64_t *)q->bounds.p : nullptr;
+            uint32_t grid = grid_cap;
+            size_t slot = 0;
+            if (timed) QMX_TRY(timing_begin(q, &slot));
+            QMX_TRY(launch_scan(q, qt, SCAN_TOPK, a, &grid));
+            if (timed) QMX_TRY(timing_end(q, slot));
+            QMX_TRY(launch_merge_keys(q->stream, (const uint64_t *)q->partial.p, grid, (uint32_t)qt, nq_tile, ptop,
+                                      d_out + (size_t)tile0 * top, d_counts + tile0, top, off,
+                                      n_pass > 1 ? (uint64_t *)q->bounds.p : nullptr));
+            if (counters) counters->kernel_launches += 2;
+        }
     }
     if (counters) {
-        counters->vectors_scored += (uint64_t)q->nq * n_cand;
-        counters->bytes_read += (uint64_t)((q->nq + TQ - 1) / TQ) * n_cand * s->row_bytes;
+        counters->vectors_scored += (uint64_t)q->nq * n_cand * n_pass;
+        counters->bytes_read += (uint64_t)((q->nq + TQ - 1) / TQ) * n_cand * s->row_bytes * n_pass;
     }
     return QMX_OK;
 }
@@ -887,7 +899,7 @@ int32_t qmx_search_topk(qmx_query *q, uint32_t top, const uint32_t *ids, uint64_
                         uint32_t *out_counts, const volatile uint8_t *is_stopped, qmx_counters *counters) {
     QMX_REQUIRE(q && out && out_counts, QMX_ERR_BAD_ARG, "NULL argument");
     QMX_REQUIRE(top >= 1, QMX_ERR_BAD_ARG, "top must be > 0 (FixedLengthPriorityQueue::new panics on 0)");
-    QMX_REQUIRE(top <= MAX_TOP_FAST, QMX_ERR_NOT_SUPPORTED, "top %u > %d not supported yet", top, MAX_TOP_FAST);
+    QMX_REQUIRE(top <= MAX_TOP, QMX_ERR_NOT_SUPPORTED, "top %u > %u not supported yet", top, MAX_TOP);
     QMX_HIP(hipSetDevice(q->seg->device));
     if (counters) memset(counters, 0, sizeof(*counters));
     if (q->nq == 0) return QMX_OK;
@@ -927,7 +939,7 @@ int32_t qmx_search_topk(qmx_query *q, uint32_t top, const uint32_t *ids, uint64_
 int32_t qmx_search_topk_async(qmx_query *q, uint32_t top, const uint32_t *ids, uint64_t n_ids,
                               qmx_scored_point *out_dev, uint32_t *out_counts_dev) {
     QMX_REQUIRE(q && out_dev && out_counts_dev, QMX_ERR_BAD_ARG, "NULL argument");
-    QMX_REQUIRE(top >= 1 && top <= MAX_TOP_FAST, QMX_ERR_NOT_SUPPORTED, "top %u not in 1..%d", top, MAX_TOP_FAST);
+    QMX_REQUIRE(top >= 1 && top <= MAX_TOP, QMX_ERR_NOT_SUPPORTED, "top %u not in 1..%u", top, MAX_TOP);
     QMX_REQUIRE(!ids || is_device_ptr(ids), QMX_ERR_BAD_ARG, "async search needs device ids");
     QMX_HIP(hipSetDevice(q->seg->device));
     if (q->nq == 0) return QMX_OK;
@@ -938,7 +950,7 @@ int32_t qmx_search_topk_async(qmx_query *q, uint32_t top, const uint32_t *ids, u
 int32_t qmx_merge_topk(int32_t device_id, const qmx_scored_point *lists, const uint32_t *list_counts, uint32_t n_lists,
                        uint32_t nq, uint32_t k, qmx_scored_point *out, uint32_t *out_counts) {
     QMX_REQUIRE(lists && out && out_counts, QMX_ERR_BAD_ARG, "NULL argument");
-    QMX_REQUIRE(k >= 1 && k <= MAX_TOP_FAST, QMX_ERR_NOT_SUPPORTED, "k %u not in 1..%d", k, MAX_TOP_FAST);
+    QMX_REQUIRE(k >= 1 && k <= MAX_TOP, QMX_ERR_NOT_SUPPORTED, "k %u not in 1..%u", k, MAX_TOP);
     QMX_TRY(check_device(device_id, nullptr));
     if (nq == 0) return QMX_OK;
     const size_t lbytes = (size_t)n_lists * nq * k * sizeof(qmx_scored_point);
@@ -977,7 +989,7 @@ int32_t qmx_merge_topk_async(int32_t device_id, void *hip_stream, const qmx_scor
                              const uint32_t *list_counts_dev, const uint32_t *list_idx_base_dev, uint32_t n_lists,
                              uint32_t nq, uint32_t k, qmx_scored_point *out_dev, uint32_t *out_counts_dev) {
     QMX_REQUIRE(lists_dev && out_dev && out_counts_dev, QMX_ERR_BAD_ARG, "NULL argument");
-    QMX_REQUIRE(k >= 1 && k <= MAX_TOP_FAST, QMX_ERR_NOT_SUPPORTED, "k %u not in 1..%d", k, MAX_TOP_FAST);
+    QMX_REQUIRE(k >= 1 && k <= MAX_TOP, QMX_ERR_NOT_SUPPORTED, "k %u not in 1..%u", k, MAX_TOP);
     QMX_HIP(hipSetDevice(device_id));
     if (nq == 0) return QMX_OK;
     return launch_merge_points((hipStream_t)hip_stream, lists_dev, list_counts_dev, list_idx_base_dev, n_lists, nq, k,
@@ -1319,7 +1331,7 @@ int32_t qmx_score_points_ragged(qmx_query *q, const uint32_t *ids, const uint32_
 int32_t qmx_rescore(qmx_query *q, const uint32_t *ids, const uint32_t *counts, uint32_t n_per_query, uint32_t top,
                     qmx_scored_point *out, uint32_t *out_counts) {
     QMX_REQUIRE(q && ids && out && out_counts, QMX_ERR_BAD_ARG, "NULL argument");
-    QMX_REQUIRE(top >= 1 && top <= MAX_TOP_FAST, QMX_ERR_NOT_SUPPORTED, "top %u not in 1..%d", top, MAX_TOP_FAST);
+    QMX_REQUIRE(top >= 1 && top <= MAX_TOP, QMX_ERR_NOT_SUPPORTED, "top %u not in 1..%u", top, MAX_TOP);
     QMX_HIP(hipSetDevice(q->device));
     if (q->nq == 0) return QMX_OK;
     if (n_per_query == 0) {

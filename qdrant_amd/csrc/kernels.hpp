@@ -27,6 +27,7 @@ struct ScanArgs {
     DeletedView del;
     uint64_t *partial;         // [grid][partial_qt][top] keys (top-k mode)
     uint32_t partial_qt;       // query stride of `partial` (the small-row kernel; the tiled one uses its QT)
+    const uint64_t *key_bound; // [QT] exclusive upper bound on accepted keys (top > 64 runs in passes of 64), or nullptr
     float *scores;             // [nq][n_cand] (score mode)
     uint64_t scores_stride;    // elements between queries in `scores`
     int *err_flag;             // set to 1 on an out-of-range id
@@ -129,9 +130,12 @@ int32_t launch_pq_encode(hipStream_t st, uint32_t dim, const qmx_pq_params &pq, 
 int32_t launch_pack_queries(hipStream_t st, int dtype, int distance, const void *src, int src_is_encoded,
                             uint32_t src_stride, uint32_t nq, uint32_t dim, void *tile, uint32_t q_stride, uint32_t aux_off);
 // top-k merge of `n_lists` key lists per query into ScoredPointOffset rows (topk_merge.hip)
+// pass p of a top > 64 search: writes out[q * out_stride + out_offset ..+top), counts accumulate when out_offset > 0,
+// next_bound[q] = key of the last entry written (0 = this query is exhausted)
 int32_t launch_merge_keys(hipStream_t st, const uint64_t *partial, uint32_t n_lists,
                           uint32_t qt_stride, uint32_t nq, uint32_t top, qmx_scored_point *out,
-                          uint32_t *out_counts);
+                          uint32_t *out_counts, uint32_t out_stride = 0, uint32_t out_offset = 0,
+                          uint64_t *next_bound = nullptr);
 int32_t launch_merge_points(hipStream_t st, const qmx_scored_point *lists, const uint32_t *list_counts,
                             const uint32_t *list_idx_base, uint32_t n_lists, uint32_t nq, uint32_t k, qmx_scored_point *out,
                             uint32_t *out_counts);

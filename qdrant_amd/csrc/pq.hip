@@ -171,7 +171,7 @@ __global__ __launch_bounds__(PQ_BLOCK) void pq_scan_kernel(const ScanArgs a, uin
             const uint64_t key = make_key(score, id);
             bool c = valid && key > readlane_u64(list, top - 1);
             if (__ballot(c)) {
-                c = c && a.del.live(id);
+                c = c && a.del.live(id) && (!a.key_bound || key < a.key_bound[q]);
                 uint64_t mask = __ballot(c);
                 while (mask) {
                     const int src = __builtin_ctzll(mask);

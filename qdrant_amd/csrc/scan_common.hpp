@@ -150,7 +150,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_kernel(const ScanArgs a) {
                         const uint64_t thr = readlane_u64(list[q], (int)a.top - 1);
                         bool c = valid[r] && (t == 0) && (key > thr);
                         if (__ballot(c)) {
-                            c = c && a.del.live(rid[r]);
+                            c = c && a.del.live(rid[r]) && (!a.key_bound || key < a.key_bound[q]);
                             uint64_t m = __ballot(c);
                             while (m) {
                                 const int src = __builtin_ctzll(m);
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(SMALL_BLOCK) void scan_small_kernel(const ScanArgs 
             const uint64_t key = make_key(score, id);
             bool cnd = valid && key > readlane_u64(list, top - 1);
             if (__ballot(cnd)) {
-                cnd = cnd && a.del.live(id);
+                cnd = cnd && a.del.live(id) && (!a.key_bound || key < a.key_bound[q]);
                 uint64_t m = __ballot(cnd);
                 while (m) {
                     const int src = __builtin_ctzll(m);

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(MF_BLOCK) void scan_f32_mfma_kernel(const ScanArgs 
                 const uint64_t key = make_key(score, res_row);
                 bool c = mine && key > thr[gp];
                 if (__ballot(c)) {
-                    c = c && a.del.live(res_row);
+                    c = c && a.del.live(res_row) && (!a.key_bound || key < a.key_bound[q]);
                     uint64_t mask = __ballot(c);
                     while (mask) {
                         const int src = __builtin_ctzll(mask);

@@ -24,11 +24,15 @@ __device__ __forceinline__ void wave_offer(uint64_t &list, uint64_t key, int top
     }
 }
 
-// block-level finish: merge the MERGE_NW wave lists, write ScoredPointOffset rows
-__device__ __forceinline__ void block_finish(uint64_t list, int top, uint32_t q, qmx_scored_point *out,
-                                             uint32_t *out_counts) {
+// block-level finish of one pass: merge the MERGE_NW wave lists, write ScoredPointOffset entries
+// out[q * out_stride + out_offset .. + top), add to / set the count, and return (to every thread) the key bound
+// of the next pass: the last key written, or 0 when fewer than `top` were found (nothing is left).
+__device__ __forceinline__ uint64_t block_finish(uint64_t list, int top, uint32_t q, qmx_scored_point *out, uint32_t out_stride,
+                                                 uint32_t out_offset, uint32_t *out_counts) {
     __shared__ uint64_t sh[MERGE_NW][WAVE];
+    __shared__ uint64_t sh_bound;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();   // a previous pass may still be reading sh / sh_bound
     sh[wave][lane] = list;
     __syncthreads();
     if (wave == 0) {
@@ -39,16 +43,23 @@ __device__ __forceinline__ void block_finish(uint64_t list, int top, uint32_t q,
             qmx_scored_point p;
             p.idx = ok ? key_idx(merged) : 0u;
             p.score = ok ? key_score(merged) : 0.0f;
-            out[(uint64_t)q * top + lane] = p;
+            out[(uint64_t)q * out_stride + out_offset + lane] = p;
         }
-        const uint64_t m = __ballot(ok);
-        if (lane == 0) out_counts[q] = (uint32_t)__popcll(m);
+        const uint32_t cnt = (uint32_t)__popcll(__ballot(ok));
+        const uint64_t last = readlane_u64(merged, top - 1);
+        if (lane == 0) {
+            out_counts[q] = (out_offset ? out_counts[q] : 0u) + cnt;
+            sh_bound = cnt == (uint32_t)top ? last : 0ull;
+        }
     }
+    __syncthreads();
+    return sh_bound;
 }
 
 __global__ __launch_bounds__(MERGE_BLOCK) void merge_keys_kernel(const uint64_t *partial, uint32_t n_lists,
                                                                  uint32_t qt_stride, uint32_t top,
-                                                                 qmx_scored_point *out, uint32_t *out_counts) {
+                                                                 qmx_scored_point *out, uint32_t *out_counts, uint32_t out_stride,
+                                                                 uint32_t out_offset, uint64_t *next_bound) {
     const uint32_t q = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint64_t list = 0;
@@ -56,19 +67,21 @@ __global__ __launch_bounds__(MERGE_BLOCK) void merge_keys_kernel(const uint64_t 
         const uint64_t key = lane < (int)top ? partial[((uint64_t)l * qt_stride + q) * top + lane] : 0;
         wave_offer(list, key, (int)top, lane);
     }
-    block_finish(list, (int)top, q, out, out_counts);
+    const uint64_t nb = block_finish(list, (int)top, q, out, out_stride, out_offset, out_counts);
+    if (next_bound && threadIdx.x == 0) next_bound[q] = nb;
 }
 
 // Items are visited in the aggregator's order (list-major, then position); an id that was already
 // pushed by an earlier item is dropped whatever its score (`if self.seen.insert(point.id)`,
 // search_result_aggregator.rs:28-37).  The id of every item is staged in LDS and each item looks
 // for an earlier twin: O(T^2 / 256) compares per thread, T = n_lists * k is a few hundred at most.
+// k > 64 runs in passes of 64: pass p keeps the best 64 keys below the last key of pass p - 1.
 __global__ __launch_bounds__(MERGE_BLOCK) void merge_points_kernel(const qmx_scored_point *lists,
                                                                    const uint32_t *list_counts,
                                                                    const uint32_t *list_idx_base, uint32_t n_lists,
                                                                    uint32_t nq, uint32_t k, qmx_scored_point *out,
                                                                    uint32_t *out_counts) {
-    extern __shared__ uint32_t seen_ids[];   // [n_lists * k]; 0xFFFFFFFF = no item
+    extern __shared__ uint32_t seen_ids[];   // [n_lists * k]; 0xFFFFFFFF = no item or a duplicate
     const uint32_t q = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t total = n_lists * k;
@@ -79,23 +92,32 @@ __global__ __launch_bounds__(MERGE_BLOCK) void merge_points_kernel(const qmx_sco
                               : 0xFFFFFFFFu;
     }
     __syncthreads();
-    uint64_t list = 0;
-    for (uint32_t l = wave; l < n_lists; l += MERGE_NW) {
-        const uint32_t cnt = list_counts ? list_counts[(uint64_t)l * nq + q] : k;
-        for (uint32_t base = 0; base < k; base += WAVE) {
-            const uint32_t i = base + lane;
-            uint64_t key = 0;
-            if (i < k && i < cnt) {
-                const uint32_t j = l * k + i;
-                const uint32_t id = seen_ids[j];
-                bool dup = false;
-                for (uint32_t e = 0; e < j; ++e) dup = dup || (seen_ids[e] == id);
-                if (!dup) key = make_key(lists[((uint64_t)l * nq + q) * k + i].score, id);
+    uint64_t bound = ~0ull;
+    for (uint32_t off = 0; off < k; off += WAVE) {
+        const int top = (int)(k - off < (uint32_t)WAVE ? k - off : (uint32_t)WAVE);
+        uint64_t list = 0;
+        for (uint32_t l = wave; l < n_lists; l += MERGE_NW) {
+            const uint32_t cnt = list_counts ? list_counts[(uint64_t)l * nq + q] : k;
+            for (uint32_t base = 0; base < k; base += WAVE) {
+                const uint32_t i = base + lane;
+                uint64_t key = 0;
+                if (i < k && i < cnt) {
+                    const uint32_t j = l * k + i;
+                    const uint32_t id = seen_ids[j];
+                    bool dup = false;
+                    for (uint32_t e = 0; e < j; ++e) dup = dup || (seen_ids[e] == id);
+                    if (!dup) key = make_key(lists[((uint64_t)l * nq + q) * k + i].score, id);
+                    if (key >= bound) key = 0;
+                }
+                wave_offer(list, key, top, lane);
             }
-            wave_offer(list, key, (int)k, lane);
+        }
+        bound = block_finish(list, top, q, out, k, off, out_counts);
+        if (bound == 0) {   // exhausted: clear the tail of the row
+            for (uint32_t i = off + WAVE + threadIdx.x; i < k; i += MERGE_BLOCK) out[(uint64_t)q * k + i] = qmx_scored_point{0u, 0.0f};
+            break;
         }
     }
-    block_finish(list, (int)k, q, out, out_counts);
 }
 
 __global__ __launch_bounds__(MERGE_BLOCK) void sort_scored_kernel(const float *scores, const uint32_t *ids,
@@ -105,20 +127,32 @@ __global__ __launch_bounds__(MERGE_BLOCK) void sort_scored_kernel(const float *s
     const uint32_t q = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t cnt = counts ? (counts[q] < n_per_query ? counts[q] : n_per_query) : n_per_query;
-    uint64_t list = 0;
-    for (uint32_t base = wave * WAVE; base < cnt; base += MERGE_BLOCK) {
-        const uint32_t i = base + lane;
-        const uint64_t key = i < cnt ? make_key(scores[(uint64_t)q * n_per_query + i], ids[(uint64_t)q * n_per_query + i]) : 0;
-        wave_offer(list, key, (int)top, lane);
+    uint64_t bound = ~0ull;
+    for (uint32_t off = 0; off < top; off += WAVE) {
+        const int ptop = (int)(top - off < (uint32_t)WAVE ? top - off : (uint32_t)WAVE);
+        uint64_t list = 0;
+        for (uint32_t base = wave * WAVE; base < cnt; base += MERGE_BLOCK) {
+            const uint32_t i = base + lane;
+            uint64_t key = i < cnt ? make_key(scores[(uint64_t)q * n_per_query + i], ids[(uint64_t)q * n_per_query + i]) : 0;
+            if (key >= bound) key = 0;
+            wave_offer(list, key, ptop, lane);
+        }
+        bound = block_finish(list, ptop, q, out, top, off, out_counts);
+        if (bound == 0) {
+            for (uint32_t i = off + WAVE + threadIdx.x; i < top; i += MERGE_BLOCK) out[(uint64_t)q * top + i] = qmx_scored_point{0u, 0.0f};
+            break;
+        }
     }
-    block_finish(list, (int)top, q, out, out_counts);
 }
 
 int32_t launch_merge_keys(hipStream_t st, const uint64_t *partial, uint32_t n_lists, uint32_t qt_stride,
-                          uint32_t nq, uint32_t top, qmx_scored_point *out, uint32_t *out_counts) {
+                          uint32_t nq, uint32_t top, qmx_scored_point *out, uint32_t *out_counts, uint32_t out_stride,
+                          uint32_t out_offset, uint64_t *next_bound) {
     if (nq == 0) return QMX_OK;
+    if (out_stride == 0) out_stride = top;
     ::qmx::clear_stale_error();
-    hipLaunchKernelGGL(merge_keys_kernel, dim3(nq), dim3(MERGE_BLOCK), 0, st, partial, n_lists, qt_stride, top, out, out_counts);
+    hipLaunchKernelGGL(merge_keys_kernel, dim3(nq), dim3(MERGE_BLOCK), 0, st, partial, n_lists, qt_stride, top, out, out_counts,
+                       out_stride, out_offset, next_bound);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }

@@ -1,0 +1,112 @@
+"""GPU parity for top / limit > 64 (the reference's FixedLengthPriorityQueue has no size limit,
+lib/common/common/src/fixed_length_priority_queue.rs:20-45): the device keeps 64 entries per wavefront list and
+runs ceil(top / 64) bounded passes; the concatenation must be exactly the oracle's sorted list."""
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def qa():
+    import qdrant_amd
+    assert qdrant_amd.device_count() >= 1
+    return qdrant_amd
+
+
+def _check(got, want):
+    for g, w in zip(got, want):
+        assert len(g) == len(w)
+        assert np.array_equal(g["score"].view(np.uint32), w["score"].view(np.uint32))
+        uniq = np.array([(w["score"] == x).sum() == 1 for x in w["score"]], dtype=bool)
+        assert np.array_equal(g["idx"][uniq], w["idx"][uniq])
+
+
+@pytest.mark.parametrize("nq,top,dim", [(3, 65, 48), (3, 200, 48), (20, 130, 64), (2, 1000, 16), (9, 300, 100)])
+def test_dense_f32_large_top(qa, nq, top, dim):
+    rng = np.random.default_rng(top + nq)
+    n = 5000
+    rows = O.preprocess(O.COSINE, rng.standard_normal((n, dim)).astype(np.float32))
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    deleted = rng.random(n) < 0.1
+    st = qa.VectorStorage(rows, qa.Distance.Cosine)
+    st.set_deleted(deleted, None)
+    truth = O.DenseStorage(O.F32, O.COSINE, rows, point_deleted=deleted)
+    s = qa.BatchFilteredSearcher(queries, st, top)
+    _check(s.peek_top_all(), truth.peek_top(queries, top))
+    ids = rng.permutation(n)[:777].astype(np.uint32)
+    _check(s.peek_top_iter(ids), truth.peek_top(queries, top, ids=ids))          # fewer live candidates than top in places
+
+
+def test_fewer_points_than_top(qa):
+    rng = np.random.default_rng(1)
+    rows = rng.standard_normal((150, 32)).astype(np.float32)
+    queries = rng.standard_normal((2, 32)).astype(np.float32)
+    st = qa.VectorStorage(rows, qa.Distance.Dot)
+    got = qa.BatchFilteredSearcher(queries, st, 500).peek_top_all()
+    want = O.DenseStorage(O.F32, O.DOT, rows).peek_top(queries, 500)
+    assert all(len(g) == 150 for g in got)
+    _check(got, want)
+
+
+def test_sq_and_pq_large_top(qa):
+    rng = np.random.default_rng(2)
+    n, dim, nq, top = 4000, 64, 3, 150
+    vecs = O.preprocess(O.DOT, rng.standard_normal((n, dim)).astype(np.float32))
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    quant = qa.ScalarQuantizer.from_min_max(vecs, dim, qa.Distance.Dot)
+    osq = O.SqOracle(O.DOT, dim, quant.alpha, quant.offset)
+    codes = osq.encode_rows(vecs)
+    enc = qa.EncodedVectorsU8(codes, quant)
+    got = qa.BatchFilteredSearcher(queries, enc, top).peek_top_all()
+    sc = osq.score_points(queries, np.arange(n))
+    for qi in range(nq):
+        order = np.argsort(-sc[qi], kind="stable")[:top]
+        assert np.array_equal(got[qi]["score"].view(np.uint32), sc[qi][order].view(np.uint32))
+    cen = O.PqOracle.train(vecs[:2000], dim, 8, 256, iters=3)
+    opq = O.PqOracle(O.DOT, dim, 8, cen)
+    pcodes = opq.encode(vecs)
+    penc = qa.EncodedVectorsPQ(pcodes, qa.ProductQuantizer(dim, qa.Distance.Dot, 8, cen))
+    got = qa.BatchFilteredSearcher(queries, penc, top).peek_top_all()
+    sc = opq.score_points(queries, np.arange(n))
+    for qi in range(nq):
+        order = np.argsort(-sc[qi], kind="stable")[:top]
+        assert np.array_equal(got[qi]["score"].view(np.uint32), sc[qi][order].view(np.uint32))
+
+
+def test_rescore_and_merge_large(qa):
+    from qdrant_amd import _ffi as F
+    rng = np.random.default_rng(3)
+    n, dim, nq = 3000, 48, 4
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    st = qa.VectorStorage(rows, qa.Distance.Euclid)
+    scorer = qa.new_raw_scorer(queries, st)
+    ids = np.stack([rng.permutation(n)[:400] for _ in range(nq)]).astype(np.uint32)
+    cnt = np.array([400, 399, 130, 0], dtype=np.uint32)
+    res = scorer.rescore(ids, 250, cnt)
+    truth = O.DenseStorage(O.F32, O.EUCLID, rows)
+    for qi in range(nq):
+        sc = truth.score_points(queries[qi:qi + 1], ids[qi, :cnt[qi]])[0]
+        order = np.argsort(-sc, kind="stable")[:250]
+        assert len(res[qi]) == min(250, cnt[qi])
+        assert np.array_equal(res[qi]["score"].view(np.uint32), sc[order].view(np.uint32))
+        assert res[qi]["idx"].tolist() == ids[qi, :cnt[qi]][order].tolist()
+    # merge of 5 lists of 100 (disjoint ids)
+    k, n_lists = 100, 5
+    lists = np.zeros((n_lists, nq, k), dtype=O.ScoredPointOffset)
+    for l in range(n_lists):
+        for q in range(nq):
+            lists[l, q]["score"] = np.sort(rng.standard_normal(k).astype(np.float32))[::-1]
+            lists[l, q]["idx"] = l * 10000 + rng.permutation(10000)[:k]
+    counts = rng.integers(0, k + 1, size=(n_lists, nq)).astype(np.uint32)
+    out = np.zeros((nq, k), dtype=O.ScoredPointOffset)
+    oc = np.zeros(nq, dtype=np.uint32)
+    F.check(F.lib().qmx_merge_topk(0, F.ptr(lists), F.ptr(counts), n_lists, nq, k, F.ptr(out), F.ptr(oc)))
+    want = O.merge_topk(lists, counts, k)
+    for q in range(nq):
+        assert oc[q] == len(want[q])
+        assert out[q, :oc[q]]["idx"].tolist() == want[q]["idx"].tolist()
+        assert out[q, :oc[q]]["score"].tolist() == want[q]["score"].tolist()
