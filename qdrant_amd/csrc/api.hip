@@ -183,12 +183,14 @@ struct qmx_query {
 
 // f32 dot / cosine rows of >= 32 elements scan 8..32 queries per pass on the f32 matrix cores (scan_mfma.hip)
 static bool mfma_scan_ok(const qmx_segment *s) {
+    if (s->dtype == QMX_DTYPE_SQ_U8) return sq_mfma_ok(s->distance, s->scan_dim) && getenv("QMX_NO_MFMA_SCAN") == nullptr;
     return s->dtype == QMX_DTYPE_F32 && (s->distance == QMX_DISTANCE_DOT || s->distance == QMX_DISTANCE_COSINE) && s->dim >= 32 &&
            s->fast_layout() && getenv("QMX_NO_MFMA_SCAN") == nullptr;
 }
 constexpr uint32_t MAX_QT_MFMA = 32;
 // queries scored per pass of the stored block
 static uint32_t tile_qt(const qmx_segment *s) {
+    if (s->dtype == QMX_DTYPE_SQ_U8) return mfma_scan_ok(s) ? MAX_QT_MFMA : MAX_QT;
     return mfma_scan_ok(s) && (size_t)MAX_QT_MFMA * (((size_t)s->dim * 4 + 127) / 128 * 128 + QUERY_AUX_BYTES) <= 150 * 1024 ? MAX_QT_MFMA : MAX_QT;
 }
 
@@ -784,7 +786,10 @@ static int32_t launch_scan(const qmx_query *q, int qt, ScanMode mode, const Scan
         if (qt >= 8 && mfma_scan_ok(s)) return launch_scan_f32_mfma(q->stream, qt, mode, a, s->num_cus, grid);
         return launch_scan_dense(q->stream, (int)s->dtype, (int)s->distance, qt, mode, a, s->num_cus, grid);
     }
-    if (s->dtype == QMX_DTYPE_SQ_U8) return launch_scan_sq(q->stream, (int)s->distance, qt, mode, a, s->num_cus, grid);
+    if (s->dtype == QMX_DTYPE_SQ_U8) {
+        if (qt >= 8 && mfma_scan_ok(s)) return launch_scan_sq_mfma(q->stream, qt, mode, a, s->num_cus, grid);
+        return launch_scan_sq(q->stream, (int)s->distance, std::min(qt, (int)MAX_QT), mode, a, s->num_cus, grid);
+    }
     if (s->dtype == QMX_DTYPE_PQ) return launch_scan_pq(q->stream, mode, a, s->num_cus, grid);
     set_error("dtype %u not built yet", s->dtype);
     return QMX_ERR_NOT_SUPPORTED;

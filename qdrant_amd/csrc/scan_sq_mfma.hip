@@ -1,0 +1,262 @@
+// scan_sq_mfma.hip — EncodedVectorsU8 (scalar int8) brute-force scan for LARGE query tiles (8..32 queries per
+// pass) on the int8 matrix cores.
+//
+// Same reference loops as scan_quant.hip: BatchFilteredSearcher::peek_top_iter
+// (lib/segment/src/index/hnsw_index/point_scorer.rs:423-472) over EncodedVectorsU8::score_point_avx
+// (lib/quantization/src/encoded_vectors_u8.rs:471-490 -> cpp/avx2.c:25-63 impl_score_dot_avx) and
+// postprocess_score (:100-103).  Dot / cosine / euclid (all three are the integer dot of the codes, only
+// multiplier and offsets differ, :205-221); Manhattan (sad) stays on the VALU kernel.
+//
+// Exactness.  Codes are <= 127, so every product and every i32 partial sum is exact in any order.  The AVX2
+// leaf converts its 8 i32 lane sums to f32 and adds them (HSUM256_PS); while 127^2 * actual_dim < 2^24 those
+// f32 adds are exact too, so the leaf's result is (float)(total integer dot) whatever the association — the
+// same argument RowSQ<false, false> rests on.  Above that bound (actual_dim >= 1041) the f32 adds may round and
+// the VALU kernel, which keeps the 8 lanes apart, is used instead (`sq_mfma_ok`).
+//
+// Mapping: v_mfma_i32_16x16x64_i8, one instruction = 16 stored rows x 16 queries x 64 code bytes.
+//   lane = m + 16 kg:  A = bytes [64 s + 16 kg, +16) of row m (one global_load_dwordx4 per lane per step; the 4
+//   lanes of a row read 64 contiguous bytes, the next step the other half of the line), B = the same bytes of
+//   query n = lane % 16 from the LDS tile (ds_read_b128), D[r] = rows 4 (lane / 16) + r x query lane % 16.
+//   A wave therefore finishes 16 rows x QW queries with QW / 16 accumulators of 4 registers.
+// HBM-bound: 4 + actual_dim bytes per scored row (772 B at d = 768), 12 MFMAs per 16 rows x 16 queries.
+#include "scan_common.hpp"
+
+namespace qmx {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SQM_BLOCK = 512;
+constexpr int SQM_NW = SQM_BLOCK / WAVE;
+
+template <int QW, int D, bool HAS_IDS, int MODE>
+__global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NG = QW / 16;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.queries);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        const uint32_t n16 = (uint32_t)QW * a.q_stride / 16;
+        for (uint32_t i = tid; i < n16; i += SQM_BLOCK) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const int n = lane & 15;       // A: stored row of the tile; B / D: query of the group
+    const int kg = lane >> 4;      // which 16 bytes of the 64-byte step; D: rows 4 kg .. 4 kg + 3
+    const unsigned char *rows = reinterpret_cast<const unsigned char *>(a.rows);
+    const uint32_t nbytes = a.dim;                          // actual_dim code bytes per row (multiple of 16)
+    const uint32_t nstep = (nbytes + 63) / 64;
+    const unsigned char *qbase = smem + (uint32_t)n * a.q_stride + (uint32_t)kg * 16;   // + g * 16 * q_stride + s * 64
+    const uint32_t gstride = 16u * a.q_stride;
+    const int top = (int)a.top;
+
+    float q_off[NG];               // EncodedQueryU8.offset of the lane's queries
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+        q_off[g] = reinterpret_cast<const QueryAux *>(smem + (uint32_t)(16 * g + n) * a.q_stride + a.aux_off)->f0;
+
+    uint64_t list[QW];
+    uint64_t thr[NG];              // k-th best key of query 16 g + n
+#pragma unroll
+    for (int q = 0; q < QW; ++q) list[q] = 0;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) thr[g] = 0;
+
+    const uint32_t gw = blockIdx.x * SQM_NW + wave;
+    const uint32_t tw = gridDim.x * SQM_NW;
+    const uint64_t n_tiles = (a.n_cand + 15) / 16;
+
+    auto row_of = [&](uint64_t tile, int m, bool *ok) -> uint32_t {
+        const uint64_t c = tile * 16 + (uint32_t)m;
+        bool v = c < a.n_cand;
+        uint32_t id = HAS_IDS ? a.ids[v ? c : 0] : (uint32_t)(v ? c : 0);
+        if (HAS_IDS && id >= a.n_rows) {
+            if (v) *a.err_flag = 1;
+            id = 0;
+            v = false;
+        }
+        if (ok) *ok = v;
+        return id;
+    };
+    // the step's 16 bytes of this lane; bytes past the row (last, partial step) are zero and never read
+    auto load_piece = [&](const unsigned char *rp, uint32_t s) -> uint4 {
+        const uint32_t off = s * 64 + (uint32_t)kg * 16;
+        if (off < nbytes) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(rp + off));
+            return make_uint4(v[0], v[1], v[2], v[3]);
+        }
+        return make_uint4(0, 0, 0, 0);
+    };
+
+    uint4 cur[D], nxt[D];
+    const unsigned char *rp = rows + (uint64_t)row_of(gw < n_tiles ? gw : 0, n, nullptr) * a.row_stride;
+#pragma unroll
+    for (int d = 0; d < D; ++d) cur[d] = load_piece(rp, (uint32_t)d < nstep ? d : 0);
+
+    for (uint64_t tile = gw; tile < n_tiles; tile += tw) {
+        // the 4 result rows of this lane (rows 4 kg + r) and their vector offsets
+        uint32_t rid[4];
+        bool valid[4];
+        float v_off[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            rid[r] = row_of(tile, 4 * kg + r, &valid[r]);
+            v_off[r] = a.row_offsets[rid[r]];
+        }
+        const unsigned char *rp_next = rows + (uint64_t)row_of(tile + tw < n_tiles ? tile + tw : 0, n, nullptr) * a.row_stride;
+
+        i32x4 acc[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[g] = (i32x4){0, 0, 0, 0};
+
+        for (uint32_t s0 = 0; s0 < nstep; s0 += D) {
+            const bool last_chunk = s0 + D >= nstep;
+            const unsigned char *np = last_chunk ? rp_next : rp;
+            const uint32_t ns0 = last_chunk ? 0 : s0 + D;
+#pragma unroll
+            for (int d = 0; d < D; ++d) nxt[d] = load_piece(np, ns0 + d < nstep ? ns0 + d : nstep - 1);
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                if (s0 + d < nstep) {
+                    const i32x4 av = (i32x4){(int)cur[d].x, (int)cur[d].y, (int)cur[d].z, (int)cur[d].w};
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        const uint4 qq = *reinterpret_cast<const uint4 *>(qbase + (uint32_t)g * gstride + (s0 + d) * 64);
+                        const i32x4 bv = (i32x4){(int)qq.x, (int)qq.y, (int)qq.z, (int)qq.w};
+                        acc[g] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bv, acc[g], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < D; ++d) cur[d] = nxt[d];
+        }
+        rp = rp_next;
+
+        // ---- postprocess_score (multiplier * dot + query_offset + vector_offset, left to right, not fused) + top-k ----
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const uint32_t q = (uint32_t)(16 * g + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float f = (float)acc[g][r];
+                const float m1 = a.sq_multiplier * f;
+                const float mq = m1 + q_off[g];
+                const float score = mq + v_off[r];
+                const bool mine = valid[r] && q < a.nq;
+                if (MODE == SCAN_SCORES) {
+                    if (mine) a.scores[(uint64_t)q * a.scores_stride + (tile * 16 + (uint32_t)(4 * kg + r))] = score;
+                } else {
+                    const uint64_t key = make_key(score, rid[r]);
+                    bool c = mine && key > thr[g];
+                    if (__ballot(c)) {
+                        c = c && a.del.live(rid[r]) && (!a.key_bound || key < a.key_bound[q]);
+                        uint64_t mask = __ballot(c);
+                        while (mask) {
+                            const int src = __builtin_ctzll(mask);
+                            mask &= mask - 1;
+                            const uint64_t nk = readlane_u64(key, src);
+                            const int ql = 16 * g + (src & 15);
+#pragma unroll
+                            for (int qq = 16 * g; qq < 16 * g + 16; ++qq) {
+                                if (ql == qq) {
+                                    if (nk > readlane_u64(list[qq], top - 1)) {
+                                        wave_list_insert(list[qq], nk, lane);
+                                        const uint64_t nt = readlane_u64(list[qq], top - 1);
+                                        if (n == qq - 16 * g) thr[g] = nt;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    if (MODE == SCAN_SCORES) return;
+
+    // ---- block merge: 8 wave lists -> 1 list per query, one global write per block ----
+    __syncthreads();
+    uint64_t *lds_keys = reinterpret_cast<uint64_t *>(smem);
+    const uint32_t utop = a.top;
+#pragma unroll
+    for (int q = 0; q < QW; ++q)
+        if (lane < top) lds_keys[((uint32_t)wave * QW + q) * utop + lane] = list[q];
+    __syncthreads();
+    for (uint32_t q = wave; q < a.nq; q += SQM_NW) {
+        uint64_t merged = 0;
+        for (int sw = 0; sw < SQM_NW; ++sw) {
+            const uint64_t key = lane < top ? lds_keys[((uint32_t)sw * QW + q) * utop + lane] : 0;
+            uint64_t mk = __ballot(key > readlane_u64(merged, top - 1));
+            while (mk) {
+                const int src = __builtin_ctzll(mk);
+                mk &= mk - 1;
+                const uint64_t nk = readlane_u64(key, src);
+                if (nk > readlane_u64(merged, top - 1)) wave_list_insert(merged, nk, lane);
+            }
+        }
+        if (lane < top) a.partial[((uint64_t)blockIdx.x * a.partial_qt + q) * utop + lane] = merged;
+    }
+}
+
+template <int QW, int D, bool HAS_IDS, int MODE>
+static int32_t launch_sqm_inst(hipStream_t st, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
+    size_t lds = (size_t)QW * a.q_stride;
+    if (MODE == SCAN_TOPK) {
+        const size_t lk = (size_t)SQM_NW * QW * a.top * sizeof(uint64_t);
+        if (lk > lds) lds = lk;
+    }
+    lds = (lds + 15) & ~(size_t)15;
+    QMX_REQUIRE(lds <= 160 * 1024, QMX_ERR_NOT_SUPPORTED, "query tile needs %zu B of LDS (> 160 KiB)", lds);
+    auto kfn = scan_sq_mfma_kernel<QW, D, HAS_IDS, MODE>;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    int per_cu = 0;
+    QMX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, SQM_BLOCK, lds));
+    if (per_cu < 1) per_cu = 1;
+    const uint64_t n_tiles = (a.n_cand + 15) / 16;
+    const uint64_t want = (n_tiles + SQM_NW - 1) / SQM_NW;
+    const uint64_t cap = (uint64_t)num_cus * per_cu;
+    uint32_t grid = (uint32_t)(want < cap ? want : cap);
+    if (grid < 1) grid = 1;
+    if (grid_out) {
+        if (*grid_out && MODE == SCAN_TOPK && grid > *grid_out) grid = *grid_out;
+        *grid_out = grid;
+    }
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(SQM_BLOCK), lds, st, a);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
+template <int QW, int D>
+static int32_t launch_sqm_qt(hipStream_t st, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid) {
+    const bool ids = a.ids != nullptr;
+    if (mode == SCAN_TOPK)
+        return ids ? launch_sqm_inst<QW, D, true, SCAN_TOPK>(st, a, num_cus, grid) : launch_sqm_inst<QW, D, false, SCAN_TOPK>(st, a, num_cus, grid);
+    return ids ? launch_sqm_inst<QW, D, true, SCAN_SCORES>(st, a, num_cus, grid) : launch_sqm_inst<QW, D, false, SCAN_SCORES>(st, a, num_cus, grid);
+}
+
+// the f32 adds of the AVX2 leaf stay exact (and its result order-free) while every partial sum is < 2^24
+bool sq_mfma_ok(uint32_t distance, uint32_t actual_dim) {
+    return distance != QMX_DISTANCE_MANHATTAN && (uint64_t)127 * 127 * actual_dim < (1ull << 24);
+}
+
+// qt in {8, 16, 32}: 8 and 16 run the 16-query kernel (one accumulator), 32 two accumulators
+int32_t launch_scan_sq_mfma(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
+    switch (qt) {
+        case 8:
+        case 16: return launch_sqm_qt<16, 6>(st, mode, a, num_cus, grid_out);
+        case 32: return launch_sqm_qt<32, 6>(st, mode, a, num_cus, grid_out);
+    }
+    set_error("unsupported SQ MFMA query tile %d", qt);
+    return QMX_ERR_BAD_ARG;
+}
+
+}  // namespace qmx

@@ -90,3 +90,61 @@ def test_large_scan_property(qa):
     for g, v in zip(got, valu):
         assert g["idx"].tolist() == v["idx"].tolist()
         assert np.array_equal(g["score"].view(np.uint32), v["score"].view(np.uint32))
+
+
+# ---- SQ int8 on v_mfma_i32_16x16x64_i8 (scan_sq_mfma.hip) ---------------------------------------------------------
+def _dist_all(qa, d):
+    return {O.COSINE: qa.Distance.Cosine, O.DOT: qa.Distance.Dot, O.EUCLID: qa.Distance.Euclid}[d]
+
+
+@pytest.mark.parametrize("dist", [O.DOT, O.COSINE, O.EUCLID])
+@pytest.mark.parametrize("dim", [16, 65, 768, 1024, 1100])    # 1100: past the exact-f32 bound -> stays on the VALU kernel
+@pytest.mark.parametrize("nq", [8, 16, 32, 45])
+def test_sq_scores_bit_exact(qa, dist, dim, nq):
+    rng = np.random.default_rng(dim * 3 + nq + dist)
+    n = 517
+    vecs = O.preprocess(dist, rng.standard_normal((n, dim)).astype(np.float32))
+    quant = qa.ScalarQuantizer.from_min_max(vecs, dim, _dist_all(qa, dist))
+    osq = O.SqOracle(dist, dim, quant.alpha, quant.offset)
+    codes = osq.encode_rows(vecs)
+    st = qa.EncodedVectorsU8(codes, quant)
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    qpre = O.preprocess(dist, queries)
+    scorer = qa.new_raw_scorer(queries, st)
+    ids = np.concatenate([np.arange(n, dtype=np.uint32), rng.integers(0, n, 33).astype(np.uint32)])
+    got = scorer.score_points(ids)
+    want = osq.score_points(qpre, ids)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    os.environ["QMX_NO_MFMA_SCAN"] = "1"
+    try:
+        valu = scorer.score_points(ids)
+    finally:
+        del os.environ["QMX_NO_MFMA_SCAN"]
+    assert np.array_equal(got.view(np.uint32), valu.view(np.uint32))
+
+
+@pytest.mark.parametrize("nq,top", [(8, 10), (16, 64), (32, 3), (40, 100)])
+def test_sq_topk_with_deleted_and_id_lists(qa, nq, top):
+    rng = np.random.default_rng(nq * 5 + top)
+    n, dim = 30011, 96
+    vecs = O.preprocess(O.DOT, rng.standard_normal((n, dim)).astype(np.float32))
+    quant = qa.ScalarQuantizer.from_min_max(vecs, dim, qa.Distance.Dot)
+    codes = quant.encode(vecs)
+    st = qa.EncodedVectorsU8(codes, quant)
+    deleted = rng.random(n) < 0.2
+    st.set_deleted(deleted, None)
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    s = qa.BatchFilteredSearcher(queries, st, top)
+    os.environ["QMX_NO_MFMA_SCAN"] = "1"
+    try:
+        s_valu = qa.BatchFilteredSearcher(queries, st, top)
+        want_all = s_valu.peek_top_all()
+        ids = rng.permutation(n)[:9999].astype(np.uint32)
+        want_ids = s_valu.peek_top_iter(ids)
+    finally:
+        del os.environ["QMX_NO_MFMA_SCAN"]
+    for got, want in ((s.peek_top_all(), want_all), (s.peek_top_iter(ids), want_ids)):
+        for g, w in zip(got, want):      # both kernels produce the same exact scores and break ties by the lower id
+            assert g["idx"].tolist() == w["idx"].tolist()
+            assert np.array_equal(g["score"].view(np.uint32), w["score"].view(np.uint32))
+            assert not deleted[g["idx"]].any()
