@@ -36,8 +36,6 @@ namespace qmx {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int MF_BLOCK = 512;
-constexpr int MF_NW = MF_BLOCK / WAVE;
 
 template <int XORMASK>
 __device__ __forceinline__ float swz_xor(float v) {
@@ -54,8 +52,9 @@ __device__ __forceinline__ float swap16_add(float a, float b) {
 
 // QW queries per wave, QSPLIT waves share one row stream (each scores its own QW queries of the
 // QW * QSPLIT-query tile; the second read of a row line hits L1 / L2), D row loads in flight per lane.
-template <int QW, int QSPLIT, int D, bool NT, bool HAS_IDS, int MODE>
-__global__ __launch_bounds__(MF_BLOCK) void scan_f32_mfma_kernel(const ScanArgs a) {
+template <int QW, int QSPLIT, int D, bool NT, int NWAVES, bool FAST, bool HAS_IDS, int MODE>
+__global__ __launch_bounds__(NWAVES * 64) void scan_f32_mfma_kernel(const ScanArgs a) {
+    constexpr int MF_BLOCK = NWAVES * 64, MF_NW = NWAVES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NG = QW / 4;
     constexpr int QT = QW * QSPLIT;
@@ -159,37 +158,68 @@ __global__ __launch_bounds__(MF_BLOCK) void scan_f32_mfma_kernel(const ScanArgs 
 #pragma unroll
         for (int g = 0; g < NG; ++g) qq[0][g] = *reinterpret_cast<const uint4 *>(qbase + (uint32_t)g * gstride);
 
-        for (uint32_t s0 = 0; s0 < nseg; s0 += D) {
-            const bool last_chunk = s0 + D >= nseg;
-            const unsigned char *np = last_chunk ? rp_next : rp;
-            const uint32_t ns0 = last_chunk ? 0 : s0 + D;
+        // one 32-float step: 4 MFMAs per query group on the row piece `vv` and the query pieces `qv`
+        auto step_mfma = [&](const uint4 &vv, const uint4 (&qv)[NG]) {
+            const float v0 = __uint_as_float(vv.x), v1 = __uint_as_float(vv.y), v2 = __uint_as_float(vv.z), v3 = __uint_as_float(vv.w);
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
-                const uint32_t sn = ns0 + d < nseg ? ns0 + d : nseg - 1;
-                nxt[d] = load_piece(np + (uint64_t)sn * 128);
+            for (int g = 0; g < NG; ++g) {
+                // _mm256_fmadd_ps(v1, v2, sum) of chain 4u + t for rows 4rh..4rh+3 x queries q0+4g..q0+4g+3
+                acc[g][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(v0, __uint_as_float(qv[g].x), acc[g][0], 0, 0, 0);
+                acc[g][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(v1, __uint_as_float(qv[g].y), acc[g][1], 0, 0, 0);
+                acc[g][2] = __builtin_amdgcn_mfma_f32_4x4x1f32(v2, __uint_as_float(qv[g].z), acc[g][2], 0, 0, 0);
+                acc[g][3] = __builtin_amdgcn_mfma_f32_4x4x1f32(v3, __uint_as_float(qv[g].w), acc[g][3], 0, 0, 0);
             }
+        };
+        if constexpr (FAST) {
+            // nseg is a multiple of 2 D: chunks alternate between the two register buffers (no copies, no guards, constant
+            // offsets inside a chunk); `cur` holds chunk c, `nxt` chunk c + 1, the refill of `cur` is chunk c + 2 of this
+            // tile or chunk 0 of the next one.  The query piece of step s + 1 is read while step s multiplies; the read
+            // past the last step lands in the slack behind the tile entry and is never used.
+            const uint32_t nchunk = nseg / D;
+            for (uint32_t c = 0; c < nchunk; c += 2) {
+                const unsigned char *pb = rp + (uint64_t)(c + 1) * D * 128;
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
-                const uint32_t sq = s0 + d + 1 < nseg ? s0 + d + 1 : 0;     // query pieces of the next step
+                for (int d = 0; d < D; ++d) nxt[d] = load_piece(pb + d * 128);
+                const unsigned char *qc = qbase + (c * D + 1) * 128;
 #pragma unroll
-                for (int g = 0; g < NG; ++g)
-                    qq[(d + 1) & 1][g] = *reinterpret_cast<const uint4 *>(qbase + (uint32_t)g * gstride + sq * 128);
-                if (s0 + d < nseg) {
-                    const float v0 = __uint_as_float(cur[d].x), v1 = __uint_as_float(cur[d].y), v2 = __uint_as_float(cur[d].z),
-                                v3 = __uint_as_float(cur[d].w);
+                for (int d = 0; d < D; ++d) {
 #pragma unroll
-                    for (int g = 0; g < NG; ++g) {
-                        const uint4 q4 = qq[d & 1][g];
-                        // _mm256_fmadd_ps(v1, v2, sum) of chain 4u + t for rows 4rh..4rh+3 x queries q0+4g..q0+4g+3
-                        acc[g][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(v0, __uint_as_float(q4.x), acc[g][0], 0, 0, 0);
-                        acc[g][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(v1, __uint_as_float(q4.y), acc[g][1], 0, 0, 0);
-                        acc[g][2] = __builtin_amdgcn_mfma_f32_4x4x1f32(v2, __uint_as_float(q4.z), acc[g][2], 0, 0, 0);
-                        acc[g][3] = __builtin_amdgcn_mfma_f32_4x4x1f32(v3, __uint_as_float(q4.w), acc[g][3], 0, 0, 0);
-                    }
+                    for (int g = 0; g < NG; ++g) qq[(d + 1) & 1][g] = *reinterpret_cast<const uint4 *>(qc + (uint32_t)g * gstride + d * 128);
+                    step_mfma(cur[d], qq[d & 1]);
+                }
+                const bool more = c + 2 < nchunk;
+                const unsigned char *pa = more ? rp + (uint64_t)(c + 2) * D * 128 : rp_next;
+#pragma unroll
+                for (int d = 0; d < D; ++d) cur[d] = load_piece(pa + d * 128);
+                const unsigned char *qd = qbase + ((c + 1) * D + 1) * 128;
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) qq[(d + 1) & 1][g] = *reinterpret_cast<const uint4 *>(qd + (uint32_t)g * gstride + d * 128);
+                    step_mfma(nxt[d], qq[d & 1]);
                 }
             }
-#pragma unroll
-            for (int d = 0; d < D; ++d) cur[d] = nxt[d];
+        } else {
+            for (uint32_t s0 = 0; s0 < nseg; s0 += D) {
+                const bool last_chunk = s0 + D >= nseg;
+                const unsigned char *np = last_chunk ? rp_next : rp;
+                const uint32_t ns0 = last_chunk ? 0 : s0 + D;
+    #pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const uint32_t sn = ns0 + d < nseg ? ns0 + d : nseg - 1;
+                    nxt[d] = load_piece(np + (uint64_t)sn * 128);
+                }
+    #pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const uint32_t sq = s0 + d + 1 < nseg ? s0 + d + 1 : 0;     // query pieces of the next step
+    #pragma unroll
+                    for (int g = 0; g < NG; ++g)
+                        qq[(d + 1) & 1][g] = *reinterpret_cast<const uint4 *>(qbase + (uint32_t)g * gstride + sq * 128);
+                    if (s0 + d < nseg) step_mfma(cur[d], qq[d & 1]);
+                }
+    #pragma unroll
+                for (int d = 0; d < D; ++d) cur[d] = nxt[d];
+            }
         }
         rp = rp_next;
 
@@ -279,18 +309,19 @@ __global__ __launch_bounds__(MF_BLOCK) void scan_f32_mfma_kernel(const ScanArgs 
     }
 }
 
-template <int QW, int QSPLIT, int D, bool NT, bool HAS_IDS, int MODE>
+template <int QW, int QSPLIT, int D, bool NT, int NWAVES, bool FAST, bool HAS_IDS, int MODE>
 static int32_t launch_mfma_inst(hipStream_t st, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
     constexpr int QT = QW * QSPLIT;
+    constexpr int MF_BLOCK = NWAVES * 64, MF_NW = NWAVES;
     constexpr int NSTREAM = MF_NW / QSPLIT;
-    size_t lds = (size_t)QT * a.q_stride;
+    size_t lds = (size_t)QT * a.q_stride + 256;   // slack: the FAST path reads one step past the last entry
     if (MODE == SCAN_TOPK) {
         const size_t lk = (size_t)NSTREAM * QT * a.top * sizeof(uint64_t);
         if (lk > lds) lds = lk;
     }
     lds = (lds + 15) & ~(size_t)15;
     QMX_REQUIRE(lds <= 160 * 1024, QMX_ERR_NOT_SUPPORTED, "query tile needs %zu B of LDS (> 160 KiB)", lds);
-    auto kfn = scan_f32_mfma_kernel<QW, QSPLIT, D, NT, HAS_IDS, MODE>;
+    auto kfn = scan_f32_mfma_kernel<QW, QSPLIT, D, NT, NWAVES, FAST, HAS_IDS, MODE>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -314,14 +345,14 @@ static int32_t launch_mfma_inst(hipStream_t st, const ScanArgs &a, int num_cus, 
     return QMX_OK;
 }
 
-template <int QW, int QSPLIT, int D, bool NT>
+template <int QW, int QSPLIT, int D, bool NT, int NWAVES = 8, bool FAST = false>
 static int32_t launch_mfma_qt(hipStream_t st, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid) {
     const bool ids = a.ids != nullptr;
     if (mode == SCAN_TOPK)
-        return ids ? launch_mfma_inst<QW, QSPLIT, D, NT, true, SCAN_TOPK>(st, a, num_cus, grid)
-                   : launch_mfma_inst<QW, QSPLIT, D, NT, false, SCAN_TOPK>(st, a, num_cus, grid);
-    return ids ? launch_mfma_inst<QW, QSPLIT, D, NT, true, SCAN_SCORES>(st, a, num_cus, grid)
-               : launch_mfma_inst<QW, QSPLIT, D, NT, false, SCAN_SCORES>(st, a, num_cus, grid);
+        return ids ? launch_mfma_inst<QW, QSPLIT, D, NT, NWAVES, FAST, true, SCAN_TOPK>(st, a, num_cus, grid)
+                   : launch_mfma_inst<QW, QSPLIT, D, NT, NWAVES, FAST, false, SCAN_TOPK>(st, a, num_cus, grid);
+    return ids ? launch_mfma_inst<QW, QSPLIT, D, NT, NWAVES, FAST, true, SCAN_SCORES>(st, a, num_cus, grid)
+               : launch_mfma_inst<QW, QSPLIT, D, NT, NWAVES, FAST, false, SCAN_SCORES>(st, a, num_cus, grid);
 }
 
 // qt in {8, 16, 32}; f32 rows, dot (or cosine on normalised rows), dim >= 32
@@ -332,8 +363,18 @@ int32_t launch_scan_f32_mfma(hipStream_t st, int qt, ScanMode mode, const ScanAr
             static const bool nt = getenv("QMX_MFMA_NO_NT") == nullptr;
             return nt ? launch_mfma_qt<8, 1, 4, true>(st, mode, a, num_cus, grid_out) : launch_mfma_qt<8, 1, 4, false>(st, mode, a, num_cus, grid_out);
         }
-        case 16: return launch_mfma_qt<16, 1, 12, true>(st, mode, a, num_cus, grid_out);
-        case 32: return launch_mfma_qt<16, 2, 12, true>(st, mode, a, num_cus, grid_out);
+        case 16:
+            // rows of a multiple of 384 floats (768, 1536, ...): guard-free ping-pong main loop
+            if (a.nseg % 12 == 0 && getenv("QMX_MFMA_NO_FAST") == nullptr) return launch_mfma_qt<16, 1, 6, true, 8, true>(st, mode, a, num_cus, grid_out);
+            return launch_mfma_qt<16, 1, 12, true>(st, mode, a, num_cus, grid_out);
+        case 32: {
+            static const int variant = getenv("QMX_MFMA_VARIANT") ? atoi(getenv("QMX_MFMA_VARIANT")) : 0;   // tuning experiments
+            if (variant == 1) return launch_mfma_qt<32, 1, 12, true, 4>(st, mode, a, num_cus, grid_out);   // 1 wave / SIMD, 512 registers
+            if (variant == 2) return launch_mfma_qt<32, 1, 8, true, 4>(st, mode, a, num_cus, grid_out);
+            if (variant == 3) return launch_mfma_qt<32, 1, 4, true, 8>(st, mode, a, num_cus, grid_out);
+            if (a.nseg % 12 == 0 && getenv("QMX_MFMA_NO_FAST") == nullptr) return launch_mfma_qt<16, 2, 6, true, 8, true>(st, mode, a, num_cus, grid_out);
+            return launch_mfma_qt<16, 2, 12, true>(st, mode, a, num_cus, grid_out);
+        }
     }
     set_error("unsupported MFMA query tile %d", qt);
     return QMX_ERR_BAD_ARG;
