@@ -362,6 +362,41 @@ QMX_API int32_t qmx_hnsw_search_async(const qmx_hnsw *g, qmx_query *q, uint32_t 
                                       qmx_scored_point *out_dev, uint32_t *out_counts_dev,
                                       uint32_t *out_scored_dev);
 
+/* ---- HNSW build on device ------------------------------------------------------------------------ */
+
+/* `HnswConfig` subset used by `GraphLayersBuilder` (graph_layers_builder.rs:230-262). */
+typedef struct qmx_hnsw_build_params {
+    uint32_t m;                 /* links per point on levels > 0                                  */
+    uint32_t m0;                /* links per point on level 0 (the reference uses 2 m); <= 64     */
+    uint32_t ef_construct;      /* beam width of the insertion searches; <= 512                   */
+    uint32_t entry_points_num;  /* extra entry points kept (highest levels), reference default 10 */
+    uint64_t seed;              /* level draw: level(i) = round(-ln U(seed, i) / ln max(m, 2))    */
+    uint32_t max_batch;         /* points inserted concurrently (0 = default 16384); a batch never exceeds
+                                   1/32 of the points already linked                              */
+    uint32_t reserved;
+} qmx_hnsw_build_params;
+
+/* Sizes of the plain arrays of a graph (for qmx_hnsw_export_plain). */
+typedef struct qmx_hnsw_info {
+    uint32_t m, m0, n_points, n_levels;
+    uint64_t n_offsets, n_neighbors;
+    uint32_t n_entry_points, n_extra_entry_points;
+} qmx_hnsw_info;
+
+/* Builds the HNSW graph of a dense f32 / f16 segment on its GPU: the work of `GraphLayersBuilder::link_new_point`
+ * (graph_layers_builder.rs:417-474) for every non-deleted point, batch-parallel — the counterpart of
+ * the reference's rayon / Vulkan builders (hnsw/build.rs:355, hnsw/gpu_build.rs).  Insertion order inside a batch
+ * is concurrent, so the graph is not link-for-link the sequential CPU graph; it obeys the same invariants (<= m0 / m
+ * links, no self links, no duplicates, links only to points of at least that level) and is checked by recall.
+ * The result is searchable at once (qmx_hnsw_search) and exportable as plain GraphLinks arrays. */
+QMX_API int32_t qmx_hnsw_build(const qmx_segment *seg, const qmx_hnsw_build_params *params, qmx_hnsw **out);
+QMX_API int32_t qmx_hnsw_get_info(const qmx_hnsw *g, qmx_hnsw_info *out);
+/* Copies the plain arrays of a graph built by qmx_hnsw_build into caller (host) buffers sized per qmx_hnsw_get_info:
+ * reindex [n_points], level_offsets [n_levels + 1], offsets [n_offsets], neighbors [n_neighbors], entry points. */
+QMX_API int32_t qmx_hnsw_export_plain(const qmx_hnsw *g, uint32_t *reindex, uint64_t *level_offsets, uint64_t *offsets,
+                                      uint32_t *neighbors, uint32_t *entry_point_ids, uint32_t *entry_point_levels,
+                                      uint32_t *extra_entry_point_ids, uint32_t *extra_entry_point_levels);
+
 /* ---- quantizers -------------------------------------------------------------------------------- */
 
 /* `EncodedVectorsU8::encode` row loop (encoded_vectors_u8.rs:236-296) for given params:

@@ -58,6 +58,17 @@ class HnswDesc(C.Structure):
                 ("extra_entry_point_levels", C.c_void_p), ("device_id", C.c_int32), ("reserved", C.c_int32)]
 
 
+class HnswBuildParams(C.Structure):
+    _fields_ = [("m", C.c_uint32), ("m0", C.c_uint32), ("ef_construct", C.c_uint32), ("entry_points_num", C.c_uint32),
+                ("seed", C.c_uint64), ("max_batch", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class HnswInfo(C.Structure):
+    _fields_ = [("m", C.c_uint32), ("m0", C.c_uint32), ("n_points", C.c_uint32), ("n_levels", C.c_uint32),
+                ("n_offsets", C.c_uint64), ("n_neighbors", C.c_uint64), ("n_entry_points", C.c_uint32),
+                ("n_extra_entry_points", C.c_uint32)]
+
+
 class QmxError(RuntimeError):
     def __init__(self, status, message):
         self.status = status
@@ -100,6 +111,9 @@ SIGNATURES = {
     "qmx_hnsw_create": (C.c_int32, [C.POINTER(HnswDesc), C.POINTER(_P)]),
     "qmx_hnsw_create_from_plain_file": (C.c_int32, [_P, C.c_uint64, C.POINTER(HnswDesc), C.POINTER(_P)]),
     "qmx_hnsw_destroy": (C.c_int32, [_P]),
+    "qmx_hnsw_build": (C.c_int32, [_P, C.POINTER(HnswBuildParams), C.POINTER(_P)]),
+    "qmx_hnsw_get_info": (C.c_int32, [_P, C.POINTER(HnswInfo)]),
+    "qmx_hnsw_export_plain": (C.c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qmx_hnsw_search": (C.c_int32, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, _P, C.POINTER(Counters)]),
     "qmx_hnsw_search_async": (C.c_int32, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, _P]),
     "qmx_sq_encode": (C.c_int32, [C.c_int32, C.c_uint32, C.POINTER(SqParams), _P, C.c_uint64, C.c_uint32, _P]),

@@ -1012,6 +1012,9 @@ struct qmx_hnsw {
     uint32_t *d_reindex = nullptr, *d_neighbors = nullptr, *d_ep_ids = nullptr, *d_ep_levels = nullptr, *d_xp_ids = nullptr,
              *d_xp_levels = nullptr;
     uint64_t *d_level_offsets = nullptr, *d_offsets = nullptr;
+    // host copy of the plain arrays (graphs built by qmx_hnsw_build; empty otherwise) for qmx_hnsw_export_plain
+    std::vector<uint32_t> h_reindex, h_neighbors, h_ep_ids, h_ep_levels, h_xp_ids, h_xp_levels;
+    std::vector<uint64_t> h_level_offsets, h_offsets;
 };
 
 int32_t qmx_hnsw_destroy(qmx_hnsw *g) {
@@ -1134,6 +1137,269 @@ int32_t qmx_hnsw_create_from_plain_file(const void *bytes, uint64_t n_bytes, con
     return qmx_hnsw_create(&d, out);
 }
 
+constexpr uint32_t HNSW_SLOT_CAP = 4096;
+constexpr uint32_t HNSW_LOG_CAP = 16384;                    // words logged per search before falling back to a full clear
+constexpr uint64_t HNSW_VIS_BUDGET = 8ull << 30;            // bytes of visited bitmaps per query handle
+
+// ---------------------------------------------------------------------------------------------
+// HNSW build on device (hnsw_build.hpp)
+// ---------------------------------------------------------------------------------------------
+static inline uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+static void fill_args_segment(const qmx_segment *s, ScanArgs &a) {
+    memset(&a, 0, sizeof(a));
+    a.rows = s->d_rows;
+    a.n_rows = s->n;
+    a.row_stride = s->row_stride;
+    a.dim = s->scan_dim;
+    const uint32_t eb = elem_bytes(s->dtype);
+    const uint32_t full = s->scan_dim - s->scan_dim % 32;
+    a.nseg = full * eb / 128;
+    a.rem_pieces = (full * eb % 128) / 16;
+    a.tail_start = full;
+    a.del = s->deleted_view();
+    a.flags = s->flags;
+}
+
+int32_t qmx_hnsw_get_info(const qmx_hnsw *g, qmx_hnsw_info *out) {
+    QMX_REQUIRE(g && out, QMX_ERR_BAD_ARG, "NULL argument");
+    out->m = g->m; out->m0 = g->m0; out->n_points = g->n_points; out->n_levels = g->n_levels;
+    out->n_offsets = g->n_offsets; out->n_neighbors = g->n_neighbors;
+    out->n_entry_points = g->n_ep; out->n_extra_entry_points = g->n_xp;
+    return QMX_OK;
+}
+
+int32_t qmx_hnsw_export_plain(const qmx_hnsw *g, uint32_t *reindex, uint64_t *level_offsets, uint64_t *offsets, uint32_t *neighbors,
+                              uint32_t *ep_ids, uint32_t *ep_levels, uint32_t *xp_ids, uint32_t *xp_levels) {
+    QMX_REQUIRE(g, QMX_ERR_BAD_ARG, "NULL argument");
+    QMX_REQUIRE(g->n_points == 0 || !g->h_offsets.empty(), QMX_ERR_NOT_SUPPORTED, "only graphs built by qmx_hnsw_build keep a host copy to export");
+    auto cp = [](void *dst, const void *src, size_t bytes) { if (dst && bytes) memcpy(dst, src, bytes); };
+    cp(reindex, g->h_reindex.data(), g->h_reindex.size() * 4);
+    cp(level_offsets, g->h_level_offsets.data(), g->h_level_offsets.size() * 8);
+    cp(offsets, g->h_offsets.data(), g->h_offsets.size() * 8);
+    cp(neighbors, g->h_neighbors.data(), g->h_neighbors.size() * 4);
+    cp(ep_ids, g->h_ep_ids.data(), g->h_ep_ids.size() * 4);
+    cp(ep_levels, g->h_ep_levels.data(), g->h_ep_levels.size() * 4);
+    cp(xp_ids, g->h_xp_ids.data(), g->h_xp_ids.size() * 4);
+    cp(xp_levels, g->h_xp_levels.data(), g->h_xp_levels.size() * 4);
+    return QMX_OK;
+}
+
+int32_t qmx_hnsw_build(const qmx_segment *seg, const qmx_hnsw_build_params *bp, qmx_hnsw **out) {
+    QMX_REQUIRE(seg && bp && out, QMX_ERR_BAD_ARG, "NULL argument");
+    *out = nullptr;
+    QMX_REQUIRE(seg->dtype == QMX_DTYPE_F32 || seg->dtype == QMX_DTYPE_F16, QMX_ERR_NOT_SUPPORTED,
+                "device HNSW build needs a dense f32 / f16 segment (dtype %u)", seg->dtype);
+    QMX_REQUIRE(seg->fast_layout(), QMX_ERR_NOT_SUPPORTED, "adopted device block is not 16-byte aligned");
+    QMX_REQUIRE(bp->m >= 1 && bp->m0 >= bp->m && bp->m0 <= 64, QMX_ERR_BAD_ARG, "need 1 <= m <= m0 <= 64");
+    QMX_REQUIRE(bp->ef_construct >= 1 && bp->ef_construct <= HNSW_MAX_EF, QMX_ERR_NOT_SUPPORTED, "ef_construct %u not in 1..%u",
+                bp->ef_construct, HNSW_MAX_EF);
+    QMX_REQUIRE(seg->n <= 0xFFFFFFFFull, QMX_ERR_BAD_ARG, "too many rows");
+    QMX_HIP(hipSetDevice(seg->device));
+    const uint32_t n = (uint32_t)seg->n, m = bp->m, m0 = bp->m0;
+    const uint32_t max_batch = bp->max_batch ? bp->max_batch : 16384;
+
+    // ---- levels (graph_layers_builder.rs:388-396), the same draw as the CPU oracle ----
+    std::vector<uint8_t> level(std::max<uint32_t>(n, 1));
+    std::vector<uint32_t> up_off(std::max<uint32_t>(n, 1));
+    const double level_factor = 1.0 / log((double)(m > 2 ? m : 2));
+    uint64_t n_up = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint64_t r = splitmix64(bp->seed ^ (0xA0761D6478BD642Full * ((uint64_t)i + 1)));
+        const double u = ((double)(r >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+        double lv = round(-log(u) * level_factor);
+        if (lv > (double)(HNSW_BUILD_MAX_LEVELS - 1)) lv = HNSW_BUILD_MAX_LEVELS - 1;
+        level[i] = (uint8_t)lv;
+        up_off[i] = (uint32_t)n_up;
+        n_up += level[i];
+    }
+    QMX_REQUIRE(n_up <= 0xFFFFFFFFull, QMX_ERR_BAD_ARG, "too many upper-level lists");
+    // deleted flags on the host: deleted points are never indexed and never entry points
+    std::vector<uint64_t> pdel, vdel;
+    if (seg->d_point_deleted) { pdel.resize((seg->n_point_bits + 63) / 64); QMX_HIP(hipMemcpy(pdel.data(), seg->d_point_deleted, pdel.size() * 8, hipMemcpyDeviceToHost)); }
+    if (seg->d_vec_deleted) { vdel.resize((seg->n_vec_bits + 63) / 64); QMX_HIP(hipMemcpy(vdel.data(), seg->d_vec_deleted, vdel.size() * 8, hipMemcpyDeviceToHost)); }
+    auto live = [&](uint32_t id) {
+        const bool vd = (!vdel.empty() && id < seg->n_vec_bits) ? ((vdel[id >> 6] >> (id & 63)) & 1) : false;
+        const bool pd = !pdel.empty() ? (id < seg->n_point_bits ? ((pdel[id >> 6] >> (id & 63)) & 1) : true) : false;
+        return !vd && !pd;
+    };
+
+    // ---- device state ----
+    DevBuf b_level, b_upoff, b_links0, b_cnt0, b_linksU, b_cntU, b_lock, b_vis, b_log, b_sel, b_sels, b_selc;
+    auto release_all = [&]() {
+        for (DevBuf *b : {&b_level, &b_upoff, &b_links0, &b_cnt0, &b_linksU, &b_cntU, &b_lock, &b_vis, &b_log, &b_sel, &b_sels, &b_selc}) b->release();
+    };
+    int32_t rc = QMX_OK;
+    qmx_hnsw *g = nullptr;
+    do {
+#define QB(expr) if ((rc = (expr)) != QMX_OK) break
+#define QH(expr) if ((expr) != hipSuccess) { rc = hip_status(hipGetLastError(), #expr, __FILE__, __LINE__); if (rc == QMX_OK) rc = QMX_ERR_OTHER; break; }
+        const size_t nn = std::max<uint32_t>(n, 1);
+        QB(b_level.reserve(nn)); QB(b_upoff.reserve(nn * 4));
+        QB(b_links0.reserve(nn * m0 * 4)); QB(b_cnt0.reserve(nn * 4));
+        QB(b_linksU.reserve(std::max<uint64_t>(n_up, 1) * m * 4)); QB(b_cntU.reserve(std::max<uint64_t>(n_up, 1) * 4));
+        QB(b_lock.reserve(nn * 4));
+        QH(hipMemcpy(b_level.p, level.data(), nn, hipMemcpyHostToDevice));
+        QH(hipMemcpy(b_upoff.p, up_off.data(), nn * 4, hipMemcpyHostToDevice));
+        QH(hipMemset(b_cnt0.p, 0, nn * 4));
+        QH(hipMemset(b_cntU.p, 0, std::max<uint64_t>(n_up, 1) * 4));
+        QH(hipMemset(b_lock.p, 0, nn * 4));
+        QB(b_sel.reserve((size_t)max_batch * HNSW_BUILD_MAX_LEVELS * m0 * 4));
+        QB(b_sels.reserve((size_t)max_batch * HNSW_BUILD_MAX_LEVELS * m0 * 4));
+        QB(b_selc.reserve((size_t)max_batch * HNSW_BUILD_MAX_LEVELS * 4));
+
+        ScanArgs a;
+        fill_args_segment(seg, a);
+        HnswBuildArgs h;
+        memset(&h, 0, sizeof(h));
+        h.g.links0 = (uint32_t *)b_links0.p; h.g.cnt0 = (uint32_t *)b_cnt0.p; h.g.linksU = (uint32_t *)b_linksU.p; h.g.cntU = (uint32_t *)b_cntU.p;
+        h.g.up_off = (const uint32_t *)b_upoff.p; h.g.m = m; h.g.m0 = m0;
+        h.level = (const uint8_t *)b_level.p;
+        h.n_points = n;
+        h.ef_construct = bp->ef_construct;
+        h.sel_ids = (uint32_t *)b_sel.p; h.sel_scores = (float *)b_sels.p; h.sel_cnt = (uint32_t *)b_selc.p;
+        h.lock = (uint32_t *)b_lock.p;
+        h.row_bytes = (uint32_t)seg->row_bytes;
+        h.lds_query_bytes = (uint32_t)((seg->row_bytes + 127) / 128 * 128 + 128);
+        if (h.lds_query_bytes > HNSW_LDS_QUERY_MAX) {
+            set_error("rows of %llu bytes do not fit the LDS query slot", (unsigned long long)seg->row_bytes);
+            rc = QMX_ERR_NOT_SUPPORTED;
+            break;
+        }
+        h.log_cap = 16384;
+        h.vis_words = ((uint64_t)n + 31) / 32;
+        if (h.vis_words == 0) h.vis_words = 1;
+        int per_cu1 = 1, per_cu2 = 1;
+        QB(launch_hnsw_build_dense(nullptr, (int)seg->dtype, (int)seg->distance, a, h, 1, 0, &per_cu1));
+        QB(launch_hnsw_build_dense(nullptr, (int)seg->dtype, (int)seg->distance, a, h, 2, 0, &per_cu2));
+        uint64_t slots1 = std::min<uint64_t>({(uint64_t)seg->num_cus * per_cu1, (uint64_t)HNSW_SLOT_CAP, (uint64_t)max_batch});
+        slots1 = std::max<uint64_t>(1, std::min<uint64_t>(slots1, HNSW_VIS_BUDGET / (h.vis_words * 4)));
+        const uint64_t slots2 = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)seg->num_cus * per_cu2, max_batch));
+        QB(b_vis.reserve((size_t)slots1 * h.vis_words * 4));
+        QB(b_log.reserve((size_t)slots1 * h.log_cap * 4));
+        QH(hipMemset(b_vis.p, 0, (size_t)slots1 * h.vis_words * 4));
+        h.visited = (uint32_t *)b_vis.p;
+        h.vis_log = (uint32_t *)b_log.p;
+
+        // ---- insertion loop ----
+        // EntryPoints (entry_points.rs:46-94) kept on the host: the live point of the highest level seen first is the
+        // entry; the `entry_points_num` highest others are the extra entries
+        bool have_ep = false;
+        uint32_t ep_id = 0, ep_level = 0, inserted = 0;
+        std::vector<std::pair<uint32_t, uint32_t>> extra;   // (level, id)
+        auto note_point = [&](uint32_t id) {
+            const uint32_t lv = level[id];
+            if (!have_ep) { have_ep = true; ep_id = id; ep_level = lv; return; }
+            std::pair<uint32_t, uint32_t> other(lv, id);
+            if (lv > ep_level) { other = {ep_level, ep_id}; ep_id = id; ep_level = lv; }
+            if (bp->entry_points_num == 0) return;
+            if (extra.size() < bp->entry_points_num) { extra.push_back(other); return; }
+            size_t lo = 0;
+            for (size_t i = 1; i < extra.size(); ++i) if (extra[i].first < extra[lo].first) lo = i;
+            if (extra[lo].first < other.first) extra[lo] = other;
+        };
+        uint32_t next = 0;
+        while (next < n && rc == QMX_OK) {
+            if (!have_ep) {                      // the first live point: nothing to link to
+                if (live(next)) { note_point(next); ++inserted; }
+                ++next;
+                continue;
+            }
+            uint32_t count = std::min<uint32_t>({max_batch, std::max<uint32_t>(1, inserted / 32), n - next});
+            // a point above the current top level ends its batch: the next batch starts from it
+            for (uint32_t i = 0; i < count; ++i)
+                if (level[next + i] > ep_level && live(next + i)) { count = i + 1; break; }
+            h.first = next; h.count = count; h.ep_id = ep_id; h.ep_level = ep_level;
+            QB(launch_hnsw_build_dense(nullptr, (int)seg->dtype, (int)seg->distance, a, h, 1, (uint32_t)std::min<uint64_t>(slots1, count), &per_cu1));
+            QB(launch_hnsw_build_dense(nullptr, (int)seg->dtype, (int)seg->distance, a, h, 2, (uint32_t)std::min<uint64_t>(slots2, count), &per_cu2));
+            for (uint32_t i = 0; i < count; ++i)
+                if (live(next + i)) { note_point(next + i); ++inserted; }
+            next += count;
+        }
+        if (rc != QMX_OK) break;
+        QH(hipDeviceSynchronize());
+
+        // ---- export: fixed-capacity lists -> plain GraphLinks arrays (graph_links/serializer.rs:52-209) ----
+        std::vector<uint32_t> links0((size_t)nn * m0), cnt0(nn), linksU(std::max<uint64_t>(n_up, 1) * m), cntU(std::max<uint64_t>(n_up, 1));
+        QH(hipMemcpy(links0.data(), b_links0.p, links0.size() * 4, hipMemcpyDeviceToHost));
+        QH(hipMemcpy(cnt0.data(), b_cnt0.p, cnt0.size() * 4, hipMemcpyDeviceToHost));
+        QH(hipMemcpy(linksU.data(), b_linksU.p, linksU.size() * 4, hipMemcpyDeviceToHost));
+        QH(hipMemcpy(cntU.data(), b_cntU.p, cntU.size() * 4, hipMemcpyDeviceToHost));
+        release_all();
+        uint32_t maxl = 0;
+        for (uint32_t i = 0; i < n; ++i) maxl = std::max<uint32_t>(maxl, level[i]);
+        const uint32_t L = n ? maxl + 1 : 0;
+        g = new (std::nothrow) qmx_hnsw();
+        if (!g) { rc = QMX_ERR_OUT_OF_MEMORY; break; }
+        std::vector<uint64_t> count_ge(L + 1, 0);
+        for (uint32_t i = 0; i < n; ++i) for (uint32_t l = 0; l <= level[i]; ++l) count_ge[l]++;
+        // back_index: points by descending level, ties by id
+        std::vector<uint32_t> back(nn);
+        {
+            std::vector<uint64_t> start(L + 1, 0);
+            uint64_t acc = 0;
+            for (int32_t l = (int32_t)L - 1; l >= 0; --l) { start[l] = acc; acc += count_ge[l] - (l + 1 < (int32_t)L ? count_ge[l + 1] : 0); }
+            for (uint32_t i = 0; i < n; ++i) back[start[level[i]]++] = i;
+        }
+        g->h_reindex.resize(n);
+        for (uint32_t i = 0; i < n; ++i) g->h_reindex[back[i]] = i;
+        uint64_t total_slots = 0;
+        for (uint32_t l = 0; l < L; ++l) total_slots += count_ge[l];
+        g->h_level_offsets.assign(L + 1, 0);
+        g->h_offsets.assign(total_slots + 1, 0);
+        uint64_t nnb = 0;
+        for (uint32_t i = 0; i < n; ++i) { nnb += cnt0[i]; for (uint32_t l = 1; l <= level[i]; ++l) nnb += cntU[up_off[i] + l - 1]; }
+        g->h_neighbors.resize(nnb);
+        uint64_t off = 0, slot = 0;
+        for (uint32_t l = 0; l < L; ++l) {
+            g->h_level_offsets[l] = slot;
+            for (uint64_t j = 0; j < count_ge[l]; ++j) {
+                const uint32_t id = l == 0 ? (uint32_t)j : back[j];
+                g->h_offsets[slot++] = off;
+                const uint32_t len = l == 0 ? cnt0[id] : cntU[up_off[id] + l - 1];
+                const uint32_t *src = l == 0 ? &links0[(size_t)id * m0] : &linksU[((size_t)up_off[id] + l - 1) * m];
+                memcpy(g->h_neighbors.data() + off, src, (size_t)len * 4);
+                off += len;
+            }
+        }
+        g->h_level_offsets[L] = slot;
+        g->h_offsets[slot] = off;
+        if (have_ep) { g->h_ep_ids.push_back(ep_id); g->h_ep_levels.push_back(ep_level); }
+        for (auto &e : extra) { g->h_xp_ids.push_back(e.second); g->h_xp_levels.push_back(e.first); }
+        qmx_hnsw_desc d;
+        memset(&d, 0, sizeof(d));
+        d.m = m; d.m0 = m0; d.n_points = n; d.n_levels = L;
+        d.reindex = g->h_reindex.data(); d.level_offsets = g->h_level_offsets.data(); d.offsets = g->h_offsets.data();
+        d.n_offsets = g->h_offsets.size(); d.neighbors = g->h_neighbors.data(); d.n_neighbors = g->h_neighbors.size();
+        d.entry_point_ids = g->h_ep_ids.data(); d.entry_point_levels = g->h_ep_levels.data(); d.n_entry_points = (uint32_t)g->h_ep_ids.size();
+        d.extra_entry_point_ids = g->h_xp_ids.data(); d.extra_entry_point_levels = g->h_xp_levels.data();
+        d.n_extra_entry_points = (uint32_t)g->h_xp_ids.size();
+        d.device_id = seg->device;
+        qmx_hnsw *dev = nullptr;
+        QB(qmx_hnsw_create(&d, &dev));
+        // move the device arrays into g (which owns the host copy)
+        g->device = dev->device; g->m = dev->m; g->m0 = dev->m0; g->n_points = dev->n_points; g->n_levels = dev->n_levels;
+        g->n_ep = dev->n_ep; g->n_xp = dev->n_xp; g->n_offsets = dev->n_offsets; g->n_neighbors = dev->n_neighbors;
+        g->d_reindex = dev->d_reindex; g->d_neighbors = dev->d_neighbors; g->d_ep_ids = dev->d_ep_ids; g->d_ep_levels = dev->d_ep_levels;
+        g->d_xp_ids = dev->d_xp_ids; g->d_xp_levels = dev->d_xp_levels; g->d_level_offsets = dev->d_level_offsets; g->d_offsets = dev->d_offsets;
+        delete dev;
+#undef QB
+#undef QH
+    } while (0);
+    release_all();
+    if (rc != QMX_OK) {
+        if (g) qmx_hnsw_destroy(g);
+        return rc;
+    }
+    *out = g;
+    return QMX_OK;
+}
+
 static int32_t launch_hnsw(const qmx_query *q, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
     const qmx_segment *s = q->seg;
     if (s->dtype <= QMX_DTYPE_U8) {
@@ -1146,9 +1412,6 @@ static int32_t launch_hnsw(const qmx_query *q, const ScanArgs &a, const HnswArgs
     return QMX_ERR_NOT_SUPPORTED;
 }
 
-constexpr uint32_t HNSW_SLOT_CAP = 4096;
-constexpr uint32_t HNSW_LOG_CAP = 16384;                    // words logged per search before falling back to a full clear
-constexpr uint64_t HNSW_VIS_BUDGET = 8ull << 30;            // bytes of visited bitmaps per query handle
 
 static int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef, qmx_scored_point *d_out,
                             uint32_t *d_counts, uint32_t *d_scored, bool timed) {

@@ -1,0 +1,358 @@
+// hnsw_build.hpp — HNSW graph construction on the device, batch-parallel.
+//
+// Replaces GraphLayersBuilder::link_new_point (lib/segment/src/index/hnsw_index/graph_layers_builder.rs:417-474:
+// search_entry above the point's level, then per level search_on_level(ef_construct) -> link_with_heuristic
+// :532-556) and LinksContainer::{fill_from_sorted_with_heuristic :47-71, connect_with_heuristic :106-132}
+// for dense f32 / f16 storages.  The reference builds with a rayon pool of threads inserting points concurrently
+// under per-point locks (hnsw/build.rs:355) and has a Vulkan batch builder (hnsw_index/gpu/*); neither has a
+// deterministic insertion order, so — like for those — parity of a built graph is defined by its invariants and
+// by search quality (recall equal to the CPU oracle's build within noise), not link-for-link.
+//
+// Scheme: points are inserted in id order, in batches that never exceed 1/32 of the points already in the graph.
+//   phase 1 (hnsw_build_search_kernel)  one wavefront per new point, graph READ-ONLY: greedy descent to the point's
+//            level, then on every level l <= level(p): beam search with ef_construct (same register beam / visited
+//            bitmap as the search kernel, hnsw.hpp) -> candidates -> heuristic selection -> sel[p][l] (+ scores)
+//   phase 2 (hnsw_build_link_kernel)    one wavefront per new point, no searches running: publish p's own link
+//            lists, then for every selected neighbour q: lock(q), append p or — when q is full — re-select q's links
+//            among links(q) + p with the same heuristic, unlock.
+// Scores are the scan's lane policies (bit-identical to the x86 reference); a stored row is used as a "query entry"
+// directly (dense rows need no aux block), the new point's row is staged in LDS.
+//
+// Graph storage while building: fixed-capacity lists, level 0: links0[p][m0] + cnt0[p]; levels >= 1:
+// linksU[up_off[p] + l - 1][m] + cntU[...].  Exported afterwards to the plain GraphLinks arrays.
+#pragma once
+#include "hnsw.hpp"
+
+namespace qmx {
+
+// loads / stores of link lists in phase 2 go to L2 (agent scope): another CU may have rewritten the list under its lock
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// fill_from_sorted_with_heuristic (links_container.rs:47-71): candidates sorted by descending score to the target;
+// keep c unless it is closer to an already kept link than to the target.  cand_* and sel_* live in LDS.
+// Returns the number kept (wave-uniform).  `a.rows` rows double as query entries.
+template <class H>
+__device__ __forceinline__ uint32_t heuristic_fill(const ScanArgs &a, const uint32_t *cand_ids, const float *cand_scores, uint32_t n_cand,
+                                                   uint32_t lm, uint32_t *sel_ids, float *sel_scores, uint32_t *hop_ids, float *hop_scores,
+                                                   int lane) {
+    uint32_t n_sel = 0;
+    const unsigned char *rows = reinterpret_cast<const unsigned char *>(a.rows);
+    for (uint32_t c = 0; c < n_cand && n_sel < lm; ++c) {
+        const uint32_t cid = cand_ids[c];
+        const float cs = cand_scores[c];
+        bool skip = false;
+        for (uint32_t base = 0; base < n_sel && !skip; base += 64) {
+            const uint32_t k = n_sel - base < 64 ? n_sel - base : 64;
+            __syncthreads();
+            if ((uint32_t)lane < k) hop_ids[lane] = sel_ids[base + lane];
+            hop_score<H>(a, rows + (uint64_t)cid * a.row_stride, hop_ids, hop_scores, k, lane);   // score(candidate, kept link)
+            const bool bad = (uint32_t)lane < k && hop_scores[lane] > cs;
+            skip = __ballot(bad) != 0;
+        }
+        if (skip) continue;
+        __syncthreads();
+        if (lane == 0) {
+            sel_ids[n_sel] = cid;
+            sel_scores[n_sel] = cs;
+        }
+        ++n_sel;
+    }
+    __syncthreads();
+    return n_sel;
+}
+
+// ---- phase 1 ----------------------------------------------------------------------------------------------------
+template <class H, int E>
+__global__ __launch_bounds__(64) void hnsw_build_search_kernel(const ScanArgs a, const HnswBuildArgs h) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    uint32_t *hop_ids = reinterpret_cast<uint32_t *>(smem);
+    float *hop_scores = reinterpret_cast<float *>(smem + 256);
+    uint32_t *cand_ids = reinterpret_cast<uint32_t *>(smem + 512);                     // [64 E]
+    float *cand_scores = reinterpret_cast<float *>(smem + 512 + 256 * E);
+    uint32_t *sel_ids = reinterpret_cast<uint32_t *>(smem + 512 + 512 * E);            // [64]
+    float *sel_scores = reinterpret_cast<float *>(smem + 512 + 512 * E + 256);
+    unsigned char *q_lds = smem + 512 + 512 * E + 512;
+    uint32_t *vis = h.visited + (uint64_t)blockIdx.x * h.vis_words;
+    uint32_t *vlog = h.vis_log + (uint64_t)blockIdx.x * h.log_cap;
+    const unsigned char *rows = reinterpret_cast<const unsigned char *>(a.rows);
+    const uint32_t ef = h.ef_construct;
+
+    for (uint32_t bi = blockIdx.x; bi < h.count; bi += gridDim.x) {
+        const uint32_t p = h.first + bi;
+        const uint32_t lp = h.level[p];
+        uint32_t *my_cnt = h.sel_cnt + (uint64_t)bi * HNSW_BUILD_MAX_LEVELS;
+        if (lane < (int)HNSW_BUILD_MAX_LEVELS) my_cnt[lane] = 0;
+        if (!a.del.live(p)) continue;            // deleted points are never indexed (hnsw/build.rs:293-300)
+
+        // stage the new point's row as the query entry (zero padded to whole 128-byte steps)
+        __syncthreads();
+        {
+            const unsigned char *src = rows + (uint64_t)p * a.row_stride;
+            for (uint32_t i = (uint32_t)lane * 16; i < h.lds_query_bytes; i += 64 * 16) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (i + 16 <= h.row_bytes) v = *reinterpret_cast<const uint4 *>(src + i);
+                else if (i < h.row_bytes) {
+                    unsigned char tmp[16];
+                    for (uint32_t b = 0; b < 16; ++b) tmp[b] = i + b < h.row_bytes ? src[i + b] : 0;
+                    v = *reinterpret_cast<const uint4 *>(tmp);
+                }
+                *reinterpret_cast<uint4 *>(q_lds + i) = v;
+            }
+        }
+        __syncthreads();
+
+        // ---- search_entry: greedy descent from the entry point's level to level(p) + 1 ----
+        uint32_t cur_id = h.ep_id;
+        float cur_score;
+        {
+            if (lane == 0) hop_ids[0] = cur_id;
+            hop_score<H>(a, q_lds, hop_ids, hop_scores, 1, lane);
+            cur_score = hop_scores[0];
+        }
+        for (uint32_t level = h.ep_level; level > lp; --level) {
+            bool changed = true;
+            while (changed) {
+                changed = false;
+                const uint32_t *lst = h.g.list(cur_id, level);
+                const uint32_t len = *h.g.count(cur_id, level);
+                for (uint32_t base = 0; base < len; base += 64) {
+                    const uint32_t i = base + (uint32_t)lane;
+                    const bool on = i < len;
+                    const uint32_t id = on ? lst[i] : 0;
+                    const uint64_t mask = __ballot(on);
+                    const uint32_t k = (uint32_t)__popcll(mask);
+                    __syncthreads();
+                    if (on) hop_ids[lane] = id;
+                    hop_score<H>(a, q_lds, hop_ids, hop_scores, k, lane);
+                    uint64_t mk = 0;
+                    if ((uint32_t)lane < k && hop_scores[lane] > cur_score)
+                        mk = ((uint64_t)score_to_ord(hop_scores[lane]) << 32) | (uint32_t)(~(uint32_t)lane);
+                    const uint64_t best = wave_max_u64(mk);
+                    if (best) {
+                        const uint32_t bl = ~(uint32_t)best;
+                        cur_id = hop_ids[bl];
+                        cur_score = hop_scores[bl];
+                        changed = true;
+                    }
+                }
+            }
+        }
+
+        // ---- per level: search_on_level(ef_construct) -> heuristic -> sel ----
+        const uint32_t top_link_level = lp < h.ep_level ? lp : h.ep_level;
+        for (int32_t lv = (int32_t)top_link_level; lv >= 0; --lv) {
+            const uint32_t level = (uint32_t)lv;
+            Beam<E> beam;
+            beam.clear();
+            uint32_t log_cnt = 1;
+            if (lane == 0) {
+                atomicOr(&vis[cur_id >> 5], 1u << (cur_id & 31));
+                vlog[0] = cur_id >> 5;
+            }
+            beam.insert(make_key(cur_score, cur_id), ef, lane);
+            while (true) {
+                const uint64_t ck = beam.pop_best(lane);
+                if (ck == 0) break;
+                const uint32_t cand = key_idx(ck);
+                const uint32_t *lst = h.g.list(cand, level);
+                const uint32_t len = *h.g.count(cand, level);
+                for (uint32_t base = 0; base < len; base += 64) {
+                    const uint32_t i = base + (uint32_t)lane;
+                    const bool on = i < len;
+                    const uint32_t id = on ? lst[i] : 0;
+                    const bool live = on && id < h.n_points;
+                    const uint32_t bit = 1u << (id & 31);
+                    const uint32_t old = live ? atomicOr(&vis[id >> 5], bit) : bit;
+                    const bool keep = live && !(old & bit);
+                    const uint64_t mask = __ballot(keep);
+                    const uint32_t rank = (uint32_t)__popcll(mask & lt_mask);
+                    const uint32_t k = (uint32_t)__popcll(mask);
+                    __syncthreads();
+                    if (keep) {
+                        hop_ids[rank] = id;
+                        if (log_cnt + rank < h.log_cap) vlog[log_cnt + rank] = id >> 5;
+                    }
+                    log_cnt += k;
+                    hop_score<H>(a, q_lds, hop_ids, hop_scores, k, lane);
+                    const uint64_t mykey = (uint32_t)lane < k ? make_key(hop_scores[lane], hop_ids[lane]) : 0;
+                    uint64_t mm = __ballot(mykey > beam.at(ef - 1));
+                    while (mm) {
+                        const int src = __builtin_ctzll(mm);
+                        mm &= mm - 1;
+                        const uint64_t nk = readlane_u64(mykey, src);
+                        if (nk > beam.at(ef - 1)) beam.insert(nk, ef, lane);
+                    }
+                }
+            }
+            // candidates, best first
+            __syncthreads();
+            uint32_t n_cand = 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const uint32_t idx = (uint32_t)e * 64 + (uint32_t)lane;
+                const bool ok = beam.key[e] != 0;
+                if (ok) {
+                    cand_ids[idx] = key_idx(beam.key[e]);
+                    cand_scores[idx] = key_score(beam.key[e]);
+                }
+                n_cand += (uint32_t)__popcll(__ballot(ok));
+            }
+            __syncthreads();
+            // give the visited bitmap back all-zero (fresh VisitedList per level, graph_layers.rs:108-116)
+            if (log_cnt <= h.log_cap) {
+                for (uint32_t i = (uint32_t)lane; i < log_cnt; i += 64) vis[vlog[i]] = 0;
+            } else {
+                for (uint64_t w = (uint64_t)lane; w < h.vis_words; w += 64) vis[w] = 0;
+            }
+            __threadfence();
+            if (n_cand) {                       // next level starts from the nearest candidate (:512-517)
+                cur_id = cand_ids[0];
+                cur_score = cand_scores[0];
+            }
+            const uint32_t lm = h.g.level_m(level);
+            const uint32_t n_sel = heuristic_fill<H>(a, cand_ids, cand_scores, n_cand, lm, sel_ids, sel_scores, hop_ids, hop_scores, lane);
+            const uint64_t so = ((uint64_t)bi * HNSW_BUILD_MAX_LEVELS + level) * h.g.m0;
+            for (uint32_t i = (uint32_t)lane; i < n_sel; i += 64) {
+                h.sel_ids[so + i] = sel_ids[i];
+                h.sel_scores[so + i] = sel_scores[i];
+            }
+            if (lane == 0) my_cnt[level] = n_sel;
+            __syncthreads();
+        }
+    }
+}
+
+// ---- phase 2 ----------------------------------------------------------------------------------------------------
+template <class H>
+__global__ __launch_bounds__(64) void hnsw_build_link_kernel(const ScanArgs a, const HnswBuildArgs h) {
+    __shared__ uint32_t hop_ids[64];
+    __shared__ float hop_scores[64];
+    __shared__ uint32_t cand_ids[80];
+    __shared__ float cand_scores[80];
+    __shared__ uint32_t srt_ids[80];
+    __shared__ float srt_scores[80];
+    __shared__ uint32_t sel_ids[64];
+    __shared__ float sel_scores[64];
+    const int lane = threadIdx.x;
+    const unsigned char *rows = reinterpret_cast<const unsigned char *>(a.rows);
+    for (uint32_t bi = blockIdx.x; bi < h.count; bi += gridDim.x) {
+        const uint32_t p = h.first + bi;
+        const uint32_t lp = h.level[p];
+        const uint32_t *my_cnt = h.sel_cnt + (uint64_t)bi * HNSW_BUILD_MAX_LEVELS;
+        for (uint32_t level = 0; level <= lp && level < HNSW_BUILD_MAX_LEVELS; ++level) {
+            const uint32_t n_sel = my_cnt[level];
+            if (n_sel == 0) continue;
+            const uint64_t so = ((uint64_t)bi * HNSW_BUILD_MAX_LEVELS + level) * h.g.m0;
+            const uint32_t lm = h.g.level_m(level);
+            // p's own list: nobody else touches it during this phase (p was not in the graph in phase 1)
+            uint32_t *mine = h.g.list(p, level);
+            for (uint32_t i = (uint32_t)lane; i < n_sel; i += 64) st_agent(mine + i, h.sel_ids[so + i]);
+            if (lane == 0) st_agent(h.g.count(p, level), n_sel);
+            // back links: LinksContainer::connect_with_heuristic(p, q) under q's lock
+            for (uint32_t k = 0; k < n_sel; ++k) {
+                const uint32_t q = h.sel_ids[so + k];
+                const float s_qp = h.sel_scores[so + k];       // score(p, q) == score(q, p), bit for bit
+                if (lane == 0) {
+                    while (atomicCAS(&h.lock[q], 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(8);
+                }
+                __syncthreads();
+                __threadfence();
+                uint32_t *lst = h.g.list(q, level);
+                uint32_t *cntp = h.g.count(q, level);
+                const uint32_t len = ld_agent(cntp);
+                if (len < lm) {
+                    if (lane == 0) {
+                        st_agent(lst + len, p);
+                        st_agent(cntp, len + 1);
+                    }
+                } else {
+                    // candidates = links(q) + p with their scores to q, sorted descending (total_cmp; equal keys keep
+                    // input order, the new point last), then the heuristic again
+                    const uint32_t n_c = len + 1;               // <= m0 + 1 <= 65
+                    for (uint32_t base = 0; base < len; base += 64) {
+                        const uint32_t kk = len - base < 64 ? len - base : 64;
+                        __syncthreads();
+                        if ((uint32_t)lane < kk) {
+                            const uint32_t id = ld_agent(lst + base + lane);
+                            hop_ids[lane] = id;
+                            cand_ids[base + lane] = id;
+                        }
+                        hop_score<H>(a, rows + (uint64_t)q * a.row_stride, hop_ids, hop_scores, kk, lane);
+                        if ((uint32_t)lane < kk) cand_scores[base + lane] = hop_scores[lane];
+                    }
+                    if (lane == 0) {
+                        cand_ids[len] = p;
+                        cand_scores[len] = s_qp;
+                    }
+                    __syncthreads();
+                    for (uint32_t i = (uint32_t)lane; i < n_c; i += 64) {
+                        const uint32_t oi = score_to_ord(cand_scores[i]);
+                        uint32_t rank = 0;
+                        for (uint32_t j = 0; j < n_c; ++j) {
+                            const uint32_t oj = score_to_ord(cand_scores[j]);
+                            rank += (oj > oi || (oj == oi && j < i)) ? 1u : 0u;
+                        }
+                        srt_ids[rank] = cand_ids[i];
+                        srt_scores[rank] = cand_scores[i];
+                    }
+                    __syncthreads();
+                    const uint32_t n_new = heuristic_fill<H>(a, srt_ids, srt_scores, n_c, lm, sel_ids, sel_scores, hop_ids, hop_scores, lane);
+                    for (uint32_t i = (uint32_t)lane; i < n_new; i += 64) st_agent(lst + i, sel_ids[i]);
+                    if (lane == 0) st_agent(cntp, n_new);
+                }
+                __threadfence();
+                __syncthreads();
+                if (lane == 0) atomicExch(&h.lock[q], 0u);
+            }
+        }
+    }
+}
+
+template <class H>
+int32_t launch_hnsw_build_hop(hipStream_t st, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu) {
+    QMX_REQUIRE(h.ef_construct >= 1 && h.ef_construct <= HNSW_MAX_EF, QMX_ERR_NOT_SUPPORTED, "ef_construct %u not in 1..%u", h.ef_construct,
+                HNSW_MAX_EF);
+    const bool big = h.ef_construct > 128;
+    const size_t lds1 = 512 + 512 * (big ? 8 : 2) + 512 + h.lds_query_bytes;
+    if (phase == 1) {
+        auto k2 = hnsw_build_search_kernel<H, 2>;
+        auto k8 = hnsw_build_search_kernel<H, 8>;
+        if (grid == 0) {
+            int n = 0;
+            if (big) QMX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k8, 64, lds1));
+            else QMX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k2, 64, lds1));
+            *per_cu = n < 1 ? 1 : n;
+            return QMX_OK;
+        }
+        ::qmx::clear_stale_error();
+        if (big) hipLaunchKernelGGL(k8, dim3(grid), dim3(64), lds1, st, a, h);
+        else hipLaunchKernelGGL(k2, dim3(grid), dim3(64), lds1, st, a, h);
+        QMX_HIP(hipGetLastError());
+        return QMX_OK;
+    }
+    if (grid == 0) {
+        int n = 0;
+        QMX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, hnsw_build_link_kernel<H>, 64, 0));
+        *per_cu = n < 1 ? 1 : n;
+        return QMX_OK;
+    }
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL((hnsw_build_link_kernel<H>), dim3(grid), dim3(64), 0, st, a, h);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
+struct HnswBuildLauncher {
+    hipStream_t st;
+    const HnswBuildArgs *h;
+    int phase;
+    uint32_t grid;
+    int *per_cu;
+    template <class P> int32_t row(const ScanArgs &a) const { return launch_hnsw_build_hop<HopRow<P>>(st, a, *h, phase, grid, per_cu); }
+    template <class S> int32_t small(const ScanArgs &a) const { return launch_hnsw_build_hop<HopSmall<S>>(st, a, *h, phase, grid, per_cu); }
+};
+
+}  // namespace qmx

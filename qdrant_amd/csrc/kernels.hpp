@@ -76,6 +76,44 @@ int32_t launch_hnsw_dense(hipStream_t st, int dtype, int distance, const ScanArg
 int32_t launch_hnsw_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_pq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 constexpr uint32_t HNSW_MAX_EF = 512;
+// HNSW build (hnsw_build.hpp)
+constexpr uint32_t HNSW_BUILD_MAX_LEVELS = 16;   // levels 0..15 (P(level >= 16) ~ m^-15.5)
+struct BuildLinks {
+    uint32_t *links0, *cnt0, *linksU, *cntU;
+    const uint32_t *up_off;
+    uint32_t m, m0;
+#if defined(__HIPCC__)
+    __device__ __forceinline__ uint32_t *list(uint32_t p, uint32_t level) const {
+        return level == 0 ? links0 + (uint64_t)p * m0 : linksU + ((uint64_t)up_off[p] + level - 1) * m;
+    }
+    __device__ __forceinline__ uint32_t *count(uint32_t p, uint32_t level) const {
+        return level == 0 ? cnt0 + p : cntU + ((uint64_t)up_off[p] + level - 1);
+    }
+    __device__ __forceinline__ uint32_t level_m(uint32_t level) const { return level == 0 ? m0 : m; }
+#endif
+};
+struct HnswBuildArgs {
+    BuildLinks g;
+    const uint8_t *level;        // [n] level of every point
+    uint32_t n_points;
+    uint32_t first, count;       // the batch: points first .. first + count
+    uint32_t ep_id, ep_level;    // entry point of the graph before the batch
+    uint32_t ef_construct;
+    uint32_t *visited;           // [slots][vis_words]
+    uint64_t vis_words;
+    uint32_t *vis_log;           // [slots][log_cap]
+    uint32_t log_cap;
+    // phase 1 -> phase 2: sel[(bi * HNSW_BUILD_MAX_LEVELS + l) * m0 + k]
+    uint32_t *sel_ids;
+    float *sel_scores;
+    uint32_t *sel_cnt;           // [count][HNSW_BUILD_MAX_LEVELS]
+    uint32_t *lock;              // [n]
+    uint32_t lds_query_bytes;    // row bytes rounded up to whole 128-byte steps, staged per new point
+    uint32_t row_bytes;
+};
+// phase 1 = insertion searches + heuristic selection, phase 2 = linking; grid == 0: report occupancy only
+int32_t launch_hnsw_build_dense(hipStream_t st, int dtype, int distance, const ScanArgs &a, const HnswBuildArgs &h, int phase,
+                                uint32_t grid, int *per_cu);
 constexpr uint32_t HNSW_LDS_QUERY_MAX = 150 * 1024;
 
 // dense f32 / f16 / u8 (scan_dense.hip)

@@ -7,7 +7,7 @@
 //        lib/segment/src/spaces/metric_uint/simple_*.rs      (scalar order, QMX_SEG_U8_SCALAR_ORDER)   bit-exact
 // Compiled with -ffp-contract=off: every fused multiply-add below is an explicit fmaf, every
 // separate mul/add stays separate, as in the Rust/C reference.
-#include "hnsw.hpp"
+#include "hnsw_build.hpp"
 
 namespace qmx {
 
@@ -355,6 +355,10 @@ int32_t launch_pairs_dense(hipStream_t st, int dtype, int distance, const ScanAr
 }
 int32_t launch_hnsw_dense(hipStream_t st, int dtype, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
     return dispatch_dense(HnswLauncher{st, &h, grid, per_cu}, dtype, distance, a);
+}
+int32_t launch_hnsw_build_dense(hipStream_t st, int dtype, int distance, const ScanArgs &a, const HnswBuildArgs &h, int phase,
+                                uint32_t grid, int *per_cu) {
+    return dispatch_dense(HnswBuildLauncher{st, &h, phase, grid, per_cu}, dtype, distance, a);
 }
 
 }  // namespace qmx

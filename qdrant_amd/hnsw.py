@@ -71,6 +71,43 @@ class GraphLayers:
         self.counters = F.Counters()
         return self
 
+    @classmethod
+    def build(cls, storage, m: int = 16, m0: Optional[int] = None, ef_construct: int = 100, seed: int = 42,
+              entry_points_num: int = 10, max_batch: int = 0):
+        """`GraphLayersBuilder` over a dense f32 / f16 VectorStorage, on its GPU (qmx_hnsw_build)."""
+        self = cls.__new__(cls)
+        self.m, self.m0 = int(m), int(2 * m if m0 is None else m0)
+        p = F.HnswBuildParams()
+        p.m, p.m0, p.ef_construct, p.entry_points_num, p.seed, p.max_batch = self.m, self.m0, ef_construct, entry_points_num, seed, max_batch
+        self._keep = []
+        self._h = C.c_void_p()
+        F.check(F.lib().qmx_hnsw_build(storage._h, C.byref(p), C.byref(self._h)))
+        self.n_points = storage.count
+        self.counters = F.Counters()
+        return self
+
+    def export_plain(self):
+        """The plain GraphLinks arrays + entry points of a graph built on the device (an object with the fields
+        `from_plain` takes)."""
+        info = F.HnswInfo()
+        F.check(F.lib().qmx_hnsw_get_info(self._h, C.byref(info)))
+
+        class Plain:
+            pass
+        o = Plain()
+        o.m, o.m0 = info.m, info.m0
+        o.reindex = np.zeros(info.n_points, dtype=np.uint32)
+        o.level_offsets = np.zeros(info.n_levels + 1, dtype=np.uint64)
+        o.offsets = np.zeros(info.n_offsets, dtype=np.uint64)
+        o.neighbors = np.zeros(max(info.n_neighbors, 1), dtype=np.uint32)
+        o.ep_ids, o.ep_levels = np.zeros(info.n_entry_points, dtype=np.uint32), np.zeros(info.n_entry_points, dtype=np.uint32)
+        o.xp_ids = np.zeros(info.n_extra_entry_points, dtype=np.uint32)
+        o.xp_levels = np.zeros(info.n_extra_entry_points, dtype=np.uint32)
+        F.check(F.lib().qmx_hnsw_export_plain(self._h, F.ptr(o.reindex), F.ptr(o.level_offsets), F.ptr(o.offsets), F.ptr(o.neighbors),
+                                              F.ptr(o.ep_ids), F.ptr(o.ep_levels), F.ptr(o.xp_ids), F.ptr(o.xp_levels)))
+        o.neighbors = o.neighbors[:info.n_neighbors]
+        return o
+
     def search(self, top: int, ef: int, points_scorer: RawScorer, is_stopped=None, with_scored: bool = False):
         """`GraphLayers::search(top, ef, Hnsw, points_scorer, None, is_stopped)` for every query of the
         scorer batch -> list of ScoredPointOffset arrays (descending score, at most `top`)."""

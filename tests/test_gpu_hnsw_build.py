@@ -1,0 +1,127 @@
+"""Device HNSW build (`qmx_hnsw_build`, hnsw_build.hpp) against the CPU oracle's GraphLayersBuilder restatement.
+
+A concurrently built graph is not link-for-link the sequential one (the reference's own rayon / Vulkan builders are not
+either), so the bars are the reference's own for its builders (graph_layers_builder.rs tests, hnsw/tests): structural
+invariants, the same level draw, and search quality equal to the sequential CPU build within noise."""
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def qa():
+    import qdrant_amd
+    assert qdrant_amd.device_count() >= 1
+    return qdrant_amd
+
+
+def _dist(qa, d):
+    return {O.COSINE: qa.Distance.Cosine, O.DOT: qa.Distance.Dot, O.EUCLID: qa.Distance.Euclid,
+            O.MANHATTAN: qa.Distance.Manhattan}[d]
+
+
+def _clustered(n, dim, seed, k=64):
+    """Low intrinsic dimension (mixture of gaussians): HNSW recall is meaningful here, unlike on iid noise in d >> 10."""
+    rng = np.random.default_rng(seed)
+    centers = rng.standard_normal((k, dim)).astype(np.float32) * 2.0
+    return (centers[rng.integers(0, k, n)] + rng.standard_normal((n, dim)).astype(np.float32) * 0.6).astype(np.float32)
+
+
+def _recall(got, want):
+    return sum(len(set(g["idx"].tolist()) & set(w["idx"].tolist())) for g, w in zip(got, want)) / float(sum(len(w) for w in want))
+
+
+def _levels_of(plain, n):
+    lv = np.zeros(n, dtype=np.int64)
+    L = len(plain.level_offsets) - 1
+    order = np.argsort(plain.reindex)
+    for l in range(1, L):
+        cnt = int(plain.level_offsets[l + 1] - plain.level_offsets[l])
+        lv[order[:cnt]] = l
+    return lv
+
+
+@pytest.mark.parametrize("distance,dim", [(O.COSINE, 48), (O.EUCLID, 100), (O.DOT, 24)])
+def test_build_invariants_levels_and_recall(qa, distance, dim):
+    n, m, efc, seed = 6000, 8, 64, 7
+    rows = O.preprocess(distance, _clustered(n, dim, seed))
+    st = O.DenseStorage(O.F32, distance, rows)
+    cpu = O.Hnsw(st, m=m, ef_construct=efc, seed=seed)
+    vs = qa.VectorStorage(rows, _dist(qa, distance))
+    gpu = qa.GraphLayers.build(vs, m=m, ef_construct=efc, seed=seed)
+    p = gpu.export_plain()
+    # same level draw as the oracle (graph_layers_builder.rs:388-396)
+    lv = _levels_of(p, n)
+    assert lv.tolist() == [cpu.point_level(i) for i in range(n)]
+    assert int(p.level_offsets[1]) == n and sorted(p.reindex.tolist()) == list(range(n))
+    # structural invariants
+    L = len(p.level_offsets) - 1
+    order = np.argsort(p.reindex)
+    empty0 = 0
+    for l in range(L):
+        cnt = int(p.level_offsets[l + 1] - p.level_offsets[l])
+        for j in range(0, cnt, 7 if l == 0 else 1):
+            pid = j if l == 0 else int(order[j])
+            slot = int(p.level_offsets[l]) + j
+            ln = p.neighbors[int(p.offsets[slot]):int(p.offsets[slot + 1])]
+            assert len(ln) <= (2 * m if l == 0 else m)
+            assert len(set(ln.tolist())) == len(ln) and pid not in ln
+            assert np.all(lv[ln] >= l)
+            empty0 += int(l == 0 and len(ln) == 0)
+    assert empty0 == 0
+    ep_l = int(p.ep_levels[0])
+    assert ep_l == lv.max() and lv[int(p.ep_ids[0])] == ep_l
+    # search quality: device-built graph vs the sequential CPU build, same ef, both searched on the device
+    queries = O.preprocess(distance, _clustered(200, dim, seed + 1)) if distance == O.COSINE else _clustered(200, dim, seed + 1)
+    scorer = qa.new_raw_scorer(queries, vs)
+    exact = st.peek_top(queries, 10)
+    r_gpu = _recall(gpu.search(10, 64, scorer), exact)
+    r_cpu = _recall(qa.GraphLayers.from_plain(cpu.export_plain()).search(10, 64, scorer), exact)
+    assert r_cpu > 0.6 and r_gpu > r_cpu - 0.03, (r_gpu, r_cpu)
+    # the exported arrays round-trip through qmx_hnsw_create and the oracle-side plain file writer
+    again = qa.GraphLayers.from_plain(p)
+    a, b = gpu.search(10, 64, scorer), again.search(10, 64, scorer)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+def test_build_skips_deleted_points_and_handles_tiny_inputs(qa):
+    dim = 32
+    rows = O.preprocess(O.COSINE, _clustered(3000, dim, 3))
+    deleted = np.zeros(3000, dtype=bool)
+    deleted[::5] = True
+    deleted[0] = True
+    vs = qa.VectorStorage(rows, qa.Distance.Cosine)
+    vs.set_deleted(deleted, None)
+    g = qa.GraphLayers.build(vs, m=8, ef_construct=48, seed=1)
+    p = g.export_plain()
+    for i in range(0, 3000, 5):                       # deleted points: no links in or out
+        assert int(p.offsets[i + 1]) == int(p.offsets[i])
+    assert not deleted[p.neighbors].any() and not deleted[p.ep_ids].any()
+    queries = O.preprocess(O.COSINE, _clustered(50, dim, 4))
+    st = O.DenseStorage(O.F32, O.COSINE, rows, point_deleted=deleted)
+    scorer = qa.new_raw_scorer(queries, vs)
+    assert _recall(g.search(10, 128, scorer), st.peek_top(queries, 10)) > 0.7
+    for n in (1, 2, 5):                              # tiny graphs
+        small = qa.VectorStorage(rows[:n], qa.Distance.Cosine)
+        gs = qa.GraphLayers.build(small, m=4, ef_construct=8, seed=2)
+        res = gs.search(3, 8, qa.new_raw_scorer(queries[:4], small))
+        assert all(len(r) == min(3, n) for r in res)
+    with pytest.raises(qa.QmxError):                 # quantized / u8 storages are built from their originals
+        quant = qa.ScalarQuantizer.from_min_max(rows, dim, qa.Distance.Dot)
+        qa.GraphLayers.build(qa.EncodedVectorsU8(quant.encode(rows), quant))
+
+
+def test_f16_build_and_large_batches(qa):
+    n, dim = 20000, 64
+    rows = O.preprocess(O.COSINE, _clustered(n, dim, 11))
+    stored = O.to_f16(rows)
+    vs = qa.VectorStorage(stored.view(np.float16), qa.Distance.Cosine, qa.VectorStorageDatatype.Float16)
+    g = qa.GraphLayers.build(vs, m=16, ef_construct=100, seed=5, max_batch=4096)
+    queries = _clustered(100, dim, 12)
+    scorer = qa.new_raw_scorer(queries, vs)
+    exact = O.DenseStorage(O.F16, O.COSINE, stored).peek_top(queries, 10)
+    assert _recall(g.search(10, 256, scorer), exact) > 0.8
