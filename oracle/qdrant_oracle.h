@@ -176,6 +176,10 @@ uint32_t qo_hnsw_links(const qo_hnsw *g, uint32_t id, uint32_t level, uint32_t *
 /* primary entry points (EntryPoints.entry_points): ids / levels, returns count (call with NULLs to size) */
 uint32_t qo_hnsw_entry_points(const qo_hnsw *g, uint32_t *ids, uint32_t *levels, uint32_t cap);
 uint32_t qo_hnsw_extra_entry_points(const qo_hnsw *g, uint32_t *ids, uint32_t *levels, uint32_t cap);
+qo_hnsw *qo_hnsw_import_plain(uint32_t n, uint32_t m, uint32_t m0, uint32_t n_levels, const uint32_t *reindex,
+                              const uint64_t *level_offsets, const uint64_t *offsets, const uint32_t *neighbors,
+                              const uint32_t *ep_ids, const uint32_t *ep_levels, uint32_t n_ep,
+                              const uint32_t *xp_ids, const uint32_t *xp_levels, uint32_t n_xp);   /* GraphLayers::load, plain links */
 /* the plain GraphLinks view (graph_links/view.rs:42-60,211-218 ; serializer.rs:52-87):
  *   reindex[n]            point -> rank in descending-level order
  *   level_offsets[L + 1]  index into `offsets` where each level starts (level 0 at 0, n entries), last = total

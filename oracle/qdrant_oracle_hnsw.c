@@ -631,6 +631,51 @@ void qo_hnsw_export_plain(const qo_hnsw *g, uint32_t *n_levels, uint64_t *n_offs
     free(count_ge);
 }
 
+/* ---- GraphLayers::load from the plain GraphLinks arrays (graph_links/view.rs) -------------------------------------
+ * Lets the oracle WALK a graph it did not build (e.g. one built on the device) for parity checks of the search. */
+qo_hnsw *qo_hnsw_import_plain(uint32_t n, uint32_t m, uint32_t m0, uint32_t n_levels, const uint32_t *reindex,
+                              const uint64_t *level_offsets, const uint64_t *offsets, const uint32_t *neighbors,
+                              const uint32_t *ep_ids, const uint32_t *ep_levels, uint32_t n_ep,
+                              const uint32_t *xp_ids, const uint32_t *xp_levels, uint32_t n_xp) {
+    qo_hnsw *g = (qo_hnsw *)calloc(1, sizeof(*g));
+    g->n = n; g->m = m; g->m0 = m0; g->entry_points_num = n_xp; g->use_heuristic = 1;
+    g->level = (uint32_t *)calloc(n ? n : 1, sizeof(uint32_t));
+    g->links = (uint32_t **)calloc(n ? n : 1, sizeof(uint32_t *));
+    g->lens = (uint16_t **)calloc(n ? n : 1, sizeof(uint16_t *));
+    g->ready = (_Atomic uint8_t *)calloc(n ? n : 1, 1);
+    pthread_mutex_init(&g->ep_lock, NULL);
+    uint32_t maxl = 0;
+    for (uint32_t i = 0; i < n; i++) {       /* level(p) = highest l whose slot range still holds reindex[p] */
+        uint32_t lv = 0;
+        for (uint32_t l = 1; l < n_levels; l++) if ((uint64_t)reindex[i] < level_offsets[l + 1] - level_offsets[l]) lv = l;
+        g->level[i] = lv;
+        if (lv > maxl) maxl = lv;
+        g->links[i] = (uint32_t *)malloc(sizeof(uint32_t) * (m0 + (size_t)lv * m + 1));
+        g->lens[i] = (uint16_t *)calloc(lv + 1, sizeof(uint16_t));
+        for (uint32_t l = 0; l <= lv; l++) {
+            const uint64_t slot = l == 0 ? i : level_offsets[l] + reindex[i];
+            const uint64_t len = offsets[slot + 1] - offsets[slot];
+            const uint32_t cap = level_m(g, l);
+            g->lens[i][l] = (uint16_t)(len < cap ? len : cap);
+            memcpy(links_ptr(g, i, l), neighbors + offsets[slot], sizeof(uint32_t) * g->lens[i][l]);
+        }
+        atomic_store(&g->ready[i], 1);
+    }
+    atomic_store(&g->max_level, maxl);
+    g->ep_cap = n_ep ? n_ep : 1;
+    g->ep_ids = (uint32_t *)malloc(sizeof(uint32_t) * g->ep_cap);
+    g->ep_levels = (uint32_t *)malloc(sizeof(uint32_t) * g->ep_cap);
+    memcpy(g->ep_ids, ep_ids, sizeof(uint32_t) * n_ep);
+    memcpy(g->ep_levels, ep_levels, sizeof(uint32_t) * n_ep);
+    g->ep_len = n_ep;
+    g->xp_ids = (uint32_t *)calloc(n_xp ? n_xp : 1, sizeof(uint32_t));
+    g->xp_levels = (uint32_t *)calloc(n_xp ? n_xp : 1, sizeof(uint32_t));
+    memcpy(g->xp_ids, xp_ids, sizeof(uint32_t) * n_xp);
+    memcpy(g->xp_levels, xp_levels, sizeof(uint32_t) * n_xp);
+    g->xp_len = n_xp;
+    return g;
+}
+
 /* ---- GraphLayers::search (graph_layers.rs:530-562) ------------------------------------------------ */
 uint32_t qo_hnsw_search(const qo_hnsw *g, const qo_scorer *scorer, uint32_t top, uint32_t ef, qo_scored_point *out,
                         uint64_t *n_scored) {

@@ -337,6 +337,7 @@ _sig("qo_hnsw_max_level", C.c_uint32, [_P])
 _sig("qo_hnsw_links", C.c_uint32, [_P, C.c_uint32, C.c_uint32, _P])
 _sig("qo_hnsw_entry_points", C.c_uint32, [_P, _P, _P, C.c_uint32])
 _sig("qo_hnsw_extra_entry_points", C.c_uint32, [_P, _P, _P, C.c_uint32])
+_sig("qo_hnsw_import_plain", _P, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P, C.c_uint32, _P, _P, C.c_uint32])
 _sig("qo_hnsw_export_plain", None, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _P, _P, _P, _P])
 _sig("qo_hnsw_search", C.c_uint32, [_P, C.POINTER(Scorer), C.c_uint32, C.c_uint32, _P, C.POINTER(C.c_uint64)])
 _sig("qo_links_heuristic", C.c_uint32, [_P, C.c_uint32, C.c_uint32, _P, C.c_uint32, _P])
@@ -394,6 +395,20 @@ class Hnsw:
             self.h = _lib.qo_hnsw_build(C.byref(storage.st), self.m, self.m0, ef_construct, entry_points_num,
                                         1 if use_heuristic else 0, seed)
         self.n = storage.rows.shape[0]
+
+    @classmethod
+    def from_plain(cls, p, n):
+        """GraphLayers::load of plain GraphLinks arrays: the oracle walks a graph it did not build."""
+        self = cls.__new__(cls)
+        self.storage, self.m, self.m0, self.n = None, p.m, p.m0, n
+        arrs = [np.ascontiguousarray(p.reindex, dtype=np.uint32), np.ascontiguousarray(p.level_offsets, dtype=np.uint64),
+                np.ascontiguousarray(p.offsets, dtype=np.uint64), np.ascontiguousarray(p.neighbors, dtype=np.uint32),
+                np.ascontiguousarray(p.ep_ids, dtype=np.uint32), np.ascontiguousarray(p.ep_levels, dtype=np.uint32),
+                np.ascontiguousarray(p.xp_ids, dtype=np.uint32), np.ascontiguousarray(p.xp_levels, dtype=np.uint32)]
+        self.h = _lib.qo_hnsw_import_plain(n, p.m, p.m0, len(arrs[1]) - 1, _p(arrs[0]), _p(arrs[1]), _p(arrs[2]),
+                                           _p(arrs[3]) if len(arrs[3]) else None, _p(arrs[4]), _p(arrs[5]), len(arrs[4]),
+                                           _p(arrs[6]) if len(arrs[6]) else None, _p(arrs[7]) if len(arrs[7]) else None, len(arrs[6]))
+        return self
 
     def __del__(self):
         try:

@@ -81,6 +81,15 @@ def test_build_invariants_levels_and_recall(qa, distance, dim):
     r_gpu = _recall(gpu.search(10, 64, scorer), exact)
     r_cpu = _recall(qa.GraphLayers.from_plain(cpu.export_plain()).search(10, 64, scorer), exact)
     assert r_cpu > 0.6 and r_gpu > r_cpu - 0.03, (r_gpu, r_cpu)
+    # the CPU oracle walks the DEVICE-built graph exactly like the device does (ids, score bits, scored points)
+    walk = O.Hnsw.from_plain(p, n)
+    want, stats = walk.search_dense(st, queries[:60], 10, 64, with_stats=True)
+    scorer60 = qa.new_raw_scorer(queries[:60], vs)
+    got, scored = gpu.search(10, 64, scorer60, with_scored=True)
+    for gq, wq in zip(got, want):
+        assert gq["idx"].tolist() == wq["idx"].tolist()
+        assert np.array_equal(gq["score"].view(np.uint32), wq["score"].view(np.uint32))
+    assert scored == sum(stats)
     # the exported arrays round-trip through qmx_hnsw_create and the oracle-side plain file writer
     again = qa.GraphLayers.from_plain(p)
     a, b = gpu.search(10, 64, scorer), again.search(10, 64, scorer)

@@ -173,3 +173,21 @@ def test_merge_matches_a_single_queue():
     dup[1, 0] = [(5, 9.0), (8, 2.5), (9, 0.5)]
     r = O.merge_topk(dup, None, 3)[0]
     assert r["idx"].tolist() == [5, 8, 6] and r["score"].tolist() == [3.0, 2.5, 2.0]
+
+
+def test_import_of_exported_plain_links_walks_identically():
+    """qo_hnsw_import_plain (GraphLayers::load of the plain arrays) == the graph it came from, for the search."""
+    n, dim = 1500, 24
+    st = O.DenseStorage(O.F32, O.EUCLID, _data(n, dim, 31, O.EUCLID))
+    g = O.Hnsw(st, m=8, ef_construct=48, seed=9)
+    g2 = O.Hnsw.from_plain(g.export_plain(), n)
+    assert [g2.point_level(i) for i in range(n)] == [g.point_level(i) for i in range(n)]
+    for i in range(0, n, 17):
+        for lv in range(g.point_level(i) + 1):
+            assert g2.links(i, lv).tolist() == g.links(i, lv).tolist()
+    queries = O.synth(32, 0, 12, dim)
+    a, sa = g.search_dense(st, queries, 10, 64, with_stats=True)
+    b, sb = g2.search_dense(st, queries, 10, 64, with_stats=True)
+    assert sa == sb
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)

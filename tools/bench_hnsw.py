@@ -1,17 +1,15 @@
 #!/usr/bin/env python3
-"""HNSW search on the device vs the CPU oracle's restatement of GraphLayers::search, on one graph.
+"""HNSW build + search on the device (C3 / C4 style path of BASELINE.json), one JSON line per scorer.
 
-Not the round's headline bench (bench.py = C2 brute force): this measures the C3 / C4 style path of
-BASELINE.json at a size whose graph the CPU oracle can build in a minute or two on the GPU box's host
-cores (the 10 M-point graphs of C3 / C4 need a device-side builder).
-
-  rows: N x dim f32, N(0,1) synthetic, cosine-normalised; graph: oracle HNSW (m, ef_construct), parallel build
-  scorer: f32 | sq (EncodedVectorsU8, dot) | pq (EncodedVectorsPQ chunk 16, dot)
-  device: qmx_hnsw_search of `nq` queries in one launch (one wavefront per search)
-  checks: first `--check` queries against the oracle's walk (ids + score bits), recall@10 vs exact search
-  cpu:    oracle search, single thread, `--cpu-queries` queries (the reference runs one search per thread)
-
-Prints one JSON line.  Usage: python tools/bench_hnsw.py --rows 1000000 --dim 768 --scorer sq
+  rows   : N x dim f32 generated ON THE DEVICE: `--data clustered` (mixture of 4096 gaussians around unit-norm centres,
+           per-coordinate sigma 0.35 / sqrt(dim): low intrinsic dimension, recall is meaningful) or `--data iid` (N(0,1)
+           per coordinate as hnsw_quantized_search_test.rs:66-78: in d = 768 nearest neighbours are nearly equidistant,
+           recall collapses for the CPU reference and the device alike); cosine-normalised
+  graph  : `--build gpu` qmx_hnsw_build (device, batch-parallel) or `--build cpu` the oracle's parallel builder
+  scorer : f32 | sq (EncodedVectorsU8, dot over normalised rows) | pq (EncodedVectorsPQ chunk 16)
+  search : qmx_hnsw_search of `--nq` queries in one launch (+ qmx_rescore with the f32 rows for sq / pq, oversampling 2)
+  checks : first `--check` searches against the CPU oracle walking THE SAME graph (ids + score bits), recall@10 against
+           exact brute force (device), CPU baseline = oracle search, one thread, on the same graph (rows <= --cpu-max-rows)
 """
 import argparse
 import ctypes as C
@@ -29,7 +27,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=768)
-    ap.add_argument("--scorer", default="sq", help="f32 | sq | pq, or a comma list: one graph, one JSON line per scorer")
+    ap.add_argument("--scorer", default="sq", help="comma list of f32 | sq | pq")
+    ap.add_argument("--build", choices=["gpu", "cpu"], default="gpu")
+    ap.add_argument("--data", choices=["clustered", "iid"], default="clustered")
     ap.add_argument("--m", type=int, default=16)
     ap.add_argument("--ef-construct", type=int, default=100)
     ap.add_argument("--ef", type=int, default=128)
@@ -38,100 +38,159 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--check", type=int, default=64)
     ap.add_argument("--cpu-queries", type=int, default=256)
+    ap.add_argument("--cpu-max-rows", type=int, default=2_000_000, help="above this the oracle (host copy of the rows) is skipped")
+    ap.add_argument("--max-batch", type=int, default=0)
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 8)
     args = ap.parse_args()
 
     import numpy as np
-    import torch  # noqa: F401  (HIP runtime load order, see tests/conftest.py)
+    import torch
     import qdrant_amd as qa
     from qdrant_amd import _ffi as F
     import oracle_ffi as O   # the checker and the CPU baseline
 
-    n, dim, nq = args.rows, args.dim, args.nq
-    t0 = time.time()
-    rows = O.preprocess(O.COSINE, O.synth(0x5EED0003, 0, n, dim))
-    queries = O.synth(0x5EED0004, 0, nq, dim)
-    qpre = O.preprocess(O.COSINE, queries)
-    st = O.DenseStorage(O.F32, O.COSINE, rows)
-    t_data = time.time() - t0
-    t0 = time.time()
-    g = O.Hnsw(st, m=args.m, ef_construct=args.ef_construct, seed=42, threads=args.threads)
-    t_build = time.time() - t0
-    plain = g.export_plain()
+    lib = F.lib()
+    dev = torch.device("cuda", 0)
+    n, dim, nq, top = args.rows, args.dim, args.nq, args.top
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0x5EED0003)
 
-    def run_one(which):
-        vs = vs_f32
-        # ---- device side ----
+    def make(count, centres):
+        out = torch.empty((count, dim), dtype=torch.float32, device=dev)
+        for s in range(0, count, 1 << 20):
+            e = min(count, s + (1 << 20))
+            x = torch.randn((e - s, dim), generator=gen, device=dev, dtype=torch.float32)
+            if centres is not None:
+                idx = torch.randint(0, centres.shape[0], (e - s,), generator=gen, device=dev)
+                x = centres[idx] + x * (0.35 / dim ** 0.5)
+            out[s:e] = x
+        F.check(lib.qmx_preprocess_f32(0, int(qa.Distance.Cosine), F.ptr(out), count, dim, F.ptr(out)))
+        torch.cuda.synchronize()
+        return out
+
+    t0 = time.time()
+    centres = None
+    if args.data == "clustered":
+        centres = torch.randn((4096, dim), generator=gen, device=dev, dtype=torch.float32)
+        centres = centres / centres.norm(dim=1, keepdim=True)
+    rows = make(n, centres)
+    queries_d = make(nq, centres)
+    queries = queries_d.cpu().numpy()
+    t_data = time.time() - t0
+    with_oracle = n <= args.cpu_max_rows
+    host_rows = rows.cpu().numpy() if with_oracle else None
+    st = O.DenseStorage(O.F32, O.COSINE, host_rows) if with_oracle else None
+
+    vs = qa.VectorStorage(rows, qa.Distance.Cosine)        # adopts the device block
+    t0 = time.time()
+    if args.build == "gpu":
+        graph = qa.GraphLayers.build(vs, m=args.m, ef_construct=args.ef_construct, seed=42, max_batch=args.max_batch)
+        t_build = time.time() - t0
+        plain = graph.export_plain()
+        walker = O.Hnsw.from_plain(plain, n) if with_oracle else None
+    else:
+        assert with_oracle, "--build cpu needs the rows on the host"
+        walker = O.Hnsw(st, m=args.m, ef_construct=args.ef_construct, seed=42, threads=args.threads)
+        t_build = time.time() - t0
+        plain = walker.export_plain()
+        graph = qa.GraphLayers.from_plain(plain)
+    n_links0 = int(plain.offsets[n]) if n else 0
+
+    exact_n = min(256, nq)
+    exact = qa.BatchFilteredSearcher(queries[:exact_n], vs, top).peek_top_all()
+    raw_scorer = qa.new_raw_scorer(queries, vs)
+
+    def recall(res):
+        return sum(len(set(a["idx"].tolist()) & set(b["idx"].tolist())) for a, b in zip(res[:exact_n], exact)) / float(exact_n * top)
+
+    for which in args.scorer.split(","):
         oracle_search = None
+        oversample = 1
         if which == "f32":
-            enc, row_bytes = vs, dim * 4
-            oracle_search = lambda qs: g.search_dense(st, qs, args.top, args.ef)                      # noqa: E731
-            dev_queries = queries
+            row_bytes, scorer = dim * 4, raw_scorer
+            if with_oracle:
+                oracle_search = lambda qs: walker.search_dense(st, qs, args.top, args.ef)                       # noqa: E731
         elif which == "sq":
-            quant = qa.ScalarQuantizer.from_min_max(rows, dim, qa.Distance.Dot)
-            codes = quant.encode(rows)
-            enc, row_bytes = qa.EncodedVectorsU8(codes, quant), codes.shape[1]
-            osq = O.SqOracle(O.DOT, dim, quant.alpha, quant.offset)
-            osq.rows = codes
-            oracle_search = lambda qs: g.search_sq(st, osq, O.preprocess(O.COSINE, qs), args.top, args.ef)   # noqa: E731
-            dev_queries = qpre            # the quantized storage is a Dot storage over normalised vectors
+            mn, mx = float(rows.min().item()), float(rows.max().item())
+            quant = qa.ScalarQuantizer(dim, qa.Distance.Dot, (np.float32(mx) - np.float32(mn)) / np.float32(127.0), np.float32(mn))
+            p = quant.params()
+            codes_d = torch.empty((n, quant.quantized_vector_size()), dtype=torch.uint8, device=dev)
+            F.check(lib.qmx_sq_encode(0, int(qa.Distance.Dot), C.byref(p), F.ptr(rows), n, dim, F.ptr(codes_d)))
+            enc = qa.EncodedVectorsU8.__new__(qa.EncodedVectorsU8)
+            enc.quantizer, enc.distance, enc.datatype, enc.dim, enc.count, enc._keep, enc._sq = quant, quant.distance, None, dim, n, None, p
+            d = F.SegmentDesc()
+            d.dtype, d.distance, d.dim, d.n, d.data, d.device_id, d.sq = F.DTYPE_SQ_U8, int(qa.Distance.Dot), dim, n, F.ptr(codes_d).value, 0, C.pointer(p)
+            enc._h = C.c_void_p()
+            F.check(lib.qmx_segment_create(C.byref(d), C.byref(enc._h)))
+            row_bytes, oversample = quant.quantized_vector_size(), 2
+            if with_oracle:
+                osq = O.SqOracle(O.DOT, dim, quant.alpha, quant.offset)
+                osq.rows = codes_d.cpu().numpy()
+                oracle_search = lambda qs: walker.search_sq(st, osq, qs, args.top * 2, args.ef)                 # noqa: E731
+            del codes_d
+            scorer = qa.new_raw_scorer(queries, enc)
         else:
             chunk = 16
-            cen = O.PqOracle.train(rows[:20000], dim, chunk, 256, iters=5)
+            sample = rows[:20000].cpu().numpy()
+            cen = O.PqOracle.train(sample, dim, chunk, 256, iters=5)
             quant = qa.ProductQuantizer(dim, qa.Distance.Dot, chunk, cen)
-            codes = quant.encode(rows)
-            enc, row_bytes = qa.EncodedVectorsPQ(codes, quant), codes.shape[1]
-            opq = O.PqOracle(O.DOT, dim, chunk, cen)
-            opq.codes = codes
-            oracle_search = lambda qs: g.search_pq(st, opq, O.preprocess(O.COSINE, qs), args.top, args.ef)   # noqa: E731
-            dev_queries = qpre
-        graph = qa.GraphLayers.from_plain(plain)
-        scorer = qa.new_raw_scorer(dev_queries, enc)
-        lib = F.lib()
+            p = quant.params()
+            codes_d = torch.empty((n, quant.m), dtype=torch.uint8, device=dev)
+            F.check(lib.qmx_pq_encode(0, C.byref(p), F.ptr(rows), n, dim, F.ptr(codes_d)))
+            host_codes = codes_d.cpu().numpy()
+            del codes_d
+            enc = qa.EncodedVectorsPQ(host_codes, quant)
+            row_bytes, oversample = quant.m, 2
+            if with_oracle:
+                opq = O.PqOracle(O.DOT, dim, chunk, cen)
+                opq.codes = host_codes
+                oracle_search = lambda qs: walker.search_pq(st, opq, qs, args.top * 2, args.ef)                 # noqa: E731
+            scorer = qa.new_raw_scorer(queries, enc)
+        stop = args.top * oversample
         F.check(lib.qmx_query_set_timing(scorer._h, 1))
-        got = graph.search(args.top, args.ef, scorer)       # warm-up (allocates the visited bitmaps)
+        got = graph.search(stop, args.ef, scorer)           # warm-up (allocates the visited bitmaps)
         ms, nl = C.c_float(), C.c_uint32()
         F.check(lib.qmx_query_timing(scorer._h, C.byref(ms), C.byref(nl)))
         wall, scored = [], 0
         for _ in range(args.reps):
             t0 = time.time()
-            got, scored = graph.search(args.top, args.ef, scorer, with_scored=True)
+            got, scored = graph.search(stop, args.ef, scorer, with_scored=True)
             wall.append(time.time() - t0)
         F.check(lib.qmx_query_timing(scorer._h, C.byref(ms), C.byref(nl)))
         kernel_ms = ms.value / max(nl.value, 1)
-
-        # ---- parity with the oracle's walk, recall vs exact ----
-        want = oracle_search(queries[:args.check])
-        same_ids = sum(int(a["idx"].tolist() == b["idx"].tolist()) for a, b in zip(got, want))
-        same_scores = sum(int(np.array_equal(a["score"].view(np.uint32), b["score"].view(np.uint32))) for a, b in zip(got, want))
-        exact = qa.BatchFilteredSearcher(queries[:256], vs, args.top).peek_top_all()
-        recall = sum(len(set(a["idx"].tolist()) & set(b["idx"].tolist())) for a, b in zip(got[:256], exact)) / (256.0 * args.top)
-
-        # ---- CPU baseline: the oracle's search, one thread ----
-        t0 = time.time()
-        cpu_res = oracle_search(queries[:args.cpu_queries])
-        t_cpu = time.time() - t0
-        cpu_recall = sum(len(set(a["idx"].tolist()) & set(b["idx"].tolist())) for a, b in zip(cpu_res[:256], exact)) / (
-            min(256, args.cpu_queries) * float(args.top))
-
+        final = got
+        t_rescore = 0.0
+        if oversample > 1:                                   # postprocess_search_result: rescore with the original vectors
+            ids = np.zeros((nq, stop), dtype=np.uint32)
+            cnt = np.zeros(nq, dtype=np.uint32)
+            for i, r in enumerate(got):
+                ids[i, :len(r)] = r["idx"]
+                cnt[i] = len(r)
+            t0 = time.time()
+            final = raw_scorer.rescore(ids, top, cnt)
+            t_rescore = time.time() - t0
         out = {
-            "metric": "HNSW search QPS (device-resident walk)", "scorer": which, "rows": n, "dim": dim, "m": args.m,
-            "ef_construct": args.ef_construct, "ef": args.ef, "top": args.top, "nq": nq,
+            "metric": "HNSW search QPS (device-resident walk)", "scorer": which, "data": args.data, "build": args.build,
+            "rows": n, "dim": dim, "m": args.m, "ef_construct": args.ef_construct, "ef": args.ef, "top": top, "oversampling": oversample, "nq": nq,
+            "build_s": round(t_build, 2), "build_points_per_s": round(n / max(t_build, 1e-9), 1), "links_level0": n_links0,
             "qps_kernel": round(nq / (kernel_ms * 1e-3), 1), "kernel_ms": round(kernel_ms, 3),
-            "qps_wall_incl_copies": round(nq / min(wall), 1),
+            "qps_wall_incl_copies": round(nq / min(wall), 1), "rescore_wall_s": round(t_rescore, 4),
             "points_scored_per_query": round(scored / nq, 1),
             "gather_GBps": round(scored * row_bytes / (kernel_ms * 1e-3) / 1e9, 1), "row_bytes": int(row_bytes),
-            "recall_at_10": round(recall, 4), "cpu_recall_at_10": round(cpu_recall, 4),
-            "oracle_walk_same_ids": f"{same_ids}/{len(want)}", "oracle_walk_same_score_bits": f"{same_scores}/{len(want)}",
-            "cpu_baseline": {"qps_one_thread": round(args.cpu_queries / t_cpu, 1), "kind": "port", "cores": 1,
-                             "host_cores": os.cpu_count()},
-            "build_s": round(t_build, 1), "data_s": round(t_data, 1), "build_threads": args.threads,
+            "recall_at_10": round(recall(final), 4), "data_s": round(t_data, 1),
         }
+        if oracle_search is not None:
+            want = oracle_search(queries[:args.check])      # rows and queries are already normalised: Cosine == Dot here
+            out["oracle_walk_same_ids"] = "%d/%d" % (sum(int(a["idx"].tolist() == b["idx"].tolist()) for a, b in zip(got, want)), len(want))
+            out["oracle_walk_same_score_bits"] = "%d/%d" % (
+                sum(int(np.array_equal(a["score"].view(np.uint32), b["score"].view(np.uint32))) for a, b in zip(got, want)), len(want))
+            t0 = time.time()
+            cpu_res = oracle_search(queries[:args.cpu_queries])
+            t_cpu = time.time() - t0
+            out["cpu_baseline"] = {"qps_one_thread": round(args.cpu_queries / t_cpu, 1), "kind": "port", "cores": 1, "host_cores": os.cpu_count()}
+            if oversample == 1:
+                out["cpu_recall_at_10"] = round(recall(cpu_res), 4)
         print(json.dumps(out), flush=True)
-
-    vs_f32 = qa.VectorStorage(rows, qa.Distance.Cosine)
-    for which in args.scorer.split(","):
-        run_one(which)
 
 
 if __name__ == "__main__":
