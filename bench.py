@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--verify", type=int, default=1, help="check the first batch against the oracle on the CPU sample")
+    ap.add_argument("--hnsw-rows", type=int, default=1_000_000,
+                    help="rows of the secondary HNSW measurement (device build + SQ search + rescoring), 0 = skip")
     return ap.parse_args()
 
 
@@ -160,11 +162,77 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(args, rows, queries, out, counts, n, dim, Q, top, lib, qh, F, qa, np, torch)
+    if rank == 0 and world == 1 and args.hnsw_rows > 0:
+        try:
+            result["hnsw"] = hnsw_section(args, dev, dim, top, lib, F, qa, np, torch)
+        except Exception as e:  # the headline line must survive a failure of the secondary measurement
+            result["hnsw"] = {"error": repr(e)[:300]}
     if rank == 0:
         print(json.dumps(result), flush=True)
     backend.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def hnsw_section(args, dev, dim, top, lib, F, qa, np, torch):
+    """Secondary measurement, outside the timed region (the metric names "brute-force + HNSW"): the C3-style path on
+    `--hnsw-rows` clustered rows: device HNSW build (qmx_hnsw_build), SQ-int8 walk (qmx_hnsw_search, oversampling 2),
+    rescoring with the f32 rows (qmx_rescore), recall@10 against the exact device search.  tools/bench_hnsw.py is the
+    full tool (CPU-oracle walk parity, 10 M rows)."""
+    n, nq, ef, m = args.hnsw_rows, 8192, 128, 16
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0x5EED0003)
+    centres = torch.randn((4096, dim), generator=gen, device=dev, dtype=torch.float32)
+    centres = centres / centres.norm(dim=1, keepdim=True)
+
+    def make(count):
+        x = centres[torch.randint(0, 4096, (count,), generator=gen, device=dev)] + torch.randn((count, dim), generator=gen, device=dev) * (0.35 / dim ** 0.5)
+        F.check(lib.qmx_preprocess_f32(dev.index or 0, int(qa.Distance.Cosine), F.ptr(x), count, dim, F.ptr(x)))
+        return x
+    rows, queries_d = make(n), make(nq)
+    torch.cuda.synchronize(dev)
+    queries = queries_d.cpu().numpy()
+    vs = qa.VectorStorage(rows, qa.Distance.Cosine)
+    t0 = time.perf_counter()
+    graph = qa.GraphLayers.build(vs, m=m, ef_construct=100, seed=42)
+    t_build = time.perf_counter() - t0
+    mn, mx = float(rows.min().item()), float(rows.max().item())
+    quant = qa.ScalarQuantizer(dim, qa.Distance.Dot, (np.float32(mx) - np.float32(mn)) / np.float32(127.0), np.float32(mn))
+    p = quant.params()
+    codes = torch.empty((n, quant.quantized_vector_size()), dtype=torch.uint8, device=dev)
+    F.check(lib.qmx_sq_encode(dev.index or 0, int(qa.Distance.Dot), C.byref(p), F.ptr(rows), n, dim, F.ptr(codes)))
+    d = F.SegmentDesc()
+    d.dtype, d.distance, d.dim, d.n, d.data, d.device_id, d.sq = F.DTYPE_SQ_U8, int(qa.Distance.Dot), dim, n, F.ptr(codes).value, dev.index or 0, C.pointer(p)
+    enc = qa.EncodedVectorsU8.__new__(qa.EncodedVectorsU8)
+    enc.quantizer, enc.distance, enc.datatype, enc.dim, enc.count, enc._keep, enc._sq, enc._h = quant, quant.distance, None, dim, n, None, p, C.c_void_p()
+    F.check(lib.qmx_segment_create(C.byref(d), C.byref(enc._h)))
+    del codes
+    scorer = qa.new_raw_scorer(queries, enc)
+    raw = qa.new_raw_scorer(queries, vs)
+    F.check(lib.qmx_query_set_timing(scorer._h, 1))
+    graph.search(2 * top, ef, scorer)
+    ms, nl = C.c_float(), C.c_uint32()
+    F.check(lib.qmx_query_timing(scorer._h, C.byref(ms), C.byref(nl)))
+    t0 = time.perf_counter()
+    got, scored = graph.search(2 * top, ef, scorer, with_scored=True)
+    ids = np.zeros((nq, 2 * top), dtype=np.uint32)
+    cnt = np.zeros(nq, dtype=np.uint32)
+    for i, r in enumerate(got):
+        ids[i, :len(r)] = r["idx"]
+        cnt[i] = len(r)
+    final = raw.rescore(ids, top, cnt)
+    wall = time.perf_counter() - t0
+    F.check(lib.qmx_query_timing(scorer._h, C.byref(ms), C.byref(nl)))
+    exact = qa.BatchFilteredSearcher(queries[:256], vs, top).peek_top_all()
+    recall = sum(len(set(a["idx"].tolist()) & set(b["idx"].tolist())) for a, b in zip(final[:256], exact)) / (256.0 * top)
+    kernel_ms = ms.value / max(nl.value, 1)
+    return {"workload": "C3-style: %s x d=%d clustered rows, device HNSW build (m=%d, ef_construct=100), SQ-int8 walk ef=%d, oversampling 2 + f32 rescoring, %d queries per launch"
+                        % (_human(n), dim, m, ef, nq),
+            "build_s": round(t_build, 2), "build_points_per_s": round(n / t_build, 1),
+            "search_qps_kernel": round(nq / (kernel_ms * 1e-3), 1), "search_kernel_ms": round(kernel_ms, 3),
+            "search_qps_wall_incl_host_copies_and_rescoring": round(nq / wall, 1),
+            "points_scored_per_query": round(scored / nq, 1), "gather_GBps": round(scored * quant.quantized_vector_size() / (kernel_ms * 1e-3) / 1e9, 1),
+            "recall_at_10_after_rescoring": round(recall, 4)}
 
 
 def cpu_baseline(args, rows, queries, out, counts, n, dim, Q, top, lib, qh, F, qa, np, torch):
