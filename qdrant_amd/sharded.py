@@ -122,6 +122,52 @@ class HipBackend:
             self.qh = C.c_void_p()
 
 
+class HipHnswBackend(HipBackend):
+    """Local HNSW search instead of the brute-force scan: the graph of this rank's segment (built on this GPU with
+    `GraphLayers.build`, segments are independent: no communication at build time), walked with the scorer of
+    `storage` (dense, SQ or PQ); when `rescore_storage` is given the walk returns `oversampling * top` candidates and
+    they are re-scored with the original vectors (`postprocess_search_result`).  Same output contract as HipBackend,
+    so ShardedSearcher's all-gather + merge is unchanged."""
+
+    def __init__(self, storage, graph, nq: int, device_id: int, ef: int = 128, rescore_storage=None, oversampling: int = 2,
+                 stream: Optional[torch.cuda.Stream] = None):
+        super().__init__(storage, nq, device_id, stream)
+        self.graph, self.ef = graph, ef
+        self.rescore_storage, self.oversampling = rescore_storage, (oversampling if rescore_storage is not None else 1)
+        self.rqh = C.c_void_p()
+        if rescore_storage is not None:
+            zeros = torch.zeros((nq, rescore_storage.dim), dtype=torch.float32, device=self.device)
+            F.check(self.lib.qmx_query_create(rescore_storage._h, F.ptr(zeros), nq, C.byref(self.rqh)))
+            F.check(self.lib.qmx_query_set_stream(self.rqh, C.c_void_p(self.stream.cuda_stream)))
+        self._cand = None
+
+    def local_topk(self, queries: torch.Tensor, top: int, out: torch.Tensor, counts: torch.Tensor):
+        assert queries.is_cuda and queries.shape[0] == self.nq
+        stop = top * self.oversampling
+        if self.rescore_storage is not None and (self._cand is None or self._cand[0].shape[1] != stop):
+            self._cand = (torch.zeros((self.nq, stop, 2), dtype=torch.int32, device=self.device),
+                          torch.zeros((self.nq,), dtype=torch.int32, device=self.device),
+                          torch.zeros((self.nq, stop), dtype=torch.int32, device=self.device))
+        cur = self._enter(queries, out, counts)
+        F.check(self.lib.qmx_query_update(self.qh, F.ptr(queries)))
+        if self.rescore_storage is None:
+            F.check(self.lib.qmx_hnsw_search_async(self.graph._h, self.qh, top, self.ef, F.ptr(out), F.ptr(counts), None))
+        else:
+            cand, ccnt, cids = self._cand
+            F.check(self.lib.qmx_hnsw_search_async(self.graph._h, self.qh, stop, self.ef, F.ptr(cand), F.ptr(ccnt), None))
+            with torch.cuda.stream(self.stream):
+                cids.copy_(cand[:, :, 0])                      # ScoredPointOffset.idx column
+            F.check(self.lib.qmx_query_update(self.rqh, F.ptr(queries)))
+            F.check(self.lib.qmx_rescore(self.rqh, F.ptr(cids), F.ptr(ccnt), stop, top, F.ptr(out), F.ptr(counts)))
+        self._leave(cur)
+
+    def close(self):
+        if self.rqh:
+            self.lib.qmx_query_destroy(self.rqh)
+            self.rqh = C.c_void_p()
+        super().close()
+
+
 class ShardedSearcher:
     """search(queries) on every rank returns the merged top-k over all ranks' segments.
 

@@ -98,3 +98,56 @@ def test_sharded_searcher_world_size_one():
         for (gi, gs), w in zip(s.results(), truth.peek_top(q, top)):
             assert gi.tolist() == w["idx"].tolist() and gs.tolist() == w["score"].tolist()
     b.close()
+
+
+def test_sharded_hnsw_backend_world_size_one_and_two_segments():
+    """HNSW variant of the per-rank search: device-built graph per segment, SQ walk + f32 rescoring, same gather/merge."""
+    import torch
+    import qdrant_amd as qa
+    from qdrant_amd import sharded
+    rng = np.random.default_rng(4)
+    dim, nq, top = 64, 8, 10
+    centers = rng.standard_normal((32, dim)).astype(np.float32) * 2
+    segs = [O.preprocess(O.COSINE, (centers[rng.integers(0, 32, n)] + 0.5 * rng.standard_normal((n, dim))).astype(np.float32)) for n in (4000, 2500)]
+    queries = O.preprocess(O.COSINE, (centers[rng.integers(0, 32, nq)] + 0.5 * rng.standard_normal((nq, dim))).astype(np.float32))
+    dev = torch.device("cuda", 0)
+    qd = torch.from_numpy(queries).to(dev)
+    gathered = torch.zeros((2, nq, top, 2), dtype=torch.int32, device=dev)
+    gcounts = torch.zeros((2, nq), dtype=torch.int32, device=dev)
+    keep = []
+    for r, rows in enumerate(segs):
+        vs = qa.VectorStorage(rows, qa.Distance.Cosine)
+        graph = qa.GraphLayers.build(vs, m=8, ef_construct=64, seed=r)
+        quant = qa.ScalarQuantizer.from_min_max(rows, dim, qa.Distance.Dot)
+        enc = qa.EncodedVectorsU8(quant.encode(rows), quant)
+        b = sharded.HipHnswBackend(enc, graph, nq, 0, ef=96, rescore_storage=vs, oversampling=3)
+        b.local_topk(qd, top, gathered[r], gcounts[r])
+        keep.append((vs, graph, enc, b))
+    base = torch.tensor([0, len(segs[0])], dtype=torch.int32, device=dev)
+    merged = torch.zeros((nq, top, 2), dtype=torch.int32, device=dev)
+    mcounts = torch.zeros((nq,), dtype=torch.int32, device=dev)
+    keep[0][3].merge(gathered, gcounts, base, top, merged, mcounts)
+    torch.cuda.synchronize()
+    m, c = merged.cpu().numpy(), mcounts.cpu().numpy()
+    truth = O.DenseStorage(O.F32, O.COSINE, np.concatenate(segs))
+    exact = truth.peek_top(queries, top)
+    hits = 0
+    for i in range(nq):
+        assert c[i] == top
+        ids = m[i, :, 0].view(np.uint32)
+        sc = m[i, :, 1].copy().view(np.float32)
+        hits += len(set(ids.tolist()) & set(exact[i]["idx"].tolist()))
+        w = truth.score_points(queries[i:i + 1], ids)[0]            # rescored: exact f32 scores of the globalised ids
+        assert np.array_equal(sc.view(np.uint32), w.view(np.uint32)) and np.all(np.diff(sc) <= 0)
+    assert hits / (nq * top) > 0.8
+    # a walk without rescoring, through ShardedSearcher at world size 1
+    vs, graph, enc, _ = keep[0]
+    b1 = sharded.HipHnswBackend(vs, graph, nq, 0, ef=96)
+    s = sharded.ShardedSearcher(b1, len(segs[0]), nq, top, device=dev)
+    s.search(qd)
+    want = graph.search(top, 96, qa.new_raw_scorer(queries, vs))
+    for (gi, gs), w in zip(s.results(), want):
+        assert gi.tolist() == w["idx"].tolist() and gs.tolist() == w["score"].tolist()
+    for _, _, _, b in keep:
+        b.close()
+    b1.close()
