@@ -1,0 +1,126 @@
+"""Parity at BASELINE.json's FULL sizes (10 M rows) through size-independent properties — the oracle cannot score
+10 M x 768 in seconds, so at this size the device is checked against itself along independent code paths and against
+the oracle on a sample:
+
+  C2 (10 M x 768 f32 cosine)  matrix-core scan (16 queries / pass) == VALU scan (bit-exact kernels, different lane
+                              maps and reduction hardware); search over everything == merge of searches over 8
+                              disjoint id slabs (`BatchResultAggregator` over segments of one collection); top-k
+                              restricted to a 200 k sample == the CPU oracle on that sample
+  C3 (10 M x 768 SQ int8)     int8 matrix-core scan == VALU dot4 scan; encode on device == oracle on the first rows;
+                              the SQ error bound of lib/quantization/tests/integration/test_avx2.rs on the top-k
+Skipped when the device has < 100 GB free (the driver's MI355X has 288 GB)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+
+pytestmark = pytest.mark.gpu
+
+N, DIM, TOP, NQ = 10_000_000, 768, 10, 16
+
+
+@pytest.fixture(scope="module")
+def world():
+    import torch
+    import qdrant_amd as qa
+    from qdrant_amd import _ffi as F
+    free, _ = torch.cuda.mem_get_info(0)
+    if free < 100 * (1 << 30):
+        pytest.skip("needs ~50 GB of HBM")
+    dev = torch.device("cuda", 0)
+    rows = torch.empty((N, DIM), dtype=torch.float32, device=dev)
+    F.check(F.lib().qmx_synth_fill_f32(0, 0x5EED0002, 0, N, DIM, F.ptr(rows)))
+    F.check(F.lib().qmx_preprocess_f32(0, int(qa.Distance.Cosine), F.ptr(rows), N, DIM, F.ptr(rows)))
+    torch.cuda.synchronize()
+    queries = O.synth(0x5EED0012, 0, NQ, DIM)
+    st = qa.VectorStorage(rows, qa.Distance.Cosine)
+    yield dict(torch=torch, qa=qa, F=F, dev=dev, rows=rows, queries=queries, st=st)
+    st.close()
+    del rows
+    torch.cuda.empty_cache()
+
+
+def _same(a, b):
+    for x, y in zip(a, b):
+        assert x["idx"].tolist() == y["idx"].tolist()
+        assert np.array_equal(x["score"].view(np.uint32), y["score"].view(np.uint32))
+
+
+def test_c2_full_size_properties(world):
+    qa, F, torch = world["qa"], world["F"], world["torch"]
+    s = qa.BatchFilteredSearcher(world["queries"], world["st"], TOP)
+    full = s.peek_top_all()
+    assert all(len(r) == TOP and np.all(np.diff(r["score"]) <= 0) for r in full)
+    # (1) the VALU kernels give the same lists (16 queries as 4 passes of 4)
+    os.environ["QMX_NO_MFMA_SCAN"] = "1"
+    try:
+        valu = []
+        for q0 in range(0, NQ, 4):
+            valu += qa.BatchFilteredSearcher(world["queries"][q0:q0 + 4], world["st"], TOP).peek_top_all()
+    finally:
+        del os.environ["QMX_NO_MFMA_SCAN"]
+    _same(full, valu)
+    # (2) whole == merge of 8 slabs (ids already global, so qmx_merge_topk needs no base)
+    slabs = np.linspace(0, N, 9).astype(np.int64)
+    lists = np.zeros((8, NQ, TOP), dtype=O.ScoredPointOffset)
+    for i in range(8):
+        ids = torch.arange(int(slabs[i]), int(slabs[i + 1]), dtype=torch.int32, device=world["dev"])
+        out = torch.zeros((NQ, TOP, 2), dtype=torch.int32, device=world["dev"])
+        cnt = torch.zeros((NQ,), dtype=torch.int32, device=world["dev"])
+        F.check(F.lib().qmx_search_topk_async(s.scorer._h, TOP, F.ptr(ids), len(ids), F.ptr(out), F.ptr(cnt)))
+        F.check(F.lib().qmx_query_synchronize(s.scorer._h))
+        o = out.cpu().numpy()
+        lists[i]["idx"] = o[:, :, 0].view(np.uint32)
+        lists[i]["score"] = o[:, :, 1].copy().view(np.float32)
+    merged = np.zeros((NQ, TOP), dtype=O.ScoredPointOffset)
+    mc = np.zeros(NQ, dtype=np.uint32)
+    F.check(F.lib().qmx_merge_topk(0, F.ptr(lists), None, 8, NQ, TOP, F.ptr(merged), F.ptr(mc)))
+    _same(full, [merged[i, :mc[i]] for i in range(NQ)])
+    # (3) the oracle on a 200 k sample (rows 4 000 000 .. 4 200 000)
+    a, b = 4_000_000, 4_200_000
+    host = world["rows"][a:b].cpu().numpy()
+    want = O.DenseStorage(O.F32, O.COSINE, host).peek_top(world["queries"], TOP)
+    got = s.peek_top_iter(np.arange(a, b, dtype=np.uint32))
+    for g, w in zip(got, want):
+        assert (g["idx"] - a).tolist() == w["idx"].tolist()
+        assert np.array_equal(g["score"].view(np.uint32), w["score"].view(np.uint32))
+
+
+def test_c3_full_size_properties(world):
+    qa, F, torch = world["qa"], world["F"], world["torch"]
+    rows, dev = world["rows"], world["dev"]
+    mn, mx = float(rows.min().item()), float(rows.max().item())
+    quant = qa.ScalarQuantizer(DIM, qa.Distance.Dot, (np.float32(mx) - np.float32(mn)) / np.float32(127.0), np.float32(mn))
+    p = quant.params()
+    codes = torch.empty((N, quant.quantized_vector_size()), dtype=torch.uint8, device=dev)
+    F.check(F.lib().qmx_sq_encode(0, int(qa.Distance.Dot), C.byref(p), F.ptr(rows), N, DIM, F.ptr(codes)))
+    osq = O.SqOracle(O.DOT, DIM, quant.alpha, quant.offset)
+    assert np.array_equal(osq.encode_rows(rows[:1000].cpu().numpy()), codes[:1000].cpu().numpy())
+    assert np.array_equal(osq.encode_rows(rows[N - 500:].cpu().numpy()), codes[N - 500:].cpu().numpy())
+    d = F.SegmentDesc()
+    d.dtype, d.distance, d.dim, d.n, d.data, d.device_id, d.sq = F.DTYPE_SQ_U8, int(qa.Distance.Dot), DIM, N, F.ptr(codes).value, 0, C.pointer(p)
+    enc = qa.EncodedVectorsU8.__new__(qa.EncodedVectorsU8)
+    enc.quantizer, enc.distance, enc.datatype, enc.dim, enc.count, enc._keep, enc._sq, enc._h = quant, quant.distance, None, DIM, N, None, p, C.c_void_p()
+    F.check(F.lib().qmx_segment_create(C.byref(d), C.byref(enc._h)))
+    del codes
+    queries = O.preprocess(O.COSINE, world["queries"])
+    s = qa.BatchFilteredSearcher(queries, enc, TOP)
+    full = s.peek_top_all()
+    os.environ["QMX_NO_MFMA_SCAN"] = "1"
+    try:
+        valu = []
+        for q0 in range(0, NQ, 4):
+            valu += qa.BatchFilteredSearcher(queries[q0:q0 + 4], enc, TOP).peek_top_all()
+    finally:
+        del os.environ["QMX_NO_MFMA_SCAN"]
+    _same(full, valu)
+    # quantization error of the returned scores vs the exact f32 scores: abs(delta) < 0.1 * dim in test_avx2.rs:16-57 for
+    # N(0,1) coordinates; rows here are unit vectors, so the same relative bound is 0.1 * dim * (1 / dim) = 0.1
+    raw = qa.new_raw_scorer(world["queries"], world["st"])
+    for qi, r in enumerate(full):
+        exact = raw.score_points(r["idx"])[qi]
+        assert np.all(np.abs(exact - r["score"]) < 0.1)
+    enc.close()
