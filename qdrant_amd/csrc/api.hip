@@ -184,7 +184,7 @@ struct qmx_query {
 // f32 dot / cosine rows of >= 32 elements scan 8..32 queries per pass on the f32 matrix cores (scan_mfma.hip)
 static bool mfma_scan_ok(const qmx_segment *s) {
     if (s->dtype == QMX_DTYPE_SQ_U8) return sq_mfma_ok(s->distance, s->scan_dim) && getenv("QMX_NO_MFMA_SCAN") == nullptr;
-    return s->dtype == QMX_DTYPE_F32 && (s->distance == QMX_DISTANCE_DOT || s->distance == QMX_DISTANCE_COSINE) && s->dim >= 32 &&
+    return (s->dtype == QMX_DTYPE_F32 || s->dtype == QMX_DTYPE_F16) && (s->distance == QMX_DISTANCE_DOT || s->distance == QMX_DISTANCE_COSINE) && s->dim >= 32 &&
            s->fast_layout() && getenv("QMX_NO_MFMA_SCAN") == nullptr;
 }
 constexpr uint32_t MAX_QT_MFMA = 32;
@@ -783,7 +783,9 @@ static int32_t launch_scan(const qmx_query *q, int qt, ScanMode mode, const Scan
         QMX_REQUIRE(s->fast_layout(), QMX_ERR_NOT_SUPPORTED,
                     "dtype %u dim %u: an adopted device block needs a 16-byte aligned base and row stride (got stride %llu); "
                     "let qmx_segment_create upload it instead", s->dtype, s->dim, (unsigned long long)s->row_stride);
-        if (qt >= 8 && mfma_scan_ok(s)) return launch_scan_f32_mfma(q->stream, qt, mode, a, s->num_cus, grid);
+        if (qt >= 8 && mfma_scan_ok(s))
+            return s->dtype == QMX_DTYPE_F32 ? launch_scan_f32_mfma(q->stream, qt, mode, a, s->num_cus, grid)
+                                              : launch_scan_f16_mfma(q->stream, qt, mode, a, s->num_cus, grid);
         return launch_scan_dense(q->stream, (int)s->dtype, (int)s->distance, qt, mode, a, s->num_cus, grid);
     }
     if (s->dtype == QMX_DTYPE_SQ_U8) {

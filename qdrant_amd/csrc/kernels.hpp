@@ -124,6 +124,7 @@ int32_t launch_scan_f32_mfma(hipStream_t st, int qt, ScanMode mode, const ScanAr
 // SQ int8 dot / cosine / euclid, 8..32 queries per pass on v_mfma_i32_16x16x64_i8 (scan_sq_mfma.hip)
 bool sq_mfma_ok(uint32_t distance, uint32_t actual_dim);
 int32_t launch_scan_sq_mfma(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out);
+int32_t launch_scan_f16_mfma(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out);
 // which query an item belongs to: explicit list, or fixed-size slots (item / per_query, with the
 // live prefix of each slot given by counts), or item == query (score_internal)
 struct PairSel {

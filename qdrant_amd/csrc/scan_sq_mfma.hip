@@ -24,11 +24,46 @@
 namespace qmx {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// What differs between the element types that share this kernel (64 row bytes per lane-step, 16 rows x 16 queries per MFMA)
+struct SqOps {     // EncodedVectorsU8: exact integer dot, then postprocess_score
+    typedef i32x4 acc_t;
+    static __device__ __forceinline__ uint32_t body_bytes(const ScanArgs &a) { return a.dim; }   // actual_dim code bytes
+    static __device__ __forceinline__ acc_t mfma(const uint4 &x, const uint4 &y, acc_t c) {
+        return __builtin_amdgcn_mfma_i32_16x16x64_i8((i32x4){(int)x.x, (int)x.y, (int)x.z, (int)x.w}, (i32x4){(int)y.x, (int)y.y, (int)y.z, (int)y.w},
+                                                     c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float row_aux(const ScanArgs &a, uint32_t rid) { return a.row_offsets[rid]; }
+    // multiplier * dot + query_offset + vector_offset, left to right, not fused (encoded_vectors_u8.rs:100-103)
+    static __device__ __forceinline__ float finish(const ScanArgs &a, int acc, const unsigned char *q_entry, const unsigned char *, float v_off) {
+        const float m1 = a.sq_multiplier * (float)acc;
+        const float mq = m1 + reinterpret_cast<const QueryAux *>(q_entry + a.aux_off)->f0;
+        return mq + v_off;
+    }
+};
+struct F16Ops {    // Metric<f16> dot / cosine: f16 products are exact in f32, f32 accumulation (order differs from the
+                   // x86 leaf: within 1e-5 of it, the bar of the f16 path), scalar tail as in metric_f16/avx/dot.rs:64-66
+    typedef f32x4 acc_t;
+    static __device__ __forceinline__ uint32_t body_bytes(const ScanArgs &a) { return a.tail_start * 2; }
+    static __device__ __forceinline__ acc_t mfma(const uint4 &x, const uint4 &y, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8 *>(&x), *reinterpret_cast<const f16x8 *>(&y), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float row_aux(const ScanArgs &, uint32_t) { return 0.0f; }
+    static __device__ __forceinline__ float finish(const ScanArgs &a, float acc, const unsigned char *q_entry, const unsigned char *row, float) {
+        float result = acc;
+        const _Float16 *qh = reinterpret_cast<const _Float16 *>(q_entry);
+        const _Float16 *vh = reinterpret_cast<const _Float16 *>(row);
+        for (uint32_t i = a.tail_start; i < a.dim; ++i) result += (float)qh[i] * (float)vh[i];
+        return result;
+    }
+};
 
 constexpr int SQM_BLOCK = 512;
 constexpr int SQM_NW = SQM_BLOCK / WAVE;
 
-template <int QW, int D, bool HAS_IDS, int MODE>
+template <class Ops, int QW, int D, bool HAS_IDS, int MODE>
 __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NG = QW / 16;
@@ -46,16 +81,11 @@ __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs 
     const int n = lane & 15;       // A: stored row of the tile; B / D: query of the group
     const int kg = lane >> 4;      // which 16 bytes of the 64-byte step; D: rows 4 kg .. 4 kg + 3
     const unsigned char *rows = reinterpret_cast<const unsigned char *>(a.rows);
-    const uint32_t nbytes = a.dim;                          // actual_dim code bytes per row (multiple of 16)
+    const uint32_t nbytes = Ops::body_bytes(a);             // bytes of the SIMD body per row (multiple of 16)
     const uint32_t nstep = (nbytes + 63) / 64;
     const unsigned char *qbase = smem + (uint32_t)n * a.q_stride + (uint32_t)kg * 16;   // + g * 16 * q_stride + s * 64
     const uint32_t gstride = 16u * a.q_stride;
     const int top = (int)a.top;
-
-    float q_off[NG];               // EncodedQueryU8.offset of the lane's queries
-#pragma unroll
-    for (int g = 0; g < NG; ++g)
-        q_off[g] = reinterpret_cast<const QueryAux *>(smem + (uint32_t)(16 * g + n) * a.q_stride + a.aux_off)->f0;
 
     uint64_t list[QW];
     uint64_t thr[NG];              // k-th best key of query 16 g + n
@@ -104,13 +134,13 @@ __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             rid[r] = row_of(tile, 4 * kg + r, &valid[r]);
-            v_off[r] = a.row_offsets[rid[r]];
+            v_off[r] = Ops::row_aux(a, rid[r]);
         }
         const unsigned char *rp_next = rows + (uint64_t)row_of(tile + tw < n_tiles ? tile + tw : 0, n, nullptr) * a.row_stride;
 
-        i32x4 acc[NG];
+        typename Ops::acc_t acc[NG];
 #pragma unroll
-        for (int g = 0; g < NG; ++g) acc[g] = (i32x4){0, 0, 0, 0};
+        for (int g = 0; g < NG; ++g) acc[g] = (typename Ops::acc_t){0, 0, 0, 0};
 
         for (uint32_t s0 = 0; s0 < nstep; s0 += D) {
             const bool last_chunk = s0 + D >= nstep;
@@ -121,12 +151,10 @@ __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs 
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 if (s0 + d < nstep) {
-                    const i32x4 av = (i32x4){(int)cur[d].x, (int)cur[d].y, (int)cur[d].z, (int)cur[d].w};
 #pragma unroll
                     for (int g = 0; g < NG; ++g) {
                         const uint4 qq = *reinterpret_cast<const uint4 *>(qbase + (uint32_t)g * gstride + (s0 + d) * 64);
-                        const i32x4 bv = (i32x4){(int)qq.x, (int)qq.y, (int)qq.z, (int)qq.w};
-                        acc[g] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bv, acc[g], 0, 0, 0);
+                        acc[g] = Ops::mfma(cur[d], qq, acc[g]);
                     }
                 }
             }
@@ -141,10 +169,7 @@ __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs 
             const uint32_t q = (uint32_t)(16 * g + n);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float f = (float)acc[g][r];
-                const float m1 = a.sq_multiplier * f;
-                const float mq = m1 + q_off[g];
-                const float score = mq + v_off[r];
+                const float score = Ops::finish(a, acc[g][r], smem + q * a.q_stride, rows + (uint64_t)rid[r] * a.row_stride, v_off[r]);
                 const bool mine = valid[r] && q < a.nq;
                 if (MODE == SCAN_SCORES) {
                     if (mine) a.scores[(uint64_t)q * a.scores_stride + (tile * 16 + (uint32_t)(4 * kg + r))] = score;
@@ -202,7 +227,7 @@ __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs 
     }
 }
 
-template <int QW, int D, bool HAS_IDS, int MODE>
+template <class Ops, int QW, int D, bool HAS_IDS, int MODE>
 static int32_t launch_sqm_inst(hipStream_t st, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
     size_t lds = (size_t)QW * a.q_stride;
     if (MODE == SCAN_TOPK) {
@@ -211,7 +236,7 @@ static int32_t launch_sqm_inst(hipStream_t st, const ScanArgs &a, int num_cus, u
     }
     lds = (lds + 15) & ~(size_t)15;
     QMX_REQUIRE(lds <= 160 * 1024, QMX_ERR_NOT_SUPPORTED, "query tile needs %zu B of LDS (> 160 KiB)", lds);
-    auto kfn = scan_sq_mfma_kernel<QW, D, HAS_IDS, MODE>;
+    auto kfn = scan_sq_mfma_kernel<Ops, QW, D, HAS_IDS, MODE>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -235,12 +260,12 @@ static int32_t launch_sqm_inst(hipStream_t st, const ScanArgs &a, int num_cus, u
     return QMX_OK;
 }
 
-template <int QW, int D>
+template <class Ops, int QW, int D>
 static int32_t launch_sqm_qt(hipStream_t st, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid) {
     const bool ids = a.ids != nullptr;
     if (mode == SCAN_TOPK)
-        return ids ? launch_sqm_inst<QW, D, true, SCAN_TOPK>(st, a, num_cus, grid) : launch_sqm_inst<QW, D, false, SCAN_TOPK>(st, a, num_cus, grid);
-    return ids ? launch_sqm_inst<QW, D, true, SCAN_SCORES>(st, a, num_cus, grid) : launch_sqm_inst<QW, D, false, SCAN_SCORES>(st, a, num_cus, grid);
+        return ids ? launch_sqm_inst<Ops, QW, D, true, SCAN_TOPK>(st, a, num_cus, grid) : launch_sqm_inst<Ops, QW, D, false, SCAN_TOPK>(st, a, num_cus, grid);
+    return ids ? launch_sqm_inst<Ops, QW, D, true, SCAN_SCORES>(st, a, num_cus, grid) : launch_sqm_inst<Ops, QW, D, false, SCAN_SCORES>(st, a, num_cus, grid);
 }
 
 // the f32 adds of the AVX2 leaf stay exact (and its result order-free) while every partial sum is < 2^24
@@ -252,10 +277,21 @@ bool sq_mfma_ok(uint32_t distance, uint32_t actual_dim) {
 int32_t launch_scan_sq_mfma(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
     switch (qt) {
         case 8:
-        case 16: return launch_sqm_qt<16, 6>(st, mode, a, num_cus, grid_out);
-        case 32: return launch_sqm_qt<32, 6>(st, mode, a, num_cus, grid_out);
+        case 16: return launch_sqm_qt<SqOps, 16, 6>(st, mode, a, num_cus, grid_out);
+        case 32: return launch_sqm_qt<SqOps, 32, 6>(st, mode, a, num_cus, grid_out);
     }
     set_error("unsupported SQ MFMA query tile %d", qt);
+    return QMX_ERR_BAD_ARG;
+}
+
+// f16 rows, dot / cosine, dim >= 32: v_mfma_f32_16x16x32_f16, same streaming structure (64 row bytes = 32 halfs per step)
+int32_t launch_scan_f16_mfma(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
+    switch (qt) {
+        case 8:
+        case 16: return launch_sqm_qt<F16Ops, 16, 6>(st, mode, a, num_cus, grid_out);
+        case 32: return launch_sqm_qt<F16Ops, 32, 6>(st, mode, a, num_cus, grid_out);
+    }
+    set_error("unsupported f16 MFMA query tile %d", qt);
     return QMX_ERR_BAD_ARG;
 }
 

@@ -148,3 +148,32 @@ def test_sq_topk_with_deleted_and_id_lists(qa, nq, top):
             assert g["idx"].tolist() == w["idx"].tolist()
             assert np.array_equal(g["score"].view(np.uint32), w["score"].view(np.uint32))
             assert not deleted[g["idx"]].any()
+
+
+# ---- f16 on v_mfma_f32_16x16x32_f16 (scan_sq_mfma.hip, F16Ops) ------------------------------------------------------
+@pytest.mark.parametrize("dist", [O.DOT, O.COSINE])
+@pytest.mark.parametrize("dim", [32, 40, 100, 768, 1000])
+@pytest.mark.parametrize("nq", [8, 16, 32, 45])
+def test_f16_scores_within_1e5(qa, dist, dim, nq):
+    """f16 path: products are exact in f32, only the f32 summation order differs from the x86 leaf -> the f16 bar:
+    |got - oracle| <= 1e-5 * sum(abs(terms)) (the reference's own SIMD-vs-scalar f16 test allows 5e-4)."""
+    rng = np.random.default_rng(dim * 13 + nq + dist)
+    n = 411
+    rows16 = O.to_f16(O.preprocess(dist, rng.standard_normal((n, dim)).astype(np.float32)))
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    st = qa.VectorStorage(rows16.view(np.float16), _dist(qa, dist), qa.VectorStorageDatatype.Float16)
+    scorer = qa.new_raw_scorer(queries, st)
+    ost = O.DenseStorage(O.F16, dist, rows16)
+    q16 = ost.encode_queries(queries)
+    ids = np.arange(n, dtype=np.uint32)
+    got = scorer.score_points(ids)
+    want = ost.score_points(queries, ids)
+    scale = np.abs(O.f16_to_f32(q16).astype(np.float64)[:, None, :] * O.f16_to_f32(rows16).astype(np.float64)[None, :, :]).sum(-1)
+    assert np.all(np.abs(got.astype(np.float64) - want) <= 1e-5 * scale + 1e-30)
+    # top-k: same id sets as the oracle wherever the k-th and (k+1)-th oracle scores are further apart than the tolerance
+    s = qa.BatchFilteredSearcher(queries, st, 10)
+    res = s.peek_top_all()
+    wtop = ost.peek_top(queries, 11)
+    for qi, (g, w) in enumerate(zip(res, wtop)):
+        if w["score"][9] - w["score"][10] > 4e-5 * scale[qi].max():
+            assert set(g["idx"].tolist()) == set(w["idx"][:10].tolist())

@@ -124,6 +124,35 @@ def main():
         run("C3: 10M x 768 SQ-int8 dot, brute-force top-10", seg, dim, quant.quantized_vector_size(), queries, check)
         F.check(lib.qmx_segment_destroy(seg))
 
+    if "f16" in args.configs:
+        dim = 768
+        rows = make_rows(dim, 0x5EED0002)
+        rows16 = torch.empty((n, dim), dtype=torch.float16, device=dev)
+        F.check(lib.qmx_cast_f32(0, F.DTYPE_F16, F.ptr(rows), n * dim, F.ptr(rows16)))
+        torch.cuda.synchronize()
+        host16 = rows16[:S].cpu().numpy().view(np.uint16)
+        del rows
+        torch.cuda.empty_cache()
+        d = F.SegmentDesc()
+        d.dtype, d.distance, d.dim, d.flags, d.n, d.data, d.device_id = F.DTYPE_F16, int(qa.Distance.Cosine), dim, F.SEG_DATA_ON_DEVICE, n, F.ptr(rows16).value, 0
+        seg = C.c_void_p()
+        F.check(lib.qmx_segment_create(C.byref(d), C.byref(seg)))
+        ost = O.DenseStorage(O.F16, O.COSINE, host16)
+        queries = O.synth(0x5EED0012, 0, 64, dim)
+        ids = torch.arange(S, dtype=torch.int32, device=dev)
+
+        def check(qh, Q, out, counts):
+            F.check(lib.qmx_search_topk_async(qh, top, F.ptr(ids), S, F.ptr(out), F.ptr(counts)))
+            F.check(lib.qmx_query_synchronize(qh))
+            g = out.cpu().numpy()
+            gs = g[:, :, 1].copy().view(np.float32)
+            want = ost.peek_top(queries[:min(Q, 2)], top)
+            return all(np.allclose(gs[i], want[i]["score"], rtol=1e-4, atol=1e-6) for i in range(min(Q, 2)))
+        run("C2-f16: 10M x 768 f16 cosine, brute-force top-10", seg, dim, dim * 2, queries, check)
+        F.check(lib.qmx_segment_destroy(seg))
+        del rows16
+        torch.cuda.empty_cache()
+
     if "c4" in args.configs:
         dim, chunk = 1536, 16
         rows = make_rows(dim, 0x5EED0004)
