@@ -163,6 +163,12 @@ QMX_API uint32_t qmx_abi_version(void);
  * (raw_scorer.rs:60-114 matches on it) / `GpuVectorStorage::new`
  * (hnsw_index/gpu/gpu_vector_storage/mod.rs).  OOM => QMX_ERR_OUT_OF_MEMORY, caller keeps CPU. */
 QMX_API int32_t qmx_segment_create(const qmx_segment_desc *desc, qmx_segment **out);
+/* Same for a CHUNKED appendable storage (`ChunkedVectors<T>`, lib/segment/src/vector_storage/chunked_vectors.rs: fixed-size
+ * chunks of CHUNK_SIZE = 32 MiB, vector_storage/common.rs:27; row `key` lives in chunk key / rows_per_chunk at row
+ * key % rows_per_chunk): `chunks[c]` points at chunk c (host or device), every chunk but the last holds `rows_per_chunk`
+ * rows; `desc->data` is ignored, `desc->n` is the total row count.  The rows are gathered into one HBM block. */
+QMX_API int32_t qmx_segment_create_chunked(const qmx_segment_desc *desc, const void *const *chunks, uint64_t rows_per_chunk,
+                                           uint32_t n_chunks, qmx_segment **out);
 QMX_API int32_t qmx_segment_destroy(qmx_segment *seg);
 /* Deleted flags = the two `BitSlice<u64, Lsb0>` of `NotDeletedChecker`
  * (raw_scorer.rs:580-603; layout lib/common/common/src/bitvec.rs:6-7).  A point past

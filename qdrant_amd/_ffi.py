@@ -83,6 +83,7 @@ SIGNATURES = {
     "qmx_device_count": (C.c_int32, [C.POINTER(C.c_int32)]),
     "qmx_last_error": (C.c_int32, [C.c_char_p, C.c_size_t]),
     "qmx_segment_create": (C.c_int32, [C.POINTER(SegmentDesc), C.POINTER(_P)]),
+    "qmx_segment_create_chunked": (C.c_int32, [C.POINTER(SegmentDesc), _P, C.c_uint64, C.c_uint32, C.POINTER(_P)]),
     "qmx_segment_destroy": (C.c_int32, [_P]),
     "qmx_segment_set_deleted": (C.c_int32, [_P, _P, C.c_uint64, _P, C.c_uint64]),
     "qmx_segment_read_rows": (C.c_int32, [_P, _P, C.c_uint32, _P]),

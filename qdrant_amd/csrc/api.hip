@@ -418,6 +418,45 @@ int32_t qmx_segment_create(const qmx_segment_desc *desc, qmx_segment **out) {
     return QMX_OK;
 }
 
+int32_t qmx_segment_create_chunked(const qmx_segment_desc *desc, const void *const *chunks, uint64_t rows_per_chunk, uint32_t n_chunks,
+                                   qmx_segment **out) {
+    QMX_REQUIRE(desc && out && (n_chunks == 0 || chunks), QMX_ERR_BAD_ARG, "NULL argument");
+    *out = nullptr;
+    QMX_REQUIRE(desc->dtype <= QMX_DTYPE_U8, QMX_ERR_NOT_SUPPORTED, "chunked storages hold raw vectors (f32 / f16 / u8), not dtype %u", desc->dtype);
+    QMX_REQUIRE(desc->distance <= QMX_DISTANCE_MANHATTAN && desc->dim > 0, QMX_ERR_BAD_ARG, "bad distance / dim");
+    QMX_REQUIRE(desc->n <= 0xFFFFFFFFull, QMX_ERR_BAD_ARG, "PointOffsetType is u32: n=%llu too large", (unsigned long long)desc->n);
+    QMX_REQUIRE(desc->n == 0 || (rows_per_chunk > 0 && (uint64_t)n_chunks * rows_per_chunk >= desc->n), QMX_ERR_BAD_ARG,
+                "%u chunks of %llu rows cannot hold %llu rows", n_chunks, (unsigned long long)rows_per_chunk, (unsigned long long)desc->n);
+    QMX_REQUIRE(!(desc->flags & QMX_SEG_DATA_ON_DEVICE), QMX_ERR_BAD_ARG, "chunks are copied into one block: QMX_SEG_DATA_ON_DEVICE does not apply");
+    hipDeviceProp_t prop;
+    QMX_TRY(check_device(desc->device_id, &prop));
+    qmx_segment *s = new (std::nothrow) qmx_segment();
+    QMX_REQUIRE(s, QMX_ERR_OUT_OF_MEMORY, "host allocation failed");
+    s->device = desc->device_id;
+    s->num_cus = prop.multiProcessorCount;
+    s->dtype = desc->dtype; s->distance = desc->distance; s->dim = desc->dim; s->flags = desc->flags; s->n = desc->n;
+    s->scan_dim = desc->dim;
+    s->row_bytes = (uint64_t)desc->dim * elem_bytes(desc->dtype);
+    const uint64_t src_stride = desc->row_stride_bytes ? desc->row_stride_bytes : s->row_bytes;
+    s->row_stride = (s->row_bytes + 15) & ~15ull;
+    const size_t bytes = (size_t)std::max<uint64_t>(1, s->n) * s->row_stride;
+    hipError_t e = src_stride >= s->row_bytes ? hipMalloc(&s->d_rows, bytes) : hipErrorInvalidValue;
+    s->owns_rows = e == hipSuccess;
+    if (e == hipSuccess && s->row_stride != s->row_bytes) e = hipMemset(s->d_rows, 0, bytes);
+    for (uint32_t c = 0; e == hipSuccess && c < n_chunks && (uint64_t)c * rows_per_chunk < s->n; ++c) {
+        const uint64_t row0 = (uint64_t)c * rows_per_chunk, cnt = std::min<uint64_t>(rows_per_chunk, s->n - row0);
+        if (!chunks[c]) { e = hipErrorInvalidValue; break; }
+        e = hipMemcpy2D((char *)s->d_rows + row0 * s->row_stride, s->row_stride, chunks[c], src_stride, s->row_bytes, cnt, hipMemcpyDefault);
+    }
+    if (e != hipSuccess) {
+        const int32_t rc = hip_status(e, "chunk upload", __FILE__, __LINE__);
+        segment_free(s);
+        return rc;
+    }
+    *out = s;
+    return QMX_OK;
+}
+
 int32_t qmx_segment_destroy(qmx_segment *seg) {
     if (!seg) return QMX_OK;
     (void)hipSetDevice(seg->device);

@@ -234,3 +234,28 @@ def test_device_resident_block_and_synth(qa):
     for g, w in zip(got, want):
         assert g["idx"].tolist() == w["idx"].tolist()
         assert np.array_equal(g["score"].view(np.uint32), w["score"].view(np.uint32))
+
+
+def test_chunked_storage_ingest_equals_contiguous(qa):
+    """`ChunkedVectors` (32 MiB chunks, chunked_vectors.rs): rows gathered from a chunk list score like the contiguous block."""
+    import ctypes as C
+    from qdrant_amd import _ffi as F
+    rng = np.random.default_rng(12)
+    n, dim, per = 1000, 40, 300                       # 4 chunks, the last one partial; dim * 4 = 160 B rows
+    rows = O.preprocess(O.COSINE, rng.standard_normal((n, dim)).astype(np.float32))
+    chunks = [np.ascontiguousarray(rows[i:i + per]) for i in range(0, n, per)]
+    ptrs = (C.c_void_p * len(chunks))(*[c.ctypes.data for c in chunks])
+    d = F.SegmentDesc()
+    d.dtype, d.distance, d.dim, d.n, d.device_id = F.DTYPE_F32, int(qa.Distance.Cosine), dim, n, 0
+    st = qa.VectorStorage.__new__(qa.VectorStorage)
+    st._h, st.distance, st.datatype, st.dim, st.count, st._keep = C.c_void_p(), qa.Distance.Cosine, qa.VectorStorageDatatype.Float32, dim, n, None
+    F.check(F.lib().qmx_segment_create_chunked(C.byref(d), ptrs, per, len(chunks), C.byref(st._h)))
+    assert np.array_equal(st.get_dense([0, 299, 300, 999]), rows[[0, 299, 300, 999]])
+    queries = rng.standard_normal((9, dim)).astype(np.float32)
+    got = qa.BatchFilteredSearcher(queries, st, 10).peek_top_all()
+    want = O.DenseStorage(O.F32, O.COSINE, rows).peek_top(queries, 10)
+    for g, w in zip(got, want):
+        assert g["idx"].tolist() == w["idx"].tolist()
+        assert np.array_equal(g["score"].view(np.uint32), w["score"].view(np.uint32))
+    bad = F.lib().qmx_segment_create_chunked(C.byref(d), ptrs, 200, len(chunks), C.byref(C.c_void_p()))   # 4 x 200 < 1000 rows
+    assert bad == F.ERR_BAD_ARG
