@@ -52,11 +52,16 @@ __device__ __forceinline__ float swap16_add(float a, float b) {
 
 // QW queries per wave, QSPLIT waves share one row stream (each scores its own QW queries of the
 // QW * QSPLIT-query tile; the second read of a row line hits L1 / L2), D row loads in flight per lane.
-template <int QW, int QSPLIT, int D, bool NT, int NWAVES, bool FAST, bool HAS_IDS, int MODE>
+template <int QW, int QSPLIT, int D, bool NT, int NWAVES, bool FAST, bool QH, bool HAS_IDS, int MODE>
 __global__ __launch_bounds__(NWAVES * 64) void scan_f32_mfma_kernel(const ScanArgs a) {
     constexpr int MF_BLOCK = NWAVES * 64, MF_NW = NWAVES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NG = QW / 4;
+    // QH = false: lane bit 5 (`rh`) picks the row half of an 8-row tile, a query group is 4 queries;
+    // QH = true : lane bit 5 picks the QUERY half of a group of 8, the tile has 4 rows (each row piece is loaded by two
+    //             lanes of the same instruction: one fetch): twice the queries per accumulator register
+    constexpr int GQ = QH ? 8 : 4;              // queries per group
+    constexpr int TR = QH ? 4 : 8;              // rows per tile
+    constexpr int NG = QW / GQ;
     constexpr int QT = QW * QSPLIT;
     constexpr int NSTREAM = MF_NW / QSPLIT;
     const int tid = threadIdx.x;
@@ -76,33 +81,37 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_f32_mfma_kernel(const ScanAr
     const int u0 = (lane >> 2) & 1, u2 = (lane >> 3) & 1, u1 = (lane >> 4) & 1;
     const int u = u0 + 2 * u1 + 4 * u2;
     const int rh = lane >> 5;
+    const int rofs = QH ? 0 : 4 * rh;           // first row (inside the tile) of the lane's 4 rows
+    const int qofs = QH ? 4 * rh + x : x;       // the lane's query inside a group
     constexpr int NGH = NG / 2;                 // finished (row, query) results per lane and tile
-    const int my_m = 2 * u1 + u2;               // ... for row 4 rh + my_m
+    const int my_m = 2 * u1 + u2;               // ... for row rofs + my_m
     const unsigned char *rows = reinterpret_cast<const unsigned char *>(a.rows);
     const uint32_t q0 = (uint32_t)qs * QW;                       // first query of this wave
-    const unsigned char *qbase = smem + (q0 + (uint32_t)x) * a.q_stride + (uint32_t)u * 16;   // + g * 4 * q_stride + s * 128
-    const uint32_t gstride = 4u * a.q_stride;
+    const unsigned char *qbase = smem + (q0 + (uint32_t)qofs) * a.q_stride + (uint32_t)u * 16;   // + g * GQ * q_stride + s * 128
+    const uint32_t gstride = (uint32_t)GQ * a.q_stride;
     const int top = (int)a.top;
 
     uint64_t list[QW];
     uint64_t thr[NGH];    // k-th best key of the lane's own queries
+    float thr_f[NGH];     // ... its score (-inf while the list is not full)
     int my_q[NGH];        // ... which are (wave-local index) 4 (gp + u0 NGH) + x
 #pragma unroll
     for (int q = 0; q < QW; ++q) list[q] = 0;
 #pragma unroll
     for (int gp = 0; gp < NGH; ++gp) {
         thr[gp] = 0;
-        my_q[gp] = 4 * (gp + u0 * NGH) + x;
+        thr_f[gp] = -__builtin_inff();
+        my_q[gp] = GQ * (gp + u0 * NGH) + qofs;
     }
 
     const uint32_t gw = blockIdx.x * NSTREAM + stream;
     const uint32_t tw = gridDim.x * NSTREAM;
-    const uint64_t n_tiles = (a.n_cand + 7) / 8;
+    const uint64_t n_tiles = (a.n_cand + TR - 1) / TR;
     const uint32_t nseg = a.nseg;
 
     // row pointer of this lane for a tile (the lane streams row 4rh + x of it); out-of-range tiles alias tile 0
     auto lane_row_ptr = [&](uint64_t tile) -> const unsigned char * {
-        uint64_t c = tile * 8 + (uint32_t)(4 * rh + x);
+        uint64_t c = tile * TR + (uint32_t)(rofs + x);
         if (c >= a.n_cand) c = 0;
         uint32_t id = HAS_IDS ? a.ids[c] : (uint32_t)c;
         if (HAS_IDS && id >= a.n_rows) id = 0;
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_f32_mfma_kernel(const ScanAr
         bool valid[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            const uint64_t c = tile * 8 + (uint32_t)(4 * rh + m);
+            const uint64_t c = tile * TR + (uint32_t)(rofs + m);
             valid[m] = c < a.n_cand;
             const uint64_t cc = valid[m] ? c : 0;
             uint32_t id = HAS_IDS ? a.ids[cc] : (uint32_t)cc;
@@ -253,12 +262,14 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_f32_mfma_kernel(const ScanAr
             }
             const bool mine = res_valid && q < a.nq;
             if (MODE == SCAN_SCORES) {
-                if (mine) a.scores[(uint64_t)q * a.scores_stride + (tile * 8 + (uint32_t)(4 * rh + my_m))] = score;
+                if (mine) a.scores[(uint64_t)q * a.scores_stride + (tile * TR + (uint32_t)(rofs + my_m))] = score;
             } else {
-                const uint64_t key = make_key(score, res_row);
-                bool c = mine && key > thr[gp];
+                // cheap reject on the score alone; ties with the k-th score and NaN (greatest in OrderedFloat) fall through
+                // to the exact key compare
+                bool c = mine && !(score < thr_f[gp]);
                 if (__ballot(c)) {
-                    c = c && a.del.live(res_row) && (!a.key_bound || key < a.key_bound[q]);
+                    const uint64_t key = make_key(score, res_row);
+                    c = c && key > thr[gp] && a.del.live(res_row) && (!a.key_bound || key < a.key_bound[q]);
                     uint64_t mask = __ballot(c);
                     while (mask) {
                         const int src = __builtin_ctzll(mask);
@@ -273,7 +284,10 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_f32_mfma_kernel(const ScanAr
                                     const uint64_t nt = readlane_u64(list[qq], top - 1);
 #pragma unroll
                                     for (int gg = 0; gg < NGH; ++gg)
-                                        if (my_q[gg] == qq) thr[gg] = nt;
+                                        if (my_q[gg] == qq) {
+                                            thr[gg] = nt;
+                                            thr_f[gg] = nt ? key_score(nt) : -__builtin_inff();
+                                        }
                                 }
                             }
                         }
@@ -309,7 +323,7 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_f32_mfma_kernel(const ScanAr
     }
 }
 
-template <int QW, int QSPLIT, int D, bool NT, int NWAVES, bool FAST, bool HAS_IDS, int MODE>
+template <int QW, int QSPLIT, int D, bool NT, int NWAVES, bool FAST, bool QH, bool HAS_IDS, int MODE>
 static int32_t launch_mfma_inst(hipStream_t st, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
     constexpr int QT = QW * QSPLIT;
     constexpr int MF_BLOCK = NWAVES * 64, MF_NW = NWAVES;
@@ -321,7 +335,7 @@ static int32_t launch_mfma_inst(hipStream_t st, const ScanArgs &a, int num_cus, 
     }
     lds = (lds + 15) & ~(size_t)15;
     QMX_REQUIRE(lds <= 160 * 1024, QMX_ERR_NOT_SUPPORTED, "query tile needs %zu B of LDS (> 160 KiB)", lds);
-    auto kfn = scan_f32_mfma_kernel<QW, QSPLIT, D, NT, NWAVES, FAST, HAS_IDS, MODE>;
+    auto kfn = scan_f32_mfma_kernel<QW, QSPLIT, D, NT, NWAVES, FAST, QH, HAS_IDS, MODE>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -330,7 +344,7 @@ static int32_t launch_mfma_inst(hipStream_t st, const ScanArgs &a, int num_cus, 
     int per_cu = 0;
     QMX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, MF_BLOCK, lds));
     if (per_cu < 1) per_cu = 1;
-    const uint64_t n_tiles = (a.n_cand + 7) / 8;
+    const uint64_t n_tiles = (a.n_cand + (QH ? 3 : 7)) / (QH ? 4 : 8);
     const uint64_t want = (n_tiles + NSTREAM - 1) / NSTREAM;
     const uint64_t cap = (uint64_t)num_cus * per_cu;
     uint32_t grid = (uint32_t)(want < cap ? want : cap);
@@ -345,14 +359,14 @@ static int32_t launch_mfma_inst(hipStream_t st, const ScanArgs &a, int num_cus, 
     return QMX_OK;
 }
 
-template <int QW, int QSPLIT, int D, bool NT, int NWAVES = 8, bool FAST = false>
+template <int QW, int QSPLIT, int D, bool NT, int NWAVES = 8, bool FAST = false, bool QH = false>
 static int32_t launch_mfma_qt(hipStream_t st, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid) {
     const bool ids = a.ids != nullptr;
     if (mode == SCAN_TOPK)
-        return ids ? launch_mfma_inst<QW, QSPLIT, D, NT, NWAVES, FAST, true, SCAN_TOPK>(st, a, num_cus, grid)
-                   : launch_mfma_inst<QW, QSPLIT, D, NT, NWAVES, FAST, false, SCAN_TOPK>(st, a, num_cus, grid);
-    return ids ? launch_mfma_inst<QW, QSPLIT, D, NT, NWAVES, FAST, true, SCAN_SCORES>(st, a, num_cus, grid)
-               : launch_mfma_inst<QW, QSPLIT, D, NT, NWAVES, FAST, false, SCAN_SCORES>(st, a, num_cus, grid);
+        return ids ? launch_mfma_inst<QW, QSPLIT, D, NT, NWAVES, FAST, QH, true, SCAN_TOPK>(st, a, num_cus, grid)
+                   : launch_mfma_inst<QW, QSPLIT, D, NT, NWAVES, FAST, QH, false, SCAN_TOPK>(st, a, num_cus, grid);
+    return ids ? launch_mfma_inst<QW, QSPLIT, D, NT, NWAVES, FAST, QH, true, SCAN_SCORES>(st, a, num_cus, grid)
+               : launch_mfma_inst<QW, QSPLIT, D, NT, NWAVES, FAST, QH, false, SCAN_SCORES>(st, a, num_cus, grid);
 }
 
 // qt in {8, 16, 32}; f32 rows, dot (or cosine on normalised rows), dim >= 32
@@ -369,9 +383,9 @@ int32_t launch_scan_f32_mfma(hipStream_t st, int qt, ScanMode mode, const ScanAr
             return launch_mfma_qt<16, 1, 12, true>(st, mode, a, num_cus, grid_out);
         case 32: {
             static const int variant = getenv("QMX_MFMA_VARIANT") ? atoi(getenv("QMX_MFMA_VARIANT")) : 0;   // tuning experiments
-            if (variant == 1) return launch_mfma_qt<32, 1, 12, true, 4>(st, mode, a, num_cus, grid_out);   // 1 wave / SIMD, 512 registers
-            if (variant == 2) return launch_mfma_qt<32, 1, 8, true, 4>(st, mode, a, num_cus, grid_out);
-            if (variant == 3) return launch_mfma_qt<32, 1, 4, true, 8>(st, mode, a, num_cus, grid_out);
+            if (variant == 1) return launch_mfma_qt<32, 1, 6, true, 8, false, true>(st, mode, a, num_cus, grid_out);   // query-half layout, generic loop
+            if (variant == 2 && a.nseg % 12 == 0) return launch_mfma_qt<32, 1, 6, true, 8, true, true>(st, mode, a, num_cus, grid_out);   // + ping-pong
+            if (variant == 3 && a.nseg % 24 == 0) return launch_mfma_qt<32, 1, 12, true, 8, true, true>(st, mode, a, num_cus, grid_out);
             if (a.nseg % 12 == 0 && getenv("QMX_MFMA_NO_FAST") == nullptr) return launch_mfma_qt<16, 2, 6, true, 8, true>(st, mode, a, num_cus, grid_out);
             return launch_mfma_qt<16, 2, 12, true>(st, mode, a, num_cus, grid_out);
         }
