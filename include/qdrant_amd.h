@@ -409,6 +409,12 @@ QMX_API int32_t qmx_hnsw_export_plain(const qmx_hnsw *g, uint32_t *reindex, uint
  * in [n][dim] f32 -> out [n][4 + actual_dim] reference rows. */
 QMX_API int32_t qmx_sq_encode(int32_t device_id, uint32_t distance, const qmx_sq_params *params,
                               const float *in, uint64_t n, uint32_t dim, void *out_rows);
+/* The `quantile = None` parameter fit of `EncodedVectorsU8::encode` (encoded_vectors_u8.rs:193, 516-527 ->
+ * `find_min_max_from_iter`, quantile.rs:19-33; multiplier :210-226): global min / max of the data on device (NaN never
+ * wins a comparison, as in the reference's fold), alpha = (max - min) / 127, offset = min.  Deterministic, unlike the
+ * quantile estimate.  in [n][dim] f32 host or device; fills every field of `out`. */
+QMX_API int32_t qmx_sq_fit_min_max(int32_t device_id, uint32_t distance, const float *in, uint64_t n, uint32_t dim,
+                                   qmx_sq_params *out);
 /* `EncodedVectorsPQ::encode_vector` (encoded_vectors_pq.rs:301-329): L2 argmin per chunk,
  * first minimum wins.  in [n][dim] f32 -> out [n][m] u8. */
 QMX_API int32_t qmx_pq_encode(int32_t device_id, const qmx_pq_params *params, const float *in,

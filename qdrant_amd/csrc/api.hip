@@ -1809,6 +1809,34 @@ int32_t qmx_sq_encode(int32_t device_id, uint32_t distance, const qmx_sq_params 
     return rc;
 }
 
+int32_t qmx_sq_fit_min_max(int32_t device_id, uint32_t distance, const float *in, uint64_t n, uint32_t dim, qmx_sq_params *out) {
+    QMX_REQUIRE(out && (n == 0 || in) && dim > 0, QMX_ERR_BAD_ARG, "bad argument");
+    QMX_REQUIRE(distance <= QMX_DISTANCE_MANHATTAN, QMX_ERR_BAD_ARG, "bad distance");
+    QMX_TRY(check_device(device_id, nullptr));
+    DevBuf bin;
+    const float *d_in = in;
+    if (n && !is_device_ptr(in)) {
+        QMX_TRY(bin.reserve((size_t)n * dim * 4));
+        if (hipMemcpy(bin.p, in, (size_t)n * dim * 4, hipMemcpyHostToDevice) != hipSuccess) { bin.release(); return QMX_ERR_OTHER; }
+        d_in = (const float *)bin.p;
+    }
+    float mn = 0.f, mx = 0.f;
+    const int32_t rc = launch_minmax_f32(nullptr, d_in, n * dim, &mn, &mx);
+    bin.release();
+    QMX_TRY(rc);
+    memset(out, 0, sizeof(*out));
+    out->actual_dim = ((dim + 15) / 16) * 16;                 // get_actual_dim (:622-624)
+    out->alpha = (mx - mn) / 127.0f;                          // alpha_offset_from_min_max (:523-527)
+    out->offset = mn;
+    out->invert = (distance == QMX_DISTANCE_EUCLID || distance == QMX_DISTANCE_MANHATTAN) ? 1 : 0;   // quantized_vectors.rs:232
+    float m;
+    if (distance == QMX_DISTANCE_DOT || distance == QMX_DISTANCE_COSINE) m = out->alpha * out->alpha;      // :210-221
+    else if (distance == QMX_DISTANCE_MANHATTAN) m = out->alpha;
+    else m = -2.0f * out->alpha * out->alpha;
+    out->multiplier = out->invert ? -m : m;
+    return QMX_OK;
+}
+
 int32_t qmx_pq_encode(int32_t device_id, const qmx_pq_params *params, const float *in, uint64_t n, uint32_t dim, uint8_t *out_codes) {
     QMX_REQUIRE(params && params->centroids && (n == 0 || (in && out_codes)) && dim > 0, QMX_ERR_BAD_ARG, "bad argument");
     QMX_REQUIRE(params->chunk_size >= 1 && params->chunk_size <= 256 && params->n_centroids >= 1 && params->n_centroids <= 256,

@@ -188,6 +188,7 @@ int32_t launch_sort_scored(hipStream_t st, const float *scores, const uint32_t *
 // Metric::preprocess + element casts (preprocess.hip)
 int32_t launch_cosine_preprocess_f32(hipStream_t st, const float *in, float *out, uint64_t n, uint32_t dim);
 int32_t launch_cast_f32(hipStream_t st, int dst_dtype, const float *in, void *out, uint64_t count);
+int32_t launch_minmax_f32(hipStream_t st, const float *in, uint64_t count, float *min_out, float *max_out);
 int32_t launch_synth_fill(hipStream_t st, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, float *out);
 int32_t launch_gather_rows(hipStream_t st, const void *rows, uint64_t row_stride, uint64_t row_bytes,
                            const uint32_t *ids, uint32_t n, uint64_t n_rows, void *out, int *err_flag);

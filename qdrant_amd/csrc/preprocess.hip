@@ -219,4 +219,56 @@ int32_t launch_gather_rows(hipStream_t st, const void *rows, uint64_t row_stride
     return QMX_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// find_min_max_from_iter (lib/quantization/src/quantile.rs:19-33): fold with `value < min` / `value > max` from
+// (f32::MAX, f32::MIN): NaN never replaces either.  min / max are order-independent, so a parallel reduction gives
+// the reference's result exactly.  out[0] = ordered bits of min, out[1] = ordered bits of max (score_to_ord).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void minmax_kernel(const float *in, uint64_t count, uint32_t *out) {
+    uint32_t lo = score_to_ord(3.402823466e+38f), hi = score_to_ord(-3.402823466e+38f);
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256) {
+        const float v = in[i];
+        if (v == v) {
+            const uint32_t o = score_to_ord(v);
+            lo = o < lo ? o : lo;
+            hi = o > hi ? o : hi;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t l2 = (uint32_t)__shfl_xor((int)lo, off, 64), h2 = (uint32_t)__shfl_xor((int)hi, off, 64);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&out[0], lo);
+        atomicMax(&out[1], hi);
+    }
+}
+int32_t launch_minmax_f32(hipStream_t st, const float *in, uint64_t count, float *min_out, float *max_out) {
+    uint32_t *d = nullptr;
+    QMX_HIP(hipMalloc((void **)&d, 8));
+    // host-side images of score_to_ord(f32::MAX) and score_to_ord(f32::MIN)
+    const uint32_t init[2] = {0x7F7FFFFFu | 0x80000000u, ~0xFF7FFFFFu};
+    hipError_t e = hipMemcpyAsync(d, init, 8, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && count) {
+        ::qmx::clear_stale_error();
+        hipLaunchKernelGGL(minmax_kernel, dim3(2048), dim3(256), 0, st, in, count, d);
+        e = hipGetLastError();
+    }
+    uint32_t res[2] = {init[0], init[1]};
+    if (e == hipSuccess) e = hipMemcpyAsync(res, d, 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    QMX_HIP(e);
+    auto unord = [](uint32_t o) {
+        union { uint32_t u; float f; } cv;
+        cv.u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+        return cv.f;
+    };
+    *min_out = unord(res[0]);
+    *max_out = unord(res[1]);
+    return QMX_OK;
+}
+
 }  // namespace qmx

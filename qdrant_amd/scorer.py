@@ -141,6 +141,15 @@ class ScalarQuantizer:
         mn, mx = np.float32(d.min()), np.float32(d.max())
         return cls(dim, distance, (mx - mn) / np.float32(127.0), mn)
 
+    @classmethod
+    def fit(cls, data, dim: int, distance: Distance, device_id: int = 0):
+        """Same fit on the device (`qmx_sq_fit_min_max`); `data`: numpy [n, dim] f32 or a torch CUDA tensor."""
+        on_device = hasattr(data, "data_ptr") and getattr(data, "is_cuda", False)
+        d = data if on_device else np.ascontiguousarray(data, dtype=np.float32)
+        p = F.SqParams()
+        F.check(F.lib().qmx_sq_fit_min_max(device_id, int(distance), F.ptr(d), int(d.shape[0]), int(dim), C.byref(p)))
+        return cls(dim, distance, p.alpha, p.offset)
+
     def params(self) -> "F.SqParams":
         p = F.SqParams()
         p.actual_dim = self.actual_dim

@@ -170,3 +170,21 @@ def test_ragged_score_points_and_counts(qa):
             assert len(r) == min(5, counts[i])
             assert set(r["idx"]) <= set(ids[i][:counts[i]])
             assert np.all(np.diff(r["score"]) <= 0)
+
+
+def test_sq_fit_min_max_on_device(qa):
+    """`quantile = None` fit (find_min_max_from_iter, quantile.rs:19-33): exact, NaN never wins, all derived fields."""
+    import ctypes as C
+    from qdrant_amd import _ffi as F
+    rng = np.random.default_rng(77)
+    for dist in (O.DOT, O.EUCLID, O.MANHATTAN, O.COSINE):
+        dim = 70
+        data = (rng.standard_normal((5000, dim)) * 3).astype(np.float32)
+        data[17, 3] = np.nan
+        ref = qa.ScalarQuantizer.from_min_max(data[~np.isnan(data).any(axis=1)], dim, _dist(qa, dist))
+        fit = qa.ScalarQuantizer.fit(data, dim, _dist(qa, dist))
+        assert fit.alpha == ref.alpha and fit.offset == ref.offset and fit.multiplier == ref.multiplier and fit.actual_dim == ref.actual_dim
+        p = F.SqParams()
+        F.check(F.lib().qmx_sq_fit_min_max(0, int(_dist(qa, dist)), F.ptr(data), len(data), dim, C.byref(p)))
+        osq = O.SqOracle(dist, dim, p.alpha, p.offset)
+        assert np.float32(osq.sq.multiplier) == np.float32(p.multiplier) and osq.sq.actual_dim == p.actual_dim and bool(osq.sq.invert) == bool(p.invert)
