@@ -409,6 +409,17 @@ QMX_API int32_t qmx_hnsw_export_plain(const qmx_hnsw *g, uint32_t *reindex, uint
  * in [n][dim] f32 -> out [n][4 + actual_dim] reference rows. */
 QMX_API int32_t qmx_sq_encode(int32_t device_id, uint32_t distance, const qmx_sq_params *params,
                               const float *in, uint64_t n, uint32_t dim, void *out_rows);
+/* PQ codebook training = `kmeans` (lib/quantization/src/kmeans.rs:9-169) for every chunk of `find_centroids`
+ * (encoded_vectors_pq.rs:342-407) on a GIVEN sample [n][dim] (the reference draws <= KMEANS_SAMPLE_SIZE = 10 000
+ * vectors with a randomly keyed Permutor: unpinned, so the sample is an input): first-k init, update_indexes,
+ * update_centroids with `threads` row ranges accumulated in f64 in row order and summed in range order (the
+ * reference's per-rayon-thread CentroidsCounter; pass its `max_kmeans_threads`), stop per chunk when
+ * sum(|old - new|) < accuracy (KMEANS_ACCURACY = 1e-5) or after max_iterations (KMEANS_MAX_ITERATIONS = 100).
+ * An empty cluster keeps its centroid (the reference re-seeds it with a random vector: unpinned).
+ * out_centroids [n_centroids][dim] (host or device) = `Metadata.centroids`; out_iterations [m] (host, may be NULL). */
+QMX_API int32_t qmx_pq_train(int32_t device_id, const float *sample, uint64_t n, uint32_t dim, uint32_t chunk_size,
+                             uint32_t n_centroids, uint32_t max_iterations, float accuracy, uint32_t threads,
+                             float *out_centroids, uint32_t *out_iterations);
 /* The `quantile = None` parameter fit of `EncodedVectorsU8::encode` (encoded_vectors_u8.rs:193, 516-527 ->
  * `find_min_max_from_iter`, quantile.rs:19-33; multiplier :210-226): global min / max of the data on device (NaN never
  * wins a comparison, as in the reference's fold), alpha = (max - min) / 127, offset = min.  Deterministic, unlike the

@@ -1070,6 +1070,73 @@ void qo_pq_train(uint32_t dim, uint32_t chunk_size, uint32_t n_centroids, const 
     free(acc); free(cnt);
 }
 
+/* kmeans (lib/quantization/src/kmeans.rs:9-169) on a GIVEN sample, per chunk as find_centroids calls it
+ * (encoded_vectors_pq.rs:342-407): first-k init (:27), update_indexes (:139-169: f32 sum of (a-b)^2, first minimum),
+ * update_centroids (:51-137): `threads` row ranges, each accumulated in f64 in row order, partials added in thread
+ * order, mean cast to f32, stop when sum(|old - new|) (f32, index order) < accuracy or after max_iters.
+ * Unpinned in the reference: the sample (Permutor) and the random re-seed of EMPTY clusters (:113-120) — an empty
+ * cluster keeps its previous centroid here.  iters_done[c] (optional) = update steps executed for chunk c. */
+void qo_pq_train_ex(uint32_t dim, uint32_t chunk_size, uint32_t n_centroids, const float *data, size_t n, uint32_t max_iters,
+                    float accuracy, uint32_t threads, float *centroids_out, uint32_t *iters_done) {
+    const uint32_t m = (dim + chunk_size - 1) / chunk_size;
+    if (threads == 0) threads = 1;
+    if (n <= n_centroids) {  /* encoded_vectors_pq.rs:354-362 */
+        memset(centroids_out, 0, sizeof(float) * (size_t)n_centroids * dim);
+        for (size_t i = 0; i < n; i++) memcpy(centroids_out + i * dim, data + i * dim, sizeof(float) * dim);
+        if (iters_done) for (uint32_t c = 0; c < m; c++) iters_done[c] = 0;
+        return;
+    }
+    double *acc = (double *)malloc(sizeof(double) * n_centroids * chunk_size);
+    double *part = (double *)malloc(sizeof(double) * n_centroids * chunk_size);
+    size_t *cnt = (size_t *)malloc(sizeof(size_t) * n_centroids);
+    uint32_t *idx = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    for (uint32_t c = 0; c < m; c++) {
+        uint32_t lo = c * chunk_size, hi = lo + chunk_size; if (hi > dim) hi = dim;
+        const uint32_t w = hi - lo;
+        for (uint32_t j = 0; j < n_centroids; j++)
+            memcpy(centroids_out + (size_t)j * dim + lo, data + (size_t)j * dim + lo, sizeof(float) * w);
+        uint32_t it = 0;
+        for (; it < max_iters; ) {
+            for (size_t r = 0; r < n; r++) {                      /* update_indexes */
+                const float *v = data + r * dim + lo;
+                float best = 3.40282347e+38f; uint32_t bj = 0;
+                for (uint32_t j = 0; j < n_centroids; j++) {
+                    const float *cen = centroids_out + (size_t)j * dim + lo;
+                    float sm = -0.0f;
+                    for (uint32_t i = 0; i < w; i++) { const float d = v[i] - cen[i]; sm += d * d; }
+                    if (sm < best) { best = sm; bj = j; }
+                }
+                idx[r] = bj;
+            }
+            memset(acc, 0, sizeof(double) * n_centroids * chunk_size);
+            memset(cnt, 0, sizeof(size_t) * n_centroids);
+            const size_t per = n / threads;
+            for (uint32_t t = 0; t < threads; t++) {              /* one CentroidsCounter per thread, summed in order */
+                const size_t r0 = per * t, r1 = (t + 1 == threads) ? n : per * (t + 1);
+                memset(part, 0, sizeof(double) * n_centroids * chunk_size);
+                for (size_t r = r0; r < r1; r++) {
+                    const float *v = data + r * dim + lo;
+                    cnt[idx[r]]++;
+                    for (uint32_t i = 0; i < w; i++) part[(size_t)idx[r] * chunk_size + i] += (double)v[i];
+                }
+                for (size_t k = 0; k < (size_t)n_centroids * chunk_size; k++) acc[k] += part[k];
+            }
+            float diff = -0.0f;
+            for (uint32_t j = 0; j < n_centroids; j++)
+                for (uint32_t i = 0; i < w; i++) {
+                    float *cp = &centroids_out[(size_t)j * dim + lo + i];
+                    const float nv = cnt[j] ? (float)(acc[(size_t)j * chunk_size + i] / (double)cnt[j]) : *cp;
+                    diff += fabsf(*cp - nv);
+                    *cp = nv;
+                }
+            it++;
+            if (diff < accuracy) break;
+        }
+        if (iters_done) iters_done[c] = it;
+    }
+    free(acc); free(part); free(cnt); free(idx);
+}
+
 /* ------------------------------------------------------------------------------------------
  * synthetic data: counter-based, integer-only (Irwin-Hall of four 16-bit uniforms), so the
  * device generator (qdrant_amd/csrc/synth.hip) reproduces it bit-for-bit without libm.

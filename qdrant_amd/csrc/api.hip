@@ -1809,6 +1809,43 @@ int32_t qmx_sq_encode(int32_t device_id, uint32_t distance, const qmx_sq_params 
     return rc;
 }
 
+int32_t qmx_pq_train(int32_t device_id, const float *sample, uint64_t n, uint32_t dim, uint32_t chunk_size, uint32_t n_centroids,
+                     uint32_t max_iterations, float accuracy, uint32_t threads, float *out_centroids, uint32_t *out_iterations) {
+    QMX_REQUIRE(out_centroids && (n == 0 || sample) && dim > 0, QMX_ERR_BAD_ARG, "bad argument");
+    QMX_REQUIRE(chunk_size >= 1 && chunk_size <= 256 && n_centroids >= 1 && n_centroids <= 256, QMX_ERR_BAD_ARG, "chunk_size / n_centroids out of range");
+    QMX_TRY(check_device(device_id, nullptr));
+    const uint32_t m = (dim + chunk_size - 1) / chunk_size;
+    const size_t cbytes = (size_t)n_centroids * dim * sizeof(float);
+    if (n <= n_centroids) {   // not enough vectors: the points are the centroids, the rest zeros (encoded_vectors_pq.rs:354-362)
+        std::vector<float> tmp((size_t)n_centroids * dim, 0.0f);
+        if (n) QMX_HIP(hipMemcpy(tmp.data(), sample, (size_t)n * dim * 4, hipMemcpyDefault));
+        QMX_HIP(hipMemcpy(out_centroids, tmp.data(), cbytes, hipMemcpyDefault));
+        if (out_iterations) for (uint32_t c = 0; c < m; ++c) out_iterations[c] = 0;
+        return QMX_OK;
+    }
+    DevBuf bin, bcen;
+    const float *d_in = sample;
+    float *d_cen = out_centroids;
+    int32_t rc = QMX_OK;
+    do {
+        if (!is_device_ptr(sample)) {
+            if ((rc = bin.reserve((size_t)n * dim * 4)) != QMX_OK) break;
+            if (hipMemcpy(bin.p, sample, (size_t)n * dim * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = QMX_ERR_OTHER; break; }
+            d_in = (const float *)bin.p;
+        }
+        const bool out_dev = is_device_ptr(out_centroids);
+        if (!out_dev) {
+            if ((rc = bcen.reserve(cbytes)) != QMX_OK) break;
+            d_cen = (float *)bcen.p;
+        }
+        if ((rc = launch_pq_train(nullptr, dim, chunk_size, n_centroids, d_in, n, max_iterations, accuracy, threads, d_cen, out_iterations)) != QMX_OK) break;
+        if (!out_dev && hipMemcpy(out_centroids, d_cen, cbytes, hipMemcpyDeviceToHost) != hipSuccess) rc = QMX_ERR_OTHER;
+    } while (0);
+    bin.release();
+    bcen.release();
+    return rc;
+}
+
 int32_t qmx_sq_fit_min_max(int32_t device_id, uint32_t distance, const float *in, uint64_t n, uint32_t dim, qmx_sq_params *out) {
     QMX_REQUIRE(out && (n == 0 || in) && dim > 0, QMX_ERR_BAD_ARG, "bad argument");
     QMX_REQUIRE(distance <= QMX_DISTANCE_MANHATTAN, QMX_ERR_BAD_ARG, "bad distance");

@@ -166,6 +166,8 @@ int32_t launch_pq_lut(hipStream_t st, uint32_t distance, uint32_t dim, const qmx
 int32_t launch_pq_internal(hipStream_t st, uint32_t distance, uint32_t dim, const qmx_pq_params &pq, const float *d_centroids,
                            const void *rows, uint64_t row_stride, uint64_t n_rows, const uint32_t *a_ids, const uint32_t *b_ids,
                            uint32_t n, float *out, int *err_flag);
+int32_t launch_pq_train(hipStream_t st, uint32_t dim, uint32_t chunk_size, uint32_t n_centroids, const float *d_data, uint64_t n,
+                        uint32_t max_iters, float accuracy, uint32_t threads, float *d_centroids, uint32_t *iters_host);
 int32_t launch_pq_encode(hipStream_t st, uint32_t dim, const qmx_pq_params &pq, const float *d_centroids, const float *d_in,
                          uint64_t n, uint8_t *d_codes);
 // query tile packing: preprocessed f32 queries -> element type, padded, + aux (preprocess.hip)

@@ -407,4 +407,100 @@ int32_t launch_pq_encode(hipStream_t st, uint32_t dim, const qmx_pq_params &pq, 
     return QMX_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// k-means on a given sample (kmeans.rs:9-169, called per chunk by find_centroids, encoded_vectors_pq.rs:342-407).
+// One launch of pq_encode_kernel is update_indexes for EVERY chunk at once (chunks are independent k-means problems);
+// pq_train_update_kernel is update_centroids: thread (chunk c, centroid j, component i) walks the sample in row order
+// inside each of the `threads` row ranges, f64 partial per range, partials added in range order — the reference's
+// CentroidsCounter per rayon thread — then the mean, cast to f32; an empty cluster keeps its centroid (the reference
+// re-seeds it randomly: unpinned).  pq_train_diff_kernel: sum(|old - new|) in f32, index order, per chunk -> done flag.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pq_train_update_kernel(PqGeom g, const float *data, uint64_t n, const uint8_t *codes, uint32_t threads,
+                                                              const uint8_t *done, float *centroids, float *absdiff) {
+    const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t per_chunk = g.ncent * g.chunk;
+    const uint32_t c = (uint32_t)(gid / per_chunk);
+    if (c >= g.m) return;
+    const uint32_t rem = (uint32_t)(gid % per_chunk), j = rem / g.chunk, i = rem % g.chunk;
+    const uint32_t lo = c * g.chunk, hi = min(lo + g.chunk, g.dim);
+    if (lo + i >= hi) { absdiff[gid] = 0.0f; return; }
+    float *cp = centroids + (uint64_t)j * g.dim + lo + i;
+    if (done[c]) { absdiff[gid] = 0.0f; return; }
+    double acc = 0.0;
+    uint64_t cnt = 0;
+    const uint64_t per = n / threads;
+    for (uint32_t t = 0; t < threads; ++t) {
+        const uint64_t r0 = per * t, r1 = (t + 1 == threads) ? n : per * (t + 1);
+        double part = 0.0;
+        for (uint64_t r = r0; r < r1; ++r)
+            if (codes[r * g.m + c] == j) {
+                part += (double)data[r * g.dim + lo + i];
+                ++cnt;
+            }
+        acc += part;
+    }
+    const float old = *cp;
+    const float nv = cnt ? (float)(acc / (double)cnt) : old;
+    absdiff[gid] = __builtin_fabsf(old - nv);
+    *cp = nv;
+}
+__global__ void pq_train_diff_kernel(PqGeom g, const float *absdiff, float accuracy, uint8_t *done, uint32_t *iters) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= g.m || done[c]) return;
+    const uint32_t lo = c * g.chunk, hi = min(lo + g.chunk, g.dim), w = hi - lo;
+    float diff = -0.0f;
+    for (uint32_t j = 0; j < g.ncent; ++j)
+        for (uint32_t i = 0; i < w; ++i) diff += absdiff[(uint64_t)c * g.ncent * g.chunk + (uint64_t)j * g.chunk + i];
+    iters[c] += 1;
+    if (diff < accuracy) done[c] = 1;
+}
+
+int32_t launch_pq_train(hipStream_t st, uint32_t dim, uint32_t chunk_size, uint32_t n_centroids, const float *d_data, uint64_t n,
+                        uint32_t max_iters, float accuracy, uint32_t threads, float *d_centroids, uint32_t *iters_host) {
+    qmx_pq_params pq = {};
+    pq.chunk_size = chunk_size;
+    pq.n_centroids = n_centroids;
+    const PqGeom g = make_geom(QMX_DISTANCE_DOT, dim, pq);
+    if (threads == 0) threads = 1;
+    // first-k init (kmeans.rs:27): centroid j = sample row j, every chunk
+    QMX_HIP(hipMemcpyAsync(d_centroids, d_data, (size_t)n_centroids * dim * sizeof(float), hipMemcpyDeviceToDevice, st));
+    uint8_t *d_codes = nullptr, *d_done = nullptr;
+    float *d_abs = nullptr;
+    uint32_t *d_iters = nullptr;
+    const size_t n_thr = (size_t)g.m * n_centroids * chunk_size;
+    int32_t rc = QMX_OK;
+    do {
+        if (hipMalloc((void **)&d_codes, (size_t)n * g.m) != hipSuccess || hipMalloc((void **)&d_done, g.m) != hipSuccess ||
+            hipMalloc((void **)&d_abs, n_thr * sizeof(float)) != hipSuccess || hipMalloc((void **)&d_iters, (size_t)g.m * 4) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("out of device memory for k-means scratch");
+            rc = QMX_ERR_OUT_OF_MEMORY;
+            break;
+        }
+        if (hipMemsetAsync(d_done, 0, g.m, st) != hipSuccess || hipMemsetAsync(d_iters, 0, (size_t)g.m * 4, st) != hipSuccess) { rc = QMX_ERR_OTHER; break; }
+        std::vector<uint8_t> done(g.m);
+        for (uint32_t it = 0; it < max_iters && rc == QMX_OK; ++it) {
+            if ((rc = launch_pq_encode(st, dim, pq, d_centroids, d_data, n, d_codes)) != QMX_OK) break;     // update_indexes
+            ::qmx::clear_stale_error();
+            hipLaunchKernelGGL(pq_train_update_kernel, dim3((uint32_t)((n_thr + 255) / 256)), dim3(256), 0, st, g, d_data, n, d_codes, threads,
+                               d_done, d_centroids, d_abs);
+            hipLaunchKernelGGL(pq_train_diff_kernel, dim3((g.m + 63) / 64), dim3(64), 0, st, g, d_abs, accuracy, d_done, d_iters);
+            if (hipGetLastError() != hipSuccess) { rc = QMX_ERR_OTHER; break; }
+            if ((it & 3) == 3 || it + 1 == max_iters) {           // all chunks converged?  (poll every 4 iterations)
+                if (hipMemcpyAsync(done.data(), d_done, g.m, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = QMX_ERR_OTHER; break; }
+                bool all = true;
+                for (uint8_t d : done) all = all && d;
+                if (all) break;
+            }
+        }
+        if (rc == QMX_OK && iters_host && hipMemcpyAsync(iters_host, d_iters, (size_t)g.m * 4, hipMemcpyDeviceToHost, st) != hipSuccess) rc = QMX_ERR_OTHER;
+        if (rc == QMX_OK && hipStreamSynchronize(st) != hipSuccess) rc = QMX_ERR_OTHER;
+    } while (0);
+    if (d_codes) (void)hipFree(d_codes);
+    if (d_done) (void)hipFree(d_done);
+    if (d_abs) (void)hipFree(d_abs);
+    if (d_iters) (void)hipFree(d_iters);
+    return rc;
+}
+
 }  // namespace qmx

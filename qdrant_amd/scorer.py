@@ -243,6 +243,18 @@ class ProductQuantizer:
         return out
 
 
+def pq_train(sample, dim: int, chunk_size: int, n_centroids: int = 256, max_iterations: int = 100, accuracy: float = 1e-5,
+             threads: int = 1, device_id: int = 0):
+    """`find_centroids` / `kmeans` on a given sample, on the device (qmx_pq_train) -> (centroids [n_centroids, dim], iterations [m])."""
+    s = np.ascontiguousarray(sample, dtype=np.float32)
+    cen = np.zeros((n_centroids, dim), dtype=np.float32)
+    m = (dim + chunk_size - 1) // chunk_size
+    iters = np.zeros(m, dtype=np.uint32)
+    F.check(F.lib().qmx_pq_train(device_id, F.ptr(s), s.shape[0], dim, chunk_size, n_centroids, max_iterations, float(accuracy), threads,
+                                 F.ptr(cen), F.ptr(iters)))
+    return cen, iters
+
+
 class EncodedVectorsPQ(VectorStorage):
     """Device-resident `EncodedVectorsPQ` storage: rows = [n, m] u8 centroid indices."""
 

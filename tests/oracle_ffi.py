@@ -90,6 +90,7 @@ _sig("qo_pq_encode_query", None, [C.POINTER(Pq), _P, _P])
 _sig("qo_pq_score", _f, [C.POINTER(Pq), _P, _P, C.c_int])
 _sig("qo_pq_score_internal", _f, [C.POINTER(Pq), _P, _P])
 _sig("qo_pq_train", None, [C.c_uint32, C.c_uint32, C.c_uint32, _P, C.c_size_t, C.c_int, _P])
+_sig("qo_pq_train_ex", None, [C.c_uint32, C.c_uint32, C.c_uint32, _P, C.c_size_t, C.c_uint32, C.c_float, C.c_uint32, _P, _P])
 
 lib = _lib
 _NP = {F32: np.float32, F16: np.uint16, U8: np.uint8}
@@ -290,6 +291,16 @@ class PqOracle:
         cen = np.zeros((n_centroids, dim), dtype=np.float32)
         _lib.qo_pq_train(dim, chunk_size, n_centroids, _p(data), data.shape[0], iters, _p(cen))
         return cen
+
+    @staticmethod
+    def train_ex(data, dim, chunk_size, n_centroids, max_iters=100, accuracy=1e-5, threads=1):
+        """kmeans.rs on a given sample: returns (centroids [n_centroids, dim], update steps per chunk)."""
+        data = f32(data)
+        cen = np.zeros((n_centroids, dim), dtype=np.float32)
+        m = (dim + chunk_size - 1) // chunk_size
+        iters = np.zeros(m, dtype=np.uint32)
+        _lib.qo_pq_train_ex(dim, chunk_size, n_centroids, _p(data), data.shape[0], max_iters, float(accuracy), threads, _p(cen), _p(iters))
+        return cen, iters
 
     def encode(self, vectors):
         v = f32(vectors)

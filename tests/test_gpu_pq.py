@@ -137,3 +137,26 @@ def test_pq_brute_force_topk(qa, dist):
         assert np.array_equal(got[i]["score"].view(np.uint32), s[order].view(np.uint32))
     sc = qa.new_raw_scorer(queries[:2], st)
     assert np.array_equal(sc.score_bytes(codes[:50]).view(np.uint32), sc.score_points(np.arange(50, dtype=np.uint32)).view(np.uint32))
+
+
+@pytest.mark.parametrize("dim,chunk,ncent,n,threads", [(64, 8, 256, 3000, 1), (70, 16, 100, 1500, 3), (32, 1, 16, 500, 8), (48, 16, 256, 200, 1)])
+def test_pq_train_kmeans_bit_exact(qa, dim, chunk, ncent, n, threads):
+    """k-means on a given sample (kmeans.rs): centroids and per-chunk iteration counts equal the oracle's restatement,
+    bit for bit, for any number of accumulation ranges (`max_kmeans_threads`)."""
+    rng = np.random.default_rng(dim + n)
+    centers = rng.standard_normal((20, dim)).astype(np.float32) * 2
+    sample = (centers[rng.integers(0, 20, n)] + rng.standard_normal((n, dim)).astype(np.float32)).astype(np.float32)
+    want, witers = O.PqOracle.train_ex(sample, dim, chunk, ncent, max_iters=25, accuracy=1e-5, threads=threads)
+    got, giters = qa.pq_train(sample, dim, chunk, ncent, max_iterations=25, accuracy=1e-5, threads=threads)
+    assert giters.tolist() == witers.tolist()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    if n > ncent:       # a usable codebook: encoding with it beats encoding with the first-k init
+        quant = qa.ProductQuantizer(dim, qa.Distance.Euclid, chunk, got)
+        codes = quant.encode(sample)
+        m = quant.m
+        recon = np.concatenate([got[codes[:, c], c * chunk:min((c + 1) * chunk, dim)] for c in range(m)], axis=1)
+        init = np.zeros_like(got)
+        init[:] = sample[:ncent] if n >= ncent else 0
+        codes0 = qa.ProductQuantizer(dim, qa.Distance.Euclid, chunk, init).encode(sample)
+        recon0 = np.concatenate([init[codes0[:, c], c * chunk:min((c + 1) * chunk, dim)] for c in range(m)], axis=1)
+        assert ((sample - recon) ** 2).sum() < ((sample - recon0) ** 2).sum()

@@ -131,8 +131,8 @@ def main():
             scorer = qa.new_raw_scorer(queries, enc)
         else:
             chunk = 16
-            sample = rows[:20000].cpu().numpy()
-            cen = O.PqOracle.train(sample, dim, chunk, 256, iters=5)
+            sample = rows[:10000].cpu().numpy()
+            cen, _ = qa.pq_train(sample, dim, chunk, 256, max_iterations=100, accuracy=1e-5)
             quant = qa.ProductQuantizer(dim, qa.Distance.Dot, chunk, cen)
             p = quant.params()
             codes_d = torch.empty((n, quant.m), dtype=torch.uint8, device=dev)
