@@ -1468,6 +1468,9 @@ static int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint3
     h.ef = ef; h.top = top; h.nq = q->nq;
     h.out = d_out; h.out_counts = d_counts; h.out_scored = d_scored;
     h.lds_query_bytes = q->q_stride <= HNSW_LDS_QUERY_MAX ? q->q_stride : 0;
+    // A PQ LUT of more than half the LDS leaves one search per CU; the walk is a chain of dependent memory round trips,
+    // so many searches per CU with the LUT read through L2 win (measured: tools/bench_hnsw.py)
+    if (s->dtype == QMX_DTYPE_PQ && q->q_stride > 16 * 1024 && getenv("QMX_HNSW_PQ_LDS_LUT") == nullptr) h.lds_query_bytes = 0;
     h.log_cap = HNSW_LOG_CAP;
     if (const char *e = getenv("QMX_HNSW_LOG_CAP")) {   // tests: force the whole-bitmap clear path
         const long v = atol(e);

@@ -275,17 +275,40 @@ struct HopPQ {
         const uint8_t *codes = reinterpret_cast<const uint8_t *>(a.rows) + (uint64_t)id * a.row_stride;
         const uint32_t m = a.pq_m, ncent = a.pq_ncent, m4 = m & ~3u;
         float l = 0.0f;
-        if ((reinterpret_cast<uintptr_t>(codes) & 3) == 0) {
-            for (uint32_t c = 0; c < m4; c += 4) {
+        uint32_t c = 0;
+        if ((reinterpret_cast<uintptr_t>(codes) & 15) == 0 && m4 <= 128) {
+            // the walk is latency-bound (one search per CU when the LUT fills the LDS): fetch the whole code row with
+            // independent loads first (one HBM round trip), then 8 LUT gathers in flight per 8 adds, adds in chunk order
+            uint4 w[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) w[k] = (uint32_t)(16 * k) < m4 ? *reinterpret_cast<const uint4 *>(codes + 16 * k) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                if ((uint32_t)(32 * h) < m4) {
+                    const uint32_t ws[8] = {w[2 * h].x, w[2 * h].y, w[2 * h].z, w[2 * h].w, w[2 * h + 1].x, w[2 * h + 1].y, w[2 * h + 1].z, w[2 * h + 1].w};
+                    float v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const uint32_t cc = 32 * h + 4 * k;
+                        v[k] = cc < m4 ? lut[(cc + (uint32_t)sub) * ncent + ((ws[k] >> (8 * sub)) & 0xFF)] : 0.0f;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if ((uint32_t)(32 * h + 4 * k) < m4) l += v[k];
+                }
+            }
+            c = m4;
+        } else if ((reinterpret_cast<uintptr_t>(codes) & 3) == 0) {
+            for (; c < m4; c += 4) {
                 const uint32_t w = *reinterpret_cast<const uint32_t *>(codes + c);
                 l += lut[(c + (uint32_t)sub) * ncent + ((w >> (8 * sub)) & 0xFF)];
             }
         } else {
-            for (uint32_t c = 0; c < m4; c += 4) l += lut[(c + (uint32_t)sub) * ncent + codes[c + (uint32_t)sub]];
+            for (; c < m4; c += 4) l += lut[(c + (uint32_t)sub) * ncent + codes[c + (uint32_t)sub]];
         }
         const float x = l + dpp_f32<DPP_QUAD_XOR2>(l);          // lane 0: l0 + l2, lane 1: l1 + l3
         float sum = x + dpp_f32<DPP_QUAD_XOR1>(x);              // lane 0: (l0 + l2) + (l1 + l3)
-        for (uint32_t c = m4; c < m; ++c) sum += lut[c * ncent + codes[c]];
+        for (c = m4; c < m; ++c) sum += lut[c * ncent + codes[c]];
         return sum;
     }
 };
