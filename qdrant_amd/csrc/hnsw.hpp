@@ -38,13 +38,19 @@ namespace qmx {
 template <class P>
 struct HopRow {
     static constexpr int LPI = 8;
+    static constexpr bool MULTI = true;     // score_multi<R>: R rows per 8-lane group in one pass
     static __device__ __forceinline__ float score(const ScanArgs &a, const unsigned char *qp, uint32_t id, int sub) {
         return group_score<P>(a, qp, id, sub);
+    }
+    template <int R>
+    static __device__ __forceinline__ void score_multi(const ScanArgs &a, const unsigned char *qp, const uint32_t (&ids)[R], int sub, float (&out)[R]) {
+        group_score_multi<P, R>(a, qp, ids, sub, out);
     }
 };
 template <class S>
 struct HopSmall {
     static constexpr int LPI = 1;
+    static constexpr bool MULTI = false;
     static __device__ __forceinline__ float score(const ScanArgs &a, const unsigned char *qp, uint32_t id, int) {
         return S::score(qp, reinterpret_cast<const unsigned char *>(a.rows) + (uint64_t)id * a.row_stride, id, a);
     }
@@ -118,13 +124,38 @@ __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
 }
 
 // scores hop_ids[0..k) into hop_scores[0..k); uniform control flow, k <= 64
+template <class H, int R>
+__device__ __forceinline__ void hop_score_pass(const ScanArgs &a, const unsigned char *qp, const uint32_t *hop_ids, float *hop_scores,
+                                               uint32_t base, uint32_t k, int sub, int g) {
+    constexpr int IPP = 64 / H::LPI;
+    uint32_t ids[R];
+    float sc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t j = base + (uint32_t)(r * IPP + g);
+        ids[r] = hop_ids[j < k ? j : 0];
+    }
+    H::template score_multi<R>(a, qp, ids, sub, sc);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t j = base + (uint32_t)(r * IPP + g);
+        if (j < k && sub == 0) hop_scores[j] = sc[r];
+    }
+}
+
 template <class H>
 __device__ __forceinline__ void hop_score(const ScanArgs &a, const unsigned char *qp, const uint32_t *hop_ids,
                                           float *hop_scores, uint32_t k, int lane) {
     constexpr int IPP = 64 / H::LPI;
     const int sub = lane % H::LPI, g = lane / H::LPI;
     __syncthreads();   // hop_ids written by other lanes
-    for (uint32_t base = 0; base < k; base += IPP) {
+    uint32_t base = 0;
+    if constexpr (H::MULTI) {
+        // the usual hop (9..32 fresh neighbours) in ONE pass with 2 or 4 rows per lane group: one round of gathers
+        for (; base + 2 * IPP < k; base += 4 * IPP) hop_score_pass<H, 4>(a, qp, hop_ids, hop_scores, base, k, sub, g);
+        for (; base + IPP < k; base += 2 * IPP) hop_score_pass<H, 2>(a, qp, hop_ids, hop_scores, base, k, sub, g);
+    }
+    for (; base < k; base += IPP) {
         const uint32_t j = base + (uint32_t)g;
         const bool on = j < k;
         const uint32_t id = hop_ids[on ? j : 0];

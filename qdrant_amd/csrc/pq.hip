@@ -270,6 +270,7 @@ int32_t launch_pairs_pq(hipStream_t st, const ScanArgs &a, const PairSel &sel, u
 // sub, sub+4, ... added in order), the quad is folded as (l0 + l2) + (l1 + l3) like pq_score_row.
 struct HopPQ {
     static constexpr int LPI = 4;
+    static constexpr bool MULTI = false;
     static __device__ __forceinline__ float score(const ScanArgs &a, const unsigned char *qp, uint32_t id, int sub) {
         const float *lut = reinterpret_cast<const float *>(qp);
         const uint8_t *codes = reinterpret_cast<const uint8_t *>(a.rows) + (uint64_t)id * a.row_stride;

@@ -399,6 +399,48 @@ __device__ __forceinline__ float group_score(const ScanArgs &a, const unsigned c
     return P::finish(acc[0][0], raux[0], qp, row, id, a);
 }
 
+// R rows of one 8-lane group against one query in a single pass: R x UNROLL row pieces in flight per lane instead of
+// UNROLL (the HNSW hop scores <= m0 rows and is bound by the round-trip time of its gathers).  Same accumulators,
+// same order per row as group_score: same bits.
+template <class P, int R>
+__device__ __forceinline__ void group_score_multi(const ScanArgs &a, const unsigned char *qp, const uint32_t (&ids)[R], int t, float (&out)[R]) {
+    constexpr int NRA = P::NRAUX > 0 ? P::NRAUX : 1;
+    const int piece = lane_piece(t);
+    const int piece_off = piece * 16;
+    const bool piece_in_rem = piece < (int)a.rem_pieces;
+    const unsigned char *rp[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) rp[r] = reinterpret_cast<const unsigned char *>(a.rows) + (uint64_t)ids[r] * a.row_stride + piece_off;
+    typename P::acc_t acc[1][R][P::NACC];
+    typename P::acc_t raux[R][NRA];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int k = 0; k < P::NACC; ++k) acc[0][r][k] = 0;
+#pragma unroll
+        for (int k = 0; k < NRA; ++k) raux[r][k] = 0;
+    }
+#pragma unroll 4
+    for (uint32_t s = 0; s < a.nseg; ++s) {
+        uint4 v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = *reinterpret_cast<const uint4 *>(rp[r] + (uint64_t)s * 128);
+        scan_step<P, 1, R>(acc, raux, v, qp + s * 128 + piece_off, 0, true);
+    }
+    if (a.rem_pieces) {
+        uint4 v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            v[r] = make_uint4(0, 0, 0, 0);
+            if (piece_in_rem) v[r] = *reinterpret_cast<const uint4 *>(rp[r] + (uint64_t)a.nseg * 128);
+        }
+        scan_step<P, 1, R>(acc, raux, v, qp + a.nseg * 128 + piece_off, 0, piece_in_rem);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        out[r] = P::finish(acc[0][r], raux[r], qp, reinterpret_cast<const unsigned char *>(a.rows) + (uint64_t)ids[r] * a.row_stride, ids[r], a);
+}
+
 template <class P>
 __global__ __launch_bounds__(PAIR_BLOCK) void pair_kernel(const ScanArgs a, const PairSel sel, uint64_t n_items) {
     constexpr int NW = PAIR_BLOCK / WAVE;
