@@ -1053,6 +1053,8 @@ struct qmx_hnsw {
     uint32_t *d_reindex = nullptr, *d_neighbors = nullptr, *d_ep_ids = nullptr, *d_ep_levels = nullptr, *d_xp_ids = nullptr,
              *d_xp_levels = nullptr;
     uint64_t *d_level_offsets = nullptr, *d_offsets = nullptr;
+    uint32_t *d_l0 = nullptr;     // packed level 0 [n_points][l0_stride]: count, links (built when every list fits 63 links)
+    uint32_t l0_stride = 0;
     // host copy of the plain arrays (graphs built by qmx_hnsw_build; empty otherwise) for qmx_hnsw_export_plain
     std::vector<uint32_t> h_reindex, h_neighbors, h_ep_ids, h_ep_levels, h_xp_ids, h_xp_levels;
     std::vector<uint64_t> h_level_offsets, h_offsets;
@@ -1061,7 +1063,7 @@ struct qmx_hnsw {
 int32_t qmx_hnsw_destroy(qmx_hnsw *g) {
     if (!g) return QMX_OK;
     (void)hipSetDevice(g->device);
-    void *ptrs[] = {g->d_reindex, g->d_neighbors, g->d_ep_ids, g->d_ep_levels, g->d_xp_ids, g->d_xp_levels, g->d_level_offsets, g->d_offsets};
+    void *ptrs[] = {g->d_reindex, g->d_neighbors, g->d_ep_ids, g->d_ep_levels, g->d_xp_ids, g->d_xp_levels, g->d_level_offsets, g->d_offsets, g->d_l0};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete g;
@@ -1126,6 +1128,22 @@ int32_t qmx_hnsw_create(const qmx_hnsw_desc *d, qmx_hnsw **out) {
         if ((rc = upload_array(&g->d_xp_ids, d->extra_entry_point_ids, d->n_extra_entry_points)) != QMX_OK) break;
         if ((rc = upload_array(&g->d_xp_levels, d->extra_entry_point_levels, d->n_extra_entry_points)) != QMX_OK) break;
     } while (0);
+    // packed level-0 table (one round trip per hop instead of two); lists longer than m0 or 63 keep the CSR path
+    if (rc == QMX_OK && d->n_points && d->m0 <= 63 && getenv("QMX_HNSW_NO_PACKED_L0") == nullptr) {
+        const uint32_t stride = d->m0 + 1;
+        bool fits = true;
+        if (!is_device_ptr(d->offsets))
+            for (uint64_t i = 0; i < d->n_points && fits; ++i) fits = d->offsets[i + 1] - d->offsets[i] <= d->m0;
+        else fits = false;   // device-side arrays are not inspected
+        if (fits && hipMalloc((void **)&g->d_l0, (size_t)d->n_points * stride * 4) == hipSuccess) {
+            g->l0_stride = stride;
+            rc = launch_hnsw_pack_level0(nullptr, g->d_offsets, g->d_neighbors, d->n_points, stride, g->d_l0);
+            if (rc == QMX_OK && hipDeviceSynchronize() != hipSuccess) rc = QMX_ERR_OTHER;
+        } else {
+            (void)hipGetLastError();
+            g->d_l0 = nullptr;
+        }
+    }
     if (rc != QMX_OK) {
         qmx_hnsw_destroy(g);
         return rc;
@@ -1428,6 +1446,7 @@ int32_t qmx_hnsw_build(const qmx_segment *seg, const qmx_hnsw_build_params *bp, 
         g->n_ep = dev->n_ep; g->n_xp = dev->n_xp; g->n_offsets = dev->n_offsets; g->n_neighbors = dev->n_neighbors;
         g->d_reindex = dev->d_reindex; g->d_neighbors = dev->d_neighbors; g->d_ep_ids = dev->d_ep_ids; g->d_ep_levels = dev->d_ep_levels;
         g->d_xp_ids = dev->d_xp_ids; g->d_xp_levels = dev->d_xp_levels; g->d_level_offsets = dev->d_level_offsets; g->d_offsets = dev->d_offsets;
+        g->d_l0 = dev->d_l0; g->l0_stride = dev->l0_stride;
         delete dev;
 #undef QB
 #undef QH
@@ -1462,6 +1481,7 @@ static int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint3
     HnswArgs h;
     memset(&h, 0, sizeof(h));
     h.reindex = g->d_reindex; h.level_offsets = g->d_level_offsets; h.offsets = g->d_offsets; h.neighbors = g->d_neighbors;
+    h.l0 = g->d_l0; h.l0_stride = g->l0_stride;
     h.n_points = g->n_points; h.n_levels = g->n_levels; h.m = g->m; h.m0 = g->m0;
     h.ep_ids = g->d_ep_ids; h.ep_levels = g->d_ep_levels; h.n_ep = g->n_ep;
     h.xp_ids = g->d_xp_ids; h.xp_levels = g->d_xp_levels; h.n_xp = g->n_xp;

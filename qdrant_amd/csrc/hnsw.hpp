@@ -266,12 +266,23 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
         const uint64_t ck = beam.pop_best(lane);
         if (ck == 0) break;
         const uint32_t cand = key_idx(ck);
-        const uint64_t o0 = h.offsets[cand], o1 = h.offsets[(uint64_t)cand + 1];
+        // links of `cand` on level 0: the packed table needs ONE round trip (count and links are independent loads of the
+        // same row), the CSR arrays two (offsets, then neighbors)
+        uint64_t o0 = 0, o1 = 0;
+        uint32_t packed_id = 0;
+        if (h.l0) {
+            const uint32_t *rowp = h.l0 + (uint64_t)cand * h.l0_stride;
+            packed_id = (uint32_t)lane + 1 < h.l0_stride ? rowp[lane + 1] : 0;
+            o1 = rowp[0];
+        } else {
+            o0 = h.offsets[cand];
+            o1 = h.offsets[(uint64_t)cand + 1];
+        }
         uint32_t remaining = h.m0;
         for (uint64_t base = o0; base < o1 && remaining > 0; base += 64) {
             const uint64_t i = base + (uint64_t)lane;
             const bool on = i < o1;
-            const uint32_t id = on ? h.neighbors[i] : 0;
+            const uint32_t id = h.l0 ? (on ? packed_id : 0) : (on ? h.neighbors[i] : 0);
             const bool live = on && id < h.n_points && a.del.live(id);
             const uint32_t bit = 1u << (id & 31);
             const uint32_t old = live ? atomicOr(&vis[id >> 5], bit) : bit;

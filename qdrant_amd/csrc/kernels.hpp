@@ -55,6 +55,8 @@ struct HnswArgs {
     const uint64_t *level_offsets;  // [n_levels + 1] first offsets-slot of each level
     const uint64_t *offsets;        // [n_slots + 1]  start of each links list inside `neighbors`
     const uint32_t *neighbors;
+    const uint32_t *l0;             // optional packed level 0: l0[p * l0_stride] = count, then the links (one round trip per hop)
+    uint32_t l0_stride;
     uint32_t n_points, n_levels, m, m0;
     const uint32_t *ep_ids, *ep_levels;   // EntryPoints::entry_points
     uint32_t n_ep;
@@ -75,6 +77,7 @@ struct HnswArgs {
 int32_t launch_hnsw_dense(hipStream_t st, int dtype, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_pq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
+int32_t launch_hnsw_pack_level0(hipStream_t st, const uint64_t *offsets, const uint32_t *neighbors, uint32_t n_points, uint32_t stride, uint32_t *l0);
 constexpr uint32_t HNSW_MAX_EF = 512;
 // HNSW build (hnsw_build.hpp)
 constexpr uint32_t HNSW_BUILD_MAX_LEVELS = 16;   // levels 0..15 (P(level >= 16) ~ m^-15.5)

@@ -176,4 +176,22 @@ int32_t launch_sort_scored(hipStream_t st, const float *scores, const uint32_t *
     return QMX_OK;
 }
 
+// packed level-0 link table of an HNSW graph: row p = [count, links...] (hnsw.hpp reads it with one round trip per hop)
+__global__ void hnsw_pack_level0_kernel(const uint64_t *offsets, const uint32_t *neighbors, uint32_t n_points, uint32_t stride, uint32_t *l0) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t p = gid / stride;
+    const uint32_t slot = (uint32_t)(gid % stride);
+    if (p >= n_points) return;
+    const uint64_t o0 = offsets[p], len = offsets[p + 1] - o0;
+    l0[gid] = slot == 0 ? (uint32_t)len : (slot - 1 < len ? neighbors[o0 + slot - 1] : 0u);
+}
+int32_t launch_hnsw_pack_level0(hipStream_t st, const uint64_t *offsets, const uint32_t *neighbors, uint32_t n_points, uint32_t stride, uint32_t *l0) {
+    if (n_points == 0) return QMX_OK;
+    const uint64_t total = (uint64_t)n_points * stride;
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(hnsw_pack_level0_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, offsets, neighbors, n_points, stride, l0);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
 }  // namespace qmx
