@@ -113,11 +113,9 @@ __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs 
     // the step's 16 bytes of this lane; bytes past the row (last, partial step) are zero and never read
     auto load_piece = [&](const unsigned char *rp, uint32_t s) -> uint4 {
         const uint32_t off = s * 64 + (uint32_t)kg * 16;
-        if (off < nbytes) {
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(rp + off));
-            return make_uint4(v[0], v[1], v[2], v[3]);
-        }
+        // plain (temporal) loads: the 4 lanes of a row touch half a 128-byte line per step, the other half is the next
+        // step's load — it must still be in L1 / L2 then
+        if (off < nbytes) return *reinterpret_cast<const uint4 *>(rp + off);
         return make_uint4(0, 0, 0, 0);
     };
 
