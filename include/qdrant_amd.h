@@ -213,6 +213,13 @@ QMX_API int32_t qmx_query_create_internal(const qmx_segment *seg, const uint32_t
  * scorer slot): only enqueues the preprocess / cast kernels on the query's stream, no allocation.
  * `queries` host or device. */
 QMX_API int32_t qmx_query_update(qmx_query *q, const float *queries);
+/* The payload filter of `ScorerFilters` (hnsw_index/point_scorer.rs:78-85: `check_vector(id)` = not deleted AND
+ * `filter_context.check(id)`) for this query batch, evaluated by the caller's payload index into an allow bitmap
+ * (`BitSlice<u64, Lsb0>`, bit id = point id passes; ids past n_bits are rejected).  Applies to the brute-force
+ * stream (like `peek_top_iter` over filtered points), to qmx_hnsw_search (filtered walk: rejected points are neither
+ * scored nor traversed, as in `FilteredScorer::score_points`) — not to the plain score_points entry points, which
+ * score what they are given.  NULL clears the filter.  The bitmap is copied. */
+QMX_API int32_t qmx_query_set_filter(qmx_query *q, const uint64_t *allowed, uint64_t n_bits);
 QMX_API int32_t qmx_query_destroy(qmx_query *q);
 /* Run this query batch's kernels on a caller-owned hipStream_t (NULL = the query's own stream). */
 QMX_API int32_t qmx_query_set_stream(qmx_query *q, void *hip_stream);

@@ -93,6 +93,7 @@ SIGNATURES = {
     "qmx_query_create": (C.c_int32, [_P, _P, C.c_uint32, C.POINTER(_P)]),
     "qmx_query_create_internal": (C.c_int32, [_P, _P, C.c_uint32, C.POINTER(_P)]),
     "qmx_query_update": (C.c_int32, [_P, _P]),
+    "qmx_query_set_filter": (C.c_int32, [_P, _P, C.c_uint64]),
     "qmx_query_destroy": (C.c_int32, [_P]),
     "qmx_query_set_stream": (C.c_int32, [_P, _P]),
     "qmx_query_synchronize": (C.c_int32, [_P]),

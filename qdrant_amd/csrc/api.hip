@@ -149,6 +149,8 @@ struct qmx_segment {
         v.vec_deleted = d_vec_deleted;
         v.n_vec_bits = n_vec_bits;
         v.n_rows = n;
+        v.allowed = nullptr;
+        v.n_allowed_bits = 0;
         return v;
     }
     // rows the brute-force stream visits: iter_zeros(point_deleted) ends at the bitslice length
@@ -173,6 +175,9 @@ struct qmx_query {
     float timing_ms = 0.f;
     uint32_t timing_launches = 0;
     DevBuf partial, out, counts, ids, scores, misc, enc, bounds;
+    DevBuf filter;             // payload-filter allow bitmap of this query batch (qmx_query_set_filter)
+    uint64_t n_filter_bits = 0;
+    bool has_filter = false;
     DevBuf hnsw_vis, hnsw_log, hnsw_scored;   // HNSW scratch: per-slot visited bitmaps (kept all-zero between launches) + logs
     uint32_t hnsw_slots = 0;
     uint64_t hnsw_vis_words = 0;
@@ -724,6 +729,7 @@ int32_t qmx_query_destroy(qmx_query *q) {
     q->misc.release();
     q->enc.release();
     q->bounds.release();
+    q->filter.release();
     q->hnsw_vis.release();
     q->hnsw_log.release();
     q->hnsw_scored.release();
@@ -733,6 +739,23 @@ int32_t qmx_query_destroy(qmx_query *q) {
     }
     if (q->own_stream) (void)hipStreamDestroy(q->own_stream);
     delete q;
+    return QMX_OK;
+}
+
+int32_t qmx_query_set_filter(qmx_query *q, const uint64_t *allowed, uint64_t n_bits) {
+    QMX_REQUIRE(q, QMX_ERR_BAD_ARG, "NULL query");
+    QMX_HIP(hipSetDevice(q->device));
+    if (!allowed) {
+        q->has_filter = false;
+        q->n_filter_bits = 0;
+        return QMX_OK;
+    }
+    const size_t words = (size_t)((n_bits + 63) / 64);
+    QMX_TRY(q->filter.reserve(std::max<size_t>(words, 1) * 8));
+    if (words) QMX_HIP(hipMemcpyAsync(q->filter.p, allowed, words * 8, hipMemcpyDefault, q->stream));
+    QMX_HIP(hipStreamSynchronize(q->stream));     // the caller's buffer may go away
+    q->n_filter_bits = n_bits;
+    q->has_filter = true;
     return QMX_OK;
 }
 
@@ -808,6 +831,10 @@ static void fill_args(const qmx_query *q, uint32_t tile0, uint32_t nq_tile, Scan
         a.tail_start = full;
     }
     a.del = s->deleted_view();
+    if (q->has_filter) {
+        a.del.allowed = (const uint64_t *)q->filter.p;
+        a.del.n_allowed_bits = q->n_filter_bits;
+    }
     a.err_flag = q->d_err;
     a.flags = s->flags;
     a.sq_multiplier = s->sq.multiplier;

@@ -98,17 +98,22 @@ __device__ __forceinline__ bool bit_get(const uint64_t *bits, uint64_t i) {
     return (bits[i >> 6] >> (i & 63)) & 1ull;
 }
 // NotDeletedChecker::check (lib/segment/src/vector_storage/raw_scorer.rs:596-603)
+// + the optional payload filter of ScorerFilters (hnsw_index/point_scorer.rs:78-85, 160-181: `filters.check_vector(id)`
+//   = not deleted AND filter_context.check(id)), given as an allow bitmap evaluated by the caller's payload index
 struct DeletedView {
     const uint64_t *point_deleted;
     uint64_t n_point_bits;
     const uint64_t *vec_deleted;
     uint64_t n_vec_bits;
     uint64_t n_rows;
+    const uint64_t *allowed;     // nullptr = no payload filter; ids past n_allowed_bits are rejected
+    uint64_t n_allowed_bits;
     __device__ __forceinline__ bool live(uint32_t id) const {
         bool vdel = (vec_deleted && id < n_vec_bits) ? bit_get(vec_deleted, id) : false;
         bool pdel = point_deleted ? (id < n_point_bits ? bit_get(point_deleted, id) : true)
                                   : !(id < n_rows);
-        return !vdel && !pdel;
+        bool ok = allowed ? (id < n_allowed_bits && bit_get(allowed, id)) : true;
+        return !vdel && !pdel && ok;
     }
 };
 

@@ -297,6 +297,14 @@ class RawScorer:
         self.storage = storage
         self.nq = nq
 
+    def set_filter(self, allowed=None):
+        """Payload filter of `ScorerFilters` as an allow mask (bool array over point ids); None clears it."""
+        if allowed is None:
+            F.check(F.lib().qmx_query_set_filter(self._h, None, 0))
+            return
+        words = _bits_to_words(np.asarray(allowed, dtype=bool))
+        F.check(F.lib().qmx_query_set_filter(self._h, F.ptr(words), len(allowed)))
+
     def score_points(self, points: Sequence[int]) -> np.ndarray:
         """scores[qi, i] = similarity(query qi, stored point points[i])  (raw_scorer.rs:40)."""
         ids = np.ascontiguousarray(points, dtype=np.uint32)

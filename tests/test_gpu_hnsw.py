@@ -280,3 +280,29 @@ def test_plain_links_file_ingestion(qa):
                                                plain.xp_ids, plain.xp_levels)
     assert from_file.n_points == n
     _same(from_file.search(10, 64, scorer), g.search_dense(st, queries, 10, 64))
+
+
+def test_payload_filter_bitmap_brute_force_and_walk(qa):
+    """ScorerFilters' payload filter as an allow bitmap (qmx_query_set_filter): for the oracle a rejected point is a
+    deleted point (`check_vector` = not deleted AND filter), so both must agree — brute force and filtered walk."""
+    n, dim, m, nq = 3000, 32, 8, 20
+    rows, st_all, g, plain = _graph(O.COSINE, n, dim, m, 0x5EED0370)
+    queries = O.synth(0x5EED0371, 0, nq, dim)
+    rng = np.random.default_rng(8)
+    allowed = rng.random(n) < 0.4
+    deleted = rng.random(n) < 0.1
+    vs = qa.VectorStorage(rows, qa.Distance.Cosine)
+    vs.set_deleted(deleted, None)
+    st_f = O.DenseStorage(O.F32, O.COSINE, rows, point_deleted=deleted | ~allowed)
+    s = qa.BatchFilteredSearcher(queries, vs, 10)
+    s.scorer.set_filter(allowed)
+    _same(s.peek_top_all(), st_f.peek_top(queries, 10))
+    graph = qa.GraphLayers.from_plain(plain)
+    want, stats = g.search_dense(st_f, queries, 10, 64, with_stats=True)
+    got, scored = graph.search(10, 64, s.scorer, with_scored=True)
+    _same(got, want)
+    assert scored == sum(stats)
+    for r in got:
+        assert allowed[r["idx"]].all() and not deleted[r["idx"]].any()
+    s.scorer.set_filter(None)                                   # cleared: back to the deleted flags alone
+    _same(s.peek_top_all(), O.DenseStorage(O.F32, O.COSINE, rows, point_deleted=deleted).peek_top(queries, 10))
