@@ -146,6 +146,7 @@ typedef struct qmx_segment_desc {
 
 typedef struct qmx_segment qmx_segment;
 typedef struct qmx_query qmx_query;
+typedef struct qmx_hnsw qmx_hnsw;
 
 /* ---- library / device ------------------------------------------------------------------ */
 
@@ -293,6 +294,27 @@ QMX_API int32_t qmx_rescore(qmx_query *q, const uint32_t *ids, const uint32_t *c
                             uint32_t n_per_query, uint32_t top, qmx_scored_point *out,
                             uint32_t *out_counts);
 
+/* `SearchParams.quantization` subset + `hnsw_ef` (lib/segment/src/types.rs: QuantizationSearchParams{ignore, rescore,
+ * oversampling}); `ignore` / `exact` are expressed by passing the original-vector batch as the searched one. */
+typedef struct qmx_search_params {
+    uint32_t top;
+    float oversampling;   /* > 1.0: the quantized stage returns (oversampling * top) as usize candidates (:27-46) */
+    uint8_t rescore;      /* re-score the candidates with the original vectors (default_rescoring or the request's) */
+    uint8_t pad_[3];
+    uint32_t hnsw_ef;     /* only with a graph; raised to the oversampled top (graph_layers.rs:549) */
+} qmx_search_params;
+
+/* One call for `PlainVectorIndexReadView::search` (plain_vector_index/read_view/search.rs:54-135, g == NULL) or the
+ * graph arm of `HNSWIndexReadView::search` (hnsw/read_view/search.rs:30-179, g != NULL), including
+ * `get_oversampled_top` and `postprocess_search_result` (vector_index_search_common.rs:27-91): stage 1 searches the
+ * batch `searched` (the quantized scorers when `is_quantized_search`, else the original ones) for the oversampled top,
+ * stage 2 re-scores those candidates with `original` (same queries over the original vectors; may be NULL when
+ * rescore == 0), sorts descending and truncates to `top`.  Candidates stay on the device between the stages.
+ * ids / n_ids: optional candidate list of the brute-force stage (payload-filtered points), ignored with a graph. */
+QMX_API int32_t qmx_search_quantized(const qmx_hnsw *g, qmx_query *searched, qmx_query *original, const qmx_search_params *params,
+                                     const uint32_t *ids, uint64_t n_ids, qmx_scored_point *out, uint32_t *out_counts,
+                                     const volatile uint8_t *is_stopped, qmx_counters *counters);
+
 /* k-way merge of per-segment / per-GPU result lists = `BatchResultAggregator`
  * (lib/shard/src/search_result_aggregator.rs:50-121) with all point versions equal:
  * lists[(l * nq + qi) * k ..], idx already globalised by the caller.  Items are pushed in list
@@ -338,8 +360,6 @@ typedef struct qmx_hnsw_desc {
     int32_t device_id;
     int32_t reserved;
 } qmx_hnsw_desc;
-
-typedef struct qmx_hnsw qmx_hnsw;
 
 /* Uploads the graph (replaces `GraphLayers::load` for the search side).  Immutable afterwards and
  * safe for concurrent searches from any number of threads (each with its own qmx_query). */

@@ -175,6 +175,7 @@ struct qmx_query {
     float timing_ms = 0.f;
     uint32_t timing_launches = 0;
     DevBuf partial, out, counts, ids, scores, misc, enc, bounds;
+    DevBuf cand, cand_cnt, cand_ids;   // qmx_search_quantized: oversampled candidates of the quantized stage
     DevBuf filter;             // payload-filter allow bitmap of this query batch (qmx_query_set_filter)
     uint64_t n_filter_bits = 0;
     bool has_filter = false;
@@ -730,6 +731,9 @@ int32_t qmx_query_destroy(qmx_query *q) {
     q->enc.release();
     q->bounds.release();
     q->filter.release();
+    q->cand.release();
+    q->cand_cnt.release();
+    q->cand_ids.release();
     q->hnsw_vis.release();
     q->hnsw_log.release();
     q->hnsw_scored.release();
@@ -1715,6 +1719,57 @@ int32_t qmx_rescore(qmx_query *q, const uint32_t *ids, const uint32_t *counts, u
     if (!out_dev) QMX_TRY(copy_out(q->stream, out, d_out, (size_t)q->nq * top * sizeof(qmx_scored_point)));
     if (!cnt_dev) QMX_TRY(copy_out(q->stream, out_counts, d_oc, (size_t)q->nq * 4));
     return check_err_flag(q);
+}
+
+int32_t qmx_search_quantized(const qmx_hnsw *g, qmx_query *quantized, qmx_query *raw, const qmx_search_params *p, const uint32_t *ids,
+                             uint64_t n_ids, qmx_scored_point *out, uint32_t *out_counts, const volatile uint8_t *is_stopped,
+                             qmx_counters *counters) {
+    QMX_REQUIRE(quantized && p && out && out_counts, QMX_ERR_BAD_ARG, "NULL argument");
+    QMX_REQUIRE(p->top >= 1, QMX_ERR_BAD_ARG, "top must be > 0");
+    const bool rescore = p->rescore != 0;
+    QMX_REQUIRE(!rescore || raw, QMX_ERR_BAD_ARG, "rescoring needs the original-vector query batch");
+    QMX_REQUIRE(!raw || (raw->nq == quantized->nq && raw->device == quantized->device), QMX_ERR_BAD_ARG, "the two query batches must match");
+    // get_oversampled_top (vector_index_search_common.rs:27-46): (oversampling * top as f64) as usize when > 1.0
+    uint32_t otop = p->top;
+    if (p->oversampling > 1.0f) otop = (uint32_t)std::min<double>((double)p->oversampling * (double)p->top, (double)MAX_TOP);
+    QMX_REQUIRE(otop <= (g ? HNSW_MAX_EF : MAX_TOP), QMX_ERR_NOT_SUPPORTED, "oversampled top %u too large", otop);
+    QMX_HIP(hipSetDevice(quantized->device));
+    if (counters) memset(counters, 0, sizeof(*counters));
+    const uint32_t nq = quantized->nq;
+    if (nq == 0) return QMX_OK;
+    QMX_TRY(quantized->cand.reserve((size_t)nq * otop * sizeof(qmx_scored_point)));
+    QMX_TRY(quantized->cand_cnt.reserve((size_t)nq * 4));
+    QMX_TRY(quantized->cand_ids.reserve((size_t)nq * otop * 4));
+    qmx_scored_point *d_cand = (qmx_scored_point *)quantized->cand.p;
+    uint32_t *d_cnt = (uint32_t *)quantized->cand_cnt.p, *d_ids = (uint32_t *)quantized->cand_ids.p;
+    // stage 1: the quantized (or raw, when the caller passes the raw batch as `quantized`) search with the oversampled top
+    if (g) {
+        const uint32_t ef = std::max(p->hnsw_ef, otop);     // graph_layers.rs:549
+        QMX_TRY(qmx_hnsw_search(g, quantized, otop, ef, d_cand, d_cnt, is_stopped, counters));
+    } else {
+        QMX_TRY(qmx_search_topk(quantized, otop, ids, n_ids, d_cand, d_cnt, is_stopped, counters));
+    }
+    const bool out_dev = is_device_ptr(out), cnt_dev = is_device_ptr(out_counts);
+    if (!rescore) {   // search_result.truncate(top)
+        qmx_scored_point *d_out = out;
+        uint32_t *d_oc = out_counts;
+        if (!out_dev) { QMX_TRY(quantized->out.reserve((size_t)nq * p->top * sizeof(qmx_scored_point))); d_out = (qmx_scored_point *)quantized->out.p; }
+        if (!cnt_dev) { QMX_TRY(quantized->counts.reserve((size_t)nq * 4)); d_oc = (uint32_t *)quantized->counts.p; }
+        QMX_TRY(launch_split_candidates(quantized->stream, d_cand, d_cnt, otop, nq, nullptr, p->top, d_out, d_oc));
+        if (!out_dev) QMX_TRY(copy_out(quantized->stream, out, d_out, (size_t)nq * p->top * sizeof(qmx_scored_point)));
+        if (!cnt_dev) QMX_TRY(copy_out(quantized->stream, out_counts, d_oc, (size_t)nq * 4));
+        QMX_HIP(hipStreamSynchronize(quantized->stream));
+        return QMX_OK;
+    }
+    // stage 2: postprocess_search_result (:48-91): re-score the candidates with the original vectors, sort, truncate
+    QMX_TRY(launch_split_candidates(quantized->stream, d_cand, d_cnt, otop, nq, d_ids, 0, nullptr, nullptr));
+    QMX_HIP(hipStreamSynchronize(quantized->stream));
+    QMX_TRY(qmx_rescore(raw, d_ids, d_cnt, otop, std::min(p->top, otop), out, out_counts));
+    if (counters) {
+        counters->bytes_read += (uint64_t)nq * otop * raw->seg->row_bytes;
+        counters->kernel_launches += 2;
+    }
+    return QMX_OK;
 }
 
 int32_t qmx_score_internal(const qmx_segment *seg, const uint32_t *a_ids, const uint32_t *b_ids, uint32_t n, float *out) {

@@ -194,4 +194,28 @@ int32_t launch_hnsw_pack_level0(hipStream_t st, const uint64_t *offsets, const u
     return QMX_OK;
 }
 
+// candidates [nq][n_per] (ScoredPointOffset) -> ids [nq][n_per] (for the rescoring pass) and, when out != nullptr, the
+// first `top` entries + clamped counts (no rescoring: search_result.truncate(top), vector_index_search_common.rs:89)
+__global__ void split_candidates_kernel(const qmx_scored_point *cand, const uint32_t *cand_cnt, uint32_t n_per, uint32_t nq, uint32_t *ids,
+                                        uint32_t top, qmx_scored_point *out, uint32_t *out_counts) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (uint64_t)nq * n_per) return;
+    const uint32_t q = (uint32_t)(gid / n_per), i = (uint32_t)(gid % n_per);
+    const qmx_scored_point p = cand[gid];
+    if (ids) ids[gid] = p.idx;
+    if (out) {
+        if (i < top) out[(uint64_t)q * top + i] = i < cand_cnt[q] ? p : qmx_scored_point{0u, 0.0f};
+        if (i == 0) out_counts[q] = cand_cnt[q] < top ? cand_cnt[q] : top;
+    }
+}
+int32_t launch_split_candidates(hipStream_t st, const qmx_scored_point *cand, const uint32_t *cand_cnt, uint32_t n_per, uint32_t nq,
+                                uint32_t *ids, uint32_t top, qmx_scored_point *out, uint32_t *out_counts) {
+    const uint64_t total = (uint64_t)nq * n_per;
+    if (total == 0) return QMX_OK;
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(split_candidates_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, cand, cand_cnt, n_per, nq, ids, top, out, out_counts);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
 }  // namespace qmx

@@ -406,6 +406,25 @@ def new_raw_scorer_internal(point_ids, storage: VectorStorage) -> RawScorer:
     return RawScorer(h, storage, len(ids))
 
 
+def search_quantized(searched: RawScorer, original: Optional[RawScorer], top: int, oversampling: float = 0.0, rescore: bool = True,
+                     graph=None, hnsw_ef: int = 0, ids=None, is_stopped=None) -> List[np.ndarray]:
+    """`PlainVectorIndexReadView::search` (graph is None) or the graph arm of `HNSWIndexReadView::search`, with
+    `get_oversampled_top` and `postprocess_search_result` (vector_index_search_common.rs:27-91) in one device-side call."""
+    p = F.SearchParams()
+    p.top, p.oversampling, p.rescore, p.hnsw_ef = int(top), float(oversampling), 1 if rescore else 0, int(hnsw_ef)
+    nq = searched.nq
+    out = np.zeros((nq, top), dtype=ScoredPointOffset)
+    counts = np.zeros(nq, dtype=np.uint32)
+    stop = None
+    if is_stopped is not None:
+        stop = is_stopped if isinstance(is_stopped, np.ndarray) else np.array([1 if is_stopped else 0], dtype=np.uint8)
+    idarr = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint32)
+    F.check(F.lib().qmx_search_quantized(None if graph is None else graph._h, searched._h, None if original is None else original._h,
+                                         C.byref(p), F.ptr(idarr), 0 if idarr is None else len(idarr), F.ptr(out), F.ptr(counts),
+                                         F.ptr(stop), None))
+    return [out[i, :counts[i]].copy() for i in range(nq)]
+
+
 class BatchFilteredSearcher:
     """`BatchFilteredSearcher` (point_scorer.rs:307-472): one scorer + one bounded queue per query."""
 

@@ -188,3 +188,47 @@ def test_sq_fit_min_max_on_device(qa):
         F.check(F.lib().qmx_sq_fit_min_max(0, int(_dist(qa, dist)), F.ptr(data), len(data), dim, C.byref(p)))
         osq = O.SqOracle(dist, dim, p.alpha, p.offset)
         assert np.float32(osq.sq.multiplier) == np.float32(p.multiplier) and osq.sq.actual_dim == p.actual_dim and bool(osq.sq.invert) == bool(p.invert)
+
+
+def test_search_quantized_pipeline_matches_the_reference_flow(qa):
+    """get_oversampled_top + quantized search + postprocess_search_result (vector_index_search_common.rs:27-91) in one
+    call == the same steps done by hand with the oracle, for the plain index and for the graph."""
+    rng = np.random.default_rng(91)
+    n, dim, nq, top = 4000, 64, 6, 10
+    centers = rng.standard_normal((16, dim)).astype(np.float32) * 2
+    vecs = O.preprocess(O.COSINE, (centers[rng.integers(0, 16, n)] + 0.7 * rng.standard_normal((n, dim))).astype(np.float32))
+    queries = O.preprocess(O.COSINE, rng.standard_normal((nq, dim)).astype(np.float32))
+    quant = qa.ScalarQuantizer.fit(vecs, dim, qa.Distance.Dot)
+    osq = O.SqOracle(O.DOT, dim, quant.alpha, quant.offset)
+    codes = osq.encode_rows(vecs)
+    enc = qa.EncodedVectorsU8(codes, quant)
+    vs = qa.VectorStorage(vecs, qa.Distance.Cosine)
+    sq_scorer, raw_scorer = qa.new_raw_scorer(queries, enc), qa.new_raw_scorer(queries, vs)
+    truth = O.DenseStorage(O.F32, O.COSINE, vecs)
+    sq_scores = osq.score_points(queries, np.arange(n))
+    for oversampling, otop in [(2.5, 25), (1.0, 10), (0.0, 10), (7.3, 73)]:          # 73 > 64: two bounded passes inside
+        got = qa.search_quantized(sq_scorer, raw_scorer, top, oversampling=oversampling, rescore=True)
+        for qi in range(nq):
+            cand = np.argsort(-sq_scores[qi], kind="stable")[:otop]
+            exact = truth.score_points(queries[qi:qi + 1], cand)[0]
+            order = np.argsort(-exact, kind="stable")[:top]
+            assert np.array_equal(got[qi]["score"].view(np.uint32), exact[order].view(np.uint32))
+            assert set(got[qi]["idx"].tolist()) == set(cand[order].tolist())
+        plain = qa.search_quantized(sq_scorer, None, top, oversampling=oversampling, rescore=False)   # truncate(top) of the quantized list
+        for qi in range(nq):
+            want = np.sort(sq_scores[qi])[::-1][:top]
+            assert np.array_equal(plain[qi]["score"].view(np.uint32), want.view(np.uint32))
+    # graph arm: == qmx_hnsw_search(oversampled top, max(ef, oversampled top)) + qmx_rescore by hand
+    graph = qa.GraphLayers.build(vs, m=8, ef_construct=64, seed=4)
+    got = qa.search_quantized(sq_scorer, raw_scorer, top, oversampling=3.0, rescore=True, graph=graph, hnsw_ef=16)
+    walk = graph.search(30, 30, sq_scorer)
+    ids = np.zeros((nq, 30), dtype=np.uint32)
+    cnt = np.zeros(nq, dtype=np.uint32)
+    for i, r in enumerate(walk):
+        ids[i, :len(r)] = r["idx"]
+        cnt[i] = len(r)
+    want = raw_scorer.rescore(ids, top, cnt)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    with pytest.raises(qa.QmxError):
+        qa.search_quantized(sq_scorer, None, top, rescore=True)                       # rescoring needs the original batch
