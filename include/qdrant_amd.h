@@ -315,6 +315,37 @@ QMX_API int32_t qmx_search_quantized(const qmx_hnsw *g, qmx_query *searched, qmx
                                      const uint32_t *ids, uint64_t n_ids, qmx_scored_point *out, uint32_t *out_counts,
                                      const volatile uint8_t *is_stopped, qmx_counters *counters);
 
+/* ---- custom queries (recommend / discover / context) ---------------------------------------------- */
+
+/* `QueryVector::{RecommendBestScore, RecommendSumScores, Discover, Context}` scored by `CustomQueryScorer`
+ * (lib/segment/src/vector_storage/query_scorer/custom_query_scorer.rs:44-121): score(point) =
+ * query.score_by(|example| Metric::similarity(example, point)).  The EXAMPLE vectors of all custom queries of a request
+ * form one ordinary query batch (`qmx_query_create`: each example is preprocessed and cast like a Nearest query,
+ * custom_query_scorer.rs:58-66); a qmx_custom_query names its slice of that batch in the reference's `flat_iter()`
+ * order: reco: n_a positives then n_b negatives (vector_storage/query/reco_query.rs:25-27, 68-131); discover: the
+ * target (n_a = 1) then n_b (positive, negative) pairs (discover_query.rs:34-73); context: n_b pairs, n_a = 0
+ * (context_query.rs:53-62, 95-118). */
+typedef enum qmx_custom_kind {
+    QMX_CUSTOM_RECO_BEST_SCORE = 0,
+    QMX_CUSTOM_RECO_SUM_SCORES = 1,
+    QMX_CUSTOM_DISCOVER = 2,
+    QMX_CUSTOM_CONTEXT = 3
+} qmx_custom_kind;
+typedef struct qmx_custom_query {
+    uint32_t kind;   /* qmx_custom_kind */
+    uint32_t first;  /* index of the query's first example inside the example batch */
+    uint32_t n_a;
+    uint32_t n_b;
+} qmx_custom_query;
+
+/* `RawScorer::score_points` of custom scorers: scores[qi * n + i] = custom query qi against stored point ids[i]. */
+QMX_API int32_t qmx_custom_score_points(qmx_query *examples, const qmx_custom_query *queries, uint32_t n_queries,
+                                        const uint32_t *ids, uint32_t n, float *scores);
+/* The brute-force search with custom scorers (`BatchFilteredSearcher` over them, point_scorer.rs:423-472): candidates =
+ * `ids` or every live point; deleted flags and the batch's payload filter apply; out [n_queries][top]. */
+QMX_API int32_t qmx_custom_search_topk(qmx_query *examples, const qmx_custom_query *queries, uint32_t n_queries, uint32_t top,
+                                       const uint32_t *ids, uint64_t n_ids, qmx_scored_point *out, uint32_t *out_counts);
+
 /* k-way merge of per-segment / per-GPU result lists = `BatchResultAggregator`
  * (lib/shard/src/search_result_aggregator.rs:50-121) with all point versions equal:
  * lists[(l * nq + qi) * k ..], idx already globalised by the caller.  Items are pushed in list

@@ -1138,6 +1138,47 @@ void qo_pq_train_ex(uint32_t dim, uint32_t chunk_size, uint32_t n_centroids, con
 }
 
 /* ------------------------------------------------------------------------------------------
+ * custom queries: Query::score_by of RecoBestScoreQuery (vector_storage/query/reco_query.rs:68-92),
+ * RecoSumScoresQuery (:114-131), DiscoverQuery (discover_query.rs:45-73, ContextPair::rank_by context_query.rs:38-45),
+ * ContextQuery (context_query.rs:53-62, 112-118); fast_sigmoid / scaled_fast_sigmoid lib/common/common/src/math.rs:7-18.
+ * sims = similarity(example, point) in flat_iter() order.  kind: 0 best score, 1 sum scores, 2 discover, 3 context.
+ * ---------------------------------------------------------------------------------------- */
+static int f32_total_cmp(float a, float b) {
+    int32_t x, y;
+    memcpy(&x, &a, 4); memcpy(&y, &b, 4);
+    x ^= (int32_t)(((uint32_t)(x >> 31)) >> 1);
+    y ^= (int32_t)(((uint32_t)(y >> 31)) >> 1);
+    return x < y ? -1 : x > y ? 1 : 0;
+}
+static float fast_sigmoid(float x) { return x / (1.0f + fabsf(x)); }
+static float scaled_fast_sigmoid(float x) { return 0.5f * (fast_sigmoid(x) + 1.0f); }
+float qo_custom_combine(int kind, uint32_t n_a, uint32_t n_b, const float *sims) {
+    if (kind == 0) {
+        float max_pos = -INFINITY, max_neg = -INFINITY;
+        for (uint32_t i = 0; i < n_a; i++) if (f32_total_cmp(sims[i], max_pos) > 0) max_pos = sims[i];
+        for (uint32_t i = 0; i < n_b; i++) if (f32_total_cmp(sims[n_a + i], max_neg) > 0) max_neg = sims[n_a + i];
+        return max_pos > max_neg ? scaled_fast_sigmoid(max_pos) : -scaled_fast_sigmoid(max_neg);
+    }
+    if (kind == 1) {
+        float pos = 0.0f, neg = 0.0f;
+        for (uint32_t i = 0; i < n_a; i++) pos += sims[i];
+        for (uint32_t i = 0; i < n_b; i++) neg += sims[n_a + i];
+        return pos - neg;
+    }
+    if (kind == 2) {
+        int32_t rank = 0;
+        for (uint32_t i = 0; i < n_b; i++) rank += f32_total_cmp(sims[1 + 2 * i], sims[2 + 2 * i]);
+        return (float)rank + scaled_fast_sigmoid(sims[0]);
+    }
+    float sum = 0.0f;
+    for (uint32_t i = 0; i < n_b; i++) {
+        const float difference = sims[2 * i] - sims[2 * i + 1] - 1.1920929e-07f;    /* ScoreType::EPSILON */
+        sum += fast_sigmoid(fminf(difference, 0.0f));
+    }
+    return sum;
+}
+
+/* ------------------------------------------------------------------------------------------
  * synthetic data: counter-based, integer-only (Irwin-Hall of four 16-bit uniforms), so the
  * device generator (qdrant_amd/csrc/synth.hip) reproduces it bit-for-bit without libm.
  * ---------------------------------------------------------------------------------------- */

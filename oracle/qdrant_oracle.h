@@ -135,6 +135,7 @@ float qo_pq_score_internal(const qo_pq *pq, const uint8_t *ci, const uint8_t *cj
  * clusters randomly, so centroids are an INPUT to parity, never compared) */
 void qo_pq_train(uint32_t dim, uint32_t chunk_size, uint32_t n_centroids, const float *data,
                  size_t n, int iters, float *centroids_out);
+float qo_custom_combine(int kind, uint32_t n_a, uint32_t n_b, const float *sims);   /* Query::score_by of the custom queries */
 void qo_pq_train_ex(uint32_t dim, uint32_t chunk_size, uint32_t n_centroids, const float *data, size_t n, uint32_t max_iters,
                     float accuracy, uint32_t threads, float *centroids_out, uint32_t *iters_done);   /* kmeans.rs:9-169 on a given sample */
 

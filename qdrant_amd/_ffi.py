@@ -73,6 +73,13 @@ class SearchParams(C.Structure):
     _fields_ = [("top", C.c_uint32), ("oversampling", C.c_float), ("rescore", C.c_uint8), ("pad_", C.c_uint8 * 3), ("hnsw_ef", C.c_uint32)]
 
 
+class CustomQuery(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("first", C.c_uint32), ("n_a", C.c_uint32), ("n_b", C.c_uint32)]
+
+
+CUSTOM_RECO_BEST_SCORE, CUSTOM_RECO_SUM_SCORES, CUSTOM_DISCOVER, CUSTOM_CONTEXT = range(4)
+
+
 class QmxError(RuntimeError):
     def __init__(self, status, message):
         self.status = status
@@ -113,6 +120,8 @@ SIGNATURES = {
     "qmx_search_topk_async": (C.c_int32, [_P, C.c_uint32, _P, C.c_uint64, _P, _P]),
     "qmx_rescore": (C.c_int32, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, _P]),
     "qmx_search_quantized": (C.c_int32, [_P, _P, _P, C.POINTER(SearchParams), _P, C.c_uint64, _P, _P, _P, C.POINTER(Counters)]),
+    "qmx_custom_score_points": (C.c_int32, [_P, _P, C.c_uint32, _P, C.c_uint32, _P]),
+    "qmx_custom_search_topk": (C.c_int32, [_P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint64, _P, _P]),
     "qmx_merge_topk": (C.c_int32, [C.c_int32, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P]),
     "qmx_merge_topk_async": (C.c_int32, [C.c_int32, _P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P]),
     "qmx_hnsw_create": (C.c_int32, [C.POINTER(HnswDesc), C.POINTER(_P)]),

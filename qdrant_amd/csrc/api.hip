@@ -175,6 +175,7 @@ struct qmx_query {
     float timing_ms = 0.f;
     uint32_t timing_launches = 0;
     DevBuf partial, out, counts, ids, scores, misc, enc, bounds;
+    DevBuf cq_sims, cq_scores, cq_desc;   // custom queries: example similarities, combined scores, descriptors
     DevBuf cand, cand_cnt, cand_ids;   // qmx_search_quantized: oversampled candidates of the quantized stage
     DevBuf filter;             // payload-filter allow bitmap of this query batch (qmx_query_set_filter)
     uint64_t n_filter_bits = 0;
@@ -731,6 +732,9 @@ int32_t qmx_query_destroy(qmx_query *q) {
     q->enc.release();
     q->bounds.release();
     q->filter.release();
+    q->cq_sims.release();
+    q->cq_scores.release();
+    q->cq_desc.release();
     q->cand.release();
     q->cand_cnt.release();
     q->cand_ids.release();
@@ -1719,6 +1723,71 @@ int32_t qmx_rescore(qmx_query *q, const uint32_t *ids, const uint32_t *counts, u
     if (!out_dev) QMX_TRY(copy_out(q->stream, out, d_out, (size_t)q->nq * top * sizeof(qmx_scored_point)));
     if (!cnt_dev) QMX_TRY(copy_out(q->stream, out_counts, d_oc, (size_t)q->nq * 4));
     return check_err_flag(q);
+}
+
+// ---------------------------------------------------------------------------------------------
+// custom queries (custom_query.hip)
+// ---------------------------------------------------------------------------------------------
+static int32_t custom_prepare(qmx_query *ex, const qmx_custom_query *queries, uint32_t n_queries, const uint32_t *d_ids, uint64_t n) {
+    for (uint32_t i = 0; i < n_queries; ++i) {
+        const qmx_custom_query &c = queries[i];
+        QMX_REQUIRE(c.kind <= QMX_CUSTOM_CONTEXT, QMX_ERR_BAD_ARG, "bad custom query kind %u", c.kind);
+        const uint64_t ne = c.kind <= QMX_CUSTOM_RECO_SUM_SCORES ? (uint64_t)c.n_a + c.n_b : (uint64_t)c.n_a + 2ull * c.n_b;
+        QMX_REQUIRE(c.kind != QMX_CUSTOM_DISCOVER || c.n_a == 1, QMX_ERR_BAD_ARG, "a discover query has exactly one target");
+        QMX_REQUIRE(c.kind != QMX_CUSTOM_CONTEXT || c.n_a == 0, QMX_ERR_BAD_ARG, "a context query has pairs only");
+        QMX_REQUIRE((uint64_t)c.first + ne <= ex->nq, QMX_ERR_OUT_OF_BOUNDS, "custom query %u reaches past the %u examples of the batch", i, ex->nq);
+    }
+    QMX_REQUIRE((uint64_t)ex->nq * n * 4 <= (48ull << 30), QMX_ERR_NOT_SUPPORTED, "example similarity matrix of %llu x %u floats is too large",
+                (unsigned long long)n, ex->nq);
+    QMX_TRY(ex->cq_sims.reserve((size_t)ex->nq * n * 4));
+    QMX_TRY(ex->cq_scores.reserve((size_t)n_queries * n * 4));
+    QMX_TRY(ex->cq_desc.reserve((size_t)n_queries * sizeof(qmx_custom_query)));
+    QMX_HIP(hipMemcpyAsync(ex->cq_desc.p, queries, (size_t)n_queries * sizeof(qmx_custom_query), hipMemcpyDefault, ex->stream));
+    QMX_TRY(score_ids_device(ex, d_ids, n, (float *)ex->cq_sims.p, nullptr));     // similarity(example, point), every example x candidate
+    return launch_custom_combine(ex->stream, (const qmx_custom_query *)ex->cq_desc.p, n_queries, (const float *)ex->cq_sims.p, n, (float *)ex->cq_scores.p);
+}
+
+int32_t qmx_custom_score_points(qmx_query *ex, const qmx_custom_query *queries, uint32_t n_queries, const uint32_t *ids, uint32_t n, float *scores) {
+    QMX_REQUIRE(ex && (n_queries == 0 || queries) && (n == 0 || (ids && scores)), QMX_ERR_BAD_ARG, "NULL argument");
+    QMX_REQUIRE(ex->seg->dtype <= QMX_DTYPE_U8, QMX_ERR_NOT_SUPPORTED, "custom queries score original vectors (dense storages)");
+    QMX_HIP(hipSetDevice(ex->device));
+    if (n == 0 || n_queries == 0) return QMX_OK;
+    const void *d_ids = nullptr;
+    QMX_TRY(stage_in(ex, ex->ids, ids, (size_t)n * 4, &d_ids));
+    QMX_TRY(custom_prepare(ex, queries, n_queries, (const uint32_t *)d_ids, n));
+    QMX_TRY(copy_out(ex->stream, scores, ex->cq_scores.p, (size_t)n_queries * n * 4));
+    return check_err_flag(ex);
+}
+
+int32_t qmx_custom_search_topk(qmx_query *ex, const qmx_custom_query *queries, uint32_t n_queries, uint32_t top, const uint32_t *ids, uint64_t n_ids,
+                               qmx_scored_point *out, uint32_t *out_counts) {
+    QMX_REQUIRE(ex && (n_queries == 0 || queries) && out && out_counts, QMX_ERR_BAD_ARG, "NULL argument");
+    QMX_REQUIRE(ex->seg->dtype <= QMX_DTYPE_U8, QMX_ERR_NOT_SUPPORTED, "custom queries score original vectors (dense storages)");
+    QMX_REQUIRE(top >= 1 && top <= MAX_TOP, QMX_ERR_NOT_SUPPORTED, "top %u not in 1..%u", top, MAX_TOP);
+    QMX_HIP(hipSetDevice(ex->device));
+    if (n_queries == 0) return QMX_OK;
+    const void *d_ids = nullptr;
+    uint64_t n = ex->seg->scan_rows();
+    if (ids) {
+        n = n_ids;
+        if (n_ids) QMX_TRY(stage_in(ex, ex->ids, ids, (size_t)n_ids * 4, &d_ids));
+    }
+    const bool out_dev = is_device_ptr(out), cnt_dev = is_device_ptr(out_counts);
+    qmx_scored_point *d_out = out;
+    uint32_t *d_oc = out_counts;
+    if (!out_dev) { QMX_TRY(ex->out.reserve((size_t)n_queries * top * sizeof(qmx_scored_point))); d_out = (qmx_scored_point *)ex->out.p; }
+    if (!cnt_dev) { QMX_TRY(ex->counts.reserve((size_t)n_queries * 4)); d_oc = (uint32_t *)ex->counts.p; }
+    if (n == 0) {
+        QMX_HIP(hipMemsetAsync(d_oc, 0, (size_t)n_queries * 4, ex->stream));
+    } else {
+        QMX_TRY(custom_prepare(ex, queries, n_queries, (const uint32_t *)d_ids, n));
+        DeletedView del = ex->seg->deleted_view();
+        if (ex->has_filter) { del.allowed = (const uint64_t *)ex->filter.p; del.n_allowed_bits = ex->n_filter_bits; }
+        QMX_TRY(launch_custom_topk(ex->stream, (const float *)ex->cq_scores.p, n, (const uint32_t *)d_ids, del, n_queries, top, d_out, d_oc));
+    }
+    if (!out_dev) QMX_TRY(copy_out(ex->stream, out, d_out, (size_t)n_queries * top * sizeof(qmx_scored_point)));
+    if (!cnt_dev) QMX_TRY(copy_out(ex->stream, out_counts, d_oc, (size_t)n_queries * 4));
+    return check_err_flag(ex);
 }
 
 int32_t qmx_search_quantized(const qmx_hnsw *g, qmx_query *quantized, qmx_query *raw, const qmx_search_params *p, const uint32_t *ids,

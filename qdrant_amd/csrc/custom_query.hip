@@ -1,0 +1,155 @@
+// custom_query.hip — the custom-query scorers of qdrant on top of the per-example similarity matrix.
+//
+// Reference: CustomQueryScorer (lib/segment/src/vector_storage/query_scorer/custom_query_scorer.rs:44-121):
+//   score(point) = query.score_by(|example| Metric::similarity(example, point))
+// with the Query implementations
+//   RecoBestScoreQuery::score_by   vector_storage/query/reco_query.rs:68-92    (max by total_cmp, scaled_fast_sigmoid)
+//   RecoSumScoresQuery::score_by   reco_query.rs:114-131                        (sequential f32 sums, pos - neg)
+//   DiscoverQuery::score_by        discover_query.rs:45-73 (+ ContextPair::rank_by context_query.rs:38-45)
+//   ContextQuery::score_by         context_query.rs:53-62, 112-118              (sum of fast_sigmoid(min(pos - neg - EPSILON, 0)))
+//   fast_sigmoid / scaled_fast_sigmoid  lib/common/common/src/math.rs:7-18
+// The similarities are the scan kernels' (bit-identical to the x86 leaves), the combination is a handful of f32
+// operations in the reference's order: bit-exact end to end.  Example order inside a query = the reference's
+// flat_iter(): reco: positives, then negatives; discover: target, then (positive, negative) per pair; context: pairs.
+#include "kernels.hpp"
+
+namespace qmx {
+
+__device__ __forceinline__ int f32_total_cmp(float a, float b) {   // f32::total_cmp
+    int32_t x = __float_as_int(a), y = __float_as_int(b);
+    x ^= (int32_t)(((uint32_t)(x >> 31)) >> 1);
+    y ^= (int32_t)(((uint32_t)(y >> 31)) >> 1);
+    return x < y ? -1 : x > y ? 1 : 0;
+}
+__device__ __forceinline__ float fast_sigmoid(float x) { return x / (1.0f + __builtin_fabsf(x)); }
+__device__ __forceinline__ float scaled_fast_sigmoid(float x) { return 0.5f * (fast_sigmoid(x) + 1.0f); }
+
+// sims[e * stride] = similarity of example (first + e) with this candidate
+__device__ __forceinline__ float custom_combine(const qmx_custom_query &q, const float *sims, uint64_t stride) {
+    const float *s = sims + (uint64_t)q.first * stride;
+    switch (q.kind) {
+        case QMX_CUSTOM_RECO_BEST_SCORE: {
+            float max_pos = -__builtin_inff(), max_neg = -__builtin_inff();
+            for (uint32_t i = 0; i < q.n_a; ++i) { const float v = s[(uint64_t)i * stride]; if (f32_total_cmp(v, max_pos) > 0) max_pos = v; }
+            for (uint32_t i = 0; i < q.n_b; ++i) { const float v = s[(uint64_t)(q.n_a + i) * stride]; if (f32_total_cmp(v, max_neg) > 0) max_neg = v; }
+            return max_pos > max_neg ? scaled_fast_sigmoid(max_pos) : -scaled_fast_sigmoid(max_neg);
+        }
+        case QMX_CUSTOM_RECO_SUM_SCORES: {
+            float pos = 0.0f, neg = 0.0f;
+            for (uint32_t i = 0; i < q.n_a; ++i) pos += s[(uint64_t)i * stride];
+            for (uint32_t i = 0; i < q.n_b; ++i) neg += s[(uint64_t)(q.n_a + i) * stride];
+            return pos - neg;
+        }
+        case QMX_CUSTOM_DISCOVER: {
+            int32_t rank = 0;
+            for (uint32_t i = 0; i < q.n_b; ++i) rank += f32_total_cmp(s[(uint64_t)(1 + 2 * i) * stride], s[(uint64_t)(2 + 2 * i) * stride]);
+            return (float)rank + scaled_fast_sigmoid(s[0]);
+        }
+        default: {   // QMX_CUSTOM_CONTEXT
+            float sum = 0.0f;
+            for (uint32_t i = 0; i < q.n_b; ++i) {
+                const float difference = s[(uint64_t)(2 * i) * stride] - s[(uint64_t)(2 * i + 1) * stride] - 1.1920929e-07f;   // ScoreType::EPSILON
+                sum += fast_sigmoid(__builtin_fminf(difference, 0.0f));
+            }
+            return sum;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void custom_combine_kernel(const qmx_custom_query *queries, uint32_t n_queries, const float *sims, uint64_t n,
+                                                             float *out) {
+    const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t qi = blockIdx.y;
+    if (c >= n || qi >= n_queries) return;
+    out[(uint64_t)qi * n + c] = custom_combine(queries[qi], sims + c, n);
+}
+
+int32_t launch_custom_combine(hipStream_t st, const qmx_custom_query *d_queries, uint32_t n_queries, const float *d_sims, uint64_t n, float *d_out) {
+    if (n == 0 || n_queries == 0) return QMX_OK;
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(custom_combine_kernel, dim3((uint32_t)((n + 255) / 256), n_queries), dim3(256), 0, st, d_queries, n_queries, d_sims, n, d_out);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
+// top-k of a score row per query over the candidate stream (ids or 0..n), deleted / filtered points skipped:
+// FixedLengthPriorityQueue + into_sorted_vec as everywhere else; top > 64 in bounded passes of 64.
+constexpr int CT_BLOCK = 1024;
+constexpr int CT_NW = CT_BLOCK / WAVE;
+__global__ __launch_bounds__(CT_BLOCK) void custom_topk_kernel(const float *scores, uint64_t n, const uint32_t *ids, DeletedView del, uint32_t top,
+                                                               qmx_scored_point *out, uint32_t *out_counts) {
+    __shared__ uint64_t sh[CT_NW][WAVE];
+    __shared__ uint64_t sh_bound;
+    const uint32_t q = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float *row = scores + (uint64_t)q * n;
+    uint64_t bound = ~0ull;
+    uint32_t total = 0;
+    for (uint32_t off = 0; off < top; off += WAVE) {
+        const int ptop = (int)(top - off < (uint32_t)WAVE ? top - off : (uint32_t)WAVE);
+        uint64_t list = 0;
+        for (uint64_t base = (uint64_t)wave * WAVE; base < n; base += CT_BLOCK) {
+            const uint64_t c = base + lane;
+            uint64_t key = 0;
+            if (c < n) {
+                const uint32_t id = ids ? ids[c] : (uint32_t)c;
+                key = make_key(row[c], id);
+                if (key >= bound || key <= readlane_u64(list, ptop - 1) || !del.live(id)) key = 0;
+            }
+            uint64_t m = __ballot(key != 0);
+            while (m) {
+                const int src = __builtin_ctzll(m);
+                m &= m - 1;
+                const uint64_t nk = readlane_u64(key, src);
+                if (nk > readlane_u64(list, ptop - 1)) wave_list_insert(list, nk, lane);
+            }
+        }
+        __syncthreads();
+        sh[wave][lane] = list;
+        __syncthreads();
+        if (wave == 0) {
+            uint64_t merged = sh[0][lane];
+            for (int w = 1; w < CT_NW; ++w) {
+                const uint64_t key = sh[w][lane];
+                uint64_t m = __ballot(key > readlane_u64(merged, ptop - 1));
+                while (m) {
+                    const int src = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const uint64_t nk = readlane_u64(key, src);
+                    if (nk > readlane_u64(merged, ptop - 1)) wave_list_insert(merged, nk, lane);
+                }
+            }
+            const bool ok = lane < ptop && merged != 0;
+            if (lane < ptop) {
+                qmx_scored_point p;
+                p.idx = ok ? key_idx(merged) : 0u;
+                p.score = ok ? key_score(merged) : 0.0f;
+                out[(uint64_t)q * top + off + lane] = p;
+            }
+            const uint32_t cnt = (uint32_t)__popcll(__ballot(ok));
+            if (lane == 0) {
+                sh_bound = cnt == (uint32_t)ptop ? readlane_u64(merged, ptop - 1) : 0ull;
+                total += cnt;
+            }
+            total = (uint32_t)__builtin_amdgcn_readfirstlane((int)total);
+        }
+        __syncthreads();
+        bound = sh_bound;
+        if (bound == 0) {
+            for (uint32_t i = off + WAVE + threadIdx.x; i < top; i += CT_BLOCK) out[(uint64_t)q * top + i] = qmx_scored_point{0u, 0.0f};
+            break;
+        }
+    }
+    if (threadIdx.x == 0) out_counts[q] = total;
+}
+
+int32_t launch_custom_topk(hipStream_t st, const float *d_scores, uint64_t n, const uint32_t *d_ids, const DeletedView &del, uint32_t n_queries,
+                           uint32_t top, qmx_scored_point *d_out, uint32_t *d_counts) {
+    if (n_queries == 0) return QMX_OK;
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(custom_topk_kernel, dim3(n_queries), dim3(CT_BLOCK), 0, st, d_scores, n, d_ids, del, top, d_out, d_counts);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
+}  // namespace qmx

@@ -192,6 +192,11 @@ int32_t launch_sort_scored(hipStream_t st, const float *scores, const uint32_t *
                            const uint32_t *counts, uint32_t n_per_query, uint32_t nq, uint32_t top,
                            qmx_scored_point *out, uint32_t *out_counts);
 
+// custom queries (custom_query.hip): combine the per-example similarity matrix, top-k of a score row
+int32_t launch_custom_combine(hipStream_t st, const qmx_custom_query *d_queries, uint32_t n_queries, const float *d_sims, uint64_t n, float *d_out);
+int32_t launch_custom_topk(hipStream_t st, const float *d_scores, uint64_t n, const uint32_t *d_ids, const DeletedView &del, uint32_t n_queries,
+                           uint32_t top, qmx_scored_point *d_out, uint32_t *d_counts);
+
 // Metric::preprocess + element casts (preprocess.hip)
 int32_t launch_cosine_preprocess_f32(hipStream_t st, const float *in, float *out, uint64_t n, uint32_t dim);
 int32_t launch_cast_f32(hipStream_t st, int dst_dtype, const float *in, void *out, uint64_t count);

@@ -406,6 +406,59 @@ def new_raw_scorer_internal(point_ids, storage: VectorStorage) -> RawScorer:
     return RawScorer(h, storage, len(ids))
 
 
+class CustomQuery:
+    """One `QueryVector::{RecommendBestScore, RecommendSumScores, Discover, Context}` (vector_storage/query/*.rs);
+    vectors are ORIGINAL (un-preprocessed) f32, as for `new_raw_scorer`."""
+
+    def __init__(self, kind: int, examples, n_a: int, n_b: int):
+        self.kind, self.examples, self.n_a, self.n_b = kind, [np.asarray(v, dtype=np.float32) for v in examples], n_a, n_b
+
+    @classmethod
+    def recommend_best_score(cls, positives, negatives):
+        return cls(F.CUSTOM_RECO_BEST_SCORE, list(positives) + list(negatives), len(positives), len(negatives))
+
+    @classmethod
+    def recommend_sum_scores(cls, positives, negatives):
+        return cls(F.CUSTOM_RECO_SUM_SCORES, list(positives) + list(negatives), len(positives), len(negatives))
+
+    @classmethod
+    def discover(cls, target, pairs):
+        return cls(F.CUSTOM_DISCOVER, [target] + [v for p in pairs for v in p], 1, len(pairs))
+
+    @classmethod
+    def context(cls, pairs):
+        return cls(F.CUSTOM_CONTEXT, [v for p in pairs for v in p], 0, len(pairs))
+
+
+class CustomRawScorer:
+    """`new_raw_scorer(QueryVector::<custom>, storage)` for a batch of custom queries (raw_scorer.rs:60-114 ->
+    CustomQueryScorer): all example vectors form one device query batch, every custom query is a slice of it."""
+
+    def __init__(self, queries: Sequence[CustomQuery], storage: VectorStorage):
+        self.storage = storage
+        flat, descs, first = [], (F.CustomQuery * len(queries))(), 0
+        for i, q in enumerate(queries):
+            descs[i].kind, descs[i].first, descs[i].n_a, descs[i].n_b = q.kind, first, q.n_a, q.n_b
+            flat += q.examples
+            first += len(q.examples)
+        self._descs, self.nq = descs, len(queries)
+        self.examples = new_raw_scorer(np.stack(flat) if flat else np.zeros((0, storage.dim), dtype=np.float32), storage)
+
+    def score_points(self, points: Sequence[int]) -> np.ndarray:
+        ids = np.ascontiguousarray(points, dtype=np.uint32)
+        out = np.empty((self.nq, len(ids)), dtype=np.float32)
+        F.check(F.lib().qmx_custom_score_points(self.examples._h, self._descs, self.nq, F.ptr(ids), len(ids), F.ptr(out)))
+        return out
+
+    def peek_top(self, top: int, points=None) -> List[np.ndarray]:
+        out = np.zeros((self.nq, top), dtype=ScoredPointOffset)
+        counts = np.zeros(self.nq, dtype=np.uint32)
+        ids = None if points is None else np.ascontiguousarray(points, dtype=np.uint32)
+        F.check(F.lib().qmx_custom_search_topk(self.examples._h, self._descs, self.nq, top, F.ptr(ids), 0 if ids is None else len(ids),
+                                               F.ptr(out), F.ptr(counts)))
+        return [out[i, :counts[i]].copy() for i in range(self.nq)]
+
+
 def search_quantized(searched: RawScorer, original: Optional[RawScorer], top: int, oversampling: float = 0.0, rescore: bool = True,
                      graph=None, hnsw_ef: int = 0, ids=None, is_stopped=None) -> List[np.ndarray]:
     """`PlainVectorIndexReadView::search` (graph is None) or the graph arm of `HNSWIndexReadView::search`, with

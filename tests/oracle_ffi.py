@@ -90,6 +90,7 @@ _sig("qo_pq_encode_query", None, [C.POINTER(Pq), _P, _P])
 _sig("qo_pq_score", _f, [C.POINTER(Pq), _P, _P, C.c_int])
 _sig("qo_pq_score_internal", _f, [C.POINTER(Pq), _P, _P])
 _sig("qo_pq_train", None, [C.c_uint32, C.c_uint32, C.c_uint32, _P, C.c_size_t, C.c_int, _P])
+_sig("qo_custom_combine", _f, [C.c_int, C.c_uint32, C.c_uint32, _P])
 _sig("qo_pq_train_ex", None, [C.c_uint32, C.c_uint32, C.c_uint32, _P, C.c_size_t, C.c_uint32, C.c_float, C.c_uint32, _P, _P])
 
 lib = _lib
@@ -379,6 +380,17 @@ class PlainLinks:
     def links(self, point, level):
         idx = point if level == 0 else int(self.level_offsets[level]) + int(self.reindex[point])
         return self.neighbors[int(self.offsets[idx]):int(self.offsets[idx + 1])]
+
+
+def custom_scores(storage: "DenseStorage", examples, kind, n_a, n_b, ids):
+    """CustomQueryScorer over the oracle's similarities: examples [ne, dim] original vectors in flat_iter() order."""
+    sims = storage.score_points(examples, ids)                 # [ne, n] bit-exact leaves
+    out = np.empty(len(ids), dtype=np.float32)
+    col = np.empty(sims.shape[0], dtype=np.float32)
+    for j in range(len(ids)):
+        col[:] = sims[:, j]
+        out[j] = _lib.qo_custom_combine(kind, n_a, n_b, _p(col))
+    return out
 
 
 def plain_links_file(p: "PlainLinks") -> bytes:
