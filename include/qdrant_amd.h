@@ -61,7 +61,10 @@ typedef enum qmx_dtype {
     QMX_DTYPE_F16 = 1,
     QMX_DTYPE_U8 = 2,
     QMX_DTYPE_SQ_U8 = 3,
-    QMX_DTYPE_PQ = 4
+    QMX_DTYPE_PQ = 4,
+    QMX_DTYPE_BQ = 5   /* EncodedVectorsBin<u128>, Encoding::OneBit, QueryEncoding::SameAsStorage
+                          (lib/quantization/src/encoded_vectors_binary.rs): rows of ceil(dim / 128) * 16 bytes,
+                          bit i = vector[i] > 0; invert derives from the distance (quantized_vectors.rs:232) */
 } qmx_dtype;
 
 /* Same order as `enum Distance` (lib/segment/src/types.rs:313-322). */
@@ -98,6 +101,11 @@ typedef struct qmx_counters {
 #define QMX_SEG_U8_SCALAR_ORDER 0x2u
 /* time every scoring kernel with HIP events on its stream and report it in qmx_counters.kernel_ms */
 #define QMX_SEG_TIME_KERNELS 0x4u
+/* BQ only.  VectorParameters.invert of a segment's quantized storage is `distance == Euclid | Manhattan`
+ * (lib/segment/src/vector_storage/quantized/quantized_vectors.rs:232) and that is what a BQ segment uses by default;
+ * the reference's own quantization tests also build the opposite pairing (lib/quantization/tests/integration/
+ * test_binary.rs:77 `test_binary_dot_inverted`, :129 l1 not inverted): this flag toggles `invert`. */
+#define QMX_SEG_BQ_TOGGLE_INVERT 0x8u
 
 /* SQ-int8 parameters = `MetadataInt8` (lib/quantization/src/encoded_vectors_u8.rs:84-91).
  * Parity is defined on GIVEN (alpha, offset): the reference's quantile estimate samples
@@ -467,6 +475,9 @@ QMX_API int32_t qmx_hnsw_export_plain(const qmx_hnsw *g, uint32_t *reindex, uint
  * in [n][dim] f32 -> out [n][4 + actual_dim] reference rows. */
 QMX_API int32_t qmx_sq_encode(int32_t device_id, uint32_t distance, const qmx_sq_params *params,
                               const float *in, uint64_t n, uint32_t dim, void *out_rows);
+/* `EncodedVectorsBin::encode_vector` for Encoding::OneBit (encoded_vectors_binary.rs:535-568) with the u128 store type:
+ * in [n][dim] f32 (already metric-preprocessed, as the storage's rows are) -> out [n][ceil(dim / 128) * 16] bytes. */
+QMX_API int32_t qmx_bq_encode(int32_t device_id, const float *in, uint64_t n, uint32_t dim, void *out_rows);
 /* PQ codebook training = `kmeans` (lib/quantization/src/kmeans.rs:9-169) for every chunk of `find_centroids`
  * (encoded_vectors_pq.rs:342-407) on a GIVEN sample [n][dim] (the reference draws <= KMEANS_SAMPLE_SIZE = 10 000
  * vectors with a randomly keyed Permutor: unpinned, so the sample is an input): first-k init, update_indexes,

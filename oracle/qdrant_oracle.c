@@ -1197,3 +1197,52 @@ void qo_synth_fill_f32(uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, f
     for (uint64_t r = 0; r < n; r++)
         for (uint32_t c = 0; c < dim; c++) out[r * dim + c] = qo_synth_value(seed, row0 + r, c, dim);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * BQ: EncodedVectorsBin<u128> (lib/quantization/src/encoded_vectors_binary.rs), Encoding::OneBit,
+ * QueryEncoding::SameAsStorage.  Test infrastructure only (see the header of this file).
+ * ------------------------------------------------------------------------------------------ */
+size_t qo_bq_row_bytes(uint32_t dim) {
+    /* get_quantized_vector_size_from_params::<u128>(dim, OneBit) :829-840: get_storage_size(max(dim, 1)) * 16,
+     * get_storage_size :412-419 = ceil(size / 128) */
+    size_t size = dim > 1 ? dim : 1;
+    size_t words = size / 128;
+    if (size % 128 != 0) words += 1;
+    return words * 16;
+}
+
+void qo_bq_encode_row(uint32_t dim, const float *v, uint8_t *out) {
+    /* encode_vector :535-556 zero-fills, encode_one_bit_vector :558-568 sets bit (i % 128) of word (i / 128) when v > 0;
+     * a little-endian u128 keeps bit b in byte b / 8, bit b % 8 */
+    memset(out, 0, qo_bq_row_bytes(dim));
+    for (uint32_t i = 0; i < dim; ++i) {
+        if (v[i] > 0.0f) {
+            const uint32_t word = i / 128, bit = i % 128;
+            out[(size_t)word * 16 + bit / 8] |= (uint8_t)(1u << (bit % 8));
+        }
+    }
+}
+
+uint32_t qo_bq_xor_popcnt(const uint8_t *q, const uint8_t *v, uint32_t n_u128) {
+    /* impl_xor_popcnt_sse_uint128 (cpp/sse.c:54-75): two u64 popcounts per word, summed in an i64 */
+    int64_t result = 0;
+    for (uint32_t w = 0; w < n_u128; ++w) {
+        for (int h = 0; h < 2; ++h) {
+            uint64_t a, b;
+            memcpy(&a, q + (size_t)w * 16 + h * 8, 8);
+            memcpy(&b, v + (size_t)w * 16 + h * 8, 8);
+            result += __builtin_popcountll(a ^ b);
+        }
+    }
+    return (uint32_t)result;
+}
+
+float qo_bq_score(int distance, int invert, uint32_t dim, const uint8_t *q, const uint8_t *v) {
+    /* calculate_metric :766-810, query_bits_count == 1 */
+    const float xor_product = (float)qo_bq_xor_popcnt(q, v, (uint32_t)(qo_bq_row_bytes(dim) / 16));
+    const float fdim = (float)dim;
+    const float zeros_count = fdim - xor_product;
+    const int dot_like = distance == QO_DOT || distance == QO_COSINE;
+    if (dot_like) return invert ? xor_product - zeros_count : zeros_count - xor_product;
+    return invert ? zeros_count - xor_product : xor_product - zeros_count;
+}

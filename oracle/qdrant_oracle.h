@@ -139,6 +139,13 @@ float qo_custom_combine(int kind, uint32_t n_a, uint32_t n_b, const float *sims)
 void qo_pq_train_ex(uint32_t dim, uint32_t chunk_size, uint32_t n_centroids, const float *data, size_t n, uint32_t max_iters,
                     float accuracy, uint32_t threads, float *centroids_out, uint32_t *iters_done);   /* kmeans.rs:9-169 on a given sample */
 
+/* ---- BQ: EncodedVectorsBin<u128>, Encoding::OneBit, QueryEncoding::SameAsStorage (lib/quantization/src/encoded_vectors_binary.rs) ---- */
+size_t qo_bq_row_bytes(uint32_t dim);                                            /* :829-840 with u128::get_storage_size :412-419 */
+void qo_bq_encode_row(uint32_t dim, const float *v, uint8_t *out);               /* encode_one_bit_vector :558-568 */
+uint32_t qo_bq_xor_popcnt(const uint8_t *q, const uint8_t *v, uint32_t n_u128);  /* cpp/sse.c:54-75 */
+/* calculate_metric :766-810 with query_bits_count == 1; distance as QO_* codes; invert = VectorParameters.invert */
+float qo_bq_score(int distance, int invert, uint32_t dim, const uint8_t *q, const uint8_t *v);
+
 /* ---- cross-segment merge: BatchResultAggregator (lib/shard/src/search_result_aggregator.rs:50-121) ----
  * lists[(l * nq + qi) * k ..] with counts[l * nq + qi] valid entries; idx_base[l] (optional) is added to
  * every idx of list l (segment-local offset -> global id).  Points are pushed list by list, each list in
@@ -148,12 +155,13 @@ void qo_merge_topk(const qo_scored_point *lists, const uint32_t *counts, const u
 
 /* ---- scorer = FilteredScorer{RawScorer, NotDeletedChecker} (hnsw_index/point_scorer.rs:53-63) ---- */
 typedef struct {
-    int kind;                 /* 0 dense (Metric over st->rows), 1 SQ (EncodedVectorsU8), 2 PQ (EncodedVectorsPQ) */
+    int kind;                 /* 0 dense (Metric over st->rows), 1 SQ (EncodedVectorsU8), 2 PQ (EncodedVectorsPQ), 3 BQ (EncodedVectorsBin<u128>) */
     const qo_storage *st;     /* dense rows for kind 0; the deleted flags and n for every kind */
     const void *query;        /* kind 0: preprocessed + cast query, [dim] elements */
     const qo_sq *sq; const uint8_t *sq_rows; const uint8_t *sq_query; float sq_query_offset;
     const qo_pq *pq; const uint8_t *pq_codes; const float *pq_lut;
     int isa;                  /* leaf used for SQ / PQ scoring */
+    const uint8_t *bq_rows; const uint8_t *bq_query; uint32_t bq_dim; int bq_distance; int bq_invert;   /* kind 3 */
 } qo_scorer;
 float qo_scorer_score_point(const qo_scorer *s, uint32_t id);              /* RawScorer::score_point */
 float qo_scorer_score_internal(const qo_scorer *s, uint32_t a, uint32_t b); /* RawScorer::score_internal */

@@ -54,7 +54,8 @@ float qo_scorer_score_point(const qo_scorer *s, uint32_t id) {
         case 0: qo_score_points(s->st, s->query, &id, 1, &out); return out;
         case 1: return qo_sq_score(s->sq, s->sq_query, s->sq_query_offset,
                                    s->sq_rows + (size_t)id * (4 + s->sq->actual_dim), s->isa);
-        default: return qo_pq_score(s->pq, s->pq_lut, s->pq_codes + (size_t)id * s->pq->m, s->isa);
+        case 2: return qo_pq_score(s->pq, s->pq_lut, s->pq_codes + (size_t)id * s->pq->m, s->isa);
+        default: return qo_bq_score(s->bq_distance, s->bq_invert, s->bq_dim, s->bq_query, s->bq_rows + (size_t)id * qo_bq_row_bytes(s->bq_dim));
     }
 }
 
@@ -70,7 +71,11 @@ float qo_scorer_score_internal(const qo_scorer *s, uint32_t a, uint32_t b) {
             const size_t rb = 4 + s->sq->actual_dim;
             return qo_sq_score_internal(s->sq, s->sq_rows + (size_t)a * rb, s->sq_rows + (size_t)b * rb, s->isa);
         }
-        default: return qo_pq_score_internal(s->pq, s->pq_codes + (size_t)a * s->pq->m, s->pq_codes + (size_t)b * s->pq->m);
+        case 2: return qo_pq_score_internal(s->pq, s->pq_codes + (size_t)a * s->pq->m, s->pq_codes + (size_t)b * s->pq->m);
+        default: {  /* EncodedVectorsBin::score_internal :892-917 */
+            const size_t rb = qo_bq_row_bytes(s->bq_dim);
+            return qo_bq_score(s->bq_distance, s->bq_invert, s->bq_dim, s->bq_rows + (size_t)a * rb, s->bq_rows + (size_t)b * rb);
+        }
     }
 }
 

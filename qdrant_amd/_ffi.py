@@ -15,12 +15,13 @@ OK, ERR_OUT_OF_MEMORY, ERR_OUT_OF_BOUNDS, ERR_NOT_SUPPORTED, ERR_NOT_READY, ERR_
 STATUS_NAMES = ["OK", "OUT_OF_MEMORY", "OUT_OF_BOUNDS", "NOT_SUPPORTED", "NOT_READY", "TIMEOUT", "OTHER",
                 "CANCELLED", "BAD_ARG", "NO_DEVICE"]
 
-DTYPE_F32, DTYPE_F16, DTYPE_U8, DTYPE_SQ_U8, DTYPE_PQ = range(5)
+DTYPE_F32, DTYPE_F16, DTYPE_U8, DTYPE_SQ_U8, DTYPE_PQ, DTYPE_BQ = range(6)
 COSINE, EUCLID, DOT, MANHATTAN = range(4)
 
 SEG_DATA_ON_DEVICE = 0x1
 SEG_U8_SCALAR_ORDER = 0x2
 SEG_TIME_KERNELS = 0x4
+SEG_BQ_TOGGLE_INVERT = 0x8
 
 
 class ScoredPoint(C.Structure):
@@ -135,6 +136,7 @@ SIGNATURES = {
     "qmx_sq_encode": (C.c_int32, [C.c_int32, C.c_uint32, C.POINTER(SqParams), _P, C.c_uint64, C.c_uint32, _P]),
     "qmx_pq_train": (C.c_int32, [C.c_int32, _P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, _P, _P]),
     "qmx_sq_fit_min_max": (C.c_int32, [C.c_int32, C.c_uint32, _P, C.c_uint64, C.c_uint32, C.POINTER(SqParams)]),
+    "qmx_bq_encode": (C.c_int32, [C.c_int32, _P, C.c_uint64, C.c_uint32, _P]),
     "qmx_pq_encode": (C.c_int32, [C.c_int32, C.POINTER(PqParams), _P, C.c_uint64, C.c_uint32, _P]),
     "qmx_synth_fill_f32": (C.c_int32, [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, _P]),
 }

@@ -135,6 +135,7 @@ struct qmx_segment {
     float *d_row_offsets = nullptr;   // SQ: vector_offset column (rows hold the 16-byte aligned code block)
 
     bool fast_layout() const {
+        if (dtype == QMX_DTYPE_BQ) return row_stride % 16 == 0 && ((uintptr_t)d_rows % 16) == 0;
         if (dtype <= QMX_DTYPE_U8) {
             const uint64_t eb = dtype == QMX_DTYPE_F32 ? 4 : dtype == QMX_DTYPE_F16 ? 2 : 1;
             return dim < 32 ? (row_stride % eb == 0 && ((uintptr_t)d_rows % eb) == 0)
@@ -360,7 +361,7 @@ static int32_t segment_upload(qmx_segment *s, const qmx_segment_desc *desc) {
 int32_t qmx_segment_create(const qmx_segment_desc *desc, qmx_segment **out) {
     QMX_REQUIRE(desc && out, QMX_ERR_BAD_ARG, "NULL argument");
     *out = nullptr;
-    QMX_REQUIRE(desc->dtype <= QMX_DTYPE_PQ, QMX_ERR_BAD_ARG, "bad dtype %u", desc->dtype);
+    QMX_REQUIRE(desc->dtype <= QMX_DTYPE_BQ, QMX_ERR_BAD_ARG, "bad dtype %u", desc->dtype);
     QMX_REQUIRE(desc->distance <= QMX_DISTANCE_MANHATTAN, QMX_ERR_BAD_ARG, "bad distance %u", desc->distance);
     QMX_REQUIRE(desc->dim > 0, QMX_ERR_BAD_ARG, "dim must be > 0");
     QMX_REQUIRE(desc->n <= 0xFFFFFFFFull, QMX_ERR_BAD_ARG, "PointOffsetType is u32: n=%llu too large", (unsigned long long)desc->n);
@@ -412,6 +413,10 @@ int32_t qmx_segment_create(const qmx_segment_desc *desc, qmx_segment **out) {
             s->pq.centroids = nullptr;   // the caller's table is not referenced after create
             break;
         }
+        case QMX_DTYPE_BQ:   // get_quantized_vector_size_from_params::<u128>(dim, OneBit) (encoded_vectors_binary.rs:829-840, 412-419)
+            s->row_bytes = (((uint64_t)desc->dim + 127) / 128) * 16;
+            s->scan_dim = (uint32_t)s->row_bytes;
+            break;
         default:
             set_error("dtype %u not built yet", desc->dtype);
             rc = QMX_ERR_NOT_SUPPORTED;
@@ -647,6 +652,8 @@ static int32_t query_encode(qmx_query *q, const float *queries) {
     if (seg->dtype == QMX_DTYPE_SQ_U8)   // EncodedVectorsU8::encode_query (encoded_vectors_u8.rs:583-619)
         return launch_sq_encode(q->stream, (int)seg->distance, seg->sq, seg->dim, d_f32, nq, (uint8_t *)q->d_queries, q->q_stride,
                                 nullptr, nullptr, 1, q->aux_off);
+    if (seg->dtype == QMX_DTYPE_BQ)      // encode_query_vector, SameAsStorage (encoded_vectors_binary.rs:673-690) = encode_one_bit_vector
+        return launch_bq_encode(q->stream, d_f32, nq, seg->dim, (uint8_t *)q->d_queries, q->q_stride);
     if (seg->dtype == QMX_DTYPE_PQ)      // EncodedVectorsPQ::encode_query (encoded_vectors_pq.rs:519-541)
         return launch_pq_lut(q->stream, seg->distance, seg->dim, seg->pq, seg->d_centroids, d_f32, nq, (float *)q->d_queries);
     set_error("query encode for dtype %u not built yet", seg->dtype);
@@ -682,7 +689,7 @@ int32_t qmx_query_create_internal(const qmx_segment *seg, const uint32_t *point_
     QMX_REQUIRE(seg && out && (nq == 0 || point_ids), QMX_ERR_BAD_ARG, "NULL argument");
     *out = nullptr;
     QMX_HIP(hipSetDevice(seg->device));
-    QMX_REQUIRE(seg->dtype <= QMX_DTYPE_SQ_U8, QMX_ERR_NOT_SUPPORTED,
+    QMX_REQUIRE(seg->dtype <= QMX_DTYPE_SQ_U8 || seg->dtype == QMX_DTYPE_BQ, QMX_ERR_NOT_SUPPORTED,
                 "dtype %u has no internal encoding (EncodedVectorsPQ::encode_internal_vector returns None): pass the original vector to qmx_query_create",
                 seg->dtype);
     qmx_query *q = nullptr;
@@ -705,8 +712,11 @@ int32_t qmx_query_create_internal(const qmx_segment *seg, const uint32_t *point_
         if ((rc = q->misc.reserve((size_t)nq * seg->row_bytes)) != QMX_OK) break;
         if ((rc = launch_gather_rows(q->stream, seg->d_rows, seg->row_stride, seg->row_bytes, (const uint32_t *)d_ids, nq,
                                      seg->n, q->misc.p, q->d_err)) != QMX_OK) break;
-        if ((rc = launch_pack_queries(q->stream, (int)seg->dtype, (int)seg->distance, q->misc.p, 1, (uint32_t)seg->row_bytes,
-                                      nq, seg->dim, q->d_queries, q->q_stride, q->aux_off)) != QMX_OK) break;
+        // BQ: EncodedVectorsBin::encode_internal_vector (encoded_vectors_binary.rs:923-934) = the stored bits, packed as bytes
+        const bool bq = seg->dtype == QMX_DTYPE_BQ;
+        if ((rc = launch_pack_queries(q->stream, bq ? (int)QMX_DTYPE_U8 : (int)seg->dtype, bq ? (int)QMX_DISTANCE_DOT : (int)seg->distance,
+                                      q->misc.p, 1, (uint32_t)seg->row_bytes, nq, bq ? (uint32_t)seg->row_bytes : seg->dim, q->d_queries,
+                                      q->q_stride, q->aux_off)) != QMX_OK) break;
         if ((rc = check_err_flag(q)) != QMX_OK) break;
     } while (0);
     if (rc != QMX_OK) {
@@ -849,6 +859,9 @@ static void fill_args(const qmx_query *q, uint32_t tile0, uint32_t nq_tile, Scan
     a.row_offsets = s->d_row_offsets;
     a.pq_m = s->pq_m;
     a.pq_ncent = s->pq.n_centroids;
+    a.bq_dim = s->dim;
+    // calculate_metric's match: (Dot | Cosine, invert = false) and (L1 | L2, invert = true) -> zeros - xor; the toggled pairs -> xor - zeros
+    a.bq_flip = (s->flags & QMX_SEG_BQ_TOGGLE_INVERT) ? 1 : 0;
 }
 
 static int32_t launch_scan(const qmx_query *q, int qt, ScanMode mode, const ScanArgs &a, uint32_t *grid) {
@@ -867,6 +880,10 @@ static int32_t launch_scan(const qmx_query *q, int qt, ScanMode mode, const Scan
         return launch_scan_sq(q->stream, (int)s->distance, std::min(qt, (int)MAX_QT), mode, a, s->num_cus, grid);
     }
     if (s->dtype == QMX_DTYPE_PQ) return launch_scan_pq(q->stream, mode, a, s->num_cus, grid);
+    if (s->dtype == QMX_DTYPE_BQ) {
+        QMX_REQUIRE(s->fast_layout(), QMX_ERR_NOT_SUPPORTED, "adopted BQ block is not 16-byte aligned");
+        return launch_scan_bq(q->stream, std::min(qt, (int)MAX_QT), mode, a, s->num_cus, grid);
+    }
     set_error("dtype %u not built yet", s->dtype);
     return QMX_ERR_NOT_SUPPORTED;
 }
@@ -1503,6 +1520,7 @@ static int32_t launch_hnsw(const qmx_query *q, const ScanArgs &a, const HnswArgs
     }
     if (s->dtype == QMX_DTYPE_SQ_U8) return launch_hnsw_sq(q->stream, (int)s->distance, a, h, grid, per_cu);
     if (s->dtype == QMX_DTYPE_PQ) return launch_hnsw_pq(q->stream, a, h, grid, per_cu);
+    if (s->dtype == QMX_DTYPE_BQ) return launch_hnsw_bq(q->stream, a, h, grid, per_cu);
     set_error("dtype %u not built yet", s->dtype);
     return QMX_ERR_NOT_SUPPORTED;
 }
@@ -1648,6 +1666,8 @@ static int32_t score_pairs_device(qmx_query *q, const PairSel &sel, const uint32
         rc = launch_pairs_sq(q->stream, (int)s->distance, a, sel, n_items, s->num_cus);
     } else if (s->dtype == QMX_DTYPE_PQ) {
         rc = launch_pairs_pq(q->stream, a, sel, n_items, s->num_cus);
+    } else if (s->dtype == QMX_DTYPE_BQ) {
+        rc = launch_pairs_bq(q->stream, a, sel, n_items, s->num_cus);
     } else {
         set_error("dtype %u not built yet", s->dtype);
         rc = QMX_ERR_NOT_SUPPORTED;
@@ -1975,6 +1995,36 @@ int32_t qmx_sq_encode(int32_t device_id, uint32_t distance, const qmx_sq_params 
             d_out = bout.p;
         }
         if ((rc = launch_sq_encode(nullptr, (int)distance, *params, dim, d_in, n, nullptr, 0, nullptr, (uint8_t *)d_out, 0, 0)) != QMX_OK) break;
+        if (!out_dev && hipMemcpy(out_rows, d_out, out_bytes, hipMemcpyDeviceToHost) != hipSuccess) { rc = QMX_ERR_OTHER; break; }
+        if (hipDeviceSynchronize() != hipSuccess) rc = QMX_ERR_OTHER;
+    } while (0);
+    bin.release();
+    bout.release();
+    return rc;
+}
+
+int32_t qmx_bq_encode(int32_t device_id, const float *in, uint64_t n, uint32_t dim, void *out_rows) {
+    QMX_REQUIRE((n == 0 || (in && out_rows)) && dim > 0, QMX_ERR_BAD_ARG, "bad argument");
+    QMX_TRY(check_device(device_id, nullptr));
+    if (n == 0) return QMX_OK;
+    const size_t row_bytes = (((size_t)dim + 127) / 128) * 16;
+    const size_t in_bytes = (size_t)n * dim * 4, out_bytes = (size_t)n * row_bytes;
+    DevBuf bin, bout;
+    const float *d_in = in;
+    void *d_out = out_rows;
+    int32_t rc = QMX_OK;
+    do {
+        if (!is_device_ptr(in)) {
+            if ((rc = bin.reserve(in_bytes)) != QMX_OK) break;
+            if (hipMemcpy(bin.p, in, in_bytes, hipMemcpyHostToDevice) != hipSuccess) { rc = QMX_ERR_OTHER; break; }
+            d_in = (const float *)bin.p;
+        }
+        const bool out_dev = is_device_ptr(out_rows);
+        if (!out_dev) {
+            if ((rc = bout.reserve(out_bytes)) != QMX_OK) break;
+            d_out = bout.p;
+        }
+        if ((rc = launch_bq_encode(nullptr, d_in, n, dim, (uint8_t *)d_out, row_bytes)) != QMX_OK) break;
         if (!out_dev && hipMemcpy(out_rows, d_out, out_bytes, hipMemcpyDeviceToHost) != hipSuccess) { rc = QMX_ERR_OTHER; break; }
         if (hipDeviceSynchronize() != hipSuccess) rc = QMX_ERR_OTHER;
     } while (0);

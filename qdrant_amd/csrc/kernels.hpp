@@ -37,6 +37,9 @@ struct ScanArgs {
     uint32_t flags;            // QMX_SEG_U8_SCALAR_ORDER ...
     // PQ
     uint32_t pq_m, pq_ncent;
+    // BQ: calculate_metric (encoded_vectors_binary.rs:766-810)
+    uint32_t bq_dim;           // original dimension
+    uint32_t bq_flip;          // 0: zeros - xor (every distance with its own invert), 1: xor - zeros
 };
 
 enum ScanMode { SCAN_TOPK = 0, SCAN_SCORES = 1 };
@@ -77,6 +80,7 @@ struct HnswArgs {
 int32_t launch_hnsw_dense(hipStream_t st, int dtype, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_pq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
+int32_t launch_hnsw_bq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_pack_level0(hipStream_t st, const uint64_t *offsets, const uint32_t *neighbors, uint32_t n_points, uint32_t stride, uint32_t *l0);
 constexpr uint32_t HNSW_MAX_EF = 512;
 // HNSW build (hnsw_build.hpp)
@@ -161,6 +165,10 @@ int32_t launch_sq_gather_rows(hipStream_t st, const void *codes, const float *of
 int32_t launch_sq_internal_query(hipStream_t st, const void *codes, const float *offsets, uint32_t actual_dim, const uint32_t *ids,
                                  uint32_t nq, uint64_t n_rows, float shift, void *tile, uint32_t q_stride, uint32_t aux_off,
                                  int *err_flag);
+// BQ 1-bit (scan_bq.hip)
+int32_t launch_scan_bq(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out);
+int32_t launch_pairs_bq(hipStream_t st, const ScanArgs &a, const PairSel &sel, uint64_t n_items, int num_cus);
+int32_t launch_bq_encode(hipStream_t st, const float *d_in, uint64_t n, uint32_t dim, uint8_t *d_out, uint64_t out_stride);
 // PQ (pq.hip)
 int32_t launch_scan_pq(hipStream_t st, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out);
 int32_t launch_pairs_pq(hipStream_t st, const ScanArgs &a, const PairSel &sel, uint64_t n_items, int num_cus);

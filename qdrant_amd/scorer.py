@@ -288,6 +288,61 @@ class EncodedVectorsPQ(VectorStorage):
         return out
 
 
+class BinaryQuantizer:
+    """`Metadata{vector_parameters, encoding: OneBit, query_encoding: SameAsStorage}` of `EncodedVectorsBin<u128>`
+    (lib/quantization/src/encoded_vectors_binary.rs:43-60).  `invert` defaults to the segment's choice
+    (quantized_vectors.rs:232: Euclid | Manhattan)."""
+
+    def __init__(self, dim: int, distance: Distance, invert: Optional[bool] = None):
+        self.dim = int(dim)
+        self.distance = Distance(distance)
+        natural = self.distance in (Distance.Euclid, Distance.Manhattan)
+        self.invert = natural if invert is None else bool(invert)
+        self._toggle = self.invert != natural
+
+    def quantized_vector_size(self) -> int:
+        """get_quantized_vector_size_from_params::<u128>(dim, OneBit) (:829-840)."""
+        return (max(self.dim, 1) + 127) // 128 * 16
+
+    def encode(self, vectors, device_id: int = 0) -> np.ndarray:
+        """`encode_one_bit_vector` (:558-568) on device: [n, dim] f32 -> [n, ceil(dim / 128) * 16] bytes."""
+        v = np.ascontiguousarray(vectors, dtype=np.float32)
+        out = np.empty((v.shape[0], self.quantized_vector_size()), dtype=np.uint8)
+        F.check(F.lib().qmx_bq_encode(device_id, F.ptr(v), v.shape[0], self.dim, F.ptr(out)))
+        return out
+
+
+class EncodedVectorsBin(VectorStorage):
+    """Device-resident `EncodedVectorsBin<u128>` storage (1 bit per dimension): rows = [n, ceil(dim / 128) * 16] bytes."""
+
+    def __init__(self, rows, quantizer: BinaryQuantizer, device_id: int = 0):
+        self._h = C.c_void_p()
+        self.quantizer = quantizer
+        self.distance = quantizer.distance
+        self.datatype = None
+        rows = np.ascontiguousarray(rows, dtype=np.uint8)
+        assert rows.shape[1] == quantizer.quantized_vector_size()
+        self.dim = quantizer.dim
+        self.count = int(rows.shape[0])
+        self._keep = None
+        desc = F.SegmentDesc()
+        desc.dtype = F.DTYPE_BQ
+        desc.distance = int(quantizer.distance)
+        desc.dim = quantizer.dim
+        desc.flags = F.SEG_BQ_TOGGLE_INVERT if quantizer._toggle else 0
+        desc.n = self.count
+        desc.row_stride_bytes = 0
+        desc.data = F.ptr(rows)
+        desc.device_id = device_id
+        F.check(F.lib().qmx_segment_create(C.byref(desc), C.byref(self._h)))
+
+    def get_quantized_vector(self, ids: Sequence[int]) -> np.ndarray:
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        out = np.empty((len(ids), self.quantizer.quantized_vector_size()), dtype=np.uint8)
+        F.check(F.lib().qmx_segment_read_rows(self._h, F.ptr(ids), len(ids), F.ptr(out)))
+        return out
+
+
 class RawScorer:
     """`Box<dyn RawScorer>` for a batch of `QueryVector::Nearest` queries (raw_scorer.rs:39-58).
     One instance holds `nq` scorers; single-query use is nq == 1."""
@@ -362,6 +417,10 @@ class RawScorer:
         if isinstance(self.storage, EncodedVectorsPQ):   # EncodedQueryPQ {lut: Vec<f32>} = [m][n_centroids]
             qz = self.storage.quantizer
             out = np.empty((qz.m, qz.n_centroids), dtype=np.float32)
+            F.check(F.lib().qmx_query_read_encoded(self._h, query_index, F.ptr(out), out.nbytes, None))
+            return out
+        if isinstance(self.storage, EncodedVectorsBin):  # EncodedBinVector {encoded_vector: Vec<u128>} as bytes
+            out = np.empty(self.storage.quantizer.quantized_vector_size(), dtype=np.uint8)
             F.check(F.lib().qmx_query_read_encoded(self._h, query_index, F.ptr(out), out.nbytes, None))
             return out
         if isinstance(self.storage, EncodedVectorsU8):   # EncodedQueryU8 {offset: f32, encoded_query: Vec<u8>}

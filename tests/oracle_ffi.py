@@ -91,6 +91,10 @@ _sig("qo_pq_score", _f, [C.POINTER(Pq), _P, _P, C.c_int])
 _sig("qo_pq_score_internal", _f, [C.POINTER(Pq), _P, _P])
 _sig("qo_pq_train", None, [C.c_uint32, C.c_uint32, C.c_uint32, _P, C.c_size_t, C.c_int, _P])
 _sig("qo_custom_combine", _f, [C.c_int, C.c_uint32, C.c_uint32, _P])
+_sig("qo_bq_row_bytes", C.c_size_t, [C.c_uint32])
+_sig("qo_bq_encode_row", None, [C.c_uint32, _P, _P])
+_sig("qo_bq_xor_popcnt", C.c_uint32, [_P, _P, C.c_uint32])
+_sig("qo_bq_score", _f, [C.c_int, C.c_int, C.c_uint32, _P, _P])
 _sig("qo_pq_train_ex", None, [C.c_uint32, C.c_uint32, C.c_uint32, _P, C.c_size_t, C.c_uint32, C.c_float, C.c_uint32, _P, _P])
 
 lib = _lib
@@ -275,6 +279,40 @@ class SqOracle:
                          for i, j in zip(a, b)], dtype=np.float32)
 
 
+class BqOracle:
+    """EncodedVectorsBin<u128>, OneBit, SameAsStorage on the CPU (oracle).  invert defaults to the segment's choice
+    (quantized_vectors.rs:232: Euclid | Manhattan)."""
+
+    def __init__(self, distance, dim, invert=None):
+        self.distance, self.dim = distance, dim
+        self.invert = int(distance in (EUCLID, MANHATTAN)) if invert is None else int(invert)
+        self.row_bytes = int(_lib.qo_bq_row_bytes(dim))
+        self.rows = None
+
+    def encode(self, vectors):
+        v = f32(np.atleast_2d(vectors))
+        out = np.zeros((v.shape[0], self.row_bytes), dtype=np.uint8)
+        for i in range(v.shape[0]):
+            _lib.qo_bq_encode_row(self.dim, _p(v[i]), _p(out[i]))
+        return out
+
+    def encode_rows(self, vectors):
+        self.rows = self.encode(vectors)
+        return self.rows
+
+    def score_points(self, queries_preprocessed, ids):
+        qs = self.encode(queries_preprocessed)
+        out = np.empty((qs.shape[0], len(ids)), dtype=np.float32)
+        for qi in range(qs.shape[0]):
+            for j, i in enumerate(ids):
+                out[qi, j] = _lib.qo_bq_score(self.distance, self.invert, self.dim, _p(qs[qi]), _p(self.rows[i]))
+        return out
+
+    def score_internal(self, a, b):
+        return np.array([_lib.qo_bq_score(self.distance, self.invert, self.dim, _p(self.rows[i]), _p(self.rows[j]))
+                         for i, j in zip(a, b)], dtype=np.float32)
+
+
 class PqOracle:
     """EncodedVectorsPQ on the CPU (oracle): given centroids [n_centroids, dim]."""
 
@@ -335,7 +373,8 @@ class PqOracle:
 class Scorer(C.Structure):
     _fields_ = [("kind", C.c_int), ("st", C.POINTER(Storage)), ("query", _P),
                 ("sq", C.POINTER(Sq)), ("sq_rows", _P), ("sq_query", _P), ("sq_query_offset", _f),
-                ("pq", C.POINTER(Pq)), ("pq_codes", _P), ("pq_lut", _P), ("isa", C.c_int)]
+                ("pq", C.POINTER(Pq)), ("pq_codes", _P), ("pq_lut", _P), ("isa", C.c_int),
+                ("bq_rows", _P), ("bq_query", _P), ("bq_dim", C.c_uint32), ("bq_distance", C.c_int), ("bq_invert", C.c_int)]
 
 
 _sig("qo_merge_topk", None, [_P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P])
@@ -497,6 +536,15 @@ class Hnsw:
             s = Scorer()
             s.kind, s.st, s.sq, s.sq_rows = 1, C.pointer(flags_storage.st), C.pointer(sq.sq), sq.rows.ctypes.data
             s.sq_query, s.sq_query_offset, s.isa = codes.ctypes.data, off, sq.isa
+            res.append(self._run(s, top, ef)[0])
+        return res
+
+    def search_bq(self, flags_storage: DenseStorage, bq: "BqOracle", queries_preprocessed, top, ef):
+        res = []
+        for qb in bq.encode(queries_preprocessed):
+            s = Scorer()
+            s.kind, s.st, s.bq_rows, s.bq_query = 3, C.pointer(flags_storage.st), bq.rows.ctypes.data, qb.ctypes.data
+            s.bq_dim, s.bq_distance, s.bq_invert = bq.dim, bq.distance, bq.invert
             res.append(self._run(s, top, ef)[0])
         return res
 

@@ -1,0 +1,159 @@
+"""GPU parity: EncodedVectorsBin<u128> (binary quantization, Encoding::OneBit, QueryEncoding::SameAsStorage) through the
+C-ABI against the CPU oracle: encode, encoded query, score_point, score_internal, ragged hop scoring, brute-force top-k,
+HNSW walk, oversampled search + rescoring.  Everything here is integer work: BIT-EXACT.
+Reference: lib/quantization/src/encoded_vectors_binary.rs; its tests lib/quantization/tests/integration/test_binary.rs.
+"""
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+
+pytestmark = pytest.mark.gpu
+
+DIMS = [1, 8, 33, 65, 127, 128, 129, 3 * 129, 768, 1000, 1536, 4096]
+
+
+@pytest.fixture(scope="module")
+def qa():
+    import qdrant_amd
+    assert qdrant_amd.device_count() >= 1
+    return qdrant_amd
+
+
+def _dist(qa, d):
+    return {O.COSINE: qa.Distance.Cosine, O.DOT: qa.Distance.Dot, O.EUCLID: qa.Distance.Euclid,
+            O.MANHATTAN: qa.Distance.Manhattan}[d]
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("dist", [O.DOT, O.COSINE, O.EUCLID, O.MANHATTAN])
+@pytest.mark.parametrize("dim", DIMS)
+def test_bq_encode_and_scores_bit_exact(qa, dist, dim):
+    n, nq = 600, 5
+    rng = np.random.default_rng(dim * 7 + dist)
+    vecs = O.preprocess(dist, rng.standard_normal((n, dim)).astype(np.float32))
+    vecs[3, : min(dim, 4)] = 0.0                                     # > 0.0 only
+    quant = qa.BinaryQuantizer(dim, _dist(qa, dist))
+    obq = O.BqOracle(dist, dim)
+    assert quant.quantized_vector_size() == obq.row_bytes and int(quant.invert) == obq.invert
+    want_rows = obq.encode_rows(vecs)
+    got_rows = quant.encode(vecs)
+    assert np.array_equal(got_rows, want_rows)
+    st = qa.EncodedVectorsBin(got_rows, quant)
+    assert np.array_equal(st.get_quantized_vector([3, n - 1]), want_rows[[3, n - 1]])
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    qpre = O.preprocess(dist, queries)
+    scorer = qa.new_raw_scorer(queries, st)
+    for i in range(nq):
+        assert np.array_equal(scorer.encoded_query(i), obq.encode(qpre[i])[0])
+    ids = rng.permutation(n).astype(np.uint32)[:300]
+    want = obq.score_points(qpre, ids)
+    assert np.array_equal(_bits(scorer.score_points(ids)), _bits(want))
+    a, b = ids[:64], ids[64:128]
+    assert np.array_equal(_bits(scorer.score_internal(a, b)), _bits(obq.score_internal(a, b)))
+    lists = [ids[:7], ids[7:40], ids[40:41], ids[:0], ids[41:60]]
+    for r, (lo, hi), qi in zip(scorer.score_points_ragged(lists), [(0, 7), (7, 40), (40, 41), (0, 0), (41, 60)], range(5)):
+        assert np.array_equal(_bits(r), _bits(want[qi, lo:hi]))
+    # the stored row IS the internal query (encode_internal_vector :923-934)
+    internal = qa.new_raw_scorer_internal([1, 2, n - 1], st)
+    for i, pid in enumerate([1, 2, n - 1]):
+        assert np.array_equal(internal.encoded_query(i), want_rows[pid])
+    wi = np.stack([obq.score_internal(np.full(len(ids), pid), ids) for pid in [1, 2, n - 1]])
+    assert np.array_equal(_bits(internal.score_points(ids)), _bits(wi))
+
+
+@pytest.mark.parametrize("dist,invert", [(O.DOT, True), (O.COSINE, True), (O.EUCLID, False), (O.MANHATTAN, False)])
+def test_bq_toggled_invert_like_the_reference_tests(qa, dist, invert):
+    """test_binary.rs:77-127 (dot inverted), :238-292 (l1 not inverted): +-1 vectors, score == -+ dot exactly."""
+    n, dim = 128, 3 * 129
+    rng = np.random.default_rng(42)
+    vecs = np.where(rng.uniform(-1, 1, (n, dim)) >= 0, 1.0, -1.0).astype(np.float32)
+    query = np.where(rng.uniform(-1, 1, (1, dim)) >= 0, 1.0, -1.0).astype(np.float32)
+    quant = qa.BinaryQuantizer(dim, _dist(qa, dist), invert=invert)
+    st = qa.EncodedVectorsBin(quant.encode(vecs), quant)
+    scorer = qa.new_raw_scorer(query * 3.0, st)                      # any positive scale: same bits (cosine normalises)
+    got = scorer.score_points(np.arange(n, dtype=np.uint32))[0]
+    dot = (vecs.astype(np.float64) @ query[0].astype(np.float64)).astype(np.float32)
+    assert np.array_equal(got, -dot)
+    obq = O.BqOracle(dist, dim, invert=invert)
+    obq.encode_rows(vecs)
+    assert np.array_equal(_bits(got), _bits(obq.score_points(query, np.arange(n))[0]))
+
+
+@pytest.mark.parametrize("dist", [O.COSINE, O.EUCLID])
+@pytest.mark.parametrize("nq,top", [(1, 10), (7, 100), (33, 5)])
+def test_bq_brute_force_topk(qa, dist, nq, top):
+    n, dim = 20000, 256
+    rng = np.random.default_rng(nq + top)
+    vecs = O.preprocess(dist, rng.standard_normal((n, dim)).astype(np.float32))
+    quant = qa.BinaryQuantizer(dim, _dist(qa, dist))
+    st = qa.EncodedVectorsBin(quant.encode(vecs), quant)
+    deleted = rng.permutation(n)[:500]
+    mask = np.zeros(n, dtype=bool)
+    mask[deleted] = True
+    st.set_deleted(mask)
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    obq = O.BqOracle(dist, dim)
+    obq.encode_rows(vecs)
+    got = qa.BatchFilteredSearcher(queries, st, top).peek_top_all()
+    live = np.setdiff1d(np.arange(n), deleted)
+    want = obq.score_points(O.preprocess(dist, queries), live)
+    for qi in range(nq):
+        # integer scores tie heavily: the score list is pinned, the id set only above the boundary score
+        ws = np.sort(want[qi])[::-1][:top]
+        assert np.array_equal(_bits(got[qi]["score"]), _bits(ws))
+        sure = set(live[want[qi] > ws[-1]].tolist())
+        assert sure <= set(got[qi]["idx"].tolist())
+        assert not (set(got[qi]["idx"].tolist()) & set(deleted.tolist()))
+        by_id = dict(zip(live.tolist(), want[qi].tolist()))
+        assert all(by_id[int(i)] == s for i, s in zip(got[qi]["idx"], got[qi]["score"]))
+
+
+def test_bq_hnsw_walk_and_oversampled_rescoring(qa):
+    """hnsw_quantized_search_test.rs flow with binary quantization: walk the graph with the BQ scorer (oversampled), rescore
+    with the original vectors.  BQ scores are small integers: ties everywhere, so (as for Manhattan SQ) the walk is compared
+    on what is pinned: returned scores are true BQ scores in descending order and the recall matches the oracle's walk."""
+    n, dim, m, nq, top = 4000, 256, 8, 32, 10
+    rng = np.random.default_rng(77)
+    centers = rng.standard_normal((32, dim)).astype(np.float32)
+    rows = O.preprocess(O.COSINE, (centers[rng.integers(0, 32, n)] + 0.6 * rng.standard_normal((n, dim))).astype(np.float32))
+    queries = O.preprocess(O.COSINE, (centers[rng.integers(0, 32, nq)] + 0.6 * rng.standard_normal((nq, dim))).astype(np.float32))
+    st = O.DenseStorage(O.F32, O.COSINE, rows)
+    g = O.Hnsw(st, m=m, ef_construct=64, seed=3, threads=0)
+    graph = qa.GraphLayers.from_plain(g.export_plain())
+    quant = qa.BinaryQuantizer(dim, qa.Distance.Cosine)
+    enc = qa.EncodedVectorsBin(quant.encode(rows), quant)
+    obq = O.BqOracle(O.COSINE, dim)
+    obq.encode_rows(rows)
+    scorer = qa.new_raw_scorer(queries, enc)
+    got = graph.search(30, 64, scorer)
+    want = g.search_bq(st, obq, queries, 30, 64)
+    all_scores = obq.score_points(queries, np.arange(n))
+    exact_bq = [set(np.argsort(-all_scores[i], kind="stable")[:30].tolist()) for i in range(nq)]
+    rg = sum(len(set(r["idx"].tolist()) & e) for r, e in zip(got, exact_bq))
+    rw = sum(len(set(r["idx"].tolist()) & e) for r, e in zip(want, exact_bq))
+    assert abs(rg - rw) <= 0.05 * 30 * nq
+    for i, r in enumerate(got):
+        assert len(r) == 30 and np.all(np.diff(r["score"]) <= 0) and len(set(r["idx"].tolist())) == 30
+        assert np.array_equal(_bits(r["score"]), _bits(all_scores[i][r["idx"]]))
+    vs = qa.VectorStorage(rows, qa.Distance.Cosine)
+    raw = qa.new_raw_scorer(queries, vs)
+    res = qa.search_quantized(scorer, raw, top, oversampling=3.0, rescore=True, graph=graph, hnsw_ef=64)
+    exact = st.peek_top(queries, top)
+    hit = sum(len(set(a["idx"].tolist()) & set(b["idx"].tolist())) for a, b in zip(res, exact))
+    assert hit / (top * nq) > 0.5                                  # hnsw_quantized_search_test.rs asks for > 0.4
+    for i, r in enumerate(res):
+        w = st.score_points(queries[i:i + 1], r["idx"])[0]
+        assert np.array_equal(_bits(r["score"]), _bits(w))
+
+
+def test_bq_argument_errors(qa):
+    quant = qa.BinaryQuantizer(100, qa.Distance.Dot)
+    with pytest.raises(AssertionError):
+        qa.EncodedVectorsBin(np.zeros((4, 13), dtype=np.uint8), quant)
+    st = qa.EncodedVectorsBin(np.zeros((0, 16), dtype=np.uint8), quant)    # empty storage
+    got = qa.BatchFilteredSearcher(np.ones((2, 100), dtype=np.float32), st, 5).peek_top_all()
+    assert all(len(r) == 0 for r in got)

@@ -153,6 +153,44 @@ def main():
         del rows16
         torch.cuda.empty_cache()
 
+    if "bq" in args.configs:
+        for dim in (768, 1536):
+            rows = make_rows(dim, 0x5EED0005)
+            rb = (dim + 127) // 128 * 16
+            enc_rows = torch.empty((n, rb), dtype=torch.uint8, device=dev)
+            t0 = time.perf_counter()
+            F.check(lib.qmx_bq_encode(0, F.ptr(rows), n, dim, F.ptr(enc_rows)))
+            torch.cuda.synchronize()
+            t_enc = time.perf_counter() - t0
+            host_rows = rows[:S].cpu().numpy()
+            host_enc = enc_rows[:S].cpu().numpy()
+            del rows
+            torch.cuda.empty_cache()
+            d = F.SegmentDesc()
+            d.dtype, d.distance, d.dim, d.flags, d.n, d.data, d.device_id = F.DTYPE_BQ, int(qa.Distance.Cosine), dim, F.SEG_DATA_ON_DEVICE, n, F.ptr(enc_rows).value, 0
+            seg = C.c_void_p()
+            F.check(lib.qmx_segment_create(C.byref(d), C.byref(seg)))
+            obq = O.BqOracle(O.COSINE, dim)
+            enc_ok = bool(np.array_equal(obq.encode(host_rows[:2000]), host_enc[:2000]))
+            obq.rows = host_enc
+            queries = O.preprocess(O.COSINE, O.synth(0x5EED0015, 0, 64, dim))
+            ids = torch.arange(S, dtype=torch.int32, device=dev)
+
+            def check(qh, Q, out, counts):
+                F.check(lib.qmx_search_topk_async(qh, top, F.ptr(ids), S, F.ptr(out), F.ptr(counts)))
+                F.check(lib.qmx_query_synchronize(qh))
+                g = out.cpu().numpy()
+                gs = g[:, :, 1].copy().view(np.float32)
+                sc = obq.score_points(queries[:1], np.arange(min(S, 20000)))
+                full = out.cpu().numpy()
+                del full
+                return enc_ok and bool(np.all(np.diff(gs[0]) <= 0)) and float(gs[0][0]) >= float(sc[0].max())
+            print(json.dumps({"config": "BQ encode d=%d" % dim, "bq_encode_s": round(t_enc, 3), "rows": n, "encoded_rows_match_oracle_first_2000": enc_ok}), flush=True)
+            run("BQ: 10M x %d 1-bit (u128) cosine, brute-force top-10" % dim, seg, dim, rb, queries, check)
+            F.check(lib.qmx_segment_destroy(seg))
+            del enc_rows
+            torch.cuda.empty_cache()
+
     if "c4" in args.configs:
         dim, chunk = 1536, 16
         rows = make_rows(dim, 0x5EED0004)
