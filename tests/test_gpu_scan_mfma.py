@@ -92,6 +92,90 @@ def test_large_scan_property(qa):
         assert np.array_equal(g["score"].view(np.uint32), v["score"].view(np.uint32))
 
 
+# ---- 32-query tiles on v_mfma_f32_16x16x4_f32, chain-major (scan_mfma16.hip) -----------------------------------------
+@pytest.mark.parametrize("dist", [O.DOT, O.COSINE])
+@pytest.mark.parametrize("dim", [256, 512, 768, 1024, 1280, 1536])
+@pytest.mark.parametrize("nq", [17, 32, 45])
+def test_mfma16_every_score_bit_exact(qa, dist, dim, nq):
+    """top = 1000 of 1003 rows returns (nearly) every score: the whole accumulate + fold order of the kernel is pinned against the
+    oracle's dot_similarity_avx, including the multi-pass bound (top > 64) and rows past the last full 16-row tile."""
+    rng = np.random.default_rng(dim + nq * 3 + dist)
+    n, top = 1003, 1000
+    rows = O.preprocess(dist, (rng.standard_normal((n, dim)) * 3).astype(np.float32))
+    queries = (rng.standard_normal((nq, dim)) * 2).astype(np.float32)
+    st = qa.VectorStorage(rows, _dist(qa, dist))
+    s = qa.BatchFilteredSearcher(queries, st, top)
+    got = s.peek_top_all()
+    want = O.DenseStorage(O.F32, dist, rows).peek_top(queries, top)
+    for g, w in zip(got, want):
+        assert len(g) == top
+        assert np.array_equal(g["score"].view(np.uint32), w["score"].view(np.uint32))
+        uniq = np.array([(w["score"] == x).sum() == 1 for x in w["score"]])
+        assert np.array_equal(g["idx"][uniq], w["idx"][uniq])
+    os.environ["QMX_NO_MFMA16"] = "1"
+    try:
+        other = s.peek_top_all()
+    finally:
+        del os.environ["QMX_NO_MFMA16"]
+    for g, o in zip(got, other):
+        assert np.array_equal(g["score"].view(np.uint32), o["score"].view(np.uint32))
+
+
+@pytest.mark.parametrize("top", [1, 10, 64])
+def test_mfma16_deleted_filtered_and_ties(qa, top):
+    rng = np.random.default_rng(top)
+    n, dim, nq = 40011, 256, 32
+    rows = O.preprocess(O.COSINE, rng.standard_normal((n, dim)).astype(np.float32))
+    rows[5000:5040] = rows[17]                                # equal scores: ties -> lower id first
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    queries[3] = rows[17]
+    deleted = rng.random(n) < 0.2
+    vec_deleted = rng.random(n) < 0.05
+    st = qa.VectorStorage(rows, qa.Distance.Cosine)
+    st.set_deleted(deleted, vec_deleted)
+    truth = O.DenseStorage(O.F32, O.COSINE, rows, point_deleted=deleted, vec_deleted=vec_deleted)
+    got = qa.BatchFilteredSearcher(queries, st, top).peek_top_all()
+    want = truth.peek_top(queries, top)
+    for g, w in zip(got, want):
+        assert np.array_equal(g["score"].view(np.uint32), w["score"].view(np.uint32))
+        uniq = np.array([(w["score"] == x).sum() == 1 for x in w["score"]])
+        assert np.array_equal(g["idx"][uniq], w["idx"][uniq])
+    # payload filter bitmap (ScorerFilters) on top of the deleted flags
+    allowed = rng.random(n) < 0.3
+    fs = qa.BatchFilteredSearcher(queries, st, top)
+    fs.scorer.set_filter(allowed)
+    got = fs.peek_top_all()
+    truth2 = O.DenseStorage(O.F32, O.COSINE, rows, point_deleted=deleted | ~allowed, vec_deleted=vec_deleted)
+    for g, w in zip(got, truth2.peek_top(queries, top)):
+        assert np.array_equal(g["score"].view(np.uint32), w["score"].view(np.uint32))
+
+
+def test_mfma16_large_scan_equals_the_other_kernels(qa):
+    """2M x 768: same lists from the chain-major kernel and from the 4x4x1 kernel (both bit-exact), and every run repeats."""
+    import torch
+    from qdrant_amd import _ffi as F
+    n, dim, nq, top = 2_000_003, 768, 32, 10
+    dev = torch.device("cuda", 0)
+    rows = torch.empty((n, dim), dtype=torch.float32, device=dev)
+    F.check(F.lib().qmx_synth_fill_f32(0, 0x5EED00A1, 0, n, dim, F.ptr(rows)))
+    F.check(F.lib().qmx_preprocess_f32(0, int(qa.Distance.Cosine), F.ptr(rows), n, dim, F.ptr(rows)))
+    torch.cuda.synchronize()
+    st = qa.VectorStorage(rows, qa.Distance.Cosine)
+    queries = O.synth(0x5EED00A2, 0, nq, dim)
+    s = qa.BatchFilteredSearcher(queries, st, top)
+    got = s.peek_top_all()
+    again = s.peek_top_all()
+    os.environ["QMX_NO_MFMA16"] = "1"
+    try:
+        other = s.peek_top_all()
+    finally:
+        del os.environ["QMX_NO_MFMA16"]
+    for g, a2, o in zip(got, again, other):
+        assert np.array_equal(g, a2)
+        assert g["idx"].tolist() == o["idx"].tolist()
+        assert np.array_equal(g["score"].view(np.uint32), o["score"].view(np.uint32))
+
+
 # ---- SQ int8 on v_mfma_i32_16x16x64_i8 (scan_sq_mfma.hip) ---------------------------------------------------------
 def _dist_all(qa, d):
     return {O.COSINE: qa.Distance.Cosine, O.DOT: qa.Distance.Dot, O.EUCLID: qa.Distance.Euclid}[d]
