@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32-input MFMA peak (same guide: v_mfma_f32_16x16x4_f32 / 32x32x2, 64 FLOP/clk/SIMD)
 
 
 def parse():
@@ -40,7 +41,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=768)
-    ap.add_argument("--batch", type=int, default=16, help="queries per scan (Q)")
+    ap.add_argument("--batch", type=int, default=64, help="queries per scan (Q)")
     ap.add_argument("--top", type=int, default=10)
     ap.add_argument("--nqueries", type=int, default=1024)
     ap.add_argument("--cpu-rows", type=int, default=1_000_000, help="rows of the CPU-baseline sample")
@@ -154,10 +155,7 @@ def main():
                    "rows_per_gpu": n, "dim": dim, "batch": Q, "top": top, "distinct_queries": nbatches * Q,
                    "unit_of_value": "(query, 10M-row segment) searches per second; at n_gpus=1 this is plain QPS",
                    "collection_qps": round(Q * args.steps / elapsed, 2)},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": _pmc_traffic(n, dim, Q),
-                     "kernel": _kernel_name(Q), "kernel_ms": round(kernel_ms, 4),
-                     "launches_timed": int(kl.value), "algorithmic_bytes_per_launch": alg_bytes},
+        "roofline": _roofline(n, dim, Q, kernel_ms, alg_bytes, achieved, int(kl.value)),
     }
 
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -275,6 +273,28 @@ def cpu_baseline(args, rows, queries, out, counts, n, dim, Q, top, lib, qh, F, q
             "gpu_matches_oracle_on_sample": ok}
 
 
+def _roofline(n, dim, Q, kernel_ms, alg_bytes, achieved_gbps, launches):
+    """The dominant kernel against BOTH ceilings; `bound` is the one it sits closer to.  Up to 16 queries per pass the scan is
+    an HBM stream (every row byte read once: SURVEY 8d, 3072 B / row at d = 768); the 32- / 64-query passes of scan_mfma16.hip
+    do 2 * dim flops per (row, query) on the f32 matrix cores and cross over to the MFMA ceiling."""
+    per_pass = min(Q, _queries_per_pass(dim, Q))
+    flops = 2.0 * n * dim * per_pass
+    tflops = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+    hbm_frac, mfma_frac = achieved_gbps / HBM_PEAK_GBPS, tflops / MFMA_F32_PEAK_TFLOPS
+    common = {"traffic": _pmc_traffic(n, dim, Q), "kernel": _kernel_name(dim, Q), "kernel_ms": round(kernel_ms, 4), "launches_timed": launches,
+              "queries_per_launch": per_pass, "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_flops_per_launch": flops,
+              "hbm": {"achieved_GBps": round(achieved_gbps, 1), "peak_GBps": HBM_PEAK_GBPS, "frac": round(hbm_frac, 4)},
+              "mfma_f32": {"achieved_TFLOPs": round(tflops, 2), "peak_TFLOPs": MFMA_F32_PEAK_TFLOPS, "frac": round(mfma_frac, 4)}}
+    if mfma_frac > hbm_frac:
+        return dict({"bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(mfma_frac, 4)}, **common)
+    return dict({"bound": "hbm", "achieved": round(achieved_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(hbm_frac, 4)}, **common)
+
+
+def _queries_per_pass(dim, Q):
+    """api.hip search_enqueue: 64 per pass on the chain-major kernel (f32, dim 256 / 512 / 768, more than 32 queries), else 32."""
+    return 64 if (Q > 32 and dim % 256 == 0 and dim <= 768) else 32
+
+
 def _pmc_traffic(n, dim, Q):
     """HBM bytes per scan launch from a separate `rocprofv3 --pmc FETCH_SIZE` pass (committed under
     profiles/); null when no such pass exists for this shape."""
@@ -286,10 +306,16 @@ def _pmc_traffic(n, dim, Q):
         return None
 
 
-def _kernel_name(Q):
-    """The scan kernel a batch of Q queries runs (api.hip launch_scan): <= 4 queries per pass stream through the VALU
-    kernel, 8..32 through the f32 matrix-core kernel (scan_mfma.hip); larger batches are cut into 32-query passes."""
+def _kernel_name(dim, Q):
+    """The scan kernel a batch of Q queries runs (api.hip search_enqueue / launch_scan): <= 4 queries per pass stream through the
+    VALU kernel, 8..16 through scan_mfma.hip (v_mfma_f32_4x4x1), 17.. through the chain-major scan_mfma16.hip (v_mfma_f32_16x16x4)
+    when the rows are 256 / 512 / 768 floats."""
+    m16 = dim % 256 == 0 and dim <= 768
+    if Q > 32 and m16:
+        return "scan_f32_mfma16_kernel<KS=%d,NW=8,NT=4> (v_mfma_f32_16x16x4_f32, 64 queries per pass)" % (dim // 256)
     qt = _pow2(min(Q, 32))
+    if qt == 32 and m16:
+        return "scan_f32_mfma16_kernel<KS=%d,NW=4,NT=2> (v_mfma_f32_16x16x4_f32, 32 queries per pass)" % (dim // 256)
     if qt >= 8:
         return "scan_f32_mfma_kernel<QW=%d,QSPLIT=%d> (v_mfma_f32_4x4x1, %d queries per pass)" % (min(qt, 16), max(1, qt // 16), qt)
     return "scan_kernel<RowF32<DOT>,QT=%d>" % qt

@@ -196,6 +196,7 @@ static bool mfma_scan_ok(const qmx_segment *s) {
            s->fast_layout() && getenv("QMX_NO_MFMA_SCAN") == nullptr;
 }
 constexpr uint32_t MAX_QT_MFMA = 32;
+constexpr uint32_t MAX_QT_TOPK = 64;   // the chain-major f32 top-k scan (scan_mfma16.hip) takes 64 queries per pass of the block
 // queries scored per pass of the stored block
 static uint32_t tile_qt(const qmx_segment *s) {
     if (s->dtype == QMX_DTYPE_SQ_U8) return mfma_scan_ok(s) ? MAX_QT_MFMA : MAX_QT;
@@ -597,8 +598,8 @@ static int32_t query_alloc(const qmx_segment *seg, uint32_t nq, qmx_query **out)
     q->seg = seg;
     q->device = seg->device;
     q->nq = nq;
-    q->nq_padded = ((nq + MAX_QT_MFMA - 1) / MAX_QT_MFMA) * MAX_QT_MFMA;
-    if (q->nq_padded == 0) q->nq_padded = MAX_QT_MFMA;
+    q->nq_padded = ((nq + MAX_QT_TOPK - 1) / MAX_QT_TOPK) * MAX_QT_TOPK;
+    if (q->nq_padded == 0) q->nq_padded = MAX_QT_TOPK;
     if (seg->dtype == QMX_DTYPE_PQ) q->nq_padded = std::max<uint32_t>(nq, 1);   // LUTs are never read past nq
     // tile entry = elements zero-padded to whole 128-byte segments + the aux block
     q->aux_off = (uint32_t)((seg->scan_dim * elem_bytes(seg->dtype) + 127) & ~127u);
@@ -952,7 +953,10 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
     const uint64_t n_cand = d_ids ? n_ids : s->scan_rows();
     // partial lists: one per block; bound the grid by what the buffer holds
     const uint32_t grid_cap = (uint32_t)s->num_cus * 8;
-    const uint32_t TQ = tile_qt(s);
+    // f32 dot / cosine rows of 256, 512 or 768 floats, whole block: 64 queries per pass (scan_mfma16.hip); everything else 32 / 16
+    const bool q64 = s->dtype == QMX_DTYPE_F32 && mfma_scan_ok(s) && !d_ids && q->nq > MAX_QT_MFMA && s->dim % 256 == 0 && s->dim <= 768 &&
+                     getenv("QMX_NO_MFMA16") == nullptr && getenv("QMX_NO_MFMA16_Q64") == nullptr;
+    const uint32_t TQ = q64 ? MAX_QT_TOPK : tile_qt(s);
     const uint32_t ptop_max = std::min<uint32_t>(top, MAX_TOP_FAST);
     const uint32_t n_pass = (top + MAX_TOP_FAST - 1) / MAX_TOP_FAST;
     QMX_TRY(q->partial.reserve((size_t)grid_cap * TQ * ptop_max * sizeof(uint64_t)));

@@ -165,9 +165,9 @@ int32_t launch_sq_gather_rows(hipStream_t st, const void *codes, const float *of
 int32_t launch_sq_internal_query(hipStream_t st, const void *codes, const float *offsets, uint32_t actual_dim, const uint32_t *ids,
                                  uint32_t nq, uint64_t n_rows, float shift, void *tile, uint32_t q_stride, uint32_t aux_off,
                                  int *err_flag);
-// f32 dot / cosine, 32-query tile on v_mfma_f32_16x16x4_f32, chain-major (scan_mfma16.hip)
-bool mfma16_scan_ok(ScanMode mode, const ScanArgs &a);
-int32_t launch_scan_f32_mfma16(hipStream_t st, const ScanArgs &a, int num_cus, uint32_t *grid_out);
+// f32 dot / cosine, 32- and 64-query tiles on v_mfma_f32_16x16x4_f32, chain-major (scan_mfma16.hip)
+bool mfma16_scan_ok(int qt, ScanMode mode, const ScanArgs &a);   // qt = 32 or 64
+int32_t launch_scan_f32_mfma16(hipStream_t st, int qt, const ScanArgs &a, int num_cus, uint32_t *grid_out);
 // BQ 1-bit (scan_bq.hip)
 int32_t launch_scan_bq(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out);
 int32_t launch_pairs_bq(hipStream_t st, const ScanArgs &a, const PairSel &sel, uint64_t n_items, int num_cus);

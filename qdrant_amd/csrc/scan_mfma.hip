@@ -382,7 +382,7 @@ int32_t launch_scan_f32_mfma(hipStream_t st, int qt, ScanMode mode, const ScanAr
             if (a.nseg % 12 == 0 && getenv("QMX_MFMA_NO_FAST") == nullptr) return launch_mfma_qt<16, 1, 6, true, 8, true>(st, mode, a, num_cus, grid_out);
             return launch_mfma_qt<16, 1, 12, true>(st, mode, a, num_cus, grid_out);
         case 32: {
-            if (mfma16_scan_ok(mode, a)) return launch_scan_f32_mfma16(st, a, num_cus, grid_out);
+            if (mfma16_scan_ok(32, mode, a)) return launch_scan_f32_mfma16(st, 32, a, num_cus, grid_out);
             static const int variant = getenv("QMX_MFMA_VARIANT") ? atoi(getenv("QMX_MFMA_VARIANT")) : 0;   // tuning experiments
             if (variant == 1) return launch_mfma_qt<32, 1, 6, true, 8, false, true>(st, mode, a, num_cus, grid_out);   // query-half layout, generic loop
             if (variant == 2 && a.nseg % 12 == 0) return launch_mfma_qt<32, 1, 6, true, 8, true, true>(st, mode, a, num_cus, grid_out);   // + ping-pong
@@ -391,6 +391,7 @@ int32_t launch_scan_f32_mfma(hipStream_t st, int qt, ScanMode mode, const ScanAr
             return launch_mfma_qt<16, 2, 12, true>(st, mode, a, num_cus, grid_out);
         }
     }
+    if (qt == 64 && mfma16_scan_ok(64, mode, a)) return launch_scan_f32_mfma16(st, 64, a, num_cus, grid_out);   // api.hip only asks when it applies
     set_error("unsupported MFMA query tile %d", qt);
     return QMX_ERR_BAD_ARG;
 }

@@ -95,7 +95,7 @@ def test_large_scan_property(qa):
 # ---- 32-query tiles on v_mfma_f32_16x16x4_f32, chain-major (scan_mfma16.hip) -----------------------------------------
 @pytest.mark.parametrize("dist", [O.DOT, O.COSINE])
 @pytest.mark.parametrize("dim", [256, 512, 768, 1024, 1280, 1536])
-@pytest.mark.parametrize("nq", [17, 32, 45])
+@pytest.mark.parametrize("nq", [17, 32, 45, 64, 100])     # > 32 queries: 64-query tiles (45 -> one padded tile, 100 -> 64 + 36)
 def test_mfma16_every_score_bit_exact(qa, dist, dim, nq):
     """top = 1000 of 1003 rows returns (nearly) every score: the whole accumulate + fold order of the kernel is pinned against the
     oracle's dot_similarity_avx, including the multi-pass bound (top > 64) and rows past the last full 16-row tile."""
@@ -121,10 +121,11 @@ def test_mfma16_every_score_bit_exact(qa, dist, dim, nq):
         assert np.array_equal(g["score"].view(np.uint32), o["score"].view(np.uint32))
 
 
+@pytest.mark.parametrize("nq", [32, 64])
 @pytest.mark.parametrize("top", [1, 10, 64])
-def test_mfma16_deleted_filtered_and_ties(qa, top):
+def test_mfma16_deleted_filtered_and_ties(qa, top, nq):
     rng = np.random.default_rng(top)
-    n, dim, nq = 40011, 256, 32
+    n, dim = 40011, 256
     rows = O.preprocess(O.COSINE, rng.standard_normal((n, dim)).astype(np.float32))
     rows[5000:5040] = rows[17]                                # equal scores: ties -> lower id first
     queries = rng.standard_normal((nq, dim)).astype(np.float32)
@@ -150,11 +151,12 @@ def test_mfma16_deleted_filtered_and_ties(qa, top):
         assert np.array_equal(g["score"].view(np.uint32), w["score"].view(np.uint32))
 
 
-def test_mfma16_large_scan_equals_the_other_kernels(qa):
+@pytest.mark.parametrize("nq", [32, 64])
+def test_mfma16_large_scan_equals_the_other_kernels(qa, nq):
     """2M x 768: same lists from the chain-major kernel and from the 4x4x1 kernel (both bit-exact), and every run repeats."""
     import torch
     from qdrant_amd import _ffi as F
-    n, dim, nq, top = 2_000_003, 768, 32, 10
+    n, dim, top = 2_000_003, 768, 10
     dev = torch.device("cuda", 0)
     rows = torch.empty((n, dim), dtype=torch.float32, device=dev)
     F.check(F.lib().qmx_synth_fill_f32(0, 0x5EED00A1, 0, n, dim, F.ptr(rows)))
