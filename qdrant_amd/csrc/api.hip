@@ -175,7 +175,7 @@ struct qmx_query {
     size_t ev_used = 0;
     float timing_ms = 0.f;
     uint32_t timing_launches = 0;
-    DevBuf partial, out, counts, ids, scores, misc, enc, bounds;
+    DevBuf partial, out, counts, ids, scores, misc, enc, bounds, gthr;
     DevBuf cq_sims, cq_scores, cq_desc;   // custom queries: example similarities, combined scores, descriptors
     DevBuf cand, cand_cnt, cand_ids;   // qmx_search_quantized: oversampled candidates of the quantized stage
     DevBuf filter;             // payload-filter allow bitmap of this query batch (qmx_query_set_filter)
@@ -742,6 +742,7 @@ int32_t qmx_query_destroy(qmx_query *q) {
     q->misc.release();
     q->enc.release();
     q->bounds.release();
+    q->gthr.release();
     q->filter.release();
     q->cq_sims.release();
     q->cq_scores.release();
@@ -961,6 +962,7 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
     const uint32_t n_pass = (top + MAX_TOP_FAST - 1) / MAX_TOP_FAST;
     QMX_TRY(q->partial.reserve((size_t)grid_cap * TQ * ptop_max * sizeof(uint64_t)));
     if (n_pass > 1) QMX_TRY(q->bounds.reserve((size_t)TQ * sizeof(uint64_t)));
+    QMX_TRY(q->gthr.reserve((size_t)MAX_QT_TOPK * sizeof(uint64_t)));
     for (uint32_t tile0 = 0; tile0 < q->nq; tile0 += TQ) {
         const uint32_t nq_tile = std::min<uint32_t>(TQ, q->nq - tile0);
         const int qt = (int)pow2_ceil(nq_tile);
@@ -979,6 +981,23 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
             a.partial = (uint64_t *)q->partial.p;
             a.partial_qt = (uint32_t)qt;
             a.key_bound = pass ? (const uint64_t *)q->bounds.p : nullptr;
+            // The chain-major scan (scan_mfma16.hip) keeps one top list per wave and query: 512 lists per query on the chip, each of
+            // which would learn its reject threshold from its own 1 / 512 of the rows (~k ln(n / 512 k) insertions per list, each
+            // a wave-serial event the other waves of the block wait for at the next barrier).  A pre-scan of the first 1 / 1024 of the
+            // block gives every list the k-th best score of that prefix as a starting threshold: a lower bound of the final k-th
+            // best score, so nothing that belongs to the result is rejected (ties pass), and only ~1024 k rows per query beat it.
+            if (pass == 0 && !d_ids && n_cand >= (1u << 18) && s->dtype == QMX_DTYPE_F32 && mfma_scan_ok(s) && mfma16_scan_ok(qt, SCAN_TOPK, a) &&
+                getenv("QMX_NO_PRESCAN") == nullptr) {
+                ScanArgs pre = a;
+                static const int pre_shift = getenv("QMX_PRESCAN_SHIFT") ? atoi(getenv("QMX_PRESCAN_SHIFT")) : 10;   // tuning: measured 5..10 on C2, the main pass does not care, the pre-scan itself gets cheaper
+                pre.n_cand = std::max<uint64_t>(n_cand >> pre_shift, 1u << 13) & ~(uint64_t)15;
+                uint32_t pgrid = grid_cap;
+                QMX_TRY(launch_scan(q, qt, SCAN_TOPK, pre, &pgrid));
+                QMX_TRY(launch_merge_keys(q->stream, (const uint64_t *)q->partial.p, pgrid, (uint32_t)qt, nq_tile, ptop,
+                                          d_out + (size_t)tile0 * top, d_counts + tile0, top, 0, (uint64_t *)q->gthr.p));
+                a.gthr = (const uint64_t *)q->gthr.p;
+                if (counters) counters->kernel_launches += 2;
+            }
             uint32_t grid = grid_cap;
             size_t slot = 0;
             if (timed) QMX_TRY(timing_begin(q, &slot));

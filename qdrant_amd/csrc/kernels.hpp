@@ -27,6 +27,8 @@ struct ScanArgs {
     DeletedView del;
     uint64_t *partial;         // [grid][partial_qt][top] keys (top-k mode)
     uint32_t partial_qt;       // query stride of `partial` (the small-row kernel; the tiled one uses its QT)
+    const uint64_t *gthr;      // [QT] keys or nullptr (scan_mfma16.hip only): a key whose score is a lower bound of the query's final k-th best
+                               // score (0 = none): the k-th best of a pre-scan of a prefix of the block (api.hip search_enqueue)
     const uint64_t *key_bound; // [QT] exclusive upper bound on accepted keys (top > 64 runs in passes of 64), or nullptr
     float *scores;             // [nq][n_cand] (score mode)
     uint64_t scores_stride;    // elements between queries in `scores`

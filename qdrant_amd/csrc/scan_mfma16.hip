@@ -73,11 +73,13 @@ struct M16Shape {
     static constexpr int NBUF = NW == 4 ? 4 : 7;       // ring stages (4 waves: two blocks share the CU's 160 KiB)
     static constexpr int XCH = NW * NT * 4 * 64 * 4;   // fold exchange: [wave][query tile][reg][lane] f32
     static constexpr int LDS = NBUF * M16_STAGE + XCH;
+    static constexpr int VPS = RPW;                    // vector-memory instructions per stage and wave
     static_assert(CW * NT == 16, "a wave issues 32 MFMAs per stage: 16 (chain, query tile) pairs x 2 K-steps");
     static_assert(NT * 4 == 2 * NW, "every wave finishes two accumulator planes");
 };
 
-template <int KS /* dim / 256 */, int NW, int NT>
+template <int KS /* dim / 256 */, int NW, int NT, int DBG = 0 /* tuning experiments (QMX_M16_DBG): 2 no row loads, 3 no fold / selection */,
+          bool LAG = (NW == 8 && KS == 3) /* half of the waves run one stage behind the others, see `lag` */>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kernel(const ScanArgs a) {
     typedef M16Shape<NW, NT> S;
     constexpr int QT = S::QT, JW = S::JW, CW = S::CW, RPW = S::RPW, NBUF = S::NBUF;
@@ -86,6 +88,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kk = lane >> 4;
+    // LAG: the two waves of a SIMD would otherwise fold / select at the same time (they run between the same barriers) and leave the
+    // matrix pipe idle meanwhile.  Waves NW / 2 .. NW - 1 (the second wave of every SIMD) therefore consume the ring ONE STAGE
+    // BEHIND the others: their fold falls under the other wave's MFMAs and vice versa.  The barrier sequence B_0, B_1, ... is shared:
+    // a leading wave multiplies stage k around B_k, a lagging wave stage k - 1.  What changes: the slot refilled after B_k is that of
+    // stage k - 1 (everyone is done with it), so one stage less is in flight; a lagging wave passes B_0 before its loop and a leading
+    // wave one barrier after its loop; the fold values of a tile are complete one barrier later, so leading waves finish the
+    // previous tile during chunk 1 of the next one (lagging waves during chunk 0, as without LAG).  xch is single-buffered: safe for
+    // KS = 3 (reads of tile T happen in real stage 3 T + 4, the next writes in 3 T + 5 and 3 T + 6).
+    const bool lag = LAG && (((a.flags & 0x100u) ? (w & 1) : (w >= NW / 2)) != 0);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_byte *)smem;
     const unsigned char *rows = reinterpret_cast<const unsigned char *>(a.rows);
     const int top = (int)a.top;
@@ -109,6 +120,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
     const int my_q = 16 * tq + n;
     const bool has_kb = a.key_bound != nullptr;       // bound of a later pass of a top > 64 search (keys must stay below it)
     uint64_t kb = has_kb ? a.key_bound[my_q < (int)a.nq ? my_q : 0] : 0;
+    // lower bound of the query's final k-th best score from the host's pre-scan of a prefix of the block (0 = none): rows scoring
+    // below it are never candidates, so the wave lists start selective instead of each re-learning the threshold from its own rows
+    uint32_t g_ord = a.gthr ? (uint32_t)(a.gthr[my_q < (int)a.nq ? my_q : 0] >> 32) : 0;
     // make every query register "used" here: the compiler then waits for its own loads before the loop instead of at their first
     // use inside it (a vmcnt(N) there would drain the row stream, which it does not know about)
 #pragma unroll
@@ -118,10 +132,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
 #pragma unroll
             for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(bq[ci][s][t]));
     asm volatile("" : "+v"(kb));
+    asm volatile("" : "+v"(g_ord));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // from here on the only vector loads in flight are the row stream
 
     uint64_t list[16];        // this wave's top list of its 16 queries (lane i = i-th best key)
-    float thr_f = -__builtin_inff();   // score of the k-th best key of the lane's own query (-inf while the list is not full)
+    // reject threshold of the lane's own query: the score of the k-th best key of the wave's list once it is full, the pre-scan's bound
+    // before that (-inf without one)
+    float thr_f = g_ord ? ord_to_score(g_ord) : -__builtin_inff();
 #pragma unroll
     for (int q = 0; q < 16; ++q) list[q] = 0;
 
@@ -147,7 +164,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
         }
     };
     auto issue_row = [&](int i) {                          // row RPW w + i of the stage being issued
-        glds16(ld_row[i] + ld_kc * 1024u, lane_off, lds0 + ld_slot * M16_STAGE + (uint32_t)(RPW * w + i) * M16_ROWP);
+        if (DBG != 2) glds16(ld_row[i] + ld_kc * 1024u, lane_off, lds0 + ld_slot * M16_STAGE + (uint32_t)(RPW * w + i) * M16_ROWP);
     };
     auto ld_advance = [&]() {                              // after the rows of a stage
         ld_slot = ld_slot + 1 == NBUF ? 0 : ld_slot + 1;
@@ -158,7 +175,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
         }
     };
     ld_new_tile();
-    for (int p = 0; p < NBUF; ++p) {
+    const int n_prologue = LAG ? NBUF - 1 + (lag ? 1 : 0) : NBUF;     // LAG: every wave has issued stage k + NBUF - 1 once it is past B_k
+    for (int p = 0; p < n_prologue; ++p) {
 #pragma unroll
         for (int i = 0; i < RPW; ++i) issue_row(i);
         ld_advance();
@@ -171,7 +189,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
         return *reinterpret_cast<const float *>(stage_base + chain_rel(ci) * 4 + ks * 512);
     };
     float ax0[CW], ax1[CW];   // K-steps 0 and 1 of the current stage
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(RPW * (NBUF - 1)) : "memory");   // stage 0 of this wave has landed
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(S::VPS * (NBUF - 1 - (LAG ? 1 : 0))) : "memory");   // stage 0 of this wave has landed
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 #pragma unroll
@@ -211,7 +229,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
                         if (nk > readlane_u64(list[qq], top - 1)) {
                             wave_list_insert(list[qq], nk, lane);
                             const uint64_t nt = readlane_u64(list[qq], top - 1);
-                            if (n == qq) thr_f = nt ? key_score(nt) : -__builtin_inff();
+                            if (n == qq && nt && !(key_score(nt) < thr_f)) thr_f = key_score(nt);   // never below the pre-scan's bound
                         }
                     }
                 }
@@ -222,6 +240,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
     // The non-matrix work of a stage (LDS reads of the next operands, the refill of the ring, the scalar address arithmetic) is
     // spread BETWEEN the 32 MFMAs in program order - a wave issues in order, so whatever sits behind the last MFMA of a run waits
     // for the whole run - and the other wave on the SIMD fills what is left.
+    if (lag) {                // B_0: this wave's rows of stage 1 have landed (NBUF stages issued, NBUF - 2 of them after stage 1)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(S::VPS * (NBUF - 2)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
     uint32_t slot = 0;        // ring slot of the stage being multiplied
     for (uint64_t it = 0; it < my_tiles; ++it) {
         const uint64_t tile = blockIdx.x + it * gridDim.x;
@@ -250,7 +273,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
             }
             // this wave's loads of the next stage have landed when at most the RPW (NBUF - 2) issued after them are outstanding; the
             // barrier makes that true for every wave's rows and says every wave holds all of the current stage in registers
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(RPW * (NBUF - 2)) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(S::VPS * (NBUF - 2 - (LAG ? 1 : 0))) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             // K-step 1; the refill of the slot just freed and the K-step 0 operands of the next stage go in between
@@ -271,7 +294,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
                 if (!(kc == KS - 1 && ci >= CW / 2)) __builtin_amdgcn_sched_barrier(0);
                 // the fold values of the PREVIOUS tile sit in xch since before this stage's barrier: finish that tile here, under
                 // the matrix work of this one
-                if (kc == 0 && (ci == CW / 2 || ci == CW / 2 + 1) && it > 0) {
+                if (DBG != 3 && (ci == CW / 2 || ci == CW / 2 + 1) && it > 0 && ((kc == 0 && (!LAG || lag)) || (LAG && kc == 1 && !lag))) {
                     finalize(tile - gridDim.x, ci - CW / 2);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -281,6 +304,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
         // ---- fold: four_way_hsum (a + b) + (c + d) per SIMD lane [then hi128 + lo128]; AVX register r = ci / JW, jj = ci % JW.
         // The exchange is read behind the NEXT stage barrier (finalize above / below): no barrier of its own.  With KS >= 2 the
         // next write of xch is behind a second stage barrier, which no wave passes before it has read xch; KS == 1 needs its own.
+        if (DBG == 3 && it + 1 < my_tiles) continue;      // (keeps the accumulators alive: only the last tile folds)
         if (KS == 1) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -299,6 +323,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
 #pragma unroll
             for (int j = 0; j < 4; ++j) xch[((w * NT + t) * 4 + j) * 64 + lane] = v[j];
         }
+    }
+    if (LAG && !lag) {            // the lagging waves' last stage
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     }
     if (my_tiles) {               // the last tile
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -335,10 +364,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
     }
 }
 
-template <int KS, int NW, int NT>
+template <int KS, int NW, int NT, int DBG = 0, bool LAG = (NW == 8 && KS == 3)>
 static int32_t launch_m16(hipStream_t st, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
     typedef M16Shape<NW, NT> S;
-    auto kfn = scan_f32_mfma16_kernel<KS, NW, NT>;
+    auto kfn = scan_f32_mfma16_kernel<KS, NW, NT, DBG, LAG>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -355,8 +384,10 @@ static int32_t launch_m16(hipStream_t st, const ScanArgs &a, int num_cus, uint32
         if (*grid_out && grid > *grid_out) grid = *grid_out;
         *grid_out = grid;
     }
+    ScanArgs b = a;
+    if (getenv("QMX_M16_LAG_ODD")) b.flags |= 0x100u;       // tuning experiment: odd waves lag instead of the upper half
     ::qmx::clear_stale_error();
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), (size_t)S::LDS, st, a);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), (size_t)S::LDS, st, b);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }
@@ -378,7 +409,13 @@ int32_t launch_scan_f32_mfma16(hipStream_t st, int qt, const ScanArgs &a, int nu
     } else if (qt == 64) {
         if (ks == 1) return launch_m16<1, 8, 4>(st, a, num_cus, grid_out);
         if (ks == 2) return launch_m16<2, 8, 4>(st, a, num_cus, grid_out);
-        if (ks == 3) return launch_m16<3, 8, 4>(st, a, num_cus, grid_out);
+        if (ks == 3) {
+            const char *dbg = getenv("QMX_M16_DBG");
+            if (dbg && dbg[0] == '2') return launch_m16<3, 8, 4, 2>(st, a, num_cus, grid_out);
+            if (dbg && dbg[0] == '3') return launch_m16<3, 8, 4, 3>(st, a, num_cus, grid_out);
+            if (dbg && dbg[0] == '5') return launch_m16<3, 8, 4, 0, false>(st, a, num_cus, grid_out);   // lock-step waves
+            return launch_m16<3, 8, 4>(st, a, num_cus, grid_out);
+        }
     }
     set_error("mfma16 scan: unsupported shape");
     return QMX_ERR_BAD_ARG;
