@@ -13,11 +13,12 @@
 // ELEMENTWISE on accumulator tiles in the reference's tree (four_way_hsum, hsum256_ps_avx, simple_avx.rs:10-28) - no
 // cross-lane traffic at all.
 //
-// Two shapes of the same kernel (NW waves per block, NT = QT / 16 query tiles):
-//   QT = 32: NW = 4, two blocks per CU.  Wave w owns SIMD lanes j = w and w + 4 of the four AVX registers (8 chains).
-//   QT = 64: NW = 8, one block per CU.   Wave w owns SIMD lane j = w (4 chains).
-// Either way a wave holds 32 K-step x query-tile slices of the QUERIES in registers for the whole kernel (B operands,
-// 96 VGPRs at dim 768: the queries are never re-read), 64 accumulator VGPRs, and issues 32 MFMAs per 16 KiB stage.
+// Three shapes of the same kernel (NW waves per block, NT = QT / 16 query tiles):
+//   QT = 32, dim <= 768:  NW = 4, two blocks per CU.  Wave w owns SIMD lanes j = w and w + 4 of the four AVX registers (8 chains).
+//   QT = 64, dim <= 768:  NW = 8, one block per CU.   Wave w owns SIMD lane j = w (4 chains).
+//   QT = 32, dim <= 1536: NW = 8, one block per CU, 4 chains x 2 query tiles per wave (the longer rows need the registers).
+// Either way a wave holds its K-step x query-tile slices of the QUERIES in registers for the whole kernel (B operands,
+// 96 VGPRs at dim 768 / 1536: the queries are never re-read) and up to 64 accumulator VGPRs.
 // The fold: T_j = (s1 + s2) + (s3 + s4) per SIMD lane j (in-wave), lr_j = T_{j+4} + T_j (extractf128(x, 1) + cast(x);
 // in-wave for NW = 4), then the waves exchange through LDS and score = (lr_0 + lr_1) + (lr_2 + lr_3) (_mm_hadd_ps, p1 + p2).
 // Rows stream HBM -> LDS with global_load_lds_dwordx4 (1 KiB of ONE row per wave instruction: fully coalesced, no
@@ -25,8 +26,8 @@
 // The A operand of (chain c, K-step) is one ds_read_b32: lane (m = lane & 15, k = lane >> 4) reads element
 // c + 32 (4 step + k) of row m.  Every byte of the block is read from HBM once and from LDS once.
 //
-// Restrictions (anything else takes the scan_mfma.hip path): top-k mode over the whole block (no id list), dim 256, 512 or
-// 768 (the query registers of longer rows do not fit), 16-byte aligned rows.
+// Restrictions (anything else takes the scan_mfma.hip path): top-k mode over the whole block (no id list), dim a multiple of
+// 256 up to 1536 (64-query passes: up to 768), 16-byte aligned rows.
 #include "scan_common.hpp"
 
 namespace qmx {
@@ -74,15 +75,15 @@ struct M16Shape {
     static constexpr int XCH = NW * NT * 4 * 64 * 4;   // fold exchange: [wave][query tile][reg][lane] f32
     static constexpr int LDS = NBUF * M16_STAGE + XCH;
     static constexpr int VPS = RPW;                    // vector-memory instructions per stage and wave
-    static_assert(CW * NT == 16, "a wave issues 32 MFMAs per stage: 16 (chain, query tile) pairs x 2 K-steps");
-    static_assert(NT * 4 == 2 * NW, "every wave finishes two accumulator planes");
+    static constexpr int PW = NT * 4 / NW;             // accumulator planes (query tile, register) a wave finishes per tile
+    static_assert(PW == 1 || PW == 2, "the NT * 4 planes of a tile are split evenly over the waves");
 };
 
 template <int KS /* dim / 256 */, int NW, int NT, int DBG = 0 /* tuning experiments (QMX_M16_DBG): 2 no row loads, 3 no fold / selection */,
-          bool LAG = (NW == 8 && KS == 3) /* half of the waves run one stage behind the others, see `lag` */>
+          bool LAG = (NW == 8 && NT == 4 && KS == 3) /* half of the waves run one stage behind the others, see `lag` */>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kernel(const ScanArgs a) {
     typedef M16Shape<NW, NT> S;
-    constexpr int QT = S::QT, JW = S::JW, CW = S::CW, RPW = S::RPW, NBUF = S::NBUF;
+    constexpr int QT = S::QT, JW = S::JW, CW = S::CW, RPW = S::RPW, NBUF = S::NBUF, PW = S::PW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -115,8 +116,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
                 for (int t = 0; t < NT; ++t)
                     bq[ci][s][t] = qf[(uint32_t)(16 * t + n) * qs + (uint32_t)(chain_rel(ci) + w) + 32u * (uint32_t)(4 * s + kk)];
     }
-    // epilogue role of the wave: query tile tq (queries 16 tq + n), accumulator registers j0, j0 + 1 (rows 4 kk + j0 + p)
-    const int tq = w % NT, j0 = 2 * (w / NT);
+    // epilogue role of the wave: query tile tq (queries 16 tq + n), accumulator registers j0 .. j0 + PW - 1 (rows 4 kk + j0 + p)
+    const int tq = w % NT, j0 = PW * (w / NT);
     const int my_q = 16 * tq + n;
     const bool has_kb = a.key_bound != nullptr;       // bound of a later pass of a top > 64 search (keys must stay below it)
     uint64_t kb = has_kb ? a.key_bound[my_q < (int)a.nq ? my_q : 0] : 0;
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
                 if (!(kc == KS - 1 && ci >= CW / 2)) __builtin_amdgcn_sched_barrier(0);
                 // the fold values of the PREVIOUS tile sit in xch since before this stage's barrier: finish that tile here, under
                 // the matrix work of this one
-                if (DBG != 3 && (ci == CW / 2 || ci == CW / 2 + 1) && it > 0 && ((kc == 0 && (!LAG || lag)) || (LAG && kc == 1 && !lag))) {
+                if (DBG != 3 && ci >= CW / 2 && ci < CW / 2 + PW && it > 0 && ((kc == 0 && (!LAG || lag)) || (LAG && kc == 1 && !lag))) {
                     finalize(tile - gridDim.x, ci - CW / 2);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
         asm volatile("" ::: "memory");
         const uint64_t last = blockIdx.x + (my_tiles - 1) * gridDim.x;
         finalize(last, 0);
-        finalize(last, 1);
+        if (PW == 2) finalize(last, 1);
     }
 
     // ---- block merge: the NW / NT wave lists of each query (waves tq, tq + NT, ...) -> 1 list, one global write per block ----
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
     }
 }
 
-template <int KS, int NW, int NT, int DBG = 0, bool LAG = (NW == 8 && KS == 3)>
+template <int KS, int NW, int NT, int DBG = 0, bool LAG = (NW == 8 && NT == 4 && KS == 3)>
 static int32_t launch_m16(hipStream_t st, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
     typedef M16Shape<NW, NT> S;
     auto kfn = scan_f32_mfma16_kernel<KS, NW, NT, DBG, LAG>;
@@ -396,7 +397,7 @@ static int32_t launch_m16(hipStream_t st, const ScanArgs &a, int num_cus, uint32
 bool mfma16_scan_ok(int qt, ScanMode mode, const ScanArgs &a) {
     if (getenv("QMX_NO_MFMA16") != nullptr) return false;
     return (qt == 32 || qt == 64) && mode == SCAN_TOPK && a.ids == nullptr && a.rem_pieces == 0 && a.tail_start == a.dim && a.nseg % 8 == 0 &&
-           a.nseg / 8 >= 1 && a.nseg / 8 <= 3 && a.row_stride % 16 == 0 && a.top <= 64;
+           a.nseg / 8 >= 1 && a.nseg / 8 <= (qt == 64 ? 3u : 6u) && a.row_stride % 16 == 0 && a.top <= 64;
 }
 
 // top-k over the whole block; the caller checked mfma16_scan_ok
@@ -406,6 +407,9 @@ int32_t launch_scan_f32_mfma16(hipStream_t st, int qt, const ScanArgs &a, int nu
         if (ks == 1) return launch_m16<1, 4, 2>(st, a, num_cus, grid_out);
         if (ks == 2) return launch_m16<2, 4, 2>(st, a, num_cus, grid_out);
         if (ks == 3) return launch_m16<3, 4, 2>(st, a, num_cus, grid_out);
+        if (ks == 4) return launch_m16<4, 8, 2>(st, a, num_cus, grid_out);
+        if (ks == 5) return launch_m16<5, 8, 2>(st, a, num_cus, grid_out);
+        if (ks == 6) return launch_m16<6, 8, 2>(st, a, num_cus, grid_out);
     } else if (qt == 64) {
         if (ks == 1) return launch_m16<1, 8, 4>(st, a, num_cus, grid_out);
         if (ks == 2) return launch_m16<2, 8, 4>(st, a, num_cus, grid_out);

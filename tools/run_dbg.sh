@@ -1,3 +1,4 @@
-for sh in 5 6 7 8 9 10; do
-  QMX_PRESCAN_SHIFT=$sh python bench.py --batch 64 --steps 10 --warmup 2 --hnsw-rows 0 --no-cpu --verify 0 2>&1 | tail -1 | python -c "import sys,json; j=json.loads(sys.stdin.read()); r=j['roofline']; print('shift', $sh, r['kernel_ms'], j['ms_per_step'], j['value'])"
-done
+for d in 1024 1536; do
+for b in 16 32 64; do
+  python bench.py --dim $d --batch $b --steps 10 --warmup 2 --hnsw-rows 0 --no-cpu --verify 0 2>&1 | tail -1 | python -c "import sys,json; j=json.loads(sys.stdin.read()); r=j['roofline']; print('dim', $d, 'batch', $b, r['kernel_ms'], j['ms_per_step'], j['value'], r['hbm']['frac'], r['mfma_f32']['frac'])"
+done; done
