@@ -992,6 +992,7 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
             if (pass == 0 && !d_ids && n_cand >= (1u << 18) && s->dtype == QMX_DTYPE_F32 && mfma_scan_ok(s) && mfma16_scan_ok(qt, SCAN_TOPK, a) &&
                 getenv("QMX_NO_PRESCAN") == nullptr) {
                 ScanArgs pre = a;
+                pre.flags |= M16_FLAG_PRESCAN;
                 static const int pre_shift = getenv("QMX_PRESCAN_SHIFT") ? atoi(getenv("QMX_PRESCAN_SHIFT")) : 10;   // tuning: measured 5..10 on C2, the main pass does not care, the pre-scan itself gets cheaper
                 pre.n_cand = std::max<uint64_t>(n_cand >> pre_shift, 1u << 13) & ~(uint64_t)15;
                 uint32_t pgrid = grid_cap;

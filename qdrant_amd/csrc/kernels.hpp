@@ -168,6 +168,7 @@ int32_t launch_sq_internal_query(hipStream_t st, const void *codes, const float 
                                  uint32_t nq, uint64_t n_rows, float shift, void *tile, uint32_t q_stride, uint32_t aux_off,
                                  int *err_flag);
 // f32 dot / cosine, 32- and 64-query tiles on v_mfma_f32_16x16x4_f32, chain-major (scan_mfma16.hip)
+constexpr uint32_t M16_FLAG_PRESCAN = 0x200u;   // ScanArgs::flags: this launch is the threshold pre-scan (runs under its own kernel name)
 bool mfma16_scan_ok(int qt, ScanMode mode, const ScanArgs &a);   // qt = 32 or 64
 int32_t launch_scan_f32_mfma16(hipStream_t st, int qt, const ScanArgs &a, int num_cus, uint32_t *grid_out);
 // BQ 1-bit (scan_bq.hip)

@@ -80,7 +80,8 @@ struct M16Shape {
 };
 
 template <int KS /* dim / 256 */, int NW, int NT, int DBG = 0 /* tuning experiments (QMX_M16_DBG): 2 no row loads, 3 no fold / selection */,
-          bool LAG = (NW == 8 && NT == 4 && KS == 3) /* half of the waves run one stage behind the others, see `lag` */>
+          bool LAG = (NW == 8 && NT == 4 && KS == 3) /* half of the waves run one stage behind the others, see `lag` */,
+          bool PRE = false /* the threshold pre-scan of api.hip: same code under its own name, so that profiles keep the two apart */>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kernel(const ScanArgs a) {
     typedef M16Shape<NW, NT> S;
     constexpr int QT = S::QT, JW = S::JW, CW = S::CW, RPW = S::RPW, NBUF = S::NBUF, PW = S::PW;
@@ -365,10 +366,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
     }
 }
 
-template <int KS, int NW, int NT, int DBG = 0, bool LAG = (NW == 8 && NT == 4 && KS == 3)>
+template <int KS, int NW, int NT, int DBG = 0, bool LAG = (NW == 8 && NT == 4 && KS == 3), bool PRE = false>
 static int32_t launch_m16(hipStream_t st, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
+    if (!PRE && DBG == 0 && (a.flags & M16_FLAG_PRESCAN)) return launch_m16<KS, NW, NT, 0, LAG, true>(st, a, num_cus, grid_out);
     typedef M16Shape<NW, NT> S;
-    auto kfn = scan_f32_mfma16_kernel<KS, NW, NT, DBG, LAG>;
+    auto kfn = scan_f32_mfma16_kernel<KS, NW, NT, DBG, LAG, PRE>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
