@@ -325,26 +325,35 @@ QMX_API int32_t qmx_search_quantized(const qmx_hnsw *g, qmx_query *searched, qmx
 
 /* ---- custom queries (recommend / discover / context) ---------------------------------------------- */
 
-/* `QueryVector::{RecommendBestScore, RecommendSumScores, Discover, Context}` scored by `CustomQueryScorer`
+/* `QueryVector::{RecommendBestScore, RecommendSumScores, Discover, Context, FeedbackNaive}` scored by `CustomQueryScorer`
  * (lib/segment/src/vector_storage/query_scorer/custom_query_scorer.rs:44-121): score(point) =
  * query.score_by(|example| Metric::similarity(example, point)).  The EXAMPLE vectors of all custom queries of a request
  * form one ordinary query batch (`qmx_query_create`: each example is preprocessed and cast like a Nearest query,
  * custom_query_scorer.rs:58-66); a qmx_custom_query names its slice of that batch in the reference's `flat_iter()`
  * order: reco: n_a positives then n_b negatives (vector_storage/query/reco_query.rs:25-27, 68-131); discover: the
  * target (n_a = 1) then n_b (positive, negative) pairs (discover_query.rs:34-73); context: n_b pairs, n_a = 0
- * (context_query.rs:53-62, 95-118). */
+ * (context_query.rs:53-62, 95-118); feedback (`FeedbackQuery`, feedback_query.rs:147-227): the target (n_a = 1) then the n_b
+ * (positive, negative) context pairs that `NaiveFeedbackCoefficients::extract_context_pairs` (:117-145) kept, with the
+ * coefficients [a, partial_computation_0 .. partial_computation_{n_b-1}] at `coef_first` of the batch's coefficient array
+ * (qmx_custom_set_coefficients): score = a * sim(target) + sum_i partial_computation_i * (sim(positive_i) - sim(negative_i)),
+ * f32, in that order.  partial_computation = confidence.powf(b) * c is computed by the caller (libm's powf). */
 typedef enum qmx_custom_kind {
     QMX_CUSTOM_RECO_BEST_SCORE = 0,
     QMX_CUSTOM_RECO_SUM_SCORES = 1,
     QMX_CUSTOM_DISCOVER = 2,
-    QMX_CUSTOM_CONTEXT = 3
+    QMX_CUSTOM_CONTEXT = 3,
+    QMX_CUSTOM_FEEDBACK = 4
 } qmx_custom_kind;
 typedef struct qmx_custom_query {
-    uint32_t kind;   /* qmx_custom_kind */
-    uint32_t first;  /* index of the query's first example inside the example batch */
+    uint32_t kind;        /* qmx_custom_kind */
+    uint32_t first;       /* index of the query's first example inside the example batch */
     uint32_t n_a;
     uint32_t n_b;
+    uint32_t coef_first;  /* QMX_CUSTOM_FEEDBACK: index of `a` inside the coefficient array; ignored otherwise */
 } qmx_custom_query;
+
+/* Coefficients of the feedback queries of an example batch (copied; host or device memory). */
+QMX_API int32_t qmx_custom_set_coefficients(qmx_query *examples, const float *coefs, uint32_t n);
 
 /* `RawScorer::score_points` of custom scorers: scores[qi * n + i] = custom query qi against stored point ids[i]. */
 QMX_API int32_t qmx_custom_score_points(qmx_query *examples, const qmx_custom_query *queries, uint32_t n_queries,

@@ -1178,6 +1178,18 @@ float qo_custom_combine(int kind, uint32_t n_a, uint32_t n_b, const float *sims)
     return sum;
 }
 
+/* FeedbackQuery::score_by (lib/segment/src/vector_storage/query/feedback_query.rs:198-226):
+ *   let mut score = coefficients.a.0 * similarity(target);
+ *   for pair in context_pairs { let delta = similarity(positive) - similarity(negative); score += partial_computation.0 * delta; } */
+float qo_custom_feedback(uint32_t n_pairs, const float *sims, const float *coefs) {
+    float score = coefs[0] * sims[0];
+    for (uint32_t i = 0; i < n_pairs; i++) {
+        const float delta = sims[1 + 2 * i] - sims[2 + 2 * i];
+        score += coefs[1 + i] * delta;
+    }
+    return score;
+}
+
 /* ------------------------------------------------------------------------------------------
  * synthetic data: counter-based, integer-only (Irwin-Hall of four 16-bit uniforms), so the
  * device generator (qdrant_amd/csrc/synth.hip) reproduces it bit-for-bit without libm.

@@ -136,6 +136,8 @@ float qo_pq_score_internal(const qo_pq *pq, const uint8_t *ci, const uint8_t *cj
 void qo_pq_train(uint32_t dim, uint32_t chunk_size, uint32_t n_centroids, const float *data,
                  size_t n, int iters, float *centroids_out);
 float qo_custom_combine(int kind, uint32_t n_a, uint32_t n_b, const float *sims);   /* Query::score_by of the custom queries */
+/* FeedbackQuery::score_by (feedback_query.rs:198-226): sims = [target, pos_0, neg_0, ...], coefs = [a, partial_computation_0, ...] */
+float qo_custom_feedback(uint32_t n_pairs, const float *sims, const float *coefs);
 void qo_pq_train_ex(uint32_t dim, uint32_t chunk_size, uint32_t n_centroids, const float *data, size_t n, uint32_t max_iters,
                     float accuracy, uint32_t threads, float *centroids_out, uint32_t *iters_done);   /* kmeans.rs:9-169 on a given sample */
 

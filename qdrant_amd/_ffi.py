@@ -75,10 +75,10 @@ class SearchParams(C.Structure):
 
 
 class CustomQuery(C.Structure):
-    _fields_ = [("kind", C.c_uint32), ("first", C.c_uint32), ("n_a", C.c_uint32), ("n_b", C.c_uint32)]
+    _fields_ = [("kind", C.c_uint32), ("first", C.c_uint32), ("n_a", C.c_uint32), ("n_b", C.c_uint32), ("coef_first", C.c_uint32)]
 
 
-CUSTOM_RECO_BEST_SCORE, CUSTOM_RECO_SUM_SCORES, CUSTOM_DISCOVER, CUSTOM_CONTEXT = range(4)
+CUSTOM_RECO_BEST_SCORE, CUSTOM_RECO_SUM_SCORES, CUSTOM_DISCOVER, CUSTOM_CONTEXT, CUSTOM_FEEDBACK = range(5)
 
 
 class QmxError(RuntimeError):
@@ -136,6 +136,7 @@ SIGNATURES = {
     "qmx_sq_encode": (C.c_int32, [C.c_int32, C.c_uint32, C.POINTER(SqParams), _P, C.c_uint64, C.c_uint32, _P]),
     "qmx_pq_train": (C.c_int32, [C.c_int32, _P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, _P, _P]),
     "qmx_sq_fit_min_max": (C.c_int32, [C.c_int32, C.c_uint32, _P, C.c_uint64, C.c_uint32, C.POINTER(SqParams)]),
+    "qmx_custom_set_coefficients": (C.c_int32, [_P, _P, C.c_uint32]),
     "qmx_bq_encode": (C.c_int32, [C.c_int32, _P, C.c_uint64, C.c_uint32, _P]),
     "qmx_pq_encode": (C.c_int32, [C.c_int32, C.POINTER(PqParams), _P, C.c_uint64, C.c_uint32, _P]),
     "qmx_synth_fill_f32": (C.c_int32, [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, _P]),

@@ -176,7 +176,8 @@ struct qmx_query {
     float timing_ms = 0.f;
     uint32_t timing_launches = 0;
     DevBuf partial, out, counts, ids, scores, misc, enc, bounds, gthr;
-    DevBuf cq_sims, cq_scores, cq_desc;   // custom queries: example similarities, combined scores, descriptors
+    DevBuf cq_sims, cq_scores, cq_desc, cq_coefs;   // custom queries: example similarities, combined scores, descriptors, feedback coefficients
+    uint32_t n_cq_coefs = 0;
     DevBuf cand, cand_cnt, cand_ids;   // qmx_search_quantized: oversampled candidates of the quantized stage
     DevBuf filter;             // payload-filter allow bitmap of this query batch (qmx_query_set_filter)
     uint64_t n_filter_bits = 0;
@@ -743,6 +744,7 @@ int32_t qmx_query_destroy(qmx_query *q) {
     q->enc.release();
     q->bounds.release();
     q->gthr.release();
+    q->cq_coefs.release();
     q->filter.release();
     q->cq_sims.release();
     q->cq_scores.release();
@@ -1778,7 +1780,10 @@ int32_t qmx_rescore(qmx_query *q, const uint32_t *ids, const uint32_t *counts, u
 static int32_t custom_prepare(qmx_query *ex, const qmx_custom_query *queries, uint32_t n_queries, const uint32_t *d_ids, uint64_t n) {
     for (uint32_t i = 0; i < n_queries; ++i) {
         const qmx_custom_query &c = queries[i];
-        QMX_REQUIRE(c.kind <= QMX_CUSTOM_CONTEXT, QMX_ERR_BAD_ARG, "bad custom query kind %u", c.kind);
+        QMX_REQUIRE(c.kind <= QMX_CUSTOM_FEEDBACK, QMX_ERR_BAD_ARG, "bad custom query kind %u", c.kind);
+        QMX_REQUIRE(c.kind != QMX_CUSTOM_FEEDBACK || c.n_a == 1, QMX_ERR_BAD_ARG, "a feedback query has exactly one target");
+        QMX_REQUIRE(c.kind != QMX_CUSTOM_FEEDBACK || (uint64_t)c.coef_first + 1 + c.n_b <= ex->n_cq_coefs, QMX_ERR_OUT_OF_BOUNDS,
+                    "feedback query %u reaches past the %u coefficients set with qmx_custom_set_coefficients", i, ex->n_cq_coefs);
         const uint64_t ne = c.kind <= QMX_CUSTOM_RECO_SUM_SCORES ? (uint64_t)c.n_a + c.n_b : (uint64_t)c.n_a + 2ull * c.n_b;
         QMX_REQUIRE(c.kind != QMX_CUSTOM_DISCOVER || c.n_a == 1, QMX_ERR_BAD_ARG, "a discover query has exactly one target");
         QMX_REQUIRE(c.kind != QMX_CUSTOM_CONTEXT || c.n_a == 0, QMX_ERR_BAD_ARG, "a context query has pairs only");
@@ -1791,7 +1796,20 @@ static int32_t custom_prepare(qmx_query *ex, const qmx_custom_query *queries, ui
     QMX_TRY(ex->cq_desc.reserve((size_t)n_queries * sizeof(qmx_custom_query)));
     QMX_HIP(hipMemcpyAsync(ex->cq_desc.p, queries, (size_t)n_queries * sizeof(qmx_custom_query), hipMemcpyDefault, ex->stream));
     QMX_TRY(score_ids_device(ex, d_ids, n, (float *)ex->cq_sims.p, nullptr));     // similarity(example, point), every example x candidate
-    return launch_custom_combine(ex->stream, (const qmx_custom_query *)ex->cq_desc.p, n_queries, (const float *)ex->cq_sims.p, n, (float *)ex->cq_scores.p);
+    return launch_custom_combine(ex->stream, (const qmx_custom_query *)ex->cq_desc.p, n_queries, (const float *)ex->cq_sims.p, n, (const float *)ex->cq_coefs.p,
+                                 (float *)ex->cq_scores.p);
+}
+
+int32_t qmx_custom_set_coefficients(qmx_query *ex, const float *coefs, uint32_t n) {
+    QMX_REQUIRE(ex && (n == 0 || coefs), QMX_ERR_BAD_ARG, "NULL argument");
+    QMX_HIP(hipSetDevice(ex->device));
+    ex->n_cq_coefs = 0;
+    if (n == 0) return QMX_OK;
+    QMX_TRY(ex->cq_coefs.reserve((size_t)n * sizeof(float)));
+    QMX_HIP(hipMemcpyAsync(ex->cq_coefs.p, coefs, (size_t)n * sizeof(float), hipMemcpyDefault, ex->stream));
+    QMX_HIP(hipStreamSynchronize(ex->stream));   // the caller's buffer may go away
+    ex->n_cq_coefs = n;
+    return QMX_OK;
 }
 
 int32_t qmx_custom_score_points(qmx_query *ex, const qmx_custom_query *queries, uint32_t n_queries, const uint32_t *ids, uint32_t n, float *scores) {

@@ -7,6 +7,7 @@
 //   RecoSumScoresQuery::score_by   reco_query.rs:114-131                        (sequential f32 sums, pos - neg)
 //   DiscoverQuery::score_by        discover_query.rs:45-73 (+ ContextPair::rank_by context_query.rs:38-45)
 //   ContextQuery::score_by         context_query.rs:53-62, 112-118              (sum of fast_sigmoid(min(pos - neg - EPSILON, 0)))
+//   FeedbackQuery::score_by        feedback_query.rs:198-226                    (a * sim(target) + sum pc_i * (sim(pos_i) - sim(neg_i)))
 //   fast_sigmoid / scaled_fast_sigmoid  lib/common/common/src/math.rs:7-18
 // The similarities are the scan kernels' (bit-identical to the x86 leaves), the combination is a handful of f32
 // operations in the reference's order: bit-exact end to end.  Example order inside a query = the reference's
@@ -25,7 +26,7 @@ __device__ __forceinline__ float fast_sigmoid(float x) { return x / (1.0f + __bu
 __device__ __forceinline__ float scaled_fast_sigmoid(float x) { return 0.5f * (fast_sigmoid(x) + 1.0f); }
 
 // sims[e * stride] = similarity of example (first + e) with this candidate
-__device__ __forceinline__ float custom_combine(const qmx_custom_query &q, const float *sims, uint64_t stride) {
+__device__ __forceinline__ float custom_combine(const qmx_custom_query &q, const float *sims, uint64_t stride, const float *coefs) {
     const float *s = sims + (uint64_t)q.first * stride;
     switch (q.kind) {
         case QMX_CUSTOM_RECO_BEST_SCORE: {
@@ -45,6 +46,15 @@ __device__ __forceinline__ float custom_combine(const qmx_custom_query &q, const
             for (uint32_t i = 0; i < q.n_b; ++i) rank += f32_total_cmp(s[(uint64_t)(1 + 2 * i) * stride], s[(uint64_t)(2 + 2 * i) * stride]);
             return (float)rank + scaled_fast_sigmoid(s[0]);
         }
+        case QMX_CUSTOM_FEEDBACK: {   // FeedbackQuery::score_by (feedback_query.rs:198-226): mul, then add, pair by pair
+            const float *cf = coefs + q.coef_first;
+            float score = cf[0] * s[0];
+            for (uint32_t i = 0; i < q.n_b; ++i) {
+                const float delta = s[(uint64_t)(1 + 2 * i) * stride] - s[(uint64_t)(2 + 2 * i) * stride];
+                score += cf[1 + i] * delta;
+            }
+            return score;
+        }
         default: {   // QMX_CUSTOM_CONTEXT
             float sum = 0.0f;
             for (uint32_t i = 0; i < q.n_b; ++i) {
@@ -57,17 +67,18 @@ __device__ __forceinline__ float custom_combine(const qmx_custom_query &q, const
 }
 
 __global__ __launch_bounds__(256) void custom_combine_kernel(const qmx_custom_query *queries, uint32_t n_queries, const float *sims, uint64_t n,
-                                                             float *out) {
+                                                             const float *coefs, float *out) {
     const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint32_t qi = blockIdx.y;
     if (c >= n || qi >= n_queries) return;
-    out[(uint64_t)qi * n + c] = custom_combine(queries[qi], sims + c, n);
+    out[(uint64_t)qi * n + c] = custom_combine(queries[qi], sims + c, n, coefs);
 }
 
-int32_t launch_custom_combine(hipStream_t st, const qmx_custom_query *d_queries, uint32_t n_queries, const float *d_sims, uint64_t n, float *d_out) {
+int32_t launch_custom_combine(hipStream_t st, const qmx_custom_query *d_queries, uint32_t n_queries, const float *d_sims, uint64_t n,
+                              const float *d_coefs, float *d_out) {
     if (n == 0 || n_queries == 0) return QMX_OK;
     ::qmx::clear_stale_error();
-    hipLaunchKernelGGL(custom_combine_kernel, dim3((uint32_t)((n + 255) / 256), n_queries), dim3(256), 0, st, d_queries, n_queries, d_sims, n, d_out);
+    hipLaunchKernelGGL(custom_combine_kernel, dim3((uint32_t)((n + 255) / 256), n_queries), dim3(256), 0, st, d_queries, n_queries, d_sims, n, d_coefs, d_out);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }

@@ -207,7 +207,8 @@ int32_t launch_sort_scored(hipStream_t st, const float *scores, const uint32_t *
                            qmx_scored_point *out, uint32_t *out_counts);
 
 // custom queries (custom_query.hip): combine the per-example similarity matrix, top-k of a score row
-int32_t launch_custom_combine(hipStream_t st, const qmx_custom_query *d_queries, uint32_t n_queries, const float *d_sims, uint64_t n, float *d_out);
+int32_t launch_custom_combine(hipStream_t st, const qmx_custom_query *d_queries, uint32_t n_queries, const float *d_sims, uint64_t n,
+                              const float *d_coefs, float *d_out);
 int32_t launch_custom_topk(hipStream_t st, const float *d_scores, uint64_t n, const uint32_t *d_ids, const DeletedView &del, uint32_t n_queries,
                            uint32_t top, qmx_scored_point *d_out, uint32_t *d_counts);
 

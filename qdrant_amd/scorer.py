@@ -469,8 +469,9 @@ class CustomQuery:
     """One `QueryVector::{RecommendBestScore, RecommendSumScores, Discover, Context}` (vector_storage/query/*.rs);
     vectors are ORIGINAL (un-preprocessed) f32, as for `new_raw_scorer`."""
 
-    def __init__(self, kind: int, examples, n_a: int, n_b: int):
+    def __init__(self, kind: int, examples, n_a: int, n_b: int, coefs=None):
         self.kind, self.examples, self.n_a, self.n_b = kind, [np.asarray(v, dtype=np.float32) for v in examples], n_a, n_b
+        self.coefs = None if coefs is None else np.asarray(coefs, dtype=np.float32)
 
     @classmethod
     def recommend_best_score(cls, positives, negatives):
@@ -488,6 +489,23 @@ class CustomQuery:
     def context(cls, pairs):
         return cls(F.CUSTOM_CONTEXT, [v for p in pairs for v in p], 0, len(pairs))
 
+    @classmethod
+    def feedback_naive(cls, target, feedback, a: float, b: float, c: float, margin: float = 0.0):
+        """`NaiveFeedbackQuery::into_query` (feedback_query.rs:43-47, 117-145, 159-174): `feedback` = [(vector, score)];
+        every ordered pair with score difference above `margin` becomes a context pair with
+        partial_computation = confidence.powf(b) * c (f32; libm's powf, here numpy's)."""
+        pairs, coefs = [], [np.float32(a)]
+        for i, (pv, ps) in enumerate(feedback):                  # itertools' permutations(2) order
+            for j, (nv, ns) in enumerate(feedback):
+                if i == j:
+                    continue
+                confidence = np.float32(ps) - np.float32(ns)
+                if confidence <= np.float32(margin):
+                    continue
+                pairs.append((pv, nv))
+                coefs.append(np.float32(np.power(confidence, np.float32(b), dtype=np.float32) * np.float32(c)))
+        return cls(F.CUSTOM_FEEDBACK, [target] + [v for p in pairs for v in p], 1, len(pairs), coefs)
+
 
 class CustomRawScorer:
     """`new_raw_scorer(QueryVector::<custom>, storage)` for a batch of custom queries (raw_scorer.rs:60-114 ->
@@ -495,13 +513,18 @@ class CustomRawScorer:
 
     def __init__(self, queries: Sequence[CustomQuery], storage: VectorStorage):
         self.storage = storage
-        flat, descs, first = [], (F.CustomQuery * len(queries))(), 0
+        flat, descs, first, coefs = [], (F.CustomQuery * len(queries))(), 0, []
         for i, q in enumerate(queries):
-            descs[i].kind, descs[i].first, descs[i].n_a, descs[i].n_b = q.kind, first, q.n_a, q.n_b
+            descs[i].kind, descs[i].first, descs[i].n_a, descs[i].n_b, descs[i].coef_first = q.kind, first, q.n_a, q.n_b, len(coefs)
             flat += q.examples
             first += len(q.examples)
+            if q.coefs is not None:
+                coefs += q.coefs.tolist()
         self._descs, self.nq = descs, len(queries)
         self.examples = new_raw_scorer(np.stack(flat) if flat else np.zeros((0, storage.dim), dtype=np.float32), storage)
+        if coefs:
+            cf = np.asarray(coefs, dtype=np.float32)
+            F.check(F.lib().qmx_custom_set_coefficients(self.examples._h, F.ptr(cf), len(cf)))
 
     def score_points(self, points: Sequence[int]) -> np.ndarray:
         ids = np.ascontiguousarray(points, dtype=np.uint32)

@@ -91,6 +91,7 @@ _sig("qo_pq_score", _f, [C.POINTER(Pq), _P, _P, C.c_int])
 _sig("qo_pq_score_internal", _f, [C.POINTER(Pq), _P, _P])
 _sig("qo_pq_train", None, [C.c_uint32, C.c_uint32, C.c_uint32, _P, C.c_size_t, C.c_int, _P])
 _sig("qo_custom_combine", _f, [C.c_int, C.c_uint32, C.c_uint32, _P])
+_sig("qo_custom_feedback", _f, [C.c_uint32, _P, _P])
 _sig("qo_bq_row_bytes", C.c_size_t, [C.c_uint32])
 _sig("qo_bq_encode_row", None, [C.c_uint32, _P, _P])
 _sig("qo_bq_xor_popcnt", C.c_uint32, [_P, _P, C.c_uint32])
@@ -421,14 +422,16 @@ class PlainLinks:
         return self.neighbors[int(self.offsets[idx]):int(self.offsets[idx + 1])]
 
 
-def custom_scores(storage: "DenseStorage", examples, kind, n_a, n_b, ids):
-    """CustomQueryScorer over the oracle's similarities: examples [ne, dim] original vectors in flat_iter() order."""
+def custom_scores(storage: "DenseStorage", examples, kind, n_a, n_b, ids, coefs=None):
+    """CustomQueryScorer over the oracle's similarities: examples [ne, dim] original vectors in flat_iter() order
+    (kind 4 = FeedbackQuery: target, then (positive, negative) pairs; coefs = [a, partial_computation...])."""
     sims = storage.score_points(examples, ids)                 # [ne, n] bit-exact leaves
     out = np.empty(len(ids), dtype=np.float32)
     col = np.empty(sims.shape[0], dtype=np.float32)
+    cf = None if coefs is None else f32(coefs)
     for j in range(len(ids)):
         col[:] = sims[:, j]
-        out[j] = _lib.qo_custom_combine(kind, n_a, n_b, _p(col))
+        out[j] = _lib.qo_custom_feedback(n_b, _p(col), _p(cf)) if kind == 4 else _lib.qo_custom_combine(kind, n_a, n_b, _p(col))
     return out
 
 

@@ -1,5 +1,5 @@
-"""GPU parity of the custom-query scorers (recommend best-score / sum-scores, discover, context) against the oracle's
-restatement of Query::score_by (vector_storage/query/{reco,discover,context}_query.rs) over bit-exact similarities:
+"""GPU parity of the custom-query scorers (recommend best-score / sum-scores, discover, context, naive feedback) against the oracle's
+restatement of Query::score_by (vector_storage/query/{reco,discover,context,feedback}_query.rs) over bit-exact similarities:
 every score bit-exact, brute-force top-k identical.  Known answers from the reference's own unit tests included."""
 import ctypes as C
 
@@ -37,6 +37,9 @@ def test_combine_known_answers():
     assert comb(2, 1, 2, [1.0, 3.0, 1.0, 5.0, 2.0]) == np.float32(2.0) + sig(1.0)
     d = np.float32(1.0) - np.float32(3.0) - np.float32(1.1920929e-07)
     assert comb(3, 0, 2, [3.0, 1.0, 1.0, 3.0]) == np.float32(0.0) + d / (np.float32(1.0) + abs(d))   # first pair on the right side: loss 0
+    # FeedbackQuery::score_by (feedback_query.rs:198-226): a * sim(target) + sum pc * (sim(pos) - sim(neg))
+    sims, cf = np.asarray([2.0, 1.0, 0.25, 0.5, 3.0], dtype=np.float32), np.asarray([0.5, 2.0, 4.0], dtype=np.float32)
+    assert O._lib.qo_custom_feedback(2, O._p(sims), O._p(cf)) == np.float32(0.5 * 2.0 + 2.0 * 0.75 + 4.0 * -2.5)
 
 
 @pytest.mark.parametrize("dist", [O.COSINE, O.DOT, O.EUCLID, O.MANHATTAN])
@@ -58,14 +61,18 @@ def test_custom_scores_and_topk_bit_exact(qa, dist, dim):
         qa.CustomQuery.discover(V(1)[0], [tuple(V(2)) for _ in range(3)]),
         qa.CustomQuery.context([tuple(V(2)) for _ in range(4)]),
         qa.CustomQuery.context([]),
+        # FeedbackNaive: 4 scored feedback vectors -> 6 ordered pairs above the margin, coefficients (a, b, c)
+        qa.CustomQuery.feedback_naive(V(1)[0], list(zip(V(4), [0.9, 0.1, 0.5, 0.7])), a=0.8, b=1.5, c=0.3),
+        qa.CustomQuery.feedback_naive(V(1)[0], [(V(1)[0], 0.4)], a=1.25, b=2.0, c=1.0),        # one item: no pairs, a * sim(target)
     ]
+    assert queries[-2].n_b == 6 and len(queries[-2].coefs) == 7 and queries[-1].n_b == 0
     scorer = qa.CustomRawScorer(queries, vs)
     ids = rng.permutation(n)[:500].astype(np.uint32)
     got = scorer.score_points(ids)
     for qi, q in enumerate(queries):
         ex = np.stack(q.examples) if q.examples else np.zeros((0, dim), dtype=np.float32)
         if len(q.examples):
-            want = O.custom_scores(st, ex, q.kind, q.n_a, q.n_b, ids)
+            want = O.custom_scores(st, ex, q.kind, q.n_a, q.n_b, ids, q.coefs)
         else:
             want = np.full(len(ids), O._lib.qo_custom_combine(q.kind, q.n_a, q.n_b, None), dtype=np.float32)
         assert np.array_equal(got[qi].view(np.uint32), want.view(np.uint32)), qi
@@ -76,7 +83,7 @@ def test_custom_scores_and_topk_bit_exact(qa, dist, dim):
     for qi, q in enumerate(queries):
         if not q.examples:
             continue
-        sc = O.custom_scores(st, np.stack(q.examples), q.kind, q.n_a, q.n_b, all_ids)
+        sc = O.custom_scores(st, np.stack(q.examples), q.kind, q.n_a, q.n_b, all_ids, q.coefs)
         live = ~deleted
         order = np.lexsort((all_ids[live], -sc[live].astype(np.float64)))[:top]       # descending score, ties -> lower id
         assert np.array_equal(res[qi]["score"].view(np.uint32), sc[live][order].view(np.uint32)), qi
@@ -91,7 +98,7 @@ def test_custom_scores_and_topk_bit_exact(qa, dist, dim):
         if not q.examples:
             continue
         ok = allowed[ids] & ~deleted[ids]
-        sc = O.custom_scores(st, np.stack(q.examples), q.kind, q.n_a, q.n_b, ids)
+        sc = O.custom_scores(st, np.stack(q.examples), q.kind, q.n_a, q.n_b, ids, q.coefs)
         want = np.sort(sc[ok])[::-1][:10]
         assert np.array_equal(sub[qi]["score"].view(np.uint32), want.view(np.uint32))
         assert allowed[sub[qi]["idx"]].all()
