@@ -504,6 +504,15 @@ QMX_API int32_t qmx_pq_train(int32_t device_id, const float *sample, uint64_t n,
  * quantile estimate.  in [n][dim] f32 host or device; fills every field of `out`. */
 QMX_API int32_t qmx_sq_fit_min_max(int32_t device_id, uint32_t distance, const float *in, uint64_t n, uint32_t dim,
                                    qmx_sq_params *out);
+/* The `quantile = Some(q)` fit (encoded_vectors_u8.rs:194-205 -> `find_quantile_interval`, quantile.rs:35-84) on a GIVEN
+ * sample: the reference draws <= SAMPLE_SIZE = 5 000 random vectors (`take_random_vectors`), which vectors is not
+ * reproducible, so the sample is an input (as for qmx_pq_train); `count` = vectors in the storage.  Given the sample the
+ * interval is an exact order statistic: sorted[cut + 1] .. sorted[len - cut - 1] of the flattened sample with
+ * cut = max(1, min((len - 1) / 2, (n_sample as f32 * (1 - q) / 2) as usize)).  *found = 0 where the reference returns None
+ * (count < 127, q >= 1, fewer than 4 values, fewer than 2 left): the caller then keeps the min / max fit, as the reference does.
+ * sample [n_sample][dim] f32, host or device. */
+QMX_API int32_t qmx_sq_fit_quantile(int32_t device_id, uint32_t distance, const float *sample, uint64_t n_sample, uint32_t dim,
+                                    uint64_t count, float quantile, qmx_sq_params *out, int32_t *found);
 /* `EncodedVectorsPQ::encode_vector` (encoded_vectors_pq.rs:301-329): L2 argmin per chunk,
  * first minimum wins.  in [n][dim] f32 -> out [n][m] u8. */
 QMX_API int32_t qmx_pq_encode(int32_t device_id, const qmx_pq_params *params, const float *in,

@@ -1258,3 +1258,31 @@ float qo_bq_score(int distance, int invert, uint32_t dim, const uint8_t *q, cons
     if (dot_like) return invert ? xor_product - zeros_count : zeros_count - xor_product;
     return invert ? zeros_count - xor_product : xor_product - zeros_count;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * find_quantile_interval (lib/quantization/src/quantile.rs:35-84) on a given sample.  Test infrastructure only.
+ * ------------------------------------------------------------------------------------------ */
+static int cmp_f32_partial(const void *a, const void *b) {   /* partial_cmp(..).unwrap_or(Equal) */
+    const float x = *(const float *)a, y = *(const float *)b;
+    return x < y ? -1 : x > y ? 1 : 0;
+}
+int qo_sq_quantile_interval(const float *sample, size_t n_sample, uint32_t dim, size_t count, float quantile, float *min_out, float *max_out) {
+    if (count < 127 || quantile >= 1.0f) return 0;                                  /* :42-44 */
+    const size_t len = n_sample * dim;                                              /* data_slice: the selected vectors, flattened */
+    if (len < 4) return 0;                                                          /* :54-56 */
+    size_t cut_index = (size_t)((float)n_sample * (1.0f - quantile) / 2.0f);       /* :58-62: selected_vectors_count as f32 * (1.0 - quantile) / 2.0 */
+    if ((len - 1) / 2 < cut_index) cut_index = (len - 1) / 2;
+    if (cut_index < 1) cut_index = 1;
+    float *v = (float *)malloc(len * sizeof(float));
+    memcpy(v, sample, len * sizeof(float));
+    qsort(v, len, sizeof(float), cmp_f32_partial);
+    /* select_nth_unstable(len - cut_index) -> left part = sorted [0, len - cut_index); select_nth_unstable(cut_index) on it ->
+     * right part = sorted (cut_index, len - cut_index)                                                         :63-68 */
+    const size_t lo = cut_index + 1, hi = len - cut_index;   /* [lo, hi) */
+    if (hi < lo || hi - lo < 2) { free(v); return 0; }                              /* :70-72 */
+    float mn = 3.4028235e38f, mx = -3.4028235e38f;                                  /* find_min_max_from_iter :19-33 */
+    for (size_t i = lo; i < hi; ++i) { if (v[i] < mn) mn = v[i]; if (v[i] > mx) mx = v[i]; }
+    free(v);
+    *min_out = mn; *max_out = mx;
+    return 1;
+}

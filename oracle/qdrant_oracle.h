@@ -141,6 +141,10 @@ float qo_custom_feedback(uint32_t n_pairs, const float *sims, const float *coefs
 void qo_pq_train_ex(uint32_t dim, uint32_t chunk_size, uint32_t n_centroids, const float *data, size_t n, uint32_t max_iters,
                     float accuracy, uint32_t threads, float *centroids_out, uint32_t *iters_done);   /* kmeans.rs:9-169 on a given sample */
 
+/* find_quantile_interval (lib/quantization/src/quantile.rs:35-84) on a GIVEN sample [n_sample][dim] (the reference's choice of
+ * vectors is random); count = vectors in the storage.  Returns 1 and the interval, or 0 where the reference returns None. */
+int qo_sq_quantile_interval(const float *sample, size_t n_sample, uint32_t dim, size_t count, float quantile, float *min_out, float *max_out);
+
 /* ---- BQ: EncodedVectorsBin<u128>, Encoding::OneBit, QueryEncoding::SameAsStorage (lib/quantization/src/encoded_vectors_binary.rs) ---- */
 size_t qo_bq_row_bytes(uint32_t dim);                                            /* :829-840 with u128::get_storage_size :412-419 */
 void qo_bq_encode_row(uint32_t dim, const float *v, uint8_t *out);               /* encode_one_bit_vector :558-568 */

@@ -2143,6 +2143,52 @@ int32_t qmx_sq_fit_min_max(int32_t device_id, uint32_t distance, const float *in
     return QMX_OK;
 }
 
+static void sq_params_from_min_max(uint32_t distance, uint32_t dim, float mn, float mx, qmx_sq_params *out) {
+    memset(out, 0, sizeof(*out));
+    out->actual_dim = ((dim + 15) / 16) * 16;                 // get_actual_dim (:622-624)
+    out->alpha = (mx - mn) / 127.0f;                          // alpha_offset_from_min_max (:523-527)
+    out->offset = mn;
+    out->invert = (distance == QMX_DISTANCE_EUCLID || distance == QMX_DISTANCE_MANHATTAN) ? 1 : 0;   // quantized_vectors.rs:232
+    float m;
+    if (distance == QMX_DISTANCE_DOT || distance == QMX_DISTANCE_COSINE) m = out->alpha * out->alpha;      // :210-221
+    else if (distance == QMX_DISTANCE_MANHATTAN) m = out->alpha;
+    else m = -2.0f * out->alpha * out->alpha;
+    out->multiplier = out->invert ? -m : m;
+}
+
+int32_t qmx_sq_fit_quantile(int32_t device_id, uint32_t distance, const float *sample, uint64_t n_sample, uint32_t dim, uint64_t count,
+                            float quantile, qmx_sq_params *out, int32_t *found) {
+    QMX_REQUIRE(out && found && (n_sample == 0 || sample) && dim > 0, QMX_ERR_BAD_ARG, "bad argument");
+    QMX_REQUIRE(distance <= QMX_DISTANCE_MANHATTAN, QMX_ERR_BAD_ARG, "bad distance");
+    QMX_TRY(check_device(device_id, nullptr));
+    *found = 0;
+    if (count < 127 || quantile >= 1.0f) return QMX_OK;                                                    // quantile.rs:42-44
+    const uint64_t len = n_sample * dim;
+    if (len < 4) return QMX_OK;                                                                            // :54-56
+    uint64_t cut = std::min<uint64_t>((len - 1) / 2, (uint64_t)((float)n_sample * (1.0f - quantile) / 2.0f));   // :58-62 (f32 arithmetic, truncating cast)
+    cut = std::max<uint64_t>(cut, 1);
+    if (len - 2 * cut - 1 < 2) return QMX_OK;                                                              // :70-72
+    DevBuf bin, btmp;
+    const float *d_in = sample;
+    int32_t rc = QMX_OK;
+    float mm[2] = {0.f, 0.f};
+    do {
+        if (!is_device_ptr(sample)) {
+            if ((rc = bin.reserve((size_t)len * 4)) != QMX_OK) break;
+            if (hipMemcpy(bin.p, sample, (size_t)len * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = QMX_ERR_OTHER; break; }
+            d_in = (const float *)bin.p;
+        }
+        if ((rc = btmp.reserve((size_t)len * 4)) != QMX_OK) break;
+        rc = launch_order_statistics_f32(nullptr, d_in, (float *)btmp.p, len, cut + 1, len - cut - 1, mm);
+    } while (0);
+    bin.release();
+    btmp.release();
+    QMX_TRY(rc);
+    sq_params_from_min_max(distance, dim, mm[0], mm[1], out);
+    *found = 1;
+    return QMX_OK;
+}
+
 int32_t qmx_pq_encode(int32_t device_id, const qmx_pq_params *params, const float *in, uint64_t n, uint32_t dim, uint8_t *out_codes) {
     QMX_REQUIRE(params && params->centroids && (n == 0 || (in && out_codes)) && dim > 0, QMX_ERR_BAD_ARG, "bad argument");
     QMX_REQUIRE(params->chunk_size >= 1 && params->chunk_size <= 256 && params->n_centroids >= 1 && params->n_centroids <= 256,

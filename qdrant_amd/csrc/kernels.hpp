@@ -171,6 +171,8 @@ int32_t launch_sq_internal_query(hipStream_t st, const void *codes, const float 
 constexpr uint32_t M16_FLAG_PRESCAN = 0x200u;   // ScanArgs::flags: this launch is the threshold pre-scan (runs under its own kernel name)
 bool mfma16_scan_ok(int qt, ScanMode mode, const ScanArgs &a);   // qt = 32 or 64
 int32_t launch_scan_f32_mfma16(hipStream_t st, int qt, const ScanArgs &a, int num_cus, uint32_t *grid_out);
+// order statistics of a float array (quantile.hip): the SQ quantile interval
+int32_t launch_order_statistics_f32(hipStream_t st, const float *d_in, float *d_tmp, uint64_t n, uint64_t lo_pos, uint64_t hi_pos, float *h_out);
 // BQ 1-bit (scan_bq.hip)
 int32_t launch_scan_bq(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out);
 int32_t launch_pairs_bq(hipStream_t st, const ScanArgs &a, const PairSel &sel, uint64_t n_items, int num_cus);

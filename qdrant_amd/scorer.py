@@ -150,6 +150,20 @@ class ScalarQuantizer:
         F.check(F.lib().qmx_sq_fit_min_max(device_id, int(distance), F.ptr(d), int(d.shape[0]), int(dim), C.byref(p)))
         return cls(dim, distance, p.alpha, p.offset)
 
+    @classmethod
+    def fit_quantile(cls, data, dim: int, distance: Distance, quantile: float, sample=None, count: Optional[int] = None, device_id: int = 0):
+        """`EncodedVectorsU8::encode` with `quantile = Some(q)` (encoded_vectors_u8.rs:193-208): the interval of
+        `find_quantile_interval` (quantile.rs:35-84) over `sample` (default: the first SAMPLE_SIZE = 5 000 rows of `data`; the
+        reference samples at random), falling back to the min / max fit where the reference does."""
+        d = np.ascontiguousarray(data, dtype=np.float32)
+        smp = d[:5000] if sample is None else np.ascontiguousarray(sample, dtype=np.float32)
+        p, found = F.SqParams(), C.c_int32(0)
+        F.check(F.lib().qmx_sq_fit_quantile(device_id, int(distance), F.ptr(smp), int(smp.shape[0]), int(dim),
+                                            int(d.shape[0] if count is None else count), float(quantile), C.byref(p), C.byref(found)))
+        if not found.value:
+            return cls.fit(d, dim, distance, device_id)
+        return cls(dim, distance, p.alpha, p.offset)
+
     def params(self) -> "F.SqParams":
         p = F.SqParams()
         p.actual_dim = self.actual_dim

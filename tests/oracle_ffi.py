@@ -92,6 +92,7 @@ _sig("qo_pq_score_internal", _f, [C.POINTER(Pq), _P, _P])
 _sig("qo_pq_train", None, [C.c_uint32, C.c_uint32, C.c_uint32, _P, C.c_size_t, C.c_int, _P])
 _sig("qo_custom_combine", _f, [C.c_int, C.c_uint32, C.c_uint32, _P])
 _sig("qo_custom_feedback", _f, [C.c_uint32, _P, _P])
+_sig("qo_sq_quantile_interval", C.c_int, [_P, C.c_size_t, C.c_uint32, C.c_size_t, _f, C.POINTER(_f), C.POINTER(_f)])
 _sig("qo_bq_row_bytes", C.c_size_t, [C.c_uint32])
 _sig("qo_bq_encode_row", None, [C.c_uint32, _P, _P])
 _sig("qo_bq_xor_popcnt", C.c_uint32, [_P, _P, C.c_uint32])
@@ -278,6 +279,14 @@ class SqOracle:
     def score_internal(self, a, b):
         return np.array([_lib.qo_sq_score_internal(C.byref(self.sq), _p(self.rows[i]), _p(self.rows[j]), self.isa)
                          for i, j in zip(a, b)], dtype=np.float32)
+
+
+def sq_quantile_interval(sample, count, quantile):
+    """find_quantile_interval on a given sample -> (min, max) or None."""
+    v = f32(sample)
+    mn, mx = _f(), _f()
+    ok = _lib.qo_sq_quantile_interval(_p(v), v.shape[0], v.shape[1], count, float(quantile), C.byref(mn), C.byref(mx))
+    return (np.float32(mn.value), np.float32(mx.value)) if ok else None
 
 
 class BqOracle:

@@ -232,3 +232,34 @@ def test_search_quantized_pipeline_matches_the_reference_flow(qa):
         assert np.array_equal(g, w)
     with pytest.raises(qa.QmxError):
         qa.search_quantized(sq_scorer, None, top, rescore=True)                       # rescoring needs the original batch
+
+
+@pytest.mark.parametrize("n,dim,q", [(5000, 64, 0.99), (1000, 96, 0.95), (200, 17, 0.5), (130, 3, 0.999), (5000, 768, 0.99)])
+def test_sq_fit_quantile_is_the_reference_order_statistic(qa, n, dim, q):
+    """qmx_sq_fit_quantile == find_quantile_interval (quantile.rs:35-84) on the same sample: an exact order statistic."""
+    rng = np.random.default_rng(n + dim)
+    sample = (rng.standard_normal((n, dim)) * rng.uniform(0.5, 3.0)).astype(np.float32)
+    want = O.sq_quantile_interval(sample, n, q)
+    assert want is not None
+    quant = qa.ScalarQuantizer.fit_quantile(sample, dim, qa.Distance.Dot, q)
+    assert np.float32(quant.offset).view(np.uint32) == want[0].view(np.uint32)
+    assert np.float32(quant.alpha).view(np.uint32) == ((want[1] - want[0]) / np.float32(127.0)).view(np.uint32)
+    srt = np.sort(sample.ravel())
+    cut = max(1, min((srt.size - 1) // 2, int(np.float32(n) * (np.float32(1.0) - np.float32(q)) / np.float32(2.0))))
+    assert want[0] == srt[cut + 1] and want[1] == srt[srt.size - cut - 1]
+
+
+def test_sq_fit_quantile_fallbacks_like_the_reference(qa):
+    rng = np.random.default_rng(3)
+    small = rng.standard_normal((100, 8)).astype(np.float32)                       # count < 127 -> None -> min / max fit
+    assert O.sq_quantile_interval(small, 100, 0.99) is None
+    a, b = qa.ScalarQuantizer.fit_quantile(small, 8, qa.Distance.Dot, 0.99), qa.ScalarQuantizer.fit(small, 8, qa.Distance.Dot)
+    assert (a.alpha, a.offset) == (b.alpha, b.offset)
+    data = rng.standard_normal((500, 8)).astype(np.float32)                        # quantile >= 1 -> None
+    assert O.sq_quantile_interval(data, 500, 1.0) is None
+    a, b = qa.ScalarQuantizer.fit_quantile(data, 8, qa.Distance.Dot, 1.0), qa.ScalarQuantizer.fit(data, 8, qa.Distance.Dot)
+    assert (a.alpha, a.offset) == (b.alpha, b.offset)
+    # a sample of the storage (count says how many vectors the storage has)
+    q2 = qa.ScalarQuantizer.fit_quantile(data, 8, qa.Distance.Euclid, 0.9, sample=data[::5], count=500)
+    want = O.sq_quantile_interval(data[::5], 500, 0.9)
+    assert np.float32(q2.offset) == want[0] and q2.invert
