@@ -178,6 +178,56 @@ def test_mfma16_large_scan_equals_the_other_kernels(qa, nq):
         assert np.array_equal(g["score"].view(np.uint32), o["score"].view(np.uint32))
 
 
+@pytest.mark.parametrize("n", [1, 2, 15, 16, 17, 33])
+@pytest.mark.parametrize("nq,top", [(33, 1), (64, 10), (40, 100)])
+def test_mfma16_tiny_blocks(qa, n, nq, top):
+    """Fewer rows than one 16-row tile / fewer tiles than blocks, top larger than the block."""
+    rng = np.random.default_rng(n * 100 + nq)
+    dim = 256
+    rows = O.preprocess(O.DOT, rng.standard_normal((n, dim)).astype(np.float32))
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    st = qa.VectorStorage(rows, qa.Distance.Dot)
+    got = qa.BatchFilteredSearcher(queries, st, top).peek_top_all()
+    want = O.DenseStorage(O.F32, O.DOT, rows).peek_top(queries, top)
+    for g, w in zip(got, want):
+        assert len(g) == min(top, n)
+        assert np.array_equal(g["score"].view(np.uint32), w["score"].view(np.uint32)) and g["idx"].tolist() == w["idx"].tolist()
+
+
+@pytest.mark.parametrize("nq,top", [(40, 100), (64, 64), (20, 130)])
+def test_mfma16_prescan_with_multipass_top_and_deleted(qa, nq, top):
+    """>= 2^18 rows: the threshold pre-scan runs before pass 0; top > 64 adds bounded passes after it.  Same lists with the
+    pre-scan off and with the chain-major kernel off (all bit-exact kernels), deleted rows respected."""
+    import torch
+    from qdrant_amd import _ffi as F
+    n, dim = 300_007, 512
+    dev = torch.device("cuda", 0)
+    rows = torch.empty((n, dim), dtype=torch.float32, device=dev)
+    F.check(F.lib().qmx_synth_fill_f32(0, 0x5EED00B1 + nq, 0, n, dim, F.ptr(rows)))
+    F.check(F.lib().qmx_preprocess_f32(0, int(qa.Distance.Cosine), F.ptr(rows), n, dim, F.ptr(rows)))
+    torch.cuda.synchronize()
+    st = qa.VectorStorage(rows, qa.Distance.Cosine)
+    rng = np.random.default_rng(top)
+    deleted = rng.random(n) < 0.3
+    deleted[:4096] |= rng.random(4096) < 0.9            # most of the pre-scanned prefix is deleted: its threshold is still a valid bound
+    st.set_deleted(deleted, None)
+    queries = O.synth(0x5EED00B2, 0, nq, dim)
+    s = qa.BatchFilteredSearcher(queries, st, top)
+    got = s.peek_top_all()
+    variants = []
+    for env in ("QMX_NO_PRESCAN", "QMX_NO_MFMA16"):
+        os.environ[env] = "1"
+        try:
+            variants.append(s.peek_top_all())
+        finally:
+            del os.environ[env]
+    for qi, g in enumerate(got):
+        assert len(g) == top and not deleted[g["idx"]].any() and np.all(np.diff(g["score"]) <= 0)
+        for v in variants:
+            assert np.array_equal(g["score"].view(np.uint32), v[qi]["score"].view(np.uint32))
+            assert g["idx"].tolist() == v[qi]["idx"].tolist()
+
+
 # ---- SQ int8 on v_mfma_i32_16x16x64_i8 (scan_sq_mfma.hip) ---------------------------------------------------------
 def _dist_all(qa, d):
     return {O.COSINE: qa.Distance.Cosine, O.DOT: qa.Distance.Dot, O.EUCLID: qa.Distance.Euclid}[d]
