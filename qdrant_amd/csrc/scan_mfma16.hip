@@ -275,8 +275,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
             }
             // this wave's loads of the next stage have landed when at most the RPW (NBUF - 2) issued after them are outstanding; the
             // barrier makes that true for every wave's rows and says every wave holds all of the current stage in registers
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(S::VPS * (NBUF - 2 - (LAG ? 1 : 0))) : "memory");
-            __builtin_amdgcn_s_barrier();
+            if (DBG != 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(S::VPS * (NBUF - 2 - (LAG ? 1 : 0))) : "memory");
+            if (DBG != 4 && DBG != 6) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             // K-step 1; the refill of the slot just freed and the K-step 0 operands of the next stage go in between
 #pragma unroll
@@ -419,6 +419,9 @@ int32_t launch_scan_f32_mfma16(hipStream_t st, int qt, const ScanArgs &a, int nu
             const char *dbg = getenv("QMX_M16_DBG");
             if (dbg && dbg[0] == '2') return launch_m16<3, 8, 4, 2>(st, a, num_cus, grid_out);
             if (dbg && dbg[0] == '3') return launch_m16<3, 8, 4, 3>(st, a, num_cus, grid_out);
+            if (dbg && dbg[0] == '4') return launch_m16<3, 8, 4, 4, false>(st, a, num_cus, grid_out);   // (wrong results) no stage wait, no stage barrier
+            if (dbg && dbg[0] == '6') return launch_m16<3, 8, 4, 6, false>(st, a, num_cus, grid_out);   // (wrong results) no stage barrier
+            if (dbg && dbg[0] == '7') return launch_m16<3, 8, 4, 3, false>(st, a, num_cus, grid_out);   // no fold / selection, lock-step
             if (dbg && dbg[0] == '5') return launch_m16<3, 8, 4, 0, false>(st, a, num_cus, grid_out);   // lock-step waves
             return launch_m16<3, 8, 4>(st, a, num_cus, grid_out);
         }
