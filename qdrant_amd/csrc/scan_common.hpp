@@ -48,6 +48,13 @@ __device__ __forceinline__ void scan_step(typename P::acc_t (&acc)[QT][R][P::NAC
     }
 }
 
+// a 16-byte piece of a stored row, streamed once: nontemporal, so the lines do not push the query tile / partial lists out of L2
+__device__ __forceinline__ uint4 load_row_piece(const unsigned char *p) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
 template <class P, int QT, int R, int UNROLL, bool HAS_IDS, int MODE>
 __global__ __launch_bounds__(SCAN_BLOCK) void scan_kernel(const ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_kernel(const ScanArgs a) {
         for (uint32_t s = 0; s < nseg; ++s) {
             uint4 v[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) v[r] = *reinterpret_cast<const uint4 *>(rp[r] + (uint64_t)s * 128);
+            for (int r = 0; r < R; ++r) v[r] = load_row_piece(rp[r] + (uint64_t)s * 128);
             scan_step<P, QT, R>(acc, raux, v, smem + s * 128 + piece_off, a.q_stride, true);
         }
         if (a.rem_pieces) {
