@@ -43,7 +43,7 @@ constexpr int M16_STAGE = 16 * M16_ROWP;
 // these loads itself.
 __device__ __forceinline__ void glds16(const unsigned char *row, uint32_t lane_off, uint32_t lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(lane_off), "s"(row), "s"(lds_dst) : "memory");
 }
 __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
