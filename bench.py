@@ -318,6 +318,8 @@ def _kernel_name(dim, Q):
     if Q > 32 and m16:
         return "scan_f32_mfma16_kernel<KS=%d,NW=8,NT=4> (v_mfma_f32_16x16x4_f32, 64 queries per pass)" % (dim // 256)
     qt = _pow2(min(Q, 32))
+    if qt == 16 and dim % 256 == 0 and dim <= 1536:
+        return "scan_f32_mfma16_kernel<KS=%d,NW=4,NT=1> (v_mfma_f32_16x16x4_f32, 16 queries per pass)" % (dim // 256)
     if qt == 32 and m16:
         return "scan_f32_mfma16_kernel<KS=%d,NW=4,NT=2> (v_mfma_f32_16x16x4_f32, 32 queries per pass)" % (dim // 256)
     if qt >= 8:

@@ -378,6 +378,7 @@ int32_t launch_scan_f32_mfma(hipStream_t st, int qt, ScanMode mode, const ScanAr
             return nt ? launch_mfma_qt<8, 1, 4, true>(st, mode, a, num_cus, grid_out) : launch_mfma_qt<8, 1, 4, false>(st, mode, a, num_cus, grid_out);
         }
         case 16:
+            if (mfma16_scan_ok(16, mode, a)) return launch_scan_f32_mfma16(st, 16, a, num_cus, grid_out);
             // rows of a multiple of 384 floats (768, 1536, ...): guard-free ping-pong main loop
             if (a.nseg % 12 == 0 && getenv("QMX_MFMA_NO_FAST") == nullptr) return launch_mfma_qt<16, 1, 6, true, 8, true>(st, mode, a, num_cus, grid_out);
             return launch_mfma_qt<16, 1, 12, true>(st, mode, a, num_cus, grid_out);

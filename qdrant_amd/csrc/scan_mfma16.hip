@@ -13,7 +13,8 @@
 // ELEMENTWISE on accumulator tiles in the reference's tree (four_way_hsum, hsum256_ps_avx, simple_avx.rs:10-28) - no
 // cross-lane traffic at all.
 //
-// Three shapes of the same kernel (NW waves per block, NT = QT / 16 query tiles):
+// Four shapes of the same kernel (NW waves per block, NT = QT / 16 query tiles):
+//   QT = 16, dim <= 1536: NW = 4, two blocks per CU, 8 chains x 1 query tile per wave (the pass is an HBM stream: 0.86 of peak).
 //   QT = 32, dim <= 768:  NW = 4, two blocks per CU.  Wave w owns SIMD lanes j = w and w + 4 of the four AVX registers (8 chains).
 //   QT = 64, dim <= 768:  NW = 8, one block per CU.   Wave w owns SIMD lane j = w (4 chains).
 //   QT = 32, dim <= 1536: NW = 8, one block per CU, 4 chains x 2 query tiles per wave (the longer rows need the registers).
@@ -398,14 +399,21 @@ static int32_t launch_m16(hipStream_t st, const ScanArgs &a, int num_cus, uint32
 // qt = 32 or 64
 bool mfma16_scan_ok(int qt, ScanMode mode, const ScanArgs &a) {
     if (getenv("QMX_NO_MFMA16") != nullptr) return false;
-    return (qt == 32 || qt == 64) && mode == SCAN_TOPK && a.ids == nullptr && a.rem_pieces == 0 && a.tail_start == a.dim && a.nseg % 8 == 0 &&
+    return (qt == 16 || qt == 32 || qt == 64) && mode == SCAN_TOPK && a.ids == nullptr && a.rem_pieces == 0 && a.tail_start == a.dim && a.nseg % 8 == 0 &&
            a.nseg / 8 >= 1 && a.nseg / 8 <= (qt == 64 ? 3u : 6u) && a.row_stride % 16 == 0 && a.top <= 64;
 }
 
 // top-k over the whole block; the caller checked mfma16_scan_ok
 int32_t launch_scan_f32_mfma16(hipStream_t st, int qt, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
     const int ks = (int)(a.nseg / 8);
-    if (qt == 32) {
+    if (qt == 16) {
+        if (ks == 1) return launch_m16<1, 4, 1>(st, a, num_cus, grid_out);
+        if (ks == 2) return launch_m16<2, 4, 1>(st, a, num_cus, grid_out);
+        if (ks == 3) return launch_m16<3, 4, 1>(st, a, num_cus, grid_out);
+        if (ks == 4) return launch_m16<4, 4, 1>(st, a, num_cus, grid_out);
+        if (ks == 5) return launch_m16<5, 4, 1>(st, a, num_cus, grid_out);
+        if (ks == 6) return launch_m16<6, 4, 1>(st, a, num_cus, grid_out);
+    } else if (qt == 32) {
         if (ks == 1) return launch_m16<1, 4, 2>(st, a, num_cus, grid_out);
         if (ks == 2) return launch_m16<2, 4, 2>(st, a, num_cus, grid_out);
         if (ks == 3) return launch_m16<3, 4, 2>(st, a, num_cus, grid_out);
