@@ -27,7 +27,7 @@
 // The A operand of (chain c, K-step) is one ds_read_b32: lane (m = lane & 15, k = lane >> 4) reads element
 // c + 32 (4 step + k) of row m.  Every byte of the block is read from HBM once and from LDS once.
 //
-// Restrictions (anything else takes the scan_mfma.hip path): top-k mode over the whole block (no id list), dim a multiple of
+// Restrictions (anything else takes the scan_mfma.hip path): top-k mode (whole block or a candidate id list), dim a multiple of
 // 256 up to 1536 (64-query passes: up to 768), 16-byte aligned rows.
 #include "scan_common.hpp"
 
@@ -52,6 +52,13 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
     return ((uint64_t)hi << 32) | lo;
 }
 
+// one dword through the scalar cache (wave-uniform address): candidate ids, without touching the vector-memory counter
+__device__ __forceinline__ uint32_t sload_u32(const uint32_t *p) {
+    uint32_t v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
+
 // bit `id` of a device bitmap through the scalar cache (id is wave-uniform): no vector-memory counter involved
 __device__ __forceinline__ bool bit_get_uniform(const uint64_t *words, uint32_t id) {
     const uint64_t *p = words + (id >> 6);
@@ -74,7 +81,8 @@ struct M16Shape {
     static constexpr int RPW = 16 / NW;                // rows of a stage fetched per wave
     static constexpr int NBUF = NW == 4 ? 4 : 7;       // ring stages (4 waves: two blocks share the CU's 160 KiB)
     static constexpr int XCH = NW * NT * 4 * 64 * 4;   // fold exchange: [wave][query tile][reg][lane] f32
-    static constexpr int LDS = NBUF * M16_STAGE + XCH;
+    static constexpr int IDR = 16 * 16 * 4;            // candidate ids of the last 16 tiles [tile iteration & 15][row] (id-list scans)
+    static constexpr int LDS = NBUF * M16_STAGE + XCH + IDR;
     static constexpr int VPS = RPW;                    // vector-memory instructions per stage and wave
     static constexpr int PW = NT * 4 / NW;             // accumulator planes (query tile, register) a wave finishes per tile
     static_assert(PW == 1 || PW == 2, "the NT * 4 planes of a tile are split evenly over the waves");
@@ -82,7 +90,8 @@ struct M16Shape {
 
 template <int KS /* dim / 256 */, int NW, int NT, int DBG = 0 /* tuning experiments (QMX_M16_DBG): 2 no row loads, 3 no fold / selection */,
           bool LAG = (NW == 8 && NT == 4 && KS == 3) /* half of the waves run one stage behind the others, see `lag` */,
-          bool PRE = false /* the threshold pre-scan of api.hip: same code under its own name, so that profiles keep the two apart */>
+          bool PRE = false /* the threshold pre-scan of api.hip: same code under its own name, so that profiles keep the two apart */,
+          bool IDS = false /* candidates = a.ids[0 .. n_cand) instead of rows 0 .. n_cand) (payload-filtered scans, peek_top_iter) */>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kernel(const ScanArgs a) {
     typedef M16Shape<NW, NT> S;
     constexpr int QT = S::QT, JW = S::JW, CW = S::CW, RPW = S::RPW, NBUF = S::NBUF, PW = S::PW;
@@ -152,6 +161,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
     // fetches rows RPW w .. RPW w + RPW - 1 of the tile.  Stages past the end re-read row 0 (never consumed): the in-flight count
     // stays constant and the loop needs no tail.  All of it is scalar work: row bases are wave-uniform.
     const uint32_t lane_off = (uint32_t)lane * 16u;
+    uint32_t *idring = reinterpret_cast<uint32_t *>(smem + NBUF * M16_STAGE + S::XCH);
     uint64_t ld_it = 0;            // tile iteration of the next stage to issue
     uint32_t ld_kc = 0;            // ... and its chunk
     uint32_t ld_slot = 0;
@@ -163,6 +173,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
             uint64_t c = tile * 16 + (uint32_t)(RPW * w + i);
             if (c >= a.n_cand) c = a.n_cand - 1;           // rows past the end of a partial last tile: any valid row, results dropped
             if (ld_it >= my_tiles) c = 0;
+            if (IDS) {                                     // the candidate's row: its id travels to the tile's finalize through LDS
+                uint32_t id = sload_u32(reinterpret_cast<const uint32_t *>(uniform_u64((uint64_t)(a.ids + c))));
+                if (lane == 0) idring[((uint32_t)ld_it & 15u) * 16u + (uint32_t)(RPW * w + i)] = id;
+                c = id < a.n_rows ? id : 0;                // an id past the storage is reported by finalize; never read
+            }
             ld_row[i] = reinterpret_cast<const unsigned char *>(uniform_u64((uint64_t)(rows + c * a.row_stride)));
         }
     };
@@ -200,7 +215,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
 
     // Second half of a tile's epilogue, run one stage barrier after the tile's fold values were written to xch: the wave finishes
     // accumulator register j0 + p of query tile tq: row 4 (lane >> 4) + j0 + p of the tile, query 16 tq + (lane & 15).
-    auto finalize = [&](uint64_t tile, int p) {
+    auto finalize = [&](uint64_t it_of_tile, int p) {
+        const uint64_t tile = blockIdx.x + it_of_tile * gridDim.x;
         const int j = j0 + p;
         auto x = [&](int src_wave) { return xch[((src_wave * NT + tq) * 4 + j) * 64 + lane]; };
         float score;
@@ -211,8 +227,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
             score = (lr0 + lr1) + (lr2 + lr3);
         }
         const uint64_t c = tile * 16 + (uint32_t)(4 * kk + j);
-        const uint32_t res_row = (uint32_t)c;
-        const bool mine = c < a.n_cand && my_q < (int)a.nq;
+        uint32_t res_row = (uint32_t)c;
+        bool mine = c < a.n_cand && my_q < (int)a.nq;
+        if (IDS) {
+            res_row = idring[((uint32_t)it_of_tile & 15u) * 16u + (uint32_t)(4 * kk + j)];
+            if (mine && res_row >= a.n_rows) {             // raw_scorer.rs would panic on such an id: report it
+                *a.err_flag = 1;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (keeps the store out of the load counting; error path only)
+                mine = false;
+            }
+        }
         // cheap reject on the score alone; ties with the k-th score and NaN (greatest in OrderedFloat) fall through to the key compare
         bool cnd = mine && !(score < thr_f);
         if (__ballot(cnd)) {
@@ -250,7 +274,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
     }
     uint32_t slot = 0;        // ring slot of the stage being multiplied
     for (uint64_t it = 0; it < my_tiles; ++it) {
-        const uint64_t tile = blockIdx.x + it * gridDim.x;
         f32x4 acc[CW][NT];
 #pragma unroll
         for (int ci = 0; ci < CW; ++ci)
@@ -298,7 +321,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
                 // the fold values of the PREVIOUS tile sit in xch since before this stage's barrier: finish that tile here, under
                 // the matrix work of this one
                 if (DBG != 3 && ci >= CW / 2 && ci < CW / 2 + PW && it > 0 && ((kc == 0 && (!LAG || lag)) || (LAG && kc == 1 && !lag))) {
-                    finalize(tile - gridDim.x, ci - CW / 2);
+                    finalize(it - 1, ci - CW / 2);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -336,9 +359,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const uint64_t last = blockIdx.x + (my_tiles - 1) * gridDim.x;
-        finalize(last, 0);
-        if (PW == 2) finalize(last, 1);
+        finalize(my_tiles - 1, 0);
+        if (PW == 2) finalize(my_tiles - 1, 1);
     }
 
     // ---- block merge: the NW / NT wave lists of each query (waves tq, tq + NT, ...) -> 1 list, one global write per block ----
@@ -367,11 +389,20 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
     }
 }
 
-template <int KS, int NW, int NT, int DBG = 0, bool LAG = (NW == 8 && NT == 4 && KS == 3), bool PRE = false>
+template <int KS, int NW, int NT, int DBG = 0, bool LAG = (NW == 8 && NT == 4 && KS == 3), bool PRE = false, bool IDS = false>
 static int32_t launch_m16(hipStream_t st, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
-    if (!PRE && DBG == 0 && (a.flags & M16_FLAG_PRESCAN)) return launch_m16<KS, NW, NT, 0, LAG, true>(st, a, num_cus, grid_out);
+    if constexpr (!PRE && !IDS && DBG == 0) {
+        if ((a.flags & M16_FLAG_PRESCAN) && !a.ids) return launch_m16<KS, NW, NT, 0, LAG, true>(st, a, num_cus, grid_out);
+    }
+    if constexpr (!PRE && !IDS && DBG == 0 && LAG == (NW == 8 && NT == 4 && KS == 3)) {
+        if (a.ids) {
+            // (KS = 3 with 4 waves x 2 query tiles has no register left for the id plumbing: the 8-wave 32-query shape takes it)
+            if constexpr (KS == 3 && NW == 4 && NT == 2) return launch_m16<KS, 8, 2, 0, false, false, true>(st, a, num_cus, grid_out);
+            else return launch_m16<KS, NW, NT, 0, LAG, false, true>(st, a, num_cus, grid_out);
+        }
+    }
     typedef M16Shape<NW, NT> S;
-    auto kfn = scan_f32_mfma16_kernel<KS, NW, NT, DBG, LAG, PRE>;
+    auto kfn = scan_f32_mfma16_kernel<KS, NW, NT, DBG, LAG, PRE, IDS>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -399,7 +430,7 @@ static int32_t launch_m16(hipStream_t st, const ScanArgs &a, int num_cus, uint32
 // qt = 32 or 64
 bool mfma16_scan_ok(int qt, ScanMode mode, const ScanArgs &a) {
     if (getenv("QMX_NO_MFMA16") != nullptr) return false;
-    return (qt == 16 || qt == 32 || qt == 64) && mode == SCAN_TOPK && a.ids == nullptr && a.rem_pieces == 0 && a.tail_start == a.dim && a.nseg % 8 == 0 &&
+    return (qt == 16 || qt == 32 || qt == 64) && mode == SCAN_TOPK && a.rem_pieces == 0 && a.tail_start == a.dim && a.nseg % 8 == 0 &&
            a.nseg / 8 >= 1 && a.nseg / 8 <= (qt == 64 ? 3u : 6u) && a.row_stride % 16 == 0 && a.top <= 64;
 }
 

@@ -178,6 +178,35 @@ def test_mfma16_large_scan_equals_the_other_kernels(qa, nq):
         assert np.array_equal(g["score"].view(np.uint32), o["score"].view(np.uint32))
 
 
+@pytest.mark.parametrize("dim", [256, 768, 1536])
+@pytest.mark.parametrize("nq,top", [(12, 10), (32, 64), (64, 1), (50, 100)])
+def test_mfma16_candidate_id_lists(qa, dim, nq, top):
+    """peek_top_iter over a payload-filtered candidate list (point_scorer.rs:423-472): the chain-major kernel gathers the rows
+    of the ids; deleted flags still apply; an id past the storage is an error."""
+    rng = np.random.default_rng(dim + nq)
+    n = 6007
+    rows = O.preprocess(O.COSINE, rng.standard_normal((n, dim)).astype(np.float32))
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    deleted = rng.random(n) < 0.2
+    st = qa.VectorStorage(rows, qa.Distance.Cosine)
+    st.set_deleted(deleted, None)
+    truth = O.DenseStorage(O.F32, O.COSINE, rows, point_deleted=deleted)
+    s = qa.BatchFilteredSearcher(queries, st, top)
+    for m in (1, 15, 16, 17, 2500):
+        ids = rng.permutation(n)[:m].astype(np.uint32)
+        got = s.peek_top_iter(ids)
+        want = truth.peek_top(queries, top, ids=ids)
+        for g, w in zip(got, want):
+            assert np.array_equal(g["score"].view(np.uint32), w["score"].view(np.uint32))
+            uniq = np.array([(w["score"] == x).sum() == 1 for x in w["score"]], dtype=bool)
+            assert np.array_equal(g["idx"][uniq], w["idx"][uniq])
+    bad = np.array([5, n + 3, 7] + list(range(40)), dtype=np.uint32)
+    with pytest.raises(qa.QmxError):
+        s.peek_top_iter(bad)
+    ok = s.peek_top_iter(np.arange(100, dtype=np.uint32))              # the searcher is usable after the error
+    assert all(len(r) == min(top, int((~deleted[:100]).sum())) for r in ok)
+
+
 @pytest.mark.parametrize("n", [1, 2, 15, 16, 17, 33])
 @pytest.mark.parametrize("nq,top", [(33, 1), (64, 10), (40, 100)])
 def test_mfma16_tiny_blocks(qa, n, nq, top):
@@ -226,6 +255,16 @@ def test_mfma16_prescan_with_multipass_top_and_deleted(qa, nq, top):
         for v in variants:
             assert np.array_equal(g["score"].view(np.uint32), v[qi]["score"].view(np.uint32))
             assert g["idx"].tolist() == v[qi]["idx"].tolist()
+    # the same through a candidate id list of >= 2^18 entries (pre-scan over the head of the list)
+    ids = rng.permutation(n)[:280_000].astype(np.uint32)
+    got = s.peek_top_iter(ids)
+    os.environ["QMX_NO_MFMA16"] = "1"
+    try:
+        want = s.peek_top_iter(ids)
+    finally:
+        del os.environ["QMX_NO_MFMA16"]
+    for g, w2 in zip(got, want):
+        assert np.array_equal(g["score"].view(np.uint32), w2["score"].view(np.uint32)) and g["idx"].tolist() == w2["idx"].tolist()
 
 
 # ---- SQ int8 on v_mfma_i32_16x16x64_i8 (scan_sq_mfma.hip) ---------------------------------------------------------
