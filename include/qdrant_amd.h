@@ -172,6 +172,18 @@ QMX_API uint32_t qmx_abi_version(void);
  * (raw_scorer.rs:60-114 matches on it) / `GpuVectorStorage::new`
  * (hnsw_index/gpu/gpu_vector_storage/mod.rs).  OOM => QMX_ERR_OUT_OF_MEMORY, caller keeps CPU. */
 QMX_API int32_t qmx_segment_create(const qmx_segment_desc *desc, qmx_segment **out);
+/* Direct ingestion of the reference's storage files:
+ *   dense f32 / f16 / u8: the immutable dense vector file = 4-byte header "data", then row-major rows
+ *     (lib/segment/src/vector_storage/dense/immutable_dense_vectors.rs:25-27, 90, 105-110: num_vectors = (len - 4) / dim / sizeof(T));
+ *   SQ / PQ / BQ: the quantized storage file = flat rows of quantized_vector_size bytes, no header
+ *     (vector_storage/quantized/quantized_storage.rs:25-70); desc->sq / desc->pq carry the metadata JSON's values;
+ *   deleted_path (optional): the "drop" flags file = 4-byte header "drop", padding to 8 bytes, then the BitSlice<u64, Lsb0>
+ *     words (immutable_dense_vectors.rs:27, 364-378) -> the vector-deleted flags of the segment.
+ * desc->data is ignored; desc->n = 0 takes the row count from the file size, otherwise the file must hold at least n rows.
+ * The file is streamed through a pinned staging buffer: no host copy of the block is kept. */
+QMX_API int32_t qmx_segment_create_from_files(const qmx_segment_desc *desc, const char *vectors_path, const char *deleted_path,
+                                              qmx_segment **out);
+
 /* Same for a CHUNKED appendable storage (`ChunkedVectors<T>`, lib/segment/src/vector_storage/chunked_vectors.rs: fixed-size
  * chunks of CHUNK_SIZE = 32 MiB, vector_storage/common.rs:27; row `key` lives in chunk key / rows_per_chunk at row
  * key % rows_per_chunk): `chunks[c]` points at chunk c (host or device), every chunk but the last holds `rows_per_chunk`

@@ -432,6 +432,85 @@ int32_t qmx_segment_create(const qmx_segment_desc *desc, qmx_segment **out) {
     return QMX_OK;
 }
 
+int32_t qmx_segment_create_from_files(const qmx_segment_desc *desc, const char *vectors_path, const char *deleted_path, qmx_segment **out) {
+    QMX_REQUIRE(desc && vectors_path && out, QMX_ERR_BAD_ARG, "NULL argument");
+    *out = nullptr;
+    QMX_REQUIRE(desc->dtype <= QMX_DTYPE_BQ && desc->dim > 0, QMX_ERR_BAD_ARG, "bad dtype / dim");
+    QMX_TRY(check_device(desc->device_id, nullptr));
+    // bytes per stored row in the file and the header in front of them
+    uint64_t row_bytes = 0, header = 0;
+    switch (desc->dtype) {
+        case QMX_DTYPE_F32: case QMX_DTYPE_F16: case QMX_DTYPE_U8: row_bytes = (uint64_t)desc->dim * elem_bytes(desc->dtype); header = 4; break;
+        case QMX_DTYPE_SQ_U8:
+            QMX_REQUIRE(desc->sq, QMX_ERR_BAD_ARG, "SQ segment needs qmx_sq_params");
+            row_bytes = 4ull + desc->sq->actual_dim;
+            break;
+        case QMX_DTYPE_PQ:
+            QMX_REQUIRE(desc->pq && desc->pq->chunk_size, QMX_ERR_BAD_ARG, "PQ segment needs qmx_pq_params");
+            row_bytes = ((uint64_t)desc->dim + desc->pq->chunk_size - 1) / desc->pq->chunk_size;
+            break;
+        default: row_bytes = (((uint64_t)desc->dim + 127) / 128) * 16; break;   // BQ
+    }
+    FILE *f = fopen(vectors_path, "rb");
+    QMX_REQUIRE(f, QMX_ERR_BAD_ARG, "cannot open %s", vectors_path);
+    int32_t rc = QMX_OK;
+    void *d_tmp = nullptr, *h_pin = nullptr;
+    do {
+        if (fseek(f, 0, SEEK_END) != 0) { set_error("cannot seek %s", vectors_path); rc = QMX_ERR_OTHER; break; }
+        const uint64_t len = (uint64_t)ftell(f);
+        rewind(f);
+        if (header) {
+            char magic[4] = {0, 0, 0, 0};
+            if (len < header || fread(magic, 1, 4, f) != 4 || memcmp(magic, "data", 4) != 0) {   // VECTORS_HEADER
+                set_error("%s does not start with the dense vector file header \"data\"", vectors_path);
+                rc = QMX_ERR_BAD_ARG;
+                break;
+            }
+        }
+        const uint64_t in_file = (len - header) / row_bytes;      // num_vectors = (file_len - HEADER_SIZE) / dim / size_of::<T>()
+        const uint64_t n = desc->n ? desc->n : in_file;
+        if (n > in_file) { set_error("%s holds %llu rows, %llu asked for", vectors_path, (unsigned long long)in_file, (unsigned long long)n); rc = QMX_ERR_BAD_ARG; break; }
+        const size_t total = (size_t)n * row_bytes;
+        if (hipMalloc(&d_tmp, std::max<size_t>(total, 16)) != hipSuccess) { set_error("device allocation of %zu bytes failed", total); rc = QMX_ERR_OUT_OF_MEMORY; break; }
+        const size_t chunk = 64u << 20;
+        if (hipHostMalloc(&h_pin, chunk, hipHostMallocDefault) != hipSuccess) { set_error("pinned staging allocation failed"); rc = QMX_ERR_OUT_OF_MEMORY; break; }
+        for (size_t off = 0; off < total && rc == QMX_OK; off += chunk) {
+            const size_t want = std::min(chunk, total - off);
+            if (fread(h_pin, 1, want, f) != want) { set_error("short read from %s", vectors_path); rc = QMX_ERR_OTHER; break; }
+            if (hipMemcpy((char *)d_tmp + off, h_pin, want, hipMemcpyHostToDevice) != hipSuccess) { set_error("upload failed"); rc = QMX_ERR_OTHER; break; }
+        }
+        if (rc != QMX_OK) break;
+        qmx_segment_desc d = *desc;
+        d.n = n;
+        d.data = d_tmp;
+        d.row_stride_bytes = 0;
+        d.flags = desc->flags & ~QMX_SEG_DATA_ON_DEVICE;          // copied (and re-packed to the 16-byte row pitch) into the segment's own block
+        rc = qmx_segment_create(&d, out);
+    } while (0);
+    fclose(f);
+    if (h_pin) (void)hipHostFree(h_pin);
+    if (d_tmp) (void)hipFree(d_tmp);
+    if (rc != QMX_OK || !deleted_path) return rc;
+    // the "drop" file: header, padding to align_of::<usize>() = 8, then the bit words
+    FILE *g = fopen(deleted_path, "rb");
+    std::vector<uint64_t> words;
+    if (!g) { set_error("cannot open %s", deleted_path); rc = QMX_ERR_BAD_ARG; }
+    else {
+        char magic[8];
+        const uint64_t n = (*out)->n;
+        words.resize((size_t)((n + 63) / 64));
+        if (fread(magic, 1, 8, g) != 8 || memcmp(magic, "drop", 4) != 0) { set_error("%s does not start with the deleted-flags header \"drop\"", deleted_path); rc = QMX_ERR_BAD_ARG; }
+        else if (!words.empty() && fread(words.data(), 8, words.size(), g) != words.size()) { set_error("%s is shorter than %llu flags", deleted_path, (unsigned long long)n); rc = QMX_ERR_BAD_ARG; }
+        fclose(g);
+        if (rc == QMX_OK) rc = qmx_segment_set_deleted(*out, nullptr, 0, words.data(), n);
+    }
+    if (rc != QMX_OK) {
+        qmx_segment_destroy(*out);
+        *out = nullptr;
+    }
+    return rc;
+}
+
 int32_t qmx_segment_create_chunked(const qmx_segment_desc *desc, const void *const *chunks, uint64_t rows_per_chunk, uint32_t n_chunks,
                                    qmx_segment **out) {
     QMX_REQUIRE(desc && out && (n_chunks == 0 || chunks), QMX_ERR_BAD_ARG, "NULL argument");

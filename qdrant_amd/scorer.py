@@ -9,6 +9,7 @@ happens in libqdrant_amd.so on the GPU; there is no CPU path.
 """
 import ctypes as C
 import enum
+import os
 from typing import Iterable, List, Optional, Sequence
 
 import numpy as np
@@ -83,6 +84,23 @@ class VectorStorage:
         F.check(F.lib().qmx_segment_create(C.byref(desc), C.byref(self._h)))
         if on_device is False:
             self._keep = None  # uploaded: the host copy may go away (ownership)
+
+    @classmethod
+    def from_files(cls, vectors_path: str, dim: int, distance: Distance, datatype: VectorStorageDatatype = VectorStorageDatatype.Float32,
+                   deleted_path: Optional[str] = None, device_id: int = 0, flags: int = 0):
+        """Open the reference's immutable dense vector file ("data" header + rows) and, optionally, its "drop" flags file
+        (dense/immutable_dense_vectors.rs:25-27, 90, 364-378) straight onto the device (`qmx_segment_create_from_files`)."""
+        self = cls.__new__(cls)
+        self._h, self._keep = C.c_void_p(), None
+        self.distance, self.datatype, self.dim = Distance(distance), VectorStorageDatatype(datatype), int(dim)
+        desc = F.SegmentDesc()
+        desc.dtype, desc.distance, desc.dim, desc.flags, desc.n, desc.device_id = int(datatype), int(distance), int(dim), flags, 0, device_id
+        F.check(F.lib().qmx_segment_create_from_files(C.byref(desc), os.fsencode(vectors_path),
+                                                     None if deleted_path is None else os.fsencode(deleted_path), C.byref(self._h)))
+        rb = C.c_uint64()
+        F.check(F.lib().qmx_segment_row_bytes(self._h, C.byref(rb)))
+        self.count = (os.path.getsize(vectors_path) - 4) // rb.value
+        return self
 
     def total_vector_count(self) -> int:
         return self.count

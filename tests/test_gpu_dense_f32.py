@@ -259,3 +259,50 @@ def test_chunked_storage_ingest_equals_contiguous(qa):
         assert np.array_equal(g["score"].view(np.uint32), w["score"].view(np.uint32))
     bad = F.lib().qmx_segment_create_chunked(C.byref(d), ptrs, 200, len(chunks), C.byref(C.c_void_p()))   # 4 x 200 < 1000 rows
     assert bad == F.ERR_BAD_ARG
+
+
+def test_open_the_reference_storage_files(qa, tmp_path):
+    """qmx_segment_create_from_files: the immutable dense vector file ("data" + rows) and the "drop" flags file
+    (dense/immutable_dense_vectors.rs:25-27, 90, 364-378), and a flat quantized storage file (quantized_storage.rs:25-70)."""
+    rng = np.random.default_rng(12)
+    n, dim = 1237, 100                                           # 400-byte rows: re-packed to the 16-byte pitch on the way in
+    rows = O.preprocess(O.COSINE, rng.standard_normal((n, dim)).astype(np.float32))
+    deleted = rng.random(n) < 0.25
+    vec_file, del_file = tmp_path / "matrix.dat", tmp_path / "deleted.dat"
+    vec_file.write_bytes(b"data" + rows.tobytes())
+    words = np.packbits(np.concatenate([deleted, np.zeros((-n) % 64, dtype=bool)]).reshape(-1, 8), axis=1, bitorder="little").tobytes()
+    del_file.write_bytes(b"drop" + b"\0" * 4 + words)
+    st = qa.VectorStorage.from_files(str(vec_file), dim, qa.Distance.Cosine, deleted_path=str(del_file))
+    assert st.total_vector_count() == n
+    assert np.array_equal(st.get_dense([0, 5, n - 1]), rows[[0, 5, n - 1]])
+    queries = rng.standard_normal((5, dim)).astype(np.float32)
+    got = qa.BatchFilteredSearcher(queries, st, 10).peek_top_all()
+    want = O.DenseStorage(O.F32, O.COSINE, rows, vec_deleted=deleted).peek_top(queries, 10)
+    for g, w in zip(got, want):
+        assert np.array_equal(g["score"].view(np.uint32), w["score"].view(np.uint32)) and g["idx"].tolist() == w["idx"].tolist()
+    # wrong magic / short deleted file
+    bad = tmp_path / "bad.dat"
+    bad.write_bytes(b"dat0" + rows.tobytes())
+    with pytest.raises(qa.QmxError):
+        qa.VectorStorage.from_files(str(bad), dim, qa.Distance.Cosine)
+    short = tmp_path / "short.dat"
+    short.write_bytes(b"drop" + b"\0" * 4 + words[:8])
+    with pytest.raises(qa.QmxError):
+        qa.VectorStorage.from_files(str(vec_file), dim, qa.Distance.Cosine, deleted_path=str(short))
+    # a flat SQ storage file: [f32 offset][codes] rows, no header
+    import ctypes as C
+    from qdrant_amd import _ffi as F
+    quant = qa.ScalarQuantizer.from_min_max(rows, dim, qa.Distance.Dot)
+    sq_rows = quant.encode(rows)
+    qfile = tmp_path / "quantized.data"
+    qfile.write_bytes(sq_rows.tobytes())
+    p = quant.params()
+    d = F.SegmentDesc()
+    d.dtype, d.distance, d.dim, d.n, d.device_id, d.sq = F.DTYPE_SQ_U8, int(qa.Distance.Dot), dim, 0, 0, C.pointer(p)
+    h = C.c_void_p()
+    F.check(F.lib().qmx_segment_create_from_files(C.byref(d), str(qfile).encode(), None, C.byref(h)))
+    back = np.empty((3, quant.quantized_vector_size()), dtype=np.uint8)
+    ids = np.array([0, 7, n - 1], dtype=np.uint32)
+    F.check(F.lib().qmx_segment_read_rows(h, F.ptr(ids), 3, F.ptr(back)))
+    assert np.array_equal(back, sq_rows[ids])
+    F.check(F.lib().qmx_segment_destroy(h))
