@@ -1070,16 +1070,32 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
             // a wave-serial event the other waves of the block wait for at the next barrier).  A pre-scan of the first 1 / 1024 of the
             // block gives every list the k-th best score of that prefix as a starting threshold: a lower bound of the final k-th
             // best score, so nothing that belongs to the result is rejected (ties pass), and only ~1024 k rows per query beat it.
+            // (Running the pre-scan as a top-k pass of the chain-major kernel itself was insertion-bound: 0.2 ms instead of 0.06.)
             if (pass == 0 && n_cand >= (1u << 18) && s->dtype == QMX_DTYPE_F32 && mfma_scan_ok(s) && mfma16_scan_ok(qt, SCAN_TOPK, a) &&
                 getenv("QMX_NO_PRESCAN") == nullptr) {
-                ScanArgs pre = a;
-                pre.flags |= M16_FLAG_PRESCAN;
                 static const int pre_shift = getenv("QMX_PRESCAN_SHIFT") ? atoi(getenv("QMX_PRESCAN_SHIFT")) : 10;   // tuning: measured 5..10 on C2, the main pass does not care, the pre-scan itself gets cheaper
-                pre.n_cand = std::max<uint64_t>(n_cand >> pre_shift, 1u << 13) & ~(uint64_t)15;
-                uint32_t pgrid = grid_cap;
-                QMX_TRY(launch_scan(q, qt, SCAN_TOPK, pre, &pgrid));
-                QMX_TRY(launch_merge_keys(q->stream, (const uint64_t *)q->partial.p, pgrid, (uint32_t)qt, nq_tile, ptop,
-                                          d_out + (size_t)tile0 * top, d_counts + tile0, top, 0, (uint64_t *)q->gthr.p));
+                const uint64_t pre_n = std::max<uint64_t>(n_cand >> pre_shift, 1u << 13) & ~(uint64_t)15;
+                {
+                    // score matrix of the prefix (the score-mode kernels, <= tile_qt queries per launch), one block per query selects its
+                    // k best live candidates, the k-th becomes the bound
+                    QMX_TRY(q->scores.reserve((size_t)nq_tile * pre_n * sizeof(float)));
+                    const uint32_t SQT = tile_qt(s);
+                    for (uint32_t st0 = 0; st0 < nq_tile; st0 += SQT) {
+                        const uint32_t nq_sub = std::min<uint32_t>(SQT, nq_tile - st0);
+                        ScanArgs pre;
+                        fill_args(q, tile0 + st0, nq_sub, pre);
+                        pre.ids = d_ids;
+                        pre.n_cand = pre_n;
+                        pre.top = 1;
+                        pre.scores = (float *)q->scores.p + (size_t)st0 * pre_n;
+                        pre.scores_stride = pre_n;
+                        uint32_t pgrid = 0;
+                        QMX_TRY(launch_scan(q, (int)pow2_ceil(nq_sub), SCAN_SCORES, pre, &pgrid));
+                    }
+                    QMX_TRY(launch_custom_topk(q->stream, (const float *)q->scores.p, pre_n, d_ids, a.del, nq_tile, ptop, d_out + (size_t)tile0 * top,
+                                               d_counts + tile0));
+                    QMX_TRY(launch_bound_from_topk(q->stream, d_out + (size_t)tile0 * top, d_counts + tile0, nq_tile, ptop, (uint64_t *)q->gthr.p));
+                }
                 a.gthr = (const uint64_t *)q->gthr.p;
                 if (counters) counters->kernel_launches += 2;
             }

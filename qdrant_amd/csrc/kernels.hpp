@@ -168,7 +168,6 @@ int32_t launch_sq_internal_query(hipStream_t st, const void *codes, const float 
                                  uint32_t nq, uint64_t n_rows, float shift, void *tile, uint32_t q_stride, uint32_t aux_off,
                                  int *err_flag);
 // f32 dot / cosine, 32- and 64-query tiles on v_mfma_f32_16x16x4_f32, chain-major (scan_mfma16.hip)
-constexpr uint32_t M16_FLAG_PRESCAN = 0x200u;   // ScanArgs::flags: this launch is the threshold pre-scan (runs under its own kernel name)
 bool mfma16_scan_ok(int qt, ScanMode mode, const ScanArgs &a);   // qt = 32 or 64
 int32_t launch_scan_f32_mfma16(hipStream_t st, int qt, const ScanArgs &a, int num_cus, uint32_t *grid_out);
 // order statistics of a float array (quantile.hip): the SQ quantile interval
@@ -211,6 +210,8 @@ int32_t launch_sort_scored(hipStream_t st, const float *scores, const uint32_t *
 // custom queries (custom_query.hip): combine the per-example similarity matrix, top-k of a score row
 int32_t launch_custom_combine(hipStream_t st, const qmx_custom_query *d_queries, uint32_t n_queries, const float *d_sims, uint64_t n,
                               const float *d_coefs, float *d_out);
+// bound[q] = key of the k-th entry of a full top-k list out[q * k ..] (0 when the list is short): the pre-scan's reject bound
+int32_t launch_bound_from_topk(hipStream_t st, const qmx_scored_point *d_out, const uint32_t *d_counts, uint32_t nq, uint32_t k, uint64_t *d_bound);
 int32_t launch_custom_topk(hipStream_t st, const float *d_scores, uint64_t n, const uint32_t *d_ids, const DeletedView &del, uint32_t n_queries,
                            uint32_t top, qmx_scored_point *d_out, uint32_t *d_counts);
 

@@ -90,7 +90,6 @@ struct M16Shape {
 
 template <int KS /* dim / 256 */, int NW, int NT, int DBG = 0 /* tuning experiments (QMX_M16_DBG): 2 no row loads, 3 no fold / selection */,
           bool LAG = (NW == 8 && NT == 4 && KS == 3) /* half of the waves run one stage behind the others, see `lag` */,
-          bool PRE = false /* the threshold pre-scan of api.hip: same code under its own name, so that profiles keep the two apart */,
           bool IDS = false /* candidates = a.ids[0 .. n_cand) instead of rows 0 .. n_cand) (payload-filtered scans, peek_top_iter) */>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kernel(const ScanArgs a) {
     typedef M16Shape<NW, NT> S;
@@ -389,20 +388,17 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
     }
 }
 
-template <int KS, int NW, int NT, int DBG = 0, bool LAG = (NW == 8 && NT == 4 && KS == 3), bool PRE = false, bool IDS = false>
+template <int KS, int NW, int NT, int DBG = 0, bool LAG = (NW == 8 && NT == 4 && KS == 3), bool IDS = false>
 static int32_t launch_m16(hipStream_t st, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
-    if constexpr (!PRE && !IDS && DBG == 0) {
-        if ((a.flags & M16_FLAG_PRESCAN) && !a.ids) return launch_m16<KS, NW, NT, 0, LAG, true>(st, a, num_cus, grid_out);
-    }
-    if constexpr (!PRE && !IDS && DBG == 0 && LAG == (NW == 8 && NT == 4 && KS == 3)) {
+    if constexpr (!IDS && DBG == 0 && LAG == (NW == 8 && NT == 4 && KS == 3)) {
         if (a.ids) {
             // (KS = 3 with 4 waves x 2 query tiles has no register left for the id plumbing: the 8-wave 32-query shape takes it)
-            if constexpr (KS == 3 && NW == 4 && NT == 2) return launch_m16<KS, 8, 2, 0, false, false, true>(st, a, num_cus, grid_out);
-            else return launch_m16<KS, NW, NT, 0, LAG, false, true>(st, a, num_cus, grid_out);
+            if constexpr (KS == 3 && NW == 4 && NT == 2) return launch_m16<KS, 8, 2, 0, false, true>(st, a, num_cus, grid_out);
+            else return launch_m16<KS, NW, NT, 0, LAG, true>(st, a, num_cus, grid_out);
         }
     }
     typedef M16Shape<NW, NT> S;
-    auto kfn = scan_f32_mfma16_kernel<KS, NW, NT, DBG, LAG, PRE, IDS>;
+    auto kfn = scan_f32_mfma16_kernel<KS, NW, NT, DBG, LAG, IDS>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
