@@ -1071,8 +1071,10 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
             // block gives every list the k-th best score of that prefix as a starting threshold: a lower bound of the final k-th
             // best score, so nothing that belongs to the result is rejected (ties pass), and only ~1024 k rows per query beat it.
             // (Running the pre-scan as a top-k pass of the chain-major kernel itself was insertion-bound: 0.2 ms instead of 0.06.)
-            if (pass == 0 && n_cand >= (1u << 18) && s->dtype == QMX_DTYPE_F32 && mfma_scan_ok(s) && mfma16_scan_ok(qt, SCAN_TOPK, a) &&
-                getenv("QMX_NO_PRESCAN") == nullptr) {
+            const bool m16 = s->dtype == QMX_DTYPE_F32 && mfma_scan_ok(s) && mfma16_scan_ok(qt, SCAN_TOPK, a);
+            const bool sqm = (s->dtype == QMX_DTYPE_SQ_U8 || s->dtype == QMX_DTYPE_F16) && qt >= 8 && mfma_scan_ok(s);   // scan_sq_mfma.hip starts from the bound too
+            const bool m4 = s->dtype == QMX_DTYPE_F32 && qt >= 8 && mfma_scan_ok(s);                                        // scan_mfma.hip (4x4x1) as well
+            if (pass == 0 && n_cand >= (1u << 18) && (m16 || sqm || m4) && getenv("QMX_NO_PRESCAN") == nullptr) {
                 static const int pre_shift = getenv("QMX_PRESCAN_SHIFT") ? atoi(getenv("QMX_PRESCAN_SHIFT")) : 10;   // tuning: measured 5..10 on C2, the main pass does not care, the pre-scan itself gets cheaper
                 const uint64_t pre_n = std::max<uint64_t>(n_cand >> pre_shift, 1u << 13) & ~(uint64_t)15;
                 {

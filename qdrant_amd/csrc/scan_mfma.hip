@@ -97,11 +97,14 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_f32_mfma_kernel(const ScanAr
     int my_q[NGH];        // ... which are (wave-local index) 4 (gp + u0 NGH) + x
 #pragma unroll
     for (int q = 0; q < QW; ++q) list[q] = 0;
+    uint64_t gk[NGH];     // score part of the pre-scan's bound of the lane's queries (api.hip search_enqueue; 0 = none): equal scores pass
 #pragma unroll
     for (int gp = 0; gp < NGH; ++gp) {
-        thr[gp] = 0;
-        thr_f[gp] = -__builtin_inff();
         my_q[gp] = GQ * (gp + u0 * NGH) + qofs;
+        const uint32_t gq = (uint32_t)qs * QW + (uint32_t)my_q[gp];
+        gk[gp] = (MODE == SCAN_TOPK && a.gthr && gq < a.nq) ? (a.gthr[gq] & 0xFFFFFFFF00000000ull) : 0ull;
+        thr[gp] = gk[gp];
+        thr_f[gp] = gk[gp] ? key_score(gk[gp]) : -__builtin_inff();
     }
 
     const uint32_t gw = blockIdx.x * NSTREAM + stream;
@@ -284,9 +287,9 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_f32_mfma_kernel(const ScanAr
                                     const uint64_t nt = readlane_u64(list[qq], top - 1);
 #pragma unroll
                                     for (int gg = 0; gg < NGH; ++gg)
-                                        if (my_q[gg] == qq) {
+                                        if (my_q[gg] == qq && nt > gk[gg]) {
                                             thr[gg] = nt;
-                                            thr_f[gg] = nt ? key_score(nt) : -__builtin_inff();
+                                            thr_f[gg] = key_score(nt);
                                         }
                                 }
                             }

@@ -88,11 +88,16 @@ __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs 
     const int top = (int)a.top;
 
     uint64_t list[QW];
-    uint64_t thr[NG];              // k-th best key of query 16 g + n
+    uint64_t thr[NG];              // reject bound of query 16 g + n: the k-th best key of the wave's list, never below ...
+    uint64_t gk[NG];               // ... the score part of the pre-scan's bound (api.hip search_enqueue; 0 = none): equal scores pass
 #pragma unroll
     for (int q = 0; q < QW; ++q) list[q] = 0;
 #pragma unroll
-    for (int g = 0; g < NG; ++g) thr[g] = 0;
+    for (int g = 0; g < NG; ++g) {
+        const uint32_t q = (uint32_t)(16 * g + n);
+        gk[g] = (MODE == SCAN_TOPK && a.gthr && q < a.nq) ? (a.gthr[q] & 0xFFFFFFFF00000000ull) : 0ull;
+        thr[g] = gk[g];
+    }
 
     const uint32_t gw = blockIdx.x * SQM_NW + wave;
     const uint32_t tw = gridDim.x * SQM_NW;
@@ -188,7 +193,7 @@ __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs 
                                     if (nk > readlane_u64(list[qq], top - 1)) {
                                         wave_list_insert(list[qq], nk, lane);
                                         const uint64_t nt = readlane_u64(list[qq], top - 1);
-                                        if (n == qq - 16 * g) thr[g] = nt;
+                                        if (n == qq - 16 * g) thr[g] = nt > gk[g] ? nt : gk[g];
                                     }
                                 }
                             }
