@@ -959,7 +959,8 @@ static int32_t launch_scan(const qmx_query *q, int qt, ScanMode mode, const Scan
         return launch_scan_dense(q->stream, (int)s->dtype, (int)s->distance, qt, mode, a, s->num_cus, grid);
     }
     if (s->dtype == QMX_DTYPE_SQ_U8) {
-        if (qt >= 8 && mfma_scan_ok(s)) return launch_scan_sq_mfma(q->stream, qt, mode, a, s->num_cus, grid);
+        // (4 queries already pay for the padded 16-query matrix-core pass: 1.28 ms against 1.64 ms on the VALU kernel, 10 M x 768)
+        if (qt >= 4 && mfma_scan_ok(s)) return launch_scan_sq_mfma(q->stream, std::max(qt, 8), mode, a, s->num_cus, grid);
         return launch_scan_sq(q->stream, (int)s->distance, std::min(qt, (int)MAX_QT), mode, a, s->num_cus, grid);
     }
     if (s->dtype == QMX_DTYPE_PQ) return launch_scan_pq(q->stream, mode, a, s->num_cus, grid);
@@ -1072,7 +1073,7 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
             // best score, so nothing that belongs to the result is rejected (ties pass), and only ~1024 k rows per query beat it.
             // (Running the pre-scan as a top-k pass of the chain-major kernel itself was insertion-bound: 0.2 ms instead of 0.06.)
             const bool m16 = s->dtype == QMX_DTYPE_F32 && mfma_scan_ok(s) && mfma16_scan_ok(qt, SCAN_TOPK, a);
-            const bool sqm = (s->dtype == QMX_DTYPE_SQ_U8 || s->dtype == QMX_DTYPE_F16) && qt >= 8 && mfma_scan_ok(s);   // scan_sq_mfma.hip starts from the bound too
+            const bool sqm = (s->dtype == QMX_DTYPE_SQ_U8 ? qt >= 4 : s->dtype == QMX_DTYPE_F16 && qt >= 8) && mfma_scan_ok(s);   // scan_sq_mfma.hip starts from the bound too
             const bool m4 = s->dtype == QMX_DTYPE_F32 && qt >= 8 && mfma_scan_ok(s);                                        // scan_mfma.hip (4x4x1) as well
             if (pass == 0 && n_cand >= (1u << 18) && (m16 || sqm || m4) && getenv("QMX_NO_PRESCAN") == nullptr) {
                 static const int pre_shift = getenv("QMX_PRESCAN_SHIFT") ? atoi(getenv("QMX_PRESCAN_SHIFT")) : 10;   // tuning: measured 5..10 on C2, the main pass does not care, the pre-scan itself gets cheaper
