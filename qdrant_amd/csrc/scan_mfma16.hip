@@ -28,7 +28,8 @@
 // c + 32 (4 step + k) of row m.  Every byte of the block is read from HBM once and from LDS once.
 //
 // Restrictions (anything else takes the scan_mfma.hip path): top-k mode (whole block or a candidate id list), dim a multiple of
-// 256 up to 1536 (64-query passes: up to 768), 16-byte aligned rows.
+// 128 up to 1536 (64-query passes: up to 768), 16-byte aligned rows.  Rows of an even number of 512-byte K-steps stream in
+// 1 KiB chunks (two K-steps per ring stage), the others (384, 640, ...) in 512-byte chunks, two rows per load.
 #include "scan_common.hpp"
 
 namespace qmx {
@@ -46,6 +47,12 @@ __device__ __forceinline__ void glds16(const unsigned char *row, uint32_t lane_o
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(lane_off), "s"(row), "s"(lds_dst) : "memory");
+}
+// the same with a per-lane source address
+__device__ __forceinline__ void glds16v(const unsigned char *src, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
 }
 __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
@@ -73,27 +80,32 @@ __device__ __forceinline__ bool live_uniform(const DeletedView &d, uint32_t id) 
     return !vdel && !pdel && ok;
 }
 
-template <int NW, int NT>
+template <int NW, int NT, int KPS /* 512-byte K-steps of a row per ring stage: 2, or 1 when the row has an odd number of them */>
 struct M16Shape {
     static constexpr int QT = 16 * NT;
     static constexpr int JW = 8 / NW;                  // SIMD lanes j per wave (2: j = w, w + 4;  1: j = w)
     static constexpr int CW = 4 * JW;                  // chains per wave: ci = r * JW + jj  ->  chain 8 r + w + 4 jj
     static constexpr int RPW = 16 / NW;                // rows of a stage fetched per wave
-    static constexpr int NBUF = NW == 4 ? 4 : 7;       // ring stages (4 waves: two blocks share the CU's 160 KiB)
+    static constexpr int STAGE = KPS == 2 ? M16_STAGE : M16_STAGE / 2;   // 16 rows x 1 KiB (pitch 1040) or 8 row pairs x (2 x 512 B) (pitch 1040)
+    static constexpr int NBUF = (NW == 4 ? 4 : 7) * (KPS == 2 ? 1 : 2);   // ring stages (4 waves: two blocks share the CU's 160 KiB)
     static constexpr int XCH = NW * NT * 4 * 64 * 4;   // fold exchange: [wave][query tile][reg][lane] f32
     static constexpr int IDR = 16 * 16 * 4;            // candidate ids of the last 16 tiles [tile iteration & 15][row] (id-list scans)
-    static constexpr int LDS = NBUF * M16_STAGE + XCH + IDR;
-    static constexpr int VPS = RPW;                    // vector-memory instructions per stage and wave
+    static constexpr int LDS = NBUF * STAGE + XCH + IDR;
+    static constexpr int VPS = KPS == 2 ? RPW : RPW / 2;   // vector-memory instructions per stage and wave (a 1 KiB load holds one row chunk or two half chunks)
     static constexpr int PW = NT * 4 / NW;             // accumulator planes (query tile, register) a wave finishes per tile
     static_assert(PW == 1 || PW == 2, "the NT * 4 planes of a tile are split evenly over the waves");
 };
 
-template <int KS /* dim / 256 */, int NW, int NT, int DBG = 0 /* tuning experiments (QMX_M16_DBG): 2 no row loads, 3 no fold / selection */,
-          bool LAG = (NW == 8 && NT == 4 && KS == 3) /* half of the waves run one stage behind the others, see `lag` */,
+template <int KSTEPS /* dim / 128: 512-byte K-steps per row */, int NW, int NT, int DBG = 0 /* tuning experiments (QMX_M16_DBG): 2 no row loads, 3 no fold / selection */,
+          bool LAG = (NW == 8 && NT == 4 && KSTEPS == 6) /* half of the waves run one stage behind the others, see `lag` */,
           bool IDS = false /* candidates = a.ids[0 .. n_cand) instead of rows 0 .. n_cand) (payload-filtered scans, peek_top_iter) */>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kernel(const ScanArgs a) {
-    typedef M16Shape<NW, NT> S;
+    constexpr int KPS = KSTEPS % 2 == 0 ? 2 : 1;      // K-steps per ring stage
+    constexpr int KS = KSTEPS / KPS;                  // stages per 16-row tile
+    typedef M16Shape<NW, NT, KPS> S;
     constexpr int QT = S::QT, JW = S::JW, CW = S::CW, RPW = S::RPW, NBUF = S::NBUF, PW = S::PW;
+    constexpr int M16_STAGE_B = S::STAGE;
+    static_assert(!LAG || KPS == 2, "the lagging-wave schedule is written for two-step stages");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -114,14 +126,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
     auto chain_rel = [](int ci) { return 8 * (ci / JW) + 4 * (ci % JW); };     // chain(ci) - w
 
     // ---- this wave's slice of the queries, in B-operand layout: bq[ci][s][t] = query 16 t + n, element chain(ci) + 32 (4 s + kk)
-    float bq[CW][KS * 2][NT];
+    float bq[CW][KSTEPS][NT];
     {
         const float *qf = reinterpret_cast<const float *>(a.queries);
         const uint32_t qs = a.q_stride / 4;
 #pragma unroll
         for (int ci = 0; ci < CW; ++ci)
 #pragma unroll
-            for (int s = 0; s < KS * 2; ++s)
+            for (int s = 0; s < KSTEPS; ++s)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
                     bq[ci][s][t] = qf[(uint32_t)(16 * t + n) * qs + (uint32_t)(chain_rel(ci) + w) + 32u * (uint32_t)(4 * s + kk)];
@@ -139,7 +151,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
 #pragma unroll
     for (int ci = 0; ci < CW; ++ci)
 #pragma unroll
-        for (int s = 0; s < KS * 2; ++s)
+        for (int s = 0; s < KSTEPS; ++s)
 #pragma unroll
             for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(bq[ci][s][t]));
     asm volatile("" : "+v"(kb));
@@ -160,7 +172,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
     // fetches rows RPW w .. RPW w + RPW - 1 of the tile.  Stages past the end re-read row 0 (never consumed): the in-flight count
     // stays constant and the loop needs no tail.  All of it is scalar work: row bases are wave-uniform.
     const uint32_t lane_off = (uint32_t)lane * 16u;
-    uint32_t *idring = reinterpret_cast<uint32_t *>(smem + NBUF * M16_STAGE + S::XCH);
+    uint32_t *idring = reinterpret_cast<uint32_t *>(smem + NBUF * M16_STAGE_B + S::XCH);
     uint64_t ld_it = 0;            // tile iteration of the next stage to issue
     uint32_t ld_kc = 0;            // ... and its chunk
     uint32_t ld_slot = 0;
@@ -180,8 +192,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
             ld_row[i] = reinterpret_cast<const unsigned char *>(uniform_u64((uint64_t)(rows + c * a.row_stride)));
         }
     };
-    auto issue_row = [&](int i) {                          // row RPW w + i of the stage being issued
-        if (DBG != 2) glds16(ld_row[i] + ld_kc * 1024u, lane_off, lds0 + ld_slot * M16_STAGE + (uint32_t)(RPW * w + i) * M16_ROWP);
+    // one 1 KiB load of the stage being issued: KPS == 2: the chunk of row RPW w + i; KPS == 1: the 512-byte chunks of the row pair
+    // (RPW w + 2 i, + 1), lanes 0..31 / 32..63, landing side by side (pitch 1040 per pair keeps the 4-way bank pattern of the b32 reads)
+    auto issue_row = [&](int i) {
+        if (DBG == 2) return;
+        if (KPS == 2) {
+            glds16(ld_row[i] + ld_kc * 1024u, lane_off, lds0 + ld_slot * M16_STAGE_B + (uint32_t)(RPW * w + i) * M16_ROWP);
+        } else {
+            const unsigned char *src = (lane < 32 ? ld_row[(2 * i) % RPW] : ld_row[(2 * i + 1) % RPW]) + ld_kc * 512u + ((uint32_t)lane & 31u) * 16u;
+            glds16v(src, lds0 + ld_slot * M16_STAGE_B + (uint32_t)(RPW / 2 * w + i) * M16_ROWP);
+        }
     };
     auto ld_advance = [&]() {                              // after the rows of a stage
         ld_slot = ld_slot + 1 == NBUF ? 0 : ld_slot + 1;
@@ -195,12 +215,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
     const int n_prologue = LAG ? NBUF - 1 + (lag ? 1 : 0) : NBUF;     // LAG: every wave has issued stage k + NBUF - 1 once it is past B_k
     for (int p = 0; p < n_prologue; ++p) {
 #pragma unroll
-        for (int i = 0; i < RPW; ++i) issue_row(i);
+        for (int i = 0; i < S::VPS; ++i) issue_row(i);
         ld_advance();
     }
 
-    const uint32_t a_off = (uint32_t)n * M16_ROWP + (uint32_t)kk * 128u + (uint32_t)w * 4u;   // lane part of the A-operand address
-    float *xch = reinterpret_cast<float *>(smem + NBUF * M16_STAGE);
+    // lane part of the A-operand address: row n of the stage, 128-byte segment kk of the K-step, column w
+    const uint32_t a_off = (KPS == 2 ? (uint32_t)n * M16_ROWP : (uint32_t)(n >> 1) * M16_ROWP + (uint32_t)(n & 1) * 512u) + (uint32_t)kk * 128u + (uint32_t)w * 4u;
+    float *xch = reinterpret_cast<float *>(smem + NBUF * M16_STAGE_B);
     // A operand of (chain index ci, K-step ks) of a stage: element chain(ci) + 32 (4 ks + kk) of the 256-float chunk of row n
     auto lds_a = [&](const unsigned char *stage_base, int ks, int ci) -> float {
         return *reinterpret_cast<const float *>(stage_base + chain_rel(ci) * 4 + ks * 512);
@@ -279,51 +300,85 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[ci][t] = (f32x4){0.f, 0.f, 0.f, 0.f};   // _mm256_setzero_ps
 
+        if constexpr (KPS == 1) {
+            // One K-step per stage (rows of an odd number of 512-byte K-steps): barrier first - it says the next stage has landed and
+            // that every wave holds the current one in registers - then the refill of the current stage's slot and the LDS reads of the
+            // next stage's operands go between the MFMAs of the current one.
 #pragma unroll
-        for (int kc = 0; kc < KS; ++kc) {
-            const unsigned char *cur = smem + slot * M16_STAGE + a_off;
-            slot = slot + 1 == NBUF ? 0 : slot + 1;
-            const unsigned char *nxt = smem + slot * M16_STAGE + a_off;
-            // K-step 0 (operands read during the previous stage); the K-step 1 operands of this stage arrive underneath
+            for (int kc = 0; kc < KS; ++kc) {
+                slot = slot + 1 == NBUF ? 0 : slot + 1;
+                const unsigned char *nxt = smem + slot * M16_STAGE_B + a_off;
+                if (DBG != 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(S::VPS * (NBUF - 2)) : "memory");
+                if (DBG != 4 && DBG != 6) __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
 #pragma unroll
-            for (int ci = 0; ci < CW; ++ci) {
+                for (int ci = 0; ci < CW; ++ci) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    acc[ci][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax0[ci], bq[ci][kc * 2][t], acc[ci][t], 0, 0, 0);
-                if (ci < CW / 2) {
-                    ax1[2 * ci] = lds_a(cur, 1, 2 * ci);
-                    ax1[2 * ci + 1] = lds_a(cur, 1, 2 * ci + 1);
+                    for (int t = 0; t < NT; ++t)
+                        acc[ci][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax0[ci], bq[ci][kc][t], acc[ci][t], 0, 0, 0);
+                    if (ci < S::VPS) issue_row(ci);
+                    if (ci == S::VPS - 1) ld_advance();
+                    if (ci >= CW / 2) {
+                        ax1[2 * (ci - CW / 2)] = lds_a(nxt, 0, 2 * (ci - CW / 2));
+                        ax1[2 * (ci - CW / 2) + 1] = lds_a(nxt, 0, 2 * (ci - CW / 2) + 1);
+                    }
+                    if (!(kc == KS - 1 && ci >= CW / 2)) __builtin_amdgcn_sched_barrier(0);
+                    if (DBG != 3 && ci >= CW / 2 && ci < CW / 2 + PW && it > 0 && kc == 0) {
+                        finalize(it - 1, ci - CW / 2);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
-                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ci = 0; ci < CW; ++ci) ax0[ci] = ax1[ci];
             }
-            // this wave's loads of the next stage have landed when at most the RPW (NBUF - 2) issued after them are outstanding; the
-            // barrier makes that true for every wave's rows and says every wave holds all of the current stage in registers
-            if (DBG != 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(S::VPS * (NBUF - 2 - (LAG ? 1 : 0))) : "memory");
-            if (DBG != 4 && DBG != 6) __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            // K-step 1; the refill of the slot just freed and the K-step 0 operands of the next stage go in between
+        } else {
 #pragma unroll
-            for (int ci = 0; ci < CW; ++ci) {
+            for (int kc = 0; kc < KS; ++kc) {
+                const unsigned char *cur = smem + slot * M16_STAGE_B + a_off;
+                slot = slot + 1 == NBUF ? 0 : slot + 1;
+                const unsigned char *nxt = smem + slot * M16_STAGE_B + a_off;
+                // K-step 0 (operands read during the previous stage); the K-step 1 operands of this stage arrive underneath
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    acc[ci][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax1[ci], bq[ci][kc * 2 + 1][t], acc[ci][t], 0, 0, 0);
-                if (ci < CW / 2) {
-                    // the refill: RPW rows over the first CW / 2 slots (RPW == CW / 2 in both shapes)
-                    if (ci < RPW) issue_row(ci);
-                    if (ci == CW / 2 - 1) ld_advance();
-                } else {
-                    ax0[2 * (ci - CW / 2)] = lds_a(nxt, 0, 2 * (ci - CW / 2));
-                    ax0[2 * (ci - CW / 2) + 1] = lds_a(nxt, 0, 2 * (ci - CW / 2) + 1);
-                }
-                // (the tail of the tile's last stage is left to the scheduler: it pulls the fold's adds up between the MFMAs)
-                if (!(kc == KS - 1 && ci >= CW / 2)) __builtin_amdgcn_sched_barrier(0);
-                // the fold values of the PREVIOUS tile sit in xch since before this stage's barrier: finish that tile here, under
-                // the matrix work of this one
-                if (DBG != 3 && ci >= CW / 2 && ci < CW / 2 + PW && it > 0 && ((kc == 0 && (!LAG || lag)) || (LAG && kc == 1 && !lag))) {
-                    finalize(it - 1, ci - CW / 2);
+                for (int ci = 0; ci < CW; ++ci) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[ci][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax0[ci], bq[ci][kc * 2][t], acc[ci][t], 0, 0, 0);
+                    if (ci < CW / 2) {
+                        ax1[2 * ci] = lds_a(cur, 1, 2 * ci);
+                        ax1[2 * ci + 1] = lds_a(cur, 1, 2 * ci + 1);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                // this wave's loads of the next stage have landed when at most the RPW (NBUF - 2) issued after them are outstanding; the
+                // barrier makes that true for every wave's rows and says every wave holds all of the current stage in registers
+                if (DBG != 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(S::VPS * (NBUF - 2 - (LAG ? 1 : 0))) : "memory");
+                if (DBG != 4 && DBG != 6) __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                // K-step 1; the refill of the slot just freed and the K-step 0 operands of the next stage go in between
+#pragma unroll
+                for (int ci = 0; ci < CW; ++ci) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[ci][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax1[ci], bq[ci][kc * 2 + 1][t], acc[ci][t], 0, 0, 0);
+                    if (ci < CW / 2) {
+                        // the refill: RPW rows over the first CW / 2 slots (RPW == CW / 2 in both shapes)
+                        if (ci < RPW) issue_row(ci);
+                        if (ci == CW / 2 - 1) ld_advance();
+                    } else {
+                        ax0[2 * (ci - CW / 2)] = lds_a(nxt, 0, 2 * (ci - CW / 2));
+                        ax0[2 * (ci - CW / 2) + 1] = lds_a(nxt, 0, 2 * (ci - CW / 2) + 1);
+                    }
+                    // (the tail of the tile's last stage is left to the scheduler: it pulls the fold's adds up between the MFMAs)
+                    if (!(kc == KS - 1 && ci >= CW / 2)) __builtin_amdgcn_sched_barrier(0);
+                    // the fold values of the PREVIOUS tile sit in xch since before this stage's barrier: finish that tile here, under
+                    // the matrix work of this one
+                    if (DBG != 3 && ci >= CW / 2 && ci < CW / 2 + PW && it > 0 && ((kc == 0 && (!LAG || lag)) || (LAG && kc == 1 && !lag))) {
+                        finalize(it - 1, ci - CW / 2);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
             }
+
         }
 
         // ---- fold: four_way_hsum (a + b) + (c + d) per SIMD lane [then hi128 + lo128]; AVX register r = ci / JW, jj = ci % JW.
@@ -388,17 +443,17 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kern
     }
 }
 
-template <int KS, int NW, int NT, int DBG = 0, bool LAG = (NW == 8 && NT == 4 && KS == 3), bool IDS = false>
+template <int KSTEPS, int NW, int NT, int DBG = 0, bool LAG = (NW == 8 && NT == 4 && KSTEPS == 6), bool IDS = false>
 static int32_t launch_m16(hipStream_t st, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
-    if constexpr (!IDS && DBG == 0 && LAG == (NW == 8 && NT == 4 && KS == 3)) {
+    if constexpr (!IDS && DBG == 0 && LAG == (NW == 8 && NT == 4 && KSTEPS == 6)) {
         if (a.ids) {
-            // (KS = 3 with 4 waves x 2 query tiles has no register left for the id plumbing: the 8-wave 32-query shape takes it)
-            if constexpr (KS == 3 && NW == 4 && NT == 2) return launch_m16<KS, 8, 2, 0, false, true>(st, a, num_cus, grid_out);
-            else return launch_m16<KS, NW, NT, 0, LAG, true>(st, a, num_cus, grid_out);
+            // (4 waves x 2 query tiles at 5 or 6 K-steps have no register left for the id plumbing: the 8-wave 32-query shape takes it)
+            if constexpr (KSTEPS >= 5 && NW == 4 && NT == 2) return launch_m16<KSTEPS, 8, 2, 0, false, true>(st, a, num_cus, grid_out);
+            else return launch_m16<KSTEPS, NW, NT, 0, LAG, true>(st, a, num_cus, grid_out);
         }
     }
-    typedef M16Shape<NW, NT> S;
-    auto kfn = scan_f32_mfma16_kernel<KS, NW, NT, DBG, LAG, IDS>;
+    typedef M16Shape<NW, NT, (KSTEPS % 2 == 0 ? 2 : 1)> S;
+    auto kfn = scan_f32_mfma16_kernel<KSTEPS, NW, NT, DBG, LAG, IDS>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -423,43 +478,43 @@ static int32_t launch_m16(hipStream_t st, const ScanArgs &a, int num_cus, uint32
     return QMX_OK;
 }
 
-// qt = 32 or 64
+// qt = 16, 32 or 64; rows of dim = 128 k floats: k <= 12 (k <= 6 for 64 queries: the query registers)
 bool mfma16_scan_ok(int qt, ScanMode mode, const ScanArgs &a) {
     if (getenv("QMX_NO_MFMA16") != nullptr) return false;
-    return (qt == 16 || qt == 32 || qt == 64) && mode == SCAN_TOPK && a.rem_pieces == 0 && a.tail_start == a.dim && a.nseg % 8 == 0 &&
-           a.nseg / 8 >= 1 && a.nseg / 8 <= (qt == 64 ? 3u : 6u) && a.row_stride % 16 == 0 && a.top <= 64;
+    return (qt == 16 || qt == 32 || qt == 64) && mode == SCAN_TOPK && a.rem_pieces == 0 && a.tail_start == a.dim && a.nseg % 4 == 0 &&
+           a.nseg / 4 >= 1 && a.nseg / 4 <= (qt == 64 ? 6u : 12u) && a.row_stride % 16 == 0 && a.top <= 64;
 }
 
-// top-k over the whole block; the caller checked mfma16_scan_ok
+template <int NW, int NT, int K0, int K1>
+static int32_t launch_m16_steps(hipStream_t st, int ksteps, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
+    if constexpr (K0 <= K1) {
+        if (ksteps == K0) return launch_m16<K0, NW, NT>(st, a, num_cus, grid_out);
+        return launch_m16_steps<NW, NT, K0 + 1, K1>(st, ksteps, a, num_cus, grid_out);
+    } else {
+        set_error("mfma16 scan: unsupported row length");
+        return QMX_ERR_BAD_ARG;
+    }
+}
+
+// top-k over the whole block or a candidate id list; the caller checked mfma16_scan_ok
 int32_t launch_scan_f32_mfma16(hipStream_t st, int qt, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
-    const int ks = (int)(a.nseg / 8);
-    if (qt == 16) {
-        if (ks == 1) return launch_m16<1, 4, 1>(st, a, num_cus, grid_out);
-        if (ks == 2) return launch_m16<2, 4, 1>(st, a, num_cus, grid_out);
-        if (ks == 3) return launch_m16<3, 4, 1>(st, a, num_cus, grid_out);
-        if (ks == 4) return launch_m16<4, 4, 1>(st, a, num_cus, grid_out);
-        if (ks == 5) return launch_m16<5, 4, 1>(st, a, num_cus, grid_out);
-        if (ks == 6) return launch_m16<6, 4, 1>(st, a, num_cus, grid_out);
-    } else if (qt == 32) {
-        if (ks == 1) return launch_m16<1, 4, 2>(st, a, num_cus, grid_out);
-        if (ks == 2) return launch_m16<2, 4, 2>(st, a, num_cus, grid_out);
-        if (ks == 3) return launch_m16<3, 4, 2>(st, a, num_cus, grid_out);
-        if (ks == 4) return launch_m16<4, 8, 2>(st, a, num_cus, grid_out);
-        if (ks == 5) return launch_m16<5, 8, 2>(st, a, num_cus, grid_out);
-        if (ks == 6) return launch_m16<6, 8, 2>(st, a, num_cus, grid_out);
-    } else if (qt == 64) {
-        if (ks == 1) return launch_m16<1, 8, 4>(st, a, num_cus, grid_out);
-        if (ks == 2) return launch_m16<2, 8, 4>(st, a, num_cus, grid_out);
-        if (ks == 3) {
+    const int ksteps = (int)(a.nseg / 4);
+    if (qt == 16) return launch_m16_steps<4, 1, 1, 12>(st, ksteps, a, num_cus, grid_out);
+    if (qt == 32) {
+        if (ksteps <= 6) return launch_m16_steps<4, 2, 1, 6>(st, ksteps, a, num_cus, grid_out);
+        return launch_m16_steps<8, 2, 7, 12>(st, ksteps, a, num_cus, grid_out);
+    }
+    if (qt == 64) {
+        if (ksteps == 6) {
             const char *dbg = getenv("QMX_M16_DBG");
-            if (dbg && dbg[0] == '2') return launch_m16<3, 8, 4, 2>(st, a, num_cus, grid_out);
-            if (dbg && dbg[0] == '3') return launch_m16<3, 8, 4, 3>(st, a, num_cus, grid_out);
-            if (dbg && dbg[0] == '4') return launch_m16<3, 8, 4, 4, false>(st, a, num_cus, grid_out);   // (wrong results) no stage wait, no stage barrier
-            if (dbg && dbg[0] == '6') return launch_m16<3, 8, 4, 6, false>(st, a, num_cus, grid_out);   // (wrong results) no stage barrier
-            if (dbg && dbg[0] == '7') return launch_m16<3, 8, 4, 3, false>(st, a, num_cus, grid_out);   // no fold / selection, lock-step
-            if (dbg && dbg[0] == '5') return launch_m16<3, 8, 4, 0, false>(st, a, num_cus, grid_out);   // lock-step waves
-            return launch_m16<3, 8, 4>(st, a, num_cus, grid_out);
+            if (dbg && dbg[0] == '2') return launch_m16<6, 8, 4, 2>(st, a, num_cus, grid_out);
+            if (dbg && dbg[0] == '3') return launch_m16<6, 8, 4, 3>(st, a, num_cus, grid_out);
+            if (dbg && dbg[0] == '4') return launch_m16<6, 8, 4, 4, false>(st, a, num_cus, grid_out);   // (wrong results) no stage wait, no stage barrier
+            if (dbg && dbg[0] == '6') return launch_m16<6, 8, 4, 6, false>(st, a, num_cus, grid_out);   // (wrong results) no stage barrier
+            if (dbg && dbg[0] == '7') return launch_m16<6, 8, 4, 3, false>(st, a, num_cus, grid_out);   // no fold / selection, lock-step
+            if (dbg && dbg[0] == '5') return launch_m16<6, 8, 4, 0, false>(st, a, num_cus, grid_out);   // lock-step waves
         }
+        return launch_m16_steps<8, 4, 1, 6>(st, ksteps, a, num_cus, grid_out);
     }
     set_error("mfma16 scan: unsupported shape");
     return QMX_ERR_BAD_ARG;

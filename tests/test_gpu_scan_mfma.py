@@ -94,7 +94,7 @@ def test_large_scan_property(qa):
 
 # ---- 32-query tiles on v_mfma_f32_16x16x4_f32, chain-major (scan_mfma16.hip) -----------------------------------------
 @pytest.mark.parametrize("dist", [O.DOT, O.COSINE])
-@pytest.mark.parametrize("dim", [256, 512, 768, 1024, 1280, 1536])
+@pytest.mark.parametrize("dim", [128, 256, 384, 512, 640, 768, 896, 1024, 1152, 1280, 1408, 1536])   # odd multiples of 128: one K-step per ring stage
 @pytest.mark.parametrize("nq", [9, 16, 17, 32, 45, 64, 100])     # 9..16: the 16-query shape; > 32 queries: 64-query tiles (45 -> one padded tile, 100 -> 64 + 36)
 def test_mfma16_every_score_bit_exact(qa, dist, dim, nq):
     """top = 1000 of 1003 rows returns (nearly) every score: the whole accumulate + fold order of the kernel is pinned against the
@@ -178,7 +178,7 @@ def test_mfma16_large_scan_equals_the_other_kernels(qa, nq):
         assert np.array_equal(g["score"].view(np.uint32), o["score"].view(np.uint32))
 
 
-@pytest.mark.parametrize("dim", [256, 768, 1536])
+@pytest.mark.parametrize("dim", [128, 256, 384, 640, 768, 1152, 1536])
 @pytest.mark.parametrize("nq,top", [(12, 10), (32, 64), (64, 1), (50, 100)])
 def test_mfma16_candidate_id_lists(qa, dim, nq, top):
     """peek_top_iter over a payload-filtered candidate list (point_scorer.rs:423-472): the chain-major kernel gathers the rows
@@ -212,7 +212,7 @@ def test_mfma16_candidate_id_lists(qa, dim, nq, top):
 def test_mfma16_tiny_blocks(qa, n, nq, top):
     """Fewer rows than one 16-row tile / fewer tiles than blocks, top larger than the block."""
     rng = np.random.default_rng(n * 100 + nq)
-    dim = 256
+    dim = 256 if n % 2 else 384
     rows = O.preprocess(O.DOT, rng.standard_normal((n, dim)).astype(np.float32))
     queries = rng.standard_normal((nq, dim)).astype(np.float32)
     st = qa.VectorStorage(rows, qa.Distance.Dot)
