@@ -292,7 +292,7 @@ def _roofline(n, dim, Q, kernel_ms, alg_bytes, achieved_gbps, launches):
 
 def _queries_per_pass(dim, Q):
     """api.hip search_enqueue: 64 per pass on the chain-major kernel (f32, dim 256 / 512 / 768, more than 32 queries), else 32."""
-    if dim % 128 == 0 and 768 < dim <= 1536:
+    if dim % 128 == 0 and 768 < dim <= 2048:
         return 32 if Q > 16 else 16
     return 64 if (Q > 32 and dim % 128 == 0 and dim <= 768) else 32
 
@@ -312,13 +312,13 @@ def _kernel_name(dim, Q):
     """The scan kernel a batch of Q queries runs (api.hip search_enqueue / launch_scan): <= 4 queries per pass stream through the
     VALU kernel, 8..16 through scan_mfma.hip (v_mfma_f32_4x4x1), 17.. through the chain-major scan_mfma16.hip (v_mfma_f32_16x16x4)
     when the rows are 256 / 512 / 768 floats."""
-    if dim % 128 == 0 and 768 < dim <= 1536 and Q > 16:
+    if dim % 128 == 0 and 768 < dim <= 2048 and Q > 16:
         return "scan_f32_mfma16_kernel<KSTEPS=%d,NW=8,NT=2> (v_mfma_f32_16x16x4_f32, 32 queries per pass)" % (dim // 128)
     m16 = dim % 128 == 0 and dim <= 768
     if Q > 32 and m16:
         return "scan_f32_mfma16_kernel<KSTEPS=%d,NW=8,NT=4> (v_mfma_f32_16x16x4_f32, 64 queries per pass)" % (dim // 128)
     qt = _pow2(min(Q, 32))
-    if qt == 16 and dim % 128 == 0 and dim <= 1536:
+    if qt == 16 and dim % 128 == 0 and dim <= 2048:
         return "scan_f32_mfma16_kernel<KSTEPS=%d,NW=4,NT=1> (v_mfma_f32_16x16x4_f32, 16 queries per pass)" % (dim // 128)
     if qt == 32 and m16:
         return "scan_f32_mfma16_kernel<KSTEPS=%d,NW=4,NT=2> (v_mfma_f32_16x16x4_f32, 32 queries per pass)" % (dim // 128)

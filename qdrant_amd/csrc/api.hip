@@ -1037,10 +1037,10 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
     // partial lists: one per block; bound the grid by what the buffer holds
     const uint32_t grid_cap = (uint32_t)s->num_cus * 8;
     // f32 dot / cosine rows of 256, 512 or 768 floats, whole block: 64 queries per pass (scan_mfma16.hip); everything else 32 / 16
-    const bool q64 = s->dtype == QMX_DTYPE_F32 && mfma_scan_ok(s) && q->nq > MAX_QT_MFMA && s->dim % 128 == 0 && s->dim <= 768 &&
+    const bool q64 = s->dtype == QMX_DTYPE_F32 && mfma_scan_ok(s) && q->nq > MAX_QT_MFMA && mfma16_dim_ok(64, s->dim) &&
                      getenv("QMX_NO_MFMA16") == nullptr && getenv("QMX_NO_MFMA16_Q64") == nullptr;
     // ... and rows of 1024 .. 1536 floats 32 per pass: that kernel keeps the queries in registers, not in an LDS tile (tile_qt's limit)
-    const bool q32 = s->dtype == QMX_DTYPE_F32 && mfma_scan_ok(s) && q->nq > MAX_QT && s->dim % 128 == 0 && s->dim > 768 && s->dim <= 1536 &&
+    const bool q32 = s->dtype == QMX_DTYPE_F32 && mfma_scan_ok(s) && q->nq > MAX_QT && s->dim > 768 && mfma16_dim_ok(32, s->dim) &&
                      getenv("QMX_NO_MFMA16") == nullptr;
     const uint32_t TQ = q64 ? MAX_QT_TOPK : q32 ? MAX_QT_MFMA : tile_qt(s);
     const uint32_t ptop_max = std::min<uint32_t>(top, MAX_TOP_FAST);

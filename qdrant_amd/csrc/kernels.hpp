@@ -168,7 +168,8 @@ int32_t launch_sq_internal_query(hipStream_t st, const void *codes, const float 
                                  uint32_t nq, uint64_t n_rows, float shift, void *tile, uint32_t q_stride, uint32_t aux_off,
                                  int *err_flag);
 // f32 dot / cosine, 32- and 64-query tiles on v_mfma_f32_16x16x4_f32, chain-major (scan_mfma16.hip)
-bool mfma16_scan_ok(int qt, ScanMode mode, const ScanArgs &a);   // qt = 32 or 64
+bool mfma16_dim_ok(int qt, uint32_t dim);
+bool mfma16_scan_ok(int qt, ScanMode mode, const ScanArgs &a);   // qt = 16, 32 or 64
 int32_t launch_scan_f32_mfma16(hipStream_t st, int qt, const ScanArgs &a, int num_cus, uint32_t *grid_out);
 // order statistics of a float array (quantile.hip): the SQ quantile interval
 int32_t launch_order_statistics_f32(hipStream_t st, const float *d_in, float *d_tmp, uint64_t n, uint64_t lo_pos, uint64_t hi_pos, float *h_out);

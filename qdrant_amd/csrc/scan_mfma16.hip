@@ -28,7 +28,7 @@
 // c + 32 (4 step + k) of row m.  Every byte of the block is read from HBM once and from LDS once.
 //
 // Restrictions (anything else takes the scan_mfma.hip path): top-k mode (whole block or a candidate id list), dim a multiple of
-// 128 up to 1536 (64-query passes: up to 768), 16-byte aligned rows.  Rows of an even number of 512-byte K-steps stream in
+// 128 up to 2048 (64-query passes: up to 768), 16-byte aligned rows.  Rows of an even number of 512-byte K-steps stream in
 // 1 KiB chunks (two K-steps per ring stage), the others (384, 640, ...) in 512-byte chunks, two rows per load.
 #include "scan_common.hpp"
 
@@ -478,17 +478,26 @@ static int32_t launch_m16(hipStream_t st, const ScanArgs &a, int num_cus, uint32
     return QMX_OK;
 }
 
-// qt = 16, 32 or 64; rows of dim = 128 k floats: k <= 12 (k <= 6 for 64 queries: the query registers)
+// qt = 16, 32 or 64; rows of dim = 128 k floats: k <= 12, 14 or 16 (k <= 6 for 64 queries: the query registers)
+// row lengths the kernel is built for: dim = 128 k floats, k <= 12, 14 or 16 (k <= 6 for 64 queries: the query registers)
+bool mfma16_dim_ok(int qt, uint32_t dim) {
+    if (getenv("QMX_NO_MFMA16") != nullptr || dim % 128 != 0) return false;
+    const uint32_t k = dim / 128;
+    return k >= 1 && k <= (qt == 64 ? 6u : 16u) && !(k > 12 && k % 2 == 1);
+}
+
 bool mfma16_scan_ok(int qt, ScanMode mode, const ScanArgs &a) {
     if (getenv("QMX_NO_MFMA16") != nullptr) return false;
-    return (qt == 16 || qt == 32 || qt == 64) && mode == SCAN_TOPK && a.rem_pieces == 0 && a.tail_start == a.dim && a.nseg % 4 == 0 &&
-           a.nseg / 4 >= 1 && a.nseg / 4 <= (qt == 64 ? 6u : 12u) && a.row_stride % 16 == 0 && a.top <= 64;
+    return (qt == 16 || qt == 32 || qt == 64) && mode == SCAN_TOPK && a.rem_pieces == 0 && a.tail_start == a.dim && mfma16_dim_ok(qt, a.dim) &&
+           a.row_stride % 16 == 0 && a.top <= 64;
 }
 
 template <int NW, int NT, int K0, int K1>
 static int32_t launch_m16_steps(hipStream_t st, int ksteps, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
     if constexpr (K0 <= K1) {
-        if (ksteps == K0) return launch_m16<K0, NW, NT>(st, a, num_cus, grid_out);
+        if constexpr (!(K0 > 12 && K0 % 2 == 1)) {      // (13 / 15 one-step stages: the stage loop no longer unrolls)
+            if (ksteps == K0) return launch_m16<K0, NW, NT>(st, a, num_cus, grid_out);
+        }
         return launch_m16_steps<NW, NT, K0 + 1, K1>(st, ksteps, a, num_cus, grid_out);
     } else {
         set_error("mfma16 scan: unsupported row length");
@@ -499,10 +508,10 @@ static int32_t launch_m16_steps(hipStream_t st, int ksteps, const ScanArgs &a, i
 // top-k over the whole block or a candidate id list; the caller checked mfma16_scan_ok
 int32_t launch_scan_f32_mfma16(hipStream_t st, int qt, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
     const int ksteps = (int)(a.nseg / 4);
-    if (qt == 16) return launch_m16_steps<4, 1, 1, 12>(st, ksteps, a, num_cus, grid_out);
+    if (qt == 16) return launch_m16_steps<4, 1, 1, 16>(st, ksteps, a, num_cus, grid_out);
     if (qt == 32) {
         if (ksteps <= 6) return launch_m16_steps<4, 2, 1, 6>(st, ksteps, a, num_cus, grid_out);
-        return launch_m16_steps<8, 2, 7, 12>(st, ksteps, a, num_cus, grid_out);
+        return launch_m16_steps<8, 2, 7, 16>(st, ksteps, a, num_cus, grid_out);
     }
     if (qt == 64) {
         if (ksteps == 6) {

@@ -94,7 +94,7 @@ def test_large_scan_property(qa):
 
 # ---- 32-query tiles on v_mfma_f32_16x16x4_f32, chain-major (scan_mfma16.hip) -----------------------------------------
 @pytest.mark.parametrize("dist", [O.DOT, O.COSINE])
-@pytest.mark.parametrize("dim", [128, 256, 384, 512, 640, 768, 896, 1024, 1152, 1280, 1408, 1536])   # odd multiples of 128: one K-step per ring stage
+@pytest.mark.parametrize("dim", [128, 256, 384, 512, 640, 768, 896, 1024, 1152, 1280, 1408, 1536, 1792, 1920, 2048])   # 1920 = 15 x 128 stays on the 4x4x1 kernel; odd multiples of 128: one K-step per ring stage
 @pytest.mark.parametrize("nq", [9, 16, 17, 32, 45, 64, 100])     # 9..16: the 16-query shape; > 32 queries: 64-query tiles (45 -> one padded tile, 100 -> 64 + 36)
 def test_mfma16_every_score_bit_exact(qa, dist, dim, nq):
     """top = 1000 of 1003 rows returns (nearly) every score: the whole accumulate + fold order of the kernel is pinned against the
