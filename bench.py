@@ -220,6 +220,12 @@ def hnsw_section(args, dev, dim, top, lib, F, qa, np, torch):
         cnt[i] = len(r)
     final = raw.rescore(ids, top, cnt)
     wall = time.perf_counter() - t0
+    # the same three steps as ONE call (qmx_search_quantized: oversampled walk -> rescoring -> top, candidates stay in HBM)
+    qa.search_quantized(scorer, raw, top, oversampling=2.0, rescore=True, graph=graph, hnsw_ef=ef)
+    t0 = time.perf_counter()
+    fused = qa.search_quantized(scorer, raw, top, oversampling=2.0, rescore=True, graph=graph, hnsw_ef=ef)
+    wall_fused = time.perf_counter() - t0
+    same = sum(int(np.array_equal(a, b)) for a, b in zip(fused, final))
     F.check(lib.qmx_query_timing(scorer._h, C.byref(ms), C.byref(nl)))
     exact = qa.BatchFilteredSearcher(queries[:256], vs, top).peek_top_all()
     recall = sum(len(set(a["idx"].tolist()) & set(b["idx"].tolist())) for a, b in zip(final[:256], exact)) / (256.0 * top)
@@ -229,6 +235,7 @@ def hnsw_section(args, dev, dim, top, lib, F, qa, np, torch):
             "build_s": round(t_build, 2), "build_points_per_s": round(n / t_build, 1),
             "search_qps_kernel": round(nq / (kernel_ms * 1e-3), 1), "search_kernel_ms": round(kernel_ms, 3),
             "search_qps_wall_incl_host_copies_and_rescoring": round(nq / wall, 1),
+            "search_qps_wall_one_call_walk_rescore_on_device": round(nq / wall_fused, 1), "one_call_lists_equal_three_step_lists": "%d/%d" % (same, nq),
             "points_scored_per_query": round(scored / nq, 1), "gather_GBps": round(scored * quant.quantized_vector_size() / (kernel_ms * 1e-3) / 1e9, 1),
             "recall_at_10_after_rescoring": round(recall, 4)}
 
