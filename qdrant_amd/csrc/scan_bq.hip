@@ -18,6 +18,7 @@
 namespace qmx {
 
 struct RowBQ {
+    static constexpr bool TEMPORAL_ROWS = true;   // 96 / 192-byte rows: most rows end inside a 128-byte line
     static constexpr int NACC = 1;
     static constexpr int NRAUX = 0;
     static constexpr int R16 = 2;

@@ -49,10 +49,15 @@ __device__ __forceinline__ void scan_step(typename P::acc_t (&acc)[QT][R][P::NAC
 }
 
 // a 16-byte piece of a stored row, streamed once: nontemporal, so the lines do not push the query tile / partial lists out of L2
-// (only when rows are whole 128-byte lines: a row that ends inside a line shares it with the next row's first load, which must
-// still find it in cache - measured on 192-byte BQ rows: 0.34 ms temporal, 0.49 ms nontemporal)
-__device__ __forceinline__ uint4 load_row_piece(const unsigned char *p, bool nt) {
-    if (!nt) return *reinterpret_cast<const uint4 *>(p);
+// (not for row types whose rows end inside a line as a rule - a policy says so with `static constexpr bool TEMPORAL_ROWS = true` -:
+// such a row shares its last line with the next row's first load, which must still find it in cache; measured on 192-byte BQ
+// rows: 0.34 ms temporal, 0.49 ms nontemporal.  The choice is per policy, not per launch: a run-time branch around the load kind
+// costs the f32 scan half its bandwidth.)
+template <class P, class = void> struct rows_temporal { static constexpr bool value = false; };
+template <class P> struct rows_temporal<P, decltype((void)P::TEMPORAL_ROWS)> { static constexpr bool value = P::TEMPORAL_ROWS; };
+template <bool NT>
+__device__ __forceinline__ uint4 load_row_piece(const unsigned char *p) {
+    if (!NT) return *reinterpret_cast<const uint4 *>(p);
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
     return make_uint4(v[0], v[1], v[2], v[3]);
@@ -90,7 +95,6 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_kernel(const ScanArgs a) {
     const uint32_t tw = gridDim.x * NW;
     constexpr uint32_t TILE = 8 * R;
     const uint64_t n_tiles = (a.n_cand + TILE - 1) / TILE;
-    const bool stream_nt = (a.row_stride & 127u) == 0;
     const uint32_t nseg = a.nseg;
     const bool piece_in_rem = piece < (int)a.rem_pieces;
 
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_kernel(const ScanArgs a) {
         for (uint32_t s = 0; s < nseg; ++s) {
             uint4 v[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) v[r] = load_row_piece(rp[r] + (uint64_t)s * 128, stream_nt);
+            for (int r = 0; r < R; ++r) v[r] = load_row_piece<!rows_temporal<P>::value>(rp[r] + (uint64_t)s * 128);
             scan_step<P, QT, R>(acc, raux, v, smem + s * 128 + piece_off, a.q_stride, true);
         }
         if (a.rem_pieces) {
