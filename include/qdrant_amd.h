@@ -449,7 +449,14 @@ QMX_API int32_t qmx_hnsw_destroy(qmx_hnsw *g);
 QMX_API int32_t qmx_hnsw_search(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
                                 qmx_scored_point *out, uint32_t *out_counts,
                                 const volatile uint8_t *is_stopped, qmx_counters *counters);
-/* Same, only enqueued on the query's stream; outputs in device memory.
+/* The same with `SearchAlgorithm::Acorn` (graph_layers.rs:154-243, 550-559; chosen by hnsw/read_view/search.rs:42-90 when the
+ * request enables it and the filter is selective enough): on level 0 a link that fails `check_vector` (deleted flags + the
+ * payload filter set with qmx_query_set_filter) is not scored but explored - its own links are offered as 2-hop neighbours -
+ * with the reference's two visited lists and per-node limits.  m0 <= 64. */
+QMX_API int32_t qmx_hnsw_search_acorn(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
+                                      qmx_scored_point *out, uint32_t *out_counts,
+                                      const volatile uint8_t *is_stopped, qmx_counters *counters);
+/* qmx_hnsw_search, only enqueued on the query's stream; outputs in device memory.
  * `out_scored_dev` ([nq] points scored per search) may be NULL. */
 QMX_API int32_t qmx_hnsw_search_async(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
                                       qmx_scored_point *out_dev, uint32_t *out_counts_dev,

@@ -293,6 +293,69 @@ static qo_topk *search_on_level(const qo_hnsw *g, qscore *q, qo_scored_point lev
     return nearest;
 }
 
+/* GraphLayersBase::search_on_level_acorn (graph_layers.rs:154-243): the ACORN-1 walk.  Links whose point fails the filters are not
+ * scored but EXPLORED: their own links (2 hops from the candidate) are offered too.  Two visited lists (hop1 / hop2), limits per
+ * explored node (hop1_limit = hop2_limit = get_m(level)), scoring through score_points_unfiltered (point_scorer.rs:282-295). */
+static qo_topk *search_on_level_acorn(const qo_hnsw *g, qscore *q, qo_scored_point level_entry, uint32_t level, uint32_t ef,
+                                      visited_t *hop1_vis, visited_t *hop2_vis) {
+    visited_next(hop1_vis);
+    visited_next(hop2_vis);
+    visited_check_update(hop1_vis, level_entry.idx);
+    qo_topk *nearest = qo_topk_new(ef);
+    maxheap cands = {0, 0, 0};
+    process_candidate(nearest, &cands, level_entry);
+    const uint32_t hop1_limit = level_m(g, level), hop2_limit = level_m(g, level);
+    const uint32_t max_links = g->m0 + g->m + 1;
+    uint32_t *links = (uint32_t *)malloc(sizeof(uint32_t) * max_links);
+    uint32_t *links2 = (uint32_t *)malloc(sizeof(uint32_t) * max_links);
+    uint32_t *to_explore = (uint32_t *)malloc(sizeof(uint32_t) * max_links);
+    const size_t score_cap = (size_t)max_links * (max_links + 1);
+    uint32_t *to_score = (uint32_t *)malloc(sizeof(uint32_t) * score_cap);
+    float *scores = (float *)malloc(sizeof(float) * score_cap);
+    qo_scored_point cand;
+    while (mh_pop(&cands, &cand)) {
+        qo_scored_point worst;
+        const float lower_bound = qo_topk_top(nearest, &worst) ? worst.score : -3.40282347e+38f;
+        if (cand.score < lower_bound) break;
+        uint32_t n_explore = 0, n_score = 0;
+        /* 1-hop neighbours :196-211 */
+        const uint32_t n = read_links(g, cand.idx, level, links, 0);
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t hop1 = links[i];
+            if (visited_check_update(hop1_vis, hop1)) continue;
+            if (qs_check(q, hop1)) {
+                to_score[n_score++] = hop1;
+                if (n_score >= hop1_limit) break;
+            } else {
+                to_explore[n_explore++] = hop1;
+            }
+        }
+        /* 2-hop neighbours :213-235 */
+        for (uint32_t e = 0; e < n_explore; e++) {
+            const uint32_t total_limit = n_score + hop2_limit;
+            const uint32_t n2 = read_links(g, to_explore[e], level, links2, 0);
+            for (uint32_t i = 0; i < n2; i++) {
+                const uint32_t hop2 = links2[i];
+                if (visited_check(hop1_vis, hop2) || visited_check_update(hop2_vis, hop2)) continue;
+                if (qs_check(q, hop2)) {
+                    visited_check_update(hop1_vis, hop2);
+                    to_score[n_score++] = hop2;
+                    if (n_score >= total_limit) break;
+                }
+            }
+        }
+        /* score_points_unfiltered + process_candidate in order :237-239 */
+        for (uint32_t i = 0; i < n_score; i++) scores[i] = qs_score(q, to_score[i]);
+        for (uint32_t i = 0; i < n_score; i++) {
+            qo_scored_point sp = {to_score[i], scores[i]};
+            process_candidate(nearest, &cands, sp);
+        }
+    }
+    free(links); free(links2); free(to_explore); free(to_score); free(scores);
+    free(cands.d);
+    return nearest;
+}
+
 /* search_entry_on_level (graph_layers.rs:279-317) */
 static qo_scored_point search_entry_on_level(const qo_hnsw *g, qscore *q, uint32_t entry, uint32_t level, int only_ready) {
     const uint32_t limit = level_m(g, level);
@@ -684,15 +747,23 @@ qo_hnsw *qo_hnsw_import_plain(uint32_t n, uint32_t m, uint32_t m0, uint32_t n_le
 /* ---- GraphLayers::search (graph_layers.rs:530-562) ------------------------------------------------ */
 uint32_t qo_hnsw_search(const qo_hnsw *g, const qo_scorer *scorer, uint32_t top, uint32_t ef, qo_scored_point *out,
                         uint64_t *n_scored) {
+    return qo_hnsw_search_algo(g, scorer, top, ef, 0, out, n_scored);
+}
+/* algorithm: 0 = SearchAlgorithm::Hnsw, 1 = SearchAlgorithm::Acorn (graph_layers.rs:550-559) */
+uint32_t qo_hnsw_search_algo(const qo_hnsw *g, const qo_scorer *scorer, uint32_t top, uint32_t ef, int algorithm, qo_scored_point *out,
+                             uint64_t *n_scored) {
     qscore q = {scorer, NULL, 0, 0};
     uint32_t ep_id, ep_level;
     if (!get_entry_point(g, &q, &ep_id, &ep_level)) { if (n_scored) *n_scored = 0; return 0; }
     qo_scored_point zero_level_entry = search_entry(g, &q, ep_id, ep_level, 0, 0);
     if (ef < top) ef = top;
-    visited_t vis;
+    visited_t vis, vis2;
     visited_init(&vis, g->n);
-    qo_topk *nearest = search_on_level(g, &q, zero_level_entry, 0, ef, &vis, 0);
+    visited_init(&vis2, g->n);
+    qo_topk *nearest = algorithm == 1 ? search_on_level_acorn(g, &q, zero_level_entry, 0, ef, &vis, &vis2)
+                                      : search_on_level(g, &q, zero_level_entry, 0, ef, &vis, 0);
     free(vis.cnt);
+    free(vis2.cnt);
     qo_scored_point *sorted = (qo_scored_point *)malloc(sizeof(qo_scored_point) * (ef + 1));
     uint32_t n = (uint32_t)qo_topk_into_sorted(nearest, sorted);
     qo_topk_free(nearest);

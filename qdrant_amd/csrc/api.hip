@@ -1654,7 +1654,7 @@ static int32_t launch_hnsw(const qmx_query *q, const ScanArgs &a, const HnswArgs
 
 
 static int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef, qmx_scored_point *d_out,
-                            uint32_t *d_counts, uint32_t *d_scored, bool timed) {
+                            uint32_t *d_counts, uint32_t *d_scored, bool timed, bool acorn = false) {
     const qmx_segment *s = q->seg;
     ScanArgs a;
     fill_args(q, 0, q->nq, a);
@@ -1678,6 +1678,13 @@ static int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint3
     }
     h.vis_words = ((uint64_t)g->n_points + 31) / 32;
     if (h.vis_words == 0) h.vis_words = 1;
+    h.acorn = acorn ? 1 : 0;
+    h.hop_cap = 64;
+    if (acorn) {   // two visited lists; every explored node may add m0 points to one scoring batch
+        QMX_REQUIRE(g->m0 >= 1 && g->m0 <= 64, QMX_ERR_NOT_SUPPORTED, "ACORN walk: m0 = %u not in 1..64", g->m0);
+        h.vis_words *= 2;
+        h.hop_cap = (g->m0 * (g->m0 + 1) + 63) / 64 * 64;
+    }
     int per_cu = 1;
     QMX_TRY(launch_hnsw(q, a, h, 0, &per_cu));
     uint64_t slots = std::min<uint64_t>({(uint64_t)q->nq, (uint64_t)s->num_cus * per_cu, (uint64_t)HNSW_SLOT_CAP});
@@ -1714,8 +1721,8 @@ static int32_t hnsw_check(const qmx_hnsw *g, const qmx_query *q, uint32_t top, u
     return QMX_OK;
 }
 
-int32_t qmx_hnsw_search(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef, qmx_scored_point *out, uint32_t *out_counts,
-                        const volatile uint8_t *is_stopped, qmx_counters *counters) {
+static int32_t hnsw_search_sync(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef, qmx_scored_point *out, uint32_t *out_counts,
+                                const volatile uint8_t *is_stopped, qmx_counters *counters, bool acorn) {
     QMX_REQUIRE(g && q && out && out_counts, QMX_ERR_BAD_ARG, "NULL argument");
     QMX_TRY(hnsw_check(g, q, top, ef));
     QMX_HIP(hipSetDevice(q->device));
@@ -1737,7 +1744,7 @@ int32_t qmx_hnsw_search(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t 
     if (!cnt_dev) { QMX_TRY(q->counts.reserve((size_t)q->nq * 4)); d_counts = (uint32_t *)q->counts.p; }
     QMX_TRY(q->hnsw_scored.reserve((size_t)q->nq * 4));
     const bool timed = q->timing || (q->seg->flags & QMX_SEG_TIME_KERNELS) != 0;
-    QMX_TRY(hnsw_enqueue(g, q, top, ef, d_out, d_counts, (uint32_t *)q->hnsw_scored.p, timed));
+    QMX_TRY(hnsw_enqueue(g, q, top, ef, d_out, d_counts, (uint32_t *)q->hnsw_scored.p, timed, acorn));
     if (!out_dev) QMX_TRY(copy_out(q->stream, out, d_out, (size_t)q->nq * top * sizeof(qmx_scored_point)));
     if (!cnt_dev) QMX_TRY(copy_out(q->stream, out_counts, d_counts, (size_t)q->nq * 4));
     std::vector<uint32_t> scored(counters ? q->nq : 0);
@@ -1756,6 +1763,15 @@ int32_t qmx_hnsw_search(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t 
         if (counters) counters->kernel_ms = q->timing_ms - before;
     }
     return QMX_OK;
+}
+
+int32_t qmx_hnsw_search(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef, qmx_scored_point *out, uint32_t *out_counts,
+                        const volatile uint8_t *is_stopped, qmx_counters *counters) {
+    return hnsw_search_sync(g, q, top, ef, out, out_counts, is_stopped, counters, false);
+}
+int32_t qmx_hnsw_search_acorn(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef, qmx_scored_point *out, uint32_t *out_counts,
+                              const volatile uint8_t *is_stopped, qmx_counters *counters) {
+    return hnsw_search_sync(g, q, top, ef, out, out_counts, is_stopped, counters, true);
 }
 
 int32_t qmx_hnsw_search_async(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef, qmx_scored_point *out_dev,

@@ -262,6 +262,112 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
         log_cnt = 1;
         beam.insert(make_key(cur_score, cur_id), ef, lane);
     }
+    if (h.acorn) {
+        // ---- search_on_level_acorn (graph_layers.rs:154-243): links that fail the filters are explored instead of scored ----
+        const uint32_t half = (uint32_t)(h.vis_words / 2);           // vis = hop1_visited_list, vis + half = hop2_visited_list
+        uint32_t *to_explore = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(hop_ids) + 8 * (size_t)h.hop_cap);
+        const uint32_t hop_limit = h.m0;                                // hop1_limit = hop2_limit = get_m(0)
+        auto mask_le = [](int l) -> uint64_t { return l >= 63 ? ~0ull : ((2ull << l) - 1ull); };
+        auto nth_set = [](uint64_t m, uint32_t nth) -> int {            // lane of the nth (1-based) set bit
+            for (uint32_t i = 1; i < nth; ++i) m &= m - 1;
+            return __builtin_ctzll(m);
+        };
+        // the links of `node` on level 0, 64 per call: (id, in range)
+        auto link_of = [&](uint32_t node, uint64_t base, uint64_t o1, bool *on) -> uint32_t {
+            const uint64_t i = base + (uint64_t)lane;
+            *on = i < o1;
+            if (h.l0) return *on ? h.l0[(uint64_t)node * h.l0_stride + 1 + i] : 0;
+            return *on ? h.neighbors[i] : 0;
+        };
+        auto log_words = [&](bool mine, uint32_t word) {                 // remember the bitmap words this search dirtied
+            const uint64_t m = __ballot(mine);
+            const uint32_t r = (uint32_t)__popcll(m & lt_mask);
+            if (mine && log_cnt + r < h.log_cap) vlog[log_cnt + r] = word;
+            log_cnt += (uint32_t)__popcll(m);
+        };
+        while (true) {
+            const uint64_t ck = beam.pop_best(lane);
+            if (ck == 0) break;
+            const uint32_t cand = key_idx(ck);
+            uint32_t n_score = 0, n_explore = 0;
+            __syncthreads();
+            {   // 1-hop neighbours (:196-211): every unvisited link is marked; passing ones are scored (at most hop_limit), the others explored
+                uint64_t o0, o1;
+                if (h.l0) { o0 = 0; o1 = h.l0[(uint64_t)cand * h.l0_stride]; } else { o0 = h.offsets[cand]; o1 = h.offsets[(uint64_t)cand + 1]; }
+                bool broke = false;
+                for (uint64_t base = o0; base < o1 && !broke; base += 64) {
+                    bool on;
+                    const uint32_t id = link_of(cand, base, o1, &on);
+                    const bool valid = on && id < h.n_points;
+                    const uint32_t bit = 1u << (id & 31);
+                    const uint32_t old = valid ? atomicOr(&vis[id >> 5], bit) : bit;      // check_and_update_visited
+                    const bool fresh = valid && !(old & bit);
+                    const bool ok = fresh && a.del.live(id);                               // filters().check_vector(hop1)
+                    const uint64_t okm = __ballot(ok), frm = __ballot(fresh);
+                    int brk = 64;
+                    const uint32_t need = hop_limit - n_score;
+                    if ((uint32_t)__popcll(okm) >= need) { brk = nth_set(okm, need); broke = true; }
+                    const bool processed = lane <= brk;
+                    if (fresh && !processed) atomicAnd(&vis[id >> 5], ~bit);              // links behind the break were never looked at
+                    log_words(fresh && processed, id >> 5);
+                    const uint64_t keep = mask_le(brk);
+                    if (ok && processed) hop_ids[n_score + (uint32_t)__popcll(okm & lt_mask)] = id;
+                    const uint64_t exm = frm & ~okm & keep;
+                    if (fresh && !ok && processed) to_explore[n_explore + (uint32_t)__popcll(exm & lt_mask)] = id;
+                    n_score += (uint32_t)__popcll(okm & keep);
+                    n_explore += (uint32_t)__popcll(exm);
+                }
+            }
+            __syncthreads();
+            // 2-hop neighbours (:213-235): the links of every explored node, at most hop_limit scored per node
+            for (uint32_t e = 0; e < n_explore; ++e) {
+                const uint32_t node = to_explore[e];
+                uint64_t o0, o1;
+                if (h.l0) { o0 = 0; o1 = h.l0[(uint64_t)node * h.l0_stride]; } else { o0 = h.offsets[node]; o1 = h.offsets[(uint64_t)node + 1]; }
+                uint32_t added = 0;
+                bool broke = false;
+                for (uint64_t base = o0; base < o1 && !broke; base += 64) {
+                    bool on;
+                    const uint32_t id = link_of(node, base, o1, &on);
+                    const bool valid = on && id < h.n_points;
+                    const uint32_t bit = 1u << (id & 31);
+                    const bool s1 = valid ? (atomicOr(&vis[id >> 5], 0u) & bit) != 0 : true;            // hop1_visited_list.check(hop2)
+                    const bool c1 = valid && !s1;
+                    const uint32_t old2 = c1 ? atomicOr(&vis[half + (id >> 5)], bit) : bit;             // hop2_visited_list.check_and_update_visited(hop2)
+                    const bool fresh = c1 && !(old2 & bit);
+                    const bool ok = fresh && a.del.live(id);
+                    const uint64_t okm = __ballot(ok);
+                    int brk = 64;
+                    const uint32_t need = hop_limit - added;
+                    if ((uint32_t)__popcll(okm) >= need) { brk = nth_set(okm, need); broke = true; }
+                    const bool processed = lane <= brk;
+                    if (fresh && !processed) atomicAnd(&vis[half + (id >> 5)], ~bit);
+                    log_words(fresh && processed, half + (id >> 5));
+                    if (ok && processed) {
+                        atomicOr(&vis[id >> 5], bit);                                                     // hop1_visited_list.check_and_update_visited(hop2)
+                        hop_ids[n_score + added + (uint32_t)__popcll(okm & lt_mask)] = id;
+                    }
+                    log_words(ok && processed, id >> 5);
+                    added += (uint32_t)__popcll(okm & mask_le(brk));
+                }
+                n_score += added;
+            }
+            // score_points_unfiltered + process_candidate, in order (:237-239)
+            hop_score<H>(a, qp, hop_ids, hop_scores, n_score, lane);
+            for (uint32_t base = 0; base < n_score; base += 64) {
+                const uint32_t j = base + (uint32_t)lane;
+                const uint64_t mykey = j < n_score ? make_key(hop_scores[j], hop_ids[j]) : 0;
+                uint64_t mm = __ballot(mykey > beam.at(ef - 1));
+                while (mm) {
+                    const int src = __builtin_ctzll(mm);
+                    mm &= mm - 1;
+                    const uint64_t nk = readlane_u64(mykey, src);
+                    if (nk > beam.at(ef - 1)) beam.insert(nk, ef, lane);
+                }
+            }
+            n_scored += n_score;
+        }
+    } else
     while (true) {
         const uint64_t ck = beam.pop_best(lane);
         if (ck == 0) break;
@@ -349,9 +455,10 @@ template <class H, int E, bool QLDS>
 __global__ __launch_bounds__(64) void hnsw_search_kernel(const ScanArgs a, const HnswArgs h) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
+    // [hop ids: hop_cap u32][hop scores: hop_cap f32][ACORN: 64 ids to explore][query entry]
     uint32_t *hop_ids = reinterpret_cast<uint32_t *>(smem);
-    float *hop_scores = reinterpret_cast<float *>(smem + 256);
-    unsigned char *q_lds = smem + 512;
+    float *hop_scores = reinterpret_cast<float *>(smem + 4 * (size_t)h.hop_cap);
+    unsigned char *q_lds = smem + 8 * (size_t)h.hop_cap + (h.acorn ? 256 : 0);
     uint32_t *vis = h.visited + (uint64_t)blockIdx.x * h.vis_words;
     uint32_t *vlog = h.vis_log + (uint64_t)blockIdx.x * h.log_cap;
     for (uint32_t qi = blockIdx.x; qi < h.nq; qi += gridDim.x) {
@@ -371,14 +478,14 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const ScanArgs a, const
 
 // occupancy of an instantiation (blocks of one wave per CU) — used by the API to size the scratch
 template <class H, int E, bool QLDS>
-int32_t hnsw_occupancy_inst(uint32_t lds_query_bytes, int *per_cu) {
+int32_t hnsw_occupancy_inst(uint32_t lds_query_bytes, size_t hop_lds, int *per_cu) {
     auto kfn = hnsw_search_kernel<H, E, QLDS>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    const size_t lds = 512 + (QLDS ? lds_query_bytes : 0);
+    const size_t lds = hop_lds + (QLDS ? lds_query_bytes : 0);
     int n = 0;
     QMX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kfn, 64, lds));
     *per_cu = n < 1 ? 1 : n;
@@ -387,7 +494,7 @@ int32_t hnsw_occupancy_inst(uint32_t lds_query_bytes, int *per_cu) {
 
 template <class H, int E, bool QLDS>
 int32_t launch_hnsw_inst(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid) {
-    const size_t lds = 512 + (QLDS ? h.lds_query_bytes : 0);
+    const size_t lds = 8 * (size_t)h.hop_cap + (h.acorn ? 256 : 0) + (QLDS ? h.lds_query_bytes : 0);
     ::qmx::clear_stale_error();
     hipLaunchKernelGGL((hnsw_search_kernel<H, E, QLDS>), dim3(grid), dim3(64), lds, st, a, h);
     QMX_HIP(hipGetLastError());
@@ -401,8 +508,9 @@ int32_t launch_hnsw_hop(hipStream_t st, const ScanArgs &a, const HnswArgs &h, ui
     QMX_REQUIRE(ef >= 1 && ef <= HNSW_MAX_EF, QMX_ERR_NOT_SUPPORTED, "hnsw ef %u not in 1..%u", ef, HNSW_MAX_EF);
     const bool qlds = h.lds_query_bytes > 0;
     if (grid == 0) {
-        if (ef <= 128) return qlds ? hnsw_occupancy_inst<H, 2, true>(h.lds_query_bytes, per_cu) : hnsw_occupancy_inst<H, 2, false>(0, per_cu);
-        return qlds ? hnsw_occupancy_inst<H, 8, true>(h.lds_query_bytes, per_cu) : hnsw_occupancy_inst<H, 8, false>(0, per_cu);
+        const size_t hop_lds = 8 * (size_t)h.hop_cap + (h.acorn ? 256 : 0);
+        if (ef <= 128) return qlds ? hnsw_occupancy_inst<H, 2, true>(h.lds_query_bytes, hop_lds, per_cu) : hnsw_occupancy_inst<H, 2, false>(0, hop_lds, per_cu);
+        return qlds ? hnsw_occupancy_inst<H, 8, true>(h.lds_query_bytes, hop_lds, per_cu) : hnsw_occupancy_inst<H, 8, false>(0, hop_lds, per_cu);
     }
     if (ef <= 128) return qlds ? launch_hnsw_inst<H, 2, true>(st, a, h, grid) : launch_hnsw_inst<H, 2, false>(st, a, h, grid);
     return qlds ? launch_hnsw_inst<H, 8, true>(st, a, h, grid) : launch_hnsw_inst<H, 8, false>(st, a, h, grid);

@@ -76,6 +76,8 @@ struct HnswArgs {
     uint32_t *out_counts;           // [nq]
     uint32_t *out_scored;           // [nq] points scored by each search (HardwareCounter cpu_io), may be null
     uint32_t lds_query_bytes;       // bytes of the query entry staged in LDS (16-byte multiple)
+    uint32_t acorn;                 // SearchAlgorithm::Acorn on level 0 (graph_layers.rs:154-243): `visited` holds two bitmaps of vis_words / 2 words
+    uint32_t hop_cap;               // entries of the hop id / score buffers in LDS (64; m0 (m0 + 1) rounded up for ACORN)
 };
 
 // grid == 0: only report the occupancy (blocks of one wave per CU) of the instantiation in *per_cu

@@ -108,17 +108,18 @@ class GraphLayers:
         o.neighbors = o.neighbors[:info.n_neighbors]
         return o
 
-    def search(self, top: int, ef: int, points_scorer: RawScorer, is_stopped=None, with_scored: bool = False):
-        """`GraphLayers::search(top, ef, Hnsw, points_scorer, None, is_stopped)` for every query of the
-        scorer batch -> list of ScoredPointOffset arrays (descending score, at most `top`)."""
+    def search(self, top: int, ef: int, points_scorer: RawScorer, is_stopped=None, with_scored: bool = False, acorn: bool = False):
+        """`GraphLayers::search(top, ef, Hnsw | Acorn, points_scorer, None, is_stopped)` for every query of the
+        scorer batch -> list of ScoredPointOffset arrays (descending score, at most `top`).  `acorn`: SearchAlgorithm::Acorn
+        (filter-aware 2-hop expansion on level 0, graph_layers.rs:154-243)."""
         nq = points_scorer.nq
         out = np.zeros((nq, max(top, 1)), dtype=ScoredPointOffset)
         counts = np.zeros(nq, dtype=np.uint32)
         stop = None
         if is_stopped is not None:
             stop = is_stopped if isinstance(is_stopped, np.ndarray) else np.array([1 if is_stopped else 0], dtype=np.uint8)
-        F.check(F.lib().qmx_hnsw_search(self._h, points_scorer._h, top, ef, F.ptr(out), F.ptr(counts), F.ptr(stop),
-                                        C.byref(self.counters)))
+        fn = F.lib().qmx_hnsw_search_acorn if acorn else F.lib().qmx_hnsw_search
+        F.check(fn(self._h, points_scorer._h, top, ef, F.ptr(out), F.ptr(counts), F.ptr(stop), C.byref(self.counters)))
         res = [out[i, :counts[i]].copy() for i in range(nq)]
         return (res, int(self.counters.vectors_scored)) if with_scored else res
 

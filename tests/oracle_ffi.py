@@ -401,6 +401,7 @@ _sig("qo_hnsw_extra_entry_points", C.c_uint32, [_P, _P, _P, C.c_uint32])
 _sig("qo_hnsw_import_plain", _P, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P, C.c_uint32, _P, _P, C.c_uint32])
 _sig("qo_hnsw_export_plain", None, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _P, _P, _P, _P])
 _sig("qo_hnsw_search", C.c_uint32, [_P, C.POINTER(Scorer), C.c_uint32, C.c_uint32, _P, C.POINTER(C.c_uint64)])
+_sig("qo_hnsw_search_algo", C.c_uint32, [_P, C.POINTER(Scorer), C.c_uint32, C.c_uint32, C.c_int, _P, C.POINTER(C.c_uint64)])
 _sig("qo_links_heuristic", C.c_uint32, [_P, C.c_uint32, C.c_uint32, _P, C.c_uint32, _P])
 _sig("qo_links_connect", C.c_uint32, [_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P, C.c_uint32])
 
@@ -524,10 +525,12 @@ class Hnsw:
         return PlainLinks(self.m, self.m0, reindex, level_offsets, offsets, neighbors[:nn.value], ids, lv, xids, xlv)
 
     # -- searches: one qo_scorer per query ------------------------------------------------------------
+    algorithm = 0      # SearchAlgorithm: 0 = Hnsw, 1 = Acorn (set on the instance for a run)
+
     def _run(self, scorer, top, ef):
         out = np.zeros(max(top, 1), dtype=ScoredPointOffset)
         ns = C.c_uint64()
-        n = _lib.qo_hnsw_search(self.h, C.byref(scorer), top, ef, _p(out), C.byref(ns))
+        n = _lib.qo_hnsw_search_algo(self.h, C.byref(scorer), top, ef, self.algorithm, _p(out), C.byref(ns))
         return out[:n].copy(), ns.value
 
     def search_dense(self, storage: DenseStorage, queries, top, ef, encoded=False, with_stats=False):

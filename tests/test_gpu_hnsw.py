@@ -306,3 +306,70 @@ def test_payload_filter_bitmap_brute_force_and_walk(qa):
         assert allowed[r["idx"]].all() and not deleted[r["idx"]].any()
     s.scorer.set_filter(None)                                   # cleared: back to the deleted flags alone
     _same(s.peek_top_all(), O.DenseStorage(O.F32, O.COSINE, rows, point_deleted=deleted).peek_top(queries, 10))
+
+
+@pytest.mark.parametrize("selectivity", [0.03, 0.15, 0.5, 1.0])
+@pytest.mark.parametrize("m", [8, 16])
+def test_acorn_walk_is_the_reference_walk(qa, selectivity, m):
+    """SearchAlgorithm::Acorn (search_on_level_acorn, graph_layers.rs:154-243) on device == the oracle's restatement on the same
+    graph: ids, score bits and the number of scored points, for filters from 3 % to 100 % of the points (+ deleted points).
+    The filtered plain walk strands on low selectivity; ACORN explores through rejected points."""
+    n, dim, nq, top, ef = 4000, 32, 24, 10, 48
+    rows, st_all, g, plain = _graph(O.COSINE, n, dim, m, 0x5EED0390 + m)
+    queries = O.synth(0x5EED0391, 0, nq, dim)
+    rng = np.random.default_rng(int(selectivity * 100) + m)
+    allowed = rng.random(n) < selectivity
+    deleted = rng.random(n) < 0.05
+    vs = qa.VectorStorage(rows, qa.Distance.Cosine)
+    vs.set_deleted(deleted, None)
+    st_f = O.DenseStorage(O.F32, O.COSINE, rows, point_deleted=deleted | ~allowed)
+    scorer = qa.new_raw_scorer(queries, vs)
+    scorer.set_filter(allowed)
+    graph = qa.GraphLayers.from_plain(plain)
+    g.algorithm = 1
+    try:
+        want, stats = g.search_dense(st_f, queries, top, ef, with_stats=True)
+    finally:
+        g.algorithm = 0
+    got, scored = graph.search(top, ef, scorer, with_scored=True, acorn=True)
+    _same(got, want)
+    assert scored == sum(stats)
+    for r in got:
+        assert allowed[r["idx"]].all() and not deleted[r["idx"]].any()
+    # the visited bitmaps come back clean: a second run (plain walk, then ACORN again) gives the same lists
+    plain_walk = graph.search(top, ef, scorer)
+    again = graph.search(top, ef, scorer, acorn=True)
+    _same(again, want)
+    if selectivity <= 0.15:      # what ACORN is for: it finds more of the filtered neighbours than the plain filtered walk
+        exact = st_f.peek_top(queries, top)
+        hit = lambda res: sum(len(set(a["idx"].tolist()) & set(b["idx"].tolist())) for a, b in zip(res, exact))   # noqa: E731
+        assert hit(got) >= hit(plain_walk)
+
+
+def test_acorn_with_sq_scorer_and_log_overflow(qa):
+    n, dim, m, nq = 3000, 96, 8, 16
+    rows, st, g, plain = _graph(O.DOT, n, dim, m, 0x5EED0330 + O.DOT)
+    queries = O.synth(0x5EED0392, 0, nq, dim)
+    qpre = O.preprocess(O.DOT, queries)
+    quant = qa.ScalarQuantizer.from_min_max(rows, dim, qa.Distance.Dot)
+    osq = O.SqOracle(O.DOT, dim, quant.alpha, quant.offset)
+    osq.encode_rows(rows)
+    enc = qa.EncodedVectorsU8(quant.encode(rows), quant)
+    rng = np.random.default_rng(5)
+    allowed = rng.random(n) < 0.2
+    st_f = O.DenseStorage(O.F32, O.DOT, rows, point_deleted=~allowed)
+    scorer = qa.new_raw_scorer(queries, enc)
+    scorer.set_filter(allowed)
+    graph = qa.GraphLayers.from_plain(plain)
+    g.algorithm = 1
+    try:
+        want = g.search_sq(st_f, osq, qpre, 10, 40)
+    finally:
+        g.algorithm = 0
+    _same(graph.search(10, 40, scorer, acorn=True), want)
+    os.environ["QMX_HNSW_LOG_CAP"] = "8"                      # the visited log overflows: whole-bitmap clear of both lists
+    try:
+        _same(graph.search(10, 40, scorer, acorn=True), want)
+        _same(graph.search(10, 40, scorer, acorn=True), want)
+    finally:
+        del os.environ["QMX_HNSW_LOG_CAP"]
