@@ -320,7 +320,8 @@ typedef struct qmx_search_params {
     uint32_t top;
     float oversampling;   /* > 1.0: the quantized stage returns (oversampling * top) as usize candidates (:27-46) */
     uint8_t rescore;      /* re-score the candidates with the original vectors (default_rescoring or the request's) */
-    uint8_t pad_[3];
+    uint8_t acorn;        /* only with a graph: SearchAlgorithm::Acorn instead of Hnsw (hnsw/read_view/search.rs:42-90) */
+    uint8_t pad_[2];
     uint32_t hnsw_ef;     /* only with a graph; raised to the oversampled top (graph_layers.rs:549) */
 } qmx_search_params;
 

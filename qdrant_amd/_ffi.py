@@ -71,7 +71,7 @@ class HnswInfo(C.Structure):
 
 
 class SearchParams(C.Structure):
-    _fields_ = [("top", C.c_uint32), ("oversampling", C.c_float), ("rescore", C.c_uint8), ("pad_", C.c_uint8 * 3), ("hnsw_ef", C.c_uint32)]
+    _fields_ = [("top", C.c_uint32), ("oversampling", C.c_float), ("rescore", C.c_uint8), ("acorn", C.c_uint8), ("pad_", C.c_uint8 * 2), ("hnsw_ef", C.c_uint32)]
 
 
 class CustomQuery(C.Structure):

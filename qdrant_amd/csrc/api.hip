@@ -1993,7 +1993,7 @@ int32_t qmx_search_quantized(const qmx_hnsw *g, qmx_query *quantized, qmx_query 
     // stage 1: the quantized (or raw, when the caller passes the raw batch as `quantized`) search with the oversampled top
     if (g) {
         const uint32_t ef = std::max(p->hnsw_ef, otop);     // graph_layers.rs:549
-        QMX_TRY(qmx_hnsw_search(g, quantized, otop, ef, d_cand, d_cnt, is_stopped, counters));
+        QMX_TRY(hnsw_search_sync(g, quantized, otop, ef, d_cand, d_cnt, is_stopped, counters, p->acorn != 0));   // SearchAlgorithm of the request
     } else {
         QMX_TRY(qmx_search_topk(quantized, otop, ids, n_ids, d_cand, d_cnt, is_stopped, counters));
     }

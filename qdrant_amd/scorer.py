@@ -574,11 +574,11 @@ class CustomRawScorer:
 
 
 def search_quantized(searched: RawScorer, original: Optional[RawScorer], top: int, oversampling: float = 0.0, rescore: bool = True,
-                     graph=None, hnsw_ef: int = 0, ids=None, is_stopped=None) -> List[np.ndarray]:
+                     graph=None, hnsw_ef: int = 0, ids=None, is_stopped=None, acorn: bool = False) -> List[np.ndarray]:
     """`PlainVectorIndexReadView::search` (graph is None) or the graph arm of `HNSWIndexReadView::search`, with
     `get_oversampled_top` and `postprocess_search_result` (vector_index_search_common.rs:27-91) in one device-side call."""
     p = F.SearchParams()
-    p.top, p.oversampling, p.rescore, p.hnsw_ef = int(top), float(oversampling), 1 if rescore else 0, int(hnsw_ef)
+    p.top, p.oversampling, p.rescore, p.hnsw_ef, p.acorn = int(top), float(oversampling), 1 if rescore else 0, int(hnsw_ef), 1 if acorn else 0
     nq = searched.nq
     out = np.zeros((nq, top), dtype=ScoredPointOffset)
     counts = np.zeros(nq, dtype=np.uint32)

@@ -367,6 +367,19 @@ def test_acorn_with_sq_scorer_and_log_overflow(qa):
     finally:
         g.algorithm = 0
     _same(graph.search(10, 40, scorer, acorn=True), want)
+    # the one-call pipeline with the request's SearchAlgorithm: ACORN walk (oversampled) + rescoring == the two calls by hand
+    vs = qa.VectorStorage(rows, qa.Distance.Dot)
+    raw = qa.new_raw_scorer(queries, vs)
+    raw.set_filter(allowed)
+    fused = qa.search_quantized(scorer, raw, 10, oversampling=2.0, rescore=True, graph=graph, hnsw_ef=40, acorn=True)
+    walk = graph.search(20, 40, scorer, acorn=True)
+    ids = np.zeros((nq, 20), dtype=np.uint32)
+    cnt = np.zeros(nq, dtype=np.uint32)
+    for i, r in enumerate(walk):
+        ids[i, :len(r)] = r["idx"]
+        cnt[i] = len(r)
+    for a_, b_ in zip(fused, raw.rescore(ids, 10, cnt)):
+        assert np.array_equal(a_, b_)
     os.environ["QMX_HNSW_LOG_CAP"] = "8"                      # the visited log overflows: whole-bitmap clear of both lists
     try:
         _same(graph.search(10, 40, scorer, acorn=True), want)
