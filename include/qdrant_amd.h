@@ -138,6 +138,19 @@ typedef struct qmx_pq_params {
  * pass `file_base + 4` to skip the "data" header).  For SQ_U8 rows are the reference layout
  * `[f32 vector_offset][u8 code x actual_dim]` (encoded_vectors_u8.rs:22-24,626-629), for PQ
  * `m` code bytes (encoded_vectors_pq.rs:617-619). */
+/* Binary quantization beyond one bit: `Encoding::{TwoBits, OneAndHalfBits}` (lib/quantization/src/encoded_vectors_binary.rs:62-78,
+ * 570-672): bit i = value above the per-dimension zero band, a second bit plane marks values above it (1.5 bits: one such bit
+ * per PAIR of dimensions, OR-ed).  The band comes from `VectorStats` (vector_stats.rs: mean and stddev per dimension, computed by the
+ * reference while it reads the vectors): given here, like the SQ interval and the PQ centroids.  NULL mean / stddev = no stats.
+ * Scoring is the one-bit xor-popcount over the longer rows, with the ORIGINAL dim in calculate_metric. */
+typedef enum qmx_bq_encoding { QMX_BQ_ONE_BIT = 0, QMX_BQ_TWO_BITS = 1, QMX_BQ_ONE_AND_HALF_BITS = 2 } qmx_bq_encoding;
+typedef struct qmx_bq_params {
+    uint32_t encoding;      /* qmx_bq_encoding */
+    uint32_t reserved;
+    const float *mean;      /* [dim] host or device, or NULL */
+    const float *stddev;    /* [dim] host or device, or NULL */
+} qmx_bq_params;
+
 typedef struct qmx_segment_desc {
     uint32_t dtype;            /* qmx_dtype */
     uint32_t distance;         /* qmx_distance */
@@ -150,6 +163,7 @@ typedef struct qmx_segment_desc {
     int32_t reserved;
     const qmx_sq_params *sq;   /* required for QMX_DTYPE_SQ_U8 */
     const qmx_pq_params *pq;   /* required for QMX_DTYPE_PQ */
+    const qmx_bq_params *bq;   /* optional for QMX_DTYPE_BQ: NULL = Encoding::OneBit */
 } qmx_segment_desc;
 
 typedef struct qmx_segment qmx_segment;
@@ -507,6 +521,9 @@ QMX_API int32_t qmx_sq_encode(int32_t device_id, uint32_t distance, const qmx_sq
 /* `EncodedVectorsBin::encode_vector` for Encoding::OneBit (encoded_vectors_binary.rs:535-568) with the u128 store type:
  * in [n][dim] f32 (already metric-preprocessed, as the storage's rows are) -> out [n][ceil(dim / 128) * 16] bytes. */
 QMX_API int32_t qmx_bq_encode(int32_t device_id, const float *in, uint64_t n, uint32_t dim, void *out_rows);
+/* The same for any encoding: rows of qmx_bq_row_bytes(dim, encoding) bytes (get_quantized_vector_size_from_params::<u128>, :829-840). */
+QMX_API int32_t qmx_bq_encode_ex(int32_t device_id, const qmx_bq_params *params, const float *in, uint64_t n, uint32_t dim, void *out_rows);
+QMX_API uint64_t qmx_bq_row_bytes(uint32_t dim, uint32_t encoding);
 /* PQ codebook training = `kmeans` (lib/quantization/src/kmeans.rs:9-169) for every chunk of `find_centroids`
  * (encoded_vectors_pq.rs:342-407) on a GIVEN sample [n][dim] (the reference draws <= KMEANS_SAMPLE_SIZE = 10 000
  * vectors with a randomly keyed Permutor: unpinned, so the sample is an input): first-k init, update_indexes,

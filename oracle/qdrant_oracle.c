@@ -1286,3 +1286,50 @@ int qo_sq_quantile_interval(const float *sample, size_t n_sample, uint32_t dim, 
     *min_out = mn; *max_out = mx;
     return 1;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * BQ, Encoding::TwoBits / OneAndHalfBits (encoded_vectors_binary.rs:570-672).  Test infrastructure only.
+ * ------------------------------------------------------------------------------------------ */
+size_t qo_bq_row_bytes_ex(uint32_t dim, int encoding) {
+    /* extended_dim :833-838: dim, dim * 2, (dim * 3).div_ceil(2); get_storage_size(max(ext, 1)) * 16 */
+    size_t ext = encoding == 0 ? dim : encoding == 1 ? (size_t)dim * 2 : ((size_t)dim * 3 + 1) / 2;
+    if (ext < 1) ext = 1;
+    size_t words = ext / 128;
+    if (ext % 128 != 0) words += 1;
+    return words * 16;
+}
+/* encode_two_bits_value :626-672 */
+static void bq_two_bits_value(float value, const float *mean, const float *stddev, uint32_t i, int *b1, int *b2) {
+    if (!mean || !stddev) { *b1 = *b2 = value > 0.0f; return; }       /* element_stats = None */
+    const float sd = stddev[i];
+    if (sd < 1.1920929e-07f) { *b1 = value > 0.0f; *b2 = 0; return; }  /* sd < f32::EPSILON */
+    const float v_z = (value - mean[i]) / sd;
+    const float SIGMAS = 2.0f / 3.0f;
+    if (v_z <= -SIGMAS) { *b1 = 0; *b2 = 0; }
+    else if (v_z < SIGMAS) { *b1 = 1; *b2 = 0; }
+    else { *b1 = 1; *b2 = 1; }
+}
+static void bq_set_bit(uint8_t *out, size_t j) {   /* encoded_vector[j / 128] |= one << (j % 128), little-endian u128 */
+    out[(j / 128) * 16 + (j % 128) / 8] |= (uint8_t)(1u << (j % 8));
+}
+void qo_bq_encode_row_ex(uint32_t dim, int encoding, const float *mean, const float *stddev, const float *v, uint8_t *out) {
+    memset(out, 0, qo_bq_row_bytes_ex(dim, encoding));
+    for (uint32_t i = 0; i < dim; ++i) {
+        if (encoding == 0) {                                   /* encode_one_bit_vector :558-568 */
+            if (v[i] > 0.0f) bq_set_bit(out, i);
+            continue;
+        }
+        int b1, b2;
+        bq_two_bits_value(v[i], mean, stddev, i, &b1, &b2);
+        if (b1) bq_set_bit(out, i);
+        if (b2) bq_set_bit(out, encoding == 1 ? (size_t)dim + i : (size_t)dim + i / 2);   /* :570-624 */
+    }
+}
+float qo_bq_score_ex(int distance, int invert, uint32_t dim, int encoding, const uint8_t *q, const uint8_t *v) {
+    const float xor_product = (float)qo_bq_xor_popcnt(q, v, (uint32_t)(qo_bq_row_bytes_ex(dim, encoding) / 16));
+    const float fdim = (float)dim;                             /* metadata.vector_parameters.dim: the original dimension */
+    const float zeros_count = fdim - xor_product;
+    const int dot_like = distance == QO_DOT || distance == QO_COSINE;
+    if (dot_like) return invert ? xor_product - zeros_count : zeros_count - xor_product;
+    return invert ? zeros_count - xor_product : xor_product - zeros_count;
+}

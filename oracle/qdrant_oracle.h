@@ -151,6 +151,11 @@ void qo_bq_encode_row(uint32_t dim, const float *v, uint8_t *out);              
 uint32_t qo_bq_xor_popcnt(const uint8_t *q, const uint8_t *v, uint32_t n_u128);  /* cpp/sse.c:54-75 */
 /* calculate_metric :766-810 with query_bits_count == 1; distance as QO_* codes; invert = VectorParameters.invert */
 float qo_bq_score(int distance, int invert, uint32_t dim, const uint8_t *q, const uint8_t *v);
+/* Encoding::{OneBit = 0, TwoBits = 1, OneAndHalfBits = 2} (:62-78): row size (:829-840), encode_vector (:535-672; mean / stddev = the
+ * VectorStats of the storage, NULL = none), calculate_metric over the longer rows with the ORIGINAL dim (:766-810) */
+size_t qo_bq_row_bytes_ex(uint32_t dim, int encoding);
+void qo_bq_encode_row_ex(uint32_t dim, int encoding, const float *mean, const float *stddev, const float *v, uint8_t *out);
+float qo_bq_score_ex(int distance, int invert, uint32_t dim, int encoding, const uint8_t *q, const uint8_t *v);
 
 /* ---- cross-segment merge: BatchResultAggregator (lib/shard/src/search_result_aggregator.rs:50-121) ----
  * lists[(l * nq + qi) * k ..] with counts[l * nq + qi] valid entries; idx_base[l] (optional) is added to

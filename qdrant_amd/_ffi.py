@@ -43,11 +43,18 @@ class PqParams(C.Structure):
                 ("invert", C.c_uint8), ("lut_mfma", C.c_uint8), ("pad_", C.c_uint8 * 2)]
 
 
+class BqParams(C.Structure):
+    _fields_ = [("encoding", C.c_uint32), ("reserved", C.c_uint32), ("mean", C.c_void_p), ("stddev", C.c_void_p)]
+
+
+BQ_ONE_BIT, BQ_TWO_BITS, BQ_ONE_AND_HALF_BITS = range(3)
+
+
 class SegmentDesc(C.Structure):
     _fields_ = [("dtype", C.c_uint32), ("distance", C.c_uint32), ("dim", C.c_uint32), ("flags", C.c_uint32),
                 ("n", C.c_uint64), ("row_stride_bytes", C.c_uint64), ("data", C.c_void_p),
                 ("device_id", C.c_int32), ("reserved", C.c_int32), ("sq", C.POINTER(SqParams)),
-                ("pq", C.POINTER(PqParams))]
+                ("pq", C.POINTER(PqParams)), ("bq", C.POINTER(BqParams))]
 
 
 class HnswDesc(C.Structure):
@@ -140,6 +147,8 @@ SIGNATURES = {
     "qmx_segment_create_from_files": (C.c_int32, [C.POINTER(SegmentDesc), C.c_char_p, C.c_char_p, C.POINTER(_P)]),
     "qmx_sq_fit_quantile": (C.c_int32, [C.c_int32, C.c_uint32, _P, C.c_uint64, C.c_uint32, C.c_uint64, C.c_float, C.POINTER(SqParams), C.POINTER(C.c_int32)]),
     "qmx_custom_set_coefficients": (C.c_int32, [_P, _P, C.c_uint32]),
+    "qmx_bq_encode_ex": (C.c_int32, [C.c_int32, C.POINTER(BqParams), _P, C.c_uint64, C.c_uint32, _P]),
+    "qmx_bq_row_bytes": (C.c_uint64, [C.c_uint32, C.c_uint32]),
     "qmx_bq_encode": (C.c_int32, [C.c_int32, _P, C.c_uint64, C.c_uint32, _P]),
     "qmx_pq_encode": (C.c_int32, [C.c_int32, C.POINTER(PqParams), _P, C.c_uint64, C.c_uint32, _P]),
     "qmx_synth_fill_f32": (C.c_int32, [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, _P]),

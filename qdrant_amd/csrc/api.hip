@@ -130,6 +130,8 @@ struct qmx_segment {
     uint64_t n_vec_bits = 0;
     qmx_sq_params sq{};
     qmx_pq_params pq{};
+    uint32_t bq_encoding = 0;            // qmx_bq_encoding
+    float *d_bq_mean = nullptr, *d_bq_stddev = nullptr;   // VectorStats of the 2-bit / 1.5-bit encodings (device copies), or null
     float *d_centroids = nullptr;
     uint32_t pq_m = 0;
     float *d_row_offsets = nullptr;   // SQ: vector_offset column (rows hold the 16-byte aligned code block)
@@ -313,6 +315,8 @@ static void segment_free(qmx_segment *seg) {
     if (seg->d_vec_deleted) (void)hipFree(seg->d_vec_deleted);
     if (seg->d_centroids) (void)hipFree(seg->d_centroids);
     if (seg->d_row_offsets) (void)hipFree(seg->d_row_offsets);
+    if (seg->d_bq_mean) (void)hipFree(seg->d_bq_mean);
+    if (seg->d_bq_stddev) (void)hipFree(seg->d_bq_stddev);
     delete seg;
 }
 
@@ -415,10 +419,21 @@ int32_t qmx_segment_create(const qmx_segment_desc *desc, qmx_segment **out) {
             s->pq.centroids = nullptr;   // the caller's table is not referenced after create
             break;
         }
-        case QMX_DTYPE_BQ:   // get_quantized_vector_size_from_params::<u128>(dim, OneBit) (encoded_vectors_binary.rs:829-840, 412-419)
-            s->row_bytes = (((uint64_t)desc->dim + 127) / 128) * 16;
+        case QMX_DTYPE_BQ: {  // get_quantized_vector_size_from_params::<u128>(dim, encoding) (encoded_vectors_binary.rs:829-840, 412-419)
+            s->bq_encoding = desc->bq ? desc->bq->encoding : (uint32_t)QMX_BQ_ONE_BIT;
+            if (s->bq_encoding > QMX_BQ_ONE_AND_HALF_BITS) { set_error("bad BQ encoding %u", s->bq_encoding); rc = QMX_ERR_BAD_ARG; break; }
+            s->row_bytes = bq_row_bytes(desc->dim, s->bq_encoding);
             s->scan_dim = (uint32_t)s->row_bytes;
+            if (desc->bq && desc->bq->mean && desc->bq->stddev && s->bq_encoding != QMX_BQ_ONE_BIT) {   // the stats encode the queries later
+                const size_t b = (size_t)desc->dim * sizeof(float);
+                hipError_t e = hipMalloc((void **)&s->d_bq_mean, b);
+                if (e == hipSuccess) e = hipMalloc((void **)&s->d_bq_stddev, b);
+                if (e == hipSuccess) e = hipMemcpy(s->d_bq_mean, desc->bq->mean, b, hipMemcpyDefault);
+                if (e == hipSuccess) e = hipMemcpy(s->d_bq_stddev, desc->bq->stddev, b, hipMemcpyDefault);
+                if (e != hipSuccess) rc = hip_status(e, "BQ vector stats upload", __FILE__, __LINE__);
+            }
             break;
+        }
         default:
             set_error("dtype %u not built yet", desc->dtype);
             rc = QMX_ERR_NOT_SUPPORTED;
@@ -449,7 +464,7 @@ int32_t qmx_segment_create_from_files(const qmx_segment_desc *desc, const char *
             QMX_REQUIRE(desc->pq && desc->pq->chunk_size, QMX_ERR_BAD_ARG, "PQ segment needs qmx_pq_params");
             row_bytes = ((uint64_t)desc->dim + desc->pq->chunk_size - 1) / desc->pq->chunk_size;
             break;
-        default: row_bytes = (((uint64_t)desc->dim + 127) / 128) * 16; break;   // BQ
+        default: row_bytes = bq_row_bytes(desc->dim, desc->bq ? desc->bq->encoding : 0u); break;   // BQ
     }
     FILE *f = fopen(vectors_path, "rb");
     QMX_REQUIRE(f, QMX_ERR_BAD_ARG, "cannot open %s", vectors_path);
@@ -734,7 +749,7 @@ static int32_t query_encode(qmx_query *q, const float *queries) {
         return launch_sq_encode(q->stream, (int)seg->distance, seg->sq, seg->dim, d_f32, nq, (uint8_t *)q->d_queries, q->q_stride,
                                 nullptr, nullptr, 1, q->aux_off);
     if (seg->dtype == QMX_DTYPE_BQ)      // encode_query_vector, SameAsStorage (encoded_vectors_binary.rs:673-690) = encode_one_bit_vector
-        return launch_bq_encode(q->stream, d_f32, nq, seg->dim, (uint8_t *)q->d_queries, q->q_stride);
+        return launch_bq_encode(q->stream, d_f32, nq, seg->dim, seg->bq_encoding, seg->d_bq_mean, seg->d_bq_stddev, (uint8_t *)q->d_queries, q->q_stride);
     if (seg->dtype == QMX_DTYPE_PQ)      // EncodedVectorsPQ::encode_query (encoded_vectors_pq.rs:519-541)
         return launch_pq_lut(q->stream, seg->distance, seg->dim, seg->pq, seg->d_centroids, d_f32, nq, (float *)q->d_queries);
     set_error("query encode for dtype %u not built yet", seg->dtype);
@@ -2090,6 +2105,8 @@ int32_t qmx_score_bytes(qmx_query *q, const void *rows, uint32_t n, uint64_t str
     qmx_pq_params pq = s->pq;
     pq.centroids = s->d_centroids;
     d.pq = &pq;
+    qmx_bq_params bq = {s->bq_encoding, 0, nullptr, nullptr};   // the row size follows the encoding; scoring needs no stats
+    d.bq = &bq;
     qmx_segment *tmp = nullptr;
     QMX_TRY(qmx_segment_create(&d, &tmp));
     int32_t rc = QMX_OK;
@@ -2162,14 +2179,19 @@ int32_t qmx_sq_encode(int32_t device_id, uint32_t distance, const qmx_sq_params 
     return rc;
 }
 
-int32_t qmx_bq_encode(int32_t device_id, const float *in, uint64_t n, uint32_t dim, void *out_rows) {
+uint64_t qmx_bq_row_bytes(uint32_t dim, uint32_t encoding) { return bq_row_bytes(dim, encoding); }
+
+int32_t qmx_bq_encode_ex(int32_t device_id, const qmx_bq_params *params, const float *in, uint64_t n, uint32_t dim, void *out_rows) {
     QMX_REQUIRE((n == 0 || (in && out_rows)) && dim > 0, QMX_ERR_BAD_ARG, "bad argument");
+    const uint32_t encoding = params ? params->encoding : (uint32_t)QMX_BQ_ONE_BIT;
+    QMX_REQUIRE(encoding <= QMX_BQ_ONE_AND_HALF_BITS, QMX_ERR_BAD_ARG, "bad BQ encoding %u", encoding);
     QMX_TRY(check_device(device_id, nullptr));
     if (n == 0) return QMX_OK;
-    const size_t row_bytes = (((size_t)dim + 127) / 128) * 16;
+    const size_t row_bytes = (size_t)bq_row_bytes(dim, encoding);
     const size_t in_bytes = (size_t)n * dim * 4, out_bytes = (size_t)n * row_bytes;
-    DevBuf bin, bout;
-    const float *d_in = in;
+    const bool stats = params && params->mean && params->stddev && encoding != QMX_BQ_ONE_BIT;
+    DevBuf bin, bout, bm, bs;
+    const float *d_in = in, *d_mean = nullptr, *d_sd = nullptr;
     void *d_out = out_rows;
     int32_t rc = QMX_OK;
     do {
@@ -2178,18 +2200,31 @@ int32_t qmx_bq_encode(int32_t device_id, const float *in, uint64_t n, uint32_t d
             if (hipMemcpy(bin.p, in, in_bytes, hipMemcpyHostToDevice) != hipSuccess) { rc = QMX_ERR_OTHER; break; }
             d_in = (const float *)bin.p;
         }
+        if (stats) {
+            if ((rc = bm.reserve((size_t)dim * 4)) != QMX_OK || (rc = bs.reserve((size_t)dim * 4)) != QMX_OK) break;
+            if (hipMemcpy(bm.p, params->mean, (size_t)dim * 4, hipMemcpyDefault) != hipSuccess ||
+                hipMemcpy(bs.p, params->stddev, (size_t)dim * 4, hipMemcpyDefault) != hipSuccess) { rc = QMX_ERR_OTHER; break; }
+            d_mean = (const float *)bm.p;
+            d_sd = (const float *)bs.p;
+        }
         const bool out_dev = is_device_ptr(out_rows);
         if (!out_dev) {
             if ((rc = bout.reserve(out_bytes)) != QMX_OK) break;
             d_out = bout.p;
         }
-        if ((rc = launch_bq_encode(nullptr, d_in, n, dim, (uint8_t *)d_out, row_bytes)) != QMX_OK) break;
+        if ((rc = launch_bq_encode(nullptr, d_in, n, dim, encoding, d_mean, d_sd, (uint8_t *)d_out, row_bytes)) != QMX_OK) break;
         if (!out_dev && hipMemcpy(out_rows, d_out, out_bytes, hipMemcpyDeviceToHost) != hipSuccess) { rc = QMX_ERR_OTHER; break; }
         if (hipDeviceSynchronize() != hipSuccess) rc = QMX_ERR_OTHER;
     } while (0);
     bin.release();
     bout.release();
+    bm.release();
+    bs.release();
     return rc;
+}
+
+int32_t qmx_bq_encode(int32_t device_id, const float *in, uint64_t n, uint32_t dim, void *out_rows) {
+    return qmx_bq_encode_ex(device_id, nullptr, in, n, dim, out_rows);
 }
 
 int32_t qmx_pq_train(int32_t device_id, const float *sample, uint64_t n, uint32_t dim, uint32_t chunk_size, uint32_t n_centroids,

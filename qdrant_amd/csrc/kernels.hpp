@@ -178,7 +178,9 @@ int32_t launch_order_statistics_f32(hipStream_t st, const float *d_in, float *d_
 // BQ 1-bit (scan_bq.hip)
 int32_t launch_scan_bq(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out);
 int32_t launch_pairs_bq(hipStream_t st, const ScanArgs &a, const PairSel &sel, uint64_t n_items, int num_cus);
-int32_t launch_bq_encode(hipStream_t st, const float *d_in, uint64_t n, uint32_t dim, uint8_t *d_out, uint64_t out_stride);
+uint64_t bq_row_bytes(uint32_t dim, uint32_t encoding);
+int32_t launch_bq_encode(hipStream_t st, const float *d_in, uint64_t n, uint32_t dim, uint32_t encoding, const float *d_mean, const float *d_stddev,
+                         uint8_t *d_out, uint64_t out_stride);
 // PQ (pq.hip)
 int32_t launch_scan_pq(hipStream_t st, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out);
 int32_t launch_pairs_pq(hipStream_t st, const ScanArgs &a, const PairSel &sel, uint64_t n_items, int num_cus);

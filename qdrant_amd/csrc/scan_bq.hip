@@ -199,28 +199,61 @@ int32_t launch_hnsw_bq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uin
     return dispatch_bq(HnswLauncher{st, &h, grid, per_cu}, a);
 }
 
-// encode_one_bit_vector for a batch: in [n][dim] f32 -> out [n][out_stride] bytes (row_bytes = ceil(dim / 128) * 16, rest of
-// the stride zero).  One thread per output dword.
-__global__ __launch_bounds__(256) void bq_encode_kernel(const float *in, uint64_t n, uint32_t dim, uint32_t row_bytes, uint8_t *out,
-                                                        uint64_t out_stride) {
+// encode_vector for a batch (encoded_vectors_binary.rs:535-672): in [n][dim] f32 -> out [n][out_stride] bytes; one thread per
+// output dword.  encoding 0: bit i = v[i] > 0.  1 (TwoBits): bit i = b1(v[i]), bit dim + i = b2(v[i]).  2 (OneAndHalfBits): bit
+// i = b1(v[i]), bit dim + k = b2(v[2k]) | b2(v[2k+1]).  (b1, b2) = encode_two_bits_value (:626-672).
+__device__ __forceinline__ void bq_two_bits(float value, const float *mean, const float *stddev, uint32_t i, bool *b1, bool *b2) {
+    if (!mean || !stddev) { *b1 = *b2 = value > 0.0f; return; }                  // no stats: (true, true) / (false, false)
+    const float sd = stddev[i];
+    if (sd < 1.1920929e-07f) { *b1 = value > 0.0f; *b2 = false; return; }        // f32::EPSILON: regular BQ with the zero comparison
+    const float v_z = (value - mean[i]) / sd;
+    const float SIGMAS = 2.0f / 3.0f;
+    if (v_z <= -SIGMAS) { *b1 = false; *b2 = false; }
+    else if (v_z < SIGMAS) { *b1 = true; *b2 = false; }
+    else { *b1 = true; *b2 = true; }
+}
+__global__ __launch_bounds__(256) void bq_encode_kernel(const float *in, uint64_t n, uint32_t dim, uint32_t encoding, const float *mean,
+                                                        const float *stddev, uint32_t row_bytes, uint8_t *out, uint64_t out_stride) {
     const uint32_t words = row_bytes / 4;
     const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t r = gid / words;
     const uint32_t w = (uint32_t)(gid % words);
     if (r >= n) return;
+    const float *v = in + r * dim;
     uint32_t bits = 0;
     for (uint32_t b = 0; b < 32; ++b) {
-        const uint32_t i = w * 32 + b;
-        if (i < dim && in[r * dim + i] > 0.0f) bits |= 1u << b;
+        const uint32_t j = w * 32 + b;
+        bool on = false;
+        if (encoding == 0) {
+            on = j < dim && v[j] > 0.0f;
+        } else if (j < dim) {
+            bool b1, b2;
+            bq_two_bits(v[j], mean, stddev, j, &b1, &b2);
+            on = b1;
+        } else if (encoding == 1) {
+            const uint32_t i = j - dim;
+            if (i < dim) { bool b1, b2; bq_two_bits(v[i], mean, stddev, i, &b1, &b2); on = b2; }
+        } else {
+            const uint32_t k = j - dim;
+            for (uint32_t i = 2 * k; i < 2 * k + 2 && i < dim; ++i) { bool b1, b2; bq_two_bits(v[i], mean, stddev, i, &b1, &b2); on = on || b2; }
+        }
+        if (on) bits |= 1u << b;
     }
     *reinterpret_cast<uint32_t *>(out + r * out_stride + (uint64_t)w * 4) = bits;
 }
-int32_t launch_bq_encode(hipStream_t st, const float *d_in, uint64_t n, uint32_t dim, uint8_t *d_out, uint64_t out_stride) {
+uint64_t bq_row_bytes(uint32_t dim, uint32_t encoding) {   // get_quantized_vector_size_from_params::<u128> (:829-840)
+    uint64_t ext = encoding == 0 ? dim : encoding == 1 ? 2ull * dim : (3ull * dim + 1) / 2;
+    if (ext < 1) ext = 1;
+    return (ext + 127) / 128 * 16;
+}
+int32_t launch_bq_encode(hipStream_t st, const float *d_in, uint64_t n, uint32_t dim, uint32_t encoding, const float *d_mean, const float *d_stddev,
+                         uint8_t *d_out, uint64_t out_stride) {
     if (n == 0) return QMX_OK;
-    const uint32_t row_bytes = ((dim + 127) / 128) * 16;
+    const uint32_t row_bytes = (uint32_t)bq_row_bytes(dim, encoding);
     const uint64_t total = n * (row_bytes / 4);
     ::qmx::clear_stale_error();
-    hipLaunchKernelGGL(bq_encode_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, d_in, n, dim, row_bytes, d_out, out_stride);
+    hipLaunchKernelGGL(bq_encode_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, d_in, n, dim, encoding, d_mean, d_stddev, row_bytes,
+                       d_out, out_stride);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }

@@ -321,26 +321,38 @@ class EncodedVectorsPQ(VectorStorage):
 
 
 class BinaryQuantizer:
-    """`Metadata{vector_parameters, encoding: OneBit, query_encoding: SameAsStorage}` of `EncodedVectorsBin<u128>`
-    (lib/quantization/src/encoded_vectors_binary.rs:43-60).  `invert` defaults to the segment's choice
-    (quantized_vectors.rs:232: Euclid | Manhattan)."""
+    """`Metadata{vector_parameters, encoding, query_encoding: SameAsStorage, vector_stats}` of `EncodedVectorsBin<u128>`
+    (lib/quantization/src/encoded_vectors_binary.rs:43-78).  `invert` defaults to the segment's choice (quantized_vectors.rs:232:
+    Euclid | Manhattan).  `encoding`: 0 one bit, 1 two bits, 2 one and a half bits; the latter two take the per-dimension
+    `mean` / `stddev` of the storage (`VectorStats`, an input like the SQ interval), None = no stats."""
 
-    def __init__(self, dim: int, distance: Distance, invert: Optional[bool] = None):
+    def __init__(self, dim: int, distance: Distance, invert: Optional[bool] = None, encoding: int = 0, mean=None, stddev=None):
         self.dim = int(dim)
         self.distance = Distance(distance)
         natural = self.distance in (Distance.Euclid, Distance.Manhattan)
         self.invert = natural if invert is None else bool(invert)
         self._toggle = self.invert != natural
+        self.encoding = int(encoding)
+        self.mean = None if mean is None else np.ascontiguousarray(mean, dtype=np.float32)
+        self.stddev = None if stddev is None else np.ascontiguousarray(stddev, dtype=np.float32)
+
+    def params(self) -> "F.BqParams":
+        p = F.BqParams()
+        p.encoding = self.encoding
+        p.mean = None if self.mean is None else self.mean.ctypes.data
+        p.stddev = None if self.stddev is None else self.stddev.ctypes.data
+        return p
 
     def quantized_vector_size(self) -> int:
-        """get_quantized_vector_size_from_params::<u128>(dim, OneBit) (:829-840)."""
-        return (max(self.dim, 1) + 127) // 128 * 16
+        """get_quantized_vector_size_from_params::<u128>(dim, encoding) (:829-840)."""
+        return int(F.lib().qmx_bq_row_bytes(self.dim, self.encoding))
 
     def encode(self, vectors, device_id: int = 0) -> np.ndarray:
-        """`encode_one_bit_vector` (:558-568) on device: [n, dim] f32 -> [n, ceil(dim / 128) * 16] bytes."""
+        """`encode_vector` (:535-672) on device: [n, dim] f32 -> [n, quantized_vector_size] bytes."""
         v = np.ascontiguousarray(vectors, dtype=np.float32)
         out = np.empty((v.shape[0], self.quantized_vector_size()), dtype=np.uint8)
-        F.check(F.lib().qmx_bq_encode(device_id, F.ptr(v), v.shape[0], self.dim, F.ptr(out)))
+        p = self.params()
+        F.check(F.lib().qmx_bq_encode_ex(device_id, C.byref(p), F.ptr(v), v.shape[0], self.dim, F.ptr(out)))
         return out
 
 
@@ -362,6 +374,8 @@ class EncodedVectorsBin(VectorStorage):
         desc.distance = int(quantizer.distance)
         desc.dim = quantizer.dim
         desc.flags = F.SEG_BQ_TOGGLE_INVERT if quantizer._toggle else 0
+        self._bq = quantizer.params()
+        desc.bq = C.pointer(self._bq)
         desc.n = self.count
         desc.row_stride_bytes = 0
         desc.data = F.ptr(rows)

@@ -97,6 +97,9 @@ _sig("qo_bq_row_bytes", C.c_size_t, [C.c_uint32])
 _sig("qo_bq_encode_row", None, [C.c_uint32, _P, _P])
 _sig("qo_bq_xor_popcnt", C.c_uint32, [_P, _P, C.c_uint32])
 _sig("qo_bq_score", _f, [C.c_int, C.c_int, C.c_uint32, _P, _P])
+_sig("qo_bq_row_bytes_ex", C.c_size_t, [C.c_uint32, C.c_int])
+_sig("qo_bq_encode_row_ex", None, [C.c_uint32, C.c_int, _P, _P, _P, _P])
+_sig("qo_bq_score_ex", _f, [C.c_int, C.c_int, C.c_uint32, C.c_int, _P, _P])
 _sig("qo_pq_train_ex", None, [C.c_uint32, C.c_uint32, C.c_uint32, _P, C.c_size_t, C.c_uint32, C.c_float, C.c_uint32, _P, _P])
 
 lib = _lib
@@ -293,17 +296,19 @@ class BqOracle:
     """EncodedVectorsBin<u128>, OneBit, SameAsStorage on the CPU (oracle).  invert defaults to the segment's choice
     (quantized_vectors.rs:232: Euclid | Manhattan)."""
 
-    def __init__(self, distance, dim, invert=None):
-        self.distance, self.dim = distance, dim
+    def __init__(self, distance, dim, invert=None, encoding=0, mean=None, stddev=None):
+        self.distance, self.dim, self.encoding = distance, dim, int(encoding)
         self.invert = int(distance in (EUCLID, MANHATTAN)) if invert is None else int(invert)
-        self.row_bytes = int(_lib.qo_bq_row_bytes(dim))
+        self.row_bytes = int(_lib.qo_bq_row_bytes_ex(dim, self.encoding))
+        self.mean = None if mean is None else f32(mean)
+        self.stddev = None if stddev is None else f32(stddev)
         self.rows = None
 
     def encode(self, vectors):
         v = f32(np.atleast_2d(vectors))
         out = np.zeros((v.shape[0], self.row_bytes), dtype=np.uint8)
         for i in range(v.shape[0]):
-            _lib.qo_bq_encode_row(self.dim, _p(v[i]), _p(out[i]))
+            _lib.qo_bq_encode_row_ex(self.dim, self.encoding, _p(self.mean), _p(self.stddev), _p(v[i]), _p(out[i]))
         return out
 
     def encode_rows(self, vectors):
@@ -315,11 +320,11 @@ class BqOracle:
         out = np.empty((qs.shape[0], len(ids)), dtype=np.float32)
         for qi in range(qs.shape[0]):
             for j, i in enumerate(ids):
-                out[qi, j] = _lib.qo_bq_score(self.distance, self.invert, self.dim, _p(qs[qi]), _p(self.rows[i]))
+                out[qi, j] = _lib.qo_bq_score_ex(self.distance, self.invert, self.dim, self.encoding, _p(qs[qi]), _p(self.rows[i]))
         return out
 
     def score_internal(self, a, b):
-        return np.array([_lib.qo_bq_score(self.distance, self.invert, self.dim, _p(self.rows[i]), _p(self.rows[j]))
+        return np.array([_lib.qo_bq_score_ex(self.distance, self.invert, self.dim, self.encoding, _p(self.rows[i]), _p(self.rows[j]))
                          for i, j in zip(a, b)], dtype=np.float32)
 
 

@@ -33,7 +33,8 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(_ffi.ScoredPoint) == 8          # ScoredPointOffset is 8 bytes, #[repr(C)]
     assert C.sizeof(_ffi.Counters) == 32
     assert C.sizeof(_ffi.SqParams) == 20
-    assert C.sizeof(_ffi.SegmentDesc) == 64
+    assert C.sizeof(_ffi.SegmentDesc) == 72
+    assert C.sizeof(_ffi.BqParams) == 24
 
 
 def test_no_cpu_fallback_without_a_device():

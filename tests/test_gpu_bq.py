@@ -157,3 +157,39 @@ def test_bq_argument_errors(qa):
     st = qa.EncodedVectorsBin(np.zeros((0, 16), dtype=np.uint8), quant)    # empty storage
     got = qa.BatchFilteredSearcher(np.ones((2, 100), dtype=np.float32), st, 5).peek_top_all()
     assert all(len(r) == 0 for r in got)
+
+
+@pytest.mark.parametrize("encoding", [1, 2])                      # Encoding::TwoBits, Encoding::OneAndHalfBits
+@pytest.mark.parametrize("dist", [O.DOT, O.EUCLID])
+@pytest.mark.parametrize("dim", [1, 7, 64, 65, 129, 768])
+@pytest.mark.parametrize("with_stats", [True, False])
+def test_bq_two_bit_encodings(qa, encoding, dist, dim, with_stats):
+    """encode_two_bits_vector / encode_one_and_half_bits_vector (encoded_vectors_binary.rs:570-672) with given VectorStats, the
+    row sizes of :829-840, queries encoded the same way (SameAsStorage), scores = the one-bit metric over the longer rows with the
+    original dim.  Bit-exact vs the oracle; brute-force top-k on top."""
+    n, nq = 500, 4
+    rng = np.random.default_rng(dim * 3 + encoding + dist)
+    vecs = (rng.standard_normal((n, dim)) * rng.uniform(0.2, 2.0, dim) + rng.uniform(-0.5, 0.5, dim)).astype(np.float32)
+    mean = vecs.mean(axis=0).astype(np.float32) if with_stats else None
+    stddev = vecs.std(axis=0).astype(np.float32) if with_stats else None
+    if with_stats and dim > 2:
+        stddev[1] = 0.0                                              # sd < EPSILON: plain sign bit, no second bit
+    quant = qa.BinaryQuantizer(dim, _dist(qa, dist), encoding=encoding, mean=mean, stddev=stddev)
+    obq = O.BqOracle(dist, dim, encoding=encoding, mean=mean, stddev=stddev)
+    ext = 2 * dim if encoding == 1 else (3 * dim + 1) // 2
+    assert quant.quantized_vector_size() == obq.row_bytes == (max(ext, 1) + 127) // 128 * 16
+    want_rows = obq.encode_rows(vecs)
+    got_rows = quant.encode(vecs)
+    assert np.array_equal(got_rows, want_rows)
+    st = qa.EncodedVectorsBin(got_rows, quant)
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    scorer = qa.new_raw_scorer(queries, st)
+    for i in range(nq):
+        assert np.array_equal(scorer.encoded_query(i), obq.encode(queries[i])[0])
+    ids = rng.permutation(n).astype(np.uint32)[:200]
+    want = obq.score_points(queries, ids)
+    assert np.array_equal(_bits(scorer.score_points(ids)), _bits(want))
+    got = qa.BatchFilteredSearcher(queries, st, 5).peek_top_all()
+    allsc = obq.score_points(queries, np.arange(n))
+    for qi in range(nq):
+        assert np.array_equal(_bits(got[qi]["score"]), _bits(np.sort(allsc[qi])[::-1][:5]))
