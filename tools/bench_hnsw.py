@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--cpu-max-rows", type=int, default=2_000_000, help="above this the oracle (host copy of the rows) is skipped")
     ap.add_argument("--max-batch", type=int, default=0)
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 8)
+    ap.add_argument("--filter", type=float, default=0.0, help="also run a payload-filtered search (allow bitmap of this selectivity): plain filtered walk vs ACORN")
     args = ap.parse_args()
 
     import numpy as np
@@ -191,6 +192,30 @@ def main():
             if oversample == 1:
                 out["cpu_recall_at_10"] = round(recall(cpu_res), 4)
         print(json.dumps(out), flush=True)
+
+        if args.filter > 0.0 and which == "f32":
+            # ScorerFilters' payload filter as an allow bitmap: the plain walk only traverses passing points, ACORN (graph_layers.rs:154-243)
+            # explores through the others
+            allowed = (torch.rand(n, generator=gen, device=dev) < args.filter).cpu().numpy()
+            scorer.set_filter(allowed)
+            fs = qa.BatchFilteredSearcher(queries[:exact_n], vs, top)
+            fs.scorer.set_filter(allowed)
+            exact_f = fs.peek_top_all()
+            rec = lambda res: sum(len(set(a["idx"].tolist()) & set(b["idx"].tolist())) for a, b in zip(res[:exact_n], exact_f)) / float(max(1, sum(len(b) for b in exact_f)))   # noqa: E731
+            for acorn in (False, True):
+                graph.search(top, args.ef, scorer, acorn=acorn)
+                F.check(lib.qmx_query_timing(scorer._h, C.byref(ms), C.byref(nl)))
+                t0 = time.time()
+                res, scored = graph.search(top, args.ef, scorer, with_scored=True, acorn=acorn)
+                wall_f = time.time() - t0
+                F.check(lib.qmx_query_timing(scorer._h, C.byref(ms), C.byref(nl)))
+                kms = ms.value / max(nl.value, 1)
+                print(json.dumps({"metric": "filtered HNSW search QPS (device-resident walk)", "algorithm": "acorn" if acorn else "hnsw", "scorer": which,
+                                  "filter_selectivity": args.filter, "rows": n, "dim": dim, "m": args.m, "ef": args.ef, "top": top, "nq": nq,
+                                  "qps_kernel": round(nq / (kms * 1e-3), 1), "kernel_ms": round(kms, 3), "qps_wall_incl_copies": round(nq / wall_f, 1),
+                                  "points_scored_per_query": round(scored / nq, 1),
+                                  "recall_at_10_vs_exact_filtered": round(rec(res), 4)}), flush=True)
+            scorer.set_filter(None)
 
 
 if __name__ == "__main__":
