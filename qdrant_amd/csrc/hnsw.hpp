@@ -301,8 +301,9 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
                     const bool valid = on && id < h.n_points;
                     const uint32_t bit = 1u << (id & 31);
                     const uint32_t old = valid ? atomicOr(&vis[id >> 5], bit) : bit;      // check_and_update_visited
+                    const bool lv = valid ? a.del.live(id) : false;                        // filters().check_vector(hop1), in flight with it
                     const bool fresh = valid && !(old & bit);
-                    const bool ok = fresh && a.del.live(id);                               // filters().check_vector(hop1)
+                    const bool ok = fresh && lv;
                     const uint64_t okm = __ballot(ok), frm = __ballot(fresh);
                     int brk = 64;
                     const uint32_t need = hop_limit - n_score;
@@ -319,23 +320,42 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
                 }
             }
             __syncthreads();
-            // 2-hop neighbours (:213-235): the links of every explored node, at most hop_limit scored per node
+            // 2-hop neighbours (:213-235): the links of every explored node, at most hop_limit scored per node.  The walk is a chain of
+            // dependent memory round trips, so per node they are cut to two: the links of node e + 1 are fetched while node e is
+            // resolved, and the three lookups of a link (hop-1 bit, hop-2 test-and-set, filter bits) go out together - a hop-2 bit
+            // set for a link that turns out to sit in the hop-1 list is taken back, as the reference never sets it.
+            uint32_t nx_id = 0;
+            uint64_t nx_o1 = 0;
+            bool nx_on = false;
+            auto fetch_links = [&](uint32_t node) {
+                if (h.l0) { nx_o1 = h.l0[(uint64_t)node * h.l0_stride]; } else { nx_o1 = h.offsets[(uint64_t)node + 1] - h.offsets[node]; }
+                const uint64_t o0 = h.l0 ? 0 : h.offsets[node];
+                nx_id = link_of(node, o0, o0 + 64, &nx_on);          // validity against the real count is applied when the node is resolved
+            };
+            if (n_explore) fetch_links(to_explore[0]);
             for (uint32_t e = 0; e < n_explore; ++e) {
                 const uint32_t node = to_explore[e];
-                uint64_t o0, o1;
-                if (h.l0) { o0 = 0; o1 = h.l0[(uint64_t)node * h.l0_stride]; } else { o0 = h.offsets[node]; o1 = h.offsets[(uint64_t)node + 1]; }
+                const uint64_t cnt = nx_o1;
+                uint32_t id0 = nx_id;
+                if (e + 1 < n_explore) fetch_links(to_explore[e + 1]);
+                const uint64_t o0 = h.l0 ? 0 : h.offsets[node];
+                const uint64_t o1 = o0 + cnt;
                 uint32_t added = 0;
                 bool broke = false;
                 for (uint64_t base = o0; base < o1 && !broke; base += 64) {
-                    bool on;
-                    const uint32_t id = link_of(node, base, o1, &on);
+                    bool on = base + (uint64_t)lane < o1;
+                    uint32_t id = id0;
+                    if (base != o0) id = link_of(node, base, o1, &on);     // (more than 64 links: not reached with m0 <= 64)
                     const bool valid = on && id < h.n_points;
                     const uint32_t bit = 1u << (id & 31);
-                    const bool s1 = valid ? (atomicOr(&vis[id >> 5], 0u) & bit) != 0 : true;            // hop1_visited_list.check(hop2)
-                    const bool c1 = valid && !s1;
-                    const uint32_t old2 = c1 ? atomicOr(&vis[half + (id >> 5)], bit) : bit;             // hop2_visited_list.check_and_update_visited(hop2)
-                    const bool fresh = c1 && !(old2 & bit);
-                    const bool ok = fresh && a.del.live(id);
+                    const uint32_t r1 = valid ? atomicOr(&vis[id >> 5], 0u) : bit;                        // hop1_visited_list.check(hop2)
+                    const uint32_t old2 = valid ? atomicOr(&vis[half + (id >> 5)], bit) : bit;            // hop2_visited_list.check_and_update_visited(hop2)
+                    const bool lv = valid ? a.del.live(id) : false;                                       // filters().check_vector(hop2)
+                    const bool s1 = (r1 & bit) != 0;
+                    const bool set2 = valid && !(old2 & bit);            // this lane set the hop-2 bit
+                    if (s1 && set2) atomicAnd(&vis[half + (id >> 5)], ~bit);
+                    const bool fresh = valid && !s1 && set2;
+                    const bool ok = fresh && lv;
                     const uint64_t okm = __ballot(ok);
                     int brk = 64;
                     const uint32_t need = hop_limit - added;
