@@ -445,11 +445,41 @@ QMX_API int32_t qmx_hnsw_create(const qmx_hnsw_desc *desc, qmx_hnsw **out);
  * offsets_padding_bytes, [u8; 24]} (graph_links/header.rs:9-20, 64 bytes), level_offsets
  * [levels_count] u64, reindex [point_count] u32, neighbors u32, padding, offsets u64.
  * `desc` supplies m, m0, the entry points and the device; its array fields are ignored.
- * Compressed formats (header version 0xFFFF_FFFF_FFFF_FF01/02) => QMX_ERR_NOT_SUPPORTED:
- * convert with `GraphLinks::to_edges` + the plain serializer first. */
+ * Compressed formats (header version 0xFFFF_FFFF_FFFF_FF01/02) => QMX_ERR_NOT_SUPPORTED here:
+ * use qmx_hnsw_create_from_file, which reads all three formats. */
 QMX_API int32_t qmx_hnsw_create_from_plain_file(const void *bytes, uint64_t n_bytes, const qmx_hnsw_desc *desc,
                                                 qmx_hnsw **out);
 QMX_API int32_t qmx_hnsw_destroy(qmx_hnsw *g);
+/* The graph-links file in ANY of the reference's three formats (`GraphLinksFormat`,
+ * graph_links/format.rs): Plain (above), Compressed (HeaderCompressed, header.rs:22-37, version
+ * 0xFFFF_FFFF_FFFF_FF01: links bit-packed by `pack_links`, lib/common/common/src/bitpacking_links.rs:38-82,
+ * offsets by `bitpacking_ordered::compress`, bitpacking_ordered.rs:69-105) and CompressedWithVectors
+ * (HeaderCompressedWithVectors, header.rs:39-54, version ..FF02: per node [base vector on level 0]
+ * [varint count][packed links][padding][link vectors][padding], serializer.rs:127-171).
+ * Replaces `GraphLinksView::load` + `links()` (graph_links/view.rs:110-208, 244-275): the file is
+ * decoded ONCE on the host into the plain arrays below (the order of a node's links is the
+ * iterator's: the first level_m links ascending, as `pack_links` sorted them) and uploaded; the
+ * inline vectors of the ..FF02 format are skipped (the rows are resident in HBM already).
+ * Host-only, needs no device: every section is bounds-checked against n_bytes. */
+typedef struct qmx_graph_links {
+    uint32_t format;                  /* 0 Plain, 1 Compressed, 2 CompressedWithVectors           */
+    uint32_t m, m0;                   /* HnswM of the header (compressed formats); 0 for Plain     */
+    uint32_t n_points, n_levels;
+    uint32_t reserved;
+    uint64_t n_offsets, n_neighbors;
+    const uint32_t *reindex;          /* [n_points]                                               */
+    const uint64_t *level_offsets;    /* [n_levels + 1]; last = n_offsets - 1                     */
+    const uint64_t *offsets;          /* [n_offsets], in links (not bytes)                        */
+    const uint32_t *neighbors;        /* [n_neighbors]                                            */
+    void *owner;                      /* library-owned storage behind the four arrays             */
+} qmx_graph_links;
+QMX_API int32_t qmx_graph_links_decode(const void *bytes, uint64_t n_bytes, qmx_graph_links *out);
+QMX_API void qmx_graph_links_free(qmx_graph_links *links);
+/* qmx_graph_links_decode + qmx_hnsw_create.  `desc` supplies the entry points and the device (and m, m0
+ * for a Plain file); for the compressed formats m / m0 come from the header and a non-zero desc->m / m0
+ * that disagrees is QMX_ERR_BAD_ARG. */
+QMX_API int32_t qmx_hnsw_create_from_file(const void *bytes, uint64_t n_bytes, const qmx_hnsw_desc *desc, qmx_hnsw **out);
+
 
 /* `GraphLayers::search(top, ef, SearchAlgorithm::Hnsw, FilteredScorer, None, is_stopped)`
  * (graph_layers.rs:530-562) for every query of the batch `q`, entirely on device: entry point

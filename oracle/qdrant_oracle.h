@@ -225,6 +225,23 @@ uint32_t qo_links_heuristic(const qo_scored_point *sorted_candidates, uint32_t n
 uint32_t qo_links_connect(uint32_t *links, uint32_t len, uint32_t new_point, uint32_t target, uint32_t level_m,
                           const float *score_table, uint32_t n);
 
+/* ---- compressed graph-links files (qdrant_oracle_links.c; bitpacking.rs, bitpacking_links.rs, bitpacking_ordered.rs,
+ *      graph_links/serializer.rs + header.rs) ---- */
+uint64_t qo_bitpack_write(const uint64_t *values, const uint8_t *bits, uint32_t n, uint8_t *out, uint64_t cap);
+void qo_bitpack_read(const uint8_t *data, uint64_t len, const uint8_t *bits, uint32_t n, uint64_t *values);
+uint64_t qo_pack_links(uint32_t *raw_links, uint32_t n, uint8_t bits_per_unsorted, uint32_t sorted_count, uint8_t *out, uint64_t cap);
+uint32_t qo_iterate_packed_links(const uint8_t *links, uint64_t len, uint8_t bits_per_unsorted, uint32_t sorted_count, uint32_t *out,
+                                 uint32_t cap);
+uint64_t qo_packed_links_size(const uint8_t *data, uint64_t len, uint8_t bits_per_unsorted, uint32_t sorted_count, uint32_t total_count);
+uint64_t qo_ordered_compress(const uint64_t *values, uint64_t n, uint8_t *out, uint64_t cap, uint8_t *params3);
+uint64_t qo_ordered_compress_with(const uint64_t *values, uint64_t n, uint8_t base_bits, uint8_t delta_bits, uint8_t chunk_len_log2,
+                                  uint8_t *out, uint64_t cap);
+uint64_t qo_ordered_get(const uint8_t *data, uint64_t length, uint8_t base_bits, uint8_t delta_bits, uint8_t chunk_len_log2, uint64_t index);
+uint64_t qo_links_serialize_compressed(uint32_t m, uint32_t m0, uint32_t n_points, uint32_t n_levels, const uint32_t *reindex,
+                                       const uint64_t *level_offsets, const uint64_t *offsets, const uint32_t *neighbors,
+                                       int with_vectors, uint64_t base_size, uint8_t base_align, const uint8_t *base_vectors,
+                                       uint64_t link_size, uint8_t link_align, const uint8_t *link_vectors, uint8_t *out, uint64_t cap);
+
 /* ---- synthetic data shared bit-for-bit with the device generator ---- */
 float qo_synth_value(uint64_t seed, uint64_t row, uint32_t col, uint32_t dim);
 void qo_synth_fill_f32(uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, float *out);

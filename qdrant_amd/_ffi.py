@@ -66,6 +66,14 @@ class HnswDesc(C.Structure):
                 ("extra_entry_point_levels", C.c_void_p), ("device_id", C.c_int32), ("reserved", C.c_int32)]
 
 
+class GraphLinks(C.Structure):
+    """qmx_graph_links: a links file decoded on the host (library-owned arrays, qmx_graph_links_free)."""
+    _fields_ = [("format", C.c_uint32), ("m", C.c_uint32), ("m0", C.c_uint32), ("n_points", C.c_uint32), ("n_levels", C.c_uint32),
+                ("reserved", C.c_uint32), ("n_offsets", C.c_uint64), ("n_neighbors", C.c_uint64),
+                ("reindex", C.POINTER(C.c_uint32)), ("level_offsets", C.POINTER(C.c_uint64)), ("offsets", C.POINTER(C.c_uint64)),
+                ("neighbors", C.POINTER(C.c_uint32)), ("owner", C.c_void_p)]
+
+
 class HnswBuildParams(C.Structure):
     _fields_ = [("m", C.c_uint32), ("m0", C.c_uint32), ("ef_construct", C.c_uint32), ("entry_points_num", C.c_uint32),
                 ("seed", C.c_uint64), ("max_batch", C.c_uint32), ("reserved", C.c_uint32)]
@@ -134,6 +142,9 @@ SIGNATURES = {
     "qmx_merge_topk_async": (C.c_int32, [C.c_int32, _P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P]),
     "qmx_hnsw_create": (C.c_int32, [C.POINTER(HnswDesc), C.POINTER(_P)]),
     "qmx_hnsw_create_from_plain_file": (C.c_int32, [_P, C.c_uint64, C.POINTER(HnswDesc), C.POINTER(_P)]),
+    "qmx_hnsw_create_from_file": (C.c_int32, [_P, C.c_uint64, C.POINTER(HnswDesc), C.POINTER(_P)]),
+    "qmx_graph_links_decode": (C.c_int32, [_P, C.c_uint64, C.POINTER(GraphLinks)]),
+    "qmx_graph_links_free": (None, [C.POINTER(GraphLinks)]),
     "qmx_hnsw_destroy": (C.c_int32, [_P]),
     "qmx_hnsw_build": (C.c_int32, [_P, C.POINTER(HnswBuildParams), C.POINTER(_P)]),
     "qmx_hnsw_get_info": (C.c_int32, [_P, C.POINTER(HnswInfo)]),

@@ -72,6 +72,28 @@ class GraphLayers:
         return self
 
     @classmethod
+    def from_file(cls, data: bytes, entry_point_ids, entry_point_levels, extra_entry_point_ids=(), extra_entry_point_levels=(),
+                  m: int = 0, m0: int = 0, device_id: int = 0):
+        """The bytes of a graph-links file in any `GraphLinksFormat` (Plain needs m / m0; the compressed headers carry
+        them): `GraphLinksView::load` (graph_links/view.rs:110-208) done once on the host, then the upload."""
+        self = cls.__new__(cls)
+        ep, epl, xp, xpl = _u32(entry_point_ids), _u32(entry_point_levels), _u32(extra_entry_point_ids), _u32(extra_entry_point_levels)
+        buf = np.frombuffer(data, dtype=np.uint8)
+        self._keep = [ep, epl, xp, xpl, buf]
+        d = F.HnswDesc()
+        d.m, d.m0 = int(m), int(m0)
+        d.entry_point_ids, d.entry_point_levels, d.n_entry_points = F.ptr(ep).value, F.ptr(epl).value, len(ep)
+        d.extra_entry_point_ids, d.extra_entry_point_levels, d.n_extra_entry_points = F.ptr(xp).value, F.ptr(xpl).value, len(xp)
+        d.device_id = device_id
+        self._h = C.c_void_p()
+        F.check(F.lib().qmx_hnsw_create_from_file(F.ptr(buf), len(buf), C.byref(d), C.byref(self._h)))
+        info = F.HnswInfo()
+        F.check(F.lib().qmx_hnsw_get_info(self._h, C.byref(info)))
+        self.m, self.m0, self.n_points = info.m, info.m0, info.n_points
+        self.counters = F.Counters()
+        return self
+
+    @classmethod
     def build(cls, storage, m: int = 16, m0: Optional[int] = None, ef_construct: int = 100, seed: int = 42,
               entry_points_num: int = 10, max_batch: int = 0):
         """`GraphLayersBuilder` over a dense f32 / f16 VectorStorage, on its GPU (qmx_hnsw_build)."""
@@ -133,3 +155,23 @@ class GraphLayers:
             self.close()
         except Exception:
             pass
+
+
+def decode_links_file(data: bytes):
+    """qmx_graph_links_decode: a graph-links file (Plain / Compressed / CompressedWithVectors) unpacked on the host into the
+    plain arrays.  Needs no device.  Returns an object with format, m, m0, reindex, level_offsets, offsets, neighbors."""
+    buf = np.frombuffer(data, dtype=np.uint8)
+    g = F.GraphLinks()
+    F.check(F.lib().qmx_graph_links_decode(F.ptr(buf), len(buf), C.byref(g)))
+    try:
+        class Links:
+            pass
+        o = Links()
+        o.format, o.m, o.m0 = g.format, g.m, g.m0
+        o.reindex = np.ctypeslib.as_array(g.reindex, (g.n_points,)).copy() if g.n_points else np.zeros(0, np.uint32)
+        o.level_offsets = np.ctypeslib.as_array(g.level_offsets, (g.n_levels + 1,)).copy()
+        o.offsets = np.ctypeslib.as_array(g.offsets, (g.n_offsets,)).copy()
+        o.neighbors = np.ctypeslib.as_array(g.neighbors, (g.n_neighbors,)).copy() if g.n_neighbors else np.zeros(0, np.uint32)
+        return o
+    finally:
+        F.lib().qmx_graph_links_free(C.byref(g))

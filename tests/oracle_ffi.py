@@ -593,3 +593,85 @@ def links_connect(links, new_point, target, level_m, score_table):
     buf[:len(links)] = links
     n = _lib.qo_links_connect(_p(buf), len(links), new_point, target, level_m, _p(t), t.shape[0])
     return buf[:n].tolist()
+
+
+# ---- compressed graph-links files (oracle/qdrant_oracle_links.c) ----------------------------------------------------
+_u8c, _u32c, _u64c = C.c_uint8, C.c_uint32, C.c_uint64
+_sig("qo_bitpack_write", _u64c, [_P, _P, _u32c, _P, _u64c])
+_sig("qo_bitpack_read", None, [_P, _u64c, _P, _u32c, _P])
+_sig("qo_pack_links", _u64c, [_P, _u32c, _u8c, _u32c, _P, _u64c])
+_sig("qo_iterate_packed_links", _u32c, [_P, _u64c, _u8c, _u32c, _P, _u32c])
+_sig("qo_packed_links_size", _u64c, [_P, _u64c, _u8c, _u32c, _u32c])
+_sig("qo_ordered_compress", _u64c, [_P, _u64c, _P, _u64c, _P])
+_sig("qo_ordered_compress_with", _u64c, [_P, _u64c, _u8c, _u8c, _u8c, _P, _u64c])
+_sig("qo_ordered_get", _u64c, [_P, _u64c, _u8c, _u8c, _u8c, _u64c])
+_sig("qo_links_serialize_compressed", _u64c, [_u32c, _u32c, _u32c, _u32c, _P, _P, _P, _P, C.c_int, _u64c, _u8c, _P, _u64c, _u8c, _P,
+                                              _P, _u64c])
+
+
+def bitpack_write(values, bits) -> bytes:
+    """BitWriter (lib/common/common/src/bitpacking.rs:11-57): write(value, bits)... finish()."""
+    v, b = np.ascontiguousarray(values, dtype=np.uint64), np.ascontiguousarray(bits, dtype=np.uint8)
+    out = np.zeros(8 * len(v) + 8, dtype=np.uint8)
+    n = _lib.qo_bitpack_write(_p(v), _p(b), len(v), _p(out), len(out))
+    return out[:n].tobytes()
+
+
+def bitpack_read(data: bytes, bits):
+    """BitReader (bitpacking.rs:60-131): set_bits(b); read() per entry of `bits`."""
+    d, b = np.frombuffer(data, dtype=np.uint8).copy(), np.ascontiguousarray(bits, dtype=np.uint8)
+    out = np.zeros(len(b), dtype=np.uint64)
+    _lib.qo_bitpack_read(_p(d), len(d), _p(b), len(b), _p(out))
+    return out
+
+
+def pack_links(raw_links, bits_per_unsorted, sorted_count):
+    """pack_links (bitpacking_links.rs:38-82) -> (bytes, raw_links as the reference leaves them: first sorted_count sorted)."""
+    raw = np.ascontiguousarray(raw_links, dtype=np.uint32).copy()
+    out = np.zeros(8 * len(raw) + 16, dtype=np.uint8)
+    n = _lib.qo_pack_links(_p(raw), len(raw), bits_per_unsorted, sorted_count, _p(out), len(out))
+    return out[:n].tobytes(), raw
+
+
+def iterate_packed_links(data: bytes, bits_per_unsorted, sorted_count):
+    """iterate_packed_links(..).collect() (bitpacking_links.rs:90-207)."""
+    d = np.frombuffer(data, dtype=np.uint8).copy()
+    out = np.zeros(max(1, len(d)), dtype=np.uint32)
+    n = _lib.qo_iterate_packed_links(_p(d) if len(d) else None, len(d), bits_per_unsorted, sorted_count, _p(out), len(out))
+    return out[:n].copy()
+
+
+def packed_links_size(data: bytes, bits_per_unsorted, sorted_count, total_count):
+    d = np.frombuffer(data, dtype=np.uint8).copy()
+    return int(_lib.qo_packed_links_size(_p(d) if len(d) else None, len(d), bits_per_unsorted, sorted_count, total_count))
+
+
+def ordered_compress(values):
+    """bitpacking_ordered::compress (bitpacking_ordered.rs:69-73) -> (bytes, (base_bits, delta_bits, chunk_len_log2))."""
+    v = np.ascontiguousarray(values, dtype=np.uint64)
+    prm = np.zeros(3, dtype=np.uint8)
+    n = _lib.qo_ordered_compress(_p(v) if len(v) else None, len(v), None, 0, _p(prm))
+    out = np.zeros(n, dtype=np.uint8)
+    _lib.qo_ordered_compress(_p(v) if len(v) else None, len(v), _p(out), n, _p(prm))
+    return out.tobytes(), tuple(int(x) for x in prm)
+
+
+def ordered_get(data: bytes, length, params, index):
+    d = np.frombuffer(data, dtype=np.uint8).copy()
+    return int(_lib.qo_ordered_get(_p(d), length, params[0], params[1], params[2], index))
+
+
+def compressed_links_file(p: "PlainLinks", base_vectors=None, link_vectors=None, base_align=1, link_align=1) -> bytes:
+    """serialize_graph_links(edges, Compressed | CompressedWithVectors, HnswM{m, m0}) (graph_links/serializer.rs:23-243) of the
+    graph held in the plain arrays `p`.  With vectors: base_vectors [n, base_size] u8, link_vectors [n, link_size] u8."""
+    re, lo = np.ascontiguousarray(p.reindex, dtype=np.uint32), np.ascontiguousarray(p.level_offsets, dtype=np.uint64)
+    off, nb = np.ascontiguousarray(p.offsets, dtype=np.uint64), np.ascontiguousarray(p.neighbors, dtype=np.uint32)
+    wv = base_vectors is not None
+    bv = np.ascontiguousarray(base_vectors, dtype=np.uint8) if wv else None
+    lv = np.ascontiguousarray(link_vectors, dtype=np.uint8) if wv else None
+    args = [p.m, p.m0, len(re), len(lo) - 1, _p(re), _p(lo), _p(off), _p(nb) if len(nb) else None, 1 if wv else 0,
+            bv.shape[1] if wv else 0, base_align, _p(bv), lv.shape[1] if wv else 0, link_align, _p(lv)]
+    n = _lib.qo_links_serialize_compressed(*args, None, 0)
+    out = np.zeros(n, dtype=np.uint8)
+    _lib.qo_links_serialize_compressed(*args, _p(out), n)
+    return out.tobytes()

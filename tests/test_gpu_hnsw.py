@@ -282,6 +282,28 @@ def test_plain_links_file_ingestion(qa):
     _same(from_file.search(10, 64, scorer), g.search_dense(st, queries, 10, 64))
 
 
+def test_compressed_links_file_ingestion(qa):
+    """The reference's COMPRESSED graph-links files (GraphLinksFormat::Compressed / CompressedWithVectors,
+    graph_links/serializer.rs:23-243) upload through qmx_hnsw_create_from_file; the device walk equals the oracle's walk of
+    the same (re-ordered: first level_m links ascending) lists."""
+    from qdrant_amd.hnsw import decode_links_file
+    n, dim, m, nq = 2000, 32, 8, 16
+    rows, st, g, plain = _graph(O.COSINE, n, dim, m, 0x5EED0390)
+    queries = O.synth(0x5EED0391, 0, nq, dim)
+    vs = qa.VectorStorage(rows, qa.Distance.Cosine)
+    scorer = qa.new_raw_scorer(queries, vs)
+    rng = np.random.default_rng(1)
+    files = [O.compressed_links_file(plain),
+             O.compressed_links_file(plain, rng.integers(0, 256, (n, 16), dtype=np.uint8), rng.integers(0, 256, (n, 8), dtype=np.uint8), 8, 8)]
+    for data in files:
+        d = decode_links_file(data)
+        twin = O.Hnsw.from_plain(O.PlainLinks(d.m, d.m0, d.reindex, d.level_offsets, d.offsets, d.neighbors, plain.ep_ids,
+                                              plain.ep_levels, plain.xp_ids, plain.xp_levels), n)
+        graph = qa.GraphLayers.from_file(data, plain.ep_ids, plain.ep_levels, plain.xp_ids, plain.xp_levels)
+        assert (graph.n_points, graph.m, graph.m0) == (n, plain.m, plain.m0)
+        _same(graph.search(10, 64, scorer), twin.search_dense(st, queries, 10, 64))
+
+
 def test_payload_filter_bitmap_brute_force_and_walk(qa):
     """ScorerFilters' payload filter as an allow bitmap (qmx_query_set_filter): for the oracle a rejected point is a
     deleted point (`check_vector` = not deleted AND filter), so both must agree — brute force and filtered walk."""
