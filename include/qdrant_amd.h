@@ -166,6 +166,32 @@ typedef struct qmx_segment_desc {
     const qmx_bq_params *bq;   /* optional for QMX_DTYPE_BQ: NULL = Encoding::OneBit */
 } qmx_segment_desc;
 
+/* The quantizers' metadata file ("quantized.meta.json", vector_storage/quantized/quantized_vectors/config.rs:13) as
+ * serde_json wrote it: `MetadataInt8` (encoded_vectors_u8.rs:43-47, 84-91), PQ `Metadata` (encoded_vectors_pq.rs:46-51),
+ * BQ `Metadata` (encoded_vectors_binary.rs:112-125), each with `VectorParameters` (encoded_vectors.rs:28-39).
+ * qmx_quant_meta_parse is the read side of `EncodedVectors*::load`: it fills the parameter struct qmx_segment_desc takes
+ * for `dtype` (the other two stay zero).  Floats go through f64 and narrow to f32 exactly like serde_json, so values the
+ * reference wrote come back bit-identical.  Pointers inside (`pq.centroids`, `bq.mean`, `bq.stddev`) are library-owned
+ * host arrays, valid until qmx_quant_meta_free.  Host only: needs no device.
+ * PQ: `vector_division` must be the uniform division the reference itself produces (get_vector_division :164-169),
+ * anything else is QMX_ERR_NOT_SUPPORTED. */
+typedef struct qmx_quant_meta {
+    uint32_t dtype;                 /* QMX_DTYPE_SQ_U8 | QMX_DTYPE_PQ | QMX_DTYPE_BQ, as asked                */
+    uint32_t dim;                   /* VectorParameters.dim                                                  */
+    uint32_t distance;              /* qmx_distance of VectorParameters.distance_type (L1 = Manhattan, L2 = Euclid) */
+    uint8_t invert;                 /* VectorParameters.invert                                               */
+    uint8_t has_deprecated_count;   /* VectorParameters.count was present                                    */
+    uint8_t bq_query_encoding;      /* QueryEncoding: 0 SameAsStorage, 1 Scalar4bits, 2 Scalar8bits          */
+    uint8_t pad_;
+    uint64_t deprecated_count;
+    qmx_sq_params sq;
+    qmx_pq_params pq;
+    qmx_bq_params bq;
+    void *owner;
+} qmx_quant_meta;
+QMX_API int32_t qmx_quant_meta_parse(uint32_t dtype, const char *json, uint64_t n_bytes, qmx_quant_meta *out);
+QMX_API void qmx_quant_meta_free(qmx_quant_meta *meta);
+
 typedef struct qmx_segment qmx_segment;
 typedef struct qmx_query qmx_query;
 typedef struct qmx_hnsw qmx_hnsw;

@@ -66,6 +66,13 @@ class HnswDesc(C.Structure):
                 ("extra_entry_point_levels", C.c_void_p), ("device_id", C.c_int32), ("reserved", C.c_int32)]
 
 
+class QuantMeta(C.Structure):
+    """qmx_quant_meta: a parsed quantized.meta.json (library-owned arrays, qmx_quant_meta_free)."""
+    _fields_ = [("dtype", C.c_uint32), ("dim", C.c_uint32), ("distance", C.c_uint32), ("invert", C.c_uint8),
+                ("has_deprecated_count", C.c_uint8), ("bq_query_encoding", C.c_uint8), ("pad_", C.c_uint8),
+                ("deprecated_count", C.c_uint64), ("sq", SqParams), ("pq", PqParams), ("bq", BqParams), ("owner", C.c_void_p)]
+
+
 class GraphLinks(C.Structure):
     """qmx_graph_links: a links file decoded on the host (library-owned arrays, qmx_graph_links_free)."""
     _fields_ = [("format", C.c_uint32), ("m", C.c_uint32), ("m0", C.c_uint32), ("n_points", C.c_uint32), ("n_levels", C.c_uint32),
@@ -143,6 +150,8 @@ SIGNATURES = {
     "qmx_hnsw_create": (C.c_int32, [C.POINTER(HnswDesc), C.POINTER(_P)]),
     "qmx_hnsw_create_from_plain_file": (C.c_int32, [_P, C.c_uint64, C.POINTER(HnswDesc), C.POINTER(_P)]),
     "qmx_hnsw_create_from_file": (C.c_int32, [_P, C.c_uint64, C.POINTER(HnswDesc), C.POINTER(_P)]),
+    "qmx_quant_meta_parse": (C.c_int32, [C.c_uint32, C.c_char_p, C.c_uint64, C.POINTER(QuantMeta)]),
+    "qmx_quant_meta_free": (None, [C.POINTER(QuantMeta)]),
     "qmx_graph_links_decode": (C.c_int32, [_P, C.c_uint64, C.POINTER(GraphLinks)]),
     "qmx_graph_links_free": (None, [C.POINTER(GraphLinks)]),
     "qmx_hnsw_destroy": (C.c_int32, [_P]),

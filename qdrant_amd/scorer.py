@@ -389,6 +389,36 @@ class EncodedVectorsBin(VectorStorage):
         return out
 
 
+def load_quantizer(meta_json, dtype: int):
+    """`EncodedVectors{U8,PQ,Bin}::load`'s metadata half: the text of a segment's "quantized.meta.json"
+    (vector_storage/quantized/quantized_vectors/config.rs:13) -> ScalarQuantizer | ProductQuantizer | BinaryQuantizer,
+    parsed by the library (`qmx_quant_meta_parse`, host only).  Every value is taken from the file as written
+    (alpha, offset, multiplier, invert, centroids, stats), not re-derived."""
+    data = meta_json.encode() if isinstance(meta_json, str) else bytes(meta_json)
+    m = F.QuantMeta()
+    F.check(F.lib().qmx_quant_meta_parse(int(dtype), data, len(data), C.byref(m)))
+    try:
+        distance = Distance(m.distance)
+        if dtype == F.DTYPE_SQ_U8:
+            q = ScalarQuantizer(m.dim, distance, m.sq.alpha, m.sq.offset)
+            q.actual_dim, q.multiplier, q.invert = int(m.sq.actual_dim), np.float32(m.sq.multiplier), bool(m.sq.invert)
+            return q
+        if dtype == F.DTYPE_PQ:
+            cen = np.ctypeslib.as_array(C.cast(m.pq.centroids, C.POINTER(C.c_float)), (m.pq.n_centroids, m.dim)).copy()
+            q = ProductQuantizer(m.dim, distance, m.pq.chunk_size, cen)
+            q.invert = bool(m.pq.invert)
+            return q
+        mean = stddev = None
+        if m.bq.mean:
+            mean = np.ctypeslib.as_array(C.cast(m.bq.mean, C.POINTER(C.c_float)), (m.dim,)).copy()
+            stddev = np.ctypeslib.as_array(C.cast(m.bq.stddev, C.POINTER(C.c_float)), (m.dim,)).copy()
+        if m.bq_query_encoding != 0:
+            raise F.QmxError(F.ERR_NOT_SUPPORTED, "binary quantization with a scalar query encoding is not built (SameAsStorage only)")
+        return BinaryQuantizer(m.dim, distance, bool(m.invert), int(m.bq.encoding), mean, stddev)
+    finally:
+        F.lib().qmx_quant_meta_free(C.byref(m))
+
+
 class RawScorer:
     """`Box<dyn RawScorer>` for a batch of `QueryVector::Nearest` queries (raw_scorer.rs:39-58).
     One instance holds `nq` scorers; single-query use is nq == 1."""
