@@ -1411,12 +1411,25 @@ static void fill_args_segment(const qmx_segment *s, ScanArgs &a) {
     a.row_stride = s->row_stride;
     a.dim = s->scan_dim;
     const uint32_t eb = elem_bytes(s->dtype);
-    const uint32_t full = s->scan_dim - s->scan_dim % 32;
+    const uint32_t full = s->dtype <= QMX_DTYPE_U8 ? s->scan_dim - s->scan_dim % 32 : s->scan_dim;   // as fill_args
     a.nseg = full * eb / 128;
     a.rem_pieces = (full * eb % 128) / 16;
     a.tail_start = full;
     a.del = s->deleted_view();
     a.flags = s->flags;
+    if (s->dtype == QMX_DTYPE_SQ_U8) {
+        a.sq_multiplier = s->sq.multiplier;
+        a.row_offsets = s->d_row_offsets;
+        // get_shift (encoded_vectors_u8.rs:116-134)
+        float shift = (s->distance == QMX_DISTANCE_DOT || s->distance == QMX_DISTANCE_COSINE)
+                          ? (float)s->sq.actual_dim * s->sq.offset * s->sq.offset : 0.0f;
+        a.sq_shift = s->sq.invert ? -shift : shift;
+    }
+}
+
+static int32_t launch_hnsw_build_any(const qmx_segment *seg, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu) {
+    if (seg->dtype == QMX_DTYPE_SQ_U8) return launch_hnsw_build_sq(nullptr, (int)seg->distance, a, h, phase, grid, per_cu);
+    return launch_hnsw_build_dense(nullptr, (int)seg->dtype, (int)seg->distance, a, h, phase, grid, per_cu);
 }
 
 int32_t qmx_hnsw_get_info(const qmx_hnsw *g, qmx_hnsw_info *out) {
@@ -1446,9 +1459,9 @@ int32_t qmx_hnsw_export_plain(const qmx_hnsw *g, uint32_t *reindex, uint64_t *le
 int32_t qmx_hnsw_build(const qmx_segment *seg, const qmx_hnsw_build_params *bp, qmx_hnsw **out) {
     QMX_REQUIRE(seg && bp && out, QMX_ERR_BAD_ARG, "NULL argument");
     *out = nullptr;
-    QMX_REQUIRE(seg->dtype == QMX_DTYPE_F32 || seg->dtype == QMX_DTYPE_F16, QMX_ERR_NOT_SUPPORTED,
-                "device HNSW build needs a dense f32 / f16 segment (dtype %u)", seg->dtype);
-    QMX_REQUIRE(seg->fast_layout(), QMX_ERR_NOT_SUPPORTED, "adopted device block is not 16-byte aligned");
+    QMX_REQUIRE(seg->dtype == QMX_DTYPE_F32 || seg->dtype == QMX_DTYPE_F16 || seg->dtype == QMX_DTYPE_SQ_U8, QMX_ERR_NOT_SUPPORTED,
+                "device HNSW build needs a dense f32 / f16 or an SQ-int8 segment (dtype %u)", seg->dtype);
+    QMX_REQUIRE(seg->dtype == QMX_DTYPE_SQ_U8 || seg->fast_layout(), QMX_ERR_NOT_SUPPORTED, "adopted device block is not 16-byte aligned");
     QMX_REQUIRE(bp->m >= 1 && bp->m0 >= bp->m && bp->m0 <= 64, QMX_ERR_BAD_ARG, "need 1 <= m <= m0 <= 64");
     QMX_REQUIRE(bp->ef_construct >= 1 && bp->ef_construct <= HNSW_MAX_EF, QMX_ERR_NOT_SUPPORTED, "ef_construct %u not in 1..%u",
                 bp->ef_construct, HNSW_MAX_EF);
@@ -1517,10 +1530,12 @@ int32_t qmx_hnsw_build(const qmx_segment *seg, const qmx_hnsw_build_params *bp, 
         h.ef_construct = bp->ef_construct;
         h.sel_ids = (uint32_t *)b_sel.p; h.sel_scores = (float *)b_sels.p; h.sel_cnt = (uint32_t *)b_selc.p;
         h.lock = (uint32_t *)b_lock.p;
-        h.row_bytes = (uint32_t)seg->row_bytes;
-        h.lds_query_bytes = (uint32_t)((seg->row_bytes + 127) / 128 * 128 + 128);
+        // bytes of a row as it lies in HBM: the SQ block holds the codes only (the vector_offset column is separate)
+        const uint64_t dev_row_bytes = seg->dtype == QMX_DTYPE_SQ_U8 ? (uint64_t)seg->sq.actual_dim : seg->row_bytes;
+        h.row_bytes = (uint32_t)dev_row_bytes;
+        h.lds_query_bytes = (uint32_t)((dev_row_bytes + 127) / 128 * 128 + 128);
         if (h.lds_query_bytes > HNSW_LDS_QUERY_MAX) {
-            set_error("rows of %llu bytes do not fit the LDS query slot", (unsigned long long)seg->row_bytes);
+            set_error("rows of %llu bytes do not fit the LDS query slot", (unsigned long long)dev_row_bytes);
             rc = QMX_ERR_NOT_SUPPORTED;
             break;
         }
@@ -1528,8 +1543,8 @@ int32_t qmx_hnsw_build(const qmx_segment *seg, const qmx_hnsw_build_params *bp, 
         h.vis_words = ((uint64_t)n + 31) / 32;
         if (h.vis_words == 0) h.vis_words = 1;
         int per_cu1 = 1, per_cu2 = 1;
-        QB(launch_hnsw_build_dense(nullptr, (int)seg->dtype, (int)seg->distance, a, h, 1, 0, &per_cu1));
-        QB(launch_hnsw_build_dense(nullptr, (int)seg->dtype, (int)seg->distance, a, h, 2, 0, &per_cu2));
+        QB(launch_hnsw_build_any(seg, a, h, 1, 0, &per_cu1));
+        QB(launch_hnsw_build_any(seg, a, h, 2, 0, &per_cu2));
         uint64_t slots1 = std::min<uint64_t>({(uint64_t)seg->num_cus * per_cu1, (uint64_t)HNSW_SLOT_CAP, (uint64_t)max_batch});
         slots1 = std::max<uint64_t>(1, std::min<uint64_t>(slots1, HNSW_VIS_BUDGET / (h.vis_words * 4)));
         const uint64_t slots2 = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)seg->num_cus * per_cu2, max_batch));
@@ -1568,8 +1583,8 @@ int32_t qmx_hnsw_build(const qmx_segment *seg, const qmx_hnsw_build_params *bp, 
             for (uint32_t i = 0; i < count; ++i)
                 if (level[next + i] > ep_level && live(next + i)) { count = i + 1; break; }
             h.first = next; h.count = count; h.ep_id = ep_id; h.ep_level = ep_level;
-            QB(launch_hnsw_build_dense(nullptr, (int)seg->dtype, (int)seg->distance, a, h, 1, (uint32_t)std::min<uint64_t>(slots1, count), &per_cu1));
-            QB(launch_hnsw_build_dense(nullptr, (int)seg->dtype, (int)seg->distance, a, h, 2, (uint32_t)std::min<uint64_t>(slots2, count), &per_cu2));
+            QB(launch_hnsw_build_any(seg, a, h, 1, (uint32_t)std::min<uint64_t>(slots1, count), &per_cu1));
+            QB(launch_hnsw_build_any(seg, a, h, 2, (uint32_t)std::min<uint64_t>(slots2, count), &per_cu2));
             for (uint32_t i = 0; i < count; ++i)
                 if (live(next + i)) { note_point(next + i); ++inserted; }
             next += count;

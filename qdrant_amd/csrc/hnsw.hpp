@@ -35,9 +35,16 @@
 namespace qmx {
 
 // ---- hop scorers: LPI lanes score one stored row; the score is valid in the lane with sub == 0 ----
+// a policy whose query offset comes from ScanArgs::sq_qoff instead of the query entry's aux block (a stored SQ row as the query)
+template <class P, class = void>
+struct has_internal_qoff { static constexpr bool value = false; };
+template <class P>
+struct has_internal_qoff<P, decltype((void)P::INTERNAL_QOFF)> { static constexpr bool value = P::INTERNAL_QOFF; };
+
 template <class P>
 struct HopRow {
     static constexpr int LPI = 8;
+    static constexpr bool INTERNAL_QOFF = has_internal_qoff<P>::value;
     static constexpr bool MULTI = true;     // score_multi<R>: R rows per 8-lane group in one pass
     static __device__ __forceinline__ float score(const ScanArgs &a, const unsigned char *qp, uint32_t id, int sub) {
         return group_score<P>(a, qp, id, sub);
@@ -50,6 +57,7 @@ struct HopRow {
 template <class S>
 struct HopSmall {
     static constexpr int LPI = 1;
+    static constexpr bool INTERNAL_QOFF = false;
     static constexpr bool MULTI = false;
     static __device__ __forceinline__ float score(const ScanArgs &a, const unsigned char *qp, uint32_t id, int) {
         return S::score(qp, reinterpret_cast<const unsigned char *>(a.rows) + (uint64_t)id * a.row_stride, id, a);

@@ -3,7 +3,8 @@
 // Replaces GraphLayersBuilder::link_new_point (lib/segment/src/index/hnsw_index/graph_layers_builder.rs:417-474:
 // search_entry above the point's level, then per level search_on_level(ef_construct) -> link_with_heuristic
 // :532-556) and LinksContainer::{fill_from_sorted_with_heuristic :47-71, connect_with_heuristic :106-132}
-// for dense f32 / f16 storages.  The reference builds with a rayon pool of threads inserting points concurrently
+// for dense f32 / f16 storages and for SQ-int8 storages (the reference builds through the quantized scorer when the segment
+// has one, hnsw/build.rs:334-341: FilteredScorer::new_internal over QuantizedVectors).  The reference builds with a rayon pool of threads inserting points concurrently
 // under per-point locks (hnsw/build.rs:355) and has a Vulkan batch builder (hnsw_index/gpu/*); neither has a
 // deterministic insertion order, so — like for those — parity of a built graph is defined by its invariants and
 // by search quality (recall equal to the CPU oracle's build within noise), not link-for-link.
@@ -16,7 +17,8 @@
 //            lists, then for every selected neighbour q: lock(q), append p or — when q is full — re-select q's links
 //            among links(q) + p with the same heuristic, unlock.
 // Scores are the scan's lane policies (bit-identical to the x86 reference); a stored row is used as a "query entry"
-// directly (dense rows need no aux block), the new point's row is staged in LDS.
+// directly (dense rows need no aux block; an SQ code row takes its query offset from ScanArgs::sq_qoff, see query_args),
+// the new point's row is staged in LDS.
 //
 // Graph storage while building: fixed-capacity lists, level 0: links0[p][m0] + cnt0[p]; levels >= 1:
 // linksU[up_off[p] + l - 1][m] + cntU[...].  Exported afterwards to the plain GraphLinks arrays.
@@ -28,6 +30,16 @@ namespace qmx {
 // loads / stores of link lists in phase 2 go to L2 (agent scope): another CU may have rewritten the list under its lock
 __device__ __forceinline__ uint32_t ld_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// The scan arguments for scoring against stored row `qid` AS THE QUERY (FilteredScorer::new_internal, point_scorer.rs:183-218).
+// Dense rows need nothing.  An SQ row is its codes plus vector_offset; as a query its offset is vector_offset - shift
+// (encode_internal_vector, encoded_vectors_u8.rs:715-728 == postprocess_internal_score :105-114): handed to the policy in sq_qoff.
+template <class H>
+__device__ __forceinline__ ScanArgs query_args(const ScanArgs &a, uint32_t qid) {
+    ScanArgs b = a;
+    if constexpr (H::INTERNAL_QOFF) b.sq_qoff = a.row_offsets[qid] - a.sq_shift;
+    return b;
+}
 
 // fill_from_sorted_with_heuristic (links_container.rs:47-71): candidates sorted by descending score to the target;
 // keep c unless it is closer to an already kept link than to the target.  cand_* and sel_* live in LDS.
@@ -46,7 +58,7 @@ __device__ __forceinline__ uint32_t heuristic_fill(const ScanArgs &a, const uint
             const uint32_t k = n_sel - base < 64 ? n_sel - base : 64;
             __syncthreads();
             if ((uint32_t)lane < k) hop_ids[lane] = sel_ids[base + lane];
-            hop_score<H>(a, rows + (uint64_t)cid * a.row_stride, hop_ids, hop_scores, k, lane);   // score(candidate, kept link)
+            hop_score<H>(query_args<H>(a, cid), rows + (uint64_t)cid * a.row_stride, hop_ids, hop_scores, k, lane);   // score(candidate, kept link)
             const bool bad = (uint32_t)lane < k && hop_scores[lane] > cs;
             skip = __ballot(bad) != 0;
         }
@@ -64,7 +76,7 @@ __device__ __forceinline__ uint32_t heuristic_fill(const ScanArgs &a, const uint
 
 // ---- phase 1 ----------------------------------------------------------------------------------------------------
 template <class H, int E>
-__global__ __launch_bounds__(64) void hnsw_build_search_kernel(const ScanArgs a, const HnswBuildArgs h) {
+__global__ __launch_bounds__(64) void hnsw_build_search_kernel(const ScanArgs a0, const HnswBuildArgs h) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -77,12 +89,13 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(const ScanArgs a,
     unsigned char *q_lds = smem + 512 + 512 * E + 512;
     uint32_t *vis = h.visited + (uint64_t)blockIdx.x * h.vis_words;
     uint32_t *vlog = h.vis_log + (uint64_t)blockIdx.x * h.log_cap;
-    const unsigned char *rows = reinterpret_cast<const unsigned char *>(a.rows);
+    const unsigned char *rows = reinterpret_cast<const unsigned char *>(a0.rows);
     const uint32_t ef = h.ef_construct;
 
     for (uint32_t bi = blockIdx.x; bi < h.count; bi += gridDim.x) {
         const uint32_t p = h.first + bi;
         const uint32_t lp = h.level[p];
+        const ScanArgs a = query_args<H>(a0, p);     // the new point is the query of every score below
         uint32_t *my_cnt = h.sel_cnt + (uint64_t)bi * HNSW_BUILD_MAX_LEVELS;
         if (lane < (int)HNSW_BUILD_MAX_LEVELS) my_cnt[lane] = 0;
         if (!a.del.live(p)) continue;            // deleted points are never indexed (hnsw/build.rs:293-300)
@@ -280,7 +293,7 @@ __global__ __launch_bounds__(64) void hnsw_build_link_kernel(const ScanArgs a, c
                             hop_ids[lane] = id;
                             cand_ids[base + lane] = id;
                         }
-                        hop_score<H>(a, rows + (uint64_t)q * a.row_stride, hop_ids, hop_scores, kk, lane);
+                        hop_score<H>(query_args<H>(a, q), rows + (uint64_t)q * a.row_stride, hop_ids, hop_scores, kk, lane);
                         if ((uint32_t)lane < kk) cand_scores[base + lane] = hop_scores[lane];
                     }
                     if (lane == 0) {

@@ -36,6 +36,8 @@ struct ScanArgs {
     // SQ
     float sq_multiplier;
     const float *row_offsets;  // SQ: per-row f32 offset (SoA copy) or nullptr when inline in rows
+    float sq_shift;            // SQ: MetadataInt8::get_shift (encoded_vectors_u8.rs:116-134), used when a stored row is the query
+    float sq_qoff;             // SQ, stored row as the query (HNSW build): its query offset = vector_offset - shift (:105-114, 715-728)
     uint32_t flags;            // QMX_SEG_U8_SCALAR_ORDER ...
     // PQ
     uint32_t pq_m, pq_ncent;
@@ -123,6 +125,7 @@ struct HnswBuildArgs {
     uint32_t row_bytes;
 };
 // phase 1 = insertion searches + heuristic selection, phase 2 = linking; grid == 0: report occupancy only
+int32_t launch_hnsw_build_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_build_dense(hipStream_t st, int dtype, int distance, const ScanArgs &a, const HnswBuildArgs &h, int phase,
                                 uint32_t grid, int *per_cu);
 constexpr uint32_t HNSW_LDS_QUERY_MAX = 150 * 1024;

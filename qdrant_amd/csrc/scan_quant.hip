@@ -11,7 +11,7 @@
 // HBM layout: the reference row `[f32 vector_offset][u8 code x actual_dim]` (772 B at d=768, only
 // 4-byte aligned) is split at upload into a 16-byte aligned code block [n][actual_dim] and an
 // offset column [n] f32; algorithmic bytes per scored row stay 4 + actual_dim.
-#include "hnsw.hpp"
+#include "hnsw_build.hpp"
 
 namespace qmx {
 
@@ -69,6 +69,32 @@ struct RowSQ {
     }
 };
 
+// The same row policy with a STORED ROW as the query (HNSW build): the query entry is a bare code row, its offset
+// (vector_offset - shift, postprocess_internal_score :105-114) arrives in ScanArgs::sq_qoff (hnsw_build.hpp query_args).
+template <bool L1, bool SEP>
+struct RowSQInternal : RowSQ<L1, SEP> {
+    typedef RowSQ<L1, SEP> B;
+    static constexpr bool INTERNAL_QOFF = true;
+    static __device__ __forceinline__ float finish(typename B::acc_t (&a)[B::NACC], typename B::acc_t (&)[1], const unsigned char *,
+                                                   const unsigned char *, uint32_t rid, const ScanArgs &args) {
+        float f;
+        if (L1) {
+            f = (float)(int32_t)reduce8_u32(a[0]);
+        } else if (!SEP) {
+            f = (float)(int32_t)reduce8_u32((a[0] + a[1]) + (a[2] + a[3]));
+        } else {
+            float l[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) l[j] = (float)(int32_t)reduce8_u32(a[j]);
+            const float x0 = l[4] + l[0], x1 = l[5] + l[1], x2 = l[6] + l[2], x3 = l[7] + l[3];
+            f = (x0 + x2) + (x1 + x3);
+        }
+        const float m = args.sq_multiplier * f;
+        const float mq = m + args.sq_qoff;
+        return mq + args.row_offsets[rid];
+    }
+};
+
 template <class L>
 static int32_t dispatch_sq(const L &l, int distance, const ScanArgs &a) {
     const bool l1 = distance == QMX_DISTANCE_MANHATTAN;
@@ -86,6 +112,14 @@ int32_t launch_pairs_sq(hipStream_t st, int distance, const ScanArgs &a, const P
 }
 int32_t launch_hnsw_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
     return dispatch_sq(HnswLauncher{st, &h, grid, per_cu}, distance, a);
+}
+int32_t launch_hnsw_build_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu) {
+    const HnswBuildLauncher l{st, &h, phase, grid, per_cu};
+    const bool l1 = distance == QMX_DISTANCE_MANHATTAN;
+    const bool sep = (uint64_t)127 * 127 * a.dim >= (1ull << 24);
+    if (l1) return l.template row<RowSQInternal<true, false>>(a);
+    if (sep) return l.template row<RowSQInternal<false, true>>(a);
+    return l.template row<RowSQInternal<false, false>>(a);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -262,3 +296,9 @@ int32_t launch_sq_internal_query(hipStream_t st, const void *codes, const float 
 }
 
 }  // namespace qmx
+
+namespace qmx {
+static_assert(HopRow<RowSQInternal<false, false>>::INTERNAL_QOFF && HopRow<RowSQInternal<true, false>>::INTERNAL_QOFF &&
+                  !HopRow<RowSQ<false, false>>::INTERNAL_QOFF,
+              "only the build-time SQ policy takes its query offset from ScanArgs::sq_qoff");
+}

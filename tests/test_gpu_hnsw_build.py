@@ -119,9 +119,9 @@ def test_build_skips_deleted_points_and_handles_tiny_inputs(qa):
         gs = qa.GraphLayers.build(small, m=4, ef_construct=8, seed=2)
         res = gs.search(3, 8, qa.new_raw_scorer(queries[:4], small))
         assert all(len(r) == min(3, n) for r in res)
-    with pytest.raises(qa.QmxError):                 # quantized / u8 storages are built from their originals
-        quant = qa.ScalarQuantizer.from_min_max(rows, dim, qa.Distance.Dot)
-        qa.GraphLayers.build(qa.EncodedVectorsU8(quant.encode(rows), quant))
+    with pytest.raises(qa.QmxError):                 # u8 rows carry no query norm: built from their originals
+        qa.GraphLayers.build(qa.VectorStorage(np.clip(rows * 100 + 100, 0, 255).astype(np.uint8), qa.Distance.Cosine,
+                                              qa.VectorStorageDatatype.Uint8))
 
 
 def test_f16_build_and_large_batches(qa):
@@ -134,3 +134,57 @@ def test_f16_build_and_large_batches(qa):
     scorer = qa.new_raw_scorer(queries, vs)
     exact = O.DenseStorage(O.F16, O.COSINE, stored).peek_top(queries, 10)
     assert _recall(g.search(10, 256, scorer), exact) > 0.8
+
+
+@pytest.mark.parametrize("distance,dim", [(O.DOT, 96), (O.EUCLID, 64), (O.MANHATTAN, 40)])
+def test_sq_build_through_the_quantized_scorer(qa, distance, dim):
+    """The reference builds the graph with the QUANTIZED scorer when the segment has one (hnsw/build.rs:334-341:
+    FilteredScorer::new_internal over QuantizedVectors; SQ scores stored <-> stored through encode_internal_vector,
+    encoded_vectors_u8.rs:715-728).  qmx_hnsw_build over an SQ-int8 segment: structural invariants, the oracle walks the
+    device-built graph with the SQ scorer exactly like the device does, and search quality (SQ walk + f32 rescoring) is
+    that of the graph built over the original vectors."""
+    n, m, efc, seed = 6000, 8, 64, 17
+    rows = O.preprocess(distance, _clustered(n, dim, seed))
+    st = O.DenseStorage(O.F32, distance, rows)
+    quant = qa.ScalarQuantizer.from_min_max(rows, dim, _dist(qa, distance))
+    osq = O.SqOracle(distance, dim, quant.alpha, quant.offset)
+    osq.encode_rows(rows)
+    enc = qa.EncodedVectorsU8(quant.encode(rows), quant)
+    vs = qa.VectorStorage(rows, _dist(qa, distance))
+    g_sq = qa.GraphLayers.build(enc, m=m, ef_construct=efc, seed=seed)
+    g_f32 = qa.GraphLayers.build(vs, m=m, ef_construct=efc, seed=seed)
+    p = g_sq.export_plain()
+    lv = _levels_of(p, n)
+    assert lv.tolist() == _levels_of(g_f32.export_plain(), n).tolist()        # the level draw does not depend on the storage
+    assert int(p.level_offsets[1]) == n and sorted(p.reindex.tolist()) == list(range(n))
+    L = len(p.level_offsets) - 1
+    order = np.argsort(p.reindex)
+    empty0 = 0
+    for l in range(L):
+        cnt = int(p.level_offsets[l + 1] - p.level_offsets[l])
+        for j in range(0, cnt, 5 if l == 0 else 1):
+            pid = j if l == 0 else int(order[j])
+            slot = int(p.level_offsets[l]) + j
+            ln = p.neighbors[int(p.offsets[slot]):int(p.offsets[slot + 1])]
+            assert len(ln) <= (2 * m if l == 0 else m)
+            assert len(set(ln.tolist())) == len(ln) and pid not in ln
+            assert np.all(lv[ln] >= l)
+            empty0 += int(l == 0 and len(ln) == 0)
+    assert empty0 == 0
+    queries = _clustered(100, dim, seed + 1)
+    qpre = O.preprocess(distance, queries)
+    sq_scorer = qa.new_raw_scorer(queries, enc)
+    # the oracle walks the device-built graph with its SQ scorer: same lists, same score bits (L1 scores tie: same quality)
+    walk = O.Hnsw.from_plain(p, n)
+    want = walk.search_sq(st, osq, qpre[:40], 10, 64)
+    got = g_sq.search(10, 64, qa.new_raw_scorer(queries[:40], enc))
+    if distance != O.MANHATTAN:
+        for gq, wq in zip(got, want):
+            assert gq["idx"].tolist() == wq["idx"].tolist()
+            assert np.array_equal(gq["score"].view(np.uint32), wq["score"].view(np.uint32))
+    # quality after rescoring with the original vectors: SQ-built graph vs f32-built graph, same SQ walk
+    raw = qa.new_raw_scorer(queries, vs)
+    exact = st.peek_top(queries, 10)
+    r_sq = _recall(qa.search_quantized(sq_scorer, raw, 10, oversampling=2.0, rescore=True, graph=g_sq, hnsw_ef=64), exact)
+    r_f32 = _recall(qa.search_quantized(sq_scorer, raw, 10, oversampling=2.0, rescore=True, graph=g_f32, hnsw_ef=64), exact)
+    assert r_f32 > 0.6 and r_sq > r_f32 - 0.05, (r_sq, r_f32)
