@@ -21,7 +21,7 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # the oracle is test infrastructure: build it on demand (gcc only, a second)
     so = os.path.join(ROOT, "oracle", "libqdrant_oracle.so")
-    srcs = [os.path.join(ROOT, "oracle", f) for f in ("qdrant_oracle.c", "qdrant_oracle_hnsw.c", "qdrant_oracle.h")]
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("qdrant_oracle.c", "qdrant_oracle_hnsw.c", "qdrant_oracle_links.c", "qdrant_oracle.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
 
