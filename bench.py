@@ -174,7 +174,7 @@ def main():
 
 def hnsw_section(args, dev, dim, top, lib, F, qa, np, torch):
     """Secondary measurement, outside the timed region (the metric names "brute-force + HNSW"): the C3-style path on
-    `--hnsw-rows` clustered rows: device HNSW build (qmx_hnsw_build), SQ-int8 walk (qmx_hnsw_search, oversampling 2),
+    `--hnsw-rows` clustered rows: SQ-int8 encode, device HNSW build through the SQ scorer (qmx_hnsw_build), SQ-int8 walk (qmx_hnsw_search, oversampling 2),
     rescoring with the f32 rows (qmx_rescore), recall@10 against the exact device search.  tools/bench_hnsw.py is the
     full tool (CPU-oracle walk parity, 10 M rows)."""
     n, nq, ef, m = args.hnsw_rows, 8192, 128, 16
@@ -191,9 +191,8 @@ def hnsw_section(args, dev, dim, top, lib, F, qa, np, torch):
     torch.cuda.synchronize(dev)
     queries = queries_d.cpu().numpy()
     vs = qa.VectorStorage(rows, qa.Distance.Cosine)
-    t0 = time.perf_counter()
-    graph = qa.GraphLayers.build(vs, m=m, ef_construct=100, seed=42)
-    t_build = time.perf_counter() - t0
+    # the reference's order for a quantized segment: quantize, then build the graph THROUGH the quantized scorer
+    # (hnsw/build.rs:334-341), then search with it and rescore with the original vectors
     mn, mx = float(rows.min().item()), float(rows.max().item())
     quant = qa.ScalarQuantizer(dim, qa.Distance.Dot, (np.float32(mx) - np.float32(mn)) / np.float32(127.0), np.float32(mn))
     p = quant.params()
@@ -205,6 +204,10 @@ def hnsw_section(args, dev, dim, top, lib, F, qa, np, torch):
     enc.quantizer, enc.distance, enc.datatype, enc.dim, enc.count, enc._keep, enc._sq, enc._h = quant, quant.distance, None, dim, n, None, p, C.c_void_p()
     F.check(lib.qmx_segment_create(C.byref(d), C.byref(enc._h)))
     del codes
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    graph = qa.GraphLayers.build(enc, m=m, ef_construct=100, seed=42)
+    t_build = time.perf_counter() - t0
     scorer = qa.new_raw_scorer(queries, enc)
     raw = qa.new_raw_scorer(queries, vs)
     F.check(lib.qmx_query_set_timing(scorer._h, 1))
@@ -230,7 +233,7 @@ def hnsw_section(args, dev, dim, top, lib, F, qa, np, torch):
     exact = qa.BatchFilteredSearcher(queries[:256], vs, top).peek_top_all()
     recall = sum(len(set(a["idx"].tolist()) & set(b["idx"].tolist())) for a, b in zip(final[:256], exact)) / (256.0 * top)
     kernel_ms = ms.value / max(nl.value, 1)
-    return {"workload": "C3-style: %s x d=%d clustered rows, device HNSW build (m=%d, ef_construct=100), SQ-int8 walk ef=%d, oversampling 2 + f32 rescoring, %d queries per launch"
+    return {"workload": "C3-style: %s x d=%d clustered rows, SQ-int8 encode, device HNSW build through the SQ scorer (m=%d, ef_construct=100), SQ-int8 walk ef=%d, oversampling 2 + f32 rescoring, %d queries per launch"
                         % (_human(n), dim, m, ef, nq),
             "build_s": round(t_build, 2), "build_points_per_s": round(n / t_build, 1),
             "search_qps_kernel": round(nq / (kernel_ms * 1e-3), 1), "search_kernel_ms": round(kernel_ms, 3),

@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--scorer", default="sq", help="comma list of f32 | sq | pq")
     ap.add_argument("--build", choices=["gpu", "cpu"], default="gpu")
+    ap.add_argument("--build-over", choices=["f32", "sq"], default="f32",
+                    help="storage the device build scores through: the original vectors, or the SQ-int8 codes as the reference does "
+                         "when the segment is quantized (hnsw/build.rs:334-341)")
     ap.add_argument("--data", choices=["clustered", "iid"], default="clustered")
     ap.add_argument("--m", type=int, default=16)
     ap.add_argument("--ef-construct", type=int, default=100)
@@ -82,10 +85,34 @@ def main():
     host_rows = rows.cpu().numpy() if with_oracle else None
     st = O.DenseStorage(O.F32, O.COSINE, host_rows) if with_oracle else None
 
+    sq_cache = {}
+
+    def make_sq():
+        """SQ-int8 twin of the rows (min / max interval), encoded on the device, as a device-resident EncodedVectorsU8."""
+        if sq_cache:
+            return sq_cache["quant"], sq_cache["enc"], sq_cache["codes"]
+        mn, mx = float(rows.min().item()), float(rows.max().item())
+        quant = qa.ScalarQuantizer(dim, qa.Distance.Dot, (np.float32(mx) - np.float32(mn)) / np.float32(127.0), np.float32(mn))
+        p = quant.params()
+        codes_d = torch.empty((n, quant.quantized_vector_size()), dtype=torch.uint8, device=dev)
+        F.check(lib.qmx_sq_encode(0, int(qa.Distance.Dot), C.byref(p), F.ptr(rows), n, dim, F.ptr(codes_d)))
+        enc = qa.EncodedVectorsU8.__new__(qa.EncodedVectorsU8)
+        enc.quantizer, enc.distance, enc.datatype, enc.dim, enc.count, enc._keep, enc._sq = quant, quant.distance, None, dim, n, None, p
+        d = F.SegmentDesc()
+        d.dtype, d.distance, d.dim, d.n, d.data, d.device_id, d.sq = F.DTYPE_SQ_U8, int(qa.Distance.Dot), dim, n, F.ptr(codes_d).value, 0, C.pointer(p)
+        enc._h = C.c_void_p()
+        F.check(lib.qmx_segment_create(C.byref(d), C.byref(enc._h)))
+        sq_cache.update(quant=quant, enc=enc, codes=codes_d.cpu().numpy() if with_oracle else None)
+        del codes_d
+        return sq_cache["quant"], sq_cache["enc"], sq_cache["codes"]
+
     vs = qa.VectorStorage(rows, qa.Distance.Cosine)        # adopts the device block
+    build_storage = vs
+    if args.build == "gpu" and args.build_over == "sq":
+        build_storage = make_sq()[1]
     t0 = time.time()
     if args.build == "gpu":
-        graph = qa.GraphLayers.build(vs, m=args.m, ef_construct=args.ef_construct, seed=42, max_batch=args.max_batch)
+        graph = qa.GraphLayers.build(build_storage, m=args.m, ef_construct=args.ef_construct, seed=42, max_batch=args.max_batch)
         t_build = time.time() - t0
         plain = graph.export_plain()
         walker = O.Hnsw.from_plain(plain, n) if with_oracle else None
@@ -112,23 +139,12 @@ def main():
             if with_oracle:
                 oracle_search = lambda qs: walker.search_dense(st, qs, args.top, args.ef)                       # noqa: E731
         elif which == "sq":
-            mn, mx = float(rows.min().item()), float(rows.max().item())
-            quant = qa.ScalarQuantizer(dim, qa.Distance.Dot, (np.float32(mx) - np.float32(mn)) / np.float32(127.0), np.float32(mn))
-            p = quant.params()
-            codes_d = torch.empty((n, quant.quantized_vector_size()), dtype=torch.uint8, device=dev)
-            F.check(lib.qmx_sq_encode(0, int(qa.Distance.Dot), C.byref(p), F.ptr(rows), n, dim, F.ptr(codes_d)))
-            enc = qa.EncodedVectorsU8.__new__(qa.EncodedVectorsU8)
-            enc.quantizer, enc.distance, enc.datatype, enc.dim, enc.count, enc._keep, enc._sq = quant, quant.distance, None, dim, n, None, p
-            d = F.SegmentDesc()
-            d.dtype, d.distance, d.dim, d.n, d.data, d.device_id, d.sq = F.DTYPE_SQ_U8, int(qa.Distance.Dot), dim, n, F.ptr(codes_d).value, 0, C.pointer(p)
-            enc._h = C.c_void_p()
-            F.check(lib.qmx_segment_create(C.byref(d), C.byref(enc._h)))
+            quant, enc, host_codes_sq = make_sq()
             row_bytes, oversample = quant.quantized_vector_size(), 2
             if with_oracle:
                 osq = O.SqOracle(O.DOT, dim, quant.alpha, quant.offset)
-                osq.rows = codes_d.cpu().numpy()
+                osq.rows = host_codes_sq
                 oracle_search = lambda qs: walker.search_sq(st, osq, qs, args.top * 2, args.ef)                 # noqa: E731
-            del codes_d
             scorer = qa.new_raw_scorer(queries, enc)
         else:
             chunk = 16
@@ -171,7 +187,7 @@ def main():
             final = raw_scorer.rescore(ids, top, cnt)
             t_rescore = time.time() - t0
         out = {
-            "metric": "HNSW search QPS (device-resident walk)", "scorer": which, "data": args.data, "build": args.build,
+            "metric": "HNSW search QPS (device-resident walk)", "scorer": which, "data": args.data, "build": args.build, "build_over": args.build_over if args.build == "gpu" else "f32",
             "rows": n, "dim": dim, "m": args.m, "ef_construct": args.ef_construct, "ef": args.ef, "top": top, "oversampling": oversample, "nq": nq,
             "build_s": round(t_build, 2), "build_points_per_s": round(n / max(t_build, 1e-9), 1), "links_level0": n_links0,
             "qps_kernel": round(nq / (kernel_ms * 1e-3), 1), "kernel_ms": round(kernel_ms, 3),
