@@ -62,7 +62,7 @@ typedef enum qmx_dtype {
     QMX_DTYPE_U8 = 2,
     QMX_DTYPE_SQ_U8 = 3,
     QMX_DTYPE_PQ = 4,
-    QMX_DTYPE_BQ = 5   /* EncodedVectorsBin<u128>, Encoding::OneBit, QueryEncoding::SameAsStorage
+    QMX_DTYPE_BQ = 5   /* EncodedVectorsBin<u128>; Encoding and QueryEncoding in qmx_bq_params (default OneBit, SameAsStorage)
                           (lib/quantization/src/encoded_vectors_binary.rs): rows of ceil(dim / 128) * 16 bytes,
                           bit i = vector[i] > 0; invert derives from the distance (quantized_vectors.rs:232) */
 } qmx_dtype;
@@ -144,9 +144,15 @@ typedef struct qmx_pq_params {
  * reference while it reads the vectors): given here, like the SQ interval and the PQ centroids.  NULL mean / stddev = no stats.
  * Scoring is the one-bit xor-popcount over the longer rows, with the ORIGINAL dim in calculate_metric. */
 typedef enum qmx_bq_encoding { QMX_BQ_ONE_BIT = 0, QMX_BQ_TWO_BITS = 1, QMX_BQ_ONE_AND_HALF_BITS = 2 } qmx_bq_encoding;
+/* `QueryEncoding` (encoded_vectors_binary.rs:48-54): how qmx_query_create encodes a query against a BQ segment.  SameAsStorage: the
+ * row encoding (xor-popcount of two bit rows).  Scalar4bits / Scalar8bits (asymmetric quantization, `encode_scalar_query_vector`
+ * :692-756): each query value keeps 4 / 8 bits over [-max_abs, max_abs], stored as bit planes; the score is the plane-weighted
+ * xor-popcount divided by 2^bits - 1 (`xor_popcnt_scalar` :337-409, `calculate_metric` :783-788).  Stored <-> stored scores
+ * (qmx_query_create_internal, qmx_score_internal) are one-bit whatever the query encoding (:892-917). */
+typedef enum qmx_bq_query_encoding { QMX_BQ_QUERY_SAME_AS_STORAGE = 0, QMX_BQ_QUERY_SCALAR_4BITS = 1, QMX_BQ_QUERY_SCALAR_8BITS = 2 } qmx_bq_query_encoding;
 typedef struct qmx_bq_params {
     uint32_t encoding;      /* qmx_bq_encoding */
-    uint32_t reserved;
+    uint32_t query_encoding; /* qmx_bq_query_encoding */
     const float *mean;      /* [dim] host or device, or NULL */
     const float *stddev;    /* [dim] host or device, or NULL */
 } qmx_bq_params;

@@ -1325,6 +1325,66 @@ void qo_bq_encode_row_ex(uint32_t dim, int encoding, const float *mean, const fl
         if (b2) bq_set_bit(out, encoding == 1 ? (size_t)dim + i : (size_t)dim + i / 2);   /* :570-624 */
     }
 }
+/* ---- QueryEncoding::Scalar4bits / Scalar8bits (encoded_vectors_binary.rs:49-54) ----
+ * encode_scalar_query_vector (:692-719) + _encode_scalar_query_vector (:721-756): bytes of the encoded query =
+ * get_storage_size(ext_len.max(1)) * bits u128 words; returns that byte count (call with out == NULL to size). */
+size_t qo_bq_encode_scalar_query(uint32_t dim, int encoding, uint32_t bits, const float *query, uint8_t *out) {
+    const size_t ext = encoding == 1 ? (size_t)dim * 2 : encoding == 2 ? (size_t)dim + ((size_t)dim + 1) / 2 : (size_t)dim;
+    const size_t len1 = ext ? ext : 1;
+    const size_t n_words = (len1 / 128 + (len1 % 128 ? 1 : 0)) * bits;          /* u128::get_storage_size :412-419 */
+    if (!out) return n_words * 16;
+    float *x = (float *)malloc(sizeof(float) * len1);
+    for (uint32_t i = 0; i < dim; i++) x[i] = query[i];
+    if (encoding == 1) for (uint32_t i = 0; i < dim; i++) x[dim + i] = query[i];
+    if (encoding == 2) {
+        for (uint32_t k = 0; 2 * k < dim; k++) {                                    /* chunks(2): max of the pair, or the odd last */
+            const float a = query[2 * k];
+            x[dim + k] = 2 * k + 1 < dim ? fmaxf(a, query[2 * k + 1]) : a;
+        }
+    }
+    memset(out, 0, n_words * 16);
+    float max_abs = 0.0f;
+    for (size_t i = 0; i < ext; i++) max_abs = fmaxf(max_abs, fabsf(x[i]));        /* fold(0.0, f32::max) */
+    const float mn = -max_abs, mx = max_abs;
+    const size_t ranges = ((size_t)1 << bits) - 1;
+    const float delta = (mx - mn) / (float)ranges;
+    for (size_t i = 0; i < ext; i++) {
+        const size_t chunk = i / 128, shift = i % 128;
+        const float shifted = x[i] - mn;
+        const float delted = delta > 1.1920929e-07f ? shifted / delta : 0.0f;
+        const float r = roundf(delted);
+        const size_t rounded = !(r >= 0.0f) ? 0 : (r >= 1.8446744e19f ? (size_t)-1 : (size_t)r);   /* `as usize` saturates, NaN -> 0 */
+        const size_t quantized = rounded % (ranges + 1);
+        for (uint32_t b = 0; b < bits; b++)
+            if ((quantized >> b) & 1) out[(bits * chunk + b) * 16 + shift / 8] |= (uint8_t)(1u << (shift % 8));
+    }
+    free(x);
+    return n_words * 16;
+}
+/* xor_popcnt_scalar, the scalar loop (:403-409): vector = n_u128 words, query = n_u128 * bits words */
+uint64_t qo_bq_xor_popcnt_scalar(const uint8_t *vector, const uint8_t *query, uint32_t n_u128, uint32_t bits) {
+    uint64_t result = 0;
+    for (uint32_t w = 0; w < n_u128; w++) {
+        uint64_t v[2];
+        memcpy(v, vector + (size_t)w * 16, 16);
+        for (uint32_t b = 0; b < bits; b++) {
+            uint64_t q[2];
+            memcpy(q, query + ((size_t)w * bits + b) * 16, 16);
+            result += (uint64_t)(__builtin_popcountll(v[0] ^ q[0]) + __builtin_popcountll(v[1] ^ q[1])) << b;
+        }
+    }
+    return result;
+}
+/* calculate_metric with query_bits_count = bits (:783-810) */
+float qo_bq_score_scalar(int distance, int invert, uint32_t dim, int encoding, uint32_t bits, const uint8_t *scalar_query, const uint8_t *v) {
+    const uint64_t x = qo_bq_xor_popcnt_scalar(v, scalar_query, (uint32_t)(qo_bq_row_bytes_ex(dim, encoding) / 16), bits);
+    const float xor_product = (float)x / (float)((1 << bits) - 1);
+    const float fdim = (float)dim;
+    const float zeros_count = fdim - xor_product;
+    const int dot_like = distance == QO_DOT || distance == QO_COSINE;
+    if (dot_like) return invert ? xor_product - zeros_count : zeros_count - xor_product;
+    return invert ? zeros_count - xor_product : xor_product - zeros_count;
+}
 float qo_bq_score_ex(int distance, int invert, uint32_t dim, int encoding, const uint8_t *q, const uint8_t *v) {
     const float xor_product = (float)qo_bq_xor_popcnt(q, v, (uint32_t)(qo_bq_row_bytes_ex(dim, encoding) / 16));
     const float fdim = (float)dim;                             /* metadata.vector_parameters.dim: the original dimension */

@@ -156,6 +156,10 @@ float qo_bq_score(int distance, int invert, uint32_t dim, const uint8_t *q, cons
 size_t qo_bq_row_bytes_ex(uint32_t dim, int encoding);
 void qo_bq_encode_row_ex(uint32_t dim, int encoding, const float *mean, const float *stddev, const float *v, uint8_t *out);
 float qo_bq_score_ex(int distance, int invert, uint32_t dim, int encoding, const uint8_t *q, const uint8_t *v);
+/* QueryEncoding::Scalar4bits / Scalar8bits (encoded_vectors_binary.rs:692-756 encode, :403-409 xor_popcnt_scalar, :783-810 metric) */
+size_t qo_bq_encode_scalar_query(uint32_t dim, int encoding, uint32_t bits, const float *query, uint8_t *out);
+uint64_t qo_bq_xor_popcnt_scalar(const uint8_t *vector, const uint8_t *query, uint32_t n_u128, uint32_t bits);
+float qo_bq_score_scalar(int distance, int invert, uint32_t dim, int encoding, uint32_t bits, const uint8_t *scalar_query, const uint8_t *v);
 
 /* ---- cross-segment merge: BatchResultAggregator (lib/shard/src/search_result_aggregator.rs:50-121) ----
  * lists[(l * nq + qi) * k ..] with counts[l * nq + qi] valid entries; idx_base[l] (optional) is added to

@@ -44,10 +44,11 @@ class PqParams(C.Structure):
 
 
 class BqParams(C.Structure):
-    _fields_ = [("encoding", C.c_uint32), ("reserved", C.c_uint32), ("mean", C.c_void_p), ("stddev", C.c_void_p)]
+    _fields_ = [("encoding", C.c_uint32), ("query_encoding", C.c_uint32), ("mean", C.c_void_p), ("stddev", C.c_void_p)]
 
 
 BQ_ONE_BIT, BQ_TWO_BITS, BQ_ONE_AND_HALF_BITS = range(3)
+BQ_QUERY_SAME_AS_STORAGE, BQ_QUERY_SCALAR_4BITS, BQ_QUERY_SCALAR_8BITS = range(3)
 
 
 class SegmentDesc(C.Structure):

@@ -131,6 +131,7 @@ struct qmx_segment {
     qmx_sq_params sq{};
     qmx_pq_params pq{};
     uint32_t bq_encoding = 0;            // qmx_bq_encoding
+    uint32_t bq_query_bits = 1;          // QueryEncoding: 1 = SameAsStorage, 4 / 8 = Scalar4bits / Scalar8bits
     float *d_bq_mean = nullptr, *d_bq_stddev = nullptr;   // VectorStats of the 2-bit / 1.5-bit encodings (device copies), or null
     float *d_centroids = nullptr;
     uint32_t pq_m = 0;
@@ -166,6 +167,7 @@ struct qmx_query {
     uint32_t nq = 0;
     uint32_t nq_padded = 0;
     uint32_t q_stride = 0;     // bytes
+    uint32_t bq_bits = 1;      // BQ: bit planes per query value (1 for SameAsStorage and for internal queries = stored rows)
     uint32_t aux_off = 0;      // bytes
     void *d_queries = nullptr; // [nq_padded][q_stride]
     hipStream_t stream = nullptr;
@@ -422,6 +424,11 @@ int32_t qmx_segment_create(const qmx_segment_desc *desc, qmx_segment **out) {
         case QMX_DTYPE_BQ: {  // get_quantized_vector_size_from_params::<u128>(dim, encoding) (encoded_vectors_binary.rs:829-840, 412-419)
             s->bq_encoding = desc->bq ? desc->bq->encoding : (uint32_t)QMX_BQ_ONE_BIT;
             if (s->bq_encoding > QMX_BQ_ONE_AND_HALF_BITS) { set_error("bad BQ encoding %u", s->bq_encoding); rc = QMX_ERR_BAD_ARG; break; }
+            {
+                const uint32_t qe = desc->bq ? desc->bq->query_encoding : (uint32_t)QMX_BQ_QUERY_SAME_AS_STORAGE;
+                if (qe > QMX_BQ_QUERY_SCALAR_8BITS) { set_error("bad BQ query encoding %u", qe); rc = QMX_ERR_BAD_ARG; break; }
+                s->bq_query_bits = qe == QMX_BQ_QUERY_SCALAR_4BITS ? 4 : qe == QMX_BQ_QUERY_SCALAR_8BITS ? 8 : 1;
+            }
             s->row_bytes = bq_row_bytes(desc->dim, s->bq_encoding);
             s->scan_dim = (uint32_t)s->row_bytes;
             if (desc->bq && desc->bq->mean && desc->bq->stddev && s->bq_encoding != QMX_BQ_ONE_BIT) {   // the stats encode the queries later
@@ -687,7 +694,7 @@ int32_t qmx_synth_fill_f32(int32_t device_id, uint64_t seed, uint64_t row0, uint
 // ---------------------------------------------------------------------------------------------
 // query batch
 // ---------------------------------------------------------------------------------------------
-static int32_t query_alloc(const qmx_segment *seg, uint32_t nq, qmx_query **out) {
+static int32_t query_alloc(const qmx_segment *seg, uint32_t nq, qmx_query **out, bool internal = false) {
     qmx_query *q = new (std::nothrow) qmx_query();
     QMX_REQUIRE(q, QMX_ERR_OUT_OF_MEMORY, "host allocation failed");
     q->seg = seg;
@@ -697,7 +704,9 @@ static int32_t query_alloc(const qmx_segment *seg, uint32_t nq, qmx_query **out)
     if (q->nq_padded == 0) q->nq_padded = MAX_QT_TOPK;
     if (seg->dtype == QMX_DTYPE_PQ) q->nq_padded = std::max<uint32_t>(nq, 1);   // LUTs are never read past nq
     // tile entry = elements zero-padded to whole 128-byte segments + the aux block
-    q->aux_off = (uint32_t)((seg->scan_dim * elem_bytes(seg->dtype) + 127) & ~127u);
+    // a scalar-encoded BQ query holds `bits` planes per row word (a stored row as the query has one: score_internal is 1-bit)
+    q->bq_bits = (seg->dtype == QMX_DTYPE_BQ && !internal) ? seg->bq_query_bits : 1;
+    q->aux_off = (uint32_t)((seg->scan_dim * elem_bytes(seg->dtype) * q->bq_bits + 127) & ~127u);
     q->q_stride = q->aux_off + QUERY_AUX_BYTES;
     if (seg->dtype == QMX_DTYPE_PQ) {   // the encoded query is the LUT [m][n_centroids] f32 (EncodedQueryPQ)
         q->q_stride = (uint32_t)(((size_t)seg->pq_m * seg->pq.n_centroids * sizeof(float) + 15) & ~(size_t)15);
@@ -748,6 +757,8 @@ static int32_t query_encode(qmx_query *q, const float *queries) {
     if (seg->dtype == QMX_DTYPE_SQ_U8)   // EncodedVectorsU8::encode_query (encoded_vectors_u8.rs:583-619)
         return launch_sq_encode(q->stream, (int)seg->distance, seg->sq, seg->dim, d_f32, nq, (uint8_t *)q->d_queries, q->q_stride,
                                 nullptr, nullptr, 1, q->aux_off);
+    if (seg->dtype == QMX_DTYPE_BQ && q->bq_bits > 1)   // encode_query_vector, Scalar4bits / Scalar8bits (:683-756)
+        return launch_bq_encode_scalar_query(q->stream, d_f32, nq, seg->dim, seg->bq_encoding, q->bq_bits, (uint8_t *)q->d_queries, q->q_stride);
     if (seg->dtype == QMX_DTYPE_BQ)      // encode_query_vector, SameAsStorage (encoded_vectors_binary.rs:673-690) = encode_one_bit_vector
         return launch_bq_encode(q->stream, d_f32, nq, seg->dim, seg->bq_encoding, seg->d_bq_mean, seg->d_bq_stddev, (uint8_t *)q->d_queries, q->q_stride);
     if (seg->dtype == QMX_DTYPE_PQ)      // EncodedVectorsPQ::encode_query (encoded_vectors_pq.rs:519-541)
@@ -789,7 +800,7 @@ int32_t qmx_query_create_internal(const qmx_segment *seg, const uint32_t *point_
                 "dtype %u has no internal encoding (EncodedVectorsPQ::encode_internal_vector returns None): pass the original vector to qmx_query_create",
                 seg->dtype);
     qmx_query *q = nullptr;
-    QMX_TRY(query_alloc(seg, nq, &q));
+    QMX_TRY(query_alloc(seg, nq, &q, true));
     int32_t rc = QMX_OK;
     do {
         if (nq == 0) break;
@@ -913,7 +924,7 @@ int32_t qmx_query_read_encoded(const qmx_query *q, uint32_t query_index, void *o
     QMX_HIP(hipSetDevice(q->seg->device));
     const bool sq = q->seg->dtype == QMX_DTYPE_SQ_U8;
     const uint64_t ebytes = q->seg->dtype == QMX_DTYPE_PQ ? (uint64_t)q->seg->pq_m * q->seg->pq.n_centroids * sizeof(float)
-                                                          : (uint64_t)q->seg->scan_dim * elem_bytes(q->seg->dtype);
+                                                          : (uint64_t)q->seg->scan_dim * elem_bytes(q->seg->dtype) * q->bq_bits;
     const uint64_t bytes = ebytes + (sq ? 4 : 0);
     QMX_REQUIRE(out_bytes >= bytes, QMX_ERR_BAD_ARG, "buffer too small: need %llu", (unsigned long long)bytes);
     QMX_HIP(hipStreamSynchronize(q->stream));
@@ -960,6 +971,7 @@ static void fill_args(const qmx_query *q, uint32_t tile0, uint32_t nq_tile, Scan
     a.bq_dim = s->dim;
     // calculate_metric's match: (Dot | Cosine, invert = false) and (L1 | L2, invert = true) -> zeros - xor; the toggled pairs -> xor - zeros
     a.bq_flip = (s->flags & QMX_SEG_BQ_TOGGLE_INVERT) ? 1 : 0;
+    a.bq_qbits = q->bq_bits;
 }
 
 static int32_t launch_scan(const qmx_query *q, int qt, ScanMode mode, const ScanArgs &a, uint32_t *grid) {

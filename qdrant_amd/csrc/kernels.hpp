@@ -44,6 +44,7 @@ struct ScanArgs {
     // BQ: calculate_metric (encoded_vectors_binary.rs:766-810)
     uint32_t bq_dim;           // original dimension
     uint32_t bq_flip;          // 0: zeros - xor (every distance with its own invert), 1: xor - zeros
+    uint32_t bq_qbits;         // bit planes per query value: 1 (QueryEncoding::SameAsStorage, internal queries), 4 or 8 (Scalar4bits / Scalar8bits)
 };
 
 enum ScanMode { SCAN_TOPK = 0, SCAN_SCORES = 1 };
@@ -182,6 +183,8 @@ int32_t launch_order_statistics_f32(hipStream_t st, const float *d_in, float *d_
 int32_t launch_scan_bq(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out);
 int32_t launch_pairs_bq(hipStream_t st, const ScanArgs &a, const PairSel &sel, uint64_t n_items, int num_cus);
 uint64_t bq_row_bytes(uint32_t dim, uint32_t encoding);
+int32_t launch_bq_encode_scalar_query(hipStream_t st, const float *d_in, uint32_t nq, uint32_t dim, uint32_t encoding, uint32_t bits, uint8_t *d_out,
+                                      uint32_t out_stride);
 int32_t launch_bq_encode(hipStream_t st, const float *d_in, uint64_t n, uint32_t dim, uint32_t encoding, const float *d_mean, const float *d_stddev,
                          uint8_t *d_out, uint64_t out_stride);
 // PQ (pq.hip)

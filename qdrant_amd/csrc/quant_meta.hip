@@ -337,7 +337,7 @@ int32_t parse_pq(const JsonValue &root, qmx_quant_meta &m, MetaOwner &o) {
 
 int32_t parse_bq(const JsonValue &root, qmx_quant_meta &m, MetaOwner &o) {
     m.bq.encoding = QMX_BQ_ONE_BIT;          // #[serde(default)]
-    m.bq_query_encoding = 0;
+    m.bq_query_encoding = QMX_BQ_QUERY_SAME_AS_STORAGE;
     if (const JsonValue *e = root.get("encoding")) {
         QMX_REQUIRE(e->kind == JsonValue::String, QMX_ERR_BAD_ARG, "metadata: \"encoding\" is not a string");
         if (e->str == "OneBit") m.bq.encoding = QMX_BQ_ONE_BIT;
@@ -350,9 +350,9 @@ int32_t parse_bq(const JsonValue &root, qmx_quant_meta &m, MetaOwner &o) {
     }
     if (const JsonValue *e = root.get("query_encoding")) {
         QMX_REQUIRE(e->kind == JsonValue::String, QMX_ERR_BAD_ARG, "metadata: \"query_encoding\" is not a string");
-        if (e->str == "SameAsStorage") m.bq_query_encoding = 0;
-        else if (e->str == "Scalar4bits") m.bq_query_encoding = 1;
-        else if (e->str == "Scalar8bits") m.bq_query_encoding = 2;
+        if (e->str == "SameAsStorage") m.bq_query_encoding = QMX_BQ_QUERY_SAME_AS_STORAGE;
+        else if (e->str == "Scalar4bits") m.bq_query_encoding = QMX_BQ_QUERY_SCALAR_4BITS;
+        else if (e->str == "Scalar8bits") m.bq_query_encoding = QMX_BQ_QUERY_SCALAR_8BITS;
         else {
             set_error("metadata: unknown query_encoding \"%s\"", e->str.c_str());
             return QMX_ERR_BAD_ARG;
@@ -377,6 +377,7 @@ int32_t parse_bq(const JsonValue &root, qmx_quant_meta &m, MetaOwner &o) {
         m.bq.mean = o.mean.data();
         m.bq.stddev = o.stddev.data();
     }
+    m.bq.query_encoding = m.bq_query_encoding;
     return QMX_OK;
 }
 

@@ -1,4 +1,4 @@
-// scan_bq.hip — EncodedVectorsBin (binary quantization) on device: Encoding::OneBit, QueryEncoding::SameAsStorage,
+// scan_bq.hip — EncodedVectorsBin (binary quantization) on device: every Encoding, QueryEncoding::SameAsStorage | Scalar4bits | Scalar8bits,
 // BitsStoreType = u128 (what single-vector segments use, vector_storage/quantized/quantized_vectors/binary/create.rs:34-37).
 //
 // Reference (lib/quantization/src/encoded_vectors_binary.rs):
@@ -36,8 +36,41 @@ struct RowBQ {
     }
 };
 
+// QueryEncoding::Scalar4bits / Scalar8bits (encoded_vectors_binary.rs:49-54, 721-756): the query keeps B bits per value, stored as B
+// bit planes per u128 word of the row (`encoded_query[B * chunk + b]`); xor_popcnt_scalar (:337-409, cpp/avx2.c / sse.c
+// impl_xor_popcnt_scalar{4,8}_*_uint128) = sum over words and planes of popcount(row_word ^ plane_b) << b, and calculate_metric
+// (:783-788) divides it by (2^B - 1) in f32 before the same zeros / xor arithmetic.  Integer sums are exact in any order; the one
+// division and the two subtractions are done in the reference's order.
+template <int B>
+struct RowBQScalar {
+    static constexpr bool TEMPORAL_ROWS = true;
+    static constexpr int NACC = 1;
+    static constexpr int NRAUX = 0;
+    static constexpr int R16 = 2;
+    static constexpr int QPIECES = B;
+    typedef uint32_t acc_t;
+    static __device__ __forceinline__ void row_aux(acc_t (&)[1], const uint4 &) {}
+    static __device__ __forceinline__ void mac(acc_t (&)[NACC], const uint4 &, const uint4 &) {}
+    static __device__ __forceinline__ void mac_pieces(acc_t (&a)[NACC], const uint4 (&q)[B], const uint4 &v) {
+#pragma unroll
+        for (int k = 0; k < B; ++k)
+            a[0] += (uint32_t)(__popc(q[k].x ^ v.x) + __popc(q[k].y ^ v.y) + __popc(q[k].z ^ v.z) + __popc(q[k].w ^ v.w)) << k;
+    }
+    static __device__ __forceinline__ float finish(acc_t (&a)[NACC], acc_t (&)[1], const unsigned char *, const unsigned char *, uint32_t,
+                                                   const ScanArgs &args) {
+        const float xor_product = (float)reduce8_u32(a[0]) / (float)((1u << B) - 1u);
+        const float dim = (float)args.bq_dim;
+        const float zeros_count = dim - xor_product;
+        return args.bq_flip ? xor_product - zeros_count : zeros_count - xor_product;
+    }
+};
+
 template <class L>
-static int32_t dispatch_bq(const L &l, const ScanArgs &a) { return l.template row<RowBQ>(a); }
+static int32_t dispatch_bq(const L &l, const ScanArgs &a) {
+    if (a.bq_qbits == 4) return l.template row<RowBQScalar<4>>(a);
+    if (a.bq_qbits == 8) return l.template row<RowBQScalar<8>>(a);
+    return l.template row<RowBQ>(a);
+}
 
 // ------------------------------------------------------------------------------------------
 // The block scan of BQ rows: ONE LANE PER ROW.  A 1-bit row is 96..192 bytes: with the 8-lanes-per-row layout of the dense
@@ -183,7 +216,7 @@ static int32_t launch_bq_rows_qt(hipStream_t st, ScanMode mode, const ScanArgs &
 int32_t launch_scan_bq(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
     // measured on 10 M x 768 / 1536 bits: 1..2 queries 0.19 / 0.34 ms on the 8-lanes-per-row layout (0.24 / 0.60 here), 4 queries
     // 0.27 / 0.64 ms here (0.44 / 0.63 there), 16 queries 0.90 / 1.21 ms here (1.8 / 2.2 there)
-    if (qt <= 2 || getenv("QMX_BQ_LANES8") != nullptr) return dispatch_bq(ScanLauncher{st, qt, mode, num_cus, grid_out}, a);
+    if (qt <= 2 || a.bq_qbits > 1 || getenv("QMX_BQ_LANES8") != nullptr) return dispatch_bq(ScanLauncher{st, qt, mode, num_cus, grid_out}, a);
     switch (qt) {
         case 4: return launch_bq_rows_qt<4>(st, mode, a, num_cus, grid_out);
         case 8: return launch_bq_rows_qt<8>(st, mode, a, num_cus, grid_out);
@@ -246,6 +279,62 @@ uint64_t bq_row_bytes(uint32_t dim, uint32_t encoding) {   // get_quantized_vect
     if (ext < 1) ext = 1;
     return (ext + 127) / 128 * 16;
 }
+// encode_scalar_query_vector + _encode_scalar_query_vector (encoded_vectors_binary.rs:692-756) for a batch of queries: one block per
+// query.  The query is extended as the row encoding extends the row (TwoBits: the values twice; OneAndHalfBits: the values, then the
+// max of each pair), quantised to `bits` bits over [-max_abs, max_abs] in the reference's f32 steps (v - min, / delta, round half
+// away, % 2^bits), and stored as bit planes: dword `part` of u128 word `bits * chunk + b` holds bit b of values chunk * 128 + part * 32 + e.
+__global__ __launch_bounds__(256) void bq_encode_scalar_query_kernel(const float *in, uint32_t dim, uint32_t encoding, uint32_t bits, uint8_t *out,
+                                                                     uint32_t out_stride) {
+    __shared__ float red[256];
+    const float *q = in + (uint64_t)blockIdx.x * dim;
+    const uint32_t ext = encoding == QMX_BQ_TWO_BITS ? 2 * dim : encoding == QMX_BQ_ONE_AND_HALF_BITS ? dim + (dim + 1) / 2 : dim;
+    auto value = [&](uint32_t i) -> float {
+        if (i < dim) return q[i];
+        if (encoding == QMX_BQ_TWO_BITS) return q[i - dim];
+        const uint32_t k = 2 * (i - dim);
+        return k + 1 < dim ? fmaxf(q[k], q[k + 1]) : q[k];        // f32::max: the non-NaN operand
+    };
+    float m = 0.0f;
+    for (uint32_t i = threadIdx.x; i < ext; i += 256) m = fmaxf(m, fabsf(value(i)));   // fold(0.0, f32::max)
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    const float max_abs = red[0];
+    const float mn = -max_abs, mx = max_abs;
+    const uint32_t ranges = (1u << bits) - 1u;
+    const float delta = (mx - mn) / (float)ranges;
+    const uint32_t n_chunks = (ext > 0 ? ext : 1) / 128 + (((ext > 0 ? ext : 1) % 128) ? 1 : 0);   // get_storage_size(len.max(1))
+    const uint32_t n_dwords = n_chunks * bits * 4;
+    uint32_t *dst = reinterpret_cast<uint32_t *>(out + (uint64_t)blockIdx.x * out_stride);
+    for (uint32_t w = threadIdx.x; w < n_dwords; w += 256) {
+        const uint32_t chunk = w / (bits * 4), b = (w / 4) % bits, part = w % 4;
+        uint32_t word = 0;
+        for (uint32_t e = 0; e < 32; ++e) {
+            const uint32_t i = chunk * 128 + part * 32 + e;
+            if (i >= ext) break;
+            const float shifted = value(i) - mn;
+            const float delted = delta > 1.1920929e-07f ? shifted / delta : 0.0f;     // f32::EPSILON
+            const float r = roundf(delted);
+            const uint32_t rounded = !(r >= 0.0f) ? 0u : (r >= 1073741824.0f ? 1073741824u : (uint32_t)r);   // `as usize`: NaN / negative -> 0
+            const uint32_t quantized = rounded % (ranges + 1u);
+            word |= ((quantized >> b) & 1u) << e;
+        }
+        dst[w] = word;
+    }
+}
+int32_t launch_bq_encode_scalar_query(hipStream_t st, const float *d_in, uint32_t nq, uint32_t dim, uint32_t encoding, uint32_t bits, uint8_t *d_out,
+                                      uint32_t out_stride) {
+    if (nq == 0) return QMX_OK;
+    QMX_REQUIRE(bits == 4 || bits == 8, QMX_ERR_BAD_ARG, "scalar query encoding of %u bits", bits);
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(bq_encode_scalar_query_kernel, dim3(nq), dim3(256), 0, st, d_in, dim, encoding, bits, d_out, out_stride);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
 int32_t launch_bq_encode(hipStream_t st, const float *d_in, uint64_t n, uint32_t dim, uint32_t encoding, const float *d_mean, const float *d_stddev,
                          uint8_t *d_out, uint64_t out_stride) {
     if (n == 0) return QMX_OK;

@@ -29,22 +29,41 @@ namespace qmx {
 // half" is row_half_mirror.
 __device__ __forceinline__ int lane_piece(int t) { return 2 * (t & 3) + (t >> 2); }
 
-// one 128-byte segment step: the lane's 16-byte row pieces (R rows) against every query of the tile
+// A policy whose query entry holds QPIECES 16-byte pieces per 16-byte row piece (binary quantization with a scalar-encoded
+// query: QPIECES bit planes per u128 word, encoded_vectors_binary.rs:721-756) says so with `static constexpr int QPIECES = n`
+// and takes them in `mac_pieces`; everything else has one query piece per row piece.
+template <class P, class = void> struct query_pieces { static constexpr int value = 1; };
+template <class P> struct query_pieces<P, decltype((void)P::QPIECES)> { static constexpr int value = P::QPIECES; };
+
+// one 128-byte segment step: the lane's 16-byte row pieces (R rows) against every query of the tile; the lane's query piece(s)
+// sit at byte q_off (x QPIECES) of each query entry
 template <class P, int QT, int R>
 __device__ __forceinline__ void scan_step(typename P::acc_t (&acc)[QT][R][P::NACC],
                                           typename P::acc_t (&raux)[R][P::NRAUX > 0 ? P::NRAUX : 1],
-                                          const uint4 (&v)[R], const unsigned char *q_lds, uint32_t q_stride,
+                                          const uint4 (&v)[R], const unsigned char *q_base, uint32_t q_off, uint32_t q_stride,
                                           bool lane_on) {
+    constexpr int QP = query_pieces<P>::value;
     if (P::NRAUX > 0) {
 #pragma unroll
         for (int r = 0; r < R; ++r) P::row_aux(raux[r], v[r]);
     }
 #pragma unroll
     for (int q = 0; q < QT; ++q) {
-        uint4 qv = *reinterpret_cast<const uint4 *>(q_lds + (uint32_t)q * q_stride);
-        if (!lane_on) qv = make_uint4(0, 0, 0, 0);   // partial segment: the scalar-tail elements sit right behind the body
+        if constexpr (QP == 1) {
+            uint4 qv = *reinterpret_cast<const uint4 *>(q_base + q_off + (uint32_t)q * q_stride);
+            if (!lane_on) qv = make_uint4(0, 0, 0, 0);   // partial segment: the scalar-tail elements sit right behind the body
 #pragma unroll
-        for (int r = 0; r < R; ++r) P::mac(acc[q][r], qv, v[r]);
+            for (int r = 0; r < R; ++r) P::mac(acc[q][r], qv, v[r]);
+        } else {
+            uint4 qv[QP];
+#pragma unroll
+            for (int k = 0; k < QP; ++k) {
+                qv[k] = *reinterpret_cast<const uint4 *>(q_base + q_off * QP + k * 16 + (uint32_t)q * q_stride);
+                if (!lane_on) qv[k] = make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) P::mac_pieces(acc[q][r], qv, v[r]);
+        }
     }
 }
 
@@ -137,7 +156,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_kernel(const ScanArgs a) {
             uint4 v[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) v[r] = load_row_piece<!rows_temporal<P>::value>(rp[r] + (uint64_t)s * 128);
-            scan_step<P, QT, R>(acc, raux, v, smem + s * 128 + piece_off, a.q_stride, true);
+            scan_step<P, QT, R>(acc, raux, v, smem, s * 128 + piece_off, a.q_stride, true);
         }
         if (a.rem_pieces) {
             // last, partial segment of the SIMD body (element types narrower than f32): pieces past
@@ -148,7 +167,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_kernel(const ScanArgs a) {
                 v[r] = make_uint4(0, 0, 0, 0);
                 if (piece_in_rem) v[r] = *reinterpret_cast<const uint4 *>(rp[r] + (uint64_t)nseg * 128);
             }
-            scan_step<P, QT, R>(acc, raux, v, smem + nseg * 128 + piece_off, a.q_stride, piece_in_rem);
+            scan_step<P, QT, R>(acc, raux, v, smem, nseg * 128 + piece_off, a.q_stride, piece_in_rem);
         }
 
 #pragma unroll
@@ -403,13 +422,13 @@ __device__ __forceinline__ float group_score(const ScanArgs &a, const unsigned c
     for (uint32_t s = 0; s < a.nseg; ++s) {
         uint4 v[1];
         v[0] = *reinterpret_cast<const uint4 *>(rp + (uint64_t)s * 128);
-        scan_step<P, 1, 1>(acc, raux, v, qp + s * 128 + piece_off, 0, true);
+        scan_step<P, 1, 1>(acc, raux, v, qp, s * 128 + piece_off, 0, true);
     }
     if (a.rem_pieces) {
         uint4 v[1];
         v[0] = make_uint4(0, 0, 0, 0);
         if (piece_in_rem) v[0] = *reinterpret_cast<const uint4 *>(rp + (uint64_t)a.nseg * 128);
-        scan_step<P, 1, 1>(acc, raux, v, qp + a.nseg * 128 + piece_off, 0, piece_in_rem);
+        scan_step<P, 1, 1>(acc, raux, v, qp, a.nseg * 128 + piece_off, 0, piece_in_rem);
     }
     return P::finish(acc[0][0], raux[0], qp, row, id, a);
 }
@@ -440,7 +459,7 @@ __device__ __forceinline__ void group_score_multi(const ScanArgs &a, const unsig
         uint4 v[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) v[r] = *reinterpret_cast<const uint4 *>(rp[r] + (uint64_t)s * 128);
-        scan_step<P, 1, R>(acc, raux, v, qp + s * 128 + piece_off, 0, true);
+        scan_step<P, 1, R>(acc, raux, v, qp, s * 128 + piece_off, 0, true);
     }
     if (a.rem_pieces) {
         uint4 v[R];
@@ -449,7 +468,7 @@ __device__ __forceinline__ void group_score_multi(const ScanArgs &a, const unsig
             v[r] = make_uint4(0, 0, 0, 0);
             if (piece_in_rem) v[r] = *reinterpret_cast<const uint4 *>(rp[r] + (uint64_t)a.nseg * 128);
         }
-        scan_step<P, 1, R>(acc, raux, v, qp + a.nseg * 128 + piece_off, 0, piece_in_rem);
+        scan_step<P, 1, R>(acc, raux, v, qp, a.nseg * 128 + piece_off, 0, piece_in_rem);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r)

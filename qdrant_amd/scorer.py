@@ -326,7 +326,9 @@ class BinaryQuantizer:
     Euclid | Manhattan).  `encoding`: 0 one bit, 1 two bits, 2 one and a half bits; the latter two take the per-dimension
     `mean` / `stddev` of the storage (`VectorStats`, an input like the SQ interval), None = no stats."""
 
-    def __init__(self, dim: int, distance: Distance, invert: Optional[bool] = None, encoding: int = 0, mean=None, stddev=None):
+    def __init__(self, dim: int, distance: Distance, invert: Optional[bool] = None, encoding: int = 0, mean=None, stddev=None,
+                 query_encoding: int = 0):
+        self.query_encoding = int(query_encoding)     # QueryEncoding: 0 SameAsStorage, 1 Scalar4bits, 2 Scalar8bits
         self.dim = int(dim)
         self.distance = Distance(distance)
         natural = self.distance in (Distance.Euclid, Distance.Manhattan)
@@ -339,6 +341,7 @@ class BinaryQuantizer:
     def params(self) -> "F.BqParams":
         p = F.BqParams()
         p.encoding = self.encoding
+        p.query_encoding = self.query_encoding
         p.mean = None if self.mean is None else self.mean.ctypes.data
         p.stddev = None if self.stddev is None else self.stddev.ctypes.data
         return p
@@ -412,9 +415,7 @@ def load_quantizer(meta_json, dtype: int):
         if m.bq.mean:
             mean = np.ctypeslib.as_array(C.cast(m.bq.mean, C.POINTER(C.c_float)), (m.dim,)).copy()
             stddev = np.ctypeslib.as_array(C.cast(m.bq.stddev, C.POINTER(C.c_float)), (m.dim,)).copy()
-        if m.bq_query_encoding != 0:
-            raise F.QmxError(F.ERR_NOT_SUPPORTED, "binary quantization with a scalar query encoding is not built (SameAsStorage only)")
-        return BinaryQuantizer(m.dim, distance, bool(m.invert), int(m.bq.encoding), mean, stddev)
+        return BinaryQuantizer(m.dim, distance, bool(m.invert), int(m.bq.encoding), mean, stddev, int(m.bq_query_encoding))
     finally:
         F.lib().qmx_quant_meta_free(C.byref(m))
 
@@ -496,7 +497,10 @@ class RawScorer:
             F.check(F.lib().qmx_query_read_encoded(self._h, query_index, F.ptr(out), out.nbytes, None))
             return out
         if isinstance(self.storage, EncodedVectorsBin):  # EncodedBinVector {encoded_vector: Vec<u128>} as bytes
-            out = np.empty(self.storage.quantizer.quantized_vector_size(), dtype=np.uint8)
+            # a scalar-encoded query (Scalar4bits / Scalar8bits) holds 4 / 8 bit planes per row word; internal queries are rows
+            qz = self.storage.quantizer
+            planes = {0: 1, 1: 4, 2: 8}[qz.query_encoding] if not getattr(self, "_internal", False) else 1
+            out = np.empty(qz.quantized_vector_size() * planes, dtype=np.uint8)
             F.check(F.lib().qmx_query_read_encoded(self._h, query_index, F.ptr(out), out.nbytes, None))
             return out
         if isinstance(self.storage, EncodedVectorsU8):   # EncodedQueryU8 {offset: f32, encoded_query: Vec<u8>}
@@ -538,7 +542,9 @@ def new_raw_scorer_internal(point_ids, storage: VectorStorage) -> RawScorer:
     ids = np.ascontiguousarray(np.atleast_1d(point_ids), dtype=np.uint32)
     h = C.c_void_p()
     F.check(F.lib().qmx_query_create_internal(storage._h, F.ptr(ids), len(ids), C.byref(h)))
-    return RawScorer(h, storage, len(ids))
+    scorer = RawScorer(h, storage, len(ids))
+    scorer._internal = True
+    return scorer
 
 
 class CustomQuery:

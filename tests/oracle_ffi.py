@@ -292,6 +292,11 @@ def sq_quantile_interval(sample, count, quantile):
     return (np.float32(mn.value), np.float32(mx.value)) if ok else None
 
 
+_sig("qo_bq_encode_scalar_query", C.c_size_t, [C.c_uint32, C.c_int, C.c_uint32, _P, _P])
+_sig("qo_bq_xor_popcnt_scalar", C.c_uint64, [_P, _P, C.c_uint32, C.c_uint32])
+_sig("qo_bq_score_scalar", _f, [C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_uint32, _P, _P])
+
+
 class BqOracle:
     """EncodedVectorsBin<u128>, OneBit, SameAsStorage on the CPU (oracle).  invert defaults to the segment's choice
     (quantized_vectors.rs:232: Euclid | Manhattan)."""
@@ -321,6 +326,23 @@ class BqOracle:
         for qi in range(qs.shape[0]):
             for j, i in enumerate(ids):
                 out[qi, j] = _lib.qo_bq_score_ex(self.distance, self.invert, self.dim, self.encoding, _p(qs[qi]), _p(self.rows[i]))
+        return out
+
+    def encode_scalar_queries(self, queries_preprocessed, bits):
+        """encode_query_vector with QueryEncoding::Scalar4bits / Scalar8bits (encoded_vectors_binary.rs:683-756)."""
+        v = f32(np.atleast_2d(queries_preprocessed))
+        nb = int(_lib.qo_bq_encode_scalar_query(self.dim, self.encoding, bits, _p(v[0]), None))
+        out = np.zeros((v.shape[0], nb), dtype=np.uint8)
+        for i in range(v.shape[0]):
+            _lib.qo_bq_encode_scalar_query(self.dim, self.encoding, bits, _p(v[i]), _p(out[i]))
+        return out
+
+    def score_points_scalar(self, queries_preprocessed, ids, bits):
+        qs = self.encode_scalar_queries(queries_preprocessed, bits)
+        out = np.empty((qs.shape[0], len(ids)), dtype=np.float32)
+        for qi in range(qs.shape[0]):
+            for j, i in enumerate(ids):
+                out[qi, j] = _lib.qo_bq_score_scalar(self.distance, self.invert, self.dim, self.encoding, bits, _p(qs[qi]), _p(self.rows[i]))
         return out
 
     def score_internal(self, a, b):

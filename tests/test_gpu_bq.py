@@ -193,3 +193,80 @@ def test_bq_two_bit_encodings(qa, encoding, dist, dim, with_stats):
     allsc = obq.score_points(queries, np.arange(n))
     for qi in range(nq):
         assert np.array_equal(_bits(got[qi]["score"]), _bits(np.sort(allsc[qi])[::-1][:5]))
+
+
+@pytest.mark.parametrize("encoding", [0, 1, 2])
+@pytest.mark.parametrize("qenc,bits", [(1, 4), (2, 8)])
+@pytest.mark.parametrize("dist,dim", [(O.DOT, 33), (O.COSINE, 129), (O.EUCLID, 768), (O.MANHATTAN, 1000), (O.DOT, 1536)])
+def test_bq_scalar_query_encodings_bit_exact(qa, dist, dim, qenc, bits, encoding):
+    """QueryEncoding::Scalar4bits / Scalar8bits (encoded_vectors_binary.rs:692-756 encode, :337-409 xor_popcnt_scalar, :783-810
+    calculate_metric): the encoded query's bytes, score_points, ragged hop scoring, brute-force top-k; stored <-> stored scores
+    stay one-bit (score_internal :892-917)."""
+    n, nq = 700, 6
+    rng = np.random.default_rng(dim * 3 + bits + encoding)
+    vecs = O.preprocess(dist, rng.standard_normal((n, dim)).astype(np.float32))
+    mean = vecs.mean(axis=0).astype(np.float32) if encoding else None
+    stddev = vecs.std(axis=0).astype(np.float32) if encoding else None
+    quant = qa.BinaryQuantizer(dim, _dist(qa, dist), encoding=encoding, mean=mean, stddev=stddev, query_encoding=qenc)
+    obq = O.BqOracle(dist, dim, encoding=encoding, mean=mean, stddev=stddev)
+    rows = obq.encode_rows(vecs)
+    st = qa.EncodedVectorsBin(quant.encode(vecs), quant)
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    queries[1] = 0.0                                                   # delta = 0
+    queries[2, : min(dim, 3)] *= 50.0                                  # one dominant value: most others land mid-range
+    qpre = O.preprocess(dist, queries)
+    scorer = qa.new_raw_scorer(queries, st)
+    want_q = obq.encode_scalar_queries(qpre, bits)
+    for i in range(nq):
+        assert np.array_equal(scorer.encoded_query(i), want_q[i])
+    ids = rng.permutation(n).astype(np.uint32)[:400]
+    want = obq.score_points_scalar(qpre, ids, bits)
+    assert np.array_equal(_bits(scorer.score_points(ids)), _bits(want))
+    lists = [ids[:9], ids[9:50], ids[:0], ids[50:51], ids[51:90], ids[90:130]]
+    for r, (lo, hi), qi in zip(scorer.score_points_ragged(lists), [(0, 9), (9, 50), (0, 0), (50, 51), (51, 90), (90, 130)], range(6)):
+        assert np.array_equal(_bits(r), _bits(want[qi, lo:hi]))
+    a, b = ids[:64], ids[64:128]
+    assert np.array_equal(_bits(scorer.score_internal(a, b)), _bits(obq.score_internal(a, b)))
+    internal = qa.new_raw_scorer_internal([5, n - 1], st)
+    assert np.array_equal(internal.encoded_query(1), rows[n - 1])
+    wi = np.stack([obq.score_internal(np.full(len(ids), pid), ids) for pid in [5, n - 1]])
+    assert np.array_equal(_bits(internal.score_points(ids)), _bits(wi))
+    # brute-force top-k over all rows, 6 queries (and a 20-query batch: two tiles)
+    full = obq.score_points_scalar(qpre, np.arange(n), bits)
+    for res, sc in zip(qa.BatchFilteredSearcher(queries, st, 10).peek_top_all(), full):
+        assert np.array_equal(_bits(res["score"]), _bits(np.sort(sc)[::-1][:10]))
+        assert np.array_equal(_bits(sc[res["idx"]]), _bits(res["score"]))
+    many = np.tile(queries, (4, 1))[:20]
+    for i, res in enumerate(qa.BatchFilteredSearcher(many, st, 7).peek_top_all()):
+        assert np.array_equal(_bits(res["score"]), _bits(np.sort(full[i % nq])[::-1][:7]))
+
+
+def test_bq_scalar_query_hnsw_walk_and_rescoring(qa):
+    """The asymmetric query through the device HNSW walk and the one-call oversampled search + rescoring: returned scores are
+    true scalar-query BQ scores in descending order; an 8-bit query finds more of the exact neighbours than the 1-bit query."""
+    n, dim, m, nq, top = 4000, 256, 8, 32, 10
+    rng = np.random.default_rng(78)
+    centers = rng.standard_normal((32, dim)).astype(np.float32)
+    rows = O.preprocess(O.COSINE, (centers[rng.integers(0, 32, n)] + 0.6 * rng.standard_normal((n, dim))).astype(np.float32))
+    queries = O.preprocess(O.COSINE, (centers[rng.integers(0, 32, nq)] + 0.6 * rng.standard_normal((nq, dim))).astype(np.float32))
+    st = O.DenseStorage(O.F32, O.COSINE, rows)
+    g = O.Hnsw(st, m=m, ef_construct=64, seed=3, threads=0)
+    graph = qa.GraphLayers.from_plain(g.export_plain())
+    obq = O.BqOracle(O.COSINE, dim)
+    obq.encode_rows(rows)
+    vs = qa.VectorStorage(rows, qa.Distance.Cosine)
+    raw = qa.new_raw_scorer(queries, vs)
+    exact = st.peek_top(queries, top)
+    hits = {}
+    for qenc, bits in [(0, 1), (2, 8)]:
+        quant = qa.BinaryQuantizer(dim, qa.Distance.Cosine, query_encoding=qenc)
+        enc = qa.EncodedVectorsBin(quant.encode(rows), quant)
+        scorer = qa.new_raw_scorer(queries, enc)
+        got = graph.search(30, 64, scorer)
+        all_scores = obq.score_points(queries, np.arange(n)) if bits == 1 else obq.score_points_scalar(queries, np.arange(n), bits)
+        for i, r in enumerate(got):
+            assert len(r) == 30 and np.all(np.diff(r["score"]) <= 0) and len(set(r["idx"].tolist())) == 30
+            assert np.array_equal(_bits(r["score"]), _bits(all_scores[i][r["idx"]]))
+        res = qa.search_quantized(scorer, raw, top, oversampling=3.0, rescore=True, graph=graph, hnsw_ef=64)
+        hits[bits] = sum(len(set(a["idx"].tolist()) & set(b["idx"].tolist())) for a, b in zip(res, exact))
+    assert hits[8] >= hits[1] and hits[8] / (top * nq) > 0.5

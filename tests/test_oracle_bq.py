@@ -75,3 +75,67 @@ def test_plus_minus_one_vectors_like_the_reference_tests(dim):
 
 def test_default_invert_is_the_segments_choice():
     assert [O.BqOracle(d, 8).invert for d in (O.COSINE, O.DOT, O.EUCLID, O.MANHATTAN)] == [0, 0, 1, 1]   # quantized_vectors.rs:232
+
+
+# ---- QueryEncoding::Scalar4bits / Scalar8bits (encoded_vectors_binary.rs:49-54, 692-756, 337-409, 783-810) ---------------------------
+# The reference's integration tests only run SameAsStorage; what pins the scalar encodings is the reference's own C kernels
+# (impl_xor_popcnt_scalar{4,8}_{avx,sse}_uint128, lib/quantization/cpp/avx2.c / sse.c, compiled into oracle/_ref) for the
+# plane-weighted popcount, and identities of the encoder that follow from its definition.  Encoder bytes: parity unpinned.
+
+@pytest.mark.parametrize("bits", [4, 8])
+def test_scalar_xor_popcnt_matches_the_reference_c_kernels(bits):
+    ref = O.load_ref_quant()
+    if ref is None:
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    fns = [getattr(ref, "impl_xor_popcnt_scalar%d_%s_uint128" % (bits, isa)) for isa in ("avx", "sse")]
+    for fn in fns:
+        fn.restype, fn.argtypes = C.c_uint32, [C.c_void_p, C.c_void_p, C.c_uint32]
+    rng = np.random.default_rng(bits)
+    for words in (1, 2, 3, 6, 7, 12, 13, 64):
+        for _ in range(20):
+            v = rng.integers(0, 256, words * 16, dtype=np.uint8)
+            q = rng.integers(0, 256, words * 16 * bits, dtype=np.uint8)
+            got = int(O.lib.qo_bq_xor_popcnt_scalar(v.ctypes.data, q.ctypes.data, words, bits))
+            for fn in fns:
+                assert int(fn(q.ctypes.data, v.ctypes.data, words)) == got
+            planes = q.reshape(words, bits, 16)
+            want = sum(int(np.unpackbits(planes[w, b] ^ v[16 * w:16 * w + 16]).sum()) << b for w in range(words) for b in range(bits))
+            assert got == want
+
+
+@pytest.mark.parametrize("encoding", [0, 1, 2])
+@pytest.mark.parametrize("bits", [4, 8])
+@pytest.mark.parametrize("dim", [1, 8, 33, 127, 128, 129, 3 * 129])
+def test_scalar_query_encoder_identities(dim, bits, encoding):
+    rng = np.random.default_rng(dim + bits + encoding)
+    q = rng.standard_normal(dim).astype(np.float32)
+    bq = O.BqOracle(O.DOT, dim, encoding=encoding, mean=np.zeros(dim, np.float32), stddev=np.ones(dim, np.float32))
+    enc = bq.encode_scalar_queries(q, bits)[0]
+    ext = {0: dim, 1: 2 * dim, 2: dim + (dim + 1) // 2}[encoding]
+    assert len(enc) == -(-ext // 128) * bits * 16 == bq.row_bytes * bits
+    # de-interleave the planes: value i = sum_b plane_b[i] << b must be round((x + max_abs) / (2 max_abs / (2^bits - 1)))
+    planes = np.unpackbits(enc.reshape(-1, bits, 16), axis=2, bitorder="little")           # [chunk, b, 128]
+    vals = (planes.astype(np.int64) << np.arange(bits)[None, :, None]).sum(axis=1).reshape(-1)
+    x = {0: q, 1: np.concatenate([q, q]),
+         2: np.concatenate([q, np.array([max(q[2 * k], q[2 * k + 1]) if 2 * k + 1 < dim else q[2 * k] for k in range((dim + 1) // 2)], np.float32)])}[encoding]
+    m = np.float32(np.abs(x).max())
+    delta = (m - (-m)) / np.float32(2 ** bits - 1)
+    want = np.floor((x - (-m)) / delta + np.float32(0.5)).astype(np.int64) % (2 ** bits)    # round half away (values >= 0)
+    assert vals[:ext].tolist() == want.tolist() and not vals[ext:].any()
+    assert vals[int(np.argmax(x))] == 2 ** bits - 1 or vals[int(np.argmin(x))] == 0             # an extreme value sits on the range's end
+
+
+@pytest.mark.parametrize("bits", [4, 8])
+@pytest.mark.parametrize("dim", [1, 33, 3 * 129])
+def test_scalar_encoded_plus_minus_one_query_scores_like_the_one_bit_query(dim, bits):
+    """+-1 queries quantise to 0 / 2^bits - 1: every plane is the sign plane, xor_scalar = (2^bits - 1) * xor, same score."""
+    rng = np.random.default_rng(dim)
+    vecs, query = _pm1(rng, 128, dim), _pm1(rng, 1, dim)
+    for distance, invert in [(O.DOT, 0), (O.DOT, 1), (O.EUCLID, 1), (O.MANHATTAN, 0)]:
+        bq = O.BqOracle(distance, dim, invert=invert)
+        bq.encode_rows(vecs)
+        assert np.array_equal(bq.score_points_scalar(query, np.arange(128), bits), bq.score_points(query, np.arange(128)))
+    zero = O.BqOracle(O.DOT, dim)
+    zero.encode_rows(vecs)
+    z = zero.encode_scalar_queries(np.zeros((1, dim), np.float32), bits)[0]                 # delta = 0: every value quantises to 0
+    assert not z.any()
