@@ -83,7 +83,10 @@ static int32_t dispatch_bq(const L &l, const ScanArgs &a) {
 constexpr int BQR_BLOCK = 256;
 constexpr int BQR_NW = BQR_BLOCK / WAVE;
 
-template <int QT, bool HAS_IDS, int MODE, bool SCALARQ>
+// B = bit planes per query value (1: SameAsStorage; 4 / 8: Scalar4bits / Scalar8bits, planes k of row word p at query piece p * B + k):
+// the plane's popcount over the four dwords of a piece is chained through v_bcnt's accumulate operand and enters the row's sum shifted
+// by k (xor_popcnt_scalar, encoded_vectors_binary.rs:403-409) - one accumulator per query whatever B.
+template <int QT, bool HAS_IDS, int MODE, bool SCALARQ, int B>
 __global__ __launch_bounds__(BQR_BLOCK) void bq_rows_kernel(const ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -124,21 +127,30 @@ __global__ __launch_bounds__(BQR_BLOCK) void bq_rows_kernel(const ScanArgs a) {
             const uint4 v = rp[p];
 #pragma unroll
             for (int q = 0; q < QT; ++q) {
-                uint4 qv;
-                if (SCALARQ) {   // wave-uniform address: the scalar unit fetches the query piece, the xor takes it as an SGPR operand
-                    const uint32_t *qg = reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(a.queries) + (uint64_t)q * a.q_stride) + 4 * p;
-                    qv = make_uint4(qg[0], qg[1], qg[2], qg[3]);
+                if constexpr (B == 1) {
+                    uint4 qv;
+                    if (SCALARQ) {   // wave-uniform address: the scalar unit fetches the query piece, the xor takes it as an SGPR operand
+                        const uint32_t *qg = reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(a.queries) + (uint64_t)q * a.q_stride) + 4 * p;
+                        qv = make_uint4(qg[0], qg[1], qg[2], qg[3]);
+                    } else {
+                        qv = sq[(uint32_t)q * pieces + p];
+                    }
+                    acc[q] += (uint32_t)(__popc(v.x ^ qv.x) + __popc(v.y ^ qv.y) + __popc(v.z ^ qv.z) + __popc(v.w ^ qv.w));
                 } else {
-                    qv = sq[(uint32_t)q * pieces + p];
+                    const uint32_t *qg = reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(a.queries) + (uint64_t)q * a.q_stride) + 4 * B * p;
+#pragma unroll
+                    for (int k = 0; k < B; ++k) {
+                        const uint32_t t = (uint32_t)(__popc(v.x ^ qg[4 * k]) + __popc(v.y ^ qg[4 * k + 1]) + __popc(v.z ^ qg[4 * k + 2]) + __popc(v.w ^ qg[4 * k + 3]));
+                        acc[q] += t << k;
+                    }
                 }
-                acc[q] += (uint32_t)(__popc(v.x ^ qv.x) + __popc(v.y ^ qv.y) + __popc(v.z ^ qv.z) + __popc(v.w ^ qv.w));
             }
         }
 #pragma unroll
         for (int q = 0; q < QT; ++q) {
             if (q < (int)a.nq) {
                 // calculate_metric (encoded_vectors_binary.rs:766-810)
-                const float xor_product = (float)acc[q];
+                const float xor_product = B == 1 ? (float)acc[q] : (float)acc[q] / (float)((1u << B) - 1u);   // :783-788
                 const float zeros_count = dimf - xor_product;
                 const float score = a.bq_flip ? xor_product - zeros_count : zeros_count - xor_product;
                 if (MODE == SCAN_SCORES) {
@@ -187,7 +199,7 @@ __global__ __launch_bounds__(BQR_BLOCK) void bq_rows_kernel(const ScanArgs a) {
     }
 }
 
-template <int QT, bool HAS_IDS, int MODE>
+template <int QT, bool HAS_IDS, int MODE, int B = 1>
 static int32_t launch_bq_rows_inst(hipStream_t st, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
     size_t lds = (size_t)QT * a.dim;
     if (MODE == SCAN_TOPK) lds = std::max(lds, (size_t)BQR_NW * QT * a.top * sizeof(uint64_t));
@@ -202,20 +214,38 @@ static int32_t launch_bq_rows_inst(hipStream_t st, const ScanArgs &a, int num_cu
         *grid_out = grid;
     }
     ::qmx::clear_stale_error();
-    hipLaunchKernelGGL((bq_rows_kernel<QT, HAS_IDS, MODE, true>), dim3(grid), dim3(BQR_BLOCK), lds, st, a);
+    hipLaunchKernelGGL((bq_rows_kernel<QT, HAS_IDS, MODE, true, B>), dim3(grid), dim3(BQR_BLOCK), lds, st, a);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }
-template <int QT>
+template <int QT, int B = 1>
 static int32_t launch_bq_rows_qt(hipStream_t st, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid) {
     const bool ids = a.ids != nullptr;
-    if (mode == SCAN_TOPK) return ids ? launch_bq_rows_inst<QT, true, SCAN_TOPK>(st, a, num_cus, grid) : launch_bq_rows_inst<QT, false, SCAN_TOPK>(st, a, num_cus, grid);
-    return ids ? launch_bq_rows_inst<QT, true, SCAN_SCORES>(st, a, num_cus, grid) : launch_bq_rows_inst<QT, false, SCAN_SCORES>(st, a, num_cus, grid);
+    if (mode == SCAN_TOPK) return ids ? launch_bq_rows_inst<QT, true, SCAN_TOPK, B>(st, a, num_cus, grid) : launch_bq_rows_inst<QT, false, SCAN_TOPK, B>(st, a, num_cus, grid);
+    return ids ? launch_bq_rows_inst<QT, true, SCAN_SCORES, B>(st, a, num_cus, grid) : launch_bq_rows_inst<QT, false, SCAN_SCORES, B>(st, a, num_cus, grid);
+}
+template <int B>
+static int32_t launch_bq_rows_planes(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid) {
+    switch (qt) {
+        case 1: return launch_bq_rows_qt<1, B>(st, mode, a, num_cus, grid);
+        case 2: return launch_bq_rows_qt<2, B>(st, mode, a, num_cus, grid);
+        case 4: return launch_bq_rows_qt<4, B>(st, mode, a, num_cus, grid);
+        case 8: return launch_bq_rows_qt<8, B>(st, mode, a, num_cus, grid);
+        case 16: return launch_bq_rows_qt<16, B>(st, mode, a, num_cus, grid);
+    }
+    set_error("unsupported BQ query tile %d", qt);
+    return QMX_ERR_BAD_ARG;
 }
 
 int32_t launch_scan_bq(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
     // measured on 10 M x 768 / 1536 bits: 1..2 queries 0.19 / 0.34 ms on the 8-lanes-per-row layout (0.24 / 0.60 here), 4 queries
     // 0.27 / 0.64 ms here (0.44 / 0.63 there), 16 queries 0.90 / 1.21 ms here (1.8 / 2.2 there)
+    // scalar-encoded queries: one lane per row (the 8-lanes-per-row layout re-reads B query pieces from LDS per row piece: 10 M x 768
+    // bits, 8 planes: 0.38 / 1.44 / 5.25 ms for 1 / 4 / 16 queries there, 0.28 / 0.73 / 2.64 ms here = 2/3 of the VALU rate of
+    // xor + bcnt per plane dword); a single query over rows of more than one line stays on the 8-lane layout (1536 bits: 0.63 vs 0.76 ms)
+    const bool rows_kernel = getenv("QMX_BQ_LANES8") == nullptr && !(qt == 1 && a.dim > 128);
+    if (a.bq_qbits == 4 && rows_kernel) return launch_bq_rows_planes<4>(st, qt, mode, a, num_cus, grid_out);
+    if (a.bq_qbits == 8 && rows_kernel) return launch_bq_rows_planes<8>(st, qt, mode, a, num_cus, grid_out);
     if (qt <= 2 || a.bq_qbits > 1 || getenv("QMX_BQ_LANES8") != nullptr) return dispatch_bq(ScanLauncher{st, qt, mode, num_cus, grid_out}, a);
     switch (qt) {
         case 4: return launch_bq_rows_qt<4>(st, mode, a, num_cus, grid_out);

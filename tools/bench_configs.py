@@ -188,6 +188,22 @@ def main():
             print(json.dumps({"config": "BQ encode d=%d" % dim, "bq_encode_s": round(t_enc, 3), "rows": n, "encoded_rows_match_oracle_first_2000": enc_ok}), flush=True)
             run("BQ: 10M x %d 1-bit (u128) cosine, brute-force top-10" % dim, seg, dim, rb, queries, check)
             F.check(lib.qmx_segment_destroy(seg))
+            # the same rows against QueryEncoding::Scalar8bits queries (asymmetric quantization: 8 bit planes per query value)
+            bqp = F.BqParams()
+            bqp.encoding, bqp.query_encoding = F.BQ_ONE_BIT, F.BQ_QUERY_SCALAR_8BITS
+            d.bq = C.pointer(bqp)
+            seg = C.c_void_p()
+            F.check(lib.qmx_segment_create(C.byref(d), C.byref(seg)))
+
+            def check8(qh, Q, out, counts):
+                F.check(lib.qmx_search_topk_async(qh, top, F.ptr(ids), S, F.ptr(out), F.ptr(counts)))
+                F.check(lib.qmx_query_synchronize(qh))
+                g = out.cpu().numpy()
+                gs = g[:, :, 1].copy().view(np.float32)
+                sc = obq.score_points_scalar(queries[:1], np.arange(min(S, 20000)), 8)
+                return enc_ok and bool(np.all(np.diff(gs[0]) <= 0)) and float(gs[0][0]) >= float(sc[0].max())
+            run("BQ: 10M x %d 1-bit rows, Scalar8bits queries, cosine, brute-force top-10" % dim, seg, dim, rb, queries, check8)
+            F.check(lib.qmx_segment_destroy(seg))
             del enc_rows
             torch.cuda.empty_cache()
 
