@@ -414,6 +414,24 @@ typedef struct qmx_custom_query {
 /* Coefficients of the feedback queries of an example batch (copied; host or device memory). */
 QMX_API int32_t qmx_custom_set_coefficients(qmx_query *examples, const float *coefs, uint32_t n);
 
+/* Multi-dense vectors with the MaxSim comparator (`MultiVectorConfig{comparator: MaxSim}`, `score_max_similarity`,
+ * lib/segment/src/vector_storage/query_scorer/mod.rs:70-97; used by `MultiMetricQueryScorer`, query_scorer/multi_metric_query_scorer.rs):
+ * the storage keeps every point's inner vectors flattened (`MultiDenseVectorStorage`: vectors + per-point offsets), so the segment here
+ * is the block of INNER rows and point p = inner rows [point_offsets[p], point_offsets[p + 1]).  `inner` is a query batch over that
+ * segment holding the inner vectors of all multi-queries back to back; multi-query j = inner queries [query_first[j], query_first[j + 1]).
+ *   score(j, p) = sum over the query's inner vectors a (in order, from 0.0) of max over the point's inner vectors b of similarity(a, b)
+ * with the segment's metric (no post-processing, as the reference).  The similarities are the dense scan's (bit-identical to the
+ * reference's leaves) and the two loops are the reference's: scores are bit-exact.  query_first [n_queries + 1] and point_offsets
+ * [n_points + 1] are host arrays.  The inner-row similarity matrix ([inner queries][inner rows] f32) is materialised in HBM (<= 48 GB).
+ *   qmx_multi_score_points: scores[j * n + i] for point ids[i].
+ *   qmx_multi_search_topk : brute force over `ids` or every point; `point_deleted` = optional BitSlice<u64, Lsb0> over POINTS
+ *                           (bit set = deleted; points past n_deleted_bits count as deleted, as NotDeletedChecker); out [n_queries][top]. */
+QMX_API int32_t qmx_multi_score_points(qmx_query *inner, const uint32_t *query_first, uint32_t n_queries, const uint64_t *point_offsets,
+                                       uint32_t n_points, const uint32_t *ids, uint32_t n, float *scores);
+QMX_API int32_t qmx_multi_search_topk(qmx_query *inner, const uint32_t *query_first, uint32_t n_queries, const uint64_t *point_offsets,
+                                      uint32_t n_points, const uint64_t *point_deleted, uint64_t n_deleted_bits, uint32_t top,
+                                      const uint32_t *ids, uint64_t n_ids, qmx_scored_point *out, uint32_t *out_counts);
+
 /* `RawScorer::score_points` of custom scorers: scores[qi * n + i] = custom query qi against stored point ids[i]. */
 QMX_API int32_t qmx_custom_score_points(qmx_query *examples, const qmx_custom_query *queries, uint32_t n_queries,
                                         const uint32_t *ids, uint32_t n, float *scores);

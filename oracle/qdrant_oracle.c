@@ -1393,3 +1393,19 @@ float qo_bq_score_ex(int distance, int invert, uint32_t dim, int encoding, const
     if (dot_like) return invert ? xor_product - zeros_count : zeros_count - xor_product;
     return invert ? zeros_count - xor_product : xor_product - zeros_count;
 }
+
+/* ---- Colbert MaxSim over multi-dense vectors: score_max_similarity (lib/segment/src/vector_storage/query_scorer/mod.rs:70-97) ----
+ * sims[a * stride + b] = TMetric::similarity(dense_a, dense_b) (computed by the leaves above); the two loops of the reference. */
+float qo_max_similarity(const float *sims, uint32_t n_a, uint32_t n_b, uint64_t stride) {
+    float sum = 0.0f;
+    for (uint32_t a = 0; a < n_a; a++) {
+        float max_sim = -INFINITY;
+        for (uint32_t b = 0; b < n_b; b++) {
+            const float sim = sims[(uint64_t)a * stride + b];
+            if (sim > max_sim) max_sim = sim;
+        }
+        sum += max_sim;
+    }
+    return sum;
+}
+

@@ -229,6 +229,9 @@ uint32_t qo_links_heuristic(const qo_scored_point *sorted_candidates, uint32_t n
 uint32_t qo_links_connect(uint32_t *links, uint32_t len, uint32_t new_point, uint32_t target, uint32_t level_m,
                           const float *score_table, uint32_t n);
 
+/* score_max_similarity (query_scorer/mod.rs:70-97) over a similarity table sims[a * stride + b] */
+float qo_max_similarity(const float *sims, uint32_t n_a, uint32_t n_b, uint64_t stride);
+
 /* ---- compressed graph-links files (qdrant_oracle_links.c; bitpacking.rs, bitpacking_links.rs, bitpacking_ordered.rs,
  *      graph_links/serializer.rs + header.rs) ---- */
 uint64_t qo_bitpack_write(const uint64_t *values, const uint8_t *bits, uint32_t n, uint8_t *out, uint64_t cap);

@@ -167,6 +167,8 @@ SIGNATURES = {
     "qmx_sq_fit_min_max": (C.c_int32, [C.c_int32, C.c_uint32, _P, C.c_uint64, C.c_uint32, C.POINTER(SqParams)]),
     "qmx_segment_create_from_files": (C.c_int32, [C.POINTER(SegmentDesc), C.c_char_p, C.c_char_p, C.POINTER(_P)]),
     "qmx_sq_fit_quantile": (C.c_int32, [C.c_int32, C.c_uint32, _P, C.c_uint64, C.c_uint32, C.c_uint64, C.c_float, C.POINTER(SqParams), C.POINTER(C.c_int32)]),
+    "qmx_multi_score_points": (C.c_int32, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32, _P]),
+    "qmx_multi_search_topk": (C.c_int32, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint64, C.c_uint32, _P, C.c_uint64, _P, _P]),
     "qmx_custom_set_coefficients": (C.c_int32, [_P, _P, C.c_uint32]),
     "qmx_bq_encode_ex": (C.c_int32, [C.c_int32, C.POINTER(BqParams), _P, C.c_uint64, C.c_uint32, _P]),
     "qmx_bq_row_bytes": (C.c_uint64, [C.c_uint32, C.c_uint32]),

@@ -180,6 +180,7 @@ struct qmx_query {
     float timing_ms = 0.f;
     uint32_t timing_launches = 0;
     DevBuf partial, out, counts, ids, scores, misc, enc, bounds, gthr;
+    DevBuf mv_qfirst, mv_offsets, mv_deleted;        // multi-vector MaxSim: query ranges, point offsets, point-level deleted bits
     DevBuf cq_sims, cq_scores, cq_desc, cq_coefs;   // custom queries: example similarities, combined scores, descriptors, feedback coefficients
     uint32_t n_cq_coefs = 0;
     DevBuf cand, cand_cnt, cand_ids;   // qmx_search_quantized: oversampled candidates of the quantized stage
@@ -852,6 +853,9 @@ int32_t qmx_query_destroy(qmx_query *q) {
     q->cq_coefs.release();
     q->filter.release();
     q->cq_sims.release();
+    q->mv_qfirst.release();
+    q->mv_offsets.release();
+    q->mv_deleted.release();
     q->cq_scores.release();
     q->cq_desc.release();
     q->cand.release();
@@ -2009,6 +2013,89 @@ int32_t qmx_custom_search_topk(qmx_query *ex, const qmx_custom_query *queries, u
     if (!out_dev) QMX_TRY(copy_out(ex->stream, out, d_out, (size_t)n_queries * top * sizeof(qmx_scored_point)));
     if (!cnt_dev) QMX_TRY(copy_out(ex->stream, out_counts, d_oc, (size_t)n_queries * 4));
     return check_err_flag(ex);
+}
+
+// ---------------------------------------------------------------------------------------------
+// multi-dense vectors: MaxSim (score_max_similarity, query_scorer/mod.rs:70-97)
+// ---------------------------------------------------------------------------------------------
+static int32_t multi_prepare(qmx_query *inner, const uint32_t *query_first, uint32_t n_queries, const uint64_t *point_offsets, uint32_t n_points,
+                             const uint32_t *d_ids, uint64_t n) {
+    const qmx_segment *s = inner->seg;
+    QMX_REQUIRE(s->dtype <= QMX_DTYPE_U8, QMX_ERR_NOT_SUPPORTED, "MaxSim scores original vectors (dense storages)");
+    const bool qf_dev = is_device_ptr(query_first), off_dev = is_device_ptr(point_offsets);
+    QMX_REQUIRE(!qf_dev && !off_dev, QMX_ERR_BAD_ARG, "query_first and point_offsets are host arrays (they are validated here)");
+    QMX_REQUIRE(query_first[0] <= query_first[n_queries] && query_first[n_queries] <= inner->nq, QMX_ERR_OUT_OF_BOUNDS,
+                "multi-queries reach past the %u inner query vectors of the batch", inner->nq);
+    for (uint32_t j = 0; j < n_queries; ++j)
+        QMX_REQUIRE(query_first[j] <= query_first[j + 1], QMX_ERR_BAD_ARG, "query_first is not ascending at %u", j);
+    const uint64_t n_rows = s->n;
+    for (uint32_t p = 0; p < n_points; ++p)
+        QMX_REQUIRE(point_offsets[p] <= point_offsets[p + 1], QMX_ERR_BAD_ARG, "point_offsets is not ascending at %u", p);
+    QMX_REQUIRE(point_offsets[n_points] <= n_rows, QMX_ERR_OUT_OF_BOUNDS, "point_offsets reach past the %llu inner rows of the segment",
+                (unsigned long long)n_rows);
+    QMX_REQUIRE((uint64_t)inner->nq * n_rows * 4 <= (48ull << 30), QMX_ERR_NOT_SUPPORTED, "similarity matrix of %llu x %u floats is too large",
+                (unsigned long long)n_rows, inner->nq);
+    QMX_TRY(inner->mv_qfirst.reserve((size_t)(n_queries + 1) * 4));
+    QMX_TRY(inner->mv_offsets.reserve((size_t)(n_points + 1) * 8));
+    QMX_HIP(hipMemcpyAsync(inner->mv_qfirst.p, query_first, (size_t)(n_queries + 1) * 4, hipMemcpyHostToDevice, inner->stream));
+    QMX_HIP(hipMemcpyAsync(inner->mv_offsets.p, point_offsets, (size_t)(n_points + 1) * 8, hipMemcpyHostToDevice, inner->stream));
+    QMX_TRY(inner->cq_sims.reserve((size_t)inner->nq * n_rows * 4));
+    QMX_TRY(inner->cq_scores.reserve((size_t)n_queries * n * 4));
+    // similarity(inner query, inner row) for every pair, with the dense scan's lane policies (score mode: deleted flags are not consulted)
+    QMX_TRY(score_ids_device(inner, nullptr, n_rows, (float *)inner->cq_sims.p, nullptr));
+    return launch_maxsim(inner->stream, (const float *)inner->cq_sims.p, n_rows, (const uint32_t *)inner->mv_qfirst.p, n_queries,
+                         (const uint64_t *)inner->mv_offsets.p, n_points, d_ids, n, (float *)inner->cq_scores.p, inner->d_err);
+}
+
+int32_t qmx_multi_score_points(qmx_query *inner, const uint32_t *query_first, uint32_t n_queries, const uint64_t *point_offsets, uint32_t n_points,
+                               const uint32_t *ids, uint32_t n, float *scores) {
+    QMX_REQUIRE(inner && query_first && point_offsets && (n == 0 || (ids && scores)), QMX_ERR_BAD_ARG, "NULL argument");
+    QMX_HIP(hipSetDevice(inner->device));
+    if (n == 0 || n_queries == 0) return QMX_OK;
+    const void *d_ids = nullptr;
+    QMX_TRY(stage_in(inner, inner->ids, ids, (size_t)n * 4, &d_ids));
+    QMX_TRY(multi_prepare(inner, query_first, n_queries, point_offsets, n_points, (const uint32_t *)d_ids, n));
+    QMX_TRY(copy_out(inner->stream, scores, inner->cq_scores.p, (size_t)n_queries * n * 4));
+    return check_err_flag(inner);
+}
+
+int32_t qmx_multi_search_topk(qmx_query *inner, const uint32_t *query_first, uint32_t n_queries, const uint64_t *point_offsets, uint32_t n_points,
+                              const uint64_t *point_deleted, uint64_t n_deleted_bits, uint32_t top, const uint32_t *ids, uint64_t n_ids,
+                              qmx_scored_point *out, uint32_t *out_counts) {
+    QMX_REQUIRE(inner && query_first && point_offsets && out && out_counts, QMX_ERR_BAD_ARG, "NULL argument");
+    QMX_REQUIRE(top >= 1 && top <= MAX_TOP, QMX_ERR_NOT_SUPPORTED, "top %u not in 1..%u", top, MAX_TOP);
+    QMX_HIP(hipSetDevice(inner->device));
+    if (n_queries == 0) return QMX_OK;
+    const void *d_ids = nullptr;
+    uint64_t n = n_points;
+    if (ids) {
+        n = n_ids;
+        if (n_ids) QMX_TRY(stage_in(inner, inner->ids, ids, (size_t)n_ids * 4, &d_ids));
+    }
+    const bool out_dev = is_device_ptr(out), cnt_dev = is_device_ptr(out_counts);
+    qmx_scored_point *d_out = out;
+    uint32_t *d_oc = out_counts;
+    if (!out_dev) { QMX_TRY(inner->out.reserve((size_t)n_queries * top * sizeof(qmx_scored_point))); d_out = (qmx_scored_point *)inner->out.p; }
+    if (!cnt_dev) { QMX_TRY(inner->counts.reserve((size_t)n_queries * 4)); d_oc = (uint32_t *)inner->counts.p; }
+    if (n == 0) {
+        QMX_HIP(hipMemsetAsync(d_oc, 0, (size_t)n_queries * 4, inner->stream));
+    } else {
+        QMX_TRY(multi_prepare(inner, query_first, n_queries, point_offsets, n_points, (const uint32_t *)d_ids, n));
+        // deletion is per POINT here (the id tracker's bitslice over multi-vector points), not per inner row
+        DeletedView del;
+        memset(&del, 0, sizeof(del));
+        del.n_rows = n_points;
+        if (point_deleted && n_deleted_bits) {
+            const void *d_bits = nullptr;
+            QMX_TRY(stage_in(inner, inner->mv_deleted, point_deleted, (size_t)((n_deleted_bits + 63) / 64) * 8, &d_bits));
+            del.point_deleted = (const uint64_t *)d_bits;
+            del.n_point_bits = n_deleted_bits;
+        }
+        QMX_TRY(launch_custom_topk(inner->stream, (const float *)inner->cq_scores.p, n, (const uint32_t *)d_ids, del, n_queries, top, d_out, d_oc));
+    }
+    if (!out_dev) QMX_TRY(copy_out(inner->stream, out, d_out, (size_t)n_queries * top * sizeof(qmx_scored_point)));
+    if (!cnt_dev) QMX_TRY(copy_out(inner->stream, out_counts, d_oc, (size_t)n_queries * 4));
+    return check_err_flag(inner);
 }
 
 int32_t qmx_search_quantized(const qmx_hnsw *g, qmx_query *quantized, qmx_query *raw, const qmx_search_params *p, const uint32_t *ids,

@@ -83,6 +83,43 @@ int32_t launch_custom_combine(hipStream_t st, const qmx_custom_query *d_queries,
     return QMX_OK;
 }
 
+// Colbert MaxSim over multi-dense vectors (score_max_similarity, lib/segment/src/vector_storage/query_scorer/mod.rs:70-97):
+// sims = [inner queries][inner rows] similarities (the dense scan's bits); multi-query j = inner queries [qfirst[j], qfirst[j + 1]);
+// point p = inner rows [offsets[p], offsets[p + 1]).  sum over the query's inner vectors (in order, from 0.0) of the max over the point's
+// inner vectors (`if sim > max_sim`, from -inf): the reference's two loops, one thread per (multi-query, candidate point).
+__global__ __launch_bounds__(256) void maxsim_kernel(const float *sims, uint64_t n_rows, const uint32_t *qfirst, uint32_t n_queries,
+                                                     const uint64_t *offsets, uint32_t n_points, const uint32_t *ids, uint64_t n, float *out, int *err_flag) {
+    const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t j = blockIdx.y;
+    if (c >= n || j >= n_queries) return;
+    const uint32_t p = ids ? ids[c] : (uint32_t)c;
+    if (p >= n_points) {
+        *err_flag = 1;
+        return;
+    }
+    const uint64_t b0 = offsets[p], b1 = offsets[p + 1];
+    float sum = 0.0f;
+    for (uint32_t a = qfirst[j]; a < qfirst[j + 1]; ++a) {
+        const float *row = sims + (uint64_t)a * n_rows;
+        float max_sim = -__builtin_inff();
+        for (uint64_t b = b0; b < b1; ++b) {
+            const float sim = row[b];
+            if (sim > max_sim) max_sim = sim;
+        }
+        sum += max_sim;
+    }
+    out[(uint64_t)j * n + c] = sum;
+}
+int32_t launch_maxsim(hipStream_t st, const float *d_sims, uint64_t n_rows, const uint32_t *d_qfirst, uint32_t n_queries, const uint64_t *d_offsets,
+                      uint32_t n_points, const uint32_t *d_ids, uint64_t n, float *d_out, int *err_flag) {
+    if (n == 0 || n_queries == 0) return QMX_OK;
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(maxsim_kernel, dim3((uint32_t)((n + 255) / 256), n_queries), dim3(256), 0, st, d_sims, n_rows, d_qfirst, n_queries, d_offsets,
+                       n_points, d_ids, n, d_out, err_flag);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
 // top-k of a score row per query over the candidate stream (ids or 0..n), deleted / filtered points skipped:
 // FixedLengthPriorityQueue + into_sorted_vec as everywhere else; top > 64 in bounded passes of 64.
 constexpr int CT_BLOCK = 1024;

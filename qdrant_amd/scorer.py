@@ -392,6 +392,49 @@ class EncodedVectorsBin(VectorStorage):
         return out
 
 
+class MultiDenseVectorStorage:
+    """`MultiDenseVectorStorage` with `MultiVectorComparator::MaxSim` (vector_storage/multi_dense/, query_scorer/mod.rs:70-97): the
+    inner vectors of all points flattened into one dense block on the device + per-point offsets."""
+
+    def __init__(self, inner_vectors, point_offsets, distance: Distance, datatype: VectorStorageDatatype = VectorStorageDatatype.Float32,
+                 device_id: int = 0):
+        self.inner = VectorStorage(inner_vectors, distance, datatype, device_id=device_id)
+        self.offsets = np.ascontiguousarray(point_offsets, dtype=np.uint64)
+        self.count = len(self.offsets) - 1
+        self.point_deleted = None
+
+    def set_deleted(self, point_deleted):
+        self.point_deleted = None if point_deleted is None else np.ascontiguousarray(point_deleted, dtype=bool)
+
+    def _queries(self, multi_queries):
+        qs = [np.atleast_2d(np.asarray(q, dtype=np.float32)) for q in multi_queries]
+        first = np.zeros(len(qs) + 1, dtype=np.uint32)
+        first[1:] = np.cumsum([len(q) for q in qs])
+        return new_raw_scorer(np.concatenate(qs, axis=0), self.inner), first
+
+    def score_points(self, multi_queries, ids) -> np.ndarray:
+        """`MultiMetricQueryScorer::score_stored_batch` for every multi-query: [n_queries, len(ids)] f32."""
+        scorer, first = self._queries(multi_queries)
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        out = np.empty((len(first) - 1, len(ids)), dtype=np.float32)
+        F.check(F.lib().qmx_multi_score_points(scorer._h, F.ptr(first), len(first) - 1, F.ptr(self.offsets), self.count, F.ptr(ids), len(ids),
+                                               F.ptr(out)))
+        return out
+
+    def peek_top_all(self, multi_queries, top: int, ids=None) -> List[np.ndarray]:
+        """`BatchFilteredSearcher::peek_top_all` over the MaxSim scorers (brute force)."""
+        scorer, first = self._queries(multi_queries)
+        nq = len(first) - 1
+        out = np.zeros((nq, top), dtype=ScoredPointOffset)
+        counts = np.zeros(nq, dtype=np.uint32)
+        idarr = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint32)
+        words = _bits_to_words(self.point_deleted)
+        F.check(F.lib().qmx_multi_search_topk(scorer._h, F.ptr(first), nq, F.ptr(self.offsets), self.count, F.ptr(words),
+                                              0 if self.point_deleted is None else len(self.point_deleted), top, F.ptr(idarr),
+                                              0 if idarr is None else len(idarr), F.ptr(out), F.ptr(counts)))
+        return [out[i, :counts[i]].copy() for i in range(nq)]
+
+
 def load_quantizer(meta_json, dtype: int):
     """`EncodedVectors{U8,PQ,Bin}::load`'s metadata half: the text of a segment's "quantized.meta.json"
     (vector_storage/quantized/quantized_vectors/config.rs:13) -> ScalarQuantizer | ProductQuantizer | BinaryQuantizer,

@@ -697,3 +697,25 @@ def compressed_links_file(p: "PlainLinks", base_vectors=None, link_vectors=None,
     out = np.zeros(n, dtype=np.uint8)
     _lib.qo_links_serialize_compressed(*args, _p(out), n)
     return out.tobytes()
+
+
+# ---- multi-dense vectors: MaxSim (query_scorer/mod.rs:70-97) -------------------------------------------------------------
+_sig("qo_max_similarity", _f, [_P, C.c_uint32, C.c_uint32, C.c_uint64])
+
+
+def max_similarity(sims):
+    """score_max_similarity over sims[a, b] = similarity(query inner vector a, point inner vector b)."""
+    t = np.ascontiguousarray(sims, dtype=np.float32)
+    return np.float32(_lib.qo_max_similarity(_p(t), t.shape[0], t.shape[1], t.shape[1]))
+
+
+def multi_scores(storage: "DenseStorage", inner_queries, query_first, point_offsets, ids):
+    """MultiMetricQueryScorer::score_stored over the oracle: inner_queries [nqi, dim] ORIGINAL vectors, multi-query j = inner queries
+    [query_first[j], query_first[j + 1]); point p = inner rows [point_offsets[p], point_offsets[p + 1]) of `storage`."""
+    n_rows = storage.rows.shape[0]
+    sims = storage.score_points(inner_queries, np.arange(n_rows, dtype=np.uint32))       # [nqi, n_rows], the leaves' bits
+    out = np.empty((len(query_first) - 1, len(ids)), dtype=np.float32)
+    for j in range(len(query_first) - 1):
+        for c, p in enumerate(ids):
+            out[j, c] = max_similarity(sims[query_first[j]:query_first[j + 1], int(point_offsets[p]):int(point_offsets[p + 1])])
+    return out
