@@ -1475,8 +1475,10 @@ int32_t qmx_hnsw_export_plain(const qmx_hnsw *g, uint32_t *reindex, uint64_t *le
 int32_t qmx_hnsw_build(const qmx_segment *seg, const qmx_hnsw_build_params *bp, qmx_hnsw **out) {
     QMX_REQUIRE(seg && bp && out, QMX_ERR_BAD_ARG, "NULL argument");
     *out = nullptr;
-    QMX_REQUIRE(seg->dtype == QMX_DTYPE_F32 || seg->dtype == QMX_DTYPE_F16 || seg->dtype == QMX_DTYPE_SQ_U8, QMX_ERR_NOT_SUPPORTED,
-                "device HNSW build needs a dense f32 / f16 or an SQ-int8 segment (dtype %u)", seg->dtype);
+    QMX_REQUIRE(seg->dtype == QMX_DTYPE_F32 || seg->dtype == QMX_DTYPE_F16 || seg->dtype == QMX_DTYPE_SQ_U8 ||
+                    (seg->dtype == QMX_DTYPE_U8 && seg->distance != QMX_DISTANCE_COSINE),
+                QMX_ERR_NOT_SUPPORTED, "device HNSW build needs a dense f32 / f16 / u8 (dot, euclid, manhattan) or an SQ-int8 segment (dtype %u, distance %u)",
+                seg->dtype, seg->distance);
     QMX_REQUIRE(seg->dtype == QMX_DTYPE_SQ_U8 || seg->fast_layout(), QMX_ERR_NOT_SUPPORTED, "adopted device block is not 16-byte aligned");
     QMX_REQUIRE(bp->m >= 1 && bp->m0 >= bp->m && bp->m0 <= 64, QMX_ERR_BAD_ARG, "need 1 <= m <= m0 <= 64");
     QMX_REQUIRE(bp->ef_construct >= 1 && bp->ef_construct <= HNSW_MAX_EF, QMX_ERR_NOT_SUPPORTED, "ef_construct %u not in 1..%u",

@@ -119,7 +119,7 @@ def test_build_skips_deleted_points_and_handles_tiny_inputs(qa):
         gs = qa.GraphLayers.build(small, m=4, ef_construct=8, seed=2)
         res = gs.search(3, 8, qa.new_raw_scorer(queries[:4], small))
         assert all(len(r) == min(3, n) for r in res)
-    with pytest.raises(qa.QmxError):                 # u8 rows carry no query norm: built from their originals
+    with pytest.raises(qa.QmxError):                 # u8 cosine rows carry no query norm: built from their originals
         qa.GraphLayers.build(qa.VectorStorage(np.clip(rows * 100 + 100, 0, 255).astype(np.uint8), qa.Distance.Cosine,
                                               qa.VectorStorageDatatype.Uint8))
 
@@ -188,3 +188,25 @@ def test_sq_build_through_the_quantized_scorer(qa, distance, dim):
     r_sq = _recall(qa.search_quantized(sq_scorer, raw, 10, oversampling=2.0, rescore=True, graph=g_sq, hnsw_ef=64), exact)
     r_f32 = _recall(qa.search_quantized(sq_scorer, raw, 10, oversampling=2.0, rescore=True, graph=g_f32, hnsw_ef=64), exact)
     assert r_f32 > 0.4 and r_sq > r_f32 - 0.05, (r_sq, r_f32)
+
+
+@pytest.mark.parametrize("distance", [O.DOT, O.EUCLID, O.MANHATTAN])
+def test_u8_build(qa, distance):
+    """Metric<u8> storages (dot / euclid / manhattan: the stored row is a complete query): invariants by construction of the same kernels,
+    the oracle walks the device-built graph like the device, recall against exact u8 search."""
+    n, dim, m, efc = 5000, 64, 8, 64
+    rows = np.clip(_clustered(n, dim, 31) * 20.0 + 128.0, 0, 255).astype(np.uint8)
+    st = O.DenseStorage(O.U8, distance, rows)
+    vs = qa.VectorStorage(rows, _dist(qa, distance), qa.VectorStorageDatatype.Uint8)
+    g = qa.GraphLayers.build(vs, m=m, ef_construct=efc, seed=9)
+    p = g.export_plain()
+    assert int(p.level_offsets[1]) == n and all(int(p.offsets[i + 1]) > int(p.offsets[i]) for i in range(0, n, 11))
+    queries = np.clip(_clustered(80, dim, 32) * 20.0 + 128.0, 0, 255).astype(np.float32)
+    scorer = qa.new_raw_scorer(queries, vs)
+    exact = st.peek_top(queries, 10)
+    got = g.search(10, 64, scorer)
+    assert _recall(got, exact) > 0.6
+    walk = O.Hnsw.from_plain(p, n)
+    want = walk.search_dense(st, queries[:30], 10, 64)
+    for gq, wq in zip(g.search(10, 64, qa.new_raw_scorer(queries[:30], vs)), want):
+        assert np.array_equal(gq["score"].view(np.uint32), wq["score"].view(np.uint32))   # integer scores tie: ids may differ among equals
