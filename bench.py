@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--cpu-rows", type=int, default=1_000_000, help="rows of the CPU-baseline sample")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-hbm-point", action="store_true", help="skip the secondary Q=16 (HBM-bound) measurement of the same scan")
     ap.add_argument("--verify", type=int, default=1, help="check the first batch against the oracle on the CPU sample")
     ap.add_argument("--hnsw-rows", type=int, default=1_000_000,
                     help="rows of the secondary HNSW measurement (device build + SQ search + rescoring), 0 = skip")
@@ -158,6 +159,13 @@ def main():
         "roofline": _roofline(n, dim, Q, kernel_ms, alg_bytes, achieved, int(kl.value)),
     }
 
+    if rank == 0 and world == 1 and Q != 16 and not args.no_hbm_point:
+        # the HBM-bound operating point of the same scan (north_star: >= 70 % of the HBM roofline on C2): 16 queries per pass, where the
+        # kernel is a pure stream of the stored block; outside the timed region, same rows, same measurement (HIP events on the kernel's stream)
+        try:
+            result["roofline_hbm_point_q16"] = hbm_point(16, storage, queries, n, dim, top, local_rank, stream, lib, F, sharded, torch)
+        except Exception as e:
+            result["roofline_hbm_point_q16"] = {"error": repr(e)[:300]}
     if rank == 0 and world == 1 and not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(args, rows, queries, out, counts, n, dim, Q, top, lib, qh, F, qa, np, torch)
     if rank == 0 and world == 1 and args.hnsw_rows > 0:
@@ -170,6 +178,35 @@ def main():
     backend.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def hbm_point(Qh, storage, queries, n, dim, top, local_rank, stream, lib, F, sharded, torch):
+    backend = sharded.HipBackend(storage, Qh, local_rank, stream)
+    try:
+        F.check(lib.qmx_query_set_timing(backend.qh, 1))
+        out = torch.zeros((Qh, top, 2), dtype=torch.int32, device=queries.device)
+        counts = torch.zeros((Qh,), dtype=torch.int32, device=queries.device)
+        nb = max(1, queries.shape[0] // Qh)
+        for i in range(3):
+            backend.local_topk(queries[(i % nb) * Qh:(i % nb + 1) * Qh], top, out, counts)
+        torch.cuda.synchronize()
+        ms, nl = C.c_float(), C.c_uint32()
+        F.check(lib.qmx_query_timing(backend.qh, C.byref(ms), C.byref(nl)))      # drop the warm-up launches
+        steps = 30
+        t0 = time.perf_counter()
+        for i in range(steps):
+            backend.local_topk(queries[(i % nb) * Qh:(i % nb + 1) * Qh], top, out, counts)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        F.check(lib.qmx_query_timing(backend.qh, C.byref(ms), C.byref(nl)))
+        kernel_ms = ms.value / max(1, nl.value)
+        alg = n * dim * 4
+        gbps = alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        return {"batch": Qh, "kernel": _kernel_name(dim, Qh), "kernel_ms": round(kernel_ms, 4), "launches_timed": int(nl.value),
+                "algorithmic_bytes_per_launch": alg, "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(gbps / HBM_PEAK_GBPS, 4), "qps": round(Qh * steps / wall, 1), "ms_per_step": round(wall / steps * 1e3, 4)}
+    finally:
+        backend.close()
 
 
 def hnsw_section(args, dev, dim, top, lib, F, qa, np, torch):

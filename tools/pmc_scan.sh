@@ -13,7 +13,7 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_SALU SQ_INSTS_BRANCH SQ_INST_LEVEL_VMEM"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --kernel-trace -d $OUT/g$i -o g$i -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu "$@" > /dev/null 2> $OUT/g$i.err
+  rocprofv3 --pmc $grp --kernel-trace -d $OUT/g$i -o g$i -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu --no-hbm-point "$@" > /dev/null 2> $OUT/g$i.err
 done
 cd $REPO
 python - <<PY
