@@ -578,8 +578,10 @@ typedef struct qmx_hnsw_info {
     uint32_t n_entry_points, n_extra_entry_points;
 } qmx_hnsw_info;
 
-/* Builds the HNSW graph of a dense f32 / f16 segment on its GPU: the work of `GraphLayersBuilder::link_new_point`
- * (graph_layers_builder.rs:417-474) for every non-deleted point, batch-parallel — the counterpart of
+/* Builds the HNSW graph of a segment on its GPU — dense f32 / f16 / u8 (u8: dot, euclid, manhattan), or SQ-int8 / BQ, where the
+ * build scores through the quantized scorer as the reference does for a quantized segment (hnsw/build.rs:334-341:
+ * `FilteredScorer::new_internal` over `QuantizedVectors`, stored rows as queries through `encode_internal_vector`) —: the work of
+ * `GraphLayersBuilder::link_new_point` (graph_layers_builder.rs:417-474) for every non-deleted point, batch-parallel — the counterpart of
  * the reference's rayon / Vulkan builders (hnsw/build.rs:355, hnsw/gpu_build.rs).  Insertion order inside a batch
  * is concurrent, so the graph is not link-for-link the sequential CPU graph; it obeys the same invariants (<= m0 / m
  * links, no self links, no duplicates, links only to points of at least that level) and is checked by recall.

@@ -1441,10 +1441,16 @@ static void fill_args_segment(const qmx_segment *s, ScanArgs &a) {
                           ? (float)s->sq.actual_dim * s->sq.offset * s->sq.offset : 0.0f;
         a.sq_shift = s->sq.invert ? -shift : shift;
     }
+    if (s->dtype == QMX_DTYPE_BQ) {   // as fill_args; stored <-> stored scores are one-bit
+        a.bq_dim = s->dim;
+        a.bq_flip = (s->flags & QMX_SEG_BQ_TOGGLE_INVERT) ? 1 : 0;
+        a.bq_qbits = 1;
+    }
 }
 
 static int32_t launch_hnsw_build_any(const qmx_segment *seg, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu) {
     if (seg->dtype == QMX_DTYPE_SQ_U8) return launch_hnsw_build_sq(nullptr, (int)seg->distance, a, h, phase, grid, per_cu);
+    if (seg->dtype == QMX_DTYPE_BQ) return launch_hnsw_build_bq(nullptr, a, h, phase, grid, per_cu);
     return launch_hnsw_build_dense(nullptr, (int)seg->dtype, (int)seg->distance, a, h, phase, grid, per_cu);
 }
 
@@ -1475,9 +1481,9 @@ int32_t qmx_hnsw_export_plain(const qmx_hnsw *g, uint32_t *reindex, uint64_t *le
 int32_t qmx_hnsw_build(const qmx_segment *seg, const qmx_hnsw_build_params *bp, qmx_hnsw **out) {
     QMX_REQUIRE(seg && bp && out, QMX_ERR_BAD_ARG, "NULL argument");
     *out = nullptr;
-    QMX_REQUIRE(seg->dtype == QMX_DTYPE_F32 || seg->dtype == QMX_DTYPE_F16 || seg->dtype == QMX_DTYPE_SQ_U8 ||
+    QMX_REQUIRE(seg->dtype == QMX_DTYPE_F32 || seg->dtype == QMX_DTYPE_F16 || seg->dtype == QMX_DTYPE_SQ_U8 || seg->dtype == QMX_DTYPE_BQ ||
                     (seg->dtype == QMX_DTYPE_U8 && seg->distance != QMX_DISTANCE_COSINE),
-                QMX_ERR_NOT_SUPPORTED, "device HNSW build needs a dense f32 / f16 / u8 (dot, euclid, manhattan) or an SQ-int8 segment (dtype %u, distance %u)",
+                QMX_ERR_NOT_SUPPORTED, "device HNSW build needs a dense f32 / f16 / u8 (dot, euclid, manhattan), an SQ-int8 or a BQ segment (dtype %u, distance %u)",
                 seg->dtype, seg->distance);
     QMX_REQUIRE(seg->dtype == QMX_DTYPE_SQ_U8 || seg->fast_layout(), QMX_ERR_NOT_SUPPORTED, "adopted device block is not 16-byte aligned");
     QMX_REQUIRE(bp->m >= 1 && bp->m0 >= bp->m && bp->m0 <= 64, QMX_ERR_BAD_ARG, "need 1 <= m <= m0 <= 64");

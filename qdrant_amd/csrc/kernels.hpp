@@ -126,6 +126,7 @@ struct HnswBuildArgs {
     uint32_t row_bytes;
 };
 // phase 1 = insertion searches + heuristic selection, phase 2 = linking; grid == 0: report occupancy only
+int32_t launch_hnsw_build_bq(hipStream_t st, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_build_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_build_dense(hipStream_t st, int dtype, int distance, const ScanArgs &a, const HnswBuildArgs &h, int phase,
                                 uint32_t grid, int *per_cu);

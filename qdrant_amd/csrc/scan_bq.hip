@@ -13,7 +13,7 @@
 //
 // The rows are 16-byte multiples: the lane policies of the dense scan apply unchanged (8 lanes per row, 16 bytes per
 // lane per 128-byte step) and with them the tiled scan, pair scoring, rescoring plumbing and the HNSW walk.
-#include "hnsw.hpp"
+#include "hnsw_build.hpp"
 
 namespace qmx {
 
@@ -260,6 +260,11 @@ int32_t launch_pairs_bq(hipStream_t st, const ScanArgs &a, const PairSel &sel, u
 }
 int32_t launch_hnsw_bq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
     return dispatch_bq(HnswLauncher{st, &h, grid, per_cu}, a);
+}
+// device HNSW build through the BQ scorer: a stored bit row IS its internal query (encode_internal_vector :923-934), one bit per value
+// whatever the segment's QueryEncoding (score_internal :892-917)
+int32_t launch_hnsw_build_bq(hipStream_t st, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu) {
+    return HnswBuildLauncher{st, &h, phase, grid, per_cu}.template row<RowBQ>(a);
 }
 
 // encode_vector for a batch (encoded_vectors_binary.rs:535-672): in [n][dim] f32 -> out [n][out_stride] bytes; one thread per

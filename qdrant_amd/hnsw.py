@@ -96,8 +96,9 @@ class GraphLayers:
     @classmethod
     def build(cls, storage, m: int = 16, m0: Optional[int] = None, ef_construct: int = 100, seed: int = 42,
               entry_points_num: int = 10, max_batch: int = 0):
-        """`GraphLayersBuilder` on the storage's GPU (qmx_hnsw_build): over a dense f32 / f16 VectorStorage, or over an
-        EncodedVectorsU8 — the reference builds through the quantized scorer when the segment has one (hnsw/build.rs:334-341)."""
+        """`GraphLayersBuilder` on the storage's GPU (qmx_hnsw_build): over a dense f32 / f16 / u8 (not cosine) VectorStorage, or over an
+        EncodedVectorsU8 / EncodedVectorsBin — the reference builds through the quantized scorer when the segment has one
+        (hnsw/build.rs:334-341)."""
         self = cls.__new__(cls)
         self.m, self.m0 = int(m), int(2 * m if m0 is None else m0)
         p = F.HnswBuildParams()

@@ -210,3 +210,42 @@ def test_u8_build(qa, distance):
     want = walk.search_dense(st, queries[:30], 10, 64)
     for gq, wq in zip(g.search(10, 64, qa.new_raw_scorer(queries[:30], vs)), want):
         assert np.array_equal(gq["score"].view(np.uint32), wq["score"].view(np.uint32))   # integer scores tie: ids may differ among equals
+
+
+@pytest.mark.parametrize("query_encoding", [0, 2])
+def test_bq_build_through_the_quantized_scorer(qa, query_encoding):
+    """Binary-quantized segments: the build scores stored <-> stored rows with the one-bit xor-popcount (score_internal,
+    encoded_vectors_binary.rs:892-917), whatever the segment's QueryEncoding.  Invariants + search quality after rescoring
+    (binary quantization rescores by default, quantized_vectors/accessors.rs:16-38) against the graph built over the originals."""
+    n, dim, m, efc, seed = 6000, 256, 8, 64, 23
+    rng = np.random.default_rng(seed)                       # the data of test_gpu_bq's walk test: sign bits must tell neighbours apart
+    centers = rng.standard_normal((32, dim)).astype(np.float32)
+
+    def draw(count):
+        return O.preprocess(O.COSINE, (centers[rng.integers(0, 32, count)] + 0.6 * rng.standard_normal((count, dim))).astype(np.float32))
+    rows = draw(n)
+    st = O.DenseStorage(O.F32, O.COSINE, rows)
+    quant = qa.BinaryQuantizer(dim, qa.Distance.Cosine, query_encoding=query_encoding)
+    enc = qa.EncodedVectorsBin(quant.encode(rows), quant)
+    vs = qa.VectorStorage(rows, qa.Distance.Cosine)
+    g_bq = qa.GraphLayers.build(enc, m=m, ef_construct=efc, seed=seed)
+    g_f32 = qa.GraphLayers.build(vs, m=m, ef_construct=efc, seed=seed)
+    p = g_bq.export_plain()
+    lv = _levels_of(p, n)
+    assert lv.tolist() == _levels_of(g_f32.export_plain(), n).tolist()
+    order = np.argsort(p.reindex)
+    for l in range(len(p.level_offsets) - 1):
+        cnt = int(p.level_offsets[l + 1] - p.level_offsets[l])
+        for j in range(0, cnt, 5 if l == 0 else 1):
+            pid = j if l == 0 else int(order[j])
+            slot = int(p.level_offsets[l]) + j
+            ln = p.neighbors[int(p.offsets[slot]):int(p.offsets[slot + 1])]
+            assert 0 < len(ln) <= (2 * m if l == 0 else m) or l > 0
+            assert len(set(ln.tolist())) == len(ln) and pid not in ln and np.all(lv[ln] >= l)
+    queries = draw(100)
+    scorer = qa.new_raw_scorer(queries, enc)
+    raw = qa.new_raw_scorer(queries, vs)
+    exact = st.peek_top(queries, 10)
+    r_bq = _recall(qa.search_quantized(scorer, raw, 10, oversampling=3.0, rescore=True, graph=g_bq, hnsw_ef=64), exact)
+    r_f32 = _recall(qa.search_quantized(scorer, raw, 10, oversampling=3.0, rescore=True, graph=g_f32, hnsw_ef=64), exact)
+    assert r_f32 > 0.4 and r_bq > r_f32 - 0.1, (r_bq, r_f32)
