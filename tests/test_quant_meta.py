@@ -177,6 +177,5 @@ def test_load_quantizer_builds_the_parameter_structs_from_the_file():
     assert (q.dim, q.chunk_size, q.m, q.n_centroids, q.invert) == (6, 4, 2, 2, False) and np.array_equal(q.centroids, cent)
     q = qa.load_quantizer('{"vector_parameters":%s,"encoding":"TwoBits"}' % _vp(9, "Dot", False), F.DTYPE_BQ)
     assert (q.dim, q.encoding, q.invert, q.mean) == (9, F.BQ_TWO_BITS, False, None)
-    with pytest.raises(qa.QmxError) as e:
-        qa.load_quantizer('{"vector_parameters":%s,"query_encoding":"Scalar8bits"}' % _vp(9, "Dot", False), F.DTYPE_BQ)
-    assert e.value.status == F.ERR_NOT_SUPPORTED
+    q = qa.load_quantizer('{"vector_parameters":%s,"query_encoding":"Scalar8bits"}' % _vp(9, "Dot", False), F.DTYPE_BQ)
+    assert (q.query_encoding, q.params().query_encoding, q.encoding) == (F.BQ_QUERY_SCALAR_8BITS, F.BQ_QUERY_SCALAR_8BITS, F.BQ_ONE_BIT)
