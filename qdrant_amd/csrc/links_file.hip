@@ -165,6 +165,11 @@ int32_t decode_plain(const uint8_t *b, uint64_t n_bytes, LinksOwner &o, qmx_grap
     for (uint64_t i = 0; i + 1 < total_offsets; ++i)
         QMX_REQUIRE(o.offsets[i] <= o.offsets[i + 1], QMX_ERR_BAD_ARG, "links file: offsets not ascending at %llu", (unsigned long long)i);
     QMX_REQUIRE(o.offsets[(size_t)total_offsets - 1] <= total_neighbors, QMX_ERR_BAD_ARG, "links file: offsets run past the neighbors section");
+    for (uint64_t l = 0; l < levels_count; ++l)
+        QMX_REQUIRE(o.level_offsets[l] <= o.level_offsets[l + 1], QMX_ERR_BAD_ARG, "links file: level offsets not ascending");
+    QMX_REQUIRE(levels_count == 0 || o.level_offsets[0] == 0, QMX_ERR_BAD_ARG, "links file: level 0 does not start at slot 0");
+    for (uint64_t i = 0; i < point_count; ++i)
+        QMX_REQUIRE(o.reindex[i] < point_count, QMX_ERR_OUT_OF_BOUNDS, "reindex entry out of range");
     g.format = 0;
     g.m = g.m0 = 0;
     g.n_points = (uint32_t)point_count;

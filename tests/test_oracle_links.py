@@ -258,3 +258,32 @@ def test_create_from_file_needs_the_device_only_after_the_file_is_valid():
     assert create(data, m=5) == F.ERR_BAD_ARG                                # header says m = 4
     assert create(data) == (F.OK if torch.cuda.is_available() else F.ERR_NO_DEVICE)
     assert create(data, m=4, m0=8) == (F.OK if torch.cuda.is_available() else F.ERR_NO_DEVICE)
+
+
+@pytest.mark.parametrize("kind", ["plain", "with_vectors"])
+def test_corrupted_plain_and_inline_vector_files_never_crash(kind):
+    """Single-bit corruptions and truncations of the other two formats: decoded with in-range links, or refused."""
+    p = _random_plain(300, 4, 8, seed=12)
+    if kind == "plain":
+        data = O.plain_links_file(p)
+    else:
+        rng = np.random.default_rng(3)
+        data = O.compressed_links_file(p, rng.integers(0, 256, (300, 12), dtype=np.uint8), rng.integers(0, 256, (300, 6), dtype=np.uint8), 4, 2)
+    assert _rc(data) == F.OK
+    rng = np.random.default_rng(1)
+    variants = [bytes(data[:k]) for k in rng.integers(0, len(data), 40)]
+    for _ in range(400):
+        bad = bytearray(data)
+        bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        variants.append(bytes(bad))
+    for v in variants:
+        buf = np.frombuffer(v, dtype=np.uint8) if len(v) else np.zeros(1, dtype=np.uint8)
+        g = F.GraphLinks()
+        rc = F.lib().qmx_graph_links_decode(F.ptr(buf), len(v), C.byref(g))
+        if rc == F.OK:
+            nb = np.ctypeslib.as_array(g.neighbors, (g.n_neighbors,)) if g.n_neighbors else np.zeros(0, np.uint32)
+            off = np.ctypeslib.as_array(g.offsets, (g.n_offsets,))
+            assert (nb < max(g.n_points, 1)).all() and (np.diff(off.astype(np.int64)) >= 0).all() and int(off[-1]) <= g.n_neighbors
+            F.lib().qmx_graph_links_free(C.byref(g))
+        else:
+            assert rc in (F.ERR_BAD_ARG, F.ERR_OUT_OF_BOUNDS)
