@@ -115,6 +115,8 @@ class QmxError(RuntimeError):
 _P = C.c_void_p
 SIGNATURES = {
     "qmx_abi_version": (C.c_uint32, []),
+    "qmx_set_option": (C.c_int32, [C.c_char_p, C.c_int64]),
+    "qmx_get_option": (C.c_int32, [C.c_char_p, C.POINTER(C.c_int64)]),
     "qmx_device_count": (C.c_int32, [C.POINTER(C.c_int32)]),
     "qmx_last_error": (C.c_int32, [C.c_char_p, C.c_size_t]),
     "qmx_segment_create": (C.c_int32, [C.POINTER(SegmentDesc), C.POINTER(_P)]),
@@ -206,6 +208,17 @@ def last_error():
 def check(status):
     if status != OK:
         raise QmxError(status, last_error())
+
+
+def set_option(name, value):
+    """qmx_set_option: pick between result-identical kernel paths (value < 0 restores the load-time value)."""
+    check(lib().qmx_set_option(name.encode(), int(value)))
+
+
+def get_option(name):
+    v = C.c_int64()
+    check(lib().qmx_get_option(name.encode(), C.byref(v)))
+    return v.value
 
 
 def ptr(x):

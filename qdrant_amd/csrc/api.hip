@@ -6,7 +6,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <ctype.h>
+
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -41,10 +44,34 @@ int32_t hip_status(hipError_t e, const char *what, const char *file, int line) {
     }
 }
 
+// ---- kernel-path options: the environment is read once, here, at load time ----
+static const char *const g_option_names[OPT_COUNT] = {"no_mfma_scan", "no_mfma16", "no_mfma16_q64", "no_prescan", "prescan_shift", "hnsw_no_packed_l0",
+                                                     "hnsw_pq_lds_lut", "hnsw_log_cap", "bq_lanes8", "mfma_no_nt", "mfma_no_fast", "no_pq_tiled", "debug"};
+struct OptionTable {
+    std::atomic<int64_t> v[OPT_COUNT];
+    int64_t initial[OPT_COUNT];
+    OptionTable() {
+        for (int i = 0; i < OPT_COUNT; ++i) {
+            char env[64] = "QMX_";
+            size_t k = 4;
+            for (const char *c = g_option_names[i]; *c && k + 1 < sizeof(env); ++c) env[k++] = (char)toupper((unsigned char)*c);
+            env[k] = 0;
+            const char *e = getenv(env);
+            int64_t val = 0;
+            if (e) { val = (*e >= '0' && *e <= '9') ? atoll(e) : 1; }   // "QMX_X=" / "QMX_X=yes" count as set
+            if (i == OPT_PRESCAN_SHIFT && !e) val = 10;
+            initial[i] = val;
+            v[i].store(val, std::memory_order_relaxed);
+        }
+    }
+};
+static OptionTable g_options;
+int64_t option(Option o) { return g_options.v[o].load(std::memory_order_relaxed); }
+
 void clear_stale_error() {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
-        static const bool debug = getenv("QMX_DEBUG") != nullptr;
+        const bool debug = option(OPT_DEBUG) != 0;
         if (debug) fprintf(stderr, "[qmx] dropped stale HIP error %d (%s) before a kernel launch\n", (int)e, hipGetErrorString(e));
     }
 }
@@ -197,9 +224,9 @@ struct qmx_query {
 
 // f32 dot / cosine rows of >= 32 elements scan 8..32 queries per pass on the f32 matrix cores (scan_mfma.hip)
 static bool mfma_scan_ok(const qmx_segment *s) {
-    if (s->dtype == QMX_DTYPE_SQ_U8) return sq_mfma_ok(s->distance, s->scan_dim) && getenv("QMX_NO_MFMA_SCAN") == nullptr;
+    if (s->dtype == QMX_DTYPE_SQ_U8) return sq_mfma_ok(s->distance, s->scan_dim) && !option(OPT_NO_MFMA_SCAN);
     return (s->dtype == QMX_DTYPE_F32 || s->dtype == QMX_DTYPE_F16) && (s->distance == QMX_DISTANCE_DOT || s->distance == QMX_DISTANCE_COSINE) && s->dim >= 32 &&
-           s->fast_layout() && getenv("QMX_NO_MFMA_SCAN") == nullptr;
+           s->fast_layout() && !option(OPT_NO_MFMA_SCAN);
 }
 constexpr uint32_t MAX_QT_MFMA = 32;
 constexpr uint32_t MAX_QT_TOPK = 64;   // the chain-major f32 top-k scan (scan_mfma16.hip) takes 64 queries per pass of the block
@@ -282,7 +309,26 @@ static uint32_t pow2_ceil(uint32_t x) {
 // ---------------------------------------------------------------------------------------------
 extern "C" {
 
-uint32_t qmx_abi_version(void) { return 1; }
+uint32_t qmx_abi_version(void) { return 2; }
+
+static int option_index(const char *name) {
+    if (!name) return -1;
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (strcmp(name, g_option_names[i]) == 0) return i;
+    return -1;
+}
+int32_t qmx_set_option(const char *name, int64_t value) {
+    const int i = option_index(name);
+    QMX_REQUIRE(i >= 0, QMX_ERR_BAD_ARG, "unknown option '%s'", name ? name : "(null)");
+    g_options.v[i].store(value < 0 ? g_options.initial[i] : value, std::memory_order_relaxed);
+    return QMX_OK;
+}
+int32_t qmx_get_option(const char *name, int64_t *out_value) {
+    const int i = option_index(name);
+    QMX_REQUIRE(i >= 0 && out_value, QMX_ERR_BAD_ARG, "unknown option '%s'", name ? name : "(null)");
+    *out_value = option((Option)i);
+    return QMX_OK;
+}
 
 int32_t qmx_last_error(char *buf, size_t buf_len) {
     if (!buf || buf_len == 0) return QMX_ERR_BAD_ARG;
@@ -1069,10 +1115,10 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
     const uint32_t grid_cap = (uint32_t)s->num_cus * 8;
     // f32 dot / cosine rows of 256, 512 or 768 floats, whole block: 64 queries per pass (scan_mfma16.hip); everything else 32 / 16
     const bool q64 = s->dtype == QMX_DTYPE_F32 && mfma_scan_ok(s) && q->nq > MAX_QT_MFMA && mfma16_dim_ok(64, s->dim) &&
-                     getenv("QMX_NO_MFMA16") == nullptr && getenv("QMX_NO_MFMA16_Q64") == nullptr;
+                     !option(OPT_NO_MFMA16) && !option(OPT_NO_MFMA16_Q64);
     // ... and rows of 1024 .. 1536 floats 32 per pass: that kernel keeps the queries in registers, not in an LDS tile (tile_qt's limit)
     const bool q32 = s->dtype == QMX_DTYPE_F32 && mfma_scan_ok(s) && q->nq > MAX_QT && s->dim > 768 && mfma16_dim_ok(32, s->dim) &&
-                     getenv("QMX_NO_MFMA16") == nullptr;
+                     !option(OPT_NO_MFMA16);
     const uint32_t TQ = q64 ? MAX_QT_TOPK : q32 ? MAX_QT_MFMA : tile_qt(s);
     const uint32_t ptop_max = std::min<uint32_t>(top, MAX_TOP_FAST);
     const uint32_t n_pass = (top + MAX_TOP_FAST - 1) / MAX_TOP_FAST;
@@ -1106,8 +1152,8 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
             const bool m16 = s->dtype == QMX_DTYPE_F32 && mfma_scan_ok(s) && mfma16_scan_ok(qt, SCAN_TOPK, a);
             const bool sqm = (s->dtype == QMX_DTYPE_SQ_U8 ? qt >= 4 : s->dtype == QMX_DTYPE_F16 && qt >= 8) && mfma_scan_ok(s);   // scan_sq_mfma.hip starts from the bound too
             const bool m4 = s->dtype == QMX_DTYPE_F32 && qt >= 8 && mfma_scan_ok(s);                                        // scan_mfma.hip (4x4x1) as well
-            if (pass == 0 && n_cand >= (1u << 18) && (m16 || sqm || m4) && getenv("QMX_NO_PRESCAN") == nullptr) {
-                static const int pre_shift = getenv("QMX_PRESCAN_SHIFT") ? atoi(getenv("QMX_PRESCAN_SHIFT")) : 10;   // tuning: measured 5..10 on C2, the main pass does not care, the pre-scan itself gets cheaper
+            if (pass == 0 && n_cand >= (1u << 18) && (m16 || sqm || m4) && !option(OPT_NO_PRESCAN)) {
+                const int pre_shift = (int)std::min<int64_t>(std::max<int64_t>(option(OPT_PRESCAN_SHIFT), 1), 20);  // tuning: measured 5..10 on C2, the main pass does not care, the pre-scan itself gets cheaper
                 const uint64_t pre_n = std::max<uint64_t>(n_cand >> pre_shift, 1u << 13) & ~(uint64_t)15;
                 {
                     // score matrix of the prefix (the score-mode kernels, <= tile_qt queries per launch), one block per query selects its
@@ -1162,7 +1208,12 @@ int32_t qmx_search_topk(qmx_query *q, uint32_t top, const uint32_t *ids, uint64_
     const void *d_ids = nullptr;
     if (ids) {
         if (n_ids == 0) {  // empty candidate list: every queue stays empty
-            for (uint32_t i = 0; i < q->nq; ++i) out_counts[i] = 0;
+            if (is_device_ptr(out_counts)) {
+                QMX_HIP(hipMemsetAsync(out_counts, 0, (size_t)q->nq * 4, q->stream));
+                QMX_HIP(hipStreamSynchronize(q->stream));
+            } else {
+                for (uint32_t i = 0; i < q->nq; ++i) out_counts[i] = 0;
+            }
             return QMX_OK;
         }
         QMX_TRY(stage_in(q, q->ids, ids, (size_t)n_ids * 4, &d_ids));
@@ -1302,8 +1353,8 @@ int32_t qmx_hnsw_create(const qmx_hnsw_desc *d, qmx_hnsw **out) {
                 "extra entry points missing");
     QMX_REQUIRE(d->n_points == 0 || d->n_offsets >= (uint64_t)d->n_points + 1, QMX_ERR_BAD_ARG,
                 "offsets must hold n_points + 1 entries at least (level 0 has a slot per point)");
-    QMX_TRY(check_device(d->device_id, nullptr));
-    // structural checks on host-visible arrays (a corrupt links file must not crash the GPU)
+    // structural checks on host-visible arrays (a corrupt links file must not crash the GPU); they run before the device is
+    // touched, so a bad file is reported as such on any host
     if (d->n_points && !is_device_ptr(d->level_offsets)) {
         QMX_REQUIRE(d->level_offsets[0] == 0 && d->level_offsets[d->n_levels] + 1 == d->n_offsets, QMX_ERR_BAD_ARG,
                     "level_offsets do not span the offsets array");
@@ -1317,10 +1368,39 @@ int32_t qmx_hnsw_create(const qmx_hnsw_desc *d, qmx_hnsw **out) {
             QMX_REQUIRE(d->offsets[i] <= d->offsets[i + 1], QMX_ERR_BAD_ARG, "offsets must be non-decreasing");
         QMX_REQUIRE(d->offsets[d->n_offsets - 1] <= d->n_neighbors, QMX_ERR_BAD_ARG, "offsets run past the neighbors array");
     }
+    // every link stored on level l >= 1 must point at a node that HAS a slot on level l (the walk indexes offsets[] with
+    // level_offsets[l] + reindex[id]); the same for an entry point and the level it claims.  The kernel bounds the slot as well.
+    const bool host_graph = d->n_points && !is_device_ptr(d->level_offsets) && !is_device_ptr(d->offsets) && !is_device_ptr(d->reindex) &&
+                            (d->n_neighbors == 0 || !is_device_ptr(d->neighbors));
+    if (host_graph) {
+        for (uint32_t i = 0; i < d->n_points; ++i)
+            QMX_REQUIRE(d->reindex[i] < d->n_points, QMX_ERR_OUT_OF_BOUNDS, "reindex entry out of range");
+        for (uint32_t l = 1; l < d->n_levels; ++l) {
+            const uint64_t size_l = d->level_offsets[l + 1] - d->level_offsets[l];
+            for (uint64_t slot = d->level_offsets[l]; slot < d->level_offsets[l + 1]; ++slot)
+                for (uint64_t j = d->offsets[slot]; j < d->offsets[slot + 1]; ++j) {
+                    const uint32_t id = d->neighbors[j];
+                    QMX_REQUIRE(id < d->n_points && d->reindex[id] < size_l, QMX_ERR_OUT_OF_BOUNDS,
+                                "link %u on level %u points at a node that is not on that level", id, l);
+                }
+        }
+        auto ep_ok = [&](uint32_t id, uint32_t lv) {
+            if (id >= d->n_points) return false;
+            const uint32_t l = std::min<uint32_t>(lv, d->n_levels - 1);
+            return l == 0 || (uint64_t)d->reindex[id] < d->level_offsets[l + 1] - d->level_offsets[l];
+        };
+        for (uint32_t i = 0; i < d->n_entry_points && !is_device_ptr(d->entry_point_ids) && !is_device_ptr(d->entry_point_levels); ++i)
+            QMX_REQUIRE(ep_ok(d->entry_point_ids[i], d->entry_point_levels[i]), QMX_ERR_OUT_OF_BOUNDS, "entry point %u is not on its level %u",
+                        d->entry_point_ids[i], d->entry_point_levels[i]);
+        for (uint32_t i = 0; i < d->n_extra_entry_points && !is_device_ptr(d->extra_entry_point_ids) && !is_device_ptr(d->extra_entry_point_levels); ++i)
+            QMX_REQUIRE(ep_ok(d->extra_entry_point_ids[i], d->extra_entry_point_levels[i]), QMX_ERR_OUT_OF_BOUNDS,
+                        "extra entry point %u is not on its level %u", d->extra_entry_point_ids[i], d->extra_entry_point_levels[i]);
+    }
     for (uint32_t i = 0; i < d->n_entry_points && !is_device_ptr(d->entry_point_ids); ++i)
         QMX_REQUIRE(d->entry_point_ids[i] < d->n_points, QMX_ERR_OUT_OF_BOUNDS, "entry point %u out of range", d->entry_point_ids[i]);
     for (uint32_t i = 0; i < d->n_extra_entry_points && !is_device_ptr(d->extra_entry_point_ids); ++i)
         QMX_REQUIRE(d->extra_entry_point_ids[i] < d->n_points, QMX_ERR_OUT_OF_BOUNDS, "extra entry point out of range");
+    QMX_TRY(check_device(d->device_id, nullptr));
     qmx_hnsw *g = new (std::nothrow) qmx_hnsw();
     QMX_REQUIRE(g, QMX_ERR_OUT_OF_MEMORY, "host allocation failed");
     g->device = d->device_id;
@@ -1339,7 +1419,7 @@ int32_t qmx_hnsw_create(const qmx_hnsw_desc *d, qmx_hnsw **out) {
         if ((rc = upload_array(&g->d_xp_levels, d->extra_entry_point_levels, d->n_extra_entry_points)) != QMX_OK) break;
     } while (0);
     // packed level-0 table (one round trip per hop instead of two); lists longer than m0 or 63 keep the CSR path
-    if (rc == QMX_OK && d->n_points && d->m0 <= 63 && getenv("QMX_HNSW_NO_PACKED_L0") == nullptr) {
+    if (rc == QMX_OK && d->n_points && d->m0 <= 63 && !option(OPT_HNSW_NO_PACKED_L0)) {
         const uint32_t stride = d->m0 + 1;
         bool fits = true;
         if (!is_device_ptr(d->offsets))
@@ -1716,6 +1796,7 @@ static int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint3
     memset(&h, 0, sizeof(h));
     h.reindex = g->d_reindex; h.level_offsets = g->d_level_offsets; h.offsets = g->d_offsets; h.neighbors = g->d_neighbors;
     h.l0 = g->d_l0; h.l0_stride = g->l0_stride;
+    h.n_offsets = g->n_offsets; h.n_neighbors = g->n_neighbors;
     h.n_points = g->n_points; h.n_levels = g->n_levels; h.m = g->m; h.m0 = g->m0;
     h.ep_ids = g->d_ep_ids; h.ep_levels = g->d_ep_levels; h.n_ep = g->n_ep;
     h.xp_ids = g->d_xp_ids; h.xp_levels = g->d_xp_levels; h.n_xp = g->n_xp;
@@ -1724,11 +1805,11 @@ static int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint3
     h.lds_query_bytes = q->q_stride <= HNSW_LDS_QUERY_MAX ? q->q_stride : 0;
     // A PQ LUT of more than half the LDS leaves one search per CU; the walk is a chain of dependent memory round trips,
     // so many searches per CU with the LUT read through L2 win (measured: tools/bench_hnsw.py)
-    if (s->dtype == QMX_DTYPE_PQ && q->q_stride > 16 * 1024 && getenv("QMX_HNSW_PQ_LDS_LUT") == nullptr) h.lds_query_bytes = 0;
+    if (s->dtype == QMX_DTYPE_PQ && q->q_stride > 16 * 1024 && !option(OPT_HNSW_PQ_LDS_LUT)) h.lds_query_bytes = 0;
     h.log_cap = HNSW_LOG_CAP;
-    if (const char *e = getenv("QMX_HNSW_LOG_CAP")) {   // tests: force the whole-bitmap clear path
-        const long v = atol(e);
-        if (v >= 1 && v <= (long)HNSW_LOG_CAP) h.log_cap = (uint32_t)v;
+    {   // tests: force the whole-bitmap clear path
+        const int64_t v = option(OPT_HNSW_LOG_CAP);
+        if (v >= 1 && v <= (int64_t)HNSW_LOG_CAP) h.log_cap = (uint32_t)v;
     }
     h.vis_words = ((uint64_t)g->n_points + 31) / 32;
     if (h.vis_words == 0) h.vis_words = 1;
@@ -1919,7 +2000,8 @@ int32_t qmx_rescore(qmx_query *q, const uint32_t *ids, const uint32_t *counts, u
     QMX_HIP(hipSetDevice(q->device));
     if (q->nq == 0) return QMX_OK;
     if (n_per_query == 0) {
-        for (uint32_t i = 0; i < q->nq; ++i) out_counts[i] = 0;
+        if (is_device_ptr(out_counts)) QMX_HIP(hipMemsetAsync(out_counts, 0, (size_t)q->nq * 4, q->stream));
+        else for (uint32_t i = 0; i < q->nq; ++i) out_counts[i] = 0;
         return QMX_OK;
     }
     const uint64_t total = (uint64_t)q->nq * n_per_query;
@@ -2115,9 +2197,15 @@ int32_t qmx_search_quantized(const qmx_hnsw *g, qmx_query *quantized, qmx_query 
     QMX_REQUIRE(!rescore || raw, QMX_ERR_BAD_ARG, "rescoring needs the original-vector query batch");
     QMX_REQUIRE(!raw || (raw->nq == quantized->nq && raw->device == quantized->device), QMX_ERR_BAD_ARG, "the two query batches must match");
     // get_oversampled_top (vector_index_search_common.rs:27-46): (oversampling * top as f64) as usize when > 1.0
+    // (never clamped: the reference never searches fewer candidates than oversampling asks for; what does not fit fails loudly)
+    const uint32_t top_limit = g ? HNSW_MAX_EF : MAX_TOP;
+    QMX_REQUIRE(p->top <= top_limit, QMX_ERR_NOT_SUPPORTED, "top %u > %u not supported", p->top, top_limit);
     uint32_t otop = p->top;
-    if (p->oversampling > 1.0f) otop = (uint32_t)std::min<double>((double)p->oversampling * (double)p->top, (double)MAX_TOP);
-    QMX_REQUIRE(otop <= (g ? HNSW_MAX_EF : MAX_TOP), QMX_ERR_NOT_SUPPORTED, "oversampled top %u too large", otop);
+    if (p->oversampling > 1.0f) {
+        const double o = (double)p->oversampling * (double)p->top;
+        QMX_REQUIRE(o <= (double)top_limit, QMX_ERR_NOT_SUPPORTED, "oversampled top %.0f > %u not supported", o, top_limit);
+        otop = (uint32_t)o;
+    }
     QMX_HIP(hipSetDevice(quantized->device));
     if (counters) memset(counters, 0, sizeof(*counters));
     const uint32_t nq = quantized->nq;

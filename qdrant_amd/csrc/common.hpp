@@ -17,6 +17,28 @@ int32_t hip_status(hipError_t e, const char *what, const char *file, int line);
 // check after the launch speaks about this launch only.  QMX_DEBUG=1 prints what was dropped.
 void clear_stale_error();
 
+// ---- kernel-path options ---------------------------------------------------------------------
+// Every option selects between kernels that produce the SAME results (parity tests run both sides); none changes a score.
+// Read once from the environment (QMX_<NAME>) when the library is loaded, changed afterwards only through
+// qmx_set_option (include/qdrant_amd.h).  Knobs that break results exist only in -DQMX_TUNING builds.
+enum Option {
+    OPT_NO_MFMA_SCAN = 0,     // 8+ query tiles keep the VALU scan
+    OPT_NO_MFMA16,            // no chain-major 16x16x4 scan (scan_mfma16.hip)
+    OPT_NO_MFMA16_Q64,        // ... only its 64-query shape
+    OPT_NO_PRESCAN,           // no threshold pre-scan in front of the top-k scans
+    OPT_PRESCAN_SHIFT,        // pre-scan over n >> shift rows (default 10)
+    OPT_HNSW_NO_PACKED_L0,    // level 0 read through the CSR arrays
+    OPT_HNSW_PQ_LDS_LUT,      // PQ walk keeps a large LUT in LDS (one search per CU)
+    OPT_HNSW_LOG_CAP,         // visited-word log entries per search before the whole-bitmap clear
+    OPT_BQ_LANES8,            // BQ scans on the 8-lanes-per-row layout
+    OPT_MFMA_NO_NT,           // 4x4x1 scan without nontemporal row loads
+    OPT_MFMA_NO_FAST,         // 4x4x1 scan without the guard-free ping-pong loop
+    OPT_NO_PQ_TILED,          // PQ scan on the one-row-per-lane kernel
+    OPT_DEBUG,                // log dropped stale HIP errors
+    OPT_COUNT
+};
+int64_t option(Option o);
+
 #define QMX_HIP(expr)                                                        \
     do {                                                                     \
         hipError_t e__ = (expr);                                             \

@@ -224,8 +224,12 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
         bool changed = true;
         while (changed) {
             changed = false;
+            // a node that has no slot on this level (an inconsistent links file: the host validates what it can see) has no links here
             const uint64_t slot = h.level_offsets[level] + h.reindex[cur_id];
-            const uint64_t o0 = h.offsets[slot], o1 = h.offsets[slot + 1];
+            const bool slot_ok = slot < h.level_offsets[level + 1] && slot + 1 < h.n_offsets;
+            uint64_t o0 = slot_ok ? h.offsets[slot] : 0, o1 = slot_ok ? h.offsets[slot + 1] : 0;
+            if (o1 > h.n_neighbors) o1 = h.n_neighbors;
+            if (o0 > o1) o0 = o1;
             uint32_t remaining = h.m;   // filter_truncate limit = level_m
             for (uint64_t base = o0; base < o1 && remaining > 0; base += 64) {
                 const uint64_t i = base + (uint64_t)lane;
@@ -338,7 +342,9 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
             auto fetch_links = [&](uint32_t node) {
                 if (h.l0) { nx_o1 = h.l0[(uint64_t)node * h.l0_stride]; } else { nx_o1 = h.offsets[(uint64_t)node + 1] - h.offsets[node]; }
                 const uint64_t o0 = h.l0 ? 0 : h.offsets[node];
-                nx_id = link_of(node, o0, o0 + 64, &nx_on);          // validity against the real count is applied when the node is resolved
+                // validity against the real count is applied when the node is resolved; the load itself stays inside the table
+                const uint64_t lim = h.l0 ? (uint64_t)(h.l0_stride - 1) : (h.n_neighbors > o0 ? h.n_neighbors - o0 : 0);
+                nx_id = link_of(node, o0, o0 + (lim < 64 ? lim : 64), &nx_on);
             };
             if (n_explore) fetch_links(to_explore[0]);
             for (uint32_t e = 0; e < n_explore; ++e) {

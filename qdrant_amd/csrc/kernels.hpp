@@ -63,6 +63,7 @@ struct HnswArgs {
     const uint64_t *level_offsets;  // [n_levels + 1] first offsets-slot of each level
     const uint64_t *offsets;        // [n_slots + 1]  start of each links list inside `neighbors`
     const uint32_t *neighbors;
+    uint64_t n_offsets, n_neighbors; // entries of `offsets` / `neighbors`: the walk never reads past them, whatever a links file claims
     const uint32_t *l0;             // optional packed level 0: l0[p * l0_stride] = count, then the links (one round trip per hop)
     uint32_t l0_stride;
     uint32_t n_points, n_levels, m, m0;

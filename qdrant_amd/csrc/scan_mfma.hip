@@ -377,21 +377,23 @@ int32_t launch_scan_f32_mfma(hipStream_t st, int qt, ScanMode mode, const ScanAr
     switch (qt) {
         // measured on MI355X, C2 (10 M x 768): nontemporal row loads and 12 steps in flight per lane are worth ~3 %
         case 8: {
-            static const bool nt = getenv("QMX_MFMA_NO_NT") == nullptr;
+            const bool nt = !option(OPT_MFMA_NO_NT);
             return nt ? launch_mfma_qt<8, 1, 4, true>(st, mode, a, num_cus, grid_out) : launch_mfma_qt<8, 1, 4, false>(st, mode, a, num_cus, grid_out);
         }
         case 16:
             if (mfma16_scan_ok(16, mode, a)) return launch_scan_f32_mfma16(st, 16, a, num_cus, grid_out);
             // rows of a multiple of 384 floats (768, 1536, ...): guard-free ping-pong main loop
-            if (a.nseg % 12 == 0 && getenv("QMX_MFMA_NO_FAST") == nullptr) return launch_mfma_qt<16, 1, 6, true, 8, true>(st, mode, a, num_cus, grid_out);
+            if (a.nseg % 12 == 0 && !option(OPT_MFMA_NO_FAST)) return launch_mfma_qt<16, 1, 6, true, 8, true>(st, mode, a, num_cus, grid_out);
             return launch_mfma_qt<16, 1, 12, true>(st, mode, a, num_cus, grid_out);
         case 32: {
             if (mfma16_scan_ok(32, mode, a)) return launch_scan_f32_mfma16(st, 32, a, num_cus, grid_out);
+#ifdef QMX_TUNING
             static const int variant = getenv("QMX_MFMA_VARIANT") ? atoi(getenv("QMX_MFMA_VARIANT")) : 0;   // tuning experiments
             if (variant == 1) return launch_mfma_qt<32, 1, 6, true, 8, false, true>(st, mode, a, num_cus, grid_out);   // query-half layout, generic loop
             if (variant == 2 && a.nseg % 12 == 0) return launch_mfma_qt<32, 1, 6, true, 8, true, true>(st, mode, a, num_cus, grid_out);   // + ping-pong
             if (variant == 3 && a.nseg % 24 == 0) return launch_mfma_qt<32, 1, 12, true, 8, true, true>(st, mode, a, num_cus, grid_out);
-            if (a.nseg % 12 == 0 && getenv("QMX_MFMA_NO_FAST") == nullptr) return launch_mfma_qt<16, 2, 6, true, 8, true>(st, mode, a, num_cus, grid_out);
+#endif
+            if (a.nseg % 12 == 0 && !option(OPT_MFMA_NO_FAST)) return launch_mfma_qt<16, 2, 6, true, 8, true>(st, mode, a, num_cus, grid_out);
             return launch_mfma_qt<16, 2, 12, true>(st, mode, a, num_cus, grid_out);
         }
     }

@@ -471,7 +471,9 @@ static int32_t launch_m16(hipStream_t st, const ScanArgs &a, int num_cus, uint32
         *grid_out = grid;
     }
     ScanArgs b = a;
+#ifdef QMX_TUNING
     if (getenv("QMX_M16_LAG_ODD")) b.flags |= 0x100u;       // tuning experiment: odd waves lag instead of the upper half
+#endif
     ::qmx::clear_stale_error();
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), (size_t)S::LDS, st, b);
     QMX_HIP(hipGetLastError());
@@ -481,13 +483,13 @@ static int32_t launch_m16(hipStream_t st, const ScanArgs &a, int num_cus, uint32
 // qt = 16, 32 or 64; rows of dim = 128 k floats: k <= 12, 14 or 16 (k <= 6 for 64 queries: the query registers)
 // row lengths the kernel is built for: dim = 128 k floats, k <= 12, 14 or 16 (k <= 6 for 64 queries: the query registers)
 bool mfma16_dim_ok(int qt, uint32_t dim) {
-    if (getenv("QMX_NO_MFMA16") != nullptr || dim % 128 != 0) return false;
+    if (option(OPT_NO_MFMA16) || dim % 128 != 0) return false;
     const uint32_t k = dim / 128;
     return k >= 1 && k <= (qt == 64 ? 6u : 16u) && !(k > 12 && k % 2 == 1);
 }
 
 bool mfma16_scan_ok(int qt, ScanMode mode, const ScanArgs &a) {
-    if (getenv("QMX_NO_MFMA16") != nullptr) return false;
+    if (option(OPT_NO_MFMA16)) return false;
     return (qt == 16 || qt == 32 || qt == 64) && mode == SCAN_TOPK && a.rem_pieces == 0 && a.tail_start == a.dim && mfma16_dim_ok(qt, a.dim) &&
            a.row_stride % 16 == 0 && a.top <= 64;
 }
@@ -514,6 +516,7 @@ int32_t launch_scan_f32_mfma16(hipStream_t st, int qt, const ScanArgs &a, int nu
         return launch_m16_steps<8, 2, 7, 16>(st, ksteps, a, num_cus, grid_out);
     }
     if (qt == 64) {
+#ifdef QMX_TUNING   // instrumented instantiations (some skip waits or barriers and return wrong results): never in the shipped library
         if (ksteps == 6) {
             const char *dbg = getenv("QMX_M16_DBG");
             if (dbg && dbg[0] == '2') return launch_m16<6, 8, 4, 2>(st, a, num_cus, grid_out);
@@ -523,6 +526,7 @@ int32_t launch_scan_f32_mfma16(hipStream_t st, int qt, const ScanArgs &a, int nu
             if (dbg && dbg[0] == '7') return launch_m16<6, 8, 4, 3, false>(st, a, num_cus, grid_out);   // no fold / selection, lock-step
             if (dbg && dbg[0] == '5') return launch_m16<6, 8, 4, 0, false>(st, a, num_cus, grid_out);   // lock-step waves
         }
+#endif
         return launch_m16_steps<8, 4, 1, 6>(st, ksteps, a, num_cus, grid_out);
     }
     set_error("mfma16 scan: unsupported shape");

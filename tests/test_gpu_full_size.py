@@ -55,13 +55,13 @@ def test_c2_full_size_properties(world):
     full = s.peek_top_all()
     assert all(len(r) == TOP and np.all(np.diff(r["score"]) <= 0) for r in full)
     # (1) the VALU kernels give the same lists (16 queries as 4 passes of 4)
-    os.environ["QMX_NO_MFMA_SCAN"] = "1"
+    qa.set_option("no_mfma_scan", 1)
     try:
         valu = []
         for q0 in range(0, NQ, 4):
             valu += qa.BatchFilteredSearcher(world["queries"][q0:q0 + 4], world["st"], TOP).peek_top_all()
     finally:
-        del os.environ["QMX_NO_MFMA_SCAN"]
+        qa.set_option("no_mfma_scan", -1)
     _same(full, valu)
     # (2) whole == merge of 8 slabs (ids already global, so qmx_merge_topk needs no base)
     slabs = np.linspace(0, N, 9).astype(np.int64)
@@ -109,13 +109,13 @@ def test_c3_full_size_properties(world):
     queries = O.preprocess(O.COSINE, world["queries"])
     s = qa.BatchFilteredSearcher(queries, enc, TOP)
     full = s.peek_top_all()
-    os.environ["QMX_NO_MFMA_SCAN"] = "1"
+    qa.set_option("no_mfma_scan", 1)
     try:
         valu = []
         for q0 in range(0, NQ, 4):
             valu += qa.BatchFilteredSearcher(queries[q0:q0 + 4], enc, TOP).peek_top_all()
     finally:
-        del os.environ["QMX_NO_MFMA_SCAN"]
+        qa.set_option("no_mfma_scan", -1)
     _same(full, valu)
     # quantization error of the returned scores vs the exact f32 scores: abs(delta) < 0.1 * dim in test_avx2.rs:16-57 for
     # N(0,1) coordinates; rows here are unit vectors, so the same relative bound is 0.1 * dim * (1 / dim) = 0.1

@@ -118,11 +118,11 @@ def test_more_queries_than_slots_and_repeatability(qa):
     vs = qa.VectorStorage(rows, qa.Distance.Dot)
     graph = qa.GraphLayers.from_plain(plain)
     want = g.search_dense(st, base, 10, 48)
-    for cap in (None, "4"):                         # "4": the log overflows at once -> whole-bitmap clear path
+    for cap in (None, 4):                         # "4": the log overflows at once -> whole-bitmap clear path
         if cap is None:
-            os.environ.pop("QMX_HNSW_LOG_CAP", None)
+            qa.set_option("hnsw_log_cap", -1)
         else:
-            os.environ["QMX_HNSW_LOG_CAP"] = cap
+            qa.set_option("hnsw_log_cap", cap)
         try:
             scorer = qa.new_raw_scorer(queries, vs)
             for _ in range(2):                      # second launch reuses the same scratch
@@ -132,7 +132,7 @@ def test_more_queries_than_slots_and_repeatability(qa):
                     for j in (0, 17, 49):
                         assert np.array_equal(got[rep * 50 + j], got[j])
         finally:
-            os.environ.pop("QMX_HNSW_LOG_CAP", None)
+            qa.set_option("hnsw_log_cap", -1)
 
 
 @pytest.mark.parametrize("distance", [O.DOT, O.EUCLID, O.MANHATTAN])
@@ -402,9 +402,56 @@ def test_acorn_with_sq_scorer_and_log_overflow(qa):
         cnt[i] = len(r)
     for a_, b_ in zip(fused, raw.rescore(ids, 10, cnt)):
         assert np.array_equal(a_, b_)
-    os.environ["QMX_HNSW_LOG_CAP"] = "8"                      # the visited log overflows: whole-bitmap clear of both lists
+    qa.set_option("hnsw_log_cap", 8)                      # the visited log overflows: whole-bitmap clear of both lists
     try:
         _same(graph.search(10, 40, scorer, acorn=True), want)
         _same(graph.search(10, 40, scorer, acorn=True), want)
     finally:
-        del os.environ["QMX_HNSW_LOG_CAP"]
+        qa.set_option("hnsw_log_cap", -1)
+
+
+def test_walk_survives_a_graph_whose_levels_are_inconsistent(qa):
+    """a decodable links file can name, on level L, a node without a slot on level L, or an entry point with a level it does not
+    have.  Host-visible arrays are refused by qmx_hnsw_create (tests/test_oracle_links.py); arrays handed over as DEVICE memory are not
+    inspected, so the kernel itself must bound the slot: the search returns (some) valid result instead of faulting."""
+    import ctypes as C
+    import torch
+    from qdrant_amd import _ffi as F
+    n, dim, m, nq = 3000, 32, 8, 64
+    rows, st, g, plain = _graph(O.DOT, n, dim, m, 0x5EED0390)
+    lo, off, re_ = np.asarray(plain.level_offsets), np.asarray(plain.offsets), np.asarray(plain.reindex)
+    assert len(lo) - 1 >= 2
+    top_level = len(lo) - 2
+    size1 = int(lo[2] - lo[1])
+    low_nodes = np.flatnonzero(re_ >= size1)                       # points that exist on level 0 only
+    nb = np.array(plain.neighbors, dtype=np.uint32)
+    rng = np.random.default_rng(9)
+    for s in range(int(lo[1]), int(lo[-1])):                       # every upper-level list gets one link to a level-0-only node
+        if off[s + 1] > off[s]:
+            nb[int(off[s])] = low_nodes[int(rng.integers(0, len(low_nodes)))]
+    dev = torch.device("cuda", 0)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(np.int64 if dt == np.uint64 else np.int32)).to(dev)  # noqa: E731
+    keep = [t(np.asarray(plain.reindex, dtype=np.uint32), np.uint32), t(np.asarray(lo, dtype=np.uint64), np.uint64),
+            t(np.asarray(off, dtype=np.uint64), np.uint64), t(nb, np.uint32),
+            t(np.array([int(low_nodes[0])], dtype=np.uint32), np.uint32), t(np.array([top_level], dtype=np.uint32), np.uint32)]
+    d = F.HnswDesc()
+    d.m, d.m0, d.n_points, d.n_levels = plain.m, plain.m0, n, len(lo) - 1
+    d.reindex, d.level_offsets, d.offsets, d.n_offsets = keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), len(off)
+    d.neighbors, d.n_neighbors = keep[3].data_ptr(), len(nb)
+    d.entry_point_ids, d.entry_point_levels, d.n_entry_points = keep[4].data_ptr(), keep[5].data_ptr(), 1   # an entry point far above its level
+    h = C.c_void_p()
+    F.check(F.lib().qmx_hnsw_create(C.byref(d), C.byref(h)))
+    try:
+        vs = qa.VectorStorage(rows, qa.Distance.Dot)
+        scorer = qa.new_raw_scorer(O.synth(0x5EED0391, 0, nq, dim), vs)
+        out = np.zeros((nq, 10), dtype=O.ScoredPointOffset)
+        cnt = np.zeros(nq, dtype=np.uint32)
+        for acorn in (False, True):
+            fn = F.lib().qmx_hnsw_search_acorn if acorn else F.lib().qmx_hnsw_search
+            F.check(fn(h, scorer._h, 10, 64, F.ptr(out), F.ptr(cnt), None, None))
+            assert (cnt >= 1).all() and (cnt <= 10).all()
+            for i in range(nq):
+                assert (out["idx"][i, :cnt[i]] < n).all()
+        torch.cuda.synchronize()
+    finally:
+        F.lib().qmx_hnsw_destroy(h)

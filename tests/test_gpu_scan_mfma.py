@@ -1,7 +1,7 @@
 """GPU parity of the matrix-core f32 scan (scan_mfma.hip: 8..32 queries per pass on v_mfma_f32_4x4x1,
 dot / cosine) — scores must carry the BITS of the x86 AVX2+FMA reference (dot_similarity_avx,
 lib/segment/src/spaces/simple_avx.rs:167-213), exactly like the VALU scan it replaces for large batches.
-Checked against the oracle and against the VALU kernels (QMX_NO_MFMA_SCAN=1) on the same inputs."""
+Checked against the oracle and against the VALU kernels (qmx_set_option("no_mfma_scan", 1)) on the same inputs."""
 import os
 
 import numpy as np
@@ -37,11 +37,11 @@ def test_scores_bit_exact(qa, dist, dim, nq):
     got = scorer.score_points(ids)
     want = O.DenseStorage(O.F32, dist, rows).score_points(queries, ids)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
-    os.environ["QMX_NO_MFMA_SCAN"] = "1"
+    qa.set_option("no_mfma_scan", 1)
     try:
         valu = scorer.score_points(ids)
     finally:
-        del os.environ["QMX_NO_MFMA_SCAN"]
+        qa.set_option("no_mfma_scan", -1)
     assert np.array_equal(got.view(np.uint32), valu.view(np.uint32))
 
 
@@ -82,11 +82,11 @@ def test_large_scan_property(qa):
     queries = O.synth(0x5EED009A, 0, nq, dim)
     s = qa.BatchFilteredSearcher(queries, st, top)
     got = s.peek_top_all()
-    os.environ["QMX_NO_MFMA_SCAN"] = "1"
+    qa.set_option("no_mfma_scan", 1)
     try:
         valu = s.peek_top_all()
     finally:
-        del os.environ["QMX_NO_MFMA_SCAN"]
+        qa.set_option("no_mfma_scan", -1)
     for g, v in zip(got, valu):
         assert g["idx"].tolist() == v["idx"].tolist()
         assert np.array_equal(g["score"].view(np.uint32), v["score"].view(np.uint32))
@@ -112,11 +112,11 @@ def test_mfma16_every_score_bit_exact(qa, dist, dim, nq):
         assert np.array_equal(g["score"].view(np.uint32), w["score"].view(np.uint32))
         uniq = np.array([(w["score"] == x).sum() == 1 for x in w["score"]])
         assert np.array_equal(g["idx"][uniq], w["idx"][uniq])
-    os.environ["QMX_NO_MFMA16"] = "1"
+    qa.set_option("no_mfma16", 1)
     try:
         other = s.peek_top_all()
     finally:
-        del os.environ["QMX_NO_MFMA16"]
+        qa.set_option("no_mfma16", -1)
     for g, o in zip(got, other):
         assert np.array_equal(g["score"].view(np.uint32), o["score"].view(np.uint32))
 
@@ -167,11 +167,11 @@ def test_mfma16_large_scan_equals_the_other_kernels(qa, nq):
     s = qa.BatchFilteredSearcher(queries, st, top)
     got = s.peek_top_all()
     again = s.peek_top_all()
-    os.environ["QMX_NO_MFMA16"] = "1"
+    qa.set_option("no_mfma16", 1)
     try:
         other = s.peek_top_all()
     finally:
-        del os.environ["QMX_NO_MFMA16"]
+        qa.set_option("no_mfma16", -1)
     for g, a2, o in zip(got, again, other):
         assert np.array_equal(g, a2)
         assert g["idx"].tolist() == o["idx"].tolist()
@@ -244,12 +244,12 @@ def test_mfma16_prescan_with_multipass_top_and_deleted(qa, nq, top):
     s = qa.BatchFilteredSearcher(queries, st, top)
     got = s.peek_top_all()
     variants = []
-    for env in ("QMX_NO_PRESCAN", "QMX_NO_MFMA16"):
-        os.environ[env] = "1"
+    for opt in ("no_prescan", "no_mfma16"):
+        qa.set_option(opt, 1)
         try:
             variants.append(s.peek_top_all())
         finally:
-            del os.environ[env]
+            qa.set_option(opt, -1)
     for qi, g in enumerate(got):
         assert len(g) == top and not deleted[g["idx"]].any() and np.all(np.diff(g["score"]) <= 0)
         for v in variants:
@@ -258,11 +258,11 @@ def test_mfma16_prescan_with_multipass_top_and_deleted(qa, nq, top):
     # the same through a candidate id list of >= 2^18 entries (pre-scan over the head of the list)
     ids = rng.permutation(n)[:280_000].astype(np.uint32)
     got = s.peek_top_iter(ids)
-    os.environ["QMX_NO_MFMA16"] = "1"
+    qa.set_option("no_mfma16", 1)
     try:
         want = s.peek_top_iter(ids)
     finally:
-        del os.environ["QMX_NO_MFMA16"]
+        qa.set_option("no_mfma16", -1)
     for g, w2 in zip(got, want):
         assert np.array_equal(g["score"].view(np.uint32), w2["score"].view(np.uint32)) and g["idx"].tolist() == w2["idx"].tolist()
 
@@ -290,11 +290,11 @@ def test_sq_scores_bit_exact(qa, dist, dim, nq):
     got = scorer.score_points(ids)
     want = osq.score_points(qpre, ids)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
-    os.environ["QMX_NO_MFMA_SCAN"] = "1"
+    qa.set_option("no_mfma_scan", 1)
     try:
         valu = scorer.score_points(ids)
     finally:
-        del os.environ["QMX_NO_MFMA_SCAN"]
+        qa.set_option("no_mfma_scan", -1)
     assert np.array_equal(got.view(np.uint32), valu.view(np.uint32))
 
 
@@ -310,14 +310,14 @@ def test_sq_topk_with_deleted_and_id_lists(qa, nq, top):
     st.set_deleted(deleted, None)
     queries = rng.standard_normal((nq, dim)).astype(np.float32)
     s = qa.BatchFilteredSearcher(queries, st, top)
-    os.environ["QMX_NO_MFMA_SCAN"] = "1"
+    qa.set_option("no_mfma_scan", 1)
     try:
         s_valu = qa.BatchFilteredSearcher(queries, st, top)
         want_all = s_valu.peek_top_all()
         ids = rng.permutation(n)[:9999].astype(np.uint32)
         want_ids = s_valu.peek_top_iter(ids)
     finally:
-        del os.environ["QMX_NO_MFMA_SCAN"]
+        qa.set_option("no_mfma_scan", -1)
     for got, want in ((s.peek_top_all(), want_all), (s.peek_top_iter(ids), want_ids)):
         for g, w in zip(got, want):      # both kernels produce the same exact scores and break ties by the lower id
             assert g["idx"].tolist() == w["idx"].tolist()

@@ -7,6 +7,7 @@ bitpacking_links.rs `test_random` cases (:230-312: only-unsorted / only-sorted /
 bitpacking_ordered.rs `test_compress_decompress` sequences (:331-406),
 graph_links/tests.rs `test_save_load` shapes (random links of random levels, every format)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -93,8 +94,10 @@ def test_ordered_compress_round_trip():
             assert O.ordered_get(data, len(values), params, int(i)) == int(values[int(i)])
 
 
-def _random_plain(n, m, m0, seed, max_level=4, full=False):
-    """graph_links/tests.rs random_links: every point gets a random level and random link lists of random length."""
+def _random_plain(n, m, m0, seed, max_level=4, full=False, consistent=False):
+    """graph_links/tests.rs random_links: every point gets a random level and random link lists of random length.
+    `consistent`: links on level l only name points of level >= l, as every built graph does (the reference's format tests
+    draw them from all points: fine for the codecs, but such a graph cannot be walked and qmx_hnsw_create refuses it)."""
     rng = np.random.default_rng(seed)
     levels = np.minimum((-np.log(rng.random(n)) * (1.0 / np.log(max(m, 2)))).round().astype(np.int64), max_level)
     if n:
@@ -112,8 +115,8 @@ def _random_plain(n, m, m0, seed, max_level=4, full=False):
         for _ in ids:
             # up to 2 x level_m links: lists longer than level_m exercise the unsorted tail (the reference allows it, tests.rs)
             k = lm if full else int(rng.integers(0, 2 * lm + 1))
-            k = min(k, n)
-            neighbors.extend(rng.choice(n, size=k, replace=False).tolist() if k else [])
+            k = min(k, len(ids) if consistent else n)
+            neighbors.extend(rng.choice(ids if consistent else n, size=k, replace=False).tolist() if k else [])
             offsets.append(len(neighbors))
             slot += 1
     level_offsets.append(slot)
@@ -240,7 +243,7 @@ def test_malformed_compressed_files_are_refused():
 
 def test_create_from_file_needs_the_device_only_after_the_file_is_valid():
     import torch
-    p = _random_plain(300, 4, 8, seed=4)
+    p = _random_plain(300, 4, 8, seed=4, consistent=True)
     data = O.compressed_links_file(p)
 
     def create(buf, m=0, m0=0):
@@ -287,3 +290,54 @@ def test_corrupted_plain_and_inline_vector_files_never_crash(kind):
             F.lib().qmx_graph_links_free(C.byref(g))
         else:
             assert rc in (F.ERR_BAD_ARG, F.ERR_OUT_OF_BOUNDS)
+
+
+def test_links_to_nodes_missing_on_their_level_are_refused_on_any_host():
+    """A decodable links file may still name, on level L >= 1, a node that has no slot on level L (or an entry point with a level it
+    does not have): the walk would index offsets[] out of range.  qmx_hnsw_create refuses it before it needs a device."""
+    import torch
+    p = _random_plain(400, 4, 8, seed=21, consistent=True)
+    assert len(p.level_offsets) - 1 >= 2
+    expect_ok = F.OK if torch.cuda.is_available() else F.ERR_NO_DEVICE
+
+    def create(neighbors, ep_ids, ep_levels):
+        d = F.HnswDesc()
+        re, lo, off = (np.ascontiguousarray(p.reindex, dtype=np.uint32), np.ascontiguousarray(p.level_offsets, dtype=np.uint64),
+                       np.ascontiguousarray(p.offsets, dtype=np.uint64))
+        nb, ep, epl = (np.ascontiguousarray(neighbors, dtype=np.uint32), np.ascontiguousarray(ep_ids, dtype=np.uint32),
+                       np.ascontiguousarray(ep_levels, dtype=np.uint32))
+        d.m, d.m0, d.n_points, d.n_levels = p.m, p.m0, len(re), len(lo) - 1
+        d.reindex, d.level_offsets, d.offsets, d.n_offsets = re.ctypes.data, lo.ctypes.data, off.ctypes.data, len(off)
+        d.neighbors, d.n_neighbors = nb.ctypes.data, len(nb)
+        d.entry_point_ids, d.entry_point_levels, d.n_entry_points = ep.ctypes.data, epl.ctypes.data, len(ep)
+        h = C.c_void_p()
+        rc = F.lib().qmx_hnsw_create(C.byref(d), C.byref(h))
+        if rc == F.OK:
+            F.lib().qmx_hnsw_destroy(h)
+        return rc
+    assert create(p.neighbors, p.ep_ids, p.ep_levels) == expect_ok
+    # a level-1 list that names a level-0-only node
+    lo, off = np.asarray(p.level_offsets), np.asarray(p.offsets)
+    size1 = int(lo[2] - lo[1])
+    low = int(np.flatnonzero(np.asarray(p.reindex) >= size1)[0])          # a point that is not on level 1
+    first = next(s for s in range(int(lo[1]), int(lo[2])) if off[s + 1] > off[s])
+    bad = np.array(p.neighbors, dtype=np.uint32)
+    bad[int(off[first])] = low
+    assert create(bad, p.ep_ids, p.ep_levels) == F.ERR_OUT_OF_BOUNDS
+    # an entry point that claims a level it is not on
+    assert create(p.neighbors, [low], [1]) == F.ERR_OUT_OF_BOUNDS
+    assert create(p.neighbors, [low], [0]) == expect_ok
+
+
+def test_kernel_path_options_are_read_once_and_switchable():
+    lib = F.lib()
+    v = C.c_int64(-7)
+    assert lib.qmx_get_option(b"prescan_shift", C.byref(v)) == F.OK and v.value == int(os.environ.get("QMX_PRESCAN_SHIFT", "10"))
+    assert lib.qmx_set_option(b"no_mfma16", 1) == F.OK
+    assert lib.qmx_get_option(b"no_mfma16", C.byref(v)) == F.OK and v.value == 1
+    os.environ["QMX_NO_MFMA16"] = "0"                     # the environment is NOT consulted again
+    assert lib.qmx_set_option(b"no_mfma16", -1) == F.OK   # back to the load-time value
+    del os.environ["QMX_NO_MFMA16"]
+    assert lib.qmx_get_option(b"no_mfma16", C.byref(v)) == F.OK and v.value == int(os.environ.get("QMX_NO_MFMA16", "0") != "0")
+    assert lib.qmx_set_option(b"m16_dbg", 4) == F.ERR_BAD_ARG         # result-breaking debug knobs do not exist in the shipped library
+    assert lib.qmx_set_option(None, 1) == F.ERR_BAD_ARG

@@ -56,7 +56,7 @@ def main():
         print(json.dumps({"workload": "filtered brute force: %d of %d x %d f32 cosine, top-10" % (m, n, dim), "batch": Q,
                           "scan_kernel_ms": round(kms, 3), "launches_per_search": nl.value / args.reps, "ms_per_search_wall": round(wall * 1e3, 3),
                           "qps": round(Q / wall, 1), "gathered_GBps": round(m * dim * 4 / (kms * 1e-3) / 1e9, 1),
-                          "chain_major": os.environ.get("QMX_NO_MFMA16") is None}), flush=True)
+                          "chain_major": qa.get_option("no_mfma16") == 0}), flush=True)
 
 
 if __name__ == "__main__":

@@ -36,9 +36,9 @@ def main():
                 F.check(lib.qmx_search_topk_async(qh, top, F.ptr(ids) if use_ids else None, ids.numel() if use_ids else 0, F.ptr(out), F.ptr(counts)))
                 F.check(lib.qmx_query_synchronize(qh))
                 return out.clone()
-            os.environ["QMX_NO_MFMA16"] = "1"
+            qa.set_option("no_mfma16", 1)
             ref = run()
-            del os.environ["QMX_NO_MFMA16"]
+            qa.set_option("no_mfma16", -1)
             diff = sum(int(not torch.equal(run(), ref)) for _ in range(reps))
             bad += diff
             print("Q=%d ids=%s: %d / %d runs differ from the reference kernels' lists" % (Q, use_ids, diff, reps), flush=True)
