@@ -1,24 +1,34 @@
 #!/usr/bin/env python3
-"""bench.py — QPS of brute-force top-10 search on the MI355X scorer (BASELINE.json metric).
+"""bench.py — QPS of brute-force top-10 search on the MI355X scorer (BASELINE.json metric), + the other single-GPU configs.
 
-Workload at N=1 = BASELINE.json configs[1] ("C2"): one segment of 10 M x d=768 f32, cosine,
-brute-force exact top-10, resident in HBM.  A *step* = one pass of the hot path over one batch of
-Q queries: Metric::preprocess of the batch (qmx_query_update) + one scan of the whole segment with
-per-query top-k (qmx_search_topk_async = BatchFilteredSearcher::peek_top_iter) [+ for N>1 the RCCL
-all-gather of the per-GPU top-k and the k-way merge].  1024 distinct queries are cycled in batches.
+Timed region (the JSON line's `value`).  Workload at N=1 = BASELINE.json configs[1] ("C2"): one segment of 10 M x d=768 f32, cosine,
+brute-force exact top-10, resident in HBM.  A *step* = one pass of the hot path over one batch of Q queries: Metric::preprocess of
+the batch (qmx_query_update) + one scan of the whole segment with per-query top-k (qmx_search_topk_async =
+BatchFilteredSearcher::peek_top_iter) [+ for N>1 the RCCL all-gather of the per-GPU top-k and the k-way merge].  1024 distinct
+queries are cycled in batches.
 
-N>1 (torchrun, one rank per GPU) = configs[4] ("C5"): rank r holds its own 10 M-row segment
-(seed + r), every rank scores the same query batch against its segment, the per-rank top-k lists
-(Q x 10 x 8 B) are all-gathered over RCCL/xGMI and merged (BatchResultAggregator semantics).
-Weak scaling: per-GPU work is fixed.  The counted unit is one (query, 10 M-row segment) search, so
-value = N * Q * steps / time; at N=1 this is plain QPS on C2.  The collection-level QPS of the
-N-segment collection (= value / N) is reported in config.collection_qps.
+N>1 (torchrun, one rank per GPU):
+  --scaling weak (default) = configs[4] ("C5"): rank r holds its own 10 M-row segment (seed + r), every rank scores the same query batch
+      against its segment, the per-rank top-k lists (Q x 10 x 8 B) are all-gathered over RCCL/xGMI and merged (BatchResultAggregator
+      semantics).  Per-GPU work is fixed.  The counted unit is one (query, 10 M-row segment) search: value = N * Q * steps / time; at
+      N=1 this is plain QPS on C2.  The collection-level QPS of the N-segment collection (= value / N) is in config.collection_qps.
+  --scaling strong: ONE 10 M-row segment row-split over the ranks, same gather + merge; total work is fixed, value = Q *
+      steps / time.
 
-Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes of one scan launch
-(rows x 3072 B) / the scan kernel's mean duration, measured with HIP-event pairs recorded on the
-kernel's own stream inside the timed region (qmx_query_set_timing / qmx_query_timing).
-`cpu_baseline` = the CPU oracle (AVX2+FMA restatement of the reference's scorer and its
-peek_top_iter loop) timed on this box's host cores on a bounded sample of the same rows.
+Outside the timed region, rank 0, N=1 (the `configs` object; each entry carries its own roofline, recall@10 against exact search on
+the device, and an in-run check of a sample against the CPU oracle):
+  C3  10 M x 768 SQ-int8, dot: brute force with oversampling 2 + f32 rescoring at Q = 1 and 32 (qmx_search_quantized), and the HNSW path:
+      device build THROUGH the SQ scorer, SQ walk ef = 128, oversampling 2, f32 rescoring.
+  C4  10 M x 1536 PQ m = 96 (LUT on the matrix cores), HNSW ef = 128: device k-means + encode, device build through the PQ scorer
+      (qmx_hnsw_build_quantized), PQ walk, with and without f32 rescoring.
+Rows of C3 / C4 have low intrinsic dimension (qmx_synth_fill_latent_f32, 32 latent coordinates + noise): recall is meaningful there;
+C2's brute force is data-independent and keeps the iid rows of SURVEY 8d.
+
+Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes of one scan launch (rows x 3072 B) / the scan kernel's mean
+duration, measured with HIP-event pairs recorded on the kernel's own stream inside the timed region (qmx_query_set_timing /
+qmx_query_timing); `roofline.kernel` is the symbol the library reports for the launch (qmx_query_last_kernel).  `cpu_baseline` = the
+CPU oracle (AVX2+FMA restatement of the reference's scorer and its peek_top_iter loop) timed on this box's host cores on a bounded
+sample of the same rows, single-threaded (the reference's unit of work: one (batch, segment) task) and on every usable core.
 """
 import argparse
 import ctypes as C
@@ -32,6 +42,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32-input MFMA peak (same guide: v_mfma_f32_16x16x4_f32 / 32x32x2, 64 FLOP/clk/SIMD)
+QUERY_ROW0 = 1 << 40   # latent-model queries: rows of the same generator (same basis), far past the stored range
 
 
 def parse():
@@ -44,14 +55,29 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="queries per scan (Q)")
     ap.add_argument("--top", type=int, default=10)
     ap.add_argument("--nqueries", type=int, default=1024)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N>1: weak = one --rows segment per GPU (C5); strong = ONE --rows segment row-split over the GPUs")
     ap.add_argument("--cpu-rows", type=int, default=1_000_000, help="rows of the CPU-baseline sample")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-hbm-point", action="store_true", help="skip the secondary Q=16 (HBM-bound) measurement of the same scan")
-    ap.add_argument("--verify", type=int, default=1, help="check the first batch against the oracle on the CPU sample")
-    ap.add_argument("--hnsw-rows", type=int, default=1_000_000,
-                    help="rows of the secondary HNSW measurement (device build + SQ search + rescoring), 0 = skip")
+    ap.add_argument("--verify", type=int, default=1, help="check samples against the oracle (C2 first batch, C3 / C4 scans and walks)")
+    ap.add_argument("--configs", default="c3,c4", help="comma list of the secondary single-GPU configs to run (empty = none)")
+    ap.add_argument("--config-rows", type=int, default=0, help="rows of C3 / C4 (0 = --rows)")
+    ap.add_argument("--hnsw-queries", type=int, default=8192, help="searches per launch of the HNSW walks")
     return ap.parse_args()
+
+
+def usable_cores():
+    """Cores this process may actually run on: the affinity mask, cut by the cgroup CPU quota (os.cpu_count() reports the host's)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return n
 
 
 def main():
@@ -61,37 +87,49 @@ def main():
     import numpy as np
     import qdrant_amd as qa
     from qdrant_amd import _ffi as F
+    from qdrant_amd import sharded
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rccl_ranks = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+        # prove the collective spans N ranks before anything is timed: a real all-gather of one word per rank over RCCL
+        probe = torch.zeros(world, dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(probe, torch.full((1,), rank + 1, dtype=torch.int32, device=dev))
+        torch.cuda.synchronize(dev)
+        rccl_ranks = int((probe > 0).sum().item())
+        assert probe.tolist() == list(range(1, world + 1)), probe.tolist()
 
     lib = F.lib()
-    n, dim, Q, top = args.rows, args.dim, args.batch, args.top
+    dim, Q, top = args.dim, args.batch, args.top
     seed = 0x5EED0002  # 0x5EED0000 + config id
+    strong = world > 1 and args.scaling == "strong"
+    if strong:
+        row0, n = sharded.row_split(args.rows)          # this rank's slice of the ONE segment
+        row_seed = seed
+    else:
+        row0, n = 0, args.rows
+        row_seed = seed + 16 * rank                     # this rank's own segment
 
     # ---- the stored block: generated and normalised on device, adopted without copying ----
     rows = torch.empty((n, dim), dtype=torch.float32, device=dev)
-    F.check(lib.qmx_synth_fill_f32(local_rank, seed + 16 * rank, 0, n, dim, F.ptr(rows)))
+    F.check(lib.qmx_synth_fill_f32(local_rank, row_seed, row0, n, dim, F.ptr(rows)))
     F.check(lib.qmx_preprocess_f32(local_rank, int(qa.Distance.Cosine), F.ptr(rows), n, dim, F.ptr(rows)))
     storage = qa.VectorStorage(rows, qa.Distance.Cosine, device_id=local_rank)
 
     nbatches = max(1, args.nqueries // Q)
     queries = torch.empty((nbatches * Q, dim), dtype=torch.float32, device=dev)
     F.check(lib.qmx_synth_fill_f32(local_rank, seed + 1, 0, nbatches * Q, dim, F.ptr(queries)))
-    qbytes = Q * dim * 4
 
     stream = torch.cuda.Stream(dev)  # every kernel, the RCCL gather and the merge are ordered on this stream
     torch.cuda.set_stream(stream)
-    from qdrant_amd import sharded
     backend = sharded.HipBackend(storage, Q, local_rank, stream)      # owns the qmx_query of this rank
     qh = backend.qh
     F.check(lib.qmx_query_set_timing(qh, 1))
@@ -127,6 +165,7 @@ def main():
 
     kms, kl = C.c_float(), C.c_uint32()
     F.check(lib.qmx_query_timing(qh, C.byref(kms), C.byref(kl)))
+    kernel_symbol = F.last_kernel(qh)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -140,46 +179,69 @@ def main():
     row_bytes = dim * 4
     alg_bytes = n * row_bytes  # per scan launch (3072 B/row at d=768), queries/outputs negligible
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    value = world * Q * args.steps / elapsed
+    launches_per_step = max(1, int(kl.value)) / float(max(1, args.steps))
+    units = Q * args.steps * (1 if strong else world)
+    value = units / elapsed
 
     if world == 1:
         workload = "C2: 1 segment %s x d=%d f32 cosine, brute-force exact top-%d, batch Q=%d" % (_human(n), dim, top, Q)
+    elif strong:
+        workload = ("C2 row-split: ONE segment %s x d=%d f32 cosine split by contiguous row range over %d GPUs (%s rows each), top-%d, batch Q=%d, "
+                    "RCCL all-gather + merge" % (_human(args.rows), dim, world, _human(n), top, Q))
     else:
         workload = ("C5: %d segments (one per GPU) x %s x d=%d f32 cosine, top-%d, batch Q=%d, RCCL all-gather + merge"
                     % (world, _human(n), dim, top, Q))
     result = {
-        "metric": "QPS @ recall@10, brute-force, d=%d %s vecs, f32 cosine top-%d" % (dim, _human(n), top),
+        "metric": "QPS @ recall@10, brute-force, d=%d %s vecs, f32 cosine top-%d" % (dim, _human(args.rows), top),
         "value": round(value, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "rccl_ranks": rccl_ranks,
         "config": {"workload": workload,
                    "rows_per_gpu": n, "dim": dim, "batch": Q, "top": top, "distinct_queries": nbatches * Q,
-                   "unit_of_value": "(query, 10M-row segment) searches per second; at n_gpus=1 this is plain QPS",
+                   "unit_of_value": ("queries per second against the ONE row-split segment" if strong else
+                                     "(query, 10M-row segment) searches per second; at n_gpus=1 this is plain QPS"),
                    "collection_qps": round(Q * args.steps / elapsed, 2)},
-        "roofline": _roofline(n, dim, Q, kernel_ms, alg_bytes, achieved, int(kl.value)),
+        "roofline": _roofline(n, dim, kernel_ms, alg_bytes, achieved, int(kl.value), launches_per_step, Q, kernel_symbol),
     }
 
-    if rank == 0 and world == 1 and Q != 16 and not args.no_hbm_point:
+    solo = rank == 0 and world == 1
+    if solo and Q != 16 and not args.no_hbm_point:
         # the HBM-bound operating point of the same scan (north_star: >= 70 % of the HBM roofline on C2): 16 queries per pass, where the
         # kernel is a pure stream of the stored block; outside the timed region, same rows, same measurement (HIP events on the kernel's stream)
         try:
             result["roofline_hbm_point_q16"] = hbm_point(16, storage, queries, n, dim, top, local_rank, stream, lib, F, sharded, torch)
         except Exception as e:
             result["roofline_hbm_point_q16"] = {"error": repr(e)[:300]}
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if solo and not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(args, rows, queries, out, counts, n, dim, Q, top, lib, qh, F, qa, np, torch)
-    if rank == 0 and world == 1 and args.hnsw_rows > 0:
-        try:
-            result["hnsw"] = hnsw_section(args, dev, dim, top, lib, F, qa, np, torch)
-        except Exception as e:  # the headline line must survive a failure of the secondary measurement
-            result["hnsw"] = {"error": repr(e)[:300]}
+    backend.close()
+    wanted = [c for c in args.configs.lower().split(",") if c]
+    if solo and wanted:
+        cfg = {}
+        del searcher, backend, storage, out, counts
+        ctx = dict(args=args, dev=dev, lib=lib, F=F, qa=qa, np=np, torch=torch)
+        if "c3" in wanted:
+            try:
+                cfg["C3"], rows = c3_section(ctx, rows)
+            except Exception as e:  # the headline line must survive a failure of a secondary measurement
+                cfg["C3"] = {"error": repr(e)[:400]}
+        del rows
+        torch.cuda.empty_cache()
+        if "c4" in wanted:
+            try:
+                cfg["C4"] = c4_section(ctx)
+            except Exception as e:
+                cfg["C4"] = {"error": repr(e)[:400]}
+        result["configs"] = cfg
     if rank == 0:
         print(json.dumps(result), flush=True)
-    backend.close()
     if world > 1:
         dist.destroy_process_group()
 
 
+# ------------------------------------------------------------------------------------------------------------------------
+# C2 helpers
+# ------------------------------------------------------------------------------------------------------------------------
 def hbm_point(Qh, storage, queries, n, dim, top, local_rank, stream, lib, F, sharded, torch):
     backend = sharded.HipBackend(storage, Qh, local_rank, stream)
     try:
@@ -202,82 +264,11 @@ def hbm_point(Qh, storage, queries, n, dim, top, local_rank, stream, lib, F, sha
         kernel_ms = ms.value / max(1, nl.value)
         alg = n * dim * 4
         gbps = alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        return {"batch": Qh, "kernel": _kernel_name(dim, Qh), "kernel_ms": round(kernel_ms, 4), "launches_timed": int(nl.value),
+        return {"batch": Qh, "kernel": F.last_kernel(backend.qh), "kernel_ms": round(kernel_ms, 4), "launches_timed": int(nl.value),
                 "algorithmic_bytes_per_launch": alg, "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(gbps / HBM_PEAK_GBPS, 4), "qps": round(Qh * steps / wall, 1), "ms_per_step": round(wall / steps * 1e3, 4)}
     finally:
         backend.close()
-
-
-def hnsw_section(args, dev, dim, top, lib, F, qa, np, torch):
-    """Secondary measurement, outside the timed region (the metric names "brute-force + HNSW"): the C3-style path on
-    `--hnsw-rows` clustered rows: SQ-int8 encode, device HNSW build through the SQ scorer (qmx_hnsw_build), SQ-int8 walk (qmx_hnsw_search, oversampling 2),
-    rescoring with the f32 rows (qmx_rescore), recall@10 against the exact device search.  tools/bench_hnsw.py is the
-    full tool (CPU-oracle walk parity, 10 M rows)."""
-    n, nq, ef, m = args.hnsw_rows, 8192, 128, 16
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(0x5EED0003)
-    centres = torch.randn((4096, dim), generator=gen, device=dev, dtype=torch.float32)
-    centres = centres / centres.norm(dim=1, keepdim=True)
-
-    def make(count):
-        x = centres[torch.randint(0, 4096, (count,), generator=gen, device=dev)] + torch.randn((count, dim), generator=gen, device=dev) * (0.35 / dim ** 0.5)
-        F.check(lib.qmx_preprocess_f32(dev.index or 0, int(qa.Distance.Cosine), F.ptr(x), count, dim, F.ptr(x)))
-        return x
-    rows, queries_d = make(n), make(nq)
-    torch.cuda.synchronize(dev)
-    queries = queries_d.cpu().numpy()
-    vs = qa.VectorStorage(rows, qa.Distance.Cosine)
-    # the reference's order for a quantized segment: quantize, then build the graph THROUGH the quantized scorer
-    # (hnsw/build.rs:334-341), then search with it and rescore with the original vectors
-    mn, mx = float(rows.min().item()), float(rows.max().item())
-    quant = qa.ScalarQuantizer(dim, qa.Distance.Dot, (np.float32(mx) - np.float32(mn)) / np.float32(127.0), np.float32(mn))
-    p = quant.params()
-    codes = torch.empty((n, quant.quantized_vector_size()), dtype=torch.uint8, device=dev)
-    F.check(lib.qmx_sq_encode(dev.index or 0, int(qa.Distance.Dot), C.byref(p), F.ptr(rows), n, dim, F.ptr(codes)))
-    d = F.SegmentDesc()
-    d.dtype, d.distance, d.dim, d.n, d.data, d.device_id, d.sq = F.DTYPE_SQ_U8, int(qa.Distance.Dot), dim, n, F.ptr(codes).value, dev.index or 0, C.pointer(p)
-    enc = qa.EncodedVectorsU8.__new__(qa.EncodedVectorsU8)
-    enc.quantizer, enc.distance, enc.datatype, enc.dim, enc.count, enc._keep, enc._sq, enc._h = quant, quant.distance, None, dim, n, None, p, C.c_void_p()
-    F.check(lib.qmx_segment_create(C.byref(d), C.byref(enc._h)))
-    del codes
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    graph = qa.GraphLayers.build(enc, m=m, ef_construct=100, seed=42)
-    t_build = time.perf_counter() - t0
-    scorer = qa.new_raw_scorer(queries, enc)
-    raw = qa.new_raw_scorer(queries, vs)
-    F.check(lib.qmx_query_set_timing(scorer._h, 1))
-    graph.search(2 * top, ef, scorer)
-    ms, nl = C.c_float(), C.c_uint32()
-    F.check(lib.qmx_query_timing(scorer._h, C.byref(ms), C.byref(nl)))
-    t0 = time.perf_counter()
-    got, scored = graph.search(2 * top, ef, scorer, with_scored=True)
-    ids = np.zeros((nq, 2 * top), dtype=np.uint32)
-    cnt = np.zeros(nq, dtype=np.uint32)
-    for i, r in enumerate(got):
-        ids[i, :len(r)] = r["idx"]
-        cnt[i] = len(r)
-    final = raw.rescore(ids, top, cnt)
-    wall = time.perf_counter() - t0
-    # the same three steps as ONE call (qmx_search_quantized: oversampled walk -> rescoring -> top, candidates stay in HBM)
-    qa.search_quantized(scorer, raw, top, oversampling=2.0, rescore=True, graph=graph, hnsw_ef=ef)
-    t0 = time.perf_counter()
-    fused = qa.search_quantized(scorer, raw, top, oversampling=2.0, rescore=True, graph=graph, hnsw_ef=ef)
-    wall_fused = time.perf_counter() - t0
-    same = sum(int(np.array_equal(a, b)) for a, b in zip(fused, final))
-    F.check(lib.qmx_query_timing(scorer._h, C.byref(ms), C.byref(nl)))
-    exact = qa.BatchFilteredSearcher(queries[:256], vs, top).peek_top_all()
-    recall = sum(len(set(a["idx"].tolist()) & set(b["idx"].tolist())) for a, b in zip(final[:256], exact)) / (256.0 * top)
-    kernel_ms = ms.value / max(nl.value, 1)
-    return {"workload": "C3-style: %s x d=%d clustered rows, SQ-int8 encode, device HNSW build through the SQ scorer (m=%d, ef_construct=100), SQ-int8 walk ef=%d, oversampling 2 + f32 rescoring, %d queries per launch"
-                        % (_human(n), dim, m, ef, nq),
-            "build_s": round(t_build, 2), "build_points_per_s": round(n / t_build, 1),
-            "search_qps_kernel": round(nq / (kernel_ms * 1e-3), 1), "search_kernel_ms": round(kernel_ms, 3),
-            "search_qps_wall_incl_host_copies_and_rescoring": round(nq / wall, 1),
-            "search_qps_wall_one_call_walk_rescore_on_device": round(nq / wall_fused, 1), "one_call_lists_equal_three_step_lists": "%d/%d" % (same, nq),
-            "points_scored_per_query": round(scored / nq, 1), "gather_GBps": round(scored * quant.quantized_vector_size() / (kernel_ms * 1e-3) / 1e9, 1),
-            "recall_at_10_after_rescoring": round(recall, 4)}
 
 
 def cpu_baseline(args, rows, queries, out, counts, n, dim, Q, top, lib, qh, F, qa, np, torch):
@@ -290,14 +281,29 @@ def cpu_baseline(args, rows, queries, out, counts, n, dim, Q, top, lib, qh, F, q
     host_q = queries[:Q].cpu().numpy()
     ost = O.DenseStorage(O.F32, O.COSINE, host_rows)
     enc = ost.encode_queries(host_q)
-    threads = os.cpu_count() or 1
-    reps, t0 = 0, time.perf_counter()
+    cores = usable_cores()
+
+    def run(threads, budget):
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            res = ost.peek_top(enc, top, encoded=True, threads=threads)
+            reps += 1
+            el = time.perf_counter() - t0
+            if el >= budget or reps >= 1000:
+                return res, reps, el
+    # (a) the reference's unit of work: one thread runs one (query batch, segment) task; a smaller sample keeps it bounded
+    S1 = min(S, 100_000)
+    ost1 = O.DenseStorage(O.F32, O.COSINE, host_rows[:S1])
+    reps1, t0 = 0, time.perf_counter()
     while True:
-        res = ost.peek_top(enc, top, encoded=True, threads=threads)
-        reps += 1
-        el = time.perf_counter() - t0
-        if el >= args.cpu_seconds or reps >= 1000:
+        ost1.peek_top(enc, top, encoded=True, threads=0)
+        reps1 += 1
+        el1 = time.perf_counter() - t0
+        if el1 >= args.cpu_seconds * 0.4 or reps1 >= 1000:
             break
+    qps1 = Q * reps1 / el1 * (S1 / n)
+    # (b) every usable core on disjoint row ranges (the reference's segment-parallel model)
+    res, reps, el = run(cores, args.cpu_seconds * 0.6)
     cpu_qps = Q * reps / el * (S / n)
     ok = None
     if args.verify:
@@ -310,25 +316,31 @@ def cpu_baseline(args, rows, queries, out, counts, n, dim, Q, top, lib, qh, F, q
         gi = g[:, :, 0].view(np.uint32)
         gs = g[:, :, 1].copy().view(np.float32)
         ok = all(gi[i].tolist() == res[i]["idx"].tolist() and
-                 np.allclose(gs[i], res[i]["score"], rtol=1e-5, atol=0) for i in range(Q))
+                 np.array_equal(gs[i].view(np.uint32), res[i]["score"].view(np.uint32)) for i in range(Q))
         if not ok:
             print("PARITY FAILURE: GPU top-k differs from the oracle on the CPU sample", file=sys.stderr)
-    return {"value": round(cpu_qps, 3), "unit": "queries/s", "cores": threads, "kind": "port",
+    flops = 2.0 * dim
+    return {"value": round(cpu_qps, 3), "unit": "queries/s", "cores": cores, "kind": "port",
             "sample": "oracle peek_top_iter (AVX2+FMA dot, 64-id chunks, heap of %d) over the first %d of %d rows, Q=%d, "
-                      "%d threads on disjoint row ranges, %d scans in %.1f s; QPS scaled by %d/%d to the full segment"
-                      % (top, S, n, Q, threads, reps, el, S, n),
-            "gpu_matches_oracle_on_sample": ok}
+                      "%d threads on disjoint row ranges (usable cores: affinity + cgroup quota; os.cpu_count() = %d), %d scans in %.1f s; "
+                      "QPS scaled by %d/%d to the full segment" % (top, S, n, Q, cores, os.cpu_count() or 0, reps, el, S, n),
+            "gflops_all_cores": round(flops * S * Q * reps / el / 1e9, 1),
+            "single_thread": {"value": round(qps1, 4), "unit": "queries/s", "cores": 1,
+                              "gflops": round(flops * S1 * Q * reps1 / el1 / 1e9, 2), "ns_per_row_per_query": round(el1 / (reps1 * S1 * Q) * 1e9, 2),
+                              "sample": "the same loop, one thread, first %d rows, %d scans in %.1f s, scaled by %d/%d" % (S1, reps1, el1, S1, n)},
+            "gpu_matches_oracle_on_sample_bit_exact": ok}
 
 
-def _roofline(n, dim, Q, kernel_ms, alg_bytes, achieved_gbps, launches):
+def _roofline(n, dim, kernel_ms, alg_bytes, achieved_gbps, launches, launches_per_step, Q, kernel_symbol):
     """The dominant kernel against BOTH ceilings; `bound` is the one it sits closer to.  Up to 16 queries per pass the scan is
     an HBM stream (every row byte read once: SURVEY 8d, 3072 B / row at d = 768); the 32- / 64-query passes of scan_mfma16.hip
     do 2 * dim flops per (row, query) on the f32 matrix cores and cross over to the MFMA ceiling."""
-    per_pass = min(Q, _queries_per_pass(dim, Q))
+    per_pass = Q / max(1.0, round(launches_per_step))       # queries one launch serves: MEASURED launches per step, not a dispatch guess
     flops = 2.0 * n * dim * per_pass
     tflops = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
     hbm_frac, mfma_frac = achieved_gbps / HBM_PEAK_GBPS, tflops / MFMA_F32_PEAK_TFLOPS
-    common = {"traffic": _pmc_traffic(n, dim, Q), "kernel": _kernel_name(dim, Q), "kernel_ms": round(kernel_ms, 4), "launches_timed": launches,
+    traffic, traffic_src = _pmc_traffic(n, dim, Q, kernel_symbol)
+    common = {"traffic": traffic, "traffic_source": traffic_src, "kernel": kernel_symbol, "kernel_ms": round(kernel_ms, 4), "launches_timed": launches,
               "queries_per_launch": per_pass, "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_flops_per_launch": flops,
               "hbm": {"achieved_GBps": round(achieved_gbps, 1), "peak_GBps": HBM_PEAK_GBPS, "frac": round(hbm_frac, 4)},
               "mfma_f32": {"achieved_TFLOPs": round(tflops, 2), "peak_TFLOPs": MFMA_F32_PEAK_TFLOPS, "frac": round(mfma_frac, 4)}}
@@ -337,52 +349,278 @@ def _roofline(n, dim, Q, kernel_ms, alg_bytes, achieved_gbps, launches):
     return dict({"bound": "hbm", "achieved": round(achieved_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(hbm_frac, 4)}, **common)
 
 
-def _queries_per_pass(dim, Q):
-    """api.hip search_enqueue: 64 per pass on the chain-major kernel (f32, dim 256 / 512 / 768, more than 32 queries), else 32."""
-    if dim % 128 == 0 and 768 < dim <= 2048:
-        return 32 if Q > 16 else 16
-    return 64 if (Q > 32 and dim % 128 == 0 and dim <= 768) else 32
-
-
-def _pmc_traffic(n, dim, Q):
-    """HBM bytes per scan launch from a separate `rocprofv3 --pmc FETCH_SIZE` pass (committed under
-    profiles/); null when no such pass exists for this shape."""
+def _pmc_traffic(n, dim, Q, kernel_symbol):
+    """HBM bytes per scan launch from a separate `rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE` pass (counters cannot be read from inside
+    the process): profiles/pmc_traffic.json maps "<rows>x<dim>_q<Q>" to {"bytes", "kernel", "profile"}.  The entry only counts when it
+    was taken on the SAME kernel symbol this run launched; otherwise null (a stale number is worse than none)."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
-        d = json.load(open(p))
-        return d.get("%dx%d_q%d" % (n, dim, Q))
+        e = json.load(open(p)).get("%dx%d_q%d" % (n, dim, Q))
+        if isinstance(e, dict) and e.get("kernel") and _same_kernel(e["kernel"], kernel_symbol):
+            return e["bytes"], "%s (rocprofv3 --pmc pass on this kernel)" % e.get("profile", "profiles/pmc_traffic.json")
     except Exception:
-        return None
+        pass
+    return None, None
 
 
-def _kernel_name(dim, Q):
-    """The scan kernel a batch of Q queries runs (api.hip search_enqueue / launch_scan): <= 4 queries per pass stream through the
-    VALU kernel, 8..16 through scan_mfma.hip (v_mfma_f32_4x4x1), 17.. through the chain-major scan_mfma16.hip (v_mfma_f32_16x16x4)
-    when the rows are 256 / 512 / 768 floats."""
-    if dim % 128 == 0 and 768 < dim <= 2048 and Q > 16:
-        return "scan_f32_mfma16_kernel<KSTEPS=%d,NW=8,NT=2> (v_mfma_f32_16x16x4_f32, 32 queries per pass)" % (dim // 128)
-    m16 = dim % 128 == 0 and dim <= 768
-    if Q > 32 and m16:
-        return "scan_f32_mfma16_kernel<KSTEPS=%d,NW=8,NT=4> (v_mfma_f32_16x16x4_f32, 64 queries per pass)" % (dim // 128)
-    qt = _pow2(min(Q, 32))
-    if qt == 16 and dim % 128 == 0 and dim <= 2048:
-        return "scan_f32_mfma16_kernel<KSTEPS=%d,NW=4,NT=1> (v_mfma_f32_16x16x4_f32, 16 queries per pass)" % (dim // 128)
-    if qt == 32 and m16:
-        return "scan_f32_mfma16_kernel<KSTEPS=%d,NW=4,NT=2> (v_mfma_f32_16x16x4_f32, 32 queries per pass)" % (dim // 128)
-    if qt >= 8:
-        return "scan_f32_mfma_kernel<QW=%d,QSPLIT=%d> (v_mfma_f32_4x4x1, %d queries per pass)" % (min(qt, 16), max(1, qt // 16), qt)
-    return "scan_kernel<RowF32<DOT>,QT=%d>" % qt
+def _same_kernel(a, b):
+    norm = lambda s: "".join(str(s).replace("void ", "").split())   # noqa: E731
+    a, b = norm(a), norm(b)
+    return a.split("(")[0] == b.split("(")[0]
 
 
 def _human(n):
     return ("%dM" % (n // 1_000_000)) if n % 1_000_000 == 0 else ("%dk" % (n // 1000)) if n % 1000 == 0 else str(n)
 
 
-def _pow2(x):
-    p = 1
-    while p < x:
-        p <<= 1
-    return p
+# ------------------------------------------------------------------------------------------------------------------------
+# C3 / C4 (rank 0, N = 1, outside the timed region)
+# ------------------------------------------------------------------------------------------------------------------------
+def _latent(ctx, seed, row0, count, dim, out=None):
+    lib, F, qa, torch, dev = ctx["lib"], ctx["F"], ctx["qa"], ctx["torch"], ctx["dev"]
+    x = out if out is not None else torch.empty((count, dim), dtype=torch.float32, device=dev)
+    F.check(lib.qmx_synth_fill_latent_f32(dev.index or 0, seed, row0, count, dim, 32, 1.0, F.ptr(x)))
+    F.check(lib.qmx_preprocess_f32(dev.index or 0, int(qa.Distance.Cosine), F.ptr(x), count, dim, F.ptr(x)))
+    return x
+
+
+def _recall(got, exact, top):
+    return sum(len(set(a["idx"].tolist()) & set(b["idx"].tolist())) for a, b in zip(got, exact)) / float(max(1, len(exact)) * top)
+
+
+def _timed_quantized(ctx, scorer, raw, top, oversampling, rescore, graph, ef, reps, row_bytes, n_rows_scanned=None):
+    """reps calls of qmx_search_quantized; kernel time = HIP events around the quantized stage's scoring kernel (scan or walk)."""
+    lib, F, qa = ctx["lib"], ctx["F"], ctx["qa"]
+    F.check(lib.qmx_query_set_timing(scorer._h, 1))
+    cnt = F.Counters()
+    qa.search_quantized(scorer, raw, top, oversampling=oversampling, rescore=rescore, graph=graph, hnsw_ef=ef)          # warm-up
+    ms, nl = C.c_float(), C.c_uint32()
+    F.check(lib.qmx_query_timing(scorer._h, C.byref(ms), C.byref(nl)))
+    scored = 0
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res = qa.search_quantized(scorer, raw, top, oversampling=oversampling, rescore=rescore, graph=graph, hnsw_ef=ef, counters=cnt)
+        scored += int(cnt.vectors_scored)
+    wall = (time.perf_counter() - t0) / reps
+    F.check(lib.qmx_query_timing(scorer._h, C.byref(ms), C.byref(nl)))
+    launches = max(1, int(nl.value))
+    kernel_ms = ms.value / launches                        # per launch of the quantized stage's kernel
+    per_launch_rows = (n_rows_scanned if n_rows_scanned is not None else scored / float(launches))
+    gbps = per_launch_rows * row_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    return res, {"kernel": F.last_kernel(scorer._h), "kernel_ms": round(kernel_ms, 4), "launches_per_search": launches / float(reps),
+                 "wall_ms_per_search": round(wall * 1e3, 3), "qps_wall": round(scorer.nq / wall, 1),
+                 "roofline": {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
+                              "algorithmic_bytes_per_launch": int(per_launch_rows * row_bytes), "bytes_per_scored_row": row_bytes, "traffic": None}}, scored / float(reps)
+
+
+def c3_section(ctx, rows):
+    """BASELINE.json configs[2]: 10 M x 768 SQ-int8, dot; brute force + HNSW rescoring."""
+    args, dev, lib, F, qa, np, torch = (ctx[k] for k in ("args", "dev", "lib", "F", "qa", "np", "torch"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    dim, top = 768, 10
+    n = args.config_rows or args.rows
+    seed = 0x5EED0003
+    t0 = time.perf_counter()
+    if rows.shape != (n, dim):
+        del rows
+        torch.cuda.empty_cache()
+        rows = torch.empty((n, dim), dtype=torch.float32, device=dev)
+    _latent(ctx, seed, 0, n, dim, out=rows)                 # refills the C2 block in place (30.72 GB, adopted, never copied)
+    nq_h = args.hnsw_queries
+    queries = _latent(ctx, seed, QUERY_ROW0, max(nq_h, 256), dim)
+    torch.cuda.synchronize(dev)
+    t_data = time.perf_counter() - t0
+    vs = qa.VectorStorage(rows, qa.Distance.Cosine)
+    # ---- quantize: quantile = None fit (global min / max), encode on the device ----
+    t0 = time.perf_counter()
+    quant = qa.ScalarQuantizer.fit(rows, dim, qa.Distance.Dot)
+    p = quant.params()
+    codes = torch.empty((n, quant.quantized_vector_size()), dtype=torch.uint8, device=dev)
+    F.check(lib.qmx_sq_encode(dev.index or 0, int(qa.Distance.Dot), C.byref(p), F.ptr(rows), n, dim, F.ptr(codes)))
+    torch.cuda.synchronize(dev)
+    t_enc = time.perf_counter() - t0
+    enc = qa.EncodedVectorsU8(codes, quant)
+    S = min(n, 200_000)
+    host_codes_sample = codes[:S].cpu().numpy()
+    host_rows_sample = rows[:2000].cpu().numpy()
+    keep_codes = codes if args.verify else None
+    del codes
+    row_bytes = quant.quantized_vector_size()               # 772 B: SURVEY 8d
+    out = {"workload": "C3: %s x d=768 SQ-int8 (min/max fit), dot; rows of low intrinsic dimension (32 latent coordinates + noise), cosine-normalised" % _human(n),
+           "rows": n, "dim": dim, "row_bytes": row_bytes, "data_s": round(t_data, 2), "sq_fit_and_encode_s": round(t_enc, 3)}
+    # ---- exact ground truth on the device (f32 brute force) ----
+    n_gt = 256
+    exact = qa.BatchFilteredSearcher(queries[:n_gt].cpu().numpy(), vs, top).peek_top_all()
+    # ---- brute force over the codes, oversampling 2 + rescoring (PlainVectorIndex::search with quantization) ----
+    bf = {}
+    for Qb in (1, 32):
+        nb = min(n_gt // Qb, 8)
+        recs, stats = [], None
+        for b in range(nb):
+            qb = queries[b * Qb:(b + 1) * Qb].contiguous()
+            scorer, raw = qa.new_raw_scorer(qb, enc), qa.new_raw_scorer(qb, vs)
+            res, st, _ = _timed_quantized(ctx, scorer, raw, top, 2.0, True, None, 0, 5 if b == 0 else 1, row_bytes, n_rows_scanned=n)
+            stats = stats or st
+            recs.append(_recall(res, exact[b * Qb:(b + 1) * Qb], top))
+        stats["recall_at_10_vs_exact"] = round(float(np.mean(recs)), 4)
+        stats["queries_checked"] = nb * Qb
+        bf["Q%d" % Qb] = stats
+    out["brute_force_oversampling2_rescore"] = bf
+    # ---- in-run oracle check: top-k over a sample of the codes, bit-exact scores; encoded rows byte-exact ----
+    if args.verify:
+        import oracle_ffi as O
+        osq = O.SqOracle(O.DOT, dim, quant.alpha, quant.offset)
+        enc_ok = bool(np.array_equal(osq.encode_rows(host_rows_sample), host_codes_sample[:2000]))
+        osq.rows = host_codes_sample
+        qpre = queries[:2].cpu().numpy()
+        ids = np.arange(S, dtype=np.uint32)
+        got = qa.BatchFilteredSearcher(qpre, vs, top, quantized_vectors=enc).peek_top_iter(ids)
+        sc = osq.score_points(qpre, ids)
+        top_ok = all(np.array_equal(np.sort(sc[i])[::-1][:top].view(np.uint32), got[i]["score"].view(np.uint32)) for i in range(2))
+        out["oracle_check"] = {"encoded_rows_byte_exact_first_2000": enc_ok, "topk_scores_bit_exact_on_%dk_sample" % (S // 1000): bool(top_ok)}
+    # ---- HNSW: build THROUGH the SQ scorer (hnsw/build.rs:334-341), SQ walk, oversampling 2, f32 rescoring ----
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    graph = qa.GraphLayers.build(enc, m=16, ef_construct=100, seed=42)
+    t_build = time.perf_counter() - t0
+    qh_all = queries[:nq_h].contiguous()
+    scorer, raw = qa.new_raw_scorer(qh_all, enc), qa.new_raw_scorer(qh_all, vs)
+    res, st, scored = _timed_quantized(ctx, scorer, raw, top, 2.0, True, graph, 128, 3, row_bytes)
+    st.update({"m": 16, "ef_construct": 100, "ef": 128, "oversampling": 2.0, "searches_per_launch": nq_h,
+               "build_s": round(t_build, 2), "build_points_per_s": round(n / t_build, 1),
+               "points_scored_per_query": round(scored / nq_h, 1), "recall_at_10_vs_exact": round(_recall(res[:n_gt], exact, top), 4)})
+    # recall-vs-ef of the same graph, f32 walk (graph quality without the quantizer)
+    st["recall_f32_walk_vs_ef"] = {str(ef): round(_recall(graph.search(top, ef, qa.new_raw_scorer(queries[:n_gt].contiguous(), vs)), exact, top), 4)
+                                   for ef in (64, 128, 256)}
+    if args.verify:
+        # the CPU oracle walks THE SAME graph with its SQ scorer: identical ids and score bits expected (host copy of the codes + links)
+        import oracle_ffi as O
+        try:
+            t0 = time.perf_counter()
+            osq_all = O.SqOracle(O.DOT, dim, quant.alpha, quant.offset)
+            osq_all.rows = keep_codes.cpu().numpy()
+            walker = O.Hnsw.from_plain(graph.export_plain(), n)
+            flags = O.DenseStorage(O.F32, O.DOT, np.zeros((1, dim), dtype=np.float32))
+            flags.st.n = n
+            nchk = 16
+            want = walker.search_sq(flags, osq_all, queries[:nchk].cpu().numpy(), 2 * top, 128)
+            got = graph.search(2 * top, 128, qa.new_raw_scorer(queries[:nchk].contiguous(), enc))
+            st["oracle_walk_check"] = {"same_ids": "%d/%d" % (sum(int(a["idx"].tolist() == b["idx"].tolist()) for a, b in zip(got, want)), nchk),
+                                       "same_score_bits": "%d/%d" % (sum(int(np.array_equal(a["score"].view(np.uint32), b["score"].view(np.uint32)))
+                                                                         for a, b in zip(got, want)), nchk),
+                                       "seconds": round(time.perf_counter() - t0, 1)}
+            del osq_all, walker
+        except Exception as e:
+            st["oracle_walk_check"] = {"error": repr(e)[:300]}
+    out["hnsw_sq_walk_rescore"] = st
+    del keep_codes, graph, enc, vs
+    return out, rows
+
+
+def c4_section(ctx):
+    """BASELINE.json configs[3]: 10 M x 1536, PQ m = 96 (8-bit), HNSW ef = 128, LUT on the matrix cores."""
+    args, dev, lib, F, qa, np, torch = (ctx[k] for k in ("args", "dev", "lib", "F", "qa", "np", "torch"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    dim, chunk, top = 1536, 16, 10
+    n = args.config_rows or args.rows
+    seed = 0x5EED0004
+    t0 = time.perf_counter()
+    rows = _latent(ctx, seed, 0, n, dim)                    # 61.4 GB at 10 M rows
+    nq_h = args.hnsw_queries
+    queries = _latent(ctx, seed, QUERY_ROW0, max(nq_h, 256), dim)
+    torch.cuda.synchronize(dev)
+    t_data = time.perf_counter() - t0
+    vs = qa.VectorStorage(rows, qa.Distance.Cosine)
+    # ---- codebook: kmeans.rs on a 10 000-row sample (KMEANS_SAMPLE_SIZE), on the device; encode on the device ----
+    t0 = time.perf_counter()
+    stride = max(1, n // 10000)
+    sample = rows[::stride][:10000].contiguous()
+    cen = torch.zeros((256, dim), dtype=torch.float32, device=dev)
+    iters = np.zeros(dim // chunk, dtype=np.uint32)
+    F.check(lib.qmx_pq_train(dev.index or 0, F.ptr(sample), sample.shape[0], dim, chunk, 256, 100, 1e-5, 1, F.ptr(cen), F.ptr(iters)))
+    torch.cuda.synchronize(dev)
+    t_train = time.perf_counter() - t0
+    cen_h = cen.cpu().numpy()
+    quant = qa.ProductQuantizer(dim, qa.Distance.Dot, chunk, cen_h, lut_mfma=True)    # north_star: PQ LUT build via MFMA
+    p = quant.params()
+    codes = torch.empty((n, quant.m), dtype=torch.uint8, device=dev)
+    t0 = time.perf_counter()
+    F.check(lib.qmx_pq_encode(dev.index or 0, C.byref(p), F.ptr(rows), n, dim, F.ptr(codes)))
+    torch.cuda.synchronize(dev)
+    t_enc = time.perf_counter() - t0
+    enc = qa.EncodedVectorsPQ(codes, quant)
+    out = {"workload": "C4: %s x d=1536 PQ m=%d (chunk 16, 256 centroids), dot; rows of low intrinsic dimension, cosine-normalised; LUT via v_mfma_f32_32x32x2_f32"
+                       % (_human(n), quant.m), "rows": n, "dim": dim, "row_bytes": quant.m, "data_s": round(t_data, 2),
+           "pq_kmeans_train_s": round(t_train, 3), "kmeans_iterations_max": int(iters.max()), "pq_encode_s": round(t_enc, 3)}
+    n_gt = 256
+    exact = qa.BatchFilteredSearcher(queries[:n_gt].cpu().numpy(), vs, top).peek_top_all()
+    # ---- LUT build on the matrix cores: time of encode_query for a batch (qmx_query_update), its flops against the f32 MFMA peak ----
+    qh_all = queries[:nq_h].contiguous()
+    scorer = qa.new_raw_scorer(qh_all, enc)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        F.check(lib.qmx_query_update(scorer._h, F.ptr(qh_all)))
+    F.check(lib.qmx_query_synchronize(scorer._h))
+    lut_ms = (time.perf_counter() - t0) / 3 * 1e3
+    lut_flops = 2.0 * 256 * dim * nq_h                       # SURVEY 8d: 2 x 256 x d flop per query
+    out["lut_build_mfma"] = {"queries": nq_h, "ms_incl_preprocess": round(lut_ms, 3), "flops": lut_flops,
+                             "roofline": {"bound": "mfma", "achieved": round(lut_flops / (lut_ms * 1e-3) / 1e12, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                          "frac": round(lut_flops / (lut_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                                          "note": "wall time of qmx_query_update (cosine preprocess + LUT + the 96 KiB/query LUT write: %d MB): write-bound, not MFMA-bound" % (nq_h * 96 // 1024)}}
+    # ---- HNSW: build through the PQ scorer (point_scorer.rs:197-212), PQ walk ef = 128 ----
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    graph = qa.GraphLayers.build(enc, m=16, ef_construct=100, seed=42, original=vs)
+    t_build = time.perf_counter() - t0
+    raw = qa.new_raw_scorer(qh_all, vs)
+    walks = {}
+    for name, over, resc in (("no_rescoring", 0.0, False), ("oversampling2_rescore", 2.0, True), ("oversampling4_rescore", 4.0, True)):
+        res, st, scored = _timed_quantized(ctx, scorer, raw, top, over, resc, graph, 128, 3, quant.m)
+        st.update({"points_scored_per_query": round(scored / nq_h, 1), "recall_at_10_vs_exact": round(_recall(res[:n_gt], exact, top), 4)})
+        walks[name] = st
+    hn = {"m": 16, "ef_construct": 100, "ef": 128, "searches_per_launch": nq_h, "build_through": "PQ scorer (LUT of the original vector per insertion, score_internal for the heuristic)",
+          "build_s": round(t_build, 2), "build_points_per_s": round(n / t_build, 1), "walks": walks}
+    hn["recall_f32_walk_vs_ef"] = {str(ef): round(_recall(graph.search(top, ef, qa.new_raw_scorer(queries[:n_gt].contiguous(), vs)), exact, top), 4)
+                                   for ef in (64, 128, 256)}
+    # brute force over the codes for reference (what the quantizer alone can do on these rows)
+    bfs = qa.new_raw_scorer(queries[:32].contiguous(), enc)
+    bfr = qa.new_raw_scorer(queries[:32].contiguous(), vs)
+    res, st, _ = _timed_quantized(ctx, bfs, bfr, top, 2.0, True, None, 0, 3, quant.m, n_rows_scanned=n)
+    st["recall_at_10_vs_exact"] = round(_recall(res, exact[:32], top), 4)
+    out["brute_force_Q32_oversampling2_rescore"] = st
+    if args.verify:
+        import oracle_ffi as O
+        try:
+            t0 = time.perf_counter()
+            opq = O.PqOracle(O.DOT, dim, chunk, cen_h)
+            host_codes = codes.cpu().numpy()
+            enc_ok = bool(np.array_equal(opq.encode(rows[:1000].cpu().numpy()), host_codes[:1000]))
+            opq.codes = host_codes
+            walker = O.Hnsw.from_plain(graph.export_plain(), n)
+            flags = O.DenseStorage(O.F32, O.DOT, np.zeros((1, dim), dtype=np.float32))
+            flags.st.n = n
+            nchk = 16
+            qpre = queries[:nchk].cpu().numpy()
+            # the oracle's LUT is the exact-order one; the device walk under test uses the MFMA LUT (<= 1e-5): compare against a device walk
+            # with the exact-order LUT for bits, and report how the MFMA-LUT walk compares
+            quant_exact = qa.ProductQuantizer(dim, qa.Distance.Dot, chunk, cen_h, lut_mfma=False)
+            enc_exact = qa.EncodedVectorsPQ(codes, quant_exact)
+            want = walker.search_pq(flags, opq, qpre, 2 * top, 128)
+            got = graph.search(2 * top, 128, qa.new_raw_scorer(queries[:nchk].contiguous(), enc_exact))
+            got_mfma = graph.search(2 * top, 128, qa.new_raw_scorer(queries[:nchk].contiguous(), enc))
+            hn["oracle_walk_check"] = {"codes_byte_exact_first_1000": enc_ok,
+                                       "exact_lut_same_ids": "%d/%d" % (sum(int(a["idx"].tolist() == b["idx"].tolist()) for a, b in zip(got, want)), nchk),
+                                       "exact_lut_same_score_bits": "%d/%d" % (sum(int(np.array_equal(a["score"].view(np.uint32), b["score"].view(np.uint32)))
+                                                                                   for a, b in zip(got, want)), nchk),
+                                       "mfma_lut_same_id_sets": "%d/%d" % (sum(int(set(a["idx"].tolist()) == set(b["idx"].tolist())) for a, b in zip(got_mfma, want)), nchk),
+                                       "mfma_lut_max_rel_score_err": float(max(np.max(np.abs(a["score"][:min(len(a), len(b))] - b["score"][:min(len(a), len(b))]) /
+                                                                                      np.maximum(np.abs(b["score"][:min(len(a), len(b))]), 1e-30)) for a, b in zip(got_mfma, want))),
+                                       "seconds": round(time.perf_counter() - t0, 1)}
+        except Exception as e:
+            hn["oracle_walk_check"] = {"error": repr(e)[:300]}
+    out["hnsw_pq_walk"] = hn
+    return out
 
 
 if __name__ == "__main__":

@@ -214,7 +214,7 @@ QMX_API uint32_t qmx_abi_version(void);
 /* Kernel-path options (process-wide).  Each selects between kernels that return IDENTICAL results - the parity tests run
  * both sides of every option - so they are tuning / triage switches, never correctness switches: "no_mfma_scan", "no_mfma16",
  * "no_mfma16_q64", "no_prescan", "prescan_shift", "hnsw_no_packed_l0", "hnsw_pq_lds_lut", "hnsw_log_cap", "bq_lanes8",
- * "mfma_no_nt", "mfma_no_fast", "no_pq_tiled", "debug".  Initial values come from the environment variables QMX_<NAME> read
+ * "mfma_no_nt", "mfma_no_fast", "no_pq_tiled", "no_pq_pair", "debug".  Initial values come from the environment variables QMX_<NAME> read
  * ONCE when the library is loaded; value < 0 restores that initial value.  Unknown name => QMX_ERR_BAD_ARG.  (No reference
  * counterpart: the reference selects its SIMD leaf by cpu feature detection, spaces/simple.rs:15-33.) */
 QMX_API int32_t qmx_set_option(const char *name, int64_t value);
@@ -305,6 +305,10 @@ QMX_API int32_t qmx_query_synchronize(qmx_query *q);
  * launch count since the previous call and resets them (how bench.py derives roofline.achieved). */
 QMX_API int32_t qmx_query_set_timing(qmx_query *q, int32_t enabled);
 QMX_API int32_t qmx_query_timing(qmx_query *q, float *total_ms, uint32_t *n_launches);
+/* The (demangled) symbol of the scoring kernel the last qmx_search_topk* / qmx_hnsw_search* call of this batch launched - what a
+ * profiler trace of the same call shows - so that measurements name the kernel they timed instead of guessing the dispatch.
+ * Empty string before the first search.  (The reference's counterpart is its per-leaf dispatch, spaces/simple.rs:15-33.) */
+QMX_API int32_t qmx_query_last_kernel(const qmx_query *q, char *buf, size_t buf_len);
 /* Encoded form read-back for tests: f32/f16/u8 preprocessed+cast query; SQ: [f32 offset][codes];
  * PQ: the LUT [m][n_centroids] f32. */
 QMX_API int32_t qmx_query_read_encoded(const qmx_query *q, uint32_t query_index, void *out,
@@ -595,6 +599,14 @@ typedef struct qmx_hnsw_info {
  * links, no self links, no duplicates, links only to points of at least that level) and is checked by recall.
  * The result is searchable at once (qmx_hnsw_search) and exportable as plain GraphLinks arrays. */
 QMX_API int32_t qmx_hnsw_build(const qmx_segment *seg, const qmx_hnsw_build_params *params, qmx_hnsw **out);
+/* The build of a QUANTIZED segment whose storage cannot turn a stored row into a query — product quantization
+ * (EncodedVectorsPQ::encode_internal_vector -> None, encoded_vectors_pq.rs:620-623).  FilteredScorer::new_internal
+ * (hnsw_index/point_scorer.rs:183-218) then scores the searches of an insertion with quantized_vectors.raw_scorer(ORIGINAL vector of
+ * the point) = its LUT, while the heuristic and the back links use the storage's score_internal (centroid <-> centroid distances,
+ * :574-618).  `original` = the f32 segment the PQ segment was encoded from (same rows, same device); for every other dtype it may be
+ * NULL and the call equals qmx_hnsw_build. */
+QMX_API int32_t qmx_hnsw_build_quantized(const qmx_segment *quantized, const qmx_segment *original, const qmx_hnsw_build_params *params,
+                                         qmx_hnsw **out);
 QMX_API int32_t qmx_hnsw_get_info(const qmx_hnsw *g, qmx_hnsw_info *out);
 /* Copies the plain arrays of a graph built by qmx_hnsw_build into caller (host) buffers sized per qmx_hnsw_get_info:
  * reindex [n_points], level_offsets [n_levels + 1], offsets [n_offsets], neighbors [n_neighbors], entry points. */
@@ -652,6 +664,12 @@ QMX_API int32_t qmx_pq_encode(int32_t device_id, const qmx_pq_params *params, co
  * [n][dim] f32 starting at row `row0`. */
 QMX_API int32_t qmx_synth_fill_f32(int32_t device_id, uint64_t seed, uint64_t row0, uint64_t n,
                                    uint32_t dim, float *out_dev);
+/* Rows of low intrinsic dimension — the regime ANN indexes and quantizers are built for (iid N(0,1) rows in d = 768 have
+ * nearly equidistant neighbours: recall collapses for the CPU reference and the device alike, hnsw_quantized_search_test.rs
+ * asserts only > 40 % on such data): x[r][c] = sum_k z[r][k] W[k][c] + noise * e[r][c], z / W / e from the generator above,
+ * the sum one fmaf chain in k order, so the CPU oracle's twin (qo_synth_fill_latent_f32) is bit-identical. */
+QMX_API int32_t qmx_synth_fill_latent_f32(int32_t device_id, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim,
+                                          uint32_t latent_dim, float noise, float *out_dev);
 
 #ifdef __cplusplus
 }

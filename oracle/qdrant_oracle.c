@@ -1209,6 +1209,26 @@ void qo_synth_fill_f32(uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, f
     for (uint64_t r = 0; r < n; r++)
         for (uint32_t c = 0; c < dim; c++) out[r * dim + c] = qo_synth_value(seed, row0 + r, c, dim);
 }
+/* twin of qmx_synth_fill_latent_f32 (qdrant_amd/csrc/preprocess.hip synth_latent_kernel): one fmaf chain over the latent coordinates */
+void qo_synth_fill_latent_f32(uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, uint32_t K, float noise, float *out) {
+    float *W = (float *)malloc((size_t)K * dim * sizeof(float));
+    float *z = (float *)malloc((size_t)K * sizeof(float));
+    qo_synth_fill_f32(seed ^ 0x57ull, 0, K, dim, W);
+    for (uint64_t r = 0; r < n; r++) {
+        for (uint32_t k = 0; k < K; k++) z[k] = qo_synth_value(seed, row0 + r, k, K);
+        float *o = out + r * dim;
+        for (uint32_t c = 0; c < dim; c++) o[c] = 0.0f;
+        for (uint32_t k = 0; k < K; k++) {
+            const float zk = z[k];
+            const float *w = W + (size_t)k * dim;
+            for (uint32_t c = 0; c < dim; c++) o[c] = fmaf(zk, w[c], o[c]);
+        }
+        if (noise != 0.0f)
+            for (uint32_t c = 0; c < dim; c++) o[c] = fmaf(noise, qo_synth_value(seed ^ 0xE5ull, row0 + r, c, dim), o[c]);
+    }
+    free(W);
+    free(z);
+}
 
 /* ------------------------------------------------------------------------------------------
  * BQ: EncodedVectorsBin<u128> (lib/quantization/src/encoded_vectors_binary.rs), Encoding::OneBit,

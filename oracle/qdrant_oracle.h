@@ -194,6 +194,10 @@ qo_hnsw *qo_hnsw_build(const qo_storage *st, uint32_t m, uint32_t m0, uint32_t e
  * (hnsw/build.rs:285-356): like the reference's rayon build the result depends on thread timing. */
 qo_hnsw *qo_hnsw_build_parallel(const qo_storage *st, uint32_t m, uint32_t m0, uint32_t ef_construct,
                                 uint32_t entry_points_num, int use_heuristic, uint64_t seed, int threads);
+/* the build of a QUANTIZED segment (hnsw/build.rs:334-341, point_scorer.rs:183-218): tmpl = the quantized storage as a scorer
+ * template over tmpl->st (original dense storage); PQ scores each insertion's searches with the LUT of the original vector */
+qo_hnsw *qo_hnsw_build_with(const qo_scorer *tmpl, uint32_t m, uint32_t m0, uint32_t ef_construct, uint32_t entry_points_num,
+                            int use_heuristic, uint64_t seed);
 void qo_hnsw_free(qo_hnsw *g);
 uint32_t qo_hnsw_point_level(const qo_hnsw *g, uint32_t id);
 uint32_t qo_hnsw_max_level(const qo_hnsw *g);
@@ -252,6 +256,7 @@ uint64_t qo_links_serialize_compressed(uint32_t m, uint32_t m0, uint32_t n_point
 /* ---- synthetic data shared bit-for-bit with the device generator ---- */
 float qo_synth_value(uint64_t seed, uint64_t row, uint32_t col, uint32_t dim);
 void qo_synth_fill_f32(uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, float *out);
+void qo_synth_fill_latent_f32(uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, uint32_t K, float noise, float *out);
 
 #ifdef __cplusplus
 }

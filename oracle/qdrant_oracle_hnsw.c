@@ -510,6 +510,23 @@ static float internal_score(void *c, uint32_t a, uint32_t b) { return qo_scorer_
 /* ---- GraphLayersBuilder::link_new_point (graph_layers_builder.rs:417-474) --------------------- */
 static void link_new_point(qo_hnsw *g, const qo_scorer *tmpl, uint32_t p, visited_t *vis) {
     qscore q = {NULL, tmpl, p, 0};
+    /* FilteredScorer::new_internal (point_scorer.rs:183-218): a quantized storage that cannot rebuild a query from a stored row
+     * (EncodedVectorsPQ::encode_internal_vector -> None) scores the searches of this insertion through
+     * quantized_vectors.raw_scorer(ORIGINAL vector of p) = the LUT of the preprocessed original (quantized_query_scorer.rs:39-41);
+     * score_internal (entry score below, the heuristic, the back links) stays the storage's symmetric one */
+    qo_scorer own;
+    float *lut = NULL;
+    if (tmpl->kind == 2) {
+        const qo_storage *st = tmpl->st;
+        float *qv = (float *)malloc(sizeof(float) * st->dim);
+        qo_preprocess_f32(st->distance, (const float *)st->rows + (size_t)p * st->dim, qv, st->dim);
+        lut = (float *)malloc(sizeof(float) * (size_t)tmpl->pq->m * tmpl->pq->n_centroids);
+        qo_pq_encode_query(tmpl->pq, qv, lut);
+        free(qv);
+        own = *tmpl;
+        own.pq_lut = lut;
+        q.s = &own;
+    }
     const uint32_t level = g->level[p];
     uint32_t ep_id = 0, ep_level = 0;
     pthread_mutex_lock(&g->ep_lock);
@@ -566,6 +583,7 @@ static void link_new_point(qo_hnsw *g, const qo_scorer *tmpl, uint32_t p, visite
     pthread_mutex_lock(&g->ep_lock);
     entry_new_point(g, &q, p, level);
     pthread_mutex_unlock(&g->ep_lock);
+    free(lut);
 }
 
 static inline uint64_t splitmix64(uint64_t x) {
@@ -619,6 +637,22 @@ qo_hnsw *qo_hnsw_build(const qo_storage *st, uint32_t m, uint32_t m0, uint32_t e
     for (uint32_t p = 0; p < g->n; p++) {
         if (!qo_scorer_check_vector(&tmpl, p)) continue;     /* deleted points are never indexed (hnsw/build.rs:293-300) */
         link_new_point(g, &tmpl, p, &vis);
+    }
+    free(vis.cnt);
+    return g;
+}
+
+/* hnsw/build.rs:334-341: a segment with quantized vectors builds its graph THROUGH the quantized scorer.  `tmpl` = the quantized
+ * storage as a scorer template (kind 1 SQ / 2 PQ / 3 BQ; its `st` = the original dense storage: deleted flags, n, and — for PQ —
+ * the original vectors the per-point LUTs are made of).  Sequential, like the reference's deterministic test builds. */
+qo_hnsw *qo_hnsw_build_with(const qo_scorer *tmpl, uint32_t m, uint32_t m0, uint32_t ef_construct, uint32_t entry_points_num,
+                            int use_heuristic, uint64_t seed) {
+    qo_hnsw *g = hnsw_alloc(tmpl->st, m, m0, ef_construct, entry_points_num, use_heuristic, seed, 0);
+    visited_t vis;
+    visited_init(&vis, g->n);
+    for (uint32_t p = 0; p < g->n; p++) {
+        if (!qo_scorer_check_vector(tmpl, p)) continue;
+        link_new_point(g, tmpl, p, &vis);
     }
     free(vis.cnt);
     return g;

@@ -136,6 +136,7 @@ SIGNATURES = {
     "qmx_query_synchronize": (C.c_int32, [_P]),
     "qmx_query_set_timing": (C.c_int32, [_P, C.c_int32]),
     "qmx_query_timing": (C.c_int32, [_P, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
+    "qmx_query_last_kernel": (C.c_int32, [_P, C.c_char_p, C.c_size_t]),
     "qmx_query_read_encoded": (C.c_int32, [_P, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "qmx_score_points": (C.c_int32, [_P, _P, C.c_uint32, _P, C.POINTER(Counters)]),
     "qmx_score_points_ragged": (C.c_int32, [_P, _P, _P, _P, C.POINTER(Counters)]),
@@ -159,6 +160,7 @@ SIGNATURES = {
     "qmx_graph_links_free": (None, [C.POINTER(GraphLinks)]),
     "qmx_hnsw_destroy": (C.c_int32, [_P]),
     "qmx_hnsw_build": (C.c_int32, [_P, C.POINTER(HnswBuildParams), C.POINTER(_P)]),
+    "qmx_hnsw_build_quantized": (C.c_int32, [_P, _P, C.POINTER(HnswBuildParams), C.POINTER(_P)]),
     "qmx_hnsw_get_info": (C.c_int32, [_P, C.POINTER(HnswInfo)]),
     "qmx_hnsw_export_plain": (C.c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qmx_hnsw_search": (C.c_int32, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, _P, C.POINTER(Counters)]),
@@ -177,6 +179,7 @@ SIGNATURES = {
     "qmx_bq_encode": (C.c_int32, [C.c_int32, _P, C.c_uint64, C.c_uint32, _P]),
     "qmx_pq_encode": (C.c_int32, [C.c_int32, C.POINTER(PqParams), _P, C.c_uint64, C.c_uint32, _P]),
     "qmx_synth_fill_f32": (C.c_int32, [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, _P]),
+    "qmx_synth_fill_latent_f32": (C.c_int32, [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_float, _P]),
 }
 
 _lib = None
@@ -219,6 +222,13 @@ def get_option(name):
     v = C.c_int64()
     check(lib().qmx_get_option(name.encode(), C.byref(v)))
     return v.value
+
+
+def last_kernel(query_handle):
+    """qmx_query_last_kernel: the demangled symbol of the scoring kernel the batch's last search launched."""
+    buf = C.create_string_buffer(1024)
+    check(lib().qmx_query_last_kernel(query_handle, buf, len(buf)))
+    return buf.value.decode(errors="replace")
 
 
 def ptr(x):

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <ctype.h>
+#include <cxxabi.h>
 
 #include <algorithm>
 #include <atomic>
@@ -46,7 +47,7 @@ int32_t hip_status(hipError_t e, const char *what, const char *file, int line) {
 
 // ---- kernel-path options: the environment is read once, here, at load time ----
 static const char *const g_option_names[OPT_COUNT] = {"no_mfma_scan", "no_mfma16", "no_mfma16_q64", "no_prescan", "prescan_shift", "hnsw_no_packed_l0",
-                                                     "hnsw_pq_lds_lut", "hnsw_log_cap", "bq_lanes8", "mfma_no_nt", "mfma_no_fast", "no_pq_tiled", "debug"};
+                                                     "hnsw_pq_lds_lut", "hnsw_log_cap", "bq_lanes8", "mfma_no_nt", "mfma_no_fast", "no_pq_tiled", "no_pq_pair", "debug"};
 struct OptionTable {
     std::atomic<int64_t> v[OPT_COUNT];
     int64_t initial[OPT_COUNT];
@@ -67,6 +68,9 @@ struct OptionTable {
 };
 static OptionTable g_options;
 int64_t option(Option o) { return g_options.v[o].load(std::memory_order_relaxed); }
+
+static thread_local const void *g_last_kernel = nullptr;
+void note_kernel(const void *host_function) { g_last_kernel = host_function; }
 
 void clear_stale_error() {
     hipError_t e = hipGetLastError();
@@ -161,6 +165,7 @@ struct qmx_segment {
     uint32_t bq_query_bits = 1;          // QueryEncoding: 1 = SameAsStorage, 4 / 8 = Scalar4bits / Scalar8bits
     float *d_bq_mean = nullptr, *d_bq_stddev = nullptr;   // VectorStats of the 2-bit / 1.5-bit encodings (device copies), or null
     float *d_centroids = nullptr;
+    float *d_pq_pair = nullptr;       // [m][ncent][ncent] chunk distances between centroids (score_internal terms; built when <= 256 MB)
     uint32_t pq_m = 0;
     float *d_row_offsets = nullptr;   // SQ: vector_offset column (rows hold the 16-byte aligned code block)
 
@@ -220,6 +225,7 @@ struct qmx_query {
     int *d_err = nullptr;
     uint32_t partial_grid_cap = 0;
     bool timing = false;
+    const void *last_kernel = nullptr;   // host handle of the last top-k scan / graph walk kernel launched for this batch
 };
 
 // f32 dot / cosine rows of >= 32 elements scan 8..32 queries per pass on the f32 matrix cores (scan_mfma.hip)
@@ -363,6 +369,7 @@ static void segment_free(qmx_segment *seg) {
     if (seg->d_point_deleted) (void)hipFree(seg->d_point_deleted);
     if (seg->d_vec_deleted) (void)hipFree(seg->d_vec_deleted);
     if (seg->d_centroids) (void)hipFree(seg->d_centroids);
+    if (seg->d_pq_pair) (void)hipFree(seg->d_pq_pair);
     if (seg->d_row_offsets) (void)hipFree(seg->d_row_offsets);
     if (seg->d_bq_mean) (void)hipFree(seg->d_bq_mean);
     if (seg->d_bq_stddev) (void)hipFree(seg->d_bq_stddev);
@@ -466,6 +473,14 @@ int32_t qmx_segment_create(const qmx_segment_desc *desc, qmx_segment **out) {
             if (e == hipSuccess) e = hipMemcpy(s->d_centroids, desc->pq->centroids, cbytes, hipMemcpyDefault);
             if (e != hipSuccess) rc = hip_status(e, "PQ centroids upload", __FILE__, __LINE__);
             s->pq.centroids = nullptr;   // the caller's table is not referenced after create
+            // score_internal's chunk terms, tabulated once (the HNSW build over a PQ segment scores stored <-> stored pairs with them)
+            const size_t pbytes = (size_t)s->pq_m * s->pq.n_centroids * s->pq.n_centroids * sizeof(float);
+            if (rc == QMX_OK && pbytes <= (256u << 20)) {
+                e = hipMalloc((void **)&s->d_pq_pair, pbytes);
+                if (e != hipSuccess) { rc = hip_status(e, "PQ pair table", __FILE__, __LINE__); break; }
+                rc = launch_pq_pair_table(nullptr, desc->distance, desc->dim, s->pq, s->d_centroids, s->d_pq_pair);
+                if (rc == QMX_OK && hipDeviceSynchronize() != hipSuccess) rc = QMX_ERR_OTHER;
+            }
             break;
         }
         case QMX_DTYPE_BQ: {  // get_quantized_vector_size_from_params::<u128>(dim, encoding) (encoded_vectors_binary.rs:829-840, 412-419)
@@ -738,6 +753,19 @@ int32_t qmx_synth_fill_f32(int32_t device_id, uint64_t seed, uint64_t row0, uint
     return QMX_OK;
 }
 
+int32_t qmx_synth_fill_latent_f32(int32_t device_id, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, uint32_t latent_dim, float noise,
+                                  float *out_dev) {
+    QMX_REQUIRE(out_dev && dim > 0 && latent_dim >= 1 && latent_dim <= 1024, QMX_ERR_BAD_ARG, "bad argument (latent_dim must be 1..1024)");
+    QMX_TRY(check_device(device_id, nullptr));
+    QMX_REQUIRE(is_device_ptr(out_dev), QMX_ERR_BAD_ARG, "out_dev must be device memory");
+    DevBuf w;
+    QMX_TRY(w.reserve((size_t)latent_dim * dim * sizeof(float)));
+    int32_t rc = launch_synth_latent(nullptr, seed, row0, n, dim, latent_dim, noise, (float *)w.p, out_dev);
+    if (rc == QMX_OK && hipDeviceSynchronize() != hipSuccess) rc = QMX_ERR_OTHER;
+    w.release();
+    return rc;
+}
+
 // ---------------------------------------------------------------------------------------------
 // query batch
 // ---------------------------------------------------------------------------------------------
@@ -961,6 +989,19 @@ int32_t qmx_query_timing(qmx_query *q, float *total_ms, uint32_t *n_launches) {
     return QMX_OK;
 }
 
+int32_t qmx_query_last_kernel(const qmx_query *q, char *buf, size_t buf_len) {
+    QMX_REQUIRE(q && buf && buf_len > 0, QMX_ERR_BAD_ARG, "NULL argument");
+    buf[0] = 0;
+    if (!q->last_kernel) return QMX_OK;
+    const char *mangled = hipKernelNameRefByPtr(q->last_kernel, q->stream);
+    if (!mangled) return QMX_OK;
+    int status = 0;
+    char *dem = abi::__cxa_demangle(mangled, nullptr, nullptr, &status);
+    snprintf(buf, buf_len, "%s", (status == 0 && dem) ? dem : mangled);
+    free(dem);
+    return QMX_OK;
+}
+
 int32_t qmx_query_synchronize(qmx_query *q) {
     QMX_REQUIRE(q, QMX_ERR_BAD_ARG, "NULL query");
     QMX_HIP(hipSetDevice(q->seg->device));
@@ -1018,6 +1059,8 @@ static void fill_args(const qmx_query *q, uint32_t tile0, uint32_t nq_tile, Scan
     a.row_offsets = s->d_row_offsets;
     a.pq_m = s->pq_m;
     a.pq_ncent = s->pq.n_centroids;
+    a.pq_pair = s->d_pq_pair;
+    a.pq_invert = s->pq.invert;
     a.bq_dim = s->dim;
     // calculate_metric's match: (Dot | Cosine, invert = false) and (L1 | L2, invert = true) -> zeros - xor; the toggled pairs -> xor - zeros
     a.bq_flip = (s->flags & QMX_SEG_BQ_TOGGLE_INVERT) ? 1 : 0;
@@ -1183,6 +1226,7 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
             size_t slot = 0;
             if (timed) QMX_TRY(timing_begin(q, &slot));
             QMX_TRY(launch_scan(q, qt, SCAN_TOPK, a, &grid));
+            q->last_kernel = g_last_kernel;
             if (timed) QMX_TRY(timing_end(q, slot));
             QMX_TRY(launch_merge_keys(q->stream, (const uint64_t *)q->partial.p, grid, (uint32_t)qt, nq_tile, ptop,
                                       d_out + (size_t)tile0 * top, d_counts + tile0, top, off,
@@ -1521,6 +1565,12 @@ static void fill_args_segment(const qmx_segment *s, ScanArgs &a) {
                           ? (float)s->sq.actual_dim * s->sq.offset * s->sq.offset : 0.0f;
         a.sq_shift = s->sq.invert ? -shift : shift;
     }
+    if (s->dtype == QMX_DTYPE_PQ) {
+        a.pq_m = s->pq_m;
+        a.pq_ncent = s->pq.n_centroids;
+        a.pq_pair = s->d_pq_pair;
+        a.pq_invert = s->pq.invert;
+    }
     if (s->dtype == QMX_DTYPE_BQ) {   // as fill_args; stored <-> stored scores are one-bit
         a.bq_dim = s->dim;
         a.bq_flip = (s->flags & QMX_SEG_BQ_TOGGLE_INVERT) ? 1 : 0;
@@ -1531,6 +1581,7 @@ static void fill_args_segment(const qmx_segment *s, ScanArgs &a) {
 static int32_t launch_hnsw_build_any(const qmx_segment *seg, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu) {
     if (seg->dtype == QMX_DTYPE_SQ_U8) return launch_hnsw_build_sq(nullptr, (int)seg->distance, a, h, phase, grid, per_cu);
     if (seg->dtype == QMX_DTYPE_BQ) return launch_hnsw_build_bq(nullptr, a, h, phase, grid, per_cu);
+    if (seg->dtype == QMX_DTYPE_PQ) return launch_hnsw_build_pq(nullptr, a, h, phase, grid, per_cu);
     return launch_hnsw_build_dense(nullptr, (int)seg->dtype, (int)seg->distance, a, h, phase, grid, per_cu);
 }
 
@@ -1559,13 +1610,22 @@ int32_t qmx_hnsw_export_plain(const qmx_hnsw *g, uint32_t *reindex, uint64_t *le
 }
 
 int32_t qmx_hnsw_build(const qmx_segment *seg, const qmx_hnsw_build_params *bp, qmx_hnsw **out) {
+    return qmx_hnsw_build_quantized(seg, nullptr, bp, out);
+}
+
+int32_t qmx_hnsw_build_quantized(const qmx_segment *seg, const qmx_segment *original, const qmx_hnsw_build_params *bp, qmx_hnsw **out) {
     QMX_REQUIRE(seg && bp && out, QMX_ERR_BAD_ARG, "NULL argument");
     *out = nullptr;
-    QMX_REQUIRE(seg->dtype == QMX_DTYPE_F32 || seg->dtype == QMX_DTYPE_F16 || seg->dtype == QMX_DTYPE_SQ_U8 || seg->dtype == QMX_DTYPE_BQ ||
-                    (seg->dtype == QMX_DTYPE_U8 && seg->distance != QMX_DISTANCE_COSINE),
-                QMX_ERR_NOT_SUPPORTED, "device HNSW build needs a dense f32 / f16 / u8 (dot, euclid, manhattan), an SQ-int8 or a BQ segment (dtype %u, distance %u)",
-                seg->dtype, seg->distance);
-    QMX_REQUIRE(seg->dtype == QMX_DTYPE_SQ_U8 || seg->fast_layout(), QMX_ERR_NOT_SUPPORTED, "adopted device block is not 16-byte aligned");
+    QMX_REQUIRE(seg->dtype <= QMX_DTYPE_BQ, QMX_ERR_NOT_SUPPORTED, "device HNSW build: dtype %u not supported", seg->dtype);
+    if (seg->dtype == QMX_DTYPE_PQ) {   // point_scorer.rs:197-212: the insertion searches score through the LUT of the ORIGINAL vector
+        QMX_REQUIRE(original, QMX_ERR_NOT_SUPPORTED,
+                    "a PQ segment cannot score a stored row as a query (encode_internal_vector -> None): pass the original f32 segment to qmx_hnsw_build_quantized");
+        QMX_REQUIRE(original->dtype == QMX_DTYPE_F32 && original->dim == seg->dim && original->n >= seg->n && original->device == seg->device,
+                    QMX_ERR_BAD_ARG, "the original segment must be f32, of the same dim, on the same device and hold every row of the PQ segment");
+        QMX_REQUIRE(seg->d_pq_pair, QMX_ERR_NOT_SUPPORTED, "PQ build: the centroid pair table (m x n_centroids^2 floats) exceeds 256 MB");
+    }
+    QMX_REQUIRE(seg->dtype == QMX_DTYPE_SQ_U8 || seg->dtype == QMX_DTYPE_PQ || seg->fast_layout(), QMX_ERR_NOT_SUPPORTED,
+                "adopted device block is not 16-byte aligned");
     QMX_REQUIRE(bp->m >= 1 && bp->m0 >= bp->m && bp->m0 <= 64, QMX_ERR_BAD_ARG, "need 1 <= m <= m0 <= 64");
     QMX_REQUIRE(bp->ef_construct >= 1 && bp->ef_construct <= HNSW_MAX_EF, QMX_ERR_NOT_SUPPORTED, "ef_construct %u not in 1..%u",
                 bp->ef_construct, HNSW_MAX_EF);
@@ -1600,9 +1660,10 @@ int32_t qmx_hnsw_build(const qmx_segment *seg, const qmx_hnsw_build_params *bp, 
     };
 
     // ---- device state ----
-    DevBuf b_level, b_upoff, b_links0, b_cnt0, b_linksU, b_cntU, b_lock, b_vis, b_log, b_sel, b_sels, b_selc;
+    DevBuf b_level, b_upoff, b_links0, b_cnt0, b_linksU, b_cntU, b_lock, b_vis, b_log, b_sel, b_sels, b_selc, b_normf, b_normi, b_bq, b_bqsrc;
     auto release_all = [&]() {
-        for (DevBuf *b : {&b_level, &b_upoff, &b_links0, &b_cnt0, &b_linksU, &b_cntU, &b_lock, &b_vis, &b_log, &b_sel, &b_sels, &b_selc}) b->release();
+        for (DevBuf *b : {&b_level, &b_upoff, &b_links0, &b_cnt0, &b_linksU, &b_cntU, &b_lock, &b_vis, &b_log, &b_sel, &b_sels, &b_selc, &b_normf, &b_normi,
+                          &b_bq, &b_bqsrc}) b->release();
     };
     int32_t rc = QMX_OK;
     qmx_hnsw *g = nullptr;
@@ -1638,6 +1699,21 @@ int32_t qmx_hnsw_build(const qmx_segment *seg, const qmx_hnsw_build_params *bp, 
         const uint64_t dev_row_bytes = seg->dtype == QMX_DTYPE_SQ_U8 ? (uint64_t)seg->sq.actual_dim : seg->row_bytes;
         h.row_bytes = (uint32_t)dev_row_bytes;
         h.lds_query_bytes = (uint32_t)((dev_row_bytes + 127) / 128 * 128 + 128);
+        uint64_t lut_stride = 0;
+        if (seg->dtype == QMX_DTYPE_PQ) {   // query entries = LUTs of the batch's original vectors, read through L2 (as the PQ walk does)
+            lut_stride = ((uint64_t)seg->pq_m * seg->pq.n_centroids * sizeof(float) + 15) & ~15ull;
+            QB(b_bq.reserve((size_t)max_batch * lut_stride));
+            QB(b_bqsrc.reserve((size_t)max_batch * seg->dim * sizeof(float)));
+            h.batch_queries = (const unsigned char *)b_bq.p;
+            h.batch_q_stride = lut_stride;
+            h.lds_query_bytes = 0;
+        }
+        if (seg->dtype == QMX_DTYPE_U8 && seg->distance == QMX_DISTANCE_COSINE && seg->dim >= 32) {   // the per-pair cosine's query norm of a stored row
+            QB(b_normf.reserve(nn * 4)); QB(b_normi.reserve(nn * 4));
+            QB(launch_u8_row_norms(nullptr, seg->d_rows, seg->row_stride, n, seg->dim, seg->flags, (float *)b_normf.p, (int32_t *)b_normi.p));
+            a.row_norms_f = (const float *)b_normf.p;
+            a.row_norms_i = (const int32_t *)b_normi.p;
+        }
         if (h.lds_query_bytes > HNSW_LDS_QUERY_MAX) {
             set_error("rows of %llu bytes do not fit the LDS query slot", (unsigned long long)dev_row_bytes);
             rc = QMX_ERR_NOT_SUPPORTED;
@@ -1687,6 +1763,15 @@ int32_t qmx_hnsw_build(const qmx_segment *seg, const qmx_hnsw_build_params *bp, 
             for (uint32_t i = 0; i < count; ++i)
                 if (level[next + i] > ep_level && live(next + i)) { count = i + 1; break; }
             h.first = next; h.count = count; h.ep_id = ep_id; h.ep_level = ep_level;
+            if (seg->dtype == QMX_DTYPE_PQ) {
+                // quantized_vectors.raw_scorer(original vector): Metric::preprocess (quantized_query_scorer.rs:39-41; identity for a row
+                // normalised at insert, up to the reference's 1e-6 rule), then EncodedVectorsPQ::encode_query for every point of the batch
+                float *src = (float *)b_bqsrc.p;
+                QH(hipMemcpy2DAsync(src, (size_t)seg->dim * 4, (const char *)original->d_rows + (uint64_t)next * original->row_stride, original->row_stride,
+                                    (size_t)seg->dim * 4, count, hipMemcpyDeviceToDevice, nullptr));
+                if (seg->distance == QMX_DISTANCE_COSINE) QB(launch_cosine_preprocess_f32(nullptr, src, src, count, seg->dim));
+                QB(launch_pq_lut(nullptr, seg->distance, seg->dim, seg->pq, seg->d_centroids, src, count, (float *)b_bq.p));
+            }
             QB(launch_hnsw_build_any(seg, a, h, 1, (uint32_t)std::min<uint64_t>(slots1, count), &per_cu1));
             QB(launch_hnsw_build_any(seg, a, h, 2, (uint32_t)std::min<uint64_t>(slots2, count), &per_cu2));
             for (uint32_t i = 0; i < count; ++i)
@@ -1842,6 +1927,7 @@ static int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint3
     size_t slot = 0;
     if (timed) QMX_TRY(timing_begin(q, &slot));
     QMX_TRY(launch_hnsw(q, a, h, (uint32_t)slots, &per_cu));
+    q->last_kernel = g_last_kernel;
     if (timed) QMX_TRY(timing_end(q, slot));
     return QMX_OK;
 }
@@ -2259,7 +2345,7 @@ int32_t qmx_score_internal(const qmx_segment *seg, const uint32_t *a_ids, const 
             if (e == hipSuccess) e = hipMemcpy(bb.p, b_ids, (size_t)n * 4, hipMemcpyDefault);
             if (e == hipSuccess) e = hipMemset(be.p, 0, 4);
             if (e != hipSuccess) { rc = hip_status(e, "stage ids", __FILE__, __LINE__); break; }
-            if ((rc = launch_pq_internal(nullptr, seg->distance, seg->dim, seg->pq, seg->d_centroids, seg->d_rows, seg->row_stride, seg->n,
+            if ((rc = launch_pq_internal(nullptr, seg->distance, seg->dim, seg->pq, seg->d_centroids, seg->d_pq_pair, seg->d_rows, seg->row_stride, seg->n,
                                          (const uint32_t *)ba.p, (const uint32_t *)bb.p, n, (float *)bo.p, (int *)be.p)) != QMX_OK) break;
             int flag = 0;
             e = hipMemcpy(&flag, be.p, 4, hipMemcpyDeviceToHost);

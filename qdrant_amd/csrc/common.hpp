@@ -34,10 +34,14 @@ enum Option {
     OPT_MFMA_NO_NT,           // 4x4x1 scan without nontemporal row loads
     OPT_MFMA_NO_FAST,         // 4x4x1 scan without the guard-free ping-pong loop
     OPT_NO_PQ_TILED,          // PQ scan on the one-row-per-lane kernel
+    OPT_NO_PQ_PAIR,           // PQ score_internal recomputes the centroid distances instead of reading the pair table
     OPT_DEBUG,                // log dropped stale HIP errors
     OPT_COUNT
 };
 int64_t option(Option o);
+// the host-side handle of the scoring kernel this thread launched last (qmx_query_last_kernel reports its symbol)
+void note_kernel(const void *host_function);
+#define QMX_NOTE_KERNEL(fn) ::qmx::note_kernel(reinterpret_cast<const void *>(fn))
 
 #define QMX_HIP(expr)                                                        \
     do {                                                                     \

@@ -174,6 +174,13 @@ struct RowU8 {
     static __device__ __forceinline__ float finish(acc_t (&a)[NACC], acc_t (&ra)[NRAUX > 0 ? NRAUX : 1],
                                                    const unsigned char *q_lds, const unsigned char *row, uint32_t,
                                                    const ScanArgs &args) {
+        const QueryAux *aux = reinterpret_cast<const QueryAux *>(q_lds + args.aux_off);
+        return finish_with(a, ra, q_lds, row, args, METRIC == M_COSINE ? aux->f0 : 0.0f, METRIC == M_COSINE ? aux->i0 : 0);
+    }
+    // norm1_f / norm1_i: the query's sum of squares (AVX2 order as f32 / scalar order as i32), only read by the cosine
+    static __device__ __forceinline__ float finish_with(acc_t (&a)[NACC], acc_t (&ra)[NRAUX > 0 ? NRAUX : 1],
+                                                        const unsigned char *q_lds, const unsigned char *row,
+                                                        const ScanArgs &args, float norm1_f, int32_t norm1_i) {
         uint32_t lt[4], nt[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -192,7 +199,6 @@ struct RowU8 {
             else rem += x > y ? x - y : y - x;
             if (METRIC == M_COSINE) rem_n2 += y * y;
         }
-        const QueryAux *aux = reinterpret_cast<const QueryAux *>(q_lds + args.aux_off);
         if (args.flags & QMX_SEG_U8_SCALAR_ORDER) {
             // metric_uint/simple_*.rs: one i32 total, cast once
             const int32_t tot = (int32_t)((lt[0] + lt[1]) + (lt[2] + lt[3]));
@@ -200,7 +206,7 @@ struct RowU8 {
             if (METRIC == M_COSINE) {
                 const int32_t n2h = (int32_t)((nt[0] + nt[1]) + (nt[2] + nt[3]));
                 const int32_t n2 = n2h + dpp_i32<DPP_ROW_HALF_MIRROR>(n2h) + rem_n2;
-                const int32_t n1 = aux->i0;
+                const int32_t n1 = norm1_i;
                 if (n1 == 0 || n2 == 0) return 0.0f;                       // simple_cosine.rs:71-73
                 return (float)all / __builtin_sqrtf((float)n1 * (float)n2);
             }
@@ -211,11 +217,24 @@ struct RowU8 {
         if (METRIC == M_COSINE) {
             float norm2 = avx_hsum_i32(nt);
             if (has_rem) norm2 += (float)rem_n2;
-            const float denominator = aux->f0 * norm2;                     // norm1 * norm2, cosine.rs:103-108
+            const float denominator = norm1_f * norm2;                     // norm1 * norm2, cosine.rs:103-108
             if (denominator == 0.0f) return 0.0f;
             return score / __builtin_sqrtf(denominator);
         }
         return (METRIC == M_DOT) ? score : -score;
+    }
+};
+
+// The same row policy with a STORED ROW as the query (HNSW build over a u8 segment, FilteredScorer::new_internal): the per-pair
+// cosine (metric_uint/avx2/cosine.rs:47-108, simple_cosine.rs) needs the query's norm, which the aux block of a query entry carries
+// and a bare stored row does not: it arrives in ScanArgs::u8_qnorm_* from the per-row norm column (hnsw_build.hpp query_args).
+template <int METRIC>
+struct RowU8Internal : RowU8<METRIC> {
+    typedef RowU8<METRIC> B;
+    static constexpr bool INTERNAL_NORM = METRIC == M_COSINE;
+    static __device__ __forceinline__ float finish(typename B::acc_t (&a)[B::NACC], typename B::acc_t (&ra)[B::NRAUX > 0 ? B::NRAUX : 1],
+                                                   const unsigned char *q_lds, const unsigned char *row, uint32_t, const ScanArgs &args) {
+        return B::finish_with(a, ra, q_lds, row, args, args.u8_qnorm_f, args.u8_qnorm_i);
     }
 };
 

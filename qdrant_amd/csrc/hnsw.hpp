@@ -41,10 +41,22 @@ struct has_internal_qoff { static constexpr bool value = false; };
 template <class P>
 struct has_internal_qoff<P, decltype((void)P::INTERNAL_QOFF)> { static constexpr bool value = P::INTERNAL_QOFF; };
 
+// ... or whose query norm comes from ScanArgs::u8_qnorm_* (a stored u8 row as the query of the per-pair cosine)
+template <class P, class = void>
+struct has_internal_norm { static constexpr bool value = false; };
+template <class P>
+struct has_internal_norm<P, decltype((void)P::INTERNAL_NORM)> { static constexpr bool value = P::INTERNAL_NORM; };
+// a hop scorer whose stored <-> stored score is NOT the score of the search (PQ: LUT of the original vector vs centroid <-> centroid)
+template <class H, class = void>
+struct is_asymmetric { static constexpr bool value = false; };
+template <class H>
+struct is_asymmetric<H, decltype((void)H::ASYMMETRIC)> { static constexpr bool value = H::ASYMMETRIC; };
+
 template <class P>
 struct HopRow {
     static constexpr int LPI = 8;
     static constexpr bool INTERNAL_QOFF = has_internal_qoff<P>::value;
+    static constexpr bool INTERNAL_NORM = has_internal_norm<P>::value;
     static constexpr bool MULTI = true;     // score_multi<R>: R rows per 8-lane group in one pass
     static __device__ __forceinline__ float score(const ScanArgs &a, const unsigned char *qp, uint32_t id, int sub) {
         return group_score<P>(a, qp, id, sub);
@@ -58,6 +70,7 @@ template <class S>
 struct HopSmall {
     static constexpr int LPI = 1;
     static constexpr bool INTERNAL_QOFF = false;
+    static constexpr bool INTERNAL_NORM = false;
     static constexpr bool MULTI = false;
     static __device__ __forceinline__ float score(const ScanArgs &a, const unsigned char *qp, uint32_t id, int) {
         return S::score(qp, reinterpret_cast<const unsigned char *>(a.rows) + (uint64_t)id * a.row_stride, id, a);
@@ -530,6 +543,7 @@ template <class H, int E, bool QLDS>
 int32_t launch_hnsw_inst(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid) {
     const size_t lds = 8 * (size_t)h.hop_cap + (h.acorn ? 256 : 0) + (QLDS ? h.lds_query_bytes : 0);
     ::qmx::clear_stale_error();
+    QMX_NOTE_KERNEL((hnsw_search_kernel<H, E, QLDS>));
     hipLaunchKernelGGL((hnsw_search_kernel<H, E, QLDS>), dim3(grid), dim3(64), lds, st, a, h);
     QMX_HIP(hipGetLastError());
     return QMX_OK;

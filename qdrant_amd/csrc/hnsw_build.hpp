@@ -38,6 +38,10 @@ template <class H>
 __device__ __forceinline__ ScanArgs query_args(const ScanArgs &a, uint32_t qid) {
     ScanArgs b = a;
     if constexpr (H::INTERNAL_QOFF) b.sq_qoff = a.row_offsets[qid] - a.sq_shift;
+    if constexpr (H::INTERNAL_NORM) {   // per-pair u8 cosine: the stored row's own norm is the query norm (cosine.rs computes both the same way)
+        b.u8_qnorm_f = a.row_norms_f[qid];
+        b.u8_qnorm_i = a.row_norms_i[qid];
+    }
     return b;
 }
 
@@ -75,7 +79,9 @@ __device__ __forceinline__ uint32_t heuristic_fill(const ScanArgs &a, const uint
 }
 
 // ---- phase 1 ----------------------------------------------------------------------------------------------------
-template <class H, int E>
+// H scores the searches of an insertion (the new point as the query), HI scores stored <-> stored pairs (score_internal: the heuristic).
+// They are the same policy except for storages without an internal query (PQ): H = the LUT of the original vector, HI = centroid tables.
+template <class H, class HI, int E>
 __global__ __launch_bounds__(64) void hnsw_build_search_kernel(const ScanArgs a0, const HnswBuildArgs h) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -100,9 +106,13 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(const ScanArgs a0
         if (lane < (int)HNSW_BUILD_MAX_LEVELS) my_cnt[lane] = 0;
         if (!a.del.live(p)) continue;            // deleted points are never indexed (hnsw/build.rs:293-300)
 
-        // stage the new point's row as the query entry (zero padded to whole 128-byte steps)
+        // the query entry of the new point: made from its original vector before this launch (batch_queries), or its own stored row
+        // staged in LDS (zero padded to whole 128-byte steps)
+        const unsigned char *qp = q_lds;
         __syncthreads();
-        {
+        if (h.batch_queries) {
+            qp = h.batch_queries + (uint64_t)bi * h.batch_q_stride;
+        } else {
             const unsigned char *src = rows + (uint64_t)p * a.row_stride;
             for (uint32_t i = (uint32_t)lane * 16; i < h.lds_query_bytes; i += 64 * 16) {
                 uint4 v = make_uint4(0, 0, 0, 0);
@@ -122,7 +132,11 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(const ScanArgs a0
         float cur_score;
         {
             if (lane == 0) hop_ids[0] = cur_id;
-            hop_score<H>(a, q_lds, hop_ids, hop_scores, 1, lane);
+            // graph_layers_builder.rs:441-447: an entry point at or below the new point's level is taken with score_internal(p, entry)
+            if (is_asymmetric<HI>::value && h.ep_level <= lp)
+                hop_score<HI>(query_args<HI>(a0, p), rows + (uint64_t)p * a0.row_stride, hop_ids, hop_scores, 1, lane);
+            else
+                hop_score<H>(a, qp, hop_ids, hop_scores, 1, lane);
             cur_score = hop_scores[0];
         }
         for (uint32_t level = h.ep_level; level > lp; --level) {
@@ -139,7 +153,7 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(const ScanArgs a0
                     const uint32_t k = (uint32_t)__popcll(mask);
                     __syncthreads();
                     if (on) hop_ids[lane] = id;
-                    hop_score<H>(a, q_lds, hop_ids, hop_scores, k, lane);
+                    hop_score<H>(a, qp, hop_ids, hop_scores, k, lane);
                     uint64_t mk = 0;
                     if ((uint32_t)lane < k && hop_scores[lane] > cur_score)
                         mk = ((uint64_t)score_to_ord(hop_scores[lane]) << 32) | (uint32_t)(~(uint32_t)lane);
@@ -189,7 +203,7 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(const ScanArgs a0
                         if (log_cnt + rank < h.log_cap) vlog[log_cnt + rank] = id >> 5;
                     }
                     log_cnt += k;
-                    hop_score<H>(a, q_lds, hop_ids, hop_scores, k, lane);
+                    hop_score<H>(a, qp, hop_ids, hop_scores, k, lane);
                     const uint64_t mykey = (uint32_t)lane < k ? make_key(hop_scores[lane], hop_ids[lane]) : 0;
                     uint64_t mm = __ballot(mykey > beam.at(ef - 1));
                     while (mm) {
@@ -226,7 +240,7 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(const ScanArgs a0
                 cur_score = cand_scores[0];
             }
             const uint32_t lm = h.g.level_m(level);
-            const uint32_t n_sel = heuristic_fill<H>(a, cand_ids, cand_scores, n_cand, lm, sel_ids, sel_scores, hop_ids, hop_scores, lane);
+            const uint32_t n_sel = heuristic_fill<HI>(a0, cand_ids, cand_scores, n_cand, lm, sel_ids, sel_scores, hop_ids, hop_scores, lane);
             const uint64_t so = ((uint64_t)bi * HNSW_BUILD_MAX_LEVELS + level) * h.g.m0;
             for (uint32_t i = (uint32_t)lane; i < n_sel; i += 64) {
                 h.sel_ids[so + i] = sel_ids[i];
@@ -267,7 +281,13 @@ __global__ __launch_bounds__(64) void hnsw_build_link_kernel(const ScanArgs a, c
             // back links: LinksContainer::connect_with_heuristic(p, q) under q's lock
             for (uint32_t k = 0; k < n_sel; ++k) {
                 const uint32_t q = h.sel_ids[so + k];
-                const float s_qp = h.sel_scores[so + k];       // score(p, q) == score(q, p), bit for bit
+                float s_qp = h.sel_scores[so + k];             // score(p, q) == score(q, p), bit for bit ...
+                if constexpr (is_asymmetric<H>::value) {       // ... unless the search score is not the storage's score_internal (PQ)
+                    __syncthreads();
+                    if (lane == 0) hop_ids[0] = p;
+                    hop_score<H>(query_args<H>(a, q), rows + (uint64_t)q * a.row_stride, hop_ids, hop_scores, 1, lane);
+                    s_qp = hop_scores[0];
+                }
                 if (lane == 0) {
                     while (atomicCAS(&h.lock[q], 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(8);
                 }
@@ -324,15 +344,16 @@ __global__ __launch_bounds__(64) void hnsw_build_link_kernel(const ScanArgs a, c
     }
 }
 
-template <class H>
+// H: the scorer of the insertion searches; HI: the stored <-> stored scorer (phase 2 and the heuristic), H itself unless given
+template <class H, class HI = H>
 int32_t launch_hnsw_build_hop(hipStream_t st, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu) {
     QMX_REQUIRE(h.ef_construct >= 1 && h.ef_construct <= HNSW_MAX_EF, QMX_ERR_NOT_SUPPORTED, "ef_construct %u not in 1..%u", h.ef_construct,
                 HNSW_MAX_EF);
     const bool big = h.ef_construct > 128;
     const size_t lds1 = 512 + 512 * (big ? 8 : 2) + 512 + h.lds_query_bytes;
     if (phase == 1) {
-        auto k2 = hnsw_build_search_kernel<H, 2>;
-        auto k8 = hnsw_build_search_kernel<H, 8>;
+        auto k2 = hnsw_build_search_kernel<H, HI, 2>;
+        auto k8 = hnsw_build_search_kernel<H, HI, 8>;
         if (grid == 0) {
             int n = 0;
             if (big) QMX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k8, 64, lds1));
@@ -348,12 +369,12 @@ int32_t launch_hnsw_build_hop(hipStream_t st, const ScanArgs &a, const HnswBuild
     }
     if (grid == 0) {
         int n = 0;
-        QMX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, hnsw_build_link_kernel<H>, 64, 0));
+        QMX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, hnsw_build_link_kernel<HI>, 64, 0));
         *per_cu = n < 1 ? 1 : n;
         return QMX_OK;
     }
     ::qmx::clear_stale_error();
-    hipLaunchKernelGGL((hnsw_build_link_kernel<H>), dim3(grid), dim3(64), 0, st, a, h);
+    hipLaunchKernelGGL((hnsw_build_link_kernel<HI>), dim3(grid), dim3(64), 0, st, a, h);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }

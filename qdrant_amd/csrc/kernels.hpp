@@ -39,8 +39,15 @@ struct ScanArgs {
     float sq_shift;            // SQ: MetadataInt8::get_shift (encoded_vectors_u8.rs:116-134), used when a stored row is the query
     float sq_qoff;             // SQ, stored row as the query (HNSW build): its query offset = vector_offset - shift (:105-114, 715-728)
     uint32_t flags;            // QMX_SEG_U8_SCALAR_ORDER ...
+    // u8 cosine with a STORED ROW as the query (HNSW build): the row's own norm stands in for the aux block of a query entry
+    const float *row_norms_f;  // [n] sum of squares of every stored u8 row, in the AVX2 leaf's order (or nullptr)
+    const int32_t *row_norms_i; // [n] the same as one exact i32 (scalar-order leaf)
+    float u8_qnorm_f;          // set per query row by hnsw_build.hpp query_args
+    int32_t u8_qnorm_i;
     // PQ
     uint32_t pq_m, pq_ncent;
+    const float *pq_pair;      // [m][ncent][ncent] chunk distances between centroids = the terms of EncodedVectorsPQ::score_internal, or nullptr
+    uint32_t pq_invert;
     // BQ: calculate_metric (encoded_vectors_binary.rs:766-810)
     uint32_t bq_dim;           // original dimension
     uint32_t bq_flip;          // 0: zeros - xor (every distance with its own invert), 1: xor - zeros
@@ -125,12 +132,21 @@ struct HnswBuildArgs {
     uint32_t *lock;              // [n]
     uint32_t lds_query_bytes;    // row bytes rounded up to whole 128-byte steps, staged per new point
     uint32_t row_bytes;
+    // quantized storages that cannot turn a stored row into a query (PQ): the query entries of the batch, made from the ORIGINAL vectors
+    // (point_scorer.rs:197-212) before phase 1; entry bi = batch_queries + bi * batch_q_stride (global memory; nullptr = stage the row)
+    const unsigned char *batch_queries;
+    uint64_t batch_q_stride;
 };
 // phase 1 = insertion searches + heuristic selection, phase 2 = linking; grid == 0: report occupancy only
 int32_t launch_hnsw_build_bq(hipStream_t st, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_build_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_build_dense(hipStream_t st, int dtype, int distance, const ScanArgs &a, const HnswBuildArgs &h, int phase,
                                 uint32_t grid, int *per_cu);
+int32_t launch_hnsw_build_pq(hipStream_t st, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu);
+// pair[c][i][j] = DistanceType::distance(centroid i chunk c, centroid j chunk c): the per-chunk terms of score_internal (encoded_vectors_pq.rs:574-618)
+int32_t launch_pq_pair_table(hipStream_t st, uint32_t distance, uint32_t dim, const qmx_pq_params &pq, const float *d_centroids, float *d_pair);
+// norms[r] = sum of squares of u8 row r as the cosine leaf computes it for a stored row (metric_uint/avx2/cosine.rs, simple_cosine.rs)
+int32_t launch_u8_row_norms(hipStream_t st, const void *rows, uint64_t row_stride, uint64_t n, uint32_t dim, uint32_t flags, float *norms_f, int32_t *norms_i);
 constexpr uint32_t HNSW_LDS_QUERY_MAX = 150 * 1024;
 
 // dense f32 / f16 / u8 (scan_dense.hip)
@@ -195,7 +211,7 @@ int32_t launch_pairs_pq(hipStream_t st, const ScanArgs &a, const PairSel &sel, u
 int32_t launch_pq_lut(hipStream_t st, uint32_t distance, uint32_t dim, const qmx_pq_params &pq, const float *d_centroids,
                       const float *d_queries, uint32_t nq, float *d_lut);
 int32_t launch_pq_internal(hipStream_t st, uint32_t distance, uint32_t dim, const qmx_pq_params &pq, const float *d_centroids,
-                           const void *rows, uint64_t row_stride, uint64_t n_rows, const uint32_t *a_ids, const uint32_t *b_ids,
+                           const float *d_pair, const void *rows, uint64_t row_stride, uint64_t n_rows, const uint32_t *a_ids, const uint32_t *b_ids,
                            uint32_t n, float *out, int *err_flag);
 int32_t launch_pq_train(hipStream_t st, uint32_t dim, uint32_t chunk_size, uint32_t n_centroids, const float *d_data, uint64_t n,
                         uint32_t max_iters, float accuracy, uint32_t threads, float *d_centroids, uint32_t *iters_host);
@@ -235,6 +251,7 @@ int32_t launch_cosine_preprocess_f32(hipStream_t st, const float *in, float *out
 int32_t launch_cast_f32(hipStream_t st, int dst_dtype, const float *in, void *out, uint64_t count);
 int32_t launch_minmax_f32(hipStream_t st, const float *in, uint64_t count, float *min_out, float *max_out);
 int32_t launch_synth_fill(hipStream_t st, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, float *out);
+int32_t launch_synth_latent(hipStream_t st, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, uint32_t K, float noise, float *W_scratch, float *out);
 int32_t launch_gather_rows(hipStream_t st, const void *rows, uint64_t row_stride, uint64_t row_bytes,
                            const uint32_t *ids, uint32_t n, uint64_t n_rows, void *out, int *err_flag);
 

@@ -13,7 +13,7 @@
 // contraction [nq x chunk] . [chunk x 256] per chunk with f32 inputs (v_mfma_f32_32x32x2_f32: an fmaf
 // chain, so <= 1e-5 relative to the reference's mul+add chain; the exact-order VALU kernel is the
 // bit-parity variant).
-#include "hnsw.hpp"
+#include "hnsw_build.hpp"
 
 namespace qmx {
 
@@ -219,6 +219,7 @@ static int32_t launch_pq_scan_inst(hipStream_t st, const ScanArgs &a, int num_cu
         *grid_out = slabs;
     }
     ::qmx::clear_stale_error();
+    QMX_NOTE_KERNEL(kfn);
     hipLaunchKernelGGL(kfn, dim3(slabs * a.nq), dim3(PQ_BLOCK), lds, st, a, slabs);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
@@ -318,10 +319,55 @@ int32_t launch_hnsw_pq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uin
 }
 
 // ------------------------------------------------------------------------------------------
+// HNSW build over a PQ segment (hnsw/build.rs:334-341 + point_scorer.rs:183-218).  EncodedVectorsPQ cannot turn a stored row
+// into a query (encode_internal_vector -> None), so the searches of an insertion score through the LUT of the point's ORIGINAL
+// vector (HopPQ over the batch's LUTs, made by api.hip before phase 1) while everything stored <-> stored — the heuristic, the
+// back links, an entry point at or below the new point's level — is EncodedVectorsPQ::score_internal (:574-618): the sum over
+// chunks of the distance between the two rows' centroids.  Those chunk distances are tabulated once per segment
+// (pair[c][i][j], m x 256 x 256 f32 = 25 MB at m = 96) with the reference's own inner loop, so a pair score is m table gathers
+// added in chunk order: the bits of the reference.  One lane per stored row, the "query" row's codes are wave-uniform.
+// ------------------------------------------------------------------------------------------
+struct HopPQInternal {
+    static constexpr int LPI = 1;
+    static constexpr bool MULTI = false;
+    static constexpr bool INTERNAL_QOFF = false;
+    static constexpr bool INTERNAL_NORM = false;
+    static constexpr bool ASYMMETRIC = true;
+    static __device__ __forceinline__ float score(const ScanArgs &a, const unsigned char *qp, uint32_t id, int) {
+        const uint8_t *cb = reinterpret_cast<const uint8_t *>(a.rows) + (uint64_t)id * a.row_stride;
+        const uint32_t m = a.pq_m, nc = a.pq_ncent;
+        float s = -0.0f;
+        for (uint32_t c = 0; c < m; ++c) s += a.pq_pair[((uint64_t)c * nc + qp[c]) * nc + cb[c]];
+        return a.pq_invert ? -s : s;
+    }
+};
+struct HopPQBuild : HopPQ {
+    static constexpr bool INTERNAL_QOFF = false;
+    static constexpr bool INTERNAL_NORM = false;
+};
+int32_t launch_hnsw_build_pq(hipStream_t st, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu) {
+    QMX_REQUIRE(a.pq_pair && h.batch_queries, QMX_ERR_BAD_ARG, "PQ build needs the centroid pair table and the batch LUTs");
+    return launch_hnsw_build_hop<HopPQBuild, HopPQInternal>(st, a, h, phase, grid, per_cu);
+}
+
+// pair[c][i][j]: grid (m, ncent), thread j
+__global__ __launch_bounds__(256) void pq_pair_table_kernel(PqGeom g, const float *centroids, float *pair) {
+    const uint32_t c = blockIdx.x, i = blockIdx.y;
+    const uint32_t lo = c * g.chunk, hi = min(lo + g.chunk, g.dim);
+    const float *da = centroids + (uint64_t)i * g.dim;
+    for (uint32_t j = threadIdx.x; j < g.ncent; j += 256) {
+        const float *db = centroids + (uint64_t)j * g.dim;
+        float d = -0.0f;
+        for (uint32_t k = lo; k < hi; ++k) d += pq_term(g.kind, da[k], db[k]);
+        pair[((uint64_t)c * g.ncent + i) * g.ncent + j] = d;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // score_internal (:574-618): out[i] = (+/-) sum_c distance(centroid[a_code[c]] chunk c, centroid[b_code[c]] chunk c)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pq_internal_kernel(PqGeom g, const uint8_t *rows, uint64_t row_stride, uint64_t n_rows,
-                                                          const float *centroids, const uint32_t *a_ids, const uint32_t *b_ids,
+                                                          const float *centroids, const float *pair, const uint32_t *a_ids, const uint32_t *b_ids,
                                                           uint32_t n, float *out, int *err_flag) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -332,6 +378,11 @@ __global__ __launch_bounds__(256) void pq_internal_kernel(PqGeom g, const uint8_
     }
     const uint8_t *ca = rows + (uint64_t)ia * row_stride, *cb = rows + (uint64_t)ib * row_stride;
     float s = -0.0f;
+    if (pair) {   // the tabulated chunk terms (pq_pair_table_kernel: the loop below, once per centroid pair)
+        for (uint32_t c = 0; c < g.m; ++c) s += pair[((uint64_t)c * g.ncent + ca[c]) * g.ncent + cb[c]];
+        out[i] = g.invert ? -s : s;
+        return;
+    }
     for (uint32_t c = 0; c < g.m; ++c) {
         const uint32_t lo = c * g.chunk, hi = min(lo + g.chunk, g.dim);
         const float *da = centroids + (uint64_t)ca[c] * g.dim, *db = centroids + (uint64_t)cb[c] * g.dim;
@@ -402,14 +453,22 @@ int32_t launch_pq_lut(hipStream_t st, uint32_t distance, uint32_t dim, const qmx
     return QMX_OK;
 }
 
+int32_t launch_pq_pair_table(hipStream_t st, uint32_t distance, uint32_t dim, const qmx_pq_params &pq, const float *d_centroids, float *d_pair) {
+    const PqGeom g = make_geom(distance, dim, pq);
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(pq_pair_table_kernel, dim3(g.m, g.ncent), dim3(256), 0, st, g, d_centroids, d_pair);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
 int32_t launch_pq_internal(hipStream_t st, uint32_t distance, uint32_t dim, const qmx_pq_params &pq, const float *d_centroids,
-                           const void *rows, uint64_t row_stride, uint64_t n_rows, const uint32_t *a_ids, const uint32_t *b_ids,
+                           const float *d_pair, const void *rows, uint64_t row_stride, uint64_t n_rows, const uint32_t *a_ids, const uint32_t *b_ids,
                            uint32_t n, float *out, int *err_flag) {
     if (n == 0) return QMX_OK;
     const PqGeom g = make_geom(distance, dim, pq);
     ::qmx::clear_stale_error();
     hipLaunchKernelGGL(pq_internal_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g, (const uint8_t *)rows, row_stride, n_rows,
-                       d_centroids, a_ids, b_ids, n, out, err_flag);
+                       d_centroids, option(OPT_NO_PQ_PAIR) ? nullptr : d_pair, a_ids, b_ids, n, out, err_flag);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }

@@ -214,6 +214,7 @@ static int32_t launch_bq_rows_inst(hipStream_t st, const ScanArgs &a, int num_cu
         *grid_out = grid;
     }
     ::qmx::clear_stale_error();
+    QMX_NOTE_KERNEL((bq_rows_kernel<QT, HAS_IDS, MODE, true, B>));
     hipLaunchKernelGGL((bq_rows_kernel<QT, HAS_IDS, MODE, true, B>), dim3(grid), dim3(BQR_BLOCK), lds, st, a);
     QMX_HIP(hipGetLastError());
     return QMX_OK;

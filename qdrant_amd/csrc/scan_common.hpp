@@ -257,6 +257,7 @@ int32_t launch_scan_inst(hipStream_t st, const ScanArgs &a, int num_cus, uint32_
         *grid_out = grid;
     }
     ::qmx::clear_stale_error();
+    QMX_NOTE_KERNEL(kfn);
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(SCAN_BLOCK), lds, st, a);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
@@ -377,6 +378,7 @@ int32_t launch_small_inst(hipStream_t st, const ScanArgs &a, int num_cus, uint32
         *grid_out = grid;
     }
     ::qmx::clear_stale_error();
+    QMX_NOTE_KERNEL((scan_small_kernel<S, HAS_IDS, MODE>));
     hipLaunchKernelGGL((scan_small_kernel<S, HAS_IDS, MODE>), dim3(grid, a.nq), dim3(SMALL_BLOCK), 0, st, a);
     QMX_HIP(hipGetLastError());
     return QMX_OK;

@@ -357,6 +357,7 @@ static int32_t launch_mfma_inst(hipStream_t st, const ScanArgs &a, int num_cus, 
         *grid_out = grid;
     }
     ::qmx::clear_stale_error();
+    QMX_NOTE_KERNEL(kfn);
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(MF_BLOCK), lds, st, a);
     QMX_HIP(hipGetLastError());
     return QMX_OK;

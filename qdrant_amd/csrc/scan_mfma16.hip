@@ -475,6 +475,7 @@ static int32_t launch_m16(hipStream_t st, const ScanArgs &a, int num_cus, uint32
     if (getenv("QMX_M16_LAG_ODD")) b.flags |= 0x100u;       // tuning experiment: odd waves lag instead of the upper half
 #endif
     ::qmx::clear_stale_error();
+    QMX_NOTE_KERNEL(kfn);
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), (size_t)S::LDS, st, b);
     QMX_HIP(hipGetLastError());
     return QMX_OK;

@@ -258,6 +258,7 @@ static int32_t launch_sqm_inst(hipStream_t st, const ScanArgs &a, int num_cus, u
         *grid_out = grid;
     }
     ::qmx::clear_stale_error();
+    QMX_NOTE_KERNEL(kfn);
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(SQM_BLOCK), lds, st, a);
     QMX_HIP(hipGetLastError());
     return QMX_OK;

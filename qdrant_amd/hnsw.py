@@ -95,7 +95,7 @@ class GraphLayers:
 
     @classmethod
     def build(cls, storage, m: int = 16, m0: Optional[int] = None, ef_construct: int = 100, seed: int = 42,
-              entry_points_num: int = 10, max_batch: int = 0):
+              entry_points_num: int = 10, max_batch: int = 0, original=None):
         """`GraphLayersBuilder` on the storage's GPU (qmx_hnsw_build): over a dense f32 / f16 / u8 (not cosine) VectorStorage, or over an
         EncodedVectorsU8 / EncodedVectorsBin — the reference builds through the quantized scorer when the segment has one
         (hnsw/build.rs:334-341)."""
@@ -105,7 +105,9 @@ class GraphLayers:
         p.m, p.m0, p.ef_construct, p.entry_points_num, p.seed, p.max_batch = self.m, self.m0, ef_construct, entry_points_num, seed, max_batch
         self._keep = []
         self._h = C.c_void_p()
-        F.check(F.lib().qmx_hnsw_build(storage._h, C.byref(p), C.byref(self._h)))
+        # `original`: the f32 VectorStorage a PQ storage was encoded from (its insertion searches score through the LUT of the original
+        # vector, point_scorer.rs:197-212); ignored by storages that can use a stored row as the query
+        F.check(F.lib().qmx_hnsw_build_quantized(storage._h, original._h if original is not None else None, C.byref(p), C.byref(self._h)))
         self.n_points = storage.count
         self.counters = F.Counters()
         return self

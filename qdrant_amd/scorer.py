@@ -213,7 +213,9 @@ class EncodedVectorsU8(VectorStorage):
         self.quantizer = quantizer
         self.distance = quantizer.distance
         self.datatype = None
-        rows = np.ascontiguousarray(rows, dtype=np.uint8)
+        on_device = hasattr(rows, "data_ptr") and getattr(rows, "is_cuda", False)   # a torch CUDA tensor: split on the device, no host copy
+        if not on_device:
+            rows = np.ascontiguousarray(rows, dtype=np.uint8)
         assert rows.shape[1] == quantizer.quantized_vector_size()
         self.dim = quantizer.dim
         self.count = int(rows.shape[0])
@@ -295,17 +297,19 @@ class EncodedVectorsPQ(VectorStorage):
         self.quantizer = quantizer
         self.distance = quantizer.distance
         self.datatype = None
-        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        on_device = hasattr(codes, "data_ptr") and getattr(codes, "is_cuda", False)   # a torch CUDA tensor is adopted in place
+        if not on_device:
+            codes = np.ascontiguousarray(codes, dtype=np.uint8)
         assert codes.shape[1] == quantizer.m
         self.dim = quantizer.dim
         self.count = int(codes.shape[0])
-        self._keep = None
+        self._keep = codes if on_device else None
         self._pq = quantizer.params()
         desc = F.SegmentDesc()
         desc.dtype = F.DTYPE_PQ
         desc.distance = int(quantizer.distance)
         desc.dim = quantizer.dim
-        desc.flags = 0
+        desc.flags = F.SEG_DATA_ON_DEVICE if on_device else 0
         desc.n = self.count
         desc.row_stride_bytes = 0
         desc.data = F.ptr(codes)
@@ -572,7 +576,11 @@ class RawScorer:
 def new_raw_scorer(query, storage: VectorStorage) -> RawScorer:
     """`new_raw_scorer(QueryVector::Nearest(query), storage, hc)` (raw_scorer.rs:60-114).
     `query`: [dim] or [nq, dim] f32 ORIGINAL vectors; preprocessing + cast happen on device."""
-    q = np.ascontiguousarray(np.atleast_2d(query), dtype=np.float32)
+    if hasattr(query, "data_ptr") and getattr(query, "is_cuda", False):    # a contiguous [nq, dim] f32 torch CUDA tensor: no host copy
+        q = query
+        assert q.dim() == 2 and q.is_contiguous() and str(q.dtype) == "torch.float32"
+    else:
+        q = np.ascontiguousarray(np.atleast_2d(query), dtype=np.float32)
     if q.shape[1] != storage.dim:
         raise ValueError(f"query dim {q.shape[1]} != storage dim {storage.dim}")
     h = C.c_void_p()
@@ -667,7 +675,7 @@ class CustomRawScorer:
 
 
 def search_quantized(searched: RawScorer, original: Optional[RawScorer], top: int, oversampling: float = 0.0, rescore: bool = True,
-                     graph=None, hnsw_ef: int = 0, ids=None, is_stopped=None, acorn: bool = False) -> List[np.ndarray]:
+                     graph=None, hnsw_ef: int = 0, ids=None, is_stopped=None, acorn: bool = False, counters=None) -> List[np.ndarray]:
     """`PlainVectorIndexReadView::search` (graph is None) or the graph arm of `HNSWIndexReadView::search`, with
     `get_oversampled_top` and `postprocess_search_result` (vector_index_search_common.rs:27-91) in one device-side call."""
     p = F.SearchParams()
@@ -681,7 +689,7 @@ def search_quantized(searched: RawScorer, original: Optional[RawScorer], top: in
     idarr = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint32)
     F.check(F.lib().qmx_search_quantized(None if graph is None else graph._h, searched._h, None if original is None else original._h,
                                          C.byref(p), F.ptr(idarr), 0 if idarr is None else len(idarr), F.ptr(out), F.ptr(counts),
-                                         F.ptr(stop), None))
+                                         F.ptr(stop), None if counters is None else C.byref(counters)))
     return [out[i, :counts[i]].copy() for i in range(nq)]
 
 

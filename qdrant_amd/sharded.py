@@ -45,6 +45,15 @@ def segment_id_bases(n_local: int, group=None, device=None) -> torch.Tensor:
     return base.to(torch.int32)  # bit pattern of u32
 
 
+def row_split(n_total: int, group=None):
+    """Strong scaling of ONE big segment ("if a collection is one big segment, split by contiguous row range"): rank r
+    holds rows [row0, row0 + n_local) of the segment; with `segment_id_bases(n_local)` as the id base the merged result is the
+    single-segment result (segments_searcher.rs:250-285 merges per-segment lists the same way)."""
+    rank, world = _world(group)
+    row0 = n_total * rank // world
+    return row0, n_total * (rank + 1) // world - row0
+
+
 def gather_topk(local_out: torch.Tensor, local_counts: torch.Tensor, gathered: Optional[torch.Tensor] = None,
                 gcounts: Optional[torch.Tensor] = None, group=None):
     """All-gather of the per-rank result lists.

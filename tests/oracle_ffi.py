@@ -47,6 +47,7 @@ _sig("qo_topk_push", None, [_P, C.c_uint32, _f])
 _sig("qo_topk_into_sorted", C.c_size_t, [_P, _P])
 _sig("qo_synth_value", _f, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32])
 _sig("qo_synth_fill_f32", None, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, _P])
+_sig("qo_synth_fill_latent_f32", None, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_float, _P])
 
 
 class Storage(C.Structure):
@@ -228,6 +229,13 @@ def topk_push_all(pairs, length):
 def synth(seed, row0, n, dim):
     out = np.empty((n, dim), dtype=np.float32)
     _lib.qo_synth_fill_f32(seed, row0, n, dim, _p(out))
+    return out
+
+
+def synth_latent(seed, row0, n, dim, latent_dim=32, noise=0.0):
+    """Rows of low intrinsic dimension, bit-identical to qmx_synth_fill_latent_f32 on the device."""
+    out = np.empty((n, dim), dtype=np.float32)
+    _lib.qo_synth_fill_latent_f32(seed, row0, n, dim, latent_dim, noise, _p(out))
     return out
 
 
@@ -419,6 +427,7 @@ _sig("qo_scorer_score_point", _f, [C.POINTER(Scorer), C.c_uint32])
 _sig("qo_scorer_score_internal", _f, [C.POINTER(Scorer), C.c_uint32, C.c_uint32])
 _sig("qo_hnsw_build", _P, [C.POINTER(Storage), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint64])
 _sig("qo_hnsw_build_parallel", _P, [C.POINTER(Storage), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint64, C.c_int])
+_sig("qo_hnsw_build_with", _P, [C.POINTER(Scorer), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint64])
 _sig("qo_hnsw_free", None, [_P])
 _sig("qo_hnsw_point_level", C.c_uint32, [_P, C.c_uint32])
 _sig("qo_hnsw_max_level", C.c_uint32, [_P])
@@ -497,6 +506,18 @@ class Hnsw:
             self.h = _lib.qo_hnsw_build(C.byref(storage.st), self.m, self.m0, ef_construct, entry_points_num,
                                         1 if use_heuristic else 0, seed)
         self.n = storage.rows.shape[0]
+
+    @classmethod
+    def build_pq(cls, storage: DenseStorage, pq: "PqOracle", m=16, m0=None, ef_construct=100, entry_points_num=10, seed=42):
+        """The build of a PQ-quantized segment (hnsw/build.rs:334-341 + point_scorer.rs:183-218): searches of an insertion score
+        through the LUT of the point's ORIGINAL vector (storage rows), heuristic / back links through EncodedVectorsPQ::score_internal."""
+        self = cls.__new__(cls)
+        self.storage, self.m, self.m0, self.n = storage, m, (2 * m if m0 is None else m0), storage.rows.shape[0]
+        s = Scorer()
+        s.kind, s.st, s.pq, s.pq_codes, s.isa = 2, C.pointer(storage.st), C.pointer(pq.pq), pq.codes.ctypes.data, pq.isa
+        self._keep = (s, pq)
+        self.h = _lib.qo_hnsw_build_with(C.byref(s), self.m, self.m0, ef_construct, entry_points_num, 1, seed)
+        return self
 
     @classmethod
     def from_plain(cls, p, n):

@@ -249,3 +249,112 @@ def test_bq_build_through_the_quantized_scorer(qa, query_encoding):
     r_bq = _recall(qa.search_quantized(scorer, raw, 10, oversampling=3.0, rescore=True, graph=g_bq, hnsw_ef=64), exact)
     r_f32 = _recall(qa.search_quantized(scorer, raw, 10, oversampling=3.0, rescore=True, graph=g_f32, hnsw_ef=64), exact)
     assert r_f32 > 0.4 and r_bq > r_f32 - 0.1, (r_bq, r_f32)
+
+
+def _check_invariants(p, n, m):
+    lv = _levels_of(p, n)
+    assert int(p.level_offsets[1]) == n and sorted(p.reindex.tolist()) == list(range(n))
+    order = np.argsort(p.reindex)
+    for l in range(len(p.level_offsets) - 1):
+        cnt = int(p.level_offsets[l + 1] - p.level_offsets[l])
+        for j in range(0, cnt, 5 if l == 0 else 1):
+            pid = j if l == 0 else int(order[j])
+            slot = int(p.level_offsets[l]) + j
+            ln = p.neighbors[int(p.offsets[slot]):int(p.offsets[slot + 1])]
+            assert len(ln) <= (2 * m if l == 0 else m) and (len(ln) > 0 or l > 0)
+            assert len(set(ln.tolist())) == len(ln) and pid not in ln and np.all(lv[ln] >= l)
+    return lv
+
+
+@pytest.mark.parametrize("distance,lut_mfma", [(O.DOT, False), (O.EUCLID, False), (O.DOT, True)])
+def test_pq_build_through_the_quantized_scorer(qa, distance, lut_mfma):
+    """A PQ segment builds its graph like the reference (hnsw/build.rs:334-341, point_scorer.rs:183-218): insertion searches score
+    through the LUT of the point's ORIGINAL vector, the heuristic and the back links through EncodedVectorsPQ::score_internal.
+    Bars: the structural invariants; the oracle's PQ walk of the device-built graph == the device's (ids, score bits: exact-order LUT);
+    recall after rescoring within 0.05 of (a) the graph the ORACLE builds the same way on the CPU and (b) the f32-built graph."""
+    n, dim, chunk, m, efc, seed = 5000, 64, 4, 8, 64, 11
+    rows = O.preprocess(distance, _clustered(n, dim, seed, k=48))
+    st = O.DenseStorage(O.F32, distance, rows)
+    cen = O.PqOracle.train(rows[:2000], dim, chunk, 256, iters=4)
+    opq = O.PqOracle(distance, dim, chunk, cen)
+    codes = opq.encode(rows)
+    quant = qa.ProductQuantizer(dim, _dist(qa, distance), chunk, cen, lut_mfma=lut_mfma)
+    enc = qa.EncodedVectorsPQ(codes, quant)
+    vs = qa.VectorStorage(rows, _dist(qa, distance))
+    with pytest.raises(qa.QmxError) as e:                     # without the original vectors there is no query for a stored PQ row
+        qa.GraphLayers.build(enc, m=m, ef_construct=efc, seed=seed)
+    assert e.value.status == qa._ffi.ERR_NOT_SUPPORTED
+    g_pq = qa.GraphLayers.build(enc, m=m, ef_construct=efc, seed=seed, original=vs)
+    g_f32 = qa.GraphLayers.build(vs, m=m, ef_construct=efc, seed=seed)
+    p = g_pq.export_plain()
+    lv = _check_invariants(p, n, m)
+    assert lv.tolist() == _levels_of(g_f32.export_plain(), n).tolist()
+    queries = _clustered(100, dim, seed + 1, k=48)
+    qpre = O.preprocess(distance, queries)
+    pq_scorer = qa.new_raw_scorer(queries, enc)
+    if not lut_mfma:
+        walk = O.Hnsw.from_plain(p, n)
+        want = walk.search_pq(st, opq, qpre[:40], 10, 64)
+        got = g_pq.search(10, 64, qa.new_raw_scorer(queries[:40], enc))
+        for gq, wq in zip(got, want):
+            assert gq["idx"].tolist() == wq["idx"].tolist()
+            assert np.array_equal(gq["score"].view(np.uint32), wq["score"].view(np.uint32))
+    raw = qa.new_raw_scorer(queries, vs)
+    exact = st.peek_top(queries, 10)
+    r_pq = _recall(qa.search_quantized(pq_scorer, raw, 10, oversampling=4.0, rescore=True, graph=g_pq, hnsw_ef=64), exact)
+    r_f32 = _recall(qa.search_quantized(pq_scorer, raw, 10, oversampling=4.0, rescore=True, graph=g_f32, hnsw_ef=64), exact)
+    # the oracle's sequential build through the same scorers (asymmetric searches, symmetric heuristic), walked by the device
+    cpu = O.Hnsw.build_pq(st, opq, m=m, ef_construct=efc, seed=seed)
+    g_cpu = qa.GraphLayers.from_plain(cpu.export_plain())
+    r_cpu = _recall(qa.search_quantized(pq_scorer, raw, 10, oversampling=4.0, rescore=True, graph=g_cpu, hnsw_ef=64), exact)
+    assert r_f32 > 0.4 and r_pq > r_f32 - 0.05 and r_pq > r_cpu - 0.05, (r_pq, r_cpu, r_f32)
+
+
+def test_pq_pair_table_is_score_internal(qa):
+    """The tabulated chunk distances give EncodedVectorsPQ::score_internal bit for bit (the build's stored <-> stored score)."""
+    n, dim, chunk = 600, 40, 8
+    rows = _clustered(n, dim, 5, k=16)
+    cen = O.PqOracle.train(rows, dim, chunk, 64, iters=3)
+    for distance in (O.DOT, O.EUCLID, O.MANHATTAN):
+        opq = O.PqOracle(distance, dim, chunk, cen)
+        codes = opq.encode(rows)
+        enc = qa.EncodedVectorsPQ(codes, qa.ProductQuantizer(dim, _dist(qa, distance), chunk, cen))
+        # qmx_score_internal reads the same table the build's HopPQInternal reads (and, with the option, recomputes the centroid distances)
+        a = np.arange(0, 500, dtype=np.uint32)
+        b = ((a * 7 + 3) % n).astype(np.uint32)
+        from qdrant_amd import _ffi as F
+        want = opq.score_internal(a.tolist(), b.tolist())
+        for no_table in (0, 1):
+            qa.set_option("no_pq_pair", no_table)
+            try:
+                out = np.zeros(len(a), dtype=np.float32)
+                F.check(F.lib().qmx_score_internal(enc._h, F.ptr(a), F.ptr(b), len(a), F.ptr(out)))
+            finally:
+                qa.set_option("no_pq_pair", -1)
+            assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("scalar_order", [False, True])
+@pytest.mark.parametrize("dim", [24, 100])        # 24: SSE leaf (one lane per row, both norms computed per pair); 100: AVX2 leaf + remainder
+def test_u8_cosine_build(qa, scalar_order, dim):
+    """Metric<u8> with the per-pair cosine (metric_uint/avx2/cosine.rs, simple_cosine.rs): a stored row as the query takes its norm from
+    the per-row norm column.  The oracle walks the device-built graph with identical score bits; recall against exact u8 search."""
+    n, m, efc = 5000, 8, 64
+    rows = np.clip(_clustered(n, dim, 41) * 20.0 + 128.0, 0, 255).astype(np.uint8)
+    st = O.DenseStorage(O.U8, O.COSINE, rows, u8_isa=O.ISA_SCALAR if scalar_order else O.ISA_AUTO)
+    vs = qa.VectorStorage(rows, qa.Distance.Cosine, qa.VectorStorageDatatype.Uint8, flags=qa._ffi.SEG_U8_SCALAR_ORDER if scalar_order else 0)
+    g = qa.GraphLayers.build(vs, m=m, ef_construct=efc, seed=9)
+    p = g.export_plain()
+    _check_invariants(p, n, m)
+    queries = np.clip(_clustered(80, dim, 42) * 20.0 + 128.0, 0, 255).astype(np.float32)
+    exact = st.peek_top(queries, 10)
+    got = g.search(10, 64, qa.new_raw_scorer(queries, vs))
+    assert _recall(got, exact) > 0.6
+    walk = O.Hnsw.from_plain(p, n)
+    want = walk.search_dense(st, queries[:30], 10, 64)
+    for gq, wq in zip(got[:30], want):
+        assert np.array_equal(gq["score"].view(np.uint32), wq["score"].view(np.uint32))
+    # the graph is as good as the one the oracle builds sequentially with the same per-pair cosine
+    cpu = O.Hnsw(st, m=m, ef_construct=efc, seed=9)
+    r_cpu = _recall(qa.GraphLayers.from_plain(cpu.export_plain()).search(10, 64, qa.new_raw_scorer(queries, vs)), exact)
+    assert _recall(got, exact) > r_cpu - 0.03
