@@ -232,6 +232,10 @@ uint32_t qo_links_heuristic(const qo_scored_point *sorted_candidates, uint32_t n
                             const float *score_table, uint32_t n, uint32_t *out_links);
 uint32_t qo_links_connect(uint32_t *links, uint32_t len, uint32_t new_point, uint32_t target, uint32_t level_m,
                           const float *score_table, uint32_t n);
+/* LinksContainer::connect_with_heuristic (:139-222; restated as its own reference implementation connect_with_heuristic_simple :107-132,
+ * which the reference's test_connect_new_point_with_heuristic holds equal) over a score table */
+uint32_t qo_links_connect_heuristic(uint32_t *links, uint32_t len, uint32_t new_point, uint32_t target, uint32_t lm,
+                                    const float *score_table, uint32_t n);
 
 /* score_max_similarity (query_scorer/mod.rs:70-97) over a similarity table sims[a * stride + b] */
 float qo_max_similarity(const float *sims, uint32_t n_a, uint32_t n_b, uint64_t stride);

@@ -505,6 +505,12 @@ uint32_t qo_links_connect(uint32_t *links, uint32_t len, uint32_t new_point, uin
     return connect_plain(links, len, new_point, target, lm, table_score, &t);
 }
 
+uint32_t qo_links_connect_heuristic(uint32_t *links, uint32_t len, uint32_t new_point, uint32_t target, uint32_t lm,
+                                    const float *score_table, uint32_t n) {
+    table_ctx t = {score_table, n};
+    return connect_with_heuristic(links, len, new_point, target, lm, table_score, &t);
+}
+
 static float internal_score(void *c, uint32_t a, uint32_t b) { return qo_scorer_score_internal((const qo_scorer *)c, a, b); }
 
 /* ---- GraphLayersBuilder::link_new_point (graph_layers_builder.rs:417-474) --------------------- */

@@ -361,10 +361,12 @@ class BqOracle:
 class PqOracle:
     """EncodedVectorsPQ on the CPU (oracle): given centroids [n_centroids, dim]."""
 
-    def __init__(self, distance, dim, chunk_size, centroids, isa=ISA_AUTO):
+    def __init__(self, distance, dim, chunk_size, centroids, isa=ISA_AUTO, invert=None):
         self.centroids = f32(centroids)
         self.pq = Pq()
-        invert = 1 if distance in (EUCLID, MANHATTAN) else 0
+        if invert is None:
+            invert = 1 if distance in (EUCLID, MANHATTAN) else 0      # the segment's choice (quantized_vectors.rs:232)
+        invert = int(invert)
         _lib.qo_pq_init(C.byref(self.pq), distance, invert, dim, chunk_size, self.centroids.shape[0], _p(self.centroids))
         self.m, self.nc, self.isa, self.dim = self.pq.m, self.centroids.shape[0], isa, dim
         self.codes = None
@@ -440,6 +442,7 @@ _sig("qo_hnsw_search", C.c_uint32, [_P, C.POINTER(Scorer), C.c_uint32, C.c_uint3
 _sig("qo_hnsw_search_algo", C.c_uint32, [_P, C.POINTER(Scorer), C.c_uint32, C.c_uint32, C.c_int, _P, C.POINTER(C.c_uint64)])
 _sig("qo_links_heuristic", C.c_uint32, [_P, C.c_uint32, C.c_uint32, _P, C.c_uint32, _P])
 _sig("qo_links_connect", C.c_uint32, [_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P, C.c_uint32])
+_sig("qo_links_connect_heuristic", C.c_uint32, [_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P, C.c_uint32])
 
 
 def merge_topk(lists, counts, k, idx_base=None):
@@ -635,6 +638,14 @@ def links_connect(links, new_point, target, level_m, score_table):
     buf = np.zeros(level_m + 1, dtype=np.uint32)
     buf[:len(links)] = links
     n = _lib.qo_links_connect(_p(buf), len(links), new_point, target, level_m, _p(t), t.shape[0])
+    return buf[:n].tolist()
+
+
+def links_connect_heuristic(links, new_point, target, level_m, score_table):
+    t = f32(score_table)
+    buf = np.zeros(level_m + 1, dtype=np.uint32)
+    buf[:len(links)] = links
+    n = _lib.qo_links_connect_heuristic(_p(buf), len(links), new_point, target, level_m, _p(t), t.shape[0])
     return buf[:n].tolist()
 
 

@@ -89,6 +89,55 @@ def test_c2_full_size_properties(world):
         assert np.array_equal(g["score"].view(np.uint32), w["score"].view(np.uint32))
 
 
+@pytest.mark.parametrize("nq", [16, 32, 64])
+def test_c2_full_size_every_batch_shape(world, nq):
+    """the kernel bench.py times — scan_f32_mfma16_kernel<6, 8, 4, LAG = true, IDS = false>, 64 queries per pass over
+    the WHOLE block (its wave-lag schedule and phantom-stage tail depend on the tile count) — checked at the headline size, next to the 16-
+    and 32-query shapes: the lists must equal (1) the VALU kernel's (4 queries per pass, no matrix cores, no pre-scan, a different
+    reduction tree: the only thing they share is the reference's bits), (2) the oracle's on a 200 k-row window reached through an id
+    list (the IDS = true instantiation), and (3) the merge of the lists of 5 uneven slabs."""
+    qa, F, torch = world["qa"], world["F"], world["torch"]
+    queries = O.synth(0x5EED0042 + nq, 0, nq, DIM)
+    s = qa.BatchFilteredSearcher(queries, world["st"], TOP)
+    full = s.peek_top_all()
+    kernel = F.last_kernel(s.scorer._h)
+    assert "scan_f32_mfma16_kernel<6, %s" % {16: "4, 1", 32: "4, 2", 64: "8, 4"}[nq] in kernel, kernel
+    assert all(len(r) == TOP and np.all(np.diff(r["score"]) <= 0) for r in full)
+    qa.set_option("no_mfma_scan", 1)
+    try:
+        valu = []
+        for q0 in range(0, nq, 4):
+            sv = qa.BatchFilteredSearcher(queries[q0:q0 + 4], world["st"], TOP)
+            valu += sv.peek_top_all()
+        assert "scan_kernel<" in F.last_kernel(sv.scorer._h)
+    finally:
+        qa.set_option("no_mfma_scan", -1)
+    _same(full, valu)
+    a, b = 7_300_000, 7_500_000
+    host = world["rows"][a:b].cpu().numpy()
+    want = O.DenseStorage(O.F32, O.COSINE, host).peek_top(queries, TOP)
+    for g, w in zip(s.peek_top_iter(np.arange(a, b, dtype=np.uint32)), want):
+        assert (g["idx"] - a).tolist() == w["idx"].tolist()
+        assert np.array_equal(g["score"].view(np.uint32), w["score"].view(np.uint32))
+    cuts = [0, 1_000_003, 2_718_281, 6_000_000, 9_999_984, N]       # uneven slabs, one of them 16 rows
+    lists = np.zeros((len(cuts) - 1, nq, TOP), dtype=O.ScoredPointOffset)
+    cnts = np.zeros((len(cuts) - 1, nq), dtype=np.uint32)
+    for i in range(len(cuts) - 1):
+        ids = torch.arange(cuts[i], cuts[i + 1], dtype=torch.int32, device=world["dev"])
+        o = torch.zeros((nq, TOP, 2), dtype=torch.int32, device=world["dev"])
+        c = torch.zeros((nq,), dtype=torch.int32, device=world["dev"])
+        F.check(F.lib().qmx_search_topk_async(s.scorer._h, TOP, F.ptr(ids), ids.numel(), F.ptr(o), F.ptr(c)))
+        F.check(F.lib().qmx_query_synchronize(s.scorer._h))
+        oh = o.cpu().numpy()
+        lists[i]["idx"] = oh[:, :, 0].view(np.uint32)
+        lists[i]["score"] = oh[:, :, 1].copy().view(np.float32)
+        cnts[i] = c.cpu().numpy().view(np.uint32)
+    merged = np.zeros((nq, TOP), dtype=O.ScoredPointOffset)
+    mc = np.zeros(nq, dtype=np.uint32)
+    F.check(F.lib().qmx_merge_topk(0, F.ptr(lists), F.ptr(cnts), len(cuts) - 1, nq, TOP, F.ptr(merged), F.ptr(mc)))
+    _same(full, [merged[i, :mc[i]] for i in range(nq)])
+
+
 def test_c3_full_size_properties(world):
     qa, F, torch = world["qa"], world["F"], world["torch"]
     rows, dev = world["rows"], world["dev"]

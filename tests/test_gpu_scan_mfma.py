@@ -344,7 +344,16 @@ def test_f16_scores_within_1e5(qa, dist, dim, nq):
     got = scorer.score_points(ids)
     want = ost.score_points(queries, ids)
     scale = np.abs(O.f16_to_f32(q16).astype(np.float64)[:, None, :] * O.f16_to_f32(rows16).astype(np.float64)[None, :, :]).sum(-1)
-    assert np.all(np.abs(got.astype(np.float64) - want) <= 1e-5 * scale + 1e-30)
+    err = np.abs(got.astype(np.float64) - want)
+    assert np.all(err <= 1e-5 * scale + 1e-30)
+    # 1e-5 * sum|terms| is far looser than "1e-5 relative to the score" for near-orthogonal vectors.  What the kernel
+    # actually delivers: two f32 summation orders of EXACT products differ by a few ulps of the running sum, i.e. |err| <= ~8 eps * sum|terms|
+    # (measured worst over this matrix of cases: 2.4e-7 * sum|terms|) -- asserted here at 1e-6; and relative to the SCORE it is below 1e-5
+    # wherever the score is not a cancellation (|score| >= 0.1 * sum|terms|); both worst cases are reported by tools/f16_error_report.py.
+    assert np.all(err <= 1e-6 * scale + 1e-30), float((err / scale).max())
+    solid = np.abs(want) >= 0.1 * scale
+    if solid.any():
+        assert float((err[solid] / np.abs(want[solid])).max()) <= 1e-5
     # top-k: same id sets as the oracle wherever the k-th and (k+1)-th oracle scores are further apart than the tolerance
     s = qa.BatchFilteredSearcher(queries, st, 10)
     res = s.peek_top_all()

@@ -92,6 +92,41 @@ def _worker(rank, world, port, sizes, dim, nq, top, distance):
         dist.destroy_process_group()
 
 
+def _worker_strong(rank, world, port, n_total, dim, nq, top, distance):
+    """--scaling strong of bench.py: ONE segment row-split over the ranks (sharded.row_split); the merged result must be the
+    single-process search of the whole segment, ids included (base = first row of the slice)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle_ffi as O
+        from qdrant_amd import sharded
+        seed = 0x5EED0006
+        row0, n_local = sharded.row_split(n_total)
+        assert (row0, n_local) == (n_total * rank // world, n_total * (rank + 1) // world - n_total * rank // world)
+        whole = O.preprocess(distance, O.synth(seed, 0, n_total, dim))
+        mine = O.preprocess(distance, O.synth(seed, row0, n_local, dim))      # the generator is counter-based: a slice is the slice
+        assert np.array_equal(mine.view(np.uint32), whole[row0:row0 + n_local].view(np.uint32))
+        s = sharded.ShardedSearcher(OracleBackend(O, mine, distance), n_local, nq, top)
+        assert int(s.idx_base.numpy().view(np.uint32)[rank]) == row0
+        truth = O.DenseStorage(O.F32, distance, whole)
+        for batch in range(2):
+            queries = O.synth(seed + 1, batch * nq, nq, dim)
+            s.search(torch.from_numpy(queries))
+            for (gi, gs), w in zip(s.results(), truth.peek_top(queries, top)):
+                assert gi.tolist() == w["idx"].tolist() and gs.tolist() == w["score"].tolist()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_total", [(2, 1001), (3, 700)])
+def test_row_split_of_one_segment_matches_the_single_segment_search(world, n_total):
+    import oracle_ffi  # noqa: F401
+    mp.spawn(_worker_strong, args=(world, _free_port(), n_total, 40, 4, 10, 0), nprocs=world, join=True)
+
+
 @pytest.mark.parametrize("world,sizes", [(2, [700, 500]), (3, [300, 5, 450])])
 def test_sharded_search_matches_single_process(world, sizes):
     import oracle_ffi  # noqa: F401  (builds the oracle before the workers start)

@@ -201,6 +201,21 @@ def main():
             out["oracle_walk_same_ids"] = "%d/%d" % (sum(int(a["idx"].tolist() == b["idx"].tolist()) for a, b in zip(got, want)), len(want))
             out["oracle_walk_same_score_bits"] = "%d/%d" % (
                 sum(int(np.array_equal(a["score"].view(np.uint32), b["score"].view(np.uint32))) for a, b in zip(got, want)), len(want))
+            # every query whose id list differs: is it a tie (equal score bits at the differing positions, or at the cut after `top`)?
+            diffs = []
+            for qi, (a, b) in enumerate(zip(got, want)):
+                if a["idx"].tolist() != b["idx"].tolist():
+                    pos = [i for i in range(min(len(a), len(b))) if a["idx"][i] != b["idx"][i]]
+                    ids = sorted(set(a["idx"][pos].tolist()) | set(b["idx"][pos].tolist()))
+                    rs = scorer.score_points(ids)[qi] if hasattr(scorer, "score_points") else None
+                    dup = None
+                    if host_rows is not None and len(ids) == 2:
+                        dup = bool(np.array_equal(host_rows[ids[0]], host_rows[ids[1]]))
+                    diffs.append({"query": qi, "positions": pos, "device_ids": a["idx"][pos].tolist(), "oracle_ids": b["idx"][pos].tolist(),
+                                  "device_score_bits": [int(x) for x in a["score"].view(np.uint32)[pos]], "oracle_score_bits": [int(x) for x in b["score"].view(np.uint32)[pos]],
+                                  "ids_involved": ids, "their_scores_bits": None if rs is None else [int(x) for x in rs.view(np.uint32)],
+                                  "rows_bit_identical": dup})
+            out["oracle_walk_differences"] = diffs
             t0 = time.time()
             cpu_res = oracle_search(queries[:args.cpu_queries])
             t_cpu = time.time() - t0
