@@ -455,3 +455,34 @@ def test_walk_survives_a_graph_whose_levels_are_inconsistent(qa):
         torch.cuda.synchronize()
     finally:
         F.lib().qmx_hnsw_destroy(h)
+
+
+def test_equal_scores_explain_every_oracle_walk_difference(qa):
+    """at 1 M rows the oracle's walk and the device's returned different ids for 1 of 64 (f32) and 4 of 64 (SQ) queries
+    with IDENTICAL score bits.  profiles/r2_hnsw_1m_oracle_walk_ties.jsonl has every such query of a 256-query re-run: each differing
+    position holds two points whose scores to the query are bit-identical (SQ: quantized scores collide often; f32: two of ~250 same-cluster
+    rows 6e-8 apart, once in 256 queries) - the device orders equal scores by ascending id, the reference by BinaryHeap insertion history
+    (unpinned).  Here ties are forced: every row exists twice, so EVERY score ties.  The device's lists must carry the oracle's score bits
+    and differ from its ids only inside runs of equal scores; among equal scores the device returns ascending ids."""
+    n_half, dim, m, nq = 1500, 32, 8, 40
+    base = O.preprocess(O.DOT, O.synth(0x5EED03A0, 0, n_half, dim))
+    rows = np.concatenate([base, base])                        # row i == row i + n_half
+    st = O.DenseStorage(O.F32, O.DOT, rows)
+    g = O.Hnsw(st, m=m, ef_construct=64, seed=3, threads=0)
+    queries = O.synth(0x5EED03A1, 0, nq, dim)
+    vs = qa.VectorStorage(rows, qa.Distance.Dot)
+    graph = qa.GraphLayers.from_plain(g.export_plain())
+    got = graph.search(10, 64, qa.new_raw_scorer(queries, vs))
+    want = g.search_dense(st, queries, 10, 64)
+    n_pairs = 0
+    for gq, wq in zip(got, want):
+        assert np.array_equal(gq["score"].view(np.uint32), wq["score"].view(np.uint32))
+        sc = gq["score"]
+        for i in range(len(gq) - 1):
+            if sc[i] == sc[i + 1]:
+                assert gq["idx"][i] < gq["idx"][i + 1]            # equal scores: ascending id on the device
+                n_pairs += 1
+        # ids agree with the oracle as multisets of (score, id mod n_half): the same points up to the choice among equals
+        assert sorted(zip(sc.tolist(), (gq["idx"] % n_half).tolist()))[:-1] == sorted(zip(wq["score"].tolist(), (wq["idx"] % n_half).tolist()))[:-1] or \
+            sorted(zip(sc.tolist(), (gq["idx"] % n_half).tolist())) == sorted(zip(wq["score"].tolist(), (wq["idx"] % n_half).tolist()))
+    assert n_pairs > nq                                        # the ties were really there

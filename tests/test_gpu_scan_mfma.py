@@ -348,8 +348,9 @@ def test_f16_scores_within_1e5(qa, dist, dim, nq):
     assert np.all(err <= 1e-5 * scale + 1e-30)
     # 1e-5 * sum|terms| is far looser than "1e-5 relative to the score" for near-orthogonal vectors.  What the kernel
     # actually delivers: two f32 summation orders of EXACT products differ by a few ulps of the running sum, i.e. |err| <= ~8 eps * sum|terms|
-    # (measured worst over this matrix of cases: 2.4e-7 * sum|terms|) -- asserted here at 1e-6; and relative to the SCORE it is below 1e-5
-    # wherever the score is not a cancellation (|score| >= 0.1 * sum|terms|); both worst cases are reported by tools/f16_error_report.py.
+    # (measured worst, profiles/r2_f16_error_report.json: 1.6e-7 * sum|terms|) -- asserted here at 1e-6; and relative to the SCORE it is below 1e-5
+    # wherever the score is not a cancellation (|score| >= 0.1 * sum|terms|; over ALL pairs, near-zero scores included, the worst relative
+    # error is 1.6e-2, over the top-10 a search returns 5.5e-7); tools/f16_error_report.py prints all three.
     assert np.all(err <= 1e-6 * scale + 1e-30), float((err / scale).max())
     solid = np.abs(want) >= 0.1 * scale
     if solid.any():
