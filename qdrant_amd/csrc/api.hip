@@ -47,7 +47,7 @@ int32_t hip_status(hipError_t e, const char *what, const char *file, int line) {
 
 // ---- kernel-path options: the environment is read once, here, at load time ----
 static const char *const g_option_names[OPT_COUNT] = {"no_mfma_scan", "no_mfma16", "no_mfma16_q64", "no_prescan", "prescan_shift", "hnsw_no_packed_l0",
-                                                     "hnsw_pq_lds_lut", "hnsw_log_cap", "bq_lanes8", "mfma_no_nt", "mfma_no_fast", "no_pq_tiled", "no_pq_pair", "debug"};
+                                                     "hnsw_pq_lds_lut", "hnsw_log_cap", "bq_lanes8", "mfma_no_nt", "mfma_no_fast", "no_pq_tiled", "no_split_scan", "no_pq_pair", "debug"};
 struct OptionTable {
     std::atomic<int64_t> v[OPT_COUNT];
     int64_t initial[OPT_COUNT];
@@ -168,6 +168,9 @@ struct qmx_segment {
     float *d_pq_pair = nullptr;       // [m][ncent][ncent] chunk distances between centroids (score_internal terms; built when <= 256 MB)
     uint32_t pq_m = 0;
     float *d_row_offsets = nullptr;   // SQ: vector_offset column (rows hold the 16-byte aligned code block)
+    // f32 dot / cosine blocks large enough for the split prefilter (scan_split.hip): max |x| and max row norm, taken once at create
+    bool split_stats = false;
+    float row_maxabs = 0.f, row_norm_max = 0.f;
 
     bool fast_layout() const {
         if (dtype == QMX_DTYPE_BQ) return row_stride % 16 == 0 && ((uintptr_t)d_rows % 16) == 0;
@@ -216,6 +219,9 @@ struct qmx_query {
     DevBuf cq_sims, cq_scores, cq_desc, cq_coefs;   // custom queries: example similarities, combined scores, descriptors, feedback coefficients
     uint32_t n_cq_coefs = 0;
     DevBuf cand, cand_cnt, cand_ids;   // qmx_search_quantized: oversampled candidates of the quantized stage
+    // split prefilter (scan_split.hip): split queries, per-query norms / thresholds / bands, scales, candidate and verification buffers, flag
+    DevBuf sp_bq, sp_f32, sp_cand, sp_cnt, sp_ver, sp_vscores, sp_sample;
+    uint64_t sp_sample_n = 0, sp_sample_of = 0;
     DevBuf filter;             // payload-filter allow bitmap of this query batch (qmx_query_set_filter)
     uint64_t n_filter_bits = 0;
     bool has_filter = false;
@@ -420,6 +426,29 @@ static int32_t segment_upload(qmx_segment *s, const qmx_segment_desc *desc) {
     return QMX_OK;
 }
 
+// one pass over an f32 dot / cosine block that the split prefilter may serve: the power-of-two scale of its rows and the norm bound of
+// the verification band (4.5 ms per 30 GB; nothing for other storages)
+static int32_t segment_split_stats(qmx_segment *s) {
+    if (s->dtype != QMX_DTYPE_F32 || (s->distance != QMX_DISTANCE_DOT && s->distance != QMX_DISTANCE_COSINE) || s->dim % 32 != 0 ||
+        s->n < (1u << 18) || !s->fast_layout())
+        return QMX_OK;
+    uint32_t *d_stats = nullptr;
+    QMX_HIP(hipMalloc((void **)&d_stats, 8));
+    int32_t rc = QMX_OK;
+    uint32_t h[2] = {0, 0};
+    if (hipMemset(d_stats, 0, 8) != hipSuccess) rc = QMX_ERR_OTHER;
+    if (rc == QMX_OK) rc = launch_split_row_stats(nullptr, s->d_rows, s->row_stride, s->n, s->dim, d_stats);
+    if (rc == QMX_OK && hipMemcpy(h, d_stats, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = QMX_ERR_OTHER;
+    (void)hipFree(d_stats);
+    if (rc != QMX_OK) return rc;
+    memcpy(&s->row_maxabs, &h[0], 4);
+    float mss;
+    memcpy(&mss, &h[1], 4);
+    s->row_norm_max = sqrtf(mss);
+    s->split_stats = s->row_maxabs > 0.f && s->row_maxabs < 3.0e38f && s->row_norm_max < 3.0e38f;   // (NaN / inf rows: the exact scan only)
+    return QMX_OK;
+}
+
 int32_t qmx_segment_create(const qmx_segment_desc *desc, qmx_segment **out) {
     QMX_REQUIRE(desc && out, QMX_ERR_BAD_ARG, "NULL argument");
     *out = nullptr;
@@ -508,6 +537,7 @@ int32_t qmx_segment_create(const qmx_segment_desc *desc, qmx_segment **out) {
             rc = QMX_ERR_NOT_SUPPORTED;
     }
     if (rc == QMX_OK) rc = segment_upload(s, desc);
+    if (rc == QMX_OK) rc = segment_split_stats(s);
     if (rc != QMX_OK) {
         segment_free(s);
         return rc;
@@ -932,6 +962,7 @@ int32_t qmx_query_destroy(qmx_query *q) {
     q->mv_deleted.release();
     q->cq_scores.release();
     q->cq_desc.release();
+    q->sp_bq.release(); q->sp_f32.release(); q->sp_cand.release(); q->sp_cnt.release(); q->sp_ver.release(); q->sp_vscores.release(); q->sp_sample.release();
     q->cand.release();
     q->cand_cnt.release();
     q->cand_ids.release();
@@ -1149,6 +1180,29 @@ int32_t qmx_score_point(qmx_query *q, uint32_t query_index, uint32_t id, float *
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t MAX_TOP = 1024;   // top > MAX_TOP_FAST runs in passes of MAX_TOP_FAST, each bounded by the last key of the one before
 
+static int32_t score_pairs_device(qmx_query *q, const PairSel &sel, const uint32_t *d_ids, uint64_t n_items, float *d_scores, bool timed);
+
+// triage aid (qmx_set_option("debug", 2)): synchronise after every stage of the split path and name it on stderr
+static int32_t split_stage(qmx_query *q, const char *what) {
+    if (option(OPT_DEBUG) < 2) return QMX_OK;
+    hipError_t e = hipStreamSynchronize(q->stream);
+    fprintf(stderr, "[qmx] split stage %-28s %s\n", what, e == hipSuccess ? "ok" : hipGetErrorString(e));
+    fflush(stderr);
+    return e == hipSuccess ? QMX_OK : QMX_ERR_OTHER;
+}
+
+constexpr uint32_t SPLIT_QT = 128;          // queries per pass of the split prefilter (scan_split.hip)
+constexpr uint32_t SPLIT_CAND_CAP = 32768;  // candidate keys per query and pass (expected: ~1000 k)
+constexpr uint32_t SPLIT_VCAP = 128;        // rows per query that get an exact score (expected: ~k)
+constexpr float SPLIT_REL_BAND = 1.0e-4f;   // |approximate - exact| <= band * |q| * max |row|: 100x the split error, above the worst-case f32
+                                            // accumulation bounds of both sides (dim * 2^-24 each) up to dim 1600
+
+// ids of a strided sample of the candidates (rows 0, step, 2 step, ...): a sample that sees the whole block, whatever its order
+__global__ void sample_ids_kernel(uint32_t *ids, uint32_t n, uint64_t step) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ids[i] = (uint32_t)((uint64_t)i * step);
+}
+
 static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids, uint64_t n_ids,
                               qmx_scored_point *d_out, uint32_t *d_counts, const volatile uint8_t *is_stopped,
                               qmx_counters *counters, bool timed) {
@@ -1162,14 +1216,98 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
     // ... and rows of 1024 .. 1536 floats 32 per pass: that kernel keeps the queries in registers, not in an LDS tile (tile_qt's limit)
     const bool q32 = s->dtype == QMX_DTYPE_F32 && mfma_scan_ok(s) && q->nq > MAX_QT && s->dim > 768 && mfma16_dim_ok(32, s->dim) &&
                      !option(OPT_NO_MFMA16);
-    const uint32_t TQ = q64 ? MAX_QT_TOPK : q32 ? MAX_QT_MFMA : tile_qt(s);
+    // more than 64 queries over a large f32 dot / cosine block: 128 per pass through the f16-split matrix-core prefilter, the survivors
+    // re-scored exactly (scan_split.hip); the result is the exact scan's, bit for bit
+    const bool split = q64 && s->split_stats && !d_ids && top <= MAX_TOP_FAST && n_cand >= (1u << 18) && s->dim % 32 == 0 && s->row_stride % 16 == 0 &&
+                       !option(OPT_NO_SPLIT_SCAN);
+    const uint32_t TQ = split ? SPLIT_QT : q64 ? MAX_QT_TOPK : q32 ? MAX_QT_MFMA : tile_qt(s);
     const uint32_t ptop_max = std::min<uint32_t>(top, MAX_TOP_FAST);
     const uint32_t n_pass = (top + MAX_TOP_FAST - 1) / MAX_TOP_FAST;
-    QMX_TRY(q->partial.reserve((size_t)grid_cap * TQ * ptop_max * sizeof(uint64_t)));
+    QMX_TRY(q->partial.reserve((size_t)grid_cap * std::min<uint32_t>(TQ, MAX_QT_TOPK) * ptop_max * sizeof(uint64_t)));
     if (n_pass > 1) QMX_TRY(q->bounds.reserve((size_t)TQ * sizeof(uint64_t)));
-    QMX_TRY(q->gthr.reserve((size_t)MAX_QT_TOPK * sizeof(uint64_t)));
+    QMX_TRY(q->gthr.reserve((size_t)std::max<uint32_t>(q->nq_padded, SPLIT_QT) * sizeof(uint64_t)));
+    // ---- split passes first (their verification and, if ever needed, the exact fallback run once for all of them afterwards) ----
+    std::vector<std::pair<uint32_t, uint32_t>> split_tiles;      // (tile0, nq_tile)
+    float *sp_qnorm = nullptr, *sp_thr = nullptr, *sp_band = nullptr, *sp_scales = nullptr;
+    int *sp_overflow = nullptr;
+    if (split) {
+        QMX_TRY(q->sp_bq.reserve(split_query_bytes(s->dim)));
+        QMX_TRY(q->sp_f32.reserve(1024 * sizeof(float)));
+        QMX_TRY(q->sp_cand.reserve((size_t)SPLIT_QT * SPLIT_CAND_CAP * sizeof(uint64_t)));
+        QMX_TRY(q->sp_cnt.reserve((size_t)SPLIT_QT * 4));
+        QMX_TRY(q->sp_ver.reserve((size_t)q->nq * (SPLIT_VCAP + 1) * 4));
+        QMX_TRY(q->sp_vscores.reserve((size_t)q->nq * SPLIT_VCAP * 4));
+        float *f = (float *)q->sp_f32.p;
+        sp_qnorm = f; sp_thr = f + 128; sp_band = f + 256; sp_scales = f + 384; sp_overflow = (int *)(f + 392);
+        // the sample: every (n_cand / S)-th row, S = n_cand / 1024 (at least 8192)
+        const uint64_t S = std::min<uint64_t>(n_cand, std::max<uint64_t>(n_cand >> 10, 8192));
+        if (q->sp_sample_n != S || q->sp_sample_of != n_cand) {
+            QMX_TRY(q->sp_sample.reserve((size_t)S * 4));
+            ::qmx::clear_stale_error();
+            hipLaunchKernelGGL(sample_ids_kernel, dim3((uint32_t)((S + 255) / 256)), dim3(256), 0, q->stream, (uint32_t *)q->sp_sample.p, (uint32_t)S, n_cand / S);
+            QMX_HIP(hipGetLastError());
+            q->sp_sample_n = S;
+            q->sp_sample_of = n_cand;
+        }
+        QMX_HIP(hipMemsetAsync(sp_overflow, 0, sizeof(int), q->stream));
+    }
     for (uint32_t tile0 = 0; tile0 < q->nq; tile0 += TQ) {
         const uint32_t nq_tile = std::min<uint32_t>(TQ, q->nq - tile0);
+        if (split && nq_tile > MAX_QT_TOPK) {
+            if (is_stopped && *is_stopped) {
+                set_error("search cancelled");
+                return QMX_ERR_CANCELLED;
+            }
+            const uint32_t S = (uint32_t)q->sp_sample_n;
+            const uint32_t *d_sample = (const uint32_t *)q->sp_sample.p;
+            uint64_t *gthr = (uint64_t *)q->gthr.p + tile0;
+            ScanArgs a;
+            fill_args(q, tile0, nq_tile, a);
+            a.n_cand = n_cand;
+            a.top = top;
+            // 1. exact scores of the sample -> the k-th best of each query = a lower bound of its final k-th best
+            QMX_TRY(q->scores.reserve((size_t)nq_tile * S * sizeof(float)));
+            const uint32_t SQT = tile_qt(s);
+            for (uint32_t st0 = 0; st0 < nq_tile; st0 += SQT) {
+                const uint32_t nq_sub = std::min<uint32_t>(SQT, nq_tile - st0);
+                ScanArgs pre;
+                fill_args(q, tile0 + st0, nq_sub, pre);
+                pre.ids = d_sample;
+                pre.n_cand = S;
+                pre.top = 1;
+                pre.scores = (float *)q->scores.p + (size_t)st0 * S;
+                pre.scores_stride = S;
+                uint32_t pgrid = 0;
+                QMX_TRY(launch_scan(q, (int)pow2_ceil(nq_sub), SCAN_SCORES, pre, &pgrid));
+            }
+            QMX_TRY(launch_custom_topk(q->stream, (const float *)q->scores.p, S, d_sample, a.del, nq_tile, top, d_out + (size_t)tile0 * top, d_counts + tile0));
+            QMX_TRY(launch_bound_from_topk(q->stream, d_out + (size_t)tile0 * top, d_counts + tile0, nq_tile, top, gthr));
+            QMX_TRY(split_stage(q, "prescan"));
+            // 2. the batch's queries split into f16 pairs; thresholds and bands in accumulator / score units
+            const float row_scale = split_row_scale(s->row_maxabs);
+            QMX_TRY(launch_split_pack_queries(q->stream, (const float *)q->enc.p + (size_t)tile0 * s->dim, nq_tile, s->dim, row_scale, (uint32_t *)(sp_scales + 4),
+                                              sp_qnorm, sp_scales, q->sp_bq.p));
+            QMX_TRY(launch_split_thresholds(q->stream, gthr, sp_qnorm, nq_tile, SPLIT_REL_BAND, s->row_norm_max, sp_scales, sp_thr, sp_band));
+            QMX_HIP(hipMemsetAsync(q->sp_cnt.p, 0, (size_t)SPLIT_QT * 4, q->stream));
+            QMX_TRY(split_stage(q, "pack + thresholds"));
+            // 3. the approximate scan of the whole block
+            size_t slot = 0;
+            if (timed) QMX_TRY(timing_begin(q, &slot));
+            QMX_TRY(launch_scan_f32_split(q->stream, a, q->sp_bq.p, row_scale, sp_scales, sp_thr, (uint64_t *)q->sp_cand.p, (uint32_t *)q->sp_cnt.p, SPLIT_CAND_CAP,
+                                          s->num_cus));
+            q->last_kernel = g_last_kernel;
+            if (timed) QMX_TRY(timing_end(q, slot));
+            QMX_TRY(split_stage(q, "split kernel"));
+            // 4. the rows worth an exact score
+            uint32_t *ver_ids = (uint32_t *)q->sp_ver.p + (size_t)tile0 * SPLIT_VCAP;
+            uint32_t *ver_cnt = (uint32_t *)q->sp_ver.p + (size_t)q->nq * SPLIT_VCAP + tile0;
+            QMX_TRY(launch_split_select(q->stream, (const uint64_t *)q->sp_cand.p, (const uint32_t *)q->sp_cnt.p, SPLIT_CAND_CAP, sp_band, nq_tile, top, SPLIT_VCAP,
+                                        ver_ids, ver_cnt, sp_overflow));
+            QMX_TRY(split_stage(q, "select"));
+            split_tiles.push_back({tile0, nq_tile});
+            if (counters) counters->kernel_launches += 8;
+            continue;
+        }
         const int qt = (int)pow2_ceil(nq_tile);
         for (uint32_t pass = 0; pass < n_pass; ++pass) {
             if (is_stopped && *is_stopped) {
@@ -1233,6 +1371,41 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
                                       n_pass > 1 ? (uint64_t *)q->bounds.p : nullptr));
             if (counters) counters->kernel_launches += 2;
         }
+    }
+    if (!split_tiles.empty()) {
+        // 5. exact scores of the survivors (the gather kernel of qmx_rescore: the reference's bits), sorted by (score, lower id first)
+        uint32_t *ver_all = (uint32_t *)q->sp_ver.p, *cnt_all = ver_all + (size_t)q->nq * SPLIT_VCAP;
+        const void *split_kernel = q->last_kernel;
+        const uint32_t first = split_tiles.front().first, last = split_tiles.back().first + split_tiles.back().second;
+        PairSel sel{nullptr, SPLIT_VCAP, cnt_all};
+        // the gather addresses query item / SPLIT_VCAP: split tiles are a prefix of the batch (the remainder tile, if any, comes last)
+        QMX_REQUIRE(first == 0, QMX_ERR_OTHER, "split tiles must start at query 0");
+        QMX_TRY(score_pairs_device(q, sel, ver_all, (uint64_t)last * SPLIT_VCAP, (float *)q->sp_vscores.p, false));
+        QMX_TRY(split_stage(q, "verify gather"));
+        QMX_TRY(launch_sort_scored(q->stream, (const float *)q->sp_vscores.p, ver_all, cnt_all, SPLIT_VCAP, last, top, d_out, d_counts));
+        QMX_TRY(split_stage(q, "verify sort"));
+        // 6. the exact scan of those queries, which runs only if a buffer overflowed somewhere (the kernels start, read the flag, return)
+        for (auto &t : split_tiles) {
+            for (uint32_t sub0 = t.first; sub0 < t.first + t.second; sub0 += MAX_QT_TOPK) {
+                const uint32_t nq_sub = std::min<uint32_t>(MAX_QT_TOPK, t.first + t.second - sub0);
+                ScanArgs a;
+                fill_args(q, sub0, nq_sub, a);
+                a.n_cand = n_cand;
+                a.top = top;
+                a.partial = (uint64_t *)q->partial.p;
+                a.gthr = (const uint64_t *)q->gthr.p + sub0;
+                a.run_if = sp_overflow;
+                const int fqt = (int)std::max<uint32_t>(16, pow2_ceil(nq_sub));
+                a.partial_qt = (uint32_t)fqt;
+                uint32_t grid = grid_cap;
+                QMX_REQUIRE(mfma16_scan_ok(fqt, SCAN_TOPK, a), QMX_ERR_OTHER, "split fallback shape");
+                QMX_TRY(launch_scan_f32_mfma16(q->stream, fqt, a, s->num_cus, &grid));
+                QMX_TRY(launch_merge_keys(q->stream, (const uint64_t *)q->partial.p, grid, (uint32_t)fqt, nq_sub, top, d_out + (size_t)sub0 * top,
+                                          d_counts + sub0, top, 0, nullptr, sp_overflow));
+            }
+        }
+        QMX_TRY(split_stage(q, "fallback (conditional)"));
+        q->last_kernel = split_kernel;      // (the fallback launches above are not what ran)
     }
     if (counters) {
         counters->vectors_scored += (uint64_t)q->nq * n_cand * n_pass;

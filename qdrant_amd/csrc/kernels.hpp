@@ -33,6 +33,7 @@ struct ScanArgs {
     float *scores;             // [nq][n_cand] (score mode)
     uint64_t scores_stride;    // elements between queries in `scores`
     int *err_flag;             // set to 1 on an out-of-range id
+    const int *run_if;         // nullptr, or: the kernel returns at once unless *run_if != 0 (the exact scan behind the split prefilter, scan_split.hip)
     // SQ
     float sq_multiplier;
     const float *row_offsets;  // SQ: per-row f32 offset (SoA copy) or nullptr when inline in rows
@@ -195,6 +196,19 @@ int32_t launch_sq_internal_query(hipStream_t st, const void *codes, const float 
 bool mfma16_dim_ok(int qt, uint32_t dim);
 bool mfma16_scan_ok(int qt, ScanMode mode, const ScanArgs &a);   // qt = 16, 32 or 64
 int32_t launch_scan_f32_mfma16(hipStream_t st, int qt, const ScanArgs &a, int num_cus, uint32_t *grid_out);
+// f32 dot / cosine, 65..128 queries per pass: f16-split matrix-core prefilter + exact verification (scan_split.hip)
+bool split_scan_ok(const ScanArgs &a);
+size_t split_query_bytes(uint32_t dim);
+float split_row_scale(float row_maxabs);
+int32_t launch_split_row_stats(hipStream_t st, const void *rows, uint64_t row_stride, uint64_t n, uint32_t dim, uint32_t *d_stats);
+int32_t launch_split_pack_queries(hipStream_t st, const float *d_q, uint32_t nq, uint32_t dim, float row_scale, uint32_t *d_stats, float *d_qnorm,
+                                  float *d_scales, void *d_bq);
+int32_t launch_split_thresholds(hipStream_t st, const uint64_t *d_gthr, const float *d_qnorm, uint32_t nq, float rel_band, float row_norm_max,
+                                const float *d_scales, float *d_thr, float *d_band);
+int32_t launch_scan_f32_split(hipStream_t st, const ScanArgs &a, const void *d_bq, float row_scale, const float *d_scales, const float *d_thr,
+                              uint64_t *d_cand, uint32_t *d_cand_cnt, uint32_t cap, int num_cus);
+int32_t launch_split_select(hipStream_t st, const uint64_t *d_cand, const uint32_t *d_cand_cnt, uint32_t cap, const float *d_band, uint32_t nq, uint32_t top,
+                            uint32_t vcap, uint32_t *d_ver_ids, uint32_t *d_ver_cnt, int *d_overflow);
 // order statistics of a float array (quantile.hip): the SQ quantile interval
 int32_t launch_order_statistics_f32(hipStream_t st, const float *d_in, float *d_tmp, uint64_t n, uint64_t lo_pos, uint64_t hi_pos, float *h_out);
 // BQ 1-bit (scan_bq.hip)
@@ -226,7 +240,7 @@ int32_t launch_pack_queries(hipStream_t st, int dtype, int distance, const void 
 int32_t launch_merge_keys(hipStream_t st, const uint64_t *partial, uint32_t n_lists,
                           uint32_t qt_stride, uint32_t nq, uint32_t top, qmx_scored_point *out,
                           uint32_t *out_counts, uint32_t out_stride = 0, uint32_t out_offset = 0,
-                          uint64_t *next_bound = nullptr);
+                          uint64_t *next_bound = nullptr, const int *run_if = nullptr);
 int32_t launch_merge_points(hipStream_t st, const qmx_scored_point *lists, const uint32_t *list_counts,
                             const uint32_t *list_idx_base, uint32_t n_lists, uint32_t nq, uint32_t k, qmx_scored_point *out,
                             uint32_t *out_counts);

@@ -100,6 +100,7 @@ template <int KSTEPS /* dim / 128: 512-byte K-steps per row */, int NW, int NT, 
           bool LAG = (NW == 8 && NT == 4 && KSTEPS == 6) /* half of the waves run one stage behind the others, see `lag` */,
           bool IDS = false /* candidates = a.ids[0 .. n_cand) instead of rows 0 .. n_cand) (payload-filtered scans, peek_top_iter) */>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void scan_f32_mfma16_kernel(const ScanArgs a) {
+    if (a.run_if && *a.run_if == 0) return;           // the exact pass behind the split prefilter was not needed (scan_split.hip)
     constexpr int KPS = KSTEPS % 2 == 0 ? 2 : 1;      // K-steps per ring stage
     constexpr int KS = KSTEPS / KPS;                  // stages per 16-row tile
     typedef M16Shape<NW, NT, KPS> S;

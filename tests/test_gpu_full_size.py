@@ -89,7 +89,7 @@ def test_c2_full_size_properties(world):
         assert np.array_equal(g["score"].view(np.uint32), w["score"].view(np.uint32))
 
 
-@pytest.mark.parametrize("nq", [16, 32, 64])
+@pytest.mark.parametrize("nq", [16, 32, 64, 128])
 def test_c2_full_size_every_batch_shape(world, nq):
     """the kernel bench.py times — scan_f32_mfma16_kernel<6, 8, 4, LAG = true, IDS = false>, 64 queries per pass over
     the WHOLE block (its wave-lag schedule and phantom-stage tail depend on the tile count) — checked at the headline size, next to the 16-
@@ -101,7 +101,8 @@ def test_c2_full_size_every_batch_shape(world, nq):
     s = qa.BatchFilteredSearcher(queries, world["st"], TOP)
     full = s.peek_top_all()
     kernel = F.last_kernel(s.scorer._h)
-    assert "scan_f32_mfma16_kernel<6, %s" % {16: "4, 1", 32: "4, 2", 64: "8, 4"}[nq] in kernel, kernel
+    # (128 queries: the f16-split prefilter + exact verification, scan_split.hip)
+    assert ("scan_f32_split_kernel" if nq == 128 else "scan_f32_mfma16_kernel<6, %s" % {16: "4, 1", 32: "4, 2", 64: "8, 4"}[nq]) in kernel, kernel
     assert all(len(r) == TOP and np.all(np.diff(r["score"]) <= 0) for r in full)
     qa.set_option("no_mfma_scan", 1)
     try:

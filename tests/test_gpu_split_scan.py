@@ -1,0 +1,128 @@
+"""The split prefilter (qdrant_amd/csrc/scan_split.hip): f32 dot / cosine top-k of more than 64 queries over a large block runs 128
+queries per pass on the f16 matrix cores (x = h + l, three products), keeps every row whose approximate score is within a rigorous band
+of the running k-th best, and re-scores the survivors with the exact gather kernel.  The approximate scores never leave the library:
+the result must be the exact scan's — the oracle's — ids and score bits, ties included.  Whatever does not fit the buffers (masses of
+equal scores, a sample without live rows) raises a device flag and the exact scan runs behind it."""
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def qa():
+    import qdrant_amd
+    assert qdrant_amd.device_count() >= 1
+    return qdrant_amd
+
+
+def _same(got, want):
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g["idx"].tolist() == w["idx"].tolist()
+        assert np.array_equal(g["score"].view(np.uint32), w["score"].view(np.uint32))
+
+
+def _kernel(qa, searcher):
+    return qa._ffi.last_kernel(searcher.scorer._h)
+
+
+N = 300_000          # >= 2^18: the prefilter applies
+
+
+@pytest.mark.parametrize("distance,dim", [(O.COSINE, 128), (O.DOT, 256), (O.COSINE, 768)])
+@pytest.mark.parametrize("nq,top", [(65, 10), (128, 1), (200, 10), (130, 64)])
+def test_split_scan_returns_the_exact_scan(qa, distance, dim, nq, top):
+    n = N if dim < 768 else 270_000
+    rows = O.preprocess(distance, O.synth(0x5EED0500 + dim, 0, n, dim))
+    queries = O.synth(0x5EED0501 + nq, 0, nq, dim)
+    st = O.DenseStorage(O.F32, distance, rows)
+    vs = qa.VectorStorage(rows, qa.Distance.Cosine if distance == O.COSINE else qa.Distance.Dot)
+    s = qa.BatchFilteredSearcher(queries, vs, top)
+    got = s.peek_top_all()
+    if nq % 128 == 0 or nq % 128 > 64:
+        assert "scan_f32_split_kernel" in _kernel(qa, s), _kernel(qa, s)
+    _same(got, st.peek_top(queries, top, threads=8))
+    qa.set_option("no_split_scan", 1)                    # ... and the exact kernels agree (they are what the fallback runs)
+    try:
+        s2 = qa.BatchFilteredSearcher(queries, vs, top)
+        _same(s2.peek_top_all(), got)
+        assert "scan_f32_split_kernel" not in _kernel(qa, s2)
+    finally:
+        qa.set_option("no_split_scan", -1)
+
+
+def test_split_scan_with_deleted_rows_and_filter(qa):
+    n, dim, nq, top = N, 128, 100, 10
+    rng = np.random.default_rng(3)
+    rows = O.preprocess(O.COSINE, O.synth(0x5EED0510, 0, n, dim))
+    queries = O.synth(0x5EED0511, 0, nq, dim)
+    deleted = rng.random(n) < 0.4
+    vdel = rng.random(n) < 0.05
+    st = O.DenseStorage(O.F32, O.COSINE, rows, point_deleted=deleted, vec_deleted=vdel)
+    vs = qa.VectorStorage(rows, qa.Distance.Cosine)
+    vs.set_deleted(deleted, vdel)
+    s = qa.BatchFilteredSearcher(queries, vs, top)
+    got = s.peek_top_all()
+    assert "scan_f32_split_kernel" in _kernel(qa, s)
+    _same(got, st.peek_top(queries, top, threads=8))
+    for r in got:
+        assert not deleted[r["idx"]].any() and not vdel[r["idx"]].any()
+    # payload filter as an allow bitmap on top of the deleted flags
+    allowed = rng.random(n) < 0.3
+    s.scorer.set_filter(allowed)
+    st_f = O.DenseStorage(O.F32, O.COSINE, rows, point_deleted=deleted | ~allowed, vec_deleted=vdel)
+    _same(s.peek_top_all(), st_f.peek_top(queries, top, threads=8))
+
+
+def test_split_scan_falls_back_when_scores_tie_in_masses(qa):
+    """Every row exists 400 times: the verification band holds 400 x k rows per query, more than the list takes -> the overflow flag
+    -> the exact scan runs behind the prefilter in the same stream.  Equal scores come back in ascending id order, like the oracle's."""
+    dim, nq, top, rep = 64, 70, 10, 400
+    base = O.preprocess(O.COSINE, O.synth(0x5EED0520, 0, N // rep, dim))
+    rows = np.tile(base, (rep, 1))                       # row i == row i + len(base)
+    queries = O.synth(0x5EED0521, 0, nq, dim)
+    st = O.DenseStorage(O.F32, O.COSINE, rows)
+    vs = qa.VectorStorage(rows, qa.Distance.Cosine)
+    got = qa.BatchFilteredSearcher(queries, vs, top).peek_top_all()
+    want = st.peek_top(queries, top)                      # sequential: the linear scan keeps the FIRST of equal scores (strict <, :53-57)
+    for g, w in zip(got, want):
+        assert np.array_equal(g["score"].view(np.uint32), w["score"].view(np.uint32))
+        # the same rows up to the choice among copies; the k best copies are the k lowest ids of the best row(s)
+        assert sorted((g["idx"] % len(base)).tolist()) == sorted((w["idx"] % len(base)).tolist())
+        assert sorted(g["idx"].tolist()) == sorted(w["idx"].tolist())
+        for i in range(len(g) - 1):
+            if g["score"][i] == g["score"][i + 1]:
+                assert g["idx"][i] < g["idx"][i + 1]      # equal scores come back in ascending id order
+
+
+def test_split_scan_when_the_sample_is_all_deleted(qa):
+    """The strided sample (every 32nd row here) is deleted entirely: no threshold -> every row is a candidate -> the candidate buffers
+    overflow -> the exact scan takes over.  Same result as ever."""
+    n, dim, nq, top = N, 64, 80, 5
+    rows = O.preprocess(O.COSINE, O.synth(0x5EED0530, 0, n, dim))
+    queries = O.synth(0x5EED0531, 0, nq, dim)
+    S = max(n >> 10, 8192)
+    step = n // S
+    deleted = np.zeros(n, dtype=bool)
+    deleted[::step] = True
+    st = O.DenseStorage(O.F32, O.COSINE, rows, point_deleted=deleted)
+    vs = qa.VectorStorage(rows, qa.Distance.Cosine)
+    vs.set_deleted(deleted, None)
+    _same(qa.BatchFilteredSearcher(queries, vs, top).peek_top_all(), st.peek_top(queries, top, threads=8))
+
+
+@pytest.mark.parametrize("row_mag,query_mag", [(1000.0, 1e-3), (1e-4, 1e4), (37.0, 1.0)])
+def test_split_scan_dot_with_any_magnitudes(qa, row_mag, query_mag):
+    """Dot distance, un-normalised rows: the power-of-two scales come from max |x| of the block and of the batch."""
+    n, dim, nq, top = N, 128, 90, 10
+    rows = (O.synth(0x5EED0540, 0, n, dim) * np.float32(row_mag)).astype(np.float32)
+    queries = (O.synth(0x5EED0541, 0, nq, dim) * np.float32(query_mag)).astype(np.float32)
+    st = O.DenseStorage(O.F32, O.DOT, rows)
+    vs = qa.VectorStorage(rows, qa.Distance.Dot)
+    s = qa.BatchFilteredSearcher(queries, vs, top)
+    got = s.peek_top_all()
+    assert "scan_f32_split_kernel" in _kernel(qa, s)
+    _same(got, st.peek_top(queries, top, threads=8))
