@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--cpu-rows", type=int, default=1_000_000, help="rows of the CPU-baseline sample")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--split-copy", choices=["half", "pair", "none"], default="half",
+                    help="Q > 64: which derived copy of the block the prefilter scans (half: f16 high parts, 2 B / element; pair: f16 pairs, 4 B; none: the f32 block itself)")
     ap.add_argument("--no-hbm-point", action="store_true", help="skip the secondary Q=16 (HBM-bound) measurement of the same scan")
     ap.add_argument("--verify", type=int, default=1, help="check samples against the oracle (C2 first batch, C3 / C4 scans and walks)")
     ap.add_argument("--configs", default="c3,c4", help="comma list of the secondary single-GPU configs to run (empty = none)")
@@ -122,7 +124,9 @@ def main():
     rows = torch.empty((n, dim), dtype=torch.float32, device=dev)
     F.check(lib.qmx_synth_fill_f32(local_rank, row_seed, row0, n, dim, F.ptr(rows)))
     F.check(lib.qmx_preprocess_f32(local_rank, int(qa.Distance.Cosine), F.ptr(rows), n, dim, F.ptr(rows)))
-    storage = qa.VectorStorage(rows, qa.Distance.Cosine, device_id=local_rank)
+    # (+ the f16-pair copy of the block when batches of more than 64 queries will scan it: scan_split.hip; 4 more bytes per element)
+    copy_flag = {"none": 0, "pair": F.SEG_SPLIT_COPY, "half": F.SEG_HALF_COPY}[args.split_copy] if Q > 64 else 0
+    storage = qa.VectorStorage(rows, qa.Distance.Cosine, device_id=local_rank, flags=copy_flag)
 
     nbatches = max(1, args.nqueries // Q)
     queries = torch.empty((nbatches * Q, dim), dtype=torch.float32, device=dev)

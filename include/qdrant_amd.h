@@ -106,6 +106,16 @@ typedef struct qmx_counters {
  * the reference's own quantization tests also build the opposite pairing (lib/quantization/tests/integration/
  * test_binary.rs:77 `test_binary_dot_inverted`, :129 l1 not inverted): this flag toggles `invert`. */
 #define QMX_SEG_BQ_TOGGLE_INVERT 0x8u
+/* f32 dot / cosine blocks: also keep the block as f16 PAIRS (x 2^e = h + l exactly to 2^-22, 4 bytes per element like the original) in the
+ * layout the matrix cores read.  Batches of more than 64 queries then scan that copy at the HBM rate and re-score the few survivors from
+ * the f32 original: the results stay the reference's bits (qdrant_amd/csrc/scan_split.hip).  Costs a second copy of the block in HBM; if it
+ * does not fit the segment is created without it.  (The reference keeps derived copies of a storage the same way: its quantized storages.) */
+#define QMX_SEG_SPLIT_COPY 0x10u
+/* The same with the HIGH parts only (x 2^e ~ h, 2 bytes per element, half the block again in HBM): the prefilter then reads half the bytes
+ * and multiplies once per element instead of three times; its band is 10x wider (each operand is within 2^-11 of its value), so a few more
+ * rows are re-scored exactly.  Results are still the reference's bits; data whose best scores crowd inside 1e-3 |q| |row| of each other
+ * overflow the verification list and take the exact scan instead. */
+#define QMX_SEG_HALF_COPY 0x20u
 
 /* SQ-int8 parameters = `MetadataInt8` (lib/quantization/src/encoded_vectors_u8.rs:84-91).
  * Parity is defined on GIVEN (alpha, offset): the reference's quantile estimate samples

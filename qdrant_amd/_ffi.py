@@ -22,6 +22,8 @@ SEG_DATA_ON_DEVICE = 0x1
 SEG_U8_SCALAR_ORDER = 0x2
 SEG_TIME_KERNELS = 0x4
 SEG_BQ_TOGGLE_INVERT = 0x8
+SEG_SPLIT_COPY = 0x10
+SEG_HALF_COPY = 0x20
 
 
 class ScoredPoint(C.Structure):

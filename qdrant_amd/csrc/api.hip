@@ -171,6 +171,8 @@ struct qmx_segment {
     // f32 dot / cosine blocks large enough for the split prefilter (scan_split.hip): max |x| and max row norm, taken once at create
     bool split_stats = false;
     float row_maxabs = 0.f, row_norm_max = 0.f;
+    void *d_rows_split = nullptr;     // QMX_SEG_SPLIT_COPY / QMX_SEG_HALF_COPY: the block as f16 pairs / f16 high parts in the matrix cores' LDS layout
+    bool split_half = false;          // ... which of the two
 
     bool fast_layout() const {
         if (dtype == QMX_DTYPE_BQ) return row_stride % 16 == 0 && ((uintptr_t)d_rows % 16) == 0;
@@ -376,6 +378,7 @@ static void segment_free(qmx_segment *seg) {
     if (seg->d_vec_deleted) (void)hipFree(seg->d_vec_deleted);
     if (seg->d_centroids) (void)hipFree(seg->d_centroids);
     if (seg->d_pq_pair) (void)hipFree(seg->d_pq_pair);
+    if (seg->d_rows_split) (void)hipFree(seg->d_rows_split);
     if (seg->d_row_offsets) (void)hipFree(seg->d_row_offsets);
     if (seg->d_bq_mean) (void)hipFree(seg->d_bq_mean);
     if (seg->d_bq_stddev) (void)hipFree(seg->d_bq_stddev);
@@ -446,6 +449,18 @@ static int32_t segment_split_stats(qmx_segment *s) {
     memcpy(&mss, &h[1], 4);
     s->row_norm_max = sqrtf(mss);
     s->split_stats = s->row_maxabs > 0.f && s->row_maxabs < 3.0e38f && s->row_norm_max < 3.0e38f;   // (NaN / inf rows: the exact scan only)
+    if (s->split_stats && (s->flags & (QMX_SEG_SPLIT_COPY | QMX_SEG_HALF_COPY)) && s->dim % 128 == 0) {
+        // the derived copy (one pass: read 4 B, write 4 or 2 B per element).  Out of memory is not an error: the converting kernel serves.
+        s->split_half = (s->flags & QMX_SEG_HALF_COPY) != 0;
+        if (hipMalloc(&s->d_rows_split, split_copy_bytes(s->n, s->dim, s->split_half)) != hipSuccess) {
+            (void)hipGetLastError();
+            s->d_rows_split = nullptr;
+            s->split_half = false;
+        } else {
+            QMX_TRY(launch_split_copy(nullptr, s->d_rows, s->row_stride, s->n, s->dim, split_row_scale(s->row_maxabs), s->d_rows_split, s->split_half));
+            QMX_HIP(hipDeviceSynchronize());
+        }
+    }
     return QMX_OK;
 }
 
@@ -1193,7 +1208,8 @@ static int32_t split_stage(qmx_query *q, const char *what) {
 
 constexpr uint32_t SPLIT_QT = 128;          // queries per pass of the split prefilter (scan_split.hip)
 constexpr uint32_t SPLIT_CAND_CAP = 32768;  // candidate keys per query and pass (expected: ~1000 k)
-constexpr uint32_t SPLIT_VCAP = 128;        // rows per query that get an exact score (expected: ~k)
+constexpr uint32_t SPLIT_VCAP = 512;        // rows per query that get an exact score (expected: ~k; the one-product mode's band holds more)
+constexpr float SPLIT_REL_BAND_HALF = 1.0e-3f;   // one product of f16-rounded operands: each within 2^-11 of its value -> 2^-10 |x y| per term
 constexpr float SPLIT_REL_BAND = 1.0e-4f;   // |approximate - exact| <= band * |q| * max |row|: 100x the split error, above the worst-case f32
                                             // accumulation bounds of both sides (dim * 2^-24 each) up to dim 1600
 
@@ -1218,7 +1234,7 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
                      !option(OPT_NO_MFMA16);
     // more than 64 queries over a large f32 dot / cosine block: 128 per pass through the f16-split matrix-core prefilter, the survivors
     // re-scored exactly (scan_split.hip); the result is the exact scan's, bit for bit
-    const bool split = q64 && s->split_stats && !d_ids && top <= MAX_TOP_FAST && n_cand >= (1u << 18) && s->dim % 32 == 0 && s->row_stride % 16 == 0 &&
+    const bool split = q64 && s->split_stats && !d_ids && top <= MAX_TOP_FAST && n_cand >= (1u << 18) && s->dim % 128 == 0 && s->row_stride % 16 == 0 &&
                        !option(OPT_NO_SPLIT_SCAN);
     const uint32_t TQ = split ? SPLIT_QT : q64 ? MAX_QT_TOPK : q32 ? MAX_QT_MFMA : tile_qt(s);
     const uint32_t ptop_max = std::min<uint32_t>(top, MAX_TOP_FAST);
@@ -1239,8 +1255,9 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
         QMX_TRY(q->sp_vscores.reserve((size_t)q->nq * SPLIT_VCAP * 4));
         float *f = (float *)q->sp_f32.p;
         sp_qnorm = f; sp_thr = f + 128; sp_band = f + 256; sp_scales = f + 384; sp_overflow = (int *)(f + 392);
-        // the sample: every (n_cand / S)-th row, S = n_cand / 1024 (at least 8192)
-        const uint64_t S = std::min<uint64_t>(n_cand, std::max<uint64_t>(n_cand >> 10, 8192));
+        // the sample: every (n_cand / S)-th row, S = n_cand / 128 (at least 8192): its k-th best leaves ~128 k candidates per query to the
+        // main pass (one in 8 (wave, tile) pairs holds one), at 1 / 128 of the pass's row traffic for the sample's exact scores
+        const uint64_t S = std::min<uint64_t>(n_cand, std::max<uint64_t>(n_cand >> 7, 8192));
         if (q->sp_sample_n != S || q->sp_sample_of != n_cand) {
             QMX_TRY(q->sp_sample.reserve((size_t)S * 4));
             ::qmx::clear_stale_error();
@@ -1285,16 +1302,18 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
             QMX_TRY(split_stage(q, "prescan"));
             // 2. the batch's queries split into f16 pairs; thresholds and bands in accumulator / score units
             const float row_scale = split_row_scale(s->row_maxabs);
+            const int half = s->split_half ? 1 : 0;
             QMX_TRY(launch_split_pack_queries(q->stream, (const float *)q->enc.p + (size_t)tile0 * s->dim, nq_tile, s->dim, row_scale, (uint32_t *)(sp_scales + 4),
-                                              sp_qnorm, sp_scales, q->sp_bq.p));
-            QMX_TRY(launch_split_thresholds(q->stream, gthr, sp_qnorm, nq_tile, SPLIT_REL_BAND, s->row_norm_max, sp_scales, sp_thr, sp_band));
+                                              sp_qnorm, sp_scales, q->sp_bq.p, half));
+            QMX_TRY(launch_split_thresholds(q->stream, gthr, sp_qnorm, nq_tile, half ? SPLIT_REL_BAND_HALF : SPLIT_REL_BAND, s->row_norm_max, sp_scales, sp_thr,
+                                            sp_band));
             QMX_HIP(hipMemsetAsync(q->sp_cnt.p, 0, (size_t)SPLIT_QT * 4, q->stream));
             QMX_TRY(split_stage(q, "pack + thresholds"));
             // 3. the approximate scan of the whole block
             size_t slot = 0;
             if (timed) QMX_TRY(timing_begin(q, &slot));
             QMX_TRY(launch_scan_f32_split(q->stream, a, q->sp_bq.p, row_scale, sp_scales, sp_thr, (uint64_t *)q->sp_cand.p, (uint32_t *)q->sp_cnt.p, SPLIT_CAND_CAP,
-                                          s->num_cus));
+                                          s->num_cus, s->d_rows_split, half));
             q->last_kernel = g_last_kernel;
             if (timed) QMX_TRY(timing_end(q, slot));
             QMX_TRY(split_stage(q, "split kernel"));

@@ -37,21 +37,24 @@ typedef float f32x4s __attribute__((ext_vector_type(4)));
 
 constexpr int SP_BM = 256;            // rows per tile
 constexpr int SP_QT = 128;            // queries per pass
-constexpr int SP_THREADS = 512;
+constexpr int SP_THREADS = 768;          // 8 consumer waves (matrix cores) + 4 producer waves (HBM stream, f32 -> f16 pairs): 2 + 1 per SIMD
+constexpr int SP_CONSUMERS = 8;
 constexpr int SP_A_UNITS = SP_BM * 2 * 4;     // 16-byte units of one A chunk buffer (256 rows x {h, l} x 4 k-groups) = 32 KB
 constexpr int SP_B_UNITS = SP_QT * 2 * 4;     // ... of one B chunk buffer = 16 KB
-constexpr int SP_LDS = (2 * SP_A_UNITS + 2 * SP_B_UNITS) * 16;
+constexpr int SP_BRING = 4;           // LDS buffers of the queries' chunks: an LDS-DMA copy lands ~1.1 us after its issue (MI355X guide, ldsdma-fill),
+                                      // longer than a stage lasts, so chunk g + 3 is requested while chunk g is multiplied
+constexpr int SP_LDS = (2 * SP_A_UNITS + SP_BRING * SP_B_UNITS) * 16;
 
 // unit index of (16-row or 16-query tile t, half hl, k-group kq, row-in-tile m) inside a chunk buffer
 __device__ __forceinline__ uint32_t sp_unit(uint32_t t, uint32_t hl, uint32_t kq, uint32_t m) { return ((t * 2 + hl) * 4 + kq) * 16 + (m ^ (2 * kq)); }
 
 // x * scale = h + l (+ a residual below 2^-22 |x * scale|); round to nearest even both times
+// (scale is a power of two, so x * scale is exact and fma(x, scale, -h) == x * scale - h: two v_fma_mix instructions per value)
 __device__ __forceinline__ void sp_split4(const f32x4s v, float scale, half4 &h, half4 &l) {
-    const float x[4] = {v[0] * scale, v[1] * scale, v[2] * scale, v[3] * scale};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        h[i] = (_Float16)x[i];
-        l[i] = (_Float16)(x[i] - (float)h[i]);
+        h[i] = (_Float16)__builtin_fmaf(v[i], scale, 0.0f);
+        l[i] = (_Float16)__builtin_fmaf(v[i], scale, -(float)h[i]);
     }
 }
 
@@ -98,22 +101,26 @@ __global__ void sp_scales_kernel(const uint32_t *stats, float row_scale, float *
     scales[2] = 1.0f / (row_scale * qs);
 }
 // one thread per 16-byte unit: bq[kc][nt][hl][kq][n ^ 2 kq] = 8 halfs, k = 32 kc + 8 kq + e, query 16 nt + n (zero beyond nq)
-__global__ void sp_pack_queries_kernel(const float *q, uint32_t nq, uint32_t dim, const float *scales, uint4 *bq) {
+// half != 0 (the one-product mode): a chunk is 64 floats, the two unit planes hold the high parts of its two 32-float halves
+__global__ void sp_pack_queries_kernel(const float *q, uint32_t nq, uint32_t dim, const float *scales, uint4 *bq, int half) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t nchunks = dim / 32;
-    if (gid >= nchunks * SP_QT * 4) return;
-    const uint32_t kc = gid / (SP_QT * 4), r = gid % (SP_QT * 4);
+    if (gid >= (dim / 32) * SP_QT * 4) return;
+    const uint32_t k32 = gid / (SP_QT * 4), r = gid % (SP_QT * 4);          // 32-float group of the row
     const uint32_t nt = r / 64, kq = (r / 16) % 4, n = r % 16;
     const uint32_t qi = nt * 16 + n;
     const float scale = scales[0];
     half8 h, l;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const float x = qi < nq ? q[(uint64_t)qi * dim + kc * 32 + kq * 8 + e] * scale : 0.0f;
+        const float x = qi < nq ? q[(uint64_t)qi * dim + k32 * 32 + kq * 8 + e] * scale : 0.0f;
         h[e] = (_Float16)x;
         l[e] = (_Float16)(x - (float)h[e]);
     }
-    uint4 *chunk = bq + (uint64_t)kc * SP_B_UNITS;
+    if (half) {
+        bq[(uint64_t)(k32 / 2) * SP_B_UNITS + sp_unit(nt, k32 & 1u, kq, n)] = *reinterpret_cast<const uint4 *>(&h);
+        return;
+    }
+    uint4 *chunk = bq + (uint64_t)k32 * SP_B_UNITS;
     chunk[sp_unit(nt, 0, kq, n)] = *reinterpret_cast<const uint4 *>(&h);
     chunk[sp_unit(nt, 1, kq, n)] = *reinterpret_cast<const uint4 *>(&l);
 }
@@ -147,56 +154,123 @@ struct SplitArgs {
     float row_scale;        // power of two applied to the rows before the split
     const float *scales;    // device: [1] = accumulator units per score unit, [2] = inverse
     const float *thr;       // [128] candidate threshold, accumulator units
+    const uint4 *rows_split; // the pre-split copy of the block (scan_f16pair_kernel), or nullptr
     uint64_t *cand;         // [128][cap] keys (approximate score, row)
     uint32_t *cand_cnt;     // [128] appended (may run past cap: overflow)
     uint32_t cap;
 };
 
-__global__ __launch_bounds__(SP_THREADS, 1) __attribute__((amdgpu_waves_per_eu(1, 2))) void scan_f32_split_kernel(const ScanArgs a, const SplitArgs s) {
+// The stage barrier.  NOT __syncthreads(): its workgroup fence makes the compiler wait for every outstanding global load (vmcnt(0)) in front of
+// the barrier, which would drain the producers' row stream at every stage (measured: a stage then lasts one loaded HBM round trip, 2.3 us).
+// LDS traffic is all that crosses this barrier: wait for this wave's LDS operations, then s_barrier.
+__device__ __forceinline__ void sp_stage_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+__global__ __launch_bounds__(SP_THREADS, 1) void scan_f32_split_kernel(const ScanArgs a, const SplitArgs s) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint4 *lds = reinterpret_cast<uint4 *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t wm = (uint32_t)w & 3u, wn = (uint32_t)w >> 2;
     const unsigned char *rows = reinterpret_cast<const unsigned char *>(a.rows);
     const uint64_t n_tiles = (a.n_cand + SP_BM - 1) / SP_BM;
-    const uint32_t nch = s.nchunks;
-    const float rscale = s.row_scale;
+    const uint32_t nch = s.nchunks;                       // a multiple of 4 (the host takes this path for dim % 128 == 0)
+    const uint64_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const uint64_t G = my_tiles * nch;                    // stages of this block = its (tile, K-chunk) pairs, in order
+    if (G == 0) return;
 
-    // loader role: rows 32 w + 8 j + (lane >> 3), j = 0..3, 16-byte piece p = lane & 7 of the chunk's 128 bytes
-    const uint32_t p = (uint32_t)lane & 7u, lrow0 = (uint32_t)w * 32u + ((uint32_t)lane >> 3);
-    const uint32_t kq_w = p >> 1;                      // k-group of the piece
-    uint32_t a_wr[4];                                  // byte offsets of this thread's 8-byte stores inside an A buffer (h half; l is + 64 units)
+    if (w >= SP_CONSUMERS) {
+        // ================= producers (4 waves): HBM -> registers -> split -> LDS, one K-chunk per stage, three chunks of rows in flight ==========
+        // rows 64 pw + 8 rr + (lane >> 3), rr = 0..7, 16-byte piece p = lane & 7 of the chunk's 128 bytes: a wave instruction reads 8 rows x one
+        // full 128-byte line, every byte once
+        const uint32_t pw = (uint32_t)w - SP_CONSUMERS;
+        const uint32_t p = (uint32_t)lane & 7u, lrow0 = pw * 64u + ((uint32_t)lane >> 3);
+        const float rscale = s.row_scale;
+        // byte offset of this thread's 8-byte stores inside an A buffer: row rl = lrow0 + 8 rr -> tile rl >> 4 = 4 pw + (rr >> 1), row-in-tile
+        // (lane >> 3) + 8 (rr & 1); h half (l is + 64 units)
+        const uint32_t kq_w = p >> 1;
+        uint32_t a_wr[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t rl = lrow0 + 8u * (uint32_t)j;
-        a_wr[j] = sp_unit(rl >> 4, 0, kq_w, rl & 15u) * 16u + (p & 1u) * 8u;
+        for (int e = 0; e < 2; ++e) a_wr[e] = sp_unit(pw * 4u, 0, kq_w, ((uint32_t)lane >> 3) + 8u * (uint32_t)e) * 16u + (p & 1u) * 8u;
+        f32x4s areg[3][8];                                // [slot = chunk % 3][rr]
+        // the tile's first row through SGPRs + one 32-bit lane offset per row group: no 64-bit vector address arithmetic per load
+        typedef const __attribute__((address_space(1))) unsigned char *sp_gptr;   // (an explicit global pointer: rebuilt from SGPR halves, it would be "flat")
+        sp_gptr tile_base = (sp_gptr)(uintptr_t)rows;     // wave-uniform: row 0 of the tile being requested
+        uint32_t voff[8];                                 // lane part: (row-in-tile) * stride + 16 p, clamped to the rows that exist
+        uint64_t ld_g = 0, ld_it = 0;                     // next chunk to request: global index, its tile iteration
+        uint32_t ld_kc = 0;
+        auto set_tile = [&](uint64_t it) {
+            const uint64_t tile = blockIdx.x + it * gridDim.x;
+            const uint64_t first = tile * SP_BM;
+            const uint64_t left = a.n_cand - first;       // rows of the tile that exist (> 0: the tile is one of this block's)
+            const uint64_t tb = (uint64_t)(uintptr_t)(rows + first * a.row_stride);
+            tile_base = (sp_gptr)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(tb >> 32)) << 32) |
+                                             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tb));
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {              // rows past the end of the block re-read its last row: results masked
+                const uint64_t rl = lrow0 + 8u * (uint32_t)rr;
+                voff[rr] = (uint32_t)((rl < left ? rl : left - 1) * a.row_stride) + p * 16u;
+            }
+        };
+        auto issue = [&](int slot) {                      // request the next chunk into register slot `slot`
+            if (ld_g >= G) return;
+            sp_gptr cb = tile_base + ld_kc * 128u;
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr)
+                areg[slot][rr] = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) f32x4s *>(cb + voff[rr]));
+            ++ld_g;
+            if (++ld_kc == nch) {
+                ld_kc = 0;
+                ++ld_it;
+                if (ld_g < G) set_tile(ld_it);
+            }
+        };
+        auto convert = [&](int slot, uint32_t buf) {      // slot -> A buffer `buf`
+            unsigned char *ab = reinterpret_cast<unsigned char *>(lds + buf * SP_A_UNITS);
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                half4 h, l;
+                sp_split4(areg[slot][rr], rscale, h, l);
+                const uint32_t off = a_wr[rr & 1] + (uint32_t)(rr >> 1) * (128u * 16u);   // + one 16-row tile (128 units) per two rr
+                *reinterpret_cast<half4 *>(ab + off) = h;
+                *reinterpret_cast<half4 *>(ab + off + 64 * 16) = l;
+            }
+        };
+        set_tile(0);
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl) issue(sl);
+        convert(0, 0);
+        issue(0);
+        sp_stage_barrier();                                  // stage 0 may start
+        for (uint64_t g = 0; g < G; g += 6) {             // (unrolled by 6: the register slot is g % 3, the LDS buffer g % 2)
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                if (g + u >= G) break;
+                // stage g + u: the consumers multiply buffer (g + u) & 1 while chunk g + u + 1 is prepared in the other one
+                if (g + u + 1 < G) {
+                    convert((u + 1) % 3, (uint32_t)(u + 1) & 1u);
+                    issue((u + 1) % 3);
+                }
+                sp_stage_barrier();
+            }
+        }
+        return;
     }
-    // MFMA role: A units of row tile 4 wm + mt, B units of query tile 4 wn + nt; k-group lane >> 4, row / query lane & 15
+
+    // ================= consumers (8 waves = 4 row quarters x 2 query halves): LDS -> matrix cores, candidates of every finished tile ==========
+    const uint32_t wm = (uint32_t)w & 3u, wn = (uint32_t)w >> 2;
     const uint32_t kq_r = (uint32_t)lane >> 4, m_r = (uint32_t)lane & 15u;
     const uint32_t a_rd = sp_unit(wm * 4, 0, kq_r, m_r), b_rd = sp_unit(wn * 4, 0, kq_r, m_r);   // + 128 units per tile, + 64 for the l half
-
     float thr[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) thr[nt] = s.thr[wn * 64 + nt * 16 + m_r];
     const float inv_scale = s.scales[2];
-
-    f32x4s areg[4];
-    const unsigned char *rowp[4];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(sp_lds_byte *)smem_raw;
     const uint32_t lane_off = (uint32_t)lane * 16u;
-    auto set_tile = [&](uint64_t tile) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            uint64_t r = tile * SP_BM + lrow0 + 8u * (uint32_t)j;
-            if (r >= a.n_cand) r = a.n_cand - 1;         // rows past the end: any valid row, results masked
-            rowp[j] = rows + r * a.row_stride + p * 16u;
-        }
-    };
-    // rows of chunk kc -> registers; the queries' chunk kc -> LDS buffer `bbuf` directly (this wave's 2 KiB of its 16 KiB)
-    auto load_chunk = [&](uint32_t kc, uint32_t bbuf) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) areg[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4s *>(rowp[j] + kc * 128u));
+    // the queries' chunk kc -> LDS buffer `bbuf` directly (this wave's 2 KiB of its 16 KiB): the only vector-memory traffic of a consumer
+    auto load_b = [&](uint32_t kc, uint32_t bbuf) {
         const unsigned char *bsrc = reinterpret_cast<const unsigned char *>(s.bq + (uint64_t)kc * SP_B_UNITS) + (uint32_t)w * 2048u;
         const uint32_t dst = lds0 + (2u * SP_A_UNITS + bbuf * SP_B_UNITS) * 16u + (uint32_t)w * 2048u;
         // (wave-uniform base through SGPRs; readfirstlane returns a signed int: widen the halves as unsigned)
@@ -206,42 +280,32 @@ __global__ __launch_bounds__(SP_THREADS, 1) __attribute__((amdgpu_waves_per_eu(1
         sp_glds16(ub, lane_off, dst);
         sp_glds16(ub + 1024u, lane_off, dst + 1024u);
     };
-    auto store_chunk = [&](uint32_t buf) {
-        unsigned char *ab = reinterpret_cast<unsigned char *>(lds + buf * SP_A_UNITS);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            half4 h, l;
-            sp_split4(areg[j], rscale, h, l);
-            *reinterpret_cast<half4 *>(ab + a_wr[j]) = h;
-            *reinterpret_cast<half4 *>(ab + a_wr[j] + 64 * 16) = l;
-        }
+    // chunks 0, 1, 2 are on their way before stage 0; every stage requests one more (indices wrap: the queries are the same for every tile;
+    // the requests past the last stage land in buffers nobody reads) so that the count of outstanding copies is the same at every wait
+    uint32_t b_kc = 0;                                    // K-chunk of the next request
+    uint32_t b_slot = 0;                                  // ... and its ring slot
+    auto request_b = [&]() {
+        load_b(b_kc, b_slot);
+        b_kc = b_kc + 1 == nch ? 0 : b_kc + 1;
+        b_slot = (b_slot + 1) & (SP_BRING - 1);
     };
-
-    uint32_t buf = 0;
-    uint64_t tile = blockIdx.x;
-    if (tile < n_tiles) {
-        set_tile(tile);
-        load_chunk(0, 0);
-    }
-    for (; tile < n_tiles; tile += gridDim.x) {
+    request_b();
+    request_b();
+    request_b();
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // chunk 0 has landed (2 copies per chunk and wave; chunks 1 and 2 may still travel)
+    sp_stage_barrier();
+    uint32_t buf = 0, bbuf = 0;
+    for (uint64_t it = 0; it < my_tiles; ++it) {
+        const uint64_t tile = blockIdx.x + it * gridDim.x;
         f32x4s acc[4][4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4s){0.f, 0.f, 0.f, 0.f};
         for (uint32_t kc = 0; kc < nch; ++kc) {
-            store_chunk(buf);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the queries' chunk (LDS-DMA, not counted by the compiler) has landed
-            __syncthreads();
-            // the next chunk (of this tile or of the block's next one) travels while this one is multiplied
-            if (kc + 1 < nch) {
-                load_chunk(kc + 1, buf ^ 1);
-            } else if (tile + gridDim.x < n_tiles) {
-                set_tile(tile + gridDim.x);
-                load_chunk(0, buf ^ 1);
-            }
+            request_b();                                  // chunk g + 3 -> the slot chunk g - 1 was read from (everybody is past that stage's barrier)
             const uint4 *ab = lds + buf * SP_A_UNITS + a_rd;
-            const uint4 *bb = lds + 2 * SP_A_UNITS + buf * SP_B_UNITS + b_rd;
+            const uint4 *bb = lds + 2 * SP_A_UNITS + bbuf * SP_B_UNITS + b_rd;
             half8 bh[4], bl[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
@@ -253,33 +317,255 @@ __global__ __launch_bounds__(SP_THREADS, 1) __attribute__((amdgpu_waves_per_eu(1
                 const half8 ah = *reinterpret_cast<const half8 *>(ab + mt * 128);
                 const half8 al = *reinterpret_cast<const half8 *>(ab + mt * 128 + 64);
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[nt], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[nt], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[nt], acc[mt][nt], 0, 0, 0);
-                }
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[nt], acc[mt][nt], 0, 0, 0);
             }
             buf ^= 1;
+            bbuf = (bbuf + 1) & (SP_BRING - 1);
+            if (kc + 1 == nch) {
+                // ---- candidates of the tile: accumulator register j of (mt, nt) = row 64 wm + 16 mt + 4 (lane >> 4) + j, query 64 wn + 16 nt + (lane & 15)
+                const uint32_t row0 = (uint32_t)(tile * SP_BM) + wm * 64 + 4 * kq_r;      // (row ids are u32: PointOffsetType)
+                const uint32_t n_rows32 = (uint32_t)a.n_cand;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float v = acc[mt][nt][j];
+                            const uint32_t row = row0 + (uint32_t)mt * 16 + (uint32_t)j;
+                            const bool c = !(v < thr[nt]) && row < n_rows32;           // NaN (greatest in OrderedFloat) is a candidate; thr = +inf past nq
+                            if (__ballot(c)) {
+                                uint32_t q = wn * 64 + (uint32_t)nt * 16 + m_r;
+                                asm volatile("" : "+v"(q));                            // (keeps the buffer addresses out of the registers of the main loop)
+                                if (c && q < s.nq && a.del.live(row)) {
+                                    const uint32_t slot = atomicAdd(&s.cand_cnt[q], 1u);
+                                    if (slot < s.cap) s.cand[(uint64_t)q * s.cap + slot] = make_key(v * inv_scale, row);
+                                }
+                            }
+                        }
+                    }
+            }
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // the queries' NEXT chunk has landed (the two behind it may still travel)
+            sp_stage_barrier();
         }
-        // ---- candidates of the tile: accumulator register j of (mt, nt) = row 64 wm + 16 mt + 4 (lane >> 4) + j, query 64 wn + 16 nt + (lane & 15)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // nothing may land in LDS after the block is gone
+}
+
+// =====================================================================================================================================
+// The same scan over a PRE-SPLIT copy of the block (QMX_SEG_SPLIT_COPY): the f16 pairs are made once, when the segment is created, and laid
+// out in HBM as the LDS images the multiplication wants — [256-row tile][K-chunk][2048 16-byte units] — so a stage's 32 KiB of rows are ONE
+// contiguous run that the waves copy straight into LDS (LDS-DMA, 1 KiB per wave instruction, no registers, no vector-ALU work at all).
+// The vector ALU shares its issue port with the matrix instructions (measured on the converting kernel above: 33 % VALU + 36 % MFMA busy,
+// not overlapped), so taking the conversion out of the scan is what lets the pass run at the HBM stream.  Costs a second copy of the
+// block in HBM (4 bytes per element, like the f32 original, which stays: the verification gathers from it).
+// block = 512 threads = 8 waves (4 row quarters x 2 query halves), every wave multiplies and copies; three-deep rings for rows and queries
+// (a copy lands ~1.1 us after its issue, a stage lasts ~0.7 us): stage g requests stage g + 2 and multiplies stage g.
+// =====================================================================================================================================
+constexpr int SP3_THREADS = 512;
+constexpr int SP3_BM = SP_BM;                                // 256 rows per tile: a stage is 32 KiB of rows + 16 KiB of queries
+constexpr int SP3_A_UNITS = SP_A_UNITS;
+constexpr int SP3_ARING = 3;                                 // row stages in LDS: one being multiplied, two on their way
+constexpr int SP3_BRING = 4;                                 // query stages: one being multiplied, three requested
+constexpr int SP3_LDS = (SP3_ARING * SP3_A_UNITS + SP3_BRING * SP_B_UNITS) * 16;      // 96 + 64 = 160 KiB: the whole LDS of the CU
+
+template <bool HALF /* one product per element (high parts only, 64-float chunks) instead of three */>
+__global__ __launch_bounds__(SP3_THREADS, 1) void scan_f16pair_kernel(const ScanArgs a, const SplitArgs s) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint4 *lds = reinterpret_cast<uint4 *>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint64_t n_tiles = (a.n_cand + SP3_BM - 1) / SP3_BM;
+    const uint32_t nch = s.nchunks;
+    const uint64_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    if (my_tiles == 0) return;
+    const uint32_t wm = (uint32_t)w & 3u, wn = (uint32_t)w >> 2;
+    const uint32_t kq_r = (uint32_t)lane >> 4, m_r = (uint32_t)lane & 15u;
+    const uint32_t a_rd = sp_unit(wm * 4, 0, kq_r, m_r), b_rd = sp_unit(wn * 4, 0, kq_r, m_r);
+    float thr[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) thr[nt] = s.thr[wn * 64 + nt * 16 + m_r];
+    const float inv_scale = s.scales[2];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // from here on the kernel counts its vector-memory traffic itself
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(sp_lds_byte *)smem_raw;
+    const uint32_t lane_off = (uint32_t)lane * 16u;
+    uint4 *b_lds = lds + SP3_ARING * SP3_A_UNITS;
+    // The copy streams (LDS-DMA, 1 KiB per wave instruction): stage = (tile iteration, K-chunk) in order; per stage a wave copies 4 KiB of the
+    // rows (from HBM) and 2 KiB of the queries (from L2).  The vector-memory counter retires in order, so the order of the requests fixes what a
+    // wait can mean: at stage g a wave requests [queries of stage g + 3, rows of stage g + 2] and waits until only those 6 copies are out -
+    // then the rows of stage g + 1 (requested a stage ago) and the queries of stage g + 2 (a stage ago, BEFORE those rows) have landed: every
+    // copy has two stages to arrive.  A copy requested and awaited inside one stage makes the stage last a memory round trip (1.1 - 2 us
+    // measured, whatever its size).  Requests past the last stage repeat the last one into a slot nobody reads: the count in flight is constant.
+    uint64_t ra_it = 0;
+    uint32_t ra_kc = 0, ra_slot = 0, rb_kc = 0, rb_slot = 0;
+    auto uniform_ptr = [&](uint64_t v) {
+        return reinterpret_cast<const unsigned char *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
+                                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v));
+    };
+    // one 1 KiB copy each, so that the requests of a stage can sit BETWEEN its matrix instructions (a wave issues in order: six copies in a
+    // row in front of the MFMAs keep the matrix pipe idle for ~600 cycles per stage while both waves of the SIMD are busy requesting)
+    const unsigned char *ra_src = nullptr, *rb_src = nullptr;
+    uint32_t ra_dst = 0, rb_dst = 0;
+    auto rows_begin = [&]() {
+        const uint64_t tile = blockIdx.x + ra_it * gridDim.x;
+        ra_src = uniform_ptr((uint64_t)(uintptr_t)(s.rows_split + (tile * nch + ra_kc) * SP3_A_UNITS) + (uint32_t)w * 4096u);
+        ra_dst = lds0 + (ra_slot * SP3_A_UNITS) * 16u + (uint32_t)w * 4096u;
+        ra_slot = ra_slot + 1 == SP3_ARING ? 0 : ra_slot + 1;
+        if (ra_kc + 1 < nch) ++ra_kc;
+        else if (ra_it + 1 < my_tiles) { ra_kc = 0; ++ra_it; }
+    };
+    auto rows_piece = [&](int i) { sp_glds16(ra_src + i * 1024, lane_off, ra_dst + i * 1024); };
+    auto queries_begin = [&]() {
+        rb_src = uniform_ptr((uint64_t)(uintptr_t)(s.bq + (uint64_t)rb_kc * SP_B_UNITS) + (uint32_t)w * 2048u);
+        rb_dst = lds0 + (SP3_ARING * SP3_A_UNITS + rb_slot * SP_B_UNITS) * 16u + (uint32_t)w * 2048u;
+        rb_slot = (rb_slot + 1) & (SP3_BRING - 1);
+        rb_kc = rb_kc + 1 == nch ? 0 : rb_kc + 1;
+    };
+    auto queries_piece = [&](int i) { sp_glds16(rb_src + i * 1024, lane_off, rb_dst + i * 1024); };
+    auto request_rows = [&]() {
+        rows_begin();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rows_piece(i);
+    };
+    auto request_queries = [&]() {
+        queries_begin();
+        queries_piece(0);
+        queries_piece(1);
+    };
+    request_queries();                                    // queries of stage 0
+    request_queries();                                    // ... 1
+    request_rows();                                       // rows of stage 0
+    request_queries();                                    // queries of stage 2
+    request_rows();                                       // rows of stage 1
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // queries 0, 1 and rows 0 have landed
+    sp_stage_barrier();
+    uint32_t slot = 0, bslot = 0;
+    for (uint64_t it = 0; it < my_tiles; ++it) {
+        const uint64_t tile = blockIdx.x + it * gridDim.x;
+        f32x4s acc[4][4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const uint32_t q = wn * 64 + (uint32_t)nt * 16 + m_r;
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4s){0.f, 0.f, 0.f, 0.f};
+        for (uint32_t kc = 0; kc < nch; ++kc) {
+            queries_begin();                              // stage g + 3 -> the slot stage g - 1 was read from (everybody is past that barrier)
+            rows_begin();                                 // stage g + 2 -> likewise
+            const uint4 *ab = lds + slot * SP3_A_UNITS + a_rd;
+            const uint4 *bb = b_lds + bslot * SP_B_UNITS + b_rd;
+            half8 bh[4], bl[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v = acc[mt][nt][j];
-                    const uint64_t row = tile * SP_BM + wm * 64 + (uint32_t)mt * 16 + 4 * kq_r + (uint32_t)j;
-                    const bool c = !(v < thr[nt]) && row < a.n_cand && q < s.nq;     // NaN (greatest in OrderedFloat) is a candidate
-                    if (__ballot(c)) {
-                        if (c && a.del.live((uint32_t)row)) {
-                            const uint32_t slot = atomicAdd(&s.cand_cnt[q], 1u);
-                            if (slot < s.cap) s.cand[(uint64_t)q * s.cap + slot] = make_key(v * inv_scale, (uint32_t)row);
+            for (int nt = 0; nt < 4; ++nt) {
+                bh[nt] = *reinterpret_cast<const half8 *>(bb + nt * 128);
+                bl[nt] = *reinterpret_cast<const half8 *>(bb + nt * 128 + 64);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const half8 ah = *reinterpret_cast<const half8 *>(ab + mt * 128);
+                const half8 al = *reinterpret_cast<const half8 *>(ab + mt * 128 + 64);
+                // pair mode: x y = h h' + h l' + l h' (small terms first); half mode: the two planes are the two halves of a 64-float chunk
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, HALF ? bl[nt] : bh[nt], acc[mt][nt], 0, 0, 0);
+                // the stage's six copy requests, in the order the wait below relies on (queries first), spread over the matrix work
+                if (mt == 0) queries_piece(0);
+                if (mt == 1) queries_piece(1);
+                if (mt == 2) { rows_piece(0); rows_piece(1); }
+                if (mt == 3) { rows_piece(2); rows_piece(3); }
+                __builtin_amdgcn_sched_barrier(0);
+                if (!HALF) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[nt], acc[mt][nt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[nt], acc[mt][nt], 0, 0, 0);
+            }
+            slot = slot + 1 == SP3_ARING ? 0 : slot + 1;
+            bslot = (bslot + 1) & (SP3_BRING - 1);
+            if (kc + 1 == nch) {
+                const uint32_t row0 = (uint32_t)(tile * SP3_BM) + wm * 64 + 4 * kq_r;
+                const uint32_t n_rows32 = (uint32_t)a.n_cand;
+                bool any = false;
+                // most (wave, tile) pairs hold no candidate once the thresholds bite: one maximum per query tile decides that in 60 instructions
+                bool maybe = false;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    float mx = -__builtin_inff();
+                    bool nan = false;
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            mx = __builtin_fmaxf(mx, acc[mt][nt][j]);
+                            nan = nan || acc[mt][nt][j] != acc[mt][nt][j];
+                        }
+                    maybe = maybe || !(mx < thr[nt]) || nan;
+                }
+                if (__ballot(maybe))
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float v = acc[mt][nt][j];
+                            const uint32_t row = row0 + (uint32_t)mt * 16 + (uint32_t)j;
+                            const bool c = !(v < thr[nt]) && row < n_rows32;
+                            if (__ballot(c)) {
+                                any = true;
+                                uint32_t q = wn * 64 + (uint32_t)nt * 16 + m_r;
+                                asm volatile("" : "+v"(q));
+                                if (c && q < s.nq && a.del.live(row)) {
+                                    const uint32_t cslot = atomicAdd(&s.cand_cnt[q], 1u);
+                                    if (cslot < s.cap) s.cand[(uint64_t)q * s.cap + cslot] = make_key(v * inv_scale, row);
+                                }
+                            }
                         }
                     }
-                }
+                // (the compiler counted the loads / atomics of the branch without knowing about the copies in flight; drain once, the count
+                // below holds again)
+                if (any) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // rows of stage g + 1 and queries of stage g + 2 have landed
+            sp_stage_barrier();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // nothing may land in LDS after the block is gone
+}
+
+// the pre-split copy: one thread per (row, 8-float group): out[(tile * nch + kc) * 2048 + unit(row, h / l, kq)]; rows past n are zero
+__global__ __launch_bounds__(256) void sp_split_copy_kernel(const unsigned char *rows, uint64_t row_stride, uint64_t n, uint32_t dim, float scale, uint4 *out,
+                                                            int half) {
+    const uint32_t groups = dim / 8;
+    const uint32_t nch = half ? dim / 64 : dim / 32;
+    const uint64_t n_pad = (n + SP3_BM - 1) / SP3_BM * SP3_BM;
+    for (uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x; gid < n_pad * groups; gid += (uint64_t)gridDim.x * 256) {
+        const uint64_t r = gid / groups;
+        const uint32_t gq = (uint32_t)(gid % groups), k32 = gq / 4, kq = gq % 4;
+        half8 h, l;
+        if (r < n) {
+            const float *v = reinterpret_cast<const float *>(rows + r * row_stride) + k32 * 32 + kq * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                h[e] = (_Float16)__builtin_fmaf(v[e], scale, 0.0f);
+                l[e] = (_Float16)__builtin_fmaf(v[e], scale, -(float)h[e]);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { h[e] = (_Float16)0.0f; l[e] = (_Float16)0.0f; }
+        }
+        const uint64_t tile = r / SP3_BM;
+        const uint32_t rl = (uint32_t)(r % SP3_BM);
+        if (half) {   // one plane pair per 64 floats: the high parts of the two 32-float halves
+            out[(tile * nch + k32 / 2) * SP3_A_UNITS + sp_unit(rl >> 4, k32 & 1u, kq, rl & 15u)] = *reinterpret_cast<const uint4 *>(&h);
+        } else {
+            uint4 *chunk = out + (tile * nch + k32) * SP3_A_UNITS;
+            chunk[sp_unit(rl >> 4, 0, kq, rl & 15u)] = *reinterpret_cast<const uint4 *>(&h);
+            chunk[sp_unit(rl >> 4, 1, kq, rl & 15u)] = *reinterpret_cast<const uint4 *>(&l);
+        }
     }
 }
 
@@ -375,10 +661,10 @@ __global__ __launch_bounds__(256) void sp_row_stats_kernel(const unsigned char *
 
 // ---------------------------------------------------------------------------------------------------------------------------
 bool split_scan_ok(const ScanArgs &a) {
-    return a.dim % 32 == 0 && a.dim >= 32 && a.rem_pieces == 0 && a.tail_start == a.dim && a.row_stride % 16 == 0 && a.ids == nullptr && a.top <= 64 &&
+    return a.dim % 128 == 0 && a.dim >= 128 && a.rem_pieces == 0 && a.tail_start == a.dim && a.row_stride % 16 == 0 && a.ids == nullptr && a.top <= 64 &&
            !option(OPT_NO_SPLIT_SCAN);
 }
-size_t split_query_bytes(uint32_t dim) { return (size_t)(dim / 32) * SP_B_UNITS * 16; }
+size_t split_query_bytes(uint32_t dim) { return (size_t)(dim / 32) * SP_B_UNITS * 16; }   // (the half mode needs half of it)
 
 int32_t launch_split_row_stats(hipStream_t st, const void *rows, uint64_t row_stride, uint64_t n, uint32_t dim, uint32_t *d_stats) {
     if (n == 0) return QMX_OK;
@@ -398,13 +684,13 @@ float split_row_scale(float row_maxabs) {
 
 // queries (preprocessed f32, [nq][dim] contiguous) -> bq, qnorm, scales.  d_stats: one zeroed u32.
 int32_t launch_split_pack_queries(hipStream_t st, const float *d_q, uint32_t nq, uint32_t dim, float row_scale, uint32_t *d_stats, float *d_qnorm,
-                                  float *d_scales, void *d_bq) {
+                                  float *d_scales, void *d_bq, int half) {
     ::qmx::clear_stale_error();
     QMX_HIP(hipMemsetAsync(d_stats, 0, 4, st));
     hipLaunchKernelGGL(sp_query_stats_kernel, dim3(nq), dim3(256), 0, st, d_q, nq, dim, d_stats, d_qnorm);
     hipLaunchKernelGGL(sp_scales_kernel, dim3(1), dim3(1), 0, st, d_stats, row_scale, d_scales);
     const uint32_t units = (dim / 32) * SP_QT * 4;
-    hipLaunchKernelGGL(sp_pack_queries_kernel, dim3((units + 255) / 256), dim3(256), 0, st, d_q, nq, dim, d_scales, (uint4 *)d_bq);
+    hipLaunchKernelGGL(sp_pack_queries_kernel, dim3((units + 255) / 256), dim3(256), 0, st, d_q, nq, dim, d_scales, (uint4 *)d_bq, half);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }
@@ -415,17 +701,32 @@ int32_t launch_split_thresholds(hipStream_t st, const uint64_t *d_gthr, const fl
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }
+size_t split_copy_bytes(uint64_t n, uint32_t dim, int half) { return (size_t)((n + SP3_BM - 1) / SP3_BM) * (dim / (half ? 64 : 32)) * SP3_A_UNITS * 16; }
+int32_t launch_split_copy(hipStream_t st, const void *rows, uint64_t row_stride, uint64_t n, uint32_t dim, float row_scale, void *d_out, int half) {
+    if (n == 0) return QMX_OK;
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(sp_split_copy_kernel, dim3(8192), dim3(256), 0, st, (const unsigned char *)rows, row_stride, n, dim, row_scale, (uint4 *)d_out, half);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
 int32_t launch_scan_f32_split(hipStream_t st, const ScanArgs &a, const void *d_bq, float row_scale, const float *d_scales, const float *d_thr,
-                              uint64_t *d_cand, uint32_t *d_cand_cnt, uint32_t cap, int num_cus) {
+                              uint64_t *d_cand, uint32_t *d_cand_cnt, uint32_t cap, int num_cus, const void *d_rows_split, int half) {
     auto kfn = scan_f32_split_kernel;
+    auto kfn3 = scan_f16pair_kernel<false>;
+    auto kfn3h = scan_f16pair_kernel<true>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS));
+        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn3), hipFuncAttributeMaxDynamicSharedMemorySize, SP3_LDS));
+        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn3h), hipFuncAttributeMaxDynamicSharedMemorySize, SP3_LDS));
         attr_set = true;
     }
+    QMX_REQUIRE(!half || d_rows_split, QMX_ERR_BAD_ARG, "the one-product mode scans the half copy only");
     SplitArgs s;
+    s.rows_split = (const uint4 *)d_rows_split;
     s.bq = (const uint4 *)d_bq;
-    s.nchunks = a.dim / 32;
+    s.nchunks = a.dim / (half ? 64 : 32);
     s.nq = a.nq;
     s.row_scale = row_scale;
     s.scales = d_scales;
@@ -433,11 +734,19 @@ int32_t launch_scan_f32_split(hipStream_t st, const ScanArgs &a, const void *d_b
     s.cand = d_cand;
     s.cand_cnt = d_cand_cnt;
     s.cap = cap;
-    const uint64_t n_tiles = (a.n_cand + SP_BM - 1) / SP_BM;
+    const uint64_t n_tiles = (a.n_cand + (d_rows_split ? SP3_BM : SP_BM) - 1) / (d_rows_split ? SP3_BM : SP_BM);
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, (uint64_t)num_cus));
     ::qmx::clear_stale_error();
-    QMX_NOTE_KERNEL(kfn);
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(SP_THREADS), (size_t)SP_LDS, st, a, s);
+    if (d_rows_split && half) {
+        QMX_NOTE_KERNEL(kfn3h);
+        hipLaunchKernelGGL(kfn3h, dim3(grid), dim3(SP3_THREADS), (size_t)SP3_LDS, st, a, s);
+    } else if (d_rows_split) {
+        QMX_NOTE_KERNEL(kfn3);
+        hipLaunchKernelGGL(kfn3, dim3(grid), dim3(SP3_THREADS), (size_t)SP3_LDS, st, a, s);
+    } else {
+        QMX_NOTE_KERNEL(kfn);
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(SP_THREADS), (size_t)SP_LDS, st, a, s);
+    }
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }

@@ -36,7 +36,7 @@ def world():
     F.check(F.lib().qmx_preprocess_f32(0, int(qa.Distance.Cosine), F.ptr(rows), N, DIM, F.ptr(rows)))
     torch.cuda.synchronize()
     queries = O.synth(0x5EED0012, 0, NQ, DIM)
-    st = qa.VectorStorage(rows, qa.Distance.Cosine)
+    st = qa.VectorStorage(rows, qa.Distance.Cosine, flags=F.SEG_HALF_COPY)      # + the f16 high-part copy of the block (15.36 GB more)
     yield dict(torch=torch, qa=qa, F=F, dev=dev, rows=rows, queries=queries, st=st)
     st.close()
     del rows
@@ -102,7 +102,7 @@ def test_c2_full_size_every_batch_shape(world, nq):
     full = s.peek_top_all()
     kernel = F.last_kernel(s.scorer._h)
     # (128 queries: the f16-split prefilter + exact verification, scan_split.hip)
-    assert ("scan_f32_split_kernel" if nq == 128 else "scan_f32_mfma16_kernel<6, %s" % {16: "4, 1", 32: "4, 2", 64: "8, 4"}[nq]) in kernel, kernel
+    assert ("scan_f16pair_kernel" if nq == 128 else "scan_f32_mfma16_kernel<6, %s" % {16: "4, 1", 32: "4, 2", 64: "8, 4"}[nq]) in kernel, kernel
     assert all(len(r) == TOP and np.all(np.diff(r["score"]) <= 0) for r in full)
     qa.set_option("no_mfma_scan", 1)
     try:

@@ -34,22 +34,23 @@ N = 300_000          # >= 2^18: the prefilter applies
 
 @pytest.mark.parametrize("distance,dim", [(O.COSINE, 128), (O.DOT, 256), (O.COSINE, 768)])
 @pytest.mark.parametrize("nq,top", [(65, 10), (128, 1), (200, 10), (130, 64)])
-def test_split_scan_returns_the_exact_scan(qa, distance, dim, nq, top):
+@pytest.mark.parametrize("copy", [0, 1, 2])           # 1: QMX_SEG_SPLIT_COPY (f16 pairs, three products), 2: QMX_SEG_HALF_COPY (high parts, one product)
+def test_split_scan_returns_the_exact_scan(qa, distance, dim, nq, top, copy):
     n = N if dim < 768 else 270_000
     rows = O.preprocess(distance, O.synth(0x5EED0500 + dim, 0, n, dim))
     queries = O.synth(0x5EED0501 + nq, 0, nq, dim)
     st = O.DenseStorage(O.F32, distance, rows)
-    vs = qa.VectorStorage(rows, qa.Distance.Cosine if distance == O.COSINE else qa.Distance.Dot)
+    vs = qa.VectorStorage(rows, qa.Distance.Cosine if distance == O.COSINE else qa.Distance.Dot, flags=[0, qa._ffi.SEG_SPLIT_COPY, qa._ffi.SEG_HALF_COPY][copy])
     s = qa.BatchFilteredSearcher(queries, vs, top)
     got = s.peek_top_all()
     if nq % 128 == 0 or nq % 128 > 64:
-        assert "scan_f32_split_kernel" in _kernel(qa, s), _kernel(qa, s)
+        assert ["scan_f32_split_kernel", "scan_f16pair_kernel<false>", "scan_f16pair_kernel<true>"][copy] in _kernel(qa, s), _kernel(qa, s)
     _same(got, st.peek_top(queries, top, threads=8))
     qa.set_option("no_split_scan", 1)                    # ... and the exact kernels agree (they are what the fallback runs)
     try:
         s2 = qa.BatchFilteredSearcher(queries, vs, top)
         _same(s2.peek_top_all(), got)
-        assert "scan_f32_split_kernel" not in _kernel(qa, s2)
+        assert "scan_f32_split_kernel" not in _kernel(qa, s2) and "scan_f16pair_kernel" not in _kernel(qa, s2)
     finally:
         qa.set_option("no_split_scan", -1)
 
@@ -62,11 +63,11 @@ def test_split_scan_with_deleted_rows_and_filter(qa):
     deleted = rng.random(n) < 0.4
     vdel = rng.random(n) < 0.05
     st = O.DenseStorage(O.F32, O.COSINE, rows, point_deleted=deleted, vec_deleted=vdel)
-    vs = qa.VectorStorage(rows, qa.Distance.Cosine)
+    vs = qa.VectorStorage(rows, qa.Distance.Cosine, flags=qa._ffi.SEG_HALF_COPY)
     vs.set_deleted(deleted, vdel)
     s = qa.BatchFilteredSearcher(queries, vs, top)
     got = s.peek_top_all()
-    assert "scan_f32_split_kernel" in _kernel(qa, s)
+    assert "scan_f16pair_kernel" in _kernel(qa, s)
     _same(got, st.peek_top(queries, top, threads=8))
     for r in got:
         assert not deleted[r["idx"]].any() and not vdel[r["idx"]].any()
@@ -117,12 +118,13 @@ def test_split_scan_when_the_sample_is_all_deleted(qa):
 @pytest.mark.parametrize("row_mag,query_mag", [(1000.0, 1e-3), (1e-4, 1e4), (37.0, 1.0)])
 def test_split_scan_dot_with_any_magnitudes(qa, row_mag, query_mag):
     """Dot distance, un-normalised rows: the power-of-two scales come from max |x| of the block and of the batch."""
-    n, dim, nq, top = N, 128, 90, 10
+    n, dim, nq, top = N - 77, 128, 90, 10            # (a partial last 256-row tile)
     rows = (O.synth(0x5EED0540, 0, n, dim) * np.float32(row_mag)).astype(np.float32)
     queries = (O.synth(0x5EED0541, 0, nq, dim) * np.float32(query_mag)).astype(np.float32)
     st = O.DenseStorage(O.F32, O.DOT, rows)
-    vs = qa.VectorStorage(rows, qa.Distance.Dot)
-    s = qa.BatchFilteredSearcher(queries, vs, top)
-    got = s.peek_top_all()
-    assert "scan_f32_split_kernel" in _kernel(qa, s)
-    _same(got, st.peek_top(queries, top, threads=8))
+    for copy in (0, 1, 2):
+        vs = qa.VectorStorage(rows, qa.Distance.Dot, flags=[0, qa._ffi.SEG_SPLIT_COPY, qa._ffi.SEG_HALF_COPY][copy])
+        s = qa.BatchFilteredSearcher(queries, vs, top)
+        got = s.peek_top_all()
+        assert ["scan_f32_split_kernel", "scan_f16pair_kernel<false>", "scan_f16pair_kernel<true>"][copy] in _kernel(qa, s)
+        _same(got, st.peek_top(queries, top, threads=8))
