@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=768)
-    ap.add_argument("--batch", type=int, default=64, help="queries per scan (Q)")
+    ap.add_argument("--batch", type=int, default=128, help="queries per step (Q); more than 64 run 128 per pass through the f16 prefilter + exact verification")
     ap.add_argument("--top", type=int, default=10)
     ap.add_argument("--nqueries", type=int, default=1024)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--split-copy", choices=["half", "pair", "none"], default="half",
-                    help="Q > 64: which derived copy of the block the prefilter scans (half: f16 high parts, 2 B / element; pair: f16 pairs, 4 B; none: the f32 block itself)")
+                    help="which derived copy of the block the prefilter scans (half: f16 high parts, 2 B / element; pair: f16 pairs, 4 B; none: the f32 block itself)")
     ap.add_argument("--no-hbm-point", action="store_true", help="skip the secondary Q=16 (HBM-bound) measurement of the same scan")
     ap.add_argument("--verify", type=int, default=1, help="check samples against the oracle (C2 first batch, C3 / C4 scans and walks)")
     ap.add_argument("--configs", default="c3,c4", help="comma list of the secondary single-GPU configs to run (empty = none)")
@@ -125,7 +125,7 @@ def main():
     F.check(lib.qmx_synth_fill_f32(local_rank, row_seed, row0, n, dim, F.ptr(rows)))
     F.check(lib.qmx_preprocess_f32(local_rank, int(qa.Distance.Cosine), F.ptr(rows), n, dim, F.ptr(rows)))
     # (+ the f16-pair copy of the block when batches of more than 64 queries will scan it: scan_split.hip; 4 more bytes per element)
-    copy_flag = {"none": 0, "pair": F.SEG_SPLIT_COPY, "half": F.SEG_HALF_COPY}[args.split_copy] if Q > 64 else 0
+    copy_flag = {"none": 0, "pair": F.SEG_SPLIT_COPY, "half": F.SEG_HALF_COPY}[args.split_copy]
     storage = qa.VectorStorage(rows, qa.Distance.Cosine, device_id=local_rank, flags=copy_flag)
 
     nbatches = max(1, args.nqueries // Q)
@@ -180,8 +180,11 @@ def main():
     else:
         kernel_ms = kms.value / max(1, kl.value)
 
-    row_bytes = dim * 4
-    alg_bytes = n * row_bytes  # per scan launch (3072 B/row at d=768), queries/outputs negligible
+    # bytes the dominant kernel has to read per launch: the f32 block (3072 B/row at d=768) for the exact scans; the derived copy
+    # the prefilter scans (QMX_SEG_HALF_COPY: 2 B / element, QMX_SEG_SPLIT_COPY: 4 B) when that is the kernel that ran
+    elem_bytes = 2 if "scan_f16pair_kernel<true>" in kernel_symbol else 4
+    row_bytes = dim * elem_bytes
+    alg_bytes = n * row_bytes
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     launches_per_step = max(1, int(kl.value)) / float(max(1, args.steps))
     units = Q * args.steps * (1 if strong else world)
@@ -209,13 +212,28 @@ def main():
     }
 
     solo = rank == 0 and world == 1
+    if solo and args.verify and (Q > 64 or copy_flag):
+        # the timed path (prefilter + exact verification) against the exact chain-major scan, whole block, first batch: ids and score bits
+        step(0)
+        torch.cuda.synchronize(dev)
+        a_out, a_cnt = out.clone(), counts.clone()
+        qa.set_option("no_split_scan", 1)
+        try:
+            step(0)
+            torch.cuda.synchronize(dev)
+        finally:
+            qa.set_option("no_split_scan", -1)
+        result["prefilter_equals_exact_scan_whole_block"] = bool(torch.equal(a_out, out) and torch.equal(a_cnt, counts))
     if solo and Q != 16 and not args.no_hbm_point:
         # the HBM-bound operating point of the same scan (north_star: >= 70 % of the HBM roofline on C2): 16 queries per pass, where the
         # kernel is a pure stream of the stored block; outside the timed region, same rows, same measurement (HIP events on the kernel's stream)
+        qa.set_option("no_split_scan", 1)      # (this point is the EXACT scan's: the f32 block itself, streamed once for 16 queries)
         try:
             result["roofline_hbm_point_q16"] = hbm_point(16, storage, queries, n, dim, top, local_rank, stream, lib, F, sharded, torch)
         except Exception as e:
             result["roofline_hbm_point_q16"] = {"error": repr(e)[:300]}
+        finally:
+            qa.set_option("no_split_scan", -1)
     if solo and not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(args, rows, queries, out, counts, n, dim, Q, top, lib, qh, F, qa, np, torch)
     backend.close()
@@ -335,21 +353,30 @@ def cpu_baseline(args, rows, queries, out, counts, n, dim, Q, top, lib, qh, F, q
             "gpu_matches_oracle_on_sample_bit_exact": ok}
 
 
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16 / bf16 MFMA peak (same guide); 2377 measured in a bare loop (profiles/r2_mfma_issue_rates.txt)
+
+
 def _roofline(n, dim, kernel_ms, alg_bytes, achieved_gbps, launches, launches_per_step, Q, kernel_symbol):
     """The dominant kernel against BOTH ceilings; `bound` is the one it sits closer to.  Up to 16 queries per pass the scan is
     an HBM stream (every row byte read once: SURVEY 8d, 3072 B / row at d = 768); the 32- / 64-query passes of scan_mfma16.hip
-    do 2 * dim flops per (row, query) on the f32 matrix cores and cross over to the MFMA ceiling."""
+    do 2 * dim flops per (row, query) on the f32 matrix cores and cross over to the MFMA ceiling; the prefilter of scan_split.hip
+    (more than 64 queries) streams a derived f16 copy of the block and multiplies on the f16 matrix cores (1 or 3 products per element)."""
     per_pass = Q / max(1.0, round(launches_per_step))       # queries one launch serves: MEASURED launches per step, not a dispatch guess
-    flops = 2.0 * n * dim * per_pass
+    split = "scan_f16pair_kernel" in kernel_symbol or "scan_f32_split_kernel" in kernel_symbol
+    products = 1 if "scan_f16pair_kernel<true>" in kernel_symbol else 3 if split else 1
+    flops = 2.0 * n * dim * (128 if split else per_pass) * products      # (the prefilter multiplies a padded 128-query tile)
     tflops = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
-    hbm_frac, mfma_frac = achieved_gbps / HBM_PEAK_GBPS, tflops / MFMA_F32_PEAK_TFLOPS
+    mfma_peak = MFMA_F16_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
+    hbm_frac, mfma_frac = achieved_gbps / HBM_PEAK_GBPS, tflops / mfma_peak
     traffic, traffic_src = _pmc_traffic(n, dim, Q, kernel_symbol)
     common = {"traffic": traffic, "traffic_source": traffic_src, "kernel": kernel_symbol, "kernel_ms": round(kernel_ms, 4), "launches_timed": launches,
               "queries_per_launch": per_pass, "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_flops_per_launch": flops,
               "hbm": {"achieved_GBps": round(achieved_gbps, 1), "peak_GBps": HBM_PEAK_GBPS, "frac": round(hbm_frac, 4)},
-              "mfma_f32": {"achieved_TFLOPs": round(tflops, 2), "peak_TFLOPs": MFMA_F32_PEAK_TFLOPS, "frac": round(mfma_frac, 4)}}
+              "mfma": {"dtype": "f16 (x = h + l prefilter, f32 accumulate; results re-scored exactly in f32)" if split else "f32",
+                       "achieved_TFLOPs": round(tflops, 2), "peak_TFLOPs": mfma_peak, "frac": round(mfma_frac, 4)},
+              "f32_block_equivalent_GBps": round(n * dim * 4 / (kernel_ms * 1e-3) / 1e9, 1) if kernel_ms > 0 else 0.0}
     if mfma_frac > hbm_frac:
-        return dict({"bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(mfma_frac, 4)}, **common)
+        return dict({"bound": "mfma", "achieved": round(tflops, 2), "peak": mfma_peak, "unit": "TFLOP/s", "frac": round(mfma_frac, 4)}, **common)
     return dict({"bound": "hbm", "achieved": round(achieved_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(hbm_frac, 4)}, **common)
 
 

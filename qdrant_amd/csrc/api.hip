@@ -47,7 +47,7 @@ int32_t hip_status(hipError_t e, const char *what, const char *file, int line) {
 
 // ---- kernel-path options: the environment is read once, here, at load time ----
 static const char *const g_option_names[OPT_COUNT] = {"no_mfma_scan", "no_mfma16", "no_mfma16_q64", "no_prescan", "prescan_shift", "hnsw_no_packed_l0",
-                                                     "hnsw_pq_lds_lut", "hnsw_log_cap", "bq_lanes8", "mfma_no_nt", "mfma_no_fast", "no_pq_tiled", "no_split_scan", "no_pq_pair", "debug"};
+                                                     "hnsw_pq_lds_lut", "hnsw_log_cap", "bq_lanes8", "mfma_no_nt", "mfma_no_fast", "no_pq_tiled", "no_split_scan", "split_min_queries", "no_pq_pair", "debug"};
 struct OptionTable {
     std::atomic<int64_t> v[OPT_COUNT];
     int64_t initial[OPT_COUNT];
@@ -61,6 +61,7 @@ struct OptionTable {
             int64_t val = 0;
             if (e) { val = (*e >= '0' && *e <= '9') ? atoll(e) : 1; }   // "QMX_X=" / "QMX_X=yes" count as set
             if (i == OPT_PRESCAN_SHIFT && !e) val = 10;
+            if (i == OPT_SPLIT_MIN_QUERIES && !e) val = 1;
             initial[i] = val;
             v[i].store(val, std::memory_order_relaxed);
         }
@@ -1234,8 +1235,11 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
                      !option(OPT_NO_MFMA16);
     // more than 64 queries over a large f32 dot / cosine block: 128 per pass through the f16-split matrix-core prefilter, the survivors
     // re-scored exactly (scan_split.hip); the result is the exact scan's, bit for bit
-    const bool split = q64 && s->split_stats && !d_ids && top <= MAX_TOP_FAST && n_cand >= (1u << 18) && s->dim % 128 == 0 && s->row_stride % 16 == 0 &&
-                       !option(OPT_NO_SPLIT_SCAN);
+    // ... and with a derived copy of the block (QMX_SEG_HALF_COPY / QMX_SEG_SPLIT_COPY) that path serves EVERY batch size: it streams 2 (4) bytes
+    // per element instead of 4 and is HBM-bound whatever the number of queries (10 M x 768: 3.0 ms per pass against 4.4 ms for the f32 stream)
+    const bool split_dims = s->dtype == QMX_DTYPE_F32 && mfma_scan_ok(s) && mfma16_dim_ok(64, s->dim) && !option(OPT_NO_MFMA16);
+    const bool split = split_dims && (q64 || (s->d_rows_split && q->nq >= (uint32_t)std::max<int64_t>(1, option(OPT_SPLIT_MIN_QUERIES)))) && s->split_stats &&
+                       !d_ids && top <= MAX_TOP_FAST && n_cand >= (1u << 18) && s->dim % 128 == 0 && s->row_stride % 16 == 0 && !option(OPT_NO_SPLIT_SCAN);
     const uint32_t TQ = split ? SPLIT_QT : q64 ? MAX_QT_TOPK : q32 ? MAX_QT_MFMA : tile_qt(s);
     const uint32_t ptop_max = std::min<uint32_t>(top, MAX_TOP_FAST);
     const uint32_t n_pass = (top + MAX_TOP_FAST - 1) / MAX_TOP_FAST;
@@ -1255,9 +1259,11 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
         QMX_TRY(q->sp_vscores.reserve((size_t)q->nq * SPLIT_VCAP * 4));
         float *f = (float *)q->sp_f32.p;
         sp_qnorm = f; sp_thr = f + 128; sp_band = f + 256; sp_scales = f + 384; sp_overflow = (int *)(f + 392);
-        // the sample: every (n_cand / S)-th row, S = n_cand / 128 (at least 8192): its k-th best leaves ~128 k candidates per query to the
-        // main pass (one in 8 (wave, tile) pairs holds one), at 1 / 128 of the pass's row traffic for the sample's exact scores
-        const uint64_t S = std::min<uint64_t>(n_cand, std::max<uint64_t>(n_cand >> 7, 8192));
+        // the sample: every (n_cand / S)-th row, S = n_cand / 256 (at least 8192): its k-th best leaves ~256 k candidates per query to the
+        // main pass, at 1 / 256 of the pass's row traffic for the sample's exact scores (measured on C2: 1/128 .. 1/512 are equally good)
+        // ("prescan_shift" - 2: the option of the exact scans' prefix pre-scan, 10 by default, moves this sample with it)
+        const int sshift = (int)std::min<int64_t>(std::max<int64_t>(option(OPT_PRESCAN_SHIFT) - 2, 1), 20);
+        const uint64_t S = std::min<uint64_t>(n_cand, std::max<uint64_t>(n_cand >> sshift, 8192));
         if (q->sp_sample_n != S || q->sp_sample_of != n_cand) {
             QMX_TRY(q->sp_sample.reserve((size_t)S * 4));
             ::qmx::clear_stale_error();
@@ -1270,7 +1276,7 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
     }
     for (uint32_t tile0 = 0; tile0 < q->nq; tile0 += TQ) {
         const uint32_t nq_tile = std::min<uint32_t>(TQ, q->nq - tile0);
-        if (split && nq_tile > MAX_QT_TOPK) {
+        if (split && (nq_tile > MAX_QT_TOPK || s->d_rows_split)) {
             if (is_stopped && *is_stopped) {
                 set_error("search cancelled");
                 return QMX_ERR_CANCELLED;

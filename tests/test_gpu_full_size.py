@@ -89,20 +89,27 @@ def test_c2_full_size_properties(world):
         assert np.array_equal(g["score"].view(np.uint32), w["score"].view(np.uint32))
 
 
+@pytest.mark.parametrize("path", ["exact", "prefilter"])
 @pytest.mark.parametrize("nq", [16, 32, 64, 128])
-def test_c2_full_size_every_batch_shape(world, nq):
-    """the kernel bench.py times — scan_f32_mfma16_kernel<6, 8, 4, LAG = true, IDS = false>, 64 queries per pass over
-    the WHOLE block (its wave-lag schedule and phantom-stage tail depend on the tile count) — checked at the headline size, next to the 16-
-    and 32-query shapes: the lists must equal (1) the VALU kernel's (4 queries per pass, no matrix cores, no pre-scan, a different
-    reduction tree: the only thing they share is the reference's bits), (2) the oracle's on a 200 k-row window reached through an id
-    list (the IDS = true instantiation), and (3) the merge of the lists of 5 uneven slabs."""
+def test_c2_full_size_every_batch_shape(world, nq, path):
+    """the kernels bench.py times, checked at the headline size over the WHOLE block (their wave-lag schedule, stage
+    rings and tails depend on the tile count), for 16 / 32 / 64 / 128 queries per pass and along both tracks:
+      exact      scan_f32_mfma16_kernel<6, ...> (what a segment without a derived copy runs; option no_split_scan here),
+      prefilter  scan_f16pair_kernel<true> over the 2 B / element copy + exact verification (scan_split.hip).
+    The lists must equal (1) the VALU kernel's (4 queries per pass, no matrix cores, no pre-scan, a different reduction tree: the only
+    thing they share is the reference's bits), (2) the oracle's on a 200 k-row window reached through an id list (the IDS = true
+    instantiation), and (3) the merge of the lists of 5 uneven slabs."""
     qa, F, torch = world["qa"], world["F"], world["torch"]
     queries = O.synth(0x5EED0042 + nq, 0, nq, DIM)
     s = qa.BatchFilteredSearcher(queries, world["st"], TOP)
-    full = s.peek_top_all()
+    qa.set_option("no_split_scan", 1 if path == "exact" else -1)
+    try:
+        full = s.peek_top_all()
+    finally:
+        qa.set_option("no_split_scan", -1)
     kernel = F.last_kernel(s.scorer._h)
-    # (128 queries: the f16-split prefilter + exact verification, scan_split.hip)
-    assert ("scan_f16pair_kernel" if nq == 128 else "scan_f32_mfma16_kernel<6, %s" % {16: "4, 1", 32: "4, 2", 64: "8, 4"}[nq]) in kernel, kernel
+    want_kernel = "scan_f16pair_kernel<true>" if path == "prefilter" else "scan_f32_mfma16_kernel<6, %s" % {16: "4, 1", 32: "4, 2", 64: "8, 4", 128: "8, 4"}[nq]
+    assert want_kernel in kernel, kernel
     assert all(len(r) == TOP and np.all(np.diff(r["score"]) <= 0) for r in full)
     qa.set_option("no_mfma_scan", 1)
     try:
