@@ -1210,9 +1210,16 @@ static int32_t split_stage(qmx_query *q, const char *what) {
 constexpr uint32_t SPLIT_QT = 128;          // queries per pass of the split prefilter (scan_split.hip)
 constexpr uint32_t SPLIT_CAND_CAP = 32768;  // candidate keys per query and pass (expected: ~1000 k)
 constexpr uint32_t SPLIT_VCAP = 512;        // rows per query that get an exact score (expected: ~k; the one-product mode's band holds more)
-constexpr float SPLIT_REL_BAND_HALF = 1.0e-3f;   // one product of f16-rounded operands: each within 2^-11 of its value -> 2^-10 |x y| per term
-constexpr float SPLIT_REL_BAND = 1.0e-4f;   // |approximate - exact| <= band * |q| * max |row|: 100x the split error, above the worst-case f32
-                                            // accumulation bounds of both sides (dim * 2^-24 each) up to dim 1600
+// |approximate - exact| <= band * |q| * max |row|, worst case, every term at its bound:
+//   one product of f16-rounded operands (HALF copy): each operand within 2^-11 of its value -> (2^-10 + 2^-22) sum |q_i r_i| <= ... |q| |r|
+//   three products of f16 pairs: x - (h + l) within 2^-22 |x|, the dropped l.l term 2^-22                    -> 3 * 2^-22
+//   f32 accumulation of the matrix cores over dim terms: dim * 2^-23 * sum |terms| (a round-off of 2^-23 per addition covers
+//   truncating adders as well), f16 subnormal flush of tiny elements: < 2^-27 sqrt(dim)
+// both rounded up generously; the exact side carries no error (the survivors are re-scored by the reference-order kernel).
+static inline float split_rel_band(bool half, uint32_t dim) {
+    const float acc = (float)dim * 1.1920929e-7f;                      // dim * 2^-23
+    return (half ? 9.765625e-4f + 9.5367432e-7f : 1.9073486e-6f) + acc;  // 2^-10 + 2^-20 | 2^-19
+}
 
 // ids of a strided sample of the candidates (rows 0, step, 2 step, ...): a sample that sees the whole block, whatever its order
 __global__ void sample_ids_kernel(uint32_t *ids, uint32_t n, uint64_t step) {
@@ -1311,7 +1318,7 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
             const int half = s->split_half ? 1 : 0;
             QMX_TRY(launch_split_pack_queries(q->stream, (const float *)q->enc.p + (size_t)tile0 * s->dim, nq_tile, s->dim, row_scale, (uint32_t *)(sp_scales + 4),
                                               sp_qnorm, sp_scales, q->sp_bq.p, half));
-            QMX_TRY(launch_split_thresholds(q->stream, gthr, sp_qnorm, nq_tile, half ? SPLIT_REL_BAND_HALF : SPLIT_REL_BAND, s->row_norm_max, sp_scales, sp_thr,
+            QMX_TRY(launch_split_thresholds(q->stream, gthr, sp_qnorm, nq_tile, split_rel_band(half, s->dim), s->row_norm_max, sp_scales, sp_thr,
                                             sp_band));
             QMX_HIP(hipMemsetAsync(q->sp_cnt.p, 0, (size_t)SPLIT_QT * 4, q->stream));
             QMX_TRY(split_stage(q, "pack + thresholds"));
