@@ -33,6 +33,7 @@ sample of the same rows, single-threaded (the reference's unit of work: one (bat
 import argparse
 import ctypes as C
 import json
+import math
 import os
 import sys
 import time
@@ -184,9 +185,14 @@ def main():
     # the prefilter scans (QMX_SEG_HALF_COPY: 2 B / element, QMX_SEG_SPLIT_COPY: 4 B) when that is the kernel that ran
     elem_bytes = 2 if "scan_f16pair_kernel<true>" in kernel_symbol else 4
     row_bytes = dim * elem_bytes
-    alg_bytes = n * row_bytes
-    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     launches_per_step = max(1, int(kl.value)) / float(max(1, args.steps))
+    # the prefilter over a derived copy covers the block in TWO launches of the same kernel (the strided sixteenth of the tiles, then the rest
+    # under the threshold the first one tightened): bytes and flops per launch are the per-launch AVERAGES, like kernel_ms, so that
+    # achieved = sum of bytes / sum of kernel time
+    prefilter = "scan_f16pair_kernel" in kernel_symbol
+    launches_per_pass = max(1.0, launches_per_step / math.ceil(Q / 128.0)) if prefilter else 1.0
+    alg_bytes = int(n * row_bytes / launches_per_pass)
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     units = Q * args.steps * (1 if strong else world)
     value = units / elapsed
 
@@ -208,7 +214,7 @@ def main():
                    "unit_of_value": ("queries per second against the ONE row-split segment" if strong else
                                      "(query, 10M-row segment) searches per second; at n_gpus=1 this is plain QPS"),
                    "collection_qps": round(Q * args.steps / elapsed, 2)},
-        "roofline": _roofline(n, dim, kernel_ms, alg_bytes, achieved, int(kl.value), launches_per_step, Q, kernel_symbol),
+        "roofline": _roofline(n, dim, kernel_ms, alg_bytes, achieved, int(kl.value), launches_per_step, Q, kernel_symbol, launches_per_pass),
     }
 
     solo = rank == 0 and world == 1
@@ -356,25 +362,25 @@ def cpu_baseline(args, rows, queries, out, counts, n, dim, Q, top, lib, qh, F, q
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16 / bf16 MFMA peak (same guide); 2377 measured in a bare loop (profiles/r2_mfma_issue_rates.txt)
 
 
-def _roofline(n, dim, kernel_ms, alg_bytes, achieved_gbps, launches, launches_per_step, Q, kernel_symbol):
+def _roofline(n, dim, kernel_ms, alg_bytes, achieved_gbps, launches, launches_per_step, Q, kernel_symbol, launches_per_pass=1.0):
     """The dominant kernel against BOTH ceilings; `bound` is the one it sits closer to.  Up to 16 queries per pass the scan is
     an HBM stream (every row byte read once: SURVEY 8d, 3072 B / row at d = 768); the 32- / 64-query passes of scan_mfma16.hip
     do 2 * dim flops per (row, query) on the f32 matrix cores and cross over to the MFMA ceiling; the prefilter of scan_split.hip
     (more than 64 queries) streams a derived f16 copy of the block and multiplies on the f16 matrix cores (1 or 3 products per element)."""
-    per_pass = Q / max(1.0, round(launches_per_step))       # queries one launch serves: MEASURED launches per step, not a dispatch guess
+    per_pass = Q / max(1.0, round(launches_per_step / launches_per_pass))   # queries one pass over the block serves: MEASURED launches per step, not a dispatch guess
     split = "scan_f16pair_kernel" in kernel_symbol or "scan_f32_split_kernel" in kernel_symbol
     products = 1 if "scan_f16pair_kernel<true>" in kernel_symbol else 3 if split else 1
-    flops = 2.0 * n * dim * (128 if split else per_pass) * products      # (the prefilter multiplies a padded 128-query tile)
+    flops = 2.0 * n * dim * (128 if split else per_pass) * products / launches_per_pass     # (the prefilter multiplies a padded 128-query tile)
     tflops = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
     mfma_peak = MFMA_F16_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
     hbm_frac, mfma_frac = achieved_gbps / HBM_PEAK_GBPS, tflops / mfma_peak
     traffic, traffic_src = _pmc_traffic(n, dim, Q, kernel_symbol)
     common = {"traffic": traffic, "traffic_source": traffic_src, "kernel": kernel_symbol, "kernel_ms": round(kernel_ms, 4), "launches_timed": launches,
-              "queries_per_launch": per_pass, "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_flops_per_launch": flops,
+              "queries_per_pass": per_pass, "launches_per_pass": launches_per_pass, "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_flops_per_launch": flops,
               "hbm": {"achieved_GBps": round(achieved_gbps, 1), "peak_GBps": HBM_PEAK_GBPS, "frac": round(hbm_frac, 4)},
               "mfma": {"dtype": "f16 (x = h + l prefilter, f32 accumulate; results re-scored exactly in f32)" if split else "f32",
                        "achieved_TFLOPs": round(tflops, 2), "peak_TFLOPs": mfma_peak, "frac": round(mfma_frac, 4)},
-              "f32_block_equivalent_GBps": round(n * dim * 4 / (kernel_ms * 1e-3) / 1e9, 1) if kernel_ms > 0 else 0.0}
+              "f32_block_equivalent_GBps": round(n * dim * 4 / (kernel_ms * launches_per_pass * 1e-3) / 1e9, 1) if kernel_ms > 0 else 0.0}
     if mfma_frac > hbm_frac:
         return dict({"bound": "mfma", "achieved": round(tflops, 2), "peak": mfma_peak, "unit": "TFLOP/s", "frac": round(mfma_frac, 4)}, **common)
     return dict({"bound": "hbm", "achieved": round(achieved_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(hbm_frac, 4)}, **common)

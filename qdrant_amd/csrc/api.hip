@@ -223,7 +223,7 @@ struct qmx_query {
     uint32_t n_cq_coefs = 0;
     DevBuf cand, cand_cnt, cand_ids;   // qmx_search_quantized: oversampled candidates of the quantized stage
     // split prefilter (scan_split.hip): split queries, per-query norms / thresholds / bands, scales, candidate and verification buffers, flag
-    DevBuf sp_bq, sp_f32, sp_cand, sp_cnt, sp_ver, sp_vscores, sp_sample;
+    DevBuf sp_bq, sp_f32, sp_cand, sp_cnt, sp_ver, sp_vscores, sp_sample, sp_wl;
     uint64_t sp_sample_n = 0, sp_sample_of = 0;
     DevBuf filter;             // payload-filter allow bitmap of this query batch (qmx_query_set_filter)
     uint64_t n_filter_bits = 0;
@@ -978,7 +978,7 @@ int32_t qmx_query_destroy(qmx_query *q) {
     q->mv_deleted.release();
     q->cq_scores.release();
     q->cq_desc.release();
-    q->sp_bq.release(); q->sp_f32.release(); q->sp_cand.release(); q->sp_cnt.release(); q->sp_ver.release(); q->sp_vscores.release(); q->sp_sample.release();
+    q->sp_bq.release(); q->sp_f32.release(); q->sp_cand.release(); q->sp_cnt.release(); q->sp_ver.release(); q->sp_vscores.release(); q->sp_sample.release(); q->sp_wl.release();
     q->cand.release();
     q->cand_cnt.release();
     q->cand_ids.release();
@@ -1262,6 +1262,7 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
         QMX_TRY(q->sp_f32.reserve(1024 * sizeof(float)));
         QMX_TRY(q->sp_cand.reserve((size_t)SPLIT_QT * SPLIT_CAND_CAP * sizeof(uint64_t)));
         QMX_TRY(q->sp_cnt.reserve((size_t)SPLIT_QT * 4));
+        if (s->d_rows_split) QMX_TRY(q->sp_wl.reserve(split_wlists_bytes(s->num_cus)));
         QMX_TRY(q->sp_ver.reserve((size_t)q->nq * (SPLIT_VCAP + 1) * 4));
         QMX_TRY(q->sp_vscores.reserve((size_t)q->nq * SPLIT_VCAP * 4));
         float *f = (float *)q->sp_f32.p;
@@ -1269,7 +1270,7 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
         // the sample: every (n_cand / S)-th row, S = n_cand / 256 (at least 8192): its k-th best leaves ~256 k candidates per query to the
         // main pass, at 1 / 256 of the pass's row traffic for the sample's exact scores (measured on C2: 1/128 .. 1/512 are equally good)
         // ("prescan_shift" - 2: the option of the exact scans' prefix pre-scan, 10 by default, moves this sample with it)
-        const int sshift = (int)std::min<int64_t>(std::max<int64_t>(option(OPT_PRESCAN_SHIFT) - 2, 1), 20);
+        const int sshift = (int)std::min<int64_t>(std::max<int64_t>(option(OPT_PRESCAN_SHIFT) - (s->d_rows_split ? 0 : 2), 1), 20);
         const uint64_t S = std::min<uint64_t>(n_cand, std::max<uint64_t>(n_cand >> sshift, 8192));
         if (q->sp_sample_n != S || q->sp_sample_of != n_cand) {
             QMX_TRY(q->sp_sample.reserve((size_t)S * 4));
@@ -1323,12 +1324,22 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
             QMX_HIP(hipMemsetAsync(q->sp_cnt.p, 0, (size_t)SPLIT_QT * 4, q->stream));
             QMX_TRY(split_stage(q, "pack + thresholds"));
             // 3. the approximate scan of the whole block
-            size_t slot = 0;
-            if (timed) QMX_TRY(timing_begin(q, &slot));
-            QMX_TRY(launch_scan_f32_split(q->stream, a, q->sp_bq.p, row_scale, sp_scales, sp_thr, (uint64_t *)q->sp_cand.p, (uint32_t *)q->sp_cnt.p, SPLIT_CAND_CAP,
-                                          s->num_cus, s->d_rows_split, half));
-            q->last_kernel = g_last_kernel;
-            if (timed) QMX_TRY(timing_end(q, slot));
+            // over a derived copy in two launches: the strided sixteenth of the tiles first, whose k-th best approximate score tightens the
+            // threshold of the other fifteen (sp_refine_kernel): ~16 k candidates per query instead of ~10 k x 16 from the sample's threshold alone
+            for (uint32_t phase = s->d_rows_split ? 1 : 0; phase <= (s->d_rows_split ? 2u : 0u); ++phase) {
+                size_t slot = 0;
+                if (timed) QMX_TRY(timing_begin(q, &slot));
+                QMX_TRY(launch_scan_f32_split(q->stream, a, q->sp_bq.p, row_scale, sp_scales, sp_thr, (uint64_t *)q->sp_cand.p, (uint32_t *)q->sp_cnt.p,
+                                              SPLIT_CAND_CAP, s->num_cus, s->d_rows_split, half, q->sp_wl.p, phase));
+                q->last_kernel = g_last_kernel;
+                if (timed) QMX_TRY(timing_end(q, slot));
+                if (s->d_rows_split)
+                    QMX_TRY(launch_split_regroup(q->stream, a, q->sp_wl.p, s->num_cus, (uint64_t *)q->sp_cand.p, (uint32_t *)q->sp_cnt.p, SPLIT_CAND_CAP,
+                                                 sp_overflow, phase));
+                if (phase == 1)
+                    QMX_TRY(launch_split_refine(q->stream, (const uint64_t *)q->sp_cand.p, (const uint32_t *)q->sp_cnt.p, SPLIT_CAND_CAP, sp_band, nq_tile, top,
+                                                sp_scales, sp_thr));
+            }
             QMX_TRY(split_stage(q, "split kernel"));
             // 4. the rows worth an exact score
             uint32_t *ver_ids = (uint32_t *)q->sp_ver.p + (size_t)tile0 * SPLIT_VCAP;

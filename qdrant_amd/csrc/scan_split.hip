@@ -155,6 +155,10 @@ struct SplitArgs {
     const float *scales;    // device: [1] = accumulator units per score unit, [2] = inverse
     const float *thr;       // [128] candidate threshold, accumulator units
     const uint4 *rows_split; // the pre-split copy of the block (scan_f16pair_kernel), or nullptr
+    uint32_t phase;         // scan_f16pair_kernel: 0 = every tile, 1 = tiles 0, 16, 32, ... (the strided sixteenth), 2 = all the others
+    uint4 *wlist;           // scan_f16pair_kernel: [waves][wcap] (key lo, key hi, query, 0): candidates in the order each wave met them
+    uint32_t *wcnt;         // [waves] entries each wave wanted to append (may run past wcap: overflow)
+    uint32_t wcap;
     uint64_t *cand;         // [128][cap] keys (approximate score, row)
     uint32_t *cand_cnt;     // [128] appended (may run past cap: overflow)
     uint32_t cap;
@@ -367,6 +371,12 @@ __global__ __launch_bounds__(SP_THREADS, 1) void scan_f32_split_kernel(const Sca
 // (a copy lands ~1.1 us after its issue, a stage lasts ~0.7 us): stage g requests stage g + 2 and multiplies stage g.
 // =====================================================================================================================================
 constexpr int SP3_THREADS = 512;
+constexpr uint32_t SP_PHASE_STRIDE = 16;
+__host__ __device__ inline uint64_t split_phase_tiles(uint64_t all_tiles, uint32_t phase) {
+    const uint64_t first = (all_tiles + SP_PHASE_STRIDE - 1) / SP_PHASE_STRIDE;
+    return phase == 0 ? all_tiles : phase == 1 ? first : all_tiles - first;
+}
+constexpr uint32_t SP_WCAP = 2048;                           // candidates one wave may list per pass (expected: ~200; more -> overflow -> the exact scan)
 constexpr int SP3_BM = SP_BM;                                // 256 rows per tile: a stage is 32 KiB of rows + 16 KiB of queries
 constexpr int SP3_A_UNITS = SP_A_UNITS;
 constexpr int SP3_ARING = 3;                                 // row stages in LDS: one being multiplied, two on their way
@@ -379,10 +389,18 @@ __global__ __launch_bounds__(SP3_THREADS, 1) void scan_f16pair_kernel(const Scan
     uint4 *lds = reinterpret_cast<uint4 *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint64_t n_tiles = (a.n_cand + SP3_BM - 1) / SP3_BM;
+    const uint64_t all_tiles = (a.n_cand + SP3_BM - 1) / SP3_BM;
+    const uint64_t n_tiles = split_phase_tiles(all_tiles, s.phase);
     const uint32_t nch = s.nchunks;
     const uint64_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-    if (my_tiles == 0) return;
+    const uint32_t phase = s.phase;
+    // the j-th tile of this launch: every tile | the strided sixteenth (0, 16, 32, ...: a sample that sees the whole block, whatever its
+    // order) | the complement (j + j / 15 + 1 skips the multiples of 16)
+    auto tile_of = [&](uint64_t j) -> uint64_t { return phase == 0 ? j : phase == 1 ? j * SP_PHASE_STRIDE : j + j / (SP_PHASE_STRIDE - 1) + 1; };
+    if (my_tiles == 0) {
+        if (lane == 0) s.wcnt[blockIdx.x * (SP3_THREADS / 64) + (uint32_t)w] = 0;
+        return;
+    }
     const uint32_t wm = (uint32_t)w & 3u, wn = (uint32_t)w >> 2;
     const uint32_t kq_r = (uint32_t)lane >> 4, m_r = (uint32_t)lane & 15u;
     const uint32_t a_rd = sp_unit(wm * 4, 0, kq_r, m_r), b_rd = sp_unit(wn * 4, 0, kq_r, m_r);
@@ -411,7 +429,7 @@ __global__ __launch_bounds__(SP3_THREADS, 1) void scan_f16pair_kernel(const Scan
     const unsigned char *ra_src = nullptr, *rb_src = nullptr;
     uint32_t ra_dst = 0, rb_dst = 0;
     auto rows_begin = [&]() {
-        const uint64_t tile = blockIdx.x + ra_it * gridDim.x;
+        const uint64_t tile = tile_of(blockIdx.x + ra_it * gridDim.x);
         ra_src = uniform_ptr((uint64_t)(uintptr_t)(s.rows_split + (tile * nch + ra_kc) * SP3_A_UNITS) + (uint32_t)w * 4096u);
         ra_dst = lds0 + (ra_slot * SP3_A_UNITS) * 16u + (uint32_t)w * 4096u;
         ra_slot = ra_slot + 1 == SP3_ARING ? 0 : ra_slot + 1;
@@ -444,9 +462,58 @@ __global__ __launch_bounds__(SP3_THREADS, 1) void scan_f16pair_kernel(const Scan
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // queries 0, 1 and rows 0 have landed
     sp_stage_barrier();
     uint32_t slot = 0, bslot = 0;
+    f32x4s acc[4][4];
+    // Candidates go to a list of this wave's own (position = a wave-uniform counter + the lane's rank in the ballot): plain stores, nothing
+    // that RETURNS - a returning operation (an atomic slot, a deleted-flag lookup) can only be awaited together with every copy requested
+    // before it (the counter retires in order), i.e. it drains the two-stage prefetch: ~2 us per tile with a hit, 0.4 ms per pass at 128
+    // queries.  The tile's epilogue therefore also runs at the TOP of the next stage, in front of that stage's requests: the wait at the end
+    // of a stage leaves exactly the stage's own six copies out, stores included or not.  sp_regroup_kernel sorts the lists by query afterwards
+    // (and drops deleted rows).
+    uint4 *const wl = s.wlist + (uint64_t)(blockIdx.x * (SP3_THREADS / 64) + (uint32_t)w) * s.wcap;
+    uint32_t wcount = 0;
+    auto epilogue = [&](uint64_t tile) {
+        const uint32_t row0 = (uint32_t)(tile * SP3_BM) + wm * 64 + 4 * kq_r;
+        const uint32_t n_rows32 = (uint32_t)a.n_cand;
+        // most (wave, tile) pairs hold no candidate once the thresholds bite: one maximum per query tile decides that in 60 instructions
+        bool maybe = false;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            float mx = -__builtin_inff();
+            bool nan = false;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    mx = __builtin_fmaxf(mx, acc[mt][nt][j]);
+                    nan = nan || acc[mt][nt][j] != acc[mt][nt][j];
+                }
+            maybe = maybe || !(mx < thr[nt]) || nan;
+        }
+        if (!__ballot(maybe)) return;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const uint32_t q = wn * 64 + (uint32_t)nt * 16 + m_r;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = acc[mt][nt][j];
+                    const uint32_t row = row0 + (uint32_t)mt * 16 + (uint32_t)j;
+                    const bool c = !(v < thr[nt]) && row < n_rows32 && q < s.nq;       // NaN (greatest in OrderedFloat) is a candidate
+                    const uint64_t hits = __ballot(c);
+                    if (hits) {
+                        const uint32_t at = wcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u));
+                        if (c && at < s.wcap) {
+                            const uint64_t key = make_key(v * inv_scale, row);
+                            wl[at] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), q, 0u);
+                        }
+                        wcount += (uint32_t)__builtin_popcountll(hits);
+                    }
+                }
+            }
+    };
     for (uint64_t it = 0; it < my_tiles; ++it) {
-        const uint64_t tile = blockIdx.x + it * gridDim.x;
-        f32x4s acc[4][4];
+        if (it) epilogue(tile_of(blockIdx.x + (it - 1) * gridDim.x));
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -485,55 +552,49 @@ __global__ __launch_bounds__(SP3_THREADS, 1) void scan_f16pair_kernel(const Scan
             }
             slot = slot + 1 == SP3_ARING ? 0 : slot + 1;
             bslot = (bslot + 1) & (SP3_BRING - 1);
-            if (kc + 1 == nch) {
-                const uint32_t row0 = (uint32_t)(tile * SP3_BM) + wm * 64 + 4 * kq_r;
-                const uint32_t n_rows32 = (uint32_t)a.n_cand;
-                bool any = false;
-                // most (wave, tile) pairs hold no candidate once the thresholds bite: one maximum per query tile decides that in 60 instructions
-                bool maybe = false;
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    float mx = -__builtin_inff();
-                    bool nan = false;
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            mx = __builtin_fmaxf(mx, acc[mt][nt][j]);
-                            nan = nan || acc[mt][nt][j] != acc[mt][nt][j];
-                        }
-                    maybe = maybe || !(mx < thr[nt]) || nan;
-                }
-                if (__ballot(maybe))
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float v = acc[mt][nt][j];
-                            const uint32_t row = row0 + (uint32_t)mt * 16 + (uint32_t)j;
-                            const bool c = !(v < thr[nt]) && row < n_rows32;
-                            if (__ballot(c)) {
-                                any = true;
-                                uint32_t q = wn * 64 + (uint32_t)nt * 16 + m_r;
-                                asm volatile("" : "+v"(q));
-                                if (c && q < s.nq && a.del.live(row)) {
-                                    const uint32_t cslot = atomicAdd(&s.cand_cnt[q], 1u);
-                                    if (cslot < s.cap) s.cand[(uint64_t)q * s.cap + cslot] = make_key(v * inv_scale, row);
-                                }
-                            }
-                        }
-                    }
-                // (the compiler counted the loads / atomics of the branch without knowing about the copies in flight; drain once, the count
-                // below holds again)
-                if (any) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // rows of stage g + 1 and queries of stage g + 2 have landed
             sp_stage_barrier();
         }
     }
+    epilogue(tile_of(blockIdx.x + (my_tiles - 1) * gridDim.x));
+    if (lane == 0) s.wcnt[blockIdx.x * (SP3_THREADS / 64) + (uint32_t)w] = wcount;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // nothing may land in LDS after the block is gone
+}
+
+// per-wave candidate lists -> per-query lists (what sp_select_kernel reads), deleted rows dropped.  One block per RG_LISTS wave lists: count per
+// query in LDS, reserve the block's range of every query's list with ONE global atomic per query, then place.
+constexpr int RG_LISTS = 16;
+__global__ __launch_bounds__(256) void sp_regroup_kernel(const uint4 *wlist, const uint32_t *wcnt, uint32_t wcap, uint32_t n_lists, DeletedView del,
+                                                         uint64_t *cand, uint32_t *cand_cnt, uint32_t cap, int *overflow) {
+    __shared__ uint32_t hist[SP_QT], base[SP_QT];
+    if (threadIdx.x < SP_QT) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t l0 = blockIdx.x * RG_LISTS, l1 = l0 + RG_LISTS < n_lists ? l0 + RG_LISTS : n_lists;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (uint32_t l = l0; l < l1; ++l) {
+            uint32_t cnt = wcnt[l];
+            if (cnt > wcap) {
+                if (pass == 0 && threadIdx.x == 0) *overflow = 1;
+                cnt = wcap;
+            }
+            for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
+                const uint4 e = wlist[(uint64_t)l * wcap + i];
+                if (!del.live(e.x ^ 0xFFFFFFFFu)) continue;
+                if (pass == 0) atomicAdd(&hist[e.z], 1u);
+                else {
+                    const uint32_t at = base[e.z] + atomicAdd(&hist[e.z], 1u);
+                    if (at < cap) cand[(uint64_t)e.z * cap + at] = ((uint64_t)e.y << 32) | e.x;
+                }
+            }
+        }
+        __syncthreads();
+        if (pass == 0 && threadIdx.x < SP_QT) {
+            const uint32_t c = hist[threadIdx.x];
+            base[threadIdx.x] = c ? atomicAdd(&cand_cnt[threadIdx.x], c) : 0;
+            hist[threadIdx.x] = 0;
+        }
+        __syncthreads();
+    }
 }
 
 // the pre-split copy: one thread per (row, 8-float group): out[(tile * nch + kc) * 2048 + unit(row, h / l, kq)]; rows past n are zero
@@ -571,20 +632,9 @@ __global__ __launch_bounds__(256) void sp_split_copy_kernel(const unsigned char 
 
 // ---- candidates -> the rows worth an exact score: A_k = k-th best approximate key, keep A >= A_k - 2 band (at most vcap per query) ----
 constexpr int SEL_BLOCK = 512;
-__global__ __launch_bounds__(SEL_BLOCK) void sp_select_kernel(const uint64_t *cand, const uint32_t *cand_cnt, uint32_t cap, const float *band, uint32_t top,
-                                                              uint32_t vcap, uint32_t *ver_ids, uint32_t *ver_cnt, int *overflow) {
-    __shared__ uint64_t sh[SEL_BLOCK / WAVE][WAVE];
-    __shared__ float sh_cut;
-    __shared__ uint32_t sh_n;
-    const uint32_t q = blockIdx.x;
+// k-th best of raw keys (0 when there are fewer than k), whole block; the result is valid in wave 0 (and broadcast through *sh_out after the sync)
+__device__ __forceinline__ void block_kth_key(const uint64_t *c, uint32_t raw, int ptop, uint64_t (*sh)[WAVE], uint64_t *sh_out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t raw = cand_cnt[q];
-    if (raw > cap) {                          // the candidate buffer overflowed: this pass cannot be trusted
-        if (threadIdx.x == 0) { *overflow = 1; ver_cnt[q] = 0; }
-        return;
-    }
-    const uint64_t *c = cand + (uint64_t)q * cap;
-    const int ptop = (int)top;
     uint64_t list = 0;
     for (uint32_t base = wave * WAVE; base < raw; base += SEL_BLOCK) {
         const uint32_t i = base + lane;
@@ -599,7 +649,6 @@ __global__ __launch_bounds__(SEL_BLOCK) void sp_select_kernel(const uint64_t *ca
         }
     }
     sh[wave][lane] = list;
-    if (threadIdx.x == 0) sh_n = 0;
     __syncthreads();
     if (wave == 0) {
         uint64_t merged = sh[0][lane];
@@ -613,10 +662,44 @@ __global__ __launch_bounds__(SEL_BLOCK) void sp_select_kernel(const uint64_t *ca
                 if (nk > readlane_u64(merged, ptop - 1)) wave_list_insert(merged, nk, lane);
             }
         }
-        const uint64_t kth = readlane_u64(merged, ptop - 1);
-        // fewer than k candidates: keep all of them (cut = -inf)
-        if (lane == 0) sh_cut = kth ? key_score(kth) - 2.0f * band[q] : -__builtin_inff();
+        if (lane == 0) *sh_out = readlane_u64(merged, ptop - 1);
     }
+    __syncthreads();
+}
+
+// After the strided sixteenth of the block: the k-th best APPROXIMATE score A among its rows proves k rows with an exact score >= A - band,
+// so a result row has an approximate score >= A - 2 band: the threshold of the other fifteen sixteenths (never lowered).
+__global__ __launch_bounds__(SEL_BLOCK) void sp_refine_kernel(const uint64_t *cand, const uint32_t *cand_cnt, uint32_t cap, const float *band, uint32_t top,
+                                                              const float *scales, float *thr) {
+    __shared__ uint64_t sh[SEL_BLOCK / WAVE][WAVE];
+    __shared__ uint64_t sh_kth;
+    const uint32_t q = blockIdx.x;
+    const uint32_t raw = cand_cnt[q];
+    if (raw > cap || raw < top) return;                      // overflow is sp_select_kernel's to report; fewer than k rows prove nothing
+    block_kth_key(cand + (uint64_t)q * cap, raw, (int)top, sh, &sh_kth);
+    if (threadIdx.x == 0 && sh_kth) {
+        const float t = (key_score(sh_kth) - 2.0f * band[q]) * scales[1];
+        if (t > thr[q]) thr[q] = t;
+    }
+}
+
+__global__ __launch_bounds__(SEL_BLOCK) void sp_select_kernel(const uint64_t *cand, const uint32_t *cand_cnt, uint32_t cap, const float *band, uint32_t top,
+                                                              uint32_t vcap, uint32_t *ver_ids, uint32_t *ver_cnt, int *overflow) {
+    __shared__ uint64_t sh[SEL_BLOCK / WAVE][WAVE];
+    __shared__ uint64_t sh_kth;
+    __shared__ float sh_cut;
+    __shared__ uint32_t sh_n;
+    const uint32_t q = blockIdx.x;
+    const uint32_t raw = cand_cnt[q];
+    if (raw > cap) {                          // the candidate buffer overflowed: this pass cannot be trusted
+        if (threadIdx.x == 0) { *overflow = 1; ver_cnt[q] = 0; }
+        return;
+    }
+    const uint64_t *c = cand + (uint64_t)q * cap;
+    if (threadIdx.x == 0) sh_n = 0;
+    block_kth_key(c, raw, (int)top, sh, &sh_kth);
+    // fewer than k candidates: keep all of them (cut = -inf)
+    if (threadIdx.x == 0) sh_cut = sh_kth ? key_score(sh_kth) - 2.0f * band[q] : -__builtin_inff();
     __syncthreads();
     const float cut = sh_cut;
     for (uint32_t base = 0; base < raw; base += SEL_BLOCK) {
@@ -664,6 +747,8 @@ bool split_scan_ok(const ScanArgs &a) {
     return a.dim % 128 == 0 && a.dim >= 128 && a.rem_pieces == 0 && a.tail_start == a.dim && a.row_stride % 16 == 0 && a.ids == nullptr && a.top <= 64 &&
            !option(OPT_NO_SPLIT_SCAN);
 }
+size_t split_wlists_counts_bytes(int num_cus) { return ((size_t)num_cus * (SP3_THREADS / 64) * 4 + 255) / 256 * 256; }
+size_t split_wlists_bytes(int num_cus) { return split_wlists_counts_bytes(num_cus) + (size_t)num_cus * (SP3_THREADS / 64) * SP_WCAP * 16; }
 size_t split_query_bytes(uint32_t dim) { return (size_t)(dim / 32) * SP_B_UNITS * 16; }   // (the half mode needs half of it)
 
 int32_t launch_split_row_stats(hipStream_t st, const void *rows, uint64_t row_stride, uint64_t n, uint32_t dim, uint32_t *d_stats) {
@@ -711,7 +796,7 @@ int32_t launch_split_copy(hipStream_t st, const void *rows, uint64_t row_stride,
 }
 
 int32_t launch_scan_f32_split(hipStream_t st, const ScanArgs &a, const void *d_bq, float row_scale, const float *d_scales, const float *d_thr,
-                              uint64_t *d_cand, uint32_t *d_cand_cnt, uint32_t cap, int num_cus, const void *d_rows_split, int half) {
+                              uint64_t *d_cand, uint32_t *d_cand_cnt, uint32_t cap, int num_cus, const void *d_rows_split, int half, void *d_wlists, uint32_t phase) {
     auto kfn = scan_f32_split_kernel;
     auto kfn3 = scan_f16pair_kernel<false>;
     auto kfn3h = scan_f16pair_kernel<true>;
@@ -734,7 +819,15 @@ int32_t launch_scan_f32_split(hipStream_t st, const ScanArgs &a, const void *d_b
     s.cand = d_cand;
     s.cand_cnt = d_cand_cnt;
     s.cap = cap;
-    const uint64_t n_tiles = (a.n_cand + (d_rows_split ? SP3_BM : SP_BM) - 1) / (d_rows_split ? SP3_BM : SP_BM);
+    s.wcap = SP_WCAP;
+    s.wcnt = (uint32_t *)d_wlists;                                                  // [waves] counts, then the lists (16-byte aligned)
+    s.wlist = (uint4 *)((unsigned char *)d_wlists + split_wlists_counts_bytes(num_cus));
+    QMX_REQUIRE(!d_rows_split || d_wlists, QMX_ERR_BAD_ARG, "the scan over a derived copy writes per-wave candidate lists");
+    QMX_REQUIRE(phase == 0 || d_rows_split, QMX_ERR_BAD_ARG, "phases exist for the scan over a derived copy");
+    s.phase = phase;
+    const uint64_t all_tiles = (a.n_cand + (d_rows_split ? SP3_BM : SP_BM) - 1) / (d_rows_split ? SP3_BM : SP_BM);
+    const uint64_t n_tiles = d_rows_split ? split_phase_tiles(all_tiles, phase) : all_tiles;
+    if (n_tiles == 0) return QMX_OK;
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, (uint64_t)num_cus));
     ::qmx::clear_stale_error();
     if (d_rows_split && half) {
@@ -747,6 +840,27 @@ int32_t launch_scan_f32_split(hipStream_t st, const ScanArgs &a, const void *d_b
         QMX_NOTE_KERNEL(kfn);
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(SP_THREADS), (size_t)SP_LDS, st, a, s);
     }
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+// per-wave lists of launch_scan_f32_split (over a derived copy) -> d_cand / d_cand_cnt; d_cand_cnt zeroed by the caller before the scan
+int32_t launch_split_regroup(hipStream_t st, const ScanArgs &a, const void *d_wlists, int num_cus, uint64_t *d_cand, uint32_t *d_cand_cnt, uint32_t cap,
+                             int *d_overflow, uint32_t phase) {
+    const uint64_t n_tiles = split_phase_tiles((a.n_cand + SP3_BM - 1) / SP3_BM, phase);
+    if (n_tiles == 0) return QMX_OK;
+    const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, (uint64_t)num_cus));
+    const uint32_t n_lists = grid * (SP3_THREADS / 64);
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(sp_regroup_kernel, dim3((n_lists + RG_LISTS - 1) / RG_LISTS), dim3(256), 0, st,
+                       (const uint4 *)((const unsigned char *)d_wlists + split_wlists_counts_bytes(num_cus)), (const uint32_t *)d_wlists, (uint32_t)SP_WCAP, n_lists,
+                       a.del, d_cand, d_cand_cnt, cap, d_overflow);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+int32_t launch_split_refine(hipStream_t st, const uint64_t *d_cand, const uint32_t *d_cand_cnt, uint32_t cap, const float *d_band, uint32_t nq, uint32_t top,
+                            const float *d_scales, float *d_thr) {
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(sp_refine_kernel, dim3(nq), dim3(SEL_BLOCK), 0, st, d_cand, d_cand_cnt, cap, d_band, top, d_scales, d_thr);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }
