@@ -454,6 +454,21 @@ QMX_API int32_t qmx_multi_search_topk(qmx_query *inner, const uint32_t *query_fi
                                       uint32_t n_points, const uint64_t *point_deleted, uint64_t n_deleted_bits, uint32_t top,
                                       const uint32_t *ids, uint64_t n_ids, qmx_scored_point *out, uint32_t *out_counts);
 
+/* QUANTIZED multi-vectors (`QuantizedMultivectorStorage`, lib/segment/src/vector_storage/quantized/quantized_multivector_storage/mod.rs:76-393,
+ * `MultivectorOffset{start, count}` :39-42): the two calls above accept an `inner` batch over an SQ, PQ or BQ segment of the quantized INNER
+ * rows; the similarities are then the quantized scorer's (`quantized_storage.score(inner_query, vector)`), max / sum as
+ * `score_point_max_similarity` (:339-363).
+ *
+ * The HNSW walk over multi-vector points (`GraphLayers::search` with `MultiMetricQueryScorer`, query_scorer/multi_metric_query_scorer.rs:18-127, or the
+ * quantized `QuantizedMultiQueryScorer`, quantized/quantized_multi_query_scorer.rs): `g` is the graph over the n_points POINTS; every hop candidate
+ * is scored by MaxSim of the multi-query against the point's inner rows, inside the walk kernel (dense, SQ and BQ inner rows; PQ:
+ * QMX_ERR_NOT_SUPPORTED).  A multi-query's inner vectors must fit the LDS (16 + tokens x query-entry bytes <= 150 KiB).  Deleted flags are per
+ * point, as in qmx_multi_search_topk; a filter set with qmx_query_set_filter on `inner` is read as a bitmap over POINTS.  out [n_queries][top],
+ * counters->vectors_scored = points scored. */
+QMX_API int32_t qmx_multi_hnsw_search(const qmx_hnsw *g, qmx_query *inner, const uint32_t *query_first, uint32_t n_queries,
+                                      const uint64_t *point_offsets, uint32_t n_points, const uint64_t *point_deleted, uint64_t n_deleted_bits,
+                                      uint32_t top, uint32_t ef, qmx_scored_point *out, uint32_t *out_counts, qmx_counters *counters);
+
 /* `RawScorer::score_points` of custom scorers: scores[qi * n + i] = custom query qi against stored point ids[i]. */
 QMX_API int32_t qmx_custom_score_points(qmx_query *examples, const qmx_custom_query *queries, uint32_t n_queries,
                                         const uint32_t *ids, uint32_t n, float *scores);

@@ -169,14 +169,21 @@ void qo_merge_topk(const qo_scored_point *lists, const uint32_t *counts, const u
                    uint32_t n_lists, uint32_t nq, uint32_t k, qo_scored_point *out, uint32_t *out_counts);
 
 /* ---- scorer = FilteredScorer{RawScorer, NotDeletedChecker} (hnsw_index/point_scorer.rs:53-63) ---- */
-typedef struct {
-    int kind;                 /* 0 dense (Metric over st->rows), 1 SQ (EncodedVectorsU8), 2 PQ (EncodedVectorsPQ), 3 BQ (EncodedVectorsBin<u128>) */
+typedef struct qo_scorer {
+    int kind;                 /* 0 dense (Metric over st->rows), 1 SQ (EncodedVectorsU8), 2 PQ (EncodedVectorsPQ), 3 BQ (EncodedVectorsBin<u128>),
+                                 4 multi-vector MaxSim over an inner scorer of one of the kinds above (fields mv_*) */
     const qo_storage *st;     /* dense rows for kind 0; the deleted flags and n for every kind */
     const void *query;        /* kind 0: preprocessed + cast query, [dim] elements */
     const qo_sq *sq; const uint8_t *sq_rows; const uint8_t *sq_query; float sq_query_offset;
     const qo_pq *pq; const uint8_t *pq_codes; const float *pq_lut;
     int isa;                  /* leaf used for SQ / PQ scoring */
     const uint8_t *bq_rows; const uint8_t *bq_query; uint32_t bq_dim; int bq_distance; int bq_invert;   /* kind 3 */
+    /* kind 4: `st` = the POINT-level storage (n = points, deleted flags of points; rows unused).  Point p = inner rows
+     * [mv_offsets[p], mv_offsets[p + 1]) of the inner storage; the query = mv_n_tokens inner scorers (one per inner query vector, each a
+     * complete scorer of the inner kind over the inner rows).  score_point = score_max_similarity (query_scorer/mod.rs:70-97, dense) =
+     * QuantizedMultivectorStorage::score_point_max_similarity (quantized_multivector_storage/mod.rs:339-363); score_internal =
+     * score_internal_max_similarity (:366-393) / MultiMetricQueryScorer::score_internal through mv_tokens[0] as the inner template. */
+    const struct qo_scorer *mv_tokens; uint32_t mv_n_tokens; const uint64_t *mv_offsets;
 } qo_scorer;
 float qo_scorer_score_point(const qo_scorer *s, uint32_t id);              /* RawScorer::score_point */
 float qo_scorer_score_internal(const qo_scorer *s, uint32_t a, uint32_t b); /* RawScorer::score_internal */

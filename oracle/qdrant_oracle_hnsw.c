@@ -50,6 +50,18 @@ int qo_scorer_check_vector(const qo_scorer *s, uint32_t id) { /* NotDeletedCheck
 
 float qo_scorer_score_point(const qo_scorer *s, uint32_t id) {
     float out = 0.f;
+    if (s->kind == 4) {   /* sum over the query's inner vectors (from 0.0) of the max over the point's inner vectors (`if max_sim < sim`, from -inf) */
+        float sum = 0.0f;
+        for (uint32_t t = 0; t < s->mv_n_tokens; t++) {
+            float max_sim = -INFINITY;
+            for (uint64_t b = s->mv_offsets[id]; b < s->mv_offsets[id + 1]; b++) {
+                const float sim = qo_scorer_score_point(&s->mv_tokens[t], (uint32_t)b);
+                if (max_sim < sim) max_sim = sim;
+            }
+            sum += max_sim;
+        }
+        return sum;
+    }
     switch (s->kind) {
         case 0: qo_score_points(s->st, s->query, &id, 1, &out); return out;
         case 1: return qo_sq_score(s->sq, s->sq_query, s->sq_query_offset,
@@ -61,6 +73,18 @@ float qo_scorer_score_point(const qo_scorer *s, uint32_t id) {
 
 float qo_scorer_score_internal(const qo_scorer *s, uint32_t a, uint32_t b) {
     float out = 0.f;
+    if (s->kind == 4) {   /* score_internal_max_similarity: every inner vector of a against the inner vectors of b (`if sim > max_sim`) */
+        float sum = 0.0f;
+        for (uint64_t i = s->mv_offsets[a]; i < s->mv_offsets[a + 1]; i++) {
+            float max_sim = -INFINITY;
+            for (uint64_t j = s->mv_offsets[b]; j < s->mv_offsets[b + 1]; j++) {
+                const float sim = qo_scorer_score_internal(&s->mv_tokens[0], (uint32_t)i, (uint32_t)j);
+                if (sim > max_sim) max_sim = sim;
+            }
+            sum += max_sim;
+        }
+        return sum;
+    }
     switch (s->kind) {
         case 0: { /* MetricQueryScorer::score_internal: similarity(get_dense(a), get_dense(b)), metric_query_scorer.rs:94-99 */
             const char *ra = (const char *)s->st->rows + (size_t)a * s->st->dim * elem_size(s->st->dtype);

@@ -2074,8 +2074,26 @@ int32_t qmx_hnsw_build_quantized(const qmx_segment *seg, const qmx_segment *orig
     return QMX_OK;
 }
 
+// the MaxSim walk over multi-vector points (qmx_multi_hnsw_search): device arrays of the query / point partitions and the POINT-level deleted view
+struct MultiWalk {
+    const uint32_t *d_qfirst;
+    const uint64_t *d_offsets;
+    uint32_t n_queries, max_tokens;
+    DeletedView del;
+};
+
 static int32_t launch_hnsw(const qmx_query *q, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
     const qmx_segment *s = q->seg;
+    if (a.mv_offsets) {
+        if (s->dtype <= QMX_DTYPE_U8) {
+            QMX_REQUIRE(s->fast_layout(), QMX_ERR_NOT_SUPPORTED, "adopted device block is not 16-byte aligned");
+            return launch_hnsw_maxsim_dense(q->stream, (int)s->dtype, (int)s->distance, a, h, grid, per_cu);
+        }
+        if (s->dtype == QMX_DTYPE_SQ_U8) return launch_hnsw_maxsim_sq(q->stream, (int)s->distance, a, h, grid, per_cu);
+        if (s->dtype == QMX_DTYPE_BQ) return launch_hnsw_maxsim_bq(q->stream, a, h, grid, per_cu);
+        set_error("MaxSim walk: inner rows of dtype %u are not built (dense, SQ and BQ are)", s->dtype);
+        return QMX_ERR_NOT_SUPPORTED;
+    }
     if (s->dtype <= QMX_DTYPE_U8) {
         QMX_REQUIRE(s->fast_layout(), QMX_ERR_NOT_SUPPORTED, "adopted device block is not 16-byte aligned");
         return launch_hnsw_dense(q->stream, (int)s->dtype, (int)s->distance, a, h, grid, per_cu);
@@ -2089,10 +2107,16 @@ static int32_t launch_hnsw(const qmx_query *q, const ScanArgs &a, const HnswArgs
 
 
 static int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef, qmx_scored_point *d_out,
-                            uint32_t *d_counts, uint32_t *d_scored, bool timed, bool acorn = false) {
+                            uint32_t *d_counts, uint32_t *d_scored, bool timed, bool acorn = false, const MultiWalk *mw = nullptr) {
     const qmx_segment *s = q->seg;
     ScanArgs a;
     fill_args(q, 0, q->nq, a);
+    const uint32_t n_searches = mw ? mw->n_queries : q->nq;
+    if (mw) {
+        a.mv_offsets = mw->d_offsets;
+        a.mv_qfirst = mw->d_qfirst;
+        a.del = mw->del;
+    }
     HnswArgs h;
     memset(&h, 0, sizeof(h));
     h.reindex = g->d_reindex; h.level_offsets = g->d_level_offsets; h.offsets = g->d_offsets; h.neighbors = g->d_neighbors;
@@ -2101,9 +2125,15 @@ static int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint3
     h.n_points = g->n_points; h.n_levels = g->n_levels; h.m = g->m; h.m0 = g->m0;
     h.ep_ids = g->d_ep_ids; h.ep_levels = g->d_ep_levels; h.n_ep = g->n_ep;
     h.xp_ids = g->d_xp_ids; h.xp_levels = g->d_xp_levels; h.n_xp = g->n_xp;
-    h.ef = ef; h.top = top; h.nq = q->nq;
+    h.ef = ef; h.top = top; h.nq = n_searches;
     h.out = d_out; h.out_counts = d_counts; h.out_scored = d_scored;
     h.lds_query_bytes = q->q_stride <= HNSW_LDS_QUERY_MAX ? q->q_stride : 0;
+    if (mw) {   // [16-byte header][the multi-query's inner vectors]
+        const uint64_t need = 16 + (uint64_t)std::max<uint32_t>(mw->max_tokens, 1) * q->q_stride;
+        QMX_REQUIRE(need <= HNSW_LDS_QUERY_MAX, QMX_ERR_NOT_SUPPORTED, "a multi-query of %u inner vectors x %u bytes does not fit the LDS", mw->max_tokens,
+                    q->q_stride);
+        h.lds_query_bytes = (uint32_t)need;
+    }
     // A PQ LUT of more than half the LDS leaves one search per CU; the walk is a chain of dependent memory round trips,
     // so many searches per CU with the LUT read through L2 win (measured: tools/bench_hnsw.py)
     if (s->dtype == QMX_DTYPE_PQ && q->q_stride > 16 * 1024 && !option(OPT_HNSW_PQ_LDS_LUT)) h.lds_query_bytes = 0;
@@ -2123,12 +2153,12 @@ static int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint3
     }
     int per_cu = 1;
     QMX_TRY(launch_hnsw(q, a, h, 0, &per_cu));
-    uint64_t slots = std::min<uint64_t>({(uint64_t)q->nq, (uint64_t)s->num_cus * per_cu, (uint64_t)HNSW_SLOT_CAP});
+    uint64_t slots = std::min<uint64_t>({(uint64_t)n_searches, (uint64_t)s->num_cus * per_cu, (uint64_t)HNSW_SLOT_CAP});
     const uint64_t by_budget = std::max<uint64_t>(1, HNSW_VIS_BUDGET / (h.vis_words * 4));
     slots = std::max<uint64_t>(1, std::min(slots, by_budget));
     if (q->hnsw_slots < slots || q->hnsw_vis_words != h.vis_words) {
         // (re)allocate for the largest slot count this handle can use, zero once: the kernel returns the bitmaps all-zero
-        const uint64_t want = std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)std::max<uint32_t>(q->nq, 1), (uint64_t)s->num_cus * per_cu,
+        const uint64_t want = std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)std::max<uint32_t>(std::max(q->nq, n_searches), 1), (uint64_t)s->num_cus * per_cu,
                                                                        (uint64_t)HNSW_SLOT_CAP, by_budget}));
         QMX_HIP(hipStreamSynchronize(q->stream));
         q->hnsw_slots = 0;
@@ -2413,7 +2443,6 @@ int32_t qmx_custom_search_topk(qmx_query *ex, const qmx_custom_query *queries, u
 static int32_t multi_prepare(qmx_query *inner, const uint32_t *query_first, uint32_t n_queries, const uint64_t *point_offsets, uint32_t n_points,
                              const uint32_t *d_ids, uint64_t n) {
     const qmx_segment *s = inner->seg;
-    QMX_REQUIRE(s->dtype <= QMX_DTYPE_U8, QMX_ERR_NOT_SUPPORTED, "MaxSim scores original vectors (dense storages)");
     const bool qf_dev = is_device_ptr(query_first), off_dev = is_device_ptr(point_offsets);
     QMX_REQUIRE(!qf_dev && !off_dev, QMX_ERR_BAD_ARG, "query_first and point_offsets are host arrays (they are validated here)");
     QMX_REQUIRE(query_first[0] <= query_first[n_queries] && query_first[n_queries] <= inner->nq, QMX_ERR_OUT_OF_BOUNDS,
@@ -2488,6 +2517,75 @@ int32_t qmx_multi_search_topk(qmx_query *inner, const uint32_t *query_first, uin
     if (!out_dev) QMX_TRY(copy_out(inner->stream, out, d_out, (size_t)n_queries * top * sizeof(qmx_scored_point)));
     if (!cnt_dev) QMX_TRY(copy_out(inner->stream, out_counts, d_oc, (size_t)n_queries * 4));
     return check_err_flag(inner);
+}
+
+int32_t qmx_multi_hnsw_search(const qmx_hnsw *g, qmx_query *inner, const uint32_t *query_first, uint32_t n_queries, const uint64_t *point_offsets,
+                              uint32_t n_points, const uint64_t *point_deleted, uint64_t n_deleted_bits, uint32_t top, uint32_t ef,
+                              qmx_scored_point *out, uint32_t *out_counts, qmx_counters *counters) {
+    QMX_REQUIRE(g && inner && query_first && point_offsets && out && out_counts, QMX_ERR_BAD_ARG, "NULL argument");
+    const qmx_segment *s = inner->seg;
+    QMX_REQUIRE(g->device == s->device, QMX_ERR_BAD_ARG, "graph lives on device %d, the segment on %d", g->device, s->device);
+    QMX_REQUIRE(g->n_points <= n_points, QMX_ERR_OUT_OF_BOUNDS, "graph has %u points, the multi-vector storage %u", g->n_points, n_points);
+    QMX_REQUIRE(top >= 1, QMX_ERR_BAD_ARG, "top must be > 0");
+    QMX_REQUIRE(std::max(top, ef) <= HNSW_MAX_EF, QMX_ERR_NOT_SUPPORTED, "max(top, ef) = %u > %u not supported yet", std::max(top, ef), HNSW_MAX_EF);
+    QMX_REQUIRE(!is_device_ptr(query_first) && !is_device_ptr(point_offsets), QMX_ERR_BAD_ARG, "query_first and point_offsets are host arrays");
+    QMX_HIP(hipSetDevice(inner->device));
+    if (counters) memset(counters, 0, sizeof(*counters));
+    if (n_queries == 0) return QMX_OK;
+    QMX_REQUIRE(query_first[n_queries] <= inner->nq, QMX_ERR_OUT_OF_BOUNDS, "multi-queries reach past the %u inner query vectors of the batch", inner->nq);
+    uint32_t max_tokens = 0;
+    for (uint32_t j = 0; j < n_queries; ++j) {
+        QMX_REQUIRE(query_first[j] <= query_first[j + 1], QMX_ERR_BAD_ARG, "query_first is not ascending at %u", j);
+        max_tokens = std::max(max_tokens, query_first[j + 1] - query_first[j]);
+    }
+    for (uint32_t p = 0; p < n_points; ++p)
+        QMX_REQUIRE(point_offsets[p] <= point_offsets[p + 1], QMX_ERR_BAD_ARG, "point_offsets is not ascending at %u", p);
+    QMX_REQUIRE(point_offsets[n_points] <= s->n, QMX_ERR_OUT_OF_BOUNDS, "point_offsets reach past the %llu inner rows of the segment",
+                (unsigned long long)s->n);
+    const bool out_dev = is_device_ptr(out), cnt_dev = is_device_ptr(out_counts);
+    if (g->n_points == 0) {   // get_entry_point() -> None
+        if (cnt_dev) QMX_HIP(hipMemset(out_counts, 0, (size_t)n_queries * 4));
+        else memset(out_counts, 0, (size_t)n_queries * 4);
+        return QMX_OK;
+    }
+    QMX_TRY(inner->mv_qfirst.reserve((size_t)(n_queries + 1) * 4));
+    QMX_TRY(inner->mv_offsets.reserve((size_t)(n_points + 1) * 8));
+    QMX_HIP(hipMemcpyAsync(inner->mv_qfirst.p, query_first, (size_t)(n_queries + 1) * 4, hipMemcpyHostToDevice, inner->stream));
+    QMX_HIP(hipMemcpyAsync(inner->mv_offsets.p, point_offsets, (size_t)(n_points + 1) * 8, hipMemcpyHostToDevice, inner->stream));
+    MultiWalk mw;
+    memset(&mw, 0, sizeof(mw));
+    mw.d_qfirst = (const uint32_t *)inner->mv_qfirst.p;
+    mw.d_offsets = (const uint64_t *)inner->mv_offsets.p;
+    mw.n_queries = n_queries;
+    mw.max_tokens = max_tokens;
+    mw.del.n_rows = n_points;      // deletion is per POINT (the id tracker's bitslice over multi-vector points), not per inner row
+    if (point_deleted && n_deleted_bits) {
+        const void *d_bits = nullptr;
+        QMX_TRY(stage_in(inner, inner->mv_deleted, point_deleted, (size_t)((n_deleted_bits + 63) / 64) * 8, &d_bits));
+        mw.del.point_deleted = (const uint64_t *)d_bits;
+        mw.del.n_point_bits = n_deleted_bits;
+    }
+    if (inner->has_filter) { mw.del.allowed = (const uint64_t *)inner->filter.p; mw.del.n_allowed_bits = inner->n_filter_bits; }
+    qmx_scored_point *d_out = out;
+    uint32_t *d_counts = out_counts;
+    if (!out_dev) { QMX_TRY(inner->out.reserve((size_t)n_queries * top * sizeof(qmx_scored_point))); d_out = (qmx_scored_point *)inner->out.p; }
+    if (!cnt_dev) { QMX_TRY(inner->counts.reserve((size_t)n_queries * 4)); d_counts = (uint32_t *)inner->counts.p; }
+    QMX_TRY(inner->hnsw_scored.reserve((size_t)n_queries * 4));
+    const bool timed = inner->timing || (s->flags & QMX_SEG_TIME_KERNELS) != 0;
+    QMX_TRY(hnsw_enqueue(g, inner, top, ef, d_out, d_counts, (uint32_t *)inner->hnsw_scored.p, timed, false, &mw));
+    if (!out_dev) QMX_TRY(copy_out(inner->stream, out, d_out, (size_t)n_queries * top * sizeof(qmx_scored_point)));
+    if (!cnt_dev) QMX_TRY(copy_out(inner->stream, out_counts, d_counts, (size_t)n_queries * 4));
+    QMX_TRY(check_err_flag(inner));    // synchronises (the staged partitions may go away)
+    if (counters) {
+        std::vector<uint32_t> sc(n_queries);
+        QMX_HIP(hipMemcpy(sc.data(), inner->hnsw_scored.p, (size_t)n_queries * 4, hipMemcpyDeviceToHost));
+        uint64_t total = 0;
+        for (uint32_t v : sc) total += v;
+        counters->vectors_scored = total;            // POINTS scored (each costs |query| x |point| inner scores)
+        counters->kernel_launches = 1;
+        if (timed) { const float before = inner->timing_ms; QMX_TRY(timing_fold(inner)); counters->kernel_ms = inner->timing_ms - before; }
+    }
+    return QMX_OK;
 }
 
 int32_t qmx_search_quantized(const qmx_hnsw *g, qmx_query *quantized, qmx_query *raw, const qmx_search_params *p, const uint32_t *ids,

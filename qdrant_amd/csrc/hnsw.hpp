@@ -77,6 +77,39 @@ struct HopSmall {
     }
 };
 
+// Multi-vector points with the MaxSim comparator (MultiMetricQueryScorer, query_scorer/multi_metric_query_scorer.rs + score_max_similarity,
+// query_scorer/mod.rs:70-97; quantized: QuantizedMultivectorStorage::score_point_max_similarity, quantized_multivector_storage/mod.rs:339-363):
+// the graph's points are multi-vectors, a hop candidate's score is the sum over the query's inner vectors (in order, from 0.0) of the max
+// over the point's inner vectors (`if max_sim < sim`, from -inf) of the inner policy's score.  The query entry in LDS is
+// [16-byte header: number of inner query vectors][that many tile entries]; qp points at the first entry.
+template <class H, class = void>
+struct is_maxsim { static constexpr bool value = false; };
+template <class H>
+struct is_maxsim<H, decltype((void)H::MAXSIM)> { static constexpr bool value = H::MAXSIM; };
+template <class HI>
+struct HopMaxSim {
+    static constexpr int LPI = HI::LPI;
+    static constexpr bool INTERNAL_QOFF = false;
+    static constexpr bool INTERNAL_NORM = false;
+    static constexpr bool MULTI = false;
+    static constexpr bool MAXSIM = true;
+    static __device__ __forceinline__ float score(const ScanArgs &a, const unsigned char *qp, uint32_t id, int sub) {
+        const uint32_t n_tokens = *reinterpret_cast<const uint32_t *>(qp - 16);
+        const uint64_t b0 = a.mv_offsets[id], b1 = a.mv_offsets[id + 1];
+        float sum = 0.0f;
+        for (uint32_t t = 0; t < n_tokens; ++t) {
+            const unsigned char *qe = qp + (size_t)t * a.q_stride;
+            float max_sim = -__builtin_inff();
+            for (uint64_t b = b0; b < b1; ++b) {
+                const float sim = HI::score(a, qe, (uint32_t)b, sub);
+                if (max_sim < sim) max_sim = sim;
+            }
+            sum += max_sim;
+        }
+        return sum;
+    }
+};
+
 // ---- the beam: sorted descending, entry index = e * 64 + lane ------------------------------------
 template <int E>
 struct Beam {
@@ -509,6 +542,19 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const ScanArgs a, const
     uint32_t *vis = h.visited + (uint64_t)blockIdx.x * h.vis_words;
     uint32_t *vlog = h.vis_log + (uint64_t)blockIdx.x * h.log_cap;
     for (uint32_t qi = blockIdx.x; qi < h.nq; qi += gridDim.x) {
+        if constexpr (is_maxsim<H>::value) {
+            // (always staged in LDS: launch_hnsw_hop refuses a multi-query that does not fit)
+            const uint32_t t0 = a.mv_qfirst[qi], n_tokens = a.mv_qfirst[qi + 1] - t0;
+            const unsigned char *qg = reinterpret_cast<const unsigned char *>(a.queries) + (uint64_t)t0 * a.q_stride;
+            __syncthreads();
+            const uint4 *src = reinterpret_cast<const uint4 *>(qg);
+            uint4 *dst = reinterpret_cast<uint4 *>(q_lds + 16);
+            for (uint32_t i = (uint32_t)lane; i < n_tokens * (a.q_stride / 16); i += 64) dst[i] = src[i];
+            if (lane == 0) *reinterpret_cast<uint32_t *>(q_lds) = n_tokens;
+            __syncthreads();
+            hnsw_search_one<H, E>(a, h, q_lds + 16, hop_ids, hop_scores, vis, vlog, qi, lane);
+            continue;
+        }
         const unsigned char *qg = reinterpret_cast<const unsigned char *>(a.queries) + (uint64_t)qi * a.q_stride;
         if constexpr (QLDS) {
             __syncthreads();
@@ -555,6 +601,7 @@ int32_t launch_hnsw_hop(hipStream_t st, const ScanArgs &a, const HnswArgs &h, ui
     const uint32_t ef = h.ef > h.top ? h.ef : h.top;
     QMX_REQUIRE(ef >= 1 && ef <= HNSW_MAX_EF, QMX_ERR_NOT_SUPPORTED, "hnsw ef %u not in 1..%u", ef, HNSW_MAX_EF);
     const bool qlds = h.lds_query_bytes > 0;
+    if constexpr (is_maxsim<H>::value) QMX_REQUIRE(qlds, QMX_ERR_NOT_SUPPORTED, "the inner vectors of a multi-query must fit the LDS");
     if (grid == 0) {
         const size_t hop_lds = 8 * (size_t)h.hop_cap + (h.acorn ? 256 : 0);
         if (ef <= 128) return qlds ? hnsw_occupancy_inst<H, 2, true>(h.lds_query_bytes, hop_lds, per_cu) : hnsw_occupancy_inst<H, 2, false>(0, hop_lds, per_cu);
@@ -572,6 +619,14 @@ struct HnswLauncher {
     int *per_cu;
     template <class P> int32_t row(const ScanArgs &a) const { return launch_hnsw_hop<HopRow<P>>(st, a, *h, grid, per_cu); }
     template <class S> int32_t small(const ScanArgs &a) const { return launch_hnsw_hop<HopSmall<S>>(st, a, *h, grid, per_cu); }
+};
+struct HnswMaxSimLauncher {
+    hipStream_t st;
+    const HnswArgs *h;
+    uint32_t grid;
+    int *per_cu;
+    template <class P> int32_t row(const ScanArgs &a) const { return launch_hnsw_hop<HopMaxSim<HopRow<P>>>(st, a, *h, grid, per_cu); }
+    template <class S> int32_t small(const ScanArgs &a) const { return launch_hnsw_hop<HopMaxSim<HopSmall<S>>>(st, a, *h, grid, per_cu); }
 };
 
 }  // namespace qmx

@@ -53,6 +53,10 @@ struct ScanArgs {
     uint32_t bq_dim;           // original dimension
     uint32_t bq_flip;          // 0: zeros - xor (every distance with its own invert), 1: xor - zeros
     uint32_t bq_qbits;         // bit planes per query value: 1 (QueryEncoding::SameAsStorage, internal queries), 4 or 8 (Scalar4bits / Scalar8bits)
+    // multi-vectors (MaxSim walk, hnsw.hpp HopMaxSim): point p = inner rows [mv_offsets[p], mv_offsets[p + 1]); multi-query j = query entries
+    // [mv_qfirst[j], mv_qfirst[j + 1])
+    const uint64_t *mv_offsets;
+    const uint32_t *mv_qfirst;
 };
 
 enum ScanMode { SCAN_TOPK = 0, SCAN_SCORES = 1 };
@@ -94,6 +98,10 @@ struct HnswArgs {
 
 // grid == 0: only report the occupancy (blocks of one wave per CU) of the instantiation in *per_cu
 int32_t launch_hnsw_dense(hipStream_t st, int dtype, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
+// the MaxSim walk over multi-vector points (HopMaxSim): dense, SQ and BQ inner rows
+int32_t launch_hnsw_maxsim_dense(hipStream_t st, int dtype, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
+int32_t launch_hnsw_maxsim_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
+int32_t launch_hnsw_maxsim_bq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_pq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_bq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);

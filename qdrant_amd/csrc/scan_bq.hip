@@ -262,6 +262,9 @@ int32_t launch_pairs_bq(hipStream_t st, const ScanArgs &a, const PairSel &sel, u
 int32_t launch_hnsw_bq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
     return dispatch_bq(HnswLauncher{st, &h, grid, per_cu}, a);
 }
+int32_t launch_hnsw_maxsim_bq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
+    return dispatch_bq(HnswMaxSimLauncher{st, &h, grid, per_cu}, a);
+}
 // device HNSW build through the BQ scorer: a stored bit row IS its internal query (encode_internal_vector :923-934), one bit per value
 // whatever the segment's QueryEncoding (score_internal :892-917)
 int32_t launch_hnsw_build_bq(hipStream_t st, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu) {

@@ -113,6 +113,9 @@ int32_t launch_pairs_sq(hipStream_t st, int distance, const ScanArgs &a, const P
 int32_t launch_hnsw_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
     return dispatch_sq(HnswLauncher{st, &h, grid, per_cu}, distance, a);
 }
+int32_t launch_hnsw_maxsim_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
+    return dispatch_sq(HnswMaxSimLauncher{st, &h, grid, per_cu}, distance, a);
+}
 int32_t launch_hnsw_build_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu) {
     const HnswBuildLauncher l{st, &h, phase, grid, per_cu};
     const bool l1 = distance == QMX_DISTANCE_MANHATTAN;

@@ -401,8 +401,8 @@ class MultiDenseVectorStorage:
     inner vectors of all points flattened into one dense block on the device + per-point offsets."""
 
     def __init__(self, inner_vectors, point_offsets, distance: Distance, datatype: VectorStorageDatatype = VectorStorageDatatype.Float32,
-                 device_id: int = 0):
-        self.inner = VectorStorage(inner_vectors, distance, datatype, device_id=device_id)
+                 device_id: int = 0, inner_storage=None):
+        self.inner = inner_storage if inner_storage is not None else VectorStorage(inner_vectors, distance, datatype, device_id=device_id)
         self.offsets = np.ascontiguousarray(point_offsets, dtype=np.uint64)
         self.count = len(self.offsets) - 1
         self.point_deleted = None
@@ -437,6 +437,30 @@ class MultiDenseVectorStorage:
                                               0 if self.point_deleted is None else len(self.point_deleted), top, F.ptr(idarr),
                                               0 if idarr is None else len(idarr), F.ptr(out), F.ptr(counts)))
         return [out[i, :counts[i]].copy() for i in range(nq)]
+
+    def search_hnsw(self, graph, multi_queries, top: int, ef: int, with_counters: bool = False):
+        """`GraphLayers::search` over the multi-vector POINTS with the MaxSim scorer of every multi-query (`MultiMetricQueryScorer` /
+        `QuantizedMultiQueryScorer` behind `FilteredScorer`), on device."""
+        scorer, first = self._queries(multi_queries)
+        nq = len(first) - 1
+        out = np.zeros((nq, top), dtype=ScoredPointOffset)
+        counts = np.zeros(nq, dtype=np.uint32)
+        words = _bits_to_words(self.point_deleted)
+        ctr = F.Counters()
+        F.check(F.lib().qmx_multi_hnsw_search(graph._h, scorer._h, F.ptr(first), nq, F.ptr(self.offsets), self.count, F.ptr(words),
+                                              0 if self.point_deleted is None else len(self.point_deleted), top, ef, F.ptr(out), F.ptr(counts),
+                                              C.byref(ctr)))
+        res = [out[i, :counts[i]].copy() for i in range(nq)]
+        return (res, ctr) if with_counters else res
+
+
+class QuantizedMultivectorStorage(MultiDenseVectorStorage):
+    """`QuantizedMultivectorStorage<QuantizedStorage, Offsets>` (vector_storage/quantized/quantized_multivector_storage/mod.rs:76-130): the
+    quantized INNER rows (an `EncodedVectorsU8` / `EncodedVectorsPQ` / `EncodedVectorsBin` storage on the device) + `MultivectorOffset`s as
+    ascending `[n_points + 1]` row offsets; MaxSim over the quantized scores (`score_point_max_similarity`, :339-363)."""
+
+    def __init__(self, quantized_inner_storage, point_offsets):
+        super().__init__(None, point_offsets, None, inner_storage=quantized_inner_storage)
 
 
 def load_quantizer(meta_json, dtype: int):

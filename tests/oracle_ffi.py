@@ -421,7 +421,8 @@ class Scorer(C.Structure):
     _fields_ = [("kind", C.c_int), ("st", C.POINTER(Storage)), ("query", _P),
                 ("sq", C.POINTER(Sq)), ("sq_rows", _P), ("sq_query", _P), ("sq_query_offset", _f),
                 ("pq", C.POINTER(Pq)), ("pq_codes", _P), ("pq_lut", _P), ("isa", C.c_int),
-                ("bq_rows", _P), ("bq_query", _P), ("bq_dim", C.c_uint32), ("bq_distance", C.c_int), ("bq_invert", C.c_int)]
+                ("bq_rows", _P), ("bq_query", _P), ("bq_dim", C.c_uint32), ("bq_distance", C.c_int), ("bq_invert", C.c_int),
+                ("mv_tokens", _P), ("mv_n_tokens", C.c_uint32), ("mv_offsets", _P)]
 
 
 _sig("qo_merge_topk", None, [_P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P])
@@ -623,6 +624,89 @@ class Hnsw:
             s.pq_lut, s.isa = lut.ctypes.data, pq.isa
             res.append(self._run(s, top, ef)[0])
         return res
+
+
+class MultiOracle:
+    """Multi-vector points with MaxSim over an inner scorer (qo_scorer kind 4): `MultiMetricQueryScorer` over dense inner rows, or
+    `QuantizedMultivectorStorage` over SQ / BQ / PQ inner rows.  inner = ("dense", DenseStorage) | ("sq", DenseStorage, SqOracle) |
+    ("bq", DenseStorage, BqOracle) | ("pq", DenseStorage, PqOracle) where the DenseStorage holds the PREPROCESSED inner rows (for the
+    quantized kinds only its row count and, for PQ builds, its rows matter).  offsets: [n_points + 1] ascending inner-row offsets."""
+
+    def __init__(self, inner, offsets, point_deleted=None):
+        self.inner, self.kind = inner, inner[0]
+        self.offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self.n_points = len(self.offsets) - 1
+        # the POINT-level storage: n, deleted flags (rows unused)
+        self.points = DenseStorage(F32, DOT, np.zeros((self.n_points, 1), dtype=np.float32), point_deleted=point_deleted)
+
+    def _token(self, qv):
+        """one inner scorer for one PREPROCESSED inner query vector; returns (Scorer, keep-alive)"""
+        s = Scorer()
+        st = self.inner[1]
+        if self.kind == "dense":
+            enc = np.ascontiguousarray(cast(st.dtype, f32(qv)[None, :]))[0]
+            s.kind, s.st, s.query = 0, C.pointer(st.st), enc.ctypes.data
+            return s, enc
+        if self.kind == "sq":
+            sq = self.inner[2]
+            codes, off = sq.encode_query(f32(qv))
+            s.kind, s.st, s.sq, s.sq_rows = 1, C.pointer(st.st), C.pointer(sq.sq), sq.rows.ctypes.data
+            s.sq_query, s.sq_query_offset, s.isa = codes.ctypes.data, off, sq.isa
+            return s, codes
+        if self.kind == "bq":
+            bq = self.inner[2]
+            qb = bq.encode(f32(qv)[None, :])[0]
+            s.kind, s.st, s.bq_rows, s.bq_query = 3, C.pointer(st.st), bq.rows.ctypes.data, qb.ctypes.data
+            s.bq_dim, s.bq_distance, s.bq_invert = bq.dim, bq.distance, bq.invert
+            return s, qb
+        pq = self.inner[2]
+        lut = pq.lut(f32(qv))
+        s.kind, s.st, s.pq, s.pq_codes = 2, C.pointer(st.st), C.pointer(pq.pq), pq.codes.ctypes.data
+        s.pq_lut, s.isa = lut.ctypes.data, pq.isa
+        return s, lut
+
+    def scorer(self, multi_query_preprocessed):
+        """qo_scorer of kind 4 for one multi-query ([tokens, dim] preprocessed f32); returns (Scorer, keep-alive)"""
+        toks = [self._token(q) for q in f32(np.atleast_2d(multi_query_preprocessed))]
+        arr = (Scorer * max(1, len(toks)))(*[t[0] for t in toks])
+        s = Scorer()
+        s.kind, s.st = 4, C.pointer(self.points.st)
+        s.mv_tokens, s.mv_n_tokens, s.mv_offsets = C.addressof(arr), len(toks), self.offsets.ctypes.data
+        return s, (arr, toks)
+
+    def template(self):
+        """the storage as a scorer template (builds: only score_internal is used, through mv_tokens[0])"""
+        return self.scorer(np.zeros((1, self.inner[1].rows.shape[1]), dtype=np.float32))
+
+    def score_points(self, multi_queries_preprocessed, ids):
+        out = np.empty((len(multi_queries_preprocessed), len(ids)), dtype=np.float32)
+        for j, mq in enumerate(multi_queries_preprocessed):
+            s, keep = self.scorer(mq)
+            for i, p in enumerate(ids):
+                out[j, i] = _lib.qo_scorer_score_point(C.byref(s), int(p))
+        return out
+
+    def score_internal(self, a, b):
+        s, keep = self.template()
+        return np.float32(_lib.qo_scorer_score_internal(C.byref(s), int(a), int(b)))
+
+    def build(self, m=8, m0=None, ef_construct=32, entry_points_num=4, seed=42) -> "Hnsw":
+        """GraphLayersBuilder over the multi-vector points through score_internal_max_similarity (sequential, as the reference's tests)."""
+        g = Hnsw.__new__(Hnsw)
+        g.storage, g.m, g.m0, g.n = None, m, (2 * m if m0 is None else m0), self.n_points
+        s, keep = self.template()
+        g._keep = (s, keep, self)
+        g.h = _lib.qo_hnsw_build_with(C.byref(s), g.m, g.m0, ef_construct, entry_points_num, 1, seed)
+        return g
+
+    def search(self, graph: "Hnsw", multi_queries_preprocessed, top, ef):
+        res, stats = [], []
+        for mq in multi_queries_preprocessed:
+            s, keep = self.scorer(mq)
+            r, ns = graph._run(s, top, ef)
+            res.append(r)
+            stats.append(ns)
+        return res, stats
 
 
 def links_heuristic(sorted_candidates, level_m, score_table):

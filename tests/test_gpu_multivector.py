@@ -82,3 +82,127 @@ def test_maxsim_argument_errors(qa):
     bad = qa.MultiDenseVectorStorage(inner, [0, 25], qa.Distance.Dot)
     with pytest.raises(qa.QmxError):
         bad.score_points([inner[:2]], [0])                      # offsets past the inner rows
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Quantized multi-vector storages (QuantizedMultivectorStorage, quantized_multivector_storage/mod.rs:76-393) and the HNSW walk over
+# multi-vector points (MultiMetricQueryScorer / QuantizedMultiQueryScorer behind GraphLayers::search)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _multi_world(qa, kind, distance, dim, n_points, seed, max_len=9):
+    """inner rows (preprocessed), offsets, the device storage and the oracle's MultiOracle for inner kind `kind`"""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(1, max_len, n_points)
+    offsets = np.zeros(n_points + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(lens)
+    centers = rng.standard_normal((24, dim)).astype(np.float32) * 2.0              # clustered points: the walks have something to find
+    owner = np.repeat(np.arange(n_points) % 24, lens)
+    inner = O.preprocess(distance, (centers[owner] + rng.standard_normal((int(offsets[-1]), dim))).astype(np.float32))
+    ost = O.DenseStorage(O.F32, distance, inner)
+    if kind == "dense":
+        dev = qa.MultiDenseVectorStorage(inner, offsets, _dist(qa, distance))
+        orc = O.MultiOracle(("dense", ost), offsets)
+    elif kind == "sq":
+        quant = qa.ScalarQuantizer.from_min_max(inner, dim, _dist(qa, distance))
+        osq = O.SqOracle(distance, dim, quant.alpha, quant.offset)
+        rows = osq.encode_rows(inner)
+        osq.rows = rows
+        dev = qa.QuantizedMultivectorStorage(qa.EncodedVectorsU8(quant.encode(inner), quant), offsets)
+        orc = O.MultiOracle(("sq", ost, osq), offsets)
+    elif kind == "bq":
+        quant = qa.BinaryQuantizer(dim, _dist(qa, distance))
+        obq = O.BqOracle(distance, dim)
+        obq.rows = obq.encode_rows(inner)
+        dev = qa.QuantizedMultivectorStorage(qa.EncodedVectorsBin(quant.encode(inner), quant), offsets)
+        orc = O.MultiOracle(("bq", ost, obq), offsets)
+    else:
+        raise ValueError(kind)
+    queries = [(centers[rng.integers(24)] + rng.standard_normal((k, dim))).astype(np.float32) for k in (1, 3, 8, 17, 5, 2)]
+    return rng, offsets, dev, orc, queries
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,distance,dim", [("sq", O.DOT, 128), ("sq", O.COSINE, 96), ("sq", O.EUCLID, 64), ("bq", O.DOT, 128), ("bq", O.COSINE, 256)])
+def test_quantized_multivector_maxsim_bit_exact(qa, kind, distance, dim):
+    """score_point_max_similarity over the QUANTIZED scores of the inner rows: brute-force scores and top-k equal the oracle's bits."""
+    rng, offsets, dev, orc, queries = _multi_world(qa, kind, distance, dim, 300, seed=dim + distance)
+    qpre = [O.preprocess(distance, q) for q in queries]
+    ids = rng.permutation(300).astype(np.uint32)[:120]
+    want = orc.score_points(qpre, ids)
+    assert np.array_equal(_bits(dev.score_points(queries, ids)), _bits(want))
+    full = orc.score_points(qpre, np.arange(300))
+    for res, sc in zip(dev.peek_top_all(queries, 10), full):
+        assert np.array_equal(_bits(res["score"]), _bits(np.sort(sc)[::-1][:10]))
+        assert np.array_equal(_bits(sc[res["idx"]]), _bits(res["score"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,distance,dim", [("dense", O.DOT, 128), ("dense", O.COSINE, 96), ("dense", O.EUCLID, 16), ("sq", O.DOT, 128),
+                                                 ("sq", O.COSINE, 64), ("bq", O.DOT, 128)])
+def test_multivector_hnsw_walk_equals_the_oracle(qa, kind, distance, dim):
+    """GraphLayers::search over multi-vector points: graph built by the oracle's GraphLayersBuilder through score_internal_max_similarity,
+    walked on the device with the MaxSim hop scorer: ids, score bits and the number of scored points equal the oracle's walk."""
+    n_points = 1200
+    rng, offsets, dev, orc, queries = _multi_world(qa, kind, distance, dim, n_points, seed=7 * dim + distance)
+    graph_o = orc.build(m=8, ef_construct=32)
+    plain = graph_o.export_plain()
+    graph = qa.GraphLayers.from_plain(plain)
+    qpre = [O.preprocess(distance, q) for q in queries]
+    for top, ef in ((5, 16), (10, 64), (3, 200)):
+        want, want_scored = orc.search(graph_o, qpre, top, ef)
+        got, ctr = dev.search_hnsw(graph, queries, top, ef, with_counters=True)
+        if kind == "bq":
+            # integer-valued scores tie all over the beam and the order among equals inside Rust's BinaryHeap is unpinned (DESIGN 4):
+            # every returned pair must be a true (point, MaxSim score) pair, sorted, and the walk as good as the oracle's
+            for g, w, mq in zip(got, want, qpre):
+                assert np.all(np.diff(g["score"]) <= 0) and len(g) == len(w)
+                assert np.array_equal(_bits(orc.score_points([mq], g["idx"])[0]), _bits(g["score"]))
+            assert np.mean([g["score"].mean() for g in got]) >= np.mean([w["score"].mean() for w in want]) * 0.995
+            continue
+        for g, w in zip(got, want):
+            assert g["idx"].tolist() == w["idx"].tolist()
+            assert np.array_equal(_bits(g["score"]), _bits(w["score"]))
+        assert ctr.vectors_scored == sum(want_scored)
+    # deleted points are never returned and never entered
+    deleted = rng.random(n_points) < 0.25
+    dev.set_deleted(deleted)
+    orc_del = O.MultiOracle(orc.inner, offsets, point_deleted=deleted)
+    want, _ = orc_del.search(graph_o, qpre, 8, 48)
+    got = dev.search_hnsw(graph, queries, 8, 48)
+    for g, w in zip(got, want):
+        assert not deleted[g["idx"]].any()
+        if kind != "bq":
+            assert g["idx"].tolist() == w["idx"].tolist()
+            assert np.array_equal(_bits(g["score"]), _bits(w["score"]))
+
+
+@pytest.mark.gpu
+def test_multivector_hnsw_argument_errors(qa):
+    rng, offsets, dev, orc, queries = _multi_world(qa, "dense", O.DOT, 64, 200, seed=3)
+    graph = qa.GraphLayers.from_plain(orc.build(m=4, ef_construct=16).export_plain())
+    with pytest.raises(qa.QmxError):                 # ef beyond the register beam
+        dev.search_hnsw(graph, queries, 5, 4096)
+    big = [rng.standard_normal((700, 64)).astype(np.float32)]     # 700 x (256 + 64) bytes > 150 KiB of LDS
+    with pytest.raises(qa.QmxError):
+        dev.search_hnsw(graph, big, 5, 16)
+
+
+def test_oracle_multi_scorer_equals_the_table_form():
+    """qo_scorer kind 4 (the form the HNSW oracle walks with) == max_similarity over the similarity table (the form pinned to the
+    reference's literal above); score_internal == the same with a stored point as the query."""
+    rng = np.random.default_rng(5)
+    n, dim = 60, 24
+    lens = rng.integers(1, 6, n)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lens)
+    for distance in (O.DOT, O.COSINE, O.EUCLID, O.MANHATTAN):
+        inner = O.preprocess(distance, rng.standard_normal((int(off[-1]), dim)).astype(np.float32))
+        ost = O.DenseStorage(O.F32, distance, inner)
+        m = O.MultiOracle(("dense", ost), off)
+        q = rng.standard_normal((4, dim)).astype(np.float32)
+        qpre = O.preprocess(distance, q)
+        want = O.multi_scores(ost, q, np.array([0, 4]), off, np.arange(n))
+        assert np.array_equal(_bits(m.score_points([qpre], np.arange(n))), _bits(want))
+        a, b = 7, 31
+        ra = inner[int(off[a]):int(off[a + 1])]
+        tab = ost.score_points(ra, np.arange(int(off[b]), int(off[b + 1]), dtype=np.uint32), encoded=True)
+        assert _bits(m.score_internal(a, b)) == _bits(O.max_similarity(tab))
