@@ -454,6 +454,19 @@ QMX_API int32_t qmx_multi_search_topk(qmx_query *inner, const uint32_t *query_fi
                                       uint32_t n_points, const uint64_t *point_deleted, uint64_t n_deleted_bits, uint32_t top,
                                       const uint32_t *ids, uint64_t n_ids, qmx_scored_point *out, uint32_t *out_counts);
 
+/* `GraphLayers::search_with_vectors` (graph_layers.rs:564-596; taken by hnsw/read_view/search.rs:88-134 when the graph has inline storage -
+ * `GraphLinksFormat::CompressedWithVectors` - and the search is quantized): the walk (`search_entry_with_vectors` :391-449,
+ * `search_on_level_with_vectors` :336-389) is steered by the LINKS scorer - the quantized vectors stored next to each link, i.e. the rows of
+ * the quantized segment `links` was made over - while every candidate the level-0 loop pops (the one that ends the loop included) is scored
+ * by the BASE scorer - the full vector stored in front of the node's links, i.e. the rows of the original segment `base` was made over -
+ * into a second `SearchContext(ef)`; its best `top` are the result: rescoring fused into the walk.  On the device the link and base vectors
+ * are read from the two segments in HBM (the same bytes the file carries inline); the walk kernel lists the popped candidates and the pair
+ * kernel scores them (exact bits of the base scorer).  ef <= 512, top <= 1024; a search that pops more than 32 max(ef, top) + 256 candidates
+ * => QMX_ERR_NOT_SUPPORTED.  counters->vectors_scored = link vectors + base vectors scored. */
+QMX_API int32_t qmx_hnsw_search_with_vectors(const qmx_hnsw *g, qmx_query *links, qmx_query *base, uint32_t top, uint32_t ef,
+                                             qmx_scored_point *out, uint32_t *out_counts, const volatile uint8_t *is_stopped,
+                                             qmx_counters *counters);
+
 /* QUANTIZED multi-vectors (`QuantizedMultivectorStorage`, lib/segment/src/vector_storage/quantized/quantized_multivector_storage/mod.rs:76-393,
  * `MultivectorOffset{start, count}` :39-42): the two calls above accept an `inner` batch over an SQ, PQ or BQ segment of the quantized INNER
  * rows; the similarities are then the quantized scorer's (`quantized_storage.score(inner_query, vector)`), max / sum as

@@ -233,6 +233,10 @@ uint32_t qo_hnsw_search(const qo_hnsw *g, const qo_scorer *scorer, uint32_t top,
 /* the same with SearchAlgorithm: 0 = Hnsw, 1 = Acorn (search_on_level_acorn, graph_layers.rs:154-243) */
 uint32_t qo_hnsw_search_algo(const qo_hnsw *g, const qo_scorer *scorer, uint32_t top, uint32_t ef, int algorithm, qo_scored_point *out,
                              uint64_t *n_scored);
+/* GraphLayers::search_with_vectors (graph_layers.rs:564-596) for graphs with inline storage: the walk is steered by `links_scorer` (the
+ * quantized link vectors), every popped candidate is scored by `base_scorer` (its full base vector) and the best `top` of those are returned. */
+uint32_t qo_hnsw_search_with_vectors(const qo_hnsw *g, const qo_scorer *links_scorer, const qo_scorer *base_scorer, uint32_t top, uint32_t ef,
+                                     qo_scored_point *out, uint64_t *n_scored, uint64_t *n_base_scored);
 /* LinksContainer::fill_from_sorted_with_heuristic (links_container.rs:47-71) and ::connect (:74-103) on
  * an explicit pairwise score table score[a * n + b]; for the reference's literal test (:312-391). */
 uint32_t qo_links_heuristic(const qo_scored_point *sorted_candidates, uint32_t n_cand, uint32_t level_m,

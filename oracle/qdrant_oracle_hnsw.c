@@ -814,6 +814,72 @@ uint32_t qo_hnsw_search(const qo_hnsw *g, const qo_scorer *scorer, uint32_t top,
     return qo_hnsw_search_algo(g, scorer, top, ef, 0, out, n_scored);
 }
 /* algorithm: 0 = SearchAlgorithm::Hnsw, 1 = SearchAlgorithm::Acorn (graph_layers.rs:550-559) */
+/* GraphLayersWithVectors::search_on_level_with_vectors (graph_layers.rs:336-389): the walk of search_on_level steered by the LINKS scorer
+ * (the quantized "link vectors" stored next to the links), while every candidate that is popped - the one that ends the loop included -
+ * is scored by the BASE scorer (the full "base vector" stored in front of its links) into a second SearchContext, which is the result. */
+static qo_topk *search_on_level_with_vectors(const qo_hnsw *g, qscore *q, const qo_scorer *base, qo_scored_point level_entry, uint32_t level,
+                                             uint32_t ef, visited_t *vis, uint64_t *n_base) {
+    visited_next(vis);
+    visited_check_update(vis, level_entry.idx);
+    qo_topk *links_nearest = qo_topk_new(ef), *base_nearest = qo_topk_new(ef);
+    maxheap cands = {0, 0, 0}, base_cands = {0, 0, 0};
+    process_candidate(links_nearest, &cands, level_entry);
+    const uint32_t limit = level_m(g, level);
+    uint32_t *ids = (uint32_t *)malloc(sizeof(uint32_t) * (g->m0 + g->m + 1));
+    qo_scored_point cand;
+    while (mh_pop(&cands, &cand)) {
+        qo_scored_point worst;
+        const float lower_bound = qo_topk_top(links_nearest, &worst) ? worst.score : -3.40282347e+38f;
+        qo_scored_point b = {cand.idx, qo_scorer_score_point(base, cand.idx)};      /* base_scorer.score_bytes(base_vector) */
+        (*n_base)++;
+        if (cand.score < lower_bound) {
+            process_candidate(base_nearest, &base_cands, b);
+            break;
+        }
+        uint32_t n = read_links(g, cand.idx, level, ids, 0), k = 0;
+        for (uint32_t i = 0; i < n; i++) if (!visited_check(vis, ids[i])) ids[k++] = ids[i];
+        process_candidate(base_nearest, &base_cands, b);
+        k = filter_truncate(q, ids, k, limit);
+        float scores[512];
+        for (uint32_t i = 0; i < k; i++) scores[i] = qs_score(q, ids[i]);
+        for (uint32_t i = 0; i < k; i++) {
+            qo_scored_point sp = {ids[i], scores[i]};
+            process_candidate(links_nearest, &cands, sp);
+            visited_check_update(vis, ids[i]);
+        }
+    }
+    free(ids);
+    free(cands.d);
+    free(base_cands.d);
+    qo_topk_free(links_nearest);
+    return base_nearest;
+}
+
+/* GraphLayers::search_with_vectors (graph_layers.rs:564-596).  search_entry_with_vectors (:391-449) is search_entry with the links scorer
+ * (score_point of the entry, then score_points(links, limit) per level): the same function here. */
+uint32_t qo_hnsw_search_with_vectors(const qo_hnsw *g, const qo_scorer *links_scorer, const qo_scorer *base_scorer, uint32_t top, uint32_t ef,
+                                     qo_scored_point *out, uint64_t *n_scored, uint64_t *n_base_scored) {
+    qscore q = {links_scorer, NULL, 0, 0};
+    uint32_t ep_id, ep_level;
+    uint64_t n_base = 0;
+    if (!get_entry_point(g, &q, &ep_id, &ep_level)) { if (n_scored) *n_scored = 0; if (n_base_scored) *n_base_scored = 0; return 0; }
+    qo_scored_point zero_level_entry = search_entry(g, &q, ep_id, ep_level, 0, 0);
+    if (ef < top) ef = top;
+    visited_t vis;
+    visited_init(&vis, g->n);
+    qo_topk *nearest = search_on_level_with_vectors(g, &q, base_scorer, zero_level_entry, 0, ef, &vis, &n_base);
+    free(vis.cnt);
+    qo_scored_point *sorted = (qo_scored_point *)malloc(sizeof(qo_scored_point) * (ef + 1));
+    uint32_t n = (uint32_t)qo_topk_into_sorted(nearest, sorted);
+    qo_topk_free(nearest);
+    if (n > top) n = top;
+    memcpy(out, sorted, sizeof(qo_scored_point) * n);
+    free(sorted);
+    if (n_scored) *n_scored = q.n_scored;
+    if (n_base_scored) *n_base_scored = n_base;
+    return n;
+}
+
 uint32_t qo_hnsw_search_algo(const qo_hnsw *g, const qo_scorer *scorer, uint32_t top, uint32_t ef, int algorithm, qo_scored_point *out,
                              uint64_t *n_scored) {
     qscore q = {scorer, NULL, 0, 0};

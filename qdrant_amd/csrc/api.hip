@@ -223,7 +223,7 @@ struct qmx_query {
     uint32_t n_cq_coefs = 0;
     DevBuf cand, cand_cnt, cand_ids;   // qmx_search_quantized: oversampled candidates of the quantized stage
     // split prefilter (scan_split.hip): split queries, per-query norms / thresholds / bands, scales, candidate and verification buffers, flag
-    DevBuf sp_bq, sp_f32, sp_cand, sp_cnt, sp_ver, sp_vscores, sp_sample, sp_wl;
+    DevBuf sp_bq, sp_f32, sp_cand, sp_cnt, sp_ver, sp_vscores, sp_sample, sp_wl, xcnt;
     uint64_t sp_sample_n = 0, sp_sample_of = 0;
     DevBuf filter;             // payload-filter allow bitmap of this query batch (qmx_query_set_filter)
     uint64_t n_filter_bits = 0;
@@ -978,7 +978,7 @@ int32_t qmx_query_destroy(qmx_query *q) {
     q->mv_deleted.release();
     q->cq_scores.release();
     q->cq_desc.release();
-    q->sp_bq.release(); q->sp_f32.release(); q->sp_cand.release(); q->sp_cnt.release(); q->sp_ver.release(); q->sp_vscores.release(); q->sp_sample.release(); q->sp_wl.release();
+    q->sp_bq.release(); q->sp_f32.release(); q->sp_cand.release(); q->sp_cnt.release(); q->sp_ver.release(); q->sp_vscores.release(); q->sp_sample.release(); q->sp_wl.release(); q->xcnt.release();
     q->cand.release();
     q->cand_cnt.release();
     q->cand_ids.release();
@@ -2075,6 +2075,11 @@ int32_t qmx_hnsw_build_quantized(const qmx_segment *seg, const qmx_segment *orig
 }
 
 // the MaxSim walk over multi-vector points (qmx_multi_hnsw_search): device arrays of the query / point partitions and the POINT-level deleted view
+// search_on_level_with_vectors: where the walk lists the candidates it pops
+struct ExpandedOut {
+    uint32_t *d_ids, *d_cnt;
+    uint32_t xcap;
+};
 struct MultiWalk {
     const uint32_t *d_qfirst;
     const uint64_t *d_offsets;
@@ -2107,7 +2112,8 @@ static int32_t launch_hnsw(const qmx_query *q, const ScanArgs &a, const HnswArgs
 
 
 static int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef, qmx_scored_point *d_out,
-                            uint32_t *d_counts, uint32_t *d_scored, bool timed, bool acorn = false, const MultiWalk *mw = nullptr) {
+                            uint32_t *d_counts, uint32_t *d_scored, bool timed, bool acorn = false, const MultiWalk *mw = nullptr,
+                            const ExpandedOut *xo = nullptr) {
     const qmx_segment *s = q->seg;
     ScanArgs a;
     fill_args(q, 0, q->nq, a);
@@ -2127,6 +2133,7 @@ static int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint3
     h.xp_ids = g->d_xp_ids; h.xp_levels = g->d_xp_levels; h.n_xp = g->n_xp;
     h.ef = ef; h.top = top; h.nq = n_searches;
     h.out = d_out; h.out_counts = d_counts; h.out_scored = d_scored;
+    if (xo) { h.expanded = xo->d_ids; h.expanded_cnt = xo->d_cnt; h.xcap = xo->xcap; }
     h.lds_query_bytes = q->q_stride <= HNSW_LDS_QUERY_MAX ? q->q_stride : 0;
     if (mw) {   // [16-byte header][the multi-query's inner vectors]
         const uint64_t need = 16 + (uint64_t)std::max<uint32_t>(mw->max_tokens, 1) * q->q_stride;
@@ -2517,6 +2524,60 @@ int32_t qmx_multi_search_topk(qmx_query *inner, const uint32_t *query_first, uin
     if (!out_dev) QMX_TRY(copy_out(inner->stream, out, d_out, (size_t)n_queries * top * sizeof(qmx_scored_point)));
     if (!cnt_dev) QMX_TRY(copy_out(inner->stream, out_counts, d_oc, (size_t)n_queries * 4));
     return check_err_flag(inner);
+}
+
+int32_t qmx_hnsw_search_with_vectors(const qmx_hnsw *g, qmx_query *links, qmx_query *base, uint32_t top, uint32_t ef, qmx_scored_point *out,
+                                     uint32_t *out_counts, const volatile uint8_t *is_stopped, qmx_counters *counters) {
+    QMX_REQUIRE(g && links && base && out && out_counts, QMX_ERR_BAD_ARG, "NULL argument");
+    QMX_REQUIRE(base->nq == links->nq && base->device == links->device, QMX_ERR_BAD_ARG, "the two query batches must match");
+    QMX_REQUIRE(base->seg->n >= g->n_points, QMX_ERR_OUT_OF_BOUNDS, "graph has %u points, the base-vector segment %llu rows", g->n_points,
+                (unsigned long long)base->seg->n);
+    QMX_TRY(hnsw_check(g, links, top, ef));
+    QMX_REQUIRE(top <= MAX_TOP, QMX_ERR_NOT_SUPPORTED, "top %u > %u", top, MAX_TOP);
+    QMX_HIP(hipSetDevice(links->device));
+    if (counters) memset(counters, 0, sizeof(*counters));
+    const uint32_t nq = links->nq;
+    if (nq == 0) return QMX_OK;
+    if (is_stopped && *is_stopped) {
+        set_error("search cancelled");
+        return QMX_ERR_CANCELLED;
+    }
+    if (g->n_points == 0) {
+        if (is_device_ptr(out_counts)) QMX_HIP(hipMemset(out_counts, 0, (size_t)nq * 4));
+        else memset(out_counts, 0, (size_t)nq * 4);
+        return QMX_OK;
+    }
+    const uint32_t beam_ef = std::max(top, ef);
+    // a search pops about ef..2 ef candidates; the list is sized for 32 ef (or every point) and a search that pops more is reported
+    const uint32_t xcap = (uint32_t)std::min<uint64_t>(g->n_points, (uint64_t)32 * beam_ef + 256);
+    QMX_TRY(links->cand.reserve((size_t)nq * beam_ef * sizeof(qmx_scored_point)));
+    QMX_TRY(links->cand_cnt.reserve((size_t)nq * 4));
+    QMX_TRY(links->cand_ids.reserve((size_t)nq * xcap * 4));
+    QMX_TRY(links->hnsw_scored.reserve((size_t)nq * 4));
+    QMX_TRY(links->xcnt.reserve((size_t)nq * 4));
+    ExpandedOut xo{(uint32_t *)links->cand_ids.p, (uint32_t *)links->xcnt.p, xcap};
+    const bool timed = links->timing || (links->seg->flags & QMX_SEG_TIME_KERNELS) != 0;
+    QMX_TRY(hnsw_enqueue(g, links, std::min(top, beam_ef), ef, (qmx_scored_point *)links->cand.p, (uint32_t *)links->cand_cnt.p,
+                         (uint32_t *)links->hnsw_scored.p, timed, false, nullptr, &xo));
+    std::vector<uint32_t> cnt(nq), sc(nq);
+    QMX_HIP(hipMemcpyAsync(cnt.data(), links->xcnt.p, (size_t)nq * 4, hipMemcpyDeviceToHost, links->stream));
+    QMX_HIP(hipMemcpyAsync(sc.data(), links->hnsw_scored.p, (size_t)nq * 4, hipMemcpyDeviceToHost, links->stream));
+    QMX_TRY(check_err_flag(links));     // synchronises
+    uint64_t popped = 0, scored = 0;
+    for (uint32_t i = 0; i < nq; ++i) {
+        QMX_REQUIRE(cnt[i] <= xcap, QMX_ERR_NOT_SUPPORTED, "search %u popped %u candidates, more than the %u the base-scoring list holds", i, cnt[i], xcap);
+        popped += cnt[i];
+        scored += sc[i];
+    }
+    // base_search_context: FixedLengthPriorityQueue(ef) over the base scores of the popped candidates, into_iter_sorted().take(top)
+    QMX_TRY(qmx_rescore(base, (const uint32_t *)links->cand_ids.p, (const uint32_t *)links->xcnt.p, xcap, top, out, out_counts));
+    if (counters) {
+        counters->vectors_scored = scored + popped;
+        counters->bytes_read = scored * links->seg->row_bytes + popped * base->seg->row_bytes;
+        counters->kernel_launches = 3;
+        if (timed) { const float before = links->timing_ms; QMX_TRY(timing_fold(links)); counters->kernel_ms = links->timing_ms - before; }
+    }
+    return QMX_OK;
 }
 
 int32_t qmx_multi_hnsw_search(const qmx_hnsw *g, qmx_query *inner, const uint32_t *query_first, uint32_t n_queries, const uint64_t *point_offsets,

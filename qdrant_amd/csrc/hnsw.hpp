@@ -148,6 +148,13 @@ struct Beam {
             carry_d = last_d;
         }
     }
+    __device__ __forceinline__ bool done_at(uint32_t idx) const {   // idx uniform
+        uint32_t r = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if ((idx >> 6) == (uint32_t)e) r = (uint32_t)__builtin_amdgcn_readlane((int)done[e], (int)(idx & 63));
+        return r != 0;
+    }
     // best unexpanded entry -> its key (0 if none); marks it expanded
     __device__ __forceinline__ uint64_t pop_best(int lane) {
         uint64_t ck = 0;
@@ -251,6 +258,7 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
         if (lane == 0) {
             h.out_counts[qi] = 0;
             if (h.out_scored) h.out_scored[qi] = 0;
+            if (h.expanded) h.expanded_cnt[qi] = 0;
         }
         return;
     }
@@ -447,11 +455,19 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
             }
             n_scored += n_score;
         }
-    } else
+    } else {
+    // search_on_level_with_vectors: `candidates` also holds what `nearest` evicted before it was expanded; when every entry of the beam is
+    // expanded the reference pops the best of those, scores its base vector and stops (`candidate.score < lower_bound`)
+    uint64_t evicted_best = 0;
+    uint32_t n_exp = 0;
     while (true) {
         const uint64_t ck = beam.pop_best(lane);
         if (ck == 0) break;
         const uint32_t cand = key_idx(ck);
+        if (h.expanded) {
+            if (lane == 0 && n_exp < h.xcap) h.expanded[(uint64_t)qi * h.xcap + n_exp] = cand;
+            ++n_exp;
+        }
         // links of `cand` on level 0: the packed table needs ONE round trip (count and links are independent loads of the
         // same row), the CSR arrays two (offsets, then neighbors)
         uint64_t o0 = 0, o1 = 0;
@@ -494,10 +510,22 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
                 const int src = __builtin_ctzll(mm);
                 mm &= mm - 1;
                 const uint64_t nk = readlane_u64(mykey, src);
-                if (nk > beam.at(ef - 1)) beam.insert(nk, ef, lane);
+                const uint64_t last = beam.at(ef - 1);
+                if (nk > last) {
+                    if (h.expanded && last > evicted_best && !beam.done_at(ef - 1)) evicted_best = last;
+                    beam.insert(nk, ef, lane);
+                }
             }
             n_scored += k;
         }
+    }
+    if (h.expanded) {
+        if (evicted_best) {
+            if (lane == 0 && n_exp < h.xcap) h.expanded[(uint64_t)qi * h.xcap + n_exp] = key_idx(evicted_best);
+            ++n_exp;
+        }
+        if (lane == 0) h.expanded_cnt[qi] = n_exp;
+    }
     }
 
     // ---- nearest.into_iter_sorted().take(top) ----

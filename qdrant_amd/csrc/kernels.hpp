@@ -94,6 +94,11 @@ struct HnswArgs {
     uint32_t lds_query_bytes;       // bytes of the query entry staged in LDS (16-byte multiple)
     uint32_t acorn;                 // SearchAlgorithm::Acorn on level 0 (graph_layers.rs:154-243): `visited` holds two bitmaps of vis_words / 2 words
     uint32_t hop_cap;               // entries of the hop id / score buffers in LDS (64; m0 (m0 + 1) rounded up for ACORN)
+    // search_on_level_with_vectors (graph_layers.rs:336-389): the candidates the level-0 loop POPS (the one that ends it included) are what
+    // the base scorer sees; they are listed here for the base scoring that follows the walk (api.hip qmx_hnsw_search_with_vectors)
+    uint32_t *expanded;             // [nq][xcap] or nullptr
+    uint32_t *expanded_cnt;         // [nq] popped candidates (may exceed xcap: the list is then incomplete)
+    uint32_t xcap;
 };
 
 // grid == 0: only report the occupancy (blocks of one wave per CU) of the instantiation in *per_cu

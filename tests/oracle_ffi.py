@@ -441,6 +441,8 @@ _sig("qo_hnsw_import_plain", _P, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32
 _sig("qo_hnsw_export_plain", None, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _P, _P, _P, _P])
 _sig("qo_hnsw_search", C.c_uint32, [_P, C.POINTER(Scorer), C.c_uint32, C.c_uint32, _P, C.POINTER(C.c_uint64)])
 _sig("qo_hnsw_search_algo", C.c_uint32, [_P, C.POINTER(Scorer), C.c_uint32, C.c_uint32, C.c_int, _P, C.POINTER(C.c_uint64)])
+_sig("qo_hnsw_search_with_vectors", C.c_uint32, [_P, C.POINTER(Scorer), C.POINTER(Scorer), C.c_uint32, C.c_uint32, _P, C.POINTER(C.c_uint64),
+                                                 C.POINTER(C.c_uint64)])
 _sig("qo_links_heuristic", C.c_uint32, [_P, C.c_uint32, C.c_uint32, _P, C.c_uint32, _P])
 _sig("qo_links_connect", C.c_uint32, [_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P, C.c_uint32])
 _sig("qo_links_connect_heuristic", C.c_uint32, [_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P, C.c_uint32])
@@ -614,6 +616,38 @@ class Hnsw:
             s.bq_dim, s.bq_distance, s.bq_invert = bq.dim, bq.distance, bq.invert
             res.append(self._run(s, top, ef)[0])
         return res
+
+    def search_with_vectors(self, base_storage: DenseStorage, links, queries, top, ef):
+        """GraphLayers::search_with_vectors: links = ("sq", SqOracle) | ("bq", BqOracle) | ("pq", PqOracle) over the same points as
+        `base_storage` (preprocessed original rows).  Returns (results, link vectors scored, base vectors scored) per query."""
+        qpre = preprocess(base_storage.distance, f32(np.atleast_2d(queries)))
+        qbase = base_storage.encode_queries(queries)
+        res, n_links, n_base = [], [], []
+        for i in range(qpre.shape[0]):
+            b = Scorer()
+            b.kind, b.st, b.query = 0, C.pointer(base_storage.st), qbase[i].ctypes.data
+            s = Scorer()
+            kind, quant = links
+            if kind == "sq":
+                codes, off = quant.encode_query(qpre[i])
+                s.kind, s.st, s.sq, s.sq_rows = 1, C.pointer(base_storage.st), C.pointer(quant.sq), quant.rows.ctypes.data
+                s.sq_query, s.sq_query_offset, s.isa = codes.ctypes.data, off, quant.isa
+                keep = codes
+            elif kind == "bq":
+                keep = quant.encode(qpre[i][None, :])[0]
+                s.kind, s.st, s.bq_rows, s.bq_query = 3, C.pointer(base_storage.st), quant.rows.ctypes.data, keep.ctypes.data
+                s.bq_dim, s.bq_distance, s.bq_invert = quant.dim, quant.distance, quant.invert
+            else:
+                keep = quant.lut(qpre[i])
+                s.kind, s.st, s.pq, s.pq_codes = 2, C.pointer(base_storage.st), C.pointer(quant.pq), quant.codes.ctypes.data
+                s.pq_lut, s.isa = keep.ctypes.data, quant.isa
+            out = np.zeros(max(top, 1), dtype=ScoredPointOffset)
+            nl, nb = C.c_uint64(), C.c_uint64()
+            n = _lib.qo_hnsw_search_with_vectors(self.h, C.byref(s), C.byref(b), top, ef, _p(out), C.byref(nl), C.byref(nb))
+            res.append(out[:n].copy())
+            n_links.append(nl.value)
+            n_base.append(nb.value)
+        return res, n_links, n_base
 
     def search_pq(self, flags_storage: DenseStorage, pq: "PqOracle", queries_preprocessed, top, ef):
         res = []

@@ -114,6 +114,13 @@ def _multi_world(qa, kind, distance, dim, n_points, seed, max_len=9):
         obq.rows = obq.encode_rows(inner)
         dev = qa.QuantizedMultivectorStorage(qa.EncodedVectorsBin(quant.encode(inner), quant), offsets)
         orc = O.MultiOracle(("bq", ost, obq), offsets)
+    elif kind == "pq":
+        cen = O.PqOracle.train(inner[:2000], dim, 8, 256, iters=3)
+        opq = O.PqOracle(distance, dim, 8, cen)
+        opq.codes = opq.encode(inner)
+        quant = qa.ProductQuantizer(dim, _dist(qa, distance), 8, cen)
+        dev = qa.QuantizedMultivectorStorage(qa.EncodedVectorsPQ(quant.encode(inner), quant), offsets)
+        orc = O.MultiOracle(("pq", ost, opq), offsets)
     else:
         raise ValueError(kind)
     queries = [(centers[rng.integers(24)] + rng.standard_normal((k, dim))).astype(np.float32) for k in (1, 3, 8, 17, 5, 2)]
@@ -121,7 +128,8 @@ def _multi_world(qa, kind, distance, dim, n_points, seed, max_len=9):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,distance,dim", [("sq", O.DOT, 128), ("sq", O.COSINE, 96), ("sq", O.EUCLID, 64), ("bq", O.DOT, 128), ("bq", O.COSINE, 256)])
+@pytest.mark.parametrize("kind,distance,dim", [("sq", O.DOT, 128), ("sq", O.COSINE, 96), ("sq", O.EUCLID, 64), ("bq", O.DOT, 128), ("bq", O.COSINE, 256),
+                                                 ("pq", O.DOT, 64), ("pq", O.EUCLID, 128)])
 def test_quantized_multivector_maxsim_bit_exact(qa, kind, distance, dim):
     """score_point_max_similarity over the QUANTIZED scores of the inner rows: brute-force scores and top-k equal the oracle's bits."""
     rng, offsets, dev, orc, queries = _multi_world(qa, kind, distance, dim, 300, seed=dim + distance)
