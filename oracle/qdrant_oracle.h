@@ -161,6 +161,26 @@ size_t qo_bq_encode_scalar_query(uint32_t dim, int encoding, uint32_t bits, cons
 uint64_t qo_bq_xor_popcnt_scalar(const uint8_t *vector, const uint8_t *query, uint32_t n_u128, uint32_t bits);
 float qo_bq_score_scalar(int distance, int invert, uint32_t dim, int encoding, uint32_t bits, const uint8_t *scalar_query, const uint8_t *v);
 
+/* ---- TurboQuant: lib/quantization/src/turboquant/ behind EncodedVectorsTQ (oracle/qdrant_oracle_tq.c; TQMode::Normal) ----
+ * bits: TQBits in the reference's order {Bits4 = 0, Bits2 = 1, Bits1_5 = 2, Bits1 = 3}; distance: QO_DOT | QO_COSINE | QO_EUCLID. */
+typedef struct qo_tq qo_tq;
+typedef struct qo_tq_query qo_tq_query;
+uint32_t qo_tq_padded_dim_for(uint32_t dim, int bits);                                 /* encoding.rs:194-201 */
+void qo_tq_permutation_map(uint64_t seed, uint32_t count, uint32_t *map);             /* permutation.rs:108-115 on the identity */
+uint32_t qo_tq_chunk_sizes(uint32_t dim, uint32_t *out);                               /* rotation.rs:222-233 */
+void qo_tq_wht(double *x, uint32_t n);                                                 /* rotation.rs:158-176 */
+qo_tq *qo_tq_new(uint32_t dim, int bits, int distance, int rotation_unpadded);         /* TurboQuantizer::new (quantization.rs:127-158) */
+void qo_tq_free(qo_tq *t);
+uint32_t qo_tq_padded_dim(const qo_tq *t);
+uint32_t qo_tq_quantized_size(const qo_tq *t);                                         /* encoding.rs:172-190 */
+void qo_tq_rotate(const qo_tq *t, double *x);                                          /* HadamardRotation::apply on x[..rotation dim] */
+void qo_tq_quantize(const qo_tq *t, const float *vec, uint8_t *out);                   /* TurboQuantizer::quantize */
+qo_tq_query *qo_tq_precompute_query(const qo_tq *t, const float *query);               /* precompute_query */
+void qo_tq_query_free(qo_tq_query *e);
+void qo_tq_query_export(const qo_tq *t, const qo_tq_query *e, int32_t *q_out, float *postprocess_scale, float *l2_norm, int64_t *sum_q);
+float qo_tq_score_precomputed(const qo_tq *t, const qo_tq_query *e, const uint8_t *vec);   /* score_precomputed (before `invert`) */
+float qo_tq_score_symmetric(const qo_tq *t, const uint8_t *v1, const uint8_t *v2);         /* score_symmetric (before `invert`) */
+
 /* ---- cross-segment merge: BatchResultAggregator (lib/shard/src/search_result_aggregator.rs:50-121) ----
  * lists[(l * nq + qi) * k ..] with counts[l * nq + qi] valid entries; idx_base[l] (optional) is added to
  * every idx of list l (segment-local offset -> global id).  Points are pushed list by list, each list in

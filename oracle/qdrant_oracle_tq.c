@@ -1,0 +1,326 @@
+/* oracle/qdrant_oracle_tq.c — TEST INFRASTRUCTURE (see qdrant_oracle.h): CPU restatement of the reference's TurboQuant quantizer,
+ * lib/quantization/src/turboquant/ (v1.19.0) as used by EncodedVectorsTQ (lib/quantization/src/encoded_vectors_tq.rs).
+ *
+ *   permutation.rs:9-36,108-115,151-153   ReversibleLcg (Knuth MMIX), Permutation::permute (Fisher-Yates replay), bounded_rand
+ *   rotation.rs:4-10,32-77,97-131,222-233,264-280   PERMUTATION_SEEDS, HadamardRotation::{new, apply}, wht_and_gather_rounds,
+ *                                          compute_chunk_sizes, wht_normalized_chunks; in_place_walsh_hadamard_transform :158-176
+ *                                          (the SIMD variants of simd/hadamard.rs are bit-equal to it by the crate's own tests)
+ *   lloyd_max.rs:3-31                      CENTROIDS_{1,2,4}BIT and their midpoint boundaries
+ *   quantization.rs:160-209,211-296,299-318   preprocess_into, quantize_impl (TQMode::Normal), compute_centroid_norm
+ *   encoding.rs:117-134,194-206,211-221,231-258   pack_vector, padded_dim, compute_l2_length, pack_extras_into (+ size_for :31-56)
+ *   quantization.rs:496-567,569-620        precompute_query, score_precomputed (Dot / Cosine / L2)
+ *   quantization.rs:395-445                score_symmetric (Dot / Cosine / L2)
+ *   simd/query4bit/mod.rs (x86_64 constants :64-90, new :186-248, dotprod :257-261, dotprod_raw :300-346, score_4bit_internal_* :414-434)
+ *   simd/query2bit/mod.rs, simd/query1bit/mod.rs   the same for 2 bits and for the bit-plane form of 1 bit (BITS = 8)
+ *
+ * Scope: TQMode::Normal (no TQ+ error correction: its per-coordinate shift / scale come from a P-square pre-pass over randomly sampled
+ * vectors), TQBits 4 / 2 / 1.5 / 1, TQRotation Padded and Unpadded, distances Dot, Cosine, L2.  L1 (full dequantisation + inverse
+ * rotation per score) is not restated.
+ *
+ * PARITY UNPINNED at the bit level: the reference holds tolerance tests only for this quantizer (tests/integration/test_tq.rs: error =
+ * coef(bits) * signal_std) plus literals for the chunk decomposition (rotation.rs:283-315) and the codebooks; all of them are mirrored in
+ * tests/test_oracle_tq.py.  The integer kernels are exact in any order, so the only order-sensitive parts are the f64 sums, restated in
+ * the reference's sequential order. */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "qdrant_oracle.h"
+
+enum { TQ_BITS4 = 0, TQ_BITS2 = 1, TQ_BITS1_5 = 2, TQ_BITS1 = 3 };
+
+static const float CENTROIDS_1BIT[2] = {-0.7978846f, 0.7978846f};
+static const float CENTROIDS_2BIT[4] = {-1.510f, -0.4528f, 0.4528f, 1.510f};
+static const float CENTROIDS_4BIT[16] = {-2.733f, -2.069f, -1.618f, -1.256f, -0.9424f, -0.6568f, -0.3881f, -0.1284f,
+                                         0.1284f, 0.3881f, 0.6568f, 0.9424f, 1.256f, 1.618f, 2.069f, 2.733f};
+/* x86_64 integer codebooks (simd/query{4,2}bit/mod.rs): c_u = c_signed + 128 */
+static const uint8_t CODEBOOK_U8_4BIT[16] = {0, 31, 52, 69, 84, 97, 110, 122, 134, 146, 159, 172, 187, 204, 225, 255};
+static const uint8_t CODEBOOK_U8_2BIT[4] = {0, 90, 166, 255};
+#define TQ_CODEBOOK_OFFSET 128
+#define TQ_QUERY_ABS_MAX 8127.0f
+#define TQ_QUERY_HIGH_COEF 128
+
+struct qo_tq {
+    uint32_t dim, padded_dim, rot_dim;
+    int bits, distance;
+    uint32_t *maps[3];     /* forward_maps */
+};
+
+static int bit_size(int bits) { return bits == TQ_BITS4 ? 4 : bits == TQ_BITS2 ? 2 : 1; }
+static const float *centroids_of(int bits, int *n) {
+    if (bits == TQ_BITS4) { *n = 16; return CENTROIDS_4BIT; }
+    if (bits == TQ_BITS2) { *n = 4; return CENTROIDS_2BIT; }
+    *n = 2;
+    return CENTROIDS_1BIT;
+}
+static uint32_t next_multiple(uint32_t x, uint32_t m) { return (x + m - 1) / m * m; }
+uint32_t qo_tq_padded_dim_for(uint32_t dim, int bits) {           /* encoding.rs:194-201 */
+    switch (bits) {
+        case TQ_BITS1: return next_multiple(dim, 8);
+        case TQ_BITS1_5: return next_multiple(dim * 3 / 2, 8);
+        case TQ_BITS2: return next_multiple(dim, 4);
+        default: return next_multiple(dim, 2);
+    }
+}
+static uint32_t extras_size(int distance) { return distance == QO_EUCLID ? 8 : 4; }   /* size_for, TQMode::Normal */
+
+/* permutation.rs: forward map of Permutation::new_one_way(seed, count).permute(identity) */
+void qo_tq_permutation_map(uint64_t seed, uint32_t count, uint32_t *map) {
+    for (uint32_t i = 0; i < count; i++) map[i] = i;
+    uint64_t state = seed;
+    for (uint32_t i = count; i-- > 1;) {                  /* (1..count).rev().zip(rng) */
+        state = state * 6364136223846793005ull + 1442695040888963407ull;
+        const uint32_t j = (uint32_t)((state >> 32) % ((uint64_t)i + 1));
+        const uint32_t t = map[i]; map[i] = map[j]; map[j] = t;
+    }
+}
+
+uint32_t qo_tq_chunk_sizes(uint32_t dim, uint32_t *out) {  /* compute_chunk_sizes: decreasing powers of two summing to dim */
+    uint32_t n = 0, bits = dim;
+    while (bits) {
+        uint32_t highest = 1u << (31 - __builtin_clz(bits));
+        bits ^= highest;
+        out[n++] = highest;
+    }
+    return n;
+}
+
+void qo_tq_wht(double *x, uint32_t n) {                    /* in_place_walsh_hadamard_transform */
+    for (uint32_t h = 1; h < n; h *= 2)
+        for (uint32_t i = 0; i < n; i += h * 2)
+            for (uint32_t j = i; j < i + h; j++) {
+                const double a = x[j], b = x[j + h];
+                x[j] = a + b;
+                x[j + h] = a - b;
+            }
+}
+static void wht_normalized_chunks(double *buf, uint32_t len) {
+    uint32_t sizes[32];
+    const uint32_t n = qo_tq_chunk_sizes(len, sizes);
+    uint32_t off = 0;
+    for (uint32_t c = 0; c < n; c++) {
+        const double norm = 1.0 / sqrt((double)sizes[c]);
+        qo_tq_wht(buf + off, sizes[c]);
+        for (uint32_t i = 0; i < sizes[c]; i++) buf[off + i] *= norm;
+        off += sizes[c];
+    }
+}
+
+qo_tq *qo_tq_new(uint32_t dim, int bits, int distance, int rotation_unpadded) {
+    qo_tq *t = (qo_tq *)calloc(1, sizeof(qo_tq));
+    static const uint64_t SEEDS[3] = {654605292835415893ull, 8636605637963351413ull, 1775280196666917949ull};
+    t->dim = dim; t->bits = bits; t->distance = distance;
+    t->padded_dim = qo_tq_padded_dim_for(dim, bits);
+    t->rot_dim = rotation_unpadded ? dim : t->padded_dim;
+    for (int p = 0; p < 3; p++) {
+        t->maps[p] = (uint32_t *)malloc(sizeof(uint32_t) * (t->rot_dim ? t->rot_dim : 1));
+        qo_tq_permutation_map(SEEDS[p], t->rot_dim, t->maps[p]);
+    }
+    return t;
+}
+void qo_tq_free(qo_tq *t) {
+    if (!t) return;
+    for (int p = 0; p < 3; p++) free(t->maps[p]);
+    free(t);
+}
+uint32_t qo_tq_padded_dim(const qo_tq *t) { return t->padded_dim; }
+uint32_t qo_tq_quantized_size(const qo_tq *t) { return t->padded_dim * bit_size(t->bits) / 8 + extras_size(t->distance); }
+
+/* HadamardRotation::apply on buf[..rot_dim] */
+void qo_tq_rotate(const qo_tq *t, double *x) {
+    const uint32_t n = t->rot_dim;
+    if (n == 0) return;
+    double *scratch = (double *)malloc(sizeof(double) * n);
+    wht_normalized_chunks(x, n);
+    double *src = x, *dst = scratch;
+    for (int p = 0; p < 3; p++) {
+        for (uint32_t k = 0; k < n; k++) dst[k] = src[t->maps[p][k]];
+        wht_normalized_chunks(dst, n);
+        double *s = src; src = dst; dst = s;
+    }
+    if (src != x) memcpy(x, src, sizeof(double) * n);
+    free(scratch);
+}
+
+static uint32_t centroid_index(const float *centroids, int n, double val) {   /* boundaries.partition_point(|&b| (val as f32) > b) */
+    const float v = (float)val;
+    uint32_t idx = 0;
+    for (int i = 0; i + 1 < n; i++) {
+        const float b = (centroids[i] + centroids[i + 1]) / 2.0f;
+        if (v > b) idx = (uint32_t)i + 1; else break;
+    }
+    return idx;
+}
+
+/* TurboQuantizer::quantize (TQMode::Normal): out = [codes][scaling_factor f32][l2_length f32 (L2 only)] */
+void qo_tq_quantize(const qo_tq *t, const float *vec, uint8_t *out) {
+    const uint32_t pd = t->padded_dim;
+    double *buf = (double *)calloc(pd ? pd : 1, sizeof(double));
+    for (uint32_t i = 0; i < t->dim; i++) buf[i] = (double)vec[i];
+    qo_tq_rotate(t, buf);
+    int has_l2 = t->distance != QO_COSINE;
+    float l2_length = 1.0f;
+    if (has_l2) {
+        double s = 0.0;
+        for (uint32_t i = 0; i < pd; i++) s += buf[i] * buf[i];
+        l2_length = (float)sqrt(s);
+    }
+    const double length = (double)l2_length;
+    if (length > 0.0) {
+        const double length_scale = sqrt((double)pd) / length;
+        for (uint32_t i = 0; i < pd; i++) buf[i] *= length_scale;
+    }
+    int nc;
+    const float *centroids = centroids_of(t->bits, &nc);
+    /* centroid norm (Dot / L2: always; Cosine: sqrt(padded_dim) for a zero vector) */
+    float centroid_norm;
+    {
+        int degenerate = 0;
+        if (t->distance == QO_COSINE) {
+            double s = 0.0;
+            for (uint32_t i = 0; i < pd; i++) s += buf[i] * buf[i];
+            degenerate = s < 1e-12;
+        }
+        if (degenerate) centroid_norm = sqrtf((float)pd);
+        else {
+            double sq = 0.0;
+            for (uint32_t i = 0; i < pd; i++) {
+                const double c = (double)centroids[centroid_index(centroids, nc, buf[i])];
+                sq += c * c;
+            }
+            centroid_norm = (float)sqrt(sq);
+        }
+    }
+    const uint32_t bs = (uint32_t)bit_size(t->bits), code_bytes = pd * bs / 8;
+    memset(out, 0, code_bytes);
+    for (uint32_t i = 0; i < pd; i++) {                       /* BitWriter, LSB first */
+        const uint32_t idx = centroid_index(centroids, nc, buf[i]), bit = i * bs;
+        out[bit / 8] |= (uint8_t)(idx << (bit % 8));
+    }
+    const float scaling_factor = (has_l2 ? l2_length : 1.0f) / centroid_norm;
+    memcpy(out + code_bytes, &scaling_factor, 4);
+    if (t->distance == QO_EUCLID) memcpy(out + code_bytes + 4, &l2_length, 4);
+    free(buf);
+}
+
+struct qo_tq_query {
+    int32_t *q;            /* q_signed per padded dim */
+    float postprocess_scale, l2_norm;
+    int64_t sum_q;
+    float *rotated_f32;
+};
+
+qo_tq_query *qo_tq_precompute_query(const qo_tq *t, const float *query) {
+    const uint32_t pd = t->padded_dim;
+    qo_tq_query *e = (qo_tq_query *)calloc(1, sizeof(qo_tq_query));
+    double *rot = (double *)calloc(pd ? pd : 1, sizeof(double));
+    for (uint32_t i = 0; i < t->dim; i++) rot[i] = (double)query[i];
+    qo_tq_rotate(t, rot);
+    e->l2_norm = 1.0f;
+    if (t->distance != QO_COSINE) {
+        double s = 0.0;
+        for (uint32_t i = 0; i < pd; i++) s += rot[i] * rot[i];
+        e->l2_norm = (float)sqrt(s);
+    }
+    e->rotated_f32 = (float *)malloc(sizeof(float) * (pd ? pd : 1));
+    e->q = (int32_t *)malloc(sizeof(int32_t) * (pd ? pd : 1));
+    float q_abs_max = 0.0f;
+    for (uint32_t i = 0; i < pd; i++) {
+        e->rotated_f32[i] = (float)rot[i];
+        const float a = fabsf(e->rotated_f32[i]);
+        if (a > q_abs_max) q_abs_max = a;                      /* fold(0.0, f32::max) */
+    }
+    if (!(q_abs_max > 1.1920929e-7f)) q_abs_max = 1.1920929e-7f;   /* .max(f32::EPSILON) */
+    const int one_bit = t->bits == TQ_BITS1 || t->bits == TQ_BITS1_5;
+    const float abs_max_int = one_bit ? 127.0f : TQ_QUERY_ABS_MAX;     /* (1 << (BITS - 1)) - 1 with BITS = 8 */
+    const float q_scale = abs_max_int / q_abs_max;
+    for (uint32_t i = 0; i < pd; i++) {
+        float v = roundf(e->rotated_f32[i] * q_scale);
+        if (v > abs_max_int) v = abs_max_int;
+        if (v < -abs_max_int) v = -abs_max_int;
+        e->q[i] = (int32_t)v;
+        e->sum_q += e->q[i];
+    }
+    if (one_bit) e->postprocess_scale = 0.7978846f / q_scale;                         /* CENTROID_ABS / q_scale */
+    else {
+        const float codebook_scale = 128.0f / (t->bits == TQ_BITS4 ? 2.733f : 1.510f);
+        e->postprocess_scale = 1.0f / (q_scale * codebook_scale);
+    }
+    free(rot);
+    return e;
+}
+void qo_tq_query_free(qo_tq_query *e) {
+    if (!e) return;
+    free(e->q); free(e->rotated_f32); free(e);
+}
+/* the encoded query as the device holds it: q_signed [padded_dim], postprocess_scale, l2_norm, sum of q_signed */
+void qo_tq_query_export(const qo_tq *t, const qo_tq_query *e, int32_t *q_out, float *postprocess_scale, float *l2_norm, int64_t *sum_q) {
+    if (q_out) memcpy(q_out, e->q, sizeof(int32_t) * t->padded_dim);
+    if (postprocess_scale) *postprocess_scale = e->postprocess_scale;
+    if (l2_norm) *l2_norm = e->l2_norm;
+    if (sum_q) *sum_q = e->sum_q;
+}
+
+static uint32_t code_at(const uint8_t *codes, uint32_t i, uint32_t bs) { return (codes[i * bs / 8] >> (i * bs % 8)) & ((1u << bs) - 1u); }
+
+/* Query{N}bitSimd::dotprod: the float "raw_dot" */
+static float tq_raw_dot(const qo_tq *t, const qo_tq_query *e, const uint8_t *codes) {
+    const uint32_t pd = t->padded_dim;
+    if (t->bits == TQ_BITS1 || t->bits == TQ_BITS1_5) {
+        int64_t v_dot_q = 0;                                   /* sum over set bits of q (the two's-complement bit planes add up to q) */
+        for (uint32_t i = 0; i < pd; i++) if (code_at(codes, i, 1)) v_dot_q += e->q[i];
+        const int64_t signed_dot = 2 * v_dot_q - e->sum_q;
+        return e->postprocess_scale * (float)signed_dot;
+    }
+    const uint32_t bs = (uint32_t)bit_size(t->bits);
+    const uint8_t *book = t->bits == TQ_BITS4 ? CODEBOOK_U8_4BIT : CODEBOOK_U8_2BIT;
+    int64_t dot_raw = 0;                                       /* acc_low + 128 acc_high = sum q_signed * c_u */
+    for (uint32_t i = 0; i < pd; i++) dot_raw += (int64_t)e->q[i] * (int64_t)book[code_at(codes, i, bs)];
+    const int64_t bias = (int64_t)TQ_CODEBOOK_OFFSET * e->sum_q;
+    return e->postprocess_scale * (float)(dot_raw - bias);
+}
+
+float qo_tq_score_precomputed(const qo_tq *t, const qo_tq_query *e, const uint8_t *vec) {
+    const uint32_t code_bytes = t->padded_dim * (uint32_t)bit_size(t->bits) / 8;
+    float scaling_factor, l2 = 0.0f;
+    memcpy(&scaling_factor, vec + code_bytes, 4);
+    const float dot = tq_raw_dot(t, e, vec) + 0.0f;            /* + query.ec_correction (0.0 without TQ+) */
+    if (t->distance == QO_EUCLID) {
+        memcpy(&l2, vec + code_bytes + 4, 4);
+        const float ql = e->l2_norm;
+        return ql * ql + l2 * l2 - 2.0f * dot * scaling_factor;
+    }
+    return dot * scaling_factor;
+}
+
+float qo_tq_score_symmetric(const qo_tq *t, const uint8_t *v1, const uint8_t *v2) {
+    const uint32_t pd = t->padded_dim, bs = (uint32_t)bit_size(t->bits), code_bytes = pd * bs / 8;
+    float raw_dot;
+    if (bs == 1) {
+        uint64_t popcnt = 0;
+        for (uint32_t i = 0; i < code_bytes; i++) popcnt += (uint64_t)__builtin_popcount((unsigned)(v1[i] ^ v2[i]));
+        const int64_t sign_sum = (int64_t)code_bytes * 8 - 2 * (int64_t)popcnt;
+        const float centroid_sq = 0.7978846f * 0.7978846f;
+        raw_dot = centroid_sq * (float)sign_sum;
+    } else {
+        const uint8_t *book = t->bits == TQ_BITS4 ? CODEBOOK_U8_4BIT : CODEBOOK_U8_2BIT;
+        int64_t acc = 0;
+        for (uint32_t i = 0; i < pd; i++)
+            acc += ((int64_t)book[code_at(v1, i, bs)] - TQ_CODEBOOK_OFFSET) * ((int64_t)book[code_at(v2, i, bs)] - TQ_CODEBOOK_OFFSET);
+        const float codebook_scale = 128.0f / (t->bits == TQ_BITS4 ? 2.733f : 1.510f);
+        raw_dot = (float)acc / (codebook_scale * codebook_scale);
+    }
+    float s1, s2;
+    memcpy(&s1, v1 + code_bytes, 4);
+    memcpy(&s2, v2 + code_bytes, 4);
+    if (t->distance == QO_EUCLID) {
+        float a, b;
+        memcpy(&a, v1 + code_bytes + 4, 4);
+        memcpy(&b, v2 + code_bytes + 4, 4);
+        return a * a + b * b - 2.0f * s1 * s2 * raw_dot;
+    }
+    return raw_dot * s1 * s2;
+}
+
+/* TurboQuantizer::dequantize (Normal mode) followed by apply_inverse_rotation is not restated (L1 only). */

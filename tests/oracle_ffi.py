@@ -869,3 +869,82 @@ def multi_scores(storage: "DenseStorage", inner_queries, query_first, point_offs
         for c, p in enumerate(ids):
             out[j, c] = max_similarity(sims[query_first[j]:query_first[j + 1], int(point_offsets[p]):int(point_offsets[p + 1])])
     return out
+
+
+# ---- TurboQuant (oracle/qdrant_oracle_tq.c) ---------------------------------------------------------------------------
+TQ_BITS4, TQ_BITS2, TQ_BITS1_5, TQ_BITS1 = range(4)
+_sig("qo_tq_padded_dim_for", C.c_uint32, [C.c_uint32, C.c_int])
+_sig("qo_tq_permutation_map", None, [C.c_uint64, C.c_uint32, _P])
+_sig("qo_tq_chunk_sizes", C.c_uint32, [C.c_uint32, _P])
+_sig("qo_tq_wht", None, [_P, C.c_uint32])
+_sig("qo_tq_new", _P, [C.c_uint32, C.c_int, C.c_int, C.c_int])
+_sig("qo_tq_free", None, [_P])
+_sig("qo_tq_padded_dim", C.c_uint32, [_P])
+_sig("qo_tq_quantized_size", C.c_uint32, [_P])
+_sig("qo_tq_rotate", None, [_P, _P])
+_sig("qo_tq_quantize", None, [_P, _P, _P])
+_sig("qo_tq_precompute_query", _P, [_P, _P])
+_sig("qo_tq_query_free", None, [_P])
+_sig("qo_tq_query_export", None, [_P, _P, _P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int64)])
+_sig("qo_tq_score_precomputed", _f, [_P, _P, _P])
+_sig("qo_tq_score_symmetric", _f, [_P, _P, _P])
+
+
+class TqOracle:
+    """TurboQuantizer (TQMode::Normal) + the EncodedVectorsTQ glue (`invert`)."""
+
+    def __init__(self, distance, dim, bits, rotation_unpadded=False, invert=None):
+        self.distance, self.dim, self.bits = distance, dim, bits
+        self.invert = (distance in (EUCLID, MANHATTAN)) if invert is None else bool(invert)   # quantized_vectors.rs:232
+        self.h = _lib.qo_tq_new(dim, bits, distance, 1 if rotation_unpadded else 0)
+        self.padded_dim = _lib.qo_tq_padded_dim(self.h)
+        self.row_bytes = _lib.qo_tq_quantized_size(self.h)
+        self.rows = None
+
+    def __del__(self):
+        try:
+            _lib.qo_tq_free(self.h)
+        except Exception:
+            pass
+
+    def rotate(self, x):
+        buf = np.zeros(self.padded_dim, dtype=np.float64)
+        buf[:len(x)] = x
+        _lib.qo_tq_rotate(self.h, _p(buf))
+        return buf
+
+    def encode_rows(self, vectors):
+        v = f32(np.atleast_2d(vectors))
+        out = np.zeros((v.shape[0], self.row_bytes), dtype=np.uint8)
+        for i in range(v.shape[0]):
+            _lib.qo_tq_quantize(self.h, _p(v[i]), _p(out[i]))
+        self.rows = out
+        return out
+
+    def query(self, q):
+        """(q_signed [padded_dim] i32, postprocess_scale, l2_norm, sum_q) of precompute_query"""
+        e = _lib.qo_tq_precompute_query(self.h, _p(f32(q)))
+        qs = np.zeros(self.padded_dim, dtype=np.int32)
+        ps, l2, sq = C.c_float(), C.c_float(), C.c_int64()
+        _lib.qo_tq_query_export(self.h, e, _p(qs), C.byref(ps), C.byref(l2), C.byref(sq))
+        _lib.qo_tq_query_free(e)
+        return qs, np.float32(ps.value), np.float32(l2.value), sq.value
+
+    def score_points(self, queries, ids):
+        """EncodedVectorsTQ::score_point for every (query, id): ORIGINAL (un-rotated) query vectors, as the storage stores them."""
+        q = f32(np.atleast_2d(queries))
+        out = np.empty((q.shape[0], len(ids)), dtype=np.float32)
+        for i in range(q.shape[0]):
+            e = _lib.qo_tq_precompute_query(self.h, _p(q[i]))
+            for j, p in enumerate(ids):
+                s = _lib.qo_tq_score_precomputed(self.h, e, _p(self.rows[int(p)]))
+                out[i, j] = -s if self.invert else s
+            _lib.qo_tq_query_free(e)
+        return out
+
+    def score_internal(self, a, b):
+        out = np.empty(len(a), dtype=np.float32)
+        for k, (i, j) in enumerate(zip(a, b)):
+            s = _lib.qo_tq_score_symmetric(self.h, _p(self.rows[int(i)]), _p(self.rows[int(j)]))
+            out[k] = -s if self.invert else s
+        return out

@@ -1,0 +1,169 @@
+"""The oracle's TurboQuant restatement (oracle/qdrant_oracle_tq.c) against everything the reference's own tests hold for it (CPU only).
+
+  rotation.rs:283-315       test_compute_chunk_sizes: literal decompositions
+  permutation.rs:163-190    lcg / permute round trips (the forward maps are permutations)
+  rotation.rs (tests)       the rotation is orthonormal: norms and dot products are preserved; Hadamard spreads concentrated energy
+  simd/query{4,2}bit        test_codebook_matches_lloyd_max: the integer codebooks are round(c * scale) + 128 of the f32 centroids
+  lloyd_max.rs:170-190      the centroid constants are the Lloyd-Max solution for N(0, 1) (checked here by the fixed-point property)
+  tests/integration/test_tq.rs:19-60,262-475,770-870   |score - exact| < coef(bits) * signal_std for dot / cosine / l2, asymmetric and
+                                                       internal, with the reference's data model (U[-1, 1]^d), dims and bits
+  encoding.rs:172-201       quantized sizes and padded dims
+Nothing here is a bit-level pin (the reference has none for this quantizer): DESIGN 4."""
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+
+BITS = [O.TQ_BITS4, O.TQ_BITS2, O.TQ_BITS1_5, O.TQ_BITS1]
+COEF = {O.TQ_BITS1: 5.1, O.TQ_BITS1_5: 4.0, O.TQ_BITS2: 3.0, O.TQ_BITS4: 0.9}
+MIN_DIM = {O.TQ_BITS1: 64, O.TQ_BITS1_5: 48, O.TQ_BITS2: 32, O.TQ_BITS4: 8}
+DIMS = [16, 64, 65, 128, 384, 512]
+
+
+def test_chunk_sizes_literals():
+    def chunks(d):
+        out = np.zeros(32, dtype=np.uint32)
+        n = O._lib.qo_tq_chunk_sizes(d, O._p(out))
+        return out[:n].tolist()
+    assert chunks(128) == [128]
+    assert chunks(700) == [512, 128, 32, 16, 8, 4]
+    assert chunks(1536) == [1024, 512]
+    assert chunks(4096) == [4096]
+    for d in [5, 128, 129, 300, 700, 712, 1536, 4096]:
+        c = chunks(d)
+        assert sum(c) == d and all(x & (x - 1) == 0 for x in c) and c == sorted(c, reverse=True)
+
+
+def test_padded_dims_and_sizes():
+    assert O._lib.qo_tq_padded_dim_for(65, O.TQ_BITS1) == 72 and O._lib.qo_tq_padded_dim_for(65, O.TQ_BITS2) == 68
+    assert O._lib.qo_tq_padded_dim_for(65, O.TQ_BITS4) == 66 and O._lib.qo_tq_padded_dim_for(64, O.TQ_BITS1_5) == 96
+    assert O.TqOracle(O.DOT, 768, O.TQ_BITS4).row_bytes == 384 + 4 and O.TqOracle(O.EUCLID, 768, O.TQ_BITS2).row_bytes == 192 + 8
+    assert O.TqOracle(O.COSINE, 128, O.TQ_BITS1_5).row_bytes == 24 + 4
+
+
+def test_permutation_maps_are_permutations_and_differ_by_seed():
+    for count in (2, 5, 64, 300, 1024, 1536):
+        maps = []
+        for seed in (654605292835415893, 8636605637963351413, 1775280196666917949, 42):
+            m = np.zeros(count, dtype=np.uint32)
+            O._lib.qo_tq_permutation_map(seed, count, O._p(m))
+            assert sorted(m.tolist()) == list(range(count))
+            maps.append(m)
+        if count >= 64:
+            assert not np.array_equal(maps[0], maps[1]) and not np.array_equal(maps[0], np.arange(count))
+    # Fisher-Yates replay by hand for a tiny case: LCG state = state * A + C, j = (state >> 32) % (i + 1), swap(i, j) for i = n-1 .. 1
+    A, Cc, M = 6364136223846793005, 1442695040888963407, (1 << 64) - 1
+    arr, state = list(range(7)), 42
+    for i in range(6, 0, -1):
+        state = (state * A + Cc) & M
+        j = (state >> 32) % (i + 1)
+        arr[i], arr[j] = arr[j], arr[i]
+    m = np.zeros(7, dtype=np.uint32)
+    O._lib.qo_tq_permutation_map(42, 7, O._p(m))
+    assert m.tolist() == arr
+
+
+@pytest.mark.parametrize("dim", [100, 101, 300, 384, 512, 1024, 1025, 1586])
+def test_rotation_is_orthonormal_and_spreads_energy(dim):
+    rng = np.random.default_rng(dim)
+    t = O.TqOracle(O.DOT, dim, O.TQ_BITS4)
+    a, b = rng.standard_normal(dim), rng.standard_normal(dim)
+    ra, rb = t.rotate(a), t.rotate(b)
+    assert abs(np.dot(ra, rb) - np.dot(a, b)) < 1e-9 * dim and abs(np.linalg.norm(ra) - np.linalg.norm(a)) < 1e-9
+    spike = np.zeros(dim)
+    spike[3] = 1.0
+    r = t.rotate(spike)
+    assert np.abs(r).max() < 0.5 and abs(np.linalg.norm(r) - 1.0) < 1e-12          # energy no longer sits in one coordinate
+    # the WHT is its own inverse up to n
+    x = rng.standard_normal(256)
+    y = x.copy()
+    O._lib.qo_tq_wht(O._p(y), 256)
+    O._lib.qo_tq_wht(O._p(y), 256)
+    assert np.allclose(y / 256.0, x, atol=1e-12)
+
+
+def test_integer_codebooks_match_the_lloyd_max_centroids():
+    c4 = np.array([-2.733, -2.069, -1.618, -1.256, -0.9424, -0.6568, -0.3881, -0.1284, 0.1284, 0.3881, 0.6568, 0.9424, 1.256, 1.618, 2.069, 2.733])
+    want4 = [0, 31, 52, 69, 84, 97, 110, 122, 134, 146, 159, 172, 187, 204, 225, 255]
+    assert np.clip(np.round(c4 * (128.0 / 2.733)) + 128, 0, 255).astype(int).tolist() == want4
+    c2 = np.array([-1.510, -0.4528, 0.4528, 1.510])
+    assert np.clip(np.round(c2 * (128.0 / 1.510)) + 128, 0, 255).astype(int).tolist() == [0, 90, 166, 255]
+    # Lloyd-Max fixed point for N(0, 1): each centroid is the conditional mean of its cell (lloyd_max.rs tests, tolerance 1e-3)
+    from math import erf, exp, pi, sqrt
+    pdf = lambda x: exp(-0.5 * x * x) / sqrt(2 * pi)      # noqa: E731
+    cdf = lambda x: 0.5 * (1 + erf(x / sqrt(2)))          # noqa: E731
+    for c in (c4, c2, np.array([-0.7978846, 0.7978846])):
+        edges = [-np.inf] + ((c[:-1] + c[1:]) / 2).tolist() + [np.inf]
+        for i, ci in enumerate(c):
+            a, b = edges[i], edges[i + 1]
+            pa, pb = (0.0 if a == -np.inf else pdf(a)), (0.0 if b == np.inf else pdf(b))
+            ca, cb = (0.0 if a == -np.inf else cdf(a)), (1.0 if b == np.inf else cdf(b))
+            assert abs((pa - pb) / (cb - ca) - ci) < 1e-3
+
+
+def _data(dim, n, seed, normalize=False):
+    rng = np.random.default_rng(seed)
+    v = rng.uniform(-1.0, 1.0, (n + 1, dim)).astype(np.float32)
+    if normalize:
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+    return v[:n], v[n]
+
+
+@pytest.mark.parametrize("bits", BITS)
+@pytest.mark.parametrize("dim", DIMS)
+def test_scores_within_the_reference_error_model(bits, dim):
+    """test_tq_dot / test_tq_cosine / test_tq_l2 and their _internal variants (TQMode::Normal): 513 vectors, one query."""
+    if dim < MIN_DIM[bits]:
+        pytest.skip("should_test(dim, bits) is false in the reference")
+    n = 513
+    dot_std, cos_std = (dim / 9.0) ** 0.5, 1.0 / dim ** 0.5
+    for distance, std, normalize in ((O.DOT, dot_std, False), (O.COSINE, cos_std, True), (O.EUCLID, 2 * dot_std, False)):
+        vecs, q = _data(dim, n, seed=42 + dim, normalize=normalize)
+        t = O.TqOracle(distance, dim, bits, invert=False)
+        t.encode_rows(vecs)
+        err = COEF[bits] * std
+        got = t.score_points(q[None, :], np.arange(n))[0]
+        if distance == O.EUCLID:
+            exact = ((vecs - q) ** 2).sum(axis=1)
+        elif distance == O.COSINE:
+            exact = (vecs @ q) / (np.linalg.norm(vecs, axis=1) * np.linalg.norm(q))
+        else:
+            exact = vecs @ q
+        assert np.abs(got - exact).max() < err
+        gi = t.score_internal(np.zeros(n - 1, dtype=int), np.arange(1, n))
+        if distance == O.EUCLID:
+            ei = ((vecs[1:] - vecs[0]) ** 2).sum(axis=1)
+        elif distance == O.COSINE:
+            ei = (vecs[1:] @ vecs[0]) / (np.linalg.norm(vecs[1:], axis=1) * np.linalg.norm(vecs[0]))
+        else:
+            ei = vecs[1:] @ vecs[0]
+        assert np.abs(gi - ei).max() < err
+
+
+@pytest.mark.parametrize("bits", BITS)
+def test_zero_vectors_and_zero_queries(bits):
+    """test_tq_zero_vector_* / test_tq_zero_query_*: finite scores, a zero query scores 0 (dot) against everything."""
+    dim = 128
+    vecs, q = _data(dim, 32, seed=7)
+    vecs[5] = 0.0
+    for distance in (O.DOT, O.COSINE):
+        t = O.TqOracle(distance, dim, bits, invert=False)
+        t.encode_rows(vecs)
+        s = t.score_points(np.stack([q, np.zeros(dim, dtype=np.float32)]), np.arange(32))
+        assert np.isfinite(s).all()
+        assert abs(s[0, 5]) < COEF[bits] * (dim / 9.0) ** 0.5 and np.abs(s[1]).max() < 1e-3
+
+
+def test_query_encoding_fields():
+    """Query4bitSimd::new: q_signed = clamp(round(v * 8127 / max|v|)), postprocess_scale = 1 / (q_scale * 128 / 2.733); 1 bit: 127, 0.7978846 / q_scale"""
+    dim = 64
+    rng = np.random.default_rng(3)
+    q = rng.standard_normal(dim).astype(np.float32)
+    for bits, qmax in ((O.TQ_BITS4, 8127), (O.TQ_BITS2, 8127), (O.TQ_BITS1, 127)):
+        t = O.TqOracle(O.DOT, dim, bits)
+        qs, ps, l2, sq = t.query(q)
+        rot = t.rotate(q.astype(np.float64)).astype(np.float32)
+        scale = np.float32(qmax) / np.abs(rot).max()
+        assert np.abs(qs).max() == qmax and int(qs.sum()) == sq
+        assert np.array_equal(qs, np.clip(np.sign(rot * scale) * np.floor(np.abs(rot * scale) + np.float32(0.5)), -qmax, qmax).astype(np.int32))
+        assert abs(float(l2) - np.linalg.norm(q)) < 1e-4
