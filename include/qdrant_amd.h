@@ -62,9 +62,12 @@ typedef enum qmx_dtype {
     QMX_DTYPE_U8 = 2,
     QMX_DTYPE_SQ_U8 = 3,
     QMX_DTYPE_PQ = 4,
-    QMX_DTYPE_BQ = 5   /* EncodedVectorsBin<u128>; Encoding and QueryEncoding in qmx_bq_params (default OneBit, SameAsStorage)
+    QMX_DTYPE_BQ = 5,  /* EncodedVectorsBin<u128>; Encoding and QueryEncoding in qmx_bq_params (default OneBit, SameAsStorage)
                           (lib/quantization/src/encoded_vectors_binary.rs): rows of ceil(dim / 128) * 16 bytes,
                           bit i = vector[i] > 0; invert derives from the distance (quantized_vectors.rs:232) */
+    QMX_DTYPE_TQ = 6   /* EncodedVectorsTQ (lib/quantization/src/encoded_vectors_tq.rs over turboquant/): rows as TurboQuantizer::quantize
+                          writes them, [codes: padded_dim * bits / 8 bytes][scaling_factor f32][l2_length f32 for Euclid]
+                          (turboquant/encoding.rs:117-134, 172-258); qmx_tq_params required */
 } qmx_dtype;
 
 /* Same order as `enum Distance` (lib/segment/src/types.rs:313-322). */
@@ -167,6 +170,22 @@ typedef struct qmx_bq_params {
     const float *stddev;    /* [dim] host or device, or NULL */
 } qmx_bq_params;
 
+/* TurboQuant (`TurboQuantizer`, lib/quantization/src/turboquant/quantization.rs:14-158; `Metadata`, encoded_vectors_tq.rs:33-46).
+ * TQMode::Normal only: a TQ+ storage (per-coordinate error correction) is QMX_ERR_NOT_SUPPORTED.  Distances Dot, Cosine, Euclid (L1 scores need a
+ * full dequantisation + inverse rotation per pair in the reference: QMX_ERR_NOT_SUPPORTED).  Queries are rotated (HadamardRotation, f64, the
+ * reference's fixed permutation seeds) and integer-encoded on the device (`precompute_query` :496-567 with the x86_64 constants of
+ * turboquant/simd/query{4,2,1}bit); scores are `score_precomputed` (:569-620) negated when `invert`; qmx_score_internal is
+ * `score_symmetric` (:395-445).  `encode_internal_vector` is None (:453-459): qmx_query_create_internal is QMX_ERR_NOT_SUPPORTED, as for PQ. */
+typedef enum qmx_tq_bits { QMX_TQ_BITS4 = 0, QMX_TQ_BITS2 = 1, QMX_TQ_BITS1_5 = 2, QMX_TQ_BITS1 = 3 } qmx_tq_bits;   /* TQBits, turboquant/mod.rs:15-20 */
+typedef struct qmx_tq_params {
+    uint32_t bits;               /* qmx_tq_bits */
+    uint32_t rotation_unpadded;  /* TQRotation: 0 = Padded (rotate all padded_dim coordinates), 1 = Unpadded (only the first dim) */
+    uint8_t invert;              /* VectorParameters.invert */
+    uint8_t plus_mode;           /* TQMode::Plus: must be 0 */
+    uint8_t pad_[2];
+    uint32_t reserved;
+} qmx_tq_params;
+
 typedef struct qmx_segment_desc {
     uint32_t dtype;            /* qmx_dtype */
     uint32_t distance;         /* qmx_distance */
@@ -180,6 +199,7 @@ typedef struct qmx_segment_desc {
     const qmx_sq_params *sq;   /* required for QMX_DTYPE_SQ_U8 */
     const qmx_pq_params *pq;   /* required for QMX_DTYPE_PQ */
     const qmx_bq_params *bq;   /* optional for QMX_DTYPE_BQ: NULL = Encoding::OneBit */
+    const qmx_tq_params *tq;   /* required for QMX_DTYPE_TQ */
 } qmx_segment_desc;
 
 /* The quantizers' metadata file ("quantized.meta.json", vector_storage/quantized/quantized_vectors/config.rs:13) as

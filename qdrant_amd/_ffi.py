@@ -15,7 +15,7 @@ OK, ERR_OUT_OF_MEMORY, ERR_OUT_OF_BOUNDS, ERR_NOT_SUPPORTED, ERR_NOT_READY, ERR_
 STATUS_NAMES = ["OK", "OUT_OF_MEMORY", "OUT_OF_BOUNDS", "NOT_SUPPORTED", "NOT_READY", "TIMEOUT", "OTHER",
                 "CANCELLED", "BAD_ARG", "NO_DEVICE"]
 
-DTYPE_F32, DTYPE_F16, DTYPE_U8, DTYPE_SQ_U8, DTYPE_PQ, DTYPE_BQ = range(6)
+DTYPE_F32, DTYPE_F16, DTYPE_U8, DTYPE_SQ_U8, DTYPE_PQ, DTYPE_BQ, DTYPE_TQ = range(7)
 COSINE, EUCLID, DOT, MANHATTAN = range(4)
 
 SEG_DATA_ON_DEVICE = 0x1
@@ -49,6 +49,12 @@ class BqParams(C.Structure):
     _fields_ = [("encoding", C.c_uint32), ("query_encoding", C.c_uint32), ("mean", C.c_void_p), ("stddev", C.c_void_p)]
 
 
+class TqParams(C.Structure):
+    _fields_ = [("bits", C.c_uint32), ("rotation_unpadded", C.c_uint32), ("invert", C.c_uint8), ("plus_mode", C.c_uint8), ("pad_", C.c_uint8 * 2),
+                ("reserved", C.c_uint32)]
+
+
+TQ_BITS4, TQ_BITS2, TQ_BITS1_5, TQ_BITS1 = range(4)
 BQ_ONE_BIT, BQ_TWO_BITS, BQ_ONE_AND_HALF_BITS = range(3)
 BQ_QUERY_SAME_AS_STORAGE, BQ_QUERY_SCALAR_4BITS, BQ_QUERY_SCALAR_8BITS = range(3)
 
@@ -57,7 +63,7 @@ class SegmentDesc(C.Structure):
     _fields_ = [("dtype", C.c_uint32), ("distance", C.c_uint32), ("dim", C.c_uint32), ("flags", C.c_uint32),
                 ("n", C.c_uint64), ("row_stride_bytes", C.c_uint64), ("data", C.c_void_p),
                 ("device_id", C.c_int32), ("reserved", C.c_int32), ("sq", C.POINTER(SqParams)),
-                ("pq", C.POINTER(PqParams)), ("bq", C.POINTER(BqParams))]
+                ("pq", C.POINTER(PqParams)), ("bq", C.POINTER(BqParams)), ("tq", C.POINTER(TqParams))]
 
 
 class HnswDesc(C.Structure):

@@ -169,6 +169,12 @@ struct qmx_segment {
     float *d_pq_pair = nullptr;       // [m][ncent][ncent] chunk distances between centroids (score_internal terms; built when <= 256 MB)
     uint32_t pq_m = 0;
     float *d_row_offsets = nullptr;   // SQ: vector_offset column (rows hold the 16-byte aligned code block)
+    // TurboQuant (scan_tq.hip): parameters, the extras columns and the rotation tables
+    uint32_t tq_bits = 0, tq_value_bits = 0, tq_padded_dim = 0, tq_rot_dim = 0, tq_code_bytes = 0, tq_n_chunks = 0;
+    bool tq_invert = false;
+    float *d_tq_sf = nullptr, *d_tq_l2 = nullptr;
+    uint32_t *d_tq_tables = nullptr;   // [3][rot_dim] maps, then chunk offsets and sizes
+    double *d_tq_norms = nullptr;      // [n_chunks]
     // f32 dot / cosine blocks large enough for the split prefilter (scan_split.hip): max |x| and max row norm, taken once at create
     bool split_stats = false;
     float row_maxabs = 0.f, row_norm_max = 0.f;
@@ -176,7 +182,7 @@ struct qmx_segment {
     bool split_half = false;          // ... which of the two
 
     bool fast_layout() const {
-        if (dtype == QMX_DTYPE_BQ) return row_stride % 16 == 0 && ((uintptr_t)d_rows % 16) == 0;
+        if (dtype == QMX_DTYPE_BQ || dtype == QMX_DTYPE_TQ) return row_stride % 16 == 0 && ((uintptr_t)d_rows % 16) == 0;
         if (dtype <= QMX_DTYPE_U8) {
             const uint64_t eb = dtype == QMX_DTYPE_F32 ? 4 : dtype == QMX_DTYPE_F16 ? 2 : 1;
             return dim < 32 ? (row_stride % eb == 0 && ((uintptr_t)d_rows % eb) == 0)
@@ -223,7 +229,7 @@ struct qmx_query {
     uint32_t n_cq_coefs = 0;
     DevBuf cand, cand_cnt, cand_ids;   // qmx_search_quantized: oversampled candidates of the quantized stage
     // split prefilter (scan_split.hip): split queries, per-query norms / thresholds / bands, scales, candidate and verification buffers, flag
-    DevBuf sp_bq, sp_f32, sp_cand, sp_cnt, sp_ver, sp_vscores, sp_sample, sp_wl, xcnt;
+    DevBuf sp_bq, sp_f32, sp_cand, sp_cnt, sp_ver, sp_vscores, sp_sample, sp_wl, xcnt, tq_rot;
     uint64_t sp_sample_n = 0, sp_sample_of = 0;
     DevBuf filter;             // payload-filter allow bitmap of this query batch (qmx_query_set_filter)
     uint64_t n_filter_bits = 0;
@@ -324,7 +330,7 @@ static uint32_t pow2_ceil(uint32_t x) {
 // ---------------------------------------------------------------------------------------------
 extern "C" {
 
-uint32_t qmx_abi_version(void) { return 2; }
+uint32_t qmx_abi_version(void) { return 3; }
 
 static int option_index(const char *name) {
     if (!name) return -1;
@@ -383,6 +389,10 @@ static void segment_free(qmx_segment *seg) {
     if (seg->d_row_offsets) (void)hipFree(seg->d_row_offsets);
     if (seg->d_bq_mean) (void)hipFree(seg->d_bq_mean);
     if (seg->d_bq_stddev) (void)hipFree(seg->d_bq_stddev);
+    if (seg->d_tq_sf) (void)hipFree(seg->d_tq_sf);
+    if (seg->d_tq_l2) (void)hipFree(seg->d_tq_l2);
+    if (seg->d_tq_tables) (void)hipFree(seg->d_tq_tables);
+    if (seg->d_tq_norms) (void)hipFree(seg->d_tq_norms);
     delete seg;
 }
 
@@ -408,6 +418,29 @@ static int32_t segment_upload(qmx_segment *s, const qmx_segment_desc *desc) {
             d_src = tmp.p;
         }
         int32_t rc = launch_sq_split(nullptr, d_src, src_stride, s->n, ad, s->d_rows, s->d_row_offsets);
+        if (rc == QMX_OK && hipDeviceSynchronize() != hipSuccess) rc = QMX_ERR_OTHER;
+        tmp.release();
+        return rc;
+    }
+    if (s->dtype == QMX_DTYPE_TQ) {
+        // split [codes][scaling_factor][l2_length] rows into a 16-byte aligned, zero padded code block + the extras columns
+        const bool has_l2 = s->distance == QMX_DISTANCE_EUCLID;
+        s->row_stride = s->scan_dim;
+        QMX_HIP(hipMalloc(&s->d_rows, (size_t)std::max<uint64_t>(1, s->n) * s->row_stride));
+        s->owns_rows = true;
+        QMX_HIP(hipMalloc((void **)&s->d_tq_sf, (size_t)std::max<uint64_t>(1, s->n) * sizeof(float)));
+        if (has_l2) QMX_HIP(hipMalloc((void **)&s->d_tq_l2, (size_t)std::max<uint64_t>(1, s->n) * sizeof(float)));
+        if (s->n == 0) return QMX_OK;
+        const void *d_src = desc->data;
+        DevBuf tmp;
+        if (!on_device && !is_device_ptr(desc->data)) {
+            QMX_TRY(tmp.reserve((size_t)s->n * src_stride));
+            hipError_t e = hipMemcpy(tmp.p, desc->data, (size_t)(s->n - 1) * src_stride + s->row_bytes, hipMemcpyHostToDevice);
+            if (e != hipSuccess) { tmp.release(); return hip_status(e, "hipMemcpy(TQ rows)", __FILE__, __LINE__); }
+            d_src = tmp.p;
+        }
+        int32_t rc = launch_tq_split(nullptr, d_src, src_stride, s->n, s->tq_code_bytes, (uint32_t)s->row_stride, has_l2 ? 1 : 0, s->d_rows, s->d_tq_sf,
+                                     s->d_tq_l2);
         if (rc == QMX_OK && hipDeviceSynchronize() != hipSuccess) rc = QMX_ERR_OTHER;
         tmp.release();
         return rc;
@@ -465,10 +498,79 @@ static int32_t segment_split_stats(qmx_segment *s) {
     return QMX_OK;
 }
 
+// TurboQuantizer::new (turboquant/quantization.rs:127-158): padded dim (encoding.rs:194-201), the rotation's three permutation maps
+// (rotation.rs:4-10,32-63 over permutation.rs: Fisher-Yates driven by Knuth's MMIX LCG, upper 32 bits mod bound) and its chunk decomposition
+// (rotation.rs:222-233,264-280: decreasing powers of two, each WHT normalised by 1 / sqrt(size))
+static int32_t tq_segment_setup(qmx_segment *s, const qmx_segment_desc *desc) {
+    QMX_REQUIRE(desc->tq, QMX_ERR_BAD_ARG, "TQ segment needs qmx_tq_params");
+    const qmx_tq_params &t = *desc->tq;
+    QMX_REQUIRE(t.bits <= QMX_TQ_BITS1, QMX_ERR_BAD_ARG, "bad TQBits %u", t.bits);
+    QMX_REQUIRE(!t.plus_mode, QMX_ERR_NOT_SUPPORTED, "TQMode::Plus (per-coordinate error correction) is not built");
+    QMX_REQUIRE(desc->distance != QMX_DISTANCE_MANHATTAN, QMX_ERR_NOT_SUPPORTED, "TurboQuant L1 scores (dequantise + inverse rotation per pair) are not built");
+    QMX_REQUIRE(!(t.bits == QMX_TQ_BITS1_5 && t.rotation_unpadded), QMX_ERR_BAD_ARG, "Bits1_5 requires TQRotation::Padded");
+    auto next_multiple = [](uint64_t x, uint64_t m) { return (x + m - 1) / m * m; };
+    const uint64_t dim = desc->dim;
+    uint64_t padded = 0;
+    switch (t.bits) {
+        case QMX_TQ_BITS1: padded = next_multiple(dim, 8); s->tq_value_bits = 1; break;
+        case QMX_TQ_BITS1_5: padded = next_multiple(dim * 3 / 2, 8); s->tq_value_bits = 1; break;
+        case QMX_TQ_BITS2: padded = next_multiple(dim, 4); s->tq_value_bits = 2; break;
+        default: padded = next_multiple(dim, 2); s->tq_value_bits = 4; break;
+    }
+    QMX_REQUIRE(padded <= 8192, QMX_ERR_NOT_SUPPORTED, "TurboQuant: padded dim %llu > 8192 (the rotation runs in LDS)", (unsigned long long)padded);
+    s->tq_bits = t.bits;
+    s->tq_invert = t.invert != 0;
+    s->tq_padded_dim = (uint32_t)padded;
+    s->tq_rot_dim = t.rotation_unpadded ? (uint32_t)dim : (uint32_t)padded;
+    s->tq_code_bytes = (uint32_t)(padded * s->tq_value_bits / 8);
+    s->row_bytes = s->tq_code_bytes + (desc->distance == QMX_DISTANCE_EUCLID ? 8 : 4);
+    s->scan_dim = (s->tq_code_bytes + 15) & ~15u;        // bytes of a row of the device code block
+    // the rotation tables
+    const uint32_t rd = s->tq_rot_dim;
+    static const uint64_t SEEDS[3] = {654605292835415893ull, 8636605637963351413ull, 1775280196666917949ull};
+    std::vector<uint32_t> tables((size_t)3 * rd + 64);
+    for (int p = 0; p < 3; ++p) {
+        uint32_t *map = tables.data() + (size_t)p * rd;
+        for (uint32_t i = 0; i < rd; ++i) map[i] = i;
+        uint64_t state = SEEDS[p];
+        for (uint32_t i = rd; i-- > 1;) {
+            state = state * 6364136223846793005ull + 1442695040888963407ull;
+            const uint32_t j = (uint32_t)((state >> 32) % ((uint64_t)i + 1));
+            std::swap(map[i], map[j]);
+        }
+    }
+    std::vector<double> norms;
+    uint32_t nchunks = 0, off = 0;
+    for (uint32_t rest = rd; rest;) {
+        const uint32_t size = 1u << (31 - __builtin_clz(rest));
+        rest ^= size;
+        tables[(size_t)3 * rd + nchunks] = off;
+        tables[(size_t)3 * rd + 32 + nchunks] = size;
+        norms.push_back(1.0 / std::sqrt((double)size));
+        off += size;
+        ++nchunks;
+    }
+    s->tq_n_chunks = nchunks;
+    QMX_HIP(hipMalloc((void **)&s->d_tq_tables, tables.size() * 4));
+    QMX_HIP(hipMemcpy(s->d_tq_tables, tables.data(), tables.size() * 4, hipMemcpyHostToDevice));
+    QMX_HIP(hipMalloc((void **)&s->d_tq_norms, std::max<size_t>(1, norms.size()) * 8));
+    if (!norms.empty()) QMX_HIP(hipMemcpy(s->d_tq_norms, norms.data(), norms.size() * 8, hipMemcpyHostToDevice));
+    return QMX_OK;
+}
+static TqRotationHost tq_rotation(const qmx_segment *s) {
+    TqRotationHost h;
+    h.d_maps = s->d_tq_tables;
+    h.d_chunk_off = s->d_tq_tables + (size_t)3 * s->tq_rot_dim;
+    h.d_chunk_size = h.d_chunk_off + 32;
+    h.d_chunk_norm = s->d_tq_norms;
+    h.n_chunks = s->tq_n_chunks; h.rot_dim = s->tq_rot_dim; h.padded_dim = s->tq_padded_dim; h.dim = s->dim;
+    return h;
+}
+
 int32_t qmx_segment_create(const qmx_segment_desc *desc, qmx_segment **out) {
     QMX_REQUIRE(desc && out, QMX_ERR_BAD_ARG, "NULL argument");
     *out = nullptr;
-    QMX_REQUIRE(desc->dtype <= QMX_DTYPE_BQ, QMX_ERR_BAD_ARG, "bad dtype %u", desc->dtype);
+    QMX_REQUIRE(desc->dtype <= QMX_DTYPE_TQ, QMX_ERR_BAD_ARG, "bad dtype %u", desc->dtype);
     QMX_REQUIRE(desc->distance <= QMX_DISTANCE_MANHATTAN, QMX_ERR_BAD_ARG, "bad distance %u", desc->distance);
     QMX_REQUIRE(desc->dim > 0, QMX_ERR_BAD_ARG, "dim must be > 0");
     QMX_REQUIRE(desc->n <= 0xFFFFFFFFull, QMX_ERR_BAD_ARG, "PointOffsetType is u32: n=%llu too large", (unsigned long long)desc->n);
@@ -548,6 +650,7 @@ int32_t qmx_segment_create(const qmx_segment_desc *desc, qmx_segment **out) {
             }
             break;
         }
+        case QMX_DTYPE_TQ: rc = tq_segment_setup(s, desc); break;
         default:
             set_error("dtype %u not built yet", desc->dtype);
             rc = QMX_ERR_NOT_SUPPORTED;
@@ -725,6 +828,17 @@ int32_t qmx_segment_read_rows(const qmx_segment *seg, const uint32_t *ids, uint3
         }
         return QMX_OK;
     }
+    if (seg->dtype == QMX_DTYPE_TQ) {
+        const bool has_l2 = seg->d_tq_l2 != nullptr;
+        for (uint32_t i = 0; i < n; ++i) {
+            QMX_REQUIRE(ids[i] < seg->n, QMX_ERR_OUT_OF_BOUNDS, "row %u out of range", ids[i]);
+            char *dst = (char *)out_rows + (size_t)i * seg->row_bytes;
+            QMX_HIP(hipMemcpy(dst, (const char *)seg->d_rows + (size_t)ids[i] * seg->row_stride, seg->tq_code_bytes, hipMemcpyDefault));
+            QMX_HIP(hipMemcpy(dst + seg->tq_code_bytes, seg->d_tq_sf + ids[i], 4, hipMemcpyDefault));
+            if (has_l2) QMX_HIP(hipMemcpy(dst + seg->tq_code_bytes + 4, seg->d_tq_l2 + ids[i], 4, hipMemcpyDefault));
+        }
+        return QMX_OK;
+    }
     for (uint32_t i = 0; i < n; ++i) {
         QMX_REQUIRE(ids[i] < seg->n, QMX_ERR_OUT_OF_BOUNDS, "row %u out of range", ids[i]);
         QMX_HIP(hipMemcpy((char *)out_rows + (size_t)i * seg->row_bytes,
@@ -827,6 +941,7 @@ static int32_t query_alloc(const qmx_segment *seg, uint32_t nq, qmx_query **out,
     // tile entry = elements zero-padded to whole 128-byte segments + the aux block
     // a scalar-encoded BQ query holds `bits` planes per row word (a stored row as the query has one: score_internal is 1-bit)
     q->bq_bits = (seg->dtype == QMX_DTYPE_BQ && !internal) ? seg->bq_query_bits : 1;
+    if (seg->dtype == QMX_DTYPE_TQ) q->bq_bits = seg->tq_value_bits == 4 ? 4 : 8;   // query pieces per 16-byte row piece (scan_tq.hip)
     q->aux_off = (uint32_t)((seg->scan_dim * elem_bytes(seg->dtype) * q->bq_bits + 127) & ~127u);
     q->q_stride = q->aux_off + QUERY_AUX_BYTES;
     if (seg->dtype == QMX_DTYPE_PQ) {   // the encoded query is the LUT [m][n_centroids] f32 (EncodedQueryPQ)
@@ -882,6 +997,12 @@ static int32_t query_encode(qmx_query *q, const float *queries) {
         return launch_bq_encode_scalar_query(q->stream, d_f32, nq, seg->dim, seg->bq_encoding, q->bq_bits, (uint8_t *)q->d_queries, q->q_stride);
     if (seg->dtype == QMX_DTYPE_BQ)      // encode_query_vector, SameAsStorage (encoded_vectors_binary.rs:673-690) = encode_one_bit_vector
         return launch_bq_encode(q->stream, d_f32, nq, seg->dim, seg->bq_encoding, seg->d_bq_mean, seg->d_bq_stddev, (uint8_t *)q->d_queries, q->q_stride);
+    if (seg->dtype == QMX_DTYPE_TQ) {    // TurboQuantizer::precompute_query (turboquant/quantization.rs:496-567)
+        QMX_TRY(q->tq_rot.reserve((size_t)nq * seg->tq_padded_dim * sizeof(double)));
+        QMX_TRY(launch_tq_rotate(q->stream, d_f32, nq, tq_rotation(seg), (double *)q->tq_rot.p));
+        return launch_tq_query_encode(q->stream, (const double *)q->tq_rot.p, nq, seg->tq_padded_dim, seg->tq_value_bits,
+                                      seg->distance == QMX_DISTANCE_EUCLID ? 1 : 0, q->d_queries, q->q_stride, q->aux_off);
+    }
     if (seg->dtype == QMX_DTYPE_PQ)      // EncodedVectorsPQ::encode_query (encoded_vectors_pq.rs:519-541)
         return launch_pq_lut(q->stream, seg->distance, seg->dim, seg->pq, seg->d_centroids, d_f32, nq, (float *)q->d_queries);
     set_error("query encode for dtype %u not built yet", seg->dtype);
@@ -978,7 +1099,7 @@ int32_t qmx_query_destroy(qmx_query *q) {
     q->mv_deleted.release();
     q->cq_scores.release();
     q->cq_desc.release();
-    q->sp_bq.release(); q->sp_f32.release(); q->sp_cand.release(); q->sp_cnt.release(); q->sp_ver.release(); q->sp_vscores.release(); q->sp_sample.release(); q->sp_wl.release(); q->xcnt.release();
+    q->sp_bq.release(); q->sp_f32.release(); q->sp_cand.release(); q->sp_cnt.release(); q->sp_ver.release(); q->sp_vscores.release(); q->sp_sample.release(); q->sp_wl.release(); q->xcnt.release(); q->tq_rot.release();
     q->cand.release();
     q->cand_cnt.release();
     q->cand_ids.release();
@@ -1112,6 +1233,10 @@ static void fill_args(const qmx_query *q, uint32_t tile0, uint32_t nq_tile, Scan
     // calculate_metric's match: (Dot | Cosine, invert = false) and (L1 | L2, invert = true) -> zeros - xor; the toggled pairs -> xor - zeros
     a.bq_flip = (s->flags & QMX_SEG_BQ_TOGGLE_INVERT) ? 1 : 0;
     a.bq_qbits = q->bq_bits;
+    a.tq_sf = s->d_tq_sf;
+    a.tq_l2 = s->d_tq_l2;
+    a.tq_bits = s->tq_value_bits;
+    a.tq_invert = s->tq_invert ? 1 : 0;
 }
 
 static int32_t launch_scan(const qmx_query *q, int qt, ScanMode mode, const ScanArgs &a, uint32_t *grid) {
@@ -1135,6 +1260,7 @@ static int32_t launch_scan(const qmx_query *q, int qt, ScanMode mode, const Scan
         QMX_REQUIRE(s->fast_layout(), QMX_ERR_NOT_SUPPORTED, "adopted BQ block is not 16-byte aligned");
         return launch_scan_bq(q->stream, std::min(qt, (int)MAX_QT), mode, a, s->num_cus, grid);
     }
+    if (s->dtype == QMX_DTYPE_TQ) return launch_scan_tq(q->stream, std::min(qt, (int)MAX_QT), mode, a, s->num_cus, grid);
     set_error("dtype %u not built yet", s->dtype);
     return QMX_ERR_NOT_SUPPORTED;
 }
@@ -2106,6 +2232,7 @@ static int32_t launch_hnsw(const qmx_query *q, const ScanArgs &a, const HnswArgs
     if (s->dtype == QMX_DTYPE_SQ_U8) return launch_hnsw_sq(q->stream, (int)s->distance, a, h, grid, per_cu);
     if (s->dtype == QMX_DTYPE_PQ) return launch_hnsw_pq(q->stream, a, h, grid, per_cu);
     if (s->dtype == QMX_DTYPE_BQ) return launch_hnsw_bq(q->stream, a, h, grid, per_cu);
+    if (s->dtype == QMX_DTYPE_TQ) return launch_hnsw_tq(q->stream, a, h, grid, per_cu);
     set_error("dtype %u not built yet", s->dtype);
     return QMX_ERR_NOT_SUPPORTED;
 }
@@ -2283,6 +2410,8 @@ static int32_t score_pairs_device(qmx_query *q, const PairSel &sel, const uint32
         rc = launch_pairs_sq(q->stream, (int)s->distance, a, sel, n_items, s->num_cus);
     } else if (s->dtype == QMX_DTYPE_PQ) {
         rc = launch_pairs_pq(q->stream, a, sel, n_items, s->num_cus);
+    } else if (s->dtype == QMX_DTYPE_TQ) {
+        rc = launch_pairs_tq(q->stream, a, sel, n_items, s->num_cus);
     } else if (s->dtype == QMX_DTYPE_BQ) {
         rc = launch_pairs_bq(q->stream, a, sel, n_items, s->num_cus);
     } else {
@@ -2709,7 +2838,7 @@ int32_t qmx_search_quantized(const qmx_hnsw *g, qmx_query *quantized, qmx_query 
 int32_t qmx_score_internal(const qmx_segment *seg, const uint32_t *a_ids, const uint32_t *b_ids, uint32_t n, float *out) {
     QMX_REQUIRE(seg && (n == 0 || (a_ids && b_ids && out)), QMX_ERR_BAD_ARG, "NULL argument");
     if (n == 0) return QMX_OK;
-    if (seg->dtype == QMX_DTYPE_PQ) {   // centroid <-> centroid (encoded_vectors_pq.rs:574-618); no query involved
+    if (seg->dtype == QMX_DTYPE_PQ || seg->dtype == QMX_DTYPE_TQ) {   // centroid <-> centroid (encoded_vectors_pq.rs:574-618 | TurboQuantizer::score_symmetric); no query involved
         QMX_HIP(hipSetDevice(seg->device));
         DevBuf ba, bb, bo, be;
         int32_t rc = QMX_OK;
@@ -2720,8 +2849,13 @@ int32_t qmx_score_internal(const qmx_segment *seg, const uint32_t *a_ids, const 
             if (e == hipSuccess) e = hipMemcpy(bb.p, b_ids, (size_t)n * 4, hipMemcpyDefault);
             if (e == hipSuccess) e = hipMemset(be.p, 0, 4);
             if (e != hipSuccess) { rc = hip_status(e, "stage ids", __FILE__, __LINE__); break; }
-            if ((rc = launch_pq_internal(nullptr, seg->distance, seg->dim, seg->pq, seg->d_centroids, seg->d_pq_pair, seg->d_rows, seg->row_stride, seg->n,
-                                         (const uint32_t *)ba.p, (const uint32_t *)bb.p, n, (float *)bo.p, (int *)be.p)) != QMX_OK) break;
+            if (seg->dtype == QMX_DTYPE_TQ)
+                rc = launch_tq_internal(nullptr, seg->d_rows, (uint32_t)seg->row_stride, seg->d_tq_sf, seg->d_tq_l2, seg->tq_code_bytes, seg->tq_value_bits,
+                                        seg->tq_invert ? 1 : 0, seg->n, (const uint32_t *)ba.p, (const uint32_t *)bb.p, n, (float *)bo.p, (int *)be.p);
+            else
+                rc = launch_pq_internal(nullptr, seg->distance, seg->dim, seg->pq, seg->d_centroids, seg->d_pq_pair, seg->d_rows, seg->row_stride, seg->n,
+                                        (const uint32_t *)ba.p, (const uint32_t *)bb.p, n, (float *)bo.p, (int *)be.p);
+            if (rc != QMX_OK) break;
             int flag = 0;
             e = hipMemcpy(&flag, be.p, 4, hipMemcpyDeviceToHost);
             if (e == hipSuccess) e = hipMemcpy(out, bo.p, (size_t)n * 4, hipMemcpyDefault);

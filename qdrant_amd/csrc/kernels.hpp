@@ -53,6 +53,10 @@ struct ScanArgs {
     uint32_t bq_dim;           // original dimension
     uint32_t bq_flip;          // 0: zeros - xor (every distance with its own invert), 1: xor - zeros
     uint32_t bq_qbits;         // bit planes per query value: 1 (QueryEncoding::SameAsStorage, internal queries), 4 or 8 (Scalar4bits / Scalar8bits)
+    // TurboQuant (scan_tq.hip): per-row extras columns, bits per value (4 | 2 | 1), VectorParameters.invert
+    const float *tq_sf;        // [n] scaling_factor
+    const float *tq_l2;        // [n] l2_length (DistanceType::L2) or nullptr
+    uint32_t tq_bits, tq_invert;
     // multi-vectors (MaxSim walk, hnsw.hpp HopMaxSim): point p = inner rows [mv_offsets[p], mv_offsets[p + 1]); multi-query j = query entries
     // [mv_qfirst[j], mv_qfirst[j + 1])
     const uint64_t *mv_offsets;
@@ -103,6 +107,23 @@ struct HnswArgs {
 
 // grid == 0: only report the occupancy (blocks of one wave per CU) of the instantiation in *per_cu
 int32_t launch_hnsw_dense(hipStream_t st, int dtype, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
+// TurboQuant (scan_tq.hip)
+struct TqRotationHost {        // HadamardRotation on the device: forward maps, chunk decomposition, per-chunk 1 / sqrt(size)
+    const uint32_t *d_maps, *d_chunk_off, *d_chunk_size;
+    const double *d_chunk_norm;
+    uint32_t n_chunks, rot_dim, padded_dim, dim;
+};
+int32_t launch_scan_tq(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out);
+int32_t launch_hnsw_tq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
+int32_t launch_tq_split(hipStream_t st, const void *rows, uint64_t src_stride, uint64_t n, uint32_t code_bytes, uint32_t dst_stride, int has_l2,
+                        void *codes, float *sf, float *l2);
+int32_t launch_tq_gather_rows(hipStream_t st, const void *codes, uint32_t dst_stride, const float *sf, const float *l2, uint32_t code_bytes, int has_l2,
+                              const uint32_t *ids, uint32_t n, uint64_t n_rows, void *out, uint32_t out_stride, int *err_flag);
+int32_t launch_tq_rotate(hipStream_t st, const float *d_in, uint32_t n, const TqRotationHost &h, double *d_out);
+int32_t launch_tq_query_encode(hipStream_t st, const double *d_rot, uint32_t nq, uint32_t padded_dim, uint32_t bits, int need_l2, void *tile, uint32_t q_stride,
+                               uint32_t aux_off);
+int32_t launch_tq_internal(hipStream_t st, const void *codes, uint32_t stride, const float *sf, const float *l2, uint32_t code_bytes, uint32_t bits,
+                           int invert, uint64_t n_rows, const uint32_t *a_ids, const uint32_t *b_ids, uint32_t n, float *out, int *err_flag);
 // the MaxSim walk over multi-vector points (HopMaxSim): dense, SQ and BQ inner rows
 int32_t launch_hnsw_maxsim_dense(hipStream_t st, int dtype, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_maxsim_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
@@ -234,6 +255,7 @@ int32_t launch_order_statistics_f32(hipStream_t st, const float *d_in, float *d_
 // BQ 1-bit (scan_bq.hip)
 int32_t launch_scan_bq(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out);
 int32_t launch_pairs_bq(hipStream_t st, const ScanArgs &a, const PairSel &sel, uint64_t n_items, int num_cus);
+int32_t launch_pairs_tq(hipStream_t st, const ScanArgs &a, const PairSel &sel, uint64_t n_items, int num_cus);
 uint64_t bq_row_bytes(uint32_t dim, uint32_t encoding);
 int32_t launch_bq_encode_scalar_query(hipStream_t st, const float *d_in, uint32_t nq, uint32_t dim, uint32_t encoding, uint32_t bits, uint8_t *d_out,
                                       uint32_t out_stride);

@@ -1,0 +1,444 @@
+// scan_tq.hip — EncodedVectorsTQ (TurboQuant, lib/quantization/src/turboquant/ behind lib/quantization/src/encoded_vectors_tq.rs) on device.
+//
+// Reference:
+//   TurboQuantizer::precompute_query   turboquant/quantization.rs:496-567   rotate the (preprocessed) query in f64, narrow to f32, encode as integers
+//   HadamardRotation::apply            turboquant/rotation.rs:69-131,264-280 WHT + 1/sqrt(size) over decreasing power-of-two chunks, three
+//                                                                             fixed permutations (permutation.rs: Knuth-MMIX LCG Fisher-Yates)
+//   Query{4,2}bitSimd::{new, dotprod}  turboquant/simd/query{4,2}bit/mod.rs   q_signed = clamp(round(v * 8127 / max|v|)); dot_raw = sum q_signed * c_u;
+//                                                                             score = postprocess_scale * (dot_raw - 128 sum q_signed) as f32
+//   Query1bitSimd<8>::{new, dotprod}   turboquant/simd/query1bit/mod.rs       q in [-127, 127] as 8 two's-complement bit planes per 16-byte block;
+//                                                                             v.q = sum_b w_b popcount(v & plane_b), score = scale * (2 v.q - sum q)
+//   score_precomputed                  turboquant/quantization.rs:569-620     dot * scaling_factor | |q|^2 + |v|^2 - 2 dot scaling_factor  (then `invert`)
+//   score_symmetric                    turboquant/quantization.rs:395-445 + score_{4,2,1}bit_internal (simd/*/mod.rs)
+//   row layout                         turboquant/encoding.rs:117-134,172-258 [codes: padded_dim * bits / 8 bytes, LSB first][scaling_factor f32][l2 f32 (L2)]
+// The x86_64 constants are the ones restated (the reference's aarch64 build uses other integer ranges: its scores differ in the last bits).
+// Everything between the rotation and the final f32 products is integer arithmetic, exact in any order: scores are bit-identical to the
+// reference's whatever SIMD path it took.  TQMode::Normal only (no TQ+ error correction); distances Dot, Cosine, L2.
+//
+// HBM layout: code block [n][code bytes rounded up to 16] (zero padded) + one or two f32 columns (scaling_factor, l2_length), like SQ.
+// A query entry holds QPIECES 16-byte pieces per 16-byte row piece, ordered the way the decode of a row dword produces its operands:
+//   4 bits  byte k of a row piece = dims 2k (low nibble), 2k + 1 (high nibble): pieces [low half of the even dims][low half of the odd dims]
+//           [high half of the even dims][high half of the odd dims]  (q_signed = 128 high + low, both halves in [-64, 63])
+//   2 bits  byte k = dims 4k .. 4k + 3: pieces [low half of dims = j mod 4] j = 0..3, then the four high-half pieces
+//   1 bit   bit i of the piece = dim i: pieces = the 8 bit planes of q
+#include "hnsw_build.hpp"
+
+namespace qmx {
+
+__device__ __forceinline__ int32_t sdot4(uint32_t a, uint32_t b, int32_t c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, false); }
+
+// codebook values as signed bytes: c_signed = CODEBOOK_U8 - 128 (query4bit/mod.rs:64-72, query2bit/mod.rs)
+//   4 bits: -128 -97 -76 -59 -44 -31 -18 -6 | 6 18 31 44 59 76 97 127
+//   2 bits: -128 -38 38 127
+constexpr uint32_t TQ4_T0 = 0xC5B49F80u, TQ4_T1 = 0xFAEEE1D4u, TQ4_T2 = 0x2C1F1206u, TQ4_T3 = 0x7F614C3Bu;
+constexpr uint32_t TQ2_T = 0x7F26DA80u;
+
+// sel: four 4-bit selectors, one per byte -> the four codebook bytes
+__device__ __forceinline__ uint32_t tq4_lookup(uint32_t sel) {
+    const uint32_t s = sel & 0x07070707u;
+    const uint32_t lo = __builtin_amdgcn_perm(TQ4_T1, TQ4_T0, s);      // selector byte 0..3 -> T0, 4..7 -> T1
+    const uint32_t hi = __builtin_amdgcn_perm(TQ4_T3, TQ4_T2, s);
+    const uint32_t m = ((sel >> 3) & 0x01010101u) * 0xFFu;             // 0xFF where the selector was >= 8
+    return (hi & m) | (lo & ~m);
+}
+
+template <bool L2>
+__device__ __forceinline__ float tq_postprocess(float dot, const unsigned char *q_lds, uint32_t rid, const ScanArgs &args) {
+    const QueryAux *aux = reinterpret_cast<const QueryAux *>(q_lds + args.aux_off);
+    const float sf = args.tq_sf[rid];
+    float score;
+    if (L2) {
+        const float ql = __uint_as_float(aux->pad[0]), l2 = args.tq_l2[rid];
+        const float a = ql * ql, b = l2 * l2, c = (2.0f * dot) * sf;
+        score = (a + b) - c;
+    } else {
+        score = dot * sf;
+    }
+    return args.tq_invert ? -score : score;
+}
+
+template <bool L2>
+struct RowTQ4 {
+    static constexpr bool TEMPORAL_ROWS = true;
+    static constexpr int NACC = 2;      // sum low * c, sum high * c
+    static constexpr int NRAUX = 0;
+    static constexpr int R16 = 2;
+    static constexpr int QPIECES = 4;
+    typedef uint32_t acc_t;
+    static __device__ __forceinline__ void row_aux(acc_t (&)[1], const uint4 &) {}
+    static __device__ __forceinline__ void mac(acc_t (&)[NACC], const uint4 &, const uint4 &) {}
+    static __device__ __forceinline__ void mac_pieces(acc_t (&a)[NACC], const uint4 (&q)[4], const uint4 &v) {
+        const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+        const uint32_t le[4] = {q[0].x, q[0].y, q[0].z, q[0].w}, lo[4] = {q[1].x, q[1].y, q[1].z, q[1].w};
+        const uint32_t he[4] = {q[2].x, q[2].y, q[2].z, q[2].w}, ho[4] = {q[3].x, q[3].y, q[3].z, q[3].w};
+        int32_t al = (int32_t)a[0], ah = (int32_t)a[1];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t ce = tq4_lookup(vv[w] & 0x0F0F0F0Fu), co = tq4_lookup((vv[w] >> 4) & 0x0F0F0F0Fu);
+            al = sdot4(le[w], ce, al);
+            al = sdot4(lo[w], co, al);
+            ah = sdot4(he[w], ce, ah);
+            ah = sdot4(ho[w], co, ah);
+        }
+        a[0] = (uint32_t)al;
+        a[1] = (uint32_t)ah;
+    }
+    static __device__ __forceinline__ float finish(acc_t (&a)[NACC], acc_t (&)[1], const unsigned char *q_lds, const unsigned char *, uint32_t rid,
+                                                   const ScanArgs &args) {
+        const int64_t low = (int64_t)(int32_t)reduce8_u32(a[0]), high = (int64_t)(int32_t)reduce8_u32(a[1]);
+        const int64_t s = low + 128 * high;                                   // = dot_raw - bias_correction
+        const QueryAux *aux = reinterpret_cast<const QueryAux *>(q_lds + args.aux_off);
+        const float raw = aux->f0 * (float)s;
+        return tq_postprocess<L2>(raw + 0.0f, q_lds, rid, args);
+    }
+};
+
+template <bool L2>
+struct RowTQ2 {
+    static constexpr bool TEMPORAL_ROWS = true;
+    static constexpr int NACC = 2;
+    static constexpr int NRAUX = 0;
+    static constexpr int R16 = 1;
+    static constexpr int QPIECES = 8;
+    typedef uint32_t acc_t;
+    static __device__ __forceinline__ void row_aux(acc_t (&)[1], const uint4 &) {}
+    static __device__ __forceinline__ void mac(acc_t (&)[NACC], const uint4 &, const uint4 &) {}
+    static __device__ __forceinline__ void mac_pieces(acc_t (&a)[NACC], const uint4 (&q)[8], const uint4 &v) {
+        const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+        int32_t al = (int32_t)a[0], ah = (int32_t)a[1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t ql[4] = {q[j].x, q[j].y, q[j].z, q[j].w}, qh[4] = {q[4 + j].x, q[4 + j].y, q[4 + j].z, q[4 + j].w};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const uint32_t c = __builtin_amdgcn_perm(0u, TQ2_T, (vv[w] >> (2 * j)) & 0x03030303u);
+                al = sdot4(ql[w], c, al);
+                ah = sdot4(qh[w], c, ah);
+            }
+        }
+        a[0] = (uint32_t)al;
+        a[1] = (uint32_t)ah;
+    }
+    static __device__ __forceinline__ float finish(acc_t (&a)[NACC], acc_t (&)[1], const unsigned char *q_lds, const unsigned char *, uint32_t rid,
+                                                   const ScanArgs &args) {
+        const int64_t low = (int64_t)(int32_t)reduce8_u32(a[0]), high = (int64_t)(int32_t)reduce8_u32(a[1]);
+        const int64_t s = low + 128 * high;
+        const QueryAux *aux = reinterpret_cast<const QueryAux *>(q_lds + args.aux_off);
+        const float raw = aux->f0 * (float)s;
+        return tq_postprocess<L2>(raw + 0.0f, q_lds, rid, args);
+    }
+};
+
+template <bool L2>
+struct RowTQ1 {
+    static constexpr bool TEMPORAL_ROWS = true;
+    static constexpr int NACC = 1;
+    static constexpr int NRAUX = 0;
+    static constexpr int R16 = 2;
+    static constexpr int QPIECES = 8;
+    typedef uint32_t acc_t;
+    static __device__ __forceinline__ void row_aux(acc_t (&)[1], const uint4 &) {}
+    static __device__ __forceinline__ void mac(acc_t (&)[NACC], const uint4 &, const uint4 &) {}
+    static __device__ __forceinline__ void mac_pieces(acc_t (&a)[NACC], const uint4 (&q)[8], const uint4 &v) {
+        int32_t s = (int32_t)a[0];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int32_t c = __popc(q[k].x & v.x) + __popc(q[k].y & v.y) + __popc(q[k].z & v.z) + __popc(q[k].w & v.w);
+            s += k == 7 ? -(c << 7) : (c << k);                             // w_b = 2^b, the sign plane -2^7
+        }
+        a[0] = (uint32_t)s;
+    }
+    static __device__ __forceinline__ float finish(acc_t (&a)[NACC], acc_t (&)[1], const unsigned char *q_lds, const unsigned char *, uint32_t rid,
+                                                   const ScanArgs &args) {
+        const int64_t v_dot_q = (int64_t)(int32_t)reduce8_u32(a[0]);
+        const QueryAux *aux = reinterpret_cast<const QueryAux *>(q_lds + args.aux_off);
+        const int64_t sum_q = (int64_t)(((uint64_t)aux->pad[2] << 32) | aux->pad[1]);
+        const int64_t signed_dot = 2 * v_dot_q - sum_q;
+        const float raw = aux->f0 * (float)signed_dot;
+        return tq_postprocess<L2>(raw + 0.0f, q_lds, rid, args);
+    }
+};
+
+template <class L>
+static int32_t dispatch_tq(const L &l, const ScanArgs &a) {
+    const bool l2 = a.tq_l2 != nullptr;
+    switch (a.tq_bits) {
+        case 4: return l2 ? l.template row<RowTQ4<true>>(a) : l.template row<RowTQ4<false>>(a);
+        case 2: return l2 ? l.template row<RowTQ2<true>>(a) : l.template row<RowTQ2<false>>(a);
+        case 1: return l2 ? l.template row<RowTQ1<true>>(a) : l.template row<RowTQ1<false>>(a);
+    }
+    set_error("TurboQuant: %u bits per value not supported", a.tq_bits);
+    return QMX_ERR_NOT_SUPPORTED;
+}
+int32_t launch_scan_tq(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
+    return dispatch_tq(ScanLauncher{st, qt, mode, num_cus, grid_out}, a);
+}
+int32_t launch_pairs_tq(hipStream_t st, const ScanArgs &a, const PairSel &sel, uint64_t n_items, int num_cus) {
+    return dispatch_tq(PairLauncher{st, sel, n_items, num_cus}, a);
+}
+int32_t launch_hnsw_tq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
+    return dispatch_tq(HnswLauncher{st, &h, grid, per_cu}, a);
+}
+
+// ---- upload: reference rows [codes][extras] -> code block (16-byte multiple, zero padded) + extras columns ----
+__global__ __launch_bounds__(256) void tq_split_kernel(const uint8_t *rows, uint64_t src_stride, uint64_t n, uint32_t code_bytes, uint32_t dst_stride,
+                                                       int has_l2, uint8_t *codes, float *sf, float *l2) {
+    const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const int lane = threadIdx.x & 63;
+    const uint8_t *src = rows + r * src_stride;
+    uint8_t *dst = codes + r * dst_stride;
+    for (uint32_t i = lane; i < dst_stride; i += 64) dst[i] = i < code_bytes ? src[i] : 0;
+    if (lane == 0) {
+        float f;
+        memcpy(&f, src + code_bytes, 4);
+        sf[r] = f;
+        if (has_l2) {
+            memcpy(&f, src + code_bytes + 4, 4);
+            l2[r] = f;
+        }
+    }
+}
+int32_t launch_tq_split(hipStream_t st, const void *rows, uint64_t src_stride, uint64_t n, uint32_t code_bytes, uint32_t dst_stride, int has_l2,
+                        void *codes, float *sf, float *l2) {
+    if (n == 0) return QMX_OK;
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(tq_split_kernel, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, st, (const uint8_t *)rows, src_stride, n, code_bytes, dst_stride, has_l2,
+                       (uint8_t *)codes, sf, l2);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+// the reference row of point ids[i] back together (qmx_segment_read_rows)
+__global__ __launch_bounds__(64) void tq_gather_kernel(const uint8_t *codes, uint32_t dst_stride, const float *sf, const float *l2, uint32_t code_bytes,
+                                                       int has_l2, const uint32_t *ids, uint64_t n_rows, uint8_t *out, uint32_t out_stride, int *err_flag) {
+    const uint32_t id = ids[blockIdx.x];
+    if (id >= n_rows) {
+        if (threadIdx.x == 0) *err_flag = 1;
+        return;
+    }
+    uint8_t *dst = out + (uint64_t)blockIdx.x * out_stride;
+    for (uint32_t i = threadIdx.x; i < code_bytes; i += 64) dst[i] = codes[(uint64_t)id * dst_stride + i];
+    if (threadIdx.x == 0) {
+        memcpy(dst + code_bytes, &sf[id], 4);
+        if (has_l2) memcpy(dst + code_bytes + 4, &l2[id], 4);
+    }
+}
+int32_t launch_tq_gather_rows(hipStream_t st, const void *codes, uint32_t dst_stride, const float *sf, const float *l2, uint32_t code_bytes, int has_l2,
+                              const uint32_t *ids, uint32_t n, uint64_t n_rows, void *out, uint32_t out_stride, int *err_flag) {
+    if (n == 0) return QMX_OK;
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(tq_gather_kernel, dim3(n), dim3(64), 0, st, (const uint8_t *)codes, dst_stride, sf, l2, code_bytes, has_l2, ids, n_rows, (uint8_t *)out,
+                       out_stride, err_flag);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
+// ---- HadamardRotation::apply for a batch of vectors: in [n][dim] f32 -> out [n][padded_dim] f64 (the zero padding past rot_dim untouched) ----
+// One block per vector, the vector in LDS (two f64 buffers: the gathers ping-pong).  Every element sees the reference's operation sequence:
+// one add or sub per butterfly stage in ascending stride order, one multiply by 1 / sqrt(size), so the f64 results are bit-identical.
+struct TqRotation {
+    const uint32_t *maps;       // [3][rot_dim] forward maps
+    const uint32_t *chunk_off;  // [n_chunks] first element of each power-of-two chunk
+    const uint32_t *chunk_size; // [n_chunks]
+    const double *chunk_norm;   // [n_chunks] 1 / sqrt(size), computed on the host like the reference does
+    uint32_t n_chunks, rot_dim, padded_dim, dim;
+};
+__device__ __forceinline__ void tq_wht_chunks(double *x, const TqRotation &r) {
+    for (uint32_t c = 0; c < r.n_chunks; ++c) {
+        double *xc = x + r.chunk_off[c];
+        const uint32_t size = r.chunk_size[c];
+        for (uint32_t h = 1; h < size; h *= 2) {
+            for (uint32_t p = threadIdx.x; p < size / 2; p += blockDim.x) {
+                const uint32_t j = (p / h) * 2 * h + (p % h);
+                const double a = xc[j], b = xc[j + h];
+                xc[j] = a + b;
+                xc[j + h] = a - b;
+            }
+            __syncthreads();
+        }
+        const double norm = r.chunk_norm[c];
+        for (uint32_t i = threadIdx.x; i < size; i += blockDim.x) xc[i] *= norm;
+    }
+    __syncthreads();
+}
+__global__ __launch_bounds__(256) void tq_rotate_kernel(const float *in, uint64_t in_stride, uint32_t n, TqRotation r, double *out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_tq[];
+    double *a = reinterpret_cast<double *>(smem_tq), *b = a + r.rot_dim;
+    const uint32_t v = blockIdx.x;
+    if (v >= n) return;
+    const float *src = in + (uint64_t)v * in_stride;
+    for (uint32_t i = threadIdx.x; i < r.rot_dim; i += blockDim.x) a[i] = i < r.dim ? (double)src[i] : 0.0;
+    __syncthreads();
+    tq_wht_chunks(a, r);
+    double *s = a, *d = b;
+    for (int p = 0; p < 3; ++p) {
+        const uint32_t *map = r.maps + (size_t)p * r.rot_dim;
+        for (uint32_t k = threadIdx.x; k < r.rot_dim; k += blockDim.x) d[k] = s[map[k]];
+        __syncthreads();
+        tq_wht_chunks(d, r);
+        double *t = s; s = d; d = t;
+    }
+    double *o = out + (uint64_t)v * r.padded_dim;
+    for (uint32_t i = threadIdx.x; i < r.padded_dim; i += blockDim.x) o[i] = i < r.rot_dim ? s[i] : (i < r.dim ? (double)src[i] : 0.0);
+}
+int32_t launch_tq_rotate(hipStream_t st, const float *d_in, uint32_t n, const TqRotationHost &h, double *d_out) {
+    if (n == 0) return QMX_OK;
+    TqRotation r;
+    r.maps = h.d_maps; r.chunk_off = h.d_chunk_off; r.chunk_size = h.d_chunk_size; r.chunk_norm = h.d_chunk_norm;
+    r.n_chunks = h.n_chunks; r.rot_dim = h.rot_dim; r.padded_dim = h.padded_dim; r.dim = h.dim;
+    const size_t lds = (size_t)2 * h.rot_dim * sizeof(double);
+    QMX_REQUIRE(lds <= 150 * 1024, QMX_ERR_NOT_SUPPORTED, "TurboQuant rotation over %u coordinates does not fit the LDS", h.rot_dim);
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tq_rotate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+    }
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(tq_rotate_kernel, dim3(n), dim3(256), lds, st, d_in, (uint64_t)h.dim, n, r, d_out);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
+// ---- Query{N}bitSimd::new on the rotated queries: rot [nq][padded_dim] f64 -> tile entries ----
+__global__ __launch_bounds__(256) void tq_query_encode_kernel(const double *rot, uint32_t padded_dim, uint32_t bits, int need_l2, uint8_t *tile,
+                                                              uint32_t q_stride, uint32_t aux_off) {
+    __shared__ float sh_max[256];
+    __shared__ float sh_scale;
+    __shared__ unsigned long long sh_sum;
+    const uint32_t q = blockIdx.x;
+    const double *x = rot + (uint64_t)q * padded_dim;
+    uint8_t *entry = tile + (uint64_t)q * q_stride;
+    // zero the entry's pieces (dims past padded_dim inside the last 16-byte row piece must read as q = 0)
+    for (uint32_t i = threadIdx.x; i < aux_off / 4; i += blockDim.x) reinterpret_cast<uint32_t *>(entry)[i] = 0;
+    float m = 0.0f;
+    for (uint32_t i = threadIdx.x; i < padded_dim; i += blockDim.x) m = fmaxf(m, fabsf((float)x[i]));
+    sh_max[threadIdx.x] = m;
+    if (threadIdx.x == 0) sh_sum = 0;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o) sh_max[threadIdx.x] = fmaxf(sh_max[threadIdx.x], sh_max[threadIdx.x + o]);
+        __syncthreads();
+    }
+    const float abs_max_int = bits == 1 ? 127.0f : 8127.0f;
+    if (threadIdx.x == 0) {
+        float q_abs_max = sh_max[0];
+        if (!(q_abs_max > 1.1920929e-7f)) q_abs_max = 1.1920929e-7f;              // .max(f32::EPSILON)
+        const float q_scale = abs_max_int / q_abs_max;
+        sh_scale = q_scale;
+        QueryAux *aux = reinterpret_cast<QueryAux *>(entry + aux_off);
+        const float codebook_scale = 128.0f / (bits == 4 ? 2.733f : 1.510f);
+        aux->f0 = bits == 1 ? 0.7978846f / q_scale : 1.0f / (q_scale * codebook_scale);
+        float l2 = 1.0f;
+        if (need_l2) {                                                             // rotated.iter().map(|&i| i * i).sum::<f64>().sqrt() as f32, in order
+            double s = 0.0;
+            for (uint32_t i = 0; i < padded_dim; ++i) s = s + x[i] * x[i];
+            l2 = (float)sqrt(s);
+        }
+        aux->pad[0] = __float_as_uint(l2);
+    }
+    __syncthreads();
+    const float q_scale = sh_scale;
+    long long local = 0;
+    for (uint32_t i = threadIdx.x; i < padded_dim; i += blockDim.x) {
+        float v = roundf((float)x[i] * q_scale);
+        v = fminf(fmaxf(v, -abs_max_int), abs_max_int);
+        const int32_t qs = (int32_t)v;
+        local += qs;
+        if (bits == 1) {
+            // planes of the 16-byte block holding dim i: plane b at piece (block * 8 + b), bit (i % 128) of it
+            const uint32_t block = i / 128, bit = i % 128;
+            const uint32_t u = (uint32_t)qs & 0xFFu;
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+                if ((u >> b) & 1u) atomicOr(reinterpret_cast<uint32_t *>(entry + ((size_t)block * 8 + b) * 16 + (bit / 32) * 4), 1u << (bit % 32));
+        } else {
+            // balanced split q_signed = 128 h + l, l in [-64, 63]
+            int32_t l_mod = qs % 128;
+            if (l_mod < 0) l_mod += 128;                                           // rem_euclid
+            const int32_t l = l_mod >= 64 ? l_mod - 128 : l_mod;
+            const int32_t hh = (qs - l) / 128;
+            if (bits == 4) {
+                const uint32_t piece = i / 32, d = i % 32;                         // 32 dims per 16-byte row piece
+                const uint32_t odd = d & 1u, k = d >> 1;                           // byte k of the piece, low / high nibble
+                entry[((size_t)piece * 4 + odd) * 16 + k] = (uint8_t)(int8_t)l;
+                entry[((size_t)piece * 4 + 2 + odd) * 16 + k] = (uint8_t)(int8_t)hh;
+            } else {
+                const uint32_t piece = i / 64, d = i % 64;                         // 64 dims per row piece
+                const uint32_t j = d & 3u, k = d >> 2;
+                entry[((size_t)piece * 8 + j) * 16 + k] = (uint8_t)(int8_t)l;
+                entry[((size_t)piece * 8 + 4 + j) * 16 + k] = (uint8_t)(int8_t)hh;
+            }
+        }
+    }
+    atomicAdd(&sh_sum, (unsigned long long)local);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        QueryAux *aux = reinterpret_cast<QueryAux *>(entry + aux_off);
+        aux->pad[1] = (uint32_t)sh_sum;
+        aux->pad[2] = (uint32_t)(sh_sum >> 32);
+    }
+}
+int32_t launch_tq_query_encode(hipStream_t st, const double *d_rot, uint32_t nq, uint32_t padded_dim, uint32_t bits, int need_l2, void *tile, uint32_t q_stride,
+                               uint32_t aux_off) {
+    if (nq == 0) return QMX_OK;
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(tq_query_encode_kernel, dim3(nq), dim3(256), 0, st, d_rot, padded_dim, bits, need_l2, (uint8_t *)tile, q_stride, aux_off);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
+// ---- score_symmetric (EncodedVectorsTQ::score_internal): one thread per pair ----
+__device__ __constant__ int8_t TQ4_SIGNED[16] = {-128, -97, -76, -59, -44, -31, -18, -6, 6, 18, 31, 44, 59, 76, 97, 127};
+__device__ __constant__ int8_t TQ2_SIGNED[4] = {-128, -38, 38, 127};
+__global__ __launch_bounds__(256) void tq_internal_kernel(const uint8_t *codes, uint32_t stride, const float *sf, const float *l2, uint32_t code_bytes,
+                                                          uint32_t bits, int invert, uint64_t n_rows, const uint32_t *a_ids, const uint32_t *b_ids, uint32_t n,
+                                                          float *out, int *err_flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t ia = a_ids[i], ib = b_ids[i];
+    if (ia >= n_rows || ib >= n_rows) {
+        *err_flag = 1;
+        return;
+    }
+    const uint8_t *a = codes + (uint64_t)ia * stride, *b = codes + (uint64_t)ib * stride;
+    float raw_dot;
+    if (bits == 1) {
+        uint64_t popcnt = 0;
+        for (uint32_t k = 0; k < code_bytes; ++k) popcnt += (uint64_t)__popc((uint32_t)(a[k] ^ b[k]));
+        const int64_t sign_sum = (int64_t)code_bytes * 8 - 2 * (int64_t)popcnt;
+        const float centroid_sq = 0.7978846f * 0.7978846f;
+        raw_dot = centroid_sq * (float)sign_sum;
+    } else {
+        int64_t acc = 0;
+        if (bits == 4) {
+            for (uint32_t k = 0; k < code_bytes; ++k)
+                acc += (int64_t)TQ4_SIGNED[a[k] & 15] * TQ4_SIGNED[b[k] & 15] + (int64_t)TQ4_SIGNED[a[k] >> 4] * TQ4_SIGNED[b[k] >> 4];
+        } else {
+            for (uint32_t k = 0; k < code_bytes; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc += (int64_t)TQ2_SIGNED[(a[k] >> (2 * j)) & 3] * TQ2_SIGNED[(b[k] >> (2 * j)) & 3];
+        }
+        const float codebook_scale = 128.0f / (bits == 4 ? 2.733f : 1.510f);
+        raw_dot = (float)acc / (codebook_scale * codebook_scale);
+    }
+    const float s1 = sf[ia], s2 = sf[ib];
+    float score;
+    if (l2) {
+        const float x = l2[ia], y = l2[ib];
+        score = (x * x + y * y) - ((2.0f * s1) * s2) * raw_dot;
+    } else {
+        score = (raw_dot * s1) * s2;
+    }
+    out[i] = invert ? -score : score;
+}
+int32_t launch_tq_internal(hipStream_t st, const void *codes, uint32_t stride, const float *sf, const float *l2, uint32_t code_bytes, uint32_t bits,
+                           int invert, uint64_t n_rows, const uint32_t *a_ids, const uint32_t *b_ids, uint32_t n, float *out, int *err_flag) {
+    if (n == 0) return QMX_OK;
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(tq_internal_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const uint8_t *)codes, stride, sf, l2, code_bytes, bits, invert, n_rows,
+                       a_ids, b_ids, n, out, err_flag);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
+}  // namespace qmx

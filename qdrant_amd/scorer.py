@@ -396,6 +396,64 @@ class EncodedVectorsBin(VectorStorage):
         return out
 
 
+class TurboQuantizer:
+    """`Metadata{vector_parameters, bits, mode: Normal, rotation}` of `EncodedVectorsTQ` (lib/quantization/src/encoded_vectors_tq.rs:33-46) =
+    `TurboQuantizer::new(dim, bits, TQMode::Normal, distance, rotation, None)` (turboquant/quantization.rs:127-158).  `bits`: 0 = Bits4,
+    1 = Bits2, 2 = Bits1_5, 3 = Bits1 (TQBits).  Rows are produced by the reference's `quantize` (an input here, like PQ codes)."""
+
+    def __init__(self, dim: int, distance: Distance, bits: int, rotation_unpadded: bool = False, invert: Optional[bool] = None):
+        self.dim, self.distance, self.bits = int(dim), Distance(distance), int(bits)
+        self.rotation_unpadded = bool(rotation_unpadded)
+        self.invert = (self.distance in (Distance.Euclid, Distance.Manhattan)) if invert is None else bool(invert)
+        value_bits = {0: 4, 1: 2, 2: 1, 3: 1}[self.bits]
+        mult = {0: 2, 1: 4, 2: 8, 3: 8}[self.bits]
+        d = self.dim * 3 // 2 if self.bits == 2 else self.dim
+        self.padded_dim = (d + mult - 1) // mult * mult
+        self.code_bytes = self.padded_dim * value_bits // 8
+
+    def params(self) -> "F.TqParams":
+        p = F.TqParams()
+        p.bits, p.rotation_unpadded, p.invert, p.plus_mode = self.bits, 1 if self.rotation_unpadded else 0, 1 if self.invert else 0, 0
+        return p
+
+    def quantized_vector_size(self) -> int:
+        """TurboQuantizer::quantized_size_for (turboquant/encoding.rs:172-190)."""
+        return self.code_bytes + (8 if self.distance == Distance.Euclid else 4)
+
+
+class EncodedVectorsTQ(VectorStorage):
+    """Device-resident `EncodedVectorsTQ` storage: rows = [n, quantized_vector_size] bytes as `TurboQuantizer::quantize` writes them."""
+
+    def __init__(self, rows, quantizer: TurboQuantizer, device_id: int = 0):
+        self._h = C.c_void_p()
+        self.quantizer = quantizer
+        self.distance = quantizer.distance
+        self.datatype = None
+        rows = np.ascontiguousarray(rows, dtype=np.uint8)
+        assert rows.shape[1] == quantizer.quantized_vector_size()
+        self.dim = quantizer.dim
+        self.count = int(rows.shape[0])
+        self._keep = None
+        desc = F.SegmentDesc()
+        desc.dtype = F.DTYPE_TQ
+        desc.distance = int(quantizer.distance)
+        desc.dim = quantizer.dim
+        desc.flags = 0
+        self._tq = quantizer.params()
+        desc.tq = C.pointer(self._tq)
+        desc.n = self.count
+        desc.row_stride_bytes = 0
+        desc.data = F.ptr(rows)
+        desc.device_id = device_id
+        F.check(F.lib().qmx_segment_create(C.byref(desc), C.byref(self._h)))
+
+    def get_quantized_vector(self, ids: Sequence[int]) -> np.ndarray:
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        out = np.empty((len(ids), self.quantizer.quantized_vector_size()), dtype=np.uint8)
+        F.check(F.lib().qmx_segment_read_rows(self._h, F.ptr(ids), len(ids), F.ptr(out)))
+        return out
+
+
 class MultiDenseVectorStorage:
     """`MultiDenseVectorStorage` with `MultiVectorComparator::MaxSim` (vector_storage/multi_dense/, query_scorer/mod.rs:70-97): the
     inner vectors of all points flattened into one dense block on the device + per-point offsets."""

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = _ffi.lib()  # raises if the .so is missing or a symbol is absent
     for name in _declared():
         assert hasattr(lib, name), name
-    assert lib.qmx_abi_version() == 2
+    assert lib.qmx_abi_version() == 3
 
 
 def test_struct_layouts_match_the_header():
@@ -33,7 +33,8 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(_ffi.ScoredPoint) == 8          # ScoredPointOffset is 8 bytes, #[repr(C)]
     assert C.sizeof(_ffi.Counters) == 32
     assert C.sizeof(_ffi.SqParams) == 20
-    assert C.sizeof(_ffi.SegmentDesc) == 72
+    assert C.sizeof(_ffi.SegmentDesc) == 80          # + the qmx_tq_params pointer (ABI 3)
+    assert C.sizeof(_ffi.TqParams) == 16
     assert C.sizeof(_ffi.BqParams) == 24
 
 

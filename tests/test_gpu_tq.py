@@ -1,0 +1,113 @@
+"""GPU parity: EncodedVectorsTQ (TurboQuant, lib/quantization/src/turboquant/ behind encoded_vectors_tq.rs) through the C-ABI against the CPU oracle
+(oracle/qdrant_oracle_tq.c; what pins the oracle: tests/test_oracle_tq.py).  The query rotation runs in f64 with the reference's operation order,
+everything after it is integer arithmetic: the encoded query, every score and every top-k list must equal the oracle's BIT FOR BIT."""
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+
+pytestmark = pytest.mark.gpu
+
+BITS = [O.TQ_BITS4, O.TQ_BITS2, O.TQ_BITS1_5, O.TQ_BITS1]
+
+
+@pytest.fixture(scope="module")
+def qa():
+    import qdrant_amd
+    assert qdrant_amd.device_count() >= 1
+    return qdrant_amd
+
+
+def _dist(qa, d):
+    return {O.COSINE: qa.Distance.Cosine, O.DOT: qa.Distance.Dot, O.EUCLID: qa.Distance.Euclid}[d]
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _world(qa, distance, dim, bits, n, seed, unpadded=False):
+    rng = np.random.default_rng(seed)
+    vecs = O.preprocess(distance, rng.uniform(-1.0, 1.0, (n, dim)).astype(np.float32))
+    otq = O.TqOracle(distance, dim, bits, rotation_unpadded=unpadded)
+    rows = otq.encode_rows(vecs)
+    quant = qa.TurboQuantizer(dim, _dist(qa, distance), bits, rotation_unpadded=unpadded)
+    assert quant.quantized_vector_size() == otq.row_bytes and quant.padded_dim == otq.padded_dim and quant.invert == otq.invert
+    st = qa.EncodedVectorsTQ(rows, quant)
+    return rng, vecs, otq, rows, st
+
+
+@pytest.mark.parametrize("bits", BITS)
+@pytest.mark.parametrize("distance", [O.DOT, O.COSINE, O.EUCLID])
+@pytest.mark.parametrize("dim", [16, 65, 128, 384, 700, 768, 1536])
+def test_tq_scores_bit_exact(qa, distance, dim, bits):
+    n, nq = 300, 5
+    rng, vecs, otq, rows, st = _world(qa, distance, dim, bits, n, seed=dim * 11 + bits * 3 + distance)
+    assert np.array_equal(st.get_quantized_vector([0, 7, n - 1]), rows[[0, 7, n - 1]])
+    queries = rng.uniform(-1.0, 1.0, (nq, dim)).astype(np.float32)
+    queries[3] = 0.0                                                      # test_tq_zero_query_*
+    scorer = qa.new_raw_scorer(queries, st)
+    ids = rng.permutation(n).astype(np.uint32)[:200]
+    got = scorer.score_points(ids)
+    want = otq.score_points(O.preprocess(distance, queries), ids)
+    assert np.array_equal(_bits(got), _bits(want))
+    # ragged (HNSW hop) scoring == dense scoring
+    rag = scorer.score_points_ragged([ids[:9], ids[9:40], ids[40:41], ids[:0], ids[41:60]])
+    assert np.array_equal(_bits(rag[1]), _bits(want[1, 9:40])) and np.array_equal(_bits(rag[4]), _bits(want[4, 41:60]))
+    # score_symmetric
+    a, b = ids[:64], ids[64:128]
+    assert np.array_equal(_bits(scorer.score_internal(a, b)), _bits(otq.score_internal(a, b)))
+    # no internal query encoding (encode_internal_vector -> None)
+    with pytest.raises(qa.QmxError) as e:
+        qa.new_raw_scorer_internal([1, 2], st)
+    assert e.value.status == qa._ffi.ERR_NOT_SUPPORTED
+
+
+@pytest.mark.parametrize("bits", BITS)
+@pytest.mark.parametrize("distance", [O.DOT, O.EUCLID])
+def test_tq_brute_force_topk_and_deleted(qa, distance, bits):
+    n, dim, nq = 20000, 256, 19
+    rng, vecs, otq, rows, st = _world(qa, distance, dim, bits, n, seed=1000 + bits + distance)
+    queries = rng.uniform(-1.0, 1.0, (nq, dim)).astype(np.float32)
+    deleted = rng.random(n) < 0.2
+    st.set_deleted(deleted)
+    res = qa.BatchFilteredSearcher(queries, st, 10).peek_top_all()
+    sample = rng.permutation(n)[:3000]
+    want = otq.score_points(O.preprocess(distance, queries), np.arange(n)) if n <= 20000 else None
+    for qi, r in enumerate(res):
+        sc = want[qi].copy()
+        sc[deleted] = -np.inf
+        assert not deleted[r["idx"]].any()
+        assert np.array_equal(_bits(r["score"]), _bits(np.sort(sc)[::-1][:10]))
+        assert np.array_equal(_bits(want[qi][r["idx"]]), _bits(r["score"]))
+
+
+def test_tq_unpadded_rotation_and_hnsw_walk(qa):
+    """TQRotation::Unpadded (the TQ-as-datatype storages) and the HNSW walk with the TQ scorer == the oracle's walk"""
+    n, dim = 3000, 100
+    rng, vecs, otq, rows, st = _world(qa, O.COSINE, dim, O.TQ_BITS4, n, seed=77, unpadded=True)
+    queries = rng.uniform(-1.0, 1.0, (16, dim)).astype(np.float32)
+    ids = np.arange(200, dtype=np.uint32)
+    scorer = qa.new_raw_scorer(queries, st)
+    want = otq.score_points(O.preprocess(O.COSINE, queries), ids)
+    assert np.array_equal(_bits(scorer.score_points(ids)), _bits(want))
+    dense = O.DenseStorage(O.F32, O.COSINE, vecs)
+    g = O.Hnsw(dense, m=8, ef_construct=48, seed=5)
+    graph = qa.GraphLayers.from_plain(g.export_plain())
+    got = graph.search(10, 64, scorer)
+    full = otq.score_points(O.preprocess(O.COSINE, queries), np.arange(n))
+    for qi, r in enumerate(got):
+        assert len(r) == 10 and np.all(np.diff(r["score"]) <= 0)
+        assert np.array_equal(_bits(full[qi][r["idx"]]), _bits(r["score"]))                # true TQ scores of the returned points
+        best = np.sort(full[qi])[::-1][:10]
+        assert len(np.intersect1d(_bits(r["score"]), _bits(best))) >= 5                    # a walk, not a scan: most of the true top-10
+
+
+def test_tq_argument_errors(qa):
+    quant = qa.TurboQuantizer(64, qa.Distance.Manhattan, O.TQ_BITS4)
+    with pytest.raises(qa.QmxError) as e:
+        qa.EncodedVectorsTQ(np.zeros((4, quant.quantized_vector_size()), dtype=np.uint8), quant)
+    assert e.value.status == qa._ffi.ERR_NOT_SUPPORTED                                       # L1 scoring is not built
+    big = qa.TurboQuantizer(100000, qa.Distance.Dot, O.TQ_BITS4)
+    with pytest.raises(qa.QmxError):                                                          # the rotation runs in LDS: padded dim <= 8192
+        qa.EncodedVectorsTQ(np.zeros((2, big.quantized_vector_size()), dtype=np.uint8), big)
