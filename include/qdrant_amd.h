@@ -186,6 +186,13 @@ typedef struct qmx_tq_params {
     uint32_t reserved;
 } qmx_tq_params;
 
+/* `TurboQuantizer::quantize` (turboquant/quantization.rs:211-296, TQMode::Normal) for a batch, on the device: vectors [n][dim] f32 as the storage
+ * holds them (cosine: normalised; host or device) -> out_rows [n][quantized size] bytes (host or device), the rows a QMX_DTYPE_TQ segment takes.
+ * Rotation, length rescale and the two f64 sums (l2 length, centroid norm) follow the reference's operation order: rows are byte-identical to
+ * the oracle's restatement. */
+QMX_API int32_t qmx_tq_encode(int32_t device_id, uint32_t distance, uint32_t dim, const qmx_tq_params *params, const float *vectors, uint64_t n,
+                              void *out_rows);
+
 typedef struct qmx_segment_desc {
     uint32_t dtype;            /* qmx_dtype */
     uint32_t distance;         /* qmx_distance */

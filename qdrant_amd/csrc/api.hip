@@ -567,6 +567,46 @@ static TqRotationHost tq_rotation(const qmx_segment *s) {
     return h;
 }
 
+int32_t qmx_tq_encode(int32_t device_id, uint32_t distance, uint32_t dim, const qmx_tq_params *params, const float *vectors, uint64_t n, void *out_rows) {
+    QMX_REQUIRE(params && (n == 0 || (vectors && out_rows)) && dim > 0, QMX_ERR_BAD_ARG, "bad argument");
+    QMX_REQUIRE(distance <= QMX_DISTANCE_MANHATTAN && distance != QMX_DISTANCE_MANHATTAN, QMX_ERR_NOT_SUPPORTED, "TurboQuant: distance %u not built", distance);
+    QMX_TRY(check_device(device_id, nullptr));
+    if (n == 0) return QMX_OK;
+    qmx_segment tmp;                       // parameter holder only: the rotation tables of TurboQuantizer::new
+    qmx_segment_desc d;
+    memset(&d, 0, sizeof(d));
+    d.dtype = QMX_DTYPE_TQ; d.distance = distance; d.dim = dim; d.tq = params; d.device_id = device_id;
+    tmp.device = device_id; tmp.dtype = QMX_DTYPE_TQ; tmp.distance = distance; tmp.dim = dim;
+    int32_t rc = tq_segment_setup(&tmp, &d);
+    DevBuf bin, brot, bout;
+    do {
+        if (rc != QMX_OK) break;
+        const uint32_t row_bytes = (uint32_t)tmp.row_bytes;
+        const uint64_t CH = 65536;         // vectors per pass (the f64 scratch is padded_dim * 8 bytes per vector)
+        const bool in_dev = is_device_ptr(vectors), out_dev = is_device_ptr(out_rows);
+        if ((rc = brot.reserve((size_t)std::min<uint64_t>(n, CH) * tmp.tq_padded_dim * 8)) != QMX_OK) break;
+        if (!in_dev && (rc = bin.reserve((size_t)std::min<uint64_t>(n, CH) * dim * 4)) != QMX_OK) break;
+        if (!out_dev && (rc = bout.reserve((size_t)std::min<uint64_t>(n, CH) * row_bytes)) != QMX_OK) break;
+        for (uint64_t r0 = 0; r0 < n && rc == QMX_OK; r0 += CH) {
+            const uint32_t cnt = (uint32_t)std::min<uint64_t>(CH, n - r0);
+            const float *d_in = vectors + r0 * dim;
+            if (!in_dev) {
+                if (hipMemcpy(bin.p, vectors + r0 * dim, (size_t)cnt * dim * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = QMX_ERR_OTHER; break; }
+                d_in = (const float *)bin.p;
+            }
+            void *d_out = out_dev ? (void *)((char *)out_rows + r0 * row_bytes) : bout.p;
+            if ((rc = launch_tq_rotate(nullptr, d_in, cnt, tq_rotation(&tmp), (double *)brot.p)) != QMX_OK) break;
+            if ((rc = launch_tq_quantize(nullptr, (double *)brot.p, cnt, tmp.tq_padded_dim, tmp.tq_value_bits, distance, d_out, row_bytes)) != QMX_OK) break;
+            if (hipDeviceSynchronize() != hipSuccess) { rc = QMX_ERR_OTHER; break; }
+            if (!out_dev && hipMemcpy((char *)out_rows + r0 * row_bytes, bout.p, (size_t)cnt * row_bytes, hipMemcpyDeviceToHost) != hipSuccess) { rc = QMX_ERR_OTHER; break; }
+        }
+    } while (0);
+    bin.release(); brot.release(); bout.release();
+    if (tmp.d_tq_tables) (void)hipFree(tmp.d_tq_tables);
+    if (tmp.d_tq_norms) (void)hipFree(tmp.d_tq_norms);
+    return rc;
+}
+
 int32_t qmx_segment_create(const qmx_segment_desc *desc, qmx_segment **out) {
     QMX_REQUIRE(desc && out, QMX_ERR_BAD_ARG, "NULL argument");
     *out = nullptr;

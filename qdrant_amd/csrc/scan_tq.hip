@@ -299,6 +299,88 @@ int32_t launch_tq_rotate(hipStream_t st, const float *d_in, uint32_t n, const Tq
     return QMX_OK;
 }
 
+// ---- TurboQuantizer::quantize (TQMode::Normal) on rotated vectors: rot [n][padded_dim] f64 (overwritten by the rescale) -> reference rows ----
+// The two f64 sums (l2 length, centroid norm) run in index order in one thread, like the reference's iterator sums; everything else is elementwise.
+__global__ __launch_bounds__(256) void tq_quantize_kernel(double *rot, uint32_t n, uint32_t padded_dim, uint32_t value_bits, uint32_t distance, uint8_t *out,
+                                                          uint32_t out_stride) {
+    __shared__ double sh_scale;
+    __shared__ float sh_l2;
+    const uint32_t v = blockIdx.x;
+    if (v >= n) return;
+    double *x = rot + (uint64_t)v * padded_dim;
+    uint8_t *row = out + (uint64_t)v * out_stride;
+    const uint32_t code_bytes = padded_dim * value_bits / 8;
+    const bool has_l2 = distance != QMX_DISTANCE_COSINE;
+    if (threadIdx.x == 0) {
+        float l2_length = 1.0f;
+        if (has_l2) {
+            double s = 0.0;
+            for (uint32_t i = 0; i < padded_dim; ++i) s = s + x[i] * x[i];
+            l2_length = (float)sqrt(s);
+        }
+        sh_l2 = l2_length;
+        const double length = (double)l2_length;
+        sh_scale = length > 0.0 ? sqrt((double)padded_dim) / length : 1.0;
+    }
+    __syncthreads();
+    if ((double)sh_l2 > 0.0) {
+        const double length_scale = sh_scale;
+        for (uint32_t i = threadIdx.x; i < padded_dim; i += blockDim.x) x[i] = x[i] * length_scale;
+    }
+    __syncthreads();
+    // centroid of each value: boundaries.partition_point(|&b| (val as f32) > b) with the midpoint boundaries of lloyd_max.rs
+    const float C1[2] = {-0.7978846f, 0.7978846f};
+    const float C2[4] = {-1.510f, -0.4528f, 0.4528f, 1.510f};
+    const float C4[16] = {-2.733f, -2.069f, -1.618f, -1.256f, -0.9424f, -0.6568f, -0.3881f, -0.1284f, 0.1284f, 0.3881f, 0.6568f, 0.9424f, 1.256f, 1.618f, 2.069f, 2.733f};
+    auto centroid_index = [&](double val) -> uint32_t {
+        const float f = (float)val;
+        const int nc = value_bits == 4 ? 16 : value_bits == 2 ? 4 : 2;
+        uint32_t idx = 0;
+        for (int i = 0; i + 1 < nc; ++i) {
+            const float lo = value_bits == 4 ? C4[i] : value_bits == 2 ? C2[i] : C1[i];
+            const float hi = value_bits == 4 ? C4[i + 1] : value_bits == 2 ? C2[i + 1] : C1[i + 1];
+            if (f > (lo + hi) / 2.0f) idx = (uint32_t)i + 1; else break;
+        }
+        return idx;
+    };
+    auto centroid_value = [&](uint32_t idx) -> float { return value_bits == 4 ? C4[idx] : value_bits == 2 ? C2[idx] : C1[idx]; };
+    for (uint32_t i = threadIdx.x; i < code_bytes; i += blockDim.x) {          // BitWriter, LSB first: byte i holds 8 / bits values
+        const uint32_t per = 8 / value_bits;
+        uint32_t b = 0;
+        for (uint32_t k = 0; k < per; ++k) b |= centroid_index(x[i * per + k]) << (k * value_bits);
+        row[i] = (uint8_t)b;
+    }
+    if (threadIdx.x == 0) {
+        int degenerate = 0;
+        if (distance == QMX_DISTANCE_COSINE) {
+            double s = 0.0;
+            for (uint32_t i = 0; i < padded_dim; ++i) s = s + x[i] * x[i];
+            degenerate = s < 1e-12;
+        }
+        float centroid_norm;
+        if (degenerate) centroid_norm = sqrtf((float)padded_dim);
+        else {
+            double sq = 0.0;
+            for (uint32_t i = 0; i < padded_dim; ++i) {
+                const double c = (double)centroid_value(centroid_index(x[i]));
+                sq = sq + c * c;
+            }
+            centroid_norm = (float)sqrt(sq);
+        }
+        const float scaling_factor = (has_l2 ? sh_l2 : 1.0f) / centroid_norm;
+        memcpy(row + code_bytes, &scaling_factor, 4);
+        if (distance == QMX_DISTANCE_EUCLID) { const float l = sh_l2; memcpy(row + code_bytes + 4, &l, 4); }
+    }
+}
+int32_t launch_tq_quantize(hipStream_t st, double *d_rot, uint32_t n, uint32_t padded_dim, uint32_t value_bits, uint32_t distance, void *d_out,
+                           uint32_t out_stride) {
+    if (n == 0) return QMX_OK;
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(tq_quantize_kernel, dim3(n), dim3(256), 0, st, d_rot, n, padded_dim, value_bits, distance, (uint8_t *)d_out, out_stride);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
 // ---- Query{N}bitSimd::new on the rotated queries: rot [nq][padded_dim] f64 -> tile entries ----
 __global__ __launch_bounds__(256) void tq_query_encode_kernel(const double *rot, uint32_t padded_dim, uint32_t bits, int need_l2, uint8_t *tile,
                                                               uint32_t q_stride, uint32_t aux_off) {

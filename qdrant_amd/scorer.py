@@ -420,6 +420,14 @@ class TurboQuantizer:
         """TurboQuantizer::quantized_size_for (turboquant/encoding.rs:172-190)."""
         return self.code_bytes + (8 if self.distance == Distance.Euclid else 4)
 
+    def encode(self, vectors, device_id: int = 0) -> np.ndarray:
+        """`TurboQuantizer::quantize` on device: [n, dim] f32 (as stored: cosine rows normalised) -> [n, quantized_vector_size] bytes."""
+        v = np.ascontiguousarray(vectors, dtype=np.float32)
+        out = np.empty((v.shape[0], self.quantized_vector_size()), dtype=np.uint8)
+        p = self.params()
+        F.check(F.lib().qmx_tq_encode(device_id, int(self.distance), self.dim, C.byref(p), F.ptr(v), v.shape[0], F.ptr(out)))
+        return out
+
 
 class EncodedVectorsTQ(VectorStorage):
     """Device-resident `EncodedVectorsTQ` storage: rows = [n, quantized_vector_size] bytes as `TurboQuantizer::quantize` writes them."""

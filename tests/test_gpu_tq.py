@@ -82,6 +82,39 @@ def test_tq_brute_force_topk_and_deleted(qa, distance, bits):
         assert np.array_equal(_bits(want[qi][r["idx"]]), _bits(r["score"]))
 
 
+@pytest.mark.parametrize("bits", BITS)
+@pytest.mark.parametrize("distance", [O.DOT, O.COSINE, O.EUCLID])
+def test_tq_encode_on_device_byte_exact(qa, distance, bits):
+    """TurboQuantizer::quantize on the device: codes and extras equal the oracle's bytes (rotation, rescale, the f64 sums in the reference's order)"""
+    for dim, unpadded in ((65, False), (384, False), (700, False), (1536, False), (100, True)):
+        if unpadded and bits == O.TQ_BITS1_5:
+            continue
+        rng = np.random.default_rng(dim + bits)
+        vecs = O.preprocess(distance, rng.uniform(-1.0, 1.0, (40, dim)).astype(np.float32))
+        vecs[7] = 0.0                                                         # zero vector: the length-rescale guard, the cosine centroid-norm guard
+        otq = O.TqOracle(distance, dim, bits, rotation_unpadded=unpadded)
+        quant = qa.TurboQuantizer(dim, _dist(qa, distance), bits, rotation_unpadded=unpadded)
+        assert np.array_equal(quant.encode(vecs), otq.encode_rows(vecs))
+
+
+def test_tq_oversampled_search_with_rescoring(qa):
+    """the quantized stage + postprocess_search_result over a TQ storage (qmx_search_quantized): after rescoring the scores are the exact ones"""
+    n, dim = 30000, 128
+    rng, vecs, otq, rows, st = _world(qa, O.COSINE, dim, O.TQ_BITS4, n, seed=9)
+    vs = qa.VectorStorage(vecs, qa.Distance.Cosine)
+    queries = rng.uniform(-1.0, 1.0, (8, dim)).astype(np.float32)
+    exact = O.DenseStorage(O.F32, O.COSINE, vecs).peek_top(queries, 10)
+    got = qa.search_quantized(qa.new_raw_scorer(queries, st), qa.new_raw_scorer(queries, vs), top=10, oversampling=3.0, rescore=True)
+    hits = 0
+    for g, e in zip(got, exact):
+        hits += len(set(g["idx"].tolist()) & set(e["idx"].tolist()))
+        pos = {int(i): k for k, i in enumerate(e["idx"])}
+        for i, s_ in zip(g["idx"], g["score"]):
+            if int(i) in pos:
+                assert np.float32(s_).view(np.uint32) == e["score"][pos[int(i)]].view(np.uint32)
+    assert hits >= 0.9 * 80
+
+
 def test_tq_unpadded_rotation_and_hnsw_walk(qa):
     """TQRotation::Unpadded (the TQ-as-datatype storages) and the HNSW walk with the TQ scorer == the oracle's walk"""
     n, dim = 3000, 100
