@@ -35,6 +35,10 @@ __device__ __forceinline__ int lane_piece(int t) { return 2 * (t & 3) + (t >> 2)
 template <class P, class = void> struct query_pieces { static constexpr int value = 1; };
 template <class P> struct query_pieces<P, decltype((void)P::QPIECES)> { static constexpr int value = P::QPIECES; };
 
+// a policy with `typedef ... dec_t`, `decode(v, dec)` and `mac_decoded(acc, q, dec)` has its row pieces decoded once per step (scan_tq.hip)
+template <class P, class = void> struct has_row_decode { static constexpr bool value = false; };
+template <class P> struct has_row_decode<P, decltype((void)sizeof(typename P::dec_t))> { static constexpr bool value = true; };
+
 // one 128-byte segment step: the lane's 16-byte row pieces (R rows) against every query of the tile; the lane's query piece(s)
 // sit at byte q_off (x QPIECES) of each query entry
 template <class P, int QT, int R>
@@ -54,7 +58,7 @@ __device__ __forceinline__ void scan_step(typename P::acc_t (&acc)[QT][R][P::NAC
             if (!lane_on) qv = make_uint4(0, 0, 0, 0);   // partial segment: the scalar-tail elements sit right behind the body
 #pragma unroll
             for (int r = 0; r < R; ++r) P::mac(acc[q][r], qv, v[r]);
-        } else {
+        } else if constexpr (!has_row_decode<P>::value) {
             uint4 qv[QP];
 #pragma unroll
             for (int k = 0; k < QP; ++k) {
@@ -63,6 +67,23 @@ __device__ __forceinline__ void scan_step(typename P::acc_t (&acc)[QT][R][P::NAC
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) P::mac_pieces(acc[q][r], qv, v[r]);
+        }
+    }
+    if constexpr (has_row_decode<P>::value) {
+        // rows whose pieces are DECODED before they meet a query (TurboQuant codes -> codebook bytes): once per row piece, not once per query
+        typename P::dec_t dec[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) P::decode(v[r], dec[r]);
+#pragma unroll
+        for (int q = 0; q < QT; ++q) {
+            uint4 qv[QP];
+#pragma unroll
+            for (int k = 0; k < QP; ++k) {
+                qv[k] = *reinterpret_cast<const uint4 *>(q_base + q_off * QP + k * 16 + (uint32_t)q * q_stride);
+                if (!lane_on) qv[k] = make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) P::mac_decoded(acc[q][r], qv, dec[r]);
         }
     }
 }

@@ -67,21 +67,33 @@ struct RowTQ4 {
     typedef uint32_t acc_t;
     static __device__ __forceinline__ void row_aux(acc_t (&)[1], const uint4 &) {}
     static __device__ __forceinline__ void mac(acc_t (&)[NACC], const uint4 &, const uint4 &) {}
-    static __device__ __forceinline__ void mac_pieces(acc_t (&a)[NACC], const uint4 (&q)[4], const uint4 &v) {
+    struct dec_t { uint32_t ce[4], co[4]; };    // codebook bytes of the even / odd dims of the piece
+    static __device__ __forceinline__ void decode(const uint4 &v, dec_t &d) {
         const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            d.ce[w] = tq4_lookup(vv[w] & 0x0F0F0F0Fu);
+            d.co[w] = tq4_lookup((vv[w] >> 4) & 0x0F0F0F0Fu);
+        }
+    }
+    static __device__ __forceinline__ void mac_decoded(acc_t (&a)[NACC], const uint4 (&q)[4], const dec_t &d) {
         const uint32_t le[4] = {q[0].x, q[0].y, q[0].z, q[0].w}, lo[4] = {q[1].x, q[1].y, q[1].z, q[1].w};
         const uint32_t he[4] = {q[2].x, q[2].y, q[2].z, q[2].w}, ho[4] = {q[3].x, q[3].y, q[3].z, q[3].w};
         int32_t al = (int32_t)a[0], ah = (int32_t)a[1];
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            const uint32_t ce = tq4_lookup(vv[w] & 0x0F0F0F0Fu), co = tq4_lookup((vv[w] >> 4) & 0x0F0F0F0Fu);
-            al = sdot4(le[w], ce, al);
-            al = sdot4(lo[w], co, al);
-            ah = sdot4(he[w], ce, ah);
-            ah = sdot4(ho[w], co, ah);
+            al = sdot4(le[w], d.ce[w], al);
+            al = sdot4(lo[w], d.co[w], al);
+            ah = sdot4(he[w], d.ce[w], ah);
+            ah = sdot4(ho[w], d.co[w], ah);
         }
         a[0] = (uint32_t)al;
         a[1] = (uint32_t)ah;
+    }
+    static __device__ __forceinline__ void mac_pieces(acc_t (&a)[NACC], const uint4 (&q)[4], const uint4 &v) {
+        dec_t d;
+        decode(v, d);
+        mac_decoded(a, q, d);
     }
     static __device__ __forceinline__ float finish(acc_t (&a)[NACC], acc_t (&)[1], const unsigned char *q_lds, const unsigned char *, uint32_t rid,
                                                    const ScanArgs &args) {
@@ -98,26 +110,37 @@ struct RowTQ2 {
     static constexpr bool TEMPORAL_ROWS = true;
     static constexpr int NACC = 2;
     static constexpr int NRAUX = 0;
-    static constexpr int R16 = 1;
+    static constexpr int R16 = 2;
     static constexpr int QPIECES = 8;
     typedef uint32_t acc_t;
     static __device__ __forceinline__ void row_aux(acc_t (&)[1], const uint4 &) {}
     static __device__ __forceinline__ void mac(acc_t (&)[NACC], const uint4 &, const uint4 &) {}
-    static __device__ __forceinline__ void mac_pieces(acc_t (&a)[NACC], const uint4 (&q)[8], const uint4 &v) {
+    struct dec_t { uint32_t c[4][4]; };         // codebook bytes of the dims = j mod 4, per dword
+    static __device__ __forceinline__ void decode(const uint4 &v, dec_t &d) {
         const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) d.c[j][w] = __builtin_amdgcn_perm(0u, TQ2_T, (vv[w] >> (2 * j)) & 0x03030303u);
+    }
+    static __device__ __forceinline__ void mac_decoded(acc_t (&a)[NACC], const uint4 (&q)[8], const dec_t &d) {
         int32_t al = (int32_t)a[0], ah = (int32_t)a[1];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t ql[4] = {q[j].x, q[j].y, q[j].z, q[j].w}, qh[4] = {q[4 + j].x, q[4 + j].y, q[4 + j].z, q[4 + j].w};
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                const uint32_t c = __builtin_amdgcn_perm(0u, TQ2_T, (vv[w] >> (2 * j)) & 0x03030303u);
-                al = sdot4(ql[w], c, al);
-                ah = sdot4(qh[w], c, ah);
+                al = sdot4(ql[w], d.c[j][w], al);
+                ah = sdot4(qh[w], d.c[j][w], ah);
             }
         }
         a[0] = (uint32_t)al;
         a[1] = (uint32_t)ah;
+    }
+    static __device__ __forceinline__ void mac_pieces(acc_t (&a)[NACC], const uint4 (&q)[8], const uint4 &v) {
+        dec_t d;
+        decode(v, d);
+        mac_decoded(a, q, d);
     }
     static __device__ __forceinline__ float finish(acc_t (&a)[NACC], acc_t (&)[1], const unsigned char *q_lds, const unsigned char *, uint32_t rid,
                                                    const ScanArgs &args) {

@@ -153,6 +153,47 @@ def main():
         del rows16
         torch.cuda.empty_cache()
 
+    if "tq" in args.configs:
+        dim = 768
+        for bits, label in ((O.TQ_BITS4, "4-bit"), (O.TQ_BITS2, "2-bit"), (O.TQ_BITS1, "1-bit")):
+            rows = make_rows(dim, 0x5EED0007)
+            quant = qa.TurboQuantizer(dim, qa.Distance.Dot, bits)
+            p = quant.params()
+            rb = quant.quantized_vector_size()
+            enc_rows = torch.empty((n, rb), dtype=torch.uint8, device=dev)
+            t0 = time.perf_counter()
+            F.check(lib.qmx_tq_encode(0, int(qa.Distance.Dot), dim, C.byref(p), F.ptr(rows), n, F.ptr(enc_rows)))
+            torch.cuda.synchronize()
+            t_enc = time.perf_counter() - t0
+            host_rows = rows[:S].cpu().numpy()
+            host_enc = enc_rows[:S].cpu().numpy()
+            del rows
+            torch.cuda.empty_cache()
+            d = F.SegmentDesc()
+            d.dtype, d.distance, d.dim, d.flags, d.n, d.data, d.device_id = F.DTYPE_TQ, int(qa.Distance.Dot), dim, 0, n, F.ptr(enc_rows).value, 0
+            d.tq = C.pointer(p)
+            seg = C.c_void_p()
+            F.check(lib.qmx_segment_create(C.byref(d), C.byref(seg)))
+            del enc_rows
+            torch.cuda.empty_cache()
+            otq = O.TqOracle(O.DOT, dim, bits)
+            enc_ok = bool(np.array_equal(otq.encode_rows(host_rows[:500]), host_enc[:500]))
+            otq.rows = host_enc
+            queries = O.preprocess(O.COSINE, O.synth(0x5EED0017, 0, 64, dim))
+            S_tq = min(S, 20000)
+            ids = torch.arange(S_tq, dtype=torch.int32, device=dev)
+
+            def check_tq(qh, Q, out, counts):
+                F.check(lib.qmx_search_topk_async(qh, top, F.ptr(ids), S_tq, F.ptr(out), F.ptr(counts)))
+                F.check(lib.qmx_query_synchronize(qh))
+                gs = out.cpu().numpy()[:, :, 1].copy().view(np.float32)
+                sc = otq.score_points(queries[:1], np.arange(S_tq))
+                return enc_ok and bool(np.array_equal(np.sort(sc[0])[::-1][:top].view(np.uint32), gs[0].view(np.uint32)))
+            print(json.dumps({"config": "TQ %s encode" % label, "tq_encode_s": round(t_enc, 3), "rows": n,
+                              "encoded_rows_match_oracle_first_500": enc_ok}), flush=True)
+            run("TQ %s: 10M x %d TurboQuant dot, brute-force top-10" % (label, dim), seg, dim, rb, queries, check_tq)
+            F.check(lib.qmx_segment_destroy(seg))
+
     if "bq" in args.configs:
         for dim in (768, 1536):
             rows = make_rows(dim, 0x5EED0005)
