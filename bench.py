@@ -425,6 +425,22 @@ def _recall(got, exact, top):
     return sum(len(set(a["idx"].tolist()) & set(b["idx"].tolist())) for a, b in zip(got, exact)) / float(max(1, len(exact)) * top)
 
 
+
+def _with_vectors(ctx, graph, scorer, raw, top, ef, n_gt, exact, reps=3):
+    """GraphLayers::search_with_vectors (inline storage): the walk steered by the quantized scorer, every popped candidate scored on its original
+    vector, the best base scores returned - rescoring fused into the walk (qmx_hnsw_search_with_vectors)."""
+    try:
+        res = graph.search_with_vectors(top, ef, scorer, raw)                     # warm-up
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            res, scored = graph.search_with_vectors(top, ef, scorer, raw, with_scored=True)
+        wall = (time.perf_counter() - t0) / reps
+        return {"wall_ms_per_search": round(wall * 1e3, 3), "qps_wall": round(scorer.nq / wall, 1), "link_plus_base_vectors_scored_per_query": round(scored / scorer.nq, 1),
+                "recall_at_10_vs_exact": round(_recall(res[:n_gt], exact, top), 4)}
+    except Exception as e:
+        return {"error": repr(e)[:300]}
+
+
 def _timed_quantized(ctx, scorer, raw, top, oversampling, rescore, graph, ef, reps, row_bytes, n_rows_scanned=None):
     """reps calls of qmx_search_quantized; kernel time = HIP events around the quantized stage's scoring kernel (scan or walk)."""
     lib, F, qa = ctx["lib"], ctx["F"], ctx["qa"]
@@ -526,6 +542,7 @@ def c3_section(ctx, rows):
     st.update({"m": 16, "ef_construct": 100, "ef": 128, "oversampling": 2.0, "searches_per_launch": nq_h,
                "build_s": round(t_build, 2), "build_points_per_s": round(n / t_build, 1),
                "points_scored_per_query": round(scored / nq_h, 1), "recall_at_10_vs_exact": round(_recall(res[:n_gt], exact, top), 4)})
+    st["search_with_vectors_ef128"] = _with_vectors(ctx, graph, scorer, raw, top, 128, n_gt, exact)
     # recall-vs-ef of the same graph, f32 walk (graph quality without the quantizer)
     st["recall_f32_walk_vs_ef"] = {str(ef): round(_recall(graph.search(top, ef, qa.new_raw_scorer(queries[:n_gt].contiguous(), vs)), exact, top), 4)
                                    for ef in (64, 128, 256)}
@@ -618,6 +635,7 @@ def c4_section(ctx):
         walks[name] = st
     hn = {"m": 16, "ef_construct": 100, "ef": 128, "searches_per_launch": nq_h, "build_through": "PQ scorer (LUT of the original vector per insertion, score_internal for the heuristic)",
           "build_s": round(t_build, 2), "build_points_per_s": round(n / t_build, 1), "walks": walks}
+    hn["search_with_vectors_ef128"] = _with_vectors(ctx, graph, scorer, raw, top, 128, n_gt, exact)
     hn["recall_f32_walk_vs_ef"] = {str(ef): round(_recall(graph.search(top, ef, qa.new_raw_scorer(queries[:n_gt].contiguous(), vs)), exact, top), 4)
                                    for ef in (64, 128, 256)}
     # brute force over the codes for reference (what the quantizer alone can do on these rows)
