@@ -1542,7 +1542,8 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
             const bool m16 = s->dtype == QMX_DTYPE_F32 && mfma_scan_ok(s) && mfma16_scan_ok(qt, SCAN_TOPK, a);
             const bool sqm = (s->dtype == QMX_DTYPE_SQ_U8 ? qt >= 4 : s->dtype == QMX_DTYPE_F16 && qt >= 8) && mfma_scan_ok(s);   // scan_sq_mfma.hip starts from the bound too
             const bool m4 = s->dtype == QMX_DTYPE_F32 && qt >= 8 && mfma_scan_ok(s);                                        // scan_mfma.hip (4x4x1) as well
-            if (pass == 0 && n_cand >= (1u << 18) && (m16 || sqm || m4) && !option(OPT_NO_PRESCAN)) {
+            const bool bqk = s->dtype == QMX_DTYPE_BQ && qt >= 4;   // bq_rows_kernel: integer scores, selection-bound without a starting threshold
+            if (pass == 0 && n_cand >= (1u << 18) && (m16 || sqm || m4 || bqk) && !option(OPT_NO_PRESCAN)) {
                 const int pre_shift = (int)std::min<int64_t>(std::max<int64_t>(option(OPT_PRESCAN_SHIFT), 1), 20);  // tuning: measured 5..10 on C2, the main pass does not care, the pre-scan itself gets cheaper
                 const uint64_t pre_n = std::max<uint64_t>(n_cand >> pre_shift, 1u << 13) & ~(uint64_t)15;
                 {

@@ -105,8 +105,12 @@ __global__ __launch_bounds__(BQR_BLOCK) void bq_rows_kernel(const ScanArgs a) {
     const int top = (int)a.top;
     const float dimf = (float)a.bq_dim;
     uint64_t list[QT];
+    uint64_t floor_key[QT];   // a.gthr: a key known to be <= the query's final k-th best key (the k-th best of a pre-scanned prefix, api.hip): keys below it never enter a list
 #pragma unroll
-    for (int q = 0; q < QT; ++q) list[q] = 0;
+    for (int q = 0; q < QT; ++q) {
+        list[q] = 0;
+        floor_key[q] = (a.gthr && q < (int)a.nq) ? a.gthr[q] : 0;
+    }
 
     const uint64_t stride = (uint64_t)gridDim.x * BQR_BLOCK;
     for (uint64_t base = ((uint64_t)blockIdx.x * BQR_NW + wave) * WAVE; base < a.n_cand; base += stride) {
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(BQR_BLOCK) void bq_rows_kernel(const ScanArgs a) {
                 } else {
                     const uint64_t key = make_key(score, id);
                     const uint64_t thr = readlane_u64(list[q], top - 1);
-                    bool cnd = valid && key > thr;
+                    bool cnd = valid && key > thr && key >= floor_key[q];
                     if (__ballot(cnd)) {
                         cnd = cnd && a.del.live(id) && (!a.key_bound || key < a.key_bound[q]);
                         uint64_t m = __ballot(cnd);
