@@ -219,7 +219,7 @@ typedef struct qmx_segment_desc {
  * PQ: `vector_division` must be the uniform division the reference itself produces (get_vector_division :164-169),
  * anything else is QMX_ERR_NOT_SUPPORTED. */
 typedef struct qmx_quant_meta {
-    uint32_t dtype;                 /* QMX_DTYPE_SQ_U8 | QMX_DTYPE_PQ | QMX_DTYPE_BQ, as asked                */
+    uint32_t dtype;                 /* QMX_DTYPE_SQ_U8 | QMX_DTYPE_PQ | QMX_DTYPE_BQ | QMX_DTYPE_TQ, as asked  */
     uint32_t dim;                   /* VectorParameters.dim                                                  */
     uint32_t distance;              /* qmx_distance of VectorParameters.distance_type (L1 = Manhattan, L2 = Euclid) */
     uint8_t invert;                 /* VectorParameters.invert                                               */
@@ -230,6 +230,7 @@ typedef struct qmx_quant_meta {
     qmx_sq_params sq;
     qmx_pq_params pq;
     qmx_bq_params bq;
+    qmx_tq_params tq;               /* EncodedVectorsTQ `Metadata` (encoded_vectors_tq.rs:33-46): bits, mode (plus_mode), rotation; invert copied */
     void *owner;
 } qmx_quant_meta;
 QMX_API int32_t qmx_quant_meta_parse(uint32_t dtype, const char *json, uint64_t n_bytes, qmx_quant_meta *out);

@@ -49,14 +49,16 @@ class BqParams(C.Structure):
     _fields_ = [("encoding", C.c_uint32), ("query_encoding", C.c_uint32), ("mean", C.c_void_p), ("stddev", C.c_void_p)]
 
 
+BQ_ONE_BIT, BQ_TWO_BITS, BQ_ONE_AND_HALF_BITS = range(3)
+BQ_QUERY_SAME_AS_STORAGE, BQ_QUERY_SCALAR_4BITS, BQ_QUERY_SCALAR_8BITS = range(3)
+
+
 class TqParams(C.Structure):
     _fields_ = [("bits", C.c_uint32), ("rotation_unpadded", C.c_uint32), ("invert", C.c_uint8), ("plus_mode", C.c_uint8), ("pad_", C.c_uint8 * 2),
                 ("reserved", C.c_uint32)]
 
 
 TQ_BITS4, TQ_BITS2, TQ_BITS1_5, TQ_BITS1 = range(4)
-BQ_ONE_BIT, BQ_TWO_BITS, BQ_ONE_AND_HALF_BITS = range(3)
-BQ_QUERY_SAME_AS_STORAGE, BQ_QUERY_SCALAR_4BITS, BQ_QUERY_SCALAR_8BITS = range(3)
 
 
 class SegmentDesc(C.Structure):
@@ -79,7 +81,7 @@ class QuantMeta(C.Structure):
     """qmx_quant_meta: a parsed quantized.meta.json (library-owned arrays, qmx_quant_meta_free)."""
     _fields_ = [("dtype", C.c_uint32), ("dim", C.c_uint32), ("distance", C.c_uint32), ("invert", C.c_uint8),
                 ("has_deprecated_count", C.c_uint8), ("bq_query_encoding", C.c_uint8), ("pad_", C.c_uint8),
-                ("deprecated_count", C.c_uint64), ("sq", SqParams), ("pq", PqParams), ("bq", BqParams), ("owner", C.c_void_p)]
+                ("deprecated_count", C.c_uint64), ("sq", SqParams), ("pq", PqParams), ("bq", BqParams), ("tq", TqParams), ("owner", C.c_void_p)]
 
 
 class GraphLinks(C.Structure):

@@ -708,7 +708,7 @@ int32_t qmx_segment_create(const qmx_segment_desc *desc, qmx_segment **out) {
 int32_t qmx_segment_create_from_files(const qmx_segment_desc *desc, const char *vectors_path, const char *deleted_path, qmx_segment **out) {
     QMX_REQUIRE(desc && vectors_path && out, QMX_ERR_BAD_ARG, "NULL argument");
     *out = nullptr;
-    QMX_REQUIRE(desc->dtype <= QMX_DTYPE_BQ && desc->dim > 0, QMX_ERR_BAD_ARG, "bad dtype / dim");
+    QMX_REQUIRE(desc->dtype <= QMX_DTYPE_TQ && desc->dim > 0, QMX_ERR_BAD_ARG, "bad dtype / dim");
     QMX_TRY(check_device(desc->device_id, nullptr));
     // bytes per stored row in the file and the header in front of them
     uint64_t row_bytes = 0, header = 0;
@@ -722,6 +722,15 @@ int32_t qmx_segment_create_from_files(const qmx_segment_desc *desc, const char *
             QMX_REQUIRE(desc->pq && desc->pq->chunk_size, QMX_ERR_BAD_ARG, "PQ segment needs qmx_pq_params");
             row_bytes = ((uint64_t)desc->dim + desc->pq->chunk_size - 1) / desc->pq->chunk_size;
             break;
+        case QMX_DTYPE_TQ: {    // TurboQuantizer::quantized_size_for (turboquant/encoding.rs:172-201)
+            QMX_REQUIRE(desc->tq && desc->tq->bits <= QMX_TQ_BITS1, QMX_ERR_BAD_ARG, "TQ segment needs qmx_tq_params");
+            const uint64_t d = desc->dim;
+            const uint64_t padded = desc->tq->bits == QMX_TQ_BITS1 ? (d + 7) / 8 * 8 : desc->tq->bits == QMX_TQ_BITS1_5 ? (d * 3 / 2 + 7) / 8 * 8
+                                  : desc->tq->bits == QMX_TQ_BITS2 ? (d + 3) / 4 * 4 : (d + 1) / 2 * 2;
+            const uint64_t vb = desc->tq->bits == QMX_TQ_BITS4 ? 4 : desc->tq->bits == QMX_TQ_BITS2 ? 2 : 1;
+            row_bytes = padded * vb / 8 + (desc->distance == QMX_DISTANCE_EUCLID ? 8 : 4);
+            break;
+        }
         default: row_bytes = bq_row_bytes(desc->dim, desc->bq ? desc->bq->encoding : 0u); break;   // BQ
     }
     FILE *f = fopen(vectors_path, "rb");

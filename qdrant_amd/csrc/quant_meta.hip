@@ -381,6 +381,41 @@ int32_t parse_bq(const JsonValue &root, qmx_quant_meta &m, MetaOwner &o) {
     return QMX_OK;
 }
 
+// EncodedVectorsTQ Metadata (encoded_vectors_tq.rs:33-46): {"vector_parameters", "bits": "bits4" | "bits2" | "bits1_5" | "bits1",
+// "mode": "normal" | "plus", "error_correction": null | {"shift", "scale"}, "rotation"?: "padded" | "unpadded"} (serde rename_all = snake_case)
+int32_t parse_tq(const JsonValue &root, qmx_quant_meta &m) {
+    const JsonValue *b = root.get("bits");
+    QMX_REQUIRE(b && b->kind == JsonValue::String, QMX_ERR_BAD_ARG, "metadata: \"bits\" is missing or not a string");
+    if (b->str == "bits4") m.tq.bits = QMX_TQ_BITS4;
+    else if (b->str == "bits2") m.tq.bits = QMX_TQ_BITS2;
+    else if (b->str == "bits1_5") m.tq.bits = QMX_TQ_BITS1_5;
+    else if (b->str == "bits1") m.tq.bits = QMX_TQ_BITS1;
+    else {
+        set_error("metadata: unknown TQBits \"%s\"", b->str.c_str());
+        return QMX_ERR_BAD_ARG;
+    }
+    const JsonValue *md = root.get("mode");
+    QMX_REQUIRE(md && md->kind == JsonValue::String, QMX_ERR_BAD_ARG, "metadata: \"mode\" is missing or not a string");
+    if (md->str == "normal") m.tq.plus_mode = 0;
+    else if (md->str == "plus") m.tq.plus_mode = 1;      // qmx_segment_create refuses it (TQ+ is not built): the caller keeps its CPU scorer
+    else {
+        set_error("metadata: unknown TQMode \"%s\"", md->str.c_str());
+        return QMX_ERR_BAD_ARG;
+    }
+    m.tq.rotation_unpadded = 0;                           // #[serde(default = "default_rotation")]: Padded
+    if (const JsonValue *r = root.get("rotation")) {
+        QMX_REQUIRE(r->kind == JsonValue::String, QMX_ERR_BAD_ARG, "metadata: \"rotation\" is not a string");
+        if (r->str == "padded") m.tq.rotation_unpadded = 0;
+        else if (r->str == "unpadded") m.tq.rotation_unpadded = 1;
+        else {
+            set_error("metadata: unknown TQRotation \"%s\"", r->str.c_str());
+            return QMX_ERR_BAD_ARG;
+        }
+    }
+    m.tq.invert = m.invert;
+    return QMX_OK;
+}
+
 }  // namespace
 }  // namespace qmx
 
@@ -391,7 +426,7 @@ extern "C" {
 int32_t qmx_quant_meta_parse(uint32_t dtype, const char *json, uint64_t n_bytes, qmx_quant_meta *out) {
     QMX_REQUIRE(json && out, QMX_ERR_BAD_ARG, "NULL argument");
     memset(out, 0, sizeof(*out));
-    QMX_REQUIRE(dtype == QMX_DTYPE_SQ_U8 || dtype == QMX_DTYPE_PQ || dtype == QMX_DTYPE_BQ, QMX_ERR_BAD_ARG,
+    QMX_REQUIRE(dtype == QMX_DTYPE_SQ_U8 || dtype == QMX_DTYPE_PQ || dtype == QMX_DTYPE_BQ || dtype == QMX_DTYPE_TQ, QMX_ERR_BAD_ARG,
                 "dtype %u has no quantizer metadata", dtype);
     int32_t rc = QMX_OK;
     MetaOwner *o = nullptr;
@@ -413,6 +448,7 @@ int32_t qmx_quant_meta_parse(uint32_t dtype, const char *json, uint64_t n_bytes,
         if (rc == QMX_OK) {
             if (dtype == QMX_DTYPE_SQ_U8) rc = parse_sq(root, m);
             else if (dtype == QMX_DTYPE_PQ) rc = parse_pq(root, m, *o);
+            else if (dtype == QMX_DTYPE_TQ) rc = parse_tq(root, m);
             else rc = parse_bq(root, m, *o);
         }
     } catch (const std::bad_alloc &) {

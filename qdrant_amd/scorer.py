@@ -413,7 +413,8 @@ class TurboQuantizer:
 
     def params(self) -> "F.TqParams":
         p = F.TqParams()
-        p.bits, p.rotation_unpadded, p.invert, p.plus_mode = self.bits, 1 if self.rotation_unpadded else 0, 1 if self.invert else 0, 0
+        p.bits, p.rotation_unpadded, p.invert = self.bits, 1 if self.rotation_unpadded else 0, 1 if self.invert else 0
+        p.plus_mode = 1 if getattr(self, "plus_mode", False) else 0
         return p
 
     def quantized_vector_size(self) -> int:
@@ -547,6 +548,10 @@ def load_quantizer(meta_json, dtype: int):
             cen = np.ctypeslib.as_array(C.cast(m.pq.centroids, C.POINTER(C.c_float)), (m.pq.n_centroids, m.dim)).copy()
             q = ProductQuantizer(m.dim, distance, m.pq.chunk_size, cen)
             q.invert = bool(m.pq.invert)
+            return q
+        if dtype == F.DTYPE_TQ:
+            q = TurboQuantizer(m.dim, distance, int(m.tq.bits), bool(m.tq.rotation_unpadded), bool(m.tq.invert))
+            q.plus_mode = bool(m.tq.plus_mode)
             return q
         mean = stddev = None
         if m.bq.mean:

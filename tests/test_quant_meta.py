@@ -179,3 +179,27 @@ def test_load_quantizer_builds_the_parameter_structs_from_the_file():
     assert (q.dim, q.encoding, q.invert, q.mean) == (9, F.BQ_TWO_BITS, False, None)
     q = qa.load_quantizer('{"vector_parameters":%s,"query_encoding":"Scalar8bits"}' % _vp(9, "Dot", False), F.DTYPE_BQ)
     assert (q.query_encoding, q.params().query_encoding, q.encoding) == (F.BQ_QUERY_SCALAR_8BITS, F.BQ_QUERY_SCALAR_8BITS, F.BQ_ONE_BIT)
+
+
+@pytest.mark.parametrize("bits_text,bits", [("bits4", 0), ("bits2", 1), ("bits1_5", 2), ("bits1", 3)])
+def test_tq_metadata(bits_text, bits):
+    """EncodedVectorsTQ `Metadata` (lib/quantization/src/encoded_vectors_tq.rs:33-46; TQBits / TQMode / TQRotation are
+    `#[serde(rename_all = "snake_case")]`, turboquant/mod.rs:13-100; `rotation` has a serde default: Padded)."""
+    for rotation, unp in ((None, 0), ("padded", 0), ("unpadded", 1)):
+        text = '{"vector_parameters":%s,"bits":"%s","mode":"normal","error_correction":null%s}' % (
+            _vp(768, "L2", True), bits_text, "" if rotation is None else ',"rotation":"%s"' % rotation)
+        rc, m = _parse(F.DTYPE_TQ, text)
+        assert rc == 0, F.last_error()
+        assert (m.dim, m.distance, m.invert) == (768, F.EUCLID, 1)
+        assert (m.tq.bits, m.tq.rotation_unpadded, m.tq.invert, m.tq.plus_mode) == (bits, unp, 1, 0)
+        _free(m)
+    # TQ+ documents parse (the flag says so); creating a segment from them is refused
+    text = '{"vector_parameters":%s,"bits":"%s","mode":"plus","error_correction":{"shift":[0.5],"scale":[1.5]}}' % (_vp(1, "Dot", False), bits_text)
+    rc, m = _parse(F.DTYPE_TQ, text)
+    assert rc == 0 and m.tq.plus_mode == 1
+    _free(m)
+    for bad in ('{"vector_parameters":%s,"bits":"bits3","mode":"normal"}' % _vp(4, "Dot", False),
+                '{"vector_parameters":%s,"bits":"%s"}' % (_vp(4, "Dot", False), bits_text),
+                '{"vector_parameters":%s,"bits":"%s","mode":"normal","rotation":"sideways"}' % (_vp(4, "Dot", False), bits_text)):
+        rc, m = _parse(F.DTYPE_TQ, bad)
+        assert rc == F.ERR_BAD_ARG
