@@ -183,14 +183,16 @@ def main():
 
     # bytes the dominant kernel has to read per launch: the f32 block (3072 B/row at d=768) for the exact scans; the derived copy
     # the prefilter scans (QMX_SEG_HALF_COPY: 2 B / element, QMX_SEG_SPLIT_COPY: 4 B) when that is the kernel that ran
-    elem_bytes = 2 if "scan_f16pair_kernel<true>" in kernel_symbol else 4
+    half_copy = "scan_f16pair_kernel<true>" in kernel_symbol or "scan_f16half256_kernel" in kernel_symbol
+    tile_q = 256.0 if "scan_f16half256_kernel" in kernel_symbol else 128.0            # queries per pass of the prefilter shape that ran
+    elem_bytes = 2 if half_copy else 4
     row_bytes = dim * elem_bytes
     launches_per_step = max(1, int(kl.value)) / float(max(1, args.steps))
     # the prefilter over a derived copy covers the block in TWO launches of the same kernel (the strided sixteenth of the tiles, then the rest
     # under the threshold the first one tightened): bytes and flops per launch are the per-launch AVERAGES, like kernel_ms, so that
     # achieved = sum of bytes / sum of kernel time
-    prefilter = "scan_f16pair_kernel" in kernel_symbol
-    launches_per_pass = max(1.0, launches_per_step / math.ceil(Q / 128.0)) if prefilter else 1.0
+    prefilter = "scan_f16pair_kernel" in kernel_symbol or "scan_f16half256_kernel" in kernel_symbol
+    launches_per_pass = max(1.0, launches_per_step / math.ceil(Q / tile_q)) if prefilter else 1.0
     alg_bytes = int(n * row_bytes / launches_per_pass)
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     units = Q * args.steps * (1 if strong else world)
@@ -240,6 +242,16 @@ def main():
             result["roofline_hbm_point_q16"] = {"error": repr(e)[:300]}
         finally:
             qa.set_option("no_split_scan", -1)
+    if solo and Q != 256 and copy_flag == F.SEG_HALF_COPY and queries.shape[0] >= 256 and not args.no_hbm_point:
+        # the same search at 256 queries per step: the 256-query shape of the prefilter (half the copy's bytes per query; issue-bound, not
+        # HBM-bound: more queries per second at a lower fraction of either roof)
+        try:
+            p = hbm_point(256, storage, queries, n, dim, top, local_rank, stream, lib, F, sharded, torch, bytes_per_pass=n * dim * 2)
+            tfl = 2.0 * n * dim * 256 / p["launches_per_pass"] / (p["kernel_ms"] * 1e-3) / 1e12 if p["kernel_ms"] > 0 else 0.0
+            p["mfma_f16"] = {"achieved_TFLOPs": round(tfl, 1), "peak_TFLOPs": MFMA_F16_PEAK_TFLOPS, "frac": round(tfl / MFMA_F16_PEAK_TFLOPS, 4)}
+            result["throughput_point_q256"] = p
+        except Exception as e:
+            result["throughput_point_q256"] = {"error": repr(e)[:300]}
     if solo and not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(args, rows, queries, out, counts, n, dim, Q, top, lib, qh, F, qa, np, torch)
     backend.close()
@@ -270,7 +282,7 @@ def main():
 # ------------------------------------------------------------------------------------------------------------------------
 # C2 helpers
 # ------------------------------------------------------------------------------------------------------------------------
-def hbm_point(Qh, storage, queries, n, dim, top, local_rank, stream, lib, F, sharded, torch):
+def hbm_point(Qh, storage, queries, n, dim, top, local_rank, stream, lib, F, sharded, torch, bytes_per_pass=None):
     backend = sharded.HipBackend(storage, Qh, local_rank, stream)
     try:
         F.check(lib.qmx_query_set_timing(backend.qh, 1))
@@ -290,9 +302,10 @@ def hbm_point(Qh, storage, queries, n, dim, top, local_rank, stream, lib, F, sha
         wall = time.perf_counter() - t0
         F.check(lib.qmx_query_timing(backend.qh, C.byref(ms), C.byref(nl)))
         kernel_ms = ms.value / max(1, nl.value)
-        alg = n * dim * 4
+        per_step = max(1.0, nl.value / float(steps))            # launches per pass over the block (the prefilter over a derived copy: 2)
+        alg = int((bytes_per_pass if bytes_per_pass else n * dim * 4) / per_step)
         gbps = alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        return {"batch": Qh, "kernel": F.last_kernel(backend.qh), "kernel_ms": round(kernel_ms, 4), "launches_timed": int(nl.value),
+        return {"batch": Qh, "kernel": F.last_kernel(backend.qh), "kernel_ms": round(kernel_ms, 4), "launches_timed": int(nl.value), "launches_per_pass": per_step,
                 "algorithmic_bytes_per_launch": alg, "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(gbps / HBM_PEAK_GBPS, 4), "qps": round(Qh * steps / wall, 1), "ms_per_step": round(wall / steps * 1e3, 4)}
     finally:
@@ -368,9 +381,10 @@ def _roofline(n, dim, kernel_ms, alg_bytes, achieved_gbps, launches, launches_pe
     do 2 * dim flops per (row, query) on the f32 matrix cores and cross over to the MFMA ceiling; the prefilter of scan_split.hip
     (more than 64 queries) streams a derived f16 copy of the block and multiplies on the f16 matrix cores (1 or 3 products per element)."""
     per_pass = Q / max(1.0, round(launches_per_step / launches_per_pass))   # queries one pass over the block serves: MEASURED launches per step, not a dispatch guess
-    split = "scan_f16pair_kernel" in kernel_symbol or "scan_f32_split_kernel" in kernel_symbol
-    products = 1 if "scan_f16pair_kernel<true>" in kernel_symbol else 3 if split else 1
-    flops = 2.0 * n * dim * (128 if split else per_pass) * products / launches_per_pass     # (the prefilter multiplies a padded 128-query tile)
+    half256 = "scan_f16half256_kernel" in kernel_symbol
+    split = "scan_f16pair_kernel" in kernel_symbol or "scan_f32_split_kernel" in kernel_symbol or half256
+    products = 1 if ("scan_f16pair_kernel<true>" in kernel_symbol or half256) else 3 if split else 1
+    flops = 2.0 * n * dim * ((256 if half256 else 128) if split else per_pass) * products / launches_per_pass     # (the prefilter multiplies a padded 128- / 256-query tile)
     tflops = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
     mfma_peak = MFMA_F16_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
     hbm_frac, mfma_frac = achieved_gbps / HBM_PEAK_GBPS, tflops / mfma_peak

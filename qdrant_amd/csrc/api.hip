@@ -47,7 +47,7 @@ int32_t hip_status(hipError_t e, const char *what, const char *file, int line) {
 
 // ---- kernel-path options: the environment is read once, here, at load time ----
 static const char *const g_option_names[OPT_COUNT] = {"no_mfma_scan", "no_mfma16", "no_mfma16_q64", "no_prescan", "prescan_shift", "hnsw_no_packed_l0",
-                                                     "hnsw_pq_lds_lut", "hnsw_log_cap", "bq_lanes8", "mfma_no_nt", "mfma_no_fast", "no_pq_tiled", "no_split_scan", "split_min_queries", "no_pq_pair", "debug"};
+                                                     "hnsw_pq_lds_lut", "hnsw_log_cap", "bq_lanes8", "mfma_no_nt", "mfma_no_fast", "no_pq_tiled", "no_split_scan", "split_min_queries", "no_split256", "no_pq_pair", "debug"};
 struct OptionTable {
     std::atomic<int64_t> v[OPT_COUNT];
     int64_t initial[OPT_COUNT];
@@ -1382,7 +1382,8 @@ static int32_t split_stage(qmx_query *q, const char *what) {
     return e == hipSuccess ? QMX_OK : QMX_ERR_OTHER;
 }
 
-constexpr uint32_t SPLIT_QT = 128;          // queries per pass of the split prefilter (scan_split.hip)
+constexpr uint32_t SPLIT_QT = 128;          // queries per pass of the split prefilter (scan_split.hip) ...
+constexpr uint32_t SPLIT_QT_MAX = 256;      // ... and of its 256-query shape over a half copy (batches of more than 128 queries)
 constexpr uint32_t SPLIT_CAND_CAP = 32768;  // candidate keys per query and pass (expected: ~1000 k)
 constexpr uint32_t SPLIT_VCAP = 512;        // rows per query that get an exact score (expected: ~k; the one-product mode's band holds more)
 // |approximate - exact| <= band * |q| * max |row|, worst case, every term at its bound:
@@ -1422,12 +1423,14 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
     const bool split_dims = s->dtype == QMX_DTYPE_F32 && mfma_scan_ok(s) && mfma16_dim_ok(64, s->dim) && !option(OPT_NO_MFMA16);
     const bool split = split_dims && (q64 || (s->d_rows_split && q->nq >= (uint32_t)std::max<int64_t>(1, option(OPT_SPLIT_MIN_QUERIES)))) && s->split_stats &&
                        !d_ids && top <= MAX_TOP_FAST && n_cand >= (1u << 18) && s->dim % 128 == 0 && s->row_stride % 16 == 0 && !option(OPT_NO_SPLIT_SCAN);
-    const uint32_t TQ = split ? SPLIT_QT : q64 ? MAX_QT_TOPK : q32 ? MAX_QT_MFMA : tile_qt(s);
+    // the 256-query shape halves the bytes streamed per query; a batch that does not fill it is served by the 128-query shape (less matrix work)
+    const uint32_t split_qt = (split && s->d_rows_split && s->split_half && q->nq > SPLIT_QT && !option(OPT_NO_SPLIT256)) ? SPLIT_QT_MAX : SPLIT_QT;
+    const uint32_t TQ = split ? split_qt : q64 ? MAX_QT_TOPK : q32 ? MAX_QT_MFMA : tile_qt(s);
     const uint32_t ptop_max = std::min<uint32_t>(top, MAX_TOP_FAST);
     const uint32_t n_pass = (top + MAX_TOP_FAST - 1) / MAX_TOP_FAST;
     QMX_TRY(q->partial.reserve((size_t)grid_cap * std::min<uint32_t>(TQ, MAX_QT_TOPK) * ptop_max * sizeof(uint64_t)));
     if (n_pass > 1) QMX_TRY(q->bounds.reserve((size_t)TQ * sizeof(uint64_t)));
-    QMX_TRY(q->gthr.reserve((size_t)std::max<uint32_t>(q->nq_padded, SPLIT_QT) * sizeof(uint64_t)));
+    QMX_TRY(q->gthr.reserve((size_t)std::max<uint32_t>(q->nq_padded, SPLIT_QT_MAX) * sizeof(uint64_t)));
     // ---- split passes first (their verification and, if ever needed, the exact fallback run once for all of them afterwards) ----
     std::vector<std::pair<uint32_t, uint32_t>> split_tiles;      // (tile0, nq_tile)
     float *sp_qnorm = nullptr, *sp_thr = nullptr, *sp_band = nullptr, *sp_scales = nullptr;
@@ -1435,13 +1438,13 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
     if (split) {
         QMX_TRY(q->sp_bq.reserve(split_query_bytes(s->dim)));
         QMX_TRY(q->sp_f32.reserve(1024 * sizeof(float)));
-        QMX_TRY(q->sp_cand.reserve((size_t)SPLIT_QT * SPLIT_CAND_CAP * sizeof(uint64_t)));
-        QMX_TRY(q->sp_cnt.reserve((size_t)SPLIT_QT * 4));
+        QMX_TRY(q->sp_cand.reserve((size_t)split_qt * SPLIT_CAND_CAP * sizeof(uint64_t)));
+        QMX_TRY(q->sp_cnt.reserve((size_t)SPLIT_QT_MAX * 4));
         if (s->d_rows_split) QMX_TRY(q->sp_wl.reserve(split_wlists_bytes(s->num_cus)));
         QMX_TRY(q->sp_ver.reserve((size_t)q->nq * (SPLIT_VCAP + 1) * 4));
         QMX_TRY(q->sp_vscores.reserve((size_t)q->nq * SPLIT_VCAP * 4));
         float *f = (float *)q->sp_f32.p;
-        sp_qnorm = f; sp_thr = f + 128; sp_band = f + 256; sp_scales = f + 384; sp_overflow = (int *)(f + 392);
+        sp_qnorm = f; sp_thr = f + 256; sp_band = f + 512; sp_scales = f + 768; sp_overflow = (int *)(f + 776);
         // the sample: every (n_cand / S)-th row, S = n_cand / 256 (at least 8192): its k-th best leaves ~256 k candidates per query to the
         // main pass, at 1 / 256 of the pass's row traffic for the sample's exact scores (measured on C2: 1/128 .. 1/512 are equally good)
         // ("prescan_shift" - 2: the option of the exact scans' prefix pre-scan, 10 by default, moves this sample with it)
@@ -1492,11 +1495,12 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
             // 2. the batch's queries split into f16 pairs; thresholds and bands in accumulator / score units
             const float row_scale = split_row_scale(s->row_maxabs);
             const int half = s->split_half ? 1 : 0;
+            const uint32_t tqt = nq_tile > SPLIT_QT ? SPLIT_QT_MAX : SPLIT_QT;      // the shape of THIS tile (a remainder of <= 128 queries takes the 128 shape)
             QMX_TRY(launch_split_pack_queries(q->stream, (const float *)q->enc.p + (size_t)tile0 * s->dim, nq_tile, s->dim, row_scale, (uint32_t *)(sp_scales + 4),
-                                              sp_qnorm, sp_scales, q->sp_bq.p, half));
+                                              sp_qnorm, sp_scales, q->sp_bq.p, half, tqt));
             QMX_TRY(launch_split_thresholds(q->stream, gthr, sp_qnorm, nq_tile, split_rel_band(half, s->dim), s->row_norm_max, sp_scales, sp_thr,
-                                            sp_band));
-            QMX_HIP(hipMemsetAsync(q->sp_cnt.p, 0, (size_t)SPLIT_QT * 4, q->stream));
+                                            sp_band, tqt));
+            QMX_HIP(hipMemsetAsync(q->sp_cnt.p, 0, (size_t)SPLIT_QT_MAX * 4, q->stream));
             QMX_TRY(split_stage(q, "pack + thresholds"));
             // 3. the approximate scan of the whole block
             // over a derived copy in two launches: the strided sixteenth of the tiles first, whose k-th best approximate score tightens the
@@ -1505,12 +1509,12 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
                 size_t slot = 0;
                 if (timed) QMX_TRY(timing_begin(q, &slot));
                 QMX_TRY(launch_scan_f32_split(q->stream, a, q->sp_bq.p, row_scale, sp_scales, sp_thr, (uint64_t *)q->sp_cand.p, (uint32_t *)q->sp_cnt.p,
-                                              SPLIT_CAND_CAP, s->num_cus, s->d_rows_split, half, q->sp_wl.p, phase));
+                                              SPLIT_CAND_CAP, s->num_cus, s->d_rows_split, half, q->sp_wl.p, phase, tqt));
                 q->last_kernel = g_last_kernel;
                 if (timed) QMX_TRY(timing_end(q, slot));
                 if (s->d_rows_split)
                     QMX_TRY(launch_split_regroup(q->stream, a, q->sp_wl.p, s->num_cus, (uint64_t *)q->sp_cand.p, (uint32_t *)q->sp_cnt.p, SPLIT_CAND_CAP,
-                                                 sp_overflow, phase));
+                                                 sp_overflow, phase, tqt));
                 if (phase == 1)
                     QMX_TRY(launch_split_refine(q->stream, (const uint64_t *)q->sp_cand.p, (const uint32_t *)q->sp_cnt.p, SPLIT_CAND_CAP, sp_band, nq_tile, top,
                                                 sp_scales, sp_thr));

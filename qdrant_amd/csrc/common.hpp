@@ -36,6 +36,7 @@ enum Option {
     OPT_NO_PQ_TILED,          // PQ scan on the one-row-per-lane kernel
     OPT_NO_SPLIT_SCAN,        // f32 scans of more than 64 queries keep the exact chain-major kernel (no f16-split prefilter + verification)
     OPT_SPLIT_MIN_QUERIES,    // with a derived copy of the block: batches of at least this many queries take the prefilter (default 1: all)
+    OPT_NO_SPLIT256,          // batches of more than 128 queries over a half copy: keep the 128-query shape of the prefilter
     OPT_NO_PQ_PAIR,           // PQ score_internal recomputes the centroid distances instead of reading the pair table
     OPT_DEBUG,                // log dropped stale HIP errors
     OPT_COUNT

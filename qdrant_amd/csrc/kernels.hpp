@@ -238,16 +238,16 @@ size_t split_query_bytes(uint32_t dim);
 float split_row_scale(float row_maxabs);
 int32_t launch_split_row_stats(hipStream_t st, const void *rows, uint64_t row_stride, uint64_t n, uint32_t dim, uint32_t *d_stats);
 int32_t launch_split_pack_queries(hipStream_t st, const float *d_q, uint32_t nq, uint32_t dim, float row_scale, uint32_t *d_stats, float *d_qnorm,
-                                  float *d_scales, void *d_bq, int half);
+                                  float *d_scales, void *d_bq, int half, uint32_t qt);
 int32_t launch_split_thresholds(hipStream_t st, const uint64_t *d_gthr, const float *d_qnorm, uint32_t nq, float rel_band, float row_norm_max,
-                                const float *d_scales, float *d_thr, float *d_band);
+                                const float *d_scales, float *d_thr, float *d_band, uint32_t qt);
 int32_t launch_scan_f32_split(hipStream_t st, const ScanArgs &a, const void *d_bq, float row_scale, const float *d_scales, const float *d_thr,
-                              uint64_t *d_cand, uint32_t *d_cand_cnt, uint32_t cap, int num_cus, const void *d_rows_split, int half, void *d_wlists, uint32_t phase);
+                              uint64_t *d_cand, uint32_t *d_cand_cnt, uint32_t cap, int num_cus, const void *d_rows_split, int half, void *d_wlists, uint32_t phase, uint32_t qt);
 int32_t launch_split_refine(hipStream_t st, const uint64_t *d_cand, const uint32_t *d_cand_cnt, uint32_t cap, const float *d_band, uint32_t nq, uint32_t top,
                             const float *d_scales, float *d_thr);
 size_t split_wlists_bytes(int num_cus);
 int32_t launch_split_regroup(hipStream_t st, const ScanArgs &a, const void *d_wlists, int num_cus, uint64_t *d_cand, uint32_t *d_cand_cnt, uint32_t cap,
-                             int *d_overflow, uint32_t phase);
+                             int *d_overflow, uint32_t phase, uint32_t qt);
 size_t split_copy_bytes(uint64_t n, uint32_t dim, int half);
 int32_t launch_split_copy(hipStream_t st, const void *rows, uint64_t row_stride, uint64_t n, uint32_t dim, float row_scale, void *d_out, int half);
 int32_t launch_split_select(hipStream_t st, const uint64_t *d_cand, const uint32_t *d_cand_cnt, uint32_t cap, const float *d_band, uint32_t nq, uint32_t top,

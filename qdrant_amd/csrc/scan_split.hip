@@ -27,6 +27,8 @@
 //   LDS units are swizzled (row ^ 2 kq) so that both the 8-byte stores of the loaders and the 16-byte loads of the MFMA lanes are
 //   conflict-free in the bank groups of /opt/skills/guides/MI355X_MICROARCH.md (LDS table).
 // Roofline: HBM (3072 B per row at d = 768, once); matrix time 3 x 2 x 128 x 768 flop per row = 2.4 ms per 10 M rows at the f16 peak.
+#include <type_traits>
+
 #include "scan_common.hpp"
 
 namespace qmx {
@@ -37,6 +39,7 @@ typedef float f32x4s __attribute__((ext_vector_type(4)));
 
 constexpr int SP_BM = 256;            // rows per tile
 constexpr int SP_QT = 128;            // queries per pass
+constexpr int SP_QT_MAX = 256;        // ... of the 256-query shape over the half copy (scan_f16half256_kernel)
 constexpr int SP_THREADS = 768;          // 8 consumer waves (matrix cores) + 4 producer waves (HBM stream, f32 -> f16 pairs): 2 + 1 per SIMD
 constexpr int SP_CONSUMERS = 8;
 constexpr int SP_A_UNITS = SP_BM * 2 * 4;     // 16-byte units of one A chunk buffer (256 rows x {h, l} x 4 k-groups) = 32 KB
@@ -102,10 +105,11 @@ __global__ void sp_scales_kernel(const uint32_t *stats, float row_scale, float *
 }
 // one thread per 16-byte unit: bq[kc][nt][hl][kq][n ^ 2 kq] = 8 halfs, k = 32 kc + 8 kq + e, query 16 nt + n (zero beyond nq)
 // half != 0 (the one-product mode): a chunk is 64 floats, the two unit planes hold the high parts of its two 32-float halves
-__global__ void sp_pack_queries_kernel(const float *q, uint32_t nq, uint32_t dim, const float *scales, uint4 *bq, int half) {
+__global__ void sp_pack_queries_kernel(const float *q, uint32_t nq, uint32_t dim, const float *scales, uint4 *bq, int half, uint32_t qt) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (dim / 32) * SP_QT * 4) return;
-    const uint32_t k32 = gid / (SP_QT * 4), r = gid % (SP_QT * 4);          // 32-float group of the row
+    if (gid >= (dim / 32) * qt * 4) return;
+    const uint32_t b_units = qt * 8;                                    // 16-byte units of one chunk of the tile (128 queries: SP_B_UNITS)
+    const uint32_t k32 = gid / (qt * 4), r = gid % (qt * 4);            // 32-float group of the row
     const uint32_t nt = r / 64, kq = (r / 16) % 4, n = r % 16;
     const uint32_t qi = nt * 16 + n;
     const float scale = scales[0];
@@ -117,10 +121,10 @@ __global__ void sp_pack_queries_kernel(const float *q, uint32_t nq, uint32_t dim
         l[e] = (_Float16)(x - (float)h[e]);
     }
     if (half) {
-        bq[(uint64_t)(k32 / 2) * SP_B_UNITS + sp_unit(nt, k32 & 1u, kq, n)] = *reinterpret_cast<const uint4 *>(&h);
+        bq[(uint64_t)(k32 / 2) * b_units + sp_unit(nt, k32 & 1u, kq, n)] = *reinterpret_cast<const uint4 *>(&h);
         return;
     }
-    uint4 *chunk = bq + (uint64_t)k32 * SP_B_UNITS;
+    uint4 *chunk = bq + (uint64_t)k32 * b_units;
     chunk[sp_unit(nt, 0, kq, n)] = *reinterpret_cast<const uint4 *>(&h);
     chunk[sp_unit(nt, 1, kq, n)] = *reinterpret_cast<const uint4 *>(&l);
 }
@@ -128,8 +132,7 @@ __global__ void sp_pack_queries_kernel(const float *q, uint32_t nq, uint32_t dim
 // the buffers overflow, the exact scan takes over).  band[q] = rel_band * row_norm_max * |q| (score units).
 __global__ void sp_thresholds_kernel(const uint64_t *gthr, const float *qnorm, uint32_t nq, float rel_band, float row_norm_max, const float *scales,
                                      float *thr, float *band) {
-    const uint32_t q = threadIdx.x;
-    if (q >= SP_QT) return;
+    const uint32_t q = threadIdx.x;                   // blockDim.x = queries of the tile (128 | 256)
     if (q >= nq) { thr[q] = __builtin_inff(); band[q] = 0.0f; return; }
     const float b = rel_band * row_norm_max * qnorm[q];
     band[q] = b;
@@ -145,6 +148,11 @@ __device__ __forceinline__ void sp_glds16(const unsigned char *src, uint32_t lan
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(lane_off), "s"(src), "s"(lds_dst) : "memory");
+}
+
+// the same without saving m0 (the kernel that uses it declares m0 clobbered: no other user of m0 in it)
+__device__ __forceinline__ void sp_glds16_m0(const unsigned char *src, uint32_t lane_off, uint32_t lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(lane_off), "s"(src), "s"(lds_dst) : "memory");   // (m0 is a reserved register: the compiler neither allocates nor tracks it)
 }
 
 struct SplitArgs {
@@ -561,13 +569,222 @@ __global__ __launch_bounds__(SP3_THREADS, 1) void scan_f16pair_kernel(const Scan
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // nothing may land in LDS after the block is gone
 }
 
+// =====================================================================================================================================
+// 256 queries per pass over the HALF copy.  The pass above is HBM-bound (6.05 TB/s of the ~6.3 the part delivers): the only way to more
+// queries per second is fewer bytes per query, i.e. more queries per pass.  Here a stage is 128 rows (16 KiB from HBM: half of a 256-row
+// tile of the copy, whose image is tile-of-16 major) against 256 queries (32 KiB from L2): the same 64 x 64 block of accumulators and the same
+// 32 matrix instructions per wave and stage as above for half the HBM bytes.  8 waves = 2 (row halves) x 4 (query quarters); rings of three
+// stages each (rows 48 KiB + queries 96 KiB = 144 KiB of LDS); per stage a wave requests [4 KiB of the queries, 2 KiB of the rows] of
+// stage g + 2: six copies as above, so the same `s_waitcnt vmcnt(6)` means "stage g + 1 has landed".
+// =====================================================================================================================================
+#ifndef SP4_DBG
+#define SP4_DBG 0          // QMX_TUNING builds: 1 = no copies at all (matrix loop alone), 3 = no query copies (wrong results)
+#endif
+constexpr int SP4_BM = 128;
+constexpr int SP4_QT = 256;
+constexpr int SP4_A_UNITS = SP4_BM * 2 * 4;                  // 1024 units = 16 KiB
+constexpr int SP4_B_UNITS = SP4_QT * 2 * 4;                  // 2048 units = 32 KiB
+constexpr int SP4_RING = 3;
+constexpr int SP4_LDS = SP4_RING * (SP4_A_UNITS + SP4_B_UNITS) * 16;      // 144 KiB
+
+__global__ __launch_bounds__(SP3_THREADS, 1) void scan_f16half256_kernel(const ScanArgs a, const SplitArgs s) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint4 *lds = reinterpret_cast<uint4 *>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint64_t all_tiles = (a.n_cand + SP4_BM - 1) / SP4_BM;
+    const uint64_t n_tiles = split_phase_tiles(all_tiles, s.phase);
+    const uint32_t nch = s.nchunks;
+    const uint64_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const uint32_t phase = s.phase;
+    auto tile_of = [&](uint64_t j) -> uint64_t { return phase == 0 ? j : phase == 1 ? j * SP_PHASE_STRIDE : j + j / (SP_PHASE_STRIDE - 1) + 1; };
+    if (my_tiles == 0) {
+        if (lane == 0) s.wcnt[blockIdx.x * (SP3_THREADS / 64) + (uint32_t)w] = 0;
+        return;
+    }
+    const uint32_t wm = (uint32_t)w & 1u, wn = (uint32_t)w >> 1;
+    const uint32_t kq_r = (uint32_t)lane >> 4, m_r = (uint32_t)lane & 15u;
+    const uint32_t a_rd = sp_unit(wm * 4, 0, kq_r, m_r), b_rd = sp_unit(wn * 4, 0, kq_r, m_r);
+    float thr[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) thr[nt] = s.thr[wn * 64 + nt * 16 + m_r];
+    const float inv_scale = s.scales[2];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // from here on the kernel counts its vector-memory traffic itself
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(sp_lds_byte *)smem_raw;
+    const uint32_t lane_off = (uint32_t)lane * 16u;
+    uint4 *b_lds = lds + SP4_RING * SP4_A_UNITS;
+    // The two copy streams advance by plain pointer increments (a stage of the rows is 32 KiB further in the copy, the tile's image being
+    // contiguous over the K-chunks; the queries wrap after nch stages); the tile's address is computed once per tile.  The scalar unit
+    // shares the issue port with the matrix instructions: ~90 scalar instructions per stage cost as much as the 32 MFMAs themselves.
+    uint64_t ra_it = 0;
+    uint32_t ra_kc = 0, ra_slot = 0, rb_kc = 0, rb_slot = 0;
+    auto uniform_ptr = [&](uint64_t v) {
+        return reinterpret_cast<const unsigned char *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
+                                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v));
+    };
+    auto tile_ptr = [&](uint64_t j) {      // first stage of the j-th tile of this block: half (tile & 1) of the copy's 256-row tile tile / 2
+        const uint64_t tile = tile_of(blockIdx.x + j * gridDim.x);
+        return uniform_ptr((uint64_t)(uintptr_t)(s.rows_split + (tile >> 1) * nch * SP3_A_UNITS + (tile & 1) * SP4_A_UNITS) + (uint32_t)w * 2048u);
+    };
+    const unsigned char *ra_cur = tile_ptr(0);
+    const unsigned char *const rb_first = uniform_ptr((uint64_t)(uintptr_t)s.bq + (uint32_t)w * 4096u);
+    const unsigned char *rb_cur = rb_first;
+    const unsigned char *ra_src = nullptr, *rb_src = nullptr;
+    uint32_t ra_dst = 0, rb_dst = 0;
+    const uint32_t ra_dst0 = lds0 + (uint32_t)w * 2048u, rb_dst0 = lds0 + SP4_RING * SP4_A_UNITS * 16u + (uint32_t)w * 4096u;
+    auto rows_begin = [&]() {
+        ra_src = ra_cur;
+        ra_dst = ra_dst0 + ra_slot * (SP4_A_UNITS * 16u);
+        ra_slot = ra_slot + 1 == SP4_RING ? 0 : ra_slot + 1;
+        if (ra_kc + 1 < nch) { ++ra_kc; ra_cur += SP3_A_UNITS * 16; }
+        else if (ra_it + 1 < my_tiles) { ra_kc = 0; ++ra_it; ra_cur = tile_ptr(ra_it); }
+    };
+    auto rows_piece = [&](int i) {
+#if SP4_DBG != 1
+        sp_glds16_m0(ra_src + i * 1024, lane_off, ra_dst + i * 1024);
+#endif
+    };
+    auto queries_begin = [&]() {
+        rb_src = rb_cur;
+        rb_dst = rb_dst0 + rb_slot * (SP4_B_UNITS * 16u);
+        rb_slot = rb_slot + 1 == SP4_RING ? 0 : rb_slot + 1;
+        if (rb_kc + 1 == nch) { rb_kc = 0; rb_cur = rb_first; }
+        else { ++rb_kc; rb_cur += SP4_B_UNITS * 16; }
+    };
+    auto queries_piece = [&](int i) {
+#if SP4_DBG != 1 && SP4_DBG != 3
+        sp_glds16_m0(rb_src + i * 1024, lane_off, rb_dst + i * 1024);
+#endif
+    };
+    auto request_stage = [&]() {
+        queries_begin();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) queries_piece(i);
+        rows_begin();
+        rows_piece(0);
+        rows_piece(1);
+    };
+    request_stage();                                      // stage 0
+    request_stage();                                      // stage 1
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // stage 0 has landed
+    sp_stage_barrier();
+    uint32_t slot = 0;
+    f32x4s acc[4][4];
+    uint4 *const wl = s.wlist + (uint64_t)(blockIdx.x * (SP3_THREADS / 64) + (uint32_t)w) * s.wcap;
+    uint32_t wcount = 0;
+    auto epilogue = [&](uint64_t tile) {
+        const uint32_t row0 = (uint32_t)(tile * SP4_BM) + wm * 64 + 4 * kq_r;
+        const uint32_t n_rows32 = (uint32_t)a.n_cand;
+        bool maybe = false;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            float mx = -__builtin_inff();
+            bool nan = false;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    mx = __builtin_fmaxf(mx, acc[mt][nt][j]);
+                    nan = nan || acc[mt][nt][j] != acc[mt][nt][j];
+                }
+            maybe = maybe || !(mx < thr[nt]) || nan;
+        }
+        if (!__ballot(maybe)) return;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const uint32_t q = wn * 64 + (uint32_t)nt * 16 + m_r;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = acc[mt][nt][j];
+                    const uint32_t row = row0 + (uint32_t)mt * 16 + (uint32_t)j;
+                    const bool c = !(v < thr[nt]) && row < n_rows32 && q < s.nq;
+                    const uint64_t hits = __ballot(c);
+                    if (hits) {
+                        const uint32_t at = wcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u));
+                        if (c && at < s.wcap) {
+                            const uint64_t key = make_key(v * inv_scale, row);
+                            wl[at] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), q, 0u);
+                        }
+                        wcount += (uint32_t)__builtin_popcountll(hits);
+                    }
+                }
+            }
+    };
+    // Operands are read ONE STAGE AHEAD: a stage's barrier sits after its third row tile (when the copies of stage g + 1 are known to have landed:
+    // everything but the five requests this stage has issued by then), and the fourth tile is multiplied while the operands of stage g + 1
+    // are already being read - the burst of 8 waves x 12 ds_read_b128 after a barrier no longer stands in front of idle matrix pipes.
+    // Slot (g + 2) % 3 is free for the requests of stage g: its last readers finished before the barrier of stage g - 1.
+    half8 bh[2][4], bl[2][4], ah[2], al[2];
+    auto read_b = [&](auto Pc, uint32_t from_slot) {
+        constexpr int P = decltype(Pc)::value;
+        const uint4 *bb = b_lds + from_slot * SP4_B_UNITS + b_rd;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bl[P][nt] = *reinterpret_cast<const half8 *>(bb + nt * 128 + 64);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bh[P][nt] = *reinterpret_cast<const half8 *>(bb + nt * 128);
+    };
+    auto read_a = [&](int set, uint32_t from_slot, int mt) {
+        const uint4 *ab = lds + from_slot * SP4_A_UNITS + a_rd + mt * 128;
+        al[set] = *reinterpret_cast<const half8 *>(ab + 64);
+        ah[set] = *reinterpret_cast<const half8 *>(ab);
+    };
+    read_a(0, 0, 0);
+    read_b(std::integral_constant<int, 0>{}, 0);
+    auto stage = [&](auto Pc) {
+        constexpr int P = decltype(Pc)::value;
+        queries_begin();                                  // stage g + 2 -> the slots stage g - 1 was read from
+        rows_begin();
+        const uint32_t next_slot = slot + 1 == SP4_RING ? 0 : slot + 1;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int cur = mt & 1, nxt = cur ^ 1;
+            if (mt < 3) read_a(nxt, slot, mt + 1);
+            else {
+                read_a(nxt, next_slot, 0);                // (mt = 3 uses set 1: set 0 is free for the next stage's first tile)
+                read_b(std::integral_constant<int, P ^ 1>{}, next_slot);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cur], bl[P][nt], acc[mt][nt], 0, 0, 0);
+            if (mt == 0) { queries_piece(0); queries_piece(1); }
+            if (mt == 1) { queries_piece(2); queries_piece(3); }
+            if (mt == 2) rows_piece(0);
+            if (mt == 3) rows_piece(1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur], bh[P][nt], acc[mt][nt], 0, 0, 0);
+            if (mt == 2) {
+                asm volatile("s_waitcnt vmcnt(5)" ::: "memory");     // stage g + 1 has landed (this stage has requested five copies so far)
+                sp_stage_barrier();
+            }
+        }
+        slot = next_slot;
+    };
+    for (uint64_t it = 0; it < my_tiles; ++it) {
+        if (it) epilogue(tile_of(blockIdx.x + (it - 1) * gridDim.x));
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4s){0.f, 0.f, 0.f, 0.f};
+        for (uint32_t kc = 0; kc < nch; kc += 2) {        // (dim is a multiple of 128: an even number of 64-float stages)
+            stage(std::integral_constant<int, 0>{});
+            stage(std::integral_constant<int, 1>{});
+        }
+    }
+    epilogue(tile_of(blockIdx.x + (my_tiles - 1) * gridDim.x));
+    if (lane == 0) s.wcnt[blockIdx.x * (SP3_THREADS / 64) + (uint32_t)w] = wcount;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // nothing may land in LDS after the block is gone
+}
+
 // per-wave candidate lists -> per-query lists (what sp_select_kernel reads), deleted rows dropped.  One block per RG_LISTS wave lists: count per
 // query in LDS, reserve the block's range of every query's list with ONE global atomic per query, then place.
 constexpr int RG_LISTS = 16;
 __global__ __launch_bounds__(256) void sp_regroup_kernel(const uint4 *wlist, const uint32_t *wcnt, uint32_t wcap, uint32_t n_lists, DeletedView del,
                                                          uint64_t *cand, uint32_t *cand_cnt, uint32_t cap, int *overflow) {
-    __shared__ uint32_t hist[SP_QT], base[SP_QT];
-    if (threadIdx.x < SP_QT) hist[threadIdx.x] = 0;
+    __shared__ uint32_t hist[SP_QT_MAX], base[SP_QT_MAX];
+    if (threadIdx.x < SP_QT_MAX) hist[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t l0 = blockIdx.x * RG_LISTS, l1 = l0 + RG_LISTS < n_lists ? l0 + RG_LISTS : n_lists;
     for (int pass = 0; pass < 2; ++pass) {
@@ -588,7 +805,7 @@ __global__ __launch_bounds__(256) void sp_regroup_kernel(const uint4 *wlist, con
             }
         }
         __syncthreads();
-        if (pass == 0 && threadIdx.x < SP_QT) {
+        if (pass == 0 && threadIdx.x < SP_QT_MAX) {
             const uint32_t c = hist[threadIdx.x];
             base[threadIdx.x] = c ? atomicAdd(&cand_cnt[threadIdx.x], c) : 0;
             hist[threadIdx.x] = 0;
@@ -749,7 +966,7 @@ bool split_scan_ok(const ScanArgs &a) {
 }
 size_t split_wlists_counts_bytes(int num_cus) { return ((size_t)num_cus * (SP3_THREADS / 64) * 4 + 255) / 256 * 256; }
 size_t split_wlists_bytes(int num_cus) { return split_wlists_counts_bytes(num_cus) + (size_t)num_cus * (SP3_THREADS / 64) * SP_WCAP * 16; }
-size_t split_query_bytes(uint32_t dim) { return (size_t)(dim / 32) * SP_B_UNITS * 16; }   // (the half mode needs half of it)
+size_t split_query_bytes(uint32_t dim) { return (size_t)(dim / 32) * SP4_B_UNITS * 16; }   // (sized for the 256-query tile; the half mode needs half of it)
 
 int32_t launch_split_row_stats(hipStream_t st, const void *rows, uint64_t row_stride, uint64_t n, uint32_t dim, uint32_t *d_stats) {
     if (n == 0) return QMX_OK;
@@ -769,20 +986,20 @@ float split_row_scale(float row_maxabs) {
 
 // queries (preprocessed f32, [nq][dim] contiguous) -> bq, qnorm, scales.  d_stats: one zeroed u32.
 int32_t launch_split_pack_queries(hipStream_t st, const float *d_q, uint32_t nq, uint32_t dim, float row_scale, uint32_t *d_stats, float *d_qnorm,
-                                  float *d_scales, void *d_bq, int half) {
+                                  float *d_scales, void *d_bq, int half, uint32_t qt) {
     ::qmx::clear_stale_error();
     QMX_HIP(hipMemsetAsync(d_stats, 0, 4, st));
     hipLaunchKernelGGL(sp_query_stats_kernel, dim3(nq), dim3(256), 0, st, d_q, nq, dim, d_stats, d_qnorm);
     hipLaunchKernelGGL(sp_scales_kernel, dim3(1), dim3(1), 0, st, d_stats, row_scale, d_scales);
-    const uint32_t units = (dim / 32) * SP_QT * 4;
-    hipLaunchKernelGGL(sp_pack_queries_kernel, dim3((units + 255) / 256), dim3(256), 0, st, d_q, nq, dim, d_scales, (uint4 *)d_bq, half);
+    const uint32_t units = (dim / 32) * qt * 4;
+    hipLaunchKernelGGL(sp_pack_queries_kernel, dim3((units + 255) / 256), dim3(256), 0, st, d_q, nq, dim, d_scales, (uint4 *)d_bq, half, qt);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }
 int32_t launch_split_thresholds(hipStream_t st, const uint64_t *d_gthr, const float *d_qnorm, uint32_t nq, float rel_band, float row_norm_max,
-                                const float *d_scales, float *d_thr, float *d_band) {
+                                const float *d_scales, float *d_thr, float *d_band, uint32_t qt) {
     ::qmx::clear_stale_error();
-    hipLaunchKernelGGL(sp_thresholds_kernel, dim3(1), dim3(SP_QT), 0, st, d_gthr, d_qnorm, nq, rel_band, row_norm_max, d_scales, d_thr, d_band);
+    hipLaunchKernelGGL(sp_thresholds_kernel, dim3(1), dim3(qt), 0, st, d_gthr, d_qnorm, nq, rel_band, row_norm_max, d_scales, d_thr, d_band);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }
@@ -796,15 +1013,19 @@ int32_t launch_split_copy(hipStream_t st, const void *rows, uint64_t row_stride,
 }
 
 int32_t launch_scan_f32_split(hipStream_t st, const ScanArgs &a, const void *d_bq, float row_scale, const float *d_scales, const float *d_thr,
-                              uint64_t *d_cand, uint32_t *d_cand_cnt, uint32_t cap, int num_cus, const void *d_rows_split, int half, void *d_wlists, uint32_t phase) {
+                              uint64_t *d_cand, uint32_t *d_cand_cnt, uint32_t cap, int num_cus, const void *d_rows_split, int half, void *d_wlists, uint32_t phase,
+                              uint32_t qt) {
     auto kfn = scan_f32_split_kernel;
     auto kfn3 = scan_f16pair_kernel<false>;
     auto kfn3h = scan_f16pair_kernel<true>;
+    auto kfn4 = scan_f16half256_kernel;
+    QMX_REQUIRE(qt == SP_QT || (qt == SP4_QT && half && d_rows_split), QMX_ERR_BAD_ARG, "the 256-query shape scans the half copy");
     static thread_local bool attr_set = false;
     if (!attr_set) {
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS));
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn3), hipFuncAttributeMaxDynamicSharedMemorySize, SP3_LDS));
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn3h), hipFuncAttributeMaxDynamicSharedMemorySize, SP3_LDS));
+        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn4), hipFuncAttributeMaxDynamicSharedMemorySize, SP4_LDS));
         attr_set = true;
     }
     QMX_REQUIRE(!half || d_rows_split, QMX_ERR_BAD_ARG, "the one-product mode scans the half copy only");
@@ -825,12 +1046,16 @@ int32_t launch_scan_f32_split(hipStream_t st, const ScanArgs &a, const void *d_b
     QMX_REQUIRE(!d_rows_split || d_wlists, QMX_ERR_BAD_ARG, "the scan over a derived copy writes per-wave candidate lists");
     QMX_REQUIRE(phase == 0 || d_rows_split, QMX_ERR_BAD_ARG, "phases exist for the scan over a derived copy");
     s.phase = phase;
-    const uint64_t all_tiles = (a.n_cand + (d_rows_split ? SP3_BM : SP_BM) - 1) / (d_rows_split ? SP3_BM : SP_BM);
+    const uint32_t bm = qt == SP4_QT ? SP4_BM : d_rows_split ? SP3_BM : SP_BM;
+    const uint64_t all_tiles = (a.n_cand + bm - 1) / bm;
     const uint64_t n_tiles = d_rows_split ? split_phase_tiles(all_tiles, phase) : all_tiles;
     if (n_tiles == 0) return QMX_OK;
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, (uint64_t)num_cus));
     ::qmx::clear_stale_error();
-    if (d_rows_split && half) {
+    if (qt == SP4_QT) {
+        QMX_NOTE_KERNEL(kfn4);
+        hipLaunchKernelGGL(kfn4, dim3(grid), dim3(SP3_THREADS), (size_t)SP4_LDS, st, a, s);
+    } else if (d_rows_split && half) {
         QMX_NOTE_KERNEL(kfn3h);
         hipLaunchKernelGGL(kfn3h, dim3(grid), dim3(SP3_THREADS), (size_t)SP3_LDS, st, a, s);
     } else if (d_rows_split) {
@@ -845,8 +1070,9 @@ int32_t launch_scan_f32_split(hipStream_t st, const ScanArgs &a, const void *d_b
 }
 // per-wave lists of launch_scan_f32_split (over a derived copy) -> d_cand / d_cand_cnt; d_cand_cnt zeroed by the caller before the scan
 int32_t launch_split_regroup(hipStream_t st, const ScanArgs &a, const void *d_wlists, int num_cus, uint64_t *d_cand, uint32_t *d_cand_cnt, uint32_t cap,
-                             int *d_overflow, uint32_t phase) {
-    const uint64_t n_tiles = split_phase_tiles((a.n_cand + SP3_BM - 1) / SP3_BM, phase);
+                             int *d_overflow, uint32_t phase, uint32_t qt) {
+    const uint32_t bm = qt == SP4_QT ? SP4_BM : SP3_BM;
+    const uint64_t n_tiles = split_phase_tiles((a.n_cand + bm - 1) / bm, phase);
     if (n_tiles == 0) return QMX_OK;
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, (uint64_t)num_cus));
     const uint32_t n_lists = grid * (SP3_THREADS / 64);

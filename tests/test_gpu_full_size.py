@@ -90,12 +90,12 @@ def test_c2_full_size_properties(world):
 
 
 @pytest.mark.parametrize("path", ["exact", "prefilter"])
-@pytest.mark.parametrize("nq", [16, 32, 64, 128])
+@pytest.mark.parametrize("nq", [16, 32, 64, 128, 256])
 def test_c2_full_size_every_batch_shape(world, nq, path):
     """the kernels bench.py times, checked at the headline size over the WHOLE block (their wave-lag schedule, stage
     rings and tails depend on the tile count), for 16 / 32 / 64 / 128 queries per pass and along both tracks:
       exact      scan_f32_mfma16_kernel<6, ...> (what a segment without a derived copy runs; option no_split_scan here),
-      prefilter  scan_f16pair_kernel<true> over the 2 B / element copy + exact verification (scan_split.hip).
+      prefilter  scan_f16pair_kernel<true> (up to 128 queries) / scan_f16half256_kernel (256) over the 2 B / element copy + exact verification.
     The lists must equal (1) the VALU kernel's (4 queries per pass, no matrix cores, no pre-scan, a different reduction tree: the only
     thing they share is the reference's bits), (2) the oracle's on a 200 k-row window reached through an id list (the IDS = true
     instantiation), and (3) the merge of the lists of 5 uneven slabs."""
@@ -108,7 +108,8 @@ def test_c2_full_size_every_batch_shape(world, nq, path):
     finally:
         qa.set_option("no_split_scan", -1)
     kernel = F.last_kernel(s.scorer._h)
-    want_kernel = "scan_f16pair_kernel<true>" if path == "prefilter" else "scan_f32_mfma16_kernel<6, %s" % {16: "4, 1", 32: "4, 2", 64: "8, 4", 128: "8, 4"}[nq]
+    want_kernel = (("scan_f16half256_kernel" if nq > 128 else "scan_f16pair_kernel<true>") if path == "prefilter"
+                   else "scan_f32_mfma16_kernel<6, %s" % {16: "4, 1", 32: "4, 2", 64: "8, 4", 128: "8, 4", 256: "8, 4"}[nq])
     assert want_kernel in kernel, kernel
     assert all(len(r) == TOP and np.all(np.diff(r["score"]) <= 0) for r in full)
     qa.set_option("no_mfma_scan", 1)
