@@ -170,6 +170,8 @@ void qo_tq_permutation_map(uint64_t seed, uint32_t count, uint32_t *map);       
 uint32_t qo_tq_chunk_sizes(uint32_t dim, uint32_t *out);                               /* rotation.rs:222-233 */
 void qo_tq_wht(double *x, uint32_t n);                                                 /* rotation.rs:158-176 */
 qo_tq *qo_tq_new(uint32_t dim, int bits, int distance, int rotation_unpadded);         /* TurboQuantizer::new (quantization.rs:127-158) */
+qo_tq *qo_tq_new_plus(uint32_t dim, int bits, int distance, int rotation_unpadded, const float *shift, const float *scale);   /* TQMode::Plus with given ErrorCorrection */
+float qo_tq_query_ec_correction(const qo_tq_query *e);
 void qo_tq_free(qo_tq *t);
 uint32_t qo_tq_padded_dim(const qo_tq *t);
 uint32_t qo_tq_quantized_size(const qo_tq *t);                                         /* encoding.rs:172-190 */

@@ -13,8 +13,8 @@
  *   simd/query4bit/mod.rs (x86_64 constants :64-90, new :186-248, dotprod :257-261, dotprod_raw :300-346, score_4bit_internal_* :414-434)
  *   simd/query2bit/mod.rs, simd/query1bit/mod.rs   the same for 2 bits and for the bit-plane form of 1 bit (BITS = 8)
  *
- * Scope: TQMode::Normal (no TQ+ error correction: its per-coordinate shift / scale come from a P-square pre-pass over randomly sampled
- * vectors), TQBits 4 / 2 / 1.5 / 1, TQRotation Padded and Unpadded, distances Dot, Cosine, L2.  L1 (full dequantisation + inverse
+ * Scope: TQMode::Normal and TQMode::Plus with GIVEN ErrorCorrection shift / scale (the reference fits them with P-square quantile estimators over
+ * randomly sampled vectors, encoded_vectors_tq.rs:156-240, and persists them in the metadata: an input, like PQ centroids), TQBits 4 / 2 / 1.5 / 1, TQRotation Padded and Unpadded, distances Dot, Cosine, L2.  L1 (full dequantisation + inverse
  * rotation per score) is not restated.
  *
  * PARITY UNPINNED at the bit level: the reference holds tolerance tests only for this quantizer (tests/integration/test_tq.rs: error =
@@ -45,6 +45,10 @@ struct qo_tq {
     uint32_t dim, padded_dim, rot_dim;
     int bits, distance;
     uint32_t *maps[3];     /* forward_maps */
+    /* TQ+ (TQMode::Plus): ErrorCorrection (quantization.rs:28-96), NULL without */
+    float *shift, *scale;
+    int16_t *d_prime_sq_i16;
+    float weight_scale, mm_const;
 };
 
 static int bit_size(int bits) { return bits == TQ_BITS4 ? 4 : bits == TQ_BITS2 ? 2 : 1; }
@@ -63,7 +67,7 @@ uint32_t qo_tq_padded_dim_for(uint32_t dim, int bits) {           /* encoding.rs
         default: return next_multiple(dim, 2);
     }
 }
-static uint32_t extras_size(int distance) { return distance == QO_EUCLID ? 8 : 4; }   /* size_for, TQMode::Normal */
+static uint32_t extras_size_mode(int distance, int plus) { return (distance == QO_EUCLID ? 8u : 4u) + (plus ? 4u : 0u); }   /* size_for (encoding.rs:31-56) */
 
 /* permutation.rs: forward map of Permutation::new_one_way(seed, count).permute(identity) */
 void qo_tq_permutation_map(uint64_t seed, uint32_t count, uint32_t *map) {
@@ -119,13 +123,43 @@ qo_tq *qo_tq_new(uint32_t dim, int bits, int distance, int rotation_unpadded) {
     }
     return t;
 }
+/* ErrorCorrection::new (quantization.rs:49-96): shift / scale [padded_dim] as persisted in the metadata (encoded_vectors_tq.rs:93-96) */
+qo_tq *qo_tq_new_plus(uint32_t dim, int bits, int distance, int rotation_unpadded, const float *shift, const float *scale) {
+    qo_tq *t = qo_tq_new(dim, bits, distance, rotation_unpadded);
+    const uint32_t pd = t->padded_dim;
+    t->shift = (float *)malloc(sizeof(float) * pd);
+    t->scale = (float *)malloc(sizeof(float) * pd);
+    t->d_prime_sq_i16 = (int16_t *)malloc(sizeof(int16_t) * pd);
+    memcpy(t->shift, shift, sizeof(float) * pd);
+    memcpy(t->scale, scale, sizeof(float) * pd);
+    float mm = 0.0f;                                             /* shift.iter().map(|&s| s * s).sum() (f32, in order) */
+    for (uint32_t i = 0; i < pd; i++) mm += shift[i] * shift[i];
+    t->mm_const = mm;
+    float *dps = (float *)malloc(sizeof(float) * pd);
+    float max_dps = 0.0f;
+    for (uint32_t i = 0; i < pd; i++) {
+        dps[i] = fabsf(scale[i]) > 1.1920929e-7f ? 1.0f / (scale[i] * scale[i]) : 0.0f;      /* (s * s).recip() */
+        if (dps[i] > max_dps) max_dps = dps[i];
+    }
+    const float QUANT_CAP = 32766.0f;                           /* i16::MAX - 1 */
+    t->weight_scale = max_dps > 1.1920929e-7f ? QUANT_CAP / max_dps : 1.0f;
+    for (uint32_t i = 0; i < pd; i++) {
+        float v = roundf(dps[i] * t->weight_scale);
+        if (v < 0.0f) v = 0.0f;
+        if (v > QUANT_CAP) v = QUANT_CAP;
+        t->d_prime_sq_i16[i] = (int16_t)v;
+    }
+    free(dps);
+    return t;
+}
 void qo_tq_free(qo_tq *t) {
     if (!t) return;
     for (int p = 0; p < 3; p++) free(t->maps[p]);
+    free(t->shift); free(t->scale); free(t->d_prime_sq_i16);
     free(t);
 }
 uint32_t qo_tq_padded_dim(const qo_tq *t) { return t->padded_dim; }
-uint32_t qo_tq_quantized_size(const qo_tq *t) { return t->padded_dim * bit_size(t->bits) / 8 + extras_size(t->distance); }
+uint32_t qo_tq_quantized_size(const qo_tq *t) { return t->padded_dim * bit_size(t->bits) / 8 + extras_size_mode(t->distance, t->shift != NULL); }
 
 /* HadamardRotation::apply on buf[..rot_dim] */
 void qo_tq_rotate(const qo_tq *t, double *x) {
@@ -171,6 +205,21 @@ void qo_tq_quantize(const qo_tq *t, const float *vec, uint8_t *out) {
         const double length_scale = sqrt((double)pd) / length;
         for (uint32_t i = 0; i < pd; i++) buf[i] *= length_scale;
     }
+    /* TQ+: xm = <X, M> on the rescaled vector, then the per-coordinate shift + scale (skipped for an all-zero vector) :231-247 */
+    float xm = 0.0f;
+    int ec_applied = 0;
+    if (t->shift) {
+        double l2sq = 0.0;
+        for (uint32_t i = 0; i < pd; i++) l2sq += buf[i] * buf[i];
+        if (!(l2sq < 1e-12)) {
+            double x = 0.0;
+            for (uint32_t i = 0; i < pd; i++) x += buf[i] * (double)(-t->shift[i]);
+            for (uint32_t i = 0; i < pd; i++) buf[i] = (buf[i] + (double)t->shift[i]) * (double)t->scale[i];
+            xm = (float)x;
+            ec_applied = 1;
+        }
+    }
+    (void)ec_applied;
     int nc;
     const float *centroids = centroids_of(t->bits, &nc);
     /* centroid norm (Dot / L2: always; Cosine: sqrt(padded_dim) for a zero vector) */
@@ -186,7 +235,8 @@ void qo_tq_quantize(const qo_tq *t, const float *vec, uint8_t *out) {
         else {
             double sq = 0.0;
             for (uint32_t i = 0; i < pd; i++) {
-                const double c = (double)centroids[centroid_index(centroids, nc, buf[i])];
+                double c = (double)centroids[centroid_index(centroids, nc, buf[i])];
+                if (t->shift) c = c / (double)t->scale[i] - (double)t->shift[i];     /* compute_centroid_norm reverts the EC :311-314 */
                 sq += c * c;
             }
             centroid_norm = (float)sqrt(sq);
@@ -201,12 +251,13 @@ void qo_tq_quantize(const qo_tq *t, const float *vec, uint8_t *out) {
     const float scaling_factor = (has_l2 ? l2_length : 1.0f) / centroid_norm;
     memcpy(out + code_bytes, &scaling_factor, 4);
     if (t->distance == QO_EUCLID) memcpy(out + code_bytes + 4, &l2_length, 4);
+    if (t->shift) memcpy(out + code_bytes + (t->distance == QO_EUCLID ? 8 : 4), &xm, 4);      /* the trailing f32 of the extras */
     free(buf);
 }
 
 struct qo_tq_query {
     int32_t *q;            /* q_signed per padded dim */
-    float postprocess_scale, l2_norm;
+    float postprocess_scale, l2_norm, ec_correction;
     int64_t sum_q;
     float *rotated_f32;
 };
@@ -223,6 +274,12 @@ qo_tq_query *qo_tq_precompute_query(const qo_tq *t, const float *query) {
         for (uint32_t i = 0; i < pd; i++) s += rot[i] * rot[i];
         e->l2_norm = (float)sqrt(s);
     }
+    if (t->shift) {        /* qm = <Q, M>, then Q .* D' (:526-540) */
+        double qm = 0.0;
+        for (uint32_t i = 0; i < pd; i++) qm += rot[i] * (double)(-t->shift[i]);
+        for (uint32_t i = 0; i < pd; i++) rot[i] /= (double)t->scale[i];
+        e->ec_correction = (float)qm;
+    }
     e->rotated_f32 = (float *)malloc(sizeof(float) * (pd ? pd : 1));
     e->q = (int32_t *)malloc(sizeof(int32_t) * (pd ? pd : 1));
     float q_abs_max = 0.0f;
@@ -233,7 +290,8 @@ qo_tq_query *qo_tq_precompute_query(const qo_tq *t, const float *query) {
     }
     if (!(q_abs_max > 1.1920929e-7f)) q_abs_max = 1.1920929e-7f;   /* .max(f32::EPSILON) */
     const int one_bit = t->bits == TQ_BITS1 || t->bits == TQ_BITS1_5;
-    const float abs_max_int = one_bit ? 127.0f : TQ_QUERY_ABS_MAX;     /* (1 << (BITS - 1)) - 1 with BITS = 8 */
+    /* (1 << (BITS - 1)) - 1 with BITS = 8; TQ+ over 1-bit storage widens the query to Query1bitSimd<16> (:557-563) */
+    const float abs_max_int = one_bit ? (t->shift ? 32767.0f : 127.0f) : TQ_QUERY_ABS_MAX;
     const float q_scale = abs_max_int / q_abs_max;
     for (uint32_t i = 0; i < pd; i++) {
         float v = roundf(e->rotated_f32[i] * q_scale);
@@ -255,6 +313,7 @@ void qo_tq_query_free(qo_tq_query *e) {
     free(e->q); free(e->rotated_f32); free(e);
 }
 /* the encoded query as the device holds it: q_signed [padded_dim], postprocess_scale, l2_norm, sum of q_signed */
+float qo_tq_query_ec_correction(const qo_tq_query *e) { return e->ec_correction; }
 void qo_tq_query_export(const qo_tq *t, const qo_tq_query *e, int32_t *q_out, float *postprocess_scale, float *l2_norm, int64_t *sum_q) {
     if (q_out) memcpy(q_out, e->q, sizeof(int32_t) * t->padded_dim);
     if (postprocess_scale) *postprocess_scale = e->postprocess_scale;
@@ -285,7 +344,7 @@ float qo_tq_score_precomputed(const qo_tq *t, const qo_tq_query *e, const uint8_
     const uint32_t code_bytes = t->padded_dim * (uint32_t)bit_size(t->bits) / 8;
     float scaling_factor, l2 = 0.0f;
     memcpy(&scaling_factor, vec + code_bytes, 4);
-    const float dot = tq_raw_dot(t, e, vec) + 0.0f;            /* + query.ec_correction (0.0 without TQ+) */
+    const float dot = tq_raw_dot(t, e, vec) + e->ec_correction;   /* 0.0 without TQ+ */
     if (t->distance == QO_EUCLID) {
         memcpy(&l2, vec + code_bytes + 4, 4);
         const float ql = e->l2_norm;
@@ -297,7 +356,21 @@ float qo_tq_score_precomputed(const qo_tq *t, const qo_tq_query *e, const uint8_
 float qo_tq_score_symmetric(const qo_tq *t, const uint8_t *v1, const uint8_t *v2) {
     const uint32_t pd = t->padded_dim, bs = (uint32_t)bit_size(t->bits), code_bytes = pd * bs / 8;
     float raw_dot;
-    if (bs == 1) {
+    if (t->shift && bs != 1) {      /* score_symmetric_ec (:447-494): weighted integer dot / (weight_scale * CODEBOOK_SCALE^2) + xm_a + xm_b - <M, M> */
+        const uint8_t *book = t->bits == TQ_BITS4 ? CODEBOOK_U8_4BIT : CODEBOOK_U8_2BIT;
+        int64_t acc = 0;
+        for (uint32_t i = 0; i < pd; i++)
+            acc += ((int64_t)book[code_at(v1, i, bs)] - TQ_CODEBOOK_OFFSET) * ((int64_t)book[code_at(v2, i, bs)] - TQ_CODEBOOK_OFFSET) *
+                   (int64_t)t->d_prime_sq_i16[i];
+        const float codebook_scale = 128.0f / (t->bits == TQ_BITS4 ? 2.733f : 1.510f);
+        const float codebook_scale_sq = codebook_scale * codebook_scale;
+        const float weighted = (float)acc / (t->weight_scale * codebook_scale_sq);
+        const uint32_t xoff = code_bytes + (t->distance == QO_EUCLID ? 8 : 4);
+        float xa, xb;
+        memcpy(&xa, v1 + xoff, 4);
+        memcpy(&xb, v2 + xoff, 4);
+        raw_dot = weighted + xa + xb - t->mm_const;
+    } else if (bs == 1) {
         uint64_t popcnt = 0;
         for (uint32_t i = 0; i < code_bytes; i++) popcnt += (uint64_t)__builtin_popcount((unsigned)(v1[i] ^ v2[i]));
         const int64_t sign_sum = (int64_t)code_bytes * 8 - 2 * (int64_t)popcnt;

@@ -878,6 +878,8 @@ _sig("qo_tq_permutation_map", None, [C.c_uint64, C.c_uint32, _P])
 _sig("qo_tq_chunk_sizes", C.c_uint32, [C.c_uint32, _P])
 _sig("qo_tq_wht", None, [_P, C.c_uint32])
 _sig("qo_tq_new", _P, [C.c_uint32, C.c_int, C.c_int, C.c_int])
+_sig("qo_tq_new_plus", _P, [C.c_uint32, C.c_int, C.c_int, C.c_int, _P, _P])
+_sig("qo_tq_query_ec_correction", _f, [_P])
 _sig("qo_tq_free", None, [_P])
 _sig("qo_tq_padded_dim", C.c_uint32, [_P])
 _sig("qo_tq_quantized_size", C.c_uint32, [_P])
@@ -893,10 +895,15 @@ _sig("qo_tq_score_symmetric", _f, [_P, _P, _P])
 class TqOracle:
     """TurboQuantizer (TQMode::Normal) + the EncodedVectorsTQ glue (`invert`)."""
 
-    def __init__(self, distance, dim, bits, rotation_unpadded=False, invert=None):
+    def __init__(self, distance, dim, bits, rotation_unpadded=False, invert=None, shift=None, scale=None):
         self.distance, self.dim, self.bits = distance, dim, bits
         self.invert = (distance in (EUCLID, MANHATTAN)) if invert is None else bool(invert)   # quantized_vectors.rs:232
-        self.h = _lib.qo_tq_new(dim, bits, distance, 1 if rotation_unpadded else 0)
+        if shift is not None:                           # TQMode::Plus with the given ErrorCorrection
+            self.shift, self.scale = f32(shift), f32(scale)
+            self.h = _lib.qo_tq_new_plus(dim, bits, distance, 1 if rotation_unpadded else 0, _p(self.shift), _p(self.scale))
+        else:
+            self.shift = self.scale = None
+            self.h = _lib.qo_tq_new(dim, bits, distance, 1 if rotation_unpadded else 0)
         self.padded_dim = _lib.qo_tq_padded_dim(self.h)
         self.row_bytes = _lib.qo_tq_quantized_size(self.h)
         self.rows = None
@@ -948,3 +955,25 @@ class TqOracle:
             s = _lib.qo_tq_score_symmetric(self.h, _p(self.rows[int(i)]), _p(self.rows[int(j)]))
             out[k] = -s if self.invert else s
         return out
+
+
+def tq_plus_fit(distance, dim, bits, vectors, rotation_unpadded=False):
+    """shift / scale of TQ+ as EncodedVectorsTQ::encode derives them (encoded_vectors_tq.rs:156-240) from per-coordinate quantiles of the rotated,
+    length-rescaled vectors at Phi(+-c_outer) - here exact quantiles of the given vectors instead of the reference's P-square estimates over a
+    random sample (the parameters are an INPUT of the scorer either way: they are persisted in the metadata)."""
+    from math import erf, sqrt
+    plain = TqOracle(distance, dim, bits, rotation_unpadded=rotation_unpadded)
+    pd = plain.padded_dim
+    rot = np.stack([plain.rotate(v.astype(np.float64)) for v in f32(vectors)])
+    if distance != COSINE:
+        ln = np.sqrt((rot * rot).sum(axis=1, keepdims=True))
+        rot = np.where(ln > 0, rot * (np.sqrt(pd) / np.where(ln > 0, ln, 1.0)), rot)
+    else:
+        rot = rot * np.sqrt(pd)
+    c_outer = {TQ_BITS4: 2.733, TQ_BITS2: 1.510, TQ_BITS1_5: 0.7978846, TQ_BITS1: 0.7978846}[bits]
+    p = 0.5 * (1.0 + erf(c_outer / sqrt(2.0)))
+    q_lo, q_hi = np.quantile(rot.astype(np.float32), 1.0 - p, axis=0), np.quantile(rot.astype(np.float32), p, axis=0)
+    shift = (-(q_lo + q_hi) / 2.0).astype(np.float32)
+    denom = (q_hi - q_lo).astype(np.float32)
+    scale = np.where(denom > 1e-3, np.float32(2.0 * c_outer) / np.where(denom > 1e-3, denom, 1.0), 1.0).astype(np.float32)
+    return shift, scale

@@ -167,3 +167,44 @@ def test_query_encoding_fields():
         assert np.abs(qs).max() == qmax and int(qs.sum()) == sq
         assert np.array_equal(qs, np.clip(np.sign(rot * scale) * np.floor(np.abs(rot * scale) + np.float32(0.5)), -qmax, qmax).astype(np.int32))
         assert abs(float(l2) - np.linalg.norm(q)) < 1e-4
+
+
+@pytest.mark.parametrize("bits", BITS)
+@pytest.mark.parametrize("dim", [64, 128, 384])
+def test_plus_mode_within_the_reference_error_model(bits, dim):
+    """TQMode::Plus (test_tq_dot / _cosine / _l2 and the _internal variants, #[case::plus]): the same bars with per-coordinate error correction.
+    The data is made anisotropic (a few coordinates with a large offset) so that the correction has something to do."""
+    if dim < MIN_DIM[bits]:
+        pytest.skip("should_test(dim, bits) is false in the reference")
+    n = 513
+    dot_std, cos_std = (dim / 9.0) ** 0.5, 1.0 / dim ** 0.5
+    for distance, std, normalize in ((O.DOT, dot_std, False), (O.COSINE, cos_std, True), (O.EUCLID, 2 * dot_std, False)):
+        vecs, q = _data(dim, n, seed=4242 + dim, normalize=normalize)
+        shift, scale = O.tq_plus_fit(distance, dim, bits, vecs)
+        t = O.TqOracle(distance, dim, bits, invert=False, shift=shift, scale=scale)
+        assert t.row_bytes == O.TqOracle(distance, dim, bits).row_bytes + 4           # the trailing xm of TqVectorExtras
+        t.encode_rows(vecs)
+        err = COEF[bits] * std
+        got = t.score_points(q[None, :], np.arange(n))[0]
+        if distance == O.EUCLID:
+            exact, ei = ((vecs - q) ** 2).sum(axis=1), ((vecs[1:] - vecs[0]) ** 2).sum(axis=1)
+        elif distance == O.COSINE:
+            exact = (vecs @ q) / (np.linalg.norm(vecs, axis=1) * np.linalg.norm(q))
+            ei = (vecs[1:] @ vecs[0]) / (np.linalg.norm(vecs[1:], axis=1) * np.linalg.norm(vecs[0]))
+        else:
+            exact, ei = vecs @ q, vecs[1:] @ vecs[0]
+        assert np.abs(got - exact).max() < err
+        gi = t.score_internal(np.zeros(n - 1, dtype=int), np.arange(1, n))
+        assert np.abs(gi - ei).max() < err
+
+
+def test_plus_mode_with_identity_correction_equals_normal_mode_scores():
+    """shift = 0, scale = 1: X+ = X, D' = 1, M = 0 - the asymmetric scores are the Normal-mode scores (1-bit: up to the wider 16-bit query)"""
+    dim, n = 128, 64
+    vecs, q = _data(dim, n, seed=5)
+    for bits in (O.TQ_BITS4, O.TQ_BITS2):
+        a = O.TqOracle(O.DOT, dim, bits, invert=False)
+        b = O.TqOracle(O.DOT, dim, bits, invert=False, shift=np.zeros(a.padded_dim), scale=np.ones(a.padded_dim))
+        ra, rb = a.encode_rows(vecs), b.encode_rows(vecs)
+        assert np.array_equal(ra, rb[:, :a.row_bytes]) and np.all(rb[:, a.row_bytes:].view(np.float32) == 0.0)      # same codes, same scaling factor, xm = -0 * x = 0
+        assert np.array_equal(a.score_points(q[None, :], np.arange(n)).view(np.uint32), b.score_points(q[None, :], np.arange(n)).view(np.uint32))
