@@ -171,7 +171,8 @@ typedef struct qmx_bq_params {
 } qmx_bq_params;
 
 /* TurboQuant (`TurboQuantizer`, lib/quantization/src/turboquant/quantization.rs:14-158; `Metadata`, encoded_vectors_tq.rs:33-46).
- * TQMode::Normal only: a TQ+ storage (per-coordinate error correction) is QMX_ERR_NOT_SUPPORTED.  Distances Dot, Cosine, Euclid (L1 scores need a
+ * TQMode::Normal, and TQMode::Plus with the storage's persisted error correction (`shift` / `scale` per rotated coordinate: the reference fits them with
+ * P-square quantile estimators over randomly sampled vectors, encoded_vectors_tq.rs:156-240 - an input here, like PQ centroids).  Distances Dot, Cosine, Euclid (L1 scores need a
  * full dequantisation + inverse rotation per pair in the reference: QMX_ERR_NOT_SUPPORTED).  Queries are rotated (HadamardRotation, f64, the
  * reference's fixed permutation seeds) and integer-encoded on the device (`precompute_query` :496-567 with the x86_64 constants of
  * turboquant/simd/query{4,2,1}bit); scores are `score_precomputed` (:569-620) negated when `invert`; qmx_score_internal is
@@ -181,9 +182,11 @@ typedef struct qmx_tq_params {
     uint32_t bits;               /* qmx_tq_bits */
     uint32_t rotation_unpadded;  /* TQRotation: 0 = Padded (rotate all padded_dim coordinates), 1 = Unpadded (only the first dim) */
     uint8_t invert;              /* VectorParameters.invert */
-    uint8_t plus_mode;           /* TQMode::Plus: must be 0 */
+    uint8_t plus_mode;           /* TQMode::Plus: needs ec_shift / ec_scale */
     uint8_t pad_[2];
     uint32_t reserved;
+    const float *ec_shift;       /* TQ+ `ErrorCorrectionMetadata.shift` [padded_dim] (encoded_vectors_tq.rs:93-96), HOST array, or NULL */
+    const float *ec_scale;       /* ... `.scale` [padded_dim] */
 } qmx_tq_params;
 
 /* `TurboQuantizer::quantize` (turboquant/quantization.rs:211-296, TQMode::Normal) for a batch, on the device: vectors [n][dim] f32 as the storage

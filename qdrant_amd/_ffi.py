@@ -55,7 +55,7 @@ BQ_QUERY_SAME_AS_STORAGE, BQ_QUERY_SCALAR_4BITS, BQ_QUERY_SCALAR_8BITS = range(3
 
 class TqParams(C.Structure):
     _fields_ = [("bits", C.c_uint32), ("rotation_unpadded", C.c_uint32), ("invert", C.c_uint8), ("plus_mode", C.c_uint8), ("pad_", C.c_uint8 * 2),
-                ("reserved", C.c_uint32)]
+                ("reserved", C.c_uint32), ("ec_shift", C.c_void_p), ("ec_scale", C.c_void_p)]
 
 
 TQ_BITS4, TQ_BITS2, TQ_BITS1_5, TQ_BITS1 = range(4)

@@ -172,7 +172,10 @@ struct qmx_segment {
     // TurboQuant (scan_tq.hip): parameters, the extras columns and the rotation tables
     uint32_t tq_bits = 0, tq_value_bits = 0, tq_padded_dim = 0, tq_rot_dim = 0, tq_code_bytes = 0, tq_n_chunks = 0;
     bool tq_invert = false;
-    float *d_tq_sf = nullptr, *d_tq_l2 = nullptr;
+    float *d_tq_sf = nullptr, *d_tq_l2 = nullptr, *d_tq_xm = nullptr;   // extras columns (xm: TQ+ only)
+    float *d_tq_shift = nullptr, *d_tq_scale = nullptr;                   // TQ+ ErrorCorrection (device copies), or null
+    int16_t *d_tq_weights = nullptr;                                      // ... d_prime_sq_i16
+    float tq_weight_scale = 1.0f, tq_mm_const = 0.0f;
     uint32_t *d_tq_tables = nullptr;   // [3][rot_dim] maps, then chunk offsets and sizes
     double *d_tq_norms = nullptr;      // [n_chunks]
     // f32 dot / cosine blocks large enough for the split prefilter (scan_split.hip): max |x| and max row norm, taken once at create
@@ -391,6 +394,10 @@ static void segment_free(qmx_segment *seg) {
     if (seg->d_bq_stddev) (void)hipFree(seg->d_bq_stddev);
     if (seg->d_tq_sf) (void)hipFree(seg->d_tq_sf);
     if (seg->d_tq_l2) (void)hipFree(seg->d_tq_l2);
+    if (seg->d_tq_xm) (void)hipFree(seg->d_tq_xm);
+    if (seg->d_tq_shift) (void)hipFree(seg->d_tq_shift);
+    if (seg->d_tq_scale) (void)hipFree(seg->d_tq_scale);
+    if (seg->d_tq_weights) (void)hipFree(seg->d_tq_weights);
     if (seg->d_tq_tables) (void)hipFree(seg->d_tq_tables);
     if (seg->d_tq_norms) (void)hipFree(seg->d_tq_norms);
     delete seg;
@@ -430,6 +437,7 @@ static int32_t segment_upload(qmx_segment *s, const qmx_segment_desc *desc) {
         s->owns_rows = true;
         QMX_HIP(hipMalloc((void **)&s->d_tq_sf, (size_t)std::max<uint64_t>(1, s->n) * sizeof(float)));
         if (has_l2) QMX_HIP(hipMalloc((void **)&s->d_tq_l2, (size_t)std::max<uint64_t>(1, s->n) * sizeof(float)));
+        if (s->d_tq_shift) QMX_HIP(hipMalloc((void **)&s->d_tq_xm, (size_t)std::max<uint64_t>(1, s->n) * sizeof(float)));
         if (s->n == 0) return QMX_OK;
         const void *d_src = desc->data;
         DevBuf tmp;
@@ -440,7 +448,7 @@ static int32_t segment_upload(qmx_segment *s, const qmx_segment_desc *desc) {
             d_src = tmp.p;
         }
         int32_t rc = launch_tq_split(nullptr, d_src, src_stride, s->n, s->tq_code_bytes, (uint32_t)s->row_stride, has_l2 ? 1 : 0, s->d_rows, s->d_tq_sf,
-                                     s->d_tq_l2);
+                                     s->d_tq_l2, s->d_tq_xm);
         if (rc == QMX_OK && hipDeviceSynchronize() != hipSuccess) rc = QMX_ERR_OTHER;
         tmp.release();
         return rc;
@@ -505,7 +513,8 @@ static int32_t tq_segment_setup(qmx_segment *s, const qmx_segment_desc *desc) {
     QMX_REQUIRE(desc->tq, QMX_ERR_BAD_ARG, "TQ segment needs qmx_tq_params");
     const qmx_tq_params &t = *desc->tq;
     QMX_REQUIRE(t.bits <= QMX_TQ_BITS1, QMX_ERR_BAD_ARG, "bad TQBits %u", t.bits);
-    QMX_REQUIRE(!t.plus_mode, QMX_ERR_NOT_SUPPORTED, "TQMode::Plus (per-coordinate error correction) is not built");
+    QMX_REQUIRE(!t.plus_mode || (t.ec_shift && t.ec_scale), QMX_ERR_BAD_ARG, "TQMode::Plus needs the storage's error correction (ec_shift / ec_scale)");
+    QMX_REQUIRE(!t.plus_mode || (!is_device_ptr(t.ec_shift) && !is_device_ptr(t.ec_scale)), QMX_ERR_BAD_ARG, "ec_shift / ec_scale are host arrays");
     QMX_REQUIRE(desc->distance != QMX_DISTANCE_MANHATTAN, QMX_ERR_NOT_SUPPORTED, "TurboQuant L1 scores (dequantise + inverse rotation per pair) are not built");
     QMX_REQUIRE(!(t.bits == QMX_TQ_BITS1_5 && t.rotation_unpadded), QMX_ERR_BAD_ARG, "Bits1_5 requires TQRotation::Padded");
     auto next_multiple = [](uint64_t x, uint64_t m) { return (x + m - 1) / m * m; };
@@ -523,8 +532,30 @@ static int32_t tq_segment_setup(qmx_segment *s, const qmx_segment_desc *desc) {
     s->tq_padded_dim = (uint32_t)padded;
     s->tq_rot_dim = t.rotation_unpadded ? (uint32_t)dim : (uint32_t)padded;
     s->tq_code_bytes = (uint32_t)(padded * s->tq_value_bits / 8);
-    s->row_bytes = s->tq_code_bytes + (desc->distance == QMX_DISTANCE_EUCLID ? 8 : 4);
+    s->row_bytes = s->tq_code_bytes + (desc->distance == QMX_DISTANCE_EUCLID ? 8 : 4) + (t.plus_mode ? 4 : 0);
     s->scan_dim = (s->tq_code_bytes + 15) & ~15u;        // bytes of a row of the device code block
+    if (t.plus_mode) {   // ErrorCorrection::new (turboquant/quantization.rs:49-96): D'^2 as i16 weights, their scale, <M, M>
+        const uint32_t pd = s->tq_padded_dim;
+        std::vector<float> dps(pd);
+        float mm = 0.0f, max_dps = 0.0f;
+        for (uint32_t i = 0; i < pd; ++i) {
+            mm += t.ec_shift[i] * t.ec_shift[i];
+            const float sc = t.ec_scale[i];
+            dps[i] = std::fabs(sc) > 1.1920929e-7f ? 1.0f / (sc * sc) : 0.0f;
+            max_dps = std::max(max_dps, dps[i]);
+        }
+        const float QUANT_CAP = 32766.0f;
+        s->tq_mm_const = mm;
+        s->tq_weight_scale = max_dps > 1.1920929e-7f ? QUANT_CAP / max_dps : 1.0f;
+        std::vector<int16_t> w(pd);
+        for (uint32_t i = 0; i < pd; ++i) w[i] = (int16_t)std::min(std::max(std::round(dps[i] * s->tq_weight_scale), 0.0f), QUANT_CAP);
+        QMX_HIP(hipMalloc((void **)&s->d_tq_shift, (size_t)pd * 4));
+        QMX_HIP(hipMalloc((void **)&s->d_tq_scale, (size_t)pd * 4));
+        QMX_HIP(hipMalloc((void **)&s->d_tq_weights, (size_t)pd * 2));
+        QMX_HIP(hipMemcpy(s->d_tq_shift, t.ec_shift, (size_t)pd * 4, hipMemcpyHostToDevice));
+        QMX_HIP(hipMemcpy(s->d_tq_scale, t.ec_scale, (size_t)pd * 4, hipMemcpyHostToDevice));
+        QMX_HIP(hipMemcpy(s->d_tq_weights, w.data(), (size_t)pd * 2, hipMemcpyHostToDevice));
+    }
     // the rotation tables
     const uint32_t rd = s->tq_rot_dim;
     static const uint64_t SEEDS[3] = {654605292835415893ull, 8636605637963351413ull, 1775280196666917949ull};
@@ -596,7 +627,8 @@ int32_t qmx_tq_encode(int32_t device_id, uint32_t distance, uint32_t dim, const 
             }
             void *d_out = out_dev ? (void *)((char *)out_rows + r0 * row_bytes) : bout.p;
             if ((rc = launch_tq_rotate(nullptr, d_in, cnt, tq_rotation(&tmp), (double *)brot.p)) != QMX_OK) break;
-            if ((rc = launch_tq_quantize(nullptr, (double *)brot.p, cnt, tmp.tq_padded_dim, tmp.tq_value_bits, distance, d_out, row_bytes)) != QMX_OK) break;
+            if ((rc = launch_tq_quantize(nullptr, (double *)brot.p, cnt, tmp.tq_padded_dim, tmp.tq_value_bits, distance, d_out, row_bytes, tmp.d_tq_shift,
+                                         tmp.d_tq_scale)) != QMX_OK) break;
             if (hipDeviceSynchronize() != hipSuccess) { rc = QMX_ERR_OTHER; break; }
             if (!out_dev && hipMemcpy((char *)out_rows + r0 * row_bytes, bout.p, (size_t)cnt * row_bytes, hipMemcpyDeviceToHost) != hipSuccess) { rc = QMX_ERR_OTHER; break; }
         }
@@ -604,6 +636,9 @@ int32_t qmx_tq_encode(int32_t device_id, uint32_t distance, uint32_t dim, const 
     bin.release(); brot.release(); bout.release();
     if (tmp.d_tq_tables) (void)hipFree(tmp.d_tq_tables);
     if (tmp.d_tq_norms) (void)hipFree(tmp.d_tq_norms);
+    if (tmp.d_tq_shift) (void)hipFree(tmp.d_tq_shift);
+    if (tmp.d_tq_scale) (void)hipFree(tmp.d_tq_scale);
+    if (tmp.d_tq_weights) (void)hipFree(tmp.d_tq_weights);
     return rc;
 }
 
@@ -728,7 +763,7 @@ int32_t qmx_segment_create_from_files(const qmx_segment_desc *desc, const char *
             const uint64_t padded = desc->tq->bits == QMX_TQ_BITS1 ? (d + 7) / 8 * 8 : desc->tq->bits == QMX_TQ_BITS1_5 ? (d * 3 / 2 + 7) / 8 * 8
                                   : desc->tq->bits == QMX_TQ_BITS2 ? (d + 3) / 4 * 4 : (d + 1) / 2 * 2;
             const uint64_t vb = desc->tq->bits == QMX_TQ_BITS4 ? 4 : desc->tq->bits == QMX_TQ_BITS2 ? 2 : 1;
-            row_bytes = padded * vb / 8 + (desc->distance == QMX_DISTANCE_EUCLID ? 8 : 4);
+            row_bytes = padded * vb / 8 + (desc->distance == QMX_DISTANCE_EUCLID ? 8 : 4) + (desc->tq->plus_mode ? 4 : 0);
             break;
         }
         default: row_bytes = bq_row_bytes(desc->dim, desc->bq ? desc->bq->encoding : 0u); break;   // BQ
@@ -885,6 +920,7 @@ int32_t qmx_segment_read_rows(const qmx_segment *seg, const uint32_t *ids, uint3
             QMX_HIP(hipMemcpy(dst, (const char *)seg->d_rows + (size_t)ids[i] * seg->row_stride, seg->tq_code_bytes, hipMemcpyDefault));
             QMX_HIP(hipMemcpy(dst + seg->tq_code_bytes, seg->d_tq_sf + ids[i], 4, hipMemcpyDefault));
             if (has_l2) QMX_HIP(hipMemcpy(dst + seg->tq_code_bytes + 4, seg->d_tq_l2 + ids[i], 4, hipMemcpyDefault));
+            if (seg->d_tq_xm) QMX_HIP(hipMemcpy(dst + seg->tq_code_bytes + (has_l2 ? 8 : 4), seg->d_tq_xm + ids[i], 4, hipMemcpyDefault));
         }
         return QMX_OK;
     }
@@ -990,7 +1026,8 @@ static int32_t query_alloc(const qmx_segment *seg, uint32_t nq, qmx_query **out,
     // tile entry = elements zero-padded to whole 128-byte segments + the aux block
     // a scalar-encoded BQ query holds `bits` planes per row word (a stored row as the query has one: score_internal is 1-bit)
     q->bq_bits = (seg->dtype == QMX_DTYPE_BQ && !internal) ? seg->bq_query_bits : 1;
-    if (seg->dtype == QMX_DTYPE_TQ) q->bq_bits = seg->tq_value_bits == 4 ? 4 : 8;   // query pieces per 16-byte row piece (scan_tq.hip)
+    if (seg->dtype == QMX_DTYPE_TQ)   // query pieces per 16-byte row piece (scan_tq.hip); 1-bit storage under TQ+: 16 bit planes
+        q->bq_bits = seg->tq_value_bits == 4 ? 4 : (seg->tq_value_bits == 1 && seg->d_tq_shift) ? 16 : 8;
     q->aux_off = (uint32_t)((seg->scan_dim * elem_bytes(seg->dtype) * q->bq_bits + 127) & ~127u);
     q->q_stride = q->aux_off + QUERY_AUX_BYTES;
     if (seg->dtype == QMX_DTYPE_PQ) {   // the encoded query is the LUT [m][n_centroids] f32 (EncodedQueryPQ)
@@ -1049,8 +1086,8 @@ static int32_t query_encode(qmx_query *q, const float *queries) {
     if (seg->dtype == QMX_DTYPE_TQ) {    // TurboQuantizer::precompute_query (turboquant/quantization.rs:496-567)
         QMX_TRY(q->tq_rot.reserve((size_t)nq * seg->tq_padded_dim * sizeof(double)));
         QMX_TRY(launch_tq_rotate(q->stream, d_f32, nq, tq_rotation(seg), (double *)q->tq_rot.p));
-        return launch_tq_query_encode(q->stream, (const double *)q->tq_rot.p, nq, seg->tq_padded_dim, seg->tq_value_bits,
-                                      seg->distance == QMX_DISTANCE_EUCLID ? 1 : 0, q->d_queries, q->q_stride, q->aux_off);
+        return launch_tq_query_encode(q->stream, (double *)q->tq_rot.p, nq, seg->tq_padded_dim, seg->tq_value_bits,
+                                      seg->distance == QMX_DISTANCE_EUCLID ? 1 : 0, q->d_queries, q->q_stride, q->aux_off, seg->d_tq_shift, seg->d_tq_scale);
     }
     if (seg->dtype == QMX_DTYPE_PQ)      // EncodedVectorsPQ::encode_query (encoded_vectors_pq.rs:519-541)
         return launch_pq_lut(q->stream, seg->distance, seg->dim, seg->pq, seg->d_centroids, d_f32, nq, (float *)q->d_queries);
@@ -1286,6 +1323,7 @@ static void fill_args(const qmx_query *q, uint32_t tile0, uint32_t nq_tile, Scan
     a.tq_l2 = s->d_tq_l2;
     a.tq_bits = s->tq_value_bits;
     a.tq_invert = s->tq_invert ? 1 : 0;
+    a.tq_planes = (s->tq_value_bits == 1 && s->d_tq_shift) ? 16 : 8;
 }
 
 static int32_t launch_scan(const qmx_query *q, int qt, ScanMode mode, const ScanArgs &a, uint32_t *grid) {
@@ -2904,8 +2942,12 @@ int32_t qmx_score_internal(const qmx_segment *seg, const uint32_t *a_ids, const 
             if (e == hipSuccess) e = hipMemset(be.p, 0, 4);
             if (e != hipSuccess) { rc = hip_status(e, "stage ids", __FILE__, __LINE__); break; }
             if (seg->dtype == QMX_DTYPE_TQ)
+            {
+                TqEc ec{seg->d_tq_weights, seg->d_tq_xm, seg->tq_weight_scale, seg->tq_mm_const};
                 rc = launch_tq_internal(nullptr, seg->d_rows, (uint32_t)seg->row_stride, seg->d_tq_sf, seg->d_tq_l2, seg->tq_code_bytes, seg->tq_value_bits,
-                                        seg->tq_invert ? 1 : 0, seg->n, (const uint32_t *)ba.p, (const uint32_t *)bb.p, n, (float *)bo.p, (int *)be.p);
+                                        seg->tq_invert ? 1 : 0, seg->n, (const uint32_t *)ba.p, (const uint32_t *)bb.p, n, (float *)bo.p, (int *)be.p,
+                                        seg->d_tq_weights ? &ec : nullptr);
+            }
             else
                 rc = launch_pq_internal(nullptr, seg->distance, seg->dim, seg->pq, seg->d_centroids, seg->d_pq_pair, seg->d_rows, seg->row_stride, seg->n,
                                         (const uint32_t *)ba.p, (const uint32_t *)bb.p, n, (float *)bo.p, (int *)be.p);

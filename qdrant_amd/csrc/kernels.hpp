@@ -57,6 +57,7 @@ struct ScanArgs {
     const float *tq_sf;        // [n] scaling_factor
     const float *tq_l2;        // [n] l2_length (DistanceType::L2) or nullptr
     uint32_t tq_bits, tq_invert;
+    uint32_t tq_planes;        // 1-bit storage: bit planes of the query (8; 16 under TQ+)
     // multi-vectors (MaxSim walk, hnsw.hpp HopMaxSim): point p = inner rows [mv_offsets[p], mv_offsets[p + 1]); multi-query j = query entries
     // [mv_qfirst[j], mv_qfirst[j + 1])
     const uint64_t *mv_offsets;
@@ -116,16 +117,21 @@ struct TqRotationHost {        // HadamardRotation on the device: forward maps, 
 int32_t launch_scan_tq(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out);
 int32_t launch_hnsw_tq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_tq_split(hipStream_t st, const void *rows, uint64_t src_stride, uint64_t n, uint32_t code_bytes, uint32_t dst_stride, int has_l2,
-                        void *codes, float *sf, float *l2);
+                        void *codes, float *sf, float *l2, float *xm);
 int32_t launch_tq_gather_rows(hipStream_t st, const void *codes, uint32_t dst_stride, const float *sf, const float *l2, uint32_t code_bytes, int has_l2,
                               const uint32_t *ids, uint32_t n, uint64_t n_rows, void *out, uint32_t out_stride, int *err_flag);
 int32_t launch_tq_rotate(hipStream_t st, const float *d_in, uint32_t n, const TqRotationHost &h, double *d_out);
 int32_t launch_tq_quantize(hipStream_t st, double *d_rot, uint32_t n, uint32_t padded_dim, uint32_t value_bits, uint32_t distance, void *d_out,
-                           uint32_t out_stride);
-int32_t launch_tq_query_encode(hipStream_t st, const double *d_rot, uint32_t nq, uint32_t padded_dim, uint32_t bits, int need_l2, void *tile, uint32_t q_stride,
-                               uint32_t aux_off);
+                           uint32_t out_stride, const float *d_shift, const float *d_scale);
+int32_t launch_tq_query_encode(hipStream_t st, double *d_rot, uint32_t nq, uint32_t padded_dim, uint32_t bits, int need_l2, void *tile, uint32_t q_stride,
+                               uint32_t aux_off, const float *d_shift, const float *d_scale);
+struct TqEc {                  // TQ+ symmetric scoring (score_symmetric_ec): i16 weights D'^2 per coordinate, their scale, <M, M>, the rows' xm column
+    const int16_t *weights;
+    const float *xm;
+    float weight_scale, mm_const;
+};
 int32_t launch_tq_internal(hipStream_t st, const void *codes, uint32_t stride, const float *sf, const float *l2, uint32_t code_bytes, uint32_t bits,
-                           int invert, uint64_t n_rows, const uint32_t *a_ids, const uint32_t *b_ids, uint32_t n, float *out, int *err_flag);
+                           int invert, uint64_t n_rows, const uint32_t *a_ids, const uint32_t *b_ids, uint32_t n, float *out, int *err_flag, const TqEc *ec);
 // the MaxSim walk over multi-vector points (HopMaxSim): dense, SQ and BQ inner rows
 int32_t launch_hnsw_maxsim_dense(hipStream_t st, int dtype, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_maxsim_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);

@@ -237,7 +237,7 @@ struct JsonParser {
 };
 
 struct MetaOwner {
-    std::vector<float> centroids, mean, stddev;
+    std::vector<float> centroids, mean, stddev, tq_shift, tq_scale;
 };
 
 // field accessors with serde's strictness: a missing or mistyped required field is an error
@@ -383,7 +383,7 @@ int32_t parse_bq(const JsonValue &root, qmx_quant_meta &m, MetaOwner &o) {
 
 // EncodedVectorsTQ Metadata (encoded_vectors_tq.rs:33-46): {"vector_parameters", "bits": "bits4" | "bits2" | "bits1_5" | "bits1",
 // "mode": "normal" | "plus", "error_correction": null | {"shift", "scale"}, "rotation"?: "padded" | "unpadded"} (serde rename_all = snake_case)
-int32_t parse_tq(const JsonValue &root, qmx_quant_meta &m) {
+int32_t parse_tq(const JsonValue &root, qmx_quant_meta &m, MetaOwner &o) {
     const JsonValue *b = root.get("bits");
     QMX_REQUIRE(b && b->kind == JsonValue::String, QMX_ERR_BAD_ARG, "metadata: \"bits\" is missing or not a string");
     if (b->str == "bits4") m.tq.bits = QMX_TQ_BITS4;
@@ -413,6 +413,31 @@ int32_t parse_tq(const JsonValue &root, qmx_quant_meta &m) {
         }
     }
     m.tq.invert = m.invert;
+    // error_correction: Option<ErrorCorrectionMetadata {shift, scale}> (:93-96); lengths are checked against padded_dim by qmx_segment_create's caller
+    // contract (new_error_correction_from_metadata :70-91): here they must match each other and be present in Plus mode
+    const JsonValue *ec = root.get("error_correction");
+    if (ec && ec->kind == JsonValue::Object) {
+        const JsonValue *sh = ec->get("shift"), *sc = ec->get("scale");
+        QMX_REQUIRE(sh && sc && sh->kind == JsonValue::Array && sc->kind == JsonValue::Array && sh->items.size() == sc->items.size(), QMX_ERR_BAD_ARG,
+                    "metadata: error_correction needs \"shift\" and \"scale\" arrays of one length");
+        o.tq_shift.resize(sh->items.size());
+        o.tq_scale.resize(sc->items.size());
+        for (size_t i = 0; i < sh->items.size(); ++i) {
+            QMX_REQUIRE(sh->items[i].kind == JsonValue::Number && sc->items[i].kind == JsonValue::Number, QMX_ERR_BAD_ARG,
+                        "metadata: error_correction entry %zu is not a number", i);
+            o.tq_shift[i] = (float)sh->items[i].num;
+            o.tq_scale[i] = (float)sc->items[i].num;
+        }
+        uint64_t d = m.dim, padded = m.tq.bits == QMX_TQ_BITS1 ? (d + 7) / 8 * 8 : m.tq.bits == QMX_TQ_BITS1_5 ? (d * 3 / 2 + 7) / 8 * 8
+                                   : m.tq.bits == QMX_TQ_BITS2 ? (d + 3) / 4 * 4 : (d + 1) / 2 * 2;
+        QMX_REQUIRE(o.tq_shift.size() == padded, QMX_ERR_BAD_ARG, "metadata: ErrorCorrection length %zu, expected the padded dim %llu", o.tq_shift.size(),
+                    (unsigned long long)padded);
+        m.tq.ec_shift = o.tq_shift.data();
+        m.tq.ec_scale = o.tq_scale.data();
+    } else {
+        QMX_REQUIRE(!ec || ec->kind == JsonValue::Null, QMX_ERR_BAD_ARG, "metadata: \"error_correction\" is neither null nor an object");
+    }
+    QMX_REQUIRE(!m.tq.plus_mode || m.tq.ec_shift, QMX_ERR_BAD_ARG, "metadata: mode \"plus\" without error_correction");
     return QMX_OK;
 }
 
@@ -448,7 +473,7 @@ int32_t qmx_quant_meta_parse(uint32_t dtype, const char *json, uint64_t n_bytes,
         if (rc == QMX_OK) {
             if (dtype == QMX_DTYPE_SQ_U8) rc = parse_sq(root, m);
             else if (dtype == QMX_DTYPE_PQ) rc = parse_pq(root, m, *o);
-            else if (dtype == QMX_DTYPE_TQ) rc = parse_tq(root, m);
+            else if (dtype == QMX_DTYPE_TQ) rc = parse_tq(root, m, *o);
             else rc = parse_bq(root, m, *o);
         }
     } catch (const std::bad_alloc &) {

@@ -101,7 +101,7 @@ struct RowTQ4 {
         const int64_t s = low + 128 * high;                                   // = dot_raw - bias_correction
         const QueryAux *aux = reinterpret_cast<const QueryAux *>(q_lds + args.aux_off);
         const float raw = aux->f0 * (float)s;
-        return tq_postprocess<L2>(raw + 0.0f, q_lds, rid, args);
+        return tq_postprocess<L2>(raw + __uint_as_float(aux->pad[3]), q_lds, rid, args);   // + query.ec_correction (0.0 without TQ+)
     }
 };
 
@@ -148,26 +148,26 @@ struct RowTQ2 {
         const int64_t s = low + 128 * high;
         const QueryAux *aux = reinterpret_cast<const QueryAux *>(q_lds + args.aux_off);
         const float raw = aux->f0 * (float)s;
-        return tq_postprocess<L2>(raw + 0.0f, q_lds, rid, args);
+        return tq_postprocess<L2>(raw + __uint_as_float(aux->pad[3]), q_lds, rid, args);   // + query.ec_correction (0.0 without TQ+)
     }
 };
 
-template <bool L2>
+template <bool L2, int PLANES = 8>       // PLANES = BITS of Query1bitSimd<BITS>: 8, or 16 under TQ+ (Bits1Wide)
 struct RowTQ1 {
     static constexpr bool TEMPORAL_ROWS = true;
     static constexpr int NACC = 1;
     static constexpr int NRAUX = 0;
-    static constexpr int R16 = 2;
-    static constexpr int QPIECES = 8;
+    static constexpr int R16 = PLANES == 8 ? 2 : 1;
+    static constexpr int QPIECES = PLANES;
     typedef uint32_t acc_t;
     static __device__ __forceinline__ void row_aux(acc_t (&)[1], const uint4 &) {}
     static __device__ __forceinline__ void mac(acc_t (&)[NACC], const uint4 &, const uint4 &) {}
-    static __device__ __forceinline__ void mac_pieces(acc_t (&a)[NACC], const uint4 (&q)[8], const uint4 &v) {
+    static __device__ __forceinline__ void mac_pieces(acc_t (&a)[NACC], const uint4 (&q)[PLANES], const uint4 &v) {
         int32_t s = (int32_t)a[0];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < PLANES; ++k) {
             const int32_t c = __popc(q[k].x & v.x) + __popc(q[k].y & v.y) + __popc(q[k].z & v.z) + __popc(q[k].w & v.w);
-            s += k == 7 ? -(c << 7) : (c << k);                             // w_b = 2^b, the sign plane -2^7
+            s += k == PLANES - 1 ? -(c << k) : (c << k);                    // w_b = 2^b, the sign plane -2^(BITS - 1)
         }
         a[0] = (uint32_t)s;
     }
@@ -178,7 +178,7 @@ struct RowTQ1 {
         const int64_t sum_q = (int64_t)(((uint64_t)aux->pad[2] << 32) | aux->pad[1]);
         const int64_t signed_dot = 2 * v_dot_q - sum_q;
         const float raw = aux->f0 * (float)signed_dot;
-        return tq_postprocess<L2>(raw + 0.0f, q_lds, rid, args);
+        return tq_postprocess<L2>(raw + __uint_as_float(aux->pad[3]), q_lds, rid, args);   // + query.ec_correction (0.0 without TQ+)
     }
 };
 
@@ -188,7 +188,9 @@ static int32_t dispatch_tq(const L &l, const ScanArgs &a) {
     switch (a.tq_bits) {
         case 4: return l2 ? l.template row<RowTQ4<true>>(a) : l.template row<RowTQ4<false>>(a);
         case 2: return l2 ? l.template row<RowTQ2<true>>(a) : l.template row<RowTQ2<false>>(a);
-        case 1: return l2 ? l.template row<RowTQ1<true>>(a) : l.template row<RowTQ1<false>>(a);
+        case 1:
+            if (a.tq_planes == 16) return l2 ? l.template row<RowTQ1<true, 16>>(a) : l.template row<RowTQ1<false, 16>>(a);
+            return l2 ? l.template row<RowTQ1<true>>(a) : l.template row<RowTQ1<false>>(a);
     }
     set_error("TurboQuant: %u bits per value not supported", a.tq_bits);
     return QMX_ERR_NOT_SUPPORTED;
@@ -205,7 +207,7 @@ int32_t launch_hnsw_tq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uin
 
 // ---- upload: reference rows [codes][extras] -> code block (16-byte multiple, zero padded) + extras columns ----
 __global__ __launch_bounds__(256) void tq_split_kernel(const uint8_t *rows, uint64_t src_stride, uint64_t n, uint32_t code_bytes, uint32_t dst_stride,
-                                                       int has_l2, uint8_t *codes, float *sf, float *l2) {
+                                                       int has_l2, uint8_t *codes, float *sf, float *l2, float *xm) {
     const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n) return;
     const int lane = threadIdx.x & 63;
@@ -220,14 +222,18 @@ __global__ __launch_bounds__(256) void tq_split_kernel(const uint8_t *rows, uint
             memcpy(&f, src + code_bytes + 4, 4);
             l2[r] = f;
         }
+        if (xm) {                                                         // TQ+: the trailing f32 of the extras
+            memcpy(&f, src + code_bytes + (has_l2 ? 8 : 4), 4);
+            xm[r] = f;
+        }
     }
 }
 int32_t launch_tq_split(hipStream_t st, const void *rows, uint64_t src_stride, uint64_t n, uint32_t code_bytes, uint32_t dst_stride, int has_l2,
-                        void *codes, float *sf, float *l2) {
+                        void *codes, float *sf, float *l2, float *xm) {
     if (n == 0) return QMX_OK;
     ::qmx::clear_stale_error();
     hipLaunchKernelGGL(tq_split_kernel, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, st, (const uint8_t *)rows, src_stride, n, code_bytes, dst_stride, has_l2,
-                       (uint8_t *)codes, sf, l2);
+                       (uint8_t *)codes, sf, l2, xm);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }
@@ -325,7 +331,9 @@ int32_t launch_tq_rotate(hipStream_t st, const float *d_in, uint32_t n, const Tq
 // ---- TurboQuantizer::quantize (TQMode::Normal) on rotated vectors: rot [n][padded_dim] f64 (overwritten by the rescale) -> reference rows ----
 // The two f64 sums (l2 length, centroid norm) run in index order in one thread, like the reference's iterator sums; everything else is elementwise.
 __global__ __launch_bounds__(256) void tq_quantize_kernel(double *rot, uint32_t n, uint32_t padded_dim, uint32_t value_bits, uint32_t distance, uint8_t *out,
-                                                          uint32_t out_stride) {
+                                                          uint32_t out_stride, const float *shift, const float *scale) {
+    __shared__ float sh_xm;
+    __shared__ int sh_ec;
     __shared__ double sh_scale;
     __shared__ float sh_l2;
     const uint32_t v = blockIdx.x;
@@ -351,6 +359,23 @@ __global__ __launch_bounds__(256) void tq_quantize_kernel(double *rot, uint32_t 
         for (uint32_t i = threadIdx.x; i < padded_dim; i += blockDim.x) x[i] = x[i] * length_scale;
     }
     __syncthreads();
+    // TQ+ (:231-247): xm = <X, M> on the rescaled vector (f64, in order), then x <- (x + shift) * scale; skipped for an all-zero vector
+    if (shift) {
+        if (threadIdx.x == 0) {
+            double l2sq = 0.0;
+            for (uint32_t i = 0; i < padded_dim; ++i) l2sq = l2sq + x[i] * x[i];
+            const int apply = !(l2sq < 1e-12);
+            double xm = 0.0;
+            if (apply)
+                for (uint32_t i = 0; i < padded_dim; ++i) xm = xm + x[i] * (double)(-shift[i]);
+            sh_xm = apply ? (float)xm : 0.0f;
+            sh_ec = apply;
+        }
+        __syncthreads();
+        if (sh_ec)
+            for (uint32_t i = threadIdx.x; i < padded_dim; i += blockDim.x) x[i] = (x[i] + (double)shift[i]) * (double)scale[i];
+        __syncthreads();
+    }
     // centroid of each value: boundaries.partition_point(|&b| (val as f32) > b) with the midpoint boundaries of lloyd_max.rs
     const float C1[2] = {-0.7978846f, 0.7978846f};
     const float C2[4] = {-1.510f, -0.4528f, 0.4528f, 1.510f};
@@ -385,7 +410,8 @@ __global__ __launch_bounds__(256) void tq_quantize_kernel(double *rot, uint32_t 
         else {
             double sq = 0.0;
             for (uint32_t i = 0; i < padded_dim; ++i) {
-                const double c = (double)centroid_value(centroid_index(x[i]));
+                double c = (double)centroid_value(centroid_index(x[i]));
+                if (shift) c = c / (double)scale[i] - (double)shift[i];            // compute_centroid_norm reverts the correction (:311-314)
                 sq = sq + c * c;
             }
             centroid_norm = (float)sqrt(sq);
@@ -393,25 +419,47 @@ __global__ __launch_bounds__(256) void tq_quantize_kernel(double *rot, uint32_t 
         const float scaling_factor = (has_l2 ? sh_l2 : 1.0f) / centroid_norm;
         memcpy(row + code_bytes, &scaling_factor, 4);
         if (distance == QMX_DISTANCE_EUCLID) { const float l = sh_l2; memcpy(row + code_bytes + 4, &l, 4); }
+        if (shift) { const float xm = sh_xm; memcpy(row + code_bytes + (distance == QMX_DISTANCE_EUCLID ? 8 : 4), &xm, 4); }
     }
 }
 int32_t launch_tq_quantize(hipStream_t st, double *d_rot, uint32_t n, uint32_t padded_dim, uint32_t value_bits, uint32_t distance, void *d_out,
-                           uint32_t out_stride) {
+                           uint32_t out_stride, const float *d_shift, const float *d_scale) {
     if (n == 0) return QMX_OK;
     ::qmx::clear_stale_error();
-    hipLaunchKernelGGL(tq_quantize_kernel, dim3(n), dim3(256), 0, st, d_rot, n, padded_dim, value_bits, distance, (uint8_t *)d_out, out_stride);
+    hipLaunchKernelGGL(tq_quantize_kernel, dim3(n), dim3(256), 0, st, d_rot, n, padded_dim, value_bits, distance, (uint8_t *)d_out, out_stride, d_shift, d_scale);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }
 
 // ---- Query{N}bitSimd::new on the rotated queries: rot [nq][padded_dim] f64 -> tile entries ----
-__global__ __launch_bounds__(256) void tq_query_encode_kernel(const double *rot, uint32_t padded_dim, uint32_t bits, int need_l2, uint8_t *tile,
-                                                              uint32_t q_stride, uint32_t aux_off) {
+__global__ __launch_bounds__(256) void tq_query_encode_kernel(double *rot, uint32_t padded_dim, uint32_t bits, int need_l2, uint8_t *tile,
+                                                              uint32_t q_stride, uint32_t aux_off, const float *shift, const float *scale) {
     __shared__ float sh_max[256];
     __shared__ float sh_scale;
     __shared__ unsigned long long sh_sum;
+    __shared__ float sh_l2q, sh_qm;
     const uint32_t q = blockIdx.x;
-    const double *x = rot + (uint64_t)q * padded_dim;
+    double *x = rot + (uint64_t)q * padded_dim;
+    const uint32_t planes = (bits == 1 && shift) ? 16u : 8u;           // TQ+ over 1-bit storage: Query1bitSimd<16> (:557-563)
+    // the query's l2 norm (of the rotated query, before the TQ+ rescale) and, under TQ+, qm = <Q, M>, then Q .* D' (:526-540): f64, in order
+    if (threadIdx.x == 0) {
+        float l2 = 1.0f;
+        if (need_l2) {                                                             // rotated.iter().map(|&i| i * i).sum::<f64>().sqrt() as f32
+            double s = 0.0;
+            for (uint32_t i = 0; i < padded_dim; ++i) s = s + x[i] * x[i];
+            l2 = (float)sqrt(s);
+        }
+        sh_l2q = l2;
+        double qm = 0.0;
+        if (shift)
+            for (uint32_t i = 0; i < padded_dim; ++i) qm = qm + x[i] * (double)(-shift[i]);
+        sh_qm = (float)qm;
+    }
+    __syncthreads();
+    if (shift) {
+        for (uint32_t i = threadIdx.x; i < padded_dim; i += blockDim.x) x[i] = x[i] / (double)scale[i];
+        __syncthreads();
+    }
     uint8_t *entry = tile + (uint64_t)q * q_stride;
     // zero the entry's pieces (dims past padded_dim inside the last 16-byte row piece must read as q = 0)
     for (uint32_t i = threadIdx.x; i < aux_off / 4; i += blockDim.x) reinterpret_cast<uint32_t *>(entry)[i] = 0;
@@ -424,7 +472,7 @@ __global__ __launch_bounds__(256) void tq_query_encode_kernel(const double *rot,
         if ((int)threadIdx.x < o) sh_max[threadIdx.x] = fmaxf(sh_max[threadIdx.x], sh_max[threadIdx.x + o]);
         __syncthreads();
     }
-    const float abs_max_int = bits == 1 ? 127.0f : 8127.0f;
+    const float abs_max_int = bits == 1 ? (planes == 16 ? 32767.0f : 127.0f) : 8127.0f;
     if (threadIdx.x == 0) {
         float q_abs_max = sh_max[0];
         if (!(q_abs_max > 1.1920929e-7f)) q_abs_max = 1.1920929e-7f;              // .max(f32::EPSILON)
@@ -433,13 +481,8 @@ __global__ __launch_bounds__(256) void tq_query_encode_kernel(const double *rot,
         QueryAux *aux = reinterpret_cast<QueryAux *>(entry + aux_off);
         const float codebook_scale = 128.0f / (bits == 4 ? 2.733f : 1.510f);
         aux->f0 = bits == 1 ? 0.7978846f / q_scale : 1.0f / (q_scale * codebook_scale);
-        float l2 = 1.0f;
-        if (need_l2) {                                                             // rotated.iter().map(|&i| i * i).sum::<f64>().sqrt() as f32, in order
-            double s = 0.0;
-            for (uint32_t i = 0; i < padded_dim; ++i) s = s + x[i] * x[i];
-            l2 = (float)sqrt(s);
-        }
-        aux->pad[0] = __float_as_uint(l2);
+        aux->pad[0] = __float_as_uint(sh_l2q);
+        aux->pad[3] = __float_as_uint(shift ? sh_qm : 0.0f);                       // EncodedQueryTQ::ec_correction
     }
     __syncthreads();
     const float q_scale = sh_scale;
@@ -452,10 +495,9 @@ __global__ __launch_bounds__(256) void tq_query_encode_kernel(const double *rot,
         if (bits == 1) {
             // planes of the 16-byte block holding dim i: plane b at piece (block * 8 + b), bit (i % 128) of it
             const uint32_t block = i / 128, bit = i % 128;
-            const uint32_t u = (uint32_t)qs & 0xFFu;
-#pragma unroll
-            for (int b = 0; b < 8; ++b)
-                if ((u >> b) & 1u) atomicOr(reinterpret_cast<uint32_t *>(entry + ((size_t)block * 8 + b) * 16 + (bit / 32) * 4), 1u << (bit % 32));
+            const uint32_t u = (uint32_t)qs & (planes == 16 ? 0xFFFFu : 0xFFu);
+            for (uint32_t b = 0; b < planes; ++b)
+                if ((u >> b) & 1u) atomicOr(reinterpret_cast<uint32_t *>(entry + ((size_t)block * planes + b) * 16 + (bit / 32) * 4), 1u << (bit % 32));
         } else {
             // balanced split q_signed = 128 h + l, l in [-64, 63]
             int32_t l_mod = qs % 128;
@@ -483,11 +525,11 @@ __global__ __launch_bounds__(256) void tq_query_encode_kernel(const double *rot,
         aux->pad[2] = (uint32_t)(sh_sum >> 32);
     }
 }
-int32_t launch_tq_query_encode(hipStream_t st, const double *d_rot, uint32_t nq, uint32_t padded_dim, uint32_t bits, int need_l2, void *tile, uint32_t q_stride,
-                               uint32_t aux_off) {
+int32_t launch_tq_query_encode(hipStream_t st, double *d_rot, uint32_t nq, uint32_t padded_dim, uint32_t bits, int need_l2, void *tile, uint32_t q_stride,
+                               uint32_t aux_off, const float *d_shift, const float *d_scale) {
     if (nq == 0) return QMX_OK;
     ::qmx::clear_stale_error();
-    hipLaunchKernelGGL(tq_query_encode_kernel, dim3(nq), dim3(256), 0, st, d_rot, padded_dim, bits, need_l2, (uint8_t *)tile, q_stride, aux_off);
+    hipLaunchKernelGGL(tq_query_encode_kernel, dim3(nq), dim3(256), 0, st, d_rot, padded_dim, bits, need_l2, (uint8_t *)tile, q_stride, aux_off, d_shift, d_scale);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }
@@ -497,7 +539,7 @@ __device__ __constant__ int8_t TQ4_SIGNED[16] = {-128, -97, -76, -59, -44, -31, 
 __device__ __constant__ int8_t TQ2_SIGNED[4] = {-128, -38, 38, 127};
 __global__ __launch_bounds__(256) void tq_internal_kernel(const uint8_t *codes, uint32_t stride, const float *sf, const float *l2, uint32_t code_bytes,
                                                           uint32_t bits, int invert, uint64_t n_rows, const uint32_t *a_ids, const uint32_t *b_ids, uint32_t n,
-                                                          float *out, int *err_flag) {
+                                                          float *out, int *err_flag, TqEc ec) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t ia = a_ids[i], ib = b_ids[i];
@@ -513,6 +555,21 @@ __global__ __launch_bounds__(256) void tq_internal_kernel(const uint8_t *codes, 
         const int64_t sign_sum = (int64_t)code_bytes * 8 - 2 * (int64_t)popcnt;
         const float centroid_sq = 0.7978846f * 0.7978846f;
         raw_dot = centroid_sq * (float)sign_sum;
+    } else if (ec.weights) {   // score_symmetric_ec (:447-494): sum c_a c_b w_i16 / (weight_scale * CODEBOOK_SCALE^2) + xm_a + xm_b - <M, M>
+        int64_t acc = 0;
+        if (bits == 4) {
+            for (uint32_t k = 0; k < code_bytes; ++k)
+                acc += (int64_t)TQ4_SIGNED[a[k] & 15] * TQ4_SIGNED[b[k] & 15] * ec.weights[2 * k] +
+                       (int64_t)TQ4_SIGNED[a[k] >> 4] * TQ4_SIGNED[b[k] >> 4] * ec.weights[2 * k + 1];
+        } else {
+            for (uint32_t k = 0; k < code_bytes; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc += (int64_t)TQ2_SIGNED[(a[k] >> (2 * j)) & 3] * TQ2_SIGNED[(b[k] >> (2 * j)) & 3] * ec.weights[4 * k + j];
+        }
+        const float codebook_scale = 128.0f / (bits == 4 ? 2.733f : 1.510f);
+        const float codebook_scale_sq = codebook_scale * codebook_scale;
+        const float weighted = (float)acc / (ec.weight_scale * codebook_scale_sq);
+        raw_dot = ((weighted + ec.xm[ia]) + ec.xm[ib]) - ec.mm_const;
     } else {
         int64_t acc = 0;
         if (bits == 4) {
@@ -537,11 +594,13 @@ __global__ __launch_bounds__(256) void tq_internal_kernel(const uint8_t *codes, 
     out[i] = invert ? -score : score;
 }
 int32_t launch_tq_internal(hipStream_t st, const void *codes, uint32_t stride, const float *sf, const float *l2, uint32_t code_bytes, uint32_t bits,
-                           int invert, uint64_t n_rows, const uint32_t *a_ids, const uint32_t *b_ids, uint32_t n, float *out, int *err_flag) {
+                           int invert, uint64_t n_rows, const uint32_t *a_ids, const uint32_t *b_ids, uint32_t n, float *out, int *err_flag, const TqEc *ec) {
     if (n == 0) return QMX_OK;
+    TqEc e{nullptr, nullptr, 1.0f, 0.0f};
+    if (ec) e = *ec;
     ::qmx::clear_stale_error();
     hipLaunchKernelGGL(tq_internal_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const uint8_t *)codes, stride, sf, l2, code_bytes, bits, invert, n_rows,
-                       a_ids, b_ids, n, out, err_flag);
+                       a_ids, b_ids, n, out, err_flag, e);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }

@@ -401,8 +401,12 @@ class TurboQuantizer:
     `TurboQuantizer::new(dim, bits, TQMode::Normal, distance, rotation, None)` (turboquant/quantization.rs:127-158).  `bits`: 0 = Bits4,
     1 = Bits2, 2 = Bits1_5, 3 = Bits1 (TQBits).  Rows are produced by the reference's `quantize` (an input here, like PQ codes)."""
 
-    def __init__(self, dim: int, distance: Distance, bits: int, rotation_unpadded: bool = False, invert: Optional[bool] = None):
+    def __init__(self, dim: int, distance: Distance, bits: int, rotation_unpadded: bool = False, invert: Optional[bool] = None, shift=None, scale=None):
         self.dim, self.distance, self.bits = int(dim), Distance(distance), int(bits)
+        # TQMode::Plus: the storage's persisted ErrorCorrection (shift / scale per rotated coordinate), or None = TQMode::Normal
+        self.shift = None if shift is None else np.ascontiguousarray(shift, dtype=np.float32)
+        self.scale = None if scale is None else np.ascontiguousarray(scale, dtype=np.float32)
+        self.plus_mode = self.shift is not None
         self.rotation_unpadded = bool(rotation_unpadded)
         self.invert = (self.distance in (Distance.Euclid, Distance.Manhattan)) if invert is None else bool(invert)
         value_bits = {0: 4, 1: 2, 2: 1, 3: 1}[self.bits]
@@ -415,11 +419,13 @@ class TurboQuantizer:
         p = F.TqParams()
         p.bits, p.rotation_unpadded, p.invert = self.bits, 1 if self.rotation_unpadded else 0, 1 if self.invert else 0
         p.plus_mode = 1 if getattr(self, "plus_mode", False) else 0
+        if self.shift is not None:
+            p.ec_shift, p.ec_scale = self.shift.ctypes.data, self.scale.ctypes.data
         return p
 
     def quantized_vector_size(self) -> int:
         """TurboQuantizer::quantized_size_for (turboquant/encoding.rs:172-190)."""
-        return self.code_bytes + (8 if self.distance == Distance.Euclid else 4)
+        return self.code_bytes + (8 if self.distance == Distance.Euclid else 4) + (4 if getattr(self, "plus_mode", False) else 0)
 
     def encode(self, vectors, device_id: int = 0) -> np.ndarray:
         """`TurboQuantizer::quantize` on device: [n, dim] f32 (as stored: cosine rows normalised) -> [n, quantized_vector_size] bytes."""
@@ -550,7 +556,12 @@ def load_quantizer(meta_json, dtype: int):
             q.invert = bool(m.pq.invert)
             return q
         if dtype == F.DTYPE_TQ:
-            q = TurboQuantizer(m.dim, distance, int(m.tq.bits), bool(m.tq.rotation_unpadded), bool(m.tq.invert))
+            shift = scale = None
+            if m.tq.ec_shift:
+                q0 = TurboQuantizer(m.dim, distance, int(m.tq.bits))
+                shift = np.ctypeslib.as_array(C.cast(m.tq.ec_shift, C.POINTER(C.c_float)), (q0.padded_dim,)).copy()
+                scale = np.ctypeslib.as_array(C.cast(m.tq.ec_scale, C.POINTER(C.c_float)), (q0.padded_dim,)).copy()
+            q = TurboQuantizer(m.dim, distance, int(m.tq.bits), bool(m.tq.rotation_unpadded), bool(m.tq.invert), shift, scale)
             q.plus_mode = bool(m.tq.plus_mode)
             return q
         mean = stddev = None

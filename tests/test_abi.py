@@ -34,7 +34,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(_ffi.Counters) == 32
     assert C.sizeof(_ffi.SqParams) == 20
     assert C.sizeof(_ffi.SegmentDesc) == 80          # + the qmx_tq_params pointer (ABI 3)
-    assert C.sizeof(_ffi.TqParams) == 16
+    assert C.sizeof(_ffi.TqParams) == 32
     assert C.sizeof(_ffi.BqParams) == 24
 
 

@@ -144,3 +144,34 @@ def test_tq_argument_errors(qa):
     big = qa.TurboQuantizer(100000, qa.Distance.Dot, O.TQ_BITS4)
     with pytest.raises(qa.QmxError):                                                          # the rotation runs in LDS: padded dim <= 8192
         qa.EncodedVectorsTQ(np.zeros((2, big.quantized_vector_size()), dtype=np.uint8), big)
+
+
+@pytest.mark.parametrize("bits", BITS)
+@pytest.mark.parametrize("distance", [O.DOT, O.COSINE, O.EUCLID])
+def test_tq_plus_mode_bit_exact(qa, distance, bits):
+    """TQMode::Plus with the storage's error correction (shift / scale per rotated coordinate, fitted here from exact quantiles of the data):
+    rows encoded on the device, asymmetric scores (16-bit query planes for 1-bit storages), score_symmetric_ec - all equal to the oracle's bits."""
+    for dim in (65, 128, 384):
+        n, nq = 260, 4
+        rng = np.random.default_rng(dim * 5 + bits + distance)
+        raw = rng.uniform(-1.0, 1.0, (n, dim)).astype(np.float32)
+        raw[:, : dim // 8] += 1.5                                         # anisotropic: the correction has something to do
+        vecs = O.preprocess(distance, raw)
+        shift, scale = O.tq_plus_fit(distance, dim, bits, vecs)
+        otq = O.TqOracle(distance, dim, bits, shift=shift, scale=scale)
+        quant = qa.TurboQuantizer(dim, _dist(qa, distance), bits, shift=shift, scale=scale)
+        assert quant.quantized_vector_size() == otq.row_bytes
+        rows = otq.encode_rows(vecs)
+        assert np.array_equal(quant.encode(vecs), rows)
+        st = qa.EncodedVectorsTQ(rows, quant)
+        assert np.array_equal(st.get_quantized_vector([0, n - 1]), rows[[0, n - 1]])
+        queries = rng.uniform(-1.0, 1.0, (nq, dim)).astype(np.float32)
+        scorer = qa.new_raw_scorer(queries, st)
+        ids = rng.permutation(n).astype(np.uint32)[:200]
+        assert np.array_equal(_bits(scorer.score_points(ids)), _bits(otq.score_points(O.preprocess(distance, queries), ids)))
+        a, b = ids[:64], ids[64:128]
+        assert np.array_equal(_bits(scorer.score_internal(a, b)), _bits(otq.score_internal(a, b)))
+        res = qa.BatchFilteredSearcher(queries, st, 5).peek_top_all()
+        full = otq.score_points(O.preprocess(distance, queries), np.arange(n))
+        for qi, r in enumerate(res):
+            assert np.array_equal(_bits(r["score"]), _bits(np.sort(full[qi])[::-1][:5]))

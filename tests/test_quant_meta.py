@@ -194,10 +194,20 @@ def test_tq_metadata(bits_text, bits):
         assert (m.tq.bits, m.tq.rotation_unpadded, m.tq.invert, m.tq.plus_mode) == (bits, unp, 1, 0)
         _free(m)
     # TQ+ documents parse (the flag says so); creating a segment from them is refused
-    text = '{"vector_parameters":%s,"bits":"%s","mode":"plus","error_correction":{"shift":[0.5],"scale":[1.5]}}' % (_vp(1, "Dot", False), bits_text)
+    pd = {0: 6, 1: 8, 2: 8, 3: 8}[bits]                      # padded dim of dim = 5
+    vals = [0.5 + 0.25 * i for i in range(pd)]
+    text = '{"vector_parameters":%s,"bits":"%s","mode":"plus","error_correction":{"shift":%s,"scale":%s}}' % (
+        _vp(5, "Dot", False), bits_text, json.dumps(vals), json.dumps([v + 1.0 for v in vals]))
     rc, m = _parse(F.DTYPE_TQ, text)
-    assert rc == 0 and m.tq.plus_mode == 1
+    assert rc == 0 and m.tq.plus_mode == 1, F.last_error()
+    got = np.ctypeslib.as_array(C.cast(m.tq.ec_shift, C.POINTER(C.c_float)), (pd,)).copy()
+    got2 = np.ctypeslib.as_array(C.cast(m.tq.ec_scale, C.POINTER(C.c_float)), (pd,)).copy()
+    assert got.tolist() == vals and got2.tolist() == [v + 1.0 for v in vals]
     _free(m)
+    rc, m = _parse(F.DTYPE_TQ, text.replace(json.dumps(vals), json.dumps(vals[:-1])))     # wrong length (new_error_correction_from_metadata :70-91)
+    assert rc == F.ERR_BAD_ARG
+    rc, m = _parse(F.DTYPE_TQ, '{"vector_parameters":%s,"bits":"%s","mode":"plus","error_correction":null}' % (_vp(5, "Dot", False), bits_text))
+    assert rc == F.ERR_BAD_ARG
     for bad in ('{"vector_parameters":%s,"bits":"bits3","mode":"normal"}' % _vp(4, "Dot", False),
                 '{"vector_parameters":%s,"bits":"%s"}' % (_vp(4, "Dot", False), bits_text),
                 '{"vector_parameters":%s,"bits":"%s","mode":"normal","rotation":"sideways"}' % (_vp(4, "Dot", False), bits_text)):
