@@ -249,6 +249,7 @@ struct qmx_query {
 // f32 dot / cosine rows of >= 32 elements scan 8..32 queries per pass on the f32 matrix cores (scan_mfma.hip)
 static bool mfma_scan_ok(const qmx_segment *s) {
     if (s->dtype == QMX_DTYPE_SQ_U8) return sq_mfma_ok(s->distance, s->scan_dim) && !option(OPT_NO_MFMA_SCAN);
+    if (s->dtype == QMX_DTYPE_TQ) return s->tq_value_bits != 1 && !option(OPT_NO_MFMA_SCAN);   // 4 / 2 bits: scan_sq_mfma.hip TqOps
     return (s->dtype == QMX_DTYPE_F32 || s->dtype == QMX_DTYPE_F16) && (s->distance == QMX_DISTANCE_DOT || s->distance == QMX_DISTANCE_COSINE) && s->dim >= 32 &&
            s->fast_layout() && !option(OPT_NO_MFMA_SCAN);
 }
@@ -257,6 +258,7 @@ constexpr uint32_t MAX_QT_TOPK = 64;   // the chain-major f32 top-k scan (scan_m
 // queries scored per pass of the stored block
 static uint32_t tile_qt(const qmx_segment *s) {
     if (s->dtype == QMX_DTYPE_SQ_U8) return mfma_scan_ok(s) ? MAX_QT_MFMA : MAX_QT;
+    if (s->dtype == QMX_DTYPE_TQ) return mfma_scan_ok(s) && (size_t)MAX_QT_MFMA * ((size_t)s->scan_dim * (s->tq_value_bits == 4 ? 4 : 8) + 128 + QUERY_AUX_BYTES) <= 150 * 1024 ? MAX_QT_MFMA : MAX_QT;
     return mfma_scan_ok(s) && (size_t)MAX_QT_MFMA * (((size_t)s->dim * 4 + 127) / 128 * 128 + QUERY_AUX_BYTES) <= 150 * 1024 ? MAX_QT_MFMA : MAX_QT;
 }
 
@@ -1029,6 +1031,8 @@ static int32_t query_alloc(const qmx_segment *seg, uint32_t nq, qmx_query **out,
     if (seg->dtype == QMX_DTYPE_TQ)   // query pieces per 16-byte row piece (scan_tq.hip); 1-bit storage under TQ+: 16 bit planes
         q->bq_bits = seg->tq_value_bits == 4 ? 4 : (seg->tq_value_bits == 1 && seg->d_tq_shift) ? 16 : 8;
     q->aux_off = (uint32_t)((seg->scan_dim * elem_bytes(seg->dtype) * q->bq_bits + 127) & ~127u);
+    // TurboQuant: the matrix-core scan (scan_sq_mfma.hip TqOps) reads whole 64-byte row steps: the zero padding of the entry must cover the last one
+    if (seg->dtype == QMX_DTYPE_TQ) q->aux_off = ((seg->scan_dim + 63) & ~63u) * q->bq_bits;
     q->q_stride = q->aux_off + QUERY_AUX_BYTES;
     if (seg->dtype == QMX_DTYPE_PQ) {   // the encoded query is the LUT [m][n_centroids] f32 (EncodedQueryPQ)
         q->q_stride = (uint32_t)(((size_t)seg->pq_m * seg->pq.n_centroids * sizeof(float) + 15) & ~(size_t)15);
@@ -1347,7 +1351,11 @@ static int32_t launch_scan(const qmx_query *q, int qt, ScanMode mode, const Scan
         QMX_REQUIRE(s->fast_layout(), QMX_ERR_NOT_SUPPORTED, "adopted BQ block is not 16-byte aligned");
         return launch_scan_bq(q->stream, std::min(qt, (int)MAX_QT), mode, a, s->num_cus, grid);
     }
-    if (s->dtype == QMX_DTYPE_TQ) return launch_scan_tq(q->stream, std::min(qt, (int)MAX_QT), mode, a, s->num_cus, grid);
+    if (s->dtype == QMX_DTYPE_TQ) {
+        // 4 queries already pay for the padded 16-query matrix-core pass (integer arithmetic either way: the same bits)
+        if (qt >= 4 && mfma_scan_ok(s)) return launch_scan_tq_mfma(q->stream, std::max(qt, 8), mode, a, s->num_cus, grid);
+        return launch_scan_tq(q->stream, std::min(qt, (int)MAX_QT), mode, a, s->num_cus, grid);
+    }
     set_error("dtype %u not built yet", s->dtype);
     return QMX_ERR_NOT_SUPPORTED;
 }
@@ -1591,7 +1599,7 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
             // best score, so nothing that belongs to the result is rejected (ties pass), and only ~1024 k rows per query beat it.
             // (Running the pre-scan as a top-k pass of the chain-major kernel itself was insertion-bound: 0.2 ms instead of 0.06.)
             const bool m16 = s->dtype == QMX_DTYPE_F32 && mfma_scan_ok(s) && mfma16_scan_ok(qt, SCAN_TOPK, a);
-            const bool sqm = (s->dtype == QMX_DTYPE_SQ_U8 ? qt >= 4 : s->dtype == QMX_DTYPE_F16 && qt >= 8) && mfma_scan_ok(s);   // scan_sq_mfma.hip starts from the bound too
+            const bool sqm = (s->dtype == QMX_DTYPE_SQ_U8 || s->dtype == QMX_DTYPE_TQ ? qt >= 4 : s->dtype == QMX_DTYPE_F16 && qt >= 8) && mfma_scan_ok(s);   // scan_sq_mfma.hip starts from the bound too
             const bool m4 = s->dtype == QMX_DTYPE_F32 && qt >= 8 && mfma_scan_ok(s);                                        // scan_mfma.hip (4x4x1) as well
             const bool bqk = s->dtype == QMX_DTYPE_BQ && qt >= 4;   // bq_rows_kernel: integer scores, selection-bound without a starting threshold
             if (pass == 0 && n_cand >= (1u << 18) && (m16 || sqm || m4 || bqk) && !option(OPT_NO_PRESCAN)) {

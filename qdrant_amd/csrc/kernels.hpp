@@ -115,6 +115,7 @@ struct TqRotationHost {        // HadamardRotation on the device: forward maps, 
     uint32_t n_chunks, rot_dim, padded_dim, dim;
 };
 int32_t launch_scan_tq(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out);
+int32_t launch_scan_tq_mfma(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out);   // scan_sq_mfma.hip, 4 / 2 bits
 int32_t launch_hnsw_tq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_tq_split(hipStream_t st, const void *rows, uint64_t src_stride, uint64_t n, uint32_t code_bytes, uint32_t dst_stride, int has_l2,
                         void *codes, float *sf, float *l2, float *xm);

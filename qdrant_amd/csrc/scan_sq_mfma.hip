@@ -28,31 +28,104 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // What differs between the element types that share this kernel (64 row bytes per lane-step, 16 rows x 16 queries per MFMA)
+__device__ __forceinline__ i32x4 mfma_i8(const uint4 &x, const uint4 &y, i32x4 c) {
+    return __builtin_amdgcn_mfma_i32_16x16x64_i8((i32x4){(int)x.x, (int)x.y, (int)x.z, (int)x.w}, (i32x4){(int)y.x, (int)y.y, (int)y.z, (int)y.w}, c, 0, 0, 0);
+}
+// An Ops type says: NA accumulators per 16-query group, QSTEP query bytes per 64-byte row step (the lane's share: QSTEP / 4 at kg * QSTEP / 4),
+// how a lane's 16 row bytes are decoded (once per step, not once per query group) and multiplied, and how a score is finished.
 struct SqOps {     // EncodedVectorsU8: exact integer dot, then postprocess_score
     typedef i32x4 acc_t;
+    static constexpr int NA = 1;
+    static constexpr uint32_t QSTEP = 64;
+    typedef uint4 dec_t;
     static __device__ __forceinline__ uint32_t body_bytes(const ScanArgs &a) { return a.dim; }   // actual_dim code bytes
-    static __device__ __forceinline__ acc_t mfma(const uint4 &x, const uint4 &y, acc_t c) {
-        return __builtin_amdgcn_mfma_i32_16x16x64_i8((i32x4){(int)x.x, (int)x.y, (int)x.z, (int)x.w}, (i32x4){(int)y.x, (int)y.y, (int)y.z, (int)y.w},
-                                                     c, 0, 0, 0);
+    static __device__ __forceinline__ void decode(const uint4 &x, dec_t &d) { d = x; }
+    static __device__ __forceinline__ void mac(const dec_t &d, const unsigned char *qp, acc_t (&acc)[NA]) {
+        acc[0] = mfma_i8(d, *reinterpret_cast<const uint4 *>(qp), acc[0]);
     }
     static __device__ __forceinline__ float row_aux(const ScanArgs &a, uint32_t rid) { return a.row_offsets[rid]; }
     // multiplier * dot + query_offset + vector_offset, left to right, not fused (encoded_vectors_u8.rs:100-103)
-    static __device__ __forceinline__ float finish(const ScanArgs &a, int acc, const unsigned char *q_entry, const unsigned char *, float v_off) {
-        const float m1 = a.sq_multiplier * (float)acc;
+    static __device__ __forceinline__ float finish(const ScanArgs &a, const acc_t (&acc)[NA], int r, const unsigned char *q_entry, const unsigned char *, uint32_t,
+                                                   float v_off) {
+        const float m1 = a.sq_multiplier * (float)acc[0][r];
         const float mq = m1 + reinterpret_cast<const QueryAux *>(q_entry + a.aux_off)->f0;
         return mq + v_off;
+    }
+};
+// TurboQuant 4 / 2 bits (scan_tq.hip: the same integer arithmetic on the VALU): a lane's 16 code bytes are 32 / 64 dims; decoded to signed codebook
+// bytes they are 2 / 4 operand registers (even / odd dims; dims = j mod 4), each multiplied with the low and the high half of the query
+// (q_signed = 128 high + low): 4 / 8 matrix instructions per step and group, two i32 accumulators.  The query entry keeps its scan_tq.hip layout:
+// per 16-byte row piece [low pieces][high pieces], i.e. 64 / 128 query bytes per lane and step.
+template <int BITS, bool L2>
+struct TqOps {
+    typedef i32x4 acc_t;
+    static constexpr int NA = 2;                      // sum low * c, sum high * c
+    static constexpr int NP = BITS == 4 ? 2 : 4;      // operand registers a decoded piece fills
+    static constexpr uint32_t QSTEP = 64 * 2 * NP;    // query bytes per 64-byte row step
+    struct dec_t { uint4 c[NP]; };
+    static __device__ __forceinline__ uint32_t body_bytes(const ScanArgs &a) { return a.dim; }   // code bytes of a device row (16-byte multiple)
+    static __device__ __forceinline__ uint32_t lut4(uint32_t sel) {
+        const uint32_t s = sel & 0x07070707u;
+        const uint32_t lo = __builtin_amdgcn_perm(0xFAEEE1D4u, 0xC5B49F80u, s), hi = __builtin_amdgcn_perm(0x7F614C3Bu, 0x2C1F1206u, s);
+        const uint32_t m = ((sel >> 3) & 0x01010101u) * 0xFFu;
+        return (hi & m) | (lo & ~m);
+    }
+    static __device__ __forceinline__ void decode(const uint4 &x, dec_t &d) {
+        const uint32_t v[4] = {x.x, x.y, x.z, x.w};
+        uint32_t o[NP][4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (BITS == 4) {
+                o[0][w] = lut4(v[w] & 0x0F0F0F0Fu);
+                o[1][w] = lut4((v[w] >> 4) & 0x0F0F0F0Fu);
+            } else {
+#pragma unroll
+                for (int j = 0; j < NP; ++j) o[j][w] = __builtin_amdgcn_perm(0u, 0x7F26DA80u, (v[w] >> (2 * j)) & 0x03030303u);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) d.c[j] = make_uint4(o[j][0], o[j][1], o[j][2], o[j][3]);
+    }
+    static __device__ __forceinline__ void mac(const dec_t &d, const unsigned char *qp, acc_t (&acc)[NA]) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            acc[0] = mfma_i8(d.c[j], *reinterpret_cast<const uint4 *>(qp + j * 16), acc[0]);
+            acc[1] = mfma_i8(d.c[j], *reinterpret_cast<const uint4 *>(qp + (NP + j) * 16), acc[1]);
+        }
+    }
+    static __device__ __forceinline__ float row_aux(const ScanArgs &a, uint32_t rid) { return a.tq_sf[rid]; }
+    static __device__ __forceinline__ float finish(const ScanArgs &a, const acc_t (&acc)[NA], int r, const unsigned char *q_entry, const unsigned char *, uint32_t rid,
+                                                   float sf) {
+        const int64_t sum = (int64_t)acc[0][r] + 128 * (int64_t)acc[1][r];
+        const QueryAux *aux = reinterpret_cast<const QueryAux *>(q_entry + a.aux_off);
+        const float dot = aux->f0 * (float)sum + __uint_as_float(aux->pad[3]);
+        float score;
+        if (L2) {
+            const float ql = __uint_as_float(aux->pad[0]), l2 = a.tq_l2[rid];
+            const float x = ql * ql, y = l2 * l2, z = (2.0f * dot) * sf;
+            score = (x + y) - z;
+        } else {
+            score = dot * sf;
+        }
+        return a.tq_invert ? -score : score;
     }
 };
 struct F16Ops {    // Metric<f16> dot / cosine: f16 products are exact in f32, f32 accumulation (order differs from the
                    // x86 leaf: within 1e-5 of it, the bar of the f16 path), scalar tail as in metric_f16/avx/dot.rs:64-66
     typedef f32x4 acc_t;
+    static constexpr int NA = 1;
+    static constexpr uint32_t QSTEP = 64;
+    typedef uint4 dec_t;
     static __device__ __forceinline__ uint32_t body_bytes(const ScanArgs &a) { return a.tail_start * 2; }
-    static __device__ __forceinline__ acc_t mfma(const uint4 &x, const uint4 &y, acc_t c) {
-        return __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8 *>(&x), *reinterpret_cast<const f16x8 *>(&y), c, 0, 0, 0);
+    static __device__ __forceinline__ void decode(const uint4 &x, dec_t &d) { d = x; }
+    static __device__ __forceinline__ void mac(const dec_t &d, const unsigned char *qp, acc_t (&acc)[NA]) {
+        const uint4 y = *reinterpret_cast<const uint4 *>(qp);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8 *>(&d), *reinterpret_cast<const f16x8 *>(&y), acc[0], 0, 0, 0);
     }
     static __device__ __forceinline__ float row_aux(const ScanArgs &, uint32_t) { return 0.0f; }
-    static __device__ __forceinline__ float finish(const ScanArgs &a, float acc, const unsigned char *q_entry, const unsigned char *row, float) {
-        float result = acc;
+    static __device__ __forceinline__ float finish(const ScanArgs &a, const acc_t (&accs)[NA], int r, const unsigned char *q_entry, const unsigned char *row, uint32_t,
+                                                   float) {
+        float result = accs[0][r];
         const _Float16 *qh = reinterpret_cast<const _Float16 *>(q_entry);
         const _Float16 *vh = reinterpret_cast<const _Float16 *>(row);
         for (uint32_t i = a.tail_start; i < a.dim; ++i) result += (float)qh[i] * (float)vh[i];
@@ -83,7 +156,7 @@ __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs 
     const unsigned char *rows = reinterpret_cast<const unsigned char *>(a.rows);
     const uint32_t nbytes = Ops::body_bytes(a);             // bytes of the SIMD body per row (multiple of 16)
     const uint32_t nstep = (nbytes + 63) / 64;
-    const unsigned char *qbase = smem + (uint32_t)n * a.q_stride + (uint32_t)kg * 16;   // + g * 16 * q_stride + s * 64
+    const unsigned char *qbase = smem + (uint32_t)n * a.q_stride + (uint32_t)kg * (Ops::QSTEP / 4);   // + g * 16 * q_stride + s * QSTEP
     const uint32_t gstride = 16u * a.q_stride;
     const int top = (int)a.top;
 
@@ -141,9 +214,11 @@ __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs 
         }
         const unsigned char *rp_next = rows + (uint64_t)row_of(tile + tw < n_tiles ? tile + tw : 0, n, nullptr) * a.row_stride;
 
-        typename Ops::acc_t acc[NG];
+        typename Ops::acc_t acc[NG][Ops::NA];
 #pragma unroll
-        for (int g = 0; g < NG; ++g) acc[g] = (typename Ops::acc_t){0, 0, 0, 0};
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int k = 0; k < Ops::NA; ++k) acc[g][k] = (typename Ops::acc_t){0, 0, 0, 0};
 
         for (uint32_t s0 = 0; s0 < nstep; s0 += D) {
             const bool last_chunk = s0 + D >= nstep;
@@ -154,11 +229,10 @@ __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs 
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 if (s0 + d < nstep) {
+                    typename Ops::dec_t dec;
+                    Ops::decode(cur[d], dec);
 #pragma unroll
-                    for (int g = 0; g < NG; ++g) {
-                        const uint4 qq = *reinterpret_cast<const uint4 *>(qbase + (uint32_t)g * gstride + (s0 + d) * 64);
-                        acc[g] = Ops::mfma(cur[d], qq, acc[g]);
-                    }
+                    for (int g = 0; g < NG; ++g) Ops::mac(dec, qbase + (uint32_t)g * gstride + (s0 + d) * Ops::QSTEP, acc[g]);
                 }
             }
 #pragma unroll
@@ -172,7 +246,7 @@ __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs 
             const uint32_t q = (uint32_t)(16 * g + n);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float score = Ops::finish(a, acc[g][r], smem + q * a.q_stride, rows + (uint64_t)rid[r] * a.row_stride, v_off[r]);
+                const float score = Ops::finish(a, acc[g], r, smem + q * a.q_stride, rows + (uint64_t)rid[r] * a.row_stride, rid[r], v_off[r]);
                 const bool mine = valid[r] && q < a.nq;
                 if (MODE == SCAN_SCORES) {
                     if (mine) a.scores[(uint64_t)q * a.scores_stride + (tile * 16 + (uint32_t)(4 * kg + r))] = score;
@@ -286,6 +360,23 @@ int32_t launch_scan_sq_mfma(hipStream_t st, int qt, ScanMode mode, const ScanArg
     }
     set_error("unsupported SQ MFMA query tile %d", qt);
     return QMX_ERR_BAD_ARG;
+}
+
+// TurboQuant 4 / 2 bits, 4..32 queries per pass (1-bit storages keep the VALU kernel of scan_tq.hip)
+int32_t launch_scan_tq_mfma(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
+    const bool l2 = a.tq_l2 != nullptr;
+#define QMX_TQM(B, L)                                                                       \
+    if (a.tq_bits == B && l2 == L) {                                                        \
+        if (qt <= 16) return launch_sqm_qt<TqOps<B, L>, 16, 4>(st, mode, a, num_cus, grid_out); \
+        return launch_sqm_qt<TqOps<B, L>, 32, 4>(st, mode, a, num_cus, grid_out);           \
+    }
+    QMX_TQM(4, false)
+    QMX_TQM(4, true)
+    QMX_TQM(2, false)
+    QMX_TQM(2, true)
+#undef QMX_TQM
+    set_error("TurboQuant matrix-core scan: %u bits not supported", a.tq_bits);
+    return QMX_ERR_NOT_SUPPORTED;
 }
 
 // f16 rows, dot / cosine, dim >= 32: v_mfma_f32_16x16x32_f16, same streaming structure (64 row bytes = 32 halfs per step)
