@@ -215,6 +215,7 @@ struct qmx_query {
     uint32_t nq_padded = 0;
     uint32_t q_stride = 0;     // bytes
     uint32_t bq_bits = 1;      // BQ: bit planes per query value (1 for SameAsStorage and for internal queries = stored rows)
+    uint32_t tq_qbytes_off = 0; // TurboQuant 1-bit: where the i8 form of the query sits inside an entry
     uint32_t aux_off = 0;      // bytes
     void *d_queries = nullptr; // [nq_padded][q_stride]
     hipStream_t stream = nullptr;
@@ -249,7 +250,7 @@ struct qmx_query {
 // f32 dot / cosine rows of >= 32 elements scan 8..32 queries per pass on the f32 matrix cores (scan_mfma.hip)
 static bool mfma_scan_ok(const qmx_segment *s) {
     if (s->dtype == QMX_DTYPE_SQ_U8) return sq_mfma_ok(s->distance, s->scan_dim) && !option(OPT_NO_MFMA_SCAN);
-    if (s->dtype == QMX_DTYPE_TQ) return s->tq_value_bits != 1 && !option(OPT_NO_MFMA_SCAN);   // 4 / 2 bits: scan_sq_mfma.hip TqOps
+    if (s->dtype == QMX_DTYPE_TQ) return !option(OPT_NO_MFMA_SCAN);   // scan_sq_mfma.hip TqOps / Tq1Ops
     return (s->dtype == QMX_DTYPE_F32 || s->dtype == QMX_DTYPE_F16) && (s->distance == QMX_DISTANCE_DOT || s->distance == QMX_DISTANCE_COSINE) && s->dim >= 32 &&
            s->fast_layout() && !option(OPT_NO_MFMA_SCAN);
 }
@@ -258,7 +259,7 @@ constexpr uint32_t MAX_QT_TOPK = 64;   // the chain-major f32 top-k scan (scan_m
 // queries scored per pass of the stored block
 static uint32_t tile_qt(const qmx_segment *s) {
     if (s->dtype == QMX_DTYPE_SQ_U8) return mfma_scan_ok(s) ? MAX_QT_MFMA : MAX_QT;
-    if (s->dtype == QMX_DTYPE_TQ) return mfma_scan_ok(s) && (size_t)MAX_QT_MFMA * ((size_t)s->scan_dim * (s->tq_value_bits == 4 ? 4 : 8) + 128 + QUERY_AUX_BYTES) <= 150 * 1024 ? MAX_QT_MFMA : MAX_QT;
+    if (s->dtype == QMX_DTYPE_TQ) return mfma_scan_ok(s) && (size_t)MAX_QT_MFMA * (((size_t)s->scan_dim + 63) * (s->tq_value_bits == 4 ? 4 : s->tq_value_bits == 2 ? 8 : 32) + QUERY_AUX_BYTES) <= 150 * 1024 ? MAX_QT_MFMA : MAX_QT;
     return mfma_scan_ok(s) && (size_t)MAX_QT_MFMA * (((size_t)s->dim * 4 + 127) / 128 * 128 + QUERY_AUX_BYTES) <= 150 * 1024 ? MAX_QT_MFMA : MAX_QT;
 }
 
@@ -1032,7 +1033,14 @@ static int32_t query_alloc(const qmx_segment *seg, uint32_t nq, qmx_query **out,
         q->bq_bits = seg->tq_value_bits == 4 ? 4 : (seg->tq_value_bits == 1 && seg->d_tq_shift) ? 16 : 8;
     q->aux_off = (uint32_t)((seg->scan_dim * elem_bytes(seg->dtype) * q->bq_bits + 127) & ~127u);
     // TurboQuant: the matrix-core scan (scan_sq_mfma.hip TqOps) reads whole 64-byte row steps: the zero padding of the entry must cover the last one
-    if (seg->dtype == QMX_DTYPE_TQ) q->aux_off = ((seg->scan_dim + 63) & ~63u) * q->bq_bits;
+    if (seg->dtype == QMX_DTYPE_TQ) {
+        const uint32_t body = (seg->scan_dim + 63) & ~63u;
+        q->aux_off = body * q->bq_bits;
+        if (seg->tq_value_bits == 1) {   // behind the bit planes: the same query as i8 bytes (8 per row byte; 16 with the two halves of a 16-bit TQ+ query)
+            q->tq_qbytes_off = q->aux_off;
+            q->aux_off += body * (q->bq_bits == 16 ? 16 : 8);
+        }
+    }
     q->q_stride = q->aux_off + QUERY_AUX_BYTES;
     if (seg->dtype == QMX_DTYPE_PQ) {   // the encoded query is the LUT [m][n_centroids] f32 (EncodedQueryPQ)
         q->q_stride = (uint32_t)(((size_t)seg->pq_m * seg->pq.n_centroids * sizeof(float) + 15) & ~(size_t)15);
@@ -1091,7 +1099,8 @@ static int32_t query_encode(qmx_query *q, const float *queries) {
         QMX_TRY(q->tq_rot.reserve((size_t)nq * seg->tq_padded_dim * sizeof(double)));
         QMX_TRY(launch_tq_rotate(q->stream, d_f32, nq, tq_rotation(seg), (double *)q->tq_rot.p));
         return launch_tq_query_encode(q->stream, (double *)q->tq_rot.p, nq, seg->tq_padded_dim, seg->tq_value_bits,
-                                      seg->distance == QMX_DISTANCE_EUCLID ? 1 : 0, q->d_queries, q->q_stride, q->aux_off, seg->d_tq_shift, seg->d_tq_scale);
+                                      seg->distance == QMX_DISTANCE_EUCLID ? 1 : 0, q->d_queries, q->q_stride, q->aux_off, seg->d_tq_shift, seg->d_tq_scale,
+                                      q->tq_qbytes_off);
     }
     if (seg->dtype == QMX_DTYPE_PQ)      // EncodedVectorsPQ::encode_query (encoded_vectors_pq.rs:519-541)
         return launch_pq_lut(q->stream, seg->distance, seg->dim, seg->pq, seg->d_centroids, d_f32, nq, (float *)q->d_queries);
@@ -1328,6 +1337,7 @@ static void fill_args(const qmx_query *q, uint32_t tile0, uint32_t nq_tile, Scan
     a.tq_bits = s->tq_value_bits;
     a.tq_invert = s->tq_invert ? 1 : 0;
     a.tq_planes = (s->tq_value_bits == 1 && s->d_tq_shift) ? 16 : 8;
+    a.tq_qbytes_off = q->tq_qbytes_off;
 }
 
 static int32_t launch_scan(const qmx_query *q, int qt, ScanMode mode, const ScanArgs &a, uint32_t *grid) {

@@ -58,6 +58,7 @@ struct ScanArgs {
     const float *tq_l2;        // [n] l2_length (DistanceType::L2) or nullptr
     uint32_t tq_bits, tq_invert;
     uint32_t tq_planes;        // 1-bit storage: bit planes of the query (8; 16 under TQ+)
+    uint32_t tq_qbytes_off;    // 1-bit storage: byte offset, inside a query entry, of the i8 form of the query (the matrix-core scan's operand)
     // multi-vectors (MaxSim walk, hnsw.hpp HopMaxSim): point p = inner rows [mv_offsets[p], mv_offsets[p + 1]); multi-query j = query entries
     // [mv_qfirst[j], mv_qfirst[j + 1])
     const uint64_t *mv_offsets;
@@ -125,7 +126,7 @@ int32_t launch_tq_rotate(hipStream_t st, const float *d_in, uint32_t n, const Tq
 int32_t launch_tq_quantize(hipStream_t st, double *d_rot, uint32_t n, uint32_t padded_dim, uint32_t value_bits, uint32_t distance, void *d_out,
                            uint32_t out_stride, const float *d_shift, const float *d_scale);
 int32_t launch_tq_query_encode(hipStream_t st, double *d_rot, uint32_t nq, uint32_t padded_dim, uint32_t bits, int need_l2, void *tile, uint32_t q_stride,
-                               uint32_t aux_off, const float *d_shift, const float *d_scale);
+                               uint32_t aux_off, const float *d_shift, const float *d_scale, uint32_t qbytes_off);
 struct TqEc {                  // TQ+ symmetric scoring (score_symmetric_ec): i16 weights D'^2 per coordinate, their scale, <M, M>, the rows' xm column
     const int16_t *weights;
     const float *xm;

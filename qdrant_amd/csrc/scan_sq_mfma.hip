@@ -28,6 +28,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // What differs between the element types that share this kernel (64 row bytes per lane-step, 16 rows x 16 queries per MFMA)
+// byte offset, inside a query entry, of the operand this kernel reads (Tq1Ops: the i8 form behind the bit planes); 0 unless the Ops say otherwise
+// whether finish() wants the number of set bits of the row (counted from the pieces the wave reads anyway)
+template <class Ops, class = void> struct ops_row_ones { static constexpr bool value = false; };
+template <class Ops> struct ops_row_ones<Ops, decltype((void)Ops::ROW_ONES)> { static constexpr bool value = Ops::ROW_ONES; };
+template <class Ops, class = void> struct ops_query_off { static __device__ __forceinline__ uint32_t get(const ScanArgs &) { return 0; } };
+template <class Ops> struct ops_query_off<Ops, decltype((void)&Ops::query_off)> { static __device__ __forceinline__ uint32_t get(const ScanArgs &a) { return Ops::query_off(a); } };
+
 __device__ __forceinline__ i32x4 mfma_i8(const uint4 &x, const uint4 &y, i32x4 c) {
     return __builtin_amdgcn_mfma_i32_16x16x64_i8((i32x4){(int)x.x, (int)x.y, (int)x.z, (int)x.w}, (i32x4){(int)y.x, (int)y.y, (int)y.z, (int)y.w}, c, 0, 0, 0);
 }
@@ -46,7 +53,7 @@ struct SqOps {     // EncodedVectorsU8: exact integer dot, then postprocess_scor
     static __device__ __forceinline__ float row_aux(const ScanArgs &a, uint32_t rid) { return a.row_offsets[rid]; }
     // multiplier * dot + query_offset + vector_offset, left to right, not fused (encoded_vectors_u8.rs:100-103)
     static __device__ __forceinline__ float finish(const ScanArgs &a, const acc_t (&acc)[NA], int r, const unsigned char *q_entry, const unsigned char *, uint32_t,
-                                                   float v_off) {
+                                                   float v_off, uint32_t) {
         const float m1 = a.sq_multiplier * (float)acc[0][r];
         const float mq = m1 + reinterpret_cast<const QueryAux *>(q_entry + a.aux_off)->f0;
         return mq + v_off;
@@ -95,7 +102,7 @@ struct TqOps {
     }
     static __device__ __forceinline__ float row_aux(const ScanArgs &a, uint32_t rid) { return a.tq_sf[rid]; }
     static __device__ __forceinline__ float finish(const ScanArgs &a, const acc_t (&acc)[NA], int r, const unsigned char *q_entry, const unsigned char *, uint32_t rid,
-                                                   float sf) {
+                                                   float sf, uint32_t) {
         const int64_t sum = (int64_t)acc[0][r] + 128 * (int64_t)acc[1][r];
         const QueryAux *aux = reinterpret_cast<const QueryAux *>(q_entry + a.aux_off);
         const float dot = aux->f0 * (float)sum + __uint_as_float(aux->pad[3]);
@@ -110,6 +117,52 @@ struct TqOps {
         return a.tq_invert ? -score : score;
     }
 };
+// TurboQuant 1 bit (and 1.5): a lane's 16 row bytes are 128 dims; bit j of every byte -> operand register j (0 / 1 bytes, the dims = j mod 8 in
+// row-byte order) against the i8 form of the query (scan_tq.hip tq_query_encode_kernel): v . q = sum over set bits of q, 8 matrix instructions per
+// step and group (16 with the two halves of a 16-bit TQ+ query: NA = 2; +-32767 does not fit two signed digits, so the low one is stored
+// less 128 and the row's count of set bits, ROW_ONES, pays it back).  score = scale * (2 v . q - sum q), as RowTQ1.
+template <int NA_, bool L2>
+struct Tq1Ops {
+    typedef i32x4 acc_t;
+    static constexpr int NA = NA_;
+    static constexpr uint32_t QSTEP = 4 * 128 * NA_;
+    static constexpr bool ROW_ONES = NA_ == 2;
+    struct dec_t { uint4 c[8]; };
+    static __device__ __forceinline__ uint32_t body_bytes(const ScanArgs &a) { return a.dim; }
+    static __device__ __forceinline__ uint32_t query_off(const ScanArgs &a) { return a.tq_qbytes_off; }
+    static __device__ __forceinline__ void decode(const uint4 &x, dec_t &d) {
+        const uint32_t v[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            d.c[j] = make_uint4((v[0] >> j) & 0x01010101u, (v[1] >> j) & 0x01010101u, (v[2] >> j) & 0x01010101u, (v[3] >> j) & 0x01010101u);
+    }
+    static __device__ __forceinline__ void mac(const dec_t &d, const unsigned char *qp, acc_t (&acc)[NA]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc[0] = mfma_i8(d.c[j], *reinterpret_cast<const uint4 *>(qp + j * 16), acc[0]);
+            if (NA == 2) acc[NA - 1] = mfma_i8(d.c[j], *reinterpret_cast<const uint4 *>(qp + (8 + j) * 16), acc[NA - 1]);
+        }
+    }
+    static __device__ __forceinline__ float row_aux(const ScanArgs &a, uint32_t rid) { return a.tq_sf[rid]; }
+    static __device__ __forceinline__ float finish(const ScanArgs &a, const acc_t (&acc)[NA], int r, const unsigned char *q_entry, const unsigned char *, uint32_t rid,
+                                                   float sf, uint32_t ones) {
+        int64_t v_dot_q = (int64_t)acc[0][r];
+        if (NA == 2) v_dot_q += 256 * (int64_t)acc[NA - 1][r] + 128 * (int64_t)ones;   // q = 256 (q >> 8) + ((q & 255) - 128) + 128
+        const QueryAux *aux = reinterpret_cast<const QueryAux *>(q_entry + a.aux_off);
+        const int64_t sum_q = (int64_t)(((uint64_t)aux->pad[2] << 32) | aux->pad[1]);
+        const float dot = aux->f0 * (float)(2 * v_dot_q - sum_q) + __uint_as_float(aux->pad[3]);
+        float score;
+        if (L2) {
+            const float ql = __uint_as_float(aux->pad[0]), l2 = a.tq_l2[rid];
+            const float x = ql * ql, y = l2 * l2, z = (2.0f * dot) * sf;
+            score = (x + y) - z;
+        } else {
+            score = dot * sf;
+        }
+        return a.tq_invert ? -score : score;
+    }
+};
+
 struct F16Ops {    // Metric<f16> dot / cosine: f16 products are exact in f32, f32 accumulation (order differs from the
                    // x86 leaf: within 1e-5 of it, the bar of the f16 path), scalar tail as in metric_f16/avx/dot.rs:64-66
     typedef f32x4 acc_t;
@@ -124,7 +177,7 @@ struct F16Ops {    // Metric<f16> dot / cosine: f16 products are exact in f32, f
     }
     static __device__ __forceinline__ float row_aux(const ScanArgs &, uint32_t) { return 0.0f; }
     static __device__ __forceinline__ float finish(const ScanArgs &a, const acc_t (&accs)[NA], int r, const unsigned char *q_entry, const unsigned char *row, uint32_t,
-                                                   float) {
+                                                   float, uint32_t) {
         float result = accs[0][r];
         const _Float16 *qh = reinterpret_cast<const _Float16 *>(q_entry);
         const _Float16 *vh = reinterpret_cast<const _Float16 *>(row);
@@ -156,7 +209,7 @@ __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs 
     const unsigned char *rows = reinterpret_cast<const unsigned char *>(a.rows);
     const uint32_t nbytes = Ops::body_bytes(a);             // bytes of the SIMD body per row (multiple of 16)
     const uint32_t nstep = (nbytes + 63) / 64;
-    const unsigned char *qbase = smem + (uint32_t)n * a.q_stride + (uint32_t)kg * (Ops::QSTEP / 4);   // + g * 16 * q_stride + s * QSTEP
+    const unsigned char *qbase = smem + (uint32_t)n * a.q_stride + ops_query_off<Ops>::get(a) + (uint32_t)kg * (Ops::QSTEP / 4);   // + g * 16 * q_stride + s * QSTEP
     const uint32_t gstride = 16u * a.q_stride;
     const int top = (int)a.top;
 
@@ -220,6 +273,7 @@ __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs 
 #pragma unroll
             for (int k = 0; k < Ops::NA; ++k) acc[g][k] = (typename Ops::acc_t){0, 0, 0, 0};
 
+        uint32_t ones = 0;
         for (uint32_t s0 = 0; s0 < nstep; s0 += D) {
             const bool last_chunk = s0 + D >= nstep;
             const unsigned char *np = last_chunk ? rp_next : rp;
@@ -231,6 +285,7 @@ __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs 
                 if (s0 + d < nstep) {
                     typename Ops::dec_t dec;
                     Ops::decode(cur[d], dec);
+                    if (ops_row_ones<Ops>::value) ones += __popc(cur[d].x) + __popc(cur[d].y) + __popc(cur[d].z) + __popc(cur[d].w);
 #pragma unroll
                     for (int g = 0; g < NG; ++g) Ops::mac(dec, qbase + (uint32_t)g * gstride + (s0 + d) * Ops::QSTEP, acc[g]);
                 }
@@ -239,6 +294,13 @@ __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs 
             for (int d = 0; d < D; ++d) cur[d] = nxt[d];
         }
         rp = rp_next;
+        uint32_t row_ones[4] = {0, 0, 0, 0};
+        if (ops_row_ones<Ops>::value) {   // lanes n, n + 16, n + 32, n + 48 hold row n's pieces; the results of rows 4 kg + r sit in this lane
+            ones += __shfl_xor(ones, 16);
+            ones += __shfl_xor(ones, 32);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) row_ones[r] = __shfl(ones, 4 * kg + r);
+        }
 
         // ---- postprocess_score (multiplier * dot + query_offset + vector_offset, left to right, not fused) + top-k ----
 #pragma unroll
@@ -246,7 +308,7 @@ __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs 
             const uint32_t q = (uint32_t)(16 * g + n);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float score = Ops::finish(a, acc[g], r, smem + q * a.q_stride, rows + (uint64_t)rid[r] * a.row_stride, rid[r], v_off[r]);
+                const float score = Ops::finish(a, acc[g], r, smem + q * a.q_stride, rows + (uint64_t)rid[r] * a.row_stride, rid[r], v_off[r], row_ones[r]);
                 const bool mine = valid[r] && q < a.nq;
                 if (MODE == SCAN_SCORES) {
                     if (mine) a.scores[(uint64_t)q * a.scores_stride + (tile * 16 + (uint32_t)(4 * kg + r))] = score;
@@ -375,6 +437,18 @@ int32_t launch_scan_tq_mfma(hipStream_t st, int qt, ScanMode mode, const ScanArg
     QMX_TQM(2, false)
     QMX_TQM(2, true)
 #undef QMX_TQM
+    if (a.tq_bits == 1) {   // 8-bit query values: one accumulator; 16-bit (TQ+): two halves
+#define QMX_TQ1(NA, L)                                                                         \
+        if ((a.tq_planes == 16 ? 2 : 1) == NA && l2 == L) {                                      \
+            if (qt <= 16) return launch_sqm_qt<Tq1Ops<NA, L>, 16, 2>(st, mode, a, num_cus, grid_out); \
+            return launch_sqm_qt<Tq1Ops<NA, L>, 32, 2>(st, mode, a, num_cus, grid_out);           \
+        }
+        QMX_TQ1(1, false)
+        QMX_TQ1(1, true)
+        QMX_TQ1(2, false)
+        QMX_TQ1(2, true)
+#undef QMX_TQ1
+    }
     set_error("TurboQuant matrix-core scan: %u bits not supported", a.tq_bits);
     return QMX_ERR_NOT_SUPPORTED;
 }

@@ -433,7 +433,7 @@ int32_t launch_tq_quantize(hipStream_t st, double *d_rot, uint32_t n, uint32_t p
 
 // ---- Query{N}bitSimd::new on the rotated queries: rot [nq][padded_dim] f64 -> tile entries ----
 __global__ __launch_bounds__(256) void tq_query_encode_kernel(double *rot, uint32_t padded_dim, uint32_t bits, int need_l2, uint8_t *tile,
-                                                              uint32_t q_stride, uint32_t aux_off, const float *shift, const float *scale) {
+                                                              uint32_t q_stride, uint32_t aux_off, const float *shift, const float *scale, uint32_t qbytes_off) {
     __shared__ float sh_max[256];
     __shared__ float sh_scale;
     __shared__ unsigned long long sh_sum;
@@ -498,6 +498,18 @@ __global__ __launch_bounds__(256) void tq_query_encode_kernel(double *rot, uint3
             const uint32_t u = (uint32_t)qs & (planes == 16 ? 0xFFFFu : 0xFFu);
             for (uint32_t b = 0; b < planes; ++b)
                 if ((u >> b) & 1u) atomicOr(reinterpret_cast<uint32_t *>(entry + ((size_t)block * planes + b) * 16 + (bit / 32) * 4), 1u << (bit % 32));
+            // the same value as i8 bytes for the matrix-core scan (scan_sq_mfma.hip Tq1Ops): per 16-byte row piece 8 pieces, piece j = the dims
+            // = j mod 8 in row-byte order; 16-bit values (TQ+) as q = 256 high + (low - 128), both stored halves in [-128, 127]
+            {
+                const uint32_t j = bit % 8, k = bit / 8;
+                if (planes == 16) {
+                    const int32_t hi = qs >> 8, lo = (qs & 255) - 128;   // qs = 256 hi + lo + 128: the scan adds 128 per set bit of the row
+                    entry[qbytes_off + ((size_t)block * 16 + j) * 16 + k] = (uint8_t)(int8_t)lo;
+                    entry[qbytes_off + ((size_t)block * 16 + 8 + j) * 16 + k] = (uint8_t)(int8_t)hi;
+                } else {
+                    entry[qbytes_off + ((size_t)block * 8 + j) * 16 + k] = (uint8_t)(int8_t)qs;
+                }
+            }
         } else {
             // balanced split q_signed = 128 h + l, l in [-64, 63]
             int32_t l_mod = qs % 128;
@@ -526,10 +538,10 @@ __global__ __launch_bounds__(256) void tq_query_encode_kernel(double *rot, uint3
     }
 }
 int32_t launch_tq_query_encode(hipStream_t st, double *d_rot, uint32_t nq, uint32_t padded_dim, uint32_t bits, int need_l2, void *tile, uint32_t q_stride,
-                               uint32_t aux_off, const float *d_shift, const float *d_scale) {
+                               uint32_t aux_off, const float *d_shift, const float *d_scale, uint32_t qbytes_off) {
     if (nq == 0) return QMX_OK;
     ::qmx::clear_stale_error();
-    hipLaunchKernelGGL(tq_query_encode_kernel, dim3(nq), dim3(256), 0, st, d_rot, padded_dim, bits, need_l2, (uint8_t *)tile, q_stride, aux_off, d_shift, d_scale);
+    hipLaunchKernelGGL(tq_query_encode_kernel, dim3(nq), dim3(256), 0, st, d_rot, padded_dim, bits, need_l2, (uint8_t *)tile, q_stride, aux_off, d_shift, d_scale, qbytes_off);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }
