@@ -257,10 +257,18 @@ static bool mfma_scan_ok(const qmx_segment *s) {
 constexpr uint32_t MAX_QT_MFMA = 32;
 constexpr uint32_t MAX_QT_TOPK = 64;   // the chain-major f32 top-k scan (scan_mfma16.hip) takes 64 queries per pass of the block
 // queries scored per pass of the stored block
-static uint32_t tile_qt(const qmx_segment *s) {
+static bool bq_mfma_ok(const qmx_query *q);
+static uint32_t tile_qt(const qmx_segment *s, const qmx_query *q) {
+    if (s->dtype == QMX_DTYPE_BQ) return bq_mfma_ok(q) && (size_t)MAX_QT_MFMA * q->q_stride <= 150 * 1024 ? MAX_QT_MFMA : MAX_QT;
     if (s->dtype == QMX_DTYPE_SQ_U8) return mfma_scan_ok(s) ? MAX_QT_MFMA : MAX_QT;
     if (s->dtype == QMX_DTYPE_TQ) return mfma_scan_ok(s) && (size_t)MAX_QT_MFMA * (((size_t)s->scan_dim + 63) * (s->tq_value_bits == 4 ? 4 : s->tq_value_bits == 2 ? 8 : 32) + QUERY_AUX_BYTES) <= 150 * 1024 ? MAX_QT_MFMA : MAX_QT;
     return mfma_scan_ok(s) && (size_t)MAX_QT_MFMA * (((size_t)s->dim * 4 + 127) / 128 * 128 + QUERY_AUX_BYTES) <= 150 * 1024 ? MAX_QT_MFMA : MAX_QT;
+}
+
+// BQ rows against scalar-encoded queries (4 / 8 bit planes): 4 queries and more go to the int8 matrix cores (scan_sq_mfma.hip BqOps); the entries carry
+// the byte form of the values for it (query_alloc)
+static bool bq_mfma_ok(const qmx_query *q) {
+    return q->seg->dtype == QMX_DTYPE_BQ && q->tq_qbytes_off != 0 && !option(OPT_NO_MFMA_SCAN) && (size_t)MAX_QT * q->q_stride <= 150 * 1024;
 }
 
 // stage a possibly-host buffer on the query's stream; returns a device pointer
@@ -1041,6 +1049,10 @@ static int32_t query_alloc(const qmx_segment *seg, uint32_t nq, qmx_query **out,
             q->aux_off += body * (q->bq_bits == 16 ? 16 : 8);
         }
     }
+    if (seg->dtype == QMX_DTYPE_BQ && q->bq_bits > 1 && seg->fast_layout()) {   // behind the planes: the values as bytes (scan_sq_mfma.hip BqOps), 8 per row byte
+        q->tq_qbytes_off = q->aux_off;
+        q->aux_off += ((seg->scan_dim + 63) & ~63u) * 8;
+    }
     q->q_stride = q->aux_off + QUERY_AUX_BYTES;
     if (seg->dtype == QMX_DTYPE_PQ) {   // the encoded query is the LUT [m][n_centroids] f32 (EncodedQueryPQ)
         q->q_stride = (uint32_t)(((size_t)seg->pq_m * seg->pq.n_centroids * sizeof(float) + 15) & ~(size_t)15);
@@ -1092,7 +1104,8 @@ static int32_t query_encode(qmx_query *q, const float *queries) {
         return launch_sq_encode(q->stream, (int)seg->distance, seg->sq, seg->dim, d_f32, nq, (uint8_t *)q->d_queries, q->q_stride,
                                 nullptr, nullptr, 1, q->aux_off);
     if (seg->dtype == QMX_DTYPE_BQ && q->bq_bits > 1)   // encode_query_vector, Scalar4bits / Scalar8bits (:683-756)
-        return launch_bq_encode_scalar_query(q->stream, d_f32, nq, seg->dim, seg->bq_encoding, q->bq_bits, (uint8_t *)q->d_queries, q->q_stride);
+        return launch_bq_encode_scalar_query(q->stream, d_f32, nq, seg->dim, seg->bq_encoding, q->bq_bits, (uint8_t *)q->d_queries, q->q_stride, q->tq_qbytes_off,
+                                             q->aux_off, (seg->scan_dim + 63) & ~63u);
     if (seg->dtype == QMX_DTYPE_BQ)      // encode_query_vector, SameAsStorage (encoded_vectors_binary.rs:673-690) = encode_one_bit_vector
         return launch_bq_encode(q->stream, d_f32, nq, seg->dim, seg->bq_encoding, seg->d_bq_mean, seg->d_bq_stddev, (uint8_t *)q->d_queries, q->q_stride);
     if (seg->dtype == QMX_DTYPE_TQ) {    // TurboQuantizer::precompute_query (turboquant/quantization.rs:496-567)
@@ -1359,6 +1372,7 @@ static int32_t launch_scan(const qmx_query *q, int qt, ScanMode mode, const Scan
     if (s->dtype == QMX_DTYPE_PQ) return launch_scan_pq(q->stream, mode, a, s->num_cus, grid);
     if (s->dtype == QMX_DTYPE_BQ) {
         QMX_REQUIRE(s->fast_layout(), QMX_ERR_NOT_SUPPORTED, "adopted BQ block is not 16-byte aligned");
+        if (qt >= 4 && bq_mfma_ok(q)) return launch_scan_bq_mfma(q->stream, std::max(qt, 8), mode, a, s->num_cus, grid);
         return launch_scan_bq(q->stream, std::min(qt, (int)MAX_QT), mode, a, s->num_cus, grid);
     }
     if (s->dtype == QMX_DTYPE_TQ) {
@@ -1373,7 +1387,7 @@ static int32_t launch_scan(const qmx_query *q, int qt, ScanMode mode, const Scan
 // scores[qi * n + i] for every query of the batch
 static int32_t score_ids_device(qmx_query *q, const uint32_t *d_ids, uint64_t n, float *d_scores, qmx_counters *counters) {
     const qmx_segment *s = q->seg;
-    const uint32_t TQ = tile_qt(s);
+    const uint32_t TQ = tile_qt(s, q);
     for (uint32_t tile0 = 0; tile0 < q->nq; tile0 += TQ) {
         const uint32_t nq_tile = std::min<uint32_t>(TQ, q->nq - tile0);
         ScanArgs a;
@@ -1481,7 +1495,7 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
                        !d_ids && top <= MAX_TOP_FAST && n_cand >= (1u << 18) && s->dim % 128 == 0 && s->row_stride % 16 == 0 && !option(OPT_NO_SPLIT_SCAN);
     // the 256-query shape halves the bytes streamed per query; a batch that does not fill it is served by the 128-query shape (less matrix work)
     const uint32_t split_qt = (split && s->d_rows_split && s->split_half && q->nq > SPLIT_QT && !option(OPT_NO_SPLIT256)) ? SPLIT_QT_MAX : SPLIT_QT;
-    const uint32_t TQ = split ? split_qt : q64 ? MAX_QT_TOPK : q32 ? MAX_QT_MFMA : tile_qt(s);
+    const uint32_t TQ = split ? split_qt : q64 ? MAX_QT_TOPK : q32 ? MAX_QT_MFMA : tile_qt(s, q);
     const uint32_t ptop_max = std::min<uint32_t>(top, MAX_TOP_FAST);
     const uint32_t n_pass = (top + MAX_TOP_FAST - 1) / MAX_TOP_FAST;
     QMX_TRY(q->partial.reserve((size_t)grid_cap * std::min<uint32_t>(TQ, MAX_QT_TOPK) * ptop_max * sizeof(uint64_t)));
@@ -1532,7 +1546,7 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
             a.top = top;
             // 1. exact scores of the sample -> the k-th best of each query = a lower bound of its final k-th best
             QMX_TRY(q->scores.reserve((size_t)nq_tile * S * sizeof(float)));
-            const uint32_t SQT = tile_qt(s);
+            const uint32_t SQT = tile_qt(s, q);
             for (uint32_t st0 = 0; st0 < nq_tile; st0 += SQT) {
                 const uint32_t nq_sub = std::min<uint32_t>(SQT, nq_tile - st0);
                 ScanArgs pre;
@@ -1619,7 +1633,7 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
                     // score matrix of the prefix (the score-mode kernels, <= tile_qt queries per launch), one block per query selects its
                     // k best live candidates, the k-th becomes the bound
                     QMX_TRY(q->scores.reserve((size_t)nq_tile * pre_n * sizeof(float)));
-                    const uint32_t SQT = tile_qt(s);
+                    const uint32_t SQT = tile_qt(s, q);
                     for (uint32_t st0 = 0; st0 < nq_tile; st0 += SQT) {
                         const uint32_t nq_sub = std::min<uint32_t>(SQT, nq_tile - st0);
                         ScanArgs pre;

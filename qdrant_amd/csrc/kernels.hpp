@@ -116,6 +116,7 @@ struct TqRotationHost {        // HadamardRotation on the device: forward maps, 
     uint32_t n_chunks, rot_dim, padded_dim, dim;
 };
 int32_t launch_scan_tq(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out);
+int32_t launch_scan_bq_mfma(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out);
 int32_t launch_scan_tq_mfma(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out);   // scan_sq_mfma.hip, 4 / 2 bits
 int32_t launch_hnsw_tq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_tq_split(hipStream_t st, const void *rows, uint64_t src_stride, uint64_t n, uint32_t code_bytes, uint32_t dst_stride, int has_l2,
@@ -268,7 +269,7 @@ int32_t launch_pairs_bq(hipStream_t st, const ScanArgs &a, const PairSel &sel, u
 int32_t launch_pairs_tq(hipStream_t st, const ScanArgs &a, const PairSel &sel, uint64_t n_items, int num_cus);
 uint64_t bq_row_bytes(uint32_t dim, uint32_t encoding);
 int32_t launch_bq_encode_scalar_query(hipStream_t st, const float *d_in, uint32_t nq, uint32_t dim, uint32_t encoding, uint32_t bits, uint8_t *d_out,
-                                      uint32_t out_stride);
+                                      uint32_t out_stride, uint32_t qbytes_off, uint32_t aux_off, uint32_t body);
 int32_t launch_bq_encode(hipStream_t st, const float *d_in, uint64_t n, uint32_t dim, uint32_t encoding, const float *d_mean, const float *d_stddev,
                          uint8_t *d_out, uint64_t out_stride);
 // PQ (pq.hip)

@@ -326,9 +326,13 @@ uint64_t bq_row_bytes(uint32_t dim, uint32_t encoding) {   // get_quantized_vect
 // query.  The query is extended as the row encoding extends the row (TwoBits: the values twice; OneAndHalfBits: the values, then the
 // max of each pair), quantised to `bits` bits over [-max_abs, max_abs] in the reference's f32 steps (v - min, / delta, round half
 // away, % 2^bits), and stored as bit planes: dword `part` of u128 word `bits * chunk + b` holds bit b of values chunk * 128 + part * 32 + e.
+// Behind the planes (qbytes_off; 0 = not wanted) the same values as bytes for the matrix-core scan (scan_sq_mfma.hip BqOps): per 16-byte row piece 8
+// pieces, piece j = the values of the row bits = j mod 8 in row-byte order, 8-bit values less 128 (i8); their sum goes to the entry's aux block.
 __global__ __launch_bounds__(256) void bq_encode_scalar_query_kernel(const float *in, uint32_t dim, uint32_t encoding, uint32_t bits, uint8_t *out,
-                                                                     uint32_t out_stride) {
+                                                                     uint32_t out_stride, uint32_t qbytes_off, uint32_t aux_off, uint32_t body) {
     __shared__ float red[256];
+    __shared__ uint32_t value_sum;
+    if (threadIdx.x == 0) value_sum = 0;
     const float *q = in + (uint64_t)blockIdx.x * dim;
     const uint32_t ext = encoding == QMX_BQ_TWO_BITS ? 2 * dim : encoding == QMX_BQ_ONE_AND_HALF_BITS ? dim + (dim + 1) / 2 : dim;
     auto value = [&](uint32_t i) -> float {
@@ -367,13 +371,32 @@ __global__ __launch_bounds__(256) void bq_encode_scalar_query_kernel(const float
         }
         dst[w] = word;
     }
+    if (!qbytes_off) return;
+    uint8_t *entry = out + (uint64_t)blockIdx.x * out_stride;
+    uint32_t mine = 0;
+    for (uint32_t i = threadIdx.x; i < body * 8; i += 256) {
+        uint32_t quantized = 0;
+        if (i < ext) {
+            const float shifted = value(i) - mn;
+            const float delted = delta > 1.1920929e-07f ? shifted / delta : 0.0f;
+            const float r = roundf(delted);
+            const uint32_t rounded = !(r >= 0.0f) ? 0u : (r >= 1073741824.0f ? 1073741824u : (uint32_t)r);
+            quantized = rounded % (ranges + 1u);
+            mine += quantized;
+        }
+        const uint32_t piece = i / 128, d = i % 128;
+        entry[qbytes_off + ((size_t)piece * 8 + d % 8) * 16 + d / 8] = i < ext ? (uint8_t)(int8_t)((int32_t)quantized - (bits == 8 ? 128 : 0)) : 0;
+    }
+    atomicAdd(&value_sum, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) reinterpret_cast<QueryAux *>(entry + aux_off)->pad[1] = value_sum;
 }
 int32_t launch_bq_encode_scalar_query(hipStream_t st, const float *d_in, uint32_t nq, uint32_t dim, uint32_t encoding, uint32_t bits, uint8_t *d_out,
-                                      uint32_t out_stride) {
+                                      uint32_t out_stride, uint32_t qbytes_off, uint32_t aux_off, uint32_t body) {
     if (nq == 0) return QMX_OK;
     QMX_REQUIRE(bits == 4 || bits == 8, QMX_ERR_BAD_ARG, "scalar query encoding of %u bits", bits);
     ::qmx::clear_stale_error();
-    hipLaunchKernelGGL(bq_encode_scalar_query_kernel, dim3(nq), dim3(256), 0, st, d_in, dim, encoding, bits, d_out, out_stride);
+    hipLaunchKernelGGL(bq_encode_scalar_query_kernel, dim3(nq), dim3(256), 0, st, d_in, dim, encoding, bits, d_out, out_stride, qbytes_off, aux_off, body);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }

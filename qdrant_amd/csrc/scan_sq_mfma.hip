@@ -163,6 +163,34 @@ struct Tq1Ops {
     }
 };
 
+// Binary quantization with Scalar4bits / Scalar8bits queries (scan_bq.hip RowBQScalar<B>): the plane-weighted xor-popcount of a row v against a
+// query whose values are t_i in [0, 2^B - 1] is  sum_i (v_i ? 2^B - 1 - t_i : t_i)  =  sum t + (2^B - 1) ones(v) - 2 v . t  - the row's bits
+// expanded to 0 / 1 bytes as in Tq1Ops against the values as i8 (8-bit ones less 128: + 128 ones(v)), bq_encode_scalar_query_kernel writes them and
+// sum t behind the planes.  Same integer, then calculate_metric's f32 expression.
+template <int B>
+struct BqOps {
+    typedef i32x4 acc_t;
+    static constexpr int NA = 1;
+    static constexpr uint32_t QSTEP = 4 * 128;
+    static constexpr bool ROW_ONES = true;
+    typedef typename Tq1Ops<1, false>::dec_t dec_t;
+    static __device__ __forceinline__ uint32_t body_bytes(const ScanArgs &a) { return a.dim; }
+    static __device__ __forceinline__ uint32_t query_off(const ScanArgs &a) { return a.tq_qbytes_off; }
+    static __device__ __forceinline__ void decode(const uint4 &x, dec_t &d) { Tq1Ops<1, false>::decode(x, d); }
+    static __device__ __forceinline__ void mac(const dec_t &d, const unsigned char *qp, acc_t (&acc)[NA]) { Tq1Ops<1, false>::mac(d, qp, acc); }
+    static __device__ __forceinline__ float row_aux(const ScanArgs &, uint32_t) { return 0.0f; }
+    static __device__ __forceinline__ float finish(const ScanArgs &a, const acc_t (&acc)[NA], int r, const unsigned char *q_entry, const unsigned char *, uint32_t,
+                                                   float, uint32_t ones) {
+        const QueryAux *aux = reinterpret_cast<const QueryAux *>(q_entry + a.aux_off);
+        constexpr int32_t M = (1 << B) - 1;
+        const int32_t v_dot_t = acc[0][r] + (B == 8 ? 128 * (int32_t)ones : 0);
+        const uint32_t weighted = (uint32_t)((int32_t)aux->pad[1] + M * (int32_t)ones - 2 * v_dot_t);
+        const float xor_product = (float)weighted / (float)M;   // calculate_metric (encoded_vectors_binary.rs:766-810)
+        const float zeros_count = (float)a.bq_dim - xor_product;
+        return a.bq_flip ? xor_product - zeros_count : zeros_count - xor_product;
+    }
+};
+
 struct F16Ops {    // Metric<f16> dot / cosine: f16 products are exact in f32, f32 accumulation (order differs from the
                    // x86 leaf: within 1e-5 of it, the bar of the f16 path), scalar tail as in metric_f16/avx/dot.rs:64-66
     typedef f32x4 acc_t;
@@ -424,7 +452,15 @@ int32_t launch_scan_sq_mfma(hipStream_t st, int qt, ScanMode mode, const ScanArg
     return QMX_ERR_BAD_ARG;
 }
 
-// TurboQuant 4 / 2 bits, 4..32 queries per pass (1-bit storages keep the VALU kernel of scan_tq.hip)
+// BQ rows against Scalar4bits / Scalar8bits queries, 4..32 queries per pass
+int32_t launch_scan_bq_mfma(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
+    if (a.bq_qbits == 4) return qt <= 16 ? launch_sqm_qt<BqOps<4>, 16, 2>(st, mode, a, num_cus, grid_out) : launch_sqm_qt<BqOps<4>, 32, 2>(st, mode, a, num_cus, grid_out);
+    if (a.bq_qbits == 8) return qt <= 16 ? launch_sqm_qt<BqOps<8>, 16, 2>(st, mode, a, num_cus, grid_out) : launch_sqm_qt<BqOps<8>, 32, 2>(st, mode, a, num_cus, grid_out);
+    set_error("BQ matrix-core scan: %u-bit queries not supported", a.bq_qbits);
+    return QMX_ERR_NOT_SUPPORTED;
+}
+
+// TurboQuant, 4..32 queries per pass
 int32_t launch_scan_tq_mfma(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
     const bool l2 = a.tq_l2 != nullptr;
 #define QMX_TQM(B, L)                                                                       \
