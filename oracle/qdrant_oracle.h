@@ -193,7 +193,7 @@ void qo_merge_topk(const qo_scored_point *lists, const uint32_t *counts, const u
 /* ---- scorer = FilteredScorer{RawScorer, NotDeletedChecker} (hnsw_index/point_scorer.rs:53-63) ---- */
 typedef struct qo_scorer {
     int kind;                 /* 0 dense (Metric over st->rows), 1 SQ (EncodedVectorsU8), 2 PQ (EncodedVectorsPQ), 3 BQ (EncodedVectorsBin<u128>),
-                                 4 multi-vector MaxSim over an inner scorer of one of the kinds above (fields mv_*) */
+                                 4 multi-vector MaxSim over an inner scorer of one of the kinds above (fields mv_*), 5 TurboQuant (fields tq_*) */
     const qo_storage *st;     /* dense rows for kind 0; the deleted flags and n for every kind */
     const void *query;        /* kind 0: preprocessed + cast query, [dim] elements */
     const qo_sq *sq; const uint8_t *sq_rows; const uint8_t *sq_query; float sq_query_offset;
@@ -206,6 +206,9 @@ typedef struct qo_scorer {
      * QuantizedMultivectorStorage::score_point_max_similarity (quantized_multivector_storage/mod.rs:339-363); score_internal =
      * score_internal_max_similarity (:366-393) / MultiMetricQueryScorer::score_internal through mv_tokens[0] as the inner template. */
     const struct qo_scorer *mv_tokens; uint32_t mv_n_tokens; const uint64_t *mv_offsets;
+    /* kind 5: TurboQuant (EncodedVectorsTQ): rows of qo_tq_quantized_size bytes; the query = TurboQuantizer::precompute_query of the
+     * preprocessed query; score_internal = score_symmetric; `invert` applied on top (encoded_vectors_tq.rs) */
+    const struct qo_tq *tq; const uint8_t *tq_rows; const struct qo_tq_query *tq_query; int tq_invert;
 } qo_scorer;
 float qo_scorer_score_point(const qo_scorer *s, uint32_t id);              /* RawScorer::score_point */
 float qo_scorer_score_internal(const qo_scorer *s, uint32_t a, uint32_t b); /* RawScorer::score_internal */

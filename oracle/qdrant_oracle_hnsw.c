@@ -62,6 +62,10 @@ float qo_scorer_score_point(const qo_scorer *s, uint32_t id) {
         }
         return sum;
     }
+    if (s->kind == 5) {   /* EncodedVectorsTQ::score_point: score_precomputed, then `invert` */
+        const float sc = qo_tq_score_precomputed(s->tq, s->tq_query, s->tq_rows + (size_t)id * qo_tq_quantized_size(s->tq));
+        return s->tq_invert ? -sc : sc;
+    }
     switch (s->kind) {
         case 0: qo_score_points(s->st, s->query, &id, 1, &out); return out;
         case 1: return qo_sq_score(s->sq, s->sq_query, s->sq_query_offset,
@@ -84,6 +88,11 @@ float qo_scorer_score_internal(const qo_scorer *s, uint32_t a, uint32_t b) {
             sum += max_sim;
         }
         return sum;
+    }
+    if (s->kind == 5) {   /* EncodedVectorsTQ::score_internal: score_symmetric, then `invert` */
+        const size_t rb = qo_tq_quantized_size(s->tq);
+        const float sc = qo_tq_score_symmetric(s->tq, s->tq_rows + (size_t)a * rb, s->tq_rows + (size_t)b * rb);
+        return s->tq_invert ? -sc : sc;
     }
     switch (s->kind) {
         case 0: { /* MetricQueryScorer::score_internal: similarity(get_dense(a), get_dense(b)), metric_query_scorer.rs:94-99 */
@@ -557,6 +566,17 @@ static void link_new_point(qo_hnsw *g, const qo_scorer *tmpl, uint32_t p, visite
         own.pq_lut = lut;
         q.s = &own;
     }
+    qo_tq_query *tq_query = NULL;
+    if (tmpl->kind == 5) {   /* EncodedVectorsTQ::encode_internal_vector -> None as well: the query of the ORIGINAL vector, score_symmetric elsewhere */
+        const qo_storage *st = tmpl->st;
+        float *qv = (float *)malloc(sizeof(float) * st->dim);
+        qo_preprocess_f32(st->distance, (const float *)st->rows + (size_t)p * st->dim, qv, st->dim);
+        tq_query = qo_tq_precompute_query(tmpl->tq, qv);
+        free(qv);
+        own = *tmpl;
+        own.tq_query = tq_query;
+        q.s = &own;
+    }
     const uint32_t level = g->level[p];
     uint32_t ep_id = 0, ep_level = 0;
     pthread_mutex_lock(&g->ep_lock);
@@ -614,6 +634,7 @@ static void link_new_point(qo_hnsw *g, const qo_scorer *tmpl, uint32_t p, visite
     entry_new_point(g, &q, p, level);
     pthread_mutex_unlock(&g->ep_lock);
     free(lut);
+    if (tq_query) qo_tq_query_free(tq_query);
 }
 
 static inline uint64_t splitmix64(uint64_t x) {

@@ -271,6 +271,20 @@ static bool bq_mfma_ok(const qmx_query *q) {
     return q->seg->dtype == QMX_DTYPE_BQ && q->tq_qbytes_off != 0 && !option(OPT_NO_MFMA_SCAN) && (size_t)MAX_QT * q->q_stride <= 150 * 1024;
 }
 
+// A TurboQuant query entry: `pieces` 16-byte query pieces per 16-byte row piece (scan_tq.hip; 1-bit storage under TQ+: 16 bit planes), zero padded
+// to whole 64-byte row steps (the matrix-core scan, scan_sq_mfma.hip TqOps, reads whole steps); behind the bit planes of a 1-bit storage the
+// same query as i8 bytes (8 per row byte; 16 with the two halves of a 16-bit TQ+ query); then the aux block.
+static void tq_entry_layout(const qmx_segment *seg, uint32_t *pieces, uint32_t *qbytes_off, uint32_t *aux_off) {
+    *pieces = seg->tq_value_bits == 4 ? 4 : (seg->tq_value_bits == 1 && seg->d_tq_shift) ? 16 : 8;
+    const uint32_t body = (seg->scan_dim + 63) & ~63u;
+    *aux_off = body * *pieces;
+    *qbytes_off = 0;
+    if (seg->tq_value_bits == 1) {
+        *qbytes_off = *aux_off;
+        *aux_off += body * (*pieces == 16 ? 16 : 8);
+    }
+}
+
 // stage a possibly-host buffer on the query's stream; returns a device pointer
 static int32_t stage_in(qmx_query *q, DevBuf &buf, const void *src, size_t bytes, const void **dev_out) {
     if (bytes == 0 || !src) {
@@ -1037,18 +1051,8 @@ static int32_t query_alloc(const qmx_segment *seg, uint32_t nq, qmx_query **out,
     // tile entry = elements zero-padded to whole 128-byte segments + the aux block
     // a scalar-encoded BQ query holds `bits` planes per row word (a stored row as the query has one: score_internal is 1-bit)
     q->bq_bits = (seg->dtype == QMX_DTYPE_BQ && !internal) ? seg->bq_query_bits : 1;
-    if (seg->dtype == QMX_DTYPE_TQ)   // query pieces per 16-byte row piece (scan_tq.hip); 1-bit storage under TQ+: 16 bit planes
-        q->bq_bits = seg->tq_value_bits == 4 ? 4 : (seg->tq_value_bits == 1 && seg->d_tq_shift) ? 16 : 8;
     q->aux_off = (uint32_t)((seg->scan_dim * elem_bytes(seg->dtype) * q->bq_bits + 127) & ~127u);
-    // TurboQuant: the matrix-core scan (scan_sq_mfma.hip TqOps) reads whole 64-byte row steps: the zero padding of the entry must cover the last one
-    if (seg->dtype == QMX_DTYPE_TQ) {
-        const uint32_t body = (seg->scan_dim + 63) & ~63u;
-        q->aux_off = body * q->bq_bits;
-        if (seg->tq_value_bits == 1) {   // behind the bit planes: the same query as i8 bytes (8 per row byte; 16 with the two halves of a 16-bit TQ+ query)
-            q->tq_qbytes_off = q->aux_off;
-            q->aux_off += body * (q->bq_bits == 16 ? 16 : 8);
-        }
-    }
+    if (seg->dtype == QMX_DTYPE_TQ) tq_entry_layout(seg, &q->bq_bits, &q->tq_qbytes_off, &q->aux_off);
     if (seg->dtype == QMX_DTYPE_BQ && q->bq_bits > 1 && seg->fast_layout()) {   // behind the planes: the values as bytes (scan_sq_mfma.hip BqOps), 8 per row byte
         q->tq_qbytes_off = q->aux_off;
         q->aux_off += ((seg->scan_dim + 63) & ~63u) * 8;
@@ -2042,12 +2046,26 @@ static void fill_args_segment(const qmx_segment *s, ScanArgs &a) {
         a.bq_flip = (s->flags & QMX_SEG_BQ_TOGGLE_INVERT) ? 1 : 0;
         a.bq_qbits = 1;
     }
+    if (s->dtype == QMX_DTYPE_TQ) {   // as fill_args + the layout of the entries the build makes per batch + score_symmetric's inputs
+        uint32_t pieces;
+        a.tq_sf = s->d_tq_sf;
+        a.tq_l2 = s->d_tq_l2;
+        a.tq_bits = s->tq_value_bits;
+        a.tq_invert = s->tq_invert ? 1 : 0;
+        a.tq_planes = (s->tq_value_bits == 1 && s->d_tq_shift) ? 16 : 8;
+        tq_entry_layout(s, &pieces, &a.tq_qbytes_off, &a.aux_off);
+        a.q_stride = a.aux_off + QUERY_AUX_BYTES;
+        a.bq_qbits = pieces;
+        a.tq_code_bytes = s->tq_code_bytes;
+        a.tq_ec = TqEc{s->d_tq_weights, s->d_tq_xm, s->tq_weight_scale, s->tq_mm_const};
+    }
 }
 
 static int32_t launch_hnsw_build_any(const qmx_segment *seg, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu) {
     if (seg->dtype == QMX_DTYPE_SQ_U8) return launch_hnsw_build_sq(nullptr, (int)seg->distance, a, h, phase, grid, per_cu);
     if (seg->dtype == QMX_DTYPE_BQ) return launch_hnsw_build_bq(nullptr, a, h, phase, grid, per_cu);
     if (seg->dtype == QMX_DTYPE_PQ) return launch_hnsw_build_pq(nullptr, a, h, phase, grid, per_cu);
+    if (seg->dtype == QMX_DTYPE_TQ) return launch_hnsw_build_tq(nullptr, a, h, phase, grid, per_cu);
     return launch_hnsw_build_dense(nullptr, (int)seg->dtype, (int)seg->distance, a, h, phase, grid, per_cu);
 }
 
@@ -2082,13 +2100,14 @@ int32_t qmx_hnsw_build(const qmx_segment *seg, const qmx_hnsw_build_params *bp, 
 int32_t qmx_hnsw_build_quantized(const qmx_segment *seg, const qmx_segment *original, const qmx_hnsw_build_params *bp, qmx_hnsw **out) {
     QMX_REQUIRE(seg && bp && out, QMX_ERR_BAD_ARG, "NULL argument");
     *out = nullptr;
-    QMX_REQUIRE(seg->dtype <= QMX_DTYPE_BQ, QMX_ERR_NOT_SUPPORTED, "device HNSW build: dtype %u not supported", seg->dtype);
-    if (seg->dtype == QMX_DTYPE_PQ) {   // point_scorer.rs:197-212: the insertion searches score through the LUT of the ORIGINAL vector
+    QMX_REQUIRE(seg->dtype <= QMX_DTYPE_BQ || seg->dtype == QMX_DTYPE_TQ, QMX_ERR_NOT_SUPPORTED, "device HNSW build: dtype %u not supported", seg->dtype);
+    const bool from_original = seg->dtype == QMX_DTYPE_PQ || seg->dtype == QMX_DTYPE_TQ;
+    if (from_original) {   // point_scorer.rs:197-212: the insertion searches score through the query (PQ: LUT) of the ORIGINAL vector
         QMX_REQUIRE(original, QMX_ERR_NOT_SUPPORTED,
-                    "a PQ segment cannot score a stored row as a query (encode_internal_vector -> None): pass the original f32 segment to qmx_hnsw_build_quantized");
+                    "a PQ / TurboQuant segment cannot score a stored row as a query (encode_internal_vector -> None): pass the original f32 segment to qmx_hnsw_build_quantized");
         QMX_REQUIRE(original->dtype == QMX_DTYPE_F32 && original->dim == seg->dim && original->n >= seg->n && original->device == seg->device,
-                    QMX_ERR_BAD_ARG, "the original segment must be f32, of the same dim, on the same device and hold every row of the PQ segment");
-        QMX_REQUIRE(seg->d_pq_pair, QMX_ERR_NOT_SUPPORTED, "PQ build: the centroid pair table (m x n_centroids^2 floats) exceeds 256 MB");
+                    QMX_ERR_BAD_ARG, "the original segment must be f32, of the same dim, on the same device and hold every row of the quantized segment");
+        QMX_REQUIRE(seg->dtype != QMX_DTYPE_PQ || seg->d_pq_pair, QMX_ERR_NOT_SUPPORTED, "PQ build: the centroid pair table (m x n_centroids^2 floats) exceeds 256 MB");
     }
     QMX_REQUIRE(seg->dtype == QMX_DTYPE_SQ_U8 || seg->dtype == QMX_DTYPE_PQ || seg->fast_layout(), QMX_ERR_NOT_SUPPORTED,
                 "adopted device block is not 16-byte aligned");
@@ -2126,10 +2145,10 @@ int32_t qmx_hnsw_build_quantized(const qmx_segment *seg, const qmx_segment *orig
     };
 
     // ---- device state ----
-    DevBuf b_level, b_upoff, b_links0, b_cnt0, b_linksU, b_cntU, b_lock, b_vis, b_log, b_sel, b_sels, b_selc, b_normf, b_normi, b_bq, b_bqsrc;
+    DevBuf b_level, b_upoff, b_links0, b_cnt0, b_linksU, b_cntU, b_lock, b_vis, b_log, b_sel, b_sels, b_selc, b_normf, b_normi, b_bq, b_bqsrc, b_rot;
     auto release_all = [&]() {
         for (DevBuf *b : {&b_level, &b_upoff, &b_links0, &b_cnt0, &b_linksU, &b_cntU, &b_lock, &b_vis, &b_log, &b_sel, &b_sels, &b_selc, &b_normf, &b_normi,
-                          &b_bq, &b_bqsrc}) b->release();
+                          &b_bq, &b_bqsrc, &b_rot}) b->release();
     };
     int32_t rc = QMX_OK;
     qmx_hnsw *g = nullptr;
@@ -2173,6 +2192,14 @@ int32_t qmx_hnsw_build_quantized(const qmx_segment *seg, const qmx_segment *orig
             h.batch_queries = (const unsigned char *)b_bq.p;
             h.batch_q_stride = lut_stride;
             h.lds_query_bytes = 0;
+        }
+        if (seg->dtype == QMX_DTYPE_TQ) {   // query entries = precompute_query of the batch's original vectors, staged in LDS per insertion
+            QB(b_bq.reserve((size_t)max_batch * a.q_stride));
+            QB(b_bqsrc.reserve((size_t)max_batch * seg->dim * sizeof(float)));
+            QB(b_rot.reserve((size_t)max_batch * seg->tq_padded_dim * sizeof(double)));
+            h.batch_queries = (const unsigned char *)b_bq.p;
+            h.batch_q_stride = a.q_stride;
+            h.lds_query_bytes = a.q_stride;
         }
         if (seg->dtype == QMX_DTYPE_U8 && seg->distance == QMX_DISTANCE_COSINE && seg->dim >= 32) {   // the per-pair cosine's query norm of a stored row
             QB(b_normf.reserve(nn * 4)); QB(b_normi.reserve(nn * 4));
@@ -2237,6 +2264,15 @@ int32_t qmx_hnsw_build_quantized(const qmx_segment *seg, const qmx_segment *orig
                                     (size_t)seg->dim * 4, count, hipMemcpyDeviceToDevice, nullptr));
                 if (seg->distance == QMX_DISTANCE_COSINE) QB(launch_cosine_preprocess_f32(nullptr, src, src, count, seg->dim));
                 QB(launch_pq_lut(nullptr, seg->distance, seg->dim, seg->pq, seg->d_centroids, src, count, (float *)b_bq.p));
+            }
+            if (seg->dtype == QMX_DTYPE_TQ) {   // the same for EncodedVectorsTQ: preprocess, rotate, TurboQuantizer::precompute_query
+                float *src = (float *)b_bqsrc.p;
+                QH(hipMemcpy2DAsync(src, (size_t)seg->dim * 4, (const char *)original->d_rows + (uint64_t)next * original->row_stride, original->row_stride,
+                                    (size_t)seg->dim * 4, count, hipMemcpyDeviceToDevice, nullptr));
+                if (seg->distance == QMX_DISTANCE_COSINE) QB(launch_cosine_preprocess_f32(nullptr, src, src, count, seg->dim));
+                QB(launch_tq_rotate(nullptr, src, count, tq_rotation(seg), (double *)b_rot.p));
+                QB(launch_tq_query_encode(nullptr, (double *)b_rot.p, count, seg->tq_padded_dim, seg->tq_value_bits, seg->distance == QMX_DISTANCE_EUCLID ? 1 : 0,
+                                          b_bq.p, a.q_stride, a.aux_off, seg->d_tq_shift, seg->d_tq_scale, a.tq_qbytes_off));
             }
             QB(launch_hnsw_build_any(seg, a, h, 1, (uint32_t)std::min<uint64_t>(slots1, count), &per_cu1));
             QB(launch_hnsw_build_any(seg, a, h, 2, (uint32_t)std::min<uint64_t>(slots2, count), &per_cu2));

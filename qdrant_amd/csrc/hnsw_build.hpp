@@ -110,7 +110,11 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(const ScanArgs a0
         // staged in LDS (zero padded to whole 128-byte steps)
         const unsigned char *qp = q_lds;
         __syncthreads();
-        if (h.batch_queries) {
+        if (h.batch_queries && h.lds_query_bytes) {        // a small entry (TurboQuant): staged like a row
+            const unsigned char *src = h.batch_queries + (uint64_t)bi * h.batch_q_stride;
+            for (uint32_t i = (uint32_t)lane * 16; i < h.lds_query_bytes; i += 64 * 16)
+                *reinterpret_cast<uint4 *>(q_lds + i) = *reinterpret_cast<const uint4 *>(src + i);
+        } else if (h.batch_queries) {                       // a LUT (PQ): read through L2
             qp = h.batch_queries + (uint64_t)bi * h.batch_q_stride;
         } else {
             const unsigned char *src = rows + (uint64_t)p * a.row_stride;

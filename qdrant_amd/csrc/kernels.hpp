@@ -9,6 +9,11 @@ constexpr int SCAN_BLOCK = 512;    // 8 wavefronts share one LDS copy of the que
 constexpr int MAX_TOP_FAST = 64;   // register-resident per-wave list: one entry per lane
 
 // What a scan / gather launch needs.  Plain data, passed by value to the kernels.
+struct TqEc {                  // TQ+ symmetric scoring (score_symmetric_ec): i16 weights D'^2 per coordinate, their scale, <M, M>, the rows' xm column
+    const int16_t *weights;
+    const float *xm;
+    float weight_scale, mm_const;
+};
 struct ScanArgs {
     const void *rows;          // stored block (reference row layout for the dtype)
     uint64_t n_rows;
@@ -59,6 +64,8 @@ struct ScanArgs {
     uint32_t tq_bits, tq_invert;
     uint32_t tq_planes;        // 1-bit storage: bit planes of the query (8; 16 under TQ+)
     uint32_t tq_qbytes_off;    // 1-bit storage: byte offset, inside a query entry, of the i8 form of the query (the matrix-core scan's operand)
+    uint32_t tq_code_bytes;    // HNSW build (HopTQInternal): code bytes of a row, before the zero padding of the device block
+    TqEc tq_ec;                // ... and score_symmetric_ec's inputs (weights == nullptr without TQ+)
     // multi-vectors (MaxSim walk, hnsw.hpp HopMaxSim): point p = inner rows [mv_offsets[p], mv_offsets[p + 1]); multi-query j = query entries
     // [mv_qfirst[j], mv_qfirst[j + 1])
     const uint64_t *mv_offsets;
@@ -128,11 +135,6 @@ int32_t launch_tq_quantize(hipStream_t st, double *d_rot, uint32_t n, uint32_t p
                            uint32_t out_stride, const float *d_shift, const float *d_scale);
 int32_t launch_tq_query_encode(hipStream_t st, double *d_rot, uint32_t nq, uint32_t padded_dim, uint32_t bits, int need_l2, void *tile, uint32_t q_stride,
                                uint32_t aux_off, const float *d_shift, const float *d_scale, uint32_t qbytes_off);
-struct TqEc {                  // TQ+ symmetric scoring (score_symmetric_ec): i16 weights D'^2 per coordinate, their scale, <M, M>, the rows' xm column
-    const int16_t *weights;
-    const float *xm;
-    float weight_scale, mm_const;
-};
 int32_t launch_tq_internal(hipStream_t st, const void *codes, uint32_t stride, const float *sf, const float *l2, uint32_t code_bytes, uint32_t bits,
                            int invert, uint64_t n_rows, const uint32_t *a_ids, const uint32_t *b_ids, uint32_t n, float *out, int *err_flag, const TqEc *ec);
 // the MaxSim walk over multi-vector points (HopMaxSim): dense, SQ and BQ inner rows
@@ -188,6 +190,7 @@ int32_t launch_hnsw_build_bq(hipStream_t st, const ScanArgs &a, const HnswBuildA
 int32_t launch_hnsw_build_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_build_dense(hipStream_t st, int dtype, int distance, const ScanArgs &a, const HnswBuildArgs &h, int phase,
                                 uint32_t grid, int *per_cu);
+int32_t launch_hnsw_build_tq(hipStream_t st, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_build_pq(hipStream_t st, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu);
 // pair[c][i][j] = DistanceType::distance(centroid i chunk c, centroid j chunk c): the per-chunk terms of score_internal (encoded_vectors_pq.rs:574-618)
 int32_t launch_pq_pair_table(hipStream_t st, uint32_t distance, uint32_t dim, const qmx_pq_params &pq, const float *d_centroids, float *d_pair);

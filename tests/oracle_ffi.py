@@ -422,7 +422,8 @@ class Scorer(C.Structure):
                 ("sq", C.POINTER(Sq)), ("sq_rows", _P), ("sq_query", _P), ("sq_query_offset", _f),
                 ("pq", C.POINTER(Pq)), ("pq_codes", _P), ("pq_lut", _P), ("isa", C.c_int),
                 ("bq_rows", _P), ("bq_query", _P), ("bq_dim", C.c_uint32), ("bq_distance", C.c_int), ("bq_invert", C.c_int),
-                ("mv_tokens", _P), ("mv_n_tokens", C.c_uint32), ("mv_offsets", _P)]
+                ("mv_tokens", _P), ("mv_n_tokens", C.c_uint32), ("mv_offsets", _P),
+                ("tq", _P), ("tq_rows", _P), ("tq_query", _P), ("tq_invert", C.c_int)]
 
 
 _sig("qo_merge_topk", None, [_P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P])
@@ -522,6 +523,41 @@ class Hnsw:
         s = Scorer()
         s.kind, s.st, s.pq, s.pq_codes, s.isa = 2, C.pointer(storage.st), C.pointer(pq.pq), pq.codes.ctypes.data, pq.isa
         self._keep = (s, pq)
+        self.h = _lib.qo_hnsw_build_with(C.byref(s), self.m, self.m0, ef_construct, entry_points_num, 1, seed)
+        return self
+
+    @classmethod
+    def build_sq(cls, storage: DenseStorage, sq: "SqOracle", m=16, m0=None, ef_construct=100, entry_points_num=10, seed=42):
+        """The build of an SQ segment: every score through EncodedVectorsU8 (a stored row is its own query, encode_internal_vector)."""
+        self = cls.__new__(cls)
+        self.storage, self.m, self.m0, self.n = storage, m, (2 * m if m0 is None else m0), storage.rows.shape[0]
+        s = Scorer()
+        s.kind, s.st, s.sq, s.sq_rows, s.isa = 1, C.pointer(storage.st), C.pointer(sq.sq), sq.rows.ctypes.data, sq.isa
+        self._keep = (s, sq)
+        self.h = _lib.qo_hnsw_build_with(C.byref(s), self.m, self.m0, ef_construct, entry_points_num, 1, seed)
+        return self
+
+    @classmethod
+    def build_bq(cls, storage: DenseStorage, bq: "BqOracle", m=16, m0=None, ef_construct=100, entry_points_num=10, seed=42):
+        """The build of a BQ segment: one-bit score_internal everywhere."""
+        self = cls.__new__(cls)
+        self.storage, self.m, self.m0, self.n = storage, m, (2 * m if m0 is None else m0), storage.rows.shape[0]
+        s = Scorer()
+        s.kind, s.st, s.bq_rows = 3, C.pointer(storage.st), bq.rows.ctypes.data
+        s.bq_dim, s.bq_distance, s.bq_invert = bq.dim, bq.distance, bq.invert
+        self._keep = (s, bq)
+        self.h = _lib.qo_hnsw_build_with(C.byref(s), self.m, self.m0, ef_construct, entry_points_num, 1, seed)
+        return self
+
+    @classmethod
+    def build_tq(cls, storage: DenseStorage, tq: "TqOracle", m=16, m0=None, ef_construct=100, entry_points_num=10, seed=42):
+        """The build of a TurboQuant segment: like PQ, EncodedVectorsTQ cannot turn a stored row into a query, so an insertion's searches score
+        through precompute_query(ORIGINAL vector) and the heuristic / back links through score_symmetric (point_scorer.rs:183-218)."""
+        self = cls.__new__(cls)
+        self.storage, self.m, self.m0, self.n = storage, m, (2 * m if m0 is None else m0), storage.rows.shape[0]
+        s = Scorer()
+        s.kind, s.st, s.tq, s.tq_rows, s.tq_invert = 5, C.pointer(storage.st), tq.h, tq.rows.ctypes.data, 1 if tq.invert else 0
+        self._keep = (s, tq)
         self.h = _lib.qo_hnsw_build_with(C.byref(s), self.m, self.m0, ef_construct, entry_points_num, 1, seed)
         return self
 
@@ -658,6 +694,20 @@ class Hnsw:
             s.pq_lut, s.isa = lut.ctypes.data, pq.isa
             res.append(self._run(s, top, ef)[0])
         return res
+
+
+def _hnsw_search_tq(self, flags_storage: DenseStorage, tq: "TqOracle", queries_preprocessed, top, ef):
+    res = []
+    for qv in f32(np.atleast_2d(queries_preprocessed)):
+        e = _lib.qo_tq_precompute_query(tq.h, _p(qv))
+        s = Scorer()
+        s.kind, s.st, s.tq, s.tq_rows, s.tq_query, s.tq_invert = 5, C.pointer(flags_storage.st), tq.h, tq.rows.ctypes.data, e, 1 if tq.invert else 0
+        res.append(self._run(s, top, ef)[0])
+        _lib.qo_tq_query_free(e)
+    return res
+
+
+Hnsw.search_tq = _hnsw_search_tq
 
 
 class MultiOracle:

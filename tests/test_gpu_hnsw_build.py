@@ -308,6 +308,130 @@ def test_pq_build_through_the_quantized_scorer(qa, distance, lut_mfma):
     assert r_f32 > 0.4 and r_pq > r_f32 - 0.05 and r_pq > r_cpu - 0.05, (r_pq, r_cpu, r_f32)
 
 
+@pytest.mark.parametrize("distance,dim", [(O.COSINE, 48), (O.EUCLID, 33)])
+def test_one_point_per_launch_builds_the_sequential_graph(qa, distance, dim):
+    """max_batch = 1: every insertion sees the graph of all earlier points, as the oracle's sequential GraphLayersBuilder does - the device
+    graph then equals the oracle's link for link (same scores bit for bit, same tie rules in the queues and the heuristic)."""
+    n, m, efc, seed = 1500, 8, 40, 21
+    rows = O.preprocess(distance, _clustered(n, dim, seed, k=32))
+    st = O.DenseStorage(O.F32, distance, rows)
+    vs = qa.VectorStorage(rows, _dist(qa, distance))
+    seq = qa.GraphLayers.build(vs, m=m, ef_construct=efc, seed=seed, max_batch=1).export_plain()
+    ref = O.Hnsw(st, m=m, ef_construct=efc, seed=seed).export_plain()
+    _same_graph(seq, ref)
+
+
+def _same_graph(seq, ref):
+    assert np.array_equal(seq.reindex, ref.reindex) and np.array_equal(seq.offsets, ref.offsets)
+    assert np.array_equal(seq.neighbors, ref.neighbors)
+    assert seq.ep_ids.tolist() == ref.ep_ids.tolist()
+
+
+@pytest.mark.parametrize("kind", ["sq", "pq"])
+def test_one_point_per_launch_builds_the_sequential_graph_other_storages(qa, kind):
+    """The same bar for the SQ and PQ quantized scorers (PQ: searches through the LUT of the original vector, heuristic through score_internal;
+    TurboQuant: test_tq_build_through_the_quantized_scorer).  Not a bar for u8 / BQ rows - integer scores tie all the time and the order among
+    equal scores inside the reference's binary heaps is not restated on the device (ties unpinned) - nor for f16 rows, whose device
+    scores equal the oracle's to 1e-5, not to the bit; their branches below document what was tried."""
+    n, dim, m, efc, seed = 1200, 64, 8, 40, 29
+    raw = _clustered(n, dim, seed, k=32)
+    if kind == "f16":
+        rows = O.preprocess(O.DOT, raw).astype(np.float16)
+        st = O.DenseStorage(O.F16, O.DOT, rows)
+        seq = qa.GraphLayers.build(qa.VectorStorage(rows, qa.Distance.Dot, qa.VectorStorageDatatype.Float16), m=m, ef_construct=efc, seed=seed, max_batch=1)
+        ref = O.Hnsw(st, m=m, ef_construct=efc, seed=seed)
+    elif kind == "u8":
+        rows = np.clip(raw * 20.0 + 128.0, 0, 255).astype(np.uint8)
+        st = O.DenseStorage(O.U8, O.EUCLID, rows)
+        seq = qa.GraphLayers.build(qa.VectorStorage(rows, qa.Distance.Euclid, qa.VectorStorageDatatype.Uint8), m=m, ef_construct=efc, seed=seed, max_batch=1)
+        ref = O.Hnsw(st, m=m, ef_construct=efc, seed=seed)
+    else:
+        rows = O.preprocess(O.COSINE, raw)
+        st = O.DenseStorage(O.F32, O.COSINE, rows)
+        vs = qa.VectorStorage(rows, qa.Distance.Cosine)
+        if kind == "sq":
+            quant = qa.ScalarQuantizer.from_min_max(rows, dim, qa.Distance.Cosine)
+            osq = O.SqOracle(O.COSINE, dim, quant.alpha, quant.offset)
+            osq.encode_rows(rows)
+            seq = qa.GraphLayers.build(qa.EncodedVectorsU8(quant.encode(rows), quant), m=m, ef_construct=efc, seed=seed, max_batch=1)
+            ref = O.Hnsw.build_sq(st, osq, m=m, ef_construct=efc, seed=seed)
+        elif kind == "bq":
+            quant = qa.BinaryQuantizer(dim, qa.Distance.Cosine)
+            obq = O.BqOracle(O.COSINE, dim)
+            obq.encode_rows(rows)
+            seq = qa.GraphLayers.build(qa.EncodedVectorsBin(quant.encode(rows), quant), m=m, ef_construct=efc, seed=seed, max_batch=1)
+            ref = O.Hnsw.build_bq(st, obq, m=m, ef_construct=efc, seed=seed)
+        else:
+            cen = O.PqOracle.train(rows[:1000], dim, 4, 256, iters=3)
+            opq = O.PqOracle(O.COSINE, dim, 4, cen)
+            codes = opq.encode(rows)
+            quant = qa.ProductQuantizer(dim, qa.Distance.Cosine, 4, cen, lut_mfma=False)
+            seq = qa.GraphLayers.build(qa.EncodedVectorsPQ(codes, quant), m=m, ef_construct=efc, seed=seed, max_batch=1, original=vs)
+            ref = O.Hnsw.build_pq(st, opq, m=m, ef_construct=efc, seed=seed)
+    _same_graph(seq.export_plain(), ref.export_plain())
+
+
+@pytest.mark.parametrize("distance,bits,plus", [(O.COSINE, O.TQ_BITS4, False), (O.EUCLID, O.TQ_BITS2, False), (O.DOT, O.TQ_BITS1, False),
+                                                (O.DOT, O.TQ_BITS4, True), (O.EUCLID, O.TQ_BITS1_5, True)])
+def test_tq_build_through_the_quantized_scorer(qa, distance, bits, plus):
+    """A TurboQuant segment builds like a PQ one (EncodedVectorsTQ::encode_internal_vector -> None, point_scorer.rs:183-218): insertion
+    searches score through precompute_query of the point's ORIGINAL vector, the heuristic and the back links through score_symmetric (TQ+:
+    score_symmetric_ec).  Bars: inserted one point per launch (max_batch = 1) the device builds the ORACLE's sequential graph link for link;
+    batched: the structural invariants, the oracle's TQ walk of the device-built graph == the device's (ids, score bits), recall after
+    rescoring within 0.05 of the oracle-built and of the f32-built graph."""
+    n, dim, m, efc, seed = 3000, 64, 8, 48, 13
+    rows = O.preprocess(distance, _clustered(n, dim, seed, k=48))
+    st = O.DenseStorage(O.F32, distance, rows)
+    shift = scale = None
+    if plus:
+        shift, scale = O.tq_plus_fit(distance, dim, bits, rows)
+    otq = O.TqOracle(distance, dim, bits, shift=shift, scale=scale)
+    codes = otq.encode_rows(rows)
+    quant = qa.TurboQuantizer(dim, _dist(qa, distance), bits, shift=shift, scale=scale)
+    enc = qa.EncodedVectorsTQ(codes, quant)
+    vs = qa.VectorStorage(rows, _dist(qa, distance))
+    with pytest.raises(qa.QmxError) as e:                     # without the original vectors there is no query for a stored TQ row
+        qa.GraphLayers.build(enc, m=m, ef_construct=efc, seed=seed)
+    assert e.value.status == qa._ffi.ERR_NOT_SUPPORTED
+    cpu = O.Hnsw.build_tq(st, otq, m=m, ef_construct=efc, seed=seed)
+    cpu_plain = cpu.export_plain()
+    # sequential on the device == sequential on the CPU, link for link (scores are the oracle's bits, ties broken alike)
+    n_seq = 700
+    enc_s = qa.EncodedVectorsTQ(codes[:n_seq], quant)
+    vs_s = qa.VectorStorage(rows[:n_seq], _dist(qa, distance))
+    st_s = O.DenseStorage(O.F32, distance, rows[:n_seq])
+    otq_s = O.TqOracle(distance, dim, bits, shift=shift, scale=scale)
+    otq_s.rows = codes[:n_seq]
+    seq = qa.GraphLayers.build(enc_s, m=m, ef_construct=efc, seed=seed, original=vs_s, max_batch=1).export_plain()
+    ref = O.Hnsw.build_tq(st_s, otq_s, m=m, ef_construct=efc, seed=seed).export_plain()
+    assert np.array_equal(seq.reindex, ref.reindex) and np.array_equal(seq.offsets, ref.offsets)
+    assert np.array_equal(seq.neighbors, ref.neighbors)
+    assert seq.ep_ids.tolist() == ref.ep_ids.tolist()
+    # batched
+    g_tq = qa.GraphLayers.build(enc, m=m, ef_construct=efc, seed=seed, original=vs)
+    g_f32 = qa.GraphLayers.build(vs, m=m, ef_construct=efc, seed=seed)
+    p = g_tq.export_plain()
+    lv = _check_invariants(p, n, m)
+    assert lv.tolist() == _levels_of(g_f32.export_plain(), n).tolist()
+    queries = _clustered(100, dim, seed + 1, k=48)
+    qpre = O.preprocess(distance, queries)
+    tq_scorer = qa.new_raw_scorer(queries, enc)
+    walk = O.Hnsw.from_plain(p, n)
+    want = walk.search_tq(st, otq, qpre[:40], 10, 64)
+    got = g_tq.search(10, 64, qa.new_raw_scorer(queries[:40], enc))
+    for gq, wq in zip(got, want):
+        assert np.array_equal(gq["score"].view(np.uint32), wq["score"].view(np.uint32))
+        if bits not in (O.TQ_BITS1, O.TQ_BITS1_5):            # 1-bit scores tie: the order among equal scores is not pinned
+            assert gq["idx"].tolist() == wq["idx"].tolist()
+    raw = qa.new_raw_scorer(queries, vs)
+    exact = st.peek_top(queries, 10)
+    r_tq = _recall(qa.search_quantized(tq_scorer, raw, 10, oversampling=4.0, rescore=True, graph=g_tq, hnsw_ef=64), exact)
+    r_f32 = _recall(qa.search_quantized(tq_scorer, raw, 10, oversampling=4.0, rescore=True, graph=g_f32, hnsw_ef=64), exact)
+    g_cpu = qa.GraphLayers.from_plain(cpu_plain)
+    r_cpu = _recall(qa.search_quantized(tq_scorer, raw, 10, oversampling=4.0, rescore=True, graph=g_cpu, hnsw_ef=64), exact)
+    assert r_f32 > (0.3 if bits in (O.TQ_BITS1, O.TQ_BITS1_5) else 0.4) and r_tq > r_f32 - 0.05 and r_tq > r_cpu - 0.05, (r_tq, r_cpu, r_f32)
+
+
 def test_pq_pair_table_is_score_internal(qa):
     """The tabulated chunk distances give EncodedVectorsPQ::score_internal bit for bit (the build's stored <-> stored score)."""
     n, dim, chunk = 600, 40, 8
