@@ -665,15 +665,17 @@ typedef struct qmx_hnsw_info {
  * `GraphLayersBuilder::link_new_point` (graph_layers_builder.rs:417-474) for every non-deleted point, batch-parallel — the counterpart of
  * the reference's rayon / Vulkan builders (hnsw/build.rs:355, hnsw/gpu_build.rs).  Insertion order inside a batch
  * is concurrent, so the graph is not link-for-link the sequential CPU graph; it obeys the same invariants (<= m0 / m
- * links, no self links, no duplicates, links only to points of at least that level) and is checked by recall.
+ * links, no self links, no duplicates, links only to points of at least that level) and is checked by recall.  With
+ * params->max_batch = 1 (one insertion per launch) it IS the sequential graph, link for link, wherever scores do not tie.
  * The result is searchable at once (qmx_hnsw_search) and exportable as plain GraphLinks arrays. */
 QMX_API int32_t qmx_hnsw_build(const qmx_segment *seg, const qmx_hnsw_build_params *params, qmx_hnsw **out);
 /* The build of a QUANTIZED segment whose storage cannot turn a stored row into a query — product quantization
- * (EncodedVectorsPQ::encode_internal_vector -> None, encoded_vectors_pq.rs:620-623).  FilteredScorer::new_internal
- * (hnsw_index/point_scorer.rs:183-218) then scores the searches of an insertion with quantized_vectors.raw_scorer(ORIGINAL vector of
- * the point) = its LUT, while the heuristic and the back links use the storage's score_internal (centroid <-> centroid distances,
- * :574-618).  `original` = the f32 segment the PQ segment was encoded from (same rows, same device); for every other dtype it may be
- * NULL and the call equals qmx_hnsw_build. */
+ * (EncodedVectorsPQ::encode_internal_vector -> None, encoded_vectors_pq.rs:620-623) and TurboQuant (EncodedVectorsTQ, likewise).
+ * FilteredScorer::new_internal (hnsw_index/point_scorer.rs:183-218) then scores the searches of an insertion with
+ * quantized_vectors.raw_scorer(ORIGINAL vector of the point) = its LUT (PQ) / its precompute_query (TQ), while the heuristic and the back
+ * links use the storage's score_internal (PQ: centroid <-> centroid distances, :574-618; TQ: score_symmetric, turboquant/quantization.rs:395-494).
+ * `original` = the f32 segment the quantized segment was encoded from (same rows, same device; QMX_ERR_NOT_SUPPORTED without it); for
+ * every other dtype it may be NULL and the call equals qmx_hnsw_build. */
 QMX_API int32_t qmx_hnsw_build_quantized(const qmx_segment *quantized, const qmx_segment *original, const qmx_hnsw_build_params *params,
                                          qmx_hnsw **out);
 QMX_API int32_t qmx_hnsw_get_info(const qmx_hnsw *g, qmx_hnsw_info *out);

@@ -128,6 +128,9 @@ def test_tq_unpadded_rotation_and_hnsw_walk(qa):
     g = O.Hnsw(dense, m=8, ef_construct=48, seed=5)
     graph = qa.GraphLayers.from_plain(g.export_plain())
     got = graph.search(10, 64, scorer)
+    want = g.search_tq(dense, otq, O.preprocess(O.COSINE, queries), 10, 64)                # the oracle walks the same graph with its TQ scorer
+    for gq, wq in zip(got, want):
+        assert gq["idx"].tolist() == wq["idx"].tolist() and np.array_equal(_bits(gq["score"]), _bits(wq["score"]))
     full = otq.score_points(O.preprocess(O.COSINE, queries), np.arange(n))
     for qi, r in enumerate(got):
         assert len(r) == 10 and np.all(np.diff(r["score"]) <= 0)

@@ -27,9 +27,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=768)
-    ap.add_argument("--scorer", default="sq", help="comma list of f32 | sq | pq")
+    ap.add_argument("--scorer", default="sq", help="comma list of f32 | sq | pq | tq (TurboQuant 4 bits)")
     ap.add_argument("--build", choices=["gpu", "cpu"], default="gpu")
-    ap.add_argument("--build-over", choices=["f32", "sq"], default="f32",
+    ap.add_argument("--build-over", choices=["f32", "sq", "tq"], default="f32",
                     help="storage the device build scores through: the original vectors, or the SQ-int8 codes as the reference does "
                          "when the segment is quantized (hnsw/build.rs:334-341)")
     ap.add_argument("--data", choices=["clustered", "iid"], default="clustered")
@@ -106,13 +106,33 @@ def main():
         del codes_d
         return sq_cache["quant"], sq_cache["enc"], sq_cache["codes"]
 
+    tq_cache = {}
+
+    def make_tq():
+        """TurboQuant 4-bit twin of the rows, encoded on the device (qmx_tq_encode)."""
+        if tq_cache:
+            return tq_cache["quant"], tq_cache["enc"], tq_cache["codes"]
+        quant = qa.TurboQuantizer(dim, qa.Distance.Dot, O.TQ_BITS4)
+        p = quant.params()
+        codes_d = torch.empty((n, quant.quantized_vector_size()), dtype=torch.uint8, device=dev)
+        t0 = time.time()
+        F.check(lib.qmx_tq_encode(0, int(qa.Distance.Dot), dim, C.byref(p), F.ptr(rows), n, F.ptr(codes_d)))
+        torch.cuda.synchronize()
+        tq_cache["encode_s"] = time.time() - t0
+        host = codes_d.cpu().numpy()
+        del codes_d
+        tq_cache.update(quant=quant, enc=qa.EncodedVectorsTQ(host, quant), codes=host)
+        return tq_cache["quant"], tq_cache["enc"], tq_cache["codes"]
+
     vs = qa.VectorStorage(rows, qa.Distance.Cosine)        # adopts the device block
-    build_storage = vs
+    build_storage, original = vs, None
     if args.build == "gpu" and args.build_over == "sq":
         build_storage = make_sq()[1]
+    if args.build == "gpu" and args.build_over == "tq":
+        build_storage, original = make_tq()[1], vs
     t0 = time.time()
     if args.build == "gpu":
-        graph = qa.GraphLayers.build(build_storage, m=args.m, ef_construct=args.ef_construct, seed=42, max_batch=args.max_batch)
+        graph = qa.GraphLayers.build(build_storage, m=args.m, ef_construct=args.ef_construct, seed=42, max_batch=args.max_batch, original=original)
         t_build = time.time() - t0
         plain = graph.export_plain()
         walker = O.Hnsw.from_plain(plain, n) if with_oracle else None
@@ -145,6 +165,14 @@ def main():
                 osq = O.SqOracle(O.DOT, dim, quant.alpha, quant.offset)
                 osq.rows = host_codes_sq
                 oracle_search = lambda qs: walker.search_sq(st, osq, qs, args.top * 2, args.ef)                 # noqa: E731
+            scorer = qa.new_raw_scorer(queries, enc)
+        elif which == "tq":
+            quant, enc, host_codes_tq = make_tq()
+            row_bytes, oversample = quant.quantized_vector_size(), 2
+            if with_oracle:
+                otq = O.TqOracle(O.DOT, dim, O.TQ_BITS4)
+                otq.rows = host_codes_tq
+                oracle_search = lambda qs: walker.search_tq(st, otq, qs, args.top * 2, args.ef)                 # noqa: E731
             scorer = qa.new_raw_scorer(queries, enc)
         else:
             chunk = 16
