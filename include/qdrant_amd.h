@@ -171,8 +171,8 @@ typedef struct qmx_bq_params {
 } qmx_bq_params;
 
 /* TurboQuant (`TurboQuantizer`, lib/quantization/src/turboquant/quantization.rs:14-158; `Metadata`, encoded_vectors_tq.rs:33-46).
- * TQMode::Normal, and TQMode::Plus with the storage's persisted error correction (`shift` / `scale` per rotated coordinate: the reference fits them with
- * P-square quantile estimators over randomly sampled vectors, encoded_vectors_tq.rs:156-240 - an input here, like PQ centroids).  Distances Dot, Cosine, Euclid (L1 scores need a
+ * TQMode::Normal, and TQMode::Plus with the storage's persisted error correction (`shift` / `scale` per rotated coordinate: fitted by qmx_tq_fit_plus
+ * as the reference does, with P-square quantile estimators over sampled vectors, encoded_vectors_tq.rs:156-240).  Distances Dot, Cosine, Euclid (L1 scores need a
  * full dequantisation + inverse rotation per pair in the reference: QMX_ERR_NOT_SUPPORTED).  Queries are rotated (HadamardRotation, f64, the
  * reference's fixed permutation seeds) and integer-encoded on the device (`precompute_query` :496-567 with the x86_64 constants of
  * turboquant/simd/query{4,2,1}bit); scores are `score_precomputed` (:569-620) negated when `invert`; qmx_score_internal is
@@ -188,6 +188,16 @@ typedef struct qmx_tq_params {
     const float *ec_shift;       /* TQ+ `ErrorCorrectionMetadata.shift` [padded_dim] (encoded_vectors_tq.rs:93-96), HOST array, or NULL */
     const float *ec_scale;       /* ... `.scale` [padded_dim] */
 } qmx_tq_params;
+
+/* The first pass of `EncodedVectorsTQ::encode` under TQMode::Plus (encoded_vectors_tq.rs:156-234): every sampled vector is rotated and rescaled to
+ * norm sqrt(padded_dim) (`TurboQuantizer::preprocess_into`, quantization.rs:169-207) and each rotated coordinate feeds a pair of 7-marker P-square
+ * estimators (`find_quantile_interval_per_coordinate_with_preprocess`, quantile.rs:130-281; p_square.rs, its x86_64 AVX2 + FMA arithmetic) tracking the
+ * quantiles Phi(-+c_outer); shift = -(q_lo + q_hi) / 2, scale = 2 c_outer / (q_hi - q_lo) (1 below MIN_QUANTILE_WIDTH).  `sample` = the sampled vectors
+ * [n_sample][dim] f32 (host or device) in ascending index order - WHICH vectors is the reference's `Permutor` over `bits.sample_size()` = 2 048 / 4 096 /
+ * 8 192 indices: an input, like the PQ k-means sample.  `params`: bits and rotation; its error-correction fields are ignored.  shift_out / scale_out:
+ * [padded_dim] f32 (host or device), the arrays `qmx_tq_params.ec_shift / ec_scale` and the metadata take.  Equal to the oracle's restatement bit for bit. */
+QMX_API int32_t qmx_tq_fit_plus(int32_t device_id, uint32_t distance, uint32_t dim, const qmx_tq_params *params, const float *sample, uint64_t n_sample,
+                                float *shift_out, float *scale_out);
 
 /* `TurboQuantizer::quantize` (turboquant/quantization.rs:211-296, TQMode::Normal) for a batch, on the device: vectors [n][dim] f32 as the storage
  * holds them (cosine: normalised; host or device) -> out_rows [n][quantized size] bytes (host or device), the rows a QMX_DTYPE_TQ segment takes.

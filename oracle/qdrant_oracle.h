@@ -180,6 +180,11 @@ void qo_tq_quantize(const qo_tq *t, const float *vec, uint8_t *out);            
 qo_tq_query *qo_tq_precompute_query(const qo_tq *t, const float *query);               /* precompute_query */
 void qo_tq_query_free(qo_tq_query *e);
 void qo_tq_query_export(const qo_tq *t, const qo_tq_query *e, int32_t *q_out, float *postprocess_scale, float *l2_norm, int64_t *sum_q);
+/* TQ+ fit (TQMode::Plus first pass, encoded_vectors_tq.rs:156-234): per-coordinate P-square quantile estimators over the sampled vectors */
+double qo_p2_quantile(double q, const double *values, uint64_t n, double *grid);   /* P2Quantile<7>: new, push*, estimate */
+void qo_tq_plus_quantiles(int bits, double *min_q, double *max_q, float *c_outer);
+void qo_tq_preprocess(const qo_tq *t, const float *vec, double *buf);                  /* preprocess_into */
+void qo_tq_plus_fit(const qo_tq *t, const float *sample, uint32_t n_sample, float *shift, float *scale);
 float qo_tq_score_precomputed(const qo_tq *t, const qo_tq_query *e, const uint8_t *vec);   /* score_precomputed (before `invert`) */
 float qo_tq_score_symmetric(const qo_tq *t, const uint8_t *v1, const uint8_t *v2);         /* score_symmetric (before `invert`) */
 

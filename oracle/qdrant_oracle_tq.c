@@ -187,6 +187,158 @@ static uint32_t centroid_index(const float *centroids, int n, double val) {   /*
     return idx;
 }
 
+/* ---- TQ+ parameter fit: EncodedVectorsTQ::encode's first pass (encoded_vectors_tq.rs:156-234) over
+ * find_quantile_interval_per_coordinate_with_preprocess (quantile.rs:130-281) and the extended P-square estimator
+ * (p_square.rs, Jain & Chlamtac with P2_MARKERS = 7 markers, x86_64 AVX2 + FMA dispatch restated: the desired positions of markers
+ * 0..3 are one fused multiply-add, markers 4..6 `1.0 + p * (count - 1)` in two roundings; find_marker counts heights[1..N-1] < x).
+ * Which vectors are sampled (Permutor, a third-party permutation iterator; bits.sample_size() of them, ascending index order) is an
+ * input: `sample` holds them in that order.  Parity unpinned: the reference's tests of this code are statistical. ---- */
+#define QO_P2_N 7
+typedef struct { int count; double obs[QO_P2_N]; double q, h[QO_P2_N], n[QO_P2_N], nd[QO_P2_N], tp[QO_P2_N]; } qo_p2;
+static void p2_init(qo_p2 *e, double q) { memset(e, 0, sizeof(*e)); e->q = q; }
+static int cmp_f64(const void *a, const void *b) { const double x = *(const double *)a, y = *(const double *)b; return x < y ? -1 : x > y ? 1 : 0; }
+static void p2_grid(double q, double *p) {     /* generate_grid_probabilities (p_square.rs:171-214) */
+    const int extra = (QO_P2_N - 5) / 2;
+    p[0] = 0.0;
+    p[1] = q * 0.5;
+    for (int i = 0; i < extra; i++) p[i + 2] = q * (0.7 + 0.3 * (double)(i + 1) / ((double)extra + 2.0));
+    p[QO_P2_N / 2] = q;
+    for (int i = 0; i < extra; i++) p[QO_P2_N / 2 + 1 + i] = 1.0 + (q - 1.0) * (0.7 + 0.3 * (double)(extra - i) / ((double)extra + 2.0));
+    p[QO_P2_N - 2] = 1.0 + (q - 1.0) * 0.5;
+    p[QO_P2_N - 1] = 1.0;
+}
+static void p2_adjust_step(qo_p2 *e, int i, double dsign) {     /* adjust_step (:456-488) */
+    const double prev_h = e->h[i - 1], next_h = e->h[i + 1], prev_n = e->n[i - 1], next_n = e->n[i + 1], cur_h = e->h[i], cur_n = e->n[i];
+    const double denom = next_n - prev_n;
+    double h_par = cur_h;
+    if (denom != 0.0) {
+        const double a = (cur_n - prev_n + dsign) / (next_n - cur_n) * (next_h - cur_h);
+        const double b = (next_n - cur_n - dsign) / (cur_n - prev_n) * (cur_h - prev_h);
+        h_par = cur_h + (a + b) * dsign / denom;
+    }
+    if (h_par > prev_h && h_par < next_h && isfinite(h_par)) e->h[i] = h_par;
+    else if (dsign > 0.0) e->h[i] = cur_h + (next_h - cur_h) / (next_n - cur_n);
+    else e->h[i] = cur_h + (prev_h - cur_h) / (prev_n - cur_n);
+    e->n[i] += dsign;
+}
+static void p2_push(qo_p2 *e, double x) {      /* P2Quantile::push (:40-58) + P2QuantileImpl::push (:123-160) */
+    if (isnan(x) || !isfinite(x)) return;
+    if (e->count < QO_P2_N) {
+        e->obs[e->count++] = x;
+        if (e->count == QO_P2_N) {             /* new_from_linear (:91-116) */
+            double buf[QO_P2_N];
+            memcpy(buf, e->obs, sizeof(buf));
+            qsort(buf, QO_P2_N, sizeof(double), cmp_f64);
+            p2_grid(e->q, e->tp);
+            for (int i = 0; i < QO_P2_N; i++) {
+                e->h[i] = buf[i];
+                e->n[i] = (double)(i + 1);
+                e->nd[i] = 1.0 + e->tp[i] * (double)(QO_P2_N - 1);
+            }
+        }
+        return;
+    }
+    e->count += 1;
+    int k;
+    if (x < e->h[0]) { e->h[0] = x; k = 0; }
+    else if (x > e->h[QO_P2_N - 1]) { e->h[QO_P2_N - 1] = x; k = QO_P2_N - 1; }
+    else { k = 0; for (int i = 1; i < QO_P2_N; i++) if (e->h[i] < x) k++; }     /* find_marker_avx2 (:369-397) */
+    for (int i = k + 1; i < QO_P2_N; i++) e->n[i] += 1.0;
+    const double cm1 = (double)(e->count - 1);
+    for (int i = 0; i < QO_P2_N; i++)          /* update_desired_avx2 (:401-432): 4-lane fmadd, scalar tail */
+        e->nd[i] = i < (QO_P2_N / 4) * 4 ? fma(e->tp[i], cm1, 1.0) : 1.0 + e->tp[i] * cm1;
+    for (int i = 1; i < QO_P2_N - 1; i++) {    /* adjust_marker (:438-454) */
+        for (;;) {
+            const double di = e->nd[i] - e->n[i];
+            if (di >= 1.0 && (e->n[i + 1] - e->n[i]) > 1.0) p2_adjust_step(e, i, 1.0);
+            else if (di <= -1.0 && (e->n[i - 1] - e->n[i]) < -1.0) p2_adjust_step(e, i, -1.0);
+            else break;
+        }
+    }
+}
+static double p2_estimate(qo_p2 *e) {          /* estimate (:61-66,118-121) / estimate_quantile_from_slice (:502-521) */
+    if (e->count >= QO_P2_N) return e->h[QO_P2_N / 2];
+    if (e->count == 0) return 0.0;
+    if (e->count == 1) return e->obs[0];
+    double buf[QO_P2_N];
+    memcpy(buf, e->obs, sizeof(double) * (size_t)e->count);
+    qsort(buf, (size_t)e->count, sizeof(double), cmp_f64);
+    const double k = e->q * ((double)e->count - 1.0);
+    const size_t lo = (size_t)floor(k), hi = (size_t)ceil(k);
+    if (lo == hi) return buf[lo];
+    return buf[lo] + (k - (double)lo) * (buf[hi] - buf[lo]);
+}
+/* one estimator over a stream (the reference's own tests drive it this way, p_square.rs:631-812); grid = its 7 target probabilities */
+double qo_p2_quantile(double q, const double *values, uint64_t n, double *grid) {
+    qo_p2 e;
+    p2_init(&e, q);
+    for (uint64_t i = 0; i < n; i++) p2_push(&e, values[i]);
+    if (grid) p2_grid(q, grid);
+    return p2_estimate(&e);
+}
+/* turboquant/math.rs:3-15 */
+static double std_normal_cdf(double x) {
+    const double y = x / 1.4142135623730951;   /* std::f64::consts::SQRT_2 */
+    const double a = fabs(y);
+    const double t = 1.0 / (1.0 + 0.3275911 * a);
+    const double poly = t * (0.254829592 + t * (-0.284496736 + t * (1.421413741 + t * (-1.453152027 + t * 1.061405429))));
+    const double r = 1.0 - poly * exp(-a * a);
+    return 0.5 * (1.0 + (y >= 0.0 ? r : -r));
+}
+/* the two quantiles the estimators track for `bits` (encoded_vectors_tq.rs:172-184 + quantile.rs:155-156) and the outermost centroid */
+void qo_tq_plus_quantiles(int bits, double *min_q, double *max_q, float *c_outer_out) {
+    int nc;
+    const float *centroids = centroids_of(bits, &nc);
+    float c_outer = 0.0f;
+    for (int i = 0; i < nc; i++) { const float a = fabsf(centroids[i]); c_outer = c_outer > a ? c_outer : a; }   /* fold(0.0, |acc, c| acc.max(c.abs())) */
+    const double p_outer = std_normal_cdf((double)c_outer);
+    float qp = (float)(2.0 * p_outer - 1.0);
+    qp = qp < 0.0f ? 0.0f : qp > 0.99999f ? 0.99999f : qp;
+    *min_q = (1.0 - (double)qp) / 2.0;
+    *max_q = 1.0 - *min_q;
+    *c_outer_out = c_outer;
+}
+/* TurboQuantizer::preprocess_into (quantization.rs:169-207): pad, rotate, rescale to norm sqrt(padded_dim); buf[padded_dim] */
+void qo_tq_preprocess(const qo_tq *t, const float *vec, double *buf) {
+    const uint32_t pd = t->padded_dim;
+    for (uint32_t i = 0; i < pd; i++) buf[i] = i < t->dim ? (double)vec[i] : 0.0;
+    qo_tq_rotate(t, buf);
+    float l2_length = 1.0f;
+    if (t->distance != QO_COSINE) {
+        double s = 0.0;
+        for (uint32_t i = 0; i < pd; i++) s += buf[i] * buf[i];
+        l2_length = (float)sqrt(s);
+    }
+    const double length = (double)l2_length;
+    if (length > 0.0) {
+        const double length_scale = sqrt((double)pd) / length;
+        for (uint32_t i = 0; i < pd; i++) buf[i] *= length_scale;
+    }
+}
+/* shift / scale [padded_dim] from `n_sample` sampled vectors in their iteration order; `t` = the TQMode::Normal pre-quantizer */
+void qo_tq_plus_fit(const qo_tq *t, const float *sample, uint32_t n_sample, float *shift, float *scale) {
+    const uint32_t pd = t->padded_dim;
+    double min_q, max_q;
+    float c_outer;
+    qo_tq_plus_quantiles(t->bits, &min_q, &max_q, &c_outer);
+    qo_p2 *est = (qo_p2 *)malloc(sizeof(qo_p2) * 2 * (size_t)pd);
+    for (uint32_t d = 0; d < pd; d++) { p2_init(&est[2 * d], min_q); p2_init(&est[2 * d + 1], max_q); }
+    double *buf = (double *)malloc(sizeof(double) * (pd ? pd : 1));
+    for (uint32_t v = 0; v < n_sample; v++) {
+        qo_tq_preprocess(t, sample + (size_t)v * t->dim, buf);
+        for (uint32_t d = 0; d < pd; d++) { p2_push(&est[2 * d], buf[d]); p2_push(&est[2 * d + 1], buf[d]); }
+    }
+    for (uint32_t d = 0; d < pd; d++) {
+        float q_lo = 0.0f, q_hi = 0.0f;
+        if (n_sample) { q_lo = (float)p2_estimate(&est[2 * d]); q_hi = (float)p2_estimate(&est[2 * d + 1]); }   /* count == 0: zero pairs (:151-153) */
+        shift[d] = -(q_lo + q_hi) / 2.0f;
+        const float denom = q_hi - q_lo;
+        scale[d] = denom > 1e-3f ? (2.0f * c_outer) / denom : 1.0f;     /* MIN_QUANTILE_WIDTH */
+    }
+    free(buf);
+    free(est);
+}
+
 /* TurboQuantizer::quantize (TQMode::Normal): out = [codes][scaling_factor f32][l2_length f32 (L2 only)] */
 void qo_tq_quantize(const qo_tq *t, const float *vec, uint8_t *out) {
     const uint32_t pd = t->padded_dim;

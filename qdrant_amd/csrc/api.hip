@@ -623,6 +623,66 @@ static TqRotationHost tq_rotation(const qmx_segment *s) {
     return h;
 }
 
+// turboquant/math.rs:3-15 (Abramowitz & Stegun 7.1.26)
+static double tq_std_normal_cdf(double x) {
+    const double y = x / 1.4142135623730951;
+    const double a = fabs(y);
+    const double t = 1.0 / (1.0 + 0.3275911 * a);
+    const double poly = t * (0.254829592 + t * (-0.284496736 + t * (1.421413741 + t * (-1.453152027 + t * 1.061405429))));
+    const double r = 1.0 - poly * exp(-a * a);
+    return 0.5 * (1.0 + (y >= 0.0 ? r : -r));
+}
+
+int32_t qmx_tq_fit_plus(int32_t device_id, uint32_t distance, uint32_t dim, const qmx_tq_params *params, const float *sample, uint64_t n_sample,
+                        float *shift_out, float *scale_out) {
+    QMX_REQUIRE(params && shift_out && scale_out && (n_sample == 0 || sample) && dim > 0, QMX_ERR_BAD_ARG, "bad argument");
+    QMX_REQUIRE(distance <= QMX_DISTANCE_MANHATTAN && distance != QMX_DISTANCE_MANHATTAN, QMX_ERR_NOT_SUPPORTED, "TurboQuant: distance %u not built", distance);
+    QMX_REQUIRE(n_sample <= (1u << 20), QMX_ERR_BAD_ARG, "sample of %llu vectors (the reference takes 2 048 .. 8 192)", (unsigned long long)n_sample);
+    QMX_TRY(check_device(device_id, nullptr));
+    qmx_tq_params pre = *params;           // the pre-quantizer of the stats pass: TQMode::Normal, no error correction (:159-165)
+    pre.plus_mode = 0; pre.ec_shift = nullptr; pre.ec_scale = nullptr;
+    qmx_segment tmp;
+    qmx_segment_desc d;
+    memset(&d, 0, sizeof(d));
+    d.dtype = QMX_DTYPE_TQ; d.distance = distance; d.dim = dim; d.tq = &pre; d.device_id = device_id;
+    tmp.device = device_id; tmp.dtype = QMX_DTYPE_TQ; tmp.distance = distance; tmp.dim = dim;
+    int32_t rc = tq_segment_setup(&tmp, &d);
+    DevBuf bin, brot, bsh, bsc;
+    do {
+        if (rc != QMX_OK) break;
+        const uint32_t pd = tmp.tq_padded_dim, n = (uint32_t)n_sample;
+        // the outermost centroid and the two quantiles Phi(-+c_outer) (:172-184, quantile.rs:155-156)
+        const float c_outer = tmp.tq_value_bits == 4 ? 2.733f : tmp.tq_value_bits == 2 ? 1.510f : 0.7978846f;
+        const double p_outer = tq_std_normal_cdf((double)c_outer);
+        float qp = (float)(2.0 * p_outer - 1.0);
+        qp = qp < 0.0f ? 0.0f : qp > 0.99999f ? 0.99999f : qp;
+        const double min_q = (1.0 - (double)qp) / 2.0, max_q = 1.0 - min_q;
+        if ((rc = brot.reserve((size_t)std::max<uint32_t>(n, 1) * pd * 8)) != QMX_OK) break;
+        if ((rc = bsh.reserve((size_t)pd * 4)) != QMX_OK || (rc = bsc.reserve((size_t)pd * 4)) != QMX_OK) break;
+        const float *d_in = sample;
+        if (n && !is_device_ptr(sample)) {
+            if ((rc = bin.reserve((size_t)n * dim * 4)) != QMX_OK) break;
+            if (hipMemcpy(bin.p, sample, (size_t)n * dim * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = QMX_ERR_OTHER; break; }
+            d_in = (const float *)bin.p;
+        }
+        if (n && (rc = launch_tq_rotate(nullptr, d_in, n, tq_rotation(&tmp), (double *)brot.p)) != QMX_OK) break;
+        if ((rc = launch_tq_plus_fit(nullptr, (double *)brot.p, n, pd, distance, min_q, max_q, c_outer, (float *)bsh.p, (float *)bsc.p)) != QMX_OK) break;
+        if (hipDeviceSynchronize() != hipSuccess) { rc = QMX_ERR_OTHER; break; }
+        if (hipMemcpy(shift_out, bsh.p, (size_t)pd * 4, hipMemcpyDefault) != hipSuccess || hipMemcpy(scale_out, bsc.p, (size_t)pd * 4, hipMemcpyDefault) != hipSuccess) {
+            rc = QMX_ERR_OTHER;
+            break;
+        }
+    } while (0);
+    bin.release(); brot.release(); bsh.release(); bsc.release();
+    if (tmp.d_tq_tables) (void)hipFree(tmp.d_tq_tables);
+    if (tmp.d_tq_norms) (void)hipFree(tmp.d_tq_norms);
+    if (tmp.d_tq_shift) (void)hipFree(tmp.d_tq_shift);
+    if (tmp.d_tq_scale) (void)hipFree(tmp.d_tq_scale);
+    if (tmp.d_tq_weights) (void)hipFree(tmp.d_tq_weights);
+    if (rc == QMX_ERR_OTHER) set_error("qmx_tq_fit_plus: HIP error");
+    return rc;
+}
+
 int32_t qmx_tq_encode(int32_t device_id, uint32_t distance, uint32_t dim, const qmx_tq_params *params, const float *vectors, uint64_t n, void *out_rows) {
     QMX_REQUIRE(params && (n == 0 || (vectors && out_rows)) && dim > 0, QMX_ERR_BAD_ARG, "bad argument");
     QMX_REQUIRE(distance <= QMX_DISTANCE_MANHATTAN && distance != QMX_DISTANCE_MANHATTAN, QMX_ERR_NOT_SUPPORTED, "TurboQuant: distance %u not built", distance);

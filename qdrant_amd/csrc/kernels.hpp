@@ -131,6 +131,8 @@ int32_t launch_tq_split(hipStream_t st, const void *rows, uint64_t src_stride, u
 int32_t launch_tq_gather_rows(hipStream_t st, const void *codes, uint32_t dst_stride, const float *sf, const float *l2, uint32_t code_bytes, int has_l2,
                               const uint32_t *ids, uint32_t n, uint64_t n_rows, void *out, uint32_t out_stride, int *err_flag);
 int32_t launch_tq_rotate(hipStream_t st, const float *d_in, uint32_t n, const TqRotationHost &h, double *d_out);
+int32_t launch_tq_plus_fit(hipStream_t st, double *d_rot, uint32_t n, uint32_t padded_dim, uint32_t distance, double min_q, double max_q, float c_outer,
+                           float *d_shift, float *d_scale);
 int32_t launch_tq_quantize(hipStream_t st, double *d_rot, uint32_t n, uint32_t padded_dim, uint32_t value_bits, uint32_t distance, void *d_out,
                            uint32_t out_stride, const float *d_shift, const float *d_scale);
 int32_t launch_tq_query_encode(hipStream_t st, double *d_rot, uint32_t nq, uint32_t padded_dim, uint32_t bits, int need_l2, void *tile, uint32_t q_stride,

@@ -522,6 +522,140 @@ __global__ __launch_bounds__(256) void tq_quantize_kernel(double *rot, uint32_t 
         if (shift) { const float xm = sh_xm; memcpy(row + code_bytes + (distance == QMX_DISTANCE_EUCLID ? 8 : 4), &xm, 4); }
     }
 }
+// ---- TQ+ parameter fit: the first pass of EncodedVectorsTQ::encode (encoded_vectors_tq.rs:156-234) ----
+// preprocess_into's length rescale (turboquant/quantization.rs:169-207) of already rotated vectors, in place: norm -> sqrt(padded_dim)
+__global__ __launch_bounds__(256) void tq_rescale_kernel(double *rot, uint32_t n, uint32_t padded_dim, uint32_t distance) {
+    __shared__ double sh_scale;
+    __shared__ int sh_apply;
+    const uint32_t v = blockIdx.x;
+    if (v >= n) return;
+    double *x = rot + (uint64_t)v * padded_dim;
+    if (threadIdx.x == 0) {
+        float l2_length = 1.0f;
+        if (distance != QMX_DISTANCE_COSINE) {
+            double s = 0.0;
+            for (uint32_t i = 0; i < padded_dim; ++i) s = s + x[i] * x[i];
+            l2_length = (float)sqrt(s);
+        }
+        const double length = (double)l2_length;
+        sh_apply = length > 0.0;
+        sh_scale = length > 0.0 ? sqrt((double)padded_dim) / length : 1.0;
+    }
+    __syncthreads();
+    if (sh_apply)
+        for (uint32_t i = threadIdx.x; i < padded_dim; i += blockDim.x) x[i] = x[i] * sh_scale;
+}
+// The extended P-square estimator (p_square.rs; Jain & Chlamtac 1985 with P2_MARKERS = 7 markers), x86_64 AVX2 + FMA dispatch: the desired
+// positions of markers 0..3 are one fused multiply-add, markers 4..6 `1.0 + p * (count - 1)`; find_marker counts heights[1..N-1] < x.
+struct P2 {
+    static constexpr int N = 7;
+    int count;
+    double q, h[N], n[N], nd[N], tp[N];     // before the N-th observation h[] holds the observations
+    __device__ void init(double quantile) {
+        count = 0;
+        q = quantile;
+        const int extra = (N - 5) / 2;      // generate_grid_probabilities (:171-214)
+        tp[0] = 0.0;
+        tp[1] = q * 0.5;
+        for (int i = 0; i < extra; ++i) tp[i + 2] = q * (0.7 + 0.3 * (double)(i + 1) / ((double)extra + 2.0));
+        tp[N / 2] = q;
+        for (int i = 0; i < extra; ++i) tp[N / 2 + 1 + i] = 1.0 + (q - 1.0) * (0.7 + 0.3 * (double)(extra - i) / ((double)extra + 2.0));
+        tp[N - 2] = 1.0 + (q - 1.0) * 0.5;
+        tp[N - 1] = 1.0;
+    }
+    __device__ static void sort(double *b, int m) {
+        for (int i = 1; i < m; ++i) {
+            const double x = b[i];
+            int j = i - 1;
+            while (j >= 0 && b[j] > x) { b[j + 1] = b[j]; --j; }
+            b[j + 1] = x;
+        }
+    }
+    __device__ void step(int i, double dsign) {     // adjust_step (:456-488)
+        const double prev_h = h[i - 1], next_h = h[i + 1], prev_n = n[i - 1], next_n = n[i + 1], cur_h = h[i], cur_n = n[i];
+        const double denom = next_n - prev_n;
+        double h_par = cur_h;
+        if (denom != 0.0) {
+            const double a = (cur_n - prev_n + dsign) / (next_n - cur_n) * (next_h - cur_h);
+            const double b = (next_n - cur_n - dsign) / (cur_n - prev_n) * (cur_h - prev_h);
+            h_par = cur_h + (a + b) * dsign / denom;
+        }
+        if (h_par > prev_h && h_par < next_h && isfinite(h_par)) h[i] = h_par;
+        else if (dsign > 0.0) h[i] = cur_h + (next_h - cur_h) / (next_n - cur_n);
+        else h[i] = cur_h + (prev_h - cur_h) / (prev_n - cur_n);
+        n[i] += dsign;
+    }
+    __device__ void push(double x) {
+        if (isnan(x) || !isfinite(x)) return;
+        if (count < N) {
+            h[count++] = x;
+            if (count == N) {                   // new_from_linear (:91-116)
+                sort(h, N);
+                for (int i = 0; i < N; ++i) {
+                    n[i] = (double)(i + 1);
+                    nd[i] = 1.0 + tp[i] * (double)(N - 1);
+                }
+            }
+            return;
+        }
+        count += 1;
+        int k;
+        if (x < h[0]) { h[0] = x; k = 0; }
+        else if (x > h[N - 1]) { h[N - 1] = x; k = N - 1; }
+        else { k = 0; for (int i = 1; i < N; ++i) k += h[i] < x ? 1 : 0; }
+        for (int i = 0; i < N; ++i) n[i] += i > k ? 1.0 : 0.0;
+        const double cm1 = (double)(count - 1);
+        for (int i = 0; i < N; ++i) nd[i] = i < (N / 4) * 4 ? fma(tp[i], cm1, 1.0) : 1.0 + tp[i] * cm1;
+        for (int i = 1; i < N - 1; ++i) {       // adjust_marker (:438-454)
+            for (;;) {
+                const double di = nd[i] - n[i];
+                if (di >= 1.0 && (n[i + 1] - n[i]) > 1.0) step(i, 1.0);
+                else if (di <= -1.0 && (n[i - 1] - n[i]) < -1.0) step(i, -1.0);
+                else break;
+            }
+        }
+    }
+    __device__ double estimate() {              // :61-66, :118-121, estimate_quantile_from_slice (:502-521)
+        if (count >= N) return h[N / 2];
+        if (count == 0) return 0.0;
+        if (count == 1) return h[0];
+        sort(h, count);
+        const double k = q * ((double)count - 1.0);
+        const int lo = (int)floor(k), hi = (int)ceil(k);
+        if (lo == hi) return h[lo];
+        return h[lo] + (k - (double)lo) * (h[hi] - h[lo]);
+    }
+};
+// one thread per rotated coordinate: both estimators over the sample in order (find_quantile_interval_per_coordinate_with_preprocess,
+// quantile.rs:130-281), then shift / scale (encoded_vectors_tq.rs:219-233)
+__global__ __launch_bounds__(64) void tq_p2_fit_kernel(const double *rot, uint32_t n, uint32_t padded_dim, double min_q, double max_q, float c_outer,
+                                                       float *shift, float *scale) {
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= padded_dim) return;
+    P2 lo, hi;
+    lo.init(min_q);
+    hi.init(max_q);
+    for (uint32_t v = 0; v < n; ++v) {
+        const double x = rot[(uint64_t)v * padded_dim + d];
+        lo.push(x);
+        hi.push(x);
+    }
+    float q_lo = 0.0f, q_hi = 0.0f;
+    if (n) { q_lo = (float)lo.estimate(); q_hi = (float)hi.estimate(); }
+    shift[d] = -(q_lo + q_hi) / 2.0f;
+    const float denom = q_hi - q_lo;
+    scale[d] = denom > 1e-3f ? (2.0f * c_outer) / denom : 1.0f;     // MIN_QUANTILE_WIDTH
+}
+int32_t launch_tq_plus_fit(hipStream_t st, double *d_rot, uint32_t n, uint32_t padded_dim, uint32_t distance, double min_q, double max_q, float c_outer,
+                           float *d_shift, float *d_scale) {
+    ::qmx::clear_stale_error();
+    if (n) hipLaunchKernelGGL(tq_rescale_kernel, dim3(n), dim3(256), 0, st, d_rot, n, padded_dim, distance);
+    hipLaunchKernelGGL(tq_p2_fit_kernel, dim3((padded_dim + 63) / 64), dim3(64), 0, st, (const double *)d_rot, n, padded_dim, min_q, max_q, c_outer, d_shift,
+                       d_scale);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
 int32_t launch_tq_quantize(hipStream_t st, double *d_rot, uint32_t n, uint32_t padded_dim, uint32_t value_bits, uint32_t distance, void *d_out,
                            uint32_t out_stride, const float *d_shift, const float *d_scale) {
     if (n == 0) return QMX_OK;

@@ -423,6 +423,20 @@ class TurboQuantizer:
             p.ec_shift, p.ec_scale = self.shift.ctypes.data, self.scale.ctypes.data
         return p
 
+    @classmethod
+    def fit_plus(cls, sample, dim: int, distance: Distance, bits: int, rotation_unpadded: bool = False, invert: Optional[bool] = None,
+                 device_id: int = 0) -> "TurboQuantizer":
+        """TQMode::Plus: the error correction fitted on the device as `EncodedVectorsTQ::encode`'s first pass fits it (P-square estimates of the
+        quantiles Phi(-+c_outer) of every rotated coordinate, qmx_tq_fit_plus).  `sample`: the sampled vectors as stored (cosine rows normalised), in
+        ascending index order - the reference draws `sample_size` = 8 192 / 4 096 / 2 048 (4 / 2 / 1 bits) indices with its Permutor."""
+        plain = cls(dim, distance, bits, rotation_unpadded, invert)
+        v = np.ascontiguousarray(np.atleast_2d(sample), dtype=np.float32).reshape(-1, dim)
+        shift, scale = np.empty(plain.padded_dim, dtype=np.float32), np.empty(plain.padded_dim, dtype=np.float32)
+        p = plain.params()
+        F.check(F.lib().qmx_tq_fit_plus(device_id, int(plain.distance), plain.dim, C.byref(p), F.ptr(v) if len(v) else None, len(v), F.ptr(shift),
+                                        F.ptr(scale)))
+        return cls(dim, distance, bits, rotation_unpadded, invert, shift=shift, scale=scale)
+
     def quantized_vector_size(self) -> int:
         """TurboQuantizer::quantized_size_for (turboquant/encoding.rs:172-190)."""
         return self.code_bytes + (8 if self.distance == Distance.Euclid else 4) + (4 if getattr(self, "plus_mode", False) else 0)

@@ -1007,6 +1007,36 @@ class TqOracle:
         return out
 
 
+_sig("qo_tq_plus_quantiles", None, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_float)])
+_sig("qo_tq_preprocess", None, [_P, _P, _P])
+_sig("qo_p2_quantile", C.c_double, [C.c_double, _P, C.c_uint64, _P])
+
+
+def p2_quantile(q, values, with_grid=False):
+    v = np.ascontiguousarray(values, dtype=np.float64)
+    grid = np.zeros(7, dtype=np.float64)
+    r = _lib.qo_p2_quantile(float(q), _p(v) if len(v) else None, len(v), _p(grid))
+    return (r, grid) if with_grid else r
+
+_sig("qo_tq_plus_fit", None, [_P, _P, C.c_uint32, _P, _P])
+
+
+def tq_plus_fit_p2(distance, dim, bits, sample, rotation_unpadded=False):
+    """shift / scale of TQ+ as the reference's first pass estimates them: one pair of 7-marker P-square estimators per rotated coordinate, fed
+    with the sampled vectors in iteration order (which vectors: the reference's Permutor - an input here)."""
+    plain = TqOracle(distance, dim, bits, rotation_unpadded=rotation_unpadded)
+    v = f32(np.atleast_2d(sample))
+    shift, scale = np.zeros(plain.padded_dim, dtype=np.float32), np.zeros(plain.padded_dim, dtype=np.float32)
+    _lib.qo_tq_plus_fit(plain.h, _p(v), v.shape[0], _p(shift), _p(scale))
+    return shift, scale
+
+
+def tq_plus_quantiles(bits):
+    a, b, c = C.c_double(), C.c_double(), C.c_float()
+    _lib.qo_tq_plus_quantiles(bits, C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, np.float32(c.value)
+
+
 def tq_plus_fit(distance, dim, bits, vectors, rotation_unpadded=False):
     """shift / scale of TQ+ as EncodedVectorsTQ::encode derives them (encoded_vectors_tq.rs:156-240) from per-coordinate quantiles of the rotated,
     length-rescaled vectors at Phi(+-c_outer) - here exact quantiles of the given vectors instead of the reference's P-square estimates over a

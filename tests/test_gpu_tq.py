@@ -178,3 +178,30 @@ def test_tq_plus_mode_bit_exact(qa, distance, bits):
         full = otq.score_points(O.preprocess(distance, queries), np.arange(n))
         for qi, r in enumerate(res):
             assert np.array_equal(_bits(r["score"]), _bits(np.sort(full[qi])[::-1][:5]))
+
+
+@pytest.mark.parametrize("bits", BITS)
+@pytest.mark.parametrize("distance", [O.DOT, O.COSINE, O.EUCLID])
+def test_tq_plus_fit_on_device_equals_the_oracle(qa, distance, bits):
+    """qmx_tq_fit_plus (rotation, length rescale, one pair of 7-marker P-square estimators per rotated coordinate, shift / scale) == the oracle's
+    restatement of the reference's first pass, bit for bit - f64 arithmetic in the reference's operation order incl. the fused desired-position
+    update of its AVX2 path; then the fitted quantizer encodes and scores like the oracle's TQ+ quantizer with the same parameters."""
+    for dim, n in ((65, 300), (128, 2048), (384, 4)):
+        rng = np.random.default_rng(dim * 7 + bits * 3 + distance)
+        raw = rng.standard_normal((n, dim)).astype(np.float32)
+        raw[:, : dim // 8] += 1.5
+        raw[:, dim // 8] = 0.25 if distance != O.COSINE else raw[:, dim // 8]             # a constant coordinate before the rotation
+        if n > 10:
+            raw[5] = 0.0                                                                   # zero vector: no rescale, zeros pushed
+        vecs = O.preprocess(distance, raw)
+        want_shift, want_scale = O.tq_plus_fit_p2(distance, dim, bits, vecs)
+        quant = qa.TurboQuantizer.fit_plus(vecs, dim, _dist(qa, distance), bits)
+        assert np.array_equal(_bits(quant.shift), _bits(want_shift)) and np.array_equal(_bits(quant.scale), _bits(want_scale))
+        assert quant.plus_mode and np.all(np.isfinite(quant.scale)) and np.all(quant.scale > 0)
+    # the fitted quantizer is a TQ+ quantizer like any other
+    otq = O.TqOracle(distance, dim, bits, shift=want_shift, scale=want_scale)
+    data = O.preprocess(distance, rng.standard_normal((50, dim)).astype(np.float32))
+    assert np.array_equal(quant.encode(data), otq.encode_rows(data))
+    # no sample: identity parameters (quantile.rs:151-153)
+    empty = qa.TurboQuantizer.fit_plus(np.zeros((0, 32), dtype=np.float32), 32, _dist(qa, distance), bits)
+    assert np.all(empty.shift == 0.0) and np.all(empty.scale == 1.0)

@@ -208,3 +208,52 @@ def test_plus_mode_with_identity_correction_equals_normal_mode_scores():
         ra, rb = a.encode_rows(vecs), b.encode_rows(vecs)
         assert np.array_equal(ra, rb[:, :a.row_bytes]) and np.all(rb[:, a.row_bytes:].view(np.float32) == 0.0)      # same codes, same scaling factor, xm = -0 * x = 0
         assert np.array_equal(a.score_points(q[None, :], np.arange(n)).view(np.uint32), b.score_points(q[None, :], np.arange(n)).view(np.uint32))
+
+
+def test_p_square_estimator_properties():
+    """The reference's own tests of its extended P-square estimator (p_square.rs:631-832), mirrored: uniform / normal / Student / Poisson
+    streams of 10 000 values land within its tolerances of the exact sample quantile, all-zero streams and streams shorter than the
+    marker count are exact, the 7-marker grid is increasing."""
+    rng = np.random.default_rng(42)
+    u = rng.random(10000)
+    p = O.p2_quantile(0.99, u)
+    assert abs(p - np.quantile(u, 0.99)) < 1e-2 and abs(p - 0.99) < 1e-2                    # test_p_square
+    g = rng.standard_normal(10000)
+    assert abs(O.p2_quantile(0.99, g) - np.quantile(g, 0.99)) < 0.1                          # test_p_square_normal (ERROR = 0.1)
+    assert abs(O.p2_quantile(0.01, g) - np.quantile(g, 0.01)) < 0.1                          # test_p_square_normal_low
+    t = rng.standard_t(5, 10000)
+    assert abs(O.p2_quantile(0.99, t) - np.quantile(t, 0.99)) < 0.5                          # test_p_square_student (heavy tails)
+    po = rng.poisson(4.0, 10000).astype(np.float64)
+    assert abs(O.p2_quantile(0.99, po) - np.quantile(po, 0.99)) < 1.0                        # test_p_square_poisson (ties)
+    assert O.p2_quantile(0.99, np.zeros(10000)) == 0.0                                       # test_p_square_zeros
+    assert O.p2_quantile(0.99, np.zeros(3)) == 0.0                                           # test_p_square_linear
+    assert O.p2_quantile(0.5, []) == 0.0 and O.p2_quantile(0.5, [3.5]) == 3.5
+    assert O.p2_quantile(0.25, [4.0, 0.0, 2.0]) == 1.0                                       # estimate_quantile_from_slice: k = 0.5 between 0 and 2
+    assert O.p2_quantile(0.9, [1.0, np.nan, np.inf, 2.0]) == pytest.approx(1.9)              # NaN / inf observations are dropped
+    _, grid = O.p2_quantile(0.99, [], with_grid=True)
+    assert np.all(np.diff(grid) > 0) and grid[0] == 0.0 and grid[3] == 0.99 and grid[6] == 1.0   # test_p_square_extended_grid
+    assert grid[1] == 0.99 * 0.5 and grid[2] == 0.99 * (0.7 + 0.3 * 1.0 / 3.0)
+
+
+def test_tq_plus_fit_from_p_square_estimates():
+    """TQMode::Plus first pass: quantiles at Phi(+-c_outer) of every rotated, length-rescaled coordinate; data that already is N(0, 1) per
+    coordinate gives shift ~ 0, scale ~ 1 (encoded_vectors_tq.rs:150-155); an anisotropic block is pulled back onto the codebook grid."""
+    lo, hi, c = O.tq_plus_quantiles(O.TQ_BITS4)
+    assert c == np.float32(2.733) and abs(hi - 0.99686) < 1e-4 and lo == pytest.approx(1.0 - hi)
+    assert O.tq_plus_quantiles(O.TQ_BITS1)[2] == np.float32(0.7978846)
+    rng = np.random.default_rng(7)
+    dim = 128
+    iso = rng.standard_normal((4096, dim)).astype(np.float32)
+    shift, scale = O.tq_plus_fit_p2(O.DOT, dim, O.TQ_BITS2, iso)
+    assert np.abs(shift).max() < 0.2 and np.abs(scale - 1.0).max() < 0.2
+    aniso = iso.copy()
+    aniso[:, :16] += 2.0
+    s_exact, c_exact = O.tq_plus_fit(O.DOT, dim, O.TQ_BITS2, aniso)
+    s_p2, c_p2 = O.tq_plus_fit_p2(O.DOT, dim, O.TQ_BITS2, aniso)
+    assert np.abs(s_exact - s_p2).max() < 0.2 and np.abs(c_exact / c_p2 - 1.0).max() < 0.2
+    assert np.abs(s_p2).max() > 0.3                                                          # there is something to correct
+    # degenerate inputs: no sample -> identity; a constant coordinate keeps scale = 1 (MIN_QUANTILE_WIDTH)
+    s0, c0 = O.tq_plus_fit_p2(O.DOT, dim, O.TQ_BITS4, iso[:0])
+    assert np.all(s0 == 0.0) and np.all(c0 == 1.0)
+    sz, cz = O.tq_plus_fit_p2(O.COSINE, dim, O.TQ_BITS4, np.zeros((100, dim), dtype=np.float32))
+    assert np.all(sz == 0.0) and np.all(cz == 1.0)
