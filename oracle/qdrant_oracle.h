@@ -12,8 +12,10 @@
  * Pinning: checked in tests/test_oracle_golden.py against every known-answer vector the
  * reference's own unit tests hold for this path and, for the SQ integer
  * leaves, against the reference's own C kernels compiled into oracle/_ref/.
- * Unpinned by the reference (stated): order among EQUAL scores in the bounded
- * heap (Rust std BinaryHeap, restated here from its published algorithm).
+ * Unpinned by the reference (stated per row in DESIGN.md 4): order among EQUAL scores in the bounded
+ * heap (Rust std BinaryHeap, restated here from its published algorithm); accumulation ORDER of the f32 / u8 leaves (its literals
+ * are small integers); f16 leaves; PQ, k-means, the HNSW builder / search and the TurboQuant sections incl. the TQ+ P-square fit
+ * (the reference's tests for those are tolerance / property tests: mirrored, no literal to hold the bits).
  */
 #ifndef QDRANT_ORACLE_H
 #define QDRANT_ORACLE_H
