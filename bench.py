@@ -19,6 +19,8 @@ Outside the timed region, rank 0, N=1 (the `configs` object; each entry carries 
 the device, and an in-run check of a sample against the CPU oracle):
   C3  10 M x 768 SQ-int8, dot: brute force with oversampling 2 + f32 rescoring at Q = 1 and 32 (qmx_search_quantized), and the HNSW path:
       device build THROUGH the SQ scorer, SQ walk ef = 128, oversampling 2, f32 rescoring.
+  TQ4 the rows of C3 as TurboQuant 4-bit: device encode (qmx_tq_encode), brute force with oversampling 2 + f32 rescoring at Q = 1 and 32
+      (int8 matrix cores from 4 queries up).
   C4  10 M x 1536 PQ m = 96 (LUT on the matrix cores), HNSW ef = 128: device k-means + encode, device build through the PQ scorer
       (qmx_hnsw_build_quantized), PQ walk, with and without f32 rescoring.
 Rows of C3 / C4 have low intrinsic dimension (qmx_synth_fill_latent_f32, 32 latent coordinates + noise): recall is meaningful there;
@@ -65,7 +67,7 @@ def parse():
                     help="which derived copy of the block the prefilter scans (half: f16 high parts, 2 B / element; pair: f16 pairs, 4 B; none: the f32 block itself)")
     ap.add_argument("--no-hbm-point", action="store_true", help="skip the secondary Q=16 (HBM-bound) measurement of the same scan")
     ap.add_argument("--verify", type=int, default=1, help="check samples against the oracle (C2 first batch, C3 / C4 scans and walks)")
-    ap.add_argument("--configs", default="c3,c4", help="comma list of the secondary single-GPU configs to run (empty = none)")
+    ap.add_argument("--configs", default="c3,tq,c4", help="comma list of the secondary single-GPU configs to run (empty = none)")
     ap.add_argument("--config-rows", type=int, default=0, help="rows of C3 / C4 (0 = --rows)")
     ap.add_argument("--hnsw-queries", type=int, default=8192, help="searches per launch of the HNSW walks")
     return ap.parse_args()
@@ -265,6 +267,11 @@ def main():
                 cfg["C3"], rows = c3_section(ctx, rows)
             except Exception as e:  # the headline line must survive a failure of a secondary measurement
                 cfg["C3"] = {"error": repr(e)[:400]}
+        if "tq" in wanted and "C3" in cfg and "error" not in cfg["C3"]:
+            try:
+                cfg["TQ4"] = tq_section(ctx, rows)      # the rows of C3, TurboQuant 4 bits instead of SQ int8
+            except Exception as e:
+                cfg["TQ4"] = {"error": repr(e)[:400]}
         del rows
         torch.cuda.empty_cache()
         if "c4" in wanted:
@@ -583,6 +590,61 @@ def c3_section(ctx, rows):
     out["hnsw_sq_walk_rescore"] = st
     del keep_codes, graph, enc, vs
     return out, rows
+
+
+def tq_section(ctx, rows):
+    """The C3 rows quantized with TurboQuant (4 bits, TQMode::Normal, dot): device encode, brute force with oversampling 2 + f32 rescoring."""
+    args, dev, lib, F, qa, np, torch = (ctx[k] for k in ("args", "dev", "lib", "F", "qa", "np", "torch"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    n, dim = rows.shape
+    top, seed = 10, 0x5EED0003
+    queries = _latent(ctx, seed, QUERY_ROW0, 256, dim)
+    vs = qa.VectorStorage(rows, qa.Distance.Cosine)
+    quant = qa.TurboQuantizer(dim, qa.Distance.Dot, 0)
+    p = quant.params()
+    row_bytes = quant.quantized_vector_size()
+    codes = torch.empty((n, row_bytes), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    F.check(lib.qmx_tq_encode(dev.index or 0, int(qa.Distance.Dot), dim, C.byref(p), F.ptr(rows), n, F.ptr(codes)))
+    torch.cuda.synchronize(dev)
+    t_enc = time.perf_counter() - t0
+    enc = qa.EncodedVectorsTQ(codes, quant)
+    S = min(n, 20_000)
+    host_codes_sample = codes[:S].cpu().numpy()
+    host_rows_sample = rows[:300].cpu().numpy()
+    del codes
+    out = {"workload": "the rows of C3 as TurboQuant 4-bit (Hadamard rotation + Lloyd-Max codebook), dot: %s x d=%d" % (_human(n), dim),
+           "rows": n, "dim": dim, "row_bytes": row_bytes, "tq_encode_s": round(t_enc, 3)}
+    n_gt = 256
+    exact = qa.BatchFilteredSearcher(queries[:n_gt].cpu().numpy(), vs, top).peek_top_all()
+    bf = {}
+    for Qb in (1, 32):
+        nb = min(n_gt // Qb, 8)
+        recs, stats = [], None
+        for b in range(nb):
+            qb = queries[b * Qb:(b + 1) * Qb].contiguous()
+            scorer, raw = qa.new_raw_scorer(qb, enc), qa.new_raw_scorer(qb, vs)
+            res, st, _ = _timed_quantized(ctx, scorer, raw, top, 2.0, True, None, 0, 5 if b == 0 else 1, row_bytes, n_rows_scanned=n)
+            stats = stats or st
+            recs.append(_recall(res, exact[b * Qb:(b + 1) * Qb], top))
+        stats["recall_at_10_vs_exact"] = round(float(np.mean(recs)), 4)
+        stats["queries_checked"] = nb * Qb
+        bf["Q%d" % Qb] = stats
+    out["brute_force_oversampling2_rescore"] = bf
+    if args.verify:
+        import oracle_ffi as O
+        otq = O.TqOracle(O.DOT, dim, O.TQ_BITS4)
+        enc_ok = bool(np.array_equal(otq.encode_rows(host_rows_sample), host_codes_sample[:300]))
+        otq.rows = host_codes_sample
+        qpre = queries[:2].cpu().numpy()
+        ids = np.arange(S, dtype=np.uint32)
+        got = qa.BatchFilteredSearcher(qpre, vs, top, quantized_vectors=enc).peek_top_iter(ids)
+        sc = otq.score_points(qpre, ids)
+        top_ok = all(np.array_equal(np.sort(sc[i])[::-1][:top].view(np.uint32), got[i]["score"].view(np.uint32)) for i in range(2))
+        out["oracle_check"] = {"encoded_rows_byte_exact_first_300": enc_ok, "topk_scores_bit_exact_on_%dk_sample" % (S // 1000): bool(top_ok)}
+    del enc, vs
+    return out
 
 
 def c4_section(ctx):

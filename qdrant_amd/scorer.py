@@ -458,7 +458,9 @@ class EncodedVectorsTQ(VectorStorage):
         self.quantizer = quantizer
         self.distance = quantizer.distance
         self.datatype = None
-        rows = np.ascontiguousarray(rows, dtype=np.uint8)
+        on_device = hasattr(rows, "data_ptr") and getattr(rows, "is_cuda", False)   # a torch CUDA tensor: split on the device, no host copy
+        if not on_device:
+            rows = np.ascontiguousarray(rows, dtype=np.uint8)
         assert rows.shape[1] == quantizer.quantized_vector_size()
         self.dim = quantizer.dim
         self.count = int(rows.shape[0])
