@@ -261,7 +261,7 @@ static bool bq_mfma_ok(const qmx_query *q);
 static uint32_t tile_qt(const qmx_segment *s, const qmx_query *q) {
     if (s->dtype == QMX_DTYPE_BQ) return bq_mfma_ok(q) && (size_t)MAX_QT_MFMA * q->q_stride <= 150 * 1024 ? MAX_QT_MFMA : MAX_QT;
     if (s->dtype == QMX_DTYPE_SQ_U8) return mfma_scan_ok(s) ? MAX_QT_MFMA : MAX_QT;
-    if (s->dtype == QMX_DTYPE_TQ) return mfma_scan_ok(s) && (size_t)MAX_QT_MFMA * (((size_t)s->scan_dim + 63) * (s->tq_value_bits == 4 ? 4 : s->tq_value_bits == 2 ? 8 : 32) + QUERY_AUX_BYTES) <= 150 * 1024 ? MAX_QT_MFMA : MAX_QT;
+    if (s->dtype == QMX_DTYPE_TQ) return mfma_scan_ok(s) && (size_t)MAX_QT_MFMA * q->q_stride <= 150 * 1024 ? MAX_QT_MFMA : MAX_QT;
     return mfma_scan_ok(s) && (size_t)MAX_QT_MFMA * (((size_t)s->dim * 4 + 127) / 128 * 128 + QUERY_AUX_BYTES) <= 150 * 1024 ? MAX_QT_MFMA : MAX_QT;
 }
 
@@ -270,6 +270,12 @@ static uint32_t tile_qt(const qmx_segment *s, const qmx_query *q) {
 static bool bq_mfma_ok(const qmx_query *q) {
     return q->seg->dtype == QMX_DTYPE_BQ && q->tq_qbytes_off != 0 && !option(OPT_NO_MFMA_SCAN) && (size_t)MAX_QT * q->q_stride <= 150 * 1024;
 }
+
+// Entries of a query tile that scan_sq_mfma.hip keeps in LDS: its B operand is one ds_read_b128 per lane at (query n) * stride + (16-byte piece kg),
+// 16 lanes per LDS cycle over 64 banks - a stride of 64 bytes mod 256 (what 128-byte aligned bodies + the 64-byte aux block give) puts queries n and
+// n + 4 on the same banks (SQ_LDS_BANK_CONFLICT 74 % of the LDS cycles of the 1-bit scan); 16 bytes mod 256 spreads the 16 queries of a group over
+// the 16 slots of a bank row.
+static uint32_t lds_tile_stride(uint32_t bytes) { return bytes + (16u + 256u - bytes % 256u) % 256u; }
 
 // A TurboQuant query entry: `pieces` 16-byte query pieces per 16-byte row piece (scan_tq.hip; 1-bit storage under TQ+: 16 bit planes), zero padded
 // to whole 64-byte row steps (the matrix-core scan, scan_sq_mfma.hip TqOps, reads whole steps); behind the bit planes of a 1-bit storage the
@@ -1118,6 +1124,8 @@ static int32_t query_alloc(const qmx_segment *seg, uint32_t nq, qmx_query **out,
         q->aux_off += ((seg->scan_dim + 63) & ~63u) * 8;
     }
     q->q_stride = q->aux_off + QUERY_AUX_BYTES;
+    if (seg->dtype == QMX_DTYPE_SQ_U8 || seg->dtype == QMX_DTYPE_F16 || seg->dtype == QMX_DTYPE_TQ || (seg->dtype == QMX_DTYPE_BQ && q->tq_qbytes_off))
+        q->q_stride = lds_tile_stride(q->q_stride);
     if (seg->dtype == QMX_DTYPE_PQ) {   // the encoded query is the LUT [m][n_centroids] f32 (EncodedQueryPQ)
         q->q_stride = (uint32_t)(((size_t)seg->pq_m * seg->pq.n_centroids * sizeof(float) + 15) & ~(size_t)15);
         q->aux_off = 0;
@@ -2114,7 +2122,7 @@ static void fill_args_segment(const qmx_segment *s, ScanArgs &a) {
         a.tq_invert = s->tq_invert ? 1 : 0;
         a.tq_planes = (s->tq_value_bits == 1 && s->d_tq_shift) ? 16 : 8;
         tq_entry_layout(s, &pieces, &a.tq_qbytes_off, &a.aux_off);
-        a.q_stride = a.aux_off + QUERY_AUX_BYTES;
+        a.q_stride = lds_tile_stride(a.aux_off + QUERY_AUX_BYTES);
         a.bq_qbits = pieces;
         a.tq_code_bytes = s->tq_code_bytes;
         a.tq_ec = TqEc{s->d_tq_weights, s->d_tq_xm, s->tq_weight_scale, s->tq_mm_const};

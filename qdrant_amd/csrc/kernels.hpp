@@ -75,6 +75,9 @@ struct ScanArgs {
 enum ScanMode { SCAN_TOPK = 0, SCAN_SCORES = 1 };
 
 // per-query aux block (64 bytes after the padded elements of each query in the tile)
+// Byte form of a 1-bit-storage query (scan_sq_mfma.hip Tq1Ops<1> / BqOps): row piece p = 4 s + kg of step s sits at slot 4 s + (0, 2, 1, 3)[kg]
+__host__ __device__ inline uint32_t byte_form_slot(uint32_t piece) { return (piece & ~3u) | ((piece & 1u) << 1) | ((piece >> 1) & 1u); }
+
 struct QueryAux {
     float f0;           // u8 cosine: norm1 (reference order) ; SQ: query offset
     int32_t i0;         // u8 cosine scalar order: norm1 as i32

@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void bq_encode_scalar_query_kernel(const float
             mine += quantized;
         }
         const uint32_t piece = i / 128, d = i % 128;
-        entry[qbytes_off + ((size_t)piece * 8 + d % 8) * 16 + d / 8] = i < ext ? (uint8_t)(int8_t)((int32_t)quantized - (bits == 8 ? 128 : 0)) : 0;
+        entry[qbytes_off + ((size_t)byte_form_slot(piece) * 8 + d % 8) * 16 + d / 8] = i < ext ? (uint8_t)(int8_t)((int32_t)quantized - (bits == 8 ? 128 : 0)) : 0;
     }
     atomicAdd(&value_sum, mine);
     __syncthreads();

@@ -32,6 +32,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // whether finish() wants the number of set bits of the row (counted from the pieces the wave reads anyway)
 template <class Ops, class = void> struct ops_row_ones { static constexpr bool value = false; };
 template <class Ops> struct ops_row_ones<Ops, decltype((void)Ops::ROW_ONES)> { static constexpr bool value = Ops::ROW_ONES; };
+// where the 16 bytes x pieces of lane group kg sit inside a step of the query entry: kg * QSTEP / 4 unless the Ops permute them
+template <class Ops, class = void> struct ops_kg_off { static __device__ __forceinline__ uint32_t get(int kg) { return (uint32_t)kg * (Ops::QSTEP / 4); } };
+template <class Ops> struct ops_kg_off<Ops, decltype((void)&Ops::kg_off)> { static __device__ __forceinline__ uint32_t get(int kg) { return Ops::kg_off(kg); } };
 template <class Ops, class = void> struct ops_query_off { static __device__ __forceinline__ uint32_t get(const ScanArgs &) { return 0; } };
 template <class Ops> struct ops_query_off<Ops, decltype((void)&Ops::query_off)> { static __device__ __forceinline__ uint32_t get(const ScanArgs &a) { return Ops::query_off(a); } };
 
@@ -130,6 +133,9 @@ struct Tq1Ops {
     struct dec_t { uint4 c[8]; };
     static __device__ __forceinline__ uint32_t body_bytes(const ScanArgs &a) { return a.dim; }
     static __device__ __forceinline__ uint32_t query_off(const ScanArgs &a) { return a.tq_qbytes_off; }
+    // 8-bit values: a lane group's 8 pieces are 128 bytes; groups 0 / 1 (and 2 / 3) are read in the same LDS cycle, so they sit 256 bytes apart
+    // (order 0, 2, 1, 3 inside the step - tq_piece_slot below is what the encoders use)
+    static __device__ __forceinline__ uint32_t kg_off(int kg) { return NA_ == 1 ? (uint32_t)(((kg & 1) << 1) | (kg >> 1)) * 128u : (uint32_t)kg * 256u; }
     static __device__ __forceinline__ void decode(const uint4 &x, dec_t &d) {
         const uint32_t v[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
@@ -176,6 +182,7 @@ struct BqOps {
     typedef typename Tq1Ops<1, false>::dec_t dec_t;
     static __device__ __forceinline__ uint32_t body_bytes(const ScanArgs &a) { return a.dim; }
     static __device__ __forceinline__ uint32_t query_off(const ScanArgs &a) { return a.tq_qbytes_off; }
+    static __device__ __forceinline__ uint32_t kg_off(int kg) { return Tq1Ops<1, false>::kg_off(kg); }
     static __device__ __forceinline__ void decode(const uint4 &x, dec_t &d) { Tq1Ops<1, false>::decode(x, d); }
     static __device__ __forceinline__ void mac(const dec_t &d, const unsigned char *qp, acc_t (&acc)[NA]) { Tq1Ops<1, false>::mac(d, qp, acc); }
     static __device__ __forceinline__ float row_aux(const ScanArgs &, uint32_t) { return 0.0f; }
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs 
     const unsigned char *rows = reinterpret_cast<const unsigned char *>(a.rows);
     const uint32_t nbytes = Ops::body_bytes(a);             // bytes of the SIMD body per row (multiple of 16)
     const uint32_t nstep = (nbytes + 63) / 64;
-    const unsigned char *qbase = smem + (uint32_t)n * a.q_stride + ops_query_off<Ops>::get(a) + (uint32_t)kg * (Ops::QSTEP / 4);   // + g * 16 * q_stride + s * QSTEP
+    const unsigned char *qbase = smem + (uint32_t)n * a.q_stride + ops_query_off<Ops>::get(a) + ops_kg_off<Ops>::get(kg);   // + g * 16 * q_stride + s * QSTEP
     const uint32_t gstride = 16u * a.q_stride;
     const int top = (int)a.top;
 

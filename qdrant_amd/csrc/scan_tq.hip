@@ -741,7 +741,7 @@ __global__ __launch_bounds__(256) void tq_query_encode_kernel(double *rot, uint3
                     entry[qbytes_off + ((size_t)block * 16 + j) * 16 + k] = (uint8_t)(int8_t)lo;
                     entry[qbytes_off + ((size_t)block * 16 + 8 + j) * 16 + k] = (uint8_t)(int8_t)hi;
                 } else {
-                    entry[qbytes_off + ((size_t)block * 8 + j) * 16 + k] = (uint8_t)(int8_t)qs;
+                    entry[qbytes_off + ((size_t)byte_form_slot(block) * 8 + j) * 16 + k] = (uint8_t)(int8_t)qs;
                 }
             }
         } else {
