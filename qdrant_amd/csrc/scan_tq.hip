@@ -13,7 +13,7 @@
 //   row layout                         turboquant/encoding.rs:117-134,172-258 [codes: padded_dim * bits / 8 bytes, LSB first][scaling_factor f32][l2 f32 (L2)]
 // The x86_64 constants are the ones restated (the reference's aarch64 build uses other integer ranges: its scores differ in the last bits).
 // Everything between the rotation and the final f32 products is integer arithmetic, exact in any order: scores are bit-identical to the
-// reference's whatever SIMD path it took.  TQMode::Normal only (no TQ+ error correction); distances Dot, Cosine, L2.
+// reference's whatever SIMD path it took.  TQMode::Normal and TQMode::Plus (error correction given or fitted by tq_p2_fit_kernel below); distances Dot, Cosine, L2.
 //
 // HBM layout: code block [n][code bytes rounded up to 16] (zero padded) + one or two f32 columns (scaling_factor, l2_length), like SQ.
 // A query entry holds QPIECES 16-byte pieces per 16-byte row piece, ordered the way the decode of a row dword produces its operands:
