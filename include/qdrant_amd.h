@@ -701,6 +701,12 @@ QMX_API int32_t qmx_hnsw_export_plain(const qmx_hnsw *g, uint32_t *reindex, uint
  * in [n][dim] f32 -> out [n][4 + actual_dim] reference rows. */
 QMX_API int32_t qmx_sq_encode(int32_t device_id, uint32_t distance, const qmx_sq_params *params,
                               const float *in, uint64_t n, uint32_t dim, void *out_rows);
+/* `VectorStats::build` (lib/quantization/src/vector_stats.rs:27-117): the per-dimension statistics Encoding::TwoBits / OneAndHalfBits of the binary
+ * quantizer encode against (encoded_vectors_binary.rs:456: over ALL vectors of the storage, in order) - streaming Welford in f64 (mean, sample stddev)
+ * and f32 min / max; vectors [n][dim] f32 (host or device); outputs [dim] f32 (host or device; min_out / max_out may be NULL).  One thread per dimension
+ * runs the reference's sequential update: the oracle's bits.  The arrays are what qmx_bq_params.mean / .stddev take. */
+QMX_API int32_t qmx_vector_stats(int32_t device_id, const float *vectors, uint64_t n, uint32_t dim, float *min_out, float *max_out, float *mean_out,
+                                 float *stddev_out);
 /* `EncodedVectorsBin::encode_vector` for Encoding::OneBit (encoded_vectors_binary.rs:535-568) with the u128 store type:
  * in [n][dim] f32 (already metric-preprocessed, as the storage's rows are) -> out [n][ceil(dim / 128) * 16] bytes. */
 QMX_API int32_t qmx_bq_encode(int32_t device_id, const float *in, uint64_t n, uint32_t dim, void *out_rows);

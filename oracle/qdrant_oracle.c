@@ -1332,6 +1332,33 @@ static void bq_two_bits_value(float value, const float *mean, const float *stdde
 static void bq_set_bit(uint8_t *out, size_t j) {   /* encoded_vector[j / 128] |= one << (j % 128), little-endian u128 */
     out[(j / 128) * 16 + (j % 128) / 8] |= (uint8_t)(1u << (j % 8));
 }
+/* VectorStatsBuilder::add for every row, then build (vector_stats.rs:48-102) */
+void qo_vector_stats(const float *rows, uint64_t n, uint32_t dim, float *min, float *max, float *mean, float *stddev) {
+    double *means = (double *)calloc(dim ? dim : 1, sizeof(double)), *m2 = (double *)calloc(dim ? dim : 1, sizeof(double));
+    for (uint32_t d = 0; d < dim; d++) { min[d] = 3.40282347e+38f; max[d] = -3.40282347e+38f; }   /* f32::MAX, f32::MIN */
+    uint64_t count = 0;
+    for (uint64_t r = 0; r < n; r++) {
+        count += 1;
+        const double count_f64 = (double)count;
+        const float *v = rows + r * dim;
+        for (uint32_t d = 0; d < dim; d++) {
+            const double value = (double)v[d];
+            const float value_f32 = (float)value;
+            if (value_f32 < min[d]) min[d] = value_f32;
+            if (value_f32 > max[d]) max[d] = value_f32;
+            const double delta = value - means[d];
+            means[d] += delta / count_f64;
+            m2[d] += delta * (value - means[d]);
+        }
+    }
+    for (uint32_t d = 0; d < dim; d++) {
+        stddev[d] = count > 1 ? (float)sqrt(m2[d] / (double)(count - 1)) : 0.0f;
+        mean[d] = (float)means[d];
+    }
+    free(means);
+    free(m2);
+}
+
 void qo_bq_encode_row_ex(uint32_t dim, int encoding, const float *mean, const float *stddev, const float *v, uint8_t *out) {
     memset(out, 0, qo_bq_row_bytes_ex(dim, encoding));
     for (uint32_t i = 0; i < dim; ++i) {

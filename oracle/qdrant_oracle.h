@@ -197,6 +197,10 @@ float qo_tq_score_symmetric(const qo_tq *t, const uint8_t *v1, const uint8_t *v2
 void qo_merge_topk(const qo_scored_point *lists, const uint32_t *counts, const uint32_t *idx_base,
                    uint32_t n_lists, uint32_t nq, uint32_t k, qo_scored_point *out, uint32_t *out_counts);
 
+/* VectorStats::build (lib/quantization/src/vector_stats.rs:27-117): streaming Welford (f64) mean / sample stddev and f32 min / max of every dimension over
+ * ALL vectors in order - the statistics Encoding::TwoBits / OneAndHalfBits of the binary quantizer encode against (encoded_vectors_binary.rs:456). */
+void qo_vector_stats(const float *rows, uint64_t n, uint32_t dim, float *min, float *max, float *mean, float *stddev);
+
 /* ---- scorer = FilteredScorer{RawScorer, NotDeletedChecker} (hnsw_index/point_scorer.rs:53-63) ---- */
 typedef struct qo_scorer {
     int kind;                 /* 0 dense (Metric over st->rows), 1 SQ (EncodedVectorsU8), 2 PQ (EncodedVectorsPQ), 3 BQ (EncodedVectorsBin<u128>),

@@ -7,5 +7,5 @@ from ._ffi import (COSINE, DOT, DTYPE_BQ, DTYPE_F16, DTYPE_F32, DTYPE_PQ, DTYPE_
                    QmxError, get_option, lib, set_option)
 from .scorer import (BatchFilteredSearcher, Distance, EncodedVectorsPQ, EncodedVectorsU8, ProductQuantizer, RawScorer, ScalarQuantizer,  # noqa: F401
                      ScoredPointOffset, VectorStorage, VectorStorageDatatype, device_count, new_raw_scorer,
-                     new_raw_scorer_internal, pq_train, search_quantized, CustomQuery, CustomRawScorer, BinaryQuantizer, EncodedVectorsBin, load_quantizer, MultiDenseVectorStorage, QuantizedMultivectorStorage, TurboQuantizer, EncodedVectorsTQ)
+                     new_raw_scorer_internal, pq_train, search_quantized, CustomQuery, CustomRawScorer, BinaryQuantizer, EncodedVectorsBin, load_quantizer, MultiDenseVectorStorage, QuantizedMultivectorStorage, TurboQuantizer, EncodedVectorsTQ, vector_stats)
 from .hnsw import GraphLayers, decode_links_file  # noqa: F401

@@ -184,6 +184,7 @@ SIGNATURES = {
     "qmx_multi_score_points": (C.c_int32, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32, _P]),
     "qmx_multi_search_topk": (C.c_int32, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint64, C.c_uint32, _P, C.c_uint64, _P, _P]),
     "qmx_tq_encode": (C.c_int32, [C.c_int32, C.c_uint32, C.c_uint32, _P, _P, C.c_uint64, _P]),
+    "qmx_vector_stats": (C.c_int32, [C.c_int32, _P, C.c_uint64, C.c_uint32, _P, _P, _P, _P]),
     "qmx_tq_fit_plus": (C.c_int32, [C.c_int32, C.c_uint32, C.c_uint32, _P, _P, C.c_uint64, _P, _P]),
     "qmx_hnsw_search_with_vectors": (C.c_int32, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, _P, _P, _P]),
     "qmx_multi_hnsw_search": (C.c_int32, [_P, _P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint64, C.c_uint32, C.c_uint32, _P, _P, _P]),

@@ -3260,6 +3260,31 @@ int32_t qmx_bq_encode_ex(int32_t device_id, const qmx_bq_params *params, const f
     return rc;
 }
 
+int32_t qmx_vector_stats(int32_t device_id, const float *vectors, uint64_t n, uint32_t dim, float *min_out, float *max_out, float *mean_out, float *stddev_out) {
+    QMX_REQUIRE((n == 0 || vectors) && dim > 0 && mean_out && stddev_out, QMX_ERR_BAD_ARG, "bad argument");
+    QMX_TRY(check_device(device_id, nullptr));
+    DevBuf bin, bout;
+    int32_t rc = QMX_OK;
+    do {
+        const float *d_in = vectors;
+        if (n && !is_device_ptr(vectors)) {
+            if ((rc = bin.reserve((size_t)n * dim * 4)) != QMX_OK) break;
+            if (hipMemcpy(bin.p, vectors, (size_t)n * dim * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = QMX_ERR_OTHER; break; }
+            d_in = (const float *)bin.p;
+        }
+        if ((rc = bout.reserve((size_t)dim * 16)) != QMX_OK) break;
+        float *o = (float *)bout.p;
+        if ((rc = launch_vector_stats(nullptr, d_in, (uint64_t)dim * 4, n, dim, o, o + dim, o + 2 * (size_t)dim, o + 3 * (size_t)dim)) != QMX_OK) break;
+        if (hipDeviceSynchronize() != hipSuccess) { rc = QMX_ERR_OTHER; break; }
+        float *dst[4] = {min_out, max_out, mean_out, stddev_out};
+        for (int k = 0; k < 4 && rc == QMX_OK; ++k)
+            if (dst[k] && hipMemcpy(dst[k], o + (size_t)k * dim, (size_t)dim * 4, hipMemcpyDefault) != hipSuccess) rc = QMX_ERR_OTHER;
+    } while (0);
+    bin.release(); bout.release();
+    if (rc == QMX_ERR_OTHER) set_error("qmx_vector_stats: HIP error");
+    return rc;
+}
+
 int32_t qmx_bq_encode(int32_t device_id, const float *in, uint64_t n, uint32_t dim, void *out_rows) {
     return qmx_bq_encode_ex(device_id, nullptr, in, n, dim, out_rows);
 }

@@ -278,6 +278,8 @@ int32_t launch_pairs_tq(hipStream_t st, const ScanArgs &a, const PairSel &sel, u
 uint64_t bq_row_bytes(uint32_t dim, uint32_t encoding);
 int32_t launch_bq_encode_scalar_query(hipStream_t st, const float *d_in, uint32_t nq, uint32_t dim, uint32_t encoding, uint32_t bits, uint8_t *d_out,
                                       uint32_t out_stride, uint32_t qbytes_off, uint32_t aux_off, uint32_t body);
+int32_t launch_vector_stats(hipStream_t st, const float *d_rows, uint64_t row_stride_bytes, uint64_t n, uint32_t dim, float *d_min, float *d_max, float *d_mean,
+                            float *d_stddev);
 int32_t launch_bq_encode(hipStream_t st, const float *d_in, uint64_t n, uint32_t dim, uint32_t encoding, const float *d_mean, const float *d_stddev,
                          uint8_t *d_out, uint64_t out_stride);
 // PQ (pq.hip)

@@ -401,6 +401,52 @@ int32_t launch_bq_encode_scalar_query(hipStream_t st, const float *d_in, uint32_
     return QMX_OK;
 }
 
+// VectorStats::build (vector_stats.rs:27-117): one thread per dimension runs the streaming Welford update over the rows in order (f64 mean / m2, the
+// division by the running count included - the reference's bits), rows read 8 ahead; adjacent threads read adjacent floats of a row.
+__global__ __launch_bounds__(64) void vector_stats_kernel(const float *rows, uint64_t row_stride_f, uint64_t n, uint32_t dim, float *mn, float *mx, float *mean,
+                                                          float *stddev) {
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= dim) return;
+    float lo = 3.40282347e+38f, hi = -3.40282347e+38f;
+    double m = 0.0, m2 = 0.0;
+    const float *p = rows + d;
+    uint64_t r = 0;
+    for (; r + 8 <= n; r += 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(p + (r + k) * row_stride_f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const double value = (double)v[k];
+            lo = v[k] < lo ? v[k] : lo;
+            hi = v[k] > hi ? v[k] : hi;
+            const double delta = value - m;
+            m += delta / (double)(r + k + 1);
+            m2 += delta * (value - m);
+        }
+    }
+    for (; r < n; ++r) {
+        const float x = p[r * row_stride_f];
+        const double value = (double)x;
+        lo = x < lo ? x : lo;
+        hi = x > hi ? x : hi;
+        const double delta = value - m;
+        m += delta / (double)(r + 1);
+        m2 += delta * (value - m);
+    }
+    mn[d] = lo;
+    mx[d] = hi;
+    mean[d] = (float)m;
+    stddev[d] = n > 1 ? (float)sqrt(m2 / (double)(n - 1)) : 0.0f;
+}
+int32_t launch_vector_stats(hipStream_t st, const float *d_rows, uint64_t row_stride_bytes, uint64_t n, uint32_t dim, float *d_min, float *d_max, float *d_mean,
+                            float *d_stddev) {
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(vector_stats_kernel, dim3((dim + 63) / 64), dim3(64), 0, st, d_rows, row_stride_bytes / 4, n, dim, d_min, d_max, d_mean, d_stddev);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
 int32_t launch_bq_encode(hipStream_t st, const float *d_in, uint64_t n, uint32_t dim, uint32_t encoding, const float *d_mean, const float *d_stddev,
                          uint8_t *d_out, uint64_t out_stride) {
     if (n == 0) return QMX_OK;

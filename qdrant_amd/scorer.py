@@ -324,6 +324,17 @@ class EncodedVectorsPQ(VectorStorage):
         return out
 
 
+def vector_stats(vectors, dim: int, device_id: int = 0):
+    """`VectorStats::build` (vector_stats.rs): (min, max, mean, stddev) of every dimension over the vectors in order, on the device."""
+    on_device = hasattr(vectors, "data_ptr") and getattr(vectors, "is_cuda", False)
+    if not on_device:
+        vectors = np.ascontiguousarray(vectors, dtype=np.float32).reshape(-1, dim)
+    n = int(vectors.shape[0])
+    out = [np.empty(dim, dtype=np.float32) for _ in range(4)]
+    F.check(F.lib().qmx_vector_stats(device_id, F.ptr(vectors) if n else None, n, dim, *[F.ptr(o) for o in out]))
+    return tuple(out)
+
+
 class BinaryQuantizer:
     """`Metadata{vector_parameters, encoding, query_encoding: SameAsStorage, vector_stats}` of `EncodedVectorsBin<u128>`
     (lib/quantization/src/encoded_vectors_binary.rs:43-78).  `invert` defaults to the segment's choice (quantized_vectors.rs:232:
@@ -341,6 +352,16 @@ class BinaryQuantizer:
         self.encoding = int(encoding)
         self.mean = None if mean is None else np.ascontiguousarray(mean, dtype=np.float32)
         self.stddev = None if stddev is None else np.ascontiguousarray(stddev, dtype=np.float32)
+
+    @classmethod
+    def fit(cls, vectors, dim: int, distance: Distance, encoding: int, invert: Optional[bool] = None, query_encoding: int = 0,
+            device_id: int = 0) -> "BinaryQuantizer":
+        """The quantizer of a new storage: `VectorStats::build` over ALL its vectors in order (qmx_vector_stats on the device: streaming Welford in
+        f64, the oracle's bits) for Encoding::TwoBits / OneAndHalfBits; Encoding::OneBit needs no statistics.  `vectors`: numpy or a torch CUDA tensor."""
+        if int(encoding) == 0:
+            return cls(dim, distance, invert, 0, None, None, query_encoding)
+        mean, stddev = vector_stats(vectors, dim, device_id)[2:]
+        return cls(dim, distance, invert, encoding, mean, stddev, query_encoding)
 
     def params(self) -> "F.BqParams":
         p = F.BqParams()

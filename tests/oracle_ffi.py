@@ -1007,6 +1007,18 @@ class TqOracle:
         return out
 
 
+_sig("qo_vector_stats", None, [_P, C.c_uint64, C.c_uint32, _P, _P, _P, _P])
+
+
+def vector_stats(rows):
+    """VectorStats::build: (min, max, mean, stddev) per dimension, streaming Welford over the rows in order."""
+    v = f32(np.atleast_2d(rows))
+    n, dim = v.shape
+    out = [np.zeros(dim, dtype=np.float32) for _ in range(4)]
+    _lib.qo_vector_stats(_p(v) if n else None, n, dim, *[_p(o) for o in out])
+    return tuple(out)
+
+
 _sig("qo_tq_plus_quantiles", None, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_float)])
 _sig("qo_tq_preprocess", None, [_P, _P, _P])
 _sig("qo_p2_quantile", C.c_double, [C.c_double, _P, C.c_uint64, _P])

@@ -270,3 +270,20 @@ def test_bq_scalar_query_hnsw_walk_and_rescoring(qa):
         res = qa.search_quantized(scorer, raw, top, oversampling=3.0, rescore=True, graph=graph, hnsw_ef=64)
         hits[bits] = sum(len(set(a["idx"].tolist()) & set(b["idx"].tolist())) for a, b in zip(res, exact))
     assert hits[8] >= hits[1] and hits[8] / (top * nq) > 0.5
+
+
+def test_vector_stats_on_device_equals_the_oracle(qa):
+    """qmx_vector_stats (VectorStats::build: the statistics of the 2-bit / 1.5-bit encodings) == the oracle's streaming Welford, bit for bit, for
+    row counts around the kernel's 8-row unroll; BinaryQuantizer.fit encodes like a quantizer given those statistics."""
+    rng = np.random.default_rng(11)
+    for n, dim in ((0, 5), (1, 7), (7, 64), (8, 65), (1003, 130), (20000, 96)):
+        x = (rng.standard_normal((n, dim)) * 2.0 + rng.standard_normal(dim)).astype(np.float32)
+        want = O.vector_stats(x)
+        got = qa.vector_stats(x, dim)
+        for g, w in zip(got, want):
+            assert np.array_equal(g.view(np.uint32), w.view(np.uint32))
+    quant = qa.BinaryQuantizer.fit(x, dim, qa.Distance.Dot, 1)
+    ref = qa.BinaryQuantizer(dim, qa.Distance.Dot, encoding=1, mean=want[2], stddev=want[3])
+    assert np.array_equal(quant.encode(x[:200]), ref.encode(x[:200]))
+    obq = O.BqOracle(O.DOT, dim, encoding=1, mean=want[2], stddev=want[3])
+    assert np.array_equal(quant.encode(x[:200]), obq.encode_rows(x[:200]))

@@ -257,3 +257,17 @@ def test_tq_plus_fit_from_p_square_estimates():
     assert np.all(s0 == 0.0) and np.all(c0 == 1.0)
     sz, cz = O.tq_plus_fit_p2(O.COSINE, dim, O.TQ_BITS4, np.zeros((100, dim), dtype=np.float32))
     assert np.all(sz == 0.0) and np.all(cz == 1.0)
+
+
+def test_vector_stats_welford():
+    """VectorStats::build (vector_stats.rs): streaming Welford == the two-pass mean / sample stddev up to rounding; min / max exact; the degenerate
+    counts of its build() (0 rows: mean 0, stddev 0, min = f32::MAX, max = f32::MIN; 1 row: stddev 0)."""
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((5000, 33)) * 3.0 + 1.5).astype(np.float32)
+    mn, mx, mean, sd = O.vector_stats(x)
+    assert np.array_equal(mn, x.min(axis=0)) and np.array_equal(mx, x.max(axis=0))
+    assert np.allclose(mean, x.astype(np.float64).mean(axis=0), rtol=1e-6) and np.allclose(sd, x.astype(np.float64).std(axis=0, ddof=1), rtol=1e-6)
+    mn, mx, mean, sd = O.vector_stats(x[:1])
+    assert np.array_equal(mean, x[0]) and np.all(sd == 0.0) and np.array_equal(mn, x[0]) and np.array_equal(mx, x[0])
+    mn, mx, mean, sd = O.vector_stats(np.zeros((0, 4), dtype=np.float32))
+    assert np.all(mean == 0.0) and np.all(sd == 0.0) and np.all(mn == np.finfo(np.float32).max) and np.all(mx == np.finfo(np.float32).min)
