@@ -205,3 +205,27 @@ def test_tq_plus_fit_on_device_equals_the_oracle(qa, distance, bits):
     # no sample: identity parameters (quantile.rs:151-153)
     empty = qa.TurboQuantizer.fit_plus(np.zeros((0, 32), dtype=np.float32), 32, _dist(qa, distance), bits)
     assert np.all(empty.shift == 0.0) and np.all(empty.scale == 1.0)
+
+
+@pytest.mark.parametrize("bits", [O.TQ_BITS4, O.TQ_BITS1])
+def test_tq_large_top_many_queries_and_id_lists(qa, bits):
+    """top beyond one wave list (multi-pass selection), 40 queries (two matrix-core tiles, the second one ragged), an id list with a deleted
+    flag set: scores and order == the oracle's."""
+    n, dim, nq, top = 6000, 200, 40, 300
+    rng, vecs, otq, rows, st = _world(qa, O.DOT, dim, bits, n, seed=4242 + bits)
+    queries = rng.uniform(-1.0, 1.0, (nq, dim)).astype(np.float32)
+    deleted = rng.random(n) < 0.1
+    st.set_deleted(deleted)
+    full = otq.score_points(O.preprocess(O.DOT, queries), np.arange(n))
+    res = qa.BatchFilteredSearcher(queries, st, top).peek_top_all()
+    for qi, r in enumerate(res):
+        sc = full[qi].copy()
+        sc[deleted] = -np.inf
+        assert len(r) == top and np.array_equal(_bits(r["score"]), _bits(np.sort(sc)[::-1][:top]))
+        assert not deleted[r["idx"]].any() and np.array_equal(_bits(full[qi][r["idx"]]), _bits(r["score"]))
+    ids = rng.permutation(n).astype(np.uint32)[:1500]
+    res = qa.BatchFilteredSearcher(queries, st, 25).peek_top_iter(ids)
+    for qi, r in enumerate(res):
+        sc = full[qi][ids].copy()
+        sc[deleted[ids]] = -np.inf
+        assert np.array_equal(_bits(r["score"]), _bits(np.sort(sc)[::-1][:25]))
