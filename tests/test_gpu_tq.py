@@ -147,6 +147,21 @@ def test_tq_argument_errors(qa):
     big = qa.TurboQuantizer(100000, qa.Distance.Dot, O.TQ_BITS4)
     with pytest.raises(qa.QmxError):                                                          # the rotation runs in LDS: padded dim <= 8192
         qa.EncodedVectorsTQ(np.zeros((2, big.quantized_vector_size()), dtype=np.uint8), big)
+    # the fit and the statistics refuse what they cannot do, loudly
+    import ctypes as C
+    F = qa._ffi
+    buf = np.zeros(64, dtype=np.float32)
+    p = qa.TurboQuantizer(64, qa.Distance.Dot, O.TQ_BITS4).params()
+    assert F.lib().qmx_tq_fit_plus(0, int(qa.Distance.Manhattan), 64, C.byref(p), F.ptr(buf), 1, F.ptr(buf), F.ptr(buf)) == F.ERR_NOT_SUPPORTED
+    assert F.lib().qmx_tq_fit_plus(0, int(qa.Distance.Dot), 64, None, F.ptr(buf), 1, F.ptr(buf), F.ptr(buf)) == F.ERR_BAD_ARG
+    assert F.lib().qmx_tq_fit_plus(0, int(qa.Distance.Dot), 64, C.byref(p), None, 1, F.ptr(buf), F.ptr(buf)) == F.ERR_BAD_ARG
+    assert F.lib().qmx_tq_fit_plus(99, int(qa.Distance.Dot), 64, C.byref(p), F.ptr(buf), 1, F.ptr(buf), F.ptr(buf)) != F.OK
+    assert F.lib().qmx_vector_stats(0, None, 3, 64, None, None, F.ptr(buf), F.ptr(buf)) == F.ERR_BAD_ARG
+    assert F.lib().qmx_vector_stats(0, F.ptr(buf), 1, 64, None, None, None, F.ptr(buf)) == F.ERR_BAD_ARG
+    with pytest.raises(qa.QmxError) as e:                                                     # a TQ build needs the original vectors
+        rows = qa.TurboQuantizer(64, qa.Distance.Dot, O.TQ_BITS4).encode(np.ones((8, 64), dtype=np.float32))
+        qa.GraphLayers.build(qa.EncodedVectorsTQ(rows, qa.TurboQuantizer(64, qa.Distance.Dot, O.TQ_BITS4)), m=4, ef_construct=8)
+    assert e.value.status == F.ERR_NOT_SUPPORTED
 
 
 @pytest.mark.parametrize("bits", BITS)
