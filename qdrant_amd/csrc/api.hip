@@ -1423,6 +1423,8 @@ static void fill_args(const qmx_query *q, uint32_t tile0, uint32_t nq_tile, Scan
     a.tq_invert = s->tq_invert ? 1 : 0;
     a.tq_planes = (s->tq_value_bits == 1 && s->d_tq_shift) ? 16 : 8;
     a.tq_qbytes_off = q->tq_qbytes_off;
+    // |low + 128 high| <= 8127 * 128 * dims (4 / 2 bits); |2 v.q - sum q| <= 3 * 32767 * dims (1 bit, 16-bit TQ+ queries)
+    a.tq_i32 = s->dtype == QMX_DTYPE_TQ && (s->tq_value_bits == 1 ? s->tq_padded_dim <= 16384 : s->tq_padded_dim <= 2000) ? 1 : 0;
 }
 
 static int32_t launch_scan(const qmx_query *q, int qt, ScanMode mode, const ScanArgs &a, uint32_t *grid) {

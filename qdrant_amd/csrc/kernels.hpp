@@ -64,6 +64,7 @@ struct ScanArgs {
     uint32_t tq_bits, tq_invert;
     uint32_t tq_planes;        // 1-bit storage: bit planes of the query (8; 16 under TQ+)
     uint32_t tq_qbytes_off;    // 1-bit storage: byte offset, inside a query entry, of the i8 form of the query (the matrix-core scan's operand)
+    uint32_t tq_i32;           // the integer dot of a (row, query) pair fits 32 bits (scan_sq_mfma.hip finish): 4 / 2 bits below 2000 coordinates, 1 bit below 16384
     uint32_t tq_code_bytes;    // HNSW build (HopTQInternal): code bytes of a row, before the zero padding of the device block
     TqEc tq_ec;                // ... and score_symmetric_ec's inputs (weights == nullptr without TQ+)
     // multi-vectors (MaxSim walk, hnsw.hpp HopMaxSim): point p = inner rows [mv_offsets[p], mv_offsets[p + 1]); multi-query j = query entries

@@ -55,10 +55,14 @@ struct SqOps {     // EncodedVectorsU8: exact integer dot, then postprocess_scor
     }
     static __device__ __forceinline__ float row_aux(const ScanArgs &a, uint32_t rid) { return a.row_offsets[rid]; }
     // multiplier * dot + query_offset + vector_offset, left to right, not fused (encoded_vectors_u8.rs:100-103)
-    static __device__ __forceinline__ float finish(const ScanArgs &a, const acc_t (&acc)[NA], int r, const unsigned char *q_entry, const unsigned char *, uint32_t,
+    struct qc_t { float q_off; };     // what finish() needs of the lane's query, read from the LDS tile once per launch
+    static __device__ __forceinline__ qc_t load_qc(const ScanArgs &a, const unsigned char *q_entry) {
+        return qc_t{reinterpret_cast<const QueryAux *>(q_entry + a.aux_off)->f0};
+    }
+    static __device__ __forceinline__ float finish(const ScanArgs &a, const acc_t (&acc)[NA], int r, const qc_t &qc, const unsigned char *, uint32_t,
                                                    float v_off, uint32_t) {
         const float m1 = a.sq_multiplier * (float)acc[0][r];
-        const float mq = m1 + reinterpret_cast<const QueryAux *>(q_entry + a.aux_off)->f0;
+        const float mq = m1 + qc.q_off;
         return mq + v_off;
     }
 };
@@ -104,16 +108,22 @@ struct TqOps {
         }
     }
     static __device__ __forceinline__ float row_aux(const ScanArgs &a, uint32_t rid) { return a.tq_sf[rid]; }
-    static __device__ __forceinline__ float finish(const ScanArgs &a, const acc_t (&acc)[NA], int r, const unsigned char *q_entry, const unsigned char *, uint32_t rid,
-                                                   float sf, uint32_t) {
-        const int64_t sum = (int64_t)acc[0][r] + 128 * (int64_t)acc[1][r];
+    struct qc_t { float f0, ec, qlsq; };
+    static __device__ __forceinline__ qc_t load_qc(const ScanArgs &a, const unsigned char *q_entry) {
         const QueryAux *aux = reinterpret_cast<const QueryAux *>(q_entry + a.aux_off);
-        const float dot = aux->f0 * (float)sum + __uint_as_float(aux->pad[3]);
+        const float ql = __uint_as_float(aux->pad[0]);
+        return qc_t{aux->f0, __uint_as_float(aux->pad[3]), ql * ql};
+    }
+    static __device__ __forceinline__ float finish(const ScanArgs &a, const acc_t (&acc)[NA], int r, const qc_t &qc, const unsigned char *, uint32_t rid,
+                                                   float sf, uint32_t) {
+        // low + 128 high: |.| < 2^31 below ~2000 coordinates (api.hip sets tq_i32): one v_cvt instead of the i64 -> f32 sequence, the same value
+        const float sumf = a.tq_i32 ? (float)(acc[0][r] + 128 * acc[1][r]) : (float)((int64_t)acc[0][r] + 128 * (int64_t)acc[1][r]);
+        const float dot = qc.f0 * sumf + qc.ec;
         float score;
         if (L2) {
-            const float ql = __uint_as_float(aux->pad[0]), l2 = a.tq_l2[rid];
-            const float x = ql * ql, y = l2 * l2, z = (2.0f * dot) * sf;
-            score = (x + y) - z;
+            const float l2 = a.tq_l2[rid];
+            const float y = l2 * l2, z = (2.0f * dot) * sf;
+            score = (qc.qlsq + y) - z;
         } else {
             score = dot * sf;
         }
@@ -150,18 +160,30 @@ struct Tq1Ops {
         }
     }
     static __device__ __forceinline__ float row_aux(const ScanArgs &a, uint32_t rid) { return a.tq_sf[rid]; }
-    static __device__ __forceinline__ float finish(const ScanArgs &a, const acc_t (&acc)[NA], int r, const unsigned char *q_entry, const unsigned char *, uint32_t rid,
-                                                   float sf, uint32_t ones) {
-        int64_t v_dot_q = (int64_t)acc[0][r];
-        if (NA == 2) v_dot_q += 256 * (int64_t)acc[NA - 1][r] + 128 * (int64_t)ones;   // q = 256 (q >> 8) + ((q & 255) - 128) + 128
+    struct qc_t { float f0, ec, qlsq; int64_t sum_q; };
+    static __device__ __forceinline__ qc_t load_qc(const ScanArgs &a, const unsigned char *q_entry) {
         const QueryAux *aux = reinterpret_cast<const QueryAux *>(q_entry + a.aux_off);
-        const int64_t sum_q = (int64_t)(((uint64_t)aux->pad[2] << 32) | aux->pad[1]);
-        const float dot = aux->f0 * (float)(2 * v_dot_q - sum_q) + __uint_as_float(aux->pad[3]);
+        const float ql = __uint_as_float(aux->pad[0]);
+        return qc_t{aux->f0, __uint_as_float(aux->pad[3]), ql * ql, (int64_t)(((uint64_t)aux->pad[2] << 32) | aux->pad[1])};
+    }
+    static __device__ __forceinline__ float finish(const ScanArgs &a, const acc_t (&acc)[NA], int r, const qc_t &qc, const unsigned char *, uint32_t rid,
+                                                   float sf, uint32_t ones) {
+        float signed_dot;
+        if (a.tq_i32) {      // |2 v.q - sum q| < 2^31 (api.hip): 32-bit arithmetic, one v_cvt; the same value as the i64 form
+            int32_t v_dot_q = acc[0][r];
+            if (NA == 2) v_dot_q += 256 * acc[NA - 1][r] + 128 * (int32_t)ones;          // q = 256 (q >> 8) + ((q & 255) - 128) + 128
+            signed_dot = (float)(2 * v_dot_q - (int32_t)qc.sum_q);
+        } else {
+            int64_t v_dot_q = (int64_t)acc[0][r];
+            if (NA == 2) v_dot_q += 256 * (int64_t)acc[NA - 1][r] + 128 * (int64_t)ones;
+            signed_dot = (float)(2 * v_dot_q - qc.sum_q);
+        }
+        const float dot = qc.f0 * signed_dot + qc.ec;
         float score;
         if (L2) {
-            const float ql = __uint_as_float(aux->pad[0]), l2 = a.tq_l2[rid];
-            const float x = ql * ql, y = l2 * l2, z = (2.0f * dot) * sf;
-            score = (x + y) - z;
+            const float l2 = a.tq_l2[rid];
+            const float y = l2 * l2, z = (2.0f * dot) * sf;
+            score = (qc.qlsq + y) - z;
         } else {
             score = dot * sf;
         }
@@ -186,12 +208,15 @@ struct BqOps {
     static __device__ __forceinline__ void decode(const uint4 &x, dec_t &d) { Tq1Ops<1, false>::decode(x, d); }
     static __device__ __forceinline__ void mac(const dec_t &d, const unsigned char *qp, acc_t (&acc)[NA]) { Tq1Ops<1, false>::mac(d, qp, acc); }
     static __device__ __forceinline__ float row_aux(const ScanArgs &, uint32_t) { return 0.0f; }
-    static __device__ __forceinline__ float finish(const ScanArgs &a, const acc_t (&acc)[NA], int r, const unsigned char *q_entry, const unsigned char *, uint32_t,
+    struct qc_t { int32_t sum_t; };
+    static __device__ __forceinline__ qc_t load_qc(const ScanArgs &a, const unsigned char *q_entry) {
+        return qc_t{(int32_t)reinterpret_cast<const QueryAux *>(q_entry + a.aux_off)->pad[1]};
+    }
+    static __device__ __forceinline__ float finish(const ScanArgs &a, const acc_t (&acc)[NA], int r, const qc_t &qc, const unsigned char *, uint32_t,
                                                    float, uint32_t ones) {
-        const QueryAux *aux = reinterpret_cast<const QueryAux *>(q_entry + a.aux_off);
         constexpr int32_t M = (1 << B) - 1;
         const int32_t v_dot_t = acc[0][r] + (B == 8 ? 128 * (int32_t)ones : 0);
-        const uint32_t weighted = (uint32_t)((int32_t)aux->pad[1] + M * (int32_t)ones - 2 * v_dot_t);
+        const uint32_t weighted = (uint32_t)(qc.sum_t + M * (int32_t)ones - 2 * v_dot_t);
         const float xor_product = (float)weighted / (float)M;   // calculate_metric (encoded_vectors_binary.rs:766-810)
         const float zeros_count = (float)a.bq_dim - xor_product;
         return a.bq_flip ? xor_product - zeros_count : zeros_count - xor_product;
@@ -211,10 +236,12 @@ struct F16Ops {    // Metric<f16> dot / cosine: f16 products are exact in f32, f
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8 *>(&d), *reinterpret_cast<const f16x8 *>(&y), acc[0], 0, 0, 0);
     }
     static __device__ __forceinline__ float row_aux(const ScanArgs &, uint32_t) { return 0.0f; }
-    static __device__ __forceinline__ float finish(const ScanArgs &a, const acc_t (&accs)[NA], int r, const unsigned char *q_entry, const unsigned char *row, uint32_t,
+    struct qc_t { const unsigned char *q_entry; };
+    static __device__ __forceinline__ qc_t load_qc(const ScanArgs &, const unsigned char *q_entry) { return qc_t{q_entry}; }
+    static __device__ __forceinline__ float finish(const ScanArgs &a, const acc_t (&accs)[NA], int r, const qc_t &qc, const unsigned char *row, uint32_t,
                                                    float, uint32_t) {
         float result = accs[0][r];
-        const _Float16 *qh = reinterpret_cast<const _Float16 *>(q_entry);
+        const _Float16 *qh = reinterpret_cast<const _Float16 *>(qc.q_entry);
         const _Float16 *vh = reinterpret_cast<const _Float16 *>(row);
         for (uint32_t i = a.tail_start; i < a.dim; ++i) result += (float)qh[i] * (float)vh[i];
         return result;
@@ -247,6 +274,10 @@ __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs 
     const unsigned char *qbase = smem + (uint32_t)n * a.q_stride + ops_query_off<Ops>::get(a) + ops_kg_off<Ops>::get(kg);   // + g * 16 * q_stride + s * QSTEP
     const uint32_t gstride = 16u * a.q_stride;
     const int top = (int)a.top;
+
+    typename Ops::qc_t qc[NG];     // the lane's query (16 g + n of the tile) as finish() needs it
+#pragma unroll
+    for (int g = 0; g < NG; ++g) qc[g] = Ops::load_qc(a, smem + (uint32_t)(16 * g + n) * a.q_stride);
 
     uint64_t list[QW];
     uint64_t thr[NG];              // reject bound of query 16 g + n: the k-th best key of the wave's list, never below ...
@@ -343,7 +374,7 @@ __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs 
             const uint32_t q = (uint32_t)(16 * g + n);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float score = Ops::finish(a, acc[g], r, smem + q * a.q_stride, rows + (uint64_t)rid[r] * a.row_stride, rid[r], v_off[r], row_ones[r]);
+                const float score = Ops::finish(a, acc[g], r, qc[g], rows + (uint64_t)rid[r] * a.row_stride, rid[r], v_off[r], row_ones[r]);
                 const bool mine = valid[r] && q < a.nq;
                 if (MODE == SCAN_SCORES) {
                     if (mine) a.scores[(uint64_t)q * a.scores_stride + (tile * 16 + (uint32_t)(4 * kg + r))] = score;
