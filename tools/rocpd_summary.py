@@ -23,8 +23,9 @@ def main():
         rows = list(c.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
         if rows:
             lines.append("| kernel | calls | total_ms | avg_ms | % |\n|---|---|---|---|---|")
-            for n, calls, tot, avg, pct in rows[:12]:
-                lines.append(f"| `{n[:110]}` | {calls} | {tot / 1e3:.1f} | {avg / 1e3:.2f} | {pct:.2f} |")
+            keep = rows[:12] + [r for r in rows[12:] if any(k in r[0] for k in ("scan", "rows_kernel", "hnsw", "pair_kernel"))][:40]   # the top 12 + every scan / walk kernel
+            for n, calls, tot, avg, pct in keep:
+                lines.append(f"| `{n[:110]}` | {calls} | {tot / 1e3:.1f} | {avg / 1e3:.3f} | {pct:.2f} |")
             lines.append("")
         try:
             pmc = list(c.execute(
