@@ -21,289 +21,17 @@
 //           [high half of the even dims][high half of the odd dims]  (q_signed = 128 high + low, both halves in [-64, 63])
 //   2 bits  byte k = dims 4k .. 4k + 3: pieces [low half of dims = j mod 4] j = 0..3, then the four high-half pieces
 //   1 bit   bit i of the piece = dim i: pieces = the 8 bit planes of q
-#include "hnsw_build.hpp"
+#include "tq_policies.hpp"
 
 namespace qmx {
 
-__device__ __forceinline__ int32_t sdot4(uint32_t a, uint32_t b, int32_t c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, false); }
-
-// codebook values as signed bytes: c_signed = CODEBOOK_U8 - 128 (query4bit/mod.rs:64-72, query2bit/mod.rs)
-//   4 bits: -128 -97 -76 -59 -44 -31 -18 -6 | 6 18 31 44 59 76 97 127
-//   2 bits: -128 -38 38 127
-constexpr uint32_t TQ4_T0 = 0xC5B49F80u, TQ4_T1 = 0xFAEEE1D4u, TQ4_T2 = 0x2C1F1206u, TQ4_T3 = 0x7F614C3Bu;
-constexpr uint32_t TQ2_T = 0x7F26DA80u;
-
-// sel: four 4-bit selectors, one per byte -> the four codebook bytes
-__device__ __forceinline__ uint32_t tq4_lookup(uint32_t sel) {
-    const uint32_t s = sel & 0x07070707u;
-    const uint32_t lo = __builtin_amdgcn_perm(TQ4_T1, TQ4_T0, s);      // selector byte 0..3 -> T0, 4..7 -> T1
-    const uint32_t hi = __builtin_amdgcn_perm(TQ4_T3, TQ4_T2, s);
-    const uint32_t m = ((sel >> 3) & 0x01010101u) * 0xFFu;             // 0xFF where the selector was >= 8
-    return (hi & m) | (lo & ~m);
-}
-
-template <bool L2>
-__device__ __forceinline__ float tq_postprocess(float dot, const unsigned char *q_lds, uint32_t rid, const ScanArgs &args) {
-    const QueryAux *aux = reinterpret_cast<const QueryAux *>(q_lds + args.aux_off);
-    const float sf = args.tq_sf[rid];
-    float score;
-    if (L2) {
-        const float ql = __uint_as_float(aux->pad[0]), l2 = args.tq_l2[rid];
-        const float a = ql * ql, b = l2 * l2, c = (2.0f * dot) * sf;
-        score = (a + b) - c;
-    } else {
-        score = dot * sf;
-    }
-    return args.tq_invert ? -score : score;
-}
-
-template <bool L2>
-struct RowTQ4 {
-    static constexpr bool TEMPORAL_ROWS = true;
-    static constexpr int NACC = 2;      // sum low * c, sum high * c
-    static constexpr int NRAUX = 0;
-    static constexpr int R16 = 2;
-    static constexpr int QPIECES = 4;
-    typedef uint32_t acc_t;
-    static __device__ __forceinline__ void row_aux(acc_t (&)[1], const uint4 &) {}
-    static __device__ __forceinline__ void mac(acc_t (&)[NACC], const uint4 &, const uint4 &) {}
-    struct dec_t { uint32_t ce[4], co[4]; };    // codebook bytes of the even / odd dims of the piece
-    static __device__ __forceinline__ void decode(const uint4 &v, dec_t &d) {
-        const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            d.ce[w] = tq4_lookup(vv[w] & 0x0F0F0F0Fu);
-            d.co[w] = tq4_lookup((vv[w] >> 4) & 0x0F0F0F0Fu);
-        }
-    }
-    static __device__ __forceinline__ void mac_decoded(acc_t (&a)[NACC], const uint4 (&q)[4], const dec_t &d) {
-        const uint32_t le[4] = {q[0].x, q[0].y, q[0].z, q[0].w}, lo[4] = {q[1].x, q[1].y, q[1].z, q[1].w};
-        const uint32_t he[4] = {q[2].x, q[2].y, q[2].z, q[2].w}, ho[4] = {q[3].x, q[3].y, q[3].z, q[3].w};
-        int32_t al = (int32_t)a[0], ah = (int32_t)a[1];
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            al = sdot4(le[w], d.ce[w], al);
-            al = sdot4(lo[w], d.co[w], al);
-            ah = sdot4(he[w], d.ce[w], ah);
-            ah = sdot4(ho[w], d.co[w], ah);
-        }
-        a[0] = (uint32_t)al;
-        a[1] = (uint32_t)ah;
-    }
-    static __device__ __forceinline__ void mac_pieces(acc_t (&a)[NACC], const uint4 (&q)[4], const uint4 &v) {
-        dec_t d;
-        decode(v, d);
-        mac_decoded(a, q, d);
-    }
-    static __device__ __forceinline__ float finish(acc_t (&a)[NACC], acc_t (&)[1], const unsigned char *q_lds, const unsigned char *, uint32_t rid,
-                                                   const ScanArgs &args) {
-        const int64_t low = (int64_t)(int32_t)reduce8_u32(a[0]), high = (int64_t)(int32_t)reduce8_u32(a[1]);
-        const int64_t s = low + 128 * high;                                   // = dot_raw - bias_correction
-        const QueryAux *aux = reinterpret_cast<const QueryAux *>(q_lds + args.aux_off);
-        const float raw = aux->f0 * (float)s;
-        return tq_postprocess<L2>(raw + __uint_as_float(aux->pad[3]), q_lds, rid, args);   // + query.ec_correction (0.0 without TQ+)
-    }
-};
-
-template <bool L2>
-struct RowTQ2 {
-    static constexpr bool TEMPORAL_ROWS = true;
-    static constexpr int NACC = 2;
-    static constexpr int NRAUX = 0;
-    static constexpr int R16 = 2;
-    static constexpr int QPIECES = 8;
-    typedef uint32_t acc_t;
-    static __device__ __forceinline__ void row_aux(acc_t (&)[1], const uint4 &) {}
-    static __device__ __forceinline__ void mac(acc_t (&)[NACC], const uint4 &, const uint4 &) {}
-    struct dec_t { uint32_t c[4][4]; };         // codebook bytes of the dims = j mod 4, per dword
-    static __device__ __forceinline__ void decode(const uint4 &v, dec_t &d) {
-        const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int w = 0; w < 4; ++w) d.c[j][w] = __builtin_amdgcn_perm(0u, TQ2_T, (vv[w] >> (2 * j)) & 0x03030303u);
-    }
-    static __device__ __forceinline__ void mac_decoded(acc_t (&a)[NACC], const uint4 (&q)[8], const dec_t &d) {
-        int32_t al = (int32_t)a[0], ah = (int32_t)a[1];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t ql[4] = {q[j].x, q[j].y, q[j].z, q[j].w}, qh[4] = {q[4 + j].x, q[4 + j].y, q[4 + j].z, q[4 + j].w};
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                al = sdot4(ql[w], d.c[j][w], al);
-                ah = sdot4(qh[w], d.c[j][w], ah);
-            }
-        }
-        a[0] = (uint32_t)al;
-        a[1] = (uint32_t)ah;
-    }
-    static __device__ __forceinline__ void mac_pieces(acc_t (&a)[NACC], const uint4 (&q)[8], const uint4 &v) {
-        dec_t d;
-        decode(v, d);
-        mac_decoded(a, q, d);
-    }
-    static __device__ __forceinline__ float finish(acc_t (&a)[NACC], acc_t (&)[1], const unsigned char *q_lds, const unsigned char *, uint32_t rid,
-                                                   const ScanArgs &args) {
-        const int64_t low = (int64_t)(int32_t)reduce8_u32(a[0]), high = (int64_t)(int32_t)reduce8_u32(a[1]);
-        const int64_t s = low + 128 * high;
-        const QueryAux *aux = reinterpret_cast<const QueryAux *>(q_lds + args.aux_off);
-        const float raw = aux->f0 * (float)s;
-        return tq_postprocess<L2>(raw + __uint_as_float(aux->pad[3]), q_lds, rid, args);   // + query.ec_correction (0.0 without TQ+)
-    }
-};
-
-template <bool L2, int PLANES = 8>       // PLANES = BITS of Query1bitSimd<BITS>: 8, or 16 under TQ+ (Bits1Wide)
-struct RowTQ1 {
-    static constexpr bool TEMPORAL_ROWS = true;
-    static constexpr int NACC = 1;
-    static constexpr int NRAUX = 0;
-    static constexpr int R16 = PLANES == 8 ? 2 : 1;
-    static constexpr int QPIECES = PLANES;
-    typedef uint32_t acc_t;
-    static __device__ __forceinline__ void row_aux(acc_t (&)[1], const uint4 &) {}
-    static __device__ __forceinline__ void mac(acc_t (&)[NACC], const uint4 &, const uint4 &) {}
-    static __device__ __forceinline__ void mac_pieces(acc_t (&a)[NACC], const uint4 (&q)[PLANES], const uint4 &v) {
-        int32_t s = (int32_t)a[0];
-#pragma unroll
-        for (int k = 0; k < PLANES; ++k) {
-            const int32_t c = __popc(q[k].x & v.x) + __popc(q[k].y & v.y) + __popc(q[k].z & v.z) + __popc(q[k].w & v.w);
-            s += k == PLANES - 1 ? -(c << k) : (c << k);                    // w_b = 2^b, the sign plane -2^(BITS - 1)
-        }
-        a[0] = (uint32_t)s;
-    }
-    static __device__ __forceinline__ float finish(acc_t (&a)[NACC], acc_t (&)[1], const unsigned char *q_lds, const unsigned char *, uint32_t rid,
-                                                   const ScanArgs &args) {
-        const int64_t v_dot_q = (int64_t)(int32_t)reduce8_u32(a[0]);
-        const QueryAux *aux = reinterpret_cast<const QueryAux *>(q_lds + args.aux_off);
-        const int64_t sum_q = (int64_t)(((uint64_t)aux->pad[2] << 32) | aux->pad[1]);
-        const int64_t signed_dot = 2 * v_dot_q - sum_q;
-        const float raw = aux->f0 * (float)signed_dot;
-        return tq_postprocess<L2>(raw + __uint_as_float(aux->pad[3]), q_lds, rid, args);   // + query.ec_correction (0.0 without TQ+)
-    }
-};
-
-template <class L>
-static int32_t dispatch_tq(const L &l, const ScanArgs &a) {
-    const bool l2 = a.tq_l2 != nullptr;
-    switch (a.tq_bits) {
-        case 4: return l2 ? l.template row<RowTQ4<true>>(a) : l.template row<RowTQ4<false>>(a);
-        case 2: return l2 ? l.template row<RowTQ2<true>>(a) : l.template row<RowTQ2<false>>(a);
-        case 1:
-            if (a.tq_planes == 16) return l2 ? l.template row<RowTQ1<true, 16>>(a) : l.template row<RowTQ1<false, 16>>(a);
-            return l2 ? l.template row<RowTQ1<true>>(a) : l.template row<RowTQ1<false>>(a);
-    }
-    set_error("TurboQuant: %u bits per value not supported", a.tq_bits);
-    return QMX_ERR_NOT_SUPPORTED;
-}
 int32_t launch_scan_tq(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
     return dispatch_tq(ScanLauncher{st, qt, mode, num_cus, grid_out}, a);
 }
 int32_t launch_pairs_tq(hipStream_t st, const ScanArgs &a, const PairSel &sel, uint64_t n_items, int num_cus) {
     return dispatch_tq(PairLauncher{st, sel, n_items, num_cus}, a);
 }
-int32_t launch_hnsw_tq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
-    return dispatch_tq(HnswLauncher{st, &h, grid, per_cu}, a);
-}
 
-// ------------------------------------------------------------------------------------------
-// HNSW build over a TurboQuant segment (hnsw/build.rs:334-341 + point_scorer.rs:183-218).  EncodedVectorsTQ cannot turn a stored row into a
-// query (encode_internal_vector -> None), so - as for PQ - the searches of an insertion score through precompute_query of the point's ORIGINAL
-// vector (the RowTQ* policies over the batch's entries, made by api.hip before phase 1 and staged in LDS per insertion) while everything
-// stored <-> stored - the heuristic, the back links, an entry point at or below the new point's level - is score_symmetric
-// (turboquant/quantization.rs:395-494): the integer dot of the two rows' codebook bytes (1 bit: dim - 2 popcount(a ^ b)), as tq_internal_kernel
-// below.  One lane per stored row; `qp` is the other row's code bytes inside the block, so its index - the extras columns - follows from the pointer.
-// ------------------------------------------------------------------------------------------
-__device__ __constant__ int8_t TQ4_SIGNED_B[16] = {-128, -97, -76, -59, -44, -31, -18, -6, 6, 18, 31, 44, 59, 76, 97, 127};
-__device__ __constant__ int8_t TQ2_SIGNED_B[4] = {-128, -38, 38, 127};
-template <int BITS, bool L2>
-struct HopTQInternal {
-    static constexpr int LPI = 1;
-    static constexpr bool MULTI = false;
-    static constexpr bool INTERNAL_QOFF = false;
-    static constexpr bool INTERNAL_NORM = false;
-    static constexpr bool ASYMMETRIC = true;
-    static __device__ __forceinline__ float score(const ScanArgs &a, const unsigned char *qp, uint32_t id, int) {
-        const unsigned char *rows = reinterpret_cast<const unsigned char *>(a.rows);
-        const uint32_t ia = (uint32_t)((uint64_t)(qp - rows) / a.row_stride), ib = id;
-        const unsigned char *ra = qp, *rb = rows + (uint64_t)ib * a.row_stride;
-        const uint32_t nb = a.tq_code_bytes, nd = nb / 4;
-        const uint32_t *wa = reinterpret_cast<const uint32_t *>(ra), *wb = reinterpret_cast<const uint32_t *>(rb);
-        float raw_dot;
-        if (BITS == 1) {
-            uint32_t pop = 0;
-            for (uint32_t w = 0; w < (nb + 3) / 4; ++w) pop += (uint32_t)__popc(wa[w] ^ wb[w]);   // the block's padding bytes are zero in both rows
-            const int64_t sign_sum = (int64_t)nb * 8 - 2 * (int64_t)pop;
-            const float centroid_sq = 0.7978846f * 0.7978846f;
-            raw_dot = centroid_sq * (float)sign_sum;
-        } else if (a.tq_ec.weights) {   // score_symmetric_ec: the i16 weight of every coordinate
-            const int16_t *wt = a.tq_ec.weights;
-            int64_t acc = 0;
-            if (BITS == 4) {
-                for (uint32_t k = 0; k < nb; ++k)
-                    acc += (int64_t)TQ4_SIGNED_B[ra[k] & 15] * TQ4_SIGNED_B[rb[k] & 15] * wt[2 * k] + (int64_t)TQ4_SIGNED_B[ra[k] >> 4] * TQ4_SIGNED_B[rb[k] >> 4] * wt[2 * k + 1];
-            } else {
-                for (uint32_t k = 0; k < nb; ++k)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc += (int64_t)TQ2_SIGNED_B[(ra[k] >> (2 * j)) & 3] * TQ2_SIGNED_B[(rb[k] >> (2 * j)) & 3] * wt[4 * k + j];
-            }
-            const float codebook_scale = 128.0f / (BITS == 4 ? 2.733f : 1.510f);
-            const float weighted = (float)acc / (a.tq_ec.weight_scale * (codebook_scale * codebook_scale));
-            raw_dot = ((weighted + a.tq_ec.xm[ia]) + a.tq_ec.xm[ib]) - a.tq_ec.mm_const;
-        } else {
-            int32_t acc = 0;   // |c_a c_b| <= 2^14 per coordinate: exact in i32 below 2^17 coordinates
-            if (BITS == 4) {
-                for (uint32_t w = 0; w < nd; ++w) {
-                    const uint32_t x = wa[w], y = wb[w];
-                    acc = sdot4(tq4_lookup(x & 0x0F0F0F0Fu), tq4_lookup(y & 0x0F0F0F0Fu), acc);
-                    acc = sdot4(tq4_lookup((x >> 4) & 0x0F0F0F0Fu), tq4_lookup((y >> 4) & 0x0F0F0F0Fu), acc);
-                }
-                for (uint32_t k = nd * 4; k < nb; ++k)
-                    acc += (int32_t)TQ4_SIGNED_B[ra[k] & 15] * TQ4_SIGNED_B[rb[k] & 15] + (int32_t)TQ4_SIGNED_B[ra[k] >> 4] * TQ4_SIGNED_B[rb[k] >> 4];
-            } else {
-                for (uint32_t w = 0; w < nd; ++w) {
-                    const uint32_t x = wa[w], y = wb[w];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc = sdot4(__builtin_amdgcn_perm(0u, TQ2_T, (x >> (2 * j)) & 0x03030303u), __builtin_amdgcn_perm(0u, TQ2_T, (y >> (2 * j)) & 0x03030303u), acc);
-                }
-                for (uint32_t k = nd * 4; k < nb; ++k)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc += (int32_t)TQ2_SIGNED_B[(ra[k] >> (2 * j)) & 3] * TQ2_SIGNED_B[(rb[k] >> (2 * j)) & 3];
-            }
-            const float codebook_scale = 128.0f / (BITS == 4 ? 2.733f : 1.510f);
-            raw_dot = (float)acc / (codebook_scale * codebook_scale);
-        }
-        const float s1 = a.tq_sf[ia], s2 = a.tq_sf[ib];
-        float score;
-        if (L2) {
-            const float x = a.tq_l2[ia], y = a.tq_l2[ib];
-            score = (x * x + y * y) - ((2.0f * s1) * s2) * raw_dot;
-        } else {
-            score = (raw_dot * s1) * s2;
-        }
-        return a.tq_invert ? -score : score;
-    }
-};
-int32_t launch_hnsw_build_tq(hipStream_t st, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu) {
-    QMX_REQUIRE(h.batch_queries, QMX_ERR_BAD_ARG, "TurboQuant build needs the batch's query entries");
-    const bool l2 = a.tq_l2 != nullptr;
-#define QMX_TQB(B, L, ROW)                                                                                                      \
-    if (a.tq_bits == B && l2 == L) return launch_hnsw_build_hop<HopRow<ROW>, HopTQInternal<B, L>>(st, a, h, phase, grid, per_cu);
-    QMX_TQB(4, false, RowTQ4<false>)
-    QMX_TQB(4, true, RowTQ4<true>)
-    QMX_TQB(2, false, RowTQ2<false>)
-    QMX_TQB(2, true, RowTQ2<true>)
-#undef QMX_TQB
-    if (a.tq_bits == 1) {
-        if (a.tq_planes == 16)
-            return l2 ? launch_hnsw_build_hop<HopRow<RowTQ1<true, 16>>, HopTQInternal<1, true>>(st, a, h, phase, grid, per_cu)
-                      : launch_hnsw_build_hop<HopRow<RowTQ1<false, 16>>, HopTQInternal<1, false>>(st, a, h, phase, grid, per_cu);
-        return l2 ? launch_hnsw_build_hop<HopRow<RowTQ1<true>>, HopTQInternal<1, true>>(st, a, h, phase, grid, per_cu)
-                  : launch_hnsw_build_hop<HopRow<RowTQ1<false>>, HopTQInternal<1, false>>(st, a, h, phase, grid, per_cu);
-    }
-    set_error("TurboQuant build: %u bits per value not supported", a.tq_bits);
-    return QMX_ERR_NOT_SUPPORTED;
-}
 
 // ---- upload: reference rows [codes][extras] -> code block (16-byte multiple, zero padded) + extras columns ----
 __global__ __launch_bounds__(256) void tq_split_kernel(const uint8_t *rows, uint64_t src_stride, uint64_t n, uint32_t code_bytes, uint32_t dst_stride,
