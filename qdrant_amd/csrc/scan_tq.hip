@@ -25,11 +25,24 @@
 
 namespace qmx {
 
+// the scan / pair kernels of each bit width are a translation unit of their own (scan_tq4.hip, scan_tq2.hip, scan_tq1.hip: compile time)
 int32_t launch_scan_tq(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
-    return dispatch_tq(ScanLauncher{st, qt, mode, num_cus, grid_out}, a);
+    switch (a.tq_bits) {
+        case 4: return launch_scan_tq4(st, qt, mode, a, num_cus, grid_out);
+        case 2: return launch_scan_tq2(st, qt, mode, a, num_cus, grid_out);
+        case 1: return launch_scan_tq1(st, qt, mode, a, num_cus, grid_out);
+    }
+    set_error("TurboQuant: %u bits per value not supported", a.tq_bits);
+    return QMX_ERR_NOT_SUPPORTED;
 }
 int32_t launch_pairs_tq(hipStream_t st, const ScanArgs &a, const PairSel &sel, uint64_t n_items, int num_cus) {
-    return dispatch_tq(PairLauncher{st, sel, n_items, num_cus}, a);
+    switch (a.tq_bits) {
+        case 4: return launch_pairs_tq4(st, a, sel, n_items, num_cus);
+        case 2: return launch_pairs_tq2(st, a, sel, n_items, num_cus);
+        case 1: return launch_pairs_tq1(st, a, sel, n_items, num_cus);
+    }
+    set_error("TurboQuant: %u bits per value not supported", a.tq_bits);
+    return QMX_ERR_NOT_SUPPORTED;
 }
 
 

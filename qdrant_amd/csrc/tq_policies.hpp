@@ -176,4 +176,12 @@ static int32_t dispatch_tq(const L &l, const ScanArgs &a) {
     return QMX_ERR_NOT_SUPPORTED;
 }
 
+// per bit width: scan_tq{4,2,1}.hip
+int32_t launch_scan_tq4(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out);
+int32_t launch_scan_tq2(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out);
+int32_t launch_scan_tq1(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out);
+int32_t launch_pairs_tq4(hipStream_t st, const ScanArgs &a, const PairSel &sel, uint64_t n_items, int num_cus);
+int32_t launch_pairs_tq2(hipStream_t st, const ScanArgs &a, const PairSel &sel, uint64_t n_items, int num_cus);
+int32_t launch_pairs_tq1(hipStream_t st, const ScanArgs &a, const PairSel &sel, uint64_t n_items, int num_cus);
+
 }  // namespace qmx
