@@ -271,3 +271,16 @@ def test_vector_stats_welford():
     assert np.array_equal(mean, x[0]) and np.all(sd == 0.0) and np.array_equal(mn, x[0]) and np.array_equal(mx, x[0])
     mn, mx, mean, sd = O.vector_stats(np.zeros((0, 4), dtype=np.float32))
     assert np.all(mean == 0.0) and np.all(sd == 0.0) and np.all(mn == np.finfo(np.float32).max) and np.all(mx == np.finfo(np.float32).min)
+
+
+@pytest.mark.parametrize("quantile", [0.95])
+def test_quantile_interval_per_coordinate_property(quantile):
+    """quantile.rs:330-385 (test_quantile_interval_per_coord) mirrored: 2 048 sampled vectors of uniform [0, 1) coordinates, identity preprocess - each
+    coordinate's pair of P-square estimates lands within 0.05 of ((1 - q) / 2, 1 - (1 - q) / 2)."""
+    rng = np.random.default_rng(42)
+    data = rng.random((2048, 4)).astype(np.float32)
+    lo_want = (1.0 - quantile) / 2.0
+    for d in range(4):
+        col = data[:, d].astype(np.float64)
+        assert abs(O.p2_quantile(lo_want, col) - lo_want) < 0.05
+        assert abs(O.p2_quantile(1.0 - lo_want, col) - (1.0 - lo_want)) < 0.05
