@@ -6,7 +6,8 @@
            per coordinate as hnsw_quantized_search_test.rs:66-78: in d = 768 nearest neighbours are nearly equidistant,
            recall collapses for the CPU reference and the device alike); cosine-normalised
   graph  : `--build gpu` qmx_hnsw_build (device, batch-parallel) or `--build cpu` the oracle's parallel builder
-  scorer : f32 | sq (EncodedVectorsU8, dot over normalised rows) | pq (EncodedVectorsPQ chunk 16)
+  scorer : f32 | sq (EncodedVectorsU8, dot over normalised rows) | pq (EncodedVectorsPQ chunk 16) | tq (EncodedVectorsTQ, 4 bits)
+  build  : `--build-over f32|sq|tq`: through the original rows or through the quantized scorer (tq: qmx_hnsw_build_quantized with the original rows)
   search : qmx_hnsw_search of `--nq` queries in one launch (+ qmx_rescore with the f32 rows for sq / pq, oversampling 2)
   checks : first `--check` searches against the CPU oracle walking THE SAME graph (ids + score bits), recall@10 against
            exact brute force (device), CPU baseline = oracle search, one thread, on the same graph (rows <= --cpu-max-rows)
