@@ -93,6 +93,14 @@ typedef struct qmx_counters {
     uint64_t kernel_launches;
     float kernel_ms;         /* HIP-event time of the scoring kernels of the call (0 if not timed) */
     float reserved;
+    /* Brute force through the prefilter (QMX_SEG_HALF_COPY / QMX_SEG_SPLIT_COPY blocks, f32 batches of more than 64 queries): what it cost on THIS
+     * data.  All zero on the exact track.  bytes_read counts what was really streamed: the derived copy, the sample, the re-scored rows and the
+     * exact passes of the queries that fell back - not rows x row_bytes. */
+    uint64_t prefilter_candidates; /* (row, query) pairs the approximate scan let through (live rows)              */
+    uint64_t verified_rows;        /* of those, re-scored exactly from the f32 rows                                */
+    uint32_t fallback_queries;     /* queries whose candidate / verification lists overflowed (masses of near-equal
+                                      scores): these, and only these, took the exact scan of the block             */
+    uint32_t prefilter_queries;    /* queries of the batch served by the prefilter                                 */
 } qmx_counters;
 
 /* Flags for qmx_segment_desc.flags */
@@ -415,6 +423,10 @@ QMX_API int32_t qmx_search_topk(qmx_query *q, uint32_t top, const uint32_t *ids,
 QMX_API int32_t qmx_search_topk_async(qmx_query *q, uint32_t top, const uint32_t *ids,
                                       uint64_t n_ids, qmx_scored_point *out_dev,
                                       uint32_t *out_counts_dev);
+/* The counters of the last qmx_search_topk[_async] enqueued on this batch (synchronises its stream): what the asynchronous form cannot
+ * hand back at enqueue time - the `HardwareCounterCell` increments of the search (metric_query_scorer.rs:75-85), incl. the prefilter's
+ * candidates / re-scored rows / fallback queries. */
+QMX_API int32_t qmx_query_last_counters(qmx_query *q, qmx_counters *out);
 
 /* `postprocess_search_result` rescoring (lib/segment/src/index/vector_index_search_common.rs:73-90):
  * query qi re-scores ids[qi * n_per_query .. +counts[qi]) with the ORIGINAL-vector scorer `q`,
@@ -547,6 +559,35 @@ QMX_API int32_t qmx_merge_topk_async(int32_t device_id, void *hip_stream, const 
                                      const uint32_t *list_counts_dev, const uint32_t *list_idx_base_dev,
                                      uint32_t n_lists, uint32_t nq, uint32_t k, qmx_scored_point *out_dev,
                                      uint32_t *out_counts_dev);
+
+/* ---- one batch against N segments (N devices), one call ---------------------------------------- */
+
+/* `SegmentsSearcher::search` (lib/collection/src/collection_manager/segments_searcher.rs:250-285) runs one search task per segment and
+ * hands the per-segment lists to `BatchResultAggregator` (lib/shard/src/search_result_aggregator.rs:50-121).  This is that fan-out and
+ * merge for the ONE host process that owns all segments: queries[i] is the batch bound to segment i (qmx_query_create(segment_i, ...), the
+ * same nq everywhere, the same queries: qmx_sharded_query_update); the segments may live on different devices (one 10 M-row segment per
+ * MI355X, BASELINE configs[4]) or on one.  Every segment's brute-force top-k is enqueued on its own batch's stream - the devices work
+ * concurrently -, its Q x top x 8 B list is copied to the device of queries[0] (hipMemcpyPeerAsync over xGMI when it lives elsewhere: the
+ * one exchange step of the path), and the k-way merge (qmx_merge_topk's kernel, ids + id_bases[i]) runs there.
+ *   id_bases : [n_segments] added to segment-local offsets (NULL = zeros).  With the segments created over consecutive row ranges of ONE block
+ *              (desc.data = block + r_i * stride, desc.n = rows of the range) and id_bases[i] = r_i the result is the single-segment search of
+ *              that block, list for list: the row-split (strong-scaling) form of SURVEY 8e.
+ *   out / out_counts : [nq][top] / [nq], host or device (device: on the device of queries[0]).
+ * n_segments * top <= 16384.  Errors as qmx_search_topk. */
+QMX_API int32_t qmx_sharded_search_topk(qmx_query *const *queries, uint32_t n_segments, uint32_t top, const uint32_t *id_bases,
+                                        qmx_scored_point *out, uint32_t *out_counts, const volatile uint8_t *is_stopped,
+                                        qmx_counters *counters);
+/* Same, enqueue only: out_dev / out_counts_dev on the device of queries[0]; complete with qmx_query_synchronize(queries[0]) (its stream is
+ * ordered behind every segment's stream by the merge). */
+QMX_API int32_t qmx_sharded_search_topk_async(qmx_query *const *queries, uint32_t n_segments, uint32_t top, const uint32_t *id_bases,
+                                              qmx_scored_point *out_dev, uint32_t *out_counts_dev);
+/* The local stage as an HNSW walk of each segment's own graph (graphs[i] built over segment i; hnsw/read_view/search.rs) instead of the scan. */
+QMX_API int32_t qmx_sharded_hnsw_search(const qmx_hnsw *const *graphs, qmx_query *const *queries, uint32_t n_segments, uint32_t top,
+                                        uint32_t ef, const uint32_t *id_bases, qmx_scored_point *out, uint32_t *out_counts,
+                                        const volatile uint8_t *is_stopped, qmx_counters *counters);
+/* qmx_query_update of every segment's batch with the same queries (host or device memory; device memory must be readable from every
+ * segment's device). */
+QMX_API int32_t qmx_sharded_query_update(qmx_query *const *queries, uint32_t n_segments, const float *batch);
 
 /* ---- HNSW search on device -------------------------------------------------------------------- */
 

@@ -204,7 +204,8 @@ void qo_vector_stats(const float *rows, uint64_t n, uint32_t dim, float *min, fl
 /* ---- scorer = FilteredScorer{RawScorer, NotDeletedChecker} (hnsw_index/point_scorer.rs:53-63) ---- */
 typedef struct qo_scorer {
     int kind;                 /* 0 dense (Metric over st->rows), 1 SQ (EncodedVectorsU8), 2 PQ (EncodedVectorsPQ), 3 BQ (EncodedVectorsBin<u128>),
-                                 4 multi-vector MaxSim over an inner scorer of one of the kinds above (fields mv_*), 5 TurboQuant (fields tq_*) */
+                                 4 multi-vector MaxSim over an inner scorer of one of the kinds above (fields mv_*), 5 TurboQuant (fields tq_*),
+                                 6 custom query (Recommend / Discover / Context / Feedback) over example scorers of any other kind (fields cq_*) */
     const qo_storage *st;     /* dense rows for kind 0; the deleted flags and n for every kind */
     const void *query;        /* kind 0: preprocessed + cast query, [dim] elements */
     const qo_sq *sq; const uint8_t *sq_rows; const uint8_t *sq_query; float sq_query_offset;
@@ -220,6 +221,11 @@ typedef struct qo_scorer {
     /* kind 5: TurboQuant (EncodedVectorsTQ): rows of qo_tq_quantized_size bytes; the query = TurboQuantizer::precompute_query of the
      * preprocessed query; score_internal = score_symmetric; `invert` applied on top (encoded_vectors_tq.rs) */
     const struct qo_tq *tq; const uint8_t *tq_rows; const struct qo_tq_query *tq_query; int tq_invert;
+    /* kind 6: CustomQueryScorer (query_scorer/custom_query_scorer.rs:44-121), QuantizedCustomQueryScorer (quantized/quantized_custom_query_scorer.rs:13-113),
+     * TurboCustomQueryScorer (query_scorer/turbo_custom_query_scorer.rs:17-113), MultiCustomQueryScorer (query_scorer/multi_custom_query_scorer.rs:19-130; examples
+     * of kind 4): score_point = query.score_by(|example| example_scorer.score_point(id)); the examples in the query's flat_iter() order, each a complete
+     * scorer (the example transformed / encoded as that storage's query); cq_kind as qo_custom_combine (4 = feedback with cq_coefs).  `st` = the flags. */
+    const struct qo_scorer *cq_examples; uint32_t cq_kind, cq_n_a, cq_n_b; const float *cq_coefs;
 } qo_scorer;
 float qo_scorer_score_point(const qo_scorer *s, uint32_t id);              /* RawScorer::score_point */
 float qo_scorer_score_internal(const qo_scorer *s, uint32_t a, uint32_t b); /* RawScorer::score_internal */

@@ -50,6 +50,15 @@ int qo_scorer_check_vector(const qo_scorer *s, uint32_t id) { /* NotDeletedCheck
 
 float qo_scorer_score_point(const qo_scorer *s, uint32_t id) {
     float out = 0.f;
+    if (s->kind == 6) {   /* query.score_by(|example| similarity(example, point)): the example similarities in flat_iter() order, then the query's own formula */
+        const uint32_t ne = s->cq_kind <= 1 ? s->cq_n_a + s->cq_n_b : s->cq_n_a + 2 * s->cq_n_b;
+        float sims[256];
+        float *buf = ne <= 256 ? sims : (float *)malloc((size_t)ne * sizeof(float));
+        for (uint32_t e = 0; e < ne; e++) buf[e] = qo_scorer_score_point(&s->cq_examples[e], id);
+        const float r = s->cq_kind == 4 ? qo_custom_feedback(s->cq_n_b, buf, s->cq_coefs) : qo_custom_combine((int)s->cq_kind, s->cq_n_a, s->cq_n_b, buf);
+        if (buf != sims) free(buf);
+        return r;
+    }
     if (s->kind == 4) {   /* sum over the query's inner vectors (from 0.0) of the max over the point's inner vectors (`if max_sim < sim`, from -inf) */
         float sum = 0.0f;
         for (uint32_t t = 0; t < s->mv_n_tokens; t++) {

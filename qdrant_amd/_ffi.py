@@ -32,7 +32,8 @@ class ScoredPoint(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [("vectors_scored", C.c_uint64), ("bytes_read", C.c_uint64), ("kernel_launches", C.c_uint64),
-                ("kernel_ms", C.c_float), ("reserved", C.c_float)]
+                ("kernel_ms", C.c_float), ("reserved", C.c_float),
+                ("prefilter_candidates", C.c_uint64), ("verified_rows", C.c_uint64), ("fallback_queries", C.c_uint32), ("prefilter_queries", C.c_uint32)]
 
 
 class SqParams(C.Structure):
@@ -155,12 +156,17 @@ SIGNATURES = {
     "qmx_score_bytes": (C.c_int32, [_P, _P, C.c_uint32, C.c_uint64, _P]),
     "qmx_search_topk": (C.c_int32, [_P, C.c_uint32, _P, C.c_uint64, _P, _P, _P, C.POINTER(Counters)]),
     "qmx_search_topk_async": (C.c_int32, [_P, C.c_uint32, _P, C.c_uint64, _P, _P]),
+    "qmx_query_last_counters": (C.c_int32, [_P, C.POINTER(Counters)]),
     "qmx_rescore": (C.c_int32, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, _P]),
     "qmx_search_quantized": (C.c_int32, [_P, _P, _P, C.POINTER(SearchParams), _P, C.c_uint64, _P, _P, _P, C.POINTER(Counters)]),
     "qmx_custom_score_points": (C.c_int32, [_P, _P, C.c_uint32, _P, C.c_uint32, _P]),
     "qmx_custom_search_topk": (C.c_int32, [_P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint64, _P, _P]),
     "qmx_merge_topk": (C.c_int32, [C.c_int32, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P]),
     "qmx_merge_topk_async": (C.c_int32, [C.c_int32, _P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P]),
+    "qmx_sharded_search_topk": (C.c_int32, [_P, C.c_uint32, C.c_uint32, _P, _P, _P, _P, C.POINTER(Counters)]),
+    "qmx_sharded_search_topk_async": (C.c_int32, [_P, C.c_uint32, C.c_uint32, _P, _P, _P]),
+    "qmx_sharded_hnsw_search": (C.c_int32, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P, _P, C.POINTER(Counters)]),
+    "qmx_sharded_query_update": (C.c_int32, [_P, C.c_uint32, _P]),
     "qmx_hnsw_create": (C.c_int32, [C.POINTER(HnswDesc), C.POINTER(_P)]),
     "qmx_hnsw_create_from_plain_file": (C.c_int32, [_P, C.c_uint64, C.POINTER(HnswDesc), C.POINTER(_P)]),
     "qmx_hnsw_create_from_file": (C.c_int32, [_P, C.c_uint64, C.POINTER(HnswDesc), C.POINTER(_P)]),

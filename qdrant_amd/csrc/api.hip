@@ -234,6 +234,15 @@ struct qmx_query {
     DevBuf cand, cand_cnt, cand_ids;   // qmx_search_quantized: oversampled candidates of the quantized stage
     // split prefilter (scan_split.hip): split queries, per-query norms / thresholds / bands, scales, candidate and verification buffers, flag
     DevBuf sp_bq, sp_f32, sp_cand, sp_cnt, sp_ver, sp_vscores, sp_sample, sp_wl, xcnt, tq_rot;
+    DevBuf sh_lists, sh_out;   // qmx_sharded_*: the segments' lists gathered on this (the first) batch's device, the merged lists of a host-output call
+    std::vector<uint32_t> sh_bases_host;
+    hipEvent_t sh_done = nullptr;   // "this segment's list arrived on the merging device"
+    DevBuf sp_plan, sp_fq;     // ... the per-query overflow flags + the plan of the conditional exact passes (SplitPlanLayout), the overflowed queries packed
+    // counters of the last search enqueued on this batch: the host's share is known at enqueue, the prefilter's share sits in sp_plan until
+    // the stream is synchronised (qmx_query_last_counters / the synchronous entry points fold it in)
+    qmx_counters last_counters{};
+    bool last_split = false;
+    uint64_t last_row_bytes = 0, last_n_cand = 0;
     uint64_t sp_sample_n = 0, sp_sample_of = 0;
     DevBuf filter;             // payload-filter allow bitmap of this query batch (qmx_query_set_filter)
     uint64_t n_filter_bits = 0;
@@ -364,7 +373,7 @@ static uint32_t pow2_ceil(uint32_t x) {
 // ---------------------------------------------------------------------------------------------
 extern "C" {
 
-uint32_t qmx_abi_version(void) { return 3; }
+uint32_t qmx_abi_version(void) { return 4; }
 
 static int option_index(const char *name) {
     if (!name) return -1;
@@ -1283,7 +1292,8 @@ int32_t qmx_query_destroy(qmx_query *q) {
     q->mv_deleted.release();
     q->cq_scores.release();
     q->cq_desc.release();
-    q->sp_bq.release(); q->sp_f32.release(); q->sp_cand.release(); q->sp_cnt.release(); q->sp_ver.release(); q->sp_vscores.release(); q->sp_sample.release(); q->sp_wl.release(); q->xcnt.release(); q->tq_rot.release();
+    q->sp_bq.release(); q->sp_f32.release(); q->sp_cand.release(); q->sp_cnt.release(); q->sp_ver.release(); q->sp_vscores.release(); q->sp_sample.release(); q->sp_wl.release(); q->xcnt.release(); q->tq_rot.release(); q->sp_plan.release(); q->sp_fq.release(); q->sh_lists.release(); q->sh_out.release();
+    if (q->sh_done) (void)hipEventDestroy(q->sh_done);
     q->cand.release();
     q->cand_cnt.release();
     q->cand_ids.release();
@@ -1529,7 +1539,25 @@ static int32_t split_stage(qmx_query *q, const char *what) {
 constexpr uint32_t SPLIT_QT = 128;          // queries per pass of the split prefilter (scan_split.hip) ...
 constexpr uint32_t SPLIT_QT_MAX = 256;      // ... and of its 256-query shape over a half copy (batches of more than 128 queries)
 constexpr uint32_t SPLIT_CAND_CAP = 32768;  // candidate keys per query and pass (expected: ~1000 k)
-constexpr uint32_t SPLIT_VCAP = 512;        // rows per query that get an exact score (expected: ~k; the one-product mode's band holds more)
+constexpr uint32_t SPLIT_VCAP = 2048;       // rows per query that get an exact score (expected: ~k; the one-product mode's band holds ~60 on iid rows, more where
+                                            // scores crowd: 2048 rows x 3 KiB are 6 MB of gathers per query, still far below its share of a block pass)
+constexpr uint32_t SPLIT_FQT = 64;          // queries per conditional exact pass behind the prefilter (one 16-query pass instead when 1..16 overflowed)
+// device block behind qmx_query::sp_plan: what the prefilter of one search did and which of its queries take the exact scan after all
+struct SplitPlanLayout {
+    size_t count, run16, run64, tile_ovf, ovf_q, zero_bytes, list, gthr_packed, bytes;   // byte offsets (SplitStats sits at 0)
+    uint32_t n_run64, list_cap;
+    explicit SplitPlanLayout(uint32_t nq) {
+        n_run64 = (nq + SPLIT_FQT - 1) / SPLIT_FQT;
+        list_cap = n_run64 * SPLIT_FQT;
+        count = 32; run16 = 36; run64 = 40;
+        tile_ovf = run64 + (size_t)n_run64 * 4;
+        ovf_q = tile_ovf + ((size_t)nq / 128 + 1) * 4;
+        zero_bytes = ovf_q + (size_t)nq * 4;                       // everything up to here starts a search as zeros
+        list = (zero_bytes + 7) / 8 * 8;
+        gthr_packed = (list + (size_t)list_cap * 4 + 7) / 8 * 8;
+        bytes = gthr_packed + (size_t)list_cap * 8;
+    }
+};
 // |approximate - exact| <= band * |q| * max |row|, worst case, every term at its bound:
 //   one product of f16-rounded operands (HALF copy): each operand within 2^-11 of its value -> (2^-10 + 2^-22) sum |q_i r_i| <= ... |q| |r|
 //   three products of f16 pairs: x - (h + l) within 2^-22 |x|, the dropped l.l term 2^-22                    -> 3 * 2^-22
@@ -1578,7 +1606,10 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
     // ---- split passes first (their verification and, if ever needed, the exact fallback run once for all of them afterwards) ----
     std::vector<std::pair<uint32_t, uint32_t>> split_tiles;      // (tile0, nq_tile)
     float *sp_qnorm = nullptr, *sp_thr = nullptr, *sp_band = nullptr, *sp_scales = nullptr;
-    int *sp_overflow = nullptr;
+    const SplitPlanLayout pl(q->nq);
+    unsigned char *plan = nullptr;
+    q->last_counters = qmx_counters{};
+    q->last_split = false;
     if (split) {
         QMX_TRY(q->sp_bq.reserve(split_query_bytes(s->dim)));
         QMX_TRY(q->sp_f32.reserve(1024 * sizeof(float)));
@@ -1587,8 +1618,11 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
         if (s->d_rows_split) QMX_TRY(q->sp_wl.reserve(split_wlists_bytes(s->num_cus)));
         QMX_TRY(q->sp_ver.reserve((size_t)q->nq * (SPLIT_VCAP + 1) * 4));
         QMX_TRY(q->sp_vscores.reserve((size_t)q->nq * SPLIT_VCAP * 4));
+        QMX_TRY(q->sp_plan.reserve(pl.bytes));
+        QMX_TRY(q->sp_fq.reserve((size_t)pl.list_cap * q->q_stride));
+        plan = (unsigned char *)q->sp_plan.p;
         float *f = (float *)q->sp_f32.p;
-        sp_qnorm = f; sp_thr = f + 256; sp_band = f + 512; sp_scales = f + 768; sp_overflow = (int *)(f + 776);
+        sp_qnorm = f; sp_thr = f + 256; sp_band = f + 512; sp_scales = f + 768;
         // the sample: every (n_cand / S)-th row, S = n_cand / 256 (at least 8192): its k-th best leaves ~256 k candidates per query to the
         // main pass, at 1 / 256 of the pass's row traffic for the sample's exact scores (measured on C2: 1/128 .. 1/512 are equally good)
         // ("prescan_shift" - 2: the option of the exact scans' prefix pre-scan, 10 by default, moves this sample with it)
@@ -1602,7 +1636,7 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
             q->sp_sample_n = S;
             q->sp_sample_of = n_cand;
         }
-        QMX_HIP(hipMemsetAsync(sp_overflow, 0, sizeof(int), q->stream));
+        QMX_HIP(hipMemsetAsync(plan, 0, pl.zero_bytes, q->stream));
     }
     for (uint32_t tile0 = 0; tile0 < q->nq; tile0 += TQ) {
         const uint32_t nq_tile = std::min<uint32_t>(TQ, q->nq - tile0);
@@ -1658,7 +1692,7 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
                 if (timed) QMX_TRY(timing_end(q, slot));
                 if (s->d_rows_split)
                     QMX_TRY(launch_split_regroup(q->stream, a, q->sp_wl.p, s->num_cus, (uint64_t *)q->sp_cand.p, (uint32_t *)q->sp_cnt.p, SPLIT_CAND_CAP,
-                                                 sp_overflow, phase, tqt));
+                                                 (int *)(plan + pl.tile_ovf) + split_tiles.size(), phase, tqt));
                 if (phase == 1)
                     QMX_TRY(launch_split_refine(q->stream, (const uint64_t *)q->sp_cand.p, (const uint32_t *)q->sp_cnt.p, SPLIT_CAND_CAP, sp_band, nq_tile, top,
                                                 sp_scales, sp_thr));
@@ -1668,7 +1702,8 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
             uint32_t *ver_ids = (uint32_t *)q->sp_ver.p + (size_t)tile0 * SPLIT_VCAP;
             uint32_t *ver_cnt = (uint32_t *)q->sp_ver.p + (size_t)q->nq * SPLIT_VCAP + tile0;
             QMX_TRY(launch_split_select(q->stream, (const uint64_t *)q->sp_cand.p, (const uint32_t *)q->sp_cnt.p, SPLIT_CAND_CAP, sp_band, nq_tile, top, SPLIT_VCAP,
-                                        ver_ids, ver_cnt, sp_overflow));
+                                        ver_ids, ver_cnt, (const int *)(plan + pl.tile_ovf) + split_tiles.size(), (uint32_t *)(plan + pl.ovf_q) + tile0,
+                                        (SplitStats *)plan));
             QMX_TRY(split_stage(q, "select"));
             split_tiles.push_back({tile0, nq_tile});
             if (counters) counters->kernel_launches += 8;
@@ -1722,9 +1757,10 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
                     }
                     QMX_TRY(launch_custom_topk(q->stream, (const float *)q->scores.p, pre_n, d_ids, a.del, nq_tile, ptop, d_out + (size_t)tile0 * top,
                                                d_counts + tile0));
-                    QMX_TRY(launch_bound_from_topk(q->stream, d_out + (size_t)tile0 * top, d_counts + tile0, nq_tile, ptop, (uint64_t *)q->gthr.p));
+                    // (at the tile's own offset: the bounds of earlier split tiles are read again by the plan of their exact passes)
+                    QMX_TRY(launch_bound_from_topk(q->stream, d_out + (size_t)tile0 * top, d_counts + tile0, nq_tile, ptop, (uint64_t *)q->gthr.p + tile0));
                 }
-                a.gthr = (const uint64_t *)q->gthr.p;
+                a.gthr = (const uint64_t *)q->gthr.p + tile0;
                 if (counters) counters->kernel_launches += 2;
             }
             uint32_t grid = grid_cap;
@@ -1751,32 +1787,82 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
         QMX_TRY(split_stage(q, "verify gather"));
         QMX_TRY(launch_sort_scored(q->stream, (const float *)q->sp_vscores.p, ver_all, cnt_all, SPLIT_VCAP, last, top, d_out, d_counts));
         QMX_TRY(split_stage(q, "verify sort"));
-        // 6. the exact scan of those queries, which runs only if a buffer overflowed somewhere (the kernels start, read the flag, return)
-        for (auto &t : split_tiles) {
-            for (uint32_t sub0 = t.first; sub0 < t.first + t.second; sub0 += MAX_QT_TOPK) {
-                const uint32_t nq_sub = std::min<uint32_t>(MAX_QT_TOPK, t.first + t.second - sub0);
-                ScanArgs a;
-                fill_args(q, sub0, nq_sub, a);
-                a.n_cand = n_cand;
-                a.top = top;
-                a.partial = (uint64_t *)q->partial.p;
-                a.gthr = (const uint64_t *)q->gthr.p + sub0;
-                a.run_if = sp_overflow;
-                const int fqt = (int)std::max<uint32_t>(16, pow2_ceil(nq_sub));
-                a.partial_qt = (uint32_t)fqt;
-                uint32_t grid = grid_cap;
-                QMX_REQUIRE(mfma16_scan_ok(fqt, SCAN_TOPK, a), QMX_ERR_OTHER, "split fallback shape");
-                QMX_TRY(launch_scan_f32_mfma16(q->stream, fqt, a, s->num_cus, &grid));
-                QMX_TRY(launch_merge_keys(q->stream, (const uint64_t *)q->partial.p, grid, (uint32_t)fqt, nq_sub, top, d_out + (size_t)sub0 * top,
-                                          d_counts + sub0, top, 0, nullptr, sp_overflow));
-            }
+        // 6. the exact scan of the queries whose lists overflowed (masses of near-equal scores, a sample that is all deleted), and of those only:
+        // packed, one 16-query pass when 1..16 of them, passes of 64 otherwise.  The kernels start, read their flag and return when it is clear.
+        uint32_t *ovf_list = (uint32_t *)(plan + pl.list);
+        uint64_t *gthr_packed = (uint64_t *)(plan + pl.gthr_packed);
+        const uint32_t n_run64 = (last + SPLIT_FQT - 1) / SPLIT_FQT, n_slots = n_run64 * SPLIT_FQT;
+        QMX_TRY(launch_split_plan(q->stream, (const uint32_t *)(plan + pl.ovf_q), last, (const uint64_t *)q->gthr.p, ovf_list, gthr_packed, n_slots,
+                                  (uint32_t *)(plan + pl.count), (int *)(plan + pl.run16), (int *)(plan + pl.run64), n_run64, (SplitStats *)plan, q->d_queries,
+                                  q->q_stride, q->sp_fq.p));
+        for (uint32_t pass = 0; pass <= n_run64; ++pass) {      // pass 0: the 16-query shape; pass p >= 1: packed queries 64 (p - 1) ..
+            if (pass && last <= 16) break;
+            const uint32_t p0 = pass ? (pass - 1) * SPLIT_FQT : 0;
+            const uint32_t nq_sub = pass ? std::min<uint32_t>(SPLIT_FQT, last - p0) : std::min<uint32_t>(16, last);
+            const int *run_if = pass ? (const int *)(plan + pl.run64) + (pass - 1) : (const int *)(plan + pl.run16);
+            ScanArgs a;
+            fill_args(q, 0, nq_sub, a);
+            a.queries = (const char *)q->sp_fq.p + (size_t)p0 * q->q_stride;
+            a.n_cand = n_cand;
+            a.top = top;
+            a.partial = (uint64_t *)q->partial.p;
+            a.gthr = gthr_packed + p0;
+            a.run_if = run_if;
+            const int fqt = (int)std::max<uint32_t>(16, pow2_ceil(nq_sub));
+            a.partial_qt = (uint32_t)fqt;
+            uint32_t grid = grid_cap;
+            QMX_REQUIRE(mfma16_scan_ok(fqt, SCAN_TOPK, a), QMX_ERR_OTHER, "split fallback shape");
+            QMX_TRY(launch_scan_f32_mfma16(q->stream, fqt, a, s->num_cus, &grid));
+            QMX_TRY(launch_merge_keys(q->stream, (const uint64_t *)q->partial.p, grid, (uint32_t)fqt, nq_sub, top, d_out, d_counts, top, 0, nullptr, run_if,
+                                      ovf_list + p0));
         }
         QMX_TRY(split_stage(q, "fallback (conditional)"));
         q->last_kernel = split_kernel;      // (the fallback launches above are not what ran)
+        q->last_split = true;
     }
-    if (counters) {
-        counters->vectors_scored += (uint64_t)q->nq * n_cand * n_pass;
-        counters->bytes_read += (uint64_t)((q->nq + TQ - 1) / TQ) * n_cand * s->row_bytes * n_pass;
+    {
+        // what the host knows at enqueue; the prefilter's own share (candidates, verified rows, exact passes of overflowed queries) is on the device
+        // until the stream is synchronised: fold_split_counters
+        qmx_counters &c = q->last_counters;
+        uint32_t split_q = 0;
+        uint64_t bytes = 0;
+        for (auto &t : split_tiles) {
+            split_q += t.second;
+            // one pass over the derived copy (2 or 4 bytes per element; the f32 rows themselves when there is none) + the sample's exact scores
+            bytes += n_cand * (uint64_t)s->dim * (s->d_rows_split && s->split_half ? 2 : 4);
+            bytes += (uint64_t)((t.second + tile_qt(s, q) - 1) / tile_qt(s, q)) * q->sp_sample_n * s->row_bytes;
+        }
+        const uint32_t rest = q->nq - split_q;
+        bytes += (uint64_t)((rest + TQ - 1) / TQ) * n_cand * s->row_bytes * n_pass;
+        c.vectors_scored = (uint64_t)q->nq * n_cand * n_pass;
+        c.bytes_read = bytes;
+        c.kernel_launches = counters ? counters->kernel_launches : 0;
+        c.prefilter_queries = split_q;
+        q->last_row_bytes = s->row_bytes;
+        q->last_n_cand = n_cand;
+        if (counters) {
+            const uint64_t launches = counters->kernel_launches;
+            *counters = c;
+            counters->kernel_launches = launches;
+        }
+    }
+    return QMX_OK;
+}
+
+// after the stream is synchronised: the device's share of the last search's counters (prefilter candidates, exactly re-scored rows, the queries
+// that took the exact scan) -> c, bytes_read completed with the rows those steps read
+static int32_t fold_split_counters(qmx_query *q, qmx_counters *c) {
+    if (!q->last_split || !q->sp_plan.p) return QMX_OK;
+    SplitStats st;
+    QMX_HIP(hipMemcpy(&st, q->sp_plan.p, sizeof(st), hipMemcpyDeviceToHost));
+    c->prefilter_candidates = st.candidates;
+    c->verified_rows = st.verified;
+    c->fallback_queries = st.fallback_queries;
+    c->bytes_read += st.verified * q->last_row_bytes;
+    if (st.fallback_queries) {
+        const uint32_t f = st.fallback_queries;
+        const uint64_t passes = f <= 16 ? 1 : (f + SPLIT_FQT - 1) / SPLIT_FQT;
+        c->bytes_read += passes * q->last_n_cand * q->last_row_bytes;
     }
     return QMX_OK;
 }
@@ -1819,12 +1905,21 @@ int32_t qmx_search_topk(qmx_query *q, uint32_t top, const uint32_t *ids, uint64_
     if (!out_dev) QMX_TRY(copy_out(q->stream, out, d_out, (size_t)q->nq * top * sizeof(qmx_scored_point)));
     if (!cnt_dev) QMX_TRY(copy_out(q->stream, out_counts, d_counts, (size_t)q->nq * sizeof(uint32_t)));
     QMX_TRY(check_err_flag(q));  // synchronises the stream
+    if (counters) QMX_TRY(fold_split_counters(q, counters));
     if (timed) {
         const float before = q->timing_ms;
         QMX_TRY(timing_fold(q));
         if (counters) counters->kernel_ms = q->timing_ms - before;
     }
     return QMX_OK;
+}
+
+int32_t qmx_query_last_counters(qmx_query *q, qmx_counters *out) {
+    QMX_REQUIRE(q && out, QMX_ERR_BAD_ARG, "NULL argument");
+    QMX_HIP(hipSetDevice(q->device));
+    QMX_HIP(hipStreamSynchronize(q->stream));
+    *out = q->last_counters;
+    return fold_split_counters(q, out);
 }
 
 int32_t qmx_search_topk_async(qmx_query *q, uint32_t top, const uint32_t *ids, uint64_t n_ids,
@@ -2617,6 +2712,157 @@ int32_t qmx_hnsw_search_async(const qmx_hnsw *g, qmx_query *q, uint32_t top, uin
     }
     const bool timed = q->timing || (q->seg->flags & QMX_SEG_TIME_KERNELS) != 0;
     return hnsw_enqueue(g, q, top, ef, out_dev, out_counts_dev, out_scored_dev, timed);
+}
+
+// ---------------------------------------------------------------------------------------------
+// one query batch against N segments, possibly on N devices, from ONE host thread: the fan-out of SegmentsSearcher::search
+// (lib/collection/src/collection_manager/segments_searcher.rs:250-285) + the merge of the per-segment lists (BatchResultAggregator,
+// lib/shard/src/search_result_aggregator.rs:50-121) behind one call.  Every segment's local stage is enqueued on its own batch's stream
+// (the devices run concurrently), its Q x top x 8 B list travels to the first batch's device (a peer copy over xGMI when it lives
+// elsewhere: the one exchange step of SURVEY 8e), the k-way merge runs there behind the N "list arrived" events.
+// ---------------------------------------------------------------------------------------------
+static int32_t sharded_enqueue(qmx_query *const *queries, const qmx_hnsw *const *graphs, uint32_t n_segments, uint32_t top, uint32_t ef, const uint32_t *id_bases,
+                               qmx_scored_point *d_out, uint32_t *d_counts, const volatile uint8_t *is_stopped, qmx_counters *counters) {
+    qmx_query *root = queries[0];
+    const uint32_t nq = root->nq;
+    const size_t lbytes = (size_t)nq * top * sizeof(qmx_scored_point), cbytes = (size_t)nq * 4;
+    for (uint32_t i = 0; i < n_segments; ++i) {
+        QMX_REQUIRE(queries[i] && queries[i]->nq == nq, QMX_ERR_BAD_ARG, "segment %u: every batch must hold the same %u queries", i, nq);
+        for (uint32_t j = 0; j < i; ++j) QMX_REQUIRE(queries[j] != queries[i], QMX_ERR_BAD_ARG, "segments %u and %u share one query batch (one qmx_query per (batch, segment))", j, i);
+        if (graphs) {
+            QMX_REQUIRE(graphs[i], QMX_ERR_BAD_ARG, "segment %u: NULL graph", i);
+            QMX_TRY(hnsw_check(graphs[i], queries[i], top, ef));
+        }
+    }
+    if (counters) memset(counters, 0, sizeof(*counters));
+    QMX_HIP(hipSetDevice(root->device));
+    QMX_TRY(root->sh_lists.reserve(n_segments * (lbytes + cbytes) + (size_t)n_segments * 4));
+    unsigned char *gl = (unsigned char *)root->sh_lists.p;
+    qmx_scored_point *g_lists = (qmx_scored_point *)gl;
+    uint32_t *g_counts = (uint32_t *)(gl + n_segments * lbytes);
+    uint32_t *g_bases = g_counts + (size_t)n_segments * nq;
+    {   // id bases: segment-local offsets + base = the caller's id space (0 when NULL)
+        std::vector<uint32_t> &hb = root->sh_bases_host;
+        hb.assign(n_segments, 0u);
+        if (id_bases) for (uint32_t i = 0; i < n_segments; ++i) hb[i] = id_bases[i];
+        QMX_HIP(hipMemcpyAsync(g_bases, hb.data(), (size_t)n_segments * 4, hipMemcpyHostToDevice, root->stream));
+    }
+    for (uint32_t i = 0; i < n_segments; ++i) {
+        qmx_query *q = queries[i];
+        if (is_stopped && *is_stopped) {
+            set_error("search cancelled");
+            return QMX_ERR_CANCELLED;
+        }
+        QMX_HIP(hipSetDevice(q->device));
+        QMX_TRY(q->out.reserve(lbytes));
+        QMX_TRY(q->counts.reserve(cbytes));
+        const bool timed = q->timing || (q->seg->flags & QMX_SEG_TIME_KERNELS) != 0;
+        qmx_counters local{};
+        if (graphs) {
+            if (graphs[i]->n_points == 0) QMX_HIP(hipMemsetAsync(q->counts.p, 0, cbytes, q->stream));
+            else QMX_TRY(hnsw_enqueue(graphs[i], q, top, ef, (qmx_scored_point *)q->out.p, (uint32_t *)q->counts.p, nullptr, timed));
+            local.kernel_launches = 1;
+        } else {
+            QMX_TRY(search_enqueue(q, top, nullptr, 0, (qmx_scored_point *)q->out.p, (uint32_t *)q->counts.p, is_stopped, &local, timed));
+        }
+        if (counters) {
+            counters->vectors_scored += local.vectors_scored;
+            counters->bytes_read += local.bytes_read;
+            counters->kernel_launches += local.kernel_launches + 1;
+            counters->prefilter_queries += local.prefilter_queries;
+        }
+        // the list travels on the producing stream (ordered behind the scan without an event), then "arrived" is recorded for the merge
+        if (q->device != root->device) {
+            int can = 0;
+            (void)hipDeviceCanAccessPeer(&can, root->device, q->device);
+            if (can) {   // direct xGMI writes instead of a staged copy; "already enabled" is not an error
+                QMX_HIP(hipSetDevice(root->device));
+                hipError_t e = hipDeviceEnablePeerAccess(q->device, 0);
+                if (e != hipSuccess) (void)hipGetLastError();
+                QMX_HIP(hipSetDevice(q->device));
+            }
+            QMX_HIP(hipMemcpyPeerAsync((unsigned char *)g_lists + i * lbytes, root->device, q->out.p, q->device, lbytes, q->stream));
+            QMX_HIP(hipMemcpyPeerAsync(g_counts + (size_t)i * nq, root->device, q->counts.p, q->device, cbytes, q->stream));
+        } else {
+            QMX_HIP(hipMemcpyAsync((unsigned char *)g_lists + i * lbytes, q->out.p, lbytes, hipMemcpyDeviceToDevice, q->stream));
+            QMX_HIP(hipMemcpyAsync(g_counts + (size_t)i * nq, q->counts.p, cbytes, hipMemcpyDeviceToDevice, q->stream));
+        }
+        if (q != root) {
+            if (!q->sh_done) QMX_HIP(hipEventCreateWithFlags(&q->sh_done, hipEventDisableTiming));
+            QMX_HIP(hipEventRecord(q->sh_done, q->stream));
+        }
+    }
+    QMX_HIP(hipSetDevice(root->device));
+    for (uint32_t i = 1; i < n_segments; ++i) QMX_HIP(hipStreamWaitEvent(root->stream, queries[i]->sh_done, 0));
+    return launch_merge_points(root->stream, g_lists, g_counts, g_bases, n_segments, nq, top, d_out, d_counts);
+}
+
+static int32_t sharded_sync(qmx_query *const *queries, const qmx_hnsw *const *graphs, uint32_t n_segments, uint32_t top, uint32_t ef, const uint32_t *id_bases,
+                            qmx_scored_point *out, uint32_t *out_counts, const volatile uint8_t *is_stopped, qmx_counters *counters) {
+    QMX_REQUIRE(queries && n_segments >= 1 && queries[0] && out && out_counts, QMX_ERR_BAD_ARG, "NULL argument");
+    QMX_REQUIRE(top >= 1 && top <= MAX_TOP, QMX_ERR_NOT_SUPPORTED, "top %u not in 1..%u", top, MAX_TOP);
+    qmx_query *root = queries[0];
+    if (root->nq == 0) return QMX_OK;
+    QMX_HIP(hipSetDevice(root->device));
+    const bool out_dev = is_device_ptr(out), cnt_dev = is_device_ptr(out_counts);
+    const size_t lbytes = (size_t)root->nq * top * sizeof(qmx_scored_point), cbytes = (size_t)root->nq * 4;
+    qmx_scored_point *d_out = out;
+    uint32_t *d_counts = out_counts;
+    if (!out_dev) { QMX_TRY(root->sh_out.reserve(lbytes + cbytes)); d_out = (qmx_scored_point *)root->sh_out.p; }
+    if (!cnt_dev) { QMX_TRY(root->sh_out.reserve(lbytes + cbytes)); d_counts = (uint32_t *)((unsigned char *)root->sh_out.p + lbytes); }
+    QMX_TRY(sharded_enqueue(queries, graphs, n_segments, top, ef, id_bases, d_out, d_counts, is_stopped, counters));
+    if (!out_dev) QMX_TRY(copy_out(root->stream, out, d_out, lbytes));
+    if (!cnt_dev) QMX_TRY(copy_out(root->stream, out_counts, d_counts, cbytes));
+    // the root's stream is behind every segment's stream (the merge waited for their events): one wait completes the call; the other batches'
+    // error flags are read behind their own (already finished) streams
+    int32_t rc = QMX_OK;
+    for (uint32_t i = 0; i < n_segments; ++i) {
+        QMX_HIP(hipSetDevice(queries[i]->device));
+        const int32_t r = check_err_flag(queries[i]);
+        if (r != QMX_OK && rc == QMX_OK) rc = r;
+        if (counters && !graphs) {
+            qmx_counters c{};
+            (void)fold_split_counters(queries[i], &c);
+            counters->prefilter_candidates += c.prefilter_candidates;
+            counters->verified_rows += c.verified_rows;
+            counters->fallback_queries += c.fallback_queries;
+            counters->bytes_read += c.bytes_read;
+        }
+        const bool timed = queries[i]->timing || (queries[i]->seg->flags & QMX_SEG_TIME_KERNELS) != 0;
+        if (timed) {
+            const float before = queries[i]->timing_ms;
+            QMX_TRY(timing_fold(queries[i]));
+            if (counters) counters->kernel_ms += queries[i]->timing_ms - before;
+        }
+    }
+    QMX_HIP(hipSetDevice(root->device));
+    return rc;
+}
+
+int32_t qmx_sharded_search_topk(qmx_query *const *queries, uint32_t n_segments, uint32_t top, const uint32_t *id_bases, qmx_scored_point *out,
+                                uint32_t *out_counts, const volatile uint8_t *is_stopped, qmx_counters *counters) {
+    return sharded_sync(queries, nullptr, n_segments, top, 0, id_bases, out, out_counts, is_stopped, counters);
+}
+int32_t qmx_sharded_hnsw_search(const qmx_hnsw *const *graphs, qmx_query *const *queries, uint32_t n_segments, uint32_t top, uint32_t ef,
+                                const uint32_t *id_bases, qmx_scored_point *out, uint32_t *out_counts, const volatile uint8_t *is_stopped,
+                                qmx_counters *counters) {
+    QMX_REQUIRE(graphs, QMX_ERR_BAD_ARG, "NULL argument");
+    return sharded_sync(queries, graphs, n_segments, top, ef, id_bases, out, out_counts, is_stopped, counters);
+}
+int32_t qmx_sharded_search_topk_async(qmx_query *const *queries, uint32_t n_segments, uint32_t top, const uint32_t *id_bases, qmx_scored_point *out_dev,
+                                      uint32_t *out_counts_dev) {
+    QMX_REQUIRE(queries && n_segments >= 1 && queries[0] && out_dev && out_counts_dev, QMX_ERR_BAD_ARG, "NULL argument");
+    QMX_REQUIRE(top >= 1 && top <= MAX_TOP, QMX_ERR_NOT_SUPPORTED, "top %u not in 1..%u", top, MAX_TOP);
+    if (queries[0]->nq == 0) return QMX_OK;
+    return sharded_enqueue(queries, nullptr, n_segments, top, 0, id_bases, out_dev, out_counts_dev, nullptr, nullptr);
+}
+int32_t qmx_sharded_query_update(qmx_query *const *queries, uint32_t n_segments, const float *batch) {
+    QMX_REQUIRE(queries && n_segments >= 1 && batch, QMX_ERR_BAD_ARG, "NULL argument");
+    for (uint32_t i = 0; i < n_segments; ++i) {
+        QMX_REQUIRE(queries[i], QMX_ERR_BAD_ARG, "segment %u: NULL batch", i);
+        QMX_TRY(qmx_query_update(queries[i], batch));
+    }
+    return QMX_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

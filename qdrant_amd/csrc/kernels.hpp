@@ -268,8 +268,19 @@ int32_t launch_split_regroup(hipStream_t st, const ScanArgs &a, const void *d_wl
                              int *d_overflow, uint32_t phase, uint32_t qt);
 size_t split_copy_bytes(uint64_t n, uint32_t dim, int half);
 int32_t launch_split_copy(hipStream_t st, const void *rows, uint64_t row_stride, uint64_t n, uint32_t dim, float row_scale, void *d_out, int half);
+// what one search through the prefilter did (device side; api.hip folds it into qmx_counters)
+struct SplitStats {
+    unsigned long long candidates;   // (row, query) pairs the approximate scan let through, deleted rows dropped
+    unsigned long long verified;     // of those, re-scored exactly from the f32 rows
+    uint32_t fallback_queries;       // queries whose lists overflowed: they took the exact scan of the block
+    uint32_t pad;
+};
 int32_t launch_split_select(hipStream_t st, const uint64_t *d_cand, const uint32_t *d_cand_cnt, uint32_t cap, const float *d_band, uint32_t nq, uint32_t top,
-                            uint32_t vcap, uint32_t *d_ver_ids, uint32_t *d_ver_cnt, int *d_overflow);
+                            uint32_t vcap, uint32_t *d_ver_ids, uint32_t *d_ver_cnt, const int *d_tile_overflow, uint32_t *d_ovf_q, SplitStats *d_stats);
+// the overflowed queries packed for the conditional exact passes: list, their pre-scan bounds, the passes' run flags
+int32_t launch_split_plan(hipStream_t st, const uint32_t *d_ovf_q, uint32_t nq, const uint64_t *d_gthr, uint32_t *d_list, uint64_t *d_gthr_packed, uint32_t list_cap,
+                          uint32_t *d_count, int *d_run16, int *d_run64, uint32_t n_run64, SplitStats *d_stats, const void *d_queries, uint32_t q_stride,
+                          void *d_packed_queries);
 // order statistics of a float array (quantile.hip): the SQ quantile interval
 int32_t launch_order_statistics_f32(hipStream_t st, const float *d_in, float *d_tmp, uint64_t n, uint64_t lo_pos, uint64_t hi_pos, float *h_out);
 // BQ 1-bit (scan_bq.hip)
@@ -304,7 +315,7 @@ int32_t launch_pack_queries(hipStream_t st, int dtype, int distance, const void 
 int32_t launch_merge_keys(hipStream_t st, const uint64_t *partial, uint32_t n_lists,
                           uint32_t qt_stride, uint32_t nq, uint32_t top, qmx_scored_point *out,
                           uint32_t *out_counts, uint32_t out_stride = 0, uint32_t out_offset = 0,
-                          uint64_t *next_bound = nullptr, const int *run_if = nullptr);
+                          uint64_t *next_bound = nullptr, const int *run_if = nullptr, const uint32_t *out_map = nullptr);
 int32_t launch_merge_points(hipStream_t st, const qmx_scored_point *lists, const uint32_t *list_counts,
                             const uint32_t *list_idx_base, uint32_t n_lists, uint32_t nq, uint32_t k, qmx_scored_point *out,
                             uint32_t *out_counts);

@@ -782,7 +782,7 @@ __global__ __launch_bounds__(SP3_THREADS, 1) void scan_f16half256_kernel(const S
 // query in LDS, reserve the block's range of every query's list with ONE global atomic per query, then place.
 constexpr int RG_LISTS = 16;
 __global__ __launch_bounds__(256) void sp_regroup_kernel(const uint4 *wlist, const uint32_t *wcnt, uint32_t wcap, uint32_t n_lists, DeletedView del,
-                                                         uint64_t *cand, uint32_t *cand_cnt, uint32_t cap, int *overflow) {
+                                                         uint64_t *cand, uint32_t *cand_cnt, uint32_t cap, int *overflow /* of the tile: every query of it */) {
     __shared__ uint32_t hist[SP_QT_MAX], base[SP_QT_MAX];
     if (threadIdx.x < SP_QT_MAX) hist[threadIdx.x] = 0;
     __syncthreads();
@@ -901,15 +901,18 @@ __global__ __launch_bounds__(SEL_BLOCK) void sp_refine_kernel(const uint64_t *ca
 }
 
 __global__ __launch_bounds__(SEL_BLOCK) void sp_select_kernel(const uint64_t *cand, const uint32_t *cand_cnt, uint32_t cap, const float *band, uint32_t top,
-                                                              uint32_t vcap, uint32_t *ver_ids, uint32_t *ver_cnt, int *overflow) {
+                                                              uint32_t vcap, uint32_t *ver_ids, uint32_t *ver_cnt, const int *tile_overflow, uint32_t *ovf_q,
+                                                              SplitStats *stats) {
     __shared__ uint64_t sh[SEL_BLOCK / WAVE][WAVE];
     __shared__ uint64_t sh_kth;
     __shared__ float sh_cut;
     __shared__ uint32_t sh_n;
     const uint32_t q = blockIdx.x;
     const uint32_t raw = cand_cnt[q];
-    if (raw > cap) {                          // the candidate buffer overflowed: this pass cannot be trusted
-        if (threadIdx.x == 0) { *overflow = 1; ver_cnt[q] = 0; }
+    // a wave list of the scan overflowed (its dropped entries could be anybody's), or this query's candidate buffer did: the pass cannot be
+    // trusted for this query, which takes the exact scan (the other queries of the batch keep their lists)
+    if (*tile_overflow || raw > cap) {
+        if (threadIdx.x == 0) { ovf_q[q] = 1; ver_cnt[q] = 0; }
         return;
     }
     const uint64_t *c = cand + (uint64_t)q * cap;
@@ -931,8 +934,52 @@ __global__ __launch_bounds__(SEL_BLOCK) void sp_select_kernel(const uint64_t *ca
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (sh_n > vcap) { *overflow = 1; ver_cnt[q] = 0; }
-        else ver_cnt[q] = sh_n;
+        const bool over = sh_n > vcap;
+        ovf_q[q] = over ? 1u : 0u;
+        ver_cnt[q] = over ? 0u : sh_n;
+        atomicAdd(&stats->candidates, (unsigned long long)raw);
+        if (!over) atomicAdd(&stats->verified, (unsigned long long)sh_n);
+    }
+}
+
+// ---- the queries whose lists overflowed, packed: list[j] = j-th such query (0xFFFFFFFF behind the last), its pre-scan bound next to it; the run flags of
+// the conditional exact passes (api.hip: one 16-query pass when 1..16 queries overflowed, else passes of 64) ----
+__global__ __launch_bounds__(256) void sp_plan_kernel(const uint32_t *ovf_q, uint32_t nq, const uint64_t *gthr, uint32_t *list, uint64_t *gthr_packed,
+                                                       uint32_t list_cap, uint32_t *count, int *run16, int *run64, uint32_t n_run64, SplitStats *stats,
+                                                       const uint4 *queries, uint32_t units_per_query, uint4 *packed_queries) {
+    __shared__ uint32_t sh_cnt;
+    const uint32_t lane = threadIdx.x & 63;
+    if (threadIdx.x < 64) {
+        uint32_t cnt = 0;
+        for (uint32_t base = 0; base < nq; base += 64) {
+            const uint32_t i = base + lane;
+            const bool f = i < nq && ovf_q[i] != 0;
+            const uint64_t m = __ballot(f);
+            if (f) {
+                const uint32_t at = cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                list[at] = i;
+                gthr_packed[at] = gthr[i];
+            }
+            cnt += (uint32_t)__popcll(m);
+        }
+        for (uint32_t i = cnt + lane; i < list_cap; i += 64) { list[i] = 0xFFFFFFFFu; gthr_packed[i] = 0; }
+        if (lane == 0) {
+            *count = cnt;
+            *run16 = cnt >= 1 && cnt <= 16;
+            for (uint32_t p = 0; p < n_run64; ++p) run64[p] = cnt > (p ? 64u * p : 16u);
+            stats->fallback_queries = cnt;
+            sh_cnt = cnt;
+        }
+    }
+    __syncthreads();
+    const uint32_t cnt = sh_cnt;
+    if (cnt == 0) return;
+    // their query entries, packed the same way (slots behind the last repeat the first: valid operands, results dropped); a rare path, one block does it
+    __threadfence_block();
+    for (uint64_t gid = threadIdx.x; gid < (uint64_t)list_cap * units_per_query; gid += 256) {
+        const uint32_t j = (uint32_t)(gid / units_per_query), u = (uint32_t)(gid % units_per_query);
+        const uint32_t src = list[j < cnt ? j : 0];
+        packed_queries[gid] = queries[(uint64_t)src * units_per_query + u];
     }
 }
 
@@ -1091,9 +1138,20 @@ int32_t launch_split_refine(hipStream_t st, const uint64_t *d_cand, const uint32
     return QMX_OK;
 }
 int32_t launch_split_select(hipStream_t st, const uint64_t *d_cand, const uint32_t *d_cand_cnt, uint32_t cap, const float *d_band, uint32_t nq, uint32_t top,
-                            uint32_t vcap, uint32_t *d_ver_ids, uint32_t *d_ver_cnt, int *d_overflow) {
+                            uint32_t vcap, uint32_t *d_ver_ids, uint32_t *d_ver_cnt, const int *d_tile_overflow, uint32_t *d_ovf_q, SplitStats *d_stats) {
     ::qmx::clear_stale_error();
-    hipLaunchKernelGGL(sp_select_kernel, dim3(nq), dim3(SEL_BLOCK), 0, st, d_cand, d_cand_cnt, cap, d_band, top, vcap, d_ver_ids, d_ver_cnt, d_overflow);
+    hipLaunchKernelGGL(sp_select_kernel, dim3(nq), dim3(SEL_BLOCK), 0, st, d_cand, d_cand_cnt, cap, d_band, top, vcap, d_ver_ids, d_ver_cnt, d_tile_overflow,
+                       d_ovf_q, d_stats);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+int32_t launch_split_plan(hipStream_t st, const uint32_t *d_ovf_q, uint32_t nq, const uint64_t *d_gthr, uint32_t *d_list, uint64_t *d_gthr_packed, uint32_t list_cap,
+                          uint32_t *d_count, int *d_run16, int *d_run64, uint32_t n_run64, SplitStats *d_stats, const void *d_queries, uint32_t q_stride,
+                          void *d_packed_queries) {
+    QMX_REQUIRE(q_stride % 16 == 0, QMX_ERR_OTHER, "query entries are whole 16-byte units");
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(sp_plan_kernel, dim3(1), dim3(256), 0, st, d_ovf_q, nq, d_gthr, d_list, d_gthr_packed, list_cap, d_count, d_run16, d_run64, n_run64, d_stats,
+                       (const uint4 *)d_queries, q_stride / 16, (uint4 *)d_packed_queries);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }

@@ -59,16 +59,19 @@ __device__ __forceinline__ uint64_t block_finish(uint64_t list, int top, uint32_
 __global__ __launch_bounds__(MERGE_BLOCK) void merge_keys_kernel(const uint64_t *partial, uint32_t n_lists,
                                                                  uint32_t qt_stride, uint32_t top,
                                                                  qmx_scored_point *out, uint32_t *out_counts, uint32_t out_stride,
-                                                                 uint32_t out_offset, uint64_t *next_bound, const int *run_if) {
+                                                                 uint32_t out_offset, uint64_t *next_bound, const int *run_if, const uint32_t *out_map) {
     if (run_if && *run_if == 0) return;      // the exact pass behind the split prefilter was not needed (scan_split.hip)
     const uint32_t q = blockIdx.x;
+    // out_map: list q of the scan belongs to query out_map[q] of the batch (the packed exact pass behind the prefilter); 0xFFFFFFFF = a padding slot
+    const uint32_t oq = out_map ? out_map[q] : q;
+    if (oq == 0xFFFFFFFFu) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint64_t list = 0;
     for (uint32_t l = wave; l < n_lists; l += MERGE_NW) {
         const uint64_t key = lane < (int)top ? partial[((uint64_t)l * qt_stride + q) * top + lane] : 0;
         wave_offer(list, key, (int)top, lane);
     }
-    const uint64_t nb = block_finish(list, (int)top, q, out, out_stride, out_offset, out_counts);
+    const uint64_t nb = block_finish(list, (int)top, oq, out, out_stride, out_offset, out_counts);
     if (next_bound && threadIdx.x == 0) next_bound[q] = nb;
 }
 
@@ -148,12 +151,12 @@ __global__ __launch_bounds__(MERGE_BLOCK) void sort_scored_kernel(const float *s
 
 int32_t launch_merge_keys(hipStream_t st, const uint64_t *partial, uint32_t n_lists, uint32_t qt_stride,
                           uint32_t nq, uint32_t top, qmx_scored_point *out, uint32_t *out_counts, uint32_t out_stride,
-                          uint32_t out_offset, uint64_t *next_bound, const int *run_if) {
+                          uint32_t out_offset, uint64_t *next_bound, const int *run_if, const uint32_t *out_map) {
     if (nq == 0) return QMX_OK;
     if (out_stride == 0) out_stride = top;
     ::qmx::clear_stale_error();
     hipLaunchKernelGGL(merge_keys_kernel, dim3(nq), dim3(MERGE_BLOCK), 0, st, partial, n_lists, qt_stride, top, out, out_counts,
-                       out_stride, out_offset, next_bound, run_if);
+                       out_stride, out_offset, next_bound, run_if, out_map);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }

@@ -704,6 +704,12 @@ class RawScorer:
         F.check(F.lib().qmx_query_read_encoded(self._h, query_index, F.ptr(out), nbytes, C.byref(written)))
         return out[:written.value].view(_NP_ELEM[int(self.storage.datatype)])
 
+    def last_counters(self) -> "F.Counters":
+        """qmx_query_last_counters: the `HardwareCounterCell` increments of the batch's last brute-force search (synchronises)."""
+        c = F.Counters()
+        F.check(F.lib().qmx_query_last_counters(self._h, C.byref(c)))
+        return c
+
     def close(self):
         if self._h:
             F.lib().qmx_query_destroy(self._h)

@@ -208,3 +208,68 @@ class ShardedSearcher:
         c = self.mcounts.cpu().numpy()
         import numpy as np
         return [(m[i, :c[i], 0].view(np.uint32).copy(), m[i, :c[i], 1].copy().view(np.float32)) for i in range(self.nq)]
+
+
+class SegmentsSearcher:
+    """ONE host process that owns every segment (the reference's shape: `SegmentsSearcher::search`, segments_searcher.rs:250-285):
+    `qmx_sharded_search_topk` enqueues the local stage of every segment on its own device, gathers the lists by peer copies and
+    merges them on the first segment's device.  `storages[i]` may live on any device; `id_bases[i]` globalises segment-local offsets
+    (default: the exclusive prefix sum of the segment sizes).  With `graphs` the local stage is each segment's HNSW walk."""
+
+    def __init__(self, storages, nq: int, id_bases=None, graphs=None):
+        import numpy as np
+        self.lib = F.lib()
+        self.storages, self.nq, self.graphs = list(storages), int(nq), (list(graphs) if graphs is not None else None)
+        n = len(self.storages)
+        if id_bases is None:
+            sizes = [int(s.total_vector_count()) for s in self.storages]
+            id_bases = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+        self.id_bases = np.ascontiguousarray(id_bases, dtype=np.uint32)
+        assert len(self.id_bases) == n
+        self._handles = (C.c_void_p * n)()
+        zeros = np.zeros((nq, self.storages[0].dim), dtype=np.float32)
+        for i, st in enumerate(self.storages):
+            h = C.c_void_p()
+            F.check(self.lib.qmx_query_create(st._h, F.ptr(zeros), nq, C.byref(h)))
+            self._handles[i] = h.value
+        self._graph_handles = None
+        if self.graphs is not None:
+            self._graph_handles = (C.c_void_p * n)(*[g._h.value if hasattr(g._h, "value") else g._h for g in self.graphs])
+        self.counters = F.Counters()
+
+    def search(self, queries, top: int, ef: int = 0):
+        """queries [nq, dim] f32 (numpy, or a torch tensor every segment's device can read) -> list of ScoredPointOffset arrays."""
+        import numpy as np
+        n = len(self.storages)
+        q = queries if hasattr(queries, "data_ptr") else np.ascontiguousarray(queries, dtype=np.float32)
+        assert tuple(q.shape) == (self.nq, self.storages[0].dim)
+        F.check(self.lib.qmx_sharded_query_update(self._handles, n, F.ptr(q)))
+        out = np.zeros((self.nq, top), dtype=np.dtype([("idx", np.uint32), ("score", np.float32)]))
+        counts = np.zeros(self.nq, dtype=np.uint32)
+        if self._graph_handles is not None:
+            F.check(self.lib.qmx_sharded_hnsw_search(self._graph_handles, self._handles, n, top, ef, F.ptr(self.id_bases), F.ptr(out), F.ptr(counts),
+                                                      None, C.byref(self.counters)))
+        else:
+            F.check(self.lib.qmx_sharded_search_topk(self._handles, n, top, F.ptr(self.id_bases), F.ptr(out), F.ptr(counts), None,
+                                                      C.byref(self.counters)))
+        return [out[i, :counts[i]].copy() for i in range(self.nq)]
+
+    def search_async(self, queries, top: int, out, counts):
+        """Enqueue only: `queries`, `out` [nq, top, 2] int32 and `counts` [nq] int32 are torch tensors on the first segment's device."""
+        F.check(self.lib.qmx_sharded_query_update(self._handles, len(self.storages), F.ptr(queries)))
+        F.check(self.lib.qmx_sharded_search_topk_async(self._handles, len(self.storages), top, F.ptr(self.id_bases), F.ptr(out), F.ptr(counts)))
+
+    def synchronize(self):
+        F.check(self.lib.qmx_query_synchronize(C.c_void_p(self._handles[0])))
+
+    def close(self):
+        for i in range(len(self.storages)):
+            if self._handles[i]:
+                self.lib.qmx_query_destroy(C.c_void_p(self._handles[i]))
+                self._handles[i] = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

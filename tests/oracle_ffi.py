@@ -423,7 +423,8 @@ class Scorer(C.Structure):
                 ("pq", C.POINTER(Pq)), ("pq_codes", _P), ("pq_lut", _P), ("isa", C.c_int),
                 ("bq_rows", _P), ("bq_query", _P), ("bq_dim", C.c_uint32), ("bq_distance", C.c_int), ("bq_invert", C.c_int),
                 ("mv_tokens", _P), ("mv_n_tokens", C.c_uint32), ("mv_offsets", _P),
-                ("tq", _P), ("tq_rows", _P), ("tq_query", _P), ("tq_invert", C.c_int)]
+                ("tq", _P), ("tq_rows", _P), ("tq_query", _P), ("tq_invert", C.c_int),
+                ("cq_examples", _P), ("cq_kind", C.c_uint32), ("cq_n_a", C.c_uint32), ("cq_n_b", C.c_uint32), ("cq_coefs", _P)]
 
 
 _sig("qo_merge_topk", None, [_P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P])

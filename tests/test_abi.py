@@ -25,13 +25,13 @@ def test_library_exports_every_declared_symbol():
     lib = _ffi.lib()  # raises if the .so is missing or a symbol is absent
     for name in _declared():
         assert hasattr(lib, name), name
-    assert lib.qmx_abi_version() == 3
+    assert lib.qmx_abi_version() == 4
 
 
 def test_struct_layouts_match_the_header():
     from qdrant_amd import _ffi
     assert C.sizeof(_ffi.ScoredPoint) == 8          # ScoredPointOffset is 8 bytes, #[repr(C)]
-    assert C.sizeof(_ffi.Counters) == 32
+    assert C.sizeof(_ffi.Counters) == 56
     assert C.sizeof(_ffi.SqParams) == 20
     assert C.sizeof(_ffi.SegmentDesc) == 80          # + the qmx_tq_params pointer (ABI 3)
     assert C.sizeof(_ffi.TqParams) == 32

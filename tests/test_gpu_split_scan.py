@@ -1,8 +1,8 @@
 """The split prefilter (qdrant_amd/csrc/scan_split.hip): f32 dot / cosine top-k of more than 64 queries over a large block runs 128
 queries per pass on the f16 matrix cores (x = h + l, three products), keeps every row whose approximate score is within a rigorous band
 of the running k-th best, and re-scores the survivors with the exact gather kernel.  The approximate scores never leave the library:
-the result must be the exact scan's — the oracle's — ids and score bits, ties included.  Whatever does not fit the buffers (masses of
-equal scores, a sample without live rows) raises a device flag and the exact scan runs behind it."""
+the result must be the exact scan's — the oracle's — ids and score bits, ties included.  A query whose lists do not fit the buffers (masses
+of equal scores, a sample without live rows) raises its own device flag and the exact scan of THOSE queries runs behind the prefilter."""
 import numpy as np
 import pytest
 
@@ -81,41 +81,91 @@ def test_split_scan_with_deleted_rows_and_filter(qa):
     _same(s.peek_top_all(), st_f.peek_top(queries, top, threads=8))
 
 
-def test_split_scan_falls_back_when_scores_tie_in_masses(qa):
-    """Every row exists 400 times: the verification band holds 400 x k rows per query, more than the list takes -> the overflow flag
-    -> the exact scan runs behind the prefilter in the same stream.  Equal scores come back in ascending id order, like the oracle's."""
-    dim, nq, top, rep = 64, 70, 10, 400
+def _same_up_to_equal_scores(got, want):
+    """Score bits identical; ids identical as sets; among equal scores the lower id first (the linear scan keeps the FIRST of equal scores:
+    strict <, fixed_length_priority_queue.rs:53-57)."""
+    for g, w in zip(got, want):
+        assert np.array_equal(g["score"].view(np.uint32), w["score"].view(np.uint32))
+        assert sorted(g["idx"].tolist()) == sorted(w["idx"].tolist())
+        for i in range(len(g) - 1):
+            if g["score"][i] == g["score"][i + 1]:
+                assert g["idx"][i] < g["idx"][i + 1]
+
+
+@pytest.mark.parametrize("copy", [0, 1, 2])
+def test_split_scan_falls_back_when_scores_tie_in_masses(qa, copy):
+    """Every row exists 400 times: the verification band holds 400 x k rows per query, more than the list takes -> every query's overflow flag
+    -> the exact scan of those queries runs behind the prefilter in the same stream.  Equal scores come back in ascending id order, like the oracle's."""
+    dim, nq, top, rep = 128, 70, 10, 400
     base = O.preprocess(O.COSINE, O.synth(0x5EED0520, 0, N // rep, dim))
     rows = np.tile(base, (rep, 1))                       # row i == row i + len(base)
     queries = O.synth(0x5EED0521, 0, nq, dim)
     st = O.DenseStorage(O.F32, O.COSINE, rows)
-    vs = qa.VectorStorage(rows, qa.Distance.Cosine)
-    got = qa.BatchFilteredSearcher(queries, vs, top).peek_top_all()
-    want = st.peek_top(queries, top)                      # sequential: the linear scan keeps the FIRST of equal scores (strict <, :53-57)
+    vs = qa.VectorStorage(rows, qa.Distance.Cosine, flags=[0, qa._ffi.SEG_SPLIT_COPY, qa._ffi.SEG_HALF_COPY][copy])
+    s = qa.BatchFilteredSearcher(queries, vs, top)
+    got = s.peek_top_all()
+    assert ["scan_f32_split_kernel", "scan_f16pair_kernel<false>", "scan_f16pair_kernel<true>"][copy] in _kernel(qa, s)
+    assert s.counters.prefilter_queries == nq and s.counters.fallback_queries == nq      # the prefilter ran, every query overflowed
+    want = st.peek_top(queries, top)                      # sequential
+    _same_up_to_equal_scores(got, want)
     for g, w in zip(got, want):
-        assert np.array_equal(g["score"].view(np.uint32), w["score"].view(np.uint32))
-        # the same rows up to the choice among copies; the k best copies are the k lowest ids of the best row(s)
         assert sorted((g["idx"] % len(base)).tolist()) == sorted((w["idx"] % len(base)).tolist())
-        assert sorted(g["idx"].tolist()) == sorted(w["idx"].tolist())
-        for i in range(len(g) - 1):
-            if g["score"][i] == g["score"][i + 1]:
-                assert g["idx"][i] < g["idx"][i + 1]      # equal scores come back in ascending id order
 
 
-def test_split_scan_when_the_sample_is_all_deleted(qa):
-    """The strided sample (every 32nd row here) is deleted entirely: no threshold -> every row is a candidate -> the candidate buffers
-    overflow -> the exact scan takes over.  Same result as ever."""
-    n, dim, nq, top = N, 64, 80, 5
+@pytest.mark.parametrize("copy", [0, 2])
+def test_split_scan_when_the_sample_is_all_deleted(qa, copy):
+    """The strided sample is deleted entirely: no threshold -> every row is a candidate -> the candidate buffers
+    overflow -> the exact scan takes over for every query.  Same result as ever."""
+    n, dim, nq, top = N, 128, 80, 5
     rows = O.preprocess(O.COSINE, O.synth(0x5EED0530, 0, n, dim))
     queries = O.synth(0x5EED0531, 0, nq, dim)
-    S = max(n >> 10, 8192)
+    S = max(n >> (10 if copy else 8), 8192)              # (api.hip search_enqueue: the sample of a block without a copy is four times denser)
     step = n // S
     deleted = np.zeros(n, dtype=bool)
     deleted[::step] = True
     st = O.DenseStorage(O.F32, O.COSINE, rows, point_deleted=deleted)
-    vs = qa.VectorStorage(rows, qa.Distance.Cosine)
+    vs = qa.VectorStorage(rows, qa.Distance.Cosine, flags=[0, 0, qa._ffi.SEG_HALF_COPY][copy])
     vs.set_deleted(deleted, None)
-    _same(qa.BatchFilteredSearcher(queries, vs, top).peek_top_all(), st.peek_top(queries, top, threads=8))
+    s = qa.BatchFilteredSearcher(queries, vs, top)
+    got = s.peek_top_all()
+    assert ["scan_f32_split_kernel", "", "scan_f16pair_kernel<true>"][copy] in _kernel(qa, s)
+    assert s.counters.fallback_queries == nq
+    _same(got, st.peek_top(queries, top, threads=8))
+
+
+@pytest.mark.parametrize("copy", [0, 1, 2])
+@pytest.mark.parametrize("nq,n_hot", [(150, 5), (128, 1), (100, 20), (300, 70), (256, 17)])
+def test_only_the_overflowing_queries_take_the_exact_scan(qa, copy, nq, n_hot):
+    """3000 rows of the block are copies of one vector v.  A query near v has 3000 equal scores at the top of its list: more than its
+    verification list takes, so THAT query is re-scanned exactly; the other queries of the batch keep the prefilter's (verified) lists.
+    qmx_counters.fallback_queries says how many took the exact scan.  nq = 150 without a copy: the last 22 queries take the regular exact
+    path, whose pre-scan bounds once overwrote those of queries 0..21 before their deferred exact pass read them (round-2 advisor finding)."""
+    n, dim, top, n_dup = N, 128, 10, 3000
+    rng = np.random.default_rng(11)
+    raw = O.synth(0x5EED0550, 0, n, dim)
+    v = O.synth(0x5EED0551, 0, 1, dim)[0]
+    dup_at = rng.choice(n, n_dup, replace=False)
+    raw[dup_at] = v
+    rows = O.preprocess(O.COSINE, raw)
+    queries = O.synth(0x5EED0552 + nq, 0, nq, dim)
+    hot = rng.choice(nq, n_hot, replace=False)
+    queries[hot] = v + 0.05 * O.synth(0x5EED0553, 0, n_hot, dim)
+    st = O.DenseStorage(O.F32, O.COSINE, rows)
+    vs = qa.VectorStorage(rows, qa.Distance.Cosine, flags=[0, qa._ffi.SEG_SPLIT_COPY, qa._ffi.SEG_HALF_COPY][copy])
+    s = qa.BatchFilteredSearcher(queries, vs, top)
+    got = s.peek_top_all()
+    c = s.counters
+    # without a copy a last tile of <= 64 queries takes the regular exact path: its hot queries never see the prefilter
+    n_split = nq if copy or nq % 128 == 0 or nq % 128 > 64 else nq - nq % 128
+    assert c.prefilter_queries == n_split
+    assert c.fallback_queries == int((hot < n_split).sum()), (c.fallback_queries, sorted(hot.tolist()))
+    assert c.verified_rows >= top * (n_split - c.fallback_queries) and c.prefilter_candidates >= c.verified_rows
+    want = st.peek_top(queries, top)
+    cold = [i for i in range(nq) if i not in set(hot.tolist())]
+    _same([got[i] for i in cold], [want[i] for i in cold])
+    _same_up_to_equal_scores([got[i] for i in hot], [want[i] for i in hot])
+    for i in hot:
+        assert set(got[i]["idx"].tolist()) <= set(dup_at.tolist())         # (the copies of v are the best rows of a query near v)
 
 
 @pytest.mark.parametrize("row_mag,query_mag", [(1000.0, 1e-3), (1e-4, 1e4), (37.0, 1.0)])
