@@ -379,6 +379,7 @@ def robustness(args, dev, c2_rows, queries_iid, n, dim, Q, top, local_rank, stre
             torch.cuda.synchronize(dev)
             wall = time.perf_counter() - t0
             per_batch, same = [], True
+            kernel = F.last_kernel(backend.qh)
             for b in range(nb):
                 backend.local_topk(qs[b * Q:(b + 1) * Q], top, o, cn)
                 c = F.Counters()
@@ -392,7 +393,7 @@ def robustness(args, dev, c2_rows, queries_iid, n, dim, Q, top, local_rank, stre
                 finally:
                     qa.set_option("no_split_scan", -1)
                 same = same and bool(torch.equal(a_o, o) and torch.equal(a_c, cn))
-            out[name] = {"rows": what, "batch": Q, "qps": round(Q * steps / wall, 1), "ms_per_step": round(wall / steps * 1e3, 4), "kernel": F.last_kernel(backend.qh),
+            out[name] = {"rows": what, "batch": Q, "qps": round(Q * steps / wall, 1), "ms_per_step": round(wall / steps * 1e3, 4), "kernel": kernel,
                          "batches_checked": nb, "equals_exact_scan_whole_block": same,
                          "candidates_per_query": round(sum(p["candidates_per_query"] for p in per_batch) / nb, 1),
                          "verified_rows_per_query": round(sum(p["verified_rows_per_query"] for p in per_batch) / nb, 1),

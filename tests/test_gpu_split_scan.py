@@ -94,9 +94,9 @@ def _same_up_to_equal_scores(got, want):
 
 @pytest.mark.parametrize("copy", [0, 1, 2])
 def test_split_scan_falls_back_when_scores_tie_in_masses(qa, copy):
-    """Every row exists 400 times: the verification band holds 400 x k rows per query, more than the list takes -> every query's overflow flag
+    """Every row exists 3000 times: the verification band holds at least 3000 rows per query, more than the list takes -> every query's overflow flag
     -> the exact scan of those queries runs behind the prefilter in the same stream.  Equal scores come back in ascending id order, like the oracle's."""
-    dim, nq, top, rep = 128, 70, 10, 400
+    dim, nq, top, rep = 128, 70, 10, 3000
     base = O.preprocess(O.COSINE, O.synth(0x5EED0520, 0, N // rep, dim))
     rows = np.tile(base, (rep, 1))                       # row i == row i + len(base)
     queries = O.synth(0x5EED0521, 0, nq, dim)
