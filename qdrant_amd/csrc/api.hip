@@ -47,7 +47,7 @@ int32_t hip_status(hipError_t e, const char *what, const char *file, int line) {
 
 // ---- kernel-path options: the environment is read once, here, at load time ----
 static const char *const g_option_names[OPT_COUNT] = {"no_mfma_scan", "no_mfma16", "no_mfma16_q64", "no_prescan", "prescan_shift", "hnsw_no_packed_l0",
-                                                     "hnsw_pq_lds_lut", "hnsw_log_cap", "bq_lanes8", "mfma_no_nt", "mfma_no_fast", "no_pq_tiled", "no_split_scan", "split_min_queries", "no_split256", "no_pq_pair", "debug"};
+                                                     "hnsw_pq_lds_lut", "hnsw_log_cap", "bq_lanes8", "mfma_no_nt", "mfma_no_fast", "no_pq_tiled", "no_split_scan", "split_min_queries", "no_split256", "no_pq_pair", "no_pq_prefilter", "pq_prefilter_min_queries", "debug"};
 struct OptionTable {
     std::atomic<int64_t> v[OPT_COUNT];
     int64_t initial[OPT_COUNT];
@@ -62,6 +62,7 @@ struct OptionTable {
             if (e) { val = (*e >= '0' && *e <= '9') ? atoll(e) : 1; }   // "QMX_X=" / "QMX_X=yes" count as set
             if (i == OPT_PRESCAN_SHIFT && !e) val = 10;
             if (i == OPT_SPLIT_MIN_QUERIES && !e) val = 1;
+            if (i == OPT_PQ_PREFILTER_MIN_QUERIES && !e) val = 4;
             initial[i] = val;
             v[i].store(val, std::memory_order_relaxed);
         }
@@ -168,6 +169,7 @@ struct qmx_segment {
     float *d_centroids = nullptr;
     float *d_pq_pair = nullptr;       // [m][ncent][ncent] chunk distances between centroids (score_internal terms; built when <= 256 MB)
     uint32_t pq_m = 0;
+    void *d_pq_rot = nullptr;         // PQ blocks of 2^18 rows and more, m <= 96: the rotated copy of the codes the 6-bit prefilter scans (pq_prefilter.hip)
     float *d_row_offsets = nullptr;   // SQ: vector_offset column (rows hold the 16-byte aligned code block)
     // TurboQuant (scan_tq.hip): parameters, the extras columns and the rotation tables
     uint32_t tq_bits = 0, tq_value_bits = 0, tq_padded_dim = 0, tq_rot_dim = 0, tq_code_bytes = 0, tq_n_chunks = 0;
@@ -237,11 +239,12 @@ struct qmx_query {
     DevBuf sh_lists, sh_out;   // qmx_sharded_*: the segments' lists gathered on this (the first) batch's device, the merged lists of a host-output call
     std::vector<uint32_t> sh_bases_host;
     hipEvent_t sh_done = nullptr;   // "this segment's list arrived on the merging device"
+    DevBuf pq_table;           // PQ prefilter: the 6-bit tables of the tile's query groups, their integer thresholds behind them
     DevBuf sp_plan, sp_fq;     // ... the per-query overflow flags + the plan of the conditional exact passes (SplitPlanLayout), the overflowed queries packed
     // counters of the last search enqueued on this batch: the host's share is known at enqueue, the prefilter's share sits in sp_plan until
     // the stream is synchronised (qmx_query_last_counters / the synchronous entry points fold it in)
     qmx_counters last_counters{};
-    bool last_split = false;
+    bool last_split = false, last_pq = false;
     uint64_t last_row_bytes = 0, last_n_cand = 0;
     uint64_t sp_sample_n = 0, sp_sample_of = 0;
     DevBuf filter;             // payload-filter allow bitmap of this query batch (qmx_query_set_filter)
@@ -428,6 +431,7 @@ static void segment_free(qmx_segment *seg) {
     if (seg->d_vec_deleted) (void)hipFree(seg->d_vec_deleted);
     if (seg->d_centroids) (void)hipFree(seg->d_centroids);
     if (seg->d_pq_pair) (void)hipFree(seg->d_pq_pair);
+    if (seg->d_pq_rot) (void)hipFree(seg->d_pq_rot);
     if (seg->d_rows_split) (void)hipFree(seg->d_rows_split);
     if (seg->d_row_offsets) (void)hipFree(seg->d_row_offsets);
     if (seg->d_bq_mean) (void)hipFree(seg->d_bq_mean);
@@ -508,6 +512,20 @@ static int32_t segment_upload(qmx_segment *s, const qmx_segment_desc *desc) {
         if (s->row_stride != s->row_bytes) QMX_HIP(hipMemset(s->d_rows, 0, bytes));
         QMX_HIP(hipMemcpy2D(s->d_rows, s->row_stride, desc->data, src_stride, s->row_bytes, s->n, hipMemcpyDefault));
     }
+    return QMX_OK;
+}
+
+// PQ blocks large enough for the 6-bit prefilter (pq_prefilter.hip): the rotated copy of the codes, m_pad bytes per row next to the m of the block
+// (10 M x 96: 0.96 GB, one pass).  Out of memory is not an error: the exact kernel serves.
+static int32_t segment_pq_rot(qmx_segment *s) {
+    if (s->dtype != QMX_DTYPE_PQ || s->n < (1u << 18) || !pq_prefilter_shape_ok(s->pq_m, s->pq.n_centroids) || option(OPT_NO_PQ_PREFILTER)) return QMX_OK;
+    if (hipMalloc(&s->d_pq_rot, pq_rot_bytes(s->n, s->pq_m)) != hipSuccess) {
+        (void)hipGetLastError();
+        s->d_pq_rot = nullptr;
+        return QMX_OK;
+    }
+    QMX_TRY(launch_pq_rotate(nullptr, s->d_rows, s->row_stride, s->n, s->pq_m, s->d_pq_rot));
+    QMX_HIP(hipDeviceSynchronize());
     return QMX_OK;
 }
 
@@ -832,6 +850,7 @@ int32_t qmx_segment_create(const qmx_segment_desc *desc, qmx_segment **out) {
     }
     if (rc == QMX_OK) rc = segment_upload(s, desc);
     if (rc == QMX_OK) rc = segment_split_stats(s);
+    if (rc == QMX_OK) rc = segment_pq_rot(s);
     if (rc != QMX_OK) {
         segment_free(s);
         return rc;
@@ -1292,7 +1311,7 @@ int32_t qmx_query_destroy(qmx_query *q) {
     q->mv_deleted.release();
     q->cq_scores.release();
     q->cq_desc.release();
-    q->sp_bq.release(); q->sp_f32.release(); q->sp_cand.release(); q->sp_cnt.release(); q->sp_ver.release(); q->sp_vscores.release(); q->sp_sample.release(); q->sp_wl.release(); q->xcnt.release(); q->tq_rot.release(); q->sp_plan.release(); q->sp_fq.release(); q->sh_lists.release(); q->sh_out.release();
+    q->sp_bq.release(); q->sp_f32.release(); q->sp_cand.release(); q->sp_cnt.release(); q->sp_ver.release(); q->sp_vscores.release(); q->sp_sample.release(); q->sp_wl.release(); q->xcnt.release(); q->tq_rot.release(); q->sp_plan.release(); q->sp_fq.release(); q->pq_table.release(); q->sh_lists.release(); q->sh_out.release();
     if (q->sh_done) (void)hipEventDestroy(q->sh_done);
     q->cand.release();
     q->cand_cnt.release();
@@ -1575,11 +1594,148 @@ __global__ void sample_ids_kernel(uint32_t *ids, uint32_t n, uint64_t step) {
     if (i < n) ids[i] = (uint32_t)((uint64_t)i * step);
 }
 
+// ---- PQ top-k of 4 and more queries over a large block: the 6-bit prefilter + exact verification (pq_prefilter.hip).  Same contract as the f32
+// prefilter below: the lists are the exact scan's, a query whose lists overflow takes the exact scan alone. ----
+constexpr uint32_t PQF_TILE = 256;          // queries per pass (64 four-query groups; the regroup kernel's histogram)
+constexpr uint32_t PQF_WCAP = 512;          // candidates one wave may list per pass (expected: tens)
+static int32_t pq_prefilter_enqueue(qmx_query *q, uint32_t top, uint64_t n_cand, qmx_scored_point *d_out, uint32_t *d_counts,
+                                    const volatile uint8_t *is_stopped, qmx_counters *counters, bool timed) {
+    const qmx_segment *s = q->seg;
+    const SplitPlanLayout pl(q->nq);
+    const uint32_t m = s->pq_m, m_pad = (m + 31) / 32 * 32;
+    const uint32_t tile_max = std::min<uint32_t>(PQF_TILE, q->nq);
+    const uint32_t grid_max = pq_prefilter_grid(s->num_cus, tile_max, nullptr);
+    QMX_TRY(q->gthr.reserve((size_t)std::max<uint32_t>(q->nq_padded, PQF_TILE) * sizeof(uint64_t)));
+    QMX_TRY(q->pq_table.reserve(pq_prefilter_table_bytes(m, tile_max) + (size_t)(PQF_TILE + 4) * 4));
+    QMX_TRY(q->sp_f32.reserve(1024 * sizeof(float)));
+    QMX_TRY(q->sp_cand.reserve((size_t)tile_max * SPLIT_CAND_CAP * sizeof(uint64_t)));
+    QMX_TRY(q->sp_cnt.reserve((size_t)SPLIT_QT_MAX * 4));
+    {   // (the grid of a smaller last tile may be larger than the first tile's: size for the worst over tile sizes 1..tile_max)
+        uint32_t g = grid_max;
+        for (uint32_t t = 4; t <= tile_max; t += 4) g = std::max(g, pq_prefilter_grid(s->num_cus, t, nullptr));
+        QMX_TRY(q->sp_wl.reserve(pq_prefilter_wlists_bytes(g, PQF_WCAP)));
+    }
+    QMX_TRY(q->sp_ver.reserve((size_t)q->nq * (SPLIT_VCAP + 1) * 4));
+    QMX_TRY(q->sp_vscores.reserve((size_t)q->nq * SPLIT_VCAP * 4));
+    QMX_TRY(q->sp_plan.reserve(pl.bytes));
+    unsigned char *plan = (unsigned char *)q->sp_plan.p;
+    float *band = (float *)q->sp_f32.p;                       // [PQF_TILE] in units of the integer score
+    q->last_counters = qmx_counters{};
+    q->last_split = false;
+    // the sample (as for the f32 prefilter): its k-th best exact score per query is a lower bound of the final k-th best
+    const int sshift = (int)std::min<int64_t>(std::max<int64_t>(option(OPT_PRESCAN_SHIFT) - 2, 1), 20);
+    const uint64_t S = std::min<uint64_t>(n_cand, std::max<uint64_t>(n_cand >> sshift, 8192));
+    if (q->sp_sample_n != S || q->sp_sample_of != n_cand) {
+        QMX_TRY(q->sp_sample.reserve((size_t)S * 4));
+        ::qmx::clear_stale_error();
+        hipLaunchKernelGGL(sample_ids_kernel, dim3((uint32_t)((S + 255) / 256)), dim3(256), 0, q->stream, (uint32_t *)q->sp_sample.p, (uint32_t)S, n_cand / S);
+        QMX_HIP(hipGetLastError());
+        q->sp_sample_n = S;
+        q->sp_sample_of = n_cand;
+    }
+    const uint32_t *d_sample = (const uint32_t *)q->sp_sample.p;
+    QMX_HIP(hipMemsetAsync(plan, 0, pl.zero_bytes, q->stream));
+    uint32_t *ver_all = (uint32_t *)q->sp_ver.p, *cnt_all = ver_all + (size_t)q->nq * SPLIT_VCAP;
+    uint32_t n_tiles = 0, launches = 0;
+    for (uint32_t tile0 = 0; tile0 < q->nq; tile0 += PQF_TILE, ++n_tiles) {
+        const uint32_t nq_tile = std::min<uint32_t>(PQF_TILE, q->nq - tile0);
+        if (is_stopped && *is_stopped) {
+            set_error("search cancelled");
+            return QMX_ERR_CANCELLED;
+        }
+        uint64_t *gthr = (uint64_t *)q->gthr.p + tile0;
+        ScanArgs a;
+        fill_args(q, tile0, nq_tile, a);
+        a.n_cand = n_cand;
+        a.top = top;
+        // 1. exact scores of the sample (the exact kernel's score mode over an id list) -> k-th best per query
+        QMX_TRY(q->scores.reserve((size_t)nq_tile * S * sizeof(float)));
+        const uint32_t SQT = tile_qt(s, q);
+        for (uint32_t st0 = 0; st0 < nq_tile; st0 += SQT) {
+            const uint32_t nq_sub = std::min<uint32_t>(SQT, nq_tile - st0);
+            ScanArgs pre;
+            fill_args(q, tile0 + st0, nq_sub, pre);
+            pre.ids = d_sample;
+            pre.n_cand = S;
+            pre.top = 1;
+            pre.scores = (float *)q->scores.p + (size_t)st0 * S;
+            pre.scores_stride = S;
+            uint32_t pgrid = 0;
+            QMX_TRY(launch_scan(q, (int)pow2_ceil(nq_sub), SCAN_SCORES, pre, &pgrid));
+            ++launches;
+        }
+        QMX_TRY(launch_custom_topk(q->stream, (const float *)q->scores.p, S, d_sample, a.del, nq_tile, top, d_out + (size_t)tile0 * top, d_counts + tile0));
+        QMX_TRY(launch_bound_from_topk(q->stream, d_out + (size_t)tile0 * top, d_counts + tile0, nq_tile, top, gthr));
+        // 2. the 6-bit tables of the tile's query groups, thresholds and bands in units of the integer score
+        int32_t *thr = (int32_t *)((unsigned char *)q->pq_table.p + pq_prefilter_table_bytes(m, tile_max));
+        QMX_TRY(launch_pq_lut8(q->stream, a.queries, q->q_stride, nq_tile, m, s->pq.n_centroids, gthr, q->pq_table.p, thr, band));
+        QMX_HIP(hipMemsetAsync(q->sp_cnt.p, 0, (size_t)SPLIT_QT_MAX * 4, q->stream));
+        // 3. the approximate scan of the whole block over the rotated copy
+        uint32_t grid = 0;
+        size_t slot = 0;
+        if (timed) QMX_TRY(timing_begin(q, &slot));
+        QMX_TRY(launch_pq_prefilter(q->stream, a, s->d_pq_rot, q->pq_table.p, thr, nq_tile, s->num_cus, q->sp_wl.p, PQF_WCAP, &grid));
+        q->last_kernel = g_last_kernel;
+        if (timed) QMX_TRY(timing_end(q, slot));
+        // 4. per-wave lists -> per-query lists (deleted rows dropped), then the rows worth an exact score
+        int *tile_ovf = (int *)(plan + pl.tile_ovf) + n_tiles;
+        QMX_TRY(launch_regroup_lists(q->stream, a.del, (const unsigned char *)q->sp_wl.p + pq_prefilter_wlists_counts_bytes(grid), (const uint32_t *)q->sp_wl.p, PQF_WCAP,
+                                     grid * 16, (uint64_t *)q->sp_cand.p, (uint32_t *)q->sp_cnt.p, SPLIT_CAND_CAP, tile_ovf));
+        QMX_TRY(launch_split_select(q->stream, (const uint64_t *)q->sp_cand.p, (const uint32_t *)q->sp_cnt.p, SPLIT_CAND_CAP, band, nq_tile, top, SPLIT_VCAP,
+                                    ver_all + (size_t)tile0 * SPLIT_VCAP, cnt_all + tile0, tile_ovf, (uint32_t *)(plan + pl.ovf_q) + tile0, (SplitStats *)plan));
+        launches += 6;
+    }
+    const void *pf_kernel = q->last_kernel;
+    // 5. exact scores of the survivors (pq_pair_kernel: score_point_sse's order), sorted by (score, lower id first)
+    PairSel sel{nullptr, SPLIT_VCAP, cnt_all};
+    QMX_TRY(score_pairs_device(q, sel, ver_all, (uint64_t)q->nq * SPLIT_VCAP, (float *)q->sp_vscores.p, false));
+    QMX_TRY(launch_sort_scored(q->stream, (const float *)q->sp_vscores.p, ver_all, cnt_all, SPLIT_VCAP, q->nq, top, d_out, d_counts));
+    // 6. the exact scan of the queries whose lists overflowed, and of those only (the kernels start, read the count and return when it is zero)
+    uint32_t *ovf_list = (uint32_t *)(plan + pl.list);
+    QMX_TRY(launch_split_plan(q->stream, (const uint32_t *)(plan + pl.ovf_q), q->nq, (const uint64_t *)q->gthr.p, ovf_list, (uint64_t *)(plan + pl.gthr_packed),
+                              pl.list_cap, (uint32_t *)(plan + pl.count), (int *)(plan + pl.run16), (int *)(plan + pl.run64), pl.n_run64, (SplitStats *)plan, nullptr, 0,
+                              nullptr));
+    {
+        ScanArgs a;
+        fill_args(q, 0, q->nq, a);
+        a.n_cand = n_cand;
+        a.top = top;
+        a.q_map = ovf_list;
+        a.run_if = (const int *)(plan + pl.count);
+        const uint64_t want = (n_cand + 1023) / 1024, cap = std::max<uint64_t>(1, ((uint64_t)s->num_cus * 2 + q->nq - 1) / q->nq);
+        uint32_t slabs = (uint32_t)std::max<uint64_t>(1, std::min(want, cap));
+        QMX_TRY(q->partial.reserve((size_t)slabs * q->nq * top * sizeof(uint64_t)));
+        a.partial = (uint64_t *)q->partial.p;
+        a.partial_qt = q->nq;
+        QMX_TRY(launch_scan_pq(q->stream, SCAN_TOPK, a, s->num_cus, &slabs));
+        QMX_TRY(launch_merge_keys(q->stream, (const uint64_t *)q->partial.p, slabs, q->nq, q->nq, top, d_out, d_counts, top, 0, nullptr, a.run_if, ovf_list));
+        launches += 5;
+    }
+    q->last_kernel = pf_kernel;
+    q->last_split = true;
+    q->last_pq = true;
+    {
+        qmx_counters &c = q->last_counters;
+        c.vectors_scored = (uint64_t)q->nq * n_cand;
+        // the rotated copy once per four-query group (all but the first find it in L2) + the sample's rows per query
+        c.bytes_read = (uint64_t)((q->nq + 3) / 4) * n_cand * m_pad + (uint64_t)q->nq * S * s->row_bytes;
+        c.kernel_launches = launches;
+        c.prefilter_queries = q->nq;
+        q->last_row_bytes = s->row_bytes;
+        q->last_n_cand = n_cand;
+        if (counters) *counters = c;
+    }
+    return QMX_OK;
+}
+
 static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids, uint64_t n_ids,
                               qmx_scored_point *d_out, uint32_t *d_counts, const volatile uint8_t *is_stopped,
                               qmx_counters *counters, bool timed) {
     const qmx_segment *s = q->seg;
     const uint64_t n_cand = d_ids ? n_ids : s->scan_rows();
+    if (s->dtype == QMX_DTYPE_PQ && s->d_pq_rot && !d_ids && top <= MAX_TOP_FAST && n_cand >= (1u << 18) && !option(OPT_NO_PQ_PREFILTER) &&
+        q->nq >= (uint32_t)std::max<int64_t>(1, option(OPT_PQ_PREFILTER_MIN_QUERIES)))
+        return pq_prefilter_enqueue(q, top, n_cand, d_out, d_counts, is_stopped, counters, timed);
     // partial lists: one per block; bound the grid by what the buffer holds
     const uint32_t grid_cap = (uint32_t)s->num_cus * 8;
     // f32 dot / cosine rows of 256, 512 or 768 floats, whole block: 64 queries per pass (scan_mfma16.hip); everything else 32 / 16
@@ -1819,6 +1975,7 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
         QMX_TRY(split_stage(q, "fallback (conditional)"));
         q->last_kernel = split_kernel;      // (the fallback launches above are not what ran)
         q->last_split = true;
+        q->last_pq = false;
     }
     {
         // what the host knows at enqueue; the prefilter's own share (candidates, verified rows, exact passes of overflowed queries) is on the device
@@ -1861,7 +2018,7 @@ static int32_t fold_split_counters(qmx_query *q, qmx_counters *c) {
     c->bytes_read += st.verified * q->last_row_bytes;
     if (st.fallback_queries) {
         const uint32_t f = st.fallback_queries;
-        const uint64_t passes = f <= 16 ? 1 : (f + SPLIT_FQT - 1) / SPLIT_FQT;
+        const uint64_t passes = q->last_pq ? f : f <= 16 ? 1 : (f + SPLIT_FQT - 1) / SPLIT_FQT;     // (the exact PQ kernel streams the codes once per query)
         c->bytes_read += passes * q->last_n_cand * q->last_row_bytes;
     }
     return QMX_OK;

@@ -38,6 +38,8 @@ enum Option {
     OPT_SPLIT_MIN_QUERIES,    // with a derived copy of the block: batches of at least this many queries take the prefilter (default 1: all)
     OPT_NO_SPLIT256,          // batches of more than 128 queries over a half copy: keep the 128-query shape of the prefilter
     OPT_NO_PQ_PAIR,           // PQ score_internal recomputes the centroid distances instead of reading the pair table
+    OPT_NO_PQ_PREFILTER,      // PQ top-k scans of 4+ queries keep the exact one-LUT-per-block kernel (no 6-bit prefilter + verification)
+    OPT_PQ_PREFILTER_MIN_QUERIES,   // ... from this many queries on (default 4)
     OPT_DEBUG,                // log dropped stale HIP errors
     OPT_COUNT
 };

@@ -39,6 +39,7 @@ struct ScanArgs {
     uint64_t scores_stride;    // elements between queries in `scores`
     int *err_flag;             // set to 1 on an out-of-range id
     const int *run_if;         // nullptr, or: the kernel returns at once unless *run_if != 0 (the exact scan behind the split prefilter, scan_split.hip)
+    const uint32_t *q_map;     // pq_scan_kernel only: list q of the launch scores query q_map[q] of the batch (0xFFFFFFFF: a padding slot), or nullptr
     // SQ
     float sq_multiplier;
     const float *row_offsets;  // SQ: per-row f32 offset (SoA copy) or nullptr when inline in rows
@@ -261,6 +262,20 @@ int32_t launch_split_thresholds(hipStream_t st, const uint64_t *d_gthr, const fl
                                 const float *d_scales, float *d_thr, float *d_band, uint32_t qt);
 int32_t launch_scan_f32_split(hipStream_t st, const ScanArgs &a, const void *d_bq, float row_scale, const float *d_scales, const float *d_thr,
                               uint64_t *d_cand, uint32_t *d_cand_cnt, uint32_t cap, int num_cus, const void *d_rows_split, int half, void *d_wlists, uint32_t phase, uint32_t qt);
+int32_t launch_regroup_lists(hipStream_t st, const DeletedView &del, const void *d_wlist, const uint32_t *d_wcnt, uint32_t wcap, uint32_t n_lists, uint64_t *d_cand,
+                             uint32_t *d_cand_cnt, uint32_t cap, int *d_overflow);
+// PQ prefilter (pq_prefilter.hip): rotated copy of the code block, 6-bit tables + thresholds per query, the approximate scan
+size_t pq_rot_bytes(uint64_t n, uint32_t m);
+bool pq_prefilter_shape_ok(uint32_t m, uint32_t ncent);
+int32_t launch_pq_rotate(hipStream_t st, const void *codes, uint64_t row_stride, uint64_t n, uint32_t m, void *d_out);
+size_t pq_prefilter_table_bytes(uint32_t m, uint32_t nq);
+uint32_t pq_prefilter_grid(int num_cus, uint32_t nq, uint32_t *n_slabs_out);
+size_t pq_prefilter_wlists_counts_bytes(uint32_t grid);
+size_t pq_prefilter_wlists_bytes(uint32_t grid, uint32_t wcap);
+int32_t launch_pq_lut8(hipStream_t st, const void *d_luts, uint32_t q_stride, uint32_t nq, uint32_t m, uint32_t ncent, const uint64_t *d_gthr, void *d_table8,
+                       int32_t *d_thr, float *d_band);
+int32_t launch_pq_prefilter(hipStream_t st, const ScanArgs &a, const void *d_rot, const void *d_table8, const int32_t *d_thr, uint32_t nq, int num_cus,
+                            void *d_wlists, uint32_t wcap, uint32_t *grid_out);
 int32_t launch_split_refine(hipStream_t st, const uint64_t *d_cand, const uint32_t *d_cand_cnt, uint32_t cap, const float *d_band, uint32_t nq, uint32_t top,
                             const float *d_scales, float *d_thr);
 size_t split_wlists_bytes(int num_cus);

@@ -134,11 +134,14 @@ __global__ __launch_bounds__(PQ_BLOCK) void pq_scan_kernel(const ScanArgs a, uin
     constexpr int NW = PQ_BLOCK / WAVE;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (a.run_if && *a.run_if == 0) return;      // the exact pass behind the 6-bit prefilter was not needed (pq_prefilter.hip)
     // block -> (slab, query): query varies fastest
     const uint32_t q = blockIdx.x % a.nq;
     const uint32_t slab = blockIdx.x / a.nq;
     const uint32_t m = a.pq_m, ncent = a.pq_ncent;
-    const float *glut = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(a.queries) + (uint64_t)q * a.q_stride);
+    const uint32_t qsrc = a.q_map ? a.q_map[q] : q;          // (packed exact pass: list q belongs to query q_map[q] of the batch)
+    if (qsrc == 0xFFFFFFFFu) return;
+    const float *glut = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(a.queries) + (uint64_t)qsrc * a.q_stride);
     if (LDS_LUT) {
         const uint4 *src = reinterpret_cast<const uint4 *>(glut);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);

@@ -128,16 +128,16 @@ __global__ void sp_pack_queries_kernel(const float *q, uint32_t nq, uint32_t dim
     chunk[sp_unit(nt, 0, kq, n)] = *reinterpret_cast<const uint4 *>(&h);
     chunk[sp_unit(nt, 1, kq, n)] = *reinterpret_cast<const uint4 *>(&l);
 }
-// thr[q] in accumulator units: (exact k-th best of the sample - band) * scale; -inf when the sample has no k-th best (everything is a candidate,
-// the buffers overflow, the exact scan takes over).  band[q] = rel_band * row_norm_max * |q| (score units).
+// thr[q] in accumulator units: (exact k-th best of the sample - band) * scale.  band[q] = rel_band * row_norm_max * |q| (score units).
 __global__ void sp_thresholds_kernel(const uint64_t *gthr, const float *qnorm, uint32_t nq, float rel_band, float row_norm_max, const float *scales,
                                      float *thr, float *band) {
     const uint32_t q = threadIdx.x;                   // blockDim.x = queries of the tile (128 | 256)
     if (q >= nq) { thr[q] = __builtin_inff(); band[q] = 0.0f; return; }
     const float b = rel_band * row_norm_max * qnorm[q];
-    band[q] = b;
     const uint64_t k = gthr[q];
-    thr[q] = k ? (key_score(k) - b) * scales[1] : -__builtin_inff();
+    // no bound (the sample holds fewer than k live rows): no candidates for this query, and its infinite band sends it - alone - to the exact scan
+    band[q] = k ? b : __builtin_inff();
+    thr[q] = k ? (key_score(k) - b) * scales[1] : __builtin_inff();
 }
 
 typedef __attribute__((address_space(3))) unsigned char sp_lds_byte;
@@ -892,7 +892,7 @@ __global__ __launch_bounds__(SEL_BLOCK) void sp_refine_kernel(const uint64_t *ca
     __shared__ uint64_t sh_kth;
     const uint32_t q = blockIdx.x;
     const uint32_t raw = cand_cnt[q];
-    if (raw > cap || raw < top) return;                      // overflow is sp_select_kernel's to report; fewer than k rows prove nothing
+    if (raw > cap || raw < top || !(band[q] < 3.0e38f)) return;   // overflow is sp_select_kernel's to report; fewer than k rows prove nothing
     block_kth_key(cand + (uint64_t)q * cap, raw, (int)top, sh, &sh_kth);
     if (threadIdx.x == 0 && sh_kth) {
         const float t = (key_score(sh_kth) - 2.0f * band[q]) * scales[1];
@@ -911,7 +911,7 @@ __global__ __launch_bounds__(SEL_BLOCK) void sp_select_kernel(const uint64_t *ca
     const uint32_t raw = cand_cnt[q];
     // a wave list of the scan overflowed (its dropped entries could be anybody's), or this query's candidate buffer did: the pass cannot be
     // trusted for this query, which takes the exact scan (the other queries of the batch keep their lists)
-    if (*tile_overflow || raw > cap) {
+    if (*tile_overflow || raw > cap || !(band[q] < 3.0e38f)) {      // (an infinite band: the query had no usable threshold)
         if (threadIdx.x == 0) { ovf_q[q] = 1; ver_cnt[q] = 0; }
         return;
     }
@@ -1127,6 +1127,16 @@ int32_t launch_split_regroup(hipStream_t st, const ScanArgs &a, const void *d_wl
     hipLaunchKernelGGL(sp_regroup_kernel, dim3((n_lists + RG_LISTS - 1) / RG_LISTS), dim3(256), 0, st,
                        (const uint4 *)((const unsigned char *)d_wlists + split_wlists_counts_bytes(num_cus)), (const uint32_t *)d_wlists, (uint32_t)SP_WCAP, n_lists,
                        a.del, d_cand, d_cand_cnt, cap, d_overflow);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+// any set of per-wave candidate lists (the PQ prefilter's, pq_prefilter.hip) -> per-query lists
+int32_t launch_regroup_lists(hipStream_t st, const DeletedView &del, const void *d_wlist, const uint32_t *d_wcnt, uint32_t wcap, uint32_t n_lists, uint64_t *d_cand,
+                             uint32_t *d_cand_cnt, uint32_t cap, int *d_overflow) {
+    if (n_lists == 0) return QMX_OK;
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(sp_regroup_kernel, dim3((n_lists + RG_LISTS - 1) / RG_LISTS), dim3(256), 0, st, (const uint4 *)d_wlist, d_wcnt, wcap, n_lists, del, d_cand,
+                       d_cand_cnt, cap, d_overflow);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }
