@@ -3,18 +3,22 @@
 // Why.  `EncodedVectorsPQ::score_point` (lib/quantization/src/encoded_vectors_pq.rs:409-493) is m table gathers per (row, query):
 // 96 random 4-byte reads of a 96 KiB LUT at m = 96.  With one lane per row and the f32 LUT of ONE query in LDS (pq.hip, pq_scan_kernel)
 // the gathers of a wave land on random banks: counters say 68 % of the LDS cycles are conflicts, and a 32-query scan of 10 M rows takes
-// 3.2 ms for 0.96 GB of codes (0.04 of the HBM stream).  The f32 sums cannot be reordered (score_point_sse's four lane accumulators are
-// sequential in chunk order: the bits), so the exact kernel cannot be laid out conflict-free.  An approximate integer score can:
-//   * the LUT of a query is quantised to 6 bits per entry with ONE step for the whole query: LUT[c][j] = lo_c + step (q_cj + d), |d| <= 1/2,
+// 2 x 3.2 ms for 0.96 GB of codes (0.04 of the HBM stream).  The f32 sums cannot be reordered (score_point_sse's four lane accumulators
+// are sequential in chunk order: the bits), so the exact kernel cannot be laid out conflict-free.  An approximate integer score can:
+//   * the LUT of a query is quantised to 8 bits per entry with ONE step for the whole query: LUT[c][j] = lo_c + step (q_cj + d), |d| <= 1/2,
 //     so   exact score = sum_c lo_c + step (A + D),  A = sum_c q_{c, code_c} (an integer), |D| <= m / 2: a rigorous band around A;
-//   * four queries share a dword (one byte each): ONE ds_read_b32 per (row, chunk) serves four queries, and the byte-parallel add
-//     `acc += dword` sums four of them at once (4 x 63 < 256: no carry between bytes; widened to 16 bits every fourth chunk);
+//   * four queries share a dword (one byte each): ONE ds_read_b32 per (row, chunk) serves four queries;
 //   * conflict-free by construction: the LDS table is [code][slot], slot = chunk (+ chunks 0..30 once more behind the last), and lane i
 //     of a 32-lane group visits the chunks of ITS row in the rotated order i, i + 1, i + 2, ... (mod m_pad): at every step the 32 lanes
 //     of a group read 32 consecutive slots = 32 different banks, whatever their codes (MI355X guide, LDS table: ds_read_b32 is served in
 //     two groups of 32 lanes over 32 banks).  The rotation lives in the data: a derived copy of the code block (`pq_rotate_kernel`, built
 //     once per segment, m_pad bytes per row) stores byte t of row r as the code of chunk (t + r mod 32) mod m_pad, so a lane's code bytes
-//     sit at fixed register positions and the gather address is code * stride + 4 i (+ 4 t as the instruction's immediate offset).
+//     sit at fixed register positions and the gather address is code * stride + 4 i (+ 4 t as the instruction's immediate offset);
+//   * the byte sums cost no vector instruction: the four dwords a lane gathers for four consecutive chunks ARE the A operand of one
+//     v_mfma_i32_16x16x64_i8 (16 bytes per lane), and a constant 0 / 1 B operand routes byte k of lane group g to output column 4 g + k:
+//     D[m][4 g + k] += sum of the bytes of query k in the 4 dwords of lane m + 16 g.  The matrix core is used as a 64-lane byte-unpacking
+//     adder with i32 accumulators (entries are stored less 128: the operand is signed), which leaves two vector instructions per gather
+//     (code extraction, address) - the integer ALU rate (one wave instruction per clock and CU) is what bounds this kernel.
 // The approximate score is never returned.  Like the f32 prefilter (scan_split.hip): a strided sample scored exactly gives T_q <= the final
 // k-th best score; rows with A >= (T_q - L) / step - band become candidates (per-wave lists, plain stores); `sp_select_kernel` keeps those
 // within two bands of the k-th best approximate score; `pq_pair_kernel` re-scores them in the reference's order and `sort_scored_kernel`
@@ -22,8 +26,8 @@
 // takes the exact scan, alone (api.hip).
 //
 // Roofline: the stream is m_pad bytes per row and 4-query group (through L2 for all groups but the first: blocks of one row slab and
-// different query groups are placed on the same XCD, see `pqf_block_role`); the bound that binds is LDS issue + VALU: one ds_read_b32 and
-// ~4 vector instructions per (row, chunk, 4 queries).
+// different query groups are placed on the same XCD, see `pqf_block_role`); what binds from 8 queries up is LDS issue (2 cycles per
+// ds_read_b32) and the two vector instructions per gather.
 #include <algorithm>
 #include <atomic>
 
@@ -33,8 +37,12 @@ namespace qmx {
 
 constexpr int PQF_THREADS = 1024;
 constexpr int PQF_WAVES = PQF_THREADS / 64;
-constexpr int PQF_QBITS = 6;                      // bits per quantised LUT entry: four entries add up inside one byte
-constexpr int PQF_QMAX = (1 << PQF_QBITS) - 1;
+constexpr int PQF_QMAX = 255;                     // quantised LUT entries 0..255, stored less 128 (the matrix core's int8 operand is signed)
+typedef int pqf_i32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const int pqf_lds_int;
+typedef __attribute__((address_space(3))) unsigned char pqf_lds_byte;
+// dwords per code row of the LDS table: the chunks, chunks 0..31 once more behind them, rounded up to a power of two (the gather address is a shift + or)
+__host__ __device__ constexpr uint32_t pqf_slots(uint32_t m_pad) { return m_pad <= 32 ? 64u : 128u; }
 
 // ---- the rotated copy: out[(T * NP + p) * 32 + i] = 16 code bytes of row 32 T + i: byte e = code of chunk (16 p + e + i) mod m_pad
 // (0 for chunks >= m and rows >= n: their table entries are 0) ----
@@ -73,14 +81,14 @@ int32_t launch_pq_rotate(hipStream_t st, const void *codes, uint64_t row_stride,
     return QMX_OK;
 }
 
-// ---- per query: the 6-bit table, the candidate threshold and the band ----
+// ---- per query: the 8-bit table, the candidate threshold and the band ----
 // One block per query, thread j = centroid j.  lut = the query's f32 LUT [m][ncent] (EncodedQueryPQ, encode_query :519-541).
-//   lo_c = min_j LUT[c][j], R = max_c (max_j - min_j), step = R / 63, q_cj = rint((LUT[c][j] - lo_c) / step)  in 0..63
+//   lo_c = min_j LUT[c][j], R = max_c (max_j - min_j), step = R / 255, q_cj = rint((LUT[c][j] - lo_c) / step)  in 0..255
 //   exact score (real arithmetic) = L + step (A + D), L = sum_c lo_c, |D| <= 0.50002 m  (0.5 per chunk + the f32 rounding of the quotient)
 //   the f32 score the exact kernels return differs from the real sum by at most E = (m + 1) 2^-24 sum_c max_j |LUT[c][j]|
 //   => a row with exact score >= T has A >= (T - L - E) / step - 0.50002 m =: thr (floored, minus 1);   band (A units) = 0.50002 m + E / step + 1
-// table8: bytes, [group][code][slots] dwords, byte k of a dword = query 4 group + k; slots >= m_pad repeat chunks 0..31.  The caller zeroes the
-// table first (padding chunks, missing centroids and the unused query bytes of the last group must read 0).
+// table8: bytes (q - 128 as int8), [group][code][slots] dwords, byte k of a dword = query 4 group + k; slots >= m_pad repeat chunks 0..31.  The
+// caller fills the table with 0x80 (= 0) first: padding chunks, missing centroids and the unused query bytes of the last group must read 0.
 __global__ __launch_bounds__(256) void pq_lut8_kernel(const unsigned char *luts, uint32_t q_stride, uint32_t nq, uint32_t m, uint32_t ncent, uint32_t m_pad,
                                                       const uint64_t *gthr, uint8_t *table8, int32_t *thr, float *band) {
     __shared__ float sh_lo[128], sh_red[3][4];
@@ -88,7 +96,7 @@ __global__ __launch_bounds__(256) void pq_lut8_kernel(const unsigned char *luts,
     const uint32_t q = blockIdx.x, j = threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float *lut = reinterpret_cast<const float *>(luts + (uint64_t)q * q_stride);
-    const uint32_t slots = m_pad + 32;
+    const uint32_t slots = pqf_slots(m_pad);
     if (j == 0) sh_bad = 0;
     __syncthreads();
     float R = 0.0f, E = 0.0f;
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(256) void pq_lut8_kernel(const unsigned char *luts,
             const float v = lut[(uint64_t)c * ncent + j];
             float x = __builtin_rintf((v - sh_lo[c]) * inv_step);
             x = __builtin_fminf(__builtin_fmaxf(x, 0.0f), (float)PQF_QMAX);
-            const uint8_t b = flat ? (uint8_t)0 : (uint8_t)x;
+            const uint8_t b = (uint8_t)((flat ? 0u : (uint32_t)x) ^ 0x80u);
             tab[(uint64_t)c * 4] = b;
             if (c < 32) tab[(uint64_t)(m_pad + c) * 4] = b;
         }
@@ -170,7 +178,7 @@ __device__ __forceinline__ void pqf_block_role(uint32_t b, uint32_t n_groups, ui
 template <int NP /* 16-byte pieces of a rotated row: m_pad = 16 NP */>
 __global__ __launch_bounds__(PQF_THREADS, 1) void pq_prefilter_kernel(const ScanArgs a, const PqfArgs f) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr uint32_t M_PAD = 16 * NP, SLOTS = M_PAD + 32, STRIDE = SLOTS * 4;
+    constexpr uint32_t M_PAD = 16 * NP, SLOTS = pqf_slots(M_PAD), SH = SLOTS == 64 ? 8 : 9;      // a code row = SLOTS dwords = 1 << SH bytes
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t slab, group;
@@ -180,9 +188,18 @@ __global__ __launch_bounds__(PQF_THREADS, 1) void pq_prefilter_kernel(const Scan
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
         for (uint32_t i = threadIdx.x; i < 256 * SLOTS / 4; i += PQF_THREADS) dst[i] = src[i];
     }
-    const int thr0 = f.thr[group * 4 + 0], thr1 = f.thr[group * 4 + 1], thr2 = f.thr[group * 4 + 2], thr3 = f.thr[group * 4 + 3];
+    // the routing operand: B[K][n] = 1 iff n == 4 (K / 16) + K % 4.  Lane n + 16 kg holds B[16 kg .. 16 kg + 15][n]: ones at bytes k, 4 + k, 8 + k, 12 + k
+    // when n / 4 == kg (k = n % 4), zeros otherwise.
+    const uint32_t bword = (((uint32_t)lane & 15u) >> 2) == ((uint32_t)lane >> 4) ? (1u << (8 * ((uint32_t)lane & 3u))) : 0u;
+    const pqf_i32x4 B = {(int)bword, (int)bword, (int)bword, (int)bword};
+    // D[r] of this lane = the sum, over the chunks so far, of query (lane & 3)'s entries for the row of lane dl0 + r
+    const uint32_t dl0 = 4 * ((uint32_t)lane >> 4) + 16 * (((uint32_t)lane & 15u) >> 2);
+    const uint32_t my_q = group * 4 + ((uint32_t)lane & 3u);
+    const int bias = 128 * (int)M_PAD;                        // every slot of the table holds (entry - 128)
+    const int my_thr = f.thr[my_q] - bias;
     __syncthreads();
-    const uint32_t i = (uint32_t)lane & 31u, i4 = i * 4;
+    const uint32_t i = (uint32_t)lane & 31u;
+    const uint32_t i4 = i * 4 + (uint32_t)(uintptr_t)(pqf_lds_byte *)smem;     // (the table starts at LDS address 0: 4 i stays below the row pitch)
     const uint32_t wave_global = blockIdx.x * PQF_WAVES + (uint32_t)wave;
     uint4 *my_list = f.wlist + (uint64_t)wave_global * f.wcap;
     uint32_t wcount = 0;
@@ -192,37 +209,41 @@ __global__ __launch_bounds__(PQF_THREADS, 1) void pq_prefilter_kernel(const Scan
         uint4 w[NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p) w[p] = f.rot[(T * NP + p) * 32 + i];
-        uint32_t acc8 = 0, lo = 0, hi = 0;
+        pqf_i32x4 acc = {0, 0, 0, 0};
 #pragma unroll
-        for (int t = 0; t < (int)M_PAD; ++t) {
-            const uint4 &piece = w[t / 16];
-            const uint32_t d = (t / 4) % 4 == 0 ? piece.x : (t / 4) % 4 == 1 ? piece.y : (t / 4) % 4 == 2 ? piece.z : piece.w;
-            const uint32_t code = (d >> (8 * (t % 4))) & 0xFFu;
-            const uint32_t addr = code * STRIDE + i4;
-            acc8 += *reinterpret_cast<const uint32_t *>(smem + addr + 4 * t);
-            if (t % 4 == 3) {      // four 6-bit entries per byte so far: widen before the next could carry
-                lo += acc8 & 0x00FF00FFu;
-                hi += (acc8 >> 8) & 0x00FF00FFu;
-                acc8 = 0;
+        for (int t4 = 0; t4 < (int)M_PAD / 4; ++t4) {
+            const uint4 &piece = w[t4 / 4];
+            const uint32_t d = t4 % 4 == 0 ? piece.x : t4 % 4 == 1 ? piece.y : t4 % 4 == 2 ? piece.z : piece.w;
+            pqf_i32x4 g;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // byte e of d, times the row pitch, or'ed with the lane's slot offset (4 i < 128 <= pitch): two vector instructions per gather
+                // (written out: the compiler's own choice for the two low bytes is shift + and + add)
+                uint32_t addr;
+                if (8 * e < (int)SH) {
+                    const uint32_t shifted = d << (SH - 8 * e);
+                    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(addr) : "v"(shifted), "s"(0xFFu << SH), "v"(i4));
+                } else {
+                    const uint32_t code = e == 3 ? d >> 24 : (d >> (8 * e)) & 0xFFu;
+                    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(addr) : "v"(code), "s"(SH), "v"(i4));
+                }
+                // (an LDS address outright - the table's base is folded into i4 -, so that the slot offset becomes the instruction's immediate)
+                g[e] = *reinterpret_cast<pqf_lds_int *>(addr + 4 * (4 * t4 + e));
             }
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(g, B, acc, 0, 0, 0);
         }
-        const uint64_t id64 = T * 32 + i;
-        const bool valid = id64 < a.n_cand;
-        const uint32_t id = (uint32_t)id64;
-        const int A0 = (int)(lo & 0xFFFFu), A2 = (int)(lo >> 16), A1 = (int)(hi & 0xFFFFu), A3 = (int)(hi >> 16);
-        const bool h0 = valid && A0 >= thr0, h1 = valid && A1 >= thr1, h2 = valid && A2 >= thr2, h3 = valid && A3 >= thr3;
-        if (__ballot(h0 || h1 || h2 || h3)) {
-            auto emit = [&](bool h, int A, uint32_t k) {
+        if (__ballot(acc[0] >= my_thr || acc[1] >= my_thr || acc[2] >= my_thr || acc[3] >= my_thr)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint64_t id64 = wt * 64 + dl0 + (uint32_t)r;
+                const bool h = id64 < a.n_cand && acc[r] >= my_thr;
                 const uint64_t mk = __ballot(h);
-                if (!mk) return;
-                const uint32_t pos = wcount + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull));
-                if (h && pos < f.wcap) my_list[pos] = make_uint4(~id, score_to_ord((float)A), (group * 4 + k), 0u);
-                wcount += (uint32_t)__popcll(mk);
-            };
-            emit(h0, A0, 0);
-            emit(h1, A1, 1);
-            emit(h2, A2, 2);
-            emit(h3, A3, 3);
+                if (mk) {
+                    const uint32_t pos = wcount + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull));
+                    if (h && pos < f.wcap) my_list[pos] = make_uint4(~(uint32_t)id64, score_to_ord((float)(acc[r] + bias)), my_q, 0u);
+                    wcount += (uint32_t)__popcll(mk);
+                }
+            }
         }
     }
     if (lane == 0) f.wcnt[wave_global] = wcount;
@@ -230,7 +251,7 @@ __global__ __launch_bounds__(PQF_THREADS, 1) void pq_prefilter_kernel(const Scan
 
 size_t pq_prefilter_table_bytes(uint32_t m, uint32_t nq) {
     const uint32_t m_pad = (m + 31) / 32 * 32;
-    return (size_t)((nq + 3) / 4) * 256 * (m_pad + 32) * 4;
+    return (size_t)((nq + 3) / 4) * 256 * pqf_slots(m_pad) * 4;
 }
 uint32_t pq_prefilter_grid(int num_cus, uint32_t nq, uint32_t *n_slabs_out) {
     const uint32_t n_groups = (nq + 3) / 4;
@@ -245,7 +266,7 @@ int32_t launch_pq_lut8(hipStream_t st, const void *d_luts, uint32_t q_stride, ui
                        int32_t *d_thr, float *d_band) {
     const uint32_t m_pad = (m + 31) / 32 * 32;
     QMX_REQUIRE(pq_prefilter_shape_ok(m, ncent), QMX_ERR_NOT_SUPPORTED, "PQ prefilter: m = %u chunks / %u centroids", m, ncent);
-    QMX_HIP(hipMemsetAsync(d_table8, 0, pq_prefilter_table_bytes(m, nq), st));
+    QMX_HIP(hipMemsetAsync(d_table8, 0x80, pq_prefilter_table_bytes(m, nq), st));
     // the unused query slots of the last group never produce candidates
     const uint32_t padded = (nq + 3) / 4 * 4;
     if (padded != nq) QMX_HIP(hipMemsetAsync(d_thr + nq, 0x7F, (size_t)(padded - nq) * 4, st));
@@ -269,7 +290,7 @@ int32_t launch_pq_prefilter(hipStream_t st, const ScanArgs &a, const void *d_rot
     f.wlist = (uint4 *)((unsigned char *)d_wlists + pq_prefilter_wlists_counts_bytes(grid));
     f.wcap = wcap;
     if (grid_out) *grid_out = grid;
-    const size_t lds = (size_t)256 * (m_pad + 32) * 4;
+    const size_t lds = (size_t)256 * pqf_slots(m_pad) * 4;
     auto k2 = pq_prefilter_kernel<2>;
     auto k4 = pq_prefilter_kernel<4>;
     auto k6 = pq_prefilter_kernel<6>;
@@ -278,7 +299,7 @@ int32_t launch_pq_prefilter(hipStream_t st, const ScanArgs &a, const void *d_rot
     static std::atomic<uint64_t> attr_done{0};         // one bit per device
     if (dev < 64 && !(attr_done.load(std::memory_order_relaxed) & (1ull << dev))) {
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k6), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_done.fetch_or(1ull << dev, std::memory_order_relaxed);
     }

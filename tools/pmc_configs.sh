@@ -21,7 +21,7 @@ print("rocprofv3 --pmc (two passes) over tools/bench_configs.py --configs $CFG $
 for db in sorted(glob.glob("$OUT/g*/**/*.db", recursive=True)):
     c = sqlite3.connect(db)
     try:
-        rows = list(c.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection where kernel_name like '%scan%' or kernel_name like '%rows_kernel%' group by kernel_name, counter_name"))
+        rows = list(c.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection where kernel_name like '%scan%' or kernel_name like '%rows_kernel%' or kernel_name like '%prefilter%' group by kernel_name, counter_name"))
     except Exception as e:
         print(db, e); continue
     for n, cn, k, avg in rows:
