@@ -543,6 +543,27 @@ QMX_API int32_t qmx_custom_score_points(qmx_query *examples, const qmx_custom_qu
 QMX_API int32_t qmx_custom_search_topk(qmx_query *examples, const qmx_custom_query *queries, uint32_t n_queries, uint32_t top,
                                        const uint32_t *ids, uint64_t n_ids, qmx_scored_point *out, uint32_t *out_counts);
 
+/* `GraphLayers::search` with a custom query as the points scorer: raw_scorer.rs:228-333 builds a CustomQueryScorer (dense storages), a
+ * QuantizedCustomQueryScorer (SQ / PQ / BQ: quantized/quantized_custom_query_scorer.rs:13-113) or a TurboCustomQueryScorer
+ * (query_scorer/turbo_custom_query_scorer.rs:17-113) for whatever storage `ex` is bound to - every example encoded as that storage's query -
+ * and graph_layers.rs:108-149 walks with it.  Search qi = custom query queries[qi]; the walk scores a hop candidate against every example of
+ * the query and combines (`score_by`).  Same results contract as qmx_hnsw_search; qmx_custom_set_coefficients first for feedback queries. */
+QMX_API int32_t qmx_custom_hnsw_search(const qmx_hnsw *g, qmx_query *ex, const qmx_custom_query *queries, uint32_t n_queries, uint32_t top,
+                                       uint32_t ef, qmx_scored_point *out, uint32_t *out_counts, const volatile uint8_t *is_stopped,
+                                       qmx_counters *counters);
+
+/* Custom queries whose examples are MULTI-VECTORS (`MultiCustomQueryScorer`, query_scorer/multi_custom_query_scorer.rs:19-130; over quantized
+ * inner rows `QuantizedMultiCustomQueryScorer`, quantized/quantized_multi_custom_query_scorer.rs:19-96): similarity(example, point) =
+ * score_max_similarity (query_scorer/mod.rs:70-97), then the query's score_by.  `inner` holds the inner vectors of all examples; example e = inner
+ * query vectors [example_first[e], example_first[e + 1]); queries[i].first / n_a / n_b count EXAMPLES; points as in qmx_multi_score_points. */
+QMX_API int32_t qmx_multi_custom_score_points(qmx_query *inner, const uint32_t *example_first, uint32_t n_examples,
+                                              const qmx_custom_query *queries, uint32_t n_queries, const uint64_t *point_offsets,
+                                              uint32_t n_points, const uint32_t *ids, uint32_t n, float *scores /* [n_queries][n] */);
+QMX_API int32_t qmx_multi_custom_search_topk(qmx_query *inner, const uint32_t *example_first, uint32_t n_examples,
+                                             const qmx_custom_query *queries, uint32_t n_queries, const uint64_t *point_offsets,
+                                             uint32_t n_points, const uint64_t *point_deleted, uint64_t n_deleted_bits, uint32_t top,
+                                             const uint32_t *ids, uint64_t n_ids, qmx_scored_point *out, uint32_t *out_counts);
+
 /* k-way merge of per-segment / per-GPU result lists = `BatchResultAggregator`
  * (lib/shard/src/search_result_aggregator.rs:50-121) with all point versions equal:
  * lists[(l * nq + qi) * k ..], idx already globalised by the caller.  Items are pushed in list

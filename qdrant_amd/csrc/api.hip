@@ -231,6 +231,7 @@ struct qmx_query {
     uint32_t timing_launches = 0;
     DevBuf partial, out, counts, ids, scores, misc, enc, bounds, gthr;
     DevBuf mv_qfirst, mv_offsets, mv_deleted;        // multi-vector MaxSim: query ranges, point offsets, point-level deleted bits
+    DevBuf cq_multi;          // custom queries over multi-vector points: the combined scores (cq_scores holds the per-example MaxSim rows)
     DevBuf cq_sims, cq_scores, cq_desc, cq_coefs;   // custom queries: example similarities, combined scores, descriptors, feedback coefficients
     uint32_t n_cq_coefs = 0;
     DevBuf cand, cand_cnt, cand_ids;   // qmx_search_quantized: oversampled candidates of the quantized stage
@@ -1311,6 +1312,7 @@ int32_t qmx_query_destroy(qmx_query *q) {
     q->mv_deleted.release();
     q->cq_scores.release();
     q->cq_desc.release();
+    q->cq_multi.release();
     q->sp_bq.release(); q->sp_f32.release(); q->sp_cand.release(); q->sp_cnt.release(); q->sp_ver.release(); q->sp_vscores.release(); q->sp_sample.release(); q->sp_wl.release(); q->xcnt.release(); q->tq_rot.release(); q->sp_plan.release(); q->sp_fq.release(); q->pq_table.release(); q->sh_lists.release(); q->sh_out.release();
     if (q->sh_done) (void)hipEventDestroy(q->sh_done);
     q->cand.release();
@@ -2695,8 +2697,28 @@ struct MultiWalk {
     DeletedView del;
 };
 
+// a custom query (Recommend / Discover / Context / Feedback) as the walk's scorer (qmx_custom_hnsw_search): the descriptors on the device, the
+// largest number of examples one query has
+struct CustomWalk {
+    const qmx_custom_query *d_desc;
+    const float *d_coefs;
+    uint32_t n_queries, max_examples;
+};
+
 static int32_t launch_hnsw(const qmx_query *q, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
     const qmx_segment *s = q->seg;
+    if (a.cq_desc) {
+        if (s->dtype <= QMX_DTYPE_U8) {
+            QMX_REQUIRE(s->fast_layout(), QMX_ERR_NOT_SUPPORTED, "adopted device block is not 16-byte aligned");
+            return launch_hnsw_custom_dense(q->stream, (int)s->dtype, (int)s->distance, a, h, grid, per_cu);
+        }
+        if (s->dtype == QMX_DTYPE_SQ_U8) return launch_hnsw_custom_sq(q->stream, (int)s->distance, a, h, grid, per_cu);
+        if (s->dtype == QMX_DTYPE_PQ) return launch_hnsw_custom_pq(q->stream, a, h, grid, per_cu);
+        if (s->dtype == QMX_DTYPE_BQ) return launch_hnsw_custom_bq(q->stream, a, h, grid, per_cu);
+        if (s->dtype == QMX_DTYPE_TQ) return launch_hnsw_custom_tq(q->stream, a, h, grid, per_cu);
+        set_error("dtype %u not built yet", s->dtype);
+        return QMX_ERR_NOT_SUPPORTED;
+    }
     if (a.mv_offsets) {
         if (s->dtype <= QMX_DTYPE_U8) {
             QMX_REQUIRE(s->fast_layout(), QMX_ERR_NOT_SUPPORTED, "adopted device block is not 16-byte aligned");
@@ -2722,11 +2744,15 @@ static int32_t launch_hnsw(const qmx_query *q, const ScanArgs &a, const HnswArgs
 
 static int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef, qmx_scored_point *d_out,
                             uint32_t *d_counts, uint32_t *d_scored, bool timed, bool acorn = false, const MultiWalk *mw = nullptr,
-                            const ExpandedOut *xo = nullptr) {
+                            const ExpandedOut *xo = nullptr, const CustomWalk *cw = nullptr) {
     const qmx_segment *s = q->seg;
     ScanArgs a;
     fill_args(q, 0, q->nq, a);
-    const uint32_t n_searches = mw ? mw->n_queries : q->nq;
+    const uint32_t n_searches = mw ? mw->n_queries : cw ? cw->n_queries : q->nq;
+    if (cw) {
+        a.cq_desc = cw->d_desc;
+        a.cq_coefs = cw->d_coefs;
+    }
     if (mw) {
         a.mv_offsets = mw->d_offsets;
         a.mv_qfirst = mw->d_qfirst;
@@ -2753,6 +2779,10 @@ static int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint3
     // A PQ LUT of more than half the LDS leaves one search per CU; the walk is a chain of dependent memory round trips,
     // so many searches per CU with the LUT read through L2 win (measured: tools/bench_hnsw.py)
     if (s->dtype == QMX_DTYPE_PQ && q->q_stride > 16 * 1024 && !option(OPT_HNSW_PQ_LDS_LUT)) h.lds_query_bytes = 0;
+    if (cw) {   // [32-byte header][the examples' entries]: staged when they fit a modest share of the LDS, read through L2 otherwise (PQ LUTs always)
+        const uint64_t need = 32 + (uint64_t)std::max<uint32_t>(cw->max_examples, 1) * q->q_stride;
+        h.lds_query_bytes = (need <= 48 * 1024 && h.lds_query_bytes != 0) ? (uint32_t)need : 32;
+    }
     h.log_cap = HNSW_LOG_CAP;
     {   // tests: force the whole-bitmap clear path
         const int64_t v = option(OPT_HNSW_LOG_CAP);
@@ -3128,7 +3158,10 @@ int32_t qmx_rescore(qmx_query *q, const uint32_t *ids, const uint32_t *counts, u
 // ---------------------------------------------------------------------------------------------
 // custom queries (custom_query.hip)
 // ---------------------------------------------------------------------------------------------
-static int32_t custom_prepare(qmx_query *ex, const qmx_custom_query *queries, uint32_t n_queries, const uint32_t *d_ids, uint64_t n) {
+// `n_examples`: how many examples the batch holds (for multi-vector examples: the number of example multi-vectors, not of inner vectors)
+static int32_t custom_validate(const qmx_query *ex, const qmx_custom_query *queries, uint32_t n_queries, uint32_t n_examples, uint32_t *max_examples) {
+    QMX_REQUIRE(!is_device_ptr(queries), QMX_ERR_BAD_ARG, "the custom query descriptors are a host array (they are validated here)");
+    if (max_examples) *max_examples = 0;
     for (uint32_t i = 0; i < n_queries; ++i) {
         const qmx_custom_query &c = queries[i];
         QMX_REQUIRE(c.kind <= QMX_CUSTOM_FEEDBACK, QMX_ERR_BAD_ARG, "bad custom query kind %u", c.kind);
@@ -3138,8 +3171,14 @@ static int32_t custom_prepare(qmx_query *ex, const qmx_custom_query *queries, ui
         const uint64_t ne = c.kind <= QMX_CUSTOM_RECO_SUM_SCORES ? (uint64_t)c.n_a + c.n_b : (uint64_t)c.n_a + 2ull * c.n_b;
         QMX_REQUIRE(c.kind != QMX_CUSTOM_DISCOVER || c.n_a == 1, QMX_ERR_BAD_ARG, "a discover query has exactly one target");
         QMX_REQUIRE(c.kind != QMX_CUSTOM_CONTEXT || c.n_a == 0, QMX_ERR_BAD_ARG, "a context query has pairs only");
-        QMX_REQUIRE((uint64_t)c.first + ne <= ex->nq, QMX_ERR_OUT_OF_BOUNDS, "custom query %u reaches past the %u examples of the batch", i, ex->nq);
+        QMX_REQUIRE((uint64_t)c.first + ne <= n_examples, QMX_ERR_OUT_OF_BOUNDS, "custom query %u reaches past the %u examples of the batch", i, n_examples);
+        if (max_examples) *max_examples = std::max<uint32_t>(*max_examples, (uint32_t)ne);
     }
+    return QMX_OK;
+}
+
+static int32_t custom_prepare(qmx_query *ex, const qmx_custom_query *queries, uint32_t n_queries, const uint32_t *d_ids, uint64_t n) {
+    QMX_TRY(custom_validate(ex, queries, n_queries, ex->nq, nullptr));
     QMX_REQUIRE((uint64_t)ex->nq * n * 4 <= (48ull << 30), QMX_ERR_NOT_SUPPORTED, "example similarity matrix of %llu x %u floats is too large",
                 (unsigned long long)n, ex->nq);
     QMX_TRY(ex->cq_sims.reserve((size_t)ex->nq * n * 4));
@@ -3165,7 +3204,6 @@ int32_t qmx_custom_set_coefficients(qmx_query *ex, const float *coefs, uint32_t 
 
 int32_t qmx_custom_score_points(qmx_query *ex, const qmx_custom_query *queries, uint32_t n_queries, const uint32_t *ids, uint32_t n, float *scores) {
     QMX_REQUIRE(ex && (n_queries == 0 || queries) && (n == 0 || (ids && scores)), QMX_ERR_BAD_ARG, "NULL argument");
-    QMX_REQUIRE(ex->seg->dtype <= QMX_DTYPE_U8, QMX_ERR_NOT_SUPPORTED, "custom queries score original vectors (dense storages)");
     QMX_HIP(hipSetDevice(ex->device));
     if (n == 0 || n_queries == 0) return QMX_OK;
     const void *d_ids = nullptr;
@@ -3178,7 +3216,6 @@ int32_t qmx_custom_score_points(qmx_query *ex, const qmx_custom_query *queries, 
 int32_t qmx_custom_search_topk(qmx_query *ex, const qmx_custom_query *queries, uint32_t n_queries, uint32_t top, const uint32_t *ids, uint64_t n_ids,
                                qmx_scored_point *out, uint32_t *out_counts) {
     QMX_REQUIRE(ex && (n_queries == 0 || queries) && out && out_counts, QMX_ERR_BAD_ARG, "NULL argument");
-    QMX_REQUIRE(ex->seg->dtype <= QMX_DTYPE_U8, QMX_ERR_NOT_SUPPORTED, "custom queries score original vectors (dense storages)");
     QMX_REQUIRE(top >= 1 && top <= MAX_TOP, QMX_ERR_NOT_SUPPORTED, "top %u not in 1..%u", top, MAX_TOP);
     QMX_HIP(hipSetDevice(ex->device));
     if (n_queries == 0) return QMX_OK;
@@ -3204,6 +3241,51 @@ int32_t qmx_custom_search_topk(qmx_query *ex, const qmx_custom_query *queries, u
     if (!out_dev) QMX_TRY(copy_out(ex->stream, out, d_out, (size_t)n_queries * top * sizeof(qmx_scored_point)));
     if (!cnt_dev) QMX_TRY(copy_out(ex->stream, out_counts, d_oc, (size_t)n_queries * 4));
     return check_err_flag(ex);
+}
+
+// GraphLayers::search with a custom query as the points scorer (graph_layers.rs:108-149 walks with whatever scorer raw_scorer.rs:228-333 built)
+int32_t qmx_custom_hnsw_search(const qmx_hnsw *g, qmx_query *ex, const qmx_custom_query *queries, uint32_t n_queries, uint32_t top, uint32_t ef,
+                               qmx_scored_point *out, uint32_t *out_counts, const volatile uint8_t *is_stopped, qmx_counters *counters) {
+    QMX_REQUIRE(g && ex && (n_queries == 0 || queries) && out && out_counts, QMX_ERR_BAD_ARG, "NULL argument");
+    QMX_TRY(hnsw_check(g, ex, top, ef));
+    QMX_HIP(hipSetDevice(ex->device));
+    if (counters) memset(counters, 0, sizeof(*counters));
+    if (n_queries == 0) return QMX_OK;
+    if (is_stopped && *is_stopped) {
+        set_error("search cancelled");
+        return QMX_ERR_CANCELLED;
+    }
+    uint32_t max_examples = 0;
+    QMX_TRY(custom_validate(ex, queries, n_queries, ex->nq, &max_examples));
+    const bool out_dev = is_device_ptr(out), cnt_dev = is_device_ptr(out_counts);
+    if (g->n_points == 0) {   // get_entry_point() -> None
+        if (cnt_dev) QMX_HIP(hipMemset(out_counts, 0, (size_t)n_queries * 4));
+        else memset(out_counts, 0, (size_t)n_queries * 4);
+        return QMX_OK;
+    }
+    QMX_TRY(ex->cq_desc.reserve((size_t)n_queries * sizeof(qmx_custom_query)));
+    QMX_HIP(hipMemcpyAsync(ex->cq_desc.p, queries, (size_t)n_queries * sizeof(qmx_custom_query), hipMemcpyHostToDevice, ex->stream));
+    CustomWalk cw{(const qmx_custom_query *)ex->cq_desc.p, (const float *)ex->cq_coefs.p, n_queries, max_examples};
+    qmx_scored_point *d_out = out;
+    uint32_t *d_counts = out_counts;
+    if (!out_dev) { QMX_TRY(ex->out.reserve((size_t)n_queries * top * sizeof(qmx_scored_point))); d_out = (qmx_scored_point *)ex->out.p; }
+    if (!cnt_dev) { QMX_TRY(ex->counts.reserve((size_t)n_queries * 4)); d_counts = (uint32_t *)ex->counts.p; }
+    QMX_TRY(ex->hnsw_scored.reserve((size_t)n_queries * 4));
+    const bool timed = ex->timing || (ex->seg->flags & QMX_SEG_TIME_KERNELS) != 0;
+    QMX_TRY(hnsw_enqueue(g, ex, top, ef, d_out, d_counts, (uint32_t *)ex->hnsw_scored.p, timed, false, nullptr, nullptr, &cw));
+    if (!out_dev) QMX_TRY(copy_out(ex->stream, out, d_out, (size_t)n_queries * top * sizeof(qmx_scored_point)));
+    if (!cnt_dev) QMX_TRY(copy_out(ex->stream, out_counts, d_counts, (size_t)n_queries * 4));
+    QMX_TRY(check_err_flag(ex));    // synchronises (the caller's descriptors may go away)
+    if (counters) {
+        std::vector<uint32_t> sc(n_queries);
+        QMX_HIP(hipMemcpy(sc.data(), ex->hnsw_scored.p, (size_t)n_queries * 4, hipMemcpyDeviceToHost));
+        uint64_t total = 0;
+        for (uint32_t v : sc) total += v;
+        counters->vectors_scored = total;            // POINTS scored (each costs one similarity per example of its query)
+        counters->kernel_launches = 1;
+        if (timed) { const float before = ex->timing_ms; QMX_TRY(timing_fold(ex)); counters->kernel_ms = ex->timing_ms - before; }
+    }
+    return QMX_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3282,6 +3364,70 @@ int32_t qmx_multi_search_topk(qmx_query *inner, const uint32_t *query_first, uin
             del.n_point_bits = n_deleted_bits;
         }
         QMX_TRY(launch_custom_topk(inner->stream, (const float *)inner->cq_scores.p, n, (const uint32_t *)d_ids, del, n_queries, top, d_out, d_oc));
+    }
+    if (!out_dev) QMX_TRY(copy_out(inner->stream, out, d_out, (size_t)n_queries * top * sizeof(qmx_scored_point)));
+    if (!cnt_dev) QMX_TRY(copy_out(inner->stream, out_counts, d_oc, (size_t)n_queries * 4));
+    return check_err_flag(inner);
+}
+
+// Custom queries whose examples are multi-vectors (MultiCustomQueryScorer, query_scorer/multi_custom_query_scorer.rs:19-130; over quantized inner rows
+// QuantizedMultiCustomQueryScorer, quantized/quantized_multi_custom_query_scorer.rs:19-96): similarity(example, point) = score_max_similarity, then the
+// query's score_by.  The MaxSim row of every example (multi_prepare, as for plain multi-queries), then the combination over those rows.
+static int32_t multi_custom_prepare(qmx_query *inner, const uint32_t *example_first, uint32_t n_examples, const qmx_custom_query *queries, uint32_t n_queries,
+                                    const uint64_t *point_offsets, uint32_t n_points, const uint32_t *d_ids, uint64_t n) {
+    QMX_TRY(custom_validate(inner, queries, n_queries, n_examples, nullptr));
+    QMX_TRY(multi_prepare(inner, example_first, n_examples, point_offsets, n_points, d_ids, n));       // cq_scores[e * n + c] = MaxSim(example e, candidate c)
+    QMX_TRY(inner->cq_multi.reserve((size_t)n_queries * n * 4));
+    QMX_TRY(inner->cq_desc.reserve((size_t)n_queries * sizeof(qmx_custom_query)));
+    QMX_HIP(hipMemcpyAsync(inner->cq_desc.p, queries, (size_t)n_queries * sizeof(qmx_custom_query), hipMemcpyHostToDevice, inner->stream));
+    return launch_custom_combine(inner->stream, (const qmx_custom_query *)inner->cq_desc.p, n_queries, (const float *)inner->cq_scores.p, n,
+                                 (const float *)inner->cq_coefs.p, (float *)inner->cq_multi.p);
+}
+
+int32_t qmx_multi_custom_score_points(qmx_query *inner, const uint32_t *example_first, uint32_t n_examples, const qmx_custom_query *queries, uint32_t n_queries,
+                                      const uint64_t *point_offsets, uint32_t n_points, const uint32_t *ids, uint32_t n, float *scores) {
+    QMX_REQUIRE(inner && example_first && point_offsets && (n_queries == 0 || queries) && (n == 0 || (ids && scores)), QMX_ERR_BAD_ARG, "NULL argument");
+    QMX_HIP(hipSetDevice(inner->device));
+    if (n == 0 || n_queries == 0) return QMX_OK;
+    const void *d_ids = nullptr;
+    QMX_TRY(stage_in(inner, inner->ids, ids, (size_t)n * 4, &d_ids));
+    QMX_TRY(multi_custom_prepare(inner, example_first, n_examples, queries, n_queries, point_offsets, n_points, (const uint32_t *)d_ids, n));
+    QMX_TRY(copy_out(inner->stream, scores, inner->cq_multi.p, (size_t)n_queries * n * 4));
+    return check_err_flag(inner);
+}
+
+int32_t qmx_multi_custom_search_topk(qmx_query *inner, const uint32_t *example_first, uint32_t n_examples, const qmx_custom_query *queries, uint32_t n_queries,
+                                     const uint64_t *point_offsets, uint32_t n_points, const uint64_t *point_deleted, uint64_t n_deleted_bits, uint32_t top,
+                                     const uint32_t *ids, uint64_t n_ids, qmx_scored_point *out, uint32_t *out_counts) {
+    QMX_REQUIRE(inner && example_first && point_offsets && (n_queries == 0 || queries) && out && out_counts, QMX_ERR_BAD_ARG, "NULL argument");
+    QMX_REQUIRE(top >= 1 && top <= MAX_TOP, QMX_ERR_NOT_SUPPORTED, "top %u not in 1..%u", top, MAX_TOP);
+    QMX_HIP(hipSetDevice(inner->device));
+    if (n_queries == 0) return QMX_OK;
+    const void *d_ids = nullptr;
+    uint64_t n = n_points;
+    if (ids) {
+        n = n_ids;
+        if (n_ids) QMX_TRY(stage_in(inner, inner->ids, ids, (size_t)n_ids * 4, &d_ids));
+    }
+    const bool out_dev = is_device_ptr(out), cnt_dev = is_device_ptr(out_counts);
+    qmx_scored_point *d_out = out;
+    uint32_t *d_oc = out_counts;
+    if (!out_dev) { QMX_TRY(inner->out.reserve((size_t)n_queries * top * sizeof(qmx_scored_point))); d_out = (qmx_scored_point *)inner->out.p; }
+    if (!cnt_dev) { QMX_TRY(inner->counts.reserve((size_t)n_queries * 4)); d_oc = (uint32_t *)inner->counts.p; }
+    if (n == 0) {
+        QMX_HIP(hipMemsetAsync(d_oc, 0, (size_t)n_queries * 4, inner->stream));
+    } else {
+        QMX_TRY(multi_custom_prepare(inner, example_first, n_examples, queries, n_queries, point_offsets, n_points, (const uint32_t *)d_ids, n));
+        DeletedView del;      // deletion is per POINT (the id tracker's bitslice over multi-vector points)
+        memset(&del, 0, sizeof(del));
+        del.n_rows = n_points;
+        if (point_deleted && n_deleted_bits) {
+            const void *d_bits = nullptr;
+            QMX_TRY(stage_in(inner, inner->mv_deleted, point_deleted, (size_t)((n_deleted_bits + 63) / 64) * 8, &d_bits));
+            del.point_deleted = (const uint64_t *)d_bits;
+            del.n_point_bits = n_deleted_bits;
+        }
+        QMX_TRY(launch_custom_topk(inner->stream, (const float *)inner->cq_multi.p, n, (const uint32_t *)d_ids, del, n_queries, top, d_out, d_oc));
     }
     if (!out_dev) QMX_TRY(copy_out(inner->stream, out, d_out, (size_t)n_queries * top * sizeof(qmx_scored_point)));
     if (!cnt_dev) QMX_TRY(copy_out(inner->stream, out_counts, d_oc, (size_t)n_queries * 4));

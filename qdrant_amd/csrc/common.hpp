@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 
 #include "../../include/qdrant_amd.h"
@@ -44,6 +45,17 @@ enum Option {
     OPT_COUNT
 };
 int64_t option(Option o);
+// hipFuncSetAttribute (the opt-in to more than 64 KiB of dynamic LDS) is per DEVICE: a call site remembers on which devices it ran, so that a host thread
+// serving segments on several GPUs sets it on each of them (a `static thread_local bool` set it on the thread's first device only)
+struct DeviceOnce {
+    std::atomic<uint64_t> done{0};
+    int dev = 0;
+    bool need() {
+        if (hipGetDevice(&dev) != hipSuccess) { dev = 0; return true; }
+        return dev >= 64 || !(done.load(std::memory_order_acquire) & (1ull << dev));
+    }
+    void mark() { if (dev < 64) done.fetch_or(1ull << dev, std::memory_order_release); }
+};
 // the host-side handle of the scoring kernel this thread launched last (qmx_query_last_kernel reports its symbol)
 void note_kernel(const void *host_function);
 #define QMX_NOTE_KERNEL(fn) ::qmx::note_kernel(reinterpret_cast<const void *>(fn))

@@ -12,58 +12,15 @@
 // The similarities are the scan kernels' (bit-identical to the x86 leaves), the combination is a handful of f32
 // operations in the reference's order: bit-exact end to end.  Example order inside a query = the reference's
 // flat_iter(): reco: positives, then negatives; discover: target, then (positive, negative) per pair; context: pairs.
+#include "custom_combine.hpp"
 #include "kernels.hpp"
 
 namespace qmx {
 
-__device__ __forceinline__ int f32_total_cmp(float a, float b) {   // f32::total_cmp
-    int32_t x = __float_as_int(a), y = __float_as_int(b);
-    x ^= (int32_t)(((uint32_t)(x >> 31)) >> 1);
-    y ^= (int32_t)(((uint32_t)(y >> 31)) >> 1);
-    return x < y ? -1 : x > y ? 1 : 0;
-}
-__device__ __forceinline__ float fast_sigmoid(float x) { return x / (1.0f + __builtin_fabsf(x)); }
-__device__ __forceinline__ float scaled_fast_sigmoid(float x) { return 0.5f * (fast_sigmoid(x) + 1.0f); }
-
 // sims[e * stride] = similarity of example (first + e) with this candidate
 __device__ __forceinline__ float custom_combine(const qmx_custom_query &q, const float *sims, uint64_t stride, const float *coefs) {
     const float *s = sims + (uint64_t)q.first * stride;
-    switch (q.kind) {
-        case QMX_CUSTOM_RECO_BEST_SCORE: {
-            float max_pos = -__builtin_inff(), max_neg = -__builtin_inff();
-            for (uint32_t i = 0; i < q.n_a; ++i) { const float v = s[(uint64_t)i * stride]; if (f32_total_cmp(v, max_pos) > 0) max_pos = v; }
-            for (uint32_t i = 0; i < q.n_b; ++i) { const float v = s[(uint64_t)(q.n_a + i) * stride]; if (f32_total_cmp(v, max_neg) > 0) max_neg = v; }
-            return max_pos > max_neg ? scaled_fast_sigmoid(max_pos) : -scaled_fast_sigmoid(max_neg);
-        }
-        case QMX_CUSTOM_RECO_SUM_SCORES: {
-            float pos = 0.0f, neg = 0.0f;
-            for (uint32_t i = 0; i < q.n_a; ++i) pos += s[(uint64_t)i * stride];
-            for (uint32_t i = 0; i < q.n_b; ++i) neg += s[(uint64_t)(q.n_a + i) * stride];
-            return pos - neg;
-        }
-        case QMX_CUSTOM_DISCOVER: {
-            int32_t rank = 0;
-            for (uint32_t i = 0; i < q.n_b; ++i) rank += f32_total_cmp(s[(uint64_t)(1 + 2 * i) * stride], s[(uint64_t)(2 + 2 * i) * stride]);
-            return (float)rank + scaled_fast_sigmoid(s[0]);
-        }
-        case QMX_CUSTOM_FEEDBACK: {   // FeedbackQuery::score_by (feedback_query.rs:198-226): mul, then add, pair by pair
-            const float *cf = coefs + q.coef_first;
-            float score = cf[0] * s[0];
-            for (uint32_t i = 0; i < q.n_b; ++i) {
-                const float delta = s[(uint64_t)(1 + 2 * i) * stride] - s[(uint64_t)(2 + 2 * i) * stride];
-                score += cf[1 + i] * delta;
-            }
-            return score;
-        }
-        default: {   // QMX_CUSTOM_CONTEXT
-            float sum = 0.0f;
-            for (uint32_t i = 0; i < q.n_b; ++i) {
-                const float difference = s[(uint64_t)(2 * i) * stride] - s[(uint64_t)(2 * i + 1) * stride] - 1.1920929e-07f;   // ScoreType::EPSILON
-                sum += fast_sigmoid(__builtin_fminf(difference, 0.0f));
-            }
-            return sum;
-        }
-    }
+    return custom_score_by(q.kind, q.n_a, q.n_b, coefs + q.coef_first, [&](uint32_t e) { return s[(uint64_t)e * stride]; });
 }
 
 __global__ __launch_bounds__(256) void custom_combine_kernel(const qmx_custom_query *queries, uint32_t n_queries, const float *sims, uint64_t n,

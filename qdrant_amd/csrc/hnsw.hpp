@@ -30,6 +30,7 @@
 //   * links = the plain GraphLinks arrays (graph_links/view.rs: reindex, level_offsets, offsets,
 //     neighbors) as serialised by graph_links/serializer.rs:52-176.
 #pragma once
+#include "custom_combine.hpp"
 #include "scan_common.hpp"
 
 namespace qmx {
@@ -107,6 +108,36 @@ struct HopMaxSim {
             sum += max_sim;
         }
         return sum;
+    }
+};
+
+// Custom queries as the scorer of the walk (raw_scorer.rs:228-333 builds a CustomQueryScorer / QuantizedCustomQueryScorer / TurboCustomQueryScorer for
+// whatever storage the segment has; graph_layers.rs:108-149 walks with whatever scorer it gets): a hop candidate's score is
+// query.score_by(|example| inner policy's score(example, candidate)) - the examples of ONE custom query, in flat_iter() order, are what the search stages.
+// The query block in LDS is [32-byte CustomHeader][the examples' entries, when they fit: else the header points at them in global memory]; qp points
+// behind the header.
+struct CustomHeader {
+    uint32_t kind, n_a, n_b, coef_first;
+    const unsigned char *entries;       // the examples' query entries, a.q_stride apart (LDS or global)
+    uint64_t pad;
+};
+static_assert(sizeof(CustomHeader) == 32, "the custom walk's LDS header");
+template <class H, class = void>
+struct is_custom { static constexpr bool value = false; };
+template <class H>
+struct is_custom<H, decltype((void)H::CUSTOM)> { static constexpr bool value = H::CUSTOM; };
+template <class HI>
+struct HopCustom {
+    static constexpr int LPI = HI::LPI;
+    static constexpr bool INTERNAL_QOFF = false;
+    static constexpr bool INTERNAL_NORM = false;
+    static constexpr bool MULTI = false;
+    static constexpr bool CUSTOM = true;
+    static __device__ __forceinline__ float score(const ScanArgs &a, const unsigned char *qp, uint32_t id, int sub) {
+        const CustomHeader *hd = reinterpret_cast<const CustomHeader *>(qp - sizeof(CustomHeader));
+        const unsigned char *ent = hd->entries;
+        return custom_score_by(hd->kind, hd->n_a, hd->n_b, a.cq_coefs + hd->coef_first,
+                               [&](uint32_t e) { return HI::score(a, ent + (size_t)e * a.q_stride, id, sub); });
     }
 };
 
@@ -583,6 +614,28 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const ScanArgs a, const
             hnsw_search_one<H, E>(a, h, q_lds + 16, hop_ids, hop_scores, vis, vlog, qi, lane);
             continue;
         }
+        if constexpr (is_custom<H>::value) {
+            // (the header always sits in LDS: launch_hnsw_hop grants at least its 32 bytes; the examples follow when the launch's budget holds them)
+            const qmx_custom_query cq = a.cq_desc[qi];
+            const uint32_t ne = cq.kind <= QMX_CUSTOM_RECO_SUM_SCORES ? cq.n_a + cq.n_b : cq.n_a + 2 * cq.n_b;
+            const unsigned char *qg = reinterpret_cast<const unsigned char *>(a.queries) + (uint64_t)cq.first * a.q_stride;
+            const bool fits = sizeof(CustomHeader) + (uint64_t)ne * a.q_stride <= h.lds_query_bytes;
+            __syncthreads();
+            if (fits) {
+                const uint4 *src = reinterpret_cast<const uint4 *>(qg);
+                uint4 *dst = reinterpret_cast<uint4 *>(q_lds + sizeof(CustomHeader));
+                for (uint32_t i = (uint32_t)lane; i < ne * (a.q_stride / 16); i += 64) dst[i] = src[i];
+            }
+            if (lane == 0) {
+                CustomHeader *hd = reinterpret_cast<CustomHeader *>(q_lds);
+                hd->kind = cq.kind; hd->n_a = cq.n_a; hd->n_b = cq.n_b; hd->coef_first = cq.coef_first;
+                hd->entries = fits ? q_lds + sizeof(CustomHeader) : qg;
+                hd->pad = 0;
+            }
+            __syncthreads();
+            hnsw_search_one<H, E>(a, h, q_lds + sizeof(CustomHeader), hop_ids, hop_scores, vis, vlog, qi, lane);
+            continue;
+        }
         const unsigned char *qg = reinterpret_cast<const unsigned char *>(a.queries) + (uint64_t)qi * a.q_stride;
         if constexpr (QLDS) {
             __syncthreads();
@@ -601,10 +654,10 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const ScanArgs a, const
 template <class H, int E, bool QLDS>
 int32_t hnsw_occupancy_inst(uint32_t lds_query_bytes, size_t hop_lds, int *per_cu) {
     auto kfn = hnsw_search_kernel<H, E, QLDS>;
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
+    static thread_local DeviceOnce attr_once;
+    if (attr_once.need()) {
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_once.mark();
     }
     const size_t lds = hop_lds + (QLDS ? lds_query_bytes : 0);
     int n = 0;
@@ -630,6 +683,14 @@ int32_t launch_hnsw_hop(hipStream_t st, const ScanArgs &a, const HnswArgs &h, ui
     QMX_REQUIRE(ef >= 1 && ef <= HNSW_MAX_EF, QMX_ERR_NOT_SUPPORTED, "hnsw ef %u not in 1..%u", ef, HNSW_MAX_EF);
     const bool qlds = h.lds_query_bytes > 0;
     if constexpr (is_maxsim<H>::value) QMX_REQUIRE(qlds, QMX_ERR_NOT_SUPPORTED, "the inner vectors of a multi-query must fit the LDS");
+    if constexpr (is_custom<H>::value) QMX_REQUIRE(h.lds_query_bytes >= sizeof(CustomHeader), QMX_ERR_OTHER, "the custom walk keeps its header in LDS");
+    if constexpr (is_custom<H>::value || is_maxsim<H>::value) {      // (always staged: no instantiation that reads the entry from global memory)
+        if (grid == 0) {
+            const size_t hop_lds = 8 * (size_t)h.hop_cap + (h.acorn ? 256 : 0);
+            return ef <= 128 ? hnsw_occupancy_inst<H, 2, true>(h.lds_query_bytes, hop_lds, per_cu) : hnsw_occupancy_inst<H, 8, true>(h.lds_query_bytes, hop_lds, per_cu);
+        }
+        return ef <= 128 ? launch_hnsw_inst<H, 2, true>(st, a, h, grid) : launch_hnsw_inst<H, 8, true>(st, a, h, grid);
+    } else {
     if (grid == 0) {
         const size_t hop_lds = 8 * (size_t)h.hop_cap + (h.acorn ? 256 : 0);
         if (ef <= 128) return qlds ? hnsw_occupancy_inst<H, 2, true>(h.lds_query_bytes, hop_lds, per_cu) : hnsw_occupancy_inst<H, 2, false>(0, hop_lds, per_cu);
@@ -637,6 +698,7 @@ int32_t launch_hnsw_hop(hipStream_t st, const ScanArgs &a, const HnswArgs &h, ui
     }
     if (ef <= 128) return qlds ? launch_hnsw_inst<H, 2, true>(st, a, h, grid) : launch_hnsw_inst<H, 2, false>(st, a, h, grid);
     return qlds ? launch_hnsw_inst<H, 8, true>(st, a, h, grid) : launch_hnsw_inst<H, 8, false>(st, a, h, grid);
+    }
 }
 
 // launch functor for the per-dtype dispatchers (dispatch_dense / dispatch_sq)
@@ -647,6 +709,14 @@ struct HnswLauncher {
     int *per_cu;
     template <class P> int32_t row(const ScanArgs &a) const { return launch_hnsw_hop<HopRow<P>>(st, a, *h, grid, per_cu); }
     template <class S> int32_t small(const ScanArgs &a) const { return launch_hnsw_hop<HopSmall<S>>(st, a, *h, grid, per_cu); }
+};
+struct HnswCustomLauncher {
+    hipStream_t st;
+    const HnswArgs *h;
+    uint32_t grid;
+    int *per_cu;
+    template <class P> int32_t row(const ScanArgs &a) const { return launch_hnsw_hop<HopCustom<HopRow<P>>>(st, a, *h, grid, per_cu); }
+    template <class S> int32_t small(const ScanArgs &a) const { return launch_hnsw_hop<HopCustom<HopSmall<S>>>(st, a, *h, grid, per_cu); }
 };
 struct HnswMaxSimLauncher {
     hipStream_t st;

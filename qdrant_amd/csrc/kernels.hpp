@@ -72,6 +72,9 @@ struct ScanArgs {
     // [mv_qfirst[j], mv_qfirst[j + 1])
     const uint64_t *mv_offsets;
     const uint32_t *mv_qfirst;
+    // custom queries as the walk's scorer (hnsw.hpp HopCustom): search qi = custom query cq_desc[qi] over the example entries of `queries`
+    const qmx_custom_query *cq_desc;
+    const float *cq_coefs;
 };
 
 enum ScanMode { SCAN_TOPK = 0, SCAN_SCORES = 1 };
@@ -145,6 +148,12 @@ int32_t launch_tq_query_encode(hipStream_t st, double *d_rot, uint32_t nq, uint3
 int32_t launch_tq_internal(hipStream_t st, const void *codes, uint32_t stride, const float *sf, const float *l2, uint32_t code_bytes, uint32_t bits,
                            int invert, uint64_t n_rows, const uint32_t *a_ids, const uint32_t *b_ids, uint32_t n, float *out, int *err_flag, const TqEc *ec);
 // the MaxSim walk over multi-vector points (HopMaxSim): dense, SQ and BQ inner rows
+// ... with a custom query (Recommend / Discover / Context / Feedback) as the scorer (hnsw.hpp HopCustom over the storage's own hop policy)
+int32_t launch_hnsw_custom_dense(hipStream_t st, int dtype, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
+int32_t launch_hnsw_custom_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
+int32_t launch_hnsw_custom_bq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
+int32_t launch_hnsw_custom_pq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
+int32_t launch_hnsw_custom_tq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_maxsim_dense(hipStream_t st, int dtype, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_maxsim_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_maxsim_bq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);

@@ -208,10 +208,10 @@ template <bool LDS_LUT, bool HAS_IDS, int MODE>
 static int32_t launch_pq_scan_inst(hipStream_t st, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
     const size_t lds = LDS_LUT ? (((size_t)a.pq_m * a.pq_ncent * 4 + 15) & ~(size_t)15) : 0;
     auto kfn = pq_scan_kernel<LDS_LUT, HAS_IDS, MODE>;
-    static thread_local bool attr_set = false;
-    if (!attr_set && LDS_LUT) {
+    static thread_local DeviceOnce attr_once;
+    if (LDS_LUT && attr_once.need()) {
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));   // + 8 KiB static
-        attr_set = true;
+        attr_once.mark();
     }
     // slabs: enough blocks to fill the chip with nq queries each, bounded by the work
     uint64_t want = (a.n_cand + PQ_BLOCK - 1) / PQ_BLOCK;
@@ -319,6 +319,10 @@ struct HopPQ {
 };
 int32_t launch_hnsw_pq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
     return launch_hnsw_hop<HopPQ>(st, a, h, grid, per_cu);
+}
+// ... with a custom query as the scorer: every example's LUT stays in global memory (read through L2, like the plain PQ walk's large LUTs)
+int32_t launch_hnsw_custom_pq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
+    return launch_hnsw_hop<HopCustom<HopPQ>>(st, a, h, grid, per_cu);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -482,10 +486,10 @@ int32_t launch_pq_encode(hipStream_t st, uint32_t dim, const qmx_pq_params &pq, 
     const PqGeom g = make_geom(QMX_DISTANCE_EUCLID, dim, pq);
     const size_t lds = ((size_t)g.ncent * g.chunk + (size_t)g.chunk * 256) * sizeof(float);
     QMX_REQUIRE(lds <= 150 * 1024, QMX_ERR_NOT_SUPPORTED, "PQ encode: chunk %u x %u centroids needs %zu B of LDS", g.chunk, g.ncent, lds);
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
+    static thread_local DeviceOnce attr_once;
+    if (attr_once.need()) {
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pq_encode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_set = true;
+        attr_once.mark();
     }
     ::qmx::clear_stale_error();
     hipLaunchKernelGGL(pq_encode_kernel, dim3((uint32_t)((n + 255) / 256), g.m), dim3(256), lds, st, g, d_in, n, d_centroids, d_codes);

@@ -294,14 +294,12 @@ int32_t launch_pq_prefilter(hipStream_t st, const ScanArgs &a, const void *d_rot
     auto k2 = pq_prefilter_kernel<2>;
     auto k4 = pq_prefilter_kernel<4>;
     auto k6 = pq_prefilter_kernel<6>;
-    int dev = 0;
-    QMX_HIP(hipGetDevice(&dev));
-    static std::atomic<uint64_t> attr_done{0};         // one bit per device
-    if (dev < 64 && !(attr_done.load(std::memory_order_relaxed) & (1ull << dev))) {
+    static thread_local DeviceOnce attr_once;
+    if (attr_once.need()) {
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k6), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        attr_done.fetch_or(1ull << dev, std::memory_order_relaxed);
+        attr_once.mark();
     }
     ::qmx::clear_stale_error();
     if (m_pad == 32) {

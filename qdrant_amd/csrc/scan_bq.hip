@@ -266,6 +266,9 @@ int32_t launch_pairs_bq(hipStream_t st, const ScanArgs &a, const PairSel &sel, u
 int32_t launch_hnsw_bq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
     return dispatch_bq(HnswLauncher{st, &h, grid, per_cu}, a);
 }
+int32_t launch_hnsw_custom_bq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
+    return dispatch_bq(HnswCustomLauncher{st, &h, grid, per_cu}, a);
+}
 int32_t launch_hnsw_maxsim_bq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
     return dispatch_bq(HnswMaxSimLauncher{st, &h, grid, per_cu}, a);
 }

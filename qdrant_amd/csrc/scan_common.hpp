@@ -259,11 +259,11 @@ int32_t launch_scan_inst(hipStream_t st, const ScanArgs &a, int num_cus, uint32_
     lds = (lds + 15) & ~(size_t)15;
     QMX_REQUIRE(lds <= 160 * 1024, QMX_ERR_NOT_SUPPORTED, "query tile needs %zu B of LDS (> 160 KiB)", lds);
     auto kfn = scan_kernel<P, QT, R, UNROLL, HAS_IDS, MODE>;
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
+    static thread_local DeviceOnce attr_once;
+    if (attr_once.need()) {
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_once.mark();
     }
     int per_cu = 0;
     QMX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, SCAN_BLOCK, lds));

@@ -455,10 +455,10 @@ static int32_t launch_m16(hipStream_t st, const ScanArgs &a, int num_cus, uint32
     }
     typedef M16Shape<NW, NT, (KSTEPS % 2 == 0 ? 2 : 1)> S;
     auto kfn = scan_f32_mfma16_kernel<KSTEPS, NW, NT, DBG, LAG, IDS>;
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
+    static thread_local DeviceOnce attr_once;
+    if (attr_once.need()) {
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_once.mark();
     }
     const uint64_t n_tiles = (a.n_cand + 15) / 16;
     int per_cu = 0;

@@ -113,6 +113,9 @@ int32_t launch_pairs_sq(hipStream_t st, int distance, const ScanArgs &a, const P
 int32_t launch_hnsw_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
     return dispatch_sq(HnswLauncher{st, &h, grid, per_cu}, distance, a);
 }
+int32_t launch_hnsw_custom_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
+    return dispatch_sq(HnswCustomLauncher{st, &h, grid, per_cu}, distance, a);
+}
 int32_t launch_hnsw_maxsim_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
     return dispatch_sq(HnswMaxSimLauncher{st, &h, grid, per_cu}, distance, a);
 }

@@ -1067,13 +1067,13 @@ int32_t launch_scan_f32_split(hipStream_t st, const ScanArgs &a, const void *d_b
     auto kfn3h = scan_f16pair_kernel<true>;
     auto kfn4 = scan_f16half256_kernel;
     QMX_REQUIRE(qt == SP_QT || (qt == SP4_QT && half && d_rows_split), QMX_ERR_BAD_ARG, "the 256-query shape scans the half copy");
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
+    static thread_local DeviceOnce attr_once;
+    if (attr_once.need()) {
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS));
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn3), hipFuncAttributeMaxDynamicSharedMemorySize, SP3_LDS));
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn3h), hipFuncAttributeMaxDynamicSharedMemorySize, SP3_LDS));
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn4), hipFuncAttributeMaxDynamicSharedMemorySize, SP4_LDS));
-        attr_set = true;
+        attr_once.mark();
     }
     QMX_REQUIRE(!half || d_rows_split, QMX_ERR_BAD_ARG, "the one-product mode scans the half copy only");
     SplitArgs s;

@@ -442,10 +442,10 @@ static int32_t launch_sqm_inst(hipStream_t st, const ScanArgs &a, int num_cus, u
     lds = (lds + 15) & ~(size_t)15;
     QMX_REQUIRE(lds <= 160 * 1024, QMX_ERR_NOT_SUPPORTED, "query tile needs %zu B of LDS (> 160 KiB)", lds);
     auto kfn = scan_sq_mfma_kernel<Ops, QW, D, HAS_IDS, MODE>;
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
+    static thread_local DeviceOnce attr_once;
+    if (attr_once.need()) {
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_once.mark();
     }
     int per_cu = 0;
     QMX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, SQM_BLOCK, lds));

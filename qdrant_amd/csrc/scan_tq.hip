@@ -158,10 +158,10 @@ int32_t launch_tq_rotate(hipStream_t st, const float *d_in, uint32_t n, const Tq
     r.n_chunks = h.n_chunks; r.rot_dim = h.rot_dim; r.padded_dim = h.padded_dim; r.dim = h.dim;
     const size_t lds = (size_t)2 * h.rot_dim * sizeof(double);
     QMX_REQUIRE(lds <= 150 * 1024, QMX_ERR_NOT_SUPPORTED, "TurboQuant rotation over %u coordinates does not fit the LDS", h.rot_dim);
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
+    static thread_local DeviceOnce attr_once;
+    if (attr_once.need()) {
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tq_rotate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_set = true;
+        attr_once.mark();
     }
     ::qmx::clear_stale_error();
     hipLaunchKernelGGL(tq_rotate_kernel, dim3(n), dim3(256), lds, st, d_in, (uint64_t)h.dim, n, r, d_out);

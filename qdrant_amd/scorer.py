@@ -548,6 +548,43 @@ class MultiDenseVectorStorage:
                                               0 if idarr is None else len(idarr), F.ptr(out), F.ptr(counts)))
         return [out[i, :counts[i]].copy() for i in range(nq)]
 
+    def _custom(self, queries):
+        """custom queries whose examples are multi-vectors -> (inner scorer, example_first, descriptors)"""
+        flat, descs, first, coefs = [], (F.CustomQuery * len(queries))(), 0, []
+        for i, q in enumerate(queries):
+            descs[i].kind, descs[i].first, descs[i].n_a, descs[i].n_b, descs[i].coef_first = q.kind, first, q.n_a, q.n_b, len(coefs)
+            flat += [np.atleast_2d(np.asarray(e, dtype=np.float32)) for e in q.examples]
+            first += len(q.examples)
+            if q.coefs is not None:
+                coefs += q.coefs.tolist()
+        scorer, efirst = self._queries(flat)
+        if coefs:
+            cf = np.asarray(coefs, dtype=np.float32)
+            F.check(F.lib().qmx_custom_set_coefficients(scorer._h, F.ptr(cf), len(cf)))
+        return scorer, efirst, descs
+
+    def custom_score_points(self, queries, ids) -> np.ndarray:
+        """`MultiCustomQueryScorer` / `QuantizedMultiCustomQueryScorer`: `queries` = MultiCustomQuery-like objects (CustomQuery whose examples are
+        [tokens, dim] arrays) -> [n_queries, len(ids)] f32."""
+        scorer, efirst, descs = self._custom(queries)
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        out = np.empty((len(queries), len(ids)), dtype=np.float32)
+        F.check(F.lib().qmx_multi_custom_score_points(scorer._h, F.ptr(efirst), len(efirst) - 1, descs, len(queries), F.ptr(self.offsets), self.count,
+                                                      F.ptr(ids), len(ids), F.ptr(out)))
+        return out
+
+    def custom_peek_top(self, queries, top: int, ids=None) -> List[np.ndarray]:
+        scorer, efirst, descs = self._custom(queries)
+        nq = len(queries)
+        out = np.zeros((nq, top), dtype=ScoredPointOffset)
+        counts = np.zeros(nq, dtype=np.uint32)
+        idarr = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint32)
+        words = _bits_to_words(self.point_deleted)
+        F.check(F.lib().qmx_multi_custom_search_topk(scorer._h, F.ptr(efirst), len(efirst) - 1, descs, nq, F.ptr(self.offsets), self.count, F.ptr(words),
+                                                     0 if self.point_deleted is None else len(self.point_deleted), top, F.ptr(idarr),
+                                                     0 if idarr is None else len(idarr), F.ptr(out), F.ptr(counts)))
+        return [out[i, :counts[i]].copy() for i in range(nq)]
+
     def search_hnsw(self, graph, multi_queries, top: int, ef: int, with_counters: bool = False):
         """`GraphLayers::search` over the multi-vector POINTS with the MaxSim scorer of every multi-query (`MultiMetricQueryScorer` /
         `QuantizedMultiQueryScorer` behind `FilteredScorer`), on device."""
@@ -821,6 +858,16 @@ class CustomRawScorer:
         F.check(F.lib().qmx_custom_search_topk(self.examples._h, self._descs, self.nq, top, F.ptr(ids), 0 if ids is None else len(ids),
                                                F.ptr(out), F.ptr(counts)))
         return [out[i, :counts[i]].copy() for i in range(self.nq)]
+
+    def search_hnsw(self, graph, top: int, ef: int, with_scored: bool = False):
+        """`GraphLayers::search(top, ef, Hnsw, points_scorer = the custom scorer)` for every custom query of the batch, on device
+        (qmx_custom_hnsw_search): dense, SQ, PQ, BQ and TurboQuant storages."""
+        out = np.zeros((self.nq, max(top, 1)), dtype=ScoredPointOffset)
+        counts = np.zeros(self.nq, dtype=np.uint32)
+        ctr = F.Counters()
+        F.check(F.lib().qmx_custom_hnsw_search(graph._h, self.examples._h, self._descs, self.nq, top, ef, F.ptr(out), F.ptr(counts), None, C.byref(ctr)))
+        res = [out[i, :counts[i]].copy() for i in range(self.nq)]
+        return (res, int(ctr.vectors_scored)) if with_scored else res
 
 
 def search_quantized(searched: RawScorer, original: Optional[RawScorer], top: int, oversampling: float = 0.0, rescore: bool = True,

@@ -1070,3 +1070,74 @@ def tq_plus_fit(distance, dim, bits, vectors, rotation_unpadded=False):
     denom = (q_hi - q_lo).astype(np.float32)
     scale = np.where(denom > 1e-3, np.float32(2.0 * c_outer) / np.where(denom > 1e-3, denom, 1.0), 1.0).astype(np.float32)
     return shift, scale
+
+
+# ---- scorers as values: any storage kind, custom queries over them (qo_scorer kind 6) ----------------------------------
+class ScorerFactory:
+    """One qo_scorer per (preprocessed) query vector over a storage of the oracle:
+      ("dense", DenseStorage) | ("sq", flags DenseStorage, SqOracle) | ("pq", flags, PqOracle) | ("bq", flags, BqOracle) | ("tq", flags, TqOracle)
+      | ("multi", MultiOracle)  (the "query vector" is then a [tokens, dim] multi-vector).
+    Returned scorers come with what they point at (keep it alive as long as the scorer is used)."""
+
+    def __init__(self, *spec):
+        self.spec, self.kind = spec, spec[0]
+        self.flags = spec[1].points if self.kind == "multi" else spec[1]
+        self._tq_queries = []
+
+    def __del__(self):
+        for e in self._tq_queries:
+            _lib.qo_tq_query_free(e)
+
+    def scorer(self, qpre):
+        s = Scorer()
+        if self.kind == "multi":
+            return self.spec[1].scorer(qpre)
+        st = self.spec[1]
+        qv = f32(qpre)
+        if self.kind == "dense":
+            enc = np.ascontiguousarray(cast(st.dtype, qv[None, :]))[0]
+            s.kind, s.st, s.query = 0, C.pointer(st.st), enc.ctypes.data
+            return s, enc
+        quant = self.spec[2]
+        if self.kind == "sq":
+            codes, off = quant.encode_query(qv)
+            s.kind, s.st, s.sq, s.sq_rows = 1, C.pointer(st.st), C.pointer(quant.sq), quant.rows.ctypes.data
+            s.sq_query, s.sq_query_offset, s.isa = codes.ctypes.data, off, quant.isa
+            return s, codes
+        if self.kind == "bq":
+            qb = quant.encode(qv[None, :])[0]
+            s.kind, s.st, s.bq_rows, s.bq_query = 3, C.pointer(st.st), quant.rows.ctypes.data, qb.ctypes.data
+            s.bq_dim, s.bq_distance, s.bq_invert = quant.dim, quant.distance, quant.invert
+            return s, qb
+        if self.kind == "pq":
+            lut = quant.lut(qv)
+            s.kind, s.st, s.pq, s.pq_codes = 2, C.pointer(st.st), C.pointer(quant.pq), quant.codes.ctypes.data
+            s.pq_lut, s.isa = lut.ctypes.data, quant.isa
+            return s, lut
+        e = _lib.qo_tq_precompute_query(quant.h, _p(qv))
+        self._tq_queries.append(e)
+        s.kind, s.st, s.tq, s.tq_rows, s.tq_query, s.tq_invert = 5, C.pointer(st.st), quant.h, quant.rows.ctypes.data, e, 1 if quant.invert else 0
+        return s, qv
+
+    def custom(self, examples_pre, kind, n_a, n_b, coefs=None):
+        """qo_scorer kind 6: a custom query over this storage; `examples_pre` in flat_iter() order, preprocessed."""
+        ex = [self.scorer(e) for e in examples_pre]
+        arr = (Scorer * max(1, len(ex)))(*[e[0] for e in ex])
+        cf = None if coefs is None else f32(coefs)
+        s = Scorer()
+        s.kind, s.st = 6, C.pointer(self.flags.st)
+        s.cq_examples, s.cq_kind, s.cq_n_a, s.cq_n_b = C.addressof(arr), kind, n_a, n_b
+        s.cq_coefs = None if cf is None else cf.ctypes.data
+        return s, (arr, ex, cf)
+
+
+def scorer_score_points(scorer, ids):
+    return np.array([_lib.qo_scorer_score_point(C.byref(scorer), int(i)) for i in ids], dtype=np.float32)
+
+
+def _hnsw_search_scorer(self, scorer, top, ef):
+    """GraphLayers::search with any qo_scorer as the points scorer -> (results, points scored)"""
+    return self._run(scorer, top, ef)
+
+
+Hnsw.search_scorer = _hnsw_search_scorer
