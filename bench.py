@@ -429,9 +429,11 @@ def hbm_point(Qh, storage, queries, n, dim, top, local_rank, stream, lib, F, sha
         per_step = max(1.0, nl.value / float(steps))            # launches per pass over the block (the prefilter over a derived copy: 2)
         alg = int((bytes_per_pass if bytes_per_pass else n * dim * 4) / per_step)
         gbps = alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        return {"batch": Qh, "kernel": F.last_kernel(backend.qh), "kernel_ms": round(kernel_ms, 4), "launches_timed": int(nl.value), "launches_per_pass": per_step,
-                "algorithmic_bytes_per_launch": alg, "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(gbps / HBM_PEAK_GBPS, 4), "qps": round(Qh * steps / wall, 1), "ms_per_step": round(wall / steps * 1e3, 4)}
+        sym = F.last_kernel(backend.qh)
+        return _attach_traffic({"batch": Qh, "kernel": sym, "kernel_ms": round(kernel_ms, 4), "launches_timed": int(nl.value), "launches_per_pass": per_step,
+                                "algorithmic_bytes_per_launch": alg, "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": None, "qps": round(Qh * steps / wall, 1),
+                                "ms_per_step": round(wall / steps * 1e3, 4)}, sym, n)
     finally:
         backend.close()
 
@@ -514,7 +516,7 @@ def _roofline(n, dim, kernel_ms, alg_bytes, achieved_gbps, launches, launches_pe
     mfma_peak = MFMA_F16_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
     hbm_frac, mfma_frac = achieved_gbps / HBM_PEAK_GBPS, tflops / mfma_peak
     traffic, traffic_src = _pmc_traffic(n, dim, Q, kernel_symbol)
-    common = {"traffic": traffic, "traffic_source": traffic_src, "kernel": kernel_symbol, "kernel_ms": round(kernel_ms, 4), "launches_timed": launches,
+    common = {"traffic": traffic, "traffic_source": traffic_src, "traffic_over_algorithmic": round(traffic / float(alg_bytes), 4) if traffic and alg_bytes else None, "kernel": kernel_symbol, "kernel_ms": round(kernel_ms, 4), "launches_timed": launches,
               "queries_per_pass": per_pass, "launches_per_pass": launches_per_pass, "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_flops_per_launch": flops,
               "hbm": {"achieved_GBps": round(achieved_gbps, 1), "peak_GBps": HBM_PEAK_GBPS, "frac": round(hbm_frac, 4)},
               "mfma": {"dtype": "f16 (x = h + l prefilter, f32 accumulate; results re-scored exactly in f32)" if split else "f32",
@@ -532,18 +534,44 @@ def _roofline(n, dim, kernel_ms, alg_bytes, achieved_gbps, launches, launches_pe
     return dict({"bound": "hbm", "achieved": round(achieved_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(hbm_frac, 4)}, **common)
 
 
-def _pmc_traffic(n, dim, Q, kernel_symbol):
-    """HBM bytes per scan launch from a separate `rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE` pass (counters cannot be read from inside
-    the process): profiles/pmc_traffic.json maps "<rows>x<dim>_q<Q>" to {"bytes", "kernel", "profile"}.  The entry only counts when it
-    was taken on the SAME kernel symbol this run launched; otherwise null (a stale number is worse than none)."""
+def _pmc_entry(kernel_symbol):
+    """The entry of profiles/pmc_traffic.json for this kernel symbol (template arguments included), or None.  HBM bytes per launch come from
+    separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over tools/traffic_workloads.py (counters cannot be read from inside the
+    process)."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
-        e = json.load(open(p)).get("%dx%d_q%d" % (n, dim, Q))
-        if isinstance(e, dict) and e.get("kernel") and _same_kernel(e["kernel"], kernel_symbol):
-            return e["bytes"], "%s (rocprofv3 --pmc pass on this kernel)" % e.get("profile", "profiles/pmc_traffic.json")
+        for k, e in json.load(open(p)).get("by_kernel", {}).items():
+            if _same_kernel(k, kernel_symbol):
+                return e
     except Exception:
         pass
+    return None
+
+
+def _pmc_traffic(n, dim, Q, kernel_symbol):
+    """(bytes per launch, source) when the table holds THIS kernel symbol at THIS row count; otherwise (None, None): a stale number is worse than none."""
+    e = _pmc_entry(kernel_symbol)
+    if e and e.get("rows") == n and "over_algorithmic" not in e:
+        return e["bytes"], "%s (rocprofv3 --pmc passes on this kernel: %s)" % (e.get("profile", "profiles/pmc_traffic.json"), e.get("workload", ""))
     return None, None
+
+
+def _attach_traffic(roof, kernel_symbol, n):
+    """fills roof['traffic'] (+ the ratio to the algorithmic bytes) from the PMC table; graph walks carry the ratio measured on a smaller graph"""
+    e = _pmc_entry(kernel_symbol)
+    if not e:
+        return roof
+    if "over_algorithmic" in e:
+        roof["traffic_measured_elsewhere"] = {"rows": e["rows"], "searches": e.get("searches"), "bytes_per_launch": e["bytes"],
+                                              "algorithmic_bytes_per_launch": e.get("algorithmic_bytes"), "over_algorithmic": e["over_algorithmic"],
+                                              "source": e.get("profile"), "note": e.get("workload")}
+    elif e.get("rows") == n:
+        roof["traffic"] = e["bytes"]
+        roof["traffic_source"] = e.get("profile")
+        alg = roof.get("algorithmic_bytes_per_launch")
+        if alg:
+            roof["traffic_over_algorithmic"] = round(e["bytes"] / float(alg), 4)
+    return roof
 
 
 def _same_kernel(a, b):
@@ -606,10 +634,12 @@ def _timed_quantized(ctx, scorer, raw, top, oversampling, rescore, graph, ef, re
     kernel_ms = ms.value / launches                        # per launch of the quantized stage's kernel
     per_launch_rows = (n_rows_scanned if n_rows_scanned is not None else scored / float(launches))
     gbps = per_launch_rows * row_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    return res, {"kernel": F.last_kernel(scorer._h), "kernel_ms": round(kernel_ms, 4), "launches_per_search": launches / float(reps),
-                 "wall_ms_per_search": round(wall * 1e3, 3), "qps_wall": round(scorer.nq / wall, 1),
-                 "roofline": {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
-                              "algorithmic_bytes_per_launch": int(per_launch_rows * row_bytes), "bytes_per_scored_row": row_bytes, "traffic": None}}, scored / float(reps)
+    sym = F.last_kernel(scorer._h)
+    roof = _attach_traffic({"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
+                            "algorithmic_bytes_per_launch": int(per_launch_rows * row_bytes), "bytes_per_scored_row": row_bytes, "traffic": None}, sym,
+                           n_rows_scanned if n_rows_scanned is not None else ctx["args"].config_rows or ctx["args"].rows)
+    return res, {"kernel": sym, "kernel_ms": round(kernel_ms, 4), "launches_per_search": launches / float(reps),
+                 "wall_ms_per_search": round(wall * 1e3, 3), "qps_wall": round(scorer.nq / wall, 1), "roofline": roof}, scored / float(reps)
 
 
 def c3_section(ctx, rows):
