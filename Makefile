@@ -8,8 +8,13 @@ SRCS     := $(wildcard $(CSRC)/*.hip)
 OBJS     := $(patsubst $(CSRC)/%.hip,build/%.o,$(SRCS))
 HDRS     := $(wildcard $(CSRC)/*.hpp) include/qdrant_amd.h
 LIB      := qdrant_amd/libqdrant_amd.so
+# synthetic row generators of bench.py / tools / tests: their own library, not part of the product
+TESTDATA := qdrant_amd/libqmx_testdata.so
 
-all: $(LIB) oracle
+all: $(LIB) $(TESTDATA) oracle
+
+$(TESTDATA): qdrant_amd/testdata/synth.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -shared -o $@ $<
 
 build/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p build
@@ -22,6 +27,6 @@ oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -rf build $(LIB)
+	rm -rf build $(LIB) $(TESTDATA)
 	$(MAKE) -C oracle clean
 .PHONY: all oracle clean

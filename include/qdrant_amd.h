@@ -300,7 +300,10 @@ QMX_API int32_t qmx_segment_create_from_files(const qmx_segment_desc *desc, cons
 /* Same for a CHUNKED appendable storage (`ChunkedVectors<T>`, lib/segment/src/vector_storage/chunked_vectors.rs: fixed-size
  * chunks of CHUNK_SIZE = 32 MiB, vector_storage/common.rs:27; row `key` lives in chunk key / rows_per_chunk at row
  * key % rows_per_chunk): `chunks[c]` points at chunk c (host or device), every chunk but the last holds `rows_per_chunk`
- * rows; `desc->data` is ignored, `desc->n` is the total row count.  The rows are gathered into one HBM block. */
+ * rows; `desc->data` is ignored, `desc->n` is the total row count.  The rows are gathered into one HBM block.
+ * Quantized chunked storages too (`QuantizedChunkedMmapStorage`, vector_storage/quantized/quantized_chunked_mmap_storage/read_only.rs:20,
+ * read_write.rs:18: the appendable form of the quantized storages): SQ / PQ / BQ / TQ dtypes with the quantizer's parameters in `desc`, rows in the
+ * quantizer's own layout. */
 QMX_API int32_t qmx_segment_create_chunked(const qmx_segment_desc *desc, const void *const *chunks, uint64_t rows_per_chunk,
                                            uint32_t n_chunks, qmx_segment **out);
 QMX_API int32_t qmx_segment_destroy(qmx_segment *seg);
@@ -409,7 +412,7 @@ QMX_API int32_t qmx_score_bytes(qmx_query *q, const void *rows, uint32_t n, uint
  * lib/common/common/src/fixed_length_priority_queue.rs:47-59) and returns them sorted by
  * descending score (`into_sorted_vec`, :63-65); among equal scores the lower id comes first
  * (the reference's order among equals is heap-dependent).
- *   top        : 1..1024.  Up to 64 entries live in one register list per wavefront; a larger `top` runs
+ *   top        : 1..65536.  Up to 64 entries live in one register list per wavefront; a larger `top` runs
  *                ceil(top / 64) passes over the candidates, pass p keeping the best 64 keys strictly below the
  *                last key of pass p - 1 (keys are unique: score, then offset), so the result is the same list.
  *   out        : [nq][top] ScoredPointOffset;  out_counts : [nq] number of valid entries.
@@ -514,7 +517,7 @@ QMX_API int32_t qmx_multi_search_topk(qmx_query *inner, const uint32_t *query_fi
  * by the BASE scorer - the full vector stored in front of the node's links, i.e. the rows of the original segment `base` was made over -
  * into a second `SearchContext(ef)`; its best `top` are the result: rescoring fused into the walk.  On the device the link and base vectors
  * are read from the two segments in HBM (the same bytes the file carries inline); the walk kernel lists the popped candidates and the pair
- * kernel scores them (exact bits of the base scorer).  ef <= 512, top <= 1024; a search that pops more than 32 max(ef, top) + 256 candidates
+ * kernel scores them (exact bits of the base scorer).  ef <= 512, top <= 65536; a search that pops more than 32 max(ef, top) + 256 candidates
  * => QMX_ERR_NOT_SUPPORTED.  counters->vectors_scored = link vectors + base vectors scored. */
 QMX_API int32_t qmx_hnsw_search_with_vectors(const qmx_hnsw *g, qmx_query *links, qmx_query *base, uint32_t top, uint32_t ef,
                                              qmx_scored_point *out, uint32_t *out_counts, const volatile uint8_t *is_stopped,
@@ -805,20 +808,6 @@ QMX_API int32_t qmx_sq_fit_quantile(int32_t device_id, uint32_t distance, const 
  * first minimum wins.  in [n][dim] f32 -> out [n][m] u8. */
 QMX_API int32_t qmx_pq_encode(int32_t device_id, const qmx_pq_params *params, const float *in,
                               uint64_t n, uint32_t dim, uint8_t *out_codes);
-
-/* ---- synthetic data (bench / tests) -------------------------------------------------------------- */
-
-/* Counter-based generator (integer Irwin-Hall of four 16-bit uniforms, no libm), reproducible on any host:
- * element (row, col) depends only on (seed, row, col).  Fills device or host-visible memory
- * [n][dim] f32 starting at row `row0`. */
-QMX_API int32_t qmx_synth_fill_f32(int32_t device_id, uint64_t seed, uint64_t row0, uint64_t n,
-                                   uint32_t dim, float *out_dev);
-/* Rows of low intrinsic dimension — the regime ANN indexes and quantizers are built for (iid N(0,1) rows in d = 768 have
- * nearly equidistant neighbours: recall collapses for the CPU reference and the device alike, hnsw_quantized_search_test.rs
- * asserts only > 40 % on such data): x[r][c] = sum_k z[r][k] W[k][c] + noise * e[r][c], z / W / e from the generator above,
- * the sum one fmaf chain in k order, so the CPU oracle's twin (qo_synth_fill_latent_f32) is bit-identical. */
-QMX_API int32_t qmx_synth_fill_latent_f32(int32_t device_id, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim,
-                                          uint32_t latent_dim, float noise, float *out_dev);
 
 #ifdef __cplusplus
 }

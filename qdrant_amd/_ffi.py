@@ -8,6 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libqdrant_amd.so")
+TESTDATA_LIB_PATH = os.path.join(_HERE, "libqmx_testdata.so")     # synthetic row generators of bench.py / tools / tests: NOT part of the product library
 
 # status codes (qmx_status)
 OK, ERR_OUT_OF_MEMORY, ERR_OUT_OF_BOUNDS, ERR_NOT_SUPPORTED, ERR_NOT_READY, ERR_TIMEOUT, ERR_OTHER, \
@@ -124,6 +125,11 @@ class QmxError(RuntimeError):
 
 # every exported symbol of include/qdrant_amd.h with its signature (checked by tests/test_abi.py)
 _P = C.c_void_p
+TESTDATA_SIGNATURES = {
+    "qmx_synth_fill_f32": (C.c_int32, [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]),
+    "qmx_synth_fill_latent_f32": (C.c_int32, [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p]),
+}
+
 SIGNATURES = {
     "qmx_abi_version": (C.c_uint32, []),
     "qmx_set_option": (C.c_int32, [C.c_char_p, C.c_int64]),
@@ -202,8 +208,6 @@ SIGNATURES = {
     "qmx_bq_row_bytes": (C.c_uint64, [C.c_uint32, C.c_uint32]),
     "qmx_bq_encode": (C.c_int32, [C.c_int32, _P, C.c_uint64, C.c_uint32, _P]),
     "qmx_pq_encode": (C.c_int32, [C.c_int32, C.POINTER(PqParams), _P, C.c_uint64, C.c_uint32, _P]),
-    "qmx_synth_fill_f32": (C.c_int32, [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, _P]),
-    "qmx_synth_fill_latent_f32": (C.c_int32, [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_float, _P]),
 }
 
 _lib = None
@@ -222,6 +226,15 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        # the harnesses' data generators live in their own library; when it is there its entry points are reachable through the same handle
+        # (lib.qmx_synth_fill_f32 / lib.qmx_synth_fill_latent_f32), so that bench.py and the tests read as before
+        if os.path.exists(TESTDATA_LIB_PATH):
+            td = C.CDLL(TESTDATA_LIB_PATH)
+            for name, (res, args) in TESTDATA_SIGNATURES.items():
+                fn = getattr(td, name)
+                fn.restype = res
+                fn.argtypes = args
+                setattr(handle, name, fn)
         _lib = handle
     return _lib
 

@@ -860,12 +860,8 @@ int32_t qmx_segment_create(const qmx_segment_desc *desc, qmx_segment **out) {
     return QMX_OK;
 }
 
-int32_t qmx_segment_create_from_files(const qmx_segment_desc *desc, const char *vectors_path, const char *deleted_path, qmx_segment **out) {
-    QMX_REQUIRE(desc && vectors_path && out, QMX_ERR_BAD_ARG, "NULL argument");
-    *out = nullptr;
-    QMX_REQUIRE(desc->dtype <= QMX_DTYPE_TQ && desc->dim > 0, QMX_ERR_BAD_ARG, "bad dtype / dim");
-    QMX_TRY(check_device(desc->device_id, nullptr));
-    // bytes per stored row in the file and the header in front of them
+// bytes per stored row of a storage file (reference row layout) and the header in front of the rows
+static int32_t file_row_bytes(const qmx_segment_desc *desc, uint64_t *row_bytes_out, uint64_t *header_out) {
     uint64_t row_bytes = 0, header = 0;
     switch (desc->dtype) {
         case QMX_DTYPE_F32: case QMX_DTYPE_F16: case QMX_DTYPE_U8: row_bytes = (uint64_t)desc->dim * elem_bytes(desc->dtype); header = 4; break;
@@ -888,6 +884,18 @@ int32_t qmx_segment_create_from_files(const qmx_segment_desc *desc, const char *
         }
         default: row_bytes = bq_row_bytes(desc->dim, desc->bq ? desc->bq->encoding : 0u); break;   // BQ
     }
+    *row_bytes_out = row_bytes;
+    *header_out = header;
+    return QMX_OK;
+}
+
+int32_t qmx_segment_create_from_files(const qmx_segment_desc *desc, const char *vectors_path, const char *deleted_path, qmx_segment **out) {
+    QMX_REQUIRE(desc && vectors_path && out, QMX_ERR_BAD_ARG, "NULL argument");
+    *out = nullptr;
+    QMX_REQUIRE(desc->dtype <= QMX_DTYPE_TQ && desc->dim > 0, QMX_ERR_BAD_ARG, "bad dtype / dim");
+    QMX_TRY(check_device(desc->device_id, nullptr));
+    uint64_t row_bytes = 0, header = 0;
+    QMX_TRY(file_row_bytes(desc, &row_bytes, &header));
     FILE *f = fopen(vectors_path, "rb");
     QMX_REQUIRE(f, QMX_ERR_BAD_ARG, "cannot open %s", vectors_path);
     int32_t rc = QMX_OK;
@@ -952,7 +960,7 @@ int32_t qmx_segment_create_chunked(const qmx_segment_desc *desc, const void *con
                                    qmx_segment **out) {
     QMX_REQUIRE(desc && out && (n_chunks == 0 || chunks), QMX_ERR_BAD_ARG, "NULL argument");
     *out = nullptr;
-    QMX_REQUIRE(desc->dtype <= QMX_DTYPE_U8, QMX_ERR_NOT_SUPPORTED, "chunked storages hold raw vectors (f32 / f16 / u8), not dtype %u", desc->dtype);
+    QMX_REQUIRE(desc->dtype <= QMX_DTYPE_TQ, QMX_ERR_BAD_ARG, "bad dtype %u", desc->dtype);
     QMX_REQUIRE(desc->distance <= QMX_DISTANCE_MANHATTAN && desc->dim > 0, QMX_ERR_BAD_ARG, "bad distance / dim");
     QMX_REQUIRE(desc->n <= 0xFFFFFFFFull, QMX_ERR_BAD_ARG, "PointOffsetType is u32: n=%llu too large", (unsigned long long)desc->n);
     QMX_REQUIRE(desc->n == 0 || (rows_per_chunk > 0 && (uint64_t)n_chunks * rows_per_chunk >= desc->n), QMX_ERR_BAD_ARG,
@@ -960,6 +968,36 @@ int32_t qmx_segment_create_chunked(const qmx_segment_desc *desc, const void *con
     QMX_REQUIRE(!(desc->flags & QMX_SEG_DATA_ON_DEVICE), QMX_ERR_BAD_ARG, "chunks are copied into one block: QMX_SEG_DATA_ON_DEVICE does not apply");
     hipDeviceProp_t prop;
     QMX_TRY(check_device(desc->device_id, &prop));
+    if (desc->dtype > QMX_DTYPE_U8) {
+        // Quantized chunked (appendable) storages (vector_storage/quantized/quantized_chunked_mmap_storage/{read_only.rs:20, read_write.rs:18}): the chunks'
+        // rows (reference row layout of the quantizer) are gathered into one device block, which then takes the ordinary route of qmx_segment_create -
+        // SQ / TQ rows are split into their aligned code block + extras columns, PQ / BQ blocks are kept as they are (the segment owns the gathered block).
+        uint64_t row_bytes = 0, header = 0;
+        QMX_TRY(file_row_bytes(desc, &row_bytes, &header));
+        const uint64_t src_stride = desc->row_stride_bytes ? desc->row_stride_bytes : row_bytes;
+        QMX_REQUIRE(src_stride >= row_bytes, QMX_ERR_BAD_ARG, "row_stride_bytes %llu < row size %llu", (unsigned long long)src_stride, (unsigned long long)row_bytes);
+        void *d_tmp = nullptr;
+        QMX_HIP(hipMalloc(&d_tmp, (size_t)std::max<uint64_t>(1, desc->n) * row_bytes));
+        hipError_t e = hipSuccess;
+        for (uint32_t c = 0; e == hipSuccess && c < n_chunks && (uint64_t)c * rows_per_chunk < desc->n; ++c) {
+            const uint64_t row0 = (uint64_t)c * rows_per_chunk, cnt = std::min<uint64_t>(rows_per_chunk, desc->n - row0);
+            if (!chunks[c]) { e = hipErrorInvalidValue; break; }
+            e = hipMemcpy2D((char *)d_tmp + row0 * row_bytes, row_bytes, chunks[c], src_stride, row_bytes, cnt, hipMemcpyDefault);
+        }
+        if (e != hipSuccess) {
+            (void)hipFree(d_tmp);
+            return hip_status(e, "chunk upload", __FILE__, __LINE__);
+        }
+        qmx_segment_desc d2 = *desc;
+        d2.data = d_tmp;
+        d2.row_stride_bytes = row_bytes;
+        d2.flags |= QMX_SEG_DATA_ON_DEVICE;
+        const int32_t rc = qmx_segment_create(&d2, out);
+        if (rc != QMX_OK || !*out || (*out)->d_rows != d_tmp) (void)hipFree(d_tmp);     // (split into the segment's own blocks, or refused)
+        else (*out)->owns_rows = true;                                                   // PQ / BQ: the gathered block IS the segment's block
+        if (rc == QMX_OK && *out) (*out)->flags &= ~QMX_SEG_DATA_ON_DEVICE;
+        return rc;
+    }
     qmx_segment *s = new (std::nothrow) qmx_segment();
     QMX_REQUIRE(s, QMX_ERR_OUT_OF_MEMORY, "host allocation failed");
     s->device = desc->device_id;
@@ -1106,28 +1144,6 @@ int32_t qmx_cast_f32(int32_t device_id, uint32_t dst_dtype, const float *in, uin
     if (rc == QMX_OK && hipDeviceSynchronize() != hipSuccess) rc = QMX_ERR_OTHER;
     bin.release();
     bout.release();
-    return rc;
-}
-
-int32_t qmx_synth_fill_f32(int32_t device_id, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, float *out_dev) {
-    QMX_REQUIRE(out_dev && dim > 0, QMX_ERR_BAD_ARG, "bad argument");
-    QMX_TRY(check_device(device_id, nullptr));
-    QMX_REQUIRE(is_device_ptr(out_dev), QMX_ERR_BAD_ARG, "out_dev must be device memory");
-    QMX_TRY(launch_synth_fill(nullptr, seed, row0, n, dim, out_dev));
-    QMX_HIP(hipDeviceSynchronize());
-    return QMX_OK;
-}
-
-int32_t qmx_synth_fill_latent_f32(int32_t device_id, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, uint32_t latent_dim, float noise,
-                                  float *out_dev) {
-    QMX_REQUIRE(out_dev && dim > 0 && latent_dim >= 1 && latent_dim <= 1024, QMX_ERR_BAD_ARG, "bad argument (latent_dim must be 1..1024)");
-    QMX_TRY(check_device(device_id, nullptr));
-    QMX_REQUIRE(is_device_ptr(out_dev), QMX_ERR_BAD_ARG, "out_dev must be device memory");
-    DevBuf w;
-    QMX_TRY(w.reserve((size_t)latent_dim * dim * sizeof(float)));
-    int32_t rc = launch_synth_latent(nullptr, seed, row0, n, dim, latent_dim, noise, (float *)w.p, out_dev);
-    if (rc == QMX_OK && hipDeviceSynchronize() != hipSuccess) rc = QMX_ERR_OTHER;
-    w.release();
     return rc;
 }
 
@@ -1544,7 +1560,7 @@ int32_t qmx_score_point(qmx_query *q, uint32_t query_index, uint32_t id, float *
 // ---------------------------------------------------------------------------------------------
 // brute-force top-k
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t MAX_TOP = 1024;   // top > MAX_TOP_FAST runs in passes of MAX_TOP_FAST, each bounded by the last key of the one before
+constexpr uint32_t MAX_TOP = 65536;  // top > MAX_TOP_FAST runs in passes of MAX_TOP_FAST, each bounded by the last key of the one before (a top of 65536: 1024 passes)
 
 static int32_t score_pairs_device(qmx_query *q, const PairSel &sel, const uint32_t *d_ids, uint64_t n_items, float *d_scores, bool timed);
 

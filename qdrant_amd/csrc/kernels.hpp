@@ -363,8 +363,6 @@ int32_t launch_custom_topk(hipStream_t st, const float *d_scores, uint64_t n, co
 int32_t launch_cosine_preprocess_f32(hipStream_t st, const float *in, float *out, uint64_t n, uint32_t dim);
 int32_t launch_cast_f32(hipStream_t st, int dst_dtype, const float *in, void *out, uint64_t count);
 int32_t launch_minmax_f32(hipStream_t st, const float *in, uint64_t count, float *min_out, float *max_out);
-int32_t launch_synth_fill(hipStream_t st, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, float *out);
-int32_t launch_synth_latent(hipStream_t st, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, uint32_t K, float noise, float *W_scratch, float *out);
 int32_t launch_gather_rows(hipStream_t st, const void *rows, uint64_t row_stride, uint64_t row_bytes,
                            const uint32_t *ids, uint32_t n, uint64_t n_rows, void *out, int *err_flag);
 

@@ -1,4 +1,4 @@
-// preprocess.hip — Metric::preprocess, element casts, row gather, synthetic data.
+// preprocess.hip — Metric::preprocess, element casts, row gather.
 #include <algorithm>
 
 #include "kernels.hpp"
@@ -158,89 +158,6 @@ int32_t launch_pack_queries(hipStream_t st, int dtype, int distance, const void 
     ::qmx::clear_stale_error();
     hipLaunchKernelGGL(pack_queries_kernel, dim3(nq), dim3(64), 0, st, dtype, distance, src, src_is_encoded, src_stride, dim,
                        (unsigned char *)tile, q_stride, aux_off);
-    QMX_HIP(hipGetLastError());
-    return QMX_OK;
-}
-
-// ------------------------------------------------------------------------------------------
-// counter-based synthetic rows (integer Irwin-Hall, no libm): the tests re-derive any element on the CPU
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
-    x += 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    return x ^ (x >> 31);
-}
-__global__ void synth_fill_kernel(uint64_t seed_mixed, uint64_t row0, uint64_t n, uint32_t dim, float *out) {
-    const uint64_t total = n * dim;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const uint64_t h = splitmix64(seed_mixed ^ (row0 * dim + i));
-        const int s = (int)(h & 0xFFFF) + (int)((h >> 16) & 0xFFFF) + (int)((h >> 32) & 0xFFFF) + (int)(h >> 48);
-        out[i] = (float)(s - 131070) * (1.0f / 37837.0f);
-    }
-}
-static uint64_t host_splitmix64(uint64_t x) {
-    x += 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    return x ^ (x >> 31);
-}
-int32_t launch_synth_fill(hipStream_t st, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, float *out) {
-    if (n == 0) return QMX_OK;
-    ::qmx::clear_stale_error();
-    hipLaunchKernelGGL(synth_fill_kernel, dim3(4096), dim3(256), 0, st, host_splitmix64(seed), row0, n, dim, out);
-    QMX_HIP(hipGetLastError());
-    return QMX_OK;
-}
-
-// Rows of low intrinsic dimension (what embedding models produce, and what an ANN index is for): x[r][c] = sum_k z[r][k] * W[k][c]
-// (+ noise * e[r][c]) with z, W, e from the generator above (z: seed, W: seed ^ 0x57, e: seed ^ 0xE5) and the sum as ONE fmaf chain
-// in k order, so the CPU oracle reproduces every element bit for bit.  Block = 8 rows; their latent coordinates sit in LDS.
-__global__ __launch_bounds__(256) void synth_latent_kernel(uint64_t seed_z, uint64_t seed_e, const float *W, uint64_t row0, uint64_t n, uint32_t dim,
-                                                           uint32_t K, float noise, float *out) {
-    extern __shared__ float z[];                                   // [8][K]
-    for (uint64_t rb = (uint64_t)blockIdx.x * 8; rb < n; rb += (uint64_t)gridDim.x * 8) {
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < 8 * K; i += 256) {
-            const uint64_t r = rb + i / K;
-            const uint64_t h = splitmix64(seed_z ^ ((row0 + r) * K + i % K));
-            const int s = (int)(h & 0xFFFF) + (int)((h >> 16) & 0xFFFF) + (int)((h >> 32) & 0xFFFF) + (int)(h >> 48);
-            z[i] = (float)(s - 131070) * (1.0f / 37837.0f);
-        }
-        __syncthreads();
-        for (uint32_t c = threadIdx.x; c < dim; c += 256) {
-            float acc[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) acc[r] = 0.0f;
-            for (uint32_t k = 0; k < K; ++k) {
-                const float w = W[(uint64_t)k * dim + c];
-#pragma unroll
-                for (int r = 0; r < 8; ++r) acc[r] = __builtin_fmaf(z[r * K + k], w, acc[r]);
-            }
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const uint64_t row = rb + r;
-                if (row >= n) break;
-                float v = acc[r];
-                if (noise != 0.0f) {
-                    const uint64_t h = splitmix64(seed_e ^ ((row0 + row) * dim + c));
-                    const int s = (int)(h & 0xFFFF) + (int)((h >> 16) & 0xFFFF) + (int)((h >> 32) & 0xFFFF) + (int)(h >> 48);
-                    v = __builtin_fmaf(noise, (float)(s - 131070) * (1.0f / 37837.0f), v);
-                }
-                out[row * dim + c] = v;
-            }
-        }
-    }
-}
-int32_t launch_synth_latent(hipStream_t st, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, uint32_t K, float noise, float *W_scratch,
-                            float *out) {
-    if (n == 0) return QMX_OK;
-    QMX_TRY(launch_synth_fill(st, seed ^ 0x57ull, 0, K, dim, W_scratch));
-    ::qmx::clear_stale_error();
-    const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 7) / 8, 1u << 16);
-    hipLaunchKernelGGL(synth_latent_kernel, dim3(grid), dim3(256), (size_t)8 * K * sizeof(float), st, host_splitmix64(seed), host_splitmix64(seed ^ 0xE5ull), W_scratch,
-                       row0, n, dim, K, noise, out);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }

@@ -306,3 +306,55 @@ def test_open_the_reference_storage_files(qa, tmp_path):
     F.check(F.lib().qmx_segment_read_rows(h, F.ptr(ids), 3, F.ptr(back)))
     assert np.array_equal(back, sq_rows[ids])
     F.check(F.lib().qmx_segment_destroy(h))
+
+
+@pytest.mark.parametrize("kind", ["sq", "pq", "bq", "tq"])
+def test_chunked_quantized_storage_equals_contiguous(qa, kind):
+    """`QuantizedChunkedMmapStorage` (quantized_chunked_mmap_storage/read_only.rs:20, read_write.rs:18): the appendable form of the quantized
+    storages.  Rows gathered from a chunk list (the quantizer's own row layout) score bit for bit like the contiguous storage."""
+    import ctypes as C
+    from qdrant_amd import _ffi as F
+    rng = np.random.default_rng(21)
+    n, dim, per = 1000, 64, 300
+    vecs = O.preprocess(O.DOT, rng.standard_normal((n, dim)).astype(np.float32))
+    d = F.SegmentDesc()
+    d.distance, d.dim, d.n, d.device_id = int(qa.Distance.Dot), dim, n, 0
+    if kind == "sq":
+        quant = qa.ScalarQuantizer.from_min_max(vecs, dim, qa.Distance.Dot)
+        rows, whole = quant.encode(vecs), None
+        whole = qa.EncodedVectorsU8(rows, quant)
+        p = quant.params()
+        d.dtype, d.sq = F.DTYPE_SQ_U8, C.pointer(p)
+    elif kind == "pq":
+        cen = O.PqOracle.train(vecs, dim, 8, 256, iters=2)
+        quant = qa.ProductQuantizer(dim, qa.Distance.Dot, 8, cen)
+        rows = quant.encode(vecs)
+        whole = qa.EncodedVectorsPQ(rows, quant)
+        p = quant.params()
+        d.dtype, d.pq = F.DTYPE_PQ, C.pointer(p)
+    elif kind == "bq":
+        quant = qa.BinaryQuantizer(dim, qa.Distance.Dot)
+        rows = quant.encode(vecs)
+        whole = qa.EncodedVectorsBin(rows, quant)
+        p = quant.params()
+        d.dtype, d.bq = F.DTYPE_BQ, C.pointer(p)
+    else:
+        quant = qa.TurboQuantizer(dim, qa.Distance.Dot, O.TQ_BITS4)
+        rows = quant.encode(vecs)
+        whole = qa.EncodedVectorsTQ(rows, quant)
+        p = quant.params()
+        d.dtype, d.tq = F.DTYPE_TQ, C.pointer(p)
+    chunks = [np.ascontiguousarray(rows[i:i + per]) for i in range(0, n, per)]
+    ptrs = (C.c_void_p * len(chunks))(*[c.ctypes.data for c in chunks])
+    st = type(whole).__new__(type(whole))
+    st.__dict__.update({k: v for k, v in whole.__dict__.items() if k != "_h"})
+    st._h = C.c_void_p()
+    F.check(F.lib().qmx_segment_create_chunked(C.byref(d), ptrs, per, len(chunks), C.byref(st._h)))
+    queries = rng.standard_normal((7, dim)).astype(np.float32)
+    ids = rng.permutation(n)[:333].astype(np.uint32)
+    a, b = qa.new_raw_scorer(queries, st), qa.new_raw_scorer(queries, whole)
+    assert np.array_equal(a.score_points(ids).view(np.uint32), b.score_points(ids).view(np.uint32))
+    got, want = qa.BatchFilteredSearcher(queries, st, 10).peek_top_all(), qa.BatchFilteredSearcher(queries, whole, 10).peek_top_all()
+    for g, w in zip(got, want):
+        assert g["idx"].tolist() == w["idx"].tolist() and np.array_equal(g["score"].view(np.uint32), w["score"].view(np.uint32))
+    assert np.array_equal(st.get_quantized_vector([0, 299, 300, 999]), rows[[0, 299, 300, 999]])

@@ -24,7 +24,7 @@ def _check(got, want):
         assert np.array_equal(g["idx"][uniq], w["idx"][uniq])
 
 
-@pytest.mark.parametrize("nq,top,dim", [(3, 65, 48), (3, 200, 48), (20, 130, 64), (2, 1000, 16), (9, 300, 100)])
+@pytest.mark.parametrize("nq,top,dim", [(3, 65, 48), (3, 200, 48), (20, 130, 64), (2, 1000, 16), (9, 300, 100), (2, 1025, 32), (1, 4000, 16)])
 def test_dense_f32_large_top(qa, nq, top, dim):
     rng = np.random.default_rng(top + nq)
     n = 5000
