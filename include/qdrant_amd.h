@@ -207,7 +207,8 @@ typedef struct qmx_tq_params {
 QMX_API int32_t qmx_tq_fit_plus(int32_t device_id, uint32_t distance, uint32_t dim, const qmx_tq_params *params, const float *sample, uint64_t n_sample,
                                 float *shift_out, float *scale_out);
 
-/* `TurboQuantizer::quantize` (turboquant/quantization.rs:211-296, TQMode::Normal) for a batch, on the device: vectors [n][dim] f32 as the storage
+/* `TurboQuantizer::quantize` (turboquant/quantization.rs:211-296; TQMode::Normal, and TQMode::Plus when `params` carries ec_shift / ec_scale: the shift / scale are applied to the rotated
+ * coordinates and `xm` joins the row's extras) for a batch, on the device: vectors [n][dim] f32 as the storage
  * holds them (cosine: normalised; host or device) -> out_rows [n][quantized size] bytes (host or device), the rows a QMX_DTYPE_TQ segment takes.
  * Rotation, length rescale and the two f64 sums (l2 length, centroid norm) follow the reference's operation order: rows are byte-identical to
  * the oracle's restatement. */
@@ -566,6 +567,13 @@ QMX_API int32_t qmx_multi_custom_search_topk(qmx_query *inner, const uint32_t *e
                                              const qmx_custom_query *queries, uint32_t n_queries, const uint64_t *point_offsets,
                                              uint32_t n_points, const uint64_t *point_deleted, uint64_t n_deleted_bits, uint32_t top,
                                              const uint32_t *ids, uint64_t n_ids, qmx_scored_point *out, uint32_t *out_counts);
+/* ... and as the scorer of the HNSW walk over the multi-vector POINTS (`g` as for qmx_multi_hnsw_search): every hop candidate is scored by MaxSim against
+ * every example of the query, then `score_by`.  Dense and SQ inner rows; a query's examples must fit the LDS (header + 16 bytes and the tokens per example
+ * <= 150 KiB).  Deleted flags are per point; a filter set on `inner` is read as a bitmap over points. */
+QMX_API int32_t qmx_multi_custom_hnsw_search(const qmx_hnsw *g, qmx_query *inner, const uint32_t *example_first, uint32_t n_examples,
+                                             const qmx_custom_query *queries, uint32_t n_queries, const uint64_t *point_offsets, uint32_t n_points,
+                                             const uint64_t *point_deleted, uint64_t n_deleted_bits, uint32_t top, uint32_t ef, qmx_scored_point *out,
+                                             uint32_t *out_counts, qmx_counters *counters);
 
 /* k-way merge of per-segment / per-GPU result lists = `BatchResultAggregator`
  * (lib/shard/src/search_result_aggregator.rs:50-121) with all point versions equal:

@@ -170,6 +170,8 @@ SIGNATURES = {
     "qmx_custom_hnsw_search": (C.c_int32, [_P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P, C.POINTER(Counters)]),
     "qmx_multi_custom_score_points": (C.c_int32, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32, _P]),
     "qmx_multi_custom_search_topk": (C.c_int32, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint64, C.c_uint32, _P, C.c_uint64, _P, _P]),
+    "qmx_multi_custom_hnsw_search": (C.c_int32, [_P, _P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint64, C.c_uint32, C.c_uint32, _P, _P,
+                                                 C.POINTER(Counters)]),
     "qmx_merge_topk": (C.c_int32, [C.c_int32, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P]),
     "qmx_merge_topk_async": (C.c_int32, [C.c_int32, _P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P]),
     "qmx_sharded_search_topk": (C.c_int32, [_P, C.c_uint32, C.c_uint32, _P, _P, _P, _P, C.POINTER(Counters)]),

@@ -2719,10 +2719,20 @@ struct CustomWalk {
     const qmx_custom_query *d_desc;
     const float *d_coefs;
     uint32_t n_queries, max_examples;
+    uint32_t lds_bytes = 0;      // multi-vector examples: bytes of the largest staged query block (header + offset table + the examples' tokens)
 };
 
 static int32_t launch_hnsw(const qmx_query *q, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
     const qmx_segment *s = q->seg;
+    if (a.cq_desc && a.mv_offsets) {
+        if (s->dtype <= QMX_DTYPE_U8) {
+            QMX_REQUIRE(s->fast_layout(), QMX_ERR_NOT_SUPPORTED, "adopted device block is not 16-byte aligned");
+            return launch_hnsw_custom_maxsim_dense(q->stream, (int)s->dtype, (int)s->distance, a, h, grid, per_cu);
+        }
+        if (s->dtype == QMX_DTYPE_SQ_U8) return launch_hnsw_custom_maxsim_sq(q->stream, (int)s->distance, a, h, grid, per_cu);
+        set_error("custom walk over multi-vector points: inner rows of dtype %u are not built (dense and SQ are)", s->dtype);
+        return QMX_ERR_NOT_SUPPORTED;
+    }
     if (a.cq_desc) {
         if (s->dtype <= QMX_DTYPE_U8) {
             QMX_REQUIRE(s->fast_layout(), QMX_ERR_NOT_SUPPORTED, "adopted device block is not 16-byte aligned");
@@ -2764,7 +2774,7 @@ static int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint3
     const qmx_segment *s = q->seg;
     ScanArgs a;
     fill_args(q, 0, q->nq, a);
-    const uint32_t n_searches = mw ? mw->n_queries : cw ? cw->n_queries : q->nq;
+    const uint32_t n_searches = cw ? cw->n_queries : mw ? mw->n_queries : q->nq;
     if (cw) {
         a.cq_desc = cw->d_desc;
         a.cq_coefs = cw->d_coefs;
@@ -2798,6 +2808,10 @@ static int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint3
     if (cw) {   // [32-byte header][the examples' entries]: staged when they fit a modest share of the LDS, read through L2 otherwise (PQ LUTs always)
         const uint64_t need = 32 + (uint64_t)std::max<uint32_t>(cw->max_examples, 1) * q->q_stride;
         h.lds_query_bytes = (need <= 48 * 1024 && h.lds_query_bytes != 0) ? (uint32_t)need : 32;
+        if (cw->lds_bytes) {      // multi-vector examples: always staged (the MaxSim policy reads its tokens from LDS)
+            QMX_REQUIRE(cw->lds_bytes <= HNSW_LDS_QUERY_MAX, QMX_ERR_NOT_SUPPORTED, "a custom query of %u bytes of example tokens does not fit the LDS", cw->lds_bytes);
+            h.lds_query_bytes = cw->lds_bytes;
+        }
     }
     h.log_cap = HNSW_LOG_CAP;
     {   // tests: force the whole-bitmap clear path
@@ -3449,6 +3463,85 @@ int32_t qmx_multi_custom_search_topk(qmx_query *inner, const uint32_t *example_f
     if (!out_dev) QMX_TRY(copy_out(inner->stream, out, d_out, (size_t)n_queries * top * sizeof(qmx_scored_point)));
     if (!cnt_dev) QMX_TRY(copy_out(inner->stream, out_counts, d_oc, (size_t)n_queries * 4));
     return check_err_flag(inner);
+}
+
+// GraphLayers::search over multi-vector POINTS with a custom query whose examples are multi-vectors (MultiCustomQueryScorer behind FilteredScorer)
+int32_t qmx_multi_custom_hnsw_search(const qmx_hnsw *g, qmx_query *inner, const uint32_t *example_first, uint32_t n_examples, const qmx_custom_query *queries,
+                                     uint32_t n_queries, const uint64_t *point_offsets, uint32_t n_points, const uint64_t *point_deleted, uint64_t n_deleted_bits,
+                                     uint32_t top, uint32_t ef, qmx_scored_point *out, uint32_t *out_counts, qmx_counters *counters) {
+    QMX_REQUIRE(g && inner && example_first && point_offsets && (n_queries == 0 || queries) && out && out_counts, QMX_ERR_BAD_ARG, "NULL argument");
+    const qmx_segment *s = inner->seg;
+    QMX_REQUIRE(g->device == s->device, QMX_ERR_BAD_ARG, "graph lives on device %d, the segment on %d", g->device, s->device);
+    QMX_REQUIRE(g->n_points <= n_points, QMX_ERR_OUT_OF_BOUNDS, "graph has %u points, the multi-vector storage %u", g->n_points, n_points);
+    QMX_REQUIRE(top >= 1, QMX_ERR_BAD_ARG, "top must be > 0");
+    QMX_REQUIRE(std::max(top, ef) <= HNSW_MAX_EF, QMX_ERR_NOT_SUPPORTED, "max(top, ef) = %u > %u not supported yet", std::max(top, ef), HNSW_MAX_EF);
+    QMX_REQUIRE(!is_device_ptr(example_first) && !is_device_ptr(point_offsets), QMX_ERR_BAD_ARG, "example_first and point_offsets are host arrays");
+    QMX_HIP(hipSetDevice(inner->device));
+    if (counters) memset(counters, 0, sizeof(*counters));
+    if (n_queries == 0) return QMX_OK;
+    QMX_REQUIRE(example_first[n_examples] <= inner->nq, QMX_ERR_OUT_OF_BOUNDS, "examples reach past the %u inner query vectors of the batch", inner->nq);
+    for (uint32_t e = 0; e < n_examples; ++e) QMX_REQUIRE(example_first[e] <= example_first[e + 1], QMX_ERR_BAD_ARG, "example_first is not ascending at %u", e);
+    for (uint32_t p = 0; p < n_points; ++p) QMX_REQUIRE(point_offsets[p] <= point_offsets[p + 1], QMX_ERR_BAD_ARG, "point_offsets is not ascending at %u", p);
+    QMX_REQUIRE(point_offsets[n_points] <= s->n, QMX_ERR_OUT_OF_BOUNDS, "point_offsets reach past the %llu inner rows of the segment", (unsigned long long)s->n);
+    uint32_t max_examples = 0;
+    QMX_TRY(custom_validate(inner, queries, n_queries, n_examples, &max_examples));
+    uint64_t lds_need = 0;        // the largest staged block: header + offset table + per example (16-byte MaxSim header + its tokens)
+    for (uint32_t i = 0; i < n_queries; ++i) {
+        const qmx_custom_query &c = queries[i];
+        const uint32_t ne = c.kind <= QMX_CUSTOM_RECO_SUM_SCORES ? c.n_a + c.n_b : c.n_a + 2 * c.n_b;
+        uint64_t need = 32 + ((4ull * ne + 15) & ~15ull);
+        for (uint32_t e = 0; e < ne; ++e) need += 16 + (uint64_t)(example_first[c.first + e + 1] - example_first[c.first + e]) * inner->q_stride;
+        lds_need = std::max(lds_need, need);
+    }
+    QMX_REQUIRE(lds_need <= HNSW_LDS_QUERY_MAX, QMX_ERR_NOT_SUPPORTED, "a custom query of %llu bytes of example tokens does not fit the LDS",
+                (unsigned long long)lds_need);
+    const bool out_dev = is_device_ptr(out), cnt_dev = is_device_ptr(out_counts);
+    if (g->n_points == 0) {
+        if (cnt_dev) QMX_HIP(hipMemset(out_counts, 0, (size_t)n_queries * 4));
+        else memset(out_counts, 0, (size_t)n_queries * 4);
+        return QMX_OK;
+    }
+    QMX_TRY(inner->mv_qfirst.reserve((size_t)(n_examples + 1) * 4));
+    QMX_TRY(inner->mv_offsets.reserve((size_t)(n_points + 1) * 8));
+    QMX_TRY(inner->cq_desc.reserve((size_t)n_queries * sizeof(qmx_custom_query)));
+    QMX_HIP(hipMemcpyAsync(inner->mv_qfirst.p, example_first, (size_t)(n_examples + 1) * 4, hipMemcpyHostToDevice, inner->stream));
+    QMX_HIP(hipMemcpyAsync(inner->mv_offsets.p, point_offsets, (size_t)(n_points + 1) * 8, hipMemcpyHostToDevice, inner->stream));
+    QMX_HIP(hipMemcpyAsync(inner->cq_desc.p, queries, (size_t)n_queries * sizeof(qmx_custom_query), hipMemcpyHostToDevice, inner->stream));
+    MultiWalk mw;
+    memset(&mw, 0, sizeof(mw));
+    mw.d_qfirst = (const uint32_t *)inner->mv_qfirst.p;
+    mw.d_offsets = (const uint64_t *)inner->mv_offsets.p;
+    mw.n_queries = n_queries;
+    mw.max_tokens = 1;
+    mw.del.n_rows = n_points;
+    if (point_deleted && n_deleted_bits) {
+        const void *d_bits = nullptr;
+        QMX_TRY(stage_in(inner, inner->mv_deleted, point_deleted, (size_t)((n_deleted_bits + 63) / 64) * 8, &d_bits));
+        mw.del.point_deleted = (const uint64_t *)d_bits;
+        mw.del.n_point_bits = n_deleted_bits;
+    }
+    if (inner->has_filter) { mw.del.allowed = (const uint64_t *)inner->filter.p; mw.del.n_allowed_bits = inner->n_filter_bits; }
+    CustomWalk cw{(const qmx_custom_query *)inner->cq_desc.p, (const float *)inner->cq_coefs.p, n_queries, max_examples, (uint32_t)lds_need};
+    qmx_scored_point *d_out = out;
+    uint32_t *d_counts = out_counts;
+    if (!out_dev) { QMX_TRY(inner->out.reserve((size_t)n_queries * top * sizeof(qmx_scored_point))); d_out = (qmx_scored_point *)inner->out.p; }
+    if (!cnt_dev) { QMX_TRY(inner->counts.reserve((size_t)n_queries * 4)); d_counts = (uint32_t *)inner->counts.p; }
+    QMX_TRY(inner->hnsw_scored.reserve((size_t)n_queries * 4));
+    const bool timed = inner->timing || (s->flags & QMX_SEG_TIME_KERNELS) != 0;
+    QMX_TRY(hnsw_enqueue(g, inner, top, ef, d_out, d_counts, (uint32_t *)inner->hnsw_scored.p, timed, false, &mw, nullptr, &cw));
+    if (!out_dev) QMX_TRY(copy_out(inner->stream, out, d_out, (size_t)n_queries * top * sizeof(qmx_scored_point)));
+    if (!cnt_dev) QMX_TRY(copy_out(inner->stream, out_counts, d_counts, (size_t)n_queries * 4));
+    QMX_TRY(check_err_flag(inner));
+    if (counters) {
+        std::vector<uint32_t> sc(n_queries);
+        QMX_HIP(hipMemcpy(sc.data(), inner->hnsw_scored.p, (size_t)n_queries * 4, hipMemcpyDeviceToHost));
+        uint64_t total = 0;
+        for (uint32_t v : sc) total += v;
+        counters->vectors_scored = total;
+        counters->kernel_launches = 1;
+        if (timed) { const float before = inner->timing_ms; QMX_TRY(timing_fold(inner)); counters->kernel_ms = inner->timing_ms - before; }
+    }
+    return QMX_OK;
 }
 
 int32_t qmx_hnsw_search_with_vectors(const qmx_hnsw *g, qmx_query *links, qmx_query *base, uint32_t top, uint32_t ef, qmx_scored_point *out,

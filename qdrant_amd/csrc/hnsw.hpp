@@ -118,8 +118,8 @@ struct HopMaxSim {
 // behind the header.
 struct CustomHeader {
     uint32_t kind, n_a, n_b, coef_first;
-    const unsigned char *entries;       // the examples' query entries, a.q_stride apart (LDS or global)
-    uint64_t pad;
+    const unsigned char *entries;       // the examples' query entries, a.q_stride apart (LDS or global) ...
+    const uint32_t *ex_off;             // ... or, when the examples are multi-vectors of different lengths: byte offset of example e's first token from `entries`
 };
 static_assert(sizeof(CustomHeader) == 32, "the custom walk's LDS header");
 template <class H, class = void>
@@ -133,11 +133,14 @@ struct HopCustom {
     static constexpr bool INTERNAL_NORM = false;
     static constexpr bool MULTI = false;
     static constexpr bool CUSTOM = true;
+    static constexpr bool MULTI_EXAMPLES = is_maxsim<HI>::value;      // MultiCustomQueryScorer: every example is a multi-vector scored by MaxSim
     static __device__ __forceinline__ float score(const ScanArgs &a, const unsigned char *qp, uint32_t id, int sub) {
         const CustomHeader *hd = reinterpret_cast<const CustomHeader *>(qp - sizeof(CustomHeader));
         const unsigned char *ent = hd->entries;
-        return custom_score_by(hd->kind, hd->n_a, hd->n_b, a.cq_coefs + hd->coef_first,
-                               [&](uint32_t e) { return HI::score(a, ent + (size_t)e * a.q_stride, id, sub); });
+        const uint32_t *off = hd->ex_off;
+        return custom_score_by(hd->kind, hd->n_a, hd->n_b, a.cq_coefs + hd->coef_first, [&](uint32_t e) {
+            return HI::score(a, MULTI_EXAMPLES ? ent + off[e] : ent + (size_t)e * a.q_stride, id, sub);
+        });
     }
 };
 
@@ -619,6 +622,33 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const ScanArgs a, const
             const qmx_custom_query cq = a.cq_desc[qi];
             const uint32_t ne = cq.kind <= QMX_CUSTOM_RECO_SUM_SCORES ? cq.n_a + cq.n_b : cq.n_a + 2 * cq.n_b;
             const unsigned char *qg = reinterpret_cast<const unsigned char *>(a.queries) + (uint64_t)cq.first * a.q_stride;
+            if constexpr (H::MULTI_EXAMPLES) {
+                // [header][offset table, 16-byte padded][per example: 16-byte MaxSim header (its token count) + its tokens]; the API sized the launch for it
+                unsigned char *base = q_lds + sizeof(CustomHeader);
+                uint32_t *tab = reinterpret_cast<uint32_t *>(base);
+                uint32_t off = (4 * ne + 15u) & ~15u;
+                __syncthreads();
+                for (uint32_t e = 0; e < ne; ++e) {
+                    const uint32_t t0 = a.mv_qfirst[cq.first + e], nt = a.mv_qfirst[cq.first + e + 1] - t0;
+                    if (lane == 0) {
+                        tab[e] = off + 16;
+                        *reinterpret_cast<uint32_t *>(base + off) = nt;
+                    }
+                    const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(a.queries) + (uint64_t)t0 * a.q_stride);
+                    uint4 *dst = reinterpret_cast<uint4 *>(base + off + 16);
+                    for (uint32_t i = (uint32_t)lane; i < nt * (a.q_stride / 16); i += 64) dst[i] = src[i];
+                    off += 16 + nt * a.q_stride;
+                }
+                if (lane == 0) {
+                    CustomHeader *hd = reinterpret_cast<CustomHeader *>(q_lds);
+                    hd->kind = cq.kind; hd->n_a = cq.n_a; hd->n_b = cq.n_b; hd->coef_first = cq.coef_first;
+                    hd->entries = base;
+                    hd->ex_off = tab;
+                }
+                __syncthreads();
+                hnsw_search_one<H, E>(a, h, q_lds + sizeof(CustomHeader), hop_ids, hop_scores, vis, vlog, qi, lane);
+                continue;
+            }
             const bool fits = sizeof(CustomHeader) + (uint64_t)ne * a.q_stride <= h.lds_query_bytes;
             __syncthreads();
             if (fits) {
@@ -630,7 +660,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const ScanArgs a, const
                 CustomHeader *hd = reinterpret_cast<CustomHeader *>(q_lds);
                 hd->kind = cq.kind; hd->n_a = cq.n_a; hd->n_b = cq.n_b; hd->coef_first = cq.coef_first;
                 hd->entries = fits ? q_lds + sizeof(CustomHeader) : qg;
-                hd->pad = 0;
+                hd->ex_off = nullptr;
             }
             __syncthreads();
             hnsw_search_one<H, E>(a, h, q_lds + sizeof(CustomHeader), hop_ids, hop_scores, vis, vlog, qi, lane);
@@ -717,6 +747,14 @@ struct HnswCustomLauncher {
     int *per_cu;
     template <class P> int32_t row(const ScanArgs &a) const { return launch_hnsw_hop<HopCustom<HopRow<P>>>(st, a, *h, grid, per_cu); }
     template <class S> int32_t small(const ScanArgs &a) const { return launch_hnsw_hop<HopCustom<HopSmall<S>>>(st, a, *h, grid, per_cu); }
+};
+struct HnswCustomMaxSimLauncher {
+    hipStream_t st;
+    const HnswArgs *h;
+    uint32_t grid;
+    int *per_cu;
+    template <class P> int32_t row(const ScanArgs &a) const { return launch_hnsw_hop<HopCustom<HopMaxSim<HopRow<P>>>>(st, a, *h, grid, per_cu); }
+    template <class S> int32_t small(const ScanArgs &a) const { return launch_hnsw_hop<HopCustom<HopMaxSim<HopSmall<S>>>>(st, a, *h, grid, per_cu); }
 };
 struct HnswMaxSimLauncher {
     hipStream_t st;

@@ -9,4 +9,8 @@ int32_t launch_hnsw_custom_dense(hipStream_t st, int dtype, int distance, const 
     return dispatch_dense(HnswCustomLauncher{st, &h, grid, per_cu}, dtype, distance, a);
 }
 
+int32_t launch_hnsw_custom_maxsim_dense(hipStream_t st, int dtype, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
+    return dispatch_dense(HnswCustomMaxSimLauncher{st, &h, grid, per_cu}, dtype, distance, a);
+}
+
 }  // namespace qmx

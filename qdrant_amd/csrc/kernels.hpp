@@ -136,8 +136,6 @@ int32_t launch_scan_tq_mfma(hipStream_t st, int qt, ScanMode mode, const ScanArg
 int32_t launch_hnsw_tq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_tq_split(hipStream_t st, const void *rows, uint64_t src_stride, uint64_t n, uint32_t code_bytes, uint32_t dst_stride, int has_l2,
                         void *codes, float *sf, float *l2, float *xm);
-int32_t launch_tq_gather_rows(hipStream_t st, const void *codes, uint32_t dst_stride, const float *sf, const float *l2, uint32_t code_bytes, int has_l2,
-                              const uint32_t *ids, uint32_t n, uint64_t n_rows, void *out, uint32_t out_stride, int *err_flag);
 int32_t launch_tq_rotate(hipStream_t st, const float *d_in, uint32_t n, const TqRotationHost &h, double *d_out);
 int32_t launch_tq_plus_fit(hipStream_t st, double *d_rot, uint32_t n, uint32_t padded_dim, uint32_t distance, double min_q, double max_q, float c_outer,
                            float *d_shift, float *d_scale);
@@ -154,6 +152,9 @@ int32_t launch_hnsw_custom_sq(hipStream_t st, int distance, const ScanArgs &a, c
 int32_t launch_hnsw_custom_bq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_custom_pq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_custom_tq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
+// ... whose examples are multi-vectors over multi-vector points (MultiCustomQueryScorer: HopCustom over HopMaxSim); dense and SQ inner rows
+int32_t launch_hnsw_custom_maxsim_dense(hipStream_t st, int dtype, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
+int32_t launch_hnsw_custom_maxsim_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_maxsim_dense(hipStream_t st, int dtype, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_maxsim_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_maxsim_bq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);

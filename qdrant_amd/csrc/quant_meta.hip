@@ -397,7 +397,7 @@ int32_t parse_tq(const JsonValue &root, qmx_quant_meta &m, MetaOwner &o) {
     const JsonValue *md = root.get("mode");
     QMX_REQUIRE(md && md->kind == JsonValue::String, QMX_ERR_BAD_ARG, "metadata: \"mode\" is missing or not a string");
     if (md->str == "normal") m.tq.plus_mode = 0;
-    else if (md->str == "plus") m.tq.plus_mode = 1;      // qmx_segment_create refuses it (TQ+ is not built): the caller keeps its CPU scorer
+    else if (md->str == "plus") m.tq.plus_mode = 1;      // (the per-coordinate shift / scale arrays travel in qmx_tq_params.ec_shift / ec_scale)
     else {
         set_error("metadata: unknown TQMode \"%s\"", md->str.c_str());
         return QMX_ERR_BAD_ARG;

@@ -116,6 +116,9 @@ int32_t launch_hnsw_sq(hipStream_t st, int distance, const ScanArgs &a, const Hn
 int32_t launch_hnsw_custom_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
     return dispatch_sq(HnswCustomLauncher{st, &h, grid, per_cu}, distance, a);
 }
+int32_t launch_hnsw_custom_maxsim_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
+    return dispatch_sq(HnswCustomMaxSimLauncher{st, &h, grid, per_cu}, distance, a);
+}
 int32_t launch_hnsw_maxsim_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
     return dispatch_sq(HnswMaxSimLauncher{st, &h, grid, per_cu}, distance, a);
 }

@@ -78,31 +78,6 @@ int32_t launch_tq_split(hipStream_t st, const void *rows, uint64_t src_stride, u
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }
-// the reference row of point ids[i] back together (qmx_segment_read_rows)
-__global__ __launch_bounds__(64) void tq_gather_kernel(const uint8_t *codes, uint32_t dst_stride, const float *sf, const float *l2, uint32_t code_bytes,
-                                                       int has_l2, const uint32_t *ids, uint64_t n_rows, uint8_t *out, uint32_t out_stride, int *err_flag) {
-    const uint32_t id = ids[blockIdx.x];
-    if (id >= n_rows) {
-        if (threadIdx.x == 0) *err_flag = 1;
-        return;
-    }
-    uint8_t *dst = out + (uint64_t)blockIdx.x * out_stride;
-    for (uint32_t i = threadIdx.x; i < code_bytes; i += 64) dst[i] = codes[(uint64_t)id * dst_stride + i];
-    if (threadIdx.x == 0) {
-        memcpy(dst + code_bytes, &sf[id], 4);
-        if (has_l2) memcpy(dst + code_bytes + 4, &l2[id], 4);
-    }
-}
-int32_t launch_tq_gather_rows(hipStream_t st, const void *codes, uint32_t dst_stride, const float *sf, const float *l2, uint32_t code_bytes, int has_l2,
-                              const uint32_t *ids, uint32_t n, uint64_t n_rows, void *out, uint32_t out_stride, int *err_flag) {
-    if (n == 0) return QMX_OK;
-    ::qmx::clear_stale_error();
-    hipLaunchKernelGGL(tq_gather_kernel, dim3(n), dim3(64), 0, st, (const uint8_t *)codes, dst_stride, sf, l2, code_bytes, has_l2, ids, n_rows, (uint8_t *)out,
-                       out_stride, err_flag);
-    QMX_HIP(hipGetLastError());
-    return QMX_OK;
-}
-
 // ---- HadamardRotation::apply for a batch of vectors: in [n][dim] f32 -> out [n][padded_dim] f64 (the zero padding past rot_dim untouched) ----
 // One block per vector, the vector in LDS (two f64 buffers: the gathers ping-pong).  Every element sees the reference's operation sequence:
 // one add or sub per butterfly stage in ascending stride order, one multiply by 1 / sqrt(size), so the f64 results are bit-identical.

@@ -585,6 +585,20 @@ class MultiDenseVectorStorage:
                                                      0 if idarr is None else len(idarr), F.ptr(out), F.ptr(counts)))
         return [out[i, :counts[i]].copy() for i in range(nq)]
 
+    def custom_search_hnsw(self, graph, queries, top: int, ef: int, with_counters: bool = False):
+        """`GraphLayers::search` over the multi-vector POINTS with a `MultiCustomQueryScorer` per custom query (examples = multi-vectors), on device."""
+        scorer, efirst, descs = self._custom(queries)
+        nq = len(queries)
+        out = np.zeros((nq, max(top, 1)), dtype=ScoredPointOffset)
+        counts = np.zeros(nq, dtype=np.uint32)
+        words = _bits_to_words(self.point_deleted)
+        ctr = F.Counters()
+        F.check(F.lib().qmx_multi_custom_hnsw_search(graph._h, scorer._h, F.ptr(efirst), len(efirst) - 1, descs, nq, F.ptr(self.offsets), self.count,
+                                                     F.ptr(words), 0 if self.point_deleted is None else len(self.point_deleted), top, ef, F.ptr(out),
+                                                     F.ptr(counts), C.byref(ctr)))
+        res = [out[i, :counts[i]].copy() for i in range(nq)]
+        return (res, ctr) if with_counters else res
+
     def search_hnsw(self, graph, multi_queries, top: int, ef: int, with_counters: bool = False):
         """`GraphLayers::search` over the multi-vector POINTS with the MaxSim scorer of every multi-query (`MultiMetricQueryScorer` /
         `QuantizedMultiQueryScorer` behind `FilteredScorer`), on device."""

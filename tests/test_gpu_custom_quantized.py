@@ -198,3 +198,51 @@ def test_custom_queries_over_multivector_points(qa, inner_kind):
         uniq = np.array([(top[qi]["score"] == x).sum() == 1 for x in top[qi]["score"]])
         assert np.array_equal(top[qi]["idx"][uniq], all_ids[live][order][uniq])
         assert not deleted[top[qi]["idx"]].any()
+
+
+@pytest.mark.parametrize("inner_kind", ["dense", "sq"])
+def test_multivector_custom_walk_equals_the_oracle_walk(qa, inner_kind):
+    """GraphLayers::search over multi-vector points with a MultiCustomQueryScorer: the oracle builds the graph (score_internal_max_similarity) and walks it
+    with qo_scorer kind 6 over kind-4 example scorers; the device walks the same graph with HopCustom over HopMaxSim."""
+    distance, dim, n_points = O.DOT, 64, 900
+    rng = np.random.default_rng(41)
+    centers = rng.standard_normal((20, dim)).astype(np.float32) * 2
+    lens = rng.integers(1, 7, n_points)
+    offsets = np.zeros(n_points + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(lens)
+    inner = O.preprocess(distance, (centers[rng.integers(20, size=int(offsets[-1]))] + rng.standard_normal((int(offsets[-1]), dim))).astype(np.float32))
+    deleted = rng.random(n_points) < 0.15
+    ost = O.DenseStorage(O.F32, distance, inner)
+    if inner_kind == "dense":
+        st = qa.MultiDenseVectorStorage(inner, offsets, _dist(qa, distance))
+        mo = O.MultiOracle(("dense", ost), offsets, point_deleted=deleted)
+    else:
+        quant = qa.ScalarQuantizer.from_min_max(inner, dim, _dist(qa, distance))
+        osq = O.SqOracle(distance, dim, quant.alpha, quant.offset)
+        osq.rows = osq.encode_rows(inner)
+        st = qa.QuantizedMultivectorStorage(qa.EncodedVectorsU8(quant.encode(inner), quant), offsets)
+        mo = O.MultiOracle(("sq", ost, osq), offsets, point_deleted=deleted)
+    st.set_deleted(deleted)
+    graph_o = mo.build(m=8, ef_construct=32)
+    graph = qa.GraphLayers.from_plain(graph_o.export_plain())
+    fac = O.ScorerFactory("multi", mo)
+    MV = lambda k: [(centers[rng.integers(20)] + rng.standard_normal((int(rng.integers(1, 6)), dim))).astype(np.float32) for _ in range(k)]       # noqa: E731
+    queries = [
+        qa.CustomQuery.recommend_best_score(MV(2), MV(2)),
+        qa.CustomQuery.recommend_sum_scores(MV(3), MV(1)),
+        qa.CustomQuery.discover(MV(1)[0], [tuple(MV(2)) for _ in range(2)]),
+        qa.CustomQuery.feedback_naive(MV(1)[0], list(zip(MV(3), [0.9, 0.2, 0.6])), a=0.7, b=1.2, c=0.5),
+    ]
+    for q in queries:
+        q.examples = [np.atleast_2d(e) for e in q.examples]
+    for top, ef in ((10, 64), (5, 16)):
+        got, ctr = st.custom_search_hnsw(graph, queries, top, ef, with_counters=True)
+        total = 0
+        for qi, q in enumerate(queries):
+            s, keep = fac.custom([O.preprocess(distance, e) for e in q.examples], q.kind, q.n_a, q.n_b, q.coefs)
+            want, ns = graph_o.search_scorer(s, top, ef)
+            total += ns
+            assert got[qi]["idx"].tolist() == want["idx"].tolist(), (inner_kind, qi, top, ef)
+            assert np.array_equal(_bits(got[qi]["score"]), _bits(want["score"])), (inner_kind, qi)
+            assert not deleted[got[qi]["idx"]].any()
+        assert ctr.vectors_scored == total
