@@ -427,7 +427,9 @@ def hbm_point(Qh, storage, queries, n, dim, top, local_rank, stream, lib, F, sha
         F.check(lib.qmx_query_timing(backend.qh, C.byref(ms), C.byref(nl)))
         kernel_ms = ms.value / max(1, nl.value)
         per_step = max(1.0, nl.value / float(steps))            # launches per pass over the block (the prefilter over a derived copy: 2)
-        alg = int((bytes_per_pass if bytes_per_pass else n * dim * 4) / per_step)
+        # exact track: every launch streams the whole f32 block (a batch of more than 64 queries is several such passes); prefilter: the derived copy
+        # is covered by the pass's two launches, the figure is their mean
+        alg = int(bytes_per_pass / per_step) if bytes_per_pass else n * dim * 4
         gbps = alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         sym = F.last_kernel(backend.qh)
         return _attach_traffic({"batch": Qh, "kernel": sym, "kernel_ms": round(kernel_ms, 4), "launches_timed": int(nl.value), "launches_per_pass": per_step,

@@ -242,7 +242,9 @@ def test_multivector_custom_walk_equals_the_oracle_walk(qa, inner_kind):
             s, keep = fac.custom([O.preprocess(distance, e) for e in q.examples], q.kind, q.n_a, q.n_b, q.coefs)
             want, ns = graph_o.search_scorer(s, top, ef)
             total += ns
-            assert got[qi]["idx"].tolist() == want["idx"].tolist(), (inner_kind, qi, top, ef)
             assert np.array_equal(_bits(got[qi]["score"]), _bits(want["score"])), (inner_kind, qi)
+            # (SQ scores are integers times a constant: two points can tie, and the order among equals is unpinned - compare tie groups as sets)
+            for sc in np.unique(want["score"]):
+                assert set(got[qi]["idx"][got[qi]["score"] == sc].tolist()) == set(want["idx"][want["score"] == sc].tolist()), (inner_kind, qi, top, ef)
             assert not deleted[got[qi]["idx"]].any()
         assert ctr.vectors_scored == total
