@@ -274,7 +274,7 @@ static bool bq_mfma_ok(const qmx_query *q);
 static uint32_t tile_qt(const qmx_segment *s, const qmx_query *q) {
     if (s->dtype == QMX_DTYPE_BQ) return bq_mfma_ok(q) && (size_t)MAX_QT_MFMA * q->q_stride <= 150 * 1024 ? MAX_QT_MFMA : MAX_QT;
     if (s->dtype == QMX_DTYPE_SQ_U8) return mfma_scan_ok(s) ? MAX_QT_MFMA : MAX_QT;
-    if (s->dtype == QMX_DTYPE_TQ) return mfma_scan_ok(s) && (size_t)MAX_QT_MFMA * q->q_stride <= 150 * 1024 ? MAX_QT_MFMA : MAX_QT;
+    if (s->dtype == QMX_DTYPE_TQ) return mfma_scan_ok(s) && (size_t)MAX_QT_MFMA * q->q_stride <= 150 * 1024 ? MAX_QT_MFMA : 4;      // (the VALU kernels of TurboQuant are built for 1, 2 and 4 queries)
     return mfma_scan_ok(s) && (size_t)MAX_QT_MFMA * (((size_t)s->dim * 4 + 127) / 128 * 128 + QUERY_AUX_BYTES) <= 150 * 1024 ? MAX_QT_MFMA : MAX_QT;
 }
 
@@ -1499,7 +1499,7 @@ static int32_t launch_scan(const qmx_query *q, int qt, ScanMode mode, const Scan
     if (s->dtype == QMX_DTYPE_TQ) {
         // 4 queries already pay for the padded 16-query matrix-core pass (integer arithmetic either way: the same bits)
         if (qt >= 4 && mfma_scan_ok(s)) return launch_scan_tq_mfma(q->stream, std::max(qt, 8), mode, a, s->num_cus, grid);
-        return launch_scan_tq(q->stream, std::min(qt, (int)MAX_QT), mode, a, s->num_cus, grid);
+        return launch_scan_tq(q->stream, std::min(qt, 4), mode, a, s->num_cus, grid);
     }
     set_error("dtype %u not built yet", s->dtype);
     return QMX_ERR_NOT_SUPPORTED;

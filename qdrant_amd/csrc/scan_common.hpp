@@ -295,16 +295,29 @@ int32_t launch_qt(hipStream_t st, ScanMode mode, const ScanArgs &a, int num_cus,
                : launch_scan_inst<P, QT, R, U, false, SCAN_SCORES>(st, a, num_cus, grid);
 }
 
+// Policies whose batches of 4 and more queries run on the matrix cores (TurboQuant: scan_sq_mfma.hip) say MAX_VALU_QT = 4: their 8- and 16-query
+// tiled VALU kernels (the largest instantiations of this file's kernel, and the slowest to compile) are not built; api.hip tiles by 4 for them
+// when the matrix-core route is switched off.
+template <class P, class = void>
+struct max_valu_qt { static constexpr int value = 16; };
+template <class P>
+struct max_valu_qt<P, decltype((void)P::MAX_VALU_QT)> { static constexpr int value = P::MAX_VALU_QT; };
+
 template <class P>
 int32_t launch_policy(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid) {
     switch (qt) {
         case 1: return launch_qt<P, 1, 4, 4>(st, mode, a, num_cus, grid);
         case 2: return launch_qt<P, 2, 4, 2>(st, mode, a, num_cus, grid);
         case 4: return launch_qt<P, 4, 2, 4>(st, mode, a, num_cus, grid);
-        case 8: return launch_qt<P, 8, 2, 2>(st, mode, a, num_cus, grid);
-        case 16: return launch_qt<P, 16, P::R16, 2>(st, mode, a, num_cus, grid);
-        default: set_error("unsupported query tile %d", qt); return QMX_ERR_BAD_ARG;
+        case 8:
+            if constexpr (max_valu_qt<P>::value >= 8) return launch_qt<P, 8, 2, 2>(st, mode, a, num_cus, grid);
+            break;
+        case 16:
+            if constexpr (max_valu_qt<P>::value >= 16) return launch_qt<P, 16, P::R16, 2>(st, mode, a, num_cus, grid);
+            break;
     }
+    set_error("unsupported query tile %d", qt);
+    return QMX_ERR_BAD_ARG;
 }
 
 // 8-lane reductions of the per-lane partials of one row (DPP only, no LDS)

@@ -44,6 +44,7 @@ struct RowTQ4 {
     static constexpr int NRAUX = 0;
     static constexpr int R16 = 2;
     static constexpr int QPIECES = 4;
+    static constexpr int MAX_VALU_QT = 4;       // 4 queries and more: the int8 matrix cores (scan_sq_mfma.hip TqOps)
     typedef uint32_t acc_t;
     static __device__ __forceinline__ void row_aux(acc_t (&)[1], const uint4 &) {}
     static __device__ __forceinline__ void mac(acc_t (&)[NACC], const uint4 &, const uint4 &) {}
@@ -92,6 +93,7 @@ struct RowTQ2 {
     static constexpr int NRAUX = 0;
     static constexpr int R16 = 2;
     static constexpr int QPIECES = 8;
+    static constexpr int MAX_VALU_QT = 4;
     typedef uint32_t acc_t;
     static __device__ __forceinline__ void row_aux(acc_t (&)[1], const uint4 &) {}
     static __device__ __forceinline__ void mac(acc_t (&)[NACC], const uint4 &, const uint4 &) {}
@@ -139,6 +141,7 @@ struct RowTQ1 {
     static constexpr int NRAUX = 0;
     static constexpr int R16 = PLANES == 8 ? 2 : 1;
     static constexpr int QPIECES = PLANES;
+    static constexpr int MAX_VALU_QT = 4;
     typedef uint32_t acc_t;
     static __device__ __forceinline__ void row_aux(acc_t (&)[1], const uint4 &) {}
     static __device__ __forceinline__ void mac(acc_t (&)[NACC], const uint4 &, const uint4 &) {}
