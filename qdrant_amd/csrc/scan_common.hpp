@@ -530,6 +530,8 @@ __global__ __launch_bounds__(PAIR_BLOCK) void pair_kernel(const ScanArgs a, cons
             id = 0;
             qi = 0;
         }
+        // (a slot's dead tail - per-query lists are sized for the worst case, counts[] says how much is live - costs nothing: a wave whose eight items are all dead moves on)
+        if (!__ballot(valid)) continue;
         const float score = group_score<P>(a, queries + (uint64_t)qi * a.q_stride, id, t);
         if (valid && t == 0) a.scores[item] = score;
     }
