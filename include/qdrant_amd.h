@@ -761,6 +761,14 @@ QMX_API int32_t qmx_hnsw_build(const qmx_segment *seg, const qmx_hnsw_build_para
  * every other dtype it may be NULL and the call equals qmx_hnsw_build. */
 QMX_API int32_t qmx_hnsw_build_quantized(const qmx_segment *quantized, const qmx_segment *original, const qmx_hnsw_build_params *params,
                                          qmx_hnsw **out);
+
+/* The HNSW build over multi-vector points (hnsw/build.rs:334-341 through `FilteredScorer::new_internal`, point_scorer.rs:183-218: every score of
+ * the build is `MultiMetricQueryScorer::score_internal`, multi_metric_query_scorer.rs, or for quantized inner rows `score_internal_max_similarity`,
+ * quantized_multivector_storage/mod.rs:366-393): as qmx_hnsw_build, with point p = inner rows [point_offsets[p], point_offsets[p + 1]) of `inner`
+ * (f32, f16, SQ or BQ rows; anything else: QMX_ERR_NOT_SUPPORTED) and the deleted flags per POINT (host arrays, as in qmx_multi_hnsw_search; the
+ * inner segment's own flags are not read).  The graph has n_points points; search it with qmx_multi_hnsw_search. */
+QMX_API int32_t qmx_multi_hnsw_build(const qmx_segment *inner, const uint64_t *point_offsets, uint32_t n_points, const uint64_t *point_deleted,
+                                     uint64_t n_deleted_bits, const qmx_hnsw_build_params *params, qmx_hnsw **out);
 QMX_API int32_t qmx_hnsw_get_info(const qmx_hnsw *g, qmx_hnsw_info *out);
 /* Copies the plain arrays of a graph built by qmx_hnsw_build into caller (host) buffers sized per qmx_hnsw_get_info:
  * reindex [n_points], level_offsets [n_levels + 1], offsets [n_offsets], neighbors [n_neighbors], entry points. */

@@ -2402,6 +2402,11 @@ static void fill_args_segment(const qmx_segment *s, ScanArgs &a) {
 }
 
 static int32_t launch_hnsw_build_any(const qmx_segment *seg, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu) {
+    if (a.mv_offsets) {   // multi-vector points (qmx_multi_hnsw_build)
+        if (seg->dtype == QMX_DTYPE_SQ_U8) return launch_hnsw_build_maxsim_sq(nullptr, (int)seg->distance, a, h, phase, grid, per_cu);
+        if (seg->dtype == QMX_DTYPE_BQ) return launch_hnsw_build_maxsim_bq(nullptr, a, h, phase, grid, per_cu);
+        return launch_hnsw_build_maxsim_dense(nullptr, (int)seg->dtype, (int)seg->distance, a, h, phase, grid, per_cu);
+    }
     if (seg->dtype == QMX_DTYPE_SQ_U8) return launch_hnsw_build_sq(nullptr, (int)seg->distance, a, h, phase, grid, per_cu);
     if (seg->dtype == QMX_DTYPE_BQ) return launch_hnsw_build_bq(nullptr, a, h, phase, grid, per_cu);
     if (seg->dtype == QMX_DTYPE_PQ) return launch_hnsw_build_pq(nullptr, a, h, phase, grid, per_cu);
@@ -2437,7 +2442,35 @@ int32_t qmx_hnsw_build(const qmx_segment *seg, const qmx_hnsw_build_params *bp, 
     return qmx_hnsw_build_quantized(seg, nullptr, bp, out);
 }
 
+// the points of a build over multi-vectors (qmx_multi_hnsw_build): point p = inner rows [offsets[p], offsets[p + 1]) of the segment, deleted flags per POINT
+struct MultiBuild {
+    const uint64_t *h_offsets;
+    uint32_t n_points;
+    const uint64_t *h_deleted;
+    uint64_t n_deleted_bits;
+};
+static int32_t hnsw_build_impl(const qmx_segment *seg, const qmx_segment *original, const qmx_hnsw_build_params *bp, qmx_hnsw **out, const MultiBuild *mb);
+
 int32_t qmx_hnsw_build_quantized(const qmx_segment *seg, const qmx_segment *original, const qmx_hnsw_build_params *bp, qmx_hnsw **out) {
+    return hnsw_build_impl(seg, original, bp, out, nullptr);
+}
+
+int32_t qmx_multi_hnsw_build(const qmx_segment *inner, const uint64_t *point_offsets, uint32_t n_points, const uint64_t *point_deleted,
+                             uint64_t n_deleted_bits, const qmx_hnsw_build_params *bp, qmx_hnsw **out) {
+    QMX_REQUIRE(inner && point_offsets && bp && out, QMX_ERR_BAD_ARG, "NULL argument");
+    *out = nullptr;
+    QMX_REQUIRE(inner->dtype == QMX_DTYPE_F32 || inner->dtype == QMX_DTYPE_F16 || inner->dtype == QMX_DTYPE_SQ_U8 || inner->dtype == QMX_DTYPE_BQ,
+                QMX_ERR_NOT_SUPPORTED, "device HNSW build over multi-vectors: inner dtype %u not supported (f32, f16, SQ, BQ)", inner->dtype);
+    QMX_REQUIRE(!is_device_ptr(point_offsets) && !is_device_ptr(point_deleted), QMX_ERR_BAD_ARG, "point_offsets and point_deleted are host arrays");
+    for (uint32_t p = 0; p < n_points; ++p)
+        QMX_REQUIRE(point_offsets[p] <= point_offsets[p + 1], QMX_ERR_BAD_ARG, "point_offsets is not ascending at %u", p);
+    QMX_REQUIRE(point_offsets[n_points] <= inner->n, QMX_ERR_OUT_OF_BOUNDS, "point_offsets reach past the %llu inner rows of the segment",
+                (unsigned long long)inner->n);
+    const MultiBuild mb{point_offsets, n_points, (point_deleted && n_deleted_bits) ? point_deleted : nullptr, point_deleted ? n_deleted_bits : 0};
+    return hnsw_build_impl(inner, nullptr, bp, out, &mb);
+}
+
+static int32_t hnsw_build_impl(const qmx_segment *seg, const qmx_segment *original, const qmx_hnsw_build_params *bp, qmx_hnsw **out, const MultiBuild *mb) {
     QMX_REQUIRE(seg && bp && out, QMX_ERR_BAD_ARG, "NULL argument");
     *out = nullptr;
     QMX_REQUIRE(seg->dtype <= QMX_DTYPE_BQ || seg->dtype == QMX_DTYPE_TQ, QMX_ERR_NOT_SUPPORTED, "device HNSW build: dtype %u not supported", seg->dtype);
@@ -2456,7 +2489,7 @@ int32_t qmx_hnsw_build_quantized(const qmx_segment *seg, const qmx_segment *orig
                 bp->ef_construct, HNSW_MAX_EF);
     QMX_REQUIRE(seg->n <= 0xFFFFFFFFull, QMX_ERR_BAD_ARG, "too many rows");
     QMX_HIP(hipSetDevice(seg->device));
-    const uint32_t n = (uint32_t)seg->n, m = bp->m, m0 = bp->m0;
+    const uint32_t n = mb ? mb->n_points : (uint32_t)seg->n, m = bp->m, m0 = bp->m0;
     const uint32_t max_batch = bp->max_batch ? bp->max_batch : 16384;
 
     // ---- levels (graph_layers_builder.rs:388-396), the same draw as the CPU oracle ----
@@ -2476,19 +2509,24 @@ int32_t qmx_hnsw_build_quantized(const qmx_segment *seg, const qmx_segment *orig
     QMX_REQUIRE(n_up <= 0xFFFFFFFFull, QMX_ERR_BAD_ARG, "too many upper-level lists");
     // deleted flags on the host: deleted points are never indexed and never entry points
     std::vector<uint64_t> pdel, vdel;
+    if (mb) {
+        if (mb->h_deleted) pdel.assign(mb->h_deleted, mb->h_deleted + (mb->n_deleted_bits + 63) / 64);
+    } else
     if (seg->d_point_deleted) { pdel.resize((seg->n_point_bits + 63) / 64); QMX_HIP(hipMemcpy(pdel.data(), seg->d_point_deleted, pdel.size() * 8, hipMemcpyDeviceToHost)); }
-    if (seg->d_vec_deleted) { vdel.resize((seg->n_vec_bits + 63) / 64); QMX_HIP(hipMemcpy(vdel.data(), seg->d_vec_deleted, vdel.size() * 8, hipMemcpyDeviceToHost)); }
+    if (!mb && seg->d_vec_deleted) { vdel.resize((seg->n_vec_bits + 63) / 64); QMX_HIP(hipMemcpy(vdel.data(), seg->d_vec_deleted, vdel.size() * 8, hipMemcpyDeviceToHost)); }
+    const uint64_t n_point_bits = mb ? mb->n_deleted_bits : seg->n_point_bits;
     auto live = [&](uint32_t id) {
         const bool vd = (!vdel.empty() && id < seg->n_vec_bits) ? ((vdel[id >> 6] >> (id & 63)) & 1) : false;
-        const bool pd = !pdel.empty() ? (id < seg->n_point_bits ? ((pdel[id >> 6] >> (id & 63)) & 1) : true) : false;
+        const bool pd = !pdel.empty() ? (id < n_point_bits ? ((pdel[id >> 6] >> (id & 63)) & 1) : true) : false;
         return !vd && !pd;
     };
 
     // ---- device state ----
-    DevBuf b_level, b_upoff, b_links0, b_cnt0, b_linksU, b_cntU, b_lock, b_vis, b_log, b_sel, b_sels, b_selc, b_normf, b_normi, b_bq, b_bqsrc, b_rot;
+    DevBuf b_level, b_upoff, b_links0, b_cnt0, b_linksU, b_cntU, b_lock, b_vis, b_log, b_sel, b_sels, b_selc, b_normf, b_normi, b_bq, b_bqsrc, b_rot, b_mvoff,
+        b_mvdel;
     auto release_all = [&]() {
         for (DevBuf *b : {&b_level, &b_upoff, &b_links0, &b_cnt0, &b_linksU, &b_cntU, &b_lock, &b_vis, &b_log, &b_sel, &b_sels, &b_selc, &b_normf, &b_normi,
-                          &b_bq, &b_bqsrc, &b_rot}) b->release();
+                          &b_bq, &b_bqsrc, &b_rot, &b_mvoff, &b_mvdel}) b->release();
     };
     int32_t rc = QMX_OK;
     qmx_hnsw *g = nullptr;
@@ -2511,6 +2549,21 @@ int32_t qmx_hnsw_build_quantized(const qmx_segment *seg, const qmx_segment *orig
 
         ScanArgs a;
         fill_args_segment(seg, a);
+        if (mb) {   // the graph's points are multi-vectors: offsets into the inner rows, deletion per POINT (the inner rows carry no flags of their own)
+            QB(b_mvoff.reserve((size_t)(n + 1) * 8));
+            QH(hipMemcpy(b_mvoff.p, mb->h_offsets, (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
+            a.mv_offsets = (const uint64_t *)b_mvoff.p;
+            DeletedView dv;
+            memset(&dv, 0, sizeof(dv));
+            dv.n_rows = n;
+            if (!pdel.empty()) {
+                QB(b_mvdel.reserve(pdel.size() * 8));
+                QH(hipMemcpy(b_mvdel.p, pdel.data(), pdel.size() * 8, hipMemcpyHostToDevice));
+                dv.point_deleted = (const uint64_t *)b_mvdel.p;
+                dv.n_point_bits = mb->n_deleted_bits;
+            }
+            a.del = dv;
+        }
         HnswBuildArgs h;
         memset(&h, 0, sizeof(h));
         h.g.links0 = (uint32_t *)b_links0.p; h.g.cnt0 = (uint32_t *)b_cnt0.p; h.g.linksU = (uint32_t *)b_linksU.p; h.g.cntU = (uint32_t *)b_cntU.p;
@@ -2541,6 +2594,7 @@ int32_t qmx_hnsw_build_quantized(const qmx_segment *seg, const qmx_segment *orig
             h.batch_q_stride = a.q_stride;
             h.lds_query_bytes = a.q_stride;
         }
+        if (mb) h.lds_query_bytes = 0;      // nothing staged: the inner rows of the new point are read where they lie
         if (seg->dtype == QMX_DTYPE_U8 && seg->distance == QMX_DISTANCE_COSINE && seg->dim >= 32) {   // the per-pair cosine's query norm of a stored row
             QB(b_normf.reserve(nn * 4)); QB(b_normi.reserve(nn * 4));
             QB(launch_u8_row_norms(nullptr, seg->d_rows, seg->row_stride, n, seg->dim, seg->flags, (float *)b_normf.p, (int32_t *)b_normi.p));

@@ -111,6 +111,48 @@ struct HopMaxSim {
     }
 };
 
+// The same points scored stored <-> stored (HNSW build over multi-vector points, hnsw/build.rs:334-341 through FilteredScorer::new_internal:
+// MultiMetricQueryScorer::score_internal, multi_metric_query_scorer.rs; quantized: score_internal_max_similarity,
+// quantized_multivector_storage/mod.rs:366-393): sum over the inner vectors of point a (in order, from 0.0) of the max over the inner vectors of
+// point b (`if sim > max_sim`, from -inf) of the inner storage's score_internal.  The "query entry" of a stored multi-vector is its point id
+// (stored_query in hnsw_build.hpp hands it over in the pointer); the inner rows are read from HBM / L2 on every pair.  Not symmetric.
+template <class H, class = void>
+struct is_maxsim_internal { static constexpr bool value = false; };
+template <class H>
+struct is_maxsim_internal<H, decltype((void)H::MAXSIM_INTERNAL)> { static constexpr bool value = H::MAXSIM_INTERNAL; };
+template <class HI>
+struct HopMaxSimInternal {
+    static constexpr int LPI = HI::LPI;
+    static constexpr bool INTERNAL_QOFF = false;     // the inner rows' offsets / norms are looked up per inner row below
+    static constexpr bool INTERNAL_NORM = false;
+    static constexpr bool MULTI = false;
+    static constexpr bool ASYMMETRIC = true;
+    static constexpr bool MAXSIM_INTERNAL = true;
+    static __device__ __forceinline__ float score(const ScanArgs &a, const unsigned char *qp, uint32_t id, int sub) {
+        const uint32_t p = (uint32_t)reinterpret_cast<uintptr_t>(qp);
+        const unsigned char *rows = reinterpret_cast<const unsigned char *>(a.rows);
+        const uint64_t a0 = a.mv_offsets[p], a1 = a.mv_offsets[p + 1];
+        const uint64_t b0 = a.mv_offsets[id], b1 = a.mv_offsets[id + 1];
+        float sum = 0.0f;
+        for (uint64_t i = a0; i < a1; ++i) {
+            ScanArgs b = a;
+            if constexpr (HI::INTERNAL_QOFF) b.sq_qoff = a.row_offsets[i] - a.sq_shift;
+            if constexpr (HI::INTERNAL_NORM) {
+                b.u8_qnorm_f = a.row_norms_f[i];
+                b.u8_qnorm_i = a.row_norms_i[i];
+            }
+            const unsigned char *qe = rows + i * a.row_stride;
+            float max_sim = -__builtin_inff();
+            for (uint64_t j = b0; j < b1; ++j) {
+                const float sim = HI::score(b, qe, (uint32_t)j, sub);
+                if (sim > max_sim) max_sim = sim;
+            }
+            sum += max_sim;
+        }
+        return sum;
+    }
+};
+
 // Custom queries as the scorer of the walk (raw_scorer.rs:228-333 builds a CustomQueryScorer / QuantizedCustomQueryScorer / TurboCustomQueryScorer for
 // whatever storage the segment has; graph_layers.rs:108-149 walks with whatever scorer it gets): a hop candidate's score is
 // query.score_by(|example| inner policy's score(example, candidate)) - the examples of ONE custom query, in flat_iter() order, are what the search stages.

@@ -45,6 +45,13 @@ __device__ __forceinline__ ScanArgs query_args(const ScanArgs &a, uint32_t qid) 
     return b;
 }
 
+// The query entry of stored point `id`: its row; for multi-vector points (HopMaxSimInternal) the id itself, carried in the pointer.
+template <class H>
+__device__ __forceinline__ const unsigned char *stored_query(const ScanArgs &a, uint32_t id) {
+    if constexpr (is_maxsim_internal<H>::value) return reinterpret_cast<const unsigned char *>((uintptr_t)id);
+    else return reinterpret_cast<const unsigned char *>(a.rows) + (uint64_t)id * a.row_stride;
+}
+
 // fill_from_sorted_with_heuristic (links_container.rs:47-71): candidates sorted by descending score to the target;
 // keep c unless it is closer to an already kept link than to the target.  cand_* and sel_* live in LDS.
 // Returns the number kept (wave-uniform).  `a.rows` rows double as query entries.
@@ -53,7 +60,6 @@ __device__ __forceinline__ uint32_t heuristic_fill(const ScanArgs &a, const uint
                                                    uint32_t lm, uint32_t *sel_ids, float *sel_scores, uint32_t *hop_ids, float *hop_scores,
                                                    int lane) {
     uint32_t n_sel = 0;
-    const unsigned char *rows = reinterpret_cast<const unsigned char *>(a.rows);
     for (uint32_t c = 0; c < n_cand && n_sel < lm; ++c) {
         const uint32_t cid = cand_ids[c];
         const float cs = cand_scores[c];
@@ -62,7 +68,7 @@ __device__ __forceinline__ uint32_t heuristic_fill(const ScanArgs &a, const uint
             const uint32_t k = n_sel - base < 64 ? n_sel - base : 64;
             __syncthreads();
             if ((uint32_t)lane < k) hop_ids[lane] = sel_ids[base + lane];
-            hop_score<H>(query_args<H>(a, cid), rows + (uint64_t)cid * a.row_stride, hop_ids, hop_scores, k, lane);   // score(candidate, kept link)
+            hop_score<H>(query_args<H>(a, cid), stored_query<H>(a, cid), hop_ids, hop_scores, k, lane);   // score(candidate, kept link)
             const bool bad = (uint32_t)lane < k && hop_scores[lane] > cs;
             skip = __ballot(bad) != 0;
         }
@@ -110,7 +116,9 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(const ScanArgs a0
         // staged in LDS (zero padded to whole 128-byte steps)
         const unsigned char *qp = q_lds;
         __syncthreads();
-        if (h.batch_queries && h.lds_query_bytes) {        // a small entry (TurboQuant): staged like a row
+        if constexpr (is_maxsim_internal<H>::value) {       // a multi-vector point: its inner rows stay in HBM
+            qp = stored_query<H>(a0, p);
+        } else if (h.batch_queries && h.lds_query_bytes) {        // a small entry (TurboQuant): staged like a row
             const unsigned char *src = h.batch_queries + (uint64_t)bi * h.batch_q_stride;
             for (uint32_t i = (uint32_t)lane * 16; i < h.lds_query_bytes; i += 64 * 16)
                 *reinterpret_cast<uint4 *>(q_lds + i) = *reinterpret_cast<const uint4 *>(src + i);
@@ -138,7 +146,7 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(const ScanArgs a0
             if (lane == 0) hop_ids[0] = cur_id;
             // graph_layers_builder.rs:441-447: an entry point at or below the new point's level is taken with score_internal(p, entry)
             if (is_asymmetric<HI>::value && h.ep_level <= lp)
-                hop_score<HI>(query_args<HI>(a0, p), rows + (uint64_t)p * a0.row_stride, hop_ids, hop_scores, 1, lane);
+                hop_score<HI>(query_args<HI>(a0, p), stored_query<HI>(a0, p), hop_ids, hop_scores, 1, lane);
             else
                 hop_score<H>(a, qp, hop_ids, hop_scores, 1, lane);
             cur_score = hop_scores[0];
@@ -268,7 +276,6 @@ __global__ __launch_bounds__(64) void hnsw_build_link_kernel(const ScanArgs a, c
     __shared__ uint32_t sel_ids[64];
     __shared__ float sel_scores[64];
     const int lane = threadIdx.x;
-    const unsigned char *rows = reinterpret_cast<const unsigned char *>(a.rows);
     for (uint32_t bi = blockIdx.x; bi < h.count; bi += gridDim.x) {
         const uint32_t p = h.first + bi;
         const uint32_t lp = h.level[p];
@@ -289,7 +296,7 @@ __global__ __launch_bounds__(64) void hnsw_build_link_kernel(const ScanArgs a, c
                 if constexpr (is_asymmetric<H>::value) {       // ... unless the search score is not the storage's score_internal (PQ)
                     __syncthreads();
                     if (lane == 0) hop_ids[0] = p;
-                    hop_score<H>(query_args<H>(a, q), rows + (uint64_t)q * a.row_stride, hop_ids, hop_scores, 1, lane);
+                    hop_score<H>(query_args<H>(a, q), stored_query<H>(a, q), hop_ids, hop_scores, 1, lane);
                     s_qp = hop_scores[0];
                 }
                 if (lane == 0) {
@@ -317,7 +324,7 @@ __global__ __launch_bounds__(64) void hnsw_build_link_kernel(const ScanArgs a, c
                             hop_ids[lane] = id;
                             cand_ids[base + lane] = id;
                         }
-                        hop_score<H>(query_args<H>(a, q), rows + (uint64_t)q * a.row_stride, hop_ids, hop_scores, kk, lane);
+                        hop_score<H>(query_args<H>(a, q), stored_query<H>(a, q), hop_ids, hop_scores, kk, lane);
                         if ((uint32_t)lane < kk) cand_scores[base + lane] = hop_scores[lane];
                     }
                     if (lane == 0) {
@@ -391,6 +398,17 @@ struct HnswBuildLauncher {
     int *per_cu;
     template <class P> int32_t row(const ScanArgs &a) const { return launch_hnsw_build_hop<HopRow<P>>(st, a, *h, phase, grid, per_cu); }
     template <class S> int32_t small(const ScanArgs &a) const { return launch_hnsw_build_hop<HopSmall<S>>(st, a, *h, phase, grid, per_cu); }
+};
+
+// points = multi-vectors over the segment's inner rows (ScanArgs::mv_offsets), MaxSim between stored points
+struct HnswBuildMaxSimLauncher {
+    hipStream_t st;
+    const HnswBuildArgs *h;
+    int phase;
+    uint32_t grid;
+    int *per_cu;
+    template <class P> int32_t row(const ScanArgs &a) const { return launch_hnsw_build_hop<HopMaxSimInternal<HopRow<P>>>(st, a, *h, phase, grid, per_cu); }
+    template <class S> int32_t small(const ScanArgs &a) const { return launch_hnsw_build_hop<HopMaxSimInternal<HopSmall<S>>>(st, a, *h, phase, grid, per_cu); }
 };
 
 }  // namespace qmx

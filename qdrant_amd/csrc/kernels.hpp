@@ -207,6 +207,10 @@ int32_t launch_hnsw_build_bq(hipStream_t st, const ScanArgs &a, const HnswBuildA
 int32_t launch_hnsw_build_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_build_dense(hipStream_t st, int dtype, int distance, const ScanArgs &a, const HnswBuildArgs &h, int phase,
                                 uint32_t grid, int *per_cu);
+int32_t launch_hnsw_build_maxsim_dense(hipStream_t st, int dtype, int distance, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid,
+                                       int *per_cu);
+int32_t launch_hnsw_build_maxsim_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu);
+int32_t launch_hnsw_build_maxsim_bq(hipStream_t st, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_build_tq(hipStream_t st, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_build_pq(hipStream_t st, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu);
 // pair[c][i][j] = DistanceType::distance(centroid i chunk c, centroid j chunk c): the per-chunk terms of score_internal (encoded_vectors_pq.rs:574-618)

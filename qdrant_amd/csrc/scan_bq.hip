@@ -277,6 +277,9 @@ int32_t launch_hnsw_maxsim_bq(hipStream_t st, const ScanArgs &a, const HnswArgs 
 int32_t launch_hnsw_build_bq(hipStream_t st, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu) {
     return HnswBuildLauncher{st, &h, phase, grid, per_cu}.template row<RowBQ>(a);
 }
+int32_t launch_hnsw_build_maxsim_bq(hipStream_t st, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu) {
+    return HnswBuildMaxSimLauncher{st, &h, phase, grid, per_cu}.template row<RowBQ>(a);
+}
 
 // encode_vector for a batch (encoded_vectors_binary.rs:535-672): in [n][dim] f32 -> out [n][out_stride] bytes; one thread per
 // output dword.  encoding 0: bit i = v[i] > 0.  1 (TwoBits): bit i = b1(v[i]), bit dim + i = b2(v[i]).  2 (OneAndHalfBits): bit

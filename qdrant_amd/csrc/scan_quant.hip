@@ -130,6 +130,15 @@ int32_t launch_hnsw_build_sq(hipStream_t st, int distance, const ScanArgs &a, co
     if (sep) return l.template row<RowSQInternal<false, true>>(a);
     return l.template row<RowSQInternal<false, false>>(a);
 }
+// ... over multi-vector points whose inner rows are SQ codes (score_internal_max_similarity, quantized_multivector_storage/mod.rs:366-393)
+int32_t launch_hnsw_build_maxsim_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu) {
+    const HnswBuildMaxSimLauncher l{st, &h, phase, grid, per_cu};
+    const bool l1 = distance == QMX_DISTANCE_MANHATTAN;
+    const bool sep = (uint64_t)127 * 127 * a.dim >= (1ull << 24);
+    if (l1) return l.template row<RowSQInternal<true, false>>(a);
+    if (sep) return l.template row<RowSQInternal<false, true>>(a);
+    return l.template row<RowSQInternal<false, false>>(a);
+}
 
 // ------------------------------------------------------------------------------------------
 // encode

@@ -112,6 +112,28 @@ class GraphLayers:
         self.counters = F.Counters()
         return self
 
+    @classmethod
+    def build_multi(cls, multi_storage, m: int = 16, m0: Optional[int] = None, ef_construct: int = 100, seed: int = 42,
+                    entry_points_num: int = 10, max_batch: int = 0):
+        """`GraphLayersBuilder` over the POINTS of a MultiDenseVectorStorage / QuantizedMultivectorStorage on its GPU (qmx_multi_hnsw_build): every
+        score of the build is MaxSim between two stored multi-vectors (`score_internal`, multi_metric_query_scorer.rs; quantized inner rows:
+        `score_internal_max_similarity`, quantized_multivector_storage/mod.rs:366-393)."""
+        self = cls.__new__(cls)
+        self.m, self.m0 = int(m), int(2 * m if m0 is None else m0)
+        p = F.HnswBuildParams()
+        p.m, p.m0, p.ef_construct, p.entry_points_num, p.seed, p.max_batch = self.m, self.m0, ef_construct, entry_points_num, seed, max_batch
+        self._keep = []
+        self._h = C.c_void_p()
+        deleted = multi_storage.point_deleted
+        words = None if deleted is None else np.packbits(np.asarray(deleted, dtype=bool), bitorder="little")
+        if words is not None:
+            words = np.ascontiguousarray(np.pad(words, (0, (-len(words)) % 8))).view(np.uint64)
+        F.check(F.lib().qmx_multi_hnsw_build(multi_storage.inner._h, F.ptr(multi_storage.offsets), multi_storage.count, F.ptr(words),
+                                             0 if deleted is None else len(deleted), C.byref(p), C.byref(self._h)))
+        self.n_points = multi_storage.count
+        self.counters = F.Counters()
+        return self
+
     def export_plain(self):
         """The plain GraphLinks arrays + entry points of a graph built on the device (an object with the fields
         `from_plain` takes)."""

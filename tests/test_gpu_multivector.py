@@ -183,6 +183,86 @@ def test_multivector_hnsw_walk_equals_the_oracle(qa, kind, distance, dim):
             assert np.array_equal(_bits(g["score"]), _bits(w["score"]))
 
 
+def _same_graph(seq, ref):
+    assert np.array_equal(seq.reindex, ref.reindex) and np.array_equal(seq.offsets, ref.offsets)
+    assert np.array_equal(seq.neighbors, ref.neighbors)
+    assert seq.ep_ids.tolist() == ref.ep_ids.tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,distance,dim", [("dense", O.DOT, 64), ("dense", O.COSINE, 48), ("dense", O.EUCLID, 20), ("dense", O.MANHATTAN, 33),
+                                                 ("sq", O.COSINE, 64), ("sq", O.DOT, 128)])
+def test_multivector_build_one_point_per_launch_is_the_sequential_graph(qa, kind, distance, dim):
+    """The device build over multi-vector POINTS (hnsw/build.rs:334-341 through score_internal / score_internal_max_similarity): inserted one point
+    per launch it is the oracle's sequential GraphLayersBuilder link for link - MaxSim is not symmetric, so this also pins which of the two points
+    is the query in the insertion searches, in the heuristic and in the back links.  Then with deleted points.  (SQ Euclid rows are not a case:
+    their scores are alpha^2 x an integer and tie - 3 of 696 lists came out with two equal-score neighbours swapped, the heap order DESIGN 4 leaves
+    unpinned.)"""
+    n_points, m, efc, seed = 500, 8, 32, 17
+    rng, offsets, dev, orc, queries = _multi_world(qa, kind, distance, dim, n_points, seed=dim + 7 * distance)
+    seq = qa.GraphLayers.build_multi(dev, m=m, ef_construct=efc, seed=seed, entry_points_num=4, max_batch=1).export_plain()
+    ref = orc.build(m=m, ef_construct=efc, seed=seed, entry_points_num=4).export_plain()
+    _same_graph(seq, ref)
+    deleted = rng.random(n_points) < 0.2
+    deleted[0] = True                                   # the first live point is not point 0
+    dev.set_deleted(deleted)
+    orc_del = O.MultiOracle(orc.inner, offsets, point_deleted=deleted)
+    seq = qa.GraphLayers.build_multi(dev, m=m, ef_construct=efc, seed=seed, entry_points_num=4, max_batch=1).export_plain()
+    ref = orc_del.build(m=m, ef_construct=efc, seed=seed, entry_points_num=4).export_plain()
+    _same_graph(seq, ref)
+    for p in np.flatnonzero(deleted):                   # deleted points have no links and nobody links to them
+        assert seq.offsets[p + 1] == seq.offsets[p]
+    assert not deleted[seq.neighbors].any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,distance,dim", [("dense", O.DOT, 64), ("dense", O.COSINE, 128), ("sq", O.DOT, 128), ("bq", O.COSINE, 256)])
+def test_multivector_batched_build_searches_like_the_oracle_built_graph(qa, kind, distance, dim):
+    """Batched (the default): structural invariants of the graph, the oracle's walk of the device-built graph == the device's walk of it (ids and
+    score bits; BQ: true pairs), and recall against the brute-force MaxSim top-10 within 0.05 of the oracle-built graph's."""
+    n_points, m, efc, seed = 2500, 8, 48, 23
+    rng, offsets, dev, orc, queries = _multi_world(qa, kind, distance, dim, n_points, seed=3 * dim + distance)
+    graph = qa.GraphLayers.build_multi(dev, m=m, ef_construct=efc, seed=seed)
+    plain = graph.export_plain()
+    assert len(plain.reindex) == n_points
+    deg0 = np.diff(plain.offsets[:n_points + 1].astype(np.int64))
+    assert deg0.max() <= 2 * m and deg0.min() >= 1
+    for p in range(n_points):                           # no self links, no duplicates
+        l = plain.neighbors[int(plain.offsets[p]):int(plain.offsets[p + 1])]
+        assert p not in l and len(set(l.tolist())) == len(l)
+    qpre = [O.preprocess(distance, q) for q in queries]
+    got = dev.search_hnsw(graph, queries, 10, 64)
+    want, _ = orc.search(O.Hnsw.from_plain(plain, n_points), qpre, 10, 64)
+    for g, w, mq in zip(got, want, qpre):
+        if kind == "bq":
+            assert np.array_equal(_bits(orc.score_points([mq], g["idx"])[0]), _bits(g["score"]))
+        else:
+            assert g["idx"].tolist() == w["idx"].tolist() and np.array_equal(_bits(g["score"]), _bits(w["score"]))
+    exact = dev.peek_top_all(queries, 10)
+    ref_graph = qa.GraphLayers.from_plain(orc.build(m=m, ef_construct=efc, seed=seed).export_plain())
+    ref_got = dev.search_hnsw(ref_graph, queries, 10, 64)
+
+    def recall(res):
+        return np.mean([len(set(r["idx"].tolist()) & set(e["idx"].tolist())) / max(1, len(e)) for r, e in zip(res, exact)])
+    assert recall(got) >= recall(ref_got) - 0.05 and recall(got) > 0.6, (recall(got), recall(ref_got))
+
+
+@pytest.mark.gpu
+def test_multivector_build_argument_errors(qa):
+    rng, offsets, dev, orc, queries = _multi_world(qa, "pq", O.DOT, 64, 300, seed=9)
+    with pytest.raises(qa.QmxError) as e:               # PQ inner rows: no stored row is a query (encode_internal_vector -> None)
+        qa.GraphLayers.build_multi(dev, m=4, ef_construct=16)
+    assert e.value.status == qa._ffi.ERR_NOT_SUPPORTED
+    rng, offsets, dev, orc, queries = _multi_world(qa, "dense", O.DOT, 32, 100, seed=9)
+    dev.offsets = dev.offsets.copy()
+    dev.offsets[-1] += 5                                # offsets past the inner rows
+    with pytest.raises(qa.QmxError):
+        qa.GraphLayers.build_multi(dev, m=4, ef_construct=16)
+    empty = qa.MultiDenseVectorStorage(np.zeros((1, 32), dtype=np.float32), [0], qa.Distance.Dot)
+    g = qa.GraphLayers.build_multi(empty, m=4, ef_construct=16)       # no points: an empty graph
+    assert g.n_points == 0
+
+
 @pytest.mark.gpu
 def test_multivector_hnsw_argument_errors(qa):
     rng, offsets, dev, orc, queries = _multi_world(qa, "dense", O.DOT, 64, 200, seed=3)
