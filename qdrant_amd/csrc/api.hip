@@ -1505,24 +1505,38 @@ static int32_t launch_scan(const qmx_query *q, int qt, ScanMode mode, const Scan
     return QMX_ERR_NOT_SUPPORTED;
 }
 
+// The score matrix of queries [tile0, tile0 + nq_tile) of the batch against the candidates ids[0..n) (rows 0..n without ids): scores[(qi - tile0) * stride + i].
+// One launch per tile_qt queries; the f32 matrix-core kernel takes them all in one launch (scan_mfma.hip: score mode loops over its query tiles).
+static int32_t score_matrix_enqueue(const qmx_query *q, uint32_t tile0, uint32_t nq_tile, const uint32_t *d_ids, uint64_t n, float *d_scores, uint64_t stride,
+                                    uint32_t *launches) {
+    const qmx_segment *s = q->seg;
+    const uint32_t SQT = tile_qt(s, q);
+    const bool loops = s->dtype == QMX_DTYPE_F32 && SQT >= 8 && mfma_scan_ok(s);
+    const uint32_t step = loops ? nq_tile : SQT;
+    for (uint32_t st0 = 0; st0 < nq_tile; st0 += step) {
+        const uint32_t nq_sub = std::min<uint32_t>(step, nq_tile - st0);
+        ScanArgs pre;
+        fill_args(q, tile0 + st0, nq_sub, pre);
+        pre.ids = d_ids;
+        pre.n_cand = n;
+        pre.top = 1;
+        pre.scores = d_scores + (size_t)st0 * stride;
+        pre.scores_stride = stride;
+        uint32_t pgrid = 0;
+        QMX_TRY(launch_scan(q, (int)std::min<uint32_t>(pow2_ceil(nq_sub), std::max<uint32_t>(SQT, 8)), SCAN_SCORES, pre, &pgrid));
+        if (launches) ++*launches;
+    }
+    return QMX_OK;
+}
+
 // scores[qi * n + i] for every query of the batch
 static int32_t score_ids_device(qmx_query *q, const uint32_t *d_ids, uint64_t n, float *d_scores, qmx_counters *counters) {
     const qmx_segment *s = q->seg;
     const uint32_t TQ = tile_qt(s, q);
-    for (uint32_t tile0 = 0; tile0 < q->nq; tile0 += TQ) {
-        const uint32_t nq_tile = std::min<uint32_t>(TQ, q->nq - tile0);
-        ScanArgs a;
-        fill_args(q, tile0, nq_tile, a);
-        a.ids = d_ids;
-        a.n_cand = n;
-        a.top = 1;
-        a.scores = d_scores + (size_t)tile0 * n;
-        a.scores_stride = n;
-        uint32_t grid = 0;
-        QMX_TRY(launch_scan(q, (int)pow2_ceil(nq_tile), SCAN_SCORES, a, &grid));
-        if (counters) counters->kernel_launches++;
-    }
+    uint32_t launches = 0;
+    QMX_TRY(score_matrix_enqueue(q, 0, q->nq, d_ids, n, d_scores, n, &launches));
     if (counters) {
+        counters->kernel_launches += launches;
         counters->vectors_scored += (uint64_t)q->nq * n;
         counters->bytes_read += (uint64_t)((q->nq + TQ - 1) / TQ) * n * s->row_bytes;
     }
@@ -1682,8 +1696,7 @@ static int32_t pq_prefilter_enqueue(qmx_query *q, uint32_t top, uint64_t n_cand,
             QMX_TRY(launch_scan(q, (int)pow2_ceil(nq_sub), SCAN_SCORES, pre, &pgrid));
             ++launches;
         }
-        QMX_TRY(launch_custom_topk(q->stream, (const float *)q->scores.p, S, d_sample, a.del, nq_tile, top, d_out + (size_t)tile0 * top, d_counts + tile0));
-        QMX_TRY(launch_bound_from_topk(q->stream, d_out + (size_t)tile0 * top, d_counts + tile0, nq_tile, top, gthr));
+        QMX_TRY(launch_custom_topk(q->stream, (const float *)q->scores.p, S, d_sample, a.del, nq_tile, top, d_out + (size_t)tile0 * top, d_counts + tile0, gthr));
         // 2. the 6-bit tables of the tile's query groups, thresholds and bands in units of the integer score
         int32_t *thr = (int32_t *)((unsigned char *)q->pq_table.p + pq_prefilter_table_bytes(m, tile_max));
         QMX_TRY(launch_pq_lut8(q->stream, a.queries, q->q_stride, nq_tile, m, s->pq.n_centroids, gthr, q->pq_table.p, thr, band));
@@ -1779,14 +1792,14 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
     QMX_TRY(q->gthr.reserve((size_t)std::max<uint32_t>(q->nq_padded, SPLIT_QT_MAX) * sizeof(uint64_t)));
     // ---- split passes first (their verification and, if ever needed, the exact fallback run once for all of them afterwards) ----
     std::vector<std::pair<uint32_t, uint32_t>> split_tiles;      // (tile0, nq_tile)
-    float *sp_qnorm = nullptr, *sp_thr = nullptr, *sp_band = nullptr, *sp_scales = nullptr;
+    float *sp_qnorm = nullptr, *sp_thr = nullptr, *sp_band = nullptr, *sp_scales = nullptr, *sp_qmax = nullptr;
     const SplitPlanLayout pl(q->nq);
     unsigned char *plan = nullptr;
     q->last_counters = qmx_counters{};
     q->last_split = false;
     if (split) {
         QMX_TRY(q->sp_bq.reserve(split_query_bytes(s->dim)));
-        QMX_TRY(q->sp_f32.reserve(1024 * sizeof(float)));
+        QMX_TRY(q->sp_f32.reserve(1280 * sizeof(float)));
         QMX_TRY(q->sp_cand.reserve((size_t)split_qt * SPLIT_CAND_CAP * sizeof(uint64_t)));
         QMX_TRY(q->sp_cnt.reserve((size_t)SPLIT_QT_MAX * 4));
         if (s->d_rows_split) QMX_TRY(q->sp_wl.reserve(split_wlists_bytes(s->num_cus)));
@@ -1796,11 +1809,13 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
         QMX_TRY(q->sp_fq.reserve((size_t)pl.list_cap * q->q_stride));
         plan = (unsigned char *)q->sp_plan.p;
         float *f = (float *)q->sp_f32.p;
-        sp_qnorm = f; sp_thr = f + 256; sp_band = f + 512; sp_scales = f + 768;
+        sp_qnorm = f; sp_thr = f + 256; sp_band = f + 512; sp_scales = f + 768; sp_qmax = f + 1024;
         // the sample: every (n_cand / S)-th row, S = n_cand / 256 (at least 8192): its k-th best leaves ~256 k candidates per query to the
         // main pass, at 1 / 256 of the pass's row traffic for the sample's exact scores (measured on C2: 1/128 .. 1/512 are equally good)
         // ("prescan_shift" - 2: the option of the exact scans' prefix pre-scan, 10 by default, moves this sample with it)
-        const int sshift = (int)std::min<int64_t>(std::max<int64_t>(option(OPT_PRESCAN_SHIFT) - (s->d_rows_split ? 0 : 2), 1), 20);
+        // (with the derived copy: one more halving - 8 192 rows of a 10 M block are one tile per row stream of the sample scan, and the
+        // refine step after the first sixteenth of the block owns the threshold anyway: 26 us of the step, measured)
+        const int sshift = (int)std::min<int64_t>(std::max<int64_t>(option(OPT_PRESCAN_SHIFT) + (s->d_rows_split ? 1 : -2), 1), 20);
         const uint64_t S = std::min<uint64_t>(n_cand, std::max<uint64_t>(n_cand >> sshift, 8192));
         if (q->sp_sample_n != S || q->sp_sample_of != n_cand) {
             QMX_TRY(q->sp_sample.reserve((size_t)S * 4));
@@ -1828,31 +1843,16 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
             a.top = top;
             // 1. exact scores of the sample -> the k-th best of each query = a lower bound of its final k-th best
             QMX_TRY(q->scores.reserve((size_t)nq_tile * S * sizeof(float)));
-            const uint32_t SQT = tile_qt(s, q);
-            for (uint32_t st0 = 0; st0 < nq_tile; st0 += SQT) {
-                const uint32_t nq_sub = std::min<uint32_t>(SQT, nq_tile - st0);
-                ScanArgs pre;
-                fill_args(q, tile0 + st0, nq_sub, pre);
-                pre.ids = d_sample;
-                pre.n_cand = S;
-                pre.top = 1;
-                pre.scores = (float *)q->scores.p + (size_t)st0 * S;
-                pre.scores_stride = S;
-                uint32_t pgrid = 0;
-                QMX_TRY(launch_scan(q, (int)pow2_ceil(nq_sub), SCAN_SCORES, pre, &pgrid));
-            }
-            QMX_TRY(launch_custom_topk(q->stream, (const float *)q->scores.p, S, d_sample, a.del, nq_tile, top, d_out + (size_t)tile0 * top, d_counts + tile0));
-            QMX_TRY(launch_bound_from_topk(q->stream, d_out + (size_t)tile0 * top, d_counts + tile0, nq_tile, top, gthr));
+            QMX_TRY(score_matrix_enqueue(q, tile0, nq_tile, d_sample, S, (float *)q->scores.p, S, nullptr));
+            QMX_TRY(launch_custom_topk(q->stream, (const float *)q->scores.p, S, d_sample, a.del, nq_tile, top, d_out + (size_t)tile0 * top, d_counts + tile0, gthr));
             QMX_TRY(split_stage(q, "prescan"));
             // 2. the batch's queries split into f16 pairs; thresholds and bands in accumulator / score units
             const float row_scale = split_row_scale(s->row_maxabs);
             const int half = s->split_half ? 1 : 0;
             const uint32_t tqt = nq_tile > SPLIT_QT ? SPLIT_QT_MAX : SPLIT_QT;      // the shape of THIS tile (a remainder of <= 128 queries takes the 128 shape)
-            QMX_TRY(launch_split_pack_queries(q->stream, (const float *)q->enc.p + (size_t)tile0 * s->dim, nq_tile, s->dim, row_scale, (uint32_t *)(sp_scales + 4),
-                                              sp_qnorm, sp_scales, q->sp_bq.p, half, tqt));
-            QMX_TRY(launch_split_thresholds(q->stream, gthr, sp_qnorm, nq_tile, split_rel_band(half, s->dim), s->row_norm_max, sp_scales, sp_thr,
-                                            sp_band, tqt));
-            QMX_HIP(hipMemsetAsync(q->sp_cnt.p, 0, (size_t)SPLIT_QT_MAX * 4, q->stream));
+            QMX_TRY(launch_split_pack_queries(q->stream, (const float *)q->enc.p + (size_t)tile0 * s->dim, nq_tile, s->dim, sp_qmax, sp_qnorm, q->sp_bq.p, half, tqt));
+            QMX_TRY(launch_split_thresholds(q->stream, gthr, sp_qnorm, sp_qmax, nq_tile, split_rel_band(half, s->dim), s->row_norm_max, row_scale, sp_scales, sp_thr,
+                                            sp_band, tqt, (uint32_t *)q->sp_cnt.p, SPLIT_QT_MAX));
             QMX_TRY(split_stage(q, "pack + thresholds"));
             // 3. the approximate scan of the whole block
             // over a derived copy in two launches: the strided sixteenth of the tiles first, whose k-th best approximate score tightens the
@@ -1916,23 +1916,10 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
                     // score matrix of the prefix (the score-mode kernels, <= tile_qt queries per launch), one block per query selects its
                     // k best live candidates, the k-th becomes the bound
                     QMX_TRY(q->scores.reserve((size_t)nq_tile * pre_n * sizeof(float)));
-                    const uint32_t SQT = tile_qt(s, q);
-                    for (uint32_t st0 = 0; st0 < nq_tile; st0 += SQT) {
-                        const uint32_t nq_sub = std::min<uint32_t>(SQT, nq_tile - st0);
-                        ScanArgs pre;
-                        fill_args(q, tile0 + st0, nq_sub, pre);
-                        pre.ids = d_ids;
-                        pre.n_cand = pre_n;
-                        pre.top = 1;
-                        pre.scores = (float *)q->scores.p + (size_t)st0 * pre_n;
-                        pre.scores_stride = pre_n;
-                        uint32_t pgrid = 0;
-                        QMX_TRY(launch_scan(q, (int)pow2_ceil(nq_sub), SCAN_SCORES, pre, &pgrid));
-                    }
+                    QMX_TRY(score_matrix_enqueue(q, tile0, nq_tile, d_ids, pre_n, (float *)q->scores.p, pre_n, nullptr));
+// (the bound at the tile's own offset: the bounds of earlier split tiles are read again by the plan of their exact passes)
                     QMX_TRY(launch_custom_topk(q->stream, (const float *)q->scores.p, pre_n, d_ids, a.del, nq_tile, ptop, d_out + (size_t)tile0 * top,
-                                               d_counts + tile0));
-                    // (at the tile's own offset: the bounds of earlier split tiles are read again by the plan of their exact passes)
-                    QMX_TRY(launch_bound_from_topk(q->stream, d_out + (size_t)tile0 * top, d_counts + tile0, nq_tile, ptop, (uint64_t *)q->gthr.p + tile0));
+                                               d_counts + tile0, (uint64_t *)q->gthr.p + tile0));
                 }
                 a.gthr = (const uint64_t *)q->gthr.p + tile0;
                 if (counters) counters->kernel_launches += 2;

@@ -79,10 +79,39 @@ int32_t launch_maxsim(hipStream_t st, const float *d_sims, uint64_t n_rows, cons
 
 // top-k of a score row per query over the candidate stream (ids or 0..n), deleted / filtered points skipped:
 // FixedLengthPriorityQueue + into_sorted_vec as everywhere else; top > 64 in bounded passes of 64.
+// DeletedView::live for U ids at once, as masks (all ones = live): the bitmap words of the U ids are loaded before any of them is looked at (the
+// branches around the loads are wave-uniform: which bitmaps exist), so the round trips overlap
+template <int U>
+__device__ __forceinline__ void live_masks(const DeletedView &d, const uint32_t (&id)[U], uint64_t (&keep)[U]) {
+    uint64_t wp[U], wv[U], wa[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) wp[u] = wv[u] = wa[u] = 0;
+    if (d.point_deleted && d.n_point_bits) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) wp[u] = d.point_deleted[(id[u] < d.n_point_bits ? id[u] : 0u) >> 6];
+    }
+    if (d.vec_deleted && d.n_vec_bits) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) wv[u] = d.vec_deleted[(id[u] < d.n_vec_bits ? id[u] : 0u) >> 6];
+    }
+    if (d.allowed && d.n_allowed_bits) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) wa[u] = d.allowed[(id[u] < d.n_allowed_bits ? id[u] : 0u) >> 6];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint64_t bit = 1ull << (id[u] & 63u);
+        const bool vdel = d.vec_deleted && id[u] < d.n_vec_bits && (wv[u] & bit);
+        const bool pdel = d.point_deleted ? (id[u] < d.n_point_bits ? (wp[u] & bit) != 0 : true) : !(id[u] < d.n_rows);
+        const bool ok = d.allowed ? (id[u] < d.n_allowed_bits && (wa[u] & bit)) : true;
+        keep[u] = (!vdel && !pdel && ok) ? ~0ull : 0ull;
+    }
+}
+
 constexpr int CT_BLOCK = 1024;
 constexpr int CT_NW = CT_BLOCK / WAVE;
 __global__ __launch_bounds__(CT_BLOCK) void custom_topk_kernel(const float *scores, uint64_t n, const uint32_t *ids, DeletedView del, uint32_t top,
-                                                               qmx_scored_point *out, uint32_t *out_counts) {
+                                                               qmx_scored_point *out, uint32_t *out_counts, uint64_t *bound_out) {
     __shared__ uint64_t sh[CT_NW][WAVE];
     __shared__ uint64_t sh_bound;
     const uint32_t q = blockIdx.x;
@@ -93,20 +122,35 @@ __global__ __launch_bounds__(CT_BLOCK) void custom_topk_kernel(const float *scor
     for (uint32_t off = 0; off < top; off += WAVE) {
         const int ptop = (int)(top - off < (uint32_t)WAVE ? top - off : (uint32_t)WAVE);
         uint64_t list = 0;
-        for (uint64_t base = (uint64_t)wave * WAVE; base < n; base += CT_BLOCK) {
-            const uint64_t c = base + lane;
-            uint64_t key = 0;
-            if (c < n) {
-                const uint32_t id = ids ? ids[c] : (uint32_t)c;
-                key = make_key(row[c], id);
-                if (key >= bound || key <= readlane_u64(list, ptop - 1) || !del.live(id)) key = 0;
+        // CT_U chunks per trip: their id / score / deleted-bit loads are in flight together (the walk over a short score row - the sample
+        // pre-scans hand over ~8 k scores per query - is three dependent loads per chunk otherwise)
+        constexpr int CT_U = 4;
+        for (uint64_t base = (uint64_t)wave * WAVE; base < n; base += (uint64_t)CT_BLOCK * CT_U) {
+            uint64_t key[CT_U];
+            uint32_t id[CT_U];
+#pragma unroll
+            for (int u = 0; u < CT_U; ++u) {
+                const uint64_t c = base + (uint64_t)u * CT_BLOCK + lane;
+                const uint64_t cc = c < n ? c : 0;
+                id[u] = ids ? ids[cc] : (uint32_t)cc;
+                key[u] = c < n ? make_key(row[cc], id[u]) : 0ull;
             }
-            uint64_t m = __ballot(key != 0);
-            while (m) {
-                const int src = __builtin_ctzll(m);
-                m &= m - 1;
-                const uint64_t nk = readlane_u64(key, src);
-                if (nk > readlane_u64(list, ptop - 1)) wave_list_insert(list, nk, lane);
+            // (as a mask, not as `if (... || !live) key = 0`: clang 19's AMDGPU control-flow lowering dropped the assignment of that form here -
+            // deleted rows came back in the lists; tests/test_gpu_custom_queries.py and the all-deleted-sample test of the split scan caught it)
+            uint64_t keep[CT_U];
+            live_masks<CT_U>(del, id, keep);
+#pragma unroll
+            for (int u = 0; u < CT_U; ++u) key[u] = key[u] < bound ? key[u] & keep[u] : 0ull;
+#pragma unroll
+            for (int u = 0; u < CT_U; ++u) {
+                if (key[u] <= readlane_u64(list, ptop - 1)) key[u] = 0;
+                uint64_t m = __ballot(key[u] != 0);
+                while (m) {
+                    const int src = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const uint64_t nk = readlane_u64(key[u], src);
+                    if (nk > readlane_u64(list, ptop - 1)) wave_list_insert(list, nk, lane);
+                }
             }
         }
         __syncthreads();
@@ -145,14 +189,18 @@ __global__ __launch_bounds__(CT_BLOCK) void custom_topk_kernel(const float *scor
             break;
         }
     }
-    if (threadIdx.x == 0) out_counts[q] = total;
+    if (threadIdx.x == 0) {
+        out_counts[q] = total;
+        // the k-th best key when there are k results (what bound_from_topk_kernel reads back out of `out`): the starting threshold of a scan
+        if (bound_out) bound_out[q] = total == top ? bound : 0ull;
+    }
 }
 
 int32_t launch_custom_topk(hipStream_t st, const float *d_scores, uint64_t n, const uint32_t *d_ids, const DeletedView &del, uint32_t n_queries,
-                           uint32_t top, qmx_scored_point *d_out, uint32_t *d_counts) {
+                           uint32_t top, qmx_scored_point *d_out, uint32_t *d_counts, uint64_t *d_bound) {
     if (n_queries == 0) return QMX_OK;
     ::qmx::clear_stale_error();
-    hipLaunchKernelGGL(custom_topk_kernel, dim3(n_queries), dim3(CT_BLOCK), 0, st, d_scores, n, d_ids, del, top, d_out, d_counts);
+    hipLaunchKernelGGL(custom_topk_kernel, dim3(n_queries), dim3(CT_BLOCK), 0, st, d_scores, n, d_ids, del, top, d_out, d_counts, d_bound);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }

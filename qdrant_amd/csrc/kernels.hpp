@@ -270,10 +270,9 @@ bool split_scan_ok(const ScanArgs &a);
 size_t split_query_bytes(uint32_t dim);
 float split_row_scale(float row_maxabs);
 int32_t launch_split_row_stats(hipStream_t st, const void *rows, uint64_t row_stride, uint64_t n, uint32_t dim, uint32_t *d_stats);
-int32_t launch_split_pack_queries(hipStream_t st, const float *d_q, uint32_t nq, uint32_t dim, float row_scale, uint32_t *d_stats, float *d_qnorm,
-                                  float *d_scales, void *d_bq, int half, uint32_t qt);
-int32_t launch_split_thresholds(hipStream_t st, const uint64_t *d_gthr, const float *d_qnorm, uint32_t nq, float rel_band, float row_norm_max,
-                                const float *d_scales, float *d_thr, float *d_band, uint32_t qt);
+int32_t launch_split_pack_queries(hipStream_t st, const float *d_q, uint32_t nq, uint32_t dim, float *d_qmax, float *d_qnorm, void *d_bq, int half, uint32_t qt);
+int32_t launch_split_thresholds(hipStream_t st, const uint64_t *d_gthr, const float *d_qnorm, const float *d_qmax, uint32_t nq, float rel_band, float row_norm_max,
+                                float row_scale, float *d_scales, float *d_thr, float *d_band, uint32_t qt, uint32_t *d_cand_cnt, uint32_t n_cnt);
 int32_t launch_scan_f32_split(hipStream_t st, const ScanArgs &a, const void *d_bq, float row_scale, const float *d_scales, const float *d_thr,
                               uint64_t *d_cand, uint32_t *d_cand_cnt, uint32_t cap, int num_cus, const void *d_rows_split, int half, void *d_wlists, uint32_t phase, uint32_t qt);
 int32_t launch_regroup_lists(hipStream_t st, const DeletedView &del, const void *d_wlist, const uint32_t *d_wcnt, uint32_t wcap, uint32_t n_lists, uint64_t *d_cand,
@@ -362,7 +361,7 @@ int32_t launch_maxsim(hipStream_t st, const float *d_sims, uint64_t n_rows, cons
 // bound[q] = key of the k-th entry of a full top-k list out[q * k ..] (0 when the list is short): the pre-scan's reject bound
 int32_t launch_bound_from_topk(hipStream_t st, const qmx_scored_point *d_out, const uint32_t *d_counts, uint32_t nq, uint32_t k, uint64_t *d_bound);
 int32_t launch_custom_topk(hipStream_t st, const float *d_scores, uint64_t n, const uint32_t *d_ids, const DeletedView &del, uint32_t n_queries,
-                           uint32_t top, qmx_scored_point *d_out, uint32_t *d_counts);
+                           uint32_t top, qmx_scored_point *d_out, uint32_t *d_counts, uint64_t *d_bound = nullptr);   // d_bound[q] = the k-th best key of a full list, else 0
 
 // Metric::preprocess + element casts (preprocess.hip)
 int32_t launch_cosine_preprocess_f32(hipStream_t st, const float *in, float *out, uint64_t n, uint32_t dim);

@@ -53,9 +53,8 @@ __device__ __forceinline__ float swap16_add(float a, float b) {
 // QW queries per wave, QSPLIT waves share one row stream (each scores its own QW queries of the
 // QW * QSPLIT-query tile; the second read of a row line hits L1 / L2), D row loads in flight per lane.
 template <int QW, int QSPLIT, int D, bool NT, int NWAVES, bool FAST, bool QH, bool HAS_IDS, int MODE>
-__global__ __launch_bounds__(NWAVES * 64) void scan_f32_mfma_kernel(const ScanArgs a) {
+__device__ __forceinline__ void scan_f32_mfma_body(const ScanArgs &a, unsigned char *smem) {
     constexpr int MF_BLOCK = NWAVES * 64, MF_NW = NWAVES;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // QH = false: lane bit 5 (`rh`) picks the row half of an 8-row tile, a query group is 4 queries;
     // QH = true : lane bit 5 picks the QUERY half of a group of 8, the tile has 4 rows (each row piece is loaded by two
     //             lanes of the same instruction: one fetch): twice the queries per accumulator register
@@ -323,6 +322,27 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_f32_mfma_kernel(const ScanAr
             }
         }
         if (lane < top) a.partial[((uint64_t)blockIdx.x * QT + q) * utop + lane] = merged;
+    }
+}
+
+template <int QW, int QSPLIT, int D, bool NT, int NWAVES, bool FAST, bool QH, bool HAS_IDS, int MODE>
+__global__ __launch_bounds__(NWAVES * 64) void scan_f32_mfma_kernel(const ScanArgs a0) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if constexpr (MODE == SCAN_SCORES) {
+        // score mode takes any number of queries: the block scores its rows against one QW * QSPLIT-query tile after the other (one launch
+        // instead of one per tile: the sample pre-scans of a 128-query batch are four latency-bound passes over ~10 k rows, which
+        // stay in L2 between the passes)
+        constexpr uint32_t QT = QW * QSPLIT;
+        for (uint32_t g0 = 0; g0 < a0.nq; g0 += QT) {
+            ScanArgs a = a0;
+            a.queries = reinterpret_cast<const unsigned char *>(a0.queries) + (size_t)g0 * a0.q_stride;
+            a.scores = a0.scores + (uint64_t)g0 * a0.scores_stride;
+            a.nq = a0.nq - g0 < QT ? a0.nq - g0 : QT;
+            if (g0) __syncthreads();        // every wave is done with the previous tile's entries
+            scan_f32_mfma_body<QW, QSPLIT, D, NT, NWAVES, FAST, QH, HAS_IDS, MODE>(a, smem);
+        }
+    } else {
+        scan_f32_mfma_body<QW, QSPLIT, D, NT, NWAVES, FAST, QH, HAS_IDS, MODE>(a0, smem);
     }
 }
 

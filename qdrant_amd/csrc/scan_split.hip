@@ -63,7 +63,7 @@ __device__ __forceinline__ void sp_split4(const f32x4s v, float scale, half4 &h,
 
 // ---- once per query batch: preprocessed f32 queries -> split f16 in the B-operand layout, per-query norms, the scale of the batch ----
 // stats[0] = max |q| over the batch (uint bits of a non-negative float order like the float)
-__global__ void sp_query_stats_kernel(const float *q, uint32_t nq, uint32_t dim, uint32_t *stats, float *qnorm) {
+__global__ void sp_query_stats_kernel(const float *q, uint32_t nq, uint32_t dim, float *qmax, float *qnorm) {
     const uint32_t qi = blockIdx.x;
     float mx = 0.0f, ss = 0.0f;
     for (uint32_t i = threadIdx.x; i < dim; i += blockDim.x) {
@@ -83,7 +83,7 @@ __global__ void sp_query_stats_kernel(const float *q, uint32_t nq, uint32_t dim,
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        atomicMax(stats, __float_as_uint(smx[0]));
+        qmax[qi] = smx[0];
         qnorm[qi] = __builtin_sqrtf(sss[0]);
     }
 }
@@ -97,22 +97,28 @@ __device__ __forceinline__ float sp_pow2_scale(float maxabs) {
     return __builtin_ldexpf(1.0f, s);
 }
 // scales[0] = query scale, scales[1] = row scale * query scale (accumulator units per score unit), scales[2] = its inverse
-__global__ void sp_scales_kernel(const uint32_t *stats, float row_scale, float *scales) {
-    const float qs = sp_pow2_scale(__uint_as_float(stats[0]));
-    scales[0] = qs;
-    scales[1] = row_scale * qs;
-    scales[2] = 1.0f / (row_scale * qs);
+// the batch's query scale from the per-query maxima (at most 256 of them), by every thread of a block of a multiple of 64 threads (<= 256); `sh`: 4 floats of LDS
+__device__ __forceinline__ float sp_batch_scale(const float *qmax, uint32_t nq, float *sh) {
+    float mx = 0.0f;
+    for (uint32_t i = threadIdx.x; i < nq; i += blockDim.x) mx = __builtin_fmaxf(mx, qmax[i]);
+    for (int o = 32; o >= 1; o >>= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = sh[0];
+    for (uint32_t w = 1; w < blockDim.x / 64; ++w) mx = __builtin_fmaxf(mx, sh[w]);
+    return sp_pow2_scale(mx);
 }
 // one thread per 16-byte unit: bq[kc][nt][hl][kq][n ^ 2 kq] = 8 halfs, k = 32 kc + 8 kq + e, query 16 nt + n (zero beyond nq)
 // half != 0 (the one-product mode): a chunk is 64 floats, the two unit planes hold the high parts of its two 32-float halves
-__global__ void sp_pack_queries_kernel(const float *q, uint32_t nq, uint32_t dim, const float *scales, uint4 *bq, int half, uint32_t qt) {
+__global__ __launch_bounds__(256) void sp_pack_queries_kernel(const float *q, uint32_t nq, uint32_t dim, const float *qmax, uint4 *bq, int half, uint32_t qt) {
+    __shared__ float sh_mx[4];
+    const float scale = sp_batch_scale(qmax, nq, sh_mx);
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (dim / 32) * qt * 4) return;
     const uint32_t b_units = qt * 8;                                    // 16-byte units of one chunk of the tile (128 queries: SP_B_UNITS)
     const uint32_t k32 = gid / (qt * 4), r = gid % (qt * 4);            // 32-float group of the row
     const uint32_t nt = r / 64, kq = (r / 16) % 4, n = r % 16;
     const uint32_t qi = nt * 16 + n;
-    const float scale = scales[0];
     half8 h, l;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -129,15 +135,26 @@ __global__ void sp_pack_queries_kernel(const float *q, uint32_t nq, uint32_t dim
     chunk[sp_unit(nt, 1, kq, n)] = *reinterpret_cast<const uint4 *>(&l);
 }
 // thr[q] in accumulator units: (exact k-th best of the sample - band) * scale.  band[q] = rel_band * row_norm_max * |q| (score units).
-__global__ void sp_thresholds_kernel(const uint64_t *gthr, const float *qnorm, uint32_t nq, float rel_band, float row_norm_max, const float *scales,
-                                     float *thr, float *band) {
+// Also: the batch's scales (scales[0] = query scale, [1] = row scale x query scale = accumulator units per score unit, [2] = its inverse) and the
+// zeroed candidate counters of the pass.
+__global__ __launch_bounds__(256) void sp_thresholds_kernel(const uint64_t *gthr, const float *qnorm, const float *qmax, uint32_t nq, float rel_band,
+                                                            float row_norm_max, float row_scale, float *scales, float *thr, float *band, uint32_t *cand_cnt,
+                                                            uint32_t n_cnt) {
+    __shared__ float sh_mx[4];
+    const float qs = sp_batch_scale(qmax, nq, sh_mx);
     const uint32_t q = threadIdx.x;                   // blockDim.x = queries of the tile (128 | 256)
+    if (q == 0) {
+        scales[0] = qs;
+        scales[1] = row_scale * qs;
+        scales[2] = 1.0f / (row_scale * qs);
+    }
+    for (uint32_t i = q; i < n_cnt; i += blockDim.x) cand_cnt[i] = 0;
     if (q >= nq) { thr[q] = __builtin_inff(); band[q] = 0.0f; return; }
     const float b = rel_band * row_norm_max * qnorm[q];
     const uint64_t k = gthr[q];
     // no bound (the sample holds fewer than k live rows): no candidates for this query, and its infinite band sends it - alone - to the exact scan
     band[q] = k ? b : __builtin_inff();
-    thr[q] = k ? (key_score(k) - b) * scales[1] : __builtin_inff();
+    thr[q] = k ? (key_score(k) - b) * (row_scale * qs) : __builtin_inff();
 }
 
 typedef __attribute__((address_space(3))) unsigned char sp_lds_byte;
@@ -784,33 +801,51 @@ constexpr int RG_LISTS = 16;
 __global__ __launch_bounds__(256) void sp_regroup_kernel(const uint4 *wlist, const uint32_t *wcnt, uint32_t wcap, uint32_t n_lists, DeletedView del,
                                                          uint64_t *cand, uint32_t *cand_cnt, uint32_t cap, int *overflow /* of the tile: every query of it */) {
     __shared__ uint32_t hist[SP_QT_MAX], base[SP_QT_MAX];
+    __shared__ uint32_t pre[RG_LISTS + 1];        // entries of the block's lists in front of list j
     if (threadIdx.x < SP_QT_MAX) hist[threadIdx.x] = 0;
-    __syncthreads();
     const uint32_t l0 = blockIdx.x * RG_LISTS, l1 = l0 + RG_LISTS < n_lists ? l0 + RG_LISTS : n_lists;
-    for (int pass = 0; pass < 2; ++pass) {
-        for (uint32_t l = l0; l < l1; ++l) {
-            uint32_t cnt = wcnt[l];
-            if (cnt > wcap) {
-                if (pass == 0 && threadIdx.x == 0) *overflow = 1;
-                cnt = wcap;
-            }
-            for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
-                const uint4 e = wlist[(uint64_t)l * wcap + i];
-                if (!del.live(e.x ^ 0xFFFFFFFFu)) continue;
-                if (pass == 0) atomicAdd(&hist[e.z], 1u);
-                else {
-                    const uint32_t at = base[e.z] + atomicAdd(&hist[e.z], 1u);
-                    if (at < cap) cand[(uint64_t)e.z * cap + at] = ((uint64_t)e.y << 32) | e.x;
-                }
-            }
+    if (threadIdx.x < 64) {                       // the lists' lengths in one load, their prefix sums across the wave
+        const uint32_t l = l0 + threadIdx.x;
+        uint32_t cnt = threadIdx.x < RG_LISTS && l < l1 ? wcnt[l] : 0;
+        if (cnt > wcap) {
+            *overflow = 1;
+            cnt = wcap;
         }
-        __syncthreads();
-        if (pass == 0 && threadIdx.x < SP_QT_MAX) {
-            const uint32_t c = hist[threadIdx.x];
-            base[threadIdx.x] = c ? atomicAdd(&cand_cnt[threadIdx.x], c) : 0;
-            hist[threadIdx.x] = 0;
+        uint32_t inc = cnt;
+        for (int o = 1; o < RG_LISTS; o <<= 1) {
+            const uint32_t up = __shfl_up(inc, o, 64);
+            if ((int)threadIdx.x >= o) inc += up;
         }
-        __syncthreads();
+        if (threadIdx.x < RG_LISTS) pre[threadIdx.x + 1] = inc;
+        if (threadIdx.x == 0) pre[0] = 0;
+    }
+    __syncthreads();
+    const uint32_t total = pre[RG_LISTS];
+    // the block's entries as one sequence: every trip of the loops below has 256 independent loads in flight (the lists are short - a few
+    // dozen entries each - and walking them one after the other was a chain of dependent round trips: 25 us per launch, twice per step)
+    auto entry = [&](uint32_t i) -> uint4 {
+        uint32_t j = 0;
+#pragma unroll
+        for (int s2 = RG_LISTS / 2; s2 >= 1; s2 >>= 1)
+            if (pre[j + s2] <= i) j += s2;
+        return wlist[(uint64_t)(l0 + j) * wcap + (i - pre[j])];
+    };
+    for (uint32_t i = threadIdx.x; i < total; i += 256) {
+        const uint4 e = entry(i);
+        if (del.live(e.x ^ 0xFFFFFFFFu)) atomicAdd(&hist[e.z], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < SP_QT_MAX) {
+        const uint32_t c = hist[threadIdx.x];
+        base[threadIdx.x] = c ? atomicAdd(&cand_cnt[threadIdx.x], c) : 0;
+        hist[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < total; i += 256) {
+        const uint4 e = entry(i);
+        if (!del.live(e.x ^ 0xFFFFFFFFu)) continue;
+        const uint32_t at = base[e.z] + atomicAdd(&hist[e.z], 1u);
+        if (at < cap) cand[(uint64_t)e.z * cap + at] = ((uint64_t)e.y << 32) | e.x;
     }
 }
 
@@ -1031,22 +1066,21 @@ float split_row_scale(float row_maxabs) {
     return ldexpf(1.0f, s);
 }
 
-// queries (preprocessed f32, [nq][dim] contiguous) -> bq, qnorm, scales.  d_stats: one zeroed u32.
-int32_t launch_split_pack_queries(hipStream_t st, const float *d_q, uint32_t nq, uint32_t dim, float row_scale, uint32_t *d_stats, float *d_qnorm,
-                                  float *d_scales, void *d_bq, int half, uint32_t qt) {
+// queries (preprocessed f32, [nq][dim] contiguous) -> bq, qnorm, qmax (per query: the scale of the batch is derived from them where it is needed)
+int32_t launch_split_pack_queries(hipStream_t st, const float *d_q, uint32_t nq, uint32_t dim, float *d_qmax, float *d_qnorm, void *d_bq, int half, uint32_t qt) {
+    QMX_REQUIRE(nq <= SP_QT_MAX, QMX_ERR_BAD_ARG, "split tile of %u queries", nq);
     ::qmx::clear_stale_error();
-    QMX_HIP(hipMemsetAsync(d_stats, 0, 4, st));
-    hipLaunchKernelGGL(sp_query_stats_kernel, dim3(nq), dim3(256), 0, st, d_q, nq, dim, d_stats, d_qnorm);
-    hipLaunchKernelGGL(sp_scales_kernel, dim3(1), dim3(1), 0, st, d_stats, row_scale, d_scales);
+    hipLaunchKernelGGL(sp_query_stats_kernel, dim3(nq), dim3(256), 0, st, d_q, nq, dim, d_qmax, d_qnorm);
     const uint32_t units = (dim / 32) * qt * 4;
-    hipLaunchKernelGGL(sp_pack_queries_kernel, dim3((units + 255) / 256), dim3(256), 0, st, d_q, nq, dim, d_scales, (uint4 *)d_bq, half, qt);
+    hipLaunchKernelGGL(sp_pack_queries_kernel, dim3((units + 255) / 256), dim3(256), 0, st, d_q, nq, dim, d_qmax, (uint4 *)d_bq, half, qt);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }
-int32_t launch_split_thresholds(hipStream_t st, const uint64_t *d_gthr, const float *d_qnorm, uint32_t nq, float rel_band, float row_norm_max,
-                                const float *d_scales, float *d_thr, float *d_band, uint32_t qt) {
+int32_t launch_split_thresholds(hipStream_t st, const uint64_t *d_gthr, const float *d_qnorm, const float *d_qmax, uint32_t nq, float rel_band, float row_norm_max,
+                                float row_scale, float *d_scales, float *d_thr, float *d_band, uint32_t qt, uint32_t *d_cand_cnt, uint32_t n_cnt) {
     ::qmx::clear_stale_error();
-    hipLaunchKernelGGL(sp_thresholds_kernel, dim3(1), dim3(qt), 0, st, d_gthr, d_qnorm, nq, rel_band, row_norm_max, d_scales, d_thr, d_band);
+    hipLaunchKernelGGL(sp_thresholds_kernel, dim3(1), dim3(qt), 0, st, d_gthr, d_qnorm, d_qmax, nq, rel_band, row_norm_max, row_scale, d_scales, d_thr, d_band,
+                       d_cand_cnt, n_cnt);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }
