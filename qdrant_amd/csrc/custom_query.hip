@@ -191,7 +191,7 @@ __global__ __launch_bounds__(CT_BLOCK) void custom_topk_kernel(const float *scor
     }
     if (threadIdx.x == 0) {
         out_counts[q] = total;
-        // the k-th best key when there are k results (what bound_from_topk_kernel reads back out of `out`): the starting threshold of a scan
+        // the k-th best key when there are k results (the key of out[top - 1]): the starting threshold of a scan
         if (bound_out) bound_out[q] = total == top ? bound : 0ull;
     }
 }
@@ -201,20 +201,6 @@ int32_t launch_custom_topk(hipStream_t st, const float *d_scores, uint64_t n, co
     if (n_queries == 0) return QMX_OK;
     ::qmx::clear_stale_error();
     hipLaunchKernelGGL(custom_topk_kernel, dim3(n_queries), dim3(CT_BLOCK), 0, st, d_scores, n, d_ids, del, top, d_out, d_counts, d_bound);
-    QMX_HIP(hipGetLastError());
-    return QMX_OK;
-}
-
-__global__ void bound_from_topk_kernel(const qmx_scored_point *out, const uint32_t *counts, uint32_t nq, uint32_t k, uint64_t *bound) {
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nq) return;
-    const qmx_scored_point p = out[(uint64_t)q * k + (k - 1)];
-    bound[q] = counts[q] == k ? make_key(p.score, p.idx) : 0ull;
-}
-int32_t launch_bound_from_topk(hipStream_t st, const qmx_scored_point *d_out, const uint32_t *d_counts, uint32_t nq, uint32_t k, uint64_t *d_bound) {
-    if (nq == 0) return QMX_OK;
-    ::qmx::clear_stale_error();
-    hipLaunchKernelGGL(bound_from_topk_kernel, dim3((nq + 63) / 64), dim3(64), 0, st, d_out, d_counts, nq, k, d_bound);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }

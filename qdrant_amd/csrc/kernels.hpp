@@ -358,8 +358,6 @@ int32_t launch_custom_combine(hipStream_t st, const qmx_custom_query *d_queries,
                               const float *d_coefs, float *d_out);
 int32_t launch_maxsim(hipStream_t st, const float *d_sims, uint64_t n_rows, const uint32_t *d_qfirst, uint32_t n_queries, const uint64_t *d_offsets,
                       uint32_t n_points, const uint32_t *d_ids, uint64_t n, float *d_out, int *err_flag);
-// bound[q] = key of the k-th entry of a full top-k list out[q * k ..] (0 when the list is short): the pre-scan's reject bound
-int32_t launch_bound_from_topk(hipStream_t st, const qmx_scored_point *d_out, const uint32_t *d_counts, uint32_t nq, uint32_t k, uint64_t *d_bound);
 int32_t launch_custom_topk(hipStream_t st, const float *d_scores, uint64_t n, const uint32_t *d_ids, const DeletedView &del, uint32_t n_queries,
                            uint32_t top, qmx_scored_point *d_out, uint32_t *d_counts, uint64_t *d_bound = nullptr);   // d_bound[q] = the k-th best key of a full list, else 0
 

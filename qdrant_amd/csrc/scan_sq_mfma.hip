@@ -81,8 +81,7 @@ struct TqOps {
     static __device__ __forceinline__ uint32_t lut4(uint32_t sel) {
         const uint32_t s = sel & 0x07070707u;
         const uint32_t lo = __builtin_amdgcn_perm(0xFAEEE1D4u, 0xC5B49F80u, s), hi = __builtin_amdgcn_perm(0x7F614C3Bu, 0x2C1F1206u, s);
-        const uint32_t m = ((sel >> 3) & 0x01010101u) * 0xFFu;
-        return (hi & m) | (lo & ~m);
+        return __builtin_amdgcn_perm(hi, lo, ((sel >> 1) & 0x04040404u) | 0x03020100u);   // byte i: lo's, or hi's where bit 3 of the code is set (as tq4_lookup, tq_policies.hpp)
     }
     static __device__ __forceinline__ void decode(const uint4 &x, dec_t &d) {
         const uint32_t v[4] = {x.x, x.y, x.z, x.w};
@@ -282,6 +281,7 @@ __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs 
     uint64_t list[QW];
     uint64_t thr[NG];              // reject bound of query 16 g + n: the k-th best key of the wave's list, never below ...
     uint64_t gk[NG];               // ... the score part of the pre-scan's bound (api.hip search_enqueue; 0 = none): equal scores pass
+    float thr_f[NG];               // the score of thr (-inf without one): one float compare rejects a pair before its key is even made
 #pragma unroll
     for (int q = 0; q < QW; ++q) list[q] = 0;
 #pragma unroll
@@ -289,6 +289,7 @@ __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs 
         const uint32_t q = (uint32_t)(16 * g + n);
         gk[g] = (MODE == SCAN_TOPK && a.gthr && q < a.nq) ? (a.gthr[q] & 0xFFFFFFFF00000000ull) : 0ull;
         thr[g] = gk[g];
+        thr_f[g] = gk[g] ? key_score(gk[g]) : -__builtin_inff();
     }
 
     const uint32_t gw = blockIdx.x * SQM_NW + wave;
@@ -379,10 +380,12 @@ __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs 
                 if (MODE == SCAN_SCORES) {
                     if (mine) a.scores[(uint64_t)q * a.scores_stride + (tile * 16 + (uint32_t)(4 * kg + r))] = score;
                 } else {
-                    const uint64_t key = make_key(score, rid[r]);
-                    bool c = mine && key > thr[g];
+                    // cheap reject on the score alone (the epilogue is a third of the kernel's issue slots at 32 queries); ties with the k-th score
+                    // and NaN (greatest in OrderedFloat) fall through to the exact key compare
+                    bool c = mine && !(score < thr_f[g]);
                     if (__ballot(c)) {
-                        c = c && a.del.live(rid[r]) && (!a.key_bound || key < a.key_bound[q]);
+                        const uint64_t key = make_key(score, rid[r]);
+                        c = c && key > thr[g] && a.del.live(rid[r]) && (!a.key_bound || key < a.key_bound[q]);
                         uint64_t mask = __ballot(c);
                         while (mask) {
                             const int src = __builtin_ctzll(mask);
@@ -395,7 +398,10 @@ __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs 
                                     if (nk > readlane_u64(list[qq], top - 1)) {
                                         wave_list_insert(list[qq], nk, lane);
                                         const uint64_t nt = readlane_u64(list[qq], top - 1);
-                                        if (n == qq - 16 * g) thr[g] = nt > gk[g] ? nt : gk[g];
+                                        if (n == qq - 16 * g) {
+                                            thr[g] = nt > gk[g] ? nt : gk[g];
+                                            thr_f[g] = thr[g] ? key_score(thr[g]) : -__builtin_inff();
+                                        }
                                     }
                                 }
                             }
