@@ -164,7 +164,7 @@ uint64_t qo_bq_xor_popcnt_scalar(const uint8_t *vector, const uint8_t *query, ui
 float qo_bq_score_scalar(int distance, int invert, uint32_t dim, int encoding, uint32_t bits, const uint8_t *scalar_query, const uint8_t *v);
 
 /* ---- TurboQuant: lib/quantization/src/turboquant/ behind EncodedVectorsTQ (oracle/qdrant_oracle_tq.c; TQMode::Normal) ----
- * bits: TQBits in the reference's order {Bits4 = 0, Bits2 = 1, Bits1_5 = 2, Bits1 = 3}; distance: QO_DOT | QO_COSINE | QO_EUCLID. */
+ * bits: TQBits in the reference's order {Bits4 = 0, Bits2 = 1, Bits1_5 = 2, Bits1 = 3}; distance: QO_DOT | QO_COSINE | QO_EUCLID | QO_MANHATTAN (DistanceType::L1: the dequantise-and-rotate-back fallback). */
 typedef struct qo_tq qo_tq;
 typedef struct qo_tq_query qo_tq_query;
 uint32_t qo_tq_padded_dim_for(uint32_t dim, int bits);                                 /* encoding.rs:194-201 */
@@ -189,6 +189,8 @@ void qo_tq_preprocess(const qo_tq *t, const float *vec, double *buf);           
 void qo_tq_plus_fit(const qo_tq *t, const float *sample, uint32_t n_sample, float *shift, float *scale);
 float qo_tq_score_precomputed(const qo_tq *t, const qo_tq_query *e, const uint8_t *vec);   /* score_precomputed (before `invert`) */
 float qo_tq_score_symmetric(const qo_tq *t, const uint8_t *v1, const uint8_t *v2);         /* score_symmetric (before `invert`) */
+void qo_tq_dequantize(const qo_tq *t, const uint8_t *vec, double *out);                   /* dequantize::<f64> (quantization.rs:321-376), rotated space */
+void qo_tq_rotate_inverse(const qo_tq *t, double *x);                                     /* HadamardRotation::apply_inverse on x[..rotation dim] */
 
 /* ---- cross-segment merge: BatchResultAggregator (lib/shard/src/search_result_aggregator.rs:50-121) ----
  * lists[(l * nq + qi) * k ..] with counts[l * nq + qi] valid entries; idx_base[l] (optional) is added to

@@ -400,7 +400,8 @@ void qo_tq_quantize(const qo_tq *t, const float *vec, uint8_t *out) {
         const uint32_t idx = centroid_index(centroids, nc, buf[i]), bit = i * bs;
         out[bit / 8] |= (uint8_t)(idx << (bit % 8));
     }
-    const float scaling_factor = (has_l2 ? l2_length : 1.0f) / centroid_norm;
+    /* pack_extras_into (encoding.rs:218-247): l2 / centroid_norm; L1 stores the bare l2 length (no centroid norm, quantization.rs:275) */
+    const float scaling_factor = t->distance == QO_MANHATTAN ? l2_length : (has_l2 ? l2_length : 1.0f) / centroid_norm;
     memcpy(out + code_bytes, &scaling_factor, 4);
     if (t->distance == QO_EUCLID) memcpy(out + code_bytes + 4, &l2_length, 4);
     if (t->shift) memcpy(out + code_bytes + (t->distance == QO_EUCLID ? 8 : 4), &xm, 4);      /* the trailing f32 of the extras */
@@ -412,6 +413,7 @@ struct qo_tq_query {
     float postprocess_scale, l2_norm, ec_correction;
     int64_t sum_q;
     float *rotated_f32;
+    float *raw;            /* DistanceType::L1 keeps the query as given (quantization.rs:532-535), NULL otherwise */
 };
 
 qo_tq_query *qo_tq_precompute_query(const qo_tq *t, const float *query) {
@@ -457,12 +459,16 @@ qo_tq_query *qo_tq_precompute_query(const qo_tq *t, const float *query) {
         const float codebook_scale = 128.0f / (t->bits == TQ_BITS4 ? 2.733f : 1.510f);
         e->postprocess_scale = 1.0f / (q_scale * codebook_scale);
     }
+    if (t->distance == QO_MANHATTAN) {
+        e->raw = (float *)malloc(sizeof(float) * (t->dim ? t->dim : 1));
+        memcpy(e->raw, query, sizeof(float) * t->dim);
+    }
     free(rot);
     return e;
 }
 void qo_tq_query_free(qo_tq_query *e) {
     if (!e) return;
-    free(e->q); free(e->rotated_f32); free(e);
+    free(e->q); free(e->rotated_f32); free(e->raw); free(e);
 }
 /* the encoded query as the device holds it: q_signed [padded_dim], postprocess_scale, l2_norm, sum of q_signed */
 float qo_tq_query_ec_correction(const qo_tq_query *e) { return e->ec_correction; }
@@ -492,8 +498,67 @@ static float tq_raw_dot(const qo_tq *t, const qo_tq_query *e, const uint8_t *cod
     return e->postprocess_scale * (float)(dot_raw - bias);
 }
 
+/* HadamardRotation::apply_inverse on x[..rot_dim] (rotation.rs:76-79): the same WHT / gather rounds over the backward maps, last map first;
+ * backward_maps[p][forward_maps[p][k]] = k (rotation.rs:47-53) */
+void qo_tq_rotate_inverse(const qo_tq *t, double *x) {
+    const uint32_t n = t->rot_dim;
+    if (n == 0) return;
+    double *scratch = (double *)malloc(sizeof(double) * n);
+    uint32_t *inv = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    wht_normalized_chunks(x, n);
+    double *src = x, *dst = scratch;
+    for (int p = 2; p >= 0; p--) {
+        for (uint32_t k = 0; k < n; k++) inv[t->maps[p][k]] = k;
+        for (uint32_t k = 0; k < n; k++) dst[k] = src[inv[k]];
+        wht_normalized_chunks(dst, n);
+        double *s2 = src; src = dst; dst = s2;
+    }
+    if (src != x) memcpy(x, src, sizeof(double) * n);
+    free(scratch); free(inv);
+}
+/* TurboQuantizer::dequantize::<f64> (quantization.rs:321-376): out[padded_dim], still in the rotated space */
+void qo_tq_dequantize(const qo_tq *t, const uint8_t *vec, double *out) {
+    const uint32_t pd = t->padded_dim, bs = (uint32_t)bit_size(t->bits), code_bytes = pd * bs / 8;
+    int nc;
+    const float *centroids = centroids_of(t->bits, &nc);
+    float sf;
+    memcpy(&sf, vec + code_bytes, 4);
+    const double scaling_factor = (double)sf;
+    for (uint32_t i = 0; i < pd; i++) out[i] = (double)centroids[code_at(vec, i, bs)];
+    double recovered_l2;
+    if (t->distance == QO_DOT || t->distance == QO_COSINE) {
+        double sq = 0.0;
+        for (uint32_t i = 0; i < pd; i++) {
+            const double r = t->shift ? out[i] / (double)t->scale[i] - (double)t->shift[i] : out[i];
+            sq += r * r;
+        }
+        recovered_l2 = scaling_factor * sqrt(sq);
+    } else if (t->distance == QO_EUCLID) {
+        float l2;
+        memcpy(&l2, vec + code_bytes + 4, 4);
+        recovered_l2 = (double)l2;
+    } else {
+        recovered_l2 = scaling_factor;
+    }
+    const double scale = recovered_l2 / sqrt((double)pd);
+    for (uint32_t i = 0; i < pd; i++) {
+        const double r = t->shift ? out[i] / (double)t->scale[i] - (double)t->shift[i] : out[i];
+        out[i] = r * scale;
+    }
+}
+
 float qo_tq_score_precomputed(const qo_tq *t, const qo_tq_query *e, const uint8_t *vec) {
     const uint32_t code_bytes = t->padded_dim * (uint32_t)bit_size(t->bits) / 8;
+    if (t->distance == QO_MANHATTAN) {     /* :596-607: dequantize, rotate back, sum of |q - v| as f32 over the query's coordinates, in order */
+        double *deq = (double *)malloc(sizeof(double) * (t->padded_dim ? t->padded_dim : 1));
+        qo_tq_dequantize(t, vec, deq);
+        qo_tq_rotate_inverse(t, deq);
+        float sum = 0.0f;
+        const uint32_t n = t->dim < t->padded_dim ? t->dim : t->padded_dim;
+        for (uint32_t i = 0; i < n; i++) sum += (float)fabs((double)e->raw[i] - deq[i]);
+        free(deq);
+        return sum;
+    }
     float scaling_factor, l2 = 0.0f;
     memcpy(&scaling_factor, vec + code_bytes, 4);
     const float dot = tq_raw_dot(t, e, vec) + e->ec_correction;   /* 0.0 without TQ+ */
@@ -507,6 +572,17 @@ float qo_tq_score_precomputed(const qo_tq *t, const qo_tq_query *e, const uint8_
 
 float qo_tq_score_symmetric(const qo_tq *t, const uint8_t *v1, const uint8_t *v2) {
     const uint32_t pd = t->padded_dim, bs = (uint32_t)bit_size(t->bits), code_bytes = pd * bs / 8;
+    if (t->distance == QO_MANHATTAN) {     /* :429-440: both dequantized, ONE inverse rotation of the difference, sum of |x| as f32 over padded_dim */
+        double *d1 = (double *)malloc(sizeof(double) * (pd ? pd : 1)), *d2 = (double *)malloc(sizeof(double) * (pd ? pd : 1));
+        qo_tq_dequantize(t, v1, d1);
+        qo_tq_dequantize(t, v2, d2);
+        for (uint32_t i = 0; i < pd; i++) d2[i] = d1[i] - d2[i];
+        qo_tq_rotate_inverse(t, d2);
+        float sum = 0.0f;
+        for (uint32_t i = 0; i < pd; i++) sum += (float)fabs(d2[i]);
+        free(d1); free(d2);
+        return sum;
+    }
     float raw_dot;
     if (t->shift && bs != 1) {      /* score_symmetric_ec (:447-494): weighted integer dot / (weight_scale * CODEBOOK_SCALE^2) + xm_a + xm_b - <M, M> */
         const uint8_t *book = t->bits == TQ_BITS4 ? CODEBOOK_U8_4BIT : CODEBOOK_U8_2BIT;
@@ -548,4 +624,3 @@ float qo_tq_score_symmetric(const qo_tq *t, const uint8_t *v1, const uint8_t *v2
     return raw_dot * s1 * s2;
 }
 
-/* TurboQuantizer::dequantize (Normal mode) followed by apply_inverse_rotation is not restated (L1 only). */

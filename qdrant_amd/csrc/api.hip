@@ -574,7 +574,6 @@ static int32_t tq_segment_setup(qmx_segment *s, const qmx_segment_desc *desc) {
     QMX_REQUIRE(t.bits <= QMX_TQ_BITS1, QMX_ERR_BAD_ARG, "bad TQBits %u", t.bits);
     QMX_REQUIRE(!t.plus_mode || (t.ec_shift && t.ec_scale), QMX_ERR_BAD_ARG, "TQMode::Plus needs the storage's error correction (ec_shift / ec_scale)");
     QMX_REQUIRE(!t.plus_mode || (!is_device_ptr(t.ec_shift) && !is_device_ptr(t.ec_scale)), QMX_ERR_BAD_ARG, "ec_shift / ec_scale are host arrays");
-    QMX_REQUIRE(desc->distance != QMX_DISTANCE_MANHATTAN, QMX_ERR_NOT_SUPPORTED, "TurboQuant L1 scores (dequantise + inverse rotation per pair) are not built");
     QMX_REQUIRE(!(t.bits == QMX_TQ_BITS1_5 && t.rotation_unpadded), QMX_ERR_BAD_ARG, "Bits1_5 requires TQRotation::Padded");
     auto next_multiple = [](uint64_t x, uint64_t m) { return (x + m - 1) / m * m; };
     const uint64_t dim = desc->dim;
@@ -618,7 +617,7 @@ static int32_t tq_segment_setup(qmx_segment *s, const qmx_segment_desc *desc) {
     // the rotation tables
     const uint32_t rd = s->tq_rot_dim;
     static const uint64_t SEEDS[3] = {654605292835415893ull, 8636605637963351413ull, 1775280196666917949ull};
-    std::vector<uint32_t> tables((size_t)3 * rd + 64);
+    std::vector<uint32_t> tables((size_t)6 * rd + 64);    // forward maps, chunk offsets / sizes, backward maps (last permutation first: apply_inverse's order)
     for (int p = 0; p < 3; ++p) {
         uint32_t *map = tables.data() + (size_t)p * rd;
         for (uint32_t i = 0; i < rd; ++i) map[i] = i;
@@ -628,6 +627,11 @@ static int32_t tq_segment_setup(qmx_segment *s, const qmx_segment_desc *desc) {
             const uint32_t j = (uint32_t)((state >> 32) % ((uint64_t)i + 1));
             std::swap(map[i], map[j]);
         }
+    }
+    for (int p = 0; p < 3; ++p) {       // backward_maps[p][forward_maps[p][k]] = k (rotation.rs:47-53)
+        const uint32_t *fwd = tables.data() + (size_t)p * rd;
+        uint32_t *inv = tables.data() + (size_t)3 * rd + 64 + (size_t)(2 - p) * rd;
+        for (uint32_t k = 0; k < rd; ++k) inv[fwd[k]] = k;
     }
     std::vector<double> norms;
     uint32_t nchunks = 0, off = 0;
@@ -657,6 +661,15 @@ static TqRotationHost tq_rotation(const qmx_segment *s) {
     return h;
 }
 
+// HadamardRotation::apply_inverse: the same rounds over the backward maps
+static TqRotationHost tq_rotation_inverse(const qmx_segment *s) {
+    TqRotationHost h = tq_rotation(s);
+    h.d_maps = s->d_tq_tables + (size_t)3 * s->tq_rot_dim + 64;
+    return h;
+}
+// EncodedVectorsTQ over Distance::Manhattan: no integer kernel, every score dequantises and rotates the row back (tq_l1.hip)
+static bool tq_l1(const qmx_segment *s) { return s->dtype == QMX_DTYPE_TQ && s->distance == QMX_DISTANCE_MANHATTAN; }
+
 // turboquant/math.rs:3-15 (Abramowitz & Stegun 7.1.26)
 static double tq_std_normal_cdf(double x) {
     const double y = x / 1.4142135623730951;
@@ -670,7 +683,7 @@ static double tq_std_normal_cdf(double x) {
 int32_t qmx_tq_fit_plus(int32_t device_id, uint32_t distance, uint32_t dim, const qmx_tq_params *params, const float *sample, uint64_t n_sample,
                         float *shift_out, float *scale_out) {
     QMX_REQUIRE(params && shift_out && scale_out && (n_sample == 0 || sample) && dim > 0, QMX_ERR_BAD_ARG, "bad argument");
-    QMX_REQUIRE(distance <= QMX_DISTANCE_MANHATTAN && distance != QMX_DISTANCE_MANHATTAN, QMX_ERR_NOT_SUPPORTED, "TurboQuant: distance %u not built", distance);
+    QMX_REQUIRE(distance <= QMX_DISTANCE_MANHATTAN, QMX_ERR_BAD_ARG, "bad distance %u", distance);
     QMX_REQUIRE(n_sample <= (1u << 20), QMX_ERR_BAD_ARG, "sample of %llu vectors (the reference takes 2 048 .. 8 192)", (unsigned long long)n_sample);
     QMX_TRY(check_device(device_id, nullptr));
     qmx_tq_params pre = *params;           // the pre-quantizer of the stats pass: TQMode::Normal, no error correction (:159-165)
@@ -719,7 +732,7 @@ int32_t qmx_tq_fit_plus(int32_t device_id, uint32_t distance, uint32_t dim, cons
 
 int32_t qmx_tq_encode(int32_t device_id, uint32_t distance, uint32_t dim, const qmx_tq_params *params, const float *vectors, uint64_t n, void *out_rows) {
     QMX_REQUIRE(params && (n == 0 || (vectors && out_rows)) && dim > 0, QMX_ERR_BAD_ARG, "bad argument");
-    QMX_REQUIRE(distance <= QMX_DISTANCE_MANHATTAN && distance != QMX_DISTANCE_MANHATTAN, QMX_ERR_NOT_SUPPORTED, "TurboQuant: distance %u not built", distance);
+    QMX_REQUIRE(distance <= QMX_DISTANCE_MANHATTAN, QMX_ERR_BAD_ARG, "bad distance %u", distance);
     QMX_TRY(check_device(device_id, nullptr));
     if (n == 0) return QMX_OK;
     qmx_segment tmp;                       // parameter holder only: the rotation tables of TurboQuantizer::new
@@ -1225,6 +1238,7 @@ static int32_t query_encode(qmx_query *q, const float *queries) {
                                              q->aux_off, (seg->scan_dim + 63) & ~63u);
     if (seg->dtype == QMX_DTYPE_BQ)      // encode_query_vector, SameAsStorage (encoded_vectors_binary.rs:673-690) = encode_one_bit_vector
         return launch_bq_encode(q->stream, d_f32, nq, seg->dim, seg->bq_encoding, seg->d_bq_mean, seg->d_bq_stddev, (uint8_t *)q->d_queries, q->q_stride);
+    if (tq_l1(seg)) return QMX_OK;       // DistanceType::L1 scores against the query as given (quantization.rs:532-535): q->enc holds it
     if (seg->dtype == QMX_DTYPE_TQ) {    // TurboQuantizer::precompute_query (turboquant/quantization.rs:496-567)
         QMX_TRY(q->tq_rot.reserve((size_t)nq * seg->tq_padded_dim * sizeof(double)));
         QMX_TRY(launch_tq_rotate(q->stream, d_f32, nq, tq_rotation(seg), (double *)q->tq_rot.p));
@@ -1505,11 +1519,34 @@ static int32_t launch_scan(const qmx_query *q, int qt, ScanMode mode, const Scan
     return QMX_ERR_NOT_SUPPORTED;
 }
 
+// TurboQuant over Manhattan: scores of queries [q0, q0 + nq) against the candidates d_ids[0..n) (rows 0..n without ids) into d_scores[(qi - q0) * stride + i],
+// or - sel - of the (query, candidate) items of a PairSel into d_scores[i].  Batches of 65 536 rows: dequantise, rotate back, sum |q - v|.
+static int32_t tq_l1_scores_device(qmx_query *q, uint32_t q0, uint32_t nq, const uint32_t *d_ids, uint64_t n, float *d_scores, uint64_t stride, const PairSel *sel) {
+    const qmx_segment *s = q->seg;
+    const uint64_t B = 65536;
+    QMX_TRY(q->tq_rot.reserve((size_t)std::min<uint64_t>(n, B) * s->tq_padded_dim * sizeof(double)));
+    double *buf = (double *)q->tq_rot.p;
+    const float *d_q = (const float *)q->enc.p + (size_t)q0 * s->dim;
+    for (uint64_t r0 = 0; r0 < n; r0 += B) {
+        const uint32_t cnt = (uint32_t)std::min<uint64_t>(B, n - r0);
+        QMX_TRY(launch_tq_l1_dequant(q->stream, s->d_rows, s->row_stride, s->d_tq_sf, d_ids ? d_ids + r0 : nullptr, r0, cnt, s->n, s->tq_padded_dim, s->tq_value_bits,
+                                     s->d_tq_shift, s->d_tq_scale, buf, q->d_err, sel));
+        QMX_TRY(launch_tq_rotate_f64(q->stream, buf, cnt, tq_rotation_inverse(s)));
+        QMX_TRY(launch_tq_l1_scores(q->stream, buf, cnt, s->tq_padded_dim, s->dim, sel ? (const float *)q->enc.p : d_q, s->dim, 0, nq, d_scores, stride, r0,
+                                    s->tq_invert ? 1 : 0, sel, r0));
+    }
+    return QMX_OK;
+}
+
 // The score matrix of queries [tile0, tile0 + nq_tile) of the batch against the candidates ids[0..n) (rows 0..n without ids): scores[(qi - tile0) * stride + i].
 // One launch per tile_qt queries; the f32 matrix-core kernel takes them all in one launch (scan_mfma.hip: score mode loops over its query tiles).
 static int32_t score_matrix_enqueue(const qmx_query *q, uint32_t tile0, uint32_t nq_tile, const uint32_t *d_ids, uint64_t n, float *d_scores, uint64_t stride,
                                     uint32_t *launches) {
     const qmx_segment *s = q->seg;
+    if (tq_l1(s)) {
+        if (launches) *launches += 3 * (uint32_t)((n + 65535) / 65536);
+        return tq_l1_scores_device(const_cast<qmx_query *>(q), tile0, nq_tile, d_ids, n, d_scores, stride, nullptr);
+    }
     const uint32_t SQT = tile_qt(s, q);
     const bool loops = s->dtype == QMX_DTYPE_F32 && SQT >= 8 && mfma_scan_ok(s);
     const uint32_t step = loops ? nq_tile : SQT;
@@ -1764,6 +1801,29 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
                               qmx_counters *counters, bool timed) {
     const qmx_segment *s = q->seg;
     const uint64_t n_cand = d_ids ? n_ids : s->scan_rows();
+    if (tq_l1(s)) {     // the score matrix (tiles of queries: at most 2^31 scores at a time), then one block per query selects its k best live candidates
+        q->last_counters = qmx_counters{};
+        q->last_split = false;
+        ScanArgs a;
+        fill_args(q, 0, q->nq, a);
+        const uint32_t qtile = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(q->nq, (1ull << 31) / std::max<uint64_t>(n_cand, 1)));
+        QMX_TRY(q->scores.reserve((size_t)qtile * std::max<uint64_t>(n_cand, 1) * sizeof(float)));
+        for (uint32_t q0 = 0; q0 < q->nq; q0 += qtile) {
+            if (is_stopped && *is_stopped) {
+                set_error("search cancelled");
+                return QMX_ERR_CANCELLED;
+            }
+            const uint32_t nq_tile = std::min<uint32_t>(qtile, q->nq - q0);
+            QMX_TRY(tq_l1_scores_device(q, q0, nq_tile, d_ids, n_cand, (float *)q->scores.p, n_cand, nullptr));
+            QMX_TRY(launch_custom_topk(q->stream, (const float *)q->scores.p, n_cand, d_ids, a.del, nq_tile, top, d_out + (size_t)q0 * top, d_counts + q0));
+            if (counters) counters->kernel_launches += 1 + 3 * (uint32_t)((n_cand + 65535) / 65536);
+        }
+        if (counters) {
+            counters->vectors_scored += (uint64_t)q->nq * n_cand;
+            counters->bytes_read += (uint64_t)((q->nq + qtile - 1) / qtile) * n_cand * s->row_bytes;
+        }
+        return QMX_OK;
+    }
     if (s->dtype == QMX_DTYPE_PQ && s->d_pq_rot && !d_ids && top <= MAX_TOP_FAST && n_cand >= (1u << 18) && !option(OPT_NO_PQ_PREFILTER) &&
         q->nq >= (uint32_t)std::max<int64_t>(1, option(OPT_PQ_PREFILTER_MIN_QUERIES)))
         return pq_prefilter_enqueue(q, top, n_cand, d_out, d_counts, is_stopped, counters, timed);
@@ -2461,6 +2521,7 @@ static int32_t hnsw_build_impl(const qmx_segment *seg, const qmx_segment *origin
     QMX_REQUIRE(seg && bp && out, QMX_ERR_BAD_ARG, "NULL argument");
     *out = nullptr;
     QMX_REQUIRE(seg->dtype <= QMX_DTYPE_BQ || seg->dtype == QMX_DTYPE_TQ, QMX_ERR_NOT_SUPPORTED, "device HNSW build: dtype %u not supported", seg->dtype);
+    QMX_REQUIRE(!tq_l1(seg), QMX_ERR_NOT_SUPPORTED, "device HNSW build through a TurboQuant storage over Manhattan is not built (build over the original vectors)");
     const bool from_original = seg->dtype == QMX_DTYPE_PQ || seg->dtype == QMX_DTYPE_TQ;
     if (from_original) {   // point_scorer.rs:197-212: the insertion searches score through the query (PQ: LUT) of the ORIGINAL vector
         QMX_REQUIRE(original, QMX_ERR_NOT_SUPPORTED,
@@ -2813,6 +2874,9 @@ static int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint3
                             uint32_t *d_counts, uint32_t *d_scored, bool timed, bool acorn = false, const MultiWalk *mw = nullptr,
                             const ExpandedOut *xo = nullptr, const CustomWalk *cw = nullptr) {
     const qmx_segment *s = q->seg;
+    QMX_REQUIRE(!tq_l1(s), QMX_ERR_NOT_SUPPORTED,
+                "HNSW walk through a TurboQuant storage over Manhattan: every hop score is a dequantisation + inverse rotation (tq_l1.hip serves score_points, "
+                "brute force, score_internal and rescoring); walk the graph with the original vectors' scorer");
     ScanArgs a;
     fill_args(q, 0, q->nq, a);
     const uint32_t n_searches = cw ? cw->n_queries : mw ? mw->n_queries : q->nq;
@@ -3138,7 +3202,9 @@ static int32_t score_pairs_device(qmx_query *q, const PairSel &sel, const uint32
     size_t slot = 0;
     if (timed) QMX_TRY(timing_begin(q, &slot));
     int32_t rc;
-    if (s->dtype <= QMX_DTYPE_U8) {
+    if (tq_l1(s)) {
+        rc = tq_l1_scores_device(q, 0, q->nq, d_ids, n_items, d_scores, 0, &sel);
+    } else if (s->dtype <= QMX_DTYPE_U8) {
         QMX_REQUIRE(s->fast_layout(), QMX_ERR_NOT_SUPPORTED, "adopted device block is not 16-byte aligned");
         rc = launch_pairs_dense(q->stream, (int)s->dtype, (int)s->distance, a, sel, n_items, s->num_cus);
     } else if (s->dtype == QMX_DTYPE_SQ_U8) {
@@ -3779,7 +3845,27 @@ int32_t qmx_score_internal(const qmx_segment *seg, const uint32_t *a_ids, const 
             if (e == hipSuccess) e = hipMemcpy(bb.p, b_ids, (size_t)n * 4, hipMemcpyDefault);
             if (e == hipSuccess) e = hipMemset(be.p, 0, 4);
             if (e != hipSuccess) { rc = hip_status(e, "stage ids", __FILE__, __LINE__); break; }
-            if (seg->dtype == QMX_DTYPE_TQ)
+            if (tq_l1(seg)) {    // score_symmetric's L1 arm (quantization.rs:429-440): both rows dequantised, ONE inverse rotation of the difference, sum |x| over padded_dim
+                DevBuf da, db;
+                const uint32_t pd = seg->tq_padded_dim;
+                const uint64_t B = 32768;
+                if ((rc = da.reserve((size_t)std::min<uint64_t>(n, B) * pd * 8)) == QMX_OK) rc = db.reserve((size_t)std::min<uint64_t>(n, B) * pd * 8);
+                for (uint64_t r0 = 0; r0 < n && rc == QMX_OK; r0 += B) {
+                    const uint32_t cnt = (uint32_t)std::min<uint64_t>(B, n - r0);
+                    rc = launch_tq_l1_dequant(nullptr, seg->d_rows, seg->row_stride, seg->d_tq_sf, (const uint32_t *)ba.p + r0, 0, cnt, seg->n, pd, seg->tq_value_bits,
+                                              seg->d_tq_shift, seg->d_tq_scale, (double *)da.p, (int *)be.p, nullptr);
+                    if (rc == QMX_OK)
+                        rc = launch_tq_l1_dequant(nullptr, seg->d_rows, seg->row_stride, seg->d_tq_sf, (const uint32_t *)bb.p + r0, 0, cnt, seg->n, pd, seg->tq_value_bits,
+                                                  seg->d_tq_shift, seg->d_tq_scale, (double *)db.p, (int *)be.p, nullptr);
+                    if (rc == QMX_OK) rc = launch_tq_l1_diff(nullptr, (double *)da.p, (const double *)db.p, (uint64_t)cnt * pd);
+                    if (rc == QMX_OK) rc = launch_tq_rotate_f64(nullptr, (double *)da.p, cnt, tq_rotation_inverse(seg));
+                    if (rc == QMX_OK)
+                        rc = launch_tq_l1_scores(nullptr, (const double *)da.p, cnt, pd, pd, nullptr, pd, 0, 1, (float *)bo.p, 0, r0, seg->tq_invert ? 1 : 0, nullptr, 0);
+                }
+                if (rc == QMX_OK && hipDeviceSynchronize() != hipSuccess) rc = QMX_ERR_OTHER;
+                da.release(); db.release();
+            }
+            else if (seg->dtype == QMX_DTYPE_TQ)
             {
                 TqEc ec{seg->d_tq_weights, seg->d_tq_xm, seg->tq_weight_scale, seg->tq_mm_const};
                 rc = launch_tq_internal(nullptr, seg->d_rows, (uint32_t)seg->row_stride, seg->d_tq_sf, seg->d_tq_l2, seg->tq_code_bytes, seg->tq_value_bits,

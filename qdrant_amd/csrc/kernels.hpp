@@ -137,6 +137,17 @@ int32_t launch_hnsw_tq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uin
 int32_t launch_tq_split(hipStream_t st, const void *rows, uint64_t src_stride, uint64_t n, uint32_t code_bytes, uint32_t dst_stride, int has_l2,
                         void *codes, float *sf, float *l2, float *xm);
 int32_t launch_tq_rotate(hipStream_t st, const float *d_in, uint32_t n, const TqRotationHost &h, double *d_out);
+int32_t launch_tq_rotate_f64(hipStream_t st, double *d_buf, uint32_t n, const TqRotationHost &h);   // in place, h = the inverse rotation's tables
+// TurboQuant over Manhattan (tq_l1.hip): DistanceType::L1 scores = dequantise + inverse rotation per row, then sum |q - v|
+struct PairSel;
+int32_t launch_tq_l1_dequant(hipStream_t st, const void *codes, uint64_t row_stride, const float *sf, const uint32_t *d_ids, uint64_t id0, uint64_t n,
+                             uint64_t n_rows, uint32_t padded_dim, uint32_t value_bits, const float *d_shift, const float *d_scale, double *d_out, int *err_flag,
+                             const PairSel *sel);   // rows d_ids[r], or id0 + r; sel: item id0 + r of a pair list (dead slots give zeros)
+int32_t launch_tq_l1_diff(hipStream_t st, double *d_a, const double *d_b, uint64_t n_elems);      // a <- a - b
+// scores[q * stride + col0 + i] for rows i of d_deq ([n][padded_dim]) and queries [q0, q0 + nq): the sum over k < dim of (f32)|q[k] - v[k]| in order,
+// negated when `invert`; d_queries = f32 [.][q_dim] (nullptr: the zero query); sel != nullptr: one (query, row) pair per row of d_deq, scores[col0 + i]
+int32_t launch_tq_l1_scores(hipStream_t st, const double *d_deq, uint64_t n, uint32_t padded_dim, uint32_t dim, const float *d_queries, uint32_t q_dim,
+                            uint32_t q0, uint32_t nq, float *d_scores, uint64_t stride, uint64_t col0, int invert, const PairSel *sel, uint64_t item0);
 int32_t launch_tq_plus_fit(hipStream_t st, double *d_rot, uint32_t n, uint32_t padded_dim, uint32_t distance, double min_q, double max_q, float c_outer,
                            float *d_shift, float *d_scale);
 int32_t launch_tq_quantize(hipStream_t st, double *d_rot, uint32_t n, uint32_t padded_dim, uint32_t value_bits, uint32_t distance, void *d_out,

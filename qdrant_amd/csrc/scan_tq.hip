@@ -106,12 +106,13 @@ __device__ __forceinline__ void tq_wht_chunks(double *x, const TqRotation &r) {
     }
     __syncthreads();
 }
-__global__ __launch_bounds__(256) void tq_rotate_kernel(const float *in, uint64_t in_stride, uint32_t n, TqRotation r, double *out) {
+template <class T>      // T = float: vectors as given (HadamardRotation::apply); double: dequantized rows, possibly in place (apply_inverse, with the backward maps)
+__global__ __launch_bounds__(256) void tq_rotate_kernel(const T *in, uint64_t in_stride, uint32_t n, TqRotation r, double *out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_tq[];
     double *a = reinterpret_cast<double *>(smem_tq), *b = a + r.rot_dim;
     const uint32_t v = blockIdx.x;
     if (v >= n) return;
-    const float *src = in + (uint64_t)v * in_stride;
+    const T *src = in + (uint64_t)v * in_stride;
     for (uint32_t i = threadIdx.x; i < r.rot_dim; i += blockDim.x) a[i] = i < r.dim ? (double)src[i] : 0.0;
     __syncthreads();
     tq_wht_chunks(a, r);
@@ -135,11 +136,31 @@ int32_t launch_tq_rotate(hipStream_t st, const float *d_in, uint32_t n, const Tq
     QMX_REQUIRE(lds <= 150 * 1024, QMX_ERR_NOT_SUPPORTED, "TurboQuant rotation over %u coordinates does not fit the LDS", h.rot_dim);
     static thread_local DeviceOnce attr_once;
     if (attr_once.need()) {
-        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tq_rotate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tq_rotate_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tq_rotate_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_once.mark();
     }
     ::qmx::clear_stale_error();
-    hipLaunchKernelGGL(tq_rotate_kernel, dim3(n), dim3(256), lds, st, d_in, (uint64_t)h.dim, n, r, d_out);
+    hipLaunchKernelGGL(tq_rotate_kernel<float>, dim3(n), dim3(256), lds, st, d_in, (uint64_t)h.dim, n, r, d_out);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+// HadamardRotation::apply_inverse on [n][padded_dim] f64 vectors in place: `h` carries the backward maps, last permutation first (api.hip
+// tq_rotation_inverse); the coordinates past rot_dim stay as they are (quantization.rs:382-388)
+int32_t launch_tq_rotate_f64(hipStream_t st, double *d_buf, uint32_t n, const TqRotationHost &h) {
+    if (n == 0) return QMX_OK;
+    TqRotation r;
+    r.maps = h.d_maps; r.chunk_off = h.d_chunk_off; r.chunk_size = h.d_chunk_size; r.chunk_norm = h.d_chunk_norm;
+    r.n_chunks = h.n_chunks; r.rot_dim = h.rot_dim; r.padded_dim = h.padded_dim; r.dim = h.padded_dim;
+    const size_t lds = (size_t)2 * h.rot_dim * sizeof(double);
+    QMX_REQUIRE(lds <= 150 * 1024, QMX_ERR_NOT_SUPPORTED, "TurboQuant rotation over %u coordinates does not fit the LDS", h.rot_dim);
+    static thread_local DeviceOnce attr_once;
+    if (attr_once.need()) {
+        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tq_rotate_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_once.mark();
+    }
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(tq_rotate_kernel<double>, dim3(n), dim3(256), lds, st, (const double *)d_buf, (uint64_t)h.padded_dim, n, r, d_buf);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }
@@ -266,7 +287,8 @@ __global__ __launch_bounds__(64) void tq_quantize_kernel(const double *rot, uint
     if (!live) return;
     const bool degenerate = distance == QMX_DISTANCE_COSINE && s_deg < 1e-12;
     const float centroid_norm = degenerate ? sqrtf((float)padded_dim) : (float)sqrt(sq);
-    const float scaling_factor = (has_l2 ? l2_length : 1.0f) / centroid_norm;
+    // pack_extras_into (encoding.rs:218-247): l2 / centroid norm; DistanceType::L1 stores the bare l2 length
+    const float scaling_factor = distance == QMX_DISTANCE_MANHATTAN ? l2_length : (has_l2 ? l2_length : 1.0f) / centroid_norm;
     memcpy(row + code_bytes, &scaling_factor, 4);
     if (distance == QMX_DISTANCE_EUCLID) memcpy(row + code_bytes + 4, &l2_length, 4);
     if (shift) memcpy(row + code_bytes + (distance == QMX_DISTANCE_EUCLID ? 8 : 4), &xm_f, 4);

@@ -941,6 +941,8 @@ _sig("qo_tq_query_free", None, [_P])
 _sig("qo_tq_query_export", None, [_P, _P, _P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int64)])
 _sig("qo_tq_score_precomputed", _f, [_P, _P, _P])
 _sig("qo_tq_score_symmetric", _f, [_P, _P, _P])
+_sig("qo_tq_dequantize", None, [_P, _P, _P])
+_sig("qo_tq_rotate_inverse", None, [_P, _P])
 
 
 class TqOracle:
@@ -999,6 +1001,19 @@ class TqOracle:
                 out[i, j] = -s if self.invert else s
             _lib.qo_tq_query_free(e)
         return out
+
+    def dequantize(self, row, rotate_back=True):
+        """TurboQuantizer::dequantize::<f64> (+ apply_inverse_rotation): [padded_dim] f64"""
+        out = np.zeros(self.padded_dim, dtype=np.float64)
+        _lib.qo_tq_dequantize(self.h, _p(np.ascontiguousarray(row, dtype=np.uint8)), _p(out))
+        if rotate_back:
+            _lib.qo_tq_rotate_inverse(self.h, _p(out))
+        return out
+
+    def rotate_inverse(self, x):
+        buf = np.array(x, dtype=np.float64)
+        _lib.qo_tq_rotate_inverse(self.h, _p(buf))
+        return buf
 
     def score_internal(self, a, b):
         out = np.empty(len(a), dtype=np.float32)

@@ -19,7 +19,7 @@ def qa():
 
 
 def _dist(qa, d):
-    return {O.COSINE: qa.Distance.Cosine, O.DOT: qa.Distance.Dot, O.EUCLID: qa.Distance.Euclid}[d]
+    return {O.COSINE: qa.Distance.Cosine, O.DOT: qa.Distance.Dot, O.EUCLID: qa.Distance.Euclid, O.MANHATTAN: qa.Distance.Manhattan}[d]
 
 
 def _bits(a):
@@ -140,10 +140,6 @@ def test_tq_unpadded_rotation_and_hnsw_walk(qa):
 
 
 def test_tq_argument_errors(qa):
-    quant = qa.TurboQuantizer(64, qa.Distance.Manhattan, O.TQ_BITS4)
-    with pytest.raises(qa.QmxError) as e:
-        qa.EncodedVectorsTQ(np.zeros((4, quant.quantized_vector_size()), dtype=np.uint8), quant)
-    assert e.value.status == qa._ffi.ERR_NOT_SUPPORTED                                       # L1 scoring is not built
     big = qa.TurboQuantizer(100000, qa.Distance.Dot, O.TQ_BITS4)
     with pytest.raises(qa.QmxError):                                                          # the rotation runs in LDS: padded dim <= 8192
         qa.EncodedVectorsTQ(np.zeros((2, big.quantized_vector_size()), dtype=np.uint8), big)
@@ -152,7 +148,6 @@ def test_tq_argument_errors(qa):
     F = qa._ffi
     buf = np.zeros(64, dtype=np.float32)
     p = qa.TurboQuantizer(64, qa.Distance.Dot, O.TQ_BITS4).params()
-    assert F.lib().qmx_tq_fit_plus(0, int(qa.Distance.Manhattan), 64, C.byref(p), F.ptr(buf), 1, F.ptr(buf), F.ptr(buf)) == F.ERR_NOT_SUPPORTED
     assert F.lib().qmx_tq_fit_plus(0, int(qa.Distance.Dot), 64, None, F.ptr(buf), 1, F.ptr(buf), F.ptr(buf)) == F.ERR_BAD_ARG
     assert F.lib().qmx_tq_fit_plus(0, int(qa.Distance.Dot), 64, C.byref(p), None, 1, F.ptr(buf), F.ptr(buf)) == F.ERR_BAD_ARG
     assert F.lib().qmx_tq_fit_plus(99, int(qa.Distance.Dot), 64, C.byref(p), F.ptr(buf), 1, F.ptr(buf), F.ptr(buf)) != F.OK
@@ -244,3 +239,74 @@ def test_tq_large_top_many_queries_and_id_lists(qa, bits):
         sc = full[qi][ids].copy()
         sc[deleted[ids]] = -np.inf
         assert np.array_equal(_bits(r["score"]), _bits(np.sort(sc)[::-1][:25]))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Distance::Manhattan (DistanceType::L1): no integer kernel in the reference - score_precomputed dequantises the row, rotates it back and sums
+# |q - v| (turboquant/quantization.rs:596-607), score_symmetric does it with the difference of two rows (:429-440); tq_l1.hip
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("bits,plus,unpadded,dim", [(O.TQ_BITS4, False, False, 96), (O.TQ_BITS4, False, False, 768), (O.TQ_BITS2, False, True, 100),
+                                                     (O.TQ_BITS1, False, False, 65), (O.TQ_BITS1_5, False, False, 64), (O.TQ_BITS4, True, False, 128),
+                                                     (O.TQ_BITS2, True, False, 70)])
+def test_tq_manhattan_scores_bit_exact(qa, bits, plus, unpadded, dim):
+    n, nq = 500, 11
+    rng = np.random.default_rng(dim * 7 + bits)
+    vecs = rng.uniform(-1.0, 1.0, (n, dim)).astype(np.float32)          # ManhattanMetric::preprocess is the identity
+    vecs[5] = 0.0
+    shift = scale = None
+    if plus:
+        shift, scale = O.tq_plus_fit(O.MANHATTAN, dim, bits, vecs)
+    otq = O.TqOracle(O.MANHATTAN, dim, bits, rotation_unpadded=unpadded, shift=shift, scale=scale)
+    rows = otq.encode_rows(vecs)
+    quant = qa.TurboQuantizer(dim, qa.Distance.Manhattan, bits, rotation_unpadded=unpadded, shift=shift, scale=scale)
+    assert quant.quantized_vector_size() == otq.row_bytes and quant.invert and otq.invert
+    assert np.array_equal(quant.encode(vecs), rows)                      # quantize: the scaling factor of L1 rows is the bare l2 length
+    st = qa.EncodedVectorsTQ(rows, quant)
+    queries = rng.uniform(-1.0, 1.0, (nq, dim)).astype(np.float32)
+    queries[3] = 0.0
+    scorer = qa.new_raw_scorer(queries, st)
+    ids = rng.permutation(n).astype(np.uint32)[:200]
+    want = otq.score_points(queries, ids)
+    assert np.array_equal(_bits(scorer.score_points(ids)), _bits(want))
+    assert (want <= 0).all()                                             # `invert`: the negated distance
+    rag = scorer.score_points_ragged([ids[:9], ids[9:40], ids[40:41], ids[:0], ids[41:60]] + [ids[:1]] * (nq - 5))
+    assert np.array_equal(_bits(rag[1]), _bits(want[1, 9:40])) and np.array_equal(_bits(rag[4]), _bits(want[4, 41:60]))
+    a, b = ids[:64], ids[64:128]
+    assert np.array_equal(_bits(scorer.score_internal(a, b)), _bits(otq.score_internal(a, b)))
+    # brute force with deleted points: BatchFilteredSearcher over the L1 scorer
+    deleted = rng.random(n) < 0.2
+    st.set_deleted(deleted)
+    res = qa.BatchFilteredSearcher(queries, st, 10).peek_top_all()
+    full = otq.score_points(queries, np.arange(n))
+    for qi, r in enumerate(res):
+        sc = full[qi].copy()
+        sc[deleted] = -np.inf
+        assert not deleted[r["idx"]].any()
+        assert np.array_equal(_bits(r["score"]), _bits(np.sort(sc)[::-1][:10]))
+        assert np.array_equal(_bits(full[qi][r["idx"]]), _bits(r["score"]))
+    # the walk through this scorer is the one thing not built
+    graph = qa.GraphLayers.from_plain(O.Hnsw(O.DenseStorage(O.F32, O.MANHATTAN, vecs), m=8, ef_construct=32).export_plain())
+    with pytest.raises(qa.QmxError) as e:
+        graph.search(5, 32, scorer)
+    assert e.value.status == qa._ffi.ERR_NOT_SUPPORTED
+
+
+def test_tq_manhattan_oversampled_search_with_rescoring(qa):
+    """qmx_search_quantized over a TQ-L1 storage: the quantized stage ranks by the dequantised L1, the rescoring gives the exact Manhattan scores"""
+    n, dim = 20000, 128
+    rng = np.random.default_rng(77)
+    vecs = rng.uniform(-1.0, 1.0, (n, dim)).astype(np.float32)
+    quant = qa.TurboQuantizer(dim, qa.Distance.Manhattan, O.TQ_BITS4)
+    st = qa.EncodedVectorsTQ(quant.encode(vecs), quant)
+    vs = qa.VectorStorage(vecs, qa.Distance.Manhattan)
+    queries = rng.uniform(-1.0, 1.0, (8, dim)).astype(np.float32)
+    exact = O.DenseStorage(O.F32, O.MANHATTAN, vecs).peek_top(queries, 10)
+    got = qa.search_quantized(qa.new_raw_scorer(queries, st), qa.new_raw_scorer(queries, vs), top=10, oversampling=3.0, rescore=True)
+    hits = 0
+    for g, e in zip(got, exact):
+        hits += len(set(g["idx"].tolist()) & set(e["idx"].tolist()))
+        pos = {int(i): k for k, i in enumerate(e["idx"])}
+        for i, s_ in zip(g["idx"], g["score"]):
+            if int(i) in pos:
+                assert np.float32(s_).view(np.uint32) == e["score"][pos[int(i)]].view(np.uint32)
+    assert hits >= 0.85 * 80

@@ -284,3 +284,45 @@ def test_quantile_interval_per_coordinate_property(quantile):
         col = data[:, d].astype(np.float64)
         assert abs(O.p2_quantile(lo_want, col) - lo_want) < 0.05
         assert abs(O.p2_quantile(1.0 - lo_want, col) - (1.0 - lo_want)) < 0.05
+
+
+# error_l1 (lib/quantization/tests/integration/test_tq.rs:59-77): per-bits coefficient x sqrt(dim)
+L1_COEF = {O.TQ_BITS1: 7.5, O.TQ_BITS1_5: 4.5, O.TQ_BITS2: 3.0, O.TQ_BITS4: 0.7}
+
+
+@pytest.mark.parametrize("plus", [False, True])
+@pytest.mark.parametrize("bits", BITS)
+def test_l1_scores_within_the_reference_error_model(bits, plus):
+    """test_tq_l1 / test_tq_l1_internal (test_tq.rs:871-1010), TQMode::Normal and Plus: 513 vectors of U[-1, 1]^d, one query; the dequantise + inverse rotation
+    fallback (turboquant/quantization.rs:429-440,596-607) within error_l1 of the true L1 distance.  What pins qo_tq_dequantize / qo_tq_rotate_inverse:
+    the same bars as the reference's own tests - tolerances, no literals (parity of the L1 path at the bit level: unpinned, as for the rest of TurboQuant)."""
+    for dim in DIMS:
+        if dim < MIN_DIM[bits]:
+            continue
+        n = 513 if dim <= 256 else 129
+        vecs, q = _data(dim, n, seed=42 + dim)
+        shift = scale = None
+        if plus:
+            shift, scale = O.tq_plus_fit(O.MANHATTAN, dim, bits, vecs)
+        t = O.TqOracle(O.MANHATTAN, dim, bits, invert=False, shift=shift, scale=scale)
+        t.encode_rows(vecs)
+        err = L1_COEF[bits] * dim ** 0.5
+        got = t.score_points(q[None, :], np.arange(n))[0]
+        assert np.abs(got - np.abs(vecs - q).sum(axis=1)).max() < err
+        gi = t.score_internal(np.zeros(n - 1, dtype=int), np.arange(1, n))
+        assert np.abs(gi - np.abs(vecs[1:] - vecs[0]).sum(axis=1)).max() < err
+
+
+def test_inverse_rotation_undoes_the_rotation():
+    """HadamardRotation::apply_inverse(apply(x)) == x (rotation.rs test_rotation_roundtrip: 1e-9), padded and unpadded, chunked dims included"""
+    rng = np.random.default_rng(3)
+    for dim, unpadded in ((64, False), (100, True), (700, False), (768, False), (1000, True)):
+        t = O.TqOracle(O.MANHATTAN, dim, O.TQ_BITS4, rotation_unpadded=unpadded)
+        x = rng.standard_normal(dim)
+        y = t.rotate(x)
+        assert np.abs(t.rotate_inverse(y)[:dim] - x).max() < 1e-9
+        # the padding tail of an unpadded rotation is not touched
+        if unpadded and t.padded_dim > dim:
+            y2 = y.copy()
+            y2[dim:] = 5.0
+            assert (t.rotate_inverse(y2)[dim:] == 5.0).all()
