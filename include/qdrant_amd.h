@@ -520,7 +520,7 @@ QMX_API int32_t qmx_multi_search_topk(qmx_query *inner, const uint32_t *query_fi
  * by the BASE scorer - the full vector stored in front of the node's links, i.e. the rows of the original segment `base` was made over -
  * into a second `SearchContext(ef)`; its best `top` are the result: rescoring fused into the walk.  On the device the link and base vectors
  * are read from the two segments in HBM (the same bytes the file carries inline); the walk kernel lists the popped candidates and the pair
- * kernel scores them (exact bits of the base scorer).  ef <= 512, top <= 65536; a search that pops more than 32 max(ef, top) + 256 candidates
+ * kernel scores them (exact bits of the base scorer).  max(top, ef) <= 4096; a search that pops more than 32 max(ef, top) + 256 candidates
  * => QMX_ERR_NOT_SUPPORTED.  counters->vectors_scored = link vectors + base vectors scored. */
 QMX_API int32_t qmx_hnsw_search_with_vectors(const qmx_hnsw *g, qmx_query *links, qmx_query *base, uint32_t top, uint32_t ef,
                                              qmx_scored_point *out, uint32_t *out_counts, const volatile uint8_t *is_stopped,
@@ -703,7 +703,8 @@ QMX_API int32_t qmx_hnsw_create_from_file(const void *bytes, uint64_t n_bytes, c
  * (`search_entry`, :247-317), the ef-bounded beam on level 0 (`search_on_level`, :108-149) and
  * `into_iter_sorted().take(top)`.  `q` may belong to a dense, SQ or PQ segment (the quantized
  * scorer of `is_quantized_search`); rescoring with the original vectors is a separate
- * qmx_rescore call, as in hnsw/read_view/search.rs.  ef is raised to `top` (:549); ef <= 512.
+ * qmx_rescore call, as in hnsw/read_view/search.rs.  ef is raised to `top` (:549); max(top, ef) <= 4096
+ * (up to 512 the beam lives in registers, beyond it in LDS).
  *   out : [nq][top], out_counts : [nq].  Results equal the reference's whenever the scores met
  *   on the walk are distinct (ties are BinaryHeap-order dependent in the reference).
  *   counters->vectors_scored = points scored over all searches (HardwareCounter cpu). */

@@ -2533,8 +2533,8 @@ static int32_t hnsw_build_impl(const qmx_segment *seg, const qmx_segment *origin
     QMX_REQUIRE(seg->dtype == QMX_DTYPE_SQ_U8 || seg->dtype == QMX_DTYPE_PQ || seg->fast_layout(), QMX_ERR_NOT_SUPPORTED,
                 "adopted device block is not 16-byte aligned");
     QMX_REQUIRE(bp->m >= 1 && bp->m0 >= bp->m && bp->m0 <= 64, QMX_ERR_BAD_ARG, "need 1 <= m <= m0 <= 64");
-    QMX_REQUIRE(bp->ef_construct >= 1 && bp->ef_construct <= HNSW_MAX_EF, QMX_ERR_NOT_SUPPORTED, "ef_construct %u not in 1..%u",
-                bp->ef_construct, HNSW_MAX_EF);
+    QMX_REQUIRE(bp->ef_construct >= 1 && bp->ef_construct <= HNSW_MAX_EF_REG, QMX_ERR_NOT_SUPPORTED, "ef_construct %u not in 1..%u",
+                bp->ef_construct, HNSW_MAX_EF_REG);
     QMX_REQUIRE(seg->n <= 0xFFFFFFFFull, QMX_ERR_BAD_ARG, "too many rows");
     QMX_HIP(hipSetDevice(seg->device));
     const uint32_t n = mb ? mb->n_points : (uint32_t)seg->n, m = bp->m, m0 = bp->m0;
@@ -2917,6 +2917,12 @@ static int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint3
             QMX_REQUIRE(cw->lds_bytes <= HNSW_LDS_QUERY_MAX, QMX_ERR_NOT_SUPPORTED, "a custom query of %u bytes of example tokens does not fit the LDS", cw->lds_bytes);
             h.lds_query_bytes = cw->lds_bytes;
         }
+    }
+    if (std::max(top, ef) > HNSW_MAX_EF_REG && !mw && !cw) {   // a list this long lives in LDS behind the query entry, which is then always staged (a PQ LUT too)
+        const size_t beam = ((size_t)std::max(top, ef) * 9 + 15) / 16 * 16;
+        QMX_REQUIRE((size_t)q->q_stride + beam + 2048 <= 160 * 1024, QMX_ERR_NOT_SUPPORTED,
+                    "hnsw max(top, ef) = %u: the query entry (%u bytes) and the list do not fit the LDS together", std::max(top, ef), q->q_stride);
+        h.lds_query_bytes = q->q_stride;
     }
     h.log_cap = HNSW_LOG_CAP;
     {   // tests: force the whole-bitmap clear path

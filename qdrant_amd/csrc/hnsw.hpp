@@ -249,6 +249,65 @@ struct Beam {
     }
 };
 
+// The same list for ef > 512, kept in LDS (the walk kernel appends `cap` keys + `cap` flag bytes to its dynamic LDS): the same interface, every
+// operation wave-cooperative.  insert: the position by a two-level search (64 block ends, then the block), then the tail moves up one entry, 64
+// at a time from the end; pop_best scans from a hint below which every entry is expanded.  Slower per operation than the register beam, and meant
+// to be: searches this wide are rare.
+template <>
+struct Beam<0> {
+    uint64_t *key;
+    unsigned char *done;
+    uint32_t len, hint;
+    __device__ __forceinline__ void init(unsigned char *lds, uint32_t cap) {
+        key = reinterpret_cast<uint64_t *>(lds);
+        done = lds + 8 * (size_t)cap;
+    }
+    __device__ __forceinline__ void clear() { len = 0; hint = 0; }
+    __device__ __forceinline__ uint64_t at(uint32_t idx) const { return idx < len ? key[idx] : 0ull; }        // idx uniform
+    __device__ __forceinline__ bool done_at(uint32_t idx) const { return idx < len && done[idx] != 0; }
+    __device__ __forceinline__ void insert(uint64_t nk, uint32_t cap, int lane) {
+        // p = number of keys above nk (descending, distinct keys)
+        uint32_t p = 0;
+        if (len) {
+            const uint32_t stride = (len + 63) / 64;                       // <= 64 while cap <= 4096
+            const uint32_t last = (uint32_t)lane * stride + stride - 1;     // the end of the lane's block
+            const bool whole = last < len && key[last] > nk;                // the block lies above nk as a whole
+            const uint32_t b = (uint32_t)__popcll(__ballot(whole));         // (monotone: the first b blocks)
+            const uint32_t i = b * stride + (uint32_t)lane;
+            const bool above = (uint32_t)lane < stride && i < len && key[i] > nk;
+            p = b * stride + (uint32_t)__popcll(__ballot(above));
+        }
+        const uint32_t new_len = len < cap ? len + 1 : cap;
+        if (p >= new_len) return;                                           // (below a full list: the callers test against at(cap - 1) first)
+        for (uint32_t hi = new_len - 1; hi > p;) {                          // entries [p, new_len - 1) move up by one, the last of a full list drops out
+            const uint32_t lo = hi - p > 64 ? hi - 63 : p + 1;
+            const uint32_t i = lo + (uint32_t)lane;
+            uint64_t k = 0;
+            unsigned char d = 0;
+            if (i <= hi) { k = key[i - 1]; d = done[i - 1]; }
+            if (i <= hi) { key[i] = k; done[i] = d; }
+            hi = lo - 1;
+        }
+        if (lane == 0) { key[p] = nk; done[p] = 0; }
+        len = new_len;
+        if (p < hint) hint = p;
+    }
+    __device__ __forceinline__ uint64_t pop_best(int lane) {
+        for (uint32_t base = hint; base < len; base += 64) {
+            const uint32_t i = base + (uint32_t)lane;
+            const uint64_t m = __ballot(i < len && done[i] == 0);
+            if (m) {
+                const uint32_t at = base + (uint32_t)__builtin_ctzll(m);
+                if (i == at) done[i] = 1;
+                hint = at + 1;
+                return key[at];
+            }
+        }
+        hint = len;
+        return 0ull;
+    }
+};
+
 __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -306,7 +365,7 @@ __device__ __forceinline__ void hop_score(const ScanArgs &a, const unsigned char
 template <class H, int E>
 __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArgs &h, const unsigned char *qp,
                                                 uint32_t *hop_ids, float *hop_scores, uint32_t *vis, uint32_t *vlog,
-                                                uint32_t qi, int lane) {
+                                                uint32_t qi, int lane, unsigned char *beam_lds = nullptr) {
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     uint32_t n_scored = 0;
 
@@ -394,6 +453,10 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
     // ---- search_on_level(level 0, ef) ----
     const uint32_t ef = h.ef > h.top ? h.ef : h.top;
     Beam<E> beam;
+    if constexpr (E == 0) {
+        __syncthreads();                    // (the previous search of this block is done with the LDS list)
+        beam.init(beam_lds, ef);
+    }
     beam.clear();
     uint32_t log_cnt = 0;
     {
@@ -607,8 +670,22 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
     // ---- nearest.into_iter_sorted().take(top) ----
     {
         uint32_t count = 0;
+        if constexpr (E == 0) {
+            for (uint32_t base = 0; base < h.top; base += 64) {
+                const uint32_t idx = base + (uint32_t)lane;
+                const uint64_t k = idx < h.top ? beam.at(idx) : 0ull;
+                const bool ok = k != 0;
+                if (ok) {
+                    qmx_scored_point p;
+                    p.idx = key_idx(k);
+                    p.score = key_score(k);
+                    h.out[(uint64_t)qi * h.top + idx] = p;
+                }
+                count += (uint32_t)__popcll(__ballot(ok));
+            }
+        } else {
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
+        for (int e = 0; e < (E ? E : 1); ++e) {
             const uint32_t idx = (uint32_t)e * 64 + (uint32_t)lane;
             const bool ok = beam.key[e] != 0 && idx < h.top;
             if (ok) {
@@ -618,6 +695,7 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
                 h.out[(uint64_t)qi * h.top + idx] = p;
             }
             count += (uint32_t)__popcll(__ballot(ok));
+        }
         }
         if (lane == 0) {
             h.out_counts[qi] = count;
@@ -643,6 +721,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const ScanArgs a, const
     uint32_t *hop_ids = reinterpret_cast<uint32_t *>(smem);
     float *hop_scores = reinterpret_cast<float *>(smem + 4 * (size_t)h.hop_cap);
     unsigned char *q_lds = smem + 8 * (size_t)h.hop_cap + (h.acorn ? 256 : 0);
+    unsigned char *beam_lds = q_lds + (QLDS ? ((size_t)h.lds_query_bytes + 15) / 16 * 16 : 0);      // E == 0: the LDS beam behind the query entry
     uint32_t *vis = h.visited + (uint64_t)blockIdx.x * h.vis_words;
     uint32_t *vlog = h.vis_log + (uint64_t)blockIdx.x * h.log_cap;
     for (uint32_t qi = blockIdx.x; qi < h.nq; qi += gridDim.x) {
@@ -656,7 +735,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const ScanArgs a, const
             for (uint32_t i = (uint32_t)lane; i < n_tokens * (a.q_stride / 16); i += 64) dst[i] = src[i];
             if (lane == 0) *reinterpret_cast<uint32_t *>(q_lds) = n_tokens;
             __syncthreads();
-            hnsw_search_one<H, E>(a, h, q_lds + 16, hop_ids, hop_scores, vis, vlog, qi, lane);
+            hnsw_search_one<H, E>(a, h, q_lds + 16, hop_ids, hop_scores, vis, vlog, qi, lane, beam_lds);
             continue;
         }
         if constexpr (is_custom<H>::value) {
@@ -688,7 +767,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const ScanArgs a, const
                     hd->ex_off = tab;
                 }
                 __syncthreads();
-                hnsw_search_one<H, E>(a, h, q_lds + sizeof(CustomHeader), hop_ids, hop_scores, vis, vlog, qi, lane);
+                hnsw_search_one<H, E>(a, h, q_lds + sizeof(CustomHeader), hop_ids, hop_scores, vis, vlog, qi, lane, beam_lds);
                 continue;
             }
             const bool fits = sizeof(CustomHeader) + (uint64_t)ne * a.q_stride <= h.lds_query_bytes;
@@ -705,7 +784,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const ScanArgs a, const
                 hd->ex_off = nullptr;
             }
             __syncthreads();
-            hnsw_search_one<H, E>(a, h, q_lds + sizeof(CustomHeader), hop_ids, hop_scores, vis, vlog, qi, lane);
+            hnsw_search_one<H, E>(a, h, q_lds + sizeof(CustomHeader), hop_ids, hop_scores, vis, vlog, qi, lane, beam_lds);
             continue;
         }
         const unsigned char *qg = reinterpret_cast<const unsigned char *>(a.queries) + (uint64_t)qi * a.q_stride;
@@ -715,12 +794,15 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const ScanArgs a, const
             uint4 *dst = reinterpret_cast<uint4 *>(q_lds);
             for (uint32_t i = (uint32_t)lane; i < h.lds_query_bytes / 16; i += 64) dst[i] = src[i];
             __syncthreads();
-            hnsw_search_one<H, E>(a, h, q_lds, hop_ids, hop_scores, vis, vlog, qi, lane);
+            hnsw_search_one<H, E>(a, h, q_lds, hop_ids, hop_scores, vis, vlog, qi, lane, beam_lds);
         } else {
-            hnsw_search_one<H, E>(a, h, qg, hop_ids, hop_scores, vis, vlog, qi, lane);
+            hnsw_search_one<H, E>(a, h, qg, hop_ids, hop_scores, vis, vlog, qi, lane, beam_lds);
         }
     }
 }
+
+// bytes of the LDS beam of a walk with max(top, ef) = ef > HNSW_MAX_EF_REG: keys + expanded flags
+static inline size_t hnsw_beam_lds(uint32_t ef) { return ((size_t)ef * 9 + 15) / 16 * 16; }
 
 // occupancy of an instantiation (blocks of one wave per CU) — used by the API to size the scratch
 template <class H, int E, bool QLDS>
@@ -731,7 +813,7 @@ int32_t hnsw_occupancy_inst(uint32_t lds_query_bytes, size_t hop_lds, int *per_c
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_once.mark();
     }
-    const size_t lds = hop_lds + (QLDS ? lds_query_bytes : 0);
+    const size_t lds = hop_lds + (QLDS ? ((size_t)lds_query_bytes + 15) / 16 * 16 : 0);     // (hop_lds carries the LDS beam of an E == 0 instantiation)
     int n = 0;
     QMX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kfn, 64, lds));
     *per_cu = n < 1 ? 1 : n;
@@ -740,7 +822,9 @@ int32_t hnsw_occupancy_inst(uint32_t lds_query_bytes, size_t hop_lds, int *per_c
 
 template <class H, int E, bool QLDS>
 int32_t launch_hnsw_inst(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid) {
-    const size_t lds = 8 * (size_t)h.hop_cap + (h.acorn ? 256 : 0) + (QLDS ? h.lds_query_bytes : 0);
+    const uint32_t ef = h.ef > h.top ? h.ef : h.top;
+    const size_t lds = 8 * (size_t)h.hop_cap + (h.acorn ? 256 : 0) + (QLDS ? ((size_t)h.lds_query_bytes + 15) / 16 * 16 : 0) + (E == 0 ? hnsw_beam_lds(ef) : 0);
+    QMX_REQUIRE(lds <= 160 * 1024, QMX_ERR_NOT_SUPPORTED, "hnsw walk: %zu bytes of LDS (query entry + a list of %u)", lds, ef);
     ::qmx::clear_stale_error();
     QMX_NOTE_KERNEL((hnsw_search_kernel<H, E, QLDS>));
     hipLaunchKernelGGL((hnsw_search_kernel<H, E, QLDS>), dim3(grid), dim3(64), lds, st, a, h);
@@ -756,6 +840,11 @@ int32_t launch_hnsw_hop(hipStream_t st, const ScanArgs &a, const HnswArgs &h, ui
     const bool qlds = h.lds_query_bytes > 0;
     if constexpr (is_maxsim<H>::value) QMX_REQUIRE(qlds, QMX_ERR_NOT_SUPPORTED, "the inner vectors of a multi-query must fit the LDS");
     if constexpr (is_custom<H>::value) QMX_REQUIRE(h.lds_query_bytes >= sizeof(CustomHeader), QMX_ERR_OTHER, "the custom walk keeps its header in LDS");
+    if (ef > HNSW_MAX_EF_REG) {        // the LDS beam: one instantiation per policy, the query entry staged
+        QMX_REQUIRE(qlds, QMX_ERR_NOT_SUPPORTED, "hnsw ef %u > %u needs the query entry in LDS (it does not fit)", ef, HNSW_MAX_EF_REG);
+        if (grid == 0) return hnsw_occupancy_inst<H, 0, true>(h.lds_query_bytes, 8 * (size_t)h.hop_cap + (h.acorn ? 256 : 0) + hnsw_beam_lds(ef), per_cu);
+        return launch_hnsw_inst<H, 0, true>(st, a, h, grid);
+    }
     if constexpr (is_custom<H>::value || is_maxsim<H>::value) {      // (always staged: no instantiation that reads the entry from global memory)
         if (grid == 0) {
             const size_t hop_lds = 8 * (size_t)h.hop_cap + (h.acorn ? 256 : 0);

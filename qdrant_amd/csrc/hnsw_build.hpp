@@ -358,8 +358,8 @@ __global__ __launch_bounds__(64) void hnsw_build_link_kernel(const ScanArgs a, c
 // H: the scorer of the insertion searches; HI: the stored <-> stored scorer (phase 2 and the heuristic), H itself unless given
 template <class H, class HI = H>
 int32_t launch_hnsw_build_hop(hipStream_t st, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu) {
-    QMX_REQUIRE(h.ef_construct >= 1 && h.ef_construct <= HNSW_MAX_EF, QMX_ERR_NOT_SUPPORTED, "ef_construct %u not in 1..%u", h.ef_construct,
-                HNSW_MAX_EF);
+    QMX_REQUIRE(h.ef_construct >= 1 && h.ef_construct <= HNSW_MAX_EF_REG, QMX_ERR_NOT_SUPPORTED, "ef_construct %u not in 1..%u", h.ef_construct,
+                HNSW_MAX_EF_REG);
     const bool big = h.ef_construct > 128;
     const size_t lds1 = 512 + 512 * (big ? 8 : 2) + 512 + h.lds_query_bytes;
     if (phase == 1) {

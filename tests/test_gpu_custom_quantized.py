@@ -111,7 +111,7 @@ def test_custom_walk_equals_the_oracle_walk(qa, kind):
     graph = qa.GraphLayers.from_plain(g.export_plain())
     queries = _queries(qa, rng, dim, centers)
     scorer = qa.CustomRawScorer(queries, st)
-    for top, ef in ((10, 64), (5, 16), (10, 200)):
+    for top, ef in ((10, 64), (5, 16), (10, 200), (10, 700)):          # (700: the LDS beam, hnsw.hpp Beam<0>)
         got, scored = scorer.search_hnsw(graph, top, ef, with_scored=True)
         total, ties = 0, False
         for qi, q in enumerate(queries):

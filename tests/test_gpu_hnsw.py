@@ -234,6 +234,50 @@ def test_f16_u8_search_recall(qa, dtype):
         assert len(r) == 10 and np.all(np.diff(r["score"]) <= 0)
 
 
+@pytest.mark.parametrize("kind", ["f32", "sq", "acorn"])
+def test_wide_searches_use_the_lds_beam_and_stay_the_reference_walk(qa, kind):
+    """max(top, ef) > 512: the list of the walk lives in LDS (hnsw.hpp Beam<0>) - the same walk, decision for decision: ids, score bits and the number
+    of scored points equal the oracle's at ef 600 / 1000 / 2500 and top up to 700, through the f32 and SQ scorers and the ACORN expansion (custom queries,
+    multi-vectors, the other quantized scorers: a wide case in their own walk tests)."""
+    n, dim, m, nq = 6000, 48, 8, 12
+    rows, st, g, plain = _graph(O.DOT, n, dim, m, 0x5EED0390)
+    queries = O.synth(0x5EED0391, 0, nq, dim)
+    vs = qa.VectorStorage(rows, qa.Distance.Dot)
+    graph = qa.GraphLayers.from_plain(plain)
+    cases = [(10, 600), (100, 1000), (700, 700), (10, 2500), (513, 16)]
+    if kind == "f32":
+        scorer = qa.new_raw_scorer(queries, vs)
+        for top, ef in cases:
+            want, stats = g.search_dense(st, queries, top, ef, with_stats=True)
+            got, scored = graph.search(top, ef, scorer, with_scored=True)
+            _same(got, want)
+            assert scored == sum(stats)
+        assert "hnsw_search_kernel" in qa._ffi.last_kernel(scorer._h)
+    elif kind == "sq":
+        quant = qa.ScalarQuantizer.from_min_max(rows, dim, qa.Distance.Dot)
+        osq = O.SqOracle(O.DOT, dim, quant.alpha, quant.offset)
+        osq.encode_rows(rows)
+        scorer = qa.new_raw_scorer(queries, qa.EncodedVectorsU8(quant.encode(rows), quant))
+        for top, ef in cases[:3]:
+            want = g.search_sq(st, osq, queries, top, ef)
+            _same_modulo_ties(graph.search(top, ef, scorer), want)
+    elif kind == "acorn":
+        rng = np.random.default_rng(5)
+        allowed = rng.random(n) < 0.3
+        scorer = qa.new_raw_scorer(queries, vs)
+        scorer.set_filter(allowed)
+        ost = O.DenseStorage(O.F32, O.DOT, rows, point_deleted=~allowed)
+        g.algorithm = 1
+        try:
+            for top, ef in cases[:3]:
+                want, stats = g.search_dense(ost, queries, top, ef, with_stats=True)
+                got, scored = graph.search(top, ef, scorer, with_scored=True, acorn=True)
+                _same(got, want)
+                assert scored == sum(stats)
+        finally:
+            g.algorithm = 0
+
+
 def test_tiny_graphs_and_argument_errors(qa):
     dim = 32
     rows = O.preprocess(O.COSINE, O.synth(1, 0, 3, dim))
@@ -244,8 +288,9 @@ def test_tiny_graphs_and_argument_errors(qa):
     queries = O.synth(2, 0, 5, dim)
     scorer = qa.new_raw_scorer(queries, vs)
     _same(graph.search(10, 4, scorer), g.search_dense(st, queries, 10, 4))     # fewer points than top
+    _same(graph.search(10, 1000, scorer), g.search_dense(st, queries, 10, 1000))   # ef beyond the register beam: the LDS list
     with pytest.raises(qa.QmxError) as e:
-        graph.search(10, 1000, scorer)                                          # ef beyond the register beam
+        graph.search(10, 5000, scorer)                                          # ... which ends at 4096
     assert e.value.status == qa._ffi.ERR_NOT_SUPPORTED
     with pytest.raises(qa.QmxError) as e:
         graph.search(0, 10, scorer)

@@ -155,7 +155,7 @@ def test_multivector_hnsw_walk_equals_the_oracle(qa, kind, distance, dim):
     plain = graph_o.export_plain()
     graph = qa.GraphLayers.from_plain(plain)
     qpre = [O.preprocess(distance, q) for q in queries]
-    for top, ef in ((5, 16), (10, 64), (3, 200)):
+    for top, ef in ((5, 16), (10, 64), (3, 200), (10, 600)):
         want, want_scored = orc.search(graph_o, qpre, top, ef)
         got, ctr = dev.search_hnsw(graph, queries, top, ef, with_counters=True)
         if kind == "bq":
@@ -267,8 +267,8 @@ def test_multivector_build_argument_errors(qa):
 def test_multivector_hnsw_argument_errors(qa):
     rng, offsets, dev, orc, queries = _multi_world(qa, "dense", O.DOT, 64, 200, seed=3)
     graph = qa.GraphLayers.from_plain(orc.build(m=4, ef_construct=16).export_plain())
-    with pytest.raises(qa.QmxError):                 # ef beyond the register beam
-        dev.search_hnsw(graph, queries, 5, 4096)
+    with pytest.raises(qa.QmxError):                 # ef beyond the LDS beam
+        dev.search_hnsw(graph, queries, 5, 5000)
     big = [rng.standard_normal((700, 64)).astype(np.float32)]     # 700 x (256 + 64) bytes > 150 KiB of LDS
     with pytest.raises(qa.QmxError):
         dev.search_hnsw(graph, big, 5, 16)
