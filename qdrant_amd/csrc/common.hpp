@@ -42,6 +42,7 @@ enum Option {
     OPT_NO_PQ_PREFILTER,      // PQ top-k scans of 4+ queries keep the exact one-LUT-per-block kernel (no 6-bit prefilter + verification)
     OPT_PQ_PREFILTER_MIN_QUERIES,   // ... from this many queries on (default 4)
     OPT_HNSW_PQ_PER_CU,       // PQ walk with the LUT read through L2: at most this many concurrent searches per CU (0 = what fits)
+    OPT_TQ_ROTATE_BLOCK,      // TurboQuant rotation by the one-block-per-vector kernel (not one wave per vector)
     OPT_DEBUG,                // log dropped stale HIP errors
     OPT_COUNT
 };

@@ -127,23 +127,116 @@ __global__ __launch_bounds__(256) void tq_rotate_kernel(const T *in, uint64_t in
     double *o = out + (uint64_t)v * r.padded_dim;
     for (uint32_t i = threadIdx.x; i < r.padded_dim; i += blockDim.x) o[i] = i < r.rot_dim ? s[i] : (i < r.dim ? (double)src[i] : 0.0);
 }
+// The same rotation with ONE VECTOR PER WAVE, for rotations of a multiple of E coordinates (E = 16 / 32 / 64 per lane, up to 64 E in all): element i
+// lives in lane i / E, register i % E.  Every power-of-two chunk then covers whole lanes, aligned: butterfly stages of stride < E run inside the lane,
+// stages of stride h >= E pair lane l with l ^ (h / E) (a lane joins while its chunk is longer than h) - the same adds and subtracts per element in the
+// same ascending-stride order, then the chunk's norm: the same bits as the block kernel above, without its 40-odd block barriers per vector.  The
+// permutation between two transforms goes through a per-wave LDS image of the vector.
+template <class T, int E>
+__global__ __launch_bounds__(64) void tq_rotate_wave_kernel(const T *in, uint64_t in_stride, uint32_t n, TqRotation r, double *out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_tqw[];
+    double *buf = reinterpret_cast<double *>(smem_tqw);
+    const int lane = threadIdx.x;
+    const uint32_t v = blockIdx.x;
+    if (v >= n) return;
+    const T *src = in + (uint64_t)v * in_stride;
+    const uint32_t first = (uint32_t)lane * E;                 // this lane's first coordinate
+    const bool act = first < r.rot_dim;
+    uint32_t my_size = 0;
+    double my_norm = 1.0;
+    for (uint32_t c = 0; c < r.n_chunks; ++c) {
+        const uint32_t off = r.chunk_off[c], size = r.chunk_size[c];
+        if (act && first >= off && first < off + size) { my_size = size; my_norm = r.chunk_norm[c]; }
+    }
+    double x[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) x[k] = (act && first + k < r.dim) ? (double)src[first + k] : 0.0;
+    auto wht = [&]() {
+#pragma unroll
+        for (int h = 1; h < E; h *= 2) {
+#pragma unroll
+            for (int j = 0; j < E; ++j)
+                if ((j & h) == 0) {
+                    const double a = x[j], b = x[j + h];
+                    x[j] = a + b;
+                    x[j + h] = a - b;
+                }
+        }
+        for (uint32_t hl = 1; hl < 64; hl *= 2) {
+            const bool on = my_size > hl * E;
+            if (!__ballot(on)) break;                          // (chunk sizes only shrink along the vector: nobody joins a later stage either)
+            const bool upper = ((uint32_t)lane & hl) != 0;
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                const double p = __shfl_xor(x[k], (int)hl, 64);
+                const double lo = upper ? p : x[k], hi = upper ? x[k] : p;      // the pair (x[j], x[j + h]) as the reference names it
+                if (on) x[k] = upper ? lo - hi : lo + hi;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < E; ++k) x[k] = x[k] * my_norm;
+    };
+    wht();
+    for (int p = 0; p < 3; ++p) {
+        const uint32_t *map = r.maps + (size_t)p * r.rot_dim;
+        __syncthreads();
+        if (act) {
+#pragma unroll
+            for (int k = 0; k < E; ++k) buf[first + k] = x[k];
+        }
+        __syncthreads();
+        if (act) {
+#pragma unroll
+            for (int k4 = 0; k4 < E; k4 += 4) {
+                const uint4 m4 = *reinterpret_cast<const uint4 *>(map + first + k4);
+                x[k4] = buf[m4.x]; x[k4 + 1] = buf[m4.y]; x[k4 + 2] = buf[m4.z]; x[k4 + 3] = buf[m4.w];
+            }
+        }
+        wht();
+    }
+    double *o = out + (uint64_t)v * r.padded_dim;
+    // (in place - the inverse rotation - too: the wave read its whole vector before this point, and a coordinate past the rotation is read and written
+    // by the same lane)
+    if (act) {
+#pragma unroll
+        for (int k = 0; k < E; ++k) o[first + k] = x[k];
+    }
+    for (uint32_t i = r.rot_dim + (uint32_t)lane; i < r.padded_dim; i += 64) o[i] = i < r.dim ? (double)src[i] : 0.0;
+}
+template <class T>
+static int32_t launch_tq_rotate_any(hipStream_t st, const T *d_in, uint64_t in_stride, uint32_t n, const TqRotation &r, double *d_out) {
+    const uint32_t rd = r.rot_dim;
+    int e = 0;
+    if (!option(OPT_TQ_ROTATE_BLOCK) && rd >= 64) {
+        if (rd % 16 == 0 && rd <= 1024) e = 16;
+        else if (rd % 32 == 0 && rd <= 2048) e = 32;
+        else if (rd % 64 == 0 && rd <= 4096) e = 64;
+    }
+    ::qmx::clear_stale_error();
+    const size_t lds_w = (size_t)rd * sizeof(double);
+    if (e == 16) hipLaunchKernelGGL((tq_rotate_wave_kernel<T, 16>), dim3(n), dim3(64), lds_w, st, d_in, in_stride, n, r, d_out);
+    else if (e == 32) hipLaunchKernelGGL((tq_rotate_wave_kernel<T, 32>), dim3(n), dim3(64), lds_w, st, d_in, in_stride, n, r, d_out);
+    else if (e == 64) hipLaunchKernelGGL((tq_rotate_wave_kernel<T, 64>), dim3(n), dim3(64), lds_w, st, d_in, in_stride, n, r, d_out);
+    else {
+        const size_t lds = (size_t)2 * rd * sizeof(double);
+        QMX_REQUIRE(lds <= 150 * 1024, QMX_ERR_NOT_SUPPORTED, "TurboQuant rotation over %u coordinates does not fit the LDS", rd);
+        static thread_local DeviceOnce attr_once;
+        if (attr_once.need()) {
+            QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tq_rotate_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tq_rotate_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            attr_once.mark();
+        }
+        hipLaunchKernelGGL(tq_rotate_kernel<T>, dim3(n), dim3(256), lds, st, d_in, in_stride, n, r, d_out);
+    }
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
 int32_t launch_tq_rotate(hipStream_t st, const float *d_in, uint32_t n, const TqRotationHost &h, double *d_out) {
     if (n == 0) return QMX_OK;
     TqRotation r;
     r.maps = h.d_maps; r.chunk_off = h.d_chunk_off; r.chunk_size = h.d_chunk_size; r.chunk_norm = h.d_chunk_norm;
     r.n_chunks = h.n_chunks; r.rot_dim = h.rot_dim; r.padded_dim = h.padded_dim; r.dim = h.dim;
-    const size_t lds = (size_t)2 * h.rot_dim * sizeof(double);
-    QMX_REQUIRE(lds <= 150 * 1024, QMX_ERR_NOT_SUPPORTED, "TurboQuant rotation over %u coordinates does not fit the LDS", h.rot_dim);
-    static thread_local DeviceOnce attr_once;
-    if (attr_once.need()) {
-        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tq_rotate_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tq_rotate_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_once.mark();
-    }
-    ::qmx::clear_stale_error();
-    hipLaunchKernelGGL(tq_rotate_kernel<float>, dim3(n), dim3(256), lds, st, d_in, (uint64_t)h.dim, n, r, d_out);
-    QMX_HIP(hipGetLastError());
-    return QMX_OK;
+    return launch_tq_rotate_any<float>(st, d_in, (uint64_t)h.dim, n, r, d_out);
 }
 // HadamardRotation::apply_inverse on [n][padded_dim] f64 vectors in place: `h` carries the backward maps, last permutation first (api.hip
 // tq_rotation_inverse); the coordinates past rot_dim stay as they are (quantization.rs:382-388)
@@ -152,17 +245,7 @@ int32_t launch_tq_rotate_f64(hipStream_t st, double *d_buf, uint32_t n, const Tq
     TqRotation r;
     r.maps = h.d_maps; r.chunk_off = h.d_chunk_off; r.chunk_size = h.d_chunk_size; r.chunk_norm = h.d_chunk_norm;
     r.n_chunks = h.n_chunks; r.rot_dim = h.rot_dim; r.padded_dim = h.padded_dim; r.dim = h.padded_dim;
-    const size_t lds = (size_t)2 * h.rot_dim * sizeof(double);
-    QMX_REQUIRE(lds <= 150 * 1024, QMX_ERR_NOT_SUPPORTED, "TurboQuant rotation over %u coordinates does not fit the LDS", h.rot_dim);
-    static thread_local DeviceOnce attr_once;
-    if (attr_once.need()) {
-        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tq_rotate_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_once.mark();
-    }
-    ::qmx::clear_stale_error();
-    hipLaunchKernelGGL(tq_rotate_kernel<double>, dim3(n), dim3(256), lds, st, (const double *)d_buf, (uint64_t)h.padded_dim, n, r, d_buf);
-    QMX_HIP(hipGetLastError());
-    return QMX_OK;
+    return launch_tq_rotate_any<double>(st, (const double *)d_buf, (uint64_t)h.padded_dim, n, r, d_buf);
 }
 
 // ---- TurboQuantizer::quantize on rotated vectors: rot [n][padded_dim] f64 -> reference rows ----

@@ -97,6 +97,24 @@ def test_tq_encode_on_device_byte_exact(qa, distance, bits):
         assert np.array_equal(quant.encode(vecs), otq.encode_rows(vecs))
 
 
+def test_tq_rotation_kernels_agree(qa):
+    """The rotation runs one vector per wave where the rotated length is a multiple of 16 (up to 1024), 32 (2048) or 64 (4096) coordinates, one block per
+    vector otherwise (option tq_rotate_block forces it): the same adds in the same order - the encoded rows of both are the oracle's bytes."""
+    for dim, bits, unpadded in ((768, O.TQ_BITS4, False), (1024, O.TQ_BITS2, False), (1536, O.TQ_BITS4, False), (3072, O.TQ_BITS1, False), (96, O.TQ_BITS4, True),
+                                (80, O.TQ_BITS4, True), (72, O.TQ_BITS4, True), (2080, O.TQ_BITS2, False)):
+        rng = np.random.default_rng(dim)
+        vecs = rng.uniform(-1.0, 1.0, (70, dim)).astype(np.float32)
+        otq = O.TqOracle(O.DOT, dim, bits, rotation_unpadded=unpadded)
+        want = otq.encode_rows(vecs)
+        quant = qa.TurboQuantizer(dim, qa.Distance.Dot, bits, rotation_unpadded=unpadded)
+        assert np.array_equal(quant.encode(vecs), want), (dim, "wave")
+        qa.set_option("tq_rotate_block", 1)
+        try:
+            assert np.array_equal(quant.encode(vecs), want), (dim, "block")
+        finally:
+            qa.set_option("tq_rotate_block", -1)
+
+
 def test_tq_oversampled_search_with_rescoring(qa):
     """the quantized stage + postprocess_search_result over a TQ storage (qmx_search_quantized): after rescoring the scores are the exact ones"""
     n, dim = 30000, 128
