@@ -43,6 +43,7 @@ enum Option {
     OPT_PQ_PREFILTER_MIN_QUERIES,   // ... from this many queries on (default 4)
     OPT_HNSW_PQ_PER_CU,       // PQ walk with the LUT read through L2: at most this many concurrent searches per CU (0 = what fits)
     OPT_TQ_ROTATE_BLOCK,      // TurboQuant rotation by the one-block-per-vector kernel (not one wave per vector)
+    OPT_NO_TOPK_SMALL,        // top-k of short score rows by the insertion kernel (not the rank-sort of the pruned row)
     OPT_DEBUG,                // log dropped stale HIP errors
     OPT_COUNT
 };

@@ -196,10 +196,109 @@ __global__ __launch_bounds__(CT_BLOCK) void custom_topk_kernel(const float *scor
     }
 }
 
+// The same selection for SHORT score rows (n <= 16 384: the sample pre-scans, filtered candidate lists) without a single serial insertion: every thread
+// keeps its <= 16 keys in registers; per pass of <= 64 results the wave-wide k-th largest of the 64 lane maxima is a lower bound of the k-th best key (k lanes
+// hold a key that large), the largest such bound over the 16 waves prunes the row to a few times k survivors in LDS, and those are ranked against each other
+// (rank = number of larger keys: keys are distinct) - rank r goes to slot r.  Same lists, same tie order (the key carries the id) as the kernel above.
+constexpr int CTS_E = 16;
+constexpr uint64_t CTS_MAX_N = (uint64_t)CT_BLOCK * CTS_E;
+__global__ __launch_bounds__(CT_BLOCK) void custom_topk_small_kernel(const float *scores, uint32_t n, const uint32_t *ids, DeletedView del, uint32_t top,
+                                                                     qmx_scored_point *out, uint32_t *out_counts, uint64_t *bound_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_cts[];
+    uint64_t *surv = reinterpret_cast<uint64_t *>(smem_cts);          // [n]
+    __shared__ uint64_t sh_t[CT_NW];
+    __shared__ uint64_t sh_bound;
+    __shared__ uint32_t sh_cnt;
+    const uint32_t q = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float *row = scores + (uint64_t)q * n;
+    uint64_t kreg[CTS_E];
+#pragma unroll
+    for (int e0 = 0; e0 < CTS_E; e0 += 4) {
+        uint32_t id[4];
+        uint64_t key[4], keep[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t c = (uint32_t)(e0 + u) * CT_BLOCK + threadIdx.x;
+            const uint32_t cc = c < n ? c : 0;
+            id[u] = ids ? ids[cc] : cc;
+            key[u] = c < n ? make_key(row[cc], id[u]) : 0ull;
+        }
+        live_masks<4>(del, id, keep);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) kreg[e0 + u] = key[u] & keep[u];
+    }
+    uint64_t bound = ~0ull;
+    uint32_t total = 0;
+    for (uint32_t off = 0; off < top; off += WAVE) {
+        const uint32_t ptop = top - off < (uint32_t)WAVE ? top - off : (uint32_t)WAVE;
+        uint64_t m = 0;
+#pragma unroll
+        for (int e = 0; e < CTS_E; ++e) {
+            const uint64_t k = kreg[e] < bound ? kreg[e] : 0ull;
+            m = k > m ? k : m;
+        }
+        uint32_t rank = 0;
+        for (int j = 0; j < WAVE; ++j) rank += readlane_u64(m, j) > m ? 1u : 0u;
+        const uint64_t sel = __ballot(rank == ptop - 1 && m != 0);
+        const uint64_t tw = sel ? readlane_u64(m, __builtin_ctzll(sel)) : 0ull;
+        if (lane == 0) sh_t[wave] = tw;
+        if (threadIdx.x == 0) { sh_cnt = 0; sh_bound = 0; }
+        __syncthreads();
+        uint64_t t = 0;
+#pragma unroll
+        for (int w = 0; w < CT_NW; ++w) t = sh_t[w] > t ? sh_t[w] : t;
+        // the survivors: every live key below the previous passes' bound and not below t (t = 0: fewer than ptop lanes of any wave hold a key - all of them)
+#pragma unroll
+        for (int e = 0; e < CTS_E; ++e) {
+            const uint64_t k = kreg[e] < bound ? kreg[e] : 0ull;
+            if (k != 0 && k >= t) surv[atomicAdd(&sh_cnt, 1u)] = k;
+        }
+        __syncthreads();
+        const uint32_t cnt = sh_cnt;
+        for (uint32_t i = threadIdx.x; i < cnt; i += CT_BLOCK) {
+            const uint64_t my = surv[i];
+            uint32_t r = 0;
+            for (uint32_t j = 0; j < cnt; ++j) r += (surv[j] > my || (surv[j] == my && j < i)) ? 1u : 0u;    // (equal keys - a candidate listed twice - keep distinct slots)
+            if (r < ptop) {
+                qmx_scored_point p;
+                p.idx = key_idx(my);
+                p.score = key_score(my);
+                out[(uint64_t)q * top + off + r] = p;
+                if (r == ptop - 1) sh_bound = my;
+            }
+        }
+        const uint32_t found = cnt < ptop ? cnt : ptop;
+        for (uint32_t i = found + threadIdx.x; i < ptop; i += CT_BLOCK) out[(uint64_t)q * top + off + i] = qmx_scored_point{0u, 0.0f};
+        total += found;
+        __syncthreads();
+        bound = sh_bound;                                   // the pass's k-th key when it is full, else 0: nothing is left
+        if (bound == 0) {
+            for (uint32_t i = off + WAVE + threadIdx.x; i < top; i += CT_BLOCK) out[(uint64_t)q * top + i] = qmx_scored_point{0u, 0.0f};
+            break;
+        }
+        __syncthreads();                                    // (sh_bound / sh_cnt are reset at the top of the next pass)
+    }
+    if (threadIdx.x == 0) {
+        out_counts[q] = total;
+        if (bound_out) bound_out[q] = total == top ? bound : 0ull;
+    }
+}
+
 int32_t launch_custom_topk(hipStream_t st, const float *d_scores, uint64_t n, const uint32_t *d_ids, const DeletedView &del, uint32_t n_queries,
                            uint32_t top, qmx_scored_point *d_out, uint32_t *d_counts, uint64_t *d_bound) {
     if (n_queries == 0) return QMX_OK;
     ::qmx::clear_stale_error();
+    if (n >= 1 && n <= CTS_MAX_N && !option(OPT_NO_TOPK_SMALL)) {
+        static thread_local DeviceOnce attr_once;
+        if (attr_once.need()) {
+            QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(custom_topk_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CTS_MAX_N * 8)));
+            attr_once.mark();
+        }
+        hipLaunchKernelGGL(custom_topk_small_kernel, dim3(n_queries), dim3(CT_BLOCK), (size_t)n * 8, st, d_scores, (uint32_t)n, d_ids, del, top, d_out, d_counts, d_bound);
+        QMX_HIP(hipGetLastError());
+        return QMX_OK;
+    }
     hipLaunchKernelGGL(custom_topk_kernel, dim3(n_queries), dim3(CT_BLOCK), 0, st, d_scores, n, d_ids, del, top, d_out, d_counts, d_bound);
     QMX_HIP(hipGetLastError());
     return QMX_OK;

@@ -116,3 +116,33 @@ def test_custom_query_argument_errors(qa):
     assert F.lib().qmx_custom_score_points(ex._h, d, 1, F.ptr(ids), 4, F.ptr(out)) == F.ERR_OUT_OF_BOUNDS
     d[0].kind, d[0].first, d[0].n_a, d[0].n_b = F.CUSTOM_DISCOVER, 0, 2, 0                        # two targets
     assert F.lib().qmx_custom_score_points(ex._h, d, 1, F.ptr(ids), 4, F.ptr(out)) == F.ERR_BAD_ARG
+
+
+@pytest.mark.parametrize("n,top", [(700, 10), (8192, 10), (9765, 64), (16384, 100), (16385, 10), (5000, 700), (300, 1), (40, 64)])
+def test_topk_of_short_score_rows_both_kernels(qa, n, top):
+    """launch_custom_topk: rows of up to 16 384 scores are pruned by a bound from the lane maxima and rank-sorted (custom_topk_small_kernel), longer ones and
+    option no_topk_small = 1 go through the insertion kernel: the same lists - descending score, ties by ascending id, deleted points skipped - as numpy's."""
+    dim = 16
+    rng = np.random.default_rng(n + top)
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    rows[n // 3] = rows[n // 5]                                   # equal scores: ordered by id
+    vs = qa.VectorStorage(rows, qa.Distance.Dot)
+    deleted = rng.random(n) < 0.3
+    vs.set_deleted(deleted, None)
+    queries = [qa.CustomQuery.recommend_sum_scores([rng.standard_normal(dim).astype(np.float32)], []) for _ in range(5)]
+    scorer = qa.CustomRawScorer(queries, vs)
+    sc = scorer.score_points(np.arange(n, dtype=np.uint32))
+    lists = []
+    for flag in (0, 1):
+        qa.set_option("no_topk_small", flag)
+        try:
+            lists.append(scorer.peek_top(top))
+        finally:
+            qa.set_option("no_topk_small", -1)
+    ids = np.arange(n)
+    for qi in range(len(queries)):
+        live = ~deleted
+        order = np.lexsort((ids[live], -sc[qi][live].astype(np.float64)))[:top]
+        for res in lists:
+            assert res[qi]["idx"].tolist() == ids[live][order].tolist()
+            assert np.array_equal(res[qi]["score"].view(np.uint32), sc[qi][live][order].view(np.uint32))
