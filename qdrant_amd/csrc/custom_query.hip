@@ -213,20 +213,26 @@ __global__ __launch_bounds__(CT_BLOCK) void custom_topk_small_kernel(const float
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float *row = scores + (uint64_t)q * n;
     uint64_t kreg[CTS_E];
+    // two round trips per 8 192 scores: the ids and scores of eight keys per thread go out together, then their deleted / filter words
 #pragma unroll
-    for (int e0 = 0; e0 < CTS_E; e0 += 4) {
-        uint32_t id[4];
-        uint64_t key[4], keep[4];
+    for (int e0 = 0; e0 < CTS_E; e0 += 8) {
+        if ((uint32_t)e0 * CT_BLOCK >= n) {                 // (uniform: a row of up to 8 192 scores has no second half)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) kreg[e0 + u] = 0ull;
+            continue;
+        }
+        uint32_t id[8];
+        uint64_t key[8], keep[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
             const uint32_t c = (uint32_t)(e0 + u) * CT_BLOCK + threadIdx.x;
             const uint32_t cc = c < n ? c : 0;
             id[u] = ids ? ids[cc] : cc;
             key[u] = c < n ? make_key(row[cc], id[u]) : 0ull;
         }
-        live_masks<4>(del, id, keep);
+        live_masks<8>(del, id, keep);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) kreg[e0 + u] = key[u] & keep[u];
+        for (int u = 0; u < 8; ++u) kreg[e0 + u] = key[u] & keep[u];
     }
     uint64_t bound = ~0ull;
     uint32_t total = 0;

@@ -440,7 +440,7 @@ constexpr int PAIR_BLOCK = 256;
 // valid in every lane of the group.  `qp` = the query's tile entry (elements, zero padding, aux) in
 // LDS or in global memory.  Shared by pair_kernel and the HNSW hop scorer, so both produce the
 // bits of the scan.
-template <class P>
+template <class P, int UNROLL = 4>      // UNROLL row pieces (and their query pieces) in flight per lane
 __device__ __forceinline__ float group_score(const ScanArgs &a, const unsigned char *qp, uint32_t id, int t) {
     constexpr int NRA = P::NRAUX > 0 ? P::NRAUX : 1;
     const int piece = lane_piece(t);
@@ -454,7 +454,7 @@ __device__ __forceinline__ float group_score(const ScanArgs &a, const unsigned c
     for (int k = 0; k < P::NACC; ++k) acc[0][0][k] = 0;
 #pragma unroll
     for (int k = 0; k < NRA; ++k) raux[0][k] = 0;
-#pragma unroll 4
+#pragma unroll UNROLL
     for (uint32_t s = 0; s < a.nseg; ++s) {
         uint4 v[1];
         v[0] = *reinterpret_cast<const uint4 *>(rp + (uint64_t)s * 128);
@@ -532,7 +532,8 @@ __global__ __launch_bounds__(PAIR_BLOCK) void pair_kernel(const ScanArgs a, cons
         }
         // (a slot's dead tail - per-query lists are sized for the worst case, counts[] says how much is live - costs nothing: a wave whose eight items are all dead moves on)
         if (!__ballot(valid)) continue;
-        const float score = group_score<P>(a, queries + (uint64_t)qi * a.q_stride, id, t);
+        // (a pair is one gathered row: the kernel is a chain of round trips, so twelve row pieces per lane are requested at once)
+        const float score = group_score<P, 12>(a, queries + (uint64_t)qi * a.q_stride, id, t);
         if (valid && t == 0) a.scores[item] = score;
     }
 }

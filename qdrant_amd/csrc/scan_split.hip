@@ -919,16 +919,62 @@ __device__ __forceinline__ void block_kth_key(const uint64_t *c, uint32_t raw, i
     __syncthreads();
 }
 
+// The same for lists of up to 8 keys per thread (the usual ~1 000 candidates of a query) without serial insertions, as custom_topk_small_kernel does it:
+// the k-th largest of a wave's 64 lane maxima bounds the k-th best key from below, the largest such bound over the waves prunes the list to a few
+// times k survivors in LDS, and the survivor with k - 1 larger ones is the answer (keys are distinct: they carry the row id).
+constexpr int SEL_E = 8;
+constexpr int SEL_SURV = SEL_BLOCK * SEL_E;
+struct SelScratch {
+    uint64_t surv[SEL_SURV];
+    uint64_t t[SEL_BLOCK / WAVE];
+    uint32_t cnt;
+};
+__device__ __forceinline__ void block_kth_key_ranked(const uint64_t *c, uint32_t raw, uint32_t ptop, SelScratch *sc, uint64_t *sh_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t kreg[SEL_E];
+    uint64_t m = 0;
+#pragma unroll
+    for (int e = 0; e < SEL_E; ++e) {
+        const uint32_t i = (uint32_t)e * SEL_BLOCK + threadIdx.x;
+        kreg[e] = i < raw ? c[i] : 0ull;
+        m = kreg[e] > m ? kreg[e] : m;
+    }
+    uint32_t rank = 0;
+    for (int j = 0; j < WAVE; ++j) rank += readlane_u64(m, j) > m ? 1u : 0u;
+    const uint64_t sel = __ballot(rank == ptop - 1 && m != 0);
+    const uint64_t tw = sel ? readlane_u64(m, __builtin_ctzll(sel)) : 0ull;
+    if (lane == 0) sc->t[wave] = tw;
+    if (threadIdx.x == 0) { sc->cnt = 0; *sh_out = 0; }
+    __syncthreads();
+    uint64_t t = 0;
+#pragma unroll
+    for (int w = 0; w < SEL_BLOCK / WAVE; ++w) t = sc->t[w] > t ? sc->t[w] : t;
+#pragma unroll
+    for (int e = 0; e < SEL_E; ++e)
+        if (kreg[e] != 0 && kreg[e] >= t) sc->surv[atomicAdd(&sc->cnt, 1u)] = kreg[e];
+    __syncthreads();
+    const uint32_t cnt = sc->cnt;
+    for (uint32_t i = threadIdx.x; i < cnt; i += SEL_BLOCK) {
+        const uint64_t my = sc->surv[i];
+        uint32_t r = 0;
+        for (uint32_t j = 0; j < cnt; ++j) r += (sc->surv[j] > my || (sc->surv[j] == my && j < i)) ? 1u : 0u;
+        if (r == ptop - 1) *sh_out = my;
+    }
+    __syncthreads();
+}
+
 // After the strided sixteenth of the block: the k-th best APPROXIMATE score A among its rows proves k rows with an exact score >= A - band,
 // so a result row has an approximate score >= A - 2 band: the threshold of the other fifteen sixteenths (never lowered).
 __global__ __launch_bounds__(SEL_BLOCK) void sp_refine_kernel(const uint64_t *cand, const uint32_t *cand_cnt, uint32_t cap, const float *band, uint32_t top,
                                                               const float *scales, float *thr) {
     __shared__ uint64_t sh[SEL_BLOCK / WAVE][WAVE];
     __shared__ uint64_t sh_kth;
+    __shared__ SelScratch scratch;
     const uint32_t q = blockIdx.x;
     const uint32_t raw = cand_cnt[q];
     if (raw > cap || raw < top || !(band[q] < 3.0e38f)) return;   // overflow is sp_select_kernel's to report; fewer than k rows prove nothing
-    block_kth_key(cand + (uint64_t)q * cap, raw, (int)top, sh, &sh_kth);
+    if (raw <= (uint32_t)SEL_SURV) block_kth_key_ranked(cand + (uint64_t)q * cap, raw, top, &scratch, &sh_kth);
+    else block_kth_key(cand + (uint64_t)q * cap, raw, (int)top, sh, &sh_kth);
     if (threadIdx.x == 0 && sh_kth) {
         const float t = (key_score(sh_kth) - 2.0f * band[q]) * scales[1];
         if (t > thr[q]) thr[q] = t;
@@ -942,6 +988,7 @@ __global__ __launch_bounds__(SEL_BLOCK) void sp_select_kernel(const uint64_t *ca
     __shared__ uint64_t sh_kth;
     __shared__ float sh_cut;
     __shared__ uint32_t sh_n;
+    __shared__ SelScratch scratch;
     const uint32_t q = blockIdx.x;
     const uint32_t raw = cand_cnt[q];
     // a wave list of the scan overflowed (its dropped entries could be anybody's), or this query's candidate buffer did: the pass cannot be
@@ -952,7 +999,8 @@ __global__ __launch_bounds__(SEL_BLOCK) void sp_select_kernel(const uint64_t *ca
     }
     const uint64_t *c = cand + (uint64_t)q * cap;
     if (threadIdx.x == 0) sh_n = 0;
-    block_kth_key(c, raw, (int)top, sh, &sh_kth);
+    if (raw <= (uint32_t)SEL_SURV) block_kth_key_ranked(c, raw, top, &scratch, &sh_kth);
+    else block_kth_key(c, raw, (int)top, sh, &sh_kth);
     // fewer than k candidates: keep all of them (cut = -inf)
     if (threadIdx.x == 0) sh_cut = sh_kth ? key_score(sh_kth) - 2.0f * band[q] : -__builtin_inff();
     __syncthreads();
