@@ -717,7 +717,7 @@ QMX_API int32_t qmx_hnsw_search(const qmx_hnsw *g, qmx_query *q, uint32_t top, u
 /* The same with `SearchAlgorithm::Acorn` (graph_layers.rs:154-243, 550-559; chosen by hnsw/read_view/search.rs:42-90 when the
  * request enables it and the filter is selective enough): on level 0 a link that fails `check_vector` (deleted flags + the
  * payload filter set with qmx_query_set_filter) is not scored but explored - its own links are offered as 2-hop neighbours -
- * with the reference's two visited lists and per-node limits.  m0 <= 64. */
+ * with the reference's two visited lists and per-node limits.  m0 <= 128. */
 QMX_API int32_t qmx_hnsw_search_acorn(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
                                       qmx_scored_point *out, uint32_t *out_counts,
                                       const volatile uint8_t *is_stopped, qmx_counters *counters);
@@ -732,7 +732,7 @@ QMX_API int32_t qmx_hnsw_search_async(const qmx_hnsw *g, qmx_query *q, uint32_t 
 /* `HnswConfig` subset used by `GraphLayersBuilder` (graph_layers_builder.rs:230-262). */
 typedef struct qmx_hnsw_build_params {
     uint32_t m;                 /* links per point on levels > 0                                  */
-    uint32_t m0;                /* links per point on level 0 (the reference uses 2 m); <= 64     */
+    uint32_t m0;                /* links per point on level 0 (the reference uses 2 m); <= 128    */
     uint32_t ef_construct;      /* beam width of the insertion searches; <= 512                   */
     uint32_t entry_points_num;  /* extra entry points kept (highest levels), reference default 10 */
     uint64_t seed;              /* level draw: level(i) = round(-ln U(seed, i) / ln max(m, 2))    */

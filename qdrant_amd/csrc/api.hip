@@ -2532,7 +2532,7 @@ static int32_t hnsw_build_impl(const qmx_segment *seg, const qmx_segment *origin
     }
     QMX_REQUIRE(seg->dtype == QMX_DTYPE_SQ_U8 || seg->dtype == QMX_DTYPE_PQ || seg->fast_layout(), QMX_ERR_NOT_SUPPORTED,
                 "adopted device block is not 16-byte aligned");
-    QMX_REQUIRE(bp->m >= 1 && bp->m0 >= bp->m && bp->m0 <= 64, QMX_ERR_BAD_ARG, "need 1 <= m <= m0 <= 64");
+    QMX_REQUIRE(bp->m >= 1 && bp->m0 >= bp->m && bp->m0 <= HNSW_BUILD_MAX_M0, QMX_ERR_BAD_ARG, "need 1 <= m <= m0 <= %u", HNSW_BUILD_MAX_M0);
     QMX_REQUIRE(bp->ef_construct >= 1 && bp->ef_construct <= HNSW_MAX_EF_REG, QMX_ERR_NOT_SUPPORTED, "ef_construct %u not in 1..%u",
                 bp->ef_construct, HNSW_MAX_EF_REG);
     QMX_REQUIRE(seg->n <= 0xFFFFFFFFull, QMX_ERR_BAD_ARG, "too many rows");
@@ -2934,9 +2934,9 @@ static int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint3
     h.acorn = acorn ? 1 : 0;
     h.hop_cap = 64;
     if (acorn) {   // two visited lists; every explored node may add m0 points to one scoring batch
-        QMX_REQUIRE(g->m0 >= 1 && g->m0 <= 64, QMX_ERR_NOT_SUPPORTED, "ACORN walk: m0 = %u not in 1..64", g->m0);
+        QMX_REQUIRE(g->m0 >= 1 && g->m0 <= 128, QMX_ERR_NOT_SUPPORTED, "ACORN walk: m0 = %u not in 1..128", g->m0);
         h.vis_words *= 2;
-        h.hop_cap = (g->m0 * (g->m0 + 1) + 63) / 64 * 64;
+        h.hop_cap = std::min<uint32_t>((g->m0 * (g->m0 + 1) + 63) / 64 * 64, 4160);    // (m0 > 64: the kernel scores what it holds before the buffer could overflow)
     }
     int per_cu = 1;
     QMX_TRY(launch_hnsw(q, a, h, 0, &per_cu));

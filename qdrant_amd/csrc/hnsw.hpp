@@ -35,6 +35,9 @@
 
 namespace qmx {
 
+// bytes of the ACORN walk's list of nodes to explore (one per link of the popped candidate: m0 ids, 64 at least)
+__host__ __device__ static inline uint32_t hnsw_acorn_lds(uint32_t acorn, uint32_t m0) { return acorn ? 4u * (((m0 < 64u ? 64u : m0) + 63u) / 64u * 64u) : 0u; }
+
 // ---- hop scorers: LPI lanes score one stored row; the score is valid in the lane with sub == 0 ----
 // a policy whose query offset comes from ScanArgs::sq_qoff instead of the query entry's aux block (a stored SQ row as the query)
 template <class P, class = void>
@@ -490,11 +493,32 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
             if (mine && log_cnt + r < h.log_cap) vlog[log_cnt + r] = word;
             log_cnt += (uint32_t)__popcll(m);
         };
+        uint32_t n_score = 0;
+        // the points collected so far are scored and offered to the beam, in order: once per popped candidate - or earlier, when the next explored node's
+        // links might not fit the hop buffer (m0 > 64: up to m0 (m0 + 1) points per candidate; process_candidate touches the beam only, so scoring a
+        // prefix early changes nothing)
+        auto flush_scores = [&]() {
+            hop_score<H>(a, qp, hop_ids, hop_scores, n_score, lane);
+            for (uint32_t base = 0; base < n_score; base += 64) {
+                const uint32_t j = base + (uint32_t)lane;
+                const uint64_t mykey = j < n_score ? make_key(hop_scores[j], hop_ids[j]) : 0;
+                uint64_t mm = __ballot(mykey > beam.at(ef - 1));
+                while (mm) {
+                    const int src = __builtin_ctzll(mm);
+                    mm &= mm - 1;
+                    const uint64_t nk = readlane_u64(mykey, src);
+                    if (nk > beam.at(ef - 1)) beam.insert(nk, ef, lane);
+                }
+            }
+            n_scored += n_score;
+            n_score = 0;
+            __syncthreads();
+        };
         while (true) {
             const uint64_t ck = beam.pop_best(lane);
             if (ck == 0) break;
             const uint32_t cand = key_idx(ck);
-            uint32_t n_score = 0, n_explore = 0;
+            uint32_t n_explore = 0;
             __syncthreads();
             {   // 1-hop neighbours (:196-211): every unvisited link is marked; passing ones are scored (at most hop_limit), the others explored
                 uint64_t o0, o1;
@@ -541,6 +565,7 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
             };
             if (n_explore) fetch_links(to_explore[0]);
             for (uint32_t e = 0; e < n_explore; ++e) {
+                if (n_score + hop_limit > h.hop_cap) flush_scores();
                 const uint32_t node = to_explore[e];
                 const uint64_t cnt = nx_o1;
                 uint32_t id0 = nx_id;
@@ -580,19 +605,7 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
                 n_score += added;
             }
             // score_points_unfiltered + process_candidate, in order (:237-239)
-            hop_score<H>(a, qp, hop_ids, hop_scores, n_score, lane);
-            for (uint32_t base = 0; base < n_score; base += 64) {
-                const uint32_t j = base + (uint32_t)lane;
-                const uint64_t mykey = j < n_score ? make_key(hop_scores[j], hop_ids[j]) : 0;
-                uint64_t mm = __ballot(mykey > beam.at(ef - 1));
-                while (mm) {
-                    const int src = __builtin_ctzll(mm);
-                    mm &= mm - 1;
-                    const uint64_t nk = readlane_u64(mykey, src);
-                    if (nk > beam.at(ef - 1)) beam.insert(nk, ef, lane);
-                }
-            }
-            n_scored += n_score;
+            flush_scores();
         }
     } else {
     // search_on_level_with_vectors: `candidates` also holds what `nearest` evicted before it was expanded; when every entry of the beam is
@@ -720,7 +733,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const ScanArgs a, const
     // [hop ids: hop_cap u32][hop scores: hop_cap f32][ACORN: 64 ids to explore][query entry]
     uint32_t *hop_ids = reinterpret_cast<uint32_t *>(smem);
     float *hop_scores = reinterpret_cast<float *>(smem + 4 * (size_t)h.hop_cap);
-    unsigned char *q_lds = smem + 8 * (size_t)h.hop_cap + (h.acorn ? 256 : 0);
+    unsigned char *q_lds = smem + 8 * (size_t)h.hop_cap + hnsw_acorn_lds(h.acorn, h.m0);
     unsigned char *beam_lds = q_lds + (QLDS ? ((size_t)h.lds_query_bytes + 15) / 16 * 16 : 0);      // E == 0: the LDS beam behind the query entry
     uint32_t *vis = h.visited + (uint64_t)blockIdx.x * h.vis_words;
     uint32_t *vlog = h.vis_log + (uint64_t)blockIdx.x * h.log_cap;
@@ -823,7 +836,7 @@ int32_t hnsw_occupancy_inst(uint32_t lds_query_bytes, size_t hop_lds, int *per_c
 template <class H, int E, bool QLDS>
 int32_t launch_hnsw_inst(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid) {
     const uint32_t ef = h.ef > h.top ? h.ef : h.top;
-    const size_t lds = 8 * (size_t)h.hop_cap + (h.acorn ? 256 : 0) + (QLDS ? ((size_t)h.lds_query_bytes + 15) / 16 * 16 : 0) + (E == 0 ? hnsw_beam_lds(ef) : 0);
+    const size_t lds = 8 * (size_t)h.hop_cap + hnsw_acorn_lds(h.acorn, h.m0) + (QLDS ? ((size_t)h.lds_query_bytes + 15) / 16 * 16 : 0) + (E == 0 ? hnsw_beam_lds(ef) : 0);
     QMX_REQUIRE(lds <= 160 * 1024, QMX_ERR_NOT_SUPPORTED, "hnsw walk: %zu bytes of LDS (query entry + a list of %u)", lds, ef);
     ::qmx::clear_stale_error();
     QMX_NOTE_KERNEL((hnsw_search_kernel<H, E, QLDS>));
@@ -842,18 +855,18 @@ int32_t launch_hnsw_hop(hipStream_t st, const ScanArgs &a, const HnswArgs &h, ui
     if constexpr (is_custom<H>::value) QMX_REQUIRE(h.lds_query_bytes >= sizeof(CustomHeader), QMX_ERR_OTHER, "the custom walk keeps its header in LDS");
     if (ef > HNSW_MAX_EF_REG) {        // the LDS beam: one instantiation per policy, the query entry staged
         QMX_REQUIRE(qlds, QMX_ERR_NOT_SUPPORTED, "hnsw ef %u > %u needs the query entry in LDS (it does not fit)", ef, HNSW_MAX_EF_REG);
-        if (grid == 0) return hnsw_occupancy_inst<H, 0, true>(h.lds_query_bytes, 8 * (size_t)h.hop_cap + (h.acorn ? 256 : 0) + hnsw_beam_lds(ef), per_cu);
+        if (grid == 0) return hnsw_occupancy_inst<H, 0, true>(h.lds_query_bytes, 8 * (size_t)h.hop_cap + hnsw_acorn_lds(h.acorn, h.m0) + hnsw_beam_lds(ef), per_cu);
         return launch_hnsw_inst<H, 0, true>(st, a, h, grid);
     }
     if constexpr (is_custom<H>::value || is_maxsim<H>::value) {      // (always staged: no instantiation that reads the entry from global memory)
         if (grid == 0) {
-            const size_t hop_lds = 8 * (size_t)h.hop_cap + (h.acorn ? 256 : 0);
+            const size_t hop_lds = 8 * (size_t)h.hop_cap + hnsw_acorn_lds(h.acorn, h.m0);
             return ef <= 128 ? hnsw_occupancy_inst<H, 2, true>(h.lds_query_bytes, hop_lds, per_cu) : hnsw_occupancy_inst<H, 8, true>(h.lds_query_bytes, hop_lds, per_cu);
         }
         return ef <= 128 ? launch_hnsw_inst<H, 2, true>(st, a, h, grid) : launch_hnsw_inst<H, 8, true>(st, a, h, grid);
     } else {
     if (grid == 0) {
-        const size_t hop_lds = 8 * (size_t)h.hop_cap + (h.acorn ? 256 : 0);
+        const size_t hop_lds = 8 * (size_t)h.hop_cap + hnsw_acorn_lds(h.acorn, h.m0);
         if (ef <= 128) return qlds ? hnsw_occupancy_inst<H, 2, true>(h.lds_query_bytes, hop_lds, per_cu) : hnsw_occupancy_inst<H, 2, false>(0, hop_lds, per_cu);
         return qlds ? hnsw_occupancy_inst<H, 8, true>(h.lds_query_bytes, hop_lds, per_cu) : hnsw_occupancy_inst<H, 8, false>(0, hop_lds, per_cu);
     }

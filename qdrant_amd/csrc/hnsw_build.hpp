@@ -96,9 +96,9 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(const ScanArgs a0
     float *hop_scores = reinterpret_cast<float *>(smem + 256);
     uint32_t *cand_ids = reinterpret_cast<uint32_t *>(smem + 512);                     // [64 E]
     float *cand_scores = reinterpret_cast<float *>(smem + 512 + 256 * E);
-    uint32_t *sel_ids = reinterpret_cast<uint32_t *>(smem + 512 + 512 * E);            // [64]
-    float *sel_scores = reinterpret_cast<float *>(smem + 512 + 512 * E + 256);
-    unsigned char *q_lds = smem + 512 + 512 * E + 512;
+    uint32_t *sel_ids = reinterpret_cast<uint32_t *>(smem + 512 + 512 * E);            // [HNSW_BUILD_MAX_M0]
+    float *sel_scores = reinterpret_cast<float *>(smem + 512 + 512 * E + 4 * HNSW_BUILD_MAX_M0);
+    unsigned char *q_lds = smem + 512 + 512 * E + 8 * HNSW_BUILD_MAX_M0;
     uint32_t *vis = h.visited + (uint64_t)blockIdx.x * h.vis_words;
     uint32_t *vlog = h.vis_log + (uint64_t)blockIdx.x * h.log_cap;
     const unsigned char *rows = reinterpret_cast<const unsigned char *>(a0.rows);
@@ -269,12 +269,12 @@ template <class H>
 __global__ __launch_bounds__(64) void hnsw_build_link_kernel(const ScanArgs a, const HnswBuildArgs h) {
     __shared__ uint32_t hop_ids[64];
     __shared__ float hop_scores[64];
-    __shared__ uint32_t cand_ids[80];
-    __shared__ float cand_scores[80];
-    __shared__ uint32_t srt_ids[80];
-    __shared__ float srt_scores[80];
-    __shared__ uint32_t sel_ids[64];
-    __shared__ float sel_scores[64];
+    __shared__ uint32_t cand_ids[HNSW_BUILD_MAX_M0 + 16];
+    __shared__ float cand_scores[HNSW_BUILD_MAX_M0 + 16];
+    __shared__ uint32_t srt_ids[HNSW_BUILD_MAX_M0 + 16];
+    __shared__ float srt_scores[HNSW_BUILD_MAX_M0 + 16];
+    __shared__ uint32_t sel_ids[HNSW_BUILD_MAX_M0];
+    __shared__ float sel_scores[HNSW_BUILD_MAX_M0];
     const int lane = threadIdx.x;
     for (uint32_t bi = blockIdx.x; bi < h.count; bi += gridDim.x) {
         const uint32_t p = h.first + bi;
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(64) void hnsw_build_link_kernel(const ScanArgs a, c
                 } else {
                     // candidates = links(q) + p with their scores to q, sorted descending (total_cmp; equal keys keep
                     // input order, the new point last), then the heuristic again
-                    const uint32_t n_c = len + 1;               // <= m0 + 1 <= 65
+                    const uint32_t n_c = len + 1;               // <= m0 + 1 <= HNSW_BUILD_MAX_M0 + 1
                     for (uint32_t base = 0; base < len; base += 64) {
                         const uint32_t kk = len - base < 64 ? len - base : 64;
                         __syncthreads();
@@ -361,7 +361,7 @@ int32_t launch_hnsw_build_hop(hipStream_t st, const ScanArgs &a, const HnswBuild
     QMX_REQUIRE(h.ef_construct >= 1 && h.ef_construct <= HNSW_MAX_EF_REG, QMX_ERR_NOT_SUPPORTED, "ef_construct %u not in 1..%u", h.ef_construct,
                 HNSW_MAX_EF_REG);
     const bool big = h.ef_construct > 128;
-    const size_t lds1 = 512 + 512 * (big ? 8 : 2) + 512 + h.lds_query_bytes;
+    const size_t lds1 = 512 + 512 * (big ? 8 : 2) + 8 * HNSW_BUILD_MAX_M0 + h.lds_query_bytes;
     if (phase == 1) {
         auto k2 = hnsw_build_search_kernel<H, HI, 2>;
         auto k8 = hnsw_build_search_kernel<H, HI, 8>;

@@ -174,6 +174,7 @@ int32_t launch_hnsw_pq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uin
 int32_t launch_hnsw_bq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_pack_level0(hipStream_t st, const uint64_t *offsets, const uint32_t *neighbors, uint32_t n_points, uint32_t stride, uint32_t *l0);
 constexpr uint32_t HNSW_MAX_EF = 4096;          // max(top, ef) of a walk: up to 512 in a register beam, beyond it in an LDS beam (hnsw.hpp Beam<0>)
+constexpr uint32_t HNSW_BUILD_MAX_M0 = 128;     // links per level-0 list of a device build (m <= m0 <= 128)
 constexpr uint32_t HNSW_MAX_EF_REG = 512;       // ... and of ef_construct (the build keeps its beam in registers)
 // HNSW build (hnsw_build.hpp)
 constexpr uint32_t HNSW_BUILD_MAX_LEVELS = 16;   // levels 0..15 (P(level >= 16) ~ m^-15.5)

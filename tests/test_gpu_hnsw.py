@@ -376,7 +376,7 @@ def test_payload_filter_bitmap_brute_force_and_walk(qa):
 
 
 @pytest.mark.parametrize("selectivity", [0.03, 0.15, 0.5, 1.0])
-@pytest.mark.parametrize("m", [8, 16, 32])                 # m0 = 64: up to 4160 ids in one scoring batch
+@pytest.mark.parametrize("m", [8, 16, 32, 48, 64])         # m0 = 64: up to 4160 ids in one scoring batch; m0 = 96 / 128: scored in several in-order batches
 def test_acorn_walk_is_the_reference_walk(qa, selectivity, m):
     """SearchAlgorithm::Acorn (search_on_level_acorn, graph_layers.rs:154-243) on device == the oracle's restatement on the same
     graph: ids, score bits and the number of scored points, for filters from 3 % to 100 % of the points (+ deleted points).

@@ -321,6 +321,37 @@ def test_one_point_per_launch_builds_the_sequential_graph(qa, distance, dim):
     _same_graph(seq, ref)
 
 
+@pytest.mark.parametrize("m,m0", [(40, 80), (64, 128), (24, 100)])
+def test_wide_link_lists_build_the_sequential_graph(qa, m, m0):
+    """m0 up to 128 (m = 64 collections): the same bar as above - one point per launch, the oracle's sequential graph link for link - and the plain walk of
+    the result equals the oracle's walk (lists of more than 63 links: the CSR arrays, 64 links per trip)."""
+    # rows whose similarities factor, sim(i, j) = s_i s_j with s ascending in insertion order: the heuristic drops a candidate only for a kept link with
+    # a larger s than the TARGET's, and the point being inserted always has the largest s so far - its lists fill to the brim (natural data rarely gets
+    # past ~60 links under the heuristic); distinct s keep the scores distinct
+    n, efc, seed = 400, 200, 5
+    dim = n + 1
+    w = np.linspace(0.5, 2.0, n) + np.random.default_rng(seed).uniform(0, 1e-3, n)
+    rows = np.zeros((n, dim), dtype=np.float32)
+    rows[np.arange(n), np.arange(n)] = 1.0
+    rows[:, n] = w
+    rows = O.preprocess(O.COSINE, rows)
+    st = O.DenseStorage(O.F32, O.COSINE, rows)
+    vs = qa.VectorStorage(rows, qa.Distance.Cosine)
+    g = qa.GraphLayers.build(vs, m=m, m0=m0, ef_construct=efc, seed=seed, max_batch=1)
+    ref = O.Hnsw(st, m=m, m0=m0, ef_construct=efc, seed=seed)
+    seq = g.export_plain()
+    _same_graph(seq, ref.export_plain())
+    assert np.diff(seq.offsets[:n + 1].astype(np.int64)).max() > 64          # the case is what it says
+    queries = O.synth(77, 0, 10, dim)
+    scorer = qa.new_raw_scorer(queries, vs)
+    want = ref.search_dense(st, queries, 10, 64)
+    got = g.search(10, 64, scorer)
+    for a, b in zip(got, want):
+        assert a["idx"].tolist() == b["idx"].tolist() and np.array_equal(a["score"].view(np.uint32), b["score"].view(np.uint32))
+    with pytest.raises(qa.QmxError):
+        qa.GraphLayers.build(vs, m=64, m0=129, ef_construct=efc, seed=seed)
+
+
 def _same_graph(seq, ref):
     assert np.array_equal(seq.reindex, ref.reindex) and np.array_equal(seq.offsets, ref.offsets)
     assert np.array_equal(seq.neighbors, ref.neighbors)
