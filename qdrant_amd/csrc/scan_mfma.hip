@@ -333,12 +333,15 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_f32_mfma_kernel(const ScanAr
         // instead of one per tile: the sample pre-scans of a 128-query batch are four latency-bound passes over ~10 k rows, which
         // stay in L2 between the passes)
         constexpr uint32_t QT = QW * QSPLIT;
-        for (uint32_t g0 = 0; g0 < a0.nq; g0 += QT) {
+        // (gridDim.y > 1: the launcher found room for every query tile's blocks at once - a short candidate list against many queries - and each
+        // block scores ONE tile: the passes run side by side instead of one after the other)
+        const uint32_t g_first = gridDim.y > 1 ? blockIdx.y * QT : 0u, g_end = gridDim.y > 1 ? g_first + 1u : a0.nq;
+        for (uint32_t g0 = g_first; g0 < g_end && g0 < a0.nq; g0 += QT) {
             ScanArgs a = a0;
             a.queries = reinterpret_cast<const unsigned char *>(a0.queries) + (size_t)g0 * a0.q_stride;
             a.scores = a0.scores + (uint64_t)g0 * a0.scores_stride;
             a.nq = a0.nq - g0 < QT ? a0.nq - g0 : QT;
-            if (g0) __syncthreads();        // every wave is done with the previous tile's entries
+            if (g0 != g_first) __syncthreads();        // every wave is done with the previous tile's entries
             scan_f32_mfma_body<QW, QSPLIT, D, NT, NWAVES, FAST, QH, HAS_IDS, MODE>(a, smem);
         }
     } else {
@@ -376,9 +379,14 @@ static int32_t launch_mfma_inst(hipStream_t st, const ScanArgs &a, int num_cus, 
         if (*grid_out && MODE == SCAN_TOPK && grid > *grid_out) grid = *grid_out;
         *grid_out = grid;
     }
+    uint32_t grid_y = 1;
+    if (MODE == SCAN_SCORES && a.nq > (uint32_t)QT) {
+        const uint32_t groups = (a.nq + QT - 1) / QT;
+        if ((uint64_t)grid * groups <= cap) grid_y = groups;
+    }
     ::qmx::clear_stale_error();
     QMX_NOTE_KERNEL(kfn);
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(MF_BLOCK), lds, st, a);
+    hipLaunchKernelGGL(kfn, dim3(grid, grid_y), dim3(MF_BLOCK), lds, st, a);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }
