@@ -183,7 +183,8 @@ typedef struct qmx_bq_params {
  * as the reference does, with P-square quantile estimators over sampled vectors, encoded_vectors_tq.rs:156-240).  Distances Dot, Cosine, Euclid - and Manhattan
  * (DistanceType::L1: the reference has no integer kernel for it, score_precomputed :596-607 dequantises the row, rotates it back and sums |q - v|,
  * score_symmetric :429-440 likewise on the difference of two rows; served here for qmx_score_points[_ragged], qmx_search_topk, qmx_score_internal,
- * qmx_search_quantized and qmx_tq_encode - a walk or a build THROUGH such a storage is QMX_ERR_NOT_SUPPORTED).  Queries are rotated (HadamardRotation, f64, the
+ * qmx_search_quantized, qmx_tq_encode and qmx_hnsw_search - the walk for rotations over a multiple of 16 coordinates up to 1024, of 32 up to 2048 or of 64
+ * up to 4096; other lengths, custom / multi-vector walks and the BUILD through such a storage: QMX_ERR_NOT_SUPPORTED).  Queries are rotated (HadamardRotation, f64, the
  * reference's fixed permutation seeds) and integer-encoded on the device (`precompute_query` :496-567 with the x86_64 constants of
  * turboquant/simd/query{4,2,1}bit); scores are `score_precomputed` (:569-620) negated when `invert`; qmx_score_internal is
  * `score_symmetric` (:395-445).  `encode_internal_vector` is None (:453-459): qmx_query_create_internal is QMX_ERR_NOT_SUPPORTED, as for PQ. */

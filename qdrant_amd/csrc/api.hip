@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "tq_rotate.hpp"
 
 namespace qmx {
 
@@ -179,6 +180,7 @@ struct qmx_segment {
     int16_t *d_tq_weights = nullptr;                                      // ... d_prime_sq_i16
     float tq_weight_scale = 1.0f, tq_mm_const = 0.0f;
     uint32_t *d_tq_tables = nullptr;   // [3][rot_dim] maps, then chunk offsets and sizes
+    void *d_tq_l1 = nullptr;           // Manhattan: the TqL1Dev of the walk (tq_rotate.hpp)
     double *d_tq_norms = nullptr;      // [n_chunks]
     // f32 dot / cosine blocks large enough for the split prefilter (scan_split.hip): max |x| and max row norm, taken once at create
     bool split_stats = false;
@@ -444,6 +446,7 @@ static void segment_free(qmx_segment *seg) {
     if (seg->d_tq_scale) (void)hipFree(seg->d_tq_scale);
     if (seg->d_tq_weights) (void)hipFree(seg->d_tq_weights);
     if (seg->d_tq_tables) (void)hipFree(seg->d_tq_tables);
+    if (seg->d_tq_l1) (void)hipFree(seg->d_tq_l1);
     if (seg->d_tq_norms) (void)hipFree(seg->d_tq_norms);
     delete seg;
 }
@@ -649,6 +652,19 @@ static int32_t tq_segment_setup(qmx_segment *s, const qmx_segment_desc *desc) {
     QMX_HIP(hipMemcpy(s->d_tq_tables, tables.data(), tables.size() * 4, hipMemcpyHostToDevice));
     QMX_HIP(hipMalloc((void **)&s->d_tq_norms, std::max<size_t>(1, norms.size()) * 8));
     if (!norms.empty()) QMX_HIP(hipMemcpy(s->d_tq_norms, norms.data(), norms.size() * 8, hipMemcpyHostToDevice));
+    if (desc->distance == QMX_DISTANCE_MANHATTAN) {   // what the L1 walk reads (tq_l1_policy.hpp)
+        TqL1Dev d;
+        memset(&d, 0, sizeof(d));
+        d.inv.maps = s->d_tq_tables + (size_t)3 * rd + 64;
+        d.inv.chunk_off = s->d_tq_tables + (size_t)3 * rd;
+        d.inv.chunk_size = d.inv.chunk_off + 32;
+        d.inv.chunk_norm = s->d_tq_norms;
+        d.inv.n_chunks = nchunks; d.inv.rot_dim = rd; d.inv.padded_dim = s->tq_padded_dim; d.inv.dim = s->tq_padded_dim;
+        d.shift = s->d_tq_shift; d.scale = s->d_tq_scale;
+        d.value_bits = s->tq_value_bits; d.dim = (uint32_t)dim;
+        QMX_HIP(hipMalloc(&s->d_tq_l1, sizeof(d)));
+        QMX_HIP(hipMemcpy(s->d_tq_l1, &d, sizeof(d), hipMemcpyHostToDevice));
+    }
     return QMX_OK;
 }
 static TqRotationHost tq_rotation(const qmx_segment *s) {
@@ -722,6 +738,7 @@ int32_t qmx_tq_fit_plus(int32_t device_id, uint32_t distance, uint32_t dim, cons
     } while (0);
     bin.release(); brot.release(); bsh.release(); bsc.release();
     if (tmp.d_tq_tables) (void)hipFree(tmp.d_tq_tables);
+    if (tmp.d_tq_l1) (void)hipFree(tmp.d_tq_l1);
     if (tmp.d_tq_norms) (void)hipFree(tmp.d_tq_norms);
     if (tmp.d_tq_shift) (void)hipFree(tmp.d_tq_shift);
     if (tmp.d_tq_scale) (void)hipFree(tmp.d_tq_scale);
@@ -767,6 +784,7 @@ int32_t qmx_tq_encode(int32_t device_id, uint32_t distance, uint32_t dim, const 
     } while (0);
     bin.release(); brot.release(); bout.release();
     if (tmp.d_tq_tables) (void)hipFree(tmp.d_tq_tables);
+    if (tmp.d_tq_l1) (void)hipFree(tmp.d_tq_l1);
     if (tmp.d_tq_norms) (void)hipFree(tmp.d_tq_norms);
     if (tmp.d_tq_shift) (void)hipFree(tmp.d_tq_shift);
     if (tmp.d_tq_scale) (void)hipFree(tmp.d_tq_scale);
@@ -1467,6 +1485,7 @@ static void fill_args(const qmx_query *q, uint32_t tile0, uint32_t nq_tile, Scan
         a.del.n_allowed_bits = q->n_filter_bits;
     }
     a.err_flag = q->d_err;
+    a.tq_l1 = s->d_tq_l1;
     a.flags = s->flags;
     a.sq_multiplier = s->sq.multiplier;
     a.row_offsets = s->d_row_offsets;
@@ -2866,6 +2885,7 @@ static int32_t launch_hnsw(const qmx_query *q, const ScanArgs &a, const HnswArgs
     if (s->dtype == QMX_DTYPE_SQ_U8) return launch_hnsw_sq(q->stream, (int)s->distance, a, h, grid, per_cu);
     if (s->dtype == QMX_DTYPE_PQ) return launch_hnsw_pq(q->stream, a, h, grid, per_cu);
     if (s->dtype == QMX_DTYPE_BQ) return launch_hnsw_bq(q->stream, a, h, grid, per_cu);
+    if (tq_l1(s)) return launch_hnsw_tq_l1(q->stream, a, h, grid, per_cu, s->tq_rot_dim);
     if (s->dtype == QMX_DTYPE_TQ) return launch_hnsw_tq(q->stream, a, h, grid, per_cu);
     set_error("dtype %u not built yet", s->dtype);
     return QMX_ERR_NOT_SUPPORTED;
@@ -2876,11 +2896,17 @@ static int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint3
                             uint32_t *d_counts, uint32_t *d_scored, bool timed, bool acorn = false, const MultiWalk *mw = nullptr,
                             const ExpandedOut *xo = nullptr, const CustomWalk *cw = nullptr) {
     const qmx_segment *s = q->seg;
-    QMX_REQUIRE(!tq_l1(s), QMX_ERR_NOT_SUPPORTED,
-                "HNSW walk through a TurboQuant storage over Manhattan: every hop score is a dequantisation + inverse rotation (tq_l1.hip serves score_points, "
-                "brute force, score_internal and rescoring); walk the graph with the original vectors' scorer");
+    QMX_REQUIRE(!tq_l1(s) || (!mw && !cw), QMX_ERR_NOT_SUPPORTED, "custom / multi-vector walks through a TurboQuant storage over Manhattan are not built");
     ScanArgs a;
     fill_args(q, 0, q->nq, a);
+    if (tq_l1(s)) {   // the walk scores against the query as given (tq_l1_policy.hpp): f32 entries of dim floats, 16-byte padded
+        const uint32_t qs = tq_l1_query_bytes(s->dim);
+        QMX_TRY(q->tq_rot.reserve((size_t)q->nq * qs));
+        QMX_HIP(hipMemsetAsync(q->tq_rot.p, 0, (size_t)q->nq * qs, q->stream));
+        QMX_HIP(hipMemcpy2DAsync(q->tq_rot.p, qs, q->enc.p, (size_t)s->dim * 4, (size_t)s->dim * 4, q->nq, hipMemcpyDeviceToDevice, q->stream));
+        a.queries = q->tq_rot.p;
+        a.q_stride = qs;
+    }
     const uint32_t n_searches = cw ? cw->n_queries : mw ? mw->n_queries : q->nq;
     if (cw) {
         a.cq_desc = cw->d_desc;
@@ -2903,6 +2929,10 @@ static int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint3
     h.out = d_out; h.out_counts = d_counts; h.out_scored = d_scored;
     if (xo) { h.expanded = xo->d_ids; h.expanded_cnt = xo->d_cnt; h.xcap = xo->xcap; }
     h.lds_query_bytes = q->q_stride <= HNSW_LDS_QUERY_MAX ? q->q_stride : 0;
+    if (tq_l1(s)) {
+        h.lds_query_bytes = tq_l1_lds_bytes(s->dim, s->tq_rot_dim);
+        QMX_REQUIRE(h.lds_query_bytes <= HNSW_LDS_QUERY_MAX, QMX_ERR_NOT_SUPPORTED, "TurboQuant over Manhattan, the walk: %u bytes of LDS per search", h.lds_query_bytes);
+    }
     if (mw) {   // [16-byte header][the multi-query's inner vectors]
         const uint64_t need = 16 + (uint64_t)std::max<uint32_t>(mw->max_tokens, 1) * q->q_stride;
         QMX_REQUIRE(need <= HNSW_LDS_QUERY_MAX, QMX_ERR_NOT_SUPPORTED, "a multi-query of %u inner vectors x %u bytes does not fit the LDS", mw->max_tokens,
@@ -2920,7 +2950,7 @@ static int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint3
             h.lds_query_bytes = cw->lds_bytes;
         }
     }
-    if (std::max(top, ef) > HNSW_MAX_EF_REG && !mw && !cw) {   // a list this long lives in LDS behind the query entry, which is then always staged (a PQ LUT too)
+    if (std::max(top, ef) > HNSW_MAX_EF_REG && !mw && !cw && !tq_l1(s)) {   // a list this long lives in LDS behind the query entry, which is then always staged (a PQ LUT too)
         const size_t beam = ((size_t)std::max(top, ef) * 9 + 15) / 16 * 16;
         QMX_REQUIRE((size_t)q->q_stride + beam + 2048 <= 160 * 1024, QMX_ERR_NOT_SUPPORTED,
                     "hnsw max(top, ef) = %u: the query entry (%u bytes) and the list do not fit the LDS together", std::max(top, ef), q->q_stride);

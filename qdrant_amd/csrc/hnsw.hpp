@@ -156,6 +156,12 @@ struct HopMaxSimInternal {
     }
 };
 
+// a hop policy that scores a whole hop itself, wave-cooperatively (H::hop): TurboQuant over Manhattan, tq_l1_policy.hpp
+template <class H, class = void>
+struct is_tql1 { static constexpr bool value = false; };
+template <class H>
+struct is_tql1<H, decltype((void)H::TQL1)> { static constexpr bool value = H::TQL1; };
+
 // Custom queries as the scorer of the walk (raw_scorer.rs:228-333 builds a CustomQueryScorer / QuantizedCustomQueryScorer / TurboCustomQueryScorer for
 // whatever storage the segment has; graph_layers.rs:108-149 walks with whatever scorer it gets): a hop candidate's score is
 // query.score_by(|example| inner policy's score(example, candidate)) - the examples of ONE custom query, in flat_iter() order, are what the search stages.
@@ -348,6 +354,10 @@ __device__ __forceinline__ void hop_score(const ScanArgs &a, const unsigned char
     constexpr int IPP = 64 / H::LPI;
     const int sub = lane % H::LPI, g = lane / H::LPI;
     __syncthreads();   // hop_ids written by other lanes
+    if constexpr (is_tql1<H>::value) {      // the policy scores the hop as a wave (it ends on a barrier, like the loop below)
+        H::hop(a, qp, hop_ids, hop_scores, k, lane);
+        return;
+    }
     uint32_t base = 0;
     if constexpr (H::MULTI) {
         // the usual hop (9..32 fresh neighbours) in ONE pass with 2 or 4 rows per lane group: one round of gathers
@@ -805,7 +815,8 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const ScanArgs a, const
             __syncthreads();
             const uint4 *src = reinterpret_cast<const uint4 *>(qg);
             uint4 *dst = reinterpret_cast<uint4 *>(q_lds);
-            for (uint32_t i = (uint32_t)lane; i < h.lds_query_bytes / 16; i += 64) dst[i] = src[i];
+            const uint32_t q_units = (h.lds_query_bytes < a.q_stride ? h.lds_query_bytes : a.q_stride) / 16;     // (a policy may own scratch behind its entry)
+            for (uint32_t i = (uint32_t)lane; i < q_units; i += 64) dst[i] = src[i];
             __syncthreads();
             hnsw_search_one<H, E>(a, h, q_lds, hop_ids, hop_scores, vis, vlog, qi, lane, beam_lds);
         } else {

@@ -75,6 +75,8 @@ struct ScanArgs {
     // custom queries as the walk's scorer (hnsw.hpp HopCustom): search qi = custom query cq_desc[qi] over the example entries of `queries`
     const qmx_custom_query *cq_desc;
     const float *cq_coefs;
+    // TurboQuant over Manhattan, the walk (tq_l1_policy.hpp): the segment's TqL1Dev (tq_rotate.hpp) on the device
+    const void *tq_l1;
 };
 
 enum ScanMode { SCAN_TOPK = 0, SCAN_SCORES = 1 };
@@ -134,6 +136,7 @@ int32_t launch_scan_tq(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a,
 int32_t launch_scan_bq_mfma(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out);
 int32_t launch_scan_tq_mfma(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out);   // scan_sq_mfma.hip, 4 / 2 bits
 int32_t launch_hnsw_tq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
+int32_t launch_hnsw_tq_l1(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu, uint32_t rot_dim);   // hnsw_tq_l1.hip
 int32_t launch_tq_split(hipStream_t st, const void *rows, uint64_t src_stride, uint64_t n, uint32_t code_bytes, uint32_t dst_stride, int has_l2,
                         void *codes, float *sf, float *l2, float *xm);
 int32_t launch_tq_rotate(hipStream_t st, const float *d_in, uint32_t n, const TqRotationHost &h, double *d_out);

@@ -22,6 +22,7 @@
 //   2 bits  byte k = dims 4k .. 4k + 3: pieces [low half of dims = j mod 4] j = 0..3, then the four high-half pieces
 //   1 bit   bit i of the piece = dim i: pieces = the 8 bit planes of q
 #include "tq_policies.hpp"
+#include "tq_rotate.hpp"
 
 namespace qmx {
 
@@ -81,13 +82,6 @@ int32_t launch_tq_split(hipStream_t st, const void *rows, uint64_t src_stride, u
 // ---- HadamardRotation::apply for a batch of vectors: in [n][dim] f32 -> out [n][padded_dim] f64 (the zero padding past rot_dim untouched) ----
 // One block per vector, the vector in LDS (two f64 buffers: the gathers ping-pong).  Every element sees the reference's operation sequence:
 // one add or sub per butterfly stage in ascending stride order, one multiply by 1 / sqrt(size), so the f64 results are bit-identical.
-struct TqRotation {
-    const uint32_t *maps;       // [3][rot_dim] forward maps
-    const uint32_t *chunk_off;  // [n_chunks] first element of each power-of-two chunk
-    const uint32_t *chunk_size; // [n_chunks]
-    const double *chunk_norm;   // [n_chunks] 1 / sqrt(size), computed on the host like the reference does
-    uint32_t n_chunks, rot_dim, padded_dim, dim;
-};
 __device__ __forceinline__ void tq_wht_chunks(double *x, const TqRotation &r) {
     for (uint32_t c = 0; c < r.n_chunks; ++c) {
         double *xc = x + r.chunk_off[c];
@@ -142,58 +136,13 @@ __global__ __launch_bounds__(64) void tq_rotate_wave_kernel(const T *in, uint64_
     const T *src = in + (uint64_t)v * in_stride;
     const uint32_t first = (uint32_t)lane * E;                 // this lane's first coordinate
     const bool act = first < r.rot_dim;
-    uint32_t my_size = 0;
-    double my_norm = 1.0;
-    for (uint32_t c = 0; c < r.n_chunks; ++c) {
-        const uint32_t off = r.chunk_off[c], size = r.chunk_size[c];
-        if (act && first >= off && first < off + size) { my_size = size; my_norm = r.chunk_norm[c]; }
-    }
+    uint32_t my_size;
+    double my_norm;
+    tq_wave_lane_chunk<E>(r, lane, &my_size, &my_norm);
     double x[E];
 #pragma unroll
     for (int k = 0; k < E; ++k) x[k] = (act && first + k < r.dim) ? (double)src[first + k] : 0.0;
-    auto wht = [&]() {
-#pragma unroll
-        for (int h = 1; h < E; h *= 2) {
-#pragma unroll
-            for (int j = 0; j < E; ++j)
-                if ((j & h) == 0) {
-                    const double a = x[j], b = x[j + h];
-                    x[j] = a + b;
-                    x[j + h] = a - b;
-                }
-        }
-        for (uint32_t hl = 1; hl < 64; hl *= 2) {
-            const bool on = my_size > hl * E;
-            if (!__ballot(on)) break;                          // (chunk sizes only shrink along the vector: nobody joins a later stage either)
-            const bool upper = ((uint32_t)lane & hl) != 0;
-#pragma unroll
-            for (int k = 0; k < E; ++k) {
-                const double p = __shfl_xor(x[k], (int)hl, 64);
-                const double lo = upper ? p : x[k], hi = upper ? x[k] : p;      // the pair (x[j], x[j + h]) as the reference names it
-                if (on) x[k] = upper ? lo - hi : lo + hi;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < E; ++k) x[k] = x[k] * my_norm;
-    };
-    wht();
-    for (int p = 0; p < 3; ++p) {
-        const uint32_t *map = r.maps + (size_t)p * r.rot_dim;
-        __syncthreads();
-        if (act) {
-#pragma unroll
-            for (int k = 0; k < E; ++k) buf[first + k] = x[k];
-        }
-        __syncthreads();
-        if (act) {
-#pragma unroll
-            for (int k4 = 0; k4 < E; k4 += 4) {
-                const uint4 m4 = *reinterpret_cast<const uint4 *>(map + first + k4);
-                x[k4] = buf[m4.x]; x[k4 + 1] = buf[m4.y]; x[k4 + 2] = buf[m4.z]; x[k4 + 3] = buf[m4.w];
-            }
-        }
-        wht();
-    }
+    tq_wave_rotate<E>(x, r, buf, my_size, my_norm, lane);
     double *o = out + (uint64_t)v * r.padded_dim;
     // (in place - the inverse rotation - too: the wave read its whole vector before this point, and a coordinate past the rotation is read and written
     // by the same lane)

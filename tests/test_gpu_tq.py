@@ -302,11 +302,23 @@ def test_tq_manhattan_scores_bit_exact(qa, bits, plus, unpadded, dim):
         assert not deleted[r["idx"]].any()
         assert np.array_equal(_bits(r["score"]), _bits(np.sort(sc)[::-1][:10]))
         assert np.array_equal(_bits(full[qi][r["idx"]]), _bits(r["score"]))
-    # the walk through this scorer is the one thing not built
-    graph = qa.GraphLayers.from_plain(O.Hnsw(O.DenseStorage(O.F32, O.MANHATTAN, vecs), m=8, ef_construct=32).export_plain())
-    with pytest.raises(qa.QmxError) as e:
-        graph.search(5, 32, scorer)
-    assert e.value.status == qa._ffi.ERR_NOT_SUPPORTED
+    # the walk THROUGH this scorer (what a Manhattan collection with TurboQuant searches its graph with): every hop dequantises and rotates back its
+    # candidates (tq_l1_policy.hpp) - the oracle's walk with its L1 scorer, ids and score bits; rotations that are not a multiple of 16 coordinates: refused
+    st.set_deleted(None)
+    flags = O.DenseStorage(O.F32, O.MANHATTAN, vecs)
+    og = O.Hnsw(flags, m=8, ef_construct=32)
+    graph = qa.GraphLayers.from_plain(og.export_plain())
+    rot_dim = dim if unpadded else otq.padded_dim
+    if rot_dim % 16 == 0:
+        for top, ef in ((5, 32), (10, 64), (3, 600)):
+            want = og.search_tq(flags, otq, queries, top, ef)
+            got = graph.search(top, ef, scorer)
+            for g_, w_ in zip(got, want):
+                assert g_["idx"].tolist() == w_["idx"].tolist() and np.array_equal(_bits(g_["score"]), _bits(w_["score"]))
+    else:
+        with pytest.raises(qa.QmxError) as e:
+            graph.search(5, 32, scorer)
+        assert e.value.status == qa._ffi.ERR_NOT_SUPPORTED
 
 
 def test_tq_manhattan_oversampled_search_with_rescoring(qa):
