@@ -171,7 +171,8 @@ class GraphLayers:
         res = [out[i, :counts[i]].copy() for i in range(nq)]
         return (res, int(self.counters.vectors_scored)) if with_scored else res
 
-    def search_with_vectors(self, top: int, ef: int, links_scorer: RawScorer, base_scorer: RawScorer, is_stopped=None, with_scored: bool = False):
+    def search_with_vectors(self, top: int, ef: int, links_scorer: RawScorer, base_scorer: RawScorer, is_stopped=None, with_scored: bool = False,
+                            raw_output: bool = False):
         """`GraphLayers::search_with_vectors(top, ef, links_scorer, links_scorer_bytes, base_scorer, None, is_stopped)` (graph_layers.rs:564-596):
         the walk over a graph with inline storage - steered by the quantized link vectors (`links_scorer`, over the quantized storage), every
         popped candidate scored on its full base vector (`base_scorer`, over the original storage); the best `top` base scores are returned."""
@@ -183,7 +184,7 @@ class GraphLayers:
             stop = is_stopped if isinstance(is_stopped, np.ndarray) else np.array([1 if is_stopped else 0], dtype=np.uint8)
         F.check(F.lib().qmx_hnsw_search_with_vectors(self._h, links_scorer._h, base_scorer._h, top, ef, F.ptr(out), F.ptr(counts), F.ptr(stop),
                                                      C.byref(self.counters)))
-        res = [out[i, :counts[i]].copy() for i in range(nq)]
+        res = (out, counts) if raw_output else [out[i, :counts[i]].copy() for i in range(nq)]
         return (res, int(self.counters.vectors_scored)) if with_scored else res
 
     def close(self):

@@ -885,7 +885,7 @@ class CustomRawScorer:
 
 
 def search_quantized(searched: RawScorer, original: Optional[RawScorer], top: int, oversampling: float = 0.0, rescore: bool = True,
-                     graph=None, hnsw_ef: int = 0, ids=None, is_stopped=None, acorn: bool = False, counters=None) -> List[np.ndarray]:
+                     graph=None, hnsw_ef: int = 0, ids=None, is_stopped=None, acorn: bool = False, counters=None, raw_output: bool = False):
     """`PlainVectorIndexReadView::search` (graph is None) or the graph arm of `HNSWIndexReadView::search`, with
     `get_oversampled_top` and `postprocess_search_result` (vector_index_search_common.rs:27-91) in one device-side call."""
     p = F.SearchParams()
@@ -900,6 +900,8 @@ def search_quantized(searched: RawScorer, original: Optional[RawScorer], top: in
     F.check(F.lib().qmx_search_quantized(None if graph is None else graph._h, searched._h, None if original is None else original._h,
                                          C.byref(p), F.ptr(idarr), 0 if idarr is None else len(idarr), F.ptr(out), F.ptr(counts),
                                          F.ptr(stop), None if counters is None else C.byref(counters)))
+    if raw_output:          # ([nq, top] ScoredPointOffset, [nq] counts) as the library wrote them: what a caller timing the call wants (no per-query slicing)
+        return out, counts
     return [out[i, :counts[i]].copy() for i in range(nq)]
 
 
