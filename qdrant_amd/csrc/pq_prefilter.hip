@@ -91,40 +91,51 @@ int32_t launch_pq_rotate(hipStream_t st, const void *codes, uint64_t row_stride,
 // caller fills the table with 0x80 (= 0) first: padding chunks, missing centroids and the unused query bytes of the last group must read 0.
 __global__ __launch_bounds__(256) void pq_lut8_kernel(const unsigned char *luts, uint32_t q_stride, uint32_t nq, uint32_t m, uint32_t ncent, uint32_t m_pad,
                                                       const uint64_t *gthr, uint8_t *table8, int32_t *thr, float *band) {
-    __shared__ float sh_lo[128], sh_red[3][4];
+    __shared__ float sh_lo[128], sh_hi[128], sh_ab[128];
     __shared__ int sh_bad;
+    __shared__ float sh_R, sh_E;
+    __shared__ double sh_L;
     const uint32_t q = blockIdx.x, j = threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float *lut = reinterpret_cast<const float *>(luts + (uint64_t)q * q_stride);
     const uint32_t slots = pqf_slots(m_pad);
     if (j == 0) sh_bad = 0;
     __syncthreads();
-    float R = 0.0f, E = 0.0f;
-    double L = 0.0;
+    // per chunk: min, max, max |.| of its centroids' entries - a WAVE per chunk (chunks wave, wave + 4, ...: no block barrier inside the loop, and the
+    // loads of the wave's next chunks are in flight while one is reduced; the first version synchronised the block twice per chunk: 100 us per launch)
     int bad = 0;
-    for (uint32_t c = 0; c < m; ++c) {
-        const float v = j < ncent ? lut[(uint64_t)c * ncent + j] : 0.0f;
-        const bool fin = !(v != v) && __builtin_fabsf(v) < 3.0e38f;
-        if (j < ncent && !fin) bad = 1;
-        float mn = j < ncent ? v : __builtin_inff(), mx = j < ncent ? v : -__builtin_inff(), ab = j < ncent ? __builtin_fabsf(v) : 0.0f;
+    for (uint32_t c = (uint32_t)wave; c < m; c += 4) {
+        float mn = __builtin_inff(), mx = -__builtin_inff(), ab = 0.0f;
+        for (uint32_t jj = (uint32_t)lane; jj < ncent; jj += 64) {
+            const float v = lut[(uint64_t)c * ncent + jj];
+            const bool fin = !(v != v) && __builtin_fabsf(v) < 3.0e38f;
+            if (!fin) bad = 1;
+            mn = __builtin_fminf(mn, v);
+            mx = __builtin_fmaxf(mx, v);
+            ab = __builtin_fmaxf(ab, __builtin_fabsf(v));
+        }
         for (int o = 32; o >= 1; o >>= 1) {
             mn = __builtin_fminf(mn, __shfl_xor(mn, o, 64));
             mx = __builtin_fmaxf(mx, __shfl_xor(mx, o, 64));
             ab = __builtin_fmaxf(ab, __shfl_xor(ab, o, 64));
         }
-        if (lane == 0) { sh_red[0][wave] = mn; sh_red[1][wave] = mx; sh_red[2][wave] = ab; }
-        __syncthreads();
-        mn = __builtin_fminf(__builtin_fminf(sh_red[0][0], sh_red[0][1]), __builtin_fminf(sh_red[0][2], sh_red[0][3]));
-        mx = __builtin_fmaxf(__builtin_fmaxf(sh_red[1][0], sh_red[1][1]), __builtin_fmaxf(sh_red[1][2], sh_red[1][3]));
-        ab = __builtin_fmaxf(__builtin_fmaxf(sh_red[2][0], sh_red[2][1]), __builtin_fmaxf(sh_red[2][2], sh_red[2][3]));
-        if (j == 0) sh_lo[c] = mn;
-        R = __builtin_fmaxf(R, mx - mn);
-        E += ab;
-        L += (double)mn;
-        __syncthreads();
+        if (lane == 0) { sh_lo[c] = mn; sh_hi[c] = mx; sh_ab[c] = ab; }
     }
     if (bad) sh_bad = 1;
     __syncthreads();
+    if (j == 0) {           // the sums in chunk order, as before
+        float R0 = 0.0f, E0 = 0.0f;
+        double L0 = 0.0;
+        for (uint32_t c = 0; c < m; ++c) {
+            R0 = __builtin_fmaxf(R0, sh_hi[c] - sh_lo[c]);
+            E0 += sh_ab[c];
+            L0 += (double)sh_lo[c];
+        }
+        sh_R = R0; sh_E = E0; sh_L = L0;
+    }
+    __syncthreads();
+    const float R = sh_R, E = sh_E;
+    const double L = sh_L;
     bad = sh_bad;
     // degenerate tables (every entry equal, or non-finite entries): all-zero table, see `usable` below
     const bool flat = !(R > 0.0f) || !(R < 3.0e38f) || bad;
@@ -132,13 +143,23 @@ __global__ __launch_bounds__(256) void pq_lut8_kernel(const unsigned char *luts,
     const uint32_t group = q / 4, k = q % 4;
     uint8_t *tab = table8 + ((uint64_t)group * 256 + j) * slots * 4 + k;
     if (j < ncent) {
-        for (uint32_t c = 0; c < m; ++c) {
-            const float v = lut[(uint64_t)c * ncent + j];
-            float x = __builtin_rintf((v - sh_lo[c]) * inv_step);
-            x = __builtin_fminf(__builtin_fmaxf(x, 0.0f), (float)PQF_QMAX);
-            const uint8_t b = (uint8_t)((flat ? 0u : (uint32_t)x) ^ 0x80u);
-            tab[(uint64_t)c * 4] = b;
-            if (c < 32) tab[(uint64_t)(m_pad + c) * 4] = b;
+        // eight entries per trip: their loads go out together (a byte store may alias anything, so the compiler keeps every load of a plain loop behind
+        // the stores of the iteration before it: 96 dependent round trips)
+        for (uint32_t c0 = 0; c0 < m; c0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = c0 + u < m ? lut[(uint64_t)(c0 + u) * ncent + j] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t c = c0 + (uint32_t)u;
+                if (c < m) {
+                    float x = __builtin_rintf((v[u] - sh_lo[c]) * inv_step);
+                    x = __builtin_fminf(__builtin_fmaxf(x, 0.0f), (float)PQF_QMAX);
+                    const uint8_t b = (uint8_t)((flat ? 0u : (uint32_t)x) ^ 0x80u);
+                    tab[(uint64_t)c * 4] = b;
+                    if (c < 32) tab[(uint64_t)(m_pad + c) * 4] = b;
+                }
+            }
         }
     }
     if (j == 0) {
