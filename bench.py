@@ -67,9 +67,12 @@ def parse():
     ap.add_argument("--cpu-rows", type=int, default=1_000_000, help="rows of the CPU-baseline sample")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--split-copy", choices=["half", "pair", "none"], default="half",
-                    help="which derived copy of the block the prefilter scans (half: f16 high parts, 2 B / element; pair: f16 pairs, 4 B; none: the f32 block itself)")
+    ap.add_argument("--split-copy", choices=["half", "pair", "i8", "none"], default="i8",
+                    help="which derived copy of the block the prefilter scans (half: f16 high parts, 2 B / element; pair: f16 pairs, 4 B; i8: int8 codes, 1 B; "
+                         "none: the f32 block itself)")
     ap.add_argument("--no-hbm-point", action="store_true", help="skip the secondary Q=16 (HBM-bound) measurement of the same scan")
+    ap.add_argument("--no-other-copy-point", action="store_true",
+                    help="skip the secondary measurement of the same search over the OTHER derived copy (the f16 half copy when the int8 copy is timed, and vice versa)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the Q in {1, 8, 32, 128} x {exact, prefilter} sweep")
     ap.add_argument("--no-robustness", action="store_true", help="skip the C2 search on latent / duplicated rows (needs 46 GB more HBM)")
     ap.add_argument("--verify", type=int, default=1, help="check samples against the oracle (C2 first batch, C3 / C4 scans and walks)")
@@ -134,7 +137,7 @@ def main():
     F.check(lib.qmx_synth_fill_f32(local_rank, row_seed, row0, n, dim, F.ptr(rows)))
     F.check(lib.qmx_preprocess_f32(local_rank, int(qa.Distance.Cosine), F.ptr(rows), n, dim, F.ptr(rows)))
     # (+ the f16-pair copy of the block when batches of more than 64 queries will scan it: scan_split.hip; 4 more bytes per element)
-    copy_flag = {"none": 0, "pair": F.SEG_SPLIT_COPY, "half": F.SEG_HALF_COPY}[args.split_copy]
+    copy_flag = {"none": 0, "pair": F.SEG_SPLIT_COPY, "half": F.SEG_HALF_COPY, "i8": F.SEG_I8_COPY}[args.split_copy]
     storage = qa.VectorStorage(rows, qa.Distance.Cosine, device_id=local_rank, flags=copy_flag)
 
     nbatches = max(1, args.nqueries // Q)
@@ -193,13 +196,14 @@ def main():
     # the prefilter scans (QMX_SEG_HALF_COPY: 2 B / element, QMX_SEG_SPLIT_COPY: 4 B) when that is the kernel that ran
     half_copy = "scan_f16pair_kernel<true>" in kernel_symbol or "scan_f16half256_kernel" in kernel_symbol
     tile_q = 256.0 if "scan_f16half256_kernel" in kernel_symbol else 128.0            # queries per pass of the prefilter shape that ran
-    elem_bytes = 2 if half_copy else 4
+    i8_copy = "scan_i8copy_kernel" in kernel_symbol
+    elem_bytes = 1 if i8_copy else 2 if half_copy else 4
     row_bytes = dim * elem_bytes
     launches_per_step = max(1, int(kl.value)) / float(max(1, args.steps))
     # the prefilter over a derived copy covers the block in TWO launches of the same kernel (the strided sixteenth of the tiles, then the rest
     # under the threshold the first one tightened): bytes and flops per launch are the per-launch AVERAGES, like kernel_ms, so that
     # achieved = sum of bytes / sum of kernel time
-    prefilter = "scan_f16pair_kernel" in kernel_symbol or "scan_f16half256_kernel" in kernel_symbol
+    prefilter = "scan_f16pair_kernel" in kernel_symbol or "scan_f16half256_kernel" in kernel_symbol or i8_copy
     launches_per_pass = max(1.0, launches_per_step / math.ceil(Q / tile_q)) if prefilter else 1.0
     alg_bytes = int(n * row_bytes / launches_per_pass)
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
@@ -263,6 +267,16 @@ def main():
             result["throughput_point_q256"] = p
         except Exception as e:
             result["throughput_point_q256"] = {"error": repr(e)[:300]}
+    if solo and copy_flag in (F.SEG_I8_COPY, F.SEG_HALF_COPY) and not args.no_other_copy_point and queries.shape[0] >= Q:
+        # the same search over the OTHER derived copy of the block - the f16 half copy (2 B / element, band 1e-3 |q| |row|: the round-2 / round-3
+        # headline) when the int8 copy (1 B / element, worst-case band of the two roundings) is the timed one, and vice versa: lists checked against
+        # the exact scan inside the leg; a secondary point
+        other = F.SEG_HALF_COPY if copy_flag == F.SEG_I8_COPY else F.SEG_I8_COPY
+        key = "half_copy_point" if other == F.SEG_HALF_COPY else "int8_copy_point"
+        try:
+            result[key] = derived_copy_point(other, rows, queries, n, dim, Q, top, local_rank, stream, lib, F, qa, sharded, torch)
+        except Exception as e:
+            result[key] = {"error": repr(e)[:300]}
     if solo and not args.no_hbm_point and not args.no_sweep:
         # BASELINE.md / SURVEY 8d name Q in {1, 8, 32}: both tracks at each batch size, same rows, same measurement
         sweep = {}
@@ -272,7 +286,7 @@ def main():
             for track in (("exact", "prefilter") if copy_flag else ("exact",)):
                 qa.set_option("no_split_scan", 1 if track == "exact" else -1)
                 try:
-                    bpp = None if track == "exact" else n * dim * (2 if copy_flag == F.SEG_HALF_COPY else 4)
+                    bpp = None if track == "exact" else n * dim * (1 if copy_flag == F.SEG_I8_COPY else 2 if copy_flag == F.SEG_HALF_COPY else 4)
                     sweep["Q%d_%s" % (Qs, track)] = hbm_point(Qs, storage, queries, n, dim, top, local_rank, stream, lib, F, sharded, torch, bytes_per_pass=bpp, steps=20)
                 except Exception as e:
                     sweep["Q%d_%s" % (Qs, track)] = {"error": repr(e)[:300]}
@@ -440,6 +454,44 @@ def hbm_point(Qh, storage, queries, n, dim, top, local_rank, stream, lib, F, sha
         backend.close()
 
 
+def derived_copy_point(flag, rows, queries, n, dim, Q, top, local_rank, stream, lib, F, qa, sharded, torch):
+    """The timed search of the headline (same rows, same Q) through another derived copy of the block (QMX_SEG_I8_COPY / QMX_SEG_HALF_COPY): QPS
+    (wall), the scan kernel against the HBM roof on the bytes of THAT copy (HIP events on the kernel's stream), what the prefilter let through, and
+    whether every list of the first batch equals the exact scan's, bit for bit."""
+    i8 = flag == F.SEG_I8_COPY
+    st = qa.VectorStorage(rows, qa.Distance.Cosine, device_id=local_rank, flags=flag)      # (adopts the device block; + 1 or 2 B / element)
+    try:
+        p = hbm_point(Q, st, queries, n, dim, top, local_rank, stream, lib, F, sharded, torch, bytes_per_pass=n * dim * (1 if i8 else 2), steps=50)
+        if p["kernel_ms"] > 0:
+            tops = 2.0 * n * dim * 128 / p["launches_per_pass"] / (p["kernel_ms"] * 1e-3) / 1e12
+            peak = MFMA_I8_PEAK_TOPS if i8 else MFMA_F16_PEAK_TFLOPS
+            p["mfma_i8" if i8 else "mfma_f16"] = {"achieved_TOPs": round(tops, 1), "peak_TOPs": peak, "frac": round(tops / peak, 4)}
+        backend = sharded.HipBackend(st, Q, local_rank, stream)
+        try:
+            o = torch.zeros((Q, top, 2), dtype=torch.int32, device=queries.device)
+            cn = torch.zeros((Q,), dtype=torch.int32, device=queries.device)
+            backend.local_topk(queries[:Q], top, o, cn)
+            torch.cuda.synchronize()
+            c = F.Counters()
+            F.check(lib.qmx_query_last_counters(backend.qh, C.byref(c)))
+            p["prefilter_per_batch"] = _counters_dict(c, Q)
+            a_o, a_c = o.clone(), cn.clone()
+            qa.set_option("no_split_scan", 1)
+            try:
+                backend.local_topk(queries[:Q], top, o, cn)
+                torch.cuda.synchronize()
+            finally:
+                qa.set_option("no_split_scan", -1)
+            p["equals_exact_scan_whole_block"] = bool(torch.equal(a_o, o) and torch.equal(a_c, cn))
+        finally:
+            backend.close()
+        p["copy"] = ("int8 codes, one scale per column and per query, 1 B / element (+ 25 % of the block in HBM); worst-case band, exact bounds renewed after each launch"
+                     if i8 else "f16 high parts, 2 B / element (+ 50 % of the block in HBM); band 1e-3 |q| |row|")
+        return p
+    finally:
+        st.close()
+
+
 def cpu_baseline(args, rows, queries, out, counts, n, dim, Q, top, lib, qh, F, qa, np, torch):
     """Times the oracle (checker, never the product) on a bounded sample; also verifies the GPU
     result of batch 0 on that sample (same rows, bit-identical generator)."""
@@ -502,6 +554,7 @@ def cpu_baseline(args, rows, queries, out, counts, n, dim, Q, top, lib, qh, F, q
 
 
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16 / bf16 MFMA peak (same guide); 2377 measured in a bare loop (profiles/r2_mfma_issue_rates.txt)
+MFMA_I8_PEAK_TOPS = 5000.0  # dense int8 MFMA peak (same guide: twice the f16 rate; v_mfma_i32_16x16x64_i8)
 
 
 def _roofline(n, dim, kernel_ms, alg_bytes, achieved_gbps, launches, launches_per_step, Q, kernel_symbol, launches_per_pass=1.0):
@@ -511,17 +564,19 @@ def _roofline(n, dim, kernel_ms, alg_bytes, achieved_gbps, launches, launches_pe
     (more than 64 queries) streams a derived f16 copy of the block and multiplies on the f16 matrix cores (1 or 3 products per element)."""
     per_pass = Q / max(1.0, round(launches_per_step / launches_per_pass))   # queries one pass over the block serves: MEASURED launches per step, not a dispatch guess
     half256 = "scan_f16half256_kernel" in kernel_symbol
-    split = "scan_f16pair_kernel" in kernel_symbol or "scan_f32_split_kernel" in kernel_symbol or half256
-    products = 1 if ("scan_f16pair_kernel<true>" in kernel_symbol or half256) else 3 if split else 1
+    i8 = "scan_i8copy_kernel" in kernel_symbol
+    split = "scan_f16pair_kernel" in kernel_symbol or "scan_f32_split_kernel" in kernel_symbol or half256 or i8
+    products = 1 if ("scan_f16pair_kernel<true>" in kernel_symbol or half256 or i8) else 3 if split else 1
     flops = 2.0 * n * dim * ((256 if half256 else 128) if split else per_pass) * products / launches_per_pass     # (the prefilter multiplies a padded 128- / 256-query tile)
     tflops = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
-    mfma_peak = MFMA_F16_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
+    mfma_peak = MFMA_I8_PEAK_TOPS if i8 else MFMA_F16_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
     hbm_frac, mfma_frac = achieved_gbps / HBM_PEAK_GBPS, tflops / mfma_peak
     traffic, traffic_src = _pmc_traffic(n, dim, Q, kernel_symbol)
     common = {"traffic": traffic, "traffic_source": traffic_src, "traffic_over_algorithmic": round(traffic / float(alg_bytes), 4) if traffic and alg_bytes else None, "kernel": kernel_symbol, "kernel_ms": round(kernel_ms, 4), "launches_timed": launches,
               "queries_per_pass": per_pass, "launches_per_pass": launches_per_pass, "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_flops_per_launch": flops,
               "hbm": {"achieved_GBps": round(achieved_gbps, 1), "peak_GBps": HBM_PEAK_GBPS, "frac": round(hbm_frac, 4)},
-              "mfma": {"dtype": "f16 (x = h + l prefilter, f32 accumulate; results re-scored exactly in f32)" if split else "f32",
+              "mfma": {"dtype": "int8 (column- and query-scaled codes, i32 accumulate; results re-scored exactly in f32)" if i8 else
+                                "f16 (x = h + l prefilter, f32 accumulate; results re-scored exactly in f32)" if split else "f32",
                        "achieved_TFLOPs": round(tflops, 2), "peak_TFLOPs": mfma_peak, "frac": round(mfma_frac, 4)},
               "f32_block_equivalent_GBps": round(n * dim * 4 / (kernel_ms * launches_per_pass * 1e-3) / 1e9, 1) if kernel_ms > 0 else 0.0}
     if split:
@@ -529,7 +584,7 @@ def _roofline(n, dim, kernel_ms, alg_bytes, achieved_gbps, launches, launches_pe
         common["frac_of_copy_stream"] = round(hbm_frac, 4)
         common["f32_block_equivalent"] = {"GBps": eq, "frac_of_peak": round(eq / HBM_PEAK_GBPS, 4),
                                           "note": "SURVEY 8(d) counts 4 B / element of the stored f32 block per scan; those bytes are NOT streamed by this kernel: it streams a derived "
-                                                  "f16 copy (achieved / frac above are bytes of the copy / kernel time) and re-scores the survivors from the f32 rows.  The 8(d)-conformant "
+                                                  + ("int8" if i8 else "f16") + " copy (achieved / frac above are bytes of the copy / kernel time) and re-scores the survivors from the f32 rows.  The 8(d)-conformant "
                                                   "figure (the f32 block itself streamed once) is roofline_hbm_point_q16 / batch_sweep.Q*_exact."}
     if mfma_frac > hbm_frac:
         return dict({"bound": "mfma", "achieved": round(tflops, 2), "peak": mfma_peak, "unit": "TFLOP/s", "frac": round(mfma_frac, 4)}, **common)

@@ -127,6 +127,12 @@ typedef struct qmx_counters {
  * rows are re-scored exactly.  Results are still the reference's bits; data whose best scores crowd inside 1e-3 |q| |row| of each other
  * overflow the verification list and take the exact scan instead. */
 #define QMX_SEG_HALF_COPY 0x20u
+/* The same with INT8 codes (1 byte per element: a quarter of the block again in HBM; dim a multiple of 128, at most 4096): one scale per column, one
+ * per query, the integer product on the int8 matrix cores.  The band is a worst-case bound of the two roundings (about 0.7 standard deviations of the
+ * score on unit Gaussian rows), so the pass renews an EXACT lower bound of the k-th best score after each of its launches and re-scores the rows
+ * whose approximate score lies within one band of it: a few hundred per query.  Results are still the reference's bits; the same per-query exact
+ * fallback.  Takes precedence over the two flags above; a block with an element that is not finite gets no int8 copy. */
+#define QMX_SEG_I8_COPY 0x40u
 
 /* SQ-int8 parameters = `MetadataInt8` (lib/quantization/src/encoded_vectors_u8.rs:84-91).
  * Parity is defined on GIVEN (alpha, offset): the reference's quantile estimate samples

@@ -25,6 +25,7 @@ SEG_TIME_KERNELS = 0x4
 SEG_BQ_TOGGLE_INVERT = 0x8
 SEG_SPLIT_COPY = 0x10
 SEG_HALF_COPY = 0x20
+SEG_I8_COPY = 0x40
 
 
 class ScoredPoint(C.Structure):

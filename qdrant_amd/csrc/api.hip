@@ -187,6 +187,9 @@ struct qmx_segment {
     float row_maxabs = 0.f, row_norm_max = 0.f;
     void *d_rows_split = nullptr;     // QMX_SEG_SPLIT_COPY / QMX_SEG_HALF_COPY: the block as f16 pairs / f16 high parts in the matrix cores' LDS layout
     bool split_half = false;          // ... which of the two
+    bool split_i8 = false;            // QMX_SEG_I8_COPY: d_rows_split holds int8 codes instead (scan_split.hip, "The INT8 copy")
+    float *d_i8_scale = nullptr;      // ... the columns' scales [dim]
+    uint32_t *d_i8_stats = nullptr;   // ... {C1, C2^2, -, -}: the worst row's sum |c| and sum c^2
 
     bool fast_layout() const {
         if (dtype == QMX_DTYPE_BQ || dtype == QMX_DTYPE_TQ) return row_stride % 16 == 0 && ((uintptr_t)d_rows % 16) == 0;
@@ -243,6 +246,7 @@ struct qmx_query {
     std::vector<uint32_t> sh_bases_host;
     hipEvent_t sh_done = nullptr;   // "this segment's list arrived on the merging device"
     DevBuf pq_table;           // PQ prefilter: the 6-bit tables of the tile's query groups, their integer thresholds behind them
+    DevBuf sp_probe, sp_pscores;   // the int8 copy's passes: [nq][64] probe ids + [nq] counts, their exact scores
     DevBuf sp_plan, sp_fq;     // ... the per-query overflow flags + the plan of the conditional exact passes (SplitPlanLayout), the overflowed queries packed
     // counters of the last search enqueued on this batch: the host's share is known at enqueue, the prefilter's share sits in sp_plan until
     // the stream is synchronised (qmx_query_last_counters / the synchronous entry points fold it in)
@@ -436,6 +440,8 @@ static void segment_free(qmx_segment *seg) {
     if (seg->d_pq_pair) (void)hipFree(seg->d_pq_pair);
     if (seg->d_pq_rot) (void)hipFree(seg->d_pq_rot);
     if (seg->d_rows_split) (void)hipFree(seg->d_rows_split);
+    if (seg->d_i8_scale) (void)hipFree(seg->d_i8_scale);
+    if (seg->d_i8_stats) (void)hipFree(seg->d_i8_stats);
     if (seg->d_row_offsets) (void)hipFree(seg->d_row_offsets);
     if (seg->d_bq_mean) (void)hipFree(seg->d_bq_mean);
     if (seg->d_bq_stddev) (void)hipFree(seg->d_bq_stddev);
@@ -553,6 +559,27 @@ static int32_t segment_split_stats(qmx_segment *s) {
     memcpy(&mss, &h[1], 4);
     s->row_norm_max = sqrtf(mss);
     s->split_stats = s->row_maxabs > 0.f && s->row_maxabs < 3.0e38f && s->row_norm_max < 3.0e38f;   // (NaN / inf rows: the exact scan only)
+    if (s->split_stats && (s->flags & QMX_SEG_I8_COPY) && split_i8_dim_ok(s->dim)) {
+        // the int8 copy: column scales and the worst row's code norms (two passes over the block), then the codes (a third).  Out of memory, or an
+        // element that is not finite: no copy, the other flags (if any) apply.
+        uint32_t *d_colmax = nullptr;
+        uint32_t h[4] = {0, 0, 1, 0};
+        bool ok = hipMalloc((void **)&d_colmax, (size_t)s->dim * 4) == hipSuccess && hipMalloc((void **)&s->d_i8_scale, (size_t)s->dim * 4) == hipSuccess &&
+                  hipMalloc((void **)&s->d_i8_stats, 16) == hipSuccess;
+        if (ok) ok = launch_split_i8_stats(nullptr, s->d_rows, s->row_stride, s->n, s->dim, d_colmax, s->d_i8_scale, s->d_i8_stats) == QMX_OK &&
+                     hipMemcpy(h, s->d_i8_stats, 16, hipMemcpyDeviceToHost) == hipSuccess && h[2] == 0;
+        if (ok) ok = hipMalloc(&s->d_rows_split, split_i8_copy_bytes(s->n, s->dim)) == hipSuccess;
+        if (ok) ok = launch_split_i8_copy(nullptr, s->d_rows, s->row_stride, s->n, s->dim, s->d_i8_scale, s->d_rows_split) == QMX_OK &&
+                     hipDeviceSynchronize() == hipSuccess;
+        if (d_colmax) (void)hipFree(d_colmax);
+        (void)hipGetLastError();
+        if (ok) {
+            s->split_i8 = true;
+            return QMX_OK;
+        }
+        if (s->d_rows_split) (void)hipFree(s->d_rows_split);
+        s->d_rows_split = nullptr;
+    }
     if (s->split_stats && (s->flags & (QMX_SEG_SPLIT_COPY | QMX_SEG_HALF_COPY)) && s->dim % 128 == 0) {
         // the derived copy (one pass: read 4 B, write 4 or 2 B per element).  Out of memory is not an error: the converting kernel serves.
         s->split_half = (s->flags & QMX_SEG_HALF_COPY) != 0;
@@ -1361,7 +1388,7 @@ int32_t qmx_query_destroy(qmx_query *q) {
     q->cq_scores.release();
     q->cq_desc.release();
     q->cq_multi.release();
-    q->sp_bq.release(); q->sp_f32.release(); q->sp_cand.release(); q->sp_cnt.release(); q->sp_ver.release(); q->sp_vscores.release(); q->sp_sample.release(); q->sp_wl.release(); q->xcnt.release(); q->tq_rot.release(); q->sp_plan.release(); q->sp_fq.release(); q->pq_table.release(); q->sh_lists.release(); q->sh_out.release();
+    q->sp_bq.release(); q->sp_f32.release(); q->sp_cand.release(); q->sp_cnt.release(); q->sp_ver.release(); q->sp_vscores.release(); q->sp_sample.release(); q->sp_wl.release(); q->xcnt.release(); q->tq_rot.release(); q->sp_plan.release(); q->sp_fq.release(); q->sp_probe.release(); q->sp_pscores.release(); q->pq_table.release(); q->sh_lists.release(); q->sh_out.release();
     if (q->sh_done) (void)hipEventDestroy(q->sh_done);
     q->cand.release();
     q->cand_cnt.release();
@@ -1886,6 +1913,11 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
         QMX_TRY(q->sp_vscores.reserve((size_t)q->nq * SPLIT_VCAP * 4));
         QMX_TRY(q->sp_plan.reserve(pl.bytes));
         QMX_TRY(q->sp_fq.reserve((size_t)pl.list_cap * q->q_stride));
+        if (s->split_i8) {
+            QMX_TRY(q->sp_probe.reserve((size_t)q->nq * (split_i8_probe() + 1) * 4));
+            QMX_TRY(q->sp_pscores.reserve((size_t)q->nq * split_i8_probe() * 4));
+            QMX_HIP(hipMemsetAsync((uint32_t *)q->sp_probe.p + (size_t)q->nq * split_i8_probe(), 0, (size_t)q->nq * 4, q->stream));   // the probe lists start empty
+        }
         plan = (unsigned char *)q->sp_plan.p;
         float *f = (float *)q->sp_f32.p;
         sp_qnorm = f; sp_thr = f + 256; sp_band = f + 512; sp_scales = f + 768; sp_qmax = f + 1024;
@@ -1927,6 +1959,44 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
             QMX_TRY(score_matrix_enqueue(q, tile0, nq_tile, d_sample, S, (float *)q->scores.p, S, nullptr));
             QMX_TRY(launch_custom_topk(q->stream, (const float *)q->scores.p, S, d_sample, a.del, nq_tile, top, d_out + (size_t)tile0 * top, d_counts + tile0, gthr));
             QMX_TRY(split_stage(q, "prescan"));
+            if (s->split_i8) {
+                // 2'. the int8 copy: codes, scales, worst-case bands, thresholds from the sample's exact k-th best (sp_f32: qnorm -> T_exact, qmax -> the scales)
+                float *sp_texact = sp_qnorm, *sp_qscale = sp_qmax;
+                QMX_TRY(launch_split_i8_pack(q->stream, (const float *)q->enc.p + (size_t)tile0 * s->dim, nq_tile, s->dim, s->d_i8_scale, gthr, s->d_i8_stats,
+                                             s->row_norm_max, q->sp_bq.p, sp_qscale, sp_band, sp_thr, sp_texact, (uint32_t *)q->sp_cnt.p, SPLIT_QT_MAX));
+                QMX_TRY(split_stage(q, "int8 pack"));
+                // 3'. the strided sixteenth, then the rest; after each launch the exact scores of the k best candidates so far renew the bound
+                const uint32_t np = split_i8_probe();
+                uint32_t *probe_ids = (uint32_t *)q->sp_probe.p, *probe_cnt = probe_ids + (size_t)q->nq * np;
+                int *tile_ovf = (int *)(plan + pl.tile_ovf) + split_tiles.size();
+                for (uint32_t phase = 1; phase <= 2; ++phase) {
+                    size_t slot = 0;
+                    if (timed) QMX_TRY(timing_begin(q, &slot));
+                    QMX_TRY(launch_scan_i8copy(q->stream, a, q->sp_bq.p, sp_qscale, sp_thr, s->num_cus, s->d_rows_split, q->sp_wl.p, phase));
+                    q->last_kernel = g_last_kernel;
+                    if (timed) QMX_TRY(timing_end(q, slot));
+                    QMX_TRY(launch_split_regroup(q->stream, a, q->sp_wl.p, s->num_cus, (uint64_t *)q->sp_cand.p, (uint32_t *)q->sp_cnt.p, SPLIT_CAND_CAP, tile_ovf,
+                                                 phase, SPLIT_QT));
+                    QMX_TRY(launch_split_i8_probe(q->stream, (const uint64_t *)q->sp_cand.p, (const uint32_t *)q->sp_cnt.p, SPLIT_CAND_CAP, sp_band, nq_tile, top, tile_ovf,
+                                                  probe_ids + (size_t)tile0 * np, probe_cnt + tile0));
+                    const void *scan_kernel = q->last_kernel;
+                    PairSel psel{nullptr, np, probe_cnt};
+                    QMX_TRY(score_pairs_device(q, psel, probe_ids, (uint64_t)(tile0 + nq_tile) * np, (float *)q->sp_pscores.p, false));
+                    q->last_kernel = scan_kernel;
+                    QMX_TRY(launch_split_i8_bound(q->stream, (const float *)q->sp_pscores.p + (size_t)tile0 * np, probe_cnt + tile0, nq_tile, top, sp_band, sp_qscale,
+                                                  sp_thr, sp_texact));
+                }
+                QMX_TRY(split_stage(q, "int8 scan"));
+                // 4'. the rows worth an exact score: approximate score >= T_exact - band
+                uint32_t *ver_ids = (uint32_t *)q->sp_ver.p + (size_t)tile0 * SPLIT_VCAP;
+                uint32_t *ver_cnt = (uint32_t *)q->sp_ver.p + (size_t)q->nq * SPLIT_VCAP + tile0;
+                QMX_TRY(launch_split_select(q->stream, (const uint64_t *)q->sp_cand.p, (const uint32_t *)q->sp_cnt.p, SPLIT_CAND_CAP, sp_band, nq_tile, top, SPLIT_VCAP,
+                                            ver_ids, ver_cnt, tile_ovf, (uint32_t *)(plan + pl.ovf_q) + tile0, (SplitStats *)plan, sp_texact));
+                QMX_TRY(split_stage(q, "select"));
+                split_tiles.push_back({tile0, nq_tile});
+                if (counters) counters->kernel_launches += 13;
+                continue;
+            }
             // 2. the batch's queries split into f16 pairs; thresholds and bands in accumulator / score units
             const float row_scale = split_row_scale(s->row_maxabs);
             const int half = s->split_half ? 1 : 0;
@@ -2072,7 +2142,7 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
         for (auto &t : split_tiles) {
             split_q += t.second;
             // one pass over the derived copy (2 or 4 bytes per element; the f32 rows themselves when there is none) + the sample's exact scores
-            bytes += n_cand * (uint64_t)s->dim * (s->d_rows_split && s->split_half ? 2 : 4);
+            bytes += n_cand * (uint64_t)s->dim * (s->split_i8 ? 1 : s->d_rows_split && s->split_half ? 2 : 4);
             bytes += (uint64_t)((t.second + tile_qt(s, q) - 1) / tile_qt(s, q)) * q->sp_sample_n * s->row_bytes;
         }
         const uint32_t rest = q->nq - split_q;

@@ -320,7 +320,23 @@ struct SplitStats {
     uint32_t pad;
 };
 int32_t launch_split_select(hipStream_t st, const uint64_t *d_cand, const uint32_t *d_cand_cnt, uint32_t cap, const float *d_band, uint32_t nq, uint32_t top,
-                            uint32_t vcap, uint32_t *d_ver_ids, uint32_t *d_ver_cnt, const int *d_tile_overflow, uint32_t *d_ovf_q, SplitStats *d_stats);
+                            uint32_t vcap, uint32_t *d_ver_ids, uint32_t *d_ver_cnt, const int *d_tile_overflow, uint32_t *d_ovf_q, SplitStats *d_stats,
+                            const float *d_t_exact = nullptr);
+// the int8 copy of an f32 block (QMX_SEG_I8_COPY) and its passes (scan_split.hip, "The INT8 copy")
+bool split_i8_dim_ok(uint32_t dim);
+size_t split_i8_copy_bytes(uint64_t n, uint32_t dim);
+size_t split_i8_query_bytes(uint32_t dim);
+uint32_t split_i8_probe();
+int32_t launch_split_i8_stats(hipStream_t st, const void *rows, uint64_t row_stride, uint64_t n, uint32_t dim, uint32_t *d_colmax, float *d_scale, uint32_t *d_stats);
+int32_t launch_split_i8_copy(hipStream_t st, const void *rows, uint64_t row_stride, uint64_t n, uint32_t dim, const float *d_scale, void *d_out);
+int32_t launch_split_i8_pack(hipStream_t st, const float *d_q, uint32_t nq, uint32_t dim, const float *d_scale, const uint64_t *d_gthr, const uint32_t *d_row_stats,
+                             float row_norm_max, void *d_bq, float *d_qscale, float *d_band, float *d_thr, float *d_t_exact, uint32_t *d_cand_cnt, uint32_t n_cnt);
+int32_t launch_scan_i8copy(hipStream_t st, const ScanArgs &a, const void *d_bq, const float *d_qscale, const float *d_thr, int num_cus, const void *d_rows_i8,
+                           void *d_wlists, uint32_t phase);
+int32_t launch_split_i8_probe(hipStream_t st, const uint64_t *d_cand, const uint32_t *d_cand_cnt, uint32_t cap, const float *d_band, uint32_t nq, uint32_t top,
+                              const int *d_tile_overflow, uint32_t *d_probe_ids, uint32_t *d_probe_cnt);
+int32_t launch_split_i8_bound(hipStream_t st, const float *d_scores, uint32_t *d_probe_cnt, uint32_t nq, uint32_t top, const float *d_band, const float *d_qscale,
+                              float *d_thr, float *d_t_exact);
 // the overflowed queries packed for the conditional exact passes: list, their pre-scan bounds, the passes' run flags
 int32_t launch_split_plan(hipStream_t st, const uint32_t *d_ovf_q, uint32_t nq, const uint64_t *d_gthr, uint32_t *d_list, uint64_t *d_gthr_packed, uint32_t list_cap,
                           uint32_t *d_count, int *d_run16, int *d_run64, uint32_t n_run64, SplitStats *d_stats, const void *d_queries, uint32_t q_stride,

@@ -983,7 +983,7 @@ __global__ __launch_bounds__(SEL_BLOCK) void sp_refine_kernel(const uint64_t *ca
 
 __global__ __launch_bounds__(SEL_BLOCK) void sp_select_kernel(const uint64_t *cand, const uint32_t *cand_cnt, uint32_t cap, const float *band, uint32_t top,
                                                               uint32_t vcap, uint32_t *ver_ids, uint32_t *ver_cnt, const int *tile_overflow, uint32_t *ovf_q,
-                                                              SplitStats *stats) {
+                                                              SplitStats *stats, const float *t_exact /* or nullptr: an exact lower bound of the k-th best score per query */) {
     __shared__ uint64_t sh[SEL_BLOCK / WAVE][WAVE];
     __shared__ uint64_t sh_kth;
     __shared__ float sh_cut;
@@ -999,10 +999,17 @@ __global__ __launch_bounds__(SEL_BLOCK) void sp_select_kernel(const uint64_t *ca
     }
     const uint64_t *c = cand + (uint64_t)q * cap;
     if (threadIdx.x == 0) sh_n = 0;
-    if (raw <= (uint32_t)SEL_SURV) block_kth_key_ranked(c, raw, top, &scratch, &sh_kth);
-    else block_kth_key(c, raw, (int)top, sh, &sh_kth);
-    // fewer than k candidates: keep all of them (cut = -inf)
-    if (threadIdx.x == 0) sh_cut = sh_kth ? key_score(sh_kth) - 2.0f * band[q] : -__builtin_inff();
+    // with an exact bound T (the int8 copy's passes): a result row's approximate score is >= T - band; without: the k-th best approximate score A_k
+    // proves k rows with an exact score >= A_k - band, so >= A_k - 2 band
+    const bool have_t = t_exact != nullptr && t_exact[q] > -__builtin_inff();
+    if (have_t) {
+        if (threadIdx.x == 0) sh_cut = t_exact[q] - band[q];
+    } else {
+        if (raw <= (uint32_t)SEL_SURV) block_kth_key_ranked(c, raw, top, &scratch, &sh_kth);
+        else block_kth_key(c, raw, (int)top, sh, &sh_kth);
+        // fewer than k candidates: keep all of them (cut = -inf)
+        if (threadIdx.x == 0) sh_cut = sh_kth ? key_score(sh_kth) - 2.0f * band[q] : -__builtin_inff();
+    }
     __syncthreads();
     const float cut = sh_cut;
     for (uint32_t base = 0; base < raw; base += SEL_BLOCK) {
@@ -1086,6 +1093,397 @@ __global__ __launch_bounds__(256) void sp_row_stats_kernel(const unsigned char *
     if (lane == 0) {
         atomicMax(&stats[0], __float_as_uint(mx));
         atomicMax(&stats[1], __float_as_uint(mss));
+    }
+}
+
+// =====================================================================================================================================
+// The INT8 copy (QMX_SEG_I8_COPY): one byte per element, the same LDS images, the same staging - half the bytes of the half copy per query.
+//   rows     x_i = s_i (c_i + e_i),  s_i = max_r |x_ri| / 127 (one scale per COLUMN: an outlier coordinate costs the others nothing, and the
+//            scale folds into the query), c_i = rint(x_i / s_i) in [-127, 127], |e_i| <= 1/2
+//   queries  q_i s_i = t (d_i + f_i),  t = max_i |q_i s_i| / 127 (one scale per QUERY), d_i = rint(q_i s_i / t), |f_i| <= 1/2
+//   score    sum x_i q_i = t [ sum c_i d_i  +  sum c_i f_i + sum e_i d_i + sum e_i f_i ]
+// The first sum is the integer the matrix cores deliver (v_mfma_i32_16x16x64_i8, exact); the other three are bounded, worst case, by
+//   band_q = t [ min(C1 / 2, C2 |f|_2) + (sum |d_i|) / 2 + dim / 4 ],   C1 = max_r sum_i |c_ri|,  C2 = max_r |c_r|_2   (taken once per segment)
+// (+ the round-off of the f32 evaluation the exact scores carry).  On unit Gaussian rows that is ~0.7 standard deviations of the score - two
+// orders above the error that really occurs, the price of a bound nobody can break - so the pass works with EXACT lower bounds T_q of the
+// k-th best score instead of approximate ones: a row of the result has an approximate score >= T_q - band_q (one band, not two).  T_q comes from
+// the exact sample scores first, then - after each of the two launches - from the exact scores of the k best candidates so far
+// (sp_i8_probe_kernel, the gather kernel of qmx_rescore, sp_i8_bound_kernel): ~a few hundred rows per query are re-scored at the end.
+// Everything else (per-wave candidate lists, regroup, verification, per-query exact fallback) is the f16 path's.
+// =====================================================================================================================================
+typedef int i32x4s __attribute__((ext_vector_type(4)));
+constexpr uint32_t SP_I8_PROBE = 64;                         // slots per query for the candidates whose exact scores renew the bound after a launch (k <= 64 of them)
+constexpr uint32_t SP_I8_MAX_DIM = 4096;                     // (sp_i8_colmax_kernel keeps a column maximum per thread and 256 columns)
+
+// column maxima: colmax[c] = max_r |x_rc| (uint bits of a non-negative float order like the float); thread t owns columns t, t + 256, ...
+__global__ __launch_bounds__(256) void sp_i8_colmax_kernel(const unsigned char *rows, uint64_t row_stride, uint64_t n, uint32_t dim, uint32_t *colmax) {
+    float mx[SP_I8_MAX_DIM / 256];
+#pragma unroll
+    for (int j = 0; j < (int)(SP_I8_MAX_DIM / 256); ++j) mx[j] = 0.0f;
+    for (uint64_t r = blockIdx.x; r < n; r += gridDim.x) {
+        const float *v = reinterpret_cast<const float *>(rows + r * row_stride);
+#pragma unroll
+        for (int j = 0; j < (int)(SP_I8_MAX_DIM / 256); ++j) {
+            const uint32_t c = threadIdx.x + 256u * (uint32_t)j;
+            if (c < dim) mx[j] = __builtin_fmaxf(mx[j], __builtin_fabsf(v[c]));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < (int)(SP_I8_MAX_DIM / 256); ++j) {
+        const uint32_t c = threadIdx.x + 256u * (uint32_t)j;
+        if (c < dim) atomicMax(&colmax[c], __float_as_uint(mx[j]));
+    }
+}
+__global__ void sp_i8_scales_kernel(const uint32_t *colmax, uint32_t dim, float *scale) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= dim) return;
+    const float m = __uint_as_float(colmax[i]);
+    scale[i] = m > 1.0e-30f ? m / 127.0f : 1.0f;            // (an all-zero or vanishing column: codes 0, |e| = |x| <= 1/2 all the same)
+}
+__device__ __forceinline__ int sp_i8_code(float x, float s) {
+    int c = (int)__builtin_rintf(x / s);
+    return c > 127 ? 127 : (c < -127 ? -127 : c);
+}
+// stats[0] = C1 = max_r sum |c_ri|, stats[1] = C2^2 = max_r sum c_ri^2, stats[2] != 0: an element that is not finite (no int8 copy for this block)
+__global__ __launch_bounds__(256) void sp_i8_row_stats_kernel(const unsigned char *rows, uint64_t row_stride, uint64_t n, uint32_t dim, const float *scale,
+                                                              uint32_t *stats) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (uint64_t)gridDim.x * 4;
+    uint32_t m1 = 0, m2 = 0;
+    bool bad = false;
+    for (uint64_t r = wave; r < n; r += nwaves) {
+        const float *v = reinterpret_cast<const float *>(rows + r * row_stride);
+        uint32_t c1 = 0, c2 = 0;
+        for (uint32_t i = lane; i < dim; i += 64) {
+            const float x = v[i];
+            bad = bad || !(__builtin_fabsf(x) < __builtin_inff());
+            const int c = sp_i8_code(x, scale[i]);
+            c1 += (uint32_t)(c < 0 ? -c : c);
+            c2 += (uint32_t)(c * c);
+        }
+        for (int o = 32; o >= 1; o >>= 1) {
+            c1 += __shfl_xor(c1, o, 64);
+            c2 += __shfl_xor(c2, o, 64);
+        }
+        m1 = c1 > m1 ? c1 : m1;
+        m2 = c2 > m2 ? c2 : m2;
+    }
+    if (lane == 0) {
+        atomicMax(&stats[0], m1);
+        atomicMax(&stats[1], m2);
+    }
+    if (bad) atomicOr(&stats[2], 1u);
+}
+// the copy: one thread per (row, 16-coordinate unit): out[(tile * nch + k128) * 2048 + unit(row, plane = which 64 of the 128, kq)]; rows past n are zero
+__global__ __launch_bounds__(256) void sp_i8_copy_kernel(const unsigned char *rows, uint64_t row_stride, uint64_t n, uint32_t dim, const float *scale, uint4 *out) {
+    const uint32_t groups = dim / 16, nch = dim / 128;
+    const uint64_t n_pad = (n + SP3_BM - 1) / SP3_BM * SP3_BM;
+    for (uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x; gid < n_pad * groups; gid += (uint64_t)gridDim.x * 256) {
+        const uint64_t r = gid / groups;
+        const uint32_t g = (uint32_t)(gid % groups), k128 = g / 8, hl = (g / 4) & 1u, kq = g % 4;
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        if (r < n) {
+            const float *v = reinterpret_cast<const float *>(rows + r * row_stride) + g * 16;
+            const float *sc = scale + g * 16;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) w[e / 4] |= ((uint32_t)sp_i8_code(v[e], sc[e]) & 0xFFu) << (8 * (e % 4));
+        }
+        const uint64_t tile = r / SP3_BM;
+        const uint32_t rl = (uint32_t)(r % SP3_BM);
+        out[(tile * nch + k128) * SP3_A_UNITS + sp_unit(rl >> 4, hl, kq, rl & 15u)] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// ---- once per 128-query tile: one block per query slot.  The query in the columns' scales, its own scale, its codes in the B-operand images
+// (bq[k128][unit(query, plane, kq)], zeros past nq), its band, its first threshold (from the sample's exact k-th best score) ----
+__device__ __forceinline__ float sp_block_max(float v, float *sh) {
+    for (int o = 32; o >= 1; o >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return __builtin_fmaxf(__builtin_fmaxf(sh[0], sh[1]), __builtin_fmaxf(sh[2], sh[3]));
+}
+__device__ __forceinline__ float sp_block_sum(float v, float *sh) {
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ __launch_bounds__(256) void sp_i8_pack_kernel(const float *q, uint32_t nq, uint32_t dim, const float *scale, const uint64_t *gthr,
+                                                         const uint32_t *row_stats, float row_norm_max, uint4 *bq, float *qscale, float *band, float *thr,
+                                                         float *t_exact, uint32_t *cand_cnt, uint32_t n_cnt) {
+    extern __shared__ __attribute__((aligned(16))) float sh_q[];      // the query in the columns' scales
+    __shared__ float sh_red[4];
+    const uint32_t qi = blockIdx.x;
+    const bool live = qi < nq;
+    if (qi == 0)
+        for (uint32_t i = threadIdx.x; i < n_cnt; i += 256) cand_cnt[i] = 0;
+    float mx = 0.0f, ss = 0.0f, bad = 0.0f;
+    for (uint32_t i = threadIdx.x; i < dim; i += 256) {
+        const float raw = live ? q[(uint64_t)qi * dim + i] : 0.0f;
+        const float v = raw * scale[i];
+        sh_q[i] = v;
+        mx = __builtin_fmaxf(mx, __builtin_fabsf(v));
+        ss = __builtin_fmaf(raw, raw, ss);
+        if (!(__builtin_fabsf(v) < __builtin_inff())) bad = 1.0f;
+    }
+    mx = sp_block_max(mx, sh_red);
+    ss = sp_block_sum(ss, sh_red);
+    bad = sp_block_max(bad, sh_red);                                  // (the barriers inside also publish sh_q)
+    const float t = mx > 1.0e-30f ? mx / 127.0f : 1.0f;
+    float sabs = 0.0f, sf2 = 0.0f;                                    // sum |d_i| (an integer below 2^24: exact in f32), sum f_i^2
+    for (uint32_t u = threadIdx.x; u < dim / 16; u += 256) {
+        const uint32_t k128 = u / 8, hl = (u / 4) & 1u, kq = u % 4;
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float x = sh_q[u * 16 + e] / t;
+            float c = __builtin_rintf(x);
+            c = c > 127.0f ? 127.0f : (c < -127.0f ? -127.0f : c);
+            if (!(c == c)) c = 0.0f;
+            const float f = x - c;
+            sabs += __builtin_fabsf(c);
+            sf2 = __builtin_fmaf(f, f, sf2);
+            w[e / 4] |= ((uint32_t)(int)c & 0xFFu) << (8 * (e % 4));
+        }
+        bq[(uint64_t)k128 * SP_B_UNITS + sp_unit(qi >> 4, hl, kq, qi & 15u)] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    sabs = sp_block_sum(sabs, sh_red);
+    sf2 = sp_block_sum(sf2, sh_red);
+    if (threadIdx.x != 0) return;
+    if (!live) {
+        qscale[qi] = 0.0f;
+        band[qi] = 0.0f;
+        thr[qi] = __builtin_inff();
+        t_exact[qi] = -__builtin_inff();
+        return;
+    }
+    const float c1 = (float)row_stats[0], c2 = __builtin_sqrtf((float)row_stats[1]);
+    const float cf = __builtin_fminf(0.5f * c1, c2 * __builtin_sqrtf(sf2));
+    // (1.001: the roundings of x / s, q s, q s / t and of this sum; the last term: the f32 evaluation of the exact score, dim 2^-23 |q| |row|, twice)
+    const float b = t * (cf + 0.5f * sabs + 0.25f * (float)dim) * 1.001f + 2.0f * (float)dim * 1.1920929e-7f * row_norm_max * __builtin_sqrtf(ss);
+    const uint64_t k = gthr[qi];
+    const bool ok = bad == 0.0f && k != 0 && b < 3.0e38f;
+    // no bound (the sample holds fewer than k live rows) or a query that is not finite: no candidates, and the infinite band sends the query - alone -
+    // to the exact scan
+    qscale[qi] = t;
+    band[qi] = ok ? b : __builtin_inff();
+    t_exact[qi] = ok ? key_score(k) : -__builtin_inff();
+    thr[qi] = ok ? (key_score(k) - b) / t : __builtin_inff();
+}
+
+// The scan: scan_f16pair_kernel<true> with the int8 instruction.  A stage is 256 rows x 128 coordinates (two planes of 64) = 32 KiB of rows + 16 KiB of
+// queries, 32 matrix instructions per wave as there; nch = dim / 128 stages per tile.  s.scales = the queries' scales (score units per accumulator
+// unit), s.thr in accumulator units.
+__global__ __launch_bounds__(SP3_THREADS, 1) void scan_i8copy_kernel(const ScanArgs a, const SplitArgs s) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint4 *lds = reinterpret_cast<uint4 *>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint64_t all_tiles = (a.n_cand + SP3_BM - 1) / SP3_BM;
+    const uint64_t n_tiles = split_phase_tiles(all_tiles, s.phase);
+    const uint32_t nch = s.nchunks;
+    const uint64_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const uint32_t phase = s.phase;
+    auto tile_of = [&](uint64_t j) -> uint64_t { return phase == 0 ? j : phase == 1 ? j * SP_PHASE_STRIDE : j + j / (SP_PHASE_STRIDE - 1) + 1; };
+    if (my_tiles == 0) {
+        if (lane == 0) s.wcnt[blockIdx.x * (SP3_THREADS / 64) + (uint32_t)w] = 0;
+        return;
+    }
+    const uint32_t wm = (uint32_t)w & 3u, wn = (uint32_t)w >> 2;
+    const uint32_t kq_r = (uint32_t)lane >> 4, m_r = (uint32_t)lane & 15u;
+    const uint32_t a_rd = sp_unit(wm * 4, 0, kq_r, m_r), b_rd = sp_unit(wn * 4, 0, kq_r, m_r);
+    float thr[4], qs[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        thr[nt] = s.thr[wn * 64 + nt * 16 + m_r];
+        qs[nt] = s.scales[wn * 64 + nt * 16 + m_r];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // from here on the kernel counts its vector-memory traffic itself
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(sp_lds_byte *)smem_raw;
+    const uint32_t lane_off = (uint32_t)lane * 16u;
+    uint4 *b_lds = lds + SP3_ARING * SP3_A_UNITS;
+    // the copy streams and their bookkeeping: scan_f16pair_kernel's, word for word (stage g requests [queries of g + 3, rows of g + 2], six 1 KiB
+    // copies per wave, `vmcnt(6)` = the rows of g + 1 and the queries of g + 2 have landed)
+    uint64_t ra_it = 0;
+    uint32_t ra_kc = 0, ra_slot = 0, rb_kc = 0, rb_slot = 0;
+    auto uniform_ptr = [&](uint64_t v) {
+        return reinterpret_cast<const unsigned char *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
+                                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v));
+    };
+    const unsigned char *ra_src = nullptr, *rb_src = nullptr;
+    uint32_t ra_dst = 0, rb_dst = 0;
+    auto rows_begin = [&]() {
+        const uint64_t tile = tile_of(blockIdx.x + ra_it * gridDim.x);
+        ra_src = uniform_ptr((uint64_t)(uintptr_t)(s.rows_split + (tile * nch + ra_kc) * SP3_A_UNITS) + (uint32_t)w * 4096u);
+        ra_dst = lds0 + (ra_slot * SP3_A_UNITS) * 16u + (uint32_t)w * 4096u;
+        ra_slot = ra_slot + 1 == SP3_ARING ? 0 : ra_slot + 1;
+        if (ra_kc + 1 < nch) ++ra_kc;
+        else if (ra_it + 1 < my_tiles) { ra_kc = 0; ++ra_it; }
+    };
+    auto rows_piece = [&](int i) { sp_glds16(ra_src + i * 1024, lane_off, ra_dst + i * 1024); };
+    auto queries_begin = [&]() {
+        rb_src = uniform_ptr((uint64_t)(uintptr_t)(s.bq + (uint64_t)rb_kc * SP_B_UNITS) + (uint32_t)w * 2048u);
+        rb_dst = lds0 + (SP3_ARING * SP3_A_UNITS + rb_slot * SP_B_UNITS) * 16u + (uint32_t)w * 2048u;
+        rb_slot = (rb_slot + 1) & (SP3_BRING - 1);
+        rb_kc = rb_kc + 1 == nch ? 0 : rb_kc + 1;
+    };
+    auto queries_piece = [&](int i) { sp_glds16(rb_src + i * 1024, lane_off, rb_dst + i * 1024); };
+    auto request_rows = [&]() {
+        rows_begin();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rows_piece(i);
+    };
+    auto request_queries = [&]() {
+        queries_begin();
+        queries_piece(0);
+        queries_piece(1);
+    };
+    request_queries();                                    // queries of stage 0
+    request_queries();                                    // ... 1
+    request_rows();                                       // rows of stage 0
+    request_queries();                                    // queries of stage 2
+    request_rows();                                       // rows of stage 1
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // queries 0, 1 and rows 0 have landed
+    sp_stage_barrier();
+    uint32_t slot = 0, bslot = 0;
+    i32x4s acc[4][4];
+    uint4 *const wl = s.wlist + (uint64_t)(blockIdx.x * (SP3_THREADS / 64) + (uint32_t)w) * s.wcap;
+    uint32_t wcount = 0;
+    auto epilogue = [&](uint64_t tile) {
+        const uint32_t row0 = (uint32_t)(tile * SP3_BM) + wm * 64 + 4 * kq_r;
+        const uint32_t n_rows32 = (uint32_t)a.n_cand;
+        bool maybe = false;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            int mx = acc[0][nt][0];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mx = acc[mt][nt][j] > mx ? acc[mt][nt][j] : mx;
+            maybe = maybe || !((float)mx < thr[nt]);
+        }
+        if (!__ballot(maybe)) return;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const uint32_t q = wn * 64 + (uint32_t)nt * 16 + m_r;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = (float)acc[mt][nt][j];
+                    const uint32_t row = row0 + (uint32_t)mt * 16 + (uint32_t)j;
+                    const bool c = !(v < thr[nt]) && row < n_rows32 && q < s.nq;
+                    const uint64_t hits = __ballot(c);
+                    if (hits) {
+                        const uint32_t at = wcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u));
+                        if (c && at < s.wcap) {
+                            const uint64_t key = make_key(v * qs[nt], row);
+                            wl[at] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), q, 0u);
+                        }
+                        wcount += (uint32_t)__builtin_popcountll(hits);
+                    }
+                }
+            }
+    };
+    for (uint64_t it = 0; it < my_tiles; ++it) {
+        if (it) epilogue(tile_of(blockIdx.x + (it - 1) * gridDim.x));
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (i32x4s){0, 0, 0, 0};
+        for (uint32_t kc = 0; kc < nch; ++kc) {
+            queries_begin();                              // stage g + 3 -> the slot stage g - 1 was read from (everybody is past that barrier)
+            rows_begin();                                 // stage g + 2 -> likewise
+            const uint4 *ab = lds + slot * SP3_A_UNITS + a_rd;
+            const uint4 *bb = b_lds + bslot * SP_B_UNITS + b_rd;
+            i32x4s b0[4], b1[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                b0[nt] = *reinterpret_cast<const i32x4s *>(bb + nt * 128);
+                b1[nt] = *reinterpret_cast<const i32x4s *>(bb + nt * 128 + 64);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const i32x4s a0 = *reinterpret_cast<const i32x4s *>(ab + mt * 128);
+                const i32x4s a1 = *reinterpret_cast<const i32x4s *>(ab + mt * 128 + 64);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1[nt], acc[mt][nt], 0, 0, 0);
+                // the stage's six copy requests, in the order the wait below relies on (queries first), spread over the matrix work
+                if (mt == 0) queries_piece(0);
+                if (mt == 1) queries_piece(1);
+                if (mt == 2) { rows_piece(0); rows_piece(1); }
+                if (mt == 3) { rows_piece(2); rows_piece(3); }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0[nt], acc[mt][nt], 0, 0, 0);
+            }
+            slot = slot + 1 == SP3_ARING ? 0 : slot + 1;
+            bslot = (bslot + 1) & (SP3_BRING - 1);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // rows of stage g + 1 and queries of stage g + 2 have landed
+            sp_stage_barrier();
+        }
+    }
+    epilogue(tile_of(blockIdx.x + (my_tiles - 1) * gridDim.x));
+    if (lane == 0) s.wcnt[blockIdx.x * (SP3_THREADS / 64) + (uint32_t)w] = wcount;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // nothing may land in LDS after the block is gone
+}
+
+// ---- after a launch: the k best candidates (by approximate score) of every query, for an exact look.  k of them are enough: approximate and exact
+// scores differ by a hundredth of the band in practice, so the worst exact score among the k best approximate ones is the k-th best exact score so far
+// or next to it - and finding k keys is what the bound-and-rank selection is quick at (the 64 best of ~5 000 took 100 - 190 us, these take ~15) ----
+__global__ __launch_bounds__(SEL_BLOCK) void sp_i8_probe_kernel(const uint64_t *cand, const uint32_t *cand_cnt, uint32_t cap, const float *band,
+                                                                const int *tile_overflow, uint32_t top, uint32_t *probe_ids, uint32_t *probe_cnt) {
+    __shared__ uint64_t sh[SEL_BLOCK / WAVE][WAVE];
+    __shared__ uint64_t sh_kth;
+    __shared__ uint32_t sh_n;
+    __shared__ SelScratch scratch;
+    const uint32_t q = blockIdx.x;
+    const uint32_t raw = cand_cnt[q];
+    if (*tile_overflow || raw > cap || raw == 0 || !(band[q] < 3.0e38f)) {       // (sp_select_kernel reports; nothing to learn here)
+        if (threadIdx.x == 0) probe_cnt[q] = 0;
+        return;
+    }
+    const uint64_t *c = cand + (uint64_t)q * cap;
+    const uint32_t k = top < SP_I8_PROBE ? top : SP_I8_PROBE;
+    const uint32_t want = raw < k ? raw : k;
+    if (threadIdx.x == 0) sh_n = 0;
+    if (raw <= (uint32_t)SEL_SURV) block_kth_key_ranked(c, raw, want, &scratch, &sh_kth);
+    else block_kth_key(c, raw, (int)want, sh, &sh_kth);
+    const uint64_t kth = sh_kth;                                                  // (keys are distinct - they carry the row -: exactly `want` keys are >= it)
+    for (uint32_t base = 0; base < raw; base += SEL_BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        if (i < raw) {
+            const uint64_t key = c[i];
+            if (kth != 0 && key >= kth) {                                          // (`k` is taken: the candidate's key)
+                const uint32_t slot = atomicAdd(&sh_n, 1u);
+                if (slot < SP_I8_PROBE) probe_ids[(uint64_t)q * SP_I8_PROBE + slot] = key_idx(key);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) probe_cnt[q] = sh_n < SP_I8_PROBE ? sh_n : SP_I8_PROBE;
+}
+// ... and what their exact scores say: T = the k-th best of them is a lower bound of the final k-th best score; the threshold of the next launch
+// and the cut of the selection follow it (never lowered).  One wave per query; the probe list is emptied for the next round.
+__global__ __launch_bounds__(64) void sp_i8_bound_kernel(const float *scores, uint32_t *probe_cnt, uint32_t top, const float *band, const float *qscale,
+                                                         float *thr, float *t_exact) {
+    const uint32_t q = blockIdx.x;
+    const int lane = threadIdx.x;
+    const uint32_t n = probe_cnt[q];
+    const float sc = (uint32_t)lane < n ? scores[(uint64_t)q * SP_I8_PROBE + lane] : -__builtin_inff();
+    uint32_t rank = 0;
+    for (int j = 0; j < 64; ++j) {
+        const float o = __shfl(sc, j, 64);
+        rank += (o > sc || (o == sc && j < lane)) ? 1u : 0u;
+    }
+    if (lane == 0) probe_cnt[q] = 0;
+    if (n < top || !(band[q] < 3.0e38f)) return;
+    if ((uint32_t)lane < n && rank == top - 1 && sc == sc) {
+        if (sc > t_exact[q]) t_exact[q] = sc;
+        const float t = (sc - band[q]) / qscale[q];
+        if (t > thr[q]) thr[q] = t;
     }
 }
 
@@ -1230,10 +1628,11 @@ int32_t launch_split_refine(hipStream_t st, const uint64_t *d_cand, const uint32
     return QMX_OK;
 }
 int32_t launch_split_select(hipStream_t st, const uint64_t *d_cand, const uint32_t *d_cand_cnt, uint32_t cap, const float *d_band, uint32_t nq, uint32_t top,
-                            uint32_t vcap, uint32_t *d_ver_ids, uint32_t *d_ver_cnt, const int *d_tile_overflow, uint32_t *d_ovf_q, SplitStats *d_stats) {
+                            uint32_t vcap, uint32_t *d_ver_ids, uint32_t *d_ver_cnt, const int *d_tile_overflow, uint32_t *d_ovf_q, SplitStats *d_stats,
+                            const float *d_t_exact) {
     ::qmx::clear_stale_error();
     hipLaunchKernelGGL(sp_select_kernel, dim3(nq), dim3(SEL_BLOCK), 0, st, d_cand, d_cand_cnt, cap, d_band, top, vcap, d_ver_ids, d_ver_cnt, d_tile_overflow,
-                       d_ovf_q, d_stats);
+                       d_ovf_q, d_stats, d_t_exact);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }
@@ -1244,6 +1643,89 @@ int32_t launch_split_plan(hipStream_t st, const uint32_t *d_ovf_q, uint32_t nq, 
     ::qmx::clear_stale_error();
     hipLaunchKernelGGL(sp_plan_kernel, dim3(1), dim3(256), 0, st, d_ovf_q, nq, d_gthr, d_list, d_gthr_packed, list_cap, d_count, d_run16, d_run64, n_run64, d_stats,
                        (const uint4 *)d_queries, q_stride / 16, (uint4 *)d_packed_queries);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
+// ---- the int8 copy ----
+bool split_i8_dim_ok(uint32_t dim) { return dim % 128 == 0 && dim >= 128 && dim <= SP_I8_MAX_DIM; }
+size_t split_i8_copy_bytes(uint64_t n, uint32_t dim) { return (size_t)((n + SP3_BM - 1) / SP3_BM) * (dim / 128) * SP3_A_UNITS * 16; }
+size_t split_i8_query_bytes(uint32_t dim) { return (size_t)(dim / 128) * SP_B_UNITS * 16; }
+uint32_t split_i8_probe() { return SP_I8_PROBE; }
+// d_scale [dim] <- the columns' scales, d_stats [4] <- {C1, C2^2, not finite, -} (zeroed here); then the copy itself (split_i8_copy_bytes)
+int32_t launch_split_i8_stats(hipStream_t st, const void *rows, uint64_t row_stride, uint64_t n, uint32_t dim, uint32_t *d_colmax, float *d_scale,
+                              uint32_t *d_stats) {
+    QMX_REQUIRE(split_i8_dim_ok(dim), QMX_ERR_BAD_ARG, "int8 copy of dim %u", dim);
+    ::qmx::clear_stale_error();
+    QMX_HIP(hipMemsetAsync(d_colmax, 0, (size_t)dim * 4, st));
+    QMX_HIP(hipMemsetAsync(d_stats, 0, 16, st));
+    if (n) hipLaunchKernelGGL(sp_i8_colmax_kernel, dim3(2048), dim3(256), 0, st, (const unsigned char *)rows, row_stride, n, dim, d_colmax);
+    hipLaunchKernelGGL(sp_i8_scales_kernel, dim3((dim + 255) / 256), dim3(256), 0, st, (const uint32_t *)d_colmax, dim, d_scale);
+    if (n) hipLaunchKernelGGL(sp_i8_row_stats_kernel, dim3(2048), dim3(256), 0, st, (const unsigned char *)rows, row_stride, n, dim, (const float *)d_scale, d_stats);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+int32_t launch_split_i8_copy(hipStream_t st, const void *rows, uint64_t row_stride, uint64_t n, uint32_t dim, const float *d_scale, void *d_out) {
+    if (n == 0) return QMX_OK;
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(sp_i8_copy_kernel, dim3(8192), dim3(256), 0, st, (const unsigned char *)rows, row_stride, n, dim, d_scale, (uint4 *)d_out);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+// one 128-query tile: codes, scales, bands, first thresholds (d_gthr: the sample's exact k-th best keys); zeroes the tile's candidate counters
+int32_t launch_split_i8_pack(hipStream_t st, const float *d_q, uint32_t nq, uint32_t dim, const float *d_scale, const uint64_t *d_gthr, const uint32_t *d_row_stats,
+                             float row_norm_max, void *d_bq, float *d_qscale, float *d_band, float *d_thr, float *d_t_exact, uint32_t *d_cand_cnt, uint32_t n_cnt) {
+    QMX_REQUIRE(nq <= (uint32_t)SP_QT, QMX_ERR_BAD_ARG, "int8 tile of %u queries", nq);
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(sp_i8_pack_kernel, dim3(SP_QT), dim3(256), (size_t)dim * 4, st, d_q, nq, dim, d_scale, d_gthr, d_row_stats, row_norm_max, (uint4 *)d_bq,
+                       d_qscale, d_band, d_thr, d_t_exact, d_cand_cnt, n_cnt);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+int32_t launch_scan_i8copy(hipStream_t st, const ScanArgs &a, const void *d_bq, const float *d_qscale, const float *d_thr, int num_cus, const void *d_rows_i8,
+                           void *d_wlists, uint32_t phase) {
+    auto kfn = scan_i8copy_kernel;
+    static thread_local DeviceOnce attr_once;
+    if (attr_once.need()) {
+        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SP3_LDS));
+        attr_once.mark();
+    }
+    QMX_REQUIRE(d_rows_i8 && d_wlists && split_i8_dim_ok(a.dim), QMX_ERR_BAD_ARG, "the int8 scan reads the int8 copy and writes per-wave candidate lists");
+    SplitArgs s;
+    s.rows_split = (const uint4 *)d_rows_i8;
+    s.bq = (const uint4 *)d_bq;
+    s.nchunks = a.dim / 128;
+    s.nq = a.nq;
+    s.row_scale = 1.0f;
+    s.scales = d_qscale;
+    s.thr = d_thr;
+    s.cand = nullptr;
+    s.cand_cnt = nullptr;
+    s.cap = 0;
+    s.wcap = SP_WCAP;
+    s.wcnt = (uint32_t *)d_wlists;
+    s.wlist = (uint4 *)((unsigned char *)d_wlists + split_wlists_counts_bytes(num_cus));
+    s.phase = phase;
+    const uint64_t n_tiles = split_phase_tiles((a.n_cand + SP3_BM - 1) / SP3_BM, phase);
+    if (n_tiles == 0) return QMX_OK;
+    const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, (uint64_t)num_cus));
+    ::qmx::clear_stale_error();
+    QMX_NOTE_KERNEL(kfn);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(SP3_THREADS), (size_t)SP3_LDS, st, a, s);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+int32_t launch_split_i8_probe(hipStream_t st, const uint64_t *d_cand, const uint32_t *d_cand_cnt, uint32_t cap, const float *d_band, uint32_t nq, uint32_t top,
+                              const int *d_tile_overflow, uint32_t *d_probe_ids, uint32_t *d_probe_cnt) {
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(sp_i8_probe_kernel, dim3(nq), dim3(SEL_BLOCK), 0, st, d_cand, d_cand_cnt, cap, d_band, d_tile_overflow, top, d_probe_ids, d_probe_cnt);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+int32_t launch_split_i8_bound(hipStream_t st, const float *d_scores, uint32_t *d_probe_cnt, uint32_t nq, uint32_t top, const float *d_band, const float *d_qscale,
+                              float *d_thr, float *d_t_exact) {
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(sp_i8_bound_kernel, dim3(nq), dim3(64), 0, st, d_scores, d_probe_cnt, top, d_band, d_qscale, d_thr, d_t_exact);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }

@@ -15,7 +15,7 @@ python3 - "$CSV" > $OUT/timeline.txt <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-big = [i for i, r in enumerate(rows) if ("scan_f16pair" in r["Kernel_Name"] or "scan_f32_mfma16" in r["Kernel_Name"]) and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 1_000_000]
+big = [i for i, r in enumerate(rows) if ("scan_f16pair" in r["Kernel_Name"] or "scan_i8copy" in r["Kernel_Name"] or "scan_f32_mfma16" in r["Kernel_Name"]) and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 1_000_000]
 if len(big) < 6:
     print("too few main-kernel launches", len(big)); sys.exit(0)
 a, b = big[-4], big[-3]

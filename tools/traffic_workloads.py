@@ -71,6 +71,18 @@ def main():
         st.close()
         del rows, st
         torch.cuda.empty_cache()
+    if "c2i8" in what:           # the C2 block through its int8 copy (bench.py's default since the end of round 3)
+        dim = 768
+        rows = torch.empty((n, dim), dtype=torch.float32, device=dev)
+        F.check(lib.qmx_synth_fill_f32(0, 0x5EED0002, 0, n, dim, F.ptr(rows)))
+        F.check(lib.qmx_preprocess_f32(0, int(qa.Distance.Cosine), F.ptr(rows), n, dim, F.ptr(rows)))
+        queries = torch.empty((256, dim), dtype=torch.float32, device=dev)
+        F.check(lib.qmx_synth_fill_f32(0, 0x5EED0003, 0, 256, dim, F.ptr(queries)))
+        st = qa.VectorStorage(rows, qa.Distance.Cosine, flags=F.SEG_I8_COPY)
+        scans(st, queries, 128, "c2 int8 prefilter")
+        st.close()
+        del rows, st
+        torch.cuda.empty_cache()
     if "c3" in what:
         dim = 768
         rows = latent(0x5EED0003, 0, n, dim)
