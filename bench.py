@@ -25,12 +25,14 @@ the device, and an in-run check of a sample against the CPU oracle):
       (qmx_hnsw_build_quantized), PQ walk, with and without f32 rescoring.
 Rows of C3 / C4 have low intrinsic dimension (qmx_synth_fill_latent_f32, 32 latent coordinates + noise): recall is meaningful there.
 C2 keeps the iid rows of SURVEY 8d.  Its RESULT is data-independent (the exact top-10, bit for bit); its SPEED is not: the timed path is
-the f16 prefilter + exact verification (scan_split.hip), whose verification lists grow where scores crowd near the k-th best and whose
-overflowing queries take the exact scan.  `robustness` therefore repeats the same search, outside the timed region, on the latent rows of
+a prefilter over a derived copy of the block + exact verification (scan_split.hip: the int8 copy, --split-copy i8, by default; the f16 half copy
+is timed beside it, `half_copy_point`), whose verification lists grow where scores crowd near the k-th best (and, for the int8 copy, where
+columns carry rare extreme values) and whose overflowing queries take the exact scan.  `robustness` therefore repeats the same search, outside the timed region, on the latent rows of
 C3 and on a block with 1 % duplicated rows, and reports candidates / re-scored rows / fallback queries per batch (qmx_counters) next to
 QPS and the comparison with the exact scan; `batch_sweep` runs Q in {1, 8, 32, 128} on both tracks (exact f32 stream | prefilter).
 
-Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes of one scan launch (rows x 3072 B) / the scan kernel's mean
+Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes of one scan launch (the bytes of the block the launched kernel streams: rows x
+3072 B for the exact scans, the derived copy's bytes - 768 B per row for the int8 copy, two launches per pass - for the prefilter) / the scan kernel's mean
 duration, measured with HIP-event pairs recorded on the kernel's own stream inside the timed region (qmx_query_set_timing /
 qmx_query_timing); `roofline.kernel` is the symbol the library reports for the launch (qmx_query_last_kernel).  `cpu_baseline` = the
 CPU oracle (AVX2+FMA restatement of the reference's scorer and its peek_top_iter loop) timed on this box's host cores on a bounded
@@ -193,7 +195,7 @@ def main():
         kernel_ms = kms.value / max(1, kl.value)
 
     # bytes the dominant kernel has to read per launch: the f32 block (3072 B/row at d=768) for the exact scans; the derived copy
-    # the prefilter scans (QMX_SEG_HALF_COPY: 2 B / element, QMX_SEG_SPLIT_COPY: 4 B) when that is the kernel that ran
+    # the prefilter scans (QMX_SEG_I8_COPY: 1 B / element, QMX_SEG_HALF_COPY: 2 B, QMX_SEG_SPLIT_COPY: 4 B) when that is the kernel that ran
     half_copy = "scan_f16pair_kernel<true>" in kernel_symbol or "scan_f16half256_kernel" in kernel_symbol
     tile_q = 256.0 if "scan_f16half256_kernel" in kernel_symbol else 128.0            # queries per pass of the prefilter shape that ran
     i8_copy = "scan_i8copy_kernel" in kernel_symbol
