@@ -1916,7 +1916,8 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
         if (s->split_i8) {
             QMX_TRY(q->sp_probe.reserve((size_t)q->nq * (split_i8_probe() + 1) * 4));
             QMX_TRY(q->sp_pscores.reserve((size_t)q->nq * split_i8_probe() * 4));
-            QMX_HIP(hipMemsetAsync((uint32_t *)q->sp_probe.p + (size_t)q->nq * split_i8_probe(), 0, (size_t)q->nq * 4, q->stream));   // the probe lists start empty
+            // (no memset of the probe counts: the gather of a tile reads the counts of the tiles up to it - its own, written by the probe kernel in front
+            // of it, and the earlier ones', emptied by their bound kernels)
         }
         plan = (unsigned char *)q->sp_plan.p;
         float *f = (float *)q->sp_f32.p;
