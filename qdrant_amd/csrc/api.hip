@@ -559,7 +559,7 @@ static int32_t segment_split_stats(qmx_segment *s) {
     memcpy(&mss, &h[1], 4);
     s->row_norm_max = sqrtf(mss);
     s->split_stats = s->row_maxabs > 0.f && s->row_maxabs < 3.0e38f && s->row_norm_max < 3.0e38f;   // (NaN / inf rows: the exact scan only)
-    if (s->split_stats && (s->flags & QMX_SEG_I8_COPY) && split_i8_dim_ok(s->dim)) {
+    if (s->split_stats && (s->flags & QMX_SEG_I8_COPY) && split_i8_dim_ok(s->dim) && mfma16_dim_ok(64, s->dim)) {      // (dims the prefilter path serves: search_enqueue)
         // the int8 copy: column scales and the worst row's code norms (two passes over the block), then the codes (a third).  Out of memory, or an
         // element that is not finite: no copy, the other flags (if any) apply.
         uint32_t *d_colmax = nullptr;
