@@ -229,7 +229,8 @@ def main():
                    "rows_per_gpu": n, "dim": dim, "batch": Q, "top": top, "distinct_queries": nbatches * Q,
                    "unit_of_value": ("queries per second against the ONE row-split segment" if strong else
                                      "(query, 10M-row segment) searches per second; at n_gpus=1 this is plain QPS"),
-                   "collection_qps": round(Q * args.steps / elapsed, 2)},
+                   "collection_qps": round(Q * args.steps / elapsed, 2),
+                   "timed_path": _timed_path(kernel_symbol)},
         "roofline": _roofline(n, dim, kernel_ms, alg_bytes, achieved, int(kl.value), launches_per_step, Q, kernel_symbol, launches_per_pass),
     }
 
@@ -591,6 +592,22 @@ def _roofline(n, dim, kernel_ms, alg_bytes, achieved_gbps, launches, launches_pe
     if mfma_frac > hbm_frac:
         return dict({"bound": "mfma", "achieved": round(tflops, 2), "peak": mfma_peak, "unit": "TFLOP/s", "frac": round(mfma_frac, 4)}, **common)
     return dict({"bound": "hbm", "achieved": round(achieved_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(hbm_frac, 4)}, **common)
+
+
+def _timed_path(kernel_symbol):
+    """What the timed step is, in words, from the symbol of the kernel that ran (config.timed_path of the JSON line)."""
+    what = None
+    if "scan_i8copy_kernel" in kernel_symbol:
+        what = "prefilter over an int8 copy of the block (1 B / element, int8 matrix cores)"
+    elif "scan_f16pair_kernel<true>" in kernel_symbol or "scan_f16half256_kernel" in kernel_symbol:
+        what = "prefilter over an f16 copy of the block (2 B / element, f16 matrix cores)"
+    elif "scan_f16pair_kernel" in kernel_symbol:
+        what = "prefilter over an f16-pair copy of the block (4 B / element, f16 matrix cores)"
+    elif "scan_f32_split_kernel" in kernel_symbol:
+        what = "prefilter converting the f32 rows to f16 pairs on the fly (f16 matrix cores)"
+    if what is None:
+        return "exact f32 scan"
+    return what + " + exact f32 re-scoring of the survivors: the returned lists are the exact f32 scan's, bit for bit (checked in the run)"
 
 
 def _pmc_entry(kernel_symbol):

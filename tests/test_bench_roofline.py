@@ -62,3 +62,11 @@ def test_committed_bench_lines_are_self_consistent(name):
     if "half_copy_point" in d:
         assert d["half_copy_point"]["equals_exact_scan_whole_block"] is True and "scan_f16pair_kernel<true>" in d["half_copy_point"]["kernel"]
         assert "scan_i8copy_kernel" in r["kernel"]
+
+
+def test_timed_path_names_what_ran():
+    assert bench._timed_path(I8).startswith("prefilter over an int8 copy") and "bit for bit" in bench._timed_path(I8)
+    assert bench._timed_path(HALF).startswith("prefilter over an f16 copy")
+    assert bench._timed_path("void qmx::scan_f16pair_kernel<false>(qmx::ScanArgs, qmx::SplitArgs)").startswith("prefilter over an f16-pair copy")
+    assert bench._timed_path("qmx::scan_f32_split_kernel(qmx::ScanArgs, qmx::SplitArgs)").startswith("prefilter converting")
+    assert bench._timed_path(EXACT16) == "exact f32 scan"
