@@ -191,3 +191,27 @@ def test_import_of_exported_plain_links_walks_identically():
     assert sa == sb
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
+
+
+def test_discover_queries_walk_the_graph_like_the_reference_asks():
+    """hnsw_discover_precision (lib/segment/tests/integration/hnsw_discover_test.rs:57-168): 5 000 points of 8 uniform coordinates, cosine, m = 16,
+    ef_construct = 64, built single-threaded; 100 DiscoverQuery searches (a target + 1..2 context pairs), top 3 with ef 32 through the graph against the
+    plain search of the same query: at most 5 of 100 may differ."""
+    rng = np.random.default_rng(42)
+    dim, n, top, ef, attempts, max_failures = 8, 5000, 3, 32, 100, 5
+    rows = O.preprocess(O.COSINE, rng.random((n, dim), dtype=np.float32))
+    st = O.DenseStorage(O.F32, O.COSINE, rows)
+    graph = O.Hnsw(st, m=16, ef_construct=64, seed=42)
+    factory = O.ScorerFactory("dense", st)
+    ids = np.arange(n, dtype=np.uint32)
+    hits = 0
+    for _ in range(attempts):
+        pairs = int(rng.integers(1, 3))                                           # rng.random_range(1..MAX_EXAMPLE_PAIRS), MAX_EXAMPLE_PAIRS = 3
+        examples = O.preprocess(O.COSINE, rng.random((1 + 2 * pairs, dim), dtype=np.float32))      # target, then (positive, negative) pairs
+        scorer, keep = factory.custom(list(examples), 2, 1, pairs)
+        walked, _ = graph.search_scorer(scorer, top, ef)
+        scores = O.scorer_score_points(scorer, ids)
+        plain = np.lexsort((ids, -scores.astype(np.float64)))[:top]
+        same = walked["idx"].tolist() == plain.tolist() and np.array_equal(walked["score"].view(np.uint32), scores[plain].view(np.uint32))
+        hits += int(same)
+    assert attempts - hits <= max_failures, hits
