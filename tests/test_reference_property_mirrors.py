@@ -169,3 +169,21 @@ def test_pq_error_bounds_of_the_reference(distance, invert):
         internal = pq.score_internal([0] * (VECTORS_COUNT - 1), list(range(1, VECTORS_COUNT)))
         for i in range(1, VECTORS_COUNT):
             assert abs(internal[i - 1] - sign * _exact(distance, data[0], data[i])) < ERROR
+
+
+def test_byte_storage_ranks_like_the_float_storage():
+    """test_byte_storage_hnsw (lib/segment/tests/integration/byte_storage_hnsw_test.rs:39-47, 262-266), its plain-search half for the Uint8 datatype:
+    5 000 vectors of 8 byte-valued coordinates (`random_dense_byte_vector`: 0 ..= 255), cosine; the same points in an f32 segment (normalised at insert)
+    and in a u8 segment (bytes as they are, the cosine taken per pair); 100 nearest queries of the same kind, top 3: the same ids, scores within 1e-3.
+    (Its HNSW half searches under a payload range filter through payload-index sub-graphs: outside the scoring path.)"""
+    rng = np.random.default_rng(42)
+    n, dim, top = 5000, 8, 3
+    raw = np.floor(rng.uniform(0.0, 256.0, (n, dim))).clip(0, 255).astype(np.float32)
+    st_f32 = O.DenseStorage(O.F32, O.COSINE, O.preprocess(O.COSINE, raw))
+    st_u8 = O.DenseStorage(O.U8, O.COSINE, raw.astype(np.uint8))
+    queries = np.floor(rng.uniform(0.0, 256.0, (100, dim))).clip(0, 255).astype(np.float32)
+    a = st_f32.peek_top(queries, top)
+    b = st_u8.peek_top(queries, top)
+    for x, y in zip(a, b):
+        assert x["idx"].tolist() == y["idx"].tolist()
+        assert np.abs(x["score"] - y["score"]).max() < 1e-3
