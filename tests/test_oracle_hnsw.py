@@ -215,3 +215,21 @@ def test_discover_queries_walk_the_graph_like_the_reference_asks():
         same = walked["idx"].tolist() == plain.tolist() and np.array_equal(walked["score"].view(np.uint32), scores[plain].view(np.uint32))
         hits += int(same)
     assert attempts - hits <= max_failures, hits
+
+
+def test_search_on_level_of_a_hand_made_graph():
+    """test_search_on_level (graph_layers.rs:920-978): ten points of 8 coordinates, dot; point 0 links to 1..6 on level 0, nobody else has links; a walk from
+    entry point 0 with ef 32 for the stored vector of point 7 meets exactly point 0 and its six links, every one with the score of (7, that point)."""
+    rng = np.random.default_rng(42)
+    n, dim = 10, 8
+    rows = rng.random((n, dim), dtype=np.float32)
+    st = O.DenseStorage(O.F32, O.DOT, rows)
+    links0 = [[1, 2, 3, 4, 5, 6]] + [[] for _ in range(n - 1)]
+    offsets = np.cumsum([0] + [len(x) for x in links0]).astype(np.uint64)
+    plain = O.PlainLinks(8, 16, reindex=np.arange(n, dtype=np.uint32), level_offsets=np.array([0, n], dtype=np.uint64), offsets=offsets,
+                         neighbors=np.array(sum(links0, []), dtype=np.uint32), ep_ids=[0], ep_levels=[0])
+    graph = O.Hnsw.from_plain(plain, n)
+    got = graph.search_dense(st, rows[7:8], 32, 32)[0]
+    assert sorted(got["idx"].tolist()) == [0, 1, 2, 3, 4, 5, 6]
+    want = st.score_points(rows[7:8], got["idx"])[0]
+    assert np.array_equal(got["score"].view(np.uint32), want.view(np.uint32))
