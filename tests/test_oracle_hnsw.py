@@ -233,3 +233,17 @@ def test_search_on_level_of_a_hand_made_graph():
     assert sorted(got["idx"].tolist()) == [0, 1, 2, 3, 4, 5, 6]
     want = st.score_points(rows[7:8], got["idx"])[0]
     assert np.array_equal(got["score"].view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("threads", [0, 4])
+def test_every_point_has_an_inbound_link(threads):
+    """test_graph_connectivity (hnsw_index/tests/test_graph_connectivity.rs:25-112): 1 000 points of 32 coordinates uniform in -1 .. 1, cosine, m = 16,
+    ef_construct = 100, built on 4 threads there: no point of the level-0 graph is without an inbound link."""
+    rng = np.random.default_rng(5)
+    n, dim = 1000, 32
+    rows = O.preprocess(O.COSINE, rng.uniform(-1.0, 1.0, (n, dim)).astype(np.float32))
+    graph = O.Hnsw(O.DenseStorage(O.F32, O.COSINE, rows), m=16, ef_construct=100, seed=42, threads=threads)
+    inbound = np.zeros(n, dtype=np.int64)
+    for p in range(n):
+        inbound[np.asarray(graph.links(p, 0), dtype=np.int64)] += 1
+    assert (inbound > 0).all(), np.flatnonzero(inbound == 0)[:10]
