@@ -6,7 +6,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fvisi
 CSRC     := qdrant_amd/csrc
 SRCS     := $(wildcard $(CSRC)/*.hip)
 OBJS     := $(patsubst $(CSRC)/%.hip,build/%.o,$(SRCS))
-HDRS     := $(wildcard $(CSRC)/*.hpp) include/qdrant_amd.h
+DEPS     := $(OBJS:.o=.d)
 LIB      := qdrant_amd/libqdrant_amd.so
 # synthetic row generators of bench.py / tools / tests: their own library, not part of the product
 TESTDATA := qdrant_amd/libqmx_testdata.so
@@ -16,9 +16,11 @@ all: $(LIB) $(TESTDATA) oracle
 $(TESTDATA): qdrant_amd/testdata/synth.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -shared -o $@ $<
 
-build/%.o: $(CSRC)/%.hip $(HDRS)
+# (-MMD: every object depends on the headers IT includes - a change to hnsw.hpp rebuilds the walk's translation units, not the scans)
+build/%.o: $(CSRC)/%.hip
 	@mkdir -p build
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) -MMD -MP -c $< -o $@
+-include $(DEPS)
 
 $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)

@@ -69,7 +69,7 @@ def parse():
     ap.add_argument("--cpu-rows", type=int, default=1_000_000, help="rows of the CPU-baseline sample")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--split-copy", choices=["half", "pair", "i8", "none"], default="i8",
+    ap.add_argument("--split-copy", choices=["auto", "half", "pair", "i8", "none"], default="auto",
                     help="which derived copy of the block the prefilter scans (half: f16 high parts, 2 B / element; pair: f16 pairs, 4 B; i8: int8 codes, 1 B; "
                          "none: the f32 block itself)")
     ap.add_argument("--no-hbm-point", action="store_true", help="skip the secondary Q=16 (HBM-bound) measurement of the same scan")
@@ -81,6 +81,8 @@ def parse():
     ap.add_argument("--configs", default="c3,tq,c4", help="comma list of the secondary single-GPU configs to run (empty = none)")
     ap.add_argument("--config-rows", type=int, default=0, help="rows of C3 / C4 (0 = --rows)")
     ap.add_argument("--hnsw-queries", type=int, default=8192, help="searches per launch of the HNSW walks")
+    ap.add_argument("--fanout-rows", type=int, default=1_000_000,
+                    help="rows per segment of the one-process fan-out legs (qmx_sharded_hnsw_build + qmx_sharded_search_topk over one segment per device); 0 = skip")
     return ap.parse_args()
 
 
@@ -139,8 +141,10 @@ def main():
     F.check(lib.qmx_synth_fill_f32(local_rank, row_seed, row0, n, dim, F.ptr(rows)))
     F.check(lib.qmx_preprocess_f32(local_rank, int(qa.Distance.Cosine), F.ptr(rows), n, dim, F.ptr(rows)))
     # (+ the f16-pair copy of the block when batches of more than 64 queries will scan it: scan_split.hip; 4 more bytes per element)
-    copy_flag = {"none": 0, "pair": F.SEG_SPLIT_COPY, "half": F.SEG_HALF_COPY, "i8": F.SEG_I8_COPY}[args.split_copy]
+    copy_flag = {"none": 0, "pair": F.SEG_SPLIT_COPY, "half": F.SEG_HALF_COPY, "i8": F.SEG_I8_COPY, "auto": F.SEG_AUTO_COPY}[args.split_copy]
     storage = qa.VectorStorage(rows, qa.Distance.Cosine, device_id=local_rank, flags=copy_flag)
+    seg_info = storage.info()       # which copy the segment holds (under "auto": the library's own choice, measured at create) and what the trial saw
+    eff_flag = {"i8": F.SEG_I8_COPY, "half": F.SEG_HALF_COPY, "pair": F.SEG_SPLIT_COPY, None: 0}[seg_info["derived_copy"]]
 
     nbatches = max(1, args.nqueries // Q)
     queries = torch.empty((nbatches * Q, dim), dtype=torch.float32, device=dev)
@@ -175,11 +179,19 @@ def main():
     F.check(lib.qmx_query_timing(qh, C.byref(ms0), C.byref(l0)))  # drop warm-up launches
 
     fence()
+    # (the spread of the timed region, without touching it: an event on the stream every `gsz` steps, read after the closing fence)
+    gsz = max(1, args.steps // 10)
+    marks = [torch.cuda.Event(enable_timing=True)]
     t0 = time.perf_counter()
+    marks[0].record(stream)
     for i in range(args.steps):
         step(i)
+        if (i + 1) % gsz == 0:
+            marks.append(torch.cuda.Event(enable_timing=True))
+            marks[-1].record(stream)
     fence()
     elapsed = time.perf_counter() - t0
+    group_ms = [marks[j].elapsed_time(marks[j + 1]) / gsz for j in range(len(marks) - 1)]      # device time per step, per group of gsz steps
 
     kms, kl = C.c_float(), C.c_uint32()
     F.check(lib.qmx_query_timing(qh, C.byref(kms), C.byref(kl)))
@@ -223,14 +235,20 @@ def main():
     result = {
         "metric": "QPS @ recall@10, brute-force, d=%d %s vecs, f32 cosine top-%d" % (dim, _human(args.rows), top),
         "value": round(value, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak",
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        # spread over groups of steps inside the timed region (device time between stream events): standard deviation of the groups' QPS
+        "value_stddev": round(_stddev([Q * (1 if strong else world) / (m * 1e-3) for m in group_ms if m > 0]), 2),
+        "step_groups": {"steps_per_group": gsz, "ms_per_step_min": round(min(group_ms), 4) if group_ms else None,
+                        "ms_per_step_max": round(max(group_ms), 4) if group_ms else None},
+        "higher_is_better": True, "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic", "rccl_ranks": rccl_ranks,
         "config": {"workload": workload,
                    "rows_per_gpu": n, "dim": dim, "batch": Q, "top": top, "distinct_queries": nbatches * Q,
                    "unit_of_value": ("queries per second against the ONE row-split segment" if strong else
                                      "(query, 10M-row segment) searches per second; at n_gpus=1 this is plain QPS"),
                    "collection_qps": round(Q * args.steps / elapsed, 2),
-                   "timed_path": _timed_path(kernel_symbol)},
+                   "timed_path": _timed_path(kernel_symbol),
+                   "derived_copy": dict(seg_info, requested=args.split_copy)},
         "roofline": _roofline(n, dim, kernel_ms, alg_bytes, achieved, int(kl.value), launches_per_step, Q, kernel_symbol, launches_per_pass),
     }
 
@@ -260,7 +278,7 @@ def main():
             result["roofline_hbm_point_q16"] = {"error": repr(e)[:300]}
         finally:
             qa.set_option("no_split_scan", -1)
-    if solo and Q != 256 and copy_flag == F.SEG_HALF_COPY and queries.shape[0] >= 256 and not args.no_hbm_point:
+    if solo and Q != 256 and eff_flag == F.SEG_HALF_COPY and queries.shape[0] >= 256 and not args.no_hbm_point:
         # the same search at 256 queries per step: the 256-query shape of the prefilter (half the copy's bytes per query; issue-bound, not
         # HBM-bound: more queries per second at a lower fraction of either roof)
         try:
@@ -270,11 +288,11 @@ def main():
             result["throughput_point_q256"] = p
         except Exception as e:
             result["throughput_point_q256"] = {"error": repr(e)[:300]}
-    if solo and copy_flag in (F.SEG_I8_COPY, F.SEG_HALF_COPY) and not args.no_other_copy_point and queries.shape[0] >= Q:
+    if solo and eff_flag in (F.SEG_I8_COPY, F.SEG_HALF_COPY) and not args.no_other_copy_point and queries.shape[0] >= Q:
         # the same search over the OTHER derived copy of the block - the f16 half copy (2 B / element, band 1e-3 |q| |row|: the round-2 / round-3
         # headline) when the int8 copy (1 B / element, worst-case band of the two roundings) is the timed one, and vice versa: lists checked against
         # the exact scan inside the leg; a secondary point
-        other = F.SEG_HALF_COPY if copy_flag == F.SEG_I8_COPY else F.SEG_I8_COPY
+        other = F.SEG_HALF_COPY if eff_flag == F.SEG_I8_COPY else F.SEG_I8_COPY
         key = "half_copy_point" if other == F.SEG_HALF_COPY else "int8_copy_point"
         try:
             result[key] = derived_copy_point(other, rows, queries, n, dim, Q, top, local_rank, stream, lib, F, qa, sharded, torch)
@@ -286,10 +304,10 @@ def main():
         for Qs in (1, 8, 32, 128):
             if queries.shape[0] < Qs:
                 continue
-            for track in (("exact", "prefilter") if copy_flag else ("exact",)):
+            for track in (("exact", "prefilter") if eff_flag else ("exact",)):
                 qa.set_option("no_split_scan", 1 if track == "exact" else -1)
                 try:
-                    bpp = None if track == "exact" else n * dim * (1 if copy_flag == F.SEG_I8_COPY else 2 if copy_flag == F.SEG_HALF_COPY else 4)
+                    bpp = None if track == "exact" else n * dim * (1 if eff_flag == F.SEG_I8_COPY else 2 if eff_flag == F.SEG_HALF_COPY else 4)
                     sweep["Q%d_%s" % (Qs, track)] = hbm_point(Qs, storage, queries, n, dim, top, local_rank, stream, lib, F, sharded, torch, bytes_per_pass=bpp, steps=20)
                 except Exception as e:
                     sweep["Q%d_%s" % (Qs, track)] = {"error": repr(e)[:300]}
@@ -309,6 +327,16 @@ def main():
             result["roofline"]["prefilter_per_batch"] = _counters_dict(c, Q)
         except Exception as e:
             result["roofline"]["prefilter_per_batch"] = {"error": repr(e)[:200]}
+    if rank == 0 and args.fanout_rows > 0:
+        # the ONE-PROCESS fan-out behind the C-ABI (what a Rust host that owns all segments of a node calls): index build over independent segments
+        # and the sharded search with its merge, over one segment per visible device of this run (world > 1: the other ranks wait at the barrier
+        # below; a single GPU: two segments on it, which exercises the same code path)
+        try:
+            result["one_process_fanout"] = one_process_fanout(args, world, dim, Q, top, lib, F, qa, torch, np)
+        except Exception as e:
+            result["one_process_fanout"] = {"error": repr(e)[:400]}
+    if world > 1:
+        dist.barrier()
     if solo and not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(args, rows, queries, out, counts, n, dim, Q, top, lib, qh, F, qa, np, torch)
     backend.close()
@@ -352,75 +380,225 @@ def _counters_dict(c, Q):
             "fallback_rate": round(c.fallback_queries / float(pq), 4), "bytes_read": int(c.bytes_read)}
 
 
+def _family_rows(torch, dev, kind, n, dim, seed, out=None, chunk=1_000_000):
+    """Unit rows of the families of DESIGN 3.1e on which the int8 copy's worst-case band is widest: 'student5' (heavy-tailed elements: Student t, 5 degrees
+    of freedom) and 'dominant8' (Gaussian with 8 coordinates twelve times the others).  Generated on the device in chunks (torch's generator: harness only)."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    buf = out if out is not None else torch.empty((n, dim), dtype=torch.float32, device=dev)
+    for r0 in range(0, n, chunk):
+        m = min(chunk, n - r0)
+        x = torch.randn((m, dim), generator=g, device=dev, dtype=torch.float32)
+        if kind == "student5":
+            chi = torch.zeros((m, dim), device=dev, dtype=torch.float32)
+            for _ in range(5):
+                chi += torch.randn((m, dim), generator=g, device=dev, dtype=torch.float32) ** 2
+            x = x / torch.sqrt(chi / 5.0)
+            del chi
+        elif kind == "dominant8":
+            x[:, :8] *= 12.0
+        buf[r0:r0 + m] = x / x.norm(dim=1, keepdim=True)
+    return buf
+
+
+def _robust_leg(buf, qs, flag, Q, top, local_rank, stream, lib, F, qa, sharded, torch, dev, what, check_all=True, deleted=None):
+    """One timed search of `qs` (batches of Q) over `buf` with the derived-copy flag `flag`: QPS, the prefilter's counters per batch, which copy the
+    segment holds (qmx_segment_get_info) and whether every list equals the exact scan's, bit for bit."""
+    st = qa.VectorStorage(buf, qa.Distance.Cosine, device_id=local_rank, flags=flag)
+    if deleted is not None:
+        st.set_deleted(deleted)
+    backend = sharded.HipBackend(st, Q, local_rank, stream)
+    try:
+        o = torch.zeros((Q, top, 2), dtype=torch.int32, device=dev)
+        cn = torch.zeros((Q,), dtype=torch.int32, device=dev)
+        nb = max(1, qs.shape[0] // Q)
+        for i in range(3):
+            backend.local_topk(qs[(i % nb) * Q:(i % nb + 1) * Q], top, o, cn)
+        torch.cuda.synchronize(dev)
+        steps = 20
+        t0 = time.perf_counter()
+        for i in range(steps):
+            backend.local_topk(qs[(i % nb) * Q:(i % nb + 1) * Q], top, o, cn)
+        torch.cuda.synchronize(dev)
+        wall = time.perf_counter() - t0
+        per_batch, same = [], True
+        kernel = F.last_kernel(backend.qh)
+        for b in range(nb if check_all else 1):
+            backend.local_topk(qs[b * Q:(b + 1) * Q], top, o, cn)
+            c = F.Counters()
+            F.check(lib.qmx_query_last_counters(backend.qh, C.byref(c)))
+            per_batch.append(_counters_dict(c, Q))
+            a_o, a_c = o.clone(), cn.clone()
+            qa.set_option("no_split_scan", 1)
+            try:
+                backend.local_topk(qs[b * Q:(b + 1) * Q], top, o, cn)
+                torch.cuda.synchronize(dev)
+            finally:
+                qa.set_option("no_split_scan", -1)
+            same = same and bool(torch.equal(a_o, o) and torch.equal(a_c, cn))
+        nchk = len(per_batch)
+        info = st.info()
+        return {"rows": what, "batch": Q, "qps": round(Q * steps / wall, 1), "ms_per_step": round(wall / steps * 1e3, 4), "kernel": kernel,
+                "copy": info["derived_copy"], "copy_chosen_by_trial": info["chosen_by_trial"], "i8_scale_balance": round(info["i8_scale_balance"], 2),
+                "trial": ({"i8_ms": round(info["trial_i8_ms"], 3), "half_ms": round(info["trial_half_ms"], 3),
+                           "i8_verified_rows_per_query": round(info["trial_i8_verified_rows"], 1),
+                           "i8_fallback_queries": info["trial_i8_fallback_queries"]} if info["chosen_by_trial"] else None),
+                "batches_checked": nchk, "equals_exact_scan_whole_block": same,
+                "candidates_per_query": round(sum(p["candidates_per_query"] for p in per_batch) / nchk, 1),
+                "verified_rows_per_query": round(sum(p["verified_rows_per_query"] for p in per_batch) / nchk, 1),
+                "fallback_queries_per_batch": [p["fallback_queries"] for p in per_batch],
+                "fallback_rate": round(sum(p["fallback_queries"] for p in per_batch) / float(nchk * Q), 4)}
+    finally:
+        backend.close()
+        st.close()
+
+
 def robustness(args, dev, c2_rows, queries_iid, n, dim, Q, top, local_rank, stream, copy_flag, lib, F, qa, sharded, torch):
-    """The timed search (same Q, same copy flag) on rows where scores crowd: (a) the latent rows of C3 (32 latent coordinates + noise, queries
-    from the same model), (b) the iid block with 1 % of its rows overwritten by copies of 1 000 source rows (100 copies each).  Reports QPS, the
-    prefilter's counters per batch (qmx_query_last_counters) and whether every list equals the exact scan's, bit for bit."""
+    """The timed search (same Q) on rows that are not the friendly iid block:
+      (a) the latent rows of C3 (32 latent coordinates + noise, queries from the same model) and (b) the iid block with 1 % of its rows overwritten by
+          copies of 1 000 source rows (100 copies each) - rows where scores crowd -, through the timed copy flag;
+      (c) SURVEY 8(d)'s run with 1 % random deleted bits on the C2 block;
+      (d) the families on which the int8 copy's worst-case band is widest - Student-t(5) elements, 8 dominant coordinates - through the
+          int8 copy, the half copy and QMX_SEG_AUTO_COPY (the library's own choice, measured at create): QPS, fallback rate, verified rows per family
+          and copy, and which copy AUTO kept.
+    Every leg reports whether every list equals the exact scan's, bit for bit."""
     out = {}
     buf = torch.empty((n, dim), dtype=torch.float32, device=dev)
     seed = 0x5EED0003
-    cases = []
+    leg = lambda b, qs, flag, what, **kw: _robust_leg(b, qs, flag, Q, top, local_rank, stream, lib, F, qa, sharded, torch, dev, what, **kw)
+    nqs = max(Q, 256)
     # (a) latent rows + latent queries
     F.check(lib.qmx_synth_fill_latent_f32(local_rank, seed, 0, n, dim, 32, 1.0, F.ptr(buf)))
     F.check(lib.qmx_preprocess_f32(local_rank, int(qa.Distance.Cosine), F.ptr(buf), n, dim, F.ptr(buf)))
-    ql = torch.empty((max(Q, 256), dim), dtype=torch.float32, device=dev)
+    ql = torch.empty((nqs, dim), dtype=torch.float32, device=dev)
     F.check(lib.qmx_synth_fill_latent_f32(local_rank, seed, QUERY_ROW0, ql.shape[0], dim, 32, 1.0, F.ptr(ql)))
-    cases.append(("latent_rows_of_C3", "10M x 768 rows of low intrinsic dimension (32 latent coordinates + noise), queries of the same model", ql))
-    cases.append(("iid_with_1pct_duplicates", "the C2 block with 1 % of its rows overwritten by copies of 1000 source rows (100 copies each); "
-                  "half of the queries are noisy copies of source rows, so their best scores are 100-fold ties", None))
-    for name, what, qs in cases:
-        if qs is None:
-            g = torch.Generator(device="cpu").manual_seed(1234)
-            n_dup = n // 100
-            src = torch.randint(0, n, (1000,), generator=g)
-            dst = torch.randperm(n, generator=g)[:n_dup]
-            buf.copy_(c2_rows)
-            buf[dst.to(dev)] = c2_rows[src.to(dev)].repeat_interleave(n_dup // 1000, dim=0)[:n_dup]
-            qs = queries_iid[:max(Q, 256)].clone()
-            half = qs.shape[0] // 2
-            qs[:half] = c2_rows[src[:half].to(dev)] + 0.02 * qs[:half]
+    torch.cuda.synchronize(dev)
+    out["latent_rows_of_C3"] = leg(buf, ql, copy_flag, "10M x 768 rows of low intrinsic dimension (32 latent coordinates + noise), queries of the same model")
+    # (b) duplicates
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    n_dup = n // 100
+    src = torch.randint(0, n, (1000,), generator=g)
+    dst = torch.randperm(n, generator=g)[:n_dup]
+    buf.copy_(c2_rows)
+    buf[dst.to(dev)] = c2_rows[src.to(dev)].repeat_interleave(n_dup // 1000, dim=0)[:n_dup]
+    qs = queries_iid[:nqs].clone()
+    half = qs.shape[0] // 2
+    qs[:half] = c2_rows[src[:half].to(dev)] + 0.02 * qs[:half]
+    torch.cuda.synchronize(dev)
+    out["iid_with_1pct_duplicates"] = leg(buf, qs, copy_flag, "the C2 block with 1 % of its rows overwritten by copies of 1000 source rows (100 copies each); "
+                                          "half of the queries are noisy copies of source rows, so their best scores are 100-fold ties")
+    # (c) SURVEY 8(d): 1 % random deleted bits on the C2 block itself
+    import numpy as np
+    deleted = np.random.default_rng(77).random(n) < 0.01
+    out["c2_with_1pct_deleted"] = leg(c2_rows, queries_iid[:nqs], copy_flag, "the C2 block with 1 % of its points deleted at random (SURVEY 8d)", deleted=deleted)
+    out["c2_with_1pct_deleted"]["deleted_points"] = int(deleted.sum())
+    # (d) the hard families, every copy + the library's own choice
+    flags = (("int8_copy", F.SEG_I8_COPY), ("half_copy", F.SEG_HALF_COPY), ("auto_copy", F.SEG_AUTO_COPY))
+    for kind, what in (("student5", "10M x 768 unit rows with Student-t(5) elements (heavy tails: column maximum / column spread ~ 25)"),
+                       ("dominant8", "10M x 768 unit Gaussian rows with 8 coordinates twelve times the others (60 % of the score lives on 8 columns)")):
+        _family_rows(torch, dev, kind, n, dim, 0xFA0000 + len(kind), out=buf)
+        qf = _family_rows(torch, dev, kind, nqs, dim, 0xFA1000 + len(kind))
         torch.cuda.synchronize(dev)
-        st = qa.VectorStorage(buf, qa.Distance.Cosine, device_id=local_rank, flags=copy_flag)
-        backend = sharded.HipBackend(st, Q, local_rank, stream)
-        try:
-            o = torch.zeros((Q, top, 2), dtype=torch.int32, device=dev)
-            cn = torch.zeros((Q,), dtype=torch.int32, device=dev)
-            nb = max(1, qs.shape[0] // Q)
-            for i in range(3):
-                backend.local_topk(qs[(i % nb) * Q:(i % nb + 1) * Q], top, o, cn)
-            torch.cuda.synchronize(dev)
-            steps = 20
-            t0 = time.perf_counter()
-            for i in range(steps):
-                backend.local_topk(qs[(i % nb) * Q:(i % nb + 1) * Q], top, o, cn)
-            torch.cuda.synchronize(dev)
-            wall = time.perf_counter() - t0
-            per_batch, same = [], True
-            kernel = F.last_kernel(backend.qh)
-            for b in range(nb):
-                backend.local_topk(qs[b * Q:(b + 1) * Q], top, o, cn)
-                c = F.Counters()
-                F.check(lib.qmx_query_last_counters(backend.qh, C.byref(c)))
-                per_batch.append(_counters_dict(c, Q))
-                a_o, a_c = o.clone(), cn.clone()
-                qa.set_option("no_split_scan", 1)
-                try:
-                    backend.local_topk(qs[b * Q:(b + 1) * Q], top, o, cn)
-                    torch.cuda.synchronize(dev)
-                finally:
-                    qa.set_option("no_split_scan", -1)
-                same = same and bool(torch.equal(a_o, o) and torch.equal(a_c, cn))
-            out[name] = {"rows": what, "batch": Q, "qps": round(Q * steps / wall, 1), "ms_per_step": round(wall / steps * 1e3, 4), "kernel": kernel,
-                         "batches_checked": nb, "equals_exact_scan_whole_block": same,
-                         "candidates_per_query": round(sum(p["candidates_per_query"] for p in per_batch) / nb, 1),
-                         "verified_rows_per_query": round(sum(p["verified_rows_per_query"] for p in per_batch) / nb, 1),
-                         "fallback_queries_per_batch": [p["fallback_queries"] for p in per_batch],
-                         "fallback_rate": round(sum(p["fallback_queries"] for p in per_batch) / float(nb * Q), 4)}
-        finally:
-            backend.close()
-            st.close()
+        fam = {}
+        for name, flag in flags:
+            try:
+                fam[name] = leg(buf, qf, flag, what, check_all=False)
+            except Exception as e:
+                fam[name] = {"error": repr(e)[:300]}
+        ok = [k for k in fam if "qps" in fam[k]]
+        if "auto_copy" in ok and len(ok) == 3:
+            fam["auto_vs_best_fixed"] = round(fam["auto_copy"]["qps"] / max(fam["int8_copy"]["qps"], fam["half_copy"]["qps"]), 3)
+        out[kind] = fam
     del buf
     torch.cuda.empty_cache()
+    return out
+
+
+def one_process_fanout(args, world, dim, Q, top, lib, F, qa, torch, np):
+    """north_star's multi-GPU sentence behind the C-ABI, from ONE host process: `qmx_sharded_hnsw_build` (one host thread per segment inside the
+    library, each on its segment's device: the reference locks one GPU of its pool per segment build, gpu_devices_manager.rs:120-143) and
+    `qmx_sharded_search_topk` (per-device scans enqueued side by side, per-segment lists copied to the first device over xGMI, merged there:
+    segments_searcher.rs:250-285 + search_result_aggregator.rs:50-121).  Segments: `--fanout-rows` x dim f32 cosine each, one per device (two on the
+    only device of a 1-GPU run).  Reports points/s of the build fan-out against the same builds one after the other, and QPS of the sharded search
+    against one segment alone; the merged lists are checked against the per-segment searches merged on the host."""
+    n = args.fanout_rows
+    devs = list(range(world)) if world > 1 else [0, 0]
+    nseg = len(devs)
+    rows, storages = [], []
+    for i, d in enumerate(devs):
+        r = torch.empty((n, dim), dtype=torch.float32, device=torch.device("cuda", d))
+        F.check(lib.qmx_synth_fill_f32(d, 0x5EED0500 + i, 0, n, dim, F.ptr(r)))
+        F.check(lib.qmx_preprocess_f32(d, int(qa.Distance.Cosine), F.ptr(r), n, dim, F.ptr(r)))
+        rows.append(r)
+        storages.append(qa.VectorStorage(r, qa.Distance.Cosine, device_id=d, flags=F.SEG_AUTO_COPY))
+    for d in set(devs):
+        torch.cuda.synchronize(d)
+    out = {"segments": nseg, "devices": sorted(set(devs)), "rows_per_segment": n, "dim": dim}
+    # ---- build fan-out ----
+    kw = dict(m=16, ef_construct=100, seed=42)
+    t0 = time.perf_counter()
+    graphs = qa.GraphLayers.build_sharded(storages, **kw)
+    t_fan = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    g_one = qa.GraphLayers.build(storages[0], **kw)
+    t_one = time.perf_counter() - t0
+    g_one.close()
+    out["build"] = {"what": "qmx_sharded_hnsw_build: HNSW m=16 ef_construct=100 over every segment at once, one host thread per segment",
+                    "seconds": round(t_fan, 3), "points_per_s": round(nseg * n / t_fan, 1),
+                    "one_segment_alone_seconds": round(t_one, 3), "one_segment_alone_points_per_s": round(n / t_one, 1),
+                    "speedup_over_sequential": round(nseg * t_one / t_fan, 3)}
+    # ---- sharded search ----
+    qs = torch.empty((Q, dim), dtype=torch.float32, device=torch.device("cuda", devs[0]))
+    F.check(lib.qmx_synth_fill_f32(devs[0], 0x5EED0501, 0, Q, dim, F.ptr(qs)))
+    torch.cuda.synchronize(devs[0])
+    qh_host = qs.cpu().numpy()
+    handles = []
+    for st in storages:
+        h = C.c_void_p()
+        F.check(lib.qmx_query_create(st._h, F.ptr(qh_host), Q, C.byref(h)))
+        handles.append(h)
+    arr = (C.c_void_p * nseg)(*[h.value for h in handles])
+    bases = np.arange(nseg, dtype=np.uint32) * np.uint32(n)
+    merged = np.zeros((Q, top), dtype=np.dtype([("idx", np.uint32), ("score", np.float32)]))
+    mcnt = np.zeros(Q, dtype=np.uint32)
+    steps = 20
+    for _ in range(3):
+        F.check(lib.qmx_sharded_search_topk(arr, nseg, top, F.ptr(bases), F.ptr(merged), F.ptr(mcnt), None, None))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        F.check(lib.qmx_sharded_search_topk(arr, nseg, top, F.ptr(bases), F.ptr(merged), F.ptr(mcnt), None, None))
+    t_sh = (time.perf_counter() - t0) / steps
+    one = np.zeros_like(merged)
+    ocnt = np.zeros(Q, dtype=np.uint32)
+    for _ in range(3):
+        F.check(lib.qmx_search_topk(handles[0], top, None, 0, F.ptr(one), F.ptr(ocnt), None, None))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        F.check(lib.qmx_search_topk(handles[0], top, None, 0, F.ptr(one), F.ptr(ocnt), None, None))
+    t_1 = (time.perf_counter() - t0) / steps
+    # the merged lists against the per-segment lists merged on the host (descending score, lower global id first among equals)
+    per = []
+    for i, h in enumerate(handles):
+        o = np.zeros_like(merged)
+        c = np.zeros(Q, dtype=np.uint32)
+        F.check(lib.qmx_search_topk(h, top, None, 0, F.ptr(o), F.ptr(c), None, None))
+        o["idx"] += np.uint32(i * n)
+        per.append(o)
+    allp = np.concatenate(per, axis=1)
+    same = True
+    for qi in range(Q):
+        order = np.lexsort((allp[qi]["idx"], -allp[qi]["score"].astype(np.float64)))[:top]
+        same = same and np.array_equal(allp[qi][order], merged[qi])
+    out["search"] = {"what": "qmx_sharded_search_topk: %d segments x %s rows, batch Q=%d, top-%d, host-synchronous (lists back on the host)" % (nseg, _human(n), Q, top),
+                     "ms_per_batch": round(t_sh * 1e3, 4), "qps_collection": round(Q / t_sh, 1), "segment_searches_per_s": round(nseg * Q / t_sh, 1),
+                     "one_segment_alone_ms": round(t_1 * 1e3, 4), "efficiency_vs_one_segment": round(t_1 / t_sh if world > 1 else nseg * t_1 / t_sh, 3),
+                     "merged_equals_host_merge": bool(same)}
+    for h in handles:
+        lib.qmx_query_destroy(h)
+    for g in graphs:
+        g.close()
+    for st in storages:
+        st.close()
+    del rows
     return out
 
 
@@ -592,6 +770,13 @@ def _roofline(n, dim, kernel_ms, alg_bytes, achieved_gbps, launches, launches_pe
     if mfma_frac > hbm_frac:
         return dict({"bound": "mfma", "achieved": round(tflops, 2), "peak": mfma_peak, "unit": "TFLOP/s", "frac": round(mfma_frac, 4)}, **common)
     return dict({"bound": "hbm", "achieved": round(achieved_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(hbm_frac, 4)}, **common)
+
+
+def _stddev(xs):
+    if len(xs) < 2:
+        return 0.0
+    m = sum(xs) / len(xs)
+    return math.sqrt(sum((x - m) ** 2 for x in xs) / (len(xs) - 1))
 
 
 def _timed_path(kernel_symbol):

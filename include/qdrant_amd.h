@@ -133,6 +133,18 @@ typedef struct qmx_counters {
  * whose approximate score lies within one band of it: a few hundred per query.  Results are still the reference's bits; the same per-query exact
  * fallback.  Takes precedence over the two flags above; a block with an element that is not finite gets no int8 copy. */
 #define QMX_SEG_I8_COPY 0x40u
+/* Let the library choose the derived copy for THIS block (takes precedence over the three flags above).  The int8 copy is the fastest where its
+ * worst-case band is narrow (Gaussian-like and low-intrinsic-dimension rows, rows with a few dominant coordinates: the column scales are balanced
+ * for those) and the slowest where it is wide (heavy-tailed elements: most rows inside the band are re-scored, or the lists overflow and the query
+ * pays the prefilter AND the exact scan).  So the choice is measured at create: the int8 copy is built, 128 stored rows (a strided sample: queries
+ * distributed like the rows) are searched through it, and unless they verify few rows each the half copy is built beside it, the same batch is timed
+ * through both and the faster copy stays (the other is freed).  Costs ~50 - 100 ms per 10 M x 768 block on top of the copies' passes; what was
+ * chosen and what the trial measured: qmx_segment_get_info.  Results are the reference's bits either way. */
+#define QMX_SEG_AUTO_COPY 0x80u
+/* PQ blocks of 2^18 rows and more carry a rotated copy of their codes (ceil32(m) bytes per row) that the 8-bit prefilter of batches of 4 and more
+ * queries scans (pq_prefilter.hip).  It is built by default when it at most doubles the codes' footprint (m >= 16); this flag asks for it on narrower
+ * codes too (m = 8: 32 bytes per row beside the 8 of the codes). */
+#define QMX_SEG_PQ_PREFILTER_COPY 0x100u
 
 /* SQ-int8 parameters = `MetadataInt8` (lib/quantization/src/encoded_vectors_u8.rs:84-91).
  * Parity is defined on GIVEN (alpha, offset): the reference's quantile estimate samples
@@ -329,6 +341,21 @@ QMX_API int32_t qmx_segment_set_deleted(qmx_segment *seg, const uint64_t *point_
 QMX_API int32_t qmx_segment_read_rows(const qmx_segment *seg, const uint32_t *ids, uint32_t n,
                                       void *out_rows /* [n][row_bytes] reference layout */);
 QMX_API int32_t qmx_segment_row_bytes(const qmx_segment *seg, uint64_t *out);
+/* What a segment holds beside its rows: the derived copy of an f32 dot / cosine block (QMX_SEG_*_COPY flags) and, under QMX_SEG_AUTO_COPY, what the
+ * trial at create measured.  (The reference's counterpart is the segment telemetry, `VectorIndexSearchesTelemetry` / `SegmentInfo`: which index and
+ * quantization serve a segment is reported, not guessed.) */
+typedef struct qmx_segment_info {
+    uint32_t derived_copy;          /* 0 = none, else ONE of QMX_SEG_I8_COPY / QMX_SEG_HALF_COPY / QMX_SEG_SPLIT_COPY: the copy the prefilter streams */
+    uint32_t chosen_by_trial;       /* 1 = QMX_SEG_AUTO_COPY decided it                                                                            */
+    uint64_t derived_copy_bytes;    /* HBM the copy takes                                                                                          */
+    float i8_scale_balance;         /* int8 copy: the range ratio G the column scales were balanced to (0 = every column at max |x| / 127)         */
+    float trial_i8_ms;              /* AUTO: the 128-query trial batch through the int8 copy, milliseconds (best of three)                         */
+    float trial_half_ms;            /* ... through the half copy (0 = not tried: the int8 trial verified few rows per query)                       */
+    float trial_i8_verified_rows;   /* ... exactly re-scored rows per query of the int8 trial                                                       */
+    uint32_t trial_i8_fallback_queries; /* ... of its 128 queries, how many overflowed their lists and took the exact scan                          */
+    uint32_t reserved;
+} qmx_segment_info;
+QMX_API int32_t qmx_segment_get_info(const qmx_segment *seg, qmx_segment_info *out);
 
 /* ---- Metric::preprocess ---------------------------------------------------------------- */
 
@@ -774,6 +801,19 @@ QMX_API int32_t qmx_hnsw_build(const qmx_segment *seg, const qmx_hnsw_build_para
  * every other dtype it may be NULL and the call equals qmx_hnsw_build. */
 QMX_API int32_t qmx_hnsw_build_quantized(const qmx_segment *quantized, const qmx_segment *original, const qmx_hnsw_build_params *params,
                                          qmx_hnsw **out);
+
+/* Index build over INDEPENDENT segments, fanned out over their devices (north_star: "index build over independent segments shards across the 8 GPUs").
+ * The reference builds one segment's graph per optimizer task, each task locking one GPU of the device pool for the duration of its build
+ * (`GpuDevicesMaganer::lock_device`, index/hnsw_index/gpu/gpu_devices_manager.rs:120-143; the build itself: hnsw/build.rs:53 `build_hnsw_on_gpu`
+ * under the rayon pool of :199,355) - builds of different segments share nothing.  Here: one host thread per segment inside the call, each running
+ * qmx_hnsw_build_quantized(segments[i], originals ? originals[i] : NULL, params, &out_graphs[i]) on its segment's device (`originals` as there:
+ * the f32 segments PQ / TurboQuant segments were encoded from, NULL entries - or a NULL array - where not needed).  Segments may share a
+ * device (their builds then interleave on it) or sit one per device (the 8-GPU node: eight builds side by side, no exchange of any kind).
+ * out_status[i] (may be NULL) receives each build's own status; the call returns the first failure in segment order, or QMX_OK.  Graphs of failed
+ * builds are NULL; the others are complete and owned by the caller whatever the call returned.  Every graph equals what the single call builds
+ * (tests/test_gpu_threads.py: N threads x N graphs on one device == the sequential builds, link for link). */
+QMX_API int32_t qmx_sharded_hnsw_build(const qmx_segment *const *segments, const qmx_segment *const *originals, uint32_t n_segments,
+                                       const qmx_hnsw_build_params *params, qmx_hnsw **out_graphs, int32_t *out_status);
 
 /* The HNSW build over multi-vector points (hnsw/build.rs:334-341 through `FilteredScorer::new_internal`, point_scorer.rs:183-218: every score of
  * the build is `MultiMetricQueryScorer::score_internal`, multi_metric_query_scorer.rs, or for quantized inner rows `score_internal_max_similarity`,

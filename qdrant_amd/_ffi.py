@@ -26,6 +26,8 @@ SEG_BQ_TOGGLE_INVERT = 0x8
 SEG_SPLIT_COPY = 0x10
 SEG_HALF_COPY = 0x20
 SEG_I8_COPY = 0x40
+SEG_AUTO_COPY = 0x80
+SEG_PQ_PREFILTER_COPY = 0x100
 
 
 class ScoredPoint(C.Structure):
@@ -62,6 +64,13 @@ class TqParams(C.Structure):
 
 
 TQ_BITS4, TQ_BITS2, TQ_BITS1_5, TQ_BITS1 = range(4)
+
+
+class SegmentInfo(C.Structure):
+    """qmx_segment_info: the derived copy a segment holds and what the QMX_SEG_AUTO_COPY trial measured."""
+    _fields_ = [("derived_copy", C.c_uint32), ("chosen_by_trial", C.c_uint32), ("derived_copy_bytes", C.c_uint64), ("i8_scale_balance", C.c_float),
+                ("trial_i8_ms", C.c_float), ("trial_half_ms", C.c_float), ("trial_i8_verified_rows", C.c_float), ("trial_i8_fallback_queries", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
 
 class SegmentDesc(C.Structure):
@@ -143,6 +152,7 @@ SIGNATURES = {
     "qmx_segment_set_deleted": (C.c_int32, [_P, _P, C.c_uint64, _P, C.c_uint64]),
     "qmx_segment_read_rows": (C.c_int32, [_P, _P, C.c_uint32, _P]),
     "qmx_segment_row_bytes": (C.c_int32, [_P, C.POINTER(C.c_uint64)]),
+    "qmx_segment_get_info": (C.c_int32, [_P, C.POINTER(SegmentInfo)]),
     "qmx_preprocess_f32": (C.c_int32, [C.c_int32, C.c_uint32, _P, C.c_uint64, C.c_uint32, _P]),
     "qmx_cast_f32": (C.c_int32, [C.c_int32, C.c_uint32, _P, C.c_uint64, _P]),
     "qmx_query_create": (C.c_int32, [_P, _P, C.c_uint32, C.POINTER(_P)]),
@@ -189,6 +199,7 @@ SIGNATURES = {
     "qmx_hnsw_destroy": (C.c_int32, [_P]),
     "qmx_hnsw_build": (C.c_int32, [_P, C.POINTER(HnswBuildParams), C.POINTER(_P)]),
     "qmx_hnsw_build_quantized": (C.c_int32, [_P, _P, C.POINTER(HnswBuildParams), C.POINTER(_P)]),
+    "qmx_sharded_hnsw_build": (C.c_int32, [C.POINTER(_P), C.POINTER(_P), C.c_uint32, C.POINTER(HnswBuildParams), C.POINTER(_P), C.POINTER(C.c_int32)]),
     "qmx_hnsw_get_info": (C.c_int32, [_P, C.POINTER(HnswInfo)]),
     "qmx_hnsw_export_plain": (C.c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qmx_hnsw_search": (C.c_int32, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, _P, C.POINTER(Counters)]),

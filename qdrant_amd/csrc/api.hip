@@ -12,6 +12,8 @@
 #include <algorithm>
 #include <atomic>
 #include <mutex>
+#include <string>
+#include <thread>
 #include <new>
 #include <vector>
 
@@ -48,7 +50,8 @@ int32_t hip_status(hipError_t e, const char *what, const char *file, int line) {
 
 // ---- kernel-path options: the environment is read once, here, at load time ----
 static const char *const g_option_names[OPT_COUNT] = {"no_mfma_scan", "no_mfma16", "no_mfma16_q64", "no_prescan", "prescan_shift", "hnsw_no_packed_l0",
-                                                     "hnsw_pq_lds_lut", "hnsw_log_cap", "bq_lanes8", "mfma_no_nt", "mfma_no_fast", "no_pq_tiled", "no_split_scan", "split_min_queries", "no_split256", "no_pq_pair", "no_pq_prefilter", "pq_prefilter_min_queries", "hnsw_pq_per_cu", "tq_rotate_block", "no_topk_small", "debug"};
+                                                     "hnsw_pq_lds_lut", "hnsw_log_cap", "bq_lanes8", "mfma_no_nt", "mfma_no_fast", "no_pq_tiled", "no_split_scan", "split_min_queries", "no_split256", "no_pq_pair", "no_pq_prefilter", "pq_prefilter_min_queries", "hnsw_pq_per_cu", "tq_rotate_block", "no_topk_small", "verify_max_per_query", "no_hnsw_pq_block",
+                                                     "hnsw_pq_block_waves", "debug"};
 struct OptionTable {
     std::atomic<int64_t> v[OPT_COUNT];
     int64_t initial[OPT_COUNT];
@@ -190,6 +193,11 @@ struct qmx_segment {
     bool split_i8 = false;            // QMX_SEG_I8_COPY: d_rows_split holds int8 codes instead (scan_split.hip, "The INT8 copy")
     float *d_i8_scale = nullptr;      // ... the columns' scales [dim]
     uint32_t *d_i8_stats = nullptr;   // ... {C1, C2^2, -, -}: the worst row's sum |c| and sum c^2
+    float i8_balance = 0.0f;          // ... the range ratio G the scales were balanced to (0 = every column at its floor max |x| / 127)
+    uint64_t copy_bytes = 0;          // bytes of d_rows_split
+    bool auto_choice = false;         // QMX_SEG_AUTO_COPY: the copy was chosen by the trial of segment_auto_copy; what it measured:
+    float auto_i8_ms = 0.0f, auto_half_ms = 0.0f, auto_i8_verified = 0.0f;
+    uint32_t auto_i8_fallback = 0;
 
     bool fast_layout() const {
         if (dtype == QMX_DTYPE_BQ || dtype == QMX_DTYPE_TQ) return row_stride % 16 == 0 && ((uintptr_t)d_rows % 16) == 0;
@@ -245,6 +253,7 @@ struct qmx_query {
     DevBuf sh_lists, sh_out;   // qmx_sharded_*: the segments' lists gathered on this (the first) batch's device, the merged lists of a host-output call
     std::vector<uint32_t> sh_bases_host;
     hipEvent_t sh_done = nullptr;   // "this segment's list arrived on the merging device"
+    hipEvent_t sh_merged = nullptr; // (root batch) "the merge of the previous sharded call has read the shared lists": the segments' next copies into them wait for it
     DevBuf pq_table;           // PQ prefilter: the 6-bit tables of the tile's query groups, their integer thresholds behind them
     DevBuf sp_probe, sp_pscores;   // the int8 copy's passes: [nq][64] probe ids + [nq] counts, their exact scores
     DevBuf sp_plan, sp_fq;     // ... the per-query overflow flags + the plan of the conditional exact passes (SplitPlanLayout), the overflowed queries packed
@@ -383,7 +392,7 @@ static uint32_t pow2_ceil(uint32_t x) {
 // ---------------------------------------------------------------------------------------------
 extern "C" {
 
-uint32_t qmx_abi_version(void) { return 4; }
+uint32_t qmx_abi_version(void) { return 5; }
 
 static int option_index(const char *name) {
     if (!name) return -1;
@@ -527,20 +536,172 @@ static int32_t segment_upload(qmx_segment *s, const qmx_segment_desc *desc) {
 
 // PQ blocks large enough for the 6-bit prefilter (pq_prefilter.hip): the rotated copy of the codes, m_pad bytes per row next to the m of the block
 // (10 M x 96: 0.96 GB, one pass).  Out of memory is not an error: the exact kernel serves.
+// The rotated copy of a PQ block's codes that the 8-bit prefilter scans (pq_prefilter.hip): ceil32(m) bytes per row beside the m-byte codes.  Built where
+// it pays and costs little: blocks of 2^18 rows and more, at most twice the codes' own size (m >= 16: an m = 8 block would grow five-fold for it; opt in
+// with QMX_SEG_PQ_PREFILTER_COPY).  Out of memory or a failed pass is not an error: the exact kernel serves every batch size.
 static int32_t segment_pq_rot(qmx_segment *s) {
     if (s->dtype != QMX_DTYPE_PQ || s->n < (1u << 18) || !pq_prefilter_shape_ok(s->pq_m, s->pq.n_centroids) || option(OPT_NO_PQ_PREFILTER)) return QMX_OK;
+    const uint32_t m_pad = (s->pq_m + 31u) & ~31u;
+    if (m_pad > 2 * s->pq_m && !(s->flags & QMX_SEG_PQ_PREFILTER_COPY)) return QMX_OK;
     if (hipMalloc(&s->d_pq_rot, pq_rot_bytes(s->n, s->pq_m)) != hipSuccess) {
         (void)hipGetLastError();
         s->d_pq_rot = nullptr;
         return QMX_OK;
     }
-    QMX_TRY(launch_pq_rotate(nullptr, s->d_rows, s->row_stride, s->n, s->pq_m, s->d_pq_rot));
-    QMX_HIP(hipDeviceSynchronize());
+    if (launch_pq_rotate(nullptr, s->d_rows, s->row_stride, s->n, s->pq_m, s->d_pq_rot) != QMX_OK || hipDeviceSynchronize() != hipSuccess) {
+        (void)hipGetLastError();
+        ::qmx::clear_stale_error();
+        (void)hipFree(s->d_pq_rot);
+        s->d_pq_rot = nullptr;
+    }
     return QMX_OK;
 }
 
 // one pass over an f32 dot / cosine block that the split prefilter may serve: the power-of-two scale of its rows and the norm bound of
 // the verification band (4.5 ms per 30 GB; nothing for other storages)
+// ---- derived copies of an f32 dot / cosine block (scan_split.hip): what the prefilters stream instead of the f32 rows ----
+static void segment_drop_copy(qmx_segment *s) {
+    if (s->d_rows_split) (void)hipFree(s->d_rows_split);
+    if (s->d_i8_scale) (void)hipFree(s->d_i8_scale);
+    if (s->d_i8_stats) (void)hipFree(s->d_i8_stats);
+    s->d_rows_split = nullptr;
+    s->d_i8_scale = nullptr;
+    s->d_i8_stats = nullptr;
+    s->split_i8 = false;
+    s->split_half = false;
+    s->copy_bytes = 0;
+    (void)hipGetLastError();
+}
+static bool segment_i8_eligible(const qmx_segment *s) { return s->split_stats && split_i8_dim_ok(s->dim) && mfma16_dim_ok(64, s->dim); }    // (dims the prefilter path serves: search_enqueue)
+static bool segment_f16_eligible(const qmx_segment *s) { return s->split_stats && s->dim % 128 == 0; }
+// the int8 copy: column maxima / sums of squares (one pass), the scales (host: split_i8_choose_scales), the worst row's code norms under them (a second
+// pass), the codes (a third).  false: out of memory, or an element that is not finite - no copy is left behind
+static bool segment_build_i8(qmx_segment *s) {
+    uint32_t *d_colmax = nullptr;
+    float *d_colsq = nullptr;
+    uint32_t h[4] = {0, 0, 1, 0};
+    std::vector<float> colmax(s->dim), colsq(s->dim), scale(s->dim);
+    bool ok = hipMalloc((void **)&d_colmax, (size_t)s->dim * 4) == hipSuccess && hipMalloc((void **)&d_colsq, (size_t)s->dim * 4) == hipSuccess &&
+              hipMalloc((void **)&s->d_i8_scale, (size_t)s->dim * 4) == hipSuccess && hipMalloc((void **)&s->d_i8_stats, 16) == hipSuccess;
+    if (ok) ok = launch_split_i8_colstats(nullptr, s->d_rows, s->row_stride, s->n, s->dim, d_colmax, d_colsq) == QMX_OK &&
+                 hipMemcpy(colmax.data(), d_colmax, (size_t)s->dim * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+                 hipMemcpy(colsq.data(), d_colsq, (size_t)s->dim * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    if (ok) {
+        s->i8_balance = split_i8_choose_scales(colmax.data(), colsq.data(), s->n, s->dim, scale.data());
+        ok = hipMemcpy(s->d_i8_scale, scale.data(), (size_t)s->dim * 4, hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if (ok) ok = launch_split_i8_rowstats(nullptr, s->d_rows, s->row_stride, s->n, s->dim, s->d_i8_scale, s->d_i8_stats) == QMX_OK &&
+                 hipMemcpy(h, s->d_i8_stats, 16, hipMemcpyDeviceToHost) == hipSuccess && h[2] == 0;
+    if (ok) ok = hipMalloc(&s->d_rows_split, split_i8_copy_bytes(s->n, s->dim)) == hipSuccess;
+    if (ok) ok = launch_split_i8_copy(nullptr, s->d_rows, s->row_stride, s->n, s->dim, s->d_i8_scale, s->d_rows_split) == QMX_OK &&
+                 hipDeviceSynchronize() == hipSuccess;
+    if (d_colmax) (void)hipFree(d_colmax);
+    if (d_colsq) (void)hipFree(d_colsq);
+    (void)hipGetLastError();
+    if (!ok) {
+        segment_drop_copy(s);
+        return false;
+    }
+    s->split_i8 = true;
+    s->copy_bytes = split_i8_copy_bytes(s->n, s->dim);
+    return true;
+}
+// the f16 copies (one pass: read 4 B, write 4 or 2 B per element).  Out of memory is not an error: the converting kernel serves
+static int32_t segment_build_f16(qmx_segment *s, bool half) {
+    s->split_half = half;
+    if (hipMalloc(&s->d_rows_split, split_copy_bytes(s->n, s->dim, half)) != hipSuccess) {
+        (void)hipGetLastError();
+        s->d_rows_split = nullptr;
+        s->split_half = false;
+        return QMX_OK;
+    }
+    QMX_TRY(launch_split_copy(nullptr, s->d_rows, s->row_stride, s->n, s->dim, split_row_scale(s->row_maxabs), s->d_rows_split, half));
+    QMX_HIP(hipDeviceSynchronize());
+    s->copy_bytes = split_copy_bytes(s->n, s->dim, half);
+    return QMX_OK;
+}
+
+// QMX_SEG_AUTO_COPY: which copy serves THIS block is measured, not guessed.  The int8 copy halves the half copy's bytes per query but its band is a
+// worst-case bound that scales with sum_i |q_i| max_r |x_ri|: on rows with heavy-tailed elements more rows fall inside it than the verification is
+// worth (or than its lists take: the query then pays the prefilter AND the exact scan).  So: build the int8 copy, search 128 stored rows (a strided
+// sample of the block: queries distributed like the rows) for their 10 nearest through it, read the counters; a block whose queries verify few rows
+// keeps it without further ado, any other gets the half copy built beside it, the same batch is timed through both, and the faster one stays.
+constexpr uint32_t AUTO_TRIAL_QUERIES = 128, AUTO_TRIAL_TOP = 10, AUTO_EASY_VERIFIED = 1024;
+static int32_t auto_trial(qmx_segment *s, const float *d_trial_queries, float *ms_out, qmx_counters *c_out) {
+    qmx_query *q = nullptr;
+    QMX_TRY(qmx_query_create(s, d_trial_queries, AUTO_TRIAL_QUERIES, &q));
+    std::vector<qmx_scored_point> out((size_t)AUTO_TRIAL_QUERIES * AUTO_TRIAL_TOP);
+    std::vector<uint32_t> counts(AUTO_TRIAL_QUERIES);
+    int32_t rc = QMX_OK;
+    float best = 3.0e38f;
+    for (int rep = 0; rep < 3 && rc == QMX_OK; ++rep) {            // (the first run pays the scratch allocations: the best of three is the step)
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) rc = QMX_ERR_OTHER;
+        if (rc == QMX_OK && hipEventRecord(e0, q->stream) != hipSuccess) rc = QMX_ERR_OTHER;
+        if (rc == QMX_OK) rc = qmx_search_topk(q, AUTO_TRIAL_TOP, nullptr, 0, out.data(), counts.data(), nullptr, c_out);
+        if (rc == QMX_OK && (hipEventRecord(e1, q->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)) rc = QMX_ERR_OTHER;
+        float ms = 0.0f;
+        if (rc == QMX_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best) best = ms;
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+    if (rc == QMX_OK) rc = qmx_query_last_counters(q, c_out);
+    qmx_query_destroy(q);
+    *ms_out = best;
+    return rc;
+}
+static int32_t segment_auto_copy(qmx_segment *s) {
+    s->auto_choice = true;
+    if (!segment_i8_eligible(s) || !segment_build_i8(s)) {
+        if (segment_f16_eligible(s)) QMX_TRY(segment_build_f16(s, true));
+        return QMX_OK;
+    }
+    // the trial batch: rows n / 256, 3 n / 256, ... (stored rows are preprocessed: the query path normalises them again - a no-op up to round-off)
+    float *d_tq = nullptr;
+    if (hipMalloc((void **)&d_tq, (size_t)AUTO_TRIAL_QUERIES * s->dim * 4) != hipSuccess) {
+        (void)hipGetLastError();
+        return QMX_OK;                                                  // (no room for a trial: the int8 copy stays, its fallback is exact whatever happens)
+    }
+    const uint64_t step = s->n / AUTO_TRIAL_QUERIES;
+    bool ok = true;
+    for (uint32_t i = 0; i < AUTO_TRIAL_QUERIES && ok; ++i)
+        ok = hipMemcpyAsync(d_tq + (size_t)i * s->dim, (const unsigned char *)s->d_rows + (step * i + step / 2) * s->row_stride, (size_t)s->dim * 4,
+                            hipMemcpyDeviceToDevice, nullptr) == hipSuccess;
+    ok = ok && hipDeviceSynchronize() == hipSuccess;
+    qmx_counters c_i8{}, c_half{};
+    int32_t rc = ok ? auto_trial(s, d_tq, &s->auto_i8_ms, &c_i8) : QMX_ERR_OTHER;
+    if (rc == QMX_OK) {
+        s->auto_i8_verified = (float)c_i8.verified_rows / (float)AUTO_TRIAL_QUERIES;
+        s->auto_i8_fallback = c_i8.fallback_queries;
+        const bool easy = c_i8.fallback_queries == 0 && c_i8.verified_rows <= (uint64_t)AUTO_EASY_VERIFIED * AUTO_TRIAL_QUERIES;
+        if (!easy && segment_f16_eligible(s)) {
+            // the half copy beside it: park the int8 copy, build, time, keep the faster
+            void *i8_rows = s->d_rows_split;
+            float *i8_scale = s->d_i8_scale;
+            uint32_t *i8_stats = s->d_i8_stats;
+            const uint64_t i8_bytes = s->copy_bytes;
+            s->d_rows_split = nullptr; s->d_i8_scale = nullptr; s->d_i8_stats = nullptr; s->split_i8 = false;
+            rc = segment_build_f16(s, true);
+            if (rc == QMX_OK && s->d_rows_split) rc = auto_trial(s, d_tq, &s->auto_half_ms, &c_half);
+            const bool half_wins = rc == QMX_OK && s->d_rows_split && s->auto_half_ms < s->auto_i8_ms;
+            if (half_wins) {
+                (void)hipFree(i8_rows); (void)hipFree(i8_scale); (void)hipFree(i8_stats);
+            } else {
+                if (s->d_rows_split) (void)hipFree(s->d_rows_split);
+                s->d_rows_split = i8_rows; s->d_i8_scale = i8_scale; s->d_i8_stats = i8_stats; s->split_i8 = true; s->split_half = false;
+                s->copy_bytes = i8_bytes;
+                if (rc != QMX_OK) { rc = QMX_OK; ::qmx::clear_stale_error(); }    // (the half copy could not be tried: the int8 copy serves)
+            }
+        }
+    } else {
+        rc = QMX_OK;                                                    // (a trial that could not run decides nothing: the int8 copy stays)
+        ::qmx::clear_stale_error();
+    }
+    (void)hipFree(d_tq);
+    (void)hipGetLastError();
+    return rc;
+}
+
 static int32_t segment_split_stats(qmx_segment *s) {
     if (s->dtype != QMX_DTYPE_F32 || (s->distance != QMX_DISTANCE_DOT && s->distance != QMX_DISTANCE_COSINE) || s->dim % 32 != 0 ||
         s->n < (1u << 18) || !s->fast_layout())
@@ -559,39 +720,11 @@ static int32_t segment_split_stats(qmx_segment *s) {
     memcpy(&mss, &h[1], 4);
     s->row_norm_max = sqrtf(mss);
     s->split_stats = s->row_maxabs > 0.f && s->row_maxabs < 3.0e38f && s->row_norm_max < 3.0e38f;   // (NaN / inf rows: the exact scan only)
-    if (s->split_stats && (s->flags & QMX_SEG_I8_COPY) && split_i8_dim_ok(s->dim) && mfma16_dim_ok(64, s->dim)) {      // (dims the prefilter path serves: search_enqueue)
-        // the int8 copy: column scales and the worst row's code norms (two passes over the block), then the codes (a third).  Out of memory, or an
-        // element that is not finite: no copy, the other flags (if any) apply.
-        uint32_t *d_colmax = nullptr;
-        uint32_t h[4] = {0, 0, 1, 0};
-        bool ok = hipMalloc((void **)&d_colmax, (size_t)s->dim * 4) == hipSuccess && hipMalloc((void **)&s->d_i8_scale, (size_t)s->dim * 4) == hipSuccess &&
-                  hipMalloc((void **)&s->d_i8_stats, 16) == hipSuccess;
-        if (ok) ok = launch_split_i8_stats(nullptr, s->d_rows, s->row_stride, s->n, s->dim, d_colmax, s->d_i8_scale, s->d_i8_stats) == QMX_OK &&
-                     hipMemcpy(h, s->d_i8_stats, 16, hipMemcpyDeviceToHost) == hipSuccess && h[2] == 0;
-        if (ok) ok = hipMalloc(&s->d_rows_split, split_i8_copy_bytes(s->n, s->dim)) == hipSuccess;
-        if (ok) ok = launch_split_i8_copy(nullptr, s->d_rows, s->row_stride, s->n, s->dim, s->d_i8_scale, s->d_rows_split) == QMX_OK &&
-                     hipDeviceSynchronize() == hipSuccess;
-        if (d_colmax) (void)hipFree(d_colmax);
-        (void)hipGetLastError();
-        if (ok) {
-            s->split_i8 = true;
-            return QMX_OK;
-        }
-        if (s->d_rows_split) (void)hipFree(s->d_rows_split);
-        s->d_rows_split = nullptr;
-    }
-    if (s->split_stats && (s->flags & (QMX_SEG_SPLIT_COPY | QMX_SEG_HALF_COPY)) && s->dim % 128 == 0) {
-        // the derived copy (one pass: read 4 B, write 4 or 2 B per element).  Out of memory is not an error: the converting kernel serves.
-        s->split_half = (s->flags & QMX_SEG_HALF_COPY) != 0;
-        if (hipMalloc(&s->d_rows_split, split_copy_bytes(s->n, s->dim, s->split_half)) != hipSuccess) {
-            (void)hipGetLastError();
-            s->d_rows_split = nullptr;
-            s->split_half = false;
-        } else {
-            QMX_TRY(launch_split_copy(nullptr, s->d_rows, s->row_stride, s->n, s->dim, split_row_scale(s->row_maxabs), s->d_rows_split, s->split_half));
-            QMX_HIP(hipDeviceSynchronize());
-        }
-    }
+    if (!s->split_stats) return QMX_OK;
+    if (s->flags & QMX_SEG_AUTO_COPY) return segment_auto_copy(s);
+    // an explicit flag: that copy; where it cannot be built (dims, memory, an element that is not finite) the other flags (if any) apply
+    if ((s->flags & QMX_SEG_I8_COPY) && segment_i8_eligible(s) && segment_build_i8(s)) return QMX_OK;
+    if ((s->flags & (QMX_SEG_SPLIT_COPY | QMX_SEG_HALF_COPY)) && segment_f16_eligible(s)) return segment_build_f16(s, (s->flags & QMX_SEG_HALF_COPY) != 0);
     return QMX_OK;
 }
 
@@ -1116,6 +1249,20 @@ int32_t qmx_segment_row_bytes(const qmx_segment *seg, uint64_t *out) {
     return QMX_OK;
 }
 
+int32_t qmx_segment_get_info(const qmx_segment *seg, qmx_segment_info *out) {
+    QMX_REQUIRE(seg && out, QMX_ERR_BAD_ARG, "NULL argument");
+    memset(out, 0, sizeof(*out));
+    out->derived_copy = !seg->d_rows_split ? 0u : seg->split_i8 ? QMX_SEG_I8_COPY : seg->split_half ? QMX_SEG_HALF_COPY : QMX_SEG_SPLIT_COPY;
+    out->chosen_by_trial = seg->auto_choice ? 1u : 0u;
+    out->derived_copy_bytes = seg->d_rows_split ? seg->copy_bytes : 0;
+    out->i8_scale_balance = seg->split_i8 ? seg->i8_balance : 0.0f;
+    out->trial_i8_ms = seg->auto_i8_ms;
+    out->trial_half_ms = seg->auto_half_ms;
+    out->trial_i8_verified_rows = seg->auto_i8_verified;
+    out->trial_i8_fallback_queries = seg->auto_i8_fallback;
+    return QMX_OK;
+}
+
 int32_t qmx_segment_read_rows(const qmx_segment *seg, const uint32_t *ids, uint32_t n, void *out_rows) {
     QMX_REQUIRE(seg && (n == 0 || (ids && out_rows)), QMX_ERR_BAD_ARG, "NULL argument");
     QMX_HIP(hipSetDevice(seg->device));
@@ -1390,6 +1537,7 @@ int32_t qmx_query_destroy(qmx_query *q) {
     q->cq_multi.release();
     q->sp_bq.release(); q->sp_f32.release(); q->sp_cand.release(); q->sp_cnt.release(); q->sp_ver.release(); q->sp_vscores.release(); q->sp_sample.release(); q->sp_wl.release(); q->xcnt.release(); q->tq_rot.release(); q->sp_plan.release(); q->sp_fq.release(); q->sp_probe.release(); q->sp_pscores.release(); q->pq_table.release(); q->sh_lists.release(); q->sh_out.release();
     if (q->sh_done) (void)hipEventDestroy(q->sh_done);
+    if (q->sh_merged) (void)hipEventDestroy(q->sh_merged);
     q->cand.release();
     q->cand_cnt.release();
     q->cand_ids.release();
@@ -1672,9 +1820,11 @@ static int32_t split_stage(qmx_query *q, const char *what) {
 
 constexpr uint32_t SPLIT_QT = 128;          // queries per pass of the split prefilter (scan_split.hip) ...
 constexpr uint32_t SPLIT_QT_MAX = 256;      // ... and of its 256-query shape over a half copy (batches of more than 128 queries)
-constexpr uint32_t SPLIT_CAND_CAP = 32768;  // candidate keys per query and pass (expected: ~1000 k)
-constexpr uint32_t SPLIT_VCAP = 2048;       // rows per query that get an exact score (expected: ~k; the one-product mode's band holds ~60 on iid rows, more where
-                                            // scores crowd: 2048 rows x 3 KiB are 6 MB of gathers per query, still far below its share of a block pass)
+constexpr uint32_t SPLIT_CAND_CAP = 131072; // candidate keys per query and pass (expected: ~1000 k; heavy-tailed rows under the int8 band: tens of thousands)
+constexpr uint32_t SPLIT_VCAP = 16384;      // rows that get an exact score, per query of the batch ON AVERAGE: the batch shares one pool (verify_pool) from which a query
+                                            // takes what it needs (expected: ~k; the one-product mode's band holds ~60 on iid rows, the int8 band ~100 on Gaussian rows,
+                                            // thousands - with a long tail over the queries - where a few coordinates dominate): 16384 rows x 3 KiB are 50 MB of
+                                            // gathers - a 128-query batch that fills the pool gathers a fifth of a block pass; beyond that the exact scan is cheaper
 constexpr uint32_t SPLIT_FQT = 64;          // queries per conditional exact pass behind the prefilter (one 16-query pass instead when 1..16 overflowed)
 // device block behind qmx_query::sp_plan: what the prefilter of one search did and which of its queries take the exact scan after all
 struct SplitPlanLayout {
@@ -1692,6 +1842,23 @@ struct SplitPlanLayout {
         bytes = gthr_packed + (size_t)list_cap * 8;
     }
 };
+// the verification pool of a search (kernels.hpp VerifyPool): SPLIT_VCAP entries per query of the batch, shared - behind qmx_query::sp_ver as
+// [ids: cap][qsel: cap][off: nq][cnt: nq], exact scores in sp_vscores, the fill level in the plan block (byte 24: zeroed with it at the start of a search)
+static int32_t verify_pool(qmx_query *q, unsigned char *plan, VerifyPool *vp) {
+    const uint32_t cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((uint64_t)q->nq * SPLIT_VCAP, 262144), 1u << 26);
+    QMX_TRY(q->sp_ver.reserve(((size_t)cap * 2 + (size_t)q->nq * 2) * 4));
+    QMX_TRY(q->sp_vscores.reserve((size_t)cap * 4));
+    uint32_t *b = (uint32_t *)q->sp_ver.p;
+    vp->ids = b;
+    vp->qsel = b + cap;
+    vp->off = b + (size_t)2 * cap;
+    vp->cnt = vp->off + q->nq;
+    vp->used = (uint32_t *)(plan + 24);
+    vp->cap = cap;
+    const int64_t mx = option(OPT_VERIFY_MAX_PER_QUERY);
+    vp->max_per_query = mx > 0 ? (uint32_t)std::min<int64_t>(mx, cap) : cap;
+    return QMX_OK;
+}
 // |approximate - exact| <= band * |q| * max |row|, worst case, every term at its bound:
 //   one product of f16-rounded operands (HALF copy): each operand within 2^-11 of its value -> (2^-10 + 2^-22) sum |q_i r_i| <= ... |q| |r|
 //   three products of f16 pairs: x - (h + l) within 2^-22 |x|, the dropped l.l term 2^-22                    -> 3 * 2^-22
@@ -1730,10 +1897,10 @@ static int32_t pq_prefilter_enqueue(qmx_query *q, uint32_t top, uint64_t n_cand,
         for (uint32_t t = 4; t <= tile_max; t += 4) g = std::max(g, pq_prefilter_grid(s->num_cus, t, nullptr));
         QMX_TRY(q->sp_wl.reserve(pq_prefilter_wlists_bytes(g, PQF_WCAP)));
     }
-    QMX_TRY(q->sp_ver.reserve((size_t)q->nq * (SPLIT_VCAP + 1) * 4));
-    QMX_TRY(q->sp_vscores.reserve((size_t)q->nq * SPLIT_VCAP * 4));
     QMX_TRY(q->sp_plan.reserve(pl.bytes));
     unsigned char *plan = (unsigned char *)q->sp_plan.p;
+    VerifyPool vp;
+    QMX_TRY(verify_pool(q, plan, &vp));
     float *band = (float *)q->sp_f32.p;                       // [PQF_TILE] in units of the integer score
     q->last_counters = qmx_counters{};
     q->last_split = false;
@@ -1750,7 +1917,6 @@ static int32_t pq_prefilter_enqueue(qmx_query *q, uint32_t top, uint64_t n_cand,
     }
     const uint32_t *d_sample = (const uint32_t *)q->sp_sample.p;
     QMX_HIP(hipMemsetAsync(plan, 0, pl.zero_bytes, q->stream));
-    uint32_t *ver_all = (uint32_t *)q->sp_ver.p, *cnt_all = ver_all + (size_t)q->nq * SPLIT_VCAP;
     uint32_t n_tiles = 0, launches = 0;
     for (uint32_t tile0 = 0; tile0 < q->nq; tile0 += PQF_TILE, ++n_tiles) {
         const uint32_t nq_tile = std::min<uint32_t>(PQF_TILE, q->nq - tile0);
@@ -1795,15 +1961,15 @@ static int32_t pq_prefilter_enqueue(qmx_query *q, uint32_t top, uint64_t n_cand,
         int *tile_ovf = (int *)(plan + pl.tile_ovf) + n_tiles;
         QMX_TRY(launch_regroup_lists(q->stream, a.del, (const unsigned char *)q->sp_wl.p + pq_prefilter_wlists_counts_bytes(grid), (const uint32_t *)q->sp_wl.p, PQF_WCAP,
                                      grid * 16, (uint64_t *)q->sp_cand.p, (uint32_t *)q->sp_cnt.p, SPLIT_CAND_CAP, tile_ovf));
-        QMX_TRY(launch_split_select(q->stream, (const uint64_t *)q->sp_cand.p, (const uint32_t *)q->sp_cnt.p, SPLIT_CAND_CAP, band, nq_tile, top, SPLIT_VCAP,
-                                    ver_all + (size_t)tile0 * SPLIT_VCAP, cnt_all + tile0, tile_ovf, (uint32_t *)(plan + pl.ovf_q) + tile0, (SplitStats *)plan));
+        QMX_TRY(launch_split_select(q->stream, (const uint64_t *)q->sp_cand.p, (const uint32_t *)q->sp_cnt.p, SPLIT_CAND_CAP, band, nq_tile, top, vp, tile0,
+                                    tile_ovf, (uint32_t *)(plan + pl.ovf_q) + tile0, (SplitStats *)plan));
         launches += 6;
     }
     const void *pf_kernel = q->last_kernel;
     // 5. exact scores of the survivors (pq_pair_kernel: score_point_sse's order), sorted by (score, lower id first)
-    PairSel sel{nullptr, SPLIT_VCAP, cnt_all};
-    QMX_TRY(score_pairs_device(q, sel, ver_all, (uint64_t)q->nq * SPLIT_VCAP, (float *)q->sp_vscores.p, false));
-    QMX_TRY(launch_sort_scored(q->stream, (const float *)q->sp_vscores.p, ver_all, cnt_all, SPLIT_VCAP, q->nq, top, d_out, d_counts));
+    PairSel sel{vp.qsel, 0, nullptr, vp.used};
+    QMX_TRY(score_pairs_device(q, sel, vp.ids, vp.cap, (float *)q->sp_vscores.p, false));
+    QMX_TRY(launch_sort_scored(q->stream, (const float *)q->sp_vscores.p, vp.ids, vp.cnt, 0, q->nq, top, d_out, d_counts, vp.off));
     // 6. the exact scan of the queries whose lists overflowed, and of those only (the kernels start, read the count and return when it is zero)
     uint32_t *ovf_list = (uint32_t *)(plan + pl.list);
     QMX_TRY(launch_split_plan(q->stream, (const uint32_t *)(plan + pl.ovf_q), q->nq, (const uint64_t *)q->gthr.p, ovf_list, (uint64_t *)(plan + pl.gthr_packed),
@@ -1901,6 +2067,7 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
     float *sp_qnorm = nullptr, *sp_thr = nullptr, *sp_band = nullptr, *sp_scales = nullptr, *sp_qmax = nullptr;
     const SplitPlanLayout pl(q->nq);
     unsigned char *plan = nullptr;
+    VerifyPool vp{};
     q->last_counters = qmx_counters{};
     q->last_split = false;
     if (split) {
@@ -1909,9 +2076,8 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
         QMX_TRY(q->sp_cand.reserve((size_t)split_qt * SPLIT_CAND_CAP * sizeof(uint64_t)));
         QMX_TRY(q->sp_cnt.reserve((size_t)SPLIT_QT_MAX * 4));
         if (s->d_rows_split) QMX_TRY(q->sp_wl.reserve(split_wlists_bytes(s->num_cus)));
-        QMX_TRY(q->sp_ver.reserve((size_t)q->nq * (SPLIT_VCAP + 1) * 4));
-        QMX_TRY(q->sp_vscores.reserve((size_t)q->nq * SPLIT_VCAP * 4));
         QMX_TRY(q->sp_plan.reserve(pl.bytes));
+        QMX_TRY(verify_pool(q, (unsigned char *)q->sp_plan.p, &vp));
         QMX_TRY(q->sp_fq.reserve((size_t)pl.list_cap * q->q_stride));
         if (s->split_i8) {
             QMX_TRY(q->sp_probe.reserve((size_t)q->nq * (split_i8_probe() + 1) * 4));
@@ -1989,10 +2155,8 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
                 }
                 QMX_TRY(split_stage(q, "int8 scan"));
                 // 4'. the rows worth an exact score: approximate score >= T_exact - band
-                uint32_t *ver_ids = (uint32_t *)q->sp_ver.p + (size_t)tile0 * SPLIT_VCAP;
-                uint32_t *ver_cnt = (uint32_t *)q->sp_ver.p + (size_t)q->nq * SPLIT_VCAP + tile0;
-                QMX_TRY(launch_split_select(q->stream, (const uint64_t *)q->sp_cand.p, (const uint32_t *)q->sp_cnt.p, SPLIT_CAND_CAP, sp_band, nq_tile, top, SPLIT_VCAP,
-                                            ver_ids, ver_cnt, tile_ovf, (uint32_t *)(plan + pl.ovf_q) + tile0, (SplitStats *)plan, sp_texact));
+                QMX_TRY(launch_split_select(q->stream, (const uint64_t *)q->sp_cand.p, (const uint32_t *)q->sp_cnt.p, SPLIT_CAND_CAP, sp_band, nq_tile, top, vp, tile0,
+                                            tile_ovf, (uint32_t *)(plan + pl.ovf_q) + tile0, (SplitStats *)plan, sp_texact));
                 QMX_TRY(split_stage(q, "select"));
                 split_tiles.push_back({tile0, nq_tile});
                 if (counters) counters->kernel_launches += 13;
@@ -2025,11 +2189,8 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
             }
             QMX_TRY(split_stage(q, "split kernel"));
             // 4. the rows worth an exact score
-            uint32_t *ver_ids = (uint32_t *)q->sp_ver.p + (size_t)tile0 * SPLIT_VCAP;
-            uint32_t *ver_cnt = (uint32_t *)q->sp_ver.p + (size_t)q->nq * SPLIT_VCAP + tile0;
-            QMX_TRY(launch_split_select(q->stream, (const uint64_t *)q->sp_cand.p, (const uint32_t *)q->sp_cnt.p, SPLIT_CAND_CAP, sp_band, nq_tile, top, SPLIT_VCAP,
-                                        ver_ids, ver_cnt, (const int *)(plan + pl.tile_ovf) + split_tiles.size(), (uint32_t *)(plan + pl.ovf_q) + tile0,
-                                        (SplitStats *)plan));
+            QMX_TRY(launch_split_select(q->stream, (const uint64_t *)q->sp_cand.p, (const uint32_t *)q->sp_cnt.p, SPLIT_CAND_CAP, sp_band, nq_tile, top, vp, tile0,
+                                        (const int *)(plan + pl.tile_ovf) + split_tiles.size(), (uint32_t *)(plan + pl.ovf_q) + tile0, (SplitStats *)plan));
             QMX_TRY(split_stage(q, "select"));
             split_tiles.push_back({tile0, nq_tile});
             if (counters) counters->kernel_launches += 8;
@@ -2090,15 +2251,14 @@ static int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids,
     }
     if (!split_tiles.empty()) {
         // 5. exact scores of the survivors (the gather kernel of qmx_rescore: the reference's bits), sorted by (score, lower id first)
-        uint32_t *ver_all = (uint32_t *)q->sp_ver.p, *cnt_all = ver_all + (size_t)q->nq * SPLIT_VCAP;
         const void *split_kernel = q->last_kernel;
         const uint32_t first = split_tiles.front().first, last = split_tiles.back().first + split_tiles.back().second;
-        PairSel sel{nullptr, SPLIT_VCAP, cnt_all};
-        // the gather addresses query item / SPLIT_VCAP: split tiles are a prefix of the batch (the remainder tile, if any, comes last)
+        // (split tiles are a prefix of the batch - the remainder tile, if any, comes last -: the sort walks queries 0 .. last)
         QMX_REQUIRE(first == 0, QMX_ERR_OTHER, "split tiles must start at query 0");
-        QMX_TRY(score_pairs_device(q, sel, ver_all, (uint64_t)last * SPLIT_VCAP, (float *)q->sp_vscores.p, false));
+        PairSel sel{vp.qsel, 0, nullptr, vp.used};
+        QMX_TRY(score_pairs_device(q, sel, vp.ids, vp.cap, (float *)q->sp_vscores.p, false));
         QMX_TRY(split_stage(q, "verify gather"));
-        QMX_TRY(launch_sort_scored(q->stream, (const float *)q->sp_vscores.p, ver_all, cnt_all, SPLIT_VCAP, last, top, d_out, d_counts));
+        QMX_TRY(launch_sort_scored(q->stream, (const float *)q->sp_vscores.p, vp.ids, vp.cnt, 0, last, top, d_out, d_counts, vp.off));
         QMX_TRY(split_stage(q, "verify sort"));
         // 6. the exact scan of the queries whose lists overflowed (masses of near-equal scores, a sample that is all deleted), and of those only:
         // packed, one 16-query pass when 1..16 of them, passes of 64 otherwise.  The kernels start, read their flag and return when it is clear.
@@ -2594,6 +2754,41 @@ int32_t qmx_hnsw_build_quantized(const qmx_segment *seg, const qmx_segment *orig
     return hnsw_build_impl(seg, original, bp, out, nullptr);
 }
 
+// Build fan-out over independent segments (gpu_devices_manager.rs:120-143 + hnsw/build.rs:53: one device locked per segment build, builds share nothing):
+// one host thread per segment, each driving its segment's device; the thread's own error text travels back with its status.
+int32_t qmx_sharded_hnsw_build(const qmx_segment *const *segments, const qmx_segment *const *originals, uint32_t n_segments,
+                               const qmx_hnsw_build_params *bp, qmx_hnsw **out_graphs, int32_t *out_status) {
+    QMX_REQUIRE(segments && bp && out_graphs && n_segments >= 1, QMX_ERR_BAD_ARG, "NULL argument");
+    for (uint32_t i = 0; i < n_segments; ++i) {
+        out_graphs[i] = nullptr;
+        if (out_status) out_status[i] = QMX_OK;
+    }
+    for (uint32_t i = 0; i < n_segments; ++i) QMX_REQUIRE(segments[i], QMX_ERR_BAD_ARG, "segment %u: NULL", i);
+    std::vector<int32_t> rcs(n_segments, QMX_OK);
+    std::vector<std::string> errs(n_segments);
+    auto work = [&](uint32_t i) {
+        rcs[i] = hnsw_build_impl(segments[i], originals ? originals[i] : nullptr, bp, &out_graphs[i], nullptr);
+        if (rcs[i] != QMX_OK) errs[i] = g_last_error;          // (thread-local: copied out before the thread ends)
+    };
+    if (n_segments == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        pool.reserve(n_segments);
+        for (uint32_t i = 0; i < n_segments; ++i) pool.emplace_back(work, i);
+        for (auto &t : pool) t.join();
+    }
+    int32_t first = QMX_OK;
+    for (uint32_t i = 0; i < n_segments; ++i) {
+        if (out_status) out_status[i] = rcs[i];
+        if (rcs[i] != QMX_OK && first == QMX_OK) {
+            first = rcs[i];
+            set_error("segment %u: %s", i, errs[i].c_str());
+        }
+    }
+    return first;
+}
+
 int32_t qmx_multi_hnsw_build(const qmx_segment *inner, const uint64_t *point_offsets, uint32_t n_points, const uint64_t *point_deleted,
                              uint64_t n_deleted_bits, const qmx_hnsw_build_params *bp, qmx_hnsw **out) {
     QMX_REQUIRE(inner && point_offsets && bp && out, QMX_ERR_BAD_ARG, "NULL argument");
@@ -2954,7 +3149,14 @@ static int32_t launch_hnsw(const qmx_query *q, const ScanArgs &a, const HnswArgs
         return launch_hnsw_dense(q->stream, (int)s->dtype, (int)s->distance, a, h, grid, per_cu);
     }
     if (s->dtype == QMX_DTYPE_SQ_U8) return launch_hnsw_sq(q->stream, (int)s->distance, a, h, grid, per_cu);
-    if (s->dtype == QMX_DTYPE_PQ) return launch_hnsw_pq(q->stream, a, h, grid, per_cu);
+    if (s->dtype == QMX_DTYPE_PQ) {
+        // a LUT too large to stage once per wave (the old kernel then gathers it through L2): one block per search, the LUT in LDS (hnsw_pq_block.hip)
+        if (q->q_stride > 16 * 1024 && !option(OPT_NO_HNSW_PQ_BLOCK) && !option(OPT_HNSW_PQ_LDS_LUT) && pq_block_walk_ok(a, h)) {
+            const int64_t wv = option(OPT_HNSW_PQ_BLOCK_WAVES);
+            return launch_hnsw_pq_block(q->stream, a, h, grid, per_cu, wv > 0 ? (int)wv : 8);
+        }
+        return launch_hnsw_pq(q->stream, a, h, grid, per_cu);
+    }
     if (s->dtype == QMX_DTYPE_BQ) return launch_hnsw_bq(q->stream, a, h, grid, per_cu);
     if (tq_l1(s)) return launch_hnsw_tq_l1(q->stream, a, h, grid, per_cu, s->tq_rot_dim);
     if (s->dtype == QMX_DTYPE_TQ) return launch_hnsw_tq(q->stream, a, h, grid, per_cu);
@@ -3166,6 +3368,8 @@ static int32_t sharded_enqueue(qmx_query *const *queries, const qmx_hnsw *const 
             QMX_TRY(hnsw_check(graphs[i], queries[i], top, ef));
         }
     }
+    // (the merge kernel's limit, checked before anything is enqueued: the async form would return with every segment's scan in flight)
+    QMX_REQUIRE((uint64_t)n_segments * top <= 16384, QMX_ERR_NOT_SUPPORTED, "merge of %u segments x top %u exceeds 16384 entries per query", n_segments, top);
     if (counters) memset(counters, 0, sizeof(*counters));
     QMX_HIP(hipSetDevice(root->device));
     QMX_TRY(root->sh_lists.reserve(n_segments * (lbytes + cbytes) + (size_t)n_segments * 4));
@@ -3203,7 +3407,10 @@ static int32_t sharded_enqueue(qmx_query *const *queries, const qmx_hnsw *const 
             counters->kernel_launches += local.kernel_launches + 1;
             counters->prefilter_queries += local.prefilter_queries;
         }
-        // the list travels on the producing stream (ordered behind the scan without an event), then "arrived" is recorded for the merge
+        // the list travels on the producing stream (ordered behind the scan without an event), then "arrived" is recorded for the merge.  The shared
+        // lists may still be read by the merge of the PREVIOUS call (async calls pipelined without a sync in between: that merge waits for its slowest
+        // segment, a fast segment's stream is long past it): the copy into them waits for that merge first
+        if (q != root && root->sh_merged) QMX_HIP(hipStreamWaitEvent(q->stream, root->sh_merged, 0));
         if (q->device != root->device) {
             int can = 0;
             (void)hipDeviceCanAccessPeer(&can, root->device, q->device);
@@ -3226,7 +3433,10 @@ static int32_t sharded_enqueue(qmx_query *const *queries, const qmx_hnsw *const 
     }
     QMX_HIP(hipSetDevice(root->device));
     for (uint32_t i = 1; i < n_segments; ++i) QMX_HIP(hipStreamWaitEvent(root->stream, queries[i]->sh_done, 0));
-    return launch_merge_points(root->stream, g_lists, g_counts, g_bases, n_segments, nq, top, d_out, d_counts);
+    QMX_TRY(launch_merge_points(root->stream, g_lists, g_counts, g_bases, n_segments, nq, top, d_out, d_counts));
+    if (!root->sh_merged) QMX_HIP(hipEventCreateWithFlags(&root->sh_merged, hipEventDisableTiming));
+    QMX_HIP(hipEventRecord(root->sh_merged, root->stream));
+    return QMX_OK;
 }
 
 static int32_t sharded_sync(qmx_query *const *queries, const qmx_hnsw *const *graphs, uint32_t n_segments, uint32_t top, uint32_t ef, const uint32_t *id_bases,

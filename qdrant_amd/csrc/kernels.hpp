@@ -124,6 +124,10 @@ struct HnswArgs {
     uint32_t xcap;
 };
 
+// The PQ walk with one BLOCK per search (hnsw_pq_block.hip): the LUT in LDS, a controller wave and speculating worker waves.  pq_block_walk_ok: whether this
+// launch can take it (plain walk, packed level 0, aligned code rows, ef in the register beam, LUT + scratch inside the LDS); grid == 0: report blocks per CU
+bool pq_block_walk_ok(const ScanArgs &a, const HnswArgs &h);
+int32_t launch_hnsw_pq_block(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu, int waves);
 // grid == 0: only report the occupancy (blocks of one wave per CU) of the instantiation in *per_cu
 int32_t launch_hnsw_dense(hipStream_t st, int dtype, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 // TurboQuant (scan_tq.hip)
@@ -250,12 +254,14 @@ struct PairSel {
     const uint32_t *qsel;      // explicit query index per item, or nullptr
     uint32_t per_query;        // > 0: query = item / per_query
     const uint32_t *counts;    // with per_query: only the first counts[query] items of a slot are live
+    const uint32_t *limit;     // or nullptr: a device-side item count - items at and behind *limit are dead (a pool filled on the device: the host knows its capacity only)
     __device__ __forceinline__ uint32_t query_of(uint64_t item) const {
         if (qsel) return qsel[item];
         if (per_query) return (uint32_t)(item / per_query);
         return (uint32_t)item;
     }
     __device__ __forceinline__ bool live(uint64_t item, uint32_t qi) const {
+        if (limit && item >= (uint64_t)*limit) return false;
         if (per_query && counts) return (uint32_t)(item % per_query) < counts[qi];
         return true;
     }
@@ -319,15 +325,26 @@ struct SplitStats {
     uint32_t fallback_queries;       // queries whose lists overflowed: they took the exact scan of the block
     uint32_t pad;
 };
+// the verification pool of one search: the rows worth an exact score, of all its queries, as one ragged list filled on the device - query q's rows sit at
+// ids[off[q] .. off[q] + cnt[q]) with qsel[] = q beside them (the gather kernel's explicit query index), *used = entries taken so far (zeroed per search).
+// A query takes what it needs (a few hundred rows on friendly data, tens of thousands where a worst-case band is wide): only a pool that is full sends a
+// query to the exact scan.
+struct VerifyPool {
+    uint32_t *ids, *qsel, *off, *cnt, *used;
+    uint32_t cap;
+    uint32_t max_per_query;     // a query with more rows than this inside its band takes the exact scan whatever room the pool has (option verify_max_per_query; default: cap)
+};
 int32_t launch_split_select(hipStream_t st, const uint64_t *d_cand, const uint32_t *d_cand_cnt, uint32_t cap, const float *d_band, uint32_t nq, uint32_t top,
-                            uint32_t vcap, uint32_t *d_ver_ids, uint32_t *d_ver_cnt, const int *d_tile_overflow, uint32_t *d_ovf_q, SplitStats *d_stats,
+                            const VerifyPool &pool, uint32_t q_base, const int *d_tile_overflow, uint32_t *d_ovf_q, SplitStats *d_stats,
                             const float *d_t_exact = nullptr);
 // the int8 copy of an f32 block (QMX_SEG_I8_COPY) and its passes (scan_split.hip, "The INT8 copy")
 bool split_i8_dim_ok(uint32_t dim);
 size_t split_i8_copy_bytes(uint64_t n, uint32_t dim);
 size_t split_i8_query_bytes(uint32_t dim);
 uint32_t split_i8_probe();
-int32_t launch_split_i8_stats(hipStream_t st, const void *rows, uint64_t row_stride, uint64_t n, uint32_t dim, uint32_t *d_colmax, float *d_scale, uint32_t *d_stats);
+int32_t launch_split_i8_colstats(hipStream_t st, const void *rows, uint64_t row_stride, uint64_t n, uint32_t dim, uint32_t *d_colmax, float *d_colsq);
+float split_i8_choose_scales(const float *colmax, const float *colsq, uint64_t n, uint32_t dim, float *scale);   // host; returns the balance G (0 = floor scales)
+int32_t launch_split_i8_rowstats(hipStream_t st, const void *rows, uint64_t row_stride, uint64_t n, uint32_t dim, const float *d_scale, uint32_t *d_stats);
 int32_t launch_split_i8_copy(hipStream_t st, const void *rows, uint64_t row_stride, uint64_t n, uint32_t dim, const float *d_scale, void *d_out);
 int32_t launch_split_i8_pack(hipStream_t st, const float *d_q, uint32_t nq, uint32_t dim, const float *d_scale, const uint64_t *d_gthr, const uint32_t *d_row_stats,
                              float row_norm_max, void *d_bq, float *d_qscale, float *d_band, float *d_thr, float *d_t_exact, uint32_t *d_cand_cnt, uint32_t n_cnt);
@@ -381,9 +398,8 @@ int32_t launch_merge_points(hipStream_t st, const qmx_scored_point *lists, const
                             uint32_t *out_counts);
 int32_t launch_split_candidates(hipStream_t st, const qmx_scored_point *cand, const uint32_t *cand_cnt, uint32_t n_per, uint32_t nq,
                                 uint32_t *ids, uint32_t top, qmx_scored_point *out, uint32_t *out_counts);
-int32_t launch_sort_scored(hipStream_t st, const float *scores, const uint32_t *ids,
-                           const uint32_t *counts, uint32_t n_per_query, uint32_t nq, uint32_t top,
-                           qmx_scored_point *out, uint32_t *out_counts);
+int32_t launch_sort_scored(hipStream_t st, const float *scores, const uint32_t *ids, const uint32_t *counts, uint32_t n_per_query, uint32_t nq, uint32_t top,
+                           qmx_scored_point *out, uint32_t *out_counts, const uint32_t *offsets = nullptr);   // offsets: query q's entries start at offsets[q] (ragged), not at q * n_per_query
 
 // custom queries (custom_query.hip): combine the per-example similarity matrix, top-k of a score row
 int32_t launch_custom_combine(hipStream_t st, const qmx_custom_query *d_queries, uint32_t n_queries, const float *d_sims, uint64_t n,

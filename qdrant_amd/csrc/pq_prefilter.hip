@@ -37,7 +37,12 @@ namespace qmx {
 
 constexpr int PQF_THREADS = 1024;
 constexpr int PQF_WAVES = PQF_THREADS / 64;
+// rounding of one chunk's quantised entry, in table units: 1/2 from rint, plus the f32 evaluation of (v - lo) * inv_step - the subtraction, the rounded
+// inv_step and the product each within 2^-24 relative of a value of at most PQF_QMAX: 3 * PQF_QMAX * 2^-24 = 4.6e-5 at 255 - rounded up to 1e-4.  Tied to
+// PQF_QMAX: a wider table needs a wider constant.
 constexpr int PQF_QMAX = 255;                     // quantised LUT entries 0..255, stored less 128 (the matrix core's int8 operand is signed)
+constexpr double PQF_ROUND = 0.5 + 1.0e-4;
+static_assert(3.0 * PQF_QMAX * 5.9604644775390625e-08 < 1.0e-4, "PQF_ROUND must cover the f32 rounding of a quantised LUT entry");
 typedef int pqf_i32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const int pqf_lds_int;
 typedef __attribute__((address_space(3))) unsigned char pqf_lds_byte;
@@ -84,9 +89,9 @@ int32_t launch_pq_rotate(hipStream_t st, const void *codes, uint64_t row_stride,
 // ---- per query: the 8-bit table, the candidate threshold and the band ----
 // One block per query, thread j = centroid j.  lut = the query's f32 LUT [m][ncent] (EncodedQueryPQ, encode_query :519-541).
 //   lo_c = min_j LUT[c][j], R = max_c (max_j - min_j), step = R / 255, q_cj = rint((LUT[c][j] - lo_c) / step)  in 0..255
-//   exact score (real arithmetic) = L + step (A + D), L = sum_c lo_c, |D| <= 0.50002 m  (0.5 per chunk + the f32 rounding of the quotient)
+//   exact score (real arithmetic) = L + step (A + D), L = sum_c lo_c, |D| <= PQF_ROUND m  (0.5 per chunk + the f32 rounding of the quotient: see PQF_ROUND)
 //   the f32 score the exact kernels return differs from the real sum by at most E = (m + 1) 2^-24 sum_c max_j |LUT[c][j]|
-//   => a row with exact score >= T has A >= (T - L - E) / step - 0.50002 m =: thr (floored, minus 1);   band (A units) = 0.50002 m + E / step + 1
+//   => a row with exact score >= T has A >= (T - L - E) / step - PQF_ROUND m =: thr (floored, minus 1);   band (A units) = PQF_ROUND m + E / step + 1
 // table8: bytes (q - 128 as int8), [group][code][slots] dwords, byte k of a dword = query 4 group + k; slots >= m_pad repeat chunks 0..31.  The
 // caller fills the table with 0x80 (= 0) first: padding chunks, missing centroids and the unused query bytes of the last group must read 0.
 __global__ __launch_bounds__(256) void pq_lut8_kernel(const unsigned char *luts, uint32_t q_stride, uint32_t nq, uint32_t m, uint32_t ncent, uint32_t m_pad,
@@ -165,12 +170,12 @@ __global__ __launch_bounds__(256) void pq_lut8_kernel(const unsigned char *luts,
     if (j == 0) {
         const double step = flat ? 1.0 : (double)R / (double)PQF_QMAX;
         const double Es = (double)(m + 1) * 5.9604644775390625e-08 * (double)E;      // 2^-24
-        const double bnd = 0.50002 * (double)m + Es / step + 1.0;
+        const double bnd = PQF_ROUND * (double)m + Es / step + 1.0;
         const uint64_t key = gthr[q];
         // no sample bound (fewer than k live rows in the sample) or a degenerate table: no candidates, and the infinite band tells
         // sp_select_kernel that this query takes the exact scan
         const bool usable = key != 0 && !flat;
-        double t = usable ? ((double)key_score(key) - L - Es) / step - 0.50002 * (double)m - 1.0 : 0.0;
+        double t = usable ? ((double)key_score(key) - L - Es) / step - PQF_ROUND * (double)m - 1.0 : 0.0;
         t = __builtin_floor(t);
         thr[q] = !usable ? 0x7F7F7F7F : (t < 0.0 ? 0 : (t > 1.0e6 ? 1000000 : (int32_t)t));
         band[q] = usable ? (float)bnd : __builtin_inff();

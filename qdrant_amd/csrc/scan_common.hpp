@@ -518,23 +518,32 @@ __global__ __launch_bounds__(PAIR_BLOCK) void pair_kernel(const ScanArgs a, cons
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int t = lane & 7, g = lane >> 3;
     const unsigned char *queries = reinterpret_cast<const unsigned char *>(a.queries);
-    for (uint64_t base = ((uint64_t)blockIdx.x * NW + wave) * 8; base < n_items; base += (uint64_t)gridDim.x * NW * 8) {
-        const uint64_t item = base + g;
-        bool valid = item < n_items;
-        uint32_t qi = valid ? sel.query_of(item) : 0;
-        valid = valid && sel.live(item, qi);
-        uint32_t id = valid ? a.ids[item] : 0;
-        if (valid && (id >= a.n_rows || qi >= a.nq)) {
-            *a.err_flag = 1;
-            valid = false;
-            id = 0;
-            qi = 0;
+    // Two shapes of the same loop.  gridDim.y == 1: the items as one sequence, strided over the grid.  gridDim.y > 1 (per-query slots with counts -
+    // the verification lists of the prefilters, sized for the worst case): blockIdx.y owns a run of slots, its blocks walk the LIVE head of each
+    // (count entries), so a slot of 16 384 entries that holds 100 costs what 100 entries cost.
+    const bool lists = gridDim.y > 1;
+    const uint64_t slots = lists ? n_items / sel.per_query : 1;
+    for (uint64_t slot = lists ? blockIdx.y : 0; slot < slots; slot += gridDim.y) {
+        const uint64_t first = lists ? slot * sel.per_query : 0;
+        const uint64_t end = lists ? first + (sel.counts[slot] < sel.per_query ? sel.counts[slot] : sel.per_query) : n_items;
+        for (uint64_t base = first + ((uint64_t)blockIdx.x * NW + wave) * 8; base < end; base += (uint64_t)gridDim.x * NW * 8) {
+            const uint64_t item = base + g;
+            bool valid = item < end;
+            uint32_t qi = valid ? sel.query_of(item) : 0;
+            valid = valid && sel.live(item, qi);
+            uint32_t id = valid ? a.ids[item] : 0;
+            if (valid && (id >= a.n_rows || qi >= a.nq)) {
+                *a.err_flag = 1;
+                valid = false;
+                id = 0;
+                qi = 0;
+            }
+            // (a slot's dead tail - per-query lists are sized for the worst case, counts[] says how much is live - costs nothing: a wave whose eight items are all dead moves on)
+            if (!__ballot(valid)) continue;
+            // (a pair is one gathered row: the kernel is a chain of round trips, so twelve row pieces per lane are requested at once)
+            const float score = group_score<P, 12>(a, queries + (uint64_t)qi * a.q_stride, id, t);
+            if (valid && t == 0) a.scores[item] = score;
         }
-        // (a slot's dead tail - per-query lists are sized for the worst case, counts[] says how much is live - costs nothing: a wave whose eight items are all dead moves on)
-        if (!__ballot(valid)) continue;
-        // (a pair is one gathered row: the kernel is a chain of round trips, so twelve row pieces per lane are requested at once)
-        const float score = group_score<P, 12>(a, queries + (uint64_t)qi * a.q_stride, id, t);
-        if (valid && t == 0) a.scores[item] = score;
     }
 }
 
@@ -574,8 +583,16 @@ struct PairLauncher {
         if (n_items == 0) return QMX_OK;
         uint64_t want = (n_items + 31) / 32;
         uint32_t grid = (uint32_t)(want < (uint64_t)num_cus * 8 ? want : (uint64_t)num_cus * 8);
+        dim3 g3(grid);
+        if (!sel.qsel && sel.per_query >= 1024 && sel.counts && n_items % sel.per_query == 0 && n_items / sel.per_query >= 2) {
+            // long slots with counts: blocks per slot (32 items per block trip), rows of the grid over the slots
+            const uint64_t slots = n_items / sel.per_query;
+            const uint32_t gy = (uint32_t)(slots < 1024 ? slots : 1024);
+            const uint32_t per_slot = (uint32_t)std::min<uint64_t>((sel.per_query + 31) / 32, std::max<uint64_t>(1, (uint64_t)num_cus * 16 / gy));
+            g3 = dim3(per_slot, gy);
+        }
         ::qmx::clear_stale_error();
-        hipLaunchKernelGGL((pair_kernel<P>), dim3(grid), dim3(PAIR_BLOCK), 0, st, a, sel, n_items);
+        hipLaunchKernelGGL((pair_kernel<P>), g3, dim3(PAIR_BLOCK), 0, st, a, sel, n_items);
         QMX_HIP(hipGetLastError());
         return QMX_OK;
     }

@@ -401,7 +401,7 @@ __host__ __device__ inline uint64_t split_phase_tiles(uint64_t all_tiles, uint32
     const uint64_t first = (all_tiles + SP_PHASE_STRIDE - 1) / SP_PHASE_STRIDE;
     return phase == 0 ? all_tiles : phase == 1 ? first : all_tiles - first;
 }
-constexpr uint32_t SP_WCAP = 2048;                           // candidates one wave may list per pass (expected: ~200; more -> overflow -> the exact scan)
+constexpr uint32_t SP_WCAP = 8192;                           // candidates one wave may list per pass (expected: ~200, heavy-tailed rows under the int8 band: thousands; more -> overflow -> the exact scan)
 constexpr int SP3_BM = SP_BM;                                // 256 rows per tile: a stage is 32 KiB of rows + 16 KiB of queries
 constexpr int SP3_A_UNITS = SP_A_UNITS;
 constexpr int SP3_ARING = 3;                                 // row stages in LDS: one being multiplied, two on their way
@@ -982,19 +982,19 @@ __global__ __launch_bounds__(SEL_BLOCK) void sp_refine_kernel(const uint64_t *ca
 }
 
 __global__ __launch_bounds__(SEL_BLOCK) void sp_select_kernel(const uint64_t *cand, const uint32_t *cand_cnt, uint32_t cap, const float *band, uint32_t top,
-                                                              uint32_t vcap, uint32_t *ver_ids, uint32_t *ver_cnt, const int *tile_overflow, uint32_t *ovf_q,
+                                                              const VerifyPool pool, uint32_t q_base, const int *tile_overflow, uint32_t *ovf_q,
                                                               SplitStats *stats, const float *t_exact /* or nullptr: an exact lower bound of the k-th best score per query */) {
     __shared__ uint64_t sh[SEL_BLOCK / WAVE][WAVE];
     __shared__ uint64_t sh_kth;
     __shared__ float sh_cut;
-    __shared__ uint32_t sh_n;
+    __shared__ uint32_t sh_n, sh_off;
     __shared__ SelScratch scratch;
     const uint32_t q = blockIdx.x;
     const uint32_t raw = cand_cnt[q];
     // a wave list of the scan overflowed (its dropped entries could be anybody's), or this query's candidate buffer did: the pass cannot be
     // trusted for this query, which takes the exact scan (the other queries of the batch keep their lists)
     if (*tile_overflow || raw > cap || !(band[q] < 3.0e38f)) {      // (an infinite band: the query had no usable threshold)
-        if (threadIdx.x == 0) { ovf_q[q] = 1; ver_cnt[q] = 0; }
+        if (threadIdx.x == 0) { ovf_q[q] = 1; pool.cnt[q_base + q] = 0; pool.off[q_base + q] = 0; }
         return;
     }
     const uint64_t *c = cand + (uint64_t)q * cap;
@@ -1012,23 +1012,45 @@ __global__ __launch_bounds__(SEL_BLOCK) void sp_select_kernel(const uint64_t *ca
     }
     __syncthreads();
     const float cut = sh_cut;
-    for (uint32_t base = 0; base < raw; base += SEL_BLOCK) {
-        const uint32_t i = base + threadIdx.x;
-        if (i < raw) {
-            const uint64_t key = c[i];
-            if (!(key_score(key) < cut)) {
-                const uint32_t slot = atomicAdd(&sh_n, 1u);
-                if (slot < vcap) ver_ids[(uint64_t)q * vcap + slot] = key_idx(key);
-            }
-        }
+    // how many rows the query verifies, then its range of the pool (one global atomic per query), then the rows
+    uint32_t mine = 0;
+    for (uint32_t i = threadIdx.x; i < raw; i += SEL_BLOCK) mine += !(key_score(c[i]) < cut) ? 1u : 0u;
+    if (mine) atomicAdd(&sh_n, mine);
+    __syncthreads();
+    const uint32_t n = sh_n;
+    if (threadIdx.x == 0) {
+        const bool too_many = n > pool.max_per_query;                     // (more rows than a query may verify: it reserves nothing)
+        const uint32_t off = (n && !too_many) ? atomicAdd(pool.used, n) : 0u;
+        const bool over = too_many || (n != 0 && ((uint64_t)off + n > pool.cap));     // (or the pool is full: this query - alone - takes the exact scan)
+        sh_off = over ? 0xFFFFFFFFu : off;
+        sh_kth = too_many ? (uint64_t)pool.cap : (uint64_t)off;           // (the raw offset: what a query that ran over the pool's end must fill, below)
+        ovf_q[q] = over ? 1u : 0u;
+        pool.off[q_base + q] = over ? 0u : off;
+        pool.cnt[q_base + q] = over ? 0u : n;
+        atomicAdd(&stats->candidates, (unsigned long long)raw);
+        if (!over) atomicAdd(&stats->verified, (unsigned long long)n);
+        sh_n = 0;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const bool over = sh_n > vcap;
-        ovf_q[q] = over ? 1u : 0u;
-        ver_cnt[q] = over ? 0u : sh_n;
-        atomicAdd(&stats->candidates, (unsigned long long)raw);
-        if (!over) atomicAdd(&stats->verified, (unsigned long long)sh_n);
+    const uint32_t off = sh_off;
+    if (off == 0xFFFFFFFFu) {
+        // what this query reserved inside the pool before it ran over stays in front of `used`: the gather visits those entries, so they name a row
+        // that exists (row 0: its score is dropped - the query's count is zero)
+        const uint64_t lo = sh_kth;
+        for (uint64_t i = lo + threadIdx.x; i < pool.cap; i += SEL_BLOCK) {
+            pool.ids[i] = 0;
+            pool.qsel[i] = q_base + q;
+        }
+        return;
+    }
+    if (n == 0) return;
+    for (uint32_t i = threadIdx.x; i < raw; i += SEL_BLOCK) {
+        const uint64_t key = c[i];
+        if (!(key_score(key) < cut)) {
+            const uint32_t slot = off + atomicAdd(&sh_n, 1u);
+            pool.ids[slot] = key_idx(key);
+            pool.qsel[slot] = q_base + q;
+        }
     }
 }
 
@@ -1115,30 +1137,32 @@ typedef int i32x4s __attribute__((ext_vector_type(4)));
 constexpr uint32_t SP_I8_PROBE = 64;                         // slots per query for the candidates whose exact scores renew the bound after a launch (k <= 64 of them)
 constexpr uint32_t SP_I8_MAX_DIM = 4096;                     // (sp_i8_colmax_kernel keeps a column maximum per thread and 256 columns)
 
-// column maxima: colmax[c] = max_r |x_rc| (uint bits of a non-negative float order like the float); thread t owns columns t, t + 256, ...
-__global__ __launch_bounds__(256) void sp_i8_colmax_kernel(const unsigned char *rows, uint64_t row_stride, uint64_t n, uint32_t dim, uint32_t *colmax) {
-    float mx[SP_I8_MAX_DIM / 256];
+// column maxima and sums of squares: colmax[c] = max_r |x_rc| (uint bits of a non-negative float order like the float), colsq[c] = sum_r x_rc^2 (f32, a
+// statistic that only steers the choice of the scales); thread t owns columns t, t + 256, ...
+__global__ __launch_bounds__(256) void sp_i8_colmax_kernel(const unsigned char *rows, uint64_t row_stride, uint64_t n, uint32_t dim, uint32_t *colmax, float *colsq) {
+    float mx[SP_I8_MAX_DIM / 256], sq[SP_I8_MAX_DIM / 256];
 #pragma unroll
-    for (int j = 0; j < (int)(SP_I8_MAX_DIM / 256); ++j) mx[j] = 0.0f;
+    for (int j = 0; j < (int)(SP_I8_MAX_DIM / 256); ++j) { mx[j] = 0.0f; sq[j] = 0.0f; }
     for (uint64_t r = blockIdx.x; r < n; r += gridDim.x) {
         const float *v = reinterpret_cast<const float *>(rows + r * row_stride);
 #pragma unroll
         for (int j = 0; j < (int)(SP_I8_MAX_DIM / 256); ++j) {
             const uint32_t c = threadIdx.x + 256u * (uint32_t)j;
-            if (c < dim) mx[j] = __builtin_fmaxf(mx[j], __builtin_fabsf(v[c]));
+            if (c < dim) {
+                const float x = v[c];
+                mx[j] = __builtin_fmaxf(mx[j], __builtin_fabsf(x));
+                sq[j] = __builtin_fmaf(x, x, sq[j]);
+            }
         }
     }
 #pragma unroll
     for (int j = 0; j < (int)(SP_I8_MAX_DIM / 256); ++j) {
         const uint32_t c = threadIdx.x + 256u * (uint32_t)j;
-        if (c < dim) atomicMax(&colmax[c], __float_as_uint(mx[j]));
+        if (c < dim) {
+            atomicMax(&colmax[c], __float_as_uint(mx[j]));
+            atomicAdd(&colsq[c], sq[j]);
+        }
     }
-}
-__global__ void sp_i8_scales_kernel(const uint32_t *colmax, uint32_t dim, float *scale) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= dim) return;
-    const float m = __uint_as_float(colmax[i]);
-    scale[i] = m > 1.0e-30f ? m / 127.0f : 1.0f;            // (an all-zero or vanishing column: codes 0, |e| = |x| <= 1/2 all the same)
 }
 __device__ __forceinline__ int sp_i8_code(float x, float s) {
     int c = (int)__builtin_rintf(x / s);
@@ -1640,11 +1664,10 @@ int32_t launch_split_refine(hipStream_t st, const uint64_t *d_cand, const uint32
     return QMX_OK;
 }
 int32_t launch_split_select(hipStream_t st, const uint64_t *d_cand, const uint32_t *d_cand_cnt, uint32_t cap, const float *d_band, uint32_t nq, uint32_t top,
-                            uint32_t vcap, uint32_t *d_ver_ids, uint32_t *d_ver_cnt, const int *d_tile_overflow, uint32_t *d_ovf_q, SplitStats *d_stats,
-                            const float *d_t_exact) {
+                            const VerifyPool &pool, uint32_t q_base, const int *d_tile_overflow, uint32_t *d_ovf_q, SplitStats *d_stats, const float *d_t_exact) {
     ::qmx::clear_stale_error();
-    hipLaunchKernelGGL(sp_select_kernel, dim3(nq), dim3(SEL_BLOCK), 0, st, d_cand, d_cand_cnt, cap, d_band, top, vcap, d_ver_ids, d_ver_cnt, d_tile_overflow,
-                       d_ovf_q, d_stats, d_t_exact);
+    hipLaunchKernelGGL(sp_select_kernel, dim3(nq), dim3(SEL_BLOCK), 0, st, d_cand, d_cand_cnt, cap, d_band, top, pool, q_base, d_tile_overflow, d_ovf_q, d_stats,
+                       d_t_exact);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }
@@ -1664,16 +1687,79 @@ bool split_i8_dim_ok(uint32_t dim) { return dim % 128 == 0 && dim >= 128 && dim 
 size_t split_i8_copy_bytes(uint64_t n, uint32_t dim) { return (size_t)((n + SP3_BM - 1) / SP3_BM) * (dim / 128) * SP3_A_UNITS * 16; }
 size_t split_i8_query_bytes(uint32_t dim) { return (size_t)(dim / 128) * SP_B_UNITS * 16; }
 uint32_t split_i8_probe() { return SP_I8_PROBE; }
-// d_scale [dim] <- the columns' scales, d_stats [4] <- {C1, C2^2, not finite, -} (zeroed here); then the copy itself (split_i8_copy_bytes)
-int32_t launch_split_i8_stats(hipStream_t st, const void *rows, uint64_t row_stride, uint64_t n, uint32_t dim, uint32_t *d_colmax, float *d_scale,
-                              uint32_t *d_stats) {
+// pass 1 of the copy: d_colmax [dim] <- max_r |x_rc| (uint bits), d_colsq [dim] <- sum_r x_rc^2 (both zeroed here)
+int32_t launch_split_i8_colstats(hipStream_t st, const void *rows, uint64_t row_stride, uint64_t n, uint32_t dim, uint32_t *d_colmax, float *d_colsq) {
     QMX_REQUIRE(split_i8_dim_ok(dim), QMX_ERR_BAD_ARG, "int8 copy of dim %u", dim);
     ::qmx::clear_stale_error();
     QMX_HIP(hipMemsetAsync(d_colmax, 0, (size_t)dim * 4, st));
+    QMX_HIP(hipMemsetAsync(d_colsq, 0, (size_t)dim * 4, st));
+    if (n) hipLaunchKernelGGL(sp_i8_colmax_kernel, dim3(2048), dim3(256), 0, st, (const unsigned char *)rows, row_stride, n, dim, d_colmax, d_colsq);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+// The columns' scales (host, dim numbers).  Any s_i >= max_r |x_ri| / 127 keeps the codes inside [-127, 127] and |e_i| <= 1/2, so the band formula holds for
+// every such choice; WHICH choice decides how wide the band is.  With s_i at its floor a block whose columns differ in size (a few dominant coordinates: what
+// transformer embeddings with outlier dimensions look like) gives its queries - one scale t per query, set by the largest q_i s_i - codes of 0 / +-1 in
+// the small columns: the queries' rounding then costs C2 |f|_2 t on columns whose row codes use the full range.  Raising the small columns' scales to
+// 1 / G of the largest typical |q_i s_i| moves range from their row codes (more row error: sum |d_i| / 2 grows) to their query codes (less query error:
+// C2 shrinks): the G that minimises the predicted band for queries distributed like the rows is taken.  Predicted band (score units), |q_i| ~ sigma_i:
+//   v_i = sigma_i s_i,  t = 3 max v / 127,  rows' rounding 0.4 sum v_i,  queries' rounding t sqrt(sum (sigma_i / s_i)^2) sqrt(sum min(1/12, (v_i / t)^2))
+// (restated in tests/test_i8_prefilter_model.py: on eight coordinates twelve times the others the band drops from 1.06 to 0.43 standard deviations of the
+// score, the rows inside it from 5 200 to 360 per query; columns of one size - Gaussian, Laplace, Student rows - keep their floor scales: G changes nothing there)
+float split_i8_choose_scales(const float *colmax, const float *colsq, uint64_t n, uint32_t dim, float *scale) {
+    std::vector<double> s0(dim), sig(dim);
+    double wmax = 0.0;
+    for (uint32_t i = 0; i < dim; ++i) {
+        s0[i] = colmax[i] > 1.0e-30f ? (double)colmax[i] / 127.0 : 1.0;    // (an all-zero or vanishing column: codes 0, |e| = |x| <= 1/2 all the same)
+        sig[i] = n ? sqrt((double)colsq[i] / (double)n) : 0.0;
+        if (!(sig[i] < 1.0e30)) sig[i] = 0.0;
+        wmax = std::max(wmax, sig[i] * s0[i]);
+    }
+    auto scales_of = [&](double G, std::vector<double> &s) {
+        for (uint32_t i = 0; i < dim; ++i) {
+            const double w = sig[i] * s0[i];
+            s[i] = (w > 0.0 && wmax / G > w && colmax[i] > 1.0e-30f) ? s0[i] * (wmax / G / w) : s0[i];
+        }
+    };
+    auto predicted = [&](const std::vector<double> &s) {
+        double vmax = 0.0, vsum = 0.0, c2 = 0.0;
+        for (uint32_t i = 0; i < dim; ++i) {
+            const double v = sig[i] * s[i];
+            vmax = std::max(vmax, v);
+            vsum += v;
+            c2 += (sig[i] / s[i]) * (sig[i] / s[i]);
+        }
+        const double t = 3.0 * vmax / 127.0;
+        if (!(t > 0.0)) return 0.0;
+        double f2 = 0.0;
+        for (uint32_t i = 0; i < dim; ++i) f2 += std::min(1.0 / 12.0, (sig[i] * s[i] / t) * (sig[i] * s[i] / t));
+        return 0.4 * vsum + t * sqrt(c2) * sqrt(f2);
+    };
+    static const double grid[] = {1.0e30, 64.0, 45.0, 32.0, 23.0, 16.0, 11.0, 8.0, 5.6, 4.0, 2.8, 2.0};
+    std::vector<double> s(dim), best(dim);
+    double best_b = 0.0, best_g = grid[0];
+    for (size_t k = 0; k < sizeof(grid) / sizeof(grid[0]); ++k) {
+        scales_of(grid[k], s);
+        const double b = predicted(s);
+        if (k == 0 || b < best_b * 0.98) {       // (a candidate has to pay: equal predictions keep the floor scales)
+            best_b = b;
+            best_g = grid[k];
+            best = s;
+        }
+    }
+    for (uint32_t i = 0; i < dim; ++i) {
+        float f = (float)best[i];
+        const float floor_s = colmax[i] > 1.0e-30f ? colmax[i] / 127.0f : 1.0f;
+        scale[i] = f >= floor_s ? f : floor_s;     // (never below the floor, whatever the roundings above did)
+    }
+    return best_g >= 1.0e29 ? 0.0f : (float)best_g;
+}
+// pass 2: d_stats [4] <- {C1, C2^2, not finite, -} under the scales d_scale (zeroed here); then the copy itself (split_i8_copy_bytes)
+int32_t launch_split_i8_rowstats(hipStream_t st, const void *rows, uint64_t row_stride, uint64_t n, uint32_t dim, const float *d_scale, uint32_t *d_stats) {
+    QMX_REQUIRE(split_i8_dim_ok(dim), QMX_ERR_BAD_ARG, "int8 copy of dim %u", dim);
+    ::qmx::clear_stale_error();
     QMX_HIP(hipMemsetAsync(d_stats, 0, 16, st));
-    if (n) hipLaunchKernelGGL(sp_i8_colmax_kernel, dim3(2048), dim3(256), 0, st, (const unsigned char *)rows, row_stride, n, dim, d_colmax);
-    hipLaunchKernelGGL(sp_i8_scales_kernel, dim3((dim + 255) / 256), dim3(256), 0, st, (const uint32_t *)d_colmax, dim, d_scale);
-    if (n) hipLaunchKernelGGL(sp_i8_row_stats_kernel, dim3(2048), dim3(256), 0, st, (const unsigned char *)rows, row_stride, n, dim, (const float *)d_scale, d_stats);
+    if (n) hipLaunchKernelGGL(sp_i8_row_stats_kernel, dim3(2048), dim3(256), 0, st, (const unsigned char *)rows, row_stride, n, dim, d_scale, d_stats);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }

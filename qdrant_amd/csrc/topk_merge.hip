@@ -127,17 +127,19 @@ __global__ __launch_bounds__(MERGE_BLOCK) void merge_points_kernel(const qmx_sco
 __global__ __launch_bounds__(MERGE_BLOCK) void sort_scored_kernel(const float *scores, const uint32_t *ids,
                                                                   const uint32_t *counts, uint32_t n_per_query,
                                                                   uint32_t top, qmx_scored_point *out,
-                                                                  uint32_t *out_counts) {
+                                                                  uint32_t *out_counts, const uint32_t *offsets) {
     const uint32_t q = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t cnt = counts ? (counts[q] < n_per_query ? counts[q] : n_per_query) : n_per_query;
+    // ragged lists (offsets): query q's entries are [offsets[q], offsets[q] + counts[q]); else slots of n_per_query entries, counts[q] of them live
+    const uint32_t cnt = offsets ? counts[q] : counts ? (counts[q] < n_per_query ? counts[q] : n_per_query) : n_per_query;
+    const uint64_t first = offsets ? (uint64_t)offsets[q] : (uint64_t)q * n_per_query;
     uint64_t bound = ~0ull;
     for (uint32_t off = 0; off < top; off += WAVE) {
         const int ptop = (int)(top - off < (uint32_t)WAVE ? top - off : (uint32_t)WAVE);
         uint64_t list = 0;
         for (uint32_t base = wave * WAVE; base < cnt; base += MERGE_BLOCK) {
             const uint32_t i = base + lane;
-            uint64_t key = i < cnt ? make_key(scores[(uint64_t)q * n_per_query + i], ids[(uint64_t)q * n_per_query + i]) : 0;
+            uint64_t key = i < cnt ? make_key(scores[first + i], ids[first + i]) : 0;
             if (key >= bound) key = 0;
             wave_offer(list, key, ptop, lane);
         }
@@ -172,10 +174,10 @@ int32_t launch_merge_points(hipStream_t st, const qmx_scored_point *lists, const
     return QMX_OK;
 }
 int32_t launch_sort_scored(hipStream_t st, const float *scores, const uint32_t *ids, const uint32_t *counts,
-                           uint32_t n_per_query, uint32_t nq, uint32_t top, qmx_scored_point *out, uint32_t *out_counts) {
+                           uint32_t n_per_query, uint32_t nq, uint32_t top, qmx_scored_point *out, uint32_t *out_counts, const uint32_t *offsets) {
     if (nq == 0) return QMX_OK;
     ::qmx::clear_stale_error();
-    hipLaunchKernelGGL(sort_scored_kernel, dim3(nq), dim3(MERGE_BLOCK), 0, st, scores, ids, counts, n_per_query, top, out, out_counts);
+    hipLaunchKernelGGL(sort_scored_kernel, dim3(nq), dim3(MERGE_BLOCK), 0, st, scores, ids, counts, n_per_query, top, out, out_counts, offsets);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }

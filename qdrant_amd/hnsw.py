@@ -113,6 +113,32 @@ class GraphLayers:
         return self
 
     @classmethod
+    def build_sharded(cls, storages, m: int = 16, m0: Optional[int] = None, ef_construct: int = 100, seed: int = 42, entry_points_num: int = 10,
+                      max_batch: int = 0, originals=None):
+        """One graph per segment, built side by side (`qmx_sharded_hnsw_build`: one host thread per segment inside the library, each on its
+        segment's device - the reference's one-locked-GPU-per-segment-build, gpu_devices_manager.rs:120-143).  Returns the graphs in segment order."""
+        n = len(storages)
+        p = F.HnswBuildParams()
+        p.m, p.m0, p.ef_construct, p.entry_points_num, p.seed, p.max_batch = int(m), int(2 * m if m0 is None else m0), ef_construct, entry_points_num, seed, max_batch
+        segs = (C.c_void_p * n)(*[s._h for s in storages])
+        orig = None if originals is None else (C.c_void_p * n)(*[None if o is None else o._h for o in originals])
+        outs = (C.c_void_p * n)()
+        status = (C.c_int32 * n)()
+        rc = F.lib().qmx_sharded_hnsw_build(segs, orig, n, C.byref(p), outs, status)
+        graphs = []
+        for i in range(n):
+            g = cls.__new__(cls)
+            g.m, g.m0, g._keep, g._h = p.m, p.m0, [], C.c_void_p(outs[i])
+            g.n_points, g.counters = storages[i].count, F.Counters()
+            graphs.append(g)
+        if rc != 0:
+            for g in graphs:
+                if g._h:
+                    g.close()
+            F.check(rc)
+        return graphs
+
+    @classmethod
     def build_multi(cls, multi_storage, m: int = 16, m0: Optional[int] = None, ef_construct: int = 100, seed: int = 42,
                     entry_points_num: int = 10, max_batch: int = 0):
         """`GraphLayersBuilder` over the POINTS of a MultiDenseVectorStorage / QuantizedMultivectorStorage on its GPU (qmx_multi_hnsw_build): every

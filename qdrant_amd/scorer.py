@@ -105,6 +105,16 @@ class VectorStorage:
     def total_vector_count(self) -> int:
         return self.count
 
+    def info(self) -> dict:
+        """`qmx_segment_get_info`: which derived copy the prefilter streams ("i8" / "half" / "pair" / None) and, under `SEG_AUTO_COPY`, what the
+        trial at create measured."""
+        i = F.SegmentInfo()
+        F.check(F.lib().qmx_segment_get_info(self._h, C.byref(i)))
+        name = {0: None, F.SEG_I8_COPY: "i8", F.SEG_HALF_COPY: "half", F.SEG_SPLIT_COPY: "pair"}[i.derived_copy]
+        return {"derived_copy": name, "chosen_by_trial": bool(i.chosen_by_trial), "derived_copy_bytes": int(i.derived_copy_bytes),
+                "i8_scale_balance": float(i.i8_scale_balance), "trial_i8_ms": float(i.trial_i8_ms), "trial_half_ms": float(i.trial_half_ms),
+                "trial_i8_verified_rows": float(i.trial_i8_verified_rows), "trial_i8_fallback_queries": int(i.trial_i8_fallback_queries)}
+
     def set_deleted(self, point_deleted=None, vec_deleted=None):
         """`NotDeletedChecker{point_deleted, vec_deleted}` (raw_scorer.rs:580-603); bool arrays."""
         pw, vw = _bits_to_words(point_deleted), _bits_to_words(vec_deleted)

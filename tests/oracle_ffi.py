@@ -686,15 +686,17 @@ class Hnsw:
             n_base.append(nb.value)
         return res, n_links, n_base
 
-    def search_pq(self, flags_storage: DenseStorage, pq: "PqOracle", queries_preprocessed, top, ef):
-        res = []
+    def search_pq(self, flags_storage: DenseStorage, pq: "PqOracle", queries_preprocessed, top, ef, with_stats=False):
+        res, stats = [], []
         for qv in f32(np.atleast_2d(queries_preprocessed)):
             lut = pq.lut(qv)
             s = Scorer()
             s.kind, s.st, s.pq, s.pq_codes = 2, C.pointer(flags_storage.st), C.pointer(pq.pq), pq.codes.ctypes.data
             s.pq_lut, s.isa = lut.ctypes.data, pq.isa
-            res.append(self._run(s, top, ef)[0])
-        return res
+            r, ns = self._run(s, top, ef)
+            res.append(r)
+            stats.append(ns)
+        return (res, stats) if with_stats else res
 
 
 def _hnsw_search_tq(self, flags_storage: DenseStorage, tq: "TqOracle", queries_preprocessed, top, ef):

@@ -37,7 +37,9 @@ def world():
     torch.cuda.synchronize()
     queries = O.synth(0x5EED0012, 0, NQ, DIM)
     st = qa.VectorStorage(rows, qa.Distance.Cosine, flags=F.SEG_HALF_COPY)      # + the f16 high-part copy of the block (15.36 GB more)
-    yield dict(torch=torch, qa=qa, F=F, dev=dev, rows=rows, queries=queries, st=st)
+    st_i8 = qa.VectorStorage(rows, qa.Distance.Cosine, flags=F.SEG_I8_COPY)     # the same rows with the int8 copy (7.68 GB more): bench.py's default
+    yield dict(torch=torch, qa=qa, F=F, dev=dev, rows=rows, queries=queries, st=st, st_i8=st_i8)
+    st_i8.close()
     st.close()
     del rows
     torch.cuda.empty_cache()
@@ -89,28 +91,32 @@ def test_c2_full_size_properties(world):
         assert np.array_equal(g["score"].view(np.uint32), w["score"].view(np.uint32))
 
 
-@pytest.mark.parametrize("path", ["exact", "prefilter"])
+@pytest.mark.parametrize("path", ["exact", "prefilter", "i8"])
 @pytest.mark.parametrize("nq", [16, 32, 64, 128, 256])
 def test_c2_full_size_every_batch_shape(world, nq, path):
     """the kernels bench.py times, checked at the headline size over the WHOLE block (their wave-lag schedule, stage
     rings and tails depend on the tile count), for 16 / 32 / 64 / 128 queries per pass and along both tracks:
       exact      scan_f32_mfma16_kernel<6, ...> (what a segment without a derived copy runs; option no_split_scan here),
-      prefilter  scan_f16pair_kernel<true> (up to 128 queries) / scan_f16half256_kernel (256) over the 2 B / element copy + exact verification.
+      prefilter  scan_f16pair_kernel<true> (up to 128 queries) / scan_f16half256_kernel (256) over the 2 B / element copy + exact verification,
+      i8         scan_i8copy_kernel over the 1 B / element copy (tiles of 128 queries: the phase-1 sixteenth, the 6-stage ring, the tails) + exact
+                 bounds + exact verification: the headline path of bench.py since round 3.
     The lists must equal (1) the VALU kernel's (4 queries per pass, no matrix cores, no pre-scan, a different reduction tree: the only
     thing they share is the reference's bits), (2) the oracle's on a 200 k-row window reached through an id list (the IDS = true
     instantiation), and (3) the merge of the lists of 5 uneven slabs."""
     qa, F, torch = world["qa"], world["F"], world["torch"]
     queries = O.synth(0x5EED0042 + nq, 0, nq, DIM)
-    s = qa.BatchFilteredSearcher(queries, world["st"], TOP)
+    s = qa.BatchFilteredSearcher(queries, world["st_i8" if path == "i8" else "st"], TOP)
     qa.set_option("no_split_scan", 1 if path == "exact" else -1)
     try:
         full = s.peek_top_all()
     finally:
         qa.set_option("no_split_scan", -1)
     kernel = F.last_kernel(s.scorer._h)
-    want_kernel = (("scan_f16half256_kernel" if nq > 128 else "scan_f16pair_kernel<true>") if path == "prefilter"
+    want_kernel = ("scan_i8copy_kernel" if path == "i8" else ("scan_f16half256_kernel" if nq > 128 else "scan_f16pair_kernel<true>") if path == "prefilter"
                    else "scan_f32_mfma16_kernel<6, %s" % {16: "4, 1", 32: "4, 2", 64: "8, 4", 128: "8, 4", 256: "8, 4"}[nq])
     assert want_kernel in kernel, kernel
+    if path != "exact":
+        assert s.counters.prefilter_queries == nq and s.counters.fallback_queries == 0
     assert all(len(r) == TOP and np.all(np.diff(r["score"]) <= 0) for r in full)
     qa.set_option("no_mfma_scan", 1)
     try:

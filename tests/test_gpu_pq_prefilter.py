@@ -139,8 +139,8 @@ def test_pq_prefilter_with_deleted_rows_and_filter(qa):
 
 
 def test_only_the_overflowing_queries_take_the_exact_pq_scan(qa):
-    """5000 rows carry the same codes: a query near them has 5000 equal scores at the top of its list - more than its verification list takes -,
-    so that query is re-scanned exactly, the others keep the prefilter's verified lists."""
+    """5000 rows carry the same codes: a query near them has 5000 equal scores at the top of its list - more than a query may verify here (option
+    verify_max_per_query = 2048) -, so that query is re-scanned exactly, the others keep the prefilter's verified lists."""
     dist, dim, chunk, nq, top, n_dup = O.DOT, 128, 8, 40, 10, 5000
     rng, vecs, quant, opq, st0 = _segment(qa, dist, dim, chunk, N, seed=17, clustered=False)
     codes = opq.codes.copy()
@@ -151,8 +151,12 @@ def test_only_the_overflowing_queries_take_the_exact_pq_scan(qa):
     queries = rng.standard_normal((nq, dim)).astype(np.float32)
     hot = np.sort(rng.choice(nq, 6, replace=False))
     queries[hot] = (3.0 * vecs[dup_at[0]] + 0.05 * rng.standard_normal((6, dim))).astype(np.float32)
-    s = qa.BatchFilteredSearcher(queries, st, top)
-    got = s.peek_top_all()
+    qa.set_option("verify_max_per_query", 2048)        # (by default a query takes what it needs from the batch's pool: 5000 tied rows would simply be verified)
+    try:
+        s = qa.BatchFilteredSearcher(queries, st, top)
+        got = s.peek_top_all()
+    finally:
+        qa.set_option("verify_max_per_query", -1)
     assert "pq_prefilter_kernel" in _kernel(qa, s)
     assert s.counters.fallback_queries == len(hot), (s.counters.fallback_queries, hot)
     _same(got, _exact(qa, queries, st, top))

@@ -92,9 +92,18 @@ def _same_up_to_equal_scores(got, want):
                 assert g["idx"][i] < g["idx"][i + 1]
 
 
+@pytest.fixture
+def max_2048_rows_per_query(qa):
+    """A query may verify at most 2048 rows (option verify_max_per_query; by default it takes what it needs from the batch's pool of 16 384 per query):
+    3000-fold ties then send exactly the tied queries to the exact scan - the per-query fallback these tests are about."""
+    qa.set_option("verify_max_per_query", 2048)
+    yield
+    qa.set_option("verify_max_per_query", -1)
+
+
 @pytest.mark.parametrize("copy", [0, 1, 2])
-def test_split_scan_falls_back_when_scores_tie_in_masses(qa, copy):
-    """Every row exists 3000 times: the verification band holds at least 3000 rows per query, more than the list takes -> every query's overflow flag
+def test_split_scan_falls_back_when_scores_tie_in_masses(qa, copy, max_2048_rows_per_query):
+    """Every row exists 3000 times: the verification band holds at least 3000 rows per query, more than a query may verify -> every query's overflow flag
     -> the exact scan of those queries runs behind the prefilter in the same stream.  Equal scores come back in ascending id order, like the oracle's."""
     dim, nq, top, rep = 128, 70, 10, 3000
     base = O.preprocess(O.COSINE, O.synth(0x5EED0520, 0, N // rep, dim))
@@ -135,7 +144,7 @@ def test_split_scan_when_the_sample_is_all_deleted(qa, copy):
 
 @pytest.mark.parametrize("copy", [0, 1, 2])
 @pytest.mark.parametrize("nq,n_hot", [(150, 5), (128, 1), (100, 20), (300, 70), (256, 17)])
-def test_only_the_overflowing_queries_take_the_exact_scan(qa, copy, nq, n_hot):
+def test_only_the_overflowing_queries_take_the_exact_scan(qa, copy, nq, n_hot, max_2048_rows_per_query):
     """3000 rows of the block are copies of one vector v.  A query near v has 3000 equal scores at the top of its list: more than its
     verification list takes, so THAT query is re-scanned exactly; the other queries of the batch keep the prefilter's (verified) lists.
     qmx_counters.fallback_queries says how many took the exact scan.  nq = 150 without a copy: the last 22 queries take the regular exact
@@ -181,3 +190,34 @@ def test_split_scan_dot_with_any_magnitudes(qa, row_mag, query_mag):
         got = s.peek_top_all()
         assert ["scan_f32_split_kernel", "scan_f16pair_kernel<false>", "scan_f16pair_kernel<true>"][copy] in _kernel(qa, s)
         _same(got, st.peek_top(queries, top, threads=8))
+
+
+@pytest.mark.parametrize("copy", [1, 2])
+def test_the_verification_pool_serves_long_tie_lists_and_overflows_query_by_query(qa, copy):
+    """By default the batch shares one pool of 16 384 rows per query: a query with 3000 tied rows at the top verifies them all (no exact scan), and when
+    the ties are so many that the pool runs out - every row exists 30 000 times: 70 queries want 2.1 M rows of a pool of 1.15 M - the queries that
+    come too late take the exact scan, one by one, while the others keep their verified lists.  Lists: the exact scan's either way."""
+    dim, nq, top = 128, 70, 10
+    flag = [0, qa._ffi.SEG_SPLIT_COPY, qa._ffi.SEG_HALF_COPY][copy]
+    for rep, want_fallback in ((3000, False), (30_000, True)):
+        base = O.preprocess(O.COSINE, O.synth(0x5EED0560, 0, N // rep, dim))
+        rows = np.tile(base, (rep, 1))
+        queries = O.synth(0x5EED0561, 0, nq, dim)
+        vs = qa.VectorStorage(rows, qa.Distance.Cosine, flags=flag)
+        s = qa.BatchFilteredSearcher(queries, vs, top)
+        got = s.peek_top_all()
+        c = s.counters
+        assert c.prefilter_queries == nq
+        if want_fallback:
+            assert 0 < c.fallback_queries < nq, c.fallback_queries
+        else:
+            assert c.fallback_queries == 0 and c.verified_rows >= 3000 * nq
+        qa.set_option("no_split_scan", 1)
+        try:
+            exact = qa.BatchFilteredSearcher(queries, vs, top).peek_top_all()
+        finally:
+            qa.set_option("no_split_scan", -1)
+        for g, e in zip(got, exact):
+            assert np.array_equal(g, e)
+        for g in got:       # the lowest offsets of the tied copies, ascending
+            assert g["idx"].tolist() == sorted(g["idx"].tolist()) and (g["idx"] < 10 * len(base)).all()
