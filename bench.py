@@ -81,6 +81,9 @@ def parse():
     ap.add_argument("--configs", default="c3,tq,c4", help="comma list of the secondary single-GPU configs to run (empty = none)")
     ap.add_argument("--config-rows", type=int, default=0, help="rows of C3 / C4 (0 = --rows)")
     ap.add_argument("--hnsw-queries", type=int, default=8192, help="searches per launch of the HNSW walks")
+    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2, 3, 4],
+                    help="query batches in flight on one GPU: 2 = consecutive steps alternate between two query handles on two streams, so that one batch's "
+                         "head (preprocess, sample pre-scan, pack) and tail (probe, verification, sort) run beside the other's scans; 1 = one handle, one stream")
     ap.add_argument("--fanout-rows", type=int, default=1_000_000,
                     help="rows per segment of the one-process fan-out legs (qmx_sharded_hnsw_build + qmx_sharded_search_topk over one segment per device); 0 = skip")
     return ap.parse_args()
@@ -157,6 +160,13 @@ def main():
     F.check(lib.qmx_query_set_timing(qh, 1))
     searcher = sharded.ShardedSearcher(backend, n, Q, top, device=dev)  # scan -> all-gather -> merge (world > 1)
     out, counts = searcher.out, searcher.counts
+    # a second batch in flight (single GPU): its own query handle, stream and result buffers; steps alternate between the two.  Every step is still one
+    # whole search of one batch - the GPU merely has the next batch's head to run while this batch's scans and tail are in flight
+    lanes = [(backend, out, counts)]
+    for _ in range(args.in_flight - 1 if world == 1 else 0):
+        backend2 = sharded.HipBackend(storage, Q, local_rank, torch.cuda.Stream(dev))
+        F.check(lib.qmx_query_set_timing(backend2.qh, 1))
+        lanes.append((backend2, torch.zeros_like(out), torch.zeros_like(counts)))
 
     def step(i):
         b = i % nbatches
@@ -164,7 +174,9 @@ def main():
         if world > 1:
             searcher.search(qb)
         else:
-            backend.local_topk(qb, top, out, counts)
+            be, o, c = lanes[i % len(lanes)]
+            with torch.cuda.stream(be.stream):
+                be.local_topk(qb, top, o, c)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -176,25 +188,30 @@ def main():
         step(i)
     fence()
     ms0, l0 = C.c_float(), C.c_uint32()
-    F.check(lib.qmx_query_timing(qh, C.byref(ms0), C.byref(l0)))  # drop warm-up launches
+    for be, _, _ in lanes:
+        F.check(lib.qmx_query_timing(be.qh, C.byref(ms0), C.byref(l0)))  # drop warm-up launches
 
     fence()
     # (the spread of the timed region, without touching it: an event on the stream every `gsz` steps, read after the closing fence)
     gsz = max(1, args.steps // 10)
     marks = [torch.cuda.Event(enable_timing=True)]
     t0 = time.perf_counter()
-    marks[0].record(stream)
+    marks[0].record(lanes[0][0].stream if world == 1 else stream)
     for i in range(args.steps):
         step(i)
         if (i + 1) % gsz == 0:
             marks.append(torch.cuda.Event(enable_timing=True))
-            marks[-1].record(stream)
+            marks[-1].record(lanes[i % len(lanes)][0].stream if world == 1 else stream)
     fence()
     elapsed = time.perf_counter() - t0
     group_ms = [marks[j].elapsed_time(marks[j + 1]) / gsz for j in range(len(marks) - 1)]      # device time per step, per group of gsz steps
 
     kms, kl = C.c_float(), C.c_uint32()
-    F.check(lib.qmx_query_timing(qh, C.byref(kms), C.byref(kl)))
+    for be, _, _ in lanes:       # the scan launches of every batch in flight
+        m1, l1 = C.c_float(), C.c_uint32()
+        F.check(lib.qmx_query_timing(be.qh, C.byref(m1), C.byref(l1)))
+        kms.value += m1.value
+        kl.value += l1.value
     kernel_symbol = F.last_kernel(qh)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -248,6 +265,7 @@ def main():
                                      "(query, 10M-row segment) searches per second; at n_gpus=1 this is plain QPS"),
                    "collection_qps": round(Q * args.steps / elapsed, 2),
                    "timed_path": _timed_path(kernel_symbol),
+                   "batches_in_flight": len(lanes),
                    "derived_copy": dict(seg_info, requested=args.split_copy)},
         "roofline": _roofline(n, dim, kernel_ms, alg_bytes, achieved, int(kl.value), launches_per_step, Q, kernel_symbol, launches_per_pass),
     }
@@ -339,6 +357,8 @@ def main():
         dist.barrier()
     if solo and not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(args, rows, queries, out, counts, n, dim, Q, top, lib, qh, F, qa, np, torch)
+    for be, _, _ in lanes[1:]:
+        be.close()
     backend.close()
     wanted = [c for c in args.configs.lower().split(",") if c]
     if solo and wanted:
@@ -995,7 +1015,7 @@ def c3_section(ctx, rows):
             walker = O.Hnsw.from_plain(graph.export_plain(), n)
             flags = O.DenseStorage(O.F32, O.DOT, np.zeros((1, dim), dtype=np.float32))
             flags.st.n = n
-            nchk = 16
+            nchk = min(256, int(queries.shape[0]))      # (16 searches were thin evidence at 10 M rows)
             want = walker.search_sq(flags, osq_all, queries[:nchk].cpu().numpy(), 2 * top, 128)
             got = graph.search(2 * top, 128, qa.new_raw_scorer(queries[:nchk].contiguous(), enc))
             st["oracle_walk_check"] = {"same_ids": "%d/%d" % (sum(int(a["idx"].tolist() == b["idx"].tolist()) for a, b in zip(got, want)), nchk),
@@ -1149,7 +1169,7 @@ def c4_section(ctx):
             walker = O.Hnsw.from_plain(graph.export_plain(), n)
             flags = O.DenseStorage(O.F32, O.DOT, np.zeros((1, dim), dtype=np.float32))
             flags.st.n = n
-            nchk = 16
+            nchk = min(256, int(queries.shape[0]))      # (16 searches were thin evidence at 10 M rows)
             qpre = queries[:nchk].cpu().numpy()
             # the oracle's LUT is the exact-order one; the device walk under test uses the MFMA LUT (<= 1e-5): compare against a device walk
             # with the exact-order LUT for bits, and report how the MFMA-LUT walk compares

@@ -45,8 +45,9 @@ enum Option {
     OPT_TQ_ROTATE_BLOCK,      // TurboQuant rotation by the one-block-per-vector kernel (not one wave per vector)
     OPT_NO_TOPK_SMALL,        // top-k of short score rows by the insertion kernel (not the rank-sort of the pruned row)
     OPT_VERIFY_MAX_PER_QUERY, // prefilters: a query with more rows inside its band than this takes the exact scan, whatever room the batch's pool has (0 = no such limit)
-    OPT_NO_HNSW_PQ_BLOCK,     // PQ walk: keep the one-wave-per-search kernel with the LUT read through L2 (not the block-per-search walk with the LUT in LDS)
-    OPT_HNSW_PQ_BLOCK_WAVES,  // ... waves of a block of that walk: one controller + (waves - 1) speculating workers (0 = default 8; 2 .. 16)
+    OPT_NO_HNSW_PQ_BLOCK,     // PQ walk: keep the one-wave-per-search kernel with the LUT read through L2 (default 1; 0 = the block-per-search walk with the LUT in LDS)
+    OPT_HNSW_PQ_BLOCK_WAVES,  // ... waves of a block of that walk: one controller + (waves - 1) speculating workers (0 = default 8; 3 .. 8)
+    OPT_HNSW_PQ_BLOCK_SET,    // ... entries of its LDS visited set (0 = what fits; tests shrink it to reach the restart on the HBM bitmap)
     OPT_DEBUG,                // log dropped stale HIP errors
     OPT_COUNT
 };

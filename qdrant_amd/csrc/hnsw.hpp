@@ -619,12 +619,20 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
         }
     } else {
     // search_on_level_with_vectors: `candidates` also holds what `nearest` evicted before it was expanded; when every entry of the beam is
-    // expanded the reference pops the best of those, scores its base vector and stops (`candidate.score < lower_bound`)
-    uint64_t evicted_best = 0;
+    // expanded the reference pops the best of those: one whose score EQUALS the lower bound is expanded like any other (the loop breaks on strict
+    // `candidate.score < lower_bound` only, graph_layers.rs:358), the first one below it has its base vector scored and ends the loop.  The four best
+    // evicted-unexpanded candidates are kept (more than four of them tying with the bound at once is not covered; among equal scores the reference's
+    // pop order is its heap's)
+    uint64_t ev[4] = {0, 0, 0, 0};
     uint32_t n_exp = 0;
     while (true) {
-        const uint64_t ck = beam.pop_best(lane);
-        if (ck == 0) break;
+        uint64_t ck = beam.pop_best(lane);
+        if (ck == 0) {
+            if (h.expanded && ev[0] && key_score(ev[0]) == key_score(beam.at(ef - 1))) {
+                ck = ev[0];
+                ev[0] = ev[1]; ev[1] = ev[2]; ev[2] = ev[3]; ev[3] = 0;
+            } else break;
+        }
         const uint32_t cand = key_idx(ck);
         if (h.expanded) {
             if (lane == 0 && n_exp < h.xcap) h.expanded[(uint64_t)qi * h.xcap + n_exp] = cand;
@@ -674,7 +682,12 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
                 const uint64_t nk = readlane_u64(mykey, src);
                 const uint64_t last = beam.at(ef - 1);
                 if (nk > last) {
-                    if (h.expanded && last > evicted_best && !beam.done_at(ef - 1)) evicted_best = last;
+                    if (h.expanded && last != 0 && !beam.done_at(ef - 1)) {      // an unexpanded entry leaves `nearest`: it stays in `candidates`
+                        uint64_t x = last;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (x > ev[i]) { const uint64_t t = ev[i]; ev[i] = x; x = t; }
+                    }
                     beam.insert(nk, ef, lane);
                 }
             }
@@ -682,8 +695,8 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
         }
     }
     if (h.expanded) {
-        if (evicted_best) {
-            if (lane == 0 && n_exp < h.xcap) h.expanded[(uint64_t)qi * h.xcap + n_exp] = key_idx(evicted_best);
+        if (ev[0]) {      // the pop that ends the loop: the best evicted candidate below the bound
+            if (lane == 0 && n_exp < h.xcap) h.expanded[(uint64_t)qi * h.xcap + n_exp] = key_idx(ev[0]);
             ++n_exp;
         }
         if (lane == 0) h.expanded_cnt[qi] = n_exp;

@@ -84,6 +84,9 @@ __device__ __forceinline__ uint32_t heuristic_fill(const ScanArgs &a, const uint
     return n_sel;
 }
 
+// entries of the candidate arrays of phase 1 (LDS): the register beam's 64 E, or ef_construct rounded up to whole waves for the LDS beam
+__host__ __device__ static inline uint32_t hnsw_build_cand_cap(int E, uint32_t ef) { return E ? 64u * (uint32_t)E : (ef + 63u) / 64u * 64u; }
+
 // ---- phase 1 ----------------------------------------------------------------------------------------------------
 // H scores the searches of an insertion (the new point as the query), HI scores stored <-> stored pairs (score_internal: the heuristic).
 // They are the same policy except for storages without an internal query (PQ): H = the LUT of the original vector, HI = centroid tables.
@@ -92,13 +95,16 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(const ScanArgs a0
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
+    // E > 0: the beam of the insertion searches in registers (64 E entries); E == 0 (ef_construct > 512): in LDS behind the query entry, as the walk's
+    const uint32_t ccap = hnsw_build_cand_cap(E, h.ef_construct);
     uint32_t *hop_ids = reinterpret_cast<uint32_t *>(smem);
     float *hop_scores = reinterpret_cast<float *>(smem + 256);
-    uint32_t *cand_ids = reinterpret_cast<uint32_t *>(smem + 512);                     // [64 E]
-    float *cand_scores = reinterpret_cast<float *>(smem + 512 + 256 * E);
-    uint32_t *sel_ids = reinterpret_cast<uint32_t *>(smem + 512 + 512 * E);            // [HNSW_BUILD_MAX_M0]
-    float *sel_scores = reinterpret_cast<float *>(smem + 512 + 512 * E + 4 * HNSW_BUILD_MAX_M0);
-    unsigned char *q_lds = smem + 512 + 512 * E + 8 * HNSW_BUILD_MAX_M0;
+    uint32_t *cand_ids = reinterpret_cast<uint32_t *>(smem + 512);                     // [ccap]
+    float *cand_scores = reinterpret_cast<float *>(smem + 512 + 4 * (size_t)ccap);
+    uint32_t *sel_ids = reinterpret_cast<uint32_t *>(smem + 512 + 8 * (size_t)ccap);   // [HNSW_BUILD_MAX_M0]
+    float *sel_scores = reinterpret_cast<float *>(smem + 512 + 8 * (size_t)ccap + 4 * HNSW_BUILD_MAX_M0);
+    unsigned char *q_lds = smem + 512 + 8 * (size_t)ccap + 8 * HNSW_BUILD_MAX_M0;
+    unsigned char *beam_lds = q_lds + ((size_t)h.lds_query_bytes + 15) / 16 * 16;
     uint32_t *vis = h.visited + (uint64_t)blockIdx.x * h.vis_words;
     uint32_t *vlog = h.vis_log + (uint64_t)blockIdx.x * h.log_cap;
     const unsigned char *rows = reinterpret_cast<const unsigned char *>(a0.rows);
@@ -185,6 +191,10 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(const ScanArgs a0
         for (int32_t lv = (int32_t)top_link_level; lv >= 0; --lv) {
             const uint32_t level = (uint32_t)lv;
             Beam<E> beam;
+            if constexpr (E == 0) {
+                __syncthreads();
+                beam.init(beam_lds, ef);
+            }
             beam.clear();
             uint32_t log_cnt = 1;
             if (lane == 0) {
@@ -229,8 +239,20 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(const ScanArgs a0
             // candidates, best first
             __syncthreads();
             uint32_t n_cand = 0;
+            if constexpr (E == 0) {
+                for (uint32_t base = 0; base < ef; base += 64) {
+                    const uint32_t idx = base + (uint32_t)lane;
+                    const uint64_t k = idx < ef ? beam.at(idx) : 0ull;
+                    const bool ok = k != 0;
+                    if (ok) {
+                        cand_ids[idx] = key_idx(k);
+                        cand_scores[idx] = key_score(k);
+                    }
+                    n_cand += (uint32_t)__popcll(__ballot(ok));
+                }
+            } else {
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
+            for (int e = 0; e < (E ? E : 1); ++e) {
                 const uint32_t idx = (uint32_t)e * 64 + (uint32_t)lane;
                 const bool ok = beam.key[e] != 0;
                 if (ok) {
@@ -238,6 +260,7 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(const ScanArgs a0
                     cand_scores[idx] = key_score(beam.key[e]);
                 }
                 n_cand += (uint32_t)__popcll(__ballot(ok));
+            }
             }
             __syncthreads();
             // give the visited bitmap back all-zero (fresh VisitedList per level, graph_layers.rs:108-116)
@@ -358,23 +381,35 @@ __global__ __launch_bounds__(64) void hnsw_build_link_kernel(const ScanArgs a, c
 // H: the scorer of the insertion searches; HI: the stored <-> stored scorer (phase 2 and the heuristic), H itself unless given
 template <class H, class HI = H>
 int32_t launch_hnsw_build_hop(hipStream_t st, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu) {
-    QMX_REQUIRE(h.ef_construct >= 1 && h.ef_construct <= HNSW_MAX_EF_REG, QMX_ERR_NOT_SUPPORTED, "ef_construct %u not in 1..%u", h.ef_construct,
-                HNSW_MAX_EF_REG);
-    const bool big = h.ef_construct > 128;
-    const size_t lds1 = 512 + 512 * (big ? 8 : 2) + 8 * HNSW_BUILD_MAX_M0 + h.lds_query_bytes;
+    QMX_REQUIRE(h.ef_construct >= 1 && h.ef_construct <= HNSW_MAX_EF, QMX_ERR_NOT_SUPPORTED, "ef_construct %u not in 1..%u", h.ef_construct, HNSW_MAX_EF);
+    // the beam of the insertion searches: 128 / 512 entries in registers, wider ones in LDS behind the query entry (as the walk's, hnsw.hpp Beam<0>)
+    const int e_sel = h.ef_construct <= 128 ? 2 : h.ef_construct <= HNSW_MAX_EF_REG ? 8 : 0;
+    const size_t lds1 = 512 + 8 * (size_t)hnsw_build_cand_cap(e_sel, h.ef_construct) + 8 * HNSW_BUILD_MAX_M0 + ((size_t)h.lds_query_bytes + 15) / 16 * 16 +
+                        (e_sel == 0 ? hnsw_beam_lds(h.ef_construct) : 0);
     if (phase == 1) {
         auto k2 = hnsw_build_search_kernel<H, HI, 2>;
         auto k8 = hnsw_build_search_kernel<H, HI, 8>;
+        auto k0 = hnsw_build_search_kernel<H, HI, 0>;
+        QMX_REQUIRE(lds1 <= 160 * 1024, QMX_ERR_NOT_SUPPORTED, "HNSW build: ef_construct %u needs %zu bytes of LDS per insertion", h.ef_construct, lds1);
+        if (e_sel == 0) {
+            static thread_local DeviceOnce attr_once;
+            if (attr_once.need()) {
+                QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_once.mark();
+            }
+        }
         if (grid == 0) {
             int n = 0;
-            if (big) QMX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k8, 64, lds1));
-            else QMX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k2, 64, lds1));
+            if (e_sel == 8) QMX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k8, 64, lds1));
+            else if (e_sel == 2) QMX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k2, 64, lds1));
+            else QMX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k0, 64, lds1));
             *per_cu = n < 1 ? 1 : n;
             return QMX_OK;
         }
         ::qmx::clear_stale_error();
-        if (big) hipLaunchKernelGGL(k8, dim3(grid), dim3(64), lds1, st, a, h);
-        else hipLaunchKernelGGL(k2, dim3(grid), dim3(64), lds1, st, a, h);
+        if (e_sel == 8) hipLaunchKernelGGL(k8, dim3(grid), dim3(64), lds1, st, a, h);
+        else if (e_sel == 2) hipLaunchKernelGGL(k2, dim3(grid), dim3(64), lds1, st, a, h);
+        else hipLaunchKernelGGL(k0, dim3(grid), dim3(64), lds1, st, a, h);
         QMX_HIP(hipGetLastError());
         return QMX_OK;
     }

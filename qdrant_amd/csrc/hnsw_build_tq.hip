@@ -6,7 +6,7 @@ namespace qmx {
 // ------------------------------------------------------------------------------------------
 // HNSW build over a TurboQuant segment (hnsw/build.rs:334-341 + point_scorer.rs:183-218).  EncodedVectorsTQ cannot turn a stored row into a
 // query (encode_internal_vector -> None), so - as for PQ - the searches of an insertion score through precompute_query of the point's ORIGINAL
-// vector (the RowTQ* policies over the batch's entries, made by api.hip before phase 1 and staged in LDS per insertion) while everything
+// vector (the RowTQ* policies over the batch's entries, made by api_hnsw.hip before phase 1 and staged in LDS per insertion) while everything
 // stored <-> stored - the heuristic, the back links, an entry point at or below the new point's level - is score_symmetric
 // (turboquant/quantization.rs:395-494): the integer dot of the two rows' codebook bytes (1 bit: dim - 2 popcount(a ^ b)), as tq_internal_kernel
 // below.  One lane per stored row; `qp` is the other row's code bytes inside the block, so its index - the extras columns - follows from the pointer.

@@ -609,6 +609,8 @@ static size_t pqb_lds_bytes(const ScanArgs &a, int waves, uint32_t *vh_n_out) {
     const size_t fixed = (size_t)a.q_stride + (size_t)(waves - 1) * sizeof(PqbSlot) + 16;
     const size_t room = fixed < 160 * 1024 ? 160 * 1024 - fixed : 0;
     uint32_t vh_n = (uint32_t)std::min<size_t>(room / 4, a.q_stride > 64 * 1024 ? 14336 : 8192) / 64 * 64;
+    const int64_t cap = option(OPT_HNSW_PQ_BLOCK_SET);
+    if (cap >= 64 && (uint64_t)cap < vh_n) vh_n = (uint32_t)cap / 64 * 64;
     if (vh_n_out) *vh_n_out = vh_n;
     return fixed + (size_t)vh_n * 4;
 }
@@ -619,7 +621,7 @@ bool pq_block_walk_ok(const ScanArgs &a, const HnswArgs &h) {
     (void)pqb_lds_bytes(a, PQB_MAX_WAVES, &vh_n);
     return !h.acorn && !h.expanded && !a.cq_desc && !a.mv_offsets && h.l0 != nullptr && h.l0_stride >= 2 && h.l0_stride - 1 <= h.m0 && ef >= 1 &&
            ef <= HNSW_MAX_EF_REG && a.pq_m >= 4 && a.pq_m <= 128 && a.row_stride % 16 == 0 && (reinterpret_cast<uintptr_t>(a.rows) & 15) == 0 && a.q_stride % 16 == 0 &&
-           (size_t)a.pq_m * a.pq_ncent * 4 <= a.q_stride && vh_n >= 2048 && h.n_points < 0xFFFFFFF0u;
+           (size_t)a.pq_m * a.pq_ncent * 4 <= a.q_stride && vh_n >= 64 && h.n_points < 0xFFFFFFF0u;
 }
 
 template <int E>

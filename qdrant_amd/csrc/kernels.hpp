@@ -33,7 +33,7 @@ struct ScanArgs {
     uint64_t *partial;         // [grid][partial_qt][top] keys (top-k mode)
     uint32_t partial_qt;       // query stride of `partial` (the small-row kernel; the tiled one uses its QT)
     const uint64_t *gthr;      // [QT] keys or nullptr (scan_mfma16.hip only): a key whose score is a lower bound of the query's final k-th best
-                               // score (0 = none): the k-th best of a pre-scan of a prefix of the block (api.hip search_enqueue)
+                               // score (0 = none): the k-th best of a pre-scan of a prefix of the block (api_search.hip search_enqueue)
     const uint64_t *key_bound; // [QT] exclusive upper bound on accepted keys (top > 64 runs in passes of 64), or nullptr
     float *scores;             // [nq][n_cand] (score mode)
     uint64_t scores_stride;    // elements between queries in `scores`
@@ -118,7 +118,7 @@ struct HnswArgs {
     uint32_t acorn;                 // SearchAlgorithm::Acorn on level 0 (graph_layers.rs:154-243): `visited` holds two bitmaps of vis_words / 2 words
     uint32_t hop_cap;               // entries of the hop id / score buffers in LDS (64; m0 (m0 + 1) rounded up for ACORN)
     // search_on_level_with_vectors (graph_layers.rs:336-389): the candidates the level-0 loop POPS (the one that ends it included) are what
-    // the base scorer sees; they are listed here for the base scoring that follows the walk (api.hip qmx_hnsw_search_with_vectors)
+    // the base scorer sees; they are listed here for the base scoring that follows the walk (api_hnsw.hip qmx_hnsw_search_with_vectors)
     uint32_t *expanded;             // [nq][xcap] or nullptr
     uint32_t *expanded_cnt;         // [nq] popped candidates (may exceed xcap: the list is then incomplete)
     uint32_t xcap;
@@ -318,7 +318,7 @@ int32_t launch_split_regroup(hipStream_t st, const ScanArgs &a, const void *d_wl
                              int *d_overflow, uint32_t phase, uint32_t qt);
 size_t split_copy_bytes(uint64_t n, uint32_t dim, int half);
 int32_t launch_split_copy(hipStream_t st, const void *rows, uint64_t row_stride, uint64_t n, uint32_t dim, float row_scale, void *d_out, int half);
-// what one search through the prefilter did (device side; api.hip folds it into qmx_counters)
+// what one search through the prefilter did (device side; api_search.hip folds it into qmx_counters)
 struct SplitStats {
     unsigned long long candidates;   // (row, query) pairs the approximate scan let through, deleted rows dropped
     unsigned long long verified;     // of those, re-scored exactly from the f32 rows

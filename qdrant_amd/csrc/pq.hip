@@ -328,7 +328,7 @@ int32_t launch_hnsw_custom_pq(hipStream_t st, const ScanArgs &a, const HnswArgs 
 // ------------------------------------------------------------------------------------------
 // HNSW build over a PQ segment (hnsw/build.rs:334-341 + point_scorer.rs:183-218).  EncodedVectorsPQ cannot turn a stored row
 // into a query (encode_internal_vector -> None), so the searches of an insertion score through the LUT of the point's ORIGINAL
-// vector (HopPQ over the batch's LUTs, made by api.hip before phase 1) while everything stored <-> stored — the heuristic, the
+// vector (HopPQ over the batch's LUTs, made by api_hnsw.hip before phase 1) while everything stored <-> stored — the heuristic, the
 // back links, an entry point at or below the new point's level — is EncodedVectorsPQ::score_internal (:574-618): the sum over
 // chunks of the distance between the two rows' centroids.  Those chunk distances are tabulated once per segment
 // (pair[c][i][j], m x 256 x 256 f32 = 25 MB at m = 96) with the reference's own inner loop, so a pair score is m table gathers

@@ -23,7 +23,7 @@
 // k-th best score; rows with A >= (T_q - L) / step - band become candidates (per-wave lists, plain stores); `sp_select_kernel` keeps those
 // within two bands of the k-th best approximate score; `pq_pair_kernel` re-scores them in the reference's order and `sort_scored_kernel`
 // returns the top k: ids, score bits and tie order of the exact scan.  A query whose lists overflow (or whose LUT has non-finite entries)
-// takes the exact scan, alone (api.hip).
+// takes the exact scan, alone (api_*.hip).
 //
 // Roofline: the stream is m_pad bytes per row and 4-query group (through L2 for all groups but the first: blocks of one row slab and
 // different query groups are placed on the same XCD, see `pqf_block_role`); what binds from 8 queries up is LDS issue (2 cycles per

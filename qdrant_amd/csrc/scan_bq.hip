@@ -105,7 +105,7 @@ __global__ __launch_bounds__(BQR_BLOCK) void bq_rows_kernel(const ScanArgs a) {
     const int top = (int)a.top;
     const float dimf = (float)a.bq_dim;
     uint64_t list[QT];
-    uint64_t floor_key[QT];   // a.gthr: a key known to be <= the query's final k-th best key (the k-th best of a pre-scanned prefix, api.hip): keys below it never enter a list
+    uint64_t floor_key[QT];   // a.gthr: a key known to be <= the query's final k-th best key (the k-th best of a pre-scanned prefix, api_*.hip): keys below it never enter a list
 #pragma unroll
     for (int q = 0; q < QT; ++q) {
         list[q] = 0;

@@ -296,7 +296,7 @@ int32_t launch_qt(hipStream_t st, ScanMode mode, const ScanArgs &a, int num_cus,
 }
 
 // Policies whose batches of 4 and more queries run on the matrix cores (TurboQuant: scan_sq_mfma.hip) say MAX_VALU_QT = 4: their 8- and 16-query
-// tiled VALU kernels (the largest instantiations of this file's kernel, and the slowest to compile) are not built; api.hip tiles by 4 for them
+// tiled VALU kernels (the largest instantiations of this file's kernel, and the slowest to compile) are not built; api_*.hip tiles by 4 for them
 // when the matrix-core route is switched off.
 template <class P, class = void>
 struct max_valu_qt { static constexpr int value = 16; };
@@ -440,7 +440,11 @@ constexpr int PAIR_BLOCK = 256;
 // valid in every lane of the group.  `qp` = the query's tile entry (elements, zero padding, aux) in
 // LDS or in global memory.  Shared by pair_kernel and the HNSW hop scorer, so both produce the
 // bits of the scan.
-template <class P, int UNROLL = 4>      // UNROLL row pieces (and their query pieces) in flight per lane
+// (The step loops below run in batches of UNROLL steps whose loads are ALL issued before the first is used, whatever the row length: a plain
+// `#pragma unroll UNROLL` over a runtime trip count leaves the remainder - every step of a row shorter than UNROLL steps, the last two of an SQ row of
+// 768 bytes at UNROLL 4 - as a loop of dependent round trips.  Steps past the row re-read its last step - a valid address, the value unused - so the
+// loads stay straight-line code.)
+template <class P, int UNROLL = 8>      // UNROLL row pieces (and their query pieces) in flight per lane
 __device__ __forceinline__ float group_score(const ScanArgs &a, const unsigned char *qp, uint32_t id, int t) {
     constexpr int NRA = P::NRAUX > 0 ? P::NRAUX : 1;
     const int piece = lane_piece(t);
@@ -454,11 +458,17 @@ __device__ __forceinline__ float group_score(const ScanArgs &a, const unsigned c
     for (int k = 0; k < P::NACC; ++k) acc[0][0][k] = 0;
 #pragma unroll
     for (int k = 0; k < NRA; ++k) raux[0][k] = 0;
-#pragma unroll UNROLL
-    for (uint32_t s = 0; s < a.nseg; ++s) {
-        uint4 v[1];
-        v[0] = *reinterpret_cast<const uint4 *>(rp + (uint64_t)s * 128);
-        scan_step<P, 1, 1>(acc, raux, v, qp, s * 128 + piece_off, 0, true);
+    const uint32_t nseg = a.nseg;
+    for (uint32_t s0 = 0; s0 < nseg; s0 += UNROLL) {
+        uint4 v[UNROLL][1];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const uint32_t s = s0 + (uint32_t)u < nseg ? s0 + (uint32_t)u : nseg - 1;
+            v[u][0] = *reinterpret_cast<const uint4 *>(rp + (uint64_t)s * 128);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+            if (s0 + (uint32_t)u < nseg) scan_step<P, 1, 1>(acc, raux, v[u], qp, (s0 + (uint32_t)u) * 128 + piece_off, 0, true);
     }
     if (a.rem_pieces) {
         uint4 v[1];
@@ -475,6 +485,7 @@ __device__ __forceinline__ float group_score(const ScanArgs &a, const unsigned c
 template <class P, int R>
 __device__ __forceinline__ void group_score_multi(const ScanArgs &a, const unsigned char *qp, const uint32_t (&ids)[R], int t, float (&out)[R]) {
     constexpr int NRA = P::NRAUX > 0 ? P::NRAUX : 1;
+    constexpr int U = R >= 4 ? 4 : 6;       // steps in flight per row: 16 / 12 pieces per lane
     const int piece = lane_piece(t);
     const int piece_off = piece * 16;
     const bool piece_in_rem = piece < (int)a.rem_pieces;
@@ -490,12 +501,18 @@ __device__ __forceinline__ void group_score_multi(const ScanArgs &a, const unsig
 #pragma unroll
         for (int k = 0; k < NRA; ++k) raux[r][k] = 0;
     }
-#pragma unroll 4
-    for (uint32_t s = 0; s < a.nseg; ++s) {
-        uint4 v[R];
+    const uint32_t nseg = a.nseg;
+    for (uint32_t s0 = 0; s0 < nseg; s0 += U) {
+        uint4 v[U][R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) v[r] = *reinterpret_cast<const uint4 *>(rp[r] + (uint64_t)s * 128);
-        scan_step<P, 1, R>(acc, raux, v, qp, s * 128 + piece_off, 0, true);
+        for (int u = 0; u < U; ++u) {
+            const uint32_t s = s0 + (uint32_t)u < nseg ? s0 + (uint32_t)u : nseg - 1;
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[u][r] = *reinterpret_cast<const uint4 *>(rp[r] + (uint64_t)s * 128);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (s0 + (uint32_t)u < nseg) scan_step<P, 1, R>(acc, raux, v[u], qp, (s0 + (uint32_t)u) * 128 + piece_off, 0, true);
     }
     if (a.rem_pieces) {
         uint4 v[R];
@@ -525,7 +542,8 @@ __global__ __launch_bounds__(PAIR_BLOCK) void pair_kernel(const ScanArgs a, cons
     const uint64_t slots = lists ? n_items / sel.per_query : 1;
     for (uint64_t slot = lists ? blockIdx.y : 0; slot < slots; slot += gridDim.y) {
         const uint64_t first = lists ? slot * sel.per_query : 0;
-        const uint64_t end = lists ? first + (sel.counts[slot] < sel.per_query ? sel.counts[slot] : sel.per_query) : n_items;
+        const uint64_t n_live = sel.limit ? (n_items < (uint64_t)*sel.limit ? n_items : (uint64_t)*sel.limit) : n_items;      // (a pool filled on the device: its count)
+        const uint64_t end = lists ? first + (sel.counts[slot] < sel.per_query ? sel.counts[slot] : sel.per_query) : n_live;
         for (uint64_t base = first + ((uint64_t)blockIdx.x * NW + wave) * 8; base < end; base += (uint64_t)gridDim.x * NW * 8) {
             const uint64_t item = base + g;
             bool valid = item < end;

@@ -96,7 +96,7 @@ __device__ __forceinline__ void scan_f32_mfma_body(const ScanArgs &a, unsigned c
     int my_q[NGH];        // ... which are (wave-local index) 4 (gp + u0 NGH) + x
 #pragma unroll
     for (int q = 0; q < QW; ++q) list[q] = 0;
-    uint64_t gk[NGH];     // score part of the pre-scan's bound of the lane's queries (api.hip search_enqueue; 0 = none): equal scores pass
+    uint64_t gk[NGH];     // score part of the pre-scan's bound of the lane's queries (api_search.hip search_enqueue; 0 = none): equal scores pass
 #pragma unroll
     for (int gp = 0; gp < NGH; ++gp) {
         my_q[gp] = GQ * (gp + u0 * NGH) + qofs;
@@ -426,7 +426,7 @@ int32_t launch_scan_f32_mfma(hipStream_t st, int qt, ScanMode mode, const ScanAr
             return launch_mfma_qt<16, 2, 12, true>(st, mode, a, num_cus, grid_out);
         }
     }
-    if (qt == 64 && mfma16_scan_ok(64, mode, a)) return launch_scan_f32_mfma16(st, 64, a, num_cus, grid_out);   // api.hip only asks when it applies
+    if (qt == 64 && mfma16_scan_ok(64, mode, a)) return launch_scan_f32_mfma16(st, 64, a, num_cus, grid_out);   // api_*.hip only asks when it applies
     set_error("unsupported MFMA query tile %d", qt);
     return QMX_ERR_BAD_ARG;
 }

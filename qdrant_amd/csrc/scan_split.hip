@@ -7,10 +7,10 @@
 //     sum x_i y_i  =  2^-(ex + ey) [ sum h h' + sum h l' + sum l h' ]  +  O(2^-21) sum |x_i y_i|
 // three v_mfma_f32_16x16x32_f16 per 16 x 16 x 32 block, f32 accumulation.  That approximate score is NOT returned to anybody: it only
 // decides which rows are worth an exact look.
-//   1. prescan   (api.hip)  exact scores of a strided sample of the block -> T_q = exact k-th best of the sample <= final k-th best
+//   1. prescan   (api_search.hip)  exact scores of a strided sample of the block -> T_q = exact k-th best of the sample <= final k-th best
 //   2. this file            approximate score A(r, q) of EVERY row; rows with A >= T_q - b_q become candidates (~1000 k per query)
 //   3. select               A_k = k-th best approximate score among the candidates; keep those with A >= A_k - 2 b_q  (~k rows)
-//   4. verify    (api.hip)  exact scores of the kept rows with the gather kernel of qmx_rescore (the reference's bits), sort, top k
+//   4. verify    (api_search.hip)  exact scores of the kept rows with the gather kernel of qmx_rescore (the reference's bits), sort, top k
 // With |A - E| <= b_q for the exact score E (b_q = 1e-4 |q| max|row|, two orders above the split error and above the worst-case f32
 // accumulation bound of both sides for dim <= 1600) every member of the exact top k survives 2. and 3., so the result is the exact
 // scan's result, bit for bit — ids, scores, ties — and the parity tests run against this path unchanged.  Anything unexpected (a
@@ -1055,7 +1055,7 @@ __global__ __launch_bounds__(SEL_BLOCK) void sp_select_kernel(const uint64_t *ca
 }
 
 // ---- the queries whose lists overflowed, packed: list[j] = j-th such query (0xFFFFFFFF behind the last), its pre-scan bound next to it; the run flags of
-// the conditional exact passes (api.hip: one 16-query pass when 1..16 queries overflowed, else passes of 64) ----
+// the conditional exact passes (api_*.hip: one 16-query pass when 1..16 queries overflowed, else passes of 64) ----
 __global__ __launch_bounds__(256) void sp_plan_kernel(const uint32_t *ovf_q, uint32_t nq, const uint64_t *gthr, uint32_t *list, uint64_t *gthr_packed,
                                                        uint32_t list_cap, uint32_t *count, int *run16, int *run64, uint32_t n_run64, SplitStats *stats,
                                                        const uint4 *queries, uint32_t units_per_query, uint4 *packed_queries) {

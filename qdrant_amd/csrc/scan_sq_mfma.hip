@@ -115,7 +115,7 @@ struct TqOps {
     }
     static __device__ __forceinline__ float finish(const ScanArgs &a, const acc_t (&acc)[NA], int r, const qc_t &qc, const unsigned char *, uint32_t rid,
                                                    float sf, uint32_t) {
-        // low + 128 high: |.| < 2^31 below ~2000 coordinates (api.hip sets tq_i32): one v_cvt instead of the i64 -> f32 sequence, the same value
+        // low + 128 high: |.| < 2^31 below ~2000 coordinates (api_query.hip sets tq_i32): one v_cvt instead of the i64 -> f32 sequence, the same value
         const float sumf = a.tq_i32 ? (float)(acc[0][r] + 128 * acc[1][r]) : (float)((int64_t)acc[0][r] + 128 * (int64_t)acc[1][r]);
         const float dot = qc.f0 * sumf + qc.ec;
         float score;
@@ -168,7 +168,7 @@ struct Tq1Ops {
     static __device__ __forceinline__ float finish(const ScanArgs &a, const acc_t (&acc)[NA], int r, const qc_t &qc, const unsigned char *, uint32_t rid,
                                                    float sf, uint32_t ones) {
         float signed_dot;
-        if (a.tq_i32) {      // |2 v.q - sum q| < 2^31 (api.hip): 32-bit arithmetic, one v_cvt; the same value as the i64 form
+        if (a.tq_i32) {      // |2 v.q - sum q| < 2^31 (api_query.hip): 32-bit arithmetic, one v_cvt; the same value as the i64 form
             int32_t v_dot_q = acc[0][r];
             if (NA == 2) v_dot_q += 256 * acc[NA - 1][r] + 128 * (int32_t)ones;          // q = 256 (q >> 8) + ((q & 255) - 128) + 128
             signed_dot = (float)(2 * v_dot_q - (int32_t)qc.sum_q);
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs 
 
     uint64_t list[QW];
     uint64_t thr[NG];              // reject bound of query 16 g + n: the k-th best key of the wave's list, never below ...
-    uint64_t gk[NG];               // ... the score part of the pre-scan's bound (api.hip search_enqueue; 0 = none): equal scores pass
+    uint64_t gk[NG];               // ... the score part of the pre-scan's bound (api_search.hip search_enqueue; 0 = none): equal scores pass
     float thr_f[NG];               // the score of thr (-inf without one): one float compare rejects a pair before its key is even made
 #pragma unroll
     for (int q = 0; q < QW; ++q) list[q] = 0;

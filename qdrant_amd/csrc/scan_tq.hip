@@ -187,7 +187,7 @@ int32_t launch_tq_rotate(hipStream_t st, const float *d_in, uint32_t n, const Tq
     r.n_chunks = h.n_chunks; r.rot_dim = h.rot_dim; r.padded_dim = h.padded_dim; r.dim = h.dim;
     return launch_tq_rotate_any<float>(st, d_in, (uint64_t)h.dim, n, r, d_out);
 }
-// HadamardRotation::apply_inverse on [n][padded_dim] f64 vectors in place: `h` carries the backward maps, last permutation first (api.hip
+// HadamardRotation::apply_inverse on [n][padded_dim] f64 vectors in place: `h` carries the backward maps, last permutation first (api_*.hip
 // tq_rotation_inverse); the coordinates past rot_dim stay as they are (quantization.rs:382-388)
 int32_t launch_tq_rotate_f64(hipStream_t st, double *d_buf, uint32_t n, const TqRotationHost &h) {
     if (n == 0) return QMX_OK;

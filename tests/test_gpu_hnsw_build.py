@@ -321,6 +321,47 @@ def test_one_point_per_launch_builds_the_sequential_graph(qa, distance, dim):
     _same_graph(seq, ref)
 
 
+@pytest.mark.parametrize("kind,efc", [("f32", 600), ("f32", 1000), ("sq", 700), ("pq", 520)])
+def test_wide_construction_beams_build_the_sequential_graph(qa, kind, efc):
+    """ef_construct above 512 (the register beam of the insertion searches): the list lives in LDS (hnsw.hpp Beam<0>, as for walks wider than 512) - one
+    insertion per launch the graph is still the oracle's sequential graph link for link, through the dense, the SQ and the PQ scorer.  The reference has
+    no limit on ef_construct (HnswConfig.ef_construct: usize); here 4 096 (HNSW_MAX_EF), refused beyond."""
+    n, dim, m, seed = 1300, 48, 8, 33
+    distance = O.COSINE if kind == "f32" else O.DOT
+    rows = O.preprocess(O.COSINE, _clustered(n, dim, seed, k=16))
+    st = O.DenseStorage(O.F32, distance, rows)
+    vs = qa.VectorStorage(rows, _dist(qa, distance))
+    if kind == "f32":
+        seq = qa.GraphLayers.build(vs, m=m, ef_construct=efc, seed=seed, max_batch=1)
+        ref = O.Hnsw(st, m=m, ef_construct=efc, seed=seed)
+    elif kind == "sq":
+        quant = qa.ScalarQuantizer.fit(rows, dim, qa.Distance.Dot)
+        osq = O.SqOracle(O.DOT, dim, quant.alpha, quant.offset)
+        osq.rows = osq.encode_rows(rows)
+        seq = qa.GraphLayers.build(qa.EncodedVectorsU8(quant.encode(rows), quant), m=m, ef_construct=efc, seed=seed, max_batch=1)
+        ref = O.Hnsw.build_sq(st, osq, m=m, ef_construct=efc, seed=seed)
+    else:
+        cen = O.PqOracle.train(rows[:1000], dim, 4, 256, iters=2)
+        opq = O.PqOracle(O.DOT, dim, 4, cen)
+        codes = opq.encode(rows)
+        quant = qa.ProductQuantizer(dim, qa.Distance.Dot, 4, cen)
+        seq = qa.GraphLayers.build(qa.EncodedVectorsPQ(codes, quant), m=m, ef_construct=efc, seed=seed, max_batch=1, original=vs)
+        ref = O.Hnsw.build_pq(st, opq, m=m, ef_construct=efc, seed=seed)
+    a, b = seq.export_plain(), ref.export_plain()
+    if kind == "sq":
+        # SQ scores are a multiplier times an INTEGER dot: with a list of 700 of the 1300 points nearly every insertion meets equal scores, and among
+        # equals the reference's order is its heap's (DESIGN 4: unpinned) - the graphs agree list for list as SETS on all but a few points
+        assert np.array_equal(a.reindex, b.reindex) and a.ep_ids.tolist() == b.ep_ids.tolist()
+        same = sum(int(set(a.neighbors[int(a.offsets[i]):int(a.offsets[i + 1])].tolist()) == set(b.neighbors[int(b.offsets[i]):int(b.offsets[i + 1])].tolist()))
+                   for i in range(len(a.offsets) - 1))
+        assert same >= 0.97 * (len(a.offsets) - 1), same
+    else:
+        _same_graph(a, b)
+    with pytest.raises(qa.QmxError) as e:
+        qa.GraphLayers.build(vs, m=m, ef_construct=5000, seed=seed)
+    assert e.value.status == qa._ffi.ERR_NOT_SUPPORTED
+
+
 @pytest.mark.parametrize("m,m0", [(40, 80), (64, 128), (24, 100)])
 def test_wide_link_lists_build_the_sequential_graph(qa, m, m0):
     """m0 up to 128 (m = 64 collections): the same bar as above - one point per launch, the oracle's sequential graph link for link - and the plain walk of

@@ -128,7 +128,7 @@ def test_split_scan_when_the_sample_is_all_deleted(qa, copy):
     n, dim, nq, top = N, 128, 80, 5
     rows = O.preprocess(O.COSINE, O.synth(0x5EED0530, 0, n, dim))
     queries = O.synth(0x5EED0531, 0, nq, dim)
-    S = max(n >> (11 if copy else 8), 8192)              # (api.hip search_enqueue: the sample of a block without a copy is eight times denser)
+    S = max(n >> (11 if copy else 8), 8192)              # (api_search.hip search_enqueue: the sample of a block without a copy is eight times denser)
     step = n // S
     deleted = np.zeros(n, dtype=bool)
     deleted[::step] = True
