@@ -287,21 +287,24 @@ struct HopPQ {
             uint4 w[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) w[k] = (uint32_t)(16 * k) < m4 ? *reinterpret_cast<const uint4 *>(codes + 16 * k) : make_uint4(0, 0, 0, 0);
+            // ... then ALL the lane's LUT gathers (m / 4 <= 32) before the first add: entries past m4 read entry 0 of the table (a valid address, the
+            // value unused), so the gathers are straight-line code and one round trip to L2 instead of one per block of eight
+            float v[4][8];
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
-                if ((uint32_t)(32 * h) < m4) {
-                    const uint32_t ws[8] = {w[2 * h].x, w[2 * h].y, w[2 * h].z, w[2 * h].w, w[2 * h + 1].x, w[2 * h + 1].y, w[2 * h + 1].z, w[2 * h + 1].w};
-                    float v[8];
+                const uint32_t ws[8] = {w[2 * h].x, w[2 * h].y, w[2 * h].z, w[2 * h].w, w[2 * h + 1].x, w[2 * h + 1].y, w[2 * h + 1].z, w[2 * h + 1].w};
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const uint32_t cc = 32 * h + 4 * k;
-                        v[k] = cc < m4 ? lut[(cc + (uint32_t)sub) * ncent + ((ws[k] >> (8 * sub)) & 0xFF)] : 0.0f;
-                    }
-#pragma unroll
-                    for (int k = 0; k < 8; ++k)
-                        if ((uint32_t)(32 * h + 4 * k) < m4) l += v[k];
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t cc = 32 * h + 4 * k;
+                    const uint32_t at = cc < m4 ? (cc + (uint32_t)sub) * ncent + ((ws[k] >> (8 * sub)) & 0xFF) : 0u;
+                    v[h][k] = lut[at];
                 }
             }
+#pragma unroll
+            for (int h = 0; h < 4; ++h)
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if ((uint32_t)(32 * h + 4 * k) < m4) l += v[h][k];
             c = m4;
         } else if ((reinterpret_cast<uintptr_t>(codes) & 3) == 0) {
             for (; c < m4; c += 4) {
@@ -344,7 +347,20 @@ struct HopPQInternal {
         const uint8_t *cb = reinterpret_cast<const uint8_t *>(a.rows) + (uint64_t)id * a.row_stride;
         const uint32_t m = a.pq_m, nc = a.pq_ncent;
         float s = -0.0f;
-        for (uint32_t c = 0; c < m; ++c) s += a.pq_pair[((uint64_t)c * nc + qp[c]) * nc + cb[c]];
+        // sixteen table gathers in flight per lane, then their adds in chunk order (the reference's sum, bit for bit): one gather at a time - what a plain
+        // loop over a runtime m compiles to - made a pair score a chain of m round trips to L2 / the Infinity Cache (the 25 MB table of m = 96 fits neither
+        // a CU's L1 nor an XCD's L2) and the build's link phase the slowest kernel of C4 (round 3: 154 s per 10 M points)
+        for (uint32_t c0 = 0; c0 < m; c0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const uint32_t c = c0 + (uint32_t)u < m ? c0 + (uint32_t)u : m - 1;      // (past the row: the last chunk again - a valid address, the value unused)
+                v[u] = a.pq_pair[((uint64_t)c * nc + qp[c]) * nc + cb[c]];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (c0 + (uint32_t)u < m) s += v[u];
+        }
         return a.pq_invert ? -s : s;
     }
 };
