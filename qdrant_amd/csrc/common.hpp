@@ -48,6 +48,8 @@ enum Option {
     OPT_NO_HNSW_PQ_BLOCK,     // PQ walk: keep the one-wave-per-search kernel with the LUT read through L2 (default 1; 0 = the block-per-search walk with the LUT in LDS)
     OPT_HNSW_PQ_BLOCK_WAVES,  // ... waves of a block of that walk: one controller + (waves - 1) speculating workers (0 = default 8; 3 .. 8)
     OPT_HNSW_PQ_BLOCK_SET,    // ... entries of its LDS visited set (0 = what fits; tests shrink it to reach the restart on the HBM bitmap)
+    OPT_SQ_MFMA_NO_STAGE,     // SQ matrix-core scan: rows straight from HBM into the operand registers (default 1; 0 = staged through wave-private LDS buffers: measured slower)
+    OPT_SQ_MFMA_NO_LLIST,     // SQ / TQ / BQ / f16 matrix-core scans: the waves' top lists in registers (default 1; 0 = in LDS behind the query tile: more waves per CU, measured no faster)
     OPT_DEBUG,                // log dropped stale HIP errors
     OPT_COUNT
 };
