@@ -127,7 +127,7 @@ typedef struct qmx_counters {
  * rows are re-scored exactly.  Results are still the reference's bits; data whose best scores crowd inside 1e-3 |q| |row| of each other
  * overflow the verification list and take the exact scan instead. */
 #define QMX_SEG_HALF_COPY 0x20u
-/* The same with INT8 codes (1 byte per element: a quarter of the block again in HBM; dim a multiple of 128, at most 768 like the two above): one scale per column, one
+/* The same with INT8 codes (1 byte per element: a quarter of the block again in HBM; dim a multiple of 128, at most 2048 like the two above - beyond 768 floats the per-query exact fallback runs in passes of 32 queries instead of 64): one scale per column, one
  * per query, the integer product on the int8 matrix cores.  The band is a worst-case bound of the two roundings (about 0.7 standard deviations of the
  * score on unit Gaussian rows), so the pass renews an EXACT lower bound of the k-th best score after each of its launches and re-scores the rows
  * whose approximate score lies within one band of it: a few hundred per query.  Results are still the reference's bits; the same per-query exact

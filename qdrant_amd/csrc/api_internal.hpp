@@ -165,6 +165,7 @@ struct qmx_query {
     // the stream is synchronised (qmx_query_last_counters / the synchronous entry points fold it in)
     qmx_counters last_counters{};
     bool last_split = false, last_pq = false;
+    uint32_t last_fqt = 64;          // queries per conditional exact pass of the last prefilter search (fold_split_counters)
     uint64_t last_row_bytes = 0, last_n_cand = 0;
     uint64_t sp_sample_n = 0, sp_sample_of = 0;
     DevBuf filter;             // payload-filter allow bitmap of this query batch (qmx_query_set_filter)
@@ -292,6 +293,10 @@ static uint32_t pow2_ceil(uint32_t x) {
 }
 
 // ---- constants and plain structs of the families, used across them ----
+// queries per conditional exact pass behind the f32 prefilters: the 64-query shape of the chain-major scan where it takes the row length (dim <= 768),
+// the 32-query shape beyond (dim <= 2048), 0: no prefilter for this row length
+static inline uint32_t split_fallback_qt(uint32_t dim) { return mfma16_dim_ok(64, dim) ? 64u : mfma16_dim_ok(32, dim) ? 32u : 0u; }
+
 // ---------------------------------------------------------------------------------------------
 // brute-force top-k
 // ---------------------------------------------------------------------------------------------
@@ -310,9 +315,9 @@ constexpr uint32_t SPLIT_FQT = 64;          // queries per conditional exact pas
 struct SplitPlanLayout {
     size_t count, run16, run64, tile_ovf, ovf_q, zero_bytes, list, gthr_packed, bytes;   // byte offsets (SplitStats sits at 0)
     uint32_t n_run64, list_cap;
-    explicit SplitPlanLayout(uint32_t nq) {
-        n_run64 = (nq + SPLIT_FQT - 1) / SPLIT_FQT;
-        list_cap = n_run64 * SPLIT_FQT;
+    explicit SplitPlanLayout(uint32_t nq, uint32_t fqt = SPLIT_FQT) {      // fqt: queries per conditional exact pass (64; 32 for rows the 64-query shape does not take)
+        n_run64 = (nq + fqt - 1) / fqt;
+        list_cap = n_run64 * fqt;
         count = 32; run16 = 36; run64 = 40;
         tile_ovf = run64 + (size_t)n_run64 * 4;
         ovf_q = tile_ovf + ((size_t)nq / 128 + 1) * 4;

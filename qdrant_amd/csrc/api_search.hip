@@ -224,7 +224,9 @@ int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids, uint64
     // re-scored exactly (scan_split.hip); the result is the exact scan's, bit for bit
     // ... and with a derived copy of the block (QMX_SEG_HALF_COPY / QMX_SEG_SPLIT_COPY) that path serves EVERY batch size: it streams 2 (4) bytes
     // per element instead of 4 and is HBM-bound whatever the number of queries (10 M x 768: 3.0 ms per pass against 4.4 ms for the f32 stream)
-    const bool split_dims = s->dtype == QMX_DTYPE_F32 && mfma_scan_ok(s) && mfma16_dim_ok(64, s->dim) && !option(OPT_NO_MFMA16);
+    // (rows of up to 768 floats: conditional exact passes of 64 queries; up to 2 048 floats - 1 024, 1 536: the 32-query shape - only over a derived copy)
+    const uint32_t split_fqt = split_fallback_qt(s->dim);
+    const bool split_dims = s->dtype == QMX_DTYPE_F32 && mfma_scan_ok(s) && (mfma16_dim_ok(64, s->dim) || (s->d_rows_split && split_fqt != 0)) && !option(OPT_NO_MFMA16);
     const bool split = split_dims && (q64 || (s->d_rows_split && q->nq >= (uint32_t)std::max<int64_t>(1, option(OPT_SPLIT_MIN_QUERIES)))) && s->split_stats &&
                        !d_ids && top <= MAX_TOP_FAST && n_cand >= (1u << 18) && s->dim % 128 == 0 && s->row_stride % 16 == 0 && !option(OPT_NO_SPLIT_SCAN);
     // the 256-query shape halves the bytes streamed per query; a batch that does not fill it is served by the 128-query shape (less matrix work)
@@ -238,7 +240,7 @@ int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids, uint64
     // ---- split passes first (their verification and, if ever needed, the exact fallback run once for all of them afterwards) ----
     std::vector<std::pair<uint32_t, uint32_t>> split_tiles;      // (tile0, nq_tile)
     float *sp_qnorm = nullptr, *sp_thr = nullptr, *sp_band = nullptr, *sp_scales = nullptr, *sp_qmax = nullptr;
-    const SplitPlanLayout pl(q->nq);
+    const SplitPlanLayout pl(q->nq, split_fqt ? split_fqt : SPLIT_FQT);
     unsigned char *plan = nullptr;
     VerifyPool vp{};
     q->last_counters = qmx_counters{};
@@ -437,14 +439,15 @@ int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids, uint64
         // packed, one 16-query pass when 1..16 of them, passes of 64 otherwise.  The kernels start, read their flag and return when it is clear.
         uint32_t *ovf_list = (uint32_t *)(plan + pl.list);
         uint64_t *gthr_packed = (uint64_t *)(plan + pl.gthr_packed);
-        const uint32_t n_run64 = (last + SPLIT_FQT - 1) / SPLIT_FQT, n_slots = n_run64 * SPLIT_FQT;
+        const uint32_t FQT = split_fqt ? split_fqt : SPLIT_FQT;
+        const uint32_t n_run64 = (last + FQT - 1) / FQT, n_slots = n_run64 * FQT;
         QMX_TRY(launch_split_plan(q->stream, (const uint32_t *)(plan + pl.ovf_q), last, (const uint64_t *)q->gthr.p, ovf_list, gthr_packed, n_slots,
                                   (uint32_t *)(plan + pl.count), (int *)(plan + pl.run16), (int *)(plan + pl.run64), n_run64, (SplitStats *)plan, q->d_queries,
                                   q->q_stride, q->sp_fq.p));
         for (uint32_t pass = 0; pass <= n_run64; ++pass) {      // pass 0: the 16-query shape; pass p >= 1: packed queries 64 (p - 1) ..
             if (pass && last <= 16) break;
-            const uint32_t p0 = pass ? (pass - 1) * SPLIT_FQT : 0;
-            const uint32_t nq_sub = pass ? std::min<uint32_t>(SPLIT_FQT, last - p0) : std::min<uint32_t>(16, last);
+            const uint32_t p0 = pass ? (pass - 1) * FQT : 0;
+            const uint32_t nq_sub = pass ? std::min<uint32_t>(FQT, last - p0) : std::min<uint32_t>(16, last);
             const int *run_if = pass ? (const int *)(plan + pl.run64) + (pass - 1) : (const int *)(plan + pl.run16);
             ScanArgs a;
             fill_args(q, 0, nq_sub, a);
@@ -466,6 +469,7 @@ int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids, uint64
         q->last_kernel = split_kernel;      // (the fallback launches above are not what ran)
         q->last_split = true;
         q->last_pq = false;
+        q->last_fqt = FQT;
     }
     {
         // what the host knows at enqueue; the prefilter's own share (candidates, verified rows, exact passes of overflowed queries) is on the device
@@ -508,7 +512,7 @@ int32_t fold_split_counters(qmx_query *q, qmx_counters *c) {
     c->bytes_read += st.verified * q->last_row_bytes;
     if (st.fallback_queries) {
         const uint32_t f = st.fallback_queries;
-        const uint64_t passes = q->last_pq ? f : f <= 16 ? 1 : (f + SPLIT_FQT - 1) / SPLIT_FQT;     // (the exact PQ kernel streams the codes once per query)
+        const uint64_t passes = q->last_pq ? f : f <= 16 ? 1 : (f + q->last_fqt - 1) / q->last_fqt;     // (the exact PQ kernel streams the codes once per query)
         c->bytes_read += passes * q->last_n_cand * q->last_row_bytes;
     }
     return QMX_OK;

@@ -138,8 +138,8 @@ static void segment_drop_copy(qmx_segment *s) {
     s->copy_bytes = 0;
     (void)hipGetLastError();
 }
-static bool segment_i8_eligible(const qmx_segment *s) { return s->split_stats && split_i8_dim_ok(s->dim) && mfma16_dim_ok(64, s->dim); }    // (dims the prefilter path serves: search_enqueue)
-static bool segment_f16_eligible(const qmx_segment *s) { return s->split_stats && s->dim % 128 == 0; }
+static bool segment_i8_eligible(const qmx_segment *s) { return s->split_stats && split_i8_dim_ok(s->dim) && split_fallback_qt(s->dim) != 0; }    // (dims the prefilter path serves: search_enqueue)
+static bool segment_f16_eligible(const qmx_segment *s) { return s->split_stats && s->dim % 128 == 0 && split_fallback_qt(s->dim) != 0; }
 // the int8 copy: column maxima / sums of squares (one pass), the scales (host: split_i8_choose_scales), the worst row's code norms under them (a second
 // pass), the codes (a third).  false: out of memory, or an element that is not finite - no copy is left behind
 static bool segment_build_i8(qmx_segment *s) {

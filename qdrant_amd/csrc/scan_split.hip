@@ -1078,7 +1078,8 @@ __global__ __launch_bounds__(256) void sp_plan_kernel(const uint32_t *ovf_q, uin
         if (lane == 0) {
             *count = cnt;
             *run16 = cnt >= 1 && cnt <= 16;
-            for (uint32_t p = 0; p < n_run64; ++p) run64[p] = cnt > (p ? 64u * p : 16u);
+            const uint32_t fqt = n_run64 ? list_cap / n_run64 : 64u;      // queries per conditional pass: 64, or 32 for rows the 64-query shape does not take
+            for (uint32_t p = 0; p < n_run64; ++p) run64[p] = cnt > (p ? fqt * p : 16u);
             stats->fallback_queries = cnt;
             sh_cnt = cnt;
         }

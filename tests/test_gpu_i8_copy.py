@@ -225,3 +225,40 @@ def test_auto_copy_is_chosen_by_the_trial_and_reported(qa, kind, want_copy):
     got = s.peek_top_all()
     assert ("scan_i8copy_kernel" if info["derived_copy"] == "i8" else "scan_f16pair_kernel<true>") in _kernel(qa, s), _kernel(qa, s)
     _same(got, O.DenseStorage(O.F32, O.COSINE, rows), queries, top)
+
+
+@pytest.mark.parametrize("dim,flag,kernel", [(1024, "i8", "scan_i8copy_kernel"), (1536, "i8", "scan_i8copy_kernel"), (1536, "half", "scan_f16pair_kernel<true>"),
+                                             (2048, "auto", "scan_i8copy_kernel")])
+def test_derived_copies_serve_rows_of_up_to_2048_floats(qa, dim, flag, kernel):
+    """Rows longer than 768 floats (1 024, 1 536: common embedding sizes; the rescoring rows of C4) take the prefilters too since round 4: the copies and
+    their scans were never limited by the row length, only the per-query exact fallback was - its 64-query shape keeps the queries in registers and
+    stops at 768 floats; beyond, the conditional passes take 32 queries each.  Lists: the oracle's; a hot query (3 000 copies of one row, a per-query
+    limit of 2 048 verified rows) exercises that fallback."""
+    n, nq, top = 262_400, 70, 10
+    rng = np.random.default_rng(dim)
+    raw = O.synth(0x5EED0790 + dim, 0, n, dim)
+    v = O.synth(0x5EED0791, 0, 1, dim)[0]
+    dup_at = rng.choice(n, 3000, replace=False)
+    raw[dup_at] = v
+    rows = O.preprocess(O.COSINE, raw)
+    queries = O.synth(0x5EED0792, 0, nq, dim)
+    hot = [3, 41]
+    queries[hot] = v + 0.05 * O.synth(0x5EED0793, 0, len(hot), dim)
+    st = O.DenseStorage(O.F32, O.COSINE, rows)
+    vs = qa.VectorStorage(rows, qa.Distance.Cosine, flags={"i8": qa._ffi.SEG_I8_COPY, "half": qa._ffi.SEG_HALF_COPY, "auto": qa._ffi.SEG_AUTO_COPY}[flag])
+    assert vs.info()["derived_copy"] == ("half" if flag == "half" else "i8")
+    s = qa.BatchFilteredSearcher(queries, vs, top)
+    got = s.peek_top_all()
+    assert kernel in _kernel(qa, s), _kernel(qa, s)
+    assert s.counters.prefilter_queries == nq and s.counters.fallback_queries == 0
+    _same(got, st, queries, top)
+    qa.set_option("verify_max_per_query", 2048)
+    try:
+        s2 = qa.BatchFilteredSearcher(queries, vs, top)
+        got2 = s2.peek_top_all()
+    finally:
+        qa.set_option("verify_max_per_query", -1)
+    # (the hot queries for sure; at 2 048 floats a cold query's int8 band may hold more than 2 048 rows too)
+    assert len(hot) <= s2.counters.fallback_queries <= len(hot) + 4, s2.counters.fallback_queries
+    for a, b in zip(got, got2):
+        assert np.array_equal(a, b)
