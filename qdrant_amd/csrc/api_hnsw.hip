@@ -237,6 +237,7 @@ static int32_t launch_hnsw_build_any(const qmx_segment *seg, const ScanArgs &a, 
     if (seg->dtype == QMX_DTYPE_SQ_U8) return launch_hnsw_build_sq(nullptr, (int)seg->distance, a, h, phase, grid, per_cu);
     if (seg->dtype == QMX_DTYPE_BQ) return launch_hnsw_build_bq(nullptr, a, h, phase, grid, per_cu);
     if (seg->dtype == QMX_DTYPE_PQ) return launch_hnsw_build_pq(nullptr, a, h, phase, grid, per_cu);
+    if (tq_l1(seg)) return launch_hnsw_build_tq_l1(nullptr, a, h, phase, grid, per_cu, seg->tq_rot_dim, seg->tq_padded_dim);
     if (seg->dtype == QMX_DTYPE_TQ) return launch_hnsw_build_tq(nullptr, a, h, phase, grid, per_cu);
     return launch_hnsw_build_dense(nullptr, (int)seg->dtype, (int)seg->distance, a, h, phase, grid, per_cu);
 }
@@ -329,7 +330,6 @@ static int32_t hnsw_build_impl(const qmx_segment *seg, const qmx_segment *origin
     QMX_REQUIRE(seg && bp && out, QMX_ERR_BAD_ARG, "NULL argument");
     *out = nullptr;
     QMX_REQUIRE(seg->dtype <= QMX_DTYPE_BQ || seg->dtype == QMX_DTYPE_TQ, QMX_ERR_NOT_SUPPORTED, "device HNSW build: dtype %u not supported", seg->dtype);
-    QMX_REQUIRE(!tq_l1(seg), QMX_ERR_NOT_SUPPORTED, "device HNSW build through a TurboQuant storage over Manhattan is not built (build over the original vectors)");
     const bool from_original = seg->dtype == QMX_DTYPE_PQ || seg->dtype == QMX_DTYPE_TQ;
     if (from_original) {   // point_scorer.rs:197-212: the insertion searches score through the query (PQ: LUT) of the ORIGINAL vector
         QMX_REQUIRE(original, QMX_ERR_NOT_SUPPORTED,
@@ -449,6 +449,14 @@ static int32_t hnsw_build_impl(const qmx_segment *seg, const qmx_segment *origin
             h.batch_queries = (const unsigned char *)b_bq.p;
             h.batch_q_stride = a.q_stride;
             h.lds_query_bytes = a.q_stride;
+            if (tq_l1(seg)) {   // over Manhattan the entry is the original vector as given (quantization.rs:532-535), its hop scratch behind it in LDS (tq_l1_policy.hpp)
+                a.tq_l1 = seg->d_tq_l1;
+                a.q_stride = tq_l1_query_bytes(seg->dim);
+                QB(b_bq.reserve((size_t)max_batch * a.q_stride));
+                h.batch_queries = (const unsigned char *)b_bq.p;
+                h.batch_q_stride = a.q_stride;
+                h.lds_query_bytes = tq_l1_lds_bytes(seg->dim, seg->tq_rot_dim);
+            }
         }
         if (mb) h.lds_query_bytes = 0;      // nothing staged: the inner rows of the new point are read where they lie
         if (seg->dtype == QMX_DTYPE_U8 && seg->distance == QMX_DISTANCE_COSINE && seg->dim >= 32) {   // the per-pair cosine's query norm of a stored row
@@ -515,7 +523,11 @@ static int32_t hnsw_build_impl(const qmx_segment *seg, const qmx_segment *origin
                 if (seg->distance == QMX_DISTANCE_COSINE) QB(launch_cosine_preprocess_f32(nullptr, src, src, count, seg->dim));
                 QB(launch_pq_lut(nullptr, seg->distance, seg->dim, seg->pq, seg->d_centroids, src, count, (float *)b_bq.p));
             }
-            if (seg->dtype == QMX_DTYPE_TQ) {   // the same for EncodedVectorsTQ: preprocess, rotate, TurboQuantizer::precompute_query
+            if (tq_l1(seg)) {   // EncodedVectorsTQ over Manhattan: no preprocessing, no rotation - the rows themselves, zero padded to whole 16 bytes
+                QH(hipMemsetAsync(b_bq.p, 0, (size_t)count * a.q_stride, nullptr));
+                QH(hipMemcpy2DAsync(b_bq.p, a.q_stride, (const char *)original->d_rows + (uint64_t)next * original->row_stride, original->row_stride,
+                                    (size_t)seg->dim * 4, count, hipMemcpyDeviceToDevice, nullptr));
+            } else if (seg->dtype == QMX_DTYPE_TQ) {   // the same for EncodedVectorsTQ: preprocess, rotate, TurboQuantizer::precompute_query
                 float *src = (float *)b_bqsrc.p;
                 QH(hipMemcpy2DAsync(src, (size_t)seg->dim * 4, (const char *)original->d_rows + (uint64_t)next * original->row_stride, original->row_stride,
                                     (size_t)seg->dim * 4, count, hipMemcpyDeviceToDevice, nullptr));
@@ -631,6 +643,7 @@ static int32_t launch_hnsw(const qmx_query *q, const ScanArgs &a, const HnswArgs
         if (s->dtype == QMX_DTYPE_SQ_U8) return launch_hnsw_custom_sq(q->stream, (int)s->distance, a, h, grid, per_cu);
         if (s->dtype == QMX_DTYPE_PQ) return launch_hnsw_custom_pq(q->stream, a, h, grid, per_cu);
         if (s->dtype == QMX_DTYPE_BQ) return launch_hnsw_custom_bq(q->stream, a, h, grid, per_cu);
+        if (tq_l1(s)) return launch_hnsw_custom_tq_l1(q->stream, a, h, grid, per_cu, s->tq_rot_dim);
         if (s->dtype == QMX_DTYPE_TQ) return launch_hnsw_custom_tq(q->stream, a, h, grid, per_cu);
         set_error("dtype %u not built yet", s->dtype);
         return QMX_ERR_NOT_SUPPORTED;
@@ -650,6 +663,7 @@ static int32_t launch_hnsw(const qmx_query *q, const ScanArgs &a, const HnswArgs
         return launch_hnsw_dense(q->stream, (int)s->dtype, (int)s->distance, a, h, grid, per_cu);
     }
     if (s->dtype == QMX_DTYPE_SQ_U8) return launch_hnsw_sq(q->stream, (int)s->distance, a, h, grid, per_cu);
+    if (s->dtype == QMX_DTYPE_PQ && a.queries == q->enc.p && !a.cq_desc && !a.mv_offsets) return launch_hnsw_pq_direct(q->stream, a, h, grid, per_cu);
     if (s->dtype == QMX_DTYPE_PQ) {
         // a LUT too large to stage once per wave (the old kernel then gathers it through L2): one block per search, the LUT in LDS (hnsw_pq_block.hip)
         if (q->q_stride > 16 * 1024 && !option(OPT_NO_HNSW_PQ_BLOCK) && !option(OPT_HNSW_PQ_LDS_LUT) && pq_block_walk_ok(a, h)) {
@@ -670,7 +684,7 @@ int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
                             uint32_t *d_counts, uint32_t *d_scored, bool timed, bool acorn, const MultiWalk *mw,
                             const ExpandedOut *xo, const CustomWalk *cw) {
     const qmx_segment *s = q->seg;
-    QMX_REQUIRE(!tq_l1(s) || (!mw && !cw), QMX_ERR_NOT_SUPPORTED, "custom / multi-vector walks through a TurboQuant storage over Manhattan are not built");
+    QMX_REQUIRE(!tq_l1(s) || !mw, QMX_ERR_NOT_SUPPORTED, "multi-vector walks through a TurboQuant storage are not built (inner rows: dense, SQ, BQ)");
     ScanArgs a;
     fill_args(q, 0, q->nq, a);
     if (tq_l1(s)) {   // the walk scores against the query as given (tq_l1_policy.hpp): f32 entries of dim floats, 16-byte padded
@@ -680,6 +694,14 @@ int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
         QMX_HIP(hipMemcpy2DAsync(q->tq_rot.p, qs, q->enc.p, (size_t)s->dim * 4, (size_t)s->dim * 4, q->nq, hipMemcpyDeviceToDevice, q->stream));
         a.queries = q->tq_rot.p;
         a.q_stride = qs;
+    }
+    // PQ: the LUT-free walk (pq.hip HopPQDirect) - the entry of a search is its preprocessed vector (q->enc keeps them), staged in LDS
+    const bool pq_direct = s->dtype == QMX_DTYPE_PQ && !cw && !mw && !option(OPT_HNSW_PQ_LUT_WALK) && option(OPT_NO_HNSW_PQ_BLOCK) && !option(OPT_HNSW_PQ_LDS_LUT) &&
+                           s->d_centroids &&
+                           pq_direct_walk_ok(s->dim, s->pq_m, s->pq.chunk_size, s->pq.n_centroids);
+    if (pq_direct) {
+        a.queries = q->enc.p;
+        a.q_stride = s->dim * 4;
     }
     const uint32_t n_searches = cw ? cw->n_queries : mw ? mw->n_queries : q->nq;
     if (cw) {
@@ -716,9 +738,17 @@ int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
     // A PQ LUT of more than half the LDS leaves one search per CU; the walk is a chain of dependent memory round trips,
     // so many searches per CU with the LUT read through L2 win (measured: tools/bench_hnsw.py)
     if (s->dtype == QMX_DTYPE_PQ && q->q_stride > 16 * 1024 && !option(OPT_HNSW_PQ_LDS_LUT)) h.lds_query_bytes = 0;
+    if (pq_direct) h.lds_query_bytes = a.q_stride;
     if (cw) {   // [32-byte header][the examples' entries]: staged when they fit a modest share of the LDS, read through L2 otherwise (PQ LUTs always)
         const uint64_t need = 32 + (uint64_t)std::max<uint32_t>(cw->max_examples, 1) * q->q_stride;
         h.lds_query_bytes = (need <= 48 * 1024 && h.lds_query_bytes != 0) ? (uint32_t)need : 32;
+        if (tq_l1(s)) {   // TurboQuant over Manhattan: [header][the examples, always staged][the hop scratch][64 scores per example] (hnsw.hpp HopCustom::hop)
+            const uint64_t ne = std::max<uint32_t>(cw->max_examples, 1);
+            const uint64_t need_l1 = 32 + ne * a.q_stride + (tq_l1_lds_bytes(s->dim, s->tq_rot_dim) - tq_l1_query_bytes(s->dim)) + ne * 256;
+            QMX_REQUIRE(need_l1 <= HNSW_LDS_QUERY_MAX, QMX_ERR_NOT_SUPPORTED, "a custom query of %u examples over TurboQuant / Manhattan needs %llu bytes of LDS",
+                        cw->max_examples, (unsigned long long)need_l1);
+            h.lds_query_bytes = (uint32_t)need_l1;
+        }
         if (cw->lds_bytes) {      // multi-vector examples: always staged (the MaxSim policy reads its tokens from LDS)
             QMX_REQUIRE(cw->lds_bytes <= HNSW_LDS_QUERY_MAX, QMX_ERR_NOT_SUPPORTED, "a custom query of %u bytes of example tokens does not fit the LDS", cw->lds_bytes);
             h.lds_query_bytes = cw->lds_bytes;
@@ -726,9 +756,9 @@ int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
     }
     if (std::max(top, ef) > HNSW_MAX_EF_REG && !mw && !cw && !tq_l1(s)) {   // a list this long lives in LDS behind the query entry, which is then always staged (a PQ LUT too)
         const size_t beam = ((size_t)std::max(top, ef) * 9 + 15) / 16 * 16;
-        QMX_REQUIRE((size_t)q->q_stride + beam + 2048 <= 160 * 1024, QMX_ERR_NOT_SUPPORTED,
-                    "hnsw max(top, ef) = %u: the query entry (%u bytes) and the list do not fit the LDS together", std::max(top, ef), q->q_stride);
-        h.lds_query_bytes = q->q_stride;
+        QMX_REQUIRE((size_t)a.q_stride + beam + 2048 <= 160 * 1024, QMX_ERR_NOT_SUPPORTED,
+                    "hnsw max(top, ef) = %u: the query entry (%u bytes) and the list do not fit the LDS together", std::max(top, ef), a.q_stride);
+        h.lds_query_bytes = a.q_stride;
     }
     h.log_cap = HNSW_LOG_CAP;
     {   // tests: force the whole-bitmap clear path

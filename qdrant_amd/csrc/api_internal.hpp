@@ -77,6 +77,7 @@ struct qmx_segment {
     float *d_centroids = nullptr;
     float *d_pq_pair = nullptr;       // [m][ncent][ncent] chunk distances between centroids (score_internal terms; built when <= 256 MB)
     uint32_t pq_m = 0;
+    bool pq_rot_w16 = false;          // ... with 16-bit codes (pq_prefilter.hip)
     void *d_pq_rot = nullptr;         // PQ blocks of 2^18 rows and more, m <= 96: the rotated copy of the codes the 6-bit prefilter scans (pq_prefilter.hip)
     float *d_row_offsets = nullptr;   // SQ: vector_offset column (rows hold the 16-byte aligned code block)
     // TurboQuant (scan_tq.hip): parameters, the extras columns and the rotation tables

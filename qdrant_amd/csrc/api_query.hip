@@ -320,6 +320,12 @@ void fill_args(const qmx_query *q, uint32_t tile0, uint32_t nq_tile, ScanArgs &a
     a.pq_ncent = s->pq.n_centroids;
     a.pq_pair = s->d_pq_pair;
     a.pq_invert = s->pq.invert;
+    if (s->dtype == QMX_DTYPE_PQ) {      // the codebook itself (the LUT-free walk, pq.hip HopPQDirect)
+        a.pq_centroids = s->d_centroids;
+        a.pq_dim = s->dim;
+        a.pq_chunk = s->pq.chunk_size;
+        a.pq_kind = (s->distance == QMX_DISTANCE_DOT || s->distance == QMX_DISTANCE_COSINE) ? 0u : s->distance == QMX_DISTANCE_MANHATTAN ? 1u : 2u;
+    }
     a.bq_dim = s->dim;
     // calculate_metric's match: (Dot | Cosine, invert = false) and (L1 | L2, invert = true) -> zeros - xor; the toggled pairs -> xor - zeros
     a.bq_flip = (s->flags & QMX_SEG_BQ_TOGGLE_INVERT) ? 1 : 0;

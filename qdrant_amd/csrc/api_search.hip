@@ -127,7 +127,7 @@ static int32_t pq_prefilter_enqueue(qmx_query *q, uint32_t top, uint64_t n_cand,
         uint32_t grid = 0;
         size_t slot = 0;
         if (timed) QMX_TRY(timing_begin(q, &slot));
-        QMX_TRY(launch_pq_prefilter(q->stream, a, s->d_pq_rot, q->pq_table.p, thr, nq_tile, s->num_cus, q->sp_wl.p, PQF_WCAP, &grid));
+        QMX_TRY(launch_pq_prefilter(q->stream, a, s->d_pq_rot, q->pq_table.p, thr, nq_tile, s->num_cus, q->sp_wl.p, PQF_WCAP, &grid, s->pq_rot_w16 ? 1 : 0));
         q->last_kernel = last_noted_kernel();
         if (timed) QMX_TRY(timing_end(q, slot));
         // 4. per-wave lists -> per-query lists (deleted rows dropped), then the rows worth an exact score
@@ -161,7 +161,8 @@ static int32_t pq_prefilter_enqueue(qmx_query *q, uint32_t top, uint64_t n_cand,
         a.partial = (uint64_t *)q->partial.p;
         a.partial_qt = q->nq;
         QMX_TRY(launch_scan_pq(q->stream, SCAN_TOPK, a, s->num_cus, &slabs));
-        QMX_TRY(launch_merge_keys(q->stream, (const uint64_t *)q->partial.p, slabs, q->nq, q->nq, top, d_out, d_counts, top, 0, nullptr, a.run_if, ovf_list));
+        QMX_TRY(launch_merge_keys(q->stream, (const uint64_t *)q->partial.p, slabs, q->nq, q->nq, top, d_out, d_counts, top, 0, nullptr, a.run_if, ovf_list,
+                                  slabs * q->nq));
         launches += 5;
     }
     q->last_kernel = pf_kernel;
@@ -171,7 +172,7 @@ static int32_t pq_prefilter_enqueue(qmx_query *q, uint32_t top, uint64_t n_cand,
         qmx_counters &c = q->last_counters;
         c.vectors_scored = (uint64_t)q->nq * n_cand;
         // the rotated copy once per four-query group (all but the first find it in L2) + the sample's rows per query
-        c.bytes_read = (uint64_t)((q->nq + 3) / 4) * n_cand * m_pad + (uint64_t)q->nq * S * s->row_bytes;
+        c.bytes_read = (uint64_t)((q->nq + 3) / 4) * n_cand * m_pad * (s->pq_rot_w16 ? 2 : 1) + (uint64_t)q->nq * S * s->row_bytes;
         c.kernel_launches = launches;
         c.prefilter_queries = q->nq;
         q->last_row_bytes = s->row_bytes;

@@ -193,6 +193,20 @@ struct HopCustom {
             return HI::score(a, MULTI_EXAMPLES ? ent + off[e] : ent + (size_t)e * a.q_stride, id, sub);
         });
     }
+    // an inner policy that scores a hop as a wave (TurboQuant over Manhattan): the hop against every example in turn - scores parked per example in LDS -
+    // then lane j combines candidate j's.  The examples are always staged; behind them [the inner policy's hop scratch][n_examples x 64 floats]
+    // (custom_tql1_lds_bytes sizes it; instantiated for such policies only)
+    static constexpr bool TQL1 = is_tql1<HI>::value;
+    static __device__ __forceinline__ void hop(const ScanArgs &a, const unsigned char *qp, const uint32_t *hop_ids, float *hop_scores, uint32_t k, int lane) {
+        const CustomHeader *hd = reinterpret_cast<const CustomHeader *>(qp - sizeof(CustomHeader));
+        const uint32_t ne = hd->kind <= QMX_CUSTOM_RECO_SUM_SCORES ? hd->n_a + hd->n_b : hd->n_a + 2 * hd->n_b;
+        unsigned char *scratch = const_cast<unsigned char *>(qp) + (size_t)ne * a.q_stride;
+        float *ex = reinterpret_cast<float *>(scratch + HI::scratch_bytes(a));
+        for (uint32_t e = 0; e < ne; ++e) HI::hop_at(a, hd->entries + (size_t)e * a.q_stride, scratch, hop_ids, ex + (size_t)e * 64, k, lane);
+        if ((uint32_t)lane < k)
+            hop_scores[lane] = custom_score_by(hd->kind, hd->n_a, hd->n_b, a.cq_coefs + hd->coef_first, [&](uint32_t e) { return ex[(size_t)e * 64 + (uint32_t)lane]; });
+        __syncthreads();
+    }
 };
 
 // ---- the beam: sorted descending, entry index = e * 64 + lane ------------------------------------

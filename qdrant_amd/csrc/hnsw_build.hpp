@@ -124,9 +124,10 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(const ScanArgs a0
         __syncthreads();
         if constexpr (is_maxsim_internal<H>::value) {       // a multi-vector point: its inner rows stay in HBM
             qp = stored_query<H>(a0, p);
-        } else if (h.batch_queries && h.lds_query_bytes) {        // a small entry (TurboQuant): staged like a row
+        } else if (h.batch_queries && h.lds_query_bytes) {        // a small entry (TurboQuant): staged like a row (a policy may own scratch behind it)
             const unsigned char *src = h.batch_queries + (uint64_t)bi * h.batch_q_stride;
-            for (uint32_t i = (uint32_t)lane * 16; i < h.lds_query_bytes; i += 64 * 16)
+            const uint32_t q_bytes = h.lds_query_bytes < h.batch_q_stride ? h.lds_query_bytes : (uint32_t)h.batch_q_stride;
+            for (uint32_t i = (uint32_t)lane * 16; i < q_bytes; i += 64 * 16)
                 *reinterpret_cast<uint4 *>(q_lds + i) = *reinterpret_cast<const uint4 *>(src + i);
         } else if (h.batch_queries) {                       // a LUT (PQ): read through L2
             qp = h.batch_queries + (uint64_t)bi * h.batch_q_stride;
@@ -396,6 +397,13 @@ int32_t launch_hnsw_build_hop(hipStream_t st, const ScanArgs &a, const HnswBuild
             if (attr_once.need()) {
                 QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 attr_once.mark();
+            }
+        } else if (lds1 > 48 * 1024) {      // a register beam behind a large query entry (TurboQuant over Manhattan: the entry and its hop scratch)
+            static thread_local DeviceOnce attr_once28;
+            if (attr_once28.need()) {
+                QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_once28.mark();
             }
         }
         if (grid == 0) {

@@ -53,6 +53,8 @@ struct ScanArgs {
     int32_t u8_qnorm_i;
     // PQ
     uint32_t pq_m, pq_ncent;
+    const float *pq_centroids; // [ncent][pq_dim] the codebook (the LUT-free walk, pq.hip HopPQDirect), or nullptr
+    uint32_t pq_dim, pq_chunk, pq_kind;      // ... its geometry: floats per vector, per chunk; 0 dot / cosine, 1 Manhattan, 2 Euclid (PqGeom::kind)
     const float *pq_pair;      // [m][ncent][ncent] chunk distances between centroids = the terms of EncodedVectorsPQ::score_internal, or nullptr
     uint32_t pq_invert;
     // BQ: calculate_metric (encoded_vectors_binary.rs:766-810)
@@ -127,6 +129,9 @@ struct HnswArgs {
 // The PQ walk with one BLOCK per search (hnsw_pq_block.hip): the LUT in LDS, a controller wave and speculating worker waves.  pq_block_walk_ok: whether this
 // launch can take it (plain walk, packed level 0, aligned code rows, ef in the register beam, LUT + scratch inside the LDS); grid == 0: report blocks per CU
 bool pq_block_walk_ok(const ScanArgs &a, const HnswArgs &h);
+// The PQ walk without LUTs (pq.hip HopPQDirect): the query entry is the preprocessed f32 vector, a LUT entry is recomputed from the codebook where it is needed
+bool pq_direct_walk_ok(uint32_t dim, uint32_t m, uint32_t chunk, uint32_t ncent);
+int32_t launch_hnsw_pq_direct(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_pq_block(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu, int waves);
 // grid == 0: only report the occupancy (blocks of one wave per CU) of the instantiation in *per_cu
 int32_t launch_hnsw_dense(hipStream_t st, int dtype, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
@@ -170,6 +175,7 @@ int32_t launch_hnsw_custom_sq(hipStream_t st, int distance, const ScanArgs &a, c
 int32_t launch_hnsw_custom_bq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_custom_pq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_custom_tq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
+int32_t launch_hnsw_custom_tq_l1(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu, uint32_t rot_dim);   // (hnsw_tq_l1.hip)
 // ... whose examples are multi-vectors over multi-vector points (MultiCustomQueryScorer: HopCustom over HopMaxSim); dense and SQ inner rows
 int32_t launch_hnsw_custom_maxsim_dense(hipStream_t st, int dtype, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_custom_maxsim_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
@@ -232,6 +238,8 @@ int32_t launch_hnsw_build_maxsim_dense(hipStream_t st, int dtype, int distance, 
 int32_t launch_hnsw_build_maxsim_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_build_maxsim_bq(hipStream_t st, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_build_tq(hipStream_t st, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu);
+int32_t launch_hnsw_build_tq_l1(hipStream_t st, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu, uint32_t rot_dim,
+                                uint32_t padded_dim);      // ... over Manhattan (hnsw_build_tq_l1.hip)
 int32_t launch_hnsw_build_pq(hipStream_t st, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu);
 // pair[c][i][j] = DistanceType::distance(centroid i chunk c, centroid j chunk c): the per-chunk terms of score_internal (encoded_vectors_pq.rs:574-618)
 int32_t launch_pq_pair_table(hipStream_t st, uint32_t distance, uint32_t dim, const qmx_pq_params &pq, const float *d_centroids, float *d_pair);
@@ -300,9 +308,9 @@ int32_t launch_scan_f32_split(hipStream_t st, const ScanArgs &a, const void *d_b
 int32_t launch_regroup_lists(hipStream_t st, const DeletedView &del, const void *d_wlist, const uint32_t *d_wcnt, uint32_t wcap, uint32_t n_lists, uint64_t *d_cand,
                              uint32_t *d_cand_cnt, uint32_t cap, int *d_overflow);
 // PQ prefilter (pq_prefilter.hip): rotated copy of the code block, 6-bit tables + thresholds per query, the approximate scan
-size_t pq_rot_bytes(uint64_t n, uint32_t m);
+size_t pq_rot_bytes(uint64_t n, uint32_t m, int w16);      // w16: the copy holds 16-bit codes (the prefilter's one-instruction gather addresses)
 bool pq_prefilter_shape_ok(uint32_t m, uint32_t ncent);
-int32_t launch_pq_rotate(hipStream_t st, const void *codes, uint64_t row_stride, uint64_t n, uint32_t m, void *d_out);
+int32_t launch_pq_rotate(hipStream_t st, const void *codes, uint64_t row_stride, uint64_t n, uint32_t m, void *d_out, int w16);
 size_t pq_prefilter_table_bytes(uint32_t m, uint32_t nq);
 uint32_t pq_prefilter_grid(int num_cus, uint32_t nq, uint32_t *n_slabs_out);
 size_t pq_prefilter_wlists_counts_bytes(uint32_t grid);
@@ -310,7 +318,7 @@ size_t pq_prefilter_wlists_bytes(uint32_t grid, uint32_t wcap);
 int32_t launch_pq_lut8(hipStream_t st, const void *d_luts, uint32_t q_stride, uint32_t nq, uint32_t m, uint32_t ncent, const uint64_t *d_gthr, void *d_table8,
                        int32_t *d_thr, float *d_band);
 int32_t launch_pq_prefilter(hipStream_t st, const ScanArgs &a, const void *d_rot, const void *d_table8, const int32_t *d_thr, uint32_t nq, int num_cus,
-                            void *d_wlists, uint32_t wcap, uint32_t *grid_out);
+                            void *d_wlists, uint32_t wcap, uint32_t *grid_out, int w16);
 int32_t launch_split_refine(hipStream_t st, const uint64_t *d_cand, const uint32_t *d_cand_cnt, uint32_t cap, const float *d_band, uint32_t nq, uint32_t top,
                             const float *d_scales, float *d_thr);
 size_t split_wlists_bytes(int num_cus);
@@ -392,7 +400,7 @@ int32_t launch_pack_queries(hipStream_t st, int dtype, int distance, const void 
 int32_t launch_merge_keys(hipStream_t st, const uint64_t *partial, uint32_t n_lists,
                           uint32_t qt_stride, uint32_t nq, uint32_t top, qmx_scored_point *out,
                           uint32_t *out_counts, uint32_t out_stride = 0, uint32_t out_offset = 0,
-                          uint64_t *next_bound = nullptr, const int *run_if = nullptr, const uint32_t *out_map = nullptr);
+                          uint64_t *next_bound = nullptr, const int *run_if = nullptr, const uint32_t *out_map = nullptr, uint32_t shared_grid = 0);
 int32_t launch_merge_points(hipStream_t st, const qmx_scored_point *lists, const uint32_t *list_counts,
                             const uint32_t *list_idx_base, uint32_t n_lists, uint32_t nq, uint32_t k, qmx_scored_point *out,
                             uint32_t *out_counts);

@@ -134,10 +134,22 @@ __global__ __launch_bounds__(PQ_BLOCK) void pq_scan_kernel(const ScanArgs a, uin
     constexpr int NW = PQ_BLOCK / WAVE;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (a.run_if && *a.run_if == 0) return;      // the exact pass behind the 6-bit prefilter was not needed (pq_prefilter.hip)
-    // block -> (slab, query): query varies fastest
-    const uint32_t q = blockIdx.x % a.nq;
-    const uint32_t slab = blockIdx.x / a.nq;
+    // block -> (slab, query): query varies fastest.  The exact pass behind the 6-bit prefilter (pq_prefilter.hip: run_if = the number of queries whose
+    // lists overflowed, q_map = those queries, packed) is launched for the worst case - every query of the batch - and shares its grid among the queries
+    // that are listed: one overflowing query of 128 is scanned by every block of the launch, not by its 1 / 128th (12 ms -> 0.1 ms at 10 M x 96)
+    uint32_t nq_eff = a.nq, pstride = a.partial_qt;
+    if (a.run_if) {
+        const uint32_t cnt = (uint32_t)*a.run_if;
+        if (cnt == 0) return;
+        if (a.q_map) {
+            nq_eff = cnt < a.nq ? cnt : a.nq;
+            n_slabs = gridDim.x / nq_eff;
+            pstride = nq_eff;
+            if (blockIdx.x >= n_slabs * nq_eff) return;
+        }
+    }
+    const uint32_t q = blockIdx.x % nq_eff;
+    const uint32_t slab = blockIdx.x / nq_eff;
     const uint32_t m = a.pq_m, ncent = a.pq_ncent;
     const uint32_t qsrc = a.q_map ? a.q_map[q] : q;          // (packed exact pass: list q belongs to query q_map[q] of the batch)
     if (qsrc == 0xFFFFFFFFu) return;
@@ -200,7 +212,7 @@ __global__ __launch_bounds__(PQ_BLOCK) void pq_scan_kernel(const ScanArgs a, uin
                 if (nk > readlane_u64(merged, top - 1)) wave_list_insert(merged, nk, lane);
             }
         }
-        if (lane < top) a.partial[((uint64_t)slab * a.partial_qt + q) * top + lane] = merged;
+        if (lane < top) a.partial[((uint64_t)slab * pstride + q) * top + lane] = merged;
     }
 }
 
@@ -323,6 +335,109 @@ struct HopPQ {
 int32_t launch_hnsw_pq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
     return launch_hnsw_hop<HopPQ>(st, a, h, grid, per_cu);
 }
+
+// ------------------------------------------------------------------------------------------
+// The same hop scorer WITHOUT the LUT (round 4).  A walk with HopPQ gathers 4-byte entries of its search's own LUT (96 KiB at m = 96): ~4 000 concurrent
+// searches keep 384 MB of LUTs in flight, every gather pulls a 64-byte sector through the fabric for 4 useful bytes (PMC: 175 GB moved for 2.9 GB of
+// codes, 0.015 of HBM on useful bytes, three rounds running) - and the LUTs themselves (768 MB per 8 192 searches) are written and read back.
+// A LUT entry is lut[c][k] = sum_i term(q[lo + i], centroid[k][lo + i]) (pq_lut_kernel: from -0.0, one multiply and one add per coordinate, in order;
+// encoded_vectors_pq.rs:519-541).  Here the lane that needs entry (c, code) computes exactly that chain from the codebook: 64 contiguous bytes of a
+// 1.5 MB table that every search shares and that stays in L2, against the query's chunk in LDS (the entry of a search is its 6 KiB preprocessed vector,
+// not a LUT).  Same bits as the exact LUT (a caller who allowed the matrix-core LUT accepted 1e-5 of it), same order of the m adds (lane `sub` of a quad
+// owns chunks sub, sub + 4, ...: score_point_sse's lanes).  CHUNK floats per chunk, dim = m x CHUNK exactly; rounds of R chunk steps keep
+// R x CHUNK / 4 sixteen-byte loads in flight per lane.
+// ------------------------------------------------------------------------------------------
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+template <int CHUNK>
+struct HopPQDirect {
+    static constexpr int LPI = 4;
+    static constexpr bool MULTI = false;
+    static constexpr bool INTERNAL_QOFF = false;
+    static constexpr bool INTERNAL_NORM = false;
+    static constexpr int V = CHUNK / 4;                      // 16-byte pieces of a chunk
+    static constexpr int R = 24 / V;                         // chunk steps per round: 24 pieces = 96 registers of codebook per lane
+    template <int KIND>
+    static __device__ __forceinline__ float sum_quads(const ScanArgs &a, const float *q, const uint4 (&w)[8], uint32_t m4, int sub) {
+        const float *cent = a.pq_centroids;
+        const uint32_t dim = a.pq_dim;
+        const uint32_t ws[32] = {w[0].x, w[0].y, w[0].z, w[0].w, w[1].x, w[1].y, w[1].z, w[1].w, w[2].x, w[2].y, w[2].z, w[2].w, w[3].x, w[3].y, w[3].z, w[3].w,
+                                 w[4].x, w[4].y, w[4].z, w[4].w, w[5].x, w[5].y, w[5].z, w[5].w, w[6].x, w[6].y, w[6].z, w[6].w, w[7].x, w[7].y, w[7].z, w[7].w};
+        float l = 0.0f;
+#pragma unroll
+        for (int s0 = 0; s0 < 32; s0 += R) {
+            if ((uint32_t)(4 * s0) >= m4) break;             // (uniform)
+            f32x4s cv[R][V];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int step = s0 + r;
+                const bool on = step < 32 && (uint32_t)(4 * step) < m4;
+                // (past the row: chunk 0 of centroid 0 - a valid address, the value unused - so the loads are straight-line code: one round trip per round)
+                const uint32_t c = on ? 4u * (uint32_t)step + (uint32_t)sub : 0u;
+                const uint32_t code = on ? (ws[step < 32 ? step : 0] >> (8 * sub)) & 0xFFu : 0u;
+                const float *p = cent + (size_t)code * dim + (size_t)c * CHUNK;
+#pragma unroll
+                for (int v = 0; v < V; ++v) cv[r][v] = *reinterpret_cast<const f32x4s *>(p + 4 * v);
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int step = s0 + r;
+                if (step < 32 && (uint32_t)(4 * step) < m4) {      // (uniform)
+                    const float *qc = q + (size_t)(4u * (uint32_t)step + (uint32_t)sub) * CHUNK;
+                    float s = -0.0f;
+#pragma unroll
+                    for (int v = 0; v < V; ++v) {
+                        const f32x4s qv = *reinterpret_cast<const f32x4s *>(qc + 4 * v);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) s += pq_term(KIND, qv[e], cv[r][v][e]);
+                    }
+                    l += a.pq_invert ? -s : s;
+                }
+            }
+        }
+        return l;
+    }
+    // entry (c, code) alone (the chunks past the last whole quad of a row: every lane of the quad computes them)
+    static __device__ __forceinline__ float entry(const ScanArgs &a, const float *q, uint32_t c, uint32_t code) {
+        const float *p = a.pq_centroids + (size_t)code * a.pq_dim + (size_t)c * CHUNK, *qc = q + (size_t)c * CHUNK;
+        float s = -0.0f;
+        for (int i = 0; i < CHUNK; ++i) s += pq_term((int)a.pq_kind, qc[i], p[i]);
+        return a.pq_invert ? -s : s;
+    }
+    static __device__ __forceinline__ float score(const ScanArgs &a, const unsigned char *qp, uint32_t id, int sub) {
+        const float *q = reinterpret_cast<const float *>(qp);
+        const uint8_t *codes = reinterpret_cast<const uint8_t *>(a.rows) + (uint64_t)id * a.row_stride;
+        const uint32_t m = a.pq_m, m4 = m & ~3u;
+        uint4 w[8];
+        if ((reinterpret_cast<uintptr_t>(codes) & 15) == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) w[k] = (uint32_t)(16 * k) < m4 ? *reinterpret_cast<const uint4 *>(codes + 16 * k) : make_uint4(0, 0, 0, 0);
+        } else {      // rows that are not 16-byte aligned (m not a multiple of 16): byte by byte
+            uint32_t t[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                t[k] = 0;
+                if ((uint32_t)(4 * k) < m4) t[k] = (uint32_t)codes[4 * k] | ((uint32_t)codes[4 * k + 1] << 8) | ((uint32_t)codes[4 * k + 2] << 16) | ((uint32_t)codes[4 * k + 3] << 24);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) w[k] = make_uint4(t[4 * k], t[4 * k + 1], t[4 * k + 2], t[4 * k + 3]);
+        }
+        const float l = a.pq_kind == 0 ? sum_quads<0>(a, q, w, m4, sub) : a.pq_kind == 1 ? sum_quads<1>(a, q, w, m4, sub) : sum_quads<2>(a, q, w, m4, sub);
+        const float x = l + dpp_f32<DPP_QUAD_XOR2>(l);          // lane 0: l0 + l2, lane 1: l1 + l3
+        float sum = x + dpp_f32<DPP_QUAD_XOR1>(x);              // lane 0: (l0 + l2) + (l1 + l3)
+        for (uint32_t c = m4; c < m; ++c) sum += entry(a, q, c, codes[c]);
+        return sum;
+    }
+};
+bool pq_direct_walk_ok(uint32_t dim, uint32_t m, uint32_t chunk, uint32_t ncent) {
+    return (chunk == 16 || chunk == 8 || chunk == 4) && (uint64_t)m * chunk == dim && m <= 128 && ncent <= 256 && (uint64_t)dim * 4 <= 64 * 1024;
+}
+int32_t launch_hnsw_pq_direct(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
+    QMX_REQUIRE(a.pq_centroids && pq_direct_walk_ok(a.pq_dim, a.pq_m, a.pq_chunk, a.pq_ncent), QMX_ERR_BAD_ARG, "the LUT-free PQ walk does not take this codebook");
+    if (a.pq_chunk == 16) return launch_hnsw_hop<HopPQDirect<16>>(st, a, h, grid, per_cu);
+    if (a.pq_chunk == 8) return launch_hnsw_hop<HopPQDirect<8>>(st, a, h, grid, per_cu);
+    return launch_hnsw_hop<HopPQDirect<4>>(st, a, h, grid, per_cu);
+}
+
 // ... with a custom query as the scorer: every example's LUT stays in global memory (read through L2, like the plain PQ walk's large LUTs)
 int32_t launch_hnsw_custom_pq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
     return launch_hnsw_hop<HopCustom<HopPQ>>(st, a, h, grid, per_cu);

@@ -849,15 +849,22 @@ __global__ __launch_bounds__(256) void sp_regroup_kernel(const uint4 *wlist, con
     }
 }
 
-// the pre-split copy: one thread per (row, 8-float group): out[(tile * nch + kc) * 2048 + unit(row, h / l, kq)]; rows past n are zero
+// the pre-split copy: one thread per 16-byte unit of the OUTPUT, out[(tile * nch + kc) * 2048 + unit(row, h / l, kq)], in the output's order (whole
+// lines written, as sp_i8_copy_kernel); rows past n are zero
 __global__ __launch_bounds__(256) void sp_split_copy_kernel(const unsigned char *rows, uint64_t row_stride, uint64_t n, uint32_t dim, float scale, uint4 *out,
                                                             int half) {
-    const uint32_t groups = dim / 8;
     const uint32_t nch = half ? dim / 64 : dim / 32;
-    const uint64_t n_pad = (n + SP3_BM - 1) / SP3_BM * SP3_BM;
-    for (uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x; gid < n_pad * groups; gid += (uint64_t)gridDim.x * 256) {
-        const uint64_t r = gid / groups;
-        const uint32_t gq = (uint32_t)(gid % groups), k32 = gq / 4, kq = gq % 4;
+    const uint64_t n_tiles = (n + SP3_BM - 1) / SP3_BM;
+    const uint64_t total = n_tiles * nch * SP3_A_UNITS;
+    for (uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (uint64_t)gridDim.x * 256) {
+        const uint32_t u = (uint32_t)(gid % SP3_A_UNITS);
+        const uint64_t blk = gid / SP3_A_UNITS, tile = blk / nch;
+        const uint32_t kc = (uint32_t)(blk % nch);
+        // sp_unit(t, hl, kq, m) = ((t * 2 + hl) * 4 + kq) * 16 + (m ^ 2 kq), inverted
+        const uint32_t kq = (u >> 4) & 3u, hl = (u >> 6) & 1u, t = u >> 7, m = (u & 15u) ^ (2u * kq);
+        const uint64_t r = tile * SP3_BM + t * 16u + m;
+        // half: a plane pair per 64 floats = the high parts of its two 32-float halves; else the high (hl = 0) and low (hl = 1) parts of 32 floats
+        const uint32_t k32 = half ? kc * 2u + hl : kc;
         half8 h, l;
         if (r < n) {
             const float *v = reinterpret_cast<const float *>(rows + r * row_stride) + k32 * 32 + kq * 8;
@@ -870,15 +877,7 @@ __global__ __launch_bounds__(256) void sp_split_copy_kernel(const unsigned char 
 #pragma unroll
             for (int e = 0; e < 8; ++e) { h[e] = (_Float16)0.0f; l[e] = (_Float16)0.0f; }
         }
-        const uint64_t tile = r / SP3_BM;
-        const uint32_t rl = (uint32_t)(r % SP3_BM);
-        if (half) {   // one plane pair per 64 floats: the high parts of the two 32-float halves
-            out[(tile * nch + k32 / 2) * SP3_A_UNITS + sp_unit(rl >> 4, k32 & 1u, kq, rl & 15u)] = *reinterpret_cast<const uint4 *>(&h);
-        } else {
-            uint4 *chunk = out + (tile * nch + k32) * SP3_A_UNITS;
-            chunk[sp_unit(rl >> 4, 0, kq, rl & 15u)] = *reinterpret_cast<const uint4 *>(&h);
-            chunk[sp_unit(rl >> 4, 1, kq, rl & 15u)] = *reinterpret_cast<const uint4 *>(&l);
-        }
+        out[gid] = (half || hl == 0) ? *reinterpret_cast<const uint4 *>(&h) : *reinterpret_cast<const uint4 *>(&l);
     }
 }
 
@@ -1199,13 +1198,21 @@ __global__ __launch_bounds__(256) void sp_i8_row_stats_kernel(const unsigned cha
     }
     if (bad) atomicOr(&stats[2], 1u);
 }
-// the copy: one thread per (row, 16-coordinate unit): out[(tile * nch + k128) * 2048 + unit(row, plane = which 64 of the 128, kq)]; rows past n are zero
+// the copy: one thread per 16-coordinate unit of the OUTPUT, out[(tile * nch + k128) * 2048 + unit(row, plane = which 64 of the 128, kq)], in the output's
+// order - a wave writes 1 KiB of consecutive units (whole lines: the row-major order of round 3 wrote 13.3 GB for a 7.68 GB copy, profiles/
+// r3_pmc_traffic_i8.md) and reads sixteen rows' 256-byte runs; rows past n are zero
 __global__ __launch_bounds__(256) void sp_i8_copy_kernel(const unsigned char *rows, uint64_t row_stride, uint64_t n, uint32_t dim, const float *scale, uint4 *out) {
-    const uint32_t groups = dim / 16, nch = dim / 128;
-    const uint64_t n_pad = (n + SP3_BM - 1) / SP3_BM * SP3_BM;
-    for (uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x; gid < n_pad * groups; gid += (uint64_t)gridDim.x * 256) {
-        const uint64_t r = gid / groups;
-        const uint32_t g = (uint32_t)(gid % groups), k128 = g / 8, hl = (g / 4) & 1u, kq = g % 4;
+    const uint32_t nch = dim / 128;
+    const uint64_t n_tiles = (n + SP3_BM - 1) / SP3_BM;
+    const uint64_t total = n_tiles * nch * SP3_A_UNITS;
+    for (uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (uint64_t)gridDim.x * 256) {
+        const uint32_t u = (uint32_t)(gid % SP3_A_UNITS);
+        const uint64_t blk = gid / SP3_A_UNITS, tile = blk / nch;
+        const uint32_t k128 = (uint32_t)(blk % nch);
+        // sp_unit(t, hl, kq, m) = ((t * 2 + hl) * 4 + kq) * 16 + (m ^ 2 kq), inverted
+        const uint32_t kq = (u >> 4) & 3u, hl = (u >> 6) & 1u, t = u >> 7, m = (u & 15u) ^ (2u * kq);
+        const uint64_t r = tile * SP3_BM + t * 16u + m;
+        const uint32_t g = k128 * 8u + hl * 4u + kq;
         uint32_t w[4] = {0u, 0u, 0u, 0u};
         if (r < n) {
             const float *v = reinterpret_cast<const float *>(rows + r * row_stride) + g * 16;
@@ -1213,9 +1220,7 @@ __global__ __launch_bounds__(256) void sp_i8_copy_kernel(const unsigned char *ro
 #pragma unroll
             for (int e = 0; e < 16; ++e) w[e / 4] |= ((uint32_t)sp_i8_code(v[e], sc[e]) & 0xFFu) << (8 * (e % 4));
         }
-        const uint64_t tile = r / SP3_BM;
-        const uint32_t rl = (uint32_t)(r % SP3_BM);
-        out[(tile * nch + k128) * SP3_A_UNITS + sp_unit(rl >> 4, hl, kq, rl & 15u)] = make_uint4(w[0], w[1], w[2], w[3]);
+        out[gid] = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
 

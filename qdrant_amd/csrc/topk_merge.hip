@@ -59,9 +59,15 @@ __device__ __forceinline__ uint64_t block_finish(uint64_t list, int top, uint32_
 __global__ __launch_bounds__(MERGE_BLOCK) void merge_keys_kernel(const uint64_t *partial, uint32_t n_lists,
                                                                  uint32_t qt_stride, uint32_t top,
                                                                  qmx_scored_point *out, uint32_t *out_counts, uint32_t out_stride,
-                                                                 uint32_t out_offset, uint64_t *next_bound, const int *run_if, const uint32_t *out_map) {
+                                                                 uint32_t out_offset, uint64_t *next_bound, const int *run_if, const uint32_t *out_map,
+                                                                 uint32_t shared_grid) {
     if (run_if && *run_if == 0) return;      // the exact pass behind the split prefilter was not needed (scan_split.hip)
     const uint32_t q = blockIdx.x;
+    if (shared_grid) {      // pq_scan_kernel's packed pass: its `shared_grid` blocks were divided among the *run_if listed queries (pq.hip)
+        const uint32_t cnt = (uint32_t)*run_if, nq_eff = cnt < gridDim.x ? cnt : gridDim.x;
+        n_lists = shared_grid / nq_eff;
+        qt_stride = nq_eff;
+    }
     // out_map: list q of the scan belongs to query out_map[q] of the batch (the packed exact pass behind the prefilter); 0xFFFFFFFF = a padding slot
     const uint32_t oq = out_map ? out_map[q] : q;
     if (oq == 0xFFFFFFFFu) return;
@@ -153,12 +159,12 @@ __global__ __launch_bounds__(MERGE_BLOCK) void sort_scored_kernel(const float *s
 
 int32_t launch_merge_keys(hipStream_t st, const uint64_t *partial, uint32_t n_lists, uint32_t qt_stride,
                           uint32_t nq, uint32_t top, qmx_scored_point *out, uint32_t *out_counts, uint32_t out_stride,
-                          uint32_t out_offset, uint64_t *next_bound, const int *run_if, const uint32_t *out_map) {
+                          uint32_t out_offset, uint64_t *next_bound, const int *run_if, const uint32_t *out_map, uint32_t shared_grid) {
     if (nq == 0) return QMX_OK;
     if (out_stride == 0) out_stride = top;
     ::qmx::clear_stale_error();
     hipLaunchKernelGGL(merge_keys_kernel, dim3(nq), dim3(MERGE_BLOCK), 0, st, partial, n_lists, qt_stride, top, out, out_counts,
-                       out_stride, out_offset, next_bound, run_if, out_map);
+                       out_stride, out_offset, next_bound, run_if, out_map, shared_grid);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }

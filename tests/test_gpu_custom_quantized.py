@@ -99,10 +99,11 @@ def test_custom_queries_over_quantized_storages(qa, kind, distance):
         assert np.array_equal(res[qi]["idx"][uniq], all_ids[order][uniq])
 
 
-@pytest.mark.parametrize("kind", ["dense", "sq", "pq", "tq", "bq"])
+@pytest.mark.parametrize("kind", ["dense", "sq", "pq", "tq", "bq", "tq_l1"])
 def test_custom_walk_equals_the_oracle_walk(qa, kind):
-    """The graph comes from the oracle (built over the original rows); both sides walk it with the custom scorer of the storage `kind`."""
-    distance, dim, n, m = O.DOT if kind != "dense" else O.COSINE, 64, 4000, 8
+    """The graph comes from the oracle (built over the original rows); both sides walk it with the custom scorer of the storage `kind`.
+    tq_l1: TurboQuant over Manhattan - every hop is scored against every example by the wave (HopCustom over HopTQL1, round 4)."""
+    distance, dim, n, m = {"dense": O.COSINE, "tq_l1": O.MANHATTAN}.get(kind, O.DOT), 64, 4000, 8
     rng = np.random.default_rng(31)
     centers = rng.standard_normal((30, dim)).astype(np.float32) * 2
     rows = O.preprocess(distance, (centers[rng.integers(30, size=n)] + rng.standard_normal((n, dim))).astype(np.float32))

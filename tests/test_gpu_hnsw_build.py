@@ -444,7 +444,10 @@ def test_one_point_per_launch_builds_the_sequential_graph_other_storages(qa, kin
 
 
 @pytest.mark.parametrize("distance,bits,plus", [(O.COSINE, O.TQ_BITS4, False), (O.EUCLID, O.TQ_BITS2, False), (O.DOT, O.TQ_BITS1, False),
-                                                (O.DOT, O.TQ_BITS4, True), (O.EUCLID, O.TQ_BITS1_5, True)])
+                                                (O.DOT, O.TQ_BITS4, True), (O.EUCLID, O.TQ_BITS1_5, True),
+                                                # over Manhattan (round 4): the searches score the original vector against the dequantised, back-rotated
+                                                # candidates (score_precomputed's L1 arm), stored <-> stored pairs through score_symmetric's (hnsw_build_tq_l1.hip)
+                                                (O.MANHATTAN, O.TQ_BITS4, False), (O.MANHATTAN, O.TQ_BITS2, True)])
 def test_tq_build_through_the_quantized_scorer(qa, distance, bits, plus):
     """A TurboQuant segment builds like a PQ one (EncodedVectorsTQ::encode_internal_vector -> None, point_scorer.rs:183-218): insertion
     searches score through precompute_query of the point's ORIGINAL vector, the heuristic and the back links through score_symmetric (TQ+:
@@ -502,6 +505,33 @@ def test_tq_build_through_the_quantized_scorer(qa, distance, bits, plus):
     g_cpu = qa.GraphLayers.from_plain(cpu_plain)
     r_cpu = _recall(qa.search_quantized(tq_scorer, raw, 10, oversampling=4.0, rescore=True, graph=g_cpu, hnsw_ef=64), exact)
     assert r_f32 > (0.3 if bits in (O.TQ_BITS1, O.TQ_BITS1_5) else 0.4) and r_tq > r_f32 - 0.05 and r_tq > r_cpu - 0.05, (r_tq, r_cpu, r_f32)
+
+
+def test_tq_manhattan_build_with_an_unpadded_rotation(qa):
+    """TQRotation::Unpadded over 96 coordinates (chunks of 64 + 32), 2-bit codes with the TQ+ correction.  One point per launch: the oracle's sequential
+    graph, link for link; the walk: the oracle's.  (A rotation shorter than the code - the 1.5-bit layout - is refused by the reference itself with an
+    unpadded rotation: `Bits1_5 requires TQRotation::Padded`.)"""
+    n, dim, m, efc, seed = 600, 96, 8, 40, 5
+    rows = _clustered(n, dim, seed, k=24)
+    st = O.DenseStorage(O.F32, O.MANHATTAN, rows)
+    shift, scale = O.tq_plus_fit(O.MANHATTAN, dim, O.TQ_BITS2, rows, rotation_unpadded=True)
+    otq = O.TqOracle(O.MANHATTAN, dim, O.TQ_BITS2, rotation_unpadded=True, shift=shift, scale=scale)
+    assert otq.padded_dim == 96
+    codes = otq.encode_rows(rows)
+    otq.rows = codes
+    quant = qa.TurboQuantizer(dim, qa.Distance.Manhattan, O.TQ_BITS2, rotation_unpadded=True, shift=shift, scale=scale)
+    enc = qa.EncodedVectorsTQ(codes, quant)
+    vs = qa.VectorStorage(rows, qa.Distance.Manhattan)
+    seq = qa.GraphLayers.build(enc, m=m, ef_construct=efc, seed=seed, original=vs, max_batch=1)
+    p = seq.export_plain()
+    ref = O.Hnsw.build_tq(st, otq, m=m, ef_construct=efc, seed=seed).export_plain()
+    assert np.array_equal(p.reindex, ref.reindex) and np.array_equal(p.offsets, ref.offsets)
+    assert np.array_equal(p.neighbors, ref.neighbors)
+    queries = _clustered(20, dim, seed + 1, k=24)
+    want = O.Hnsw.from_plain(p, n).search_tq(st, otq, queries, 10, 48)
+    got = seq.search(10, 48, qa.new_raw_scorer(queries, enc))
+    for gq, wq in zip(got, want):
+        assert np.array_equal(gq["score"].view(np.uint32), wq["score"].view(np.uint32))
 
 
 def test_pq_pair_table_is_score_internal(qa):

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--batches", default="1,4,16")
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--sample", type=int, default=200_000, help="rows of the oracle check")
+    ap.add_argument("--c4-zero-query", type=int, default=-1, help="C4: make this query of the batch all zeros (a degenerate LUT: it falls back to the exact scan, alone)")
     args = ap.parse_args()
 
     import numpy as np
@@ -73,6 +74,7 @@ def main():
 
     def run(name, seg, dim, row_bytes, queries_pre, check):
         for Q in [int(x) for x in args.batches.split(",")]:
+            assert len(queries_pre) >= Q, "the config generates %d queries" % len(queries_pre)
             q = torch.from_numpy(queries_pre[:Q].copy()).to(dev)
             qh = C.c_void_p()
             F.check(lib.qmx_query_create(seg, F.ptr(q), Q, C.byref(qh)))
@@ -80,6 +82,8 @@ def main():
             out = torch.zeros((Q, top, 2), dtype=torch.int32, device=dev)
             counts = torch.zeros((Q,), dtype=torch.int32, device=dev)
             kms, launches, wall = timed_scans(lib, F, qh, top, out, counts, args.reps)
+            cnt = F.Counters()
+            F.check(lib.qmx_query_last_counters(qh, C.byref(cnt)))
             ok = check(qh, Q, out, counts)
             F.check(lib.qmx_query_destroy(qh))
             alg = n * row_bytes
@@ -88,6 +92,7 @@ def main():
                 "scan_kernel_ms": round(kms, 3), "launches_per_search": launches, "ms_per_search_wall": round(wall * 1e3, 3),
                 "qps": round(Q / wall, 1), "achieved_GBps": round(alg / (kms * 1e-3) / 1e9, 1),
                 "frac_of_8TBps": round(alg / (kms * 1e-3) / 1e9 / 8000.0, 4), "algorithmic_bytes_per_scan": alg,
+                "prefilter_queries": int(cnt.prefilter_queries), "fallback_queries": int(cnt.fallback_queries), "verified_rows": int(cnt.verified_rows), "prefilter_candidates": int(cnt.prefilter_candidates),
                 "topk_on_sample_matches_oracle": ok}), flush=True)
 
     if "c3" in args.configs:
@@ -269,7 +274,9 @@ def main():
         opq = O.PqOracle(O.DOT, dim, chunk, cen)
         enc_ok = bool(np.array_equal(opq.encode(host_rows[:2000]), host_codes[:2000]))
         opq.codes = host_codes
-        queries = O.preprocess(O.COSINE, O.synth(0x5EED0014, 0, 64, dim))
+        queries = O.preprocess(O.COSINE, O.synth(0x5EED0014, 0, max(64, max(int(x) for x in args.batches.split(","))), dim))
+        if args.c4_zero_query >= 0:      # a degenerate LUT: that query alone takes the exact scan behind the prefilter (what does the straggler cost the batch?)
+            queries[args.c4_zero_query] = 0.0
         ids = torch.arange(S, dtype=torch.int32, device=dev)
 
         def check(qh, Q, out, counts):
