@@ -696,7 +696,7 @@ int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
         a.q_stride = qs;
     }
     // PQ: the LUT-free walk (pq.hip HopPQDirect) - the entry of a search is its preprocessed vector (q->enc keeps them), staged in LDS
-    const bool pq_direct = s->dtype == QMX_DTYPE_PQ && !cw && !mw && !option(OPT_HNSW_PQ_LUT_WALK) && option(OPT_NO_HNSW_PQ_BLOCK) && !option(OPT_HNSW_PQ_LDS_LUT) &&
+    const bool pq_direct = s->dtype == QMX_DTYPE_PQ && !cw && !mw && option(OPT_HNSW_PQ_DIRECT_WALK) > 0 && option(OPT_NO_HNSW_PQ_BLOCK) && !option(OPT_HNSW_PQ_LDS_LUT) &&
                            s->d_centroids &&
                            pq_direct_walk_ok(s->dim, s->pq_m, s->pq.chunk_size, s->pq.n_centroids);
     if (pq_direct) {

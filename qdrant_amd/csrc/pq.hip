@@ -348,55 +348,62 @@ int32_t launch_hnsw_pq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uin
 // R x CHUNK / 4 sixteen-byte loads in flight per lane.
 // ------------------------------------------------------------------------------------------
 typedef float f32x4s __attribute__((ext_vector_type(4)));
-template <int CHUNK>
+template <int CHUNK, int SPLIT, int R>      // SPLIT lanes per SSE lane (4 SPLIT lanes per code row), R chunk steps per round
 struct HopPQDirect {
-    static constexpr int LPI = 4;
+    // A hop brings 5 - 10 fresh candidates: with four lanes per row most of the wave idles and each lane walks 24 chunk steps - at R steps per round trip
+    // (R x CHUNK / 4 sixteen-byte registers of codebook in flight) a hop is a dozen dependent trips to L2.  So an SSE lane's steps are dealt to SPLIT
+    // lanes: part p computes the entries of steps [p spp, (p + 1) spp) - the expensive part, in parallel - then the running sum of the SSE lane is handed
+    // from part to part and every part adds its entries in step order: the same chain of adds, one lane at a time.
+    static constexpr int LPI = 4 * SPLIT;
     static constexpr bool MULTI = false;
     static constexpr bool INTERNAL_QOFF = false;
     static constexpr bool INTERNAL_NORM = false;
     static constexpr int V = CHUNK / 4;                      // 16-byte pieces of a chunk
-    static constexpr int R = 24 / V;                         // chunk steps per round: 24 pieces = 96 registers of codebook per lane
+    static constexpr int SPP = 32 / SPLIT;                   // steps per part at most (m <= 128)
     template <int KIND>
-    static __device__ __forceinline__ float sum_quads(const ScanArgs &a, const float *q, const uint4 (&w)[8], uint32_t m4, int sub) {
+    static __device__ __forceinline__ void entries(const ScanArgs &a, const float *q, const uint8_t *codes, uint32_t p0, uint32_t n_mine, int quad_lane, float (&t)[SPP]) {
         const float *cent = a.pq_centroids;
         const uint32_t dim = a.pq_dim;
-        const uint32_t ws[32] = {w[0].x, w[0].y, w[0].z, w[0].w, w[1].x, w[1].y, w[1].z, w[1].w, w[2].x, w[2].y, w[2].z, w[2].w, w[3].x, w[3].y, w[3].z, w[3].w,
-                                 w[4].x, w[4].y, w[4].z, w[4].w, w[5].x, w[5].y, w[5].z, w[5].w, w[6].x, w[6].y, w[6].z, w[6].w, w[7].x, w[7].y, w[7].z, w[7].w};
-        float l = 0.0f;
+        uint32_t code[SPP];
 #pragma unroll
-        for (int s0 = 0; s0 < 32; s0 += R) {
-            if ((uint32_t)(4 * s0) >= m4) break;             // (uniform)
+        for (int r = 0; r < SPP; ++r) code[r] = (uint32_t)r < n_mine ? codes[4u * (p0 + (uint32_t)r) + (uint32_t)quad_lane] : 0u;      // one round trip: the lane's code bytes
+#pragma unroll
+        for (int r0 = 0; r0 < SPP; r0 += R) {
+            if (__ballot((uint32_t)r0 < n_mine) == 0) break;
             f32x4s cv[R][V];
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int step = s0 + r;
-                const bool on = step < 32 && (uint32_t)(4 * step) < m4;
-                // (past the row: chunk 0 of centroid 0 - a valid address, the value unused - so the loads are straight-line code: one round trip per round)
-                const uint32_t c = on ? 4u * (uint32_t)step + (uint32_t)sub : 0u;
-                const uint32_t code = on ? (ws[step < 32 ? step : 0] >> (8 * sub)) & 0xFFu : 0u;
-                const float *p = cent + (size_t)code * dim + (size_t)c * CHUNK;
+            for (int rr = 0; rr < R; ++rr) {
+                const int r = r0 + rr;
+                // (past the lane's steps: chunk 0 of centroid 0 - a valid address, the value unused - so the loads are straight-line code)
+                const bool on = r < SPP && (uint32_t)r < n_mine;
+                const uint32_t c = on ? 4u * (p0 + (uint32_t)r) + (uint32_t)quad_lane : 0u;
+                const float *p = cent + (size_t)(on ? code[r < SPP ? r : 0] : 0u) * dim + (size_t)c * CHUNK;
 #pragma unroll
-                for (int v = 0; v < V; ++v) cv[r][v] = *reinterpret_cast<const f32x4s *>(p + 4 * v);
+                for (int v = 0; v < V; ++v) cv[rr][v] = *reinterpret_cast<const f32x4s *>(p + 4 * v);
             }
+            float sr[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int step = s0 + r;
-                if (step < 32 && (uint32_t)(4 * step) < m4) {      // (uniform)
-                    const float *qc = q + (size_t)(4u * (uint32_t)step + (uint32_t)sub) * CHUNK;
-                    float s = -0.0f;
+            for (int rr = 0; rr < R; ++rr) sr[rr] = -0.0f;
 #pragma unroll
-                    for (int v = 0; v < V; ++v) {
-                        const f32x4s qv = *reinterpret_cast<const f32x4s *>(qc + 4 * v);
+            for (int v = 0; v < V; ++v) {
+                f32x4s qv[R];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) s += pq_term(KIND, qv[e], cv[r][v][e]);
-                    }
-                    l += a.pq_invert ? -s : s;
+                for (int rr = 0; rr < R; ++rr) {
+                    const int r = r0 + rr;
+                    const uint32_t c = (r < SPP && (uint32_t)r < n_mine) ? 4u * (p0 + (uint32_t)r) + (uint32_t)quad_lane : 0u;
+                    qv[rr] = *reinterpret_cast<const f32x4s *>(q + (size_t)c * CHUNK + 4 * v);
                 }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int rr = 0; rr < R; ++rr) sr[rr] += pq_term(KIND, qv[rr][e], cv[rr][v][e]);
             }
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr)
+                if (r0 + rr < SPP) t[r0 + rr] = a.pq_invert ? -sr[rr] : sr[rr];
         }
-        return l;
     }
-    // entry (c, code) alone (the chunks past the last whole quad of a row: every lane of the quad computes them)
+    // entry (c, code) alone (the chunks past the last whole quad of a row)
     static __device__ __forceinline__ float entry(const ScanArgs &a, const float *q, uint32_t c, uint32_t code) {
         const float *p = a.pq_centroids + (size_t)code * a.pq_dim + (size_t)c * CHUNK, *qc = q + (size_t)c * CHUNK;
         float s = -0.0f;
@@ -406,25 +413,33 @@ struct HopPQDirect {
     static __device__ __forceinline__ float score(const ScanArgs &a, const unsigned char *qp, uint32_t id, int sub) {
         const float *q = reinterpret_cast<const float *>(qp);
         const uint8_t *codes = reinterpret_cast<const uint8_t *>(a.rows) + (uint64_t)id * a.row_stride;
-        const uint32_t m = a.pq_m, m4 = m & ~3u;
-        uint4 w[8];
-        if ((reinterpret_cast<uintptr_t>(codes) & 15) == 0) {
+        const uint32_t m = a.pq_m, nsteps = m / 4;
+        const int quad_lane = sub & 3, part = sub >> 2;
+        const uint32_t spp = (nsteps + SPLIT - 1) / SPLIT;      // steps per part (the last part may hold fewer, or none)
+        const uint32_t p0 = (uint32_t)part * spp;
+        const uint32_t n_mine = p0 < nsteps ? (nsteps - p0 < spp ? nsteps - p0 : spp) : 0u;
+        float t[SPP];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) w[k] = (uint32_t)(16 * k) < m4 ? *reinterpret_cast<const uint4 *>(codes + 16 * k) : make_uint4(0, 0, 0, 0);
-        } else {      // rows that are not 16-byte aligned (m not a multiple of 16): byte by byte
-            uint32_t t[32];
+        for (int r = 0; r < SPP; ++r) t[r] = 0.0f;
+        if (a.pq_kind == 0) entries<0>(a, q, codes, p0, n_mine, quad_lane, t);
+        else if (a.pq_kind == 1) entries<1>(a, q, codes, p0, n_mine, quad_lane, t);
+        else entries<2>(a, q, codes, p0, n_mine, quad_lane, t);
+        // the SSE lane's sum, handed from part to part: l = ((0 + t_0) + t_1) + ... in step order
+        float l = 0.0f;
 #pragma unroll
-            for (int k = 0; k < 32; ++k) {
-                t[k] = 0;
-                if ((uint32_t)(4 * k) < m4) t[k] = (uint32_t)codes[4 * k] | ((uint32_t)codes[4 * k + 1] << 8) | ((uint32_t)codes[4 * k + 2] << 16) | ((uint32_t)codes[4 * k + 3] << 24);
+        for (int p = 0; p < SPLIT; ++p) {
+            if (p > 0) l = __shfl_up(l, 4, 64);      // (part p - 1 of the same row sits four lanes below)
+            if (part == p) {
+#pragma unroll
+                for (int r = 0; r < SPP; ++r)
+                    if ((uint32_t)r < n_mine) l += t[r];
             }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) w[k] = make_uint4(t[4 * k], t[4 * k + 1], t[4 * k + 2], t[4 * k + 3]);
         }
-        const float l = a.pq_kind == 0 ? sum_quads<0>(a, q, w, m4, sub) : a.pq_kind == 1 ? sum_quads<1>(a, q, w, m4, sub) : sum_quads<2>(a, q, w, m4, sub);
+        // the last part's quad holds the four SSE lanes' sums
         const float x = l + dpp_f32<DPP_QUAD_XOR2>(l);          // lane 0: l0 + l2, lane 1: l1 + l3
         float sum = x + dpp_f32<DPP_QUAD_XOR1>(x);              // lane 0: (l0 + l2) + (l1 + l3)
-        for (uint32_t c = m4; c < m; ++c) sum += entry(a, q, c, codes[c]);
+        for (uint32_t c = nsteps * 4; c < m; ++c) sum += entry(a, q, c, codes[c]);
+        if (SPLIT > 1) sum = __shfl_down(sum, 4 * (SPLIT - 1), 64);      // to the row's first lane (the one whose score is stored)
         return sum;
     }
 };
@@ -433,9 +448,10 @@ bool pq_direct_walk_ok(uint32_t dim, uint32_t m, uint32_t chunk, uint32_t ncent)
 }
 int32_t launch_hnsw_pq_direct(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
     QMX_REQUIRE(a.pq_centroids && pq_direct_walk_ok(a.pq_dim, a.pq_m, a.pq_chunk, a.pq_ncent), QMX_ERR_BAD_ARG, "the LUT-free PQ walk does not take this codebook");
-    if (a.pq_chunk == 16) return launch_hnsw_hop<HopPQDirect<16>>(st, a, h, grid, per_cu);
-    if (a.pq_chunk == 8) return launch_hnsw_hop<HopPQDirect<8>>(st, a, h, grid, per_cu);
-    return launch_hnsw_hop<HopPQDirect<4>>(st, a, h, grid, per_cu);
+    // four lanes per SSE lane, two chunk steps (eight 16-byte loads) per round: the best of the shapes measured (profiles/r4_pq_direct_walk.md)
+    if (a.pq_chunk == 16) return launch_hnsw_hop<HopPQDirect<16, 4, 2>>(st, a, h, grid, per_cu);
+    if (a.pq_chunk == 8) return launch_hnsw_hop<HopPQDirect<8, 4, 4>>(st, a, h, grid, per_cu);
+    return launch_hnsw_hop<HopPQDirect<4, 4, 8>>(st, a, h, grid, per_cu);
 }
 
 // ... with a custom query as the scorer: every example's LUT stays in global memory (read through L2, like the plain PQ walk's large LUTs)

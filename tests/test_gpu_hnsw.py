@@ -180,8 +180,20 @@ def test_sq_scorer_walk_bit_exact_and_rescoring(qa, distance):
         assert np.array_equal(r["score"].view(np.uint32), w.view(np.uint32))
 
 
-@pytest.mark.parametrize("distance,dim,chunk", [(O.DOT, 64, 4), (O.EUCLID, 96, 16), (O.COSINE, 70, 8)])
-def test_pq_scorer_walk_bit_exact(qa, distance, dim, chunk):
+@pytest.mark.parametrize("direct", [False, True])
+@pytest.mark.parametrize("distance,dim,chunk", [(O.DOT, 64, 4), (O.EUCLID, 96, 16), (O.COSINE, 70, 8), (O.MANHATTAN, 96, 16), (O.EUCLID, 72, 8), (O.DOT, 320, 16)])
+def test_pq_scorer_walk_bit_exact(qa, distance, dim, chunk, direct):
+    """direct: the walk without LUTs (option hnsw_pq_direct_walk, pq.hip HopPQDirect) - every LUT entry recomputed from the codebook where it is needed, in
+    pq_lut_kernel's order: the same bits.  Codebooks it does not take (a ragged last chunk: 70 = 8 x 8 + 6) keep the LUT walk."""
+    if direct:
+        qa.set_option("hnsw_pq_direct_walk", 1)
+    try:
+        _pq_walk(qa, distance, dim, chunk, direct)
+    finally:
+        qa.set_option("hnsw_pq_direct_walk", -1)
+
+
+def _pq_walk(qa, distance, dim, chunk, direct):
     n, m, nq = 3000, 8, 24
     rows, st, g, plain = _graph(distance, n, dim, m, 0x5EED0340 + dim)
     queries = O.synth(0x5EED0341, 0, nq, dim)
@@ -196,6 +208,8 @@ def test_pq_scorer_walk_bit_exact(qa, distance, dim, chunk):
     # PQ scores tie now and then (sums of few LUT entries): compare the walks where the oracle's result has distinct scores
     want = g.search_pq(st, opq, qpre, 10, 64)
     got = graph.search(10, 64, scorer)
+    kernel = qa._ffi.last_kernel(scorer._h)
+    assert ("HopPQDirect" in kernel) == (direct and dim % chunk == 0), kernel
     n_cmp = 0
     for gq, wq in zip(got, want):
         assert np.array_equal(gq["score"].view(np.uint32), wq["score"].view(np.uint32))
@@ -203,6 +217,11 @@ def test_pq_scorer_walk_bit_exact(qa, distance, dim, chunk):
             assert gq["idx"].tolist() == wq["idx"].tolist()
             n_cmp += 1
     assert n_cmp >= nq // 2
+    if direct:      # the wide beam (LDS list) and the walk that returns the expanded points take the same scorer
+        want = g.search_pq(st, opq, qpre[:6], 10, 700)
+        got = graph.search(10, 700, qa.new_raw_scorer(queries[:6], enc))
+        for gq, wq in zip(got, want):
+            assert np.array_equal(gq["score"].view(np.uint32), wq["score"].view(np.uint32))
 
 
 @pytest.mark.parametrize("dtype", ["f16", "u8"])

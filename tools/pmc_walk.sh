@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 REPO=$PWD
 cd /tmp
 i=0
-for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES"; do
+for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "FETCH_SIZE"; do
   i=$((i+1))
   rocprofv3 --pmc $grp --kernel-trace -d $OUT/g$i -o g$i -- python $REPO/tools/bench_hnsw.py "$@" > $OUT/g$i.out 2> $OUT/g$i.err
 done
