@@ -586,6 +586,41 @@ static void link_new_point(qo_hnsw *g, const qo_scorer *tmpl, uint32_t p, visite
         own.tq_query = tq_query;
         q.s = &own;
     }
+    /* Multi-vector points over such inner rows (QuantizedMultivectorStorage::encode_internal_vector, quantized_multivector_storage/mod.rs:458-470: every
+     * inner row's encode_internal_vector, `?` -> None as soon as one is None): the same fallback one level up - the multi-vector query scorer of the point's
+     * ORIGINAL inner vectors (one inner query scorer per inner vector: a LUT / a precomputed TurboQuant query), score_internal_max_similarity elsewhere.
+     * tmpl->mv_tokens[0] is the inner storage as a template; its `st` holds the original inner rows. */
+    qo_scorer *mv_own = NULL;
+    float **mv_luts = NULL;
+    qo_tq_query **mv_tqq = NULL;
+    uint32_t mv_n = 0;
+    if (tmpl->kind == 4 && (tmpl->mv_tokens[0].kind == 2 || tmpl->mv_tokens[0].kind == 5)) {
+        const qo_scorer *inner = &tmpl->mv_tokens[0];
+        const qo_storage *st = inner->st;
+        const uint64_t r0 = tmpl->mv_offsets[p], r1 = tmpl->mv_offsets[p + 1];
+        mv_n = (uint32_t)(r1 - r0);
+        mv_own = (qo_scorer *)malloc(sizeof(qo_scorer) * (mv_n ? mv_n : 1));
+        mv_luts = (float **)calloc(mv_n ? mv_n : 1, sizeof(float *));
+        mv_tqq = (qo_tq_query **)calloc(mv_n ? mv_n : 1, sizeof(qo_tq_query *));
+        float *qv = (float *)malloc(sizeof(float) * st->dim);
+        for (uint32_t t = 0; t < mv_n; t++) {
+            qo_preprocess_f32(st->distance, (const float *)st->rows + (size_t)(r0 + t) * st->dim, qv, st->dim);
+            mv_own[t] = *inner;
+            if (inner->kind == 2) {
+                mv_luts[t] = (float *)malloc(sizeof(float) * (size_t)inner->pq->m * inner->pq->n_centroids);
+                qo_pq_encode_query(inner->pq, qv, mv_luts[t]);
+                mv_own[t].pq_lut = mv_luts[t];
+            } else {
+                mv_tqq[t] = qo_tq_precompute_query(inner->tq, qv);
+                mv_own[t].tq_query = mv_tqq[t];
+            }
+        }
+        free(qv);
+        own = *tmpl;
+        own.mv_tokens = mv_own;
+        own.mv_n_tokens = mv_n;
+        q.s = &own;
+    }
     const uint32_t level = g->level[p];
     uint32_t ep_id = 0, ep_level = 0;
     pthread_mutex_lock(&g->ep_lock);
@@ -644,6 +679,13 @@ static void link_new_point(qo_hnsw *g, const qo_scorer *tmpl, uint32_t p, visite
     pthread_mutex_unlock(&g->ep_lock);
     free(lut);
     if (tq_query) qo_tq_query_free(tq_query);
+    if (mv_own) {
+        for (uint32_t t = 0; t < mv_n; t++) {
+            free(mv_luts[t]);
+            if (mv_tqq[t]) qo_tq_query_free(mv_tqq[t]);
+        }
+        free(mv_luts); free(mv_tqq); free(mv_own);
+    }
 }
 
 static inline uint64_t splitmix64(uint64_t x) {

@@ -217,6 +217,7 @@ SIGNATURES = {
     "qmx_tq_fit_plus": (C.c_int32, [C.c_int32, C.c_uint32, C.c_uint32, _P, _P, C.c_uint64, _P, _P]),
     "qmx_hnsw_search_with_vectors": (C.c_int32, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, _P, _P, _P]),
     "qmx_multi_hnsw_build": (C.c_int32, [_P, _P, C.c_uint32, _P, C.c_uint64, _P, _P]),
+    "qmx_multi_hnsw_build_quantized": (C.c_int32, [_P, _P, _P, C.c_uint32, _P, C.c_uint64, _P, _P]),
     "qmx_multi_hnsw_search": (C.c_int32, [_P, _P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint64, C.c_uint32, C.c_uint32, _P, _P, _P]),
     "qmx_custom_set_coefficients": (C.c_int32, [_P, _P, C.c_uint32]),
     "qmx_bq_encode_ex": (C.c_int32, [C.c_int32, C.POINTER(BqParams), _P, C.c_uint64, C.c_uint32, _P]),

@@ -232,6 +232,8 @@ static int32_t launch_hnsw_build_any(const qmx_segment *seg, const ScanArgs &a, 
     if (a.mv_offsets) {   // multi-vector points (qmx_multi_hnsw_build)
         if (seg->dtype == QMX_DTYPE_SQ_U8) return launch_hnsw_build_maxsim_sq(nullptr, (int)seg->distance, a, h, phase, grid, per_cu);
         if (seg->dtype == QMX_DTYPE_BQ) return launch_hnsw_build_maxsim_bq(nullptr, a, h, phase, grid, per_cu);
+        if (seg->dtype == QMX_DTYPE_PQ) return launch_hnsw_build_maxsim_pq(nullptr, a, h, phase, grid, per_cu);
+        if (seg->dtype == QMX_DTYPE_TQ) return launch_hnsw_build_maxsim_tq(nullptr, a, h, phase, grid, per_cu);
         return launch_hnsw_build_maxsim_dense(nullptr, (int)seg->dtype, (int)seg->distance, a, h, phase, grid, per_cu);
     }
     if (seg->dtype == QMX_DTYPE_SQ_U8) return launch_hnsw_build_sq(nullptr, (int)seg->distance, a, h, phase, grid, per_cu);
@@ -311,19 +313,25 @@ int32_t qmx_sharded_hnsw_build(const qmx_segment *const *segments, const qmx_seg
     return first;
 }
 
-int32_t qmx_multi_hnsw_build(const qmx_segment *inner, const uint64_t *point_offsets, uint32_t n_points, const uint64_t *point_deleted,
-                             uint64_t n_deleted_bits, const qmx_hnsw_build_params *bp, qmx_hnsw **out) {
+int32_t qmx_multi_hnsw_build_quantized(const qmx_segment *inner, const qmx_segment *original_inner, const uint64_t *point_offsets, uint32_t n_points,
+                                       const uint64_t *point_deleted, uint64_t n_deleted_bits, const qmx_hnsw_build_params *bp, qmx_hnsw **out) {
     QMX_REQUIRE(inner && point_offsets && bp && out, QMX_ERR_BAD_ARG, "NULL argument");
     *out = nullptr;
-    QMX_REQUIRE(inner->dtype == QMX_DTYPE_F32 || inner->dtype == QMX_DTYPE_F16 || inner->dtype == QMX_DTYPE_SQ_U8 || inner->dtype == QMX_DTYPE_BQ,
-                QMX_ERR_NOT_SUPPORTED, "device HNSW build over multi-vectors: inner dtype %u not supported (f32, f16, SQ, BQ)", inner->dtype);
+    QMX_REQUIRE(inner->dtype == QMX_DTYPE_F32 || inner->dtype == QMX_DTYPE_F16 || inner->dtype == QMX_DTYPE_SQ_U8 || inner->dtype == QMX_DTYPE_BQ ||
+                    inner->dtype == QMX_DTYPE_PQ || (inner->dtype == QMX_DTYPE_TQ && !tq_l1(inner)),
+                QMX_ERR_NOT_SUPPORTED, "device HNSW build over multi-vectors: inner dtype %u not supported (f32, f16, SQ, BQ, PQ, TurboQuant except over Manhattan)",
+                inner->dtype);
     QMX_REQUIRE(!is_device_ptr(point_offsets) && !is_device_ptr(point_deleted), QMX_ERR_BAD_ARG, "point_offsets and point_deleted are host arrays");
     for (uint32_t p = 0; p < n_points; ++p)
         QMX_REQUIRE(point_offsets[p] <= point_offsets[p + 1], QMX_ERR_BAD_ARG, "point_offsets is not ascending at %u", p);
     QMX_REQUIRE(point_offsets[n_points] <= inner->n, QMX_ERR_OUT_OF_BOUNDS, "point_offsets reach past the %llu inner rows of the segment",
                 (unsigned long long)inner->n);
     const MultiBuild mb{point_offsets, n_points, (point_deleted && n_deleted_bits) ? point_deleted : nullptr, point_deleted ? n_deleted_bits : 0};
-    return hnsw_build_impl(inner, nullptr, bp, out, &mb);
+    return hnsw_build_impl(inner, (inner->dtype == QMX_DTYPE_PQ || inner->dtype == QMX_DTYPE_TQ) ? original_inner : nullptr, bp, out, &mb);
+}
+int32_t qmx_multi_hnsw_build(const qmx_segment *inner, const uint64_t *point_offsets, uint32_t n_points, const uint64_t *point_deleted,
+                             uint64_t n_deleted_bits, const qmx_hnsw_build_params *bp, qmx_hnsw **out) {
+    return qmx_multi_hnsw_build_quantized(inner, nullptr, point_offsets, n_points, point_deleted, n_deleted_bits, bp, out);
 }
 
 static int32_t hnsw_build_impl(const qmx_segment *seg, const qmx_segment *original, const qmx_hnsw_build_params *bp, qmx_hnsw **out, const MultiBuild *mb) {
@@ -434,18 +442,31 @@ static int32_t hnsw_build_impl(const qmx_segment *seg, const qmx_segment *origin
         h.row_bytes = (uint32_t)dev_row_bytes;
         h.lds_query_bytes = (uint32_t)((dev_row_bytes + 127) / 128 * 128 + 128);
         uint64_t lut_stride = 0;
+        uint64_t max_entries = max_batch;      // query entries a batch may need: one per point - or, multi-vector points, one per inner vector
         if (seg->dtype == QMX_DTYPE_PQ) {   // query entries = LUTs of the batch's original vectors, read through L2 (as the PQ walk does)
             lut_stride = ((uint64_t)seg->pq_m * seg->pq.n_centroids * sizeof(float) + 15) & ~15ull;
-            QB(b_bq.reserve((size_t)max_batch * lut_stride));
-            QB(b_bqsrc.reserve((size_t)max_batch * seg->dim * sizeof(float)));
+            if (mb) {   // at least the longest point, at most 1 GiB of LUTs (the insertion loop shortens a batch that would need more)
+                uint64_t longest = 1;
+                for (uint32_t p = 0; p < n; ++p) longest = std::max<uint64_t>(longest, mb->h_offsets[p + 1] - mb->h_offsets[p]);
+                max_entries = std::max<uint64_t>(longest, std::min<uint64_t>(mb->h_offsets[n] ? mb->h_offsets[n] : 1, (1ull << 30) / lut_stride));
+                a.q_stride = (uint32_t)lut_stride;
+            }
+            QB(b_bq.reserve((size_t)max_entries * lut_stride));
+            QB(b_bqsrc.reserve((size_t)max_entries * seg->dim * sizeof(float)));
             h.batch_queries = (const unsigned char *)b_bq.p;
             h.batch_q_stride = lut_stride;
             h.lds_query_bytes = 0;
         }
         if (seg->dtype == QMX_DTYPE_TQ) {   // query entries = precompute_query of the batch's original vectors, staged in LDS per insertion
-            QB(b_bq.reserve((size_t)max_batch * a.q_stride));
-            QB(b_bqsrc.reserve((size_t)max_batch * seg->dim * sizeof(float)));
-            QB(b_rot.reserve((size_t)max_batch * seg->tq_padded_dim * sizeof(double)));
+            if (mb) {   // one entry per inner vector of the batch: at least the longest point, at most 256 MiB of rotated vectors
+                uint64_t longest = 1;
+                for (uint32_t p = 0; p < n; ++p) longest = std::max<uint64_t>(longest, mb->h_offsets[p + 1] - mb->h_offsets[p]);
+                max_entries = std::max<uint64_t>(longest, std::min<uint64_t>(mb->h_offsets[n] ? mb->h_offsets[n] : 1,
+                                                                             (1ull << 28) / ((uint64_t)seg->tq_padded_dim * sizeof(double))));
+            }
+            QB(b_bq.reserve((size_t)max_entries * a.q_stride));
+            QB(b_bqsrc.reserve((size_t)max_entries * seg->dim * sizeof(float)));
+            QB(b_rot.reserve((size_t)max_entries * seg->tq_padded_dim * sizeof(double)));
             h.batch_queries = (const unsigned char *)b_bq.p;
             h.batch_q_stride = a.q_stride;
             h.lds_query_bytes = a.q_stride;
@@ -513,28 +534,37 @@ static int32_t hnsw_build_impl(const qmx_segment *seg, const qmx_segment *origin
             // a point above the current top level ends its batch: the next batch starts from it
             for (uint32_t i = 0; i < count; ++i)
                 if (level[next + i] > ep_level && live(next + i)) { count = i + 1; break; }
+            if (mb && from_original)      // the batch's inner vectors must fit the entries (a single point always does)
+                while (count > 1 && mb->h_offsets[next + count] - mb->h_offsets[next] > max_entries) --count;
             h.first = next; h.count = count; h.ep_id = ep_id; h.ep_level = ep_level;
             if (seg->dtype == QMX_DTYPE_PQ) {
                 // quantized_vectors.raw_scorer(original vector): Metric::preprocess (quantized_query_scorer.rs:39-41; identity for a row
                 // normalised at insert, up to the reference's 1e-6 rule), then EncodedVectorsPQ::encode_query for every point of the batch
+                // (multi-vector points: for every inner vector of the batch's points, in storage order)
+                const uint64_t r0 = mb ? mb->h_offsets[next] : next, nr = mb ? mb->h_offsets[next + count] - r0 : count;
                 float *src = (float *)b_bqsrc.p;
-                QH(hipMemcpy2DAsync(src, (size_t)seg->dim * 4, (const char *)original->d_rows + (uint64_t)next * original->row_stride, original->row_stride,
-                                    (size_t)seg->dim * 4, count, hipMemcpyDeviceToDevice, nullptr));
-                if (seg->distance == QMX_DISTANCE_COSINE) QB(launch_cosine_preprocess_f32(nullptr, src, src, count, seg->dim));
-                QB(launch_pq_lut(nullptr, seg->distance, seg->dim, seg->pq, seg->d_centroids, src, count, (float *)b_bq.p));
+                if (nr) {
+                    QH(hipMemcpy2DAsync(src, (size_t)seg->dim * 4, (const char *)original->d_rows + r0 * original->row_stride, original->row_stride,
+                                        (size_t)seg->dim * 4, nr, hipMemcpyDeviceToDevice, nullptr));
+                    if (seg->distance == QMX_DISTANCE_COSINE) QB(launch_cosine_preprocess_f32(nullptr, src, src, nr, seg->dim));
+                    QB(launch_pq_lut(nullptr, seg->distance, seg->dim, seg->pq, seg->d_centroids, src, (uint32_t)nr, (float *)b_bq.p));
+                }
             }
             if (tq_l1(seg)) {   // EncodedVectorsTQ over Manhattan: no preprocessing, no rotation - the rows themselves, zero padded to whole 16 bytes
                 QH(hipMemsetAsync(b_bq.p, 0, (size_t)count * a.q_stride, nullptr));
                 QH(hipMemcpy2DAsync(b_bq.p, a.q_stride, (const char *)original->d_rows + (uint64_t)next * original->row_stride, original->row_stride,
                                     (size_t)seg->dim * 4, count, hipMemcpyDeviceToDevice, nullptr));
             } else if (seg->dtype == QMX_DTYPE_TQ) {   // the same for EncodedVectorsTQ: preprocess, rotate, TurboQuantizer::precompute_query
+                const uint64_t r0 = mb ? mb->h_offsets[next] : next, nr = mb ? mb->h_offsets[next + count] - r0 : count;      // (multi-vector points: every inner vector)
                 float *src = (float *)b_bqsrc.p;
-                QH(hipMemcpy2DAsync(src, (size_t)seg->dim * 4, (const char *)original->d_rows + (uint64_t)next * original->row_stride, original->row_stride,
-                                    (size_t)seg->dim * 4, count, hipMemcpyDeviceToDevice, nullptr));
-                if (seg->distance == QMX_DISTANCE_COSINE) QB(launch_cosine_preprocess_f32(nullptr, src, src, count, seg->dim));
-                QB(launch_tq_rotate(nullptr, src, count, tq_rotation(seg), (double *)b_rot.p));
-                QB(launch_tq_query_encode(nullptr, (double *)b_rot.p, count, seg->tq_padded_dim, seg->tq_value_bits, seg->distance == QMX_DISTANCE_EUCLID ? 1 : 0,
-                                          b_bq.p, a.q_stride, a.aux_off, seg->d_tq_shift, seg->d_tq_scale, a.tq_qbytes_off));
+                if (nr) {
+                    QH(hipMemcpy2DAsync(src, (size_t)seg->dim * 4, (const char *)original->d_rows + r0 * original->row_stride, original->row_stride,
+                                        (size_t)seg->dim * 4, nr, hipMemcpyDeviceToDevice, nullptr));
+                    if (seg->distance == QMX_DISTANCE_COSINE) QB(launch_cosine_preprocess_f32(nullptr, src, src, nr, seg->dim));
+                    QB(launch_tq_rotate(nullptr, src, (uint32_t)nr, tq_rotation(seg), (double *)b_rot.p));
+                    QB(launch_tq_query_encode(nullptr, (double *)b_rot.p, (uint32_t)nr, seg->tq_padded_dim, seg->tq_value_bits, seg->distance == QMX_DISTANCE_EUCLID ? 1 : 0,
+                                              b_bq.p, a.q_stride, a.aux_off, seg->d_tq_shift, seg->d_tq_scale, a.tq_qbytes_off));
+                }
             }
             QB(launch_hnsw_build_any(seg, a, h, 1, (uint32_t)std::min<uint64_t>(slots1, count), &per_cu1));
             QB(launch_hnsw_build_any(seg, a, h, 2, (uint32_t)std::min<uint64_t>(slots2, count), &per_cu2));
@@ -655,7 +685,9 @@ static int32_t launch_hnsw(const qmx_query *q, const ScanArgs &a, const HnswArgs
         }
         if (s->dtype == QMX_DTYPE_SQ_U8) return launch_hnsw_maxsim_sq(q->stream, (int)s->distance, a, h, grid, per_cu);
         if (s->dtype == QMX_DTYPE_BQ) return launch_hnsw_maxsim_bq(q->stream, a, h, grid, per_cu);
-        set_error("MaxSim walk: inner rows of dtype %u are not built (dense, SQ and BQ are)", s->dtype);
+        if (s->dtype == QMX_DTYPE_PQ) return launch_hnsw_maxsim_pq(q->stream, a, h, grid, per_cu);
+        if (s->dtype == QMX_DTYPE_TQ) return launch_hnsw_maxsim_tq(q->stream, a, h, grid, per_cu);      // (over Manhattan: refused by hnsw_enqueue)
+        set_error("MaxSim walk: inner rows of dtype %u are not built", s->dtype);
         return QMX_ERR_NOT_SUPPORTED;
     }
     if (s->dtype <= QMX_DTYPE_U8) {
@@ -684,7 +716,7 @@ int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
                             uint32_t *d_counts, uint32_t *d_scored, bool timed, bool acorn, const MultiWalk *mw,
                             const ExpandedOut *xo, const CustomWalk *cw) {
     const qmx_segment *s = q->seg;
-    QMX_REQUIRE(!tq_l1(s) || !mw, QMX_ERR_NOT_SUPPORTED, "multi-vector walks through a TurboQuant storage are not built (inner rows: dense, SQ, BQ)");
+    QMX_REQUIRE(!tq_l1(s) || !mw, QMX_ERR_NOT_SUPPORTED, "multi-vector walks through a TurboQuant storage over Manhattan are not built");
     ScanArgs a;
     fill_args(q, 0, q->nq, a);
     if (tq_l1(s)) {   // the walk scores against the query as given (tq_l1_policy.hpp): f32 entries of dim floats, 16-byte padded
@@ -729,15 +761,13 @@ int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
         h.lds_query_bytes = tq_l1_lds_bytes(s->dim, s->tq_rot_dim);
         QMX_REQUIRE(h.lds_query_bytes <= HNSW_LDS_QUERY_MAX, QMX_ERR_NOT_SUPPORTED, "TurboQuant over Manhattan, the walk: %u bytes of LDS per search", h.lds_query_bytes);
     }
-    if (mw) {   // [16-byte header][the multi-query's inner vectors]
+    if (mw) {   // [16-byte header][the multi-query's inner vectors, when the longest fits a modest share of the LDS; else every search reads its own through L2]
         const uint64_t need = 16 + (uint64_t)std::max<uint32_t>(mw->max_tokens, 1) * q->q_stride;
-        QMX_REQUIRE(need <= HNSW_LDS_QUERY_MAX, QMX_ERR_NOT_SUPPORTED, "a multi-query of %u inner vectors x %u bytes does not fit the LDS", mw->max_tokens,
-                    q->q_stride);
-        h.lds_query_bytes = (uint32_t)need;
+        h.lds_query_bytes = need <= 64 * 1024 ? (uint32_t)need : 16;
     }
     // A PQ LUT of more than half the LDS leaves one search per CU; the walk is a chain of dependent memory round trips,
     // so many searches per CU with the LUT read through L2 win (measured: tools/bench_hnsw.py)
-    if (s->dtype == QMX_DTYPE_PQ && q->q_stride > 16 * 1024 && !option(OPT_HNSW_PQ_LDS_LUT)) h.lds_query_bytes = 0;
+    if (s->dtype == QMX_DTYPE_PQ && q->q_stride > 16 * 1024 && !option(OPT_HNSW_PQ_LDS_LUT) && !mw) h.lds_query_bytes = 0;      // (a multi-query's LUTs are always staged)
     if (pq_direct) h.lds_query_bytes = a.q_stride;
     if (cw) {   // [32-byte header][the examples' entries]: staged when they fit a modest share of the LDS, read through L2 otherwise (PQ LUTs always)
         const uint64_t need = 32 + (uint64_t)std::max<uint32_t>(cw->max_examples, 1) * q->q_stride;

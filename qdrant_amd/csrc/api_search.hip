@@ -187,12 +187,12 @@ int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids, uint64
                               qmx_counters *counters, bool timed) {
     const qmx_segment *s = q->seg;
     const uint64_t n_cand = d_ids ? n_ids : s->scan_rows();
-    if (tq_l1(s)) {     // the score matrix (tiles of queries: at most 2^31 scores at a time), then one block per query selects its k best live candidates
+    if (tq_l1(s)) {     // the score matrix (tiles of queries: at most 256 MiB of scores at a time), then one block per query selects its k best live candidates
         q->last_counters = qmx_counters{};
         q->last_split = false;
         ScanArgs a;
         fill_args(q, 0, q->nq, a);
-        const uint32_t qtile = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(q->nq, (1ull << 31) / std::max<uint64_t>(n_cand, 1)));
+        const uint32_t qtile = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(q->nq, (1ull << 26) / std::max<uint64_t>(n_cand, 1)));
         QMX_TRY(q->scores.reserve((size_t)qtile * std::max<uint64_t>(n_cand, 1) * sizeof(float)));
         for (uint32_t q0 = 0; q0 < q->nq; q0 += qtile) {
             if (is_stopped && *is_stopped) {

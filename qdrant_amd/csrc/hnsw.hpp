@@ -85,7 +85,8 @@ struct HopSmall {
 // query_scorer/mod.rs:70-97; quantized: QuantizedMultivectorStorage::score_point_max_similarity, quantized_multivector_storage/mod.rs:339-363):
 // the graph's points are multi-vectors, a hop candidate's score is the sum over the query's inner vectors (in order, from 0.0) of the max
 // over the point's inner vectors (`if max_sim < sim`, from -inf) of the inner policy's score.  The query entry in LDS is
-// [16-byte header: number of inner query vectors][that many tile entries]; qp points at the first entry.
+// [16-byte header: number of inner query vectors, pad, pointer to the first entry][the entries, when they fit the launch's LDS share - else the header points
+// at them in global memory (PQ: every inner query vector is a LUT)]; qp points behind the header.
 template <class H, class = void>
 struct is_maxsim { static constexpr bool value = false; };
 template <class H>
@@ -99,6 +100,39 @@ struct HopMaxSim {
     static constexpr bool MAXSIM = true;
     static __device__ __forceinline__ float score(const ScanArgs &a, const unsigned char *qp, uint32_t id, int sub) {
         const uint32_t n_tokens = *reinterpret_cast<const uint32_t *>(qp - 16);
+        const unsigned char *toks = *reinterpret_cast<const unsigned char *const *>(qp - 8);
+        const uint64_t b0 = a.mv_offsets[id], b1 = a.mv_offsets[id + 1];
+        float sum = 0.0f;
+        for (uint32_t t = 0; t < n_tokens; ++t) {
+            const unsigned char *qe = toks + (size_t)t * a.q_stride;
+            float max_sim = -__builtin_inff();
+            for (uint64_t b = b0; b < b1; ++b) {
+                const float sim = HI::score(a, qe, (uint32_t)b, sub);
+                if (max_sim < sim) max_sim = sim;
+            }
+            sum += max_sim;
+        }
+        return sum;
+    }
+};
+
+// The insertion searches of a build over multi-vector points whose inner storage cannot turn a stored row into a query (PQ, TurboQuant:
+// QuantizedMultivectorStorage::encode_internal_vector -> None, quantized_multivector_storage/mod.rs:458-470; point_scorer.rs:183-218 then takes the query
+// scorer of the point's ORIGINAL multi-vector): HopMaxSim over the batch's query entries - the new point's tokens are a.mv_q_tokens entries, a.q_stride
+// apart, from `qp` on (hnsw_build.hpp points it at the first; no header).
+template <class H, class = void>
+struct is_maxsim_q { static constexpr bool value = false; };
+template <class H>
+struct is_maxsim_q<H, decltype((void)H::MAXSIM_Q)> { static constexpr bool value = H::MAXSIM_Q; };
+template <class HI>
+struct HopMaxSimQ {
+    static constexpr int LPI = HI::LPI;
+    static constexpr bool INTERNAL_QOFF = false;
+    static constexpr bool INTERNAL_NORM = false;
+    static constexpr bool MULTI = false;
+    static constexpr bool MAXSIM_Q = true;
+    static __device__ __forceinline__ float score(const ScanArgs &a, const unsigned char *qp, uint32_t id, int sub) {
+        const uint32_t n_tokens = a.mv_q_tokens;
         const uint64_t b0 = a.mv_offsets[id], b1 = a.mv_offsets[id + 1];
         float sum = 0.0f;
         for (uint32_t t = 0; t < n_tokens; ++t) {
@@ -776,14 +810,20 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const ScanArgs a, const
     uint32_t *vlog = h.vis_log + (uint64_t)blockIdx.x * h.log_cap;
     for (uint32_t qi = blockIdx.x; qi < h.nq; qi += gridDim.x) {
         if constexpr (is_maxsim<H>::value) {
-            // (always staged in LDS: launch_hnsw_hop refuses a multi-query that does not fit)
+            // (the header always sits in LDS; the entries follow when the launch's budget holds them, else they are read where they lie)
             const uint32_t t0 = a.mv_qfirst[qi], n_tokens = a.mv_qfirst[qi + 1] - t0;
             const unsigned char *qg = reinterpret_cast<const unsigned char *>(a.queries) + (uint64_t)t0 * a.q_stride;
+            const bool fits = 16 + (uint64_t)n_tokens * a.q_stride <= h.lds_query_bytes;
             __syncthreads();
-            const uint4 *src = reinterpret_cast<const uint4 *>(qg);
-            uint4 *dst = reinterpret_cast<uint4 *>(q_lds + 16);
-            for (uint32_t i = (uint32_t)lane; i < n_tokens * (a.q_stride / 16); i += 64) dst[i] = src[i];
-            if (lane == 0) *reinterpret_cast<uint32_t *>(q_lds) = n_tokens;
+            if (fits) {
+                const uint4 *src = reinterpret_cast<const uint4 *>(qg);
+                uint4 *dst = reinterpret_cast<uint4 *>(q_lds + 16);
+                for (uint32_t i = (uint32_t)lane; i < n_tokens * (a.q_stride / 16); i += 64) dst[i] = src[i];
+            }
+            if (lane == 0) {
+                *reinterpret_cast<uint32_t *>(q_lds) = n_tokens;
+                *reinterpret_cast<const unsigned char **>(q_lds + 8) = fits ? q_lds + 16 : qg;
+            }
             __syncthreads();
             hnsw_search_one<H, E>(a, h, q_lds + 16, hop_ids, hop_scores, vis, vlog, qi, lane, beam_lds);
             continue;
@@ -804,6 +844,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const ScanArgs a, const
                     if (lane == 0) {
                         tab[e] = off + 16;
                         *reinterpret_cast<uint32_t *>(base + off) = nt;
+                        *reinterpret_cast<const unsigned char **>(base + off + 8) = base + off + 16;
                     }
                     const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(a.queries) + (uint64_t)t0 * a.q_stride);
                     uint4 *dst = reinterpret_cast<uint4 *>(base + off + 16);

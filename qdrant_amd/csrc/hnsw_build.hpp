@@ -42,6 +42,7 @@ __device__ __forceinline__ ScanArgs query_args(const ScanArgs &a, uint32_t qid) 
         b.u8_qnorm_f = a.row_norms_f[qid];
         b.u8_qnorm_i = a.row_norms_i[qid];
     }
+    if constexpr (is_maxsim_q<H>::value) b.mv_q_tokens = (uint32_t)(a.mv_offsets[qid + 1] - a.mv_offsets[qid]);      // the point's tokens among the batch's entries
     return b;
 }
 
@@ -131,6 +132,8 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(const ScanArgs a0
                 *reinterpret_cast<uint4 *>(q_lds + i) = *reinterpret_cast<const uint4 *>(src + i);
         } else if (h.batch_queries) {                       // a LUT (PQ): read through L2
             qp = h.batch_queries + (uint64_t)bi * h.batch_q_stride;
+            // multi-vector points: one entry per inner vector of the batch, point p's from its first inner row on
+            if constexpr (is_maxsim_q<H>::value) qp = h.batch_queries + (a0.mv_offsets[p] - a0.mv_offsets[h.first]) * h.batch_q_stride;
         } else {
             const unsigned char *src = rows + (uint64_t)p * a.row_stride;
             for (uint32_t i = (uint32_t)lane * 16; i < h.lds_query_bytes; i += 64 * 16) {

@@ -73,6 +73,7 @@ struct ScanArgs {
     // multi-vectors (MaxSim walk, hnsw.hpp HopMaxSim): point p = inner rows [mv_offsets[p], mv_offsets[p + 1]); multi-query j = query entries
     // [mv_qfirst[j], mv_qfirst[j + 1])
     const uint64_t *mv_offsets;
+    uint32_t mv_q_tokens;      // HopMaxSimQ (the build over multi-vector points with PQ / TurboQuant inner rows): query entries of the point being inserted
     const uint32_t *mv_qfirst;
     // custom queries as the walk's scorer (hnsw.hpp HopCustom): search qi = custom query cq_desc[qi] over the example entries of `queries`
     const qmx_custom_query *cq_desc;
@@ -182,6 +183,8 @@ int32_t launch_hnsw_custom_maxsim_sq(hipStream_t st, int distance, const ScanArg
 int32_t launch_hnsw_maxsim_dense(hipStream_t st, int dtype, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_maxsim_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_maxsim_bq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
+int32_t launch_hnsw_maxsim_pq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);      // (pq.hip; the query's tokens = their LUTs)
+int32_t launch_hnsw_maxsim_tq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);      // (hnsw_maxsim_tq.hip)
 int32_t launch_hnsw_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_pq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_bq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
@@ -241,6 +244,8 @@ int32_t launch_hnsw_build_tq(hipStream_t st, const ScanArgs &a, const HnswBuildA
 int32_t launch_hnsw_build_tq_l1(hipStream_t st, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu, uint32_t rot_dim,
                                 uint32_t padded_dim);      // ... over Manhattan (hnsw_build_tq_l1.hip)
 int32_t launch_hnsw_build_pq(hipStream_t st, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu);
+int32_t launch_hnsw_build_maxsim_pq(hipStream_t st, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu);   // multi-vector points over PQ inner rows
+int32_t launch_hnsw_build_maxsim_tq(hipStream_t st, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu);   // ... over TurboQuant inner rows (hnsw_build_multi_tq.hip)
 // pair[c][i][j] = DistanceType::distance(centroid i chunk c, centroid j chunk c): the per-chunk terms of score_internal (encoded_vectors_pq.rs:574-618)
 int32_t launch_pq_pair_table(hipStream_t st, uint32_t distance, uint32_t dim, const qmx_pq_params &pq, const float *d_centroids, float *d_pair);
 // norms[r] = sum of squares of u8 row r as the cosine leaf computes it for a stored row (metric_uint/avx2/cosine.rs, simple_cosine.rs)

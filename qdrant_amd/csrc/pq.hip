@@ -454,6 +454,10 @@ int32_t launch_hnsw_pq_direct(hipStream_t st, const ScanArgs &a, const HnswArgs 
     return launch_hnsw_hop<HopPQDirect<4, 4, 8>>(st, a, h, grid, per_cu);
 }
 
+// multi-vector points over PQ inner rows (QuantizedMultivectorStorage<EncodedVectorsPQ>): MaxSim over the LUTs of the query's inner vectors, staged in LDS
+int32_t launch_hnsw_maxsim_pq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
+    return launch_hnsw_hop<HopMaxSim<HopPQ>>(st, a, h, grid, per_cu);
+}
 // ... with a custom query as the scorer: every example's LUT stays in global memory (read through L2, like the plain PQ walk's large LUTs)
 int32_t launch_hnsw_custom_pq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
     return launch_hnsw_hop<HopCustom<HopPQ>>(st, a, h, grid, per_cu);
@@ -502,6 +506,13 @@ struct HopPQBuild : HopPQ {
 int32_t launch_hnsw_build_pq(hipStream_t st, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu) {
     QMX_REQUIRE(a.pq_pair && h.batch_queries, QMX_ERR_BAD_ARG, "PQ build needs the centroid pair table and the batch LUTs");
     return launch_hnsw_build_hop<HopPQBuild, HopPQInternal>(st, a, h, phase, grid, per_cu);
+}
+
+// ... over multi-vector points: the searches of an insertion through the LUTs of the new point's ORIGINAL inner vectors (HopMaxSimQ), stored <-> stored pairs
+// through score_internal_max_similarity over the pair table
+int32_t launch_hnsw_build_maxsim_pq(hipStream_t st, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu) {
+    QMX_REQUIRE(a.pq_pair && h.batch_queries && a.mv_offsets, QMX_ERR_BAD_ARG, "multi-vector PQ build needs the centroid pair table, the batch LUTs and the point offsets");
+    return launch_hnsw_build_hop<HopMaxSimQ<HopPQ>, HopMaxSimInternal<HopPQInternal>>(st, a, h, phase, grid, per_cu);
 }
 
 // pair[c][i][j]: grid (m, ncent), thread j

@@ -140,10 +140,12 @@ class GraphLayers:
 
     @classmethod
     def build_multi(cls, multi_storage, m: int = 16, m0: Optional[int] = None, ef_construct: int = 100, seed: int = 42,
-                    entry_points_num: int = 10, max_batch: int = 0):
+                    entry_points_num: int = 10, max_batch: int = 0, original=None):
         """`GraphLayersBuilder` over the POINTS of a MultiDenseVectorStorage / QuantizedMultivectorStorage on its GPU (qmx_multi_hnsw_build): every
         score of the build is MaxSim between two stored multi-vectors (`score_internal`, multi_metric_query_scorer.rs; quantized inner rows:
-        `score_internal_max_similarity`, quantized_multivector_storage/mod.rs:366-393)."""
+        `score_internal_max_similarity`, quantized_multivector_storage/mod.rs:366-393).  PQ inner rows cannot be turned back into queries: pass
+        `original` = the f32 VectorStorage of the inner rows they were encoded from (qmx_multi_hnsw_build_quantized; the searches of an insertion then
+        score through the LUTs of the point's original inner vectors, point_scorer.rs:183-218)."""
         self = cls.__new__(cls)
         self.m, self.m0 = int(m), int(2 * m if m0 is None else m0)
         p = F.HnswBuildParams()
@@ -154,8 +156,8 @@ class GraphLayers:
         words = None if deleted is None else np.packbits(np.asarray(deleted, dtype=bool), bitorder="little")
         if words is not None:
             words = np.ascontiguousarray(np.pad(words, (0, (-len(words)) % 8))).view(np.uint64)
-        F.check(F.lib().qmx_multi_hnsw_build(multi_storage.inner._h, F.ptr(multi_storage.offsets), multi_storage.count, F.ptr(words),
-                                             0 if deleted is None else len(deleted), C.byref(p), C.byref(self._h)))
+        F.check(F.lib().qmx_multi_hnsw_build_quantized(multi_storage.inner._h, None if original is None else original._h, F.ptr(multi_storage.offsets),
+                                                       multi_storage.count, F.ptr(words), 0 if deleted is None else len(deleted), C.byref(p), C.byref(self._h)))
         self.n_points = multi_storage.count
         self.counters = F.Counters()
         return self

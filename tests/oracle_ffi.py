@@ -713,10 +713,21 @@ def _hnsw_search_tq(self, flags_storage: DenseStorage, tq: "TqOracle", queries_p
 Hnsw.search_tq = _hnsw_search_tq
 
 
+class _TqQueryKeep:
+    """owns one qo_tq_query (freed with the Python object)"""
+    def __init__(self, e):
+        self.e = e
+
+    def __del__(self):
+        if self.e:
+            _lib.qo_tq_query_free(self.e)
+            self.e = None
+
+
 class MultiOracle:
     """Multi-vector points with MaxSim over an inner scorer (qo_scorer kind 4): `MultiMetricQueryScorer` over dense inner rows, or
     `QuantizedMultivectorStorage` over SQ / BQ / PQ inner rows.  inner = ("dense", DenseStorage) | ("sq", DenseStorage, SqOracle) |
-    ("bq", DenseStorage, BqOracle) | ("pq", DenseStorage, PqOracle) where the DenseStorage holds the PREPROCESSED inner rows (for the
+    ("bq", DenseStorage, BqOracle) | ("pq", DenseStorage, PqOracle) | ("tq", DenseStorage, TqOracle) where the DenseStorage holds the PREPROCESSED inner rows (for the
     quantized kinds only its row count and, for PQ builds, its rows matter).  offsets: [n_points + 1] ascending inner-row offsets."""
 
     def __init__(self, inner, offsets, point_deleted=None):
@@ -746,6 +757,11 @@ class MultiOracle:
             s.kind, s.st, s.bq_rows, s.bq_query = 3, C.pointer(st.st), bq.rows.ctypes.data, qb.ctypes.data
             s.bq_dim, s.bq_distance, s.bq_invert = bq.dim, bq.distance, bq.invert
             return s, qb
+        if self.kind == "tq":
+            tq = self.inner[2]
+            e = _lib.qo_tq_precompute_query(tq.h, _p(f32(qv)))
+            s.kind, s.st, s.tq, s.tq_rows, s.tq_query, s.tq_invert = 5, C.pointer(st.st), tq.h, tq.rows.ctypes.data, e, 1 if tq.invert else 0
+            return s, _TqQueryKeep(e)
         pq = self.inner[2]
         lut = pq.lut(f32(qv))
         s.kind, s.st, s.pq, s.pq_codes = 2, C.pointer(st.st), C.pointer(pq.pq), pq.codes.ctypes.data

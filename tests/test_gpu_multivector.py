@@ -120,7 +120,15 @@ def _multi_world(qa, kind, distance, dim, n_points, seed, max_len=9):
         opq.codes = opq.encode(inner)
         quant = qa.ProductQuantizer(dim, _dist(qa, distance), 8, cen)
         dev = qa.QuantizedMultivectorStorage(qa.EncodedVectorsPQ(quant.encode(inner), quant), offsets)
+        dev.original_inner = qa.VectorStorage(inner, _dist(qa, distance))      # what the codes were made from: the queries of a build's insertion searches
         orc = O.MultiOracle(("pq", ost, opq), offsets)
+    elif kind == "tq":
+        otq = O.TqOracle(distance, dim, O.TQ_BITS4)
+        otq.rows = otq.encode_rows(inner)
+        quant = qa.TurboQuantizer(dim, _dist(qa, distance), O.TQ_BITS4)
+        dev = qa.QuantizedMultivectorStorage(qa.EncodedVectorsTQ(otq.rows, quant), offsets)
+        dev.original_inner = qa.VectorStorage(inner, _dist(qa, distance))
+        orc = O.MultiOracle(("tq", ost, otq), offsets)
     else:
         raise ValueError(kind)
     queries = [(centers[rng.integers(24)] + rng.standard_normal((k, dim))).astype(np.float32) for k in (1, 3, 8, 17, 5, 2)]
@@ -145,7 +153,7 @@ def test_quantized_multivector_maxsim_bit_exact(qa, kind, distance, dim):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,distance,dim", [("dense", O.DOT, 128), ("dense", O.COSINE, 96), ("dense", O.EUCLID, 16), ("sq", O.DOT, 128),
-                                                 ("sq", O.COSINE, 64), ("bq", O.DOT, 128)])
+                                                 ("sq", O.COSINE, 64), ("bq", O.DOT, 128), ("pq", O.DOT, 64), ("pq", O.EUCLID, 128), ("tq", O.DOT, 64), ("tq", O.EUCLID, 96)])
 def test_multivector_hnsw_walk_equals_the_oracle(qa, kind, distance, dim):
     """GraphLayers::search over multi-vector points: graph built by the oracle's GraphLayersBuilder through score_internal_max_similarity,
     walked on the device with the MaxSim hop scorer: ids, score bits and the number of scored points equal the oracle's walk."""
@@ -191,23 +199,26 @@ def _same_graph(seq, ref):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,distance,dim", [("dense", O.DOT, 64), ("dense", O.COSINE, 48), ("dense", O.EUCLID, 20), ("dense", O.MANHATTAN, 33),
-                                                 ("sq", O.COSINE, 64), ("sq", O.DOT, 128)])
+                                                 ("sq", O.COSINE, 64), ("sq", O.DOT, 128), ("pq", O.DOT, 64), ("pq", O.COSINE, 96), ("pq", O.EUCLID, 64), ("tq", O.DOT, 64), ("tq", O.EUCLID, 96)])
 def test_multivector_build_one_point_per_launch_is_the_sequential_graph(qa, kind, distance, dim):
     """The device build over multi-vector POINTS (hnsw/build.rs:334-341 through score_internal / score_internal_max_similarity): inserted one point
     per launch it is the oracle's sequential GraphLayersBuilder link for link - MaxSim is not symmetric, so this also pins which of the two points
     is the query in the insertion searches, in the heuristic and in the back links.  Then with deleted points.  (SQ Euclid rows are not a case:
     their scores are alpha^2 x an integer and tie - 3 of 696 lists came out with two equal-score neighbours swapped, the heap order DESIGN 4 leaves
-    unpinned.)"""
+    unpinned.)  PQ inner rows (round 4): no stored row is a query (`encode_internal_vector` -> None for the whole multi-vector,
+    quantized_multivector_storage/mod.rs:458-470), so the insertion searches score through the LUTs of the point's ORIGINAL inner vectors and only stored
+    <-> stored pairs through score_internal_max_similarity - on both sides (qmx_multi_hnsw_build_quantized; the oracle's link_new_point)."""
     n_points, m, efc, seed = 500, 8, 32, 17
     rng, offsets, dev, orc, queries = _multi_world(qa, kind, distance, dim, n_points, seed=dim + 7 * distance)
-    seq = qa.GraphLayers.build_multi(dev, m=m, ef_construct=efc, seed=seed, entry_points_num=4, max_batch=1).export_plain()
+    original = getattr(dev, "original_inner", None)
+    seq = qa.GraphLayers.build_multi(dev, m=m, ef_construct=efc, seed=seed, entry_points_num=4, max_batch=1, original=original).export_plain()
     ref = orc.build(m=m, ef_construct=efc, seed=seed, entry_points_num=4).export_plain()
     _same_graph(seq, ref)
     deleted = rng.random(n_points) < 0.2
     deleted[0] = True                                   # the first live point is not point 0
     dev.set_deleted(deleted)
     orc_del = O.MultiOracle(orc.inner, offsets, point_deleted=deleted)
-    seq = qa.GraphLayers.build_multi(dev, m=m, ef_construct=efc, seed=seed, entry_points_num=4, max_batch=1).export_plain()
+    seq = qa.GraphLayers.build_multi(dev, m=m, ef_construct=efc, seed=seed, entry_points_num=4, max_batch=1, original=original).export_plain()
     ref = orc_del.build(m=m, ef_construct=efc, seed=seed, entry_points_num=4).export_plain()
     _same_graph(seq, ref)
     for p in np.flatnonzero(deleted):                   # deleted points have no links and nobody links to them
@@ -216,13 +227,13 @@ def test_multivector_build_one_point_per_launch_is_the_sequential_graph(qa, kind
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,distance,dim", [("dense", O.DOT, 64), ("dense", O.COSINE, 128), ("sq", O.DOT, 128), ("bq", O.COSINE, 256)])
+@pytest.mark.parametrize("kind,distance,dim", [("dense", O.DOT, 64), ("dense", O.COSINE, 128), ("sq", O.DOT, 128), ("bq", O.COSINE, 256), ("pq", O.DOT, 64), ("tq", O.COSINE, 64)])
 def test_multivector_batched_build_searches_like_the_oracle_built_graph(qa, kind, distance, dim):
     """Batched (the default): structural invariants of the graph, the oracle's walk of the device-built graph == the device's walk of it (ids and
     score bits; BQ: true pairs), and recall against the brute-force MaxSim top-10 within 0.05 of the oracle-built graph's."""
     n_points, m, efc, seed = 2500, 8, 48, 23
     rng, offsets, dev, orc, queries = _multi_world(qa, kind, distance, dim, n_points, seed=3 * dim + distance)
-    graph = qa.GraphLayers.build_multi(dev, m=m, ef_construct=efc, seed=seed)
+    graph = qa.GraphLayers.build_multi(dev, m=m, ef_construct=efc, seed=seed, original=getattr(dev, "original_inner", None))
     plain = graph.export_plain()
     assert len(plain.reindex) == n_points
     deg0 = np.diff(plain.offsets[:n_points + 1].astype(np.int64))
@@ -269,9 +280,12 @@ def test_multivector_hnsw_argument_errors(qa):
     graph = qa.GraphLayers.from_plain(orc.build(m=4, ef_construct=16).export_plain())
     with pytest.raises(qa.QmxError):                 # ef beyond the LDS beam
         dev.search_hnsw(graph, queries, 5, 5000)
-    big = [rng.standard_normal((700, 64)).astype(np.float32)]     # 700 x (256 + 64) bytes > 150 KiB of LDS
-    with pytest.raises(qa.QmxError):
-        dev.search_hnsw(graph, big, 5, 16)
+    # 700 x (256 + 64) bytes: more than a search's share of the LDS - the inner query vectors are then read where they lie (same walk)
+    big = [(rng.standard_normal((700, 64))).astype(np.float32)]
+    g_o = orc.build(m=4, ef_construct=16)
+    want, _ = orc.search(g_o, [O.preprocess(O.DOT, big[0])], 5, 16)
+    got = dev.search_hnsw(graph, big, 5, 16)
+    assert got[0]["idx"].tolist() == want[0]["idx"].tolist() and np.array_equal(_bits(got[0]["score"]), _bits(want[0]["score"]))
 
 
 def test_oracle_multi_scorer_equals_the_table_form():
