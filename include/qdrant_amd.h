@@ -818,14 +818,15 @@ QMX_API int32_t qmx_sharded_hnsw_build(const qmx_segment *const *segments, const
 /* The HNSW build over multi-vector points (hnsw/build.rs:334-341 through `FilteredScorer::new_internal`, point_scorer.rs:183-218: every score of
  * the build is `MultiMetricQueryScorer::score_internal`, multi_metric_query_scorer.rs, or for quantized inner rows `score_internal_max_similarity`,
  * quantized_multivector_storage/mod.rs:366-393): as qmx_hnsw_build, with point p = inner rows [point_offsets[p], point_offsets[p + 1]) of `inner`
- * (f32, f16, SQ or BQ rows; PQ rows: qmx_multi_hnsw_build_quantized below; anything else: QMX_ERR_NOT_SUPPORTED) and the deleted flags per POINT (host arrays, as in qmx_multi_hnsw_search; the
+ * (f32, f16, SQ or BQ rows; PQ and TurboQuant rows: qmx_multi_hnsw_build_quantized below) and the deleted flags per POINT (host arrays, as in qmx_multi_hnsw_search; the
  * inner segment's own flags are not read).  The graph has n_points points; search it with qmx_multi_hnsw_search. */
 QMX_API int32_t qmx_multi_hnsw_build(const qmx_segment *inner, const uint64_t *point_offsets, uint32_t n_points, const uint64_t *point_deleted,
                                      uint64_t n_deleted_bits, const qmx_hnsw_build_params *params, qmx_hnsw **out);
-/* The same over inner rows that cannot be turned back into queries - PQ (`QuantizedMultivectorStorage::encode_internal_vector`, quantized_multivector_storage/
- * mod.rs:458-470, is None as soon as one inner row's is: encoded_vectors_pq.rs:624).  As qmx_hnsw_build_quantized does for single vectors, the searches of
- * an insertion then score through the query scorer of the point's ORIGINAL multi-vector (point_scorer.rs:183-218: MaxSim over the LUTs of its inner
- * vectors) and only stored <-> stored pairs through score_internal_max_similarity: `original_inner` = the f32 segment the inner rows were encoded from
+/* The same over inner rows that cannot be turned back into queries - PQ and TurboQuant (`QuantizedMultivectorStorage::encode_internal_vector`,
+ * quantized_multivector_storage/mod.rs:458-470, is None as soon as one inner row's is: encoded_vectors_pq.rs:624, encoded_vectors_tq.rs:453; TurboQuant
+ * over Manhattan: QMX_ERR_NOT_SUPPORTED).  As qmx_hnsw_build_quantized does for single vectors, the searches of
+ * an insertion then score through the query scorer of the point's ORIGINAL multi-vector (point_scorer.rs:183-218: MaxSim over the LUTs / precomputed queries
+ * of its inner vectors) and only stored <-> stored pairs through score_internal_max_similarity: `original_inner` = the f32 segment the inner rows were encoded from
  * (same dim, same device, at least as many rows).  Inner rows that are their own queries (f32, f16, SQ, BQ): `original_inner` may be NULL and the call is
  * qmx_multi_hnsw_build. */
 QMX_API int32_t qmx_multi_hnsw_build_quantized(const qmx_segment *inner, const qmx_segment *original_inner, const uint64_t *point_offsets, uint32_t n_points,

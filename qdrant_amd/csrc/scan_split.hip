@@ -1472,6 +1472,185 @@ __global__ __launch_bounds__(SP3_THREADS, 1) void scan_i8copy_kernel(const ScanA
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // nothing may land in LDS after the block is gone
 }
 
+// The same scan with a DEEPER copy pipeline (round 4) - an experiment that answered its question with "no"; opt-in (`i8_scan_deep`), exact, tested.
+// The kernel above tops out at 0.76 of HBM whatever the number of queries (one query: 0.765).  Hypothesis: with three 32 KiB row stages in LDS - one being
+// multiplied, one landed, one on its way - a CU has 32 - 64 KiB of rows in flight, 256 CUs x 48 KiB is what the memory system returns in ~2 us at 6 TB/s,
+// so the stream is bound by its own depth.  LDS is full (96 + 64 KiB), so more depth has to come from granularity: HALF stages - one 64-coordinate plane,
+// 16 KiB of rows, 8 KiB of queries, 16 matrix instructions per wave - in rings of 7 and 6 slots (112 + 48 KiB).  The vector-memory counter retires in
+// order, so what must have landed at the end of half stage g (queries and rows of g + 1) bounds what may still be in flight to what was issued after it:
+// with the issue order r0 | q0 r1 | q1 r2 | ... and half stage g issuing [queries g + 5, rows g + 6], `vmcnt(14)` leaves rows g + 2 .. g + 6
+// outstanding: 80 KiB per CU.  Same operands, same integer sums, same epilogue, same blocks of the copy in HBM (a plane = sixteen alternate 1 KiB runs).
+// Measured (C2, 128 queries, one batch in flight): 0.749 ms per launch against 0.654 - 14 % SLOWER with 2.5 x the bytes in flight: depth was not the limit;
+// what the change doubled is the number of block-wide barriers (12 per tile instead of 6), and that is what it paid for - the stage hand-over (every
+// wave's `vmcnt` wait, the barrier, eight waves' operand reads at once) is the cost to attack next, not the ring (profiles/r4_i8_deep_ring.md).
+constexpr int SP5_ARING = 7;                                                       // half-stage slots of rows (16 KiB) ...
+constexpr int SP5_BRING = 6;                                                       // ... and of queries (8 KiB)
+constexpr int SP5_A_UNITS = SP3_A_UNITS / 2, SP5_B_UNITS = SP_B_UNITS / 2;
+constexpr int SP5_LDS = (SP5_ARING * SP5_A_UNITS + SP5_BRING * SP5_B_UNITS) * 16;  // 112 + 48 = 160 KiB
+static_assert(SP5_LDS <= 160 * 1024, "the CU's LDS");
+__global__ __launch_bounds__(SP3_THREADS, 1) void scan_i8copy_deep_kernel(const ScanArgs a, const SplitArgs s) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint4 *lds = reinterpret_cast<uint4 *>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint64_t all_tiles = (a.n_cand + SP3_BM - 1) / SP3_BM;
+    const uint64_t n_tiles = split_phase_tiles(all_tiles, s.phase);
+    const uint32_t nch = s.nchunks;
+    const uint64_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const uint32_t phase = s.phase;
+    auto tile_of = [&](uint64_t j) -> uint64_t { return phase == 0 ? j : phase == 1 ? j * SP_PHASE_STRIDE : j + j / (SP_PHASE_STRIDE - 1) + 1; };
+    if (my_tiles == 0) {
+        if (lane == 0) s.wcnt[blockIdx.x * (SP3_THREADS / 64) + (uint32_t)w] = 0;
+        return;
+    }
+    const uint32_t wm = (uint32_t)w & 3u, wn = (uint32_t)w >> 2;
+    const uint32_t kq_r = (uint32_t)lane >> 4, m_r = (uint32_t)lane & 15u;
+    // unit of (16-row / 16-query tile t, k-group kq, row m) inside a half-stage slot: sp_unit without the plane
+    const uint32_t a_rd = (wm * 4 * 4 + kq_r) * 16 + (m_r ^ (2 * kq_r)), b_rd = (wn * 4 * 4 + kq_r) * 16 + (m_r ^ (2 * kq_r));
+    float thr[4], qs[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        thr[nt] = s.thr[wn * 64 + nt * 16 + m_r];
+        qs[nt] = s.scales[wn * 64 + nt * 16 + m_r];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // from here on the kernel counts its vector-memory traffic itself
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(sp_lds_byte *)smem_raw;
+    const uint32_t lane_off = (uint32_t)lane * 16u;
+    uint4 *b_lds = lds + SP5_ARING * SP5_A_UNITS;
+    // the copy streams: positions (tile iteration, chunk, plane) of the next half stage to request, its slot; three 1 KiB copies per wave and half stage
+    uint64_t ra_it = 0;
+    uint32_t ra_kc = 0, ra_hl = 0, ra_slot = 0, rb_kc = 0, rb_hl = 0, rb_slot = 0;
+    auto uniform_ptr = [&](uint64_t v) {
+        return reinterpret_cast<const unsigned char *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
+                                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v));
+    };
+    const unsigned char *ra_src = nullptr, *rb_src = nullptr;
+    uint32_t ra_dst = 0, rb_dst = 0;
+    // wave w copies the plane's runs of row groups 2 w and 2 w + 1 (a 32 KiB block = [16 row groups][2 planes][1 KiB]) to runs 2 w, 2 w + 1 of the slot ...
+    auto rows_begin = [&]() {
+        const uint64_t tile = tile_of(blockIdx.x + ra_it * gridDim.x);
+        ra_src = uniform_ptr((uint64_t)(uintptr_t)(s.rows_split + (tile * nch + ra_kc) * SP3_A_UNITS) + (uint32_t)w * 4096u + ra_hl * 1024u);
+        ra_dst = lds0 + (ra_slot * SP5_A_UNITS) * 16u + (uint32_t)w * 2048u;
+        ra_slot = ra_slot + 1 == SP5_ARING ? 0 : ra_slot + 1;
+        if (ra_hl == 0) ra_hl = 1;      // (past the block's last half stage: the last one again - valid addresses, a slot nobody reads any more)
+        else if (ra_kc + 1 < nch) { ra_hl = 0; ++ra_kc; }
+        else if (ra_it + 1 < my_tiles) { ra_hl = 0; ra_kc = 0; ++ra_it; }
+    };
+    auto rows_piece = [&](int i) { sp_glds16(ra_src + i * 2048, lane_off, ra_dst + i * 1024); };
+    // ... and the plane's run of query group w (a 16 KiB chunk = [8 query groups][2 planes][1 KiB]) to run w
+    auto queries_begin = [&]() {
+        rb_src = uniform_ptr((uint64_t)(uintptr_t)(s.bq + (uint64_t)rb_kc * SP_B_UNITS) + (uint32_t)w * 2048u + rb_hl * 1024u);
+        rb_dst = lds0 + (SP5_ARING * SP5_A_UNITS + rb_slot * SP5_B_UNITS) * 16u + (uint32_t)w * 1024u;
+        rb_slot = rb_slot + 1 == SP5_BRING ? 0 : rb_slot + 1;
+        if (rb_hl == 0) rb_hl = 1;
+        else { rb_hl = 0; rb_kc = rb_kc + 1 == nch ? 0 : rb_kc + 1; }
+    };
+    auto queries_piece = [&]() { sp_glds16(rb_src, lane_off, rb_dst); };
+    auto request_rows = [&]() {
+        rows_begin();
+        rows_piece(0);
+        rows_piece(1);
+    };
+    auto request_queries = [&]() {
+        queries_begin();
+        queries_piece();
+    };
+    request_rows();                                       // r0 | q0 r1 | q1 r2 | q2 r3 | q3 r4 | q4 r5
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        request_queries();
+        request_rows();
+    }
+    asm volatile("s_waitcnt vmcnt(14)" ::: "memory");     // everything up to q0 has landed: rows and queries of half stage 0
+    sp_stage_barrier();
+    uint32_t slot = 0, bslot = 0;
+    i32x4s acc[4][4];
+    uint4 *const wl = s.wlist + (uint64_t)(blockIdx.x * (SP3_THREADS / 64) + (uint32_t)w) * s.wcap;
+    uint32_t wcount = 0;
+    // The epilogue of a tile.  With a band of 0.7 standard deviations a wave meets ~2 candidates per tile (the f16 passes: 0.4), so nearly every tile
+    // has one somewhere: the search for them narrows by wave-uniform steps - the query tile (16 queries x the wave's 64 rows), then the 16-row tile, then
+    // the four rows of a lane - instead of testing all 256 accumulators of a lane one ballot at a time (14 % of the kernel at 128 queries, measured
+    // against the same launch with one live query).
+    auto epilogue = [&](uint64_t tile) {
+        const uint32_t row0 = (uint32_t)(tile * SP3_BM) + wm * 64 + 4 * kq_r;
+        const uint32_t n_rows32 = (uint32_t)a.n_cand;
+        bool hit[4];
+        bool maybe = false;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            int mx = acc[0][nt][0];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mx = acc[mt][nt][j] > mx ? acc[mt][nt][j] : mx;
+            hit[nt] = !((float)mx < thr[nt]);
+            maybe = maybe || hit[nt];
+        }
+        if (!__ballot(maybe)) return;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            if (!__ballot(hit[nt])) continue;
+            const uint32_t q = wn * 64 + (uint32_t)nt * 16 + m_r;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                int m4 = acc[mt][nt][0];
+#pragma unroll
+                for (int j = 1; j < 4; ++j) m4 = acc[mt][nt][j] > m4 ? acc[mt][nt][j] : m4;
+                if (!__ballot(!((float)m4 < thr[nt]))) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = (float)acc[mt][nt][j];
+                    const uint32_t row = row0 + (uint32_t)mt * 16 + (uint32_t)j;
+                    const bool c = !(v < thr[nt]) && row < n_rows32 && q < s.nq;
+                    const uint64_t hits = __ballot(c);
+                    if (hits) {
+                        const uint32_t at = wcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u));
+                        if (c && at < s.wcap) {
+                            const uint64_t key = make_key(v * qs[nt], row);
+                            wl[at] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), q, 0u);
+                        }
+                        wcount += (uint32_t)__builtin_popcountll(hits);
+                    }
+                }
+            }
+        }
+    };
+    for (uint64_t it = 0; it < my_tiles; ++it) {
+        if (it) epilogue(tile_of(blockIdx.x + (it - 1) * gridDim.x));
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (i32x4s){0, 0, 0, 0};
+        for (uint32_t hs = 0; hs < 2 * nch; ++hs) {
+            queries_begin();                              // half stage g + 5 -> the slot half stage g - 1 was read from (everybody is past that barrier)
+            rows_begin();                                 // half stage g + 6 -> likewise
+            const uint4 *ab = lds + slot * SP5_A_UNITS + a_rd;
+            const uint4 *bb = b_lds + bslot * SP5_B_UNITS + b_rd;
+            i32x4s b0[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) b0[nt] = *reinterpret_cast<const i32x4s *>(bb + nt * 64);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const i32x4s a0 = *reinterpret_cast<const i32x4s *>(ab + mt * 64);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0[nt], acc[mt][nt], 0, 0, 0);
+                // the half stage's three copy requests, in the order the wait below relies on (queries first), spread over the matrix work
+                if (mt == 0) queries_piece();
+                if (mt == 1) rows_piece(0);
+                if (mt == 2) rows_piece(1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            slot = slot + 1 == SP5_ARING ? 0 : slot + 1;
+            bslot = bslot + 1 == SP5_BRING ? 0 : bslot + 1;
+            asm volatile("s_waitcnt vmcnt(14)" ::: "memory");    // rows and queries of half stage g + 1 have landed; rows g + 2 .. g + 6 may still be on their way
+            sp_stage_barrier();
+        }
+    }
+    epilogue(tile_of(blockIdx.x + (my_tiles - 1) * gridDim.x));
+    if (lane == 0) s.wcnt[blockIdx.x * (SP3_THREADS / 64) + (uint32_t)w] = wcount;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // nothing may land in LDS after the block is gone
+}
+
 // ---- after a launch: the k best candidates (by approximate score) of every query, for an exact look.  k of them are enough: approximate and exact
 // scores differ by a hundredth of the band in practice, so the worst exact score among the k best approximate ones is the k-th best exact score so far
 // or next to it - and finding k keys is what the bound-and-rank selection is quick at (the 64 best of ~5 000 took 100 - 190 us, these take ~15) ----
@@ -1788,10 +1967,12 @@ int32_t launch_split_i8_pack(hipStream_t st, const float *d_q, uint32_t nq, uint
 }
 int32_t launch_scan_i8copy(hipStream_t st, const ScanArgs &a, const void *d_bq, const float *d_qscale, const float *d_thr, int num_cus, const void *d_rows_i8,
                            void *d_wlists, uint32_t phase) {
-    auto kfn = scan_i8copy_kernel;
+    const bool deep = option(OPT_I8_SCAN_DEEP) > 0;      // the half-stage pipeline (scan_i8copy_deep_kernel): measured slower, opt-in
+    auto kfn = deep ? scan_i8copy_deep_kernel : scan_i8copy_kernel;
     static thread_local DeviceOnce attr_once;
     if (attr_once.need()) {
-        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SP3_LDS));
+        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_i8copy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SP3_LDS));
+        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_i8copy_deep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SP5_LDS));
         attr_once.mark();
     }
     QMX_REQUIRE(d_rows_i8 && d_wlists && split_i8_dim_ok(a.dim), QMX_ERR_BAD_ARG, "the int8 scan reads the int8 copy and writes per-wave candidate lists");
