@@ -1651,6 +1651,155 @@ __global__ __launch_bounds__(SP3_THREADS, 1) void scan_i8copy_deep_kernel(const 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // nothing may land in LDS after the block is gone
 }
 
+// The same scan with NO stage hand-over (round 4, after scan_i8copy_deep_kernel's answer): every wave owns 32 rows of the 256-row tile - the 4 KiB it has always
+// copied per 32 KiB block - and multiplies them with all 128 queries itself (2 x 8 tiles of 16 x 16 instead of 4 x 4: the same 64 accumulator registers,
+// the same 32 matrix instructions per 128 coordinates), so nobody waits for anybody: the queries' images are copied into LDS ONCE per block (nch x 16 KiB:
+// 96 KiB at d = 768, the reason this shape stops there), each wave streams its rows through a private ring of four 2 KiB slots (32 rows x 64 coordinates: one
+// being multiplied, three on their way) behind its own `vmcnt`, and the only barrier of the kernel follows the queries' copy.  Same copy of the block in HBM,
+// same integer sums, same candidates (per-wave lists as before: a wave's rows are now 32 consecutive ones).  Operand reads from LDS: 2 + 8 per half chunk
+// instead of 4 + 4 per wave (the queries' side is shared by all eight waves now): 5 x the streamed bytes instead of 4 x.
+// Measured (C2, 128 queries): 0.683 ms per launch against 0.647 - 5 % SLOWER (opt-in, `i8_scan_deep` = 2; a third shape, the rows loaded straight into the operand
+// registers with 80 KiB per CU in flight and no LDS for them at all, reached 0.678): neither the barriers nor the ring depth are what holds this scan at 0.75.
+constexpr int SP6_SLOTS = 4;                                                       // half-chunk slots of a wave's rows
+constexpr int SP6_WAVE_BYTES = SP6_SLOTS * 2048;
+__host__ __device__ static inline size_t sp6_lds_bytes(uint32_t nch) { return (size_t)nch * SP_B_UNITS * 16 + (size_t)(SP3_THREADS / 64) * SP6_WAVE_BYTES; }
+__global__ __launch_bounds__(SP3_THREADS, 1) void scan_i8copy_kernel_wo(const ScanArgs a, const SplitArgs s) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint4 *lds = reinterpret_cast<uint4 *>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint64_t all_tiles = (a.n_cand + SP3_BM - 1) / SP3_BM;
+    const uint64_t n_tiles = split_phase_tiles(all_tiles, s.phase);
+    const uint32_t nch = s.nchunks;
+    const uint64_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const uint32_t phase = s.phase;
+    auto tile_of = [&](uint64_t j) -> uint64_t { return phase == 0 ? j : phase == 1 ? j * SP_PHASE_STRIDE : j + j / (SP_PHASE_STRIDE - 1) + 1; };
+    if (my_tiles == 0) {
+        if (lane == 0) s.wcnt[blockIdx.x * (SP3_THREADS / 64) + (uint32_t)w] = 0;
+        return;
+    }
+    const uint32_t kq_r = (uint32_t)lane >> 4, m_r = (uint32_t)lane & 15u;
+    const uint32_t b_rd = sp_unit(0, 0, kq_r, m_r);                               // + 128 units per query tile, + 64 for the second plane, + SP_B_UNITS per chunk
+    const uint32_t a_rd = kq_r * 16 + (m_r ^ (2 * kq_r));                        // inside a 1 KiB run of a slot (+ 64 units for the wave's second row group)
+    float thr[8], qs[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+        thr[nt] = s.thr[nt * 16 + m_r];
+        qs[nt] = s.scales[nt * 16 + m_r];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // from here on the kernel counts its vector-memory traffic itself
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(sp_lds_byte *)smem_raw;
+    const uint32_t lane_off = (uint32_t)lane * 16u;
+    auto uniform_ptr = [&](uint64_t v) {
+        return reinterpret_cast<const unsigned char *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
+                                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v));
+    };
+    // the queries, once: nch x 16 KiB = 16 nch copies of 1 KiB, wave w takes every eighth
+    {
+        const unsigned char *src = uniform_ptr((uint64_t)(uintptr_t)s.bq);
+        for (uint32_t p = (uint32_t)w; p < 16u * nch; p += SP3_THREADS / 64) sp_glds16(src + (size_t)p * 1024, lane_off, lds0 + p * 1024u);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sp_stage_barrier();
+    }
+    const uint4 *const b_lds = lds;
+    const uint32_t ring0 = lds0 + nch * (uint32_t)(SP_B_UNITS * 16) + (uint32_t)w * (uint32_t)SP6_WAVE_BYTES;
+    const uint4 *const ring = lds + (size_t)nch * SP_B_UNITS + (size_t)w * (SP6_WAVE_BYTES / 16);
+    // the wave's row stream: half chunk (tile iteration, chunk, plane) -> the plane's 1 KiB runs of its two row groups (2 w, 2 w + 1 of the block's sixteen)
+    uint64_t r_it = 0;
+    uint32_t r_kc = 0, r_hl = 0, r_slot = 0;
+    auto request = [&]() {
+        const uint64_t tile = tile_of(blockIdx.x + r_it * gridDim.x);
+        const unsigned char *src = uniform_ptr((uint64_t)(uintptr_t)(s.rows_split + (tile * nch + r_kc) * SP3_A_UNITS) + (uint32_t)w * 4096u + r_hl * 1024u);
+        const uint32_t dst = ring0 + r_slot * 2048u;
+        sp_glds16(src, lane_off, dst);
+        sp_glds16(src + 2048, lane_off, dst + 1024u);
+        r_slot = (r_slot + 1) & (SP6_SLOTS - 1);
+        if (r_hl == 0) r_hl = 1;      // (past the wave's last half chunk: the last one again - valid addresses, a slot it never reads)
+        else if (r_kc + 1 < nch) { r_hl = 0; ++r_kc; }
+        else if (r_it + 1 < my_tiles) { r_hl = 0; r_kc = 0; ++r_it; }
+    };
+    request();
+    request();
+    request();
+    uint32_t slot = 0;
+    i32x4s acc[2][8];
+    uint4 *const wl = s.wlist + (uint64_t)(blockIdx.x * (SP3_THREADS / 64) + (uint32_t)w) * s.wcap;
+    uint32_t wcount = 0;
+    // the epilogue of a tile (scan_i8copy_kernel's narrowing search over the wave's 32 rows x 128 queries)
+    auto epilogue = [&](uint64_t tile) {
+        const uint32_t row0 = (uint32_t)(tile * SP3_BM) + (uint32_t)w * 32 + 4 * kq_r;
+        const uint32_t n_rows32 = (uint32_t)a.n_cand;
+        bool hit[8];
+        bool maybe = false;
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) {
+            int mx = acc[0][nt][0];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mx = acc[mt][nt][j] > mx ? acc[mt][nt][j] : mx;
+            hit[nt] = !((float)mx < thr[nt]);
+            maybe = maybe || hit[nt];
+        }
+        if (!__ballot(maybe)) return;
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) {
+            if (!__ballot(hit[nt])) continue;
+            const uint32_t q = (uint32_t)nt * 16 + m_r;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                int m4 = acc[mt][nt][0];
+#pragma unroll
+                for (int j = 1; j < 4; ++j) m4 = acc[mt][nt][j] > m4 ? acc[mt][nt][j] : m4;
+                if (!__ballot(!((float)m4 < thr[nt]))) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = (float)acc[mt][nt][j];
+                    const uint32_t row = row0 + (uint32_t)mt * 16 + (uint32_t)j;
+                    const bool c = !(v < thr[nt]) && row < n_rows32 && q < s.nq;
+                    const uint64_t hits = __ballot(c);
+                    if (hits) {
+                        const uint32_t at = wcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u));
+                        if (c && at < s.wcap) {
+                            const uint64_t key = make_key(v * qs[nt], row);
+                            wl[at] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), q, 0u);
+                        }
+                        wcount += (uint32_t)__builtin_popcountll(hits);
+                    }
+                }
+            }
+        }
+    };
+    for (uint64_t it = 0; it < my_tiles; ++it) {
+        if (it) epilogue(tile_of(blockIdx.x + (it - 1) * gridDim.x));
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) acc[mt][nt] = (i32x4s){0, 0, 0, 0};
+        for (uint32_t hs = 0; hs < 2 * nch; ++hs) {
+            // half chunk g + 3 -> the slot g - 1 was read from (its operands are in registers and used: the matrix instructions of g - 1 have been issued)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            request();
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // the rows of half chunk g have landed; g + 1 .. g + 3 may be on their way
+            const uint4 *ab = ring + slot * 128 + a_rd;
+            const uint4 *bb = b_lds + (size_t)(hs >> 1) * SP_B_UNITS + (hs & 1u) * 64 + b_rd;
+            const i32x4s a0 = *reinterpret_cast<const i32x4s *>(ab);
+            const i32x4s a1 = *reinterpret_cast<const i32x4s *>(ab + 64);
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+                const i32x4s b = *reinterpret_cast<const i32x4s *>(bb + nt * 128);
+                acc[0][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b, acc[0][nt], 0, 0, 0);
+                acc[1][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b, acc[1][nt], 0, 0, 0);
+            }
+            slot = (slot + 1) & (SP6_SLOTS - 1);
+        }
+    }
+    epilogue(tile_of(blockIdx.x + (my_tiles - 1) * gridDim.x));
+    if (lane == 0) s.wcnt[blockIdx.x * (SP3_THREADS / 64) + (uint32_t)w] = wcount;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // nothing may land in LDS after the wave is gone
+    __syncthreads();                                             // ... nor while another wave of the block still reads its ring (the block's LDS goes with its last wave)
+}
+
 // ---- after a launch: the k best candidates (by approximate score) of every query, for an exact look.  k of them are enough: approximate and exact
 // scores differ by a hundredth of the band in practice, so the worst exact score among the k best approximate ones is the k-th best exact score so far
 // or next to it - and finding k keys is what the bound-and-rank selection is quick at (the 64 best of ~5 000 took 100 - 190 us, these take ~15) ----
@@ -1967,10 +2116,14 @@ int32_t launch_split_i8_pack(hipStream_t st, const float *d_q, uint32_t nq, uint
 }
 int32_t launch_scan_i8copy(hipStream_t st, const ScanArgs &a, const void *d_bq, const float *d_qscale, const float *d_thr, int num_cus, const void *d_rows_i8,
                            void *d_wlists, uint32_t phase) {
-    const bool deep = option(OPT_I8_SCAN_DEEP) > 0;      // the half-stage pipeline (scan_i8copy_deep_kernel): measured slower, opt-in
-    auto kfn = deep ? scan_i8copy_deep_kernel : scan_i8copy_kernel;
+    // option i8_scan_deep: 1 = the half-stage pipeline (scan_i8copy_deep_kernel), 2 = wave-owned rows without stage hand-overs (scan_i8copy_kernel_wo; rows of
+    // up to 768 floats: the queries stay in LDS) - both exact, both measured slower (profiles/r4_i8_deep_ring.md) -, else the three-stage kernel
+    const int64_t shape = option(OPT_I8_SCAN_DEEP);
+    const bool wo = shape == 2 && sp6_lds_bytes(a.dim / 128) <= 160 * 1024;
+    auto kfn = wo ? scan_i8copy_kernel_wo : shape == 1 ? scan_i8copy_deep_kernel : scan_i8copy_kernel;
     static thread_local DeviceOnce attr_once;
     if (attr_once.need()) {
+        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_i8copy_kernel_wo), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_i8copy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SP3_LDS));
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_i8copy_deep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SP5_LDS));
         attr_once.mark();
@@ -1996,7 +2149,7 @@ int32_t launch_scan_i8copy(hipStream_t st, const ScanArgs &a, const void *d_bq, 
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, (uint64_t)num_cus));
     ::qmx::clear_stale_error();
     QMX_NOTE_KERNEL(kfn);
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(SP3_THREADS), (size_t)SP3_LDS, st, a, s);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(SP3_THREADS), wo ? sp6_lds_bytes(a.dim / 128) : (size_t)SP3_LDS, st, a, s);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }
