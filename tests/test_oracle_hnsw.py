@@ -247,3 +247,39 @@ def test_every_point_has_an_inbound_link(threads):
     for p in range(n):
         inbound[np.asarray(graph.links(p, 0), dtype=np.int64)] += 1
     assert (inbound > 0).all(), np.flatnonzero(inbound == 0)[:10]
+
+
+@pytest.mark.parametrize("kind", ["pq", "tq"])
+def test_multivector_build_over_rows_that_are_not_queries_falls_back_like_the_single_vector_build(kind):
+    """`QuantizedMultivectorStorage::encode_internal_vector` (quantized_multivector_storage/mod.rs:458-470) is None as soon as one inner row's is - PQ and
+    TurboQuant rows - so `FilteredScorer::new_internal` (point_scorer.rs:183-218) scores the searches of an insertion through the query scorer of the point's
+    ORIGINAL multi-vector and only stored <-> stored pairs through score_internal_max_similarity.  Pinned against the path that already does this for single
+    vectors: with ONE inner vector per point MaxSim is the plain score (0.0 + max(-inf, x) = x, bit for bit), so the multi-vector build must produce the graph
+    of `Hnsw.build_pq` / `build_tq` link for link - which it does not if the searches go through score_internal (what the oracle did before round 4)."""
+    n, dim, m, efc, seed = 400, 32, 6, 24, 9
+    rng = np.random.default_rng(3)
+    centers = rng.standard_normal((12, dim)).astype(np.float32) * 2
+    rows = O.preprocess(O.DOT, (centers[rng.integers(12, size=n)] + rng.standard_normal((n, dim))).astype(np.float32))
+    st = O.DenseStorage(O.F32, O.DOT, rows)
+    offsets = np.arange(n + 1, dtype=np.uint64)
+    if kind == "pq":
+        cen = O.PqOracle.train(rows, dim, 4, 256, iters=3)
+        q = O.PqOracle(O.DOT, dim, 4, cen)
+        q.codes = q.encode(rows)
+        single = O.Hnsw.build_pq(st, q, m=m, ef_construct=efc, seed=seed, entry_points_num=4)
+    else:
+        q = O.TqOracle(O.DOT, dim, O.TQ_BITS4)
+        q.rows = q.encode_rows(rows)
+        single = O.Hnsw.build_tq(st, q, m=m, ef_construct=efc, seed=seed, entry_points_num=4)
+    multi = O.MultiOracle((kind, st, q), offsets).build(m=m, ef_construct=efc, seed=seed, entry_points_num=4)
+    a, b = single.export_plain(), multi.export_plain()
+    assert np.array_equal(a.reindex, b.reindex) and np.array_equal(a.offsets, b.offsets) and np.array_equal(a.neighbors, b.neighbors)
+    assert a.ep_ids.tolist() == b.ep_ids.tolist()
+    # ... and the internal-only build (every score stored <-> stored) is a different graph: the fallback is not vacuous
+    s, keep = O.MultiOracle((kind, st, q), offsets).template()
+    lo, hi = 0, 0
+    for p in range(40, 60):
+        for o in range(5):
+            lo += O.MultiOracle((kind, st, q), offsets).score_internal(p, o) != np.float32(O.MultiOracle((kind, st, q), offsets).score_points([rows[p:p + 1]], [o])[0, 0])
+            hi += 1
+    assert lo > hi // 2          # a stored row scored as a query differs from its original's query scorer almost always
