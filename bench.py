@@ -1147,6 +1147,17 @@ def c4_section(ctx):
         res, st, scored = _timed_quantized(ctx, scorer, raw, top, over, resc, graph, 128, 3, quant.m)
         st.update({"points_scored_per_query": round(scored / nq_h, 1), "recall_at_10_vs_exact": round(_recall(res[:n_gt], exact, top), 4)})
         walks[name] = st
+    # the same walk without LUTs (option hnsw_pq_direct_walk, pq.hip HopPQDirect: every LUT entry recomputed from the codebook - the exact LUT's bits,
+    # 1 / 20 of the HBM traffic, profiles/r4_pq_direct_walk.md); timed beside the default so that the driver's line carries both at full size
+    qa.set_option("hnsw_pq_direct_walk", 1)
+    try:
+        res_d, st_d, scored_d = _timed_quantized(ctx, scorer, raw, top, 0.0, False, graph, 128, 3, quant.m)
+        st_d.update({"points_scored_per_query": round(scored_d / nq_h, 1), "recall_at_10_vs_exact": round(_recall(res_d[:n_gt], exact, top), 4)})
+        walks["no_rescoring_lut_free_walk"] = st_d
+    except Exception as e:
+        walks["no_rescoring_lut_free_walk"] = {"error": repr(e)[:200]}
+    finally:
+        qa.set_option("hnsw_pq_direct_walk", -1)
     hn = {"m": 16, "ef_construct": 100, "ef": 128, "searches_per_launch": nq_h, "build_through": "PQ scorer (LUT of the original vector per insertion, score_internal for the heuristic)",
           "build_s": round(t_build, 2), "build_points_per_s": round(n / t_build, 1), "walks": walks}
     hn["search_with_vectors_ef128"] = _with_vectors(ctx, graph, scorer, raw, top, 128, n_gt, exact)
