@@ -121,7 +121,7 @@ extern "C" {
 // library / device
 // ---------------------------------------------------------------------------------------------
 
-uint32_t qmx_abi_version(void) { return 5; }
+uint32_t qmx_abi_version(void) { return 6; }
 
 static int option_index(const char *name) {
     if (!name) return -1;

@@ -12,6 +12,11 @@ int32_t launch_hnsw_build_tq_l1(hipStream_t st, const ScanArgs &a, const HnswBui
                                 uint32_t padded_dim) {
     QMX_REQUIRE(h.batch_queries, QMX_ERR_BAD_ARG, "TurboQuant build needs the batch's query entries");
     const uint32_t hi = rot_dim > padded_dim ? rot_dim : padded_dim;
+    {   // static LDS of HopTQL1Internal<E> (rotation buffer + parked terms) + the launch's dynamic share (the entry and HopTQL1's scratch behind it, lists)
+        const uint32_t e = hi <= 1024 ? 16 : hi <= 2048 ? 32 : 64, g = e == 16 ? 8 : e == 32 ? 4 : 1;
+        const size_t need = (size_t)64 * e * 8 + (size_t)g * (64 * e + 1) * 4 + h.lds_query_bytes + 8 * 1024 + 8 * (size_t)h.ef_construct;
+        QMX_REQUIRE(need <= 160 * 1024, QMX_ERR_NOT_SUPPORTED, "HNSW build through TurboQuant over Manhattan: %u coordinates need %zu bytes of LDS per insertion", hi, need);
+    }
     if (rot_dim % 16 == 0 && hi <= 1024) return launch_hnsw_build_hop<HopTQL1<16>, HopTQL1Internal<16>>(st, a, h, phase, grid, per_cu);
     if (rot_dim % 32 == 0 && hi <= 2048) return launch_hnsw_build_hop<HopTQL1<32>, HopTQL1Internal<32>>(st, a, h, phase, grid, per_cu);
     if (rot_dim % 64 == 0 && hi <= 4096) return launch_hnsw_build_hop<HopTQL1<64>, HopTQL1Internal<64>>(st, a, h, phase, grid, per_cu);
