@@ -207,6 +207,10 @@ static void fill_args_segment(const qmx_segment *s, ScanArgs &a) {
         a.pq_ncent = s->pq.n_centroids;
         a.pq_pair = s->d_pq_pair;
         a.pq_invert = s->pq.invert;
+        a.pq_centroids = s->d_centroids;      // the codebook itself (the table-free build, pq.hip)
+        a.pq_dim = s->dim;
+        a.pq_chunk = s->pq.chunk_size;
+        a.pq_kind = (s->distance == QMX_DISTANCE_DOT || s->distance == QMX_DISTANCE_COSINE) ? 0u : s->distance == QMX_DISTANCE_MANHATTAN ? 1u : 2u;
     }
     if (s->dtype == QMX_DTYPE_BQ) {   // as fill_args; stored <-> stored scores are one-bit
         a.bq_dim = s->dim;
@@ -344,7 +348,10 @@ static int32_t hnsw_build_impl(const qmx_segment *seg, const qmx_segment *origin
                     "a PQ / TurboQuant segment cannot score a stored row as a query (encode_internal_vector -> None): pass the original f32 segment to qmx_hnsw_build_quantized");
         QMX_REQUIRE(original->dtype == QMX_DTYPE_F32 && original->dim == seg->dim && original->n >= seg->n && original->device == seg->device,
                     QMX_ERR_BAD_ARG, "the original segment must be f32, of the same dim, on the same device and hold every row of the quantized segment");
-        QMX_REQUIRE(seg->dtype != QMX_DTYPE_PQ || seg->d_pq_pair, QMX_ERR_NOT_SUPPORTED, "PQ build: the centroid pair table (m x n_centroids^2 floats) exceeds 256 MB");
+        QMX_REQUIRE(seg->dtype != QMX_DTYPE_PQ || seg->d_pq_pair ||
+                        (!mb && !option(OPT_HNSW_PQ_TABLE_BUILD) && pq_direct_walk_ok(seg->dim, seg->pq_m, seg->pq.chunk_size, seg->pq.n_centroids)),
+                    QMX_ERR_NOT_SUPPORTED,
+                    "PQ build: the centroid pair table (m x n_centroids^2 floats) exceeds 256 MB");
     }
     QMX_REQUIRE(seg->dtype == QMX_DTYPE_SQ_U8 || seg->dtype == QMX_DTYPE_PQ || seg->fast_layout(), QMX_ERR_NOT_SUPPORTED,
                 "adopted device block is not 16-byte aligned");
@@ -443,6 +450,7 @@ static int32_t hnsw_build_impl(const qmx_segment *seg, const qmx_segment *origin
         h.lds_query_bytes = (uint32_t)((dev_row_bytes + 127) / 128 * 128 + 128);
         uint64_t lut_stride = 0;
         uint64_t max_entries = max_batch;      // query entries a batch may need: one per point - or, multi-vector points, one per inner vector
+        bool pq_direct_build = false;
         if (seg->dtype == QMX_DTYPE_PQ) {   // query entries = LUTs of the batch's original vectors, read through L2 (as the PQ walk does)
             lut_stride = ((uint64_t)seg->pq_m * seg->pq.n_centroids * sizeof(float) + 15) & ~15ull;
             if (mb) {   // at least the longest point, at most 1 GiB of LUTs (the insertion loop shortens a batch that would need more)
@@ -456,6 +464,14 @@ static int32_t hnsw_build_impl(const qmx_segment *seg, const qmx_segment *origin
             h.batch_queries = (const unsigned char *)b_bq.p;
             h.batch_q_stride = lut_stride;
             h.lds_query_bytes = 0;
+            // the table-free build (pq.hip HopPQDirectBuild + HopPQInternalDirect; the default where the codebook allows, option hnsw_pq_table_build for the
+            // other): the entries are the preprocessed original vectors themselves, staged in LDS per insertion - no LUTs are made
+            pq_direct_build = !mb && !option(OPT_HNSW_PQ_TABLE_BUILD) && pq_direct_walk_ok(seg->dim, seg->pq_m, seg->pq.chunk_size, seg->pq.n_centroids);
+            if (pq_direct_build) {
+                h.batch_queries = (const unsigned char *)b_bqsrc.p;
+                h.batch_q_stride = (uint64_t)seg->dim * 4;
+                h.lds_query_bytes = seg->dim * 4;
+            }
         }
         if (seg->dtype == QMX_DTYPE_TQ) {   // query entries = precompute_query of the batch's original vectors, staged in LDS per insertion
             if (mb) {   // one entry per inner vector of the batch: at least the longest point, at most 256 MiB of rotated vectors
@@ -547,7 +563,7 @@ static int32_t hnsw_build_impl(const qmx_segment *seg, const qmx_segment *origin
                     QH(hipMemcpy2DAsync(src, (size_t)seg->dim * 4, (const char *)original->d_rows + r0 * original->row_stride, original->row_stride,
                                         (size_t)seg->dim * 4, nr, hipMemcpyDeviceToDevice, nullptr));
                     if (seg->distance == QMX_DISTANCE_COSINE) QB(launch_cosine_preprocess_f32(nullptr, src, src, nr, seg->dim));
-                    QB(launch_pq_lut(nullptr, seg->distance, seg->dim, seg->pq, seg->d_centroids, src, (uint32_t)nr, (float *)b_bq.p));
+                    if (!pq_direct_build) QB(launch_pq_lut(nullptr, seg->distance, seg->dim, seg->pq, seg->d_centroids, src, (uint32_t)nr, (float *)b_bq.p));
                 }
             }
             if (tq_l1(seg)) {   // EncodedVectorsTQ over Manhattan: no preprocessing, no rotation - the rows themselves, zero padded to whole 16 bytes

@@ -52,6 +52,8 @@ enum Option {
     OPT_SQ_MFMA_NO_LLIST,     // SQ / TQ / BQ / f16 matrix-core scans: the waves' top lists in registers (default 1; 0 = in LDS behind the query tile: more waves per CU, measured no faster)
     OPT_PQ_PREFILTER_W16,     // PQ prefilter: the rotated copy holds 16-bit codes (twice the copy; one vector instruction per gather address instead of two); read at segment create
     OPT_HNSW_PQ_DIRECT_WALK,  // the PQ walk recomputes LUT entries from the codebook (pq.hip HopPQDirect: a twentieth of the HBM traffic; 1.3 x the time on a 2 M-row graph, the same at 10 M) instead of gathering per-search LUTs
+    OPT_HNSW_PQ_TABLE_BUILD,  // the PQ build scores through per-insertion LUTs and the centroid pair table (round 2's build: 100 TB of table sectors per 2 M points) instead of
+                              // recomputing both kinds of entries from the codebook (pq.hip HopPQDirectBuild + HopPQInternalDirect, the default where the codebook allows)
     OPT_I8_SCAN_DEEP,         // the int8-copy prefilter scans through the half-stage pipeline (scan_i8copy_deep_kernel: 80 KiB of rows in flight per CU, twice the barriers: 14 % slower)
     OPT_DEBUG,                // log dropped stale HIP errors
     OPT_COUNT

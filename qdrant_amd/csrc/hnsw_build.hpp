@@ -395,17 +395,24 @@ int32_t launch_hnsw_build_hop(hipStream_t st, const ScanArgs &a, const HnswBuild
         auto k8 = hnsw_build_search_kernel<H, HI, 8>;
         auto k0 = hnsw_build_search_kernel<H, HI, 0>;
         QMX_REQUIRE(lds1 <= 160 * 1024, QMX_ERR_NOT_SUPPORTED, "HNSW build: ef_construct %u needs %zu bytes of LDS per insertion", h.ef_construct, lds1);
+        // (a policy may keep static LDS of its own - a decoded row, a rotation buffer -: the dynamic share is what is left of the CU's 160 KiB)
+        auto allow = [](const void *kfn) -> int32_t {
+            hipFuncAttributes fa;
+            QMX_HIP(hipFuncGetAttributes(&fa, kfn));
+            QMX_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)fa.sharedSizeBytes));
+            return QMX_OK;
+        };
         if (e_sel == 0) {
             static thread_local DeviceOnce attr_once;
             if (attr_once.need()) {
-                QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                QMX_TRY(allow(reinterpret_cast<const void *>(k0)));
                 attr_once.mark();
             }
         } else if (lds1 > 48 * 1024) {      // a register beam behind a large query entry (TurboQuant over Manhattan: the entry and its hop scratch)
             static thread_local DeviceOnce attr_once28;
             if (attr_once28.need()) {
-                QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                QMX_TRY(allow(reinterpret_cast<const void *>(k2)));
+                QMX_TRY(allow(reinterpret_cast<const void *>(k8)));
                 attr_once28.mark();
             }
         }

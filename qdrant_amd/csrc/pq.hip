@@ -503,7 +503,123 @@ struct HopPQBuild : HopPQ {
     static constexpr bool INTERNAL_QOFF = false;
     static constexpr bool INTERNAL_NORM = false;
 };
+// ------------------------------------------------------------------------------------------
+// The same stored <-> stored score WITHOUT the pair table (round 4; with HopPQDirect for the insertion searches: a PQ build that gathers from no
+// per-query or per-segment table at all; the default since it measured faster: 25.1 s against 32.0 s for 2 M x 1536 points, option hnsw_pq_table_build for the
+// other).  PMC of a 2 M-point build (profiles/r3_pmc_traffic.md): the link phase moves 594 GB per launch and the search
+// phase 347 GB - 100 TB per build, i.e. the build runs at the fabric's speed on 64-byte sectors of which it uses 4 bytes.  pair[c][i][j] is
+// sum_k term(centroid[i][16 c + k], centroid[j][16 c + k]) from -0.0 (pq_pair_table_kernel): a LUT entry whose "query" is the other row's own
+// centroid.  So the row that plays the query is DECODED once per hop into LDS (m chunks of its centroids: 6 KiB at d = 1536), every candidate's chunk
+// entries are recomputed against it from the 1.5 MB codebook (16 lanes per candidate, six consecutive chunks each), and the single chain of m adds
+// (`s = -0.0; s += entry[c]` in chunk order, then `invert`) is handed from lane to lane.  The policy scores a whole hop itself (hnsw.hpp hop_score).
+// ------------------------------------------------------------------------------------------
+template <int CHUNK>
+struct HopPQInternalDirect {
+    static constexpr int LPI = 16;
+    static constexpr bool MULTI = false;
+    static constexpr bool INTERNAL_QOFF = false;
+    static constexpr bool INTERNAL_NORM = false;
+    static constexpr bool ASYMMETRIC = true;
+    static constexpr bool TQL1 = true;                     // (a policy that scores the hop as a wave: H::hop)
+    static constexpr int V = CHUNK / 4;
+    static constexpr int CPL = 8;                          // chunks per lane at most (m <= 128)
+    static constexpr int R = 8 / V > 0 ? 8 / V : 1;        // chunks per round: eight 16-byte loads in flight per lane
+    static __device__ __forceinline__ float score(const ScanArgs &, const unsigned char *, uint32_t, int) { return 0.0f; }   // (never called: hop() scores)
+    template <int KIND>
+    static __device__ __forceinline__ void entries(const ScanArgs &a, const float *q, const uint8_t *codes, uint32_t c0, uint32_t n_mine, float (&t)[CPL]) {
+        const float *cent = a.pq_centroids;
+        const uint32_t dim = a.pq_dim;
+        uint32_t code[CPL];
+#pragma unroll
+        for (int r = 0; r < CPL; ++r) code[r] = (uint32_t)r < n_mine ? codes[c0 + (uint32_t)r] : 0u;
+#pragma unroll
+        for (int r0 = 0; r0 < CPL; r0 += R) {
+            if (__ballot((uint32_t)r0 < n_mine) == 0) break;
+            f32x4s cv[R][V];
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                const int r = r0 + rr;
+                const bool on = r < CPL && (uint32_t)r < n_mine;
+                const uint32_t c = on ? c0 + (uint32_t)r : 0u;
+                const float *p = cent + (size_t)(on ? code[r < CPL ? r : 0] : 0u) * dim + (size_t)c * CHUNK;
+#pragma unroll
+                for (int v = 0; v < V; ++v) cv[rr][v] = *reinterpret_cast<const f32x4s *>(p + 4 * v);
+            }
+            float sr[R];
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) sr[rr] = -0.0f;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                f32x4s qv[R];
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) {
+                    const int r = r0 + rr;
+                    const uint32_t c = (r < CPL && (uint32_t)r < n_mine) ? c0 + (uint32_t)r : 0u;
+                    qv[rr] = *reinterpret_cast<const f32x4s *>(q + (size_t)c * CHUNK + 4 * v);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int rr = 0; rr < R; ++rr) sr[rr] += pq_term(KIND, qv[rr][e], cv[rr][v][e]);
+            }
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr)
+                if (r0 + rr < CPL) t[r0 + rr] = sr[rr];
+        }
+    }
+    static __device__ __forceinline__ void hop(const ScanArgs &a, const unsigned char *qp, const uint32_t *hop_ids, float *hop_scores, uint32_t k, int lane) {
+        __shared__ __attribute__((aligned(16))) float qdec[128 * CHUNK];
+        const uint32_t m = a.pq_m, dim = a.pq_dim;
+        // the query row, decoded: chunk c of centroid qp[c]
+        for (uint32_t i = (uint32_t)lane; i < m * V; i += 64) {
+            const uint32_t c = i / V, v = i % V;
+            *reinterpret_cast<f32x4s *>(qdec + (size_t)c * CHUNK + 4 * v) =
+                *reinterpret_cast<const f32x4s *>(a.pq_centroids + (size_t)qp[c] * dim + (size_t)c * CHUNK + 4 * v);
+        }
+        __syncthreads();
+        const int sub = lane & 15, g = lane >> 4;
+        const uint32_t cpl = (m + 15) / 16;                       // consecutive chunks per lane
+        const uint32_t c0 = (uint32_t)sub * cpl;
+        const uint32_t n_mine = c0 < m ? (m - c0 < cpl ? m - c0 : cpl) : 0u;
+        for (uint32_t base = 0; base < k; base += 4) {
+            const uint32_t j = base + (uint32_t)g;
+            const bool on = j < k;
+            const uint32_t id = hop_ids[on ? j : 0];
+            const uint8_t *codes = reinterpret_cast<const uint8_t *>(a.rows) + (uint64_t)id * a.row_stride;
+            float t[CPL];
+#pragma unroll
+            for (int r = 0; r < CPL; ++r) t[r] = 0.0f;
+            if (a.pq_kind == 0) entries<0>(a, qdec, codes, c0, n_mine, t);
+            else if (a.pq_kind == 1) entries<1>(a, qdec, codes, c0, n_mine, t);
+            else entries<2>(a, qdec, codes, c0, n_mine, t);
+            // s = -0.0; s += entry[c] in chunk order: the sum walks through the sixteen lanes of the row
+            float s = -0.0f;
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                if (p > 0) s = __shfl_up(s, 1, 64);
+                if (sub == p) {
+#pragma unroll
+                    for (int r = 0; r < CPL; ++r)
+                        if ((uint32_t)r < n_mine) s += t[r];
+                }
+            }
+            if (on && sub == 15) hop_scores[j] = a.pq_invert ? -s : s;
+        }
+        __syncthreads();
+    }
+};
+static bool pq_direct_build_ok(const ScanArgs &a) {
+    return a.pq_centroids && (a.pq_chunk == 16 || a.pq_chunk == 8 || a.pq_chunk == 4) && (uint64_t)a.pq_m * a.pq_chunk == a.pq_dim && a.pq_m <= 128 && a.pq_ncent <= 256;
+}
+template <int CHUNK, int SPLIT, int R>
+struct HopPQDirectBuild : HopPQDirect<CHUNK, SPLIT, R> {};
 int32_t launch_hnsw_build_pq(hipStream_t st, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu) {
+    if (h.lds_query_bytes != 0 && pq_direct_build_ok(a)) {      // the batch's entries are the original vectors themselves (api_hnsw.hip): no table of any kind
+        QMX_REQUIRE(h.batch_queries, QMX_ERR_BAD_ARG, "PQ build needs the batch's original vectors");
+        if (a.pq_chunk == 16) return launch_hnsw_build_hop<HopPQDirectBuild<16, 4, 2>, HopPQInternalDirect<16>>(st, a, h, phase, grid, per_cu);
+        if (a.pq_chunk == 8) return launch_hnsw_build_hop<HopPQDirectBuild<8, 4, 4>, HopPQInternalDirect<8>>(st, a, h, phase, grid, per_cu);
+        return launch_hnsw_build_hop<HopPQDirectBuild<4, 4, 8>, HopPQInternalDirect<4>>(st, a, h, phase, grid, per_cu);
+    }
     QMX_REQUIRE(a.pq_pair && h.batch_queries, QMX_ERR_BAD_ARG, "PQ build needs the centroid pair table and the batch LUTs");
     return launch_hnsw_build_hop<HopPQBuild, HopPQInternal>(st, a, h, phase, grid, per_cu);
 }

@@ -534,6 +534,30 @@ def test_tq_manhattan_build_with_an_unpadded_rotation(qa):
         assert np.array_equal(gq["score"].view(np.uint32), wq["score"].view(np.uint32))
 
 
+@pytest.mark.parametrize("tables", [False, True])
+@pytest.mark.parametrize("distance,dim,chunk", [(O.COSINE, 64, 4), (O.EUCLID, 96, 16), (O.MANHATTAN, 80, 8), (O.DOT, 320, 16), (O.DOT, 70, 8)])
+def test_pq_build_with_and_without_tables_is_the_sequential_graph(qa, distance, dim, chunk, tables):
+    """The PQ build recomputes what it needs from the codebook by default (round 4, pq.hip HopPQDirectBuild + HopPQInternalDirect: the LUT entries of the
+    insertion searches in pq_lut_kernel's order, the centroid-pair terms of score_internal in pq_pair_table_kernel's - the same bits as the tables hold);
+    option hnsw_pq_table_build = round 2's build through per-insertion LUTs and the 25 MB pair table.  One point per launch both are the oracle's sequential
+    graph link for link.  (70 = 8 x 8 + 6: a ragged last chunk keeps the tables whatever the option.)"""
+    n, m, efc, seed = 900, 8, 40, 29
+    rows = O.preprocess(distance, _clustered(n, dim, seed, k=24))
+    st = O.DenseStorage(O.F32, distance, rows)
+    vs = qa.VectorStorage(rows, _dist(qa, distance))
+    cen = O.PqOracle.train(rows[:800], dim, chunk, 256, iters=3)
+    opq = O.PqOracle(distance, dim, chunk, cen)
+    codes = opq.encode(rows)
+    quant = qa.ProductQuantizer(dim, _dist(qa, distance), chunk, cen, lut_mfma=False)
+    qa.set_option("hnsw_pq_table_build", 1 if tables else 0)
+    try:
+        seq = qa.GraphLayers.build(qa.EncodedVectorsPQ(codes, quant), m=m, ef_construct=efc, seed=seed, max_batch=1, original=vs)
+    finally:
+        qa.set_option("hnsw_pq_table_build", -1)
+    ref = O.Hnsw.build_pq(st, opq, m=m, ef_construct=efc, seed=seed)
+    _same_graph(seq.export_plain(), ref.export_plain())
+
+
 def test_pq_pair_table_is_score_internal(qa):
     """The tabulated chunk distances give EncodedVectorsPQ::score_internal bit for bit (the build's stored <-> stored score)."""
     n, dim, chunk = 600, 40, 8
