@@ -197,3 +197,41 @@ def test_synth_generator_is_counter_based():
     b = O.synth(0x5EED0002, 32, 32, 96)
     assert np.array_equal(a[32:], b)
     assert abs(float(a.mean())) < 0.05 and 0.9 < float(a.std()) < 1.1
+
+
+def test_pq_lut_entry_is_the_sequential_chunk_sum_the_table_free_kernels_recompute():
+    """pq.hip's HopPQDirect / HopPQInternalDirect recompute a LUT entry (and a centroid-pair term) instead of gathering it: entry(c, k) = the chunk's terms
+    added one by one in f32 from -0.0, a multiply and an add per coordinate (no fma) - `encode_query` (encoded_vectors_pq.rs:519-541).  The restatement of
+    that claim against the oracle's LUT and its score_internal, bit for bit, for the three term kinds."""
+    import oracle_ffi as O
+    rng = np.random.default_rng(5)
+    dim, chunk, n = 48, 8, 300
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    cen = O.PqOracle.train(rows, dim, chunk, 256, iters=2)
+    m = dim // chunk
+
+    def chain(a, b, kind):
+        s = np.float32(-0.0)
+        for x, y in zip(a, b):
+            t = np.float32(x) * np.float32(y) if kind == 0 else (np.float32(abs(np.float32(x) - np.float32(y))) if kind == 1 else
+                                                               np.float32((np.float32(x) - np.float32(y)) * (np.float32(x) - np.float32(y))))
+            s = np.float32(s + t)
+        return s
+    for dist, kind in ((O.DOT, 0), (O.MANHATTAN, 1), (O.EUCLID, 2)):
+        opq = O.PqOracle(dist, dim, chunk, cen)
+        codes = opq.encode(rows)
+        opq.codes = codes
+        q = O.preprocess(dist, rng.standard_normal((1, dim)).astype(np.float32))[0]
+        lut = np.asarray(opq.lut(q), dtype=np.float32).reshape(m, 256)
+        sign = np.float32(-1.0) if dist in (O.EUCLID, O.MANHATTAN) else np.float32(1.0)      # `invert`: the segment's choice for distances (quantized_vectors.rs:232)
+        for c in (0, 3, m - 1):
+            for k in (0, 17, 255):
+                want = chain(q[c * chunk:(c + 1) * chunk], cen[k, c * chunk:(c + 1) * chunk], kind)
+                assert np.float32(sign * want).view(np.uint32) == lut[c, k].view(np.uint32), (dist, c, k)
+        # score_internal(a, b) = (+/-) the chain over chunks (from -0.0) of the chains over the two rows' centroids
+        a, b = 7, 123
+        s = np.float32(-0.0)
+        for c in range(m):
+            s = np.float32(s + chain(cen[codes[a, c], c * chunk:(c + 1) * chunk], cen[codes[b, c], c * chunk:(c + 1) * chunk], kind))
+        got = opq.score_internal(np.array([a], dtype=np.uint32), np.array([b], dtype=np.uint32))[0]
+        assert np.float32(sign * s).view(np.uint32) == np.float32(got).view(np.uint32), dist
