@@ -1,6 +1,6 @@
 #!/bin/bash
 # Everything profiles/ wants from the final build of round 4, in one gpurun call (~12 GPU-minutes):
-#   usage: /usr/local/graft/bin/gpurun --timeout 1800 -- 'bash tools/r4_final.sh'
+#   usage: /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/round4/r4_final.sh'
 set -u
 R=$PWD
 mkdir -p gpurun_out
