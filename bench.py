@@ -203,6 +203,26 @@ def compact_roofline(result):
     return out
 
 
+def _walk_summary(ow):
+    """oracle_walk_check of a walk leg in three short strings"""
+    if not isinstance(ow, dict) or not ow:
+        return None
+    if "error" in ow:
+        return {"error": str(ow["error"])[:80]}
+    g = lambda *ks: next((ow[k] for k in ks if k in ow), None)      # noqa: E731
+    out = {"default_walk": "%s ids, %s score bits" % (g("same_ids", "exact_lut_same_ids"), g("same_score_bits", "exact_lut_same_score_bits"))}
+    if "tie_explained" in ow:
+        out["tie_explained"] = ow["tie_explained"]
+    if "unexplained" in ow:
+        out["unexplained"] = len(ow["unexplained"])
+    if "reference_heap_order_same_ids" in ow:
+        out["reference_heap_order"] = "%s ids, %s score bits, %s pop sequences" % (ow["reference_heap_order_same_ids"], ow.get("reference_heap_order_same_score_bits"),
+                                                                                  ow.get("reference_heap_order_same_pops"))
+    if "mfma_lut_same_id_sets" in ow:
+        out["mfma_lut_same_id_sets"] = ow["mfma_lut_same_id_sets"]
+    return out
+
+
 def _configs_summary(cfg):
     legs, out = {}, {LEG_COLUMNS: None}
     put = lambda name, st: legs.__setitem__(name, _leg(st)) if st is not None else None      # noqa: E731
@@ -217,7 +237,7 @@ def _configs_summary(cfg):
             put("C3.scan_Q32", bf.get("Q32"))
             put("C3.walk", h)
             ow = h.get("oracle_walk_check", {})
-            out["C3"] = {"build_s": h.get("build_s"), "oracle_walk": {k: v for k, v in ow.items() if k != "seconds"} if "error" not in ow else {"error": ow["error"][:80]},
+            out["C3"] = {"build_s": h.get("build_s"), "oracle_walk": _walk_summary(ow),
                          "oracle_scan_ok": all(v is True for v in c3.get("oracle_check", {"-": None}).values())}
     tq = cfg.get("TQ4")
     if isinstance(tq, dict):
@@ -241,8 +261,7 @@ def _configs_summary(cfg):
             put("C4.scan_Q32", c4.get("brute_force_Q32_oversampling2_rescore"))
             ow = h.get("oracle_walk_check", {})
             out["C4"] = {"build_s": h.get("build_s"), "lut_mfma": _pick(lut.get("kernel_roofline", lut.get("roofline", {})), "achieved", "peak", "frac", "kernel_ms"),
-                         "oracle_walk": ({k: v for k, v in ow.items() if k not in ("seconds", "codes_byte_exact_first_1000", "mfma_lut_max_rel_score_err")}
-                                         if "error" not in ow else {"error": ow["error"][:80]})}
+                         "oracle_walk": _walk_summary(ow)}
     out[LEG_COLUMNS] = legs
     return out
 

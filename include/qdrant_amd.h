@@ -298,6 +298,7 @@ QMX_API uint32_t qmx_abi_version(void);
  * "mfma_no_nt", "mfma_no_fast", "no_pq_tiled", "no_split_scan", "split_min_queries", "no_split256", "no_pq_pair", "no_pq_prefilter",
  * "pq_prefilter_min_queries", "hnsw_pq_per_cu", "tq_rotate_block", "no_topk_small", "verify_max_per_query", "no_hnsw_pq_block", "hnsw_pq_block_waves",
  * "hnsw_pq_block_set", "sq_mfma_no_stage", "sq_mfma_no_llist", "pq_prefilter_w16" (read at segment create), "hnsw_pq_direct_walk", "hnsw_pq_table_build", "i8_scan_deep", "debug"
+ * - and one that selects the ORDER AMONG EQUAL SCORES of the plain HNSW walk: "hnsw_reference_heap_order" (see qmx_hnsw_search_traced) -
  * (qdrant_amd/csrc/common.hpp says what each selects; several are experiments that measured slower and stay opt-in).  Initial values come from the environment variables QMX_<NAME> read
  * ONCE when the library is loaded; value < 0 restores that initial value.  Unknown name => QMX_ERR_BAD_ARG.  (No reference
  * counterpart: the reference selects its SIMD leaf by cpu feature detection, spaces/simple.rs:15-33.) */
@@ -758,6 +759,17 @@ QMX_API int32_t qmx_hnsw_search(const qmx_hnsw *g, qmx_query *q, uint32_t top, u
 QMX_API int32_t qmx_hnsw_search_acorn(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
                                       qmx_scored_point *out, uint32_t *out_counts,
                                       const volatile uint8_t *is_stopped, qmx_counters *counters);
+/* qmx_hnsw_search (host outputs) that also lists, per search, the candidates the level-0 loop of `search_on_level` pops from `candidates` and
+ * expands (graph_layers.rs:120-147: every `candidate` that passes the `candidate.score < lower_bound` test), in order, with their scores:
+ *   pops : [nq][pop_cap], pop_counts : [nq] (a count above pop_cap means the list is incomplete).
+ * Test / verification aid: two walks of one graph agree exactly as long as their pop sequences agree, and where two sequences first differ the
+ * two popped candidates show WHY (equal scores = the reference's order among ties; anything else = a defect).  See also the option
+ * "hnsw_reference_heap_order" (qmx_set_option): the walk then keeps `nearest` and `candidates` as the reference's two binary heaps in std's
+ * sift order (search_context.rs:8-40, fixed_length_priority_queue.rs:47-59) and returns the reference's lists among equal scores too - one lane
+ * works the heaps, so it is slow: a verification mode for the plain walk (dense, SQ, PQ, BQ, TurboQuant scorers). */
+QMX_API int32_t qmx_hnsw_search_traced(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
+                                       qmx_scored_point *out, uint32_t *out_counts,
+                                       qmx_scored_point *pops, uint32_t pop_cap, uint32_t *pop_counts);
 /* qmx_hnsw_search, only enqueued on the query's stream; outputs in device memory.
  * `out_scored_dev` ([nq] points scored per search) may be NULL. */
 QMX_API int32_t qmx_hnsw_search_async(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,

@@ -277,6 +277,9 @@ uint32_t qo_hnsw_search(const qo_hnsw *g, const qo_scorer *scorer, uint32_t top,
 /* the same with SearchAlgorithm: 0 = Hnsw, 1 = Acorn (search_on_level_acorn, graph_layers.rs:154-243) */
 uint32_t qo_hnsw_search_algo(const qo_hnsw *g, const qo_scorer *scorer, uint32_t top, uint32_t ef, int algorithm, qo_scored_point *out,
                              uint64_t *n_scored);
+/* the same (SearchAlgorithm::Hnsw) + the candidates the level-0 loop pops and expands, in order; *n_pops may exceed pop_cap */
+uint32_t qo_hnsw_search_traced(const qo_hnsw *g, const qo_scorer *scorer, uint32_t top, uint32_t ef, qo_scored_point *out, uint64_t *n_scored,
+                               qo_scored_point *pops, uint32_t pop_cap, uint32_t *n_pops);
 /* GraphLayers::search_with_vectors (graph_layers.rs:564-596) for graphs with inline storage: the walk is steered by `links_scorer` (the
  * quantized link vectors), every popped candidate is scored by `base_scorer` (its full base vector) and the best `top` of those are returned. */
 uint32_t qo_hnsw_search_with_vectors(const qo_hnsw *g, const qo_scorer *links_scorer, const qo_scorer *base_scorer, uint32_t top, uint32_t ef,

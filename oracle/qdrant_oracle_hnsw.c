@@ -280,6 +280,9 @@ typedef struct {
     const qo_scorer *tmpl;    /* build: dense template (kind 0), query ignored */
     uint32_t self;
     uint64_t n_scored;
+    /* qo_hnsw_search_traced: the candidates search_on_level pops and expands, in order (a count above the capacity = incomplete list) */
+    qo_scored_point *trace;
+    uint32_t trace_cap, trace_n;
 } qscore;
 static inline float qs_score(qscore *q, uint32_t id) {
     q->n_scored++;
@@ -319,6 +322,7 @@ static qo_topk *search_on_level(const qo_hnsw *g, qscore *q, qo_scored_point lev
         qo_scored_point worst;
         const float lower_bound = qo_topk_top(nearest, &worst) ? worst.score : -3.40282347e+38f;   /* ScoreType::min_value() */
         if (cand.score < lower_bound) break;
+        if (q->trace) { if (q->trace_n < q->trace_cap) q->trace[q->trace_n] = cand; q->trace_n++; }
         uint32_t n = read_links(g, cand.idx, level, ids, only_ready), k = 0;
         for (uint32_t i = 0; i < n; i++) if (!visited_check(vis, ids[i])) ids[k++] = ids[i];
         k = filter_truncate(q, ids, k, limit);
@@ -952,9 +956,10 @@ uint32_t qo_hnsw_search_with_vectors(const qo_hnsw *g, const qo_scorer *links_sc
     return n;
 }
 
-uint32_t qo_hnsw_search_algo(const qo_hnsw *g, const qo_scorer *scorer, uint32_t top, uint32_t ef, int algorithm, qo_scored_point *out,
-                             uint64_t *n_scored) {
-    qscore q = {scorer, NULL, 0, 0};
+static uint32_t hnsw_search_impl(const qo_hnsw *g, const qo_scorer *scorer, uint32_t top, uint32_t ef, int algorithm, qo_scored_point *out,
+                                 uint64_t *n_scored, qo_scored_point *pops, uint32_t pop_cap, uint32_t *n_pops) {
+    qscore q = {scorer, NULL, 0, 0, pops, pop_cap, 0};
+    if (n_pops) *n_pops = 0;
     uint32_t ep_id, ep_level;
     if (!get_entry_point(g, &q, &ep_id, &ep_level)) { if (n_scored) *n_scored = 0; return 0; }
     qo_scored_point zero_level_entry = search_entry(g, &q, ep_id, ep_level, 0, 0);
@@ -973,5 +978,16 @@ uint32_t qo_hnsw_search_algo(const qo_hnsw *g, const qo_scorer *scorer, uint32_t
     memcpy(out, sorted, sizeof(qo_scored_point) * n);
     free(sorted);
     if (n_scored) *n_scored = q.n_scored;
+    if (n_pops) *n_pops = q.trace_n;
     return n;
+}
+uint32_t qo_hnsw_search_algo(const qo_hnsw *g, const qo_scorer *scorer, uint32_t top, uint32_t ef, int algorithm, qo_scored_point *out,
+                             uint64_t *n_scored) {
+    return hnsw_search_impl(g, scorer, top, ef, algorithm, out, n_scored, NULL, 0, NULL);
+}
+/* GraphLayers::search with SearchAlgorithm::Hnsw + the pop sequence of its level-0 loop (the candidates that pass the lower-bound test, in order):
+ * what qmx_hnsw_search_traced lists on the device.  *n_pops may exceed pop_cap (the list is then incomplete). */
+uint32_t qo_hnsw_search_traced(const qo_hnsw *g, const qo_scorer *scorer, uint32_t top, uint32_t ef, qo_scored_point *out, uint64_t *n_scored,
+                               qo_scored_point *pops, uint32_t pop_cap, uint32_t *n_pops) {
+    return hnsw_search_impl(g, scorer, top, ef, 0, out, n_scored, pops, pop_cap, n_pops);
 }

@@ -205,6 +205,7 @@ SIGNATURES = {
     "qmx_hnsw_search": (C.c_int32, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, _P, C.POINTER(Counters)]),
     "qmx_hnsw_search_acorn": (C.c_int32, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, _P, C.POINTER(Counters)]),
     "qmx_hnsw_search_async": (C.c_int32, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, _P]),
+    "qmx_hnsw_search_traced": (C.c_int32, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, _P, C.c_uint32, _P]),
     "qmx_sq_encode": (C.c_int32, [C.c_int32, C.c_uint32, C.POINTER(SqParams), _P, C.c_uint64, C.c_uint32, _P]),
     "qmx_pq_train": (C.c_int32, [C.c_int32, _P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, _P, _P]),
     "qmx_sq_fit_min_max": (C.c_int32, [C.c_int32, C.c_uint32, _P, C.c_uint64, C.c_uint32, C.POINTER(SqParams)]),

@@ -730,7 +730,7 @@ static int32_t launch_hnsw(const qmx_query *q, const ScanArgs &a, const HnswArgs
 
 int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef, qmx_scored_point *d_out,
                             uint32_t *d_counts, uint32_t *d_scored, bool timed, bool acorn, const MultiWalk *mw,
-                            const ExpandedOut *xo, const CustomWalk *cw) {
+                            const ExpandedOut *xo, const CustomWalk *cw, const PopTrace *pt) {
     const qmx_segment *s = q->seg;
     QMX_REQUIRE(!tq_l1(s) || !mw, QMX_ERR_NOT_SUPPORTED, "multi-vector walks through a TurboQuant storage over Manhattan are not built");
     ScanArgs a;
@@ -772,6 +772,13 @@ int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
     h.ef = ef; h.top = top; h.nq = n_searches;
     h.out = d_out; h.out_counts = d_counts; h.out_scored = d_scored;
     if (xo) { h.expanded = xo->d_ids; h.expanded_cnt = xo->d_cnt; h.xcap = xo->xcap; }
+    if (pt) {
+        QMX_REQUIRE(!xo && !acorn && !mw && !cw, QMX_ERR_NOT_SUPPORTED, "the pop trace is the plain walk's");
+        h.pops = pt->d_pops; h.pop_cnt = pt->d_cnt; h.pop_cap = pt->cap;
+    }
+    // option hnsw_reference_heap_order: the plain walk keeps the reference's two binary heaps (hnsw.hpp RefHeaps); other walks are unaffected
+    h.ref_heaps = (option(OPT_HNSW_REFERENCE_HEAP_ORDER) > 0 && !acorn && !xo && !mw && !cw && !tq_l1(s)) ? 1 : 0;
+    h.ref_cap = HNSW_REF_CAND_CAP;
     h.lds_query_bytes = q->q_stride <= HNSW_LDS_QUERY_MAX ? q->q_stride : 0;
     if (tq_l1(s)) {
         h.lds_query_bytes = tq_l1_lds_bytes(s->dim, s->tq_rot_dim);
@@ -826,6 +833,11 @@ int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
     uint64_t slots = std::min<uint64_t>({(uint64_t)n_searches, (uint64_t)s->num_cus * per_cu, (uint64_t)HNSW_SLOT_CAP});
     const uint64_t by_budget = std::max<uint64_t>(1, HNSW_VIS_BUDGET / (h.vis_words * 4));
     slots = std::max<uint64_t>(1, std::min(slots, by_budget));
+    if (h.ref_heaps) {
+        slots = std::min<uint64_t>(slots, HNSW_REF_SLOT_CAP);
+        QMX_TRY(q->hnsw_refc.reserve((size_t)slots * h.ref_cap * sizeof(uint2)));
+        h.ref_cands = (uint2 *)q->hnsw_refc.p;
+    }
     if (q->hnsw_slots < slots || q->hnsw_vis_words != h.vis_words) {
         // (re)allocate for the largest slot count this handle can use, zero once: the kernel returns the bitmaps all-zero
         const uint64_t want = std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)std::max<uint32_t>(std::max(q->nq, n_searches), 1), (uint64_t)s->num_cus * per_cu,
@@ -909,6 +921,30 @@ int32_t qmx_hnsw_search(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t 
 int32_t qmx_hnsw_search_acorn(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef, qmx_scored_point *out, uint32_t *out_counts,
                               const volatile uint8_t *is_stopped, qmx_counters *counters) {
     return hnsw_search_sync(g, q, top, ef, out, out_counts, is_stopped, counters, true);
+}
+
+int32_t qmx_hnsw_search_traced(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef, qmx_scored_point *out, uint32_t *out_counts,
+                               qmx_scored_point *pops, uint32_t pop_cap, uint32_t *pop_counts) {
+    QMX_REQUIRE(g && q && out && out_counts && pops && pop_counts && pop_cap >= 1, QMX_ERR_BAD_ARG, "NULL argument");
+    QMX_REQUIRE(!is_device_ptr(out) && !is_device_ptr(out_counts) && !is_device_ptr(pops) && !is_device_ptr(pop_counts), QMX_ERR_BAD_ARG,
+                "qmx_hnsw_search_traced writes host arrays");
+    QMX_TRY(hnsw_check(g, q, top, ef));
+    QMX_HIP(hipSetDevice(q->device));
+    if (q->nq == 0) return QMX_OK;
+    memset(out_counts, 0, (size_t)q->nq * 4);
+    memset(pop_counts, 0, (size_t)q->nq * 4);
+    if (g->n_points == 0) return QMX_OK;
+    QMX_TRY(q->out.reserve((size_t)q->nq * top * sizeof(qmx_scored_point)));
+    QMX_TRY(q->counts.reserve((size_t)q->nq * 4));
+    QMX_TRY(q->cand.reserve((size_t)q->nq * pop_cap * sizeof(qmx_scored_point)));
+    QMX_TRY(q->xcnt.reserve((size_t)q->nq * 4));
+    PopTrace pt{(qmx_scored_point *)q->cand.p, (uint32_t *)q->xcnt.p, pop_cap};
+    QMX_TRY(hnsw_enqueue(g, q, top, ef, (qmx_scored_point *)q->out.p, (uint32_t *)q->counts.p, nullptr, false, false, nullptr, nullptr, nullptr, &pt));
+    QMX_TRY(copy_out(q->stream, out, q->out.p, (size_t)q->nq * top * sizeof(qmx_scored_point)));
+    QMX_TRY(copy_out(q->stream, out_counts, q->counts.p, (size_t)q->nq * 4));
+    QMX_TRY(copy_out(q->stream, pops, q->cand.p, (size_t)q->nq * pop_cap * sizeof(qmx_scored_point)));
+    QMX_TRY(copy_out(q->stream, pop_counts, q->xcnt.p, (size_t)q->nq * 4));
+    return check_err_flag(q);   // synchronises the stream
 }
 
 int32_t qmx_hnsw_search_async(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef, qmx_scored_point *out_dev,

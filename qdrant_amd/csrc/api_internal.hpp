@@ -172,6 +172,7 @@ struct qmx_query {
     DevBuf filter;             // payload-filter allow bitmap of this query batch (qmx_query_set_filter)
     uint64_t n_filter_bits = 0;
     bool has_filter = false;
+    DevBuf hnsw_refc;          // option hnsw_reference_heap_order: the per-slot `candidates` heaps
     DevBuf hnsw_vis, hnsw_log, hnsw_scored;   // HNSW scratch: per-slot visited bitmaps (kept all-zero between launches) + logs
     uint32_t hnsw_slots = 0;
     uint64_t hnsw_vis_words = 0;
@@ -253,6 +254,10 @@ static int32_t check_err_flag(qmx_query *q) {
     QMX_HIP(hipStreamSynchronize(q->stream));
     if (flag) {
         QMX_HIP(hipMemsetAsync(q->d_err, 0, sizeof(int), q->stream));
+        if (flag == 2) {
+            set_error("hnsw_reference_heap_order: a search's `candidates` heap outgrew its scratch (%u entries)", HNSW_REF_CAND_CAP);
+            return QMX_ERR_NOT_SUPPORTED;
+        }
         set_error("point offset out of range for this segment (the reference panics here)");
         return QMX_ERR_OUT_OF_BOUNDS;
     }
@@ -365,6 +370,13 @@ struct ExpandedOut {
     uint32_t xcap;
 };
 
+// qmx_hnsw_search_traced: where the plain walk lists the candidates it pops and expands, with their scores
+struct PopTrace {
+    qmx_scored_point *d_pops;
+    uint32_t *d_cnt;
+    uint32_t cap;
+};
+
 struct MultiWalk {
     const uint32_t *d_qfirst;
     const uint64_t *d_offsets;
@@ -388,7 +400,7 @@ static bool tq_l1(const qmx_segment *s) { return s->dtype == QMX_DTYPE_TQ && s->
 extern "C" {
 int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef, qmx_scored_point *d_out,
                             uint32_t *d_counts, uint32_t *d_scored, bool timed, bool acorn = false, const MultiWalk *mw = nullptr,
-                            const ExpandedOut *xo = nullptr, const CustomWalk *cw = nullptr);
+                            const ExpandedOut *xo = nullptr, const CustomWalk *cw = nullptr, const PopTrace *pt = nullptr);
 int32_t hnsw_check(const qmx_hnsw *g, const qmx_query *q, uint32_t top, uint32_t ef);
 int32_t hnsw_search_sync(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef, qmx_scored_point *out, uint32_t *out_counts,
                                 const volatile uint8_t *is_stopped, qmx_counters *counters, bool acorn);

@@ -365,6 +365,139 @@ struct Beam<0> {
     }
 };
 
+// ---- option hnsw_reference_heap_order: the reference's two binary heaps, worked by ONE lane in std's exact sift order ---------------------
+// `nearest` = FixedLengthPriorityQueue<ScoredPointOffset> = BinaryHeap<Reverse<T>> of at most ef entries (lib/common/common/src/
+// fixed_length_priority_queue.rs:20-65; push :47-59 replaces the root only on strict root < value, through PeekMut = sift_down(0));
+// `candidates` = BinaryHeap<ScoredPointOffset> (search_context.rs:8-40; pop = swap with the last + sift_down_to_bottom(0) + sift_up).
+// ScoredPointOffset orders by OrderedFloat(score) alone, so which of two equal scores a sift moves depends on where they sit in the array:
+// reproducing the arrays is the only way to reproduce the reference's lists among equal scores (integer scorers: SQ, u8, BQ, 1-bit TQ).
+// A verification mode: every heap operation is a chain of dependent loads of one lane; `nearest` sits in LDS, `candidates` (unbounded in
+// the reference) in a per-slot HBM scratch of ref_cap entries.
+struct RefHeaps {
+    uint2 *nd;                 // nearest: x = idx, y = score bits
+    uint2 *cd;                 // candidates
+    uint32_t n_len, n_cap, c_len, c_cap;
+    bool overflow;
+    // OrderedFloat::cmp: NaN is the greatest value and equal to itself
+    static __device__ __forceinline__ int of_cmp(float a, float b) {
+        if (a < b) return -1;
+        if (a > b) return 1;
+        if (a == b) return 0;
+        const bool an = a != a, bn = b != b;
+        if (an && bn) return 0;
+        return an ? 1 : -1;
+    }
+    static __device__ __forceinline__ float sc(uint2 v) { return __uint_as_float(v.y); }
+    static __device__ __forceinline__ int rev_cmp(uint2 a, uint2 b) { return of_cmp(sc(b), sc(a)); }      // Reverse<T>
+    __device__ __forceinline__ void init(unsigned char *lds, uint32_t ef, uint2 *scratch, uint32_t cap) {
+        nd = reinterpret_cast<uint2 *>(lds);
+        cd = scratch;
+        n_len = 0; n_cap = ef ? ef : 1; c_len = 0; c_cap = cap;
+        overflow = false;
+    }
+    // BinaryHeap::sift_up(0, pos) under Reverse
+    __device__ void n_sift_up(uint32_t pos) {
+        const uint2 elt = nd[pos];
+        while (pos > 0) {
+            const uint32_t parent = (pos - 1) / 2;
+            if (rev_cmp(elt, nd[parent]) <= 0) break;
+            nd[pos] = nd[parent];
+            pos = parent;
+        }
+        nd[pos] = elt;
+    }
+    // BinaryHeap::sift_down_range(pos, end) under Reverse
+    __device__ void n_sift_down_range(uint32_t pos, uint32_t end) {
+        const uint2 elt = nd[pos];
+        uint32_t child = 2 * pos + 1;
+        while (end >= 2 && child <= end - 2) {
+            child += rev_cmp(nd[child], nd[child + 1]) <= 0 ? 1u : 0u;
+            if (rev_cmp(elt, nd[child]) >= 0) { nd[pos] = elt; return; }
+            nd[pos] = nd[child];
+            pos = child;
+            child = 2 * pos + 1;
+        }
+        if (end >= 1 && child == end - 1 && rev_cmp(elt, nd[child]) < 0) {
+            nd[pos] = nd[child];
+            pos = child;
+        }
+        nd[pos] = elt;
+    }
+    // FixedLengthPriorityQueue::push -> was the value kept (SearchContext::process_candidate's `was_added`)
+    __device__ bool n_push(uint2 v) {
+        if (n_len < n_cap) {
+            nd[n_len] = v;
+            n_sift_up(n_len);
+            ++n_len;
+            return true;                                   // None
+        }
+        if (of_cmp(sc(nd[0]), sc(v)) < 0) {
+            const uint2 removed = nd[0];
+            nd[0] = v;
+            n_sift_down_range(0, n_len);
+            return removed.x != v.x;                       // Some(removed): removed.idx != score_point.idx
+        }
+        return false;                                      // Some(value): rejected
+    }
+    __device__ void c_push(uint2 v) {
+        if (c_len == c_cap) { overflow = true; return; }
+        uint32_t pos = c_len++;
+        while (pos > 0) {                                  // sift_up(0, pos)
+            const uint32_t parent = (pos - 1) / 2;
+            const uint2 pv = cd[parent];
+            if (of_cmp(sc(v), sc(pv)) <= 0) break;
+            cd[pos] = pv;
+            pos = parent;
+        }
+        cd[pos] = v;
+    }
+    __device__ bool c_pop(uint2 *out) {
+        if (c_len == 0) return false;
+        uint2 item = cd[--c_len];
+        if (c_len > 0) {
+            const uint2 root = cd[0];
+            // sift_down_to_bottom(0) of `item`, then sift_up from where it landed
+            const uint32_t end = c_len;
+            uint32_t pos = 0, child = 1;
+            while (end >= 2 && child <= end - 2) {
+                const uint2 l = cd[child], r = cd[child + 1];
+                const bool right = of_cmp(sc(l), sc(r)) <= 0;
+                cd[pos] = right ? r : l;
+                pos = child + (right ? 1u : 0u);
+                child = 2 * pos + 1;
+            }
+            if (child == end - 1) { cd[pos] = cd[child]; pos = child; }
+            while (pos > 0) {
+                const uint32_t parent = (pos - 1) / 2;
+                const uint2 pv = cd[parent];
+                if (of_cmp(sc(item), sc(pv)) <= 0) break;
+                cd[pos] = pv;
+                pos = parent;
+            }
+            cd[pos] = item;
+            item = root;
+        }
+        *out = item;
+        return true;
+    }
+    // SearchContext::process_candidate (search_context.rs:32-40)
+    __device__ void process_candidate(uint32_t idx, float score) {
+        const uint2 v = make_uint2(idx, __float_as_uint(score));
+        if (n_push(v)) c_push(v);
+    }
+    // into_iter_sorted(): BinaryHeap::into_sorted_vec under Reverse = descending score, in place
+    __device__ uint32_t n_into_sorted() {
+        uint32_t end = n_len;
+        while (end > 1) {
+            --end;
+            const uint2 t = nd[0]; nd[0] = nd[end]; nd[end] = t;
+            n_sift_down_range(0, end);
+        }
+        return n_len;
+    }
+};
+constexpr int HNSW_E_REF = -1;       // the template value of the walk's E that selects this mode
+
 __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -513,6 +646,101 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
 
     // ---- search_on_level(level 0, ef) ----
     const uint32_t ef = h.ef > h.top ? h.ef : h.top;
+    if constexpr (E == HNSW_E_REF) {
+        // ---- option hnsw_reference_heap_order: search_on_level with the reference's own heaps (plain walk only) ----
+        __syncthreads();                    // (the previous search of this block is done with the LDS heap)
+        RefHeaps rh;
+        rh.init(beam_lds, ef, h.ref_cands + (uint64_t)blockIdx.x * h.ref_cap, h.ref_cap);
+        uint32_t log_cnt = 1, n_pop = 0;
+        if (lane == 0) {
+            atomicOr(&vis[cur_id >> 5], 1u << (cur_id & 31));
+            vlog[0] = cur_id >> 5;
+            rh.process_candidate(cur_id, cur_score);
+        }
+        while (true) {
+            uint32_t ok = 0, c_idx = 0, c_bits = 0;
+            if (lane == 0) {
+                uint2 c;
+                if (rh.c_pop(&c)) {
+                    const float lower_bound = rh.n_len ? RefHeaps::sc(rh.nd[0]) : -3.40282347e+38f;     // ScoreType::min_value()
+                    if (!(RefHeaps::sc(c) < lower_bound)) { ok = 1; c_idx = c.x; c_bits = c.y; }
+                }
+            }
+            ok = (uint32_t)__builtin_amdgcn_readfirstlane((int)ok);
+            if (!ok) break;
+            const uint32_t cand = (uint32_t)__builtin_amdgcn_readfirstlane((int)c_idx);
+            if (h.pops) {
+                if (lane == 0 && n_pop < h.pop_cap) {
+                    qmx_scored_point p;
+                    p.idx = cand;
+                    p.score = __uint_as_float(c_bits);
+                    h.pops[(uint64_t)qi * h.pop_cap + n_pop] = p;
+                }
+                ++n_pop;
+            }
+            uint64_t o0 = 0, o1 = 0;
+            uint32_t packed_id = 0;
+            if (h.l0) {
+                const uint32_t *rowp = h.l0 + (uint64_t)cand * h.l0_stride;
+                packed_id = (uint32_t)lane + 1 < h.l0_stride ? rowp[lane + 1] : 0;
+                o1 = rowp[0];
+            } else {
+                o0 = h.offsets[cand];
+                o1 = h.offsets[(uint64_t)cand + 1];
+            }
+            uint32_t remaining = h.m0;
+            for (uint64_t base = o0; base < o1 && remaining > 0; base += 64) {
+                const uint64_t i = base + (uint64_t)lane;
+                const bool on = i < o1;
+                const uint32_t id = h.l0 ? (on ? packed_id : 0) : (on ? h.neighbors[i] : 0);
+                const bool live = on && id < h.n_points && a.del.live(id);
+                const uint32_t bit = 1u << (id & 31);
+                const uint32_t old = live ? atomicOr(&vis[id >> 5], bit) : bit;
+                bool keep = live && !(old & bit);
+                const uint64_t mask = __ballot(keep);
+                const uint32_t rank = (uint32_t)__popcll(mask & lt_mask);
+                uint32_t k = (uint32_t)__popcll(mask);
+                if (k > remaining) {
+                    if (keep && rank >= remaining) { atomicAnd(&vis[id >> 5], ~bit); keep = false; }
+                    k = remaining;
+                }
+                remaining -= k;
+                __syncthreads();
+                if (keep) {
+                    hop_ids[rank] = id;
+                    if (log_cnt + rank < h.log_cap) vlog[log_cnt + rank] = id >> 5;
+                }
+                log_cnt += k;
+                hop_score<H>(a, qp, hop_ids, hop_scores, k, lane);
+                if (lane == 0)
+                    for (uint32_t j = 0; j < k; ++j) rh.process_candidate(hop_ids[j], hop_scores[j]);      // in link order (graph_layers.rs:139-143)
+                n_scored += k;
+                __syncthreads();
+            }
+        }
+        if (lane == 0) {
+            const uint32_t n = rh.n_into_sorted();
+            const uint32_t cnt = n < h.top ? n : h.top;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                qmx_scored_point p;
+                p.idx = rh.nd[i].x;
+                p.score = RefHeaps::sc(rh.nd[i]);
+                h.out[(uint64_t)qi * h.top + i] = p;
+            }
+            h.out_counts[qi] = cnt;
+            if (h.out_scored) h.out_scored[qi] = n_scored;
+            if (h.pops) h.pop_cnt[qi] = n_pop;
+            if (rh.overflow) *a.err_flag = 2;
+        }
+        __syncthreads();
+        if (log_cnt <= h.log_cap) {
+            for (uint32_t i = (uint32_t)lane; i < log_cnt; i += 64) vis[vlog[i]] = 0;
+        } else {
+            for (uint64_t w = (uint64_t)lane; w < h.vis_words; w += 64) vis[w] = 0;
+        }
+        __threadfence();
+        return;
+    } else {
     Beam<E> beam;
     if constexpr (E == 0) {
         __syncthreads();                    // (the previous search of this block is done with the LDS list)
@@ -686,6 +914,15 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
             if (lane == 0 && n_exp < h.xcap) h.expanded[(uint64_t)qi * h.xcap + n_exp] = cand;
             ++n_exp;
         }
+        if (h.pops) {     // qmx_hnsw_search_traced: the pop sequence (n_exp doubles as its counter: `expanded` and `pops` are never both set)
+            if (lane == 0 && n_exp < h.pop_cap) {
+                qmx_scored_point p;
+                p.idx = cand;
+                p.score = key_score(ck);
+                h.pops[(uint64_t)qi * h.pop_cap + n_exp] = p;
+            }
+            ++n_exp;
+        }
         // links of `cand` on level 0: the packed table needs ONE round trip (count and links are independent loads of the
         // same row), the CSR arrays two (offsets, then neighbors)
         uint64_t o0 = 0, o1 = 0;
@@ -749,6 +986,7 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
         }
         if (lane == 0) h.expanded_cnt[qi] = n_exp;
     }
+    if (h.pops && lane == 0) h.pop_cnt[qi] = n_exp;
     }
 
     // ---- nearest.into_iter_sorted().take(top) ----
@@ -795,6 +1033,7 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
         for (uint64_t w = (uint64_t)lane; w < h.vis_words; w += 64) vis[w] = 0;
     }
     __threadfence();
+    }   // E != HNSW_E_REF
 }
 
 template <class H, int E, bool QLDS>
@@ -805,7 +1044,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const ScanArgs a, const
     uint32_t *hop_ids = reinterpret_cast<uint32_t *>(smem);
     float *hop_scores = reinterpret_cast<float *>(smem + 4 * (size_t)h.hop_cap);
     unsigned char *q_lds = smem + 8 * (size_t)h.hop_cap + hnsw_acorn_lds(h.acorn, h.m0);
-    unsigned char *beam_lds = q_lds + (QLDS ? ((size_t)h.lds_query_bytes + 15) / 16 * 16 : 0);      // E == 0: the LDS beam behind the query entry
+    unsigned char *beam_lds = q_lds + (QLDS ? ((size_t)h.lds_query_bytes + 15) / 16 * 16 : 0);      // E == 0: the LDS beam behind the query entry (E == HNSW_E_REF: `nearest`)
     uint32_t *vis = h.visited + (uint64_t)blockIdx.x * h.vis_words;
     uint32_t *vlog = h.vis_log + (uint64_t)blockIdx.x * h.log_cap;
     for (uint32_t qi = blockIdx.x; qi < h.nq; qi += gridDim.x) {
@@ -915,7 +1154,7 @@ int32_t hnsw_occupancy_inst(uint32_t lds_query_bytes, size_t hop_lds, int *per_c
 template <class H, int E, bool QLDS>
 int32_t launch_hnsw_inst(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid) {
     const uint32_t ef = h.ef > h.top ? h.ef : h.top;
-    const size_t lds = 8 * (size_t)h.hop_cap + hnsw_acorn_lds(h.acorn, h.m0) + (QLDS ? ((size_t)h.lds_query_bytes + 15) / 16 * 16 : 0) + (E == 0 ? hnsw_beam_lds(ef) : 0);
+    const size_t lds = 8 * (size_t)h.hop_cap + hnsw_acorn_lds(h.acorn, h.m0) + (QLDS ? ((size_t)h.lds_query_bytes + 15) / 16 * 16 : 0) + (E <= 0 ? hnsw_beam_lds(ef) : 0);
     QMX_REQUIRE(lds <= 160 * 1024, QMX_ERR_NOT_SUPPORTED, "hnsw walk: %zu bytes of LDS (query entry + a list of %u)", lds, ef);
     ::qmx::clear_stale_error();
     QMX_NOTE_KERNEL((hnsw_search_kernel<H, E, QLDS>));
@@ -923,6 +1162,12 @@ int32_t launch_hnsw_inst(hipStream_t st, const ScanArgs &a, const HnswArgs &h, u
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }
+
+// the policies option hnsw_reference_heap_order is instantiated for: the plain single-vector walks (dense, SQ, PQ, BQ, TurboQuant)
+template <class H>
+struct ref_heaps_built {
+    static constexpr bool value = !is_custom<H>::value && !is_maxsim<H>::value && !is_maxsim_q<H>::value && !is_maxsim_internal<H>::value && !is_tql1<H>::value;
+};
 
 // grid == 0: only report the occupancy in *per_cu (no launch)
 template <class H>
@@ -932,6 +1177,17 @@ int32_t launch_hnsw_hop(hipStream_t st, const ScanArgs &a, const HnswArgs &h, ui
     const bool qlds = h.lds_query_bytes > 0;
     if constexpr (is_maxsim<H>::value) QMX_REQUIRE(qlds, QMX_ERR_NOT_SUPPORTED, "the inner vectors of a multi-query must fit the LDS");
     if constexpr (is_custom<H>::value) QMX_REQUIRE(h.lds_query_bytes >= sizeof(CustomHeader), QMX_ERR_OTHER, "the custom walk keeps its header in LDS");
+    if (h.ref_heaps) {      // option hnsw_reference_heap_order: the plain walk of the policies a stored graph is walked with
+        if constexpr (ref_heaps_built<H>::value) {
+            QMX_REQUIRE(!h.acorn && !h.expanded, QMX_ERR_NOT_SUPPORTED, "hnsw_reference_heap_order: the plain walk only (not ACORN, not search_with_vectors)");
+            const size_t hop_lds = 8 * (size_t)h.hop_cap + hnsw_beam_lds(ef);
+            if (grid == 0) return qlds ? hnsw_occupancy_inst<H, HNSW_E_REF, true>(h.lds_query_bytes, hop_lds, per_cu) : hnsw_occupancy_inst<H, HNSW_E_REF, false>(0, hop_lds, per_cu);
+            return qlds ? launch_hnsw_inst<H, HNSW_E_REF, true>(st, a, h, grid) : launch_hnsw_inst<H, HNSW_E_REF, false>(st, a, h, grid);
+        } else {
+            set_error("hnsw_reference_heap_order: not built for this scorer (custom queries, multi-vector points, TurboQuant over Manhattan)");
+            return QMX_ERR_NOT_SUPPORTED;
+        }
+    }
     if (ef > HNSW_MAX_EF_REG) {        // the LDS beam: one instantiation per policy, the query entry staged
         QMX_REQUIRE(qlds, QMX_ERR_NOT_SUPPORTED, "hnsw ef %u > %u needs the query entry in LDS (it does not fit)", ef, HNSW_MAX_EF_REG);
         if (grid == 0) return hnsw_occupancy_inst<H, 0, true>(h.lds_query_bytes, 8 * (size_t)h.hop_cap + hnsw_acorn_lds(h.acorn, h.m0) + hnsw_beam_lds(ef), per_cu);

@@ -125,6 +125,15 @@ struct HnswArgs {
     uint32_t *expanded;             // [nq][xcap] or nullptr
     uint32_t *expanded_cnt;         // [nq] popped candidates (may exceed xcap: the list is then incomplete)
     uint32_t xcap;
+    // the plain walk's pop sequence (qmx_hnsw_search_traced): every candidate the level-0 loop pops AND expands, in order, with its score
+    qmx_scored_point *pops;         // [nq][pop_cap] or nullptr
+    uint32_t *pop_cnt;              // [nq] (may exceed pop_cap: the list is then incomplete)
+    uint32_t pop_cap;
+    // option hnsw_reference_heap_order (a verification mode): `nearest` and `candidates` are the reference's two binary heaps, worked by one lane
+    // in std's exact sift order; `nearest` lives in LDS, `candidates` (unbounded in the reference) in this per-slot scratch
+    uint32_t ref_heaps;
+    uint32_t ref_cap;               // entries of a slot's candidates heap; a search that needs more raises err_flag = 2
+    uint2 *ref_cands;               // [slots][ref_cap]  (x = idx, y = score bits)
 };
 
 // The PQ walk with one BLOCK per search (hnsw_pq_block.hip): the LUT in LDS, a controller wave and speculating worker waves.  pq_block_walk_ok: whether this
@@ -189,6 +198,8 @@ int32_t launch_hnsw_sq(hipStream_t st, int distance, const ScanArgs &a, const Hn
 int32_t launch_hnsw_pq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_bq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_pack_level0(hipStream_t st, const uint64_t *offsets, const uint32_t *neighbors, uint32_t n_points, uint32_t stride, uint32_t *l0);
+constexpr uint32_t HNSW_REF_CAND_CAP = 1u << 16;   // option hnsw_reference_heap_order: entries of one search's `candidates` heap (512 KiB per slot)
+constexpr uint32_t HNSW_REF_SLOT_CAP = 1024;       // ... searches in flight in that mode
 constexpr uint32_t HNSW_MAX_EF = 4096;          // max(top, ef) of a walk: up to 512 in a register beam, beyond it in an LDS beam (hnsw.hpp Beam<0>)
 constexpr uint32_t HNSW_BUILD_MAX_M0 = 128;     // links per level-0 list of a device build (m <= m0 <= 128)
 constexpr uint32_t HNSW_MAX_EF_REG = 512;       // ... and of ef_construct (the build keeps its beam in registers)

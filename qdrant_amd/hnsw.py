@@ -199,6 +199,24 @@ class GraphLayers:
         res = [out[i, :counts[i]].copy() for i in range(nq)]
         return (res, int(self.counters.vectors_scored)) if with_scored else res
 
+    def search_traced(self, top: int, ef: int, points_scorer: RawScorer, pop_cap: int = 0):
+        """`search` that also returns, per query, the candidates `search_on_level` popped and expanded on level 0, in order, with their scores
+        (qmx_hnsw_search_traced) -> (lists, pops).  Two walks of one graph agree as long as their pop sequences agree; where they first differ,
+        the two popped candidates show why (equal scores = the reference's heap order among ties).  With
+        `set_option("hnsw_reference_heap_order", 1)` the walk keeps the reference's two binary heaps and returns ITS lists among equal scores."""
+        nq = points_scorer.nq
+        cap = int(pop_cap) if pop_cap else 32 * max(top, ef) + 256
+        out = np.zeros((nq, max(top, 1)), dtype=ScoredPointOffset)
+        counts = np.zeros(nq, dtype=np.uint32)
+        while True:
+            pops = np.zeros((nq, cap), dtype=ScoredPointOffset)
+            pcnt = np.zeros(nq, dtype=np.uint32)
+            F.check(F.lib().qmx_hnsw_search_traced(self._h, points_scorer._h, top, ef, F.ptr(out), F.ptr(counts), F.ptr(pops), cap, F.ptr(pcnt)))
+            if int(pcnt.max(initial=0)) <= cap:
+                break
+            cap = int(pcnt.max())          # (the walk is deterministic: the second run pops the same candidates, now all listed)
+        return [out[i, :counts[i]].copy() for i in range(nq)], [pops[i, :pcnt[i]].copy() for i in range(nq)]
+
     def search_with_vectors(self, top: int, ef: int, links_scorer: RawScorer, base_scorer: RawScorer, is_stopped=None, with_scored: bool = False,
                             raw_output: bool = False):
         """`GraphLayers::search_with_vectors(top, ef, links_scorer, links_scorer_bytes, base_scorer, None, is_stopped)` (graph_layers.rs:564-596):

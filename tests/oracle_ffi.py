@@ -443,6 +443,7 @@ _sig("qo_hnsw_import_plain", _P, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32
 _sig("qo_hnsw_export_plain", None, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _P, _P, _P, _P])
 _sig("qo_hnsw_search", C.c_uint32, [_P, C.POINTER(Scorer), C.c_uint32, C.c_uint32, _P, C.POINTER(C.c_uint64)])
 _sig("qo_hnsw_search_algo", C.c_uint32, [_P, C.POINTER(Scorer), C.c_uint32, C.c_uint32, C.c_int, _P, C.POINTER(C.c_uint64)])
+_sig("qo_hnsw_search_traced", C.c_uint32, [_P, C.POINTER(Scorer), C.c_uint32, C.c_uint32, _P, C.POINTER(C.c_uint64), _P, C.c_uint32, C.POINTER(C.c_uint32)])
 _sig("qo_hnsw_search_with_vectors", C.c_uint32, [_P, C.POINTER(Scorer), C.POINTER(Scorer), C.c_uint32, C.c_uint32, _P, C.POINTER(C.c_uint64),
                                                  C.POINTER(C.c_uint64)])
 _sig("qo_links_heuristic", C.c_uint32, [_P, C.c_uint32, C.c_uint32, _P, C.c_uint32, _P])
@@ -618,9 +619,21 @@ class Hnsw:
     # -- searches: one qo_scorer per query ------------------------------------------------------------
     algorithm = 0      # SearchAlgorithm: 0 = Hnsw, 1 = Acorn (set on the instance for a run)
 
+    pops = None        # a list: every search appends the candidates its level-0 loop popped and expanded (qo_hnsw_search_traced; plain walk only)
+
     def _run(self, scorer, top, ef):
         out = np.zeros(max(top, 1), dtype=ScoredPointOffset)
         ns = C.c_uint64()
+        if self.pops is not None and self.algorithm == 0:
+            cap, npop = 32 * max(top, ef) + 256, C.c_uint32()
+            while True:
+                tr = np.zeros(cap, dtype=ScoredPointOffset)
+                n = _lib.qo_hnsw_search_traced(self.h, C.byref(scorer), top, ef, _p(out), C.byref(ns), _p(tr), cap, C.byref(npop))
+                if npop.value <= cap:
+                    break
+                cap = npop.value
+            self.pops.append(tr[:npop.value].copy())
+            return out[:n].copy(), ns.value
         n = _lib.qo_hnsw_search_algo(self.h, C.byref(scorer), top, ef, self.algorithm, _p(out), C.byref(ns))
         return out[:n].copy(), ns.value
 

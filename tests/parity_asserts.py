@@ -55,3 +55,33 @@ def assert_reference_lists(got, storage, queries, top, live=None, extra=64, thre
             n_tied_boundaries += 1
         assert gi[~above].tolist() == np.sort(group)[:m].tolist(), (qi, gi[~above].tolist(), np.sort(group)[:m + 4].tolist())
     return n_tied_boundaries
+
+
+def first_divergence_is_a_tie(got_pops, want_pops, bound_score=None):
+    """Two pop sequences of `search_on_level` over ONE graph (structured arrays idx / score: qmx_hnsw_search_traced on the device,
+    qo_hnsw_search_traced in the oracle).  A walk is a deterministic function of its pop sequence, so:
+      "same"  the sequences are equal: the walks are the same walk;
+      "tie"   at the first position where they differ both popped candidates carry bit-equal scores (each walk picked another of several equal
+              candidates: the reference by the arrangement of its BinaryHeap, the device by ascending id) - or one sequence ends there and the other pops
+              one more candidate whose score is bit-equal to `bound_score` (the worst score of the full `nearest` list at that moment: the reference
+              breaks on strict `candidate.score < lower_bound` only, graph_layers.rs:126, so a candidate EQUAL to the bound is still expanded when it
+              is still in `candidates`; which of several candidates equal to the bound is still there is again the heap's choice);
+      anything else ("scores differ at i: ...") is a defect."""
+    n = min(len(got_pops), len(want_pops))
+    gi, wi = got_pops["idx"][:n], want_pops["idx"][:n]
+    gs, ws = got_pops["score"][:n].view(np.uint32), want_pops["score"][:n].view(np.uint32)
+    diff = np.nonzero(gi != wi)[0]
+    if len(diff):
+        i = int(diff[0])
+        if not np.array_equal(gs[:i], ws[:i]):
+            return "scores differ before the first id difference (%d)" % i
+        return "tie" if gs[i] == ws[i] else "scores differ at %d: %r vs %r" % (i, got_pops[i], want_pops[i])
+    if not np.array_equal(gs, ws):
+        return "equal ids with different scores"
+    if len(got_pops) == len(want_pops):
+        return "same"
+    longer = got_pops if len(got_pops) > len(want_pops) else want_pops
+    if bound_score is None:
+        return "one sequence ends at %d and no bound was given" % n
+    extra = np.float32(longer["score"][n]).view(np.uint32)
+    return "tie" if extra == np.float32(bound_score).view(np.uint32) else "one sequence ends at %d, the other pops %r (bound %r)" % (n, longer[n], bound_score)

@@ -446,6 +446,48 @@ def _timed_quantized(ctx, scorer, raw, top, oversampling, rescore, graph, ef, re
                  "wall_ms_per_search": round(wall * 1e3, 3), "qps_wall": round(scorer.nq / wall, 1), "roofline": roof}, scored / float(reps)
 
 
+def _oracle_walk_check(qa, np, graph, scorer, walker, oracle_walk, nchk, top, ef):
+    """The CPU oracle walks THE SAME graph with its scorer (host copy of the codes + links).  Three comparisons over `nchk` searches:
+      default walk      same_ids / same_score_bits of the first `top` results (the device orders equal scores by ascending id: lists may differ at ties);
+      tie_explained     per search whose pop sequence differs from the oracle's: the first differing position holds two bit-equal scores
+                        (tests/parity_asserts.first_divergence_is_a_tie) - anything else is printed as a PARITY FAILURE and listed;
+      reference order   option hnsw_reference_heap_order (the reference's two binary heaps on the device): lists AND pop sequences must be the oracle's.
+    Walks run with top = ef so that the returned list is the whole `nearest` (its last score is the bound when a walk ends)."""
+    from parity_asserts import first_divergence_is_a_tie
+    bits = lambda x: np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)      # noqa: E731
+    t0 = time.perf_counter()
+    walker.pops = []
+    want = oracle_walk(ef, ef)
+    want_pops, walker.pops = walker.pops, None
+    got, got_pops = graph.search_traced(ef, ef, scorer)
+    same_ids = sum(int(a["idx"][:top].tolist() == b["idx"][:top].tolist()) for a, b in zip(got, want))
+    same_bits = sum(int(np.array_equal(bits(a["score"][:top]), bits(b["score"][:top]))) for a, b in zip(got, want))
+    differing, explained, bad = 0, 0, []
+    for qi in range(nchk):
+        v = first_divergence_is_a_tie(got_pops[qi], want_pops[qi], bound_score=got[qi]["score"][-1] if len(got[qi]) == ef else None)
+        if v != "same":
+            differing += 1
+            explained += v == "tie"
+            if v != "tie":
+                bad.append("search %d: %s" % (qi, v))
+    out = {"same_ids": "%d/%d" % (same_ids, nchk), "same_score_bits": "%d/%d" % (same_bits, nchk),
+           "pop_sequences_equal": "%d/%d" % (nchk - differing, nchk), "tie_explained": "%d/%d" % (explained, differing)}
+    if bad:
+        out["unexplained"] = bad[:8]
+        print("PARITY FAILURE: HNSW walk differs from the oracle away from a tie: %s" % bad[:3], file=sys.stderr)
+    qa.set_option("hnsw_reference_heap_order", 1)
+    try:
+        ref, ref_pops = graph.search_traced(ef, ef, scorer)
+    finally:
+        qa.set_option("hnsw_reference_heap_order", -1)
+    out["reference_heap_order_same_ids"] = "%d/%d" % (sum(int(a["idx"].tolist() == b["idx"].tolist()) for a, b in zip(ref, want)), nchk)
+    out["reference_heap_order_same_score_bits"] = "%d/%d" % (sum(int(np.array_equal(bits(a["score"]), bits(b["score"]))) for a, b in zip(ref, want)), nchk)
+    out["reference_heap_order_same_pops"] = "%d/%d" % (sum(int(a["idx"].tolist() == b["idx"].tolist() and np.array_equal(bits(a["score"]), bits(b["score"])))
+                                                           for a, b in zip(ref_pops, want_pops)), nchk)
+    out["seconds"] = round(time.perf_counter() - t0, 1)
+    return out
+
+
 def c3_section(ctx, rows):
     """BASELINE.json configs[2]: 10 M x 768 SQ-int8, dot; brute force + HNSW rescoring."""
     args, dev, lib, F, qa, np, torch = (ctx[k] for k in ("args", "dev", "lib", "F", "qa", "np", "torch"))
@@ -536,13 +578,10 @@ def c3_section(ctx, rows):
             walker = O.Hnsw.from_plain(graph.export_plain(), n)
             flags = O.DenseStorage(O.F32, O.DOT, np.zeros((1, dim), dtype=np.float32))
             flags.st.n = n
-            nchk = min(256, int(queries.shape[0]))      # (16 searches were thin evidence at 10 M rows)
-            want = walker.search_sq(flags, osq_all, queries[:nchk].cpu().numpy(), 2 * top, 128)
-            got = graph.search(2 * top, 128, qa.new_raw_scorer(queries[:nchk].contiguous(), enc))
-            st["oracle_walk_check"] = {"same_ids": "%d/%d" % (sum(int(a["idx"].tolist() == b["idx"].tolist()) for a, b in zip(got, want)), nchk),
-                                       "same_score_bits": "%d/%d" % (sum(int(np.array_equal(a["score"].view(np.uint32), b["score"].view(np.uint32)))
-                                                                         for a, b in zip(got, want)), nchk),
-                                       "seconds": round(time.perf_counter() - t0, 1)}
+            nchk = min(256, int(queries.shape[0]))
+            qchk = queries[:nchk].cpu().numpy()
+            st["oracle_walk_check"] = _oracle_walk_check(qa, np, graph, qa.new_raw_scorer(queries[:nchk].contiguous(), enc), walker,
+                                                         lambda t, e: walker.search_sq(flags, osq_all, qchk, t, e), nchk, 2 * top, 128)
             del osq_all, walker
         except Exception as e:
             st["oracle_walk_check"] = {"error": repr(e)[:300]}
@@ -707,17 +746,17 @@ def c4_section(ctx):
             # with the exact-order LUT for bits, and report how the MFMA-LUT walk compares
             quant_exact = qa.ProductQuantizer(dim, qa.Distance.Dot, chunk, cen_h, lut_mfma=False)
             enc_exact = qa.EncodedVectorsPQ(codes, quant_exact)
+            chk = _oracle_walk_check(qa, np, graph, qa.new_raw_scorer(queries[:nchk].contiguous(), enc_exact), walker,
+                                     lambda t, e: walker.search_pq(flags, opq, qpre, t, e), nchk, 2 * top, 128)
             want = walker.search_pq(flags, opq, qpre, 2 * top, 128)
-            got = graph.search(2 * top, 128, qa.new_raw_scorer(queries[:nchk].contiguous(), enc_exact))
             got_mfma = graph.search(2 * top, 128, qa.new_raw_scorer(queries[:nchk].contiguous(), enc))
-            hn["oracle_walk_check"] = {"codes_byte_exact_first_1000": enc_ok,
-                                       "exact_lut_same_ids": "%d/%d" % (sum(int(a["idx"].tolist() == b["idx"].tolist()) for a, b in zip(got, want)), nchk),
-                                       "exact_lut_same_score_bits": "%d/%d" % (sum(int(np.array_equal(a["score"].view(np.uint32), b["score"].view(np.uint32)))
-                                                                                   for a, b in zip(got, want)), nchk),
-                                       "mfma_lut_same_id_sets": "%d/%d" % (sum(int(set(a["idx"].tolist()) == set(b["idx"].tolist())) for a, b in zip(got_mfma, want)), nchk),
-                                       "mfma_lut_max_rel_score_err": float(max(np.max(np.abs(a["score"][:min(len(a), len(b))] - b["score"][:min(len(a), len(b))]) /
-                                                                                      np.maximum(np.abs(b["score"][:min(len(a), len(b))]), 1e-30)) for a, b in zip(got_mfma, want))),
-                                       "seconds": round(time.perf_counter() - t0, 1)}
+            chk.pop("seconds")
+            hn["oracle_walk_check"] = dict({"codes_byte_exact_first_1000": enc_ok, "exact_lut_same_ids": chk.pop("same_ids"),
+                                            "exact_lut_same_score_bits": chk.pop("same_score_bits")}, **chk,
+                                           mfma_lut_same_id_sets="%d/%d" % (sum(int(set(a["idx"].tolist()) == set(b["idx"].tolist())) for a, b in zip(got_mfma, want)), nchk),
+                                           mfma_lut_max_rel_score_err=float(max(np.max(np.abs(a["score"][:min(len(a), len(b))] - b["score"][:min(len(a), len(b))]) /
+                                                                                       np.maximum(np.abs(b["score"][:min(len(a), len(b))]), 1e-30)) for a, b in zip(got_mfma, want))),
+                                           seconds=round(time.perf_counter() - t0, 1))
         except Exception as e:
             hn["oracle_walk_check"] = {"error": repr(e)[:300]}
     out["hnsw_pq_walk"] = hn
