@@ -162,15 +162,14 @@ def _leg(st):
     bound, frac = r.get("bound"), r.get("frac")
     if "lds" in r:                      # a kernel priced against the LDS issue roof carries that fraction (its HBM fraction stays in the details)
         bound, frac = "lds", r["lds"].get("frac")
-    return [_short(st.get("kernel", ""), 34).replace("_kernel", ""), st.get("kernel_ms"), bound, frac, st.get("qps_wall"), st.get("recall_at_10_vs_exact")]
+    return [_short(st.get("kernel", "")).replace("_kernel", "")[:24], st.get("kernel_ms"), bound, frac, st.get("qps_wall"), st.get("recall_at_10_vs_exact")]
 
 
 def _block_stream(p):
     if not isinstance(p, dict) or "error" in p or "kernel_ms" not in p:
         return None
     return {"kernel": _short(p["kernel"]), "batch": p["batch"], "kernel_ms": p["kernel_ms"], "launches": p.get("launches_timed"),
-            "algorithmic_bytes": p["algorithmic_bytes_per_launch"], "GBps": p["achieved"], "frac": p["frac"],
-            "traffic_over_algorithmic": p.get("traffic_over_algorithmic")}
+            "algorithmic_bytes": p["algorithmic_bytes_per_launch"], "frac": p["frac"], "traffic_over_algorithmic": p.get("traffic_over_algorithmic")}
 
 
 def compact_roofline(result):
@@ -195,10 +194,10 @@ def compact_roofline(result):
     else:
         p = result["roofline_hbm_point_q16"]
         out = {"bound": "hbm", "achieved": p["achieved"], "peak": p["peak"], "unit": "GB/s", "frac": p["frac"], "traffic": p.get("traffic"),
-               "of": "block_stream: SURVEY 8(d), the exact scan streaming the stored f32 block once for %d queries; same run" % bs["batch"],
+               "of": "block_stream: SURVEY 8(d), the exact scan over the stored f32 block, %d queries; same run" % bs["batch"],
                "block_stream": bs}
         if bs1:
-            out["block_stream_q1"] = bs1
+            out["block_stream_q1"] = _pick(bs1, "kernel", "batch", "kernel_ms", "frac", "traffic_over_algorithmic")
     out["timed_kernel"] = timed
     return out
 
@@ -210,14 +209,14 @@ def _walk_summary(ow):
     if "error" in ow:
         return {"error": str(ow["error"])[:80]}
     g = lambda *ks: next((ow[k] for k in ks if k in ow), None)      # noqa: E731
-    out = {"default_walk": "%s ids, %s score bits" % (g("same_ids", "exact_lut_same_ids"), g("same_score_bits", "exact_lut_same_score_bits"))}
+    out = {"default_walk": "ids %s, bits %s" % (g("same_ids", "exact_lut_same_ids"), g("same_score_bits", "exact_lut_same_score_bits"))}
     if "tie_explained" in ow:
         out["tie_explained"] = ow["tie_explained"]
     if "unexplained" in ow:
         out["unexplained"] = len(ow["unexplained"])
     if "reference_heap_order_same_ids" in ow:
-        out["reference_heap_order"] = "%s ids, %s score bits, %s pop sequences" % (ow["reference_heap_order_same_ids"], ow.get("reference_heap_order_same_score_bits"),
-                                                                                  ow.get("reference_heap_order_same_pops"))
+        out["reference_heap_order"] = "ids %s, bits %s, pops %s" % (ow["reference_heap_order_same_ids"], ow.get("reference_heap_order_same_score_bits"),
+                                                                   ow.get("reference_heap_order_same_pops"))
     if "mfma_lut_same_id_sets" in ow:
         out["mfma_lut_same_id_sets"] = ow["mfma_lut_same_id_sets"]
     return out
@@ -273,20 +272,22 @@ def headline(result, details_path=None):
     h["vs_baseline"] = result.get("vs_baseline")
     h.update(_pick(result, "dtype", "data", "rccl_ranks", "collective"))
     c = result.get("config", {})
-    hc = _pick(c, "workload", "rows_per_gpu", "dim", "batch", "top", "batches_in_flight", "collection_qps")
+    hc = _pick(c, "workload", "rows_per_gpu", "dim", "batch", "top", "batches_in_flight")
+    if result.get("n_gpus", 1) > 1:
+        hc["collection_qps"] = c.get("collection_qps")
     if "timed_path" in c:
-        hc["timed_path"] = c["timed_path"].split(":")[0][:150]
+        hc["timed_path"] = c["timed_path"].split(":")[0].replace(" of the block (1 B / element, int8 matrix cores)", "").replace(" of the survivors", "")[:100]
     dc = c.get("derived_copy")
     if isinstance(dc, dict):
         hc["derived_copy"] = "%s (requested %s%s)" % (dc.get("derived_copy"), dc.get("requested"),
-                                                      ", library's trial: i8 %.3f ms, half %.3f ms" % (dc.get("trial_i8_ms", 0.0), dc.get("trial_half_ms", 0.0))
+                                                      "; trial: i8 %.2f ms, half %.2f ms" % (dc.get("trial_i8_ms", 0.0), dc.get("trial_half_ms", 0.0))
                                                       if dc.get("chosen_by_trial") else "")
     h["config"] = hc
     h["roofline"] = compact_roofline(result)
     cb = result.get("cpu_baseline")
     if isinstance(cb, dict):
         h["cpu_baseline"] = _pick(cb, "value", "unit", "cores", "kind")
-        h["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:72]
+        h["cpu_baseline"]["sample"] = str(cb.get("sample_short", cb.get("sample", "")))[:64]
         if "single_thread" in cb:
             h["cpu_baseline"]["single_thread_value"] = cb["single_thread"].get("value")
         h["cpu_baseline"]["gpu_matches_oracle_on_sample_bit_exact"] = cb.get("gpu_matches_oracle_on_sample_bit_exact")

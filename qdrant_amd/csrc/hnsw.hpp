@@ -1036,8 +1036,11 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
     }   // E != HNSW_E_REF
 }
 
+#ifndef QMX_WALK_KERNEL_ATTR
+#define QMX_WALK_KERNEL_ATTR
+#endif
 template <class H, int E, bool QLDS>
-__global__ __launch_bounds__(64) void hnsw_search_kernel(const ScanArgs a, const HnswArgs h) {
+__global__ __launch_bounds__(64) QMX_WALK_KERNEL_ATTR void hnsw_search_kernel(const ScanArgs a, const HnswArgs h) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     // [hop ids: hop_cap u32][hop scores: hop_cap f32][ACORN: 64 ids to explore][query entry]

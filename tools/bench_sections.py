@@ -374,6 +374,7 @@ def cpu_baseline(args, rows, queries, out, counts, n, dim, Q, top, lib, qh, F, q
             print("PARITY FAILURE: GPU top-k differs from the oracle on the CPU sample", file=sys.stderr)
     flops = 2.0 * dim
     return {"value": round(cpu_qps, 3), "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample_short": "oracle peek_top_iter, first %s of %s rows, Q=%d, scaled" % (_human(S), _human(n), Q),
             "kind_note": "the oracle's C restatement of the reference's AVX2+FMA scorer and peek_top_iter loop, not the Rust binary (no cargo in the image)",
             "sample": "oracle peek_top_iter (AVX2+FMA dot, 64-id chunks, heap of %d) over the first %d of %d rows, Q=%d, "
                       "%d threads on disjoint row ranges (usable cores: affinity + cgroup quota; os.cpu_count() = %d), %d scans in %.1f s; "
