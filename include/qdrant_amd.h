@@ -139,7 +139,9 @@ typedef struct qmx_counters {
  * pays the prefilter AND the exact scan).  So the choice is measured at create: the int8 copy is built, 128 stored rows (a strided sample: queries
  * distributed like the rows) are searched through it, and unless they verify few rows each the half copy is built beside it, the same batch is timed
  * through both and the faster copy stays (the other is freed).  Costs ~50 - 100 ms per 10 M x 768 block on top of the copies' passes; what was
- * chosen and what the trial measured: qmx_segment_get_info.  Results are the reference's bits either way. */
+ * chosen and what the trial measured: qmx_segment_get_info (0 ms = that trial did not run or failed).  Results are the reference's bits either way.
+ * The choice is TIMING-dependent: other work on the device during the trial can tip it, so the half copy must beat the int8 copy by 10 % to replace it,
+ * and callers must not assert on which copy a segment holds - only footprint and latency differ. */
 #define QMX_SEG_AUTO_COPY 0x80u
 /* PQ blocks of 2^18 rows and more carry a rotated copy of their codes (ceil32(m) bytes per row) that the 8-bit prefilter of batches of 4 and more
  * queries scans (pq_prefilter.hip).  It is built by default when it at most doubles the codes' footprint (m >= 16); this flag asks for it on narrower
@@ -297,7 +299,7 @@ QMX_API uint32_t qmx_abi_version(void);
  * "no_mfma16_q64", "no_prescan", "prescan_shift", "hnsw_no_packed_l0", "hnsw_pq_lds_lut", "hnsw_log_cap", "bq_lanes8",
  * "mfma_no_nt", "mfma_no_fast", "no_pq_tiled", "no_split_scan", "split_min_queries", "no_split256", "no_pq_pair", "no_pq_prefilter",
  * "pq_prefilter_min_queries", "hnsw_pq_per_cu", "tq_rotate_block", "no_topk_small", "verify_max_per_query", "no_hnsw_pq_block", "hnsw_pq_block_waves",
- * "hnsw_pq_block_set", "sq_mfma_no_stage", "sq_mfma_no_llist", "pq_prefilter_w16" (read at segment create), "hnsw_pq_direct_walk", "hnsw_pq_table_build", "i8_scan_deep", "debug"
+ * "hnsw_pq_block_set", "sq_mfma_no_stage", "sq_mfma_no_llist", "pq_prefilter_w16" (read at segment create), "hnsw_pq_direct_walk", "hnsw_pq_table_build", "i8_scan_deep", "hnsw_spec", "debug"
  * - and one that selects the ORDER AMONG EQUAL SCORES of the plain HNSW walk: "hnsw_reference_heap_order" (see qmx_hnsw_search_traced) -
  * (qdrant_amd/csrc/common.hpp says what each selects; several are experiments that measured slower and stay opt-in).  Initial values come from the environment variables QMX_<NAME> read
  * ONCE when the library is loaded; value < 0 restores that initial value.  Unknown name => QMX_ERR_BAD_ARG.  (No reference

@@ -1,6 +1,8 @@
 // api_hnsw.hip — the C-ABI of include/qdrant_amd.h, HNSW graphs: create / import, the walks, the device build.
 // (One of the api_*.hip translation units; what they share: api_internal.hpp.)
 #include "api_internal.hpp"
+#include <algorithm>
+#include <atomic>
 
 extern "C" {
 
@@ -284,8 +286,19 @@ int32_t qmx_hnsw_build_quantized(const qmx_segment *seg, const qmx_segment *orig
 
 // Build fan-out over independent segments (gpu_devices_manager.rs:120-143 + hnsw/build.rs:53: one device locked per segment build, builds share nothing):
 // one host thread per segment, each driving its segment's device; the thread's own error text travels back with its status.
+static int32_t sharded_hnsw_build_body(const qmx_segment *const *segments, const qmx_segment *const *originals, uint32_t n_segments,
+                                       const qmx_hnsw_build_params *bp, qmx_hnsw **out_graphs, int32_t *out_status);
 int32_t qmx_sharded_hnsw_build(const qmx_segment *const *segments, const qmx_segment *const *originals, uint32_t n_segments,
                                const qmx_hnsw_build_params *bp, qmx_hnsw **out_graphs, int32_t *out_status) {
+    try {
+        return sharded_hnsw_build_body(segments, originals, n_segments, bp, out_graphs, out_status);
+    } catch (...) {         // nothing C++ crosses the C ABI
+        set_error("qmx_sharded_hnsw_build: out of host memory");
+        return QMX_ERR_OUT_OF_MEMORY;
+    }
+}
+static int32_t sharded_hnsw_build_body(const qmx_segment *const *segments, const qmx_segment *const *originals, uint32_t n_segments,
+                                       const qmx_hnsw_build_params *bp, qmx_hnsw **out_graphs, int32_t *out_status) {
     QMX_REQUIRE(segments && bp && out_graphs && n_segments >= 1, QMX_ERR_BAD_ARG, "NULL argument");
     for (uint32_t i = 0; i < n_segments; ++i) {
         out_graphs[i] = nullptr;
@@ -295,16 +308,47 @@ int32_t qmx_sharded_hnsw_build(const qmx_segment *const *segments, const qmx_seg
     std::vector<int32_t> rcs(n_segments, QMX_OK);
     std::vector<std::string> errs(n_segments);
     auto work = [&](uint32_t i) {
-        rcs[i] = hnsw_build_impl(segments[i], originals ? originals[i] : nullptr, bp, &out_graphs[i], nullptr);
-        if (rcs[i] != QMX_OK) errs[i] = last_error_text();          // (thread-local: copied out before the thread ends)
+        try {
+            rcs[i] = hnsw_build_impl(segments[i], originals ? originals[i] : nullptr, bp, &out_graphs[i], nullptr);
+            if (rcs[i] != QMX_OK) errs[i] = last_error_text();          // (thread-local: copied out before the thread ends)
+        } catch (...) {     // (bad_alloc of a host vector inside the build: a status, not a terminate)
+            rcs[i] = QMX_ERR_OUT_OF_MEMORY;
+        }
     };
     if (n_segments == 1) {
         work(0);
     } else {
+        // One worker thread per DEVICE x QMX_BUILDS_PER_DEVICE (the reference locks one GPU of its pool per segment build, gpu_devices_manager.rs:120-143;
+        // here a device takes up to two builds at once: each holds its full scratch - visited bitmaps, selection buffers - so the count is bounded).
+        // Workers draw segments of their device from a shared cursor.  No C++ exception leaves this extern "C" function: a thread that cannot be
+        // started leaves its share to the calling thread, which runs whatever is left inline after joining the rest.
+        constexpr uint32_t QMX_BUILDS_PER_DEVICE = 2;
+        std::vector<int> devs;
+        for (uint32_t i = 0; i < n_segments; ++i)
+            if (std::find(devs.begin(), devs.end(), segments[i]->device) == devs.end()) devs.push_back(segments[i]->device);
+        std::vector<std::atomic<uint32_t>> cursor(devs.size());
+        for (auto &c : cursor) c.store(0);
+        auto drain = [&](size_t d) {      // the next unbuilt segment of device d, until none is left
+            for (;;) {
+                const uint32_t start = cursor[d].fetch_add(1);
+                uint32_t seen = 0, pick = n_segments;
+                for (uint32_t i = 0; i < n_segments; ++i)
+                    if (segments[i]->device == devs[d] && seen++ == start) { pick = i; break; }
+                if (pick == n_segments) return;
+                work(pick);
+            }
+        };
         std::vector<std::thread> pool;
-        pool.reserve(n_segments);
-        for (uint32_t i = 0; i < n_segments; ++i) pool.emplace_back(work, i);
-        for (auto &t : pool) t.join();
+        try {
+            pool.reserve(devs.size() * QMX_BUILDS_PER_DEVICE);
+            for (size_t d = 0; d < devs.size(); ++d)
+                for (uint32_t k = 0; k < QMX_BUILDS_PER_DEVICE; ++k) pool.emplace_back(drain, d);
+        } catch (...) {
+            // (std::system_error from the thread constructor, bad_alloc: keep what started)
+        }
+        for (auto &t : pool)
+            if (t.joinable()) t.join();
+        for (size_t d = 0; d < devs.size(); ++d) drain(d);      // whatever no worker took (all of it if no thread could be started)
     }
     int32_t first = QMX_OK;
     for (uint32_t i = 0; i < n_segments; ++i) {
@@ -459,14 +503,15 @@ static int32_t hnsw_build_impl(const qmx_segment *seg, const qmx_segment *origin
                 max_entries = std::max<uint64_t>(longest, std::min<uint64_t>(mb->h_offsets[n] ? mb->h_offsets[n] : 1, (1ull << 30) / lut_stride));
                 a.q_stride = (uint32_t)lut_stride;
             }
-            QB(b_bq.reserve((size_t)max_entries * lut_stride));
+            // the table-free build (pq.hip HopPQDirectBuild + HopPQInternalDirect; the default where the codebook allows, option hnsw_pq_table_build for the
+            // other): the entries are the preprocessed original vectors themselves, staged in LDS per insertion - no LUTs are made, and none are reserved
+            // (max_entries x lut_stride is 1.6 GB at m = 96: several builds on one device would multiply it for nothing)
+            pq_direct_build = !mb && !option(OPT_HNSW_PQ_TABLE_BUILD) && pq_direct_walk_ok(seg->dim, seg->pq_m, seg->pq.chunk_size, seg->pq.n_centroids);
+            if (!pq_direct_build) QB(b_bq.reserve((size_t)max_entries * lut_stride));
             QB(b_bqsrc.reserve((size_t)max_entries * seg->dim * sizeof(float)));
             h.batch_queries = (const unsigned char *)b_bq.p;
             h.batch_q_stride = lut_stride;
             h.lds_query_bytes = 0;
-            // the table-free build (pq.hip HopPQDirectBuild + HopPQInternalDirect; the default where the codebook allows, option hnsw_pq_table_build for the
-            // other): the entries are the preprocessed original vectors themselves, staged in LDS per insertion - no LUTs are made
-            pq_direct_build = !mb && !option(OPT_HNSW_PQ_TABLE_BUILD) && pq_direct_walk_ok(seg->dim, seg->pq_m, seg->pq.chunk_size, seg->pq.n_centroids);
             if (pq_direct_build) {
                 h.batch_queries = (const unsigned char *)b_bqsrc.p;
                 h.batch_q_stride = (uint64_t)seg->dim * 4;
@@ -779,6 +824,7 @@ int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
     // option hnsw_reference_heap_order: the plain walk keeps the reference's two binary heaps (hnsw.hpp RefHeaps); other walks are unaffected
     h.ref_heaps = (option(OPT_HNSW_REFERENCE_HEAP_ORDER) > 0 && !acorn && !xo && !mw && !cw && !tq_l1(s)) ? 1 : 0;
     h.ref_cap = HNSW_REF_CAND_CAP;
+    h.spec = acorn ? 0 : (uint32_t)std::min<int64_t>(std::max<int64_t>(option(OPT_HNSW_SPEC), 0), 2);
     h.lds_query_bytes = q->q_stride <= HNSW_LDS_QUERY_MAX ? q->q_stride : 0;
     if (tq_l1(s)) {
         h.lds_query_bytes = tq_l1_lds_bytes(s->dim, s->tq_rot_dim);

@@ -55,6 +55,7 @@ enum Option {
     OPT_HNSW_PQ_TABLE_BUILD,  // the PQ build scores through per-insertion LUTs and the centroid pair table (round 2's build: 100 TB of table sectors per 2 M points) instead of
                               // recomputing both kinds of entries from the codebook (pq.hip HopPQDirectBuild + HopPQInternalDirect, the default where the codebook allows)
     OPT_I8_SCAN_DEEP,         // the int8-copy prefilter scans through the half-stage pipeline (scan_i8copy_deep_kernel: 80 KiB of rows in flight per CU, twice the barriers: 14 % slower)
+    OPT_HNSW_SPEC,            // the plain walk over a packed level 0 reads ahead for the NEXT pop: 0 = nothing, 1 = its link row, 2 (default) = and the visited words those links select (hnsw.hpp)
     OPT_HNSW_REFERENCE_HEAP_ORDER,   // the plain HNSW walk keeps `nearest` / `candidates` as the reference's two binary heaps (std sift order, one lane): the reference's lists among equal scores; slow, a verification mode
     OPT_DEBUG,                // log dropped stale HIP errors
     OPT_COUNT

@@ -485,7 +485,7 @@ __device__ __forceinline__ float group_score(const ScanArgs &a, const unsigned c
 template <class P, int R>
 __device__ __forceinline__ void group_score_multi(const ScanArgs &a, const unsigned char *qp, const uint32_t (&ids)[R], int t, float (&out)[R]) {
     constexpr int NRA = P::NRAUX > 0 ? P::NRAUX : 1;
-    constexpr int U = R >= 4 ? 4 : 6;       // steps in flight per row: 16 / 12 pieces per lane
+    constexpr int U = R >= 4 ? 3 : 6;       // steps in flight per row: 12 pieces per lane either way (R = 4 with U = 4 cost the SQ walk 146 registers = 3 waves per SIMD; 112 = 4 this way, and 6-step rows - d = 768 codes - no longer load a clamped duplicate)
     const int piece = lane_piece(t);
     const int piece_off = piece * 16;
     const bool piece_in_rem = piece < (int)a.rem_pieces;
