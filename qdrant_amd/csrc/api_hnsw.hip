@@ -876,6 +876,7 @@ int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
     int per_cu = 1;
     QMX_TRY(launch_hnsw(q, a, h, 0, &per_cu));
     if (s->dtype == QMX_DTYPE_PQ && h.lds_query_bytes == 0 && option(OPT_HNSW_PQ_PER_CU) > 0) per_cu = (int)std::min<int64_t>(per_cu, option(OPT_HNSW_PQ_PER_CU));
+    if (option(OPT_HNSW_PER_CU) > 0) per_cu = (int)std::min<int64_t>(per_cu, option(OPT_HNSW_PER_CU));
     uint64_t slots = std::min<uint64_t>({(uint64_t)n_searches, (uint64_t)s->num_cus * per_cu, (uint64_t)HNSW_SLOT_CAP});
     const uint64_t by_budget = std::max<uint64_t>(1, HNSW_VIS_BUDGET / (h.vis_words * 4));
     slots = std::max<uint64_t>(1, std::min(slots, by_budget));

@@ -56,7 +56,7 @@ struct is_asymmetric { static constexpr bool value = false; };
 template <class H>
 struct is_asymmetric<H, decltype((void)H::ASYMMETRIC)> { static constexpr bool value = H::ASYMMETRIC; };
 
-template <class P>
+template <class P, int U4 = 4>
 struct HopRow {
     static constexpr int LPI = 8;
     static constexpr bool INTERNAL_QOFF = has_internal_qoff<P>::value;
@@ -67,7 +67,7 @@ struct HopRow {
     }
     template <int R>
     static __device__ __forceinline__ void score_multi(const ScanArgs &a, const unsigned char *qp, const uint32_t (&ids)[R], int sub, float (&out)[R]) {
-        group_score_multi<P, R>(a, qp, ids, sub, out);
+        group_score_multi<P, R, U4>(a, qp, ids, sub, out);
     }
 };
 template <class S>
@@ -1276,6 +1276,15 @@ struct HnswLauncher {
     uint32_t grid;
     int *per_cu;
     template <class P> int32_t row(const ScanArgs &a) const { return launch_hnsw_hop<HopRow<P>>(st, a, *h, grid, per_cu); }
+    template <class S> int32_t small(const ScanArgs &a) const { return launch_hnsw_hop<HopSmall<S>>(st, a, *h, grid, per_cu); }
+};
+// the same with 3 steps in flight per row of a 4-row pass (option hnsw_row_u4 = 3: fewer registers, one more wave per SIMD)
+struct HnswLauncherU3 {
+    hipStream_t st;
+    const HnswArgs *h;
+    uint32_t grid;
+    int *per_cu;
+    template <class P> int32_t row(const ScanArgs &a) const { return launch_hnsw_hop<HopRow<P, 3>>(st, a, *h, grid, per_cu); }
     template <class S> int32_t small(const ScanArgs &a) const { return launch_hnsw_hop<HopSmall<S>>(st, a, *h, grid, per_cu); }
 };
 struct HnswCustomLauncher {

@@ -482,10 +482,12 @@ __device__ __forceinline__ float group_score(const ScanArgs &a, const unsigned c
 // R rows of one 8-lane group against one query in a single pass: R x UNROLL row pieces in flight per lane instead of
 // UNROLL (the HNSW hop scores <= m0 rows and is bound by the round-trip time of its gathers).  Same accumulators,
 // same order per row as group_score: same bits.
-template <class P, int R>
+template <class P, int R, int U4 = 4>
 __device__ __forceinline__ void group_score_multi(const ScanArgs &a, const unsigned char *qp, const uint32_t (&ids)[R], int t, float (&out)[R]) {
     constexpr int NRA = P::NRAUX > 0 ? P::NRAUX : 1;
-    constexpr int U = R >= 4 ? 3 : 6;       // steps in flight per row: 12 pieces per lane either way (R = 4 with U = 4 cost the SQ walk 146 registers = 3 waves per SIMD; 112 = 4 this way, and 6-step rows - d = 768 codes - no longer load a clamped duplicate)
+    // steps in flight per row: R = 4 rows x U4 steps (16 pieces per lane at U4 = 4: the SQ walk then holds 146 registers = 3 waves per SIMD; 12 at U4 = 3: 116 =
+    // 4 waves, and 6-step rows - d = 768 codes - load no clamped duplicate; measured in profiles/r5_sq_walk_*), R = 2 rows x 6 steps
+    constexpr int U = R >= 4 ? U4 : 6;
     const int piece = lane_piece(t);
     const int piece_off = piece * 16;
     const bool piece_in_rem = piece < (int)a.rem_pieces;
