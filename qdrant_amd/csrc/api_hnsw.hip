@@ -824,7 +824,6 @@ int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
     // option hnsw_reference_heap_order: the plain walk keeps the reference's two binary heaps (hnsw.hpp RefHeaps); other walks are unaffected
     h.ref_heaps = (option(OPT_HNSW_REFERENCE_HEAP_ORDER) > 0 && !acorn && !xo && !mw && !cw && !tq_l1(s)) ? 1 : 0;
     h.ref_cap = HNSW_REF_CAND_CAP;
-    h.spec = acorn ? 0 : (uint32_t)std::min<int64_t>(std::max<int64_t>(option(OPT_HNSW_SPEC), 0), 2);
     h.lds_query_bytes = q->q_stride <= HNSW_LDS_QUERY_MAX ? q->q_stride : 0;
     if (tq_l1(s)) {
         h.lds_query_bytes = tq_l1_lds_bytes(s->dim, s->tq_rot_dim);
@@ -859,6 +858,10 @@ int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
                     "hnsw max(top, ef) = %u: the query entry (%u bytes) and the list do not fit the LDS together", std::max(top, ef), a.q_stride);
         h.lds_query_bytes = a.q_stride;
     }
+    h.spec = acorn ? 0 : (uint32_t)std::min<int64_t>(std::max<int64_t>(option(OPT_HNSW_SPEC), 0), 2);
+    // the visited set in LDS (hnsw.hpp LdsVisited) where the search has room for it beside its query entry; the bitmap below stays allocated for what the
+    // table's buckets cannot hold
+    h.vis_lds = (!acorn && !h.ref_heaps && !option(OPT_HNSW_NO_LDS_VISITED) && g->n_points <= HNSW_VIS_LDS_MAX_POINTS && h.lds_query_bytes <= 32 * 1024) ? HNSW_VIS_LDS_BYTES : 0;
     h.log_cap = HNSW_LOG_CAP;
     {   // tests: force the whole-bitmap clear path
         const int64_t v = option(OPT_HNSW_LOG_CAP);

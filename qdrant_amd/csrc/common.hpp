@@ -56,6 +56,8 @@ enum Option {
                               // recomputing both kinds of entries from the codebook (pq.hip HopPQDirectBuild + HopPQInternalDirect, the default where the codebook allows)
     OPT_I8_SCAN_DEEP,         // the int8-copy prefilter scans through the half-stage pipeline (scan_i8copy_deep_kernel: 80 KiB of rows in flight per CU, twice the barriers: 14 % slower)
     OPT_HNSW_SPEC,            // the plain walk over a packed level 0 reads ahead for the NEXT pop: 0 = nothing, 1 = its link row, 2 (default) = and the visited words those links select (hnsw.hpp)
+    OPT_HNSW_NO_LDS_VISITED,  // the walk's visited set lives in the per-slot HBM bitmap only (rounds 1-4), not in the 16 KiB LDS table in front of it
+    OPT_PQ_LUT_NO_LDS,        // the MFMA LUT build reads its operands from global memory per instruction (round 1's pq_lut_mfma_kernel) instead of staging both in LDS
     OPT_HNSW_ROW_U4,          // the SQ walk's 4-row scoring pass keeps 3 (value 3) instead of 4 steps in flight per row: 116 instead of 146 registers = 4 instead of 3 waves per SIMD
     OPT_HNSW_PER_CU,          // cap on the searches resident per CU of any walk (0 = what the occupancy allows)
     OPT_HNSW_REFERENCE_HEAP_ORDER,   // the plain HNSW walk keeps `nearest` / `candidates` as the reference's two binary heaps (std sift order, one lane): the reference's lists among equal scores; slow, a verification mode

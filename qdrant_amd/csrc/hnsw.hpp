@@ -243,6 +243,9 @@ struct HopCustom {
     }
 };
 
+// bytes of the LDS beam of a walk with max(top, ef) = ef > HNSW_MAX_EF_REG: keys + expanded flags
+__host__ __device__ static inline size_t hnsw_beam_lds(uint32_t ef) { return ((size_t)ef * 9 + 15) / 16 * 16; }
+
 // ---- the beam: sorted descending, entry index = e * 64 + lane ------------------------------------
 template <int E>
 struct Beam {
@@ -383,6 +386,70 @@ struct Beam<0> {
             if (m) return key[base + (uint32_t)__builtin_ctzll(m)];
         }
         return 0ull;
+    }
+};
+
+// ---- the visited set of a search, in LDS ----------------------------------------------------------------------------------------------
+// One bit per point in a per-slot HBM bitmap costs the walk a third of its time at 10 M points: every test-and-set is an L2 atomic on a random word of a
+// 1.25 MB bitmap (5 GB over the slots in flight), i.e. an HBM read-modify-write per link - tools/micro/gather_roof measures the row gathers of a hop at
+// 6.2 TB/s alone and at 3.4 TB/s with those atomics beside them, which is where the walk sat (profiles/r5_sq_walk_visited.md).  A search inserts a few
+// thousand ids, so its set fits the LDS: 1024 buckets (id & 1023) of eight 16-bit tags ((id >> 10) + 1, 0 = empty) = 16 KiB per search.  test_and_set looks
+// the tag up in its bucket (one ds_read_b128), claims the first empty half-word with a compare-and-swap on the word that holds it (lanes of the wave insert
+// side by side; a lost race re-reads), and when the bucket is full - about 1 % of the inserts of an ef = 128 search, more for wide ones - falls back to the
+// HBM bitmap for that id.  An id is recorded in exactly one of the two places (the bucket is consulted first, and a full bucket never frees a slot while the
+// search runs, except through unset(), which the caller pairs with the place the insert reported), so the set is exact: same fresh / visited answers as the
+// bitmap alone, hence the same walk.  Graphs of more than 2^26 - 1024 points (tags would not fit), ACORN and the reference-heap mode keep the bitmap.
+struct LdsVisited {
+    uint32_t *tab;      // LDS, 4096 words; nullptr: the bitmap only
+    // -> true when `id` was visited before; *in_bitmap: the id lives (now or already) in the HBM bitmap, not in the table
+    __device__ __forceinline__ bool test_and_set(uint32_t id, uint32_t *vis, bool *in_bitmap) const {
+        const uint32_t bit = 1u << (id & 31);
+        *in_bitmap = false;
+        if (tab) {
+            uint32_t *b = tab + (id & 1023u) * 4u;
+            const uint32_t tag = (id >> 10) + 1u;
+            for (;;) {
+                const uint4 w4 = *reinterpret_cast<const uint4 *>(b);
+                const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
+                int empty = -1;
+                bool found = false;
+#pragma unroll
+                for (int d = 3; d >= 0; --d) {
+                    const uint32_t lo = w[d] & 0xFFFFu, hi = w[d] >> 16;
+                    found = found || lo == tag || hi == tag;
+                    if (hi == 0) empty = 2 * d + 1;
+                    if (lo == 0) empty = 2 * d;
+                }
+                if (found) return true;
+                if (empty < 0) break;                                    // the bucket is full: this id is the bitmap's
+                const int d = empty >> 1;
+                const uint32_t expected = w[d], desired = expected | (tag << (16 * (empty & 1)));
+                if (atomicCAS(&b[d], expected, desired) == expected) return false;
+            }
+        }
+        *in_bitmap = true;
+        return (atomicOr(&vis[id >> 5], bit) & bit) != 0;
+    }
+    // takes back an insert this search made (a link behind the level's limit: the reference never looked at it)
+    __device__ __forceinline__ void unset(uint32_t id, uint32_t *vis, bool in_bitmap) const {
+        if (in_bitmap || !tab) { atomicAnd(&vis[id >> 5], ~(1u << (id & 31))); return; }
+        uint32_t *b = tab + (id & 1023u) * 4u;
+        const uint32_t tag = (id >> 10) + 1u;
+        for (int d = 0; d < 4; ++d) {
+            for (;;) {
+                const uint32_t w = b[d];
+                uint32_t nw = w;
+                if ((w & 0xFFFFu) == tag) nw = w & 0xFFFF0000u;
+                else if ((w >> 16) == tag) nw = w & 0xFFFFu;
+                else break;
+                if (atomicCAS(&b[d], w, nw) == w) return;
+            }
+        }
+    }
+    __device__ __forceinline__ void clear(int lane) const {               // wave-cooperative; the caller barriers
+        if (!tab) return;
+        uint4 *t = reinterpret_cast<uint4 *>(tab);
+        for (uint32_t i = (uint32_t)lane; i < HNSW_VIS_LDS_BYTES / 16; i += 64) t[i] = make_uint4(0, 0, 0, 0);
     }
 };
 
@@ -580,7 +647,7 @@ __device__ __forceinline__ void hop_score(const ScanArgs &a, const unsigned char
 template <class H, int E>
 __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArgs &h, const unsigned char *qp,
                                                 uint32_t *hop_ids, float *hop_scores, uint32_t *vis, uint32_t *vlog,
-                                                uint32_t qi, int lane, unsigned char *beam_lds = nullptr) {
+                                                uint32_t qi, int lane, unsigned char *beam_lds = nullptr, uint32_t *vtab = nullptr) {
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     uint32_t n_scored = 0;
 
@@ -769,12 +836,17 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
     }
     beam.clear();
     uint32_t log_cnt = 0;
+    const LdsVisited lv{h.acorn ? nullptr : vtab};      // (ACORN keeps its two bitmaps)
     {
-        if (lane == 0) {
-            atomicOr(&vis[cur_id >> 5], 1u << (cur_id & 31));
-            vlog[0] = cur_id >> 5;
+        if (lv.tab) {
+            if (lane == 0) { bool in_bm; lv.test_and_set(cur_id, vis, &in_bm); }       // (an empty table: the entry goes in)
+        } else {
+            if (lane == 0) {
+                atomicOr(&vis[cur_id >> 5], 1u << (cur_id & 31));
+                vlog[0] = cur_id >> 5;
+            }
+            log_cnt = 1;
         }
-        log_cnt = 1;
         beam.insert(make_key(cur_score, cur_id), ef, lane);
     }
     if (h.acorn) {
@@ -989,24 +1061,32 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
             const uint32_t id = h.l0 ? (on ? packed_id : 0) : (on ? h.neighbors[i] : 0);
             const bool live = on && id < h.n_points && a.del.live(id);
             const uint32_t bit = 1u << (id & 31);
-            const bool seen = have_known && (known_vis & bit);        // (the word read ahead already shows the bit: visited, no atomic needed)
-            const uint32_t old = (live && !seen) ? atomicOr(&vis[id >> 5], bit) : bit;
-            bool keep = live && !(old & bit);
+            bool in_bm = true, was_visited = true;
+            if (lv.tab) {
+                if (live) was_visited = lv.test_and_set(id, vis, &in_bm);
+            } else {
+                const bool seen = have_known && (known_vis & bit);    // (the word read ahead already shows the bit: visited, no atomic needed)
+                const uint32_t old = (live && !seen) ? atomicOr(&vis[id >> 5], bit) : bit;
+                was_visited = (old & bit) != 0;
+            }
+            bool keep = live && !was_visited;
             const uint64_t mask = __ballot(keep);
             const uint32_t rank = (uint32_t)__popcll(mask & lt_mask);
             uint32_t k = (uint32_t)__popcll(mask);
             if (k > remaining) {   // more links than level_m: the reference scores only the first `limit`
-                if (keep && rank >= remaining) { atomicAnd(&vis[id >> 5], ~bit); keep = false; }
+                if (keep && rank >= remaining) { lv.unset(id, vis, in_bm); keep = false; }
                 k = remaining;
                 bits_cleared = true;            // (a bit was taken back: from here on a word read ahead could show it still set - no more reading ahead)
             }
             remaining -= k;
             __syncthreads();
-            if (keep) {
-                hop_ids[rank] = id;
-                if (log_cnt + rank < h.log_cap) vlog[log_cnt + rank] = id >> 5;
+            if (keep) hop_ids[rank] = id;
+            {   // the bitmap words this search dirtied (with the LDS table: only the ids of full buckets)
+                const uint64_t bm = __ballot(keep && in_bm);
+                const uint32_t brank = (uint32_t)__popcll(bm & lt_mask);
+                if (keep && in_bm && log_cnt + brank < h.log_cap) vlog[log_cnt + brank] = id >> 5;
+                log_cnt += (uint32_t)__popcll(bm);
             }
-            log_cnt += k;
             hop_score<H>(a, qp, hop_ids, hop_scores, k, lane);
             const uint64_t mykey = (uint32_t)lane < k ? make_key(hop_scores[lane], hop_ids[lane]) : 0;
             uint64_t mm = __ballot(mykey > beam.at(ef - 1));
@@ -1027,7 +1107,7 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
             }
             n_scored += k;
         }
-        if (h.spec >= 2 && sp_cand != 0xFFFFFFFFu && !bits_cleared) {
+        if (h.spec >= 2 && !lv.tab && sp_cand != 0xFFFFFFFFu && !bits_cleared) {
             // (the speculated links were requested before this hop's rows and loads return in order: no wait here.  The read goes to L2 - where the
             // atomics are performed - not through this CU's vector cache, which may still hold the word as the PREVIOUS search of this slot left it)
             const bool on = (uint32_t)lane < sp_cnt && sp_id < h.n_points;
@@ -1081,8 +1161,9 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
         }
     }
 
-    // ---- give the visited bitmap back all-zero ----
+    // ---- give the visited bitmap (and the LDS table) back all-zero ----
     __syncthreads();
+    lv.clear(lane);
     if (log_cnt <= h.log_cap) {
         for (uint32_t i = (uint32_t)lane; i < log_cnt; i += 64) vis[vlog[i]] = 0;
     } else {
@@ -1106,6 +1187,12 @@ __global__ __launch_bounds__(64) QMX_WALK_KERNEL_ATTR void hnsw_search_kernel(co
     unsigned char *beam_lds = q_lds + (QLDS ? ((size_t)h.lds_query_bytes + 15) / 16 * 16 : 0);      // E == 0: the LDS beam behind the query entry (E == HNSW_E_REF: `nearest`)
     uint32_t *vis = h.visited + (uint64_t)blockIdx.x * h.vis_words;
     uint32_t *vlog = h.vis_log + (uint64_t)blockIdx.x * h.log_cap;
+    // the search's visited table (LdsVisited), behind everything else: zero once here, every search leaves it zero
+    uint32_t *vtab = h.vis_lds ? reinterpret_cast<uint32_t *>(beam_lds + (E <= 0 ? hnsw_beam_lds(h.ef > h.top ? h.ef : h.top) : 0)) : nullptr;
+    if (vtab) {
+        LdsVisited{vtab}.clear(lane);
+        __syncthreads();
+    }
     for (uint32_t qi = blockIdx.x; qi < h.nq; qi += gridDim.x) {
         if constexpr (is_maxsim<H>::value) {
             // (the header always sits in LDS; the entries follow when the launch's budget holds them, else they are read where they lie)
@@ -1123,7 +1210,7 @@ __global__ __launch_bounds__(64) QMX_WALK_KERNEL_ATTR void hnsw_search_kernel(co
                 *reinterpret_cast<const unsigned char **>(q_lds + 8) = fits ? q_lds + 16 : qg;
             }
             __syncthreads();
-            hnsw_search_one<H, E>(a, h, q_lds + 16, hop_ids, hop_scores, vis, vlog, qi, lane, beam_lds);
+            hnsw_search_one<H, E>(a, h, q_lds + 16, hop_ids, hop_scores, vis, vlog, qi, lane, beam_lds, vtab);
             continue;
         }
         if constexpr (is_custom<H>::value) {
@@ -1156,7 +1243,7 @@ __global__ __launch_bounds__(64) QMX_WALK_KERNEL_ATTR void hnsw_search_kernel(co
                     hd->ex_off = tab;
                 }
                 __syncthreads();
-                hnsw_search_one<H, E>(a, h, q_lds + sizeof(CustomHeader), hop_ids, hop_scores, vis, vlog, qi, lane, beam_lds);
+                hnsw_search_one<H, E>(a, h, q_lds + sizeof(CustomHeader), hop_ids, hop_scores, vis, vlog, qi, lane, beam_lds, vtab);
                 continue;
             }
             const bool fits = sizeof(CustomHeader) + (uint64_t)ne * a.q_stride <= h.lds_query_bytes;
@@ -1173,7 +1260,7 @@ __global__ __launch_bounds__(64) QMX_WALK_KERNEL_ATTR void hnsw_search_kernel(co
                 hd->ex_off = nullptr;
             }
             __syncthreads();
-            hnsw_search_one<H, E>(a, h, q_lds + sizeof(CustomHeader), hop_ids, hop_scores, vis, vlog, qi, lane, beam_lds);
+            hnsw_search_one<H, E>(a, h, q_lds + sizeof(CustomHeader), hop_ids, hop_scores, vis, vlog, qi, lane, beam_lds, vtab);
             continue;
         }
         const unsigned char *qg = reinterpret_cast<const unsigned char *>(a.queries) + (uint64_t)qi * a.q_stride;
@@ -1184,15 +1271,13 @@ __global__ __launch_bounds__(64) QMX_WALK_KERNEL_ATTR void hnsw_search_kernel(co
             const uint32_t q_units = (h.lds_query_bytes < a.q_stride ? h.lds_query_bytes : a.q_stride) / 16;     // (a policy may own scratch behind its entry)
             for (uint32_t i = (uint32_t)lane; i < q_units; i += 64) dst[i] = src[i];
             __syncthreads();
-            hnsw_search_one<H, E>(a, h, q_lds, hop_ids, hop_scores, vis, vlog, qi, lane, beam_lds);
+            hnsw_search_one<H, E>(a, h, q_lds, hop_ids, hop_scores, vis, vlog, qi, lane, beam_lds, vtab);
         } else {
-            hnsw_search_one<H, E>(a, h, qg, hop_ids, hop_scores, vis, vlog, qi, lane, beam_lds);
+            hnsw_search_one<H, E>(a, h, qg, hop_ids, hop_scores, vis, vlog, qi, lane, beam_lds, vtab);
         }
     }
 }
 
-// bytes of the LDS beam of a walk with max(top, ef) = ef > HNSW_MAX_EF_REG: keys + expanded flags
-static inline size_t hnsw_beam_lds(uint32_t ef) { return ((size_t)ef * 9 + 15) / 16 * 16; }
 
 // occupancy of an instantiation (blocks of one wave per CU) — used by the API to size the scratch
 template <class H, int E, bool QLDS>
@@ -1213,7 +1298,7 @@ int32_t hnsw_occupancy_inst(uint32_t lds_query_bytes, size_t hop_lds, int *per_c
 template <class H, int E, bool QLDS>
 int32_t launch_hnsw_inst(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid) {
     const uint32_t ef = h.ef > h.top ? h.ef : h.top;
-    const size_t lds = 8 * (size_t)h.hop_cap + hnsw_acorn_lds(h.acorn, h.m0) + (QLDS ? ((size_t)h.lds_query_bytes + 15) / 16 * 16 : 0) + (E <= 0 ? hnsw_beam_lds(ef) : 0);
+    const size_t lds = 8 * (size_t)h.hop_cap + hnsw_acorn_lds(h.acorn, h.m0) + (QLDS ? ((size_t)h.lds_query_bytes + 15) / 16 * 16 : 0) + (E <= 0 ? hnsw_beam_lds(ef) : 0) + h.vis_lds;
     QMX_REQUIRE(lds <= 160 * 1024, QMX_ERR_NOT_SUPPORTED, "hnsw walk: %zu bytes of LDS (query entry + a list of %u)", lds, ef);
     ::qmx::clear_stale_error();
     QMX_NOTE_KERNEL((hnsw_search_kernel<H, E, QLDS>));
@@ -1239,7 +1324,7 @@ int32_t launch_hnsw_hop(hipStream_t st, const ScanArgs &a, const HnswArgs &h, ui
     if (h.ref_heaps) {      // option hnsw_reference_heap_order: the plain walk of the policies a stored graph is walked with
         if constexpr (ref_heaps_built<H>::value) {
             QMX_REQUIRE(!h.acorn && !h.expanded, QMX_ERR_NOT_SUPPORTED, "hnsw_reference_heap_order: the plain walk only (not ACORN, not search_with_vectors)");
-            const size_t hop_lds = 8 * (size_t)h.hop_cap + hnsw_beam_lds(ef);
+            const size_t hop_lds = 8 * (size_t)h.hop_cap + hnsw_beam_lds(ef) + h.vis_lds;
             if (grid == 0) return qlds ? hnsw_occupancy_inst<H, HNSW_E_REF, true>(h.lds_query_bytes, hop_lds, per_cu) : hnsw_occupancy_inst<H, HNSW_E_REF, false>(0, hop_lds, per_cu);
             return qlds ? launch_hnsw_inst<H, HNSW_E_REF, true>(st, a, h, grid) : launch_hnsw_inst<H, HNSW_E_REF, false>(st, a, h, grid);
         } else {
@@ -1249,18 +1334,18 @@ int32_t launch_hnsw_hop(hipStream_t st, const ScanArgs &a, const HnswArgs &h, ui
     }
     if (ef > HNSW_MAX_EF_REG) {        // the LDS beam: one instantiation per policy, the query entry staged
         QMX_REQUIRE(qlds, QMX_ERR_NOT_SUPPORTED, "hnsw ef %u > %u needs the query entry in LDS (it does not fit)", ef, HNSW_MAX_EF_REG);
-        if (grid == 0) return hnsw_occupancy_inst<H, 0, true>(h.lds_query_bytes, 8 * (size_t)h.hop_cap + hnsw_acorn_lds(h.acorn, h.m0) + hnsw_beam_lds(ef), per_cu);
+        if (grid == 0) return hnsw_occupancy_inst<H, 0, true>(h.lds_query_bytes, 8 * (size_t)h.hop_cap + hnsw_acorn_lds(h.acorn, h.m0) + hnsw_beam_lds(ef) + h.vis_lds, per_cu);
         return launch_hnsw_inst<H, 0, true>(st, a, h, grid);
     }
     if constexpr (is_custom<H>::value || is_maxsim<H>::value) {      // (always staged: no instantiation that reads the entry from global memory)
         if (grid == 0) {
-            const size_t hop_lds = 8 * (size_t)h.hop_cap + hnsw_acorn_lds(h.acorn, h.m0);
+            const size_t hop_lds = 8 * (size_t)h.hop_cap + hnsw_acorn_lds(h.acorn, h.m0) + h.vis_lds;
             return ef <= 128 ? hnsw_occupancy_inst<H, 2, true>(h.lds_query_bytes, hop_lds, per_cu) : hnsw_occupancy_inst<H, 8, true>(h.lds_query_bytes, hop_lds, per_cu);
         }
         return ef <= 128 ? launch_hnsw_inst<H, 2, true>(st, a, h, grid) : launch_hnsw_inst<H, 8, true>(st, a, h, grid);
     } else {
     if (grid == 0) {
-        const size_t hop_lds = 8 * (size_t)h.hop_cap + hnsw_acorn_lds(h.acorn, h.m0);
+        const size_t hop_lds = 8 * (size_t)h.hop_cap + hnsw_acorn_lds(h.acorn, h.m0) + h.vis_lds;
         if (ef <= 128) return qlds ? hnsw_occupancy_inst<H, 2, true>(h.lds_query_bytes, hop_lds, per_cu) : hnsw_occupancy_inst<H, 2, false>(0, hop_lds, per_cu);
         return qlds ? hnsw_occupancy_inst<H, 8, true>(h.lds_query_bytes, hop_lds, per_cu) : hnsw_occupancy_inst<H, 8, false>(0, hop_lds, per_cu);
     }

@@ -131,6 +131,7 @@ struct HnswArgs {
     uint32_t pop_cap;
     // option hnsw_reference_heap_order (a verification mode): `nearest` and `candidates` are the reference's two binary heaps, worked by one lane
     // in std's exact sift order; `nearest` lives in LDS, `candidates` (unbounded in the reference) in this per-slot scratch
+    uint32_t vis_lds;               // bytes of the search's visited table in LDS (hnsw.hpp LdsVisited: 0 or HNSW_VIS_LDS_BYTES); the HBM bitmap then holds what its buckets cannot
     uint32_t spec;                  // plain walk over a packed level 0: 1 = the next pop's link row is fetched ahead, 2 = and the visited words it selects
     uint32_t ref_heaps;
     uint32_t ref_cap;               // entries of a slot's candidates heap; a search that needs more raises err_flag = 2
@@ -199,6 +200,8 @@ int32_t launch_hnsw_sq(hipStream_t st, int distance, const ScanArgs &a, const Hn
 int32_t launch_hnsw_pq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_bq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_pack_level0(hipStream_t st, const uint64_t *offsets, const uint32_t *neighbors, uint32_t n_points, uint32_t stride, uint32_t *l0);
+constexpr uint32_t HNSW_VIS_LDS_BYTES = 16384;                 // the walk's visited table in LDS (hnsw.hpp LdsVisited): 1024 buckets x 8 tags of 16 bits
+constexpr uint32_t HNSW_VIS_LDS_MAX_POINTS = 65535u * 1024u;    // ... graphs whose (id >> 10) + 1 fits a tag
 constexpr uint32_t HNSW_REF_CAND_CAP = 1u << 16;   // option hnsw_reference_heap_order: entries of one search's `candidates` heap (512 KiB per slot)
 constexpr uint32_t HNSW_REF_SLOT_CAP = 1024;       // ... searches in flight in that mode
 constexpr uint32_t HNSW_MAX_EF = 4096;          // max(top, ef) of a walk: up to 512 in a register beam, beyond it in an LDS beam (hnsw.hpp Beam<0>)

@@ -91,6 +91,63 @@ __global__ __launch_bounds__(256) void pq_lut_mfma_kernel(PqGeom g, uint32_t nq,
     }
 }
 
+// The same contraction with both operands staged in LDS: a block of 4 waves takes 128 queries of one chunk (wave w: queries 32 w .. 32 w + 31 against every
+// centroid tile), the chunk's centroids [ncent][len] and the block's query chunks [128][len] are copied into LDS once, with coalesced loads (pq_lut_mfma_kernel
+// reads each operand element from global memory per MFMA: 32 cache lines per load instruction, eight times per tile), rows padded to an odd stride.  Same k order,
+// same instruction, same accumulators: the LUT carries the bits of pq_lut_mfma_kernel.  The kernel is bound by the LUT it WRITES (nq x m x ncent x 4 B: 805 MB
+// for 8192 queries of C4), not by the matrix cores (2 x ncent x dim flop per query: 6.4 GFLOP for the same batch = 0.04 ms of the f32 MFMA peak).
+constexpr uint32_t PQ_LUT_QB = 128;
+static inline size_t pq_lut_lds_bytes(const PqGeom &g) {
+    const uint32_t len2 = (g.chunk + 1) & ~1u;
+    return (size_t)(g.ncent + PQ_LUT_QB) * (len2 + 1) * sizeof(float);
+}
+__global__ __launch_bounds__(256) void pq_lut_mfma_lds_kernel(PqGeom g, uint32_t nq, const float *queries, const float *centroids, float *lut) {
+    extern __shared__ float pq_lut_sm[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t c = blockIdx.x;
+    const uint32_t q0 = blockIdx.y * PQ_LUT_QB;
+    const uint32_t lo = c * g.chunk, hi = min(lo + g.chunk, g.dim);
+    const uint32_t len = hi - lo;
+    const uint32_t len2 = (g.chunk + 1) & ~1u, LP = len2 + 1;
+    float *cs = pq_lut_sm, *qs = pq_lut_sm + (size_t)g.ncent * LP;
+    for (uint32_t idx = threadIdx.x; idx < g.ncent * len2; idx += 256) {
+        const uint32_t j = idx / len2, i = idx % len2;
+        cs[j * LP + i] = i < len ? centroids[(uint64_t)j * g.dim + lo + i] : 0.0f;
+    }
+    for (uint32_t idx = threadIdx.x; idx < PQ_LUT_QB * len2; idx += 256) {
+        const uint32_t r = idx / len2, i = idx % len2;
+        qs[r * LP + i] = (q0 + r < nq && i < len) ? queries[(uint64_t)(q0 + r) * g.dim + lo + i] : 0.0f;
+    }
+    __syncthreads();
+    const uint32_t qw = q0 + 32u * (uint32_t)wave;
+    if (qw >= nq) return;
+    const uint32_t khalf = lane >> 5;
+    const float *qrow = qs + (32u * (uint32_t)wave + (uint32_t)(lane & 31)) * LP;
+    for (uint32_t j0 = 0; j0 < g.ncent; j0 += 32) {
+        const uint32_t jcol = j0 + (lane & 31);
+        const float *crow = cs + (jcol < g.ncent ? jcol : 0) * LP;
+        floatx16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+        for (uint32_t k0 = 0; k0 < len; k0 += 2) {
+            const float a = qrow[k0 + khalf];                       // (columns past len are zero in LDS, queries past nq too)
+            const float b = jcol < g.ncent ? crow[k0 + khalf] : 0.0f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        if (jcol < g.ncent) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const uint32_t q = qw + 8 * (v / 4) + 4 * khalf + (v % 4);
+                if (q < nq) {
+                    const float s = acc[v];
+                    lut[((uint64_t)q * g.m + c) * g.ncent + jcol] = g.invert ? -s : s;
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // score of one code row against one LUT, in score_point_sse order
 // ------------------------------------------------------------------------------------------
@@ -725,7 +782,9 @@ int32_t launch_pq_lut(hipStream_t st, uint32_t distance, uint32_t dim, const qmx
     if (nq == 0) return QMX_OK;
     const PqGeom g = make_geom(distance, dim, pq);
     ::qmx::clear_stale_error();
-    if (pq.lut_mfma && g.kind == 0) {
+    if (pq.lut_mfma && g.kind == 0 && pq_lut_lds_bytes(g) <= 64 * 1024 && !option(OPT_PQ_LUT_NO_LDS)) {
+        hipLaunchKernelGGL(pq_lut_mfma_lds_kernel, dim3(g.m, (nq + PQ_LUT_QB - 1) / PQ_LUT_QB), dim3(256), pq_lut_lds_bytes(g), st, g, nq, d_queries, d_centroids, d_lut);
+    } else if (pq.lut_mfma && g.kind == 0) {
         hipLaunchKernelGGL(pq_lut_mfma_kernel, dim3(g.m, (nq + 31) / 32), dim3(256), 0, st, g, nq, d_queries, d_centroids, d_lut);
     } else {
         hipLaunchKernelGGL(pq_lut_kernel, dim3(g.m, nq), dim3(256), 0, st, g, d_queries, d_centroids, d_lut);

@@ -92,6 +92,33 @@ def test_pq_lut_mfma_within_tolerance(qa, dist, nq):
         assert np.all(np.abs(got[i].astype(np.float64) - want[i]) <= 1e-5 * scale + 1e-30)
 
 
+@pytest.mark.parametrize("dim,chunk,ncent,nq", [(1536, 16, 256, 300), (70, 16, 256, 130), (96, 8, 100, 33), (65, 2, 256, 1), (320, 32, 256, 129), (96, 3, 17, 260)])
+def test_pq_lut_mfma_staged_in_lds_carries_the_bits_of_the_global_operand_kernel(qa, dim, chunk, ncent, nq):
+    """pq_lut_mfma_lds_kernel (both operands staged in LDS, 128 queries per block) against pq_lut_mfma_kernel (option pq_lut_no_lds: every operand element read
+    from global memory per instruction): the same instruction in the same k order - every LUT entry must carry the same bits, for ragged last chunks, query
+    counts that do not fill a block and codebooks of fewer than 256 centroids; and both stay within 1e-5 of the exact-order LUT"""
+    rng, vecs, quant, opq = _setup(qa, O.DOT, dim, chunk, 200, ncent, seed=dim + nq, mfma=True)
+    st = qa.EncodedVectorsPQ(opq.encode(vecs), quant)
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    qpre = O.preprocess(O.DOT, queries)
+    staged = qa.new_raw_scorer(queries, st)
+    qa.set_option("pq_lut_no_lds", 1)
+    try:
+        plain = qa.new_raw_scorer(queries, st)
+    finally:
+        qa.set_option("pq_lut_no_lds", -1)
+    for i in sorted({0, 1, 31, 32, 127, 128, nq - 1} & set(range(nq))):
+        a, b = staged.encoded_query(i), plain.encoded_query(i)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), i
+        want = opq.lut(qpre[i]).astype(np.float64)
+        m = opq.m
+        sub = np.zeros((m, chunk)); cenp = np.zeros((ncent, m, chunk))
+        sub.reshape(-1)[:dim] = qpre[i]
+        cenp.reshape(ncent, -1)[:, :dim] = opq.centroids.reshape(ncent, dim)
+        scale = np.abs(sub[:, None, :] * cenp.transpose(1, 0, 2)).sum(-1)
+        assert np.all(np.abs(a.astype(np.float64).reshape(m, ncent) - want.reshape(m, ncent)) <= 1e-5 * scale + 1e-30)
+
+
 def test_pq_error_bound_like_reference_tests(qa):
     # lib/quantization/tests/integration/test_pq.rs:14-55: dim 65, 513 vectors in [0,1), chunk 1, |pq - exact| < dim * 0.05
     rng = np.random.default_rng(42)
