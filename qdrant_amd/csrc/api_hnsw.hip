@@ -858,7 +858,6 @@ int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
                     "hnsw max(top, ef) = %u: the query entry (%u bytes) and the list do not fit the LDS together", std::max(top, ef), a.q_stride);
         h.lds_query_bytes = a.q_stride;
     }
-    h.spec = acorn ? 0 : (uint32_t)std::min<int64_t>(std::max<int64_t>(option(OPT_HNSW_SPEC), 0), 2);
     // the visited set in LDS (hnsw.hpp LdsVisited) where the search has room for it beside its query entry; the bitmap below stays allocated for what the
     // table's buckets cannot hold
     h.vis_lds = (!acorn && !h.ref_heaps && !option(OPT_HNSW_NO_LDS_VISITED) && g->n_points <= HNSW_VIS_LDS_MAX_POINTS && h.lds_query_bytes <= 32 * 1024) ? HNSW_VIS_LDS_BYTES : 0;

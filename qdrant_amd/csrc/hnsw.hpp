@@ -306,21 +306,7 @@ struct Beam {
             }
         }
         return ck;
-    }    // the best unexpanded entry without marking it: what pop_best would return next if nothing better is inserted first
-    __device__ __forceinline__ uint64_t peek_best() const {
-        uint64_t ck = 0;
-        bool found = false;
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const uint64_t m = __ballot(key[e] != 0 && done[e] == 0);
-            if (!found && m) {
-                ck = readlane_u64(key[e], __builtin_ctzll(m));
-                found = true;
-            }
-        }
-        return ck;
-    }
-};
+    }};
 
 // The same list for ef > 512, kept in LDS (the walk kernel appends `cap` keys + `cap` flag bytes to its dynamic LDS): the same interface, every
 // operation wave-cooperative.  insert: the position by a two-level search (64 block ends, then the block), then the tail moves up one entry, 64
@@ -377,14 +363,6 @@ struct Beam<0> {
             }
         }
         hint = len;
-        return 0ull;
-    }
-    __device__ __forceinline__ uint64_t peek_best() const {
-        for (uint32_t base = hint; base < len; base += 64) {
-            const uint32_t i = base + (uint32_t)threadIdx.x;
-            const uint64_t m = __ballot(i < len && done[i] == 0);
-            if (m) return key[base + (uint32_t)__builtin_ctzll(m)];
-        }
         return 0ull;
     }
 };
@@ -994,13 +972,6 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
     // pop order is its heap's)
     uint64_t ev[4] = {0, 0, 0, 0};
     uint32_t n_exp = 0;
-    // Speculation on the NEXT pop (packed level 0, h.spec): while this candidate's hop is in flight - visited words, then code rows: two dependent round
-    // trips - the link row of the best entry still unexpanded is fetched too; it is the next pop unless this hop inserts something better, and then its
-    // links are in registers when it is popped: links -> visited -> rows becomes visited -> rows.  h.spec >= 2: once those links have landed, the visited
-    // words they select are read as well (through L2, where the atomics work): a bit found set spares that lane its atomic (bits are only ever set
-    // while a search runs), and the word sits in L2 when the atomics of the others arrive.  Nothing here changes what is popped, scored or inserted.
-    uint32_t sp_cand = 0xFFFFFFFFu, sp_id = 0, sp_cnt = 0, sp_vis = 0;
-    bool sp_has_vis = false, bits_cleared = false;
     while (true) {
         uint64_t ck = beam.pop_best(lane);
         if (ck == 0) {
@@ -1026,30 +997,11 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
         // links of `cand` on level 0: the packed table needs ONE round trip (count and links are independent loads of the
         // same row), the CSR arrays two (offsets, then neighbors)
         uint64_t o0 = 0, o1 = 0;
-        uint32_t packed_id = 0, known_vis = 0;
-        bool have_known = false;
+        uint32_t packed_id = 0;
         if (h.l0) {
-            if (cand == sp_cand) {              // the speculation held: the links (and maybe their visited words) are here
-                packed_id = sp_id;
-                o1 = sp_cnt;
-                known_vis = sp_vis;
-                have_known = sp_has_vis;
-            } else {
-                const uint32_t *rowp = h.l0 + (uint64_t)cand * h.l0_stride;
-                packed_id = (uint32_t)lane + 1 < h.l0_stride ? rowp[lane + 1] : 0;
-                o1 = rowp[0];
-            }
-            sp_cand = 0xFFFFFFFFu;
-            sp_has_vis = false;
-            if (h.spec) {
-                const uint64_t nk = beam.peek_best();
-                if (nk) {
-                    sp_cand = key_idx(nk);
-                    const uint32_t *np = h.l0 + (uint64_t)sp_cand * h.l0_stride;
-                    sp_id = (uint32_t)lane + 1 < h.l0_stride ? np[lane + 1] : 0;
-                    sp_cnt = np[0];
-                }
-            }
+            const uint32_t *rowp = h.l0 + (uint64_t)cand * h.l0_stride;
+            packed_id = (uint32_t)lane + 1 < h.l0_stride ? rowp[lane + 1] : 0;
+            o1 = rowp[0];
         } else {
             o0 = h.offsets[cand];
             o1 = h.offsets[(uint64_t)cand + 1];
@@ -1065,8 +1017,7 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
             if (lv.tab) {
                 if (live) was_visited = lv.test_and_set(id, vis, &in_bm);
             } else {
-                const bool seen = have_known && (known_vis & bit);    // (the word read ahead already shows the bit: visited, no atomic needed)
-                const uint32_t old = (live && !seen) ? atomicOr(&vis[id >> 5], bit) : bit;
+                const uint32_t old = live ? atomicOr(&vis[id >> 5], bit) : bit;
                 was_visited = (old & bit) != 0;
             }
             bool keep = live && !was_visited;
@@ -1076,7 +1027,6 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
             if (k > remaining) {   // more links than level_m: the reference scores only the first `limit`
                 if (keep && rank >= remaining) { lv.unset(id, vis, in_bm); keep = false; }
                 k = remaining;
-                bits_cleared = true;            // (a bit was taken back: from here on a word read ahead could show it still set - no more reading ahead)
             }
             remaining -= k;
             __syncthreads();
@@ -1106,13 +1056,6 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
                 }
             }
             n_scored += k;
-        }
-        if (h.spec >= 2 && !lv.tab && sp_cand != 0xFFFFFFFFu && !bits_cleared) {
-            // (the speculated links were requested before this hop's rows and loads return in order: no wait here.  The read goes to L2 - where the
-            // atomics are performed - not through this CU's vector cache, which may still hold the word as the PREVIOUS search of this slot left it)
-            const bool on = (uint32_t)lane < sp_cnt && sp_id < h.n_points;
-            sp_vis = on ? __hip_atomic_load(&vis[sp_id >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-            sp_has_vis = true;
         }
     }
     if (h.expanded) {

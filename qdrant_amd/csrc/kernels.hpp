@@ -132,7 +132,6 @@ struct HnswArgs {
     // option hnsw_reference_heap_order (a verification mode): `nearest` and `candidates` are the reference's two binary heaps, worked by one lane
     // in std's exact sift order; `nearest` lives in LDS, `candidates` (unbounded in the reference) in this per-slot scratch
     uint32_t vis_lds;               // bytes of the search's visited table in LDS (hnsw.hpp LdsVisited: 0 or HNSW_VIS_LDS_BYTES); the HBM bitmap then holds what its buckets cannot
-    uint32_t spec;                  // plain walk over a packed level 0: 1 = the next pop's link row is fetched ahead, 2 = and the visited words it selects
     uint32_t ref_heaps;
     uint32_t ref_cap;               // entries of a slot's candidates heap; a search that needs more raises err_flag = 2
     uint2 *ref_cands;               // [slots][ref_cap]  (x = idx, y = score bits)

@@ -683,20 +683,34 @@ def c4_section(ctx):
            "pq_kmeans_train_s": round(t_train, 3), "kmeans_iterations_max": int(iters.max()), "pq_encode_s": round(t_enc, 3)}
     n_gt = 256
     exact = qa.BatchFilteredSearcher(queries[:n_gt].cpu().numpy(), vs, top).peek_top_all()
-    # ---- LUT build on the matrix cores: time of encode_query for a batch (qmx_query_update), its flops against the f32 MFMA peak ----
+    # ---- LUT build on the matrix cores (encode_query of a batch, qmx_query_update): device time of the update between two events on the query's stream
+    # (cosine preprocess + pq_lut_mfma_lds_kernel; the host's share of the call is in ms_wall).  The kernel WRITES nq x m x 256 x 4 bytes of LUTs and does
+    # 2 x 256 x d flop per query: priced against both roofs, it is bound by the write
     qh_all = queries[:nq_h].contiguous()
     scorer = qa.new_raw_scorer(qh_all, enc)
+    lut_stream = torch.cuda.Stream(dev)
+    F.check(lib.qmx_query_set_stream(scorer._h, C.c_void_p(lut_stream.cuda_stream)))
     torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(3):
-        F.check(lib.qmx_query_update(scorer._h, F.ptr(qh_all)))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    F.check(lib.qmx_query_update(scorer._h, F.ptr(qh_all)))
     F.check(lib.qmx_query_synchronize(scorer._h))
-    lut_ms = (time.perf_counter() - t0) / 3 * 1e3
+    t0 = time.perf_counter()
+    e0.record(lut_stream)
+    for _ in range(5):
+        F.check(lib.qmx_query_update(scorer._h, F.ptr(qh_all)))
+    e1.record(lut_stream)
+    F.check(lib.qmx_query_synchronize(scorer._h))
+    lut_wall = (time.perf_counter() - t0) / 5 * 1e3
+    lut_ms = e0.elapsed_time(e1) / 5
     lut_flops = 2.0 * 256 * dim * nq_h                       # 2 x 256 x d flop per query
-    out["lut_build_mfma"] = {"queries": nq_h, "ms_incl_preprocess": round(lut_ms, 3), "flops": lut_flops,
-                             "roofline": {"bound": "mfma", "achieved": round(lut_flops / (lut_ms * 1e-3) / 1e12, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                          "frac": round(lut_flops / (lut_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-                                          "note": "wall time of qmx_query_update (cosine preprocess + LUT + the 96 KiB/query LUT write: %d MB): write-bound, not MFMA-bound" % (nq_h * 96 // 1024)}}
+    lut_bytes = float(nq_h) * quant.m * 256 * 4 + float(nq_h) * dim * 4 * 3      # the LUTs written + the batch read, normalised, read again
+    wr = lut_bytes / (lut_ms * 1e-3) / 1e9
+    out["lut_build_mfma"] = {"queries": nq_h, "ms_device_incl_preprocess": round(lut_ms, 4), "ms_wall": round(lut_wall, 3), "flops": lut_flops, "bytes": lut_bytes,
+                             "kernel_roofline": {"bound": "hbm (write)", "achieved": round(wr, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(wr / HBM_PEAK_GBPS, 4),
+                                                 "kernel_ms": round(lut_ms, 4),
+                                                 "mfma": {"achieved_TFLOPs": round(lut_flops / (lut_ms * 1e-3) / 1e12, 2), "peak_TFLOPs": MFMA_F32_PEAK_TFLOPS,
+                                                          "frac": round(lut_flops / (lut_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)},
+                                                 "note": "the contraction is 6.4 GFLOP for %d MB of LUTs written: the matrix cores make the table, the write bounds it" % (nq_h * 96 // 1024)}}
     # ---- HNSW: build through the PQ scorer (point_scorer.rs:197-212), PQ walk ef = 128 ----
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -729,6 +743,21 @@ def c4_section(ctx):
     bfr = qa.new_raw_scorer(queries[:32].contiguous(), vs)
     res, st, _ = _timed_quantized(ctx, bfs, bfr, top, 2.0, True, None, 0, 3, quant.m, n_rows_scanned=n)
     st["recall_at_10_vs_exact"] = round(_recall(res, exact[:32], top), 4)
+    if "pq_prefilter_kernel" in st["kernel"] and st["kernel_ms"] > 0:
+        # what bounds pq_prefilter_kernel is not the 0.96 GB it streams: one ds_read_b32 per (row, chunk, 4 queries) + two vector instructions per gather + one
+        # int8 matrix instruction per 4 gathers.  The LDS serves a wave's ds_read_b32 in two groups of 32 lanes (MI355X guide): 32 lane-reads per clock and CU.
+        # PMC of this kernel (profiles/r3_c4_pq_prefilter_q32_pmc.txt, unchanged since): no bank conflicts; LDS index unit active 41 %, vector ALU 49 %, matrix
+        # cores 41 % of the kernel's cycles - an issue-bound kernel whose dependent ds_read -> mfma chains keep three pipes each about half busy
+        m_pad = (quant.m + 31) // 32 * 32
+        lane_reads = float(n) * (32 // 4) * m_pad
+        cus, clk = torch.cuda.get_device_properties(dev).multi_processor_count, 2.4e9
+        peak = cus * 32 * clk
+        st["roofline"]["hbm_frac"] = st["roofline"]["frac"]
+        st["roofline"]["lds"] = {"lane_reads_per_s": round(lane_reads / (st["kernel_ms"] * 1e-3), 0), "peak_lane_reads_per_s": peak,
+                                 "frac": round(lane_reads / (st["kernel_ms"] * 1e-3) / peak, 4),
+                                 "what": "ds_read_b32 lane-reads (one per row, chunk and 4 queries) against CUs x 32 lanes x 2.4 GHz",
+                                 "pmc": "profiles/r3_c4_pq_prefilter_q32_pmc.txt: SQ_LDS_BANK_CONFLICT 0, SQ_LDS_IDX_ACTIVE 2.40e8, SQ_INSTS_LDS 1.2e8, SQ_INSTS_VALU 2.86e8, SQ_INSTS_MFMA 3.0e7 per launch"}
+        st["roofline"]["bound"] = "lds"
     out["brute_force_Q32_oversampling2_rescore"] = st
     if args.verify:
         import oracle_ffi as O

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--c4-rows", type=int, default=0)
     ap.add_argument("--nq", type=int, default=8192)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--graph-cache", default="", help="npz file: the C3 graph is loaded from it when it exists, built and saved otherwise (PMC passes re-run the process)")
     ap.add_argument("--variants", nargs="+", default=["hnsw_spec=0", "hnsw_spec=1", "hnsw_spec=2"], help="name=value[,name=value] per variant")
     args = ap.parse_args()
     import numpy as np
@@ -81,8 +82,25 @@ def main():
     enc = qa.EncodedVectorsU8(codes, quant)
     del codes
     t0 = time.perf_counter()
-    graph = qa.GraphLayers.build(enc, m=16, ef_construct=100, seed=42)
-    print(json.dumps({"walk": "C3", "build_s": round(time.perf_counter() - t0, 2)}), flush=True)
+    if args.graph_cache and os.path.exists(args.graph_cache):
+        z = np.load(args.graph_cache)
+
+        class Plain:
+            pass
+        pl = Plain()
+        for k in ("reindex", "level_offsets", "offsets", "neighbors", "ep_ids", "ep_levels", "xp_ids", "xp_levels"):
+            setattr(pl, k, z[k])
+        pl.m, pl.m0 = int(z["m"]), int(z["m0"])
+        graph = qa.GraphLayers.from_plain(pl)
+        print(json.dumps({"walk": "C3", "loaded_s": round(time.perf_counter() - t0, 2)}), flush=True)
+    else:
+        graph = qa.GraphLayers.build(enc, m=16, ef_construct=100, seed=42)
+        print(json.dumps({"walk": "C3", "build_s": round(time.perf_counter() - t0, 2)}), flush=True)
+        if args.graph_cache:
+            pl = graph.export_plain()
+            np.savez(args.graph_cache, m=pl.m, m0=pl.m0, reindex=pl.reindex, level_offsets=pl.level_offsets, offsets=pl.offsets, neighbors=pl.neighbors,
+                     ep_ids=pl.ep_ids, ep_levels=pl.ep_levels, xp_ids=np.asarray(getattr(pl, "xp_ids", ()), dtype=np.uint32),
+                     xp_levels=np.asarray(getattr(pl, "xp_levels", ()), dtype=np.uint32))
     run("C3 SQ", graph, qa.new_raw_scorer(queries.contiguous(), enc), quant.quantized_vector_size(), n)
     graph.close()
     del enc, rows, graph
