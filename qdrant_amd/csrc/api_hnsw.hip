@@ -901,6 +901,11 @@ int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
     }
     h.visited = (uint32_t *)q->hnsw_vis.p;
     h.vis_log = (uint32_t *)q->hnsw_log.p;
+    if (!option(OPT_HNSW_STATIC_SLOTS)) {      // the slots draw their searches from a counter that starts behind the first `slots` (hnsw.hpp)
+        QMX_TRY(q->hnsw_next.reserve(4));
+        QMX_HIP(hipMemsetD32Async((hipDeviceptr_t)q->hnsw_next.p, (int)slots, 1, q->stream));
+        h.next_query = (uint32_t *)q->hnsw_next.p;
+    }
     size_t slot = 0;
     if (timed) QMX_TRY(timing_begin(q, &slot));
     QMX_TRY(launch_hnsw(q, a, h, (uint32_t)slots, &per_cu));

@@ -1136,7 +1136,16 @@ __global__ __launch_bounds__(64) QMX_WALK_KERNEL_ATTR void hnsw_search_kernel(co
         LdsVisited{vtab}.clear(lane);
         __syncthreads();
     }
-    for (uint32_t qi = blockIdx.x; qi < h.nq; qi += gridDim.x) {
+    // Searches are handed out one at a time (h.next_query, set to gridDim.x by the host): a slot that finishes takes the next unstarted search.  With the
+    // static stride qi += gridDim.x the launch lasted ceil(nq / slots) searches of the slowest slot - 8 192 searches on 2 304 slots paid for 4 rounds while
+    // doing 3.56 (profiles/r5_sq_walk_visited.md).
+    auto next_search = [&](uint32_t qi) -> uint32_t {
+        if (!h.next_query) return qi + gridDim.x;
+        uint32_t v = 0;
+        if (lane == 0) v = atomicAdd(h.next_query, 1u);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    };
+    for (uint32_t qi = blockIdx.x; qi < h.nq; qi = next_search(qi)) {
         if constexpr (is_maxsim<H>::value) {
             // (the header always sits in LDS; the entries follow when the launch's budget holds them, else they are read where they lie)
             const uint32_t t0 = a.mv_qfirst[qi], n_tokens = a.mv_qfirst[qi + 1] - t0;

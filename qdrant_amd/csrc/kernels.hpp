@@ -131,6 +131,7 @@ struct HnswArgs {
     uint32_t pop_cap;
     // option hnsw_reference_heap_order (a verification mode): `nearest` and `candidates` are the reference's two binary heaps, worked by one lane
     // in std's exact sift order; `nearest` lives in LDS, `candidates` (unbounded in the reference) in this per-slot scratch
+    uint32_t *next_query;           // device counter the slots draw their next search from (starts at the grid size); nullptr: the static stride
     uint32_t vis_lds;               // bytes of the search's visited table in LDS (hnsw.hpp LdsVisited: 0 or HNSW_VIS_LDS_BYTES); the HBM bitmap then holds what its buckets cannot
     uint32_t ref_heaps;
     uint32_t ref_cap;               // entries of a slot's candidates heap; a search that needs more raises err_flag = 2
