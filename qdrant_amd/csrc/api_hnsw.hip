@@ -861,6 +861,17 @@ int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
     // the visited set in LDS (hnsw.hpp LdsVisited) where the search has room for it beside its query entry; the bitmap below stays allocated for what the
     // table's buckets cannot hold
     h.vis_lds = (!acorn && !h.ref_heaps && !option(OPT_HNSW_NO_LDS_VISITED) && g->n_points <= HNSW_VIS_LDS_MAX_POINTS && h.lds_query_bytes <= 32 * 1024) ? HNSW_VIS_LDS_BYTES : 0;
+    // the PQ walk through per-search LUTs (HopPQ, not the LUT-free / block walks): the LUTs' 8-bit images for the hop prefilter (pq.hip HopPQ::prefilter), built
+    // here from the batch's f32 LUTs.  Its 24 KiB per search take the LDS the visited table would: that walk keeps the bitmap
+    if (s->dtype == QMX_DTYPE_PQ && !pq_direct && !acorn && !xo && !mw && !cw && !h.ref_heaps && !option(OPT_HNSW_NO_PQ_PREFILTER) && a.queries == q->d_queries &&
+        s->pq_m <= 128 && s->pq.n_centroids <= 256 && q->q_stride > 16 * 1024 && h.lds_query_bytes == 0 && option(OPT_NO_HNSW_PQ_BLOCK)) {
+        const uint32_t st8 = pq_walk_lut8_stride(s->pq_m);
+        QMX_TRY(q->hnsw_pq8.reserve((size_t)n_searches * st8));
+        QMX_TRY(launch_pq_walk_lut8(q->stream, q->d_queries, q->q_stride, n_searches, s->pq_m, s->pq.n_centroids, q->hnsw_pq8.p));
+        h.pq8 = (const unsigned char *)q->hnsw_pq8.p;
+        h.pq8_stride = st8;
+        h.vis_lds = 0;
+    }
     h.log_cap = HNSW_LOG_CAP;
     {   // tests: force the whole-bitmap clear path
         const int64_t v = option(OPT_HNSW_LOG_CAP);
@@ -878,6 +889,9 @@ int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
     int per_cu = 1;
     QMX_TRY(launch_hnsw(q, a, h, 0, &per_cu));
     if (s->dtype == QMX_DTYPE_PQ && h.lds_query_bytes == 0 && option(OPT_HNSW_PQ_PER_CU) > 0) per_cu = (int)std::min<int64_t>(per_cu, option(OPT_HNSW_PQ_PER_CU));
+    // whole waves per SIMD: with 9 searches per CU one SIMD carries three waves and the others two, and the slowest SIMD sets the pace
+    // (measured on the SQ walk at 10 M points: 5.76 ms with 8 per CU, 6.09 with 9, 6.23 with 7: profiles/r5_sq_walk_visited.md)
+    if (per_cu > 4) per_cu -= per_cu % 4;
     if (option(OPT_HNSW_PER_CU) > 0) per_cu = (int)std::min<int64_t>(per_cu, option(OPT_HNSW_PER_CU));
     uint64_t slots = std::min<uint64_t>({(uint64_t)n_searches, (uint64_t)s->num_cus * per_cu, (uint64_t)HNSW_SLOT_CAP});
     const uint64_t by_budget = std::max<uint64_t>(1, HNSW_VIS_BUDGET / (h.vis_words * 4));

@@ -55,6 +55,7 @@ enum Option {
     OPT_HNSW_PQ_TABLE_BUILD,  // the PQ build scores through per-insertion LUTs and the centroid pair table (round 2's build: 100 TB of table sectors per 2 M points) instead of
                               // recomputing both kinds of entries from the codebook (pq.hip HopPQDirectBuild + HopPQInternalDirect, the default where the codebook allows)
     OPT_I8_SCAN_DEEP,         // the int8-copy prefilter scans through the half-stage pipeline (scan_i8copy_deep_kernel: 80 KiB of rows in flight per CU, twice the barriers: 14 % slower)
+    OPT_HNSW_NO_PQ_PREFILTER, // the PQ walk scores every hop candidate exactly (rounds 1-4) instead of dropping, on an 8-bit upper bound, those the beam cannot take
     OPT_HNSW_STATIC_SLOTS,    // the walk's slots take searches slot, slot + grid, ... (rounds 1-4) instead of drawing the next unstarted one from a counter
     OPT_HNSW_NO_LDS_VISITED,  // the walk's visited set lives in the per-slot HBM bitmap only (rounds 1-4), not in the 16 KiB LDS table in front of it
     OPT_PQ_LUT_NO_LDS,        // the MFMA LUT build reads its operands from global memory per instruction (round 1's pq_lut_mfma_kernel) instead of staging both in LDS

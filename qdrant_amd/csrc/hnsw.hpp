@@ -190,6 +190,12 @@ struct HopMaxSimInternal {
     }
 };
 
+// a hop policy that can drop candidates on an upper bound of their score before the exact scoring (H::prefilter): HopPQ's 8-bit LUT image, pq.hip
+template <class H, class = void>
+struct has_hop_prefilter { static constexpr bool value = false; };
+template <class H>
+struct has_hop_prefilter<H, decltype((void)H::HOP_PREFILTER)> { static constexpr bool value = H::HOP_PREFILTER; };
+
 // a hop policy that scores a whole hop itself, wave-cooperatively (H::hop): TurboQuant over Manhattan, tq_l1_policy.hpp
 template <class H, class = void>
 struct is_tql1 { static constexpr bool value = false; };
@@ -625,7 +631,7 @@ __device__ __forceinline__ void hop_score(const ScanArgs &a, const unsigned char
 template <class H, int E>
 __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArgs &h, const unsigned char *qp,
                                                 uint32_t *hop_ids, float *hop_scores, uint32_t *vis, uint32_t *vlog,
-                                                uint32_t qi, int lane, unsigned char *beam_lds = nullptr, uint32_t *vtab = nullptr) {
+                                                uint32_t qi, int lane, unsigned char *beam_lds = nullptr, uint32_t *vtab = nullptr, const unsigned char *pq8 = nullptr) {
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     uint32_t n_scored = 0;
 
@@ -1037,6 +1043,10 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
                 if (keep && in_bm && log_cnt + brank < h.log_cap) vlog[log_cnt + brank] = id >> 5;
                 log_cnt += (uint32_t)__popcll(bm);
             }
+            n_scored += k;
+            if constexpr (has_hop_prefilter<H>::value) {      // candidates that cannot beat the beam's worst entry leave here, unscored (the same walk: see H::prefilter)
+                if (pq8 && !h.expanded) k = H::prefilter(a, pq8, hop_ids, k, beam.at(ef - 1), lane);
+            }
             hop_score<H>(a, qp, hop_ids, hop_scores, k, lane);
             const uint64_t mykey = (uint32_t)lane < k ? make_key(hop_scores[lane], hop_ids[lane]) : 0;
             uint64_t mm = __ballot(mykey > beam.at(ef - 1));
@@ -1055,7 +1065,6 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
                     beam.insert(nk, ef, lane);
                 }
             }
-            n_scored += k;
         }
     }
     if (h.expanded) {
@@ -1145,7 +1154,21 @@ __global__ __launch_bounds__(64) QMX_WALK_KERNEL_ATTR void hnsw_search_kernel(co
         if (lane == 0) v = atomicAdd(h.next_query, 1u);
         return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
     };
+    // HopPQ's 8-bit LUT image of the search (HnswArgs::pq8), behind the visited table
+    unsigned char *pq8_lds = nullptr;
+    if constexpr (has_hop_prefilter<H>::value) {
+        if (h.pq8) pq8_lds = beam_lds + (E <= 0 ? hnsw_beam_lds(h.ef > h.top ? h.ef : h.top) : 0) + h.vis_lds;
+    }
     for (uint32_t qi = blockIdx.x; qi < h.nq; qi = next_search(qi)) {
+        if constexpr (has_hop_prefilter<H>::value) {
+            if (pq8_lds) {
+                __syncthreads();
+                const uint4 *src = reinterpret_cast<const uint4 *>(h.pq8 + (uint64_t)qi * h.pq8_stride);
+                uint4 *dst = reinterpret_cast<uint4 *>(pq8_lds);
+                for (uint32_t i = (uint32_t)lane; i < h.pq8_stride / 16; i += 64) dst[i] = src[i];
+                __syncthreads();
+            }
+        }
         if constexpr (is_maxsim<H>::value) {
             // (the header always sits in LDS; the entries follow when the launch's budget holds them, else they are read where they lie)
             const uint32_t t0 = a.mv_qfirst[qi], n_tokens = a.mv_qfirst[qi + 1] - t0;
@@ -1162,7 +1185,7 @@ __global__ __launch_bounds__(64) QMX_WALK_KERNEL_ATTR void hnsw_search_kernel(co
                 *reinterpret_cast<const unsigned char **>(q_lds + 8) = fits ? q_lds + 16 : qg;
             }
             __syncthreads();
-            hnsw_search_one<H, E>(a, h, q_lds + 16, hop_ids, hop_scores, vis, vlog, qi, lane, beam_lds, vtab);
+            hnsw_search_one<H, E>(a, h, q_lds + 16, hop_ids, hop_scores, vis, vlog, qi, lane, beam_lds, vtab, pq8_lds);
             continue;
         }
         if constexpr (is_custom<H>::value) {
@@ -1195,7 +1218,7 @@ __global__ __launch_bounds__(64) QMX_WALK_KERNEL_ATTR void hnsw_search_kernel(co
                     hd->ex_off = tab;
                 }
                 __syncthreads();
-                hnsw_search_one<H, E>(a, h, q_lds + sizeof(CustomHeader), hop_ids, hop_scores, vis, vlog, qi, lane, beam_lds, vtab);
+                hnsw_search_one<H, E>(a, h, q_lds + sizeof(CustomHeader), hop_ids, hop_scores, vis, vlog, qi, lane, beam_lds, vtab, pq8_lds);
                 continue;
             }
             const bool fits = sizeof(CustomHeader) + (uint64_t)ne * a.q_stride <= h.lds_query_bytes;
@@ -1212,7 +1235,7 @@ __global__ __launch_bounds__(64) QMX_WALK_KERNEL_ATTR void hnsw_search_kernel(co
                 hd->ex_off = nullptr;
             }
             __syncthreads();
-            hnsw_search_one<H, E>(a, h, q_lds + sizeof(CustomHeader), hop_ids, hop_scores, vis, vlog, qi, lane, beam_lds, vtab);
+            hnsw_search_one<H, E>(a, h, q_lds + sizeof(CustomHeader), hop_ids, hop_scores, vis, vlog, qi, lane, beam_lds, vtab, pq8_lds);
             continue;
         }
         const unsigned char *qg = reinterpret_cast<const unsigned char *>(a.queries) + (uint64_t)qi * a.q_stride;
@@ -1223,9 +1246,9 @@ __global__ __launch_bounds__(64) QMX_WALK_KERNEL_ATTR void hnsw_search_kernel(co
             const uint32_t q_units = (h.lds_query_bytes < a.q_stride ? h.lds_query_bytes : a.q_stride) / 16;     // (a policy may own scratch behind its entry)
             for (uint32_t i = (uint32_t)lane; i < q_units; i += 64) dst[i] = src[i];
             __syncthreads();
-            hnsw_search_one<H, E>(a, h, q_lds, hop_ids, hop_scores, vis, vlog, qi, lane, beam_lds, vtab);
+            hnsw_search_one<H, E>(a, h, q_lds, hop_ids, hop_scores, vis, vlog, qi, lane, beam_lds, vtab, pq8_lds);
         } else {
-            hnsw_search_one<H, E>(a, h, qg, hop_ids, hop_scores, vis, vlog, qi, lane, beam_lds, vtab);
+            hnsw_search_one<H, E>(a, h, qg, hop_ids, hop_scores, vis, vlog, qi, lane, beam_lds, vtab, pq8_lds);
         }
     }
 }
@@ -1250,7 +1273,7 @@ int32_t hnsw_occupancy_inst(uint32_t lds_query_bytes, size_t hop_lds, int *per_c
 template <class H, int E, bool QLDS>
 int32_t launch_hnsw_inst(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid) {
     const uint32_t ef = h.ef > h.top ? h.ef : h.top;
-    const size_t lds = 8 * (size_t)h.hop_cap + hnsw_acorn_lds(h.acorn, h.m0) + (QLDS ? ((size_t)h.lds_query_bytes + 15) / 16 * 16 : 0) + (E <= 0 ? hnsw_beam_lds(ef) : 0) + h.vis_lds;
+    const size_t lds = 8 * (size_t)h.hop_cap + hnsw_acorn_lds(h.acorn, h.m0) + (QLDS ? ((size_t)h.lds_query_bytes + 15) / 16 * 16 : 0) + (E <= 0 ? hnsw_beam_lds(ef) : 0) + h.vis_lds + (h.pq8 ? h.pq8_stride : 0);
     QMX_REQUIRE(lds <= 160 * 1024, QMX_ERR_NOT_SUPPORTED, "hnsw walk: %zu bytes of LDS (query entry + a list of %u)", lds, ef);
     ::qmx::clear_stale_error();
     QMX_NOTE_KERNEL((hnsw_search_kernel<H, E, QLDS>));
@@ -1276,7 +1299,7 @@ int32_t launch_hnsw_hop(hipStream_t st, const ScanArgs &a, const HnswArgs &h, ui
     if (h.ref_heaps) {      // option hnsw_reference_heap_order: the plain walk of the policies a stored graph is walked with
         if constexpr (ref_heaps_built<H>::value) {
             QMX_REQUIRE(!h.acorn && !h.expanded, QMX_ERR_NOT_SUPPORTED, "hnsw_reference_heap_order: the plain walk only (not ACORN, not search_with_vectors)");
-            const size_t hop_lds = 8 * (size_t)h.hop_cap + hnsw_beam_lds(ef) + h.vis_lds;
+            const size_t hop_lds = 8 * (size_t)h.hop_cap + hnsw_beam_lds(ef) + h.vis_lds + (h.pq8 ? h.pq8_stride : 0);
             if (grid == 0) return qlds ? hnsw_occupancy_inst<H, HNSW_E_REF, true>(h.lds_query_bytes, hop_lds, per_cu) : hnsw_occupancy_inst<H, HNSW_E_REF, false>(0, hop_lds, per_cu);
             return qlds ? launch_hnsw_inst<H, HNSW_E_REF, true>(st, a, h, grid) : launch_hnsw_inst<H, HNSW_E_REF, false>(st, a, h, grid);
         } else {
@@ -1286,18 +1309,18 @@ int32_t launch_hnsw_hop(hipStream_t st, const ScanArgs &a, const HnswArgs &h, ui
     }
     if (ef > HNSW_MAX_EF_REG) {        // the LDS beam: one instantiation per policy, the query entry staged
         QMX_REQUIRE(qlds, QMX_ERR_NOT_SUPPORTED, "hnsw ef %u > %u needs the query entry in LDS (it does not fit)", ef, HNSW_MAX_EF_REG);
-        if (grid == 0) return hnsw_occupancy_inst<H, 0, true>(h.lds_query_bytes, 8 * (size_t)h.hop_cap + hnsw_acorn_lds(h.acorn, h.m0) + hnsw_beam_lds(ef) + h.vis_lds, per_cu);
+        if (grid == 0) return hnsw_occupancy_inst<H, 0, true>(h.lds_query_bytes, 8 * (size_t)h.hop_cap + hnsw_acorn_lds(h.acorn, h.m0) + hnsw_beam_lds(ef) + h.vis_lds + (h.pq8 ? h.pq8_stride : 0), per_cu);
         return launch_hnsw_inst<H, 0, true>(st, a, h, grid);
     }
     if constexpr (is_custom<H>::value || is_maxsim<H>::value) {      // (always staged: no instantiation that reads the entry from global memory)
         if (grid == 0) {
-            const size_t hop_lds = 8 * (size_t)h.hop_cap + hnsw_acorn_lds(h.acorn, h.m0) + h.vis_lds;
+            const size_t hop_lds = 8 * (size_t)h.hop_cap + hnsw_acorn_lds(h.acorn, h.m0) + h.vis_lds + (h.pq8 ? h.pq8_stride : 0);
             return ef <= 128 ? hnsw_occupancy_inst<H, 2, true>(h.lds_query_bytes, hop_lds, per_cu) : hnsw_occupancy_inst<H, 8, true>(h.lds_query_bytes, hop_lds, per_cu);
         }
         return ef <= 128 ? launch_hnsw_inst<H, 2, true>(st, a, h, grid) : launch_hnsw_inst<H, 8, true>(st, a, h, grid);
     } else {
     if (grid == 0) {
-        const size_t hop_lds = 8 * (size_t)h.hop_cap + hnsw_acorn_lds(h.acorn, h.m0) + h.vis_lds;
+        const size_t hop_lds = 8 * (size_t)h.hop_cap + hnsw_acorn_lds(h.acorn, h.m0) + h.vis_lds + (h.pq8 ? h.pq8_stride : 0);
         if (ef <= 128) return qlds ? hnsw_occupancy_inst<H, 2, true>(h.lds_query_bytes, hop_lds, per_cu) : hnsw_occupancy_inst<H, 2, false>(0, hop_lds, per_cu);
         return qlds ? hnsw_occupancy_inst<H, 8, true>(h.lds_query_bytes, hop_lds, per_cu) : hnsw_occupancy_inst<H, 8, false>(0, hop_lds, per_cu);
     }

@@ -131,6 +131,10 @@ struct HnswArgs {
     uint32_t pop_cap;
     // option hnsw_reference_heap_order (a verification mode): `nearest` and `candidates` are the reference's two binary heaps, worked by one lane
     // in std's exact sift order; `nearest` lives in LDS, `candidates` (unbounded in the reference) in this per-slot scratch
+    // PQ walk (HopPQ): per search an 8-bit image of its LUT (pq.hip pq_walk_lut8_kernel: [32-byte header: L, Es, step as f64, usable][m x 256 bytes]) staged in
+    // LDS; a hop's candidates are scored against it first and only those whose upper bound reaches the beam's worst score are scored exactly
+    const unsigned char *pq8;       // [nq][pq8_stride] or nullptr
+    uint32_t pq8_stride;            // bytes per search (16-byte multiple) = what is staged in LDS
     uint32_t *next_query;           // device counter the slots draw their next search from (starts at the grid size); nullptr: the static stride
     uint32_t vis_lds;               // bytes of the search's visited table in LDS (hnsw.hpp LdsVisited: 0 or HNSW_VIS_LDS_BYTES); the HBM bitmap then holds what its buckets cannot
     uint32_t ref_heaps;
@@ -198,6 +202,9 @@ int32_t launch_hnsw_maxsim_pq(hipStream_t st, const ScanArgs &a, const HnswArgs 
 int32_t launch_hnsw_maxsim_tq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);      // (hnsw_maxsim_tq.hip)
 int32_t launch_hnsw_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_pq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
+// the 8-bit images of a batch's LUTs for the walk's hop prefilter (HnswArgs::pq8); bytes per search: pq_walk_lut8_stride(m)
+static inline uint32_t pq_walk_lut8_stride(uint32_t m) { return 32u + m * 256u; }
+int32_t launch_pq_walk_lut8(hipStream_t st, const void *d_luts, uint32_t q_stride, uint32_t nq, uint32_t m, uint32_t ncent, void *d_out);
 int32_t launch_hnsw_bq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_pack_level0(hipStream_t st, const uint64_t *offsets, const uint32_t *neighbors, uint32_t n_points, uint32_t stride, uint32_t *l0);
 constexpr uint32_t HNSW_VIS_LDS_BYTES = 16384;                 // the walk's visited table in LDS (hnsw.hpp LdsVisited): 1024 buckets x 8 tags of 16 bits

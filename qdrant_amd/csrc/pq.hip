@@ -388,9 +388,120 @@ struct HopPQ {
         for (c = m4; c < m; ++c) sum += lut[c * ncent + codes[c]];
         return sum;
     }
+    // ---- the hop prefilter (round 5) ----
+    // A search scores ~3 600 candidates and the beam admits a fraction of them; every exact score is m gathers from the search's own 96 KiB LUT through L2
+    // (61 x the useful bytes in HBM traffic).  The LUT quantised to 8 bits (pq_walk_lut8_kernel: q_cj = rint((LUT[c][j] - lo_c) / step), one step per query)
+    // fits the LDS, and a candidate's integer sum A bounds its exact score from above: S <= L + step (A + PQF_ROUND m) + Es (the bound of pq_prefilter.hip).
+    // A candidate whose upper bound is below the score of the beam's worst entry cannot be inserted - the reference's process_candidate would reject it on
+    // its exact score - so it is dropped WITHOUT the exact score; the others are compacted in link order and scored exactly as before.  The walk is the same
+    // walk (same inserts in the same order, same counters: the dropped candidates still count as scored, as in the reference where they were).
+    static constexpr bool HOP_PREFILTER = true;
+    // hop_ids[0..k) -> the surviving ids, in order, at hop_ids[0..k'); returns k'.  `bound` = key of the beam's worst entry (0: not full, everything passes)
+    static __device__ __forceinline__ uint32_t prefilter(const ScanArgs &a, const unsigned char *pq8, uint32_t *hop_ids, uint32_t k, uint64_t bound, int lane) {
+        const double L = *reinterpret_cast<const double *>(pq8), Es = *reinterpret_cast<const double *>(pq8 + 8), step = *reinterpret_cast<const double *>(pq8 + 16);
+        const uint32_t usable = *reinterpret_cast<const uint32_t *>(pq8 + 24);
+        if (!usable || bound == 0) return k;
+        const uint32_t m = a.pq_m;
+        double t = __builtin_floor(((double)key_score(bound) - L - Es) / step - PQ_WALK_ROUND * (double)m) - 1.0;
+        if (!(t > 0.0)) return k;                                   // (also NaN bounds: nothing is dropped)
+        const uint32_t a_min = t > 1.0e9 ? 1000000000u : (uint32_t)t;
+        const unsigned char *tab = pq8 + 32;
+        const int sub = lane & 3, g = lane >> 2;
+        const uint64_t lt_mask = (1ull << lane) - 1ull;
+        uint32_t kept = 0;
+        __syncthreads();      // hop_ids written by other lanes
+        for (uint32_t base = 0; base < k; base += 16) {
+            const uint32_t j = base + (uint32_t)g;
+            const bool on = j < k;
+            const uint32_t id = hop_ids[on ? j : 0];
+            const uint8_t *codes = reinterpret_cast<const uint8_t *>(a.rows) + (uint64_t)id * a.row_stride;
+            uint32_t sum = 0;
+            for (uint32_t c = (uint32_t)sub; c < m; c += 4) sum += tab[c * 256u + codes[c]];
+            sum += (uint32_t)__shfl_xor((int)sum, 1, 64);
+            sum += (uint32_t)__shfl_xor((int)sum, 2, 64);
+            const bool pass = on && sub == 0 && sum >= a_min;
+            const uint64_t pm = __ballot(pass);
+            if (pass) hop_ids[kept + (uint32_t)__popcll(pm & lt_mask)] = id;      // (positions <= j: never an entry a later pass still has to read)
+            kept += (uint32_t)__popcll(pm);
+        }
+        return kept;
+    }
+    static constexpr double PQ_WALK_ROUND = 0.5 + 1.0e-4;           // = PQF_ROUND of pq_prefilter.hip: rint's half + the f32 evaluation of the quotient
 };
 int32_t launch_hnsw_pq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
     return launch_hnsw_hop<HopPQ>(st, a, h, grid, per_cu);
+}
+
+// One block per query, thread j = centroid j: the 8-bit image of the query's f32 LUT [m][ncent] for HopPQ::prefilter.
+//   lo_c = min_j LUT[c][j], R = max_c (max_j - min_j), step = R / 255, q_cj = rint((LUT[c][j] - lo_c) / step) in 0..255 (centroids past ncent: 255, never read)
+//   header: L = sum_c lo_c, Es = (m + 1) 2^-24 sum_c max_j |LUT[c][j]| (the f32 rounding of the exact sum), step; usable = 0 for flat or non-finite tables
+__global__ __launch_bounds__(256) void pq_walk_lut8_kernel(const unsigned char *luts, uint32_t q_stride, uint32_t m, uint32_t ncent, unsigned char *out, uint32_t out_stride) {
+    __shared__ float sh_lo[128], sh_hi[128], sh_ab[128];
+    __shared__ int sh_bad;
+    const uint32_t q = blockIdx.x, j = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float *lut = reinterpret_cast<const float *>(luts + (uint64_t)q * q_stride);
+    unsigned char *dst = out + (uint64_t)q * out_stride;
+    if (j == 0) sh_bad = 0;
+    __syncthreads();
+    int bad = 0;
+    for (uint32_t c = (uint32_t)wave; c < m; c += 4) {
+        float mn = __builtin_inff(), mx = -__builtin_inff(), ab = 0.0f;
+        for (uint32_t jj = (uint32_t)lane; jj < ncent; jj += 64) {
+            const float v = lut[(uint64_t)c * ncent + jj];
+            if ((v != v) || !(__builtin_fabsf(v) < 3.0e38f)) bad = 1;
+            mn = __builtin_fminf(mn, v);
+            mx = __builtin_fmaxf(mx, v);
+            ab = __builtin_fmaxf(ab, __builtin_fabsf(v));
+        }
+        for (int o = 32; o >= 1; o >>= 1) {
+            mn = __builtin_fminf(mn, __shfl_xor(mn, o, 64));
+            mx = __builtin_fmaxf(mx, __shfl_xor(mx, o, 64));
+            ab = __builtin_fmaxf(ab, __shfl_xor(ab, o, 64));
+        }
+        if (lane == 0) { sh_lo[c] = mn; sh_hi[c] = mx; sh_ab[c] = ab; }
+    }
+    if (bad) sh_bad = 1;
+    __syncthreads();
+    float R = 0.0f, E = 0.0f;
+    double L = 0.0;
+    for (uint32_t c = 0; c < m; ++c) {          // (every thread: the sums in chunk order)
+        R = __builtin_fmaxf(R, sh_hi[c] - sh_lo[c]);
+        E += sh_ab[c];
+        L += (double)sh_lo[c];
+    }
+    const bool flat = !(R > 0.0f) || !(R < 3.0e38f) || sh_bad;
+    const float inv_step = flat ? 0.0f : 255.0f / R;
+    for (uint32_t c0 = 0; c0 < m; c0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (c0 + u < m && j < ncent) ? lut[(uint64_t)(c0 + u) * ncent + j] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t c = c0 + (uint32_t)u;
+            if (c < m) {
+                float x = __builtin_rintf((v[u] - sh_lo[c]) * inv_step);
+                x = __builtin_fminf(__builtin_fmaxf(x, 0.0f), 255.0f);
+                dst[32u + c * 256u + j] = (j < ncent && !flat) ? (unsigned char)(uint32_t)x : (unsigned char)255;
+            }
+        }
+    }
+    if (j == 0) {
+        double *hd = reinterpret_cast<double *>(dst);
+        hd[0] = L;
+        hd[1] = (double)(m + 1) * 5.9604644775390625e-08 * (double)E;
+        hd[2] = flat ? 1.0 : (double)R / 255.0;
+        reinterpret_cast<uint32_t *>(dst)[6] = flat ? 0u : 1u;
+        reinterpret_cast<uint32_t *>(dst)[7] = 0u;
+    }
+}
+int32_t launch_pq_walk_lut8(hipStream_t st, const void *d_luts, uint32_t q_stride, uint32_t nq, uint32_t m, uint32_t ncent, void *d_out) {
+    if (nq == 0) return QMX_OK;
+    QMX_REQUIRE(m >= 1 && m <= 128 && ncent >= 1 && ncent <= 256, QMX_ERR_NOT_SUPPORTED, "pq walk prefilter: m %u, %u centroids", m, ncent);
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(pq_walk_lut8_kernel, dim3(nq), dim3(256), 0, st, (const unsigned char *)d_luts, q_stride, m, ncent, (unsigned char *)d_out, pq_walk_lut8_stride(m));
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
 }
 
 // ------------------------------------------------------------------------------------------

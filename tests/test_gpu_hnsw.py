@@ -608,3 +608,40 @@ def test_search_with_vectors_equals_the_oracle(qa, kind, distance, dim):
     def recall(res):
         return np.mean([len(set(r["idx"].tolist()) & set(e["idx"].tolist())) / 10 for r, e in zip(res, exact)])
     assert recall(got) >= recall(plain_walk) - 0.02
+
+
+@pytest.mark.parametrize("distance,dim,chunk", [(O.DOT, 768, 8), (O.EUCLID, 384, 4), (O.COSINE, 1536, 16)])
+def test_pq_walk_hop_prefilter_is_the_same_walk(qa, distance, dim, chunk):
+    """HopPQ::prefilter (round 5): a hop's candidates meet an 8-bit image of the search's LUT in LDS first, and those whose upper bound stays below the beam's
+    worst score are dropped without their exact score.  The reference would have rejected them on the exact score, so the walk must not change at all: the same
+    lists (ids and score bits), the same pop sequence, the same number of scored points as with the option off - and the oracle's walk of the same graph.
+    m = 96 chunks (a 96 KiB LUT read through L2): the shape of BASELINE's C4."""
+    n, m, nq = 4000, 8, 24
+    rows, st, g, plain = _graph(distance, n, dim, m, 0x5EED03C0 + dim)
+    queries = O.synth(0x5EED03C1, 0, nq, dim)
+    qpre = O.preprocess(distance, queries)
+    cen = O.PqOracle.train(rows[:2000], dim, chunk, 256, iters=2)
+    opq = O.PqOracle(distance, dim, chunk, cen)
+    assert opq.m == 96
+    codes = opq.encode(rows)
+    quant = qa.ProductQuantizer(dim, _dist(qa, distance), chunk, cen)
+    graph = qa.GraphLayers.from_plain(plain)
+    scorer = qa.new_raw_scorer(queries, qa.EncodedVectorsPQ(codes, quant))
+    for top, ef in ((10, 64), (20, 128), (5, 600)):
+        (got, pops), (_, scored) = graph.search_traced(top, ef, scorer), graph.search(top, ef, scorer, with_scored=True)
+        assert "HopPQ," in qa._ffi.last_kernel(scorer._h)
+        qa.set_option("hnsw_no_pq_prefilter", 1)
+        try:
+            (plain_lists, plain_pops), (_, plain_scored) = graph.search_traced(top, ef, scorer), graph.search(top, ef, scorer, with_scored=True)
+        finally:
+            qa.set_option("hnsw_no_pq_prefilter", -1)
+        assert scored == plain_scored
+        for a, b, pa, pb in zip(got, plain_lists, pops, plain_pops):
+            assert a["idx"].tolist() == b["idx"].tolist() and np.array_equal(a["score"].view(np.uint32), b["score"].view(np.uint32))
+            assert pa["idx"].tolist() == pb["idx"].tolist() and np.array_equal(pa["score"].view(np.uint32), pb["score"].view(np.uint32))
+        want, stats = g.search_pq(st, opq, qpre, top, ef, with_stats=True)
+        assert scored == sum(stats)
+        for a, w in zip(got, want):
+            assert np.array_equal(a["score"].view(np.uint32), w["score"].view(np.uint32))
+            if len(np.unique(w["score"])) == len(w):
+                assert a["idx"].tolist() == w["idx"].tolist()
