@@ -891,7 +891,7 @@ int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
     if (s->dtype == QMX_DTYPE_PQ && h.lds_query_bytes == 0 && option(OPT_HNSW_PQ_PER_CU) > 0) per_cu = (int)std::min<int64_t>(per_cu, option(OPT_HNSW_PQ_PER_CU));
     // whole waves per SIMD: with 9 searches per CU one SIMD carries three waves and the others two, and the slowest SIMD sets the pace
     // (measured on the SQ walk at 10 M points: 5.76 ms with 8 per CU, 6.09 with 9, 6.23 with 7: profiles/r5_sq_walk_visited.md)
-    if (per_cu > 4) per_cu -= per_cu % 4;
+    if (per_cu >= 8) per_cu -= per_cu % 4;
     if (option(OPT_HNSW_PER_CU) > 0) per_cu = (int)std::min<int64_t>(per_cu, option(OPT_HNSW_PER_CU));
     uint64_t slots = std::min<uint64_t>({(uint64_t)n_searches, (uint64_t)s->num_cus * per_cu, (uint64_t)HNSW_SLOT_CAP});
     const uint64_t by_budget = std::max<uint64_t>(1, HNSW_VIS_BUDGET / (h.vis_words * 4));
