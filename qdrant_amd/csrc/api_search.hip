@@ -312,7 +312,12 @@ int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids, uint64
                 const uint32_t np = split_i8_probe();
                 uint32_t *probe_ids = (uint32_t *)q->sp_probe.p, *probe_cnt = probe_ids + (size_t)q->nq * np;
                 int *tile_ovf = (int *)(plan + pl.tile_ovf) + split_tiles.size();
-                for (uint32_t phase = 1; phase <= 2; ++phase) {
+                // (which tiles the first launch takes: every `i8_sample_stride`-th, 16 by default.  Its candidates are admitted on the SAMPLE's bound - a hundred
+                // times those of the main launch per tile -, so the first launch is bound by its candidate lists, not by its stream: a sparser sample costs the
+                // main launch a slightly weaker bound - the band, not the bound, decides how many rows it lets through - and saves the first launch's time)
+                const uint32_t sstride = (uint32_t)std::min<int64_t>(std::max<int64_t>(option(OPT_I8_SAMPLE_STRIDE), 2), 255);
+                for (uint32_t ph = 1; ph <= 2; ++ph) {
+                    const uint32_t phase = ph | (sstride << 8);
                     size_t slot = 0;
                     if (timed) QMX_TRY(timing_begin(q, &slot));
                     QMX_TRY(launch_scan_i8copy(q->stream, a, q->sp_bq.p, sp_qscale, sp_thr, s->num_cus, s->d_rows_split, q->sp_wl.p, phase));

@@ -54,6 +54,7 @@ enum Option {
     OPT_HNSW_PQ_DIRECT_WALK,  // the PQ walk recomputes LUT entries from the codebook (pq.hip HopPQDirect: a twentieth of the HBM traffic; 1.3 x the time on a 2 M-row graph, the same at 10 M) instead of gathering per-search LUTs
     OPT_HNSW_PQ_TABLE_BUILD,  // the PQ build scores through per-insertion LUTs and the centroid pair table (round 2's build: 100 TB of table sectors per 2 M points) instead of
                               // recomputing both kinds of entries from the codebook (pq.hip HopPQDirectBuild + HopPQInternalDirect, the default where the codebook allows)
+    OPT_I8_SAMPLE_STRIDE,     // the int8 prefilter's first launch takes every n-th 256-row tile (default 16); the second launch the others
     OPT_I8_SCAN_DEEP,         // the int8-copy prefilter scans through the half-stage pipeline (scan_i8copy_deep_kernel: 80 KiB of rows in flight per CU, twice the barriers: 14 % slower)
     OPT_HNSW_NO_PQ_PREFILTER, // the PQ walk scores every hop candidate exactly (rounds 1-4) instead of dropping, on an 8-bit upper bound, those the beam cannot take
     OPT_HNSW_STATIC_SLOTS,    // the walk's slots take searches slot, slot + grid, ... (rounds 1-4) instead of drawing the next unstarted one from a counter

@@ -397,9 +397,12 @@ __global__ __launch_bounds__(SP_THREADS, 1) void scan_f32_split_kernel(const Sca
 // =====================================================================================================================================
 constexpr int SP3_THREADS = 512;
 constexpr uint32_t SP_PHASE_STRIDE = 16;
+// `phase` as the launchers take it: low byte 0 = every tile, 1 = tiles 0, S, 2 S, ... (the strided sample), 2 = all the others; the bytes above = S (0: 16)
+__host__ __device__ inline uint32_t split_phase_stride(uint32_t phase) { const uint32_t st = phase >> 8; return st >= 2 ? st : SP_PHASE_STRIDE; }
 __host__ __device__ inline uint64_t split_phase_tiles(uint64_t all_tiles, uint32_t phase) {
-    const uint64_t first = (all_tiles + SP_PHASE_STRIDE - 1) / SP_PHASE_STRIDE;
-    return phase == 0 ? all_tiles : phase == 1 ? first : all_tiles - first;
+    const uint32_t st = split_phase_stride(phase), ph = phase & 0xFFu;
+    const uint64_t first = (all_tiles + st - 1) / st;
+    return ph == 0 ? all_tiles : ph == 1 ? first : all_tiles - first;
 }
 constexpr uint32_t SP_WCAP = 8192;                           // candidates one wave may list per pass (expected: ~200, heavy-tailed rows under the int8 band: thousands; more -> overflow -> the exact scan)
 constexpr int SP3_BM = SP_BM;                                // 256 rows per tile: a stage is 32 KiB of rows + 16 KiB of queries
@@ -418,10 +421,10 @@ __global__ __launch_bounds__(SP3_THREADS, 1) void scan_f16pair_kernel(const Scan
     const uint64_t n_tiles = split_phase_tiles(all_tiles, s.phase);
     const uint32_t nch = s.nchunks;
     const uint64_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-    const uint32_t phase = s.phase;
+    const uint32_t phase = s.phase & 0xFFu, pstride = split_phase_stride(s.phase);
     // the j-th tile of this launch: every tile | the strided sixteenth (0, 16, 32, ...: a sample that sees the whole block, whatever its
     // order) | the complement (j + j / 15 + 1 skips the multiples of 16)
-    auto tile_of = [&](uint64_t j) -> uint64_t { return phase == 0 ? j : phase == 1 ? j * SP_PHASE_STRIDE : j + j / (SP_PHASE_STRIDE - 1) + 1; };
+    auto tile_of = [&](uint64_t j) -> uint64_t { return phase == 0 ? j : phase == 1 ? j * pstride : j + j / (pstride - 1) + 1; };
     if (my_tiles == 0) {
         if (lane == 0) s.wcnt[blockIdx.x * (SP3_THREADS / 64) + (uint32_t)w] = 0;
         return;
@@ -613,8 +616,8 @@ __global__ __launch_bounds__(SP3_THREADS, 1) void scan_f16half256_kernel(const S
     const uint64_t n_tiles = split_phase_tiles(all_tiles, s.phase);
     const uint32_t nch = s.nchunks;
     const uint64_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-    const uint32_t phase = s.phase;
-    auto tile_of = [&](uint64_t j) -> uint64_t { return phase == 0 ? j : phase == 1 ? j * SP_PHASE_STRIDE : j + j / (SP_PHASE_STRIDE - 1) + 1; };
+    const uint32_t phase = s.phase & 0xFFu, pstride = split_phase_stride(s.phase);
+    auto tile_of = [&](uint64_t j) -> uint64_t { return phase == 0 ? j : phase == 1 ? j * pstride : j + j / (pstride - 1) + 1; };
     if (my_tiles == 0) {
         if (lane == 0) s.wcnt[blockIdx.x * (SP3_THREADS / 64) + (uint32_t)w] = 0;
         return;
@@ -1315,8 +1318,8 @@ __global__ __launch_bounds__(SP3_THREADS, 1) void scan_i8copy_kernel(const ScanA
     const uint64_t n_tiles = split_phase_tiles(all_tiles, s.phase);
     const uint32_t nch = s.nchunks;
     const uint64_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-    const uint32_t phase = s.phase;
-    auto tile_of = [&](uint64_t j) -> uint64_t { return phase == 0 ? j : phase == 1 ? j * SP_PHASE_STRIDE : j + j / (SP_PHASE_STRIDE - 1) + 1; };
+    const uint32_t phase = s.phase & 0xFFu, pstride = split_phase_stride(s.phase);
+    auto tile_of = [&](uint64_t j) -> uint64_t { return phase == 0 ? j : phase == 1 ? j * pstride : j + j / (pstride - 1) + 1; };
     if (my_tiles == 0) {
         if (lane == 0) s.wcnt[blockIdx.x * (SP3_THREADS / 64) + (uint32_t)w] = 0;
         return;
@@ -1497,8 +1500,8 @@ __global__ __launch_bounds__(SP3_THREADS, 1) void scan_i8copy_deep_kernel(const 
     const uint64_t n_tiles = split_phase_tiles(all_tiles, s.phase);
     const uint32_t nch = s.nchunks;
     const uint64_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-    const uint32_t phase = s.phase;
-    auto tile_of = [&](uint64_t j) -> uint64_t { return phase == 0 ? j : phase == 1 ? j * SP_PHASE_STRIDE : j + j / (SP_PHASE_STRIDE - 1) + 1; };
+    const uint32_t phase = s.phase & 0xFFu, pstride = split_phase_stride(s.phase);
+    auto tile_of = [&](uint64_t j) -> uint64_t { return phase == 0 ? j : phase == 1 ? j * pstride : j + j / (pstride - 1) + 1; };
     if (my_tiles == 0) {
         if (lane == 0) s.wcnt[blockIdx.x * (SP3_THREADS / 64) + (uint32_t)w] = 0;
         return;
@@ -1672,8 +1675,8 @@ __global__ __launch_bounds__(SP3_THREADS, 1) void scan_i8copy_kernel_wo(const Sc
     const uint64_t n_tiles = split_phase_tiles(all_tiles, s.phase);
     const uint32_t nch = s.nchunks;
     const uint64_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-    const uint32_t phase = s.phase;
-    auto tile_of = [&](uint64_t j) -> uint64_t { return phase == 0 ? j : phase == 1 ? j * SP_PHASE_STRIDE : j + j / (SP_PHASE_STRIDE - 1) + 1; };
+    const uint32_t phase = s.phase & 0xFFu, pstride = split_phase_stride(s.phase);
+    auto tile_of = [&](uint64_t j) -> uint64_t { return phase == 0 ? j : phase == 1 ? j * pstride : j + j / (pstride - 1) + 1; };
     if (my_tiles == 0) {
         if (lane == 0) s.wcnt[blockIdx.x * (SP3_THREADS / 64) + (uint32_t)w] = 0;
         return;
