@@ -494,7 +494,7 @@ static int32_t hnsw_build_impl(const qmx_segment *seg, const qmx_segment *origin
         h.lds_query_bytes = (uint32_t)((dev_row_bytes + 127) / 128 * 128 + 128);
         uint64_t lut_stride = 0;
         uint64_t max_entries = max_batch;      // query entries a batch may need: one per point - or, multi-vector points, one per inner vector
-        bool pq_direct_build = false;
+        bool pq_direct_build = false, pq_build_prefilter = false;
         if (seg->dtype == QMX_DTYPE_PQ) {   // query entries = LUTs of the batch's original vectors, read through L2 (as the PQ walk does)
             lut_stride = ((uint64_t)seg->pq_m * seg->pq.n_centroids * sizeof(float) + 15) & ~15ull;
             if (mb) {   // at least the longest point, at most 1 GiB of LUTs (the insertion loop shortens a batch that would need more)
@@ -516,6 +516,18 @@ static int32_t hnsw_build_impl(const qmx_segment *seg, const qmx_segment *origin
                 h.batch_queries = (const unsigned char *)b_bqsrc.p;
                 h.batch_q_stride = (uint64_t)seg->dim * 4;
                 h.lds_query_bytes = seg->dim * 4;
+                // + the 8-bit LUT image of every new point behind its vector (pq.hip pq_build_entry_kernel): the insertion searches drop, on its upper bound,
+                // the candidates their beam cannot take before the codebook arithmetic of an exact score
+                pq_build_prefilter = !option(OPT_HNSW_NO_PQ_PREFILTER) && seg->pq_m <= 128 && seg->pq.n_centroids <= 256 &&
+                                     (size_t)seg->pq_m * seg->pq.n_centroids * 4 <= 140 * 1024;
+                if (pq_build_prefilter) {
+                    const uint32_t est = seg->dim * 4 + pq_walk_lut8_stride(seg->pq_m);
+                    QB(b_bq.reserve((size_t)max_entries * est));
+                    h.batch_queries = (const unsigned char *)b_bq.p;
+                    h.batch_q_stride = est;
+                    h.lds_query_bytes = est;
+                    h.pq8_off = seg->dim * 4;
+                }
             }
         }
         if (seg->dtype == QMX_DTYPE_TQ) {   // query entries = precompute_query of the batch's original vectors, staged in LDS per insertion
@@ -609,6 +621,7 @@ static int32_t hnsw_build_impl(const qmx_segment *seg, const qmx_segment *origin
                                         (size_t)seg->dim * 4, nr, hipMemcpyDeviceToDevice, nullptr));
                     if (seg->distance == QMX_DISTANCE_COSINE) QB(launch_cosine_preprocess_f32(nullptr, src, src, nr, seg->dim));
                     if (!pq_direct_build) QB(launch_pq_lut(nullptr, seg->distance, seg->dim, seg->pq, seg->d_centroids, src, (uint32_t)nr, (float *)b_bq.p));
+                    if (pq_build_prefilter) QB(launch_pq_build_entries(nullptr, seg->distance, seg->dim, seg->pq, seg->d_centroids, src, (uint32_t)nr, b_bq.p, (uint32_t)h.batch_q_stride));
                 }
             }
             if (tq_l1(seg)) {   // EncodedVectorsTQ over Manhattan: no preprocessing, no rotation - the rows themselves, zero padded to whole 16 bytes

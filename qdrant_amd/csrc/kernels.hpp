@@ -205,6 +205,9 @@ int32_t launch_hnsw_pq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uin
 // the 8-bit images of a batch's LUTs for the walk's hop prefilter (HnswArgs::pq8); bytes per search: pq_walk_lut8_stride(m)
 static inline uint32_t pq_walk_lut8_stride(uint32_t m) { return 32u + m * 256u; }
 int32_t launch_pq_walk_lut8(hipStream_t st, const void *d_luts, uint32_t q_stride, uint32_t nq, uint32_t m, uint32_t ncent, void *d_out);
+// the entries of a table-free PQ build batch: [the preprocessed original vector: dim floats][its 8-bit LUT image: pq_walk_lut8_stride(m) bytes], out_stride apart
+int32_t launch_pq_build_entries(hipStream_t st, uint32_t distance, uint32_t dim, const qmx_pq_params &pq, const float *d_centroids, const float *d_vecs, uint32_t n,
+                                void *d_out, uint32_t out_stride);
 int32_t launch_hnsw_bq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_pack_level0(hipStream_t st, const uint64_t *offsets, const uint32_t *neighbors, uint32_t n_points, uint32_t stride, uint32_t *l0);
 constexpr uint32_t HNSW_VIS_LDS_BYTES = 16384;                 // the walk's visited table in LDS (hnsw.hpp LdsVisited): 1024 buckets x 8 tags of 16 bits
@@ -252,6 +255,7 @@ struct HnswBuildArgs {
     // (point_scorer.rs:197-212) before phase 1; entry bi = batch_queries + bi * batch_q_stride (global memory; nullptr = stage the row)
     const unsigned char *batch_queries;
     uint64_t batch_q_stride;
+    uint32_t pq8_off;            // table-free PQ build: byte offset, inside a staged batch entry, of the 8-bit LUT image the insertion searches prefilter with (0: none)
 };
 // phase 1 = insertion searches + heuristic selection, phase 2 = linking; grid == 0: report occupancy only
 int32_t launch_hnsw_build_bq(hipStream_t st, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu);

@@ -339,6 +339,39 @@ int32_t launch_pairs_pq(hipStream_t st, const ScanArgs &a, const PairSel &sel, u
     return QMX_OK;
 }
 
+// hop_ids[0..k) -> the ids whose 8-bit upper bound reaches the score of `bound` (the key of the beam's worst entry; 0: the beam is not full, everything
+// passes), in order, at hop_ids[0..k'); returns k'.  See HopPQ below for what it is for.  pq8 = [L, Es, step: f64][usable: u32][pad][m x 256 bytes] (LDS).
+constexpr double PQ_WALK_ROUND = 0.5 + 1.0e-4;           // = PQF_ROUND of pq_prefilter.hip: rint's half + the f32 evaluation of the quotient
+static __device__ __forceinline__ uint32_t pq_hop_prefilter(const ScanArgs &a, const unsigned char *pq8, uint32_t *hop_ids, uint32_t k, uint64_t bound, int lane) {
+    const double L = *reinterpret_cast<const double *>(pq8), Es = *reinterpret_cast<const double *>(pq8 + 8), step = *reinterpret_cast<const double *>(pq8 + 16);
+    const uint32_t usable = *reinterpret_cast<const uint32_t *>(pq8 + 24);
+    if (!usable || bound == 0) return k;
+    const uint32_t m = a.pq_m;
+    const double t = __builtin_floor(((double)key_score(bound) - L - Es) / step - PQ_WALK_ROUND * (double)m) - 1.0;
+    if (!(t > 0.0)) return k;                                   // (also NaN bounds: nothing is dropped)
+    const uint32_t a_min = t > 1.0e9 ? 1000000000u : (uint32_t)t;
+    const unsigned char *tab = pq8 + 32;
+    const int sub = lane & 3, g = lane >> 2;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    uint32_t kept = 0;
+    __syncthreads();      // hop_ids written by other lanes
+    for (uint32_t base = 0; base < k; base += 16) {
+        const uint32_t j = base + (uint32_t)g;
+        const bool on = j < k;
+        const uint32_t id = hop_ids[on ? j : 0];
+        const uint8_t *codes = reinterpret_cast<const uint8_t *>(a.rows) + (uint64_t)id * a.row_stride;
+        uint32_t sum = 0;
+        for (uint32_t c = (uint32_t)sub; c < m; c += 4) sum += tab[c * 256u + codes[c]];
+        sum += (uint32_t)__shfl_xor((int)sum, 1, 64);
+        sum += (uint32_t)__shfl_xor((int)sum, 2, 64);
+        const bool pass = on && sub == 0 && sum >= a_min;
+        const uint64_t pm = __ballot(pass);
+        if (pass) hop_ids[kept + (uint32_t)__popcll(pm & lt_mask)] = id;      // (positions <= j: never an entry a later pass still has to read)
+        kept += (uint32_t)__popcll(pm);
+    }
+    return kept;
+}
+
 // HNSW hop scorer: 4 lanes per code row, lane `sub` owns SSE lane `sub` of score_point_sse (chunks
 // sub, sub+4, ... added in order), the quad is folded as (l0 + l2) + (l1 + l3) like pq_score_row.
 struct HopPQ {
@@ -396,37 +429,9 @@ struct HopPQ {
     // its exact score - so it is dropped WITHOUT the exact score; the others are compacted in link order and scored exactly as before.  The walk is the same
     // walk (same inserts in the same order, same counters: the dropped candidates still count as scored, as in the reference where they were).
     static constexpr bool HOP_PREFILTER = true;
-    // hop_ids[0..k) -> the surviving ids, in order, at hop_ids[0..k'); returns k'.  `bound` = key of the beam's worst entry (0: not full, everything passes)
     static __device__ __forceinline__ uint32_t prefilter(const ScanArgs &a, const unsigned char *pq8, uint32_t *hop_ids, uint32_t k, uint64_t bound, int lane) {
-        const double L = *reinterpret_cast<const double *>(pq8), Es = *reinterpret_cast<const double *>(pq8 + 8), step = *reinterpret_cast<const double *>(pq8 + 16);
-        const uint32_t usable = *reinterpret_cast<const uint32_t *>(pq8 + 24);
-        if (!usable || bound == 0) return k;
-        const uint32_t m = a.pq_m;
-        double t = __builtin_floor(((double)key_score(bound) - L - Es) / step - PQ_WALK_ROUND * (double)m) - 1.0;
-        if (!(t > 0.0)) return k;                                   // (also NaN bounds: nothing is dropped)
-        const uint32_t a_min = t > 1.0e9 ? 1000000000u : (uint32_t)t;
-        const unsigned char *tab = pq8 + 32;
-        const int sub = lane & 3, g = lane >> 2;
-        const uint64_t lt_mask = (1ull << lane) - 1ull;
-        uint32_t kept = 0;
-        __syncthreads();      // hop_ids written by other lanes
-        for (uint32_t base = 0; base < k; base += 16) {
-            const uint32_t j = base + (uint32_t)g;
-            const bool on = j < k;
-            const uint32_t id = hop_ids[on ? j : 0];
-            const uint8_t *codes = reinterpret_cast<const uint8_t *>(a.rows) + (uint64_t)id * a.row_stride;
-            uint32_t sum = 0;
-            for (uint32_t c = (uint32_t)sub; c < m; c += 4) sum += tab[c * 256u + codes[c]];
-            sum += (uint32_t)__shfl_xor((int)sum, 1, 64);
-            sum += (uint32_t)__shfl_xor((int)sum, 2, 64);
-            const bool pass = on && sub == 0 && sum >= a_min;
-            const uint64_t pm = __ballot(pass);
-            if (pass) hop_ids[kept + (uint32_t)__popcll(pm & lt_mask)] = id;      // (positions <= j: never an entry a later pass still has to read)
-            kept += (uint32_t)__popcll(pm);
-        }
-        return kept;
+        return pq_hop_prefilter(a, pq8, hop_ids, k, bound, lane);
     }
-    static constexpr double PQ_WALK_ROUND = 0.5 + 1.0e-4;           // = PQF_ROUND of pq_prefilter.hip: rint's half + the f32 evaluation of the quotient
 };
 int32_t launch_hnsw_pq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
     return launch_hnsw_hop<HopPQ>(st, a, h, grid, per_cu);
@@ -435,14 +440,11 @@ int32_t launch_hnsw_pq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uin
 // One block per query, thread j = centroid j: the 8-bit image of the query's f32 LUT [m][ncent] for HopPQ::prefilter.
 //   lo_c = min_j LUT[c][j], R = max_c (max_j - min_j), step = R / 255, q_cj = rint((LUT[c][j] - lo_c) / step) in 0..255 (centroids past ncent: 255, never read)
 //   header: L = sum_c lo_c, Es = (m + 1) 2^-24 sum_c max_j |LUT[c][j]| (the f32 rounding of the exact sum), step; usable = 0 for flat or non-finite tables
-__global__ __launch_bounds__(256) void pq_walk_lut8_kernel(const unsigned char *luts, uint32_t q_stride, uint32_t m, uint32_t ncent, unsigned char *out, uint32_t out_stride) {
-    __shared__ float sh_lo[128], sh_hi[128], sh_ab[128];
-    __shared__ int sh_bad;
-    const uint32_t q = blockIdx.x, j = threadIdx.x;
+// (the body: `lut` may point at global memory or at LDS; 256 threads)
+static __device__ __forceinline__ void pq_walk_lut8_body(const float *lut, uint32_t m, uint32_t ncent, unsigned char *dst, float *sh_lo, float *sh_hi, float *sh_ab, int *sh_bad) {
+    const uint32_t j = threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float *lut = reinterpret_cast<const float *>(luts + (uint64_t)q * q_stride);
-    unsigned char *dst = out + (uint64_t)q * out_stride;
-    if (j == 0) sh_bad = 0;
+    if (j == 0) *sh_bad = 0;
     __syncthreads();
     int bad = 0;
     for (uint32_t c = (uint32_t)wave; c < m; c += 4) {
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(256) void pq_walk_lut8_kernel(const unsigned char *
         }
         if (lane == 0) { sh_lo[c] = mn; sh_hi[c] = mx; sh_ab[c] = ab; }
     }
-    if (bad) sh_bad = 1;
+    if (bad) *sh_bad = 1;
     __syncthreads();
     float R = 0.0f, E = 0.0f;
     double L = 0.0;
@@ -470,7 +472,7 @@ __global__ __launch_bounds__(256) void pq_walk_lut8_kernel(const unsigned char *
         E += sh_ab[c];
         L += (double)sh_lo[c];
     }
-    const bool flat = !(R > 0.0f) || !(R < 3.0e38f) || sh_bad;
+    const bool flat = !(R > 0.0f) || !(R < 3.0e38f) || *sh_bad;
     const float inv_step = flat ? 0.0f : 255.0f / R;
     for (uint32_t c0 = 0; c0 < m; c0 += 8) {
         float v[8];
@@ -494,6 +496,38 @@ __global__ __launch_bounds__(256) void pq_walk_lut8_kernel(const unsigned char *
         reinterpret_cast<uint32_t *>(dst)[6] = flat ? 0u : 1u;
         reinterpret_cast<uint32_t *>(dst)[7] = 0u;
     }
+}
+__global__ __launch_bounds__(256) void pq_walk_lut8_kernel(const unsigned char *luts, uint32_t q_stride, uint32_t m, uint32_t ncent, unsigned char *out, uint32_t out_stride) {
+    __shared__ float sh_lo[128], sh_hi[128], sh_ab[128];
+    __shared__ int sh_bad;
+    const uint32_t q = blockIdx.x;
+    pq_walk_lut8_body(reinterpret_cast<const float *>(luts + (uint64_t)q * q_stride), m, ncent, out + (uint64_t)q * out_stride, sh_lo, sh_hi, sh_ab, &sh_bad);
+}
+// The same image for the points of a build batch, made from the preprocessed ORIGINAL vector of each: out entry = [the vector, dim floats][the image].  The f32
+// LUT never leaves the LDS (m x ncent floats: 96 KiB at m = 96); its entries are pq_lut_kernel's (from -0.0, one multiply and one add per coordinate, in order),
+// so the image bounds the scores HopPQDirectBuild recomputes from the codebook in that same order.
+__global__ __launch_bounds__(256) void pq_build_entry_kernel(PqGeom g, const float *vecs, const float *centroids, unsigned char *out, uint32_t out_stride) {
+    extern __shared__ float pq_entry_lut[];
+    __shared__ float sh_lo[128], sh_hi[128], sh_ab[128], sub[256];
+    __shared__ int sh_bad;
+    const uint32_t q = blockIdx.x, j = threadIdx.x;
+    const float *v = vecs + (uint64_t)q * g.dim;
+    unsigned char *dst = out + (uint64_t)q * out_stride;
+    for (uint32_t i = j; i < g.dim; i += 256) reinterpret_cast<float *>(dst)[i] = v[i];
+    for (uint32_t c = 0; c < g.m; ++c) {
+        const uint32_t lo = c * g.chunk, hi = min(lo + g.chunk, g.dim);
+        __syncthreads();
+        if (j < hi - lo) sub[j] = v[lo + j];
+        __syncthreads();
+        if (j < g.ncent) {
+            const float *cen = centroids + (uint64_t)j * g.dim + lo;
+            float s = -0.0f;
+            for (uint32_t i = 0; i < hi - lo; ++i) s += pq_term(g.kind, sub[i], cen[i]);
+            pq_entry_lut[c * g.ncent + j] = g.invert ? -s : s;
+        }
+    }
+    __syncthreads();
+    pq_walk_lut8_body(pq_entry_lut, g.m, g.ncent, dst + (size_t)g.dim * 4, sh_lo, sh_hi, sh_ab, &sh_bad);
 }
 int32_t launch_pq_walk_lut8(hipStream_t st, const void *d_luts, uint32_t q_stride, uint32_t nq, uint32_t m, uint32_t ncent, void *d_out) {
     if (nq == 0) return QMX_OK;
@@ -526,6 +560,11 @@ struct HopPQDirect {
     static constexpr bool MULTI = false;
     static constexpr bool INTERNAL_QOFF = false;
     static constexpr bool INTERNAL_NORM = false;
+    // (the build's insertion searches: the batch entry carries the 8-bit LUT image of the new point's query behind its vector, HnswBuildArgs::pq8_off)
+    static constexpr bool HOP_PREFILTER = true;
+    static __device__ __forceinline__ uint32_t prefilter(const ScanArgs &a, const unsigned char *pq8, uint32_t *hop_ids, uint32_t k, uint64_t bound, int lane) {
+        return pq_hop_prefilter(a, pq8, hop_ids, k, bound, lane);
+    }
     static constexpr int V = CHUNK / 4;                      // 16-byte pieces of a chunk
     static constexpr int SPP = 32 / SPLIT;                   // steps per part at most (m <= 128)
     template <int KIND>
@@ -900,6 +939,23 @@ int32_t launch_pq_lut(hipStream_t st, uint32_t distance, uint32_t dim, const qmx
     } else {
         hipLaunchKernelGGL(pq_lut_kernel, dim3(g.m, nq), dim3(256), 0, st, g, d_queries, d_centroids, d_lut);
     }
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
+int32_t launch_pq_build_entries(hipStream_t st, uint32_t distance, uint32_t dim, const qmx_pq_params &pq, const float *d_centroids, const float *d_vecs, uint32_t n,
+                                void *d_out, uint32_t out_stride) {
+    if (n == 0) return QMX_OK;
+    const PqGeom g = make_geom(distance, dim, pq);
+    const size_t lds = (size_t)g.m * g.ncent * sizeof(float);
+    QMX_REQUIRE(g.m <= 128 && g.ncent <= 256 && g.chunk <= 256 && lds <= 140 * 1024, QMX_ERR_NOT_SUPPORTED, "pq build entries: m %u, %u centroids", g.m, g.ncent);
+    static thread_local DeviceOnce attr_once;
+    if (attr_once.need()) {
+        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pq_build_entry_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_once.mark();
+    }
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(pq_build_entry_kernel, dim3(n), dim3(256), lds, st, g, d_vecs, d_centroids, (unsigned char *)d_out, out_stride);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }
