@@ -951,7 +951,7 @@ int32_t launch_pq_build_entries(hipStream_t st, uint32_t distance, uint32_t dim,
     QMX_REQUIRE(g.m <= 128 && g.ncent <= 256 && g.chunk <= 256 && lds <= 140 * 1024, QMX_ERR_NOT_SUPPORTED, "pq build entries: m %u, %u centroids", g.m, g.ncent);
     static thread_local DeviceOnce attr_once;
     if (attr_once.need()) {
-        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pq_build_entry_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pq_build_entry_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
         attr_once.mark();
     }
     ::qmx::clear_stale_error();
