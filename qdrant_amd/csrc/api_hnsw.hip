@@ -518,7 +518,9 @@ static int32_t hnsw_build_impl(const qmx_segment *seg, const qmx_segment *origin
                 h.lds_query_bytes = seg->dim * 4;
                 // + the 8-bit LUT image of every new point behind its vector (pq.hip pq_build_entry_kernel): the insertion searches drop, on its upper bound,
                 // the candidates their beam cannot take before the codebook arithmetic of an exact score
-                pq_build_prefilter = !option(OPT_HNSW_NO_PQ_PREFILTER) && seg->pq_m <= 128 && seg->pq.n_centroids <= 256 &&
+                // (opt-in: at 2 M x 1536 points the build takes 25.6 s with it and 24.9 s without - what the searches save on exact scores the 30 KiB entry
+                // costs them in searches per CU: profiles/r5_sq_walk_visited.md)
+                pq_build_prefilter = option(OPT_HNSW_PQ_BUILD_PREFILTER) > 0 && seg->pq_m <= 128 && seg->pq.n_centroids <= 256 &&
                                      (size_t)seg->pq_m * seg->pq.n_centroids * 4 <= 140 * 1024;
                 if (pq_build_prefilter) {
                     const uint32_t est = seg->dim * 4 + pq_walk_lut8_stride(seg->pq_m);

@@ -56,6 +56,7 @@ enum Option {
                               // recomputing both kinds of entries from the codebook (pq.hip HopPQDirectBuild + HopPQInternalDirect, the default where the codebook allows)
     OPT_I8_SAMPLE_STRIDE,     // the int8 prefilter's first launch takes every n-th 256-row tile (default 16); the second launch the others
     OPT_I8_SCAN_DEEP,         // the int8-copy prefilter scans through the half-stage pipeline (scan_i8copy_deep_kernel: 80 KiB of rows in flight per CU, twice the barriers: 14 % slower)
+    OPT_HNSW_PQ_BUILD_PREFILTER, // the table-free PQ build prefilters the hops of its insertion searches on an 8-bit LUT image per new point (exact, measured no faster: opt-in)
     OPT_HNSW_NO_PQ_PREFILTER, // the PQ walk scores every hop candidate exactly (rounds 1-4) instead of dropping, on an 8-bit upper bound, those the beam cannot take
     OPT_HNSW_STATIC_SLOTS,    // the walk's slots take searches slot, slot + grid, ... (rounds 1-4) instead of drawing the next unstarted one from a counter
     OPT_HNSW_NO_LDS_VISITED,  // the walk's visited set lives in the per-slot HBM bitmap only (rounds 1-4), not in the 16 KiB LDS table in front of it
