@@ -16,11 +16,9 @@ cd $R
 python tools/step_from_trace.py gpurun_out/prof_r5z/s_kernel_trace.csv > gpurun_out/r5z_c2_step_timeline.txt 2>&1
 head -40 gpurun_out/prof_r5z/s_kernel_stats.csv > gpurun_out/r5z_c2_kernel_stats.csv
 rm -rf gpurun_out/prof_r5z
-timeout 400 bash tools/pmc_traffic.sh r5z --what hnsw --reps 2 > /dev/null 2>&1
 cat gpurun_out/r5z_gpu_suite.log
 tail -4 gpurun_out/r5z_smoke.log
 echo "headline bytes: $(tail -1 gpurun_out/r5z_bench_headline.json | wc -c), stdout lines: $(wc -l < gpurun_out/r5z_bench_headline.json)"
 tail -1 gpurun_out/r5z_bench_headline.json
 head -4 gpurun_out/r5z_c2_kernel_stats.csv | cut -c1-170
 tail -3 gpurun_out/r5z_c2_step_timeline.txt
-tail -6 gpurun_out/pmc_r5z/traffic.md; grep "^hnsw" gpurun_out/pmc_r5z/FETCH_SIZE.out
