@@ -437,11 +437,11 @@ static int32_t hnsw_build_impl(const qmx_segment *seg, const qmx_segment *origin
     };
 
     // ---- device state ----
-    DevBuf b_level, b_upoff, b_links0, b_cnt0, b_linksU, b_cntU, b_lock, b_vis, b_log, b_sel, b_sels, b_selc, b_normf, b_normi, b_bq, b_bqsrc, b_rot, b_mvoff,
+    DevBuf b_level, b_upoff, b_links0, b_cnt0, b_linksU, b_cntU, b_lock, b_vis, b_log, b_sel, b_sels, b_selc, b_normf, b_normi, b_bq, b_bqsrc, b_rot, b_next, b_mvoff,
         b_mvdel;
     auto release_all = [&]() {
         for (DevBuf *b : {&b_level, &b_upoff, &b_links0, &b_cnt0, &b_linksU, &b_cntU, &b_lock, &b_vis, &b_log, &b_sel, &b_sels, &b_selc, &b_normf, &b_normi,
-                          &b_bq, &b_bqsrc, &b_rot, &b_mvoff, &b_mvdel}) b->release();
+                          &b_bq, &b_bqsrc, &b_rot, &b_next, &b_mvoff, &b_mvdel}) b->release();
     };
     int32_t rc = QMX_OK;
     qmx_hnsw *g = nullptr;
@@ -575,6 +575,10 @@ static int32_t hnsw_build_impl(const qmx_segment *seg, const qmx_segment *origin
         uint64_t slots1 = std::min<uint64_t>({(uint64_t)seg->num_cus * per_cu1, (uint64_t)HNSW_SLOT_CAP, (uint64_t)max_batch});
         slots1 = std::max<uint64_t>(1, std::min<uint64_t>(slots1, HNSW_VIS_BUDGET / (h.vis_words * 4)));
         const uint64_t slots2 = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)seg->num_cus * per_cu2, max_batch));
+        if (!option(OPT_HNSW_STATIC_SLOTS)) {
+            QB(b_next.reserve(8));
+            h.next = (uint32_t *)b_next.p;
+        }
         QB(b_vis.reserve((size_t)slots1 * h.vis_words * 4));
         QB(b_log.reserve((size_t)slots1 * h.log_cap * 4));
         QH(hipMemset(b_vis.p, 0, (size_t)slots1 * h.vis_words * 4));
@@ -642,8 +646,13 @@ static int32_t hnsw_build_impl(const qmx_segment *seg, const qmx_segment *origin
                                               b_bq.p, a.q_stride, a.aux_off, seg->d_tq_shift, seg->d_tq_scale, a.tq_qbytes_off));
                 }
             }
-            QB(launch_hnsw_build_any(seg, a, h, 1, (uint32_t)std::min<uint64_t>(slots1, count), &per_cu1));
-            QB(launch_hnsw_build_any(seg, a, h, 2, (uint32_t)std::min<uint64_t>(slots2, count), &per_cu2));
+            const uint32_t grid1 = (uint32_t)std::min<uint64_t>(slots1, count), grid2 = (uint32_t)std::min<uint64_t>(slots2, count);
+            if (h.next) {
+                const uint32_t start[2] = {grid1, grid2};
+                QH(hipMemcpyAsync(h.next, start, sizeof(start), hipMemcpyHostToDevice, nullptr));      // (pageable source: the copy is staged before the call returns)
+            }
+            QB(launch_hnsw_build_any(seg, a, h, 1, grid1, &per_cu1));
+            QB(launch_hnsw_build_any(seg, a, h, 2, grid2, &per_cu2));
             for (uint32_t i = 0; i < count; ++i)
                 if (live(next + i)) { note_point(next + i); ++inserted; }
             next += count;

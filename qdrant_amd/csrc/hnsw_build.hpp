@@ -111,7 +111,15 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(const ScanArgs a0
     const unsigned char *rows = reinterpret_cast<const unsigned char *>(a0.rows);
     const uint32_t ef = h.ef_construct;
 
-    for (uint32_t bi = blockIdx.x; bi < h.count; bi += gridDim.x) {
+    // the insertions of a batch are handed out one at a time (h.next[0], set to the grid size by the host): the static stride paid ceil(count / slots)
+    // insertions of the slowest slot per batch (hnsw.hpp does the same for the searches)
+    auto next_item = [&](uint32_t bi) -> uint32_t {
+        if (!h.next) return bi + gridDim.x;
+        uint32_t v = 0;
+        if (lane == 0) v = atomicAdd(&h.next[0], 1u);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    };
+    for (uint32_t bi = blockIdx.x; bi < h.count; bi = next_item(bi)) {
         const uint32_t p = h.first + bi;
         const uint32_t lp = h.level[p];
         const ScanArgs a = query_args<H>(a0, p);     // the new point is the query of every score below
@@ -307,7 +315,13 @@ __global__ __launch_bounds__(64) void hnsw_build_link_kernel(const ScanArgs a, c
     __shared__ uint32_t sel_ids[HNSW_BUILD_MAX_M0];
     __shared__ float sel_scores[HNSW_BUILD_MAX_M0];
     const int lane = threadIdx.x;
-    for (uint32_t bi = blockIdx.x; bi < h.count; bi += gridDim.x) {
+    auto next_item = [&](uint32_t bi) -> uint32_t {      // (phase 2 draws from h.next[1])
+        if (!h.next) return bi + gridDim.x;
+        uint32_t v = 0;
+        if (lane == 0) v = atomicAdd(&h.next[1], 1u);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    };
+    for (uint32_t bi = blockIdx.x; bi < h.count; bi = next_item(bi)) {
         const uint32_t p = h.first + bi;
         const uint32_t lp = h.level[p];
         const uint32_t *my_cnt = h.sel_cnt + (uint64_t)bi * HNSW_BUILD_MAX_LEVELS;

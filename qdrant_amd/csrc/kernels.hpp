@@ -255,6 +255,7 @@ struct HnswBuildArgs {
     // (point_scorer.rs:197-212) before phase 1; entry bi = batch_queries + bi * batch_q_stride (global memory; nullptr = stage the row)
     const unsigned char *batch_queries;
     uint64_t batch_q_stride;
+    uint32_t *next;              // [2] device counters the slots of phase 1 / phase 2 draw their next insertion from (each starts at its launch's grid size); nullptr: static stride
     uint32_t pq8_off;            // table-free PQ build: byte offset, inside a staged batch entry, of the 8-bit LUT image the insertion searches prefilter with (0: none)
 };
 // phase 1 = insertion searches + heuristic selection, phase 2 = linking; grid == 0: report occupancy only

@@ -142,3 +142,30 @@ def test_gpus_2_launches_its_own_ranks_and_reports_two(tmp_path):
     want = O.DenseStorage(O.F32, O.COSINE, rows).peek_top(O.synth(seed + 1, 0, nq, dim)[b * Q:(b + 1) * Q], top)
     checksum = sum(int(w["idx"].view(np.int32).astype(np.int64).sum()) + int(w["score"].view(np.int32).astype(np.int64).sum()) for w in want)
     assert full["merged_checksum"] == checksum
+
+
+def test_the_committed_round5_headline_is_what_headline_makes_of_the_committed_details():
+    """profiles/r5_bench_headline.json is the last stdout line of the round's final `python bench.py`, profiles/r5_bench_details.json the full result of the same
+    run: the line must be reproducible from the details, fit 4 KB with nothing dropped, and carry the SURVEY 8(d) block stream as its top-level roofline."""
+    line = open(os.path.join(ROOT, "profiles", "r5_bench_headline.json")).read().strip().splitlines()[-1]
+    h = json.loads(line)
+    full = json.load(open(os.path.join(ROOT, "profiles", "r5_bench_details.json")))
+    assert len(line) <= 4096
+    assert bench.headline(full, os.path.join(ROOT, "bench_details.json")) == h
+    for k in CONTRACT:
+        assert k in h, k
+    for k in ("batch_sweep", "robustness", "one_process_fanout", "configs", "checks"):
+        assert isinstance(h[k], dict), k
+    assert h["n_gpus"] == 1 and h["rccl_ranks"] == 1 and h["vs_baseline"] is None and h["dtype"].startswith("f32 (int8 prefilter")
+    assert h["value"] == pytest.approx(h["config"]["batch"] / (h["ms_per_step"] * 1e-3), rel=1e-3)
+    r = h["roofline"]
+    assert r["bound"] == "hbm" and r["frac"] == r["block_stream"]["frac"] >= 0.70          # north_star: >= 70 % of the HBM roofline on C2
+    assert r["block_stream"]["algorithmic_bytes"] == 30_720_000_000 and r["block_stream"]["traffic_over_algorithmic"] == pytest.approx(1.0, abs=5e-3)
+    assert r["timed_kernel"]["kernel"] == "scan_i8copy_kernel" and 0.5 < r["timed_kernel"]["frac"] < 1.0
+    assert h["checks"] == {"prefilter_equals_exact_scan_whole_block": True, "recall_at_10": 1.0}
+    assert h["cpu_baseline"]["gpu_matches_oracle_on_sample_bit_exact"] is True and h["robustness"]["every_list_equals_exact_scan"] is True
+    for c in ("C3", "C4"):
+        ow = h["configs"][c]["oracle_walk"]
+        assert ow["reference_heap_order"] == "ids 256/256, bits 256/256, pops 256/256", (c, ow)
+        n, d = ow["tie_explained"].split("/")
+        assert n == d and "unexplained" not in ow
