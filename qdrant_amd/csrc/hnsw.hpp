@@ -377,12 +377,12 @@ struct Beam<0> {
 // One bit per point in a per-slot HBM bitmap costs the walk a third of its time at 10 M points: every test-and-set is an L2 atomic on a random word of a
 // 1.25 MB bitmap (5 GB over the slots in flight), i.e. an HBM read-modify-write per link - tools/micro/gather_roof measures the row gathers of a hop at
 // 6.2 TB/s alone and at 3.4 TB/s with those atomics beside them, which is where the walk sat (profiles/r5_sq_walk_visited.md).  A search inserts a few
-// thousand ids, so its set fits the LDS: 1024 buckets (id & 1023) of eight 16-bit tags ((id >> 10) + 1, 0 = empty) = 16 KiB per search.  test_and_set looks
+// thousand ids, so its set fits the LDS: 1024 buckets (id & 1023) of eight 16-bit tags ((id >> 10) + 1; 0 = empty, 0xFFFF = taken back) = 16 KiB per search.  test_and_set looks
 // the tag up in its bucket (one ds_read_b128), claims the first empty half-word with a compare-and-swap on the word that holds it (lanes of the wave insert
 // side by side; a lost race re-reads), and when the bucket is full - about 1 % of the inserts of an ef = 128 search, more for wide ones - falls back to the
 // HBM bitmap for that id.  An id is recorded in exactly one of the two places (the bucket is consulted first, and a full bucket never frees a slot while the
-// search runs, except through unset(), which the caller pairs with the place the insert reported), so the set is exact: same fresh / visited answers as the
-// bitmap alone, hence the same walk.  Graphs of more than 2^26 - 1024 points (tags would not fit), ACORN and the reference-heap mode keep the bitmap.
+// search runs: unset() marks the slot instead of emptying it), so the set is exact: same fresh / visited answers as the bitmap alone, hence the same
+// walk.  Graphs of more than 65534 x 1024 points (tags would not fit), ACORN and the reference-heap mode keep the bitmap.
 struct LdsVisited {
     uint32_t *tab;      // LDS, 4096 words; nullptr: the bitmap only
     // -> true when `id` was visited before; *in_bitmap: the id lives (now or already) in the HBM bitmap, not in the table
@@ -417,14 +417,16 @@ struct LdsVisited {
     // takes back an insert this search made (a link behind the level's limit: the reference never looked at it)
     __device__ __forceinline__ void unset(uint32_t id, uint32_t *vis, bool in_bitmap) const {
         if (in_bitmap || !tab) { atomicAnd(&vis[id >> 5], ~(1u << (id & 31))); return; }
+        // The slot is not freed but marked (tag 0xFFFF: no id of a graph this table serves has it): a bucket that was ever full stays full, so an id that
+        // went to the bitmap because its bucket was full can never be mistaken for a fresh one by a later lookup that finds room in that bucket.
         uint32_t *b = tab + (id & 1023u) * 4u;
         const uint32_t tag = (id >> 10) + 1u;
         for (int d = 0; d < 4; ++d) {
             for (;;) {
                 const uint32_t w = b[d];
                 uint32_t nw = w;
-                if ((w & 0xFFFFu) == tag) nw = w & 0xFFFF0000u;
-                else if ((w >> 16) == tag) nw = w & 0xFFFFu;
+                if ((w & 0xFFFFu) == tag) nw = w | 0xFFFFu;
+                else if ((w >> 16) == tag) nw = w | 0xFFFF0000u;
                 else break;
                 if (atomicCAS(&b[d], w, nw) == w) return;
             }

@@ -211,7 +211,7 @@ int32_t launch_pq_build_entries(hipStream_t st, uint32_t distance, uint32_t dim,
 int32_t launch_hnsw_bq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_pack_level0(hipStream_t st, const uint64_t *offsets, const uint32_t *neighbors, uint32_t n_points, uint32_t stride, uint32_t *l0);
 constexpr uint32_t HNSW_VIS_LDS_BYTES = 16384;                 // the walk's visited table in LDS (hnsw.hpp LdsVisited): 1024 buckets x 8 tags of 16 bits
-constexpr uint32_t HNSW_VIS_LDS_MAX_POINTS = 65535u * 1024u;    // ... graphs whose (id >> 10) + 1 fits a tag
+constexpr uint32_t HNSW_VIS_LDS_MAX_POINTS = 65534u * 1024u;    // ... graphs whose (id >> 10) + 1 fits a tag below the "taken back" mark 0xFFFF
 constexpr uint32_t HNSW_REF_CAND_CAP = 1u << 16;   // option hnsw_reference_heap_order: entries of one search's `candidates` heap (512 KiB per slot)
 constexpr uint32_t HNSW_REF_SLOT_CAP = 1024;       // ... searches in flight in that mode
 constexpr uint32_t HNSW_MAX_EF = 4096;          // max(top, ef) of a walk: up to 512 in a register beam, beyond it in an LDS beam (hnsw.hpp Beam<0>)

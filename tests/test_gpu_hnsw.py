@@ -645,3 +645,29 @@ def test_pq_walk_hop_prefilter_is_the_same_walk(qa, distance, dim, chunk):
             assert np.array_equal(a["score"].view(np.uint32), w["score"].view(np.uint32))
             if len(np.unique(w["score"])) == len(w):
                 assert a["idx"].tolist() == w["idx"].tolist()
+
+
+def test_lds_visited_table_answers_like_the_bitmap_with_full_buckets_and_over_long_lists(qa):
+    """hnsw.hpp LdsVisited against the per-slot HBM bitmap alone (option hnsw_no_lds_visited), where the table works hardest: searches wide enough to fill its
+    buckets (24 000 points, ef up to 3 000: ids sharing their low ten bits overflow into the bitmap) over a graph whose level-0 lists are LONGER than the m0 it
+    declares (the links behind the limit are taken back out of the set: the slot is marked, never emptied, so a bucket that was full stays full).  Same lists,
+    same score bits, same number of scored points, search after search on the same slots."""
+    import types
+    n, dim, m, nq = 24000, 16, 16, 48
+    rows, st, g, plain = _graph(O.DOT, n, dim, m, 0x5EED03D0)
+    short = types.SimpleNamespace(**{k: getattr(plain, k) for k in ("reindex", "level_offsets", "offsets", "neighbors", "ep_ids", "ep_levels", "xp_ids", "xp_levels")})
+    short.m, short.m0 = 6, 10                                     # the lists hold up to 32 links on level 0, up to 16 above
+    assert int(np.max(np.diff(np.asarray(plain.offsets)[:n + 1]))) > short.m0
+    vs = qa.VectorStorage(rows, qa.Distance.Dot)
+    scorer = qa.new_raw_scorer(O.synth(0x5EED03D1, 0, nq, dim), vs)
+    for graph in (qa.GraphLayers.from_plain(short), qa.GraphLayers.from_plain(plain)):
+        for top, ef in ((10, 64), (50, 500), (100, 3000)):
+            for _ in range(2):                                    # (the second round runs on slots the first one left behind)
+                got, scored = graph.search(top, ef, scorer, with_scored=True)
+                qa.set_option("hnsw_no_lds_visited", 1)
+                try:
+                    want, want_scored = graph.search(top, ef, scorer, with_scored=True)
+                finally:
+                    qa.set_option("hnsw_no_lds_visited", -1)
+                assert scored == want_scored
+                _same(got, want)
