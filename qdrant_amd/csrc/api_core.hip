@@ -122,7 +122,7 @@ extern "C" {
 // library / device
 // ---------------------------------------------------------------------------------------------
 
-uint32_t qmx_abi_version(void) { return 6; }
+uint32_t qmx_abi_version(void) { return 7; }   // 7: qmx_hnsw_search_traced, the options of round 5
 
 static int option_index(const char *name) {
     if (!name) return -1;
