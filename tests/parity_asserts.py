@@ -61,7 +61,7 @@ def first_divergence_is_a_tie(got_pops, want_pops, bound_score=None):
     """Two pop sequences of `search_on_level` over ONE graph (structured arrays idx / score: qmx_hnsw_search_traced on the device,
     qo_hnsw_search_traced in the oracle).  A walk is a deterministic function of its pop sequence, so:
       "same"  the sequences are equal: the walks are the same walk;
-      "tie"   at the first position where they differ both popped candidates carry bit-equal scores (each walk picked another of several equal
+      "tie"   at the first position where they differ both popped candidates carry equal scores (OrderedFloat equality: the same bits, or +0.0 / -0.0) (each walk picked another of several equal
               candidates: the reference by the arrangement of its BinaryHeap, the device by ascending id) - or one sequence ends there and the other pops
               one more candidate whose score is bit-equal to `bound_score` (the worst score of the full `nearest` list at that moment: the reference
               breaks on strict `candidate.score < lower_bound` only, graph_layers.rs:126, so a candidate EQUAL to the bound is still expanded when it
@@ -75,7 +75,9 @@ def first_divergence_is_a_tie(got_pops, want_pops, bound_score=None):
         i = int(diff[0])
         if not np.array_equal(gs[:i], ws[:i]):
             return "scores differ before the first id difference (%d)" % i
-        return "tie" if gs[i] == ws[i] else "scores differ at %d: %r vs %r" % (i, got_pops[i], want_pops[i])
+        a, b = np.float32(got_pops["score"][i]), np.float32(want_pops["score"][i])
+        equal = gs[i] == ws[i] or a == b or (a != a and b != b)          # OrderedFloat equality: the same bits, +0.0 / -0.0, NaN with NaN
+        return "tie" if equal else "scores differ at %d: %r vs %r" % (i, got_pops[i], want_pops[i])
     if not np.array_equal(gs, ws):
         return "equal ids with different scores"
     if len(got_pops) == len(want_pops):
@@ -83,5 +85,6 @@ def first_divergence_is_a_tie(got_pops, want_pops, bound_score=None):
     longer = got_pops if len(got_pops) > len(want_pops) else want_pops
     if bound_score is None:
         return "one sequence ends at %d and no bound was given" % n
-    extra = np.float32(longer["score"][n]).view(np.uint32)
-    return "tie" if extra == np.float32(bound_score).view(np.uint32) else "one sequence ends at %d, the other pops %r (bound %r)" % (n, longer[n], bound_score)
+    extra, bound = np.float32(longer["score"][n]), np.float32(bound_score)
+    equal = extra.view(np.uint32) == bound.view(np.uint32) or extra == bound or (extra != extra and bound != bound)
+    return "tie" if equal else "one sequence ends at %d, the other pops %r (bound %r)" % (n, longer[n], bound_score)

@@ -65,3 +65,29 @@ def test_assert_reference_lists_accepts_the_rule_and_rejects_a_wrong_boundary():
     heap = st.peek_top(queries, top)
     with pytest.raises(AssertionError):                                              # the heap's own lists break the rule somewhere (order or survivors)
         assert_reference_lists(heap, st, queries, top, threads=0)
+
+
+def test_first_divergence_is_a_tie_classifies_pop_sequences():
+    """tests/parity_asserts.first_divergence_is_a_tie, the rule bench.py and the GPU tests apply to a device walk's pop sequence against the oracle's."""
+    import numpy as np
+    import oracle_ffi as O
+    from parity_asserts import first_divergence_is_a_tie as f
+
+    def seq(*pairs):
+        a = np.zeros(len(pairs), dtype=O.ScoredPointOffset)
+        for i, (idx, sc) in enumerate(pairs):
+            a[i] = (idx, sc)
+        return a
+    base = seq((7, 3.0), (2, 2.5), (9, 2.5), (4, 1.0))
+    assert f(base, base.copy()) == "same"
+    assert f(seq((7, 3.0), (9, 2.5), (2, 2.5), (4, 1.0)), base) == "tie"                      # the walks part at two equal scores: what follows may differ freely
+    assert f(seq((7, 3.0), (9, 2.5), (5, 0.5)), base) == "tie"
+    assert f(seq((7, 3.0), (2, 2.5), (9, 2.5), (5, 1.5)), base).startswith("scores differ at 3")   # different candidates with different scores: a defect
+    assert f(seq((7, 3.0), (2, 2.25), (9, 2.5)), base) == "equal ids with different scores" or f(seq((7, 3.0), (2, 2.25), (9, 2.5)), base).startswith("scores differ")
+    # one walk ends, the other pops one more candidate: a tie only if that candidate equals the bound (strict `candidate.score < lower_bound` in the reference)
+    longer = seq((7, 3.0), (2, 2.5), (9, 2.5), (4, 1.0), (11, 1.0))
+    assert f(base, longer, bound_score=np.float32(1.0)) == "tie" and f(longer, base, bound_score=np.float32(1.0)) == "tie"
+    assert f(base, longer, bound_score=np.float32(0.5)).startswith("one sequence ends at 4")
+    assert f(base, longer).endswith("no bound was given")
+    # -0.0 and 0.0 are different bits and EQUAL scores for the reference's OrderedFloat: a tie
+    assert f(seq((1, 0.0)), seq((2, -0.0))) == "tie"
