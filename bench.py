@@ -5,7 +5,8 @@ Timed region (the headline's `value`).  Workload at N=1 = BASELINE.json configs[
 brute-force exact top-10, resident in HBM.  A *step* = one pass of the hot path over one batch of Q queries: Metric::preprocess of
 the batch (qmx_query_update) + one scan of the whole segment with per-query top-k (qmx_search_topk_async =
 BatchFilteredSearcher::peek_top_iter) [+ for N>1 the RCCL all-gather of the per-GPU top-k and the k-way merge].  1024 distinct
-queries are cycled in batches.  The harness whose shape this replaces: /root/reference/lib/segment/benches/vector_search.rs:21,34-104.
+queries are cycled in batches.  Before the W warm-up steps an untimed steady-state run of --prewarm-ms (150 ms, `config.prewarm_steps`) belongs to the set-up,
+like generating the block.  The harness whose shape this replaces: /root/reference/lib/segment/benches/vector_search.rs:21,34-104.
 
 N>1: one rank per GPU.  Under torchrun (RANK / WORLD_SIZE set) the ranks are the launcher's; WITHOUT it `--gpus N` launches its own ranks
 (re-exec under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`), and refuses (exit 2) when fewer than
@@ -83,6 +84,9 @@ def parse(argv=None):
                          "head (preprocess, sample pre-scan, pack) and tail (probe, verification, sort) run beside the other's scans; 1 = one handle, one stream")
     ap.add_argument("--fanout-rows", type=int, default=1_000_000,
                     help="rows per segment of the one-process fan-out legs (qmx_sharded_hnsw_build + qmx_sharded_search_topk over one segment per device); 0 = skip")
+    ap.add_argument("--prewarm-ms", type=float, default=150.0,
+                    help="untimed steady-state run BEFORE the --warmup steps (part of the set-up, like generating the block): steps are issued for this many "
+                         "milliseconds so that clocks, both batches in flight and the allocator are where a serving process has them; reported in config.prewarm_steps")
     ap.add_argument("--details", default=os.path.join(ROOT, "bench_details.json"), help="where the full result (every leg) is written")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="collective backend of N>1 (nccl = RCCL; gloo only with --test-backend)")
     ap.add_argument("--test-backend", default="",
@@ -272,7 +276,7 @@ def headline(result, details_path=None):
     h["vs_baseline"] = result.get("vs_baseline")
     h.update(_pick(result, "dtype", "data", "rccl_ranks", "collective"))
     c = result.get("config", {})
-    hc = _pick(c, "workload", "rows_per_gpu", "dim", "batch", "top", "batches_in_flight")
+    hc = _pick(c, "workload", "rows_per_gpu", "dim", "batch", "top", "batches_in_flight", "prewarm_steps")
     if result.get("n_gpus", 1) > 1:
         hc["collection_qps"] = c.get("collection_qps")
     if "timed_path" in c:
@@ -452,6 +456,17 @@ def main(argv=None):
             if hip:
                 torch.cuda.synchronize(dev)
 
+    # set-up, untimed: a short steady-state run (the driver's form of the command has 5 warm-up steps = 7 ms of work after minutes of data generation: the first
+    # timed steps then run on ramping clocks with one batch in flight: 83 k QPS at --steps 20 against 87 - 88 k at --steps 100 on the same library)
+    prewarm_steps = 0
+    if args.prewarm_ms > 0:
+        t_pre = time.perf_counter()
+        while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms and prewarm_steps < 4096:
+            step(prewarm_steps)
+            prewarm_steps += 1
+            if prewarm_steps % 16 == 0:
+                fence()
+        fence()
     for i in range(args.warmup):
         step(i)
     fence()
@@ -507,7 +522,7 @@ def main(argv=None):
                    "unit_of_value": ("queries per second against the ONE row-split segment" if strong else
                                      "(query, 10M-row segment) searches per second; at n_gpus=1 this is plain QPS"),
                    "collection_qps": round(Q * args.steps / elapsed, 2),
-                   "batches_in_flight": len(lanes)},
+                   "batches_in_flight": len(lanes), "prewarm_steps": prewarm_steps},
     }
     if not hip:
         # the launcher / collective / line under test: whatever the injected backend computed is NOT a measurement
