@@ -283,3 +283,29 @@ def test_multivector_build_over_rows_that_are_not_queries_falls_back_like_the_si
             lo += O.MultiOracle((kind, st, q), offsets).score_internal(p, o) != np.float32(O.MultiOracle((kind, st, q), offsets).score_points([rows[p:p + 1]], [o])[0, 0])
             hi += 1
     assert lo > hi // 2          # a stored row scored as a query differs from its original's query scorer almost always
+
+
+def test_traced_search_returns_the_plain_search_and_a_consistent_pop_sequence():
+    """qo_hnsw_search_traced (round 5): the same lists as qo_hnsw_search + the candidates search_on_level popped AND expanded (graph_layers.rs:120-147).  The
+    sequence never repeats a point, and every returned point is a popped point or a link of one (nothing enters `nearest` unscored; the level-0 entry is the
+    first pop)."""
+    import numpy as np
+    import oracle_ffi as O
+    n, dim, m, nq, top, ef = 3000, 24, 8, 16, 10, 48
+    rows = O.preprocess(O.COSINE, O.synth(0x5EED0720, 0, n, dim))
+    st = O.DenseStorage(O.F32, O.COSINE, rows)
+    g = O.Hnsw(st, m=m, ef_construct=48, seed=9, threads=0)
+    queries = O.synth(0x5EED0721, 0, nq, dim)
+    plain = g.search_dense(st, queries, top, ef)
+    g.pops = []
+    traced = g.search_dense(st, queries, top, ef)
+    pops, g.pops = g.pops, None
+    pl = g.export_plain()
+    off, nb = np.asarray(pl.offsets), np.asarray(pl.neighbors)
+    for a, b, p in zip(plain, traced, pops):
+        assert a["idx"].tolist() == b["idx"].tolist() and np.array_equal(a["score"].view(np.uint32), b["score"].view(np.uint32))
+        assert len(p) >= 1 and len(set(p["idx"].tolist())) == len(p)
+        reach = set(p["idx"].tolist())
+        for c in p["idx"].tolist():
+            reach.update(nb[int(off[c]):int(off[c + 1])].tolist())
+        assert set(b["idx"].tolist()) <= reach
