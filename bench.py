@@ -459,7 +459,12 @@ def main(argv=None):
     # set-up, untimed: a short steady-state run (the driver's form of the command has 5 warm-up steps = 7 ms of work after minutes of data generation: the first
     # timed steps then run on ramping clocks with one batch in flight: 83 k QPS at --steps 20 against 87 - 88 k at --steps 100 on the same library)
     prewarm_steps = 0
-    if args.prewarm_ms > 0:
+    if args.prewarm_ms > 0 and world > 1:
+        # (every rank must issue the SAME number of steps - a step holds a collective -, so the count is fixed, not timed: ~150 ms at 1.5 ms per step)
+        for prewarm_steps in range(1, 97):
+            step(prewarm_steps - 1)
+        fence()
+    elif args.prewarm_ms > 0:
         t_pre = time.perf_counter()
         while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms and prewarm_steps < 4096:
             step(prewarm_steps)

@@ -133,6 +133,7 @@ def test_gpus_2_launches_its_own_ranks_and_reports_two(tmp_path):
     assert len(lines[-1]) <= 4096
     assert h["n_gpus"] == 2 and h["rccl_ranks"] == 2 and h["collective"] == "gloo" and h["steps"] == steps and h["scaling"] == "weak"
     assert h["config"]["workload"].startswith("C5: 2 segments") and "not a measurement" in h["data"]
+    assert h["config"]["prewarm_steps"] == 96          # (a fixed count on every rank: a step holds a collective, a timed loop would desynchronise the ranks)
     assert h["value"] == pytest.approx(2 * Q * steps / (h["ms_per_step"] * 1e-3 * steps), rel=1e-2)
     full = json.load(open(details))
     # the merged lists of the last step = the oracle's exact search over the union of the two segments (ids globalised by the segment bases)
