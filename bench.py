@@ -12,10 +12,13 @@ N>1: one rank per GPU.  Under torchrun (RANK / WORLD_SIZE set) the ranks are the
 (re-exec under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`), and refuses (exit 2) when fewer than
 N devices are visible or when WORLD_SIZE disagrees with --gpus: a run never reports fewer ranks than it was asked for.
   --scaling weak (default) = configs[4] ("C5"): rank r holds its own 10 M-row segment (seed + r), every rank scores the same query batch
-      against its segment, the per-rank top-k lists (Q x 10 x 8 B) are all-gathered over RCCL/xGMI and merged (BatchResultAggregator
-      semantics).  Per-GPU work is fixed.  The counted unit is one (query, 10 M-row segment) search: value = N * Q * steps / time; at
-      N=1 this is plain QPS on C2.
+      against its segment, the per-rank answers (one packed record: Q x 10 x 8 B of lists + Q x 4 B of counts) are all-gathered over RCCL/xGMI in
+      ONE collective per step and merged (BatchResultAggregator semantics).  Per-GPU work is fixed; value = Q * steps / time = queries per second
+      against the whole collection of N x 10 M vectors (ideal weak scaling: value(N) == value(1)); config.segment_searches_per_s = N x value.
+      N > 1 runs the experiment of N = 1: the same --in-flight batches on their own streams (steps alternate between them in the same order on
+      every rank), + one collective and one merge per step; config.per_step_us reports local search / all-gather / merge from stream events.
   --scaling strong: ONE 10 M-row segment row-split over the ranks, same gather + merge; value = Q * steps / time.
+  Rank 0's side measurements (block-stream roofline, one-process fan-out) run AFTER the process group has ended: no rank waits in an RCCL barrier meanwhile.
 
 Output.  The LAST stdout line is the compact headline (<= 4 KB, `headline()`): metric / value / ms_per_step / config / `roofline` /
 `cpu_baseline` + a few numbers of every secondary leg.  Everything else (`batch_sweep`, `robustness`, `one_process_fanout`, the C3 / TQ4 / C4
@@ -76,7 +79,7 @@ def parse(argv=None):
     ap.add_argument("--no-sweep", action="store_true", help="skip the Q in {1, 8, 32, 128} x {exact, prefilter} sweep")
     ap.add_argument("--no-robustness", action="store_true", help="skip the C2 search on latent / duplicated rows (needs 46 GB more HBM)")
     ap.add_argument("--verify", type=int, default=1, help="check samples against the oracle (C2 first batch, C3 / C4 scans and walks)")
-    ap.add_argument("--configs", default="c3,tq,c4", help="comma list of the secondary single-GPU configs to run (empty = none)")
+    ap.add_argument("--configs", default="c1,c3,tq,c4", help="comma list of the secondary single-GPU configs to run (empty = none)")
     ap.add_argument("--config-rows", type=int, default=0, help="rows of C3 / C4 (0 = --rows)")
     ap.add_argument("--hnsw-queries", type=int, default=8192, help="searches per launch of the HNSW walks")
     ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2, 3, 4],
@@ -229,6 +232,14 @@ def _walk_summary(ow):
 def _configs_summary(cfg):
     legs, out = {}, {LEG_COLUMNS: None}
     put = lambda name, st: legs.__setitem__(name, _leg(st)) if st is not None else None      # noqa: E731
+    c1 = cfg.get("C1")
+    if isinstance(c1, dict):
+        if "error" in c1:
+            out["C1"] = {"error": str(c1["error"])[:80]}
+        else:
+            cp = c1.get("cpu_oracle_port", {})
+            out["C1"] = {"cpu_qps_1_thread": cp.get("one_thread", {}).get("qps"), "cpu_qps_all_cores": cp.get("all_cores", {}).get("qps"), "cores": cp.get("cores"),
+                         "device_qps_Q32": c1.get("device", {}).get("Q32", {}).get("qps_wall_sync_per_batch"), "device_equals_oracle": c1.get("device_equals_oracle_bit_exact")}
     c3 = cfg.get("C3")
     if isinstance(c3, dict):
         if "error" in c3:
@@ -278,7 +289,7 @@ def headline(result, details_path=None):
     c = result.get("config", {})
     hc = _pick(c, "workload", "rows_per_gpu", "dim", "batch", "top", "batches_in_flight", "prewarm_steps")
     if result.get("n_gpus", 1) > 1:
-        hc["collection_qps"] = c.get("collection_qps")
+        hc.update(_pick(c, "collection_qps", "segment_searches_per_s", "collectives_per_step", "per_step_us"))
     if "timed_path" in c:
         hc["timed_path"] = c["timed_path"].split(":")[0].replace(" of the block (1 B / element, int8 matrix cores)", "").replace(" of the survivors", "")[:100]
     dc = c.get("derived_copy")
@@ -428,25 +439,33 @@ def main(argv=None):
         backend, queries = getattr(importlib.import_module(mod), fn)(rank=rank, world=world, row_seed=row_seed, row0=row0, n=n, dim=dim,
                                                                      nqueries=nbatches * Q, query_seed=seed + 1)
         seg_info, eff_flag, copy_flag, stream = {}, 0, 0, None
-    searcher = sharded.ShardedSearcher(backend, n, Q, top, device=dev)  # scan -> all-gather -> merge (world > 1)
+    searcher = sharded.ShardedSearcher(backend, n, Q, top, device=dev)  # scan -> ONE all-gather -> merge (world > 1)
     out, counts = searcher.out, searcher.counts
-    # a second batch in flight (single GPU): its own query handle, stream and result buffers; steps alternate between the two.  Every step is still one
-    # whole search of one batch - the GPU merely has the next batch's head to run while this batch's scans and tail are in flight
-    lanes = [(backend, out, counts)]
-    for _ in range(args.in_flight - 1 if (world == 1 and hip) else 0):
-        backend2 = sharded.HipBackend(storage, Q, local_rank, torch.cuda.Stream(dev))
-        F.check(lib.qmx_query_set_timing(backend2.qh, 1))
-        lanes.append((backend2, torch.zeros_like(out), torch.zeros_like(counts)))
+    # Batches in flight: every lane is a query handle + its stream + its result buffers (+ at N > 1 its own ShardedSearcher: record, gathered records,
+    # merged lists); consecutive steps alternate between the lanes - i % len(lanes), the same order on every rank, so the ranks issue their collectives in
+    # the same order.  Every step is still one whole search of one batch - the GPU merely has the next batch's head to run while this batch's scans, its
+    # all-gather and its merge are in flight.  N = 1 and N > 1 run the SAME experiment: the same lanes, + per step one collective and one merge.
+    lanes = [(backend, searcher)]
+    for _ in range(args.in_flight - 1):
+        if hip:
+            backend2 = sharded.HipBackend(storage, Q, local_rank, torch.cuda.Stream(dev))
+            F.check(lib.qmx_query_set_timing(backend2.qh, 1))
+        else:
+            backend2 = backend        # the injected CPU backend is stateless between calls
+        lanes.append((backend2, sharded.ShardedSearcher(backend2, n, Q, top, device=dev)))
 
     def step(i):
         b = i % nbatches
         qb = queries[b * Q:(b + 1) * Q]
-        if world > 1 or not hip:
-            searcher.search(qb)
-        else:
-            be, o, c = lanes[i % len(lanes)]
-            with torch.cuda.stream(be.stream):
-                be.local_topk(qb, top, o, c)
+        be, se = lanes[i % len(lanes)]
+        if not hip:
+            se.search(qb)
+            return
+        with torch.cuda.stream(be.stream):
+            if world > 1:
+                se.search(qb)
+            else:
+                be.local_topk(qb, top, se.out, se.counts)
 
     def fence():
         if hip:
@@ -460,8 +479,10 @@ def main(argv=None):
     # timed steps then run on ramping clocks with one batch in flight: 83 k QPS at --steps 20 against 87 - 88 k at --steps 100 on the same library)
     prewarm_steps = 0
     if args.prewarm_ms > 0 and world > 1:
-        # (every rank must issue the SAME number of steps - a step holds a collective -, so the count is fixed, not timed: ~150 ms at 1.5 ms per step)
-        for prewarm_steps in range(1, 97):
+        # (every rank must issue the SAME number of steps - a step holds a collective -, so the count is derived from the flag, not timed:
+        # --prewarm-ms / 1.5 ms per step, a whole number of rounds over the lanes)
+        fixed = max(len(lanes), int(math.ceil(args.prewarm_ms / 1.5 / len(lanes))) * len(lanes))
+        for prewarm_steps in range(1, fixed + 1):
             step(prewarm_steps - 1)
         fence()
     elif args.prewarm_ms > 0:
@@ -477,46 +498,60 @@ def main(argv=None):
     fence()
     ms0, l0 = C.c_float(), C.c_uint32()
     if hip:
-        for be, _, _ in lanes:
+        for be, _ in lanes:
             F.check(lib.qmx_query_timing(be.qh, C.byref(ms0), C.byref(l0)))  # drop warm-up launches
 
     fence()
-    # (the spread of the timed region, without touching it: an event on the stream every `gsz` steps, read after the closing fence)
+    # (the spread of the timed region, without touching it: every `gsz` steps an event on EVERY lane's stream, read after the closing fence; a group ends
+    # when its last lane does)
     gsz = max(1, args.steps // 10)
-    marks = [torch.cuda.Event(enable_timing=True)] if hip else []
+    calls0 = sharded.COLLECTIVE_CALLS
+
+    def mark():
+        ev = []
+        for be, _ in lanes:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(be.stream)
+            ev.append(e)
+        return ev
+    marks = [mark()] if hip else []
     t0 = time.perf_counter()
-    if hip:
-        marks[0].record(lanes[0][0].stream if world == 1 else stream)
     for i in range(args.steps):
         step(i)
         if hip and (i + 1) % gsz == 0:
-            marks.append(torch.cuda.Event(enable_timing=True))
-            marks[-1].record(lanes[i % len(lanes)][0].stream if world == 1 else stream)
+            marks.append(mark())
     fence()
     elapsed = time.perf_counter() - t0
-    group_ms = [marks[j].elapsed_time(marks[j + 1]) / gsz for j in range(len(marks) - 1)]      # device time per step, per group of gsz steps
+    collectives_per_step = (sharded.COLLECTIVE_CALLS - calls0) / float(max(1, args.steps))
+    at = [max(marks[0][0].elapsed_time(e) for e in ev) for ev in marks]      # when each group's last lane passed its mark (ms after the first mark)
+    group_ms = [(at[j + 1] - at[j]) / gsz for j in range(len(at) - 1)]        # device time per step, per group of gsz steps
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    units = Q * args.steps * (1 if strong else world)
-    value = units / elapsed
+    # value = queries per second against the whole COLLECTION (at N > 1, weak: N segments of --rows rows each = one collection of N x rows; every query is
+    # answered over all of it).  Ideal weak scaling reads value(N) = value(1): the collection grows with N at constant QPS, as the reference's
+    # segment-parallel model implies (segments_searcher.rs:250-285).  (query, segment) searches per second = N x value stays in config.
+    value = Q * args.steps / elapsed
 
     if world == 1:
         workload = "C2: 1 segment %s x d=%d f32 cosine, brute-force exact top-%d, batch Q=%d" % (_human(n), dim, top, Q)
+        vecs = _human(args.rows)
     elif strong:
         workload = ("C2 row-split: ONE segment %s x d=%d f32 cosine split by contiguous row range over %d GPUs (%s rows each), top-%d, batch Q=%d, "
-                    "RCCL all-gather + merge" % (_human(args.rows), dim, world, _human(n), top, Q))
+                    "one RCCL all-gather + merge per step" % (_human(args.rows), dim, world, _human(n), top, Q))
+        vecs = _human(args.rows)
     else:
-        workload = ("C5: %d segments (one per GPU) x %s x d=%d f32 cosine, top-%d, batch Q=%d, RCCL all-gather + merge"
-                    % (world, _human(n), dim, top, Q))
+        workload = ("C5: %d segments (one per GPU) x %s x d=%d f32 cosine = one collection of %s vectors, top-%d, batch Q=%d, one RCCL all-gather + "
+                    "merge per step" % (world, _human(n), dim, _human(world * n), top, Q))
+        vecs = "%d x %s" % (world, _human(args.rows))
     result = {
-        "metric": "QPS @ recall@10, brute-force, d=%d %s vecs, f32 cosine top-%d" % (dim, _human(args.rows), top),
+        "metric": "QPS @ recall@10, brute-force, d=%d %s vecs, f32 cosine top-%d" % (dim, vecs, top),
         "value": round(value, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         # spread over groups of steps inside the timed region (device time between stream events): standard deviation of the groups' QPS
-        "value_stddev": round(_stddev([Q * (1 if strong else world) / (m * 1e-3) for m in group_ms if m > 0]), 2),
+        "value_stddev": round(_stddev([Q / (m * 1e-3) for m in group_ms if m > 0]), 2),
         "step_groups": {"steps_per_group": gsz, "ms_per_step_min": round(min(group_ms), 4) if group_ms else None,
                         "ms_per_step_max": round(max(group_ms), 4) if group_ms else None},
         "higher_is_better": True, "scaling": "strong" if strong else "weak",
@@ -525,25 +560,30 @@ def main(argv=None):
         "config": {"workload": workload,
                    "rows_per_gpu": n, "dim": dim, "batch": Q, "top": top, "distinct_queries": nbatches * Q,
                    "unit_of_value": ("queries per second against the ONE row-split segment" if strong else
-                                     "(query, 10M-row segment) searches per second; at n_gpus=1 this is plain QPS"),
-                   "collection_qps": round(Q * args.steps / elapsed, 2),
-                   "batches_in_flight": len(lanes), "prewarm_steps": prewarm_steps},
+                                     "queries per second against the whole collection (N segments of rows_per_gpu rows; at n_gpus=1 plain QPS on C2); "
+                                     "ideal weak scaling: value(N) == value(1)"),
+                   "collection_qps": round(value, 2),
+                   "segment_searches_per_s": round(value * (1 if strong else world), 2),
+                   "batches_in_flight": len(lanes), "prewarm_steps": prewarm_steps,
+                   "collectives_per_step": round(collectives_per_step, 3)},
     }
     if not hip:
         # the launcher / collective / line under test: whatever the injected backend computed is NOT a measurement
         result["data"] = "TEST BACKEND %s on CPU: not a measurement" % args.test_backend
         result["dtype"] = "test"
-        result["merged_checksum"] = int(searcher.merged.to(torch.int64).sum().item())
+        last = lanes[(args.steps - 1) % len(lanes)][1]           # the lane of the last step
+        result["merged_checksum"] = int(last.merged.to(torch.int64).sum().item())
+        result["lanes_used"] = sorted(set(i % len(lanes) for i in range(args.steps)))
         if rank == 0:
             emit(result, args.details)
         if world > 1:
             dist.destroy_process_group()
         return
 
-    from bench_sections import (c3_section, c4_section, cpu_baseline, derived_copy_point, hbm_point, one_process_fanout, robustness, tq_section,
+    from bench_sections import (c1_section, c3_section, c4_section, cpu_baseline, derived_copy_point, hbm_point, one_process_fanout, robustness, tq_section,
                                 _counters_dict)
     kms, kl = C.c_float(), C.c_uint32()
-    for be, _, _ in lanes:       # the scan launches of every batch in flight
+    for be, _ in lanes:       # the scan launches of every batch in flight
         m1, l1 = C.c_float(), C.c_uint32()
         F.check(lib.qmx_query_timing(be.qh, C.byref(m1), C.byref(l1)))
         kms.value += m1.value
@@ -576,6 +616,31 @@ def main(argv=None):
         result["dtype"] = "f32 (%s prefilter + exact f32 re-score)" % ("int8" if i8_copy else "f16")
     result["roofline"] = _roofline(n, dim, kernel_ms, alg_bytes, achieved, int(kl.value), launches_per_step, Q, kernel_symbol, launches_per_pass)
 
+    if world > 1:
+        # the three stages of a step, measured in their own untimed run (stream events around local search / all-gather / merge on every lane)
+        for _, se in lanes:
+            se.timing = True
+        for i in range(16 * len(lanes)):
+            step(i)
+        fence()
+        per = [se.stage_us() for _, se in lanes]
+        mean = lambda k: sum(p[k] for p in per) / len(per)      # noqa: E731
+        mine = torch.tensor([mean("local_search_us"), mean("allgather_us"), mean("merge_us")], dtype=torch.float64, device=dev)
+        worst = mine.clone()
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+        for _, se in lanes:
+            se.timing = False
+        result["config"]["per_step_us"] = {"of": "rank 0, mean over %d searches per lane, stream events; max over ranks beside it" % per[0]["searches"],
+                                           "local_search_us": round(float(mine[0]), 2), "allgather_us": round(float(mine[1]), 2), "merge_us": round(float(mine[2]), 2),
+                                           "allgather_us_max_over_ranks": round(float(worst[1]), 2), "local_search_us_max_over_ranks": round(float(worst[0]), 2)}
+        # Everything below is rank 0's own side measurement (the block-stream roofline of its segment, the one-process fan-out over every visible
+        # device): the process group ends HERE, so no rank sits in an RCCL barrier - a kernel spinning on a device - while rank 0 drives that device.
+        fence()
+        dist.destroy_process_group()
+        if rank != 0:
+            for be, _ in lanes:
+                be.close()
+            return
     solo = rank == 0 and world == 1
     if solo and args.verify and (Q > 64 or copy_flag):
         # the timed path (prefilter + exact verification) against the exact chain-major scan, whole block, first batch: ids and score bits
@@ -594,8 +659,8 @@ def main(argv=None):
         result["recall_at_10"] = round(hit / float(Q * top), 6)
     if rank == 0 and not args.no_hbm_point:
         # SURVEY 8(d) / north_star (>= 70 % of the HBM roofline on C2): the EXACT scan streaming the stored f32 block itself, once for 16 queries and
-        # once for 1; outside the timed region, same rows, same measurement (HIP events on the kernel's stream).  (N > 1: rank 0 measures its segment,
-        # the other ranks wait at the barrier below.)
+        # once for 1; outside the timed region, same rows, same measurement (HIP events on the kernel's stream).  (N > 1: rank 0 measures its segment
+        # after the process group has ended; the other ranks have left.)
         qa.set_option("no_split_scan", 1)
         try:
             for Qh, key in ((BLOCK_STREAM_BATCH, "roofline_hbm_point_q16"), (1, "roofline_hbm_point_q1")):
@@ -655,24 +720,28 @@ def main(argv=None):
             result["roofline"]["prefilter_per_batch"] = {"error": repr(e)[:200]}
     if rank == 0 and args.fanout_rows > 0:
         # the ONE-PROCESS fan-out behind the C-ABI (what a Rust host that owns all segments of a node calls): index build over independent segments
-        # and the sharded search with its merge, over one segment per visible device of this run (world > 1: the other ranks wait at the barrier
-        # below; a single GPU: two segments on it, which exercises the same code path)
+        # and the sharded search with its merge, over one segment per visible device of this run (world > 1: after the process group has ended and
+        # the other ranks have left their devices; a single GPU: two segments on it, which exercises the same code path)
         try:
             result["one_process_fanout"] = one_process_fanout(args, world, dim, Q, top, lib, F, qa, torch, np)
         except Exception as e:
             result["one_process_fanout"] = {"error": repr(e)[:400]}
-    if world > 1:
-        dist.barrier()
     if solo and not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(args, rows, queries, out, counts, n, dim, Q, top, lib, qh, F, qa, np, torch)
-    for be, _, _ in lanes[1:]:
+    for be, _ in lanes:
         be.close()
-    backend.close()
     wanted = [c for c in args.configs.lower().split(",") if c]
     if solo and wanted:
         cfg = {}
+        lanes.clear()                   # the lanes hold the backends, the backends the segment: release the block's copies before the other configs
+        be = se = _ = backend2 = None   # noqa: F841  (loop variables above)
         del searcher, backend, storage, out, counts
         ctx = dict(args=args, dev=dev, lib=lib, F=F, qa=qa, np=np, torch=torch)
+        if "c1" in wanted:
+            try:
+                cfg["C1"] = c1_section(ctx)
+            except Exception as e:
+                cfg["C1"] = {"error": repr(e)[:400]}
         if "c3" in wanted:
             try:
                 cfg["C3"], rows = c3_section(ctx, rows)
@@ -691,10 +760,7 @@ def main(argv=None):
             except Exception as e:
                 cfg["C4"] = {"error": repr(e)[:400]}
         result["configs"] = cfg
-    if rank == 0:
-        emit(result, args.details)
-    if world > 1:
-        dist.destroy_process_group()
+    emit(result, args.details)      # (rank 0: the other ranks returned when the process group ended)
 
 
 if __name__ == "__main__":

@@ -637,6 +637,16 @@ QMX_API int32_t qmx_merge_topk_async(int32_t device_id, void *hip_stream, const 
                                      uint32_t n_lists, uint32_t nq, uint32_t k, qmx_scored_point *out_dev,
                                      uint32_t *out_counts_dev);
 
+/* The same merge over PACKED records: one record per list = one rank's whole answer to a batch in ONE buffer, so that the exchange step of the
+ * segment-sharded search is a single all-gather (`ncclAllGather` of qmx_topk_record_bytes(nq, k) bytes per rank):
+ *     record = [nq][k] qmx_scored_point, then [nq] uint32 counts, then 0 or 4 bytes of padding (records are multiples of 8 bytes).
+ * A rank fills its record with qmx_search_topk_async(q, k, ids, n_ids, out = record, out_counts = record + nq * k * 8) - no packing kernel.
+ * `records_dev` = n_lists records back to back (the all-gather's output); everything else as qmx_merge_topk_async.  The reference merges the
+ * per-segment lists of a batch in one aggregator pass too (`BatchResultAggregator::update_batch_results`, search_result_aggregator.rs:91-106). */
+QMX_API uint64_t qmx_topk_record_bytes(uint32_t nq, uint32_t k);
+QMX_API int32_t qmx_merge_topk_packed_async(int32_t device_id, void *hip_stream, const void *records_dev, const uint32_t *list_idx_base_dev,
+                                            uint32_t n_lists, uint32_t nq, uint32_t k, qmx_scored_point *out_dev, uint32_t *out_counts_dev);
+
 /* ---- one batch against N segments (N devices), one call ---------------------------------------- */
 
 /* `SegmentsSearcher::search` (lib/collection/src/collection_manager/segments_searcher.rs:250-285) runs one search task per segment and

@@ -185,6 +185,8 @@ SIGNATURES = {
                                                  C.POINTER(Counters)]),
     "qmx_merge_topk": (C.c_int32, [C.c_int32, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P]),
     "qmx_merge_topk_async": (C.c_int32, [C.c_int32, _P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P]),
+    "qmx_topk_record_bytes": (C.c_uint64, [C.c_uint32, C.c_uint32]),
+    "qmx_merge_topk_packed_async": (C.c_int32, [C.c_int32, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P]),
     "qmx_sharded_search_topk": (C.c_int32, [_P, C.c_uint32, C.c_uint32, _P, _P, _P, _P, C.POINTER(Counters)]),
     "qmx_sharded_search_topk_async": (C.c_int32, [_P, C.c_uint32, C.c_uint32, _P, _P, _P]),
     "qmx_sharded_hnsw_search": (C.c_int32, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P, _P, C.POINTER(Counters)]),

@@ -122,7 +122,7 @@ extern "C" {
 // library / device
 // ---------------------------------------------------------------------------------------------
 
-uint32_t qmx_abi_version(void) { return 7; }   // 7: qmx_hnsw_search_traced, the options of round 5
+uint32_t qmx_abi_version(void) { return 8; }   // 8: qmx_merge_topk_packed_async / qmx_topk_record_bytes, the pruned option list of round 6
 
 static int option_index(const char *name) {
     if (!name) return -1;

@@ -640,6 +640,24 @@ int32_t qmx_merge_topk_async(int32_t device_id, void *hip_stream, const qmx_scor
 }
 
 
+uint64_t qmx_topk_record_bytes(uint32_t nq, uint32_t k) {
+    return ((uint64_t)nq * k * sizeof(qmx_scored_point) + (uint64_t)nq * sizeof(uint32_t) + 7) & ~7ull;
+}
+
+int32_t qmx_merge_topk_packed_async(int32_t device_id, void *hip_stream, const void *records_dev, const uint32_t *list_idx_base_dev, uint32_t n_lists,
+                                    uint32_t nq, uint32_t k, qmx_scored_point *out_dev, uint32_t *out_counts_dev) {
+    QMX_REQUIRE(records_dev && out_dev && out_counts_dev, QMX_ERR_BAD_ARG, "NULL argument");
+    QMX_REQUIRE(k >= 1 && k <= MAX_TOP, QMX_ERR_NOT_SUPPORTED, "k %u not in 1..%u", k, MAX_TOP);
+    QMX_REQUIRE(((uintptr_t)records_dev & 7) == 0, QMX_ERR_BAD_ARG, "records must be 8-byte aligned");
+    QMX_HIP(hipSetDevice(device_id));
+    if (nq == 0) return QMX_OK;
+    const uint64_t rec = qmx_topk_record_bytes(nq, k);
+    const qmx_scored_point *lists = (const qmx_scored_point *)records_dev;
+    const uint32_t *counts = (const uint32_t *)((const char *)records_dev + (uint64_t)nq * k * sizeof(qmx_scored_point));
+    return launch_merge_points((hipStream_t)hip_stream, lists, counts, list_idx_base_dev, n_lists, nq, k, out_dev, out_counts_dev,
+                               rec / sizeof(qmx_scored_point), rec / sizeof(uint32_t));
+}
+
 int32_t qmx_search_quantized(const qmx_hnsw *g, qmx_query *quantized, qmx_query *raw, const qmx_search_params *p, const uint32_t *ids,
                              uint64_t n_ids, qmx_scored_point *out, uint32_t *out_counts, const volatile uint8_t *is_stopped,
                              qmx_counters *counters) {

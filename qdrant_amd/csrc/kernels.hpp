@@ -435,7 +435,7 @@ int32_t launch_merge_keys(hipStream_t st, const uint64_t *partial, uint32_t n_li
                           uint64_t *next_bound = nullptr, const int *run_if = nullptr, const uint32_t *out_map = nullptr, uint32_t shared_grid = 0);
 int32_t launch_merge_points(hipStream_t st, const qmx_scored_point *lists, const uint32_t *list_counts,
                             const uint32_t *list_idx_base, uint32_t n_lists, uint32_t nq, uint32_t k, qmx_scored_point *out,
-                            uint32_t *out_counts);
+                            uint32_t *out_counts, uint64_t list_stride = 0, uint64_t count_stride = 0);   // strides in entries / words between lists (0 = contiguous arrays)
 int32_t launch_split_candidates(hipStream_t st, const qmx_scored_point *cand, const uint32_t *cand_cnt, uint32_t n_per, uint32_t nq,
                                 uint32_t *ids, uint32_t top, qmx_scored_point *out, uint32_t *out_counts);
 int32_t launch_sort_scored(hipStream_t st, const float *scores, const uint32_t *ids, const uint32_t *counts, uint32_t n_per_query, uint32_t nq, uint32_t top,

@@ -90,15 +90,17 @@ __global__ __launch_bounds__(MERGE_BLOCK) void merge_points_kernel(const qmx_sco
                                                                    const uint32_t *list_counts,
                                                                    const uint32_t *list_idx_base, uint32_t n_lists,
                                                                    uint32_t nq, uint32_t k, qmx_scored_point *out,
-                                                                   uint32_t *out_counts) {
+                                                                   uint32_t *out_counts, uint64_t list_stride, uint64_t count_stride) {
+    // list l = lists + l * list_stride entries, its counts = list_counts + l * count_stride words: nq * k and nq for contiguous arrays; the packed
+    // records of qmx_merge_topk_packed_async (one all-gathered buffer per rank: lists, then counts) have their own strides
     extern __shared__ uint32_t seen_ids[];   // [n_lists * k]; 0xFFFFFFFF = no item or a duplicate
     const uint32_t q = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t total = n_lists * k;
     for (uint32_t j = threadIdx.x; j < total; j += MERGE_BLOCK) {
         const uint32_t l = j / k, i = j - l * k;
-        const uint32_t cnt = list_counts ? list_counts[(uint64_t)l * nq + q] : k;
-        seen_ids[j] = i < cnt ? lists[((uint64_t)l * nq + q) * k + i].idx + (list_idx_base ? list_idx_base[l] : 0u)
+        const uint32_t cnt = list_counts ? list_counts[(uint64_t)l * count_stride + q] : k;
+        seen_ids[j] = i < cnt ? lists[(uint64_t)l * list_stride + (uint64_t)q * k + i].idx + (list_idx_base ? list_idx_base[l] : 0u)
                               : 0xFFFFFFFFu;
     }
     __syncthreads();
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(MERGE_BLOCK) void merge_points_kernel(const qmx_sco
         const int top = (int)(k - off < (uint32_t)WAVE ? k - off : (uint32_t)WAVE);
         uint64_t list = 0;
         for (uint32_t l = wave; l < n_lists; l += MERGE_NW) {
-            const uint32_t cnt = list_counts ? list_counts[(uint64_t)l * nq + q] : k;
+            const uint32_t cnt = list_counts ? list_counts[(uint64_t)l * count_stride + q] : k;
             for (uint32_t base = 0; base < k; base += WAVE) {
                 const uint32_t i = base + lane;
                 uint64_t key = 0;
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(MERGE_BLOCK) void merge_points_kernel(const qmx_sco
                     const uint32_t id = seen_ids[j];
                     bool dup = false;
                     for (uint32_t e = 0; e < j; ++e) dup = dup || (seen_ids[e] == id);
-                    if (!dup) key = make_key(lists[((uint64_t)l * nq + q) * k + i].score, id);
+                    if (!dup) key = make_key(lists[(uint64_t)l * list_stride + (uint64_t)q * k + i].score, id);
                     if (key >= bound) key = 0;
                 }
                 wave_offer(list, key, top, lane);
@@ -170,12 +172,15 @@ int32_t launch_merge_keys(hipStream_t st, const uint64_t *partial, uint32_t n_li
 }
 int32_t launch_merge_points(hipStream_t st, const qmx_scored_point *lists, const uint32_t *list_counts,
                             const uint32_t *list_idx_base, uint32_t n_lists, uint32_t nq, uint32_t k,
-                            qmx_scored_point *out, uint32_t *out_counts) {
+                            qmx_scored_point *out, uint32_t *out_counts, uint64_t list_stride, uint64_t count_stride) {
     if (nq == 0) return QMX_OK;
+    if (list_stride == 0) list_stride = (uint64_t)nq * k;
+    if (count_stride == 0) count_stride = nq;
     QMX_REQUIRE((uint64_t)n_lists * k * sizeof(uint32_t) <= 64 * 1024, QMX_ERR_NOT_SUPPORTED,
                 "merge of %u lists x %u entries exceeds the 64 KiB seen-id table", n_lists, k);
     ::qmx::clear_stale_error();
-    hipLaunchKernelGGL(merge_points_kernel, dim3(nq), dim3(MERGE_BLOCK), (size_t)n_lists * k * sizeof(uint32_t), st, lists, list_counts, list_idx_base, n_lists, nq, k, out, out_counts);
+    hipLaunchKernelGGL(merge_points_kernel, dim3(nq), dim3(MERGE_BLOCK), (size_t)n_lists * k * sizeof(uint32_t), st, lists, list_counts, list_idx_base, n_lists, nq, k, out, out_counts,
+                       list_stride, count_stride);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }

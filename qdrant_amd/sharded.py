@@ -4,11 +4,11 @@ The reference searches every segment of a shard independently and merges the per
 (`SegmentsSearcher::search`, lib/collection/src/collection_manager/segments_searcher.rs:212-285 ->
 `BatchResultAggregator`, lib/shard/src/search_result_aggregator.rs:50-121).  Here a segment lives on one
 GPU, every rank scores the same query batch against its own segment and the only exchange step is an
-all-gather of `Q x top x 8` bytes per rank (RCCL over xGMI under `torch.distributed`, backend "nccl"),
-followed by the k-way merge with segment-local offsets globalised by a per-segment id base.
+all-gather of ONE packed record per rank (`Q x top x 8` bytes of lists + `Q x 4` of counts; RCCL over xGMI
+under `torch.distributed`, backend "nccl"), followed by the k-way merge with segment-local offsets globalised by a per-segment id base.
 
 Host logic only.  The two compute steps are delegated to a backend object:
-  * `HipBackend`   — the product: qmx_search_topk_async + qmx_merge_topk_async of libqdrant_amd.so
+  * `HipBackend`   — the product: qmx_search_topk_async + qmx_merge_topk_packed_async of libqdrant_amd.so
                      (fails loudly without a gfx950 device; there is no CPU fallback here);
   * tests inject an oracle-based backend to exercise the collective / id-globalisation logic on CPU
     with the gloo backend (tests/test_sharded_gloo.py).
@@ -69,8 +69,10 @@ def gather_topk(local_out: torch.Tensor, local_counts: torch.Tensor, gathered: O
         gcounts[0].copy_(local_counts)
     else:
         # output viewed as the concatenation along dim 0 (the layout both RCCL and gloo accept)
+        global COLLECTIVE_CALLS
         dist.all_gather_into_tensor(gathered.view((-1,) + tuple(local_out.shape[1:])), local_out.contiguous(), group=group)
         dist.all_gather_into_tensor(gcounts.view(-1), local_counts.contiguous(), group=group)
+        COLLECTIVE_CALLS += 2
     return gathered, gcounts
 
 
@@ -110,6 +112,14 @@ class HipBackend:
         F.check(self.lib.qmx_merge_topk_async(self.device_id, C.c_void_p(self.stream.cuda_stream), F.ptr(gathered),
                                               F.ptr(gcounts), F.ptr(idx_base), n_lists, nq, top, F.ptr(merged),
                                               F.ptr(mcounts)))
+        self._leave(cur)
+
+    def merge_packed(self, records, idx_base, nq: int, top: int, merged, mcounts):
+        """records [n_lists, record_words(nq, top)] int32: the all-gathered packed records (lists + counts of every rank)."""
+        assert records.is_contiguous() and records.shape[1] == record_words(nq, top)
+        cur = self._enter(records, idx_base, merged, mcounts)
+        F.check(self.lib.qmx_merge_topk_packed_async(self.device_id, C.c_void_p(self.stream.cuda_stream), F.ptr(records), F.ptr(idx_base),
+                                                     records.shape[0], nq, top, F.ptr(merged), F.ptr(mcounts)))
         self._leave(cur)
 
     def _enter(self, *tensors):
@@ -177,11 +187,27 @@ class HipHnswBackend(HipBackend):
         super().close()
 
 
+COLLECTIVE_CALLS = 0      # data-path collectives this module issued in this process (bench.py reports the number per step)
+
+
+def record_words(nq: int, top: int) -> int:
+    """32-bit words of one packed record = qmx_topk_record_bytes(nq, top) / 4: [nq][top] ScoredPointOffset, [nq] counts, padded to 8 bytes
+    (include/qdrant_amd.h, qmx_merge_topk_packed_async)."""
+    return (nq * top * 2 + nq + 1) // 2 * 2
+
+
 class ShardedSearcher:
     """search(queries) on every rank returns the merged top-k over all ranks' segments.
 
-    All buffers are allocated once; `search` only enqueues work on the backend's stream
-    (scan -> all-gather -> merge are ordered on that stream), so consecutive batches pipeline."""
+    The exchange step is ONE collective per batch: a rank's answer - its `Q x top` lists AND their counts - is one packed record
+    (`record_words`), written in place by the local search (`out` / `counts` are views of it), all-gathered as one buffer and merged
+    from the gathered records (`qmx_merge_topk_packed_async`).  The reference's aggregator takes a batch's per-segment lists in one
+    pass as well (`BatchResultAggregator::update_batch_results`, lib/shard/src/search_result_aggregator.rs:91-106).
+
+    All buffers are allocated once; `search` only enqueues work on the backend's stream (scan -> all-gather -> merge are ordered on
+    that stream), so consecutive batches pipeline, and several searchers on several streams keep several batches in flight - every
+    rank must then call them in the same order (a search holds a collective).  `timing = True` brackets the three stages with stream
+    events (`stage_us()`), for measurement runs outside a timed region."""
 
     def __init__(self, backend, n_local: int, nq: int, top: int, device=None, group=None):
         self.backend, self.nq, self.top, self.group = backend, nq, top, group
@@ -189,18 +215,59 @@ class ShardedSearcher:
         self.device = device if device is not None else getattr(backend, "device", torch.device("cpu"))
         dev = self.device
         self.idx_base = segment_id_bases(n_local, group, dev)
-        self.out = torch.zeros((nq, top, 2), dtype=torch.int32, device=dev)
-        self.counts = torch.zeros((nq,), dtype=torch.int32, device=dev)
-        self.gathered = torch.zeros((self.world, nq, top, 2), dtype=torch.int32, device=dev)
-        self.gcounts = torch.zeros((self.world, nq), dtype=torch.int32, device=dev)
+        words, lw = record_words(nq, top), nq * top * 2
+        self.record = torch.zeros((words,), dtype=torch.int32, device=dev)
+        self.out = self.record[:lw].view(nq, top, 2)                 # [Q, top, 2]: ScoredPointOffset rows (idx bits, f32 score bits)
+        self.counts = self.record[lw:lw + nq]                        # [Q]
+        self.records = torch.zeros((self.world, words), dtype=torch.int32, device=dev)      # the all-gather's output: list l = rank l's segment
+        self.gathered = self.records[:, :lw].view(self.world, nq, top, 2)                    # views for backends without a packed merge
+        self.gcounts = self.records[:, lw:lw + nq]
         self.merged = torch.zeros((nq, top, 2), dtype=torch.int32, device=dev)
         self.mcounts = torch.zeros((nq,), dtype=torch.int32, device=dev)
+        self.collectives = 0
+        self.timing = False
+        self._events = []
+
+    def _mark(self):
+        if self.timing and self.device.type == "cuda":
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(torch.cuda.current_stream(self.device))
+            return e
+        return None
 
     def search(self, queries):
+        global COLLECTIVE_CALLS
+        t0 = self._mark()
         self.backend.local_topk(queries, self.top, self.out, self.counts)
-        gather_topk(self.out, self.counts, self.gathered, self.gcounts, self.group)
-        self.backend.merge(self.gathered, self.gcounts, self.idx_base, self.top, self.merged, self.mcounts)
+        t1 = self._mark()
+        if self.world == 1:
+            self.records[0].copy_(self.record)
+        else:
+            dist.all_gather_into_tensor(self.records.view(-1), self.record, group=self.group)
+            self.collectives += 1
+            COLLECTIVE_CALLS += 1
+        t2 = self._mark()
+        if hasattr(self.backend, "merge_packed"):
+            self.backend.merge_packed(self.records, self.idx_base, self.nq, self.top, self.merged, self.mcounts)
+        else:
+            self.backend.merge(self.gathered, self.gcounts, self.idx_base, self.top, self.merged, self.mcounts)
+        t3 = self._mark()
+        if t0 is not None:
+            self._events.append((t0, t1, t2, t3))
         return self.merged, self.mcounts
+
+    def stage_us(self):
+        """Mean device time of the three stages over the searches issued with `timing` on (synchronise first): microseconds between the
+        stream events around local search / all-gather (incl. the hand-over to and from the collective's stream) / merge."""
+        if not self._events:
+            return None
+        n = float(len(self._events))
+        out = {"searches": len(self._events),
+               "local_search_us": round(sum(a.elapsed_time(b) for a, b, _, _ in self._events) * 1e3 / n, 2),
+               "allgather_us": round(sum(b.elapsed_time(c) for _, b, c, _ in self._events) * 1e3 / n, 2),
+               "merge_us": round(sum(c.elapsed_time(d) for _, _, c, d in self._events) * 1e3 / n, 2)}
+        self._events = []
+        return out
 
     def results(self):
         """Host copy of the last search: list of (idx u32 [c], score f32 [c]) per query (synchronises)."""

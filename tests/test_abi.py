@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = _ffi.lib()  # raises if the .so is missing or a symbol is absent
     for name in _declared():
         assert hasattr(lib, name), name
-    assert lib.qmx_abi_version() == 7
+    assert lib.qmx_abi_version() == 8
 
 
 def test_struct_layouts_match_the_header():

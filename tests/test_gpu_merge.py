@@ -35,6 +35,45 @@ def test_merge_topk_matches_aggregator(n_lists, nq, k):
         assert out[q, :oc[q]]["score"].tolist() == want[q]["score"].tolist()
 
 
+@pytest.mark.parametrize("n_lists,nq,k", [(1, 1, 1), (2, 3, 10), (8, 128, 10), (5, 7, 64), (3, 5, 100)])
+def test_merge_of_packed_records_equals_the_merge_of_the_arrays(n_lists, nq, k):
+    """qmx_merge_topk_packed_async: one record per list = [nq][k] points, [nq] counts, padding to 8 bytes (the ONE buffer a rank all-gathers);
+    same lists as qmx_merge_topk_async over separate arrays and as the aggregator (search_result_aggregator.rs:50-121), id bases included."""
+    import torch
+    from qdrant_amd import _ffi as F, sharded
+    lib = F.lib()
+    rng = np.random.default_rng(n_lists * 1000 + nq * 10 + k)
+    lists = _lists(rng, n_lists, nq, k, n_ids=5000)
+    counts = rng.integers(0, k + 1, size=(n_lists, nq)).astype(np.uint32)
+    bases = (np.arange(n_lists, dtype=np.uint32) * 5000).astype(np.uint32)
+    words = sharded.record_words(nq, k)
+    assert words * 4 == lib.qmx_topk_record_bytes(nq, k)
+    rec = np.full((n_lists, words), 0x7FFFFFFF, dtype=np.int32)            # padding words hold rubbish
+    for l in range(n_lists):
+        rec[l, :nq * k * 2] = lists[l].view(np.int32).reshape(-1)
+        rec[l, nq * k * 2:nq * k * 2 + nq] = counts[l].view(np.int32)
+    dev = torch.device("cuda", 0)
+    d_rec, d_base = torch.from_numpy(rec).to(dev), torch.from_numpy(bases.view(np.int32)).to(dev)
+    out, oc = torch.zeros((nq, k, 2), dtype=torch.int32, device=dev), torch.zeros((nq,), dtype=torch.int32, device=dev)
+    st = torch.cuda.Stream(dev)
+    F.check(lib.qmx_merge_topk_packed_async(0, C.c_void_p(st.cuda_stream), F.ptr(d_rec), F.ptr(d_base), n_lists, nq, k, F.ptr(out), F.ptr(oc)))
+    st.synchronize()
+    want = O.merge_topk(lists, counts, k, bases)
+    got, gc = out.cpu().numpy(), oc.cpu().numpy()
+    for q in range(nq):
+        assert gc[q] == len(want[q])
+        assert got[q, :gc[q], 0].view(np.uint32).tolist() == want[q]["idx"].tolist()
+        assert got[q, :gc[q], 1].copy().view(np.float32).tolist() == want[q]["score"].tolist()
+    # and through ShardedSearcher at world 1: the local search writes lists and counts straight into the record
+    d_l, d_c = torch.from_numpy(lists.view(np.int32).reshape(n_lists, nq, k, 2)).to(dev), torch.from_numpy(counts.view(np.int32)).to(dev)
+    out2, oc2 = torch.zeros_like(out), torch.zeros_like(oc)
+    F.check(lib.qmx_merge_topk_async(0, C.c_void_p(st.cuda_stream), F.ptr(d_l), F.ptr(d_c), F.ptr(d_base), n_lists, nq, k, F.ptr(out2), F.ptr(oc2)))
+    st.synchronize()
+    assert torch.equal(oc, oc2)
+    for q in range(nq):
+        assert torch.equal(out[q, :gc[q]], out2[q, :gc[q]])
+
+
 def test_merge_ties_prefer_the_lower_id_and_nan_sorts_first():
     from qdrant_amd import _ffi as F
     lists = np.zeros((2, 1, 4), dtype=O.ScoredPointOffset)

@@ -82,6 +82,12 @@ def _worker(rank, world, port, sizes, dim, nq, top, distance):
             for (gi, gs), w in zip(got, want):
                 assert gi.tolist() == w["idx"].tolist(), (rank, batch)
                 assert gs.tolist() == w["score"].tolist()
+        # the exchange step was ONE collective per search: lists and counts travel in one packed record (qmx_topk_record_bytes' layout)
+        assert s.collectives == 3 and sharded.COLLECTIVE_CALLS == 3
+        words = sharded.record_words(nq, top)
+        assert words % 2 == 0 and words >= nq * top * 2 + nq and s.record.shape == (words,) and s.records.shape == (world, words)
+        assert s.out.data_ptr() == s.record.data_ptr() and s.counts.data_ptr() == s.record.data_ptr() + nq * top * 8
+        assert torch.equal(s.records[rank], s.record) and torch.equal(s.gathered[rank], s.out) and torch.equal(s.gcounts[rank], s.counts)
         # every rank holds the same merged lists
         mine = s.merged.clone()
         allm = [torch.zeros_like(mine) for _ in range(world)]
@@ -131,6 +137,14 @@ def test_row_split_of_one_segment_matches_the_single_segment_search(world, n_tot
 def test_sharded_search_matches_single_process(world, sizes):
     import oracle_ffi  # noqa: F401  (builds the oracle before the workers start)
     mp.spawn(_worker, args=(world, _free_port(), sizes, 48, 5, 10, 0), nprocs=world, join=True)
+
+
+def test_record_words_is_the_header_formula():
+    sys.path.insert(0, ROOT)
+    from qdrant_amd import sharded, _ffi as F
+    lib = F.lib()
+    for nq, top in [(1, 1), (5, 10), (128, 10), (3, 7), (4096, 64)]:
+        assert sharded.record_words(nq, top) * 4 == lib.qmx_topk_record_bytes(nq, top) == (nq * top * 8 + nq * 4 + 7) // 8 * 8
 
 
 def test_gather_topk_single_process_is_a_copy():

@@ -387,6 +387,57 @@ def cpu_baseline(args, rows, queries, out, counts, n, dim, Q, top, lib, qh, F, q
 
 
 
+def c1_section(ctx, seconds=4.0):
+    """BASELINE.json configs[0] ("C1"): one segment of 100 000 x 128 f32, cosine, brute-force exact top-10 on the CPU RawScorer - the reference's own
+    CPU-runnable case (lib/segment/benches/vector_search.rs:21,34-104).  Here: the oracle's restatement of that path (AVX2+FMA CosineMetric +
+    peek_top_iter, kind "port") timed on this box's host cores at 1 thread and at all usable cores, 1 024 distinct queries (SURVEY 8d) in batches of 32;
+    and the device through the C-ABI at Q in {1, 8, 32} on the same rows, its lists checked against the oracle's bit for bit."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_ffi as O
+    args, lib, F, qa, np, torch = (ctx[k] for k in ("args", "lib", "F", "qa", "np", "torch"))
+    n, dim, nq, top, seed = 100_000, 128, 1024, 10, 0x5EED0001
+    rows = O.preprocess(O.COSINE, O.synth(seed, 0, n, dim))
+    queries = O.synth(seed + 1, 0, nq, dim)
+    ost = O.DenseStorage(O.F32, O.COSINE, rows)
+    enc = ost.encode_queries(queries)
+    cores = usable_cores()
+    cpu = {}
+    for name, threads, budget in (("one_thread", 0, seconds * 0.5), ("all_cores", cores, seconds * 0.5)):
+        done, t0 = 0, time.perf_counter()
+        while True:
+            b = (done // 32) % (nq // 32)
+            ost.peek_top(enc[b * 32:(b + 1) * 32], top, encoded=True, threads=threads)
+            done += 32
+            el = time.perf_counter() - t0
+            if el >= budget:
+                break
+        cpu[name] = {"qps": round(done / el, 1), "threads": max(1, threads), "queries": done, "seconds": round(el, 2),
+                     "ns_per_row_per_query": round(el / (done * n) * 1e9, 3), "GBps": round(done * n * dim * 4 / 32 / el / 1e9, 2)}
+    want = ost.peek_top(enc, top, encoded=True, threads=cores)
+    st = qa.VectorStorage(rows, qa.Distance.Cosine, device_id=ctx.get("device_id", 0))
+    dev = {}
+    ok = True
+    for Q in (1, 8, 32):
+        count = nq if Q == 32 else 256 if Q == 8 else 64
+        searchers = [qa.BatchFilteredSearcher(queries[q0:q0 + Q], st, top) for q0 in range(0, count, Q)]
+        got = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in searchers:
+            got += s.peek_top_all()
+        el = time.perf_counter() - t0
+        for j, g in enumerate(got):
+            ok = ok and g["idx"].tolist() == want[j]["idx"].tolist() and np.array_equal(g["score"].view(np.uint32), want[j]["score"].view(np.uint32))
+        dev["Q%d" % Q] = {"qps_wall_sync_per_batch": round(count / el, 1), "queries": count, "kernel": F.last_kernel(searchers[-1].scorer._h)}
+    if not ok:
+        print("PARITY FAILURE: C1 device lists differ from the oracle's", file=sys.stderr)
+    return {"workload": "C1: 1 segment 100k x d=128 f32 cosine, brute-force exact top-10, 1024 queries (rows iid N(0,1), normalised; seed 0x5EED0001)",
+            "cpu_oracle_port": dict(cpu, cores=cores, kind="port",
+                                    note="BASELINE's C1 is this CPU path: the oracle's C restatement of the AVX2+FMA scorer + peek_top_iter, batches of 32"),
+            "device": dev, "device_equals_oracle_bit_exact": bool(ok),
+            "device_note": "every search is a blocking call on host buffers (query upload + scan of 51.2 MB + list download): latency-bound, not a roofline point"}
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # C3 / C4 (rank 0, N = 1, outside the timed region)
 # ------------------------------------------------------------------------------------------------------------------------
