@@ -209,7 +209,7 @@ def compact_roofline(result):
     return out
 
 
-def _walk_summary(ow):
+def _walk_summary(ow, cost=None):
     """oracle_walk_check of a walk leg in three short strings"""
     if not isinstance(ow, dict) or not ow:
         return None
@@ -224,6 +224,8 @@ def _walk_summary(ow):
     if "reference_heap_order_same_ids" in ow:
         out["reference_heap_order"] = "ids %s, bits %s, pops %s" % (ow["reference_heap_order_same_ids"], ow.get("reference_heap_order_same_score_bits"),
                                                                    ow.get("reference_heap_order_same_pops"))
+    if isinstance(cost, dict) and "kernel_ms" in cost:
+        out["reference_heap_order_ms"] = [cost["kernel_ms"], cost.get("over_default_walk")]      # [kernel ms per launch, x the default walk]
     if "mfma_lut_same_id_sets" in ow:
         out["mfma_lut_same_id_sets"] = ow["mfma_lut_same_id_sets"]
     return out
@@ -251,7 +253,7 @@ def _configs_summary(cfg):
             put("C3.scan_Q32", bf.get("Q32"))
             put("C3.walk", h)
             ow = h.get("oracle_walk_check", {})
-            out["C3"] = {"build_s": h.get("build_s"), "oracle_walk": _walk_summary(ow),
+            out["C3"] = {"build_s": h.get("build_s"), "oracle_walk": _walk_summary(ow, h.get("reference_heap_order")),
                          "oracle_scan_ok": all(v is True for v in c3.get("oracle_check", {"-": None}).values())}
     tq = cfg.get("TQ4")
     if isinstance(tq, dict):
@@ -275,7 +277,7 @@ def _configs_summary(cfg):
             put("C4.scan_Q32", c4.get("brute_force_Q32_oversampling2_rescore"))
             ow = h.get("oracle_walk_check", {})
             out["C4"] = {"build_s": h.get("build_s"), "lut_mfma": _pick(lut.get("kernel_roofline", lut.get("roofline", {})), "achieved", "peak", "frac", "kernel_ms"),
-                         "oracle_walk": _walk_summary(ow)}
+                         "oracle_walk": _walk_summary(ow, h.get("reference_heap_order"))}
     out[LEG_COLUMNS] = legs
     return out
 

@@ -296,12 +296,12 @@ QMX_API int32_t qmx_last_error(char *buf, size_t buf_len);
 QMX_API uint32_t qmx_abi_version(void);
 /* Kernel-path options (process-wide).  Each selects between kernels that return IDENTICAL results - the parity tests run
  * both sides of every option - so they are tuning / triage switches, never correctness switches: "no_mfma_scan", "no_mfma16",
- * "no_mfma16_q64", "no_prescan", "prescan_shift", "hnsw_no_packed_l0", "hnsw_pq_lds_lut", "hnsw_log_cap", "bq_lanes8",
- * "mfma_no_nt", "mfma_no_fast", "no_pq_tiled", "no_split_scan", "split_min_queries", "no_split256", "no_pq_pair", "no_pq_prefilter",
- * "pq_prefilter_min_queries", "hnsw_pq_per_cu", "tq_rotate_block", "no_topk_small", "verify_max_per_query", "no_hnsw_pq_block", "hnsw_pq_block_waves",
- * "hnsw_pq_block_set", "sq_mfma_no_stage", "sq_mfma_no_llist", "pq_prefilter_w16" (read at segment create), "hnsw_pq_direct_walk", "hnsw_pq_table_build", "i8_sample_stride", "i8_scan_deep", "hnsw_pq_build_prefilter", "hnsw_no_pq_prefilter", "hnsw_static_slots", "hnsw_no_lds_visited", "pq_lut_no_lds", "hnsw_row_u4", "hnsw_per_cu", "debug"
+ * "no_prescan", "prescan_shift", "hnsw_log_cap", "no_split_scan", "split_min_queries", "no_split256", "no_pq_pair", "no_pq_prefilter",
+ * "pq_prefilter_min_queries", "hnsw_pq_per_cu", "tq_rotate_block", "no_topk_small", "verify_max_per_query", "hnsw_pq_direct_walk",
+ * "hnsw_pq_table_build", "i8_scan_lds160", "hnsw_no_pq_prefilter", "hnsw_no_lds_visited", "pq_lut_no_lds", "hnsw_per_cu", "debug"
  * - and one that selects the ORDER AMONG EQUAL SCORES of the plain HNSW walk: "hnsw_reference_heap_order" (see qmx_hnsw_search_traced) -
- * (qdrant_amd/csrc/common.hpp says what each selects; several are experiments that measured slower and stay opt-in).  Initial values come from the environment variables QMX_<NAME> read
+ * (qdrant_amd/csrc/common.hpp says what each selects; round 6 removed the experiments that had measured slower twice: their numbers stay under
+ * profiles/).  Initial values come from the environment variables QMX_<NAME> read
  * ONCE when the library is loaded; value < 0 restores that initial value.  Unknown name => QMX_ERR_BAD_ARG.  (No reference
  * counterpart: the reference selects its SIMD leaf by cpu feature detection, spaces/simple.rs:15-33.) */
 QMX_API int32_t qmx_set_option(const char *name, int64_t value);

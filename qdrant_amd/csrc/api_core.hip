@@ -32,9 +32,7 @@ int32_t hip_status(hipError_t e, const char *what, const char *file, int line) {
 }
 
 // ---- kernel-path options: the environment is read once, here, at load time ----
-static const char *const g_option_names[OPT_COUNT] = {"no_mfma_scan", "no_mfma16", "no_mfma16_q64", "no_prescan", "prescan_shift", "hnsw_no_packed_l0",
-                                                     "hnsw_pq_lds_lut", "hnsw_log_cap", "bq_lanes8", "mfma_no_nt", "mfma_no_fast", "no_pq_tiled", "no_split_scan", "split_min_queries", "no_split256", "no_pq_pair", "no_pq_prefilter", "pq_prefilter_min_queries", "hnsw_pq_per_cu", "tq_rotate_block", "no_topk_small", "verify_max_per_query", "no_hnsw_pq_block",
-                                                     "hnsw_pq_block_waves", "hnsw_pq_block_set", "sq_mfma_no_stage", "sq_mfma_no_llist", "pq_prefilter_w16", "hnsw_pq_direct_walk", "hnsw_pq_table_build", "i8_sample_stride", "i8_scan_deep", "hnsw_pq_build_prefilter", "hnsw_no_pq_prefilter", "hnsw_static_slots", "hnsw_no_lds_visited", "pq_lut_no_lds", "hnsw_row_u4", "hnsw_per_cu", "hnsw_reference_heap_order", "debug"};
+static const char *const g_option_names[OPT_COUNT] = {"no_mfma_scan", "no_mfma16", "no_prescan", "prescan_shift", "hnsw_log_cap", "no_split_scan", "split_min_queries", "no_split256", "no_pq_pair", "no_pq_prefilter", "pq_prefilter_min_queries", "hnsw_pq_per_cu", "tq_rotate_block", "no_topk_small", "verify_max_per_query", "hnsw_pq_direct_walk", "hnsw_pq_table_build", "i8_scan_lds160", "hnsw_no_pq_prefilter", "hnsw_no_lds_visited", "pq_lut_no_lds", "hnsw_per_cu", "hnsw_reference_heap_order", "experiment", "debug"};
 struct OptionTable {
     std::atomic<int64_t> v[OPT_COUNT];
     int64_t initial[OPT_COUNT];
@@ -50,10 +48,6 @@ struct OptionTable {
             if (i == OPT_PRESCAN_SHIFT && !e) val = 10;
             if (i == OPT_SPLIT_MIN_QUERIES && !e) val = 1;
             if (i == OPT_PQ_PREFILTER_MIN_QUERIES && !e) val = 4;
-            if (i == OPT_SQ_MFMA_NO_LLIST && !e) val = 1;        // (top lists in LDS: twice the waves per CU, no gain for SQ and a loss for TurboQuant's decode-bound scan, scan_sq_mfma.hip)
-            if (i == OPT_SQ_MFMA_NO_STAGE && !e) val = 1;        // (rows staged through LDS measured SLOWER than the direct operand loads: 0.723 against 0.751 of HBM at 32 queries, scan_sq_mfma.hip)
-            if (i == OPT_I8_SAMPLE_STRIDE && !e) val = 16;
-            if (i == OPT_NO_HNSW_PQ_BLOCK && !e) val = 1;       // (the block-per-search PQ walk is opt-in: measured 2.7 x slower than the one-wave kernel, hnsw_pq_block.hip)
             initial[i] = val;
             v[i].store(val, std::memory_order_relaxed);
         }

@@ -105,7 +105,7 @@ int32_t qmx_hnsw_create(const qmx_hnsw_desc *d, qmx_hnsw **out) {
         if ((rc = upload_array(&g->d_xp_levels, d->extra_entry_point_levels, d->n_extra_entry_points)) != QMX_OK) break;
     } while (0);
     // packed level-0 table (one round trip per hop instead of two); lists longer than m0 or 63 keep the CSR path
-    if (rc == QMX_OK && d->n_points && d->m0 <= 63 && !option(OPT_HNSW_NO_PACKED_L0)) {
+    if (rc == QMX_OK && d->n_points && d->m0 <= 63) {
         const uint32_t stride = d->m0 + 1;
         bool fits = true;
         if (!is_device_ptr(d->offsets))
@@ -494,7 +494,7 @@ static int32_t hnsw_build_impl(const qmx_segment *seg, const qmx_segment *origin
         h.lds_query_bytes = (uint32_t)((dev_row_bytes + 127) / 128 * 128 + 128);
         uint64_t lut_stride = 0;
         uint64_t max_entries = max_batch;      // query entries a batch may need: one per point - or, multi-vector points, one per inner vector
-        bool pq_direct_build = false, pq_build_prefilter = false;
+        bool pq_direct_build = false;
         if (seg->dtype == QMX_DTYPE_PQ) {   // query entries = LUTs of the batch's original vectors, read through L2 (as the PQ walk does)
             lut_stride = ((uint64_t)seg->pq_m * seg->pq.n_centroids * sizeof(float) + 15) & ~15ull;
             if (mb) {   // at least the longest point, at most 1 GiB of LUTs (the insertion loop shortens a batch that would need more)
@@ -516,20 +516,8 @@ static int32_t hnsw_build_impl(const qmx_segment *seg, const qmx_segment *origin
                 h.batch_queries = (const unsigned char *)b_bqsrc.p;
                 h.batch_q_stride = (uint64_t)seg->dim * 4;
                 h.lds_query_bytes = seg->dim * 4;
-                // + the 8-bit LUT image of every new point behind its vector (pq.hip pq_build_entry_kernel): the insertion searches drop, on its upper bound,
-                // the candidates their beam cannot take before the codebook arithmetic of an exact score
-                // (opt-in: at 2 M x 1536 points the build takes 25.6 s with it and 24.9 s without - what the searches save on exact scores the 30 KiB entry
-                // costs them in searches per CU: profiles/r5_sq_walk_visited.md)
-                pq_build_prefilter = option(OPT_HNSW_PQ_BUILD_PREFILTER) > 0 && seg->pq_m <= 128 && seg->pq.n_centroids <= 256 &&
-                                     (size_t)seg->pq_m * seg->pq.n_centroids * 4 <= 140 * 1024;
-                if (pq_build_prefilter) {
-                    const uint32_t est = seg->dim * 4 + pq_walk_lut8_stride(seg->pq_m);
-                    QB(b_bq.reserve((size_t)max_entries * est));
-                    h.batch_queries = (const unsigned char *)b_bq.p;
-                    h.batch_q_stride = est;
-                    h.lds_query_bytes = est;
-                    h.pq8_off = seg->dim * 4;
-                }
+                // (round 5 tried an 8-bit LUT image per new point behind its vector, to prefilter the hops of the insertion searches: the same graph,
+                // 25.6 s against 24.9 s at 2 M x 1536 points - gone from the code since round 6, profiles/r5_walk_variants_pq_hop_prefilter.jsonl)
             }
         }
         if (seg->dtype == QMX_DTYPE_TQ) {   // query entries = precompute_query of the batch's original vectors, staged in LDS per insertion
@@ -575,10 +563,8 @@ static int32_t hnsw_build_impl(const qmx_segment *seg, const qmx_segment *origin
         uint64_t slots1 = std::min<uint64_t>({(uint64_t)seg->num_cus * per_cu1, (uint64_t)HNSW_SLOT_CAP, (uint64_t)max_batch});
         slots1 = std::max<uint64_t>(1, std::min<uint64_t>(slots1, HNSW_VIS_BUDGET / (h.vis_words * 4)));
         const uint64_t slots2 = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)seg->num_cus * per_cu2, max_batch));
-        if (!option(OPT_HNSW_STATIC_SLOTS)) {
-            QB(b_next.reserve(8));
-            h.next = (uint32_t *)b_next.p;
-        }
+        QB(b_next.reserve(8));
+        h.next = (uint32_t *)b_next.p;
         QB(b_vis.reserve((size_t)slots1 * h.vis_words * 4));
         QB(b_log.reserve((size_t)slots1 * h.log_cap * 4));
         QH(hipMemset(b_vis.p, 0, (size_t)slots1 * h.vis_words * 4));
@@ -627,7 +613,6 @@ static int32_t hnsw_build_impl(const qmx_segment *seg, const qmx_segment *origin
                                         (size_t)seg->dim * 4, nr, hipMemcpyDeviceToDevice, nullptr));
                     if (seg->distance == QMX_DISTANCE_COSINE) QB(launch_cosine_preprocess_f32(nullptr, src, src, nr, seg->dim));
                     if (!pq_direct_build) QB(launch_pq_lut(nullptr, seg->distance, seg->dim, seg->pq, seg->d_centroids, src, (uint32_t)nr, (float *)b_bq.p));
-                    if (pq_build_prefilter) QB(launch_pq_build_entries(nullptr, seg->distance, seg->dim, seg->pq, seg->d_centroids, src, (uint32_t)nr, b_bq.p, (uint32_t)h.batch_q_stride));
                 }
             }
             if (tq_l1(seg)) {   // EncodedVectorsTQ over Manhattan: no preprocessing, no rotation - the rows themselves, zero padded to whole 16 bytes
@@ -782,11 +767,6 @@ static int32_t launch_hnsw(const qmx_query *q, const ScanArgs &a, const HnswArgs
     if (s->dtype == QMX_DTYPE_SQ_U8) return launch_hnsw_sq(q->stream, (int)s->distance, a, h, grid, per_cu);
     if (s->dtype == QMX_DTYPE_PQ && a.queries == q->enc.p && !a.cq_desc && !a.mv_offsets) return launch_hnsw_pq_direct(q->stream, a, h, grid, per_cu);
     if (s->dtype == QMX_DTYPE_PQ) {
-        // a LUT too large to stage once per wave (the old kernel then gathers it through L2): one block per search, the LUT in LDS (hnsw_pq_block.hip)
-        if (q->q_stride > 16 * 1024 && !option(OPT_NO_HNSW_PQ_BLOCK) && !option(OPT_HNSW_PQ_LDS_LUT) && pq_block_walk_ok(a, h)) {
-            const int64_t wv = option(OPT_HNSW_PQ_BLOCK_WAVES);
-            return launch_hnsw_pq_block(q->stream, a, h, grid, per_cu, wv > 0 ? (int)wv : 8);
-        }
         return launch_hnsw_pq(q->stream, a, h, grid, per_cu);
     }
     if (s->dtype == QMX_DTYPE_BQ) return launch_hnsw_bq(q->stream, a, h, grid, per_cu);
@@ -813,7 +793,7 @@ int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
         a.q_stride = qs;
     }
     // PQ: the LUT-free walk (pq.hip HopPQDirect) - the entry of a search is its preprocessed vector (q->enc keeps them), staged in LDS
-    const bool pq_direct = s->dtype == QMX_DTYPE_PQ && !cw && !mw && option(OPT_HNSW_PQ_DIRECT_WALK) > 0 && option(OPT_NO_HNSW_PQ_BLOCK) && !option(OPT_HNSW_PQ_LDS_LUT) &&
+    const bool pq_direct = s->dtype == QMX_DTYPE_PQ && !cw && !mw && option(OPT_HNSW_PQ_DIRECT_WALK) > 0 &&
                            s->d_centroids &&
                            pq_direct_walk_ok(s->dim, s->pq_m, s->pq.chunk_size, s->pq.n_centroids);
     if (pq_direct) {
@@ -859,7 +839,7 @@ int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
     }
     // A PQ LUT of more than half the LDS leaves one search per CU; the walk is a chain of dependent memory round trips,
     // so many searches per CU with the LUT read through L2 win (measured: tools/bench_hnsw.py)
-    if (s->dtype == QMX_DTYPE_PQ && q->q_stride > 16 * 1024 && !option(OPT_HNSW_PQ_LDS_LUT) && !mw) h.lds_query_bytes = 0;      // (a multi-query's LUTs are always staged)
+    if (s->dtype == QMX_DTYPE_PQ && q->q_stride > 16 * 1024 && !mw) h.lds_query_bytes = 0;      // (a multi-query's LUTs are always staged)
     if (pq_direct) h.lds_query_bytes = a.q_stride;
     if (cw) {   // [32-byte header][the examples' entries]: staged when they fit a modest share of the LDS, read through L2 otherwise (PQ LUTs always)
         const uint64_t need = 32 + (uint64_t)std::max<uint32_t>(cw->max_examples, 1) * q->q_stride;
@@ -885,10 +865,10 @@ int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
     // the visited set in LDS (hnsw.hpp LdsVisited) where the search has room for it beside its query entry; the bitmap below stays allocated for what the
     // table's buckets cannot hold
     h.vis_lds = (!acorn && !h.ref_heaps && !option(OPT_HNSW_NO_LDS_VISITED) && g->n_points <= HNSW_VIS_LDS_MAX_POINTS && h.lds_query_bytes <= 32 * 1024) ? HNSW_VIS_LDS_BYTES : 0;
-    // the PQ walk through per-search LUTs (HopPQ, not the LUT-free / block walks): the LUTs' 8-bit images for the hop prefilter (pq.hip HopPQ::prefilter), built
+    // the PQ walk through per-search LUTs (HopPQ, not the LUT-free walk): the LUTs' 8-bit images for the hop prefilter (pq.hip HopPQ::prefilter), built
     // here from the batch's f32 LUTs.  Its 24 KiB per search take the LDS the visited table would: that walk keeps the bitmap
-    if (s->dtype == QMX_DTYPE_PQ && !pq_direct && !acorn && !xo && !mw && !cw && !h.ref_heaps && !option(OPT_HNSW_NO_PQ_PREFILTER) && a.queries == q->d_queries &&
-        s->pq_m <= 128 && s->pq.n_centroids <= 256 && q->q_stride > 16 * 1024 && h.lds_query_bytes == 0 && option(OPT_NO_HNSW_PQ_BLOCK)) {
+    if (s->dtype == QMX_DTYPE_PQ && !pq_direct && !acorn && !mw && !cw && !h.ref_heaps && !option(OPT_HNSW_NO_PQ_PREFILTER) && a.queries == q->d_queries &&
+        s->pq_m <= 128 && s->pq.n_centroids <= 256 && q->q_stride > 16 * 1024 && h.lds_query_bytes == 0) {
         const uint32_t st8 = pq_walk_lut8_stride(s->pq_m);
         QMX_TRY(q->hnsw_pq8.reserve((size_t)n_searches * st8));
         QMX_TRY(launch_pq_walk_lut8(q->stream, q->d_queries, q->q_stride, n_searches, s->pq_m, s->pq.n_centroids, q->hnsw_pq8.p));
@@ -920,6 +900,11 @@ int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
     uint64_t slots = std::min<uint64_t>({(uint64_t)n_searches, (uint64_t)s->num_cus * per_cu, (uint64_t)HNSW_SLOT_CAP});
     const uint64_t by_budget = std::max<uint64_t>(1, HNSW_VIS_BUDGET / (h.vis_words * 4));
     slots = std::max<uint64_t>(1, std::min(slots, by_budget));
+    if (xo) {      // search_with_vectors: a slot's stack of evicted candidates that tie with the bound (hnsw.hpp; the reference keeps every one of them in `candidates`)
+        h.ev_cap = HNSW_EV_SPILL_CAP;
+        QMX_TRY(q->hnsw_refc.reserve((size_t)slots * h.ev_cap * sizeof(uint64_t)));
+        h.ev_spill = (uint64_t *)q->hnsw_refc.p;
+    }
     if (h.ref_heaps) {
         slots = std::min<uint64_t>(slots, HNSW_REF_SLOT_CAP);
         QMX_TRY(q->hnsw_refc.reserve((size_t)slots * h.ref_cap * sizeof(uint2)));
@@ -939,11 +924,10 @@ int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
     }
     h.visited = (uint32_t *)q->hnsw_vis.p;
     h.vis_log = (uint32_t *)q->hnsw_log.p;
-    if (!option(OPT_HNSW_STATIC_SLOTS)) {      // the slots draw their searches from a counter that starts behind the first `slots` (hnsw.hpp)
-        QMX_TRY(q->hnsw_next.reserve(4));
-        QMX_HIP(hipMemsetD32Async((hipDeviceptr_t)q->hnsw_next.p, (int)slots, 1, q->stream));
-        h.next_query = (uint32_t *)q->hnsw_next.p;
-    }
+    // the slots draw their searches from a counter that starts behind the first `slots` (hnsw.hpp)
+    QMX_TRY(q->hnsw_next.reserve(4));
+    QMX_HIP(hipMemsetD32Async((hipDeviceptr_t)q->hnsw_next.p, (int)slots, 1, q->stream));
+    h.next_query = (uint32_t *)q->hnsw_next.p;
     size_t slot = 0;
     if (timed) QMX_TRY(timing_begin(q, &slot));
     QMX_TRY(launch_hnsw(q, a, h, (uint32_t)slots, &per_cu));

@@ -77,7 +77,6 @@ struct qmx_segment {
     float *d_centroids = nullptr;
     float *d_pq_pair = nullptr;       // [m][ncent][ncent] chunk distances between centroids (score_internal terms; built when <= 256 MB)
     uint32_t pq_m = 0;
-    bool pq_rot_w16 = false;          // ... with 16-bit codes (pq_prefilter.hip)
     void *d_pq_rot = nullptr;         // PQ blocks of 2^18 rows and more, m <= 96: the rotated copy of the codes the 6-bit prefilter scans (pq_prefilter.hip)
     float *d_row_offsets = nullptr;   // SQ: vector_offset column (rows hold the 16-byte aligned code block)
     // TurboQuant (scan_tq.hip): parameters, the extras columns and the rotation tables
@@ -410,7 +409,7 @@ void fill_args(const qmx_query *q, uint32_t tile0, uint32_t nq_tile, ScanArgs &a
 int32_t launch_scan(const qmx_query *q, int qt, ScanMode mode, const ScanArgs &a, uint32_t *grid);
 int32_t tq_l1_scores_device(qmx_query *q, uint32_t q0, uint32_t nq, const uint32_t *d_ids, uint64_t n, float *d_scores, uint64_t stride, const PairSel *sel);
 int32_t score_matrix_enqueue(const qmx_query *q, uint32_t tile0, uint32_t nq_tile, const uint32_t *d_ids, uint64_t n, float *d_scores, uint64_t stride,
-                                    uint32_t *launches);
+                                    uint32_t *launches, uint32_t max_qt = 0);
 int32_t score_ids_device(qmx_query *q, const uint32_t *d_ids, uint64_t n, float *d_scores, qmx_counters *counters);
 int32_t score_pairs_device(qmx_query *q, const PairSel &sel, const uint32_t *d_ids, uint64_t n_items, float *d_scores,
                                   bool timed);

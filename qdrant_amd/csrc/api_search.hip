@@ -127,7 +127,7 @@ static int32_t pq_prefilter_enqueue(qmx_query *q, uint32_t top, uint64_t n_cand,
         uint32_t grid = 0;
         size_t slot = 0;
         if (timed) QMX_TRY(timing_begin(q, &slot));
-        QMX_TRY(launch_pq_prefilter(q->stream, a, s->d_pq_rot, q->pq_table.p, thr, nq_tile, s->num_cus, q->sp_wl.p, PQF_WCAP, &grid, s->pq_rot_w16 ? 1 : 0));
+        QMX_TRY(launch_pq_prefilter(q->stream, a, s->d_pq_rot, q->pq_table.p, thr, nq_tile, s->num_cus, q->sp_wl.p, PQF_WCAP, &grid));
         q->last_kernel = last_noted_kernel();
         if (timed) QMX_TRY(timing_end(q, slot));
         // 4. per-wave lists -> per-query lists (deleted rows dropped), then the rows worth an exact score
@@ -172,7 +172,7 @@ static int32_t pq_prefilter_enqueue(qmx_query *q, uint32_t top, uint64_t n_cand,
         qmx_counters &c = q->last_counters;
         c.vectors_scored = (uint64_t)q->nq * n_cand;
         // the rotated copy once per four-query group (all but the first find it in L2) + the sample's rows per query
-        c.bytes_read = (uint64_t)((q->nq + 3) / 4) * n_cand * m_pad * (s->pq_rot_w16 ? 2 : 1) + (uint64_t)q->nq * S * s->row_bytes;
+        c.bytes_read = (uint64_t)((q->nq + 3) / 4) * n_cand * m_pad + (uint64_t)q->nq * S * s->row_bytes;
         c.kernel_launches = launches;
         c.prefilter_queries = q->nq;
         q->last_row_bytes = s->row_bytes;
@@ -217,7 +217,7 @@ int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids, uint64
     const uint32_t grid_cap = (uint32_t)s->num_cus * 8;
     // f32 dot / cosine rows of 256, 512 or 768 floats, whole block: 64 queries per pass (scan_mfma16.hip); everything else 32 / 16
     const bool q64 = s->dtype == QMX_DTYPE_F32 && mfma_scan_ok(s) && q->nq > MAX_QT_MFMA && mfma16_dim_ok(64, s->dim) &&
-                     !option(OPT_NO_MFMA16) && !option(OPT_NO_MFMA16_Q64);
+                     !option(OPT_NO_MFMA16);
     // ... and rows of 1024 .. 1536 floats 32 per pass: that kernel keeps the queries in registers, not in an LDS tile (tile_qt's limit)
     const bool q32 = s->dtype == QMX_DTYPE_F32 && mfma_scan_ok(s) && q->nq > MAX_QT && s->dim > 768 && mfma16_dim_ok(32, s->dim) &&
                      !option(OPT_NO_MFMA16);
@@ -299,7 +299,7 @@ int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids, uint64
             a.top = top;
             // 1. exact scores of the sample -> the k-th best of each query = a lower bound of its final k-th best
             QMX_TRY(q->scores.reserve((size_t)nq_tile * S * sizeof(float)));
-            QMX_TRY(score_matrix_enqueue(q, tile0, nq_tile, d_sample, S, (float *)q->scores.p, S, nullptr));
+            QMX_TRY(score_matrix_enqueue(q, tile0, nq_tile, d_sample, S, (float *)q->scores.p, S, nullptr, (option(OPT_EXPERIMENT) & 1) ? 4u : 0u));
             QMX_TRY(launch_custom_topk(q->stream, (const float *)q->scores.p, S, d_sample, a.del, nq_tile, top, d_out + (size_t)tile0 * top, d_counts + tile0, gthr));
             QMX_TRY(split_stage(q, "prescan"));
             if (s->split_i8) {
@@ -312,10 +312,10 @@ int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids, uint64
                 const uint32_t np = split_i8_probe();
                 uint32_t *probe_ids = (uint32_t *)q->sp_probe.p, *probe_cnt = probe_ids + (size_t)q->nq * np;
                 int *tile_ovf = (int *)(plan + pl.tile_ovf) + split_tiles.size();
-                // (which tiles the first launch takes: every `i8_sample_stride`-th, 16 by default.  Its candidates are admitted on the SAMPLE's bound - a hundred
-                // times those of the main launch per tile -, so the first launch is bound by its candidate lists, not by its stream: a sparser sample costs the
-                // main launch a slightly weaker bound - the band, not the bound, decides how many rows it lets through - and saves the first launch's time)
-                const uint32_t sstride = (uint32_t)std::min<int64_t>(std::max<int64_t>(option(OPT_I8_SAMPLE_STRIDE), 2), 255);
+                // (which tiles the first launch takes: every 16th.  Its candidates are admitted on the SAMPLE's bound - a hundred times those of the main launch
+                // per tile -, so the first launch is bound by its candidate lists, not by its stream; strides of 8 .. 64 measured the same step time,
+                // profiles/r5_i8_sample_stride.md)
+                const uint32_t sstride = 16;
                 for (uint32_t ph = 1; ph <= 2; ++ph) {
                     const uint32_t phase = ph | (sstride << 8);
                     size_t slot = 0;
@@ -451,6 +451,7 @@ int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids, uint64
                                   (uint32_t *)(plan + pl.count), (int *)(plan + pl.run16), (int *)(plan + pl.run64), n_run64, (SplitStats *)plan, q->d_queries,
                                   q->q_stride, q->sp_fq.p));
         for (uint32_t pass = 0; pass <= n_run64; ++pass) {      // pass 0: the 16-query shape; pass p >= 1: packed queries 64 (p - 1) ..
+            if (option(OPT_EXPERIMENT) & 2) break;
             if (pass && last <= 16) break;
             const uint32_t p0 = pass ? (pass - 1) * FQT : 0;
             const uint32_t nq_sub = pass ? std::min<uint32_t>(FQT, last - p0) : std::min<uint32_t>(16, last);

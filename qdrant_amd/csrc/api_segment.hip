@@ -109,22 +109,12 @@ static int32_t segment_pq_rot(qmx_segment *s) {
     if (s->dtype != QMX_DTYPE_PQ || s->n < (1u << 18) || !pq_prefilter_shape_ok(s->pq_m, s->pq.n_centroids) || option(OPT_NO_PQ_PREFILTER)) return QMX_OK;
     const uint32_t m_pad = (s->pq_m + 31u) & ~31u;
     if (m_pad > 2 * s->pq_m && !(s->flags & QMX_SEG_PQ_PREFILTER_COPY)) return QMX_OK;
-    // 16-bit codes (opt-in): twice the copy for half the address arithmetic of the scan.  Measured at 10 M x 96 (profiles/r4_pq_prefilter_w16.md): the same
-    // 0.96 ms at 32 queries, 6 % less at 128, twice the time at 4 (where the scan is bound by the copy's bytes) - so the 8-bit copy stays the default
-    s->pq_rot_w16 = option(OPT_PQ_PREFILTER_W16) > 0;
-    if (hipMalloc(&s->d_pq_rot, pq_rot_bytes(s->n, s->pq_m, s->pq_rot_w16)) != hipSuccess) {
+    if (hipMalloc(&s->d_pq_rot, pq_rot_bytes(s->n, s->pq_m)) != hipSuccess) {
         (void)hipGetLastError();
         s->d_pq_rot = nullptr;
-        if (s->pq_rot_w16) {      // (no room for the wide copy: the narrow one)
-            s->pq_rot_w16 = false;
-            if (hipMalloc(&s->d_pq_rot, pq_rot_bytes(s->n, s->pq_m, 0)) != hipSuccess) {
-                (void)hipGetLastError();
-                s->d_pq_rot = nullptr;
-            }
-        }
-        if (!s->d_pq_rot) return QMX_OK;
+        return QMX_OK;
     }
-    if (launch_pq_rotate(nullptr, s->d_rows, s->row_stride, s->n, s->pq_m, s->d_pq_rot, s->pq_rot_w16) != QMX_OK || hipDeviceSynchronize() != hipSuccess) {
+    if (launch_pq_rotate(nullptr, s->d_rows, s->row_stride, s->n, s->pq_m, s->d_pq_rot) != QMX_OK || hipDeviceSynchronize() != hipSuccess) {
         (void)hipGetLastError();
         ::qmx::clear_stale_error();
         (void)hipFree(s->d_pq_rot);

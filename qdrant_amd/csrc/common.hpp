@@ -25,16 +25,9 @@ void clear_stale_error();
 enum Option {
     OPT_NO_MFMA_SCAN = 0,     // 8+ query tiles keep the VALU scan
     OPT_NO_MFMA16,            // no chain-major 16x16x4 scan (scan_mfma16.hip)
-    OPT_NO_MFMA16_Q64,        // ... only its 64-query shape
     OPT_NO_PRESCAN,           // no threshold pre-scan in front of the top-k scans
     OPT_PRESCAN_SHIFT,        // pre-scan over n >> shift rows (default 10)
-    OPT_HNSW_NO_PACKED_L0,    // level 0 read through the CSR arrays
-    OPT_HNSW_PQ_LDS_LUT,      // PQ walk keeps a large LUT in LDS (one search per CU)
     OPT_HNSW_LOG_CAP,         // visited-word log entries per search before the whole-bitmap clear
-    OPT_BQ_LANES8,            // BQ scans on the 8-lanes-per-row layout
-    OPT_MFMA_NO_NT,           // 4x4x1 scan without nontemporal row loads
-    OPT_MFMA_NO_FAST,         // 4x4x1 scan without the guard-free ping-pong loop
-    OPT_NO_PQ_TILED,          // PQ scan on the one-row-per-lane kernel
     OPT_NO_SPLIT_SCAN,        // f32 scans of more than 64 queries keep the exact chain-major kernel (no f16-split prefilter + verification)
     OPT_SPLIT_MIN_QUERIES,    // with a derived copy of the block: batches of at least this many queries take the prefilter (default 1: all)
     OPT_NO_SPLIT256,          // batches of more than 128 queries over a half copy: keep the 128-query shape of the prefilter
@@ -45,25 +38,16 @@ enum Option {
     OPT_TQ_ROTATE_BLOCK,      // TurboQuant rotation by the one-block-per-vector kernel (not one wave per vector)
     OPT_NO_TOPK_SMALL,        // top-k of short score rows by the insertion kernel (not the rank-sort of the pruned row)
     OPT_VERIFY_MAX_PER_QUERY, // prefilters: a query with more rows inside its band than this takes the exact scan, whatever room the batch's pool has (0 = no such limit)
-    OPT_NO_HNSW_PQ_BLOCK,     // PQ walk: keep the one-wave-per-search kernel with the LUT read through L2 (default 1; 0 = the block-per-search walk with the LUT in LDS)
-    OPT_HNSW_PQ_BLOCK_WAVES,  // ... waves of a block of that walk: one controller + (waves - 1) speculating workers (0 = default 8; 3 .. 8)
-    OPT_HNSW_PQ_BLOCK_SET,    // ... entries of its LDS visited set (0 = what fits; tests shrink it to reach the restart on the HBM bitmap)
-    OPT_SQ_MFMA_NO_STAGE,     // SQ matrix-core scan: rows straight from HBM into the operand registers (default 1; 0 = staged through wave-private LDS buffers: measured slower)
-    OPT_SQ_MFMA_NO_LLIST,     // SQ / TQ / BQ / f16 matrix-core scans: the waves' top lists in registers (default 1; 0 = in LDS behind the query tile: more waves per CU, measured no faster)
-    OPT_PQ_PREFILTER_W16,     // PQ prefilter: the rotated copy holds 16-bit codes (twice the copy; one vector instruction per gather address instead of two); read at segment create
     OPT_HNSW_PQ_DIRECT_WALK,  // the PQ walk recomputes LUT entries from the codebook (pq.hip HopPQDirect: a twentieth of the HBM traffic; 1.3 x the time on a 2 M-row graph, the same at 10 M) instead of gathering per-search LUTs
     OPT_HNSW_PQ_TABLE_BUILD,  // the PQ build scores through per-insertion LUTs and the centroid pair table (round 2's build: 100 TB of table sectors per 2 M points) instead of
                               // recomputing both kinds of entries from the codebook (pq.hip HopPQDirectBuild + HopPQInternalDirect, the default where the codebook allows)
-    OPT_I8_SAMPLE_STRIDE,     // the int8 prefilter's first launch takes every n-th 256-row tile (default 16); the second launch the others
-    OPT_I8_SCAN_DEEP,         // the int8-copy prefilter scans through the half-stage pipeline (scan_i8copy_deep_kernel: 80 KiB of rows in flight per CU, twice the barriers: 14 % slower)
-    OPT_HNSW_PQ_BUILD_PREFILTER, // the table-free PQ build prefilters the hops of its insertion searches on an 8-bit LUT image per new point (exact, measured no faster: opt-in)
+    OPT_I8_SCAN_LDS160,       // the int8-copy prefilter keeps four query stages in LDS (rounds 3 - 5: 160 KiB, the CU's whole LDS) instead of three (144 KiB: the other batch's small kernels run beside the scan)
     OPT_HNSW_NO_PQ_PREFILTER, // the PQ walk scores every hop candidate exactly (rounds 1-4) instead of dropping, on an 8-bit upper bound, those the beam cannot take
-    OPT_HNSW_STATIC_SLOTS,    // the walk's slots take searches slot, slot + grid, ... (rounds 1-4) instead of drawing the next unstarted one from a counter
     OPT_HNSW_NO_LDS_VISITED,  // the walk's visited set lives in the per-slot HBM bitmap only (rounds 1-4), not in the 16 KiB LDS table in front of it
     OPT_PQ_LUT_NO_LDS,        // the MFMA LUT build reads its operands from global memory per instruction (round 1's pq_lut_mfma_kernel) instead of staging both in LDS
-    OPT_HNSW_ROW_U4,          // the SQ walk's 4-row scoring pass keeps 3 (value 3) instead of 4 steps in flight per row: 116 instead of 146 registers = 4 instead of 3 waves per SIMD
     OPT_HNSW_PER_CU,          // cap on the searches resident per CU of any walk (0 = what the occupancy allows)
     OPT_HNSW_REFERENCE_HEAP_ORDER,   // the plain HNSW walk keeps `nearest` / `candidates` as the reference's two binary heaps (std sift order, one lane): the reference's lists among equal scores; slow, a verification mode
+    OPT_EXPERIMENT,           // TEMPORARY (round 6 measurements): bit 0 = the prefilter's sample scores through 4-query tiles (12.5 KiB of LDS), bit 1 = no conditional fallback launches
     OPT_DEBUG,                // log dropped stale HIP errors
     OPT_COUNT
 };

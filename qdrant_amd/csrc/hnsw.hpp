@@ -56,7 +56,7 @@ struct is_asymmetric { static constexpr bool value = false; };
 template <class H>
 struct is_asymmetric<H, decltype((void)H::ASYMMETRIC)> { static constexpr bool value = H::ASYMMETRIC; };
 
-template <class P, int U4 = 4>
+template <class P>
 struct HopRow {
     static constexpr int LPI = 8;
     static constexpr bool INTERNAL_QOFF = has_internal_qoff<P>::value;
@@ -67,7 +67,7 @@ struct HopRow {
     }
     template <int R>
     static __device__ __forceinline__ void score_multi(const ScanArgs &a, const unsigned char *qp, const uint32_t (&ids)[R], int sub, float (&out)[R]) {
-        group_score_multi<P, R, U4>(a, qp, ids, sub, out);
+        group_score_multi<P, R>(a, qp, ids, sub, out);
     }
 };
 template <class S>
@@ -445,13 +445,17 @@ struct LdsVisited {
 // `candidates` = BinaryHeap<ScoredPointOffset> (search_context.rs:8-40; pop = swap with the last + sift_down_to_bottom(0) + sift_up).
 // ScoredPointOffset orders by OrderedFloat(score) alone, so which of two equal scores a sift moves depends on where they sit in the array:
 // reproducing the arrays is the only way to reproduce the reference's lists among equal scores (integer scorers: SQ, u8, BQ, 1-bit TQ).
-// A verification mode: every heap operation is a chain of dependent loads of one lane; `nearest` sits in LDS, `candidates` (unbounded in
-// the reference) in a per-slot HBM scratch of ref_cap entries.
+// Every heap operation is a chain of dependent loads of one lane; `nearest` sits in LDS, and so do the first HNSW_REF_CAND_LDS entries of
+// `candidates` (round 6: the levels every sift touches; rounds 5's heap lived in HBM whole: a pop was a dozen dependent trips to memory); the rest of
+// the array (unbounded in the reference) is a per-slot HBM scratch of ref_cap entries.
 struct RefHeaps {
     uint2 *nd;                 // nearest: x = idx, y = score bits
-    uint2 *cd;                 // candidates
-    uint32_t n_len, n_cap, c_len, c_cap;
+    uint2 *cd;                 // candidates: entries [c_lds, c_cap) live here ...
+    uint2 *cl;                 // ... entries [0, c_lds) in LDS
+    uint32_t n_len, n_cap, c_len, c_cap, c_lds;
     bool overflow;
+    __device__ __forceinline__ uint2 cget(uint32_t i) const { return i < c_lds ? cl[i] : cd[i]; }
+    __device__ __forceinline__ void cset(uint32_t i, uint2 v) { if (i < c_lds) cl[i] = v; else cd[i] = v; }
     // OrderedFloat::cmp: NaN is the greatest value and equal to itself
     static __device__ __forceinline__ int of_cmp(float a, float b) {
         if (a < b) return -1;
@@ -463,9 +467,11 @@ struct RefHeaps {
     }
     static __device__ __forceinline__ float sc(uint2 v) { return __uint_as_float(v.y); }
     static __device__ __forceinline__ int rev_cmp(uint2 a, uint2 b) { return of_cmp(sc(b), sc(a)); }      // Reverse<T>
-    __device__ __forceinline__ void init(unsigned char *lds, uint32_t ef, uint2 *scratch, uint32_t cap) {
+    __device__ __forceinline__ void init(unsigned char *lds, uint32_t ef, uint2 *scratch, uint32_t cap, unsigned char *cand_lds, uint32_t cand_lds_entries) {
         nd = reinterpret_cast<uint2 *>(lds);
         cd = scratch;
+        cl = reinterpret_cast<uint2 *>(cand_lds);
+        c_lds = cand_lds_entries;
         n_len = 0; n_cap = ef ? ef : 1; c_len = 0; c_cap = cap;
         overflow = false;
     }
@@ -518,37 +524,37 @@ struct RefHeaps {
         uint32_t pos = c_len++;
         while (pos > 0) {                                  // sift_up(0, pos)
             const uint32_t parent = (pos - 1) / 2;
-            const uint2 pv = cd[parent];
+            const uint2 pv = cget(parent);
             if (of_cmp(sc(v), sc(pv)) <= 0) break;
-            cd[pos] = pv;
+            cset(pos, pv);
             pos = parent;
         }
-        cd[pos] = v;
+        cset(pos, v);
     }
     __device__ bool c_pop(uint2 *out) {
         if (c_len == 0) return false;
-        uint2 item = cd[--c_len];
+        uint2 item = cget(--c_len);
         if (c_len > 0) {
-            const uint2 root = cd[0];
+            const uint2 root = cget(0);
             // sift_down_to_bottom(0) of `item`, then sift_up from where it landed
             const uint32_t end = c_len;
             uint32_t pos = 0, child = 1;
             while (end >= 2 && child <= end - 2) {
-                const uint2 l = cd[child], r = cd[child + 1];
+                const uint2 l = cget(child), r = cget(child + 1);
                 const bool right = of_cmp(sc(l), sc(r)) <= 0;
-                cd[pos] = right ? r : l;
+                cset(pos, right ? r : l);
                 pos = child + (right ? 1u : 0u);
                 child = 2 * pos + 1;
             }
-            if (child == end - 1) { cd[pos] = cd[child]; pos = child; }
+            if (child == end - 1) { cset(pos, cget(child)); pos = child; }
             while (pos > 0) {
                 const uint32_t parent = (pos - 1) / 2;
-                const uint2 pv = cd[parent];
+                const uint2 pv = cget(parent);
                 if (of_cmp(sc(item), sc(pv)) <= 0) break;
-                cd[pos] = pv;
+                cset(pos, pv);
                 pos = parent;
             }
-            cd[pos] = item;
+            cset(pos, item);
             item = root;
         }
         *out = item;
@@ -724,7 +730,7 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
         // ---- option hnsw_reference_heap_order: search_on_level with the reference's own heaps (plain walk only) ----
         __syncthreads();                    // (the previous search of this block is done with the LDS heap)
         RefHeaps rh;
-        rh.init(beam_lds, ef, h.ref_cands + (uint64_t)blockIdx.x * h.ref_cap, h.ref_cap);
+        rh.init(beam_lds, ef, h.ref_cands + (uint64_t)blockIdx.x * h.ref_cap, h.ref_cap, beam_lds + hnsw_beam_lds(ef), HNSW_REF_CAND_LDS);
         uint32_t log_cnt = 1, n_pop = 0;
         if (lane == 0) {
             atomicOr(&vis[cur_id >> 5], 1u << (cur_id & 31));
@@ -975,10 +981,16 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
     } else {
     // search_on_level_with_vectors: `candidates` also holds what `nearest` evicted before it was expanded; when every entry of the beam is
     // expanded the reference pops the best of those: one whose score EQUALS the lower bound is expanded like any other (the loop breaks on strict
-    // `candidate.score < lower_bound` only, graph_layers.rs:358), the first one below it has its base vector scored and ends the loop.  The four best
-    // evicted-unexpanded candidates are kept (more than four of them tying with the bound at once is not covered; among equal scores the reference's
-    // pop order is its heap's)
+    // `candidate.score < lower_bound` only, graph_layers.rs:354-365), the first one below it has its base vector scored and ends the loop.
+    // Every evicted-unexpanded candidate that can still be popped is kept.  Evictions arrive in strictly increasing key order (the entry that leaves is the
+    // beam's worst, and whatever left before was worse still), and the bound never falls - so only the evictions of the LATEST score can ever tie with
+    // the bound, and an eviction of a higher score retires all earlier ones (they can no longer tie, and the break candidate is the best key).  The
+    // latest-score group lives in ev[0..3] (best first) with its older members on a per-slot stack in global memory (h.ev_spill: ascending keys, so the top of
+    // the stack is the next best) - integer link scores (BQ, 1-bit TurboQuant) evict dozens of equal scores.  Among equal scores the pop order is the key's
+    // (lower id first) where the reference's is its heap's.
     uint64_t ev[4] = {0, 0, 0, 0};
+    uint32_t n_spill = 0;
+    uint64_t *const spill = h.ev_spill ? h.ev_spill + (uint64_t)blockIdx.x * h.ev_cap : nullptr;
     uint32_t n_exp = 0;
     while (true) {
         uint64_t ck = beam.pop_best(lane);
@@ -986,6 +998,10 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
             if (h.expanded && ev[0] && key_score(ev[0]) == key_score(beam.at(ef - 1))) {
                 ck = ev[0];
                 ev[0] = ev[1]; ev[1] = ev[2]; ev[2] = ev[3]; ev[3] = 0;
+                if (n_spill) {      // (wave-uniform; agent-scope accesses: the stack is written and read back by this wave through L2)
+                    --n_spill;
+                    ev[3] = __hip_atomic_load(&spill[n_spill], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             } else break;
         }
         const uint32_t cand = key_idx(ck);
@@ -1047,7 +1063,7 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
             }
             n_scored += k;
             if constexpr (has_hop_prefilter<H>::value) {      // candidates that cannot beat the beam's worst entry leave here, unscored (the same walk: see H::prefilter)
-                if (pq8 && !h.expanded) k = H::prefilter(a, pq8, hop_ids, k, beam.at(ef - 1), lane);
+                if (pq8) k = H::prefilter(a, pq8, hop_ids, k, beam.at(ef - 1), lane);
             }
             hop_score<H>(a, qp, hop_ids, hop_scores, k, lane);
             const uint64_t mykey = (uint32_t)lane < k ? make_key(hop_scores[lane], hop_ids[lane]) : 0;
@@ -1059,10 +1075,17 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
                 const uint64_t last = beam.at(ef - 1);
                 if (nk > last) {
                     if (h.expanded && last != 0 && !beam.done_at(ef - 1)) {      // an unexpanded entry leaves `nearest`: it stays in `candidates`
-                        uint64_t x = last;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (x > ev[i]) { const uint64_t t = ev[i]; ev[i] = x; x = t; }
+                        if (ev[0] && (last >> 32) != (ev[0] >> 32)) {             // a higher score: the earlier evictions are retired
+                            ev[0] = ev[1] = ev[2] = ev[3] = 0;
+                            n_spill = 0;
+                        }
+                        if (ev[3]) {                                              // the group's oldest member of the four makes room
+                            if (spill && n_spill < h.ev_cap) {
+                                if (lane == 0) __hip_atomic_store(&spill[n_spill], ev[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                ++n_spill;
+                            } else if (lane == 0) *a.err_flag = 2;                // (more equal scores than the stack holds: reported, never silently dropped)
+                        }
+                        ev[3] = ev[2]; ev[2] = ev[1]; ev[1] = ev[0]; ev[0] = last;
                     }
                     beam.insert(nk, ef, lane);
                 }
@@ -1275,7 +1298,8 @@ int32_t hnsw_occupancy_inst(uint32_t lds_query_bytes, size_t hop_lds, int *per_c
 template <class H, int E, bool QLDS>
 int32_t launch_hnsw_inst(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid) {
     const uint32_t ef = h.ef > h.top ? h.ef : h.top;
-    const size_t lds = 8 * (size_t)h.hop_cap + hnsw_acorn_lds(h.acorn, h.m0) + (QLDS ? ((size_t)h.lds_query_bytes + 15) / 16 * 16 : 0) + (E <= 0 ? hnsw_beam_lds(ef) : 0) + h.vis_lds + (h.pq8 ? h.pq8_stride : 0);
+    const size_t lds = 8 * (size_t)h.hop_cap + hnsw_acorn_lds(h.acorn, h.m0) + (QLDS ? ((size_t)h.lds_query_bytes + 15) / 16 * 16 : 0) + (E <= 0 ? hnsw_beam_lds(ef) : 0) +
+                       (E == HNSW_E_REF ? (size_t)HNSW_REF_CAND_LDS * 8 : 0) + h.vis_lds + (h.pq8 ? h.pq8_stride : 0);
     QMX_REQUIRE(lds <= 160 * 1024, QMX_ERR_NOT_SUPPORTED, "hnsw walk: %zu bytes of LDS (query entry + a list of %u)", lds, ef);
     ::qmx::clear_stale_error();
     QMX_NOTE_KERNEL((hnsw_search_kernel<H, E, QLDS>));
@@ -1301,7 +1325,7 @@ int32_t launch_hnsw_hop(hipStream_t st, const ScanArgs &a, const HnswArgs &h, ui
     if (h.ref_heaps) {      // option hnsw_reference_heap_order: the plain walk of the policies a stored graph is walked with
         if constexpr (ref_heaps_built<H>::value) {
             QMX_REQUIRE(!h.acorn && !h.expanded, QMX_ERR_NOT_SUPPORTED, "hnsw_reference_heap_order: the plain walk only (not ACORN, not search_with_vectors)");
-            const size_t hop_lds = 8 * (size_t)h.hop_cap + hnsw_beam_lds(ef) + h.vis_lds + (h.pq8 ? h.pq8_stride : 0);
+            const size_t hop_lds = 8 * (size_t)h.hop_cap + hnsw_beam_lds(ef) + (size_t)HNSW_REF_CAND_LDS * 8 + h.vis_lds + (h.pq8 ? h.pq8_stride : 0);
             if (grid == 0) return qlds ? hnsw_occupancy_inst<H, HNSW_E_REF, true>(h.lds_query_bytes, hop_lds, per_cu) : hnsw_occupancy_inst<H, HNSW_E_REF, false>(0, hop_lds, per_cu);
             return qlds ? launch_hnsw_inst<H, HNSW_E_REF, true>(st, a, h, grid) : launch_hnsw_inst<H, HNSW_E_REF, false>(st, a, h, grid);
         } else {
@@ -1338,15 +1362,6 @@ struct HnswLauncher {
     uint32_t grid;
     int *per_cu;
     template <class P> int32_t row(const ScanArgs &a) const { return launch_hnsw_hop<HopRow<P>>(st, a, *h, grid, per_cu); }
-    template <class S> int32_t small(const ScanArgs &a) const { return launch_hnsw_hop<HopSmall<S>>(st, a, *h, grid, per_cu); }
-};
-// the same with 3 steps in flight per row of a 4-row pass (option hnsw_row_u4 = 3: fewer registers, one more wave per SIMD)
-struct HnswLauncherU3 {
-    hipStream_t st;
-    const HnswArgs *h;
-    uint32_t grid;
-    int *per_cu;
-    template <class P> int32_t row(const ScanArgs &a) const { return launch_hnsw_hop<HopRow<P, 3>>(st, a, *h, grid, per_cu); }
     template <class S> int32_t small(const ScanArgs &a) const { return launch_hnsw_hop<HopSmall<S>>(st, a, *h, grid, per_cu); }
 };
 struct HnswCustomLauncher {

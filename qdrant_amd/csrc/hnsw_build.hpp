@@ -237,10 +237,7 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(const ScanArgs a0
                         if (log_cnt + rank < h.log_cap) vlog[log_cnt + rank] = id >> 5;
                     }
                     log_cnt += k;
-                    uint32_t ks = k;
-                    if constexpr (has_hop_prefilter<H>::value) {      // candidates the beam cannot take leave without their exact score (pq.hip pq_hop_prefilter: the same search)
-                        if (h.pq8_off) ks = H::prefilter(a, qp + h.pq8_off, hop_ids, k, beam.at(ef - 1), lane);
-                    }
+                    const uint32_t ks = k;
                     hop_score<H>(a, qp, hop_ids, hop_scores, ks, lane);
                     const uint64_t mykey = (uint32_t)lane < ks ? make_key(hop_scores[lane], hop_ids[lane]) : 0;
                     uint64_t mm = __ballot(mykey > beam.at(ef - 1));

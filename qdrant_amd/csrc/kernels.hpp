@@ -125,6 +125,8 @@ struct HnswArgs {
     uint32_t *expanded;             // [nq][xcap] or nullptr
     uint32_t *expanded_cnt;         // [nq] popped candidates (may exceed xcap: the list is then incomplete)
     uint32_t xcap;
+    uint64_t *ev_spill;             // search_with_vectors: [slots][ev_cap] keys - the evicted-unexpanded candidates of the latest score beyond the four in registers
+    uint32_t ev_cap;
     // the plain walk's pop sequence (qmx_hnsw_search_traced): every candidate the level-0 loop pops AND expands, in order, with its score
     qmx_scored_point *pops;         // [nq][pop_cap] or nullptr
     uint32_t *pop_cnt;              // [nq] (may exceed pop_cap: the list is then incomplete)
@@ -142,13 +144,9 @@ struct HnswArgs {
     uint2 *ref_cands;               // [slots][ref_cap]  (x = idx, y = score bits)
 };
 
-// The PQ walk with one BLOCK per search (hnsw_pq_block.hip): the LUT in LDS, a controller wave and speculating worker waves.  pq_block_walk_ok: whether this
-// launch can take it (plain walk, packed level 0, aligned code rows, ef in the register beam, LUT + scratch inside the LDS); grid == 0: report blocks per CU
-bool pq_block_walk_ok(const ScanArgs &a, const HnswArgs &h);
 // The PQ walk without LUTs (pq.hip HopPQDirect): the query entry is the preprocessed f32 vector, a LUT entry is recomputed from the codebook where it is needed
 bool pq_direct_walk_ok(uint32_t dim, uint32_t m, uint32_t chunk, uint32_t ncent);
 int32_t launch_hnsw_pq_direct(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
-int32_t launch_hnsw_pq_block(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu, int waves);
 // grid == 0: only report the occupancy (blocks of one wave per CU) of the instantiation in *per_cu
 int32_t launch_hnsw_dense(hipStream_t st, int dtype, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 // TurboQuant (scan_tq.hip)
@@ -205,15 +203,14 @@ int32_t launch_hnsw_pq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uin
 // the 8-bit images of a batch's LUTs for the walk's hop prefilter (HnswArgs::pq8); bytes per search: pq_walk_lut8_stride(m)
 static inline uint32_t pq_walk_lut8_stride(uint32_t m) { return 32u + m * 256u; }
 int32_t launch_pq_walk_lut8(hipStream_t st, const void *d_luts, uint32_t q_stride, uint32_t nq, uint32_t m, uint32_t ncent, void *d_out);
-// the entries of a table-free PQ build batch: [the preprocessed original vector: dim floats][its 8-bit LUT image: pq_walk_lut8_stride(m) bytes], out_stride apart
-int32_t launch_pq_build_entries(hipStream_t st, uint32_t distance, uint32_t dim, const qmx_pq_params &pq, const float *d_centroids, const float *d_vecs, uint32_t n,
-                                void *d_out, uint32_t out_stride);
 int32_t launch_hnsw_bq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_pack_level0(hipStream_t st, const uint64_t *offsets, const uint32_t *neighbors, uint32_t n_points, uint32_t stride, uint32_t *l0);
 constexpr uint32_t HNSW_VIS_LDS_BYTES = 16384;                 // the walk's visited table in LDS (hnsw.hpp LdsVisited): 1024 buckets x 8 tags of 16 bits
 constexpr uint32_t HNSW_VIS_LDS_MAX_POINTS = 65534u * 1024u;    // ... graphs whose (id >> 10) + 1 fits a tag below the "taken back" mark 0xFFFF
 constexpr uint32_t HNSW_REF_CAND_CAP = 1u << 16;   // option hnsw_reference_heap_order: entries of one search's `candidates` heap (512 KiB per slot)
-constexpr uint32_t HNSW_REF_SLOT_CAP = 1024;       // ... searches in flight in that mode
+constexpr uint32_t HNSW_EV_SPILL_CAP = 4096;      // search_with_vectors: evicted candidates of ONE score a slot can hold beyond four (32 KiB per slot; more raises err_flag = 2)
+constexpr uint32_t HNSW_REF_SLOT_CAP = 4096;       // ... searches in flight in that mode (1 024 until round 5: fewer than the default walk keeps in flight)
+constexpr uint32_t HNSW_REF_CAND_LDS = 1536;       // ... entries of that heap kept in LDS (12 KiB per search): the levels every sift touches
 constexpr uint32_t HNSW_MAX_EF = 4096;          // max(top, ef) of a walk: up to 512 in a register beam, beyond it in an LDS beam (hnsw.hpp Beam<0>)
 constexpr uint32_t HNSW_BUILD_MAX_M0 = 128;     // links per level-0 list of a device build (m <= m0 <= 128)
 constexpr uint32_t HNSW_MAX_EF_REG = 512;       // ... and of ef_construct (the build keeps its beam in registers)
@@ -256,7 +253,6 @@ struct HnswBuildArgs {
     const unsigned char *batch_queries;
     uint64_t batch_q_stride;
     uint32_t *next;              // [2] device counters the slots of phase 1 / phase 2 draw their next insertion from (each starts at its launch's grid size); nullptr: static stride
-    uint32_t pq8_off;            // table-free PQ build: byte offset, inside a staged batch entry, of the 8-bit LUT image the insertion searches prefilter with (0: none)
 };
 // phase 1 = insertion searches + heuristic selection, phase 2 = linking; grid == 0: report occupancy only
 int32_t launch_hnsw_build_bq(hipStream_t st, const ScanArgs &a, const HnswBuildArgs &h, int phase, uint32_t grid, int *per_cu);
@@ -340,9 +336,9 @@ int32_t launch_scan_f32_split(hipStream_t st, const ScanArgs &a, const void *d_b
 int32_t launch_regroup_lists(hipStream_t st, const DeletedView &del, const void *d_wlist, const uint32_t *d_wcnt, uint32_t wcap, uint32_t n_lists, uint64_t *d_cand,
                              uint32_t *d_cand_cnt, uint32_t cap, int *d_overflow);
 // PQ prefilter (pq_prefilter.hip): rotated copy of the code block, 6-bit tables + thresholds per query, the approximate scan
-size_t pq_rot_bytes(uint64_t n, uint32_t m, int w16);      // w16: the copy holds 16-bit codes (the prefilter's one-instruction gather addresses)
+size_t pq_rot_bytes(uint64_t n, uint32_t m);
 bool pq_prefilter_shape_ok(uint32_t m, uint32_t ncent);
-int32_t launch_pq_rotate(hipStream_t st, const void *codes, uint64_t row_stride, uint64_t n, uint32_t m, void *d_out, int w16);
+int32_t launch_pq_rotate(hipStream_t st, const void *codes, uint64_t row_stride, uint64_t n, uint32_t m, void *d_out);
 size_t pq_prefilter_table_bytes(uint32_t m, uint32_t nq);
 uint32_t pq_prefilter_grid(int num_cus, uint32_t nq, uint32_t *n_slabs_out);
 size_t pq_prefilter_wlists_counts_bytes(uint32_t grid);
@@ -350,7 +346,7 @@ size_t pq_prefilter_wlists_bytes(uint32_t grid, uint32_t wcap);
 int32_t launch_pq_lut8(hipStream_t st, const void *d_luts, uint32_t q_stride, uint32_t nq, uint32_t m, uint32_t ncent, const uint64_t *d_gthr, void *d_table8,
                        int32_t *d_thr, float *d_band);
 int32_t launch_pq_prefilter(hipStream_t st, const ScanArgs &a, const void *d_rot, const void *d_table8, const int32_t *d_thr, uint32_t nq, int num_cus,
-                            void *d_wlists, uint32_t wcap, uint32_t *grid_out, int w16);
+                            void *d_wlists, uint32_t wcap, uint32_t *grid_out);
 int32_t launch_split_refine(hipStream_t st, const uint64_t *d_cand, const uint32_t *d_cand_cnt, uint32_t cap, const float *d_band, uint32_t nq, uint32_t top,
                             const float *d_scales, float *d_thr);
 size_t split_wlists_bytes(int num_cus);

@@ -503,32 +503,6 @@ __global__ __launch_bounds__(256) void pq_walk_lut8_kernel(const unsigned char *
     const uint32_t q = blockIdx.x;
     pq_walk_lut8_body(reinterpret_cast<const float *>(luts + (uint64_t)q * q_stride), m, ncent, out + (uint64_t)q * out_stride, sh_lo, sh_hi, sh_ab, &sh_bad);
 }
-// The same image for the points of a build batch, made from the preprocessed ORIGINAL vector of each: out entry = [the vector, dim floats][the image].  The f32
-// LUT never leaves the LDS (m x ncent floats: 96 KiB at m = 96); its entries are pq_lut_kernel's (from -0.0, one multiply and one add per coordinate, in order),
-// so the image bounds the scores HopPQDirectBuild recomputes from the codebook in that same order.
-__global__ __launch_bounds__(256) void pq_build_entry_kernel(PqGeom g, const float *vecs, const float *centroids, unsigned char *out, uint32_t out_stride) {
-    extern __shared__ float pq_entry_lut[];
-    __shared__ float sh_lo[128], sh_hi[128], sh_ab[128], sub[256];
-    __shared__ int sh_bad;
-    const uint32_t q = blockIdx.x, j = threadIdx.x;
-    const float *v = vecs + (uint64_t)q * g.dim;
-    unsigned char *dst = out + (uint64_t)q * out_stride;
-    for (uint32_t i = j; i < g.dim; i += 256) reinterpret_cast<float *>(dst)[i] = v[i];
-    for (uint32_t c = 0; c < g.m; ++c) {
-        const uint32_t lo = c * g.chunk, hi = min(lo + g.chunk, g.dim);
-        __syncthreads();
-        if (j < hi - lo) sub[j] = v[lo + j];
-        __syncthreads();
-        if (j < g.ncent) {
-            const float *cen = centroids + (uint64_t)j * g.dim + lo;
-            float s = -0.0f;
-            for (uint32_t i = 0; i < hi - lo; ++i) s += pq_term(g.kind, sub[i], cen[i]);
-            pq_entry_lut[c * g.ncent + j] = g.invert ? -s : s;
-        }
-    }
-    __syncthreads();
-    pq_walk_lut8_body(pq_entry_lut, g.m, g.ncent, dst + (size_t)g.dim * 4, sh_lo, sh_hi, sh_ab, &sh_bad);
-}
 int32_t launch_pq_walk_lut8(hipStream_t st, const void *d_luts, uint32_t q_stride, uint32_t nq, uint32_t m, uint32_t ncent, void *d_out) {
     if (nq == 0) return QMX_OK;
     QMX_REQUIRE(m >= 1 && m <= 128 && ncent >= 1 && ncent <= 256, QMX_ERR_NOT_SUPPORTED, "pq walk prefilter: m %u, %u centroids", m, ncent);
@@ -560,11 +534,6 @@ struct HopPQDirect {
     static constexpr bool MULTI = false;
     static constexpr bool INTERNAL_QOFF = false;
     static constexpr bool INTERNAL_NORM = false;
-    // (the build's insertion searches: the batch entry carries the 8-bit LUT image of the new point's query behind its vector, HnswBuildArgs::pq8_off)
-    static constexpr bool HOP_PREFILTER = true;
-    static __device__ __forceinline__ uint32_t prefilter(const ScanArgs &a, const unsigned char *pq8, uint32_t *hop_ids, uint32_t k, uint64_t bound, int lane) {
-        return pq_hop_prefilter(a, pq8, hop_ids, k, bound, lane);
-    }
     static constexpr int V = CHUNK / 4;                      // 16-byte pieces of a chunk
     static constexpr int SPP = 32 / SPLIT;                   // steps per part at most (m <= 128)
     template <int KIND>
@@ -943,22 +912,6 @@ int32_t launch_pq_lut(hipStream_t st, uint32_t distance, uint32_t dim, const qmx
     return QMX_OK;
 }
 
-int32_t launch_pq_build_entries(hipStream_t st, uint32_t distance, uint32_t dim, const qmx_pq_params &pq, const float *d_centroids, const float *d_vecs, uint32_t n,
-                                void *d_out, uint32_t out_stride) {
-    if (n == 0) return QMX_OK;
-    const PqGeom g = make_geom(distance, dim, pq);
-    const size_t lds = (size_t)g.m * g.ncent * sizeof(float);
-    QMX_REQUIRE(g.m <= 128 && g.ncent <= 256 && g.chunk <= 256 && lds <= 140 * 1024, QMX_ERR_NOT_SUPPORTED, "pq build entries: m %u, %u centroids", g.m, g.ncent);
-    static thread_local DeviceOnce attr_once;
-    if (attr_once.need()) {
-        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pq_build_entry_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-        attr_once.mark();
-    }
-    ::qmx::clear_stale_error();
-    hipLaunchKernelGGL(pq_build_entry_kernel, dim3(n), dim3(256), lds, st, g, d_vecs, d_centroids, (unsigned char *)d_out, out_stride);
-    QMX_HIP(hipGetLastError());
-    return QMX_OK;
-}
 
 int32_t launch_pq_pair_table(hipStream_t st, uint32_t distance, uint32_t dim, const qmx_pq_params &pq, const float *d_centroids, float *d_pair) {
     const PqGeom g = make_geom(distance, dim, pq);

@@ -71,40 +71,19 @@ __global__ __launch_bounds__(256) void pq_rotate_kernel(const uint8_t *codes, ui
         out[gid] = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
-// the same copy with every code in 16 bits (round 4): a piece holds 8 codes, a row m_pad / 8 pieces.  The prefilter then makes a gather address with ONE
-// vector instruction (v_mad_u32_u16 picks the low or high half of a dword itself) instead of two - its inner loop was bound by exactly those instructions
-__global__ __launch_bounds__(256) void pq_rotate16_kernel(const uint8_t *codes, uint64_t row_stride, uint64_t n, uint32_t m, uint32_t m_pad, uint64_t n_pad,
-                                                          uint4 *out) {
-    const uint32_t np = m_pad / 8;
-    for (uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x; gid < n_pad * np; gid += (uint64_t)gridDim.x * 256) {
-        const uint64_t T = gid / (32ull * np);
-        const uint32_t rem = (uint32_t)(gid % (32ull * np)), p = rem / 32, i = rem % 32;
-        const uint64_t r = T * 32 + i;
-        uint32_t w[4] = {0, 0, 0, 0};
-        if (r < n) {
-            const uint8_t *row = codes + r * row_stride;
-#pragma unroll
-            for (uint32_t e = 0; e < 8; ++e) {
-                const uint32_t c = (8 * p + e + i) % m_pad;
-                const uint32_t v = c < m ? row[c] : 0u;
-                w[e / 2] |= v << (16 * (e % 2));
-            }
-        }
-        out[gid] = make_uint4(w[0], w[1], w[2], w[3]);
-    }
-}
-size_t pq_rot_bytes(uint64_t n, uint32_t m, int w16) {
+// (round 4 also kept this copy with every code in 16 bits - one vector instruction per gather address instead of two, twice the bytes: the same 0.96 ms at
+// 32 queries, twice the time at 4 - gone from the code since round 6, profiles/r4_pq_prefilter_w16.md)
+size_t pq_rot_bytes(uint64_t n, uint32_t m) {
     const uint32_t m_pad = (m + 31) / 32 * 32;
-    return (size_t)((n + 63) / 64 * 64) * m_pad * (w16 ? 2 : 1);
+    return (size_t)((n + 63) / 64 * 64) * m_pad;
 }
 bool pq_prefilter_shape_ok(uint32_t m, uint32_t ncent) { return m >= 1 && m <= 96 && ncent >= 1 && ncent <= 256; }
-int32_t launch_pq_rotate(hipStream_t st, const void *codes, uint64_t row_stride, uint64_t n, uint32_t m, void *d_out, int w16) {
+int32_t launch_pq_rotate(hipStream_t st, const void *codes, uint64_t row_stride, uint64_t n, uint32_t m, void *d_out) {
     if (n == 0) return QMX_OK;
     const uint32_t m_pad = (m + 31) / 32 * 32;
     const uint64_t n_pad = (n + 63) / 64 * 64;
     ::qmx::clear_stale_error();
-    if (w16) hipLaunchKernelGGL(pq_rotate16_kernel, dim3(4096), dim3(256), 0, st, (const uint8_t *)codes, row_stride, n, m, m_pad, n_pad, (uint4 *)d_out);
-    else hipLaunchKernelGGL(pq_rotate_kernel, dim3(4096), dim3(256), 0, st, (const uint8_t *)codes, row_stride, n, m, m_pad, n_pad, (uint4 *)d_out);
+    hipLaunchKernelGGL(pq_rotate_kernel, dim3(4096), dim3(256), 0, st, (const uint8_t *)codes, row_stride, n, m, m_pad, n_pad, (uint4 *)d_out);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }
@@ -224,11 +203,11 @@ __device__ __forceinline__ void pqf_block_role(uint32_t b, uint32_t n_groups, ui
     slab = (k / n_groups) * 8 + xcd;
 }
 
-template <int NP /* 16-byte pieces of a rotated row of 8-bit codes: m_pad = 16 NP */, bool W16 = false /* the copy holds 16-bit codes: 2 NP pieces per row */>
+template <int NP /* 16-byte pieces of a rotated row of 8-bit codes: m_pad = 16 NP */>
 __global__ __launch_bounds__(PQF_THREADS, 1) void pq_prefilter_kernel(const ScanArgs a, const PqfArgs f) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr uint32_t M_PAD = 16 * NP, SLOTS = pqf_slots(M_PAD), SH = SLOTS == 64 ? 8 : 9;      // a code row = SLOTS dwords = 1 << SH bytes
-    constexpr int NPW = W16 ? 2 * NP : NP;                                                         // pieces of a row in the copy
+    constexpr int NPW = NP;                                                                        // pieces of a row in the copy
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t slab, group;
@@ -264,22 +243,7 @@ __global__ __launch_bounds__(PQF_THREADS, 1) void pq_prefilter_kernel(const Scan
 #pragma unroll
         for (int t4 = 0; t4 < (int)M_PAD / 4; ++t4) {
             pqf_i32x4 g;
-            if constexpr (W16) {
-                // codes 4 t4 .. 4 t4 + 3 = the two dwords 2 t4, 2 t4 + 1 of the row: address = half-word x row pitch + the lane's slot offset, one instruction
-                const uint4 &piece = w[t4 / 2];
-                const uint32_t d0 = t4 % 2 == 0 ? piece.x : piece.z, d1 = t4 % 2 == 0 ? piece.y : piece.w;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    uint32_t addr;
-                    const uint32_t dd = e < 2 ? d0 : d1;
-                    if (e % 2 == 0) asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[0,0,0,0]" : "=v"(addr) : "v"(dd), "v"(pitch), "v"(i4));
-                    else asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(addr) : "v"(dd), "v"(pitch), "v"(i4));
-                    g[e] = *reinterpret_cast<pqf_lds_int *>(addr + 4 * (4 * t4 + e));
-                }
-                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(g, B, acc, 0, 0, 0);
-                continue;
-            }
-            const uint4 &piece = w[W16 ? 0 : t4 / 4];
+            const uint4 &piece = w[t4 / 4];
             const uint32_t d = t4 % 4 == 0 ? piece.x : t4 % 4 == 1 ? piece.y : t4 % 4 == 2 ? piece.z : piece.w;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -344,7 +308,7 @@ int32_t launch_pq_lut8(hipStream_t st, const void *d_luts, uint32_t q_stride, ui
 }
 
 int32_t launch_pq_prefilter(hipStream_t st, const ScanArgs &a, const void *d_rot, const void *d_table8, const int32_t *d_thr, uint32_t nq, int num_cus,
-                            void *d_wlists, uint32_t wcap, uint32_t *grid_out, int w16) {
+                            void *d_wlists, uint32_t wcap, uint32_t *grid_out) {
     const uint32_t m = a.pq_m, m_pad = (m + 31) / 32 * 32;
     PqfArgs f;
     f.rot = (const uint4 *)d_rot;
@@ -360,25 +324,15 @@ int32_t launch_pq_prefilter(hipStream_t st, const ScanArgs &a, const void *d_rot
     auto k2 = pq_prefilter_kernel<2>;
     auto k4 = pq_prefilter_kernel<4>;
     auto k6 = pq_prefilter_kernel<6>;
-    auto k2w = pq_prefilter_kernel<2, true>;
-    auto k4w = pq_prefilter_kernel<4, true>;
-    auto k6w = pq_prefilter_kernel<6, true>;
     static thread_local DeviceOnce attr_once;
     if (attr_once.need()) {
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k6), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2w), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k4w), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k6w), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_once.mark();
     }
     ::qmx::clear_stale_error();
-    if (w16) {
-        auto kw = m_pad == 32 ? k2w : m_pad == 64 ? k4w : k6w;
-        QMX_NOTE_KERNEL(kw);
-        hipLaunchKernelGGL(kw, dim3(grid), dim3(PQF_THREADS), lds, st, a, f);
-    } else if (m_pad == 32) {
+    if (m_pad == 32) {
         QMX_NOTE_KERNEL(k2);
         hipLaunchKernelGGL(k2, dim3(grid), dim3(PQF_THREADS), lds, st, a, f);
     } else if (m_pad == 64) {

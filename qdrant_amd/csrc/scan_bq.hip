@@ -248,10 +248,10 @@ int32_t launch_scan_bq(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a,
     // scalar-encoded queries: one lane per row (the 8-lanes-per-row layout re-reads B query pieces from LDS per row piece: 10 M x 768
     // bits, 8 planes: 0.38 / 1.44 / 5.25 ms for 1 / 4 / 16 queries there, 0.28 / 0.73 / 2.64 ms here = 2/3 of the VALU rate of
     // xor + bcnt per plane dword); a single query over rows of more than one line stays on the 8-lane layout (1536 bits: 0.63 vs 0.76 ms)
-    const bool rows_kernel = !option(OPT_BQ_LANES8) && !(qt == 1 && a.dim > 128);
+    const bool rows_kernel = !(qt == 1 && a.dim > 128);
     if (a.bq_qbits == 4 && rows_kernel) return launch_bq_rows_planes<4>(st, qt, mode, a, num_cus, grid_out);
     if (a.bq_qbits == 8 && rows_kernel) return launch_bq_rows_planes<8>(st, qt, mode, a, num_cus, grid_out);
-    if (qt <= 2 || a.bq_qbits > 1 || option(OPT_BQ_LANES8)) return dispatch_bq(ScanLauncher{st, qt, mode, num_cus, grid_out}, a);
+    if (qt <= 2 || a.bq_qbits > 1) return dispatch_bq(ScanLauncher{st, qt, mode, num_cus, grid_out}, a);
     switch (qt) {
         case 4: return launch_bq_rows_qt<4>(st, mode, a, num_cus, grid_out);
         case 8: return launch_bq_rows_qt<8>(st, mode, a, num_cus, grid_out);

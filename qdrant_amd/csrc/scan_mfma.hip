@@ -405,14 +405,11 @@ static int32_t launch_mfma_qt(hipStream_t st, ScanMode mode, const ScanArgs &a, 
 int32_t launch_scan_f32_mfma(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
     switch (qt) {
         // measured on MI355X, C2 (10 M x 768): nontemporal row loads and 12 steps in flight per lane are worth ~3 %
-        case 8: {
-            const bool nt = !option(OPT_MFMA_NO_NT);
-            return nt ? launch_mfma_qt<8, 1, 4, true>(st, mode, a, num_cus, grid_out) : launch_mfma_qt<8, 1, 4, false>(st, mode, a, num_cus, grid_out);
-        }
+        case 8: return launch_mfma_qt<8, 1, 4, true>(st, mode, a, num_cus, grid_out);
         case 16:
             if (mfma16_scan_ok(16, mode, a)) return launch_scan_f32_mfma16(st, 16, a, num_cus, grid_out);
             // rows of a multiple of 384 floats (768, 1536, ...): guard-free ping-pong main loop
-            if (a.nseg % 12 == 0 && !option(OPT_MFMA_NO_FAST)) return launch_mfma_qt<16, 1, 6, true, 8, true>(st, mode, a, num_cus, grid_out);
+            if (a.nseg % 12 == 0) return launch_mfma_qt<16, 1, 6, true, 8, true>(st, mode, a, num_cus, grid_out);
             return launch_mfma_qt<16, 1, 12, true>(st, mode, a, num_cus, grid_out);
         case 32: {
             if (mfma16_scan_ok(32, mode, a)) return launch_scan_f32_mfma16(st, 32, a, num_cus, grid_out);
@@ -422,7 +419,7 @@ int32_t launch_scan_f32_mfma(hipStream_t st, int qt, ScanMode mode, const ScanAr
             if (variant == 2 && a.nseg % 12 == 0) return launch_mfma_qt<32, 1, 6, true, 8, true, true>(st, mode, a, num_cus, grid_out);   // + ping-pong
             if (variant == 3 && a.nseg % 24 == 0) return launch_mfma_qt<32, 1, 12, true, 8, true, true>(st, mode, a, num_cus, grid_out);
 #endif
-            if (a.nseg % 12 == 0 && !option(OPT_MFMA_NO_FAST)) return launch_mfma_qt<16, 2, 6, true, 8, true>(st, mode, a, num_cus, grid_out);
+            if (a.nseg % 12 == 0) return launch_mfma_qt<16, 2, 6, true, 8, true>(st, mode, a, num_cus, grid_out);
             return launch_mfma_qt<16, 2, 12, true>(st, mode, a, num_cus, grid_out);
         }
     }

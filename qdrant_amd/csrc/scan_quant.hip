@@ -111,7 +111,6 @@ int32_t launch_pairs_sq(hipStream_t st, int distance, const ScanArgs &a, const P
     return dispatch_sq(PairLauncher{st, sel, n_items, num_cus}, distance, a);
 }
 int32_t launch_hnsw_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
-    if (option(OPT_HNSW_ROW_U4) == 3 && !h.ref_heaps) return dispatch_sq(HnswLauncherU3{st, &h, grid, per_cu}, distance, a);
     return dispatch_sq(HnswLauncher{st, &h, grid, per_cu}, distance, a);
 }
 int32_t launch_hnsw_custom_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {

@@ -924,12 +924,17 @@ __device__ __forceinline__ void block_kth_key(const uint64_t *c, uint32_t raw, i
 // The same for lists of up to 8 keys per thread (the usual ~1 000 candidates of a query) without serial insertions, as custom_topk_small_kernel does it:
 // the k-th largest of a wave's 64 lane maxima bounds the k-th best key from below, the largest such bound over the waves prunes the list to a few
 // times k survivors in LDS, and the survivor with k - 1 larger ones is the answer (keys are distinct: they carry the row id).
-constexpr int SEL_E = 8;
+constexpr int SEL_E = 3;       // (8 until round 5: 32 KiB of scratch; 3: 12 KiB - a selection block fits the 16 KiB the int8 scan leaves free on a CU)
 constexpr int SEL_SURV = SEL_BLOCK * SEL_E;
 struct SelScratch {
     uint64_t surv[SEL_SURV];
     uint64_t t[SEL_BLOCK / WAVE];
     uint32_t cnt;
+};
+// the serial-insertion path (block_kth_key) and the ranked one (block_kth_key_ranked) never run in the same block: one LDS area for both
+union SelShared {
+    uint64_t sh[SEL_BLOCK / WAVE][WAVE];
+    SelScratch scratch;
 };
 __device__ __forceinline__ void block_kth_key_ranked(const uint64_t *c, uint32_t raw, uint32_t ptop, SelScratch *sc, uint64_t *sh_out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -969,9 +974,10 @@ __device__ __forceinline__ void block_kth_key_ranked(const uint64_t *c, uint32_t
 // so a result row has an approximate score >= A - 2 band: the threshold of the other fifteen sixteenths (never lowered).
 __global__ __launch_bounds__(SEL_BLOCK) void sp_refine_kernel(const uint64_t *cand, const uint32_t *cand_cnt, uint32_t cap, const float *band, uint32_t top,
                                                               const float *scales, float *thr) {
-    __shared__ uint64_t sh[SEL_BLOCK / WAVE][WAVE];
+    __shared__ SelShared sel_sh;
+    uint64_t (*const sh)[WAVE] = sel_sh.sh;
+    SelScratch &scratch = sel_sh.scratch;
     __shared__ uint64_t sh_kth;
-    __shared__ SelScratch scratch;
     const uint32_t q = blockIdx.x;
     const uint32_t raw = cand_cnt[q];
     if (raw > cap || raw < top || !(band[q] < 3.0e38f)) return;   // overflow is sp_select_kernel's to report; fewer than k rows prove nothing
@@ -986,11 +992,12 @@ __global__ __launch_bounds__(SEL_BLOCK) void sp_refine_kernel(const uint64_t *ca
 __global__ __launch_bounds__(SEL_BLOCK) void sp_select_kernel(const uint64_t *cand, const uint32_t *cand_cnt, uint32_t cap, const float *band, uint32_t top,
                                                               const VerifyPool pool, uint32_t q_base, const int *tile_overflow, uint32_t *ovf_q,
                                                               SplitStats *stats, const float *t_exact /* or nullptr: an exact lower bound of the k-th best score per query */) {
-    __shared__ uint64_t sh[SEL_BLOCK / WAVE][WAVE];
+    __shared__ SelShared sel_sh;
+    uint64_t (*const sh)[WAVE] = sel_sh.sh;
+    SelScratch &scratch = sel_sh.scratch;
     __shared__ uint64_t sh_kth;
     __shared__ float sh_cut;
     __shared__ uint32_t sh_n, sh_off;
-    __shared__ SelScratch scratch;
     const uint32_t q = blockIdx.x;
     const uint32_t raw = cand_cnt[q];
     // a wave list of the scan overflowed (its dropped entries could be anybody's), or this query's candidate buffer did: the pass cannot be
@@ -1309,6 +1316,11 @@ __global__ __launch_bounds__(256) void sp_i8_pack_kernel(const float *q, uint32_
 // The scan: scan_f16pair_kernel<true> with the int8 instruction.  A stage is 256 rows x 128 coordinates (two planes of 64) = 32 KiB of rows + 16 KiB of
 // queries, 32 matrix instructions per wave as there; nch = dim / 128 stages per tile.  s.scales = the queries' scales (score units per accumulator
 // unit), s.thr in accumulator units.
+// BRING = query stages in LDS.  4 (rounds 3 - 5): queries requested three stages ahead, 96 + 64 = 160 KiB, the whole LDS of the CU - nothing else that
+// needs LDS can start on a CU while a block of this scan lives there.  3: two stages ahead (the 96 KiB of query images stay in L2: 2.9 us ahead is plenty),
+// 96 + 48 = 144 KiB, which leaves 16 KiB per CU to the other batch's small kernels (regroup, probe, gather, sort, pack ...): they run BESIDE the scan
+// instead of queueing behind it.
+template <int BRING>
 __global__ __launch_bounds__(SP3_THREADS, 1) void scan_i8copy_kernel(const ScanArgs a, const SplitArgs s) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint4 *lds = reinterpret_cast<uint4 *>(smem_raw);
@@ -1359,7 +1371,7 @@ __global__ __launch_bounds__(SP3_THREADS, 1) void scan_i8copy_kernel(const ScanA
     auto queries_begin = [&]() {
         rb_src = uniform_ptr((uint64_t)(uintptr_t)(s.bq + (uint64_t)rb_kc * SP_B_UNITS) + (uint32_t)w * 2048u);
         rb_dst = lds0 + (SP3_ARING * SP3_A_UNITS + rb_slot * SP_B_UNITS) * 16u + (uint32_t)w * 2048u;
-        rb_slot = (rb_slot + 1) & (SP3_BRING - 1);
+        rb_slot = rb_slot + 1 == BRING ? 0 : rb_slot + 1;
         rb_kc = rb_kc + 1 == nch ? 0 : rb_kc + 1;
     };
     auto queries_piece = [&](int i) { sp_glds16(rb_src + i * 1024, lane_off, rb_dst + i * 1024); };
@@ -1373,12 +1385,19 @@ __global__ __launch_bounds__(SP3_THREADS, 1) void scan_i8copy_kernel(const ScanA
         queries_piece(0);
         queries_piece(1);
     };
-    request_queries();                                    // queries of stage 0
-    request_queries();                                    // ... 1
-    request_rows();                                       // rows of stage 0
-    request_queries();                                    // queries of stage 2
-    request_rows();                                       // rows of stage 1
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // queries 0, 1 and rows 0 have landed
+    if constexpr (BRING >= 4) {
+        request_queries();                                // queries of stage 0
+        request_queries();                                // ... 1
+        request_rows();                                   // rows of stage 0
+        request_queries();                                // queries of stage 2
+        request_rows();                                   // rows of stage 1
+    } else {                                              // (stage g requests [queries of g + 2, rows of g + 2])
+        request_queries();                                // queries of stage 0
+        request_rows();                                   // rows of stage 0
+        request_queries();                                // queries of stage 1
+        request_rows();                                   // rows of stage 1
+    }
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // queries and rows of stage 0 have landed (BRING 4: the queries of stage 1 too)
     sp_stage_barrier();
     uint32_t slot = 0, bslot = 0;
     i32x4s acc[4][4];
@@ -1439,7 +1458,7 @@ __global__ __launch_bounds__(SP3_THREADS, 1) void scan_i8copy_kernel(const ScanA
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (i32x4s){0, 0, 0, 0};
         for (uint32_t kc = 0; kc < nch; ++kc) {
-            queries_begin();                              // stage g + 3 -> the slot stage g - 1 was read from (everybody is past that barrier)
+            queries_begin();                              // stage g + BRING - 1 -> the slot stage g - 1 was read from (everybody is past that barrier)
             rows_begin();                                 // stage g + 2 -> likewise
             const uint4 *ab = lds + slot * SP3_A_UNITS + a_rd;
             const uint4 *bb = b_lds + bslot * SP_B_UNITS + b_rd;
@@ -1465,8 +1484,8 @@ __global__ __launch_bounds__(SP3_THREADS, 1) void scan_i8copy_kernel(const ScanA
                 for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0[nt], acc[mt][nt], 0, 0, 0);
             }
             slot = slot + 1 == SP3_ARING ? 0 : slot + 1;
-            bslot = (bslot + 1) & (SP3_BRING - 1);
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // rows of stage g + 1 and queries of stage g + 2 have landed
+            bslot = bslot + 1 == BRING ? 0 : bslot + 1;
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // all but this stage's six requests have landed: rows and queries of stage g + 1 among them
             sp_stage_barrier();
         }
     }
@@ -1475,343 +1494,20 @@ __global__ __launch_bounds__(SP3_THREADS, 1) void scan_i8copy_kernel(const ScanA
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // nothing may land in LDS after the block is gone
 }
 
-// The same scan with a DEEPER copy pipeline (round 4) - an experiment that answered its question with "no"; opt-in (`i8_scan_deep`), exact, tested.
-// The kernel above tops out at 0.76 of HBM whatever the number of queries (one query: 0.765).  Hypothesis: with three 32 KiB row stages in LDS - one being
-// multiplied, one landed, one on its way - a CU has 32 - 64 KiB of rows in flight, 256 CUs x 48 KiB is what the memory system returns in ~2 us at 6 TB/s,
-// so the stream is bound by its own depth.  LDS is full (96 + 64 KiB), so more depth has to come from granularity: HALF stages - one 64-coordinate plane,
-// 16 KiB of rows, 8 KiB of queries, 16 matrix instructions per wave - in rings of 7 and 6 slots (112 + 48 KiB).  The vector-memory counter retires in
-// order, so what must have landed at the end of half stage g (queries and rows of g + 1) bounds what may still be in flight to what was issued after it:
-// with the issue order r0 | q0 r1 | q1 r2 | ... and half stage g issuing [queries g + 5, rows g + 6], `vmcnt(14)` leaves rows g + 2 .. g + 6
-// outstanding: 80 KiB per CU.  Same operands, same integer sums, same epilogue, same blocks of the copy in HBM (a plane = sixteen alternate 1 KiB runs).
-// Measured (C2, 128 queries, one batch in flight): 0.749 ms per launch against 0.654 - 14 % SLOWER with 2.5 x the bytes in flight: depth was not the limit;
-// what the change doubled is the number of block-wide barriers (12 per tile instead of 6), and that is what it paid for - the stage hand-over (every
-// wave's `vmcnt` wait, the barrier, eight waves' operand reads at once) is the cost to attack next, not the ring (profiles/r4_i8_deep_ring.md).
-constexpr int SP5_ARING = 7;                                                       // half-stage slots of rows (16 KiB) ...
-constexpr int SP5_BRING = 6;                                                       // ... and of queries (8 KiB)
-constexpr int SP5_A_UNITS = SP3_A_UNITS / 2, SP5_B_UNITS = SP_B_UNITS / 2;
-constexpr int SP5_LDS = (SP5_ARING * SP5_A_UNITS + SP5_BRING * SP5_B_UNITS) * 16;  // 112 + 48 = 160 KiB
-static_assert(SP5_LDS <= 160 * 1024, "the CU's LDS");
-__global__ __launch_bounds__(SP3_THREADS, 1) void scan_i8copy_deep_kernel(const ScanArgs a, const SplitArgs s) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    uint4 *lds = reinterpret_cast<uint4 *>(smem_raw);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint64_t all_tiles = (a.n_cand + SP3_BM - 1) / SP3_BM;
-    const uint64_t n_tiles = split_phase_tiles(all_tiles, s.phase);
-    const uint32_t nch = s.nchunks;
-    const uint64_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-    const uint32_t phase = s.phase & 0xFFu, pstride = split_phase_stride(s.phase);
-    auto tile_of = [&](uint64_t j) -> uint64_t { return phase == 0 ? j : phase == 1 ? j * pstride : j + j / (pstride - 1) + 1; };
-    if (my_tiles == 0) {
-        if (lane == 0) s.wcnt[blockIdx.x * (SP3_THREADS / 64) + (uint32_t)w] = 0;
-        return;
-    }
-    const uint32_t wm = (uint32_t)w & 3u, wn = (uint32_t)w >> 2;
-    const uint32_t kq_r = (uint32_t)lane >> 4, m_r = (uint32_t)lane & 15u;
-    // unit of (16-row / 16-query tile t, k-group kq, row m) inside a half-stage slot: sp_unit without the plane
-    const uint32_t a_rd = (wm * 4 * 4 + kq_r) * 16 + (m_r ^ (2 * kq_r)), b_rd = (wn * 4 * 4 + kq_r) * 16 + (m_r ^ (2 * kq_r));
-    float thr[4], qs[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        thr[nt] = s.thr[wn * 64 + nt * 16 + m_r];
-        qs[nt] = s.scales[wn * 64 + nt * 16 + m_r];
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // from here on the kernel counts its vector-memory traffic itself
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(sp_lds_byte *)smem_raw;
-    const uint32_t lane_off = (uint32_t)lane * 16u;
-    uint4 *b_lds = lds + SP5_ARING * SP5_A_UNITS;
-    // the copy streams: positions (tile iteration, chunk, plane) of the next half stage to request, its slot; three 1 KiB copies per wave and half stage
-    uint64_t ra_it = 0;
-    uint32_t ra_kc = 0, ra_hl = 0, ra_slot = 0, rb_kc = 0, rb_hl = 0, rb_slot = 0;
-    auto uniform_ptr = [&](uint64_t v) {
-        return reinterpret_cast<const unsigned char *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
-                                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v));
-    };
-    const unsigned char *ra_src = nullptr, *rb_src = nullptr;
-    uint32_t ra_dst = 0, rb_dst = 0;
-    // wave w copies the plane's runs of row groups 2 w and 2 w + 1 (a 32 KiB block = [16 row groups][2 planes][1 KiB]) to runs 2 w, 2 w + 1 of the slot ...
-    auto rows_begin = [&]() {
-        const uint64_t tile = tile_of(blockIdx.x + ra_it * gridDim.x);
-        ra_src = uniform_ptr((uint64_t)(uintptr_t)(s.rows_split + (tile * nch + ra_kc) * SP3_A_UNITS) + (uint32_t)w * 4096u + ra_hl * 1024u);
-        ra_dst = lds0 + (ra_slot * SP5_A_UNITS) * 16u + (uint32_t)w * 2048u;
-        ra_slot = ra_slot + 1 == SP5_ARING ? 0 : ra_slot + 1;
-        if (ra_hl == 0) ra_hl = 1;      // (past the block's last half stage: the last one again - valid addresses, a slot nobody reads any more)
-        else if (ra_kc + 1 < nch) { ra_hl = 0; ++ra_kc; }
-        else if (ra_it + 1 < my_tiles) { ra_hl = 0; ra_kc = 0; ++ra_it; }
-    };
-    auto rows_piece = [&](int i) { sp_glds16(ra_src + i * 2048, lane_off, ra_dst + i * 1024); };
-    // ... and the plane's run of query group w (a 16 KiB chunk = [8 query groups][2 planes][1 KiB]) to run w
-    auto queries_begin = [&]() {
-        rb_src = uniform_ptr((uint64_t)(uintptr_t)(s.bq + (uint64_t)rb_kc * SP_B_UNITS) + (uint32_t)w * 2048u + rb_hl * 1024u);
-        rb_dst = lds0 + (SP5_ARING * SP5_A_UNITS + rb_slot * SP5_B_UNITS) * 16u + (uint32_t)w * 1024u;
-        rb_slot = rb_slot + 1 == SP5_BRING ? 0 : rb_slot + 1;
-        if (rb_hl == 0) rb_hl = 1;
-        else { rb_hl = 0; rb_kc = rb_kc + 1 == nch ? 0 : rb_kc + 1; }
-    };
-    auto queries_piece = [&]() { sp_glds16(rb_src, lane_off, rb_dst); };
-    auto request_rows = [&]() {
-        rows_begin();
-        rows_piece(0);
-        rows_piece(1);
-    };
-    auto request_queries = [&]() {
-        queries_begin();
-        queries_piece();
-    };
-    request_rows();                                       // r0 | q0 r1 | q1 r2 | q2 r3 | q3 r4 | q4 r5
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        request_queries();
-        request_rows();
-    }
-    asm volatile("s_waitcnt vmcnt(14)" ::: "memory");     // everything up to q0 has landed: rows and queries of half stage 0
-    sp_stage_barrier();
-    uint32_t slot = 0, bslot = 0;
-    i32x4s acc[4][4];
-    uint4 *const wl = s.wlist + (uint64_t)(blockIdx.x * (SP3_THREADS / 64) + (uint32_t)w) * s.wcap;
-    uint32_t wcount = 0;
-    // The epilogue of a tile.  With a band of 0.7 standard deviations a wave meets ~2 candidates per tile (the f16 passes: 0.4), so nearly every tile
-    // has one somewhere: the search for them narrows by wave-uniform steps - the query tile (16 queries x the wave's 64 rows), then the 16-row tile, then
-    // the four rows of a lane - instead of testing all 256 accumulators of a lane one ballot at a time (14 % of the kernel at 128 queries, measured
-    // against the same launch with one live query).
-    auto epilogue = [&](uint64_t tile) {
-        const uint32_t row0 = (uint32_t)(tile * SP3_BM) + wm * 64 + 4 * kq_r;
-        const uint32_t n_rows32 = (uint32_t)a.n_cand;
-        bool hit[4];
-        bool maybe = false;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            int mx = acc[0][nt][0];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) mx = acc[mt][nt][j] > mx ? acc[mt][nt][j] : mx;
-            hit[nt] = !((float)mx < thr[nt]);
-            maybe = maybe || hit[nt];
-        }
-        if (!__ballot(maybe)) return;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            if (!__ballot(hit[nt])) continue;
-            const uint32_t q = wn * 64 + (uint32_t)nt * 16 + m_r;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                int m4 = acc[mt][nt][0];
-#pragma unroll
-                for (int j = 1; j < 4; ++j) m4 = acc[mt][nt][j] > m4 ? acc[mt][nt][j] : m4;
-                if (!__ballot(!((float)m4 < thr[nt]))) continue;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v = (float)acc[mt][nt][j];
-                    const uint32_t row = row0 + (uint32_t)mt * 16 + (uint32_t)j;
-                    const bool c = !(v < thr[nt]) && row < n_rows32 && q < s.nq;
-                    const uint64_t hits = __ballot(c);
-                    if (hits) {
-                        const uint32_t at = wcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u));
-                        if (c && at < s.wcap) {
-                            const uint64_t key = make_key(v * qs[nt], row);
-                            wl[at] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), q, 0u);
-                        }
-                        wcount += (uint32_t)__builtin_popcountll(hits);
-                    }
-                }
-            }
-        }
-    };
-    for (uint64_t it = 0; it < my_tiles; ++it) {
-        if (it) epilogue(tile_of(blockIdx.x + (it - 1) * gridDim.x));
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (i32x4s){0, 0, 0, 0};
-        for (uint32_t hs = 0; hs < 2 * nch; ++hs) {
-            queries_begin();                              // half stage g + 5 -> the slot half stage g - 1 was read from (everybody is past that barrier)
-            rows_begin();                                 // half stage g + 6 -> likewise
-            const uint4 *ab = lds + slot * SP5_A_UNITS + a_rd;
-            const uint4 *bb = b_lds + bslot * SP5_B_UNITS + b_rd;
-            i32x4s b0[4];
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) b0[nt] = *reinterpret_cast<const i32x4s *>(bb + nt * 64);
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const i32x4s a0 = *reinterpret_cast<const i32x4s *>(ab + mt * 64);
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0[nt], acc[mt][nt], 0, 0, 0);
-                // the half stage's three copy requests, in the order the wait below relies on (queries first), spread over the matrix work
-                if (mt == 0) queries_piece();
-                if (mt == 1) rows_piece(0);
-                if (mt == 2) rows_piece(1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            slot = slot + 1 == SP5_ARING ? 0 : slot + 1;
-            bslot = bslot + 1 == SP5_BRING ? 0 : bslot + 1;
-            asm volatile("s_waitcnt vmcnt(14)" ::: "memory");    // rows and queries of half stage g + 1 have landed; rows g + 2 .. g + 6 may still be on their way
-            sp_stage_barrier();
-        }
-    }
-    epilogue(tile_of(blockIdx.x + (my_tiles - 1) * gridDim.x));
-    if (lane == 0) s.wcnt[blockIdx.x * (SP3_THREADS / 64) + (uint32_t)w] = wcount;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // nothing may land in LDS after the block is gone
-}
-
-// The same scan with NO stage hand-over (round 4, after scan_i8copy_deep_kernel's answer): every wave owns 32 rows of the 256-row tile - the 4 KiB it has always
-// copied per 32 KiB block - and multiplies them with all 128 queries itself (2 x 8 tiles of 16 x 16 instead of 4 x 4: the same 64 accumulator registers,
-// the same 32 matrix instructions per 128 coordinates), so nobody waits for anybody: the queries' images are copied into LDS ONCE per block (nch x 16 KiB:
-// 96 KiB at d = 768, the reason this shape stops there), each wave streams its rows through a private ring of four 2 KiB slots (32 rows x 64 coordinates: one
-// being multiplied, three on their way) behind its own `vmcnt`, and the only barrier of the kernel follows the queries' copy.  Same copy of the block in HBM,
-// same integer sums, same candidates (per-wave lists as before: a wave's rows are now 32 consecutive ones).  Operand reads from LDS: 2 + 8 per half chunk
-// instead of 4 + 4 per wave (the queries' side is shared by all eight waves now): 5 x the streamed bytes instead of 4 x.
-// Measured (C2, 128 queries): 0.683 ms per launch against 0.647 - 5 % SLOWER (opt-in, `i8_scan_deep` = 2; a third shape, the rows loaded straight into the operand
-// registers with 80 KiB per CU in flight and no LDS for them at all, reached 0.678): neither the barriers nor the ring depth are what holds this scan at 0.75.
-constexpr int SP6_SLOTS = 4;                                                       // half-chunk slots of a wave's rows
-constexpr int SP6_WAVE_BYTES = SP6_SLOTS * 2048;
-__host__ __device__ static inline size_t sp6_lds_bytes(uint32_t nch) { return (size_t)nch * SP_B_UNITS * 16 + (size_t)(SP3_THREADS / 64) * SP6_WAVE_BYTES; }
-__global__ __launch_bounds__(SP3_THREADS, 1) void scan_i8copy_kernel_wo(const ScanArgs a, const SplitArgs s) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    uint4 *lds = reinterpret_cast<uint4 *>(smem_raw);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint64_t all_tiles = (a.n_cand + SP3_BM - 1) / SP3_BM;
-    const uint64_t n_tiles = split_phase_tiles(all_tiles, s.phase);
-    const uint32_t nch = s.nchunks;
-    const uint64_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-    const uint32_t phase = s.phase & 0xFFu, pstride = split_phase_stride(s.phase);
-    auto tile_of = [&](uint64_t j) -> uint64_t { return phase == 0 ? j : phase == 1 ? j * pstride : j + j / (pstride - 1) + 1; };
-    if (my_tiles == 0) {
-        if (lane == 0) s.wcnt[blockIdx.x * (SP3_THREADS / 64) + (uint32_t)w] = 0;
-        return;
-    }
-    const uint32_t kq_r = (uint32_t)lane >> 4, m_r = (uint32_t)lane & 15u;
-    const uint32_t b_rd = sp_unit(0, 0, kq_r, m_r);                               // + 128 units per query tile, + 64 for the second plane, + SP_B_UNITS per chunk
-    const uint32_t a_rd = kq_r * 16 + (m_r ^ (2 * kq_r));                        // inside a 1 KiB run of a slot (+ 64 units for the wave's second row group)
-    float thr[8], qs[8];
-#pragma unroll
-    for (int nt = 0; nt < 8; ++nt) {
-        thr[nt] = s.thr[nt * 16 + m_r];
-        qs[nt] = s.scales[nt * 16 + m_r];
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // from here on the kernel counts its vector-memory traffic itself
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(sp_lds_byte *)smem_raw;
-    const uint32_t lane_off = (uint32_t)lane * 16u;
-    auto uniform_ptr = [&](uint64_t v) {
-        return reinterpret_cast<const unsigned char *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
-                                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v));
-    };
-    // the queries, once: nch x 16 KiB = 16 nch copies of 1 KiB, wave w takes every eighth
-    {
-        const unsigned char *src = uniform_ptr((uint64_t)(uintptr_t)s.bq);
-        for (uint32_t p = (uint32_t)w; p < 16u * nch; p += SP3_THREADS / 64) sp_glds16(src + (size_t)p * 1024, lane_off, lds0 + p * 1024u);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        sp_stage_barrier();
-    }
-    const uint4 *const b_lds = lds;
-    const uint32_t ring0 = lds0 + nch * (uint32_t)(SP_B_UNITS * 16) + (uint32_t)w * (uint32_t)SP6_WAVE_BYTES;
-    const uint4 *const ring = lds + (size_t)nch * SP_B_UNITS + (size_t)w * (SP6_WAVE_BYTES / 16);
-    // the wave's row stream: half chunk (tile iteration, chunk, plane) -> the plane's 1 KiB runs of its two row groups (2 w, 2 w + 1 of the block's sixteen)
-    uint64_t r_it = 0;
-    uint32_t r_kc = 0, r_hl = 0, r_slot = 0;
-    auto request = [&]() {
-        const uint64_t tile = tile_of(blockIdx.x + r_it * gridDim.x);
-        const unsigned char *src = uniform_ptr((uint64_t)(uintptr_t)(s.rows_split + (tile * nch + r_kc) * SP3_A_UNITS) + (uint32_t)w * 4096u + r_hl * 1024u);
-        const uint32_t dst = ring0 + r_slot * 2048u;
-        sp_glds16(src, lane_off, dst);
-        sp_glds16(src + 2048, lane_off, dst + 1024u);
-        r_slot = (r_slot + 1) & (SP6_SLOTS - 1);
-        if (r_hl == 0) r_hl = 1;      // (past the wave's last half chunk: the last one again - valid addresses, a slot it never reads)
-        else if (r_kc + 1 < nch) { r_hl = 0; ++r_kc; }
-        else if (r_it + 1 < my_tiles) { r_hl = 0; r_kc = 0; ++r_it; }
-    };
-    request();
-    request();
-    request();
-    uint32_t slot = 0;
-    i32x4s acc[2][8];
-    uint4 *const wl = s.wlist + (uint64_t)(blockIdx.x * (SP3_THREADS / 64) + (uint32_t)w) * s.wcap;
-    uint32_t wcount = 0;
-    // the epilogue of a tile (scan_i8copy_kernel's narrowing search over the wave's 32 rows x 128 queries)
-    auto epilogue = [&](uint64_t tile) {
-        const uint32_t row0 = (uint32_t)(tile * SP3_BM) + (uint32_t)w * 32 + 4 * kq_r;
-        const uint32_t n_rows32 = (uint32_t)a.n_cand;
-        bool hit[8];
-        bool maybe = false;
-#pragma unroll
-        for (int nt = 0; nt < 8; ++nt) {
-            int mx = acc[0][nt][0];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) mx = acc[mt][nt][j] > mx ? acc[mt][nt][j] : mx;
-            hit[nt] = !((float)mx < thr[nt]);
-            maybe = maybe || hit[nt];
-        }
-        if (!__ballot(maybe)) return;
-#pragma unroll
-        for (int nt = 0; nt < 8; ++nt) {
-            if (!__ballot(hit[nt])) continue;
-            const uint32_t q = (uint32_t)nt * 16 + m_r;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                int m4 = acc[mt][nt][0];
-#pragma unroll
-                for (int j = 1; j < 4; ++j) m4 = acc[mt][nt][j] > m4 ? acc[mt][nt][j] : m4;
-                if (!__ballot(!((float)m4 < thr[nt]))) continue;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v = (float)acc[mt][nt][j];
-                    const uint32_t row = row0 + (uint32_t)mt * 16 + (uint32_t)j;
-                    const bool c = !(v < thr[nt]) && row < n_rows32 && q < s.nq;
-                    const uint64_t hits = __ballot(c);
-                    if (hits) {
-                        const uint32_t at = wcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u));
-                        if (c && at < s.wcap) {
-                            const uint64_t key = make_key(v * qs[nt], row);
-                            wl[at] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), q, 0u);
-                        }
-                        wcount += (uint32_t)__builtin_popcountll(hits);
-                    }
-                }
-            }
-        }
-    };
-    for (uint64_t it = 0; it < my_tiles; ++it) {
-        if (it) epilogue(tile_of(blockIdx.x + (it - 1) * gridDim.x));
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 8; ++nt) acc[mt][nt] = (i32x4s){0, 0, 0, 0};
-        for (uint32_t hs = 0; hs < 2 * nch; ++hs) {
-            // half chunk g + 3 -> the slot g - 1 was read from (its operands are in registers and used: the matrix instructions of g - 1 have been issued)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            request();
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // the rows of half chunk g have landed; g + 1 .. g + 3 may be on their way
-            const uint4 *ab = ring + slot * 128 + a_rd;
-            const uint4 *bb = b_lds + (size_t)(hs >> 1) * SP_B_UNITS + (hs & 1u) * 64 + b_rd;
-            const i32x4s a0 = *reinterpret_cast<const i32x4s *>(ab);
-            const i32x4s a1 = *reinterpret_cast<const i32x4s *>(ab + 64);
-#pragma unroll
-            for (int nt = 0; nt < 8; ++nt) {
-                const i32x4s b = *reinterpret_cast<const i32x4s *>(bb + nt * 128);
-                acc[0][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b, acc[0][nt], 0, 0, 0);
-                acc[1][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b, acc[1][nt], 0, 0, 0);
-            }
-            slot = (slot + 1) & (SP6_SLOTS - 1);
-        }
-    }
-    epilogue(tile_of(blockIdx.x + (my_tiles - 1) * gridDim.x));
-    if (lane == 0) s.wcnt[blockIdx.x * (SP3_THREADS / 64) + (uint32_t)w] = wcount;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // nothing may land in LDS after the wave is gone
-    __syncthreads();                                             // ... nor while another wave of the block still reads its ring (the block's LDS goes with its last wave)
-}
+// Other structures of this scan were built in round 4 and measured slower - half stages with 80 KiB of rows in flight per CU (14 % slower: twice the
+// barriers), wave-owned rows behind private rings with no stage hand-over (5 % slower), rows straight into the operand registers - and are gone from the
+// code since round 6; the measurements stay (profiles/r4_i8_deep_ring.md).
 
 // ---- after a launch: the k best candidates (by approximate score) of every query, for an exact look.  k of them are enough: approximate and exact
 // scores differ by a hundredth of the band in practice, so the worst exact score among the k best approximate ones is the k-th best exact score so far
 // or next to it - and finding k keys is what the bound-and-rank selection is quick at (the 64 best of ~5 000 took 100 - 190 us, these take ~15) ----
 __global__ __launch_bounds__(SEL_BLOCK) void sp_i8_probe_kernel(const uint64_t *cand, const uint32_t *cand_cnt, uint32_t cap, const float *band,
                                                                 const int *tile_overflow, uint32_t top, uint32_t *probe_ids, uint32_t *probe_cnt) {
-    __shared__ uint64_t sh[SEL_BLOCK / WAVE][WAVE];
+    __shared__ SelShared sel_sh;
+    uint64_t (*const sh)[WAVE] = sel_sh.sh;
+    SelScratch &scratch = sel_sh.scratch;
     __shared__ uint64_t sh_kth;
     __shared__ uint32_t sh_n;
-    __shared__ SelScratch scratch;
     const uint32_t q = blockIdx.x;
     const uint32_t raw = cand_cnt[q];
     if (*tile_overflow || raw > cap || raw == 0 || !(band[q] < 3.0e38f)) {       // (sp_select_kernel reports; nothing to learn here)
@@ -2119,16 +1815,13 @@ int32_t launch_split_i8_pack(hipStream_t st, const float *d_q, uint32_t nq, uint
 }
 int32_t launch_scan_i8copy(hipStream_t st, const ScanArgs &a, const void *d_bq, const float *d_qscale, const float *d_thr, int num_cus, const void *d_rows_i8,
                            void *d_wlists, uint32_t phase) {
-    // option i8_scan_deep: 1 = the half-stage pipeline (scan_i8copy_deep_kernel), 2 = wave-owned rows without stage hand-overs (scan_i8copy_kernel_wo; rows of
-    // up to 768 floats: the queries stay in LDS) - both exact, both measured slower (profiles/r4_i8_deep_ring.md) -, else the three-stage kernel
-    const int64_t shape = option(OPT_I8_SCAN_DEEP);
-    const bool wo = shape == 2 && sp6_lds_bytes(a.dim / 128) <= 160 * 1024;
-    auto kfn = wo ? scan_i8copy_kernel_wo : shape == 1 ? scan_i8copy_deep_kernel : scan_i8copy_kernel;
+    const bool b3 = option(OPT_I8_SCAN_LDS160) == 0;
+    auto kfn = b3 ? scan_i8copy_kernel<3> : scan_i8copy_kernel<4>;
+    const size_t lds_bytes = (size_t)(SP3_ARING * SP3_A_UNITS + (b3 ? 3 : 4) * SP_B_UNITS) * 16;
     static thread_local DeviceOnce attr_once;
     if (attr_once.need()) {
-        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_i8copy_kernel_wo), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_i8copy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SP3_LDS));
-        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_i8copy_deep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SP5_LDS));
+        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_i8copy_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, SP3_LDS));
+        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_i8copy_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, SP3_LDS));
         attr_once.mark();
     }
     QMX_REQUIRE(d_rows_i8 && d_wlists && split_i8_dim_ok(a.dim), QMX_ERR_BAD_ARG, "the int8 scan reads the int8 copy and writes per-wave candidate lists");
@@ -2152,7 +1845,7 @@ int32_t launch_scan_i8copy(hipStream_t st, const ScanArgs &a, const void *d_bq, 
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, (uint64_t)num_cus));
     ::qmx::clear_stale_error();
     QMX_NOTE_KERNEL(kfn);
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(SP3_THREADS), wo ? sp6_lds_bytes(a.dim / 128) : (size_t)SP3_LDS, st, a, s);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(SP3_THREADS), lds_bytes, st, a, s);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }

@@ -250,26 +250,10 @@ struct F16Ops {    // Metric<f16> dot / cosine: f16 products are exact in f32, f
 constexpr int SQM_BLOCK = 512;
 constexpr int SQM_NW = SQM_BLOCK / WAVE;
 
-// STAGE (round 4; contiguous rows of a multiple of 64 bytes, no id list): the rows reach the matrix cores through LDS.  The A operand gives a row to FOUR
-// lanes (16 bytes each of a 64-byte step), so a direct load instruction touches sixteen half-lines and the stream reaches HBM as half-line requests
-// (0.71 - 0.74 of the peak at 32 queries, measured rounds 2 - 3).  Staged, a wave loads its 16-row tile - 16 x row_bytes contiguous bytes - as whole
-// 1 KiB runs (lane l: bytes [1024 j + 16 l, + 16): eight full lines per instruction), parks it in a wave-private LDS buffer (row pitch + 16 bytes: the
-// sixteen rows of a lane group then sit in sixteen different 16-byte bank slots) and reads the operand pieces from there; the next tile's loads are in
-// flight while this one is multiplied.  Same products, same sums: the scores are the direct path's bits.
-// MEASURED (round 4, C3: 10 M x 768 codes, `profiles/r4_c3_sq_scan_staged_vs_direct.md`): staged 0.743 / 0.744 / 0.760 / 0.723 of the HBM peak at 4 / 8 / 16 /
-// 32 queries, direct 0.766 / 0.763 / 0.784 / 0.751 - whole-line requests do not pay for the extra LDS round trip of every row byte; the half-line
-// diagnosis of round 3 does not hold.  The staged path is kept behind `qmx_set_option("sq_mfma_no_stage", 0)` (exact, covered by tests/test_gpu_sq.py).
-constexpr int SQM_STAGE_CHUNKS = 16;         // 1 KiB runs per tile: rows of up to 1 024 bytes
-
-// LLIST (round 4, top-k mode): the waves' top lists live in LDS behind the query tile instead of in registers.  A list per query and wave is one
-// 64-bit register per lane: 64 of the kernel's ~175 registers at 32 queries, which pinned it at two waves per SIMD - eight per CU - against a stream
-// that wants more loads in flight.  An insertion is rare once the pre-scan bound is in place (a handful per wave and launch), so its cost moves
-// nothing: one LDS read, one cross-lane shift, one LDS write.  Same lists, same bits (507 GPU tests of the SQ / TQ / BQ / f16 scans with it on).
-// MEASURED (round 4, `profiles/r4_c3_sq_scan_staged_vs_direct.md`): 92 - 126 registers instead of 174 - 234, four to five waves per SIMD instead of two -
-// and C3 at 4 / 8 / 16 / 32 queries 0.758 / 0.751 / 0.775 / 0.752 of HBM against 0.757 / 0.768 / 0.783 / 0.754 with the lists in registers: nothing; the
-// TurboQuant 4-bit scan at 32 queries (decode-bound on the vector ALU) LOSES with twice the waves (1.75 against 1.36 ms).  So the stream is not waiting
-// for more loads in flight either.  Opt-in: `qmx_set_option("sq_mfma_no_llist", 0)`.
-template <class Ops, int QW, int D, bool HAS_IDS, int MODE, bool STAGE = false, bool LLIST = false>
+// Two variants of this kernel were built in round 4, measured and are gone from the code since round 6 (profiles/r4_c3_sq_scan_staged_vs_direct.md): rows
+// staged through wave-private LDS buffers as whole 1 KiB runs (0.723 against 0.751 of HBM at 32 queries: slower), and the waves' top lists in LDS behind the
+// query tile instead of in registers (twice the waves per SIMD, the same time for SQ, 1.75 against 1.36 ms for the decode-bound TurboQuant scan).
+template <class Ops, int QW, int D, bool HAS_IDS, int MODE>
 __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NG = QW / 16;
@@ -297,20 +281,12 @@ __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs 
 #pragma unroll
     for (int g = 0; g < NG; ++g) qc[g] = Ops::load_qc(a, smem + (uint32_t)(16 * g + n) * a.q_stride);
 
-    uint64_t list[LLIST ? 1 : QW];
-    const uint32_t qbytes16 = ((uint32_t)QW * a.q_stride + 15u) & ~15u;
-    uint64_t *const lkeys = reinterpret_cast<uint64_t *>(smem + qbytes16);        // LLIST: [wave][query][top] keys, descending
-    uint64_t *const mylist = lkeys + (uint32_t)wave * QW * a.top;
+    uint64_t list[QW];
     uint64_t thr[NG];              // reject bound of query 16 g + n: the k-th best key of the wave's list, never below ...
     uint64_t gk[NG];               // ... the score part of the pre-scan's bound (api_search.hip search_enqueue; 0 = none): equal scores pass
     float thr_f[NG];               // the score of thr (-inf without one): one float compare rejects a pair before its key is even made
-    if constexpr (LLIST) {
-        for (uint32_t i = (uint32_t)lane; i < (uint32_t)QW * a.top; i += 64) mylist[i] = 0;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    } else {
 #pragma unroll
-        for (int q = 0; q < QW; ++q) list[q] = 0;
-    }
+    for (int q = 0; q < QW; ++q) list[q] = 0;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         const uint32_t q = (uint32_t)(16 * g + n);
@@ -346,36 +322,9 @@ __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs 
 
     uint4 cur[D], nxt[D];
     const unsigned char *rp = rows;
-    // ---- STAGE: the wave's staging buffer and the lane's share of a tile ----
-    uint4 tl[STAGE ? SQM_STAGE_CHUNKS : 1];
-    uint32_t tl_off[STAGE ? SQM_STAGE_CHUNKS : 1];
-    const uint32_t pitch = nbytes + 16;
-    const uint32_t nchunk = nbytes / 64;                       // 16 rows x nbytes / 1024
-    unsigned char *stage = nullptr;
-    const uint64_t total_bytes = (uint64_t)a.n_rows * nbytes;
-    auto tile_load = [&](uint64_t tile) {
-        const uint64_t base = tile * 16 * (uint64_t)nbytes;
+    rp = rows + (uint64_t)row_of(gw < n_tiles ? gw : 0, n, nullptr) * a.row_stride;
 #pragma unroll
-        for (int j = 0; j < (STAGE ? SQM_STAGE_CHUNKS : 1); ++j) {
-            const uint64_t o = base + 1024u * (uint32_t)j + 16u * (uint32_t)lane;
-            tl[j] = ((uint32_t)j < nchunk && o + 16 <= total_bytes) ? *reinterpret_cast<const uint4 *>(rows + o) : make_uint4(0, 0, 0, 0);
-        }
-    };
-    if constexpr (STAGE) {
-        const uint32_t keys = MODE == SCAN_TOPK ? (uint32_t)SQM_NW * QW * (uint32_t)a.top * 8u : 0u;
-        const uint32_t head = LLIST ? qbytes16 + keys : (qbytes16 > keys ? qbytes16 : keys);
-        stage = smem + (head + 15u) / 16u * 16u + (uint32_t)wave * 16u * pitch;
-#pragma unroll
-        for (int j = 0; j < SQM_STAGE_CHUNKS; ++j) {
-            const uint32_t o = 1024u * (uint32_t)j + 16u * (uint32_t)lane;
-            tl_off[j] = (o / nbytes) * pitch + o % nbytes;
-        }
-        if (gw < n_tiles) tile_load(gw);
-    } else {
-        rp = rows + (uint64_t)row_of(gw < n_tiles ? gw : 0, n, nullptr) * a.row_stride;
-#pragma unroll
-        for (int d = 0; d < D; ++d) cur[d] = load_piece(rp, (uint32_t)d < nstep ? d : 0);
-    }
+    for (int d = 0; d < D; ++d) cur[d] = load_piece(rp, (uint32_t)d < nstep ? d : 0);
 
     for (uint64_t tile = gw; tile < n_tiles; tile += tw) {
         // the 4 result rows of this lane (rows 4 kg + r) and their vector offsets
@@ -395,24 +344,6 @@ __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs 
             for (int k = 0; k < Ops::NA; ++k) acc[g][k] = (typename Ops::acc_t){0, 0, 0, 0};
 
         uint32_t ones = 0;
-        if constexpr (STAGE) {
-            // this tile: registers -> LDS (the previous tile's reads are done: LDS instructions of a wave execute in order); the next one: HBM -> registers
-#pragma unroll
-            for (int j = 0; j < SQM_STAGE_CHUNKS; ++j)
-                if ((uint32_t)j < nchunk) *reinterpret_cast<uint4 *>(stage + tl_off[j]) = tl[j];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (tile + tw < n_tiles) tile_load(tile + tw);
-            const unsigned char *ap = stage + (uint32_t)n * pitch + (uint32_t)kg * 16u;
-#pragma unroll 2
-            for (uint32_t s0 = 0; s0 < nstep; ++s0) {
-                const uint4 piece = *reinterpret_cast<const uint4 *>(ap + s0 * 64u);
-                typename Ops::dec_t dec;
-                Ops::decode(piece, dec);
-                if (ops_row_ones<Ops>::value) ones += __popc(piece.x) + __popc(piece.y) + __popc(piece.z) + __popc(piece.w);
-#pragma unroll
-                for (int g = 0; g < NG; ++g) Ops::mac(dec, qbase + (uint32_t)g * gstride + s0 * Ops::QSTEP, acc[g]);
-            }
-        } else {
         const unsigned char *rp_next = rows + (uint64_t)row_of(tile + tw < n_tiles ? tile + tw : 0, n, nullptr) * a.row_stride;
         for (uint32_t s0 = 0; s0 < nstep; s0 += D) {
             const bool last_chunk = s0 + D >= nstep;
@@ -434,7 +365,6 @@ __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs 
             for (int d = 0; d < D; ++d) cur[d] = nxt[d];
         }
         rp = rp_next;
-        }
         uint32_t row_ones[4] = {0, 0, 0, 0};
         if (ops_row_ones<Ops>::value) {   // lanes n, n + 16, n + 32, n + 48 hold row n's pieces; the results of rows 4 kg + r sit in this lane
             ones += __shfl_xor(ones, 16);
@@ -466,24 +396,6 @@ __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs 
                             mask &= mask - 1;
                             const uint64_t nk = readlane_u64(key, src);
                             const int ql = 16 * g + (src & 15);
-                            if constexpr (LLIST) {
-                                uint64_t *const L = mylist + (uint32_t)ql * a.top;
-                                asm volatile("" ::: "memory");
-                                if (nk > L[top - 1]) {
-                                    const uint64_t cur_k = lane < top ? L[lane] : 0ull;
-                                    const int p = __popcll(__ballot(cur_k > nk));
-                                    const uint64_t up = shfl_up1_u64(cur_k);
-                                    const uint64_t nv = lane < p ? cur_k : (lane == p ? nk : up);
-                                    if (lane < top) L[lane] = nv;
-                                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                                    const uint64_t nt = readlane_u64(nv, top - 1);
-                                    if (n == (src & 15)) {
-                                        thr[g] = nt > gk[g] ? nt : gk[g];
-                                        thr_f[g] = thr[g] ? key_score(thr[g]) : -__builtin_inff();
-                                    }
-                                }
-                                continue;
-                            }
 #pragma unroll
                             for (int qq = 16 * g; qq < 16 * g + 16; ++qq) {
                                 if (ql == qq) {
@@ -508,14 +420,12 @@ __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs 
 
     // ---- block merge: 8 wave lists -> 1 list per query, one global write per block ----
     __syncthreads();
-    uint64_t *lds_keys = LLIST ? lkeys : reinterpret_cast<uint64_t *>(smem);
+    uint64_t *lds_keys = reinterpret_cast<uint64_t *>(smem);
     const uint32_t utop = a.top;
-    if constexpr (!LLIST) {
 #pragma unroll
-        for (int q = 0; q < QW; ++q)
-            if (lane < top) lds_keys[((uint32_t)wave * QW + q) * utop + lane] = list[q];
-        __syncthreads();
-    }
+    for (int q = 0; q < QW; ++q)
+        if (lane < top) lds_keys[((uint32_t)wave * QW + q) * utop + lane] = list[q];
+    __syncthreads();
     for (uint32_t q = wave; q < a.nq; q += SQM_NW) {
         uint64_t merged = 0;
         for (int sw = 0; sw < SQM_NW; ++sw) {
@@ -532,18 +442,16 @@ __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs 
     }
 }
 
-template <class Ops, int QW, int D, bool HAS_IDS, int MODE, bool STAGE = false, bool LLIST = false>
+template <class Ops, int QW, int D, bool HAS_IDS, int MODE>
 static int32_t launch_sqm_inst(hipStream_t st, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
     size_t lds = ((size_t)QW * a.q_stride + 15) & ~(size_t)15;
     if (MODE == SCAN_TOPK) {
         const size_t lk = (size_t)SQM_NW * QW * a.top * sizeof(uint64_t);
-        if (LLIST) lds += lk;              // the lists live behind the query tile for the whole launch
-        else if (lk > lds) lds = lk;       // ... or are parked over it for the block merge
+        if (lk > lds) lds = lk;            // the waves' lists are parked over the query tile for the block merge
     }
     lds = (lds + 15) & ~(size_t)15;
-    if (STAGE) lds += (size_t)SQM_NW * 16 * (a.dim + 16);      // the waves' staging buffers (sqm_stage_ok: it fits)
     QMX_REQUIRE(lds <= 160 * 1024, QMX_ERR_NOT_SUPPORTED, "query tile needs %zu B of LDS (> 160 KiB)", lds);
-    auto kfn = scan_sq_mfma_kernel<Ops, QW, D, HAS_IDS, MODE, STAGE, LLIST>;
+    auto kfn = scan_sq_mfma_kernel<Ops, QW, D, HAS_IDS, MODE>;
     static thread_local DeviceOnce attr_once;
     if (attr_once.need()) {
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -568,28 +476,9 @@ static int32_t launch_sqm_inst(hipStream_t st, const ScanArgs &a, int num_cus, u
     return QMX_OK;
 }
 
-// the staged row path serves: the whole block in row order (no id list), rows that lie back to back, a multiple of 64 bytes and at most 1 KiB each, and
-// an LDS that holds the query tile (or the top-k merge area) plus eight staging buffers
-template <int QW>
-static bool sqm_stage_ok(ScanMode mode, const ScanArgs &a) {
-    if (a.ids || a.row_stride != a.dim || a.dim % 64 != 0 || a.dim > 64u * SQM_STAGE_CHUNKS || option(OPT_SQ_MFMA_NO_STAGE)) return false;
-    size_t lds = (size_t)QW * a.q_stride;
-    if (mode == SCAN_TOPK) lds = std::max(lds, (size_t)SQM_NW * QW * a.top * sizeof(uint64_t));
-    return ((lds + 15) & ~(size_t)15) + (size_t)SQM_NW * 16 * (a.dim + 16) <= 160 * 1024;
-}
-
-// the lists fit beside the query tile, with room to spare for a second block per CU where the registers allow one (half the LDS)
-template <int QW>
-static bool sqm_llist_ok(const ScanArgs &a) {
-    const size_t lds = (((size_t)QW * a.q_stride + 15) & ~(size_t)15) + (size_t)SQM_NW * QW * a.top * sizeof(uint64_t);
-    return lds <= 80 * 1024 && !option(OPT_SQ_MFMA_NO_LLIST);
-}
 template <class Ops, int QW, int D>
 static int32_t launch_sqm_qt(hipStream_t st, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid) {
     const bool ids = a.ids != nullptr;
-    if (mode == SCAN_TOPK && sqm_llist_ok<QW>(a))
-        return ids ? launch_sqm_inst<Ops, QW, D, true, SCAN_TOPK, false, true>(st, a, num_cus, grid)
-                   : launch_sqm_inst<Ops, QW, D, false, SCAN_TOPK, false, true>(st, a, num_cus, grid);
     if (mode == SCAN_TOPK)
         return ids ? launch_sqm_inst<Ops, QW, D, true, SCAN_TOPK>(st, a, num_cus, grid) : launch_sqm_inst<Ops, QW, D, false, SCAN_TOPK>(st, a, num_cus, grid);
     return ids ? launch_sqm_inst<Ops, QW, D, true, SCAN_SCORES>(st, a, num_cus, grid) : launch_sqm_inst<Ops, QW, D, false, SCAN_SCORES>(st, a, num_cus, grid);
@@ -602,12 +491,6 @@ bool sq_mfma_ok(uint32_t distance, uint32_t actual_dim) {
 
 // qt in {8, 16, 32}: 8 and 16 run the 16-query kernel (one accumulator), 32 two accumulators
 int32_t launch_scan_sq_mfma(hipStream_t st, int qt, ScanMode mode, const ScanArgs &a, int num_cus, uint32_t *grid_out) {
-    if (qt <= 16 ? sqm_stage_ok<16>(mode, a) : sqm_stage_ok<32>(mode, a)) {      // rows through LDS (whole-line requests)
-        if (qt <= 16) return mode == SCAN_TOPK ? launch_sqm_inst<SqOps, 16, 6, false, SCAN_TOPK, true>(st, a, num_cus, grid_out)
-                                                : launch_sqm_inst<SqOps, 16, 6, false, SCAN_SCORES, true>(st, a, num_cus, grid_out);
-        if (qt == 32) return mode == SCAN_TOPK ? launch_sqm_inst<SqOps, 32, 6, false, SCAN_TOPK, true>(st, a, num_cus, grid_out)
-                                                : launch_sqm_inst<SqOps, 32, 6, false, SCAN_SCORES, true>(st, a, num_cus, grid_out);
-    }
     switch (qt) {
         case 8:
         case 16: return launch_sqm_qt<SqOps, 16, 6>(st, mode, a, num_cus, grid_out);

@@ -141,7 +141,7 @@ def test_gpus_2_launches_its_own_ranks_and_reports_two(tmp_path):
     # value = the COLLECTION's queries per second (not x world): ideal weak scaling reads value(N) == value(1)
     assert h["unit"] == "queries/s" and h["value"] == h["config"]["collection_qps"]
     assert h["value"] == pytest.approx(Q * steps / (h["ms_per_step"] * 1e-3 * steps), rel=1e-2)
-    assert h["config"]["segment_searches_per_s"] == pytest.approx(2 * h["value"], rel=1e-6)
+    assert h["config"]["segment_searches_per_s"] == pytest.approx(2 * h["value"], abs=0.05)
     full = json.load(open(details))
     assert full["lanes_used"] == [0, 1]
     # the merged lists of the last step = the oracle's exact search over the union of the two segments (ids globalised by the segment bases)

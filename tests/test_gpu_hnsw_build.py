@@ -534,7 +534,7 @@ def test_tq_manhattan_build_with_an_unpadded_rotation(qa):
         assert np.array_equal(gq["score"].view(np.uint32), wq["score"].view(np.uint32))
 
 
-@pytest.mark.parametrize("tables", [False, True, "prefilter"])
+@pytest.mark.parametrize("tables", [False, True])
 @pytest.mark.parametrize("distance,dim,chunk", [(O.COSINE, 64, 4), (O.EUCLID, 96, 16), (O.MANHATTAN, 80, 8), (O.DOT, 320, 16), (O.DOT, 70, 8)])
 def test_pq_build_with_and_without_tables_is_the_sequential_graph(qa, distance, dim, chunk, tables):
     """The PQ build recomputes what it needs from the codebook by default (round 4, pq.hip HopPQDirectBuild + HopPQInternalDirect: the LUT entries of the
@@ -549,15 +549,11 @@ def test_pq_build_with_and_without_tables_is_the_sequential_graph(qa, distance, 
     opq = O.PqOracle(distance, dim, chunk, cen)
     codes = opq.encode(rows)
     quant = qa.ProductQuantizer(dim, _dist(qa, distance), chunk, cen, lut_mfma=False)
-    # "prefilter" (round 5, option hnsw_pq_build_prefilter): the table-free build whose insertion searches drop, on the 8-bit upper bound of pq_hop_prefilter,
-    # the candidates their beam cannot take - the same searches, so the same graph
-    qa.set_option("hnsw_pq_table_build", 1 if tables is True else 0)
-    qa.set_option("hnsw_pq_build_prefilter", 1 if tables == "prefilter" else 0)
+    qa.set_option("hnsw_pq_table_build", 1 if tables else 0)
     try:
         seq = qa.GraphLayers.build(qa.EncodedVectorsPQ(codes, quant), m=m, ef_construct=efc, seed=seed, max_batch=1, original=vs)
     finally:
         qa.set_option("hnsw_pq_table_build", -1)
-        qa.set_option("hnsw_pq_build_prefilter", -1)
     ref = O.Hnsw.build_pq(st, opq, m=m, ef_construct=efc, seed=seed)
     _same_graph(seq.export_plain(), ref.export_plain())
 

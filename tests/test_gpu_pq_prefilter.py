@@ -113,30 +113,6 @@ def test_pq_prefilter_returns_the_exact_scan(qa, dist, dim, chunk, nq, top):
         assert got[i]["idx"].tolist() == want[i][0].tolist()
 
 
-@pytest.mark.parametrize("dist,dim,chunk", [(O.DOT, 768, 8), (O.EUCLID, 160, 4), (O.MANHATTAN, 66, 2)])
-def test_the_copy_of_16_bit_codes_serves_the_same_lists(qa, dist, dim, chunk):
-    """`pq_prefilter_w16`, read when the block is created, makes the rotated copy hold 16-bit codes (one vector instruction per gather address
-    instead of two, twice the copy; no faster at 32 queries - profiles/r4_pq_prefilter_w16.md - hence opt-in).  Both are the same prefilter:
-    same lists, same counters."""
-    n = N
-    rng, vecs, quant, opq, st_narrow = _segment(qa, dist, dim, chunk, n, seed=dim * 7 + chunk + dist)
-    qa.set_option("pq_prefilter_w16", 1)
-    try:
-        st_wide = qa.EncodedVectorsPQ(opq.codes, quant)
-    finally:
-        qa.set_option("pq_prefilter_w16", -1)
-    queries = (vecs[rng.integers(0, n, 37)] + 0.2 * rng.standard_normal((37, dim))).astype(np.float32)
-    res = []
-    for st, w16 in ((st_wide, "true"), (st_narrow, "false")):
-        s = qa.BatchFilteredSearcher(queries, st, 10)
-        res.append(s.peek_top_all())
-        assert "pq_prefilter_kernel" in _kernel(qa, s) and w16 in _kernel(qa, s), _kernel(qa, s)
-        res.append((s.counters.prefilter_candidates, s.counters.verified_rows, s.counters.fallback_queries))
-    _same(res[0], res[2])
-    assert res[1] == res[3]
-    _same(res[0], _exact(qa, queries, st_wide, 10))
-
-
 def test_pq_prefilter_with_deleted_rows_and_filter(qa):
     dist, dim, chunk, nq, top = O.DOT, 256, 8, 37, 10
     rng, vecs, quant, opq, st = _segment(qa, dist, dim, chunk, N, seed=91)

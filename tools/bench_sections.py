@@ -498,6 +498,22 @@ def _timed_quantized(ctx, scorer, raw, top, oversampling, rescore, graph, ef, re
                  "wall_ms_per_search": round(wall * 1e3, 3), "qps_wall": round(scorer.nq / wall, 1), "roofline": roof}, scored / float(reps)
 
 
+def _reference_order_cost(ctx, scorer, raw, top, graph, ef, default_stats):
+    """The same walk (no rescoring: the walk's own lists) with option hnsw_reference_heap_order: what "give me the reference's lists among equal scores"
+    costs beside the default walk (SearchContext's two binary heaps kept on the device, search_context.rs:8-40)."""
+    qa = ctx["qa"]
+    qa.set_option("hnsw_reference_heap_order", 1)
+    try:
+        _, st, scored = _timed_quantized(ctx, scorer, raw, top, 0.0, False, graph, ef, 2, default_stats["roofline"]["bytes_per_scored_row"])
+    except Exception as e:
+        return {"error": repr(e)[:200]}
+    finally:
+        qa.set_option("hnsw_reference_heap_order", -1)
+    return {"kernel": st["kernel"], "kernel_ms": st["kernel_ms"], "qps_wall": st["qps_wall"], "frac": st["roofline"]["frac"],
+            "over_default_walk": round(st["kernel_ms"] / default_stats["kernel_ms"], 2) if default_stats.get("kernel_ms") else None,
+            "searches_per_launch": scorer.nq, "points_scored_per_query": round(scored / scorer.nq, 1)}
+
+
 def _oracle_walk_check(qa, np, graph, scorer, walker, oracle_walk, nchk, top, ef):
     """The CPU oracle walks THE SAME graph with its scorer (host copy of the codes + links).  Three comparisons over `nchk` searches:
       default walk      same_ids / same_score_bits of the first `top` results (the device orders equal scores by ascending id: lists may differ at ties);
@@ -617,6 +633,7 @@ def c3_section(ctx, rows):
                "build_s": round(t_build, 2), "build_points_per_s": round(n / t_build, 1),
                "points_scored_per_query": round(scored / nq_h, 1), "recall_at_10_vs_exact": round(_recall(res[:n_gt], exact, top), 4)})
     st["search_with_vectors_ef128"] = _with_vectors(ctx, graph, scorer, raw, top, 128, n_gt, exact)
+    st["reference_heap_order"] = _reference_order_cost(ctx, scorer, raw, top, graph, 128, st)
     # recall-vs-ef of the same graph, f32 walk (graph quality without the quantizer)
     st["recall_f32_walk_vs_ef"] = {str(ef): round(_recall(graph.search(top, ef, qa.new_raw_scorer(queries[:n_gt].contiguous(), vs)), exact, top), 4)
                                    for ef in (64, 128, 256)}
@@ -787,6 +804,7 @@ def c4_section(ctx):
     hn = {"m": 16, "ef_construct": 100, "ef": 128, "searches_per_launch": nq_h, "build_through": "PQ scorer (LUT of the original vector per insertion, score_internal for the heuristic)",
           "build_s": round(t_build, 2), "build_points_per_s": round(n / t_build, 1), "walks": walks}
     hn["search_with_vectors_ef128"] = _with_vectors(ctx, graph, scorer, raw, top, 128, n_gt, exact)
+    hn["reference_heap_order"] = _reference_order_cost(ctx, scorer, raw, top, graph, 128, walks["no_rescoring"])
     hn["recall_f32_walk_vs_ef"] = {str(ef): round(_recall(graph.search(top, ef, qa.new_raw_scorer(queries[:n_gt].contiguous(), vs)), exact, top), 4)
                                    for ef in (64, 128, 256)}
     # brute force over the codes for reference (what the quantizer alone can do on these rows)
