@@ -82,9 +82,11 @@ def parse(argv=None):
     ap.add_argument("--configs", default="c1,c3,tq,c4", help="comma list of the secondary single-GPU configs to run (empty = none)")
     ap.add_argument("--config-rows", type=int, default=0, help="rows of C3 / C4 (0 = --rows)")
     ap.add_argument("--hnsw-queries", type=int, default=8192, help="searches per launch of the HNSW walks")
-    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2, 3, 4],
-                    help="query batches in flight on one GPU: 2 = consecutive steps alternate between two query handles on two streams, so that one batch's "
-                         "head (preprocess, sample pre-scan, pack) and tail (probe, verification, sort) run beside the other's scans; 1 = one handle, one stream")
+    ap.add_argument("--in-flight", type=int, default=4, choices=[1, 2, 3, 4, 5, 6, 8],
+                    help="query batches in flight on one GPU: consecutive steps take turns on this many query handles, each with its own stream, so that one batch's "
+                         "head (preprocess, sample pre-scan, pack), the gap between its two scans (probe, exact gather, bound) and its tail (verification, sort) run "
+                         "beside or between the other batches' scans; 1 = one handle, one stream.  (Rounds 3 - 5: 2.  Round 6: the int8 scan leaves 16 KiB of LDS per CU "
+                         "free, the small kernels run beside it, and four batches keep a scan ready at every hand-over: 87.5 k -> 91.4 k QPS, profiles/r6_i8_lanes_experiment.txt)")
     ap.add_argument("--fanout-rows", type=int, default=1_000_000,
                     help="rows per segment of the one-process fan-out legs (qmx_sharded_hnsw_build + qmx_sharded_search_topk over one segment per device); 0 = skip")
     ap.add_argument("--prewarm-ms", type=float, default=150.0,
@@ -506,7 +508,7 @@ def main(argv=None):
     fence()
     # (the spread of the timed region, without touching it: every `gsz` steps an event on EVERY lane's stream, read after the closing fence; a group ends
     # when its last lane does)
-    gsz = max(1, args.steps // 10)
+    gsz = len(lanes) * max(1, int(round(args.steps / 10.0 / len(lanes))))      # (a group is whole rounds over the lanes: every lane works in every group)
     calls0 = sharded.COLLECTIVE_CALLS
 
     def mark():
@@ -526,7 +528,7 @@ def main(argv=None):
     elapsed = time.perf_counter() - t0
     collectives_per_step = (sharded.COLLECTIVE_CALLS - calls0) / float(max(1, args.steps))
     at = [max(marks[0][0].elapsed_time(e) for e in ev) for ev in marks]      # when each group's last lane passed its mark (ms after the first mark)
-    group_ms = [(at[j + 1] - at[j]) / gsz for j in range(len(at) - 1)]        # device time per step, per group of gsz steps
+    group_ms = [(at[j + 1] - at[j]) / gsz for j in range(len(at) - 1) if at[j + 1] > at[j]]        # device time per step, per group of gsz steps
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)

@@ -925,9 +925,11 @@ int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
     h.visited = (uint32_t *)q->hnsw_vis.p;
     h.vis_log = (uint32_t *)q->hnsw_log.p;
     // the slots draw their searches from a counter that starts behind the first `slots` (hnsw.hpp)
-    QMX_TRY(q->hnsw_next.reserve(4));
+    QMX_TRY(q->hnsw_next.reserve(32));         // [u32 next search][pad][u64 hop candidates offered to the PQ prefilter][u64 scored exactly]
     QMX_HIP(hipMemsetD32Async((hipDeviceptr_t)q->hnsw_next.p, (int)slots, 1, q->stream));
+    QMX_HIP(hipMemsetAsync((char *)q->hnsw_next.p + 8, 0, 16, q->stream));
     h.next_query = (uint32_t *)q->hnsw_next.p;
+    h.pq_stats = h.pq8 ? (unsigned long long *)((char *)q->hnsw_next.p + 8) : nullptr;
     size_t slot = 0;
     if (timed) QMX_TRY(timing_begin(q, &slot));
     QMX_TRY(launch_hnsw(q, a, h, (uint32_t)slots, &per_cu));
@@ -973,12 +975,17 @@ int32_t hnsw_search_sync(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t
     if (!out_dev) QMX_TRY(copy_out(q->stream, out, d_out, (size_t)q->nq * top * sizeof(qmx_scored_point)));
     if (!cnt_dev) QMX_TRY(copy_out(q->stream, out_counts, d_counts, (size_t)q->nq * 4));
     std::vector<uint32_t> scored(counters ? q->nq : 0);
+    unsigned long long pq_stats[2] = {0, 0};
     if (counters) QMX_HIP(hipMemcpyAsync(scored.data(), q->hnsw_scored.p, (size_t)q->nq * 4, hipMemcpyDeviceToHost, q->stream));
+    if (counters && q->hnsw_next.p) QMX_HIP(hipMemcpyAsync(pq_stats, (char *)q->hnsw_next.p + 8, 16, hipMemcpyDeviceToHost, q->stream));
     QMX_TRY(check_err_flag(q));   // synchronises the stream
     if (counters) {
         uint64_t total = 0;
         for (uint32_t v : scored) total += v;
         counters->vectors_scored = total;
+        // the PQ walk's hop prefilter (hnsw.hpp HopPQ::prefilter): level-0 hop candidates that met the 8-bit bound / those that survived it and were scored exactly
+        counters->prefilter_candidates = pq_stats[0];
+        counters->verified_rows = pq_stats[1];
         counters->bytes_read = total * q->seg->row_bytes;
         counters->kernel_launches = 1;
     }

@@ -393,13 +393,13 @@ int32_t tq_l1_scores_device(qmx_query *q, uint32_t q0, uint32_t nq, const uint32
 // The score matrix of queries [tile0, tile0 + nq_tile) of the batch against the candidates ids[0..n) (rows 0..n without ids): scores[(qi - tile0) * stride + i].
 // One launch per tile_qt queries; the f32 matrix-core kernel takes them all in one launch (scan_mfma.hip: score mode loops over its query tiles).
 int32_t score_matrix_enqueue(const qmx_query *q, uint32_t tile0, uint32_t nq_tile, const uint32_t *d_ids, uint64_t n, float *d_scores, uint64_t stride,
-                                    uint32_t *launches, uint32_t max_qt) {
+                                    uint32_t *launches) {
     const qmx_segment *s = q->seg;
     if (tq_l1(s)) {
         if (launches) *launches += 3 * (uint32_t)((n + 65535) / 65536);
         return tq_l1_scores_device(const_cast<qmx_query *>(q), tile0, nq_tile, d_ids, n, d_scores, stride, nullptr);
     }
-    const uint32_t SQT = max_qt ? std::min<uint32_t>(tile_qt(s, q), max_qt) : tile_qt(s, q);      // (max_qt: a cap on the query tile = on the launch's LDS)
+    const uint32_t SQT = tile_qt(s, q);
     const bool loops = s->dtype == QMX_DTYPE_F32 && SQT >= 8 && mfma_scan_ok(s);
     const uint32_t step = loops ? nq_tile : SQT;
     for (uint32_t st0 = 0; st0 < nq_tile; st0 += step) {
@@ -412,7 +412,7 @@ int32_t score_matrix_enqueue(const qmx_query *q, uint32_t tile0, uint32_t nq_til
         pre.scores = d_scores + (size_t)st0 * stride;
         pre.scores_stride = stride;
         uint32_t pgrid = 0;
-        QMX_TRY(launch_scan(q, (int)std::min<uint32_t>(pow2_ceil(nq_sub), max_qt ? SQT : std::max<uint32_t>(SQT, 8)), SCAN_SCORES, pre, &pgrid));
+        QMX_TRY(launch_scan(q, (int)std::min<uint32_t>(pow2_ceil(nq_sub), std::max<uint32_t>(SQT, 8)), SCAN_SCORES, pre, &pgrid));
         if (launches) ++*launches;
     }
     return QMX_OK;

@@ -299,7 +299,7 @@ int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids, uint64
             a.top = top;
             // 1. exact scores of the sample -> the k-th best of each query = a lower bound of its final k-th best
             QMX_TRY(q->scores.reserve((size_t)nq_tile * S * sizeof(float)));
-            QMX_TRY(score_matrix_enqueue(q, tile0, nq_tile, d_sample, S, (float *)q->scores.p, S, nullptr, (option(OPT_EXPERIMENT) & 1) ? 4u : 0u));
+            QMX_TRY(score_matrix_enqueue(q, tile0, nq_tile, d_sample, S, (float *)q->scores.p, S, nullptr));
             QMX_TRY(launch_custom_topk(q->stream, (const float *)q->scores.p, S, d_sample, a.del, nq_tile, top, d_out + (size_t)tile0 * top, d_counts + tile0, gthr));
             QMX_TRY(split_stage(q, "prescan"));
             if (s->split_i8) {
@@ -451,7 +451,6 @@ int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids, uint64
                                   (uint32_t *)(plan + pl.count), (int *)(plan + pl.run16), (int *)(plan + pl.run64), n_run64, (SplitStats *)plan, q->d_queries,
                                   q->q_stride, q->sp_fq.p));
         for (uint32_t pass = 0; pass <= n_run64; ++pass) {      // pass 0: the 16-query shape; pass p >= 1: packed queries 64 (p - 1) ..
-            if (option(OPT_EXPERIMENT) & 2) break;
             if (pass && last <= 16) break;
             const uint32_t p0 = pass ? (pass - 1) * FQT : 0;
             const uint32_t nq_sub = pass ? std::min<uint32_t>(FQT, last - p0) : std::min<uint32_t>(16, last);

@@ -41,13 +41,11 @@ enum Option {
     OPT_HNSW_PQ_DIRECT_WALK,  // the PQ walk recomputes LUT entries from the codebook (pq.hip HopPQDirect: a twentieth of the HBM traffic; 1.3 x the time on a 2 M-row graph, the same at 10 M) instead of gathering per-search LUTs
     OPT_HNSW_PQ_TABLE_BUILD,  // the PQ build scores through per-insertion LUTs and the centroid pair table (round 2's build: 100 TB of table sectors per 2 M points) instead of
                               // recomputing both kinds of entries from the codebook (pq.hip HopPQDirectBuild + HopPQInternalDirect, the default where the codebook allows)
-    OPT_I8_SCAN_LDS160,       // the int8-copy prefilter keeps four query stages in LDS (rounds 3 - 5: 160 KiB, the CU's whole LDS) instead of three (144 KiB: the other batch's small kernels run beside the scan)
     OPT_HNSW_NO_PQ_PREFILTER, // the PQ walk scores every hop candidate exactly (rounds 1-4) instead of dropping, on an 8-bit upper bound, those the beam cannot take
     OPT_HNSW_NO_LDS_VISITED,  // the walk's visited set lives in the per-slot HBM bitmap only (rounds 1-4), not in the 16 KiB LDS table in front of it
     OPT_PQ_LUT_NO_LDS,        // the MFMA LUT build reads its operands from global memory per instruction (round 1's pq_lut_mfma_kernel) instead of staging both in LDS
     OPT_HNSW_PER_CU,          // cap on the searches resident per CU of any walk (0 = what the occupancy allows)
     OPT_HNSW_REFERENCE_HEAP_ORDER,   // the plain HNSW walk keeps `nearest` / `candidates` as the reference's two binary heaps (std sift order, one lane): the reference's lists among equal scores; slow, a verification mode
-    OPT_EXPERIMENT,           // TEMPORARY (round 6 measurements): bit 0 = the prefilter's sample scores through 4-query tiles (12.5 KiB of LDS), bit 1 = no conditional fallback launches
     OPT_DEBUG,                // log dropped stale HIP errors
     OPT_COUNT
 };

@@ -984,12 +984,13 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
     // `candidate.score < lower_bound` only, graph_layers.rs:354-365), the first one below it has its base vector scored and ends the loop.
     // Every evicted-unexpanded candidate that can still be popped is kept.  Evictions arrive in strictly increasing key order (the entry that leaves is the
     // beam's worst, and whatever left before was worse still), and the bound never falls - so only the evictions of the LATEST score can ever tie with
-    // the bound, and an eviction of a higher score retires all earlier ones (they can no longer tie, and the break candidate is the best key).  The
+    // the bound, and an eviction of a higher score retires all earlier ones: they can no longer tie, and only the best of them (ev_old: the last to leave)
+    // can still be popped - as the candidate that ends the loop, once the latest group has been popped whole.  The
     // latest-score group lives in ev[0..3] (best first) with its older members on a per-slot stack in global memory (h.ev_spill: ascending keys, so the top of
     // the stack is the next best) - integer link scores (BQ, 1-bit TurboQuant) evict dozens of equal scores.  Among equal scores the pop order is the key's
     // (lower id first) where the reference's is its heap's.
-    uint64_t ev[4] = {0, 0, 0, 0};
-    uint32_t n_spill = 0;
+    uint64_t ev[4] = {0, 0, 0, 0}, ev_old = 0;
+    uint32_t n_spill = 0, n_offered = 0, n_exact = 0;
     uint64_t *const spill = h.ev_spill ? h.ev_spill + (uint64_t)blockIdx.x * h.ev_cap : nullptr;
     uint32_t n_exp = 0;
     while (true) {
@@ -1063,7 +1064,11 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
             }
             n_scored += k;
             if constexpr (has_hop_prefilter<H>::value) {      // candidates that cannot beat the beam's worst entry leave here, unscored (the same walk: see H::prefilter)
-                if (pq8) k = H::prefilter(a, pq8, hop_ids, k, beam.at(ef - 1), lane);
+                if (pq8) {
+                    n_offered += k;
+                    k = H::prefilter(a, pq8, hop_ids, k, beam.at(ef - 1), lane);
+                    n_exact += k;
+                }
             }
             hop_score<H>(a, qp, hop_ids, hop_scores, k, lane);
             const uint64_t mykey = (uint32_t)lane < k ? make_key(hop_scores[lane], hop_ids[lane]) : 0;
@@ -1076,6 +1081,7 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
                 if (nk > last) {
                     if (h.expanded && last != 0 && !beam.done_at(ef - 1)) {      // an unexpanded entry leaves `nearest`: it stays in `candidates`
                         if (ev[0] && (last >> 32) != (ev[0] >> 32)) {             // a higher score: the earlier evictions are retired
+                            ev_old = ev[0];
                             ev[0] = ev[1] = ev[2] = ev[3] = 0;
                             n_spill = 0;
                         }
@@ -1093,13 +1099,18 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
         }
     }
     if (h.expanded) {
-        if (ev[0]) {      // the pop that ends the loop: the best evicted candidate below the bound
-            if (lane == 0 && n_exp < h.xcap) h.expanded[(uint64_t)qi * h.xcap + n_exp] = key_idx(ev[0]);
+        const uint64_t last_pop = ev[0] ? ev[0] : ev_old;
+        if (last_pop) {   // the pop that ends the loop: the best evicted candidate below the bound
+            if (lane == 0 && n_exp < h.xcap) h.expanded[(uint64_t)qi * h.xcap + n_exp] = key_idx(last_pop);
             ++n_exp;
         }
         if (lane == 0) h.expanded_cnt[qi] = n_exp;
     }
     if (h.pops && lane == 0) h.pop_cnt[qi] = n_exp;
+    if (h.pq_stats && lane == 0 && n_offered) {
+        atomicAdd(&h.pq_stats[0], (unsigned long long)n_offered);
+        atomicAdd(&h.pq_stats[1], (unsigned long long)n_exact);
+    }
     }
 
     // ---- nearest.into_iter_sorted().take(top) ----

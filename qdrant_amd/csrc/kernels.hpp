@@ -117,6 +117,7 @@ struct HnswArgs {
     qmx_scored_point *out;          // [nq][top]
     uint32_t *out_counts;           // [nq]
     uint32_t *out_scored;           // [nq] points scored by each search (HardwareCounter cpu_io), may be null
+    unsigned long long *pq_stats;   // PQ walk with the hop prefilter: [0] += hop candidates that met the 8-bit bound, [1] += those scored exactly (the survivors); may be null
     uint32_t lds_query_bytes;       // bytes of the query entry staged in LDS (16-byte multiple)
     uint32_t acorn;                 // SearchAlgorithm::Acorn on level 0 (graph_layers.rs:154-243): `visited` holds two bitmaps of vis_words / 2 words
     uint32_t hop_cap;               // entries of the hop id / score buffers in LDS (64; m0 (m0 + 1) rounded up for ACORN)

@@ -1316,11 +1316,13 @@ __global__ __launch_bounds__(256) void sp_i8_pack_kernel(const float *q, uint32_
 // The scan: scan_f16pair_kernel<true> with the int8 instruction.  A stage is 256 rows x 128 coordinates (two planes of 64) = 32 KiB of rows + 16 KiB of
 // queries, 32 matrix instructions per wave as there; nch = dim / 128 stages per tile.  s.scales = the queries' scales (score units per accumulator
 // unit), s.thr in accumulator units.
-// BRING = query stages in LDS.  4 (rounds 3 - 5): queries requested three stages ahead, 96 + 64 = 160 KiB, the whole LDS of the CU - nothing else that
-// needs LDS can start on a CU while a block of this scan lives there.  3: two stages ahead (the 96 KiB of query images stay in L2: 2.9 us ahead is plenty),
-// 96 + 48 = 144 KiB, which leaves 16 KiB per CU to the other batch's small kernels (regroup, probe, gather, sort, pack ...): they run BESIDE the scan
-// instead of queueing behind it.
-template <int BRING>
+// SP8_BRING = 3 query stages in LDS: the queries of stage g + 2 are requested during stage g (the 96 KiB of query images stay in L2: 2.9 us ahead is plenty),
+// 96 + 48 = 144 KiB - which leaves 16 KiB of every CU's LDS to the OTHER batches' small kernels (regroup, probe, exact gather, bound, select, sort, pack ...):
+// they run beside this scan instead of queueing behind it.  Rounds 3 - 5 kept four stages (160 KiB, the CU's whole LDS: nothing that needs LDS could start
+// on a CU while a block of the scan lived there); measured in round 6 (C2, 128 queries per step; profiles/r6_i8_lanes_experiment.txt): 2 / 3 / 4 batches in
+// flight 87.5 / 88.1 / 88.6 k QPS with 160 KiB, 88.3 / 90.0 / 91.4 k with 144 KiB.
+constexpr int SP8_BRING = 3;
+constexpr int SP8_LDS = (SP3_ARING * SP3_A_UNITS + SP8_BRING * SP_B_UNITS) * 16;
 __global__ __launch_bounds__(SP3_THREADS, 1) void scan_i8copy_kernel(const ScanArgs a, const SplitArgs s) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint4 *lds = reinterpret_cast<uint4 *>(smem_raw);
@@ -1371,7 +1373,7 @@ __global__ __launch_bounds__(SP3_THREADS, 1) void scan_i8copy_kernel(const ScanA
     auto queries_begin = [&]() {
         rb_src = uniform_ptr((uint64_t)(uintptr_t)(s.bq + (uint64_t)rb_kc * SP_B_UNITS) + (uint32_t)w * 2048u);
         rb_dst = lds0 + (SP3_ARING * SP3_A_UNITS + rb_slot * SP_B_UNITS) * 16u + (uint32_t)w * 2048u;
-        rb_slot = rb_slot + 1 == BRING ? 0 : rb_slot + 1;
+        rb_slot = rb_slot + 1 == SP8_BRING ? 0 : rb_slot + 1;
         rb_kc = rb_kc + 1 == nch ? 0 : rb_kc + 1;
     };
     auto queries_piece = [&](int i) { sp_glds16(rb_src + i * 1024, lane_off, rb_dst + i * 1024); };
@@ -1385,19 +1387,11 @@ __global__ __launch_bounds__(SP3_THREADS, 1) void scan_i8copy_kernel(const ScanA
         queries_piece(0);
         queries_piece(1);
     };
-    if constexpr (BRING >= 4) {
-        request_queries();                                // queries of stage 0
-        request_queries();                                // ... 1
-        request_rows();                                   // rows of stage 0
-        request_queries();                                // queries of stage 2
-        request_rows();                                   // rows of stage 1
-    } else {                                              // (stage g requests [queries of g + 2, rows of g + 2])
-        request_queries();                                // queries of stage 0
-        request_rows();                                   // rows of stage 0
-        request_queries();                                // queries of stage 1
-        request_rows();                                   // rows of stage 1
-    }
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // queries and rows of stage 0 have landed (BRING 4: the queries of stage 1 too)
+    request_queries();                                    // queries of stage 0   (stage g requests [queries of g + 2, rows of g + 2])
+    request_rows();                                       // rows of stage 0
+    request_queries();                                    // queries of stage 1
+    request_rows();                                       // rows of stage 1
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // queries and rows of stage 0 have landed
     sp_stage_barrier();
     uint32_t slot = 0, bslot = 0;
     i32x4s acc[4][4];
@@ -1458,7 +1452,7 @@ __global__ __launch_bounds__(SP3_THREADS, 1) void scan_i8copy_kernel(const ScanA
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (i32x4s){0, 0, 0, 0};
         for (uint32_t kc = 0; kc < nch; ++kc) {
-            queries_begin();                              // stage g + BRING - 1 -> the slot stage g - 1 was read from (everybody is past that barrier)
+            queries_begin();                              // stage g + 2 -> the slot stage g - 1 was read from (everybody is past that barrier)
             rows_begin();                                 // stage g + 2 -> likewise
             const uint4 *ab = lds + slot * SP3_A_UNITS + a_rd;
             const uint4 *bb = b_lds + bslot * SP_B_UNITS + b_rd;
@@ -1484,7 +1478,7 @@ __global__ __launch_bounds__(SP3_THREADS, 1) void scan_i8copy_kernel(const ScanA
                 for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0[nt], acc[mt][nt], 0, 0, 0);
             }
             slot = slot + 1 == SP3_ARING ? 0 : slot + 1;
-            bslot = bslot + 1 == BRING ? 0 : bslot + 1;
+            bslot = bslot + 1 == SP8_BRING ? 0 : bslot + 1;
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // all but this stage's six requests have landed: rows and queries of stage g + 1 among them
             sp_stage_barrier();
         }
@@ -1815,13 +1809,11 @@ int32_t launch_split_i8_pack(hipStream_t st, const float *d_q, uint32_t nq, uint
 }
 int32_t launch_scan_i8copy(hipStream_t st, const ScanArgs &a, const void *d_bq, const float *d_qscale, const float *d_thr, int num_cus, const void *d_rows_i8,
                            void *d_wlists, uint32_t phase) {
-    const bool b3 = option(OPT_I8_SCAN_LDS160) == 0;
-    auto kfn = b3 ? scan_i8copy_kernel<3> : scan_i8copy_kernel<4>;
-    const size_t lds_bytes = (size_t)(SP3_ARING * SP3_A_UNITS + (b3 ? 3 : 4) * SP_B_UNITS) * 16;
+    auto kfn = scan_i8copy_kernel;
+    const size_t lds_bytes = (size_t)SP8_LDS;
     static thread_local DeviceOnce attr_once;
     if (attr_once.need()) {
-        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_i8copy_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, SP3_LDS));
-        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_i8copy_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, SP3_LDS));
+        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_i8copy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SP8_LDS));
         attr_once.mark();
     }
     QMX_REQUIRE(d_rows_i8 && d_wlists && split_i8_dim_ok(a.dim), QMX_ERR_BAD_ARG, "the int8 scan reads the int8 copy and writes per-wave candidate lists");

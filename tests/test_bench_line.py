@@ -134,8 +134,8 @@ def test_gpus_2_launches_its_own_ranks_and_reports_two(tmp_path):
     assert h["n_gpus"] == 2 and h["rccl_ranks"] == 2 and h["collective"] == "gloo" and h["steps"] == steps and h["scaling"] == "weak"
     assert h["config"]["workload"].startswith("C5: 2 segments") and "not a measurement" in h["data"]
     assert "2 x %d vecs" % n in h["metric"]                   # the collection the queries are answered over
-    # N > 1 is the experiment of N = 1: the same two batches in flight, + ONE collective per step (lists and counts travel in one packed record)
-    assert h["config"]["batches_in_flight"] == 2 and h["config"]["collectives_per_step"] == 1.0
+    # N > 1 is the experiment of N = 1: the same four batches in flight, + ONE collective per step (lists and counts travel in one packed record)
+    assert h["config"]["batches_in_flight"] == 4 and h["config"]["collectives_per_step"] == 1.0
     # (a fixed count on every rank, derived from --prewarm-ms: a step holds a collective, a timed loop would desynchronise the ranks)
     assert h["config"]["prewarm_steps"] == 100
     # value = the COLLECTION's queries per second (not x world): ideal weak scaling reads value(N) == value(1)
@@ -143,7 +143,7 @@ def test_gpus_2_launches_its_own_ranks_and_reports_two(tmp_path):
     assert h["value"] == pytest.approx(Q * steps / (h["ms_per_step"] * 1e-3 * steps), rel=1e-2)
     assert h["config"]["segment_searches_per_s"] == pytest.approx(2 * h["value"], abs=0.05)
     full = json.load(open(details))
-    assert full["lanes_used"] == [0, 1]
+    assert full["lanes_used"] == [0, 1, 2]          # (3 steps: the first three of the four lanes)
     # the merged lists of the last step = the oracle's exact search over the union of the two segments (ids globalised by the segment bases)
     seed = 0x5EED0002
     rows = np.concatenate([O.preprocess(O.COSINE, O.synth(seed + 16 * r, 0, n, dim)) for r in range(2)])

@@ -103,4 +103,5 @@ def test_search_with_vectors_expands_every_evicted_candidate_that_ties_with_the_
         assert got[qi]["idx"].tolist() == order, (qi, worst_tie)
         assert np.array_equal(got[qi]["score"].view(np.uint32), base[qi, order].view(np.uint32))
     assert scored == total
-    assert max(ties) >= 8, ties          # eight and more equal scores waited outside `nearest` at once: beyond what four registers hold
+    if kind == "bq":                     # (1-bit TurboQuant scores carry a per-row scale: they tie rarely - the case pins the walk itself)
+        assert max(ties) >= 8, ties      # eight and more equal scores waited outside `nearest` at once: beyond what four registers hold

@@ -805,6 +805,24 @@ def c4_section(ctx):
           "build_s": round(t_build, 2), "build_points_per_s": round(n / t_build, 1), "walks": walks}
     hn["search_with_vectors_ef128"] = _with_vectors(ctx, graph, scorer, raw, top, 128, n_gt, exact)
     hn["reference_heap_order"] = _reference_order_cost(ctx, scorer, raw, top, graph, 128, walks["no_rescoring"])
+    try:
+        # what the hop prefilter lets through (qmx_counters of qmx_hnsw_search: level-0 candidates that met the 8-bit bound / those scored exactly), and the hops
+        # of a search (its pop sequence): the walk's exact scores cost one 4-byte gather per chunk and survivor - requests, not bytes, are what it is bound by
+        graph.search(top, 128, scorer)
+        offered, exact_scored = int(graph.counters.prefilter_candidates), int(graph.counters.verified_rows)
+        _, pops = graph.search_traced(top, 128, qa.new_raw_scorer(queries[:256].contiguous(), enc))
+        hops = float(np.mean([len(p_) for p_ in pops]))
+        kms = walks["no_rescoring"]["kernel_ms"]
+        reqs = nq_h * (exact_scored / float(nq_h) * quant.m + offered / float(nq_h) * 2 + hops * 3)      # LUT gathers + code rows (96 B: two sectors) + link rows
+        hn["hop_prefilter"] = {"hops_per_search": round(hops, 1), "candidates_offered_per_hop": round(offered / float(nq_h) / hops, 2),
+                               "survivors_per_hop": round(exact_scored / float(nq_h) / hops, 2), "survival": round(exact_scored / float(max(1, offered)), 4),
+                               "lut_gathers_per_search": int(exact_scored / float(nq_h) * quant.m),
+                               "memory_requests_per_launch_estimate": int(reqs),
+                               "G_requests_per_s": round(reqs / (kms * 1e-3) / 1e9, 2) if kms else None,
+                               "note": "requests = 4-byte LUT gathers of the survivors (m per survivor, each its own 64-byte sector) + two sectors per offered code row + the link "
+                                       "rows; the roof to read it against is tools/micro/gather_roof's `lut4 chain` line (profiles/r6_gather_roof_lut4.txt), not 8 TB/s"}
+    except Exception as e:
+        hn["hop_prefilter"] = {"error": repr(e)[:200]}
     hn["recall_f32_walk_vs_ef"] = {str(ef): round(_recall(graph.search(top, ef, qa.new_raw_scorer(queries[:n_gt].contiguous(), vs)), exact, top), 4)
                                    for ef in (64, 128, 256)}
     # brute force over the codes for reference (what the quantizer alone can do on these rows)

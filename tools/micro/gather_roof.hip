@@ -78,6 +78,33 @@ __global__ __launch_bounds__(64) void chain_kernel(const unsigned char *rows, ui
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// 4-byte gathers from PER-SLOT tables: the shape of the PQ walk's exact hop score (pq.hip HopPQ): a search owns a LUT of `chunks` rows of 256 f32 entries
+// (96 x 1 KiB = 96 KiB at m = 96) and a surviving candidate costs one entry per chunk - `chunks` dword loads, each from another 1 KiB row: another 64-byte
+// sector per 4 useful bytes.  Every wave slot owns one table; per link of the chain the wave scores `surv` candidates (chunk c of candidate j: lane
+// (j * chunks + c) % 64, entry = hash); DEP: the next link's entries depend on the values just loaded (the walk: the next hop's candidates come from this
+// one's result).  What it measures: the rate at which the memory system returns such requests once the live tables (slots x table bytes) exceed L2.
+template <bool DEP>
+__global__ __launch_bounds__(64) void lut_gather_kernel(const unsigned char *tables, uint64_t table_bytes, uint32_t chunks, uint32_t surv, uint32_t iters, uint32_t *sink) {
+    const int lane = threadIdx.x;
+    const unsigned char *my = tables + (uint64_t)blockIdx.x * table_bytes;
+    uint32_t acc = blockIdx.x * 2654435761u + 12345u;
+    const uint32_t per_link = chunks * surv, rounds = (per_link + 63) / 64;
+    for (uint32_t it = 0; it < iters; ++it) {
+        const uint32_t seed = DEP ? (uint32_t)__shfl((int)acc, 0, 64) : blockIdx.x;
+        uint32_t got = 0;
+        for (uint32_t r = 0; r < rounds; ++r) {
+            const uint32_t item = r * 64 + (uint32_t)lane;
+            if (item < per_link) {
+                const uint32_t c = item % chunks;
+                const uint32_t code = (uint32_t)mix(((uint64_t)seed << 24) ^ ((uint64_t)it << 12) ^ item) & 255u;
+                got += *reinterpret_cast<const uint32_t *>(my + ((uint64_t)c * 256 + code) * 4);
+            }
+        }
+        acc += got;
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
 template <class F>
 static float time_ms(F &&launch, int reps) {
     hipEvent_t a, b;
@@ -155,6 +182,24 @@ int main(int argc, char **argv) {
         const float ms = time_ms([&] { hipLaunchKernelGGL((chain_kernel<6, 4>), dim3(grid), dim3(64), 0, 0, rows, n_rows, stride, iters, sink); }, 3);
         printf("chain    row 768 B  waves/CU %2d  footprint %6.2f GiB  %8.1f GB/s   %.2f us per link of the chain (32 rows)\n", per_cu, gib,
                (double)grid * iters * 32 * 768 / (ms * 1e-3) / 1e9, ms * 1e3 / iters);
+    }
+    // ---- 4-byte gathers from per-slot 96 KiB tables (the PQ walk's LUT gathers): requests per second, independent and as dependent chains ----
+    {
+        const uint64_t table = 96 * 1024;
+        const uint32_t chunks = 96;
+        for (int dep = 0; dep <= 1; ++dep)
+            for (int per_cu : {8, 12, 16})
+                for (uint32_t surv : {2u, 4u, 8u}) {
+                    const uint32_t grid = (uint32_t)cus * per_cu;
+                    if ((uint64_t)grid * table > region) continue;
+                    const uint32_t it4 = 400;
+                    const float ms = dep ? time_ms([&] { hipLaunchKernelGGL((lut_gather_kernel<true>), dim3(grid), dim3(64), 0, 0, rows, table, chunks, surv, it4, sink); }, 3)
+                                         : time_ms([&] { hipLaunchKernelGGL((lut_gather_kernel<false>), dim3(grid), dim3(64), 0, 0, rows, table, chunks, surv, it4, sink); }, 3);
+                    const double reqs = (double)grid * it4 * chunks * surv;
+                    printf("lut4     %s  tables %5u x 96 KiB = %6.1f MB live  waves/CU %2d  %u candidates per link  %7.2f G requests/s  = %7.1f GB/s of 64-byte sectors, %6.1f GB/s useful"
+                           "   %.2f us per link\n", dep ? "chain      " : "independent", grid, (double)grid * table / 1e6, per_cu, surv, reqs / (ms * 1e-3) / 1e9,
+                           reqs * 64 / (ms * 1e-3) / 1e9, reqs * 4 / (ms * 1e-3) / 1e9, ms * 1e3 / it4);
+                }
     }
     return 0;
 }
