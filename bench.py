@@ -81,6 +81,7 @@ def parse(argv=None):
     ap.add_argument("--verify", type=int, default=1, help="check samples against the oracle (C2 first batch, C3 / C4 scans and walks)")
     ap.add_argument("--configs", default="c1,c3,tq,c4", help="comma list of the secondary single-GPU configs to run (empty = none)")
     ap.add_argument("--config-rows", type=int, default=0, help="rows of C3 / C4 (0 = --rows)")
+    ap.add_argument("--no-iid-walk", action="store_true", help="skip the C3 walk on C2's own iid rows (SURVEY 8d's C3 rows; one more 10 M-point graph build)")
     ap.add_argument("--hnsw-queries", type=int, default=8192, help="searches per launch of the HNSW walks")
     ap.add_argument("--in-flight", type=int, default=4, choices=[1, 2, 3, 4, 5, 6, 8],
                     help="query batches in flight on one GPU: consecutive steps take turns on this many query handles, each with its own stream, so that one batch's "
@@ -188,6 +189,7 @@ def compact_roofline(result):
     timed = {"kernel": _short(r.get("kernel", "")), "kernel_ms": r.get("kernel_ms"), "launches": r.get("launches_timed"),
              "launches_per_pass": r.get("launches_per_pass"), "bytes_streamed": r.get("algorithmic_bytes_per_launch"),
              "GBps": (r.get("hbm") or {}).get("achieved_GBps"), "frac": (r.get("hbm") or {}).get("frac"),
+             "kernel_ms_in_timed_region": r.get("kernel_ms_in_timed_region"),
              "traffic_over_bytes": r.get("traffic_over_algorithmic"),
              "mfma_frac": (r.get("mfma") or {}).get("frac")}
     pf = r.get("prefilter_per_batch")
@@ -251,11 +253,12 @@ def _configs_summary(cfg):
         else:
             h = c3.get("hnsw_sq_walk_rescore", {})
             bf = c3.get("brute_force_oversampling2_rescore", {})
+            put("C3.walk_iid_rows", cfg.get("C3_walk_on_iid_rows"))
             put("C3.scan_Q1", bf.get("Q1"))
             put("C3.scan_Q32", bf.get("Q32"))
             put("C3.walk", h)
             ow = h.get("oracle_walk_check", {})
-            out["C3"] = {"build_s": h.get("build_s"), "oracle_walk": _walk_summary(ow, h.get("reference_heap_order")),
+            out["C3"] = {"rows": "latent-32 (+ the walk on C2's iid rows: walk_iid_rows)", "build_s": h.get("build_s"), "oracle_walk": _walk_summary(ow, h.get("reference_heap_order")),
                          "oracle_scan_ok": all(v is True for v in c3.get("oracle_check", {"-": None}).values())}
     tq = cfg.get("TQ4")
     if isinstance(tq, dict):
@@ -278,7 +281,7 @@ def _configs_summary(cfg):
             put("C4.walk_lut_free", w.get("no_rescoring_lut_free_walk"))
             put("C4.scan_Q32", c4.get("brute_force_Q32_oversampling2_rescore"))
             ow = h.get("oracle_walk_check", {})
-            out["C4"] = {"build_s": h.get("build_s"), "lut_mfma": _pick(lut.get("kernel_roofline", lut.get("roofline", {})), "achieved", "peak", "frac", "kernel_ms"),
+            out["C4"] = {"rows": "latent-32", "build_s": h.get("build_s"), "hop_prefilter": _pick(h.get("hop_prefilter", {}), "survivors_per_hop", "G_requests_per_s"), "lut_mfma": _pick(lut.get("kernel_roofline", lut.get("roofline", {})), "achieved", "peak", "frac", "kernel_ms"),
                          "oracle_walk": _walk_summary(ow, h.get("reference_heap_order"))}
     out[LEG_COLUMNS] = legs
     return out
@@ -584,7 +587,7 @@ def main(argv=None):
             dist.destroy_process_group()
         return
 
-    from bench_sections import (c1_section, c3_section, c4_section, cpu_baseline, derived_copy_point, hbm_point, one_process_fanout, robustness, tq_section,
+    from bench_sections import (c1_section, c3_section, c4_section, cpu_baseline, iid_walk_leg, derived_copy_point, hbm_point, one_process_fanout, robustness, tq_section,
                                 _counters_dict)
     kms, kl = C.c_float(), C.c_uint32()
     for be, _ in lanes:       # the scan launches of every batch in flight
@@ -600,6 +603,22 @@ def main(argv=None):
     else:
         kernel_ms = kms.value / max(1, kl.value)
 
+    # With several batches in flight an event pair around a scan also holds the time the launch WAITED behind another batch's scan (one block per CU: the scans
+    # take turns), so the timed region's figure is not the kernel's duration.  The kernel's own: the same steps with ONE batch in flight, right here (untimed).
+    kernel_ms_in_flight = kernel_ms
+    if world == 1 and len(lanes) > 1:
+        be0, se0 = lanes[0]
+        torch.cuda.synchronize(dev)
+        F.check(lib.qmx_query_timing(be0.qh, C.byref(C.c_float()), C.byref(C.c_uint32())))      # reset
+        for i in range(16):
+            b = i % nbatches
+            with torch.cuda.stream(be0.stream):
+                be0.local_topk(queries[b * Q:(b + 1) * Q], top, se0.out, se0.counts)
+        torch.cuda.synchronize(dev)
+        m1, l1 = C.c_float(), C.c_uint32()
+        F.check(lib.qmx_query_timing(be0.qh, C.byref(m1), C.byref(l1)))
+        if l1.value:
+            kernel_ms = m1.value / l1.value
     # bytes the dominant kernel of the timed step has to read per launch: the f32 block (3072 B/row at d=768) for the exact scans; the derived
     # copy the prefilter scans (QMX_SEG_I8_COPY: 1 B / element, QMX_SEG_HALF_COPY: 2 B, QMX_SEG_SPLIT_COPY: 4 B) when that is the kernel that ran
     half_copy = "scan_f16pair_kernel<true>" in kernel_symbol or "scan_f16half256_kernel" in kernel_symbol
@@ -619,6 +638,9 @@ def main(argv=None):
     if prefilter:
         result["dtype"] = "f32 (%s prefilter + exact f32 re-score)" % ("int8" if i8_copy else "f16")
     result["roofline"] = _roofline(n, dim, kernel_ms, alg_bytes, achieved, int(kl.value), launches_per_step, Q, kernel_symbol, launches_per_pass)
+    result["roofline"]["kernel_ms_of"] = ("one batch in flight (16 steps right after the timed region): the kernel's own duration" if kernel_ms != kernel_ms_in_flight
+                                          else "the timed region")
+    result["roofline"]["kernel_ms_in_timed_region"] = round(kernel_ms_in_flight, 4)     # (event pairs there include the wait behind the other batches' scans)
 
     if world > 1:
         # the three stages of a step, measured in their own untimed run (stream events around local search / all-gather / merge on every lane)
@@ -746,6 +768,12 @@ def main(argv=None):
                 cfg["C1"] = c1_section(ctx)
             except Exception as e:
                 cfg["C1"] = {"error": repr(e)[:400]}
+        if "c3" in wanted and not args.no_iid_walk:
+            try:        # (before C3 refills the block: the C3 walk on the rows SURVEY 8(d) names - C2's own iid rows)
+                cfg["C3_walk_on_iid_rows"] = iid_walk_leg(ctx, rows, queries)
+            except Exception as e:
+                cfg["C3_walk_on_iid_rows"] = {"error": repr(e)[:400]}
+            torch.cuda.empty_cache()
         if "c3" in wanted:
             try:
                 cfg["C3"], rows = c3_section(ctx, rows)

@@ -759,8 +759,13 @@ QMX_API int32_t qmx_hnsw_create_from_file(const void *bytes, uint64_t n_bytes, c
  * qmx_rescore call, as in hnsw/read_view/search.rs.  ef is raised to `top` (:549); max(top, ef) <= 4096
  * (up to 512 the beam lives in registers, beyond it in LDS).
  *   out : [nq][top], out_counts : [nq].  Results equal the reference's whenever the scores met
- *   on the walk are distinct (ties are BinaryHeap-order dependent in the reference).
- *   counters->vectors_scored = points scored over all searches (HardwareCounter cpu). */
+ *   on the walk are distinct.  AMONG EQUAL SCORES the default walk orders candidates by ascending id where the reference's order is that of
+ *   its two binary heaps (search_context.rs:8-40): on integer-score storages (SQ, u8, BQ, 1-bit TurboQuant) the id lists can differ from the
+ *   reference's inside runs of equal scores, and a walk that parts from the reference's at a tie may visit other points afterwards.  For the
+ *   reference's own lists set the option "hnsw_reference_heap_order" (the two heaps kept on the device in std's sift order: the reference's
+ *   ids, score bits and pop sequence; see qmx_hnsw_search_traced for what it costs and what is pinned).
+ *   counters->vectors_scored = points scored over all searches (HardwareCounter cpu).  PQ walks through per-search LUTs also report the hop
+ *   prefilter: counters->prefilter_candidates = level-0 candidates that met the 8-bit bound, counters->verified_rows = those scored exactly. */
 QMX_API int32_t qmx_hnsw_search(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
                                 qmx_scored_point *out, uint32_t *out_counts,
                                 const volatile uint8_t *is_stopped, qmx_counters *counters);

@@ -383,6 +383,8 @@ struct Beam<0> {
 // HBM bitmap for that id.  An id is recorded in exactly one of the two places (the bucket is consulted first, and a full bucket never frees a slot while the
 // search runs: unset() marks the slot instead of emptying it), so the set is exact: same fresh / visited answers as the bitmap alone, hence the same
 // walk.  Graphs of more than 65534 x 1024 points (tags would not fit), ACORN and the reference-heap mode keep the bitmap.
+// (One search = one wave = one work-group of 64 threads - `__launch_bounds__(64)` on the walk kernels: the plain 16-byte read of a bucket below races with
+// nobody but the lanes of its own wave, whose LDS operations execute in order.  A launch with more than one wave per group would need atomic bucket reads.)
 struct LdsVisited {
     uint32_t *tab;      // LDS, 4096 words; nullptr: the bitmap only
     // -> true when `id` was visited before; *in_bitmap: the id lives (now or already) in the HBM bitmap, not in the table
@@ -1237,6 +1239,12 @@ __global__ __launch_bounds__(64) QMX_WALK_KERNEL_ATTR void hnsw_search_kernel(co
                 __syncthreads();
                 for (uint32_t e = 0; e < ne; ++e) {
                     const uint32_t t0 = a.mv_qfirst[cq.first + e], nt = a.mv_qfirst[cq.first + e + 1] - t0;
+                    // (the visited table and the PQ image sit right behind the query entry: an example that did not fit the launch's entry must not be
+                    // staged over them - the search is refused instead)
+                    if (sizeof(CustomHeader) + (uint64_t)off + 16 + (uint64_t)nt * a.q_stride > h.lds_query_bytes) {
+                        if (lane == 0) *a.err_flag = 1;
+                        break;
+                    }
                     if (lane == 0) {
                         tab[e] = off + 16;
                         *reinterpret_cast<uint32_t *>(base + off) = nt;

@@ -153,11 +153,11 @@ def test_gpus_2_launches_its_own_ranks_and_reports_two(tmp_path):
     assert full["merged_checksum"] == checksum
 
 
-@pytest.mark.parametrize("name", ["r5_bench", "r5_bench_driver_form"])
-def test_the_committed_round5_headline_is_what_headline_makes_of_the_committed_details(name):
-    """profiles/r5_bench_headline.json is the last stdout line of the round's final `python bench.py`, profiles/r5_bench_details.json the full result of the same
+@pytest.mark.parametrize("name", ["r6_bench", "r6_bench_driver_form"])
+def test_the_committed_round6_headline_is_what_headline_makes_of_the_committed_details(name):
+    """profiles/r6_bench_headline.json is the last stdout line of the round's final `python bench.py`, profiles/r6_bench_details.json the full result of the same
     run: the line must be reproducible from the details, fit 4 KB with nothing dropped, and carry the SURVEY 8(d) block stream as its top-level roofline."""
-    # (r5_bench: `python bench.py`, 100 steps; r5_bench_driver_form: the command as the driver runs it, `python3 bench.py --gpus 1 --steps 20 --warmup 5`, final bench.py)
+    # (r6_bench: `python bench.py`, 100 steps; r6_bench_driver_form: the command as the driver runs it, `python3 bench.py --gpus 1 --steps 20 --warmup 5`, final bench.py)
     line = open(os.path.join(ROOT, "profiles", name + "_headline.json")).read().strip().splitlines()[-1]
     h = json.loads(line)
     full = json.load(open(os.path.join(ROOT, "profiles", name + "_details.json")))

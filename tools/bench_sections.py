@@ -518,7 +518,8 @@ def _oracle_walk_check(qa, np, graph, scorer, walker, oracle_walk, nchk, top, ef
     """The CPU oracle walks THE SAME graph with its scorer (host copy of the codes + links).  Three comparisons over `nchk` searches:
       default walk      same_ids / same_score_bits of the first `top` results (the device orders equal scores by ascending id: lists may differ at ties);
       tie_explained     per search whose pop sequence differs from the oracle's: the first differing position holds two bit-equal scores
-                        (tests/parity_asserts.first_divergence_is_a_tie) - anything else is printed as a PARITY FAILURE and listed;
+                        (tests/parity_asserts.first_divergence_is_a_tie) AND the reference-order run of that search is the oracle's walk - anything
+                        else is printed as a PARITY FAILURE and listed;
       reference order   option hnsw_reference_heap_order (the reference's two binary heaps on the device): lists AND pop sequences must be the oracle's.
     Walks run with top = ef so that the returned list is the whole `nearest` (its last score is the bound when a walk ends)."""
     from parity_asserts import first_divergence_is_a_tie
@@ -530,11 +531,23 @@ def _oracle_walk_check(qa, np, graph, scorer, walker, oracle_walk, nchk, top, ef
     got, got_pops = graph.search_traced(ef, ef, scorer)
     same_ids = sum(int(a["idx"][:top].tolist() == b["idx"][:top].tolist()) for a, b in zip(got, want))
     same_bits = sum(int(np.array_equal(bits(a["score"][:top]), bits(b["score"][:top]))) for a, b in zip(got, want))
+    # the same searches with the reference's heaps on the device first: a search whose default walk parts from the oracle's at a tie is "explained" ONLY IF its
+    # reference-order run then IS the oracle's walk, pops and lists (a defect behind an early tie would show there: the first divergence alone proves little)
+    qa.set_option("hnsw_reference_heap_order", 1)
+    try:
+        ref, ref_pops = graph.search_traced(ef, ef, scorer)
+    finally:
+        qa.set_option("hnsw_reference_heap_order", -1)
+    ref_same = [bool(a["idx"].tolist() == b["idx"].tolist() and np.array_equal(bits(a["score"]), bits(b["score"]))
+                     and ap["idx"].tolist() == bp["idx"].tolist() and np.array_equal(bits(ap["score"]), bits(bp["score"])))
+                for a, b, ap, bp in zip(ref, want, ref_pops, want_pops)]
     differing, explained, bad = 0, 0, []
     for qi in range(nchk):
         v = first_divergence_is_a_tie(got_pops[qi], want_pops[qi], bound_score=got[qi]["score"][-1] if len(got[qi]) == ef else None)
         if v != "same":
             differing += 1
+            if v == "tie" and not ref_same[qi]:
+                v = "a tie at the first divergence, but the reference-order run of the same search is not the oracle's walk"
             explained += v == "tie"
             if v != "tie":
                 bad.append("search %d: %s" % (qi, v))
@@ -543,17 +556,43 @@ def _oracle_walk_check(qa, np, graph, scorer, walker, oracle_walk, nchk, top, ef
     if bad:
         out["unexplained"] = bad[:8]
         print("PARITY FAILURE: HNSW walk differs from the oracle away from a tie: %s" % bad[:3], file=sys.stderr)
-    qa.set_option("hnsw_reference_heap_order", 1)
-    try:
-        ref, ref_pops = graph.search_traced(ef, ef, scorer)
-    finally:
-        qa.set_option("hnsw_reference_heap_order", -1)
     out["reference_heap_order_same_ids"] = "%d/%d" % (sum(int(a["idx"].tolist() == b["idx"].tolist()) for a, b in zip(ref, want)), nchk)
     out["reference_heap_order_same_score_bits"] = "%d/%d" % (sum(int(np.array_equal(bits(a["score"]), bits(b["score"]))) for a, b in zip(ref, want)), nchk)
     out["reference_heap_order_same_pops"] = "%d/%d" % (sum(int(a["idx"].tolist() == b["idx"].tolist() and np.array_equal(bits(a["score"]), bits(b["score"])))
                                                            for a, b in zip(ref_pops, want_pops)), nchk)
     out["seconds"] = round(time.perf_counter() - t0, 1)
     return out
+
+
+def iid_walk_leg(ctx, rows, queries):
+    """SURVEY 8(d) names C3's rows as C2's: iid N(0,1) coordinates, normalised.  HNSW recall on such rows is hopeless (no neighbourhood structure in 768
+    dimensions), which is why the C3 / C4 legs run on rows of low intrinsic dimension - but walk THROUGHPUT depends on the data (hops per search, what the beam
+    admits), so this leg runs the C3 walk once on the rows the contract names, for the record: SQ int8 codes of the C2 block, graph built through the SQ
+    scorer (m = 16, ef_construct = 100), ef = 128, no rescoring."""
+    args, dev, lib, F, qa, np, torch = (ctx[k] for k in ("args", "dev", "lib", "F", "qa", "np", "torch"))
+    n, dim = rows.shape
+    top, nq_h = 10, min(args.hnsw_queries, int(queries.shape[0]))
+    vs = qa.VectorStorage(rows, qa.Distance.Cosine)
+    quant = qa.ScalarQuantizer.fit(rows, dim, qa.Distance.Dot)
+    p = quant.params()
+    codes = torch.empty((n, quant.quantized_vector_size()), dtype=torch.uint8, device=dev)
+    F.check(lib.qmx_sq_encode(dev.index or 0, int(qa.Distance.Dot), C.byref(p), F.ptr(rows), n, dim, F.ptr(codes)))
+    enc = qa.EncodedVectorsU8(codes, quant)
+    del codes
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    graph = qa.GraphLayers.build(enc, m=16, ef_construct=100, seed=42)
+    t_build = time.perf_counter() - t0
+    qh = queries[:nq_h].contiguous()
+    scorer, raw = qa.new_raw_scorer(qh, enc), qa.new_raw_scorer(qh, vs)
+    res, st, scored = _timed_quantized(ctx, scorer, raw, top, 0.0, False, graph, 128, 3, quant.quantized_vector_size())
+    n_gt = min(256, nq_h)
+    exact = qa.BatchFilteredSearcher(queries[:n_gt].cpu().numpy(), vs, top).peek_top_all()
+    st.update({"rows": "the C2 block: %s x d=%d iid N(0,1), normalised (SURVEY 8d's C3 rows)" % (_human(n), dim), "m": 16, "ef_construct": 100, "ef": 128,
+               "searches_per_launch": nq_h, "build_s": round(t_build, 2), "points_scored_per_query": round(scored / nq_h, 1),
+               "recall_at_10_vs_exact": round(_recall(res[:n_gt], exact, top), 4),
+               "note": "recall on iid 768-d rows is what HNSW gives there at any ef a search can afford; the figure that matters is kernel_ms / frac beside the latent-row leg's"})
+    return st
 
 
 def c3_section(ctx, rows):

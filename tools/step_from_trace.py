@@ -11,7 +11,7 @@ big = [i for i, r in enumerate(rows) if any(m in r["Kernel_Name"] for m in main)
 if len(big) < 6:
     print("too few main-kernel launches", len(big))
     sys.exit(0)
-a, b = big[-4], big[-3]
+a, b = big[len(big) // 2 - 1], big[len(big) // 2]        # (the middle of the run: the timed region, not the one-batch-in-flight steps behind it)
 t0 = int(rows[a]["End_Timestamp"])
 prev = t0
 print("one step = from the end of one main scan to the end of the next (us)")
