@@ -511,7 +511,8 @@ def main(argv=None):
     fence()
     # (the spread of the timed region, without touching it: every `gsz` steps an event on EVERY lane's stream, read after the closing fence; a group ends
     # when its last lane does)
-    gsz = len(lanes) * max(1, int(round(args.steps / 10.0 / len(lanes))))      # (a group is whole rounds over the lanes: every lane works in every group)
+    # (a group is at least two whole rounds over the lanes: the batches in flight finish out of order by up to a step, a shorter group measures that jitter)
+    gsz = len(lanes) * max(2, int(round(args.steps / 8.0 / len(lanes))))
     calls0 = sharded.COLLECTIVE_CALLS
 
     def mark():
@@ -558,7 +559,7 @@ def main(argv=None):
         "value": round(value, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         # spread over groups of steps inside the timed region (device time between stream events): standard deviation of the groups' QPS
-        "value_stddev": round(_stddev([Q / (m * 1e-3) for m in group_ms if m > 0]), 2),
+        "value_stddev": round(_stddev([Q / (m * 1e-3) for m in group_ms if m > 0]), 2) if len(group_ms) >= 3 else None,
         "step_groups": {"steps_per_group": gsz, "ms_per_step_min": round(min(group_ms), 4) if group_ms else None,
                         "ms_per_step_max": round(max(group_ms), 4) if group_ms else None},
         "higher_is_better": True, "scaling": "strong" if strong else "weak",

@@ -876,6 +876,28 @@ int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
         h.pq8_stride = st8;
         h.vis_lds = 0;
     }
+    // ... and the LUT-free walk (HopPQDirect) prefilters its hops on the image of the EXACT-ORDER LUT - the entries it recomputes; a batch whose LUTs came
+    // from the matrix cores (<= 1e-5 off that order) gets exact-order LUTs made for the image alone
+    if (pq_direct && !acorn && !xo && !h.ref_heaps && !option(OPT_HNSW_NO_PQ_PREFILTER) && s->pq_m <= 128 && s->pq.n_centroids <= 256) {
+        const uint32_t st8 = pq_walk_lut8_stride(s->pq_m);
+        const size_t lut_bytes = (size_t)s->pq_m * s->pq.n_centroids * sizeof(float);
+        const void *luts = q->d_queries;
+        uint32_t lstride = q->q_stride;
+        const bool dotlike = s->distance == QMX_DISTANCE_DOT || s->distance == QMX_DISTANCE_COSINE;
+        if (s->pq.lut_mfma && dotlike) {
+            qmx_pq_params exact = s->pq;
+            exact.lut_mfma = 0;
+            QMX_TRY(q->hnsw_lutx.reserve((size_t)n_searches * lut_bytes));
+            QMX_TRY(launch_pq_lut(q->stream, s->distance, s->dim, exact, s->d_centroids, (const float *)q->enc.p, n_searches, (float *)q->hnsw_lutx.p));
+            luts = q->hnsw_lutx.p;
+            lstride = (uint32_t)lut_bytes;
+        }
+        QMX_TRY(q->hnsw_pq8.reserve((size_t)n_searches * st8));
+        QMX_TRY(launch_pq_walk_lut8(q->stream, luts, lstride, n_searches, s->pq_m, s->pq.n_centroids, q->hnsw_pq8.p));
+        h.pq8 = (const unsigned char *)q->hnsw_pq8.p;
+        h.pq8_stride = st8;
+        h.vis_lds = 0;
+    }
     h.log_cap = HNSW_LOG_CAP;
     {   // tests: force the whole-bitmap clear path
         const int64_t v = option(OPT_HNSW_LOG_CAP);

@@ -171,6 +171,7 @@ struct qmx_query {
     DevBuf filter;             // payload-filter allow bitmap of this query batch (qmx_query_set_filter)
     uint64_t n_filter_bits = 0;
     bool has_filter = false;
+    DevBuf hnsw_lutx;          // exact-order LUTs made for the hop prefilter's image of a LUT-free walk whose batch LUTs came from the matrix cores
     DevBuf hnsw_pq8;           // the 8-bit LUT images of the batch for the PQ walk's hop prefilter (HnswArgs::pq8)
     DevBuf hnsw_next;          // the walk's work counter (HnswArgs::next_query)
     DevBuf hnsw_refc;          // option hnsw_reference_heap_order: the per-slot `candidates` heaps

@@ -196,6 +196,10 @@ int32_t qmx_query_destroy(qmx_query *q) {
     q->hnsw_vis.release();
     q->hnsw_log.release();
     q->hnsw_scored.release();
+    q->hnsw_pq8.release();
+    q->hnsw_lutx.release();
+    q->hnsw_next.release();
+    q->hnsw_refc.release();
     for (auto &p : q->evs) {
         if (p.a) (void)hipEventDestroy(p.a);
         if (p.b) (void)hipEventDestroy(p.b);

@@ -733,12 +733,18 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
         __syncthreads();                    // (the previous search of this block is done with the LDS heap)
         RefHeaps rh;
         rh.init(beam_lds, ef, h.ref_cands + (uint64_t)blockIdx.x * h.ref_cap, h.ref_cap, beam_lds + hnsw_beam_lds(ef), HNSW_REF_CAND_LDS);
-        uint32_t log_cnt = 1, n_pop = 0;
-        if (lane == 0) {
-            atomicOr(&vis[cur_id >> 5], 1u << (cur_id & 31));
-            vlog[0] = cur_id >> 5;
-            rh.process_candidate(cur_id, cur_score);
+        uint32_t log_cnt = 0, n_pop = 0;
+        const LdsVisited lv{vtab};             // (round 6: the visited set in LDS here too - an exact set either way, hnsw.hpp LdsVisited)
+        if (lv.tab) {
+            if (lane == 0) { bool in_bm; lv.test_and_set(cur_id, vis, &in_bm); }
+        } else {
+            if (lane == 0) {
+                atomicOr(&vis[cur_id >> 5], 1u << (cur_id & 31));
+                vlog[0] = cur_id >> 5;
+            }
+            log_cnt = 1;
         }
+        if (lane == 0) rh.process_candidate(cur_id, cur_score);
         while (true) {
             uint32_t ok = 0, c_idx = 0, c_bits = 0;
             if (lane == 0) {
@@ -777,25 +783,48 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
                 const uint32_t id = h.l0 ? (on ? packed_id : 0) : (on ? h.neighbors[i] : 0);
                 const bool live = on && id < h.n_points && a.del.live(id);
                 const uint32_t bit = 1u << (id & 31);
-                const uint32_t old = live ? atomicOr(&vis[id >> 5], bit) : bit;
-                bool keep = live && !(old & bit);
+                bool in_bm = true, was_visited = true;
+                if (lv.tab) {
+                    if (live) was_visited = lv.test_and_set(id, vis, &in_bm);
+                } else {
+                    const uint32_t old = live ? atomicOr(&vis[id >> 5], bit) : bit;
+                    was_visited = (old & bit) != 0;
+                }
+                bool keep = live && !was_visited;
                 const uint64_t mask = __ballot(keep);
                 const uint32_t rank = (uint32_t)__popcll(mask & lt_mask);
                 uint32_t k = (uint32_t)__popcll(mask);
                 if (k > remaining) {
-                    if (keep && rank >= remaining) { atomicAnd(&vis[id >> 5], ~bit); keep = false; }
+                    if (keep && rank >= remaining) { lv.unset(id, vis, in_bm); keep = false; }
                     k = remaining;
                 }
                 remaining -= k;
                 __syncthreads();
-                if (keep) {
-                    hop_ids[rank] = id;
-                    if (log_cnt + rank < h.log_cap) vlog[log_cnt + rank] = id >> 5;
+                if (keep) hop_ids[rank] = id;
+                {   // the bitmap words this search dirtied (with the LDS table: only the ids of full buckets)
+                    const uint64_t bm = __ballot(keep && in_bm);
+                    const uint32_t brank = (uint32_t)__popcll(bm & lt_mask);
+                    if (keep && in_bm && log_cnt + brank < h.log_cap) vlog[log_cnt + brank] = id >> 5;
+                    log_cnt += (uint32_t)__popcll(bm);
                 }
-                log_cnt += k;
                 hop_score<H>(a, qp, hop_ids, hop_scores, k, lane);
-                if (lane == 0)
-                    for (uint32_t j = 0; j < k; ++j) rh.process_candidate(hop_ids[j], hop_scores[j]);      // in link order (graph_layers.rs:139-143)
+                {
+                    // process_candidate in link order (graph_layers.rs:139-143), by one lane.  A candidate that does not beat the root of a FULL `nearest` at
+                    // the start of the hop cannot beat it later in the hop either (the root only rises): push would hand it back (`Some(value)`,
+                    // fixed_length_priority_queue.rs:47-59) and nothing changes - those are told apart by all lanes at once, the one lane walks the others
+                    const bool full = __builtin_amdgcn_readfirstlane((int)(rh.n_len >= rh.n_cap)) != 0;
+                    const uint32_t root_bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)(full ? rh.nd[0].y : 0u));
+                    const bool mine = (uint32_t)lane < k;
+                    const bool may_enter = mine && (!full || RefHeaps::of_cmp(__uint_as_float(root_bits), hop_scores[mine ? lane : 0]) < 0);
+                    uint64_t todo = __ballot(may_enter);
+                    if (lane == 0) {
+                        while (todo) {
+                            const uint32_t j = (uint32_t)__builtin_ctzll(todo);
+                            todo &= todo - 1;
+                            rh.process_candidate(hop_ids[j], hop_scores[j]);
+                        }
+                    }
+                }
                 n_scored += k;
                 __syncthreads();
             }
@@ -815,6 +844,7 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
             if (rh.overflow) *a.err_flag = 2;
         }
         __syncthreads();
+        lv.clear(lane);
         if (log_cnt <= h.log_cap) {
             for (uint32_t i = (uint32_t)lane; i < log_cnt; i += 64) vis[vlog[i]] = 0;
         } else {
@@ -1178,7 +1208,7 @@ __global__ __launch_bounds__(64) QMX_WALK_KERNEL_ATTR void hnsw_search_kernel(co
     uint32_t *vis = h.visited + (uint64_t)blockIdx.x * h.vis_words;
     uint32_t *vlog = h.vis_log + (uint64_t)blockIdx.x * h.log_cap;
     // the search's visited table (LdsVisited), behind everything else: zero once here, every search leaves it zero
-    uint32_t *vtab = h.vis_lds ? reinterpret_cast<uint32_t *>(beam_lds + (E <= 0 ? hnsw_beam_lds(h.ef > h.top ? h.ef : h.top) : 0)) : nullptr;
+    uint32_t *vtab = h.vis_lds ? reinterpret_cast<uint32_t *>(beam_lds + (E <= 0 ? hnsw_beam_lds(h.ef > h.top ? h.ef : h.top) : 0) + (E == HNSW_E_REF ? (size_t)HNSW_REF_CAND_LDS * 8 : 0)) : nullptr;
     if (vtab) {
         LdsVisited{vtab}.clear(lane);
         __syncthreads();

@@ -211,7 +211,7 @@ constexpr uint32_t HNSW_VIS_LDS_MAX_POINTS = 65534u * 1024u;    // ... graphs wh
 constexpr uint32_t HNSW_REF_CAND_CAP = 1u << 16;   // option hnsw_reference_heap_order: entries of one search's `candidates` heap (512 KiB per slot)
 constexpr uint32_t HNSW_EV_SPILL_CAP = 4096;      // search_with_vectors: evicted candidates of ONE score a slot can hold beyond four (32 KiB per slot; more raises err_flag = 2)
 constexpr uint32_t HNSW_REF_SLOT_CAP = 4096;       // ... searches in flight in that mode (1 024 until round 5: fewer than the default walk keeps in flight)
-constexpr uint32_t HNSW_REF_CAND_LDS = 1536;       // ... entries of that heap kept in LDS (12 KiB per search): the levels every sift touches
+constexpr uint32_t HNSW_REF_CAND_LDS = 1024;       // ... entries of that heap kept in LDS (8 KiB per search): the ten levels every sift touches
 constexpr uint32_t HNSW_MAX_EF = 4096;          // max(top, ef) of a walk: up to 512 in a register beam, beyond it in an LDS beam (hnsw.hpp Beam<0>)
 constexpr uint32_t HNSW_BUILD_MAX_M0 = 128;     // links per level-0 list of a device build (m <= m0 <= 128)
 constexpr uint32_t HNSW_MAX_EF_REG = 512;       // ... and of ef_construct (the build keeps its beam in registers)

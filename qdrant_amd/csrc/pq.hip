@@ -534,6 +534,14 @@ struct HopPQDirect {
     static constexpr bool MULTI = false;
     static constexpr bool INTERNAL_QOFF = false;
     static constexpr bool INTERNAL_NORM = false;
+    // The hop prefilter of HopPQ serves this walk too (round 6): the 8-bit image of the search's EXACT-ORDER LUT (HnswArgs::pq8, staged in LDS) bounds the
+    // scores recomputed here from the codebook - the same entries, pq_lut_kernel's chain -, so a candidate whose bound stays below the beam's worst score
+    // leaves without the codebook arithmetic, and the survivors' entries come from the 1.5 MB codebook every search shares in L2 instead of from a
+    // 96 KiB per-search LUT that misses it: the walk's memory requests are its code rows and link rows.
+    static constexpr bool HOP_PREFILTER = true;
+    static __device__ __forceinline__ uint32_t prefilter(const ScanArgs &a, const unsigned char *pq8, uint32_t *hop_ids, uint32_t k, uint64_t bound, int lane) {
+        return pq_hop_prefilter(a, pq8, hop_ids, k, bound, lane);
+    }
     static constexpr int V = CHUNK / 4;                      // 16-byte pieces of a chunk
     static constexpr int SPP = 32 / SPLIT;                   // steps per part at most (m <= 128)
     template <int KIND>
@@ -625,6 +633,8 @@ bool pq_direct_walk_ok(uint32_t dim, uint32_t m, uint32_t chunk, uint32_t ncent)
 int32_t launch_hnsw_pq_direct(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
     QMX_REQUIRE(a.pq_centroids && pq_direct_walk_ok(a.pq_dim, a.pq_m, a.pq_chunk, a.pq_ncent), QMX_ERR_BAD_ARG, "the LUT-free PQ walk does not take this codebook");
     // four lanes per SSE lane, two chunk steps (eight 16-byte loads) per round: the best of the shapes measured (profiles/r4_pq_direct_walk.md)
+    // (behind the hop prefilter - ~4 survivors per hop instead of ~14 candidates - eight parts per SSE lane, one round trip per pass, measured SLOWER: 17.5
+    // against 16.5 ms at 10 M x 1536 points, profiles/r6_walk_variants_ref_order.jsonl)
     if (a.pq_chunk == 16) return launch_hnsw_hop<HopPQDirect<16, 4, 2>>(st, a, h, grid, per_cu);
     if (a.pq_chunk == 8) return launch_hnsw_hop<HopPQDirect<8, 4, 4>>(st, a, h, grid, per_cu);
     return launch_hnsw_hop<HopPQDirect<4, 4, 8>>(st, a, h, grid, per_cu);

@@ -647,6 +647,48 @@ def test_pq_walk_hop_prefilter_is_the_same_walk(qa, distance, dim, chunk):
                 assert a["idx"].tolist() == w["idx"].tolist()
 
 
+@pytest.mark.parametrize("lut_mfma", [False, True])
+@pytest.mark.parametrize("distance,dim,chunk", [(O.DOT, 768, 8), (O.COSINE, 1536, 16), (O.EUCLID, 384, 4)])
+def test_lut_free_pq_walk_with_the_hop_prefilter_is_the_same_walk(qa, distance, dim, chunk, lut_mfma):
+    """Round 6: the LUT-free walk (option hnsw_pq_direct_walk, HopPQDirect: entries recomputed from the codebook in pq_lut_kernel's order) prefilters its hops
+    on the 8-bit image of the EXACT-ORDER LUT - also when the batch's own LUTs came from the matrix cores (lut_mfma: exact-order LUTs are then made for the
+    image alone).  Same walk as with the prefilter off: lists, pop sequences, scored points; and the oracle's walk (exact-order scores) of the same graph."""
+    n, m, nq = 4000, 8, 24
+    rows, st, g, plain = _graph(distance, n, dim, m, 0x5EED03D0 + dim)
+    queries = O.synth(0x5EED03D1, 0, nq, dim)
+    qpre = O.preprocess(distance, queries)
+    cen = O.PqOracle.train(rows[:2000], dim, chunk, 256, iters=2)
+    opq = O.PqOracle(distance, dim, chunk, cen)
+    codes = opq.encode(rows)
+    quant = qa.ProductQuantizer(dim, _dist(qa, distance), chunk, cen, lut_mfma=lut_mfma)
+    graph = qa.GraphLayers.from_plain(plain)
+    scorer = qa.new_raw_scorer(queries, qa.EncodedVectorsPQ(codes, quant))
+    qa.set_option("hnsw_pq_direct_walk", 1)
+    try:
+        for top, ef in ((10, 64), (20, 128)):
+            (got, pops), (_, scored) = graph.search_traced(top, ef, scorer), graph.search(top, ef, scorer, with_scored=True)
+            assert "HopPQDirect" in qa._ffi.last_kernel(scorer._h)
+            assert graph.counters.prefilter_candidates > graph.counters.verified_rows > 0          # the prefilter ran and dropped candidates
+            qa.set_option("hnsw_no_pq_prefilter", 1)
+            try:
+                (plain_lists, plain_pops), (_, plain_scored) = graph.search_traced(top, ef, scorer), graph.search(top, ef, scorer, with_scored=True)
+                assert graph.counters.prefilter_candidates == 0
+            finally:
+                qa.set_option("hnsw_no_pq_prefilter", -1)
+            assert scored == plain_scored
+            for a, b, pa, pb in zip(got, plain_lists, pops, plain_pops):
+                assert a["idx"].tolist() == b["idx"].tolist() and np.array_equal(a["score"].view(np.uint32), b["score"].view(np.uint32))
+                assert pa["idx"].tolist() == pb["idx"].tolist() and np.array_equal(pa["score"].view(np.uint32), pb["score"].view(np.uint32))
+            want, stats = g.search_pq(st, opq, qpre, top, ef, with_stats=True)
+            assert scored == sum(stats)
+            for a, w in zip(got, want):
+                assert np.array_equal(a["score"].view(np.uint32), w["score"].view(np.uint32))
+                if len(np.unique(w["score"])) == len(w):
+                    assert a["idx"].tolist() == w["idx"].tolist()
+    finally:
+        qa.set_option("hnsw_pq_direct_walk", -1)
+
+
 def test_lds_visited_table_answers_like_the_bitmap_with_full_buckets_and_over_long_lists(qa):
     """hnsw.hpp LdsVisited against the per-slot HBM bitmap alone (option hnsw_no_lds_visited), where the table works hardest: searches wide enough to fill its
     buckets (24 000 points, ef up to 3 000: ids sharing their low ten bits overflow into the bitmap) over a graph whose level-0 lists are LONGER than the m0 it
