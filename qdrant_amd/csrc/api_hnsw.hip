@@ -10,7 +10,7 @@ extern "C" {
 int32_t qmx_hnsw_destroy(qmx_hnsw *g) {
     if (!g) return QMX_OK;
     (void)hipSetDevice(g->device);
-    void *ptrs[] = {g->d_reindex, g->d_neighbors, g->d_ep_ids, g->d_ep_levels, g->d_xp_ids, g->d_xp_levels, g->d_level_offsets, g->d_offsets, g->d_l0};
+    void *ptrs[] = {g->d_reindex, g->d_neighbors, g->d_ep_ids, g->d_ep_levels, g->d_xp_ids, g->d_xp_levels, g->d_level_offsets, g->d_offsets, g->d_l0, g->d_l0x};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete g;
@@ -814,6 +814,30 @@ int32_t hnsw_enqueue(const qmx_hnsw *g, qmx_query *q, uint32_t top, uint32_t ef,
     memset(&h, 0, sizeof(h));
     h.reindex = g->d_reindex; h.level_offsets = g->d_level_offsets; h.offsets = g->d_offsets; h.neighbors = g->d_neighbors;
     h.l0 = g->d_l0; h.l0_stride = g->l0_stride;
+    // SQ segments, plain walk over a packed level 0: the link rows bring the linked rows' vector_offset along (scan_quant.hip RowSQX): the table is made once
+    // per (graph, segment) - 10 M points x 64 dwords = 2.56 GB, one gather pass - and costs the walk one more line per hop instead of a random request per row
+    if (s->dtype == QMX_DTYPE_SQ_U8 && g->d_l0 && !acorn && !xo && !mw && !cw && !(option(OPT_HNSW_REFERENCE_HEAP_ORDER) > 0) && s->d_row_offsets && g->n_points <= s->n) {
+        std::lock_guard<std::mutex> lock(g->l0x_mu);
+        // (the table belongs to the first SQ segment walked over this graph: another segment - another quantization of the same points - keeps the column;
+        // nothing is ever freed under a running kernel)
+        if (!g->d_l0x && !g->l0x_failed) {
+            const size_t bytes = (size_t)g->n_points * (2 * (g->l0_stride - 1)) * 4;
+            if (hipMalloc((void **)&g->d_l0x, bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                g->d_l0x = nullptr;
+                g->l0x_failed = true;
+            } else {
+                QMX_TRY(launch_hnsw_pack_level0_aux(q->stream, g->d_l0, g->n_points, g->l0_stride, s->d_row_offsets, s->n, g->d_l0x));
+                QMX_HIP(hipStreamSynchronize(q->stream));      // (other threads' streams read it once the lock is gone)
+                g->l0x_segment_uid = s->uid;
+            }
+        }
+        if (g->d_l0x && g->l0x_segment_uid == s->uid) {
+            h.l0 = g->d_l0x;
+            h.l0_aux_off = g->l0_stride - 1;               // = m0: the row is [m0 link slots][m0 offsets]
+            h.l0_stride = 2 * (g->l0_stride - 1);
+        }
+    }
     h.n_offsets = g->n_offsets; h.n_neighbors = g->n_neighbors;
     h.n_points = g->n_points; h.n_levels = g->n_levels; h.m = g->m; h.m0 = g->m0;
     h.ep_ids = g->d_ep_ids; h.ep_levels = g->d_ep_levels; h.n_ep = g->n_ep;

@@ -55,7 +55,12 @@ using namespace qmx;
 // ---------------------------------------------------------------------------------------------
 // handles
 // ---------------------------------------------------------------------------------------------
+inline uint64_t next_segment_uid() {
+    static std::atomic<uint64_t> counter{0};
+    return ++counter;
+}
 struct qmx_segment {
+    const uint64_t uid = next_segment_uid();      // never reused: what a cache keyed by a segment compares (a freed segment's address may come back)
     int device = 0;
     int num_cus = 256;
     uint32_t dtype = 0, distance = 0, dim = 0, flags = 0;
@@ -348,6 +353,12 @@ struct qmx_hnsw {
     uint64_t *d_level_offsets = nullptr, *d_offsets = nullptr;
     uint32_t *d_l0 = nullptr;     // packed level 0 [n_points][l0_stride]: count, links (built when every list fits 63 links)
     uint32_t l0_stride = 0;
+    // the same table with the SQ vector_offset of every linked row behind the links ([n_points][2 m0]), made at the first plain walk of an SQ segment
+    // over this graph and kept for that segment (its uid): searches share the graph across threads, hence the lock
+    mutable std::mutex l0x_mu;
+    mutable uint32_t *d_l0x = nullptr;
+    mutable uint64_t l0x_segment_uid = 0;
+    mutable bool l0x_failed = false;     // no memory for it: the walk keeps the offsets column
     // host copy of the plain arrays (graphs built by qmx_hnsw_build; empty otherwise) for qmx_hnsw_export_plain
     std::vector<uint32_t> h_reindex, h_neighbors, h_ep_ids, h_ep_levels, h_xp_ids, h_xp_levels;
     std::vector<uint64_t> h_level_offsets, h_offsets;

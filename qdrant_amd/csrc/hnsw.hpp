@@ -56,9 +56,15 @@ struct is_asymmetric { static constexpr bool value = false; };
 template <class H>
 struct is_asymmetric<H, decltype((void)H::ASYMMETRIC)> { static constexpr bool value = H::ASYMMETRIC; };
 
+template <class P, class = void>
+struct offset_by_caller { static constexpr bool value = false; };
+template <class P>
+struct offset_by_caller<P, decltype((void)P::OFFSET_BY_CALLER)> { static constexpr bool value = P::OFFSET_BY_CALLER; };
+
 template <class P>
 struct HopRow {
     static constexpr int LPI = 8;
+    static constexpr bool ADDS_OFFSET = offset_by_caller<P>::value;      // the policy's score lacks the row's offset: hop_score adds hop_scores[j]'s prefilled value
     static constexpr bool INTERNAL_QOFF = has_internal_qoff<P>::value;
     static constexpr bool INTERNAL_NORM = has_internal_norm<P>::value;
     static constexpr bool MULTI = true;     // score_multi<R>: R rows per 8-lane group in one pass
@@ -191,6 +197,10 @@ struct HopMaxSimInternal {
 };
 
 // a hop policy that can drop candidates on an upper bound of their score before the exact scoring (H::prefilter): HopPQ's 8-bit LUT image, pq.hip
+template <class H, class = void>
+struct hop_adds_offset { static constexpr bool value = false; };
+template <class H>
+struct hop_adds_offset<H, decltype((void)H::ADDS_OFFSET)> { static constexpr bool value = H::ADDS_OFFSET; };
 template <class H, class = void>
 struct has_hop_prefilter { static constexpr bool value = false; };
 template <class H>
@@ -607,16 +617,24 @@ __device__ __forceinline__ void hop_score_pass(const ScanArgs &a, const unsigned
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const uint32_t j = base + (uint32_t)(r * IPP + g);
-        if (j < k && sub == 0) hop_scores[j] = sc[r];
+        if (j < k && sub == 0) hop_scores[j] = hop_adds_offset<H>::value ? sc[r] + hop_scores[j] : sc[r];
     }
 }
 
+// (policies whose score lacks the row's offset - hop_adds_offset: RowSQX - find it in hop_scores[j]: put there by the caller with the links
+// (`have_offsets`), or gathered here from the offsets column)
 template <class H>
 __device__ __forceinline__ void hop_score(const ScanArgs &a, const unsigned char *qp, const uint32_t *hop_ids,
-                                          float *hop_scores, uint32_t k, int lane) {
+                                          float *hop_scores, uint32_t k, int lane, bool have_offsets = false) {
     constexpr int IPP = 64 / H::LPI;
     const int sub = lane % H::LPI, g = lane / H::LPI;
     __syncthreads();   // hop_ids written by other lanes
+    if constexpr (hop_adds_offset<H>::value) {
+        if (!have_offsets) {
+            for (uint32_t j = (uint32_t)lane; j < k; j += 64) hop_scores[j] = a.row_offsets[hop_ids[j]];
+            __syncthreads();
+        }
+    }
     if constexpr (is_tql1<H>::value) {      // the policy scores the hop as a wave (it ends on a barrier, like the loop below)
         H::hop(a, qp, hop_ids, hop_scores, k, lane);
         return;
@@ -632,7 +650,7 @@ __device__ __forceinline__ void hop_score(const ScanArgs &a, const unsigned char
         const bool on = j < k;
         const uint32_t id = hop_ids[on ? j : 0];
         const float s = H::score(a, qp, id, sub);
-        if (on && sub == 0) hop_scores[j] = s;
+        if (on && sub == 0) hop_scores[j] = hop_adds_offset<H>::value ? s + hop_scores[j] : s;
     }
     __syncthreads();
 }
@@ -1054,11 +1072,20 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
         // links of `cand` on level 0: the packed table needs ONE round trip (count and links are independent loads of the
         // same row), the CSR arrays two (offsets, then neighbors)
         uint64_t o0 = 0, o1 = 0;
-        uint32_t packed_id = 0;
+        uint32_t packed_id = 0, packed_off = 0;
         if (h.l0) {
             const uint32_t *rowp = h.l0 + (uint64_t)cand * h.l0_stride;
-            packed_id = (uint32_t)lane + 1 < h.l0_stride ? rowp[lane + 1] : 0;
-            o1 = rowp[0];
+            if (h.l0_aux_off) {
+                // an SQ graph's wider table (hnsw_pack_level0_aux_kernel): [m0 link slots, 0xFFFFFFFF behind the last link][the vector_offset of every linked
+                // row] - no count word, so that m0 = 32 makes a row of 256 bytes: two whole lines
+                const uint32_t link_slots = h.l0_aux_off;
+                packed_id = (uint32_t)lane < link_slots ? rowp[lane] : 0xFFFFFFFFu;
+                if constexpr (hop_adds_offset<H>::value) packed_off = (uint32_t)lane < link_slots ? rowp[link_slots + (uint32_t)lane] : 0u;
+                o1 = (uint64_t)__popcll(__ballot(packed_id != 0xFFFFFFFFu));
+            } else {
+                packed_id = (uint32_t)lane + 1 < h.l0_stride ? rowp[lane + 1] : 0;
+                o1 = rowp[0];
+            }
         } else {
             o0 = h.offsets[cand];
             o1 = h.offsets[(uint64_t)cand + 1];
@@ -1087,7 +1114,10 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
             }
             remaining -= k;
             __syncthreads();
-            if (keep) hop_ids[rank] = id;
+            if (keep) {
+                hop_ids[rank] = id;
+                if constexpr (hop_adds_offset<H>::value) hop_scores[rank] = __uint_as_float(packed_off);      // (read only when the row carried it: below)
+            }
             {   // the bitmap words this search dirtied (with the LDS table: only the ids of full buckets)
                 const uint64_t bm = __ballot(keep && in_bm);
                 const uint32_t brank = (uint32_t)__popcll(bm & lt_mask);
@@ -1102,7 +1132,7 @@ __device__ __forceinline__ void hnsw_search_one(const ScanArgs &a, const HnswArg
                     n_exact += k;
                 }
             }
-            hop_score<H>(a, qp, hop_ids, hop_scores, k, lane);
+            hop_score<H>(a, qp, hop_ids, hop_scores, k, lane, h.l0 != nullptr && h.l0_aux_off != 0);
             const uint64_t mykey = (uint32_t)lane < k ? make_key(hop_scores[lane], hop_ids[lane]) : 0;
             uint64_t mm = __ballot(mykey > beam.at(ef - 1));
             while (mm) {

@@ -104,6 +104,7 @@ struct HnswArgs {
     uint64_t n_offsets, n_neighbors; // entries of `offsets` / `neighbors`: the walk never reads past them, whatever a links file claims
     const uint32_t *l0;             // optional packed level 0: l0[p * l0_stride] = count, then the links (one round trip per hop)
     uint32_t l0_stride;
+    uint32_t l0_aux_off;            // 0, or m0: l0 is then the wider table of an SQ graph - a row = [m0 link slots, 0xFFFFFFFF behind the last][m0 f32: the linked rows' vector_offset]
     uint32_t n_points, n_levels, m, m0;
     const uint32_t *ep_ids, *ep_levels;   // EntryPoints::entry_points
     uint32_t n_ep;
@@ -206,6 +207,8 @@ static inline uint32_t pq_walk_lut8_stride(uint32_t m) { return 32u + m * 256u; 
 int32_t launch_pq_walk_lut8(hipStream_t st, const void *d_luts, uint32_t q_stride, uint32_t nq, uint32_t m, uint32_t ncent, void *d_out);
 int32_t launch_hnsw_bq(hipStream_t st, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu);
 int32_t launch_hnsw_pack_level0(hipStream_t st, const uint64_t *offsets, const uint32_t *neighbors, uint32_t n_points, uint32_t stride, uint32_t *l0);
+// the table again, each row followed by one f32 per link slot: aux[linked row] (SQ: the offsets column travels with the links)
+int32_t launch_hnsw_pack_level0_aux(hipStream_t st, const uint32_t *l0, uint32_t n_points, uint32_t stride, const float *aux, uint64_t n_aux, uint32_t *l0x);
 constexpr uint32_t HNSW_VIS_LDS_BYTES = 16384;                 // the walk's visited table in LDS (hnsw.hpp LdsVisited): 1024 buckets x 8 tags of 16 bits
 constexpr uint32_t HNSW_VIS_LDS_MAX_POINTS = 65534u * 1024u;    // ... graphs whose (id >> 10) + 1 fits a tag below the "taken back" mark 0xFFFF
 constexpr uint32_t HNSW_REF_CAND_CAP = 1u << 16;   // option hnsw_reference_heap_order: entries of one search's `candidates` heap (512 KiB per slot)

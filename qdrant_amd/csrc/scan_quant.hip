@@ -69,6 +69,34 @@ struct RowSQ {
     }
 };
 
+// RowSQ for the walk that brings the rows' offsets itself (hnsw.hpp: the level-0 link rows of an SQ graph carry the linked rows' vector_offset next to
+// their ids, so a hop's offsets arrive with its links - one more line of the link row instead of one random 4-byte request per scored row; the offsets
+// column cost the walk a fifth of its time, profiles/r6_sq_walk_offsets.md).  finish stops before the last add: multiplier * score + query_offset; the
+// caller adds vector_offset - the same three operations in the same order (postprocess_score, encoded_vectors_u8.rs:100-103).
+template <bool L1, bool SEP>
+struct RowSQX : RowSQ<L1, SEP> {
+    typedef RowSQ<L1, SEP> B;
+    static constexpr bool OFFSET_BY_CALLER = true;
+    static __device__ __forceinline__ float finish(typename B::acc_t (&a)[B::NACC], typename B::acc_t (&)[1], const unsigned char *q_lds,
+                                                   const unsigned char *, uint32_t, const ScanArgs &args) {
+        float f;
+        if (L1) {
+            f = (float)(int32_t)reduce8_u32(a[0]);
+        } else if (!SEP) {
+            f = (float)(int32_t)reduce8_u32((a[0] + a[1]) + (a[2] + a[3]));
+        } else {
+            float l[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) l[j] = (float)(int32_t)reduce8_u32(a[j]);
+            const float x0 = l[4] + l[0], x1 = l[5] + l[1], x2 = l[6] + l[2], x3 = l[7] + l[3];
+            f = (x0 + x2) + (x1 + x3);
+        }
+        const QueryAux *aux = reinterpret_cast<const QueryAux *>(q_lds + args.aux_off);
+        const float m = args.sq_multiplier * f;
+        return m + aux->f0;
+    }
+};
+
 // The same row policy with a STORED ROW as the query (HNSW build): the query entry is a bare code row, its offset
 // (vector_offset - shift, postprocess_internal_score :105-114) arrives in ScanArgs::sq_qoff (hnsw_build.hpp query_args).
 template <bool L1, bool SEP>
@@ -111,6 +139,12 @@ int32_t launch_pairs_sq(hipStream_t st, int distance, const ScanArgs &a, const P
     return dispatch_sq(PairLauncher{st, sel, n_items, num_cus}, distance, a);
 }
 int32_t launch_hnsw_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {
+    if (h.l0_aux_off) {      // the link rows carry the offsets (api_hnsw.hip: plain walks over a packed level 0)
+        const HnswLauncher l{st, &h, grid, per_cu};
+        if (distance == QMX_DISTANCE_MANHATTAN) return l.template row<RowSQX<true, false>>(a);
+        if ((uint64_t)127 * 127 * a.dim >= (1ull << 24)) return l.template row<RowSQX<false, true>>(a);
+        return l.template row<RowSQX<false, false>>(a);
+    }
     return dispatch_sq(HnswLauncher{st, &h, grid, per_cu}, distance, a);
 }
 int32_t launch_hnsw_custom_sq(hipStream_t st, int distance, const ScanArgs &a, const HnswArgs &h, uint32_t grid, int *per_cu) {

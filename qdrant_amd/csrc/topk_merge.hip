@@ -211,6 +211,28 @@ int32_t launch_hnsw_pack_level0(hipStream_t st, const uint64_t *offsets, const u
     return QMX_OK;
 }
 
+// row p of l0x = [the m0 = stride - 1 link slots of row p of l0, 0xFFFFFFFF behind the last link][aux of every link: f32 bits] (2 m0 dwords: no count word)
+__global__ void hnsw_pack_level0_aux_kernel(const uint32_t *l0, uint32_t n_points, uint32_t stride, const float *aux, uint64_t n_aux, uint32_t *l0x) {
+    const uint32_t m0 = stride - 1, stride_x = 2 * m0;
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t p = gid / m0;
+    const uint32_t slot = (uint32_t)(gid % m0);
+    if (p >= n_points) return;
+    const uint32_t cnt = l0[p * stride];
+    const uint32_t v = l0[p * stride + 1 + slot];
+    const bool on = slot < cnt;
+    l0x[p * stride_x + slot] = on ? v : 0xFFFFFFFFu;
+    l0x[p * stride_x + m0 + slot] = (on && v < n_aux) ? __float_as_uint(aux[v]) : 0u;
+}
+int32_t launch_hnsw_pack_level0_aux(hipStream_t st, const uint32_t *l0, uint32_t n_points, uint32_t stride, const float *aux, uint64_t n_aux, uint32_t *l0x) {
+    if (n_points == 0) return QMX_OK;
+    const uint64_t total = (uint64_t)n_points * (stride - 1);
+    ::qmx::clear_stale_error();
+    hipLaunchKernelGGL(hnsw_pack_level0_aux_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, l0, n_points, stride, aux, n_aux, l0x);
+    QMX_HIP(hipGetLastError());
+    return QMX_OK;
+}
+
 // candidates [nq][n_per] (ScoredPointOffset) -> ids [nq][n_per] (for the rescoring pass) and, when out != nullptr, the
 // first `top` entries + clamped counts (no rescoring: search_result.truncate(top), vector_index_search_common.rs:89)
 __global__ void split_candidates_kernel(const qmx_scored_point *cand, const uint32_t *cand_cnt, uint32_t n_per, uint32_t nq, uint32_t *ids,
