@@ -95,6 +95,10 @@ def parse(argv=None):
                          "milliseconds so that clocks, both batches in flight and the allocator are where a serving process has them; reported in config.prewarm_steps")
     ap.add_argument("--details", default=os.path.join(ROOT, "bench_details.json"), help="where the full result (every leg) is written")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="collective backend of N>1 (nccl = RCCL; gloo only with --test-backend)")
+    ap.add_argument("--ranks-share-gpu", action="store_true",
+                    help="TESTING the N > 1 path on a box with fewer GPUs than ranks: rank r runs on device r %% (visible devices), the collective is gloo over "
+                         "device tensors (--backend gloo).  Everything of the N > 1 experiment but RCCL itself runs - lanes, streams, the packed all-gather "
+                         "and merge on the device, the side legs after the process group - and the line says that it is no scaling measurement")
     ap.add_argument("--test-backend", default="",
                     help="module:factory of an injected compute backend (tests only: the launcher, the collective and the line on CPU; never a measurement)")
     return ap.parse_args(argv)
@@ -123,8 +127,12 @@ def resolve_world(args, argv, environ=None, device_count=None):
     environ = os.environ if environ is None else environ
     if args.gpus < 1:
         return ("fail", "--gpus must be >= 1")
-    if args.backend == "gloo" and not args.test_backend:
-        return ("fail", "--backend gloo needs --test-backend: the product has no CPU path")
+    if args.backend == "gloo" and not args.test_backend and not args.ranks_share_gpu:
+        return ("fail", "--backend gloo needs --test-backend (the product has no CPU path) or --ranks-share-gpu (device tensors over gloo: a test of the N > 1 path)")
+    if args.ranks_share_gpu and (args.backend != "gloo" or args.test_backend):
+        return ("fail", "--ranks-share-gpu goes with --backend gloo (RCCL refuses two ranks on one device) and the real compute backend")
+    if args.ranks_share_gpu:
+        device_count = None      # (any number of visible devices serves any number of ranks)
     if "WORLD_SIZE" in environ:
         world = int(environ["WORLD_SIZE"])
         if world != args.gpus:
@@ -392,6 +400,8 @@ def main(argv=None):
     if hip:
         import qdrant_amd as qa
         from qdrant_amd import _ffi as F
+        if args.ranks_share_gpu:
+            local_rank = local_rank % max(1, torch.cuda.device_count())      # (from here on: the DEVICE this rank runs on)
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
     else:
@@ -399,7 +409,7 @@ def main(argv=None):
     rccl_ranks = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if hip:
+        if hip and not args.ranks_share_gpu:
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
@@ -564,7 +574,8 @@ def main(argv=None):
                         "ms_per_step_max": round(max(group_ms), 4) if group_ms else None},
         "higher_is_better": True, "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic", "rccl_ranks": rccl_ranks,
-        "collective": ("none (one GPU)" if world == 1 else "RCCL over xGMI (torch.distributed nccl)" if hip else args.backend),
+        "collective": ("none (one GPU)" if world == 1 else "gloo over device tensors (--ranks-share-gpu: a test of the path, not RCCL)" if args.ranks_share_gpu else
+                       "RCCL over xGMI (torch.distributed nccl)" if hip else args.backend),
         "config": {"workload": workload,
                    "rows_per_gpu": n, "dim": dim, "batch": Q, "top": top, "distinct_queries": nbatches * Q,
                    "unit_of_value": ("queries per second against the ONE row-split segment" if strong else
@@ -575,6 +586,8 @@ def main(argv=None):
                    "batches_in_flight": len(lanes), "prewarm_steps": prewarm_steps,
                    "collectives_per_step": round(collectives_per_step, 3)},
     }
+    if args.ranks_share_gpu:
+        result["data"] = "synthetic; %d ranks SHARE %d device(s): a test of the N > 1 path, not a scaling measurement" % (world, torch.cuda.device_count())
     if not hip:
         # the launcher / collective / line under test: whatever the injected backend computed is NOT a measurement
         result["data"] = "TEST BACKEND %s on CPU: not a measurement" % args.test_backend
@@ -597,19 +610,14 @@ def main(argv=None):
         kms.value += m1.value
         kl.value += l1.value
     kernel_symbol = F.last_kernel(qh)
-    if world > 1:
-        km = torch.tensor([kms.value / max(1, kl.value)], dtype=torch.float64, device=dev)
-        dist.all_reduce(km, op=dist.ReduceOp.MAX)
-        kernel_ms = float(km.item())
-    else:
-        kernel_ms = kms.value / max(1, kl.value)
-
+    kernel_ms = kms.value / max(1, kl.value)
     # With several batches in flight an event pair around a scan also holds the time the launch WAITED behind another batch's scan (one block per CU: the scans
-    # take turns), so the timed region's figure is not the kernel's duration.  The kernel's own: the same steps with ONE batch in flight, right here (untimed).
+    # take turns), so the timed region's figure is not the kernel's duration.  The kernel's own: the same local searches with ONE batch in flight, right here
+    # (untimed; N > 1: every rank on its own device at once, no collective inside; the slowest rank's figure is reported).
     kernel_ms_in_flight = kernel_ms
-    if world == 1 and len(lanes) > 1:
+    if len(lanes) > 1:
         be0, se0 = lanes[0]
-        torch.cuda.synchronize(dev)
+        fence()
         F.check(lib.qmx_query_timing(be0.qh, C.byref(C.c_float()), C.byref(C.c_uint32())))      # reset
         for i in range(16):
             b = i % nbatches
@@ -620,6 +628,10 @@ def main(argv=None):
         F.check(lib.qmx_query_timing(be0.qh, C.byref(m1), C.byref(l1)))
         if l1.value:
             kernel_ms = m1.value / l1.value
+    if world > 1:
+        km = torch.tensor([kernel_ms, kernel_ms_in_flight], dtype=torch.float64, device=dev)
+        dist.all_reduce(km, op=dist.ReduceOp.MAX)
+        kernel_ms, kernel_ms_in_flight = float(km[0].item()), float(km[1].item())
     # bytes the dominant kernel of the timed step has to read per launch: the f32 block (3072 B/row at d=768) for the exact scans; the derived
     # copy the prefilter scans (QMX_SEG_I8_COPY: 1 B / element, QMX_SEG_HALF_COPY: 2 B, QMX_SEG_SPLIT_COPY: 4 B) when that is the kernel that ran
     half_copy = "scan_f16pair_kernel<true>" in kernel_symbol or "scan_f16half256_kernel" in kernel_symbol
@@ -750,7 +762,7 @@ def main(argv=None):
         # and the sharded search with its merge, over one segment per visible device of this run (world > 1: after the process group has ended and
         # the other ranks have left their devices; a single GPU: two segments on it, which exercises the same code path)
         try:
-            result["one_process_fanout"] = one_process_fanout(args, world, dim, Q, top, lib, F, qa, torch, np)
+            result["one_process_fanout"] = one_process_fanout(args, 1 if args.ranks_share_gpu else world, dim, Q, top, lib, F, qa, torch, np)
         except Exception as e:
             result["one_process_fanout"] = {"error": repr(e)[:400]}
     if solo and not args.no_cpu:

@@ -27,3 +27,6 @@ head -4 gpurun_out/${TAG}_c2_kernel_stats.csv | cut -c1-200
 tail -3 gpurun_out/${TAG}_c2_step_timeline.txt
 tail -3 gpurun_out/pmc_${TAG}/traffic.md
 tail -8 gpurun_out/${TAG}_gather_roof_lut4.txt
+# the N > 1 path of bench.py end to end on this one GPU: two ranks share it, gloo over device tensors (not a scaling measurement: a test that the path runs)
+timeout 600 python bench.py --gpus 2 --backend gloo --ranks-share-gpu --steps 20 --warmup 5 --configs= > gpurun_out/${TAG}_bench_two_ranks_one_gpu.json 2> gpurun_out/${TAG}_bench_two_ranks_one_gpu.err
+tail -1 gpurun_out/${TAG}_bench_two_ranks_one_gpu.json | cut -c1-1500
