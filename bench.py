@@ -213,6 +213,9 @@ def compact_roofline(result):
     else:
         p = result["roofline_hbm_point_q16"]
         out = {"bound": "hbm", "achieved": p["achieved"], "peak": p["peak"], "unit": "GB/s", "frac": p["frac"], "traffic": p.get("traffic"),
+               # (counters cannot be read from inside the process: `traffic` is this kernel symbol's entry of profiles/pmc_traffic.json - separate rocprofv3 --pmc
+               # passes at this row count, the file names the round that measured it)
+               "traffic_source": "lookup, not a counter of this run: profiles/pmc_traffic.json <- %s" % os.path.basename(str(p.get("traffic_source") or "?")),
                "of": "block_stream: SURVEY 8(d), the exact scan over the stored f32 block, %d queries; same run" % bs["batch"],
                "block_stream": bs}
         if bs1:
