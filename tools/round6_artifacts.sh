@@ -4,8 +4,10 @@ set -u
 TAG=${1:-r6}
 R=$PWD
 mkdir -p gpurun_out
-timeout 600 python bench.py > gpurun_out/${TAG}_bench_headline.json 2> gpurun_out/${TAG}_bench.err && cp bench_details.json gpurun_out/${TAG}_bench_details.json
+T0=$(date +%s); timeout 600 python bench.py > gpurun_out/${TAG}_bench_headline.json 2> gpurun_out/${TAG}_bench.err && cp bench_details.json gpurun_out/${TAG}_bench_details.json
+T1=$(date +%s); echo "default bench: $((T1 - T0)) s" > gpurun_out/${TAG}_bench_wall_seconds.txt
 timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver_form_headline.json 2> gpurun_out/${TAG}_bench_driver_form.err && cp bench_details.json gpurun_out/${TAG}_bench_driver_form_details.json
+T2=$(date +%s); echo "driver-form bench: $((T2 - T1)) s" >> gpurun_out/${TAG}_bench_wall_seconds.txt
 export TMPDIR=/tmp
 cd /tmp
 timeout 120 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG} -o s --output-format csv -- python $R/bench.py --no-sweep --no-robustness --no-cpu \
@@ -16,6 +18,7 @@ head -40 gpurun_out/prof_${TAG}/s_kernel_stats.csv > gpurun_out/${TAG}_c2_kernel
 rm -rf gpurun_out/prof_${TAG}
 timeout 200 bash tools/pmc_traffic.sh ${TAG} --what c2i8 --reps 3 > /dev/null 2>&1
 (cd tools/micro && timeout 200 ./gather_roof 1 | grep -E "^#|lut4" > $R/gpurun_out/${TAG}_gather_roof_lut4.txt)
+cat gpurun_out/${TAG}_bench_wall_seconds.txt
 tail -c 300 gpurun_out/${TAG}_bench.err
 for f in gpurun_out/${TAG}_bench_headline.json gpurun_out/${TAG}_bench_driver_form_headline.json; do tail -1 $f | python3 -c "
 import sys, json
