@@ -180,7 +180,7 @@ def _leg(st):
     bound, frac = r.get("bound"), r.get("frac")
     if "lds" in r:                      # a kernel priced against the LDS issue roof carries that fraction (its HBM fraction stays in the details)
         bound, frac = "lds", r["lds"].get("frac")
-    return [_short(st.get("kernel", "")).replace("_kernel", "")[:24], st.get("kernel_ms"), bound, frac, st.get("qps_wall"), st.get("recall_at_10_vs_exact")]
+    return [_short(st.get("kernel", "")).replace("_kernel", "").replace("hnsw_search<", "walk<")[:20], st.get("kernel_ms"), bound, frac, st.get("qps_wall"), st.get("recall_at_10_vs_exact")]
 
 
 def _block_stream(p):
@@ -215,8 +215,8 @@ def compact_roofline(result):
         out = {"bound": "hbm", "achieved": p["achieved"], "peak": p["peak"], "unit": "GB/s", "frac": p["frac"], "traffic": p.get("traffic"),
                # (counters cannot be read from inside the process: `traffic` is this kernel symbol's entry of profiles/pmc_traffic.json - separate rocprofv3 --pmc
                # passes at this row count, the file names the round that measured it)
-               "traffic_source": "lookup, not a counter of this run: profiles/pmc_traffic.json <- %s" % os.path.basename(str(p.get("traffic_source") or "?")),
-               "of": "block_stream: SURVEY 8(d), the exact scan over the stored f32 block, %d queries; same run" % bs["batch"],
+               "traffic_source": "lookup (pmc_traffic.json <- %s), no counter of this run" % os.path.basename(str(p.get("traffic_source") or "?")),
+               "of": "block_stream = SURVEY 8(d): the exact scan of the stored f32 block, %d queries, same run; `value` is timed_kernel's path, not this one" % bs["batch"],
                "block_stream": bs}
         if bs1:
             out["block_stream_q1"] = _pick(bs1, "kernel", "batch", "kernel_ms", "frac", "traffic_over_algorithmic")
@@ -269,7 +269,7 @@ def _configs_summary(cfg):
             put("C3.scan_Q32", bf.get("Q32"))
             put("C3.walk", h)
             ow = h.get("oracle_walk_check", {})
-            out["C3"] = {"rows": "latent-32 (+ the walk on C2's iid rows: walk_iid_rows)", "build_s": h.get("build_s"), "oracle_walk": _walk_summary(ow, h.get("reference_heap_order")),
+            out["C3"] = {"rows": "latent-32 (walk_iid_rows: C2's rows)", "build_s": h.get("build_s"), "oracle_walk": _walk_summary(ow, h.get("reference_heap_order")),
                          "oracle_scan_ok": all(v is True for v in c3.get("oracle_check", {"-": None}).values())}
     tq = cfg.get("TQ4")
     if isinstance(tq, dict):
@@ -307,7 +307,7 @@ def headline(result, details_path=None):
     c = result.get("config", {})
     hc = _pick(c, "workload", "rows_per_gpu", "dim", "batch", "top", "batches_in_flight", "prewarm_steps")
     if result.get("n_gpus", 1) > 1:
-        hc.update(_pick(c, "collection_qps", "segment_searches_per_s", "collectives_per_step", "per_step_us"))
+        hc.update(_pick(c, "collection_qps", "segment_searches_per_s", "collectives_per_step", "per_step_us", "unit_of_value"))
     if "timed_path" in c:
         hc["timed_path"] = c["timed_path"].split(":")[0].replace(" of the block (1 B / element, int8 matrix cores)", "").replace(" of the survivors", "")[:100]
     dc = c.get("derived_copy")

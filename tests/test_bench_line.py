@@ -44,7 +44,7 @@ def test_headline_of_a_full_run_fits_4k_and_carries_the_contract():
     assert set(h["configs"]) == {"C3", "TQ4", "C4", bench.LEG_COLUMNS}
     legs = h["configs"][bench.LEG_COLUMNS]
     assert {"C3.scan_Q32", "C3.walk", "TQ4.scan_Q32", "C4.walk", "C4.scan_Q32"} <= set(legs) and all(len(v) == 6 for v in legs.values())
-    assert legs["C3.walk"][0].startswith("hnsw_search<HopRow<RowSQ") and 0 < legs["C3.walk"][3] < 1
+    assert legs["C3.walk"][0].startswith("walk<HopRow<RowSQ") and 0 < legs["C3.walk"][3] < 1
     assert h["configs"]["C3"]["oracle_walk"]["default_walk"].startswith("ids 254/256")
     assert h["cpu_baseline"]["kind"] == "port" and h["cpu_baseline"]["cores"] >= 1 and h["cpu_baseline"]["value"] > 0
 
