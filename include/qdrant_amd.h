@@ -563,8 +563,10 @@ QMX_API int32_t qmx_multi_search_topk(qmx_query *inner, const uint32_t *query_fi
  * kernel scores them (exact bits of the base scorer).  max(top, ef) <= 4096; a search that pops more than 32 max(ef, top) + 256 candidates
  * => QMX_ERR_NOT_SUPPORTED.  counters->vectors_scored = link vectors + base vectors scored.  Ties: the reference's loop ends at the first popped
  * candidate whose score is BELOW the lower bound (:358); a candidate that `nearest` evicted before it was expanded and whose score EQUALS the bound is
- * expanded there (in whatever order its BinaryHeap pops equal scores) and ends the loop here - results can differ only when a link score ties with
- * the ef-th best, like every other tie of the walk. */
+ * expanded there - and here: every such candidate is kept (the evictions of the latest score, which are the only ones that can still tie with the bound,
+ * in four registers and a per-slot stack of 4 096 entries; a search that needs more reports QMX_ERR_NOT_SUPPORTED, never a silent drop) and expanded in the
+ * device's order among equal scores (lower id first) where the reference's is its BinaryHeap's: results can differ only inside runs of equal link
+ * scores, like every other tie of the walk (tests/test_gpu_hnsw_with_vectors_ties.py pins the rule on BQ links). */
 QMX_API int32_t qmx_hnsw_search_with_vectors(const qmx_hnsw *g, qmx_query *links, qmx_query *base, uint32_t top, uint32_t ef,
                                              qmx_scored_point *out, uint32_t *out_counts, const volatile uint8_t *is_stopped,
                                              qmx_counters *counters);

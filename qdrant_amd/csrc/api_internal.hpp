@@ -262,7 +262,8 @@ static int32_t check_err_flag(qmx_query *q) {
     if (flag) {
         QMX_HIP(hipMemsetAsync(q->d_err, 0, sizeof(int), q->stream));
         if (flag == 2) {
-            set_error("hnsw_reference_heap_order: a search's `candidates` heap outgrew its scratch (%u entries)", HNSW_REF_CAND_CAP);
+            set_error("a search outgrew its scratch: the `candidates` heap of hnsw_reference_heap_order (%u entries) or search_with_vectors' stack of evicted candidates "
+                      "that tie with the bound (%u)", HNSW_REF_CAND_CAP, HNSW_EV_SPILL_CAP);
             return QMX_ERR_NOT_SUPPORTED;
         }
         set_error("point offset out of range for this segment (the reference panics here)");
