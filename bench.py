@@ -81,7 +81,9 @@ def parse(argv=None):
     ap.add_argument("--verify", type=int, default=1, help="check samples against the oracle (C2 first batch, C3 / C4 scans and walks)")
     ap.add_argument("--configs", default="c1,c3,tq,c4", help="comma list of the secondary single-GPU configs to run (empty = none)")
     ap.add_argument("--config-rows", type=int, default=0, help="rows of C3 / C4 (0 = --rows)")
-    ap.add_argument("--no-iid-walk", action="store_true", help="skip the C3 walk on C2's own iid rows (SURVEY 8d's C3 rows; one more 10 M-point graph build)")
+    ap.add_argument("--iid-walk", action="store_true",
+                    help="also run the C3 walk on C2's own iid rows (SURVEY 8d's C3 rows): one more 10 M-point graph build, +60 s - off by default to keep the default "
+                         "command near four minutes; the round's record of it: profiles/r6_bench_with_iid_walk_details.json")
     ap.add_argument("--hnsw-queries", type=int, default=8192, help="searches per launch of the HNSW walks")
     ap.add_argument("--in-flight", type=int, default=4, choices=[1, 2, 3, 4, 5, 6, 8],
                     help="query batches in flight on one GPU: consecutive steps take turns on this many query handles, each with its own stream, so that one batch's "
@@ -572,9 +574,11 @@ def main(argv=None):
         "value": round(value, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         # spread over groups of steps inside the timed region (device time between stream events): standard deviation of the groups' QPS
-        "value_stddev": round(_stddev([Q / (m * 1e-3) for m in group_ms if m > 0]), 2) if len(group_ms) >= 3 else None,
-        "step_groups": {"steps_per_group": gsz, "ms_per_step_min": round(min(group_ms), 4) if group_ms else None,
-                        "ms_per_step_max": round(max(group_ms), 4) if group_ms else None},
+        # (one batch in flight only: with several, the lanes' streams run ahead of and behind one another by whole steps - the GPU takes their kernels in its own
+        # order - so the time between two rounds of marks measures that order, not the throughput; measured: "46 k QPS" of spread on a steady 92 k)
+        "value_stddev": round(_stddev([Q / (m * 1e-3) for m in group_ms if m > 0]), 2) if (len(group_ms) >= 3 and len(lanes) == 1) else None,
+        "step_groups": ({"steps_per_group": gsz, "ms_per_step_min": round(min(group_ms), 4) if group_ms else None,
+                         "ms_per_step_max": round(max(group_ms), 4) if group_ms else None} if len(lanes) == 1 else None),
         "higher_is_better": True, "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic", "rccl_ranks": rccl_ranks,
         "collective": ("none (one GPU)" if world == 1 else "gloo over device tensors (--ranks-share-gpu: a test of the path, not RCCL)" if args.ranks_share_gpu else
@@ -784,7 +788,7 @@ def main(argv=None):
                 cfg["C1"] = c1_section(ctx)
             except Exception as e:
                 cfg["C1"] = {"error": repr(e)[:400]}
-        if "c3" in wanted and not args.no_iid_walk:
+        if "c3" in wanted and args.iid_walk:
             try:        # (before C3 refills the block: the C3 walk on the rows SURVEY 8(d) names - C2's own iid rows)
                 cfg["C3_walk_on_iid_rows"] = iid_walk_leg(ctx, rows, queries)
             except Exception as e:
