@@ -182,6 +182,125 @@ static int32_t pq_prefilter_enqueue(qmx_query *q, uint32_t top, uint64_t n_cand,
     return QMX_OK;
 }
 
+// ---- 4-bit TurboQuant top-k of 33 and more queries over a large block: 128 queries per pass of the codes (scan_tq4w.hip).  The pass's scores are exact;
+// what it shares with the prefilters is the plumbing: a sample's k-th best score admits the candidates, per-wave lists are regrouped per query, the k best
+// keys of a query (band 0: every tie of the k-th score with them) are re-scored by the pair kernel and sorted; a query whose lists overflowed (masses of
+// equal scores, a sample that is all deleted) takes the 32-query scan - conditional launches that read their flag and return. ----
+constexpr uint32_t TQW_FQT = 32;
+static int32_t tq_wide_enqueue(qmx_query *q, uint32_t top, uint64_t n_cand, qmx_scored_point *d_out, uint32_t *d_counts, const volatile uint8_t *is_stopped,
+                               qmx_counters *counters, bool timed) {
+    const qmx_segment *s = q->seg;
+    const SplitPlanLayout pl(q->nq, TQW_FQT);
+    const uint32_t grid_cap = (uint32_t)s->num_cus * 8;
+    QMX_TRY(q->gthr.reserve((size_t)std::max<uint32_t>(q->nq_padded, SPLIT_QT) * sizeof(uint64_t)));
+    QMX_TRY(q->sp_bq.reserve(tq4w_query_bytes(s->scan_dim)));
+    QMX_TRY(q->sp_f32.reserve(1024 * sizeof(float)));
+    QMX_TRY(q->sp_cand.reserve((size_t)SPLIT_QT * SPLIT_CAND_CAP * sizeof(uint64_t)));
+    QMX_TRY(q->sp_cnt.reserve((size_t)SPLIT_QT_MAX * 4));
+    QMX_TRY(q->sp_wl.reserve(tq4w_wlists_bytes(s->num_cus)));
+    QMX_TRY(q->sp_plan.reserve(pl.bytes));
+    QMX_TRY(q->sp_fq.reserve((size_t)pl.list_cap * q->q_stride));
+    QMX_TRY(q->partial.reserve((size_t)grid_cap * TQW_FQT * std::min<uint32_t>(top, MAX_TOP_FAST) * sizeof(uint64_t)));
+    unsigned char *plan = (unsigned char *)q->sp_plan.p;
+    VerifyPool vp;
+    QMX_TRY(verify_pool(q, plan, &vp));
+    float *qinfo = (float *)q->sp_f32.p, *band = qinfo + 512;      // band: zero - the pass's scores are the exact ones - or infinite: a query without a usable bound
+    int32_t *thr_i = (int32_t *)(qinfo + 768);
+    q->last_counters = qmx_counters{};
+    q->last_split = false;
+    const int sshift = (int)std::min<int64_t>(std::max<int64_t>(option(OPT_PRESCAN_SHIFT) - 2, 1), 20);
+    const uint64_t S = std::min<uint64_t>(n_cand, std::max<uint64_t>(n_cand >> sshift, 8192));
+    if (q->sp_sample_n != S || q->sp_sample_of != n_cand) {
+        QMX_TRY(q->sp_sample.reserve((size_t)S * 4));
+        ::qmx::clear_stale_error();
+        hipLaunchKernelGGL(sample_ids_kernel, dim3((uint32_t)((S + 255) / 256)), dim3(256), 0, q->stream, (uint32_t *)q->sp_sample.p, (uint32_t)S, n_cand / S);
+        QMX_HIP(hipGetLastError());
+        q->sp_sample_n = S;
+        q->sp_sample_of = n_cand;
+    }
+    const uint32_t *d_sample = (const uint32_t *)q->sp_sample.p;
+    QMX_HIP(hipMemsetAsync(plan, 0, pl.zero_bytes, q->stream));
+    uint32_t n_tiles = 0, launches = 2;
+    const void *wide_kernel = nullptr;
+    for (uint32_t tile0 = 0; tile0 < q->nq; tile0 += SPLIT_QT, ++n_tiles) {
+        const uint32_t nq_tile = std::min<uint32_t>(SPLIT_QT, q->nq - tile0);
+        if (is_stopped && *is_stopped) {
+            set_error("search cancelled");
+            return QMX_ERR_CANCELLED;
+        }
+        uint64_t *gthr = (uint64_t *)q->gthr.p + tile0;
+        ScanArgs a;
+        fill_args(q, tile0, nq_tile, a);
+        a.n_cand = n_cand;
+        a.top = top;
+        // 1. exact scores of the sample -> the k-th best of each query = a lower bound of its final k-th best
+        QMX_TRY(q->scores.reserve((size_t)nq_tile * S * sizeof(float)));
+        QMX_TRY(score_matrix_enqueue(q, tile0, nq_tile, d_sample, S, (float *)q->scores.p, S, &launches));
+        QMX_TRY(launch_custom_topk(q->stream, (const float *)q->scores.p, S, d_sample, a.del, nq_tile, top, d_out + (size_t)tile0 * top, d_counts + tile0, gthr));
+        // 2. the queries' digits as operand images, the integer reject bounds
+        QMX_TRY(launch_tq4w_pack(q->stream, a, gthr, s->tq_sf_min, s->tq_sf_max, s->tq_l2_min, q->sp_bq.p, thr_i, qinfo, band, (uint32_t *)q->sp_cnt.p, SPLIT_QT_MAX));
+        // 3. the pass
+        uint32_t grid = 0;
+        size_t slot = 0;
+        if (timed) QMX_TRY(timing_begin(q, &slot));
+        QMX_TRY(launch_scan_tq4w(q->stream, a, q->sp_bq.p, thr_i, qinfo, s->num_cus, q->sp_wl.p, &grid));
+        wide_kernel = last_noted_kernel();
+        if (timed) QMX_TRY(timing_end(q, slot));
+        // 4. per-wave lists -> per-query lists (deleted rows dropped), then the k best keys of each query
+        int *tile_ovf = (int *)(plan + pl.tile_ovf) + n_tiles;
+        QMX_TRY(launch_regroup_lists(q->stream, a.del, (const unsigned char *)q->sp_wl.p + tq4w_wlists_counts_bytes(s->num_cus), (const uint32_t *)q->sp_wl.p, tq4w_wcap(),
+                                     grid * 8, (uint64_t *)q->sp_cand.p, (uint32_t *)q->sp_cnt.p, SPLIT_CAND_CAP, tile_ovf));
+        QMX_TRY(launch_split_select(q->stream, (const uint64_t *)q->sp_cand.p, (const uint32_t *)q->sp_cnt.p, SPLIT_CAND_CAP, band, nq_tile, top, vp, tile0, tile_ovf,
+                                    (uint32_t *)(plan + pl.ovf_q) + tile0, (SplitStats *)plan));
+        launches += 6;
+    }
+    // 5. the selected rows through the pair kernel (the same bits), sorted by (score, lower id first)
+    PairSel sel{vp.qsel, 0, nullptr, vp.used};
+    QMX_TRY(score_pairs_device(q, sel, vp.ids, vp.cap, (float *)q->sp_vscores.p, false));
+    QMX_TRY(launch_sort_scored(q->stream, (const float *)q->sp_vscores.p, vp.ids, vp.cnt, 0, q->nq, top, d_out, d_counts, vp.off));
+    // 6. the 32-query scan of the queries whose lists overflowed, packed: one 16-query pass when 1..16 of them, passes of 32 otherwise
+    uint32_t *ovf_list = (uint32_t *)(plan + pl.list);
+    uint64_t *gthr_packed = (uint64_t *)(plan + pl.gthr_packed);
+    QMX_TRY(launch_split_plan(q->stream, (const uint32_t *)(plan + pl.ovf_q), q->nq, (const uint64_t *)q->gthr.p, ovf_list, gthr_packed, pl.list_cap,
+                              (uint32_t *)(plan + pl.count), (int *)(plan + pl.run16), (int *)(plan + pl.run64), pl.n_run64, (SplitStats *)plan, q->d_queries,
+                              q->q_stride, q->sp_fq.p));
+    for (uint32_t pass = 0; pass <= pl.n_run64; ++pass) {
+        if (pass && q->nq <= 16) break;
+        const uint32_t p0 = pass ? (pass - 1) * TQW_FQT : 0;
+        const uint32_t nq_sub = pass ? std::min<uint32_t>(TQW_FQT, q->nq - p0) : std::min<uint32_t>(16, q->nq);
+        const int *run_if = pass ? (const int *)(plan + pl.run64) + (pass - 1) : (const int *)(plan + pl.run16);
+        ScanArgs a;
+        fill_args(q, 0, nq_sub, a);
+        a.queries = (const char *)q->sp_fq.p + (size_t)p0 * q->q_stride;
+        a.n_cand = n_cand;
+        a.top = top;
+        a.partial = (uint64_t *)q->partial.p;
+        a.gthr = gthr_packed + p0;
+        a.run_if = run_if;
+        const int fqt = (int)std::max<uint32_t>(16, pow2_ceil(nq_sub));
+        a.partial_qt = (uint32_t)fqt;
+        uint32_t grid = grid_cap;
+        QMX_TRY(launch_scan_tq_mfma(q->stream, fqt, SCAN_TOPK, a, s->num_cus, &grid));
+        QMX_TRY(launch_merge_keys(q->stream, (const uint64_t *)q->partial.p, grid, (uint32_t)fqt, nq_sub, top, d_out, d_counts, top, 0, nullptr, run_if, ovf_list + p0));
+        launches += 2;
+    }
+    q->last_kernel = wide_kernel;
+    q->last_split = true;
+    q->last_pq = false;
+    q->last_fqt = TQW_FQT;
+    {
+        qmx_counters &c = q->last_counters;
+        c.vectors_scored = (uint64_t)q->nq * n_cand;
+        c.bytes_read = (uint64_t)n_tiles * n_cand * s->row_bytes + (uint64_t)((q->nq + MAX_QT_MFMA - 1) / MAX_QT_MFMA) * S * s->row_bytes;
+        c.kernel_launches = launches;
+        c.prefilter_queries = q->nq;
+        q->last_row_bytes = s->row_bytes;
+        q->last_n_cand = n_cand;
+        if (counters) *counters = c;
+    }
+    return QMX_OK;
+}
+
 int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids, uint64_t n_ids,
                               qmx_scored_point *d_out, uint32_t *d_counts, const volatile uint8_t *is_stopped,
                               qmx_counters *counters, bool timed) {
@@ -213,6 +332,14 @@ int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids, uint64
     if (s->dtype == QMX_DTYPE_PQ && s->d_pq_rot && !d_ids && top <= MAX_TOP_FAST && n_cand >= (1u << 18) && !option(OPT_NO_PQ_PREFILTER) &&
         q->nq >= (uint32_t)std::max<int64_t>(1, option(OPT_PQ_PREFILTER_MIN_QUERIES)))
         return pq_prefilter_enqueue(q, top, n_cand, d_out, d_counts, is_stopped, counters, timed);
+    if (s->dtype == QMX_DTYPE_TQ && s->tq_wide && !d_ids && top <= MAX_TOP_FAST && n_cand >= (1u << 18) && mfma_scan_ok(s) && option(OPT_TQ_WIDE_MIN_QUERIES) > 0 &&
+        q->nq >= (uint32_t)option(OPT_TQ_WIDE_MIN_QUERIES) && (size_t)MAX_QT_MFMA * q->q_stride <= 150 * 1024) {
+        ScanArgs probe;
+        fill_args(q, 0, std::min<uint32_t>(q->nq, SPLIT_QT), probe);
+        probe.n_cand = n_cand;
+        probe.top = top;
+        if (tq4w_shape_ok(probe)) return tq_wide_enqueue(q, top, n_cand, d_out, d_counts, is_stopped, counters, timed);
+    }
     // partial lists: one per block; bound the grid by what the buffer holds
     const uint32_t grid_cap = (uint32_t)s->num_cus * 8;
     // f32 dot / cosine rows of 256, 512 or 768 floats, whole block: 64 queries per pass (scan_mfma16.hip); everything else 32 / 16

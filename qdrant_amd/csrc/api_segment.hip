@@ -296,6 +296,26 @@ static int32_t segment_split_stats(qmx_segment *s) {
     return QMX_OK;
 }
 
+// 4-bit TurboQuant blocks large enough for the 128-query pass (scan_tq4w.hip): the ranges of the extras columns its integer reject bound rests on
+static int32_t segment_tq_stats(qmx_segment *s) {
+    if (s->dtype != QMX_DTYPE_TQ || s->tq_value_bits != 4 || s->n < (1u << 18) || s->d_tq_l1 || !s->d_tq_sf) return QMX_OK;
+    uint32_t *d_stats = nullptr;
+    QMX_HIP(hipMalloc((void **)&d_stats, 16));
+    int32_t rc = QMX_OK;
+    uint32_t h[4] = {0x7F800000u, 0u, 0x7F800000u, 0u};
+    if (hipMemcpy(d_stats, h, 16, hipMemcpyHostToDevice) != hipSuccess) rc = QMX_ERR_OTHER;
+    if (rc == QMX_OK) rc = launch_tq4w_stats(nullptr, s->d_tq_sf, s->d_tq_l2, s->n, d_stats);
+    if (rc == QMX_OK && hipMemcpy(h, d_stats, 16, hipMemcpyDeviceToHost) != hipSuccess) rc = QMX_ERR_OTHER;
+    (void)hipFree(d_stats);
+    if (rc != QMX_OK) return rc;
+    memcpy(&s->tq_sf_min, &h[0], 4);
+    memcpy(&s->tq_sf_max, &h[1], 4);
+    memcpy(&s->tq_l2_min, &h[2], 4);
+    if (!s->d_tq_l2) s->tq_l2_min = 0.f;
+    s->tq_wide = h[3] == 0 && s->tq_sf_min > 0.f && s->tq_sf_max < 3.0e38f && s->tq_sf_min <= s->tq_sf_max;
+    return QMX_OK;
+}
+
 // TurboQuantizer::new (turboquant/quantization.rs:127-158): padded dim (encoding.rs:194-201), the rotation's three permutation maps
 // (rotation.rs:4-10,32-63 over permutation.rs: Fisher-Yates driven by Knuth's MMIX LCG, upper 32 bits mod bound) and its chunk decomposition
 // (rotation.rs:222-233,264-280: decreasing powers of two, each WHT normalised by 1 / sqrt(size))
@@ -609,6 +629,7 @@ int32_t qmx_segment_create(const qmx_segment_desc *desc, qmx_segment **out) {
     if (rc == QMX_OK) rc = segment_upload(s, desc);
     if (rc == QMX_OK) rc = segment_split_stats(s);
     if (rc == QMX_OK) rc = segment_pq_rot(s);
+    if (rc == QMX_OK) rc = segment_tq_stats(s);
     if (rc != QMX_OK) {
         segment_free(s);
         return rc;

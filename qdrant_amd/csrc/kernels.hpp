@@ -394,6 +394,17 @@ int32_t launch_split_i8_probe(hipStream_t st, const uint64_t *d_cand, const uint
                               const int *d_tile_overflow, uint32_t *d_probe_ids, uint32_t *d_probe_cnt);
 int32_t launch_split_i8_bound(hipStream_t st, const float *d_scores, uint32_t *d_probe_cnt, uint32_t nq, uint32_t top, const float *d_band, const float *d_qscale,
                               float *d_thr, float *d_t_exact);
+// TurboQuant 4 bits, 128 queries per pass: codes decoded once per tile into the matrix cores' operand images, exact scores, candidate lists (scan_tq4w.hip)
+bool tq4w_shape_ok(const ScanArgs &a);
+size_t tq4w_query_bytes(uint32_t code_bytes);
+size_t tq4w_wlists_counts_bytes(int num_cus);
+size_t tq4w_wlists_bytes(int num_cus);
+uint32_t tq4w_wcap();
+int32_t launch_tq4w_stats(hipStream_t st, const float *d_sf, const float *d_l2, uint64_t n, uint32_t *d_stats);
+int32_t launch_tq4w_pack(hipStream_t st, const ScanArgs &a, const uint64_t *d_gthr, float sf_min, float sf_max, float l2_min, void *d_bq, int32_t *d_thr_i,
+                         float *d_qinfo, float *d_band, uint32_t *d_cand_cnt, uint32_t n_cnt);
+int32_t launch_scan_tq4w(hipStream_t st, const ScanArgs &a, const void *d_bq, const int32_t *d_thr_i, const float *d_qinfo, int num_cus, void *d_wlists,
+                         uint32_t *grid_out);
 // the overflowed queries packed for the conditional exact passes: list, their pre-scan bounds, the passes' run flags
 int32_t launch_split_plan(hipStream_t st, const uint32_t *d_ovf_q, uint32_t nq, const uint64_t *d_gthr, uint32_t *d_list, uint64_t *d_gthr_packed, uint32_t list_cap,
                           uint32_t *d_count, int *d_run16, int *d_run64, uint32_t n_run64, SplitStats *d_stats, const void *d_queries, uint32_t q_stride,

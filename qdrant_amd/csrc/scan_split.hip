@@ -835,7 +835,7 @@ __global__ __launch_bounds__(256) void sp_regroup_kernel(const uint4 *wlist, con
     };
     for (uint32_t i = threadIdx.x; i < total; i += 256) {
         const uint4 e = entry(i);
-        if (del.live(e.x ^ 0xFFFFFFFFu)) atomicAdd(&hist[e.z], 1u);
+        if (e.z < (uint32_t)SP_QT_MAX && del.live(e.x ^ 0xFFFFFFFFu)) atomicAdd(&hist[e.z], 1u);      // (e.z = 0xFFFFFFFF: an entry tq4w_finish_kernel withdrew)
     }
     __syncthreads();
     if (threadIdx.x < SP_QT_MAX) {
@@ -846,7 +846,7 @@ __global__ __launch_bounds__(256) void sp_regroup_kernel(const uint4 *wlist, con
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < total; i += 256) {
         const uint4 e = entry(i);
-        if (!del.live(e.x ^ 0xFFFFFFFFu)) continue;
+        if (e.z >= (uint32_t)SP_QT_MAX || !del.live(e.x ^ 0xFFFFFFFFu)) continue;
         const uint32_t at = base[e.z] + atomicAdd(&hist[e.z], 1u);
         if (at < cap) cand[(uint64_t)e.z * cap + at] = ((uint64_t)e.y << 32) | e.x;
     }

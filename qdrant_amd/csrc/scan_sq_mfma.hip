@@ -257,6 +257,7 @@ template <class Ops, int QW, int D, bool HAS_IDS, int MODE>
 __global__ __launch_bounds__(SQM_BLOCK) void scan_sq_mfma_kernel(const ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NG = QW / 16;
+    if (a.run_if && *a.run_if == 0) return;           // the exact pass behind the 128-query TurboQuant pass was not needed (scan_tq4w.hip)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
