@@ -205,10 +205,12 @@ static int32_t tq_wide_enqueue(qmx_query *q, uint32_t top, uint64_t n_cand, qmx_
     VerifyPool vp;
     QMX_TRY(verify_pool(q, plan, &vp));
     float *qinfo = (float *)q->sp_f32.p, *band = qinfo + 512;      // band: zero - the pass's scores are the exact ones - or infinite: a query without a usable bound
-    int32_t *thr_i = (int32_t *)(qinfo + 768);
+    int32_t *thr_i = (int32_t *)(qinfo + 768);      // [256]: the bounds on the whole sum, then on the high sum alone
     q->last_counters = qmx_counters{};
     q->last_split = false;
-    const int sshift = (int)std::min<int64_t>(std::max<int64_t>(option(OPT_PRESCAN_SHIFT) - 2, 1), 20);
+    // the sample: every 128-th row (prescan_shift - 3; at least 8 192 rows): its k-th best score leaves ~128 k candidates per query to the pass - the pass's
+    // epilogue pays per candidate (10 M x 768, 128 queries: 2.07 / 2.00 / 2.01 ms with every 256-th / 128-th / 64-th row, whose own scores cost more)
+    const int sshift = (int)std::min<int64_t>(std::max<int64_t>(option(OPT_PRESCAN_SHIFT) - 3, 1), 20);
     const uint64_t S = std::min<uint64_t>(n_cand, std::max<uint64_t>(n_cand >> sshift, 8192));
     if (q->sp_sample_n != S || q->sp_sample_of != n_cand) {
         QMX_TRY(q->sp_sample.reserve((size_t)S * 4));
@@ -238,7 +240,7 @@ static int32_t tq_wide_enqueue(qmx_query *q, uint32_t top, uint64_t n_cand, qmx_
         QMX_TRY(score_matrix_enqueue(q, tile0, nq_tile, d_sample, S, (float *)q->scores.p, S, &launches));
         QMX_TRY(launch_custom_topk(q->stream, (const float *)q->scores.p, S, d_sample, a.del, nq_tile, top, d_out + (size_t)tile0 * top, d_counts + tile0, gthr));
         // 2. the queries' digits as operand images, the integer reject bounds
-        QMX_TRY(launch_tq4w_pack(q->stream, a, gthr, s->tq_sf_min, s->tq_sf_max, s->tq_l2_min, q->sp_bq.p, thr_i, qinfo, band, (uint32_t *)q->sp_cnt.p, SPLIT_QT_MAX));
+        QMX_TRY(launch_tq4w_pack(q->stream, a, gthr, s->tq_sf_min, s->tq_sf_max, s->tq_l2_min, s->tq_c1, q->sp_bq.p, thr_i, qinfo, band, (uint32_t *)q->sp_cnt.p, SPLIT_QT_MAX));
         // 3. the pass
         uint32_t grid = 0;
         size_t slot = 0;

@@ -300,18 +300,19 @@ static int32_t segment_split_stats(qmx_segment *s) {
 static int32_t segment_tq_stats(qmx_segment *s) {
     if (s->dtype != QMX_DTYPE_TQ || s->tq_value_bits != 4 || s->n < (1u << 18) || s->d_tq_l1 || !s->d_tq_sf) return QMX_OK;
     uint32_t *d_stats = nullptr;
-    QMX_HIP(hipMalloc((void **)&d_stats, 16));
+    QMX_HIP(hipMalloc((void **)&d_stats, 32));
     int32_t rc = QMX_OK;
-    uint32_t h[4] = {0x7F800000u, 0u, 0x7F800000u, 0u};
-    if (hipMemcpy(d_stats, h, 16, hipMemcpyHostToDevice) != hipSuccess) rc = QMX_ERR_OTHER;
-    if (rc == QMX_OK) rc = launch_tq4w_stats(nullptr, s->d_tq_sf, s->d_tq_l2, s->n, d_stats);
-    if (rc == QMX_OK && hipMemcpy(h, d_stats, 16, hipMemcpyDeviceToHost) != hipSuccess) rc = QMX_ERR_OTHER;
+    uint32_t h[8] = {0x7F800000u, 0u, 0x7F800000u, 0u, 0u, 0u, 0u, 0u};
+    if (hipMemcpy(d_stats, h, 32, hipMemcpyHostToDevice) != hipSuccess) rc = QMX_ERR_OTHER;
+    if (rc == QMX_OK) rc = launch_tq4w_stats(nullptr, s->d_tq_sf, s->d_tq_l2, s->d_rows, s->row_stride, (uint32_t)s->row_stride, s->n, d_stats);
+    if (rc == QMX_OK && hipMemcpy(h, d_stats, 32, hipMemcpyDeviceToHost) != hipSuccess) rc = QMX_ERR_OTHER;
     (void)hipFree(d_stats);
     if (rc != QMX_OK) return rc;
     memcpy(&s->tq_sf_min, &h[0], 4);
     memcpy(&s->tq_sf_max, &h[1], 4);
     memcpy(&s->tq_l2_min, &h[2], 4);
     if (!s->d_tq_l2) s->tq_l2_min = 0.f;
+    s->tq_c1 = h[4];
     s->tq_wide = h[3] == 0 && s->tq_sf_min > 0.f && s->tq_sf_max < 3.0e38f && s->tq_sf_min <= s->tq_sf_max;
     return QMX_OK;
 }

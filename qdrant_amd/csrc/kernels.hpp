@@ -400,8 +400,8 @@ size_t tq4w_query_bytes(uint32_t code_bytes);
 size_t tq4w_wlists_counts_bytes(int num_cus);
 size_t tq4w_wlists_bytes(int num_cus);
 uint32_t tq4w_wcap();
-int32_t launch_tq4w_stats(hipStream_t st, const float *d_sf, const float *d_l2, uint64_t n, uint32_t *d_stats);
-int32_t launch_tq4w_pack(hipStream_t st, const ScanArgs &a, const uint64_t *d_gthr, float sf_min, float sf_max, float l2_min, void *d_bq, int32_t *d_thr_i,
+int32_t launch_tq4w_stats(hipStream_t st, const float *d_sf, const float *d_l2, const void *d_rows, uint64_t row_stride, uint32_t code_bytes, uint64_t n, uint32_t *d_stats);
+int32_t launch_tq4w_pack(hipStream_t st, const ScanArgs &a, const uint64_t *d_gthr, float sf_min, float sf_max, float l2_min, uint32_t c1, void *d_bq, int32_t *d_thr_i,
                          float *d_qinfo, float *d_band, uint32_t *d_cand_cnt, uint32_t n_cnt);
 int32_t launch_scan_tq4w(hipStream_t st, const ScanArgs &a, const void *d_bq, const int32_t *d_thr_i, const float *d_qinfo, int num_cus, void *d_wlists,
                          uint32_t *grid_out);
