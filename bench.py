@@ -182,6 +182,8 @@ def _leg(st):
     bound, frac = r.get("bound"), r.get("frac")
     if "lds" in r:                      # a kernel priced against the LDS issue roof carries that fraction (its HBM fraction stays in the details)
         bound, frac = "lds", r["lds"].get("frac")
+    if isinstance(st.get("matrix_cores"), dict):      # ... against the matrix cores' peak likewise (the 128-query TurboQuant pass)
+        bound, frac = "mfma", st["matrix_cores"].get("frac")
     return [_short(st.get("kernel", "")).replace("_kernel", "").replace("hnsw_search<", "walk<")[:20], st.get("kernel_ms"), bound, frac, st.get("qps_wall"), st.get("recall_at_10_vs_exact")]
 
 

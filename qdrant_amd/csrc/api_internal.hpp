@@ -84,6 +84,9 @@ struct qmx_segment {
     uint32_t pq_m = 0;
     void *d_pq_rot = nullptr;         // PQ blocks of 2^18 rows and more, m <= 96: the rotated copy of the codes the 6-bit prefilter scans (pq_prefilter.hip)
     float *d_row_offsets = nullptr;   // SQ: vector_offset column (rows hold the 16-byte aligned code block)
+    bool sq_wide = false;             // SQ block the 128-query pass serves (scan_sqw.hip): every vector_offset finite, the largest magnitude below
+    float sq_off_absmax = 0.f;
+    int32_t *d_sq_bi = nullptr;       // ... and its column ceil(vector_offset / multiplier) + 1
     // TurboQuant (scan_tq.hip): parameters, the extras columns and the rotation tables
     uint32_t tq_bits = 0, tq_value_bits = 0, tq_padded_dim = 0, tq_rot_dim = 0, tq_code_bytes = 0, tq_n_chunks = 0;
     bool tq_invert = false;

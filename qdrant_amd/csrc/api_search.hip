@@ -182,22 +182,23 @@ static int32_t pq_prefilter_enqueue(qmx_query *q, uint32_t top, uint64_t n_cand,
     return QMX_OK;
 }
 
-// ---- 4-bit TurboQuant top-k of 33 and more queries over a large block: 128 queries per pass of the codes (scan_tq4w.hip).  The pass's scores are exact;
+// ---- 4-bit TurboQuant / scalar-int8 top-k of 33 and more queries over a large block: 128 queries per pass of the codes (scan_tq4w.hip, scan_sqw.hip).  The pass's scores are exact;
 // what it shares with the prefilters is the plumbing: a sample's k-th best score admits the candidates, per-wave lists are regrouped per query, the k best
 // keys of a query (band 0: every tie of the k-th score with them) are re-scored by the pair kernel and sorted; a query whose lists overflowed (masses of
 // equal scores, a sample that is all deleted) takes the 32-query scan - conditional launches that read their flag and return. ----
 constexpr uint32_t TQW_FQT = 32;
-static int32_t tq_wide_enqueue(qmx_query *q, uint32_t top, uint64_t n_cand, qmx_scored_point *d_out, uint32_t *d_counts, const volatile uint8_t *is_stopped,
-                               qmx_counters *counters, bool timed) {
+static int32_t wide_exact_enqueue(qmx_query *q, uint32_t top, uint64_t n_cand, qmx_scored_point *d_out, uint32_t *d_counts, const volatile uint8_t *is_stopped,
+                                  qmx_counters *counters, bool timed) {
     const qmx_segment *s = q->seg;
+    const bool sq = s->dtype == QMX_DTYPE_SQ_U8;
     const SplitPlanLayout pl(q->nq, TQW_FQT);
     const uint32_t grid_cap = (uint32_t)s->num_cus * 8;
     QMX_TRY(q->gthr.reserve((size_t)std::max<uint32_t>(q->nq_padded, SPLIT_QT) * sizeof(uint64_t)));
-    QMX_TRY(q->sp_bq.reserve(tq4w_query_bytes(s->scan_dim)));
+    QMX_TRY(q->sp_bq.reserve(sq ? sqw_query_bytes(s->scan_dim) : tq4w_query_bytes(s->scan_dim)));
     QMX_TRY(q->sp_f32.reserve(1024 * sizeof(float)));
     QMX_TRY(q->sp_cand.reserve((size_t)SPLIT_QT * SPLIT_CAND_CAP * sizeof(uint64_t)));
     QMX_TRY(q->sp_cnt.reserve((size_t)SPLIT_QT_MAX * 4));
-    QMX_TRY(q->sp_wl.reserve(tq4w_wlists_bytes(s->num_cus)));
+    QMX_TRY(q->sp_wl.reserve(sq ? sqw_wlists_bytes(s->num_cus) : tq4w_wlists_bytes(s->num_cus)));
     QMX_TRY(q->sp_plan.reserve(pl.bytes));
     QMX_TRY(q->sp_fq.reserve((size_t)pl.list_cap * q->q_stride));
     QMX_TRY(q->partial.reserve((size_t)grid_cap * TQW_FQT * std::min<uint32_t>(top, MAX_TOP_FAST) * sizeof(uint64_t)));
@@ -239,18 +240,21 @@ static int32_t tq_wide_enqueue(qmx_query *q, uint32_t top, uint64_t n_cand, qmx_
         QMX_TRY(q->scores.reserve((size_t)nq_tile * S * sizeof(float)));
         QMX_TRY(score_matrix_enqueue(q, tile0, nq_tile, d_sample, S, (float *)q->scores.p, S, &launches));
         QMX_TRY(launch_custom_topk(q->stream, (const float *)q->scores.p, S, d_sample, a.del, nq_tile, top, d_out + (size_t)tile0 * top, d_counts + tile0, gthr));
-        // 2. the queries' digits as operand images, the integer reject bounds
-        QMX_TRY(launch_tq4w_pack(q->stream, a, gthr, s->tq_sf_min, s->tq_sf_max, s->tq_l2_min, s->tq_c1, q->sp_bq.p, thr_i, qinfo, band, (uint32_t *)q->sp_cnt.p, SPLIT_QT_MAX));
+        // 2. the queries' codes / digits as operand images, the integer reject bounds
+        if (sq) QMX_TRY(launch_sqw_pack(q->stream, a, gthr, s->sq_off_absmax, q->sp_bq.p, thr_i, qinfo, band, (uint32_t *)q->sp_cnt.p, SPLIT_QT_MAX));
+        else QMX_TRY(launch_tq4w_pack(q->stream, a, gthr, s->tq_sf_min, s->tq_sf_max, s->tq_l2_min, s->tq_c1, q->sp_bq.p, thr_i, qinfo, band, (uint32_t *)q->sp_cnt.p, SPLIT_QT_MAX));
         // 3. the pass
         uint32_t grid = 0;
         size_t slot = 0;
         if (timed) QMX_TRY(timing_begin(q, &slot));
-        QMX_TRY(launch_scan_tq4w(q->stream, a, q->sp_bq.p, thr_i, qinfo, s->num_cus, q->sp_wl.p, &grid));
+        if (sq) QMX_TRY(launch_scan_sqw(q->stream, a, q->sp_bq.p, thr_i, s->d_sq_bi, qinfo, s->num_cus, q->sp_wl.p, &grid));
+        else QMX_TRY(launch_scan_tq4w(q->stream, a, q->sp_bq.p, thr_i, qinfo, s->num_cus, q->sp_wl.p, &grid));
         wide_kernel = last_noted_kernel();
         if (timed) QMX_TRY(timing_end(q, slot));
         // 4. per-wave lists -> per-query lists (deleted rows dropped), then the k best keys of each query
         int *tile_ovf = (int *)(plan + pl.tile_ovf) + n_tiles;
-        QMX_TRY(launch_regroup_lists(q->stream, a.del, (const unsigned char *)q->sp_wl.p + tq4w_wlists_counts_bytes(s->num_cus), (const uint32_t *)q->sp_wl.p, tq4w_wcap(),
+        QMX_TRY(launch_regroup_lists(q->stream, a.del, (const unsigned char *)q->sp_wl.p + (sq ? sqw_wlists_counts_bytes(s->num_cus) : tq4w_wlists_counts_bytes(s->num_cus)), (const uint32_t *)q->sp_wl.p,
+                                     sq ? sqw_wcap() : tq4w_wcap(),
                                      grid * 8, (uint64_t *)q->sp_cand.p, (uint32_t *)q->sp_cnt.p, SPLIT_CAND_CAP, tile_ovf));
         QMX_TRY(launch_split_select(q->stream, (const uint64_t *)q->sp_cand.p, (const uint32_t *)q->sp_cnt.p, SPLIT_CAND_CAP, band, nq_tile, top, vp, tile0, tile_ovf,
                                     (uint32_t *)(plan + pl.ovf_q) + tile0, (SplitStats *)plan));
@@ -282,7 +286,8 @@ static int32_t tq_wide_enqueue(qmx_query *q, uint32_t top, uint64_t n_cand, qmx_
         const int fqt = (int)std::max<uint32_t>(16, pow2_ceil(nq_sub));
         a.partial_qt = (uint32_t)fqt;
         uint32_t grid = grid_cap;
-        QMX_TRY(launch_scan_tq_mfma(q->stream, fqt, SCAN_TOPK, a, s->num_cus, &grid));
+        if (sq) QMX_TRY(launch_scan_sq_mfma(q->stream, fqt, SCAN_TOPK, a, s->num_cus, &grid));
+        else QMX_TRY(launch_scan_tq_mfma(q->stream, fqt, SCAN_TOPK, a, s->num_cus, &grid));
         QMX_TRY(launch_merge_keys(q->stream, (const uint64_t *)q->partial.p, grid, (uint32_t)fqt, nq_sub, top, d_out, d_counts, top, 0, nullptr, run_if, ovf_list + p0));
         launches += 2;
     }
@@ -340,7 +345,15 @@ int32_t search_enqueue(qmx_query *q, uint32_t top, const uint32_t *d_ids, uint64
         fill_args(q, 0, std::min<uint32_t>(q->nq, SPLIT_QT), probe);
         probe.n_cand = n_cand;
         probe.top = top;
-        if (tq4w_shape_ok(probe)) return tq_wide_enqueue(q, top, n_cand, d_out, d_counts, is_stopped, counters, timed);
+        if (tq4w_shape_ok(probe)) return wide_exact_enqueue(q, top, n_cand, d_out, d_counts, is_stopped, counters, timed);
+    }
+    if (s->dtype == QMX_DTYPE_SQ_U8 && s->sq_wide && !d_ids && top <= MAX_TOP_FAST && n_cand >= (1u << 18) && mfma_scan_ok(s) && option(OPT_SQ_WIDE_MIN_QUERIES) > 0 &&
+        q->nq >= (uint32_t)option(OPT_SQ_WIDE_MIN_QUERIES)) {
+        ScanArgs probe;
+        fill_args(q, 0, std::min<uint32_t>(q->nq, SPLIT_QT), probe);
+        probe.n_cand = n_cand;
+        probe.top = top;
+        if (sqw_shape_ok(probe)) return wide_exact_enqueue(q, top, n_cand, d_out, d_counts, is_stopped, counters, timed);
     }
     // partial lists: one per block; bound the grid by what the buffer holds
     const uint32_t grid_cap = (uint32_t)s->num_cus * 8;

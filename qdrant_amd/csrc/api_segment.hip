@@ -20,6 +20,7 @@ static void segment_free(qmx_segment *seg) {
     if (seg->d_row_offsets) (void)hipFree(seg->d_row_offsets);
     if (seg->d_bq_mean) (void)hipFree(seg->d_bq_mean);
     if (seg->d_bq_stddev) (void)hipFree(seg->d_bq_stddev);
+    if (seg->d_sq_bi) (void)hipFree(seg->d_sq_bi);
     if (seg->d_tq_sf) (void)hipFree(seg->d_tq_sf);
     if (seg->d_tq_l2) (void)hipFree(seg->d_tq_l2);
     if (seg->d_tq_xm) (void)hipFree(seg->d_tq_xm);
@@ -293,6 +294,30 @@ static int32_t segment_split_stats(qmx_segment *s) {
     // an explicit flag: that copy; where it cannot be built (dims, memory, an element that is not finite) the other flags (if any) apply
     if ((s->flags & QMX_SEG_I8_COPY) && segment_i8_eligible(s) && segment_build_i8(s)) return QMX_OK;
     if ((s->flags & (QMX_SEG_SPLIT_COPY | QMX_SEG_HALF_COPY)) && segment_f16_eligible(s)) return segment_build_f16(s, (s->flags & QMX_SEG_HALF_COPY) != 0);
+    return QMX_OK;
+}
+
+// SQ blocks large enough for the 128-query pass (scan_sqw.hip): the largest vector_offset, which its integer reject bound rests on
+static int32_t segment_sq_stats(qmx_segment *s) {
+    if (s->dtype != QMX_DTYPE_SQ_U8 || s->n < (1u << 18) || !s->d_row_offsets || !sq_mfma_ok(s->distance, s->scan_dim) || !(s->sq.multiplier > 0.f) ||
+        s->scan_dim % 128 != 0)
+        return QMX_OK;
+    if (hipMalloc((void **)&s->d_sq_bi, (size_t)s->n * sizeof(int32_t)) != hipSuccess) {      // (no memory for the column: the 32-query kernel serves)
+        (void)hipGetLastError();
+        s->d_sq_bi = nullptr;
+        return QMX_OK;
+    }
+    uint32_t *d_stats = nullptr;
+    QMX_HIP(hipMalloc((void **)&d_stats, 8));
+    int32_t rc = QMX_OK;
+    uint32_t h[2] = {0u, 0u};
+    if (hipMemset(d_stats, 0, 8) != hipSuccess) rc = QMX_ERR_OTHER;
+    if (rc == QMX_OK) rc = launch_sqw_stats(nullptr, s->d_row_offsets, s->n, s->sq.multiplier, s->d_sq_bi, d_stats);
+    if (rc == QMX_OK && hipMemcpy(h, d_stats, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = QMX_ERR_OTHER;
+    (void)hipFree(d_stats);
+    if (rc != QMX_OK) return rc;
+    memcpy(&s->sq_off_absmax, &h[0], 4);
+    s->sq_wide = h[1] == 0 && s->sq_off_absmax < 3.0e38f;
     return QMX_OK;
 }
 
@@ -631,6 +656,7 @@ int32_t qmx_segment_create(const qmx_segment_desc *desc, qmx_segment **out) {
     if (rc == QMX_OK) rc = segment_split_stats(s);
     if (rc == QMX_OK) rc = segment_pq_rot(s);
     if (rc == QMX_OK) rc = segment_tq_stats(s);
+    if (rc == QMX_OK) rc = segment_sq_stats(s);
     if (rc != QMX_OK) {
         segment_free(s);
         return rc;

@@ -405,6 +405,17 @@ int32_t launch_tq4w_pack(hipStream_t st, const ScanArgs &a, const uint64_t *d_gt
                          float *d_qinfo, float *d_band, uint32_t *d_cand_cnt, uint32_t n_cnt);
 int32_t launch_scan_tq4w(hipStream_t st, const ScanArgs &a, const void *d_bq, const int32_t *d_thr_i, const float *d_qinfo, int num_cus, void *d_wlists,
                          uint32_t *grid_out);
+// scalar int8, 128 queries per pass: a wave's lanes fetch their own operand pieces, exact integer dots, candidate lists (scan_sqw.hip)
+bool sqw_shape_ok(const ScanArgs &a);
+size_t sqw_query_bytes(uint32_t dim);
+size_t sqw_wlists_counts_bytes(int num_cus);
+size_t sqw_wlists_bytes(int num_cus);
+uint32_t sqw_wcap();
+int32_t launch_sqw_stats(hipStream_t st, const float *d_off, uint64_t n, float multiplier, int32_t *d_bi, uint32_t *d_stats);
+int32_t launch_sqw_pack(hipStream_t st, const ScanArgs &a, const uint64_t *d_gthr, float off_absmax, void *d_bq, int32_t *d_thr_i, float *d_qinfo, float *d_band,
+                        uint32_t *d_cand_cnt, uint32_t n_cnt);
+int32_t launch_scan_sqw(hipStream_t st, const ScanArgs &a, const void *d_bq, const int32_t *d_thr_i, const int32_t *d_bi, const float *d_qinfo, int num_cus,
+                        void *d_wlists, uint32_t *grid_out);
 // the overflowed queries packed for the conditional exact passes: list, their pre-scan bounds, the passes' run flags
 int32_t launch_split_plan(hipStream_t st, const uint32_t *d_ovf_q, uint32_t nq, const uint64_t *d_gthr, uint32_t *d_list, uint64_t *d_gthr_packed, uint32_t list_cap,
                           uint32_t *d_count, int *d_run16, int *d_run64, uint32_t n_run64, SplitStats *d_stats, const void *d_queries, uint32_t q_stride,

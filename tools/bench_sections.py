@@ -635,7 +635,7 @@ def c3_section(ctx, rows):
     exact = qa.BatchFilteredSearcher(queries[:n_gt].cpu().numpy(), vs, top).peek_top_all()
     # ---- brute force over the codes, oversampling 2 + rescoring (PlainVectorIndex::search with quantization) ----
     bf = {}
-    for Qb in (1, 32):
+    for Qb in (1, 32, 128):
         nb = min(n_gt // Qb, 8)
         recs, stats = [], None
         for b in range(nb):
@@ -647,6 +647,8 @@ def c3_section(ctx, rows):
         stats["recall_at_10_vs_exact"] = round(float(np.mean(recs)), 4)
         stats["queries_checked"] = nb * Qb
         bf["Q%d" % Qb] = stats
+    if "Q32" in bf and "Q128" in bf and bf["Q32"].get("kernel_ms") and bf["Q128"].get("kernel_ms"):
+        bf["Q128"]["queries_per_ms_of_scan_vs_Q32"] = round((128 / bf["Q128"]["kernel_ms"]) / (32 / bf["Q32"]["kernel_ms"]), 2)
     out["brute_force_oversampling2_rescore"] = bf
     # ---- in-run oracle check: top-k over a sample of the codes, bit-exact scores; encoded rows byte-exact ----
     if args.verify:
@@ -725,7 +727,7 @@ def tq_section(ctx, rows):
     n_gt = 256
     exact = qa.BatchFilteredSearcher(queries[:n_gt].cpu().numpy(), vs, top).peek_top_all()
     bf = {}
-    for Qb in (1, 32):
+    for Qb in (1, 32, 128):
         nb = min(n_gt // Qb, 8)
         recs, stats = [], None
         for b in range(nb):
@@ -736,7 +738,14 @@ def tq_section(ctx, rows):
             recs.append(_recall(res, exact[b * Qb:(b + 1) * Qb], top))
         stats["recall_at_10_vs_exact"] = round(float(np.mean(recs)), 4)
         stats["queries_checked"] = nb * Qb
+        if Qb == 128 and stats.get("kernel_ms"):
+            # the 128-query pass (scan_tq4w.hip) is bound by the matrix cores, not by its 3.9 GB of codes: 2 digits x 2 x 128 x d integer operations per row
+            # against the dense int8 peak (MI355X guide: 5 033 TOP/s at 2.4 GHz; the chip holds ~1.93 GHz under this load)
+            tops = 2.0 * 2 * n * dim * Qb / (stats["kernel_ms"] * 1e-3) / 1e12
+            stats["matrix_cores"] = {"bound": "mfma", "achieved": round(tops, 1), "peak": 5033.0, "unit": "TOP/s (int8)", "frac": round(tops / 5033.0, 4)}
         bf["Q%d" % Qb] = stats
+    if "Q32" in bf and "Q128" in bf and bf["Q32"].get("kernel_ms") and bf["Q128"].get("kernel_ms"):
+        bf["Q128"]["queries_per_ms_of_scan_vs_Q32"] = round((128 / bf["Q128"]["kernel_ms"]) / (32 / bf["Q32"]["kernel_ms"]), 2)
     out["brute_force_oversampling2_rescore"] = bf
     if args.verify:
         import oracle_ffi as O

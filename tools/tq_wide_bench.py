@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--queries", type=int, default=128)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--distance", default="dot")
+    ap.add_argument("--storage", default="tq4", help="tq4 | sq")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     import numpy as np
@@ -39,19 +40,32 @@ def main():
     queries = torch.randn((nq, dim), generator=g, device=dev)
     queries /= queries.norm(dim=1, keepdim=True)
     dist = {"dot": qa.Distance.Dot, "euclid": qa.Distance.Euclid, "cosine": qa.Distance.Cosine}[args.distance]
-    quant = qa.TurboQuantizer(dim, dist, 0)
-    p = quant.params()
-    row_bytes = quant.quantized_vector_size()
-    codes = torch.empty((n, row_bytes), dtype=torch.uint8, device=dev)
-    F.check(lib.qmx_tq_encode(0, int(dist), dim, C.byref(p), F.ptr(rows), n, F.ptr(codes)))
-    torch.cuda.synchronize(dev)
-    del rows
-    enc = qa.EncodedVectorsTQ(codes, quant)
+    if args.storage == "sq":
+        quant = qa.ScalarQuantizer.fit(rows, dim, dist)
+        p = quant.params()
+        row_bytes = quant.quantized_vector_size()
+        codes = torch.empty((n, row_bytes), dtype=torch.uint8, device=dev)
+        F.check(lib.qmx_sq_encode(0, int(dist), C.byref(p), F.ptr(rows), n, dim, F.ptr(codes)))
+        torch.cuda.synchronize(dev)
+        del rows
+        enc = qa.EncodedVectorsU8(codes, quant)
+        opt = "sq_wide_min_queries"
+    else:
+        quant = qa.TurboQuantizer(dim, dist, 0)
+        p = quant.params()
+        row_bytes = quant.quantized_vector_size()
+        codes = torch.empty((n, row_bytes), dtype=torch.uint8, device=dev)
+        F.check(lib.qmx_tq_encode(0, int(dist), dim, C.byref(p), F.ptr(rows), n, F.ptr(codes)))
+        torch.cuda.synchronize(dev)
+        del rows
+        enc = qa.EncodedVectorsTQ(codes, quant)
+        opt = "tq_wide_min_queries"
     del codes
-    out = {"rows": n, "dim": dim, "queries": nq, "row_bytes": row_bytes, "distance": args.distance}
+    digits = 1 if args.storage == "sq" else 2
+    out = {"storage": args.storage, "rows": n, "dim": dim, "queries": nq, "row_bytes": row_bytes, "distance": args.distance}
     lists = {}
-    for name, opt in (("narrow_32_per_pass", 0), ("wide_128_per_pass", 33)):
-        qa.set_option("tq_wide_min_queries", opt)
+    for name, optv in (("narrow_32_per_pass", 0), ("wide_128_per_pass", 33)):
+        qa.set_option(opt, optv)
         s = qa.BatchFilteredSearcher(queries.cpu().numpy(), enc, top)
         F.check(lib.qmx_query_set_timing(s.scorer._h, 1))
         res = s.peek_top_all()      # warm-up
@@ -70,10 +84,10 @@ def main():
                      "scan_ms_per_search": round(per_search, 4), "wall_ms_per_search": round(wall * 1e3, 3), "qps_wall": round(nq / wall, 1),
                      "qps_scan": round(nq / (per_search * 1e-3), 1),
                      "hbm_frac_of_8TBps": round(n * row_bytes * (launches / args.reps) / (per_search * 1e-3) / 8e12, 4),
-                     "int8_mfma_frac_of_5POPS": round(2.0 * 2 * n * dim * nq / (per_search * 1e-3) / 5.0e15, 4),
+                     "int8_mfma_frac_of_5POPS": round(2.0 * digits * n * dim * nq / (per_search * 1e-3) / 5.0e15, 4),
                      "fallback_queries": int(c.fallback_queries), "candidates": int(c.prefilter_candidates), "verified_rows": int(c.verified_rows)}
         lists[name] = res
-    qa.set_option("tq_wide_min_queries", -1)
+    qa.set_option(opt, -1)
     a, b = lists["narrow_32_per_pass"], lists["wide_128_per_pass"]
     out["lists_equal"] = bool(all(x["idx"].tolist() == y["idx"].tolist() and np.array_equal(x["score"].view(np.uint32), y["score"].view(np.uint32))
                                   for x, y in zip(a, b)))
