@@ -31,7 +31,8 @@ constexpr int SW_QT = 128;                                   // queries per pass
 constexpr int SW_B_UNITS = SW_QT * 2 * 4;                    // 16-byte units of the queries' stage: 128 queries x 2 steps of 64 codes x 4 pieces = 16 KiB
 constexpr int SW_R_UNITS = SW_BM * 8;                        // ... of a stage's codes: 256 rows x 128 bytes = 32 KiB
 constexpr int SW_RING = 3;                                   // code stages staged in LDS
-constexpr int SW_LDS = (2 * SW_B_UNITS + SW_RING * SW_R_UNITS) * 16 + SW_QT * 4 + 2 * 8 * 64 * 4;      // 32 + 96 KiB + the 128 integer bounds + the rows' column entries of two tiles
+constexpr int SW_BRING = 3;                                  // query stages in LDS
+constexpr int SW_LDS = (SW_BRING * SW_B_UNITS + SW_RING * SW_R_UNITS) * 16 + SW_QT * 4 + 2 * 8 * 64 * 4;      // 48 + 96 KiB + the 128 integer bounds + the rows' column entries of two tiles
 constexpr uint32_t SW_WCAP = 8192;                           // candidates one wave may list per pass
 
 // unit index of (16-query tile t, 64-code step hl, piece kq, query-in-tile m): scan_split.hip sp_unit, conflict-free for the operand reads
@@ -125,14 +126,15 @@ __global__ __launch_bounds__(256) void sqw_pack_kernel(const unsigned char *quer
 // (m, kg) fetches, per stage, the 16 code bytes [64 s + 16 kg, +16) of rows m and 16 + m for both 64-code steps s - exactly its operand registers of the
 // stage's four A-side (step, row tile) combinations - and multiplies with all 128 queries: 32 matrix instructions and 16 operand reads per wave and stage.
 // EVERYTHING the loop fetches arrives by LDS-DMA and is counted by the kernel itself (scan_tq4w.hip: a plain vector load inside the loop and the
-// compiler's conservative `s_waitcnt vmcnt(0)` drains the streams at every stage).  Per stage g a wave asks for the queries' images of stage g + 1 (two 1 KiB
-// pieces) and for its codes of stage g + 2 (four), reads its own operands of stage g from its staging area, multiplies, waits for the queries of stage g + 1
-// (which, vmcnt being in-order, also lands the codes of stage g + 1) and meets the others at the stage barrier - the queries' buffers are all the waves share.
-// LDS: queries 2 x 16 KiB, code staging 3 stages x 32 KiB.
+// compiler's conservative `s_waitcnt vmcnt(0)` drains the streams at every stage).  Per stage g a wave asks for the queries' images (two 1 KiB pieces) and for its codes
+// (four) of stage g + 2, reads its own operands of stage g from its staging area, multiplies, waits for everything but this stage's six requests - the queries
+// and its codes of stage g + 1, one to two stages old - and meets the others at the stage barrier (the queries' buffers are all the waves share).  (Asking for
+// the queries ONE stage ahead made the end-of-stage wait - vmcnt is in-order - land the codes asked for half a stage earlier: 1.78 ms per 10 M x 768 pass.)
+// LDS: queries 3 x 16 KiB, code staging 3 stages x 32 KiB.
 __global__ __launch_bounds__(SW_THREADS, 1) void scan_sqw_kernel(const ScanArgs a, const SqWideArgs s) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint4 *lds = reinterpret_cast<uint4 *>(smem_raw);
-    int32_t *thr_lds = reinterpret_cast<int32_t *>(smem_raw + (size_t)(2 * SW_B_UNITS + SW_RING * SW_R_UNITS) * 16);
+    int32_t *thr_lds = reinterpret_cast<int32_t *>(smem_raw + (size_t)(SW_BRING * SW_B_UNITS + SW_RING * SW_R_UNITS) * 16);
     int32_t *bi_lds = thr_lds + SW_QT;      // [tile parity][wave][64]: B of the wave's 32 rows (lanes 32..63 repeat them)
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(SW_THREADS, 1) void scan_sqw_kernel(const ScanArgs 
     const uint32_t b_rd = sw_unit(0, 0, kq_r, m_r);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(sw_lds_byte *)smem_raw;
     const uint32_t lane_off = (uint32_t)lane * 16u;
-    uint4 *const b_lds = lds, *const r_lds = lds + 2 * SW_B_UNITS;
+    uint4 *const b_lds = lds, *const r_lds = lds + SW_BRING * SW_B_UNITS;
     const unsigned char *rows = reinterpret_cast<const unsigned char *>(a.rows);
     const uint64_t last_row = a.n_cand - 1;
     const uint32_t row_stride32 = (uint32_t)a.row_stride;
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(SW_THREADS, 1) void scan_sqw_kernel(const ScanArgs 
     auto codes_begin = [&](uint64_t it, uint32_t kc, uint32_t slot) {
         const uint64_t row0 = (blockIdx.x + it * gridDim.x) * SW_BM;
         rc_src = uniform_ptr((uint64_t)(uintptr_t)(rows + row0 * a.row_stride + kc * 128u));
-        rc_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + (2 * SW_B_UNITS + slot * SW_R_UNITS) * 16u + (uint32_t)w * 1024u));
+        rc_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + (SW_BRING * SW_B_UNITS + slot * SW_R_UNITS) * 16u + (uint32_t)w * 1024u));
         rc_o0 = coff0;
         rc_o1 = coff1;
         const uint64_t room = last_row - row0;                      // (row0 <= last_row: the tile exists)
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(SW_THREADS, 1) void scan_sqw_kernel(const ScanArgs 
         const uint32_t r = (uint32_t)w * 32u + ((uint32_t)lane & 31u);
         const uint32_t rc = (uint64_t)r < room ? r : (uint32_t)room;
         const unsigned char *src = uniform_ptr((uint64_t)(uintptr_t)(s.bi + row0));
-        const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + (2 * SW_B_UNITS + SW_RING * SW_R_UNITS) * 16u + SW_QT * 4u + (((uint32_t)it & 1u) * 8u + (uint32_t)w) * 256u));
+        const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + (SW_BRING * SW_B_UNITS + SW_RING * SW_R_UNITS) * 16u + SW_QT * 4u + (((uint32_t)it & 1u) * 8u + (uint32_t)w) * 256u));
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(rc * 4u), "s"(src), "s"(dst) : "memory");
@@ -280,14 +282,16 @@ __global__ __launch_bounds__(SW_THREADS, 1) void scan_sqw_kernel(const ScanArgs 
         queries_begin(0, 0);
         queries_piece(0);
         queries_piece(1);
+        queries_begin(nch > 1 ? 1 : 0, 1);
+        queries_piece(0);
+        queries_piece(1);
         request_bi(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     sw_stage_barrier();
     uint64_t it = 0;
-    uint32_t kc = 0, rslot = 0;
+    uint32_t kc = 0, rslot = 0, bslot = 0;
     for (uint64_t g = 0; g < n_stages; ++g) {
-        const uint32_t slot = (uint32_t)g & 1u;
         if (kc == 0) {
             if (it) {
                 epilogue(it - 1);
@@ -306,8 +310,8 @@ __global__ __launch_bounds__(SW_THREADS, 1) void scan_sqw_kernel(const ScanArgs 
 #pragma unroll
             for (int i = 0; i < 4; ++i) av[i >> 1][i & 1] = src[i * 512];
         }
-        const uint32_t kc1 = kc + 1 == nch ? 0 : kc + 1;
-        queries_begin(kc1, slot ^ 1u);                      // stage g + 1 -> the buffer stage g - 1 was read from (everybody is past that barrier)
+        const uint32_t kc2 = (kc + 2) % nch;
+        queries_begin(kc2, bslot + 2 >= SW_BRING ? bslot + 2 - SW_BRING : bslot + 2);      // stage g + 2 -> the buffer stage g - 1 was read from (everybody is past that barrier)
         {
             uint64_t itp;
             uint32_t kcp;
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(SW_THREADS, 1) void scan_sqw_kernel(const ScanArgs 
             const uint32_t ws = rslot + 2 >= SW_RING ? rslot + 2 - SW_RING : rslot + 2;      // the slot stage g - 1 was read from, one stage ago
             codes_begin(itp, kcp, ws);
         }
-        const uint4 *bb = b_lds + slot * SW_B_UNITS + b_rd;
+        const uint4 *bb = b_lds + bslot * SW_B_UNITS + b_rd;
         constexpr int SW_AHEAD = 3;
         i32x4q bv[SW_AHEAD + 1];
 #pragma unroll
@@ -331,10 +335,13 @@ __global__ __launch_bounds__(SW_THREADS, 1) void scan_sqw_kernel(const ScanArgs 
             else if (k < 6) codes_piece(k - 2);
             __builtin_amdgcn_sched_barrier(0);
         }
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // the queries of stage g + 1 (and, older, the codes of stage g + 1); this stage's four code requests may be on their way
+        // all but this stage's requests have landed - six, or seven with a tile's column entries: the queries and this wave's codes of stage g + 1, a stage old
+        if (kc == 0 && it) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         sw_stage_barrier();
         if (++kc == nch) { kc = 0; ++it; }
         rslot = rslot + 1 == SW_RING ? 0 : rslot + 1;
+        bslot = bslot + 1 == SW_BRING ? 0 : bslot + 1;
     }
     epilogue(my_tiles - 1);
     if (lane == 0) s.wcnt[blockIdx.x * (SW_THREADS / 64) + (uint32_t)w] = wcount;
