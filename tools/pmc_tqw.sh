@@ -20,7 +20,7 @@ print("rocprofv3 --pmc (one pass per group) over tools/tq_wide_bench.py --reps 2
 for db in sorted(glob.glob("$OUT/g*/**/*.db", recursive=True)):
     c = sqlite3.connect(db)
     try:
-        rows = list(c.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection where kernel_name like '%scan_tq4w_kernel%' or kernel_name like '%scan_sq_mfma_kernel%' group by kernel_name, counter_name"))
+        rows = list(c.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection where kernel_name like '%scan_tq4w_kernel%' or kernel_name like '%scan_sqw_kernel%' or kernel_name like '%scan_sq_mfma_kernel%' group by kernel_name, counter_name"))
     except Exception as e:
         print(db, e); continue
     for n, cn, k, avg in rows:
