@@ -169,7 +169,12 @@ def _pick(d, *keys):
     return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
 
 
-LEG_COLUMNS = "legs[kernel,kernel_ms,bound,frac,qps_wall,recall_at_10]"
+LEG_COLUMNS = "legs[kernel,ms,bound,frac,qps,recall@10]"
+
+
+def _qps(v):
+    """whole numbers from 1 000 QPS up (the headline is 4 KB)"""
+    return int(round(v)) if isinstance(v, (int, float)) and v >= 1000 else v
 
 
 def _leg(st):
@@ -184,7 +189,8 @@ def _leg(st):
         bound, frac = "lds", r["lds"].get("frac")
     if isinstance(st.get("matrix_cores"), dict):      # ... against the matrix cores' peak likewise (the 128-query TurboQuant pass)
         bound, frac = "mfma", st["matrix_cores"].get("frac")
-    return [_short(st.get("kernel", "")).replace("_kernel", "").replace("hnsw_search<", "walk<")[:20], st.get("kernel_ms"), bound, frac, st.get("qps_wall"), st.get("recall_at_10_vs_exact")]
+    ms = st.get("kernel_ms")
+    return [_short(st.get("kernel", "")).replace("_kernel", "").replace("hnsw_search<", "walk<")[:17], round(ms, 3) if isinstance(ms, float) else ms, bound, frac, _qps(st.get("qps_wall")), st.get("recall_at_10_vs_exact")]
 
 
 def _block_stream(p):
@@ -219,8 +225,8 @@ def compact_roofline(result):
         out = {"bound": "hbm", "achieved": p["achieved"], "peak": p["peak"], "unit": "GB/s", "frac": p["frac"], "traffic": p.get("traffic"),
                # (counters cannot be read from inside the process: `traffic` is this kernel symbol's entry of profiles/pmc_traffic.json - separate rocprofv3 --pmc
                # passes at this row count, the file names the round that measured it)
-               "traffic_source": "lookup (pmc_traffic.json <- %s), no counter of this run" % os.path.basename(str(p.get("traffic_source") or "?")),
-               "of": "block_stream = SURVEY 8(d): the exact scan of the stored f32 block, %d queries, same run; `value` is timed_kernel's path, not this one" % bs["batch"],
+               "traffic_source": "lookup <- %s" % os.path.basename(str(p.get("traffic_source") or "?")),
+               "of": "block_stream = SURVEY 8(d): exact scan of the stored f32 block; `value` is timed_kernel's path",
                "block_stream": bs}
         if bs1:
             out["block_stream_q1"] = _pick(bs1, "kernel", "batch", "kernel_ms", "frac", "traffic_over_algorithmic")
@@ -245,8 +251,6 @@ def _walk_summary(ow, cost=None):
                                                                    ow.get("reference_heap_order_same_pops"))
     if isinstance(cost, dict) and "kernel_ms" in cost:
         out["reference_heap_order_ms"] = [cost["kernel_ms"], cost.get("over_default_walk")]      # [kernel ms per launch, x the default walk]
-    if "mfma_lut_same_id_sets" in ow:
-        out["mfma_lut_same_id_sets"] = ow["mfma_lut_same_id_sets"]
     return out
 
 
@@ -271,9 +275,10 @@ def _configs_summary(cfg):
             put("C3.walk_iid_rows", cfg.get("C3_walk_on_iid_rows"))
             put("C3.scan_Q1", bf.get("Q1"))
             put("C3.scan_Q32", bf.get("Q32"))
+            put("C3.scan_Q128", bf.get("Q128"))
             put("C3.walk", h)
             ow = h.get("oracle_walk_check", {})
-            out["C3"] = {"rows": "latent-32 (walk_iid_rows: C2's rows)", "build_s": h.get("build_s"), "oracle_walk": _walk_summary(ow, h.get("reference_heap_order")),
+            out["C3"] = {"rows": "latent-32", "build_s": h.get("build_s"), "oracle_walk": _walk_summary(ow, h.get("reference_heap_order")),
                          "oracle_scan_ok": all(v is True for v in c3.get("oracle_check", {"-": None}).values())}
     tq = cfg.get("TQ4")
     if isinstance(tq, dict):
@@ -292,11 +297,9 @@ def _configs_summary(cfg):
             w = h.get("walks", {})
             lut = c4.get("lut_build_mfma", {})
             put("C4.walk", w.get("no_rescoring"))
-            put("C4.walk_over2_rescore", w.get("oversampling2_rescore"))
-            put("C4.walk_lut_free", w.get("no_rescoring_lut_free_walk"))
             put("C4.scan_Q32", c4.get("brute_force_Q32_oversampling2_rescore"))
             ow = h.get("oracle_walk_check", {})
-            out["C4"] = {"rows": "latent-32", "build_s": h.get("build_s"), "hop_prefilter": _pick(h.get("hop_prefilter", {}), "survivors_per_hop", "G_requests_per_s"), "lut_mfma": _pick(lut.get("kernel_roofline", lut.get("roofline", {})), "achieved", "peak", "frac", "kernel_ms"),
+            out["C4"] = {"rows": "latent-32", "build_s": h.get("build_s"), "hop_prefilter": _pick(h.get("hop_prefilter", {}), "survivors_per_hop", "G_requests_per_s"), "lut_mfma": _pick(lut.get("kernel_roofline", lut.get("roofline", {})), "achieved", "frac", "kernel_ms"),
                          "oracle_walk": _walk_summary(ow, h.get("reference_heap_order"))}
     out[LEG_COLUMNS] = legs
     return out
@@ -312,13 +315,11 @@ def headline(result, details_path=None):
     hc = _pick(c, "workload", "rows_per_gpu", "dim", "batch", "top", "batches_in_flight", "prewarm_steps")
     if result.get("n_gpus", 1) > 1:
         hc.update(_pick(c, "collection_qps", "segment_searches_per_s", "collectives_per_step", "per_step_us", "unit_of_value"))
-    if "timed_path" in c:
+    if "timed_path" in c and result.get("n_gpus", 1) > 1:      # (at N = 1 `dtype` and roofline.timed_kernel say it; the details carry the sentence)
         hc["timed_path"] = c["timed_path"].split(":")[0].replace(" of the block (1 B / element, int8 matrix cores)", "").replace(" of the survivors", "")[:100]
     dc = c.get("derived_copy")
     if isinstance(dc, dict):
-        hc["derived_copy"] = "%s (requested %s%s)" % (dc.get("derived_copy"), dc.get("requested"),
-                                                      "; trial: i8 %.2f ms, half %.2f ms" % (dc.get("trial_i8_ms", 0.0), dc.get("trial_half_ms", 0.0))
-                                                      if dc.get("chosen_by_trial") else "")
+        hc["derived_copy"] = "%s (requested %s)" % (dc.get("derived_copy"), dc.get("requested"))      # (the trial's timings: details)
     h["config"] = hc
     h["roofline"] = compact_roofline(result)
     cb = result.get("cpu_baseline")
