@@ -289,8 +289,15 @@ __global__ __launch_bounds__(SW_THREADS, 1) void scan_sqw_kernel(const ScanArgs 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     sw_stage_barrier();
-    uint64_t it = 0;
-    uint32_t kc = 0, rslot = 0, bslot = 0;
+    uint64_t it = 0, it2 = 0;
+    uint32_t kc = 0, rslot = 0, bslot = 0, kc2c = 0;
+    {   // stage 2 as (tile, kc); past the block's last stage the requests repeat it
+        uint64_t i0;
+        uint32_t k0;
+        stage_at(2, i0, k0);
+        it2 = i0;
+        kc2c = k0;
+    }
     for (uint64_t g = 0; g < n_stages; ++g) {
         if (kc == 0) {
             if (it) {
@@ -310,12 +317,15 @@ __global__ __launch_bounds__(SW_THREADS, 1) void scan_sqw_kernel(const ScanArgs 
 #pragma unroll
             for (int i = 0; i < 4; ++i) av[i >> 1][i & 1] = src[i * 512];
         }
-        const uint32_t kc2 = (kc + 2) % nch;
+        uint32_t kc2 = kc + 2;      // (kc + 2) mod nch
+        if (kc2 >= nch) kc2 -= nch;
+        if (kc2 >= nch) kc2 -= nch;
         queries_begin(kc2, bslot + 2 >= SW_BRING ? bslot + 2 - SW_BRING : bslot + 2);      // stage g + 2 -> the buffer stage g - 1 was read from (everybody is past that barrier)
         {
-            uint64_t itp;
-            uint32_t kcp;
-            stage_at(g + 2, itp, kcp);
+            const uint64_t itp = it2;      // (stage g + 2, kept by running counters: two 64-bit divisions per stage were a third of the scalar instructions)
+            const uint32_t kcp = kc2c;
+            if (kc2c + 1 < nch) ++kc2c;
+            else if (it2 + 1 < my_tiles) { kc2c = 0; ++it2; }
             const uint32_t ws = rslot + 2 >= SW_RING ? rslot + 2 - SW_RING : rslot + 2;      // the slot stage g - 1 was read from, one stage ago
             codes_begin(itp, kcp, ws);
         }

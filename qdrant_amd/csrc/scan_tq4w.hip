@@ -422,8 +422,9 @@ __global__ __launch_bounds__(TW_THREADS, 1) void scan_tq4w_kernel(const ScanArgs
         decode_all(c0, c1);
     }
     tw_stage_barrier();
-    uint64_t it = 0, P = 0;
-    uint32_t kc = 0;
+    uint64_t it = 0, P = 0, it2 = 0;
+    uint32_t kc = 0, kp2 = 0;
+    pair_at(2, it2, kp2);
     // one stage of the loop; `sp` = its place inside its pair = the parity of g (nch is even) = the queries' buffer it reads; the operand registers
     // ping-pong between two sets (cur -> the matrix instructions, nxt <- the decode), so the loop body is a pair of stages
     auto one_stage = [&](const uint32_t sp, const uint4 (&ce)[2], const uint4 (&co)[2], uint4 (&de)[2], uint4 (&dd)[2]) __attribute__((always_inline)) {
@@ -446,17 +447,18 @@ __global__ __launch_bounds__(TW_THREADS, 1) void scan_tq4w_kernel(const ScanArgs
         queries_begin(kc1, sp ^ 1u);                        // the next stage's -> the buffer the previous stage was read from (everybody is past that barrier)
         {   // pair P + 2 -> the staging slot of pair P: its first stage's units were read a stage pair ago, its second stage's just now (sp = 0) - the
             // requests of this stage overwrite the first stage's half (sp = 0: pieces 0, 1) or the second's (sp = 1: pieces 2, 3)
-            uint64_t itp;
-            uint32_t kpp;
-            pair_at(P + 2, itp, kpp);
-            codes_begin(itp, kpp, (uint32_t)P & 1u);
+            codes_begin(it2, kp2, (uint32_t)P & 1u);      // (pair P + 2 as (tile, pair of the tile): running counters, advanced when P is)
             slot_piece0 = sp * 2u;
         }
         stage(sp, c0, c1, ce, co, de, dd);
         asm volatile("s_waitcnt vmcnt(2)" ::: "memory");    // the queries of the next stage (the two code requests behind them may be on their way)
         tw_stage_barrier();
         if (++kc == nch) { kc = 0; ++it; }
-        if (sp == 1) ++P;
+        if (sp == 1) {
+            ++P;
+            if (kp2 + 1 < npair) ++kp2;
+            else if (it2 + 1 < my_tiles) { kp2 = 0; ++it2; }
+        }
     };
     for (uint64_t g = 0; g < n_stages; g += 2) {
         one_stage(0, ae, ao, ne, no);
