@@ -92,7 +92,7 @@ struct qmx_segment {
     bool tq_invert = false;
     float *d_tq_sf = nullptr, *d_tq_l2 = nullptr, *d_tq_xm = nullptr;   // extras columns (xm: TQ+ only)
     bool tq_wide = false;              // 4-bit block the 128-query pass serves (scan_tq4w.hip): its extras columns are positive finite numbers, ranges below
-    float tq_sf_min = 0.f, tq_sf_max = 0.f, tq_l2_min = 0.f;
+    float tq_sf_min = 0.f, tq_sf_max = 0.f, tq_l2_min = 0.f, tq_l2_max = 0.f;
     uint32_t tq_c1 = 0;                // ... and the largest sum of |codebook bytes| over a row's codes
     float *d_tq_shift = nullptr, *d_tq_scale = nullptr;                   // TQ+ ErrorCorrection (device copies), or null
     int16_t *d_tq_weights = nullptr;                                      // ... d_prime_sq_i16

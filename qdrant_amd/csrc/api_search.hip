@@ -191,6 +191,9 @@ static int32_t wide_exact_enqueue(qmx_query *q, uint32_t top, uint64_t n_cand, q
                                   qmx_counters *counters, bool timed) {
     const qmx_segment *s = q->seg;
     const bool sq = s->dtype == QMX_DTYPE_SQ_U8;
+    // TurboQuant: the pass multiplies the queries' HIGH digits only; its scores are within band[q] of the exact ones, the selection keeps what an exact
+    // score >= T could hide behind (approximate >= T - band: sp_select_kernel's exact-bound form) and the pair kernel re-scores that
+    const bool tq_high = !sq && !option(OPT_TQ_WIDE_BOTH_DIGITS);
     const SplitPlanLayout pl(q->nq, TQW_FQT);
     const uint32_t grid_cap = (uint32_t)s->num_cus * 8;
     QMX_TRY(q->gthr.reserve((size_t)std::max<uint32_t>(q->nq_padded, SPLIT_QT) * sizeof(uint64_t)));
@@ -242,13 +245,14 @@ static int32_t wide_exact_enqueue(qmx_query *q, uint32_t top, uint64_t n_cand, q
         QMX_TRY(launch_custom_topk(q->stream, (const float *)q->scores.p, S, d_sample, a.del, nq_tile, top, d_out + (size_t)tile0 * top, d_counts + tile0, gthr));
         // 2. the queries' codes / digits as operand images, the integer reject bounds
         if (sq) QMX_TRY(launch_sqw_pack(q->stream, a, gthr, s->sq_off_absmax, q->sp_bq.p, thr_i, qinfo, band, (uint32_t *)q->sp_cnt.p, SPLIT_QT_MAX));
-        else QMX_TRY(launch_tq4w_pack(q->stream, a, gthr, s->tq_sf_min, s->tq_sf_max, s->tq_l2_min, s->tq_c1, q->sp_bq.p, thr_i, qinfo, band, (uint32_t *)q->sp_cnt.p, SPLIT_QT_MAX));
+        else QMX_TRY(launch_tq4w_pack(q->stream, a, gthr, s->tq_sf_min, s->tq_sf_max, s->tq_l2_min, s->tq_l2_max, s->tq_c1, tq_high ? 1 : 0, q->sp_bq.p, thr_i, qinfo, band,
+                                      (uint32_t *)q->sp_cnt.p, SPLIT_QT_MAX));
         // 3. the pass
         uint32_t grid = 0;
         size_t slot = 0;
         if (timed) QMX_TRY(timing_begin(q, &slot));
         if (sq) QMX_TRY(launch_scan_sqw(q->stream, a, q->sp_bq.p, thr_i, s->d_sq_bi, qinfo, s->num_cus, q->sp_wl.p, &grid));
-        else QMX_TRY(launch_scan_tq4w(q->stream, a, q->sp_bq.p, thr_i, qinfo, s->num_cus, q->sp_wl.p, &grid));
+        else QMX_TRY(launch_scan_tq4w(q->stream, a, q->sp_bq.p, thr_i, qinfo, tq_high ? band : nullptr, s->num_cus, q->sp_wl.p, &grid));
         wide_kernel = last_noted_kernel();
         if (timed) QMX_TRY(timing_end(q, slot));
         // 4. per-wave lists -> per-query lists (deleted rows dropped), then the k best keys of each query
@@ -257,7 +261,7 @@ static int32_t wide_exact_enqueue(qmx_query *q, uint32_t top, uint64_t n_cand, q
                                      sq ? sqw_wcap() : tq4w_wcap(),
                                      grid * 8, (uint64_t *)q->sp_cand.p, (uint32_t *)q->sp_cnt.p, SPLIT_CAND_CAP, tile_ovf));
         QMX_TRY(launch_split_select(q->stream, (const uint64_t *)q->sp_cand.p, (const uint32_t *)q->sp_cnt.p, SPLIT_CAND_CAP, band, nq_tile, top, vp, tile0, tile_ovf,
-                                    (uint32_t *)(plan + pl.ovf_q) + tile0, (SplitStats *)plan));
+                                    (uint32_t *)(plan + pl.ovf_q) + tile0, (SplitStats *)plan, tq_high ? qinfo + 3 * SPLIT_QT : nullptr, tq_high));
         launches += 6;
     }
     // 5. the selected rows through the pair kernel (the same bits), sorted by (score, lower id first)

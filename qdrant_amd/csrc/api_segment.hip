@@ -336,7 +336,8 @@ static int32_t segment_tq_stats(qmx_segment *s) {
     memcpy(&s->tq_sf_min, &h[0], 4);
     memcpy(&s->tq_sf_max, &h[1], 4);
     memcpy(&s->tq_l2_min, &h[2], 4);
-    if (!s->d_tq_l2) s->tq_l2_min = 0.f;
+    memcpy(&s->tq_l2_max, &h[5], 4);
+    if (!s->d_tq_l2) s->tq_l2_min = s->tq_l2_max = 0.f;
     s->tq_c1 = h[4];
     s->tq_wide = h[3] == 0 && s->tq_sf_min > 0.f && s->tq_sf_max < 3.0e38f && s->tq_sf_min <= s->tq_sf_max;
     return QMX_OK;

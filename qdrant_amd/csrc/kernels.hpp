@@ -376,7 +376,7 @@ struct VerifyPool {
 };
 int32_t launch_split_select(hipStream_t st, const uint64_t *d_cand, const uint32_t *d_cand_cnt, uint32_t cap, const float *d_band, uint32_t nq, uint32_t top,
                             const VerifyPool &pool, uint32_t q_base, const int *d_tile_overflow, uint32_t *d_ovf_q, SplitStats *d_stats,
-                            const float *d_t_exact = nullptr);
+                            const float *d_t_exact = nullptr, bool tighten = false);
 // the int8 copy of an f32 block (QMX_SEG_I8_COPY) and its passes (scan_split.hip, "The INT8 copy")
 bool split_i8_dim_ok(uint32_t dim);
 size_t split_i8_copy_bytes(uint64_t n, uint32_t dim);
@@ -401,10 +401,11 @@ size_t tq4w_wlists_counts_bytes(int num_cus);
 size_t tq4w_wlists_bytes(int num_cus);
 uint32_t tq4w_wcap();
 int32_t launch_tq4w_stats(hipStream_t st, const float *d_sf, const float *d_l2, const void *d_rows, uint64_t row_stride, uint32_t code_bytes, uint64_t n, uint32_t *d_stats);
-int32_t launch_tq4w_pack(hipStream_t st, const ScanArgs &a, const uint64_t *d_gthr, float sf_min, float sf_max, float l2_min, uint32_t c1, void *d_bq, int32_t *d_thr_i,
+int32_t launch_tq4w_pack(hipStream_t st, const ScanArgs &a, const uint64_t *d_gthr, float sf_min, float sf_max, float l2_min, float l2_max, uint32_t c1, int high_only,
+                         void *d_bq, int32_t *d_thr_i,
                          float *d_qinfo, float *d_band, uint32_t *d_cand_cnt, uint32_t n_cnt);
-int32_t launch_scan_tq4w(hipStream_t st, const ScanArgs &a, const void *d_bq, const int32_t *d_thr_i, const float *d_qinfo, int num_cus, void *d_wlists,
-                         uint32_t *grid_out);
+int32_t launch_scan_tq4w(hipStream_t st, const ScanArgs &a, const void *d_bq, const int32_t *d_thr_i, const float *d_qinfo, const float *d_band_high_only, int num_cus,
+                         void *d_wlists, uint32_t *grid_out);
 // scalar int8, 128 queries per pass: a wave's lanes fetch their own operand pieces, exact integer dots, candidate lists (scan_sqw.hip)
 bool sqw_shape_ok(const ScanArgs &a);
 size_t sqw_query_bytes(uint32_t dim);

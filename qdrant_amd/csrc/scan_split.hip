@@ -991,7 +991,8 @@ __global__ __launch_bounds__(SEL_BLOCK) void sp_refine_kernel(const uint64_t *ca
 
 __global__ __launch_bounds__(SEL_BLOCK) void sp_select_kernel(const uint64_t *cand, const uint32_t *cand_cnt, uint32_t cap, const float *band, uint32_t top,
                                                               const VerifyPool pool, uint32_t q_base, const int *tile_overflow, uint32_t *ovf_q,
-                                                              SplitStats *stats, const float *t_exact /* or nullptr: an exact lower bound of the k-th best score per query */) {
+                                                              SplitStats *stats, const float *t_exact /* or nullptr: an exact lower bound of the k-th best score per query */,
+                                                              bool tighten /* with t_exact: the k-th best approximate score's bound as well */) {
     __shared__ SelShared sel_sh;
     uint64_t (*const sh)[WAVE] = sel_sh.sh;
     SelScratch &scratch = sel_sh.scratch;
@@ -1011,7 +1012,15 @@ __global__ __launch_bounds__(SEL_BLOCK) void sp_select_kernel(const uint64_t *ca
     // with an exact bound T (the int8 copy's passes): a result row's approximate score is >= T - band; without: the k-th best approximate score A_k
     // proves k rows with an exact score >= A_k - band, so >= A_k - 2 band
     const bool have_t = t_exact != nullptr && t_exact[q] > -__builtin_inff();
-    if (have_t) {
+    if (have_t && tighten) {
+        // both bounds (the 128-query TurboQuant pass: T comes from a sample alone, so A_k - 2 band is usually the tighter cut)
+        if (raw <= (uint32_t)SEL_SURV) block_kth_key_ranked(c, raw, top, &scratch, &sh_kth);
+        else block_kth_key(c, raw, (int)top, sh, &sh_kth);
+        if (threadIdx.x == 0) {
+            const float by_t = t_exact[q] - band[q], by_k = sh_kth ? key_score(sh_kth) - 2.0f * band[q] : -__builtin_inff();
+            sh_cut = by_k > by_t ? by_k : by_t;
+        }
+    } else if (have_t) {
         if (threadIdx.x == 0) sh_cut = t_exact[q] - band[q];
     } else {
         if (raw <= (uint32_t)SEL_SURV) block_kth_key_ranked(c, raw, top, &scratch, &sh_kth);
@@ -1691,10 +1700,11 @@ int32_t launch_split_refine(hipStream_t st, const uint64_t *d_cand, const uint32
     return QMX_OK;
 }
 int32_t launch_split_select(hipStream_t st, const uint64_t *d_cand, const uint32_t *d_cand_cnt, uint32_t cap, const float *d_band, uint32_t nq, uint32_t top,
-                            const VerifyPool &pool, uint32_t q_base, const int *d_tile_overflow, uint32_t *d_ovf_q, SplitStats *d_stats, const float *d_t_exact) {
+                            const VerifyPool &pool, uint32_t q_base, const int *d_tile_overflow, uint32_t *d_ovf_q, SplitStats *d_stats, const float *d_t_exact,
+                            bool tighten) {
     ::qmx::clear_stale_error();
     hipLaunchKernelGGL(sp_select_kernel, dim3(nq), dim3(SEL_BLOCK), 0, st, d_cand, d_cand_cnt, cap, d_band, top, pool, q_base, d_tile_overflow, d_ovf_q, d_stats,
-                       d_t_exact);
+                       d_t_exact, tighten);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }

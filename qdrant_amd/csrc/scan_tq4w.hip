@@ -67,10 +67,10 @@ struct TqWideArgs {
     uint32_t wcap;
 };
 
-// ---- once per segment: stats[0] = min sf, [1] = max sf, [2] = min l2 (uint bits of positive floats order like the floats), [3] != 0: a value that is
+// ---- once per segment: stats[0] = min sf, [1] = max sf, [2] = min l2, [5] = max l2 (uint bits of positive floats order like the floats), [3] != 0: a value that is
 // not a positive finite number (no wide pass for this block) ----
 __global__ __launch_bounds__(256) void tq4w_stats_kernel(const float *sf, const float *l2, uint64_t n, uint32_t *stats) {
-    float lo = __builtin_inff(), hi = 0.0f, l2lo = __builtin_inff();
+    float lo = __builtin_inff(), hi = 0.0f, l2lo = __builtin_inff(), l2hi = 0.0f;
     bool bad = false;
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
         const float v = sf[i];
@@ -81,17 +81,22 @@ __global__ __launch_bounds__(256) void tq4w_stats_kernel(const float *sf, const 
             const float w = l2[i];
             bad = bad || !(w >= 0.0f && w < __builtin_inff());
             l2lo = __builtin_fminf(l2lo, w);
+            l2hi = __builtin_fmaxf(l2hi, w);
         }
     }
     for (int o = 32; o >= 1; o >>= 1) {
         lo = __builtin_fminf(lo, __shfl_xor(lo, o, 64));
         hi = __builtin_fmaxf(hi, __shfl_xor(hi, o, 64));
         l2lo = __builtin_fminf(l2lo, __shfl_xor(l2lo, o, 64));
+        l2hi = __builtin_fmaxf(l2hi, __shfl_xor(l2hi, o, 64));
     }
     if ((threadIdx.x & 63) == 0 && !bad) {
         atomicMin(&stats[0], __float_as_uint(lo));
         atomicMax(&stats[1], __float_as_uint(hi));
-        if (l2) atomicMin(&stats[2], __float_as_uint(l2lo));
+        if (l2) {
+            atomicMin(&stats[2], __float_as_uint(l2lo));
+            atomicMax(&stats[5], __float_as_uint(l2hi));
+        }
     }
     if (bad) atomicOr(&stats[3], 1u);
 }
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(256) void tq4w_c1_kernel(const unsigned char *rows,
 // A query entry (scan_tq.hip tq_query_encode_kernel) holds, per 16-byte row piece P, 64 bytes: [low digits of the even dims][low, odd][high, even][high, odd];
 // stage kc of the scan covers row pieces 4 kc .. 4 kc + 3, one MFMA the even (or the odd) dims of the four: unit (query tile, eo, p, query) of digit D.
 __global__ __launch_bounds__(256) void tq4w_pack_kernel(const unsigned char *queries, uint32_t q_stride, uint32_t aux_off, uint32_t nq, uint32_t nch,
-                                                        const uint64_t *gthr, float sf_min, float sf_max, float l2_min, uint32_t c1, int is_l2, uint4 *bq, int32_t *thr_i,
+                                                        const uint64_t *gthr, float sf_min, float sf_max, float l2_min, float l2_max, uint32_t c1, int is_l2, int high_only, uint4 *bq, int32_t *thr_i,
                                                         float *qinfo, float *band, uint32_t *cand_cnt, uint32_t n_cnt) {
     const uint32_t qi = blockIdx.x;
     const bool live = qi < nq;
@@ -173,6 +178,16 @@ __global__ __launch_bounds__(256) void tq4w_pack_kernel(const unsigned char *que
             const double dot_thr = w > 0.0 ? w / (double)sf_max : w / (double)sf_min;          // the smallest dot that can still reach W with a row's sf
             const double s_thr = (dot_thr - (double)ec) / (double)f0 - ((__builtin_fabs(dot_thr) + 2.0 * __builtin_fabs((double)ec)) * eps / (double)f0 + 4.0);
             if (s_thr == s_thr) ti = s_thr <= -2147483647.0 ? (int32_t)0x80000000 : s_thr >= 2147483520.0 ? 0x7FFFFFFF : (int32_t)__builtin_floor(s_thr);
+            if (high_only) {
+                // the pass multiplies the HIGH digits only: its score differs from the exact one by f0 * low * sf (twice that under L2), |low| <= 64 C1 -
+                // the band of the selection - plus the roundings of both f32 expressions (sizes: the threshold, the band, ec * sf, |q|^2 + |v|^2 under L2)
+                const double lowmax = 64.0 * (double)c1 * (double)f0 * (double)sf_max * (is_l2 ? 2.0 : 1.0);
+                const double sizes = __builtin_fabs((double)t) + lowmax + 2.0 * __builtin_fabs((double)ec) * (double)sf_max +
+                                     (is_l2 ? (double)qlsq + (double)l2_max * (double)l2_max : 0.0);
+                const double b = lowmax * 1.0001 + sizes * 2.0e-5;
+                bd = b < 3.0e38 ? (float)b * 1.000001f : __builtin_inff();
+                if (!(bd < 3.0e38f)) { ti = 0x7FFFFFFF; tf = __builtin_inff(); }
+            }
         }
     }
     thr_i[qi] = ti;
@@ -218,7 +233,7 @@ __device__ __forceinline__ uint32_t tw_lut4(uint32_t x) {
 // LDS: queries 2 x 32 KiB, code staging 2 stage pairs x 32 KiB, the 128 queries' two integer bounds 1 KiB.
 // The epilogue of a tile lists (low + 128 high, row, query) of every pair that meets the query's integer bound; tq4w_finish_kernel turns the entries into
 // keys (TqOps<4>::finish, the exact compare with the threshold score) before the regroup.
-template <bool L2_UNUSED>
+template <bool HO /* the high digits only: half the matrix work, scores within the band tq4w_pack_kernel states; the survivors are re-scored exactly */>
 __global__ __launch_bounds__(TW_THREADS, 1) void scan_tq4w_kernel(const ScanArgs a, const TqWideArgs s) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint4 *lds = reinterpret_cast<uint4 *>(smem_raw);
@@ -254,8 +269,10 @@ __global__ __launch_bounds__(TW_THREADS, 1) void scan_tq4w_kernel(const ScanArgs
     const unsigned char *rq_src = nullptr;
     uint32_t rq_dst = 0;
     auto queries_begin = [&](uint32_t kc, uint32_t slot) {
-        rq_src = uniform_ptr((uint64_t)(uintptr_t)(s.bq + (uint64_t)kc * TW_B_UNITS) + (uint32_t)w * 4096u);
-        rq_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + (slot * TW_B_UNITS) * 16u + (uint32_t)w * 4096u));
+        // (HO: the high digits' half of the image alone, 2 KiB per wave)
+        const uint32_t off = HO ? TW_B_DIGIT_UNITS * 16u + (uint32_t)w * 2048u : (uint32_t)w * 4096u;
+        rq_src = uniform_ptr((uint64_t)(uintptr_t)(s.bq + (uint64_t)kc * TW_B_UNITS) + off);
+        rq_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + (slot * TW_B_UNITS) * 16u + off));
     };
     auto queries_piece = [&](int i) { tw_glds16(rq_src + i * 1024, lane_off, (uint32_t)__builtin_amdgcn_readfirstlane((int)(rq_dst + i * 1024))); };
     // this wave's codes of stage pair `kp` of the block's it-th tile -> staging slot `slot`: [stage of the pair][mt][wave][lane], a lane's own 16 bytes;
@@ -308,19 +325,19 @@ __global__ __launch_bounds__(TW_THREADS, 1) void scan_tq4w_kernel(const ScanArgs
         for (int nt = 0; nt < 8; ++nt) {
             if (!__ballot((hits8 >> nt) & 1u)) continue;
             const uint32_t q = (uint32_t)nt * 16 + m_r;
-            const int ti = thr_lds[q];
+            const int ti = thr_lds[HO ? TW_QT + q : q];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 int m4 = (int)0x80000000;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int v = (acch[mt][nt][j] << 7) + accl[mt][nt][j];
+                    const int v = HO ? acch[mt][nt][j] : (acch[mt][nt][j] << 7) + accl[mt][nt][j];
                     m4 = v > m4 ? v : m4;
                 }
                 if (!__ballot(m4 >= ti)) continue;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int v = (acch[mt][nt][j] << 7) + accl[mt][nt][j];
+                    const int v = HO ? acch[mt][nt][j] : (acch[mt][nt][j] << 7) + accl[mt][nt][j];
                     const uint32_t row = row0 + (uint32_t)mt * 16 + (uint32_t)j;
                     const bool c = v >= ti && row < n_rows32 && q < s.nq;
                     const uint64_t hits = __ballot(c);
@@ -365,7 +382,7 @@ __global__ __launch_bounds__(TW_THREADS, 1) void scan_tq4w_kernel(const ScanArgs
         i32x4w bl[TW_AHEAD + 1], bh[TW_AHEAD + 1];
         auto b_read = [&](int k) {
             const int n2 = k >> 1, e2 = k & 1;
-            bl[k % (TW_AHEAD + 1)] = *reinterpret_cast<const i32x4w *>(bb + n2 * 128 + e2 * 64);
+            if (!HO) bl[k % (TW_AHEAD + 1)] = *reinterpret_cast<const i32x4w *>(bb + n2 * 128 + e2 * 64);
             bh[k % (TW_AHEAD + 1)] = *reinterpret_cast<const i32x4w *>(bb + TW_B_DIGIT_UNITS + n2 * 128 + e2 * 64);
         };
 #pragma unroll
@@ -377,15 +394,17 @@ __global__ __launch_bounds__(TW_THREADS, 1) void scan_tq4w_kernel(const ScanArgs
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const i32x4w av = as_i32x4(eo ? co[mt] : ce[mt]);
-                accl[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bl[k % (TW_AHEAD + 1)], accl[mt][nt], 0, 0, 0);
+                if (!HO) accl[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bl[k % (TW_AHEAD + 1)], accl[mt][nt], 0, 0, 0);
                 acch[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bh[k % (TW_AHEAD + 1)], acch[mt][nt], 0, 0, 0);
             }
             {   // word k of the next stage's operands: mt = k >> 3, even / odd = (k >> 2) & 1, word = k & 3
                 const uint32_t x = xs[(k >> 3) * 4 + (k & 3)];
                 dw[k] = ((k >> 2) & 1) ? tw_lut4<4>(x) : tw_lut4<0>(x);
             }
-            if (k < 4) queries_piece(k);
-            else if (k < 6) codes_piece((int)(slot_piece0 + (uint32_t)(k - 4)));
+            // the stage's copy requests, queries first (the end-of-stage wait relies on the order)
+            constexpr int NQP = HO ? 2 : 4;
+            if (k < NQP) queries_piece(k);
+            else if (k < NQP + 2) codes_piece((int)(slot_piece0 + (uint32_t)(k - NQP)));
             __builtin_amdgcn_sched_barrier(0);
         }
         de[0] = make_uint4(dw[0], dw[1], dw[2], dw[3]);
@@ -415,7 +434,7 @@ __global__ __launch_bounds__(TW_THREADS, 1) void scan_tq4w_kernel(const ScanArgs
         for (int i = 0; i < 4; ++i) codes_piece(i);
         queries_begin(0, 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) queries_piece(i);
+        for (int i = 0; i < (HO ? 2 : 4); ++i) queries_piece(i);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         uint4 c0, c1;
         read_codes(0, 0, c0, c1);
@@ -434,7 +453,7 @@ __global__ __launch_bounds__(TW_THREADS, 1) void scan_tq4w_kernel(const ScanArgs
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 8; ++nt) {
-                    accl[mt][nt] = (i32x4w){0, 0, 0, 0};
+                    if (!HO) accl[mt][nt] = (i32x4w){0, 0, 0, 0};
                     acch[mt][nt] = (i32x4w){0, 0, 0, 0};
                 }
         }
@@ -472,7 +491,7 @@ __global__ __launch_bounds__(TW_THREADS, 1) void scan_tq4w_kernel(const ScanArgs
 // ---- after the scan: an entry (low + 128 high, row, query) becomes (key lo, key hi, query) when its score - TqOps<4>::finish (scan_sq_mfma.hip), operation
 // for operation - is not below the query's threshold score (ties pass), else an entry the regroup skips (query 0xFFFFFFFF).  One wave per list. ----
 __global__ __launch_bounds__(256) void tq4w_finish_kernel(uint4 *wlist, const uint32_t *wcnt, uint32_t wcap, uint32_t n_lists, const float *sf, const float *l2,
-                                                          uint32_t invert, const float *qinfo) {
+                                                          uint32_t invert, const float *qinfo, const float *band /* or nullptr: the entries are whole sums */) {
     const uint32_t l = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (l >= n_lists) return;
     uint32_t cnt = wcnt[l];
@@ -482,7 +501,7 @@ __global__ __launch_bounds__(256) void tq4w_finish_kernel(uint4 *wlist, const ui
         const uint4 e = list[i];
         const uint32_t row = e.y, q = e.z;
         const float f0 = qinfo[q], ec = qinfo[TW_QT + q], qlsq = qinfo[2 * TW_QT + q], tf = qinfo[3 * TW_QT + q];
-        const float sumf = (float)(int32_t)e.x;               // (tq_i32: |low + 128 high| < 2^31)
+        const float sumf = band ? (float)(128 * (int32_t)e.x) : (float)(int32_t)e.x;      // (tq_i32: |low + 128 high| < 2^31; with a band: the high sum alone)
         const float dot = f0 * sumf + ec;
         const float sfr = sf[row];
         float score;
@@ -494,7 +513,7 @@ __global__ __launch_bounds__(256) void tq4w_finish_kernel(uint4 *wlist, const ui
             score = dot * sfr;
         }
         score = invert ? -score : score;
-        if (!(score < tf)) {
+        if (!(score < (band ? tf - band[q] : tf))) {
             const uint64_t key = make_key(score, row);
             list[i] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), q, 0u);
         } else {
@@ -513,7 +532,7 @@ size_t tq4w_wlists_counts_bytes(int num_cus) { return ((size_t)num_cus * (TW_THR
 size_t tq4w_wlists_bytes(int num_cus) { return tq4w_wlists_counts_bytes(num_cus) + (size_t)num_cus * (TW_THREADS / 64) * TW_WCAP * 16; }
 uint32_t tq4w_wcap() { return TW_WCAP; }
 
-int32_t launch_tq4w_stats(hipStream_t st, const float *d_sf, const float *d_l2, const void *d_rows, uint64_t row_stride, uint32_t code_bytes, uint64_t n, uint32_t *d_stats) {
+int32_t launch_tq4w_stats(hipStream_t st, const float *d_sf, const float *d_l2, const void *d_rows, uint64_t row_stride, uint32_t code_bytes, uint64_t n, uint32_t *d_stats /* [8] */) {
     ::qmx::clear_stale_error();
     const uint32_t grid = (uint32_t)std::min<uint64_t>(2048, (n + 255) / 256);
     hipLaunchKernelGGL(tq4w_stats_kernel, dim3(grid ? grid : 1), dim3(256), 0, st, d_sf, d_l2, n, d_stats);
@@ -523,18 +542,19 @@ int32_t launch_tq4w_stats(hipStream_t st, const float *d_sf, const float *d_l2, 
     return QMX_OK;
 }
 
-int32_t launch_tq4w_pack(hipStream_t st, const ScanArgs &a, const uint64_t *d_gthr, float sf_min, float sf_max, float l2_min, uint32_t c1, void *d_bq, int32_t *d_thr_i,
+int32_t launch_tq4w_pack(hipStream_t st, const ScanArgs &a, const uint64_t *d_gthr, float sf_min, float sf_max, float l2_min, float l2_max, uint32_t c1, int high_only,
+                         void *d_bq, int32_t *d_thr_i,
                          float *d_qinfo, float *d_band, uint32_t *d_cand_cnt, uint32_t n_cnt) {
     ::qmx::clear_stale_error();
     hipLaunchKernelGGL(tq4w_pack_kernel, dim3(TW_QT), dim3(256), 0, st, reinterpret_cast<const unsigned char *>(a.queries), a.q_stride, a.aux_off, a.nq, a.dim / 64,
-                       d_gthr, sf_min, sf_max, l2_min, c1, a.tq_l2 ? 1 : 0, (uint4 *)d_bq, d_thr_i, d_qinfo, d_band, d_cand_cnt, n_cnt);
+                       d_gthr, sf_min, sf_max, l2_min, l2_max, c1, a.tq_l2 ? 1 : 0, high_only, (uint4 *)d_bq, d_thr_i, d_qinfo, d_band, d_cand_cnt, n_cnt);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
 }
 
 // d_wlists: [counts: tq4w_wlists_counts_bytes][lists]; *grid_out = blocks launched (8 lists each)
-int32_t launch_scan_tq4w(hipStream_t st, const ScanArgs &a, const void *d_bq, const int32_t *d_thr_i, const float *d_qinfo, int num_cus, void *d_wlists,
-                         uint32_t *grid_out) {
+int32_t launch_scan_tq4w(hipStream_t st, const ScanArgs &a, const void *d_bq, const int32_t *d_thr_i, const float *d_qinfo, const float *d_band_high_only, int num_cus,
+                         void *d_wlists, uint32_t *grid_out) {
     QMX_REQUIRE(tq4w_shape_ok(a), QMX_ERR_NOT_SUPPORTED, "TurboQuant wide scan: shape not supported");
     TqWideArgs s;
     s.bq = (const uint4 *)d_bq;
@@ -547,18 +567,28 @@ int32_t launch_scan_tq4w(hipStream_t st, const ScanArgs &a, const void *d_bq, co
     s.wcap = TW_WCAP;
     const uint64_t n_tiles = (a.n_cand + TW_BM - 1) / TW_BM;
     const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)num_cus, n_tiles);
-    static thread_local DeviceOnce once;
+    static thread_local DeviceOnce once_both, once_high;
     ::qmx::clear_stale_error();
-    auto kfn = scan_tq4w_kernel<false>;
-    if (once.need()) {
-        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS));
-        once.mark();
+    if (d_band_high_only) {
+        auto kfn = scan_tq4w_kernel<true>;
+        if (once_high.need()) {
+            QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS));
+            once_high.mark();
+        }
+        QMX_NOTE_KERNEL(kfn);
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(TW_THREADS), TW_LDS, st, a, s);
+    } else {
+        auto kfn = scan_tq4w_kernel<false>;
+        if (once_both.need()) {
+            QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS));
+            once_both.mark();
+        }
+        QMX_NOTE_KERNEL(kfn);
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(TW_THREADS), TW_LDS, st, a, s);
     }
-    QMX_NOTE_KERNEL(kfn);
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(TW_THREADS), TW_LDS, st, a, s);
     QMX_HIP(hipGetLastError());
     const uint32_t n_lists = grid * (TW_THREADS / 64);
-    hipLaunchKernelGGL(tq4w_finish_kernel, dim3((n_lists + 3) / 4), dim3(256), 0, st, s.wlist, s.wcnt, s.wcap, n_lists, a.tq_sf, a.tq_l2, a.tq_invert, d_qinfo);
+    hipLaunchKernelGGL(tq4w_finish_kernel, dim3((n_lists + 3) / 4), dim3(256), 0, st, s.wlist, s.wcnt, s.wcap, n_lists, a.tq_sf, a.tq_l2, a.tq_invert, d_qinfo, d_band_high_only);
     QMX_HIP(hipGetLastError());
     if (grid_out) *grid_out = grid;
     return QMX_OK;
