@@ -191,9 +191,9 @@ static int32_t wide_exact_enqueue(qmx_query *q, uint32_t top, uint64_t n_cand, q
                                   qmx_counters *counters, bool timed) {
     const qmx_segment *s = q->seg;
     const bool sq = s->dtype == QMX_DTYPE_SQ_U8;
-    // TurboQuant: the pass multiplies the queries' HIGH digits only; its scores are within band[q] of the exact ones, the selection keeps what an exact
-    // score >= T could hide behind (approximate >= T - band: sp_select_kernel's exact-bound form) and the pair kernel re-scores that
-    const bool tq_high = !sq && !option(OPT_TQ_WIDE_BOTH_DIGITS);
+    // TurboQuant, option tq_wide_high_digit: the pass multiplies the queries' HIGH digits only; its scores are within band[q] of the exact ones, the selection
+    // keeps what an exact score >= T could hide behind (approximate >= max(T - band, A_k - 2 band)) and the pair kernel re-scores that
+    const bool tq_high = !sq && option(OPT_TQ_WIDE_HIGH_DIGIT) != 0;
     const SplitPlanLayout pl(q->nq, TQW_FQT);
     const uint32_t grid_cap = (uint32_t)s->num_cus * 8;
     QMX_TRY(q->gthr.reserve((size_t)std::max<uint32_t>(q->nq_padded, SPLIT_QT) * sizeof(uint64_t)));

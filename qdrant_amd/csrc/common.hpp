@@ -47,8 +47,9 @@ enum Option {
     OPT_HNSW_PER_CU,          // cap on the searches resident per CU of any walk (0 = what the occupancy allows)
     OPT_HNSW_REFERENCE_HEAP_ORDER,   // the plain HNSW walk keeps `nearest` / `candidates` as the reference's two binary heaps (std sift order, one lane): the reference's lists among equal scores; slow, a verification mode
     OPT_TQ_WIDE_MIN_QUERIES,  // 4-bit TurboQuant top-k scans of at least this many queries take the 128-query pass (scan_tq4w.hip: codes decoded once per tile; default 33, 0 = never)
-    OPT_TQ_WIDE_BOTH_DIGITS,  // the 128-query TurboQuant pass multiplies both digits of the queries (exact scores in the pass; round 6's first form) instead of the high
-                              // digits alone (half the matrix work; the pass's scores carry a band, the survivors are re-scored exactly - the same lists)
+    OPT_TQ_WIDE_HIGH_DIGIT,   // the 128-query TurboQuant pass multiplies the queries' high digits alone (half the matrix work; the pass's scores carry a band, the
+                              // survivors are re-scored exactly - the same lists) instead of both digits (exact scores in the pass).  Faster on rows whose scores
+                              // spread wide against the band (iid unit rows: 2.41 against 2.55 ms per 128 queries), much slower where they crowd (clustered: 5.8 / 3.1)
     OPT_SQ_WIDE_MIN_QUERIES,  // scalar-int8 top-k scans of at least this many queries take the 128-query pass (scan_sqw.hip; default 33, 0 = never)
     OPT_DEBUG,                // log dropped stale HIP errors
     OPT_COUNT

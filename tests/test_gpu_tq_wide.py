@@ -1,7 +1,7 @@
 """The 128-query pass over 4-bit TurboQuant blocks (qdrant_amd/csrc/scan_tq4w.hip): brute-force top-k of 33 and more queries over a block of 2^18 rows
 and more decodes the codes once per pass, in the registers of the lanes whose matrix-core operands they are, and multiplies 128 queries against them:
-by default their HIGH digits only (the pass's scores are within a stated band of the exact ones; what could hide a result row is re-scored exactly by
-the pair kernel), with option tq_wide_both_digits both digits (exact integers in the pass).  Either way the lists must be the 32-query scan's and the
+both digits of them (exact integers in the pass), or - option tq_wide_high_digit - their HIGH digits only (the pass's scores are within a stated band of
+the exact ones; what could hide a result row is re-scored exactly by the pair kernel).  Either way the lists must be the 32-query scan's and the
 oracle's (oracle/qdrant_oracle_tq.c) - ids, score bits, tie order.  A query whose candidate lists overflow (masses of equal scores) takes the 32-query
 scan alone (qmx_counters.fallback_queries)."""
 import numpy as np
@@ -100,14 +100,14 @@ def test_tq_wide_pass_returns_the_narrow_scan_and_the_oracle(qa, dist, dim, nq, 
     assert c.prefilter_queries == nq and c.prefilter_candidates >= c.verified_rows >= top * (nq - c.fallback_queries)
     assert c.fallback_queries <= 1                            # (the zero query, if its bound cannot be derived)
     _same(got, _narrow(qa, queries, st, top))
-    qa.set_option("tq_wide_both_digits", 1)                   # ... and the pass with both digits
+    qa.set_option("tq_wide_high_digit", 1)                    # ... and the pass over the high digits alone
     try:
         s2 = qa.BatchFilteredSearcher(queries, st, top)
         got2 = s2.peek_top_all()
-        assert "scan_tq4w_kernel<false>" in _kernel(qa, s2), _kernel(qa, s2)
+        assert "scan_tq4w_kernel<true>" in _kernel(qa, s2), _kernel(qa, s2)
     finally:
-        qa.set_option("tq_wide_both_digits", -1)
-    assert "scan_tq4w_kernel<true>" in _kernel(qa, s)
+        qa.set_option("tq_wide_high_digit", -1)
+    assert "scan_tq4w_kernel<false>" in _kernel(qa, s)
     _same(got2, got)
     k = 2
     want = _oracle_top(otq, rows, O.preprocess(dist, queries[:k]), n, top)

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--distance", default="dot")
     ap.add_argument("--storage", default="tq4", help="tq4 | sq")
+    ap.add_argument("--clusters", type=int, default=0, help="rows around this many centres (0: iid unit rows)")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     import numpy as np
@@ -33,11 +34,16 @@ def main():
     g.manual_seed(0x5EED0007)
     rows = torch.empty((n, dim), dtype=torch.float32, device=dev)
     step = 1 << 20
+    centres = torch.randn((max(args.clusters, 1), dim), generator=g, device=dev)
     for r0 in range(0, n, step):      # unit rows around 256 centres: scores that crowd a little, as embeddings do
         r1 = min(n, r0 + step)
         rows[r0:r1] = torch.randn((r1 - r0, dim), generator=g, device=dev)
+        if args.clusters:
+            rows[r0:r1] = 0.5 * rows[r0:r1] + centres[torch.randint(0, args.clusters, (r1 - r0,), generator=g, device=dev)]
     rows /= rows.norm(dim=1, keepdim=True)
     queries = torch.randn((nq, dim), generator=g, device=dev)
+    if args.clusters:
+        queries = 0.5 * queries + centres[torch.randint(0, args.clusters, (nq,), generator=g, device=dev)]
     queries /= queries.norm(dim=1, keepdim=True)
     dist = {"dot": qa.Distance.Dot, "euclid": qa.Distance.Euclid, "cosine": qa.Distance.Cosine}[args.distance]
     if args.storage == "sq":
