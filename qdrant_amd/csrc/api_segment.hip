@@ -300,7 +300,7 @@ static int32_t segment_split_stats(qmx_segment *s) {
 // SQ blocks large enough for the 128-query pass (scan_sqw.hip): the largest vector_offset, which its integer reject bound rests on
 static int32_t segment_sq_stats(qmx_segment *s) {
     if (s->dtype != QMX_DTYPE_SQ_U8 || s->n < (1u << 18) || !s->d_row_offsets || !sq_mfma_ok(s->distance, s->scan_dim) || !(s->sq.multiplier > 0.f) ||
-        s->scan_dim % 128 != 0)
+        s->scan_dim % 64 != 0)
         return QMX_OK;
     if (hipMalloc((void **)&s->d_sq_bi, (size_t)s->n * sizeof(int32_t)) != hipSuccess) {      // (no memory for the column: the 32-query kernel serves)
         (void)hipGetLastError();

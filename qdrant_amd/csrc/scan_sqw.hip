@@ -4,12 +4,12 @@
 // Same reference loops as scan_sq_mfma.hip SqOps: BatchFilteredSearcher::peek_top_iter (lib/segment/src/index/hnsw_index/point_scorer.rs:423-472) over
 // EncodedVectorsU8::score_point_avx (lib/quantization/src/encoded_vectors_u8.rs:471-490 -> cpp/avx2.c:25-63 impl_score_dot_avx) and postprocess_score
 // (:100-103): the exact integer dot of the codes, then multiplier * dot + query_offset + vector_offset, left to right, not fused.  Dot / cosine / euclid
-// with a positive multiplier (the usual sign: alpha^2, or 2 alpha^2 for the inverted L2), rows of a multiple of 128 codes below 1041 (sq_mfma_ok: the AVX2
+// with a positive multiplier (the usual sign: alpha^2, or 2 alpha^2 for the inverted L2), rows of a multiple of 64 codes below 1041 (sq_mfma_ok: the AVX2
 // leaf's f32 lane sums stay exact).
 //
 // Why.  The 32-query kernel (scan_sq_mfma.hip) streams the 7.7 GB of a 10 M x 768 block once per 32 queries at 0.72 - 0.74 of HBM: 128 queries cost four
 // passes, 5.3 ms.  Here a wave owns 32 rows of a 256-row tile, its lanes fetch exactly the 16-byte operand pieces v_mfma_i32_16x16x64_i8 wants from them
-// (LDS-DMA into a lane-private staging ring, three stages deep), and multiplies them with all 128 queries (their codes as B-operand images, LDS-DMA from a
+// (LDS-DMA into a lane-private staging ring, five 64-code stages ahead), and multiplies them with all 128 queries (their codes as B-operand images, LDS-DMA from a
 // 96 KiB image in L2): one pass of the block per 128 queries, bound by the HBM stream of the codes.
 //
 // Scores are exact, so the pass needs no band (scan_tq4w.hip: the same tail): a pair is a candidate when its score is not below the k-th best score of a
@@ -28,15 +28,16 @@ typedef int i32x4q __attribute__((ext_vector_type(4)));
 constexpr int SW_THREADS = 512;
 constexpr int SW_BM = 256;                                   // rows per tile
 constexpr int SW_QT = 128;                                   // queries per pass
-constexpr int SW_B_UNITS = SW_QT * 2 * 4;                    // 16-byte units of the queries' stage: 128 queries x 2 steps of 64 codes x 4 pieces = 16 KiB
-constexpr int SW_R_UNITS = SW_BM * 8;                        // ... of a stage's codes: 256 rows x 128 bytes = 32 KiB
-constexpr int SW_RING = 3;                                   // code stages staged in LDS
-constexpr int SW_BRING = 3;                                  // query stages in LDS
-constexpr int SW_LDS = (SW_BRING * SW_B_UNITS + SW_RING * SW_R_UNITS) * 16 + SW_QT * 4 + 2 * 8 * 64 * 4;      // 48 + 96 KiB + the 128 integer bounds + the rows' column entries of two tiles
+constexpr int SW_B_UNITS = SW_QT * 4;                        // 16-byte units of the queries' stage: 128 queries x 64 codes = 8 KiB
+constexpr int SW_R_UNITS = SW_BM * 4;                        // ... of a stage's codes: 256 rows x 64 bytes = 16 KiB
+constexpr int SW_DEPTH = 5;                                  // stages the requests run ahead of the matrix work
+constexpr int SW_RING = SW_DEPTH + 1;                        // stages staged in LDS (codes and queries alike)
+constexpr int SW_BI_RING = 8;                                // tiles whose column entries are staged
+constexpr int SW_LDS = SW_RING * (SW_B_UNITS + SW_R_UNITS) * 16 + SW_QT * 4 + SW_BI_RING * SW_BM * 4;      // 6 x 24 KiB + the 128 integer bounds + 8 KiB of column entries
 constexpr uint32_t SW_WCAP = 8192;                           // candidates one wave may list per pass
 
-// unit index of (16-query tile t, 64-code step hl, piece kq, query-in-tile m): scan_split.hip sp_unit, conflict-free for the operand reads
-__device__ __forceinline__ uint32_t sw_unit(uint32_t t, uint32_t hl, uint32_t kq, uint32_t m) { return ((t * 2 + hl) * 4 + kq) * 16 + (m ^ (2 * kq)); }
+// unit index of (16-query tile t, piece kq, query-in-tile m) inside a stage of the queries' image: scan_split.hip sp_unit's swizzle, conflict-free for the operand reads
+__device__ __forceinline__ uint32_t sw_unit(uint32_t t, uint32_t kq, uint32_t m) { return (t * 4 + kq) * 16 + (m ^ (2 * kq)); }
 
 typedef __attribute__((address_space(3))) unsigned char sw_lds_byte;
 // 1 KiB of global memory (wave-uniform base + per-lane offset, 16 bytes per lane) straight into LDS at the wave-uniform byte address lds_dst (+ 16 x lane)
@@ -53,7 +54,7 @@ __device__ __forceinline__ void sw_stage_barrier() {
 
 struct SqWideArgs {
     const uint4 *bq;          // [nch][SW_B_UNITS] the queries' operand images (sqw_pack_kernel)
-    uint32_t nch;             // stages per tile: codes of a row / 128
+    uint32_t nch;             // stages per tile: codes of a row / 64
     uint32_t nq;              // live queries (<= 128)
     const int32_t *thr_i;     // [128] A[query]: a pair with dot + B[row] below this cannot reach the query's threshold
     const int32_t *bi;        // [n] B[row] (sqw_stats_kernel)
@@ -88,11 +89,11 @@ __global__ __launch_bounds__(256) void sqw_pack_kernel(const unsigned char *quer
     if (qi == 0)
         for (uint32_t i = threadIdx.x; i < n_cnt; i += 256) cand_cnt[i] = 0;
     const unsigned char *entry = queries + (uint64_t)qi * q_stride;
-    for (uint32_t u = threadIdx.x; u < nch * 8; u += 256) {
-        const uint32_t kc = u >> 3, st = (u >> 2) & 1u, p = u & 3u;
+    for (uint32_t u = threadIdx.x; u < nch * 4; u += 256) {
+        const uint32_t kc = u >> 2, p = u & 3u;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (live) v = *reinterpret_cast<const uint4 *>(entry + (uint64_t)kc * 128 + st * 64 + p * 16);
-        bq[(uint64_t)kc * SW_B_UNITS + sw_unit(qi >> 4, st, p, qi & 15u)] = v;
+        if (live) v = *reinterpret_cast<const uint4 *>(entry + (uint64_t)kc * 64 + p * 16);
+        bq[(uint64_t)kc * SW_B_UNITS + sw_unit(qi >> 4, p, qi & 15u)] = v;
     }
     if (threadIdx.x != 0) return;
     float q_off = 0.0f, tf = __builtin_inff(), bd = 0.0f;
@@ -122,20 +123,21 @@ __global__ __launch_bounds__(256) void sqw_pack_kernel(const unsigned char *quer
     qinfo[SW_QT + qi] = tf;
 }
 
-// The scan.  Block = 8 waves, one block per CU, persistent over 256-row tiles; a tile = nch stages of 128 codes.  A wave OWNS 32 rows of the tile: lane
-// (m, kg) fetches, per stage, the 16 code bytes [64 s + 16 kg, +16) of rows m and 16 + m for both 64-code steps s - exactly its operand registers of the
-// stage's four A-side (step, row tile) combinations - and multiplies with all 128 queries: 32 matrix instructions and 16 operand reads per wave and stage.
+// The scan.  Block = 8 waves, one block per CU, persistent over 256-row tiles; a tile = nch stages of 64 codes.  A wave OWNS 32 rows of the tile: lane
+// (m, kg) fetches, per stage, the 16 code bytes [16 kg, +16) of rows m and 16 + m - exactly its operand registers of the stage's two row tiles - and
+// multiplies with all 128 queries: 16 matrix instructions and 8 operand reads per wave and stage.
 // EVERYTHING the loop fetches arrives by LDS-DMA and is counted by the kernel itself (scan_tq4w.hip: a plain vector load inside the loop and the
-// compiler's conservative `s_waitcnt vmcnt(0)` drains the streams at every stage).  Per stage g a wave asks for the queries' images (two 1 KiB pieces) and for its codes
-// (four) of stage g + 2, reads its own operands of stage g from its staging area, multiplies, waits for everything but this stage's six requests - the queries
-// and its codes of stage g + 1, one to two stages old - and meets the others at the stage barrier (the queries' buffers are all the waves share).  (Asking for
-// the queries ONE stage ahead made the end-of-stage wait - vmcnt is in-order - land the codes asked for half a stage earlier: 1.78 ms per 10 M x 768 pass.)
-// LDS: queries 3 x 16 KiB, code staging 3 stages x 32 KiB.
+// compiler's conservative `s_waitcnt vmcnt(0)` drains the streams at every stage).  vmcnt is IN-ORDER: waiting for the youngest thing a stage needs lands
+// everything older.  So the queries' images are asked for as far ahead as the codes - during stage g a wave asks for the queries (its 1 KiB of the 8) and
+// its codes (two 1 KiB pieces) of stage g + 5 - and the end-of-stage wait lets the last four stages' requests stay in flight: 64 - 80 KiB of codes per CU on
+// their way, what 6.4 TB/s at ~2.5 us of loaded latency needs.  (Three 128-code stages with the queries one / two stages ahead kept 32 - 64 KiB in flight: 1.78 /
+// 1.67 ms per 10 M x 768 pass; without the code requests the same loop ran 0.99 ms.)
+// LDS: 6 stages x (8 KiB of queries + 16 KiB of codes), the 128 integer bounds, the column entries of 8 tiles.
 __global__ __launch_bounds__(SW_THREADS, 1) void scan_sqw_kernel(const ScanArgs a, const SqWideArgs s) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint4 *lds = reinterpret_cast<uint4 *>(smem_raw);
-    int32_t *thr_lds = reinterpret_cast<int32_t *>(smem_raw + (size_t)(SW_BRING * SW_B_UNITS + SW_RING * SW_R_UNITS) * 16);
-    int32_t *bi_lds = thr_lds + SW_QT;      // [tile parity][wave][64]: B of the wave's 32 rows (lanes 32..63 repeat them)
+    int32_t *thr_lds = reinterpret_cast<int32_t *>(smem_raw + (size_t)SW_RING * (SW_B_UNITS + SW_R_UNITS) * 16);
+    int32_t *bi_lds = thr_lds + SW_QT;      // [tile % SW_BI_RING][256]: B of the tile's rows
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint64_t n_tiles = (a.n_cand + SW_BM - 1) / SW_BM;
@@ -148,36 +150,32 @@ __global__ __launch_bounds__(SW_THREADS, 1) void scan_sqw_kernel(const ScanArgs 
     if (tid < SW_QT) thr_lds[tid] = s.thr_i[tid];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // from here on the kernel counts its vector-memory traffic itself
     const uint32_t kq_r = (uint32_t)lane >> 4, m_r = (uint32_t)lane & 15u;
-    const uint32_t b_rd = sw_unit(0, 0, kq_r, m_r);
+    const uint32_t b_rd = sw_unit(0, kq_r, m_r);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(sw_lds_byte *)smem_raw;
     const uint32_t lane_off = (uint32_t)lane * 16u;
-    uint4 *const b_lds = lds, *const r_lds = lds + SW_BRING * SW_B_UNITS;
+    uint4 *const b_lds = lds, *const r_lds = lds + SW_RING * SW_B_UNITS;
     const unsigned char *rows = reinterpret_cast<const unsigned char *>(a.rows);
     const uint64_t last_row = a.n_cand - 1;
     const uint32_t row_stride32 = (uint32_t)a.row_stride;
     const uint32_t rl0 = (uint32_t)w * 32u + m_r, rl1 = rl0 + 16u;
     const uint32_t coff0 = rl0 * row_stride32 + kq_r * 16u, coff1 = rl1 * row_stride32 + kq_r * 16u;
+    // how many tiles ahead a tile's column entries are asked for: at least SW_DEPTH + 1 stages, so that the end-of-stage waits have landed them
+    const uint32_t bi_ahead = (SW_DEPTH + nch) / nch;        // ceil((SW_DEPTH + 1) / nch) <= 6
 
     auto uniform_ptr = [&](uint64_t v) {
         return reinterpret_cast<const unsigned char *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
                                                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v));
     };
-    // the queries' images of stage kc -> B buffer `slot`: this wave's 2 KiB of the 16
-    const unsigned char *rq_src = nullptr;
-    uint32_t rq_dst = 0;
-    auto queries_begin = [&](uint32_t kc, uint32_t slot) {
-        rq_src = uniform_ptr((uint64_t)(uintptr_t)(s.bq + (uint64_t)kc * SW_B_UNITS) + (uint32_t)w * 2048u);
-        rq_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + (slot * SW_B_UNITS) * 16u + (uint32_t)w * 2048u));
-    };
-    auto queries_piece = [&](int i) { sw_glds16(rq_src + i * 1024, lane_off, (uint32_t)__builtin_amdgcn_readfirstlane((int)(rq_dst + i * 1024))); };
-    // this wave's codes of stage kc of the block's it-th tile -> staging slot `slot`: [step][row tile][wave][lane], a lane's own 16 bytes; piece i = (step
-    // i >> 1, row tile i & 1) (rows past the block: the last row's bytes, their scores are dropped)
-    const unsigned char *rc_src = nullptr;
-    uint32_t rc_dst = 0, rc_o0 = coff0, rc_o1 = coff1;
-    auto codes_begin = [&](uint64_t it, uint32_t kc, uint32_t slot) {
+    // One stage's requests: the queries' image of stage kc (this wave's 1 KiB of the 8) and this wave's codes of stage kc of the block's it-th tile (two pieces:
+    // row tiles 0, 1; a lane's own 16 bytes; rows past the block: the last row's bytes, their scores are dropped) -> ring slot `slot`
+    const unsigned char *rq_src = nullptr, *rc_src = nullptr;
+    uint32_t rq_dst = 0, rc_dst = 0, rc_o0 = coff0, rc_o1 = coff1;
+    auto requests_begin = [&](uint64_t it, uint32_t kc, uint32_t slot) {
+        rq_src = uniform_ptr((uint64_t)(uintptr_t)(s.bq + (uint64_t)kc * SW_B_UNITS) + (uint32_t)w * 1024u);
+        rq_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + (slot * SW_B_UNITS) * 16u + (uint32_t)w * 1024u));
         const uint64_t row0 = (blockIdx.x + it * gridDim.x) * SW_BM;
-        rc_src = uniform_ptr((uint64_t)(uintptr_t)(rows + row0 * a.row_stride + kc * 128u));
-        rc_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + (SW_BRING * SW_B_UNITS + slot * SW_R_UNITS) * 16u + (uint32_t)w * 1024u));
+        rc_src = uniform_ptr((uint64_t)(uintptr_t)(rows + row0 * a.row_stride + kc * 64u));
+        rc_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + (SW_RING * SW_B_UNITS + slot * SW_R_UNITS) * 16u + (uint32_t)w * 1024u));
         rc_o0 = coff0;
         rc_o1 = coff1;
         const uint64_t room = last_row - row0;                      // (row0 <= last_row: the tile exists)
@@ -187,20 +185,24 @@ __global__ __launch_bounds__(SW_THREADS, 1) void scan_sqw_kernel(const ScanArgs 
             rc_o1 = r1 * row_stride32 + kq_r * 16u;
         }
     };
-    // B of this wave's rows of the block's it-th tile -> the column staging of that tile's parity (one 4-byte copy per lane)
+    auto request_piece = [&](int i) {      // 0: the queries; 1, 2: the codes of row tiles 0, 1
+        if (i == 0) sw_glds16(rq_src, lane_off, rq_dst);
+        else sw_glds16(rc_src, i == 1 ? rc_o0 : rc_o1, (uint32_t)__builtin_amdgcn_readfirstlane((int)(rc_dst + (uint32_t)(i - 1) * 8192u)));
+    };
+    // B of this wave's rows of the block's it-th tile -> the column staging (one 4-byte copy per lane, 32 lanes)
     auto request_bi = [&](uint64_t it) {
-        const uint64_t row0 = (blockIdx.x + it * gridDim.x) * SW_BM;
+        const uint64_t itc = it < my_tiles ? it : my_tiles - 1;
+        const uint64_t row0 = (blockIdx.x + itc * gridDim.x) * SW_BM;
         const uint64_t room = last_row - row0;
         const uint32_t r = (uint32_t)w * 32u + ((uint32_t)lane & 31u);
         const uint32_t rc = (uint64_t)r < room ? r : (uint32_t)room;
         const unsigned char *src = uniform_ptr((uint64_t)(uintptr_t)(s.bi + row0));
-        const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + (SW_BRING * SW_B_UNITS + SW_RING * SW_R_UNITS) * 16u + SW_QT * 4u + (((uint32_t)it & 1u) * 8u + (uint32_t)w) * 256u));
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(rc * 4u), "s"(src), "s"(dst) : "memory");
-    };
-    auto codes_piece = [&](int i) {
-        sw_glds16(rc_src + (i >> 1) * 64, (i & 1) ? rc_o1 : rc_o0, (uint32_t)__builtin_amdgcn_readfirstlane((int)(rc_dst + (uint32_t)i * 8192u)));
+        const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + SW_RING * (SW_B_UNITS + SW_R_UNITS) * 16u + SW_QT * 4u + (((uint32_t)it % SW_BI_RING) * SW_BM + (uint32_t)w * 32u) * 4u));
+        if (lane < 32) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(rc * 4u), "s"(src), "s"(dst) : "memory");
+        }
     };
 
     i32x4q acc[2][8];
@@ -208,14 +210,14 @@ __global__ __launch_bounds__(SW_THREADS, 1) void scan_sqw_kernel(const ScanArgs 
     uint32_t wcount = 0;
     const uint32_t n_rows32 = (uint32_t)a.n_cand;
 
-    // The epilogue of a tile: the integer bound, narrowing by wave-uniform steps (query tile, 16-row tile, the four rows of a lane)
+    // The epilogue of a tile: dot + B[row] >= A[query], narrowing by wave-uniform steps (query tile, then the lane's rows)
     auto epilogue = [&](uint64_t it) __attribute__((always_inline)) {
         const uint64_t tile = blockIdx.x + it * gridDim.x;
         const uint32_t row0 = (uint32_t)(tile * SW_BM) + (uint32_t)w * 32u + 4 * kq_r;
         // the lane's eight rows' column entries: rows 4 kq_r .. + 3 of both 16-row tiles of the wave
         int bi8[2][4];
         {
-            const int32_t *bsrc = bi_lds + (((uint32_t)it & 1u) * 8u + (uint32_t)w) * 64u + 4 * kq_r;
+            const int32_t *bsrc = bi_lds + ((uint32_t)it % SW_BI_RING) * SW_BM + (uint32_t)w * 32u + 4 * kq_r;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const int4 v = *reinterpret_cast<const int4 *>(bsrc + mt * 16);
@@ -261,97 +263,67 @@ __global__ __launch_bounds__(SW_THREADS, 1) void scan_sqw_kernel(const ScanArgs 
     auto as_i32x4 = [](const uint4 &v) { return (i32x4q){(int)v.x, (int)v.y, (int)v.z, (int)v.w}; };
 
     const uint64_t n_stages = my_tiles * nch;
-    // (stage G as (tile, kc); past the block's last stage the requests repeat it: the waits count requests, not bytes)
-    auto stage_at = [&](uint64_t G, uint64_t &it_out, uint32_t &kc_out) {
-        const uint64_t Gc = G < n_stages ? G : n_stages - 1;
-        it_out = Gc / nch;
-        kc_out = (uint32_t)(Gc % nch);
+    // the stage the requests are at, as (tile, kc), by running counters; past the block's last stage they repeat it (the waits count requests, not bytes)
+    uint64_t itr = 0;
+    uint32_t kcr = 0;
+    auto advance_r = [&]() {
+        if (kcr + 1 < nch) ++kcr;
+        else if (itr + 1 < my_tiles) { kcr = 0; ++itr; }
     };
-    // ---- prologue: the codes of stages 0 and 1, the queries of stage 0 ----
-    {
-        uint64_t itp;
-        uint32_t kcp;
-        stage_at(0, itp, kcp);
-        codes_begin(itp, kcp, 0);
+    // ---- prologue: stages 0 .. SW_DEPTH - 1 and the column entries of the first tiles asked for, stage 0 landed ----
 #pragma unroll
-        for (int i = 0; i < 4; ++i) codes_piece(i);
-        stage_at(1, itp, kcp);
-        codes_begin(itp, kcp, 1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) codes_piece(i);
-        queries_begin(0, 0);
-        queries_piece(0);
-        queries_piece(1);
-        queries_begin(nch > 1 ? 1 : 0, 1);
-        queries_piece(0);
-        queries_piece(1);
-        request_bi(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int d = 0; d < SW_DEPTH; ++d) {
+        requests_begin(itr, kcr, (uint32_t)d);
+        request_piece(0);
+        request_piece(1);
+        request_piece(2);
+        advance_r();
     }
+    for (uint32_t t = 0; t < bi_ahead; ++t) request_bi(t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     sw_stage_barrier();
-    uint64_t it = 0, it2 = 0;
-    uint32_t kc = 0, rslot = 0, bslot = 0, kc2c = 0;
-    {   // stage 2 as (tile, kc); past the block's last stage the requests repeat it
-        uint64_t i0;
-        uint32_t k0;
-        stage_at(2, i0, k0);
-        it2 = i0;
-        kc2c = k0;
-    }
+    uint64_t it = 0;
+    uint32_t kc = 0, slot = 0, rslot = SW_DEPTH;      // the slot of the running stage; the slot its requests (stage g + SW_DEPTH) go to: the one stage g - 1 was read from
     for (uint64_t g = 0; g < n_stages; ++g) {
         if (kc == 0) {
-            if (it) {
-                epilogue(it - 1);
-                request_bi(it);      // (older than this stage's query requests: landed with them, tiles before its use)
-            }
+            if (it) epilogue(it - 1);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 8; ++nt) acc[mt][nt] = (i32x4q){0, 0, 0, 0};
         }
-        // the lane's operands of this stage: [step][row tile] (landed: requested two stages ago, and every request but the last four was waited for at the
-        // end of the previous stage)
-        uint4 av[2][2];
+        // the lane's operands of this stage (landed: see the wait below)
+        uint4 av[2];
         {
-            const uint4 *src = r_lds + rslot * SW_R_UNITS + (uint32_t)tid;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) av[i >> 1][i & 1] = src[i * 512];
+            const uint4 *src = r_lds + slot * SW_R_UNITS + (uint32_t)tid;
+            av[0] = src[0];
+            av[1] = src[512];
         }
-        uint32_t kc2 = kc + 2;      // (kc + 2) mod nch
-        if (kc2 >= nch) kc2 -= nch;
-        if (kc2 >= nch) kc2 -= nch;
-        queries_begin(kc2, bslot + 2 >= SW_BRING ? bslot + 2 - SW_BRING : bslot + 2);      // stage g + 2 -> the buffer stage g - 1 was read from (everybody is past that barrier)
-        {
-            const uint64_t itp = it2;      // (stage g + 2, kept by running counters: two 64-bit divisions per stage were a third of the scalar instructions)
-            const uint32_t kcp = kc2c;
-            if (kc2c + 1 < nch) ++kc2c;
-            else if (it2 + 1 < my_tiles) { kc2c = 0; ++it2; }
-            const uint32_t ws = rslot + 2 >= SW_RING ? rslot + 2 - SW_RING : rslot + 2;      // the slot stage g - 1 was read from, one stage ago
-            codes_begin(itp, kcp, ws);
-        }
-        const uint4 *bb = b_lds + bslot * SW_B_UNITS + b_rd;
+        requests_begin(itr, kcr, rslot);
+        advance_r();
+        const uint4 *bb = b_lds + slot * SW_B_UNITS + b_rd;
         constexpr int SW_AHEAD = 3;
         i32x4q bv[SW_AHEAD + 1];
 #pragma unroll
-        for (int k = 0; k < SW_AHEAD; ++k) bv[k] = *reinterpret_cast<const i32x4q *>(bb + (k >> 1) * 128 + (k & 1) * 64);
+        for (int k = 0; k < SW_AHEAD; ++k) bv[k] = *reinterpret_cast<const i32x4q *>(bb + k * 64);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {      // (query tile nt, step st)
-            const int nt = k >> 1, st = k & 1;
-            if (k + SW_AHEAD < 16) bv[(k + SW_AHEAD) % (SW_AHEAD + 1)] = *reinterpret_cast<const i32x4q *>(bb + ((k + SW_AHEAD) >> 1) * 128 + ((k + SW_AHEAD) & 1) * 64);
+        for (int nt = 0; nt < 8; ++nt) {
+            if (nt + SW_AHEAD < 8) bv[(nt + SW_AHEAD) % (SW_AHEAD + 1)] = *reinterpret_cast<const i32x4q *>(bb + (nt + SW_AHEAD) * 64);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(as_i32x4(av[st][mt]), bv[k % (SW_AHEAD + 1)], acc[mt][nt], 0, 0, 0);
-            // the stage's six copy requests, spread over the matrix work: queries first (the wait below relies on the order)
-            if (k < 2) queries_piece(k);
-            else if (k < 6) codes_piece(k - 2);
+            for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(as_i32x4(av[mt]), bv[nt % (SW_AHEAD + 1)], acc[mt][nt], 0, 0, 0);
+            // the stage's three copy requests (and, on a tile's first stage, the column entries of a tile further on), spread over the matrix work
+            if (nt < 3) request_piece(nt);
+            if (nt == 3 && kc == 0) request_bi(it + bi_ahead);
             __builtin_amdgcn_sched_barrier(0);
         }
-        // all but this stage's requests have landed - six, or seven with a tile's column entries: the queries and this wave's codes of stage g + 1, a stage old
-        if (kc == 0 && it) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        // all but the last 3 (SW_DEPTH - 1) requests have landed: stage g + 1 (asked for during stage g + 1 - SW_DEPTH) among them.  (A tile's column request
+        // inside that window only makes the wait cover more.)
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        static_assert(3 * (SW_DEPTH - 1) == 12, "the wait above");
         sw_stage_barrier();
         if (++kc == nch) { kc = 0; ++it; }
+        slot = slot + 1 == SW_RING ? 0 : slot + 1;
         rslot = rslot + 1 == SW_RING ? 0 : rslot + 1;
-        bslot = bslot + 1 == SW_BRING ? 0 : bslot + 1;
     }
     epilogue(my_tiles - 1);
     if (lane == 0) s.wcnt[blockIdx.x * (SW_THREADS / 64) + (uint32_t)w] = wcount;
@@ -384,11 +356,11 @@ __global__ __launch_bounds__(256) void sqw_finish_kernel(uint4 *wlist, const uin
 
 // ---------------------------------------------------------------------------------------------------------------------------
 bool sqw_shape_ok(const ScanArgs &a) {
-    return a.dim >= 128 && a.dim % 128 == 0 && a.row_stride % 16 == 0 && a.row_stride * (SW_BM - 1) + a.dim < (1ull << 31) && a.ids == nullptr &&
+    return a.dim >= 64 && a.dim % 64 == 0 && a.row_stride % 16 == 0 && a.row_stride * (SW_BM - 1) + a.dim < (1ull << 31) && a.ids == nullptr &&
            a.top <= MAX_TOP_FAST && a.row_offsets != nullptr && a.sq_multiplier > 0.0f && a.sq_multiplier < __builtin_inff() && a.n_cand >= 1 &&
            a.n_cand < 0xFFFFFFFFull && (uint64_t)127 * 127 * a.dim < (1ull << 24);
 }
-size_t sqw_query_bytes(uint32_t dim) { return (size_t)(dim / 128) * SW_B_UNITS * 16; }
+size_t sqw_query_bytes(uint32_t dim) { return (size_t)(dim / 64) * SW_B_UNITS * 16; }
 size_t sqw_wlists_counts_bytes(int num_cus) { return ((size_t)num_cus * (SW_THREADS / 64) * 4 + 255) / 256 * 256; }
 size_t sqw_wlists_bytes(int num_cus) { return sqw_wlists_counts_bytes(num_cus) + (size_t)num_cus * (SW_THREADS / 64) * SW_WCAP * 16; }
 uint32_t sqw_wcap() { return SW_WCAP; }
@@ -404,7 +376,7 @@ int32_t launch_sqw_stats(hipStream_t st, const float *d_off, uint64_t n, float m
 int32_t launch_sqw_pack(hipStream_t st, const ScanArgs &a, const uint64_t *d_gthr, float off_absmax, void *d_bq, int32_t *d_thr_i, float *d_qinfo, float *d_band,
                         uint32_t *d_cand_cnt, uint32_t n_cnt) {
     ::qmx::clear_stale_error();
-    hipLaunchKernelGGL(sqw_pack_kernel, dim3(SW_QT), dim3(256), 0, st, reinterpret_cast<const unsigned char *>(a.queries), a.q_stride, a.aux_off, a.nq, a.dim / 128,
+    hipLaunchKernelGGL(sqw_pack_kernel, dim3(SW_QT), dim3(256), 0, st, reinterpret_cast<const unsigned char *>(a.queries), a.q_stride, a.aux_off, a.nq, a.dim / 64,
                        d_gthr, a.sq_multiplier, off_absmax, a.dim, (uint4 *)d_bq, d_thr_i, d_qinfo, d_band, d_cand_cnt, n_cnt);
     QMX_HIP(hipGetLastError());
     return QMX_OK;
@@ -416,7 +388,7 @@ int32_t launch_scan_sqw(hipStream_t st, const ScanArgs &a, const void *d_bq, con
     QMX_REQUIRE(sqw_shape_ok(a), QMX_ERR_NOT_SUPPORTED, "SQ wide scan: shape not supported");
     SqWideArgs s;
     s.bq = (const uint4 *)d_bq;
-    s.nch = a.dim / 128;
+    s.nch = a.dim / 64;
     s.nq = a.nq;
     s.thr_i = d_thr_i;
     s.bi = d_bi;
