@@ -9,7 +9,7 @@
 //
 // Why.  The 32-query kernel (scan_sq_mfma.hip) streams the 7.7 GB of a 10 M x 768 block once per 32 queries at 0.72 - 0.74 of HBM: 128 queries cost four
 // passes, 5.3 ms.  Here a wave owns 32 rows of a 256-row tile, its lanes fetch exactly the 16-byte operand pieces v_mfma_i32_16x16x64_i8 wants from them
-// (LDS-DMA into a lane-private staging ring, five 64-code stages ahead), and multiplies them with all 128 queries (their codes as B-operand images, LDS-DMA from a
+// (plain 16-byte loads into the operand registers themselves, four 64-code stages ahead), and multiplies them with all 128 queries (their codes as B-operand images in LDS, loaded from a
 // 96 KiB image in L2): one pass of the block per 128 queries, bound by the HBM stream of the codes.
 //
 // Scores are exact, so the pass needs no band (scan_tq4w.hip: the same tail): a pair is a candidate when its score is not below the k-th best score of a
@@ -29,23 +29,12 @@ constexpr int SW_THREADS = 512;
 constexpr int SW_BM = 256;                                   // rows per tile
 constexpr int SW_QT = 128;                                   // queries per pass
 constexpr int SW_B_UNITS = SW_QT * 4;                        // 16-byte units of the queries' stage: 128 queries x 64 codes = 8 KiB
-constexpr int SW_R_UNITS = SW_BM * 4;                        // ... of a stage's codes: 256 rows x 64 bytes = 16 KiB
-constexpr int SW_DEPTH = 5;                                  // stages the requests run ahead of the matrix work
-constexpr int SW_RING = SW_DEPTH + 1;                        // stages staged in LDS (codes and queries alike)
-constexpr int SW_BI_RING = 8;                                // tiles whose column entries are staged
-constexpr int SW_LDS = SW_RING * (SW_B_UNITS + SW_R_UNITS) * 16 + SW_QT * 4 + SW_BI_RING * SW_BM * 4;      // 6 x 24 KiB + the 128 integer bounds + 8 KiB of column entries
+constexpr int SW_LDS = 2 * SW_B_UNITS * 16 + SW_QT * 4;      // the queries' two buffers + the 128 integer bounds (the codes go to registers)
 constexpr uint32_t SW_WCAP = 8192;                           // candidates one wave may list per pass
 
 // unit index of (16-query tile t, piece kq, query-in-tile m) inside a stage of the queries' image: scan_split.hip sp_unit's swizzle, conflict-free for the operand reads
 __device__ __forceinline__ uint32_t sw_unit(uint32_t t, uint32_t kq, uint32_t m) { return (t * 4 + kq) * 16 + (m ^ (2 * kq)); }
 
-typedef __attribute__((address_space(3))) unsigned char sw_lds_byte;
-// 1 KiB of global memory (wave-uniform base + per-lane offset, 16 bytes per lane) straight into LDS at the wave-uniform byte address lds_dst (+ 16 x lane)
-__device__ __forceinline__ void sw_glds16(const unsigned char *src, uint32_t lane_off, uint32_t lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(lane_off), "s"(src), "s"(lds_dst) : "memory");
-}
 __device__ __forceinline__ void sw_stage_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -124,20 +113,26 @@ __global__ __launch_bounds__(256) void sqw_pack_kernel(const unsigned char *quer
 }
 
 // The scan.  Block = 8 waves, one block per CU, persistent over 256-row tiles; a tile = nch stages of 64 codes.  A wave OWNS 32 rows of the tile: lane
-// (m, kg) fetches, per stage, the 16 code bytes [16 kg, +16) of rows m and 16 + m - exactly its operand registers of the stage's two row tiles - and
+// (m, kg) loads, per stage, the 16 code bytes [16 kg, +16) of rows m and 16 + m - exactly its operand registers of the stage's two row tiles - and
 // multiplies with all 128 queries: 16 matrix instructions and 8 operand reads per wave and stage.
-// EVERYTHING the loop fetches arrives by LDS-DMA and is counted by the kernel itself (scan_tq4w.hip: a plain vector load inside the loop and the
-// compiler's conservative `s_waitcnt vmcnt(0)` drains the streams at every stage).  vmcnt is IN-ORDER: waiting for the youngest thing a stage needs lands
-// everything older.  So the queries' images are asked for as far ahead as the codes - during stage g a wave asks for the queries (its 1 KiB of the 8) and
-// its codes (two 1 KiB pieces) of stage g + 5 - and the end-of-stage wait lets the last four stages' requests stay in flight: 64 - 80 KiB of codes per CU on
-// their way, what 6.4 TB/s at ~2.5 us of loaded latency needs.  (Three 128-code stages with the queries one / two stages ahead kept 32 - 64 KiB in flight: 1.78 /
-// 1.67 ms per 10 M x 768 pass; without the code requests the same loop ran 0.99 ms.)
-// LDS: 6 stages x (8 KiB of queries + 16 KiB of codes), the 128 integer bounds, the column entries of 8 tiles.
+// The loads are `global_load_dwordx4` issued by inline asm INTO the operand registers, four stages ahead, and waited for by the kernel's own `s_waitcnt
+// vmcnt` (an asm statement that names the registers it releases as in-out operands, so no use or copy of them can be scheduled in front of it):
+//   * hipcc's own waits would be conservative across the loop's back edge (scan_tq4w.hip met `vmcnt(0)` at every stage);
+//   * LDS-DMA (`global_load_lds_dwordx4`), which rounds 3 - 5 of this library use for such streams, costs the issuing wave 150 - 260 cycles per 1 KiB
+//     request here - three requests per 16 matrix instructions: measured, the loop without its code requests ran 0.99 ms per 10 M x 768 pass, with them
+//     1.64 - 1.78 whatever their depth (three 128-code stages one or two ahead, six 64-code stages five ahead).  A plain load is one issue slot.
+// vmcnt is IN-ORDER: the wait of stage g lets the last 11 loads stay in flight - the codes of stages g + 1 .. g + 4 and the queries of g + 2 .. g + 4 -, which
+// lands the codes of stage g and the queries of stage g + 1; the latter go to LDS by one ds_write_b128 per lane (the queries' buffers, two of them, are all
+// the waves share: one barrier per stage).  64 KiB of codes per CU on their way.
+__device__ __forceinline__ void sw_gload16(i32x4q &dst, const unsigned char *sbase, uint32_t voff) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+constexpr int SW_AHEAD_STAGES = 4;                           // stages the loads run ahead of the matrix work
+constexpr int SW_SLOTS = SW_AHEAD_STAGES + 1;                // register sets of a stage's loads (the running stage's + those in flight)
 __global__ __launch_bounds__(SW_THREADS, 1) void scan_sqw_kernel(const ScanArgs a, const SqWideArgs s) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint4 *lds = reinterpret_cast<uint4 *>(smem_raw);
-    int32_t *thr_lds = reinterpret_cast<int32_t *>(smem_raw + (size_t)SW_RING * (SW_B_UNITS + SW_R_UNITS) * 16);
-    int32_t *bi_lds = thr_lds + SW_QT;      // [tile % SW_BI_RING][256]: B of the tile's rows
+    int32_t *thr_lds = reinterpret_cast<int32_t *>(smem_raw + (size_t)2 * SW_B_UNITS * 16);
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint64_t n_tiles = (a.n_cand + SW_BM - 1) / SW_BM;
@@ -151,79 +146,58 @@ __global__ __launch_bounds__(SW_THREADS, 1) void scan_sqw_kernel(const ScanArgs 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // from here on the kernel counts its vector-memory traffic itself
     const uint32_t kq_r = (uint32_t)lane >> 4, m_r = (uint32_t)lane & 15u;
     const uint32_t b_rd = sw_unit(0, kq_r, m_r);
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(sw_lds_byte *)smem_raw;
     const uint32_t lane_off = (uint32_t)lane * 16u;
-    uint4 *const b_lds = lds, *const r_lds = lds + SW_RING * SW_B_UNITS;
+    uint4 *const b_lds = lds;
     const unsigned char *rows = reinterpret_cast<const unsigned char *>(a.rows);
     const uint64_t last_row = a.n_cand - 1;
     const uint32_t row_stride32 = (uint32_t)a.row_stride;
     const uint32_t rl0 = (uint32_t)w * 32u + m_r, rl1 = rl0 + 16u;
     const uint32_t coff0 = rl0 * row_stride32 + kq_r * 16u, coff1 = rl1 * row_stride32 + kq_r * 16u;
-    // how many tiles ahead a tile's column entries are asked for: at least SW_DEPTH + 1 stages, so that the end-of-stage waits have landed them
-    const uint32_t bi_ahead = (SW_DEPTH + nch) / nch;        // ceil((SW_DEPTH + 1) / nch) <= 6
 
     auto uniform_ptr = [&](uint64_t v) {
         return reinterpret_cast<const unsigned char *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
                                                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v));
     };
-    // One stage's requests: the queries' image of stage kc (this wave's 1 KiB of the 8) and this wave's codes of stage kc of the block's it-th tile (two pieces:
-    // row tiles 0, 1; a lane's own 16 bytes; rows past the block: the last row's bytes, their scores are dropped) -> ring slot `slot`
-    const unsigned char *rq_src = nullptr, *rc_src = nullptr;
-    uint32_t rq_dst = 0, rc_dst = 0, rc_o0 = coff0, rc_o1 = coff1;
-    auto requests_begin = [&](uint64_t it, uint32_t kc, uint32_t slot) {
-        rq_src = uniform_ptr((uint64_t)(uintptr_t)(s.bq + (uint64_t)kc * SW_B_UNITS) + (uint32_t)w * 1024u);
-        rq_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + (slot * SW_B_UNITS) * 16u + (uint32_t)w * 1024u));
+    // One stage's three loads, in the order the waits rely on: this wave's 1 KiB of the queries' image of stage kc, then the lane's code pieces of row tiles
+    // 0 and 1 of stage kc of the block's it-th tile (rows past the block: the last row's bytes, their scores are dropped)
+    auto load_stage = [&](uint64_t it, uint32_t kc, i32x4q &rq, i32x4q &rc0, i32x4q &rc1) __attribute__((always_inline)) {
+        const unsigned char *qsrc = uniform_ptr((uint64_t)(uintptr_t)(s.bq + (uint64_t)kc * SW_B_UNITS) + (uint32_t)w * 1024u);
         const uint64_t row0 = (blockIdx.x + it * gridDim.x) * SW_BM;
-        rc_src = uniform_ptr((uint64_t)(uintptr_t)(rows + row0 * a.row_stride + kc * 64u));
-        rc_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + (SW_RING * SW_B_UNITS + slot * SW_R_UNITS) * 16u + (uint32_t)w * 1024u));
-        rc_o0 = coff0;
-        rc_o1 = coff1;
+        const unsigned char *csrc = uniform_ptr((uint64_t)(uintptr_t)(rows + row0 * a.row_stride + kc * 64u));
+        uint32_t o0 = coff0, o1 = coff1;
         const uint64_t room = last_row - row0;                      // (row0 <= last_row: the tile exists)
         if (room < SW_BM - 1) {                                     // the block's last, partial tile (wave-uniform)
             const uint32_t r0 = (uint64_t)rl0 < room ? rl0 : (uint32_t)room, r1 = (uint64_t)rl1 < room ? rl1 : (uint32_t)room;
-            rc_o0 = r0 * row_stride32 + kq_r * 16u;
-            rc_o1 = r1 * row_stride32 + kq_r * 16u;
+            o0 = r0 * row_stride32 + kq_r * 16u;
+            o1 = r1 * row_stride32 + kq_r * 16u;
         }
-    };
-    auto request_piece = [&](int i) {      // 0: the queries; 1, 2: the codes of row tiles 0, 1
-        if (i == 0) sw_glds16(rq_src, lane_off, rq_dst);
-        else sw_glds16(rc_src, i == 1 ? rc_o0 : rc_o1, (uint32_t)__builtin_amdgcn_readfirstlane((int)(rc_dst + (uint32_t)(i - 1) * 8192u)));
-    };
-    // B of this wave's rows of the block's it-th tile -> the column staging (one 4-byte copy per lane, 32 lanes)
-    auto request_bi = [&](uint64_t it) {
-        const uint64_t itc = it < my_tiles ? it : my_tiles - 1;
-        const uint64_t row0 = (blockIdx.x + itc * gridDim.x) * SW_BM;
-        const uint64_t room = last_row - row0;
-        const uint32_t r = (uint32_t)w * 32u + ((uint32_t)lane & 31u);
-        const uint32_t rc = (uint64_t)r < room ? r : (uint32_t)room;
-        const unsigned char *src = uniform_ptr((uint64_t)(uintptr_t)(s.bi + row0));
-        const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + SW_RING * (SW_B_UNITS + SW_R_UNITS) * 16u + SW_QT * 4u + (((uint32_t)it % SW_BI_RING) * SW_BM + (uint32_t)w * 32u) * 4u));
-        if (lane < 32) {
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(rc * 4u), "s"(src), "s"(dst) : "memory");
-        }
+        sw_gload16(rq, qsrc, lane_off);
+        sw_gload16(rc0, csrc, o0);
+        sw_gload16(rc1, csrc, o1);
     };
 
     i32x4q acc[2][8];
     uint4 *const wl = s.wlist + (uint64_t)(blockIdx.x * (SW_THREADS / 64) + (uint32_t)w) * s.wcap;
     uint32_t wcount = 0;
     const uint32_t n_rows32 = (uint32_t)a.n_cand;
+    // B of the lane's eight rows of the running tile (rows 4 kq_r .. + 3 of both 16-row tiles of the wave), loaded on the tile's first stage for its epilogue
+    i32x4q bi8[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    auto load_bi = [&](uint64_t it) __attribute__((always_inline)) {
+        const uint64_t row0 = (blockIdx.x + it * gridDim.x) * SW_BM;
+        const unsigned char *src = uniform_ptr((uint64_t)(uintptr_t)(s.bi + row0));
+        const uint64_t room = last_row - row0;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            uint32_t r = (uint32_t)w * 32u + (uint32_t)mt * 16u + 4 * kq_r;
+            if ((uint64_t)r + 3 > room) r = room >= 3 ? (uint32_t)room - 3u : 0u;      // (entries of rows past the block are never used; keep the 16 bytes inside the column)
+            sw_gload16(bi8[mt], src, r * 4u);
+        }
+    };
 
     // The epilogue of a tile: dot + B[row] >= A[query], narrowing by wave-uniform steps (query tile, then the lane's rows)
     auto epilogue = [&](uint64_t it) __attribute__((always_inline)) {
         const uint64_t tile = blockIdx.x + it * gridDim.x;
         const uint32_t row0 = (uint32_t)(tile * SW_BM) + (uint32_t)w * 32u + 4 * kq_r;
-        // the lane's eight rows' column entries: rows 4 kq_r .. + 3 of both 16-row tiles of the wave
-        int bi8[2][4];
-        {
-            const int32_t *bsrc = bi_lds + ((uint32_t)it % SW_BI_RING) * SW_BM + (uint32_t)w * 32u + 4 * kq_r;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const int4 v = *reinterpret_cast<const int4 *>(bsrc + mt * 16);
-                bi8[mt][0] = v.x; bi8[mt][1] = v.y; bi8[mt][2] = v.z; bi8[mt][3] = v.w;
-            }
-        }
         uint32_t hits8 = 0;
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt) {
@@ -260,48 +234,52 @@ __global__ __launch_bounds__(SW_THREADS, 1) void scan_sqw_kernel(const ScanArgs 
             }
         }
     };
-    auto as_i32x4 = [](const uint4 &v) { return (i32x4q){(int)v.x, (int)v.y, (int)v.z, (int)v.w}; };
 
     const uint64_t n_stages = my_tiles * nch;
-    // the stage the requests are at, as (tile, kc), by running counters; past the block's last stage they repeat it (the waits count requests, not bytes)
+    // the stage the loads are at, as (tile, kc), by running counters; past the block's last stage they repeat it (the waits count loads, not bytes)
     uint64_t itr = 0;
     uint32_t kcr = 0;
     auto advance_r = [&]() {
         if (kcr + 1 < nch) ++kcr;
         else if (itr + 1 < my_tiles) { kcr = 0; ++itr; }
     };
-    // ---- prologue: stages 0 .. SW_DEPTH - 1 and the column entries of the first tiles asked for, stage 0 landed ----
+    i32x4q rq[SW_SLOTS], rc[SW_SLOTS][2];
+    // ---- prologue: the loads of stages 0 .. 3; the queries of stage 0 into their buffer ----
 #pragma unroll
-    for (int d = 0; d < SW_DEPTH; ++d) {
-        requests_begin(itr, kcr, (uint32_t)d);
-        request_piece(0);
-        request_piece(1);
-        request_piece(2);
+    for (int d = 0; d < SW_AHEAD_STAGES; ++d) {
+        load_stage(itr, kcr, rq[d], rc[d][0], rc[d][1]);
         advance_r();
     }
-    for (uint32_t t = 0; t < bi_ahead; ++t) request_bi(t);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(rq[0]), "+v"(rc[0][0]), "+v"(rc[0][1]) : : "memory");
+    *reinterpret_cast<i32x4q *>(b_lds + (uint32_t)w * 64u + (uint32_t)lane) = rq[0];
     sw_stage_barrier();
     uint64_t it = 0;
-    uint32_t kc = 0, slot = 0, rslot = SW_DEPTH;      // the slot of the running stage; the slot its requests (stage g + SW_DEPTH) go to: the one stage g - 1 was read from
-    for (uint64_t g = 0; g < n_stages; ++g) {
-        if (kc == 0) {
-            if (it) epilogue(it - 1);
+    uint32_t kc = 0, bslot = 0;
+    // one stage; I = g mod SW_SLOTS selects the register sets at compile time
+    auto one_stage = [&](auto IC) __attribute__((always_inline)) {
+        constexpr int I = decltype(IC)::value, IN = (I + 1) % SW_SLOTS, IL = (I + SW_AHEAD_STAGES) % SW_SLOTS;
+        const bool first = kc == 0;
+        if (first) {
+            if (it) {
+                // (the column entries were loaded a tile ago: 3 (nch - 1) loads were issued behind them before the last wait, which let 11 stay in flight)
+                if (3 * (nch - 1) < 11) asm volatile("s_waitcnt vmcnt(0)" : "+v"(bi8[0]), "+v"(bi8[1]) : : "memory");
+                else asm volatile("" : "+v"(bi8[0]), "+v"(bi8[1]) : : "memory");
+                epilogue(it - 1);
+            }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 8; ++nt) acc[mt][nt] = (i32x4q){0, 0, 0, 0};
         }
-        // the lane's operands of this stage (landed: see the wait below)
-        uint4 av[2];
-        {
-            const uint4 *src = r_lds + slot * SW_R_UNITS + (uint32_t)tid;
-            av[0] = src[0];
-            av[1] = src[512];
-        }
-        requests_begin(itr, kcr, rslot);
+        // stage g + 4 -> the register set stage g - 1 ran on
+        load_stage(itr, kcr, rq[IL], rc[IL][0], rc[IL][1]);
         advance_r();
-        const uint4 *bb = b_lds + slot * SW_B_UNITS + b_rd;
+        // all but the last 11 loads have landed: this stage's codes and the next stage's queries among them (a tile's two column loads inside that window
+        // only make the wait cover more)
+        asm volatile("s_waitcnt vmcnt(11)" : "+v"(rq[IN]), "+v"(rc[I][0]), "+v"(rc[I][1]) : : "memory");
+        static_assert(3 * SW_AHEAD_STAGES - 1 == 11, "the wait above");
+        *reinterpret_cast<i32x4q *>(b_lds + (bslot ^ 1u) * SW_B_UNITS + (uint32_t)w * 64u + (uint32_t)lane) = rq[IN];      // the next stage's queries: this wave's 1 KiB
+        const uint4 *bb = b_lds + bslot * SW_B_UNITS + b_rd;
         constexpr int SW_AHEAD = 3;
         i32x4q bv[SW_AHEAD + 1];
 #pragma unroll
@@ -310,24 +288,25 @@ __global__ __launch_bounds__(SW_THREADS, 1) void scan_sqw_kernel(const ScanArgs 
         for (int nt = 0; nt < 8; ++nt) {
             if (nt + SW_AHEAD < 8) bv[(nt + SW_AHEAD) % (SW_AHEAD + 1)] = *reinterpret_cast<const i32x4q *>(bb + (nt + SW_AHEAD) * 64);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(as_i32x4(av[mt]), bv[nt % (SW_AHEAD + 1)], acc[mt][nt], 0, 0, 0);
-            // the stage's three copy requests (and, on a tile's first stage, the column entries of a tile further on), spread over the matrix work
-            if (nt < 3) request_piece(nt);
-            if (nt == 3 && kc == 0) request_bi(it + bi_ahead);
+            for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(rc[I][mt], bv[nt % (SW_AHEAD + 1)], acc[mt][nt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        // all but the last 3 (SW_DEPTH - 1) requests have landed: stage g + 1 (asked for during stage g + 1 - SW_DEPTH) among them.  (A tile's column request
-        // inside that window only makes the wait cover more.)
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        static_assert(3 * (SW_DEPTH - 1) == 12, "the wait above");
+        if (first) load_bi(it);      // (after the epilogue that read the previous tile's)
         sw_stage_barrier();
         if (++kc == nch) { kc = 0; ++it; }
-        slot = slot + 1 == SW_RING ? 0 : slot + 1;
-        rslot = rslot + 1 == SW_RING ? 0 : rslot + 1;
+        bslot ^= 1u;
+    };
+    for (uint64_t g = 0; g < n_stages; g += SW_SLOTS) {
+        one_stage(std::integral_constant<int, 0>{});
+        if (g + 1 < n_stages) one_stage(std::integral_constant<int, 1>{});
+        if (g + 2 < n_stages) one_stage(std::integral_constant<int, 2>{});
+        if (g + 3 < n_stages) one_stage(std::integral_constant<int, 3>{});
+        if (g + 4 < n_stages) one_stage(std::integral_constant<int, 4>{});
     }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bi8[0]), "+v"(bi8[1]) : : "memory");
     epilogue(my_tiles - 1);
     if (lane == 0) s.wcnt[blockIdx.x * (SW_THREADS / 64) + (uint32_t)w] = wcount;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // nothing may land in LDS after the block is gone
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // ---- after the scan: an entry (dot, row, query) becomes (key lo, key hi, query) when its score - SqOps::finish (scan_sq_mfma.hip), operation for operation -
