@@ -213,8 +213,9 @@ static int32_t wide_exact_enqueue(qmx_query *q, uint32_t top, uint64_t n_cand, q
     q->last_counters = qmx_counters{};
     q->last_split = false;
     // the sample: every 128-th row (prescan_shift - 3; at least 8 192 rows): its k-th best score leaves ~128 k candidates per query to the pass - the pass's
-    // epilogue pays per candidate (10 M x 768, 128 queries: 2.07 / 2.00 / 2.01 ms with every 256-th / 128-th / 64-th row, whose own scores cost more)
-    const int sshift = (int)std::min<int64_t>(std::max<int64_t>(option(OPT_PRESCAN_SHIFT) - 3, 1), 20);
+    // epilogue pays per candidate (10 M x 768, 128 queries: 2.07 / 2.00 / 2.01 ms with every 256-th / 128-th / 64-th row, whose own scores cost more).
+    // SQ: every 256-th (its epilogue is one integer add and compare per pair; the sample's scores and their selection are 0.19 ms of the search at 1 / 128)
+    const int sshift = (int)std::min<int64_t>(std::max<int64_t>(option(OPT_PRESCAN_SHIFT) - (sq ? 2 : 3), 1), 20);
     const uint64_t S = std::min<uint64_t>(n_cand, std::max<uint64_t>(n_cand >> sshift, 8192));
     if (q->sp_sample_n != S || q->sp_sample_of != n_cand) {
         QMX_TRY(q->sp_sample.reserve((size_t)S * 4));
