@@ -8,9 +8,10 @@
 // leaf's f32 lane sums stay exact).
 //
 // Why.  The 32-query kernel (scan_sq_mfma.hip) streams the 7.7 GB of a 10 M x 768 block once per 32 queries at 0.72 - 0.74 of HBM: 128 queries cost four
-// passes, 5.3 ms.  Here a wave owns 32 rows of a 256-row tile, its lanes fetch exactly the 16-byte operand pieces v_mfma_i32_16x16x64_i8 wants from them
-// (plain 16-byte loads into the operand registers themselves, four 64-code stages ahead), and multiplies them with all 128 queries (their codes as B-operand images in LDS, loaded from a
-// 96 KiB image in L2): one pass of the block per 128 queries, bound by the HBM stream of the codes.
+// passes, 5.0 ms.  Here a wave owns 32 rows of a 256-row tile, its lanes fetch exactly the 16-byte operand pieces v_mfma_i32_16x16x64_i8 wants from them
+// (plain 16-byte loads into the operand registers themselves, two 128-code groups ahead), and multiplies them with all 128 queries (their codes as
+// B-operand images RESIDENT in LDS: 96 KiB at 768 codes, copied once per block - no barrier in the loop): one pass of the block per 128 queries, 1.33 ms =
+// 0.72 of HBM on the codes.
 //
 // Scores are exact, so the pass needs no band (scan_tq4w.hip: the same tail): a pair is a candidate when its score is not below the k-th best score of a
 // strided sample of the block; the fast reject runs on integers: multiplier * dot + query_offset + vector_offset >= T  <=>  dot + vector_offset / multiplier
@@ -29,17 +30,12 @@ constexpr int SW_THREADS = 512;
 constexpr int SW_BM = 256;                                   // rows per tile
 constexpr int SW_QT = 128;                                   // queries per pass
 constexpr int SW_B_UNITS = SW_QT * 4;                        // 16-byte units of the queries' stage: 128 queries x 64 codes = 8 KiB
-constexpr int SW_LDS = 2 * SW_B_UNITS * 16 + SW_QT * 4;      // the queries' two buffers + the 128 integer bounds (the codes go to registers)
+constexpr int SW_MAX_CODES = 1024;                           // sq_mfma_ok: 127^2 x codes < 2^24
+constexpr int SW_LDS_MAX = SW_MAX_CODES / 64 * SW_B_UNITS * 16 + SW_QT * 4;      // the queries' whole image (8 KiB per 64 codes) + the 128 integer bounds: 128.5 KiB
 constexpr uint32_t SW_WCAP = 8192;                           // candidates one wave may list per pass
 
 // unit index of (16-query tile t, piece kq, query-in-tile m) inside a stage of the queries' image: scan_split.hip sp_unit's swizzle, conflict-free for the operand reads
 __device__ __forceinline__ uint32_t sw_unit(uint32_t t, uint32_t kq, uint32_t m) { return (t * 4 + kq) * 16 + (m ^ (2 * kq)); }
-
-__device__ __forceinline__ void sw_stage_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
 
 struct SqWideArgs {
     const uint4 *bq;          // [nch][SW_B_UNITS] the queries' operand images (sqw_pack_kernel)
@@ -112,78 +108,102 @@ __global__ __launch_bounds__(256) void sqw_pack_kernel(const unsigned char *quer
     qinfo[SW_QT + qi] = tf;
 }
 
-// The scan.  Block = 8 waves, one block per CU, persistent over 256-row tiles; a tile = nch stages of 64 codes.  A wave OWNS 32 rows of the tile: lane
-// (m, kg) loads, per stage, the 16 code bytes [16 kg, +16) of rows m and 16 + m - exactly its operand registers of the stage's two row tiles - and
-// multiplies with all 128 queries: 16 matrix instructions and 8 operand reads per wave and stage.
-// The loads are `global_load_dwordx4` issued by inline asm INTO the operand registers, four stages ahead, and waited for by the kernel's own `s_waitcnt
-// vmcnt` (an asm statement that names the registers it releases as in-out operands, so no use or copy of them can be scheduled in front of it):
-//   * hipcc's own waits would be conservative across the loop's back edge (scan_tq4w.hip met `vmcnt(0)` at every stage);
-//   * LDS-DMA (`global_load_lds_dwordx4`), which rounds 3 - 5 of this library use for such streams, costs the issuing wave 150 - 260 cycles per 1 KiB
-//     request here - three requests per 16 matrix instructions: measured, the loop without its code requests ran 0.99 ms per 10 M x 768 pass, with them
-//     1.64 - 1.78 whatever their depth (three 128-code stages one or two ahead, six 64-code stages five ahead).  A plain load is one issue slot.
-// vmcnt is IN-ORDER: the wait of stage g lets the last 11 loads stay in flight - the codes of stages g + 1 .. g + 4 and the queries of g + 2 .. g + 4 -, which
-// lands the codes of stage g and the queries of stage g + 1; the latter go to LDS by one ds_write_b128 per lane (the queries' buffers, two of them, are all
-// the waves share: one barrier per stage).  64 KiB of codes per CU on their way.
 __device__ __forceinline__ void sw_gload16(i32x4q &dst, const unsigned char *sbase, uint32_t voff) {
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
 }
-constexpr int SW_AHEAD_STAGES = 4;                           // stages the loads run ahead of the matrix work
-constexpr int SW_SLOTS = SW_AHEAD_STAGES + 1;                // register sets of a stage's loads (the running stage's + those in flight)
+
+// ---- The scan.  Block = 8 waves, one block per CU, persistent over 256-row tiles; a tile = nch stages of 64 codes.  The queries' WHOLE operand image is
+// RESIDENT in LDS (nch x 8 KiB: 96 KiB at 768 codes, 128 KiB at the 1 024 sq_mfma_ok admits), copied once per block.  After that copy the waves share
+// nothing, so there is no stage barrier and no lockstep: a wave OWNS 32 rows of the tile, lane (m, kg) loads, per stage, the 16 code bytes [16 kg, +16) of
+// rows m and 16 + m - exactly its operand registers of the stage's two row tiles - and multiplies them with all 128 queries: 16 matrix instructions and 8
+// operand reads per wave and stage; while one wave of a SIMD waits for its codes the other multiplies.
+// The loads are `global_load_dwordx4` issued by inline asm INTO the operand registers and waited for by the kernel's own `s_waitcnt vmcnt` (asm statements
+// that name the registers they release as in-out operands, so no use or copy of them can be scheduled in front of the wait; hipcc's own waits would be
+// conservative across the loop's back edge).  They are issued by GROUPS of G stages, AHEAD groups in front of the matrix work: the two loads of a row's
+// 128-byte line leave the wave back to back instead of a stage apart.  vmcnt is IN-ORDER: the wait of group g lets the last 2 G AHEAD loads stay in flight.
+// Measured at 10 M x 768, 128 queries (profiles/r6_sqw_resident.md): staged queries + a barrier per stage 1.70 - 1.77 ms; resident, G = 1: 1.45 whatever
+// the depth (AHEAD 4 .. 10); G = 2 / 4 / 6: 1.32 - 1.36 whatever the depth (AHEAD 1 .. 4); twelve waves per CU (168 registers: spills) 1.47. ----
+template <int I, int N, class F>
+__device__ __forceinline__ void sw_static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        sw_static_for<I + 1, N>(f);
+    }
+}
+// vmcnt(n) for a wave-uniform even n <= 14 (the immediate has to be one)
+__device__ __forceinline__ void sw_wait_vm_dyn(uint32_t n) {
+    switch (n >> 1) {
+#define SW_W(k) case k: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * k) : "memory"); break;
+        SW_W(1) SW_W(2) SW_W(3) SW_W(4) SW_W(5) SW_W(6) SW_W(7)
+#undef SW_W
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+template <int G, int AHEAD>
 __global__ __launch_bounds__(SW_THREADS, 1) void scan_sqw_kernel(const ScanArgs a, const SqWideArgs s) {
+    constexpr int WAVES = SW_THREADS / 64, T = SW_THREADS, BM = SW_BM;
+    static_assert(BM == WAVES * 32, "a wave owns 32 rows of a tile");
+    constexpr int SLOTS = AHEAD + 1;
+    static_assert(2 * G * AHEAD <= 62, "vmcnt is six bits");
+    static_assert(2 * G * (AHEAD - 1) <= 14, "sw_wait_vm_dyn covers the short-row case up to 14");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint4 *lds = reinterpret_cast<uint4 *>(smem_raw);
-    int32_t *thr_lds = reinterpret_cast<int32_t *>(smem_raw + (size_t)2 * SW_B_UNITS * 16);
+    const uint32_t nch = s.nch;
+    const uint32_t ngr = (nch + G - 1) / G;                          // groups per tile
+    int32_t *thr_lds = reinterpret_cast<int32_t *>(smem_raw + (size_t)nch * SW_B_UNITS * 16);
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint64_t n_tiles = (a.n_cand + SW_BM - 1) / SW_BM;
-    const uint32_t nch = s.nch;
+    const uint64_t n_tiles = (a.n_cand + BM - 1) / BM;
     const uint64_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
     if (my_tiles == 0) {
-        if (lane == 0) s.wcnt[blockIdx.x * (SW_THREADS / 64) + (uint32_t)w] = 0;
+        if (lane == 0) s.wcnt[blockIdx.x * (WAVES) + (uint32_t)w] = 0;
         return;
     }
+#pragma unroll 4
+    for (uint32_t u = (uint32_t)tid; u < nch * SW_B_UNITS; u += T) lds[u] = s.bq[u];
     if (tid < SW_QT) thr_lds[tid] = s.thr_i[tid];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // from here on the kernel counts its vector-memory traffic itself
+    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // from here on the kernel counts its vector-memory traffic itself
     const uint32_t kq_r = (uint32_t)lane >> 4, m_r = (uint32_t)lane & 15u;
-    const uint32_t b_rd = sw_unit(0, kq_r, m_r);
-    const uint32_t lane_off = (uint32_t)lane * 16u;
-    uint4 *const b_lds = lds;
+    const uint4 *const b_rd = lds + sw_unit(0, kq_r, m_r);
     const unsigned char *rows = reinterpret_cast<const unsigned char *>(a.rows);
     const uint64_t last_row = a.n_cand - 1;
     const uint32_t row_stride32 = (uint32_t)a.row_stride;
     const uint32_t rl0 = (uint32_t)w * 32u + m_r, rl1 = rl0 + 16u;
-    const uint32_t coff0 = rl0 * row_stride32 + kq_r * 16u, coff1 = rl1 * row_stride32 + kq_r * 16u;
 
     auto uniform_ptr = [&](uint64_t v) {
         return reinterpret_cast<const unsigned char *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
                                                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v));
     };
-    // One stage's three loads, in the order the waits rely on: this wave's 1 KiB of the queries' image of stage kc, then the lane's code pieces of row tiles
-    // 0 and 1 of stage kc of the block's it-th tile (rows past the block: the last row's bytes, their scores are dropped)
-    auto load_stage = [&](uint64_t it, uint32_t kc, i32x4q &rq, i32x4q &rc0, i32x4q &rc1) __attribute__((always_inline)) {
-        const unsigned char *qsrc = uniform_ptr((uint64_t)(uintptr_t)(s.bq + (uint64_t)kc * SW_B_UNITS) + (uint32_t)w * 1024u);
-        const uint64_t row0 = (blockIdx.x + it * gridDim.x) * SW_BM;
-        const unsigned char *csrc = uniform_ptr((uint64_t)(uintptr_t)(rows + row0 * a.row_stride + kc * 64u));
-        uint32_t o0 = coff0, o1 = coff1;
+    // One group's 2 G loads: the lane's code pieces of row tiles 0 and 1 of group b of the block's it-th tile (rows past the block: the last row's bytes,
+    // their scores are dropped; stages past the row: the group's last piece again - the waits count loads)
+    auto load_group = [&](uint64_t it, uint32_t b, i32x4q (&rc)[G][2]) __attribute__((always_inline)) {
+        const uint64_t row0 = (blockIdx.x + it * gridDim.x) * BM;
+        const unsigned char *csrc = uniform_ptr((uint64_t)(uintptr_t)(rows + row0 * a.row_stride + b * (G * 64u)));
+        const uint32_t gsz = nch - b * G < (uint32_t)G ? nch - b * G : (uint32_t)G;
+        uint32_t r0 = rl0, r1 = rl1;
         const uint64_t room = last_row - row0;                      // (row0 <= last_row: the tile exists)
-        if (room < SW_BM - 1) {                                     // the block's last, partial tile (wave-uniform)
-            const uint32_t r0 = (uint64_t)rl0 < room ? rl0 : (uint32_t)room, r1 = (uint64_t)rl1 < room ? rl1 : (uint32_t)room;
-            o0 = r0 * row_stride32 + kq_r * 16u;
-            o1 = r1 * row_stride32 + kq_r * 16u;
+        if (room < BM - 1) {                                     // the block's last, partial tile (wave-uniform)
+            r0 = (uint64_t)rl0 < room ? rl0 : (uint32_t)room;
+            r1 = (uint64_t)rl1 < room ? rl1 : (uint32_t)room;
         }
-        sw_gload16(rq, qsrc, lane_off);
-        sw_gload16(rc0, csrc, o0);
-        sw_gload16(rc1, csrc, o1);
+        const uint32_t o0 = r0 * row_stride32 + kq_r * 16u, o1 = r1 * row_stride32 + kq_r * 16u;
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const uint32_t jj = (uint32_t)j < gsz ? (uint32_t)j : gsz - 1u;
+            sw_gload16(rc[j][0], csrc, o0 + jj * 64u);
+            sw_gload16(rc[j][1], csrc, o1 + jj * 64u);
+        }
     };
 
     i32x4q acc[2][8];
-    uint4 *const wl = s.wlist + (uint64_t)(blockIdx.x * (SW_THREADS / 64) + (uint32_t)w) * s.wcap;
+    uint4 *const wl = s.wlist + (uint64_t)(blockIdx.x * (WAVES) + (uint32_t)w) * s.wcap;
     uint32_t wcount = 0;
     const uint32_t n_rows32 = (uint32_t)a.n_cand;
-    // B of the lane's eight rows of the running tile (rows 4 kq_r .. + 3 of both 16-row tiles of the wave), loaded on the tile's first stage for its epilogue
+    // B of the lane's eight rows of the running tile (rows 4 kq_r .. + 3 of both 16-row tiles of the wave)
     i32x4q bi8[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     auto load_bi = [&](uint64_t it) __attribute__((always_inline)) {
-        const uint64_t row0 = (blockIdx.x + it * gridDim.x) * SW_BM;
+        const uint64_t row0 = (blockIdx.x + it * gridDim.x) * BM;
         const unsigned char *src = uniform_ptr((uint64_t)(uintptr_t)(s.bi + row0));
         const uint64_t room = last_row - row0;
 #pragma unroll
@@ -197,7 +217,7 @@ __global__ __launch_bounds__(SW_THREADS, 1) void scan_sqw_kernel(const ScanArgs 
     // The epilogue of a tile: dot + B[row] >= A[query], narrowing by wave-uniform steps (query tile, then the lane's rows)
     auto epilogue = [&](uint64_t it) __attribute__((always_inline)) {
         const uint64_t tile = blockIdx.x + it * gridDim.x;
-        const uint32_t row0 = (uint32_t)(tile * SW_BM) + (uint32_t)w * 32u + 4 * kq_r;
+        const uint32_t row0 = (uint32_t)(tile * BM) + (uint32_t)w * 32u + 4 * kq_r;
         uint32_t hits8 = 0;
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt) {
@@ -235,77 +255,74 @@ __global__ __launch_bounds__(SW_THREADS, 1) void scan_sqw_kernel(const ScanArgs 
         }
     };
 
-    const uint64_t n_stages = my_tiles * nch;
-    // the stage the loads are at, as (tile, kc), by running counters; past the block's last stage they repeat it (the waits count loads, not bytes)
+    const uint64_t n_groups = my_tiles * ngr;
+    // the group the loads are at, as (tile, b), by running counters; past the block's last group they repeat it (the waits count loads, not bytes)
     uint64_t itr = 0;
-    uint32_t kcr = 0;
+    uint32_t br = 0;
     auto advance_r = [&]() {
-        if (kcr + 1 < nch) ++kcr;
-        else if (itr + 1 < my_tiles) { kcr = 0; ++itr; }
+        if (br + 1 < ngr) ++br;
+        else if (itr + 1 < my_tiles) { br = 0; ++itr; }
     };
-    i32x4q rq[SW_SLOTS], rc[SW_SLOTS][2];
-    // ---- prologue: the loads of stages 0 .. 3; the queries of stage 0 into their buffer ----
-#pragma unroll
-    for (int d = 0; d < SW_AHEAD_STAGES; ++d) {
-        load_stage(itr, kcr, rq[d], rc[d][0], rc[d][1]);
+    i32x4q rc[SLOTS][G][2];
+    // ---- prologue: the loads of groups 0 .. AHEAD - 1 ----
+    sw_static_for<0, AHEAD>([&](auto DC) __attribute__((always_inline)) {
+        load_group(itr, br, rc[decltype(DC)::value]);
         advance_r();
-    }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(rq[0]), "+v"(rc[0][0]), "+v"(rc[0][1]) : : "memory");
-    *reinterpret_cast<i32x4q *>(b_lds + (uint32_t)w * 64u + (uint32_t)lane) = rq[0];
-    sw_stage_barrier();
+    });
     uint64_t it = 0;
-    uint32_t kc = 0, bslot = 0;
-    // one stage; I = g mod SW_SLOTS selects the register sets at compile time
-    auto one_stage = [&](auto IC) __attribute__((always_inline)) {
-        constexpr int I = decltype(IC)::value, IN = (I + 1) % SW_SLOTS, IL = (I + SW_AHEAD_STAGES) % SW_SLOTS;
-        const bool first = kc == 0;
-        if (first) {
+    uint32_t b = 0;
+    // one group; I = g mod SLOTS selects the register sets at compile time
+    auto one_group = [&](auto IC) __attribute__((always_inline)) {
+        constexpr int I = decltype(IC)::value, IL = (I + AHEAD) % SLOTS;
+        if (b == 0) {
             if (it) {
-                // (the column entries were loaded a tile ago: 3 (nch - 1) loads were issued behind them before the last wait, which let 11 stay in flight)
-                if (3 * (nch - 1) < 11) asm volatile("s_waitcnt vmcnt(0)" : "+v"(bi8[0]), "+v"(bi8[1]) : : "memory");
-                else asm volatile("" : "+v"(bi8[0]), "+v"(bi8[1]) : : "memory");
+                // the finished tile's column entries were loaded on ITS first group, in front of that group's code loads: 2 G ngr loads have been issued
+                // behind them since, of which the last wait let 2 G AHEAD stay in flight
+                if (ngr < (uint32_t)AHEAD) sw_wait_vm_dyn(2u * G * ngr);
+                asm volatile("" : "+v"(bi8[0]), "+v"(bi8[1]) : : "memory");
                 epilogue(it - 1);
             }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 8; ++nt) acc[mt][nt] = (i32x4q){0, 0, 0, 0};
+            load_bi(it);
         }
-        // stage g + 4 -> the register set stage g - 1 ran on
-        load_stage(itr, kcr, rq[IL], rc[IL][0], rc[IL][1]);
+        // group g + AHEAD -> the register set group g - 1 ran on
+        load_group(itr, br, rc[IL]);
         advance_r();
-        // all but the last 11 loads have landed: this stage's codes and the next stage's queries among them (a tile's two column loads inside that window
-        // only make the wait cover more)
-        asm volatile("s_waitcnt vmcnt(11)" : "+v"(rq[IN]), "+v"(rc[I][0]), "+v"(rc[I][1]) : : "memory");
-        static_assert(3 * SW_AHEAD_STAGES - 1 == 11, "the wait above");
-        *reinterpret_cast<i32x4q *>(b_lds + (bslot ^ 1u) * SW_B_UNITS + (uint32_t)w * 64u + (uint32_t)lane) = rq[IN];      // the next stage's queries: this wave's 1 KiB
-        const uint4 *bb = b_lds + bslot * SW_B_UNITS + b_rd;
-        constexpr int SW_AHEAD = 3;
-        i32x4q bv[SW_AHEAD + 1];
+        const uint32_t gsz = nch - b * G < (uint32_t)G ? nch - b * G : (uint32_t)G;
+        // all but the last 2 G AHEAD loads have landed: this group's codes among them
+        asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * G * AHEAD) : "memory");
 #pragma unroll
-        for (int k = 0; k < SW_AHEAD; ++k) bv[k] = *reinterpret_cast<const i32x4q *>(bb + k * 64);
+        for (int J = 0; J < G; ++J) asm volatile("" : "+v"(rc[I][J][0]), "+v"(rc[I][J][1]) : : "memory");
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt) {
-            if (nt + SW_AHEAD < 8) bv[(nt + SW_AHEAD) % (SW_AHEAD + 1)] = *reinterpret_cast<const i32x4q *>(bb + (nt + SW_AHEAD) * 64);
+        for (int J = 0; J < G; ++J) {
+            if ((uint32_t)J < gsz) {
+                const uint4 *bb = b_rd + (b * G + J) * SW_B_UNITS;
+                constexpr int SW_AHEAD = 3;
+                i32x4q bv[SW_AHEAD + 1];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(rc[I][mt], bv[nt % (SW_AHEAD + 1)], acc[mt][nt], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int k = 0; k < SW_AHEAD; ++k) bv[k] = *reinterpret_cast<const i32x4q *>(bb + k * 64);
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) {
+                    if (nt + SW_AHEAD < 8) bv[(nt + SW_AHEAD) % (SW_AHEAD + 1)] = *reinterpret_cast<const i32x4q *>(bb + (nt + SW_AHEAD) * 64);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(rc[I][J][mt], bv[nt % (SW_AHEAD + 1)], acc[mt][nt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
-        if (first) load_bi(it);      // (after the epilogue that read the previous tile's)
-        sw_stage_barrier();
-        if (++kc == nch) { kc = 0; ++it; }
-        bslot ^= 1u;
+        if (++b == ngr) { b = 0; ++it; }
     };
-    for (uint64_t g = 0; g < n_stages; g += SW_SLOTS) {
-        one_stage(std::integral_constant<int, 0>{});
-        if (g + 1 < n_stages) one_stage(std::integral_constant<int, 1>{});
-        if (g + 2 < n_stages) one_stage(std::integral_constant<int, 2>{});
-        if (g + 3 < n_stages) one_stage(std::integral_constant<int, 3>{});
-        if (g + 4 < n_stages) one_stage(std::integral_constant<int, 4>{});
+    for (uint64_t g = 0; g < n_groups; g += SLOTS) {
+        sw_static_for<0, SLOTS>([&](auto IC) __attribute__((always_inline)) {
+            if (g + decltype(IC)::value < n_groups) one_group(IC);
+        });
     }
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(bi8[0]), "+v"(bi8[1]) : : "memory");
     epilogue(my_tiles - 1);
-    if (lane == 0) s.wcnt[blockIdx.x * (SW_THREADS / 64) + (uint32_t)w] = wcount;
+    if (lane == 0) s.wcnt[blockIdx.x * (WAVES) + (uint32_t)w] = wcount;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -337,7 +354,7 @@ __global__ __launch_bounds__(256) void sqw_finish_kernel(uint4 *wlist, const uin
 bool sqw_shape_ok(const ScanArgs &a) {
     return a.dim >= 64 && a.dim % 64 == 0 && a.row_stride % 16 == 0 && a.row_stride * (SW_BM - 1) + a.dim < (1ull << 31) && a.ids == nullptr &&
            a.top <= MAX_TOP_FAST && a.row_offsets != nullptr && a.sq_multiplier > 0.0f && a.sq_multiplier < __builtin_inff() && a.n_cand >= 1 &&
-           a.n_cand < 0xFFFFFFFFull && (uint64_t)127 * 127 * a.dim < (1ull << 24);
+           a.n_cand < 0xFFFFFFFFull && (uint64_t)127 * 127 * a.dim < (1ull << 24) && a.dim <= (uint32_t)SW_MAX_CODES;
 }
 size_t sqw_query_bytes(uint32_t dim) { return (size_t)(dim / 64) * SW_B_UNITS * 16; }
 size_t sqw_wlists_counts_bytes(int num_cus) { return ((size_t)num_cus * (SW_THREADS / 64) * 4 + 255) / 256 * 256; }
@@ -376,15 +393,16 @@ int32_t launch_scan_sqw(hipStream_t st, const ScanArgs &a, const void *d_bq, con
     s.wcap = SW_WCAP;
     const uint64_t n_tiles = (a.n_cand + SW_BM - 1) / SW_BM;
     const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)num_cus, n_tiles);
+    const size_t lds_bytes = (size_t)s.nch * SW_B_UNITS * 16 + SW_QT * 4;      // the queries' image + the 128 integer bounds
     static thread_local DeviceOnce once;
     ::qmx::clear_stale_error();
-    auto kfn = scan_sqw_kernel;
+    auto kfn = scan_sqw_kernel<2, 2>;
     if (once.need()) {
-        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS));
+        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS_MAX));
         once.mark();
     }
     QMX_NOTE_KERNEL(kfn);
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(SW_THREADS), SW_LDS, st, a, s);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(SW_THREADS), lds_bytes, st, a, s);
     QMX_HIP(hipGetLastError());
     const uint32_t n_lists = grid * (SW_THREADS / 64);
     hipLaunchKernelGGL(sqw_finish_kernel, dim3((n_lists + 3) / 4), dim3(256), 0, st, s.wlist, s.wcnt, s.wcap, n_lists, a.sq_multiplier, a.row_offsets, d_qinfo);
