@@ -298,7 +298,7 @@ QMX_API uint32_t qmx_abi_version(void);
  * both sides of every option - so they are tuning / triage switches, never correctness switches: "no_mfma_scan", "no_mfma16",
  * "no_prescan", "prescan_shift", "hnsw_log_cap", "no_split_scan", "split_min_queries", "no_split256", "no_pq_pair", "no_pq_prefilter",
  * "pq_prefilter_min_queries", "hnsw_pq_per_cu", "tq_rotate_block", "no_topk_small", "verify_max_per_query", "hnsw_pq_direct_walk",
- * "hnsw_pq_table_build", "hnsw_no_pq_prefilter", "hnsw_no_lds_visited", "pq_lut_no_lds", "hnsw_per_cu", "tq_wide_min_queries", "tq_wide_high_digit", "sq_wide_min_queries", "debug"
+ * "hnsw_pq_table_build", "hnsw_no_pq_prefilter", "hnsw_no_lds_visited", "pq_lut_no_lds", "hnsw_per_cu", "tq_wide_min_queries", "tq_wide_high_digit", "sq_wide_min_queries", "i8_resident", "debug"
  * - and one that selects the ORDER AMONG EQUAL SCORES of the plain HNSW walk: "hnsw_reference_heap_order" (see qmx_hnsw_search_traced) -
  * (qdrant_amd/csrc/common.hpp says what each selects; round 6 removed the experiments that had measured slower twice: their numbers stay under
  * profiles/).  Initial values come from the environment variables QMX_<NAME> read

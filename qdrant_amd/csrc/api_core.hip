@@ -32,7 +32,7 @@ int32_t hip_status(hipError_t e, const char *what, const char *file, int line) {
 }
 
 // ---- kernel-path options: the environment is read once, here, at load time ----
-static const char *const g_option_names[OPT_COUNT] = {"no_mfma_scan", "no_mfma16", "no_prescan", "prescan_shift", "hnsw_log_cap", "no_split_scan", "split_min_queries", "no_split256", "no_pq_pair", "no_pq_prefilter", "pq_prefilter_min_queries", "hnsw_pq_per_cu", "tq_rotate_block", "no_topk_small", "verify_max_per_query", "hnsw_pq_direct_walk", "hnsw_pq_table_build", "hnsw_no_pq_prefilter", "hnsw_no_lds_visited", "pq_lut_no_lds", "hnsw_per_cu", "hnsw_reference_heap_order", "tq_wide_min_queries", "tq_wide_high_digit", "sq_wide_min_queries", "debug"};
+static const char *const g_option_names[OPT_COUNT] = {"no_mfma_scan", "no_mfma16", "no_prescan", "prescan_shift", "hnsw_log_cap", "no_split_scan", "split_min_queries", "no_split256", "no_pq_pair", "no_pq_prefilter", "pq_prefilter_min_queries", "hnsw_pq_per_cu", "tq_rotate_block", "no_topk_small", "verify_max_per_query", "hnsw_pq_direct_walk", "hnsw_pq_table_build", "hnsw_no_pq_prefilter", "hnsw_no_lds_visited", "pq_lut_no_lds", "hnsw_per_cu", "hnsw_reference_heap_order", "tq_wide_min_queries", "tq_wide_high_digit", "sq_wide_min_queries", "i8_resident", "debug"};
 struct OptionTable {
     std::atomic<int64_t> v[OPT_COUNT];
     int64_t initial[OPT_COUNT];
@@ -50,6 +50,7 @@ struct OptionTable {
             if (i == OPT_PQ_PREFILTER_MIN_QUERIES && !e) val = 4;
             if (i == OPT_TQ_WIDE_MIN_QUERIES && !e) val = 33;
             if (i == OPT_SQ_WIDE_MIN_QUERIES && !e) val = 33;
+            if (i == OPT_I8_RESIDENT && !e) val = 1;
             initial[i] = val;
             v[i].store(val, std::memory_order_relaxed);
         }

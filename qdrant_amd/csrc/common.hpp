@@ -51,6 +51,9 @@ enum Option {
                               // survivors are re-scored exactly - the same lists) instead of both digits (exact scores in the pass).  Faster on rows whose scores
                               // spread wide against the band (iid unit rows: 2.41 against 2.55 ms per 128 queries), much slower where they crowd (clustered: 5.8 / 3.1)
     OPT_SQ_WIDE_MIN_QUERIES,  // scalar-int8 top-k scans of at least this many queries take the 128-query pass (scan_sqw.hip; default 33, 0 = never)
+    OPT_I8_RESIDENT,          // 1 (default): the int8-copy prefilter over rows of up to 1 024 coordinates keeps the queries' whole operand image resident in LDS
+                              // (scan_i8copy_kernel_res: no stage barrier, 97 KiB of LDS at 768 coordinates); 0 = the staged kernel of rounds 3 - 6 (scan_i8copy_kernel:
+                              // 144 KiB), which longer rows take anyway
     OPT_DEBUG,                // log dropped stale HIP errors
     OPT_COUNT
 };

@@ -1501,6 +1501,182 @@ __global__ __launch_bounds__(SP3_THREADS, 1) void scan_i8copy_kernel(const ScanA
 // barriers), wave-owned rows behind private rings with no stage hand-over (5 % slower), rows straight into the operand registers - and are gone from the
 // code since round 6; the measurements stay (profiles/r4_i8_deep_ring.md).
 
+// ---- The same scan with the queries' WHOLE operand image resident in LDS (round 6, last session; the structure scan_sqw.hip found for the scalar-int8 block,
+// on this copy's tiled layout).  Rows up to 1 024 coordinates: nch x 16 KiB of query images (96 KiB at 768) + 1 KiB of thresholds and scales, copied once per
+// block; after that copy the waves share nothing: no stage barrier, no LDS ring of rows.  A wave OWNS row tiles 2 w and 2 w + 1 of a 256-row tile: their operand
+// images are the 4 KiB [4 w KiB, + 4 KiB) of every 32 KiB stage of the copy (sp_unit: ((t * 2 + hl) * 4 + kq) * 16 + swizzle(m) - a lane's 16 bytes sit at one
+// lane-constant offset inside each 1 KiB image), so a stage is four `global_load_dwordx4` of 1 KiB each, contiguous, INTO the matrix instruction's operand
+// registers, issued AHEAD stages in front of the matrix work and waited for by the kernel's own vmcnt (in-order); per stage and wave 32 matrix instructions
+// against all 128 queries and 16 operand reads.  Same integers, same thresholds, same candidates as scan_i8copy_kernel (which stays for longer rows and as option
+// i8_resident = 0); LDS per CU 97 KiB instead of 144: every small kernel of the other batches in flight - the sample's exact scores with their 50 KiB query tile
+// among them - fits beside a scan. ----
+constexpr uint32_t SP8R_MAX_NCH = 8;
+__host__ __device__ constexpr size_t sp8r_lds_bytes(uint32_t nch) { return (size_t)nch * SP_B_UNITS * 16 + 2 * SP_QT * 4; }
+template <int OFF>
+__device__ __forceinline__ void sp_gload16(i32x4s &dst, const unsigned char *sbase, uint32_t voff) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void sp_static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        sp_static_for<I + 1, N>(f);
+    }
+}
+// Measured and gone from the code (profiles/r6_i8_resident.md): two / three stages of loads ahead (equal or slower: 170 / 200 registers), four row tiles per wave -
+// waves 0 - 3 on the block's even tiles, 4 - 7 on its odd ones: half the operand reads per matrix instruction, 250 registers - (equal).
+template <int AHEAD>
+__global__ __launch_bounds__(SP3_THREADS, 1) void scan_i8copy_kernel_res(const ScanArgs a, const SplitArgs s) {
+    constexpr int SLOTS = AHEAD + 1, WAVES = SP3_THREADS / 64, THREADS = SP3_THREADS, MT = 2, NL = 2 * MT;
+    static_assert(SP3_BM == WAVES * MT * 16, "a wave owns two row tiles of a 256-row tile");
+    static_assert(NL * AHEAD <= 62, "vmcnt is six bits");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint4 *lds = reinterpret_cast<uint4 *>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint64_t all_tiles = (a.n_cand + SP3_BM - 1) / SP3_BM;
+    const uint64_t n_tiles = split_phase_tiles(all_tiles, s.phase);
+    const uint32_t nch = s.nchunks;
+    const uint64_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const uint32_t phase = s.phase & 0xFFu, pstride = split_phase_stride(s.phase);
+    auto tile_of = [&](uint64_t j) -> uint64_t { return phase == 0 ? j : phase == 1 ? j * pstride : j + j / (pstride - 1) + 1; };
+    if (my_tiles == 0) {
+        if (lane == 0) s.wcnt[blockIdx.x * WAVES + (uint32_t)w] = 0;
+        return;
+    }
+    const uint32_t ws = (uint32_t)w;
+    auto my_tile = [&](uint64_t i) -> uint64_t { return tile_of(blockIdx.x + i * gridDim.x); };
+    float *thr_lds = reinterpret_cast<float *>(smem_raw + (size_t)nch * SP_B_UNITS * 16), *qs_lds = thr_lds + SP_QT;
+#pragma unroll 4
+    for (uint32_t u = (uint32_t)tid; u < nch * SP_B_UNITS; u += THREADS) lds[u] = s.bq[u];
+    for (int u = tid; u < SP_QT; u += THREADS) {
+        thr_lds[u] = s.thr[u];
+        qs_lds[u] = s.scales[u];
+    }
+    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // from here on the kernel counts its vector-memory traffic itself
+    const uint32_t kq_r = (uint32_t)lane >> 4, m_r = (uint32_t)lane & 15u;
+    const uint32_t lane_unit = kq_r * 16u + (m_r ^ (2u * kq_r));      // sp_unit(0, 0, kq_r, m_r)
+    const uint4 *const b_rd = lds + lane_unit;
+    const uint32_t lane_off = lane_unit * 16u;
+    auto uniform_ptr = [&](uint64_t v) {
+        return reinterpret_cast<const unsigned char *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
+                                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v));
+    };
+    // one stage's 2 MT loads: the images (row tile MT w + mt, plane hl) of stage kc of a tile -> rc[mt * 2 + hl]
+    auto load_stage = [&](uint64_t tile, uint32_t kc, i32x4s (&rc)[NL]) __attribute__((always_inline)) {
+        const unsigned char *src = uniform_ptr((uint64_t)(uintptr_t)(s.rows_split + (tile * nch + kc) * SP3_A_UNITS) + ws * (NL * 1024u));
+        sp_gload16<0>(rc[0], src, lane_off);
+        sp_gload16<1024>(rc[1], src, lane_off);
+        sp_gload16<2048>(rc[2], src, lane_off);
+        sp_gload16<3072>(rc[3], src, lane_off);
+    };
+    i32x4s acc[MT][8];
+    uint4 *const wl = s.wlist + (uint64_t)(blockIdx.x * WAVES + (uint32_t)w) * s.wcap;
+    uint32_t wcount = 0;
+    const uint32_t n_rows32 = (uint32_t)a.n_cand;
+    // the epilogue of a tile: scan_i8copy_kernel's test (a pair is a candidate unless its accumulator is below the query's threshold), narrowing by
+    // wave-uniform steps: the query tile, then the lane's 4 MT rows
+    auto epilogue = [&](uint64_t tile) __attribute__((always_inline)) {
+        const uint32_t row0 = (uint32_t)(tile * SP3_BM) + ws * (MT * 16u) + 4 * kq_r;
+        uint32_t hits8 = 0;
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) {
+            int mx = acc[0][nt][0];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mx = acc[mt][nt][j] > mx ? acc[mt][nt][j] : mx;
+            if (!((float)mx < thr_lds[nt * 16 + (int)m_r])) hits8 |= 1u << nt;
+        }
+        if (!__ballot(hits8 != 0)) return;
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) {
+            if (!__ballot((hits8 >> nt) & 1u)) continue;
+            const uint32_t q = (uint32_t)nt * 16 + m_r;
+            const float th = thr_lds[q], qs = qs_lds[q];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = (float)acc[mt][nt][j];
+                    const uint32_t row = row0 + (uint32_t)mt * 16 + (uint32_t)j;
+                    const bool c = !(v < th) && row < n_rows32 && q < s.nq;
+                    const uint64_t hits = __ballot(c);
+                    if (hits) {
+                        const uint32_t at = wcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u));
+                        if (c && at < s.wcap) {
+                            const uint64_t key = make_key(v * qs, row);
+                            wl[at] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), q, 0u);
+                        }
+                        wcount += (uint32_t)__builtin_popcountll(hits);
+                    }
+                }
+            }
+        }
+    };
+    const uint64_t n_stages = my_tiles * nch;
+    // the stage the loads are at, as (tile, kc), by running counters (tile_of divides: once per tile, not per stage); past the block's last stage they
+    // repeat it (the waits count loads, not bytes)
+    uint64_t itr = 0, tile_r = my_tile(0);
+    uint32_t kr = 0;
+    auto advance_r = [&]() {
+        if (kr + 1 < nch) ++kr;
+        else if (itr + 1 < my_tiles) { kr = 0; ++itr; tile_r = my_tile(itr); }
+    };
+    i32x4s rc[SLOTS][NL];
+    sp_static_for<0, AHEAD>([&](auto DC) __attribute__((always_inline)) {
+        load_stage(tile_r, kr, rc[decltype(DC)::value]);
+        advance_r();
+    });
+    uint64_t it = 0, tile_c = my_tile(0), tile_done = 0;
+    uint32_t kc = 0;
+    // one stage; I = g mod SLOTS selects the register sets at compile time
+    auto one_stage = [&](auto IC) __attribute__((always_inline)) {
+        constexpr int I = decltype(IC)::value, IL = (I + AHEAD) % SLOTS;
+        if (kc == 0) {
+            if (it) epilogue(tile_done);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) acc[mt][nt] = (i32x4s){0, 0, 0, 0};
+        }
+        load_stage(tile_r, kr, rc[IL]);                           // stage g + AHEAD -> the register set stage g - 1 ran on
+        advance_r();
+        asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NL * AHEAD) : "memory");      // all but the last 2 MT AHEAD loads have landed: this stage's among them
+        asm volatile("" : "+v"(rc[I][0]), "+v"(rc[I][1]), "+v"(rc[I][2]), "+v"(rc[I][3]) : : "memory");
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl) {
+            const uint4 *bb = b_rd + kc * SP_B_UNITS + hl * 64;
+            constexpr int RA = 3;
+            i32x4s bv[RA + 1];
+#pragma unroll
+            for (int k = 0; k < RA; ++k) bv[k] = *reinterpret_cast<const i32x4s *>(bb + k * 128);
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+                if (nt + RA < 8) bv[(nt + RA) % (RA + 1)] = *reinterpret_cast<const i32x4s *>(bb + (nt + RA) * 128);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(rc[I][mt * 2 + hl], bv[nt % (RA + 1)], acc[mt][nt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (++kc == nch) {
+            kc = 0;
+            tile_done = tile_c;
+            if (++it < my_tiles) tile_c = my_tile(it);
+        }
+    };
+    for (uint64_t g = 0; g < n_stages; g += SLOTS) {
+        sp_static_for<0, SLOTS>([&](auto IC) __attribute__((always_inline)) {
+            if (g + decltype(IC)::value < n_stages) one_stage(IC);
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    epilogue(tile_done);
+    if (lane == 0) s.wcnt[blockIdx.x * WAVES + (uint32_t)w] = wcount;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // ---- after a launch: the k best candidates (by approximate score) of every query, for an exact look.  k of them are enough: approximate and exact
 // scores differ by a hundredth of the band in practice, so the worst exact score among the k best approximate ones is the k-th best exact score so far
 // or next to it - and finding k keys is what the bound-and-rank selection is quick at (the 64 best of ~5 000 took 100 - 190 us, these take ~15) ----
@@ -1819,11 +1995,15 @@ int32_t launch_split_i8_pack(hipStream_t st, const float *d_q, uint32_t nq, uint
 }
 int32_t launch_scan_i8copy(hipStream_t st, const ScanArgs &a, const void *d_bq, const float *d_qscale, const float *d_thr, int num_cus, const void *d_rows_i8,
                            void *d_wlists, uint32_t phase) {
-    auto kfn = scan_i8copy_kernel;
-    const size_t lds_bytes = (size_t)SP8_LDS;
+    // rows of up to 1 024 coordinates: the queries' whole image resident in LDS (scan_i8copy_kernel_res; option i8_resident = 0: the staged kernel)
+    const uint32_t nch_r = a.dim / 128;
+    const bool resident = option(OPT_I8_RESIDENT) > 0 && nch_r <= SP8R_MAX_NCH;
+    void (*kfn)(const ScanArgs, const SplitArgs) = resident ? scan_i8copy_kernel_res<1> : scan_i8copy_kernel;
+    const size_t lds_bytes = resident ? sp8r_lds_bytes(nch_r) : (size_t)SP8_LDS;
     static thread_local DeviceOnce attr_once;
     if (attr_once.need()) {
         QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_i8copy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SP8_LDS));
+        QMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_i8copy_kernel_res<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp8r_lds_bytes(SP8R_MAX_NCH)));
         attr_once.mark();
     }
     QMX_REQUIRE(d_rows_i8 && d_wlists && split_i8_dim_ok(a.dim), QMX_ERR_BAD_ARG, "the int8 scan reads the int8 copy and writes per-wave candidate lists");

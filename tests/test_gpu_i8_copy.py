@@ -262,3 +262,40 @@ def test_derived_copies_serve_rows_of_up_to_2048_floats(qa, dim, flag, kernel):
     assert len(hot) <= s2.counters.fallback_queries <= len(hot) + 4, s2.counters.fallback_queries
     for a, b in zip(got, got2):
         assert np.array_equal(a, b)
+
+
+# ---- the two structures of the scan: queries resident in LDS (scan_i8copy_kernel_res<AHEAD>, rows up to 1 024 coordinates) / staged behind a barrier -------
+@pytest.mark.parametrize("ahead", [0, 1])
+@pytest.mark.parametrize("distance,dim,nq,top", [(O.COSINE, 128, 128, 10), (O.COSINE, 768, 200, 10), (O.DOT, 1024, 70, 5)])
+def test_int8_scan_with_resident_and_with_staged_queries_returns_the_exact_scan(qa, ahead, distance, dim, nq, top):
+    """Option i8_resident: 0 = the staged kernel, 1 = the resident kernel.  Same integers, same thresholds, same candidates:
+    the exact scan's lists either way (with deleted rows, a partial last tile, blocks without a tile in the first phase)."""
+    n = 270_011
+    rng = np.random.default_rng(5)
+    rows = O.preprocess(distance, O.synth(0x5EED0780 + dim, 0, n, dim))
+    queries = O.synth(0x5EED0781 + nq, 0, nq, dim)
+    deleted = rng.random(n) < 0.2
+    st = O.DenseStorage(O.F32, distance, rows, point_deleted=deleted)
+    vs = qa.VectorStorage(rows, qa.Distance.Cosine if distance == O.COSINE else qa.Distance.Dot, flags=qa._ffi.SEG_I8_COPY)
+    vs.set_deleted(deleted, None)
+    qa.set_option("i8_resident", ahead)
+    try:
+        s = qa.BatchFilteredSearcher(queries, vs, top)
+        got = s.peek_top_all()
+        want_kernel = "scan_i8copy_kernel_res<1>" if ahead else "scan_i8copy_kernel("
+        assert want_kernel in _kernel(qa, s), _kernel(qa, s)
+    finally:
+        qa.set_option("i8_resident", -1)
+    _same(got, st, queries, top, live=~deleted)
+    assert s.counters.prefilter_queries == nq and s.counters.fallback_queries == 0
+
+
+def test_int8_scan_of_long_rows_keeps_the_staged_queries(qa):
+    n, dim, nq, top = 262_400, 1152, 96, 10
+    rows = O.preprocess(O.COSINE, O.synth(0x5EED0790, 0, n, dim))
+    queries = O.synth(0x5EED0791, 0, nq, dim)
+    vs = qa.VectorStorage(rows, qa.Distance.Cosine, flags=qa._ffi.SEG_I8_COPY)
+    s = qa.BatchFilteredSearcher(queries, vs, top)
+    got = s.peek_top_all()
+    assert "scan_i8copy_kernel(" in _kernel(qa, s), _kernel(qa, s)
+    _same(got, O.DenseStorage(O.F32, O.COSINE, rows), queries, top)
