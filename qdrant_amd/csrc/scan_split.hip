@@ -1525,7 +1525,8 @@ __device__ __forceinline__ void sp_static_for(F &&f) {
 }
 // Measured and gone from the code (profiles/r6_i8_resident.md): two / three stages of loads ahead (equal or slower: 170 / 200 registers), four row tiles per wave -
 // waves 0 - 3 on the block's even tiles, 4 - 7 on its odd ones: half the operand reads per matrix instruction, 250 registers - (equal), a block's tiles consecutive
-// instead of every gridDim-th (equal).
+// instead of every gridDim-th (equal).  Ablation (wrong results, the same launches): without the matrix instructions and operand reads 0.628 ms per launch
+// instead of 0.68 - 0.69, with half of them 0.655: the stream alone - this kernel's loads and waits - is 0.76 of HBM, the matrix work costs 9 %.
 template <int AHEAD>
 __global__ __launch_bounds__(SP3_THREADS, 1) void scan_i8copy_kernel_res(const ScanArgs a, const SplitArgs s) {
     constexpr int SLOTS = AHEAD + 1, WAVES = SP3_THREADS / 64, THREADS = SP3_THREADS, MT = 2, NL = 2 * MT;
