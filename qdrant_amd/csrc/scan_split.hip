@@ -167,6 +167,13 @@ __device__ __forceinline__ void sp_glds16(const unsigned char *src, uint32_t lan
                  : "=&s"(keep) : "v"(lane_off), "s"(src), "s"(lds_dst) : "memory");
 }
 
+// the same for bytes that one CU reads once (the rows of a copy): non-temporal
+__device__ __forceinline__ void sp_glds16_nt(const unsigned char *src, uint32_t lane_off, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_off), "s"(src), "s"(lds_dst) : "memory");
+}
+
 // the same without saving m0 (the kernel that uses it declares m0 clobbered: no other user of m0 in it)
 __device__ __forceinline__ void sp_glds16_m0(const unsigned char *src, uint32_t lane_off, uint32_t lds_dst) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(lane_off), "s"(src), "s"(lds_dst) : "memory");   // (m0 is a reserved register: the compiler neither allocates nor tracks it)
@@ -1378,7 +1385,9 @@ __global__ __launch_bounds__(SP3_THREADS, 1) void scan_i8copy_kernel(const ScanA
         if (ra_kc + 1 < nch) ++ra_kc;
         else if (ra_it + 1 < my_tiles) { ra_kc = 0; ++ra_it; }
     };
-    auto rows_piece = [&](int i) { sp_glds16(ra_src + i * 1024, lane_off, ra_dst + i * 1024); };
+    // (the rows non-temporal - read once, by this CU: 0.645 - 0.652 ms per launch against 0.661 - 0.670 with the default policy; the queries' slices, which every
+    // block re-reads from L2, keep it)
+    auto rows_piece = [&](int i) { sp_glds16_nt(ra_src + i * 1024, lane_off, ra_dst + i * 1024); };
     auto queries_begin = [&]() {
         rb_src = uniform_ptr((uint64_t)(uintptr_t)(s.bq + (uint64_t)rb_kc * SP_B_UNITS) + (uint32_t)w * 2048u);
         rb_dst = lds0 + (SP3_ARING * SP3_A_UNITS + rb_slot * SP_B_UNITS) * 16u + (uint32_t)w * 2048u;
@@ -1512,9 +1521,11 @@ __global__ __launch_bounds__(SP3_THREADS, 1) void scan_i8copy_kernel(const ScanA
 // among them - fits beside a scan. ----
 constexpr uint32_t SP8R_MAX_NCH = 8;
 __host__ __device__ constexpr size_t sp8r_lds_bytes(uint32_t nch) { return (size_t)nch * SP_B_UNITS * 16 + 2 * SP_QT * 4; }
+// (non-temporal: every line of the copy is read once per pass, by one CU, whole - a load instruction covers 1 KiB of consecutive bytes; with plain loads the same
+// kernel ran at 0.68 ms per launch instead of 0.61 - 0.63, the step at 90.3 - 90.9 k QPS instead of 96.5 - 97.2 k: profiles/r6_i8_resident.md)
 template <int OFF>
 __device__ __forceinline__ void sp_gload16(i32x4s &dst, const unsigned char *sbase, uint32_t voff) {
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
 }
 template <int I, int N, class F>
 __device__ __forceinline__ void sp_static_for(F &&f) {
