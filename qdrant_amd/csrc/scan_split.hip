@@ -179,6 +179,10 @@ __device__ __forceinline__ void sp_glds16_m0(const unsigned char *src, uint32_t 
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(lane_off), "s"(src), "s"(lds_dst) : "memory");   // (m0 is a reserved register: the compiler neither allocates nor tracks it)
 }
 
+__device__ __forceinline__ void sp_glds16_m0_nt(const unsigned char *src, uint32_t lane_off, uint32_t lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" : : "v"(lane_off), "s"(src), "s"(lds_dst) : "memory");
+}
+
 struct SplitArgs {
     const uint4 *bq;        // split queries, [dim / 32][SP_B_UNITS]
     uint32_t nchunks;       // dim / 32
@@ -471,7 +475,7 @@ __global__ __launch_bounds__(SP3_THREADS, 1) void scan_f16pair_kernel(const Scan
         if (ra_kc + 1 < nch) ++ra_kc;
         else if (ra_it + 1 < my_tiles) { ra_kc = 0; ++ra_it; }
     };
-    auto rows_piece = [&](int i) { sp_glds16(ra_src + i * 1024, lane_off, ra_dst + i * 1024); };
+    auto rows_piece = [&](int i) { sp_glds16_nt(ra_src + i * 1024, lane_off, ra_dst + i * 1024); };      // (non-temporal: the copy's lines are read once, whole, by this CU)
     auto queries_begin = [&]() {
         rb_src = uniform_ptr((uint64_t)(uintptr_t)(s.bq + (uint64_t)rb_kc * SP_B_UNITS) + (uint32_t)w * 2048u);
         rb_dst = lds0 + (SP3_ARING * SP3_A_UNITS + rb_slot * SP_B_UNITS) * 16u + (uint32_t)w * 2048u;
@@ -668,7 +672,7 @@ __global__ __launch_bounds__(SP3_THREADS, 1) void scan_f16half256_kernel(const S
     };
     auto rows_piece = [&](int i) {
 #if SP4_DBG != 1
-        sp_glds16_m0(ra_src + i * 1024, lane_off, ra_dst + i * 1024);
+        sp_glds16_m0_nt(ra_src + i * 1024, lane_off, ra_dst + i * 1024);
 #endif
     };
     auto queries_begin = [&]() {

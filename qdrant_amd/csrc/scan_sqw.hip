@@ -108,6 +108,8 @@ __global__ __launch_bounds__(256) void sqw_pack_kernel(const unsigned char *quer
     qinfo[SW_QT + qi] = tf;
 }
 
+// (default cache policy: a load instruction touches sixteen 64-byte HALF-lines whose other halves the group's next load is meant to hit - with `nt` the pass takes 1.49 ms
+// instead of 1.37, profiles/r6_nt_policy_experiment.txt; the int8-copy scans, whose loads consume whole lines, gain from it: scan_split.hip)
 __device__ __forceinline__ void sw_gload16(i32x4q &dst, const unsigned char *sbase, uint32_t voff) {
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
 }
